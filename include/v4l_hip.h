@@ -1,0 +1,170 @@
+/* v4l_hip.h — C ABI of libv4l_hip.so, the MI355X (gfx950) implementation of the vision4leg PPO hot path.
+ *
+ * The reference (Mehooz/vision4leg) has no FFI for this path: the boundary is the Python object protocol of
+ * its in-tree `torchrl` package. Each entry point below therefore replaces the arithmetic
+ * behind one reference Python symbol, cited as `file:line` relative to the reference checkout. The Python
+ * shell in vision4leg_amd/torchrl binds these with ctypes and keeps the reference class/method names.
+ *
+ * Conventions
+ *   - every function returns int: 0 ok, -1 bad argument / unsupported configuration, -2 HIP error;
+ *     v4l_last_error() returns the message (thread-local, valid until the next failing call).
+ *   - plain pointers and sizes only. Pointers named *_dev are device (HBM) pointers owned by the caller;
+ *     the library never allocates or frees device memory for the caller's data and keeps no pointer
+ *     beyond what v4l_net_bind / v4l_trainer_bind register (those must stay valid until rebind/destroy).
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream). Calls only enqueue work.
+ *   - one handle = one device, driven from one host thread at a time (the reference is single-threaded,
+ *     torchrl/algo/rl_algo.py:97-168).
+ *   - all activations/params/grads are fp32; `compute` selects the contraction operand type:
+ *     V4L_F32 = exact fp32 MFMA (parity mode), V4L_BF16 = bf16 operands, fp32 accumulate (production).
+ */
+#ifndef V4L_HIP_H
+#define V4L_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define V4L_F32 0
+#define V4L_BF16 1
+
+#define V4L_NET_MLP 0  /* networks.Net + MLPBase            torchrl/networks/nets.py:16-55 (ppo_state.py)      */
+#define V4L_NET_CNN 1  /* networks.ImpalaEncoderProjNet + NatureFuseEncoder   nets.py:194-262, base.py:345-385 */
+#define V4L_NET_LOCO 2 /* networks.LocoTransformer + LocoTransformerEncoder   nets.py:909-1038, base.py:497-626 */
+
+#define V4L_MAX_HIDDEN 4
+#define V4L_STATS 24 /* floats per update record; [0..17] = the 18 logger keys of ppo.py:77-92,122-123,142-145 */
+#define V4L_OUT_LD 16 /* row stride of head outputs (action mean / value), zero padded */
+
+typedef struct v4l_net_cfg {
+  int kind;            /* V4L_NET_*                                                                      */
+  int compute;         /* V4L_F32 | V4L_BF16                                                             */
+  int state_dim;       /* S: proprio length (state_input_dim, starter/ppo_locotransformer.py:81)         */
+  int out_dim;         /* A for a policy, 1 for a value net                                              */
+  int in_channels;     /* 4 (depth stack); ignored for V4L_NET_MLP                                       */
+  int img_hw;          /* 64                                                                             */
+  int n_enc_hidden;    /* encoder.hidden_shapes / MLPBase hidden_shapes (base.py:8-44)                   */
+  int enc_hidden[V4L_MAX_HIDDEN];
+  int visual_dim;      /* V4L_NET_CNN: NatureFuseEncoder.visual_dim (base.py:358-362)                    */
+  int token_dim;       /* V4L_NET_LOCO: 64                                                               */
+  int n_layers;        /* V4L_NET_LOCO: len(transformer_params) (nets.py:948-955)                        */
+  int ff_dim;          /* V4L_NET_LOCO: dim_feedforward                                                  */
+  int n_head_hidden;   /* append_hidden_shapes (nets.py:35-50, 224-243, 973-992)                         */
+  int head_hidden[V4L_MAX_HIDDEN];
+  int has_logstd;      /* 1: Gaussian policy with a state-independent logstd parameter                   */
+} v4l_net_cfg;
+
+typedef struct v4l_net v4l_net;         /* host-side plan of one network (no device memory)  */
+typedef struct v4l_trainer v4l_trainer; /* host-side plan of the PPO update over (pf, vf, target_pf) */
+
+const char* v4l_last_error(void);
+int v4l_version(void);
+
+/* ---- network plan: replaces the nn.Module constructors' shape bookkeeping (nets.py / base.py above) ---- */
+int v4l_net_create(const v4l_net_cfg* cfg, v4l_net** out);
+void v4l_net_destroy(v4l_net* net);
+int v4l_net_num_params(const v4l_net* net);
+/* name = the reference state_dict key (SURVEY.md §8b "Checkpoint names"); shape in PyTorch layout */
+int v4l_net_param_info(const v4l_net* net, int i, const char** name, int* ndim, int64_t shape[4], int64_t* numel,
+                       int64_t* grad_offset);
+int64_t v4l_net_total_params(const v4l_net* net);   /* length of a flat grad / Adam-moment buffer (floats) */
+int64_t v4l_net_packed_bytes(const v4l_net* net);   /* bytes of the packed (contraction-ready) weight buffer */
+int64_t v4l_net_table_bytes(const v4l_net* net);    /* bytes of the small device descriptor table */
+int64_t v4l_net_ws_floats(const v4l_net* net, int n, int train); /* workspace floats for a batch of n */
+int v4l_net_state_ld(const v4l_net* net);           /* Sp: row stride of the ingested proprio array */
+/* Register where the parameters live (params_dev[i] = device pointer of parameter i, PyTorch layout) and the
+ * caller-allocated packed-weight and descriptor-table buffers. Uploads the descriptor tables (async). */
+int v4l_net_bind(v4l_net* net, float* const* params_dev, void* packed_dev, void* table_dev, void* stream);
+/* Refresh the packed weights from the current parameter values (after optimiser steps / load_state_dict). */
+int v4l_net_pack(v4l_net* net, void* stream);
+
+/* Split reference observation rows [n][S + C*H*W] fp32 (vision4leg/envs/utilities/env_utils.py:27-51,
+ * nets.py:997-1000) into state_dev[slot0+i][Sp] fp32 and image_dev[slot0+i][C*H*W] (fp32 or bf16 per
+ * `compute`). image_dev may be NULL for V4L_NET_MLP. */
+int v4l_ingest(const v4l_net* net, const float* obs_dev, int n, float* state_dev, void* image_dev, int64_t slot0,
+               void* stream);
+
+/* Forward pass == nn.Module.forward of nets.py:52-55 / 247-262 / 996-1038 on rows rowidx[i] (or i when
+ * rowidx_dev is NULL) of the ingested arrays. The head output (action mean or value) is left in the
+ * workspace; v4l_net_out_ptr gives its address: [n][V4L_OUT_LD] fp32. train=1 keeps what backward needs. */
+int v4l_net_forward(v4l_net* net, const float* state_dev, const void* image_dev, const int* rowidx_dev, int n,
+                    float* ws_dev, int train, void* stream);
+float* v4l_net_out_ptr(const v4l_net* net, float* ws_dev, int n, int train);
+float* v4l_net_dout_ptr(const v4l_net* net, float* ws_dev, int n);
+/* Backward of the same pass: reads d(out) at v4l_net_dout_ptr ([n][V4L_OUT_LD]), accumulates parameter
+ * gradients into grads_dev (flat, offsets from v4l_net_param_info; caller zeroes it). Replaces
+ * loss.backward() of ppo.py:72,117 for everything below the head output. */
+int v4l_net_backward(v4l_net* net, const float* state_dev, const void* image_dev, const int* rowidx_dev, int n,
+                     float* ws_dev, float* grads_dev, void* stream);
+
+/* GaussianContPolicyBase.{forward,explore,update} post-processing (policies/continuous_policy.py:85-146,
+ * 486-492): contiguous mean/std [n][A], clamped log_std [A], ent [n], and log_prob [n] of acts_dev ([n][A])
+ * when acts_dev != NULL. meanp_dev is v4l_net_out_ptr of the policy net. */
+int v4l_gauss_head(const float* meanp_dev, const float* logstd_dev, const float* acts_dev, int n, int A,
+                   float* mean_dev, float* std_dev, float* logstd_c_dev, float* ent_dev, float* logp_dev,
+                   void* stream);
+/* column 0 of a padded head output -> contiguous [n] (vf(x) for the collector, collector/on_policy.py:99-100) */
+int v4l_col0(const float* src_dev, int n, float* dst_dev, void* stream);
+
+/* OnPolicyReplayBufferBase.generalized_advantage_estimation (torchrl/replay_buffers/on_policy.py:17-45), fp64,
+ * bit-identical to the numpy loop. Arrays are [T][E] (the trailing 1 of the reference's [T,E,1] dropped);
+ * time_limits is [T] when tl_per_env == 0 (the collector's `[False]` rows, collector/on_policy.py:122-124) or
+ * [T][E]; use_time_limit mirrors `time_limit_filter`. advs32/rets32 (optional) receive the fp32 casts of
+ * ppo.py:138,140. */
+int v4l_gae(const double* rewards_dev, const double* values_dev, const double* terminals_dev,
+            const double* time_limits_dev, int tl_per_env, const double* last_value_dev, int T, int E, double gamma,
+            double tau, int use_time_limit, double* advs_dev, double* rets_dev, float* advs32_dev, float* rets32_dev,
+            void* stream);
+
+/* ---- PPO minibatch update: replaces PPO.update / update_critic / update_actor (ppo.py:42-153), the two
+ * clip_grad_norm_(…, 0.5) calls and the two Adam steps (a2c.py:30-40). pf and vf may share encoder parameters
+ * (same device pointers in both tables): the critic step runs first and the actor forward sees the updated
+ * encoder, exactly as ppo.py:150-151. ---- */
+typedef struct v4l_ppo_hyper {
+  float clip_para;      /* ppo.py:17 */
+  float entropy_coeff;  /* a2c.py:19 */
+  float max_grad_norm;  /* 0.5, ppo.py:73-74,118-119 */
+  float beta1, beta2, eps; /* Adam: 0.9, 0.999, 1e-5 (a2c.py:30-40) */
+  int clipped_value_loss;  /* ppo.py:105-112 */
+  int world_size;       /* data-parallel ranks; losses are scaled by 1/(n*world_size) */
+} v4l_ppo_hyper;
+
+typedef struct v4l_rollout {
+  const float* state_dev;  /* [slots][Sp]   */
+  const void* image_dev;   /* [slots][C*H*W] fp32|bf16, NULL for V4L_NET_MLP */
+  const float* acts_dev;   /* [slots][A]    */
+  const float* advs_dev;   /* [slots]       */
+  const float* rets_dev;   /* [slots]  estimate_returns */
+  const float* values_dev; /* [slots]  old values (only for clipped_value_loss) */
+} v4l_rollout;
+
+int v4l_trainer_create(v4l_net* pf, v4l_net* vf, v4l_net* target_pf, v4l_trainer** out);
+void v4l_trainer_destroy(v4l_trainer* tr);
+int64_t v4l_trainer_ws_floats(const v4l_trainer* tr, int n);
+/* grads/moments: flat fp32 buffers of v4l_net_total_params(pf|vf) floats each (moments zero-initialised by
+ * the caller == fresh torch.optim.Adam state). stats_dev: V4L_STATS floats per update. */
+int v4l_trainer_bind(v4l_trainer* tr, float* g_pf_dev, float* m_pf_dev, float* v_pf_dev, float* g_vf_dev,
+                     float* m_vf_dev, float* v_vf_dev, float* ws_dev, int64_t ws_floats, void* stream);
+/* Phases of one minibatch update. Single GPU: call v4l_trainer_update. Data parallel: critic_grads →
+ * all-reduce(g_vf ‖ stats[18..20]) → critic_step → actor_grads → all-reduce(g_pf) → actor_step. */
+int v4l_trainer_critic_grads(v4l_trainer* tr, const v4l_rollout* ro, const int* rowidx_dev, int n,
+                             const v4l_ppo_hyper* hp, float* stats_dev, void* stream);
+int v4l_trainer_critic_step(v4l_trainer* tr, const v4l_ppo_hyper* hp, double lr, int64_t step, float* stats_dev,
+                            void* stream);
+int v4l_trainer_actor_grads(v4l_trainer* tr, const v4l_rollout* ro, const int* rowidx_dev, int n,
+                            const v4l_ppo_hyper* hp, float* stats_dev, void* stream);
+int v4l_trainer_actor_step(v4l_trainer* tr, const v4l_ppo_hyper* hp, double lr, int64_t step, float* stats_dev,
+                           void* stream);
+int v4l_trainer_update(v4l_trainer* tr, const v4l_rollout* ro, const int* rowidx_dev, int n, const v4l_ppo_hyper* hp,
+                       double lr_pf, double lr_vf, int64_t step, float* stats_dev, void* stream);
+/* copy_model_params_from_to(pf, target_pf) (torchrl/algo/utils.py:23-25, ppo.py:34) + repack of the target */
+int v4l_trainer_sync_target(v4l_trainer* tr, void* stream);
+
+/* ---- introspection for tests: float offset of a named activation inside a workspace laid out for n rows
+ * ("c1","c2","c3","eh<i>","x<l>","qkv<l>","P<l>","ctx<l>","mid<l>","ff<l>","pooled","hh<i>","out","dout",…); -1 if unknown */
+int64_t v4l_net_ws_offset(const v4l_net* net, int n, const char* name);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* V4L_HIP_H */

@@ -1,0 +1,343 @@
+"""TEST INFRASTRUCTURE — CPU oracle for the vision4leg PPO hot path. NOT part of the product.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module; the product
+(vision4leg_amd/) never does and fails loudly without its HIP library.
+
+Parity status: PINNED. The reference ships no tests or golden vectors for this path, so the pin
+is the reference itself executed in the build container: tests/golden/make_golden.py imports the unmodified
+reference from /root/reference, checks this restatement against it (forward, backward, PPO.update, GAE) and
+writes the fixtures under tests/golden/ that the test-suite replays where /root/reference is absent.
+
+A plain-PyTorch (CPU, fp32) restatement of the reference's arithmetic, which itself lives in PyTorch
+(nn.Conv2d / nn.Linear / nn.TransformerEncoderLayer / optim.Adam / clip_grad_norm_ / distributions.Normal,
+unpinned `torch` dependency of /root/reference/setup.py:244-249; restated against torch 2.10 semantics).
+Every function cites the reference lines it follows (paths relative to /root/reference).
+
+Two numeric flavours:
+  mode="f32"  : what the reference computes.
+  mode="bf16" : same graph, but every contraction (Linear / Conv2d, forward and both backward products)
+                rounds its two operands to bfloat16 (round-to-nearest-even) and accumulates in fp32 — the
+                rounding points of the MI355X bf16 MFMA path. Attention score/value products, softmax,
+                LayerNorm, residuals, losses and Adam stay fp32 in both flavours.
+"""
+import math
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+LOG_SIG_MAX, LOG_SIG_MIN = 2.0, -5.0  # torchrl/policies/continuous_policy.py:8-9
+
+
+def rbf16(x):
+    return x.to(torch.bfloat16).to(torch.float32)
+
+
+class _LinearBF16(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w, b):
+        xr, wr = rbf16(x), rbf16(w)
+        ctx.save_for_backward(xr, wr)
+        return xr @ wr.t() + b
+
+    @staticmethod
+    def backward(ctx, dy):
+        xr, wr = ctx.saved_tensors
+        dyr = rbf16(dy)
+        dx = dyr @ wr
+        dw = dyr.reshape(-1, dyr.shape[-1]).t() @ xr.reshape(-1, xr.shape[-1])
+        db = dy.reshape(-1, dy.shape[-1]).sum(0)
+        return dx, dw, db
+
+
+class _ConvBF16(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w, b, stride):
+        xr, wr = rbf16(x), rbf16(w)
+        ctx.save_for_backward(xr, wr)
+        ctx.stride = stride
+        return F.conv2d(xr, wr, b, stride=stride)
+
+    @staticmethod
+    def backward(ctx, dy):
+        xr, wr = ctx.saved_tensors
+        dyr = rbf16(dy)
+        dx = torch.nn.grad.conv2d_input(xr.shape, wr, dyr, stride=ctx.stride)
+        dw = torch.nn.grad.conv2d_weight(xr, wr.shape, dyr, stride=ctx.stride)
+        db = dy.sum((0, 2, 3))
+        return dx, dw, db, None
+
+
+def linear(x, w, b, mode):
+    return F.linear(x, w, b) if mode == "f32" else _LinearBF16.apply(x, w, b)
+
+
+def conv2d(x, w, b, stride, mode):
+    return F.conv2d(x, w, b, stride=stride) if mode == "f32" else _ConvBF16.apply(x, w, b, stride)
+
+
+# ------------------------------------------------------------------------------------------ building blocks
+def mlp(p, prefix, x, n, mode):
+    """MLPBase: Linear+ReLU per hidden layer, last activation is ReLU too (torchrl/networks/base.py:8-44)."""
+    for i in range(n):
+        x = torch.relu(linear(x, p["%s.%d.weight" % (prefix, 2 * i)], p["%s.%d.bias" % (prefix, 2 * i)], mode))
+    return x
+
+
+def head(p, prefix, x, n_hidden, mode):
+    """append fcs: (Linear+ReLU)*n_hidden then Linear (nets.py:35-50, 224-243, 973-992)."""
+    x = mlp(p, prefix, x, n_hidden, mode)
+    return linear(x, p["%s.%d.weight" % (prefix, 2 * n_hidden)], p["%s.%d.bias" % (prefix, 2 * n_hidden)], mode)
+
+
+def nature_cnn(p, prefix, img, mode):
+    """NatureEncoder: conv 8/4, 4/2, 3/1 with ReLU (base.py:317-324). img [B,4,64,64] -> [B,64,4,4]."""
+    x = img
+    for i, s in zip((0, 2, 4), (4, 2, 1)):
+        x = torch.relu(conv2d(x, p["%s.layers.%d.weight" % (prefix, i)], p["%s.layers.%d.bias" % (prefix, i)], s, mode))
+    return x
+
+
+def transformer_layer(p, prefix, x, mode):
+    """nn.TransformerEncoderLayer(64, nhead=1, ff, dropout=0): post-norm, ReLU FFN, LN eps 1e-5
+    (built at nets.py:948-955, applied :1009-1011). x is batch-first [B,17,64] here; the reference runs the
+    same arithmetic sequence-first."""
+    d = x.shape[-1]
+    qkv = linear(x, p[prefix + ".self_attn.in_proj_weight"], p[prefix + ".self_attn.in_proj_bias"], mode)
+    q, k, v = qkv.split(d, dim=-1)
+    scores = (q @ k.transpose(-1, -2)) * (1.0 / math.sqrt(d))
+    ctx = torch.softmax(scores, dim=-1) @ v
+    a = linear(ctx, p[prefix + ".self_attn.out_proj.weight"], p[prefix + ".self_attn.out_proj.bias"], mode)
+    x = F.layer_norm(x + a, (d,), p[prefix + ".norm1.weight"], p[prefix + ".norm1.bias"], 1e-5)
+    f = torch.relu(linear(x, p[prefix + ".linear1.weight"], p[prefix + ".linear1.bias"], mode))
+    f = linear(f, p[prefix + ".linear2.weight"], p[prefix + ".linear2.bias"], mode)
+    return F.layer_norm(x + f, (d,), p[prefix + ".norm2.weight"], p[prefix + ".norm2.bias"], 1e-5)
+
+
+def _count(p, fmt):
+    n = 0
+    while (fmt % (2 * n)) in p:
+        n += 1
+    return n
+
+
+# ------------------------------------------------------------------------------------------ the three nets
+def split_obs(x, S):
+    """state = x[..., :S]; img = x[..., S:].view(B,4,64,64) (nets.py:997-1000, 249-252)."""
+    return x[..., :S], x[..., S:].reshape(-1, 4, 64, 64)
+
+
+def loco_forward(p, x, S, mode="f32", taps=None):
+    """LocoTransformer.forward + LocoTransformerEncoder.forward (nets.py:996-1038, base.py:550-626), depth-only."""
+    state, img = split_obs(x, S)
+    B = state.shape[0]
+    c3 = nature_cnn(p, "encoder.depth_visual_base", img, mode)                                  # base.py:578
+    up = conv2d(c3, p["encoder.depth_up_conv.weight"], p["encoder.depth_up_conv.bias"], 1, mode)   # base.py:581
+    depth_tok = up.reshape(B, 64, 16).permute(0, 2, 1)                                          # base.py:602-608
+    ne = _count(p, "encoder.base.seq_fcs.%d.weight")
+    h = mlp(p, "encoder.base.seq_fcs", state, ne, mode)                                         # base.py:611
+    st = torch.relu(linear(h, p["encoder.state_projector.projection.0.weight"],
+                           p["encoder.state_projector.projection.0.bias"], mode))               # base.py:613
+    tok = torch.cat([st.unsqueeze(1), depth_tok], dim=1)                                        # base.py:617-622
+    if taps is not None:
+        taps["c3"] = c3; taps["x0"] = tok
+    l = 0
+    while ("visual_append_layers.%d.norm1.weight" % l) in p:
+        tok = transformer_layer(p, "visual_append_layers.%d" % l, tok, mode)                    # nets.py:1009-1011
+        if taps is not None:
+            taps["x%d" % (l + 1)] = tok
+        l += 1
+    pooled = torch.cat([tok[:, 0], tok[:, 1:17].mean(dim=1)], dim=-1)                           # nets.py:1015-1034
+    nh = _count(p, "visual_seq_append_fcs.%d.weight") - 1
+    return head(p, "visual_seq_append_fcs", pooled, nh, mode)                                   # nets.py:1036
+
+
+def cnn_forward(p, x, S, mode="f32", taps=None):
+    """ImpalaEncoderProjNet.forward + NatureFuseEncoder.forward (nets.py:247-262, base.py:371-385)."""
+    state, img = split_obs(x, S)
+    c3 = nature_cnn(p, "encoder.visual_base", img, mode)
+    vis = torch.relu(linear(c3.flatten(1), p["encoder.visual_projector.projection.0.weight"],
+                            p["encoder.visual_projector.projection.0.bias"], mode))
+    ne = _count(p, "encoder.base.seq_fcs.%d.weight")
+    h = mlp(p, "encoder.base.seq_fcs", state, ne, mode)
+    nh = _count(p, "seq_append_fcs.%d.weight") - 1
+    return head(p, "seq_append_fcs", torch.cat([vis, h], dim=-1), nh, mode)
+
+
+def mlp_forward(p, x, S=None, mode="f32", taps=None):
+    """Net.forward with an MLPBase trunk (nets.py:52-55)."""
+    ne = _count(p, "base.seq_fcs.%d.weight")
+    nh = _count(p, "seq_append_fcs.%d.weight") - 1
+    return head(p, "seq_append_fcs", mlp(p, "base.seq_fcs", x, ne, mode), nh, mode)
+
+
+FORWARDS = {"loco": loco_forward, "cnn": cnn_forward, "mlp": mlp_forward}
+
+
+# ------------------------------------------------------------------------------------------ Gaussian head
+def gaussian(mean, logstd_param):
+    """forward of the policy classes: clamp, exp, broadcast (continuous_policy.py:486-492)."""
+    log_std = torch.clamp(logstd_param, LOG_SIG_MIN, LOG_SIG_MAX)
+    std = torch.exp(log_std).unsqueeze(0).expand_as(mean)
+    return mean, std, log_std
+
+
+def log_prob_entropy(mean, std, actions):
+    """Normal(mean,std).log_prob(a).sum(-1,keepdim) and .entropy().sum(-1,keepdim) (continuous_policy.py:127-146;
+    torch/distributions/normal.py)."""
+    var = std ** 2
+    lp = -((actions - mean) ** 2) / (2 * var) - std.log() - math.log(math.sqrt(2 * math.pi))
+    ent = 0.5 + 0.5 * math.log(2 * math.pi) + torch.log(std)
+    return lp.sum(-1, keepdim=True), ent.sum(-1, keepdim=True)
+
+
+# ------------------------------------------------------------------------------------------ GAE
+def gae(rewards, values, terminals, time_limits, last_value, gamma, tau, time_limit_filter):
+    """generalized_advantage_estimation (torchrl/replay_buffers/on_policy.py:17-45): float64 numpy, same
+    expression order as the reference. Arrays [T,E,1]; time_limits [T,1] or [T,E,1]; last_value [E,1]."""
+    rewards, values, terminals = (np.asarray(a, dtype=np.float64) for a in (rewards, values, terminals))
+    T = len(rewards)
+    vals = np.concatenate([values, np.array([last_value], dtype=np.float64)], 0)
+    A = 0
+    advs, rets = [None] * T, [None] * T
+    for t in reversed(range(T)):
+        delta = rewards[t] + (1 - terminals[t]) * gamma * vals[t + 1] - vals[t]
+        A = delta + (1 - terminals[t]) * gamma * tau * A
+        if time_limit_filter:
+            A = A * (1 - np.asarray(time_limits[t], dtype=np.float64))
+        advs[t] = A
+        rets[t] = A + vals[t]
+    return np.array(advs), np.array(rets)
+
+
+# ------------------------------------------------------------------------------------------ optimiser pieces
+def clip_grad_norm(grads, max_norm):
+    """torch.nn.utils.clip_grad_norm_ (ppo.py:73-74,118-119): L2 over all grads, scale by
+    min(1, max_norm/(norm+1e-6)); returns the pre-clip norm."""
+    total = torch.linalg.vector_norm(torch.stack([torch.linalg.vector_norm(g) for g in grads]))
+    coef = torch.clamp(max_norm / (total + 1e-6), max=1.0)
+    return [g * coef for g in grads], total
+
+
+def adam_step(params, grads, state, lr, step, betas=(0.9, 0.999), eps=1e-5):
+    """torch.optim.Adam, no weight decay, eps added after sqrt(v_hat) (a2c.py:30-40;
+    torch/optim/adam.py::_single_tensor_adam operation order). state: list of (m, v) per param, updated in place."""
+    b1, b2 = betas
+    bc1 = 1 - b1 ** step
+    bc2 = 1 - b2 ** step
+    step_size = lr / bc1
+    bc2_sqrt = bc2 ** 0.5
+    with torch.no_grad():
+        for p, g, (m, v) in zip(params, grads, state):
+            m.lerp_(g, 1 - b1)
+            v.mul_(b2).addcmul_(g, g, value=1 - b2)
+            denom = (v.sqrt() / bc2_sqrt).add_(eps)
+            p.addcdiv_(m, denom, value=-step_size)
+
+
+class PPOOracle:
+    """PPO.update (ppo.py:42-153) over name->tensor parameter dicts.
+
+    pf / vf dicts may hold the *same tensor objects* for shared encoder entries (the reference passes one
+    encoder module to both nets, starter/ppo_locotransformer.py:79-100): each optimiser then keeps its own
+    moments for them (a2c.py:30-40) and the critic step is visible to the actor forward (ppo.py:150-151)."""
+
+    def __init__(self, kind, pf, vf, target_pf, S, mode="f32", clip_para=0.2, entropy_coeff=0.005, max_norm=0.5,
+                 clipped_value_loss=False):
+        self.fwd = FORWARDS[kind]
+        self.pf, self.vf, self.tpf = pf, vf, target_pf
+        self.S, self.mode = S, mode
+        self.clip_para, self.entropy_coeff, self.max_norm = clip_para, entropy_coeff, max_norm
+        self.clipped_value_loss = clipped_value_loss
+        self.pf_keys = [k for k in pf]
+        self.vf_keys = [k for k in vf]
+        self.pf_state = [(torch.zeros_like(pf[k]), torch.zeros_like(pf[k])) for k in self.pf_keys]
+        self.vf_state = [(torch.zeros_like(vf[k]), torch.zeros_like(vf[k])) for k in self.vf_keys]
+        self.step = 0
+        self.last_grads = {}
+
+    def sync_target(self):
+        """copy_model_params_from_to(pf, target_pf) (algo/utils.py:23-25, ppo.py:34)"""
+        with torch.no_grad():
+            for k in self.pf_keys:
+                self.tpf[k].copy_(self.pf[k])
+
+    def _grads(self, loss, pdict, keys):
+        for k in keys:
+            pdict[k].requires_grad_(True)
+        gs = torch.autograd.grad(loss, [pdict[k] for k in keys], allow_unused=True)
+        for k in keys:
+            pdict[k].requires_grad_(False)
+        return [g if g is not None else torch.zeros_like(pdict[k]) for g, k in zip(gs, keys)]
+
+    def update(self, obs, acts, advs, est_rets, old_values, lr_pf, lr_vf):
+        """obs [B,D], acts [B,A], advs/est_rets/old_values [B,1] (fp32 tensors). Returns the 18-key info dict."""
+        info = {}
+        self.step += 1
+        info["advs/mean"] = advs.mean().item()
+        info["advs/std"] = advs.std().item()
+        info["advs/max"] = advs.max().item()
+        info["advs/min"] = advs.min().item()
+        advs = (advs - advs.mean()) / (advs.std() + 1e-5)                                    # ppo.py:148
+        # ---- critic (ppo.py:94-123)
+        for k in self.vf_keys:
+            self.vf[k].requires_grad_(True)
+        values = self.fwd(self.vf, obs, self.S, self.mode)
+        if self.clipped_value_loss:
+            vc = old_values + (values - old_values).clamp(-self.clip_para, self.clip_para)
+            vf_loss = 0.5 * torch.max((values - est_rets).pow(2), (vc - est_rets).pow(2)).mean()
+        else:
+            vf_loss = F.mse_loss(values, est_rets)
+        g = self._grads(vf_loss, self.vf, self.vf_keys)
+        self.last_grads["vf"] = dict(zip(self.vf_keys, g))
+        g, gn = clip_grad_norm(g, self.max_norm)
+        adam_step([self.vf[k] for k in self.vf_keys], g, self.vf_state, lr_vf, self.step)
+        info["Training/vf_loss"] = vf_loss.item()
+        info["grad_norm/vf"] = gn.item()
+        # ---- actor (ppo.py:42-92)
+        for k in self.pf_keys:
+            self.pf[k].requires_grad_(True)
+        mean = self.fwd({k: v for k, v in self.pf.items() if k != "logstd"}, obs, self.S, self.mode)
+        mean, std, log_std = gaussian(mean, self.pf["logstd"])
+        log_probs, ent = log_prob_entropy(mean, std, acts)
+        with torch.no_grad():
+            tmean = self.fwd({k: v for k, v in self.tpf.items() if k != "logstd"}, obs, self.S, self.mode)
+            tmean, tstd, _ = gaussian(tmean, self.tpf["logstd"])
+            target_log_probs, _ = log_prob_entropy(tmean, tstd, acts)
+        ratio = torch.exp(log_probs - target_log_probs)
+        s1 = ratio * advs
+        s2 = torch.clamp(ratio, 1.0 - self.clip_para, 1.0 + self.clip_para) * advs
+        policy_loss = -torch.mean(torch.min(s2, s1)) - self.entropy_coeff * ent.mean()
+        g = self._grads(policy_loss, self.pf, self.pf_keys)
+        self.last_grads["pf"] = dict(zip(self.pf_keys, g))
+        g, gn = clip_grad_norm(g, self.max_norm)
+        adam_step([self.pf[k] for k in self.pf_keys], g, self.pf_state, lr_pf, self.step)
+        info["Training/policy_loss"] = policy_loss.item()
+        lp = log_probs.detach()
+        info["logprob/mean"], info["logprob/std"] = lp.mean().item(), lp.std().item()
+        info["logprob/max"], info["logprob/min"] = lp.max().item(), lp.min().item()
+        ls = log_std.detach()
+        info["log_std/mean"], info["log_std/std"] = ls.mean().item(), ls.std().item()
+        info["log_std/max"], info["log_std/min"] = ls.max().item(), ls.min().item()
+        info["ratio/max"], info["ratio/min"] = ratio.max().item(), ratio.min().item()
+        info["grad_norm/pf"] = gn.item()
+        return info
+
+
+def synthetic_rollout(T, E, S, A, seed=0, with_images=True):
+    """Synthetic epoch in the distributions of BASELINE.md §3 (numpy RandomState(seed))."""
+    rs = np.random.RandomState(seed)
+    state = np.clip(rs.randn(T, E, S), -10, 10)
+    parts = [state]
+    if with_images:
+        parts.append(np.clip(rs.randn(T, E, 4 * 64 * 64), -2.5, 2.8))
+    obs = np.concatenate(parts, axis=-1)
+    return {
+        "obs": obs,
+        "acts": 0.1 * rs.randn(T, E, A),
+        "values": rs.randn(T, E, 1),
+        "rewards": rs.randn(T, E, 1),
+        "terminals": (rs.rand(T, E, 1) < 0.01).astype(np.float64),
+        "time_limits": (rs.rand(T, E, 1) < 0.002).astype(np.float64),
+        "last_value": rs.randn(E, 1),
+    }

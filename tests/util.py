@@ -1,0 +1,119 @@
+"""Shared case definitions for the parity tests and the golden generator (tests/golden/make_golden.py).
+Everything is regenerated from seeds so fixtures only carry reference *outputs*."""
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+STAT_KEYS = [
+    "advs/mean", "advs/std", "advs/max", "advs/min", "Training/vf_loss", "grad_norm/vf",
+    "Training/policy_loss", "logprob/mean", "logprob/std", "logprob/max", "logprob/min",
+    "log_std/mean", "log_std/std", "log_std/max", "log_std/min", "ratio/max", "ratio/min",
+    "grad_norm/pf",
+]
+
+# shipped hyper-parameters (config/rl/static/locotransformer/thin-goal.json:54-103); S=84 is what the configs
+# produce (no_displacement), S=93 the paper/benchmark setting
+CASES = {
+    "loco_s93": dict(kind="loco", S=93, A=6, seed=0, B=64, enc=[256, 256], head=[256, 256], layers=2, ff=256),
+    "loco_s84": dict(kind="loco", S=84, A=6, seed=1, B=32, enc=[256, 256], head=[256, 256], layers=2, ff=256),
+    "cnn_s93": dict(kind="cnn", S=93, A=6, seed=2, B=64, enc=[256, 256], head=[256, 256], visual_dim=256),
+    "mlp_s93": dict(kind="mlp", S=93, A=6, seed=3, B=128, enc=[256, 256], head=[256, 256]),
+}
+
+GAE_CASES = {
+    "t64_e8_tl_bcast": dict(T=64, E=8, seed=10, gamma=0.99, tau=0.95, tl_filter=True, tl_per_env=False),
+    "t128_e32_tl_env": dict(T=128, E=32, seed=11, gamma=0.99, tau=0.95, tl_filter=True, tl_per_env=True),
+    "t100_e1_nofilter": dict(T=100, E=1, seed=12, gamma=0.99, tau=0.95, tl_filter=False, tl_per_env=False),
+    "t7_e3_edge": dict(T=7, E=3, seed=13, gamma=0.9, tau=1.0, tl_filter=True, tl_per_env=True),
+}
+
+
+def obs_dim(case):
+    return case["S"] + (0 if case["kind"] == "mlp" else 4 * 64 * 64)
+
+
+def build_nets(networks, policies, case):
+    """pf / vf exactly as starter/ppo_{locotransformer,nature_cnn,state}.py wire them (shared encoder / base).
+    `networks` / `policies` are either the reference's modules or vision4leg_amd.torchrl's."""
+    S, A, kind = case["S"], case["A"], case["kind"]
+    net = {"append_hidden_shapes": list(case["head"]), "base_type": networks.MLPBase}
+    if kind == "loco":
+        net["transformer_params"] = [[1, case["ff"]] for _ in range(case["layers"])]
+        encoder = networks.LocoTransformerEncoder(in_channels=4, state_input_dim=S, hidden_shapes=list(case["enc"]),
+                                                  visual_dim=256)
+        pf = policies.GaussianContPolicyLocoTransformer(encoder=encoder, state_input_shape=S,
+                                                        visual_input_shape=(4, 64, 64), output_shape=A, **net)
+        vf = networks.LocoTransformer(encoder=encoder, state_input_shape=S, visual_input_shape=(4, 64, 64),
+                                      output_shape=1, **net)
+    elif kind == "cnn":
+        encoder = networks.NatureFuseEncoder(in_channels=4, state_input_dim=S, hidden_shapes=list(case["enc"]),
+                                             visual_dim=case["visual_dim"])
+        pf = policies.GaussianContPolicyImpalaEncoderProj(encoder=encoder, state_input_shape=S,
+                                                          visual_input_shape=(4, 64, 64), output_shape=A, **net)
+        vf = networks.ImpalaEncoderProjNet(encoder=encoder, state_input_shape=S, visual_input_shape=(4, 64, 64),
+                                           output_shape=1, **net)
+    else:
+        net["hidden_shapes"] = list(case["enc"])
+        pf = policies.GaussianContPolicyBasicBias(input_shape=S, output_shape=A, **net)
+        vf = networks.Net(input_shape=(S,), output_shape=1, **net)
+        vf.base = pf.base
+    return pf, vf
+
+
+def share_encoder(pf_params, vf_params, kind):
+    """Make vf's dict reference pf's tensor objects for the shared sub-module (encoder.* / base.*)."""
+    pre = "base." if kind == "mlp" else "encoder."
+    for k in vf_params:
+        if k.startswith(pre):
+            vf_params[k] = pf_params[k]
+    return vf_params
+
+
+def make_batch(case, update=0, B=None):
+    """A seeded minibatch in the distributions of BASELINE.md §3."""
+    B = case["B"] if B is None else B
+    rs = np.random.RandomState(1000 * case["seed"] + 17 + update)
+    S, A = case["S"], case["A"]
+    cols = [np.clip(rs.randn(B, S), -10, 10)]
+    if case["kind"] != "mlp":
+        cols.append(np.clip(rs.randn(B, 4 * 64 * 64), -2.5, 2.8))
+    return {
+        "obs": np.concatenate(cols, axis=1),
+        "acts": 0.1 * rs.randn(B, A),
+        "advs": rs.randn(B, 1),
+        "estimate_returns": rs.randn(B, 1),
+        "values": rs.randn(B, 1),
+    }
+
+
+def small_param_names(pf_sd, vf_sd, limit=4096):
+    return {(tag, k) for tag, sd in (("pf", pf_sd), ("vf", vf_sd)) for k, v in sd.items() if v.numel() <= limit}
+
+
+def make_gae_inputs(g):
+    rs = np.random.RandomState(g["seed"])
+    T, E = g["T"], g["E"]
+    tl = (rs.rand(T, E, 1) < 0.05).astype(np.float64) if g["tl_per_env"] else (rs.rand(T, 1) < 0.05).astype(np.float64)
+    return {
+        "rewards": rs.randn(T, E, 1),
+        "values": rs.randn(T, E, 1).astype(np.float32).astype(np.float64),  # network outputs are fp32
+        "terminals": (rs.rand(T, E, 1) < 0.05).astype(np.float64),
+        "time_limits": tl,
+        "last_value": rs.randn(E, 1).astype(np.float32).astype(np.float64),
+    }
+
+
+def load_golden(name):
+    return np.load(os.path.join(GOLDEN, name + ".npz"))
+
+
+def rel_err(a, b):
+    a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
+    return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-12))

@@ -1,0 +1,100 @@
+// vision4leg_amd — shared device/host definitions for the gfx950 (MI355X) PPO hot path.
+// Everything here is CDNA4-only: wave = 64 lanes, MFMA 16x16 tiles, LDS staging.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+namespace v4l {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+// ---------------------------------------------------------------- error state
+// The C ABI never throws; every entry returns int and leaves a message here.
+void set_error(const char* fmt, ...);
+const char* last_error();
+
+#define V4L_HIP_CHECK(expr)                                                        \
+  do {                                                                             \
+    hipError_t _e = (expr);                                                        \
+    if (_e != hipSuccess) {                                                        \
+      v4l::set_error("%s:%d: %s -> %s", __FILE__, __LINE__, #expr,                 \
+                     hipGetErrorString(_e));                                       \
+      return -2;                                                                   \
+    }                                                                              \
+  } while (0)
+
+#define V4L_REQUIRE(cond, ...)                                                     \
+  do {                                                                             \
+    if (!(cond)) {                                                                 \
+      v4l::set_error(__VA_ARGS__);                                                 \
+      return -1;                                                                   \
+    }                                                                              \
+  } while (0)
+
+#define V4L_LAUNCH_CHECK()                                                         \
+  do {                                                                             \
+    hipError_t _e = hipGetLastError();                                             \
+    if (_e != hipSuccess) {                                                        \
+      v4l::set_error("%s:%d: kernel launch -> %s", __FILE__, __LINE__,             \
+                     hipGetErrorString(_e));                                       \
+      return -2;                                                                   \
+    }                                                                              \
+  } while (0)
+
+static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+static inline int64_t cdiv64(int64_t a, int64_t b) { return (a + b - 1) / b; }
+static inline int round_up(int a, int b) { return cdiv(a, b) * b; }
+
+// ---------------------------------------------------------------- operand types
+// The contraction operand type T is either float (exact-f32 MFMA 16x16x4, used as the
+// parity mode) or __bf16 (MFMA 16x16x32 bf16, fp32 accumulate: the production mode).
+template <typename T> struct Op;
+template <> struct Op<float> {
+  static __device__ __forceinline__ float from_f32(float x) { return x; }
+  static __device__ __forceinline__ float to_f32(float x) { return x; }
+};
+template <> struct Op<__bf16> {
+  static __device__ __forceinline__ __bf16 from_f32(float x) { return (__bf16)x; }  // v_cvt_pk_bf16_f32: RNE
+  static __device__ __forceinline__ float to_f32(__bf16 x) { return (float)x; }
+};
+
+// One K=32 step of a 16x16 output tile. Every lane holds 8 operand elements whose k index is
+// 8*(lane>>4)+j for BOTH operands; row (A) / column (B) is lane&15.
+//   bf16: a single v_mfma_f32_16x16x32_bf16.
+//   f32 : eight v_mfma_f32_16x16x4_f32; in the j-th one lane group g=lane>>4 supplies k=8g+j. The
+//         hardware pairs A's and B's k by lane group, so the permuted k order is still a full
+//         contraction over the 32 k's (exact f32 fma chain, order differs from a CPU dot only).
+// C/D layout (both): col = lane&15, row = 4*(lane>>4)+r.
+__device__ __forceinline__ void mma_k32(f32x4& acc, const bf16x8& a, const bf16x8& b) {
+  acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc, 0, 0, 0);
+}
+struct __attribute__((aligned(16))) f32x8 { float v[8]; };
+__device__ __forceinline__ void mma_k32(f32x4& acc, const f32x8& a, const f32x8& b) {
+#pragma unroll
+  for (int j = 0; j < 8; ++j) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.v[j], b.v[j], acc, 0, 0, 0);
+}
+template <typename T> struct Frag;
+template <> struct Frag<__bf16> { typedef bf16x8 type; };
+template <> struct Frag<float> { typedef f32x8 type; };
+
+// 64-lane butterfly reductions
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+__device__ __forceinline__ float wave_min(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+}  // namespace v4l

@@ -1,0 +1,592 @@
+// Non-GEMM kernels of the PPO hot path: observation ingest, 17-token single-head attention (fwd/bwd),
+// residual + LayerNorm (fwd/bwd), token pooling, Gaussian-policy head, PPO losses, advantage statistics,
+// global-norm + Adam, weight packing and GAE. All fp32 (GAE fp64) on the VALU; one wave = 64 lanes.
+#pragma once
+#include "common.h"
+
+namespace v4l {
+
+constexpr int NTOK = 17;   // 1 proprio token + 4x4 depth patches (torchrl/networks/base.py:544,617-622)
+constexpr int TD = 64;     // token_dim (torchrl/networks/base.py:504)
+constexpr int OUT_LD = 16; // row stride of head outputs / their grads (A=6 or 1, zero padded)
+
+// --------------------------------------------------------------------------------- ingest
+// Splits reference observation rows [n][S + C*H*W] (torchrl/networks/nets.py:997-1000) into the two
+// device-resident arrays the kernels read: proprio [slot][Sp] fp32 (zero padded to Sp) and the depth
+// stack [slot][C*H*W] in the contraction operand type. One block per row.
+template <typename ImgT>
+__global__ __launch_bounds__(256) void ingest_kernel(const float* __restrict__ obs, int n, int S, int Sp, int img_elems,
+                                                     float* __restrict__ state, ImgT* __restrict__ image, int64_t slot0) {
+  const int r = blockIdx.x;
+  if (r >= n) return;
+  const float* src = obs + (int64_t)r * (S + img_elems);
+  float* sdst = state + (slot0 + r) * (int64_t)Sp;
+  ImgT* idst = image + (slot0 + r) * (int64_t)img_elems;
+  for (int i = threadIdx.x; i < Sp; i += 256) sdst[i] = i < S ? src[i] : 0.f;
+  const float* isrc = src + S;
+  for (int i = threadIdx.x; i < img_elems; i += 256) idst[i] = Op<ImgT>::from_f32(isrc[i]);
+}
+
+// --------------------------------------------------------------------------------- attention
+// nn.MultiheadAttention(64, 1 head) core on packed qkv rows [n*17][192] (q|k|v), per sample:
+//   P = softmax(q k^T / sqrt(64)),  ctx = P v.          (torch nn/functional.py multi_head_attention_forward;
+// built by the reference at torchrl/networks/nets.py:948-955). One wave per sample, 4 samples per block.
+constexpr int ATT_LD = TD + 1;  // +1 float: conflict-free both for lane=d and lane=(i,j) access
+constexpr int ATT_PLD = 20;
+
+__global__ __launch_bounds__(256) void attn_fwd_kernel(const float* __restrict__ qkv, int n, float* __restrict__ P,
+                                                       float* __restrict__ ctx) {
+  __shared__ float sq[4][NTOK * ATT_LD], sk[4][NTOK * ATT_LD], sv[4][NTOK * ATT_LD], sp[4][NTOK * ATT_PLD];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int b = blockIdx.x * 4 + w;
+  const bool act = b < n;
+  float *q = sq[w], *k = sk[w], *v = sv[w], *p = sp[w];
+  if (act) {
+    const float* src = qkv + (int64_t)b * NTOK * 3 * TD;
+    for (int idx = lane; idx < NTOK * 3 * TD; idx += 64) {
+      const int t = idx / (3 * TD), c = idx - t * 3 * TD;
+      const int part = c >> 6, d = c & 63;
+      const float x = src[idx];
+      (part == 0 ? q : part == 1 ? k : v)[t * ATT_LD + d] = x;
+    }
+  }
+  __syncthreads();
+  if (act) {
+    for (int pr = lane; pr < NTOK * NTOK; pr += 64) {
+      const int i = pr / NTOK, j = pr - i * NTOK;
+      float s = 0.f;
+#pragma unroll 16
+      for (int d = 0; d < TD; ++d) s = fmaf(q[i * ATT_LD + d], k[j * ATT_LD + d], s);
+      p[i * ATT_PLD + j] = s * 0.125f;
+    }
+  }
+  __syncthreads();
+  if (act && lane < NTOK) {
+    float mx = -INFINITY;
+    for (int j = 0; j < NTOK; ++j) mx = fmaxf(mx, p[lane * ATT_PLD + j]);
+    float e[NTOK], sum = 0.f;
+#pragma unroll
+    for (int j = 0; j < NTOK; ++j) { e[j] = expf(p[lane * ATT_PLD + j] - mx); sum += e[j]; }
+    const float inv = 1.f / sum;
+#pragma unroll
+    for (int j = 0; j < NTOK; ++j) {
+      const float pv = e[j] * inv;
+      p[lane * ATT_PLD + j] = pv;
+      P[((int64_t)b * NTOK + lane) * NTOK + j] = pv;
+    }
+  }
+  __syncthreads();
+  if (act) {
+    for (int i = 0; i < NTOK; ++i) {
+      float a = 0.f;
+#pragma unroll
+      for (int j = 0; j < NTOK; ++j) a = fmaf(p[i * ATT_PLD + j], v[j * ATT_LD + lane], a);
+      ctx[((int64_t)b * NTOK + i) * TD + lane] = a;
+    }
+  }
+}
+
+// Backward of the above: given dctx, saved P and qkv -> dqkv (same packed layout).
+//   dV = P^T dctx ; dP = dctx V^T ; dS = P o (dP - rowsum(P o dP)) ; dQ = dS K / 8 ; dK = dS^T Q / 8
+__global__ __launch_bounds__(128) void attn_bwd_kernel(const float* __restrict__ qkv, const float* __restrict__ P,
+                                                       const float* __restrict__ dctx, int n,
+                                                       float* __restrict__ dqkv) {
+  // 2 samples per block: four 17x65 fp32 tiles per sample would pass the 64 KiB static-LDS limit at 4
+  __shared__ float sq[2][NTOK * ATT_LD], sk[2][NTOK * ATT_LD], sv[2][NTOK * ATT_LD], sd[2][NTOK * ATT_LD];
+  __shared__ float sp[2][NTOK * ATT_PLD], sds[2][NTOK * ATT_PLD];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int b = blockIdx.x * 2 + w;
+  const bool act = b < n;
+  float *q = sq[w], *k = sk[w], *v = sv[w], *dc = sd[w], *p = sp[w], *ds = sds[w];
+  if (act) {
+    const float* src = qkv + (int64_t)b * NTOK * 3 * TD;
+    for (int idx = lane; idx < NTOK * 3 * TD; idx += 64) {
+      const int t = idx / (3 * TD), c = idx - t * 3 * TD;
+      const int part = c >> 6, d = c & 63;
+      (part == 0 ? q : part == 1 ? k : v)[t * ATT_LD + d] = src[idx];
+    }
+    for (int t = 0; t < NTOK; ++t) dc[t * ATT_LD + lane] = dctx[((int64_t)b * NTOK + t) * TD + lane];
+    for (int pr = lane; pr < NTOK * NTOK; pr += 64) {
+      const int i = pr / NTOK, j = pr - i * NTOK;
+      p[i * ATT_PLD + j] = P[(int64_t)b * NTOK * NTOK + pr];
+    }
+  }
+  __syncthreads();
+  float* dst = dqkv + (int64_t)b * NTOK * 3 * TD;
+  if (act) {
+    // dV[j][d], lane = d
+    for (int j = 0; j < NTOK; ++j) {
+      float a = 0.f;
+#pragma unroll
+      for (int i = 0; i < NTOK; ++i) a = fmaf(p[i * ATT_PLD + j], dc[i * ATT_LD + lane], a);
+      dst[j * 3 * TD + 2 * TD + lane] = a;
+    }
+    // dP[i][j], lane = pair
+    for (int pr = lane; pr < NTOK * NTOK; pr += 64) {
+      const int i = pr / NTOK, j = pr - i * NTOK;
+      float s = 0.f;
+#pragma unroll 16
+      for (int d = 0; d < TD; ++d) s = fmaf(dc[i * ATT_LD + d], v[j * ATT_LD + d], s);
+      ds[i * ATT_PLD + j] = s;
+    }
+  }
+  __syncthreads();
+  if (act && lane < NTOK) {
+    float rd = 0.f;
+#pragma unroll
+    for (int j = 0; j < NTOK; ++j) rd = fmaf(p[lane * ATT_PLD + j], ds[lane * ATT_PLD + j], rd);
+#pragma unroll
+    for (int j = 0; j < NTOK; ++j) ds[lane * ATT_PLD + j] = p[lane * ATT_PLD + j] * (ds[lane * ATT_PLD + j] - rd);
+  }
+  __syncthreads();
+  if (act) {
+    for (int i = 0; i < NTOK; ++i) {  // dQ[i][d]
+      float a = 0.f;
+#pragma unroll
+      for (int j = 0; j < NTOK; ++j) a = fmaf(ds[i * ATT_PLD + j], k[j * ATT_LD + lane], a);
+      dst[i * 3 * TD + lane] = a * 0.125f;
+    }
+    for (int j = 0; j < NTOK; ++j) {  // dK[j][d]
+      float a = 0.f;
+#pragma unroll
+      for (int i = 0; i < NTOK; ++i) a = fmaf(ds[i * ATT_PLD + j], q[i * ATT_LD + lane], a);
+      dst[j * 3 * TD + TD + lane] = a * 0.125f;
+    }
+  }
+}
+
+// --------------------------------------------------------------------------------- residual + LayerNorm
+// out = LN(x + y) * gamma + beta over 64 columns, eps 1e-5, biased variance (nn.LayerNorm inside
+// nn.TransformerEncoderLayer, post-norm). Saves xhat and rstd for the backward. One wave per row.
+__global__ __launch_bounds__(256) void add_ln_fwd_kernel(const float* __restrict__ x, const float* __restrict__ y, int rows,
+                                                         const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                         float* __restrict__ out, float* __restrict__ xhat,
+                                                         float* __restrict__ rstd) {
+  const int lane = threadIdx.x & 63;
+  const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= rows) return;
+  const int64_t o = (int64_t)r * TD + lane;
+  const float z = x[o] + y[o];
+  const float mean = wave_sum(z) * (1.f / TD);
+  const float c = z - mean;
+  const float var = wave_sum(c * c) * (1.f / TD);
+  const float rs = 1.f / sqrtf(var + 1e-5f);
+  const float xh = c * rs;
+  xhat[o] = xh;
+  out[o] = fmaf(xh, gamma[lane], beta[lane]);
+  if (lane == 0) rstd[r] = rs;
+}
+
+// d(x+y) from dout (in place allowed: dz may alias dout); dgamma/dbeta accumulated with atomics.
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ dout, const float* __restrict__ xhat,
+                                                     const float* __restrict__ rstd, const float* __restrict__ gamma,
+                                                     int rows, float* __restrict__ dz, float* __restrict__ dgamma,
+                                                     float* __restrict__ dbeta) {
+  __shared__ float sg[4][TD], sb[4][TD];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const float g = gamma[lane];
+  float ag = 0.f, ab = 0.f;
+  for (int r = blockIdx.x * 4 + w; r < rows; r += gridDim.x * 4) {
+    const int64_t o = (int64_t)r * TD + lane;
+    const float d = dout[o], xh = xhat[o];
+    ag = fmaf(d, xh, ag);
+    ab += d;
+    const float dxh = d * g;
+    const float c1 = wave_sum(dxh) * (1.f / TD);
+    const float c2 = wave_sum(dxh * xh) * (1.f / TD);
+    dz[o] = rstd[r] * (dxh - c1 - xh * c2);
+  }
+  sg[w][lane] = ag;
+  sb[w][lane] = ab;
+  __syncthreads();
+  if (w == 0) {
+    atomicAdd(dgamma + lane, sg[0][lane] + sg[1][lane] + sg[2][lane] + sg[3][lane]);
+    atomicAdd(dbeta + lane, sb[0][lane] + sb[1][lane] + sb[2][lane] + sb[3][lane]);
+  }
+}
+
+// --------------------------------------------------------------------------------- token pooling
+// [state token | mean of the 16 depth tokens] -> [n][128]  (torchrl/networks/nets.py:1015-1021,1034)
+__global__ __launch_bounds__(128) void pool_fwd_kernel(const float* __restrict__ x, int n, float* __restrict__ pooled) {
+  const int b = blockIdx.x, t = threadIdx.x;
+  if (b >= n) return;
+  const float* xb = x + (int64_t)b * NTOK * TD;
+  float o;
+  if (t < TD) o = xb[t];
+  else {
+    const int d = t - TD;
+    float s = 0.f;
+#pragma unroll
+    for (int i = 1; i < NTOK; ++i) s += xb[i * TD + d];
+    o = s * (1.f / 16.f);
+  }
+  pooled[(int64_t)b * 2 * TD + t] = o;
+}
+__global__ __launch_bounds__(64) void pool_bwd_kernel(const float* __restrict__ dpooled, int n, float* __restrict__ dx) {
+  const int b = blockIdx.x, d = threadIdx.x;
+  if (b >= n) return;
+  const float ds = dpooled[(int64_t)b * 2 * TD + d];
+  const float dm = dpooled[(int64_t)b * 2 * TD + TD + d] * (1.f / 16.f);
+  float* o = dx + (int64_t)b * NTOK * TD;
+  o[d] = ds;
+#pragma unroll
+  for (int i = 1; i < NTOK; ++i) o[i * TD + d] = dm;
+}
+
+// --------------------------------------------------------------------------------- block reductions
+struct Red4 { double s, s2; float mx, mn; };
+// 256-thread block reduction of (sum, sum of squares, max, min); result valid on all threads.
+__device__ __forceinline__ Red4 block_red4(double s, double s2, float mx, float mn) {
+  __shared__ double rs[4], rs2[4];
+  __shared__ float rmx[4], rmn[4];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    s += __shfl_xor(s, o, 64);
+    s2 += __shfl_xor(s2, o, 64);
+    mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+    mn = fminf(mn, __shfl_xor(mn, o, 64));
+  }
+  __syncthreads();  // protect reuse across consecutive calls
+  if (lane == 0) { rs[w] = s; rs2[w] = s2; rmx[w] = mx; rmn[w] = mn; }
+  __syncthreads();
+  Red4 r;
+  r.s = rs[0] + rs[1] + rs[2] + rs[3];
+  r.s2 = rs2[0] + rs2[1] + rs2[2] + rs2[3];
+  r.mx = fmaxf(fmaxf(rmx[0], rmx[1]), fmaxf(rmx[2], rmx[3]));
+  r.mn = fminf(fminf(rmn[0], rmn[1]), fminf(rmn[2], rmn[3]));
+  return r;
+}
+
+// Layout of the 24-float statistics record one PPO minibatch update produces. [0..17] are the 18 logger
+// keys of torchrl/algo/on_policy/ppo.py:77-92,122-123,142-145 in that order; the rest is internal.
+enum {
+  ST_ADV_MEAN = 0, ST_ADV_STD, ST_ADV_MAX, ST_ADV_MIN, ST_VF_LOSS, ST_GN_VF, ST_PI_LOSS,
+  ST_LP_MEAN, ST_LP_STD, ST_LP_MAX, ST_LP_MIN, ST_LS_MEAN, ST_LS_STD, ST_LS_MAX, ST_LS_MIN,
+  ST_RATIO_MAX, ST_RATIO_MIN, ST_GN_PF,
+  ST_ADV_SUM = 18, ST_ADV_SUMSQ, ST_ADV_CNT,  // raw sums for the data-parallel 3-scalar exchange
+  ST_SUMSQ_VF = 21, ST_SUMSQ_PF = 22,        // squared gradient norms (accumulated by grad_sumsq_kernel)
+  ST_SIZE = 24
+};
+
+// advs.mean(), advs.std() (Bessel), max, min of the minibatch (ppo.py:142-145). Single block.
+__global__ __launch_bounds__(256) void adv_stats_kernel(const float* __restrict__ adv, const int* __restrict__ rowidx, int n,
+                                                        float* __restrict__ st) {
+  double s = 0.0; float mx = -INFINITY, mn = INFINITY;
+  for (int i = threadIdx.x; i < n; i += 256) {
+    const float a = adv[rowidx ? rowidx[i] : i];
+    s += a; mx = fmaxf(mx, a); mn = fminf(mn, a);
+  }
+  Red4 r = block_red4(s, 0.0, mx, mn);
+  const double mean = r.s / n;
+  double q = 0.0, sq = 0.0;
+  for (int i = threadIdx.x; i < n; i += 256) {
+    const double a = adv[rowidx ? rowidx[i] : i];
+    q += (a - mean) * (a - mean);
+    sq += a * a;
+  }
+  Red4 r2 = block_red4(q, sq, 0.f, 0.f);
+  if (threadIdx.x == 0) {
+    st[ST_ADV_MEAN] = (float)mean;
+    st[ST_ADV_STD] = (float)sqrt(r2.s / (double)(n - 1));
+    st[ST_ADV_MAX] = r.mx;
+    st[ST_ADV_MIN] = r.mn;
+    st[ST_ADV_SUM] = (float)r.s;
+    st[ST_ADV_SUMSQ] = (float)r2.s2;
+    st[ST_ADV_CNT] = (float)n;
+  }
+}
+// Data-parallel: recompute mean/std from the all-reduced (sum, sumsq, count).
+__global__ void adv_stats_finalize_kernel(float* st) {
+  const double s = st[ST_ADV_SUM], s2 = st[ST_ADV_SUMSQ], c = st[ST_ADV_CNT];
+  const double mean = s / c;
+  st[ST_ADV_MEAN] = (float)mean;
+  st[ST_ADV_STD] = (float)sqrt(fmax(0.0, (s2 - c * mean * mean) / (c - 1.0)));
+}
+
+// nn.MSELoss()(values, est_rets) and its gradient (ppo.py:94-123; clipped_value_loss=False path, and the
+// clipped variant of ppo.py:105-112 when clip > 0). values is the critic output [n][OUT_LD], column 0.
+__global__ __launch_bounds__(256) void critic_loss_kernel(const float* __restrict__ values, const float* __restrict__ ret,
+                                                          const float* __restrict__ oldv, const int* __restrict__ rowidx,
+                                                          int n, float inv_n, int clipped, float clip,
+                                                          float* __restrict__ dvalues, float* __restrict__ st) {
+  double s = 0.0;
+  for (int i = threadIdx.x; i < n; i += 256) {
+    const int slot = rowidx ? rowidx[i] : i;
+    const float v = values[(int64_t)i * OUT_LD], r = ret[slot];
+    float g, l;
+    if (!clipped) {
+      const float d = v - r;
+      l = d * d;
+      g = 2.f * d * inv_n;
+    } else {
+      const float ov = oldv[slot];
+      const float dv = v - ov;
+      const float vc = ov + fminf(fmaxf(dv, -clip), clip);
+      const float l1 = (v - r) * (v - r), l2 = (vc - r) * (vc - r);
+      // 0.5 * max(l1, l2).mean(); torch.max splits ties evenly between both arguments
+      const float g1 = 2.f * (v - r);
+      const float g2 = (dv >= -clip && dv <= clip) ? 2.f * (vc - r) : 0.f;
+      l = 0.5f * fmaxf(l1, l2);
+      g = 0.5f * inv_n * (l1 > l2 ? g1 : (l1 < l2 ? g2 : 0.5f * (g1 + g2)));
+    }
+    s += l;
+#pragma unroll
+    for (int c = 0; c < OUT_LD; ++c) dvalues[(int64_t)i * OUT_LD + c] = c == 0 ? g : 0.f;
+  }
+  Red4 r = block_red4(s, 0.0, 0.f, 0.f);
+  if (threadIdx.x == 0) st[ST_VF_LOSS] = (float)(r.s * (double)inv_n);
+}
+
+constexpr float LOG_SIG_MAX = 2.f, LOG_SIG_MIN = -5.f;  // torchrl/policies/continuous_policy.py:8-9
+constexpr float HALF_LOG_2PI = 0.91893853320467274178f;
+
+// Clipped-surrogate + entropy loss of PPO.update_actor (ppo.py:42-92) and its gradient w.r.t. the policy
+// mean [n][OUT_LD] and logstd [A]. logp_old comes from the frozen target policy's mean/logstd on the same
+// minibatch. Advantages are normalised with the minibatch statistics in st (ppo.py:148). Single block.
+// inv_n is 1/(global batch) so that data-parallel ranks sum to the big-batch gradient.
+__global__ __launch_bounds__(256) void actor_loss_kernel(const float* __restrict__ mean, const float* __restrict__ logstd,
+                                                         const float* __restrict__ tmean, const float* __restrict__ tlogstd,
+                                                         const float* __restrict__ acts, const float* __restrict__ adv,
+                                                         const int* __restrict__ rowidx, int n, int A, float inv_n,
+                                                         float clip, float ent_coef, float* __restrict__ dmean,
+                                                         float* __restrict__ dlogstd, float* __restrict__ st) {
+  __shared__ float sdl[4][8];
+  float ls[8], sg[8], lsg[8], tls[8], tsg[8], tlsg[8], dl[8];
+  float ent = 0.f;
+  for (int a = 0; a < 8; ++a) {
+    dl[a] = 0.f;
+    if (a < A) {
+      ls[a] = fminf(fmaxf(logstd[a], LOG_SIG_MIN), LOG_SIG_MAX);
+      sg[a] = expf(ls[a]); lsg[a] = logf(sg[a]);
+      tls[a] = fminf(fmaxf(tlogstd[a], LOG_SIG_MIN), LOG_SIG_MAX);
+      tsg[a] = expf(tls[a]); tlsg[a] = logf(tsg[a]);
+      ent += 0.5f + HALF_LOG_2PI + lsg[a];
+    }
+  }
+  const float amean = st[ST_ADV_MEAN], astd = st[ST_ADV_STD];
+  double s_lp = 0.0, s_lp2 = 0.0, s_sur = 0.0;
+  float lp_mx = -INFINITY, lp_mn = INFINITY, r_mx = -INFINITY, r_mn = INFINITY;
+  for (int i = threadIdx.x; i < n; i += 256) {
+    const int slot = rowidx ? rowidx[i] : i;
+    float lp = 0.f, lpo = 0.f, z2[8], dm[8];
+    for (int a = 0; a < A; ++a) {
+      const float x = acts[(int64_t)slot * A + a];
+      const float d = x - mean[(int64_t)i * OUT_LD + a];
+      const float var = sg[a] * sg[a];
+      lp += -(d * d) / (2.f * var) - lsg[a] - HALF_LOG_2PI;
+      z2[a] = d * d / var;
+      dm[a] = d / var;
+      const float dt = x - tmean[(int64_t)i * OUT_LD + a];
+      lpo += -(dt * dt) / (2.f * tsg[a] * tsg[a]) - tlsg[a] - HALF_LOG_2PI;
+    }
+    const float ratio = expf(lp - lpo);
+    const float an = (adv[slot] - amean) / (astd + 1e-5f);
+    const float pre = ratio * an;
+    const float clp = fminf(fmaxf(ratio, 1.f - clip), 1.f + clip) * an;
+    s_sur += fminf(pre, clp);
+    // d(-mean(min(pre,clp)))/dlogp: the clipped branch has zero slope outside the clip range
+    const float dlp = (pre <= clp) ? -inv_n * an * ratio : 0.f;
+    for (int a = 0; a < OUT_LD; ++a) dmean[(int64_t)i * OUT_LD + a] = a < A ? dlp * dm[a] : 0.f;
+    for (int a = 0; a < A; ++a) dl[a] += dlp * (z2[a] - 1.f);
+    s_lp += lp; s_lp2 += (double)lp * lp;
+    lp_mx = fmaxf(lp_mx, lp); lp_mn = fminf(lp_mn, lp);
+    r_mx = fmaxf(r_mx, ratio); r_mn = fminf(r_mn, ratio);
+  }
+  Red4 r1 = block_red4(s_lp, s_lp2, lp_mx, lp_mn);
+  Red4 r2 = block_red4(s_sur, 0.0, r_mx, r_mn);
+  // reduce dlogstd over the block
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  for (int a = 0; a < 8; ++a) {
+    float v = wave_sum(dl[a]);
+    if (lane == 0) sdl[w][a] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x < A) {
+    const int a = threadIdx.x;
+    const float raw = logstd[a];
+    float g = sdl[0][a] + sdl[1][a] + sdl[2][a] + sdl[3][a];
+    // entropy term: -ent_coef * mean_b(sum_a log sigma_a + const); each local sample carries weight inv_n
+    g += -ent_coef * inv_n * (float)n;
+    dlogstd[a] = (raw >= LOG_SIG_MIN && raw <= LOG_SIG_MAX) ? g : 0.f;
+  }
+  if (threadIdx.x == 0) {
+    const double lpm = r1.s / n;
+    st[ST_PI_LOSS] = (float)(-(r2.s / n) - (double)ent_coef * ent);
+    st[ST_LP_MEAN] = (float)lpm;
+    st[ST_LP_STD] = (float)sqrt(fmax(0.0, (r1.s2 - n * lpm * lpm) / (double)(n - 1)));
+    st[ST_LP_MAX] = r1.mx; st[ST_LP_MIN] = r1.mn;
+    st[ST_RATIO_MAX] = r2.mx; st[ST_RATIO_MIN] = r2.mn;
+    double m = 0.0; float mx = -INFINITY, mn = INFINITY;
+    for (int a = 0; a < A; ++a) { m += ls[a]; mx = fmaxf(mx, ls[a]); mn = fminf(mn, ls[a]); }
+    m /= A;
+    double q = 0.0;
+    for (int a = 0; a < A; ++a) q += (ls[a] - m) * (ls[a] - m);
+    st[ST_LS_MEAN] = (float)m;
+    st[ST_LS_STD] = A > 1 ? (float)sqrt(q / (A - 1)) : NAN;
+    st[ST_LS_MAX] = mx; st[ST_LS_MIN] = mn;
+  }
+}
+
+// Gaussian head post-processing for the policy API (continuous_policy.py:85-146,486-492): from the padded
+// mean [n][OUT_LD] and logstd [A] produce contiguous mean/std [n][A], clamped log_std [A], ent [n] and, when
+// acts != null, log_prob [n] of those actions.
+__global__ __launch_bounds__(256) void gauss_head_kernel(const float* __restrict__ meanp, const float* __restrict__ logstd,
+                                                         const float* __restrict__ acts, int n, int A,
+                                                         float* __restrict__ mean, float* __restrict__ stdv,
+                                                         float* __restrict__ logstd_c, float* __restrict__ ent,
+                                                         float* __restrict__ logp) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  float e = 0.f, lp = 0.f;
+  for (int a = 0; a < A; ++a) {
+    const float ls = fminf(fmaxf(logstd[a], LOG_SIG_MIN), LOG_SIG_MAX);
+    const float sg = expf(ls), lsg = logf(sg);
+    e += 0.5f + HALF_LOG_2PI + lsg;
+    if (i == 0) logstd_c[a] = ls;
+    if (i < n) {
+      const float mu = meanp[(int64_t)i * OUT_LD + a];
+      mean[(int64_t)i * A + a] = mu;
+      stdv[(int64_t)i * A + a] = sg;
+      if (acts != nullptr) {
+        const float d = acts[(int64_t)i * A + a] - mu;
+        lp += -(d * d) / (2.f * sg * sg) - lsg - HALF_LOG_2PI;
+      }
+    }
+  }
+  if (i < n) {
+    ent[i] = e;
+    if (acts != nullptr) logp[i] = lp;
+  }
+}
+
+// Copy column 0 of a padded head output to a contiguous [n] vector (critic values for the collector).
+__global__ __launch_bounds__(256) void col0_kernel(const float* __restrict__ src, int n, float* __restrict__ dst) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < n) dst[i] = src[(int64_t)i * OUT_LD];
+}
+
+// --------------------------------------------------------------------------------- grad norm + Adam
+// sum of squares of a flat gradient buffer -> *acc (fp32 atomics of per-block double partials)
+__global__ __launch_bounds__(256) void grad_sumsq_kernel(const float* __restrict__ g, int64_t n, float* __restrict__ acc) {
+  double s = 0.0;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const float x = g[i];
+    s += (double)x * x;
+  }
+  Red4 r = block_red4(s, 0.0, 0.f, 0.f);
+  if (threadIdx.x == 0) atomicAdd(acc, (float)r.s);
+}
+
+// One (tensor) segment of an optimiser's parameter set: parameters live in caller-owned tensors (pointer
+// table), gradients and both Adam moments in flat buffers at offset goff.
+struct ParamSeg { float* p; int64_t goff; int64_t n; int64_t blk0; };  // blk0: first block of this segment
+
+// torch.nn.utils.clip_grad_norm_(params, max_norm) followed by torch.optim.Adam (eps after sqrt(v_hat),
+// no weight decay == AdamW with wd 0) — torchrl/algo/on_policy/ppo.py:73-75,118-120, a2c.py:30-40.
+// Operation order follows torch/optim/adam.py::_single_tensor_adam. The clip coefficient is derived from the
+// squared norm accumulated in *sumsq; thread 0 of block 0 also publishes the pre-clip norm to *norm_out.
+__global__ __launch_bounds__(256) void clip_adam_kernel(const ParamSeg* __restrict__ segs, int nseg,
+                                                        const float* __restrict__ g, float* __restrict__ m,
+                                                        float* __restrict__ v, const float* __restrict__ sumsq,
+                                                        float grad_scale, float max_norm, float beta1, float beta2,
+                                                        float eps, float step_size, float bc2_sqrt,
+                                                        float* __restrict__ norm_out) {
+  // locate segment (nseg is small: linear scan on the scalar unit)
+  int si = 0;
+  for (int i = 1; i < nseg; ++i) if ((int64_t)blockIdx.x >= segs[i].blk0) si = i;
+  const ParamSeg sg = segs[si];
+  // grad_scale: gradients in g are sums over ranks (or already means when 1.0)
+  const float tot = sqrtf(*sumsq) * grad_scale;
+  float coef = max_norm / (tot + 1e-6f);
+  coef = fminf(coef, 1.f) * grad_scale;
+  if (blockIdx.x == 0 && threadIdx.x == 0 && norm_out != nullptr) *norm_out = tot;
+  const int64_t i = ((int64_t)blockIdx.x - sg.blk0) * 256 + threadIdx.x;
+  if (i >= sg.n) return;
+  const int64_t o = sg.goff + i;
+  const float gr = g[o] * coef;
+  float mm = m[o], vv = v[o];
+  mm = mm + (gr - mm) * (1.f - beta1);           // exp_avg.lerp_(grad, 1 - beta1)
+  vv = vv * beta2 + (1.f - beta2) * (gr * gr);   // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, value=1-beta2)
+  const float denom = sqrtf(vv) / bc2_sqrt + eps;
+  sg.p[i] = sg.p[i] - step_size * (mm / denom);  // param.addcdiv_(exp_avg, denom, value=-step_size)
+  m[o] = mm;
+  v[o] = vv;
+}
+
+// --------------------------------------------------------------------------------- weight packing
+// Builds the contraction-ready copies of a weight tensor (operand type T, zero padded to the GEMM tiles).
+enum { PK_NT = 0, PK_T = 1, PK_CONV_NHWC = 2, PK_CONV_NHWC_T = 3, PK_CONV_DGRAD = 4 };
+struct PackDesc {
+  const float* src;  // PyTorch-layout weight
+  int64_t dst_off;   // element offset in the packed buffer
+  int kind;
+  int R, Cc;         // packed rows / cols (padded)
+  int N, K;          // source: [N][K] (Linear) or [N][Cin*taps] (Conv)
+  int Cin, taps, KW; // conv
+  int s, py, px, TW; // dgrad class
+  int64_t blk0;
+};
+template <typename T>
+__global__ __launch_bounds__(256) void pack_kernel(const PackDesc* __restrict__ descs, int nd, T* __restrict__ dst) {
+  int di = 0;
+  for (int i = 1; i < nd; ++i) if ((int64_t)blockIdx.x >= descs[i].blk0) di = i;
+  const PackDesc d = descs[di];
+  const int64_t e = ((int64_t)blockIdx.x - d.blk0) * 256 + threadIdx.x;
+  if (e >= (int64_t)d.R * d.Cc) return;
+  const int r = (int)(e / d.Cc), c = (int)(e - (int64_t)r * d.Cc);
+  float val = 0.f;
+  switch (d.kind) {
+    case PK_NT: if (r < d.N && c < d.K) val = d.src[(int64_t)r * d.K + c]; break;
+    case PK_T: if (r < d.K && c < d.N) val = d.src[(int64_t)c * d.K + r]; break;
+    case PK_CONV_NHWC:  // dst[n][tap*Cin+ci] = W[n][ci][tap]
+      if (r < d.N && c < d.K) { const int tap = c / d.Cin, ci = c - tap * d.Cin; val = d.src[(int64_t)r * d.K + ci * d.taps + tap]; }
+      break;
+    case PK_CONV_NHWC_T:  // dst[tap*Cin+ci][n] = W[n][ci][tap]
+      if (r < d.K && c < d.N) { const int tap = r / d.Cin, ci = r - tap * d.Cin; val = d.src[(int64_t)c * d.K + ci * d.taps + tap]; }
+      break;
+    case PK_CONV_DGRAD: {  // dst[ci][(a*TW+bb)*N + n] = W[n][ci][py+s*a][px+s*bb]
+      const int kk = d.TW * d.TW * d.N;
+      if (r < d.Cin && c < kk) {
+        const int tap = c / d.N, n = c - tap * d.N;
+        const int a = tap / d.TW, bb = tap - a * d.TW;
+        const int ky = d.py + d.s * a, kx = d.px + d.s * bb;
+        val = d.src[(int64_t)n * d.K + r * d.taps + ky * d.KW + kx];
+      }
+    } break;
+  }
+  dst[d.dst_off + e] = Op<T>::from_f32(val);
+}
+
+// --------------------------------------------------------------------------------- GAE
+// torchrl/replay_buffers/on_policy.py:17-45 — fp64, same expression order as the numpy code, FMA contraction
+// off, so the result is bit-identical to the reference's (then optionally cast once to fp32, as
+// ppo.py:138,140 does). One lane per env, sequential in t (the recursion is per-env; coalesced over e).
+// tl_stride_e: 0 when _time_limits is [T,1] (broadcast over envs), 1 when [T,E,1].
+__global__ void gae_kernel(const double* __restrict__ rewards, const double* __restrict__ values,
+                           const double* __restrict__ terminals, const double* __restrict__ time_limits,
+                           int tl_stride_e, const double* __restrict__ last_value, int T, int E, double gamma,
+                           double tau, int use_tl, double* __restrict__ advs, double* __restrict__ rets,
+                           float* __restrict__ advs32, float* __restrict__ rets32) {
+#pragma clang fp contract(off)
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= E) return;
+  double A = 0.0;
+  double vnext = last_value[e];
+  for (int t = T - 1; t >= 0; --t) {
+    const int64_t o = (int64_t)t * E + e;
+    const double nt = 1.0 - terminals[o];
+    const double vt = values[o];
+    const double c = nt * gamma;
+    double delta = rewards[o] + c * vnext;
+    delta = delta - vt;
+    A = delta + (c * tau) * A;
+    if (use_tl) A = A * (1.0 - time_limits[tl_stride_e ? o : t]);
+    const double r = A + vt;
+    advs[o] = A;
+    rets[o] = r;
+    if (advs32 != nullptr) { advs32[o] = (float)A; rets32[o] = (float)r; }
+    vnext = vt;
+  }
+}
+
+}  // namespace v4l

@@ -1,0 +1,444 @@
+// MFMA GEMM cores for the gfx950 PPO hot path.
+//
+//   gemm_nt : C[m][n] = epi( sum_k A(m,k) * Bp[n][k] )        forward linears/convs and data-grads
+//   gemm_tn : dW[n][k] += sum_m Y(m,n) * X(m,k)               weight-grads (split over m, fp32 atomics)
+//
+// A / X / Y are *loader functors*: a row context (all integer divisions hoisted out of the k loop) plus
+// a "give me 8 consecutive k as fp32" call. That is what turns one MFMA core into dense linear,
+// implicit-im2col convolution (CHW depth stack and NHWC feature maps) and gather-form conv data-grad
+// without ever materialising an im2col matrix in HBM. Operands are rounded to T (bf16 or exact f32)
+// when they are staged into LDS; accumulation is always fp32 in the MFMA accumulators.
+//
+// Tiling: 256 threads = 4 waves. gemm_nt: 128(M) x BN(N) x 64(K) per stage, wave w owns rows
+// [32w,32w+32). gemm_tn: BN(n) x 64(k) output per block, 64 rows of the reduction (m) per stage, both
+// operands are transposed on their way into LDS so the MFMA fragments are contiguous 16-byte reads.
+// Global loads for stage t+1 are issued before the MFMAs of stage t (register prefetch).
+#pragma once
+#include "common.h"
+
+namespace v4l {
+
+struct RowCtx {
+  int64_t base;   // element offset of the row's first element
+  int a, b;       // loader specific (e.g. output pixel coordinates)
+  int valid;
+};
+
+__device__ __forceinline__ void zero8(float (&v)[8]) {
+#pragma unroll
+  for (int j = 0; j < 8; ++j) v[j] = 0.f;
+}
+__device__ __forceinline__ void ld8(const float* p, float (&v)[8]) {
+  const float4 x = *reinterpret_cast<const float4*>(p);
+  const float4 y = *reinterpret_cast<const float4*>(p + 4);
+  v[0] = x.x; v[1] = x.y; v[2] = x.z; v[3] = x.w;
+  v[4] = y.x; v[5] = y.y; v[6] = y.z; v[7] = y.w;
+}
+// 8 bf16 that are only guaranteed 8-byte aligned (conv1 windows start at 4*ox elements)
+__device__ __forceinline__ void ld8(const __bf16* p, float (&v)[8]) {
+  typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+  const bf16x4 x = *reinterpret_cast<const bf16x4*>(p);
+  const bf16x4 y = *reinterpret_cast<const bf16x4*>(p + 4);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) { v[j] = (float)x[j]; v[4 + j] = (float)y[j]; }
+}
+
+// ------------------------------------------------------------------------------------ loaders
+// Dense fp32 row-major matrix. lda % 4 == 0, K % 8 == 0, base 16-byte aligned.
+// rowidx: optional gather (minibatch row -> rollout slot). tokmap: 1 = rows are the 16 depth tokens
+// of each sample inside a [B,17,D] token tensor (m -> (m/16)*17 + 1 + m%16).
+struct ADense {
+  const float* p;
+  int lda, M, K;
+  const int* rowidx;
+  int tokmap;
+  const float* mask;  // optional, same indexing as p: value passes only where mask > 0 (ReLU backward)
+  __device__ __forceinline__ RowCtx row(int m) const {
+    RowCtx rc;
+    rc.valid = m < M;
+    rc.a = rc.b = 0;
+    int r = m;
+    if (tokmap == 1) r = (m >> 4) * 17 + 1 + (m & 15);
+    if (rowidx != nullptr && rc.valid) r = rowidx[m];
+    rc.base = (int64_t)r * lda;
+    return rc;
+  }
+  __device__ __forceinline__ void load(const RowCtx& rc, int k0, float (&v)[8]) const {
+    if (rc.valid && k0 < K) {
+      ld8(p + rc.base + k0, v);
+      if (mask != nullptr) {
+        float mk[8];
+        ld8(mask + rc.base + k0, mk);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = mk[j] > 0.f ? v[j] : 0.f;
+      }
+    } else zero8(v);
+  }
+};
+
+// conv1: 8x8 stride-4 windows over the [n][C][IH][IW] depth stack (reference layout of the image
+// part of an observation row, torchrl/networks/nets.py:997-1000). k = (c, ky, kx) = PyTorch's weight
+// order, one chunk = the 8 kx of one (c,ky). SrcT is float (exact mode) or __bf16 (bf16 mode: the
+// image is stored rounded once at ingest, which is the same rounding the contraction would apply).
+template <typename SrcT>
+struct AIm2colCHW {
+  const SrcT* p;
+  int C, IH, IW, OH, OW, stride;  // KH = KW = 8
+  int M;                          // n * OH * OW
+  const int* rowidx;              // per-sample gather
+  __device__ __forceinline__ RowCtx row(int m) const {
+    RowCtx rc;
+    rc.valid = m < M;
+    const int opix = OH * OW;
+    int b = m / opix, q = m - b * opix;
+    int oy = q / OW, ox = q - oy * OW;
+    if (rowidx != nullptr && rc.valid) b = rowidx[b];
+    rc.a = oy; rc.b = ox;
+    rc.base = (int64_t)b * C * IH * IW + (int64_t)(oy * stride) * IW + ox * stride;
+    return rc;
+  }
+  __device__ __forceinline__ void load(const RowCtx& rc, int k0, float (&v)[8]) const {
+    const int c = k0 >> 6, ky = (k0 >> 3) & 7;
+    if (rc.valid && c < C) ld8(p + rc.base + (int64_t)c * IH * IW + ky * IW, v);
+    else zero8(v);
+  }
+};
+
+// conv2/conv3 forward (and the X side of their weight-grads): fp32 NHWC feature map [n][IH][IW][Cin],
+// k = (ky, kx, c) so that 8 consecutive k are 8 consecutive channels (Cin % 8 == 0).
+struct AIm2colNHWC {
+  const float* p;
+  int IH, IW, Cin, OH, OW, KH, KW, stride;
+  int M, K;  // n*OH*OW, KH*KW*Cin
+  __device__ __forceinline__ RowCtx row(int m) const {
+    RowCtx rc;
+    rc.valid = m < M;
+    const int opix = OH * OW;
+    int b = m / opix, q = m - b * opix;
+    int oy = q / OW, ox = q - oy * OW;
+    rc.a = oy; rc.b = ox;
+    rc.base = (((int64_t)b * IH + oy * stride) * IW + ox * stride) * Cin;
+    return rc;
+  }
+  __device__ __forceinline__ void load(const RowCtx& rc, int k0, float (&v)[8]) const {
+    if (rc.valid && k0 < K) {
+      const int tap = k0 / Cin, c0 = k0 - tap * Cin;
+      const int ky = tap / KW, kx = tap - ky * KW;
+      ld8(p + rc.base + (int64_t)(ky * IW + kx) * Cin + c0, v);
+    } else zero8(v);
+  }
+};
+
+// Gather-form convolution data-grad for one stride-parity class (py,px) of input pixels:
+//   dX[b,iy,ix,c] = sum_{a,bb,n} dY[b, jy-a, jx-bb, n] * W[n,c,py+s*a,px+s*bb],  iy = py+s*jy, ix = px+s*jx
+// rows m enumerate (b, jy, jx); k = (a, bb, n). Needs KH % s == 0 (4/2 and 3/1 in NatureCNN).
+struct ADgradNHWC {
+  const float* p;  // dY [n][OH][OW][Cout]
+  int OH, OW, Cout, TH, TW;  // TH = KH/s taps per axis
+  int nIy, nIx;              // pixels of this class per axis
+  int M, K;                  // n*nIy*nIx, TH*TW*Cout
+  __device__ __forceinline__ RowCtx row(int m) const {
+    RowCtx rc;
+    rc.valid = m < M;
+    const int npix = nIy * nIx;
+    int b = m / npix, q = m - b * npix;
+    int jy = q / nIx, jx = q - jy * nIx;
+    rc.a = jy; rc.b = jx;
+    rc.base = (int64_t)b * OH * OW * Cout;
+    return rc;
+  }
+  __device__ __forceinline__ void load(const RowCtx& rc, int k0, float (&v)[8]) const {
+    if (rc.valid && k0 < K) {
+      const int tap = k0 / Cout, n0 = k0 - tap * Cout;
+      const int a = tap / TW, bb = tap - a * TW;
+      const int oy = rc.a - a, ox = rc.b - bb;
+      if (oy >= 0 && oy < OH && ox >= 0 && ox < OW) {
+        ld8(p + rc.base + (int64_t)(oy * OW + ox) * Cout + n0, v);
+        return;
+      }
+    }
+    zero8(v);
+  }
+};
+
+// ------------------------------------------------------------------------------------ epilogue
+enum { ROWMAP_IDENT = 0, ROWMAP_TOK_DEPTH = 1, ROWMAP_TOK_STATE = 2, ROWMAP_DGRAD = 3 };
+
+struct Epi {
+  float* C;
+  int ldc, M, N;
+  const float* bias;  // [N] or null
+  int relu;           // max(x,0) after bias
+  const float* mask;  // null, or multiply by (mask[orow*ldmask+n] > 0): ReLU backward of the layer below
+  int ldmask;
+  int accumulate;     // C += instead of C =
+  int rowmap;
+  // ROWMAP_DGRAD: class (py,px), stride s, class pixel counts, input plane
+  int py, px, s, nIy, nIx, IH, IW;
+  __device__ __forceinline__ int64_t out_row(int m) const {
+    switch (rowmap) {
+      case ROWMAP_TOK_DEPTH: return (int64_t)(m >> 4) * 17 + 1 + (m & 15);
+      case ROWMAP_TOK_STATE: return (int64_t)m * 17;
+      case ROWMAP_DGRAD: {
+        const int npix = nIy * nIx;
+        int b = m / npix, q = m - b * npix;
+        int jy = q / nIx, jx = q - jy * nIx;
+        return ((int64_t)b * IH + (py + s * jy)) * IW + (px + s * jx);
+      }
+      default: return m;
+    }
+  }
+};
+
+template <typename T> struct Tile {
+  static constexpr int BK = 64;
+  static constexpr int LD = BK + (sizeof(T) == 2 ? 8 : 4);  // +16 bytes of row padding
+};
+
+template <typename T>
+__device__ __forceinline__ void st8(T* dst, const float (&v)[8]) {
+  typename Frag<T>::type f;
+  if constexpr (sizeof(T) == 2) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) f[j] = (__bf16)v[j];
+  } else {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) f.v[j] = v[j];
+  }
+  *reinterpret_cast<typename Frag<T>::type*>(dst) = f;
+}
+
+// ------------------------------------------------------------------------------------ gemm_nt
+template <typename T, int BN, class AL>
+__global__ __launch_bounds__(256) void gemm_nt_kernel(AL al, const T* __restrict__ Bp, int Kp, Epi ep) {
+  constexpr int BM = 128, BK = Tile<T>::BK, LD = Tile<T>::LD;
+  constexpr int NT = BN / 16;
+  constexpr int BCH = (BN * 8 + 255) / 256;  // B chunks per thread
+  typedef typename Frag<T>::type frag_t;
+  __shared__ __attribute__((aligned(16))) T sA[BM * LD];
+  __shared__ __attribute__((aligned(16))) T sB[BN * LD];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+
+  // staging ownership: A chunk q = tid + 256*i -> row q>>3, k-chunk q&7
+  RowCtx rc[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) rc[i] = al.row(m0 + ((tid + 256 * i) >> 3));
+  const int akc = (tid & 7) * 8;
+
+  float ra[4][8];
+  frag_t rb[BCH];
+
+  auto gload = [&](int kt) {
+    const int kb = kt * BK;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) al.load(rc[i], kb + akc, ra[i]);
+#pragma unroll
+    for (int i = 0; i < BCH; ++i) {
+      const int q = tid + 256 * i;
+      if (q < BN * 8) {
+        const int r = q >> 3, c = (q & 7) * 8;
+        rb[i] = *reinterpret_cast<const frag_t*>(Bp + (int64_t)(n0 + r) * Kp + kb + c);
+      }
+    }
+  };
+  auto lstore = [&]() {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) st8<T>(&sA[((tid + 256 * i) >> 3) * LD + akc], ra[i]);
+#pragma unroll
+    for (int i = 0; i < BCH; ++i) {
+      const int q = tid + 256 * i;
+      if (q < BN * 8) *reinterpret_cast<frag_t*>(&sB[(q >> 3) * LD + (q & 7) * 8]) = rb[i];
+    }
+  };
+
+  f32x4 acc[2][NT];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int nkt = Kp / BK;
+  const int fr = lane & 15, fg = (lane >> 4) * 8;
+  gload(0);
+  for (int kt = 0; kt < nkt; ++kt) {
+    lstore();
+    __syncthreads();
+    if (kt + 1 < nkt) gload(kt + 1);
+#pragma unroll
+    for (int ks = 0; ks < BK / 32; ++ks) {
+      frag_t fa[2], fb[NT];
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+        fa[i] = *reinterpret_cast<const frag_t*>(&sA[(wave * 32 + i * 16 + fr) * LD + ks * 32 + fg]);
+#pragma unroll
+      for (int j = 0; j < NT; ++j)
+        fb[j] = *reinterpret_cast<const frag_t*>(&sB[(j * 16 + fr) * LD + ks * 32 + fg]);
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) mma_k32(acc[i][j], fa[i], fb[j]);
+    }
+    __syncthreads();
+  }
+
+  // epilogue: acc[i][j][r] is C[m0 + 32*wave + 16*i + 4*(lane>>4) + r][n0 + 16*j + (lane&15)]
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int m = m0 + wave * 32 + i * 16 + (lane >> 4) * 4 + r;
+      if (m >= ep.M) continue;
+      const int64_t orow = ep.out_row(m);
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+        const int n = n0 + j * 16 + (lane & 15);
+        if (n >= ep.N) continue;
+        float v = acc[i][j][r];
+        if (ep.bias != nullptr) v += ep.bias[n];
+        if (ep.relu) v = fmaxf(v, 0.f);
+        if (ep.mask != nullptr) v = (ep.mask[orow * ep.ldmask + n] > 0.f) ? v : 0.f;
+        float* dst = ep.C + orow * ep.ldc + n;
+        if (ep.accumulate) v += *dst;
+        *dst = v;
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------ gemm_tn
+// Where the [n][k] result lands: PyTorch-layout gradient tensor dW[N][Ktorch]. The packed k order of
+// NHWC convs / NHWC flatten is (tap, c); PyTorch's is (c, tap): kt = (k % Cin) * taps + k / Cin.
+struct WgradOut {
+  float* dW;       // [N][Ktorch], accumulated with fp32 atomics (zeroed by the caller)
+  float* dbias;    // [N] or null
+  int N, K;        // logical sizes (k beyond K is padding)
+  int Ktorch;      // row length of dW
+  int Cin, taps;   // Cin == 0: identity k map
+  __device__ __forceinline__ int kmap(int k) const {
+    if (Cin == 0) return k;
+    const int t = k / Cin, c = k - t * Cin;
+    return c * taps + t;
+  }
+};
+
+template <typename T, int BN, class YL, class XL>
+__global__ __launch_bounds__(256) void gemm_tn_kernel(YL yl, XL xl, int M, int m_per_block, WgradOut out) {
+  constexpr int BKO = 64, BMR = 64;
+  constexpr int LD = BMR + (sizeof(T) == 2 ? 8 : 4);
+  constexpr int NT = BN / 16;
+  constexpr int YCH = (BN * 8 + 255) / 256;  // Y chunks (8 n) per thread per stage: 64 rows * BN/8
+  typedef typename Frag<T>::type frag_t;
+  __shared__ __attribute__((aligned(16))) T sY[BN * LD];   // [n][m]
+  __shared__ __attribute__((aligned(16))) T sX[BKO * LD];  // [k][m]
+  __shared__ float sBias[BN];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int k0 = blockIdx.x * BKO, n0 = blockIdx.y * BN;
+  const int mb = blockIdx.z * m_per_block;
+  const int me = min(M, mb + m_per_block);
+  const bool do_bias = (out.dbias != nullptr) && (blockIdx.x == 0);
+
+  float ry[YCH][8], rx[2][8];
+  float bsum[YCH][8];
+#pragma unroll
+  for (int i = 0; i < YCH; ++i) zero8(bsum[i]);
+  if (tid < BN) sBias[tid] = 0.f;
+
+  constexpr int YC_PER_ROW = BN / 8;
+  auto gload = [&](int ms) {
+#pragma unroll
+    for (int i = 0; i < YCH; ++i) {
+      const int q = tid + 256 * i;
+      if (q < BN * 8) {
+        const int r = q / YC_PER_ROW, c = (q - r * YC_PER_ROW) * 8;
+        const int m = ms + r;
+        RowCtx rc = yl.row(m);
+        rc.valid = rc.valid && (m < me);
+        yl.load(rc, n0 + c, ry[i]);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int q = tid + 256 * i;
+      const int r = q >> 3, c = (q & 7) * 8;
+      const int m = ms + r;
+      RowCtx rc = xl.row(m);
+      rc.valid = rc.valid && (m < me);
+      xl.load(rc, k0 + c, rx[i]);
+    }
+  };
+  auto lstore = [&]() {
+#pragma unroll
+    for (int i = 0; i < YCH; ++i) {
+      const int q = tid + 256 * i;
+      if (q < BN * 8) {
+        const int r = q / YC_PER_ROW, c = (q - r * YC_PER_ROW) * 8;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          sY[(c + j) * LD + r] = Op<T>::from_f32(ry[i][j]);
+          bsum[i][j] += ry[i][j];
+        }
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int q = tid + 256 * i;
+      const int r = q >> 3, c = (q & 7) * 8;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) sX[(c + j) * LD + r] = Op<T>::from_f32(rx[i][j]);
+    }
+  };
+
+  f32x4 acc[NT];
+#pragma unroll
+  for (int i = 0; i < NT; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int fr = lane & 15, fg = (lane >> 4) * 8;
+  if (mb < me) gload(mb);
+  for (int ms = mb; ms < me; ms += BMR) {
+    lstore();
+    __syncthreads();
+    if (ms + BMR < me) gload(ms + BMR);
+#pragma unroll
+    for (int ks = 0; ks < BMR / 32; ++ks) {
+      const frag_t fx = *reinterpret_cast<const frag_t*>(&sX[(wave * 16 + fr) * LD + ks * 32 + fg]);
+#pragma unroll
+      for (int i = 0; i < NT; ++i) {
+        const frag_t fy = *reinterpret_cast<const frag_t*>(&sY[(i * 16 + fr) * LD + ks * 32 + fg]);
+        mma_k32(acc[i], fy, fx);
+      }
+    }
+    __syncthreads();
+  }
+
+  // acc[i][r] = dW[n0 + 16*i + 4*(lane>>4) + r][k0 + 16*wave + (lane&15)]
+  const int k = k0 + wave * 16 + (lane & 15);
+  if (k < out.K) {
+    const int kt = out.kmap(k);
+#pragma unroll
+    for (int i = 0; i < NT; ++i)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int n = n0 + i * 16 + (lane >> 4) * 4 + r;
+        if (n < out.N) atomicAdd(out.dW + (int64_t)n * out.Ktorch + kt, acc[i][r]);
+      }
+  }
+  if (do_bias) {
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < YCH; ++i) {
+      const int q = tid + 256 * i;
+      if (q < BN * 8) {
+        const int c = (q % YC_PER_ROW) * 8;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) atomicAdd(&sBias[c + j], bsum[i][j]);
+      }
+    }
+    __syncthreads();
+    if (tid < BN && n0 + tid < out.N) atomicAdd(out.dbias + n0 + tid, sBias[tid]);
+  }
+}
+
+}  // namespace v4l

@@ -1,0 +1,105 @@
+// Host-side plans and kernel-launch drivers: one v4l_net = one reference network (state MLP, NatureCNN fuse
+// net or LocoTransformer), one v4l_trainer = the PPO minibatch update over (pf, vf, target_pf).
+#pragma once
+#include <string>
+#include <vector>
+
+#include "../../include/v4l_hip.h"
+#include "elem.h"
+#include "gemm.h"
+
+namespace v4l {
+
+struct ParamInfo {
+  std::string name;
+  int ndim;
+  int64_t shape[4];
+  int64_t numel;
+  int64_t goff;  // offset in the flat grad / moment buffers
+};
+
+struct Lin {         // nn.Linear (or the 1x1 up-conv): y = x W^T + b, W [N][K]
+  int w = -1, b = -1;
+  int N = 0, K = 0;
+  int Np = 0, Kp = 0;     // forward pack [Np][Kp]
+  int64_t pk = 0;
+  int Rt = 0, Ct = 0;     // transposed pack [Rt = pad16(K)][Ct = pad64(N)] for the data-grad
+  int64_t pkt = 0;
+  int cin = 0, taps = 0;  // > 0: input is an NHWC flatten, packed k = tap*cin + c  (PyTorch k = c*taps + tap)
+  bool need_dgrad = true;
+};
+
+struct Conv {        // nn.Conv2d, square kernel, no padding. Activations NHWC, conv1 reads the CHW depth stack.
+  int w = -1, b = -1;
+  int Cin = 0, Cout = 0, KH = 0, stride = 0, IH = 0, OH = 0;
+  int K = 0, Kp = 0, Np = 0;
+  int64_t pk = 0;
+  bool chw = false;       // conv1
+  int ncls = 0;           // stride*stride parity classes of the gather-form data-grad
+  int Kd = 0, Kdp = 0, Rd = 0;
+  int64_t pkd[4] = {0, 0, 0, 0};
+};
+
+struct LNp { int g = -1, b = -1; };
+struct TLayer { Lin inproj, outproj, ff1, ff2; LNp ln1, ln2; };
+
+struct LayerWs { int64_t qkv, P, ctx, xh1, rs1, x1, f, xh2, rs2; };
+struct Layout {
+  int n = 0;
+  int64_t c1 = 0, c2 = 0, c3 = 0;
+  std::vector<int64_t> eh;       // encoder MLP activations
+  int64_t vis = 0;               // CNN: concat buffer [n][visual_dim + enc_last]
+  std::vector<int64_t> x;        // LOCO: token tensors x[0..L]
+  std::vector<LayerWs> lw;
+  int64_t ytmp = 0;              // [R][64] sub-layer output before add+LN
+  int64_t pooled = 0;
+  std::vector<int64_t> hh;       // head hidden activations
+  int64_t out = 0, dout = 0;     // [n][OUT_LD]
+  // backward scratch
+  int64_t dxa = 0, dctx = 0, dqkv = 0, df = 0;
+  int64_t dha = 0, dhb = 0;      // [n][maxwidth] ping-pong for MLP stacks
+  int64_t dhc = 0;               // [n][maxwidth] hand-off between two stacks (head -> encoder)
+  int64_t dpool = 0, dc3 = 0, dc2 = 0, dc1 = 0;
+  int64_t total = 0;
+};
+
+}  // namespace v4l
+
+struct v4l_net {
+  v4l_net_cfg cfg;
+  int Sp = 0;
+  std::vector<v4l::ParamInfo> params;
+  int64_t total_params = 0;
+  // layers
+  v4l::Conv conv[3];
+  v4l::Lin upconv, proj;            // LOCO: depth_up_conv, state_projector ; CNN: proj = visual_projector
+  std::vector<v4l::Lin> enc;        // encoder.base / Net.base MLP
+  std::vector<v4l::TLayer> layers;
+  std::vector<v4l::Lin> head;       // append fcs + last
+  int logstd = -1;
+  int64_t packed_elems = 0;
+  std::vector<v4l::PackDesc> packs;  // src filled at bind
+  std::vector<int> pack_param;       // param index per desc
+  int64_t pack_blocks = 0;
+  // binding
+  std::vector<float*> p;             // device pointers per param
+  void* packed = nullptr;
+  v4l::PackDesc* d_packs = nullptr;
+  v4l::ParamSeg* d_segs = nullptr;
+  int64_t seg_blocks = 0;
+  bool bound = false;
+
+  int build();
+  v4l::Layout layout(int n) const;
+  int64_t table_bytes() const;
+  template <typename T> int forward_t(const float* state, const T* image, const int* rowidx, int n, float* ws, hipStream_t s);
+  template <typename T> int backward_t(const float* state, const T* image, const int* rowidx, int n, float* ws, float* grads, hipStream_t s);
+};
+
+struct v4l_trainer {
+  v4l_net *pf = nullptr, *vf = nullptr, *tpf = nullptr;
+  float *g_pf = nullptr, *m_pf = nullptr, *v_pf = nullptr, *g_vf = nullptr, *m_vf = nullptr, *v_vf = nullptr;
+  float* ws = nullptr;
+  int64_t ws_floats = 0;
+  bool bound = false;
+};

@@ -1,0 +1,958 @@
+// libv4l_hip.so — plans, launch drivers and the C ABI (include/v4l_hip.h) of the gfx950 PPO hot path.
+#include <math.h>
+#include <stdarg.h>
+
+#include <algorithm>
+
+#include "net.h"
+
+namespace v4l {
+
+// ------------------------------------------------------------------------------------------ errors
+static thread_local char g_err[1024] = "";
+void set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+const char* last_error() { return g_err; }
+
+// ------------------------------------------------------------------------------------------ launch helpers
+static inline ADense dense(const float* p, int lda, int M, int K, const int* rowidx = nullptr, int tokmap = 0,
+                           const float* mask = nullptr) {
+  ADense a;
+  a.p = p; a.lda = lda; a.M = M; a.K = K; a.rowidx = rowidx; a.tokmap = tokmap; a.mask = mask;
+  return a;
+}
+static inline Epi mk_epi(float* C, int ldc, int N, const float* bias = nullptr, int relu = 0) {
+  Epi e;
+  memset(&e, 0, sizeof(e));
+  e.C = C; e.ldc = ldc; e.N = N; e.bias = bias; e.relu = relu;
+  e.rowmap = ROWMAP_IDENT;
+  return e;
+}
+
+// C = epi(A * Bp^T): Bp is a packed [Np][Kp] operand (Np % 16 == 0, Kp % 64 == 0)
+template <typename T, class AL>
+static int launch_nt(hipStream_t s, const AL& al, int M, const T* Bp, int Np, int Kp, Epi ep) {
+  if (M <= 0) return 0;
+  ep.M = M;
+  const int gx = cdiv(M, 128);
+  if (Np % 64 == 0) {
+    hipLaunchKernelGGL((gemm_nt_kernel<T, 64, AL>), dim3(gx, Np / 64), dim3(256), 0, s, al, Bp, Kp, ep);
+  } else if (Np % 32 == 0) {
+    hipLaunchKernelGGL((gemm_nt_kernel<T, 32, AL>), dim3(gx, Np / 32), dim3(256), 0, s, al, Bp, Kp, ep);
+  } else {
+    hipLaunchKernelGGL((gemm_nt_kernel<T, 16, AL>), dim3(gx, Np / 16), dim3(256), 0, s, al, Bp, Kp, ep);
+  }
+  V4L_LAUNCH_CHECK();
+  return 0;
+}
+
+// dW[n][k] += sum_m Y(m,n) X(m,k); Kx = logical k extent of X (multiple of 8)
+template <typename T, class YL, class XL>
+static int launch_tn(hipStream_t s, const YL& yl, const XL& xl, int M, int N, int Kx, const WgradOut& out) {
+  if (M <= 0) return 0;
+  const int gx = cdiv(Kx, 64);
+  const int BN = N <= 16 ? 16 : (N <= 32 ? 32 : 64);
+  const int gy = cdiv(N, BN);
+  int splits = std::max(1, 1024 / (gx * gy));
+  splits = std::min(splits, cdiv(M, 64));
+  const int mpb = round_up(cdiv(M, splits), 64);
+  splits = cdiv(M, mpb);
+  const dim3 grid(gx, gy, splits);
+  if (BN == 64) hipLaunchKernelGGL((gemm_tn_kernel<T, 64, YL, XL>), grid, dim3(256), 0, s, yl, xl, M, mpb, out);
+  else if (BN == 32) hipLaunchKernelGGL((gemm_tn_kernel<T, 32, YL, XL>), grid, dim3(256), 0, s, yl, xl, M, mpb, out);
+  else hipLaunchKernelGGL((gemm_tn_kernel<T, 16, YL, XL>), grid, dim3(256), 0, s, yl, xl, M, mpb, out);
+  V4L_LAUNCH_CHECK();
+  return 0;
+}
+
+struct Act { float* p; int ld; int w; };
+
+struct Ctx {  // per-call view of a bound net
+  const v4l_net* net;
+  hipStream_t s;
+  float* grads;
+};
+
+template <typename T>
+static int lin_fwd(const Ctx& c, const Lin& L, const ADense& a, Epi ep) {
+  ep.bias = c.net->p[L.b];
+  return launch_nt<T>(c.s, a, a.M, (const T*)c.net->packed + L.pk, L.Np, L.Kp, ep);
+}
+template <typename T, class XL>
+static int lin_wgrad(const Ctx& c, const Lin& L, const ADense& y, const XL& x, int Kx) {
+  WgradOut o;
+  o.dW = c.grads + c.net->params[L.w].goff;
+  o.dbias = c.grads + c.net->params[L.b].goff;
+  o.N = L.N; o.K = L.K; o.Ktorch = L.K; o.Cin = L.cin; o.taps = L.taps;
+  return launch_tn<T>(c.s, y, x, y.M, L.N, Kx, o);
+}
+template <typename T>
+static int lin_dgrad(const Ctx& c, const Lin& L, const ADense& y, Epi ep) {
+  ep.N = L.K;
+  return launch_nt<T>(c.s, y, y.M, (const T*)c.net->packed + L.pkt, L.Rt, L.Ct, ep);
+}
+
+// forward through Linear(+ReLU) layers; outs[i] receives layer i's output
+template <typename T>
+static int chain_fwd(const Ctx& c, const Lin* Ls, int k, ADense in, const Act* outs, bool relu_last) {
+  for (int i = 0; i < k; ++i) {
+    Epi ep = mk_epi(outs[i].p, outs[i].ld, Ls[i].N, nullptr, (i < k - 1 || relu_last) ? 1 : 0);
+    int rc = lin_fwd<T>(c, Ls[i], in, ep);
+    if (rc) return rc;
+    in = dense(outs[i].p, outs[i].ld, in.M, outs[i].w);
+  }
+  return 0;
+}
+// backward through the same chain. y: grad w.r.t. the last layer's pre-activation. acts[i]: output of layer i.
+// din (optional): epilogue that receives the grad w.r.t. the chain input.
+template <typename T>
+static int chain_bwd(const Ctx& c, const Lin* Ls, int k, const ADense& in, const Act* acts, ADense y, float* bufa,
+                     float* bufb, const Epi* din) {
+  for (int i = k - 1; i >= 0; --i) {
+    int rc;
+    if (i == 0) rc = lin_wgrad<T>(c, Ls[0], y, in, in.K);
+    else rc = lin_wgrad<T>(c, Ls[i], y, dense(acts[i - 1].p, acts[i - 1].ld, y.M, acts[i - 1].w), acts[i - 1].w);
+    if (rc) return rc;
+    if (i > 0) {
+      Epi ep = mk_epi(bufa, acts[i - 1].w, acts[i - 1].w);
+      ep.mask = acts[i - 1].p;
+      ep.ldmask = acts[i - 1].ld;
+      rc = lin_dgrad<T>(c, Ls[i], y, ep);
+      if (rc) return rc;
+      y = dense(bufa, acts[i - 1].w, y.M, acts[i - 1].w);
+      std::swap(bufa, bufb);
+    } else if (din != nullptr) {
+      rc = lin_dgrad<T>(c, Ls[0], y, *din);
+      if (rc) return rc;
+    }
+  }
+  return 0;
+}
+
+static inline AIm2colNHWC nhwc_loader(const float* p, const Conv& cv, int n) {
+  AIm2colNHWC a;
+  a.p = p; a.IH = cv.IH; a.IW = cv.IH; a.Cin = cv.Cin; a.OH = cv.OH; a.OW = cv.OH; a.KH = cv.KH; a.KW = cv.KH;
+  a.stride = cv.stride; a.M = n * cv.OH * cv.OH; a.K = cv.K;
+  return a;
+}
+template <typename T>
+static inline AIm2colCHW<T> chw_loader(const T* img, const Conv& cv, int n, const int* rowidx) {
+  AIm2colCHW<T> a;
+  a.p = img; a.C = cv.Cin; a.IH = cv.IH; a.IW = cv.IH; a.OH = cv.OH; a.OW = cv.OH; a.stride = cv.stride;
+  a.M = n * cv.OH * cv.OH; a.rowidx = rowidx;
+  return a;
+}
+
+template <typename T>
+static int conv_stack_fwd(const Ctx& c, const T* image, const int* rowidx, int n, float* c1, float* c2, float* c3) {
+  const v4l_net* N = c.net;
+  const Conv* cv = N->conv;
+  int rc;
+  {
+    Epi ep = mk_epi(c1, cv[0].Cout, cv[0].Cout, N->p[cv[0].b], 1);
+    auto al = chw_loader<T>(image, cv[0], n, rowidx);
+    rc = launch_nt<T>(c.s, al, al.M, (const T*)N->packed + cv[0].pk, cv[0].Np, cv[0].Kp, ep);
+    if (rc) return rc;
+  }
+  float* ins[3] = {nullptr, c1, c2};
+  float* outs[3] = {c1, c2, c3};
+  for (int i = 1; i < 3; ++i) {
+    Epi ep = mk_epi(outs[i], cv[i].Cout, cv[i].Cout, N->p[cv[i].b], 1);
+    auto al = nhwc_loader(ins[i], cv[i], n);
+    rc = launch_nt<T>(c.s, al, al.M, (const T*)N->packed + cv[i].pk, cv[i].Np, cv[i].Kp, ep);
+    if (rc) return rc;
+  }
+  return 0;
+}
+
+// dc3: grad w.r.t. conv3's pre-activation [n*16][64]. Scratch dc2 [n*36][64], dc1 [n*225][32].
+template <typename T>
+static int conv_stack_bwd(const Ctx& c, const T* image, const int* rowidx, int n, const float* c1, const float* c2,
+                          float* dc3, float* dc2, float* dc1) {
+  const v4l_net* N = c.net;
+  const Conv* cv = N->conv;
+  const float* acts[3] = {nullptr, c1, c2};   // input activation of conv i
+  float* dys[3] = {dc1, dc2, dc3};            // grad w.r.t. conv i pre-activation
+  for (int i = 2; i >= 0; --i) {
+    const Conv& v = cv[i];
+    const int M = n * v.OH * v.OH;
+    ADense y = dense(dys[i], v.Cout, M, v.Cout);
+    WgradOut o;
+    o.dW = c.grads + N->params[v.w].goff;
+    o.dbias = c.grads + N->params[v.b].goff;
+    o.N = v.Cout; o.K = v.K; o.Ktorch = v.K;
+    int rc;
+    if (v.chw) {
+      o.Cin = 0; o.taps = 0;
+      auto x = chw_loader<T>(image, v, n, rowidx);
+      rc = launch_tn<T>(c.s, y, x, M, v.Cout, v.K, o);
+    } else {
+      o.Cin = v.Cin; o.taps = v.KH * v.KH;
+      auto x = nhwc_loader(acts[i], v, n);
+      rc = launch_tn<T>(c.s, y, x, M, v.Cout, v.K, o);
+    }
+    if (rc) return rc;
+    if (i == 0) break;
+    // gather-form data-grad into the input plane of conv i (= output plane of conv i-1), ReLU-masked
+    const int st = v.stride, TH = v.KH / st;
+    for (int cls = 0; cls < v.ncls; ++cls) {
+      const int py = cls / st, px = cls % st;
+      ADgradNHWC a;
+      a.p = dys[i]; a.OH = v.OH; a.OW = v.OH; a.Cout = v.Cout; a.TH = TH; a.TW = TH;
+      a.nIy = (v.IH - py + st - 1) / st; a.nIx = (v.IH - px + st - 1) / st;
+      a.M = n * a.nIy * a.nIx; a.K = v.Kd;
+      Epi ep = mk_epi(dys[i - 1], v.Cin, v.Cin);
+      ep.rowmap = ROWMAP_DGRAD;
+      ep.py = py; ep.px = px; ep.s = st; ep.nIy = a.nIy; ep.nIx = a.nIx; ep.IH = v.IH; ep.IW = v.IH;
+      ep.mask = acts[i]; ep.ldmask = v.Cin;
+      rc = launch_nt<T>(c.s, a, a.M, (const T*)N->packed + v.pkd[cls], v.Rd, v.Kdp, ep);
+      if (rc) return rc;
+    }
+  }
+  return 0;
+}
+
+}  // namespace v4l
+
+using namespace v4l;
+
+// ------------------------------------------------------------------------------------------ plan
+int v4l_net::build() {
+  const v4l_net_cfg& c = cfg;
+  V4L_REQUIRE(c.kind >= V4L_NET_MLP && c.kind <= V4L_NET_LOCO, "v4l_net_create: unknown net kind %d", c.kind);
+  V4L_REQUIRE(c.compute == V4L_F32 || c.compute == V4L_BF16, "v4l_net_create: unknown compute mode %d", c.compute);
+  V4L_REQUIRE(c.state_dim > 0 && c.out_dim > 0 && c.out_dim <= 8, "v4l_net_create: state_dim>0 and 1<=out_dim<=8 required");
+  V4L_REQUIRE(c.n_enc_hidden >= 1 && c.n_enc_hidden <= V4L_MAX_HIDDEN && c.n_head_hidden >= 0 &&
+                  c.n_head_hidden <= V4L_MAX_HIDDEN,
+              "v4l_net_create: hidden layer counts out of range");
+  for (int i = 0; i < c.n_enc_hidden; ++i)
+    V4L_REQUIRE(c.enc_hidden[i] > 0 && c.enc_hidden[i] % 8 == 0, "v4l_net_create: hidden widths must be multiples of 8");
+  for (int i = 0; i < c.n_head_hidden; ++i)
+    V4L_REQUIRE(c.head_hidden[i] > 0 && c.head_hidden[i] % 8 == 0, "v4l_net_create: hidden widths must be multiples of 8");
+  if (c.kind != V4L_NET_MLP)
+    V4L_REQUIRE(c.in_channels == 4 && c.img_hw == 64,
+                "v4l_net_create: only the 4x64x64 depth stack is supported (got %dx%dx%d)", c.in_channels, c.img_hw, c.img_hw);
+  if (c.kind == V4L_NET_LOCO)
+    V4L_REQUIRE(c.token_dim == TD && c.n_layers >= 1 && c.n_layers <= 8 && c.ff_dim > 0 && c.ff_dim % 8 == 0,
+                "v4l_net_create: LocoTransformer needs token_dim 64, 1..8 layers, ff_dim %% 8 == 0");
+  if (c.kind == V4L_NET_CNN)
+    V4L_REQUIRE(c.visual_dim > 0 && c.visual_dim % 8 == 0, "v4l_net_create: visual_dim must be a positive multiple of 8");
+  Sp = round_up(c.state_dim, 32);
+
+  auto add_param = [&](const std::string& name, std::initializer_list<int64_t> shp) {
+    ParamInfo pi;
+    pi.name = name;
+    pi.ndim = (int)shp.size();
+    pi.numel = 1;
+    int d = 0;
+    for (int64_t v : shp) { pi.shape[d++] = v; pi.numel *= v; }
+    for (; d < 4; ++d) pi.shape[d] = 1;
+    pi.goff = total_params;
+    total_params += pi.numel;
+    params.push_back(pi);
+    return (int)params.size() - 1;
+  };
+  auto make_lin = [&](const std::string& wname, const std::string& bname, int N, int K, bool need_dgrad,
+                      bool as_conv1x1 = false) {
+    Lin L;
+    if (as_conv1x1) L.w = add_param(wname, {N, K, 1, 1});
+    else L.w = add_param(wname, {N, K});
+    L.b = add_param(bname, {N});
+    L.N = N; L.K = K; L.need_dgrad = need_dgrad;
+    return L;
+  };
+  auto make_mlp = [&](const std::string& prefix, int in_dim, const int* widths, int nw, bool first_needs_dgrad,
+                      std::vector<Lin>& out) {
+    int k = in_dim;
+    for (int i = 0; i < nw; ++i) {
+      const std::string id = prefix + "." + std::to_string(2 * i);
+      out.push_back(make_lin(id + ".weight", id + ".bias", widths[i], k, i > 0 || first_needs_dgrad));
+      k = widths[i];
+    }
+    return k;
+  };
+  auto make_convs = [&](const std::string& prefix) {
+    const int spec[3][5] = {{4, 32, 8, 4, 64}, {32, 64, 4, 2, 15}, {64, 64, 3, 1, 6}};  // base.py:317-324
+    for (int i = 0; i < 3; ++i) {
+      Conv& v = conv[i];
+      v.Cin = spec[i][0]; v.Cout = spec[i][1]; v.KH = spec[i][2]; v.stride = spec[i][3]; v.IH = spec[i][4];
+      v.OH = (v.IH - v.KH) / v.stride + 1;
+      v.K = v.Cin * v.KH * v.KH;
+      v.chw = (i == 0);
+      const std::string id = prefix + ".layers." + std::to_string(2 * i);
+      v.w = add_param(id + ".weight", {v.Cout, v.Cin, v.KH, v.KH});
+      v.b = add_param(id + ".bias", {v.Cout});
+    }
+  };
+
+  int head_in = 0;
+  if (c.kind == V4L_NET_MLP) {
+    head_in = make_mlp("base.seq_fcs", c.state_dim, c.enc_hidden, c.n_enc_hidden, false, enc);
+  } else if (c.kind == V4L_NET_CNN) {
+    make_convs("encoder.visual_base");
+    proj = make_lin("encoder.visual_projector.projection.0.weight", "encoder.visual_projector.projection.0.bias",
+                    c.visual_dim, 1024, true);
+    proj.cin = 64; proj.taps = 16;
+    const int e = make_mlp("encoder.base.seq_fcs", c.state_dim, c.enc_hidden, c.n_enc_hidden, false, enc);
+    head_in = c.visual_dim + e;
+  } else {
+    make_convs("encoder.depth_visual_base");
+    upconv = make_lin("encoder.depth_up_conv.weight", "encoder.depth_up_conv.bias", TD, 64, true, true);
+    const int e = make_mlp("encoder.base.seq_fcs", c.state_dim, c.enc_hidden, c.n_enc_hidden, false, enc);
+    proj = make_lin("encoder.state_projector.projection.0.weight", "encoder.state_projector.projection.0.bias", TD, e, true);
+    for (int l = 0; l < c.n_layers; ++l) {
+      const std::string id = "visual_append_layers." + std::to_string(l);
+      TLayer t;
+      t.inproj = make_lin(id + ".self_attn.in_proj_weight", id + ".self_attn.in_proj_bias", 3 * TD, TD, true);
+      t.outproj = make_lin(id + ".self_attn.out_proj.weight", id + ".self_attn.out_proj.bias", TD, TD, true);
+      t.ff1 = make_lin(id + ".linear1.weight", id + ".linear1.bias", c.ff_dim, TD, true);
+      t.ff2 = make_lin(id + ".linear2.weight", id + ".linear2.bias", TD, c.ff_dim, true);
+      t.ln1.g = add_param(id + ".norm1.weight", {TD});
+      t.ln1.b = add_param(id + ".norm1.bias", {TD});
+      t.ln2.g = add_param(id + ".norm2.weight", {TD});
+      t.ln2.b = add_param(id + ".norm2.bias", {TD});
+      layers.push_back(t);
+    }
+    head_in = 2 * TD;
+  }
+  {
+    const std::string hp = c.kind == V4L_NET_LOCO ? "visual_seq_append_fcs" : "seq_append_fcs";
+    const int k = make_mlp(hp, head_in, c.head_hidden, c.n_head_hidden, true, head);
+    const std::string id = hp + "." + std::to_string(2 * c.n_head_hidden);
+    head.push_back(make_lin(id + ".weight", id + ".bias", c.out_dim, k, true));
+  }
+  if (c.has_logstd) logstd = add_param("logstd", {c.out_dim});
+
+  // ---- packed operand layout
+  auto align64 = [](int64_t x) { return (x + 63) / 64 * 64; };
+  auto add_pack = [&](int param, int kind, int R, int Cc, int N, int K, int cin, int taps, int KW, int s, int py, int px,
+                      int TW) {
+    PackDesc d;
+    memset(&d, 0, sizeof(d));
+    d.dst_off = packed_elems;
+    d.kind = kind; d.R = R; d.Cc = Cc; d.N = N; d.K = K; d.Cin = cin; d.taps = taps; d.KW = KW;
+    d.s = s; d.py = py; d.px = px; d.TW = TW;
+    d.blk0 = pack_blocks;
+    pack_blocks += cdiv64((int64_t)R * Cc, 256);
+    packed_elems = align64(packed_elems + (int64_t)R * Cc);
+    packs.push_back(d);
+    pack_param.push_back(param);
+    return d.dst_off;
+  };
+  auto pack_lin = [&](Lin& L) {
+    L.Np = round_up(L.N, 16); L.Kp = round_up(L.K, 64);
+    L.pk = add_pack(L.w, L.cin ? PK_CONV_NHWC : PK_NT, L.Np, L.Kp, L.N, L.K, L.cin, L.taps, 0, 0, 0, 0, 0);
+    if (L.need_dgrad) {
+      L.Rt = round_up(L.K, 16); L.Ct = round_up(L.N, 64);
+      L.pkt = add_pack(L.w, L.cin ? PK_CONV_NHWC_T : PK_T, L.Rt, L.Ct, L.N, L.K, L.cin, L.taps, 0, 0, 0, 0, 0);
+    }
+  };
+  if (c.kind != V4L_NET_MLP) {
+    for (int i = 0; i < 3; ++i) {
+      Conv& v = conv[i];
+      v.Np = round_up(v.Cout, 16); v.Kp = round_up(v.K, 64);
+      const int taps = v.KH * v.KH;
+      v.pk = add_pack(v.w, v.chw ? PK_NT : PK_CONV_NHWC, v.Np, v.Kp, v.Cout, v.K, v.Cin, taps, v.KH, 0, 0, 0, 0);
+      if (i > 0) {
+        V4L_REQUIRE(v.KH % v.stride == 0, "conv data-grad needs kernel %% stride == 0");
+        const int TH = v.KH / v.stride;
+        v.ncls = v.stride * v.stride;
+        v.Kd = TH * TH * v.Cout; v.Kdp = round_up(v.Kd, 64); v.Rd = round_up(v.Cin, 16);
+        for (int cls = 0; cls < v.ncls; ++cls)
+          v.pkd[cls] = add_pack(v.w, PK_CONV_DGRAD, v.Rd, v.Kdp, v.Cout, v.K, v.Cin, taps, v.KH, v.stride, cls / v.stride,
+                                cls % v.stride, TH);
+      }
+    }
+  }
+  if (c.kind == V4L_NET_LOCO) pack_lin(upconv);
+  if (c.kind != V4L_NET_MLP) pack_lin(proj);
+  for (Lin& L : enc) pack_lin(L);
+  for (TLayer& t : layers) { pack_lin(t.inproj); pack_lin(t.outproj); pack_lin(t.ff1); pack_lin(t.ff2); }
+  for (Lin& L : head) pack_lin(L);
+
+  seg_blocks = 0;
+  for (const ParamInfo& pi : params) seg_blocks += cdiv64(pi.numel, 256);
+  p.assign(params.size(), nullptr);
+  return 0;
+}
+
+int64_t v4l_net::table_bytes() const {
+  return (int64_t)(packs.size() * sizeof(PackDesc) + params.size() * sizeof(ParamSeg) + 256);
+}
+
+Layout v4l_net::layout(int n) const {
+  Layout L;
+  L.n = n;
+  int64_t off = 0;
+  auto take = [&](int64_t floats) { int64_t o = off; off += (floats + 63) / 64 * 64; return o; };
+  const v4l_net_cfg& c = cfg;
+  const int64_t R = (int64_t)n * NTOK;
+  int maxw = 2 * TD;
+  for (int i = 0; i < c.n_enc_hidden; ++i) maxw = std::max(maxw, c.enc_hidden[i]);
+  for (int i = 0; i < c.n_head_hidden; ++i) maxw = std::max(maxw, c.head_hidden[i]);
+  if (c.kind == V4L_NET_CNN) maxw = std::max(maxw, c.visual_dim + c.enc_hidden[c.n_enc_hidden - 1]);
+  if (c.kind != V4L_NET_MLP) {
+    L.c1 = take((int64_t)n * 225 * 32);
+    L.c2 = take((int64_t)n * 36 * 64);
+    L.c3 = take((int64_t)n * 16 * 64);
+  }
+  for (int i = 0; i < c.n_enc_hidden; ++i) L.eh.push_back(take((int64_t)n * c.enc_hidden[i]));
+  if (c.kind == V4L_NET_CNN) L.vis = take((int64_t)n * (c.visual_dim + c.enc_hidden[c.n_enc_hidden - 1]));
+  if (c.kind == V4L_NET_LOCO) {
+    for (int l = 0; l <= c.n_layers; ++l) L.x.push_back(take(R * TD));
+    for (int l = 0; l < c.n_layers; ++l) {
+      LayerWs w;
+      w.qkv = take(R * 3 * TD);
+      w.P = take((int64_t)n * NTOK * NTOK);
+      w.ctx = take(R * TD);
+      w.xh1 = take(R * TD);
+      w.rs1 = take(R);
+      w.x1 = take(R * TD);
+      w.f = take(R * c.ff_dim);
+      w.xh2 = take(R * TD);
+      w.rs2 = take(R);
+      L.lw.push_back(w);
+    }
+    L.ytmp = take(R * TD);
+    L.pooled = take((int64_t)n * 2 * TD);
+  }
+  for (int i = 0; i < c.n_head_hidden; ++i) L.hh.push_back(take((int64_t)n * c.head_hidden[i]));
+  L.out = take((int64_t)n * OUT_LD);
+  L.dout = take((int64_t)n * OUT_LD);
+  // backward scratch
+  if (c.kind == V4L_NET_LOCO) {
+    L.dxa = take(R * TD);
+    L.dctx = take(R * TD);
+    L.dqkv = take(R * 3 * TD);
+    L.df = take(R * c.ff_dim);
+    L.dpool = take((int64_t)n * 2 * TD);
+  }
+  L.dha = take((int64_t)n * maxw);
+  L.dhb = take((int64_t)n * maxw);
+  L.dhc = take((int64_t)n * maxw);
+  if (c.kind != V4L_NET_MLP) {
+    L.dc3 = take((int64_t)n * 16 * 64);
+    L.dc2 = take((int64_t)n * 36 * 64);
+    L.dc1 = take((int64_t)n * 225 * 32);
+  }
+  L.total = off;
+  return L;
+}
+
+// ------------------------------------------------------------------------------------------ forward
+template <typename T>
+int v4l_net::forward_t(const float* state, const T* image, const int* rowidx, int n, float* ws, hipStream_t s) {
+  const Layout L = layout(n);
+  const v4l_net_cfg& c = cfg;
+  Ctx cx{this, s, nullptr};
+  int rc;
+  const int ne = c.n_enc_hidden, nh = c.n_head_hidden;
+  const ADense sin = dense(state, Sp, n, Sp, rowidx);
+  Act eacts[V4L_MAX_HIDDEN];
+  for (int i = 0; i < ne; ++i) eacts[i] = Act{ws + L.eh[i], c.enc_hidden[i], c.enc_hidden[i]};
+  ADense head_in;
+  if (c.kind == V4L_NET_MLP) {
+    if ((rc = chain_fwd<T>(cx, enc.data(), ne, sin, eacts, true))) return rc;
+    head_in = dense(eacts[ne - 1].p, eacts[ne - 1].ld, n, eacts[ne - 1].w);
+  } else if (c.kind == V4L_NET_CNN) {
+    if ((rc = conv_stack_fwd<T>(cx, image, rowidx, n, ws + L.c1, ws + L.c2, ws + L.c3))) return rc;
+    const int cw = c.visual_dim + c.enc_hidden[ne - 1];
+    // visual projector on the NHWC flatten of conv3 -> columns [0, visual_dim) of the concat buffer
+    Epi ep = mk_epi(ws + L.vis, cw, c.visual_dim, nullptr, 1);
+    if ((rc = lin_fwd<T>(cx, proj, dense(ws + L.c3, 1024, n, 1024), ep))) return rc;
+    eacts[ne - 1] = Act{ws + L.vis + c.visual_dim, cw, c.enc_hidden[ne - 1]};
+    if ((rc = chain_fwd<T>(cx, enc.data(), ne, sin, eacts, true))) return rc;
+    head_in = dense(ws + L.vis, cw, n, cw);
+  } else {
+    if ((rc = conv_stack_fwd<T>(cx, image, rowidx, n, ws + L.c1, ws + L.c2, ws + L.c3))) return rc;
+    float* x0 = ws + L.x[0];
+    {  // depth_up_conv (1x1, no activation) -> tokens 1..16   (base.py:581,602-608)
+      Epi ep = mk_epi(x0, TD, TD);
+      ep.rowmap = ROWMAP_TOK_DEPTH;
+      if ((rc = lin_fwd<T>(cx, upconv, dense(ws + L.c3, 64, n * 16, 64), ep))) return rc;
+    }
+    if ((rc = chain_fwd<T>(cx, enc.data(), ne, sin, eacts, true))) return rc;
+    {  // state_projector + ReLU -> token 0   (base.py:611-615)
+      Epi ep = mk_epi(x0, TD, TD, nullptr, 1);
+      ep.rowmap = ROWMAP_TOK_STATE;
+      if ((rc = lin_fwd<T>(cx, proj, dense(eacts[ne - 1].p, eacts[ne - 1].ld, n, eacts[ne - 1].w), ep))) return rc;
+    }
+    const int R = n * NTOK;
+    for (int l = 0; l < c.n_layers; ++l) {
+      const TLayer& t = layers[l];
+      const LayerWs& w = L.lw[l];
+      float* xin = ws + L.x[l];
+      if ((rc = lin_fwd<T>(cx, t.inproj, dense(xin, TD, R, TD), mk_epi(ws + w.qkv, 3 * TD, 3 * TD)))) return rc;
+      hipLaunchKernelGGL(attn_fwd_kernel, dim3(cdiv(n, 4)), dim3(256), 0, s, ws + w.qkv, n, ws + w.P, ws + w.ctx);
+      V4L_LAUNCH_CHECK();
+      if ((rc = lin_fwd<T>(cx, t.outproj, dense(ws + w.ctx, TD, R, TD), mk_epi(ws + L.ytmp, TD, TD)))) return rc;
+      hipLaunchKernelGGL(add_ln_fwd_kernel, dim3(cdiv(R, 4)), dim3(256), 0, s, xin, ws + L.ytmp, R, p[t.ln1.g], p[t.ln1.b],
+                         ws + w.x1, ws + w.xh1, ws + w.rs1);
+      V4L_LAUNCH_CHECK();
+      if ((rc = lin_fwd<T>(cx, t.ff1, dense(ws + w.x1, TD, R, TD), mk_epi(ws + w.f, c.ff_dim, c.ff_dim, nullptr, 1)))) return rc;
+      if ((rc = lin_fwd<T>(cx, t.ff2, dense(ws + w.f, c.ff_dim, R, c.ff_dim), mk_epi(ws + L.ytmp, TD, TD)))) return rc;
+      hipLaunchKernelGGL(add_ln_fwd_kernel, dim3(cdiv(R, 4)), dim3(256), 0, s, ws + w.x1, ws + L.ytmp, R, p[t.ln2.g],
+                         p[t.ln2.b], ws + L.x[l + 1], ws + w.xh2, ws + w.rs2);
+      V4L_LAUNCH_CHECK();
+    }
+    hipLaunchKernelGGL(pool_fwd_kernel, dim3(n), dim3(128), 0, s, ws + L.x[c.n_layers], n, ws + L.pooled);
+    V4L_LAUNCH_CHECK();
+    head_in = dense(ws + L.pooled, 2 * TD, n, 2 * TD);
+  }
+  Act hacts[V4L_MAX_HIDDEN + 1];
+  for (int i = 0; i < nh; ++i) hacts[i] = Act{ws + L.hh[i], c.head_hidden[i], c.head_hidden[i]};
+  hacts[nh] = Act{ws + L.out, OUT_LD, c.out_dim};
+  // the last layer writes only out_dim columns: clear the padded row first
+  V4L_HIP_CHECK(hipMemsetAsync(ws + L.out, 0, (size_t)n * OUT_LD * sizeof(float), s));
+  return chain_fwd<T>(cx, head.data(), nh + 1, head_in, hacts, false);
+}
+
+// ------------------------------------------------------------------------------------------ backward
+template <typename T>
+int v4l_net::backward_t(const float* state, const T* image, const int* rowidx, int n, float* ws, float* grads,
+                        hipStream_t s) {
+  const Layout L = layout(n);
+  const v4l_net_cfg& c = cfg;
+  Ctx cx{this, s, grads};
+  int rc;
+  const int ne = c.n_enc_hidden, nh = c.n_head_hidden;
+  const ADense sin = dense(state, Sp, n, Sp, rowidx);
+  Act eacts[V4L_MAX_HIDDEN];
+  for (int i = 0; i < ne; ++i) eacts[i] = Act{ws + L.eh[i], c.enc_hidden[i], c.enc_hidden[i]};
+  Act hacts[V4L_MAX_HIDDEN + 1];
+  for (int i = 0; i < nh; ++i) hacts[i] = Act{ws + L.hh[i], c.head_hidden[i], c.head_hidden[i]};
+  hacts[nh] = Act{ws + L.out, OUT_LD, c.out_dim};
+  const ADense dy = dense(ws + L.dout, OUT_LD, n, OUT_LD);
+  float *bufa = ws + L.dha, *bufb = ws + L.dhb;
+
+  if (c.kind == V4L_NET_MLP) {
+    // head stack, then the base MLP; the grad w.r.t. the base output is handed over in `hand`
+    const Act& last = eacts[ne - 1];
+    float* hand = ws + L.dhc;
+    Epi din = mk_epi(hand, last.w, last.w);
+    din.mask = last.p;
+    din.ldmask = last.ld;
+    if ((rc = chain_bwd<T>(cx, head.data(), nh + 1, dense(last.p, last.ld, n, last.w), hacts, dy, bufa, bufb, &din))) return rc;
+    return chain_bwd<T>(cx, enc.data(), ne, sin, eacts, dense(hand, last.w, n, last.w), bufa, bufb, nullptr);
+  }
+
+  if (c.kind == V4L_NET_CNN) {
+    const int cw = c.visual_dim + c.enc_hidden[ne - 1];
+    eacts[ne - 1] = Act{ws + L.vis + c.visual_dim, cw, c.enc_hidden[ne - 1]};
+    float* hand = ws + L.dhc;  // grad w.r.t. the concat [visual_out | state_out], both post-ReLU
+    Epi din = mk_epi(hand, cw, cw);
+    if ((rc = chain_bwd<T>(cx, head.data(), nh + 1, dense(ws + L.vis, cw, n, cw), hacts, dy, bufa, bufb, &din))) return rc;
+    {  // visual branch: ReLU mask applied on load; data-grad lands in dc3 viewed as the NHWC flatten [n][1024]
+      ADense yv = dense(hand, cw, n, c.visual_dim, nullptr, 0, ws + L.vis);
+      if ((rc = lin_wgrad<T>(cx, proj, yv, dense(ws + L.c3, 1024, n, 1024), 1024))) return rc;
+      Epi ep = mk_epi(ws + L.dc3, 1024, 1024);
+      ep.mask = ws + L.c3;
+      ep.ldmask = 1024;
+      if ((rc = lin_dgrad<T>(cx, proj, yv, ep))) return rc;
+    }
+    {  // state branch
+      ADense ys = dense(hand + c.visual_dim, cw, n, c.enc_hidden[ne - 1], nullptr, 0, ws + L.vis + c.visual_dim);
+      if ((rc = chain_bwd<T>(cx, enc.data(), ne, sin, eacts, ys, bufa, bufb, nullptr))) return rc;
+    }
+    return conv_stack_bwd<T>(cx, image, rowidx, n, ws + L.c1, ws + L.c2, ws + L.dc3, ws + L.dc2, ws + L.dc1);
+  }
+
+  // ---- LocoTransformer
+  const int R = n * NTOK;
+  {
+    Epi din = mk_epi(ws + L.dpool, 2 * TD, 2 * TD);
+    if ((rc = chain_bwd<T>(cx, head.data(), nh + 1, dense(ws + L.pooled, 2 * TD, n, 2 * TD), hacts, dy, bufa, bufb, &din)))
+      return rc;
+  }
+  float* dx = ws + L.dxa;
+  hipLaunchKernelGGL(pool_bwd_kernel, dim3(n), dim3(64), 0, s, ws + L.dpool, n, dx);
+  V4L_LAUNCH_CHECK();
+  const int lnb = std::min(cdiv(R, 4), 1024);
+  for (int l = c.n_layers - 1; l >= 0; --l) {
+    const TLayer& t = layers[l];
+    const LayerWs& w = L.lw[l];
+    hipLaunchKernelGGL(ln_bwd_kernel, dim3(lnb), dim3(256), 0, s, dx, ws + w.xh2, ws + w.rs2, p[t.ln2.g], R, dx,
+                       grads + params[t.ln2.g].goff, grads + params[t.ln2.b].goff);
+    V4L_LAUNCH_CHECK();
+    {  // linear2 / linear1 (FFN), residual: d(x1) = dz2 + W1^T-path
+      ADense y = dense(dx, TD, R, TD);
+      if ((rc = lin_wgrad<T>(cx, t.ff2, y, dense(ws + w.f, c.ff_dim, R, c.ff_dim), c.ff_dim))) return rc;
+      Epi ep = mk_epi(ws + L.df, c.ff_dim, c.ff_dim);
+      ep.mask = ws + w.f;
+      ep.ldmask = c.ff_dim;
+      if ((rc = lin_dgrad<T>(cx, t.ff2, y, ep))) return rc;
+      ADense yf = dense(ws + L.df, c.ff_dim, R, c.ff_dim);
+      if ((rc = lin_wgrad<T>(cx, t.ff1, yf, dense(ws + w.x1, TD, R, TD), TD))) return rc;
+      Epi ea = mk_epi(dx, TD, TD);
+      ea.accumulate = 1;
+      if ((rc = lin_dgrad<T>(cx, t.ff1, yf, ea))) return rc;
+    }
+    hipLaunchKernelGGL(ln_bwd_kernel, dim3(lnb), dim3(256), 0, s, dx, ws + w.xh1, ws + w.rs1, p[t.ln1.g], R, dx,
+                       grads + params[t.ln1.g].goff, grads + params[t.ln1.b].goff);
+    V4L_LAUNCH_CHECK();
+    {  // self-attention block, residual: d(x_in) = dz1 + in_proj^T-path
+      ADense y = dense(dx, TD, R, TD);
+      if ((rc = lin_wgrad<T>(cx, t.outproj, y, dense(ws + w.ctx, TD, R, TD), TD))) return rc;
+      if ((rc = lin_dgrad<T>(cx, t.outproj, y, mk_epi(ws + L.dctx, TD, TD)))) return rc;
+      hipLaunchKernelGGL(attn_bwd_kernel, dim3(cdiv(n, 2)), dim3(128), 0, s, ws + w.qkv, ws + w.P, ws + L.dctx, n,
+                         ws + L.dqkv);
+      V4L_LAUNCH_CHECK();
+      ADense yq = dense(ws + L.dqkv, 3 * TD, R, 3 * TD);
+      if ((rc = lin_wgrad<T>(cx, t.inproj, yq, dense(ws + L.x[l], TD, R, TD), TD))) return rc;
+      Epi ea = mk_epi(dx, TD, TD);
+      ea.accumulate = 1;
+      if ((rc = lin_dgrad<T>(cx, t.inproj, yq, ea))) return rc;
+    }
+  }
+  const float* x0 = ws + L.x[0];
+  {  // token 0 -> state_projector -> encoder MLP
+    const Act& last = eacts[ne - 1];
+    ADense yp = dense(dx, NTOK * TD, n, TD, nullptr, 0, x0);
+    if ((rc = lin_wgrad<T>(cx, proj, yp, dense(last.p, last.ld, n, last.w), last.w))) return rc;
+    Epi ep = mk_epi(bufa, last.w, last.w);
+    ep.mask = last.p;
+    ep.ldmask = last.ld;
+    if ((rc = lin_dgrad<T>(cx, proj, yp, ep))) return rc;
+    if ((rc = chain_bwd<T>(cx, enc.data(), ne, sin, eacts, dense(bufa, last.w, n, last.w), bufb, bufa, nullptr))) return rc;
+  }
+  {  // tokens 1..16 -> depth_up_conv -> conv stack
+    ADense yu = dense(dx, TD, n * 16, TD, nullptr, 1);
+    if ((rc = lin_wgrad<T>(cx, upconv, yu, dense(ws + L.c3, 64, n * 16, 64), 64))) return rc;
+    Epi ep = mk_epi(ws + L.dc3, 64, 64);
+    ep.mask = ws + L.c3;
+    ep.ldmask = 64;
+    if ((rc = lin_dgrad<T>(cx, upconv, yu, ep))) return rc;
+  }
+  return conv_stack_bwd<T>(cx, image, rowidx, n, ws + L.c1, ws + L.c2, ws + L.dc3, ws + L.dc2, ws + L.dc1);
+}
+
+// ------------------------------------------------------------------------------------------ C ABI
+extern "C" {
+
+const char* v4l_last_error(void) { return v4l::last_error(); }
+int v4l_version(void) { return 100; }
+
+int v4l_net_create(const v4l_net_cfg* cfg, v4l_net** out) {
+  V4L_REQUIRE(cfg != nullptr && out != nullptr, "v4l_net_create: null argument");
+  v4l_net* n = new v4l_net();
+  n->cfg = *cfg;
+  int rc = n->build();
+  if (rc) { delete n; return rc; }
+  *out = n;
+  return 0;
+}
+void v4l_net_destroy(v4l_net* net) { delete net; }
+int v4l_net_num_params(const v4l_net* net) { return net ? (int)net->params.size() : -1; }
+int v4l_net_param_info(const v4l_net* net, int i, const char** name, int* ndim, int64_t shape[4], int64_t* numel,
+                       int64_t* grad_offset) {
+  V4L_REQUIRE(net && i >= 0 && i < (int)net->params.size(), "v4l_net_param_info: index out of range");
+  const ParamInfo& pi = net->params[i];
+  if (name) *name = pi.name.c_str();
+  if (ndim) *ndim = pi.ndim;
+  if (shape) for (int d = 0; d < 4; ++d) shape[d] = pi.shape[d];
+  if (numel) *numel = pi.numel;
+  if (grad_offset) *grad_offset = pi.goff;
+  return 0;
+}
+int64_t v4l_net_total_params(const v4l_net* net) { return net ? net->total_params : -1; }
+int64_t v4l_net_packed_bytes(const v4l_net* net) {
+  return net ? net->packed_elems * (net->cfg.compute == V4L_BF16 ? 2 : 4) + 256 : -1;
+}
+int64_t v4l_net_table_bytes(const v4l_net* net) { return net ? net->table_bytes() : -1; }
+int64_t v4l_net_ws_floats(const v4l_net* net, int n, int train) {
+  (void)train;
+  if (!net || n <= 0) return -1;
+  return net->layout(n).total;
+}
+int v4l_net_state_ld(const v4l_net* net) { return net ? net->Sp : -1; }
+
+int64_t v4l_net_ws_offset(const v4l_net* net, int n, const char* name) {
+  if (!net || !name) return -1;
+  const Layout L = net->layout(n);
+  const std::string s(name);
+  auto idx = [&](const std::string& pre, size_t cnt) -> int {
+    if (s.compare(0, pre.size(), pre) != 0) return -1;
+    int i = atoi(s.c_str() + pre.size());
+    return (i >= 0 && (size_t)i < cnt) ? i : -1;
+  };
+  if (s == "c1") return L.c1;
+  if (s == "c2") return L.c2;
+  if (s == "c3") return L.c3;
+  if (s == "vis") return L.vis;
+  if (s == "pooled") return L.pooled;
+  if (s == "out") return L.out;
+  if (s == "dout") return L.dout;
+  if (s == "dxa") return L.dxa;
+  if (s == "dhc") return L.dhc;
+  if (s == "dc1") return L.dc1;
+  if (s == "dc2") return L.dc2;
+  if (s == "dc3") return L.dc3;
+  int i;
+  if ((i = idx("eh", L.eh.size())) >= 0) return L.eh[i];
+  if ((i = idx("hh", L.hh.size())) >= 0) return L.hh[i];
+  if ((i = idx("x", L.x.size())) >= 0) return L.x[i];
+  if ((i = idx("qkv", L.lw.size())) >= 0) return L.lw[i].qkv;
+  if ((i = idx("P", L.lw.size())) >= 0) return L.lw[i].P;
+  if ((i = idx("ctx", L.lw.size())) >= 0) return L.lw[i].ctx;
+  if ((i = idx("mid", L.lw.size())) >= 0) return L.lw[i].x1;
+  if ((i = idx("ff", L.lw.size())) >= 0) return L.lw[i].f;
+  return -1;
+}
+
+int v4l_net_bind(v4l_net* net, float* const* params_dev, void* packed_dev, void* table_dev, void* stream) {
+  V4L_REQUIRE(net && params_dev && packed_dev && table_dev, "v4l_net_bind: null argument");
+  hipStream_t s = (hipStream_t)stream;
+  for (size_t i = 0; i < net->params.size(); ++i) {
+    V4L_REQUIRE(params_dev[i] != nullptr, "v4l_net_bind: parameter %s has a null device pointer", net->params[i].name.c_str());
+    net->p[i] = params_dev[i];
+  }
+  for (size_t i = 0; i < net->packs.size(); ++i) net->packs[i].src = net->p[net->pack_param[i]];
+  std::vector<ParamSeg> segs(net->params.size());
+  int64_t blk = 0;
+  for (size_t i = 0; i < net->params.size(); ++i) {
+    segs[i].p = net->p[i];
+    segs[i].goff = net->params[i].goff;
+    segs[i].n = net->params[i].numel;
+    segs[i].blk0 = blk;
+    blk += cdiv64(net->params[i].numel, 256);
+  }
+  net->packed = packed_dev;
+  net->d_packs = (PackDesc*)table_dev;
+  net->d_segs = (ParamSeg*)((char*)table_dev + (net->packs.size() * sizeof(PackDesc) + 63) / 64 * 64);
+  // synchronous pageable copies: the host vectors die at return
+  V4L_HIP_CHECK(hipStreamSynchronize(s));
+  V4L_HIP_CHECK(hipMemcpy(net->d_packs, net->packs.data(), net->packs.size() * sizeof(PackDesc), hipMemcpyHostToDevice));
+  V4L_HIP_CHECK(hipMemcpy(net->d_segs, segs.data(), segs.size() * sizeof(ParamSeg), hipMemcpyHostToDevice));
+  net->bound = true;
+  return 0;
+}
+
+int v4l_net_pack(v4l_net* net, void* stream) {
+  V4L_REQUIRE(net && net->bound, "v4l_net_pack: net is not bound");
+  hipStream_t s = (hipStream_t)stream;
+  if (net->cfg.compute == V4L_BF16)
+    hipLaunchKernelGGL(pack_kernel<__bf16>, dim3((unsigned)net->pack_blocks), dim3(256), 0, s, net->d_packs,
+                       (int)net->packs.size(), (__bf16*)net->packed);
+  else
+    hipLaunchKernelGGL(pack_kernel<float>, dim3((unsigned)net->pack_blocks), dim3(256), 0, s, net->d_packs,
+                       (int)net->packs.size(), (float*)net->packed);
+  V4L_LAUNCH_CHECK();
+  return 0;
+}
+
+int v4l_ingest(const v4l_net* net, const float* obs_dev, int n, float* state_dev, void* image_dev, int64_t slot0,
+               void* stream) {
+  V4L_REQUIRE(net && obs_dev && state_dev && n > 0, "v4l_ingest: bad argument");
+  hipStream_t s = (hipStream_t)stream;
+  const int S = net->cfg.state_dim;
+  const int img = net->cfg.kind == V4L_NET_MLP ? 0 : net->cfg.in_channels * net->cfg.img_hw * net->cfg.img_hw;
+  V4L_REQUIRE(img == 0 || image_dev != nullptr, "v4l_ingest: image_dev is null for a visual net");
+  if (net->cfg.compute == V4L_BF16)
+    hipLaunchKernelGGL(ingest_kernel<__bf16>, dim3(n), dim3(256), 0, s, obs_dev, n, S, net->Sp, img, state_dev,
+                       (__bf16*)image_dev, slot0);
+  else
+    hipLaunchKernelGGL(ingest_kernel<float>, dim3(n), dim3(256), 0, s, obs_dev, n, S, net->Sp, img, state_dev,
+                       (float*)image_dev, slot0);
+  V4L_LAUNCH_CHECK();
+  return 0;
+}
+
+int v4l_net_forward(v4l_net* net, const float* state_dev, const void* image_dev, const int* rowidx_dev, int n,
+                    float* ws_dev, int train, void* stream) {
+  (void)train;
+  V4L_REQUIRE(net && net->bound, "v4l_net_forward: net is not bound");
+  V4L_REQUIRE(state_dev && ws_dev && n > 0, "v4l_net_forward: bad argument");
+  V4L_REQUIRE(net->cfg.kind == V4L_NET_MLP || image_dev != nullptr, "v4l_net_forward: image_dev is null");
+  if (net->cfg.compute == V4L_BF16)
+    return net->forward_t<__bf16>(state_dev, (const __bf16*)image_dev, rowidx_dev, n, ws_dev, (hipStream_t)stream);
+  return net->forward_t<float>(state_dev, (const float*)image_dev, rowidx_dev, n, ws_dev, (hipStream_t)stream);
+}
+float* v4l_net_out_ptr(const v4l_net* net, float* ws_dev, int n, int train) {
+  (void)train;
+  return ws_dev + net->layout(n).out;
+}
+float* v4l_net_dout_ptr(const v4l_net* net, float* ws_dev, int n) { return ws_dev + net->layout(n).dout; }
+
+int v4l_net_backward(v4l_net* net, const float* state_dev, const void* image_dev, const int* rowidx_dev, int n,
+                     float* ws_dev, float* grads_dev, void* stream) {
+  V4L_REQUIRE(net && net->bound, "v4l_net_backward: net is not bound");
+  V4L_REQUIRE(state_dev && ws_dev && grads_dev && n > 0, "v4l_net_backward: bad argument");
+  if (net->cfg.compute == V4L_BF16)
+    return net->backward_t<__bf16>(state_dev, (const __bf16*)image_dev, rowidx_dev, n, ws_dev, grads_dev,
+                                   (hipStream_t)stream);
+  return net->backward_t<float>(state_dev, (const float*)image_dev, rowidx_dev, n, ws_dev, grads_dev, (hipStream_t)stream);
+}
+
+int v4l_gauss_head(const float* meanp_dev, const float* logstd_dev, const float* acts_dev, int n, int A,
+                   float* mean_dev, float* std_dev, float* logstd_c_dev, float* ent_dev, float* logp_dev,
+                   void* stream) {
+  V4L_REQUIRE(meanp_dev && logstd_dev && mean_dev && std_dev && logstd_c_dev && ent_dev && n > 0 && A > 0 && A <= 8,
+              "v4l_gauss_head: bad argument");
+  V4L_REQUIRE(acts_dev == nullptr || logp_dev != nullptr, "v4l_gauss_head: logp_dev is null");
+  hipLaunchKernelGGL(gauss_head_kernel, dim3(cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, meanp_dev, logstd_dev,
+                     acts_dev, n, A, mean_dev, std_dev, logstd_c_dev, ent_dev, logp_dev);
+  V4L_LAUNCH_CHECK();
+  return 0;
+}
+int v4l_col0(const float* src_dev, int n, float* dst_dev, void* stream) {
+  V4L_REQUIRE(src_dev && dst_dev && n > 0, "v4l_col0: bad argument");
+  hipLaunchKernelGGL(col0_kernel, dim3(cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, src_dev, n, dst_dev);
+  V4L_LAUNCH_CHECK();
+  return 0;
+}
+
+int v4l_gae(const double* rewards_dev, const double* values_dev, const double* terminals_dev,
+            const double* time_limits_dev, int tl_per_env, const double* last_value_dev, int T, int E, double gamma,
+            double tau, int use_time_limit, double* advs_dev, double* rets_dev, float* advs32_dev, float* rets32_dev,
+            void* stream) {
+  V4L_REQUIRE(rewards_dev && values_dev && terminals_dev && last_value_dev && advs_dev && rets_dev && T > 0 && E > 0,
+              "v4l_gae: bad argument");
+  V4L_REQUIRE(!use_time_limit || time_limits_dev != nullptr, "v4l_gae: time_limits_dev is null");
+  V4L_REQUIRE((advs32_dev == nullptr) == (rets32_dev == nullptr), "v4l_gae: advs32/rets32 must both be set or null");
+  hipLaunchKernelGGL(gae_kernel, dim3(cdiv(E, 64)), dim3(64), 0, (hipStream_t)stream, rewards_dev, values_dev,
+                     terminals_dev, time_limits_dev, tl_per_env, last_value_dev, T, E, gamma, tau, use_time_limit,
+                     advs_dev, rets_dev, advs32_dev, rets32_dev);
+  V4L_LAUNCH_CHECK();
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------ trainer
+int v4l_trainer_create(v4l_net* pf, v4l_net* vf, v4l_net* target_pf, v4l_trainer** out) {
+  V4L_REQUIRE(pf && vf && target_pf && out, "v4l_trainer_create: null argument");
+  V4L_REQUIRE(pf->cfg.has_logstd && target_pf->cfg.has_logstd && !vf->cfg.has_logstd && vf->cfg.out_dim == 1,
+              "v4l_trainer_create: pf/target_pf must be Gaussian policies and vf a scalar value net");
+  V4L_REQUIRE(pf->cfg.compute == vf->cfg.compute && pf->cfg.compute == target_pf->cfg.compute &&
+                  pf->cfg.kind == vf->cfg.kind && pf->cfg.kind == target_pf->cfg.kind &&
+                  pf->cfg.state_dim == vf->cfg.state_dim && pf->total_params == target_pf->total_params,
+              "v4l_trainer_create: pf, vf and target_pf disagree on kind/compute/shape");
+  v4l_trainer* t = new v4l_trainer();
+  t->pf = pf; t->vf = vf; t->tpf = target_pf;
+  *out = t;
+  return 0;
+}
+void v4l_trainer_destroy(v4l_trainer* tr) { delete tr; }
+int64_t v4l_trainer_ws_floats(const v4l_trainer* tr, int n) {
+  if (!tr || n <= 0) return -1;
+  return std::max(tr->pf->layout(n).total, tr->vf->layout(n).total) + tr->tpf->layout(n).total;
+}
+int v4l_trainer_bind(v4l_trainer* tr, float* g_pf_dev, float* m_pf_dev, float* v_pf_dev, float* g_vf_dev,
+                     float* m_vf_dev, float* v_vf_dev, float* ws_dev, int64_t ws_floats, void* stream) {
+  (void)stream;
+  V4L_REQUIRE(tr && g_pf_dev && m_pf_dev && v_pf_dev && g_vf_dev && m_vf_dev && v_vf_dev && ws_dev,
+              "v4l_trainer_bind: null argument");
+  V4L_REQUIRE(tr->pf->bound && tr->vf->bound && tr->tpf->bound, "v4l_trainer_bind: bind the three nets first");
+  tr->g_pf = g_pf_dev; tr->m_pf = m_pf_dev; tr->v_pf = v_pf_dev;
+  tr->g_vf = g_vf_dev; tr->m_vf = m_vf_dev; tr->v_vf = v_vf_dev;
+  tr->ws = ws_dev; tr->ws_floats = ws_floats;
+  tr->bound = true;
+  return 0;
+}
+
+static int check_update_args(const v4l_trainer* tr, const v4l_rollout* ro, int n, const v4l_ppo_hyper* hp,
+                             const float* stats) {
+  V4L_REQUIRE(tr && tr->bound, "v4l_trainer: not bound");
+  V4L_REQUIRE(ro && hp && stats && n > 1, "v4l_trainer: bad argument (n must be > 1)");
+  V4L_REQUIRE(ro->state_dev && ro->acts_dev && ro->advs_dev && ro->rets_dev, "v4l_trainer: rollout arrays missing");
+  V4L_REQUIRE(tr->pf->cfg.kind == V4L_NET_MLP || ro->image_dev, "v4l_trainer: rollout image array missing");
+  V4L_REQUIRE(!hp->clipped_value_loss || ro->values_dev, "v4l_trainer: clipped_value_loss needs values_dev");
+  V4L_REQUIRE(hp->world_size >= 1, "v4l_trainer: world_size must be >= 1");
+  V4L_REQUIRE(v4l_trainer_ws_floats(tr, n) <= tr->ws_floats, "v4l_trainer: workspace too small for n=%d", n);
+  return 0;
+}
+
+int v4l_trainer_critic_grads(v4l_trainer* tr, const v4l_rollout* ro, const int* rowidx_dev, int n,
+                             const v4l_ppo_hyper* hp, float* st, void* stream) {
+  int rc = check_update_args(tr, ro, n, hp, st);
+  if (rc) return rc;
+  hipStream_t s = (hipStream_t)stream;
+  v4l_net* vf = tr->vf;
+  V4L_HIP_CHECK(hipMemsetAsync(st, 0, V4L_STATS * sizeof(float), s));
+  V4L_HIP_CHECK(hipMemsetAsync(tr->g_vf, 0, (size_t)vf->total_params * sizeof(float), s));
+  hipLaunchKernelGGL(adv_stats_kernel, dim3(1), dim3(256), 0, s, ro->advs_dev, rowidx_dev, n, st);
+  V4L_LAUNCH_CHECK();
+  if ((rc = v4l_net_pack(vf, stream))) return rc;
+  if ((rc = v4l_net_forward(vf, ro->state_dev, ro->image_dev, rowidx_dev, n, tr->ws, 1, stream))) return rc;
+  const Layout L = vf->layout(n);
+  const float inv_n = 1.f / ((float)n * (float)hp->world_size);
+  hipLaunchKernelGGL(critic_loss_kernel, dim3(1), dim3(256), 0, s, tr->ws + L.out, ro->rets_dev, ro->values_dev,
+                     rowidx_dev, n, inv_n, hp->clipped_value_loss, hp->clip_para, tr->ws + L.dout, st);
+  V4L_LAUNCH_CHECK();
+  return v4l_net_backward(vf, ro->state_dev, ro->image_dev, rowidx_dev, n, tr->ws, tr->g_vf, stream);
+}
+
+static int adam_step(v4l_net* net, float* g, float* m, float* v, const v4l_ppo_hyper* hp, double lr, int64_t step,
+                     float* sumsq, float* norm_out, hipStream_t s) {
+  V4L_REQUIRE(step >= 1, "v4l_trainer: Adam step count starts at 1");
+  const int gb = (int)std::min<int64_t>(1024, cdiv64(net->total_params, 256));
+  hipLaunchKernelGGL(grad_sumsq_kernel, dim3(gb), dim3(256), 0, s, g, net->total_params, sumsq);
+  V4L_LAUNCH_CHECK();
+  // scalar prep in double, like torch/optim/adam.py::_single_tensor_adam
+  const double bc1 = 1.0 - pow((double)hp->beta1, (double)step);
+  const double bc2 = 1.0 - pow((double)hp->beta2, (double)step);
+  const float step_size = (float)(lr / bc1);
+  const float bc2_sqrt = (float)sqrt(bc2);
+  hipLaunchKernelGGL(clip_adam_kernel, dim3((unsigned)net->seg_blocks), dim3(256), 0, s, net->d_segs,
+                     (int)net->params.size(), g, m, v, sumsq, 1.f, hp->max_grad_norm, hp->beta1, hp->beta2, hp->eps,
+                     step_size, bc2_sqrt, norm_out);
+  V4L_LAUNCH_CHECK();
+  return 0;
+}
+
+int v4l_trainer_critic_step(v4l_trainer* tr, const v4l_ppo_hyper* hp, double lr, int64_t step, float* st, void* stream) {
+  V4L_REQUIRE(tr && tr->bound && hp && st, "v4l_trainer_critic_step: bad argument");
+  return adam_step(tr->vf, tr->g_vf, tr->m_vf, tr->v_vf, hp, lr, step, st + ST_SUMSQ_VF, st + ST_GN_VF, (hipStream_t)stream);
+}
+
+int v4l_trainer_actor_grads(v4l_trainer* tr, const v4l_rollout* ro, const int* rowidx_dev, int n,
+                            const v4l_ppo_hyper* hp, float* st, void* stream) {
+  int rc = check_update_args(tr, ro, n, hp, st);
+  if (rc) return rc;
+  hipStream_t s = (hipStream_t)stream;
+  v4l_net *pf = tr->pf, *tp = tr->tpf;
+  if (hp->world_size > 1) {
+    hipLaunchKernelGGL(adv_stats_finalize_kernel, dim3(1), dim3(1), 0, s, st);
+    V4L_LAUNCH_CHECK();
+  }
+  V4L_HIP_CHECK(hipMemsetAsync(tr->g_pf, 0, (size_t)pf->total_params * sizeof(float), s));
+  const Layout Lp = pf->layout(n), Lt = tp->layout(n);
+  float* ws_t = tr->ws + std::max(Lp.total, tr->vf->layout(n).total);
+  // frozen target policy: packed once per epoch by v4l_trainer_sync_target
+  if ((rc = v4l_net_forward(tp, ro->state_dev, ro->image_dev, rowidx_dev, n, ws_t, 0, stream))) return rc;
+  if ((rc = v4l_net_pack(pf, stream))) return rc;  // the critic step moved the shared encoder
+  if ((rc = v4l_net_forward(pf, ro->state_dev, ro->image_dev, rowidx_dev, n, tr->ws, 1, stream))) return rc;
+  const float inv_n = 1.f / ((float)n * (float)hp->world_size);
+  hipLaunchKernelGGL(actor_loss_kernel, dim3(1), dim3(256), 0, s, tr->ws + Lp.out, pf->p[pf->logstd], ws_t + Lt.out,
+                     tp->p[tp->logstd], ro->acts_dev, ro->advs_dev, rowidx_dev, n, pf->cfg.out_dim, inv_n, hp->clip_para,
+                     hp->entropy_coeff, tr->ws + Lp.dout, tr->g_pf + pf->params[pf->logstd].goff, st);
+  V4L_LAUNCH_CHECK();
+  return v4l_net_backward(pf, ro->state_dev, ro->image_dev, rowidx_dev, n, tr->ws, tr->g_pf, stream);
+}
+
+int v4l_trainer_actor_step(v4l_trainer* tr, const v4l_ppo_hyper* hp, double lr, int64_t step, float* st, void* stream) {
+  V4L_REQUIRE(tr && tr->bound && hp && st, "v4l_trainer_actor_step: bad argument");
+  return adam_step(tr->pf, tr->g_pf, tr->m_pf, tr->v_pf, hp, lr, step, st + ST_SUMSQ_PF, st + ST_GN_PF, (hipStream_t)stream);
+}
+
+int v4l_trainer_update(v4l_trainer* tr, const v4l_rollout* ro, const int* rowidx_dev, int n, const v4l_ppo_hyper* hp,
+                       double lr_pf, double lr_vf, int64_t step, float* st, void* stream) {
+  int rc;
+  if ((rc = v4l_trainer_critic_grads(tr, ro, rowidx_dev, n, hp, st, stream))) return rc;
+  if ((rc = v4l_trainer_critic_step(tr, hp, lr_vf, step, st, stream))) return rc;
+  if ((rc = v4l_trainer_actor_grads(tr, ro, rowidx_dev, n, hp, st, stream))) return rc;
+  return v4l_trainer_actor_step(tr, hp, lr_pf, step, st, stream);
+}
+
+int v4l_trainer_sync_target(v4l_trainer* tr, void* stream) {
+  V4L_REQUIRE(tr && tr->pf->bound && tr->tpf->bound, "v4l_trainer_sync_target: nets are not bound");
+  hipStream_t s = (hipStream_t)stream;
+  for (size_t i = 0; i < tr->pf->params.size(); ++i)
+    V4L_HIP_CHECK(hipMemcpyAsync(tr->tpf->p[i], tr->pf->p[i], (size_t)tr->pf->params[i].numel * sizeof(float),
+                                 hipMemcpyDeviceToDevice, s));
+  return v4l_net_pack(tr->tpf, stream);
+}
+
+}  // extern "C"

@@ -1,0 +1,348 @@
+"""Host-side glue between the torchrl-shaped Python modules and libv4l_hip.so.
+
+torch is used for device memory (tensors own the parameters, workspaces and rollout arrays) and for the
+current HIP stream; all arithmetic is enqueued through the C ABI. Nothing here falls back to torch ops.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import (V4L_BF16, V4L_F32, V4L_NET_CNN, V4L_NET_LOCO, V4L_NET_MLP, V4L_OUT_LD, V4L_STATS,
+                   NetCfg, PPOHyper, Rollout, check)
+
+
+def default_compute():
+  """Contraction operand type: bf16 (production) unless V4L_COMPUTE=f32 selects the exact-fp32 parity mode."""
+  v = os.environ.get("V4L_COMPUTE", "bf16").lower()
+  if v in ("f32", "fp32", "float32"):
+    return V4L_F32
+  if v in ("bf16", "bfloat16"):
+    return V4L_BF16
+  raise ValueError("V4L_COMPUTE must be 'bf16' or 'f32', got %r" % v)
+
+
+def _stream():
+  return torch.cuda.current_stream().cuda_stream
+
+
+def _ptr(t):
+  return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+
+def _require_gpu(t, what):
+  if not t.is_cuda:
+    raise RuntimeError(
+      "vision4leg_amd: %s must live on the GPU (got device %s). The HIP engine has no CPU path; "
+      "move the module and its inputs with .to('cuda')." % (what, t.device))
+
+
+class HipNet:
+  """One v4l_net plan bound to the parameters of a top-level module (state_dict keys = reference names)."""
+
+  def __init__(self, module, cfg):
+    self.module = module
+    self.cfg = cfg
+    self.L = _lib.lib()
+    h = C.c_void_p()
+    check(self.L.v4l_net_create(C.byref(cfg), C.byref(h)), "v4l_net_create")
+    self.h = h
+    self.kind = cfg.kind
+    self.compute = cfg.compute
+    self.out_dim = cfg.out_dim
+    self.state_dim = cfg.state_dim
+    self.img_elems = 0 if cfg.kind == V4L_NET_MLP else cfg.in_channels * cfg.img_hw * cfg.img_hw
+    self.Sp = self.L.v4l_net_state_ld(h)
+    self.total_params = self.L.v4l_net_total_params(h)
+    self.param_names, self.param_shapes, self.grad_offsets = [], [], []
+    name, ndim, numel, goff = C.c_char_p(), C.c_int(), C.c_int64(), C.c_int64()
+    shape = (C.c_int64 * 4)()
+    for i in range(self.L.v4l_net_num_params(h)):
+      check(self.L.v4l_net_param_info(h, i, C.byref(name), C.byref(ndim), shape, C.byref(numel), C.byref(goff)))
+      self.param_names.append(name.value.decode())
+      self.param_shapes.append(tuple(shape[d] for d in range(ndim.value)))
+      self.grad_offsets.append(goff.value)
+    self._ptrs = None
+    self._versions = None
+    self._dirty = True
+    self._ws = {}
+    self._stage = {}
+    self.device = None
+
+  def __del__(self):
+    try:
+      if getattr(self, "h", None):
+        self.L.v4l_net_destroy(self.h)
+        self.h = None
+    except Exception:
+      pass
+
+  # ---- parameter binding -------------------------------------------------------------------
+  def _tensors(self):
+    sd = self.module.state_dict(keep_vars=True)
+    ts = []
+    for name, shp in zip(self.param_names, self.param_shapes):
+      if name not in sd:
+        raise RuntimeError("vision4leg_amd: module has no parameter %r expected by the HIP plan" % name)
+      t = sd[name]
+      if tuple(t.shape) != shp:
+        raise RuntimeError("vision4leg_amd: parameter %s has shape %s, HIP plan expects %s"
+                           % (name, tuple(t.shape), shp))
+      if t.dtype != torch.float32 or not t.is_contiguous():
+        raise RuntimeError("vision4leg_amd: parameter %s must be contiguous float32" % name)
+      _require_gpu(t, "parameter " + name)
+      ts.append(t)
+    return ts
+
+  def ensure_bound(self):
+    ts = self._tensors()
+    ptrs = [t.data_ptr() for t in ts]
+    if ptrs != self._ptrs:
+      self.device = ts[0].device
+      with torch.cuda.device(self.device):
+        self._packed = torch.empty(self.L.v4l_net_packed_bytes(self.h), dtype=torch.uint8, device=self.device)
+        self._table = torch.empty(self.L.v4l_net_table_bytes(self.h), dtype=torch.uint8, device=self.device)
+        arr = (C.c_void_p * len(ptrs))(*ptrs)
+        check(self.L.v4l_net_bind(self.h, arr, _ptr(self._packed), _ptr(self._table), _stream()), "v4l_net_bind")
+      self._ptrs = ptrs
+      self._dirty = True
+      self._ws.clear()
+      self._stage.clear()
+    vers = [t._version for t in ts]
+    if vers != self._versions:
+      self._versions = vers
+      self._dirty = True
+    return ts
+
+  def mark_dirty(self):
+    """Parameters were changed behind torch's back (an optimiser step inside the library)."""
+    self._dirty = True
+
+  def pack_if_needed(self):
+    self.ensure_bound()
+    if self._dirty:
+      check(self.L.v4l_net_pack(self.h, _stream()), "v4l_net_pack")
+      self._dirty = False
+
+  # ---- buffers -----------------------------------------------------------------------------
+  def ws_floats(self, n):
+    return self.L.v4l_net_ws_floats(self.h, n, 1)
+
+  def workspace(self, n):
+    ws = self._ws.get(n)
+    if ws is None:
+      ws = torch.empty(self.ws_floats(n), dtype=torch.float32, device=self.device)
+      self._ws = {n: ws}  # keep one
+    return ws
+
+  def image_dtype(self):
+    return torch.bfloat16 if self.compute == V4L_BF16 else torch.float32
+
+  def alloc_rollout(self, slots, device):
+    state = torch.zeros(slots, self.Sp, dtype=torch.float32, device=device)
+    image = None
+    if self.img_elems:
+      image = torch.zeros(slots, self.img_elems, dtype=self.image_dtype(), device=device)
+    return state, image
+
+  def ingest(self, obs, state, image, slot0=0):
+    """obs: [n][S + C*H*W] float32 cuda tensor in the reference's row layout."""
+    _require_gpu(obs, "observation batch")
+    if obs.dtype != torch.float32 or not obs.is_contiguous():
+      obs = obs.contiguous().float()
+    n, d = obs.shape
+    if d != self.state_dim + self.img_elems:
+      raise RuntimeError("vision4leg_amd: observation rows have %d columns, net expects %d (+%d image)"
+                         % (d, self.state_dim, self.img_elems))
+    check(self.L.v4l_ingest(self.h, _ptr(obs), n, _ptr(state), _ptr(image), slot0, _stream()), "v4l_ingest")
+
+  def stage(self, obs):
+    """Ingest a batch of reference observation rows into per-net staging arrays; returns (state, image, n)."""
+    obs = obs.reshape(-1, obs.shape[-1])
+    n = obs.shape[0]
+    st = self._stage.get(n)
+    if st is None:
+      st = self.alloc_rollout(n, obs.device)
+      self._stage = {n: st}
+    self.ingest(obs, st[0], st[1])
+    return st[0], st[1], n
+
+  # ---- compute -----------------------------------------------------------------------------
+  def forward(self, state, image, n, rowidx=None, ws=None, train=False):
+    """Runs the net; returns the padded head output [n][V4L_OUT_LD] as a view into the workspace."""
+    self.pack_if_needed()
+    if ws is None:
+      ws = self.workspace(n)
+    check(self.L.v4l_net_forward(self.h, _ptr(state), _ptr(image), _ptr(rowidx), n, _ptr(ws), int(train), _stream()),
+          "v4l_net_forward")
+    off = self.ws_offset(n, "out")
+    return ws[off:off + n * V4L_OUT_LD].view(n, V4L_OUT_LD)
+
+  def backward(self, state, image, n, dout, grads, rowidx=None, ws=None):
+    """dout: [n][V4L_OUT_LD] (zero padded). grads: flat float32 buffer, accumulated into."""
+    if ws is None:
+      ws = self.workspace(n)
+    off = self.ws_offset(n, "dout")
+    ws[off:off + n * V4L_OUT_LD].view(n, V4L_OUT_LD).copy_(dout)
+    check(self.L.v4l_net_backward(self.h, _ptr(state), _ptr(image), _ptr(rowidx), n, _ptr(ws), _ptr(grads), _stream()),
+          "v4l_net_backward")
+
+  def ws_offset(self, n, name):
+    off = self.L.v4l_net_ws_offset(self.h, n, name.encode())
+    if off < 0:
+      raise KeyError(name)
+    return off
+
+  def ws_view(self, n, name, rows, cols, ws=None):
+    ws = self.workspace(n) if ws is None else ws
+    off = self.ws_offset(n, name)
+    return ws[off:off + rows * cols].view(rows, cols)
+
+  def grad_view(self, grads, name):
+    i = self.param_names.index(name)
+    shp = self.param_shapes[i]
+    o = self.grad_offsets[i]
+    return grads[o:o + int(np.prod(shp))].view(shp)
+
+  def value(self, obs):
+    """vf(x): [n][1]"""
+    st, im, n = self.stage(obs)
+    out = self.forward(st, im, n)
+    v = torch.empty(n, dtype=torch.float32, device=obs.device)
+    check(self.L.v4l_col0(_ptr(out), n, _ptr(v), _stream()), "v4l_col0")
+    return v.view(n, 1)
+
+  def gaussian(self, obs, logstd, acts=None):
+    """Policy head: mean/std [n][A], clamped log_std [A], ent [n][1] and log_prob [n][1] of acts (optional)."""
+    st, im, n = self.stage(obs)
+    out = self.forward(st, im, n)
+    return self.gauss_head(out, logstd, n, acts)
+
+  def gauss_head(self, out, logstd, n, acts=None):
+    A, dev = self.out_dim, out.device
+    mean = torch.empty(n, A, dtype=torch.float32, device=dev)
+    std = torch.empty(n, A, dtype=torch.float32, device=dev)
+    lsc = torch.empty(A, dtype=torch.float32, device=dev)
+    ent = torch.empty(n, dtype=torch.float32, device=dev)
+    logp = None
+    if acts is not None:
+      acts = acts.reshape(n, A).contiguous().float()
+      logp = torch.empty(n, dtype=torch.float32, device=dev)
+    check(self.L.v4l_gauss_head(_ptr(out), _ptr(logstd), _ptr(acts), n, A, _ptr(mean), _ptr(std), _ptr(lsc),
+                                _ptr(ent), _ptr(logp), _stream()), "v4l_gauss_head")
+    return mean, std, lsc, ent.view(n, 1), (logp.view(n, 1) if logp is not None else None)
+
+
+class HipTrainer:
+  """PPO minibatch update over (pf, vf, target_pf): owns the flat grad/Adam buffers, the shared workspace and
+  the per-update statistics records. Mirrors PPO.update of torchrl/algo/on_policy/ppo.py:125-153."""
+
+  def __init__(self, pf_net, vf_net, tpf_net, batch, clip_para, entropy_coeff, max_grad_norm=0.5,
+               betas=(0.9, 0.999), eps=1e-5, clipped_value_loss=False, world_size=1):
+    self.pf, self.vf, self.tpf = pf_net, vf_net, tpf_net
+    self.L = _lib.lib()
+    for net in (pf_net, vf_net, tpf_net):
+      net.ensure_bound()
+    self.device = pf_net.device
+    h = C.c_void_p()
+    check(self.L.v4l_trainer_create(pf_net.h, vf_net.h, tpf_net.h, C.byref(h)), "v4l_trainer_create")
+    self.h = h
+    dev = self.device
+    z = lambda n: torch.zeros(n, dtype=torch.float32, device=dev)
+    self.g_pf, self.m_pf, self.v_pf = z(pf_net.total_params), z(pf_net.total_params), z(pf_net.total_params)
+    self.g_vf, self.m_vf, self.v_vf = z(vf_net.total_params), z(vf_net.total_params), z(vf_net.total_params)
+    self.batch = 0
+    self._alloc_ws(batch)
+    self.hp = PPOHyper(clip_para, entropy_coeff, max_grad_norm, betas[0], betas[1], eps,
+                       int(bool(clipped_value_loss)), int(world_size))
+    self.step = 0  # Adam step count (both optimisers step once per update)
+
+  def __del__(self):
+    try:
+      if getattr(self, "h", None):
+        self.L.v4l_trainer_destroy(self.h)
+        self.h = None
+    except Exception:
+      pass
+
+  def _alloc_ws(self, n):
+    if n <= self.batch:
+      return
+    self.batch = n
+    self.ws = torch.empty(self.L.v4l_trainer_ws_floats(self.h, n), dtype=torch.float32, device=self.device)
+    check(self.L.v4l_trainer_bind(self.h, _ptr(self.g_pf), _ptr(self.m_pf), _ptr(self.v_pf), _ptr(self.g_vf),
+                                  _ptr(self.m_vf), _ptr(self.v_vf), _ptr(self.ws), self.ws.numel(), _stream()),
+          "v4l_trainer_bind")
+
+  @staticmethod
+  def rollout(state, image, acts, advs, rets, values=None):
+    ro = Rollout(state.data_ptr(), image.data_ptr() if image is not None else None, acts.data_ptr(),
+                 advs.data_ptr(), rets.data_ptr(), values.data_ptr() if values is not None else None)
+    ro._keep = (state, image, acts, advs, rets, values)
+    return ro
+
+  def sync_target(self):
+    """copy_model_params_from_to(pf, target_pf) + repack of the frozen target (ppo.py:34)."""
+    for net in (self.pf, self.tpf):
+      net.ensure_bound()
+    check(self.L.v4l_trainer_sync_target(self.h, _stream()), "v4l_trainer_sync_target")
+    self.tpf._dirty = False
+
+  def _pre(self, n):
+    self._alloc_ws(n)
+    for net in (self.pf, self.vf, self.tpf):
+      net.ensure_bound()
+    if self.tpf._dirty:
+      self.tpf.pack_if_needed()
+
+  def update(self, ro, rowidx, n, lr_pf, lr_vf, stats):
+    """One PPO.update on minibatch rows rowidx (int32 device tensor or None). stats: [V4L_STATS] device floats."""
+    self._pre(n)
+    self.step += 1
+    check(self.L.v4l_trainer_update(self.h, C.byref(ro), _ptr(rowidx), n, C.byref(self.hp), lr_pf, lr_vf, self.step,
+                                    _ptr(stats), _stream()), "v4l_trainer_update")
+    self._after_steps()
+
+  def _after_steps(self):
+    # the library repacks pf/vf itself at the start of every grads phase; other users of the nets must repack
+    for net in (self.pf, self.vf):
+      net.mark_dirty()
+
+  # phases, for the data-parallel schedule (all-reduce between grads and step)
+  def critic_grads(self, ro, rowidx, n, stats):
+    self._pre(n)
+    check(self.L.v4l_trainer_critic_grads(self.h, C.byref(ro), _ptr(rowidx), n, C.byref(self.hp), _ptr(stats), _stream()),
+          "v4l_trainer_critic_grads")
+
+  def critic_step(self, lr, stats):
+    check(self.L.v4l_trainer_critic_step(self.h, C.byref(self.hp), lr, self.step + 1, _ptr(stats), _stream()),
+          "v4l_trainer_critic_step")
+    self.vf.mark_dirty(); self.pf.mark_dirty()
+
+  def actor_grads(self, ro, rowidx, n, stats):
+    check(self.L.v4l_trainer_actor_grads(self.h, C.byref(ro), _ptr(rowidx), n, C.byref(self.hp), _ptr(stats), _stream()),
+          "v4l_trainer_actor_grads")
+
+  def actor_step(self, lr, stats):
+    check(self.L.v4l_trainer_actor_step(self.h, C.byref(self.hp), lr, self.step + 1, _ptr(stats), _stream()),
+          "v4l_trainer_actor_step")
+    self.step += 1
+    self._after_steps()
+
+
+def gae(rewards, values, terminals, time_limits, last_value, gamma, tau, use_time_limit, want32=True):
+  """HIP GAE on float64 cuda tensors [T][E] (time_limits [T] or [T][E]); returns (advs, rets, advs32, rets32)."""
+  L = _lib.lib()
+  T, E = rewards.shape
+  advs = torch.empty(T, E, dtype=torch.float64, device=rewards.device)
+  rets = torch.empty_like(advs)
+  a32 = torch.empty(T, E, dtype=torch.float32, device=rewards.device) if want32 else None
+  r32 = torch.empty_like(a32) if want32 else None
+  tl_per_env = int(time_limits is not None and time_limits.dim() == 2 and time_limits.shape[1] == E and E > 1
+                   or (time_limits is not None and time_limits.numel() == T * E and E == 1))
+  check(L.v4l_gae(_ptr(rewards), _ptr(values), _ptr(terminals), _ptr(time_limits), tl_per_env, _ptr(last_value), T, E,
+                  float(gamma), float(tau), int(bool(use_time_limit)), _ptr(advs), _ptr(rets), _ptr(a32), _ptr(r32),
+                  _stream()), "v4l_gae")
+  return advs, rets, a32, r32

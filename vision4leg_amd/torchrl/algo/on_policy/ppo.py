@@ -1,0 +1,289 @@
+"""PPO with the reference's constructor, attributes and epoch protocol
+(torchrl/algo/on_policy/ppo.py:10-161 on top of a2c.py:13-44, on_rl_algo.py:11-34, rl_algo.py:19-168).
+
+What changes is *where* the work runs: `update` enqueues one fused critic-then-actor minibatch update on the
+MI355X (forward, loss, backward, global-norm clip and Adam for both optimisers, all hand-written HIP behind
+libv4l_hip.so) and `process_epoch_samples` runs the last-value forward and the fp64 GAE kernel. With a
+`DeviceOnPolicyReplayBuffer` the observations never leave HBM and the 18 logger scalars of all 48 updates are
+read back once per epoch instead of 18 `.item()` syncs per update.
+
+Data parallel (one process per GPU, torch.distributed "nccl" == RCCL): every rank owns an env shard and its own
+rollout; gradients are summed with ONE all-reduce per optimiser step on the flat gradient buffer (the critic's
+carries the 3 advantage-normalisation scalars in its tail), then clipped and applied identically on every rank.
+"""
+import copy
+import os
+import os.path as osp
+import pathlib
+import pickle
+import time
+from collections import deque
+
+import numpy as np
+import torch
+
+from .. import utils as atu
+from ... import replay_buffers as rb
+from .... import _lib
+from ....engine import HipTrainer
+
+
+class _HipAdam:
+    """Optimiser facade: the Adam state lives in the trainer's flat device buffers; this object only carries
+    the learning rate so `update_linear_schedule` and user code can read/write `param_groups[0]['lr']`."""
+
+    def __init__(self, params, lr, eps=1e-5, betas=(0.9, 0.999)):
+        self.param_groups = [{"params": list(params), "lr": lr, "eps": eps, "betas": betas, "weight_decay": 0}]
+
+    @property
+    def lr(self):
+        return self.param_groups[0]["lr"]
+
+    def zero_grad(self):
+        pass
+
+
+def _dist_world():
+    if torch.distributed.is_available() and torch.distributed.is_initialized():
+        return torch.distributed.get_world_size()
+    return 1
+
+
+class PPO:
+    def __init__(self, pf, vf, plr=3e-4, vlr=3e-4, optimizer_class=None, entropy_coeff=0.001, clip_para=0.2,
+                 opt_epochs=10, clipped_value_loss=False, shuffle=True, tau=None, gae=True, env=None,
+                 replay_buffer=None, collector=None, logger=None, grad_clip=None, discount=0.99, num_epochs=3000,
+                 batch_size=128, device="cpu", save_interval=100, eval_interval=1, save_dir=None, **kwargs):
+        if optimizer_class is not None and optimizer_class is not torch.optim.Adam:
+            raise NotImplementedError("vision4leg_amd: PPO runs Adam on the HIP engine; optimizer_class must be Adam")
+        if not gae:
+            raise NotImplementedError("vision4leg_amd: gae=False is outside the HIP hot path")
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise RuntimeError("vision4leg_amd: PPO needs a GPU device (got %s); there is no CPU path" % self.device)
+        # ---- reference attribute surface
+        self.target_pf = copy.deepcopy(pf)  # before .to(device), as ppo.py:21
+        self.env = env
+        self.continuous = True
+        self.replay_buffer = replay_buffer
+        self.collector = collector
+        self.discount = discount
+        self.num_epochs = num_epochs
+        self.epoch_frames = getattr(collector, "epoch_frames", None)
+        self.batch_size = batch_size
+        self.training_update_num = 0
+        self.grad_clip = grad_clip
+        self.logger = logger
+        self.episode_rewards = deque(maxlen=30)
+        self.training_episode_rewards = deque(maxlen=30)
+        self.save_interval = save_interval
+        self.save_dir = save_dir
+        if save_dir is not None:
+            pathlib.Path(save_dir).mkdir(parents=True, exist_ok=True)
+        self.best_eval = None
+        self.eval_interval = eval_interval
+        self.explore_time = 0
+        self.train_time = 0
+        self.start = time.time()
+        self.shuffle = shuffle
+        self.tau = tau
+        self.gae = gae
+        self.pf = pf
+        self.vf = vf
+        self.to(self.device)
+        self.plr, self.vlr = plr, vlr
+        self.optimizer_class = torch.optim.Adam
+        self.pf_optimizer = _HipAdam(self.pf.parameters(), lr=plr)
+        self.vf_optimizer = _HipAdam(self.vf.parameters(), lr=vlr)
+        self.entropy_coeff = entropy_coeff
+        self.clip_para = clip_para
+        self.opt_epochs = opt_epochs
+        self.clipped_value_loss = clipped_value_loss
+        self.sample_key = ["obs", "acts", "advs", "estimate_returns", "values"]
+        self.current_epoch = 0
+        # ---- engine
+        self.world_size = _dist_world()
+        if self.world_size > 1:
+            for p in list(self.pf.parameters()) + list(self.vf.parameters()):
+                torch.distributed.broadcast(p.data, src=0)
+            atu.copy_model_params_from_to(self.pf, self.target_pf)
+        with torch.cuda.device(self.device):
+            self.trainer = HipTrainer(self.pf.hip, self.vf.hip, self.target_pf.hip, batch_size, clip_para,
+                                      entropy_coeff, max_grad_norm=0.5, clipped_value_loss=clipped_value_loss,
+                                      world_size=self.world_size)
+        if self.world_size > 1:
+            # one buffer per all-reduce: critic grads + (sum adv, sum adv^2, count)
+            self._vf_bucket = torch.zeros(self.vf.hip.total_params + 3, dtype=torch.float32, device=self.device)
+            self.trainer.g_vf = self._vf_bucket[:self.vf.hip.total_params]
+            self.trainer.batch = 0
+            self.trainer._alloc_ws(batch_size)
+        if isinstance(replay_buffer, rb.DeviceOnPolicyReplayBuffer):
+            replay_buffer.attach(self.pf.hip, self.device)
+        elif replay_buffer is not None:
+            replay_buffer.gae_device = self.device
+        self._stage = None
+
+    # ---- reference plumbing ------------------------------------------------------------------------
+    @property
+    def networks(self):
+        return [self.pf, self.vf, self.target_pf]
+
+    @property
+    def snapshot_networks(self):
+        return [("pf", self.pf), ("vf", self.vf)]
+
+    @property
+    def target_networks(self):
+        return []
+
+    def to(self, device):
+        for net in self.networks:
+            net.to(device)
+
+    def start_epoch(self):
+        pass
+
+    def finish_epoch(self):
+        return {}
+
+    def pretrain(self):
+        pass
+
+    def snapshot(self, prefix, epoch):
+        """state_dict checkpoints with the reference's file names (rl_algo.py:84-95)."""
+        norm = getattr(self.env, "_obs_normalizer", None)
+        if norm is not None:
+            with open(osp.join(prefix, "_obs_normalizer_{}.pkl".format(epoch)), "wb") as f:
+                pickle.dump(norm, f)
+        for name, network in self.snapshot_networks:
+            torch.save(network.state_dict(), osp.join(prefix, "model_{}_{}.pth".format(name, epoch)))
+
+    # ---- epoch ---------------------------------------------------------------------------------------
+    def process_epoch_samples(self):
+        """last_value = vf(next_obs[T-1]) * (1 - terminal) then GAE (on_rl_algo.py:23-34)."""
+        sample = self.replay_buffer.last_sample(["next_obs", "terminals", "time_limits"])
+        last_ob = torch.from_numpy(np.ascontiguousarray(sample["next_obs"], dtype=np.float32)).to(self.device)
+        last_value = self.vf(last_ob).cpu().numpy()
+        last_value = last_value * (1 - sample["terminals"])
+        self.replay_buffer.generalized_advantage_estimation(last_value, self.discount, self.tau)
+
+    def update_per_epoch(self):
+        with torch.cuda.device(self.device):
+            self.process_epoch_samples()
+            atu.update_linear_schedule(self.pf_optimizer, self.current_epoch, self.num_epochs, self.plr)
+            atu.update_linear_schedule(self.vf_optimizer, self.current_epoch, self.num_epochs, self.vlr)
+            self.trainer.sync_target()  # copy_model_params_from_to(pf, target_pf), ppo.py:34
+            if isinstance(self.replay_buffer, rb.DeviceOnPolicyReplayBuffer):
+                self._update_epoch_resident()
+                return
+            for _ in range(self.opt_epochs):
+                for batch in self.replay_buffer.one_iteration(self.batch_size, self.sample_key, self.shuffle):
+                    infos = self.update(batch)
+                    self.logger.add_update_info(infos)
+
+    def _update_epoch_resident(self):
+        buf = self.replay_buffer
+        state, image, acts, advs, rets, vals = buf.device_rollout()
+        ro = HipTrainer.rollout(state, image, acts, advs, rets, vals)
+        batches = []
+        for _ in range(self.opt_epochs):
+            for b in buf.one_iteration(self.batch_size, self.sample_key, self.shuffle):
+                batches.append(b["rowidx"])
+        rowidx = torch.from_numpy(np.stack(batches)).to(self.device)  # one upload per epoch
+        stats = torch.zeros(len(batches), _lib.V4L_STATS, dtype=torch.float32, device=self.device)
+        for i in range(len(batches)):
+            self.training_update_num += 1
+            self._update_rows(ro, rowidx[i], rowidx.shape[1], stats[i])
+        host = stats.cpu().numpy()  # the only device->host sync of the epoch's updates
+        for row in host:
+            self.logger.add_update_info({k: float(row[j]) for j, k in enumerate(_lib.STAT_KEYS)})
+
+    def _update_rows(self, ro, rowidx, n, stats):
+        lr_pf, lr_vf = self.pf_optimizer.lr, self.vf_optimizer.lr
+        tr = self.trainer
+        if self.world_size == 1:
+            tr.update(ro, rowidx, n, lr_pf, lr_vf, stats)
+            return
+        dist = torch.distributed
+        tr.critic_grads(ro, rowidx, n, stats)
+        self._vf_bucket[-3:].copy_(stats[18:21])
+        dist.all_reduce(self._vf_bucket)  # RCCL sum over env shards: critic grads + adv sums
+        stats[18:21].copy_(self._vf_bucket[-3:])
+        tr.critic_step(lr_vf, stats)
+        tr.actor_grads(ro, rowidx, n, stats)
+        dist.all_reduce(tr.g_pf)
+        tr.actor_step(lr_pf, stats)
+
+    def update(self, batch):
+        """One minibatch update from a reference-style host batch (ppo.py:125-153). Returns the 18-key info."""
+        if "rowidx" in batch:
+            raise RuntimeError("device-resident batches are consumed by update_per_epoch")
+        self.training_update_num += 1
+        dev = self.device
+        with torch.cuda.device(dev):
+            up = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(dev)
+            obs = up(batch["obs"])
+            n = obs.shape[0]
+            net = self.pf.hip
+            net.ensure_bound()
+            if self._stage is None or self._stage[0].shape[0] != n:
+                self._stage = net.alloc_rollout(n, dev)
+            net.ingest(obs, self._stage[0], self._stage[1])
+            acts = up(batch["acts"]).reshape(n, -1)
+            advs = up(batch["advs"]).reshape(n)
+            rets = up(batch["estimate_returns"]).reshape(n)
+            vals = up(batch["values"]).reshape(n)
+            ro = HipTrainer.rollout(self._stage[0], self._stage[1], acts, advs, rets, vals)
+            stats = torch.zeros(_lib.V4L_STATS, dtype=torch.float32, device=dev)
+            self._update_rows(ro, None, n, stats)
+            host = stats.cpu().numpy()
+        return {k: float(host[j]) for j, k in enumerate(_lib.STAT_KEYS)}
+
+    # ---- outer loop (rl_algo.py:97-168) ----------------------------------------------------------------
+    def train(self):
+        self.pretrain()
+        total_frames = getattr(self, "pretrain_frames", 0)
+        self.start_epoch()
+        for epoch in range(self.num_epochs):
+            self.current_epoch = epoch
+            self.start_epoch()
+            t0 = time.time()
+            training_epoch_info = self.collector.train_one_epoch()
+            for reward in training_epoch_info["train_rewards"]:
+                self.training_episode_rewards.append(reward)
+            self.explore_time += time.time() - t0
+            t0 = time.time()
+            self.update_per_epoch()
+            torch.cuda.synchronize(self.device)
+            self.train_time += time.time() - t0
+            finish_epoch_info = self.finish_epoch()
+            total_frames += self.epoch_frames
+            if epoch % self.eval_interval == 0:
+                t0 = time.time()
+                eval_infos = self.collector.eval_one_epoch()
+                eval_time = time.time() - t0
+                infos = {}
+                for reward in eval_infos["eval_rewards"]:
+                    self.episode_rewards.append(reward)
+                mean_eval = np.mean(eval_infos["eval_rewards"])
+                if self.best_eval is None or mean_eval > self.best_eval:
+                    self.best_eval = mean_eval
+                    self.snapshot(self.save_dir, "best")
+                    print("Best Saved: {:.5f},  EPoch: {}".format(mean_eval, epoch))
+                del eval_infos["eval_rewards"]
+                infos["Running_Average_Rewards"] = np.mean(self.episode_rewards)
+                infos["Train_Epoch_Reward"] = training_epoch_info["train_epoch_reward"]
+                infos["Running_Training_Average_Rewards"] = np.mean(self.training_episode_rewards)
+                infos["Explore_Time"] = self.explore_time
+                infos["Train___Time"] = self.train_time
+                infos["Eval____Time"] = eval_time
+                self.explore_time = 0
+                self.train_time = 0
+                infos.update(eval_infos)
+                infos.update(finish_epoch_info)
+                self.logger.add_epoch_info(epoch, total_frames, time.time() - self.start, infos)
+                self.start = time.time()
+            if epoch % self.save_interval == 0:
+                self.snapshot(self.save_dir, epoch)
+        self.snapshot(self.save_dir, "finish")
+        self.collector.terminate()

@@ -1,0 +1,94 @@
+"""Gaussian policies of the PPO hot path with the reference's names and method protocol
+(torchrl/policies/continuous_policy.py: GaussianContPolicyBase 77-146, ...BasicBias 239-254,
+...ImpalaEncoderProj 275-290, ...LocoTransformer 478-492).
+
+A policy is a top-level HIP net plus the state-independent `logstd` parameter. `forward/explore/eval_act/update`
+evaluate the trunk and the Gaussian head (clamp, exp, entropy, log-prob) with libv4l_hip.so kernels; only the
+random draw of `explore` uses torch's generator so that seeded rollouts consume the RNG stream exactly like
+the reference's `Normal(mean, std).sample()`.
+"""
+import numpy as np
+import torch
+import torch.nn as nn
+from torch.distributions import Normal
+
+from .. import networks
+
+LOG_SIG_MAX = 2
+LOG_SIG_MIN = -5
+
+__all__ = ["LOG_SIG_MAX", "LOG_SIG_MIN", "GaussianContPolicyBase", "GaussianContPolicyBasicBias",
+           "GaussianContPolicyImpalaEncoderProj", "GaussianContPolicyLocoTransformer"]
+
+
+class GaussianContPolicyBase:
+    """Mixin: needs `self.hip` (HipNet), `self.logstd`, `self.tanh_action`."""
+
+    def _init_policy(self, output_shape, tanh_action, log_init):
+        if tanh_action:
+            raise NotImplementedError("vision4leg_amd: tanh_action=True (TanhNormal) is not on the HIP engine; "
+                                      "every shipped PPO config uses the plain Normal head")
+        self.continuous = True
+        self.logstd = nn.Parameter(torch.ones(output_shape) * np.log(log_init))
+        self.tanh_action = tanh_action
+
+    def _gaussian(self, x, actions=None):
+        lead = x.shape[:-1]
+        x2 = x.reshape(-1, x.shape[-1])
+        mean, std, log_std, ent, logp = self.hip.gaussian(x2, self.logstd.data, actions)
+        A = mean.shape[-1]
+        mean, std = mean.view(*lead, A), std.view(*lead, A)
+        ent = ent.view(*lead, 1)
+        if logp is not None:
+            logp = logp.view(*lead, 1)
+        return mean, std, log_std, ent, logp
+
+    def forward(self, x):
+        mean, std, log_std, _, _ = self._gaussian(x)
+        return mean, std, log_std
+
+    def eval_act(self, x):
+        mean, _, _ = self.forward(x)
+        return mean.squeeze(0).cpu().numpy()
+
+    def explore(self, x, return_log_probs=False, return_pre_tanh=False):
+        mean, std, log_std, ent, _ = self._gaussian(x)
+        action = torch.normal(mean, std)  # == Normal(mean, std).sample(): same generator, same draw order
+        dic = {"mean": mean, "log_std": log_std, "std": std, "ent": ent}
+        if return_log_probs:
+            A = mean.shape[-1]
+            n = mean.numel() // A
+            padded = torch.zeros(n, 16, dtype=torch.float32, device=mean.device)  # V4L_OUT_LD rows
+            padded[:, :A] = mean.reshape(n, A)
+            *_, logp = self.hip.gauss_head(padded, self.logstd.data, n, action)
+            dic["log_prob"] = logp.view(*mean.shape[:-1], 1)
+        dic["action"] = action.squeeze(0)
+        return dic
+
+    def update(self, obs, actions):
+        mean, std, log_std, ent, logp = self._gaussian(obs, actions)
+        return {"mean": mean, "dis": Normal(mean, std), "log_std": log_std, "std": std, "log_prob": logp, "ent": ent}
+
+
+class GaussianContPolicyBasicBias(networks.Net, GaussianContPolicyBase):
+    def __init__(self, output_shape, tanh_action=False, log_init=0.125, **kwargs):
+        super().__init__(output_shape=output_shape, **kwargs)
+        self._init_policy(output_shape, tanh_action, log_init)
+
+    forward = GaussianContPolicyBase.forward
+
+
+class GaussianContPolicyImpalaEncoderProj(networks.ImpalaEncoderProjNet, GaussianContPolicyBase):
+    def __init__(self, output_shape, tanh_action=False, log_init=0.125, **kwargs):
+        super().__init__(output_shape=output_shape, **kwargs)
+        self._init_policy(output_shape, tanh_action, log_init)
+
+    forward = GaussianContPolicyBase.forward
+
+
+class GaussianContPolicyLocoTransformer(networks.LocoTransformer, GaussianContPolicyBase):
+    def __init__(self, output_shape, tanh_action=False, log_init=0.125, **kwargs):
+        super().__init__(output_shape=output_shape, **kwargs)
+        self._init_policy(output_shape, tanh_action, log_init)
+
+    forward = GaussianContPolicyBase.forward
