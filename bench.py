@@ -1,0 +1,313 @@
+#!/usr/bin/env python
+"""bench.py — PPO env-steps/s of the hot path (encoder + update, simulator excluded) on MI355X.
+
+One "step" = one PPO epoch of everything the reference does outside env.step:
+  (i)   T rollout steps at batch E: ingest of the E observation rows + pf.explore + vf forward (+ storing them)
+  (ii)  last-value forward + GAE over [T,E]
+  (iii) opt_epochs x (T*E/B) minibatch updates (critic fwd/bwd/clip/Adam, actor fwd + frozen-target fwd/bwd/clip/Adam)
+  (iv)  LR schedule + target-policy sync
+on a synthetic epoch (distributions of BASELINE.md §3) that is resident in HBM when the timed region starts.
+value = E*T*n_gpus / t_step. Multi-GPU: one process per GPU (torchrun), each rank owns an env shard (weak scaling),
+gradients cross ranks with one RCCL all-reduce per optimiser step.
+
+Prints ONE JSON line on rank 0. Extra objects: "roofline" (dominant kernel, from HIP-event timings collected by the
+library's built-in profiler on the launch stream) and "cpu_baseline" (the CPU oracle on a bounded sample).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+WORKLOADS = {
+    # BASELINE.json configs[2]: ppo_locotransformer.py thin-goal, 1 MI355X, 32 envs (headline: the metric's MFMA
+    # clause and BASELINE.md's 10x target are quoted on the LocoTransformer)
+    "loco": dict(kind="loco", S=93, A=6, E=32, T=512, B=1024, enc=[256, 256], head=[256, 256], layers=2, ff=256,
+                 name="ppo_locotransformer thin-goal: LocoTransformer S=93 A=6, E=32 envs x T=512, B=1024, 3 opt epochs"),
+    # configs[1]: ppo_nature_cnn.py, 16 envs
+    "cnn": dict(kind="cnn", S=93, A=6, E=16, T=1024, B=1024, enc=[256, 256], head=[256, 256], visual_dim=256,
+                name="ppo_nature_cnn thin-goal: NatureCNN fuse net S=93 A=6, E=16 envs x T=1024, B=1024, 3 opt epochs"),
+    # configs[0]: ppo_state.py (the reference's CPU-runnable plumbing case)
+    "mlp": dict(kind="mlp", S=93, A=6, E=1, T=16384, B=1024, enc=[256, 256], head=[256, 256],
+                name="ppo_state: state-only MLP S=93 A=6, E=1 env x T=16384, B=1024, 3 opt epochs"),
+    # configs[4] per-GPU shard: 64 envs/GPU
+    "loco64": dict(kind="loco", S=93, A=6, E=64, T=256, B=1024, enc=[256, 256], head=[256, 256], layers=2, ff=256,
+                   name="ppo_locotransformer challenge/mountain shard: E=64 envs x T=256 per GPU, B=1024"),
+}
+# algorithmic MFLOP per env-step incl. rollout inference
+MFLOP_PER_ENV_STEP = {"loco": 258.9, "loco64": 258.9, "cnn": 191.4, "mlp": 10.2}
+OPT_EPOCHS = 3
+PEAK = {"bf16": 2500.0, "f32": 157.3}  # dense TFLOP/s, MI355X_MICROARCH.md (bf16 MFMA / f32 MFMA)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", default="loco", choices=sorted(WORKLOADS))
+    ap.add_argument("--compute", default=os.environ.get("V4L_COMPUTE", "bf16"), choices=["bf16", "f32"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-rollout", action="store_true", help="time (ii)-(iv) only (the reference's Train___Time)")
+    ap.add_argument("--breakdown", default=None, help="write the per-op HIP-event breakdown to this file")
+    return ap.parse_args()
+
+
+class Epoch:
+    """Device-resident synthetic epoch + the nets/trainer that consume it."""
+
+    def __init__(self, wl, compute, dev, world):
+        os.environ["V4L_COMPUTE"] = compute
+        import util
+        import vision4leg_amd.torchrl.networks as networks
+        import vision4leg_amd.torchrl.policies as policies
+        from vision4leg_amd.torchrl.algo import PPO
+        self.wl, self.dev = wl, dev
+        case = dict(wl, seed=0)
+        torch.manual_seed(0)
+        pf, vf = util.build_nets(networks, policies, case)
+
+        class Coll: epoch_frames = wl["E"] * wl["T"]
+        self.agent = PPO(pf=pf, vf=vf, plr=1e-4, vlr=1e-4, clip_para=0.2, opt_epochs=OPT_EPOCHS, tau=0.95, shuffle=True,
+                         entropy_coeff=0.005, collector=Coll(), device=dev, discount=0.99, num_epochs=1500,
+                         batch_size=wl["B"])
+        self.pf, self.vf = self.agent.pf, self.agent.vf
+        E, T, S, A = wl["E"], wl["T"], wl["S"], wl["A"]
+        D = util.obs_dim(case)
+        g = torch.Generator(device=dev).manual_seed(1234 + (torch.distributed.get_rank() if world > 1 else 0))
+        rn = lambda *s: torch.randn(*s, device=dev, generator=g)
+        # observation rows in the reference's layout [T*E, S + 4*64*64] fp32 (what the collector would upload)
+        self.obs = torch.empty(T * E, D, device=dev)
+        self.obs[:, :S] = rn(T * E, S).clamp_(-10, 10)
+        if D > S:
+            self.obs[:, S:] = rn(T * E, D - S).clamp_(-2.5, 2.8)
+        self.rewards = rn(T, E).double()
+        self.terminals = (torch.rand(T, E, device=dev, generator=g) < 0.01).double()
+        self.time_limits = (torch.rand(T, E, device=dev, generator=g) < 0.002).double()
+        net = self.pf.hip
+        net.ensure_bound()
+        self.state, self.image = net.alloc_rollout(T * E, dev)
+        self.acts = torch.zeros(T * E, A, device=dev)
+        self.values = torch.zeros(T * E, device=dev)
+        self.stats = torch.zeros(OPT_EPOCHS * (T * E // wl["B"]), 24, device=dev)
+        self.epoch = 0
+        if wl.get("skip_rollout"):
+            self.rollout()  # populate once so updates have data
+
+    def rollout(self):
+        """(i): per env step, E rows: ingest + pf.explore + vf; results stay on the device."""
+        E, T = self.wl["E"], self.wl["T"]
+        pf, vf, net = self.pf, self.vf, self.pf.hip
+        for t in range(T):
+            ob = self.obs[t * E:(t + 1) * E]
+            out = pf.explore(ob)
+            self.acts[t * E:(t + 1) * E] = out["action"]
+            self.values[t * E:(t + 1) * E] = vf(ob).view(E)
+            net.ingest(ob, self.state, self.image, slot0=t * E)
+
+    def update(self):
+        """(ii)-(iv)"""
+        from vision4leg_amd import engine
+        from vision4leg_amd.engine import HipTrainer
+        from vision4leg_amd.torchrl.algo import utils as atu
+        wl, ag = self.wl, self.agent
+        E, T, B = wl["E"], wl["T"], wl["B"]
+        last_value = self.vf(self.obs[-E:]).view(E).double() * (1 - self.terminals[-1])
+        _, _, a32, r32 = engine.gae(self.rewards, self.values.view(T, E).double(), self.terminals, self.time_limits,
+                                    last_value, 0.99, 0.95, True)
+        ag.current_epoch = self.epoch
+        atu.update_linear_schedule(ag.pf_optimizer, ag.current_epoch, ag.num_epochs, ag.plr)
+        atu.update_linear_schedule(ag.vf_optimizer, ag.current_epoch, ag.num_epochs, ag.vlr)
+        ag.trainer.sync_target()
+        rows = B // E
+        idx = []
+        for _ in range(OPT_EPOCHS):
+            perm = np.random.permutation(T)
+            for pos in range(0, T, rows):
+                sel = perm[pos:pos + rows]
+                idx.append((sel[:, None] * E + np.arange(E)[None, :]).reshape(-1))
+        rowidx = torch.from_numpy(np.stack(idx).astype(np.int32)).to(self.dev)
+        ro = HipTrainer.rollout(self.state, self.image, self.acts, a32.reshape(-1), r32.reshape(-1), self.values)
+        for i in range(rowidx.shape[0]):
+            ag._update_rows(ro, rowidx[i], B, self.stats[i])
+        self.epoch += 1
+
+    def step(self, with_rollout=True):
+        if with_rollout:
+            self.rollout()
+        self.update()
+
+
+def cpu_baseline(wl, compute):
+    """The CPU oracle (oracle/ppo_oracle.py, kind 'port': the restatement pinned against the reference) on a bounded
+    sample of the same workload: 2 minibatch updates, 8 inference step pairs, 1 GAE; extrapolated to one epoch."""
+    import util
+    from oracle import ppo_oracle as orc
+    import vision4leg_amd.torchrl.networks as networks
+    import vision4leg_amd.torchrl.policies as policies
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    case = dict(wl, seed=0)
+    torch.manual_seed(0)
+    pf, vf = util.build_nets(networks, policies, case)
+    opf = {k: v.clone() for k, v in pf.state_dict().items()}
+    ovf = util.share_encoder(opf, {k: v.clone() for k, v in vf.state_dict().items()}, wl["kind"])
+    oracle = orc.PPOOracle(wl["kind"], opf, ovf, {k: v.clone() for k, v in opf.items()}, wl["S"], "f32")
+    oracle.sync_target()
+    B, E, T = wl["B"], wl["E"], wl["T"]
+    t = lambda a: torch.tensor(a, dtype=torch.float32)
+    b = util.make_batch(case, B=B)
+    args = (t(b["obs"]), t(b["acts"]), t(b["advs"]), t(b["estimate_returns"]), t(b["values"]), 1e-4, 1e-4)
+    oracle.update(*args)  # warm-up
+    n_upd = 2
+    t0 = time.perf_counter()
+    for _ in range(n_upd):
+        oracle.update(*args)
+    t_upd = (time.perf_counter() - t0) / n_upd
+    fwd = orc.FORWARDS[wl["kind"]]
+    ob = t(b["obs"][:E])
+    pp = {k: v for k, v in opf.items() if k != "logstd"}
+    with torch.no_grad():
+        fwd(pp, ob, wl["S"]); fwd(ovf, ob, wl["S"])
+        n_inf = 8
+        t0 = time.perf_counter()
+        for _ in range(n_inf):
+            fwd(pp, ob, wl["S"]); fwd(ovf, ob, wl["S"])
+        t_inf = (time.perf_counter() - t0) / n_inf
+    ro = orc.synthetic_rollout(T, E, 1, 1, seed=0, with_images=False)
+    t0 = time.perf_counter()
+    orc.gae(ro["rewards"], ro["values"], ro["terminals"], ro["time_limits"], ro["last_value"], 0.99, 0.95, True)
+    t_gae = time.perf_counter() - t0
+    n_mb = OPT_EPOCHS * (T * E // B)
+    t_epoch = n_mb * t_upd + T * t_inf + t_gae
+    return {
+        "value": round(E * T / t_epoch, 2), "unit": "env-steps/s", "cores": cores, "kind": "port",
+        "sample": "%d minibatch updates (B=%d) + %d rollout step pairs (pf+vf fwd, E=%d) + 1 GAE [%dx%d] of the same "
+                  "workload, fp32 torch-CPU oracle with %d threads, extrapolated to one epoch (%d updates, %d steps)"
+                  % (n_upd, B, n_inf, E, T, E, cores, n_mb, T),
+        "update_only_value": round(E * T / (n_mb * t_upd), 2),
+        "s_per_update": round(t_upd, 4), "s_per_rollout_step": round(t_inf, 5), "s_gae": round(t_gae, 4),
+    }
+
+
+def roofline(ep, compute, breakdown_path):
+    """Per-op timings of ONE profiled pass of (ii)-(iv) (HIP events around every launch, on the launch stream). The
+    dominant entry (largest total time) is reported against the dense MFMA peak of the contraction type."""
+    import ctypes as C
+    from vision4leg_amd import _lib
+    L = _lib.lib()
+    torch.cuda.synchronize()
+    L.v4l_prof_enable(1)
+    ep.update()
+    buf = C.create_string_buffer(1 << 20)
+    L.v4l_prof_collect(buf, len(buf))
+    L.v4l_prof_enable(0)
+    rows = []
+    for line in buf.value.decode().splitlines():
+        label, calls, us, flops = line.split("\t")
+        rows.append((label, int(calls), float(us), float(flops)))
+    if not rows:
+        return None
+    rows.sort(key=lambda r: -r[2])
+    total_us = sum(r[2] for r in rows)
+    if breakdown_path:
+        with open(breakdown_path, "w") as f:
+            f.write("# one profiled epoch-update (%d updates): phase|op|kernel, calls, total_us, avg_us, TFLOP/s, share\n"
+                    % ep.stats.shape[0])
+            for label, calls, us, fl in rows:
+                f.write("%-70s %6d %12.1f %9.2f %9.2f %6.2f%%\n"
+                        % (label, calls, us, us / calls, fl / us * 1e-6 if us > 0 else 0.0, 100 * us / total_us))
+            f.write("# total kernel time %.1f us\n" % total_us)
+    gemm = [r for r in rows if r[3] > 0]
+    label, calls, us, fl = gemm[0] if gemm else rows[0]
+    ach = fl / us * 1e-6  # TFLOP/s
+    all_flops = sum(r[3] for r in rows)
+    return {
+        "bound": "mfma", "kernel": label, "achieved": round(ach, 2), "peak": PEAK[compute], "unit": "TFLOP/s",
+        "frac": round(ach / PEAK[compute], 5), "traffic": None,
+        "avg_launch_us": round(us / calls, 2), "launches": calls, "share_of_kernel_time": round(us / total_us, 4),
+        "all_kernels_achieved": round(all_flops / total_us * 1e-6, 2),
+        "all_kernels_frac": round(all_flops / total_us * 1e-6 / PEAK[compute], 5),
+        "method": "HIP events around every launch of one extra (untimed) epoch-update on the launch stream; FLOPs = "
+                  "2*M*N*K of the logical contraction per launch",
+    }
+
+
+def main():
+    a = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if a.gpus > 1 and world != a.gpus:
+        raise SystemExit("launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node %d --master-addr "
+                         "127.0.0.1 bench.py --gpus %d ..." % (a.gpus, a.gpus))
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.distributed.init_process_group("nccl", device_id=dev)
+    wl = dict(WORKLOADS[a.workload])
+    if a.no_rollout:
+        wl["skip_rollout"] = True
+    np.random.seed(rank)
+    ep = Epoch(wl, a.compute, dev, world)
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        ep.step(not a.no_rollout)
+    barrier()
+    t0 = time.perf_counter()
+    t_roll = 0.0
+    for _ in range(a.steps):
+        if not a.no_rollout:
+            r0 = time.perf_counter()
+            ep.rollout()
+            torch.cuda.synchronize()
+            t_roll += time.perf_counter() - r0
+        ep.update()
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt, t_roll], device=dev, dtype=torch.float64)
+        torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
+        dt, t_roll = tt[0].item(), tt[1].item()
+    frames = wl["E"] * wl["T"] * world
+    value = frames * a.steps / dt
+    res = {
+        "metric": "PPO env-steps/s (encoder+update, sim excluded)", "value": round(value, 1), "unit": "env-steps/s",
+        "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(1e3 * dt / a.steps, 3),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": a.compute, "data": "synthetic",
+        "config": {"workload": wl["name"], "net": wl["kind"], "envs_per_gpu": wl["E"], "horizon": wl["T"],
+                   "minibatch": wl["B"], "opt_epochs": OPT_EPOCHS, "parallelism": "dp%d" % world,
+                   "includes_rollout_inference": not a.no_rollout},
+        "update_only_env_steps_per_s": round(frames * a.steps / max(dt - t_roll, 1e-9), 1),
+        "rollout_inference_ms_per_step": round(1e3 * t_roll / a.steps, 3),
+        "algorithmic_tflops": round(value * MFLOP_PER_ENV_STEP[a.workload] * 1e-6, 3),
+    }
+    if rank == 0:
+        res["roofline"] = roofline(ep, a.compute, a.breakdown)
+        if not a.no_cpu_baseline:
+            res["cpu_baseline"] = cpu_baseline(wl, a.compute)
+            res["vs_cpu_baseline"] = round(value / world / res["cpu_baseline"]["value"], 1)
+    elif world > 1:
+        ep.update()  # keep collectives matched with rank 0's profiled pass
+    if world > 1:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(res))
+
+
+if __name__ == "__main__":
+    main()

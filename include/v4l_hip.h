@@ -160,6 +160,12 @@ int v4l_trainer_update(v4l_trainer* tr, const v4l_rollout* ro, const int* rowidx
 /* copy_model_params_from_to(pf, target_pf) (torchrl/algo/utils.py:23-25, ppo.py:34) + repack of the target */
 int v4l_trainer_sync_target(v4l_trainer* tr, void* stream);
 
+/* ---- built-in per-kernel timer (HIP events on the launch stream; used by bench.py for the roofline numbers).
+ * v4l_prof_collect synchronises the device, writes "phase|op|kernel\tcalls\ttotal_us\talgorithmic_flops\n" lines
+ * into buf (NUL terminated, truncated to cap) and returns the untruncated length. */
+int v4l_prof_enable(int on);
+int64_t v4l_prof_collect(char* buf, int64_t cap);
+
 /* ---- introspection for tests: float offset of a named activation inside a workspace laid out for n rows
  * ("c1","c2","c3","eh<i>","x<l>","qkv<l>","P<l>","ctx<l>","mid<l>","ff<l>","pooled","hh<i>","out","dout",…); -1 if unknown */
 int64_t v4l_net_ws_offset(const v4l_net* net, int n, const char* name);

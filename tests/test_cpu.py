@@ -1,0 +1,161 @@
+"""CPU suite (`-m "not gpu"`): oracle vs the reference's golden outputs, host logic, C-ABI surface."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+import util
+from oracle import ppo_oracle as orc
+from oracle.gae_c import gae_c
+
+
+@pytest.mark.parametrize("name", list(util.CASES))
+def test_oracle_matches_reference_golden(name):
+    """seeded construction fingerprints + forward + one PPO.update of the oracle vs what the reference produced."""
+    import vision4leg_amd.torchrl.networks as networks
+    import vision4leg_amd.torchrl.policies as policies
+    case = util.CASES[name]
+    gold = util.load_golden("ppo_" + name)
+    torch.manual_seed(case["seed"])
+    pf, vf = util.build_nets(networks, policies, case)
+    for tag, net in (("pf", pf), ("vf", vf)):
+        sd = net.state_dict()
+        assert sorted("init_%s/%s" % (tag, k) for k in sd) == sorted(f for f in gold.files if f.startswith("init_%s/" % tag))
+        for k, v in sd.items():
+            fp = gold["init_%s/%s" % (tag, k)]  # bit-exact where the fixture was minted; last-ulp LAPACK slack elsewhere
+            assert abs(v.double().sum().item() - fp[0]) <= 1e-5 * max(1.0, fp[1]), (tag, k)
+            assert abs(v.double().abs().sum().item() - fp[1]) <= 1e-5 * max(1.0, fp[1]), (tag, k)
+    opf = {k: v.clone() for k, v in pf.state_dict().items()}
+    ovf = util.share_encoder(opf, {k: v.clone() for k, v in vf.state_dict().items()}, case["kind"])
+    b = util.make_batch(case)
+    t = lambda a: torch.tensor(a, dtype=torch.float32)
+    with torch.no_grad():
+        om = orc.FORWARDS[case["kind"]]({k: v for k, v in opf.items() if k != "logstd"}, t(b["obs"]), case["S"])
+        ov = orc.FORWARDS[case["kind"]](ovf, t(b["obs"]), case["S"])
+    assert util.rel_err(om, gold["fwd_mean"]) < 2e-5 and util.rel_err(ov, gold["fwd_value"]) < 2e-5
+    oracle = orc.PPOOracle(case["kind"], opf, ovf, {k: v.clone() for k, v in opf.items()}, case["S"])
+    oracle.sync_target()
+    info = oracle.update(t(b["obs"]), t(b["acts"]), t(b["advs"]), t(b["estimate_returns"]), t(b["values"]), 1e-4, 1e-4)
+    for k, g in zip(util.STAT_KEYS, gold["u0/info"]):
+        assert abs(info[k] - g) <= 2e-4 * max(1.0, abs(g)), (k, info[k], g)
+    for tag, onet in (("pf", opf), ("vf", ovf)):
+        for k, v in onet.items():
+            key = "u0/%s/%s" % (tag, k)
+            if key in gold.files:
+                assert np.abs(v.numpy() - gold[key]).max() <= 2e-5, key
+
+
+def test_bf16_oracle_is_close_to_fp32_oracle():
+    """the rounded flavour stays within the expected bf16 distance of the fp32 one."""
+    import vision4leg_amd.torchrl.networks as networks
+    import vision4leg_amd.torchrl.policies as policies
+    case = util.CASES["loco_s84"]
+    torch.manual_seed(case["seed"])
+    pf, _ = util.build_nets(networks, policies, case)
+    p = {k: v for k, v in pf.state_dict().items() if k != "logstd"}
+    obs = torch.tensor(util.make_batch(case, B=8)["obs"], dtype=torch.float32)
+    with torch.no_grad():
+        a = orc.loco_forward(p, obs, case["S"], "f32")
+        b = orc.loco_forward(p, obs, case["S"], "bf16")
+    e = util.rel_err(b, a)
+    assert 1e-4 < e < 3e-2, e
+
+
+@pytest.mark.parametrize("name", list(util.GAE_CASES))
+def test_gae_oracles_match_reference_golden(name):
+    g = util.GAE_CASES[name]
+    ro = util.make_gae_inputs(g)
+    gold = util.load_golden("gae")
+    oa, orr = orc.gae(ro["rewards"], ro["values"], ro["terminals"], ro["time_limits"], ro["last_value"], g["gamma"],
+                      g["tau"], g["tl_filter"])
+    assert np.array_equal(oa, gold[name + "/advs"]) and np.array_equal(orr, gold[name + "/rets"])
+    T, E = g["T"], g["E"]
+    tl = ro["time_limits"].reshape(T, -1)
+    ca, cr = gae_c(ro["rewards"].reshape(T, E), ro["values"].reshape(T, E), ro["terminals"].reshape(T, E),
+                   tl.reshape(T) if tl.shape[1] == 1 and E > 1 else tl, ro["last_value"], g["gamma"], g["tau"],
+                   g["tl_filter"])
+    assert np.array_equal(ca, oa.reshape(T, E)) and np.array_equal(cr, orr.reshape(T, E))
+
+
+def test_library_exports_every_declared_symbol():
+    """include/v4l_hip.h is the contract: every declared entry point must be exported by the built library and
+    bound by the ctypes layer (no compute calls here: there is no GPU)."""
+    from vision4leg_amd import _lib
+    hdr = open(os.path.join(util.ROOT, "include", "v4l_hip.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = sorted(set(re.findall(r"\b(v4l_[a-z0-9_]+)\s*\(", hdr)))
+    assert declared == _lib.exported_symbols()
+    assert os.path.exists(_lib.LIB_PATH), "build the HIP library first (__graft_entry__.build())"
+    dll = ctypes.CDLL(_lib.LIB_PATH)
+    for name in declared:
+        assert hasattr(dll, name), name
+    assert _lib.lib().v4l_version() >= 100
+
+
+def test_plan_matches_reference_state_dict_names():
+    """host-only part of the C ABI: the plan's parameter table equals the reference state_dict keys/shapes."""
+    import vision4leg_amd.torchrl.networks as networks
+    import vision4leg_amd.torchrl.policies as policies
+    for name, case in util.CASES.items():
+        torch.manual_seed(0)
+        pf, vf = util.build_nets(networks, policies, case)
+        for net in (pf, vf):
+            hip = net.hip
+            sd = net.state_dict()
+            assert sorted(hip.param_names) == sorted(sd.keys()), name
+            for k, shp in zip(hip.param_names, hip.param_shapes):
+                assert tuple(sd[k].shape) == shp, (name, k)
+            assert hip.total_params == sum(v.numel() for v in sd.values())
+    assert pf.hip.total_params == 222988  # state MLP pf, SURVEY.md §8a parameter inventory
+    case = util.CASES["loco_s93"]
+    pf, vf = util.build_nets(networks, policies, case)
+    assert (pf.hip.total_params, vf.hip.total_params) == (388780, 387489)
+
+
+def test_unsupported_configs_fail_loudly():
+    import vision4leg_amd.torchrl.networks as networks
+    import vision4leg_amd.torchrl.policies as policies
+    enc = networks.LocoTransformerEncoder(in_channels=4, state_input_dim=84, hidden_shapes=[256, 256])
+    with pytest.raises(NotImplementedError):
+        networks.LocoTransformer(encoder=enc, output_shape=1, state_input_shape=84, visual_input_shape=(4, 64, 64),
+                                 transformer_params=[[2, 256]], append_hidden_shapes=[256], max_pool=True).hip
+    with pytest.raises(NotImplementedError):
+        policies.GaussianContPolicyBasicBias(input_shape=8, output_shape=2, base_type=networks.MLPBase,
+                                             hidden_shapes=[16], tanh_action=True)
+    with pytest.raises(NotImplementedError):
+        enc(torch.zeros(1, 4, 64, 64), torch.zeros(1, 84))
+    net = networks.Net(input_shape=8, output_shape=2, base_type=networks.MLPBase, hidden_shapes=[16],
+                       append_hidden_shapes=[16])
+    with pytest.raises(RuntimeError):  # CPU tensors never silently fall back
+        net(torch.zeros(3, 8))
+
+
+def test_replay_buffer_iteration_matches_reference_semantics():
+    """one_iteration: batch_size/E time rows per minibatch, all envs of a row together, np.random stream."""
+    from vision4leg_amd.torchrl.replay_buffers import OnPolicyReplayBuffer
+    T, E = 8, 4
+    buf = OnPolicyReplayBuffer(max_replay_buffer_size=T * E, env_nums=E)
+    for t in range(T):
+        buf.add_sample({"obs": np.full((E, 3), t) + np.arange(E)[:, None] * 0.1, "acts": np.full((E, 2), t)})
+    assert buf._obs.shape == (T, E, 3) and buf._obs.dtype == np.float64
+    np.random.seed(0)
+    perm = np.random.permutation(T)
+    np.random.seed(0)
+    batches = list(buf.one_iteration(8, ["obs", "acts"], True))
+    assert len(batches) == 4 and batches[0]["obs"].shape == (8, 3)
+    assert np.array_equal(batches[0]["acts"][:, 0], np.repeat(perm[:2], E))
+    with pytest.raises(AssertionError):
+        list(buf.one_iteration(6, ["obs"], True))
+    assert np.array_equal(buf.last_sample(["acts"])["acts"], np.full((E, 2), T - 1))
+
+
+def test_linear_schedule_and_stat_keys():
+    from vision4leg_amd import _lib
+    from vision4leg_amd.torchrl.algo import utils as atu
+    class Opt: param_groups = [{"lr": 1.0}]
+    atu.update_linear_schedule(Opt, 750, 1500, 1e-4)
+    assert Opt.param_groups[0]["lr"] == 1e-4 - (1e-4 * (750 / 1500.0))
+    assert _lib.STAT_KEYS == util.STAT_KEYS and len(_lib.STAT_KEYS) == 18

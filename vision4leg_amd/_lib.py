@@ -104,6 +104,8 @@ _SIGS = {
                                    C.c_double, C.c_int64, _P, _P]),
   "v4l_trainer_sync_target": (C.c_int, [_P, _P]),
   "v4l_net_ws_offset": (C.c_int64, [_P, C.c_int, C.c_char_p]),
+  "v4l_prof_enable": (C.c_int, [C.c_int]),
+  "v4l_prof_collect": (C.c_int64, [C.c_char_p, C.c_int64]),
 }
 
 _lib = None

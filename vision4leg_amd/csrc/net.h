@@ -27,6 +27,7 @@ struct Lin {         // nn.Linear (or the 1x1 up-conv): y = x W^T + b, W [N][K]
   int64_t pkt = 0;
   int cin = 0, taps = 0;  // > 0: input is an NHWC flatten, packed k = tap*cin + c  (PyTorch k = c*taps + tap)
   bool need_dgrad = true;
+  std::string tag_fwd, tag_wgrad, tag_dgrad;  // profiler labels
 };
 
 struct Conv {        // nn.Conv2d, square kernel, no padding. Activations NHWC, conv1 reads the CHW depth stack.

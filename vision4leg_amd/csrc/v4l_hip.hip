@@ -18,6 +18,43 @@ void set_error(const char* fmt, ...) {
 }
 const char* last_error() { return g_err; }
 
+
+// ------------------------------------------------------------------------------------------ built-in profiler
+// Optional per-launch timing with HIP events on the launch stream (v4l_prof_enable). Off: zero overhead beyond a
+// branch. Records (phase/op label, kernel family, algorithmic FLOPs); v4l_prof_collect aggregates and clears.
+struct ProfRec { std::string label; hipEvent_t e0, e1; double flops; };
+static bool g_prof = false;
+static std::vector<ProfRec> g_recs;
+static thread_local const char* g_phase = "";
+static thread_local const char* g_op = "";
+struct PhaseScope {
+  const char* prev;
+  explicit PhaseScope(const char* p) : prev(g_phase) { g_phase = p; }
+  ~PhaseScope() { g_phase = prev; }
+};
+struct ProfGuard {
+  hipStream_t s;
+  bool on;
+  ProfGuard(const char* kname, double flops, hipStream_t st) : s(st), on(g_prof) {
+    if (!on) return;
+    ProfRec r;
+    r.label = std::string(g_phase) + "|" + g_op + "|" + kname;
+    r.flops = flops;
+    hipEventCreate(&r.e0);
+    hipEventCreate(&r.e1);
+    hipEventRecord(r.e0, s);
+    g_recs.push_back(r);
+  }
+  ~ProfGuard() {
+    if (on) hipEventRecord(g_recs.back().e1, s);
+  }
+};
+#define V4L_KLAUNCH(kname, flops, s, ...)            \
+  do {                                               \
+    v4l::ProfGuard _pg(kname, (double)(flops), s);   \
+    hipLaunchKernelGGL(__VA_ARGS__);                 \
+  } while (0)
+
 // ------------------------------------------------------------------------------------------ launch helpers
 static inline ADense dense(const float* p, int lda, int M, int K, const int* rowidx = nullptr, int tokmap = 0,
                            const float* mask = nullptr) {
@@ -35,16 +72,16 @@ static inline Epi mk_epi(float* C, int ldc, int N, const float* bias = nullptr, 
 
 // C = epi(A * Bp^T): Bp is a packed [Np][Kp] operand (Np % 16 == 0, Kp % 64 == 0)
 template <typename T, class AL>
-static int launch_nt(hipStream_t s, const AL& al, int M, const T* Bp, int Np, int Kp, Epi ep) {
+static int launch_nt(hipStream_t s, const AL& al, int M, const T* Bp, int Np, int Kp, Epi ep, double flops) {
   if (M <= 0) return 0;
   ep.M = M;
   const int gx = cdiv(M, 128);
   if (Np % 64 == 0) {
-    hipLaunchKernelGGL((gemm_nt_kernel<T, 64, AL>), dim3(gx, Np / 64), dim3(256), 0, s, al, Bp, Kp, ep);
+    V4L_KLAUNCH("gemm_nt", flops, s, (gemm_nt_kernel<T, 64, AL>), dim3(gx, Np / 64), dim3(256), 0, s, al, Bp, Kp, ep);
   } else if (Np % 32 == 0) {
-    hipLaunchKernelGGL((gemm_nt_kernel<T, 32, AL>), dim3(gx, Np / 32), dim3(256), 0, s, al, Bp, Kp, ep);
+    V4L_KLAUNCH("gemm_nt", flops, s, (gemm_nt_kernel<T, 32, AL>), dim3(gx, Np / 32), dim3(256), 0, s, al, Bp, Kp, ep);
   } else {
-    hipLaunchKernelGGL((gemm_nt_kernel<T, 16, AL>), dim3(gx, Np / 16), dim3(256), 0, s, al, Bp, Kp, ep);
+    V4L_KLAUNCH("gemm_nt", flops, s, (gemm_nt_kernel<T, 16, AL>), dim3(gx, Np / 16), dim3(256), 0, s, al, Bp, Kp, ep);
   }
   V4L_LAUNCH_CHECK();
   return 0;
@@ -52,7 +89,7 @@ static int launch_nt(hipStream_t s, const AL& al, int M, const T* Bp, int Np, in
 
 // dW[n][k] += sum_m Y(m,n) X(m,k); Kx = logical k extent of X (multiple of 8)
 template <typename T, class YL, class XL>
-static int launch_tn(hipStream_t s, const YL& yl, const XL& xl, int M, int N, int Kx, const WgradOut& out) {
+static int launch_tn(hipStream_t s, const YL& yl, const XL& xl, int M, int N, int Kx, const WgradOut& out, double flops) {
   if (M <= 0) return 0;
   const int gx = cdiv(Kx, 64);
   const int BN = N <= 16 ? 16 : (N <= 32 ? 32 : 64);
@@ -62,9 +99,9 @@ static int launch_tn(hipStream_t s, const YL& yl, const XL& xl, int M, int N, in
   const int mpb = round_up(cdiv(M, splits), 64);
   splits = cdiv(M, mpb);
   const dim3 grid(gx, gy, splits);
-  if (BN == 64) hipLaunchKernelGGL((gemm_tn_kernel<T, 64, YL, XL>), grid, dim3(256), 0, s, yl, xl, M, mpb, out);
-  else if (BN == 32) hipLaunchKernelGGL((gemm_tn_kernel<T, 32, YL, XL>), grid, dim3(256), 0, s, yl, xl, M, mpb, out);
-  else hipLaunchKernelGGL((gemm_tn_kernel<T, 16, YL, XL>), grid, dim3(256), 0, s, yl, xl, M, mpb, out);
+  if (BN == 64) V4L_KLAUNCH("gemm_tn", flops, s, (gemm_tn_kernel<T, 64, YL, XL>), grid, dim3(256), 0, s, yl, xl, M, mpb, out);
+  else if (BN == 32) V4L_KLAUNCH("gemm_tn", flops, s, (gemm_tn_kernel<T, 32, YL, XL>), grid, dim3(256), 0, s, yl, xl, M, mpb, out);
+  else V4L_KLAUNCH("gemm_tn", flops, s, (gemm_tn_kernel<T, 16, YL, XL>), grid, dim3(256), 0, s, yl, xl, M, mpb, out);
   V4L_LAUNCH_CHECK();
   return 0;
 }
@@ -80,7 +117,8 @@ struct Ctx {  // per-call view of a bound net
 template <typename T>
 static int lin_fwd(const Ctx& c, const Lin& L, const ADense& a, Epi ep) {
   ep.bias = c.net->p[L.b];
-  return launch_nt<T>(c.s, a, a.M, (const T*)c.net->packed + L.pk, L.Np, L.Kp, ep);
+  g_op = L.tag_fwd.c_str();
+  return launch_nt<T>(c.s, a, a.M, (const T*)c.net->packed + L.pk, L.Np, L.Kp, ep, 2.0 * a.M * L.N * L.K);
 }
 template <typename T, class XL>
 static int lin_wgrad(const Ctx& c, const Lin& L, const ADense& y, const XL& x, int Kx) {
@@ -88,12 +126,14 @@ static int lin_wgrad(const Ctx& c, const Lin& L, const ADense& y, const XL& x, i
   o.dW = c.grads + c.net->params[L.w].goff;
   o.dbias = c.grads + c.net->params[L.b].goff;
   o.N = L.N; o.K = L.K; o.Ktorch = L.K; o.Cin = L.cin; o.taps = L.taps;
-  return launch_tn<T>(c.s, y, x, y.M, L.N, Kx, o);
+  g_op = L.tag_wgrad.c_str();
+  return launch_tn<T>(c.s, y, x, y.M, L.N, Kx, o, 2.0 * y.M * L.N * L.K);
 }
 template <typename T>
 static int lin_dgrad(const Ctx& c, const Lin& L, const ADense& y, Epi ep) {
   ep.N = L.K;
-  return launch_nt<T>(c.s, y, y.M, (const T*)c.net->packed + L.pkt, L.Rt, L.Ct, ep);
+  g_op = L.tag_dgrad.c_str();
+  return launch_nt<T>(c.s, y, y.M, (const T*)c.net->packed + L.pkt, L.Rt, L.Ct, ep, 2.0 * y.M * L.N * L.K);
 }
 
 // forward through Linear(+ReLU) layers; outs[i] receives layer i's output
@@ -155,7 +195,8 @@ static int conv_stack_fwd(const Ctx& c, const T* image, const int* rowidx, int n
   {
     Epi ep = mk_epi(c1, cv[0].Cout, cv[0].Cout, N->p[cv[0].b], 1);
     auto al = chw_loader<T>(image, cv[0], n, rowidx);
-    rc = launch_nt<T>(c.s, al, al.M, (const T*)N->packed + cv[0].pk, cv[0].Np, cv[0].Kp, ep);
+    g_op = "conv1.fwd";
+    rc = launch_nt<T>(c.s, al, al.M, (const T*)N->packed + cv[0].pk, cv[0].Np, cv[0].Kp, ep, 2.0 * al.M * cv[0].Cout * cv[0].K);
     if (rc) return rc;
   }
   float* ins[3] = {nullptr, c1, c2};
@@ -163,7 +204,8 @@ static int conv_stack_fwd(const Ctx& c, const T* image, const int* rowidx, int n
   for (int i = 1; i < 3; ++i) {
     Epi ep = mk_epi(outs[i], cv[i].Cout, cv[i].Cout, N->p[cv[i].b], 1);
     auto al = nhwc_loader(ins[i], cv[i], n);
-    rc = launch_nt<T>(c.s, al, al.M, (const T*)N->packed + cv[i].pk, cv[i].Np, cv[i].Kp, ep);
+    g_op = i == 1 ? "conv2.fwd" : "conv3.fwd";
+    rc = launch_nt<T>(c.s, al, al.M, (const T*)N->packed + cv[i].pk, cv[i].Np, cv[i].Kp, ep, 2.0 * al.M * cv[i].Cout * cv[i].K);
     if (rc) return rc;
   }
   return 0;
@@ -189,11 +231,13 @@ static int conv_stack_bwd(const Ctx& c, const T* image, const int* rowidx, int n
     if (v.chw) {
       o.Cin = 0; o.taps = 0;
       auto x = chw_loader<T>(image, v, n, rowidx);
-      rc = launch_tn<T>(c.s, y, x, M, v.Cout, v.K, o);
+      g_op = "conv1.wgrad";
+      rc = launch_tn<T>(c.s, y, x, M, v.Cout, v.K, o, 2.0 * M * v.Cout * v.K);
     } else {
       o.Cin = v.Cin; o.taps = v.KH * v.KH;
       auto x = nhwc_loader(acts[i], v, n);
-      rc = launch_tn<T>(c.s, y, x, M, v.Cout, v.K, o);
+      g_op = i == 1 ? "conv2.wgrad" : "conv3.wgrad";
+      rc = launch_tn<T>(c.s, y, x, M, v.Cout, v.K, o, 2.0 * M * v.Cout * v.K);
     }
     if (rc) return rc;
     if (i == 0) break;
@@ -209,7 +253,8 @@ static int conv_stack_bwd(const Ctx& c, const T* image, const int* rowidx, int n
       ep.rowmap = ROWMAP_DGRAD;
       ep.py = py; ep.px = px; ep.s = st; ep.nIy = a.nIy; ep.nIx = a.nIx; ep.IH = v.IH; ep.IW = v.IH;
       ep.mask = acts[i]; ep.ldmask = v.Cin;
-      rc = launch_nt<T>(c.s, a, a.M, (const T*)N->packed + v.pkd[cls], v.Rd, v.Kdp, ep);
+      g_op = i == 1 ? "conv2.dgrad" : "conv3.dgrad";
+      rc = launch_nt<T>(c.s, a, a.M, (const T*)N->packed + v.pkd[cls], v.Rd, v.Kdp, ep, 2.0 * M * v.Cout * v.K / v.ncls);
       if (rc) return rc;
     }
   }
@@ -263,6 +308,10 @@ int v4l_net::build() {
     else L.w = add_param(wname, {N, K});
     L.b = add_param(bname, {N});
     L.N = N; L.K = K; L.need_dgrad = need_dgrad;
+    std::string t = wname;
+    const size_t cut = t.rfind('.');
+    if (cut != std::string::npos) t = t.substr(0, cut);
+    L.tag_fwd = t + ".fwd"; L.tag_wgrad = t + ".wgrad"; L.tag_dgrad = t + ".dgrad";
     return L;
   };
   auto make_mlp = [&](const std::string& prefix, int in_dim, const int* widths, int nw, bool first_needs_dgrad,
@@ -487,19 +536,23 @@ int v4l_net::forward_t(const float* state, const T* image, const int* rowidx, in
       const LayerWs& w = L.lw[l];
       float* xin = ws + L.x[l];
       if ((rc = lin_fwd<T>(cx, t.inproj, dense(xin, TD, R, TD), mk_epi(ws + w.qkv, 3 * TD, 3 * TD)))) return rc;
-      hipLaunchKernelGGL(attn_fwd_kernel, dim3(cdiv(n, 4)), dim3(256), 0, s, ws + w.qkv, n, ws + w.P, ws + w.ctx);
+      g_op = "attn";
+      V4L_KLAUNCH("attn_fwd", 4.0 * n * NTOK * NTOK * TD, s, attn_fwd_kernel, dim3(cdiv(n, 4)), dim3(256), 0, s, ws + w.qkv, n, ws + w.P, ws + w.ctx);
       V4L_LAUNCH_CHECK();
       if ((rc = lin_fwd<T>(cx, t.outproj, dense(ws + w.ctx, TD, R, TD), mk_epi(ws + L.ytmp, TD, TD)))) return rc;
-      hipLaunchKernelGGL(add_ln_fwd_kernel, dim3(cdiv(R, 4)), dim3(256), 0, s, xin, ws + L.ytmp, R, p[t.ln1.g], p[t.ln1.b],
+      g_op = "ln1";
+      V4L_KLAUNCH("add_ln_fwd", 0, s, add_ln_fwd_kernel, dim3(cdiv(R, 4)), dim3(256), 0, s, xin, ws + L.ytmp, R, p[t.ln1.g], p[t.ln1.b],
                          ws + w.x1, ws + w.xh1, ws + w.rs1);
       V4L_LAUNCH_CHECK();
       if ((rc = lin_fwd<T>(cx, t.ff1, dense(ws + w.x1, TD, R, TD), mk_epi(ws + w.f, c.ff_dim, c.ff_dim, nullptr, 1)))) return rc;
       if ((rc = lin_fwd<T>(cx, t.ff2, dense(ws + w.f, c.ff_dim, R, c.ff_dim), mk_epi(ws + L.ytmp, TD, TD)))) return rc;
-      hipLaunchKernelGGL(add_ln_fwd_kernel, dim3(cdiv(R, 4)), dim3(256), 0, s, ws + w.x1, ws + L.ytmp, R, p[t.ln2.g],
+      g_op = "ln2";
+      V4L_KLAUNCH("add_ln_fwd", 0, s, add_ln_fwd_kernel, dim3(cdiv(R, 4)), dim3(256), 0, s, ws + w.x1, ws + L.ytmp, R, p[t.ln2.g],
                          p[t.ln2.b], ws + L.x[l + 1], ws + w.xh2, ws + w.rs2);
       V4L_LAUNCH_CHECK();
     }
-    hipLaunchKernelGGL(pool_fwd_kernel, dim3(n), dim3(128), 0, s, ws + L.x[c.n_layers], n, ws + L.pooled);
+    g_op = "pool";
+    V4L_KLAUNCH("pool_fwd", 0, s, pool_fwd_kernel, dim3(n), dim3(128), 0, s, ws + L.x[c.n_layers], n, ws + L.pooled);
     V4L_LAUNCH_CHECK();
     head_in = dense(ws + L.pooled, 2 * TD, n, 2 * TD);
   }
@@ -569,13 +622,15 @@ int v4l_net::backward_t(const float* state, const T* image, const int* rowidx, i
       return rc;
   }
   float* dx = ws + L.dxa;
-  hipLaunchKernelGGL(pool_bwd_kernel, dim3(n), dim3(64), 0, s, ws + L.dpool, n, dx);
+  g_op = "pool";
+  V4L_KLAUNCH("pool_bwd", 0, s, pool_bwd_kernel, dim3(n), dim3(64), 0, s, ws + L.dpool, n, dx);
   V4L_LAUNCH_CHECK();
   const int lnb = std::min(cdiv(R, 4), 1024);
   for (int l = c.n_layers - 1; l >= 0; --l) {
     const TLayer& t = layers[l];
     const LayerWs& w = L.lw[l];
-    hipLaunchKernelGGL(ln_bwd_kernel, dim3(lnb), dim3(256), 0, s, dx, ws + w.xh2, ws + w.rs2, p[t.ln2.g], R, dx,
+    g_op = "ln2";
+    V4L_KLAUNCH("ln_bwd", 0, s, ln_bwd_kernel, dim3(lnb), dim3(256), 0, s, dx, ws + w.xh2, ws + w.rs2, p[t.ln2.g], R, dx,
                        grads + params[t.ln2.g].goff, grads + params[t.ln2.b].goff);
     V4L_LAUNCH_CHECK();
     {  // linear2 / linear1 (FFN), residual: d(x1) = dz2 + W1^T-path
@@ -591,14 +646,16 @@ int v4l_net::backward_t(const float* state, const T* image, const int* rowidx, i
       ea.accumulate = 1;
       if ((rc = lin_dgrad<T>(cx, t.ff1, yf, ea))) return rc;
     }
-    hipLaunchKernelGGL(ln_bwd_kernel, dim3(lnb), dim3(256), 0, s, dx, ws + w.xh1, ws + w.rs1, p[t.ln1.g], R, dx,
+    g_op = "ln1";
+    V4L_KLAUNCH("ln_bwd", 0, s, ln_bwd_kernel, dim3(lnb), dim3(256), 0, s, dx, ws + w.xh1, ws + w.rs1, p[t.ln1.g], R, dx,
                        grads + params[t.ln1.g].goff, grads + params[t.ln1.b].goff);
     V4L_LAUNCH_CHECK();
     {  // self-attention block, residual: d(x_in) = dz1 + in_proj^T-path
       ADense y = dense(dx, TD, R, TD);
       if ((rc = lin_wgrad<T>(cx, t.outproj, y, dense(ws + w.ctx, TD, R, TD), TD))) return rc;
       if ((rc = lin_dgrad<T>(cx, t.outproj, y, mk_epi(ws + L.dctx, TD, TD)))) return rc;
-      hipLaunchKernelGGL(attn_bwd_kernel, dim3(cdiv(n, 2)), dim3(128), 0, s, ws + w.qkv, ws + w.P, ws + L.dctx, n,
+      g_op = "attn";
+      V4L_KLAUNCH("attn_bwd", 8.0 * n * NTOK * NTOK * TD, s, attn_bwd_kernel, dim3(cdiv(n, 2)), dim3(128), 0, s, ws + w.qkv, ws + w.P, ws + L.dctx, n,
                          ws + L.dqkv);
       V4L_LAUNCH_CHECK();
       ADense yq = dense(ws + L.dqkv, 3 * TD, R, 3 * TD);
@@ -735,10 +792,10 @@ int v4l_net_pack(v4l_net* net, void* stream) {
   V4L_REQUIRE(net && net->bound, "v4l_net_pack: net is not bound");
   hipStream_t s = (hipStream_t)stream;
   if (net->cfg.compute == V4L_BF16)
-    hipLaunchKernelGGL(pack_kernel<__bf16>, dim3((unsigned)net->pack_blocks), dim3(256), 0, s, net->d_packs,
+    V4L_KLAUNCH("pack", 0, s, pack_kernel<__bf16>, dim3((unsigned)net->pack_blocks), dim3(256), 0, s, net->d_packs,
                        (int)net->packs.size(), (__bf16*)net->packed);
   else
-    hipLaunchKernelGGL(pack_kernel<float>, dim3((unsigned)net->pack_blocks), dim3(256), 0, s, net->d_packs,
+    V4L_KLAUNCH("pack", 0, s, pack_kernel<float>, dim3((unsigned)net->pack_blocks), dim3(256), 0, s, net->d_packs,
                        (int)net->packs.size(), (float*)net->packed);
   V4L_LAUNCH_CHECK();
   return 0;
@@ -820,6 +877,44 @@ int v4l_gae(const double* rewards_dev, const double* values_dev, const double* t
   return 0;
 }
 
+
+int v4l_prof_enable(int on) {
+  g_prof = on != 0;
+  return 0;
+}
+/* Writes one line per (phase|op|kernel): "label\tcalls\ttotal_us\tflops\n", clears the records. Synchronises. */
+int64_t v4l_prof_collect(char* buf, int64_t cap) {
+  if (hipDeviceSynchronize() != hipSuccess) return -2;
+  struct Agg { int64_t calls = 0; double us = 0, flops = 0; };
+  std::vector<std::pair<std::string, Agg>> agg;
+  for (ProfRec& r : g_recs) {
+    float ms = 0.f;
+    hipEventElapsedTime(&ms, r.e0, r.e1);
+    hipEventDestroy(r.e0);
+    hipEventDestroy(r.e1);
+    size_t i = 0;
+    for (; i < agg.size(); ++i) if (agg[i].first == r.label) break;
+    if (i == agg.size()) agg.push_back({r.label, Agg()});
+    agg[i].second.calls += 1;
+    agg[i].second.us += ms * 1000.0;
+    agg[i].second.flops += r.flops;
+  }
+  g_recs.clear();
+  std::string out;
+  char line[512];
+  for (auto& kv : agg) {
+    snprintf(line, sizeof(line), "%s\t%lld\t%.3f\t%.6e\n", kv.first.c_str(), (long long)kv.second.calls, kv.second.us,
+             kv.second.flops);
+    out += line;
+  }
+  if (buf && cap > 0) {
+    const int64_t n = std::min<int64_t>(cap - 1, (int64_t)out.size());
+    memcpy(buf, out.data(), n);
+    buf[n] = 0;
+  }
+  return (int64_t)out.size();
+}
+
 // ------------------------------------------------------------------------------------------ trainer
 int v4l_trainer_create(v4l_net* pf, v4l_net* vf, v4l_net* target_pf, v4l_trainer** out) {
   V4L_REQUIRE(pf && vf && target_pf && out, "v4l_trainer_create: null argument");
@@ -872,15 +967,17 @@ int v4l_trainer_critic_grads(v4l_trainer* tr, const v4l_rollout* ro, const int* 
   v4l_net* vf = tr->vf;
   V4L_HIP_CHECK(hipMemsetAsync(st, 0, V4L_STATS * sizeof(float), s));
   V4L_HIP_CHECK(hipMemsetAsync(tr->g_vf, 0, (size_t)vf->total_params * sizeof(float), s));
-  hipLaunchKernelGGL(adv_stats_kernel, dim3(1), dim3(256), 0, s, ro->advs_dev, rowidx_dev, n, st);
+  V4L_KLAUNCH("adv_stats", 0, s, adv_stats_kernel, dim3(1), dim3(256), 0, s, ro->advs_dev, rowidx_dev, n, st);
   V4L_LAUNCH_CHECK();
   if ((rc = v4l_net_pack(vf, stream))) return rc;
-  if ((rc = v4l_net_forward(vf, ro->state_dev, ro->image_dev, rowidx_dev, n, tr->ws, 1, stream))) return rc;
+  { PhaseScope ps("vf.fwd");
+  if ((rc = v4l_net_forward(vf, ro->state_dev, ro->image_dev, rowidx_dev, n, tr->ws, 1, stream))) return rc; }
   const Layout L = vf->layout(n);
   const float inv_n = 1.f / ((float)n * (float)hp->world_size);
-  hipLaunchKernelGGL(critic_loss_kernel, dim3(1), dim3(256), 0, s, tr->ws + L.out, ro->rets_dev, ro->values_dev,
+  V4L_KLAUNCH("critic_loss", 0, s, critic_loss_kernel, dim3(1), dim3(256), 0, s, tr->ws + L.out, ro->rets_dev, ro->values_dev,
                      rowidx_dev, n, inv_n, hp->clipped_value_loss, hp->clip_para, tr->ws + L.dout, st);
   V4L_LAUNCH_CHECK();
+  PhaseScope ps("vf.bwd");
   return v4l_net_backward(vf, ro->state_dev, ro->image_dev, rowidx_dev, n, tr->ws, tr->g_vf, stream);
 }
 
@@ -888,14 +985,14 @@ static int adam_step(v4l_net* net, float* g, float* m, float* v, const v4l_ppo_h
                      float* sumsq, float* norm_out, hipStream_t s) {
   V4L_REQUIRE(step >= 1, "v4l_trainer: Adam step count starts at 1");
   const int gb = (int)std::min<int64_t>(1024, cdiv64(net->total_params, 256));
-  hipLaunchKernelGGL(grad_sumsq_kernel, dim3(gb), dim3(256), 0, s, g, net->total_params, sumsq);
+  V4L_KLAUNCH("grad_sumsq", 0, s, grad_sumsq_kernel, dim3(gb), dim3(256), 0, s, g, net->total_params, sumsq);
   V4L_LAUNCH_CHECK();
   // scalar prep in double, like torch/optim/adam.py::_single_tensor_adam
   const double bc1 = 1.0 - pow((double)hp->beta1, (double)step);
   const double bc2 = 1.0 - pow((double)hp->beta2, (double)step);
   const float step_size = (float)(lr / bc1);
   const float bc2_sqrt = (float)sqrt(bc2);
-  hipLaunchKernelGGL(clip_adam_kernel, dim3((unsigned)net->seg_blocks), dim3(256), 0, s, net->d_segs,
+  V4L_KLAUNCH("clip_adam", 0, s, clip_adam_kernel, dim3((unsigned)net->seg_blocks), dim3(256), 0, s, net->d_segs,
                      (int)net->params.size(), g, m, v, sumsq, 1.f, hp->max_grad_norm, hp->beta1, hp->beta2, hp->eps,
                      step_size, bc2_sqrt, norm_out);
   V4L_LAUNCH_CHECK();
@@ -921,14 +1018,17 @@ int v4l_trainer_actor_grads(v4l_trainer* tr, const v4l_rollout* ro, const int* r
   const Layout Lp = pf->layout(n), Lt = tp->layout(n);
   float* ws_t = tr->ws + std::max(Lp.total, tr->vf->layout(n).total);
   // frozen target policy: packed once per epoch by v4l_trainer_sync_target
-  if ((rc = v4l_net_forward(tp, ro->state_dev, ro->image_dev, rowidx_dev, n, ws_t, 0, stream))) return rc;
+  { PhaseScope ps("tpf.fwd");
+  if ((rc = v4l_net_forward(tp, ro->state_dev, ro->image_dev, rowidx_dev, n, ws_t, 0, stream))) return rc; }
   if ((rc = v4l_net_pack(pf, stream))) return rc;  // the critic step moved the shared encoder
-  if ((rc = v4l_net_forward(pf, ro->state_dev, ro->image_dev, rowidx_dev, n, tr->ws, 1, stream))) return rc;
+  { PhaseScope ps("pf.fwd");
+  if ((rc = v4l_net_forward(pf, ro->state_dev, ro->image_dev, rowidx_dev, n, tr->ws, 1, stream))) return rc; }
   const float inv_n = 1.f / ((float)n * (float)hp->world_size);
-  hipLaunchKernelGGL(actor_loss_kernel, dim3(1), dim3(256), 0, s, tr->ws + Lp.out, pf->p[pf->logstd], ws_t + Lt.out,
+  V4L_KLAUNCH("actor_loss", 0, s, actor_loss_kernel, dim3(1), dim3(256), 0, s, tr->ws + Lp.out, pf->p[pf->logstd], ws_t + Lt.out,
                      tp->p[tp->logstd], ro->acts_dev, ro->advs_dev, rowidx_dev, n, pf->cfg.out_dim, inv_n, hp->clip_para,
                      hp->entropy_coeff, tr->ws + Lp.dout, tr->g_pf + pf->params[pf->logstd].goff, st);
   V4L_LAUNCH_CHECK();
+  PhaseScope ps("pf.bwd");
   return v4l_net_backward(pf, ro->state_dev, ro->image_dev, rowidx_dev, n, tr->ws, tr->g_pf, stream);
 }
 
