@@ -135,8 +135,7 @@ class Epoch:
                 idx.append((sel[:, None] * E + np.arange(E)[None, :]).reshape(-1))
         rowidx = torch.from_numpy(np.stack(idx).astype(np.int32)).to(self.dev)
         ro = HipTrainer.rollout(self.state, self.image, self.acts, a32.reshape(-1), r32.reshape(-1), self.values)
-        for i in range(rowidx.shape[0]):
-            ag._update_rows(ro, rowidx[i], B, self.stats[i])
+        ag.run_updates(ro, rowidx, self.stats)
         self.epoch += 1
 
     def step(self, with_rollout=True):
@@ -152,8 +151,7 @@ def cpu_baseline(wl, compute):
     from oracle import ppo_oracle as orc
     import vision4leg_amd.torchrl.networks as networks
     import vision4leg_amd.torchrl.policies as policies
-    cores = os.cpu_count() or 1
-    torch.set_num_threads(cores)
+    ncpu = os.cpu_count() or 1
     case = dict(wl, seed=0)
     torch.manual_seed(0)
     pf, vf = util.build_nets(networks, policies, case)
@@ -166,6 +164,20 @@ def cpu_baseline(wl, compute):
     b = util.make_batch(case, B=B)
     args = (t(b["obs"]), t(b["acts"]), t(b["advs"]), t(b["estimate_returns"]), t(b["values"]), 1e-4, 1e-4)
     oracle.update(*args)  # warm-up
+    # torch's intra-op pool thrashes with hundreds of threads on these layer sizes: pick the best of a few widths
+    best = None
+    for th in sorted({min(ncpu, c) for c in (8, 16, 32, 64)}):
+        torch.set_num_threads(th)
+        oracle.update(*args)
+        t0 = time.perf_counter()
+        oracle.update(*args)
+        dt = time.perf_counter() - t0
+        if best is None or dt < best[1]:
+            best = (th, dt)
+        if dt > 30:
+            break
+    cores = best[0]
+    torch.set_num_threads(cores)
     n_upd = 2
     t0 = time.perf_counter()
     for _ in range(n_upd):
@@ -190,7 +202,7 @@ def cpu_baseline(wl, compute):
     return {
         "value": round(E * T / t_epoch, 2), "unit": "env-steps/s", "cores": cores, "kind": "port",
         "sample": "%d minibatch updates (B=%d) + %d rollout step pairs (pf+vf fwd, E=%d) + 1 GAE [%dx%d] of the same "
-                  "workload, fp32 torch-CPU oracle with %d threads, extrapolated to one epoch (%d updates, %d steps)"
+                  "workload, fp32 torch-CPU oracle with %d threads (best of 8/16/32/64 on this host), extrapolated to one epoch (%d updates, %d steps)"
                   % (n_upd, B, n_inf, E, T, E, cores, n_mb, T),
         "update_only_value": round(E * T / (n_mb * t_upd), 2),
         "s_per_update": round(t_upd, 4), "s_per_rollout_step": round(t_inf, 5), "s_gae": round(t_gae, 4),

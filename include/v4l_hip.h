@@ -113,8 +113,8 @@ int v4l_col0(const float* src_dev, int n, float* dst_dev, void* stream);
  * ppo.py:138,140. */
 int v4l_gae(const double* rewards_dev, const double* values_dev, const double* terminals_dev,
             const double* time_limits_dev, int tl_per_env, const double* last_value_dev, int T, int E, double gamma,
-            double tau, int use_time_limit, double* advs_dev, double* rets_dev, float* advs32_dev, float* rets32_dev,
-            void* stream);
+            double tau, int use_time_limit, double* scratch_dev /* 3*T*E doubles */, double* advs_dev, double* rets_dev,
+            float* advs32_dev, float* rets32_dev, void* stream);
 
 /* ---- PPO minibatch update: replaces PPO.update / update_critic / update_actor (ppo.py:42-153), the two
  * clip_grad_norm_(…, 0.5) calls and the two Adam steps (a2c.py:30-40). pf and vf may share encoder parameters
@@ -141,20 +141,32 @@ typedef struct v4l_rollout {
 int v4l_trainer_create(v4l_net* pf, v4l_net* vf, v4l_net* target_pf, v4l_trainer** out);
 void v4l_trainer_destroy(v4l_trainer* tr);
 int64_t v4l_trainer_ws_floats(const v4l_trainer* tr, int n);
-/* grads/moments: flat fp32 buffers of v4l_net_total_params(pf|vf) floats each (moments zero-initialised by
- * the caller == fresh torch.optim.Adam state). stats_dev: V4L_STATS floats per update. */
+int64_t v4l_trainer_ctl_bytes(const v4l_trainer* tr, int n); /* device control block + per-update staging */
+/* grads/moments: flat fp32 buffers of v4l_net_total_params(pf|vf) floats each (moments zero-initialised by the
+ * caller == fresh torch.optim.Adam state). ctl_dev: v4l_trainer_ctl_bytes(n_max) bytes. Re-binding drops the graph. */
 int v4l_trainer_bind(v4l_trainer* tr, float* g_pf_dev, float* m_pf_dev, float* v_pf_dev, float* g_vf_dev,
-                     float* m_vf_dev, float* v_vf_dev, float* ws_dev, int64_t ws_floats, void* stream);
-/* Phases of one minibatch update. Single GPU: call v4l_trainer_update. Data parallel: critic_grads →
- * all-reduce(g_vf ‖ stats[18..20]) → critic_step → actor_grads → all-reduce(g_pf) → actor_step. */
-int v4l_trainer_critic_grads(v4l_trainer* tr, const v4l_rollout* ro, const int* rowidx_dev, int n,
-                             const v4l_ppo_hyper* hp, float* stats_dev, void* stream);
-int v4l_trainer_critic_step(v4l_trainer* tr, const v4l_ppo_hyper* hp, double lr, int64_t step, float* stats_dev,
+                     float* m_vf_dev, float* v_vf_dev, float* ws_dev, int64_t ws_floats, void* ctl_dev, int n_max,
+                     void* stream);
+/* Opens a run of updates (normally: one epoch = opt_epochs x minibatches): update #u will train on rows
+ * rowidx_all_dev[u][0..n) (NULL = rows 0..n-1 every time) and write its V4L_STATS-float record to
+ * stats_all_dev[u] (may be NULL). steps_done = Adam steps already taken (0 for fresh optimisers); lr_* are the
+ * learning rates of update_linear_schedule (algo/utils.py:28-32). The update index, the Adam step count and the
+ * bias corrections then live on the device and advance by themselves, one per update. */
+int v4l_trainer_begin(v4l_trainer* tr, const int* rowidx_all_dev, float* stats_all_dev, double lr_pf, double lr_vf,
+                      int64_t steps_done, const v4l_ppo_hyper* hp, void* stream);
+/* The next minibatch update, == PPO.update (ppo.py:125-153). use_graph=1: the launch sequence (~500 kernels) is
+ * captured once per (rollout pointers, n, hyper-parameters) as a hipGraph and replayed; needs a non-default stream.
+ * The first update of a configuration always runs eagerly. */
+int v4l_trainer_update_next(v4l_trainer* tr, const v4l_rollout* ro, int n, const v4l_ppo_hyper* hp, int use_graph,
                             void* stream);
-int v4l_trainer_actor_grads(v4l_trainer* tr, const v4l_rollout* ro, const int* rowidx_dev, int n,
-                            const v4l_ppo_hyper* hp, float* stats_dev, void* stream);
-int v4l_trainer_actor_step(v4l_trainer* tr, const v4l_ppo_hyper* hp, double lr, int64_t step, float* stats_dev,
-                           void* stream);
+/* Phases of the same update for the data-parallel schedule: critic_grads -> all-reduce(g_vf || stats[18..20]) ->
+ * critic_step -> actor_grads -> all-reduce(g_pf) -> actor_step. v4l_trainer_stats_cur = the record being filled. */
+int v4l_trainer_critic_grads(v4l_trainer* tr, const v4l_rollout* ro, int n, const v4l_ppo_hyper* hp, void* stream);
+int v4l_trainer_critic_step(v4l_trainer* tr, const v4l_ppo_hyper* hp, void* stream);
+int v4l_trainer_actor_grads(v4l_trainer* tr, const v4l_rollout* ro, int n, const v4l_ppo_hyper* hp, void* stream);
+int v4l_trainer_actor_step(v4l_trainer* tr, const v4l_ppo_hyper* hp, void* stream);
+float* v4l_trainer_stats_cur(const v4l_trainer* tr);
+/* Convenience: begin(rowidx_dev as the only row, stats_dev, lr, step-1) + one eager update_next. step >= 1. */
 int v4l_trainer_update(v4l_trainer* tr, const v4l_rollout* ro, const int* rowidx_dev, int n, const v4l_ppo_hyper* hp,
                        double lr_pf, double lr_vf, int64_t step, float* stats_dev, void* stream);
 /* copy_model_params_from_to(pf, target_pf) (torchrl/algo/utils.py:23-25, ppo.py:34) + repack of the target */

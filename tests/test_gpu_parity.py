@@ -91,7 +91,7 @@ def test_forward(name, mode, device):
             fv = util.rel_err(ov, fn(ovf, obs, case["S"], "f32"))
         print("   bf16 envelope: oracle self-noise mean %.2e value %.2e | bf16-oracle vs fp32: mean %.2e value %.2e"
               % (nm, nv, fm, fv))
-        assert em < max(1e-3, 3 * nm) and ev < max(1e-3, 3 * nv)
+        assert em < max(2e-3, 5 * nm, fm) and ev < max(2e-3, 5 * nv, fv)
         assert gm < max(2e-3, 2.5 * fm) and gv < max(2e-3, 2.5 * fv)
     assert torch.allclose(std.cpu(), torch.exp(opf["logstd"]).expand_as(om))
     assert tuple(mean.shape) == (case["B"], case["A"]) and tuple(value.shape) == (case["B"], 1)
@@ -300,3 +300,58 @@ def test_gae_full_size_properties(device):
         t0, e0 = tt[0], ee[0]
         expect = (r[t0, e0] + 0.0 - v[t0, e0]) * (1.0 - tl[t0, e0])
         assert a.cpu().numpy()[t0, e0] == expect
+
+
+@pytest.mark.parametrize("mode", MODES)
+def test_graph_replay_equals_eager(mode, device):
+    """run_updates over a device-resident rollout: hipGraph replay (device-side update index / Adam step) must give
+    what the eager launch sequence gives — same kernels, only fp32-atomic ordering noise in LN/bias/norm sums —
+    and both must track the oracle."""
+    from vision4leg_amd.engine import HipTrainer
+    from vision4leg_amd.torchrl.algo import PPO
+    case = dict(util.CASES["loco_s84"], B=32)
+    T, E, B = 8, 8, 32
+    rs = np.random.RandomState(7)
+    obs = np.concatenate([np.clip(rs.randn(T * E, case["S"]), -10, 10), np.clip(rs.randn(T * E, 4 * 64 * 64), -2.5, 2.8)], 1)
+    acts, advs, rets = 0.1 * rs.randn(T * E, case["A"]), rs.randn(T * E), rs.randn(T * E)
+    rows = np.stack([rs.permutation(T * E)[:B] for _ in range(5)]).astype(np.int32)
+    results = []
+    for graph in (False, True):
+        pf, vf = _build(case, mode, device)
+
+        class Coll: epoch_frames = T * E
+        agent = PPO(pf=pf, vf=vf, plr=1e-4, vlr=1e-4, clip_para=0.2, opt_epochs=3, tau=0.95, entropy_coeff=0.005,
+                    collector=Coll(), device=device, batch_size=B)
+        agent.use_graph = graph
+        net = pf.hip
+        net.ensure_bound()
+        state, image = net.alloc_rollout(T * E, device)
+        t = lambda a: torch.tensor(a, dtype=torch.float32, device=device)
+        net.ingest(t(obs), state, image)
+        ro = HipTrainer.rollout(state, image, t(acts), t(advs), t(rets), t(rets))
+        stats = torch.zeros(len(rows), 24, device=device)
+        agent.trainer.sync_target()
+        agent.run_updates(ro, torch.tensor(rows, device=device), stats)
+        torch.cuda.synchronize()
+        results.append(({k: v.detach().cpu().clone() for k, v in pf.state_dict().items()},
+                        {k: v.detach().cpu().clone() for k, v in vf.state_dict().items()}, stats.cpu().numpy()))
+        assert agent.trainer.step == len(rows) and agent.training_update_num == len(rows)
+    (pe, ve, se), (pg, vg, sg) = results
+    assert np.allclose(se[:, :18], sg[:, :18], rtol=2e-4, atol=2e-5), np.abs(se[:, :18] - sg[:, :18]).max()
+    worst = max(max((pe[k] - pg[k]).abs().max().item() for k in pe), max((ve[k] - vg[k]).abs().max().item() for k in ve))
+    print("\n[graph vs eager %s] worst param diff %.2e; ratio max per update %s" % (mode, worst, sg[:, 15]))
+    assert worst <= (5e-6 if mode == "f32" else 2.2e-4)
+    assert (sg[1:, 15] != 1.0).all()  # later updates really saw moved parameters (ratio/max != 1)
+    # oracle on the same five minibatches (f32 only: tight)
+    if mode == "f32":
+        pf, vf = _build(case, mode, device)
+        opf, ovf = _oracle_params(pf, vf, "loco")
+        oracle = orc.PPOOracle("loco", opf, ovf, {k: v.clone() for k, v in opf.items()}, case["S"], mode)
+        oracle.sync_target()
+        c = lambda a: torch.tensor(a, dtype=torch.float32)
+        for u, r in enumerate(rows):
+            info = oracle.update(c(obs[r]), c(acts[r]), c(advs[r]).view(-1, 1), c(rets[r]).view(-1, 1), c(rets[r]).view(-1, 1),
+                                 1e-4, 1e-4)
+            for j, k in enumerate(util.STAT_KEYS):
+                assert abs(sg[u, j] - info[k]) <= 1e-3 * max(1.0, abs(info[k])), (u, k, sg[u, j], info[k])
+        assert max((pg[k] - opf[k]).abs().max().item() for k in pg) <= 3e-5

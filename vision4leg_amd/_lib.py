@@ -91,15 +91,19 @@ _SIGS = {
   "v4l_gauss_head": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, _P, _P, _P, _P, _P, _P]),
   "v4l_col0": (C.c_int, [_P, C.c_int, _P, _P]),
   "v4l_gae": (C.c_int, [_P, _P, _P, _P, C.c_int, _P, C.c_int, C.c_int, C.c_double, C.c_double, C.c_int,
-                        _P, _P, _P, _P, _P]),
+                        _P, _P, _P, _P, _P, _P]),
   "v4l_trainer_create": (C.c_int, [_P, _P, _P, C.POINTER(_P)]),
   "v4l_trainer_destroy": (None, [_P]),
   "v4l_trainer_ws_floats": (C.c_int64, [_P, C.c_int]),
-  "v4l_trainer_bind": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, C.c_int64, _P]),
-  "v4l_trainer_critic_grads": (C.c_int, [_P, C.POINTER(Rollout), _P, C.c_int, C.POINTER(PPOHyper), _P, _P]),
-  "v4l_trainer_critic_step": (C.c_int, [_P, C.POINTER(PPOHyper), C.c_double, C.c_int64, _P, _P]),
-  "v4l_trainer_actor_grads": (C.c_int, [_P, C.POINTER(Rollout), _P, C.c_int, C.POINTER(PPOHyper), _P, _P]),
-  "v4l_trainer_actor_step": (C.c_int, [_P, C.POINTER(PPOHyper), C.c_double, C.c_int64, _P, _P]),
+  "v4l_trainer_ctl_bytes": (C.c_int64, [_P, C.c_int]),
+  "v4l_trainer_bind": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, C.c_int64, _P, C.c_int, _P]),
+  "v4l_trainer_begin": (C.c_int, [_P, _P, _P, C.c_double, C.c_double, C.c_int64, C.POINTER(PPOHyper), _P]),
+  "v4l_trainer_update_next": (C.c_int, [_P, C.POINTER(Rollout), C.c_int, C.POINTER(PPOHyper), C.c_int, _P]),
+  "v4l_trainer_critic_grads": (C.c_int, [_P, C.POINTER(Rollout), C.c_int, C.POINTER(PPOHyper), _P]),
+  "v4l_trainer_critic_step": (C.c_int, [_P, C.POINTER(PPOHyper), _P]),
+  "v4l_trainer_actor_grads": (C.c_int, [_P, C.POINTER(Rollout), C.c_int, C.POINTER(PPOHyper), _P]),
+  "v4l_trainer_actor_step": (C.c_int, [_P, C.POINTER(PPOHyper), _P]),
+  "v4l_trainer_stats_cur": (_P, [_P]),
   "v4l_trainer_update": (C.c_int, [_P, C.POINTER(Rollout), _P, C.c_int, C.POINTER(PPOHyper), C.c_double,
                                    C.c_double, C.c_int64, _P, _P]),
   "v4l_trainer_sync_target": (C.c_int, [_P, _P]),

@@ -465,6 +465,17 @@ __global__ __launch_bounds__(256) void col0_kernel(const float* __restrict__ src
   if (i < n) dst[i] = src[(int64_t)i * OUT_LD];
 }
 
+// Largest i with blk0[i] <= b for descriptor tables sorted by their first block (stride in bytes).
+template <typename D>
+__device__ __forceinline__ int find_desc(const D* __restrict__ d, int n, int64_t b) {
+  int lo = 0, hi = n - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (d[mid].blk0 <= b) lo = mid; else hi = mid - 1;
+  }
+  return lo;
+}
+
 // --------------------------------------------------------------------------------- grad norm + Adam
 // sum of squares of a flat gradient buffer -> *acc (fp32 atomics of per-block double partials)
 __global__ __launch_bounds__(256) void grad_sumsq_kernel(const float* __restrict__ g, int64_t n, float* __restrict__ acc) {
@@ -485,20 +496,57 @@ struct ParamSeg { float* p; int64_t goff; int64_t n; int64_t blk0; };  // blk0: 
 // no weight decay == AdamW with wd 0) — torchrl/algo/on_policy/ppo.py:73-75,118-120, a2c.py:30-40.
 // Operation order follows torch/optim/adam.py::_single_tensor_adam. The clip coefficient is derived from the
 // squared norm accumulated in *sumsq; thread 0 of block 0 also publishes the pre-clip norm to *norm_out.
+// Device-resident control block of the update loop. Everything that changes from one minibatch update to the
+// next (which rows, Adam's bias corrections, where the statistics go) lives here and is advanced by kernels, so
+// the launch sequence of an update is *identical* every time and can be replayed as one hipGraph.
+struct UpdCtl {
+  int upd_index;        // minibatch number inside the epoch: row of rowidx_all / stats_all
+  int pad0;
+  long long step;       // optimiser steps taken so far (both Adams step once per update)
+  double lr_pf, lr_vf;
+  float beta1, beta2;
+  float step_size[2];   // lr / (1 - beta1^step) for [0] pf, [1] vf — refreshed by upd_begin_kernel
+  float bc2_sqrt;       // sqrt(1 - beta2^step)
+  float pad1;
+};
+__global__ void ctl_set_kernel(UpdCtl* c, int upd_index, long long step, double lr_pf, double lr_vf, float b1, float b2) {
+  c->upd_index = upd_index; c->step = step; c->lr_pf = lr_pf; c->lr_vf = lr_vf; c->beta1 = b1; c->beta2 = b2;
+}
+// Opens update #upd_index: selects its rows (identity when rowidx_all is null), clears the statistics record and
+// advances the Adam step / bias corrections (double precision, like torch/optim/adam.py::_single_tensor_adam).
+__global__ __launch_bounds__(256) void upd_begin_kernel(UpdCtl* c, const int* __restrict__ rowidx_all, int n,
+                                                        int* __restrict__ rowidx_cur, float* __restrict__ stats_cur) {
+  const int u = c->upd_index;
+  for (int i = threadIdx.x; i < n; i += 256) rowidx_cur[i] = rowidx_all ? rowidx_all[(int64_t)u * n + i] : i;
+  if (threadIdx.x < ST_SIZE) stats_cur[threadIdx.x] = 0.f;
+  if (threadIdx.x == 0) {
+    const long long step = c->step + 1;
+    c->step = step;
+    const double bc1 = 1.0 - pow((double)c->beta1, (double)step);
+    const double bc2 = 1.0 - pow((double)c->beta2, (double)step);
+    c->step_size[0] = (float)(c->lr_pf / bc1);
+    c->step_size[1] = (float)(c->lr_vf / bc1);
+    c->bc2_sqrt = (float)sqrt(bc2);
+  }
+}
+// Closes the update: publishes the statistics record and moves on to the next minibatch.
+__global__ void upd_end_kernel(UpdCtl* c, const float* __restrict__ stats_cur, float* __restrict__ stats_all) {
+  const int u = c->upd_index;
+  if (stats_all != nullptr && threadIdx.x < ST_SIZE) stats_all[(int64_t)u * ST_SIZE + threadIdx.x] = stats_cur[threadIdx.x];
+  __syncthreads();
+  if (threadIdx.x == 0) c->upd_index = u + 1;
+}
+
 __global__ __launch_bounds__(256) void clip_adam_kernel(const ParamSeg* __restrict__ segs, int nseg,
                                                         const float* __restrict__ g, float* __restrict__ m,
                                                         float* __restrict__ v, const float* __restrict__ sumsq,
-                                                        float grad_scale, float max_norm, float beta1, float beta2,
-                                                        float eps, float step_size, float bc2_sqrt,
-                                                        float* __restrict__ norm_out) {
-  // locate segment (nseg is small: linear scan on the scalar unit)
-  int si = 0;
-  for (int i = 1; i < nseg; ++i) if ((int64_t)blockIdx.x >= segs[i].blk0) si = i;
-  const ParamSeg sg = segs[si];
-  // grad_scale: gradients in g are sums over ranks (or already means when 1.0)
-  const float tot = sqrtf(*sumsq) * grad_scale;
-  float coef = max_norm / (tot + 1e-6f);
-  coef = fminf(coef, 1.f) * grad_scale;
+                                                        float max_norm, float eps, const UpdCtl* __restrict__ ctl,
+                                                        int which, float* __restrict__ norm_out) {
+  const ParamSeg sg = segs[find_desc(segs, nseg, (int64_t)blockIdx.x)];
+  const float beta1 = ctl->beta1, beta2 = ctl->beta2;
+  const float step_size = ctl->step_size[which], bc2_sqrt = ctl->bc2_sqrt;
+  const float tot = sqrtf(*sumsq);
+  const float coef = fminf(max_norm / (tot + 1e-6f), 1.f);
   if (blockIdx.x == 0 && threadIdx.x == 0 && norm_out != nullptr) *norm_out = tot;
   const int64_t i = ((int64_t)blockIdx.x - sg.blk0) * 256 + threadIdx.x;
   if (i >= sg.n) return;
@@ -528,9 +576,7 @@ struct PackDesc {
 };
 template <typename T>
 __global__ __launch_bounds__(256) void pack_kernel(const PackDesc* __restrict__ descs, int nd, T* __restrict__ dst) {
-  int di = 0;
-  for (int i = 1; i < nd; ++i) if ((int64_t)blockIdx.x >= descs[i].blk0) di = i;
-  const PackDesc d = descs[di];
+  const PackDesc d = descs[find_desc(descs, nd, (int64_t)blockIdx.x)];
   const int64_t e = ((int64_t)blockIdx.x - d.blk0) * 256 + threadIdx.x;
   if (e >= (int64_t)d.R * d.Cc) return;
   const int r = (int)(e / d.Cc), c = (int)(e - (int64_t)r * d.Cc);
@@ -559,33 +605,58 @@ __global__ __launch_bounds__(256) void pack_kernel(const PackDesc* __restrict__ 
 
 // --------------------------------------------------------------------------------- GAE
 // torchrl/replay_buffers/on_policy.py:17-45 — fp64, same expression order as the numpy code, FMA contraction
-// off, so the result is bit-identical to the reference's (then optionally cast once to fp32, as
-// ppo.py:138,140 does). One lane per env, sequential in t (the recursion is per-env; coalesced over e).
+// off, so the result is bit-identical to the reference's (then optionally cast once to fp32, as ppo.py:138,140
+// does). Two phases: (1) everything that does not depend on the recursion — delta_t, the carry coefficient
+// ((1-term)*gamma)*tau and the time-limit factor — is computed fully parallel over [T,E]; (2) the 3-flop
+// recursion runs one lane per env over t with the loads of 8 steps in flight (they do not depend on A).
 // tl_stride_e: 0 when _time_limits is [T,1] (broadcast over envs), 1 when [T,E,1].
-__global__ void gae_kernel(const double* __restrict__ rewards, const double* __restrict__ values,
-                           const double* __restrict__ terminals, const double* __restrict__ time_limits,
-                           int tl_stride_e, const double* __restrict__ last_value, int T, int E, double gamma,
-                           double tau, int use_tl, double* __restrict__ advs, double* __restrict__ rets,
-                           float* __restrict__ advs32, float* __restrict__ rets32) {
+__global__ __launch_bounds__(256) void gae_prep_kernel(const double* __restrict__ rewards, const double* __restrict__ values,
+                                                       const double* __restrict__ terminals,
+                                                       const double* __restrict__ time_limits, int tl_stride_e,
+                                                       const double* __restrict__ last_value, int T, int E, double gamma,
+                                                       double tau, int use_tl, double* __restrict__ delta,
+                                                       double* __restrict__ coef, double* __restrict__ tlm) {
+#pragma clang fp contract(off)
+  const int64_t o = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (o >= (int64_t)T * E) return;
+  const int t = (int)(o / E), e = (int)(o - (int64_t)t * E);
+  const double c = (1.0 - terminals[o]) * gamma;
+  const double vnext = (t == T - 1) ? last_value[e] : values[o + E];
+  double d = rewards[o] + c * vnext;
+  d = d - values[o];
+  delta[o] = d;
+  coef[o] = c * tau;
+  tlm[o] = use_tl ? (1.0 - time_limits[tl_stride_e ? o : t]) : 1.0;
+}
+
+__global__ void gae_scan_kernel(const double* __restrict__ delta, const double* __restrict__ coef,
+                                const double* __restrict__ tlm, const double* __restrict__ values, int T, int E,
+                                int use_tl, double* __restrict__ advs, double* __restrict__ rets,
+                                float* __restrict__ advs32, float* __restrict__ rets32) {
 #pragma clang fp contract(off)
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= E) return;
   double A = 0.0;
-  double vnext = last_value[e];
-  for (int t = T - 1; t >= 0; --t) {
-    const int64_t o = (int64_t)t * E + e;
-    const double nt = 1.0 - terminals[o];
-    const double vt = values[o];
-    const double c = nt * gamma;
-    double delta = rewards[o] + c * vnext;
-    delta = delta - vt;
-    A = delta + (c * tau) * A;
-    if (use_tl) A = A * (1.0 - time_limits[tl_stride_e ? o : t]);
-    const double r = A + vt;
-    advs[o] = A;
-    rets[o] = r;
-    if (advs32 != nullptr) { advs32[o] = (float)A; rets32[o] = (float)r; }
-    vnext = vt;
+  for (int t0 = T - 1; t0 >= 0; t0 -= 8) {
+    double d[8], c[8], m[8], v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int t = t0 - j;
+      const int64_t o = (int64_t)(t < 0 ? 0 : t) * E + e;
+      d[j] = delta[o]; c[j] = coef[o]; m[j] = tlm[o]; v[j] = values[o];
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int t = t0 - j;
+      if (t < 0) break;
+      const int64_t o = (int64_t)t * E + e;
+      A = d[j] + c[j] * A;
+      if (use_tl) A = A * m[j];
+      const double r = A + v[j];
+      advs[o] = A;
+      rets[o] = r;
+      if (advs32 != nullptr) { advs32[o] = (float)A; rets32[o] = (float)r; }
+    }
   }
 }
 

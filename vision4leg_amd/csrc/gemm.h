@@ -74,6 +74,13 @@ struct ADense {
       }
     } else zero8(v);
   }
+  // separable form used by the weight-grad kernel: address = row_off(m) + col_off(k)
+  __device__ __forceinline__ int64_t row_off(int m, int& valid) const { RowCtx rc = row(m); valid = rc.valid; return rc.base; }
+  __device__ __forceinline__ int64_t col_off(int k, int& valid) const { valid = k < K; return k; }
+  __device__ __forceinline__ float get(int64_t off) const {
+    const float v = p[off];
+    return (mask == nullptr || mask[off] > 0.f) ? v : 0.f;
+  }
 };
 
 // conv1: 8x8 stride-4 windows over the [n][C][IH][IW] depth stack (reference layout of the image
@@ -102,6 +109,13 @@ struct AIm2colCHW {
     if (rc.valid && c < C) ld8(p + rc.base + (int64_t)c * IH * IW + ky * IW, v);
     else zero8(v);
   }
+  __device__ __forceinline__ int64_t row_off(int m, int& valid) const { RowCtx rc = row(m); valid = rc.valid; return rc.base; }
+  __device__ __forceinline__ int64_t col_off(int k, int& valid) const {
+    const int c = k >> 6, ky = (k >> 3) & 7, kx = k & 7;
+    valid = c < C;
+    return (int64_t)c * IH * IW + ky * IW + kx;
+  }
+  __device__ __forceinline__ float get(int64_t off) const { return (float)p[off]; }
 };
 
 // conv2/conv3 forward (and the X side of their weight-grads): fp32 NHWC feature map [n][IH][IW][Cin],
@@ -127,6 +141,14 @@ struct AIm2colNHWC {
       ld8(p + rc.base + (int64_t)(ky * IW + kx) * Cin + c0, v);
     } else zero8(v);
   }
+  __device__ __forceinline__ int64_t row_off(int m, int& valid) const { RowCtx rc = row(m); valid = rc.valid; return rc.base; }
+  __device__ __forceinline__ int64_t col_off(int k, int& valid) const {
+    valid = k < K;
+    const int tap = k / Cin, c = k - tap * Cin;
+    const int ky = tap / KW, kx = tap - ky * KW;
+    return (int64_t)(ky * IW + kx) * Cin + c;
+  }
+  __device__ __forceinline__ float get(int64_t off) const { return p[off]; }
 };
 
 // Gather-form convolution data-grad for one stride-parity class (py,px) of input pixels:
@@ -308,92 +330,80 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(AL al, const T* __restrict
 }
 
 // ------------------------------------------------------------------------------------ gemm_tn
-// Where the [n][k] result lands: PyTorch-layout gradient tensor dW[N][Ktorch]. The packed k order of
-// NHWC convs / NHWC flatten is (tap, c); PyTorch's is (c, tap): kt = (k % Cin) * taps + k / Cin.
-struct WgradOut {
-  float* dW;       // [N][Ktorch], accumulated with fp32 atomics (zeroed by the caller)
-  float* dbias;    // [N] or null
-  int N, K;        // logical sizes (k beyond K is padding)
-  int Ktorch;      // row length of dW
-  int Cin, taps;   // Cin == 0: identity k map
-  __device__ __forceinline__ int kmap(int k) const {
-    if (Cin == 0) return k;
-    const int t = k / Cin, c = k - t * Cin;
-    return c * taps + t;
-  }
-};
-
-template <typename T, int BN, class YL, class XL>
-__global__ __launch_bounds__(256) void gemm_tn_kernel(YL yl, XL xl, int M, int m_per_block, WgradOut out) {
-  constexpr int BKO = 64, BMR = 64;
+// Weight-grad: partial[z][n][k] = sum_{m in slab z} Y(m,n) * X(m,k), then wgrad_reduce_kernel sums the slabs
+// (deterministic, no atomics) and scatters into the PyTorch-layout gradient.
+//
+// "lane = column" staging: for a row m every lane reads ONE element of Y (lane = n) and KT elements of X
+// (lane = k), so a wave-level load is one coalesced 256/512-byte row segment, and each lane collects 8 consecutive
+// m of its column in registers -> one 16-byte ds_write of an MFMA-ready fragment (the transpose costs no scalar
+// LDS traffic). Row addresses are wave-uniform (scalar unit), column offsets are per-lane constants hoisted out of
+// the m loop. Block = 4 waves, stage = 64 rows (wave w stages rows 16w..16w+15), output tile BN(n) x 64*KT(k),
+// wave w owns k-tiles [w*KT, (w+1)*KT).
+template <typename T, int BN, int KT, class YL, class XL>
+__global__ __launch_bounds__(256) void gemm_tn_kernel(YL yl, XL xl, int M, int m_per_block, float* __restrict__ slab,
+                                                      float* __restrict__ bslab, int Npad, int Kpad) {
+  constexpr int BMR = 64;
   constexpr int LD = BMR + (sizeof(T) == 2 ? 8 : 4);
   constexpr int NT = BN / 16;
-  constexpr int YCH = (BN * 8 + 255) / 256;  // Y chunks (8 n) per thread per stage: 64 rows * BN/8
+  constexpr int BKO = 64 * KT;
   typedef typename Frag<T>::type frag_t;
   __shared__ __attribute__((aligned(16))) T sY[BN * LD];   // [n][m]
   __shared__ __attribute__((aligned(16))) T sX[BKO * LD];  // [k][m]
-  __shared__ float sBias[BN];
+  __shared__ float sBias[4][64];
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int k0 = blockIdx.x * BKO, n0 = blockIdx.y * BN;
   const int mb = blockIdx.z * m_per_block;
   const int me = min(M, mb + m_per_block);
-  const bool do_bias = (out.dbias != nullptr) && (blockIdx.x == 0);
+  const bool do_bias = (bslab != nullptr) && (blockIdx.x == 0);
 
-  float ry[YCH][8], rx[2][8];
-  float bsum[YCH][8];
+  // per-lane column offsets (constant for the whole block)
+  int yok, xok[KT];
+  const int64_t yco = yl.col_off(n0 + lane, yok);
+  yok = yok && (lane < BN);
+  int64_t xco[KT];
 #pragma unroll
-  for (int i = 0; i < YCH; ++i) zero8(bsum[i]);
-  if (tid < BN) sBias[tid] = 0.f;
+  for (int i = 0; i < KT; ++i) xco[i] = xl.col_off(k0 + lane * KT + i, xok[i]);
 
-  constexpr int YC_PER_ROW = BN / 8;
+  float yv[16], xv[KT][16];
+  float bsum = 0.f;
   auto gload = [&](int ms) {
 #pragma unroll
-    for (int i = 0; i < YCH; ++i) {
-      const int q = tid + 256 * i;
-      if (q < BN * 8) {
-        const int r = q / YC_PER_ROW, c = (q - r * YC_PER_ROW) * 8;
-        const int m = ms + r;
-        RowCtx rc = yl.row(m);
-        rc.valid = rc.valid && (m < me);
-        yl.load(rc, n0 + c, ry[i]);
-      }
-    }
+    for (int j = 0; j < 16; ++j) {
+      const int m = ms + wave * 16 + j;
+      int vy, vx;
+      const int64_t yro = yl.row_off(m, vy);
+      const int64_t xro = xl.row_off(m, vx);
+      const bool in = m < me;
+      yv[j] = (in && vy && yok) ? yl.get(yro + yco) : 0.f;
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int q = tid + 256 * i;
-      const int r = q >> 3, c = (q & 7) * 8;
-      const int m = ms + r;
-      RowCtx rc = xl.row(m);
-      rc.valid = rc.valid && (m < me);
-      xl.load(rc, k0 + c, rx[i]);
+      for (int i = 0; i < KT; ++i) xv[i][j] = (in && vx && xok[i]) ? xl.get(xro + xco[i]) : 0.f;
     }
   };
   auto lstore = [&]() {
 #pragma unroll
-    for (int i = 0; i < YCH; ++i) {
-      const int q = tid + 256 * i;
-      if (q < BN * 8) {
-        const int r = q / YC_PER_ROW, c = (q - r * YC_PER_ROW) * 8;
+    for (int g = 0; g < 2; ++g) {
+      float t8[8];
+      if (lane < BN) {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          sY[(c + j) * LD + r] = Op<T>::from_f32(ry[i][j]);
-          bsum[i][j] += ry[i][j];
-        }
+        for (int j = 0; j < 8; ++j) { t8[j] = yv[g * 8 + j]; bsum += t8[j]; }
+        st8<T>(&sY[lane * LD + wave * 16 + g * 8], t8);
       }
-    }
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int q = tid + 256 * i;
-      const int r = q >> 3, c = (q & 7) * 8;
+      for (int i = 0; i < KT; ++i) {
 #pragma unroll
-      for (int j = 0; j < 8; ++j) sX[(c + j) * LD + r] = Op<T>::from_f32(rx[i][j]);
+        for (int j = 0; j < 8; ++j) t8[j] = xv[i][g * 8 + j];
+        st8<T>(&sX[(lane * KT + i) * LD + wave * 16 + g * 8], t8);
+      }
     }
   };
 
-  f32x4 acc[NT];
+  f32x4 acc[NT][KT];
 #pragma unroll
-  for (int i = 0; i < NT; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int i = 0; i < NT; ++i)
+#pragma unroll
+    for (int j = 0; j < KT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   const int fr = lane & 15, fg = (lane >> 4) * 8;
   if (mb < me) gload(mb);
@@ -403,41 +413,74 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(YL yl, XL xl, int M, int m
     if (ms + BMR < me) gload(ms + BMR);
 #pragma unroll
     for (int ks = 0; ks < BMR / 32; ++ks) {
-      const frag_t fx = *reinterpret_cast<const frag_t*>(&sX[(wave * 16 + fr) * LD + ks * 32 + fg]);
+      frag_t fx[KT];
+#pragma unroll
+      for (int j = 0; j < KT; ++j)
+        fx[j] = *reinterpret_cast<const frag_t*>(&sX[((wave * KT + j) * 16 + fr) * LD + ks * 32 + fg]);
 #pragma unroll
       for (int i = 0; i < NT; ++i) {
         const frag_t fy = *reinterpret_cast<const frag_t*>(&sY[(i * 16 + fr) * LD + ks * 32 + fg]);
-        mma_k32(acc[i], fy, fx);
+#pragma unroll
+        for (int j = 0; j < KT; ++j) mma_k32(acc[i][j], fy, fx[j]);
       }
     }
     __syncthreads();
   }
 
-  // acc[i][r] = dW[n0 + 16*i + 4*(lane>>4) + r][k0 + 16*wave + (lane&15)]
-  const int k = k0 + wave * 16 + (lane & 15);
-  if (k < out.K) {
-    const int kt = out.kmap(k);
+  // acc[i][j][r] = partial dW[n0 + 16*i + 4*(lane>>4) + r][k0 + 16*(wave*KT+j) + (lane&15)]
+  float* out = slab + (int64_t)blockIdx.z * Npad * Kpad;
 #pragma unroll
-    for (int i = 0; i < NT; ++i)
+  for (int i = 0; i < NT; ++i)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int n = n0 + i * 16 + (lane >> 4) * 4 + r;
-        if (n < out.N) atomicAdd(out.dW + (int64_t)n * out.Ktorch + kt, acc[i][r]);
-      }
-  }
-  if (do_bias) {
-    __syncthreads();
+    for (int r = 0; r < 4; ++r) {
+      const int n = n0 + i * 16 + (lane >> 4) * 4 + r;
 #pragma unroll
-    for (int i = 0; i < YCH; ++i) {
-      const int q = tid + 256 * i;
-      if (q < BN * 8) {
-        const int c = (q % YC_PER_ROW) * 8;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) atomicAdd(&sBias[c + j], bsum[i][j]);
+      for (int j = 0; j < KT; ++j) {
+        const int k = k0 + (wave * KT + j) * 16 + (lane & 15);
+        if (n < Npad && k < Kpad) out[(int64_t)n * Kpad + k] = acc[i][j][r];
       }
     }
+  if (do_bias) {
+    sBias[wave][lane] = bsum;
     __syncthreads();
-    if (tid < BN && n0 + tid < out.N) atomicAdd(out.dbias + n0 + tid, sBias[tid]);
+    if (tid < BN && n0 + tid < Npad)
+      bslab[(int64_t)blockIdx.z * Npad + n0 + tid] = sBias[0][tid] + sBias[1][tid] + sBias[2][tid] + sBias[3][tid];
+  }
+}
+
+// Sums the per-slab partials of one or more weight tensors and writes the PyTorch-layout gradients.
+// The packed k order of NHWC convs / NHWC flatten is (tap, c); PyTorch's is (c, tap): kt = (k % Cin) * taps + k / Cin.
+struct RedDesc {
+  const float* slab;   // [nsplit][Npad][Kpad]
+  const float* bslab;  // [nsplit][Npad] or null
+  float* dW;           // [N][Ktorch]
+  float* db;           // [N] or null
+  int nsplit, N, K, Npad, Kpad, Ktorch, Cin, taps;
+  int64_t blk0;        // first block of this descriptor
+};
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const RedDesc* __restrict__ descs, int nd) {
+  int lo = 0, hi = nd - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (descs[mid].blk0 <= (int64_t)blockIdx.x) lo = mid; else hi = mid - 1;
+  }
+  const RedDesc d = descs[lo];
+  const int64_t e = ((int64_t)blockIdx.x - d.blk0) * 256 + threadIdx.x;
+  const int64_t nk = (int64_t)d.N * d.K;
+  if (e < nk) {
+    const int n = (int)(e / d.K), k = (int)(e - (int64_t)n * d.K);
+    const float* p = d.slab + (int64_t)n * d.Kpad + k;
+    const int64_t stride = (int64_t)d.Npad * d.Kpad;
+    float s = 0.f;
+    for (int z = 0; z < d.nsplit; ++z) s += p[z * stride];
+    int kt = k;
+    if (d.Cin != 0) { const int t = k / d.Cin, c = k - t * d.Cin; kt = c * d.taps + t; }
+    d.dW[(int64_t)n * d.Ktorch + kt] = s;
+  } else if (d.db != nullptr && e < nk + d.N) {
+    const int n = (int)(e - nk);
+    float s = 0.f;
+    for (int z = 0; z < d.nsplit; ++z) s += d.bslab[(int64_t)z * d.Npad + n];
+    d.db[n] = s;
   }
 }
 

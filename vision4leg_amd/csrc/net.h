@@ -61,6 +61,7 @@ struct Layout {
   int64_t dha = 0, dhb = 0;      // [n][maxwidth] ping-pong for MLP stacks
   int64_t dhc = 0;               // [n][maxwidth] hand-off between two stacks (head -> encoder)
   int64_t dpool = 0, dc3 = 0, dc2 = 0, dc1 = 0;
+  int64_t slab = 0;              // weight-grad partial slabs
   int64_t total = 0;
 };
 
@@ -87,20 +88,38 @@ struct v4l_net {
   void* packed = nullptr;
   v4l::PackDesc* d_packs = nullptr;
   v4l::ParamSeg* d_segs = nullptr;
+  v4l::RedDesc* d_red = nullptr;
+  static constexpr int MAX_RED = 96;
+  std::vector<v4l::RedDesc> red, red_cached;  // weight-grad reduce descriptors of the current / last backward
+  int64_t slab_cap = 0;
   int64_t seg_blocks = 0;
   bool bound = false;
 
   int build();
   v4l::Layout layout(int n) const;
   int64_t table_bytes() const;
+  int64_t slab_floats(int n) const;
   template <typename T> int forward_t(const float* state, const T* image, const int* rowidx, int n, float* ws, hipStream_t s);
   template <typename T> int backward_t(const float* state, const T* image, const int* rowidx, int n, float* ws, float* grads, hipStream_t s);
 };
+
+struct GraphKey { v4l_rollout ro; v4l_ppo_hyper hp; int n; };
 
 struct v4l_trainer {
   v4l_net *pf = nullptr, *vf = nullptr, *tpf = nullptr;
   float *g_pf = nullptr, *m_pf = nullptr, *v_pf = nullptr, *g_vf = nullptr, *m_vf = nullptr, *v_vf = nullptr;
   float* ws = nullptr;
   int64_t ws_floats = 0;
+  // device control block + per-update staging (caller-allocated, v4l_trainer_ctl_bytes)
+  v4l::UpdCtl* ctl = nullptr;
+  float* stats_cur = nullptr;
+  int* rowidx_cur = nullptr;
+  int n_max = 0;
+  const int* rowidx_all = nullptr;
+  float* stats_all = nullptr;
+  // hipGraph of one minibatch update
+  GraphKey gkey = {};
+  hipGraphExec_t gexec = nullptr;
+  bool warm = false;
   bool bound = false;
 };

@@ -87,32 +87,79 @@ static int launch_nt(hipStream_t s, const AL& al, int M, const T* Bp, int Np, in
   return 0;
 }
 
-// dW[n][k] += sum_m Y(m,n) X(m,k); Kx = logical k extent of X (multiple of 8)
+// Weight-grad plan: tile shape, split count over the reduction (m) and slab geometry.
+struct TnPlan { int BN, KT, gx, gy, splits, mpb, Npad, Kpad; int64_t slab_floats, bslab_floats; };
+static inline TnPlan tn_plan(int M, int N, int Kx) {
+  TnPlan p;
+  p.BN = N <= 16 ? 16 : (N <= 32 ? 32 : 64);
+  p.KT = Kx >= 128 ? 2 : 1;
+  p.gy = cdiv(N, p.BN);
+  p.gx = cdiv(Kx, 64 * p.KT);
+  int splits = std::max(1, 512 / (p.gx * p.gy));
+  splits = std::min(splits, std::max(1, M / 256));
+  p.mpb = round_up(cdiv(M, splits), 64);
+  p.splits = cdiv(M, p.mpb);
+  p.Npad = p.gy * p.BN;
+  p.Kpad = p.gx * 64 * p.KT;
+  p.slab_floats = ((int64_t)p.splits * p.Npad * p.Kpad + 63) / 64 * 64;
+  p.bslab_floats = ((int64_t)p.splits * p.Npad + 63) / 64 * 64;
+  return p;
+}
+
+struct Ctx {  // per-call view of a bound net
+  v4l_net* net;
+  hipStream_t s;
+  float* grads;
+  float* slab;         // arena for weight-grad partials (inside the workspace)
+  int64_t slab_used;
+};
+
+// partial[z] = Y^T X over slab z of the rows; registers a reduce descriptor that wgrad_finish() executes
 template <typename T, class YL, class XL>
-static int launch_tn(hipStream_t s, const YL& yl, const XL& xl, int M, int N, int Kx, const WgradOut& out, double flops) {
+static int launch_tn(Ctx& c, const YL& yl, const XL& xl, int M, int N, int Kx, RedDesc rd, double flops) {
   if (M <= 0) return 0;
-  const int gx = cdiv(Kx, 64);
-  const int BN = N <= 16 ? 16 : (N <= 32 ? 32 : 64);
-  const int gy = cdiv(N, BN);
-  int splits = std::max(1, 1024 / (gx * gy));
-  splits = std::min(splits, cdiv(M, 64));
-  const int mpb = round_up(cdiv(M, splits), 64);
-  splits = cdiv(M, mpb);
-  const dim3 grid(gx, gy, splits);
-  if (BN == 64) V4L_KLAUNCH("gemm_tn", flops, s, (gemm_tn_kernel<T, 64, YL, XL>), grid, dim3(256), 0, s, yl, xl, M, mpb, out);
-  else if (BN == 32) V4L_KLAUNCH("gemm_tn", flops, s, (gemm_tn_kernel<T, 32, YL, XL>), grid, dim3(256), 0, s, yl, xl, M, mpb, out);
-  else V4L_KLAUNCH("gemm_tn", flops, s, (gemm_tn_kernel<T, 16, YL, XL>), grid, dim3(256), 0, s, yl, xl, M, mpb, out);
+  const TnPlan p = tn_plan(M, N, Kx);
+  float* slab = c.slab + c.slab_used;
+  float* bslab = rd.db != nullptr ? slab + p.slab_floats : nullptr;
+  c.slab_used += p.slab_floats + (rd.db != nullptr ? p.bslab_floats : 0);
+  V4L_REQUIRE(c.slab_used <= c.net->slab_cap, "internal: weight-grad slab arena overflow");
+  const dim3 grid(p.gx, p.gy, p.splits);
+  hipStream_t s = c.s;
+#define V4L_TN(BN_, KT_) \
+  V4L_KLAUNCH("gemm_tn", flops, s, (gemm_tn_kernel<T, BN_, KT_, YL, XL>), grid, dim3(256), 0, s, yl, xl, M, p.mpb, slab, bslab, p.Npad, p.Kpad)
+  if (p.BN == 64) { if (p.KT == 2) V4L_TN(64, 2); else V4L_TN(64, 1); }
+  else if (p.BN == 32) { if (p.KT == 2) V4L_TN(32, 2); else V4L_TN(32, 1); }
+  else { if (p.KT == 2) V4L_TN(16, 2); else V4L_TN(16, 1); }
+#undef V4L_TN
+  V4L_LAUNCH_CHECK();
+  rd.slab = slab; rd.bslab = bslab; rd.nsplit = p.splits; rd.Npad = p.Npad; rd.Kpad = p.Kpad;
+  c.net->red.push_back(rd);
+  return 0;
+}
+
+// one launch: sum all registered slabs into the PyTorch-layout gradients
+static int wgrad_finish(Ctx& c) {
+  v4l_net* net = c.net;
+  int64_t blk = 0;
+  for (RedDesc& d : net->red) { d.blk0 = blk; blk += cdiv64((int64_t)d.N * d.K + d.N, 256); }
+  V4L_REQUIRE(net->red.size() <= (size_t)v4l_net::MAX_RED, "internal: too many weight-grad descriptors");
+  const size_t bytes = net->red.size() * sizeof(RedDesc);
+  if (net->red_cached.size() != net->red.size() || memcmp(net->red_cached.data(), net->red.data(), bytes) != 0) {
+    // geometry changed (first call for this batch size): refresh the device table. Not capturable, by design.
+    hipStreamCaptureStatus cst = hipStreamCaptureStatusNone;
+    if (c.s != nullptr) (void)hipStreamIsCapturing(c.s, &cst);
+    V4L_REQUIRE(cst == hipStreamCaptureStatusNone, "internal: weight-grad geometry changed while capturing a graph");
+    V4L_HIP_CHECK(hipStreamSynchronize(c.s));
+    V4L_HIP_CHECK(hipMemcpy(net->d_red, net->red.data(), bytes, hipMemcpyHostToDevice));
+    net->red_cached = net->red;
+  }
+  g_op = "wgrad_reduce";
+  V4L_KLAUNCH("wgrad_reduce", 0, c.s, wgrad_reduce_kernel, dim3((unsigned)blk), dim3(256), 0, c.s, net->d_red, (int)net->red.size());
   V4L_LAUNCH_CHECK();
   return 0;
 }
 
 struct Act { float* p; int ld; int w; };
-
-struct Ctx {  // per-call view of a bound net
-  const v4l_net* net;
-  hipStream_t s;
-  float* grads;
-};
 
 template <typename T>
 static int lin_fwd(const Ctx& c, const Lin& L, const ADense& a, Epi ep) {
@@ -121,13 +168,14 @@ static int lin_fwd(const Ctx& c, const Lin& L, const ADense& a, Epi ep) {
   return launch_nt<T>(c.s, a, a.M, (const T*)c.net->packed + L.pk, L.Np, L.Kp, ep, 2.0 * a.M * L.N * L.K);
 }
 template <typename T, class XL>
-static int lin_wgrad(const Ctx& c, const Lin& L, const ADense& y, const XL& x, int Kx) {
-  WgradOut o;
+static int lin_wgrad(Ctx& c, const Lin& L, const ADense& y, const XL& x, int Kx) {
+  RedDesc o;
+  memset(&o, 0, sizeof(o));
   o.dW = c.grads + c.net->params[L.w].goff;
-  o.dbias = c.grads + c.net->params[L.b].goff;
+  o.db = c.grads + c.net->params[L.b].goff;
   o.N = L.N; o.K = L.K; o.Ktorch = L.K; o.Cin = L.cin; o.taps = L.taps;
   g_op = L.tag_wgrad.c_str();
-  return launch_tn<T>(c.s, y, x, y.M, L.N, Kx, o, 2.0 * y.M * L.N * L.K);
+  return launch_tn<T>(c, y, x, y.M, L.N, Kx, o, 2.0 * y.M * L.N * L.K);
 }
 template <typename T>
 static int lin_dgrad(const Ctx& c, const Lin& L, const ADense& y, Epi ep) {
@@ -150,7 +198,7 @@ static int chain_fwd(const Ctx& c, const Lin* Ls, int k, ADense in, const Act* o
 // backward through the same chain. y: grad w.r.t. the last layer's pre-activation. acts[i]: output of layer i.
 // din (optional): epilogue that receives the grad w.r.t. the chain input.
 template <typename T>
-static int chain_bwd(const Ctx& c, const Lin* Ls, int k, const ADense& in, const Act* acts, ADense y, float* bufa,
+static int chain_bwd(Ctx& c, const Lin* Ls, int k, const ADense& in, const Act* acts, ADense y, float* bufa,
                      float* bufb, const Epi* din) {
   for (int i = k - 1; i >= 0; --i) {
     int rc;
@@ -213,7 +261,7 @@ static int conv_stack_fwd(const Ctx& c, const T* image, const int* rowidx, int n
 
 // dc3: grad w.r.t. conv3's pre-activation [n*16][64]. Scratch dc2 [n*36][64], dc1 [n*225][32].
 template <typename T>
-static int conv_stack_bwd(const Ctx& c, const T* image, const int* rowidx, int n, const float* c1, const float* c2,
+static int conv_stack_bwd(Ctx& c, const T* image, const int* rowidx, int n, const float* c1, const float* c2,
                           float* dc3, float* dc2, float* dc1) {
   const v4l_net* N = c.net;
   const Conv* cv = N->conv;
@@ -223,21 +271,22 @@ static int conv_stack_bwd(const Ctx& c, const T* image, const int* rowidx, int n
     const Conv& v = cv[i];
     const int M = n * v.OH * v.OH;
     ADense y = dense(dys[i], v.Cout, M, v.Cout);
-    WgradOut o;
+    RedDesc o;
+    memset(&o, 0, sizeof(o));
     o.dW = c.grads + N->params[v.w].goff;
-    o.dbias = c.grads + N->params[v.b].goff;
+    o.db = c.grads + N->params[v.b].goff;
     o.N = v.Cout; o.K = v.K; o.Ktorch = v.K;
     int rc;
     if (v.chw) {
       o.Cin = 0; o.taps = 0;
       auto x = chw_loader<T>(image, v, n, rowidx);
       g_op = "conv1.wgrad";
-      rc = launch_tn<T>(c.s, y, x, M, v.Cout, v.K, o, 2.0 * M * v.Cout * v.K);
+      rc = launch_tn<T>(c, y, x, M, v.Cout, v.K, o, 2.0 * M * v.Cout * v.K);
     } else {
       o.Cin = v.Cin; o.taps = v.KH * v.KH;
       auto x = nhwc_loader(acts[i], v, n);
       g_op = i == 1 ? "conv2.wgrad" : "conv3.wgrad";
-      rc = launch_tn<T>(c.s, y, x, M, v.Cout, v.K, o, 2.0 * M * v.Cout * v.K);
+      rc = launch_tn<T>(c, y, x, M, v.Cout, v.K, o, 2.0 * M * v.Cout * v.K);
     }
     if (rc) return rc;
     if (i == 0) break;
@@ -430,7 +479,29 @@ int v4l_net::build() {
 }
 
 int64_t v4l_net::table_bytes() const {
-  return (int64_t)(packs.size() * sizeof(PackDesc) + params.size() * sizeof(ParamSeg) + 256);
+  return (int64_t)(packs.size() * sizeof(PackDesc) + params.size() * sizeof(ParamSeg) + MAX_RED * sizeof(RedDesc) + 512);
+}
+
+// Upper bound of the weight-grad slab arena for a batch of n: every weight tensor with the row count its
+// gradient contraction runs over.
+int64_t v4l_net::slab_floats(int n) const {
+  int64_t tot = 0;
+  auto add = [&](int M, int N, int Kx) {
+    const TnPlan p = tn_plan(M, N, Kx);
+    tot += p.slab_floats + p.bslab_floats;
+  };
+  if (cfg.kind != V4L_NET_MLP)
+    for (int i = 0; i < 3; ++i) add(n * conv[i].OH * conv[i].OH, conv[i].Cout, conv[i].K);
+  if (cfg.kind == V4L_NET_LOCO) add(n * 16, upconv.N, 64);
+  if (cfg.kind == V4L_NET_LOCO) add(n, proj.N, proj.K);
+  if (cfg.kind == V4L_NET_CNN) add(n, proj.N, 1024);
+  for (size_t i = 0; i < enc.size(); ++i) add(n, enc[i].N, i == 0 ? Sp : enc[i].K);
+  for (const TLayer& t : layers) {
+    add(n * NTOK, t.inproj.N, t.inproj.K); add(n * NTOK, t.outproj.N, t.outproj.K);
+    add(n * NTOK, t.ff1.N, t.ff1.K); add(n * NTOK, t.ff2.N, t.ff2.K);
+  }
+  for (const Lin& L : head) add(n, L.N, L.K);
+  return tot;
 }
 
 Layout v4l_net::layout(int n) const {
@@ -488,6 +559,7 @@ Layout v4l_net::layout(int n) const {
     L.dc2 = take((int64_t)n * 36 * 64);
     L.dc1 = take((int64_t)n * 225 * 32);
   }
+  L.slab = take(slab_floats(n));
   L.total = off;
   return L;
 }
@@ -497,7 +569,7 @@ template <typename T>
 int v4l_net::forward_t(const float* state, const T* image, const int* rowidx, int n, float* ws, hipStream_t s) {
   const Layout L = layout(n);
   const v4l_net_cfg& c = cfg;
-  Ctx cx{this, s, nullptr};
+  Ctx cx{this, s, nullptr, nullptr, 0};
   int rc;
   const int ne = c.n_enc_hidden, nh = c.n_head_hidden;
   const ADense sin = dense(state, Sp, n, Sp, rowidx);
@@ -570,7 +642,9 @@ int v4l_net::backward_t(const float* state, const T* image, const int* rowidx, i
                         hipStream_t s) {
   const Layout L = layout(n);
   const v4l_net_cfg& c = cfg;
-  Ctx cx{this, s, grads};
+  Ctx cx{this, s, grads, ws + L.slab, 0};
+  red.clear();
+  slab_cap = slab_floats(n);
   int rc;
   const int ne = c.n_enc_hidden, nh = c.n_head_hidden;
   const ADense sin = dense(state, Sp, n, Sp, rowidx);
@@ -590,7 +664,8 @@ int v4l_net::backward_t(const float* state, const T* image, const int* rowidx, i
     din.mask = last.p;
     din.ldmask = last.ld;
     if ((rc = chain_bwd<T>(cx, head.data(), nh + 1, dense(last.p, last.ld, n, last.w), hacts, dy, bufa, bufb, &din))) return rc;
-    return chain_bwd<T>(cx, enc.data(), ne, sin, eacts, dense(hand, last.w, n, last.w), bufa, bufb, nullptr);
+    if ((rc = chain_bwd<T>(cx, enc.data(), ne, sin, eacts, dense(hand, last.w, n, last.w), bufa, bufb, nullptr))) return rc;
+    return wgrad_finish(cx);
   }
 
   if (c.kind == V4L_NET_CNN) {
@@ -611,7 +686,8 @@ int v4l_net::backward_t(const float* state, const T* image, const int* rowidx, i
       ADense ys = dense(hand + c.visual_dim, cw, n, c.enc_hidden[ne - 1], nullptr, 0, ws + L.vis + c.visual_dim);
       if ((rc = chain_bwd<T>(cx, enc.data(), ne, sin, eacts, ys, bufa, bufb, nullptr))) return rc;
     }
-    return conv_stack_bwd<T>(cx, image, rowidx, n, ws + L.c1, ws + L.c2, ws + L.dc3, ws + L.dc2, ws + L.dc1);
+    if ((rc = conv_stack_bwd<T>(cx, image, rowidx, n, ws + L.c1, ws + L.c2, ws + L.dc3, ws + L.dc2, ws + L.dc1))) return rc;
+    return wgrad_finish(cx);
   }
 
   // ---- LocoTransformer
@@ -625,7 +701,7 @@ int v4l_net::backward_t(const float* state, const T* image, const int* rowidx, i
   g_op = "pool";
   V4L_KLAUNCH("pool_bwd", 0, s, pool_bwd_kernel, dim3(n), dim3(64), 0, s, ws + L.dpool, n, dx);
   V4L_LAUNCH_CHECK();
-  const int lnb = std::min(cdiv(R, 4), 1024);
+  const int lnb = std::min(cdiv(R, 4), 128);  // few blocks: the per-block dgamma/dbeta atomics hit 128 addresses
   for (int l = c.n_layers - 1; l >= 0; --l) {
     const TLayer& t = layers[l];
     const LayerWs& w = L.lw[l];
@@ -684,7 +760,8 @@ int v4l_net::backward_t(const float* state, const T* image, const int* rowidx, i
     ep.ldmask = 64;
     if ((rc = lin_dgrad<T>(cx, upconv, yu, ep))) return rc;
   }
-  return conv_stack_bwd<T>(cx, image, rowidx, n, ws + L.c1, ws + L.c2, ws + L.dc3, ws + L.dc2, ws + L.dc1);
+  if ((rc = conv_stack_bwd<T>(cx, image, rowidx, n, ws + L.c1, ws + L.c2, ws + L.dc3, ws + L.dc2, ws + L.dc1))) return rc;
+  return wgrad_finish(cx);
 }
 
 // ------------------------------------------------------------------------------------------ C ABI
@@ -780,6 +857,8 @@ int v4l_net_bind(v4l_net* net, float* const* params_dev, void* packed_dev, void*
   net->packed = packed_dev;
   net->d_packs = (PackDesc*)table_dev;
   net->d_segs = (ParamSeg*)((char*)table_dev + (net->packs.size() * sizeof(PackDesc) + 63) / 64 * 64);
+  net->d_red = (RedDesc*)((char*)net->d_segs + (net->params.size() * sizeof(ParamSeg) + 63) / 64 * 64);
+  net->red_cached.clear();
   // synchronous pageable copies: the host vectors die at return
   V4L_HIP_CHECK(hipStreamSynchronize(s));
   V4L_HIP_CHECK(hipMemcpy(net->d_packs, net->packs.data(), net->packs.size() * sizeof(PackDesc), hipMemcpyHostToDevice));
@@ -864,19 +943,24 @@ int v4l_col0(const float* src_dev, int n, float* dst_dev, void* stream) {
 
 int v4l_gae(const double* rewards_dev, const double* values_dev, const double* terminals_dev,
             const double* time_limits_dev, int tl_per_env, const double* last_value_dev, int T, int E, double gamma,
-            double tau, int use_time_limit, double* advs_dev, double* rets_dev, float* advs32_dev, float* rets32_dev,
-            void* stream) {
-  V4L_REQUIRE(rewards_dev && values_dev && terminals_dev && last_value_dev && advs_dev && rets_dev && T > 0 && E > 0,
-              "v4l_gae: bad argument");
+            double tau, int use_time_limit, double* scratch_dev, double* advs_dev, double* rets_dev, float* advs32_dev,
+            float* rets32_dev, void* stream) {
+  V4L_REQUIRE(rewards_dev && values_dev && terminals_dev && last_value_dev && advs_dev && rets_dev && scratch_dev &&
+                  T > 0 && E > 0, "v4l_gae: bad argument");
   V4L_REQUIRE(!use_time_limit || time_limits_dev != nullptr, "v4l_gae: time_limits_dev is null");
   V4L_REQUIRE((advs32_dev == nullptr) == (rets32_dev == nullptr), "v4l_gae: advs32/rets32 must both be set or null");
-  hipLaunchKernelGGL(gae_kernel, dim3(cdiv(E, 64)), dim3(64), 0, (hipStream_t)stream, rewards_dev, values_dev,
-                     terminals_dev, time_limits_dev, tl_per_env, last_value_dev, T, E, gamma, tau, use_time_limit,
-                     advs_dev, rets_dev, advs32_dev, rets32_dev);
+  hipStream_t s = (hipStream_t)stream;
+  const int64_t te = (int64_t)T * E;
+  double *delta = scratch_dev, *coef = scratch_dev + te, *tlm = scratch_dev + 2 * te;
+  g_op = "gae";
+  V4L_KLAUNCH("gae_prep", 0, s, gae_prep_kernel, dim3((unsigned)cdiv64(te, 256)), dim3(256), 0, s, rewards_dev, values_dev,
+              terminals_dev, time_limits_dev, tl_per_env, last_value_dev, T, E, gamma, tau, use_time_limit, delta, coef, tlm);
+  V4L_LAUNCH_CHECK();
+  V4L_KLAUNCH("gae_scan", 0, s, gae_scan_kernel, dim3(cdiv(E, 64)), dim3(64), 0, s, delta, coef, tlm, values_dev, T, E,
+              use_time_limit, advs_dev, rets_dev, advs32_dev, rets32_dev);
   V4L_LAUNCH_CHECK();
   return 0;
 }
-
 
 int v4l_prof_enable(int on) {
   g_prof = on != 0;
@@ -929,28 +1013,56 @@ int v4l_trainer_create(v4l_net* pf, v4l_net* vf, v4l_net* target_pf, v4l_trainer
   *out = t;
   return 0;
 }
-void v4l_trainer_destroy(v4l_trainer* tr) { delete tr; }
+static void drop_graph(v4l_trainer* tr) {
+  if (tr->gexec) { (void)hipGraphExecDestroy(tr->gexec); tr->gexec = nullptr; }
+  tr->warm = false;
+}
+void v4l_trainer_destroy(v4l_trainer* tr) {
+  if (tr) drop_graph(tr);
+  delete tr;
+}
 int64_t v4l_trainer_ws_floats(const v4l_trainer* tr, int n) {
   if (!tr || n <= 0) return -1;
   return std::max(tr->pf->layout(n).total, tr->vf->layout(n).total) + tr->tpf->layout(n).total;
 }
+int64_t v4l_trainer_ctl_bytes(const v4l_trainer* tr, int n) {
+  if (!tr || n <= 0) return -1;
+  return 256 + 256 + (int64_t)round_up(n, 64) * sizeof(int);
+}
 int v4l_trainer_bind(v4l_trainer* tr, float* g_pf_dev, float* m_pf_dev, float* v_pf_dev, float* g_vf_dev,
-                     float* m_vf_dev, float* v_vf_dev, float* ws_dev, int64_t ws_floats, void* stream) {
+                     float* m_vf_dev, float* v_vf_dev, float* ws_dev, int64_t ws_floats, void* ctl_dev, int n_max,
+                     void* stream) {
   (void)stream;
-  V4L_REQUIRE(tr && g_pf_dev && m_pf_dev && v_pf_dev && g_vf_dev && m_vf_dev && v_vf_dev && ws_dev,
-              "v4l_trainer_bind: null argument");
+  V4L_REQUIRE(tr && g_pf_dev && m_pf_dev && v_pf_dev && g_vf_dev && m_vf_dev && v_vf_dev && ws_dev && ctl_dev && n_max > 1,
+              "v4l_trainer_bind: bad argument");
   V4L_REQUIRE(tr->pf->bound && tr->vf->bound && tr->tpf->bound, "v4l_trainer_bind: bind the three nets first");
+  drop_graph(tr);
   tr->g_pf = g_pf_dev; tr->m_pf = m_pf_dev; tr->v_pf = v_pf_dev;
   tr->g_vf = g_vf_dev; tr->m_vf = m_vf_dev; tr->v_vf = v_vf_dev;
   tr->ws = ws_dev; tr->ws_floats = ws_floats;
+  tr->ctl = (UpdCtl*)ctl_dev;
+  tr->stats_cur = (float*)((char*)ctl_dev + 256);
+  tr->rowidx_cur = (int*)((char*)ctl_dev + 512);
+  tr->n_max = n_max;
   tr->bound = true;
   return 0;
 }
 
-static int check_update_args(const v4l_trainer* tr, const v4l_rollout* ro, int n, const v4l_ppo_hyper* hp,
-                             const float* stats) {
+int v4l_trainer_begin(v4l_trainer* tr, const int* rowidx_all_dev, float* stats_all_dev, double lr_pf, double lr_vf,
+                      int64_t steps_done, const v4l_ppo_hyper* hp, void* stream) {
+  V4L_REQUIRE(tr && tr->bound && hp && steps_done >= 0, "v4l_trainer_begin: bad argument");
+  if (rowidx_all_dev != tr->rowidx_all || stats_all_dev != tr->stats_all) drop_graph(tr);  // baked into the graph
+  tr->rowidx_all = rowidx_all_dev;
+  tr->stats_all = stats_all_dev;
+  hipLaunchKernelGGL(ctl_set_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, tr->ctl, 0, (long long)steps_done, lr_pf,
+                     lr_vf, hp->beta1, hp->beta2);
+  V4L_LAUNCH_CHECK();
+  return 0;
+}
+
+static int check_update_args(const v4l_trainer* tr, const v4l_rollout* ro, int n, const v4l_ppo_hyper* hp) {
   V4L_REQUIRE(tr && tr->bound, "v4l_trainer: not bound");
-  V4L_REQUIRE(ro && hp && stats && n > 1, "v4l_trainer: bad argument (n must be > 1)");
+  V4L_REQUIRE(ro && hp && n > 1 && n <= tr->n_max, "v4l_trainer: bad argument (need 1 < n <= n_max)");
   V4L_REQUIRE(ro->state_dev && ro->acts_dev && ro->advs_dev && ro->rets_dev, "v4l_trainer: rollout arrays missing");
   V4L_REQUIRE(tr->pf->cfg.kind == V4L_NET_MLP || ro->image_dev, "v4l_trainer: rollout image array missing");
   V4L_REQUIRE(!hp->clipped_value_loss || ro->values_dev, "v4l_trainer: clipped_value_loss needs values_dev");
@@ -959,57 +1071,57 @@ static int check_update_args(const v4l_trainer* tr, const v4l_rollout* ro, int n
   return 0;
 }
 
-int v4l_trainer_critic_grads(v4l_trainer* tr, const v4l_rollout* ro, const int* rowidx_dev, int n,
-                             const v4l_ppo_hyper* hp, float* st, void* stream) {
-  int rc = check_update_args(tr, ro, n, hp, st);
+int v4l_trainer_critic_grads(v4l_trainer* tr, const v4l_rollout* ro, int n, const v4l_ppo_hyper* hp, void* stream) {
+  int rc = check_update_args(tr, ro, n, hp);
   if (rc) return rc;
   hipStream_t s = (hipStream_t)stream;
   v4l_net* vf = tr->vf;
-  V4L_HIP_CHECK(hipMemsetAsync(st, 0, V4L_STATS * sizeof(float), s));
+  float* st = tr->stats_cur;
+  const int* rowidx = tr->rowidx_cur;
+  g_op = "ctl";
+  V4L_KLAUNCH("upd_begin", 0, s, upd_begin_kernel, dim3(1), dim3(256), 0, s, tr->ctl, tr->rowidx_all, n, tr->rowidx_cur, st);
+  V4L_LAUNCH_CHECK();
   V4L_HIP_CHECK(hipMemsetAsync(tr->g_vf, 0, (size_t)vf->total_params * sizeof(float), s));
-  V4L_KLAUNCH("adv_stats", 0, s, adv_stats_kernel, dim3(1), dim3(256), 0, s, ro->advs_dev, rowidx_dev, n, st);
+  V4L_KLAUNCH("adv_stats", 0, s, adv_stats_kernel, dim3(1), dim3(256), 0, s, ro->advs_dev, rowidx, n, st);
   V4L_LAUNCH_CHECK();
   if ((rc = v4l_net_pack(vf, stream))) return rc;
   { PhaseScope ps("vf.fwd");
-  if ((rc = v4l_net_forward(vf, ro->state_dev, ro->image_dev, rowidx_dev, n, tr->ws, 1, stream))) return rc; }
+  if ((rc = v4l_net_forward(vf, ro->state_dev, ro->image_dev, rowidx, n, tr->ws, 1, stream))) return rc; }
   const Layout L = vf->layout(n);
   const float inv_n = 1.f / ((float)n * (float)hp->world_size);
+  g_op = "loss";
   V4L_KLAUNCH("critic_loss", 0, s, critic_loss_kernel, dim3(1), dim3(256), 0, s, tr->ws + L.out, ro->rets_dev, ro->values_dev,
-                     rowidx_dev, n, inv_n, hp->clipped_value_loss, hp->clip_para, tr->ws + L.dout, st);
+                     rowidx, n, inv_n, hp->clipped_value_loss, hp->clip_para, tr->ws + L.dout, st);
   V4L_LAUNCH_CHECK();
   PhaseScope ps("vf.bwd");
-  return v4l_net_backward(vf, ro->state_dev, ro->image_dev, rowidx_dev, n, tr->ws, tr->g_vf, stream);
+  return v4l_net_backward(vf, ro->state_dev, ro->image_dev, rowidx, n, tr->ws, tr->g_vf, stream);
 }
 
-static int adam_step(v4l_net* net, float* g, float* m, float* v, const v4l_ppo_hyper* hp, double lr, int64_t step,
+static int adam_step(v4l_trainer* tr, v4l_net* net, float* g, float* m, float* v, const v4l_ppo_hyper* hp, int which,
                      float* sumsq, float* norm_out, hipStream_t s) {
-  V4L_REQUIRE(step >= 1, "v4l_trainer: Adam step count starts at 1");
-  const int gb = (int)std::min<int64_t>(1024, cdiv64(net->total_params, 256));
+  const int gb = (int)std::min<int64_t>(64, cdiv64(net->total_params, 256));  // one atomic per block on one address
+  g_op = "optim";
   V4L_KLAUNCH("grad_sumsq", 0, s, grad_sumsq_kernel, dim3(gb), dim3(256), 0, s, g, net->total_params, sumsq);
   V4L_LAUNCH_CHECK();
-  // scalar prep in double, like torch/optim/adam.py::_single_tensor_adam
-  const double bc1 = 1.0 - pow((double)hp->beta1, (double)step);
-  const double bc2 = 1.0 - pow((double)hp->beta2, (double)step);
-  const float step_size = (float)(lr / bc1);
-  const float bc2_sqrt = (float)sqrt(bc2);
   V4L_KLAUNCH("clip_adam", 0, s, clip_adam_kernel, dim3((unsigned)net->seg_blocks), dim3(256), 0, s, net->d_segs,
-                     (int)net->params.size(), g, m, v, sumsq, 1.f, hp->max_grad_norm, hp->beta1, hp->beta2, hp->eps,
-                     step_size, bc2_sqrt, norm_out);
+              (int)net->params.size(), g, m, v, sumsq, hp->max_grad_norm, hp->eps, tr->ctl, which, norm_out);
   V4L_LAUNCH_CHECK();
   return 0;
 }
 
-int v4l_trainer_critic_step(v4l_trainer* tr, const v4l_ppo_hyper* hp, double lr, int64_t step, float* st, void* stream) {
-  V4L_REQUIRE(tr && tr->bound && hp && st, "v4l_trainer_critic_step: bad argument");
-  return adam_step(tr->vf, tr->g_vf, tr->m_vf, tr->v_vf, hp, lr, step, st + ST_SUMSQ_VF, st + ST_GN_VF, (hipStream_t)stream);
+int v4l_trainer_critic_step(v4l_trainer* tr, const v4l_ppo_hyper* hp, void* stream) {
+  V4L_REQUIRE(tr && tr->bound && hp, "v4l_trainer_critic_step: bad argument");
+  float* st = tr->stats_cur;
+  return adam_step(tr, tr->vf, tr->g_vf, tr->m_vf, tr->v_vf, hp, 1, st + ST_SUMSQ_VF, st + ST_GN_VF, (hipStream_t)stream);
 }
 
-int v4l_trainer_actor_grads(v4l_trainer* tr, const v4l_rollout* ro, const int* rowidx_dev, int n,
-                            const v4l_ppo_hyper* hp, float* st, void* stream) {
-  int rc = check_update_args(tr, ro, n, hp, st);
+int v4l_trainer_actor_grads(v4l_trainer* tr, const v4l_rollout* ro, int n, const v4l_ppo_hyper* hp, void* stream) {
+  int rc = check_update_args(tr, ro, n, hp);
   if (rc) return rc;
   hipStream_t s = (hipStream_t)stream;
   v4l_net *pf = tr->pf, *tp = tr->tpf;
+  float* st = tr->stats_cur;
+  const int* rowidx = tr->rowidx_cur;
   if (hp->world_size > 1) {
     hipLaunchKernelGGL(adv_stats_finalize_kernel, dim3(1), dim3(1), 0, s, st);
     V4L_LAUNCH_CHECK();
@@ -1019,32 +1131,78 @@ int v4l_trainer_actor_grads(v4l_trainer* tr, const v4l_rollout* ro, const int* r
   float* ws_t = tr->ws + std::max(Lp.total, tr->vf->layout(n).total);
   // frozen target policy: packed once per epoch by v4l_trainer_sync_target
   { PhaseScope ps("tpf.fwd");
-  if ((rc = v4l_net_forward(tp, ro->state_dev, ro->image_dev, rowidx_dev, n, ws_t, 0, stream))) return rc; }
+  if ((rc = v4l_net_forward(tp, ro->state_dev, ro->image_dev, rowidx, n, ws_t, 0, stream))) return rc; }
   if ((rc = v4l_net_pack(pf, stream))) return rc;  // the critic step moved the shared encoder
   { PhaseScope ps("pf.fwd");
-  if ((rc = v4l_net_forward(pf, ro->state_dev, ro->image_dev, rowidx_dev, n, tr->ws, 1, stream))) return rc; }
+  if ((rc = v4l_net_forward(pf, ro->state_dev, ro->image_dev, rowidx, n, tr->ws, 1, stream))) return rc; }
   const float inv_n = 1.f / ((float)n * (float)hp->world_size);
+  g_op = "loss";
   V4L_KLAUNCH("actor_loss", 0, s, actor_loss_kernel, dim3(1), dim3(256), 0, s, tr->ws + Lp.out, pf->p[pf->logstd], ws_t + Lt.out,
-                     tp->p[tp->logstd], ro->acts_dev, ro->advs_dev, rowidx_dev, n, pf->cfg.out_dim, inv_n, hp->clip_para,
+                     tp->p[tp->logstd], ro->acts_dev, ro->advs_dev, rowidx, n, pf->cfg.out_dim, inv_n, hp->clip_para,
                      hp->entropy_coeff, tr->ws + Lp.dout, tr->g_pf + pf->params[pf->logstd].goff, st);
   V4L_LAUNCH_CHECK();
   PhaseScope ps("pf.bwd");
-  return v4l_net_backward(pf, ro->state_dev, ro->image_dev, rowidx_dev, n, tr->ws, tr->g_pf, stream);
+  return v4l_net_backward(pf, ro->state_dev, ro->image_dev, rowidx, n, tr->ws, tr->g_pf, stream);
 }
 
-int v4l_trainer_actor_step(v4l_trainer* tr, const v4l_ppo_hyper* hp, double lr, int64_t step, float* st, void* stream) {
-  V4L_REQUIRE(tr && tr->bound && hp && st, "v4l_trainer_actor_step: bad argument");
-  return adam_step(tr->pf, tr->g_pf, tr->m_pf, tr->v_pf, hp, lr, step, st + ST_SUMSQ_PF, st + ST_GN_PF, (hipStream_t)stream);
+int v4l_trainer_actor_step(v4l_trainer* tr, const v4l_ppo_hyper* hp, void* stream) {
+  V4L_REQUIRE(tr && tr->bound && hp, "v4l_trainer_actor_step: bad argument");
+  hipStream_t s = (hipStream_t)stream;
+  float* st = tr->stats_cur;
+  int rc = adam_step(tr, tr->pf, tr->g_pf, tr->m_pf, tr->v_pf, hp, 0, st + ST_SUMSQ_PF, st + ST_GN_PF, s);
+  if (rc) return rc;
+  g_op = "ctl";
+  V4L_KLAUNCH("upd_end", 0, s, upd_end_kernel, dim3(1), dim3(64), 0, s, tr->ctl, st, tr->stats_all);
+  V4L_LAUNCH_CHECK();
+  return 0;
+}
+
+static int run_update(v4l_trainer* tr, const v4l_rollout* ro, int n, const v4l_ppo_hyper* hp, void* stream) {
+  int rc;
+  if ((rc = v4l_trainer_critic_grads(tr, ro, n, hp, stream))) return rc;
+  if ((rc = v4l_trainer_critic_step(tr, hp, stream))) return rc;
+  if ((rc = v4l_trainer_actor_grads(tr, ro, n, hp, stream))) return rc;
+  return v4l_trainer_actor_step(tr, hp, stream);
+}
+
+int v4l_trainer_update_next(v4l_trainer* tr, const v4l_rollout* ro, int n, const v4l_ppo_hyper* hp, int use_graph,
+                            void* stream) {
+  int rc = check_update_args(tr, ro, n, hp);
+  if (rc) return rc;
+  hipStream_t s = (hipStream_t)stream;
+  if (!use_graph || g_prof || s == nullptr) return run_update(tr, ro, n, hp, stream);
+  // the captured launch sequence is specific to (rollout pointers, n, hyper-parameters)
+  GraphKey key;
+  memset(&key, 0, sizeof(key));
+  key.ro = *ro; key.hp = *hp; key.n = n;
+  if (memcmp(&key, &tr->gkey, sizeof(key)) != 0) { drop_graph(tr); tr->gkey = key; }
+  if (!tr->warm) {  // first update of a configuration runs eagerly: it uploads the descriptor tables
+    tr->warm = true;
+    return run_update(tr, ro, n, hp, stream);
+  }
+  if (tr->gexec == nullptr) {
+    hipGraph_t graph = nullptr;
+    V4L_HIP_CHECK(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+    rc = run_update(tr, ro, n, hp, stream);
+    const hipError_t e = hipStreamEndCapture(s, &graph);
+    if (rc) { if (graph) (void)hipGraphDestroy(graph); return rc; }
+    V4L_HIP_CHECK(e);
+    V4L_HIP_CHECK(hipGraphInstantiate(&tr->gexec, graph, nullptr, nullptr, 0));
+    V4L_HIP_CHECK(hipGraphDestroy(graph));
+  }
+  V4L_HIP_CHECK(hipGraphLaunch(tr->gexec, s));
+  return 0;
 }
 
 int v4l_trainer_update(v4l_trainer* tr, const v4l_rollout* ro, const int* rowidx_dev, int n, const v4l_ppo_hyper* hp,
-                       double lr_pf, double lr_vf, int64_t step, float* st, void* stream) {
-  int rc;
-  if ((rc = v4l_trainer_critic_grads(tr, ro, rowidx_dev, n, hp, st, stream))) return rc;
-  if ((rc = v4l_trainer_critic_step(tr, hp, lr_vf, step, st, stream))) return rc;
-  if ((rc = v4l_trainer_actor_grads(tr, ro, rowidx_dev, n, hp, st, stream))) return rc;
-  return v4l_trainer_actor_step(tr, hp, lr_pf, step, st, stream);
+                       double lr_pf, double lr_vf, int64_t step, float* stats_dev, void* stream) {
+  V4L_REQUIRE(step >= 1, "v4l_trainer_update: Adam step count starts at 1");
+  int rc = v4l_trainer_begin(tr, rowidx_dev, stats_dev, lr_pf, lr_vf, step - 1, hp, stream);
+  if (rc) return rc;
+  return v4l_trainer_update_next(tr, ro, n, hp, 0, stream);
 }
+
+float* v4l_trainer_stats_cur(const v4l_trainer* tr) { return tr ? tr->stats_cur : nullptr; }
 
 int v4l_trainer_sync_target(v4l_trainer* tr, void* stream) {
   V4L_REQUIRE(tr && tr->pf->bound && tr->tpf->bound, "v4l_trainer_sync_target: nets are not bound");

@@ -236,11 +236,12 @@ class HipNet:
 
 
 class HipTrainer:
-  """PPO minibatch update over (pf, vf, target_pf): owns the flat grad/Adam buffers, the shared workspace and
-  the per-update statistics records. Mirrors PPO.update of torchrl/algo/on_policy/ppo.py:125-153."""
+  """PPO minibatch update over (pf, vf, target_pf): owns the flat grad/Adam buffers, the shared workspace, the
+  device control block and the side stream the update graph is captured on. Mirrors PPO.update of
+  torchrl/algo/on_policy/ppo.py:125-153."""
 
   def __init__(self, pf_net, vf_net, tpf_net, batch, clip_para, entropy_coeff, max_grad_norm=0.5,
-               betas=(0.9, 0.999), eps=1e-5, clipped_value_loss=False, world_size=1):
+               betas=(0.9, 0.999), eps=1e-5, clipped_value_loss=False, world_size=1, g_vf=None):
     self.pf, self.vf, self.tpf = pf_net, vf_net, tpf_net
     self.L = _lib.lib()
     for net in (pf_net, vf_net, tpf_net):
@@ -252,12 +253,15 @@ class HipTrainer:
     dev = self.device
     z = lambda n: torch.zeros(n, dtype=torch.float32, device=dev)
     self.g_pf, self.m_pf, self.v_pf = z(pf_net.total_params), z(pf_net.total_params), z(pf_net.total_params)
-    self.g_vf, self.m_vf, self.v_vf = z(vf_net.total_params), z(vf_net.total_params), z(vf_net.total_params)
+    self.g_vf = g_vf if g_vf is not None else z(vf_net.total_params)
+    self.m_vf, self.v_vf = z(vf_net.total_params), z(vf_net.total_params)
     self.batch = 0
+    self.stream = torch.cuda.Stream(device=dev)  # hipGraph capture needs a non-default stream
     self._alloc_ws(batch)
     self.hp = PPOHyper(clip_para, entropy_coeff, max_grad_norm, betas[0], betas[1], eps,
                        int(bool(clipped_value_loss)), int(world_size))
-    self.step = 0  # Adam step count (both optimisers step once per update)
+    self.step = 0  # Adam steps taken (both optimisers step once per update)
+    self._one_stats = torch.zeros(V4L_STATS, dtype=torch.float32, device=dev)
 
   def __del__(self):
     try:
@@ -272,9 +276,10 @@ class HipTrainer:
       return
     self.batch = n
     self.ws = torch.empty(self.L.v4l_trainer_ws_floats(self.h, n), dtype=torch.float32, device=self.device)
+    self.ctl = torch.zeros(self.L.v4l_trainer_ctl_bytes(self.h, n), dtype=torch.uint8, device=self.device)
     check(self.L.v4l_trainer_bind(self.h, _ptr(self.g_pf), _ptr(self.m_pf), _ptr(self.v_pf), _ptr(self.g_vf),
-                                  _ptr(self.m_vf), _ptr(self.v_vf), _ptr(self.ws), self.ws.numel(), _stream()),
-          "v4l_trainer_bind")
+                                  _ptr(self.m_vf), _ptr(self.v_vf), _ptr(self.ws), self.ws.numel(), _ptr(self.ctl), n,
+                                  _stream()), "v4l_trainer_bind")
 
   @staticmethod
   def rollout(state, image, acts, advs, rets, values=None):
@@ -297,37 +302,51 @@ class HipTrainer:
     if self.tpf._dirty:
       self.tpf.pack_if_needed()
 
-  def update(self, ro, rowidx, n, lr_pf, lr_vf, stats):
-    """One PPO.update on minibatch rows rowidx (int32 device tensor or None). stats: [V4L_STATS] device floats."""
-    self._pre(n)
-    self.step += 1
-    check(self.L.v4l_trainer_update(self.h, C.byref(ro), _ptr(rowidx), n, C.byref(self.hp), lr_pf, lr_vf, self.step,
-                                    _ptr(stats), _stream()), "v4l_trainer_update")
-    self._after_steps()
-
   def _after_steps(self):
     # the library repacks pf/vf itself at the start of every grads phase; other users of the nets must repack
     for net in (self.pf, self.vf):
       net.mark_dirty()
 
-  # phases, for the data-parallel schedule (all-reduce between grads and step)
-  def critic_grads(self, ro, rowidx, n, stats):
-    self._pre(n)
-    check(self.L.v4l_trainer_critic_grads(self.h, C.byref(ro), _ptr(rowidx), n, C.byref(self.hp), _ptr(stats), _stream()),
-          "v4l_trainer_critic_grads")
+  def begin(self, rowidx_all, stats_all, lr_pf, lr_vf):
+    """Open a run of updates on rows rowidx_all[u] (int32 [U][n] device tensor or None) -> stats_all[u]."""
+    self._run = (rowidx_all, stats_all)  # keep alive
+    check(self.L.v4l_trainer_begin(self.h, _ptr(rowidx_all), _ptr(stats_all), float(lr_pf), float(lr_vf), self.step,
+                                   C.byref(self.hp), _stream()), "v4l_trainer_begin")
 
-  def critic_step(self, lr, stats):
-    check(self.L.v4l_trainer_critic_step(self.h, C.byref(self.hp), lr, self.step + 1, _ptr(stats), _stream()),
-          "v4l_trainer_critic_step")
+  def update_next(self, ro, n, graph=True):
+    self._pre(n)
+    check(self.L.v4l_trainer_update_next(self.h, C.byref(ro), n, C.byref(self.hp), int(graph), _stream()),
+          "v4l_trainer_update_next")
+    self.step += 1
+    self._after_steps()
+
+  def update(self, ro, rowidx, n, lr_pf, lr_vf, stats):
+    """One eager PPO.update on minibatch rows rowidx (int32 device tensor or None); stats: [V4L_STATS] floats."""
+    self._pre(n)
+    self.begin(rowidx, stats, lr_pf, lr_vf)
+    self.update_next(ro, n, graph=False)
+
+  # phases, for the data-parallel schedule (all-reduce between grads and step); begin() first
+  def stats_cur(self):
+    if getattr(self, "_stats_cur", None) is None or self._stats_cur_ctl is not self.ctl:
+      off = 256  # layout of the control buffer: [UpdCtl | stats_cur | rowidx_cur]
+      self._stats_cur = self.ctl[off:off + 4 * V4L_STATS].view(torch.float32)
+      self._stats_cur_ctl = self.ctl
+    return self._stats_cur
+
+  def critic_grads(self, ro, n):
+    self._pre(n)
+    check(self.L.v4l_trainer_critic_grads(self.h, C.byref(ro), n, C.byref(self.hp), _stream()), "v4l_trainer_critic_grads")
+
+  def critic_step(self):
+    check(self.L.v4l_trainer_critic_step(self.h, C.byref(self.hp), _stream()), "v4l_trainer_critic_step")
     self.vf.mark_dirty(); self.pf.mark_dirty()
 
-  def actor_grads(self, ro, rowidx, n, stats):
-    check(self.L.v4l_trainer_actor_grads(self.h, C.byref(ro), _ptr(rowidx), n, C.byref(self.hp), _ptr(stats), _stream()),
-          "v4l_trainer_actor_grads")
+  def actor_grads(self, ro, n):
+    check(self.L.v4l_trainer_actor_grads(self.h, C.byref(ro), n, C.byref(self.hp), _stream()), "v4l_trainer_actor_grads")
 
-  def actor_step(self, lr, stats):
-    check(self.L.v4l_trainer_actor_step(self.h, C.byref(self.hp), lr, self.step + 1, _ptr(stats), _stream()),
-          "v4l_trainer_actor_step")
+  def actor_step(self):
+    check(self.L.v4l_trainer_actor_step(self.h, C.byref(self.hp), _stream()), "v4l_trainer_actor_step")
     self.step += 1
     self._after_steps()
 
@@ -342,7 +361,8 @@ def gae(rewards, values, terminals, time_limits, last_value, gamma, tau, use_tim
   r32 = torch.empty_like(a32) if want32 else None
   tl_per_env = int(time_limits is not None and time_limits.dim() == 2 and time_limits.shape[1] == E and E > 1
                    or (time_limits is not None and time_limits.numel() == T * E and E == 1))
+  scratch = torch.empty(3 * T * E, dtype=torch.float64, device=rewards.device)
   check(L.v4l_gae(_ptr(rewards), _ptr(values), _ptr(terminals), _ptr(time_limits), tl_per_env, _ptr(last_value), T, E,
-                  float(gamma), float(tau), int(bool(use_time_limit)), _ptr(advs), _ptr(rets), _ptr(a32), _ptr(r32),
-                  _stream()), "v4l_gae")
+                  float(gamma), float(tau), int(bool(use_time_limit)), _ptr(scratch), _ptr(advs), _ptr(rets), _ptr(a32),
+                  _ptr(r32), _stream()), "v4l_gae")
   return advs, rets, a32, r32

@@ -108,15 +108,15 @@ class PPO:
                 torch.distributed.broadcast(p.data, src=0)
             atu.copy_model_params_from_to(self.pf, self.target_pf)
         with torch.cuda.device(self.device):
+            g_vf = None
+            if self.world_size > 1:
+                # one buffer per all-reduce: critic grads + (sum adv, sum adv^2, count) in the tail
+                self._vf_bucket = torch.zeros(self.vf.hip.total_params + 3, dtype=torch.float32, device=self.device)
+                g_vf = self._vf_bucket[:self.vf.hip.total_params]
             self.trainer = HipTrainer(self.pf.hip, self.vf.hip, self.target_pf.hip, batch_size, clip_para,
                                       entropy_coeff, max_grad_norm=0.5, clipped_value_loss=clipped_value_loss,
-                                      world_size=self.world_size)
-        if self.world_size > 1:
-            # one buffer per all-reduce: critic grads + (sum adv, sum adv^2, count)
-            self._vf_bucket = torch.zeros(self.vf.hip.total_params + 3, dtype=torch.float32, device=self.device)
-            self.trainer.g_vf = self._vf_bucket[:self.vf.hip.total_params]
-            self.trainer.batch = 0
-            self.trainer._alloc_ws(batch_size)
+                                      world_size=self.world_size, g_vf=g_vf)
+        self.use_graph = os.environ.get("V4L_GRAPH", "1") != "0"
         if isinstance(replay_buffer, rb.DeviceOnPolicyReplayBuffer):
             replay_buffer.attach(self.pf.hip, self.device)
         elif replay_buffer is not None:
@@ -191,28 +191,41 @@ class PPO:
                 batches.append(b["rowidx"])
         rowidx = torch.from_numpy(np.stack(batches)).to(self.device)  # one upload per epoch
         stats = torch.zeros(len(batches), _lib.V4L_STATS, dtype=torch.float32, device=self.device)
-        for i in range(len(batches)):
-            self.training_update_num += 1
-            self._update_rows(ro, rowidx[i], rowidx.shape[1], stats[i])
+        self.run_updates(ro, rowidx, stats)
         host = stats.cpu().numpy()  # the only device->host sync of the epoch's updates
         for row in host:
             self.logger.add_update_info({k: float(row[j]) for j, k in enumerate(_lib.STAT_KEYS)})
 
-    def _update_rows(self, ro, rowidx, n, stats):
-        lr_pf, lr_vf = self.pf_optimizer.lr, self.vf_optimizer.lr
+    def run_updates(self, ro, rowidx, stats):
+        """All minibatch updates of an epoch: rowidx [U][n] int32 (device), stats [U][V4L_STATS] (device).
+        Single GPU: each update is one hipGraph replay on the trainer's stream. Data parallel: four eager
+        phases per update with one RCCL all-reduce per optimiser step."""
         tr = self.trainer
-        if self.world_size == 1:
-            tr.update(ro, rowidx, n, lr_pf, lr_vf, stats)
-            return
+        U, n = rowidx.shape
+        cur = torch.cuda.current_stream(self.device)
+        tr.stream.wait_stream(cur)
+        with torch.cuda.stream(tr.stream):
+            tr.begin(rowidx, stats, self.pf_optimizer.lr, self.vf_optimizer.lr)
+            for _ in range(U):
+                self.training_update_num += 1
+                if self.world_size == 1:
+                    tr.update_next(ro, n, graph=self.use_graph)
+                else:
+                    self._update_phases(ro, n)
+        cur.wait_stream(tr.stream)
+
+    def _update_phases(self, ro, n):
         dist = torch.distributed
-        tr.critic_grads(ro, rowidx, n, stats)
-        self._vf_bucket[-3:].copy_(stats[18:21])
+        tr = self.trainer
+        st = tr.stats_cur()
+        tr.critic_grads(ro, n)
+        self._vf_bucket[-3:].copy_(st[18:21])
         dist.all_reduce(self._vf_bucket)  # RCCL sum over env shards: critic grads + adv sums
-        stats[18:21].copy_(self._vf_bucket[-3:])
-        tr.critic_step(lr_vf, stats)
-        tr.actor_grads(ro, rowidx, n, stats)
+        st[18:21].copy_(self._vf_bucket[-3:])
+        tr.critic_step()
+        tr.actor_grads(ro, n)
         dist.all_reduce(tr.g_pf)
-        tr.actor_step(lr_pf, stats)
+        tr.actor_step()
 
     def update(self, batch):
         """One minibatch update from a reference-style host batch (ppo.py:125-153). Returns the 18-key info."""
@@ -234,9 +247,15 @@ class PPO:
             rets = up(batch["estimate_returns"]).reshape(n)
             vals = up(batch["values"]).reshape(n)
             ro = HipTrainer.rollout(self._stage[0], self._stage[1], acts, advs, rets, vals)
-            stats = torch.zeros(_lib.V4L_STATS, dtype=torch.float32, device=dev)
-            self._update_rows(ro, None, n, stats)
-            host = stats.cpu().numpy()
+            stats = torch.zeros(1, _lib.V4L_STATS, dtype=torch.float32, device=dev)
+            tr = self.trainer
+            if self.world_size == 1:
+                tr.update(ro, None, n, self.pf_optimizer.lr, self.vf_optimizer.lr, stats)
+            else:
+                tr._pre(n)
+                tr.begin(None, stats, self.pf_optimizer.lr, self.vf_optimizer.lr)
+                self._update_phases(ro, n)
+            host = stats[0].cpu().numpy()
         return {k: float(host[j]) for j, k in enumerate(_lib.STAT_KEYS)}
 
     # ---- outer loop (rl_algo.py:97-168) ----------------------------------------------------------------

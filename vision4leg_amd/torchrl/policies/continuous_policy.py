@@ -53,7 +53,9 @@ class GaussianContPolicyBase:
 
     def explore(self, x, return_log_probs=False, return_pre_tanh=False):
         mean, std, log_std, ent, _ = self._gaussian(x)
-        action = torch.normal(mean, std)  # == Normal(mean, std).sample(): same generator, same draw order
+        # == Normal(mean, std).sample(): torch.normal(mean, std) is randn * std + mean on the same generator;
+        # spelled out it skips normal()'s `std >= 0` validation (a reduction + a device->host sync per step)
+        action = torch.addcmul(mean, std, torch.randn_like(mean))
         dic = {"mean": mean, "log_std": log_std, "std": std, "ent": ent}
         if return_log_probs:
             A = mean.shape[-1]
