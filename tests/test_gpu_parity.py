@@ -354,4 +354,6 @@ def test_graph_replay_equals_eager(mode, device):
                                  1e-4, 1e-4)
             for j, k in enumerate(util.STAT_KEYS):
                 assert abs(sg[u, j] - info[k]) <= 1e-3 * max(1.0, abs(info[k])), (u, k, sg[u, j], info[k])
-        assert max((pg[k] - opf[k]).abs().max().item() for k in pg) <= 3e-5
+        # five Adam steps of ~lr*sign(g) each: elements whose tiny gradient flips sign drift by up to 2*lr per step
+        assert max((pg[k] - opf[k]).abs().max().item() for k in pg) <= 5e-4
+        assert sum((pg[k] - opf[k]).abs().sum().item() for k in pg) / sum(v.numel() for v in pg.values()) <= 2e-6

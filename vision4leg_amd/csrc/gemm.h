@@ -43,6 +43,14 @@ __device__ __forceinline__ void ld8(const __bf16* p, float (&v)[8]) {
   for (int j = 0; j < 4; ++j) { v[j] = (float)x[j]; v[4 + j] = (float)y[j]; }
 }
 
+// hipcc turns "cond ? load : 0" into a branch around the load plus an s_waitcnt vmcnt(0) per element, which
+// serialises every load of an unrolled batch behind the previous one. All loaders therefore ALWAYS load (from
+// offset 0 of their array when the element is out of range) and select afterwards.
+__device__ __forceinline__ void keep8(float (&v)[8], bool ok) {
+#pragma unroll
+  for (int j = 0; j < 8; ++j) v[j] = ok ? v[j] : 0.f;
+}
+
 // ------------------------------------------------------------------------------------ loaders
 // Dense fp32 row-major matrix. lda % 4 == 0, K % 8 == 0, base 16-byte aligned.
 // rowidx: optional gather (minibatch row -> rollout slot). tokmap: 1 = rows are the 16 depth tokens
@@ -59,27 +67,30 @@ struct ADense {
     rc.a = rc.b = 0;
     int r = m;
     if (tokmap == 1) r = (m >> 4) * 17 + 1 + (m & 15);
-    if (rowidx != nullptr && rc.valid) r = rowidx[m];
+    if (rowidx != nullptr) r = rowidx[rc.valid ? m : 0];
     rc.base = (int64_t)r * lda;
     return rc;
   }
   __device__ __forceinline__ void load(const RowCtx& rc, int k0, float (&v)[8]) const {
-    if (rc.valid && k0 < K) {
-      ld8(p + rc.base + k0, v);
-      if (mask != nullptr) {
-        float mk[8];
-        ld8(mask + rc.base + k0, mk);
+    const bool ok = rc.valid && k0 < K;
+    const int64_t off = ok ? rc.base + k0 : 0;
+    ld8(p + off, v);
+    if (mask != nullptr) {
+      float mk[8];
+      ld8(mask + off, mk);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] = mk[j] > 0.f ? v[j] : 0.f;
-      }
-    } else zero8(v);
+      for (int j = 0; j < 8; ++j) v[j] = mk[j] > 0.f ? v[j] : 0.f;
+    }
+    keep8(v, ok);
   }
   // separable form used by the weight-grad kernel: address = row_off(m) + col_off(k)
   __device__ __forceinline__ int64_t row_off(int m, int& valid) const { RowCtx rc = row(m); valid = rc.valid; return rc.base; }
   __device__ __forceinline__ int64_t col_off(int k, int& valid) const { valid = k < K; return k; }
   __device__ __forceinline__ float get(int64_t off) const {
     const float v = p[off];
-    return (mask == nullptr || mask[off] > 0.f) ? v : 0.f;
+    if (mask == nullptr) return v;  // uniform branch
+    const float mk = mask[off];
+    return mk > 0.f ? v : 0.f;
   }
 };
 
@@ -99,15 +110,16 @@ struct AIm2colCHW {
     const int opix = OH * OW;
     int b = m / opix, q = m - b * opix;
     int oy = q / OW, ox = q - oy * OW;
-    if (rowidx != nullptr && rc.valid) b = rowidx[b];
+    if (rowidx != nullptr) b = rowidx[rc.valid ? b : 0];
     rc.a = oy; rc.b = ox;
     rc.base = (int64_t)b * C * IH * IW + (int64_t)(oy * stride) * IW + ox * stride;
     return rc;
   }
   __device__ __forceinline__ void load(const RowCtx& rc, int k0, float (&v)[8]) const {
     const int c = k0 >> 6, ky = (k0 >> 3) & 7;
-    if (rc.valid && c < C) ld8(p + rc.base + (int64_t)c * IH * IW + ky * IW, v);
-    else zero8(v);
+    const bool ok = rc.valid && c < C;
+    ld8(p + (ok ? rc.base + (int64_t)c * IH * IW + ky * IW : 0), v);
+    keep8(v, ok);
   }
   __device__ __forceinline__ int64_t row_off(int m, int& valid) const { RowCtx rc = row(m); valid = rc.valid; return rc.base; }
   __device__ __forceinline__ int64_t col_off(int k, int& valid) const {
@@ -135,11 +147,11 @@ struct AIm2colNHWC {
     return rc;
   }
   __device__ __forceinline__ void load(const RowCtx& rc, int k0, float (&v)[8]) const {
-    if (rc.valid && k0 < K) {
-      const int tap = k0 / Cin, c0 = k0 - tap * Cin;
-      const int ky = tap / KW, kx = tap - ky * KW;
-      ld8(p + rc.base + (int64_t)(ky * IW + kx) * Cin + c0, v);
-    } else zero8(v);
+    const bool ok = rc.valid && k0 < K;
+    const int tap = k0 / Cin, c0 = k0 - tap * Cin;
+    const int ky = tap / KW, kx = tap - ky * KW;
+    ld8(p + (ok ? rc.base + (int64_t)(ky * IW + kx) * Cin + c0 : 0), v);
+    keep8(v, ok);
   }
   __device__ __forceinline__ int64_t row_off(int m, int& valid) const { RowCtx rc = row(m); valid = rc.valid; return rc.base; }
   __device__ __forceinline__ int64_t col_off(int k, int& valid) const {
@@ -170,16 +182,12 @@ struct ADgradNHWC {
     return rc;
   }
   __device__ __forceinline__ void load(const RowCtx& rc, int k0, float (&v)[8]) const {
-    if (rc.valid && k0 < K) {
-      const int tap = k0 / Cout, n0 = k0 - tap * Cout;
-      const int a = tap / TW, bb = tap - a * TW;
-      const int oy = rc.a - a, ox = rc.b - bb;
-      if (oy >= 0 && oy < OH && ox >= 0 && ox < OW) {
-        ld8(p + rc.base + (int64_t)(oy * OW + ox) * Cout + n0, v);
-        return;
-      }
-    }
-    zero8(v);
+    const int tap = k0 / Cout, n0 = k0 - tap * Cout;
+    const int a = tap / TW, bb = tap - a * TW;
+    const int oy = rc.a - a, ox = rc.b - bb;
+    const bool ok = rc.valid && k0 < K && oy >= 0 && oy < OH && ox >= 0 && ox < OW;
+    ld8(p + (ok ? rc.base + (int64_t)(oy * OW + ox) * Cout + n0 : 0), v);
+    keep8(v, ok);
   }
 };
 
@@ -305,27 +313,52 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(AL al, const T* __restrict
     __syncthreads();
   }
 
-  // epilogue: acc[i][j][r] is C[m0 + 32*wave + 16*i + 4*(lane>>4) + r][n0 + 16*j + (lane&15)]
+  // epilogue: acc[i][j][r] is C[m0 + 32*wave + 16*i + 4*(lane>>4) + r][n0 + 16*j + (lane&15)].
+  // Loads (bias, ReLU mask, accumulate target) are issued as one batch from always-valid addresses and waited for
+  // once; only the stores are predicated (see keep8 for why).
+  float bv[NT];
+  bool nok[NT];
+#pragma unroll
+  for (int j = 0; j < NT; ++j) {
+    const int n = n0 + j * 16 + (lane & 15);
+    nok[j] = n < ep.N;
+    bv[j] = ep.bias != nullptr ? ep.bias[nok[j] ? n : 0] : 0.f;
+  }
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
+    int64_t orow[4];
+    bool rok[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int m = m0 + wave * 32 + i * 16 + (lane >> 4) * 4 + r;
-      if (m >= ep.M) continue;
-      const int64_t orow = ep.out_row(m);
+      rok[r] = m < ep.M;
+      orow[r] = ep.out_row(rok[r] ? m : 0);
+    }
+    float mk[4][NT], old[4][NT];
+    if (ep.mask != nullptr) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+          mk[r][j] = ep.mask[(rok[r] && nok[j]) ? orow[r] * ep.ldmask + n0 + j * 16 + (lane & 15) : 0];
+    }
+    if (ep.accumulate) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+          old[r][j] = ep.C[(rok[r] && nok[j]) ? orow[r] * ep.ldc + n0 + j * 16 + (lane & 15) : 0];
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
 #pragma unroll
       for (int j = 0; j < NT; ++j) {
-        const int n = n0 + j * 16 + (lane & 15);
-        if (n >= ep.N) continue;
-        float v = acc[i][j][r];
-        if (ep.bias != nullptr) v += ep.bias[n];
+        float v = acc[i][j][r] + bv[j];
         if (ep.relu) v = fmaxf(v, 0.f);
-        if (ep.mask != nullptr) v = (ep.mask[orow * ep.ldmask + n] > 0.f) ? v : 0.f;
-        float* dst = ep.C + orow * ep.ldc + n;
-        if (ep.accumulate) v += *dst;
-        *dst = v;
+        if (ep.mask != nullptr) v = mk[r][j] > 0.f ? v : 0.f;
+        if (ep.accumulate) v += old[r][j];
+        if (rok[r] && nok[j]) ep.C[orow[r] * ep.ldc + n0 + j * 16 + (lane & 15)] = v;
       }
-    }
   }
 }
 
@@ -376,9 +409,15 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(YL yl, XL xl, int M, int m
       const int64_t yro = yl.row_off(m, vy);
       const int64_t xro = xl.row_off(m, vx);
       const bool in = m < me;
-      yv[j] = (in && vy && yok) ? yl.get(yro + yco) : 0.f;
+      const bool oky = in && vy && yok;
+      const float ty = yl.get(oky ? yro + yco : 0);  // unconditional load, select afterwards (see keep8)
+      yv[j] = oky ? ty : 0.f;
 #pragma unroll
-      for (int i = 0; i < KT; ++i) xv[i][j] = (in && vx && xok[i]) ? xl.get(xro + xco[i]) : 0.f;
+      for (int i = 0; i < KT; ++i) {
+        const bool okx = in && vx && xok[i];
+        const float tx = xl.get(okx ? xro + xco[i] : 0);
+        xv[i][j] = okx ? tx : 0.f;
+      }
     }
   };
   auto lstore = [&]() {
@@ -471,8 +510,13 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const RedDesc* __rest
     const int n = (int)(e / d.K), k = (int)(e - (int64_t)n * d.K);
     const float* p = d.slab + (int64_t)n * d.Kpad + k;
     const int64_t stride = (int64_t)d.Npad * d.Kpad;
-    float s = 0.f;
-    for (int z = 0; z < d.nsplit; ++z) s += p[z * stride];
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int z = 0;
+    for (; z + 4 <= d.nsplit; z += 4) {
+      s0 += p[z * stride]; s1 += p[(z + 1) * stride]; s2 += p[(z + 2) * stride]; s3 += p[(z + 3) * stride];
+    }
+    for (; z < d.nsplit; ++z) s0 += p[z * stride];
+    const float s = (s0 + s1) + (s2 + s3);
     int kt = k;
     if (d.Cin != 0) { const int t = k / d.Cin, c = k - t * d.Cin; kt = c * d.taps + t; }
     d.dW[(int64_t)n * d.Ktorch + kt] = s;

@@ -95,7 +95,7 @@ static inline TnPlan tn_plan(int M, int N, int Kx) {
   p.KT = Kx >= 128 ? 2 : 1;
   p.gy = cdiv(N, p.BN);
   p.gx = cdiv(Kx, 64 * p.KT);
-  int splits = std::max(1, 512 / (p.gx * p.gy));
+  int splits = std::max(1, 256 / (p.gx * p.gy));
   splits = std::min(splits, std::max(1, M / 256));
   p.mpb = round_up(cdiv(M, splits), 64);
   p.splits = cdiv(M, p.mpb);
