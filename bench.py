@@ -98,6 +98,10 @@ class Epoch:
         self.values = torch.zeros(T * E, device=dev)
         self.stats = torch.zeros(OPT_EPOCHS * (T * E // wl["B"]), 24, device=dev)
         self.epoch = 0
+        self.actor = None
+        if os.environ.get("V4L_ACTOR", "1") != "0":
+            self.actor = policies.RolloutActor(self.pf, self.vf, E, graph=os.environ.get("V4L_GRAPH", "1") != "0")
+            self.actor.attach((self.state, self.image, self.acts, self.values))
         if wl.get("skip_rollout"):
             self.rollout()  # populate once so updates have data
 
@@ -105,7 +109,12 @@ class Epoch:
         """(i): per env step, E rows: ingest + pf.explore + vf; results stay on the device."""
         E, T = self.wl["E"], self.wl["T"]
         pf, vf, net = self.pf, self.vf, self.pf.hip
-        for t in range(T):
+        if self.actor is not None:  # fused rollout step (shared encoder pass, one graph replay per env step)
+            self.actor.seek(0)
+            for t in range(T):
+                self.actor.step(self.obs[t * E:(t + 1) * E])
+            return
+        for t in range(T):  # the reference's call protocol: pf.explore(ob) then vf(ob)
             ob = self.obs[t * E:(t + 1) * E]
             out = pf.explore(ob)
             self.acts[t * E:(t + 1) * E] = out["action"]

@@ -56,6 +56,7 @@ typedef struct v4l_net_cfg {
 
 typedef struct v4l_net v4l_net;         /* host-side plan of one network (no device memory)  */
 typedef struct v4l_trainer v4l_trainer; /* host-side plan of the PPO update over (pf, vf, target_pf) */
+typedef struct v4l_actor v4l_actor;     /* host-side plan of one rollout step: policy sample + value at batch E */
 
 const char* v4l_last_error(void);
 int v4l_version(void);
@@ -115,6 +116,23 @@ int v4l_gae(const double* rewards_dev, const double* values_dev, const double* t
             const double* time_limits_dev, int tl_per_env, const double* last_value_dev, int T, int E, double gamma,
             double tau, int use_time_limit, double* scratch_dev /* 3*T*E doubles */, double* advs_dev, double* rets_dev,
             float* advs32_dev, float* rets32_dev, void* stream);
+
+/* ---- rollout step: what VecOnPolicyCollector.take_actions asks of the networks per env step
+ * (torchrl/collector/on_policy.py:90-100): out = pf.explore(ob) and values = vf(ob) for the E observation rows of the
+ * step — as ONE captured launch sequence: ingest of the rows into rollout slots [t*E,(t+1)*E), the policy forward, the
+ * value forward (shared_encoder=1: on the policy's encoder output, the two nets hold the same encoder parameters),
+ * action = mean + std*eps, and the filing of action/value into the rollout arrays. The step cursor t lives on the
+ * device (v4l_actor_seek sets it, every step advances it). obs_dev: [E][S+C*H*W] fp32 at a FIXED address the caller
+ * refreshes each step; eps_dev: [E][A] standard-normal draws (the caller's generator). Outputs: [E][A] / [E]. ---- */
+int v4l_actor_create(v4l_net* pf, v4l_net* vf, int E, v4l_actor** out);
+void v4l_actor_destroy(v4l_actor* a);
+int64_t v4l_actor_ws_floats(const v4l_actor* a);
+int64_t v4l_actor_ctl_bytes(const v4l_actor* a);
+int v4l_actor_bind(v4l_actor* a, float* ws_dev, void* ctl_dev, void* stream);
+int v4l_actor_seek(v4l_actor* a, int64_t t, void* stream);
+int v4l_actor_step(v4l_actor* a, const float* obs_dev, const float* eps_dev, float* state_roll_dev, void* image_roll_dev,
+                   float* acts_roll_dev, float* values_roll_dev, float* action_dev, float* mean_dev, float* std_dev,
+                   float* ent_dev, float* value_dev, int shared_encoder, int use_graph, void* stream);
 
 /* ---- PPO minibatch update: replaces PPO.update / update_critic / update_actor (ppo.py:42-153), the two
  * clip_grad_norm_(…, 0.5) calls and the two Adam steps (a2c.py:30-40). pf and vf may share encoder parameters

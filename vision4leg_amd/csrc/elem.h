@@ -9,6 +9,8 @@ namespace v4l {
 constexpr int NTOK = 17;   // 1 proprio token + 4x4 depth patches (torchrl/networks/base.py:544,617-622)
 constexpr int TD = 64;     // token_dim (torchrl/networks/base.py:504)
 constexpr int OUT_LD = 16; // row stride of head outputs / their grads (A=6 or 1, zero padded)
+constexpr float LOG_SIG_MAX = 2.f, LOG_SIG_MIN = -5.f;  // torchrl/policies/continuous_policy.py:8-9
+constexpr float HALF_LOG_2PI = 0.91893853320467274178f;
 
 // --------------------------------------------------------------------------------- ingest
 // Splits reference observation rows [n][S + C*H*W] (torchrl/networks/nets.py:997-1000) into the two
@@ -16,9 +18,11 @@ constexpr int OUT_LD = 16; // row stride of head outputs / their grads (A=6 or 1
 // stack [slot][C*H*W] in the contraction operand type. One block per row.
 template <typename ImgT>
 __global__ __launch_bounds__(256) void ingest_kernel(const float* __restrict__ obs, int n, int S, int Sp, int img_elems,
-                                                     float* __restrict__ state, ImgT* __restrict__ image, int64_t slot0) {
+                                                     float* __restrict__ state, ImgT* __restrict__ image, int64_t slot0,
+                                                     const long long* __restrict__ step_counter) {
   const int r = blockIdx.x;
   if (r >= n) return;
+  if (step_counter != nullptr) slot0 = (int64_t)(*step_counter) * n;  // device-side rollout cursor (actor graph)
   const float* src = obs + (int64_t)r * (S + img_elems);
   float* sdst = state + (slot0 + r) * (int64_t)Sp;
   ImgT* idst = image + (slot0 + r) * (int64_t)img_elems;
@@ -233,6 +237,47 @@ __global__ __launch_bounds__(64) void pool_bwd_kernel(const float* __restrict__ 
   for (int i = 1; i < NTOK; ++i) o[i * TD + d] = dm;
 }
 
+// --------------------------------------------------------------------------------- rollout step (actor)
+// Device-side cursor of the rollout: env step t of the epoch owns rollout slots [t*E, (t+1)*E).
+struct ActCtl { long long t; long long pad; };
+__global__ void act_set_kernel(ActCtl* c, long long t) { c->t = t; }
+__global__ __launch_bounds__(256) void act_begin_kernel(const ActCtl* __restrict__ c, int E, int* __restrict__ rowidx) {
+  const long long t = c->t;
+  for (int i = threadIdx.x; i < E; i += 256) rowidx[i] = (int)(t * E + i);
+}
+// GaussianContPolicyBase.explore (continuous_policy.py:85-125) + the value read-out of the collector
+// (collector/on_policy.py:95-100) for one env step: action = mean + std * eps (== Normal(mean,std).sample() given the
+// same standard-normal draws), entropy, value; also files action and value into the rollout arrays and advances t.
+__global__ __launch_bounds__(256) void act_finish_kernel(ActCtl* c, const float* __restrict__ meanp,
+                                                         const float* __restrict__ logstd, const float* __restrict__ valuep,
+                                                         const float* __restrict__ eps, int E, int A,
+                                                         float* __restrict__ acts_roll, float* __restrict__ values_roll,
+                                                         float* __restrict__ action, float* __restrict__ mean,
+                                                         float* __restrict__ stdv, float* __restrict__ ent,
+                                                         float* __restrict__ value) {
+  const long long t = c->t;
+  for (int i = threadIdx.x; i < E; i += 256) {
+    float e = 0.f;
+    for (int a = 0; a < A; ++a) {
+      const float ls = fminf(fmaxf(logstd[a], LOG_SIG_MIN), LOG_SIG_MAX);
+      const float sg = expf(ls);
+      e += 0.5f + HALF_LOG_2PI + logf(sg);
+      const float mu = meanp[(int64_t)i * OUT_LD + a];
+      const float act = fmaf(sg, eps[(int64_t)i * A + a], mu);
+      action[(int64_t)i * A + a] = act;
+      mean[(int64_t)i * A + a] = mu;
+      stdv[(int64_t)i * A + a] = sg;
+      if (acts_roll != nullptr) acts_roll[(t * E + i) * A + a] = act;
+    }
+    ent[i] = e;
+    const float v = valuep[(int64_t)i * OUT_LD];
+    value[i] = v;
+    if (values_roll != nullptr) values_roll[t * E + i] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) c->t = t + 1;
+}
+
 // --------------------------------------------------------------------------------- block reductions
 struct Red4 { double s, s2; float mx, mn; };
 // 256-thread block reduction of (sum, sum of squares, max, min); result valid on all threads.
@@ -338,8 +383,6 @@ __global__ __launch_bounds__(256) void critic_loss_kernel(const float* __restric
   if (threadIdx.x == 0) st[ST_VF_LOSS] = (float)(r.s * (double)inv_n);
 }
 
-constexpr float LOG_SIG_MAX = 2.f, LOG_SIG_MIN = -5.f;  // torchrl/policies/continuous_policy.py:8-9
-constexpr float HALF_LOG_2PI = 0.91893853320467274178f;
 
 // Clipped-surrogate + entropy loss of PPO.update_actor (ppo.py:42-92) and its gradient w.r.t. the policy
 // mean [n][OUT_LD] and logstd [A]. logp_old comes from the frozen target policy's mean/logstd on the same

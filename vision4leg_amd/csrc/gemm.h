@@ -43,6 +43,22 @@ __device__ __forceinline__ void ld8(const __bf16* p, float (&v)[8]) {
   for (int j = 0; j < 4; ++j) { v[j] = (float)x[j]; v[4 + j] = (float)y[j]; }
 }
 
+// W (1, 2 or 4) adjacent elements with one W*sizeof(T)-byte load (address aligned to that size)
+template <int W> __device__ __forceinline__ void ldv(const float* p, float (&v)[W]) {
+  if constexpr (W == 1) v[0] = p[0];
+  else if constexpr (W == 2) { const float2 x = *reinterpret_cast<const float2*>(p); v[0] = x.x; v[1] = x.y; }
+  else { const float4 x = *reinterpret_cast<const float4*>(p); v[0] = x.x; v[1] = x.y; v[2] = x.z; v[3] = x.w; }
+}
+template <int W> __device__ __forceinline__ void ldv(const __bf16* p, float (&v)[W]) {
+  if constexpr (W == 1) v[0] = (float)p[0];
+  else {
+    typedef __attribute__((ext_vector_type(W))) __bf16 bv_t;
+    const bv_t x = *reinterpret_cast<const bv_t*>(p);
+#pragma unroll
+    for (int i = 0; i < W; ++i) v[i] = (float)x[i];
+  }
+}
+
 // hipcc turns "cond ? load : 0" into a branch around the load plus an s_waitcnt vmcnt(0) per element, which
 // serialises every load of an unrolled batch behind the previous one. All loaders therefore ALWAYS load (from
 // offset 0 of their array when the element is out of range) and select afterwards.
@@ -92,6 +108,13 @@ struct ADense {
     const float mk = mask[off];
     return mk > 0.f ? v : 0.f;
   }
+  template <int W> __device__ __forceinline__ void getv(int64_t off, float (&v)[W]) const {
+    if (mask == nullptr) ldv<W>(p + off, v);
+    else {
+#pragma unroll
+      for (int i = 0; i < W; ++i) v[i] = get(off + i);
+    }
+  }
 };
 
 // conv1: 8x8 stride-4 windows over the [n][C][IH][IW] depth stack (reference layout of the image
@@ -128,6 +151,7 @@ struct AIm2colCHW {
     return (int64_t)c * IH * IW + ky * IW + kx;
   }
   __device__ __forceinline__ float get(int64_t off) const { return (float)p[off]; }
+  template <int W> __device__ __forceinline__ void getv(int64_t off, float (&v)[W]) const { ldv<W>(p + off, v); }
 };
 
 // conv2/conv3 forward (and the X side of their weight-grads): fp32 NHWC feature map [n][IH][IW][Cin],
@@ -161,6 +185,7 @@ struct AIm2colNHWC {
     return (int64_t)(ky * IW + kx) * Cin + c;
   }
   __device__ __forceinline__ float get(int64_t off) const { return p[off]; }
+  template <int W> __device__ __forceinline__ void getv(int64_t off, float (&v)[W]) const { ldv<W>(p + off, v); }
 };
 
 // Gather-form convolution data-grad for one stride-parity class (py,px) of input pixels:
@@ -391,13 +416,12 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(YL yl, XL xl, int M, int m
   const int me = min(M, mb + m_per_block);
   const bool do_bias = (bslab != nullptr) && (blockIdx.x == 0);
 
-  // per-lane column offsets (constant for the whole block)
-  int yok, xok[KT];
+  // per-lane column offsets (constant for the whole block). The KT columns of a lane are adjacent in memory for
+  // every loader (dense rows, NHWC channels, the 8 kx of a CHW window row) and share validity: one vector load.
+  int yok, xok;
   const int64_t yco = yl.col_off(n0 + lane, yok);
   yok = yok && (lane < BN);
-  int64_t xco[KT];
-#pragma unroll
-  for (int i = 0; i < KT; ++i) xco[i] = xl.col_off(k0 + lane * KT + i, xok[i]);
+  const int64_t xco = xl.col_off(k0 + lane * KT, xok);
 
   float yv[16], xv[KT][16];
   float bsum = 0.f;
@@ -412,12 +436,11 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(YL yl, XL xl, int M, int m
       const bool oky = in && vy && yok;
       const float ty = yl.get(oky ? yro + yco : 0);  // unconditional load, select afterwards (see keep8)
       yv[j] = oky ? ty : 0.f;
+      const bool okx = in && vx && xok;
+      float tx[KT];
+      xl.template getv<KT>(okx ? xro + xco : 0, tx);
 #pragma unroll
-      for (int i = 0; i < KT; ++i) {
-        const bool okx = in && vx && xok[i];
-        const float tx = xl.get(okx ? xro + xco[i] : 0);
-        xv[i][j] = okx ? tx : 0.f;
-      }
+      for (int i = 0; i < KT; ++i) xv[i][j] = okx ? tx[i] : 0.f;
     }
   };
   auto lstore = [&]() {

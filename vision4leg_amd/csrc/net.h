@@ -99,8 +99,21 @@ struct v4l_net {
   v4l::Layout layout(int n) const;
   int64_t table_bytes() const;
   int64_t slab_floats(int n) const;
-  template <typename T> int forward_t(const float* state, const T* image, const int* rowidx, int n, float* ws, hipStream_t s);
+  // enc_ws != null: reuse the encoder output another net (same encoder parameters and shapes) left in ITS workspace
+  template <typename T> int forward_t(const float* state, const T* image, const int* rowidx, int n, float* ws, hipStream_t s,
+                                      const float* enc_ws = nullptr);
   template <typename T> int backward_t(const float* state, const T* image, const int* rowidx, int n, float* ws, float* grads, hipStream_t s);
+};
+
+struct v4l_actor {
+  v4l_net *pf = nullptr, *vf = nullptr;
+  int E = 0;
+  float* ws = nullptr;
+  v4l::ActCtl* ctl = nullptr;
+  int* rowidx = nullptr;
+  hipGraphExec_t gexec = nullptr;
+  const void* key[12] = {};
+  bool warm = false, bound = false;
 };
 
 struct GraphKey { v4l_rollout ro; v4l_ppo_hyper hp; int n; };

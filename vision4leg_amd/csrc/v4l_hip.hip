@@ -40,13 +40,13 @@ struct ProfGuard {
     ProfRec r;
     r.label = std::string(g_phase) + "|" + g_op + "|" + kname;
     r.flops = flops;
-    hipEventCreate(&r.e0);
-    hipEventCreate(&r.e1);
-    hipEventRecord(r.e0, s);
+    (void)hipEventCreate(&r.e0);
+    (void)hipEventCreate(&r.e1);
+    (void)hipEventRecord(r.e0, s);
     g_recs.push_back(r);
   }
   ~ProfGuard() {
-    if (on) hipEventRecord(g_recs.back().e1, s);
+    if (on) (void)hipEventRecord(g_recs.back().e1, s);
   }
 };
 #define V4L_KLAUNCH(kname, flops, s, ...)            \
@@ -89,10 +89,12 @@ static int launch_nt(hipStream_t s, const AL& al, int M, const T* Bp, int Np, in
 
 // Weight-grad plan: tile shape, split count over the reduction (m) and slab geometry.
 struct TnPlan { int BN, KT, gx, gy, splits, mpb, Npad, Kpad; int64_t slab_floats, bslab_floats; };
-static inline TnPlan tn_plan(int M, int N, int Kx) {
+static inline TnPlan tn_plan(int M, int N, int Kx, bool bf16) {
   TnPlan p;
   p.BN = N <= 16 ? 16 : (N <= 32 ? 32 : 64);
-  p.KT = Kx >= 128 ? 2 : 1;
+  // wider k tiles amortise the staged Y rows over more MFMAs; the f32 operand tile of KT=4 would not fit the
+  // 64 KiB static LDS budget
+  p.KT = (Kx >= 256 && bf16 && M >= 4096) ? 4 : (Kx >= 128 ? 2 : 1);
   p.gy = cdiv(N, p.BN);
   p.gx = cdiv(Kx, 64 * p.KT);
   int splits = std::max(1, 256 / (p.gx * p.gy));
@@ -118,7 +120,7 @@ struct Ctx {  // per-call view of a bound net
 template <typename T, class YL, class XL>
 static int launch_tn(Ctx& c, const YL& yl, const XL& xl, int M, int N, int Kx, RedDesc rd, double flops) {
   if (M <= 0) return 0;
-  const TnPlan p = tn_plan(M, N, Kx);
+  const TnPlan p = tn_plan(M, N, Kx, sizeof(T) == 2);
   float* slab = c.slab + c.slab_used;
   float* bslab = rd.db != nullptr ? slab + p.slab_floats : nullptr;
   c.slab_used += p.slab_floats + (rd.db != nullptr ? p.bslab_floats : 0);
@@ -127,9 +129,13 @@ static int launch_tn(Ctx& c, const YL& yl, const XL& xl, int M, int N, int Kx, R
   hipStream_t s = c.s;
 #define V4L_TN(BN_, KT_) \
   V4L_KLAUNCH("gemm_tn", flops, s, (gemm_tn_kernel<T, BN_, KT_, YL, XL>), grid, dim3(256), 0, s, yl, xl, M, p.mpb, slab, bslab, p.Npad, p.Kpad)
-  if (p.BN == 64) { if (p.KT == 2) V4L_TN(64, 2); else V4L_TN(64, 1); }
-  else if (p.BN == 32) { if (p.KT == 2) V4L_TN(32, 2); else V4L_TN(32, 1); }
-  else { if (p.KT == 2) V4L_TN(16, 2); else V4L_TN(16, 1); }
+  if constexpr (sizeof(T) == 2) {
+    if (p.KT == 4) {
+      if (p.BN == 64) V4L_TN(64, 4); else if (p.BN == 32) V4L_TN(32, 4); else V4L_TN(16, 4);
+    }
+  }
+  if (p.KT == 2) { if (p.BN == 64) V4L_TN(64, 2); else if (p.BN == 32) V4L_TN(32, 2); else V4L_TN(16, 2); }
+  else if (p.KT == 1) { if (p.BN == 64) V4L_TN(64, 1); else if (p.BN == 32) V4L_TN(32, 1); else V4L_TN(16, 1); }
 #undef V4L_TN
   V4L_LAUNCH_CHECK();
   rd.slab = slab; rd.bslab = bslab; rd.nsplit = p.splits; rd.Npad = p.Npad; rd.Kpad = p.Kpad;
@@ -487,7 +493,7 @@ int64_t v4l_net::table_bytes() const {
 int64_t v4l_net::slab_floats(int n) const {
   int64_t tot = 0;
   auto add = [&](int M, int N, int Kx) {
-    const TnPlan p = tn_plan(M, N, Kx);
+    const TnPlan p = tn_plan(M, N, Kx, cfg.compute == V4L_BF16);
     tot += p.slab_floats + p.bslab_floats;
   };
   if (cfg.kind != V4L_NET_MLP)
@@ -566,7 +572,8 @@ Layout v4l_net::layout(int n) const {
 
 // ------------------------------------------------------------------------------------------ forward
 template <typename T>
-int v4l_net::forward_t(const float* state, const T* image, const int* rowidx, int n, float* ws, hipStream_t s) {
+int v4l_net::forward_t(const float* state, const T* image, const int* rowidx, int n, float* ws, hipStream_t s,
+                       const float* enc_ws) {
   const Layout L = layout(n);
   const v4l_net_cfg& c = cfg;
   Ctx cx{this, s, nullptr, nullptr, 0};
@@ -577,8 +584,12 @@ int v4l_net::forward_t(const float* state, const T* image, const int* rowidx, in
   for (int i = 0; i < ne; ++i) eacts[i] = Act{ws + L.eh[i], c.enc_hidden[i], c.enc_hidden[i]};
   ADense head_in;
   if (c.kind == V4L_NET_MLP) {
-    if ((rc = chain_fwd<T>(cx, enc.data(), ne, sin, eacts, true))) return rc;
+    if (enc_ws != nullptr) eacts[ne - 1].p = const_cast<float*>(enc_ws) + L.eh[ne - 1];
+    else if ((rc = chain_fwd<T>(cx, enc.data(), ne, sin, eacts, true))) return rc;
     head_in = dense(eacts[ne - 1].p, eacts[ne - 1].ld, n, eacts[ne - 1].w);
+  } else if (c.kind == V4L_NET_CNN && enc_ws != nullptr) {
+    const int cw = c.visual_dim + c.enc_hidden[ne - 1];
+    head_in = dense(enc_ws + L.vis, cw, n, cw);
   } else if (c.kind == V4L_NET_CNN) {
     if ((rc = conv_stack_fwd<T>(cx, image, rowidx, n, ws + L.c1, ws + L.c2, ws + L.c3))) return rc;
     const int cw = c.visual_dim + c.enc_hidden[ne - 1];
@@ -589,8 +600,9 @@ int v4l_net::forward_t(const float* state, const T* image, const int* rowidx, in
     if ((rc = chain_fwd<T>(cx, enc.data(), ne, sin, eacts, true))) return rc;
     head_in = dense(ws + L.vis, cw, n, cw);
   } else {
+    float* x0 = enc_ws != nullptr ? const_cast<float*>(enc_ws) + L.x[0] : ws + L.x[0];
+    if (enc_ws == nullptr) {
     if ((rc = conv_stack_fwd<T>(cx, image, rowidx, n, ws + L.c1, ws + L.c2, ws + L.c3))) return rc;
-    float* x0 = ws + L.x[0];
     {  // depth_up_conv (1x1, no activation) -> tokens 1..16   (base.py:581,602-608)
       Epi ep = mk_epi(x0, TD, TD);
       ep.rowmap = ROWMAP_TOK_DEPTH;
@@ -602,11 +614,12 @@ int v4l_net::forward_t(const float* state, const T* image, const int* rowidx, in
       ep.rowmap = ROWMAP_TOK_STATE;
       if ((rc = lin_fwd<T>(cx, proj, dense(eacts[ne - 1].p, eacts[ne - 1].ld, n, eacts[ne - 1].w), ep))) return rc;
     }
+    }
     const int R = n * NTOK;
     for (int l = 0; l < c.n_layers; ++l) {
       const TLayer& t = layers[l];
       const LayerWs& w = L.lw[l];
-      float* xin = ws + L.x[l];
+      float* xin = l == 0 ? x0 : ws + L.x[l];
       if ((rc = lin_fwd<T>(cx, t.inproj, dense(xin, TD, R, TD), mk_epi(ws + w.qkv, 3 * TD, 3 * TD)))) return rc;
       g_op = "attn";
       V4L_KLAUNCH("attn_fwd", 4.0 * n * NTOK * NTOK * TD, s, attn_fwd_kernel, dim3(cdiv(n, 4)), dim3(256), 0, s, ws + w.qkv, n, ws + w.P, ws + w.ctx);
@@ -889,10 +902,10 @@ int v4l_ingest(const v4l_net* net, const float* obs_dev, int n, float* state_dev
   V4L_REQUIRE(img == 0 || image_dev != nullptr, "v4l_ingest: image_dev is null for a visual net");
   if (net->cfg.compute == V4L_BF16)
     hipLaunchKernelGGL(ingest_kernel<__bf16>, dim3(n), dim3(256), 0, s, obs_dev, n, S, net->Sp, img, state_dev,
-                       (__bf16*)image_dev, slot0);
+                       (__bf16*)image_dev, slot0, (const long long*)nullptr);
   else
     hipLaunchKernelGGL(ingest_kernel<float>, dim3(n), dim3(256), 0, s, obs_dev, n, S, net->Sp, img, state_dev,
-                       (float*)image_dev, slot0);
+                       (float*)image_dev, slot0, (const long long*)nullptr);
   V4L_LAUNCH_CHECK();
   return 0;
 }
@@ -973,9 +986,9 @@ int64_t v4l_prof_collect(char* buf, int64_t cap) {
   std::vector<std::pair<std::string, Agg>> agg;
   for (ProfRec& r : g_recs) {
     float ms = 0.f;
-    hipEventElapsedTime(&ms, r.e0, r.e1);
-    hipEventDestroy(r.e0);
-    hipEventDestroy(r.e1);
+    (void)hipEventElapsedTime(&ms, r.e0, r.e1);
+    (void)hipEventDestroy(r.e0);
+    (void)hipEventDestroy(r.e1);
     size_t i = 0;
     for (; i < agg.size(); ++i) if (agg[i].first == r.label) break;
     if (i == agg.size()) agg.push_back({r.label, Agg()});
@@ -997,6 +1010,120 @@ int64_t v4l_prof_collect(char* buf, int64_t cap) {
     buf[n] = 0;
   }
   return (int64_t)out.size();
+}
+
+
+// ------------------------------------------------------------------------------------------ actor (rollout step)
+int v4l_actor_create(v4l_net* pf, v4l_net* vf, int E, v4l_actor** out) {
+  V4L_REQUIRE(pf && vf && out && E > 0, "v4l_actor_create: bad argument");
+  V4L_REQUIRE(pf->cfg.has_logstd && vf->cfg.out_dim == 1 && pf->cfg.kind == vf->cfg.kind &&
+                  pf->cfg.compute == vf->cfg.compute && pf->cfg.state_dim == vf->cfg.state_dim &&
+                  pf->cfg.n_enc_hidden == vf->cfg.n_enc_hidden,
+              "v4l_actor_create: pf must be a Gaussian policy and vf a value net of the same kind/compute/shape");
+  v4l_actor* a = new v4l_actor();
+  a->pf = pf; a->vf = vf; a->E = E;
+  *out = a;
+  return 0;
+}
+void v4l_actor_destroy(v4l_actor* a) {
+  if (a && a->gexec) (void)hipGraphExecDestroy(a->gexec);
+  delete a;
+}
+int64_t v4l_actor_ws_floats(const v4l_actor* a) {
+  if (!a) return -1;
+  return a->pf->layout(a->E).total + a->vf->layout(a->E).total;
+}
+int64_t v4l_actor_ctl_bytes(const v4l_actor* a) { return a ? 256 + (int64_t)round_up(a->E, 64) * sizeof(int) : -1; }
+int v4l_actor_bind(v4l_actor* a, float* ws_dev, void* ctl_dev, void* stream) {
+  (void)stream;
+  V4L_REQUIRE(a && ws_dev && ctl_dev, "v4l_actor_bind: null argument");
+  V4L_REQUIRE(a->pf->bound && a->vf->bound, "v4l_actor_bind: bind pf and vf first");
+  if (a->gexec) { (void)hipGraphExecDestroy(a->gexec); a->gexec = nullptr; }
+  a->warm = false;
+  a->ws = ws_dev;
+  a->ctl = (ActCtl*)ctl_dev;
+  a->rowidx = (int*)((char*)ctl_dev + 256);
+  a->bound = true;
+  return 0;
+}
+int v4l_actor_seek(v4l_actor* a, int64_t t, void* stream) {
+  V4L_REQUIRE(a && a->bound && t >= 0, "v4l_actor_seek: bad argument");
+  hipLaunchKernelGGL(act_set_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, a->ctl, (long long)t);
+  V4L_LAUNCH_CHECK();
+  return 0;
+}
+
+static int run_actor_step(v4l_actor* a, const float* obs, const float* eps, float* state_roll, void* image_roll,
+                          float* acts_roll, float* values_roll, float* action, float* mean, float* stdv, float* ent,
+                          float* value, int shared_encoder, void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  v4l_net *pf = a->pf, *vf = a->vf;
+  const int E = a->E;
+  int rc;
+  PhaseScope ps("rollout");
+  g_op = "ctl";
+  V4L_KLAUNCH("act_begin", 0, s, act_begin_kernel, dim3(1), dim3(256), 0, s, a->ctl, E, a->rowidx);
+  V4L_LAUNCH_CHECK();
+  const int S = pf->cfg.state_dim;
+  const int img = pf->cfg.kind == V4L_NET_MLP ? 0 : pf->cfg.in_channels * pf->cfg.img_hw * pf->cfg.img_hw;
+  g_op = "ingest";
+  if (pf->cfg.compute == V4L_BF16)
+    V4L_KLAUNCH("ingest", 0, s, ingest_kernel<__bf16>, dim3(E), dim3(256), 0, s, obs, E, S, pf->Sp, img, state_roll,
+                (__bf16*)image_roll, (int64_t)0, (const long long*)&a->ctl->t);
+  else
+    V4L_KLAUNCH("ingest", 0, s, ingest_kernel<float>, dim3(E), dim3(256), 0, s, obs, E, S, pf->Sp, img, state_roll,
+                (float*)image_roll, (int64_t)0, (const long long*)&a->ctl->t);
+  V4L_LAUNCH_CHECK();
+  float* ws_pf = a->ws;
+  float* ws_vf = a->ws + pf->layout(E).total;
+  if ((rc = v4l_net_forward(pf, state_roll, image_roll, a->rowidx, E, ws_pf, 0, stream))) return rc;
+  // the value net shares the encoder with the policy (starter/ppo_locotransformer.py:79-100): reuse its tokens
+  if (vf->cfg.compute == V4L_BF16)
+    rc = vf->forward_t<__bf16>(state_roll, (const __bf16*)image_roll, a->rowidx, E, ws_vf, s, shared_encoder ? ws_pf : nullptr);
+  else
+    rc = vf->forward_t<float>(state_roll, (const float*)image_roll, a->rowidx, E, ws_vf, s, shared_encoder ? ws_pf : nullptr);
+  if (rc) return rc;
+  g_op = "sample";
+  V4L_KLAUNCH("act_finish", 0, s, act_finish_kernel, dim3(1), dim3(256), 0, s, a->ctl, ws_pf + pf->layout(E).out,
+              pf->p[pf->logstd], ws_vf + vf->layout(E).out, eps, E, pf->cfg.out_dim, acts_roll, values_roll, action, mean,
+              stdv, ent, value);
+  V4L_LAUNCH_CHECK();
+  return 0;
+}
+
+int v4l_actor_step(v4l_actor* a, const float* obs_dev, const float* eps_dev, float* state_roll_dev, void* image_roll_dev,
+                   float* acts_roll_dev, float* values_roll_dev, float* action_dev, float* mean_dev, float* std_dev,
+                   float* ent_dev, float* value_dev, int shared_encoder, int use_graph, void* stream) {
+  V4L_REQUIRE(a && a->bound, "v4l_actor_step: actor is not bound");
+  V4L_REQUIRE(obs_dev && eps_dev && state_roll_dev && action_dev && mean_dev && std_dev && ent_dev && value_dev,
+              "v4l_actor_step: null argument");
+  V4L_REQUIRE(a->pf->cfg.kind == V4L_NET_MLP || image_roll_dev, "v4l_actor_step: image rollout array missing");
+  hipStream_t s = (hipStream_t)stream;
+  auto run = [&]() {
+    return run_actor_step(a, obs_dev, eps_dev, state_roll_dev, image_roll_dev, acts_roll_dev, values_roll_dev, action_dev,
+                          mean_dev, std_dev, ent_dev, value_dev, shared_encoder, stream);
+  };
+  if (!use_graph || g_prof || s == nullptr) return run();
+  const void* key[12] = {obs_dev, eps_dev, state_roll_dev, image_roll_dev, acts_roll_dev, values_roll_dev, action_dev,
+                         mean_dev, std_dev, ent_dev, value_dev, (const void*)(intptr_t)(shared_encoder + 1)};
+  if (memcmp(key, a->key, sizeof(key)) != 0) {
+    if (a->gexec) { (void)hipGraphExecDestroy(a->gexec); a->gexec = nullptr; }
+    a->warm = false;
+    memcpy(a->key, key, sizeof(key));
+  }
+  if (!a->warm) { a->warm = true; return run(); }
+  if (a->gexec == nullptr) {
+    hipGraph_t graph = nullptr;
+    V4L_HIP_CHECK(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+    const int rc = run();
+    const hipError_t e = hipStreamEndCapture(s, &graph);
+    if (rc) { if (graph) (void)hipGraphDestroy(graph); return rc; }
+    V4L_HIP_CHECK(e);
+    V4L_HIP_CHECK(hipGraphInstantiate(&a->gexec, graph, nullptr, nullptr, 0));
+    V4L_HIP_CHECK(hipGraphDestroy(graph));
+  }
+  V4L_HIP_CHECK(hipGraphLaunch(a->gexec, s));
+  return 0;
 }
 
 // ------------------------------------------------------------------------------------------ trainer

@@ -351,6 +351,74 @@ class HipTrainer:
     self._after_steps()
 
 
+class HipActor:
+  """One rollout step for E envs as a single captured launch sequence: pf.explore + vf on a shared encoder pass
+  (reference protocol: torchrl/collector/on_policy.py:90-100), with the step's observation rows, action and value
+  filed straight into the HBM-resident rollout arrays. The step cursor lives on the device."""
+
+  def __init__(self, pf_net, vf_net, E, rollout=None, shared_encoder=True, graph=True):
+    self.pf, self.vf, self.E = pf_net, vf_net, E
+    self.L = _lib.lib()
+    for net in (pf_net, vf_net):
+      net.ensure_bound()
+    dev = self.device = pf_net.device
+    h = C.c_void_p()
+    check(self.L.v4l_actor_create(pf_net.h, vf_net.h, E, C.byref(h)), "v4l_actor_create")
+    self.h = h
+    A = pf_net.out_dim
+    self.ws = torch.empty(self.L.v4l_actor_ws_floats(h), dtype=torch.float32, device=dev)
+    self.ctl = torch.zeros(self.L.v4l_actor_ctl_bytes(h), dtype=torch.uint8, device=dev)
+    self.obs = torch.zeros(E, pf_net.state_dim + pf_net.img_elems, dtype=torch.float32, device=dev)
+    self.eps = torch.zeros(E, A, dtype=torch.float32, device=dev)
+    z = lambda *shape: torch.zeros(*shape, dtype=torch.float32, device=dev)
+    self.action, self.mean, self.std, self.ent, self.value = z(E, A), z(E, A), z(E, A), z(E, 1), z(E, 1)
+    self.shared_encoder, self.graph = bool(shared_encoder), bool(graph)
+    self.stream = torch.cuda.Stream(device=dev)
+    self.attach(rollout)
+    check(self.L.v4l_actor_bind(h, _ptr(self.ws), _ptr(self.ctl), _stream()), "v4l_actor_bind")
+
+  def __del__(self):
+    try:
+      if getattr(self, "h", None):
+        self.L.v4l_actor_destroy(self.h)
+        self.h = None
+    except Exception:
+      pass
+
+  def attach(self, rollout):
+    """rollout = (state [slots][Sp], image [slots][C*H*W] | None, acts [slots][A] | None, values [slots] | None);
+    None: private E-slot scratch, nothing is filed and the cursor is rewound every step."""
+    self.own = rollout is None
+    if rollout is None:
+      st, im = self.pf.alloc_rollout(self.E, self.device)
+      rollout = (st, im, None, None)
+    self.rollout = rollout
+
+  def seek(self, t):
+    check(self.L.v4l_actor_seek(self.h, int(t), _stream()), "v4l_actor_seek")
+
+  def step(self, obs):
+    """obs: [E][S+C*H*W] float32 cuda rows of this env step. Returns a dict of views of fixed output buffers
+    (valid until the next step): action/mean/std [E][A], ent/value [E][1]."""
+    _require_gpu(obs, "observation batch")
+    cur = torch.cuda.current_stream(self.device)
+    with torch.cuda.stream(self.stream):
+      self.stream.wait_stream(cur)
+      self.pf.pack_if_needed()
+      self.vf.pack_if_needed()
+      if obs.data_ptr() != self.obs.data_ptr():
+        self.obs.copy_(obs.reshape(self.obs.shape), non_blocking=True)
+      self.eps.normal_()  # torch's generator: the same standard-normal draws Normal(mean, std).sample() would use
+      if self.own:
+        self.seek(0)
+      st, im, acts, vals = self.rollout
+      check(self.L.v4l_actor_step(self.h, _ptr(self.obs), _ptr(self.eps), _ptr(st), _ptr(im), _ptr(acts), _ptr(vals),
+                                  _ptr(self.action), _ptr(self.mean), _ptr(self.std), _ptr(self.ent), _ptr(self.value),
+                                  int(self.shared_encoder), int(self.graph), _stream()), "v4l_actor_step")
+    cur.wait_stream(self.stream)
+    return {"action": self.action, "mean": self.mean, "std": self.std, "ent": self.ent, "value": self.value}
+
+
 def gae(rewards, values, terminals, time_limits, last_value, gamma, tau, use_time_limit, want32=True):
   """HIP GAE on float64 cuda tensors [T][E] (time_limits [T] or [T][E]); returns (advs, rets, advs32, rets32)."""
   L = _lib.lib()

@@ -18,7 +18,28 @@ LOG_SIG_MAX = 2
 LOG_SIG_MIN = -5
 
 __all__ = ["LOG_SIG_MAX", "LOG_SIG_MIN", "GaussianContPolicyBase", "GaussianContPolicyBasicBias",
-           "GaussianContPolicyImpalaEncoderProj", "GaussianContPolicyLocoTransformer"]
+           "GaussianContPolicyImpalaEncoderProj", "GaussianContPolicyLocoTransformer", "RolloutActor"]
+
+
+class RolloutActor:
+    """MI355X-native fast path for the collector's per-step network calls (reference
+    torchrl/collector/on_policy.py:90-100 does `pf.explore(ob)` then `vf(ob)`, i.e. two full passes through the
+    encoder both nets share): one captured launch sequence per env step that runs the shared encoder once, samples
+    the action and reads the value. `step(ob)` returns {"action","mean","std","ent","value"}; with
+    `attach(replay_buffer)` of a DeviceOnPolicyReplayBuffer it also files observation/action/value into HBM."""
+
+    def __init__(self, pf, vf, env_nums, graph=True):
+        from ...engine import HipActor
+        self._actor = HipActor(pf.hip, vf.hip, env_nums, graph=graph)
+
+    def attach(self, rollout):
+        self._actor.attach(rollout)
+
+    def seek(self, t):
+        self._actor.seek(t)
+
+    def step(self, ob):
+        return self._actor.step(ob)
 
 
 class GaussianContPolicyBase:
