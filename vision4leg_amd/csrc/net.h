@@ -94,19 +94,25 @@ struct v4l_net {
   int64_t slab_cap = 0;
   int64_t seg_blocks = 0;
   bool bound = false;
+  // auxiliary stream + fork/join events for sibling-kernel concurrency (created at bind; null = serial)
+  hipStream_t aux = nullptr;
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
 
   int build();
   v4l::Layout layout(int n) const;
   int64_t table_bytes() const;
   int64_t slab_floats(int n) const;
   // enc_ws != null: reuse the encoder output another net (same encoder parameters and shapes) left in ITS workspace
+  // stage: 0 = whole net, 1 = encoder only (up to the token / concat tensor), 2 = trunk + head only
   template <typename T> int forward_t(const float* state, const T* image, const int* rowidx, int n, float* ws, hipStream_t s,
-                                      const float* enc_ws = nullptr);
+                                      const float* enc_ws = nullptr, int stage = 0);
   template <typename T> int backward_t(const float* state, const T* image, const int* rowidx, int n, float* ws, float* grads, hipStream_t s);
 };
 
 struct v4l_actor {
   v4l_net *pf = nullptr, *vf = nullptr;
+  hipStream_t aux = nullptr;
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   int E = 0;
   float* ws = nullptr;
   v4l::ActCtl* ctl = nullptr;
@@ -130,6 +136,8 @@ struct v4l_trainer {
   int n_max = 0;
   const int* rowidx_all = nullptr;
   float* stats_all = nullptr;
+  hipStream_t aux = nullptr;
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   // hipGraph of one minibatch update
   GraphKey gkey = {};
   hipGraphExec_t gexec = nullptr;

@@ -114,7 +114,28 @@ struct Ctx {  // per-call view of a bound net
   float* grads;
   float* slab;         // arena for weight-grad partials (inside the workspace)
   int64_t slab_used;
+  hipStream_t tn;      // stream weight-grad kernels go to: s, or the net's aux stream inside par_begin/par_end
 };
+
+// Fork/join of the net's auxiliary stream. Independent sibling kernels (a layer's weight-grad next to its data-grad,
+// the proprio MLP next to the conv stack) run concurrently: most kernels of this workload fill only a fraction of
+// the 256 CUs. Under stream capture the event record/wait pairs become plain graph dependencies.
+static int par_begin(Ctx& c) {
+  v4l_net* n = c.net;
+  if (n->aux == nullptr) return 0;
+  V4L_HIP_CHECK(hipEventRecord(n->ev_fork, c.s));
+  V4L_HIP_CHECK(hipStreamWaitEvent(n->aux, n->ev_fork, 0));
+  c.tn = n->aux;
+  return 0;
+}
+static int par_end(Ctx& c) {
+  v4l_net* n = c.net;
+  if (n->aux == nullptr) return 0;
+  V4L_HIP_CHECK(hipEventRecord(n->ev_join, n->aux));
+  V4L_HIP_CHECK(hipStreamWaitEvent(c.s, n->ev_join, 0));
+  c.tn = c.s;
+  return 0;
+}
 
 // partial[z] = Y^T X over slab z of the rows; registers a reduce descriptor that wgrad_finish() executes
 template <typename T, class YL, class XL>
@@ -126,7 +147,7 @@ static int launch_tn(Ctx& c, const YL& yl, const XL& xl, int M, int N, int Kx, R
   c.slab_used += p.slab_floats + (rd.db != nullptr ? p.bslab_floats : 0);
   V4L_REQUIRE(c.slab_used <= c.net->slab_cap, "internal: weight-grad slab arena overflow");
   const dim3 grid(p.gx, p.gy, p.splits);
-  hipStream_t s = c.s;
+  hipStream_t s = c.tn;
 #define V4L_TN(BN_, KT_) \
   V4L_KLAUNCH("gemm_tn", flops, s, (gemm_tn_kernel<T, BN_, KT_, YL, XL>), grid, dim3(256), 0, s, yl, xl, M, p.mpb, slab, bslab, p.Npad, p.Kpad)
   if constexpr (sizeof(T) == 2) {
@@ -208,6 +229,8 @@ static int chain_bwd(Ctx& c, const Lin* Ls, int k, const ADense& in, const Act* 
                      float* bufb, const Epi* din) {
   for (int i = k - 1; i >= 0; --i) {
     int rc;
+    const bool sibling = i > 0 || din != nullptr;  // a data-grad runs next to this weight-grad
+    if (sibling && (rc = par_begin(c))) return rc;
     if (i == 0) rc = lin_wgrad<T>(c, Ls[0], y, in, in.K);
     else rc = lin_wgrad<T>(c, Ls[i], y, dense(acts[i - 1].p, acts[i - 1].ld, y.M, acts[i - 1].w), acts[i - 1].w);
     if (rc) return rc;
@@ -217,11 +240,13 @@ static int chain_bwd(Ctx& c, const Lin* Ls, int k, const ADense& in, const Act* 
       ep.ldmask = acts[i - 1].ld;
       rc = lin_dgrad<T>(c, Ls[i], y, ep);
       if (rc) return rc;
+      if ((rc = par_end(c))) return rc;
       y = dense(bufa, acts[i - 1].w, y.M, acts[i - 1].w);
       std::swap(bufa, bufb);
     } else if (din != nullptr) {
       rc = lin_dgrad<T>(c, Ls[0], y, *din);
       if (rc) return rc;
+      if ((rc = par_end(c))) return rc;
     }
   }
   return 0;
@@ -283,6 +308,7 @@ static int conv_stack_bwd(Ctx& c, const T* image, const int* rowidx, int n, cons
     o.db = c.grads + N->params[v.b].goff;
     o.N = v.Cout; o.K = v.K; o.Ktorch = v.K;
     int rc;
+    if (i > 0 && (rc = par_begin(c))) return rc;  // weight-grad of conv i next to its data-grad
     if (v.chw) {
       o.Cin = 0; o.taps = 0;
       auto x = chw_loader<T>(image, v, n, rowidx);
@@ -312,6 +338,7 @@ static int conv_stack_bwd(Ctx& c, const T* image, const int* rowidx, int n, cons
       rc = launch_nt<T>(c.s, a, a.M, (const T*)N->packed + v.pkd[cls], v.Rd, v.Kdp, ep, 2.0 * M * v.Cout * v.K / v.ncls);
       if (rc) return rc;
     }
+    if ((rc = par_end(c))) return rc;
   }
   return 0;
 }
@@ -573,10 +600,10 @@ Layout v4l_net::layout(int n) const {
 // ------------------------------------------------------------------------------------------ forward
 template <typename T>
 int v4l_net::forward_t(const float* state, const T* image, const int* rowidx, int n, float* ws, hipStream_t s,
-                       const float* enc_ws) {
+                       const float* enc_ws, int stage) {
   const Layout L = layout(n);
   const v4l_net_cfg& c = cfg;
-  Ctx cx{this, s, nullptr, nullptr, 0};
+  Ctx cx{this, s, nullptr, nullptr, 0, s};
   int rc;
   const int ne = c.n_enc_hidden, nh = c.n_head_hidden;
   const ADense sin = dense(state, Sp, n, Sp, rowidx);
@@ -585,36 +612,49 @@ int v4l_net::forward_t(const float* state, const T* image, const int* rowidx, in
   ADense head_in;
   if (c.kind == V4L_NET_MLP) {
     if (enc_ws != nullptr) eacts[ne - 1].p = const_cast<float*>(enc_ws) + L.eh[ne - 1];
-    else if ((rc = chain_fwd<T>(cx, enc.data(), ne, sin, eacts, true))) return rc;
+    else if (stage != 2 && (rc = chain_fwd<T>(cx, enc.data(), ne, sin, eacts, true))) return rc;
     head_in = dense(eacts[ne - 1].p, eacts[ne - 1].ld, n, eacts[ne - 1].w);
   } else if (c.kind == V4L_NET_CNN && enc_ws != nullptr) {
     const int cw = c.visual_dim + c.enc_hidden[ne - 1];
     head_in = dense(enc_ws + L.vis, cw, n, cw);
   } else if (c.kind == V4L_NET_CNN) {
-    if ((rc = conv_stack_fwd<T>(cx, image, rowidx, n, ws + L.c1, ws + L.c2, ws + L.c3))) return rc;
     const int cw = c.visual_dim + c.enc_hidden[ne - 1];
-    // visual projector on the NHWC flatten of conv3 -> columns [0, visual_dim) of the concat buffer
-    Epi ep = mk_epi(ws + L.vis, cw, c.visual_dim, nullptr, 1);
-    if ((rc = lin_fwd<T>(cx, proj, dense(ws + L.c3, 1024, n, 1024), ep))) return rc;
-    eacts[ne - 1] = Act{ws + L.vis + c.visual_dim, cw, c.enc_hidden[ne - 1]};
-    if ((rc = chain_fwd<T>(cx, enc.data(), ne, sin, eacts, true))) return rc;
+    if (stage != 2) {
+      // proprio MLP on the aux stream next to the conv stack; both land in the concat buffer
+      if ((rc = par_begin(cx))) return rc;
+      Ctx cx2 = cx;
+      cx2.s = cx.tn;
+      eacts[ne - 1] = Act{ws + L.vis + c.visual_dim, cw, c.enc_hidden[ne - 1]};
+      if ((rc = chain_fwd<T>(cx2, enc.data(), ne, sin, eacts, true))) return rc;
+      if ((rc = conv_stack_fwd<T>(cx, image, rowidx, n, ws + L.c1, ws + L.c2, ws + L.c3))) return rc;
+      // visual projector on the NHWC flatten of conv3 -> columns [0, visual_dim) of the concat buffer
+      Epi ep = mk_epi(ws + L.vis, cw, c.visual_dim, nullptr, 1);
+      if ((rc = lin_fwd<T>(cx, proj, dense(ws + L.c3, 1024, n, 1024), ep))) return rc;
+      if ((rc = par_end(cx))) return rc;
+    }
     head_in = dense(ws + L.vis, cw, n, cw);
   } else {
     float* x0 = enc_ws != nullptr ? const_cast<float*>(enc_ws) + L.x[0] : ws + L.x[0];
-    if (enc_ws == nullptr) {
-    if ((rc = conv_stack_fwd<T>(cx, image, rowidx, n, ws + L.c1, ws + L.c2, ws + L.c3))) return rc;
-    {  // depth_up_conv (1x1, no activation) -> tokens 1..16   (base.py:581,602-608)
-      Epi ep = mk_epi(x0, TD, TD);
-      ep.rowmap = ROWMAP_TOK_DEPTH;
-      if ((rc = lin_fwd<T>(cx, upconv, dense(ws + L.c3, 64, n * 16, 64), ep))) return rc;
+    if (enc_ws == nullptr && stage != 2) {
+      // proprio branch (MLP + state_projector -> token 0) on the aux stream next to the conv branch (-> tokens 1..16)
+      if ((rc = par_begin(cx))) return rc;
+      Ctx cx2 = cx;
+      cx2.s = cx.tn;
+      if ((rc = chain_fwd<T>(cx2, enc.data(), ne, sin, eacts, true))) return rc;
+      {  // state_projector + ReLU -> token 0   (base.py:611-615)
+        Epi ep = mk_epi(x0, TD, TD, nullptr, 1);
+        ep.rowmap = ROWMAP_TOK_STATE;
+        if ((rc = lin_fwd<T>(cx2, proj, dense(eacts[ne - 1].p, eacts[ne - 1].ld, n, eacts[ne - 1].w), ep))) return rc;
+      }
+      if ((rc = conv_stack_fwd<T>(cx, image, rowidx, n, ws + L.c1, ws + L.c2, ws + L.c3))) return rc;
+      {  // depth_up_conv (1x1, no activation) -> tokens 1..16   (base.py:581,602-608)
+        Epi ep = mk_epi(x0, TD, TD);
+        ep.rowmap = ROWMAP_TOK_DEPTH;
+        if ((rc = lin_fwd<T>(cx, upconv, dense(ws + L.c3, 64, n * 16, 64), ep))) return rc;
+      }
+      if ((rc = par_end(cx))) return rc;
     }
-    if ((rc = chain_fwd<T>(cx, enc.data(), ne, sin, eacts, true))) return rc;
-    {  // state_projector + ReLU -> token 0   (base.py:611-615)
-      Epi ep = mk_epi(x0, TD, TD, nullptr, 1);
-      ep.rowmap = ROWMAP_TOK_STATE;
-      if ((rc = lin_fwd<T>(cx, proj, dense(eacts[ne - 1].p, eacts[ne - 1].ld, n, eacts[ne - 1].w), ep))) return rc;
-    }
-    }
+    if (stage == 1) return 0;
     const int R = n * NTOK;
     for (int l = 0; l < c.n_layers; ++l) {
       const TLayer& t = layers[l];
@@ -641,6 +681,7 @@ int v4l_net::forward_t(const float* state, const T* image, const int* rowidx, in
     V4L_LAUNCH_CHECK();
     head_in = dense(ws + L.pooled, 2 * TD, n, 2 * TD);
   }
+  if (stage == 1) return 0;
   Act hacts[V4L_MAX_HIDDEN + 1];
   for (int i = 0; i < nh; ++i) hacts[i] = Act{ws + L.hh[i], c.head_hidden[i], c.head_hidden[i]};
   hacts[nh] = Act{ws + L.out, OUT_LD, c.out_dim};
@@ -655,7 +696,7 @@ int v4l_net::backward_t(const float* state, const T* image, const int* rowidx, i
                         hipStream_t s) {
   const Layout L = layout(n);
   const v4l_net_cfg& c = cfg;
-  Ctx cx{this, s, grads, ws + L.slab, 0};
+  Ctx cx{this, s, grads, ws + L.slab, 0, s};
   red.clear();
   slab_cap = slab_floats(n);
   int rc;
@@ -689,11 +730,13 @@ int v4l_net::backward_t(const float* state, const T* image, const int* rowidx, i
     if ((rc = chain_bwd<T>(cx, head.data(), nh + 1, dense(ws + L.vis, cw, n, cw), hacts, dy, bufa, bufb, &din))) return rc;
     {  // visual branch: ReLU mask applied on load; data-grad lands in dc3 viewed as the NHWC flatten [n][1024]
       ADense yv = dense(hand, cw, n, c.visual_dim, nullptr, 0, ws + L.vis);
+      if ((rc = par_begin(cx))) return rc;
       if ((rc = lin_wgrad<T>(cx, proj, yv, dense(ws + L.c3, 1024, n, 1024), 1024))) return rc;
       Epi ep = mk_epi(ws + L.dc3, 1024, 1024);
       ep.mask = ws + L.c3;
       ep.ldmask = 1024;
       if ((rc = lin_dgrad<T>(cx, proj, yv, ep))) return rc;
+      if ((rc = par_end(cx))) return rc;
     }
     {  // state branch
       ADense ys = dense(hand + c.visual_dim, cw, n, c.enc_hidden[ne - 1], nullptr, 0, ws + L.vis + c.visual_dim);
@@ -724,16 +767,20 @@ int v4l_net::backward_t(const float* state, const T* image, const int* rowidx, i
     V4L_LAUNCH_CHECK();
     {  // linear2 / linear1 (FFN), residual: d(x1) = dz2 + W1^T-path
       ADense y = dense(dx, TD, R, TD);
+      if ((rc = par_begin(cx))) return rc;
       if ((rc = lin_wgrad<T>(cx, t.ff2, y, dense(ws + w.f, c.ff_dim, R, c.ff_dim), c.ff_dim))) return rc;
       Epi ep = mk_epi(ws + L.df, c.ff_dim, c.ff_dim);
       ep.mask = ws + w.f;
       ep.ldmask = c.ff_dim;
       if ((rc = lin_dgrad<T>(cx, t.ff2, y, ep))) return rc;
+      if ((rc = par_end(cx))) return rc;
       ADense yf = dense(ws + L.df, c.ff_dim, R, c.ff_dim);
+      if ((rc = par_begin(cx))) return rc;
       if ((rc = lin_wgrad<T>(cx, t.ff1, yf, dense(ws + w.x1, TD, R, TD), TD))) return rc;
       Epi ea = mk_epi(dx, TD, TD);
       ea.accumulate = 1;
       if ((rc = lin_dgrad<T>(cx, t.ff1, yf, ea))) return rc;
+      if ((rc = par_end(cx))) return rc;
     }
     g_op = "ln1";
     V4L_KLAUNCH("ln_bwd", 0, s, ln_bwd_kernel, dim3(lnb), dim3(256), 0, s, dx, ws + w.xh1, ws + w.rs1, p[t.ln1.g], R, dx,
@@ -741,37 +788,45 @@ int v4l_net::backward_t(const float* state, const T* image, const int* rowidx, i
     V4L_LAUNCH_CHECK();
     {  // self-attention block, residual: d(x_in) = dz1 + in_proj^T-path
       ADense y = dense(dx, TD, R, TD);
+      if ((rc = par_begin(cx))) return rc;
       if ((rc = lin_wgrad<T>(cx, t.outproj, y, dense(ws + w.ctx, TD, R, TD), TD))) return rc;
       if ((rc = lin_dgrad<T>(cx, t.outproj, y, mk_epi(ws + L.dctx, TD, TD)))) return rc;
+      if ((rc = par_end(cx))) return rc;
       g_op = "attn";
       V4L_KLAUNCH("attn_bwd", 8.0 * n * NTOK * NTOK * TD, s, attn_bwd_kernel, dim3(cdiv(n, 2)), dim3(128), 0, s, ws + w.qkv, ws + w.P, ws + L.dctx, n,
                          ws + L.dqkv);
       V4L_LAUNCH_CHECK();
       ADense yq = dense(ws + L.dqkv, 3 * TD, R, 3 * TD);
+      if ((rc = par_begin(cx))) return rc;
       if ((rc = lin_wgrad<T>(cx, t.inproj, yq, dense(ws + L.x[l], TD, R, TD), TD))) return rc;
       Epi ea = mk_epi(dx, TD, TD);
       ea.accumulate = 1;
       if ((rc = lin_dgrad<T>(cx, t.inproj, yq, ea))) return rc;
+      if ((rc = par_end(cx))) return rc;
     }
   }
   const float* x0 = ws + L.x[0];
   {  // token 0 -> state_projector -> encoder MLP
     const Act& last = eacts[ne - 1];
     ADense yp = dense(dx, NTOK * TD, n, TD, nullptr, 0, x0);
+    if ((rc = par_begin(cx))) return rc;
     if ((rc = lin_wgrad<T>(cx, proj, yp, dense(last.p, last.ld, n, last.w), last.w))) return rc;
     Epi ep = mk_epi(bufa, last.w, last.w);
     ep.mask = last.p;
     ep.ldmask = last.ld;
     if ((rc = lin_dgrad<T>(cx, proj, yp, ep))) return rc;
+    if ((rc = par_end(cx))) return rc;
     if ((rc = chain_bwd<T>(cx, enc.data(), ne, sin, eacts, dense(bufa, last.w, n, last.w), bufb, bufa, nullptr))) return rc;
   }
   {  // tokens 1..16 -> depth_up_conv -> conv stack
     ADense yu = dense(dx, TD, n * 16, TD, nullptr, 1);
+    if ((rc = par_begin(cx))) return rc;
     if ((rc = lin_wgrad<T>(cx, upconv, yu, dense(ws + L.c3, 64, n * 16, 64), 64))) return rc;
     Epi ep = mk_epi(ws + L.dc3, 64, 64);
     ep.mask = ws + L.c3;
     ep.ldmask = 64;
     if ((rc = lin_dgrad<T>(cx, upconv, yu, ep))) return rc;
+    if ((rc = par_end(cx))) return rc;
   }
   if ((rc = conv_stack_bwd<T>(cx, image, rowidx, n, ws + L.c1, ws + L.c2, ws + L.dc3, ws + L.dc2, ws + L.dc1))) return rc;
   return wgrad_finish(cx);
@@ -792,7 +847,14 @@ int v4l_net_create(const v4l_net_cfg* cfg, v4l_net** out) {
   *out = n;
   return 0;
 }
-void v4l_net_destroy(v4l_net* net) { delete net; }
+void v4l_net_destroy(v4l_net* net) {
+  if (net && net->aux) {
+    (void)hipStreamDestroy(net->aux);
+    (void)hipEventDestroy(net->ev_fork);
+    (void)hipEventDestroy(net->ev_join);
+  }
+  delete net;
+}
 int v4l_net_num_params(const v4l_net* net) { return net ? (int)net->params.size() : -1; }
 int v4l_net_param_info(const v4l_net* net, int i, const char** name, int* ndim, int64_t shape[4], int64_t* numel,
                        int64_t* grad_offset) {
@@ -866,6 +928,11 @@ int v4l_net_bind(v4l_net* net, float* const* params_dev, void* packed_dev, void*
     segs[i].n = net->params[i].numel;
     segs[i].blk0 = blk;
     blk += cdiv64(net->params[i].numel, 256);
+  }
+  if (net->aux == nullptr && (getenv("V4L_PAR") == nullptr || atoi(getenv("V4L_PAR")) != 0)) {
+    V4L_HIP_CHECK(hipStreamCreateWithFlags(&net->aux, hipStreamNonBlocking));
+    V4L_HIP_CHECK(hipEventCreateWithFlags(&net->ev_fork, hipEventDisableTiming));
+    V4L_HIP_CHECK(hipEventCreateWithFlags(&net->ev_join, hipEventDisableTiming));
   }
   net->packed = packed_dev;
   net->d_packs = (PackDesc*)table_dev;
@@ -1027,6 +1094,11 @@ int v4l_actor_create(v4l_net* pf, v4l_net* vf, int E, v4l_actor** out) {
 }
 void v4l_actor_destroy(v4l_actor* a) {
   if (a && a->gexec) (void)hipGraphExecDestroy(a->gexec);
+  if (a && a->aux) {
+    (void)hipStreamDestroy(a->aux);
+    (void)hipEventDestroy(a->ev_fork);
+    (void)hipEventDestroy(a->ev_join);
+  }
   delete a;
 }
 int64_t v4l_actor_ws_floats(const v4l_actor* a) {
@@ -1040,6 +1112,11 @@ int v4l_actor_bind(v4l_actor* a, float* ws_dev, void* ctl_dev, void* stream) {
   V4L_REQUIRE(a->pf->bound && a->vf->bound, "v4l_actor_bind: bind pf and vf first");
   if (a->gexec) { (void)hipGraphExecDestroy(a->gexec); a->gexec = nullptr; }
   a->warm = false;
+  if (a->aux == nullptr && a->pf->aux != nullptr) {
+    V4L_HIP_CHECK(hipStreamCreateWithFlags(&a->aux, hipStreamNonBlocking));
+    V4L_HIP_CHECK(hipEventCreateWithFlags(&a->ev_fork, hipEventDisableTiming));
+    V4L_HIP_CHECK(hipEventCreateWithFlags(&a->ev_join, hipEventDisableTiming));
+  }
   a->ws = ws_dev;
   a->ctl = (ActCtl*)ctl_dev;
   a->rowidx = (int*)((char*)ctl_dev + 256);
@@ -1076,13 +1153,33 @@ static int run_actor_step(v4l_actor* a, const float* obs, const float* eps, floa
   V4L_LAUNCH_CHECK();
   float* ws_pf = a->ws;
   float* ws_vf = a->ws + pf->layout(E).total;
-  if ((rc = v4l_net_forward(pf, state_roll, image_roll, a->rowidx, E, ws_pf, 0, stream))) return rc;
-  // the value net shares the encoder with the policy (starter/ppo_locotransformer.py:79-100): reuse its tokens
-  if (vf->cfg.compute == V4L_BF16)
-    rc = vf->forward_t<__bf16>(state_roll, (const __bf16*)image_roll, a->rowidx, E, ws_vf, s, shared_encoder ? ws_pf : nullptr);
-  else
-    rc = vf->forward_t<float>(state_roll, (const float*)image_roll, a->rowidx, E, ws_vf, s, shared_encoder ? ws_pf : nullptr);
-  if (rc) return rc;
+  V4L_REQUIRE(pf->bound && vf->bound, "v4l_actor_step: nets are not bound");
+  // policy encoder, then the two trunks side by side: the value net shares the encoder with the policy
+  // (starter/ppo_locotransformer.py:79-100) and continues from the policy's token tensor on the aux stream
+  const bool bf = pf->cfg.compute == V4L_BF16;
+  auto fwd = [&](v4l_net* net, float* ws, hipStream_t st, const float* enc, int stage) {
+    return bf ? net->forward_t<__bf16>(state_roll, (const __bf16*)image_roll, a->rowidx, E, ws, st, enc, stage)
+              : net->forward_t<float>(state_roll, (const float*)image_roll, a->rowidx, E, ws, st, enc, stage);
+  };
+  const bool par = shared_encoder && a->aux != nullptr;
+  if (shared_encoder) {
+    if ((rc = fwd(pf, ws_pf, s, nullptr, 1))) return rc;
+    hipStream_t sv = s;
+    if (par) {
+      V4L_HIP_CHECK(hipEventRecord(a->ev_fork, s));
+      V4L_HIP_CHECK(hipStreamWaitEvent(a->aux, a->ev_fork, 0));
+      sv = a->aux;
+    }
+    if ((rc = fwd(vf, ws_vf, sv, ws_pf, 2))) return rc;
+    if ((rc = fwd(pf, ws_pf, s, nullptr, 2))) return rc;
+    if (par) {
+      V4L_HIP_CHECK(hipEventRecord(a->ev_join, a->aux));
+      V4L_HIP_CHECK(hipStreamWaitEvent(s, a->ev_join, 0));
+    }
+  } else {
+    if ((rc = fwd(pf, ws_pf, s, nullptr, 0))) return rc;
+    if ((rc = fwd(vf, ws_vf, s, nullptr, 0))) return rc;
+  }
   g_op = "sample";
   V4L_KLAUNCH("act_finish", 0, s, act_finish_kernel, dim3(1), dim3(256), 0, s, a->ctl, ws_pf + pf->layout(E).out,
               pf->p[pf->logstd], ws_vf + vf->layout(E).out, eps, E, pf->cfg.out_dim, acts_roll, values_roll, action, mean,
@@ -1146,6 +1243,11 @@ static void drop_graph(v4l_trainer* tr) {
 }
 void v4l_trainer_destroy(v4l_trainer* tr) {
   if (tr) drop_graph(tr);
+  if (tr && tr->aux) {
+    (void)hipStreamDestroy(tr->aux);
+    (void)hipEventDestroy(tr->ev_fork);
+    (void)hipEventDestroy(tr->ev_join);
+  }
   delete tr;
 }
 int64_t v4l_trainer_ws_floats(const v4l_trainer* tr, int n) {
@@ -1167,6 +1269,11 @@ int v4l_trainer_bind(v4l_trainer* tr, float* g_pf_dev, float* m_pf_dev, float* v
   tr->g_pf = g_pf_dev; tr->m_pf = m_pf_dev; tr->v_pf = v_pf_dev;
   tr->g_vf = g_vf_dev; tr->m_vf = m_vf_dev; tr->v_vf = v_vf_dev;
   tr->ws = ws_dev; tr->ws_floats = ws_floats;
+  if (tr->aux == nullptr && tr->pf->aux != nullptr) {
+    V4L_HIP_CHECK(hipStreamCreateWithFlags(&tr->aux, hipStreamNonBlocking));
+    V4L_HIP_CHECK(hipEventCreateWithFlags(&tr->ev_fork, hipEventDisableTiming));
+    V4L_HIP_CHECK(hipEventCreateWithFlags(&tr->ev_join, hipEventDisableTiming));
+  }
   tr->ctl = (UpdCtl*)ctl_dev;
   tr->stats_cur = (float*)((char*)ctl_dev + 256);
   tr->rowidx_cur = (int*)((char*)ctl_dev + 512);
@@ -1256,12 +1363,23 @@ int v4l_trainer_actor_grads(v4l_trainer* tr, const v4l_rollout* ro, int n, const
   V4L_HIP_CHECK(hipMemsetAsync(tr->g_pf, 0, (size_t)pf->total_params * sizeof(float), s));
   const Layout Lp = pf->layout(n), Lt = tp->layout(n);
   float* ws_t = tr->ws + std::max(Lp.total, tr->vf->layout(n).total);
-  // frozen target policy: packed once per epoch by v4l_trainer_sync_target
+  // frozen target policy (packed once per epoch by v4l_trainer_sync_target) on the trainer's aux stream, next to the
+  // live policy's repack + forward: the two passes are independent until the loss
+  hipStream_t s_tgt = s;
+  if (tr->aux != nullptr) {
+    V4L_HIP_CHECK(hipEventRecord(tr->ev_fork, s));
+    V4L_HIP_CHECK(hipStreamWaitEvent(tr->aux, tr->ev_fork, 0));
+    s_tgt = tr->aux;
+  }
   { PhaseScope ps("tpf.fwd");
-  if ((rc = v4l_net_forward(tp, ro->state_dev, ro->image_dev, rowidx, n, ws_t, 0, stream))) return rc; }
+  if ((rc = v4l_net_forward(tp, ro->state_dev, ro->image_dev, rowidx, n, ws_t, 0, (void*)s_tgt))) return rc; }
   if ((rc = v4l_net_pack(pf, stream))) return rc;  // the critic step moved the shared encoder
   { PhaseScope ps("pf.fwd");
   if ((rc = v4l_net_forward(pf, ro->state_dev, ro->image_dev, rowidx, n, tr->ws, 1, stream))) return rc; }
+  if (tr->aux != nullptr) {
+    V4L_HIP_CHECK(hipEventRecord(tr->ev_join, tr->aux));
+    V4L_HIP_CHECK(hipStreamWaitEvent(s, tr->ev_join, 0));
+  }
   const float inv_n = 1.f / ((float)n * (float)hp->world_size);
   g_op = "loss";
   V4L_KLAUNCH("actor_loss", 0, s, actor_loss_kernel, dim3(1), dim3(256), 0, s, tr->ws + Lp.out, pf->p[pf->logstd], ws_t + Lt.out,
