@@ -100,7 +100,7 @@ class Epoch:
         self.epoch = 0
         self.actor = None
         if os.environ.get("V4L_ACTOR", "1") != "0":
-            self.actor = policies.RolloutActor(self.pf, self.vf, E, graph=os.environ.get("V4L_GRAPH", "1") != "0")
+            self.actor = policies.RolloutActor(self.pf, self.vf, E, graph=os.environ.get("V4L_ACTOR_GRAPH", "0") != "0")
             self.actor.attach((self.state, self.image, self.acts, self.values))
         if wl.get("skip_rollout"):
             self.rollout()  # populate once so updates have data

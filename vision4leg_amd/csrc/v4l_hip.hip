@@ -10,6 +10,8 @@ namespace v4l {
 
 // ------------------------------------------------------------------------------------------ errors
 static thread_local char g_err[1024] = "";
+static const bool g_trace = getenv("V4L_TRACE") != nullptr;
+#define V4L_TRACE(...) do { if (v4l::g_trace) { fprintf(stderr, "[v4l] " __VA_ARGS__); fputc('\n', stderr); fflush(stderr); } } while (0)
 void set_error(const char* fmt, ...) {
   va_list ap;
   va_start(ap, fmt);
@@ -120,9 +122,18 @@ struct Ctx {  // per-call view of a bound net
 // Fork/join of the net's auxiliary stream. Independent sibling kernels (a layer's weight-grad next to its data-grad,
 // the proprio MLP next to the conv stack) run concurrently: most kernels of this workload fill only a fraction of
 // the 256 CUs. Under stream capture the event record/wait pairs become plain graph dependencies.
+// ROCm 7.2: ending a capture that contains this library's fork/join pattern crashes inside hipStreamEndCapture
+// (a stand-alone reproduction of the pattern does not — tools/probe/capture_fork.hip), so the aux stream is used
+// for eager launches only; captured sequences stay on one stream.
+static inline bool capturing(hipStream_t s) {
+  hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+  if (s == nullptr || hipStreamIsCapturing(s, &st) != hipSuccess) return false;
+  return st != hipStreamCaptureStatusNone;
+}
 static int par_begin(Ctx& c) {
   v4l_net* n = c.net;
-  if (n->aux == nullptr) return 0;
+  if (n->aux == nullptr || capturing(c.s)) return 0;
+  V4L_TRACE("par_begin net=%p s=%p aux=%p", (void*)n, (void*)c.s, (void*)n->aux);
   V4L_HIP_CHECK(hipEventRecord(n->ev_fork, c.s));
   V4L_HIP_CHECK(hipStreamWaitEvent(n->aux, n->ev_fork, 0));
   c.tn = n->aux;
@@ -130,7 +141,8 @@ static int par_begin(Ctx& c) {
 }
 static int par_end(Ctx& c) {
   v4l_net* n = c.net;
-  if (n->aux == nullptr) return 0;
+  if (n->aux == nullptr || c.tn == c.s) return 0;
+  V4L_TRACE("par_end net=%p", (void*)n);
   V4L_HIP_CHECK(hipEventRecord(n->ev_join, n->aux));
   V4L_HIP_CHECK(hipStreamWaitEvent(c.s, n->ev_join, 0));
   c.tn = c.s;
@@ -1161,7 +1173,7 @@ static int run_actor_step(v4l_actor* a, const float* obs, const float* eps, floa
     return bf ? net->forward_t<__bf16>(state_roll, (const __bf16*)image_roll, a->rowidx, E, ws, st, enc, stage)
               : net->forward_t<float>(state_roll, (const float*)image_roll, a->rowidx, E, ws, st, enc, stage);
   };
-  const bool par = shared_encoder && a->aux != nullptr;
+  const bool par = shared_encoder && a->aux != nullptr && !capturing(s);
   if (shared_encoder) {
     if ((rc = fwd(pf, ws_pf, s, nullptr, 1))) return rc;
     hipStream_t sv = s;
@@ -1211,15 +1223,20 @@ int v4l_actor_step(v4l_actor* a, const float* obs_dev, const float* eps_dev, flo
   if (!a->warm) { a->warm = true; return run(); }
   if (a->gexec == nullptr) {
     hipGraph_t graph = nullptr;
+    V4L_TRACE("actor: begin capture");
     V4L_HIP_CHECK(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
     const int rc = run();
+    V4L_TRACE("actor: end capture rc=%d", rc);
     const hipError_t e = hipStreamEndCapture(s, &graph);
     if (rc) { if (graph) (void)hipGraphDestroy(graph); return rc; }
     V4L_HIP_CHECK(e);
+    V4L_TRACE("actor: instantiate");
     V4L_HIP_CHECK(hipGraphInstantiate(&a->gexec, graph, nullptr, nullptr, 0));
     V4L_HIP_CHECK(hipGraphDestroy(graph));
+    V4L_TRACE("actor: instantiated");
   }
   V4L_HIP_CHECK(hipGraphLaunch(a->gexec, s));
+  V4L_TRACE("actor: launched");
   return 0;
 }
 
@@ -1366,7 +1383,8 @@ int v4l_trainer_actor_grads(v4l_trainer* tr, const v4l_rollout* ro, int n, const
   // frozen target policy (packed once per epoch by v4l_trainer_sync_target) on the trainer's aux stream, next to the
   // live policy's repack + forward: the two passes are independent until the loss
   hipStream_t s_tgt = s;
-  if (tr->aux != nullptr) {
+  const bool par_tgt = tr->aux != nullptr && !capturing(s);
+  if (par_tgt) {
     V4L_HIP_CHECK(hipEventRecord(tr->ev_fork, s));
     V4L_HIP_CHECK(hipStreamWaitEvent(tr->aux, tr->ev_fork, 0));
     s_tgt = tr->aux;
@@ -1376,7 +1394,7 @@ int v4l_trainer_actor_grads(v4l_trainer* tr, const v4l_rollout* ro, int n, const
   if ((rc = v4l_net_pack(pf, stream))) return rc;  // the critic step moved the shared encoder
   { PhaseScope ps("pf.fwd");
   if ((rc = v4l_net_forward(pf, ro->state_dev, ro->image_dev, rowidx, n, tr->ws, 1, stream))) return rc; }
-  if (tr->aux != nullptr) {
+  if (par_tgt) {
     V4L_HIP_CHECK(hipEventRecord(tr->ev_join, tr->aux));
     V4L_HIP_CHECK(hipStreamWaitEvent(s, tr->ev_join, 0));
   }
@@ -1427,15 +1445,20 @@ int v4l_trainer_update_next(v4l_trainer* tr, const v4l_rollout* ro, int n, const
   }
   if (tr->gexec == nullptr) {
     hipGraph_t graph = nullptr;
+    V4L_TRACE("update: begin capture");
     V4L_HIP_CHECK(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
     rc = run_update(tr, ro, n, hp, stream);
+    V4L_TRACE("update: end capture rc=%d", rc);
     const hipError_t e = hipStreamEndCapture(s, &graph);
     if (rc) { if (graph) (void)hipGraphDestroy(graph); return rc; }
     V4L_HIP_CHECK(e);
+    V4L_TRACE("update: instantiate");
     V4L_HIP_CHECK(hipGraphInstantiate(&tr->gexec, graph, nullptr, nullptr, 0));
     V4L_HIP_CHECK(hipGraphDestroy(graph));
+    V4L_TRACE("update: instantiated");
   }
   V4L_HIP_CHECK(hipGraphLaunch(tr->gexec, s));
+  V4L_TRACE("update: launched");
   return 0;
 }
 
