@@ -360,8 +360,9 @@ def test_graph_replay_equals_eager(mode, device):
         assert sum((pg[k] - opf[k]).abs().sum().item() for k in pg) / sum(v.numel() for v in pg.values()) <= 1e-5
 
 
+@pytest.mark.parametrize("graph", [False, True])
 @pytest.mark.parametrize("mode", MODES)
-def test_rollout_actor_matches_separate_calls(mode, device):
+def test_rollout_actor_matches_separate_calls(mode, graph, device):
     """RolloutActor.step (shared encoder pass, graph replay, device-side cursor) == pf.explore + vf of the reference
     protocol: same mean/std/value, action = mean + std*eps, rows/actions/values filed at slots [t*E,(t+1)*E)."""
     from vision4leg_amd.torchrl.policies import RolloutActor
@@ -376,7 +377,7 @@ def test_rollout_actor_matches_separate_calls(mode, device):
     rs = np.random.RandomState(3)
     obs = torch.tensor(np.concatenate([np.clip(rs.randn(T * E, case["S"]), -10, 10),
                                        np.clip(rs.randn(T * E, 4 * 64 * 64), -2.5, 2.8)], 1), dtype=torch.float32, device=device)
-    actor = RolloutActor(pf, vf, E, graph=True)
+    actor = RolloutActor(pf, vf, E, graph=graph)
     actor.attach((state, image, acts, vals))
     actor.seek(0)
     ref_state, ref_image = net.alloc_rollout(T * E, device)
@@ -389,8 +390,14 @@ def test_rollout_actor_matches_separate_calls(mode, device):
         eps = torch.randn(E, case["A"], device=device)
         mean, std, _ = pf(ob)
         value = vf(ob)
-        assert torch.allclose(out["mean"], mean, rtol=1e-5, atol=1e-6), (t, (out["mean"] - mean).abs().max())
-        assert torch.allclose(out["value"], value, rtol=1e-5, atol=1e-6), (t, (out["value"] - value).abs().max())
-        assert torch.allclose(out["std"], std) and torch.allclose(out["action"], mean + std * eps, rtol=1e-5, atol=1e-6)
+        # fused (csrc/infer.h) vs layer-by-layer kernels: same operands per MFMA step, same k order -> fp32 noise only;
+        # bf16 additionally tolerates an occasional rounding flip (see _oracle_noise)
+        tol = 1e-5 if mode == "f32" else 4e-3
+        dm, dv = (out["mean"] - mean).abs().max().item(), (out["value"] - value).abs().max().item()
+        if t == 0:
+            print("\n[actor %s] fused vs unfused: |dmean| %.2e |dvalue| %.2e" % (mode, dm, dv))
+        assert dm <= tol * max(1.0, mean.abs().max().item()) and dv <= tol * max(1.0, value.abs().max().item()), (t, dm, dv)
+        assert torch.allclose(out["std"], std)
+        assert torch.allclose(out["action"], out["mean"] + out["std"] * eps, rtol=1e-5, atol=1e-6)
         assert torch.equal(acts[t * E:(t + 1) * E], out["action"]) and torch.equal(vals[t * E:(t + 1) * E], out["value"].view(E))
     assert torch.equal(state, ref_state) and torch.equal(image, ref_image)

@@ -1,0 +1,551 @@
+// Fused small-batch inference of the LocoTransformer for the rollout step (E = 16..64 envs): the whole per-step
+// network evaluation in FOUR launches instead of ~50 (a dependent kernel boundary costs 3.5-5 us on MI355X, more
+// than any of these layers computes at batch E):
+//
+//   infer_encoder_kernel : blocks 0..E-1: one sample each — split/ingest of the observation row, conv1 -> conv2 ->
+//                          conv3 -> 1x1 up-conv with every activation in LDS (implicit GEMM straight from the LDS
+//                          image), depth tokens out.  block E: the proprio MLP + state_projector for all E rows.
+//   infer_layer_kernel   : one TransformerEncoderLayer (in_proj, 17-token attention, out_proj, +res, LN, FFN, +res,
+//                          LN) for 4 samples (68 token rows = 5 MFMA row tiles) per block; blockIdx.y = net (pf, vf).
+//   infer_head_kernel    : pooling + the three head linears of both nets + Gaussian sampling / value read-out,
+//                          filing of action/value into the rollout arrays, advance of the device-side step cursor.
+//
+// Weights are read as MFMA B fragments straight from the packed operand copies in L2 (each block streams a layer's
+// 25-130 KB once); activations never leave LDS inside a kernel. Rounding points are those of the unfused kernels
+// (operands rounded to T when they enter an MFMA, fp32 accumulate, fp32 residual/LN/softmax), so both paths agree
+// to fp32 summation noise.
+#pragma once
+#include "elem.h"
+#include "gemm.h"
+
+namespace v4l {
+
+constexpr int INF_SPW = 4;                      // samples per block in the layer kernel
+constexpr int INF_ROWS = 80;                    // 4*17 = 68 token rows padded to 5 MFMA row tiles
+constexpr int INF_MT = INF_ROWS / 16;
+
+template <typename T> struct InfLd {            // LDS row strides (elements) with 16-byte padding
+  static constexpr int PAD = sizeof(T) == 2 ? 8 : 4;
+};
+
+// 8 consecutive k of an A row held in LDS as fp32 or as T -> MFMA fragment of T
+template <typename T>
+__device__ __forceinline__ typename Frag<T>::type afrag(const float* p) {
+  typename Frag<T>::type f;
+  const float4 x = *reinterpret_cast<const float4*>(p);
+  const float4 y = *reinterpret_cast<const float4*>(p + 4);
+  if constexpr (sizeof(T) == 2) {
+    f[0] = (__bf16)x.x; f[1] = (__bf16)x.y; f[2] = (__bf16)x.z; f[3] = (__bf16)x.w;
+    f[4] = (__bf16)y.x; f[5] = (__bf16)y.y; f[6] = (__bf16)y.z; f[7] = (__bf16)y.w;
+  } else {
+    f.v[0] = x.x; f.v[1] = x.y; f.v[2] = x.z; f.v[3] = x.w; f.v[4] = y.x; f.v[5] = y.y; f.v[6] = y.z; f.v[7] = y.w;
+  }
+  return f;
+}
+__device__ __forceinline__ bf16x8 afrag_t(const __bf16* p) {  // 8-byte aligned source (conv1 windows)
+  typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+  const bf16x4 x = *reinterpret_cast<const bf16x4*>(p);
+  const bf16x4 y = *reinterpret_cast<const bf16x4*>(p + 4);
+  bf16x8 f;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) { f[j] = x[j]; f[4 + j] = y[j]; }
+  return f;
+}
+__device__ __forceinline__ f32x8 afrag_t(const float* p) { return *reinterpret_cast<const f32x8*>(p); }
+
+// acc[mt][j] += A[mt-th row tile] * W[ntile[j]]^T over `ksteps` K=32 steps. A: LDS, row stride lda, element AT.
+template <typename T, int MT, int NTW, typename AT>
+__device__ __forceinline__ void block_gemm(f32x4 (&acc)[MT][NTW], const AT* sA, int lda, const T* __restrict__ Wp, int Kp,
+                                           int ksteps, const int (&ntile)[NTW], int lane) {
+  typedef typename Frag<T>::type frag_t;
+  const int fr = lane & 15, fg = (lane >> 4) * 8;
+  for (int ks = 0; ks < ksteps; ++ks) {
+    frag_t fb[NTW];
+#pragma unroll
+    for (int j = 0; j < NTW; ++j)
+      fb[j] = *reinterpret_cast<const frag_t*>(Wp + (int64_t)(ntile[j] * 16 + fr) * Kp + ks * 32 + fg);
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      frag_t fa;
+      if constexpr (sizeof(AT) == sizeof(T)) fa = *reinterpret_cast<const frag_t*>(sA + (mt * 16 + fr) * lda + ks * 32 + fg);
+      else fa = afrag<T>(reinterpret_cast<const float*>(sA) + (mt * 16 + fr) * lda + ks * 32 + fg);
+#pragma unroll
+      for (int j = 0; j < NTW; ++j) mma_k32(acc[mt][j], fa, fb[j]);
+    }
+  }
+}
+template <int MT, int NTW> __device__ __forceinline__ void zero_acc(f32x4 (&acc)[MT][NTW]) {
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NTW; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+}
+
+// ------------------------------------------------------------------------------------------ encoder
+struct InfEnc {
+  const void *w1, *w2, *w3, *wup;          // packed conv weights (T): [32][256] [64][512] [64][576] [64][64]
+  const float *b1, *b2, *b3, *bup;
+  const void *wf1, *wf2, *wpr;             // packed proprio MLP: [256][Kp1] [256][256] [64][256]
+  const float *bf1, *bf2, *bpr;
+  int S, Sp, Kp1;                          // proprio length, rollout row stride, padded K of fc1
+};
+
+template <typename T> struct InfEncLds {
+  static constexpr int PAD = InfLd<T>::PAD;
+  static constexpr int IMG = 4 * 64 * 64;
+  static constexpr int LD1 = 32 + PAD, LD2 = 64 + PAD;
+  static constexpr int C1 = 240 * LD1, C2 = 48 * LD2, C3 = 16 * LD2;
+  static constexpr size_t conv_bytes = (size_t)(IMG + C1 + C2 + C3) * sizeof(T);
+  static constexpr int LDS_IN = 128 + 4;   // fp32 proprio rows
+  static constexpr int LDH = 256 + PAD;
+  static constexpr int MLP_ROWS = 32;      // proprio rows per MLP block (blocks E .. E + ceil(E/32) - 1)
+  static constexpr size_t mlp_bytes = (size_t)MLP_ROWS * LDS_IN * 4 + (size_t)2 * MLP_ROWS * LDH * sizeof(T);
+  static constexpr size_t bytes = conv_bytes > mlp_bytes ? conv_bytes : mlp_bytes;
+};
+
+template <typename T>
+__global__ __launch_bounds__(256) void infer_encoder_kernel(const ActCtl* __restrict__ ctl, const float* __restrict__ obs, int E,
+                                                            InfEnc w, float* __restrict__ state_roll, T* __restrict__ image_roll,
+                                                            float* __restrict__ x0 /* [E][17][64] */) {
+  typedef typename Frag<T>::type frag_t;
+  typedef InfEncLds<T> LY;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int fr = lane & 15, fg = (lane >> 4) * 8, qr = (lane >> 4) * 4;
+  const int64_t slot0 = (int64_t)ctl->t * E;
+  const int D = w.S + LY::IMG;
+
+  if ((int)blockIdx.x >= E) {
+    // ---------------- proprio branch, 32 rows per block: Linear+ReLU, Linear+ReLU, state_projector+ReLU -> token 0
+    constexpr int MR = LY::MLP_ROWS;
+    const int r0 = ((int)blockIdx.x - E) * MR;
+    float* sin = reinterpret_cast<float*>(smem);
+    T* h1 = reinterpret_cast<T*>(smem + (size_t)MR * LY::LDS_IN * 4);
+    T* h2 = h1 + MR * LY::LDH;
+    for (int idx = tid; idx < MR * 128; idx += 256) {
+      const int r = idx >> 7, c = idx & 127;
+      const bool ok = r0 + r < E;
+      const float v = (ok && c < w.S) ? obs[(int64_t)(r0 + r) * D + c] : 0.f;
+      sin[r * LY::LDS_IN + c] = v;
+      if (ok && c < w.Sp) state_roll[(slot0 + r0 + r) * w.Sp + c] = v;
+    }
+    __syncthreads();
+    const int nt4[4] = {wave * 4, wave * 4 + 1, wave * 4 + 2, wave * 4 + 3};
+    f32x4 acc[2][4];
+    auto store_h = [&](T* h, const float* bias) {
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int row = mt * 16 + qr + r, n = nt4[j] * 16 + fr;
+            h[row * LY::LDH + n] = Op<T>::from_f32(fmaxf(acc[mt][j][r] + bias[n], 0.f));
+          }
+    };
+    zero_acc(acc);
+    block_gemm<T, 2, 4>(acc, sin, LY::LDS_IN, (const T*)w.wf1, w.Kp1, w.Kp1 / 32, nt4, lane);
+    store_h(h1, w.bf1);
+    __syncthreads();
+    zero_acc(acc);
+    block_gemm<T, 2, 4>(acc, h1, LY::LDH, (const T*)w.wf2, 256, 8, nt4, lane);
+    store_h(h2, w.bf2);
+    __syncthreads();
+    const int nt1[1] = {wave};
+    f32x4 ap[2][1];
+    zero_acc(ap);
+    block_gemm<T, 2, 1>(ap, h2, LY::LDH, (const T*)w.wpr, 256, 8, nt1, lane);
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = r0 + mt * 16 + qr + r, n = wave * 16 + fr;
+        if (row < E) x0[((int64_t)row * NTOK) * TD + n] = fmaxf(ap[mt][0][r] + w.bpr[n], 0.f);
+      }
+    return;
+  }
+
+  // ---------------- depth branch, one sample per block
+  const int b = blockIdx.x;
+  T* img = reinterpret_cast<T*>(smem);
+  T* c1 = img + LY::IMG;
+  T* c2 = c1 + LY::C1;
+  T* c3 = c2 + LY::C2;
+  {
+    const float4* src = reinterpret_cast<const float4*>(obs + (int64_t)b * D + w.S);  // 16B aligned iff S%4==0
+    const bool al = (((int64_t)b * D + w.S) & 3) == 0;
+    T* roll = image_roll + (slot0 + b) * (int64_t)LY::IMG;
+    for (int i = tid; i < LY::IMG / 4; i += 256) {
+      float4 v;
+      if (al) v = src[i];
+      else {
+        const float* s1 = obs + (int64_t)b * D + w.S + i * 4;
+        v = float4{s1[0], s1[1], s1[2], s1[3]};
+      }
+      T t4[4] = {Op<T>::from_f32(v.x), Op<T>::from_f32(v.y), Op<T>::from_f32(v.z), Op<T>::from_f32(v.w)};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { img[i * 4 + j] = t4[j]; roll[i * 4 + j] = t4[j]; }
+    }
+  }
+  __syncthreads();
+  {  // conv1: 225 pixels (15 row tiles; wave w owns tiles w, w+4, w+8, w+12), K = (c,ky,kx) = 256, N = 32
+    f32x4 acc[4][2];
+    zero_acc(acc);
+    int pbase[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int p = min((wave + 4 * i) * 16 + fr, 224);
+      pbase[i] = (p / 15) * 4 * 64 + (p % 15) * 4;
+    }
+    for (int ks = 0; ks < 8; ++ks) {
+      const int k0 = ks * 32 + fg, c = k0 >> 6, ky = (k0 >> 3) & 7;
+      frag_t fb[2];
+#pragma unroll
+      for (int j = 0; j < 2; ++j) fb[j] = *reinterpret_cast<const frag_t*>((const T*)w.w1 + (j * 16 + fr) * 256 + k0);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        if (wave + 4 * i < 15) {
+          const frag_t fa = afrag_t(img + c * 4096 + ky * 64 + pbase[i]);
+#pragma unroll
+          for (int j = 0; j < 2; ++j) mma_k32(acc[i][j], fa, fb[j]);
+        }
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int p = (wave + 4 * i) * 16 + qr + r, n = j * 16 + fr;
+          if (p < 225) c1[p * LY::LD1 + n] = Op<T>::from_f32(fmaxf(acc[i][j][r] + w.b1[n], 0.f));
+        }
+  }
+  __syncthreads();
+  {  // conv2: 36 pixels (3 row tiles), K = (ky,kx,c) = 512, N = 64: wave w owns column tile w
+    f32x4 acc[3][1];
+    zero_acc(acc);
+    int pb[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      const int p = min(i * 16 + fr, 35);
+      pb[i] = ((p / 6) * 2 * 15 + (p % 6) * 2) * LY::LD1;
+    }
+    for (int ks = 0; ks < 16; ++ks) {
+      const int tap = ks, ky = tap >> 2, kx = tap & 3;  // 32 channels per tap == one K=32 step
+      const frag_t fb = *reinterpret_cast<const frag_t*>((const T*)w.w2 + (wave * 16 + fr) * 512 + ks * 32 + fg);
+#pragma unroll
+      for (int i = 0; i < 3; ++i) {
+        const frag_t fa = afrag_t(c1 + pb[i] + (ky * 15 + kx) * LY::LD1 + fg);
+        mma_k32(acc[i][0], fa, fb);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int p = i * 16 + qr + r, n = wave * 16 + fr;
+        if (p < 36) c2[p * LY::LD2 + n] = Op<T>::from_f32(fmaxf(acc[i][0][r] + w.b2[n], 0.f));
+      }
+  }
+  __syncthreads();
+  {  // conv3: 16 pixels, K = (ky,kx,c) = 576 (two K=32 steps per tap), N = 64
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    const int pb = ((fr >> 2) * 6 + (fr & 3)) * LY::LD2;
+    for (int ks = 0; ks < 18; ++ks) {
+      const int tap = ks >> 1, ky = tap / 3, kx = tap - ky * 3, c0 = (ks & 1) * 32 + fg;
+      const frag_t fb = *reinterpret_cast<const frag_t*>((const T*)w.w3 + (wave * 16 + fr) * 576 + ks * 32 + fg);
+      const frag_t fa = afrag_t(c2 + pb + (ky * 6 + kx) * LY::LD2 + c0);
+      mma_k32(acc, fa, fb);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int p = qr + r, n = wave * 16 + fr;
+      c3[p * LY::LD2 + n] = Op<T>::from_f32(fmaxf(acc[r] + w.b3[n], 0.f));
+    }
+  }
+  __syncthreads();
+  {  // depth_up_conv (1x1, no activation) -> tokens 1..16
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    for (int ks = 0; ks < 2; ++ks) {
+      const frag_t fb = *reinterpret_cast<const frag_t*>((const T*)w.wup + (wave * 16 + fr) * 64 + ks * 32 + fg);
+      const frag_t fa = afrag_t(c3 + fr * LY::LD2 + ks * 32 + fg);
+      mma_k32(acc, fa, fb);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int p = qr + r, n = wave * 16 + fr;
+      x0[((int64_t)b * NTOK + 1 + p) * TD + n] = acc[r] + w.bup[n];
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------ transformer layer
+struct InfLayer {
+  const void *win, *wo, *w1, *w2;        // packed (T): [192][64] [64][64] [ff][64] [64][ffp]
+  const float *bin, *bo, *b1, *b2, *g1, *be1, *g2, *be2;
+  const float* xin;                      // [E*17][64] fp32
+  float* xout;
+};
+struct InfLayerPair { InfLayer n[2]; };
+
+template <typename T> struct InfLayLds {
+  static constexpr int PAD = InfLd<T>::PAD;
+  static constexpr int LDX = 64 + 4, LDQ = 192 + 4, LDF = 256 + PAD;
+  static constexpr size_t xs_b = (size_t)INF_ROWS * LDX * 4;
+  static constexpr size_t qkv_b = (size_t)INF_ROWS * LDQ * 4;
+  static constexpr size_t f_b = (size_t)INF_ROWS * LDF * sizeof(T);
+  static constexpr size_t big_b = qkv_b > f_b ? qkv_b : f_b;
+  static constexpr size_t p_b = (size_t)4 * NTOK * ATT_PLD * 4;
+  static constexpr size_t bytes = xs_b + big_b + xs_b + p_b;  // xs | qkv/z/f | ctx/z2 | scores
+};
+
+__device__ __forceinline__ void ln_rows(const float* z, int ldz, float* out, int ldo, const float* __restrict__ g,
+                                        const float* __restrict__ be, int wave, int lane) {
+  for (int r = wave; r < INF_ROWS; r += 4) {
+    const float v = z[r * ldz + lane];
+    const float mean = wave_sum(v) * (1.f / TD);
+    const float c = v - mean;
+    const float var = wave_sum(c * c) * (1.f / TD);
+    out[r * ldo + lane] = fmaf(c * (1.f / sqrtf(var + 1e-5f)), g[lane], be[lane]);
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void infer_layer_kernel(InfLayerPair pr, int E, int ff) {
+  typedef InfLayLds<T> LY;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const InfLayer& w = pr.n[blockIdx.y];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int fr = lane & 15, qr = (lane >> 4) * 4;
+  float* xs = reinterpret_cast<float*>(smem);
+  float* big = reinterpret_cast<float*>(smem + LY::xs_b);            // qkv, later z (fp32), later f (T)
+  float* cx = reinterpret_cast<float*>(smem + LY::xs_b + LY::big_b); // ctx, later z2
+  float* sp = reinterpret_cast<float*>(smem + LY::xs_b + LY::big_b + LY::xs_b);
+  const int s0 = blockIdx.x * INF_SPW;
+  const int ns = min(INF_SPW, E - s0);
+  const int nrows = ns * NTOK;
+  const float* xg = w.xin + (int64_t)s0 * NTOK * TD;
+  for (int idx = tid; idx < INF_ROWS * TD; idx += 256) {
+    const int r = idx >> 6, c = idx & 63;
+    xs[r * LY::LDX + c] = r < nrows ? xg[idx] : 0.f;
+  }
+  __syncthreads();
+  {  // in_proj: [80][64] x [192][64]^T -> qkv (fp32)
+    const int nt[3] = {wave, wave + 4, wave + 8};
+    f32x4 acc[INF_MT][3];
+    zero_acc(acc);
+    block_gemm<T, INF_MT, 3>(acc, xs, LY::LDX, (const T*)w.win, 64, 2, nt, lane);
+#pragma unroll
+    for (int mt = 0; mt < INF_MT; ++mt)
+#pragma unroll
+      for (int j = 0; j < 3; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int n = nt[j] * 16 + fr;
+          big[(mt * 16 + qr + r) * LY::LDQ + n] = acc[mt][j][r] + w.bin[n];
+        }
+  }
+  __syncthreads();
+  {  // attention of sample `wave` (17 tokens, one head, scale 1/8); inactive waves only take part in the barriers
+    const bool act = wave < ns;
+    const float* q = big + (wave * NTOK) * LY::LDQ;
+    float* p = sp + wave * NTOK * ATT_PLD;
+    if (act) {
+      for (int pr2 = lane; pr2 < NTOK * NTOK; pr2 += 64) {
+        const int i = pr2 / NTOK, j = pr2 - i * NTOK;
+        float s = 0.f;
+#pragma unroll 16
+        for (int d = 0; d < TD; ++d) s = fmaf(q[i * LY::LDQ + d], q[j * LY::LDQ + TD + d], s);
+        p[i * ATT_PLD + j] = s * 0.125f;
+      }
+    }
+    __syncthreads();
+    if (act && lane < NTOK) {
+      float mx = -INFINITY;
+      for (int j = 0; j < NTOK; ++j) mx = fmaxf(mx, p[lane * ATT_PLD + j]);
+      float e[NTOK], sum = 0.f;
+#pragma unroll
+      for (int j = 0; j < NTOK; ++j) { e[j] = expf(p[lane * ATT_PLD + j] - mx); sum += e[j]; }
+      const float inv = 1.f / sum;
+#pragma unroll
+      for (int j = 0; j < NTOK; ++j) p[lane * ATT_PLD + j] = e[j] * inv;
+    }
+    __syncthreads();
+    if (act) {
+      for (int i = 0; i < NTOK; ++i) {
+        float a = 0.f;
+#pragma unroll
+        for (int j = 0; j < NTOK; ++j) a = fmaf(p[i * ATT_PLD + j], q[j * LY::LDQ + 2 * TD + lane], a);
+        cx[(wave * NTOK + i) * LY::LDX + lane] = a;
+      }
+    }
+  }
+  for (int idx = tid; idx < (INF_ROWS - nrows) * TD; idx += 256)  // rows beyond the last sample: defined zeros
+    cx[(nrows + (idx >> 6)) * LY::LDX + (idx & 63)] = 0.f;
+  __syncthreads();
+  const int nt1[1] = {wave};
+  {  // out_proj + residual -> z (in `big`, fp32 [80][LDX])
+    f32x4 acc[INF_MT][1];
+    zero_acc(acc);
+    block_gemm<T, INF_MT, 1>(acc, cx, LY::LDX, (const T*)w.wo, 64, 2, nt1, lane);
+#pragma unroll
+    for (int mt = 0; mt < INF_MT; ++mt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = mt * 16 + qr + r, n = wave * 16 + fr;
+        big[row * LY::LDX + n] = xs[row * LY::LDX + n] + acc[mt][0][r] + w.bo[n];
+      }
+  }
+  __syncthreads();
+  ln_rows(big, LY::LDX, xs, LY::LDX, w.g1, w.be1, wave, lane);  // x1 -> xs
+  __syncthreads();
+  T* f = reinterpret_cast<T*>(big);
+  {  // linear1 + ReLU -> f (T) ; ff <= 256: wave w owns column tiles 4w..4w+3
+    const int nt4[4] = {wave * 4, wave * 4 + 1, wave * 4 + 2, wave * 4 + 3};
+    f32x4 acc[INF_MT][4];
+    zero_acc(acc);
+    block_gemm<T, INF_MT, 4>(acc, xs, LY::LDX, (const T*)w.w1, 64, 2, nt4, lane);
+#pragma unroll
+    for (int mt = 0; mt < INF_MT; ++mt)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int n = nt4[j] * 16 + fr;
+          f[(mt * 16 + qr + r) * LY::LDF + n] = Op<T>::from_f32(n < ff ? fmaxf(acc[mt][j][r] + w.b1[n], 0.f) : 0.f);
+        }
+  }
+  __syncthreads();
+  {  // linear2 + residual -> z2 (in `cx`)
+    f32x4 acc[INF_MT][1];
+    zero_acc(acc);
+    block_gemm<T, INF_MT, 1>(acc, f, LY::LDF, (const T*)w.w2, 256, 8, nt1, lane);
+#pragma unroll
+    for (int mt = 0; mt < INF_MT; ++mt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = mt * 16 + qr + r, n = wave * 16 + fr;
+        cx[row * LY::LDX + n] = xs[row * LY::LDX + n] + acc[mt][0][r] + w.b2[n];
+      }
+  }
+  __syncthreads();
+  float* xo = w.xout + (int64_t)s0 * NTOK * TD;
+  for (int r = wave; r < nrows; r += 4) {
+    const float v = cx[r * LY::LDX + lane];
+    const float mean = wave_sum(v) * (1.f / TD);
+    const float c = v - mean;
+    const float var = wave_sum(c * c) * (1.f / TD);
+    xo[r * TD + lane] = fmaf(c * (1.f / sqrtf(var + 1e-5f)), w.g2[lane], w.be2[lane]);
+  }
+}
+
+// ------------------------------------------------------------------------------------------ heads + sampling
+struct InfHead {
+  const void *w0, *w1, *w2;            // packed (T): [256][128] [256][256] [16][256]
+  const float *b0, *b1, *b2;
+  const float* x;                      // final tokens [E*17][64]
+};
+template <typename T> struct InfHeadLds {
+  static constexpr int PAD = InfLd<T>::PAD;
+  static constexpr int LDP = 128 + 4, LDH = 256 + PAD;
+  static constexpr int ROWS = 32;  // rows per pass
+  static constexpr size_t bytes = (size_t)ROWS * LDP * 4 + (size_t)2 * ROWS * LDH * sizeof(T) + (size_t)2 * 64 * 16 * 4;
+};
+
+template <typename T>
+__global__ __launch_bounds__(256) void infer_head_kernel(ActCtl* ctl, InfHead hp, InfHead hv, const float* __restrict__ logstd,
+                                                         const float* __restrict__ eps, int E, int A,
+                                                         float* __restrict__ acts_roll, float* __restrict__ values_roll,
+                                                         float* __restrict__ action, float* __restrict__ mean,
+                                                         float* __restrict__ stdv, float* __restrict__ ent,
+                                                         float* __restrict__ value) {
+  typedef InfHeadLds<T> LY;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int fr = lane & 15, qr = (lane >> 4) * 4;
+  constexpr int MR = LY::ROWS;
+  float* pooled = reinterpret_cast<float*>(smem);
+  T* h1 = reinterpret_cast<T*>(smem + (size_t)MR * LY::LDP * 4);
+  T* h2 = h1 + MR * LY::LDH;
+  float* outs = reinterpret_cast<float*>(h2 + MR * LY::LDH);  // [2][64][16]
+  const int nt4[4] = {wave * 4, wave * 4 + 1, wave * 4 + 2, wave * 4 + 3};
+  for (int net = 0; net < 2; ++net) {
+    const InfHead& h = net == 0 ? hp : hv;
+    for (int r0 = 0; r0 < E; r0 += MR) {
+      for (int idx = tid; idx < MR * 128; idx += 256) {  // [state token | mean of the 16 depth tokens]
+        const int r = idx >> 7, c = idx & 127;
+        float v = 0.f;
+        if (r0 + r < E) {
+          const float* xb = h.x + (int64_t)(r0 + r) * NTOK * TD;
+          if (c < TD) v = xb[c];
+          else {
+            float s = 0.f;
+#pragma unroll
+            for (int i = 1; i < NTOK; ++i) s += xb[i * TD + (c - TD)];
+            v = s * (1.f / 16.f);
+          }
+        }
+        pooled[r * LY::LDP + c] = v;
+      }
+      __syncthreads();
+      f32x4 acc[2][4];
+      auto store_h = [&](T* dst, const float* bias) {
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const int n = nt4[j] * 16 + fr;
+              dst[(mt * 16 + qr + r) * LY::LDH + n] = Op<T>::from_f32(fmaxf(acc[mt][j][r] + bias[n], 0.f));
+            }
+      };
+      zero_acc(acc);
+      block_gemm<T, 2, 4>(acc, pooled, LY::LDP, (const T*)h.w0, 128, 4, nt4, lane);
+      store_h(h1, h.b0);
+      __syncthreads();
+      zero_acc(acc);
+      block_gemm<T, 2, 4>(acc, h1, LY::LDH, (const T*)h.w1, 256, 8, nt4, lane);
+      store_h(h2, h.b1);
+      __syncthreads();
+      if (wave < 2) {  // last layer: one 16-column tile; wave w takes row tile w of this pass
+        const int nt0[1] = {0};
+        f32x4 a1[1][1];
+        zero_acc(a1);
+        block_gemm<T, 1, 1>(a1, h2 + wave * 16 * LY::LDH, LY::LDH, (const T*)h.w2, 256, 8, nt0, lane);
+        const int nout = net == 0 ? A : 1;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int row = r0 + wave * 16 + qr + r;
+          if (row < 64) outs[(net * 64 + row) * 16 + fr] = fr < nout ? a1[0][0][r] + h.b2[fr] : 0.f;
+        }
+      }
+      __syncthreads();
+    }
+  }
+  // GaussianContPolicyBase.explore + value read-out (see act_finish_kernel)
+  const long long t = ctl->t;
+  for (int i = tid; i < E; i += 256) {
+    float e = 0.f;
+    for (int a = 0; a < A; ++a) {
+      const float ls = fminf(fmaxf(logstd[a], LOG_SIG_MIN), LOG_SIG_MAX);
+      const float sg = expf(ls);
+      e += 0.5f + HALF_LOG_2PI + logf(sg);
+      const float mu = outs[i * 16 + a];
+      const float act = fmaf(sg, eps[(int64_t)i * A + a], mu);
+      action[(int64_t)i * A + a] = act;
+      mean[(int64_t)i * A + a] = mu;
+      stdv[(int64_t)i * A + a] = sg;
+      if (acts_roll != nullptr) acts_roll[(t * E + i) * A + a] = act;
+    }
+    ent[i] = e;
+    const float v = outs[(64 + i) * 16];
+    value[i] = v;
+    if (values_roll != nullptr) values_roll[t * E + i] = v;
+  }
+  __syncthreads();
+  if (tid == 0) ctl->t = t + 1;
+}
+
+}  // namespace v4l

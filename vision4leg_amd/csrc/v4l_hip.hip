@@ -5,6 +5,7 @@
 #include <algorithm>
 
 #include "net.h"
+#include "infer.h"
 
 namespace v4l {
 
@@ -844,6 +845,84 @@ int v4l_net::backward_t(const float* state, const T* image, const int* rowidx, i
   return wgrad_finish(cx);
 }
 
+
+// Fused rollout step for the shipped LocoTransformer shape (csrc/infer.h): 4 launches instead of ~50.
+static bool actor_fusable(const v4l_actor* a) {
+  const v4l_net_cfg &p = a->pf->cfg, &v = a->vf->cfg;
+  auto ok = [](const v4l_net_cfg& c) {
+    return c.kind == V4L_NET_LOCO && c.n_enc_hidden == 2 && c.enc_hidden[0] == 256 && c.enc_hidden[1] == 256 &&
+           c.n_head_hidden == 2 && c.head_hidden[0] == 256 && c.head_hidden[1] == 256 && c.ff_dim == 256 &&
+           c.state_dim <= 128;
+  };
+  return ok(p) && ok(v) && p.n_layers == v.n_layers && a->E <= 64 && getenv("V4L_NO_FUSED_ACTOR") == nullptr;
+}
+
+template <typename T>
+static int run_actor_fused(v4l_actor* a, const float* obs, const float* eps, float* state_roll, void* image_roll,
+                           float* acts_roll, float* values_roll, float* action, float* mean, float* stdv, float* ent,
+                           float* value, hipStream_t s) {
+  v4l_net *pf = a->pf, *vf = a->vf;
+  const int E = a->E;
+  static bool attr_done = false;
+  if (!attr_done) {
+    V4L_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&infer_encoder_kernel<T>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)InfEncLds<T>::bytes));
+    V4L_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&infer_layer_kernel<T>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)InfLayLds<T>::bytes));
+    V4L_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&infer_head_kernel<T>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)InfHeadLds<T>::bytes));
+    attr_done = true;
+  }
+  const T* pk = (const T*)pf->packed;
+  const T* vk = (const T*)vf->packed;
+  const Layout Lp = pf->layout(E), Lv = vf->layout(E);
+  float* ws_pf = a->ws;
+  float* ws_vf = a->ws + Lp.total;
+  PhaseScope ps("rollout");
+  InfEnc en;
+  en.w1 = pk + pf->conv[0].pk; en.w2 = pk + pf->conv[1].pk; en.w3 = pk + pf->conv[2].pk; en.wup = pk + pf->upconv.pk;
+  en.b1 = pf->p[pf->conv[0].b]; en.b2 = pf->p[pf->conv[1].b]; en.b3 = pf->p[pf->conv[2].b]; en.bup = pf->p[pf->upconv.b];
+  en.wf1 = pk + pf->enc[0].pk; en.wf2 = pk + pf->enc[1].pk; en.wpr = pk + pf->proj.pk;
+  en.bf1 = pf->p[pf->enc[0].b]; en.bf2 = pf->p[pf->enc[1].b]; en.bpr = pf->p[pf->proj.b];
+  en.S = pf->cfg.state_dim; en.Sp = pf->Sp; en.Kp1 = pf->enc[0].Kp;
+  float* x0 = ws_pf + Lp.x[0];
+  g_op = "encoder";
+  V4L_KLAUNCH("infer_encoder", 2.0 * E * 3678208.0, s, infer_encoder_kernel<T>, dim3(E + cdiv(E, 32)), dim3(256),
+              InfEncLds<T>::bytes, s, (const ActCtl*)a->ctl, obs, E, en, state_roll, (T*)image_roll, x0);
+  V4L_LAUNCH_CHECK();
+  auto fill = [&](InfLayer& d, v4l_net* net, const T* base, const TLayer& t, const float* xin, float* xout) {
+    d.win = base + t.inproj.pk; d.wo = base + t.outproj.pk; d.w1 = base + t.ff1.pk; d.w2 = base + t.ff2.pk;
+    d.bin = net->p[t.inproj.b]; d.bo = net->p[t.outproj.b]; d.b1 = net->p[t.ff1.b]; d.b2 = net->p[t.ff2.b];
+    d.g1 = net->p[t.ln1.g]; d.be1 = net->p[t.ln1.b]; d.g2 = net->p[t.ln2.g]; d.be2 = net->p[t.ln2.b];
+    d.xin = xin; d.xout = xout;
+  };
+  const int nl = pf->cfg.n_layers;
+  for (int l = 0; l < nl; ++l) {
+    InfLayerPair pr;
+    fill(pr.n[0], pf, pk, pf->layers[l], l == 0 ? x0 : ws_pf + Lp.x[l], ws_pf + Lp.x[l + 1]);
+    fill(pr.n[1], vf, vk, vf->layers[l], l == 0 ? x0 : ws_vf + Lv.x[l], ws_vf + Lv.x[l + 1]);
+    g_op = "layer";
+    V4L_KLAUNCH("infer_layer", 2.0 * 2 * E * 872576.0, s, infer_layer_kernel<T>, dim3(cdiv(E, INF_SPW), 2), dim3(256),
+                InfLayLds<T>::bytes, s, pr, E, pf->cfg.ff_dim);
+    V4L_LAUNCH_CHECK();
+  }
+  auto head = [&](InfHead& h, v4l_net* net, const T* base, const float* x) {
+    h.w0 = base + net->head[0].pk; h.w1 = base + net->head[1].pk; h.w2 = base + net->head[2].pk;
+    h.b0 = net->p[net->head[0].b]; h.b1 = net->p[net->head[1].b]; h.b2 = net->p[net->head[2].b];
+    h.x = x;
+  };
+  InfHead hp, hv;
+  head(hp, pf, pk, ws_pf + Lp.x[nl]);
+  head(hv, vf, vk, ws_vf + Lv.x[nl]);
+  g_op = "head";
+  V4L_KLAUNCH("infer_head", 2.0 * 2 * E * 99840.0, s, infer_head_kernel<T>, dim3(1), dim3(256), InfHeadLds<T>::bytes, s,
+              a->ctl, hp, hv, (const float*)pf->p[pf->logstd], eps, E, pf->cfg.out_dim, acts_roll, values_roll, action,
+              mean, stdv, ent, value);
+  V4L_LAUNCH_CHECK();
+  return 0;
+}
+
+
 // ------------------------------------------------------------------------------------------ C ABI
 extern "C" {
 
@@ -1149,6 +1228,13 @@ static int run_actor_step(v4l_actor* a, const float* obs, const float* eps, floa
   v4l_net *pf = a->pf, *vf = a->vf;
   const int E = a->E;
   int rc;
+  V4L_REQUIRE(pf->bound && vf->bound, "v4l_actor_step: nets are not bound");
+  if (shared_encoder && actor_fusable(a)) {
+    if (pf->cfg.compute == V4L_BF16)
+      return run_actor_fused<__bf16>(a, obs, eps, state_roll, image_roll, acts_roll, values_roll, action, mean, stdv, ent,
+                                     value, s);
+    return run_actor_fused<float>(a, obs, eps, state_roll, image_roll, acts_roll, values_roll, action, mean, stdv, ent, value, s);
+  }
   PhaseScope ps("rollout");
   g_op = "ctl";
   V4L_KLAUNCH("act_begin", 0, s, act_begin_kernel, dim3(1), dim3(256), 0, s, a->ctl, E, a->rowidx);

@@ -28,7 +28,7 @@ class RolloutActor:
     the action and reads the value. `step(ob)` returns {"action","mean","std","ent","value"}; with
     `attach(replay_buffer)` of a DeviceOnPolicyReplayBuffer it also files observation/action/value into HBM."""
 
-    def __init__(self, pf, vf, env_nums, graph=True):
+    def __init__(self, pf, vf, env_nums, graph=False):
         from ...engine import HipActor
         self._actor = HipActor(pf.hip, vf.hip, env_nums, graph=graph)
 
