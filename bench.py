@@ -129,8 +129,10 @@ class Epoch:
         wl, ag = self.wl, self.agent
         E, T, B = wl["E"], wl["T"], wl["B"]
         last_value = self.vf(self.obs[-E:]).view(E).double() * (1 - self.terminals[-1])
+        if not hasattr(self, "_gae_out"):
+            self._gae_out = {}
         _, _, a32, r32 = engine.gae(self.rewards, self.values.view(T, E).double(), self.terminals, self.time_limits,
-                                    last_value, 0.99, 0.95, True)
+                                    last_value, 0.99, 0.95, True, out=self._gae_out)
         ag.current_epoch = self.epoch
         atu.update_linear_schedule(ag.pf_optimizer, ag.current_epoch, ag.num_epochs, ag.plr)
         atu.update_linear_schedule(ag.vf_optimizer, ag.current_epoch, ag.num_epochs, ag.vlr)
@@ -297,6 +299,7 @@ def main():
             torch.cuda.synchronize()
             t_roll += time.perf_counter() - r0
         ep.update()
+        torch.cuda.synchronize()  # keeps the rollout/update split honest (one sync per epoch)
     barrier()
     dt = time.perf_counter() - t0
     if world > 1:

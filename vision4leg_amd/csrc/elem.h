@@ -40,122 +40,105 @@ constexpr int ATT_PLD = 20;
 
 __global__ __launch_bounds__(256) void attn_fwd_kernel(const float* __restrict__ qkv, int n, float* __restrict__ P,
                                                        float* __restrict__ ctx) {
-  __shared__ float sq[4][NTOK * ATT_LD], sk[4][NTOK * ATT_LD], sv[4][NTOK * ATT_LD], sp[4][NTOK * ATT_PLD];
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  const int b = blockIdx.x * 4 + w;
-  const bool act = b < n;
-  float *q = sq[w], *k = sk[w], *v = sv[w], *p = sp[w];
-  if (act) {
-    const float* src = qkv + (int64_t)b * NTOK * 3 * TD;
-    for (int idx = lane; idx < NTOK * 3 * TD; idx += 64) {
-      const int t = idx / (3 * TD), c = idx - t * 3 * TD;
-      const int part = c >> 6, d = c & 63;
-      const float x = src[idx];
-      (part == 0 ? q : part == 1 ? k : v)[t * ATT_LD + d] = x;
-    }
+  // one sample per block: the 289 scores and the 17x64 context are spread over all 256 threads (the per-sample
+  // dependency chain, not throughput, is what bounds this kernel)
+  __shared__ float q[NTOK * ATT_LD], k[NTOK * ATT_LD], v[NTOK * ATT_LD], p[NTOK * ATT_PLD];
+  const int tid = threadIdx.x;
+  const int b = blockIdx.x;
+  const float* src = qkv + (int64_t)b * NTOK * 3 * TD;
+  for (int idx = tid; idx < NTOK * 3 * TD; idx += 256) {
+    const int t = idx / (3 * TD), c = idx - t * 3 * TD;
+    const int part = c >> 6, d = c & 63;
+    (part == 0 ? q : part == 1 ? k : v)[t * ATT_LD + d] = src[idx];
   }
   __syncthreads();
-  if (act) {
-    for (int pr = lane; pr < NTOK * NTOK; pr += 64) {
-      const int i = pr / NTOK, j = pr - i * NTOK;
-      float s = 0.f;
+  for (int pr = tid; pr < NTOK * NTOK; pr += 256) {
+    const int i = pr / NTOK, j = pr - i * NTOK;
+    float s = 0.f;
 #pragma unroll 16
-      for (int d = 0; d < TD; ++d) s = fmaf(q[i * ATT_LD + d], k[j * ATT_LD + d], s);
-      p[i * ATT_PLD + j] = s * 0.125f;
-    }
+    for (int d = 0; d < TD; ++d) s = fmaf(q[i * ATT_LD + d], k[j * ATT_LD + d], s);
+    p[i * ATT_PLD + j] = s * 0.125f;
   }
   __syncthreads();
-  if (act && lane < NTOK) {
+  if (tid < NTOK) {
     float mx = -INFINITY;
-    for (int j = 0; j < NTOK; ++j) mx = fmaxf(mx, p[lane * ATT_PLD + j]);
+    for (int j = 0; j < NTOK; ++j) mx = fmaxf(mx, p[tid * ATT_PLD + j]);
     float e[NTOK], sum = 0.f;
 #pragma unroll
-    for (int j = 0; j < NTOK; ++j) { e[j] = expf(p[lane * ATT_PLD + j] - mx); sum += e[j]; }
+    for (int j = 0; j < NTOK; ++j) { e[j] = expf(p[tid * ATT_PLD + j] - mx); sum += e[j]; }
     const float inv = 1.f / sum;
 #pragma unroll
     for (int j = 0; j < NTOK; ++j) {
       const float pv = e[j] * inv;
-      p[lane * ATT_PLD + j] = pv;
-      P[((int64_t)b * NTOK + lane) * NTOK + j] = pv;
+      p[tid * ATT_PLD + j] = pv;
+      P[((int64_t)b * NTOK + tid) * NTOK + j] = pv;
     }
   }
   __syncthreads();
-  if (act) {
-    for (int i = 0; i < NTOK; ++i) {
-      float a = 0.f;
+  for (int o = tid; o < NTOK * TD; o += 256) {
+    const int i = o >> 6, d = o & 63;
+    float a = 0.f;
 #pragma unroll
-      for (int j = 0; j < NTOK; ++j) a = fmaf(p[i * ATT_PLD + j], v[j * ATT_LD + lane], a);
-      ctx[((int64_t)b * NTOK + i) * TD + lane] = a;
-    }
+    for (int j = 0; j < NTOK; ++j) a = fmaf(p[i * ATT_PLD + j], v[j * ATT_LD + d], a);
+    ctx[(int64_t)b * NTOK * TD + o] = a;
   }
 }
 
 // Backward of the above: given dctx, saved P and qkv -> dqkv (same packed layout).
 //   dV = P^T dctx ; dP = dctx V^T ; dS = P o (dP - rowsum(P o dP)) ; dQ = dS K / 8 ; dK = dS^T Q / 8
-__global__ __launch_bounds__(128) void attn_bwd_kernel(const float* __restrict__ qkv, const float* __restrict__ P,
+__global__ __launch_bounds__(256) void attn_bwd_kernel(const float* __restrict__ qkv, const float* __restrict__ P,
                                                        const float* __restrict__ dctx, int n,
                                                        float* __restrict__ dqkv) {
-  // 2 samples per block: four 17x65 fp32 tiles per sample would pass the 64 KiB static-LDS limit at 4
-  __shared__ float sq[2][NTOK * ATT_LD], sk[2][NTOK * ATT_LD], sv[2][NTOK * ATT_LD], sd[2][NTOK * ATT_LD];
-  __shared__ float sp[2][NTOK * ATT_PLD], sds[2][NTOK * ATT_PLD];
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  const int b = blockIdx.x * 2 + w;
-  const bool act = b < n;
-  float *q = sq[w], *k = sk[w], *v = sv[w], *dc = sd[w], *p = sp[w], *ds = sds[w];
-  if (act) {
-    const float* src = qkv + (int64_t)b * NTOK * 3 * TD;
-    for (int idx = lane; idx < NTOK * 3 * TD; idx += 64) {
-      const int t = idx / (3 * TD), c = idx - t * 3 * TD;
-      const int part = c >> 6, d = c & 63;
-      (part == 0 ? q : part == 1 ? k : v)[t * ATT_LD + d] = src[idx];
-    }
-    for (int t = 0; t < NTOK; ++t) dc[t * ATT_LD + lane] = dctx[((int64_t)b * NTOK + t) * TD + lane];
-    for (int pr = lane; pr < NTOK * NTOK; pr += 64) {
-      const int i = pr / NTOK, j = pr - i * NTOK;
-      p[i * ATT_PLD + j] = P[(int64_t)b * NTOK * NTOK + pr];
-    }
+  __shared__ float q[NTOK * ATT_LD], k[NTOK * ATT_LD], v[NTOK * ATT_LD], dc[NTOK * ATT_LD];
+  __shared__ float p[NTOK * ATT_PLD], ds[NTOK * ATT_PLD];
+  const int tid = threadIdx.x;
+  const int b = blockIdx.x;
+  const float* src = qkv + (int64_t)b * NTOK * 3 * TD;
+  for (int idx = tid; idx < NTOK * 3 * TD; idx += 256) {
+    const int t = idx / (3 * TD), c = idx - t * 3 * TD;
+    const int part = c >> 6, d = c & 63;
+    (part == 0 ? q : part == 1 ? k : v)[t * ATT_LD + d] = src[idx];
+  }
+  for (int o = tid; o < NTOK * TD; o += 256) dc[(o >> 6) * ATT_LD + (o & 63)] = dctx[(int64_t)b * NTOK * TD + o];
+  for (int pr = tid; pr < NTOK * NTOK; pr += 256) {
+    const int i = pr / NTOK, j = pr - i * NTOK;
+    p[i * ATT_PLD + j] = P[(int64_t)b * NTOK * NTOK + pr];
   }
   __syncthreads();
   float* dst = dqkv + (int64_t)b * NTOK * 3 * TD;
-  if (act) {
-    // dV[j][d], lane = d
-    for (int j = 0; j < NTOK; ++j) {
-      float a = 0.f;
+  for (int o = tid; o < NTOK * TD; o += 256) {  // dV[j][d]
+    const int j = o >> 6, d = o & 63;
+    float a = 0.f;
 #pragma unroll
-      for (int i = 0; i < NTOK; ++i) a = fmaf(p[i * ATT_PLD + j], dc[i * ATT_LD + lane], a);
-      dst[j * 3 * TD + 2 * TD + lane] = a;
-    }
-    // dP[i][j], lane = pair
-    for (int pr = lane; pr < NTOK * NTOK; pr += 64) {
-      const int i = pr / NTOK, j = pr - i * NTOK;
-      float s = 0.f;
+    for (int i = 0; i < NTOK; ++i) a = fmaf(p[i * ATT_PLD + j], dc[i * ATT_LD + d], a);
+    dst[j * 3 * TD + 2 * TD + d] = a;
+  }
+  for (int pr = tid; pr < NTOK * NTOK; pr += 256) {  // dP[i][j]
+    const int i = pr / NTOK, j = pr - i * NTOK;
+    float s = 0.f;
 #pragma unroll 16
-      for (int d = 0; d < TD; ++d) s = fmaf(dc[i * ATT_LD + d], v[j * ATT_LD + d], s);
-      ds[i * ATT_PLD + j] = s;
-    }
+    for (int d = 0; d < TD; ++d) s = fmaf(dc[i * ATT_LD + d], v[j * ATT_LD + d], s);
+    ds[i * ATT_PLD + j] = s;
   }
   __syncthreads();
-  if (act && lane < NTOK) {
+  if (tid < NTOK) {
     float rd = 0.f;
 #pragma unroll
-    for (int j = 0; j < NTOK; ++j) rd = fmaf(p[lane * ATT_PLD + j], ds[lane * ATT_PLD + j], rd);
+    for (int j = 0; j < NTOK; ++j) rd = fmaf(p[tid * ATT_PLD + j], ds[tid * ATT_PLD + j], rd);
 #pragma unroll
-    for (int j = 0; j < NTOK; ++j) ds[lane * ATT_PLD + j] = p[lane * ATT_PLD + j] * (ds[lane * ATT_PLD + j] - rd);
+    for (int j = 0; j < NTOK; ++j) ds[tid * ATT_PLD + j] = p[tid * ATT_PLD + j] * (ds[tid * ATT_PLD + j] - rd);
   }
   __syncthreads();
-  if (act) {
-    for (int i = 0; i < NTOK; ++i) {  // dQ[i][d]
-      float a = 0.f;
+  for (int o = tid; o < NTOK * TD; o += 256) {
+    const int t = o >> 6, d = o & 63;
+    float aq = 0.f, ak = 0.f;
 #pragma unroll
-      for (int j = 0; j < NTOK; ++j) a = fmaf(ds[i * ATT_PLD + j], k[j * ATT_LD + lane], a);
-      dst[i * 3 * TD + lane] = a * 0.125f;
+    for (int j = 0; j < NTOK; ++j) {
+      aq = fmaf(ds[t * ATT_PLD + j], k[j * ATT_LD + d], aq);  // dQ[t][d] = sum_j dS[t][j] K[j][d]
+      ak = fmaf(ds[j * ATT_PLD + t], q[j * ATT_LD + d], ak);  // dK[t][d] = sum_i dS[i][t] Q[i][d]
     }
-    for (int j = 0; j < NTOK; ++j) {  // dK[j][d]
-      float a = 0.f;
-#pragma unroll
-      for (int i = 0; i < NTOK; ++i) a = fmaf(ds[i * ATT_PLD + j], q[i * ATT_LD + lane], a);
-      dst[j * 3 * TD + TD + lane] = a * 0.125f;
-    }
+    dst[t * 3 * TD + d] = aq * 0.125f;
+    dst[t * 3 * TD + TD + d] = ak * 0.125f;
   }
 }
 
@@ -186,19 +169,42 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
                                                      const float* __restrict__ rstd, const float* __restrict__ gamma,
                                                      int rows, float* __restrict__ dz, float* __restrict__ dgamma,
                                                      float* __restrict__ dbeta) {
+  // few blocks (the per-block dgamma/dbeta atomics hit only 128 addresses), so each wave walks many rows: four rows
+  // are kept in flight per iteration to overlap their load -> reduce -> store chains
   __shared__ float sg[4][TD], sb[4][TD];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const float g = gamma[lane];
   float ag = 0.f, ab = 0.f;
-  for (int r = blockIdx.x * 4 + w; r < rows; r += gridDim.x * 4) {
-    const int64_t o = (int64_t)r * TD + lane;
-    const float d = dout[o], xh = xhat[o];
-    ag = fmaf(d, xh, ag);
-    ab += d;
-    const float dxh = d * g;
-    const float c1 = wave_sum(dxh) * (1.f / TD);
-    const float c2 = wave_sum(dxh * xh) * (1.f / TD);
-    dz[o] = rstd[r] * (dxh - c1 - xh * c2);
+  for (int r0 = (blockIdx.x * 4 + w) * 4; r0 < rows; r0 += gridDim.x * 16) {
+    float d[4], xh[4], rs[4], dxh[4], c1[4], c2[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const bool ok = r0 + u < rows;
+      const int64_t o = (int64_t)(ok ? r0 + u : 0) * TD + lane;
+      const float dd = dout[o], xx = xhat[o];
+      rs[u] = rstd[ok ? r0 + u : 0];
+      d[u] = ok ? dd : 0.f;
+      xh[u] = ok ? xx : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      ag = fmaf(d[u], xh[u], ag);
+      ab += d[u];
+      dxh[u] = d[u] * g;
+      c1[u] = dxh[u];
+      c2[u] = dxh[u] * xh[u];
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1)
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        c1[u] += __shfl_xor(c1[u], o, 64);
+        c2[u] += __shfl_xor(c2[u], o, 64);
+      }
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+      if (r0 + u < rows)
+        dz[(int64_t)(r0 + u) * TD + lane] = rs[u] * (dxh[u] - c1[u] * (1.f / TD) - xh[u] * (c2[u] * (1.f / TD)));
   }
   sg[w][lane] = ag;
   sb[w][lane] = ab;

@@ -53,24 +53,39 @@ __device__ __forceinline__ bf16x8 afrag_t(const __bf16* p) {  // 8-byte aligned 
 }
 __device__ __forceinline__ f32x8 afrag_t(const float* p) { return *reinterpret_cast<const f32x8*>(p); }
 
-// acc[mt][j] += A[mt-th row tile] * W[ntile[j]]^T over `ksteps` K=32 steps. A: LDS, row stride lda, element AT.
-template <typename T, int MT, int NTW, typename AT>
+// acc[mt][j] += A[mt-th row tile] * W[ntile[j]]^T over KS K=32 steps. A: LDS, row stride lda, element AT.
+// The weight fragments come straight from L2/HBM: a ring of PD k-steps of them is kept in flight (a load issued per
+// step consumed) so the MFMAs never wait for a just-issued global load.
+template <typename T, int MT, int NTW, int KS, typename AT>
 __device__ __forceinline__ void block_gemm(f32x4 (&acc)[MT][NTW], const AT* sA, int lda, const T* __restrict__ Wp, int Kp,
-                                           int ksteps, const int (&ntile)[NTW], int lane) {
+                                           const int (&ntile)[NTW], int lane) {
   typedef typename Frag<T>::type frag_t;
+  constexpr int PD = KS < 4 ? KS : 4;
   const int fr = lane & 15, fg = (lane >> 4) * 8;
-  for (int ks = 0; ks < ksteps; ++ks) {
-    frag_t fb[NTW];
+  const T* wrow[NTW];
 #pragma unroll
-    for (int j = 0; j < NTW; ++j)
-      fb[j] = *reinterpret_cast<const frag_t*>(Wp + (int64_t)(ntile[j] * 16 + fr) * Kp + ks * 32 + fg);
+  for (int j = 0; j < NTW; ++j) wrow[j] = Wp + (int64_t)(ntile[j] * 16 + fr) * Kp + fg;
+  frag_t fb[PD][NTW];
+#pragma unroll
+  for (int d = 0; d < PD; ++d)
+#pragma unroll
+    for (int j = 0; j < NTW; ++j) fb[d][j] = *reinterpret_cast<const frag_t*>(wrow[j] + d * 32);
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) {
+    frag_t cur[NTW];
+#pragma unroll
+    for (int j = 0; j < NTW; ++j) cur[j] = fb[ks % PD][j];
+    if (ks + PD < KS) {
+#pragma unroll
+      for (int j = 0; j < NTW; ++j) fb[ks % PD][j] = *reinterpret_cast<const frag_t*>(wrow[j] + (ks + PD) * 32);
+    }
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
       frag_t fa;
       if constexpr (sizeof(AT) == sizeof(T)) fa = *reinterpret_cast<const frag_t*>(sA + (mt * 16 + fr) * lda + ks * 32 + fg);
       else fa = afrag<T>(reinterpret_cast<const float*>(sA) + (mt * 16 + fr) * lda + ks * 32 + fg);
 #pragma unroll
-      for (int j = 0; j < NTW; ++j) mma_k32(acc[mt][j], fa, fb[j]);
+      for (int j = 0; j < NTW; ++j) mma_k32(acc[mt][j], fa, cur[j]);
     }
   }
 }
@@ -144,17 +159,18 @@ __global__ __launch_bounds__(256) void infer_encoder_kernel(const ActCtl* __rest
           }
     };
     zero_acc(acc);
-    block_gemm<T, 2, 4>(acc, sin, LY::LDS_IN, (const T*)w.wf1, w.Kp1, w.Kp1 / 32, nt4, lane);
+    if (w.Kp1 == 128) block_gemm<T, 2, 4, 4>(acc, sin, LY::LDS_IN, (const T*)w.wf1, 128, nt4, lane);
+    else block_gemm<T, 2, 4, 2>(acc, sin, LY::LDS_IN, (const T*)w.wf1, 64, nt4, lane);
     store_h(h1, w.bf1);
     __syncthreads();
     zero_acc(acc);
-    block_gemm<T, 2, 4>(acc, h1, LY::LDH, (const T*)w.wf2, 256, 8, nt4, lane);
+    block_gemm<T, 2, 4, 8>(acc, h1, LY::LDH, (const T*)w.wf2, 256, nt4, lane);
     store_h(h2, w.bf2);
     __syncthreads();
     const int nt1[1] = {wave};
     f32x4 ap[2][1];
     zero_acc(ap);
-    block_gemm<T, 2, 1>(ap, h2, LY::LDH, (const T*)w.wpr, 256, 8, nt1, lane);
+    block_gemm<T, 2, 1, 8>(ap, h2, LY::LDH, (const T*)w.wpr, 256, nt1, lane);
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
@@ -197,11 +213,16 @@ __global__ __launch_bounds__(256) void infer_encoder_kernel(const ActCtl* __rest
       const int p = min((wave + 4 * i) * 16 + fr, 224);
       pbase[i] = (p / 15) * 4 * 64 + (p % 15) * 4;
     }
+    frag_t fbn[8][2];  // all 8 k-steps of conv1's two column tiles (16 KB of weights per block) up front
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+        fbn[ks][j] = *reinterpret_cast<const frag_t*>((const T*)w.w1 + (j * 16 + fr) * 256 + ks * 32 + fg);
+#pragma unroll
     for (int ks = 0; ks < 8; ++ks) {
       const int k0 = ks * 32 + fg, c = k0 >> 6, ky = (k0 >> 3) & 7;
-      frag_t fb[2];
-#pragma unroll
-      for (int j = 0; j < 2; ++j) fb[j] = *reinterpret_cast<const frag_t*>((const T*)w.w1 + (j * 16 + fr) * 256 + k0);
+      frag_t fb[2] = {fbn[ks][0], fbn[ks][1]};
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         if (wave + 4 * i < 15) {
@@ -231,9 +252,15 @@ __global__ __launch_bounds__(256) void infer_encoder_kernel(const ActCtl* __rest
       const int p = min(i * 16 + fr, 35);
       pb[i] = ((p / 6) * 2 * 15 + (p % 6) * 2) * LY::LD1;
     }
+    const T* w2row = (const T*)w.w2 + (wave * 16 + fr) * 512 + fg;
+    frag_t ring[4];
+#pragma unroll
+    for (int d = 0; d < 4; ++d) ring[d] = *reinterpret_cast<const frag_t*>(w2row + d * 32);
+#pragma unroll
     for (int ks = 0; ks < 16; ++ks) {
       const int tap = ks, ky = tap >> 2, kx = tap & 3;  // 32 channels per tap == one K=32 step
-      const frag_t fb = *reinterpret_cast<const frag_t*>((const T*)w.w2 + (wave * 16 + fr) * 512 + ks * 32 + fg);
+      const frag_t fb = ring[ks & 3];
+      if (ks + 4 < 16) ring[ks & 3] = *reinterpret_cast<const frag_t*>(w2row + (ks + 4) * 32);
 #pragma unroll
       for (int i = 0; i < 3; ++i) {
         const frag_t fa = afrag_t(c1 + pb[i] + (ky * 15 + kx) * LY::LD1 + fg);
@@ -252,9 +279,15 @@ __global__ __launch_bounds__(256) void infer_encoder_kernel(const ActCtl* __rest
   {  // conv3: 16 pixels, K = (ky,kx,c) = 576 (two K=32 steps per tap), N = 64
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
     const int pb = ((fr >> 2) * 6 + (fr & 3)) * LY::LD2;
+    const T* w3row = (const T*)w.w3 + (wave * 16 + fr) * 576 + fg;
+    frag_t ring[6];
+#pragma unroll
+    for (int d = 0; d < 6; ++d) ring[d] = *reinterpret_cast<const frag_t*>(w3row + d * 32);
+#pragma unroll
     for (int ks = 0; ks < 18; ++ks) {
       const int tap = ks >> 1, ky = tap / 3, kx = tap - ky * 3, c0 = (ks & 1) * 32 + fg;
-      const frag_t fb = *reinterpret_cast<const frag_t*>((const T*)w.w3 + (wave * 16 + fr) * 576 + ks * 32 + fg);
+      const frag_t fb = ring[ks % 6];
+      if (ks + 6 < 18) ring[ks % 6] = *reinterpret_cast<const frag_t*>(w3row + (ks + 6) * 32);
       const frag_t fa = afrag_t(c2 + pb + (ky * 6 + kx) * LY::LD2 + c0);
       mma_k32(acc, fa, fb);
     }
@@ -335,7 +368,7 @@ __global__ __launch_bounds__(256) void infer_layer_kernel(InfLayerPair pr, int E
     const int nt[3] = {wave, wave + 4, wave + 8};
     f32x4 acc[INF_MT][3];
     zero_acc(acc);
-    block_gemm<T, INF_MT, 3>(acc, xs, LY::LDX, (const T*)w.win, 64, 2, nt, lane);
+    block_gemm<T, INF_MT, 3, 2>(acc, xs, LY::LDX, (const T*)w.win, 64, nt, lane);
 #pragma unroll
     for (int mt = 0; mt < INF_MT; ++mt)
 #pragma unroll
@@ -388,7 +421,7 @@ __global__ __launch_bounds__(256) void infer_layer_kernel(InfLayerPair pr, int E
   {  // out_proj + residual -> z (in `big`, fp32 [80][LDX])
     f32x4 acc[INF_MT][1];
     zero_acc(acc);
-    block_gemm<T, INF_MT, 1>(acc, cx, LY::LDX, (const T*)w.wo, 64, 2, nt1, lane);
+    block_gemm<T, INF_MT, 1, 2>(acc, cx, LY::LDX, (const T*)w.wo, 64, nt1, lane);
 #pragma unroll
     for (int mt = 0; mt < INF_MT; ++mt)
 #pragma unroll
@@ -405,7 +438,7 @@ __global__ __launch_bounds__(256) void infer_layer_kernel(InfLayerPair pr, int E
     const int nt4[4] = {wave * 4, wave * 4 + 1, wave * 4 + 2, wave * 4 + 3};
     f32x4 acc[INF_MT][4];
     zero_acc(acc);
-    block_gemm<T, INF_MT, 4>(acc, xs, LY::LDX, (const T*)w.w1, 64, 2, nt4, lane);
+    block_gemm<T, INF_MT, 4, 2>(acc, xs, LY::LDX, (const T*)w.w1, 64, nt4, lane);
 #pragma unroll
     for (int mt = 0; mt < INF_MT; ++mt)
 #pragma unroll
@@ -420,7 +453,7 @@ __global__ __launch_bounds__(256) void infer_layer_kernel(InfLayerPair pr, int E
   {  // linear2 + residual -> z2 (in `cx`)
     f32x4 acc[INF_MT][1];
     zero_acc(acc);
-    block_gemm<T, INF_MT, 1>(acc, f, LY::LDF, (const T*)w.w2, 256, 8, nt1, lane);
+    block_gemm<T, INF_MT, 1, 8>(acc, f, LY::LDF, (const T*)w.w2, 256, nt1, lane);
 #pragma unroll
     for (int mt = 0; mt < INF_MT; ++mt)
 #pragma unroll
@@ -502,18 +535,18 @@ __global__ __launch_bounds__(256) void infer_head_kernel(ActCtl* ctl, InfHead hp
             }
       };
       zero_acc(acc);
-      block_gemm<T, 2, 4>(acc, pooled, LY::LDP, (const T*)h.w0, 128, 4, nt4, lane);
+      block_gemm<T, 2, 4, 4>(acc, pooled, LY::LDP, (const T*)h.w0, 128, nt4, lane);
       store_h(h1, h.b0);
       __syncthreads();
       zero_acc(acc);
-      block_gemm<T, 2, 4>(acc, h1, LY::LDH, (const T*)h.w1, 256, 8, nt4, lane);
+      block_gemm<T, 2, 4, 8>(acc, h1, LY::LDH, (const T*)h.w1, 256, nt4, lane);
       store_h(h2, h.b1);
       __syncthreads();
       if (wave < 2) {  // last layer: one 16-column tile; wave w takes row tile w of this pass
         const int nt0[1] = {0};
         f32x4 a1[1][1];
         zero_acc(a1);
-        block_gemm<T, 1, 1>(a1, h2 + wave * 16 * LY::LDH, LY::LDH, (const T*)h.w2, 256, 8, nt0, lane);
+        block_gemm<T, 1, 1, 8>(a1, h2 + wave * 16 * LY::LDH, LY::LDH, (const T*)h.w2, 256, nt0, lane);
         const int nout = net == 0 ? A : 1;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {

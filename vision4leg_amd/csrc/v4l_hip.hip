@@ -675,7 +675,7 @@ int v4l_net::forward_t(const float* state, const T* image, const int* rowidx, in
       float* xin = l == 0 ? x0 : ws + L.x[l];
       if ((rc = lin_fwd<T>(cx, t.inproj, dense(xin, TD, R, TD), mk_epi(ws + w.qkv, 3 * TD, 3 * TD)))) return rc;
       g_op = "attn";
-      V4L_KLAUNCH("attn_fwd", 4.0 * n * NTOK * NTOK * TD, s, attn_fwd_kernel, dim3(cdiv(n, 4)), dim3(256), 0, s, ws + w.qkv, n, ws + w.P, ws + w.ctx);
+      V4L_KLAUNCH("attn_fwd", 4.0 * n * NTOK * NTOK * TD, s, attn_fwd_kernel, dim3(n), dim3(256), 0, s, ws + w.qkv, n, ws + w.P, ws + w.ctx);
       V4L_LAUNCH_CHECK();
       if ((rc = lin_fwd<T>(cx, t.outproj, dense(ws + w.ctx, TD, R, TD), mk_epi(ws + L.ytmp, TD, TD)))) return rc;
       g_op = "ln1";
@@ -770,7 +770,7 @@ int v4l_net::backward_t(const float* state, const T* image, const int* rowidx, i
   g_op = "pool";
   V4L_KLAUNCH("pool_bwd", 0, s, pool_bwd_kernel, dim3(n), dim3(64), 0, s, ws + L.dpool, n, dx);
   V4L_LAUNCH_CHECK();
-  const int lnb = std::min(cdiv(R, 4), 128);  // few blocks: the per-block dgamma/dbeta atomics hit 128 addresses
+  const int lnb = std::min(cdiv(R, 16), 128);  // few blocks: the per-block dgamma/dbeta atomics hit 128 addresses
   for (int l = c.n_layers - 1; l >= 0; --l) {
     const TLayer& t = layers[l];
     const LayerWs& w = L.lw[l];
@@ -806,7 +806,7 @@ int v4l_net::backward_t(const float* state, const T* image, const int* rowidx, i
       if ((rc = lin_dgrad<T>(cx, t.outproj, y, mk_epi(ws + L.dctx, TD, TD)))) return rc;
       if ((rc = par_end(cx))) return rc;
       g_op = "attn";
-      V4L_KLAUNCH("attn_bwd", 8.0 * n * NTOK * NTOK * TD, s, attn_bwd_kernel, dim3(cdiv(n, 2)), dim3(128), 0, s, ws + w.qkv, ws + w.P, ws + L.dctx, n,
+      V4L_KLAUNCH("attn_bwd", 8.0 * n * NTOK * NTOK * TD, s, attn_bwd_kernel, dim3(n), dim3(256), 0, s, ws + w.qkv, ws + w.P, ws + L.dctx, n,
                          ws + L.dqkv);
       V4L_LAUNCH_CHECK();
       ADense yq = dense(ws + L.dqkv, 3 * TD, R, 3 * TD);

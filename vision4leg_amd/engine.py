@@ -65,6 +65,8 @@ class HipNet:
       self.param_shapes.append(tuple(shape[d] for d in range(ndim.value)))
       self.grad_offsets.append(goff.value)
     self._ptrs = None
+    self._tlist = None
+    self._vsum = None
     self._versions = None
     self._dirty = True
     self._ws = {}
@@ -96,8 +98,22 @@ class HipNet:
       ts.append(t)
     return ts
 
-  def ensure_bound(self):
+  def ensure_bound(self, fast=False):
+    """Re-register parameter pointers / detect in-place parameter changes. fast=True (per-step callers) checks the
+    cached tensor list only: versions of all tensors and the storage address of the first and last one."""
+    if fast and self._tlist is not None:
+      ts = self._tlist
+      if ts[0].data_ptr() == self._ptrs[0] and ts[-1].data_ptr() == self._ptrs[-1]:
+        vers = 0
+        for t in ts:
+          vers += t._version
+        if vers != self._vsum:
+          self._vsum = vers
+          self._versions = [t._version for t in ts]
+          self._dirty = True
+        return ts
     ts = self._tensors()
+    self._tlist = ts
     ptrs = [t.data_ptr() for t in ts]
     if ptrs != self._ptrs:
       self.device = ts[0].device
@@ -114,14 +130,15 @@ class HipNet:
     if vers != self._versions:
       self._versions = vers
       self._dirty = True
+    self._vsum = sum(vers)
     return ts
 
   def mark_dirty(self):
     """Parameters were changed behind torch's back (an optimiser step inside the library)."""
     self._dirty = True
 
-  def pack_if_needed(self):
-    self.ensure_bound()
+  def pack_if_needed(self, fast=False):
+    self.ensure_bound(fast)
     if self._dirty:
       check(self.L.v4l_net_pack(self.h, _stream()), "v4l_net_pack")
       self._dirty = False
@@ -393,6 +410,12 @@ class HipActor:
       st, im = self.pf.alloc_rollout(self.E, self.device)
       rollout = (st, im, None, None)
     self.rollout = rollout
+    st, im, acts, vals = rollout
+    self._obs_ptr = self.obs.data_ptr()
+    self._args = (_ptr(self.obs), _ptr(self.eps), _ptr(st), _ptr(im), _ptr(acts), _ptr(vals), _ptr(self.action),
+                  _ptr(self.mean), _ptr(self.std), _ptr(self.ent), _ptr(self.value), int(self.shared_encoder),
+                  int(self.graph))
+    self._out = {"action": self.action, "mean": self.mean, "std": self.std, "ent": self.ent, "value": self.value}
 
   def seek(self, t):
     check(self.L.v4l_actor_seek(self.h, int(t), _stream()), "v4l_actor_seek")
@@ -401,35 +424,47 @@ class HipActor:
     """obs: [E][S+C*H*W] float32 cuda rows of this env step. Returns a dict of views of fixed output buffers
     (valid until the next step): action/mean/std [E][A], ent/value [E][1]."""
     _require_gpu(obs, "observation batch")
-    cur = torch.cuda.current_stream(self.device)
-    with torch.cuda.stream(self.stream):
+    if self.graph:  # capture needs a non-default stream
+      cur = torch.cuda.current_stream(self.device)
       self.stream.wait_stream(cur)
-      self.pf.pack_if_needed()
-      self.vf.pack_if_needed()
-      if obs.data_ptr() != self.obs.data_ptr():
-        self.obs.copy_(obs.reshape(self.obs.shape), non_blocking=True)
-      self.eps.normal_()  # torch's generator: the same standard-normal draws Normal(mean, std).sample() would use
-      if self.own:
-        self.seek(0)
-      st, im, acts, vals = self.rollout
-      check(self.L.v4l_actor_step(self.h, _ptr(self.obs), _ptr(self.eps), _ptr(st), _ptr(im), _ptr(acts), _ptr(vals),
-                                  _ptr(self.action), _ptr(self.mean), _ptr(self.std), _ptr(self.ent), _ptr(self.value),
-                                  int(self.shared_encoder), int(self.graph), _stream()), "v4l_actor_step")
-    cur.wait_stream(self.stream)
-    return {"action": self.action, "mean": self.mean, "std": self.std, "ent": self.ent, "value": self.value}
+      with torch.cuda.stream(self.stream):
+        self._step(obs)
+      cur.wait_stream(self.stream)
+    else:
+      self._step(obs)
+    return self._out
+
+  def _step(self, obs):
+    self.pf.pack_if_needed(fast=True)
+    self.vf.pack_if_needed(fast=True)
+    if obs.data_ptr() != self._obs_ptr:
+      self.obs.copy_(obs.reshape(self.obs.shape), non_blocking=True)
+    self.eps.normal_()  # torch's generator: the same standard-normal draws Normal(mean, std).sample() would use
+    if self.own:
+      self.seek(0)
+    check(self.L.v4l_actor_step(self.h, *self._args, _stream()), "v4l_actor_step")
 
 
-def gae(rewards, values, terminals, time_limits, last_value, gamma, tau, use_time_limit, want32=True):
-  """HIP GAE on float64 cuda tensors [T][E] (time_limits [T] or [T][E]); returns (advs, rets, advs32, rets32)."""
+def gae(rewards, values, terminals, time_limits, last_value, gamma, tau, use_time_limit, want32=True, out=None):
+  """HIP GAE on float64 cuda tensors [T][E] (time_limits [T] or [T][E]); returns (advs, rets, advs32, rets32).
+  out: a dict that keeps the output / scratch tensors between calls, so their addresses stay stable across epochs
+  (the captured update graph is keyed on the rollout pointers)."""
   L = _lib.lib()
   T, E = rewards.shape
-  advs = torch.empty(T, E, dtype=torch.float64, device=rewards.device)
-  rets = torch.empty_like(advs)
-  a32 = torch.empty(T, E, dtype=torch.float32, device=rewards.device) if want32 else None
-  r32 = torch.empty_like(a32) if want32 else None
+  dev = rewards.device
+  key = (T, E, bool(want32), str(dev))
+  if out is not None and out.get("key") == key:
+    advs, rets, a32, r32, scratch = out["bufs"]
+  else:
+    advs = torch.empty(T, E, dtype=torch.float64, device=dev)
+    rets = torch.empty_like(advs)
+    a32 = torch.empty(T, E, dtype=torch.float32, device=dev) if want32 else None
+    r32 = torch.empty_like(a32) if want32 else None
+    scratch = torch.empty(3 * T * E, dtype=torch.float64, device=dev)
+    if out is not None:
+      out["key"], out["bufs"] = key, (advs, rets, a32, r32, scratch)
   tl_per_env = int(time_limits is not None and time_limits.dim() == 2 and time_limits.shape[1] == E and E > 1
                    or (time_limits is not None and time_limits.numel() == T * E and E == 1))
-  scratch = torch.empty(3 * T * E, dtype=torch.float64, device=rewards.device)
   check(L.v4l_gae(_ptr(rewards), _ptr(values), _ptr(terminals), _ptr(time_limits), tl_per_env, _ptr(last_value), T, E,
                   float(gamma), float(tau), int(bool(use_time_limit)), _ptr(scratch), _ptr(advs), _ptr(rets), _ptr(a32),
                   _ptr(r32), _stream()), "v4l_gae")

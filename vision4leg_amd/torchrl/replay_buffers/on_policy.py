@@ -15,7 +15,7 @@ from .base import BaseReplayBuffer
 from ... import engine
 
 
-def _gae_on_device(rewards, values, terminals, time_limits, last_value, gamma, tau, use_tl, device):
+def _gae_on_device(rewards, values, terminals, time_limits, last_value, gamma, tau, use_tl, device, out=None):
     """numpy [T,E,1] float64 in -> numpy [T,E,1] float64 advantages / returns via libv4l_hip's v4l_gae."""
     T, E = rewards.shape[0], rewards.shape[1]
     up = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float64).reshape(T, -1)).to(device)
@@ -29,7 +29,7 @@ def _gae_on_device(rewards, values, terminals, time_limits, last_value, gamma, t
         elif tl.shape[1] != E:
             raise ValueError("time_limits has %d columns, expected 1 or %d" % (tl.shape[1], E))
     lv = torch.from_numpy(np.ascontiguousarray(last_value, dtype=np.float64).reshape(E)).to(device)
-    advs, rets, a32, r32 = engine.gae(r, v, t, tl, lv, gamma, tau, use_tl, want32=True)
+    advs, rets, a32, r32 = engine.gae(r, v, t, tl, lv, gamma, tau, use_tl, want32=True, out=out)
     return advs, rets, a32, r32
 
 
@@ -44,9 +44,11 @@ class OnPolicyReplayBufferBase:
         """GAE(lambda) over the stored epoch (reference on_policy.py:17-45); results land in _advs and
         _estimate_returns as float64 [T, E, 1] exactly like the reference."""
         dev = self.gae_device or torch.device("cuda", torch.cuda.current_device())
+        if not hasattr(self, "_gae_out"):
+            self._gae_out = {}  # persistent device outputs: stable addresses across epochs
         advs, rets, a32, r32 = _gae_on_device(self._rewards, self._values, self._terminals,
                                               getattr(self, "_time_limits", None), last_value, gamma, tau,
-                                              self.time_limit_filter, dev)
+                                              self.time_limit_filter, dev, self._gae_out)
         shape = np.shape(self._rewards)
         self._advs = advs.cpu().numpy().reshape(shape)
         self._estimate_returns = rets.cpu().numpy().reshape(shape)
@@ -125,9 +127,14 @@ class DeviceOnPolicyReplayBuffer(OnPolicyReplayBufferBase, BaseReplayBuffer):
     def device_rollout(self):
         """Device views the trainer gathers from: acts [slots][A], advs/rets/values [slots] (fp32)."""
         slots = self._max_replay_buffer_size * self.env_nums
-        acts = torch.from_numpy(np.ascontiguousarray(self._acts.reshape(slots, -1), dtype=np.float32)).to(self.device)
-        vals = torch.from_numpy(np.ascontiguousarray(self._values.reshape(slots), dtype=np.float32)).to(self.device)
-        return self._state_dev, self._image_dev, acts, self._advs32_dev, self._rets32_dev, vals
+        acts = torch.from_numpy(np.ascontiguousarray(self._acts.reshape(slots, -1), dtype=np.float32))
+        vals = torch.from_numpy(np.ascontiguousarray(self._values.reshape(slots), dtype=np.float32))
+        if self._acts_dev is None or self._acts_dev.shape != acts.shape:
+            self._acts_dev = torch.empty(acts.shape, dtype=torch.float32, device=self.device)
+            self._values32_dev = torch.empty(vals.shape, dtype=torch.float32, device=self.device)
+        self._acts_dev.copy_(acts)       # same device addresses every epoch: the update graph is keyed on them
+        self._values32_dev.copy_(vals)
+        return self._state_dev, self._image_dev, self._acts_dev, self._advs32_dev, self._rets32_dev, self._values32_dev
 
     def _gather(self, sel, sample_key):
         E = self.env_nums
