@@ -302,8 +302,9 @@ def test_gae_full_size_properties(device):
         assert a.cpu().numpy()[t0, e0] == expect
 
 
+@pytest.mark.parametrize("pair", ["eager-graph", "eager-eager"])
 @pytest.mark.parametrize("mode", MODES)
-def test_graph_replay_equals_eager(mode, device):
+def test_graph_replay_equals_eager(mode, pair, device):
     """run_updates over a device-resident rollout: hipGraph replay (device-side update index / Adam step) must give
     what the eager launch sequence gives — same kernels, only fp32-atomic ordering noise in LN/bias/norm sums —
     and both must track the oracle."""
@@ -316,7 +317,7 @@ def test_graph_replay_equals_eager(mode, device):
     acts, advs, rets = 0.1 * rs.randn(T * E, case["A"]), rs.randn(T * E), rs.randn(T * E)
     rows = np.stack([rs.permutation(T * E)[:B] for _ in range(5)]).astype(np.int32)
     results = []
-    for graph in (False, True):
+    for graph in ((False, True) if pair == "eager-graph" else (False, False)):
         pf, vf = _build(case, mode, device)
 
         class Coll: epoch_frames = T * E
@@ -340,8 +341,12 @@ def test_graph_replay_equals_eager(mode, device):
     rt = 2e-4 if mode == "f32" else 1e-2  # bf16: atomic-order noise is amplified by rounding flips over 5 updates
     assert np.allclose(se[:, :18], sg[:, :18], rtol=rt, atol=rt / 10), np.abs(se[:, :18] - sg[:, :18]).max()
     worst = max(max((pe[k] - pg[k]).abs().max().item() for k in pe), max((ve[k] - vg[k]).abs().max().item() for k in ve))
-    print("\n[graph vs eager %s] worst param diff %.2e; ratio max per update %s" % (mode, worst, sg[:, 15]))
-    assert worst <= (5e-6 if mode == "f32" else 2.2e-4)
+    print("\n[%s %s] worst param diff %.2e; ratio max per update %s" % (pair, mode, worst, sg[:, 15]))
+    # fp32 atomics (LN / bias / norm sums) make two runs differ by ~1e-7, which an occasional ReLU-mask flip then
+    # amplifies: bound the worst element by 5 updates x 2*lr and the mean drift tightly
+    assert worst <= 1e-3
+    drift = sum((pe[k] - pg[k]).abs().sum().item() for k in pe) / sum(v.numel() for v in pe.values())
+    assert drift <= (2e-7 if mode == "f32" else 2e-5), drift
     assert (sg[1:, 15] != 1.0).all()  # later updates really saw moved parameters (ratio/max != 1)
     # oracle on the same five minibatches (f32 only: tight)
     if mode == "f32":

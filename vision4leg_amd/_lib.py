@@ -7,7 +7,7 @@ import os
 import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libv4l_hip.so")
+LIB_PATH = os.environ.get("V4L_LIB", os.path.join(_HERE, "libv4l_hip.so"))  # V4L_LIB: diagnostic builds only
 SRC_DIR = os.path.join(_HERE, "csrc")
 
 V4L_F32, V4L_BF16 = 0, 1

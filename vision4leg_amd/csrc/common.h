@@ -80,21 +80,35 @@ template <typename T> struct Frag;
 template <> struct Frag<__bf16> { typedef bf16x8 type; };
 template <> struct Frag<float> { typedef f32x8 type; };
 
-// 64-lane butterfly reductions
+// 64-lane all-reduce. Rotations inside each 16-lane DPP row (v_add_f32_dpp row_ror:8/4/2/1: no LDS round trip, unlike
+// the ds_bpermute a __shfl_xor compiles to, ~10x faster) leave every lane with its row's total; the four row totals
+// are then combined through the scalar unit (v_readlane). All 64 lanes must be active.
+template <int CTRL> __device__ __forceinline__ float dpp_mov(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float lane_bcast(float v, int lane) {
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
+}
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-  return v;
+  v += dpp_mov<0x128>(v);
+  v += dpp_mov<0x124>(v);
+  v += dpp_mov<0x122>(v);
+  v += dpp_mov<0x121>(v);
+  return (lane_bcast(v, 0) + lane_bcast(v, 16)) + (lane_bcast(v, 32) + lane_bcast(v, 48));
 }
 __device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
-  return v;
+  v = fmaxf(v, dpp_mov<0x128>(v));
+  v = fmaxf(v, dpp_mov<0x124>(v));
+  v = fmaxf(v, dpp_mov<0x122>(v));
+  v = fmaxf(v, dpp_mov<0x121>(v));
+  return fmaxf(fmaxf(lane_bcast(v, 0), lane_bcast(v, 16)), fmaxf(lane_bcast(v, 32), lane_bcast(v, 48)));
 }
 __device__ __forceinline__ float wave_min(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o, 64));
-  return v;
+  v = fminf(v, dpp_mov<0x128>(v));
+  v = fminf(v, dpp_mov<0x124>(v));
+  v = fminf(v, dpp_mov<0x122>(v));
+  v = fminf(v, dpp_mov<0x121>(v));
+  return fminf(fminf(lane_bcast(v, 0), lane_bcast(v, 16)), fminf(lane_bcast(v, 32), lane_bcast(v, 48)));
 }
 
 }  // namespace v4l

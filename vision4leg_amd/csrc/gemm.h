@@ -333,57 +333,60 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(AL al, const T* __restrict
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < NT; ++j) mma_k32(acc[i][j], fa[i], fb[j]);
+        for (int j = 0; j < NT; ++j) mma_k32(acc[i][j], fb[j], fa[i]);  // transposed tile: see the epilogue
     }
     __syncthreads();
   }
 
-  // epilogue: acc[i][j][r] is C[m0 + 32*wave + 16*i + 4*(lane>>4) + r][n0 + 16*j + (lane&15)].
-  // Loads (bias, ReLU mask, accumulate target) are issued as one batch from always-valid addresses and waited for
-  // once; only the stores are predicated (see keep8 for why).
-  float bv[NT];
-  bool nok[NT];
-#pragma unroll
-  for (int j = 0; j < NT; ++j) {
-    const int n = n0 + j * 16 + (lane & 15);
-    nok[j] = n < ep.N;
-    bv[j] = ep.bias != nullptr ? ep.bias[nok[j] ? n : 0] : 0.f;
-  }
+  // epilogue. The MFMAs above were issued with the weight fragment as the "row" operand, so the accumulator tile is
+  // transposed: acc[i][j][r] = C[m][n4 + r] with m = m0 + 32*wave + 16*i + (lane&15), n4 = n0 + 16*j + 4*(lane>>4):
+  // every lane owns 4 consecutive columns of ONE output row -> one 16-byte load/store per (i,j) for bias, ReLU mask,
+  // accumulate target and result, and one row-map evaluation per i. Loads are issued from always-valid addresses and
+  // only the stores are predicated (see keep8 for why). vec: all row strides / N are multiples of 4.
+  const bool vec = ((ep.N | ep.ldc) & 3) == 0 && (ep.mask == nullptr || (ep.ldmask & 3) == 0);
+  const int ng = (lane >> 4) * 4;
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
-    int64_t orow[4];
-    bool rok[4];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int m = m0 + wave * 32 + i * 16 + (lane >> 4) * 4 + r;
-      rok[r] = m < ep.M;
-      orow[r] = ep.out_row(rok[r] ? m : 0);
-    }
-    float mk[4][NT], old[4][NT];
-    if (ep.mask != nullptr) {
-#pragma unroll
-      for (int r = 0; r < 4; ++r)
-#pragma unroll
-        for (int j = 0; j < NT; ++j)
-          mk[r][j] = ep.mask[(rok[r] && nok[j]) ? orow[r] * ep.ldmask + n0 + j * 16 + (lane & 15) : 0];
-    }
-    if (ep.accumulate) {
-#pragma unroll
-      for (int r = 0; r < 4; ++r)
-#pragma unroll
-        for (int j = 0; j < NT; ++j)
-          old[r][j] = ep.C[(rok[r] && nok[j]) ? orow[r] * ep.ldc + n0 + j * 16 + (lane & 15) : 0];
-    }
-#pragma unroll
-    for (int r = 0; r < 4; ++r)
+    const int m = m0 + wave * 32 + i * 16 + (lane & 15);
+    const bool rok = m < ep.M;
+    const int64_t orow = ep.out_row(rok ? m : 0);
+    if (vec) {
+      float4 bv[NT], mk[NT], old[NT];
 #pragma unroll
       for (int j = 0; j < NT; ++j) {
-        float v = acc[i][j][r] + bv[j];
-        if (ep.relu) v = fmaxf(v, 0.f);
-        if (ep.mask != nullptr) v = mk[r][j] > 0.f ? v : 0.f;
-        if (ep.accumulate) v += old[r][j];
-        if (rok[r] && nok[j]) ep.C[orow[r] * ep.ldc + n0 + j * 16 + (lane & 15)] = v;
+        const int n4 = n0 + j * 16 + ng;
+        const bool ok = rok && n4 < ep.N;
+        bv[j] = ep.bias != nullptr ? *reinterpret_cast<const float4*>(ep.bias + (n4 < ep.N ? n4 : 0)) : float4{0.f, 0.f, 0.f, 0.f};
+        if (ep.mask != nullptr) mk[j] = *reinterpret_cast<const float4*>(ep.mask + (ok ? orow * ep.ldmask + n4 : 0));
+        if (ep.accumulate) old[j] = *reinterpret_cast<const float4*>(ep.C + (ok ? orow * ep.ldc + n4 : 0));
       }
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+        const int n4 = n0 + j * 16 + ng;
+        float4 v = {acc[i][j][0] + bv[j].x, acc[i][j][1] + bv[j].y, acc[i][j][2] + bv[j].z, acc[i][j][3] + bv[j].w};
+        if (ep.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+        if (ep.mask != nullptr) {
+          v.x = mk[j].x > 0.f ? v.x : 0.f; v.y = mk[j].y > 0.f ? v.y : 0.f;
+          v.z = mk[j].z > 0.f ? v.z : 0.f; v.w = mk[j].w > 0.f ? v.w : 0.f;
+        }
+        if (ep.accumulate) { v.x += old[j].x; v.y += old[j].y; v.z += old[j].z; v.w += old[j].w; }
+        if (rok && n4 < ep.N) *reinterpret_cast<float4*>(ep.C + orow * ep.ldc + n4) = v;
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int n = n0 + j * 16 + ng + r;
+          const bool ok = rok && n < ep.N;
+          float v = acc[i][j][r];
+          if (ep.bias != nullptr) v += ep.bias[n < ep.N ? n : 0];
+          if (ep.relu) v = fmaxf(v, 0.f);
+          if (ep.mask != nullptr) v = ep.mask[ok ? orow * ep.ldmask + n : 0] > 0.f ? v : 0.f;
+          if (ep.accumulate) v += ep.C[ok ? orow * ep.ldc + n : 0];
+          if (ok) ep.C[orow * ep.ldc + n] = v;
+        }
+    }
   }
 }
 
@@ -483,25 +486,24 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(YL yl, XL xl, int M, int m
       for (int i = 0; i < NT; ++i) {
         const frag_t fy = *reinterpret_cast<const frag_t*>(&sY[(i * 16 + fr) * LD + ks * 32 + fg]);
 #pragma unroll
-        for (int j = 0; j < KT; ++j) mma_k32(acc[i][j], fy, fx[j]);
+        for (int j = 0; j < KT; ++j) mma_k32(acc[i][j], fx[j], fy);  // transposed tile: 4 consecutive k per lane
       }
     }
     __syncthreads();
   }
 
-  // acc[i][j][r] = partial dW[n0 + 16*i + 4*(lane>>4) + r][k0 + 16*(wave*KT+j) + (lane&15)]
+  // acc[i][j][r] = partial dW[n0 + 16*i + (lane&15)][k0 + 16*(wave*KT+j) + 4*(lane>>4) + r]: one 16-byte store each
   float* out = slab + (int64_t)blockIdx.z * Npad * Kpad;
 #pragma unroll
-  for (int i = 0; i < NT; ++i)
+  for (int i = 0; i < NT; ++i) {
+    const int n = n0 + i * 16 + (lane & 15);
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int n = n0 + i * 16 + (lane >> 4) * 4 + r;
-#pragma unroll
-      for (int j = 0; j < KT; ++j) {
-        const int k = k0 + (wave * KT + j) * 16 + (lane & 15);
-        if (n < Npad && k < Kpad) out[(int64_t)n * Kpad + k] = acc[i][j][r];
-      }
+    for (int j = 0; j < KT; ++j) {
+      const int k4 = k0 + (wave * KT + j) * 16 + (lane >> 4) * 4;
+      if (n < Npad && k4 < Kpad)
+        *reinterpret_cast<float4*>(out + (int64_t)n * Kpad + k4) = float4{acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
     }
+  }
   if (do_bias) {
     sBias[wave][lane] = bsum;
     __syncthreads();

@@ -53,7 +53,9 @@ __device__ __forceinline__ bf16x8 afrag_t(const __bf16* p) {  // 8-byte aligned 
 }
 __device__ __forceinline__ f32x8 afrag_t(const float* p) { return *reinterpret_cast<const f32x8*>(p); }
 
-// acc[mt][j] += A[mt-th row tile] * W[ntile[j]]^T over KS K=32 steps. A: LDS, row stride lda, element AT.
+// acc[mt][j] += (A[mt-th row tile] * W[ntile[j]]^T)^T over KS K=32 steps. A: LDS, row stride lda, element AT.
+// The weight fragment is the MFMA "row" operand, so a lane ends up with 4 CONSECUTIVE output columns of one row:
+// acc[mt][j][r] = out[16*mt + (lane&15)][16*ntile[j] + 4*(lane>>4) + r]  -> vector epilogue stores.
 // The weight fragments come straight from L2/HBM: a ring of PD k-steps of them is kept in flight (a load issued per
 // step consumed) so the MFMAs never wait for a just-issued global load.
 template <typename T, int MT, int NTW, int KS, typename AT>
@@ -85,9 +87,19 @@ __device__ __forceinline__ void block_gemm(f32x4 (&acc)[MT][NTW], const AT* sA, 
       if constexpr (sizeof(AT) == sizeof(T)) fa = *reinterpret_cast<const frag_t*>(sA + (mt * 16 + fr) * lda + ks * 32 + fg);
       else fa = afrag<T>(reinterpret_cast<const float*>(sA) + (mt * 16 + fr) * lda + ks * 32 + fg);
 #pragma unroll
-      for (int j = 0; j < NTW; ++j) mma_k32(acc[mt][j], fa, cur[j]);
+      for (int j = 0; j < NTW; ++j) mma_k32(acc[mt][j], cur[j], fa);  // transposed tile
     }
   }
+}
+// 4 consecutive elements of one row -> one 8/16-byte store (LDS or global), T = __bf16 | float
+__device__ __forceinline__ void st4(__bf16* p, float a, float b, float c, float d) {
+  typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+  bf16x4 v;
+  v[0] = (__bf16)a; v[1] = (__bf16)b; v[2] = (__bf16)c; v[3] = (__bf16)d;
+  *reinterpret_cast<bf16x4*>(p) = v;
+}
+__device__ __forceinline__ void st4(float* p, float a, float b, float c, float d) {
+  *reinterpret_cast<float4*>(p) = float4{a, b, c, d};
 }
 template <int MT, int NTW> __device__ __forceinline__ void zero_acc(f32x4 (&acc)[MT][NTW]) {
 #pragma unroll
@@ -149,14 +161,14 @@ __global__ __launch_bounds__(256) void infer_encoder_kernel(const ActCtl* __rest
     f32x4 acc[2][4];
     auto store_h = [&](T* h, const float* bias) {
 #pragma unroll
-      for (int mt = 0; mt < 2; ++mt)
+      for (int j = 0; j < 4; ++j) {
+        const int n4 = nt4[j] * 16 + qr;
+        const float4 bb = *reinterpret_cast<const float4*>(bias + n4);
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const int row = mt * 16 + qr + r, n = nt4[j] * 16 + fr;
-            h[row * LY::LDH + n] = Op<T>::from_f32(fmaxf(acc[mt][j][r] + bias[n], 0.f));
-          }
+        for (int mt = 0; mt < 2; ++mt)
+          st4(h + (mt * 16 + fr) * LY::LDH + n4, fmaxf(acc[mt][j][0] + bb.x, 0.f), fmaxf(acc[mt][j][1] + bb.y, 0.f),
+              fmaxf(acc[mt][j][2] + bb.z, 0.f), fmaxf(acc[mt][j][3] + bb.w, 0.f));
+      }
     };
     zero_acc(acc);
     if (w.Kp1 == 128) block_gemm<T, 2, 4, 4>(acc, sin, LY::LDS_IN, (const T*)w.wf1, 128, nt4, lane);
@@ -171,13 +183,17 @@ __global__ __launch_bounds__(256) void infer_encoder_kernel(const ActCtl* __rest
     f32x4 ap[2][1];
     zero_acc(ap);
     block_gemm<T, 2, 1, 8>(ap, h2, LY::LDH, (const T*)w.wpr, 256, nt1, lane);
+    {
+      const int n4 = wave * 16 + qr;
+      const float4 bb = *reinterpret_cast<const float4*>(w.bpr + n4);
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int row = r0 + mt * 16 + qr + r, n = wave * 16 + fr;
-        if (row < E) x0[((int64_t)row * NTOK) * TD + n] = fmaxf(ap[mt][0][r] + w.bpr[n], 0.f);
+      for (int mt = 0; mt < 2; ++mt) {
+        const int row = r0 + mt * 16 + fr;
+        if (row < E)
+          st4(x0 + ((int64_t)row * NTOK) * TD + n4, fmaxf(ap[mt][0][0] + bb.x, 0.f), fmaxf(ap[mt][0][1] + bb.y, 0.f),
+              fmaxf(ap[mt][0][2] + bb.z, 0.f), fmaxf(ap[mt][0][3] + bb.w, 0.f));
       }
+    }
     return;
   }
 
@@ -228,19 +244,22 @@ __global__ __launch_bounds__(256) void infer_encoder_kernel(const ActCtl* __rest
         if (wave + 4 * i < 15) {
           const frag_t fa = afrag_t(img + c * 4096 + ky * 64 + pbase[i]);
 #pragma unroll
-          for (int j = 0; j < 2; ++j) mma_k32(acc[i][j], fa, fb[j]);
+          for (int j = 0; j < 2; ++j) mma_k32(acc[i][j], fb[j], fa);
         }
       }
     }
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int j = 0; j < 2; ++j) {
+      const int n4 = j * 16 + qr;
+      const float4 bb = *reinterpret_cast<const float4*>(w.b1 + n4);
 #pragma unroll
-      for (int j = 0; j < 2; ++j)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int p = (wave + 4 * i) * 16 + qr + r, n = j * 16 + fr;
-          if (p < 225) c1[p * LY::LD1 + n] = Op<T>::from_f32(fmaxf(acc[i][j][r] + w.b1[n], 0.f));
-        }
+      for (int i = 0; i < 4; ++i) {
+        const int p = (wave + 4 * i) * 16 + fr;
+        if (p < 225)
+          st4(c1 + p * LY::LD1 + n4, fmaxf(acc[i][j][0] + bb.x, 0.f), fmaxf(acc[i][j][1] + bb.y, 0.f),
+              fmaxf(acc[i][j][2] + bb.z, 0.f), fmaxf(acc[i][j][3] + bb.w, 0.f));
+      }
+    }
   }
   __syncthreads();
   {  // conv2: 36 pixels (3 row tiles), K = (ky,kx,c) = 512, N = 64: wave w owns column tile w
@@ -264,16 +283,20 @@ __global__ __launch_bounds__(256) void infer_encoder_kernel(const ActCtl* __rest
 #pragma unroll
       for (int i = 0; i < 3; ++i) {
         const frag_t fa = afrag_t(c1 + pb[i] + (ky * 15 + kx) * LY::LD1 + fg);
-        mma_k32(acc[i][0], fa, fb);
+        mma_k32(acc[i][0], fb, fa);
       }
     }
+    {
+      const int n4 = wave * 16 + qr;
+      const float4 bb = *reinterpret_cast<const float4*>(w.b2 + n4);
 #pragma unroll
-    for (int i = 0; i < 3; ++i)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int p = i * 16 + qr + r, n = wave * 16 + fr;
-        if (p < 36) c2[p * LY::LD2 + n] = Op<T>::from_f32(fmaxf(acc[i][0][r] + w.b2[n], 0.f));
+      for (int i = 0; i < 3; ++i) {
+        const int p = i * 16 + fr;
+        if (p < 36)
+          st4(c2 + p * LY::LD2 + n4, fmaxf(acc[i][0][0] + bb.x, 0.f), fmaxf(acc[i][0][1] + bb.y, 0.f),
+              fmaxf(acc[i][0][2] + bb.z, 0.f), fmaxf(acc[i][0][3] + bb.w, 0.f));
       }
+    }
   }
   __syncthreads();
   {  // conv3: 16 pixels, K = (ky,kx,c) = 576 (two K=32 steps per tap), N = 64
@@ -289,13 +312,12 @@ __global__ __launch_bounds__(256) void infer_encoder_kernel(const ActCtl* __rest
       const frag_t fb = ring[ks % 6];
       if (ks + 6 < 18) ring[ks % 6] = *reinterpret_cast<const frag_t*>(w3row + (ks + 6) * 32);
       const frag_t fa = afrag_t(c2 + pb + (ky * 6 + kx) * LY::LD2 + c0);
-      mma_k32(acc, fa, fb);
+      mma_k32(acc, fb, fa);
     }
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int p = qr + r, n = wave * 16 + fr;
-      c3[p * LY::LD2 + n] = Op<T>::from_f32(fmaxf(acc[r] + w.b3[n], 0.f));
-    }
+    const int n4 = wave * 16 + qr;
+    const float4 bb = *reinterpret_cast<const float4*>(w.b3 + n4);
+    st4(c3 + fr * LY::LD2 + n4, fmaxf(acc[0] + bb.x, 0.f), fmaxf(acc[1] + bb.y, 0.f), fmaxf(acc[2] + bb.z, 0.f),
+        fmaxf(acc[3] + bb.w, 0.f));
   }
   __syncthreads();
   {  // depth_up_conv (1x1, no activation) -> tokens 1..16
@@ -303,13 +325,11 @@ __global__ __launch_bounds__(256) void infer_encoder_kernel(const ActCtl* __rest
     for (int ks = 0; ks < 2; ++ks) {
       const frag_t fb = *reinterpret_cast<const frag_t*>((const T*)w.wup + (wave * 16 + fr) * 64 + ks * 32 + fg);
       const frag_t fa = afrag_t(c3 + fr * LY::LD2 + ks * 32 + fg);
-      mma_k32(acc, fa, fb);
+      mma_k32(acc, fb, fa);
     }
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int p = qr + r, n = wave * 16 + fr;
-      x0[((int64_t)b * NTOK + 1 + p) * TD + n] = acc[r] + w.bup[n];
-    }
+    const int n4 = wave * 16 + qr;
+    const float4 bb = *reinterpret_cast<const float4*>(w.bup + n4);
+    st4(x0 + ((int64_t)b * NTOK + 1 + fr) * TD + n4, acc[0] + bb.x, acc[1] + bb.y, acc[2] + bb.z, acc[3] + bb.w);
   }
 }
 
@@ -344,9 +364,17 @@ __device__ __forceinline__ void ln_rows(const float* z, int ldz, float* out, int
   }
 }
 
+#ifdef V4L_INFER_TIMING
+__device__ long long g_inf_stamps[32];
+#define INF_STAMP(i) do { if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) g_inf_stamps[i] = clock64(); } while (0)
+#else
+#define INF_STAMP(i)
+#endif
+
 template <typename T>
 __global__ __launch_bounds__(256) void infer_layer_kernel(InfLayerPair pr, int E, int ff) {
   typedef InfLayLds<T> LY;
+  INF_STAMP(0);
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const InfLayer& w = pr.n[blockIdx.y];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -364,22 +392,24 @@ __global__ __launch_bounds__(256) void infer_layer_kernel(InfLayerPair pr, int E
     xs[r * LY::LDX + c] = r < nrows ? xg[idx] : 0.f;
   }
   __syncthreads();
+  INF_STAMP(1);
   {  // in_proj: [80][64] x [192][64]^T -> qkv (fp32)
     const int nt[3] = {wave, wave + 4, wave + 8};
     f32x4 acc[INF_MT][3];
     zero_acc(acc);
     block_gemm<T, INF_MT, 3, 2>(acc, xs, LY::LDX, (const T*)w.win, 64, nt, lane);
 #pragma unroll
-    for (int mt = 0; mt < INF_MT; ++mt)
+    for (int j = 0; j < 3; ++j) {
+      const int n4 = nt[j] * 16 + qr;
+      const float4 bb = *reinterpret_cast<const float4*>(w.bin + n4);
 #pragma unroll
-      for (int j = 0; j < 3; ++j)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int n = nt[j] * 16 + fr;
-          big[(mt * 16 + qr + r) * LY::LDQ + n] = acc[mt][j][r] + w.bin[n];
-        }
+      for (int mt = 0; mt < INF_MT; ++mt)
+        st4(big + (mt * 16 + fr) * LY::LDQ + n4, acc[mt][j][0] + bb.x, acc[mt][j][1] + bb.y, acc[mt][j][2] + bb.z,
+            acc[mt][j][3] + bb.w);
+    }
   }
   __syncthreads();
+  INF_STAMP(2);
   {  // attention of sample `wave` (17 tokens, one head, scale 1/8); inactive waves only take part in the barriers
     const bool act = wave < ns;
     const float* q = big + (wave * NTOK) * LY::LDQ;
@@ -417,22 +447,27 @@ __global__ __launch_bounds__(256) void infer_layer_kernel(InfLayerPair pr, int E
   for (int idx = tid; idx < (INF_ROWS - nrows) * TD; idx += 256)  // rows beyond the last sample: defined zeros
     cx[(nrows + (idx >> 6)) * LY::LDX + (idx & 63)] = 0.f;
   __syncthreads();
+  INF_STAMP(3);
   const int nt1[1] = {wave};
   {  // out_proj + residual -> z (in `big`, fp32 [80][LDX])
     f32x4 acc[INF_MT][1];
     zero_acc(acc);
     block_gemm<T, INF_MT, 1, 2>(acc, cx, LY::LDX, (const T*)w.wo, 64, nt1, lane);
+    const int n4 = wave * 16 + qr;
+    const float4 bb = *reinterpret_cast<const float4*>(w.bo + n4);
 #pragma unroll
-    for (int mt = 0; mt < INF_MT; ++mt)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int row = mt * 16 + qr + r, n = wave * 16 + fr;
-        big[row * LY::LDX + n] = xs[row * LY::LDX + n] + acc[mt][0][r] + w.bo[n];
-      }
+    for (int mt = 0; mt < INF_MT; ++mt) {
+      const int row = mt * 16 + fr;
+      const float4 xr = *reinterpret_cast<const float4*>(xs + row * LY::LDX + n4);
+      st4(big + row * LY::LDX + n4, xr.x + acc[mt][0][0] + bb.x, xr.y + acc[mt][0][1] + bb.y, xr.z + acc[mt][0][2] + bb.z,
+          xr.w + acc[mt][0][3] + bb.w);
+    }
   }
   __syncthreads();
+  INF_STAMP(4);
   ln_rows(big, LY::LDX, xs, LY::LDX, w.g1, w.be1, wave, lane);  // x1 -> xs
   __syncthreads();
+  INF_STAMP(5);
   T* f = reinterpret_cast<T*>(big);
   {  // linear1 + ReLU -> f (T) ; ff <= 256: wave w owns column tiles 4w..4w+3
     const int nt4[4] = {wave * 4, wave * 4 + 1, wave * 4 + 2, wave * 4 + 3};
@@ -440,29 +475,33 @@ __global__ __launch_bounds__(256) void infer_layer_kernel(InfLayerPair pr, int E
     zero_acc(acc);
     block_gemm<T, INF_MT, 4, 2>(acc, xs, LY::LDX, (const T*)w.w1, 64, nt4, lane);
 #pragma unroll
-    for (int mt = 0; mt < INF_MT; ++mt)
+    for (int j = 0; j < 4; ++j) {
+      const int n4 = nt4[j] * 16 + qr;
+      const float4 bb = *reinterpret_cast<const float4*>(w.b1 + n4);
 #pragma unroll
-      for (int j = 0; j < 4; ++j)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int n = nt4[j] * 16 + fr;
-          f[(mt * 16 + qr + r) * LY::LDF + n] = Op<T>::from_f32(n < ff ? fmaxf(acc[mt][j][r] + w.b1[n], 0.f) : 0.f);
-        }
+      for (int mt = 0; mt < INF_MT; ++mt)
+        st4(f + (mt * 16 + fr) * LY::LDF + n4, fmaxf(acc[mt][j][0] + bb.x, 0.f), fmaxf(acc[mt][j][1] + bb.y, 0.f),
+            fmaxf(acc[mt][j][2] + bb.z, 0.f), fmaxf(acc[mt][j][3] + bb.w, 0.f));
+    }
   }
   __syncthreads();
+  INF_STAMP(6);
   {  // linear2 + residual -> z2 (in `cx`)
     f32x4 acc[INF_MT][1];
     zero_acc(acc);
     block_gemm<T, INF_MT, 1, 8>(acc, f, LY::LDF, (const T*)w.w2, 256, nt1, lane);
+    const int n4 = wave * 16 + qr;
+    const float4 bb = *reinterpret_cast<const float4*>(w.b2 + n4);
 #pragma unroll
-    for (int mt = 0; mt < INF_MT; ++mt)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int row = mt * 16 + qr + r, n = wave * 16 + fr;
-        cx[row * LY::LDX + n] = xs[row * LY::LDX + n] + acc[mt][0][r] + w.b2[n];
-      }
+    for (int mt = 0; mt < INF_MT; ++mt) {
+      const int row = mt * 16 + fr;
+      const float4 xr = *reinterpret_cast<const float4*>(xs + row * LY::LDX + n4);
+      st4(cx + row * LY::LDX + n4, xr.x + acc[mt][0][0] + bb.x, xr.y + acc[mt][0][1] + bb.y, xr.z + acc[mt][0][2] + bb.z,
+          xr.w + acc[mt][0][3] + bb.w);
+    }
   }
   __syncthreads();
+  INF_STAMP(7);
   float* xo = w.xout + (int64_t)s0 * NTOK * TD;
   for (int r = wave; r < nrows; r += 4) {
     const float v = cx[r * LY::LDX + lane];
@@ -471,6 +510,7 @@ __global__ __launch_bounds__(256) void infer_layer_kernel(InfLayerPair pr, int E
     const float var = wave_sum(c * c) * (1.f / TD);
     xo[r * TD + lane] = fmaf(c * (1.f / sqrtf(var + 1e-5f)), w.g2[lane], w.be2[lane]);
   }
+  INF_STAMP(8);
 }
 
 // ------------------------------------------------------------------------------------------ heads + sampling
@@ -525,14 +565,14 @@ __global__ __launch_bounds__(256) void infer_head_kernel(ActCtl* ctl, InfHead hp
       f32x4 acc[2][4];
       auto store_h = [&](T* dst, const float* bias) {
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt)
+        for (int j = 0; j < 4; ++j) {
+          const int n4 = nt4[j] * 16 + qr;
+          const float4 bb = *reinterpret_cast<const float4*>(bias + n4);
 #pragma unroll
-          for (int j = 0; j < 4; ++j)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-              const int n = nt4[j] * 16 + fr;
-              dst[(mt * 16 + qr + r) * LY::LDH + n] = Op<T>::from_f32(fmaxf(acc[mt][j][r] + bias[n], 0.f));
-            }
+          for (int mt = 0; mt < 2; ++mt)
+            st4(dst + (mt * 16 + fr) * LY::LDH + n4, fmaxf(acc[mt][j][0] + bb.x, 0.f), fmaxf(acc[mt][j][1] + bb.y, 0.f),
+                fmaxf(acc[mt][j][2] + bb.z, 0.f), fmaxf(acc[mt][j][3] + bb.w, 0.f));
+        }
       };
       zero_acc(acc);
       block_gemm<T, 2, 4, 4>(acc, pooled, LY::LDP, (const T*)h.w0, 128, nt4, lane);
@@ -548,10 +588,11 @@ __global__ __launch_bounds__(256) void infer_head_kernel(ActCtl* ctl, InfHead hp
         zero_acc(a1);
         block_gemm<T, 1, 1, 8>(a1, h2 + wave * 16 * LY::LDH, LY::LDH, (const T*)h.w2, 256, nt0, lane);
         const int nout = net == 0 ? A : 1;
+        const int row = r0 + wave * 16 + fr;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const int row = r0 + wave * 16 + qr + r;
-          if (row < 64) outs[(net * 64 + row) * 16 + fr] = fr < nout ? a1[0][0][r] + h.b2[fr] : 0.f;
+          const int n = qr + r;
+          if (row < 64) outs[(net * 64 + row) * 16 + n] = n < nout ? a1[0][0][r] + h.b2[n] : 0.f;
         }
       }
       __syncthreads();

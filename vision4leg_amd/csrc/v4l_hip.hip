@@ -1133,6 +1133,12 @@ int v4l_gae(const double* rewards_dev, const double* values_dev, const double* t
   return 0;
 }
 
+#ifdef V4L_INFER_TIMING
+int v4l_debug_stamps(long long* out32) {
+  if (hipDeviceSynchronize() != hipSuccess) return -2;
+  return hipMemcpyFromSymbol(out32, HIP_SYMBOL(v4l::g_inf_stamps), 32 * sizeof(long long)) == hipSuccess ? 0 : -2;
+}
+#endif
 int v4l_prof_enable(int on) {
   g_prof = on != 0;
   return 0;

@@ -202,16 +202,22 @@ class PPO:
         phases per update with one RCCL all-reduce per optimiser step."""
         tr = self.trainer
         U, n = rowidx.shape
+        # the captured graph is keyed on these addresses: keep them stable from epoch to epoch
+        if getattr(self, "_rowidx_buf", None) is None or self._rowidx_buf.shape != rowidx.shape:
+            self._rowidx_buf = torch.empty_like(rowidx)
+            self._stats_buf = torch.zeros(U, _lib.V4L_STATS, dtype=torch.float32, device=self.device)
+        self._rowidx_buf.copy_(rowidx)
         cur = torch.cuda.current_stream(self.device)
         tr.stream.wait_stream(cur)
         with torch.cuda.stream(tr.stream):
-            tr.begin(rowidx, stats, self.pf_optimizer.lr, self.vf_optimizer.lr)
+            tr.begin(self._rowidx_buf, self._stats_buf, self.pf_optimizer.lr, self.vf_optimizer.lr)
             for _ in range(U):
                 self.training_update_num += 1
                 if self.world_size == 1:
                     tr.update_next(ro, n, graph=self.use_graph)
                 else:
                     self._update_phases(ro, n)
+            stats.copy_(self._stats_buf)
         cur.wait_stream(tr.stream)
 
     def _update_phases(self, ro, n):
