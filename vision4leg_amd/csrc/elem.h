@@ -164,13 +164,14 @@ __global__ __launch_bounds__(256) void add_ln_fwd_kernel(const float* __restrict
   if (lane == 0) rstd[r] = rs;
 }
 
-// d(x+y) from dout (in place allowed: dz may alias dout); dgamma/dbeta accumulated with atomics.
+// d(x+y) from dout (in place allowed: dz may alias dout); per-block dgamma/dbeta partials.
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ dout, const float* __restrict__ xhat,
                                                      const float* __restrict__ rstd, const float* __restrict__ gamma,
-                                                     int rows, float* __restrict__ dz, float* __restrict__ dgamma,
-                                                     float* __restrict__ dbeta) {
-  // few blocks (the per-block dgamma/dbeta atomics hit only 128 addresses), so each wave walks many rows: four rows
-  // are kept in flight per iteration to overlap their load -> reduce -> store chains
+                                                     int rows, float* __restrict__ dz, float* __restrict__ gpart,
+                                                     float* __restrict__ bpart) {
+  // each block leaves its partial dgamma/dbeta in gpart/bpart[blockIdx.x][64]; wgrad_reduce_kernel sums them in a
+  // fixed order (no atomics: the whole update is run-to-run deterministic). Each wave walks many rows: four rows are
+  // kept in flight per iteration to overlap their load -> reduce -> store chains
   __shared__ float sg[4][TD], sb[4][TD];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const float g = gamma[lane];
@@ -210,8 +211,8 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
   sb[w][lane] = ab;
   __syncthreads();
   if (w == 0) {
-    atomicAdd(dgamma + lane, sg[0][lane] + sg[1][lane] + sg[2][lane] + sg[3][lane]);
-    atomicAdd(dbeta + lane, sb[0][lane] + sb[1][lane] + sb[2][lane] + sb[3][lane]);
+    gpart[blockIdx.x * TD + lane] = (sg[0][lane] + sg[1][lane]) + (sg[2][lane] + sg[3][lane]);
+    bpart[blockIdx.x * TD + lane] = (sb[0][lane] + sb[1][lane]) + (sb[2][lane] + sb[3][lane]);
   }
 }
 
@@ -316,7 +317,7 @@ enum {
   ST_LP_MEAN, ST_LP_STD, ST_LP_MAX, ST_LP_MIN, ST_LS_MEAN, ST_LS_STD, ST_LS_MAX, ST_LS_MIN,
   ST_RATIO_MAX, ST_RATIO_MIN, ST_GN_PF,
   ST_ADV_SUM = 18, ST_ADV_SUMSQ, ST_ADV_CNT,  // raw sums for the data-parallel 3-scalar exchange
-  ST_SUMSQ_VF = 21, ST_SUMSQ_PF = 22,        // squared gradient norms (accumulated by grad_sumsq_kernel)
+  ST_SUMSQ_VF = 21, ST_SUMSQ_PF = 22,        // (unused since the norm partials moved to the control block)
   ST_SIZE = 24
 };
 
@@ -526,15 +527,15 @@ __device__ __forceinline__ int find_desc(const D* __restrict__ d, int n, int64_t
 }
 
 // --------------------------------------------------------------------------------- grad norm + Adam
-// sum of squares of a flat gradient buffer -> *acc (fp32 atomics of per-block double partials)
-__global__ __launch_bounds__(256) void grad_sumsq_kernel(const float* __restrict__ g, int64_t n, float* __restrict__ acc) {
+// sum of squares of a flat gradient buffer -> part[blockIdx.x] (<= 64 blocks; clip_adam_kernel adds them in order)
+__global__ __launch_bounds__(256) void grad_sumsq_kernel(const float* __restrict__ g, int64_t n, float* __restrict__ part) {
   double s = 0.0;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
     const float x = g[i];
     s += (double)x * x;
   }
   Red4 r = block_red4(s, 0.0, 0.f, 0.f);
-  if (threadIdx.x == 0) atomicAdd(acc, (float)r.s);
+  if (threadIdx.x == 0) part[blockIdx.x] = (float)r.s;
 }
 
 // One (tensor) segment of an optimiser's parameter set: parameters live in caller-owned tensors (pointer
@@ -588,13 +589,14 @@ __global__ void upd_end_kernel(UpdCtl* c, const float* __restrict__ stats_cur, f
 
 __global__ __launch_bounds__(256) void clip_adam_kernel(const ParamSeg* __restrict__ segs, int nseg,
                                                         const float* __restrict__ g, float* __restrict__ m,
-                                                        float* __restrict__ v, const float* __restrict__ sumsq,
+                                                        float* __restrict__ v, const float* __restrict__ part, int npart,
                                                         float max_norm, float eps, const UpdCtl* __restrict__ ctl,
                                                         int which, float* __restrict__ norm_out) {
   const ParamSeg sg = segs[find_desc(segs, nseg, (int64_t)blockIdx.x)];
   const float beta1 = ctl->beta1, beta2 = ctl->beta2;
   const float step_size = ctl->step_size[which], bc2_sqrt = ctl->bc2_sqrt;
-  const float tot = sqrtf(*sumsq);
+  const int lane_ = threadIdx.x & 63;
+  const float tot = sqrtf(wave_sum(lane_ < npart ? part[lane_] : 0.f));  // same order in every wave: deterministic
   const float coef = fminf(max_norm / (tot + 1e-6f), 1.f);
   if (blockIdx.x == 0 && threadIdx.x == 0 && norm_out != nullptr) *norm_out = tot;
   const int64_t i = ((int64_t)blockIdx.x - sg.blk0) * 256 + threadIdx.x;

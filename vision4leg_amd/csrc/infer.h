@@ -339,6 +339,8 @@ struct InfLayer {
   const float *bin, *bo, *b1, *b2, *g1, *be1, *g2, *be2;
   const float* xin;                      // [E*17][64] fp32
   float* xout;
+  // training forward: what the backward pass needs (all null for inference)
+  float *s_qkv, *s_P, *s_ctx, *s_xh1, *s_rs1, *s_x1, *s_f, *s_xh2, *s_rs2;
 };
 struct InfLayerPair { InfLayer n[2]; };
 
@@ -353,14 +355,23 @@ template <typename T> struct InfLayLds {
   static constexpr size_t bytes = xs_b + big_b + xs_b + p_b;  // xs | qkv/z/f | ctx/z2 | scores
 };
 
+// LayerNorm of the 80 LDS rows; optionally (training) saves xhat / rstd / the output rows < nrows to global memory
 __device__ __forceinline__ void ln_rows(const float* z, int ldz, float* out, int ldo, const float* __restrict__ g,
-                                        const float* __restrict__ be, int wave, int lane) {
+                                        const float* __restrict__ be, int wave, int lane, int nrows, float* s_xh,
+                                        float* s_rs, float* s_out) {
   for (int r = wave; r < INF_ROWS; r += 4) {
     const float v = z[r * ldz + lane];
     const float mean = wave_sum(v) * (1.f / TD);
     const float c = v - mean;
     const float var = wave_sum(c * c) * (1.f / TD);
-    out[r * ldo + lane] = fmaf(c * (1.f / sqrtf(var + 1e-5f)), g[lane], be[lane]);
+    const float rs = 1.f / sqrtf(var + 1e-5f);
+    const float xh = c * rs;
+    const float o = fmaf(xh, g[lane], be[lane]);
+    if (out != nullptr) out[r * ldo + lane] = o;
+    if (r < nrows) {
+      if (s_xh != nullptr) { s_xh[r * TD + lane] = xh; if (lane == 0) s_rs[r] = rs; }
+      if (s_out != nullptr) s_out[r * TD + lane] = o;
+    }
   }
 }
 
@@ -410,6 +421,13 @@ __global__ __launch_bounds__(256) void infer_layer_kernel(InfLayerPair pr, int E
   }
   __syncthreads();
   INF_STAMP(2);
+  const int64_t row0 = (int64_t)s0 * NTOK;  // first token row of this block
+  if (w.s_qkv != nullptr) {
+    for (int idx = tid; idx < nrows * 48; idx += 256) {  // 48 float4 per row of 192
+      const int r = idx / 48, c4 = (idx - r * 48) * 4;
+      *reinterpret_cast<float4*>(w.s_qkv + (row0 + r) * 192 + c4) = *reinterpret_cast<const float4*>(big + r * LY::LDQ + c4);
+    }
+  }
   {  // attention of sample `wave` (17 tokens, one head, scale 1/8); inactive waves only take part in the barriers
     const bool act = wave < ns;
     const float* q = big + (wave * NTOK) * LY::LDQ;
@@ -432,7 +450,11 @@ __global__ __launch_bounds__(256) void infer_layer_kernel(InfLayerPair pr, int E
       for (int j = 0; j < NTOK; ++j) { e[j] = expf(p[lane * ATT_PLD + j] - mx); sum += e[j]; }
       const float inv = 1.f / sum;
 #pragma unroll
-      for (int j = 0; j < NTOK; ++j) p[lane * ATT_PLD + j] = e[j] * inv;
+      for (int j = 0; j < NTOK; ++j) {
+        const float pv = e[j] * inv;
+        p[lane * ATT_PLD + j] = pv;
+        if (w.s_P != nullptr) w.s_P[((int64_t)(s0 + wave) * NTOK + lane) * NTOK + j] = pv;
+      }
     }
     __syncthreads();
     if (act) {
@@ -441,6 +463,7 @@ __global__ __launch_bounds__(256) void infer_layer_kernel(InfLayerPair pr, int E
 #pragma unroll
         for (int j = 0; j < NTOK; ++j) a = fmaf(p[i * ATT_PLD + j], q[j * LY::LDQ + 2 * TD + lane], a);
         cx[(wave * NTOK + i) * LY::LDX + lane] = a;
+        if (w.s_ctx != nullptr) w.s_ctx[(row0 + wave * NTOK + i) * TD + lane] = a;
       }
     }
   }
@@ -465,7 +488,8 @@ __global__ __launch_bounds__(256) void infer_layer_kernel(InfLayerPair pr, int E
   }
   __syncthreads();
   INF_STAMP(4);
-  ln_rows(big, LY::LDX, xs, LY::LDX, w.g1, w.be1, wave, lane);  // x1 -> xs
+  ln_rows(big, LY::LDX, xs, LY::LDX, w.g1, w.be1, wave, lane, nrows, w.s_xh1 ? w.s_xh1 + row0 * TD : nullptr,
+          w.s_rs1 ? w.s_rs1 + row0 : nullptr, w.s_x1 ? w.s_x1 + row0 * TD : nullptr);  // x1 -> xs
   __syncthreads();
   INF_STAMP(5);
   T* f = reinterpret_cast<T*>(big);
@@ -479,9 +503,12 @@ __global__ __launch_bounds__(256) void infer_layer_kernel(InfLayerPair pr, int E
       const int n4 = nt4[j] * 16 + qr;
       const float4 bb = *reinterpret_cast<const float4*>(w.b1 + n4);
 #pragma unroll
-      for (int mt = 0; mt < INF_MT; ++mt)
-        st4(f + (mt * 16 + fr) * LY::LDF + n4, fmaxf(acc[mt][j][0] + bb.x, 0.f), fmaxf(acc[mt][j][1] + bb.y, 0.f),
-            fmaxf(acc[mt][j][2] + bb.z, 0.f), fmaxf(acc[mt][j][3] + bb.w, 0.f));
+      for (int mt = 0; mt < INF_MT; ++mt) {
+        const float f0 = fmaxf(acc[mt][j][0] + bb.x, 0.f), f1 = fmaxf(acc[mt][j][1] + bb.y, 0.f);
+        const float f2 = fmaxf(acc[mt][j][2] + bb.z, 0.f), f3 = fmaxf(acc[mt][j][3] + bb.w, 0.f);
+        st4(f + (mt * 16 + fr) * LY::LDF + n4, f0, f1, f2, f3);
+        if (w.s_f != nullptr && mt * 16 + fr < nrows) st4(w.s_f + (row0 + mt * 16 + fr) * 256 + n4, f0, f1, f2, f3);
+      }
     }
   }
   __syncthreads();
@@ -502,14 +529,8 @@ __global__ __launch_bounds__(256) void infer_layer_kernel(InfLayerPair pr, int E
   }
   __syncthreads();
   INF_STAMP(7);
-  float* xo = w.xout + (int64_t)s0 * NTOK * TD;
-  for (int r = wave; r < nrows; r += 4) {
-    const float v = cx[r * LY::LDX + lane];
-    const float mean = wave_sum(v) * (1.f / TD);
-    const float c = v - mean;
-    const float var = wave_sum(c * c) * (1.f / TD);
-    xo[r * TD + lane] = fmaf(c * (1.f / sqrtf(var + 1e-5f)), w.g2[lane], w.be2[lane]);
-  }
+  ln_rows(cx, LY::LDX, nullptr, 0, w.g2, w.be2, wave, lane, nrows, w.s_xh2 ? w.s_xh2 + row0 * TD : nullptr,
+          w.s_rs2 ? w.s_rs2 + row0 : nullptr, w.xout + row0 * TD);
   INF_STAMP(8);
 }
 

@@ -133,6 +133,7 @@ struct v4l_trainer {
   v4l::UpdCtl* ctl = nullptr;
   float* stats_cur = nullptr;
   int* rowidx_cur = nullptr;
+  float* norm_part = nullptr;
   int n_max = 0;
   const int* rowidx_all = nullptr;
   float* stats_all = nullptr;

@@ -265,6 +265,27 @@ static int chain_bwd(Ctx& c, const Lin* Ls, int k, const ADense& in, const Act* 
   return 0;
 }
 
+// LayerNorm backward: per-block dgamma/dbeta partials go to the slab arena and are summed by wgrad_finish
+static int ln_bwd_launch(Ctx& c, int nblk, float* dx, const float* xhat, const float* rstd, const LNp& ln, int rows) {
+  v4l_net* net = c.net;
+  float* gpart = c.slab + c.slab_used;
+  float* bpart = gpart + (int64_t)nblk * TD;
+  c.slab_used += 2 * (int64_t)nblk * TD;
+  V4L_REQUIRE(c.slab_used <= net->slab_cap, "internal: weight-grad slab arena overflow");
+  V4L_KLAUNCH("ln_bwd", 0, c.s, ln_bwd_kernel, dim3(nblk), dim3(256), 0, c.s, dx, xhat, rstd, net->p[ln.g], rows, dx, gpart,
+              bpart);
+  V4L_LAUNCH_CHECK();
+  for (int k = 0; k < 2; ++k) {
+    RedDesc d;
+    memset(&d, 0, sizeof(d));
+    d.slab = k == 0 ? gpart : bpart;
+    d.dW = c.grads + net->params[k == 0 ? ln.g : ln.b].goff;
+    d.nsplit = nblk; d.N = 1; d.K = TD; d.Npad = 1; d.Kpad = TD; d.Ktorch = TD;
+    net->red.push_back(d);
+  }
+  return 0;
+}
+
 static inline AIm2colNHWC nhwc_loader(const float* p, const Conv& cv, int n) {
   AIm2colNHWC a;
   a.p = p; a.IH = cv.IH; a.IW = cv.IH; a.Cin = cv.Cin; a.OH = cv.OH; a.OW = cv.OH; a.KH = cv.KH; a.KW = cv.KH;
@@ -545,6 +566,7 @@ int64_t v4l_net::slab_floats(int n) const {
   for (const TLayer& t : layers) {
     add(n * NTOK, t.inproj.N, t.inproj.K); add(n * NTOK, t.outproj.N, t.outproj.K);
     add(n * NTOK, t.ff1.N, t.ff1.K); add(n * NTOK, t.ff2.N, t.ff2.K);
+    tot += 2 * 2 * 128 * TD;  // LayerNorm dgamma/dbeta partials (<= 128 blocks each)
   }
   for (const Lin& L : head) add(n, L.N, L.K);
   return tot;
@@ -669,7 +691,34 @@ int v4l_net::forward_t(const float* state, const T* image, const int* rowidx, in
     }
     if (stage == 1) return 0;
     const int R = n * NTOK;
-    for (int l = 0; l < c.n_layers; ++l) {
+    const bool fused_layers = c.ff_dim == 256 && getenv("V4L_NO_FUSED_LAYER") == nullptr;
+    for (int l = 0; l < c.n_layers && fused_layers; ++l) {
+      // one launch per TransformerEncoderLayer (csrc/infer.h), 4 samples per block, saving what backward_t reads
+      const TLayer& t = layers[l];
+      const LayerWs& w = L.lw[l];
+      static bool attr_done = false;
+      if (!attr_done) {
+        V4L_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&infer_layer_kernel<T>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)InfLayLds<T>::bytes));
+        attr_done = true;
+      }
+      const T* base = (const T*)packed;
+      InfLayerPair pr;
+      memset(&pr, 0, sizeof(pr));
+      InfLayer& d = pr.n[0];
+      d.win = base + t.inproj.pk; d.wo = base + t.outproj.pk; d.w1 = base + t.ff1.pk; d.w2 = base + t.ff2.pk;
+      d.bin = p[t.inproj.b]; d.bo = p[t.outproj.b]; d.b1 = p[t.ff1.b]; d.b2 = p[t.ff2.b];
+      d.g1 = p[t.ln1.g]; d.be1 = p[t.ln1.b]; d.g2 = p[t.ln2.g]; d.be2 = p[t.ln2.b];
+      d.xin = l == 0 ? x0 : ws + L.x[l];
+      d.xout = ws + L.x[l + 1];
+      d.s_qkv = ws + w.qkv; d.s_P = ws + w.P; d.s_ctx = ws + w.ctx; d.s_xh1 = ws + w.xh1; d.s_rs1 = ws + w.rs1;
+      d.s_x1 = ws + w.x1; d.s_f = ws + w.f; d.s_xh2 = ws + w.xh2; d.s_rs2 = ws + w.rs2;
+      g_op = "layer";
+      V4L_KLAUNCH("fused_layer", 2.0 * n * 872576.0, s, infer_layer_kernel<T>, dim3(cdiv(n, INF_SPW), 1), dim3(256),
+                  InfLayLds<T>::bytes, s, pr, n, c.ff_dim);
+      V4L_LAUNCH_CHECK();
+    }
+    for (int l = 0; l < c.n_layers && !fused_layers; ++l) {
       const TLayer& t = layers[l];
       const LayerWs& w = L.lw[l];
       float* xin = l == 0 ? x0 : ws + L.x[l];
@@ -775,9 +824,7 @@ int v4l_net::backward_t(const float* state, const T* image, const int* rowidx, i
     const TLayer& t = layers[l];
     const LayerWs& w = L.lw[l];
     g_op = "ln2";
-    V4L_KLAUNCH("ln_bwd", 0, s, ln_bwd_kernel, dim3(lnb), dim3(256), 0, s, dx, ws + w.xh2, ws + w.rs2, p[t.ln2.g], R, dx,
-                       grads + params[t.ln2.g].goff, grads + params[t.ln2.b].goff);
-    V4L_LAUNCH_CHECK();
+    if ((rc = ln_bwd_launch(cx, lnb, dx, ws + w.xh2, ws + w.rs2, t.ln2, R))) return rc;
     {  // linear2 / linear1 (FFN), residual: d(x1) = dz2 + W1^T-path
       ADense y = dense(dx, TD, R, TD);
       if ((rc = par_begin(cx))) return rc;
@@ -796,9 +843,7 @@ int v4l_net::backward_t(const float* state, const T* image, const int* rowidx, i
       if ((rc = par_end(cx))) return rc;
     }
     g_op = "ln1";
-    V4L_KLAUNCH("ln_bwd", 0, s, ln_bwd_kernel, dim3(lnb), dim3(256), 0, s, dx, ws + w.xh1, ws + w.rs1, p[t.ln1.g], R, dx,
-                       grads + params[t.ln1.g].goff, grads + params[t.ln1.b].goff);
-    V4L_LAUNCH_CHECK();
+    if ((rc = ln_bwd_launch(cx, lnb, dx, ws + w.xh1, ws + w.rs1, t.ln1, R))) return rc;
     {  // self-attention block, residual: d(x_in) = dz1 + in_proj^T-path
       ADense y = dense(dx, TD, R, TD);
       if ((rc = par_begin(cx))) return rc;
@@ -895,6 +940,7 @@ static int run_actor_fused(v4l_actor* a, const float* obs, const float* eps, flo
     d.bin = net->p[t.inproj.b]; d.bo = net->p[t.outproj.b]; d.b1 = net->p[t.ff1.b]; d.b2 = net->p[t.ff2.b];
     d.g1 = net->p[t.ln1.g]; d.be1 = net->p[t.ln1.b]; d.g2 = net->p[t.ln2.g]; d.be2 = net->p[t.ln2.b];
     d.xin = xin; d.xout = xout;
+    d.s_qkv = d.s_P = d.s_ctx = d.s_xh1 = d.s_rs1 = d.s_x1 = d.s_f = d.s_xh2 = d.s_rs2 = nullptr;
   };
   const int nl = pf->cfg.n_layers;
   for (int l = 0; l < nl; ++l) {
@@ -1365,7 +1411,7 @@ int64_t v4l_trainer_ws_floats(const v4l_trainer* tr, int n) {
 }
 int64_t v4l_trainer_ctl_bytes(const v4l_trainer* tr, int n) {
   if (!tr || n <= 0) return -1;
-  return 256 + 256 + (int64_t)round_up(n, 64) * sizeof(int);
+  return 256 + 256 + 512 + (int64_t)round_up(n, 64) * sizeof(int);
 }
 int v4l_trainer_bind(v4l_trainer* tr, float* g_pf_dev, float* m_pf_dev, float* v_pf_dev, float* g_vf_dev,
                      float* m_vf_dev, float* v_vf_dev, float* ws_dev, int64_t ws_floats, void* ctl_dev, int n_max,
@@ -1385,7 +1431,8 @@ int v4l_trainer_bind(v4l_trainer* tr, float* g_pf_dev, float* m_pf_dev, float* v
   }
   tr->ctl = (UpdCtl*)ctl_dev;
   tr->stats_cur = (float*)((char*)ctl_dev + 256);
-  tr->rowidx_cur = (int*)((char*)ctl_dev + 512);
+  tr->norm_part = (float*)((char*)ctl_dev + 512);  // [2][64] squared-norm partials (vf, pf)
+  tr->rowidx_cur = (int*)((char*)ctl_dev + 1024);
   tr->n_max = n_max;
   tr->bound = true;
   return 0;
@@ -1441,13 +1488,14 @@ int v4l_trainer_critic_grads(v4l_trainer* tr, const v4l_rollout* ro, int n, cons
 }
 
 static int adam_step(v4l_trainer* tr, v4l_net* net, float* g, float* m, float* v, const v4l_ppo_hyper* hp, int which,
-                     float* sumsq, float* norm_out, hipStream_t s) {
-  const int gb = (int)std::min<int64_t>(64, cdiv64(net->total_params, 256));  // one atomic per block on one address
+                     float* norm_out, hipStream_t s) {
+  const int gb = (int)std::min<int64_t>(64, cdiv64(net->total_params, 256));
+  float* part = tr->norm_part + which * 64;
   g_op = "optim";
-  V4L_KLAUNCH("grad_sumsq", 0, s, grad_sumsq_kernel, dim3(gb), dim3(256), 0, s, g, net->total_params, sumsq);
+  V4L_KLAUNCH("grad_sumsq", 0, s, grad_sumsq_kernel, dim3(gb), dim3(256), 0, s, g, net->total_params, part);
   V4L_LAUNCH_CHECK();
   V4L_KLAUNCH("clip_adam", 0, s, clip_adam_kernel, dim3((unsigned)net->seg_blocks), dim3(256), 0, s, net->d_segs,
-              (int)net->params.size(), g, m, v, sumsq, hp->max_grad_norm, hp->eps, tr->ctl, which, norm_out);
+              (int)net->params.size(), g, m, v, (const float*)part, gb, hp->max_grad_norm, hp->eps, tr->ctl, which, norm_out);
   V4L_LAUNCH_CHECK();
   return 0;
 }
@@ -1455,7 +1503,7 @@ static int adam_step(v4l_trainer* tr, v4l_net* net, float* g, float* m, float* v
 int v4l_trainer_critic_step(v4l_trainer* tr, const v4l_ppo_hyper* hp, void* stream) {
   V4L_REQUIRE(tr && tr->bound && hp, "v4l_trainer_critic_step: bad argument");
   float* st = tr->stats_cur;
-  return adam_step(tr, tr->vf, tr->g_vf, tr->m_vf, tr->v_vf, hp, 1, st + ST_SUMSQ_VF, st + ST_GN_VF, (hipStream_t)stream);
+  return adam_step(tr, tr->vf, tr->g_vf, tr->m_vf, tr->v_vf, hp, 1, st + ST_GN_VF, (hipStream_t)stream);
 }
 
 int v4l_trainer_actor_grads(v4l_trainer* tr, const v4l_rollout* ro, int n, const v4l_ppo_hyper* hp, void* stream) {
@@ -1504,7 +1552,7 @@ int v4l_trainer_actor_step(v4l_trainer* tr, const v4l_ppo_hyper* hp, void* strea
   V4L_REQUIRE(tr && tr->bound && hp, "v4l_trainer_actor_step: bad argument");
   hipStream_t s = (hipStream_t)stream;
   float* st = tr->stats_cur;
-  int rc = adam_step(tr, tr->pf, tr->g_pf, tr->m_pf, tr->v_pf, hp, 0, st + ST_SUMSQ_PF, st + ST_GN_PF, s);
+  int rc = adam_step(tr, tr->pf, tr->g_pf, tr->m_pf, tr->v_pf, hp, 0, st + ST_GN_PF, s);
   if (rc) return rc;
   g_op = "ctl";
   V4L_KLAUNCH("upd_end", 0, s, upd_end_kernel, dim3(1), dim3(64), 0, s, tr->ctl, st, tr->stats_all);
