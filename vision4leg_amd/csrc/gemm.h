@@ -226,7 +226,8 @@ struct Epi {
   int relu;           // max(x,0) after bias
   const float* mask;  // null, or multiply by (mask[orow*ldmask+n] > 0): ReLU backward of the layer below
   int ldmask;
-  int accumulate;     // C += instead of C =
+  int accumulate;     // C += instead of C =   (shorthand for addend == C)
+  const float* addend; // optional: C = result + addend[same row/col layout as C]
   int rowmap;
   // ROWMAP_DGRAD: class (py,px), stride s, class pixel counts, input plane
   int py, px, s, nIy, nIx, IH, IW;
@@ -345,6 +346,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(AL al, const T* __restrict
   // only the stores are predicated (see keep8 for why). vec: all row strides / N are multiples of 4.
   const bool vec = ((ep.N | ep.ldc) & 3) == 0 && (ep.mask == nullptr || (ep.ldmask & 3) == 0);
   const int ng = (lane >> 4) * 4;
+  const float* add = ep.accumulate ? ep.C : ep.addend;
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
     const int m = m0 + wave * 32 + i * 16 + (lane & 15);
@@ -358,7 +360,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(AL al, const T* __restrict
         const bool ok = rok && n4 < ep.N;
         bv[j] = ep.bias != nullptr ? *reinterpret_cast<const float4*>(ep.bias + (n4 < ep.N ? n4 : 0)) : float4{0.f, 0.f, 0.f, 0.f};
         if (ep.mask != nullptr) mk[j] = *reinterpret_cast<const float4*>(ep.mask + (ok ? orow * ep.ldmask + n4 : 0));
-        if (ep.accumulate) old[j] = *reinterpret_cast<const float4*>(ep.C + (ok ? orow * ep.ldc + n4 : 0));
+        if (add != nullptr) old[j] = *reinterpret_cast<const float4*>(add + (ok ? orow * ep.ldc + n4 : 0));
       }
 #pragma unroll
       for (int j = 0; j < NT; ++j) {
@@ -369,7 +371,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(AL al, const T* __restrict
           v.x = mk[j].x > 0.f ? v.x : 0.f; v.y = mk[j].y > 0.f ? v.y : 0.f;
           v.z = mk[j].z > 0.f ? v.z : 0.f; v.w = mk[j].w > 0.f ? v.w : 0.f;
         }
-        if (ep.accumulate) { v.x += old[j].x; v.y += old[j].y; v.z += old[j].z; v.w += old[j].w; }
+        if (add != nullptr) { v.x += old[j].x; v.y += old[j].y; v.z += old[j].z; v.w += old[j].w; }
         if (rok && n4 < ep.N) *reinterpret_cast<float4*>(ep.C + orow * ep.ldc + n4) = v;
       }
     } else {
@@ -383,7 +385,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(AL al, const T* __restrict
           if (ep.bias != nullptr) v += ep.bias[n < ep.N ? n : 0];
           if (ep.relu) v = fmaxf(v, 0.f);
           if (ep.mask != nullptr) v = ep.mask[ok ? orow * ep.ldmask + n : 0] > 0.f ? v : 0.f;
-          if (ep.accumulate) v += ep.C[ok ? orow * ep.ldc + n : 0];
+          if (add != nullptr) v += add[ok ? orow * ep.ldc + n : 0];
           if (ok) ep.C[orow * ep.ldc + n] = v;
         }
     }
@@ -401,8 +403,8 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(AL al, const T* __restrict
 // the m loop. Block = 4 waves, stage = 64 rows (wave w stages rows 16w..16w+15), output tile BN(n) x 64*KT(k),
 // wave w owns k-tiles [w*KT, (w+1)*KT).
 template <typename T, int BN, int KT, class YL, class XL>
-__global__ __launch_bounds__(256) void gemm_tn_kernel(YL yl, XL xl, int M, int m_per_block, float* __restrict__ slab,
-                                                      float* __restrict__ bslab, int Npad, int Kpad) {
+__device__ __forceinline__ void tn_body(const YL& yl, const XL& xl, int M, int m_per_block, float* __restrict__ slab,
+                                        float* __restrict__ bslab, int Npad, int Kpad, int bx, int by, int bz) {
   constexpr int BMR = 64;
   constexpr int LD = BMR + (sizeof(T) == 2 ? 8 : 4);
   constexpr int NT = BN / 16;
@@ -414,10 +416,10 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(YL yl, XL xl, int M, int m
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int k0 = blockIdx.x * BKO, n0 = blockIdx.y * BN;
-  const int mb = blockIdx.z * m_per_block;
+  const int k0 = bx * BKO, n0 = by * BN;
+  const int mb = bz * m_per_block;
   const int me = min(M, mb + m_per_block);
-  const bool do_bias = (bslab != nullptr) && (blockIdx.x == 0);
+  const bool do_bias = (bslab != nullptr) && (bx == 0);
 
   // per-lane column offsets (constant for the whole block). The KT columns of a lane are adjacent in memory for
   // every loader (dense rows, NHWC channels, the 8 kx of a CHW window row) and share validity: one vector load.
@@ -493,7 +495,7 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(YL yl, XL xl, int M, int m
   }
 
   // acc[i][j][r] = partial dW[n0 + 16*i + (lane&15)][k0 + 16*(wave*KT+j) + 4*(lane>>4) + r]: one 16-byte store each
-  float* out = slab + (int64_t)blockIdx.z * Npad * Kpad;
+  float* out = slab + (int64_t)bz * Npad * Kpad;
 #pragma unroll
   for (int i = 0; i < NT; ++i) {
     const int n = n0 + i * 16 + (lane & 15);
@@ -508,8 +510,36 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(YL yl, XL xl, int M, int m
     sBias[wave][lane] = bsum;
     __syncthreads();
     if (tid < BN && n0 + tid < Npad)
-      bslab[(int64_t)blockIdx.z * Npad + n0 + tid] = sBias[0][tid] + sBias[1][tid] + sBias[2][tid] + sBias[3][tid];
+      bslab[(int64_t)bz * Npad + n0 + tid] = sBias[0][tid] + sBias[1][tid] + sBias[2][tid] + sBias[3][tid];
   }
+}
+
+template <typename T, int BN, int KT, class YL, class XL>
+__global__ __launch_bounds__(256) void gemm_tn_kernel(YL yl, XL xl, int M, int m_per_block, float* __restrict__ slab,
+                                                      float* __restrict__ bslab, int Npad, int Kpad) {
+  tn_body<T, BN, KT, YL, XL>(yl, xl, M, m_per_block, slab, bslab, Npad, Kpad, blockIdx.x, blockIdx.y, blockIdx.z);
+}
+
+// All dense (Linear) weight-grads of a backward pass in ONE launch: they are mutually independent, individually too
+// small to fill the chip (12..64 blocks each) and would otherwise serialise as ~30 dependent-in-stream kernels.
+struct TnProb {
+  ADense y, x;
+  int M, mpb, Npad, Kpad, gx, gy;
+  float* slab;
+  float* bslab;
+  int64_t blk0;  // first block of this problem
+};
+template <typename T>
+__global__ __launch_bounds__(256) void gemm_tn_group_kernel(const TnProb* __restrict__ probs, int np) {
+  int lo = 0, hi = np - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (probs[mid].blk0 <= (int64_t)blockIdx.x) lo = mid; else hi = mid - 1;
+  }
+  const TnProb p = probs[lo];
+  const int lb = (int)((int64_t)blockIdx.x - p.blk0);
+  const int bx = lb % p.gx, t = lb / p.gx;
+  tn_body<T, 64, 1, ADense, ADense>(p.y, p.x, p.M, p.mpb, p.slab, p.bslab, p.Npad, p.Kpad, bx, t % p.gy, t / p.gy);
 }
 
 // Sums the per-slab partials of one or more weight tensors and writes the PyTorch-layout gradients.

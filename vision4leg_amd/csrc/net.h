@@ -45,6 +45,8 @@ struct LNp { int g = -1, b = -1; };
 struct TLayer { Lin inproj, outproj, ff1, ff2; LNp ln1, ln2; };
 
 struct LayerWs { int64_t qkv, P, ctx, xh1, rs1, x1, f, xh2, rs2; };
+// backward: every layer keeps its own gradient tensors alive until the grouped weight-grad launch at the end
+struct LayerBw { int64_t dz2, df, dx1, dz1, dctx, dqkv; };
 struct Layout {
   int n = 0;
   int64_t c1 = 0, c2 = 0, c3 = 0;
@@ -56,10 +58,12 @@ struct Layout {
   int64_t pooled = 0;
   std::vector<int64_t> hh;       // head hidden activations
   int64_t out = 0, dout = 0;     // [n][OUT_LD]
-  // backward scratch
-  int64_t dxa = 0, dctx = 0, dqkv = 0, df = 0;
-  int64_t dha = 0, dhb = 0;      // [n][maxwidth] ping-pong for MLP stacks
-  int64_t dhc = 0;               // [n][maxwidth] hand-off between two stacks (head -> encoder)
+  // backward: one buffer per gradient tensor (nothing is overwritten before the deferred weight-grads ran)
+  std::vector<int64_t> dhh;      // grad w.r.t. head hidden pre-activations
+  std::vector<int64_t> deh;      // grad w.r.t. encoder-MLP hidden pre-activations
+  std::vector<LayerBw> lb;
+  std::vector<int64_t> dxl;      // LOCO: grad w.r.t. x[l], l = 0..L
+  int64_t dhc = 0;               // [n][maxwidth] hand-off between two stacks (head -> encoder / concat)
   int64_t dpool = 0, dc3 = 0, dc2 = 0, dc1 = 0;
   int64_t slab = 0;              // weight-grad partial slabs
   int64_t total = 0;
@@ -90,6 +94,10 @@ struct v4l_net {
   v4l::ParamSeg* d_segs = nullptr;
   v4l::RedDesc* d_red = nullptr;
   static constexpr int MAX_RED = 96;
+  static constexpr int MAX_TNP = 64;
+  v4l::TnProb* d_tnp = nullptr;
+  double tnp_flops = 0;
+  std::vector<v4l::TnProb> tnp, tnp_cached;   // deferred dense weight-grad problems of the current / last backward
   std::vector<v4l::RedDesc> red, red_cached;  // weight-grad reduce descriptors of the current / last backward
   int64_t slab_cap = 0;
   int64_t seg_blocks = 0;

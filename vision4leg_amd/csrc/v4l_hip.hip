@@ -62,6 +62,7 @@ struct ProfGuard {
 static inline ADense dense(const float* p, int lda, int M, int K, const int* rowidx = nullptr, int tokmap = 0,
                            const float* mask = nullptr) {
   ADense a;
+  memset(&a, 0, sizeof(a));  // descriptors are compared bytewise (cached device tables): no stray padding
   a.p = p; a.lda = lda; a.M = M; a.K = K; a.rowidx = rowidx; a.tokmap = tokmap; a.mask = mask;
   return a;
 }
@@ -90,6 +91,14 @@ static int launch_nt(hipStream_t s, const AL& al, int M, const T* Bp, int Np, in
   return 0;
 }
 
+// ROCm 7.2: ending a capture that contains this library's fork/join pattern crashes inside hipStreamEndCapture
+// (a stand-alone reproduction of the pattern does not — tools/probe/capture_fork.hip), so the aux stream is used
+// for eager launches only; captured sequences stay on one stream.
+static inline bool capturing(hipStream_t s) {
+  hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+  if (s == nullptr || hipStreamIsCapturing(s, &st) != hipSuccess) return false;
+  return st != hipStreamCaptureStatusNone;
+}
 // Weight-grad plan: tile shape, split count over the reduction (m) and slab geometry.
 struct TnPlan { int BN, KT, gx, gy, splits, mpb, Npad, Kpad; int64_t slab_floats, bslab_floats; };
 static inline TnPlan tn_plan(int M, int N, int Kx, bool bf16) {
@@ -123,14 +132,6 @@ struct Ctx {  // per-call view of a bound net
 // Fork/join of the net's auxiliary stream. Independent sibling kernels (a layer's weight-grad next to its data-grad,
 // the proprio MLP next to the conv stack) run concurrently: most kernels of this workload fill only a fraction of
 // the 256 CUs. Under stream capture the event record/wait pairs become plain graph dependencies.
-// ROCm 7.2: ending a capture that contains this library's fork/join pattern crashes inside hipStreamEndCapture
-// (a stand-alone reproduction of the pattern does not — tools/probe/capture_fork.hip), so the aux stream is used
-// for eager launches only; captured sequences stay on one stream.
-static inline bool capturing(hipStream_t s) {
-  hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
-  if (s == nullptr || hipStreamIsCapturing(s, &st) != hipSuccess) return false;
-  return st != hipStreamCaptureStatusNone;
-}
 static int par_begin(Ctx& c) {
   v4l_net* n = c.net;
   if (n->aux == nullptr || capturing(c.s)) return 0;
@@ -178,17 +179,32 @@ static int launch_tn(Ctx& c, const YL& yl, const XL& xl, int M, int N, int Kx, R
 }
 
 // one launch: sum all registered slabs into the PyTorch-layout gradients
+template <typename T>
 static int wgrad_finish(Ctx& c) {
   v4l_net* net = c.net;
+  if (!net->tnp.empty()) {
+    V4L_REQUIRE(net->tnp.size() <= (size_t)v4l_net::MAX_TNP, "internal: too many deferred weight-grads");
+    int64_t tb = 0;
+    for (TnProb& q : net->tnp) { const int64_t nb = q.blk0; q.blk0 = tb; tb += nb; }
+    const size_t bytes = net->tnp.size() * sizeof(TnProb);
+    if (net->tnp_cached.size() != net->tnp.size() || memcmp(net->tnp_cached.data(), net->tnp.data(), bytes) != 0) {
+      V4L_REQUIRE(!capturing(c.s), "internal: weight-grad geometry changed while capturing a graph");
+      V4L_HIP_CHECK(hipStreamSynchronize(c.s));
+      V4L_HIP_CHECK(hipMemcpy(net->d_tnp, net->tnp.data(), bytes, hipMemcpyHostToDevice));
+      net->tnp_cached = net->tnp;
+    }
+    g_op = "dense.wgrad";
+    V4L_KLAUNCH("gemm_tn_group", net->tnp_flops, c.s, gemm_tn_group_kernel<T>, dim3((unsigned)tb), dim3(256), 0, c.s,
+                (const TnProb*)net->d_tnp, (int)net->tnp.size());
+    V4L_LAUNCH_CHECK();
+  }
   int64_t blk = 0;
   for (RedDesc& d : net->red) { d.blk0 = blk; blk += cdiv64((int64_t)d.N * d.K + d.N, 256); }
   V4L_REQUIRE(net->red.size() <= (size_t)v4l_net::MAX_RED, "internal: too many weight-grad descriptors");
   const size_t bytes = net->red.size() * sizeof(RedDesc);
   if (net->red_cached.size() != net->red.size() || memcmp(net->red_cached.data(), net->red.data(), bytes) != 0) {
     // geometry changed (first call for this batch size): refresh the device table. Not capturable, by design.
-    hipStreamCaptureStatus cst = hipStreamCaptureStatusNone;
-    if (c.s != nullptr) (void)hipStreamIsCapturing(c.s, &cst);
-    V4L_REQUIRE(cst == hipStreamCaptureStatusNone, "internal: weight-grad geometry changed while capturing a graph");
+    V4L_REQUIRE(!capturing(c.s), "internal: weight-grad geometry changed while capturing a graph");
     V4L_HIP_CHECK(hipStreamSynchronize(c.s));
     V4L_HIP_CHECK(hipMemcpy(net->d_red, net->red.data(), bytes, hipMemcpyHostToDevice));
     net->red_cached = net->red;
@@ -207,15 +223,38 @@ static int lin_fwd(const Ctx& c, const Lin& L, const ADense& a, Epi ep) {
   g_op = L.tag_fwd.c_str();
   return launch_nt<T>(c.s, a, a.M, (const T*)c.net->packed + L.pk, L.Np, L.Kp, ep, 2.0 * a.M * L.N * L.K);
 }
-template <typename T, class XL>
-static int lin_wgrad(Ctx& c, const Lin& L, const ADense& y, const XL& x, int Kx) {
+// Dense weight-grads are not launched where they arise: they are collected and run as ONE grouped launch at the end
+// of the backward pass (wgrad_finish), which is why every gradient tensor keeps its own buffer.
+template <typename T>
+static int lin_wgrad(Ctx& c, const Lin& L, const ADense& y, const ADense& x, int Kx) {
+  v4l_net* net = c.net;
+  const int M = y.M;
+  if (M <= 0) return 0;
+  TnProb p;
+  memset(&p, 0, sizeof(p));
+  p.y = y; p.x = x; p.M = M;
+  p.gx = cdiv(Kx, 64); p.gy = cdiv(L.N, 64);
+  int splits = M >= 4096 ? std::min(32, M / 1024) : std::max(1, M / 512);
+  p.mpb = round_up(cdiv(M, splits), 64);
+  splits = cdiv(M, p.mpb);
+  p.Npad = p.gy * 64; p.Kpad = p.gx * 64;
+  const int64_t slab_f = ((int64_t)splits * p.Npad * p.Kpad + 63) / 64 * 64;
+  const int64_t bslab_f = ((int64_t)splits * p.Npad + 63) / 64 * 64;
+  p.slab = c.slab + c.slab_used;
+  p.bslab = p.slab + slab_f;
+  c.slab_used += slab_f + bslab_f;
+  V4L_REQUIRE(c.slab_used <= net->slab_cap, "internal: weight-grad slab arena overflow");
+  p.blk0 = (int64_t)p.gx * p.gy * splits;  // block count for now; prefix-summed in wgrad_finish
+  net->tnp.push_back(p);
+  net->tnp_flops += 2.0 * M * L.N * L.K;
   RedDesc o;
   memset(&o, 0, sizeof(o));
-  o.dW = c.grads + c.net->params[L.w].goff;
-  o.db = c.grads + c.net->params[L.b].goff;
+  o.dW = c.grads + net->params[L.w].goff;
+  o.db = c.grads + net->params[L.b].goff;
   o.N = L.N; o.K = L.K; o.Ktorch = L.K; o.Cin = L.cin; o.taps = L.taps;
-  g_op = L.tag_wgrad.c_str();
-  return launch_tn<T>(c, y, x, y.M, L.N, Kx, o, 2.0 * y.M * L.N * L.K);
+  o.slab = p.slab; o.bslab = p.bslab; o.nsplit = splits; o.Npad = p.Npad; o.Kpad = p.Kpad;
+  net->red.push_back(o);
+  return 0;
 }
 template <typename T>
 static int lin_dgrad(const Ctx& c, const Lin& L, const ADense& y, Epi ep) {
@@ -236,43 +275,38 @@ static int chain_fwd(const Ctx& c, const Lin* Ls, int k, ADense in, const Act* o
   return 0;
 }
 // backward through the same chain. y: grad w.r.t. the last layer's pre-activation. acts[i]: output of layer i.
-// din (optional): epilogue that receives the grad w.r.t. the chain input.
+// dbufs[i]: where the grad w.r.t. layer i's pre-activation goes (i < k-1). din (optional): epilogue that receives the
+// grad w.r.t. the chain input.
 template <typename T>
-static int chain_bwd(Ctx& c, const Lin* Ls, int k, const ADense& in, const Act* acts, ADense y, float* bufa,
-                     float* bufb, const Epi* din) {
+static int chain_bwd(Ctx& c, const Lin* Ls, int k, const ADense& in, const Act* acts, ADense y, float* const* dbufs,
+                     const Epi* din) {
   for (int i = k - 1; i >= 0; --i) {
     int rc;
-    const bool sibling = i > 0 || din != nullptr;  // a data-grad runs next to this weight-grad
-    if (sibling && (rc = par_begin(c))) return rc;
     if (i == 0) rc = lin_wgrad<T>(c, Ls[0], y, in, in.K);
     else rc = lin_wgrad<T>(c, Ls[i], y, dense(acts[i - 1].p, acts[i - 1].ld, y.M, acts[i - 1].w), acts[i - 1].w);
     if (rc) return rc;
     if (i > 0) {
-      Epi ep = mk_epi(bufa, acts[i - 1].w, acts[i - 1].w);
+      Epi ep = mk_epi(dbufs[i - 1], acts[i - 1].w, acts[i - 1].w);
       ep.mask = acts[i - 1].p;
       ep.ldmask = acts[i - 1].ld;
-      rc = lin_dgrad<T>(c, Ls[i], y, ep);
-      if (rc) return rc;
-      if ((rc = par_end(c))) return rc;
-      y = dense(bufa, acts[i - 1].w, y.M, acts[i - 1].w);
-      std::swap(bufa, bufb);
+      if ((rc = lin_dgrad<T>(c, Ls[i], y, ep))) return rc;
+      y = dense(dbufs[i - 1], acts[i - 1].w, y.M, acts[i - 1].w);
     } else if (din != nullptr) {
-      rc = lin_dgrad<T>(c, Ls[0], y, *din);
-      if (rc) return rc;
-      if ((rc = par_end(c))) return rc;
+      if ((rc = lin_dgrad<T>(c, Ls[0], y, *din))) return rc;
     }
   }
   return 0;
 }
 
 // LayerNorm backward: per-block dgamma/dbeta partials go to the slab arena and are summed by wgrad_finish
-static int ln_bwd_launch(Ctx& c, int nblk, float* dx, const float* xhat, const float* rstd, const LNp& ln, int rows) {
+static int ln_bwd_launch(Ctx& c, int nblk, const float* dout, float* dz, const float* xhat, const float* rstd, const LNp& ln,
+                         int rows) {
   v4l_net* net = c.net;
   float* gpart = c.slab + c.slab_used;
   float* bpart = gpart + (int64_t)nblk * TD;
   c.slab_used += 2 * (int64_t)nblk * TD;
   V4L_REQUIRE(c.slab_used <= net->slab_cap, "internal: weight-grad slab arena overflow");
-  V4L_KLAUNCH("ln_bwd", 0, c.s, ln_bwd_kernel, dim3(nblk), dim3(256), 0, c.s, dx, xhat, rstd, net->p[ln.g], rows, dx, gpart,
+  V4L_KLAUNCH("ln_bwd", 0, c.s, ln_bwd_kernel, dim3(nblk), dim3(256), 0, c.s, dout, xhat, rstd, net->p[ln.g], rows, dz, gpart,
               bpart);
   V4L_LAUNCH_CHECK();
   for (int k = 0; k < 2; ++k) {
@@ -546,16 +580,19 @@ int v4l_net::build() {
 }
 
 int64_t v4l_net::table_bytes() const {
-  return (int64_t)(packs.size() * sizeof(PackDesc) + params.size() * sizeof(ParamSeg) + MAX_RED * sizeof(RedDesc) + 512);
+  return (int64_t)(packs.size() * sizeof(PackDesc) + params.size() * sizeof(ParamSeg) + MAX_RED * sizeof(RedDesc) +
+                   MAX_TNP * sizeof(TnProb) + 1024);
 }
 
 // Upper bound of the weight-grad slab arena for a batch of n: every weight tensor with the row count its
 // gradient contraction runs over.
 int64_t v4l_net::slab_floats(int n) const {
   int64_t tot = 0;
-  auto add = [&](int M, int N, int Kx) {
+  auto add = [&](int M, int N, int Kx) {   // conv weight-grads (tn_plan) and, conservatively, dense ones
     const TnPlan p = tn_plan(M, N, Kx, cfg.compute == V4L_BF16);
-    tot += p.slab_floats + p.bslab_floats;
+    const int64_t dense_splits = 32;
+    const int64_t np = round_up(N, 64), kp = round_up(Kx, 64);
+    tot += std::max<int64_t>(p.slab_floats + p.bslab_floats, dense_splits * np * (kp + 1) + 128);
   };
   if (cfg.kind != V4L_NET_MLP)
     for (int i = 0; i < 3; ++i) add(n * conv[i].OH * conv[i].OH, conv[i].Cout, conv[i].K);
@@ -611,17 +648,20 @@ Layout v4l_net::layout(int n) const {
   for (int i = 0; i < c.n_head_hidden; ++i) L.hh.push_back(take((int64_t)n * c.head_hidden[i]));
   L.out = take((int64_t)n * OUT_LD);
   L.dout = take((int64_t)n * OUT_LD);
-  // backward scratch
+  // backward tensors
+  for (int i = 0; i < c.n_head_hidden; ++i) L.dhh.push_back(take((int64_t)n * c.head_hidden[i]));
+  for (int i = 0; i < c.n_enc_hidden; ++i) L.deh.push_back(take((int64_t)n * c.enc_hidden[i]));
+  L.dhc = take((int64_t)n * maxw);
   if (c.kind == V4L_NET_LOCO) {
-    L.dxa = take(R * TD);
-    L.dctx = take(R * TD);
-    L.dqkv = take(R * 3 * TD);
-    L.df = take(R * c.ff_dim);
+    for (int l = 0; l <= c.n_layers; ++l) L.dxl.push_back(take(R * TD));
+    for (int l = 0; l < c.n_layers; ++l) {
+      LayerBw b;
+      b.dz2 = take(R * TD); b.df = take(R * c.ff_dim); b.dx1 = take(R * TD); b.dz1 = take(R * TD);
+      b.dctx = take(R * TD); b.dqkv = take(R * 3 * TD);
+      L.lb.push_back(b);
+    }
     L.dpool = take((int64_t)n * 2 * TD);
   }
-  L.dha = take((int64_t)n * maxw);
-  L.dhb = take((int64_t)n * maxw);
-  L.dhc = take((int64_t)n * maxw);
   if (c.kind != V4L_NET_MLP) {
     L.dc3 = take((int64_t)n * 16 * 64);
     L.dc2 = take((int64_t)n * 36 * 64);
@@ -760,28 +800,37 @@ int v4l_net::backward_t(const float* state, const T* image, const int* rowidx, i
   const v4l_net_cfg& c = cfg;
   Ctx cx{this, s, grads, ws + L.slab, 0, s};
   red.clear();
+  tnp.clear();
+  tnp_flops = 0;
   slab_cap = slab_floats(n);
   int rc;
   const int ne = c.n_enc_hidden, nh = c.n_head_hidden;
   const ADense sin = dense(state, Sp, n, Sp, rowidx);
   Act eacts[V4L_MAX_HIDDEN];
-  for (int i = 0; i < ne; ++i) eacts[i] = Act{ws + L.eh[i], c.enc_hidden[i], c.enc_hidden[i]};
+  float* dehp[V4L_MAX_HIDDEN];
+  for (int i = 0; i < ne; ++i) {
+    eacts[i] = Act{ws + L.eh[i], c.enc_hidden[i], c.enc_hidden[i]};
+    dehp[i] = ws + L.deh[i];
+  }
   Act hacts[V4L_MAX_HIDDEN + 1];
-  for (int i = 0; i < nh; ++i) hacts[i] = Act{ws + L.hh[i], c.head_hidden[i], c.head_hidden[i]};
+  float* dhhp[V4L_MAX_HIDDEN];
+  for (int i = 0; i < nh; ++i) {
+    hacts[i] = Act{ws + L.hh[i], c.head_hidden[i], c.head_hidden[i]};
+    dhhp[i] = ws + L.dhh[i];
+  }
   hacts[nh] = Act{ws + L.out, OUT_LD, c.out_dim};
   const ADense dy = dense(ws + L.dout, OUT_LD, n, OUT_LD);
-  float *bufa = ws + L.dha, *bufb = ws + L.dhb;
 
   if (c.kind == V4L_NET_MLP) {
-    // head stack, then the base MLP; the grad w.r.t. the base output is handed over in `hand`
+    // head stack, then the base MLP; the grad w.r.t. the base output (ReLU-masked) is handed over in `hand`
     const Act& last = eacts[ne - 1];
     float* hand = ws + L.dhc;
     Epi din = mk_epi(hand, last.w, last.w);
     din.mask = last.p;
     din.ldmask = last.ld;
-    if ((rc = chain_bwd<T>(cx, head.data(), nh + 1, dense(last.p, last.ld, n, last.w), hacts, dy, bufa, bufb, &din))) return rc;
-    if ((rc = chain_bwd<T>(cx, enc.data(), ne, sin, eacts, dense(hand, last.w, n, last.w), bufa, bufb, nullptr))) return rc;
-    return wgrad_finish(cx);
+    if ((rc = chain_bwd<T>(cx, head.data(), nh + 1, dense(last.p, last.ld, n, last.w), hacts, dy, dhhp, &din))) return rc;
+    if ((rc = chain_bwd<T>(cx, enc.data(), ne, sin, eacts, dense(hand, last.w, n, last.w), dehp, nullptr))) return rc;
+    return wgrad_finish<T>(cx);
   }
 
   if (c.kind == V4L_NET_CNN) {
@@ -789,107 +838,94 @@ int v4l_net::backward_t(const float* state, const T* image, const int* rowidx, i
     eacts[ne - 1] = Act{ws + L.vis + c.visual_dim, cw, c.enc_hidden[ne - 1]};
     float* hand = ws + L.dhc;  // grad w.r.t. the concat [visual_out | state_out], both post-ReLU
     Epi din = mk_epi(hand, cw, cw);
-    if ((rc = chain_bwd<T>(cx, head.data(), nh + 1, dense(ws + L.vis, cw, n, cw), hacts, dy, bufa, bufb, &din))) return rc;
+    if ((rc = chain_bwd<T>(cx, head.data(), nh + 1, dense(ws + L.vis, cw, n, cw), hacts, dy, dhhp, &din))) return rc;
     {  // visual branch: ReLU mask applied on load; data-grad lands in dc3 viewed as the NHWC flatten [n][1024]
       ADense yv = dense(hand, cw, n, c.visual_dim, nullptr, 0, ws + L.vis);
-      if ((rc = par_begin(cx))) return rc;
       if ((rc = lin_wgrad<T>(cx, proj, yv, dense(ws + L.c3, 1024, n, 1024), 1024))) return rc;
       Epi ep = mk_epi(ws + L.dc3, 1024, 1024);
       ep.mask = ws + L.c3;
       ep.ldmask = 1024;
       if ((rc = lin_dgrad<T>(cx, proj, yv, ep))) return rc;
-      if ((rc = par_end(cx))) return rc;
     }
     {  // state branch
       ADense ys = dense(hand + c.visual_dim, cw, n, c.enc_hidden[ne - 1], nullptr, 0, ws + L.vis + c.visual_dim);
-      if ((rc = chain_bwd<T>(cx, enc.data(), ne, sin, eacts, ys, bufa, bufb, nullptr))) return rc;
+      if ((rc = chain_bwd<T>(cx, enc.data(), ne, sin, eacts, ys, dehp, nullptr))) return rc;
     }
     if ((rc = conv_stack_bwd<T>(cx, image, rowidx, n, ws + L.c1, ws + L.c2, ws + L.dc3, ws + L.dc2, ws + L.dc1))) return rc;
-    return wgrad_finish(cx);
+    return wgrad_finish<T>(cx);
   }
 
   // ---- LocoTransformer
   const int R = n * NTOK;
   {
     Epi din = mk_epi(ws + L.dpool, 2 * TD, 2 * TD);
-    if ((rc = chain_bwd<T>(cx, head.data(), nh + 1, dense(ws + L.pooled, 2 * TD, n, 2 * TD), hacts, dy, bufa, bufb, &din)))
+    if ((rc = chain_bwd<T>(cx, head.data(), nh + 1, dense(ws + L.pooled, 2 * TD, n, 2 * TD), hacts, dy, dhhp, &din)))
       return rc;
   }
-  float* dx = ws + L.dxa;
   g_op = "pool";
-  V4L_KLAUNCH("pool_bwd", 0, s, pool_bwd_kernel, dim3(n), dim3(64), 0, s, ws + L.dpool, n, dx);
+  V4L_KLAUNCH("pool_bwd", 0, s, pool_bwd_kernel, dim3(n), dim3(64), 0, s, ws + L.dpool, n, ws + L.dxl[c.n_layers]);
   V4L_LAUNCH_CHECK();
-  const int lnb = std::min(cdiv(R, 16), 128);  // few blocks: the per-block dgamma/dbeta atomics hit 128 addresses
+  const int lnb = std::min(cdiv(R, 16), 128);
   for (int l = c.n_layers - 1; l >= 0; --l) {
     const TLayer& t = layers[l];
     const LayerWs& w = L.lw[l];
+    const LayerBw& b = L.lb[l];
+    float* dx = ws + L.dxl[l + 1];  // grad w.r.t. this layer's output
     g_op = "ln2";
-    if ((rc = ln_bwd_launch(cx, lnb, dx, ws + w.xh2, ws + w.rs2, t.ln2, R))) return rc;
-    {  // linear2 / linear1 (FFN), residual: d(x1) = dz2 + W1^T-path
-      ADense y = dense(dx, TD, R, TD);
-      if ((rc = par_begin(cx))) return rc;
+    if ((rc = ln_bwd_launch(cx, lnb, dx, ws + b.dz2, ws + w.xh2, ws + w.rs2, t.ln2, R))) return rc;
+    {  // linear2 / linear1 (FFN), residual: d(x1) = dz2 + df W1
+      ADense y = dense(ws + b.dz2, TD, R, TD);
       if ((rc = lin_wgrad<T>(cx, t.ff2, y, dense(ws + w.f, c.ff_dim, R, c.ff_dim), c.ff_dim))) return rc;
-      Epi ep = mk_epi(ws + L.df, c.ff_dim, c.ff_dim);
+      Epi ep = mk_epi(ws + b.df, c.ff_dim, c.ff_dim);
       ep.mask = ws + w.f;
       ep.ldmask = c.ff_dim;
       if ((rc = lin_dgrad<T>(cx, t.ff2, y, ep))) return rc;
-      if ((rc = par_end(cx))) return rc;
-      ADense yf = dense(ws + L.df, c.ff_dim, R, c.ff_dim);
-      if ((rc = par_begin(cx))) return rc;
+      ADense yf = dense(ws + b.df, c.ff_dim, R, c.ff_dim);
       if ((rc = lin_wgrad<T>(cx, t.ff1, yf, dense(ws + w.x1, TD, R, TD), TD))) return rc;
-      Epi ea = mk_epi(dx, TD, TD);
-      ea.accumulate = 1;
+      Epi ea = mk_epi(ws + b.dx1, TD, TD);
+      ea.addend = ws + b.dz2;
       if ((rc = lin_dgrad<T>(cx, t.ff1, yf, ea))) return rc;
-      if ((rc = par_end(cx))) return rc;
     }
     g_op = "ln1";
-    if ((rc = ln_bwd_launch(cx, lnb, dx, ws + w.xh1, ws + w.rs1, t.ln1, R))) return rc;
-    {  // self-attention block, residual: d(x_in) = dz1 + in_proj^T-path
-      ADense y = dense(dx, TD, R, TD);
-      if ((rc = par_begin(cx))) return rc;
+    if ((rc = ln_bwd_launch(cx, lnb, ws + b.dx1, ws + b.dz1, ws + w.xh1, ws + w.rs1, t.ln1, R))) return rc;
+    {  // self-attention block, residual: d(x_in) = dz1 + dqkv W_in
+      ADense y = dense(ws + b.dz1, TD, R, TD);
       if ((rc = lin_wgrad<T>(cx, t.outproj, y, dense(ws + w.ctx, TD, R, TD), TD))) return rc;
-      if ((rc = lin_dgrad<T>(cx, t.outproj, y, mk_epi(ws + L.dctx, TD, TD)))) return rc;
-      if ((rc = par_end(cx))) return rc;
+      if ((rc = lin_dgrad<T>(cx, t.outproj, y, mk_epi(ws + b.dctx, TD, TD)))) return rc;
       g_op = "attn";
-      V4L_KLAUNCH("attn_bwd", 8.0 * n * NTOK * NTOK * TD, s, attn_bwd_kernel, dim3(n), dim3(256), 0, s, ws + w.qkv, ws + w.P, ws + L.dctx, n,
-                         ws + L.dqkv);
+      V4L_KLAUNCH("attn_bwd", 8.0 * n * NTOK * NTOK * TD, s, attn_bwd_kernel, dim3(n), dim3(256), 0, s, ws + w.qkv, ws + w.P,
+                  ws + b.dctx, n, ws + b.dqkv);
       V4L_LAUNCH_CHECK();
-      ADense yq = dense(ws + L.dqkv, 3 * TD, R, 3 * TD);
-      if ((rc = par_begin(cx))) return rc;
+      ADense yq = dense(ws + b.dqkv, 3 * TD, R, 3 * TD);
       if ((rc = lin_wgrad<T>(cx, t.inproj, yq, dense(ws + L.x[l], TD, R, TD), TD))) return rc;
-      Epi ea = mk_epi(dx, TD, TD);
-      ea.accumulate = 1;
+      Epi ea = mk_epi(ws + L.dxl[l], TD, TD);
+      ea.addend = ws + b.dz1;
       if ((rc = lin_dgrad<T>(cx, t.inproj, yq, ea))) return rc;
-      if ((rc = par_end(cx))) return rc;
     }
   }
+  float* dx = ws + L.dxl[0];
   const float* x0 = ws + L.x[0];
   {  // token 0 -> state_projector -> encoder MLP
     const Act& last = eacts[ne - 1];
     ADense yp = dense(dx, NTOK * TD, n, TD, nullptr, 0, x0);
-    if ((rc = par_begin(cx))) return rc;
     if ((rc = lin_wgrad<T>(cx, proj, yp, dense(last.p, last.ld, n, last.w), last.w))) return rc;
-    Epi ep = mk_epi(bufa, last.w, last.w);
+    Epi ep = mk_epi(ws + L.dhc, last.w, last.w);
     ep.mask = last.p;
     ep.ldmask = last.ld;
     if ((rc = lin_dgrad<T>(cx, proj, yp, ep))) return rc;
-    if ((rc = par_end(cx))) return rc;
-    if ((rc = chain_bwd<T>(cx, enc.data(), ne, sin, eacts, dense(bufa, last.w, n, last.w), bufb, bufa, nullptr))) return rc;
+    if ((rc = chain_bwd<T>(cx, enc.data(), ne, sin, eacts, dense(ws + L.dhc, last.w, n, last.w), dehp, nullptr))) return rc;
   }
   {  // tokens 1..16 -> depth_up_conv -> conv stack
     ADense yu = dense(dx, TD, n * 16, TD, nullptr, 1);
-    if ((rc = par_begin(cx))) return rc;
     if ((rc = lin_wgrad<T>(cx, upconv, yu, dense(ws + L.c3, 64, n * 16, 64), 64))) return rc;
     Epi ep = mk_epi(ws + L.dc3, 64, 64);
     ep.mask = ws + L.c3;
     ep.ldmask = 64;
     if ((rc = lin_dgrad<T>(cx, upconv, yu, ep))) return rc;
-    if ((rc = par_end(cx))) return rc;
   }
   if ((rc = conv_stack_bwd<T>(cx, image, rowidx, n, ws + L.c1, ws + L.c2, ws + L.dc3, ws + L.dc2, ws + L.dc1))) return rc;
-  return wgrad_finish(cx);
+  return wgrad_finish<T>(cx);
 }
-
 
 // Fused rollout step for the shipped LocoTransformer shape (csrc/infer.h): 4 launches instead of ~50.
 static bool actor_fusable(const v4l_actor* a) {
@@ -1032,7 +1068,6 @@ int64_t v4l_net_ws_offset(const v4l_net* net, int n, const char* name) {
   if (s == "pooled") return L.pooled;
   if (s == "out") return L.out;
   if (s == "dout") return L.dout;
-  if (s == "dxa") return L.dxa;
   if (s == "dhc") return L.dhc;
   if (s == "dc1") return L.dc1;
   if (s == "dc2") return L.dc2;
@@ -1076,6 +1111,8 @@ int v4l_net_bind(v4l_net* net, float* const* params_dev, void* packed_dev, void*
   net->d_segs = (ParamSeg*)((char*)table_dev + (net->packs.size() * sizeof(PackDesc) + 63) / 64 * 64);
   net->d_red = (RedDesc*)((char*)net->d_segs + (net->params.size() * sizeof(ParamSeg) + 63) / 64 * 64);
   net->red_cached.clear();
+  net->d_tnp = (TnProb*)((char*)net->d_red + (v4l_net::MAX_RED * sizeof(RedDesc) + 63) / 64 * 64);
+  net->tnp_cached.clear();
   // synchronous pageable copies: the host vectors die at return
   V4L_HIP_CHECK(hipStreamSynchronize(s));
   V4L_HIP_CHECK(hipMemcpy(net->d_packs, net->packs.data(), net->packs.size() * sizeof(PackDesc), hipMemcpyHostToDevice));
