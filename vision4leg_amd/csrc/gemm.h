@@ -266,7 +266,7 @@ __device__ __forceinline__ void st8(T* dst, const float (&v)[8]) {
 
 // ------------------------------------------------------------------------------------ gemm_nt
 template <typename T, int BN, class AL>
-__global__ __launch_bounds__(256) void gemm_nt_kernel(AL al, const T* __restrict__ Bp, int Kp, Epi ep) {
+__device__ __forceinline__ void nt_body(const AL& al, const T* __restrict__ Bp, int Kp, const Epi& ep, int bx, int by) {
   constexpr int BM = 128, BK = Tile<T>::BK, LD = Tile<T>::LD;
   constexpr int NT = BN / 16;
   constexpr int BCH = (BN * 8 + 255) / 256;  // B chunks per thread
@@ -275,7 +275,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(AL al, const T* __restrict
   __shared__ __attribute__((aligned(16))) T sB[BN * LD];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+  const int m0 = bx * BM, n0 = by * BN;
 
   // staging ownership: A chunk q = tid + 256*i -> row q>>3, k-chunk q&7
   RowCtx rc[4];
@@ -390,6 +390,26 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(AL al, const T* __restrict
         }
     }
   }
+}
+
+template <typename T, int BN, class AL>
+__global__ __launch_bounds__(256) void gemm_nt_kernel(AL al, const T* __restrict__ Bp, int Kp, Epi ep) {
+  nt_body<T, BN, AL>(al, Bp, Kp, ep, blockIdx.x, blockIdx.y);
+}
+
+// The stride-parity classes of a gather-form conv data-grad (different row counts, weight slices and output pixel
+// maps, same tile shape) as ONE launch: blockIdx.z = class.
+template <typename T> struct DgradClasses {
+  ADgradNHWC a[4];
+  const T* B[4];
+  Epi ep[4];
+  int Kp;
+};
+template <typename T, int BN>
+__global__ __launch_bounds__(256) void gemm_nt_dgrad_kernel(DgradClasses<T> cls) {
+  const int z = blockIdx.z;
+  if ((int)blockIdx.x * 128 >= cls.a[z].M) return;  // classes differ in size: surplus blocks of the smaller ones
+  nt_body<T, BN, ADgradNHWC>(cls.a[z], cls.B[z], cls.Kp, cls.ep[z], blockIdx.x, blockIdx.y);
 }
 
 // ------------------------------------------------------------------------------------ gemm_tn
@@ -553,33 +573,49 @@ struct RedDesc {
   int64_t blk0;        // first block of this descriptor
 };
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const RedDesc* __restrict__ descs, int nd) {
+  // 64 outputs per block x 4 slab groups: thread (o, g) adds slabs g, g+4, g+8, ... (4 independent accumulators),
+  // the 4 group sums are combined through LDS in a fixed order -> deterministic and latency-tolerant
+  __shared__ float part[4][64];
   int lo = 0, hi = nd - 1;
   while (lo < hi) {
     const int mid = (lo + hi + 1) >> 1;
     if (descs[mid].blk0 <= (int64_t)blockIdx.x) lo = mid; else hi = mid - 1;
   }
   const RedDesc d = descs[lo];
-  const int64_t e = ((int64_t)blockIdx.x - d.blk0) * 256 + threadIdx.x;
+  const int o = threadIdx.x & 63, g = threadIdx.x >> 6;
+  const int64_t e = ((int64_t)blockIdx.x - d.blk0) * 64 + o;
   const int64_t nk = (int64_t)d.N * d.K;
+  const float* p = nullptr;
+  int64_t stride = 0;
+  int n = 0, k = 0;
   if (e < nk) {
-    const int n = (int)(e / d.K), k = (int)(e - (int64_t)n * d.K);
-    const float* p = d.slab + (int64_t)n * d.Kpad + k;
-    const int64_t stride = (int64_t)d.Npad * d.Kpad;
-    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-    int z = 0;
-    for (; z + 4 <= d.nsplit; z += 4) {
-      s0 += p[z * stride]; s1 += p[(z + 1) * stride]; s2 += p[(z + 2) * stride]; s3 += p[(z + 3) * stride];
-    }
-    for (; z < d.nsplit; ++z) s0 += p[z * stride];
-    const float s = (s0 + s1) + (s2 + s3);
-    int kt = k;
-    if (d.Cin != 0) { const int t = k / d.Cin, c = k - t * d.Cin; kt = c * d.taps + t; }
-    d.dW[(int64_t)n * d.Ktorch + kt] = s;
+    n = (int)(e / d.K); k = (int)(e - (int64_t)n * d.K);
+    p = d.slab + (int64_t)n * d.Kpad + k;
+    stride = (int64_t)d.Npad * d.Kpad;
   } else if (d.db != nullptr && e < nk + d.N) {
-    const int n = (int)(e - nk);
-    float s = 0.f;
-    for (int z = 0; z < d.nsplit; ++z) s += d.bslab[(int64_t)z * d.Npad + n];
-    d.db[n] = s;
+    n = (int)(e - nk);
+    p = d.bslab + n;
+    stride = d.Npad;
+  }
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  if (p != nullptr) {
+    int z = g;
+    for (; z + 12 < d.nsplit; z += 16) {
+      s0 += p[z * stride]; s1 += p[(z + 4) * stride]; s2 += p[(z + 8) * stride]; s3 += p[(z + 12) * stride];
+    }
+    for (; z < d.nsplit; z += 4) s0 += p[z * stride];
+  }
+  part[g][o] = (s0 + s1) + (s2 + s3);
+  __syncthreads();
+  if (g == 0 && p != nullptr) {
+    const float sum = (part[0][o] + part[1][o]) + (part[2][o] + part[3][o]);
+    if (e < nk) {
+      int kt = k;
+      if (d.Cin != 0) { const int t = k / d.Cin, c = k - t * d.Cin; kt = c * d.taps + t; }
+      d.dW[(int64_t)n * d.Ktorch + kt] = sum;
+    } else {
+      d.db[n] = sum;
+    }
   }
 }
 

@@ -199,7 +199,7 @@ static int wgrad_finish(Ctx& c) {
     V4L_LAUNCH_CHECK();
   }
   int64_t blk = 0;
-  for (RedDesc& d : net->red) { d.blk0 = blk; blk += cdiv64((int64_t)d.N * d.K + d.N, 256); }
+  for (RedDesc& d : net->red) { d.blk0 = blk; blk += cdiv64((int64_t)d.N * d.K + d.N, 64); }
   V4L_REQUIRE(net->red.size() <= (size_t)v4l_net::MAX_RED, "internal: too many weight-grad descriptors");
   const size_t bytes = net->red.size() * sizeof(RedDesc);
   if (net->red_cached.size() != net->red.size() || memcmp(net->red_cached.data(), net->red.data(), bytes) != 0) {
@@ -234,7 +234,7 @@ static int lin_wgrad(Ctx& c, const Lin& L, const ADense& y, const ADense& x, int
   memset(&p, 0, sizeof(p));
   p.y = y; p.x = x; p.M = M;
   p.gx = cdiv(Kx, 64); p.gy = cdiv(L.N, 64);
-  int splits = M >= 4096 ? std::min(32, M / 1024) : std::max(1, M / 512);
+  int splits = M >= 4096 ? std::min(32, M / 512) : std::max(1, M / 256);
   p.mpb = round_up(cdiv(M, splits), 64);
   splits = cdiv(M, p.mpb);
   p.Npad = p.gy * 64; p.Kpad = p.gx * 64;
@@ -390,22 +390,38 @@ static int conv_stack_bwd(Ctx& c, const T* image, const int* rowidx, int n, cons
     }
     if (rc) return rc;
     if (i == 0) break;
-    // gather-form data-grad into the input plane of conv i (= output plane of conv i-1), ReLU-masked
+    // gather-form data-grad into the input plane of conv i (= output plane of conv i-1), ReLU-masked: all
+    // stride-parity classes in one launch (blockIdx.z)
     const int st = v.stride, TH = v.KH / st;
+    DgradClasses<T> dc;
+    memset(&dc, 0, sizeof(dc));
+    dc.Kp = v.Kdp;
+    int maxM = 0;
     for (int cls = 0; cls < v.ncls; ++cls) {
       const int py = cls / st, px = cls % st;
-      ADgradNHWC a;
+      ADgradNHWC& a = dc.a[cls];
       a.p = dys[i]; a.OH = v.OH; a.OW = v.OH; a.Cout = v.Cout; a.TH = TH; a.TW = TH;
       a.nIy = (v.IH - py + st - 1) / st; a.nIx = (v.IH - px + st - 1) / st;
       a.M = n * a.nIy * a.nIx; a.K = v.Kd;
       Epi ep = mk_epi(dys[i - 1], v.Cin, v.Cin);
+      ep.M = a.M;
       ep.rowmap = ROWMAP_DGRAD;
       ep.py = py; ep.px = px; ep.s = st; ep.nIy = a.nIy; ep.nIx = a.nIx; ep.IH = v.IH; ep.IW = v.IH;
       ep.mask = acts[i]; ep.ldmask = v.Cin;
-      g_op = i == 1 ? "conv2.dgrad" : "conv3.dgrad";
-      rc = launch_nt<T>(c.s, a, a.M, (const T*)N->packed + v.pkd[cls], v.Rd, v.Kdp, ep, 2.0 * M * v.Cout * v.K / v.ncls);
-      if (rc) return rc;
+      dc.ep[cls] = ep;
+      dc.B[cls] = (const T*)N->packed + v.pkd[cls];
+      maxM = std::max(maxM, a.M);
     }
+    g_op = i == 1 ? "conv2.dgrad" : "conv3.dgrad";
+    const dim3 grid(cdiv(maxM, 128), 1, v.ncls);
+    if (v.Rd % 64 == 0) {
+      V4L_KLAUNCH("gemm_nt_dgrad", 2.0 * M * v.Cout * v.K, c.s, (gemm_nt_dgrad_kernel<T, 64>), dim3(grid.x, v.Rd / 64, grid.z),
+                  dim3(256), 0, c.s, dc);
+    } else {
+      V4L_KLAUNCH("gemm_nt_dgrad", 2.0 * M * v.Cout * v.K, c.s, (gemm_nt_dgrad_kernel<T, 32>), dim3(grid.x, v.Rd / 32, grid.z),
+                  dim3(256), 0, c.s, dc);
+    }
+    V4L_LAUNCH_CHECK();
     if ((rc = par_end(c))) return rc;
   }
   return 0;
