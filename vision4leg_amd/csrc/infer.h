@@ -117,6 +117,16 @@ struct InfEnc {
   int S, Sp, Kp1;                          // proprio length, rollout row stride, padded K of fc1
 };
 
+// Training forward: read the ingested rollout rows (gathered by rowidx) instead of raw observation rows, and save the
+// activations the backward pass needs (fp32, the layouts of the layer-by-layer kernels). All null for inference.
+struct InfEncTrain {
+  const void* image;     // [slots][4*64*64] T
+  const float* state;    // [slots][Sp]
+  const int* rowidx;     // [n] or null
+  float *s_c1, *s_c2, *s_c3;  // [n][225][32], [n][36][64], [n][16][64]
+  float *s_h1, *s_h2;         // [n][256] encoder-MLP activations
+};
+
 template <typename T> struct InfEncLds {
   static constexpr int PAD = InfLd<T>::PAD;
   static constexpr int IMG = 4 * 64 * 64;
@@ -133,13 +143,14 @@ template <typename T> struct InfEncLds {
 template <typename T>
 __global__ __launch_bounds__(256) void infer_encoder_kernel(const ActCtl* __restrict__ ctl, const float* __restrict__ obs, int E,
                                                             InfEnc w, float* __restrict__ state_roll, T* __restrict__ image_roll,
-                                                            float* __restrict__ x0 /* [E][17][64] */) {
+                                                            float* __restrict__ x0 /* [E][17][64] */, InfEncTrain tr) {
   typedef typename Frag<T>::type frag_t;
   typedef InfEncLds<T> LY;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int fr = lane & 15, fg = (lane >> 4) * 8, qr = (lane >> 4) * 4;
-  const int64_t slot0 = (int64_t)ctl->t * E;
+  const bool train = tr.image != nullptr;
+  const int64_t slot0 = train ? 0 : (int64_t)ctl->t * E;
   const int D = w.S + LY::IMG;
 
   if ((int)blockIdx.x >= E) {
@@ -152,32 +163,40 @@ __global__ __launch_bounds__(256) void infer_encoder_kernel(const ActCtl* __rest
     for (int idx = tid; idx < MR * 128; idx += 256) {
       const int r = idx >> 7, c = idx & 127;
       const bool ok = r0 + r < E;
-      const float v = (ok && c < w.S) ? obs[(int64_t)(r0 + r) * D + c] : 0.f;
+      float v = 0.f;
+      if (train) {
+        if (ok && c < w.Sp) v = tr.state[(int64_t)(tr.rowidx ? tr.rowidx[r0 + r] : r0 + r) * w.Sp + c];
+      } else {
+        if (ok && c < w.S) v = obs[(int64_t)(r0 + r) * D + c];
+        if (ok && c < w.Sp) state_roll[(slot0 + r0 + r) * w.Sp + c] = v;
+      }
       sin[r * LY::LDS_IN + c] = v;
-      if (ok && c < w.Sp) state_roll[(slot0 + r0 + r) * w.Sp + c] = v;
     }
     __syncthreads();
     const int nt4[4] = {wave * 4, wave * 4 + 1, wave * 4 + 2, wave * 4 + 3};
     f32x4 acc[2][4];
-    auto store_h = [&](T* h, const float* bias) {
+    auto store_h = [&](T* h, const float* bias, float* save) {
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const int n4 = nt4[j] * 16 + qr;
         const float4 bb = *reinterpret_cast<const float4*>(bias + n4);
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt)
-          st4(h + (mt * 16 + fr) * LY::LDH + n4, fmaxf(acc[mt][j][0] + bb.x, 0.f), fmaxf(acc[mt][j][1] + bb.y, 0.f),
-              fmaxf(acc[mt][j][2] + bb.z, 0.f), fmaxf(acc[mt][j][3] + bb.w, 0.f));
+        for (int mt = 0; mt < 2; ++mt) {
+          const float v0 = fmaxf(acc[mt][j][0] + bb.x, 0.f), v1 = fmaxf(acc[mt][j][1] + bb.y, 0.f);
+          const float v2 = fmaxf(acc[mt][j][2] + bb.z, 0.f), v3 = fmaxf(acc[mt][j][3] + bb.w, 0.f);
+          st4(h + (mt * 16 + fr) * LY::LDH + n4, v0, v1, v2, v3);
+          if (save != nullptr && r0 + mt * 16 + fr < E) st4(save + (int64_t)(r0 + mt * 16 + fr) * 256 + n4, v0, v1, v2, v3);
+        }
       }
     };
     zero_acc(acc);
     if (w.Kp1 == 128) block_gemm<T, 2, 4, 4>(acc, sin, LY::LDS_IN, (const T*)w.wf1, 128, nt4, lane);
     else block_gemm<T, 2, 4, 2>(acc, sin, LY::LDS_IN, (const T*)w.wf1, 64, nt4, lane);
-    store_h(h1, w.bf1);
+    store_h(h1, w.bf1, tr.s_h1);
     __syncthreads();
     zero_acc(acc);
     block_gemm<T, 2, 4, 8>(acc, h1, LY::LDH, (const T*)w.wf2, 256, nt4, lane);
-    store_h(h2, w.bf2);
+    store_h(h2, w.bf2, tr.s_h2);
     __syncthreads();
     const int nt1[1] = {wave};
     f32x4 ap[2][1];
@@ -203,7 +222,12 @@ __global__ __launch_bounds__(256) void infer_encoder_kernel(const ActCtl* __rest
   T* c1 = img + LY::IMG;
   T* c2 = c1 + LY::C1;
   T* c3 = c2 + LY::C2;
-  {
+  if (train) {
+    typedef typename Frag<T>::type frag_t8;  // 8 elements of T
+    const T* src = reinterpret_cast<const T*>(tr.image) + (int64_t)(tr.rowidx ? tr.rowidx[b] : b) * LY::IMG;
+    for (int i = tid; i < LY::IMG / 8; i += 256)
+      *reinterpret_cast<frag_t8*>(img + i * 8) = *reinterpret_cast<const frag_t8*>(src + i * 8);
+  } else {
     const float4* src = reinterpret_cast<const float4*>(obs + (int64_t)b * D + w.S);  // 16B aligned iff S%4==0
     const bool al = (((int64_t)b * D + w.S) & 3) == 0;
     T* roll = image_roll + (slot0 + b) * (int64_t)LY::IMG;
@@ -255,9 +279,12 @@ __global__ __launch_bounds__(256) void infer_encoder_kernel(const ActCtl* __rest
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const int p = (wave + 4 * i) * 16 + fr;
-        if (p < 225)
-          st4(c1 + p * LY::LD1 + n4, fmaxf(acc[i][j][0] + bb.x, 0.f), fmaxf(acc[i][j][1] + bb.y, 0.f),
-              fmaxf(acc[i][j][2] + bb.z, 0.f), fmaxf(acc[i][j][3] + bb.w, 0.f));
+        if (p < 225) {
+          const float v0 = fmaxf(acc[i][j][0] + bb.x, 0.f), v1 = fmaxf(acc[i][j][1] + bb.y, 0.f);
+          const float v2 = fmaxf(acc[i][j][2] + bb.z, 0.f), v3 = fmaxf(acc[i][j][3] + bb.w, 0.f);
+          st4(c1 + p * LY::LD1 + n4, v0, v1, v2, v3);
+          if (tr.s_c1 != nullptr) st4(tr.s_c1 + ((int64_t)b * 225 + p) * 32 + n4, v0, v1, v2, v3);
+        }
       }
     }
   }
@@ -292,9 +319,12 @@ __global__ __launch_bounds__(256) void infer_encoder_kernel(const ActCtl* __rest
 #pragma unroll
       for (int i = 0; i < 3; ++i) {
         const int p = i * 16 + fr;
-        if (p < 36)
-          st4(c2 + p * LY::LD2 + n4, fmaxf(acc[i][0][0] + bb.x, 0.f), fmaxf(acc[i][0][1] + bb.y, 0.f),
-              fmaxf(acc[i][0][2] + bb.z, 0.f), fmaxf(acc[i][0][3] + bb.w, 0.f));
+        if (p < 36) {
+          const float v0 = fmaxf(acc[i][0][0] + bb.x, 0.f), v1 = fmaxf(acc[i][0][1] + bb.y, 0.f);
+          const float v2 = fmaxf(acc[i][0][2] + bb.z, 0.f), v3 = fmaxf(acc[i][0][3] + bb.w, 0.f);
+          st4(c2 + p * LY::LD2 + n4, v0, v1, v2, v3);
+          if (tr.s_c2 != nullptr) st4(tr.s_c2 + ((int64_t)b * 36 + p) * 64 + n4, v0, v1, v2, v3);
+        }
       }
     }
   }
@@ -316,8 +346,10 @@ __global__ __launch_bounds__(256) void infer_encoder_kernel(const ActCtl* __rest
     }
     const int n4 = wave * 16 + qr;
     const float4 bb = *reinterpret_cast<const float4*>(w.b3 + n4);
-    st4(c3 + fr * LY::LD2 + n4, fmaxf(acc[0] + bb.x, 0.f), fmaxf(acc[1] + bb.y, 0.f), fmaxf(acc[2] + bb.z, 0.f),
-        fmaxf(acc[3] + bb.w, 0.f));
+    const float v0 = fmaxf(acc[0] + bb.x, 0.f), v1 = fmaxf(acc[1] + bb.y, 0.f);
+    const float v2 = fmaxf(acc[2] + bb.z, 0.f), v3 = fmaxf(acc[3] + bb.w, 0.f);
+    st4(c3 + fr * LY::LD2 + n4, v0, v1, v2, v3);
+    if (tr.s_c3 != nullptr) st4(tr.s_c3 + ((int64_t)b * 16 + fr) * 64 + n4, v0, v1, v2, v3);
   }
   __syncthreads();
   {  // depth_up_conv (1x1, no activation) -> tokens 1..16

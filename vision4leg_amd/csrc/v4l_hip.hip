@@ -726,7 +726,33 @@ int v4l_net::forward_t(const float* state, const T* image, const int* rowidx, in
     head_in = dense(ws + L.vis, cw, n, cw);
   } else {
     float* x0 = enc_ws != nullptr ? const_cast<float*>(enc_ws) + L.x[0] : ws + L.x[0];
-    if (enc_ws == nullptr && stage != 2) {
+    const bool fused_enc = ne == 2 && c.enc_hidden[0] == 256 && c.enc_hidden[1] == 256 && c.state_dim <= 128 &&
+                           getenv("V4L_NO_FUSED_ENC") == nullptr;
+    if (enc_ws == nullptr && stage != 2 && fused_enc) {
+      // one launch for the whole encoder (csrc/infer.h): a block per sample runs conv1..3 + up-conv out of LDS, extra
+      // blocks run the proprio MLP; the activations backward_t needs are saved on the way
+      static bool attr_done = false;
+      if (!attr_done) {
+        V4L_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&infer_encoder_kernel<T>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)InfEncLds<T>::bytes));
+        attr_done = true;
+      }
+      const T* pk = (const T*)packed;
+      InfEnc en;
+      en.w1 = pk + conv[0].pk; en.w2 = pk + conv[1].pk; en.w3 = pk + conv[2].pk; en.wup = pk + upconv.pk;
+      en.b1 = p[conv[0].b]; en.b2 = p[conv[1].b]; en.b3 = p[conv[2].b]; en.bup = p[upconv.b];
+      en.wf1 = pk + enc[0].pk; en.wf2 = pk + enc[1].pk; en.wpr = pk + proj.pk;
+      en.bf1 = p[enc[0].b]; en.bf2 = p[enc[1].b]; en.bpr = p[proj.b];
+      en.S = c.state_dim; en.Sp = Sp; en.Kp1 = enc[0].Kp;
+      InfEncTrain tr;
+      tr.image = image; tr.state = state; tr.rowidx = rowidx;
+      tr.s_c1 = ws + L.c1; tr.s_c2 = ws + L.c2; tr.s_c3 = ws + L.c3; tr.s_h1 = ws + L.eh[0]; tr.s_h2 = ws + L.eh[1];
+      g_op = "encoder";
+      V4L_KLAUNCH("fused_encoder", 2.0 * n * 3784064.0, s, infer_encoder_kernel<T>, dim3(n + cdiv(n, 32)), dim3(256),
+                  InfEncLds<T>::bytes, s, (const ActCtl*)nullptr, (const float*)nullptr, n, en, (float*)nullptr, (T*)nullptr, x0,
+                  tr);
+      V4L_LAUNCH_CHECK();
+    } else if (enc_ws == nullptr && stage != 2) {
       // proprio branch (MLP + state_projector -> token 0) on the aux stream next to the conv branch (-> tokens 1..16)
       if ((rc = par_begin(cx))) return rc;
       Ctx cx2 = cx;
@@ -985,7 +1011,7 @@ static int run_actor_fused(v4l_actor* a, const float* obs, const float* eps, flo
   float* x0 = ws_pf + Lp.x[0];
   g_op = "encoder";
   V4L_KLAUNCH("infer_encoder", 2.0 * E * 3678208.0, s, infer_encoder_kernel<T>, dim3(E + cdiv(E, 32)), dim3(256),
-              InfEncLds<T>::bytes, s, (const ActCtl*)a->ctl, obs, E, en, state_roll, (T*)image_roll, x0);
+              InfEncLds<T>::bytes, s, (const ActCtl*)a->ctl, obs, E, en, state_roll, (T*)image_roll, x0, InfEncTrain{});
   V4L_LAUNCH_CHECK();
   auto fill = [&](InfLayer& d, v4l_net* net, const T* base, const TLayer& t, const float* xin, float* xout) {
     d.win = base + t.inproj.pk; d.wo = base + t.outproj.pk; d.w1 = base + t.ff1.pk; d.w2 = base + t.ff2.pk;
