@@ -99,7 +99,13 @@ struct ADense {
     }
     keep8(v, ok);
   }
-  // separable form used by the weight-grad kernel: address = row_off(m) + col_off(k)
+  // separable form used by the weight-grad kernel: address = row_off(m) + col_off(k). RowIt walks consecutive rows
+  // without re-deriving (sample, pixel) coordinates: the weight-grad kernel visits 16 consecutive rows per stage and
+  // the integer divisions of row() would otherwise dominate its scalar-unit time.
+  struct RowIt { int m; };
+  __device__ __forceinline__ RowIt iter(int m) const { return RowIt{m}; }
+  __device__ __forceinline__ int64_t off(const RowIt& it, int& valid) const { return row_off(it.m, valid); }
+  __device__ __forceinline__ void next(RowIt& it) const { ++it.m; }
   __device__ __forceinline__ int64_t row_off(int m, int& valid) const { RowCtx rc = row(m); valid = rc.valid; return rc.base; }
   __device__ __forceinline__ int64_t col_off(int k, int& valid) const { valid = k < K; return k; }
   __device__ __forceinline__ float get(int64_t off) const {
@@ -145,6 +151,22 @@ struct AIm2colCHW {
     keep8(v, ok);
   }
   __device__ __forceinline__ int64_t row_off(int m, int& valid) const { RowCtx rc = row(m); valid = rc.valid; return rc.base; }
+  struct RowIt { int m, b, oy, ox; };
+  __device__ __forceinline__ RowIt iter(int m) const {
+    const int opix = OH * OW;
+    const int b = m / opix, q = m - b * opix;
+    const int oy = q / OW;
+    return RowIt{m, b, oy, q - oy * OW};
+  }
+  __device__ __forceinline__ int64_t off(const RowIt& it, int& valid) const {
+    valid = it.m < M;
+    const int b = rowidx != nullptr ? rowidx[valid ? it.b : 0] : it.b;
+    return (int64_t)b * C * IH * IW + (int64_t)(it.oy * stride) * IW + it.ox * stride;
+  }
+  __device__ __forceinline__ void next(RowIt& it) const {
+    ++it.m;
+    if (++it.ox == OW) { it.ox = 0; if (++it.oy == OH) { it.oy = 0; ++it.b; } }
+  }
   __device__ __forceinline__ int64_t col_off(int k, int& valid) const {
     const int c = k >> 6, ky = (k >> 3) & 7, kx = k & 7;
     valid = c < C;
@@ -178,6 +200,21 @@ struct AIm2colNHWC {
     keep8(v, ok);
   }
   __device__ __forceinline__ int64_t row_off(int m, int& valid) const { RowCtx rc = row(m); valid = rc.valid; return rc.base; }
+  struct RowIt { int m, b, oy, ox; };
+  __device__ __forceinline__ RowIt iter(int m) const {
+    const int opix = OH * OW;
+    const int b = m / opix, q = m - b * opix;
+    const int oy = q / OW;
+    return RowIt{m, b, oy, q - oy * OW};
+  }
+  __device__ __forceinline__ int64_t off(const RowIt& it, int& valid) const {
+    valid = it.m < M;
+    return (((int64_t)it.b * IH + it.oy * stride) * IW + it.ox * stride) * Cin;
+  }
+  __device__ __forceinline__ void next(RowIt& it) const {
+    ++it.m;
+    if (++it.ox == OW) { it.ox = 0; if (++it.oy == OH) { it.oy = 0; ++it.b; } }
+  }
   __device__ __forceinline__ int64_t col_off(int k, int& valid) const {
     valid = k < K;
     const int tap = k / Cin, c = k - tap * Cin;
@@ -451,12 +488,16 @@ __device__ __forceinline__ void tn_body(const YL& yl, const XL& xl, int M, int m
   float yv[16], xv[KT][16];
   float bsum = 0.f;
   auto gload = [&](int ms) {
+    typename YL::RowIt yit = yl.iter(ms + wave * 16);
+    typename XL::RowIt xit = xl.iter(ms + wave * 16);
 #pragma unroll
     for (int j = 0; j < 16; ++j) {
       const int m = ms + wave * 16 + j;
       int vy, vx;
-      const int64_t yro = yl.row_off(m, vy);
-      const int64_t xro = xl.row_off(m, vx);
+      const int64_t yro = yl.off(yit, vy);
+      const int64_t xro = xl.off(xit, vx);
+      yl.next(yit);
+      xl.next(xit);
       const bool in = m < me;
       const bool oky = in && vy && yok;
       const float ty = yl.get(oky ? yro + yco : 0);  // unconditional load, select afterwards (see keep8)
