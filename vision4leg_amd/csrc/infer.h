@@ -391,18 +391,28 @@ template <typename T> struct InfLayLds {
 __device__ __forceinline__ void ln_rows(const float* z, int ldz, float* out, int ldo, const float* __restrict__ g,
                                         const float* __restrict__ be, int wave, int lane, int nrows, float* s_xh,
                                         float* s_rs, float* s_out) {
-  for (int r = wave; r < INF_ROWS; r += 4) {
-    const float v = z[r * ldz + lane];
-    const float mean = wave_sum(v) * (1.f / TD);
-    const float c = v - mean;
-    const float var = wave_sum(c * c) * (1.f / TD);
-    const float rs = 1.f / sqrtf(var + 1e-5f);
-    const float xh = c * rs;
-    const float o = fmaf(xh, g[lane], be[lane]);
-    if (out != nullptr) out[r * ldo + lane] = o;
-    if (r < nrows) {
-      if (s_xh != nullptr) { s_xh[r * TD + lane] = xh; if (lane == 0) s_rs[r] = rs; }
-      if (s_out != nullptr) s_out[r * TD + lane] = o;
+  const float gg = g[lane], bb = be[lane];
+  // wave w owns rows w, w+4, ...: five independent rows are kept in flight (their reduce chains interleave)
+  constexpr int U = INF_ROWS / 16;
+  for (int r0 = wave; r0 < INF_ROWS; r0 += 4 * U) {
+    float v[U], mean[U], c[U], var[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) v[u] = z[(r0 + 4 * u) * ldz + lane];
+#pragma unroll
+    for (int u = 0; u < U; ++u) mean[u] = wave_sum(v[u]) * (1.f / TD);
+#pragma unroll
+    for (int u = 0; u < U; ++u) { c[u] = v[u] - mean[u]; var[u] = wave_sum(c[u] * c[u]) * (1.f / TD); }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int r = r0 + 4 * u;
+      const float rs = 1.f / sqrtf(var[u] + 1e-5f);
+      const float xh = c[u] * rs;
+      const float o = fmaf(xh, gg, bb);
+      if (out != nullptr) out[r * ldo + lane] = o;
+      if (r < nrows) {
+        if (s_xh != nullptr) { s_xh[r * TD + lane] = xh; if (lane == 0) s_rs[r] = rs; }
+        if (s_out != nullptr) s_out[r * TD + lane] = o;
+      }
     }
   }
 }
@@ -576,16 +586,13 @@ template <typename T> struct InfHeadLds {
   static constexpr int PAD = InfLd<T>::PAD;
   static constexpr int LDP = 128 + 4, LDH = 256 + PAD;
   static constexpr int ROWS = 32;  // rows per pass
-  static constexpr size_t bytes = (size_t)ROWS * LDP * 4 + (size_t)2 * ROWS * LDH * sizeof(T) + (size_t)2 * 64 * 16 * 4;
+  static constexpr size_t bytes = (size_t)ROWS * LDP * 4 + (size_t)2 * ROWS * LDH * sizeof(T);
 };
 
 template <typename T>
-__global__ __launch_bounds__(256) void infer_head_kernel(ActCtl* ctl, InfHead hp, InfHead hv, const float* __restrict__ logstd,
-                                                         const float* __restrict__ eps, int E, int A,
-                                                         float* __restrict__ acts_roll, float* __restrict__ values_roll,
-                                                         float* __restrict__ action, float* __restrict__ mean,
-                                                         float* __restrict__ stdv, float* __restrict__ ent,
-                                                         float* __restrict__ value) {
+__global__ __launch_bounds__(256) void infer_head_kernel(InfHead hp, InfHead hv, int E, int A, float* __restrict__ outp,
+                                                         float* __restrict__ outv /* each [E][OUT_LD], zero padded */) {
+  // blockIdx.x = net (0: policy -> action means, 1: value net). Sampling / filing is act_finish_kernel's job.
   typedef InfHeadLds<T> LY;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -594,85 +601,62 @@ __global__ __launch_bounds__(256) void infer_head_kernel(ActCtl* ctl, InfHead hp
   float* pooled = reinterpret_cast<float*>(smem);
   T* h1 = reinterpret_cast<T*>(smem + (size_t)MR * LY::LDP * 4);
   T* h2 = h1 + MR * LY::LDH;
-  float* outs = reinterpret_cast<float*>(h2 + MR * LY::LDH);  // [2][64][16]
   const int nt4[4] = {wave * 4, wave * 4 + 1, wave * 4 + 2, wave * 4 + 3};
-  for (int net = 0; net < 2; ++net) {
-    const InfHead& h = net == 0 ? hp : hv;
-    for (int r0 = 0; r0 < E; r0 += MR) {
-      for (int idx = tid; idx < MR * 128; idx += 256) {  // [state token | mean of the 16 depth tokens]
-        const int r = idx >> 7, c = idx & 127;
-        float v = 0.f;
-        if (r0 + r < E) {
-          const float* xb = h.x + (int64_t)(r0 + r) * NTOK * TD;
-          if (c < TD) v = xb[c];
-          else {
-            float s = 0.f;
+  const int net = blockIdx.x;
+  const InfHead& h = net == 0 ? hp : hv;
+  float* outs = net == 0 ? outp : outv;
+  const int nout = net == 0 ? A : 1;
+  for (int r0 = 0; r0 < E; r0 += MR) {
+    for (int idx = tid; idx < MR * 128; idx += 256) {  // [state token | mean of the 16 depth tokens]
+      const int r = idx >> 7, c = idx & 127;
+      float v = 0.f;
+      if (r0 + r < E) {
+        const float* xb = h.x + (int64_t)(r0 + r) * NTOK * TD;
+        if (c < TD) v = xb[c];
+        else {
+          float s = 0.f;
 #pragma unroll
-            for (int i = 1; i < NTOK; ++i) s += xb[i * TD + (c - TD)];
-            v = s * (1.f / 16.f);
-          }
-        }
-        pooled[r * LY::LDP + c] = v;
-      }
-      __syncthreads();
-      f32x4 acc[2][4];
-      auto store_h = [&](T* dst, const float* bias) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const int n4 = nt4[j] * 16 + qr;
-          const float4 bb = *reinterpret_cast<const float4*>(bias + n4);
-#pragma unroll
-          for (int mt = 0; mt < 2; ++mt)
-            st4(dst + (mt * 16 + fr) * LY::LDH + n4, fmaxf(acc[mt][j][0] + bb.x, 0.f), fmaxf(acc[mt][j][1] + bb.y, 0.f),
-                fmaxf(acc[mt][j][2] + bb.z, 0.f), fmaxf(acc[mt][j][3] + bb.w, 0.f));
-        }
-      };
-      zero_acc(acc);
-      block_gemm<T, 2, 4, 4>(acc, pooled, LY::LDP, (const T*)h.w0, 128, nt4, lane);
-      store_h(h1, h.b0);
-      __syncthreads();
-      zero_acc(acc);
-      block_gemm<T, 2, 4, 8>(acc, h1, LY::LDH, (const T*)h.w1, 256, nt4, lane);
-      store_h(h2, h.b1);
-      __syncthreads();
-      if (wave < 2) {  // last layer: one 16-column tile; wave w takes row tile w of this pass
-        const int nt0[1] = {0};
-        f32x4 a1[1][1];
-        zero_acc(a1);
-        block_gemm<T, 1, 1, 8>(a1, h2 + wave * 16 * LY::LDH, LY::LDH, (const T*)h.w2, 256, nt0, lane);
-        const int nout = net == 0 ? A : 1;
-        const int row = r0 + wave * 16 + fr;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int n = qr + r;
-          if (row < 64) outs[(net * 64 + row) * 16 + n] = n < nout ? a1[0][0][r] + h.b2[n] : 0.f;
+          for (int i = 1; i < NTOK; ++i) s += xb[i * TD + (c - TD)];
+          v = s * (1.f / 16.f);
         }
       }
-      __syncthreads();
+      pooled[r * LY::LDP + c] = v;
     }
-  }
-  // GaussianContPolicyBase.explore + value read-out (see act_finish_kernel)
-  const long long t = ctl->t;
-  for (int i = tid; i < E; i += 256) {
-    float e = 0.f;
-    for (int a = 0; a < A; ++a) {
-      const float ls = fminf(fmaxf(logstd[a], LOG_SIG_MIN), LOG_SIG_MAX);
-      const float sg = expf(ls);
-      e += 0.5f + HALF_LOG_2PI + logf(sg);
-      const float mu = outs[i * 16 + a];
-      const float act = fmaf(sg, eps[(int64_t)i * A + a], mu);
-      action[(int64_t)i * A + a] = act;
-      mean[(int64_t)i * A + a] = mu;
-      stdv[(int64_t)i * A + a] = sg;
-      if (acts_roll != nullptr) acts_roll[(t * E + i) * A + a] = act;
+    __syncthreads();
+    f32x4 acc[2][4];
+    auto store_h = [&](T* dst, const float* bias) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int n4 = nt4[j] * 16 + qr;
+        const float4 bb = *reinterpret_cast<const float4*>(bias + n4);
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+          st4(dst + (mt * 16 + fr) * LY::LDH + n4, fmaxf(acc[mt][j][0] + bb.x, 0.f), fmaxf(acc[mt][j][1] + bb.y, 0.f),
+              fmaxf(acc[mt][j][2] + bb.z, 0.f), fmaxf(acc[mt][j][3] + bb.w, 0.f));
+      }
+    };
+    zero_acc(acc);
+    block_gemm<T, 2, 4, 4>(acc, pooled, LY::LDP, (const T*)h.w0, 128, nt4, lane);
+    store_h(h1, h.b0);
+    __syncthreads();
+    zero_acc(acc);
+    block_gemm<T, 2, 4, 8>(acc, h1, LY::LDH, (const T*)h.w1, 256, nt4, lane);
+    store_h(h2, h.b1);
+    __syncthreads();
+    if (wave < 2) {  // last layer: one 16-column tile; wave w takes row tile w of this pass
+      const int nt0[1] = {0};
+      f32x4 a1[1][1];
+      zero_acc(a1);
+      block_gemm<T, 1, 1, 8>(a1, h2 + wave * 16 * LY::LDH, LY::LDH, (const T*)h.w2, 256, nt0, lane);
+      const int row = r0 + wave * 16 + fr;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int n = qr + r;
+        if (row < E) outs[(int64_t)row * OUT_LD + n] = n < nout ? a1[0][0][r] + h.b2[n] : 0.f;
+      }
     }
-    ent[i] = e;
-    const float v = outs[(64 + i) * 16];
-    value[i] = v;
-    if (values_roll != nullptr) values_roll[t * E + i] = v;
+    __syncthreads();
   }
-  __syncthreads();
-  if (tid == 0) ctl->t = t + 1;
 }
 
 }  // namespace v4l

@@ -109,7 +109,9 @@ static inline TnPlan tn_plan(int M, int N, int Kx, bool bf16) {
   p.KT = (Kx >= 256 && bf16 && M >= 4096) ? 4 : (Kx >= 128 ? 2 : 1);
   p.gy = cdiv(N, p.BN);
   p.gx = cdiv(Kx, 64 * p.KT);
-  int splits = std::max(1, 256 / (p.gx * p.gy));
+  // these kernels are latency-bound chains (rowidx -> operand rows -> LDS -> MFMA per stage): many short blocks keep
+  // more independent chains in flight per CU than few long ones
+  int splits = std::max(1, 1024 / (p.gx * p.gy));
   splits = std::min(splits, std::max(1, M / 256));
   p.mpb = round_up(cdiv(M, splits), 64);
   p.splits = cdiv(M, p.mpb);
@@ -1039,9 +1041,15 @@ static int run_actor_fused(v4l_actor* a, const float* obs, const float* eps, flo
   head(hp, pf, pk, ws_pf + Lp.x[nl]);
   head(hv, vf, vk, ws_vf + Lv.x[nl]);
   g_op = "head";
-  V4L_KLAUNCH("infer_head", 2.0 * 2 * E * 99840.0, s, infer_head_kernel<T>, dim3(1), dim3(256), InfHeadLds<T>::bytes, s,
-              a->ctl, hp, hv, (const float*)pf->p[pf->logstd], eps, E, pf->cfg.out_dim, acts_roll, values_roll, action,
-              mean, stdv, ent, value);
+  float* outp = ws_pf + Lp.out;
+  float* outv = ws_vf + Lv.out;
+  V4L_KLAUNCH("infer_head", 2.0 * 2 * E * 99840.0, s, infer_head_kernel<T>, dim3(2), dim3(256), InfHeadLds<T>::bytes, s, hp, hv,
+              E, pf->cfg.out_dim, outp, outv);
+  V4L_LAUNCH_CHECK();
+  g_op = "sample";
+  V4L_KLAUNCH("act_finish", 0, s, act_finish_kernel, dim3(1), dim3(256), 0, s, a->ctl, (const float*)outp,
+              (const float*)pf->p[pf->logstd], (const float*)outv, eps, E, pf->cfg.out_dim, acts_roll, values_roll, action, mean,
+              stdv, ent, value);
   V4L_LAUNCH_CHECK();
   return 0;
 }
