@@ -41,8 +41,10 @@ WORKLOADS = {
     "loco64": dict(kind="loco", S=93, A=6, E=64, T=256, B=1024, enc=[256, 256], head=[256, 256], layers=2, ff=256,
                    name="ppo_locotransformer challenge/mountain shard: E=64 envs x T=256 per GPU, B=1024"),
 }
-# algorithmic MFLOP per env-step incl. rollout inference
+# algorithmic MFLOP per env-step incl. rollout inference, and F_pf: the forward pass of the frozen
+# target policy that each of the 3 sample-visits skips when log pi_old is recorded at action time (§8d's declared saving)
 MFLOP_PER_ENV_STEP = {"loco": 258.9, "loco64": 258.9, "cnn": 191.4, "mlp": 10.2}
+MFLOP_TARGET_FWD = {"loco": 11.258, "loco64": 11.258, "cnn": 8.325, "mlp": 0.444}
 OPT_EPOCHS = 3
 PEAK = {"bf16": 2500.0, "f32": 157.3}  # dense TFLOP/s, MI355X_MICROARCH.md (bf16 MFMA / f32 MFMA)
 
@@ -96,12 +98,17 @@ class Epoch:
         self.state, self.image = net.alloc_rollout(T * E, dev)
         self.acts = torch.zeros(T * E, A, device=dev)
         self.values = torch.zeros(T * E, device=dev)
+        # log pi_old(a|s): recorded by the rollout step (the acting policy of an epoch is that epoch's target policy,
+        # ppo.py:34) so the update skips the target forward. V4L_STORED_LOGP=0: evaluate target_pf per minibatch.
+        self.logp = None
         self.stats = torch.zeros(OPT_EPOCHS * (T * E // wl["B"]), 24, device=dev)
         self.epoch = 0
         self.actor = None
         if os.environ.get("V4L_ACTOR", "1") != "0":
             self.actor = policies.RolloutActor(self.pf, self.vf, E, graph=os.environ.get("V4L_ACTOR_GRAPH", "0") != "0")
-            self.actor.attach((self.state, self.image, self.acts, self.values))
+            if os.environ.get("V4L_STORED_LOGP", "1") != "0":
+                self.logp = torch.zeros(T * E, device=dev)
+            self.actor.attach((self.state, self.image, self.acts, self.values, self.logp))
         if wl.get("skip_rollout"):
             self.rollout()  # populate once so updates have data
 
@@ -145,7 +152,7 @@ class Epoch:
                 sel = perm[pos:pos + rows]
                 idx.append((sel[:, None] * E + np.arange(E)[None, :]).reshape(-1))
         rowidx = torch.from_numpy(np.stack(idx).astype(np.int32)).to(self.dev)
-        ro = HipTrainer.rollout(self.state, self.image, self.acts, a32.reshape(-1), r32.reshape(-1), self.values)
+        ro = HipTrainer.rollout(self.state, self.image, self.acts, a32.reshape(-1), r32.reshape(-1), self.values, self.logp)
         ag.run_updates(ro, rowidx, self.stats)
         self.epoch += 1
 
@@ -314,10 +321,13 @@ def main():
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": a.compute, "data": "synthetic",
         "config": {"workload": wl["name"], "net": wl["kind"], "envs_per_gpu": wl["E"], "horizon": wl["T"],
                    "minibatch": wl["B"], "opt_epochs": OPT_EPOCHS, "parallelism": "dp%d" % world,
-                   "includes_rollout_inference": not a.no_rollout},
+                   "includes_rollout_inference": not a.no_rollout,
+                   "logp_old": "recorded at action time (target_pf forward skipped; SURVEY 8d declared saving)"
+                               if ep.logp is not None else "target_pf evaluated per minibatch (ppo.py:55-57)"},
         "update_only_env_steps_per_s": round(frames * a.steps / max(dt - t_roll, 1e-9), 1),
         "rollout_inference_ms_per_step": round(1e3 * t_roll / a.steps, 3),
-        "algorithmic_tflops": round(value * MFLOP_PER_ENV_STEP[a.workload] * 1e-6, 3),
+        "algorithmic_tflops": round(value * (MFLOP_PER_ENV_STEP[a.workload] - (OPT_EPOCHS * MFLOP_TARGET_FWD[a.workload]
+                                                                               if ep.logp is not None else 0.0)) * 1e-6, 3),
     }
     if rank == 0:
         res["roofline"] = roofline(ep, a.compute, a.breakdown)

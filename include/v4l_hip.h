@@ -131,8 +131,8 @@ int64_t v4l_actor_ctl_bytes(const v4l_actor* a);
 int v4l_actor_bind(v4l_actor* a, float* ws_dev, void* ctl_dev, void* stream);
 int v4l_actor_seek(v4l_actor* a, int64_t t, void* stream);
 int v4l_actor_step(v4l_actor* a, const float* obs_dev, const float* eps_dev, float* state_roll_dev, void* image_roll_dev,
-                   float* acts_roll_dev, float* values_roll_dev, float* action_dev, float* mean_dev, float* std_dev,
-                   float* ent_dev, float* value_dev, int shared_encoder, int use_graph, void* stream);
+                   float* acts_roll_dev, float* values_roll_dev, float* logp_roll_dev, float* action_dev, float* mean_dev,
+                   float* std_dev, float* ent_dev, float* value_dev, int shared_encoder, int use_graph, void* stream);
 
 /* ---- PPO minibatch update: replaces PPO.update / update_critic / update_actor (ppo.py:42-153), the two
  * clip_grad_norm_(…, 0.5) calls and the two Adam steps (a2c.py:30-40). pf and vf may share encoder parameters
@@ -154,6 +154,10 @@ typedef struct v4l_rollout {
   const float* advs_dev;   /* [slots]       */
   const float* rets_dev;   /* [slots]  estimate_returns */
   const float* values_dev; /* [slots]  old values (only for clipped_value_loss) */
+  const float* logp_old_dev; /* [slots] or NULL. log pi_old(a|s) recorded when the action was taken (v4l_actor_step).
+                              * NULL: the frozen target policy is evaluated on every minibatch, as ppo.py:55-57 does.
+                              * Non-NULL: that forward pass is skipped — same numbers (the acting policy of an epoch is
+                              * the epoch's target policy, ppo.py:34), one third less forward work per update. */
 } v4l_rollout;
 
 int v4l_trainer_create(v4l_net* pf, v4l_net* vf, v4l_net* target_pf, v4l_trainer** out);

@@ -46,7 +46,7 @@ class PPOHyper(C.Structure):
 class Rollout(C.Structure):
   _fields_ = [
     ("state_dev", C.c_void_p), ("image_dev", C.c_void_p), ("acts_dev", C.c_void_p),
-    ("advs_dev", C.c_void_p), ("rets_dev", C.c_void_p), ("values_dev", C.c_void_p),
+    ("advs_dev", C.c_void_p), ("rets_dev", C.c_void_p), ("values_dev", C.c_void_p), ("logp_old_dev", C.c_void_p),
   ]
 
 
@@ -98,7 +98,7 @@ _SIGS = {
   "v4l_actor_ctl_bytes": (C.c_int64, [_P]),
   "v4l_actor_bind": (C.c_int, [_P, _P, _P, _P]),
   "v4l_actor_seek": (C.c_int, [_P, C.c_int64, _P]),
-  "v4l_actor_step": (C.c_int, [_P] + [_P] * 11 + [C.c_int, C.c_int, _P]),
+  "v4l_actor_step": (C.c_int, [_P] + [_P] * 12 + [C.c_int, C.c_int, _P]),
   "v4l_trainer_create": (C.c_int, [_P, _P, _P, C.POINTER(_P)]),
   "v4l_trainer_destroy": (None, [_P]),
   "v4l_trainer_ws_floats": (C.c_int64, [_P, C.c_int]),

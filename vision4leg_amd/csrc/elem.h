@@ -259,12 +259,12 @@ __global__ __launch_bounds__(256) void act_finish_kernel(ActCtl* c, const float*
                                                          const float* __restrict__ logstd, const float* __restrict__ valuep,
                                                          const float* __restrict__ eps, int E, int A,
                                                          float* __restrict__ acts_roll, float* __restrict__ values_roll,
-                                                         float* __restrict__ action, float* __restrict__ mean,
-                                                         float* __restrict__ stdv, float* __restrict__ ent,
-                                                         float* __restrict__ value) {
+                                                         float* __restrict__ logp_roll, float* __restrict__ action,
+                                                         float* __restrict__ mean, float* __restrict__ stdv,
+                                                         float* __restrict__ ent, float* __restrict__ value) {
   const long long t = c->t;
   for (int i = threadIdx.x; i < E; i += 256) {
-    float e = 0.f;
+    float e = 0.f, lp = 0.f;
     for (int a = 0; a < A; ++a) {
       const float ls = fminf(fmaxf(logstd[a], LOG_SIG_MIN), LOG_SIG_MAX);
       const float sg = expf(ls);
@@ -275,11 +275,16 @@ __global__ __launch_bounds__(256) void act_finish_kernel(ActCtl* c, const float*
       mean[(int64_t)i * A + a] = mu;
       stdv[(int64_t)i * A + a] = sg;
       if (acts_roll != nullptr) acts_roll[(t * E + i) * A + a] = act;
+      // log pi(a|s) of the acting policy, with the expression actor_loss_kernel uses for the frozen target policy:
+      // the policy that acts during an epoch IS that epoch's target policy (ppo.py:34 copies it before the updates)
+      const float d = act - mu;
+      lp += -(d * d) / (2.f * sg * sg) - logf(sg) - HALF_LOG_2PI;
     }
     ent[i] = e;
     const float v = valuep[(int64_t)i * OUT_LD];
     value[i] = v;
     if (values_roll != nullptr) values_roll[t * E + i] = v;
+    if (logp_roll != nullptr) logp_roll[t * E + i] = lp;
   }
   __syncthreads();
   if (threadIdx.x == 0) c->t = t + 1;
@@ -397,6 +402,7 @@ __global__ __launch_bounds__(256) void critic_loss_kernel(const float* __restric
 // inv_n is 1/(global batch) so that data-parallel ranks sum to the big-batch gradient.
 __global__ __launch_bounds__(256) void actor_loss_kernel(const float* __restrict__ mean, const float* __restrict__ logstd,
                                                          const float* __restrict__ tmean, const float* __restrict__ tlogstd,
+                                                         const float* __restrict__ logp_old,
                                                          const float* __restrict__ acts, const float* __restrict__ adv,
                                                          const int* __restrict__ rowidx, int n, int A, float inv_n,
                                                          float clip, float ent_coef, float* __restrict__ dmean,
@@ -409,7 +415,7 @@ __global__ __launch_bounds__(256) void actor_loss_kernel(const float* __restrict
     if (a < A) {
       ls[a] = fminf(fmaxf(logstd[a], LOG_SIG_MIN), LOG_SIG_MAX);
       sg[a] = expf(ls[a]); lsg[a] = logf(sg[a]);
-      tls[a] = fminf(fmaxf(tlogstd[a], LOG_SIG_MIN), LOG_SIG_MAX);
+      tls[a] = tlogstd != nullptr ? fminf(fmaxf(tlogstd[a], LOG_SIG_MIN), LOG_SIG_MAX) : 0.f;
       tsg[a] = expf(tls[a]); tlsg[a] = logf(tsg[a]);
       ent += 0.5f + HALF_LOG_2PI + lsg[a];
     }
@@ -427,9 +433,12 @@ __global__ __launch_bounds__(256) void actor_loss_kernel(const float* __restrict
       lp += -(d * d) / (2.f * var) - lsg[a] - HALF_LOG_2PI;
       z2[a] = d * d / var;
       dm[a] = d / var;
-      const float dt = x - tmean[(int64_t)i * OUT_LD + a];
-      lpo += -(dt * dt) / (2.f * tsg[a] * tsg[a]) - tlsg[a] - HALF_LOG_2PI;
+      if (logp_old == nullptr) {
+        const float dt = x - tmean[(int64_t)i * OUT_LD + a];
+        lpo += -(dt * dt) / (2.f * tsg[a] * tsg[a]) - tlsg[a] - HALF_LOG_2PI;
+      }
     }
+    if (logp_old != nullptr) lpo = logp_old[slot];  // stored when the action was taken (== the target policy's)
     const float ratio = expf(lp - lpo);
     const float an = (adv[slot] - amean) / (astd + 1e-5f);
     const float pre = ratio * an;

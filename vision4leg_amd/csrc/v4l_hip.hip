@@ -984,8 +984,8 @@ static bool actor_fusable(const v4l_actor* a) {
 
 template <typename T>
 static int run_actor_fused(v4l_actor* a, const float* obs, const float* eps, float* state_roll, void* image_roll,
-                           float* acts_roll, float* values_roll, float* action, float* mean, float* stdv, float* ent,
-                           float* value, hipStream_t s) {
+                           float* acts_roll, float* values_roll, float* logp_roll, float* action, float* mean, float* stdv,
+                           float* ent, float* value, hipStream_t s) {
   v4l_net *pf = a->pf, *vf = a->vf;
   const int E = a->E;
   static bool attr_done = false;
@@ -1048,8 +1048,8 @@ static int run_actor_fused(v4l_actor* a, const float* obs, const float* eps, flo
   V4L_LAUNCH_CHECK();
   g_op = "sample";
   V4L_KLAUNCH("act_finish", 0, s, act_finish_kernel, dim3(1), dim3(256), 0, s, a->ctl, (const float*)outp,
-              (const float*)pf->p[pf->logstd], (const float*)outv, eps, E, pf->cfg.out_dim, acts_roll, values_roll, action, mean,
-              stdv, ent, value);
+              (const float*)pf->p[pf->logstd], (const float*)outv, eps, E, pf->cfg.out_dim, acts_roll, values_roll, logp_roll, action,
+              mean, stdv, ent, value);
   V4L_LAUNCH_CHECK();
   return 0;
 }
@@ -1361,8 +1361,8 @@ int v4l_actor_seek(v4l_actor* a, int64_t t, void* stream) {
 }
 
 static int run_actor_step(v4l_actor* a, const float* obs, const float* eps, float* state_roll, void* image_roll,
-                          float* acts_roll, float* values_roll, float* action, float* mean, float* stdv, float* ent,
-                          float* value, int shared_encoder, void* stream) {
+                          float* acts_roll, float* values_roll, float* logp_roll, float* action, float* mean, float* stdv,
+                          float* ent, float* value, int shared_encoder, void* stream) {
   hipStream_t s = (hipStream_t)stream;
   v4l_net *pf = a->pf, *vf = a->vf;
   const int E = a->E;
@@ -1370,9 +1370,10 @@ static int run_actor_step(v4l_actor* a, const float* obs, const float* eps, floa
   V4L_REQUIRE(pf->bound && vf->bound, "v4l_actor_step: nets are not bound");
   if (shared_encoder && actor_fusable(a)) {
     if (pf->cfg.compute == V4L_BF16)
-      return run_actor_fused<__bf16>(a, obs, eps, state_roll, image_roll, acts_roll, values_roll, action, mean, stdv, ent,
-                                     value, s);
-    return run_actor_fused<float>(a, obs, eps, state_roll, image_roll, acts_roll, values_roll, action, mean, stdv, ent, value, s);
+      return run_actor_fused<__bf16>(a, obs, eps, state_roll, image_roll, acts_roll, values_roll, logp_roll, action, mean,
+                                     stdv, ent, value, s);
+    return run_actor_fused<float>(a, obs, eps, state_roll, image_roll, acts_roll, values_roll, logp_roll, action, mean, stdv, ent,
+                                  value, s);
   }
   PhaseScope ps("rollout");
   g_op = "ctl";
@@ -1419,27 +1420,27 @@ static int run_actor_step(v4l_actor* a, const float* obs, const float* eps, floa
   }
   g_op = "sample";
   V4L_KLAUNCH("act_finish", 0, s, act_finish_kernel, dim3(1), dim3(256), 0, s, a->ctl, ws_pf + pf->layout(E).out,
-              pf->p[pf->logstd], ws_vf + vf->layout(E).out, eps, E, pf->cfg.out_dim, acts_roll, values_roll, action, mean,
-              stdv, ent, value);
+              pf->p[pf->logstd], ws_vf + vf->layout(E).out, eps, E, pf->cfg.out_dim, acts_roll, values_roll, logp_roll, action,
+              mean, stdv, ent, value);
   V4L_LAUNCH_CHECK();
   return 0;
 }
 
 int v4l_actor_step(v4l_actor* a, const float* obs_dev, const float* eps_dev, float* state_roll_dev, void* image_roll_dev,
-                   float* acts_roll_dev, float* values_roll_dev, float* action_dev, float* mean_dev, float* std_dev,
-                   float* ent_dev, float* value_dev, int shared_encoder, int use_graph, void* stream) {
+                   float* acts_roll_dev, float* values_roll_dev, float* logp_roll_dev, float* action_dev, float* mean_dev,
+                   float* std_dev, float* ent_dev, float* value_dev, int shared_encoder, int use_graph, void* stream) {
   V4L_REQUIRE(a && a->bound, "v4l_actor_step: actor is not bound");
   V4L_REQUIRE(obs_dev && eps_dev && state_roll_dev && action_dev && mean_dev && std_dev && ent_dev && value_dev,
               "v4l_actor_step: null argument");
   V4L_REQUIRE(a->pf->cfg.kind == V4L_NET_MLP || image_roll_dev, "v4l_actor_step: image rollout array missing");
   hipStream_t s = (hipStream_t)stream;
   auto run = [&]() {
-    return run_actor_step(a, obs_dev, eps_dev, state_roll_dev, image_roll_dev, acts_roll_dev, values_roll_dev, action_dev,
-                          mean_dev, std_dev, ent_dev, value_dev, shared_encoder, stream);
+    return run_actor_step(a, obs_dev, eps_dev, state_roll_dev, image_roll_dev, acts_roll_dev, values_roll_dev, logp_roll_dev,
+                          action_dev, mean_dev, std_dev, ent_dev, value_dev, shared_encoder, stream);
   };
   if (!use_graph || g_prof || s == nullptr) return run();
   const void* key[12] = {obs_dev, eps_dev, state_roll_dev, image_roll_dev, acts_roll_dev, values_roll_dev, action_dev,
-                         mean_dev, std_dev, ent_dev, value_dev, (const void*)(intptr_t)(shared_encoder + 1)};
+                         mean_dev, logp_roll_dev, ent_dev, value_dev, (const void*)(intptr_t)(shared_encoder + 1)};
   if (memcmp(key, a->key, sizeof(key)) != 0) {
     if (a->gexec) { (void)hipGraphExecDestroy(a->gexec); a->gexec = nullptr; }
     a->warm = false;
@@ -1608,16 +1609,20 @@ int v4l_trainer_actor_grads(v4l_trainer* tr, const v4l_rollout* ro, int n, const
   const Layout Lp = pf->layout(n), Lt = tp->layout(n);
   float* ws_t = tr->ws + std::max(Lp.total, tr->vf->layout(n).total);
   // frozen target policy (packed once per epoch by v4l_trainer_sync_target) on the trainer's aux stream, next to the
-  // live policy's repack + forward: the two passes are independent until the loss
+  // live policy's repack + forward: the two passes are independent until the loss. Skipped entirely when the rollout
+  // carries log pi_old recorded at action time.
+  const bool stored = ro->logp_old_dev != nullptr;
   hipStream_t s_tgt = s;
-  const bool par_tgt = tr->aux != nullptr && !capturing(s);
+  const bool par_tgt = !stored && tr->aux != nullptr && !capturing(s);
   if (par_tgt) {
     V4L_HIP_CHECK(hipEventRecord(tr->ev_fork, s));
     V4L_HIP_CHECK(hipStreamWaitEvent(tr->aux, tr->ev_fork, 0));
     s_tgt = tr->aux;
   }
-  { PhaseScope ps("tpf.fwd");
-  if ((rc = v4l_net_forward(tp, ro->state_dev, ro->image_dev, rowidx, n, ws_t, 0, (void*)s_tgt))) return rc; }
+  if (!stored) {
+    PhaseScope ps("tpf.fwd");
+    if ((rc = v4l_net_forward(tp, ro->state_dev, ro->image_dev, rowidx, n, ws_t, 0, (void*)s_tgt))) return rc;
+  }
   if ((rc = v4l_net_pack(pf, stream))) return rc;  // the critic step moved the shared encoder
   { PhaseScope ps("pf.fwd");
   if ((rc = v4l_net_forward(pf, ro->state_dev, ro->image_dev, rowidx, n, tr->ws, 1, stream))) return rc; }
@@ -1627,8 +1632,9 @@ int v4l_trainer_actor_grads(v4l_trainer* tr, const v4l_rollout* ro, int n, const
   }
   const float inv_n = 1.f / ((float)n * (float)hp->world_size);
   g_op = "loss";
-  V4L_KLAUNCH("actor_loss", 0, s, actor_loss_kernel, dim3(1), dim3(256), 0, s, tr->ws + Lp.out, pf->p[pf->logstd], ws_t + Lt.out,
-                     tp->p[tp->logstd], ro->acts_dev, ro->advs_dev, rowidx, n, pf->cfg.out_dim, inv_n, hp->clip_para,
+  V4L_KLAUNCH("actor_loss", 0, s, actor_loss_kernel, dim3(1), dim3(256), 0, s, tr->ws + Lp.out, pf->p[pf->logstd],
+                     stored ? (const float*)nullptr : (const float*)(ws_t + Lt.out), stored ? (const float*)nullptr : (const float*)tp->p[tp->logstd],
+                     ro->logp_old_dev, ro->acts_dev, ro->advs_dev, rowidx, n, pf->cfg.out_dim, inv_n, hp->clip_para,
                      hp->entropy_coeff, tr->ws + Lp.dout, tr->g_pf + pf->params[pf->logstd].goff, st);
   V4L_LAUNCH_CHECK();
   PhaseScope ps("pf.bwd");

@@ -299,10 +299,13 @@ class HipTrainer:
                                   _stream()), "v4l_trainer_bind")
 
   @staticmethod
-  def rollout(state, image, acts, advs, rets, values=None):
+  def rollout(state, image, acts, advs, rets, values=None, logp_old=None):
+    """logp_old: [slots] log pi_old(a|s) recorded at action time (RolloutActor) -> the update skips the frozen
+    target policy's forward pass; None -> it is evaluated per minibatch like the reference does."""
     ro = Rollout(state.data_ptr(), image.data_ptr() if image is not None else None, acts.data_ptr(),
-                 advs.data_ptr(), rets.data_ptr(), values.data_ptr() if values is not None else None)
-    ro._keep = (state, image, acts, advs, rets, values)
+                 advs.data_ptr(), rets.data_ptr(), values.data_ptr() if values is not None else None,
+                 logp_old.data_ptr() if logp_old is not None else None)
+    ro._keep = (state, image, acts, advs, rets, values, logp_old)
     return ro
 
   def sync_target(self):
@@ -403,16 +406,18 @@ class HipActor:
       pass
 
   def attach(self, rollout):
-    """rollout = (state [slots][Sp], image [slots][C*H*W] | None, acts [slots][A] | None, values [slots] | None);
-    None: private E-slot scratch, nothing is filed and the cursor is rewound every step."""
+    """rollout = (state [slots][Sp], image [slots][C*H*W] | None, acts [slots][A] | None, values [slots] | None
+    [, logp [slots] | None]); None: private E-slot scratch, nothing is filed and the cursor is rewound every step."""
     self.own = rollout is None
     if rollout is None:
       st, im = self.pf.alloc_rollout(self.E, self.device)
-      rollout = (st, im, None, None)
+      rollout = (st, im, None, None, None)
+    if len(rollout) == 4:
+      rollout = tuple(rollout) + (None,)
     self.rollout = rollout
-    st, im, acts, vals = rollout
+    st, im, acts, vals, logp = rollout
     self._obs_ptr = self.obs.data_ptr()
-    self._args = (_ptr(self.obs), _ptr(self.eps), _ptr(st), _ptr(im), _ptr(acts), _ptr(vals), _ptr(self.action),
+    self._args = (_ptr(self.obs), _ptr(self.eps), _ptr(st), _ptr(im), _ptr(acts), _ptr(vals), _ptr(logp), _ptr(self.action),
                   _ptr(self.mean), _ptr(self.std), _ptr(self.ent), _ptr(self.value), int(self.shared_encoder),
                   int(self.graph))
     self._out = {"action": self.action, "mean": self.mean, "std": self.std, "ent": self.ent, "value": self.value}
