@@ -255,6 +255,16 @@ def roofline(ep, compute, breakdown_path):
                 f.write("%-70s %6d %12.1f %9.2f %9.2f %6.2f%%\n"
                         % (label, calls, us, us / calls, fl / us * 1e-6 if us > 0 else 0.0, 100 * us / total_us))
             f.write("# total kernel time %.1f us\n" % total_us)
+            if ep.actor is not None:  # the rollout side, profiled the same way
+                L.v4l_prof_enable(1)
+                ep.rollout()
+                torch.cuda.synchronize()
+                L.v4l_prof_collect(buf, len(buf))
+                L.v4l_prof_enable(0)
+                f.write("# one profiled rollout (%d env steps x %d envs)\n" % (ep.wl["T"], ep.wl["E"]))
+                for line in buf.value.decode().splitlines():
+                    label, calls, us, fl = line.split("\t")
+                    f.write("%-70s %6d %12.1f %9.2f\n" % (label, int(calls), float(us), float(us) / int(calls)))
     gemm = [r for r in rows if r[3] > 0]
     label, calls, us, fl = gemm[0] if gemm else rows[0]
     ach = fl / us * 1e-6  # TFLOP/s

@@ -6,6 +6,7 @@
 
 #include "net.h"
 #include "infer.h"
+#include "bwd.h"
 
 namespace v4l {
 
@@ -621,7 +622,8 @@ int64_t v4l_net::slab_floats(int n) const {
   for (const TLayer& t : layers) {
     add(n * NTOK, t.inproj.N, t.inproj.K); add(n * NTOK, t.outproj.N, t.outproj.K);
     add(n * NTOK, t.ff1.N, t.ff1.K); add(n * NTOK, t.ff2.N, t.ff2.K);
-    tot += 2 * 2 * 128 * TD;  // LayerNorm dgamma/dbeta partials (<= 128 blocks each)
+    // LayerNorm dgamma/dbeta partials: one [64] row per block (<= 128 ln_bwd blocks, or n/4 fused-layer blocks)
+    tot += 2 * 2 * (int64_t)std::max(128, cdiv(n, INF_SPW)) * TD;
   }
   for (const Lin& L : head) add(n, L.N, L.K);
   return tot;
@@ -910,7 +912,51 @@ int v4l_net::backward_t(const float* state, const T* image, const int* rowidx, i
   V4L_KLAUNCH("pool_bwd", 0, s, pool_bwd_kernel, dim3(n), dim3(64), 0, s, ws + L.dpool, n, ws + L.dxl[c.n_layers]);
   V4L_LAUNCH_CHECK();
   const int lnb = std::min(cdiv(R, 16), 128);
-  for (int l = c.n_layers - 1; l >= 0; --l) {
+  const bool fused_bwd = c.ff_dim == 256 && getenv("V4L_NO_FUSED_LAYER_BWD") == nullptr;
+  for (int l = c.n_layers - 1; l >= 0 && fused_bwd; --l) {
+    // one launch per TransformerEncoderLayer (csrc/bwd.h): every data-grad of the layer with the intermediates in LDS;
+    // the four weight-grads are deferred to the grouped launch as before
+    const TLayer& t = layers[l];
+    const LayerWs& w = L.lw[l];
+    const LayerBw& b = L.lb[l];
+    static bool attr_done = false;
+    if (!attr_done) {
+      V4L_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&bwd_layer_kernel<T>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)BwdLayLds<T>::bytes));
+      attr_done = true;
+    }
+    const int nblk = cdiv(n, INF_SPW);
+    float* part = cx.slab + cx.slab_used;  // gp2 | bp2 | gp1 | bp1, [nblk][64] each
+    cx.slab_used += 4 * (int64_t)nblk * TD;
+    V4L_REQUIRE(cx.slab_used <= slab_cap, "internal: weight-grad slab arena overflow");
+    const T* base = (const T*)packed;
+    BwdLayer d;
+    d.w2t = base + t.ff2.pkt; d.w1t = base + t.ff1.pkt; d.wot = base + t.outproj.pkt; d.wint = base + t.inproj.pkt;
+    d.g1 = p[t.ln1.g]; d.g2 = p[t.ln2.g];
+    d.dy = ws + L.dxl[l + 1];
+    d.s_qkv = ws + w.qkv; d.s_P = ws + w.P; d.s_xh1 = ws + w.xh1; d.s_rs1 = ws + w.rs1; d.s_f = ws + w.f;
+    d.s_xh2 = ws + w.xh2; d.s_rs2 = ws + w.rs2;
+    d.o_dz2 = ws + b.dz2; d.o_df = ws + b.df; d.o_dz1 = ws + b.dz1; d.o_dqkv = ws + b.dqkv; d.o_dx = ws + L.dxl[l];
+    d.gp2 = part; d.bp2 = part + (int64_t)nblk * TD; d.gp1 = part + 2 * (int64_t)nblk * TD; d.bp1 = part + 3 * (int64_t)nblk * TD;
+    g_op = "layer";
+    V4L_KLAUNCH("fused_layer_bwd", 4.0 * n * 872576.0, s, bwd_layer_kernel<T>, dim3(nblk), dim3(256), BwdLayLds<T>::bytes, s, d,
+                n);
+    V4L_LAUNCH_CHECK();
+    const int lnp[4] = {t.ln2.g, t.ln2.b, t.ln1.g, t.ln1.b};
+    for (int k = 0; k < 4; ++k) {
+      RedDesc r;
+      memset(&r, 0, sizeof(r));
+      r.slab = part + (int64_t)k * nblk * TD;
+      r.dW = grads + params[lnp[k]].goff;
+      r.nsplit = nblk; r.N = 1; r.K = TD; r.Npad = 1; r.Kpad = TD; r.Ktorch = TD;
+      red.push_back(r);
+    }
+    if ((rc = lin_wgrad<T>(cx, t.ff2, dense(ws + b.dz2, TD, R, TD), dense(ws + w.f, c.ff_dim, R, c.ff_dim), c.ff_dim))) return rc;
+    if ((rc = lin_wgrad<T>(cx, t.ff1, dense(ws + b.df, c.ff_dim, R, c.ff_dim), dense(ws + w.x1, TD, R, TD), TD))) return rc;
+    if ((rc = lin_wgrad<T>(cx, t.outproj, dense(ws + b.dz1, TD, R, TD), dense(ws + w.ctx, TD, R, TD), TD))) return rc;
+    if ((rc = lin_wgrad<T>(cx, t.inproj, dense(ws + b.dqkv, 3 * TD, R, 3 * TD), dense(ws + L.x[l], TD, R, TD), TD))) return rc;
+  }
+  for (int l = c.n_layers - 1; l >= 0 && !fused_bwd; --l) {
     const TLayer& t = layers[l];
     const LayerWs& w = L.lw[l];
     const LayerBw& b = L.lb[l];

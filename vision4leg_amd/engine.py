@@ -442,12 +442,16 @@ class HipActor:
   def _step(self, obs):
     self.pf.pack_if_needed(fast=True)
     self.vf.pack_if_needed(fast=True)
+    args = self._args
     if obs.data_ptr() != self._obs_ptr:
-      self.obs.copy_(obs.reshape(self.obs.shape), non_blocking=True)
+      if self.graph or obs.dtype != torch.float32 or not obs.is_contiguous() or obs.numel() != self.obs.numel():
+        self.obs.copy_(obs.reshape(self.obs.shape), non_blocking=True)  # a captured graph reads the fixed buffer
+      else:
+        args = (C.c_void_p(obs.data_ptr()),) + args[1:]  # eager launches read the caller's rows in place
     self.eps.normal_()  # torch's generator: the same standard-normal draws Normal(mean, std).sample() would use
     if self.own:
       self.seek(0)
-    check(self.L.v4l_actor_step(self.h, *self._args, _stream()), "v4l_actor_step")
+    check(self.L.v4l_actor_step(self.h, *args, _stream()), "v4l_actor_step")
 
 
 def gae(rewards, values, terminals, time_limits, last_value, gamma, tau, use_time_limit, want32=True, out=None):
