@@ -33,18 +33,6 @@ template <typename T> struct BwdLayLds {
   static constexpr size_t bytes = 2 * a_b + big_b + p_b + red_b;     // a | b | df / qkv->dqkv | P,dS | LN partials
 };
 
-__device__ __forceinline__ float dot64(const float* a, const float* b) {  // 16-byte aligned LDS rows
-  float s0 = 0.f, s1 = 0.f;
-#pragma unroll
-  for (int d = 0; d < TD; d += 8) {
-    const float4 x0 = *reinterpret_cast<const float4*>(a + d), y0 = *reinterpret_cast<const float4*>(b + d);
-    const float4 x1 = *reinterpret_cast<const float4*>(a + d + 4), y1 = *reinterpret_cast<const float4*>(b + d + 4);
-    s0 = fmaf(x0.x, y0.x, s0); s0 = fmaf(x0.y, y0.y, s0); s0 = fmaf(x0.z, y0.z, s0); s0 = fmaf(x0.w, y0.w, s0);
-    s1 = fmaf(x1.x, y1.x, s1); s1 = fmaf(x1.y, y1.y, s1); s1 = fmaf(x1.z, y1.z, s1); s1 = fmaf(x1.w, y1.w, s1);
-  }
-  return s0 + s1;
-}
-
 // LayerNorm backward, in place over the 80 LDS rows of `d` (rows >= nrows hold zeros and stay zero); the rows < nrows
 // also go to o_dz (global). Leaves the block's dgamma/dbeta partial in gpart/bpart[64]. Contains one __syncthreads.
 __device__ __forceinline__ void ln_bwd_rows(float* d, int ld, const float* __restrict__ xh, const float* __restrict__ rs,

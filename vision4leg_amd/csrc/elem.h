@@ -246,8 +246,8 @@ __global__ __launch_bounds__(64) void pool_bwd_kernel(const float* __restrict__ 
 
 // --------------------------------------------------------------------------------- rollout step (actor)
 // Device-side cursor of the rollout: env step t of the epoch owns rollout slots [t*E, (t+1)*E).
-struct ActCtl { long long t; long long pad; };
-__global__ void act_set_kernel(ActCtl* c, long long t) { c->t = t; }
+struct ActCtl { long long t; unsigned long long done; };  // done: blocks of the step's last kernel that have finished
+__global__ void act_set_kernel(ActCtl* c, long long t) { c->t = t; c->done = 0; }
 __global__ __launch_bounds__(256) void act_begin_kernel(const ActCtl* __restrict__ c, int E, int* __restrict__ rowidx) {
   const long long t = c->t;
   for (int i = threadIdx.x; i < E; i += 256) rowidx[i] = (int)(t * E + i);

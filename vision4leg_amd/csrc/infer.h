@@ -376,25 +376,65 @@ struct InfLayer {
 };
 struct InfLayerPair { InfLayer n[2]; };
 
-template <typename T> struct InfLayLds {
-  static constexpr int PAD = InfLd<T>::PAD;
-  static constexpr int LDX = 64 + 4, LDQ = 192 + 4, LDF = 256 + PAD;
-  static constexpr size_t xs_b = (size_t)INF_ROWS * LDX * 4;
-  static constexpr size_t qkv_b = (size_t)INF_ROWS * LDQ * 4;
-  static constexpr size_t f_b = (size_t)INF_ROWS * LDF * sizeof(T);
-  static constexpr size_t big_b = qkv_b > f_b ? qkv_b : f_b;
-  static constexpr size_t p_b = (size_t)4 * NTOK * ATT_PLD * 4;
-  static constexpr size_t bytes = xs_b + big_b + xs_b + p_b;  // xs | qkv/z/f | ctx/z2 | scores
+// Heads (pool + append fcs + last linear), run by the LAST layer's blocks on their own samples
+struct InfHead {
+  const void *w0, *w1, *w2;            // packed (T): [256][128] [256][256] [16][256]
+  const float *b0, *b1, *b2;
+  float* out;                          // [E][OUT_LD], columns >= nout zeroed
+  int nout;
+  float *s_pooled, *s_h0, *s_h1;       // training forward: [E][128], [E][256], [E][256] (post-ReLU); null for inference
+};
+struct InfHeadPair { InfHead n[2]; };
+
+// Rollout step epilogue (blockIdx.y 0 = policy: sample + file the action; 1 = value net: file the value); ctl == null:
+// no sampling (training forward). The last block to finish advances the device-side step cursor.
+struct InfFinish {
+  ActCtl* ctl;
+  const float *logstd, *eps;
+  int A;
+  float *acts_roll, *values_roll, *logp_roll, *action, *mean, *stdv, *ent, *value;
 };
 
-// LayerNorm of the 80 LDS rows; optionally (training) saves xhat / rstd / the output rows < nrows to global memory
+template <int SPW> struct InfRows {
+  static constexpr int ROWS = (SPW * NTOK + 15) / 16 * 16;  // 1 -> 32, 2 -> 48, 4 -> 80
+  static constexpr int MT = ROWS / 16;
+  static constexpr int U = ROWS == 80 ? 5 : 4;             // LayerNorm rows in flight per wave (ROWS/4 % U == 0)
+};
+
+template <typename T, int SPW> struct InfLayLds {
+  static constexpr int PAD = InfLd<T>::PAD;
+  static constexpr int ROWS = InfRows<SPW>::ROWS;
+  static constexpr int LDX = 64 + 4, LDQ = 192 + 4, LDF = 256 + PAD, LDP = 128 + 4;
+  static constexpr size_t xs_b = (size_t)ROWS * LDX * 4;
+  static constexpr size_t qkv_b = (size_t)ROWS * LDQ * 4;
+  static constexpr size_t f_b = (size_t)ROWS * LDF * sizeof(T);
+  static constexpr size_t head_b = (size_t)16 * LDP * 4 + (size_t)2 * 16 * LDF * sizeof(T) + 16 * 16 * 4;
+  static constexpr size_t big0_b = qkv_b > f_b ? qkv_b : f_b;
+  static constexpr size_t big_b = big0_b > head_b ? big0_b : head_b;
+  static constexpr size_t p_b = (size_t)SPW * NTOK * ATT_PLD * 4;
+  static constexpr size_t bytes = xs_b + big_b + xs_b + p_b;  // xs | qkv/z/f/head | ctx/z2 | scores
+};
+
+__device__ __forceinline__ float dot64(const float* a, const float* b) {  // 16-byte aligned LDS rows of 64 floats
+  float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+  for (int d = 0; d < TD; d += 8) {
+    const float4 x0 = *reinterpret_cast<const float4*>(a + d), y0 = *reinterpret_cast<const float4*>(b + d);
+    const float4 x1 = *reinterpret_cast<const float4*>(a + d + 4), y1 = *reinterpret_cast<const float4*>(b + d + 4);
+    s0 = fmaf(x0.x, y0.x, s0); s0 = fmaf(x0.y, y0.y, s0); s0 = fmaf(x0.z, y0.z, s0); s0 = fmaf(x0.w, y0.w, s0);
+    s1 = fmaf(x1.x, y1.x, s1); s1 = fmaf(x1.y, y1.y, s1); s1 = fmaf(x1.z, y1.z, s1); s1 = fmaf(x1.w, y1.w, s1);
+  }
+  return s0 + s1;
+}
+
+// LayerNorm of the ROWS LDS rows; optionally (training) saves xhat / rstd / the output rows < nrows to global memory
+template <int ROWS, int U>
 __device__ __forceinline__ void ln_rows(const float* z, int ldz, float* out, int ldo, const float* __restrict__ g,
                                         const float* __restrict__ be, int wave, int lane, int nrows, float* s_xh,
                                         float* s_rs, float* s_out) {
   const float gg = g[lane], bb = be[lane];
-  // wave w owns rows w, w+4, ...: five independent rows are kept in flight (their reduce chains interleave)
-  constexpr int U = INF_ROWS / 16;
-  for (int r0 = wave; r0 < INF_ROWS; r0 += 4 * U) {
+  // wave w owns rows w, w+4, ...: U independent rows are kept in flight (their reduce chains interleave)
+  for (int r0 = wave; r0 < ROWS; r0 += 4 * U) {
     float v[U], mean[U], c[U], var[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) v[u] = z[(r0 + 4 * u) * ldz + lane];
@@ -424,39 +464,47 @@ __device__ long long g_inf_stamps[32];
 #define INF_STAMP(i)
 #endif
 
-template <typename T>
-__global__ __launch_bounds__(256) void infer_layer_kernel(InfLayerPair pr, int E, int ff) {
-  typedef InfLayLds<T> LY;
+// One nn.TransformerEncoderLayer for SPW samples per block (blockIdx.y = net). HEAD: the block continues with the
+// pooled heads of its samples (nets.py:1015-1034) and, in a rollout step, with the sampling / filing epilogue.
+//   SPW = 4: training forward (68 of 80 MFMA rows used); SPW = 1: rollout steps (E blocks per net, shortest latency)
+template <typename T, int SPW, bool HEAD>
+__global__ __launch_bounds__(256) void infer_layer_kernel(InfLayerPair pr, InfHeadPair hd, InfFinish fin, int E, int ff) {
+  typedef InfLayLds<T, SPW> LY;
+  constexpr int ROWS = InfRows<SPW>::ROWS, MT = InfRows<SPW>::MT, U = InfRows<SPW>::U;
   INF_STAMP(0);
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const InfLayer& w = pr.n[blockIdx.y];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int fr = lane & 15, qr = (lane >> 4) * 4;
   float* xs = reinterpret_cast<float*>(smem);
-  float* big = reinterpret_cast<float*>(smem + LY::xs_b);            // qkv, later z (fp32), later f (T)
+  float* big = reinterpret_cast<float*>(smem + LY::xs_b);            // qkv, later z (fp32), later f (T), later heads
   float* cx = reinterpret_cast<float*>(smem + LY::xs_b + LY::big_b); // ctx, later z2
   float* sp = reinterpret_cast<float*>(smem + LY::xs_b + LY::big_b + LY::xs_b);
-  const int s0 = blockIdx.x * INF_SPW;
-  const int ns = min(INF_SPW, E - s0);
+  const int s0 = blockIdx.x * SPW;
+  const int ns = min(SPW, E - s0);
   const int nrows = ns * NTOK;
+  long long t_step = 0;
+  if constexpr (HEAD) { if (fin.ctl != nullptr) t_step = fin.ctl->t; }
   const float* xg = w.xin + (int64_t)s0 * NTOK * TD;
-  for (int idx = tid; idx < INF_ROWS * TD; idx += 256) {
-    const int r = idx >> 6, c = idx & 63;
-    xs[r * LY::LDX + c] = r < nrows ? xg[idx] : 0.f;
+  for (int i4 = tid; i4 < ROWS * (TD / 4); i4 += 256) {
+    const int r = i4 >> 4, c4 = (i4 & 15) * 4;
+    const bool ok = r < nrows;
+    const float4 v = *reinterpret_cast<const float4*>(xg + (ok ? r : 0) * TD + c4);
+    *reinterpret_cast<float4*>(xs + r * LY::LDX + c4) = ok ? v : float4{0.f, 0.f, 0.f, 0.f};
   }
   __syncthreads();
   INF_STAMP(1);
-  {  // in_proj: [80][64] x [192][64]^T -> qkv (fp32)
+  {  // in_proj: [ROWS][64] x [192][64]^T -> qkv (fp32)
     const int nt[3] = {wave, wave + 4, wave + 8};
-    f32x4 acc[INF_MT][3];
+    f32x4 acc[MT][3];
     zero_acc(acc);
-    block_gemm<T, INF_MT, 3, 2>(acc, xs, LY::LDX, (const T*)w.win, 64, nt, lane);
+    block_gemm<T, MT, 3, 2>(acc, xs, LY::LDX, (const T*)w.win, 64, nt, lane);
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
       const int n4 = nt[j] * 16 + qr;
       const float4 bb = *reinterpret_cast<const float4*>(w.bin + n4);
 #pragma unroll
-      for (int mt = 0; mt < INF_MT; ++mt)
+      for (int mt = 0; mt < MT; ++mt)
         st4(big + (mt * 16 + fr) * LY::LDQ + n4, acc[mt][j][0] + bb.x, acc[mt][j][1] + bb.y, acc[mt][j][2] + bb.z,
             acc[mt][j][3] + bb.w);
     }
@@ -470,58 +518,55 @@ __global__ __launch_bounds__(256) void infer_layer_kernel(InfLayerPair pr, int E
       *reinterpret_cast<float4*>(w.s_qkv + (row0 + r) * 192 + c4) = *reinterpret_cast<const float4*>(big + r * LY::LDQ + c4);
     }
   }
-  {  // attention of sample `wave` (17 tokens, one head, scale 1/8); inactive waves only take part in the barriers
-    const bool act = wave < ns;
-    const float* q = big + (wave * NTOK) * LY::LDQ;
-    float* p = sp + wave * NTOK * ATT_PLD;
-    if (act) {
-      for (int pr2 = lane; pr2 < NTOK * NTOK; pr2 += 64) {
-        const int i = pr2 / NTOK, j = pr2 - i * NTOK;
-        float s = 0.f;
-#pragma unroll 16
-        for (int d = 0; d < TD; ++d) s = fmaf(q[i * LY::LDQ + d], q[j * LY::LDQ + TD + d], s);
-        p[i * ATT_PLD + j] = s * 0.125f;
-      }
+  {  // attention (17 tokens, one head, scale 1/8), fp32 VALU, the whole block on all of its samples
+    for (int idx = tid; idx < ns * NTOK * NTOK; idx += 256) {
+      const int sm = idx / (NTOK * NTOK), pr2 = idx - sm * NTOK * NTOK;
+      const int i = pr2 / NTOK, j = pr2 - i * NTOK;
+      const float* q = big + (sm * NTOK) * LY::LDQ;
+      sp[(sm * NTOK + i) * ATT_PLD + j] = dot64(q + i * LY::LDQ, q + j * LY::LDQ + TD) * 0.125f;
     }
     __syncthreads();
-    if (act && lane < NTOK) {
+    if (tid < nrows) {  // one thread per score row
+      float* p = sp + tid * ATT_PLD;
       float mx = -INFINITY;
-      for (int j = 0; j < NTOK; ++j) mx = fmaxf(mx, p[lane * ATT_PLD + j]);
+#pragma unroll
+      for (int j = 0; j < NTOK; ++j) mx = fmaxf(mx, p[j]);
       float e[NTOK], sum = 0.f;
 #pragma unroll
-      for (int j = 0; j < NTOK; ++j) { e[j] = expf(p[lane * ATT_PLD + j] - mx); sum += e[j]; }
+      for (int j = 0; j < NTOK; ++j) { e[j] = expf(p[j] - mx); sum += e[j]; }
       const float inv = 1.f / sum;
 #pragma unroll
       for (int j = 0; j < NTOK; ++j) {
         const float pv = e[j] * inv;
-        p[lane * ATT_PLD + j] = pv;
-        if (w.s_P != nullptr) w.s_P[((int64_t)(s0 + wave) * NTOK + lane) * NTOK + j] = pv;
+        p[j] = pv;
+        if (w.s_P != nullptr) w.s_P[(row0 + tid) * NTOK + j] = pv;
       }
     }
     __syncthreads();
-    if (act) {
-      for (int i = 0; i < NTOK; ++i) {
-        float a = 0.f;
+    for (int r = wave; r < ROWS; r += 4) {  // ctx row r = P[r] V(sample of r); rows beyond the last sample: zeros
+      float a = 0.f;
+      if (r < nrows) {
+        const int sm = r / NTOK;
+        const float* v = big + (sm * NTOK) * LY::LDQ + 2 * TD + lane;
+        const float* p = sp + r * ATT_PLD;
 #pragma unroll
-        for (int j = 0; j < NTOK; ++j) a = fmaf(p[i * ATT_PLD + j], q[j * LY::LDQ + 2 * TD + lane], a);
-        cx[(wave * NTOK + i) * LY::LDX + lane] = a;
-        if (w.s_ctx != nullptr) w.s_ctx[(row0 + wave * NTOK + i) * TD + lane] = a;
+        for (int j = 0; j < NTOK; ++j) a = fmaf(p[j], v[j * LY::LDQ], a);
+        if (w.s_ctx != nullptr) w.s_ctx[(row0 + r) * TD + lane] = a;
       }
+      cx[r * LY::LDX + lane] = a;
     }
   }
-  for (int idx = tid; idx < (INF_ROWS - nrows) * TD; idx += 256)  // rows beyond the last sample: defined zeros
-    cx[(nrows + (idx >> 6)) * LY::LDX + (idx & 63)] = 0.f;
   __syncthreads();
   INF_STAMP(3);
   const int nt1[1] = {wave};
-  {  // out_proj + residual -> z (in `big`, fp32 [80][LDX])
-    f32x4 acc[INF_MT][1];
+  {  // out_proj + residual -> z (in `big`, fp32 [ROWS][LDX])
+    f32x4 acc[MT][1];
     zero_acc(acc);
-    block_gemm<T, INF_MT, 1, 2>(acc, cx, LY::LDX, (const T*)w.wo, 64, nt1, lane);
+    block_gemm<T, MT, 1, 2>(acc, cx, LY::LDX, (const T*)w.wo, 64, nt1, lane);
     const int n4 = wave * 16 + qr;
     const float4 bb = *reinterpret_cast<const float4*>(w.bo + n4);
 #pragma unroll
-    for (int mt = 0; mt < INF_MT; ++mt) {
+    for (int mt = 0; mt < MT; ++mt) {
       const int row = mt * 16 + fr;
       const float4 xr = *reinterpret_cast<const float4*>(xs + row * LY::LDX + n4);
       st4(big + row * LY::LDX + n4, xr.x + acc[mt][0][0] + bb.x, xr.y + acc[mt][0][1] + bb.y, xr.z + acc[mt][0][2] + bb.z,
@@ -530,22 +575,22 @@ __global__ __launch_bounds__(256) void infer_layer_kernel(InfLayerPair pr, int E
   }
   __syncthreads();
   INF_STAMP(4);
-  ln_rows(big, LY::LDX, xs, LY::LDX, w.g1, w.be1, wave, lane, nrows, w.s_xh1 ? w.s_xh1 + row0 * TD : nullptr,
-          w.s_rs1 ? w.s_rs1 + row0 : nullptr, w.s_x1 ? w.s_x1 + row0 * TD : nullptr);  // x1 -> xs
+  ln_rows<ROWS, U>(big, LY::LDX, xs, LY::LDX, w.g1, w.be1, wave, lane, nrows, w.s_xh1 ? w.s_xh1 + row0 * TD : nullptr,
+                   w.s_rs1 ? w.s_rs1 + row0 : nullptr, w.s_x1 ? w.s_x1 + row0 * TD : nullptr);  // x1 -> xs
   __syncthreads();
   INF_STAMP(5);
   T* f = reinterpret_cast<T*>(big);
   {  // linear1 + ReLU -> f (T) ; ff <= 256: wave w owns column tiles 4w..4w+3
     const int nt4[4] = {wave * 4, wave * 4 + 1, wave * 4 + 2, wave * 4 + 3};
-    f32x4 acc[INF_MT][4];
+    f32x4 acc[MT][4];
     zero_acc(acc);
-    block_gemm<T, INF_MT, 4, 2>(acc, xs, LY::LDX, (const T*)w.w1, 64, nt4, lane);
+    block_gemm<T, MT, 4, 2>(acc, xs, LY::LDX, (const T*)w.w1, 64, nt4, lane);
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int n4 = nt4[j] * 16 + qr;
       const float4 bb = *reinterpret_cast<const float4*>(w.b1 + n4);
 #pragma unroll
-      for (int mt = 0; mt < INF_MT; ++mt) {
+      for (int mt = 0; mt < MT; ++mt) {
         const float f0 = fmaxf(acc[mt][j][0] + bb.x, 0.f), f1 = fmaxf(acc[mt][j][1] + bb.y, 0.f);
         const float f2 = fmaxf(acc[mt][j][2] + bb.z, 0.f), f3 = fmaxf(acc[mt][j][3] + bb.w, 0.f);
         st4(f + (mt * 16 + fr) * LY::LDF + n4, f0, f1, f2, f3);
@@ -556,13 +601,13 @@ __global__ __launch_bounds__(256) void infer_layer_kernel(InfLayerPair pr, int E
   __syncthreads();
   INF_STAMP(6);
   {  // linear2 + residual -> z2 (in `cx`)
-    f32x4 acc[INF_MT][1];
+    f32x4 acc[MT][1];
     zero_acc(acc);
-    block_gemm<T, INF_MT, 1, 8>(acc, f, LY::LDF, (const T*)w.w2, 256, nt1, lane);
+    block_gemm<T, MT, 1, 8>(acc, f, LY::LDF, (const T*)w.w2, 256, nt1, lane);
     const int n4 = wave * 16 + qr;
     const float4 bb = *reinterpret_cast<const float4*>(w.b2 + n4);
 #pragma unroll
-    for (int mt = 0; mt < INF_MT; ++mt) {
+    for (int mt = 0; mt < MT; ++mt) {
       const int row = mt * 16 + fr;
       const float4 xr = *reinterpret_cast<const float4*>(xs + row * LY::LDX + n4);
       st4(cx + row * LY::LDX + n4, xr.x + acc[mt][0][0] + bb.x, xr.y + acc[mt][0][1] + bb.y, xr.z + acc[mt][0][2] + bb.z,
@@ -571,91 +616,110 @@ __global__ __launch_bounds__(256) void infer_layer_kernel(InfLayerPair pr, int E
   }
   __syncthreads();
   INF_STAMP(7);
-  ln_rows(cx, LY::LDX, nullptr, 0, w.g2, w.be2, wave, lane, nrows, w.s_xh2 ? w.s_xh2 + row0 * TD : nullptr,
-          w.s_rs2 ? w.s_rs2 + row0 : nullptr, w.xout + row0 * TD);
+  ln_rows<ROWS, U>(cx, LY::LDX, HEAD ? xs : nullptr, LY::LDX, w.g2, w.be2, wave, lane, nrows,
+                   w.s_xh2 ? w.s_xh2 + row0 * TD : nullptr, w.s_rs2 ? w.s_rs2 + row0 : nullptr, w.xout + row0 * TD);
   INF_STAMP(8);
-}
-
-// ------------------------------------------------------------------------------------------ heads + sampling
-struct InfHead {
-  const void *w0, *w1, *w2;            // packed (T): [256][128] [256][256] [16][256]
-  const float *b0, *b1, *b2;
-  const float* x;                      // final tokens [E*17][64]
-};
-template <typename T> struct InfHeadLds {
-  static constexpr int PAD = InfLd<T>::PAD;
-  static constexpr int LDP = 128 + 4, LDH = 256 + PAD;
-  static constexpr int ROWS = 32;  // rows per pass
-  static constexpr size_t bytes = (size_t)ROWS * LDP * 4 + (size_t)2 * ROWS * LDH * sizeof(T);
-};
-
-template <typename T>
-__global__ __launch_bounds__(256) void infer_head_kernel(InfHead hp, InfHead hv, int E, int A, float* __restrict__ outp,
-                                                         float* __restrict__ outv /* each [E][OUT_LD], zero padded */) {
-  // blockIdx.x = net (0: policy -> action means, 1: value net). Sampling / filing is act_finish_kernel's job.
-  typedef InfHeadLds<T> LY;
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int fr = lane & 15, qr = (lane >> 4) * 4;
-  constexpr int MR = LY::ROWS;
-  float* pooled = reinterpret_cast<float*>(smem);
-  T* h1 = reinterpret_cast<T*>(smem + (size_t)MR * LY::LDP * 4);
-  T* h2 = h1 + MR * LY::LDH;
-  const int nt4[4] = {wave * 4, wave * 4 + 1, wave * 4 + 2, wave * 4 + 3};
-  const int net = blockIdx.x;
-  const InfHead& h = net == 0 ? hp : hv;
-  float* outs = net == 0 ? outp : outv;
-  const int nout = net == 0 ? A : 1;
-  for (int r0 = 0; r0 < E; r0 += MR) {
-    for (int idx = tid; idx < MR * 128; idx += 256) {  // [state token | mean of the 16 depth tokens]
+  if constexpr (HEAD) {
+    // ---- heads on this block's samples: [state token | mean of the 16 depth tokens] -> 256 -> 256 -> nout
+    const InfHead& h = hd.n[blockIdx.y];
+    float* pooled = big;                                              // [16][LDP] fp32 (rows >= ns: zeros)
+    T* h1 = reinterpret_cast<T*>(big + 16 * LY::LDP);                 // [16][LDF]
+    T* h2 = h1 + 16 * LY::LDF;
+    float* so = reinterpret_cast<float*>(h2 + 16 * LY::LDF);          // [16][16] last-layer outputs
+    __syncthreads();
+    for (int idx = tid; idx < 16 * 128; idx += 256) {
       const int r = idx >> 7, c = idx & 127;
       float v = 0.f;
-      if (r0 + r < E) {
-        const float* xb = h.x + (int64_t)(r0 + r) * NTOK * TD;
+      if (r < ns) {
+        const float* xb = xs + (r * NTOK) * LY::LDX;
         if (c < TD) v = xb[c];
         else {
           float s = 0.f;
 #pragma unroll
-          for (int i = 1; i < NTOK; ++i) s += xb[i * TD + (c - TD)];
+          for (int i = 1; i < NTOK; ++i) s += xb[i * LY::LDX + (c - TD)];
           v = s * (1.f / 16.f);
         }
+        if (h.s_pooled != nullptr) h.s_pooled[(int64_t)(s0 + r) * 128 + c] = v;
       }
       pooled[r * LY::LDP + c] = v;
     }
     __syncthreads();
-    f32x4 acc[2][4];
-    auto store_h = [&](T* dst, const float* bias) {
+    const int nt4[4] = {wave * 4, wave * 4 + 1, wave * 4 + 2, wave * 4 + 3};
+    f32x4 acc[1][4];
+    auto store_h = [&](T* dst, const float* bias, float* save) {
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const int n4 = nt4[j] * 16 + qr;
         const float4 bb = *reinterpret_cast<const float4*>(bias + n4);
-#pragma unroll
-        for (int mt = 0; mt < 2; ++mt)
-          st4(dst + (mt * 16 + fr) * LY::LDH + n4, fmaxf(acc[mt][j][0] + bb.x, 0.f), fmaxf(acc[mt][j][1] + bb.y, 0.f),
-              fmaxf(acc[mt][j][2] + bb.z, 0.f), fmaxf(acc[mt][j][3] + bb.w, 0.f));
+        const float v0 = fmaxf(acc[0][j][0] + bb.x, 0.f), v1 = fmaxf(acc[0][j][1] + bb.y, 0.f);
+        const float v2 = fmaxf(acc[0][j][2] + bb.z, 0.f), v3 = fmaxf(acc[0][j][3] + bb.w, 0.f);
+        st4(dst + fr * LY::LDF + n4, v0, v1, v2, v3);
+        if (save != nullptr && fr < ns) st4(save + (int64_t)(s0 + fr) * 256 + n4, v0, v1, v2, v3);
       }
     };
     zero_acc(acc);
-    block_gemm<T, 2, 4, 4>(acc, pooled, LY::LDP, (const T*)h.w0, 128, nt4, lane);
-    store_h(h1, h.b0);
+    block_gemm<T, 1, 4, 4>(acc, pooled, LY::LDP, (const T*)h.w0, 128, nt4, lane);
+    store_h(h1, h.b0, h.s_h0);
     __syncthreads();
     zero_acc(acc);
-    block_gemm<T, 2, 4, 8>(acc, h1, LY::LDH, (const T*)h.w1, 256, nt4, lane);
-    store_h(h2, h.b1);
+    block_gemm<T, 1, 4, 8>(acc, h1, LY::LDF, (const T*)h.w1, 256, nt4, lane);
+    store_h(h2, h.b1, h.s_h1);
     __syncthreads();
-    if (wave < 2) {  // last layer: one 16-column tile; wave w takes row tile w of this pass
+    if (wave == 0) {  // last linear: one 16-column tile
       const int nt0[1] = {0};
       f32x4 a1[1][1];
       zero_acc(a1);
-      block_gemm<T, 1, 1, 8>(a1, h2 + wave * 16 * LY::LDH, LY::LDH, (const T*)h.w2, 256, nt0, lane);
-      const int row = r0 + wave * 16 + fr;
+      block_gemm<T, 1, 1, 8>(a1, h2, LY::LDF, (const T*)h.w2, 256, nt0, lane);
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int n = qr + r;
-        if (row < E) outs[(int64_t)row * OUT_LD + n] = n < nout ? a1[0][0][r] + h.b2[n] : 0.f;
+        const int c = qr + r;
+        const float v = c < h.nout ? a1[0][0][r] + h.b2[c] : 0.f;
+        so[fr * 16 + c] = v;
+        if (fr < ns) h.out[(int64_t)(s0 + fr) * OUT_LD + c] = v;
       }
     }
-    __syncthreads();
+    if (fin.ctl != nullptr) {
+      // ---- rollout step epilogue (GaussianContPolicyBase.explore, continuous_policy.py:85-125, and the collector's
+      // value read-out, collector/on_policy.py:95-100): action = mean + std * eps, entropy, log pi(a|s); filed at
+      // rollout slot t*E + i. Same expressions as act_finish_kernel / actor_loss_kernel.
+      __syncthreads();
+      if (tid < ns) {
+        const int i = s0 + tid;
+        const int A = fin.A;
+        if (blockIdx.y == 0) {
+          float e = 0.f, lp = 0.f;
+          for (int a = 0; a < A; ++a) {
+            const float mu = so[tid * 16 + a];
+            const float ls = fminf(fmaxf(fin.logstd[a], LOG_SIG_MIN), LOG_SIG_MAX);
+            const float sg = expf(ls);
+            e += 0.5f + HALF_LOG_2PI + logf(sg);
+            const float act = fmaf(sg, fin.eps[(int64_t)i * A + a], mu);
+            fin.action[(int64_t)i * A + a] = act;
+            fin.mean[(int64_t)i * A + a] = mu;
+            fin.stdv[(int64_t)i * A + a] = sg;
+            if (fin.acts_roll != nullptr) fin.acts_roll[(t_step * E + i) * A + a] = act;
+            const float d = act - mu;
+            lp += -(d * d) / (2.f * sg * sg) - logf(sg) - HALF_LOG_2PI;
+          }
+          fin.ent[i] = e;
+          if (fin.logp_roll != nullptr) fin.logp_roll[t_step * E + i] = lp;
+        } else {
+          const float v = so[tid * 16];
+          fin.value[i] = v;
+          if (fin.values_roll != nullptr) fin.values_roll[t_step * E + i] = v;
+        }
+      }
+      // the last block to get here advances the step cursor: every block read it at entry, none reads it again
+      __syncthreads();
+      if (tid == 0) {
+        __threadfence();
+        const unsigned long long done = atomicAdd(reinterpret_cast<unsigned long long*>(&fin.ctl->done), 1ull);
+        if (done == (unsigned long long)(gridDim.x * gridDim.y) - 1) {
+          fin.ctl->done = 0;
+          fin.ctl->t = t_step + 1;
+        }
+      }
+    }
   }
 }
 

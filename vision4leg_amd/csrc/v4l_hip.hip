@@ -778,14 +778,19 @@ int v4l_net::forward_t(const float* state, const T* image, const int* rowidx, in
     if (stage == 1) return 0;
     const int R = n * NTOK;
     const bool fused_layers = c.ff_dim == 256 && getenv("V4L_NO_FUSED_LAYER") == nullptr;
+    // the last layer's blocks also run the pooled heads of their samples when the head stack has the shipped shape
+    const bool fused_head = fused_layers && c.n_layers >= 1 && nh == 2 && c.head_hidden[0] == 256 && c.head_hidden[1] == 256 &&
+                            c.out_dim <= OUT_LD && getenv("V4L_NO_FUSED_HEAD") == nullptr;
     for (int l = 0; l < c.n_layers && fused_layers; ++l) {
       // one launch per TransformerEncoderLayer (csrc/infer.h), 4 samples per block, saving what backward_t reads
       const TLayer& t = layers[l];
       const LayerWs& w = L.lw[l];
       static bool attr_done = false;
       if (!attr_done) {
-        V4L_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&infer_layer_kernel<T>),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)InfLayLds<T>::bytes));
+        V4L_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&infer_layer_kernel<T, 4, false>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)InfLayLds<T, 4>::bytes));
+        V4L_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&infer_layer_kernel<T, 4, true>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)InfLayLds<T, 4>::bytes));
         attr_done = true;
       }
       const T* base = (const T*)packed;
@@ -799,11 +804,26 @@ int v4l_net::forward_t(const float* state, const T* image, const int* rowidx, in
       d.xout = ws + L.x[l + 1];
       d.s_qkv = ws + w.qkv; d.s_P = ws + w.P; d.s_ctx = ws + w.ctx; d.s_xh1 = ws + w.xh1; d.s_rs1 = ws + w.rs1;
       d.s_x1 = ws + w.x1; d.s_f = ws + w.f; d.s_xh2 = ws + w.xh2; d.s_rs2 = ws + w.rs2;
+      InfHeadPair hd;
+      memset(&hd, 0, sizeof(hd));
+      InfFinish fin;
+      memset(&fin, 0, sizeof(fin));
       g_op = "layer";
-      V4L_KLAUNCH("fused_layer", 2.0 * n * 872576.0, s, infer_layer_kernel<T>, dim3(cdiv(n, INF_SPW), 1), dim3(256),
-                  InfLayLds<T>::bytes, s, pr, n, c.ff_dim);
+      if (fused_head && l == c.n_layers - 1) {
+        InfHead& h = hd.n[0];
+        h.w0 = base + head[0].pk; h.w1 = base + head[1].pk; h.w2 = base + head[2].pk;
+        h.b0 = p[head[0].b]; h.b1 = p[head[1].b]; h.b2 = p[head[2].b];
+        h.out = ws + L.out; h.nout = c.out_dim;
+        h.s_pooled = ws + L.pooled; h.s_h0 = ws + L.hh[0]; h.s_h1 = ws + L.hh[1];
+        V4L_KLAUNCH("fused_layer_head", 2.0 * n * (872576.0 + 99840.0), s, (infer_layer_kernel<T, 4, true>), dim3(cdiv(n, 4), 1),
+                    dim3(256), (InfLayLds<T, 4>::bytes), s, pr, hd, fin, n, c.ff_dim);
+      } else {
+        V4L_KLAUNCH("fused_layer", 2.0 * n * 872576.0, s, (infer_layer_kernel<T, 4, false>), dim3(cdiv(n, 4), 1), dim3(256),
+                    (InfLayLds<T, 4>::bytes), s, pr, hd, fin, n, c.ff_dim);
+      }
       V4L_LAUNCH_CHECK();
     }
+    if (fused_head) return 0;
     for (int l = 0; l < c.n_layers && !fused_layers; ++l) {
       const TLayer& t = layers[l];
       const LayerWs& w = L.lw[l];
@@ -1038,10 +1058,10 @@ static int run_actor_fused(v4l_actor* a, const float* obs, const float* eps, flo
   if (!attr_done) {
     V4L_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&infer_encoder_kernel<T>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)InfEncLds<T>::bytes));
-    V4L_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&infer_layer_kernel<T>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)InfLayLds<T>::bytes));
-    V4L_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&infer_head_kernel<T>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)InfHeadLds<T>::bytes));
+    V4L_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&infer_layer_kernel<T, 1, false>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)InfLayLds<T, 1>::bytes));
+    V4L_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&infer_layer_kernel<T, 1, true>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)InfLayLds<T, 1>::bytes));
     attr_done = true;
   }
   const T* pk = (const T*)pf->packed;
@@ -1070,33 +1090,35 @@ static int run_actor_fused(v4l_actor* a, const float* obs, const float* eps, flo
   };
   const int nl = pf->cfg.n_layers;
   for (int l = 0; l < nl; ++l) {
+    // one sample per block and net: 2E short blocks; the last layer's blocks go on through the heads, sample the
+    // action, file action / value / log-prob at rollout slot t*E + i and advance the step cursor
     InfLayerPair pr;
     fill(pr.n[0], pf, pk, pf->layers[l], l == 0 ? x0 : ws_pf + Lp.x[l], ws_pf + Lp.x[l + 1]);
     fill(pr.n[1], vf, vk, vf->layers[l], l == 0 ? x0 : ws_vf + Lv.x[l], ws_vf + Lv.x[l + 1]);
+    InfHeadPair hd;
+    memset(&hd, 0, sizeof(hd));
+    InfFinish fin;
+    memset(&fin, 0, sizeof(fin));
     g_op = "layer";
-    V4L_KLAUNCH("infer_layer", 2.0 * 2 * E * 872576.0, s, infer_layer_kernel<T>, dim3(cdiv(E, INF_SPW), 2), dim3(256),
-                InfLayLds<T>::bytes, s, pr, E, pf->cfg.ff_dim);
+    if (l < nl - 1) {
+      V4L_KLAUNCH("infer_layer", 2.0 * 2 * E * 872576.0, s, (infer_layer_kernel<T, 1, false>), dim3(E, 2), dim3(256),
+                  (InfLayLds<T, 1>::bytes), s, pr, hd, fin, E, pf->cfg.ff_dim);
+    } else {
+      auto head = [&](InfHead& h, v4l_net* net, const T* base, float* out) {
+        h.w0 = base + net->head[0].pk; h.w1 = base + net->head[1].pk; h.w2 = base + net->head[2].pk;
+        h.b0 = net->p[net->head[0].b]; h.b1 = net->p[net->head[1].b]; h.b2 = net->p[net->head[2].b];
+        h.out = out; h.nout = net->cfg.out_dim;
+      };
+      head(hd.n[0], pf, pk, ws_pf + Lp.out);
+      head(hd.n[1], vf, vk, ws_vf + Lv.out);
+      fin.ctl = a->ctl; fin.logstd = pf->p[pf->logstd]; fin.eps = eps; fin.A = pf->cfg.out_dim;
+      fin.acts_roll = acts_roll; fin.values_roll = values_roll; fin.logp_roll = logp_roll; fin.action = action;
+      fin.mean = mean; fin.stdv = stdv; fin.ent = ent; fin.value = value;
+      V4L_KLAUNCH("infer_layer_head", 2.0 * 2 * E * (872576.0 + 99840.0), s, (infer_layer_kernel<T, 1, true>), dim3(E, 2),
+                  dim3(256), (InfLayLds<T, 1>::bytes), s, pr, hd, fin, E, pf->cfg.ff_dim);
+    }
     V4L_LAUNCH_CHECK();
   }
-  auto head = [&](InfHead& h, v4l_net* net, const T* base, const float* x) {
-    h.w0 = base + net->head[0].pk; h.w1 = base + net->head[1].pk; h.w2 = base + net->head[2].pk;
-    h.b0 = net->p[net->head[0].b]; h.b1 = net->p[net->head[1].b]; h.b2 = net->p[net->head[2].b];
-    h.x = x;
-  };
-  InfHead hp, hv;
-  head(hp, pf, pk, ws_pf + Lp.x[nl]);
-  head(hv, vf, vk, ws_vf + Lv.x[nl]);
-  g_op = "head";
-  float* outp = ws_pf + Lp.out;
-  float* outv = ws_vf + Lv.out;
-  V4L_KLAUNCH("infer_head", 2.0 * 2 * E * 99840.0, s, infer_head_kernel<T>, dim3(2), dim3(256), InfHeadLds<T>::bytes, s, hp, hv,
-              E, pf->cfg.out_dim, outp, outv);
-  V4L_LAUNCH_CHECK();
-  g_op = "sample";
-  V4L_KLAUNCH("act_finish", 0, s, act_finish_kernel, dim3(1), dim3(256), 0, s, a->ctl, (const float*)outp,
-              (const float*)pf->p[pf->logstd], (const float*)outv, eps, E, pf->cfg.out_dim, acts_roll, values_roll, logp_roll, action,
-              mean, stdv, ent, value);
-  V4L_LAUNCH_CHECK();
   return 0;
 }
 
