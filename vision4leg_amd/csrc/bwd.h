@@ -21,6 +21,25 @@ struct BwdLayer {
   float *gp2, *bp2, *gp1, *bp1;          // [gridDim.x][64] per-block dgamma / dbeta partials of norm2 / norm1
 };
 
+// HEAD (last layer): the block first walks the pooled heads of its samples backward (nets.py:1015-1034 reversed):
+//   dout -> (W2^T, mask h1) -> dh1 -> (W1^T, mask h0) -> dh0 -> (W0^T) -> dpool -> un-pool -> dy rows in LDS
+struct BwdHead {
+  const void *w2t, *w1t, *w0t;   // data-grad packs [K][N]: [256][64] [256][256] [128][256]
+  const float* dout;             // [n][OUT_LD] grad w.r.t. the head output (columns >= out_dim are zero)
+  const float *s_h1, *s_h0;      // [n][256] post-ReLU activations of the two hidden layers
+  float *o_dh1, *o_dh0;          // [n][256] dY operands of the weight-grads of fcs[1] / fcs[0]
+};
+// TAIL (layer 0): the block continues from dx_in into the encoder (base.py:602-622 reversed): token 0 ->
+// state_projector' -> encoder MLP'; tokens 1..16 -> depth_up_conv' (-> dc3, ReLU mask of conv3)
+struct BwdTail {
+  const void *wpt, *wf2t, *wupt;  // data-grad packs: state_projector [256][64], encoder fc2 [256][256], up-conv [64][64]
+  const float* x0;                // [R][64] layer-0 input tokens (ReLU mask of token 0)
+  const float *s_e1, *s_e0;       // [n][256] encoder-MLP activations (post-ReLU)
+  const float* s_c3;              // [n*16][64] conv3 output (post-ReLU)
+  float *o_dhc, *o_de0;           // [n][256] grads w.r.t. the pre-activations of encoder fc2 / fc1
+  float* o_dc3;                   // [n*16][64]
+};
+
 template <typename T> struct BwdLayLds {
   static constexpr int PAD = InfLd<T>::PAD;
   static constexpr int LDX = 64 + 4, LDQ = 192 + 4, LDF = 256 + PAD;
@@ -81,8 +100,8 @@ __device__ __forceinline__ void ln_bwd_rows(float* d, int ld, const float* __res
   }
 }
 
-template <typename T>
-__global__ __launch_bounds__(256) void bwd_layer_kernel(BwdLayer w, int n) {
+template <typename T, bool HEAD, bool TAIL>
+__global__ __launch_bounds__(256) void bwd_layer_kernel(BwdLayer w, BwdHead hd, BwdTail tl, int n) {
   typedef BwdLayLds<T> LY;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -97,7 +116,63 @@ __global__ __launch_bounds__(256) void bwd_layer_kernel(BwdLayer w, int n) {
   const int nrows = ns * NTOK;
   const int64_t row0 = (int64_t)s0 * NTOK;
   const int nt1[1] = {wave};
-  {
+  const int nt4[4] = {wave * 4, wave * 4 + 1, wave * 4 + 2, wave * 4 + 3};
+  if constexpr (HEAD) {
+    constexpr int LDP = 128 + 4;
+    float* dt = big;                                            // [16][LDX]: dout rows, zero padded to 64 columns
+    T* dh1 = reinterpret_cast<T*>(big + 16 * LY::LDX);          // [16][LDF]
+    T* dh0 = dh1 + 16 * LY::LDF;
+    float* dpool = reinterpret_cast<float*>(dh0 + 16 * LY::LDF);  // [16][LDP]
+    for (int idx = tid; idx < 16 * TD; idx += 256) {
+      const int r = idx >> 6, c = idx & 63;
+      const bool ok = r < ns && c < OUT_LD;
+      const float v = hd.dout[ok ? (int64_t)(s0 + r) * OUT_LD + c : 0];
+      dt[r * LY::LDX + c] = ok ? v : 0.f;
+    }
+    __syncthreads();
+    f32x4 acc[1][4];
+    auto masked = [&](const float* act, T* dst, float* save) {  // ReLU mask from the saved activation, rows < ns
+      const bool ok = fr < ns;
+      float4 m[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) m[j] = *reinterpret_cast<const float4*>(act + (int64_t)(s0 + (ok ? fr : 0)) * 256 + nt4[j] * 16 + qr);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int n4 = nt4[j] * 16 + qr;
+        const float d0 = m[j].x > 0.f ? acc[0][j][0] : 0.f, d1 = m[j].y > 0.f ? acc[0][j][1] : 0.f;
+        const float d2 = m[j].z > 0.f ? acc[0][j][2] : 0.f, d3 = m[j].w > 0.f ? acc[0][j][3] : 0.f;
+        st4(dst + fr * LY::LDF + n4, d0, d1, d2, d3);
+        if (ok) st4(save + (int64_t)(s0 + fr) * 256 + n4, d0, d1, d2, d3);
+      }
+    };
+    zero_acc(acc);
+    block_gemm<T, 1, 4, 2>(acc, dt, LY::LDX, (const T*)hd.w2t, 64, nt4, lane);
+    masked(hd.s_h1, dh1, hd.o_dh1);
+    __syncthreads();
+    zero_acc(acc);
+    block_gemm<T, 1, 4, 8>(acc, dh1, LY::LDF, (const T*)hd.w1t, 256, nt4, lane);
+    masked(hd.s_h0, dh0, hd.o_dh0);
+    __syncthreads();
+    {
+      const int nt2[2] = {wave * 2, wave * 2 + 1};
+      f32x4 a2[1][2];
+      zero_acc(a2);
+      block_gemm<T, 1, 2, 8>(a2, dh0, LY::LDF, (const T*)hd.w0t, 256, nt2, lane);
+#pragma unroll
+      for (int j = 0; j < 2; ++j) st4(dpool + fr * LDP + nt2[j] * 16 + qr, a2[0][j][0], a2[0][j][1], a2[0][j][2], a2[0][j][3]);
+    }
+    __syncthreads();
+    // un-pool (pool_bwd_kernel): token 0 <- dpool[:, 0:64], tokens 1..16 <- dpool[:, 64:128] / 16
+    for (int idx = tid; idx < INF_ROWS * TD; idx += 256) {
+      const int r = idx >> 6, c = idx & 63;
+      float v = 0.f;
+      if (r < nrows) {
+        const int sm = r / NTOK, t = r - sm * NTOK;
+        v = t == 0 ? dpool[sm * LDP + c] : dpool[sm * LDP + TD + c] * (1.f / 16.f);
+      }
+      a[r * LY::LDX + c] = v;
+    }
+  } else {
     const float* dyg = w.dy + row0 * TD;
     for (int i4 = tid; i4 < INF_ROWS * (TD / 4); i4 += 256) {
       const int r = i4 >> 4, c4 = (i4 & 15) * 4;
@@ -114,7 +189,6 @@ __global__ __launch_bounds__(256) void bwd_layer_kernel(BwdLayer w, int n) {
   // ---- df = (dz2 W2) o [f > 0]   (T in LDS for the next contraction, fp32 to HBM for linear1's weight-grad)
   T* f = reinterpret_cast<T*>(big);
   {
-    const int nt4[4] = {wave * 4, wave * 4 + 1, wave * 4 + 2, wave * 4 + 3};
     f32x4 acc[INF_MT][4];
     zero_acc(acc);
     block_gemm<T, INF_MT, 4, 2>(acc, a, LY::LDX, (const T*)w.w2t, 64, nt4, lane);
@@ -257,12 +331,64 @@ __global__ __launch_bounds__(256) void bwd_layer_kernel(BwdLayer w, int n) {
 #pragma unroll
     for (int mt = 0; mt < INF_MT; ++mt) {
       const int row = mt * 16 + fr;
-      if (row < nrows) {
-        const float4 r = *reinterpret_cast<const float4*>(b + row * LY::LDX + n4);
-        st4(w.o_dx + (row0 + row) * TD + n4, r.x + acc[mt][0][0], r.y + acc[mt][0][1], r.z + acc[mt][0][2],
-            r.w + acc[mt][0][3]);
+      const float4 r = *reinterpret_cast<const float4*>(b + row * LY::LDX + n4);
+      const float v0 = r.x + acc[mt][0][0], v1 = r.y + acc[mt][0][1], v2 = r.z + acc[mt][0][2], v3 = r.w + acc[mt][0][3];
+      if (row < nrows) st4(w.o_dx + (row0 + row) * TD + n4, v0, v1, v2, v3);
+      if constexpr (TAIL) st4(a + row * LY::LDX + n4, v0, v1, v2, v3);  // dctx is dead: `a` takes dx_in (0 beyond nrows)
+    }
+  }
+  if constexpr (TAIL) {
+    __syncthreads();
+    {  // ---- tokens 1..16: dc3 = (dx_in Wup) o [c3 > 0]; the token-0 rows of the tile are computed and dropped
+      f32x4 acc[INF_MT][1];
+      zero_acc(acc);
+      block_gemm<T, INF_MT, 1, 2>(acc, a, LY::LDX, (const T*)tl.wupt, 64, nt1, lane);
+      const int n4 = wave * 16 + qr;
+#pragma unroll
+      for (int mt = 0; mt < INF_MT; ++mt) {
+        const int row = mt * 16 + fr;
+        const int sm = row / NTOK, t = row - sm * NTOK;
+        const bool ok = row < nrows && t > 0;
+        const int64_t o = ok ? ((int64_t)(s0 + sm) * 16 + (t - 1)) * TD + n4 : 0;
+        const float4 m = *reinterpret_cast<const float4*>(tl.s_c3 + o);
+        if (ok)
+          st4(tl.o_dc3 + o, m.x > 0.f ? acc[mt][0][0] : 0.f, m.y > 0.f ? acc[mt][0][1] : 0.f, m.z > 0.f ? acc[mt][0][2] : 0.f,
+              m.w > 0.f ? acc[mt][0][3] : 0.f);
       }
     }
+    // ---- token 0: (dx_in o [x0 > 0]) -> state_projector' -> [e1 > 0] -> dhc -> fc2' -> [e0 > 0] -> de0
+    float* dt = big;                                   // [16][LDX] (dqkv was consumed by the in_proj data-grad)
+    T* dh = reinterpret_cast<T*>(big + 16 * LY::LDX);  // [16][LDF]
+    __syncthreads();
+    for (int idx = tid; idx < 16 * TD; idx += 256) {
+      const int r = idx >> 6, c = idx & 63;
+      const bool ok = r < ns;
+      const float m = tl.x0[(row0 + (ok ? r * NTOK : 0)) * TD + c];
+      dt[r * LY::LDX + c] = ok && m > 0.f ? a[(r * NTOK) * LY::LDX + c] : 0.f;
+    }
+    __syncthreads();
+    f32x4 acc[1][4];
+    auto masked = [&](const float* act, T* dst, float* save) {
+      const bool ok = fr < ns;
+      float4 m[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) m[j] = *reinterpret_cast<const float4*>(act + (int64_t)(s0 + (ok ? fr : 0)) * 256 + nt4[j] * 16 + qr);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int n4 = nt4[j] * 16 + qr;
+        const float d0 = m[j].x > 0.f ? acc[0][j][0] : 0.f, d1 = m[j].y > 0.f ? acc[0][j][1] : 0.f;
+        const float d2 = m[j].z > 0.f ? acc[0][j][2] : 0.f, d3 = m[j].w > 0.f ? acc[0][j][3] : 0.f;
+        if (dst != nullptr) st4(dst + fr * LY::LDF + n4, d0, d1, d2, d3);
+        if (ok) st4(save + (int64_t)(s0 + fr) * 256 + n4, d0, d1, d2, d3);
+      }
+    };
+    zero_acc(acc);
+    block_gemm<T, 1, 4, 2>(acc, dt, LY::LDX, (const T*)tl.wpt, 64, nt4, lane);
+    masked(tl.s_e1, dh, tl.o_dhc);
+    __syncthreads();
+    zero_acc(acc);
+    block_gemm<T, 1, 4, 8>(acc, dh, LY::LDF, (const T*)tl.wf2t, 256, nt4, lane);
+    masked(tl.s_e0, (T*)nullptr, tl.o_de0);
   }
 }
 

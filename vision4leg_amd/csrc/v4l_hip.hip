@@ -923,16 +923,25 @@ int v4l_net::backward_t(const float* state, const T* image, const int* rowidx, i
 
   // ---- LocoTransformer
   const int R = n * NTOK;
-  {
+  const bool fused_bwd = c.ff_dim == 256 && getenv("V4L_NO_FUSED_LAYER_BWD") == nullptr;
+  // the last layer's launch starts from dout (heads + un-pool), layer 0's launch continues into the encoder MLP / up-conv
+  const bool fused_head = fused_bwd && c.n_layers >= 1 && nh == 2 && c.head_hidden[0] == 256 && c.head_hidden[1] == 256 &&
+                          getenv("V4L_NO_FUSED_HEAD_BWD") == nullptr;
+  const bool fused_tail = fused_bwd && c.n_layers >= 1 && ne == 2 && c.enc_hidden[0] == 256 && c.enc_hidden[1] == 256 &&
+                          getenv("V4L_NO_FUSED_TAIL_BWD") == nullptr;
+  if (fused_head) {  // only the three weight-grads are registered here
+    if ((rc = lin_wgrad<T>(cx, head[2], dy, dense(hacts[1].p, 256, n, 256), 256))) return rc;
+    if ((rc = lin_wgrad<T>(cx, head[1], dense(dhhp[1], 256, n, 256), dense(hacts[0].p, 256, n, 256), 256))) return rc;
+    if ((rc = lin_wgrad<T>(cx, head[0], dense(dhhp[0], 256, n, 256), dense(ws + L.pooled, 2 * TD, n, 2 * TD), 2 * TD))) return rc;
+  } else {
     Epi din = mk_epi(ws + L.dpool, 2 * TD, 2 * TD);
     if ((rc = chain_bwd<T>(cx, head.data(), nh + 1, dense(ws + L.pooled, 2 * TD, n, 2 * TD), hacts, dy, dhhp, &din)))
       return rc;
+    g_op = "pool";
+    V4L_KLAUNCH("pool_bwd", 0, s, pool_bwd_kernel, dim3(n), dim3(64), 0, s, ws + L.dpool, n, ws + L.dxl[c.n_layers]);
+    V4L_LAUNCH_CHECK();
   }
-  g_op = "pool";
-  V4L_KLAUNCH("pool_bwd", 0, s, pool_bwd_kernel, dim3(n), dim3(64), 0, s, ws + L.dpool, n, ws + L.dxl[c.n_layers]);
-  V4L_LAUNCH_CHECK();
   const int lnb = std::min(cdiv(R, 16), 128);
-  const bool fused_bwd = c.ff_dim == 256 && getenv("V4L_NO_FUSED_LAYER_BWD") == nullptr;
   for (int l = c.n_layers - 1; l >= 0 && fused_bwd; --l) {
     // one launch per TransformerEncoderLayer (csrc/bwd.h): every data-grad of the layer with the intermediates in LDS;
     // the four weight-grads are deferred to the grouped launch as before
@@ -941,8 +950,12 @@ int v4l_net::backward_t(const float* state, const T* image, const int* rowidx, i
     const LayerBw& b = L.lb[l];
     static bool attr_done = false;
     if (!attr_done) {
-      V4L_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&bwd_layer_kernel<T>),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)BwdLayLds<T>::bytes));
+      const void* fns[4] = {reinterpret_cast<const void*>(&bwd_layer_kernel<T, false, false>),
+                            reinterpret_cast<const void*>(&bwd_layer_kernel<T, true, false>),
+                            reinterpret_cast<const void*>(&bwd_layer_kernel<T, false, true>),
+                            reinterpret_cast<const void*>(&bwd_layer_kernel<T, true, true>)};
+      for (const void* fn : fns)
+        V4L_HIP_CHECK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)BwdLayLds<T>::bytes));
       attr_done = true;
     }
     const int nblk = cdiv(n, INF_SPW);
@@ -958,9 +971,31 @@ int v4l_net::backward_t(const float* state, const T* image, const int* rowidx, i
     d.s_xh2 = ws + w.xh2; d.s_rs2 = ws + w.rs2;
     d.o_dz2 = ws + b.dz2; d.o_df = ws + b.df; d.o_dz1 = ws + b.dz1; d.o_dqkv = ws + b.dqkv; d.o_dx = ws + L.dxl[l];
     d.gp2 = part; d.bp2 = part + (int64_t)nblk * TD; d.gp1 = part + 2 * (int64_t)nblk * TD; d.bp1 = part + 3 * (int64_t)nblk * TD;
+    const bool hd_on = fused_head && l == c.n_layers - 1, tl_on = fused_tail && l == 0;
+    BwdHead bh;
+    memset(&bh, 0, sizeof(bh));
+    if (hd_on) {
+      bh.w2t = base + head[2].pkt; bh.w1t = base + head[1].pkt; bh.w0t = base + head[0].pkt;
+      bh.dout = ws + L.dout; bh.s_h1 = hacts[1].p; bh.s_h0 = hacts[0].p; bh.o_dh1 = dhhp[1]; bh.o_dh0 = dhhp[0];
+    }
+    BwdTail bt;
+    memset(&bt, 0, sizeof(bt));
+    if (tl_on) {
+      bt.wpt = base + proj.pkt; bt.wf2t = base + enc[1].pkt; bt.wupt = base + upconv.pkt;
+      bt.x0 = ws + L.x[0]; bt.s_e1 = eacts[1].p; bt.s_e0 = eacts[0].p; bt.s_c3 = ws + L.c3;
+      bt.o_dhc = ws + L.dhc; bt.o_de0 = dehp[0]; bt.o_dc3 = ws + L.dc3;
+    }
     g_op = "layer";
-    V4L_KLAUNCH("fused_layer_bwd", 4.0 * n * 872576.0, s, bwd_layer_kernel<T>, dim3(nblk), dim3(256), BwdLayLds<T>::bytes, s, d,
-                n);
+    const double fl = 4.0 * n * 872576.0 + (hd_on ? 2.0 * n * 2 * (16 * 256 + 256 * 256 + 256 * 128) : 0.0) +
+                      (tl_on ? 2.0 * n * (64 * 256 + 256 * 256 + 16 * 64 * 64) : 0.0);
+#define V4L_BWD_LAYER(H, TL)                                                                                              \
+  V4L_KLAUNCH(H ? (TL ? "fused_layer_bwd_head_tail" : "fused_layer_bwd_head") : (TL ? "fused_layer_bwd_tail" : "fused_layer_bwd"), \
+              fl, s, (bwd_layer_kernel<T, H, TL>), dim3(nblk), dim3(256), BwdLayLds<T>::bytes, s, d, bh, bt, n)
+    if (hd_on && tl_on) V4L_BWD_LAYER(true, true);
+    else if (hd_on) V4L_BWD_LAYER(true, false);
+    else if (tl_on) V4L_BWD_LAYER(false, true);
+    else V4L_BWD_LAYER(false, false);
+#undef V4L_BWD_LAYER
     V4L_LAUNCH_CHECK();
     const int lnp[4] = {t.ln2.g, t.ln2.b, t.ln1.g, t.ln1.b};
     for (int k = 0; k < 4; ++k) {
@@ -1015,7 +1050,15 @@ int v4l_net::backward_t(const float* state, const T* image, const int* rowidx, i
   }
   float* dx = ws + L.dxl[0];
   const float* x0 = ws + L.x[0];
-  {  // token 0 -> state_projector -> encoder MLP
+  if (fused_tail) {  // data-grads done by layer 0's launch: register the four weight-grads
+    const Act& last = eacts[ne - 1];
+    if ((rc = lin_wgrad<T>(cx, proj, dense(dx, NTOK * TD, n, TD, nullptr, 0, x0), dense(last.p, last.ld, n, last.w), last.w)))
+      return rc;
+    if ((rc = lin_wgrad<T>(cx, enc[1], dense(ws + L.dhc, 256, n, 256), dense(eacts[0].p, 256, n, 256), 256))) return rc;
+    if ((rc = lin_wgrad<T>(cx, enc[0], dense(dehp[0], 256, n, 256), sin, sin.K))) return rc;
+    if ((rc = lin_wgrad<T>(cx, upconv, dense(dx, TD, n * 16, TD, nullptr, 1), dense(ws + L.c3, 64, n * 16, 64), 64))) return rc;
+  }
+  if (!fused_tail) {  // token 0 -> state_projector -> encoder MLP
     const Act& last = eacts[ne - 1];
     ADense yp = dense(dx, NTOK * TD, n, TD, nullptr, 0, x0);
     if ((rc = lin_wgrad<T>(cx, proj, yp, dense(last.p, last.ld, n, last.w), last.w))) return rc;
@@ -1025,7 +1068,7 @@ int v4l_net::backward_t(const float* state, const T* image, const int* rowidx, i
     if ((rc = lin_dgrad<T>(cx, proj, yp, ep))) return rc;
     if ((rc = chain_bwd<T>(cx, enc.data(), ne, sin, eacts, dense(ws + L.dhc, last.w, n, last.w), dehp, nullptr))) return rc;
   }
-  {  // tokens 1..16 -> depth_up_conv -> conv stack
+  if (!fused_tail) {  // tokens 1..16 -> depth_up_conv -> conv stack
     ADense yu = dense(dx, TD, n * 16, TD, nullptr, 1);
     if ((rc = lin_wgrad<T>(cx, upconv, yu, dense(ws + L.c3, 64, n * 16, 64), 64))) return rc;
     Epi ep = mk_epi(ws + L.dc3, 64, 64);
