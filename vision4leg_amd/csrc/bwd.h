@@ -15,8 +15,9 @@ struct BwdLayer {
   const void *w2t, *w1t, *wot, *wint;  // data-grad packs [K][N] (T): [ff][64] [64][ff] [64][64] [64][192]
   const float *g1, *g2;                // LayerNorm weights
   const float* dy;                     // [R][64] grad w.r.t. the layer output
-  const float *s_qkv, *s_P, *s_xh1, *s_rs1, *s_f, *s_xh2, *s_rs2;  // saved by the forward pass
-  float *o_dz2, *o_df, *o_dz1, *o_dqkv;  // dY operands of the weight-grads of linear2 / linear1 / out_proj / in_proj
+  const float *s_qkv, *s_P, *s_xh1, *s_rs1, *s_xh2, *s_rs2;  // saved by the forward pass (fp32)
+  const void* s_f;                       // [R][256] FFN activation in the contraction type T (ReLU mask)
+  void *o_dz2, *o_df, *o_dz1, *o_dqkv;   // dY operands (T) of the weight-grads of linear2 / linear1 / out_proj / in_proj
   float* o_dx;                           // [R][64] grad w.r.t. the layer input
   float *gp2, *bp2, *gp1, *bp1;          // [gridDim.x][64] per-block dgamma / dbeta partials of norm2 / norm1
 };
@@ -54,9 +55,10 @@ template <typename T> struct BwdLayLds {
 
 // LayerNorm backward, in place over the 80 LDS rows of `d` (rows >= nrows hold zeros and stay zero); the rows < nrows
 // also go to o_dz (global). Leaves the block's dgamma/dbeta partial in gpart/bpart[64]. Contains one __syncthreads.
+template <typename T>
 __device__ __forceinline__ void ln_bwd_rows(float* d, int ld, const float* __restrict__ xh, const float* __restrict__ rs,
                                             const float* __restrict__ gamma, int wave, int lane, int nrows,
-                                            float* __restrict__ o_dz, float* red, float* __restrict__ gpart,
+                                            T* __restrict__ o_dz, float* red, float* __restrict__ gpart,
                                             float* __restrict__ bpart) {
   const float g = gamma[lane];
   float ag = 0.f, ab = 0.f;
@@ -88,7 +90,7 @@ __device__ __forceinline__ void ln_bwd_rows(float* d, int ld, const float* __res
       const int r = r0 + 4 * u;
       const float dz = rr[u] * (dxh[u] - c1[u] * (1.f / TD) - x[u] * (c2[u] * (1.f / TD)));
       d[r * ld + lane] = dz;
-      if (r < nrows) o_dz[r * TD + lane] = dz;
+      if (r < nrows) o_dz[r * TD + lane] = (T)dz;
     }
   }
   red[wave * TD + lane] = ag;
@@ -183,7 +185,8 @@ __global__ __launch_bounds__(256) void bwd_layer_kernel(BwdLayer w, BwdHead hd, 
   }
   __syncthreads();
   // ---- norm2 backward: a = dz2
-  ln_bwd_rows(a, LY::LDX, w.s_xh2 + row0 * TD, w.s_rs2 + row0, w.g2, wave, lane, nrows, w.o_dz2 + row0 * TD, red,
+  ln_bwd_rows(a, LY::LDX, w.s_xh2 + row0 * TD, w.s_rs2 + row0, w.g2, wave, lane, nrows,
+              reinterpret_cast<T*>(w.o_dz2) + row0 * TD, red,
               w.gp2 + (int64_t)blockIdx.x * TD, w.bp2 + (int64_t)blockIdx.x * TD);
   __syncthreads();
   // ---- df = (dz2 W2) o [f > 0]   (T in LDS for the next contraction, fp32 to HBM for linear1's weight-grad)
@@ -199,14 +202,14 @@ __global__ __launch_bounds__(256) void bwd_layer_kernel(BwdLayer w, BwdHead hd, 
       float4 m[4];
 #pragma unroll
       for (int j = 0; j < 4; ++j)
-        m[j] = *reinterpret_cast<const float4*>(w.s_f + (row0 + (ok ? row : 0)) * 256 + nt4[j] * 16 + qr);
+        m[j] = ld4(reinterpret_cast<const T*>(w.s_f) + (row0 + (ok ? row : 0)) * 256 + nt4[j] * 16 + qr);
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const int n4 = nt4[j] * 16 + qr;
         const float d0 = m[j].x > 0.f ? acc[mt][j][0] : 0.f, d1 = m[j].y > 0.f ? acc[mt][j][1] : 0.f;
         const float d2 = m[j].z > 0.f ? acc[mt][j][2] : 0.f, d3 = m[j].w > 0.f ? acc[mt][j][3] : 0.f;
         st4(f + row * LY::LDF + n4, d0, d1, d2, d3);  // padding rows: acc == 0
-        if (ok) st4(w.o_df + (row0 + row) * 256 + n4, d0, d1, d2, d3);
+        if (ok) st4(reinterpret_cast<T*>(w.o_df) + (row0 + row) * 256 + n4, d0, d1, d2, d3);
       }
     }
   }
@@ -241,7 +244,8 @@ __global__ __launch_bounds__(256) void bwd_layer_kernel(BwdLayer w, BwdHead hd, 
     }
   }
   // ---- norm1 backward: b = dz1
-  ln_bwd_rows(b, LY::LDX, w.s_xh1 + row0 * TD, w.s_rs1 + row0, w.g1, wave, lane, nrows, w.o_dz1 + row0 * TD, red,
+  ln_bwd_rows(b, LY::LDX, w.s_xh1 + row0 * TD, w.s_rs1 + row0, w.g1, wave, lane, nrows,
+              reinterpret_cast<T*>(w.o_dz1) + row0 * TD, red,
               w.gp1 + (int64_t)blockIdx.x * TD, w.bp1 + (int64_t)blockIdx.x * TD);
   __syncthreads();
   {  // ---- dctx = dz1 Wo -> a
@@ -309,16 +313,16 @@ __global__ __launch_bounds__(256) void bwd_layer_kernel(BwdLayer w, BwdHead hd, 
           dk[j] = fmaf(si[j], qq[i], dk[j]);
         }
       }
-      float* og = w.o_dqkv + (row0 + wave * NTOK) * 192;
+      T* og = reinterpret_cast<T*>(w.o_dqkv) + (row0 + wave * NTOK) * 192;
 #pragma unroll
       for (int i = 0; i < NTOK; ++i) {
         const float q8 = dq[i] * 0.125f, k8 = dk[i] * 0.125f;
         qs[i * LY::LDQ + lane] = q8;
         qs[i * LY::LDQ + TD + lane] = k8;
         qs[i * LY::LDQ + 2 * TD + lane] = dv[i];
-        og[i * 192 + lane] = q8;
-        og[i * 192 + TD + lane] = k8;
-        og[i * 192 + 2 * TD + lane] = dv[i];
+        og[i * 192 + lane] = (T)q8;
+        og[i * 192 + TD + lane] = (T)k8;
+        og[i * 192 + 2 * TD + lane] = (T)dv[i];
       }
     }
   }

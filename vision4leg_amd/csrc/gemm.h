@@ -603,6 +603,169 @@ __global__ __launch_bounds__(256) void gemm_tn_group_kernel(const TnProb* __rest
   tn_body<T, 64, 1, ADense, ADense>(p.y, p.x, p.M, p.mpb, p.slab, p.bslab, p.Npad, p.Kpad, bx, t % p.gy, t / p.gy);
 }
 
+// ------------------------------------------------------------------------------------ gemm_tn_wide
+// Weight-grads of the transformer-layer linears (M = 17 tokens x batch rows, N, K in {64, 192, 256}): both operands
+// are plain row-major [M][C] arrays ALREADY in the contraction type T (the fused layer kernels write them that way),
+// and one block owns the WHOLE N x K output for its slab of rows -> every operand byte is fetched exactly once
+// (gemm_tn_group's 64x64 tiles re-fetch X per n-tile and Y per k-tile, from another XCD's L2 more often than not).
+// Staging: a lane loads 2 adjacent columns of 8 consecutive rows (4/8-byte loads, 128/256-byte row segments per
+// half-wave), regroups them into two 8-row column vectors in registers and writes each with one 16/32-byte ds_write
+// into the [column][row] image the MFMA fragments are read from.
+struct TnWide {
+  const void *y, *x;   // T [M][N], T [M][K]
+  int M, mpb, N, K;
+  float *slab, *bslab;  // [nsplit][N][K], [nsplit][N]
+  int blk0, pad;
+};
+template <typename T> struct Pair;
+template <> struct Pair<__bf16> { typedef __attribute__((ext_vector_type(2))) __bf16 type; };
+template <> struct Pair<float> { typedef float2 type; };
+__device__ __forceinline__ void st8raw(__bf16* dst, const __bf16 (&v)[8]) {
+  bf16x8 t;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) t[j] = v[j];
+  *reinterpret_cast<bf16x8*>(dst) = t;
+}
+__device__ __forceinline__ void st8raw(float* dst, const float (&v)[8]) {
+  *reinterpret_cast<float4*>(dst) = float4{v[0], v[1], v[2], v[3]};
+  *reinterpret_cast<float4*>(dst + 4) = float4{v[4], v[5], v[6], v[7]};
+}
+template <typename T> struct TnWideLds {
+  static constexpr int LD = 64 + (sizeof(T) == 2 ? 8 : 4);
+  static constexpr size_t bytes(int N, int K) { return (size_t)(N + K) * LD * sizeof(T) + (size_t)8 * N * 4; }
+  static constexpr size_t max_bytes = (size_t)(256 + 64) * LD * sizeof(T) + (size_t)8 * 256 * 4;
+};
+
+template <typename T, int N, int K>
+__device__ __forceinline__ void tn_wide_body(const TnWide& p, int bz, unsigned char* smem) {
+  constexpr int LD = TnWideLds<T>::LD;
+  constexpr int NC = N / 64, KC = K / 64;
+  constexpr bool SPLIT_N = N > 64;           // waves split the n-tiles (K == 64) or the k-tiles (N == 64)
+  static_assert(!SPLIT_N || K == 64, "tn_wide: unsupported shape");
+  constexpr int NT_W = SPLIT_N ? N / 64 : 4;
+  constexpr int KT_W = SPLIT_N ? 4 : K / 64;
+  typedef typename Frag<T>::type frag_t;
+  typedef typename Pair<T>::type pair_t;
+  T* sY = reinterpret_cast<T*>(smem);
+  T* sX = sY + N * LD;
+  float* sB = reinterpret_cast<float*>(sX + K * LD);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int half = lane >> 5, cl = (lane & 31) * 2;
+  const int mb = bz * p.mpb, me = min(p.M, mb + p.mpb);
+  const T* __restrict__ Y = reinterpret_cast<const T*>(p.y);
+  const T* __restrict__ X = reinterpret_cast<const T*>(p.x);
+  pair_t yv[NC][8], xv[KC][8];
+  float bs[NC][2];
+#pragma unroll
+  for (int q = 0; q < NC; ++q) bs[q][0] = bs[q][1] = 0.f;
+  auto gload = [&](int ms) {
+    const int r0 = ms + wave * 16 + half * 8;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const bool ok = r0 + j < me;
+      const int64_t r = ok ? r0 + j : mb;  // unconditional loads from a row of this slab, selected below
+#pragma unroll
+      for (int q = 0; q < NC; ++q) {
+        const pair_t v = *reinterpret_cast<const pair_t*>(Y + r * N + q * 64 + cl);
+        yv[q][j] = ok ? v : pair_t{(T)0.f, (T)0.f};
+      }
+#pragma unroll
+      for (int q = 0; q < KC; ++q) {
+        const pair_t v = *reinterpret_cast<const pair_t*>(X + r * K + q * 64 + cl);
+        xv[q][j] = ok ? v : pair_t{(T)0.f, (T)0.f};
+      }
+    }
+  };
+  auto lstore = [&]() {
+    const int m0 = wave * 16 + half * 8;
+#pragma unroll
+    for (int q = 0; q < NC; ++q) {
+      T c0[8], c1[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        c0[j] = yv[q][j].x; c1[j] = yv[q][j].y;
+        bs[q][0] += (float)c0[j]; bs[q][1] += (float)c1[j];
+      }
+      st8raw(&sY[(q * 64 + cl) * LD + m0], c0);
+      st8raw(&sY[(q * 64 + cl + 1) * LD + m0], c1);
+    }
+#pragma unroll
+    for (int q = 0; q < KC; ++q) {
+      T c0[8], c1[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { c0[j] = xv[q][j].x; c1[j] = xv[q][j].y; }
+      st8raw(&sX[(q * 64 + cl) * LD + m0], c0);
+      st8raw(&sX[(q * 64 + cl + 1) * LD + m0], c1);
+    }
+  };
+  f32x4 acc[NT_W][KT_W];
+#pragma unroll
+  for (int i = 0; i < NT_W; ++i)
+#pragma unroll
+    for (int j = 0; j < KT_W; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int fr = lane & 15, fg = (lane >> 4) * 8;
+  const int nbase = SPLIT_N ? wave * NT_W : 0, kbase = SPLIT_N ? 0 : wave * KT_W;
+  if (mb < me) gload(mb);
+  for (int ms = mb; ms < me; ms += 64) {
+    lstore();
+    __syncthreads();
+    if (ms + 64 < me) gload(ms + 64);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      frag_t fx[KT_W];
+#pragma unroll
+      for (int j = 0; j < KT_W; ++j) fx[j] = *reinterpret_cast<const frag_t*>(&sX[((kbase + j) * 16 + fr) * LD + ks * 32 + fg]);
+#pragma unroll
+      for (int i = 0; i < NT_W; ++i) {
+        const frag_t fy = *reinterpret_cast<const frag_t*>(&sY[((nbase + i) * 16 + fr) * LD + ks * 32 + fg]);
+#pragma unroll
+        for (int j = 0; j < KT_W; ++j) mma_k32(acc[i][j], fx[j], fy);  // transposed tile: 4 consecutive k per lane
+      }
+    }
+    __syncthreads();
+  }
+  float* out = p.slab + (int64_t)bz * N * K;
+#pragma unroll
+  for (int i = 0; i < NT_W; ++i) {
+    const int n = (nbase + i) * 16 + fr;
+#pragma unroll
+    for (int j = 0; j < KT_W; ++j) {
+      const int k4 = (kbase + j) * 16 + (lane >> 4) * 4;
+      *reinterpret_cast<float4*>(out + (int64_t)n * K + k4) = float4{acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+    }
+  }
+  // bias grads: column sums of Y. Eight (wave, half) row groups hold partials of every column -> fixed-order sum
+  const int g = wave * 2 + half;
+#pragma unroll
+  for (int q = 0; q < NC; ++q) {
+    sB[g * N + q * 64 + cl] = bs[q][0];
+    sB[g * N + q * 64 + cl + 1] = bs[q][1];
+  }
+  __syncthreads();
+  if (tid < N) {
+    float t = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) t += sB[k * N + tid];
+    p.bslab[(int64_t)bz * N + tid] = t;
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void gemm_tn_wide_kernel(const TnWide* __restrict__ probs, int np) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char tn_wide_smem[];
+  int pi = 0;
+  for (int i = 1; i < np; ++i) pi = probs[i].blk0 <= (int)blockIdx.x ? i : pi;
+  const TnWide p = probs[pi];
+  const int bz = (int)blockIdx.x - p.blk0;
+  if (p.N == 256 && p.K == 64) tn_wide_body<T, 256, 64>(p, bz, tn_wide_smem);
+  else if (p.N == 192 && p.K == 64) tn_wide_body<T, 192, 64>(p, bz, tn_wide_smem);
+  else if (p.N == 64 && p.K == 256) tn_wide_body<T, 64, 256>(p, bz, tn_wide_smem);
+  else tn_wide_body<T, 64, 64>(p, bz, tn_wide_smem);
+}
+static inline bool tn_wide_shape(int N, int K) {
+  return (N == 256 && K == 64) || (N == 192 && K == 64) || (N == 64 && K == 256) || (N == 64 && K == 64);
+}
+
 // Sums the per-slab partials of one or more weight tensors and writes the PyTorch-layout gradients.
 // The packed k order of NHWC convs / NHWC flatten is (tap, c); PyTorch's is (c, tap): kt = (k % Cin) * taps + k / Cin.
 struct RedDesc {

@@ -101,6 +101,13 @@ __device__ __forceinline__ void st4(__bf16* p, float a, float b, float c, float 
 __device__ __forceinline__ void st4(float* p, float a, float b, float c, float d) {
   *reinterpret_cast<float4*>(p) = float4{a, b, c, d};
 }
+// 4 consecutive elements (8/16-byte load) -> float4
+__device__ __forceinline__ float4 ld4(const __bf16* p) {
+  typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+  const bf16x4 v = *reinterpret_cast<const bf16x4*>(p);
+  return float4{(float)v[0], (float)v[1], (float)v[2], (float)v[3]};
+}
+__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 template <int MT, int NTW> __device__ __forceinline__ void zero_acc(f32x4 (&acc)[MT][NTW]) {
 #pragma unroll
   for (int i = 0; i < MT; ++i)
@@ -371,8 +378,10 @@ struct InfLayer {
   const float *bin, *bo, *b1, *b2, *g1, *be1, *g2, *be2;
   const float* xin;                      // [E*17][64] fp32
   float* xout;
-  // training forward: what the backward pass needs (all null for inference)
-  float *s_qkv, *s_P, *s_ctx, *s_xh1, *s_rs1, *s_x1, *s_f, *s_xh2, *s_rs2;
+  // training forward: what the backward pass needs (all null for inference). fp32: qkv, P, xhat / rstd of both norms;
+  // in the contraction type T (they are only ever weight-grad operands / a ReLU mask): the layer input, ctx, x1, f
+  float *s_qkv, *s_P, *s_xh1, *s_rs1, *s_xh2, *s_rs2;
+  void *s_xin, *s_ctx, *s_x1, *s_f;
 };
 struct InfLayerPair { InfLayer n[2]; };
 
@@ -428,10 +437,10 @@ __device__ __forceinline__ float dot64(const float* a, const float* b) {  // 16-
 }
 
 // LayerNorm of the ROWS LDS rows; optionally (training) saves xhat / rstd / the output rows < nrows to global memory
-template <int ROWS, int U>
+template <int ROWS, int U, typename SO>
 __device__ __forceinline__ void ln_rows(const float* z, int ldz, float* out, int ldo, const float* __restrict__ g,
                                         const float* __restrict__ be, int wave, int lane, int nrows, float* s_xh,
-                                        float* s_rs, float* s_out) {
+                                        float* s_rs, SO* s_out) {
   const float gg = g[lane], bb = be[lane];
   // wave w owns rows w, w+4, ...: U independent rows are kept in flight (their reduce chains interleave)
   for (int r0 = wave; r0 < ROWS; r0 += 4 * U) {
@@ -451,7 +460,7 @@ __device__ __forceinline__ void ln_rows(const float* z, int ldz, float* out, int
       if (out != nullptr) out[r * ldo + lane] = o;
       if (r < nrows) {
         if (s_xh != nullptr) { s_xh[r * TD + lane] = xh; if (lane == 0) s_rs[r] = rs; }
-        if (s_out != nullptr) s_out[r * TD + lane] = o;
+        if (s_out != nullptr) s_out[r * TD + lane] = (SO)o;
       }
     }
   }
@@ -483,6 +492,7 @@ __global__ __launch_bounds__(256) void infer_layer_kernel(InfLayerPair pr, InfHe
   const int s0 = blockIdx.x * SPW;
   const int ns = min(SPW, E - s0);
   const int nrows = ns * NTOK;
+  const int64_t row0 = (int64_t)s0 * NTOK;  // first token row of this block
   long long t_step = 0;
   if constexpr (HEAD) { if (fin.ctl != nullptr) t_step = fin.ctl->t; }
   const float* xg = w.xin + (int64_t)s0 * NTOK * TD;
@@ -491,6 +501,7 @@ __global__ __launch_bounds__(256) void infer_layer_kernel(InfLayerPair pr, InfHe
     const bool ok = r < nrows;
     const float4 v = *reinterpret_cast<const float4*>(xg + (ok ? r : 0) * TD + c4);
     *reinterpret_cast<float4*>(xs + r * LY::LDX + c4) = ok ? v : float4{0.f, 0.f, 0.f, 0.f};
+    if (w.s_xin != nullptr && ok) st4(reinterpret_cast<T*>(w.s_xin) + (row0 + r) * TD + c4, v.x, v.y, v.z, v.w);
   }
   __syncthreads();
   INF_STAMP(1);
@@ -511,7 +522,6 @@ __global__ __launch_bounds__(256) void infer_layer_kernel(InfLayerPair pr, InfHe
   }
   __syncthreads();
   INF_STAMP(2);
-  const int64_t row0 = (int64_t)s0 * NTOK;  // first token row of this block
   if (w.s_qkv != nullptr) {
     for (int idx = tid; idx < nrows * 48; idx += 256) {  // 48 float4 per row of 192
       const int r = idx / 48, c4 = (idx - r * 48) * 4;
@@ -551,7 +561,7 @@ __global__ __launch_bounds__(256) void infer_layer_kernel(InfLayerPair pr, InfHe
         const float* p = sp + r * ATT_PLD;
 #pragma unroll
         for (int j = 0; j < NTOK; ++j) a = fmaf(p[j], v[j * LY::LDQ], a);
-        if (w.s_ctx != nullptr) w.s_ctx[(row0 + r) * TD + lane] = a;
+        if (w.s_ctx != nullptr) reinterpret_cast<T*>(w.s_ctx)[(row0 + r) * TD + lane] = (T)a;
       }
       cx[r * LY::LDX + lane] = a;
     }
@@ -575,8 +585,9 @@ __global__ __launch_bounds__(256) void infer_layer_kernel(InfLayerPair pr, InfHe
   }
   __syncthreads();
   INF_STAMP(4);
-  ln_rows<ROWS, U>(big, LY::LDX, xs, LY::LDX, w.g1, w.be1, wave, lane, nrows, w.s_xh1 ? w.s_xh1 + row0 * TD : nullptr,
-                   w.s_rs1 ? w.s_rs1 + row0 : nullptr, w.s_x1 ? w.s_x1 + row0 * TD : nullptr);  // x1 -> xs
+  ln_rows<ROWS, U, T>(big, LY::LDX, xs, LY::LDX, w.g1, w.be1, wave, lane, nrows, w.s_xh1 ? w.s_xh1 + row0 * TD : nullptr,
+                      w.s_rs1 ? w.s_rs1 + row0 : nullptr,
+                      w.s_x1 ? reinterpret_cast<T*>(w.s_x1) + row0 * TD : nullptr);  // x1 -> xs
   __syncthreads();
   INF_STAMP(5);
   T* f = reinterpret_cast<T*>(big);
@@ -594,7 +605,8 @@ __global__ __launch_bounds__(256) void infer_layer_kernel(InfLayerPair pr, InfHe
         const float f0 = fmaxf(acc[mt][j][0] + bb.x, 0.f), f1 = fmaxf(acc[mt][j][1] + bb.y, 0.f);
         const float f2 = fmaxf(acc[mt][j][2] + bb.z, 0.f), f3 = fmaxf(acc[mt][j][3] + bb.w, 0.f);
         st4(f + (mt * 16 + fr) * LY::LDF + n4, f0, f1, f2, f3);
-        if (w.s_f != nullptr && mt * 16 + fr < nrows) st4(w.s_f + (row0 + mt * 16 + fr) * 256 + n4, f0, f1, f2, f3);
+        if (w.s_f != nullptr && mt * 16 + fr < nrows)
+          st4(reinterpret_cast<T*>(w.s_f) + (row0 + mt * 16 + fr) * 256 + n4, f0, f1, f2, f3);
       }
     }
   }
@@ -616,7 +628,7 @@ __global__ __launch_bounds__(256) void infer_layer_kernel(InfLayerPair pr, InfHe
   }
   __syncthreads();
   INF_STAMP(7);
-  ln_rows<ROWS, U>(cx, LY::LDX, HEAD ? xs : nullptr, LY::LDX, w.g2, w.be2, wave, lane, nrows,
+  ln_rows<ROWS, U, float>(cx, LY::LDX, HEAD ? xs : nullptr, LY::LDX, w.g2, w.be2, wave, lane, nrows,
                    w.s_xh2 ? w.s_xh2 + row0 * TD : nullptr, w.s_rs2 ? w.s_rs2 + row0 : nullptr, w.xout + row0 * TD);
   INF_STAMP(8);
   if constexpr (HEAD) {

@@ -44,7 +44,8 @@ struct Conv {        // nn.Conv2d, square kernel, no padding. Activations NHWC, 
 struct LNp { int g = -1, b = -1; };
 struct TLayer { Lin inproj, outproj, ff1, ff2; LNp ln1, ln2; };
 
-struct LayerWs { int64_t qkv, P, ctx, xh1, rs1, x1, f, xh2, rs2; };
+// fused layer kernels keep xin (copy of the layer input), ctx, x1, f in the contraction type T inside these fp32-sized slots
+struct LayerWs { int64_t qkv, P, ctx, xh1, rs1, x1, f, xh2, rs2, xin; };
 // backward: every layer keeps its own gradient tensors alive until the grouped weight-grad launch at the end
 struct LayerBw { int64_t dz2, df, dx1, dz1, dctx, dqkv; };
 struct Layout {
@@ -96,6 +97,10 @@ struct v4l_net {
   static constexpr int MAX_RED = 96;
   static constexpr int MAX_TNP = 64;
   v4l::TnProb* d_tnp = nullptr;
+  static constexpr int MAX_WIDE = 16;
+  v4l::TnWide* d_wide = nullptr;
+  std::vector<v4l::TnWide> wide, wide_cached;  // whole-output weight-grad problems of the fused transformer layers
+  double wide_flops = 0;
   double tnp_flops = 0;
   std::vector<v4l::TnProb> tnp, tnp_cached;   // deferred dense weight-grad problems of the current / last backward
   std::vector<v4l::RedDesc> red, red_cached;  // weight-grad reduce descriptors of the current / last backward
@@ -114,6 +119,7 @@ struct v4l_net {
   // stage: 0 = whole net, 1 = encoder only (up to the token / concat tensor), 2 = trunk + head only
   template <typename T> int forward_t(const float* state, const T* image, const int* rowidx, int n, float* ws, hipStream_t s,
                                       const float* enc_ws = nullptr, int stage = 0);
+  bool fused_layers() const;  // the transformer layers run as fused forward / backward launches (csrc/infer.h, bwd.h)
   template <typename T> int backward_t(const float* state, const T* image, const int* rowidx, int n, float* ws, float* grads, hipStream_t s);
 };
 

@@ -201,6 +201,28 @@ static int wgrad_finish(Ctx& c) {
                 (const TnProb*)net->d_tnp, (int)net->tnp.size());
     V4L_LAUNCH_CHECK();
   }
+  if (!net->wide.empty()) {
+    V4L_REQUIRE(net->wide.size() <= (size_t)v4l_net::MAX_WIDE, "internal: too many fused-layer weight-grads");
+    int tb = 0;
+    for (TnWide& q : net->wide) { const int nb = q.blk0; q.blk0 = tb; tb += nb; }
+    const size_t bytes = net->wide.size() * sizeof(TnWide);
+    if (net->wide_cached.size() != net->wide.size() || memcmp(net->wide_cached.data(), net->wide.data(), bytes) != 0) {
+      V4L_REQUIRE(!capturing(c.s), "internal: weight-grad geometry changed while capturing a graph");
+      V4L_HIP_CHECK(hipStreamSynchronize(c.s));
+      V4L_HIP_CHECK(hipMemcpy(net->d_wide, net->wide.data(), bytes, hipMemcpyHostToDevice));
+      net->wide_cached = net->wide;
+    }
+    static bool attr_done = false;
+    if (!attr_done) {
+      V4L_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_wide_kernel<T>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)TnWideLds<T>::max_bytes));
+      attr_done = true;
+    }
+    g_op = "layer.wgrad";
+    V4L_KLAUNCH("gemm_tn_wide", net->wide_flops, c.s, gemm_tn_wide_kernel<T>, dim3((unsigned)tb), dim3(256),
+                TnWideLds<T>::max_bytes, c.s, (const TnWide*)net->d_wide, (int)net->wide.size());
+    V4L_LAUNCH_CHECK();
+  }
   int64_t blk = 0;
   for (RedDesc& d : net->red) { d.blk0 = blk; blk += cdiv64((int64_t)d.N * d.K + d.N, 64); }
   V4L_REQUIRE(net->red.size() <= (size_t)v4l_net::MAX_RED, "internal: too many weight-grad descriptors");
@@ -256,6 +278,35 @@ static int lin_wgrad(Ctx& c, const Lin& L, const ADense& y, const ADense& x, int
   o.db = c.grads + net->params[L.b].goff;
   o.N = L.N; o.K = L.K; o.Ktorch = L.K; o.Cin = L.cin; o.taps = L.taps;
   o.slab = p.slab; o.bslab = p.bslab; o.nsplit = splits; o.Npad = p.Npad; o.Kpad = p.Kpad;
+  net->red.push_back(o);
+  return 0;
+}
+// Weight-grad of a transformer-layer linear whose operands y [M][N], x [M][K] the fused layer kernels left in the
+// contraction type: one block per row slab owns the whole N x K output (gemm_tn_wide_kernel)
+static int lin_wgrad_wide(Ctx& c, const Lin& L, const void* y, const void* x, int M) {
+  v4l_net* net = c.net;
+  V4L_REQUIRE(tn_wide_shape(L.N, L.K), "internal: lin_wgrad_wide on an unsupported shape");
+  TnWide p;
+  memset(&p, 0, sizeof(p));
+  p.y = y; p.x = x; p.M = M; p.N = L.N; p.K = L.K;
+  int splits = std::max(1, std::min(64, M / 256));
+  p.mpb = round_up(cdiv(M, splits), 64);
+  splits = cdiv(M, p.mpb);
+  const int64_t slab_f = ((int64_t)splits * p.N * p.K + 63) / 64 * 64;
+  const int64_t bslab_f = ((int64_t)splits * p.N + 63) / 64 * 64;
+  p.slab = c.slab + c.slab_used;
+  p.bslab = p.slab + slab_f;
+  c.slab_used += slab_f + bslab_f;
+  V4L_REQUIRE(c.slab_used <= net->slab_cap, "internal: weight-grad slab arena overflow");
+  p.blk0 = splits;  // block count for now; prefix-summed in wgrad_finish
+  net->wide.push_back(p);
+  net->wide_flops += 2.0 * M * L.N * L.K;
+  RedDesc o;
+  memset(&o, 0, sizeof(o));
+  o.dW = c.grads + net->params[L.w].goff;
+  o.db = c.grads + net->params[L.b].goff;
+  o.N = L.N; o.K = L.K; o.Ktorch = L.K; o.Cin = L.cin; o.taps = L.taps;
+  o.slab = p.slab; o.bslab = p.bslab; o.nsplit = splits; o.Npad = p.N; o.Kpad = p.K;
   net->red.push_back(o);
   return 0;
 }
@@ -600,7 +651,10 @@ int v4l_net::build() {
 
 int64_t v4l_net::table_bytes() const {
   return (int64_t)(packs.size() * sizeof(PackDesc) + params.size() * sizeof(ParamSeg) + MAX_RED * sizeof(RedDesc) +
-                   MAX_TNP * sizeof(TnProb) + 1024);
+                   MAX_TNP * sizeof(TnProb) + MAX_WIDE * sizeof(TnWide) + 1024);
+}
+bool v4l_net::fused_layers() const {
+  return cfg.kind == V4L_NET_LOCO && cfg.ff_dim == 256 && getenv("V4L_NO_FUSED_LAYER") == nullptr;
 }
 
 // Upper bound of the weight-grad slab arena for a batch of n: every weight tensor with the row count its
@@ -609,7 +663,7 @@ int64_t v4l_net::slab_floats(int n) const {
   int64_t tot = 0;
   auto add = [&](int M, int N, int Kx) {   // conv weight-grads (tn_plan) and, conservatively, dense ones
     const TnPlan p = tn_plan(M, N, Kx, cfg.compute == V4L_BF16);
-    const int64_t dense_splits = 32;
+    const int64_t dense_splits = 64;
     const int64_t np = round_up(N, 64), kp = round_up(Kx, 64);
     tot += std::max<int64_t>(p.slab_floats + p.bslab_floats, dense_splits * np * (kp + 1) + 128);
   };
@@ -660,6 +714,7 @@ Layout v4l_net::layout(int n) const {
       w.f = take(R * c.ff_dim);
       w.xh2 = take(R * TD);
       w.rs2 = take(R);
+      w.xin = take(R * TD);
       L.lw.push_back(w);
     }
     L.ytmp = take(R * TD);
@@ -777,7 +832,7 @@ int v4l_net::forward_t(const float* state, const T* image, const int* rowidx, in
     }
     if (stage == 1) return 0;
     const int R = n * NTOK;
-    const bool fused_layers = c.ff_dim == 256 && getenv("V4L_NO_FUSED_LAYER") == nullptr;
+    const bool fused_layers = this->fused_layers();
     // the last layer's blocks also run the pooled heads of their samples when the head stack has the shipped shape
     const bool fused_head = fused_layers && c.n_layers >= 1 && nh == 2 && c.head_hidden[0] == 256 && c.head_hidden[1] == 256 &&
                             c.out_dim <= OUT_LD && getenv("V4L_NO_FUSED_HEAD") == nullptr;
@@ -804,6 +859,7 @@ int v4l_net::forward_t(const float* state, const T* image, const int* rowidx, in
       d.xout = ws + L.x[l + 1];
       d.s_qkv = ws + w.qkv; d.s_P = ws + w.P; d.s_ctx = ws + w.ctx; d.s_xh1 = ws + w.xh1; d.s_rs1 = ws + w.rs1;
       d.s_x1 = ws + w.x1; d.s_f = ws + w.f; d.s_xh2 = ws + w.xh2; d.s_rs2 = ws + w.rs2;
+      d.s_xin = sizeof(T) == 2 ? ws + w.xin : nullptr;  // fp32 mode: the fp32 token tensor itself is the operand
       InfHeadPair hd;
       memset(&hd, 0, sizeof(hd));
       InfFinish fin;
@@ -868,6 +924,8 @@ int v4l_net::backward_t(const float* state, const T* image, const int* rowidx, i
   red.clear();
   tnp.clear();
   tnp_flops = 0;
+  wide.clear();
+  wide_flops = 0;
   slab_cap = slab_floats(n);
   int rc;
   const int ne = c.n_enc_hidden, nh = c.n_head_hidden;
@@ -923,7 +981,7 @@ int v4l_net::backward_t(const float* state, const T* image, const int* rowidx, i
 
   // ---- LocoTransformer
   const int R = n * NTOK;
-  const bool fused_bwd = c.ff_dim == 256 && getenv("V4L_NO_FUSED_LAYER_BWD") == nullptr;
+  const bool fused_bwd = fused_layers();  // forward and backward switch together: they share the T-typed saves
   // the last layer's launch starts from dout (heads + un-pool), layer 0's launch continues into the encoder MLP / up-conv
   const bool fused_head = fused_bwd && c.n_layers >= 1 && nh == 2 && c.head_hidden[0] == 256 && c.head_hidden[1] == 256 &&
                           getenv("V4L_NO_FUSED_HEAD_BWD") == nullptr;
@@ -1006,10 +1064,11 @@ int v4l_net::backward_t(const float* state, const T* image, const int* rowidx, i
       r.nsplit = nblk; r.N = 1; r.K = TD; r.Npad = 1; r.Kpad = TD; r.Ktorch = TD;
       red.push_back(r);
     }
-    if ((rc = lin_wgrad<T>(cx, t.ff2, dense(ws + b.dz2, TD, R, TD), dense(ws + w.f, c.ff_dim, R, c.ff_dim), c.ff_dim))) return rc;
-    if ((rc = lin_wgrad<T>(cx, t.ff1, dense(ws + b.df, c.ff_dim, R, c.ff_dim), dense(ws + w.x1, TD, R, TD), TD))) return rc;
-    if ((rc = lin_wgrad<T>(cx, t.outproj, dense(ws + b.dz1, TD, R, TD), dense(ws + w.ctx, TD, R, TD), TD))) return rc;
-    if ((rc = lin_wgrad<T>(cx, t.inproj, dense(ws + b.dqkv, 3 * TD, R, 3 * TD), dense(ws + L.x[l], TD, R, TD), TD))) return rc;
+    const float* xin = sizeof(T) == 2 ? ws + w.xin : ws + L.x[l];
+    if ((rc = lin_wgrad_wide(cx, t.ff2, ws + b.dz2, ws + w.f, R))) return rc;
+    if ((rc = lin_wgrad_wide(cx, t.ff1, ws + b.df, ws + w.x1, R))) return rc;
+    if ((rc = lin_wgrad_wide(cx, t.outproj, ws + b.dz1, ws + w.ctx, R))) return rc;
+    if ((rc = lin_wgrad_wide(cx, t.inproj, ws + b.dqkv, xin, R))) return rc;
   }
   for (int l = c.n_layers - 1; l >= 0 && !fused_bwd; --l) {
     const TLayer& t = layers[l];
@@ -1129,7 +1188,8 @@ static int run_actor_fused(v4l_actor* a, const float* obs, const float* eps, flo
     d.bin = net->p[t.inproj.b]; d.bo = net->p[t.outproj.b]; d.b1 = net->p[t.ff1.b]; d.b2 = net->p[t.ff2.b];
     d.g1 = net->p[t.ln1.g]; d.be1 = net->p[t.ln1.b]; d.g2 = net->p[t.ln2.g]; d.be2 = net->p[t.ln2.b];
     d.xin = xin; d.xout = xout;
-    d.s_qkv = d.s_P = d.s_ctx = d.s_xh1 = d.s_rs1 = d.s_x1 = d.s_f = d.s_xh2 = d.s_rs2 = nullptr;
+    d.s_qkv = d.s_P = d.s_xh1 = d.s_rs1 = d.s_xh2 = d.s_rs2 = nullptr;
+    d.s_xin = d.s_ctx = d.s_x1 = d.s_f = nullptr;
   };
   const int nl = pf->cfg.n_layers;
   for (int l = 0; l < nl; ++l) {
@@ -1273,6 +1333,7 @@ int v4l_net_bind(v4l_net* net, float* const* params_dev, void* packed_dev, void*
   net->d_red = (RedDesc*)((char*)net->d_segs + (net->params.size() * sizeof(ParamSeg) + 63) / 64 * 64);
   net->red_cached.clear();
   net->d_tnp = (TnProb*)((char*)net->d_red + (v4l_net::MAX_RED * sizeof(RedDesc) + 63) / 64 * 64);
+  net->d_wide = (TnWide*)((char*)net->d_tnp + (v4l_net::MAX_TNP * sizeof(TnProb) + 63) / 64 * 64);
   net->tnp_cached.clear();
   // synchronous pageable copies: the host vectors die at return
   V4L_HIP_CHECK(hipStreamSynchronize(s));
