@@ -111,4 +111,10 @@ __device__ __forceinline__ float wave_min(float v) {
   return fminf(fminf(lane_bcast(v, 0), lane_bcast(v, 16)), fminf(lane_bcast(v, 32), lane_bcast(v, 48)));
 }
 
+// A pointer read out of a device-side table is a generic ("flat") pointer to the compiler: its loads become flat_load,
+// which also tick the LDS counter (lgkmcnt) and so serialise against every ds_read of the MFMA loop. Such pointers
+// are converted to address space 1 and dereferenced AS global pointers (-> global_load / global_store).
+#define V4L_GLOBAL __attribute__((address_space(1)))
+template <typename P> __device__ __forceinline__ V4L_GLOBAL P* as_global(P* p) { return (V4L_GLOBAL P*)p; }
+
 }  // namespace v4l

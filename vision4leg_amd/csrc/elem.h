@@ -637,18 +637,19 @@ struct PackDesc {
 template <typename T>
 __global__ __launch_bounds__(256) void pack_kernel(const PackDesc* __restrict__ descs, int nd, T* __restrict__ dst) {
   const PackDesc d = descs[find_desc(descs, nd, (int64_t)blockIdx.x)];
+  const V4L_GLOBAL float* src = as_global(d.src);
   const int64_t e = ((int64_t)blockIdx.x - d.blk0) * 256 + threadIdx.x;
   if (e >= (int64_t)d.R * d.Cc) return;
   const int r = (int)(e / d.Cc), c = (int)(e - (int64_t)r * d.Cc);
   float val = 0.f;
   switch (d.kind) {
-    case PK_NT: if (r < d.N && c < d.K) val = d.src[(int64_t)r * d.K + c]; break;
-    case PK_T: if (r < d.K && c < d.N) val = d.src[(int64_t)c * d.K + r]; break;
+    case PK_NT: if (r < d.N && c < d.K) val = src[(int64_t)r * d.K + c]; break;
+    case PK_T: if (r < d.K && c < d.N) val = src[(int64_t)c * d.K + r]; break;
     case PK_CONV_NHWC:  // dst[n][tap*Cin+ci] = W[n][ci][tap]
-      if (r < d.N && c < d.K) { const int tap = c / d.Cin, ci = c - tap * d.Cin; val = d.src[(int64_t)r * d.K + ci * d.taps + tap]; }
+      if (r < d.N && c < d.K) { const int tap = c / d.Cin, ci = c - tap * d.Cin; val = src[(int64_t)r * d.K + ci * d.taps + tap]; }
       break;
     case PK_CONV_NHWC_T:  // dst[tap*Cin+ci][n] = W[n][ci][tap]
-      if (r < d.K && c < d.N) { const int tap = r / d.Cin, ci = r - tap * d.Cin; val = d.src[(int64_t)c * d.K + ci * d.taps + tap]; }
+      if (r < d.K && c < d.N) { const int tap = r / d.Cin, ci = r - tap * d.Cin; val = src[(int64_t)c * d.K + ci * d.taps + tap]; }
       break;
     case PK_CONV_DGRAD: {  // dst[ci][(a*TW+bb)*N + n] = W[n][ci][py+s*a][px+s*bb]
       const int kk = d.TW * d.TW * d.N;
@@ -656,7 +657,7 @@ __global__ __launch_bounds__(256) void pack_kernel(const PackDesc* __restrict__ 
         const int tap = c / d.N, n = c - tap * d.N;
         const int a = tap / d.TW, bb = tap - a * d.TW;
         const int ky = d.py + d.s * a, kx = d.px + d.s * bb;
-        val = d.src[(int64_t)n * d.K + r * d.taps + ky * d.KW + kx];
+        val = src[(int64_t)n * d.K + r * d.taps + ky * d.KW + kx];
       }
     } break;
   }

@@ -590,6 +590,39 @@ struct TnProb {
   float* bslab;
   int64_t blk0;  // first block of this problem
 };
+// ADense as the weight-grad staging code uses it, for descriptors that were read from a device-side table: the same
+// addressing, with the pointers held as global (address space 1) pointers so that the loads are global_load
+struct ADenseG {
+  const V4L_GLOBAL float* p;
+  const V4L_GLOBAL int* rowidx;
+  const V4L_GLOBAL float* mask;
+  int lda, M, K, tokmap;
+  __device__ __forceinline__ explicit ADenseG(const ADense& a)
+      : p(as_global(a.p)), rowidx(as_global(a.rowidx)), mask(as_global(a.mask)), lda(a.lda), M(a.M), K(a.K), tokmap(a.tokmap) {}
+  struct RowIt { int m; };
+  __device__ __forceinline__ RowIt iter(int m) const { return RowIt{m}; }
+  __device__ __forceinline__ void next(RowIt& it) const { ++it.m; }
+  __device__ __forceinline__ int64_t off(const RowIt& it, int& valid) const {
+    const int m = it.m;
+    valid = m < M;
+    int r = m;
+    if (tokmap == 1) r = (m >> 4) * 17 + 1 + (m & 15);
+    if (a_rowidx()) r = rowidx[valid ? m : 0];
+    return (int64_t)r * lda;
+  }
+  __device__ __forceinline__ bool a_rowidx() const { return rowidx != nullptr; }
+  __device__ __forceinline__ int64_t col_off(int k, int& valid) const { valid = k < K; return k; }
+  __device__ __forceinline__ float get(int64_t o) const {
+    const float v = p[o];
+    if (mask == nullptr) return v;  // uniform branch
+    const float mk = mask[o];
+    return mk > 0.f ? v : 0.f;
+  }
+  template <int W> __device__ __forceinline__ void getv(int64_t o, float (&v)[W]) const {
+#pragma unroll
+    for (int i = 0; i < W; ++i) v[i] = get(o + i);
+  }
+};
 template <typename T>
 __global__ __launch_bounds__(256) void gemm_tn_group_kernel(const TnProb* __restrict__ probs, int np) {
   int lo = 0, hi = np - 1;
@@ -600,7 +633,8 @@ __global__ __launch_bounds__(256) void gemm_tn_group_kernel(const TnProb* __rest
   const TnProb p = probs[lo];
   const int lb = (int)((int64_t)blockIdx.x - p.blk0);
   const int bx = lb % p.gx, t = lb / p.gx;
-  tn_body<T, 64, 1, ADense, ADense>(p.y, p.x, p.M, p.mpb, p.slab, p.bslab, p.Npad, p.Kpad, bx, t % p.gy, t / p.gy);
+  tn_body<T, 64, 1, ADenseG, ADenseG>(ADenseG(p.y), ADenseG(p.x), p.M, p.mpb, p.slab, p.bslab, p.Npad, p.Kpad, bx, t % p.gy,
+                                      t / p.gy);
 }
 
 // ------------------------------------------------------------------------------------ gemm_tn_wide
@@ -619,7 +653,7 @@ struct TnWide {
 };
 template <typename T> struct Pair;
 template <> struct Pair<__bf16> { typedef __attribute__((ext_vector_type(2))) __bf16 type; };
-template <> struct Pair<float> { typedef float2 type; };
+template <> struct Pair<float> { typedef __attribute__((ext_vector_type(2))) float type; };
 __device__ __forceinline__ void st8raw(__bf16* dst, const __bf16 (&v)[8]) {
   bf16x8 t;
 #pragma unroll
@@ -652,8 +686,9 @@ __device__ __forceinline__ void tn_wide_body(const TnWide& p, int bz, unsigned c
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int half = lane >> 5, cl = (lane & 31) * 2;
   const int mb = bz * p.mpb, me = min(p.M, mb + p.mpb);
-  const T* __restrict__ Y = reinterpret_cast<const T*>(p.y);
-  const T* __restrict__ X = reinterpret_cast<const T*>(p.x);
+  const V4L_GLOBAL T* Y = as_global(reinterpret_cast<const T*>(p.y));
+  const V4L_GLOBAL T* X = as_global(reinterpret_cast<const T*>(p.x));
+  typedef const V4L_GLOBAL pair_t* gpair_t;
   pair_t yv[NC][8], xv[KC][8];
   float bs[NC][2];
 #pragma unroll
@@ -666,12 +701,12 @@ __device__ __forceinline__ void tn_wide_body(const TnWide& p, int bz, unsigned c
       const int64_t r = ok ? r0 + j : mb;  // unconditional loads from a row of this slab, selected below
 #pragma unroll
       for (int q = 0; q < NC; ++q) {
-        const pair_t v = *reinterpret_cast<const pair_t*>(Y + r * N + q * 64 + cl);
+        const pair_t v = *(gpair_t)(Y + r * N + q * 64 + cl);
         yv[q][j] = ok ? v : pair_t{(T)0.f, (T)0.f};
       }
 #pragma unroll
       for (int q = 0; q < KC; ++q) {
-        const pair_t v = *reinterpret_cast<const pair_t*>(X + r * K + q * 64 + cl);
+        const pair_t v = *(gpair_t)(X + r * K + q * 64 + cl);
         xv[q][j] = ok ? v : pair_t{(T)0.f, (T)0.f};
       }
     }
@@ -724,14 +759,14 @@ __device__ __forceinline__ void tn_wide_body(const TnWide& p, int bz, unsigned c
     }
     __syncthreads();
   }
-  float* out = p.slab + (int64_t)bz * N * K;
+  V4L_GLOBAL float* out = as_global(p.slab) + (int64_t)bz * N * K;
 #pragma unroll
   for (int i = 0; i < NT_W; ++i) {
     const int n = (nbase + i) * 16 + fr;
 #pragma unroll
     for (int j = 0; j < KT_W; ++j) {
       const int k4 = (kbase + j) * 16 + (lane >> 4) * 4;
-      *reinterpret_cast<float4*>(out + (int64_t)n * K + k4) = float4{acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+      *(V4L_GLOBAL f32x4*)(out + (int64_t)n * K + k4) = acc[i][j];
     }
   }
   // bias grads: column sums of Y. Eight (wave, half) row groups hold partials of every column -> fixed-order sum
@@ -746,7 +781,7 @@ __device__ __forceinline__ void tn_wide_body(const TnWide& p, int bz, unsigned c
     float t = 0.f;
 #pragma unroll
     for (int k = 0; k < 8; ++k) t += sB[k * N + tid];
-    p.bslab[(int64_t)bz * N + tid] = t;
+    as_global(p.bslab)[(int64_t)bz * N + tid] = t;
   }
 }
 
@@ -789,16 +824,16 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const RedDesc* __rest
   const int o = threadIdx.x & 63, g = threadIdx.x >> 6;
   const int64_t e = ((int64_t)blockIdx.x - d.blk0) * 64 + o;
   const int64_t nk = (int64_t)d.N * d.K;
-  const float* p = nullptr;
+  const V4L_GLOBAL float* p = nullptr;
   int64_t stride = 0;
   int n = 0, k = 0;
   if (e < nk) {
     n = (int)(e / d.K); k = (int)(e - (int64_t)n * d.K);
-    p = d.slab + (int64_t)n * d.Kpad + k;
+    p = as_global(d.slab) + (int64_t)n * d.Kpad + k;
     stride = (int64_t)d.Npad * d.Kpad;
   } else if (d.db != nullptr && e < nk + d.N) {
     n = (int)(e - nk);
-    p = d.bslab + n;
+    p = as_global(d.bslab) + n;
     stride = d.Npad;
   }
   float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
@@ -816,9 +851,9 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const RedDesc* __rest
     if (e < nk) {
       int kt = k;
       if (d.Cin != 0) { const int t = k / d.Cin, c = k - t * d.Cin; kt = c * d.taps + t; }
-      d.dW[(int64_t)n * d.Ktorch + kt] = sum;
+      as_global(d.dW)[(int64_t)n * d.Ktorch + kt] = sum;
     } else {
-      d.db[n] = sum;
+      as_global(d.db)[n] = sum;
     }
   }
 }
