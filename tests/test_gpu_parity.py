@@ -462,3 +462,43 @@ def test_stored_logp_equals_target_forward(mode, device):
     assert np.allclose(ss[:, :18], st[:, :18], rtol=10 * tol, atol=10 * tol), np.abs(ss[:, :18] - st[:, :18]).max()
     drift = sum((ps[k] - pt[k]).abs().sum().item() for k in ps) / sum(v.numel() for v in ps.values())
     assert drift <= (1e-6 if mode == "f32" else 5e-5), drift
+
+
+@pytest.mark.parametrize("mode", MODES)
+@pytest.mark.parametrize("name", ["loco_s93", "cnn_s93"])
+def test_fused_conv_backward_equals_layerwise(name, mode, device):
+    """bwd_conv_kernel / bwd_conv3_wgrad_kernel (one persistent launch, dc2/dc1 and the weight-grad partials on chip) vs
+    the layer-by-layer conv backward (gemm_tn weight-grads + gather-form data-grads): same rounding points, only the
+    fp32 summation order differs."""
+    case = util.CASES[name]
+    n = case["B"]
+    b = util.make_batch(case)
+    obs = torch.tensor(b["obs"], dtype=torch.float32)
+    rs = np.random.RandomState(9)
+    w = torch.tensor(rs.randn(n, 1), dtype=torch.float32)
+    got = {}
+    for fused in (True, False):
+        if fused:
+            os.environ.pop("V4L_NO_FUSED_CONV_BWD", None)
+        else:
+            os.environ["V4L_NO_FUSED_CONV_BWD"] = "1"
+        try:
+            pf, vf = _build(case, mode, device)
+            hip = vf.hip
+            st, im, _ = hip.stage(obs.to(device))
+            hip.forward(st, im, n, train=True)
+            dout = torch.zeros(n, 16, dtype=torch.float32, device=device)
+            dout[:, :1] = w.to(device)
+            grads = torch.zeros(hip.total_params, dtype=torch.float32, device=device)
+            hip.backward(st, im, n, dout, grads)
+            torch.cuda.synchronize()
+            got[fused] = {k: hip.grad_view(grads, k).cpu().clone() for k in hip.param_names}
+        finally:
+            os.environ.pop("V4L_NO_FUSED_CONV_BWD", None)
+    conv = [k for k in got[True] if ".convs." in k or "conv" in k.lower()]
+    assert len([k for k in conv if k.endswith("weight")]) >= 3, conv
+    tol = 1e-5 if mode == "f32" else 3e-3
+    errs = {k: util.rel_err(got[True][k], got[False][k]) for k in got[True]}
+    print("\n[fused conv bwd %s %s]" % (name, mode), {k: "%.1e" % errs[k] for k in conv})
+    for k, e in errs.items():
+        assert e <= tol, (k, e)

@@ -396,4 +396,355 @@ __global__ __launch_bounds__(256) void bwd_layer_kernel(BwdLayer w, BwdHead hd, 
   }
 }
 
+
+// ------------------------------------------------------------------------------------------ conv stack backward
+// bwd_conv_kernel: the whole NatureCNN backward (networks/base.py:304-342 reversed) for the shipped geometry
+// 4x64x64 -(k8 s4)-> 15x15x32 -(k4 s2)-> 6x6x64 -(k3 s1)-> 4x4x64, one sample at a time out of LDS:
+//   dc3 -> [dW3 += dc3^T col(c2)]  dcol = dc3 W3 -> col2im -> dc2 o [c2>0]
+//       -> [dW2 += dc2^T col(c1)]  dcol = dc2 W2 (one kernel row per pass) -> col2im -> dc1 o [c1>0]
+//       -> [dW1 += dc1^T col(image)]
+// Blocks are persistent (sample = blockIdx.x, += gridDim.x): the three weight-grads accumulate in REGISTERS across a
+// block's samples and leave the chip once per block as one slab each — every activation is read from HBM exactly once
+// and dc2 / dc1 never exist in HBM. bwd_conv_kernel (512 threads, 1 block per CU) carries dW2 and dW1 (20 MFMA tiles per
+// wave); dW3's 144 tiles would not fit beside them, so bwd_conv3_wgrad_kernel (256 threads, 36 tiles per wave) does that
+// contraction on its own from dc3 and c2 (13 KB per sample).
+struct BwdConv {
+  const void *w3t, *w2t;            // data-grad packs (T): [(ky,kx,ci)][co]: [576][64], [512][64]
+  const void* image;                // T [slots][4][64][64]
+  const int* rowidx;                // minibatch row -> rollout slot, or null
+  const float *c1, *c2;             // [n*225][32], [n*36][64] post-ReLU activations
+  const float* dc3;                 // [n*16][64] grad w.r.t. conv3's pre-activation (already ReLU-masked)
+  float *slab1, *slab2, *slab3;     // [gridDim.x][32][256], [gridDim.x][64][512], [gridDim.x][64][576]
+  float *bslab1, *bslab2, *bslab3;  // [gridDim.x][32], [gridDim.x][64], [gridDim.x][64]
+  int n;
+};
+template <typename T> struct BwdConvLds {
+  static constexpr bool B16 = sizeof(T) == 2;
+  static constexpr int LF = 64 + 4;                 // fp32 rows read as MFMA A operands
+  static constexpr int LC1 = 32 + (B16 ? 8 : 0);    // c1 rows (T)
+  static constexpr int LD1 = 32 + (B16 ? 4 : 0);    // dc1 rows (fp32)
+  static constexpr int LCOL3 = 576 + 4, LCOL2 = 128 + 4;
+  static constexpr int IMGP = B16 ? 1 : 2;          // image passes (fp32: two channels at a time)
+  static constexpr size_t dc3_b = (size_t)16 * LF * 4, c2_b = (size_t)36 * LF * 4, dc2_b = (size_t)48 * LF * 4;
+  static constexpr size_t c1_b = ((size_t)225 * LC1 * sizeof(T) + 15) / 16 * 16;
+  static constexpr size_t dc1_b = (size_t)225 * LD1 * 4;
+  static constexpr size_t buf_b = (size_t)16 * LCOL3 * 4;  // dcol3 | dcol2 pass [48][LCOL2] | image (pass)
+  static_assert(buf_b >= (size_t)48 * LCOL2 * 4 && buf_b >= (size_t)(4 / IMGP) * 4096 * sizeof(T), "bwd_conv: buffer");
+  static constexpr size_t bytes = dc3_b + c2_b + dc2_b + c1_b + dc1_b + buf_b;
+};
+
+// MFMA operand (row = lane&15, 8 consecutive contraction indices 8*(lane>>4)+j) from 8 scalar values
+template <typename T> __device__ __forceinline__ typename Frag<T>::type frag_of(const float (&v)[8]) {
+  typename Frag<T>::type f;
+  if constexpr (sizeof(T) == 2) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) f[j] = (__bf16)v[j];
+  } else {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) f.v[j] = v[j];
+  }
+  return f;
+}
+__device__ __forceinline__ bf16x8 frag_of_t(const __bf16 (&v)[8]) {
+  bf16x8 f;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) f[j] = v[j];
+  return f;
+}
+__device__ __forceinline__ f32x8 frag_of_t(const float (&v)[8]) { return frag_of<float>(v); }
+
+template <typename T>
+__global__ __launch_bounds__(512) void bwd_conv_kernel(BwdConv a) {
+  typedef BwdConvLds<T> LY;
+  typedef typename Frag<T>::type frag_t;
+  constexpr int NTH = 512;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  float* sdc3 = reinterpret_cast<float*>(smem);
+  float* sc2 = reinterpret_cast<float*>(smem + LY::dc3_b);
+  float* sdc2 = reinterpret_cast<float*>(smem + LY::dc3_b + LY::c2_b);
+  T* sc1 = reinterpret_cast<T*>(smem + LY::dc3_b + LY::c2_b + LY::dc2_b);
+  float* sdc1 = reinterpret_cast<float*>(smem + LY::dc3_b + LY::c2_b + LY::dc2_b + LY::c1_b);
+  float* sbuf = reinterpret_cast<float*>(smem + LY::dc3_b + LY::c2_b + LY::dc2_b + LY::c1_b + LY::dc1_b);
+  T* simg = reinterpret_cast<T*>(sbuf);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int fr = lane & 15, g = lane >> 4, qr = g * 4;
+  // weight-grad tiles of this wave
+  const int kt2 = wave * 4;                    // conv2: k-tiles 4w..4w+3 x all 4 co-tiles
+  const int ch1 = wave >> 1, ct1 = wave & 1;   // conv1: input channel ch1 (= k-tiles 4*ch1..+3) x co-tile ct1
+  f32x4 acc2[4][4], acc1[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c) acc2[t][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+    acc1[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  float bias2 = 0.f, bias1 = 0.f;  // thread co (< 64 / 32): column sums of dc2 / dc1
+  for (int i = tid; i < 12 * LY::LF; i += NTH) sdc2[36 * LY::LF + i] = 0.f;  // MFMA padding rows 36..47 stay zero
+
+  for (int smp = blockIdx.x; smp < a.n; smp += gridDim.x) {
+    __syncthreads();  // previous sample's readers are done
+    {  // ---- dc3, c2, c1 of this sample -> LDS
+      const float* g3 = a.dc3 + (int64_t)smp * 16 * 64;
+      const float* g2 = a.c2 + (int64_t)smp * 36 * 64;
+      const float* g1 = a.c1 + (int64_t)smp * 225 * 32;
+      if (tid < 256) {
+        const int r = tid >> 4, c4 = (tid & 15) * 4;
+        *reinterpret_cast<float4*>(sdc3 + r * LY::LF + c4) = *reinterpret_cast<const float4*>(g3 + r * 64 + c4);
+      }
+      for (int i4 = tid; i4 < 36 * 16; i4 += NTH) {
+        const int r = i4 >> 4, c4 = (i4 & 15) * 4;
+        *reinterpret_cast<float4*>(sc2 + r * LY::LF + c4) = *reinterpret_cast<const float4*>(g2 + r * 64 + c4);
+      }
+      for (int i4 = tid; i4 < 225 * 8; i4 += NTH) {
+        const int r = i4 >> 3, c4 = (i4 & 7) * 4;
+        const float4 v = *reinterpret_cast<const float4*>(g1 + r * 32 + c4);
+        st4(sc1 + r * LY::LC1 + c4, v.x, v.y, v.z, v.w);
+      }
+    }
+    __syncthreads();
+    {  // ---- dcol3 = dc3 W3: [16][576] -> sbuf
+      const int nt[5] = {wave, wave + 8, wave + 16, wave + 24, wave + 32 < 36 ? wave + 32 : 35};
+      f32x4 acc[1][5];
+      zero_acc(acc);
+      block_gemm<T, 1, 5, 2>(acc, sdc3, LY::LF, (const T*)a.w3t, 64, nt, lane);
+#pragma unroll
+      for (int j = 0; j < 5; ++j)
+        if (j < 4 || wave + 32 < 36)
+          st4(sbuf + fr * LY::LCOL3 + nt[j] * 16 + qr, acc[0][j][0], acc[0][j][1], acc[0][j][2], acc[0][j][3]);
+    }
+    __syncthreads();
+    for (int idx = tid; idx < 36 * 64; idx += NTH) {  // col2im: dc2[iy][ix][ci] = sum over the 3x3 taps that reach it
+      const int px = idx >> 6, ci = idx & 63;
+      const int iy = px / 6, ix = px - iy * 6;
+      float sum = 0.f;
+#pragma unroll
+      for (int ky = 0; ky < 3; ++ky) {
+        const int oy = iy - ky;
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+          const int ox = ix - kx;
+          const bool ok = oy >= 0 && oy < 4 && ox >= 0 && ox < 4;
+          const float x = sbuf[(ok ? oy * 4 + ox : 0) * LY::LCOL3 + (ky * 3 + kx) * 64 + ci];
+          sum += ok ? x : 0.f;
+        }
+      }
+      sdc2[px * LY::LF + ci] = sc2[px * LY::LF + ci] > 0.f ? sum : 0.f;
+    }
+    __syncthreads();
+    if (tid < 64) {
+      float t = 0.f;
+      for (int p = 0; p < 36; ++p) t += sdc2[p * LY::LF + tid];
+      bias2 += t;
+    }
+    // ---- dW2 += dc2^T col(c1): contraction over the 36 output pixels (two K=32 steps)
+#pragma unroll
+    for (int st = 0; st < 2; ++st) {
+      frag_t fy[4];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const int pos = st * 32 + g * 8 + j;
+          const float x = sdc2[(pos < 48 ? pos : 0) * LY::LF + c * 16 + fr];
+          v[j] = pos < 36 ? x : 0.f;
+        }
+        fy[c] = frag_of<T>(v);
+      }
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const int kt = kt2 + t, tap = kt >> 1, ci = (kt & 1) * 16 + fr;
+        const int ky = tap >> 2, kx = tap & 3;
+        T w[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const int pos = st * 32 + g * 8 + j;
+          const bool ok = pos < 36;
+          const int pp = ok ? pos : 0, oy = pp / 6, ox = pp - oy * 6;
+          const T x = sc1[((2 * oy + ky) * 15 + 2 * ox + kx) * LY::LC1 + ci];
+          w[j] = ok ? x : (T)0.f;
+        }
+        const frag_t fx = frag_of_t(w);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) mma_k32(acc2[t][c], fx, fy[c]);
+      }
+    }
+    // ---- dc1 = col2im(dc2 W2) o [c1 > 0], one kernel row (ky) per pass through sbuf
+    for (int ky = 0; ky < 4; ++ky) {
+      __syncthreads();  // sbuf free (dcol3 / previous pass consumed)
+      {
+        const int nt[1] = {ky * 8 + wave};
+        f32x4 acc[3][1];
+        zero_acc(acc);
+        block_gemm<T, 3, 1, 2>(acc, sdc2, LY::LF, (const T*)a.w2t, 64, nt, lane);
+#pragma unroll
+        for (int mt = 0; mt < 3; ++mt)
+          st4(sbuf + (mt * 16 + fr) * LY::LCOL2 + wave * 16 + qr, acc[mt][0][0], acc[mt][0][1], acc[mt][0][2], acc[mt][0][3]);
+      }
+      __syncthreads();
+      for (int idx = tid; idx < 225 * 32; idx += NTH) {
+        const int px = idx >> 5, ci = idx & 31;
+        const int iy = px / 15, ix = px - iy * 15;
+        const int ty = iy - ky;
+        const bool oky = ty >= 0 && (ty & 1) == 0 && ty < 12;
+        float sum = ky == 0 ? 0.f : sdc1[px * LY::LD1 + ci];
+#pragma unroll
+        for (int kx = 0; kx < 4; ++kx) {
+          const int tx = ix - kx;
+          const bool ok = oky && tx >= 0 && (tx & 1) == 0 && tx < 12;
+          const float x = sbuf[(ok ? (ty >> 1) * 6 + (tx >> 1) : 0) * LY::LCOL2 + kx * 32 + ci];
+          sum += ok ? x : 0.f;
+        }
+        if (ky == 3) sum = (float)sc1[px * LY::LC1 + ci] > 0.f ? sum : 0.f;
+        sdc1[px * LY::LD1 + ci] = sum;
+      }
+    }
+    __syncthreads();
+    if (tid < 32) {
+      float t = 0.f;
+      for (int p = 0; p < 225; ++p) t += sdc1[p * LY::LD1 + tid];
+      bias1 += t;
+    }
+    // ---- dW1 += dc1^T col(image): contraction over the 225 output pixels (eight K=32 steps)
+    const int64_t slot = a.rowidx != nullptr ? a.rowidx[smp] : smp;
+    constexpr int CH = 4 / LY::IMGP;  // channels resident per image pass
+#pragma unroll 1
+    for (int h = 0; h < LY::IMGP; ++h) {
+      if (h > 0) __syncthreads();
+      {
+        const T* gi = reinterpret_cast<const T*>(a.image) + slot * 16384 + (int64_t)h * CH * 4096;
+        constexpr int V = 16 / sizeof(T);  // elements per 16-byte load
+        for (int i = tid; i < CH * 4096 / V; i += NTH)
+          *reinterpret_cast<float4*>(simg + i * V) = *reinterpret_cast<const float4*>(gi + i * V);
+      }
+      __syncthreads();
+      if (ch1 >= h * CH && ch1 < (h + 1) * CH) {  // this wave's input channel is resident
+        const T* ich = simg + (ch1 - h * CH) * 4096;
+#pragma unroll 1
+        for (int st = 0; st < 8; ++st) {
+          float v[8];
+          int po[8], po2[8];
+          bool okp[8];
+          frag_t fy;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            const int pos = st * 32 + g * 8 + j;
+            okp[j] = pos < 225;
+            const int pp = okp[j] ? pos : 0, oy = pp / 15, ox = pp - oy * 15;
+            po[j] = pp * LY::LD1;
+            po2[j] = (4 * oy) * 64 + 4 * ox;
+          }
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            const float x = sdc1[po[j] + ct1 * 16 + fr];
+            v[j] = okp[j] ? x : 0.f;
+          }
+          fy = frag_of<T>(v);
+#pragma unroll
+          for (int t = 0; t < 4; ++t) {
+            const int ky = t * 2 + (fr >> 3), kx = fr & 7;
+            T w[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+              const T x = ich[po2[j] + ky * 64 + kx];
+              w[j] = okp[j] ? x : (T)0.f;
+            }
+            mma_k32(acc1[t], frag_of_t(w), fy);
+          }
+        }
+      }
+    }
+  }
+  // ---- the block's partial weight-grads -> its slab (wgrad_reduce_kernel sums the slabs in a fixed order)
+  {
+    float* o2 = a.slab2 + (int64_t)blockIdx.x * 64 * 512;
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int c = 0; c < 4; ++c)
+        *reinterpret_cast<float4*>(o2 + (c * 16 + fr) * 512 + (kt2 + t) * 16 + qr) =
+            float4{acc2[t][c][0], acc2[t][c][1], acc2[t][c][2], acc2[t][c][3]};
+    float* o1 = a.slab1 + (int64_t)blockIdx.x * 32 * 256;
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+      *reinterpret_cast<float4*>(o1 + (ct1 * 16 + fr) * 256 + (ch1 * 4 + t) * 16 + qr) =
+          float4{acc1[t][0], acc1[t][1], acc1[t][2], acc1[t][3]};
+    if (tid < 64) a.bslab2[(int64_t)blockIdx.x * 64 + tid] = bias2;
+    if (tid < 32) a.bslab1[(int64_t)blockIdx.x * 32 + tid] = bias1;
+  }
+}
+
+
+// dW3 += dc3^T col(c2) (see above): persistent blocks, sample = blockIdx.x, += gridDim.x; wave w owns k-tiles 9w..9w+8 x all
+// four co-tiles, the contraction runs over the 16 output pixels (one zero-padded K=32 MFMA step per sample)
+template <typename T>
+__global__ __launch_bounds__(256) void bwd_conv3_wgrad_kernel(BwdConv a) {
+  typedef typename Frag<T>::type frag_t;
+  constexpr int LF = 64 + 4;
+  __shared__ __attribute__((aligned(16))) float sdc3[16 * LF];
+  __shared__ __attribute__((aligned(16))) float sc2[36 * LF];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int fr = lane & 15, g = lane >> 4, qr = g * 4;
+  const int kt3 = wave * 9;
+  f32x4 acc3[9][4];
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) acc3[t][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float bias3 = 0.f;
+  for (int smp = blockIdx.x; smp < a.n; smp += gridDim.x) {
+    __syncthreads();
+    const float* g3 = a.dc3 + (int64_t)smp * 16 * 64;
+    const float* g2 = a.c2 + (int64_t)smp * 36 * 64;
+    {
+      const int r = tid >> 4, c4 = (tid & 15) * 4;
+      *reinterpret_cast<float4*>(sdc3 + r * LF + c4) = *reinterpret_cast<const float4*>(g3 + r * 64 + c4);
+    }
+    for (int i4 = tid; i4 < 36 * 16; i4 += 256) {
+      const int r = i4 >> 4, c4 = (i4 & 15) * 4;
+      *reinterpret_cast<float4*>(sc2 + r * LF + c4) = *reinterpret_cast<const float4*>(g2 + r * 64 + c4);
+    }
+    __syncthreads();
+    if (tid < 64) {
+      float t = 0.f;
+#pragma unroll
+      for (int p = 0; p < 16; ++p) t += sdc3[p * LF + tid];
+      bias3 += t;
+    }
+    float v[8];
+    frag_t fy[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float x = sdc3[((g & 1) * 8 + j) * LF + c * 16 + fr];
+        v[j] = g < 2 ? x : 0.f;
+      }
+      fy[c] = frag_of<T>(v);
+    }
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+      const int kt = kt3 + t, tap = kt >> 2, ci = (kt & 3) * 16 + fr;
+      const int ky = tap / 3, kx = tap - ky * 3;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int pos = (g & 1) * 8 + j, oy = pos >> 2, ox = pos & 3;
+        const float x = sc2[((oy + ky) * 6 + ox + kx) * LF + ci];
+        v[j] = g < 2 ? x : 0.f;
+      }
+      const frag_t fx = frag_of<T>(v);
+#pragma unroll
+      for (int c = 0; c < 4; ++c) mma_k32(acc3[t][c], fx, fy[c]);
+    }
+  }
+  float* o3 = a.slab3 + (int64_t)blockIdx.x * 64 * 576;
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+      *reinterpret_cast<float4*>(o3 + (c * 16 + fr) * 576 + (kt3 + t) * 16 + qr) =
+          float4{acc3[t][c][0], acc3[t][c][1], acc3[t][c][2], acc3[t][c][3]};
+  if (tid < 64) a.bslab3[(int64_t)blockIdx.x * 64 + tid] = bias3;
+}
+
 }  // namespace v4l

@@ -801,6 +801,8 @@ static inline bool tn_wide_shape(int N, int K) {
   return (N == 256 && K == 64) || (N == 192 && K == 64) || (N == 64 && K == 256) || (N == 64 && K == 64);
 }
 
+constexpr int CONV_BWD_MAX_BLOCKS = 256;  // persistent blocks of the fused conv backward (one per CU)
+
 // Sums the per-slab partials of one or more weight tensors and writes the PyTorch-layout gradients.
 // The packed k order of NHWC convs / NHWC flatten is (tap, c); PyTorch's is (c, tap): kt = (k % Cin) * taps + k / Cin.
 struct RedDesc {

@@ -259,7 +259,7 @@ static int lin_wgrad(Ctx& c, const Lin& L, const ADense& y, const ADense& x, int
   memset(&p, 0, sizeof(p));
   p.y = y; p.x = x; p.M = M;
   p.gx = cdiv(Kx, 64); p.gy = cdiv(L.N, 64);
-  int splits = M >= 4096 ? std::min(32, M / 512) : std::max(1, M / 256);
+  int splits = M >= 4096 ? std::min(64, M / 256) : std::max(1, M / 128);  // 2..4 staging rounds per block: latency-bound
   p.mpb = round_up(cdiv(M, splits), 64);
   splits = cdiv(M, p.mpb);
   p.Npad = p.gy * 64; p.Kpad = p.gx * 64;
@@ -289,7 +289,8 @@ static int lin_wgrad_wide(Ctx& c, const Lin& L, const void* y, const void* x, in
   TnWide p;
   memset(&p, 0, sizeof(p));
   p.y = y; p.x = x; p.M = M; p.N = L.N; p.K = L.K;
-  int splits = std::max(1, std::min(64, M / 256));
+  static const int wide_splits = getenv("V4L_WIDE_SPLITS") ? std::max(1, std::min(64, atoi(getenv("V4L_WIDE_SPLITS")))) : 64;
+  int splits = std::max(1, std::min(wide_splits, M / 256));
   p.mpb = round_up(cdiv(M, splits), 64);
   splits = cdiv(M, p.mpb);
   const int64_t slab_f = ((int64_t)splits * p.N * p.K + 63) / 64 * 64;
@@ -412,10 +413,67 @@ static int conv_stack_fwd(const Ctx& c, const T* image, const int* rowidx, int n
   return 0;
 }
 
+// The whole conv-stack backward as one persistent launch (csrc/bwd.h) when the stack has the shipped NatureCNN geometry
+static bool conv_bwd_fusable(const v4l_net* N) {
+  const Conv* v = N->conv;
+  return v[0].chw && v[0].Cin == 4 && v[0].IH == 64 && v[0].KH == 8 && v[0].stride == 4 && v[0].Cout == 32 &&
+         v[1].Cin == 32 && v[1].KH == 4 && v[1].stride == 2 && v[1].Cout == 64 && v[1].OH == 6 &&
+         v[2].Cin == 64 && v[2].KH == 3 && v[2].stride == 1 && v[2].Cout == 64 && v[2].OH == 4 &&
+         getenv("V4L_NO_FUSED_CONV_BWD") == nullptr;
+}
+template <typename T>
+static int conv_stack_bwd_fused(Ctx& c, const T* image, const int* rowidx, int n, const float* c1, const float* c2,
+                                const float* dc3) {
+  v4l_net* N = c.net;
+  static bool attr_done = false;
+  if (!attr_done) {
+    V4L_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&bwd_conv_kernel<T>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)BwdConvLds<T>::bytes));
+    attr_done = true;
+  }
+  int nblk = std::min(n, CONV_BWD_MAX_BLOCKS);
+  if (const char* e = getenv("V4L_CONV_BWD_BLOCKS")) nblk = std::max(1, std::min(nblk, atoi(e)));
+  const int Ns[3] = {32, 64, 64}, Ks[3] = {256, 512, 576};
+  float* slab[3];
+  float* bslab[3];
+  for (int i = 0; i < 3; ++i) {
+    const int64_t sf = ((int64_t)nblk * Ns[i] * Ks[i] + 63) / 64 * 64, bf = ((int64_t)nblk * Ns[i] + 63) / 64 * 64;
+    slab[i] = c.slab + c.slab_used;
+    bslab[i] = slab[i] + sf;
+    c.slab_used += sf + bf;
+    const Conv& v = N->conv[i];
+    RedDesc o;
+    memset(&o, 0, sizeof(o));
+    o.dW = c.grads + N->params[v.w].goff;
+    o.db = c.grads + N->params[v.b].goff;
+    o.N = v.Cout; o.K = v.K; o.Ktorch = v.K;
+    o.Cin = v.chw ? 0 : v.Cin; o.taps = v.chw ? 0 : v.KH * v.KH;
+    o.slab = slab[i]; o.bslab = bslab[i]; o.nsplit = nblk; o.Npad = Ns[i]; o.Kpad = Ks[i];
+    N->red.push_back(o);
+  }
+  V4L_REQUIRE(c.slab_used <= N->slab_cap, "internal: weight-grad slab arena overflow");
+  BwdConv a;
+  memset(&a, 0, sizeof(a));
+  a.w3t = (const T*)N->packed + N->conv[2].pkt; a.w2t = (const T*)N->packed + N->conv[1].pkt;
+  a.image = image; a.rowidx = rowidx; a.c1 = c1; a.c2 = c2; a.dc3 = dc3;
+  a.slab1 = slab[0]; a.slab2 = slab[1]; a.slab3 = slab[2];
+  a.bslab1 = bslab[0]; a.bslab2 = bslab[1]; a.bslab3 = bslab[2];
+  a.n = n;
+  g_op = "conv.bwd";
+  const double fl = 2.0 * n * (16.0 * 64 * 576 + 2.0 * 36 * 64 * 512 + 225.0 * 32 * 256);
+  V4L_KLAUNCH("fused_conv_bwd", fl, c.s, bwd_conv_kernel<T>, dim3(nblk), dim3(512), BwdConvLds<T>::bytes, c.s, a);
+  V4L_LAUNCH_CHECK();
+  g_op = "conv3.wgrad";
+  V4L_KLAUNCH("fused_conv3_wgrad", 2.0 * n * 16 * 64 * 576, c.s, bwd_conv3_wgrad_kernel<T>, dim3(nblk), dim3(256), 0, c.s, a);
+  V4L_LAUNCH_CHECK();
+  return 0;
+}
+
 // dc3: grad w.r.t. conv3's pre-activation [n*16][64]. Scratch dc2 [n*36][64], dc1 [n*225][32].
 template <typename T>
 static int conv_stack_bwd(Ctx& c, const T* image, const int* rowidx, int n, const float* c1, const float* c2,
                           float* dc3, float* dc2, float* dc1) {
+  if (conv_bwd_fusable(c.net)) return conv_stack_bwd_fused<T>(c, image, rowidx, n, c1, c2, dc3);
   const v4l_net* N = c.net;
   const Conv* cv = N->conv;
   const float* acts[3] = {nullptr, c1, c2};   // input activation of conv i
@@ -634,6 +692,7 @@ int v4l_net::build() {
         for (int cls = 0; cls < v.ncls; ++cls)
           v.pkd[cls] = add_pack(v.w, PK_CONV_DGRAD, v.Rd, v.Kdp, v.Cout, v.K, v.Cin, taps, v.KH, v.stride, cls / v.stride,
                                 cls % v.stride, TH);
+        v.pkt = add_pack(v.w, PK_CONV_NHWC_T, v.K, round_up(v.Cout, 64), v.Cout, v.K, v.Cin, taps, 0, 0, 0, 0, 0);
       }
     }
   }
@@ -667,8 +726,10 @@ int64_t v4l_net::slab_floats(int n) const {
     const int64_t np = round_up(N, 64), kp = round_up(Kx, 64);
     tot += std::max<int64_t>(p.slab_floats + p.bslab_floats, dense_splits * np * (kp + 1) + 128);
   };
-  if (cfg.kind != V4L_NET_MLP)
+  if (cfg.kind != V4L_NET_MLP) {
     for (int i = 0; i < 3; ++i) add(n * conv[i].OH * conv[i].OH, conv[i].Cout, conv[i].K);
+    tot += (int64_t)CONV_BWD_MAX_BLOCKS * (32 * 256 + 64 * 512 + 64 * 576 + 3 * 64);  // fused conv backward: one slab set per block
+  }
   if (cfg.kind == V4L_NET_LOCO) add(n * 16, upconv.N, 64);
   if (cfg.kind == V4L_NET_LOCO) add(n, proj.N, proj.K);
   if (cfg.kind == V4L_NET_CNN) add(n, proj.N, 1024);
