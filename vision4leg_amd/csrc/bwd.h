@@ -400,16 +400,18 @@ __global__ __launch_bounds__(256) void bwd_layer_kernel(BwdLayer w, BwdHead hd, 
 // ------------------------------------------------------------------------------------------ conv stack backward
 // bwd_conv_kernel: the whole NatureCNN backward (networks/base.py:304-342 reversed) for the shipped geometry
 // 4x64x64 -(k8 s4)-> 15x15x32 -(k4 s2)-> 6x6x64 -(k3 s1)-> 4x4x64, one sample at a time out of LDS:
-//   dc3 -> [dW3 += dc3^T col(c2)]  dcol = dc3 W3 -> col2im -> dc2 o [c2>0]
-//       -> [dW2 += dc2^T col(c1)]  dcol = dc2 W2 (one kernel row per pass) -> col2im -> dc1 o [c1>0]
+//   dc3 -> dc2 = gather-form data-grad of conv3 (rows = the 36 input pixels, K = 9 taps x 64) o [c2 > 0]
+//       -> [dW2 += dc2^T col(c1)]
+//       -> dc1 = gather-form data-grad of conv2, one stride-parity class per wave pair (K = 4 taps x 64) o [c1 > 0]
 //       -> [dW1 += dc1^T col(image)]
-// Blocks are persistent (sample = blockIdx.x, += gridDim.x): the three weight-grads accumulate in REGISTERS across a
+// Blocks are persistent (sample = blockIdx.x, += gridDim.x): the weight-grads accumulate in REGISTERS across a
 // block's samples and leave the chip once per block as one slab each — every activation is read from HBM exactly once
 // and dc2 / dc1 never exist in HBM. bwd_conv_kernel (512 threads, 1 block per CU) carries dW2 and dW1 (20 MFMA tiles per
 // wave); dW3's 144 tiles would not fit beside them, so bwd_conv3_wgrad_kernel (256 threads, 36 tiles per wave) does that
 // contraction on its own from dc3 and c2 (13 KB per sample).
 struct BwdConv {
-  const void *w3t, *w2t;            // data-grad packs (T): [(ky,kx,ci)][co]: [576][64], [512][64]
+  const void* w3d;                  // conv3 data-grad pack (T) [ci 64][(a,b,co) 576]
+  const void* w2d[4];               // conv2 data-grad packs, one per stride-parity class (py,px): [ci 32][(a,b,co) 256]
   const void* image;                // T [slots][4][64][64]
   const int* rowidx;                // minibatch row -> rollout slot, or null
   const float *c1, *c2;             // [n*225][32], [n*36][64] post-ReLU activations
@@ -422,15 +424,15 @@ template <typename T> struct BwdConvLds {
   static constexpr bool B16 = sizeof(T) == 2;
   static constexpr int LF = 64 + 4;                 // fp32 rows read as MFMA A operands
   static constexpr int LC1 = 32 + (B16 ? 8 : 0);    // c1 rows (T)
-  static constexpr int LD1 = 32 + (B16 ? 4 : 0);    // dc1 rows (fp32)
-  static constexpr int LCOL3 = 576 + 4, LCOL2 = 128 + 4;
+  static constexpr int LD1 = 32 + 4;                // dc1 rows (fp32)
   static constexpr int IMGP = B16 ? 1 : 2;          // image passes (fp32: two channels at a time)
-  static constexpr size_t dc3_b = (size_t)16 * LF * 4, c2_b = (size_t)36 * LF * 4, dc2_b = (size_t)48 * LF * 4;
+  static constexpr size_t dc3_b = (size_t)17 * LF * 4;   // + one zero row (taps that fall outside the 4x4 plane)
+  static constexpr size_t c2_b = (size_t)36 * LF * 4;
+  static constexpr size_t dc2_b = (size_t)48 * LF * 4;   // rows 36..47: zeros (MFMA padding / out-of-plane taps)
   static constexpr size_t c1_b = ((size_t)225 * LC1 * sizeof(T) + 15) / 16 * 16;
   static constexpr size_t dc1_b = (size_t)225 * LD1 * 4;
-  static constexpr size_t buf_b = (size_t)16 * LCOL3 * 4;  // dcol3 | dcol2 pass [48][LCOL2] | image (pass)
-  static_assert(buf_b >= (size_t)48 * LCOL2 * 4 && buf_b >= (size_t)(4 / IMGP) * 4096 * sizeof(T), "bwd_conv: buffer");
-  static constexpr size_t bytes = dc3_b + c2_b + dc2_b + c1_b + dc1_b + buf_b;
+  static constexpr size_t img_b = (size_t)(4 / IMGP) * 4096 * sizeof(T);
+  static constexpr size_t bytes = dc3_b + c2_b + dc2_b + c1_b + dc1_b + img_b;
 };
 
 // MFMA operand (row = lane&15, 8 consecutive contraction indices 8*(lane>>4)+j) from 8 scalar values
@@ -453,6 +455,30 @@ __device__ __forceinline__ bf16x8 frag_of_t(const __bf16 (&v)[8]) {
 }
 __device__ __forceinline__ f32x8 frag_of_t(const float (&v)[8]) { return frag_of<float>(v); }
 
+// Gather-form data-grad GEMM of one wave: acc[mt] += A(mt, ks) * W[row = ntile*16 + lane&15][ks*32 ..]^T over KS K=32
+// steps, where the A fragment of (row tile mt, step ks) comes from the LDS row arow(mt, ks >> 1) (64 channels = two steps
+// per tap). Weight fragments stream from L2 through a ring of PD steps, like block_gemm.
+template <typename T, int MT, int KS, class RowF>
+__device__ __forceinline__ void gather_gemm(f32x4 (&acc)[MT], const T* __restrict__ W, int Kp, int ntile, int lane, RowF arow) {
+  typedef typename Frag<T>::type frag_t;
+  constexpr int PD = KS < 6 ? KS : 6;
+  const int fr = lane & 15, fg = (lane >> 4) * 8;
+  const T* wrow = W + (int64_t)(ntile * 16 + fr) * Kp + fg;
+  frag_t fb[PD];
+#pragma unroll
+  for (int d = 0; d < PD; ++d) fb[d] = *reinterpret_cast<const frag_t*>(wrow + d * 32);
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) {
+    const frag_t cur = fb[ks % PD];
+    if (ks + PD < KS) fb[ks % PD] = *reinterpret_cast<const frag_t*>(wrow + (ks + PD) * 32);
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      const frag_t fa = afrag<T>(arow(mt, ks >> 1) + (ks & 1) * 32 + fg);
+      mma_k32(acc[mt], cur, fa);  // transposed tile: acc[mt][r] = out[16*mt + lane&15][16*ntile + 4*(lane>>4) + r]
+    }
+  }
+}
+
 template <typename T>
 __global__ __launch_bounds__(512) void bwd_conv_kernel(BwdConv a) {
   typedef BwdConvLds<T> LY;
@@ -464,8 +490,7 @@ __global__ __launch_bounds__(512) void bwd_conv_kernel(BwdConv a) {
   float* sdc2 = reinterpret_cast<float*>(smem + LY::dc3_b + LY::c2_b);
   T* sc1 = reinterpret_cast<T*>(smem + LY::dc3_b + LY::c2_b + LY::dc2_b);
   float* sdc1 = reinterpret_cast<float*>(smem + LY::dc3_b + LY::c2_b + LY::dc2_b + LY::c1_b);
-  float* sbuf = reinterpret_cast<float*>(smem + LY::dc3_b + LY::c2_b + LY::dc2_b + LY::c1_b + LY::dc1_b);
-  T* simg = reinterpret_cast<T*>(sbuf);
+  T* simg = reinterpret_cast<T*>(smem + LY::dc3_b + LY::c2_b + LY::dc2_b + LY::c1_b + LY::dc1_b);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int fr = lane & 15, g = lane >> 4, qr = g * 4;
   // weight-grad tiles of this wave
@@ -479,11 +504,15 @@ __global__ __launch_bounds__(512) void bwd_conv_kernel(BwdConv a) {
     acc1[t] = f32x4{0.f, 0.f, 0.f, 0.f};
   }
   float bias2 = 0.f, bias1 = 0.f;  // thread co (< 64 / 32): column sums of dc2 / dc1
-  for (int i = tid; i < 12 * LY::LF; i += NTH) sdc2[36 * LY::LF + i] = 0.f;  // MFMA padding rows 36..47 stay zero
+  for (int i = tid; i < 12 * LY::LF; i += NTH) sdc2[36 * LY::LF + i] = 0.f;
+  for (int i = tid; i < LY::LF; i += NTH) sdc3[16 * LY::LF + i] = 0.f;
+  constexpr int CH = 4 / LY::IMGP;  // image channels resident at a time
 
   for (int smp = blockIdx.x; smp < a.n; smp += gridDim.x) {
     __syncthreads();  // previous sample's readers are done
-    {  // ---- dc3, c2, c1 of this sample -> LDS
+    const int64_t slot = a.rowidx != nullptr ? a.rowidx[smp] : smp;
+    const T* gimg = reinterpret_cast<const T*>(a.image) + slot * 16384;
+    {  // ---- dc3, c2, c1, image of this sample -> LDS
       const float* g3 = a.dc3 + (int64_t)smp * 16 * 64;
       const float* g2 = a.c2 + (int64_t)smp * 36 * 64;
       const float* g1 = a.c1 + (int64_t)smp * 225 * 32;
@@ -500,35 +529,45 @@ __global__ __launch_bounds__(512) void bwd_conv_kernel(BwdConv a) {
         const float4 v = *reinterpret_cast<const float4*>(g1 + r * 32 + c4);
         st4(sc1 + r * LY::LC1 + c4, v.x, v.y, v.z, v.w);
       }
+      constexpr int V = 16 / sizeof(T);  // elements per 16-byte load
+      for (int i = tid; i < CH * 4096 / V; i += NTH)
+        *reinterpret_cast<float4*>(simg + i * V) = *reinterpret_cast<const float4*>(gimg + i * V);
     }
     __syncthreads();
-    {  // ---- dcol3 = dc3 W3: [16][576] -> sbuf
-      const int nt[5] = {wave, wave + 8, wave + 16, wave + 24, wave + 32 < 36 ? wave + 32 : 35};
-      f32x4 acc[1][5];
-      zero_acc(acc);
-      block_gemm<T, 1, 5, 2>(acc, sdc3, LY::LF, (const T*)a.w3t, 64, nt, lane);
+    {  // ---- dc2 = conv3' (gather form): rows = 36 input pixels (3 row tiles), K = 9 taps x 64 co, N = 64 ci
+      const int nt = wave & 3;
+      const T* W = reinterpret_cast<const T*>(a.w3d);
+      auto run = [&](auto mt_tag, int mt0) {
+        constexpr int MT = decltype(mt_tag)::value;
+        int iy[MT], ix[MT];
+        bool okr[MT];
 #pragma unroll
-      for (int j = 0; j < 5; ++j)
-        if (j < 4 || wave + 32 < 36)
-          st4(sbuf + fr * LY::LCOL3 + nt[j] * 16 + qr, acc[0][j][0], acc[0][j][1], acc[0][j][2], acc[0][j][3]);
-    }
-    __syncthreads();
-    for (int idx = tid; idx < 36 * 64; idx += NTH) {  // col2im: dc2[iy][ix][ci] = sum over the 3x3 taps that reach it
-      const int px = idx >> 6, ci = idx & 63;
-      const int iy = px / 6, ix = px - iy * 6;
-      float sum = 0.f;
-#pragma unroll
-      for (int ky = 0; ky < 3; ++ky) {
-        const int oy = iy - ky;
-#pragma unroll
-        for (int kx = 0; kx < 3; ++kx) {
-          const int ox = ix - kx;
-          const bool ok = oy >= 0 && oy < 4 && ox >= 0 && ox < 4;
-          const float x = sbuf[(ok ? oy * 4 + ox : 0) * LY::LCOL3 + (ky * 3 + kx) * 64 + ci];
-          sum += ok ? x : 0.f;
+        for (int m = 0; m < MT; ++m) {
+          const int px = (mt0 + m) * 16 + fr;
+          okr[m] = px < 36;
+          iy[m] = px / 6; ix[m] = px - iy[m] * 6;
         }
-      }
-      sdc2[px * LY::LF + ci] = sc2[px * LY::LF + ci] > 0.f ? sum : 0.f;
+        f32x4 acc[MT];
+#pragma unroll
+        for (int m = 0; m < MT; ++m) acc[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+        gather_gemm<T, MT, 18>(acc, W, 576, nt, lane, [&](int m, int tap) -> const float* {
+          const int ta = tap / 3, tb = tap - ta * 3;
+          const int oy = iy[m] - ta, ox = ix[m] - tb;
+          const bool ok = okr[m] && oy >= 0 && oy < 4 && ox >= 0 && ox < 4;
+          return sdc3 + (ok ? oy * 4 + ox : 16) * LY::LF;
+        });
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+          const int px = (mt0 + m) * 16 + fr, c4 = nt * 16 + qr;
+          if (px < 36) {
+            const float4 mk = *reinterpret_cast<const float4*>(sc2 + px * LY::LF + c4);
+            st4(sdc2 + px * LY::LF + c4, mk.x > 0.f ? acc[m][0] : 0.f, mk.y > 0.f ? acc[m][1] : 0.f,
+                mk.z > 0.f ? acc[m][2] : 0.f, mk.w > 0.f ? acc[m][3] : 0.f);
+          }
+        }
+      };
+      if (wave < 4) run(std::integral_constant<int, 2>{}, 0);
+      else run(std::integral_constant<int, 1>{}, 2);
     }
     __syncthreads();
     if (tid < 64) {
@@ -569,34 +608,29 @@ __global__ __launch_bounds__(512) void bwd_conv_kernel(BwdConv a) {
         for (int c = 0; c < 4; ++c) mma_k32(acc2[t][c], fx, fy[c]);
       }
     }
-    // ---- dc1 = col2im(dc2 W2) o [c1 > 0], one kernel row (ky) per pass through sbuf
-    for (int ky = 0; ky < 4; ++ky) {
-      __syncthreads();  // sbuf free (dcol3 / previous pass consumed)
-      {
-        const int nt[1] = {ky * 8 + wave};
-        f32x4 acc[3][1];
-        zero_acc(acc);
-        block_gemm<T, 3, 1, 2>(acc, sdc2, LY::LF, (const T*)a.w2t, 64, nt, lane);
+    {  // ---- dc1 = conv2' (gather form): wave pair = stride-parity class (py,px); rows = its <= 8x8 input pixels,
+       //      K = 2x2 taps x 64 co, N = 32 ci (one 16-wide tile per wave)
+      const int cls = wave >> 1, py = cls >> 1, pxx = cls & 1, nt = wave & 1;
+      const int nIy = (15 - py + 1) >> 1, nIx = (15 - pxx + 1) >> 1;
+      int ry[4], rx[4];
 #pragma unroll
-        for (int mt = 0; mt < 3; ++mt)
-          st4(sbuf + (mt * 16 + fr) * LY::LCOL2 + wave * 16 + qr, acc[mt][0][0], acc[mt][0][1], acc[mt][0][2], acc[mt][0][3]);
-      }
-      __syncthreads();
-      for (int idx = tid; idx < 225 * 32; idx += NTH) {
-        const int px = idx >> 5, ci = idx & 31;
-        const int iy = px / 15, ix = px - iy * 15;
-        const int ty = iy - ky;
-        const bool oky = ty >= 0 && (ty & 1) == 0 && ty < 12;
-        float sum = ky == 0 ? 0.f : sdc1[px * LY::LD1 + ci];
+      for (int m = 0; m < 4; ++m) { const int r = m * 16 + fr; ry[m] = r >> 3; rx[m] = r & 7; }
+      f32x4 acc[4];
 #pragma unroll
-        for (int kx = 0; kx < 4; ++kx) {
-          const int tx = ix - kx;
-          const bool ok = oky && tx >= 0 && (tx & 1) == 0 && tx < 12;
-          const float x = sbuf[(ok ? (ty >> 1) * 6 + (tx >> 1) : 0) * LY::LCOL2 + kx * 32 + ci];
-          sum += ok ? x : 0.f;
+      for (int m = 0; m < 4; ++m) acc[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+      gather_gemm<T, 4, 8>(acc, reinterpret_cast<const T*>(a.w2d[cls]), 256, nt, lane, [&](int m, int tap) -> const float* {
+        const int oy = ry[m] - (tap >> 1), ox = rx[m] - (tap & 1);
+        const bool ok = ry[m] < nIy && rx[m] < nIx && oy >= 0 && oy < 6 && ox >= 0 && ox < 6;
+        return sdc2 + (ok ? oy * 6 + ox : 36) * LY::LF;
+      });
+#pragma unroll
+      for (int m = 0; m < 4; ++m) {
+        if (ry[m] < nIy && rx[m] < nIx) {
+          const int p = (py + 2 * ry[m]) * 15 + pxx + 2 * rx[m], c4 = nt * 16 + qr;
+          const float4 mk = ld4(sc1 + p * LY::LC1 + c4);
+          st4(sdc1 + p * LY::LD1 + c4, mk.x > 0.f ? acc[m][0] : 0.f, mk.y > 0.f ? acc[m][1] : 0.f,
+              mk.z > 0.f ? acc[m][2] : 0.f, mk.w > 0.f ? acc[m][3] : 0.f);
         }
-        if (ky == 3) sum = (float)sc1[px * LY::LC1 + ci] > 0.f ? sum : 0.f;
-        sdc1[px * LY::LD1 + ci] = sum;
       }
     }
     __syncthreads();
@@ -606,40 +640,32 @@ __global__ __launch_bounds__(512) void bwd_conv_kernel(BwdConv a) {
       bias1 += t;
     }
     // ---- dW1 += dc1^T col(image): contraction over the 225 output pixels (eight K=32 steps)
-    const int64_t slot = a.rowidx != nullptr ? a.rowidx[smp] : smp;
-    constexpr int CH = 4 / LY::IMGP;  // channels resident per image pass
 #pragma unroll 1
     for (int h = 0; h < LY::IMGP; ++h) {
-      if (h > 0) __syncthreads();
-      {
-        const T* gi = reinterpret_cast<const T*>(a.image) + slot * 16384 + (int64_t)h * CH * 4096;
-        constexpr int V = 16 / sizeof(T);  // elements per 16-byte load
+      if (h > 0) {  // fp32 parity mode: the second channel pair replaces the first
+        __syncthreads();
+        constexpr int V = 16 / sizeof(T);
         for (int i = tid; i < CH * 4096 / V; i += NTH)
-          *reinterpret_cast<float4*>(simg + i * V) = *reinterpret_cast<const float4*>(gi + i * V);
+          *reinterpret_cast<float4*>(simg + i * V) = *reinterpret_cast<const float4*>(gimg + (int64_t)h * CH * 4096 + i * V);
+        __syncthreads();
       }
-      __syncthreads();
       if (ch1 >= h * CH && ch1 < (h + 1) * CH) {  // this wave's input channel is resident
         const T* ich = simg + (ch1 - h * CH) * 4096;
 #pragma unroll 1
         for (int st = 0; st < 8; ++st) {
           float v[8];
-          int po[8], po2[8];
+          int po2[8];
           bool okp[8];
-          frag_t fy;
 #pragma unroll
           for (int j = 0; j < 8; ++j) {
             const int pos = st * 32 + g * 8 + j;
             okp[j] = pos < 225;
             const int pp = okp[j] ? pos : 0, oy = pp / 15, ox = pp - oy * 15;
-            po[j] = pp * LY::LD1;
             po2[j] = (4 * oy) * 64 + 4 * ox;
-          }
-#pragma unroll
-          for (int j = 0; j < 8; ++j) {
-            const float x = sdc1[po[j] + ct1 * 16 + fr];
+            const float x = sdc1[pp * LY::LD1 + ct1 * 16 + fr];
             v[j] = okp[j] ? x : 0.f;
           }
-          fy = frag_of<T>(v);
+          const frag_t fy = frag_of<T>(v);
 #pragma unroll
           for (int t = 0; t < 4; ++t) {
             const int ky = t * 2 + (fr >> 3), kx = fr & 7;
@@ -673,7 +699,6 @@ __global__ __launch_bounds__(512) void bwd_conv_kernel(BwdConv a) {
     if (tid < 32) a.bslab1[(int64_t)blockIdx.x * 32 + tid] = bias1;
   }
 }
-
 
 // dW3 += dc3^T col(c2) (see above): persistent blocks, sample = blockIdx.x, += gridDim.x; wave w owns k-tiles 9w..9w+8 x all
 // four co-tiles, the contraction runs over the 16 output pixels (one zero-padded K=32 MFMA step per sample)

@@ -39,7 +39,6 @@ struct Conv {        // nn.Conv2d, square kernel, no padding. Activations NHWC, 
   int ncls = 0;           // stride*stride parity classes of the gather-form data-grad
   int Kd = 0, Kdp = 0, Rd = 0;
   int64_t pkd[4] = {0, 0, 0, 0};
-  int64_t pkt = 0;        // [(ky,kx,ci)][Cout] (T): data-grad operand of the fused conv backward (csrc/bwd.h)
 };
 
 struct LNp { int g = -1, b = -1; };

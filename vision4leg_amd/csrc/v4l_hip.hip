@@ -416,7 +416,7 @@ static int conv_stack_fwd(const Ctx& c, const T* image, const int* rowidx, int n
 // The whole conv-stack backward as one persistent launch (csrc/bwd.h) when the stack has the shipped NatureCNN geometry
 static bool conv_bwd_fusable(const v4l_net* N) {
   const Conv* v = N->conv;
-  return v[0].chw && v[0].Cin == 4 && v[0].IH == 64 && v[0].KH == 8 && v[0].stride == 4 && v[0].Cout == 32 &&
+  return v[1].Rd == 32 && v[1].Kdp == 256 && v[2].Rd == 64 && v[2].Kdp == 576 && v[0].chw && v[0].Cin == 4 && v[0].IH == 64 && v[0].KH == 8 && v[0].stride == 4 && v[0].Cout == 32 &&
          v[1].Cin == 32 && v[1].KH == 4 && v[1].stride == 2 && v[1].Cout == 64 && v[1].OH == 6 &&
          v[2].Cin == 64 && v[2].KH == 3 && v[2].stride == 1 && v[2].Cout == 64 && v[2].OH == 4 &&
          getenv("V4L_NO_FUSED_CONV_BWD") == nullptr;
@@ -454,7 +454,8 @@ static int conv_stack_bwd_fused(Ctx& c, const T* image, const int* rowidx, int n
   V4L_REQUIRE(c.slab_used <= N->slab_cap, "internal: weight-grad slab arena overflow");
   BwdConv a;
   memset(&a, 0, sizeof(a));
-  a.w3t = (const T*)N->packed + N->conv[2].pkt; a.w2t = (const T*)N->packed + N->conv[1].pkt;
+  a.w3d = (const T*)N->packed + N->conv[2].pkd[0];
+  for (int cls = 0; cls < 4; ++cls) a.w2d[cls] = (const T*)N->packed + N->conv[1].pkd[cls];
   a.image = image; a.rowidx = rowidx; a.c1 = c1; a.c2 = c2; a.dc3 = dc3;
   a.slab1 = slab[0]; a.slab2 = slab[1]; a.slab3 = slab[2];
   a.bslab1 = bslab[0]; a.bslab2 = bslab[1]; a.bslab3 = bslab[2];
@@ -692,7 +693,6 @@ int v4l_net::build() {
         for (int cls = 0; cls < v.ncls; ++cls)
           v.pkd[cls] = add_pack(v.w, PK_CONV_DGRAD, v.Rd, v.Kdp, v.Cout, v.K, v.Cin, taps, v.KH, v.stride, cls / v.stride,
                                 cls % v.stride, TH);
-        v.pkt = add_pack(v.w, PK_CONV_NHWC_T, v.K, round_up(v.Cout, 64), v.Cout, v.K, v.Cin, taps, 0, 0, 0, 0, 0);
       }
     }
   }
