@@ -163,8 +163,12 @@ def test_backward(name, mode, device):
         hip.forward(st, im, n, train=True)
         dout = torch.zeros(n, 16, dtype=torch.float32, device=device)
         dout[:, :A] = w.to(device)
-        grads = torch.zeros(hip.total_params, dtype=torch.float32, device=device)
+        # NaN-filled: the backward pass must WRITE every element (the trainer does not clear its gradient buffers)
+        grads = torch.full((hip.total_params,), float("nan"), dtype=torch.float32, device=device)
         hip.backward(st, im, n, dout, grads)
+        if "logstd" in hip.param_names:
+            hip.grad_view(grads, "logstd").zero_()  # the policy's logstd gradient comes from actor_loss_kernel
+        assert not torch.isnan(grads).any(), "backward left gradient elements unwritten"
         keys = list(op)
         for k in keys:
             op[k].requires_grad_(True)

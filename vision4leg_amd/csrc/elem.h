@@ -292,10 +292,10 @@ __global__ __launch_bounds__(256) void act_finish_kernel(ActCtl* c, const float*
 
 // --------------------------------------------------------------------------------- block reductions
 struct Red4 { double s, s2; float mx, mn; };
-// 256-thread block reduction of (sum, sum of squares, max, min); result valid on all threads.
+// Block reduction (blockDim.x = 64 * nw, nw <= 16) of (sum, sum of squares, max, min); result valid on all threads.
 __device__ __forceinline__ Red4 block_red4(double s, double s2, float mx, float mn) {
-  __shared__ double rs[4], rs2[4];
-  __shared__ float rmx[4], rmn[4];
+  __shared__ double rs[16], rs2[16];
+  __shared__ float rmx[16], rmn[16];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) {
@@ -308,10 +308,12 @@ __device__ __forceinline__ Red4 block_red4(double s, double s2, float mx, float 
   if (lane == 0) { rs[w] = s; rs2[w] = s2; rmx[w] = mx; rmn[w] = mn; }
   __syncthreads();
   Red4 r;
-  r.s = rs[0] + rs[1] + rs[2] + rs[3];
-  r.s2 = rs2[0] + rs2[1] + rs2[2] + rs2[3];
-  r.mx = fmaxf(fmaxf(rmx[0], rmx[1]), fmaxf(rmx[2], rmx[3]));
-  r.mn = fminf(fminf(rmn[0], rmn[1]), fminf(rmn[2], rmn[3]));
+  r.s = 0.0; r.s2 = 0.0; r.mx = -INFINITY; r.mn = INFINITY;
+  const int nw = blockDim.x >> 6;
+  for (int k = 0; k < nw; ++k) {  // fixed order: deterministic
+    r.s += rs[k]; r.s2 += rs2[k];
+    r.mx = fmaxf(r.mx, rmx[k]); r.mn = fminf(r.mn, rmn[k]);
+  }
   return r;
 }
 
@@ -327,17 +329,16 @@ enum {
 };
 
 // advs.mean(), advs.std() (Bessel), max, min of the minibatch (ppo.py:142-145). Single block.
-__global__ __launch_bounds__(256) void adv_stats_kernel(const float* __restrict__ adv, const int* __restrict__ rowidx, int n,
-                                                        float* __restrict__ st) {
+__device__ __forceinline__ void adv_stats_body(const float* __restrict__ adv, const int* rowidx, int n, float* __restrict__ st) {
   double s = 0.0; float mx = -INFINITY, mn = INFINITY;
-  for (int i = threadIdx.x; i < n; i += 256) {
+  for (int i = threadIdx.x; i < n; i += blockDim.x) {
     const float a = adv[rowidx ? rowidx[i] : i];
     s += a; mx = fmaxf(mx, a); mn = fminf(mn, a);
   }
   Red4 r = block_red4(s, 0.0, mx, mn);
   const double mean = r.s / n;
   double q = 0.0, sq = 0.0;
-  for (int i = threadIdx.x; i < n; i += 256) {
+  for (int i = threadIdx.x; i < n; i += blockDim.x) {
     const double a = adv[rowidx ? rowidx[i] : i];
     q += (a - mean) * (a - mean);
     sq += a * a;
@@ -352,6 +353,10 @@ __global__ __launch_bounds__(256) void adv_stats_kernel(const float* __restrict_
     st[ST_ADV_SUMSQ] = (float)r2.s2;
     st[ST_ADV_CNT] = (float)n;
   }
+}
+__global__ __launch_bounds__(256) void adv_stats_kernel(const float* __restrict__ adv, const int* __restrict__ rowidx, int n,
+                                                        float* __restrict__ st) {
+  adv_stats_body(adv, rowidx, n, st);
 }
 // Data-parallel: recompute mean/std from the all-reduced (sum, sumsq, count).
 __global__ void adv_stats_finalize_kernel(float* st) {
@@ -368,7 +373,7 @@ __global__ __launch_bounds__(256) void critic_loss_kernel(const float* __restric
                                                           int n, float inv_n, int clipped, float clip,
                                                           float* __restrict__ dvalues, float* __restrict__ st) {
   double s = 0.0;
-  for (int i = threadIdx.x; i < n; i += 256) {
+  for (int i = threadIdx.x; i < n; i += blockDim.x) {
     const int slot = rowidx ? rowidx[i] : i;
     const float v = values[(int64_t)i * OUT_LD], r = ret[slot];
     float g, l;
@@ -400,14 +405,14 @@ __global__ __launch_bounds__(256) void critic_loss_kernel(const float* __restric
 // mean [n][OUT_LD] and logstd [A]. logp_old comes from the frozen target policy's mean/logstd on the same
 // minibatch. Advantages are normalised with the minibatch statistics in st (ppo.py:148). Single block.
 // inv_n is 1/(global batch) so that data-parallel ranks sum to the big-batch gradient.
-__global__ __launch_bounds__(256) void actor_loss_kernel(const float* __restrict__ mean, const float* __restrict__ logstd,
+__global__ __launch_bounds__(1024) void actor_loss_kernel(const float* __restrict__ mean, const float* __restrict__ logstd,
                                                          const float* __restrict__ tmean, const float* __restrict__ tlogstd,
                                                          const float* __restrict__ logp_old,
                                                          const float* __restrict__ acts, const float* __restrict__ adv,
                                                          const int* __restrict__ rowidx, int n, int A, float inv_n,
                                                          float clip, float ent_coef, float* __restrict__ dmean,
                                                          float* __restrict__ dlogstd, float* __restrict__ st) {
-  __shared__ float sdl[4][8];
+  __shared__ float sdl[16][8];
   float ls[8], sg[8], lsg[8], tls[8], tsg[8], tlsg[8], dl[8];
   float ent = 0.f;
   for (int a = 0; a < 8; ++a) {
@@ -423,7 +428,7 @@ __global__ __launch_bounds__(256) void actor_loss_kernel(const float* __restrict
   const float amean = st[ST_ADV_MEAN], astd = st[ST_ADV_STD];
   double s_lp = 0.0, s_lp2 = 0.0, s_sur = 0.0;
   float lp_mx = -INFINITY, lp_mn = INFINITY, r_mx = -INFINITY, r_mn = INFINITY;
-  for (int i = threadIdx.x; i < n; i += 256) {
+  for (int i = threadIdx.x; i < n; i += blockDim.x) {
     const int slot = rowidx ? rowidx[i] : i;
     float lp = 0.f, lpo = 0.f, z2[8], dm[8];
     for (int a = 0; a < A; ++a) {
@@ -464,7 +469,8 @@ __global__ __launch_bounds__(256) void actor_loss_kernel(const float* __restrict
   if (threadIdx.x < A) {
     const int a = threadIdx.x;
     const float raw = logstd[a];
-    float g = sdl[0][a] + sdl[1][a] + sdl[2][a] + sdl[3][a];
+    float g = 0.f;
+    for (int k = 0; k < (int)(blockDim.x >> 6); ++k) g += sdl[k][a];
     // entropy term: -ent_coef * mean_b(sum_a log sigma_a + const); each local sample carries weight inv_n
     g += -ent_coef * inv_n * (float)n;
     dlogstd[a] = (raw >= LOG_SIG_MIN && raw <= LOG_SIG_MAX) ? g : 0.f;
@@ -573,11 +579,16 @@ __global__ void ctl_set_kernel(UpdCtl* c, int upd_index, long long step, double 
 }
 // Opens update #upd_index: selects its rows (identity when rowidx_all is null), clears the statistics record and
 // advances the Adam step / bias corrections (double precision, like torch/optim/adam.py::_single_tensor_adam).
+// adv != null: also the advantage statistics of the selected rows (adv_stats_kernel's work, one launch less).
 __global__ __launch_bounds__(256) void upd_begin_kernel(UpdCtl* c, const int* __restrict__ rowidx_all, int n,
-                                                        int* __restrict__ rowidx_cur, float* __restrict__ stats_cur) {
+                                                        int* rowidx_cur, float* stats_cur, const float* __restrict__ adv) {
   const int u = c->upd_index;
   for (int i = threadIdx.x; i < n; i += 256) rowidx_cur[i] = rowidx_all ? rowidx_all[(int64_t)u * n + i] : i;
   if (threadIdx.x < ST_SIZE) stats_cur[threadIdx.x] = 0.f;
+  if (adv != nullptr) {
+    __syncthreads();  // rowidx_cur and the cleared record are visible to the whole block
+    adv_stats_body(adv, rowidx_cur, n, stats_cur);
+  }
   if (threadIdx.x == 0) {
     const long long step = c->step + 1;
     c->step = step;

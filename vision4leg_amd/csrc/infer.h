@@ -62,7 +62,8 @@ template <typename T, int MT, int NTW, int KS, typename AT>
 __device__ __forceinline__ void block_gemm(f32x4 (&acc)[MT][NTW], const AT* sA, int lda, const T* __restrict__ Wp, int Kp,
                                            const int (&ntile)[NTW], int lane) {
   typedef typename Frag<T>::type frag_t;
-  constexpr int PD = KS < 4 ? KS : 4;
+  // ring depth: every step in flight when that costs <= 16 fragment registers sets, else 4 steps
+  constexpr int PD = KS * NTW <= 16 ? KS : (KS < 4 ? KS : 4);
   const int fr = lane & 15, fg = (lane >> 4) * 8;
   const T* wrow[NTW];
 #pragma unroll

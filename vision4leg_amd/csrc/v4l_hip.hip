@@ -1790,11 +1790,12 @@ int v4l_trainer_critic_grads(v4l_trainer* tr, const v4l_rollout* ro, int n, cons
   float* st = tr->stats_cur;
   const int* rowidx = tr->rowidx_cur;
   g_op = "ctl";
-  V4L_KLAUNCH("upd_begin", 0, s, upd_begin_kernel, dim3(1), dim3(256), 0, s, tr->ctl, tr->rowidx_all, n, tr->rowidx_cur, st);
+  // selects the rows of this update, clears the statistics record, advances Adam's step, advantage statistics
+  V4L_KLAUNCH("upd_begin", 0, s, upd_begin_kernel, dim3(1), dim3(256), 0, s, tr->ctl, tr->rowidx_all, n, tr->rowidx_cur, st,
+              ro->advs_dev);
   V4L_LAUNCH_CHECK();
-  V4L_HIP_CHECK(hipMemsetAsync(tr->g_vf, 0, (size_t)vf->total_params * sizeof(float), s));
-  V4L_KLAUNCH("adv_stats", 0, s, adv_stats_kernel, dim3(1), dim3(256), 0, s, ro->advs_dev, rowidx, n, st);
-  V4L_LAUNCH_CHECK();
+  // (no clearing of g_vf / g_pf: v4l_net_backward writes every element of the flat gradient — tests/test_gpu_parity.py
+  // test_backward starts from a NaN-filled buffer)
   if ((rc = v4l_net_pack(vf, stream))) return rc;
   { PhaseScope ps("vf.fwd");
   if ((rc = v4l_net_forward(vf, ro->state_dev, ro->image_dev, rowidx, n, tr->ws, 1, stream))) return rc; }
@@ -1838,7 +1839,6 @@ int v4l_trainer_actor_grads(v4l_trainer* tr, const v4l_rollout* ro, int n, const
     hipLaunchKernelGGL(adv_stats_finalize_kernel, dim3(1), dim3(1), 0, s, st);
     V4L_LAUNCH_CHECK();
   }
-  V4L_HIP_CHECK(hipMemsetAsync(tr->g_pf, 0, (size_t)pf->total_params * sizeof(float), s));
   const Layout Lp = pf->layout(n), Lt = tp->layout(n);
   float* ws_t = tr->ws + std::max(Lp.total, tr->vf->layout(n).total);
   // frozen target policy (packed once per epoch by v4l_trainer_sync_target) on the trainer's aux stream, next to the
@@ -1865,7 +1865,7 @@ int v4l_trainer_actor_grads(v4l_trainer* tr, const v4l_rollout* ro, int n, const
   }
   const float inv_n = 1.f / ((float)n * (float)hp->world_size);
   g_op = "loss";
-  V4L_KLAUNCH("actor_loss", 0, s, actor_loss_kernel, dim3(1), dim3(256), 0, s, tr->ws + Lp.out, pf->p[pf->logstd],
+  V4L_KLAUNCH("actor_loss", 0, s, actor_loss_kernel, dim3(1), dim3(n >= 512 ? 1024 : 256), 0, s, tr->ws + Lp.out, pf->p[pf->logstd],
                      stored ? (const float*)nullptr : (const float*)(ws_t + Lt.out), stored ? (const float*)nullptr : (const float*)tp->p[tp->logstd],
                      ro->logp_old_dev, ro->acts_dev, ro->advs_dev, rowidx, n, pf->cfg.out_dim, inv_n, hp->clip_para,
                      hp->entropy_coeff, tr->ws + Lp.dout, tr->g_pf + pf->params[pf->logstd].goff, st);
