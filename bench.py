@@ -227,9 +227,40 @@ def cpu_baseline(wl, compute):
     }
 
 
+PEAK_HBM = 8000.0  # GB/s, MI355X_MICROARCH.md
+
+
+def algo_bytes(kernel, wl, compute):
+    """ALGORITHMIC HBM bytes of one launch of the update's big kernels (DESIGN.md section 4 derives the per-sample figures):
+    every operand / result the kernel must read / write once, at the storage width it has in this mode."""
+    n, t = wl["B"], (2 if compute == "bf16" else 4)
+    R = 17 * n                                   # token rows
+    tok = 64 * 4                                 # one fp32 token row
+    conv_act = (225 * 32 + 36 * 64 + 16 * 64) * 4  # c1 + c2 + c3 of one sample, fp32
+    blocks = min(n, 256)
+    per_launch = {
+        # image + proprio row in; c1, c2, c3, tokens, 2 MLP activations out
+        "fused_encoder": n * (16384 * t + 128 * 4 + conv_act + 17 * tok + 2 * 256 * 4),
+        # x in; x out, qkv, P, xhat1/2, rstd1/2 (fp32) + layer-input copy, ctx, x1, f (T)
+        "fused_layer": R * (2 * tok + 192 * 4 + 2 * tok + 8 + (64 + 64 + 64 + 256) * t) + n * 289 * 4,
+        # dy, xhat1/2, rstd, qkv (fp32), P, f (T) in; dz2, df, dz1, dqkv (T) + dx (fp32) out
+        "fused_layer_bwd": R * (tok + 2 * tok + 8 + 192 * 4 + 256 * t + (64 + 256 + 64 + 192) * t + tok) + n * 289 * 4,
+        # dc3, c2, c1 (fp32) + image (T) in; one dW1 + dW2 slab per block out
+        "fused_conv_bwd": n * ((16 * 64 + 36 * 64 + 225 * 32) * 4 + 16384 * t) + blocks * (32 * 256 + 64 * 512) * 4,
+        "fused_conv3_wgrad": n * (16 * 64 + 36 * 64) * 4 + blocks * 64 * 576 * 4,
+        # both operands of the 4 linears x 2 layers (T) in; 55 slabs of the 4 weight shapes x 2 layers out
+        "gemm_tn_wide": 2 * R * 2 * (64 + 256 + 64 + 192) * t + 2 * 55 * 49152 * 4,
+    }
+    for k in sorted(per_launch, key=len, reverse=True):  # longest name first: fused_layer_bwd_* before fused_layer_*
+        if kernel == k or kernel.startswith(k + "_"):
+            return float(per_launch[k])
+    return None
+
+
 def roofline(ep, compute, breakdown_path):
-    """Per-op timings of ONE profiled pass of (ii)-(iv) (HIP events around every launch, on the launch stream). The
-    dominant entry (largest total time) is reported against the dense MFMA peak of the contraction type."""
+    """Per-op timings of ONE profiled pass of (ii)-(iv): HIP events around every launch, on the launch stream. The
+    dominant kernel (largest total time) is priced against BOTH ceilings — algorithmic FLOPs / dense MFMA peak and
+    algorithmic HBM bytes / 8 TB/s — and reported against the one that bounds it (the larger lower-bound time)."""
     import ctypes as C
     from vision4leg_amd import _lib
     L = _lib.lib()
@@ -265,18 +296,42 @@ def roofline(ep, compute, breakdown_path):
                 for line in buf.value.decode().splitlines():
                     label, calls, us, fl = line.split("\t")
                     f.write("%-70s %6d %12.1f %9.2f\n" % (label, int(calls), float(us), float(us) / int(calls)))
-    gemm = [r for r in rows if r[3] > 0]
-    label, calls, us, fl = gemm[0] if gemm else rows[0]
-    ach = fl / us * 1e-6  # TFLOP/s
+    # dominant KERNEL: sum the (phase, op) rows of the same kernel name
+    per_kernel = {}
+    for label, calls, us, fl in rows:
+        k = label.split("|")[-1]
+        c0, u0, f0 = per_kernel.get(k, (0, 0.0, 0.0))
+        per_kernel[k] = (c0 + calls, u0 + us, f0 + fl)
+    kern, (calls, us, fl) = max(per_kernel.items(), key=lambda kv: kv[1][1])
+    avg_us = us / calls
+    tf = fl / us * 1e-6                      # TFLOP/s
+    by = algo_bytes(kern, ep.wl, compute)
+    gbs = by / avg_us * 1e-3 if by else None  # GB/s
+    t_mfma = fl / calls / (PEAK[compute] * 1e12) * 1e6
+    t_hbm = by / (PEAK_HBM * 1e9) * 1e6 if by else 0.0
+    hbm_bound = t_hbm >= t_mfma
+    traffic, traffic_src = None, None
+    pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")  # written by tools/pmc_pass.sh + pmc_summary.py (same command)
+    if os.path.exists(pmc):
+        try:
+            rec = json.load(open(pmc)).get(kern)
+            if rec:
+                traffic, traffic_src = rec["hbm_bytes_per_launch"], rec.get("source")
+        except Exception:
+            pass
     all_flops = sum(r[3] for r in rows)
     return {
-        "bound": "mfma", "kernel": label, "achieved": round(ach, 2), "peak": PEAK[compute], "unit": "TFLOP/s",
-        "frac": round(ach / PEAK[compute], 5), "traffic": None,
-        "avg_launch_us": round(us / calls, 2), "launches": calls, "share_of_kernel_time": round(us / total_us, 4),
-        "all_kernels_achieved": round(all_flops / total_us * 1e-6, 2),
-        "all_kernels_frac": round(all_flops / total_us * 1e-6 / PEAK[compute], 5),
-        "method": "HIP events around every launch of one extra (untimed) epoch-update on the launch stream; FLOPs = "
-                  "2*M*N*K of the logical contraction per launch",
+        "bound": "hbm" if hbm_bound else "mfma", "kernel": kern,
+        "achieved": round(gbs, 1) if hbm_bound else round(tf, 2),
+        "peak": PEAK_HBM if hbm_bound else PEAK[compute], "unit": "GB/s" if hbm_bound else "TFLOP/s",
+        "frac": round((gbs / PEAK_HBM) if hbm_bound else (tf / PEAK[compute]), 5),
+        "traffic": traffic, "traffic_source": traffic_src,
+        "algorithmic_bytes_per_launch": by, "algorithmic_flops_per_launch": fl / calls,
+        "hbm_frac": round(gbs / PEAK_HBM, 5) if gbs else None, "mfma_frac": round(tf / PEAK[compute], 5),
+        "avg_launch_us": round(avg_us, 2), "launches": calls, "share_of_kernel_time": round(us / total_us, 4),
+        "all_kernels_tflops": round(all_flops / total_us * 1e-6, 2),
+        "method": "HIP events around every launch of one extra (untimed) epoch-update on the launch stream; achieved = "
+                  "algorithmic bytes (bench.py algo_bytes, DESIGN.md section 4) or 2*M*N*K FLOPs per launch / average launch time",
     }
 
 
