@@ -1,0 +1,26 @@
+import os, sys, ctypes as C
+os.environ["V4L_LIB"] = "/root/repo/tools/probe/libv4l_timing.so"
+sys.path.insert(0,'/root/repo'); sys.path.insert(0,'/root/repo/tests')
+import numpy as np, torch, util
+os.environ["V4L_COMPUTE"]="bf16"
+import vision4leg_amd.torchrl.networks as networks, vision4leg_amd.torchrl.policies as policies
+from vision4leg_amd import _lib
+dev=torch.device("cuda:0")
+case=dict(util.CASES["loco_s93"], B=1024); n=1024
+torch.manual_seed(0); pf,vf=util.build_nets(networks,policies,case); pf,vf=pf.to(dev),vf.to(dev)
+hip=vf.hip
+obs=torch.randn(n, 93+16384, device=dev)
+st_,im,_=hip.stage(obs)
+for it in range(3):
+    hip.forward(st_, im, n, train=True)
+    dout=torch.randn(n,16,device=dev); grads=torch.zeros(hip.total_params,device=dev)
+    hip.backward(st_, im, n, dout, grads)
+torch.cuda.synchronize()
+L=_lib.lib(); L.v4l_debug_stamps.argtypes=[C.c_void_p]; L.v4l_debug_stamps.restype=C.c_int
+buf=(C.c_longlong*32)(); L.v4l_debug_stamps(buf)
+st=np.array(buf[16:23],dtype=np.int64)
+names=["loads->LDS","dgrad3 (gather GEMM)","bias2+wgrad2","dgrad2 (gather GEMM)","bias1","wgrad1"]
+print("bwd_conv_kernel block 0, sample 0, phase cycles (clock64, 100 MHz s_memtime or shader clock):")
+for nm,c in zip(names,np.diff(st)): print("  %-22s %8d"%(nm,c))
+print("  total %d"%(st[6]-st[0]))
+st=np.array(buf[:9],dtype=np.int64); print("layer kernel stamps diff", np.diff(st))

@@ -461,24 +461,38 @@ __device__ __forceinline__ f32x8 frag_of_t(const float (&v)[8]) { return frag_of
 template <typename T, int MT, int KS, class RowF>
 __device__ __forceinline__ void gather_gemm(f32x4 (&acc)[MT], const T* __restrict__ W, int Kp, int ntile, int lane, RowF arow) {
   typedef typename Frag<T>::type frag_t;
-  constexpr int PD = KS < 6 ? KS : 6;
+  constexpr int PD = KS < 4 ? KS : 4;
   const int fr = lane & 15, fg = (lane >> 4) * 8;
   const T* wrow = W + (int64_t)(ntile * 16 + fr) * Kp + fg;
   frag_t fb[PD];
 #pragma unroll
   for (int d = 0; d < PD; ++d) fb[d] = *reinterpret_cast<const frag_t*>(wrow + d * 32);
+  // the A fragments of step ks+1 are read from LDS before the MFMAs of step ks issue (their latency hides behind them)
+  frag_t fa[MT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) fa[mt] = afrag<T>(arow(mt, 0) + fg);
 #pragma unroll
   for (int ks = 0; ks < KS; ++ks) {
     const frag_t cur = fb[ks % PD];
     if (ks + PD < KS) fb[ks % PD] = *reinterpret_cast<const frag_t*>(wrow + (ks + PD) * 32);
+    frag_t fn[MT];
+    if (ks + 1 < KS) {
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) fn[mt] = afrag<T>(arow(mt, (ks + 1) >> 1) + ((ks + 1) & 1) * 32 + fg);
+    }
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
-      const frag_t fa = afrag<T>(arow(mt, ks >> 1) + (ks & 1) * 32 + fg);
-      mma_k32(acc[mt], cur, fa);  // transposed tile: acc[mt][r] = out[16*mt + lane&15][16*ntile + 4*(lane>>4) + r]
+      mma_k32(acc[mt], cur, fa[mt]);  // transposed tile: acc[mt][r] = out[16*mt + lane&15][16*ntile + 4*(lane>>4) + r]
+      if (ks + 1 < KS) fa[mt] = fn[mt];
     }
   }
 }
 
+#ifdef V4L_INFER_TIMING
+#define CONV_STAMP(i) do { if (blockIdx.x == 0 && threadIdx.x == 0 && smp == 0) g_inf_stamps[16 + (i)] = clock64(); } while (0)
+#else
+#define CONV_STAMP(i)
+#endif
 template <typename T>
 __global__ __launch_bounds__(512) void bwd_conv_kernel(BwdConv a) {
   typedef BwdConvLds<T> LY;
@@ -503,37 +517,61 @@ __global__ __launch_bounds__(512) void bwd_conv_kernel(BwdConv a) {
     for (int c = 0; c < 4; ++c) acc2[t][c] = f32x4{0.f, 0.f, 0.f, 0.f};
     acc1[t] = f32x4{0.f, 0.f, 0.f, 0.f};
   }
-  float bias2 = 0.f, bias1 = 0.f;  // thread co (< 64 / 32): column sums of dc2 / dc1
+  float bias2 = 0.f, bias1 = 0.f;  // per-thread partial column sums of dc2 (co = tid & 63) / dc1 (co = tid & 31)
   for (int i = tid; i < 12 * LY::LF; i += NTH) sdc2[36 * LY::LF + i] = 0.f;
   for (int i = tid; i < LY::LF; i += NTH) sdc3[16 * LY::LF + i] = 0.f;
   constexpr int CH = 4 / LY::IMGP;  // image channels resident at a time
 
+  // One sample's inputs as 11 16-byte loads per thread, all issued back to back (a load -> LDS-store loop compiles to
+  // one s_waitcnt vmcnt(0) per load) and issued for sample s+1 before the last MFMA phase of sample s.
+  constexpr int V = 16 / sizeof(T);  // image elements per 16-byte load
+  typedef __attribute__((ext_vector_type(4))) T t4_t;  // c1 is held in the operand type already (half the registers)
+  float4 p3, p2[2], pim[4];
+  t4_t p1[4];
+  auto preload = [&](int smp) {
+    const float* g3 = a.dc3 + (int64_t)smp * 16 * 64;
+    const float* g2 = a.c2 + (int64_t)smp * 36 * 64;
+    const float* g1 = a.c1 + (int64_t)smp * 225 * 32;
+    const int64_t slot = a.rowidx != nullptr ? a.rowidx[smp] : smp;
+    const T* gi = reinterpret_cast<const T*>(a.image) + slot * 16384;
+    p3 = *reinterpret_cast<const float4*>(g3 + (tid & 255) * 4);
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const int i4 = tid + k * NTH;
+      p2[k] = *reinterpret_cast<const float4*>(g2 + (i4 < 36 * 16 ? i4 : 0) * 4);
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int i4 = tid + k * NTH;
+      const float4 v = *reinterpret_cast<const float4*>(g1 + (i4 < 225 * 8 ? i4 : 0) * 4);
+      p1[k] = t4_t{(T)v.x, (T)v.y, (T)v.z, (T)v.w};
+      pim[k] = *reinterpret_cast<const float4*>(gi + (int64_t)i4 * V);
+    }
+  };
+  auto stage = [&]() {
+    if (tid < 256) *reinterpret_cast<float4*>(sdc3 + (tid >> 4) * LY::LF + (tid & 15) * 4) = p3;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const int i4 = tid + k * NTH;
+      if (i4 < 36 * 16) *reinterpret_cast<float4*>(sc2 + (i4 >> 4) * LY::LF + (i4 & 15) * 4) = p2[k];
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int i4 = tid + k * NTH;
+      if (i4 < 225 * 8) *reinterpret_cast<t4_t*>(sc1 + (i4 >> 3) * LY::LC1 + (i4 & 7) * 4) = p1[k];
+      *reinterpret_cast<float4*>(simg + i4 * V) = pim[k];
+    }
+  };
+  if ((int)blockIdx.x < a.n) preload(blockIdx.x);
+
   for (int smp = blockIdx.x; smp < a.n; smp += gridDim.x) {
     __syncthreads();  // previous sample's readers are done
+    CONV_STAMP(0);
     const int64_t slot = a.rowidx != nullptr ? a.rowidx[smp] : smp;
     const T* gimg = reinterpret_cast<const T*>(a.image) + slot * 16384;
-    {  // ---- dc3, c2, c1, image of this sample -> LDS
-      const float* g3 = a.dc3 + (int64_t)smp * 16 * 64;
-      const float* g2 = a.c2 + (int64_t)smp * 36 * 64;
-      const float* g1 = a.c1 + (int64_t)smp * 225 * 32;
-      if (tid < 256) {
-        const int r = tid >> 4, c4 = (tid & 15) * 4;
-        *reinterpret_cast<float4*>(sdc3 + r * LY::LF + c4) = *reinterpret_cast<const float4*>(g3 + r * 64 + c4);
-      }
-      for (int i4 = tid; i4 < 36 * 16; i4 += NTH) {
-        const int r = i4 >> 4, c4 = (i4 & 15) * 4;
-        *reinterpret_cast<float4*>(sc2 + r * LY::LF + c4) = *reinterpret_cast<const float4*>(g2 + r * 64 + c4);
-      }
-      for (int i4 = tid; i4 < 225 * 8; i4 += NTH) {
-        const int r = i4 >> 3, c4 = (i4 & 7) * 4;
-        const float4 v = *reinterpret_cast<const float4*>(g1 + r * 32 + c4);
-        st4(sc1 + r * LY::LC1 + c4, v.x, v.y, v.z, v.w);
-      }
-      constexpr int V = 16 / sizeof(T);  // elements per 16-byte load
-      for (int i = tid; i < CH * 4096 / V; i += NTH)
-        *reinterpret_cast<float4*>(simg + i * V) = *reinterpret_cast<const float4*>(gimg + i * V);
-    }
+    stage();  // dc3, c2, c1, image (first channel group) of this sample: registers -> LDS
     __syncthreads();
+    CONV_STAMP(1);
     {  // ---- dc2 = conv3' (gather form): rows = 36 input pixels (3 row tiles), K = 9 taps x 64 co, N = 64 ci
       const int nt = wave & 3;
       const T* W = reinterpret_cast<const T*>(a.w3d);
@@ -570,9 +608,10 @@ __global__ __launch_bounds__(512) void bwd_conv_kernel(BwdConv a) {
       else run(std::integral_constant<int, 1>{}, 2);
     }
     __syncthreads();
-    if (tid < 64) {
+    CONV_STAMP(2);
+    {  // column sums of dc2: thread (co = tid & 63, part = tid >> 6) takes pixels part, part + 8, ...
       float t = 0.f;
-      for (int p = 0; p < 36; ++p) t += sdc2[p * LY::LF + tid];
+      for (int p = tid >> 6; p < 36; p += 8) t += sdc2[p * LY::LF + (tid & 63)];
       bias2 += t;
     }
     // ---- dW2 += dc2^T col(c1): contraction over the 36 output pixels (two K=32 steps)
@@ -608,6 +647,7 @@ __global__ __launch_bounds__(512) void bwd_conv_kernel(BwdConv a) {
         for (int c = 0; c < 4; ++c) mma_k32(acc2[t][c], fx, fy[c]);
       }
     }
+    CONV_STAMP(3);
     {  // ---- dc1 = conv2' (gather form): wave pair = stride-parity class (py,px); rows = its <= 8x8 input pixels,
        //      K = 2x2 taps x 64 co, N = 32 ci (one 16-wide tile per wave)
       const int cls = wave >> 1, py = cls >> 1, pxx = cls & 1, nt = wave & 1;
@@ -634,17 +674,19 @@ __global__ __launch_bounds__(512) void bwd_conv_kernel(BwdConv a) {
       }
     }
     __syncthreads();
-    if (tid < 32) {
+    CONV_STAMP(4);
+    {  // column sums of dc1: thread (co = tid & 31, part = tid >> 5) takes pixels part, part + 16, ...
       float t = 0.f;
-      for (int p = 0; p < 225; ++p) t += sdc1[p * LY::LD1 + tid];
+      for (int p = tid >> 5; p < 225; p += 16) t += sdc1[p * LY::LD1 + (tid & 31)];
       bias1 += t;
     }
+    if (smp + (int)gridDim.x < a.n) preload(smp + gridDim.x);  // in flight during the dW1 phase below
+    CONV_STAMP(5);
     // ---- dW1 += dc1^T col(image): contraction over the 225 output pixels (eight K=32 steps)
 #pragma unroll 1
     for (int h = 0; h < LY::IMGP; ++h) {
       if (h > 0) {  // fp32 parity mode: the second channel pair replaces the first
         __syncthreads();
-        constexpr int V = 16 / sizeof(T);
         for (int i = tid; i < CH * 4096 / V; i += NTH)
           *reinterpret_cast<float4*>(simg + i * V) = *reinterpret_cast<const float4*>(gimg + (int64_t)h * CH * 4096 + i * V);
         __syncthreads();
@@ -680,6 +722,7 @@ __global__ __launch_bounds__(512) void bwd_conv_kernel(BwdConv a) {
         }
       }
     }
+    CONV_STAMP(6);
   }
   // ---- the block's partial weight-grads -> its slab (wgrad_reduce_kernel sums the slabs in a fixed order)
   {
@@ -695,8 +738,23 @@ __global__ __launch_bounds__(512) void bwd_conv_kernel(BwdConv a) {
     for (int t = 0; t < 4; ++t)
       *reinterpret_cast<float4*>(o1 + (ct1 * 16 + fr) * 256 + (ch1 * 4 + t) * 16 + qr) =
           float4{acc1[t][0], acc1[t][1], acc1[t][2], acc1[t][3]};
-    if (tid < 64) a.bslab2[(int64_t)blockIdx.x * 64 + tid] = bias2;
-    if (tid < 32) a.bslab1[(int64_t)blockIdx.x * 32 + tid] = bias1;
+    __syncthreads();
+    float* red = sdc1;  // 512 + 512 partials
+    red[tid] = bias2;
+    red[NTH + tid] = bias1;
+    __syncthreads();
+    if (tid < 64) {
+      float t = 0.f;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) t += red[k * 64 + tid];
+      a.bslab2[(int64_t)blockIdx.x * 64 + tid] = t;
+    }
+    if (tid < 32) {
+      float t = 0.f;
+#pragma unroll
+      for (int k = 0; k < 16; ++k) t += red[NTH + k * 32 + tid];
+      a.bslab1[(int64_t)blockIdx.x * 32 + tid] = t;
+    }
   }
 }
 
