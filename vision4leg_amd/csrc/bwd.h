@@ -467,29 +467,20 @@ __device__ __forceinline__ void gather_gemm(f32x4 (&acc)[MT], const T* __restric
   frag_t fb[PD];
 #pragma unroll
   for (int d = 0; d < PD; ++d) fb[d] = *reinterpret_cast<const frag_t*>(wrow + d * 32);
-  // the A fragments of step ks+1 are read from LDS before the MFMAs of step ks issue (their latency hides behind them)
-  frag_t fa[MT];
-#pragma unroll
-  for (int mt = 0; mt < MT; ++mt) fa[mt] = afrag<T>(arow(mt, 0) + fg);
 #pragma unroll
   for (int ks = 0; ks < KS; ++ks) {
     const frag_t cur = fb[ks % PD];
     if (ks + PD < KS) fb[ks % PD] = *reinterpret_cast<const frag_t*>(wrow + (ks + PD) * 32);
-    frag_t fn[MT];
-    if (ks + 1 < KS) {
-#pragma unroll
-      for (int mt = 0; mt < MT; ++mt) fn[mt] = afrag<T>(arow(mt, (ks + 1) >> 1) + ((ks + 1) & 1) * 32 + fg);
-    }
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
-      mma_k32(acc[mt], cur, fa[mt]);  // transposed tile: acc[mt][r] = out[16*mt + lane&15][16*ntile + 4*(lane>>4) + r]
-      if (ks + 1 < KS) fa[mt] = fn[mt];
+      const frag_t fa = afrag<T>(arow(mt, ks >> 1) + (ks & 1) * 32 + fg);
+      mma_k32(acc[mt], cur, fa);  // transposed tile: acc[mt][r] = out[16*mt + lane&15][16*ntile + 4*(lane>>4) + r]
     }
   }
 }
 
 #ifdef V4L_INFER_TIMING
-#define CONV_STAMP(i) do { if (blockIdx.x == 0 && threadIdx.x == 0 && smp == 0) g_inf_stamps[16 + (i)] = clock64(); } while (0)
+#define CONV_STAMP(i) do { if (blockIdx.x == 0 && threadIdx.x == 0 && smp == 3 * (int)gridDim.x) g_inf_stamps[16 + (i)] = clock64(); } while (0)
 #else
 #define CONV_STAMP(i)
 #endif
@@ -522,54 +513,32 @@ __global__ __launch_bounds__(512) void bwd_conv_kernel(BwdConv a) {
   for (int i = tid; i < LY::LF; i += NTH) sdc3[16 * LY::LF + i] = 0.f;
   constexpr int CH = 4 / LY::IMGP;  // image channels resident at a time
 
-  // One sample's inputs as 11 16-byte loads per thread, all issued back to back (a load -> LDS-store loop compiles to
-  // one s_waitcnt vmcnt(0) per load) and issued for sample s+1 before the last MFMA phase of sample s.
   constexpr int V = 16 / sizeof(T);  // image elements per 16-byte load
-  typedef __attribute__((ext_vector_type(4))) T t4_t;  // c1 is held in the operand type already (half the registers)
-  float4 p3, p2[2], pim[4];
-  t4_t p1[4];
-  auto preload = [&](int smp) {
-    const float* g3 = a.dc3 + (int64_t)smp * 16 * 64;
-    const float* g2 = a.c2 + (int64_t)smp * 36 * 64;
-    const float* g1 = a.c1 + (int64_t)smp * 225 * 32;
-    const int64_t slot = a.rowidx != nullptr ? a.rowidx[smp] : smp;
-    const T* gi = reinterpret_cast<const T*>(a.image) + slot * 16384;
-    p3 = *reinterpret_cast<const float4*>(g3 + (tid & 255) * 4);
-#pragma unroll
-    for (int k = 0; k < 2; ++k) {
-      const int i4 = tid + k * NTH;
-      p2[k] = *reinterpret_cast<const float4*>(g2 + (i4 < 36 * 16 ? i4 : 0) * 4);
-    }
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const int i4 = tid + k * NTH;
-      const float4 v = *reinterpret_cast<const float4*>(g1 + (i4 < 225 * 8 ? i4 : 0) * 4);
-      p1[k] = t4_t{(T)v.x, (T)v.y, (T)v.z, (T)v.w};
-      pim[k] = *reinterpret_cast<const float4*>(gi + (int64_t)i4 * V);
-    }
-  };
-  auto stage = [&]() {
-    if (tid < 256) *reinterpret_cast<float4*>(sdc3 + (tid >> 4) * LY::LF + (tid & 15) * 4) = p3;
-#pragma unroll
-    for (int k = 0; k < 2; ++k) {
-      const int i4 = tid + k * NTH;
-      if (i4 < 36 * 16) *reinterpret_cast<float4*>(sc2 + (i4 >> 4) * LY::LF + (i4 & 15) * 4) = p2[k];
-    }
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const int i4 = tid + k * NTH;
-      if (i4 < 225 * 8) *reinterpret_cast<t4_t*>(sc1 + (i4 >> 3) * LY::LC1 + (i4 & 7) * 4) = p1[k];
-      *reinterpret_cast<float4*>(simg + i4 * V) = pim[k];
-    }
-  };
-  if ((int)blockIdx.x < a.n) preload(blockIdx.x);
-
   for (int smp = blockIdx.x; smp < a.n; smp += gridDim.x) {
     __syncthreads();  // previous sample's readers are done
     CONV_STAMP(0);
     const int64_t slot = a.rowidx != nullptr ? a.rowidx[smp] : smp;
     const T* gimg = reinterpret_cast<const T*>(a.image) + slot * 16384;
-    stage();  // dc3, c2, c1, image (first channel group) of this sample: registers -> LDS
+    {  // ---- dc3, c2, c1, image of this sample -> LDS
+      const float* g3 = a.dc3 + (int64_t)smp * 16 * 64;
+      const float* g2 = a.c2 + (int64_t)smp * 36 * 64;
+      const float* g1 = a.c1 + (int64_t)smp * 225 * 32;
+      if (tid < 256) {
+        const int r = tid >> 4, c4 = (tid & 15) * 4;
+        *reinterpret_cast<float4*>(sdc3 + r * LY::LF + c4) = *reinterpret_cast<const float4*>(g3 + r * 64 + c4);
+      }
+      for (int i4 = tid; i4 < 36 * 16; i4 += NTH) {
+        const int r = i4 >> 4, c4 = (i4 & 15) * 4;
+        *reinterpret_cast<float4*>(sc2 + r * LY::LF + c4) = *reinterpret_cast<const float4*>(g2 + r * 64 + c4);
+      }
+      for (int i4 = tid; i4 < 225 * 8; i4 += NTH) {
+        const int r = i4 >> 3, c4 = (i4 & 7) * 4;
+        const float4 v = *reinterpret_cast<const float4*>(g1 + r * 32 + c4);
+        st4(sc1 + r * LY::LC1 + c4, v.x, v.y, v.z, v.w);
+      }
+      for (int i = tid; i < CH * 4096 / V; i += NTH)
+        *reinterpret_cast<float4*>(simg + i * V) = *reinterpret_cast<const float4*>(gimg + i * V);
+    }
     __syncthreads();
     CONV_STAMP(1);
     {  // ---- dc2 = conv3' (gather form): rows = 36 input pixels (3 row tiles), K = 9 taps x 64 co, N = 64 ci
@@ -680,7 +649,6 @@ __global__ __launch_bounds__(512) void bwd_conv_kernel(BwdConv a) {
       for (int p = tid >> 5; p < 225; p += 16) t += sdc1[p * LY::LD1 + (tid & 31)];
       bias1 += t;
     }
-    if (smp + (int)gridDim.x < a.n) preload(smp + gridDim.x);  // in flight during the dW1 phase below
     CONV_STAMP(5);
     // ---- dW1 += dc1^T col(image): contraction over the 225 output pixels (eight K=32 steps)
 #pragma unroll 1
