@@ -736,4 +736,414 @@ __global__ __launch_bounds__(256) void infer_layer_kernel(InfLayerPair pr, InfHe
   }
 }
 
+
+// ------------------------------------------------------------------------------------------ rollout layer (16 waves)
+// The same TransformerEncoderLayer (+ heads + sampling epilogue when HEAD) for ONE sample per block, spread over 16
+// waves: a rollout step runs only 2E blocks, one per CU, so its time is the latency of one block — every phase is cut
+// into as many independent jobs as it has (12 + 8 + 16 + 8 MFMA tiles, 17 score rows, 32 norm rows) instead of four.
+// Same arithmetic, operand rounding and k order as infer_layer_kernel<T, 1, HEAD>.
+template <typename T, bool HEAD>
+__global__ __launch_bounds__(1024) void rollout_layer_kernel(InfLayerPair pr, InfHeadPair hd, InfFinish fin, int E) {
+  typedef InfLayLds<T, 1> LY;
+  constexpr int ROWS = 32;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const InfLayer& w = pr.n[blockIdx.y];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int fr = lane & 15, qr = (lane >> 4) * 4;
+  float* xs = reinterpret_cast<float*>(smem);
+  float* big = reinterpret_cast<float*>(smem + LY::xs_b);            // qkv, later z (fp32), later f (T), later heads
+  float* cx = reinterpret_cast<float*>(smem + LY::xs_b + LY::big_b); // ctx, later z2
+  float* sp = reinterpret_cast<float*>(smem + LY::xs_b + LY::big_b + LY::xs_b);
+  const int s0 = blockIdx.x;
+  const int64_t row0 = (int64_t)s0 * NTOK;
+  long long t_step = 0;
+  if constexpr (HEAD) { if (fin.ctl != nullptr) t_step = fin.ctl->t; }
+  if (tid < ROWS * (TD / 4)) {
+    const int r = tid >> 4, c4 = (tid & 15) * 4;
+    const bool ok = r < NTOK;
+    const float4 v = *reinterpret_cast<const float4*>(w.xin + (row0 + (ok ? r : 0)) * TD + c4);
+    *reinterpret_cast<float4*>(xs + r * LY::LDX + c4) = ok ? v : float4{0.f, 0.f, 0.f, 0.f};
+  }
+  __syncthreads();
+  if (wave < 12) {  // in_proj: 12 column tiles, one per wave
+    const int nt[1] = {wave};
+    f32x4 acc[2][1];
+    zero_acc(acc);
+    block_gemm<T, 2, 1, 2>(acc, xs, LY::LDX, (const T*)w.win, 64, nt, lane);
+    const int n4 = wave * 16 + qr;
+    const float4 bb = *reinterpret_cast<const float4*>(w.bin + n4);
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+      st4(big + (mt * 16 + fr) * LY::LDQ + n4, acc[mt][0][0] + bb.x, acc[mt][0][1] + bb.y, acc[mt][0][2] + bb.z,
+          acc[mt][0][3] + bb.w);
+  }
+  __syncthreads();
+  if (tid < NTOK * NTOK) {  // scores, one (i, j) per thread
+    const int i = tid / NTOK, j = tid - i * NTOK;
+    sp[i * ATT_PLD + j] = dot64(big + i * LY::LDQ, big + j * LY::LDQ + TD) * 0.125f;
+  }
+  __syncthreads();
+  if (tid < NTOK) {
+    float* p = sp + tid * ATT_PLD;
+    float mx = -INFINITY;
+#pragma unroll
+    for (int j = 0; j < NTOK; ++j) mx = fmaxf(mx, p[j]);
+    float e[NTOK], sum = 0.f;
+#pragma unroll
+    for (int j = 0; j < NTOK; ++j) { e[j] = expf(p[j] - mx); sum += e[j]; }
+    const float inv = 1.f / sum;
+#pragma unroll
+    for (int j = 0; j < NTOK; ++j) p[j] = e[j] * inv;
+  }
+  __syncthreads();
+  for (int r = wave; r < ROWS; r += 16) {  // ctx row r = P[r] V; rows >= 17: zeros
+    float a = 0.f;
+    if (r < NTOK) {
+      const float* v = big + 2 * TD + lane;
+      const float* p = sp + r * ATT_PLD;
+#pragma unroll
+      for (int j = 0; j < NTOK; ++j) a = fmaf(p[j], v[j * LY::LDQ], a);
+    }
+    cx[r * LY::LDX + lane] = a;
+  }
+  __syncthreads();
+  if (wave < 8) {  // out_proj + residual -> z (in `big`, fp32 [32][LDX]): (row tile, column tile) = (wave >> 2, wave & 3)
+    const int nt[1] = {wave & 3}, mt = wave >> 2;
+    f32x4 acc[1][1];
+    zero_acc(acc);
+    block_gemm<T, 1, 1, 2>(acc, cx + mt * 16 * LY::LDX, LY::LDX, (const T*)w.wo, 64, nt, lane);
+    const int n4 = nt[0] * 16 + qr, row = mt * 16 + fr;
+    const float4 bb = *reinterpret_cast<const float4*>(w.bo + n4);
+    const float4 xr = *reinterpret_cast<const float4*>(xs + row * LY::LDX + n4);
+    st4(big + row * LY::LDX + n4, xr.x + acc[0][0][0] + bb.x, xr.y + acc[0][0][1] + bb.y, xr.z + acc[0][0][2] + bb.z,
+        xr.w + acc[0][0][3] + bb.w);
+  }
+  __syncthreads();
+  auto ln2rows = [&](const float* z, float* out, const float* __restrict__ g, const float* __restrict__ be, float* gout) {
+    const float gg = g[lane], bb = be[lane];  // wave w: rows w and w + 16, both in flight
+    float v[2], mean[2], c[2], var[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) v[u] = z[(wave + 16 * u) * LY::LDX + lane];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) mean[u] = wave_sum(v[u]) * (1.f / TD);
+#pragma unroll
+    for (int u = 0; u < 2; ++u) { c[u] = v[u] - mean[u]; var[u] = wave_sum(c[u] * c[u]) * (1.f / TD); }
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int r = wave + 16 * u;
+      const float o = fmaf(c[u] * (1.f / sqrtf(var[u] + 1e-5f)), gg, bb);
+      if (out != nullptr) out[r * LY::LDX + lane] = o;
+      if (gout != nullptr && r < NTOK) gout[(row0 + r) * TD + lane] = o;
+    }
+  };
+  ln2rows(big, xs, w.g1, w.be1, nullptr);  // x1 -> xs
+  __syncthreads();
+  T* f = reinterpret_cast<T*>(big);
+  {  // linear1 + ReLU -> f (T): 16 column tiles, one per wave
+    const int nt[1] = {wave};
+    f32x4 acc[2][1];
+    zero_acc(acc);
+    block_gemm<T, 2, 1, 2>(acc, xs, LY::LDX, (const T*)w.w1, 64, nt, lane);
+    const int n4 = wave * 16 + qr;
+    const float4 bb = *reinterpret_cast<const float4*>(w.b1 + n4);
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+      st4(f + (mt * 16 + fr) * LY::LDF + n4, fmaxf(acc[mt][0][0] + bb.x, 0.f), fmaxf(acc[mt][0][1] + bb.y, 0.f),
+          fmaxf(acc[mt][0][2] + bb.z, 0.f), fmaxf(acc[mt][0][3] + bb.w, 0.f));
+  }
+  __syncthreads();
+  if (wave < 8) {  // linear2 + residual -> z2 (in `cx`)
+    const int nt[1] = {wave & 3}, mt = wave >> 2;
+    f32x4 acc[1][1];
+    zero_acc(acc);
+    block_gemm<T, 1, 1, 8>(acc, f + mt * 16 * LY::LDF, LY::LDF, (const T*)w.w2, 256, nt, lane);
+    const int n4 = nt[0] * 16 + qr, row = mt * 16 + fr;
+    const float4 bb = *reinterpret_cast<const float4*>(w.b2 + n4);
+    const float4 xr = *reinterpret_cast<const float4*>(xs + row * LY::LDX + n4);
+    st4(cx + row * LY::LDX + n4, xr.x + acc[0][0][0] + bb.x, xr.y + acc[0][0][1] + bb.y, xr.z + acc[0][0][2] + bb.z,
+        xr.w + acc[0][0][3] + bb.w);
+  }
+  __syncthreads();
+  ln2rows(cx, HEAD ? xs : nullptr, w.g2, w.be2, w.xout);
+  if constexpr (HEAD) {
+    const InfHead& h = hd.n[blockIdx.y];
+    float* pooled = big;                                              // [16][LDP] fp32, row 0 = this sample
+    T* h1 = reinterpret_cast<T*>(big + 16 * LY::LDP);                 // [16][LDF]
+    T* h2 = h1 + 16 * LY::LDF;
+    float* so = reinterpret_cast<float*>(h2 + 16 * LY::LDF);          // [16][16]
+    __syncthreads();
+    for (int idx = tid; idx < 16 * 128; idx += 1024) {
+      const int r = idx >> 7, c = idx & 127;
+      float v = 0.f;
+      if (r == 0) {
+        if (c < TD) v = xs[c];
+        else {
+          float s = 0.f;
+#pragma unroll
+          for (int i = 1; i < NTOK; ++i) s += xs[i * LY::LDX + (c - TD)];
+          v = s * (1.f / 16.f);
+        }
+      }
+      pooled[r * LY::LDP + c] = v;
+    }
+    __syncthreads();
+    const int nt[1] = {wave};
+    f32x4 acc[1][1];
+    auto store_h = [&](T* dst, const float* bias) {
+      const int n4 = wave * 16 + qr;
+      const float4 bb = *reinterpret_cast<const float4*>(bias + n4);
+      st4(dst + fr * LY::LDF + n4, fmaxf(acc[0][0][0] + bb.x, 0.f), fmaxf(acc[0][0][1] + bb.y, 0.f),
+          fmaxf(acc[0][0][2] + bb.z, 0.f), fmaxf(acc[0][0][3] + bb.w, 0.f));
+    };
+    zero_acc(acc);
+    block_gemm<T, 1, 1, 4>(acc, pooled, LY::LDP, (const T*)h.w0, 128, nt, lane);
+    store_h(h1, h.b0);
+    __syncthreads();
+    zero_acc(acc);
+    block_gemm<T, 1, 1, 8>(acc, h1, LY::LDF, (const T*)h.w1, 256, nt, lane);
+    store_h(h2, h.b1);
+    __syncthreads();
+    if (wave == 0) {
+      const int nt0[1] = {0};
+      zero_acc(acc);
+      block_gemm<T, 1, 1, 8>(acc, h2, LY::LDF, (const T*)h.w2, 256, nt0, lane);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int c = qr + r;
+        const float v = c < h.nout ? acc[0][0][r] + h.b2[c] : 0.f;
+        so[fr * 16 + c] = v;
+        if (fr == 0) h.out[(int64_t)s0 * OUT_LD + c] = v;
+      }
+    }
+    if (fin.ctl != nullptr) {  // rollout step epilogue: see infer_layer_kernel
+      __syncthreads();
+      if (tid == 0) {
+        const int i = s0, A = fin.A;
+        if (blockIdx.y == 0) {
+          float e = 0.f, lp = 0.f;
+          for (int a = 0; a < A; ++a) {
+            const float mu = so[a];
+            const float ls = fminf(fmaxf(fin.logstd[a], LOG_SIG_MIN), LOG_SIG_MAX);
+            const float sg = expf(ls);
+            e += 0.5f + HALF_LOG_2PI + logf(sg);
+            const float act = fmaf(sg, fin.eps[(int64_t)i * A + a], mu);
+            fin.action[(int64_t)i * A + a] = act;
+            fin.mean[(int64_t)i * A + a] = mu;
+            fin.stdv[(int64_t)i * A + a] = sg;
+            if (fin.acts_roll != nullptr) fin.acts_roll[(t_step * E + i) * A + a] = act;
+            const float d = act - mu;
+            lp += -(d * d) / (2.f * sg * sg) - logf(sg) - HALF_LOG_2PI;
+          }
+          fin.ent[i] = e;
+          if (fin.logp_roll != nullptr) fin.logp_roll[t_step * E + i] = lp;
+        } else {
+          const float v = so[0];
+          fin.value[i] = v;
+          if (fin.values_roll != nullptr) fin.values_roll[t_step * E + i] = v;
+        }
+        __threadfence();
+        const unsigned long long done = atomicAdd(reinterpret_cast<unsigned long long*>(&fin.ctl->done), 1ull);
+        if (done == (unsigned long long)(gridDim.x * gridDim.y) - 1) {
+          fin.ctl->done = 0;
+          fin.ctl->t = t_step + 1;
+        }
+      }
+    }
+  }
+}
+
+
+// ------------------------------------------------------------------------------------------ rollout encoder (16 waves)
+// infer_encoder_kernel's inference path with every phase spread over 16 waves (see rollout_layer_kernel): conv1 one row
+// tile per wave, conv2 one (row tile, column tile) per wave, conv3 column tile x K-quarter per wave + an LDS sum, the
+// proprio MLP one column tile per wave. Same arithmetic except conv3's fp32 partial sums (4 K-quarters added in order).
+template <typename T>
+__global__ __launch_bounds__(1024) void rollout_encoder_kernel(const ActCtl* __restrict__ ctl, const float* __restrict__ obs,
+                                                               int E, InfEnc w, float* __restrict__ state_roll,
+                                                               T* __restrict__ image_roll, float* __restrict__ x0) {
+  typedef typename Frag<T>::type frag_t;
+  typedef InfEncLds<T> LY;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int fr = lane & 15, fg = (lane >> 4) * 8, qr = (lane >> 4) * 4;
+  const int64_t slot0 = (int64_t)ctl->t * E;
+  const int D = w.S + LY::IMG;
+
+  if ((int)blockIdx.x >= E) {
+    // ---------------- proprio branch, 32 rows per block: Linear+ReLU, Linear+ReLU, state_projector+ReLU -> token 0
+    constexpr int MR = LY::MLP_ROWS;
+    const int r0 = ((int)blockIdx.x - E) * MR;
+    float* sin = reinterpret_cast<float*>(smem);
+    T* h1 = reinterpret_cast<T*>(smem + (size_t)MR * LY::LDS_IN * 4);
+    T* h2 = h1 + MR * LY::LDH;
+    for (int idx = tid; idx < MR * 128; idx += 1024) {
+      const int r = idx >> 7, c = idx & 127;
+      const bool ok = r0 + r < E;
+      float v = 0.f;
+      if (ok && c < w.S) v = obs[(int64_t)(r0 + r) * D + c];
+      if (ok && c < w.Sp) state_roll[(slot0 + r0 + r) * w.Sp + c] = v;
+      sin[r * LY::LDS_IN + c] = v;
+    }
+    __syncthreads();
+    const int nt[1] = {wave};
+    f32x4 acc[2][1];
+    auto store_h = [&](T* h, const float* bias) {
+      const int n4 = wave * 16 + qr;
+      const float4 bb = *reinterpret_cast<const float4*>(bias + n4);
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt)
+        st4(h + (mt * 16 + fr) * LY::LDH + n4, fmaxf(acc[mt][0][0] + bb.x, 0.f), fmaxf(acc[mt][0][1] + bb.y, 0.f),
+            fmaxf(acc[mt][0][2] + bb.z, 0.f), fmaxf(acc[mt][0][3] + bb.w, 0.f));
+    };
+    zero_acc(acc);
+    if (w.Kp1 == 128) block_gemm<T, 2, 1, 4>(acc, sin, LY::LDS_IN, (const T*)w.wf1, 128, nt, lane);
+    else block_gemm<T, 2, 1, 2>(acc, sin, LY::LDS_IN, (const T*)w.wf1, 64, nt, lane);
+    store_h(h1, w.bf1);
+    __syncthreads();
+    zero_acc(acc);
+    block_gemm<T, 2, 1, 8>(acc, h1, LY::LDH, (const T*)w.wf2, 256, nt, lane);
+    store_h(h2, w.bf2);
+    __syncthreads();
+    if (wave < 8) {
+      const int ntp[1] = {wave & 3}, mt = wave >> 2;
+      f32x4 ap[1][1];
+      zero_acc(ap);
+      block_gemm<T, 1, 1, 8>(ap, h2 + mt * 16 * LY::LDH, LY::LDH, (const T*)w.wpr, 256, ntp, lane);
+      const int n4 = ntp[0] * 16 + qr, row = r0 + mt * 16 + fr;
+      const float4 bb = *reinterpret_cast<const float4*>(w.bpr + n4);
+      if (row < E)
+        st4(x0 + ((int64_t)row * NTOK) * TD + n4, fmaxf(ap[0][0][0] + bb.x, 0.f), fmaxf(ap[0][0][1] + bb.y, 0.f),
+            fmaxf(ap[0][0][2] + bb.z, 0.f), fmaxf(ap[0][0][3] + bb.w, 0.f));
+    }
+    return;
+  }
+
+  // ---------------- depth branch, one sample per block
+  const int b = blockIdx.x;
+  T* img = reinterpret_cast<T*>(smem);
+  T* c1 = img + LY::IMG;
+  T* c2 = c1 + LY::C1;
+  T* c3 = c2 + LY::C2;
+  {
+    const float4* src = reinterpret_cast<const float4*>(obs + (int64_t)b * D + w.S);  // 16B aligned iff S%4==0
+    const bool al = (((int64_t)b * D + w.S) & 3) == 0;
+    T* roll = image_roll + (slot0 + b) * (int64_t)LY::IMG;
+    float4 v[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {  // 4096 float4 per image: four per thread, all in flight
+      const int i = tid + k * 1024;
+      if (al) v[k] = src[i];
+      else {
+        const float* s1 = obs + (int64_t)b * D + w.S + i * 4;
+        v[k] = float4{s1[0], s1[1], s1[2], s1[3]};
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int i = tid + k * 1024;
+      st4(img + i * 4, v[k].x, v[k].y, v[k].z, v[k].w);
+      st4(roll + i * 4, v[k].x, v[k].y, v[k].z, v[k].w);
+    }
+  }
+  __syncthreads();
+  if (wave < 15) {  // conv1: 225 pixels = 15 row tiles, one per wave; K = (c,ky,kx) = 256, N = 32
+    f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+    const int p = min(wave * 16 + fr, 224);
+    const int pbase = (p / 15) * 4 * 64 + (p % 15) * 4;
+    frag_t ring[4][2];
+#pragma unroll
+    for (int d = 0; d < 4; ++d)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) ring[d][j] = *reinterpret_cast<const frag_t*>((const T*)w.w1 + (j * 16 + fr) * 256 + d * 32 + fg);
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) {
+      const int k0 = ks * 32 + fg, c = k0 >> 6, ky = (k0 >> 3) & 7;
+      const frag_t fb0 = ring[ks & 3][0], fb1 = ring[ks & 3][1];
+      if (ks + 4 < 8) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          ring[ks & 3][j] = *reinterpret_cast<const frag_t*>((const T*)w.w1 + (j * 16 + fr) * 256 + (ks + 4) * 32 + fg);
+      }
+      const frag_t fa = afrag_t(img + c * 4096 + ky * 64 + pbase);
+      mma_k32(acc[0], fb0, fa);
+      mma_k32(acc[1], fb1, fa);
+    }
+    const int pp = wave * 16 + fr;
+    if (pp < 225) {
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int n4 = j * 16 + qr;
+        const float4 bb = *reinterpret_cast<const float4*>(w.b1 + n4);
+        st4(c1 + pp * LY::LD1 + n4, fmaxf(acc[j][0] + bb.x, 0.f), fmaxf(acc[j][1] + bb.y, 0.f), fmaxf(acc[j][2] + bb.z, 0.f),
+            fmaxf(acc[j][3] + bb.w, 0.f));
+      }
+    }
+  }
+  __syncthreads();
+  if (wave < 12) {  // conv2: 36 pixels (3 row tiles) x 4 column tiles, one pair per wave; K = (ky,kx,c) = 512
+    const int mt = wave >> 2, nt = wave & 3;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    const int p = min(mt * 16 + fr, 35);
+    const int pb = ((p / 6) * 2 * 15 + (p % 6) * 2) * LY::LD1;
+    const T* w2row = (const T*)w.w2 + (nt * 16 + fr) * 512 + fg;
+    frag_t ring[8];
+#pragma unroll
+    for (int d = 0; d < 8; ++d) ring[d] = *reinterpret_cast<const frag_t*>(w2row + d * 32);
+#pragma unroll
+    for (int ks = 0; ks < 16; ++ks) {
+      const int ky = ks >> 2, kx = ks & 3;  // 32 channels per tap == one K=32 step
+      const frag_t fb = ring[ks & 7];
+      if (ks + 8 < 16) ring[ks & 7] = *reinterpret_cast<const frag_t*>(w2row + (ks + 8) * 32);
+      const frag_t fa = afrag_t(c1 + pb + (ky * 15 + kx) * LY::LD1 + fg);
+      mma_k32(acc, fb, fa);
+    }
+    const int pp = mt * 16 + fr, n4 = nt * 16 + qr;
+    const float4 bb = *reinterpret_cast<const float4*>(w.b2 + n4);
+    if (pp < 36)
+      st4(c2 + pp * LY::LD2 + n4, fmaxf(acc[0] + bb.x, 0.f), fmaxf(acc[1] + bb.y, 0.f), fmaxf(acc[2] + bb.z, 0.f),
+          fmaxf(acc[3] + bb.w, 0.f));
+  }
+  __syncthreads();
+  float* part = reinterpret_cast<float*>(img);  // [4 K-quarters][16 pixels][64] fp32 partial sums (the image is dead)
+  {  // conv3: 16 pixels, K = (ky,kx,c) = 576 = 18 steps: wave = (column tile, K-quarter of 5/5/5/3 steps)
+    const int nt = wave & 3, kq = wave >> 2;
+    const int ks0 = kq * 5, ks1 = min(18, ks0 + 5);
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    const int pb = ((fr >> 2) * 6 + (fr & 3)) * LY::LD2;
+    const T* w3row = (const T*)w.w3 + (nt * 16 + fr) * 576 + fg;
+    frag_t fbv[5];
+#pragma unroll
+    for (int d = 0; d < 5; ++d) fbv[d] = *reinterpret_cast<const frag_t*>(w3row + min(ks0 + d, 17) * 32);
+#pragma unroll
+    for (int d = 0; d < 5; ++d) {
+      const int ks = ks0 + d;
+      if (ks < ks1) {
+        const int tap = ks >> 1, ky = tap / 3, kx = tap - ky * 3, c0 = (ks & 1) * 32 + fg;
+        const frag_t fa = afrag_t(c2 + pb + (ky * 6 + kx) * LY::LD2 + c0);
+        mma_k32(acc, fbv[d], fa);
+      }
+    }
+    st4(part + (kq * 16 + fr) * 64 + nt * 16 + qr, acc[0], acc[1], acc[2], acc[3]);
+  }
+  __syncthreads();
+  {  // sum of the four K-quarters + bias + ReLU -> c3: one output per thread
+    const int pix = tid >> 6, n = tid & 63;
+    const float v = ((part[pix * 64 + n] + part[(16 + pix) * 64 + n]) + part[(32 + pix) * 64 + n]) + part[(48 + pix) * 64 + n];
+    c3[pix * LY::LD2 + n] = (T)fmaxf(v + w.b3[n], 0.f);
+  }
+  __syncthreads();
+  if (wave < 4) {  // depth_up_conv (1x1, no activation) -> tokens 1..16
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const frag_t fb = *reinterpret_cast<const frag_t*>((const T*)w.wup + (wave * 16 + fr) * 64 + ks * 32 + fg);
+      const frag_t fa = afrag_t(c3 + fr * LY::LD2 + ks * 32 + fg);
+      mma_k32(acc, fb, fa);
+    }
+    const int n4 = wave * 16 + qr;
+    const float4 bb = *reinterpret_cast<const float4*>(w.bup + n4);
+    st4(x0 + ((int64_t)b * NTOK + 1 + fr) * TD + n4, acc[0] + bb.x, acc[1] + bb.y, acc[2] + bb.z, acc[3] + bb.w);
+  }
+}
+
 }  // namespace v4l

@@ -1239,6 +1239,12 @@ static int run_actor_fused(v4l_actor* a, const float* obs, const float* eps, flo
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)InfLayLds<T, 1>::bytes));
     V4L_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&infer_layer_kernel<T, 1, true>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)InfLayLds<T, 1>::bytes));
+    V4L_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&rollout_encoder_kernel<T>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)InfEncLds<T>::bytes));
+    V4L_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&rollout_layer_kernel<T, false>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)InfLayLds<T, 1>::bytes));
+    V4L_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&rollout_layer_kernel<T, true>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)InfLayLds<T, 1>::bytes));
     attr_done = true;
   }
   const T* pk = (const T*)pf->packed;
@@ -1255,8 +1261,13 @@ static int run_actor_fused(v4l_actor* a, const float* obs, const float* eps, flo
   en.S = pf->cfg.state_dim; en.Sp = pf->Sp; en.Kp1 = pf->enc[0].Kp;
   float* x0 = ws_pf + Lp.x[0];
   g_op = "encoder";
-  V4L_KLAUNCH("infer_encoder", 2.0 * E * 3678208.0, s, infer_encoder_kernel<T>, dim3(E + cdiv(E, 32)), dim3(256),
-              InfEncLds<T>::bytes, s, (const ActCtl*)a->ctl, obs, E, en, state_roll, (T*)image_roll, x0, InfEncTrain{});
+  static const bool wide16 = getenv("V4L_ROLLOUT_4WAVE") == nullptr;  // 16-wave blocks (default) or the 4-wave kernels
+  if (wide16)
+    V4L_KLAUNCH("rollout_encoder", 2.0 * E * 3678208.0, s, rollout_encoder_kernel<T>, dim3(E + cdiv(E, 32)), dim3(1024),
+                InfEncLds<T>::bytes, s, (const ActCtl*)a->ctl, obs, E, en, state_roll, (T*)image_roll, x0);
+  else
+    V4L_KLAUNCH("infer_encoder", 2.0 * E * 3678208.0, s, infer_encoder_kernel<T>, dim3(E + cdiv(E, 32)), dim3(256),
+                InfEncLds<T>::bytes, s, (const ActCtl*)a->ctl, obs, E, en, state_roll, (T*)image_roll, x0, InfEncTrain{});
   V4L_LAUNCH_CHECK();
   auto fill = [&](InfLayer& d, v4l_net* net, const T* base, const TLayer& t, const float* xin, float* xout) {
     d.win = base + t.inproj.pk; d.wo = base + t.outproj.pk; d.w1 = base + t.ff1.pk; d.w2 = base + t.ff2.pk;
@@ -1279,8 +1290,12 @@ static int run_actor_fused(v4l_actor* a, const float* obs, const float* eps, flo
     memset(&fin, 0, sizeof(fin));
     g_op = "layer";
     if (l < nl - 1) {
-      V4L_KLAUNCH("infer_layer", 2.0 * 2 * E * 872576.0, s, (infer_layer_kernel<T, 1, false>), dim3(E, 2), dim3(256),
-                  (InfLayLds<T, 1>::bytes), s, pr, hd, fin, E, pf->cfg.ff_dim);
+      if (wide16)
+        V4L_KLAUNCH("rollout_layer", 2.0 * 2 * E * 872576.0, s, (rollout_layer_kernel<T, false>), dim3(E, 2), dim3(1024),
+                    (InfLayLds<T, 1>::bytes), s, pr, hd, fin, E);
+      else
+        V4L_KLAUNCH("infer_layer", 2.0 * 2 * E * 872576.0, s, (infer_layer_kernel<T, 1, false>), dim3(E, 2), dim3(256),
+                    (InfLayLds<T, 1>::bytes), s, pr, hd, fin, E, pf->cfg.ff_dim);
     } else {
       auto head = [&](InfHead& h, v4l_net* net, const T* base, float* out) {
         h.w0 = base + net->head[0].pk; h.w1 = base + net->head[1].pk; h.w2 = base + net->head[2].pk;
@@ -1292,8 +1307,12 @@ static int run_actor_fused(v4l_actor* a, const float* obs, const float* eps, flo
       fin.ctl = a->ctl; fin.logstd = pf->p[pf->logstd]; fin.eps = eps; fin.A = pf->cfg.out_dim;
       fin.acts_roll = acts_roll; fin.values_roll = values_roll; fin.logp_roll = logp_roll; fin.action = action;
       fin.mean = mean; fin.stdv = stdv; fin.ent = ent; fin.value = value;
-      V4L_KLAUNCH("infer_layer_head", 2.0 * 2 * E * (872576.0 + 99840.0), s, (infer_layer_kernel<T, 1, true>), dim3(E, 2),
-                  dim3(256), (InfLayLds<T, 1>::bytes), s, pr, hd, fin, E, pf->cfg.ff_dim);
+      if (wide16)
+        V4L_KLAUNCH("rollout_layer_head", 2.0 * 2 * E * (872576.0 + 99840.0), s, (rollout_layer_kernel<T, true>), dim3(E, 2),
+                    dim3(1024), (InfLayLds<T, 1>::bytes), s, pr, hd, fin, E);
+      else
+        V4L_KLAUNCH("infer_layer_head", 2.0 * 2 * E * (872576.0 + 99840.0), s, (infer_layer_kernel<T, 1, true>), dim3(E, 2),
+                    dim3(256), (InfLayLds<T, 1>::bytes), s, pr, hd, fin, E, pf->cfg.ff_dim);
     }
     V4L_LAUNCH_CHECK();
   }
