@@ -742,12 +742,13 @@ __global__ __launch_bounds__(256) void infer_layer_kernel(InfLayerPair pr, InfHe
 // waves: a rollout step runs only 2E blocks, one per CU, so its time is the latency of one block — every phase is cut
 // into as many independent jobs as it has (12 + 8 + 16 + 8 MFMA tiles, 17 score rows, 32 norm rows) instead of four.
 // Same arithmetic, operand rounding and k order as infer_layer_kernel<T, 1, HEAD>.
+constexpr int ROLLOUT_MAX_LAYERS = 4;
+struct InfLayerStack { InfLayerPair l[ROLLOUT_MAX_LAYERS]; int nl; };  // all layers of both nets: ONE launch per env step
 template <typename T, bool HEAD>
-__global__ __launch_bounds__(1024) void rollout_layer_kernel(InfLayerPair pr, InfHeadPair hd, InfFinish fin, int E) {
+__global__ __launch_bounds__(1024) void rollout_layer_kernel(InfLayerStack stk, InfHeadPair hd, InfFinish fin, int E) {
   typedef InfLayLds<T, 1> LY;
   constexpr int ROWS = 32;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  const InfLayer& w = pr.n[blockIdx.y];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int fr = lane & 15, qr = (lane >> 4) * 4;
   float* xs = reinterpret_cast<float*>(smem);
@@ -761,10 +762,32 @@ __global__ __launch_bounds__(1024) void rollout_layer_kernel(InfLayerPair pr, In
   if (tid < ROWS * (TD / 4)) {
     const int r = tid >> 4, c4 = (tid & 15) * 4;
     const bool ok = r < NTOK;
-    const float4 v = *reinterpret_cast<const float4*>(w.xin + (row0 + (ok ? r : 0)) * TD + c4);
+    const float4 v = *reinterpret_cast<const float4*>(stk.l[0].n[blockIdx.y].xin + (row0 + (ok ? r : 0)) * TD + c4);
     *reinterpret_cast<float4*>(xs + r * LY::LDX + c4) = ok ? v : float4{0.f, 0.f, 0.f, 0.f};
   }
   __syncthreads();
+  T* f = reinterpret_cast<T*>(big);
+  auto ln2rows = [&](const float* z, float* out, const float* __restrict__ g, const float* __restrict__ be, float* gout) {
+    const float gg = g[lane], bb = be[lane];  // wave w: rows w and w + 16, both in flight
+    float v[2], mean[2], c[2], var[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) v[u] = z[(wave + 16 * u) * LY::LDX + lane];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) mean[u] = wave_sum(v[u]) * (1.f / TD);
+#pragma unroll
+    for (int u = 0; u < 2; ++u) { c[u] = v[u] - mean[u]; var[u] = wave_sum(c[u] * c[u]) * (1.f / TD); }
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int r = wave + 16 * u;
+      const float o = fmaf(c[u] * (1.f / sqrtf(var[u] + 1e-5f)), gg, bb);
+      if (out != nullptr) out[r * LY::LDX + lane] = o;
+      if (gout != nullptr && r < NTOK) gout[(row0 + r) * TD + lane] = o;
+    }
+  };
+#pragma unroll 1
+  for (int l = 0; l < stk.nl; ++l) {  // the token rows stay in `xs` from one layer to the next
+  const InfLayer& w = stk.l[l].n[blockIdx.y];
+  if (l > 0) __syncthreads();
   if (wave < 12) {  // in_proj: 12 column tiles, one per wave
     const int nt[1] = {wave};
     f32x4 acc[2][1];
@@ -819,26 +842,8 @@ __global__ __launch_bounds__(1024) void rollout_layer_kernel(InfLayerPair pr, In
         xr.w + acc[0][0][3] + bb.w);
   }
   __syncthreads();
-  auto ln2rows = [&](const float* z, float* out, const float* __restrict__ g, const float* __restrict__ be, float* gout) {
-    const float gg = g[lane], bb = be[lane];  // wave w: rows w and w + 16, both in flight
-    float v[2], mean[2], c[2], var[2];
-#pragma unroll
-    for (int u = 0; u < 2; ++u) v[u] = z[(wave + 16 * u) * LY::LDX + lane];
-#pragma unroll
-    for (int u = 0; u < 2; ++u) mean[u] = wave_sum(v[u]) * (1.f / TD);
-#pragma unroll
-    for (int u = 0; u < 2; ++u) { c[u] = v[u] - mean[u]; var[u] = wave_sum(c[u] * c[u]) * (1.f / TD); }
-#pragma unroll
-    for (int u = 0; u < 2; ++u) {
-      const int r = wave + 16 * u;
-      const float o = fmaf(c[u] * (1.f / sqrtf(var[u] + 1e-5f)), gg, bb);
-      if (out != nullptr) out[r * LY::LDX + lane] = o;
-      if (gout != nullptr && r < NTOK) gout[(row0 + r) * TD + lane] = o;
-    }
-  };
   ln2rows(big, xs, w.g1, w.be1, nullptr);  // x1 -> xs
   __syncthreads();
-  T* f = reinterpret_cast<T*>(big);
   {  // linear1 + ReLU -> f (T): 16 column tiles, one per wave
     const int nt[1] = {wave};
     f32x4 acc[2][1];
@@ -864,7 +869,8 @@ __global__ __launch_bounds__(1024) void rollout_layer_kernel(InfLayerPair pr, In
         xr.w + acc[0][0][3] + bb.w);
   }
   __syncthreads();
-  ln2rows(cx, HEAD ? xs : nullptr, w.g2, w.be2, w.xout);
+  ln2rows(cx, xs, w.g2, w.be2, w.xout);  // -> xs (next layer / heads) and the net's token tensor
+  }
   if constexpr (HEAD) {
     const InfHead& h = hd.n[blockIdx.y];
     float* pooled = big;                                              // [16][LDP] fp32, row 0 = this sample

@@ -1241,8 +1241,6 @@ static int run_actor_fused(v4l_actor* a, const float* obs, const float* eps, flo
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)InfLayLds<T, 1>::bytes));
     V4L_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&rollout_encoder_kernel<T>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)InfEncLds<T>::bytes));
-    V4L_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&rollout_layer_kernel<T, false>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)InfLayLds<T, 1>::bytes));
     V4L_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&rollout_layer_kernel<T, true>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)InfLayLds<T, 1>::bytes));
     attr_done = true;
@@ -1278,41 +1276,50 @@ static int run_actor_fused(v4l_actor* a, const float* obs, const float* eps, flo
     d.s_xin = d.s_ctx = d.s_x1 = d.s_f = nullptr;
   };
   const int nl = pf->cfg.n_layers;
-  for (int l = 0; l < nl; ++l) {
-    // one sample per block and net: 2E short blocks; the last layer's blocks go on through the heads, sample the
-    // action, file action / value / log-prob at rollout slot t*E + i and advance the step cursor
+  InfHeadPair hd;
+  memset(&hd, 0, sizeof(hd));
+  InfFinish fin;
+  memset(&fin, 0, sizeof(fin));
+  auto head = [&](InfHead& h, v4l_net* net, const T* base, float* out) {
+    h.w0 = base + net->head[0].pk; h.w1 = base + net->head[1].pk; h.w2 = base + net->head[2].pk;
+    h.b0 = net->p[net->head[0].b]; h.b1 = net->p[net->head[1].b]; h.b2 = net->p[net->head[2].b];
+    h.out = out; h.nout = net->cfg.out_dim;
+  };
+  auto finish = [&]() {
+    head(hd.n[0], pf, pk, ws_pf + Lp.out);
+    head(hd.n[1], vf, vk, ws_vf + Lv.out);
+    fin.ctl = a->ctl; fin.logstd = pf->p[pf->logstd]; fin.eps = eps; fin.A = pf->cfg.out_dim;
+    fin.acts_roll = acts_roll; fin.values_roll = values_roll; fin.logp_roll = logp_roll; fin.action = action;
+    fin.mean = mean; fin.stdv = stdv; fin.ent = ent; fin.value = value;
+  };
+  g_op = "layer";
+  if (wide16 && nl <= ROLLOUT_MAX_LAYERS) {
+    // one sample per block and net (2E blocks of 16 waves): ALL layers, the heads, the sampling of the action, the filing
+    // of action / value / log-prob at rollout slot t*E + i and the advance of the step cursor in one launch
+    InfLayerStack stk;
+    memset(&stk, 0, sizeof(stk));
+    stk.nl = nl;
+    for (int l = 0; l < nl; ++l) {
+      fill(stk.l[l].n[0], pf, pk, pf->layers[l], l == 0 ? x0 : ws_pf + Lp.x[l], ws_pf + Lp.x[l + 1]);
+      fill(stk.l[l].n[1], vf, vk, vf->layers[l], l == 0 ? x0 : ws_vf + Lv.x[l], ws_vf + Lv.x[l + 1]);
+    }
+    finish();
+    V4L_KLAUNCH("rollout_layers_head", 2.0 * 2 * E * (nl * 872576.0 + 99840.0), s, (rollout_layer_kernel<T, true>), dim3(E, 2),
+                dim3(1024), (InfLayLds<T, 1>::bytes), s, stk, hd, fin, E);
+    V4L_LAUNCH_CHECK();
+    return 0;
+  }
+  for (int l = 0; l < nl; ++l) {  // 4-wave kernels, one launch per layer
     InfLayerPair pr;
     fill(pr.n[0], pf, pk, pf->layers[l], l == 0 ? x0 : ws_pf + Lp.x[l], ws_pf + Lp.x[l + 1]);
     fill(pr.n[1], vf, vk, vf->layers[l], l == 0 ? x0 : ws_vf + Lv.x[l], ws_vf + Lv.x[l + 1]);
-    InfHeadPair hd;
-    memset(&hd, 0, sizeof(hd));
-    InfFinish fin;
-    memset(&fin, 0, sizeof(fin));
-    g_op = "layer";
     if (l < nl - 1) {
-      if (wide16)
-        V4L_KLAUNCH("rollout_layer", 2.0 * 2 * E * 872576.0, s, (rollout_layer_kernel<T, false>), dim3(E, 2), dim3(1024),
-                    (InfLayLds<T, 1>::bytes), s, pr, hd, fin, E);
-      else
-        V4L_KLAUNCH("infer_layer", 2.0 * 2 * E * 872576.0, s, (infer_layer_kernel<T, 1, false>), dim3(E, 2), dim3(256),
-                    (InfLayLds<T, 1>::bytes), s, pr, hd, fin, E, pf->cfg.ff_dim);
+      V4L_KLAUNCH("infer_layer", 2.0 * 2 * E * 872576.0, s, (infer_layer_kernel<T, 1, false>), dim3(E, 2), dim3(256),
+                  (InfLayLds<T, 1>::bytes), s, pr, hd, fin, E, pf->cfg.ff_dim);
     } else {
-      auto head = [&](InfHead& h, v4l_net* net, const T* base, float* out) {
-        h.w0 = base + net->head[0].pk; h.w1 = base + net->head[1].pk; h.w2 = base + net->head[2].pk;
-        h.b0 = net->p[net->head[0].b]; h.b1 = net->p[net->head[1].b]; h.b2 = net->p[net->head[2].b];
-        h.out = out; h.nout = net->cfg.out_dim;
-      };
-      head(hd.n[0], pf, pk, ws_pf + Lp.out);
-      head(hd.n[1], vf, vk, ws_vf + Lv.out);
-      fin.ctl = a->ctl; fin.logstd = pf->p[pf->logstd]; fin.eps = eps; fin.A = pf->cfg.out_dim;
-      fin.acts_roll = acts_roll; fin.values_roll = values_roll; fin.logp_roll = logp_roll; fin.action = action;
-      fin.mean = mean; fin.stdv = stdv; fin.ent = ent; fin.value = value;
-      if (wide16)
-        V4L_KLAUNCH("rollout_layer_head", 2.0 * 2 * E * (872576.0 + 99840.0), s, (rollout_layer_kernel<T, true>), dim3(E, 2),
-                    dim3(1024), (InfLayLds<T, 1>::bytes), s, pr, hd, fin, E);
-      else
-        V4L_KLAUNCH("infer_layer_head", 2.0 * 2 * E * (872576.0 + 99840.0), s, (infer_layer_kernel<T, 1, true>), dim3(E, 2),
-                    dim3(256), (InfLayLds<T, 1>::bytes), s, pr, hd, fin, E, pf->cfg.ff_dim);
+      finish();
+      V4L_KLAUNCH("infer_layer_head", 2.0 * 2 * E * (872576.0 + 99840.0), s, (infer_layer_kernel<T, 1, true>), dim3(E, 2),
+                  dim3(256), (InfLayLds<T, 1>::bytes), s, pr, hd, fin, E, pf->cfg.ff_dim);
     }
     V4L_LAUNCH_CHECK();
   }
