@@ -506,3 +506,65 @@ def test_fused_conv_backward_equals_layerwise(name, mode, device):
     print("\n[fused conv bwd %s %s]" % (name, mode), {k: "%.1e" % errs[k] for k in conv})
     for k, e in errs.items():
         assert e <= tol, (k, e)
+
+
+def _dp_phases_worker(mode, out_path):
+    """Runs in a fresh process: 1-rank RCCL group, the data-parallel phase sequence vs the fused single-GPU update."""
+    os.environ["V4L_COMPUTE"] = mode
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(29500 + os.getpid() % 2000)
+    import torch.distributed as dist
+    from vision4leg_amd.engine import HipTrainer
+    from vision4leg_amd.torchrl.algo import PPO
+    device = torch.device("cuda", 0)
+    torch.cuda.set_device(device)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=device)
+    case = dict(util.CASES["loco_s84"], B=32)
+    T, E, B = 8, 8, 32
+    rs = np.random.RandomState(21)
+    obs = np.concatenate([np.clip(rs.randn(T * E, case["S"]), -10, 10), np.clip(rs.randn(T * E, 4 * 64 * 64), -2.5, 2.8)], 1)
+    acts, advs, rets = 0.1 * rs.randn(T * E, case["A"]), rs.randn(T * E), rs.randn(T * E)
+    rows = np.stack([rs.permutation(T * E)[:B] for _ in range(4)]).astype(np.int32)
+    res = []
+    for phases in (True, False):
+        os.environ["V4L_FORCE_DP_PHASES"] = "1" if phases else "0"
+        pf, vf = _build(case, mode, device)
+
+        class Coll: epoch_frames = T * E
+        agent = PPO(pf=pf, vf=vf, plr=1e-4, vlr=1e-4, clip_para=0.2, opt_epochs=3, tau=0.95, entropy_coeff=0.005,
+                    collector=Coll(), device=device, batch_size=B)
+        assert agent.dp_phases == phases
+        agent.use_graph = False
+        net = pf.hip
+        net.ensure_bound()
+        state, image = net.alloc_rollout(T * E, device)
+        t = lambda a: torch.tensor(a, dtype=torch.float32, device=device)
+        net.ingest(t(obs), state, image)
+        ro = HipTrainer.rollout(state, image, t(acts), t(advs), t(rets), t(rets))
+        stats = torch.zeros(len(rows), 24, device=device)
+        agent.trainer.sync_target()
+        agent.run_updates(ro, torch.tensor(rows, device=device), stats)
+        torch.cuda.synchronize()
+        res.append(({k: v.detach().cpu().clone() for k, v in pf.state_dict().items()}, stats.cpu().numpy()))
+    dist.destroy_process_group()
+    torch.save(res, out_path)
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("mode", MODES)
+def test_dp_phase_sequence_on_one_rank(mode, tmp_path):
+    """PPO._update_phases (critic grads -> all_reduce(grads + advantage sums) -> critic step -> actor grads -> all_reduce
+    -> actor step, over RCCL) on a 1-rank group must reproduce the fused single-GPU update."""
+    import torch.multiprocessing as mp
+    out = str(tmp_path / "dp.pt")
+    ctx = mp.get_context("spawn")
+    p = ctx.Process(target=_dp_phases_worker, args=(mode, out))
+    p.start()
+    p.join(540)
+    assert p.exitcode == 0, "worker failed (exit code %s)" % p.exitcode
+    (pa, sa), (pb, sb) = torch.load(out, weights_only=False)
+    tol = 2e-4 if mode == "f32" else 1e-2
+    assert np.allclose(sa[:, :18], sb[:, :18], rtol=tol, atol=tol / 10), np.abs(sa[:, :18] - sb[:, :18]).max()
+    drift = sum((pa[k] - pb[k]).abs().sum().item() for k in pa) / sum(v.numel() for v in pa.values())
+    assert drift <= (2e-7 if mode == "f32" else 2e-5), drift

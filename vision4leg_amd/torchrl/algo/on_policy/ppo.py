@@ -103,13 +103,18 @@ class PPO:
         self.current_epoch = 0
         # ---- engine
         self.world_size = _dist_world()
+        # the data-parallel update (four phases + one all-reduce per optimiser step) also runs on a 1-rank process group
+        # when asked to: that is how the RCCL path is exercised on a single-GPU box (tests/test_gpu_parity.py)
+        self.dp_phases = self.world_size > 1 or (os.environ.get("V4L_FORCE_DP_PHASES", "0") != "0"
+                                                   and torch.distributed.is_available()
+                                                   and torch.distributed.is_initialized())
         if self.world_size > 1:
             for p in list(self.pf.parameters()) + list(self.vf.parameters()):
                 torch.distributed.broadcast(p.data, src=0)
             atu.copy_model_params_from_to(self.pf, self.target_pf)
         with torch.cuda.device(self.device):
             g_vf = None
-            if self.world_size > 1:
+            if self.dp_phases:
                 # one buffer per all-reduce: critic grads + (sum adv, sum adv^2, count) in the tail
                 self._vf_bucket = torch.zeros(self.vf.hip.total_params + 3, dtype=torch.float32, device=self.device)
                 g_vf = self._vf_bucket[:self.vf.hip.total_params]
@@ -213,7 +218,7 @@ class PPO:
             tr.begin(self._rowidx_buf, self._stats_buf, self.pf_optimizer.lr, self.vf_optimizer.lr)
             for _ in range(U):
                 self.training_update_num += 1
-                if self.world_size == 1:
+                if not self.dp_phases:
                     tr.update_next(ro, n, graph=self.use_graph)
                 else:
                     self._update_phases(ro, n)
@@ -255,7 +260,7 @@ class PPO:
             ro = HipTrainer.rollout(self._stage[0], self._stage[1], acts, advs, rets, vals)
             stats = torch.zeros(1, _lib.V4L_STATS, dtype=torch.float32, device=dev)
             tr = self.trainer
-            if self.world_size == 1:
+            if not self.dp_phases:
                 tr.update(ro, None, n, self.pf_optimizer.lr, self.vf_optimizer.lr, stats)
             else:
                 tr._pre(n)
