@@ -345,8 +345,12 @@ def main():
                          "127.0.0.1 bench.py --gpus %d ..." % (a.gpus, a.gpus))
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    if world > 1:
+    # V4L_FORCE_DP_PHASES=1 under a 1-process torchrun exercises the whole multi-GPU code path (RCCL group, barriers,
+    # four-phase update with an all-reduce per optimiser step) on a single GPU
+    dist_on = world > 1 or (os.environ.get("V4L_FORCE_DP_PHASES", "0") != "0" and "RANK" in os.environ)
+    if dist_on:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         torch.distributed.init_process_group("nccl", device_id=dev)
     wl = dict(WORKLOADS[a.workload])
     if a.no_rollout:
@@ -355,7 +359,7 @@ def main():
     ep = Epoch(wl, a.compute, dev, world)
 
     def barrier():
-        if world > 1:
+        if dist_on:
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
@@ -374,7 +378,7 @@ def main():
         torch.cuda.synchronize()  # keeps the rollout/update split honest (one sync per epoch)
     barrier()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if dist_on:
         tt = torch.tensor([dt, t_roll], device=dev, dtype=torch.float64)
         torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
         dt, t_roll = tt[0].item(), tt[1].item()
@@ -399,9 +403,9 @@ def main():
         if not a.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(wl, a.compute)
             res["vs_cpu_baseline"] = round(value / world / res["cpu_baseline"]["value"], 1)
-    elif world > 1:
+    elif dist_on:
         ep.update()  # keep collectives matched with rank 0's profiled pass
-    if world > 1:
+    if dist_on:
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()
     if rank == 0:
