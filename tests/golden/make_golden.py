@@ -70,7 +70,10 @@ def main():
     from oracle.gae_c import gae_c
 
     torch.set_num_threads(8)
+    only = set(sys.argv[1:])  # optional: regenerate just these cases (e.g. `make_golden.py loco_gen`)
     for name, case in util.CASES.items():
+        if only and name not in only:
+            continue
         print("==", name, case)
         pf, vf = build_ref_nets(networks, policies, case)
         # ---- the product's containers must construct bit-identical parameters from the same seed
@@ -148,6 +151,8 @@ def main():
                   (u, info["ratio/max"], info["Training/vf_loss"], info["grad_norm/pf"]))
         np.savez_compressed(os.path.join(HERE, "ppo_%s.npz" % name), **out)
 
+    if only and not (only & set(util.GAE_CASES) or "gae" in only):
+        return
     # ---- GAE
     gout = {}
     for name, g in util.GAE_CASES.items():

@@ -25,6 +25,9 @@ CASES = {
     "loco_s84": dict(kind="loco", S=84, A=6, seed=1, B=32, enc=[256, 256], head=[256, 256], layers=2, ff=256),
     "cnn_s93": dict(kind="cnn", S=93, A=6, seed=2, B=64, enc=[256, 256], head=[256, 256], visual_dim=256),
     "mlp_s93": dict(kind="mlp", S=93, A=6, seed=3, B=128, enc=[256, 256], head=[256, 256]),
+    # a NON-shipped geometry (one layer, ff = 128, 128-wide MLPs, odd batch): runs on the general layer-by-layer kernels
+    # (gemm_nt / attn / ln / gemm_tn), not on the fused ones that are specialised for the shipped shapes
+    "loco_gen": dict(kind="loco", S=45, A=4, seed=4, B=22, enc=[128, 128], head=[128, 128], layers=1, ff=128),
 }
 
 GAE_CASES = {
