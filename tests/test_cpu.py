@@ -109,6 +109,7 @@ def test_plan_matches_reference_state_dict_names():
             for k, shp in zip(hip.param_names, hip.param_shapes):
                 assert tuple(sd[k].shape) == shp, (name, k)
             assert hip.total_params == sum(v.numel() for v in sd.values())
+    pf, vf = util.build_nets(networks, policies, util.CASES["mlp_s93"])
     assert pf.hip.total_params == 222988  # state MLP pf, SURVEY.md §8a parameter inventory
     case = util.CASES["loco_s93"]
     pf, vf = util.build_nets(networks, policies, case)
