@@ -135,9 +135,9 @@ struct Ctx {  // per-call view of a bound net
 // Fork/join of the net's auxiliary stream. Independent sibling kernels (a layer's weight-grad next to its data-grad,
 // the proprio MLP next to the conv stack) run concurrently: most kernels of this workload fill only a fraction of
 // the 256 CUs. Under stream capture the event record/wait pairs become plain graph dependencies.
-static int par_begin(Ctx& c) {
+static int par_begin(Ctx& c, bool in_capture_too = false) {
   v4l_net* n = c.net;
-  if (n->aux == nullptr || capturing(c.s)) return 0;
+  if (n->aux == nullptr || (capturing(c.s) && !in_capture_too)) return 0;
   V4L_TRACE("par_begin net=%p s=%p aux=%p", (void*)n, (void*)c.s, (void*)n->aux);
   V4L_HIP_CHECK(hipEventRecord(n->ev_fork, c.s));
   V4L_HIP_CHECK(hipStreamWaitEvent(n->aux, n->ev_fork, 0));
@@ -182,8 +182,16 @@ static int launch_tn(Ctx& c, const YL& yl, const XL& xl, int M, int N, int Kx, R
 }
 
 // one launch: sum all registered slabs into the PyTorch-layout gradients
+template <typename T> static int wgrad_dense(Ctx& c, hipStream_t ds);
+template <typename T> static int wgrad_reduce_all(Ctx& c);
 template <typename T>
 static int wgrad_finish(Ctx& c) {
+  int rc = wgrad_dense<T>(c, c.s);
+  return rc ? rc : wgrad_reduce_all<T>(c);
+}
+// the deferred dense weight-grad launches (grouped + whole-output kernels) on stream ds
+template <typename T>
+static int wgrad_dense(Ctx& c, hipStream_t ds) {
   v4l_net* net = c.net;
   if (!net->tnp.empty()) {
     V4L_REQUIRE(net->tnp.size() <= (size_t)v4l_net::MAX_TNP, "internal: too many deferred weight-grads");
@@ -197,7 +205,7 @@ static int wgrad_finish(Ctx& c) {
       net->tnp_cached = net->tnp;
     }
     g_op = "dense.wgrad";
-    V4L_KLAUNCH("gemm_tn_group", net->tnp_flops, c.s, gemm_tn_group_kernel<T>, dim3((unsigned)tb), dim3(256), 0, c.s,
+    V4L_KLAUNCH("gemm_tn_group", net->tnp_flops, ds, gemm_tn_group_kernel<T>, dim3((unsigned)tb), dim3(256), 0, ds,
                 (const TnProb*)net->d_tnp, (int)net->tnp.size());
     V4L_LAUNCH_CHECK();
   }
@@ -219,10 +227,16 @@ static int wgrad_finish(Ctx& c) {
       attr_done = true;
     }
     g_op = "layer.wgrad";
-    V4L_KLAUNCH("gemm_tn_wide", net->wide_flops, c.s, gemm_tn_wide_kernel<T>, dim3((unsigned)tb), dim3(256),
-                TnWideLds<T>::max_bytes, c.s, (const TnWide*)net->d_wide, (int)net->wide.size());
+    V4L_KLAUNCH("gemm_tn_wide", net->wide_flops, ds, gemm_tn_wide_kernel<T>, dim3((unsigned)tb), dim3(256),
+                TnWideLds<T>::max_bytes, ds, (const TnWide*)net->d_wide, (int)net->wide.size());
     V4L_LAUNCH_CHECK();
   }
+  return 0;
+}
+// one launch: sum all registered slabs into the PyTorch-layout gradients
+template <typename T>
+static int wgrad_reduce_all(Ctx& c) {
+  v4l_net* net = c.net;
   int64_t blk = 0;
   for (RedDesc& d : net->red) { d.blk0 = blk; blk += cdiv64((int64_t)d.N * d.K + d.N, 64); }
   V4L_REQUIRE(net->red.size() <= (size_t)v4l_net::MAX_RED, "internal: too many weight-grad descriptors");
@@ -465,7 +479,7 @@ static int conv_stack_bwd_fused(Ctx& c, const T* image, const int* rowidx, int n
   V4L_KLAUNCH("fused_conv_bwd", fl, c.s, bwd_conv_kernel<T>, dim3(nblk), dim3(512), BwdConvLds<T>::bytes, c.s, a);
   V4L_LAUNCH_CHECK();
   g_op = "conv3.wgrad";
-  V4L_KLAUNCH("fused_conv3_wgrad", 2.0 * n * 16 * 64 * 576, c.s, bwd_conv3_wgrad_kernel<T>, dim3(nblk), dim3(256), 0, c.s, a);
+  V4L_KLAUNCH("fused_conv3_wgrad", 2.0 * n * 16 * 64 * 576, c.tn, bwd_conv3_wgrad_kernel<T>, dim3(nblk), dim3(256), 0, c.tn, a);
   V4L_LAUNCH_CHECK();
   return 0;
 }
@@ -1210,8 +1224,15 @@ int v4l_net::backward_t(const float* state, const T* image, const int* rowidx, i
     ep.ldmask = 64;
     if ((rc = lin_dgrad<T>(cx, upconv, yu, ep))) return rc;
   }
+  // the dense weight-grad launches and dW3 only depend on what the layer kernels left behind. Forking them onto the
+  // auxiliary stream next to the conv-stack backward (V4L_PAR_WGRAD=1; a graph fork/join under capture) was measured:
+  // no gain in a graph, -3 % eagerly — bwd_conv_kernel's 256 blocks hold every CU's register file — so it is opt-in.
+  static const bool par_wgrad = getenv("V4L_PAR_WGRAD") != nullptr;
+  if (par_wgrad && (rc = par_begin(cx, true))) return rc;
+  if ((rc = wgrad_dense<T>(cx, cx.tn))) return rc;
   if ((rc = conv_stack_bwd<T>(cx, image, rowidx, n, ws + L.c1, ws + L.c2, ws + L.dc3, ws + L.dc2, ws + L.dc1))) return rc;
-  return wgrad_finish<T>(cx);
+  if ((rc = par_end(cx))) return rc;
+  return wgrad_reduce_all<T>(cx);
 }
 
 // Fused rollout step for the shipped LocoTransformer shape (csrc/infer.h): 4 launches instead of ~50.
