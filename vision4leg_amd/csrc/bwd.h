@@ -455,26 +455,35 @@ __device__ __forceinline__ bf16x8 frag_of_t(const __bf16 (&v)[8]) {
 }
 __device__ __forceinline__ f32x8 frag_of_t(const float (&v)[8]) { return frag_of<float>(v); }
 
-// Gather-form data-grad GEMM of one wave: acc[mt] += A(mt, ks) * W[row = ntile*16 + lane&15][ks*32 ..]^T over KS K=32
-// steps, where the A fragment of (row tile mt, step ks) comes from the LDS row arow(mt, ks >> 1) (64 channels = two steps
-// per tap). Weight fragments stream from L2 through a ring of PD steps, like block_gemm.
-template <typename T, int MT, int KS, class RowF>
-__device__ __forceinline__ void gather_gemm(f32x4 (&acc)[MT], const T* __restrict__ W, int Kp, int ntile, int lane, RowF arow) {
+// Gather-form data-grad GEMM of one wave: acc[mt][j] += A(mt, ks) * W[row = (nt0 + j)*16 + lane&15][ks*32 ..]^T over KS
+// K=32 steps, where the A fragment of (row tile mt, step ks) comes from the LDS row arow(mt, ks >> 1) (64 channels = two
+// steps per tap) and feeds NT column tiles. Weight fragments stream from L2 through a ring of PD steps, like block_gemm.
+template <typename T, int MT, int NT, int KS, class RowF>
+__device__ __forceinline__ void gather_gemm(f32x4 (&acc)[MT][NT], const T* __restrict__ W, int Kp, int nt0, int lane, RowF arow) {
   typedef typename Frag<T>::type frag_t;
-  constexpr int PD = KS < 4 ? KS : 4;
+  constexpr int PD = NT >= 2 ? 2 : (KS < 4 ? KS : 4);
   const int fr = lane & 15, fg = (lane >> 4) * 8;
-  const T* wrow = W + (int64_t)(ntile * 16 + fr) * Kp + fg;
-  frag_t fb[PD];
+  const T* wrow = W + (int64_t)(nt0 * 16 + fr) * Kp + fg;
+  frag_t fb[PD][NT];
 #pragma unroll
-  for (int d = 0; d < PD; ++d) fb[d] = *reinterpret_cast<const frag_t*>(wrow + d * 32);
+  for (int d = 0; d < PD; ++d)
+#pragma unroll
+    for (int j = 0; j < NT; ++j) fb[d][j] = *reinterpret_cast<const frag_t*>(wrow + (int64_t)j * 16 * Kp + d * 32);
 #pragma unroll
   for (int ks = 0; ks < KS; ++ks) {
-    const frag_t cur = fb[ks % PD];
-    if (ks + PD < KS) fb[ks % PD] = *reinterpret_cast<const frag_t*>(wrow + (ks + PD) * 32);
+    frag_t cur[NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j) cur[j] = fb[ks % PD][j];
+    if (ks + PD < KS) {
+#pragma unroll
+      for (int j = 0; j < NT; ++j) fb[ks % PD][j] = *reinterpret_cast<const frag_t*>(wrow + (int64_t)j * 16 * Kp + (ks + PD) * 32);
+    }
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
       const frag_t fa = afrag<T>(arow(mt, ks >> 1) + (ks & 1) * 32 + fg);
-      mma_k32(acc[mt], cur, fa);  // transposed tile: acc[mt][r] = out[16*mt + lane&15][16*ntile + 4*(lane>>4) + r]
+#pragma unroll
+      for (int j = 0; j < NT; ++j)
+        mma_k32(acc[mt][j], cur[j], fa);  // transposed tile: acc[mt][j][r] = out[16*mt + lane&15][16*(nt0+j) + 4*(lane>>4) + r]
     }
   }
 }
@@ -554,10 +563,10 @@ __global__ __launch_bounds__(512) void bwd_conv_kernel(BwdConv a) {
           okr[m] = px < 36;
           iy[m] = px / 6; ix[m] = px - iy[m] * 6;
         }
-        f32x4 acc[MT];
+        f32x4 acc[MT][1];
 #pragma unroll
-        for (int m = 0; m < MT; ++m) acc[m] = f32x4{0.f, 0.f, 0.f, 0.f};
-        gather_gemm<T, MT, 18>(acc, W, 576, nt, lane, [&](int m, int tap) -> const float* {
+        for (int m = 0; m < MT; ++m) acc[m][0] = f32x4{0.f, 0.f, 0.f, 0.f};
+        gather_gemm<T, MT, 1, 18>(acc, W, 576, nt, lane, [&](int m, int tap) -> const float* {
           const int ta = tap / 3, tb = tap - ta * 3;
           const int oy = iy[m] - ta, ox = ix[m] - tb;
           const bool ok = okr[m] && oy >= 0 && oy < 4 && ox >= 0 && ox < 4;
@@ -568,8 +577,8 @@ __global__ __launch_bounds__(512) void bwd_conv_kernel(BwdConv a) {
           const int px = (mt0 + m) * 16 + fr, c4 = nt * 16 + qr;
           if (px < 36) {
             const float4 mk = *reinterpret_cast<const float4*>(sc2 + px * LY::LF + c4);
-            st4(sdc2 + px * LY::LF + c4, mk.x > 0.f ? acc[m][0] : 0.f, mk.y > 0.f ? acc[m][1] : 0.f,
-                mk.z > 0.f ? acc[m][2] : 0.f, mk.w > 0.f ? acc[m][3] : 0.f);
+            st4(sdc2 + px * LY::LF + c4, mk.x > 0.f ? acc[m][0][0] : 0.f, mk.y > 0.f ? acc[m][0][1] : 0.f,
+                mk.z > 0.f ? acc[m][0][2] : 0.f, mk.w > 0.f ? acc[m][0][3] : 0.f);
           }
         }
       };
@@ -617,28 +626,32 @@ __global__ __launch_bounds__(512) void bwd_conv_kernel(BwdConv a) {
       }
     }
     CONV_STAMP(3);
-    {  // ---- dc1 = conv2' (gather form): wave pair = stride-parity class (py,px); rows = its <= 8x8 input pixels,
-       //      K = 2x2 taps x 64 co, N = 32 ci (one 16-wide tile per wave)
-      const int cls = wave >> 1, py = cls >> 1, pxx = cls & 1, nt = wave & 1;
+    {  // ---- dc1 = conv2' (gather form): wave pair = stride-parity class (py,px) with <= 8x8 input pixels; the pair
+       //      splits the 4 row tiles, each wave covers both 16-wide ci tiles (N = 32); K = 2x2 taps x 64 co
+      const int cls = wave >> 1, py = cls >> 1, pxx = cls & 1, mh = wave & 1;
       const int nIy = (15 - py + 1) >> 1, nIx = (15 - pxx + 1) >> 1;
-      int ry[4], rx[4];
+      int ry[2], rx[2];
 #pragma unroll
-      for (int m = 0; m < 4; ++m) { const int r = m * 16 + fr; ry[m] = r >> 3; rx[m] = r & 7; }
-      f32x4 acc[4];
+      for (int m = 0; m < 2; ++m) { const int r = (mh * 2 + m) * 16 + fr; ry[m] = r >> 3; rx[m] = r & 7; }
+      f32x4 acc[2][2];
 #pragma unroll
-      for (int m = 0; m < 4; ++m) acc[m] = f32x4{0.f, 0.f, 0.f, 0.f};
-      gather_gemm<T, 4, 8>(acc, reinterpret_cast<const T*>(a.w2d[cls]), 256, nt, lane, [&](int m, int tap) -> const float* {
+      for (int m = 0; m < 2; ++m) acc[m][0] = acc[m][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+      gather_gemm<T, 2, 2, 8>(acc, reinterpret_cast<const T*>(a.w2d[cls]), 256, 0, lane, [&](int m, int tap) -> const float* {
         const int oy = ry[m] - (tap >> 1), ox = rx[m] - (tap & 1);
         const bool ok = ry[m] < nIy && rx[m] < nIx && oy >= 0 && oy < 6 && ox >= 0 && ox < 6;
         return sdc2 + (ok ? oy * 6 + ox : 36) * LY::LF;
       });
 #pragma unroll
-      for (int m = 0; m < 4; ++m) {
+      for (int m = 0; m < 2; ++m) {
         if (ry[m] < nIy && rx[m] < nIx) {
-          const int p = (py + 2 * ry[m]) * 15 + pxx + 2 * rx[m], c4 = nt * 16 + qr;
-          const float4 mk = ld4(sc1 + p * LY::LC1 + c4);
-          st4(sdc1 + p * LY::LD1 + c4, mk.x > 0.f ? acc[m][0] : 0.f, mk.y > 0.f ? acc[m][1] : 0.f,
-              mk.z > 0.f ? acc[m][2] : 0.f, mk.w > 0.f ? acc[m][3] : 0.f);
+          const int p = (py + 2 * ry[m]) * 15 + pxx + 2 * rx[m];
+#pragma unroll
+          for (int j = 0; j < 2; ++j) {
+            const int c4 = j * 16 + qr;
+            const float4 mk = ld4(sc1 + p * LY::LC1 + c4);
+            st4(sdc1 + p * LY::LD1 + c4, mk.x > 0.f ? acc[m][j][0] : 0.f, mk.y > 0.f ? acc[m][j][1] : 0.f,
+                mk.z > 0.f ? acc[m][j][2] : 0.f, mk.w > 0.f ? acc[m][j][3] : 0.f);
+          }
         }
       }
     }
