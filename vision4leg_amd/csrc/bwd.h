@@ -532,6 +532,12 @@ __global__ __launch_bounds__(512) void bwd_conv_kernel(BwdConv a) {
       const float* g3 = a.dc3 + (int64_t)smp * 16 * 64;
       const float* g2 = a.c2 + (int64_t)smp * 36 * 64;
       const float* g1 = a.c1 + (int64_t)smp * 225 * 32;
+      // the image (contiguous, unpadded in LDS) goes global -> LDS directly: four 16-byte DMA transfers per lane, no
+      // staging registers, all in flight together (LDS destination = wave-uniform base + lane * 16)
+#pragma unroll
+      for (int k = 0; k < CH * 4096 / V / NTH; ++k)
+        __builtin_amdgcn_global_load_lds((const V4L_GLOBAL void*)(gimg + (int64_t)(tid + k * NTH) * V),
+                                         (__attribute__((address_space(3))) void*)(simg + ((tid & ~63) + k * NTH) * V), 16, 0, 0);
       if (tid < 256) {
         const int r = tid >> 4, c4 = (tid & 15) * 4;
         *reinterpret_cast<float4*>(sdc3 + r * LY::LF + c4) = *reinterpret_cast<const float4*>(g3 + r * 64 + c4);
@@ -545,8 +551,6 @@ __global__ __launch_bounds__(512) void bwd_conv_kernel(BwdConv a) {
         const float4 v = *reinterpret_cast<const float4*>(g1 + r * 32 + c4);
         st4(sc1 + r * LY::LC1 + c4, v.x, v.y, v.z, v.w);
       }
-      for (int i = tid; i < CH * 4096 / V; i += NTH)
-        *reinterpret_cast<float4*>(simg + i * V) = *reinterpret_cast<const float4*>(gimg + i * V);
     }
     __syncthreads();
     CONV_STAMP(1);
