@@ -231,10 +231,14 @@ __global__ __launch_bounds__(256) void infer_encoder_kernel(const ActCtl* __rest
   T* c2 = c1 + LY::C1;
   T* c3 = c2 + LY::C2;
   if (train) {
-    typedef typename Frag<T>::type frag_t8;  // 8 elements of T
+    // ingested depth stack (already in the operand type, contiguous): global -> LDS DMA, 16 bytes per lane and transfer,
+    // every transfer in flight at once (a load -> ds_write loop waits for each load before issuing the next)
     const T* src = reinterpret_cast<const T*>(tr.image) + (int64_t)(tr.rowidx ? tr.rowidx[b] : b) * LY::IMG;
-    for (int i = tid; i < LY::IMG / 8; i += 256)
-      *reinterpret_cast<frag_t8*>(img + i * 8) = *reinterpret_cast<const frag_t8*>(src + i * 8);
+    constexpr int V = 16 / sizeof(T);
+#pragma unroll
+    for (int k = 0; k < LY::IMG / V / 256; ++k)
+      __builtin_amdgcn_global_load_lds((const V4L_GLOBAL void*)(src + (int64_t)(tid + k * 256) * V),
+                                       (__attribute__((address_space(3))) void*)(img + ((tid & ~63) + k * 256) * V), 16, 0, 0);
   } else {
     const float4* src = reinterpret_cast<const float4*>(obs + (int64_t)b * D + w.S);  // 16B aligned iff S%4==0
     const bool al = (((int64_t)b * D + w.S) & 3) == 0;
