@@ -41,29 +41,30 @@ struct BwdTail {
   float* o_dc3;                   // [n*16][64]
 };
 
-template <typename T> struct BwdLayLds {
+template <typename T, int SPW> struct BwdLayLds {
+  static constexpr int ROWS = InfRows<SPW>::ROWS;
   static constexpr int PAD = InfLd<T>::PAD;
   static constexpr int LDX = 64 + 4, LDQ = 192 + 4, LDF = 256 + PAD;
-  static constexpr size_t a_b = (size_t)INF_ROWS * LDX * 4;
-  static constexpr size_t qkv_b = (size_t)INF_ROWS * LDQ * 4;
-  static constexpr size_t f_b = (size_t)INF_ROWS * LDF * sizeof(T);
+  static constexpr size_t a_b = (size_t)ROWS * LDX * 4;
+  static constexpr size_t qkv_b = (size_t)ROWS * LDQ * 4;
+  static constexpr size_t f_b = (size_t)ROWS * LDF * sizeof(T);
   static constexpr size_t big_b = qkv_b > f_b ? qkv_b : f_b;
-  static constexpr size_t p_b = (size_t)2 * 4 * NTOK * ATT_PLD * 4;  // P and dS of the 4 samples
+  static constexpr size_t p_b = (size_t)2 * SPW * NTOK * ATT_PLD * 4;  // P and dS of the block's samples
   static constexpr size_t red_b = (size_t)2 * 4 * TD * 4;
   static constexpr size_t bytes = 2 * a_b + big_b + p_b + red_b;     // a | b | df / qkv->dqkv | P,dS | LN partials
 };
 
 // LayerNorm backward, in place over the 80 LDS rows of `d` (rows >= nrows hold zeros and stay zero); the rows < nrows
 // also go to o_dz (global). Leaves the block's dgamma/dbeta partial in gpart/bpart[64]. Contains one __syncthreads.
-template <typename T>
+template <int ROWS, typename T>
 __device__ __forceinline__ void ln_bwd_rows(float* d, int ld, const float* __restrict__ xh, const float* __restrict__ rs,
                                             const float* __restrict__ gamma, int wave, int lane, int nrows,
                                             T* __restrict__ o_dz, float* red, float* __restrict__ gpart,
                                             float* __restrict__ bpart) {
   const float g = gamma[lane];
   float ag = 0.f, ab = 0.f;
-  constexpr int U = INF_ROWS / 16;
-  for (int r0 = wave; r0 < INF_ROWS; r0 += 4 * U) {
+  constexpr int U = ROWS / 16;  // 80 -> 5, 48 -> 3 rows in flight per wave
+  for (int r0 = wave; r0 < ROWS; r0 += 4 * U) {
     float dd[U], x[U], rr[U], dxh[U], c1[U], c2[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) {  // loads are unconditional (row 0 stands in for the padding rows), then selected
@@ -102,9 +103,10 @@ __device__ __forceinline__ void ln_bwd_rows(float* d, int ld, const float* __res
   }
 }
 
-template <typename T, bool HEAD, bool TAIL>
+template <typename T, int SPW, bool HEAD, bool TAIL>
 __global__ __launch_bounds__(256) void bwd_layer_kernel(BwdLayer w, BwdHead hd, BwdTail tl, int n) {
-  typedef BwdLayLds<T> LY;
+  typedef BwdLayLds<T, SPW> LY;
+  constexpr int ROWS = InfRows<SPW>::ROWS, MT = InfRows<SPW>::MT;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int fr = lane & 15, qr = (lane >> 4) * 4;
@@ -113,8 +115,8 @@ __global__ __launch_bounds__(256) void bwd_layer_kernel(BwdLayer w, BwdHead hd, 
   float* big = reinterpret_cast<float*>(smem + 2 * LY::a_b);         // df (T) -> qkv -> dqkv (fp32)
   float* sp = reinterpret_cast<float*>(smem + 2 * LY::a_b + LY::big_b);
   float* red = reinterpret_cast<float*>(smem + 2 * LY::a_b + LY::big_b + LY::p_b);
-  const int s0 = blockIdx.x * INF_SPW;
-  const int ns = min(INF_SPW, n - s0);
+  const int s0 = blockIdx.x * SPW;
+  const int ns = min(SPW, n - s0);
   const int nrows = ns * NTOK;
   const int64_t row0 = (int64_t)s0 * NTOK;
   const int nt1[1] = {wave};
@@ -165,7 +167,7 @@ __global__ __launch_bounds__(256) void bwd_layer_kernel(BwdLayer w, BwdHead hd, 
     }
     __syncthreads();
     // un-pool (pool_bwd_kernel): token 0 <- dpool[:, 0:64], tokens 1..16 <- dpool[:, 64:128] / 16
-    for (int idx = tid; idx < INF_ROWS * TD; idx += 256) {
+    for (int idx = tid; idx < ROWS * TD; idx += 256) {
       const int r = idx >> 6, c = idx & 63;
       float v = 0.f;
       if (r < nrows) {
@@ -176,7 +178,7 @@ __global__ __launch_bounds__(256) void bwd_layer_kernel(BwdLayer w, BwdHead hd, 
     }
   } else {
     const float* dyg = w.dy + row0 * TD;
-    for (int i4 = tid; i4 < INF_ROWS * (TD / 4); i4 += 256) {
+    for (int i4 = tid; i4 < ROWS * (TD / 4); i4 += 256) {
       const int r = i4 >> 4, c4 = (i4 & 15) * 4;
       const bool ok = r < nrows;
       const float4 v = *reinterpret_cast<const float4*>(dyg + (ok ? r : 0) * TD + c4);
@@ -185,18 +187,18 @@ __global__ __launch_bounds__(256) void bwd_layer_kernel(BwdLayer w, BwdHead hd, 
   }
   __syncthreads();
   // ---- norm2 backward: a = dz2
-  ln_bwd_rows(a, LY::LDX, w.s_xh2 + row0 * TD, w.s_rs2 + row0, w.g2, wave, lane, nrows,
+  ln_bwd_rows<ROWS>(a, LY::LDX, w.s_xh2 + row0 * TD, w.s_rs2 + row0, w.g2, wave, lane, nrows,
               reinterpret_cast<T*>(w.o_dz2) + row0 * TD, red,
               w.gp2 + (int64_t)blockIdx.x * TD, w.bp2 + (int64_t)blockIdx.x * TD);
   __syncthreads();
   // ---- df = (dz2 W2) o [f > 0]   (T in LDS for the next contraction, fp32 to HBM for linear1's weight-grad)
   T* f = reinterpret_cast<T*>(big);
   {
-    f32x4 acc[INF_MT][4];
+    f32x4 acc[MT][4];
     zero_acc(acc);
-    block_gemm<T, INF_MT, 4, 2>(acc, a, LY::LDX, (const T*)w.w2t, 64, nt4, lane);
+    block_gemm<T, MT, 4, 2>(acc, a, LY::LDX, (const T*)w.w2t, 64, nt4, lane);
 #pragma unroll
-    for (int mt = 0; mt < INF_MT; ++mt) {
+    for (int mt = 0; mt < MT; ++mt) {
       const int row = mt * 16 + fr;
       const bool ok = row < nrows;
       float4 m[4];
@@ -215,12 +217,12 @@ __global__ __launch_bounds__(256) void bwd_layer_kernel(BwdLayer w, BwdHead hd, 
   }
   __syncthreads();
   {  // ---- dx1 = dz2 + df W1 -> b
-    f32x4 acc[INF_MT][1];
+    f32x4 acc[MT][1];
     zero_acc(acc);
-    block_gemm<T, INF_MT, 1, 8>(acc, f, LY::LDF, (const T*)w.w1t, 256, nt1, lane);
+    block_gemm<T, MT, 1, 8>(acc, f, LY::LDF, (const T*)w.w1t, 256, nt1, lane);
     const int n4 = wave * 16 + qr;
 #pragma unroll
-    for (int mt = 0; mt < INF_MT; ++mt) {
+    for (int mt = 0; mt < MT; ++mt) {
       const int row = mt * 16 + fr;
       const float4 r = *reinterpret_cast<const float4*>(a + row * LY::LDX + n4);
       st4(b + row * LY::LDX + n4, r.x + acc[mt][0][0], r.y + acc[mt][0][1], r.z + acc[mt][0][2], r.w + acc[mt][0][3]);
@@ -230,7 +232,7 @@ __global__ __launch_bounds__(256) void bwd_layer_kernel(BwdLayer w, BwdHead hd, 
   // qkv and P of the four samples come in while norm1' and the out_proj data-grad run (`big` is free: df was consumed)
   {
     const float* qg = w.s_qkv + row0 * 192;
-    for (int i4 = tid; i4 < INF_ROWS * 48; i4 += 256) {
+    for (int i4 = tid; i4 < ROWS * 48; i4 += 256) {
       const int r = i4 / 48, c4 = (i4 - r * 48) * 4;
       const bool ok = r < nrows;
       const float4 v = *reinterpret_cast<const float4*>(qg + (ok ? r : 0) * 192 + c4);
@@ -244,17 +246,17 @@ __global__ __launch_bounds__(256) void bwd_layer_kernel(BwdLayer w, BwdHead hd, 
     }
   }
   // ---- norm1 backward: b = dz1
-  ln_bwd_rows(b, LY::LDX, w.s_xh1 + row0 * TD, w.s_rs1 + row0, w.g1, wave, lane, nrows,
+  ln_bwd_rows<ROWS>(b, LY::LDX, w.s_xh1 + row0 * TD, w.s_rs1 + row0, w.g1, wave, lane, nrows,
               reinterpret_cast<T*>(w.o_dz1) + row0 * TD, red,
               w.gp1 + (int64_t)blockIdx.x * TD, w.bp1 + (int64_t)blockIdx.x * TD);
   __syncthreads();
   {  // ---- dctx = dz1 Wo -> a
-    f32x4 acc[INF_MT][1];
+    f32x4 acc[MT][1];
     zero_acc(acc);
-    block_gemm<T, INF_MT, 1, 2>(acc, b, LY::LDX, (const T*)w.wot, 64, nt1, lane);
+    block_gemm<T, MT, 1, 2>(acc, b, LY::LDX, (const T*)w.wot, 64, nt1, lane);
     const int n4 = wave * 16 + qr;
 #pragma unroll
-    for (int mt = 0; mt < INF_MT; ++mt)
+    for (int mt = 0; mt < MT; ++mt)
       st4(a + (mt * 16 + fr) * LY::LDX + n4, acc[mt][0][0], acc[mt][0][1], acc[mt][0][2], acc[mt][0][3]);
   }
   __syncthreads();
@@ -264,7 +266,7 @@ __global__ __launch_bounds__(256) void bwd_layer_kernel(BwdLayer w, BwdHead hd, 
     const bool act = wave < ns;
     float* qs = big + wave * NTOK * LY::LDQ;
     float* p = sp + wave * NTOK * ATT_PLD;
-    float* ds = sp + (4 + wave) * NTOK * ATT_PLD;
+    float* ds = sp + (SPW + wave) * NTOK * ATT_PLD;
     const float* dc = a + wave * NTOK * LY::LDX;
     if (act) {
       for (int pr = lane; pr < NTOK * NTOK; pr += 64) {
@@ -328,12 +330,12 @@ __global__ __launch_bounds__(256) void bwd_layer_kernel(BwdLayer w, BwdHead hd, 
   }
   __syncthreads();
   {  // ---- dx_in = dz1 + dqkv Win -> global
-    f32x4 acc[INF_MT][1];
+    f32x4 acc[MT][1];
     zero_acc(acc);
-    block_gemm<T, INF_MT, 1, 6>(acc, big, LY::LDQ, (const T*)w.wint, 192, nt1, lane);
+    block_gemm<T, MT, 1, 6>(acc, big, LY::LDQ, (const T*)w.wint, 192, nt1, lane);
     const int n4 = wave * 16 + qr;
 #pragma unroll
-    for (int mt = 0; mt < INF_MT; ++mt) {
+    for (int mt = 0; mt < MT; ++mt) {
       const int row = mt * 16 + fr;
       const float4 r = *reinterpret_cast<const float4*>(b + row * LY::LDX + n4);
       const float v0 = r.x + acc[mt][0][0], v1 = r.y + acc[mt][0][1], v2 = r.z + acc[mt][0][2], v3 = r.w + acc[mt][0][3];
@@ -344,12 +346,12 @@ __global__ __launch_bounds__(256) void bwd_layer_kernel(BwdLayer w, BwdHead hd, 
   if constexpr (TAIL) {
     __syncthreads();
     {  // ---- tokens 1..16: dc3 = (dx_in Wup) o [c3 > 0]; the token-0 rows of the tile are computed and dropped
-      f32x4 acc[INF_MT][1];
+      f32x4 acc[MT][1];
       zero_acc(acc);
-      block_gemm<T, INF_MT, 1, 2>(acc, a, LY::LDX, (const T*)tl.wupt, 64, nt1, lane);
+      block_gemm<T, MT, 1, 2>(acc, a, LY::LDX, (const T*)tl.wupt, 64, nt1, lane);
       const int n4 = wave * 16 + qr;
 #pragma unroll
-      for (int mt = 0; mt < INF_MT; ++mt) {
+      for (int mt = 0; mt < MT; ++mt) {
         const int row = mt * 16 + fr;
         const int sm = row / NTOK, t = row - sm * NTOK;
         const bool ok = row < nrows && t > 0;

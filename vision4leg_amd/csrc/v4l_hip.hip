@@ -752,7 +752,7 @@ int64_t v4l_net::slab_floats(int n) const {
     add(n * NTOK, t.inproj.N, t.inproj.K); add(n * NTOK, t.outproj.N, t.outproj.K);
     add(n * NTOK, t.ff1.N, t.ff1.K); add(n * NTOK, t.ff2.N, t.ff2.K);
     // LayerNorm dgamma/dbeta partials: one [64] row per block (<= 128 ln_bwd blocks, or n/4 fused-layer blocks)
-    tot += 2 * 2 * (int64_t)std::max(128, cdiv(n, INF_SPW)) * TD;
+    tot += 2 * 2 * (int64_t)std::max(128, cdiv(n, 2)) * TD;
   }
   for (const Lin& L : head) add(n, L.N, L.K);
   return tot;
@@ -1096,16 +1096,24 @@ int v4l_net::backward_t(const float* state, const T* image, const int* rowidx, i
     const LayerWs& w = L.lw[l];
     const LayerBw& b = L.lb[l];
     static bool attr_done = false;
+    static int spw = 4;  // samples per block: 4 (80 MFMA rows, 1 block per CU) or 2 (48 rows, 2 blocks per CU): measured equal
     if (!attr_done) {
-      const void* fns[4] = {reinterpret_cast<const void*>(&bwd_layer_kernel<T, false, false>),
-                            reinterpret_cast<const void*>(&bwd_layer_kernel<T, true, false>),
-                            reinterpret_cast<const void*>(&bwd_layer_kernel<T, false, true>),
-                            reinterpret_cast<const void*>(&bwd_layer_kernel<T, true, true>)};
-      for (const void* fn : fns)
-        V4L_HIP_CHECK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)BwdLayLds<T>::bytes));
+      if (const char* e = getenv("V4L_LAYER_BWD_SPW")) spw = atoi(e) == 2 ? 2 : 4;
+      const void* f4[4] = {reinterpret_cast<const void*>(&bwd_layer_kernel<T, 4, false, false>),
+                           reinterpret_cast<const void*>(&bwd_layer_kernel<T, 4, true, false>),
+                           reinterpret_cast<const void*>(&bwd_layer_kernel<T, 4, false, true>),
+                           reinterpret_cast<const void*>(&bwd_layer_kernel<T, 4, true, true>)};
+      const void* f2[4] = {reinterpret_cast<const void*>(&bwd_layer_kernel<T, 2, false, false>),
+                           reinterpret_cast<const void*>(&bwd_layer_kernel<T, 2, true, false>),
+                           reinterpret_cast<const void*>(&bwd_layer_kernel<T, 2, false, true>),
+                           reinterpret_cast<const void*>(&bwd_layer_kernel<T, 2, true, true>)};
+      for (const void* fn : f4)
+        V4L_HIP_CHECK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)BwdLayLds<T, 4>::bytes));
+      for (const void* fn : f2)
+        V4L_HIP_CHECK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)BwdLayLds<T, 2>::bytes));
       attr_done = true;
     }
-    const int nblk = cdiv(n, INF_SPW);
+    const int nblk = cdiv(n, spw);
     float* part = cx.slab + cx.slab_used;  // gp2 | bp2 | gp1 | bp1, [nblk][64] each
     cx.slab_used += 4 * (int64_t)nblk * TD;
     V4L_REQUIRE(cx.slab_used <= slab_cap, "internal: weight-grad slab arena overflow");
@@ -1136,8 +1144,14 @@ int v4l_net::backward_t(const float* state, const T* image, const int* rowidx, i
     const double fl = 4.0 * n * 872576.0 + (hd_on ? 2.0 * n * 2 * (16 * 256 + 256 * 256 + 256 * 128) : 0.0) +
                       (tl_on ? 2.0 * n * (64 * 256 + 256 * 256 + 16 * 64 * 64) : 0.0);
 #define V4L_BWD_LAYER(H, TL)                                                                                              \
-  V4L_KLAUNCH(H ? (TL ? "fused_layer_bwd_head_tail" : "fused_layer_bwd_head") : (TL ? "fused_layer_bwd_tail" : "fused_layer_bwd"), \
-              fl, s, (bwd_layer_kernel<T, H, TL>), dim3(nblk), dim3(256), BwdLayLds<T>::bytes, s, d, bh, bt, n)
+  do {                                                                                                                    \
+    const char* kn = H ? (TL ? "fused_layer_bwd_head_tail" : "fused_layer_bwd_head")                                      \
+                       : (TL ? "fused_layer_bwd_tail" : "fused_layer_bwd");                                               \
+    if (spw == 2)                                                                                                         \
+      V4L_KLAUNCH(kn, fl, s, (bwd_layer_kernel<T, 2, H, TL>), dim3(nblk), dim3(256), (BwdLayLds<T, 2>::bytes), s, d, bh, bt, n); \
+    else                                                                                                                  \
+      V4L_KLAUNCH(kn, fl, s, (bwd_layer_kernel<T, 4, H, TL>), dim3(nblk), dim3(256), (BwdLayLds<T, 4>::bytes), s, d, bh, bt, n); \
+  } while (0)
     if (hd_on && tl_on) V4L_BWD_LAYER(true, true);
     else if (hd_on) V4L_BWD_LAYER(true, false);
     else if (tl_on) V4L_BWD_LAYER(false, true);
