@@ -371,11 +371,12 @@ def test_graph_replay_equals_eager(mode, pair, device):
 
 @pytest.mark.parametrize("graph", [False, True])
 @pytest.mark.parametrize("mode", MODES)
-def test_rollout_actor_matches_separate_calls(mode, graph, device):
+@pytest.mark.parametrize("name", ["loco_s84", "cnn_s93"])
+def test_rollout_actor_matches_separate_calls(name, mode, graph, device):
     """RolloutActor.step (shared encoder pass, graph replay, device-side cursor) == pf.explore + vf of the reference
     protocol: same mean/std/value, action = mean + std*eps, rows/actions/values filed at slots [t*E,(t+1)*E)."""
     from vision4leg_amd.torchrl.policies import RolloutActor
-    case = util.CASES["loco_s84"]
+    case = util.CASES[name]
     E, T = 8, 4
     pf, vf = _build(case, mode, device)
     net = pf.hip

@@ -1156,4 +1156,287 @@ __global__ __launch_bounds__(1024) void rollout_encoder_kernel(const ActCtl* __r
   }
 }
 
+
+// ------------------------------------------------------------------------------------------ rollout step, NatureCNN fuse net
+// The whole env step of the NatureCNN policy / value pair (networks/nets.py:194-262, base.py:345-398) for ONE sample
+// per block (blockIdx.y = net: both recompute the encoder they share): ingest -> conv1..3 -> visual projector (1024 ->
+// 256) || proprio MLP -> concat -> 3-layer head -> sample / file. 16 waves, one 16-column tile per wave in every
+// matrix-vector phase (only fragment row 0 carries data).
+struct InfCnn {
+  const void *w1, *w2, *w3;                  // packed conv weights (T): [32][256] [64][512] [64][576]
+  const float *b1, *b2, *b3;
+  const void *wpr, *wf1, *wf2;               // visual projector [256][1024] (NHWC-flatten k order), proprio MLP [256][Kp1] [256][256]
+  const float *bpr, *bf1, *bf2;
+  int S, Sp, Kp1;
+};
+struct InfCnnHead { const void *w0, *w1, *w2; const float *b0, *b1, *b2; float* out; int nout; };  // [256][512] [256][256] [16][256]
+struct InfCnnHeadPair { InfCnnHead n[2]; };
+template <typename T> struct RollCnnLds {
+  typedef InfEncLds<T> E;
+  static constexpr int LDC = 512 + InfLd<T>::PAD;
+  static constexpr size_t conv_b = E::conv_bytes;
+  static constexpr size_t sin_b = 128 * 4, cat_b = (size_t)LDC * sizeof(T), h_b = (size_t)256 * sizeof(T), so_b = 16 * 4;
+  static constexpr size_t bytes = conv_b + sin_b + cat_b + 3 * h_b + so_b + 64;
+};
+// y[16 columns of tile nt] = W[nt*16 .. +16][0..32*KS) . x: x is ONE row held in LDS (fp32 or T), so only lane group
+// fr == 0 supplies a non-zero A fragment; result acc[r] (lanes with fr == 0) = y[nt*16 + 4*(lane>>4) + r]
+template <typename T, int KS, int PD, typename AT>
+__device__ __forceinline__ f32x4 gemv_tile(const AT* x, const T* __restrict__ Wp, int Kp, int nt, int lane) {
+  typedef typename Frag<T>::type frag_t;
+  const int fr = lane & 15, fg = (lane >> 4) * 8;
+  const T* wrow = Wp + (int64_t)(nt * 16 + fr) * Kp + fg;
+  frag_t ring[PD];
+#pragma unroll
+  for (int d = 0; d < PD; ++d) ring[d] = *reinterpret_cast<const frag_t*>(wrow + d * 32);
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  frag_t zero;
+  if constexpr (sizeof(T) == 2) { for (int j = 0; j < 8; ++j) zero[j] = (__bf16)0.f; } else { for (int j = 0; j < 8; ++j) zero.v[j] = 0.f; }
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) {
+    const frag_t fb = ring[ks % PD];
+    if (ks + PD < KS) ring[ks % PD] = *reinterpret_cast<const frag_t*>(wrow + (ks + PD) * 32);
+    frag_t fa;
+    if constexpr (sizeof(AT) == sizeof(T)) fa = *reinterpret_cast<const frag_t*>(x + ks * 32 + fg);
+    else fa = afrag<T>(reinterpret_cast<const float*>(x) + ks * 32 + fg);
+    mma_k32(acc, fb, fr == 0 ? fa : zero);
+  }
+  return acc;
+}
+
+template <typename T>
+__global__ __launch_bounds__(1024) void rollout_cnn_kernel(const ActCtl* __restrict__ ctlc, const float* __restrict__ obs, int E,
+                                                           InfCnn w, InfCnnHeadPair hd, InfFinish fin,
+                                                           float* __restrict__ state_roll, T* __restrict__ image_roll) {
+  typedef typename Frag<T>::type frag_t;
+  typedef InfEncLds<T> LY;
+  typedef RollCnnLds<T> RL;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int fr = lane & 15, fg = (lane >> 4) * 8, qr = (lane >> 4) * 4;
+  const long long t_step = ctlc->t;
+  const int64_t slot0 = (int64_t)t_step * E;
+  const int D = w.S + LY::IMG;
+  const int b = blockIdx.x, net = blockIdx.y;
+  T* img = reinterpret_cast<T*>(smem);
+  T* c1 = img + LY::IMG;
+  T* c2 = c1 + LY::C1;
+  T* c3 = c2 + LY::C2;
+  float* sin = reinterpret_cast<float*>(smem + RL::conv_b);
+  T* cat = reinterpret_cast<T*>(smem + RL::conv_b + RL::sin_b);
+  T* h1 = reinterpret_cast<T*>(smem + RL::conv_b + RL::sin_b + RL::cat_b);
+  T* h2 = h1 + 256;
+  T* hs = h2 + 256;  // proprio fc1 output
+  float* so = reinterpret_cast<float*>(smem + RL::conv_b + RL::sin_b + RL::cat_b + 3 * RL::h_b);
+  {
+    const float4* src = reinterpret_cast<const float4*>(obs + (int64_t)b * D + w.S);  // 16B aligned iff S%4==0
+    const bool al = (((int64_t)b * D + w.S) & 3) == 0;
+    T* roll = image_roll + (slot0 + b) * (int64_t)LY::IMG;
+    float4 v[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int i = tid + k * 1024;
+      if (al) v[k] = src[i];
+      else {
+        const float* s1 = obs + (int64_t)b * D + w.S + i * 4;
+        v[k] = float4{s1[0], s1[1], s1[2], s1[3]};
+      }
+    }
+    if (tid < 128) {
+      const float x = tid < w.S ? obs[(int64_t)b * D + tid] : 0.f;
+      sin[tid] = x;
+      if (net == 0 && tid < w.Sp) state_roll[(slot0 + b) * w.Sp + tid] = x;
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int i = tid + k * 1024;
+      st4(img + i * 4, v[k].x, v[k].y, v[k].z, v[k].w);
+      if (net == 0) st4(roll + i * 4, v[k].x, v[k].y, v[k].z, v[k].w);
+    }
+  }
+  __syncthreads();
+  {  // proprio fc1: column tile `wave` (its output is first read after the next barriers)
+    const f32x4 a = w.Kp1 == 128 ? gemv_tile<T, 4, 4>(sin, (const T*)w.wf1, 128, wave, lane)
+                                 : gemv_tile<T, 2, 2>(sin, (const T*)w.wf1, 64, wave, lane);
+    if (fr == 0) {
+      const int n4 = wave * 16 + qr;
+      const float4 bb = *reinterpret_cast<const float4*>(w.bf1 + n4);
+      st4(hs + n4, fmaxf(a[0] + bb.x, 0.f), fmaxf(a[1] + bb.y, 0.f), fmaxf(a[2] + bb.z, 0.f), fmaxf(a[3] + bb.w, 0.f));
+    }
+  }
+  if (wave < 15) {  // conv1: one 16-pixel row tile per wave
+    f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+    const int p = min(wave * 16 + fr, 224);
+    const int pbase = (p / 15) * 4 * 64 + (p % 15) * 4;
+    frag_t ring[4][2];
+#pragma unroll
+    for (int d = 0; d < 4; ++d)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) ring[d][j] = *reinterpret_cast<const frag_t*>((const T*)w.w1 + (j * 16 + fr) * 256 + d * 32 + fg);
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) {
+      const int k0 = ks * 32 + fg, c = k0 >> 6, ky = (k0 >> 3) & 7;
+      const frag_t fb0 = ring[ks & 3][0], fb1 = ring[ks & 3][1];
+      if (ks + 4 < 8) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          ring[ks & 3][j] = *reinterpret_cast<const frag_t*>((const T*)w.w1 + (j * 16 + fr) * 256 + (ks + 4) * 32 + fg);
+      }
+      const frag_t fa = afrag_t(img + c * 4096 + ky * 64 + pbase);
+      mma_k32(acc[0], fb0, fa);
+      mma_k32(acc[1], fb1, fa);
+    }
+    const int pp = wave * 16 + fr;
+    if (pp < 225) {
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int n4 = j * 16 + qr;
+        const float4 bb = *reinterpret_cast<const float4*>(w.b1 + n4);
+        st4(c1 + pp * LY::LD1 + n4, fmaxf(acc[j][0] + bb.x, 0.f), fmaxf(acc[j][1] + bb.y, 0.f), fmaxf(acc[j][2] + bb.z, 0.f),
+            fmaxf(acc[j][3] + bb.w, 0.f));
+      }
+    }
+  }
+  __syncthreads();
+  if (wave < 12) {  // conv2: (row tile, column tile) per wave
+    const int mt = wave >> 2, nt = wave & 3;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    const int p = min(mt * 16 + fr, 35);
+    const int pb = ((p / 6) * 2 * 15 + (p % 6) * 2) * LY::LD1;
+    const T* w2row = (const T*)w.w2 + (nt * 16 + fr) * 512 + fg;
+    frag_t ring[8];
+#pragma unroll
+    for (int d = 0; d < 8; ++d) ring[d] = *reinterpret_cast<const frag_t*>(w2row + d * 32);
+#pragma unroll
+    for (int ks = 0; ks < 16; ++ks) {
+      const int ky = ks >> 2, kx = ks & 3;
+      const frag_t fb = ring[ks & 7];
+      if (ks + 8 < 16) ring[ks & 7] = *reinterpret_cast<const frag_t*>(w2row + (ks + 8) * 32);
+      const frag_t fa = afrag_t(c1 + pb + (ky * 15 + kx) * LY::LD1 + fg);
+      mma_k32(acc, fb, fa);
+    }
+    const int pp = mt * 16 + fr, n4 = nt * 16 + qr;
+    const float4 bb = *reinterpret_cast<const float4*>(w.b2 + n4);
+    if (pp < 36)
+      st4(c2 + pp * LY::LD2 + n4, fmaxf(acc[0] + bb.x, 0.f), fmaxf(acc[1] + bb.y, 0.f), fmaxf(acc[2] + bb.z, 0.f),
+          fmaxf(acc[3] + bb.w, 0.f));
+  }
+  __syncthreads();
+  float* part = reinterpret_cast<float*>(img);  // [4 K-quarters][16 pixels][64] fp32 partial sums (the image is dead)
+  {  // conv3: wave = (column tile, K-quarter)
+    const int nt = wave & 3, kq = wave >> 2;
+    const int ks0 = kq * 5, ks1 = min(18, ks0 + 5);
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    const int pb = ((fr >> 2) * 6 + (fr & 3)) * LY::LD2;
+    const T* w3row = (const T*)w.w3 + (nt * 16 + fr) * 576 + fg;
+    frag_t fbv[5];
+#pragma unroll
+    for (int d = 0; d < 5; ++d) fbv[d] = *reinterpret_cast<const frag_t*>(w3row + min(ks0 + d, 17) * 32);
+#pragma unroll
+    for (int d = 0; d < 5; ++d) {
+      const int ks = ks0 + d;
+      if (ks < ks1) {
+        const int tap = ks >> 1, ky = tap / 3, kx = tap - ky * 3, c0 = (ks & 1) * 32 + fg;
+        const frag_t fa = afrag_t(c2 + pb + (ky * 6 + kx) * LY::LD2 + c0);
+        mma_k32(acc, fbv[d], fa);
+      }
+    }
+    st4(part + (kq * 16 + fr) * 64 + nt * 16 + qr, acc[0], acc[1], acc[2], acc[3]);
+  }
+  __syncthreads();
+  {
+    const int pix = tid >> 6, n = tid & 63;
+    const float v = ((part[pix * 64 + n] + part[(16 + pix) * 64 + n]) + part[(32 + pix) * 64 + n]) + part[(48 + pix) * 64 + n];
+    c3[pix * LY::LD2 + n] = (T)fmaxf(v + w.b3[n], 0.f);
+  }
+  __syncthreads();
+  {  // visual projector over the NHWC flatten of conv3 (k = pixel*64 + c: 32 steps) and proprio fc2: tile `wave` of each
+    typedef typename Frag<T>::type fr_t;
+    const T* wrow = (const T*)w.wpr + (int64_t)(wave * 16 + fr) * 1024 + fg;
+    fr_t ring[8];
+#pragma unroll
+    for (int d = 0; d < 8; ++d) ring[d] = *reinterpret_cast<const fr_t*>(wrow + d * 32);
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    fr_t zero;
+    if constexpr (sizeof(T) == 2) { for (int j = 0; j < 8; ++j) zero[j] = (__bf16)0.f; } else { for (int j = 0; j < 8; ++j) zero.v[j] = 0.f; }
+#pragma unroll
+    for (int ks = 0; ks < 32; ++ks) {
+      const fr_t fb = ring[ks & 7];
+      if (ks + 8 < 32) ring[ks & 7] = *reinterpret_cast<const fr_t*>(wrow + (ks + 8) * 32);
+      const fr_t fa = afrag_t(c3 + (ks >> 1) * LY::LD2 + (ks & 1) * 32 + fg);
+      mma_k32(acc, fb, fr == 0 ? fa : zero);
+    }
+    const f32x4 a2 = gemv_tile<T, 8, 8>(hs, (const T*)w.wf2, 256, wave, lane);
+    if (fr == 0) {
+      const int n4 = wave * 16 + qr;
+      const float4 bp = *reinterpret_cast<const float4*>(w.bpr + n4), b2 = *reinterpret_cast<const float4*>(w.bf2 + n4);
+      st4(cat + n4, fmaxf(acc[0] + bp.x, 0.f), fmaxf(acc[1] + bp.y, 0.f), fmaxf(acc[2] + bp.z, 0.f), fmaxf(acc[3] + bp.w, 0.f));
+      st4(cat + 256 + n4, fmaxf(a2[0] + b2.x, 0.f), fmaxf(a2[1] + b2.y, 0.f), fmaxf(a2[2] + b2.z, 0.f), fmaxf(a2[3] + b2.w, 0.f));
+    }
+  }
+  __syncthreads();
+  const InfCnnHead& h = hd.n[net];
+  {
+    const f32x4 a = gemv_tile<T, 16, 8>(cat, (const T*)h.w0, 512, wave, lane);
+    if (fr == 0) {
+      const int n4 = wave * 16 + qr;
+      const float4 bb = *reinterpret_cast<const float4*>(h.b0 + n4);
+      st4(h1 + n4, fmaxf(a[0] + bb.x, 0.f), fmaxf(a[1] + bb.y, 0.f), fmaxf(a[2] + bb.z, 0.f), fmaxf(a[3] + bb.w, 0.f));
+    }
+  }
+  __syncthreads();
+  {
+    const f32x4 a = gemv_tile<T, 8, 8>(h1, (const T*)h.w1, 256, wave, lane);
+    if (fr == 0) {
+      const int n4 = wave * 16 + qr;
+      const float4 bb = *reinterpret_cast<const float4*>(h.b1 + n4);
+      st4(h2 + n4, fmaxf(a[0] + bb.x, 0.f), fmaxf(a[1] + bb.y, 0.f), fmaxf(a[2] + bb.z, 0.f), fmaxf(a[3] + bb.w, 0.f));
+    }
+  }
+  __syncthreads();
+  if (wave == 0) {
+    const f32x4 a = gemv_tile<T, 8, 8>(h2, (const T*)h.w2, 256, 0, lane);
+    if (fr == 0) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int c = qr + r;
+        const float v = c < h.nout ? a[r] + h.b2[c] : 0.f;
+        so[c] = v;
+        h.out[(int64_t)b * OUT_LD + c] = v;
+      }
+    }
+  }
+  __syncthreads();
+  if (tid == 0) {  // sampling / filing epilogue: see infer_layer_kernel
+    const int i = b, A = fin.A;
+    if (net == 0) {
+      float e = 0.f, lp = 0.f;
+      for (int a = 0; a < A; ++a) {
+        const float mu = so[a];
+        const float ls = fminf(fmaxf(fin.logstd[a], LOG_SIG_MIN), LOG_SIG_MAX);
+        const float sg = expf(ls);
+        e += 0.5f + HALF_LOG_2PI + logf(sg);
+        const float act = fmaf(sg, fin.eps[(int64_t)i * A + a], mu);
+        fin.action[(int64_t)i * A + a] = act;
+        fin.mean[(int64_t)i * A + a] = mu;
+        fin.stdv[(int64_t)i * A + a] = sg;
+        if (fin.acts_roll != nullptr) fin.acts_roll[(t_step * E + i) * A + a] = act;
+        const float d = act - mu;
+        lp += -(d * d) / (2.f * sg * sg) - logf(sg) - HALF_LOG_2PI;
+      }
+      fin.ent[i] = e;
+      if (fin.logp_roll != nullptr) fin.logp_roll[t_step * E + i] = lp;
+    } else {
+      const float v = so[0];
+      fin.value[i] = v;
+      if (fin.values_roll != nullptr) fin.values_roll[t_step * E + i] = v;
+    }
+    __threadfence();
+    const unsigned long long done = atomicAdd(reinterpret_cast<unsigned long long*>(&fin.ctl->done), 1ull);
+    if (done == (unsigned long long)(gridDim.x * gridDim.y) - 1) {
+      fin.ctl->done = 0;
+      fin.ctl->t = t_step + 1;
+    }
+  }
+}
+
 }  // namespace v4l
