@@ -1439,4 +1439,89 @@ __global__ __launch_bounds__(1024) void rollout_cnn_kernel(const ActCtl* __restr
   }
 }
 
+
+// ------------------------------------------------------------------------------------------ rollout step, state MLP
+// Net / GaussianContPolicyBasicBias pair on proprioception only (networks/nets.py:16-55, starter/ppo_state.py): shared
+// base MLP (S -> 256 -> 256, ReLU) + per-net head (256 -> 256 -> 256 -> out). One sample per block, blockIdx.y = net.
+struct InfMlp { const void *wf1, *wf2; const float *bf1, *bf2; int S, Sp, Kp1; };
+template <typename T>
+__global__ __launch_bounds__(1024) void rollout_mlp_kernel(const ActCtl* __restrict__ ctlc, const float* __restrict__ obs, int E,
+                                                           InfMlp w, InfCnnHeadPair hd, InfFinish fin,
+                                                           float* __restrict__ state_roll) {
+  __shared__ __attribute__((aligned(16))) float sin[128];
+  __shared__ __attribute__((aligned(16))) T hbuf[4][256];
+  __shared__ float so[16];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int fr = lane & 15, qr = (lane >> 4) * 4;
+  const long long t_step = ctlc->t;
+  const int b = blockIdx.x, net = blockIdx.y;
+  if (tid < 128) {
+    const float x = tid < w.S ? obs[(int64_t)b * w.S + tid] : 0.f;
+    sin[tid] = x;
+    if (net == 0 && tid < w.Sp) state_roll[((int64_t)t_step * E + b) * w.Sp + tid] = x;
+  }
+  __syncthreads();
+  auto relu_store = [&](T* dst, const f32x4& a, const float* bias) {
+    if (fr == 0) {
+      const int n4 = wave * 16 + qr;
+      const float4 bb = *reinterpret_cast<const float4*>(bias + n4);
+      st4(dst + n4, fmaxf(a[0] + bb.x, 0.f), fmaxf(a[1] + bb.y, 0.f), fmaxf(a[2] + bb.z, 0.f), fmaxf(a[3] + bb.w, 0.f));
+    }
+  };
+  relu_store(hbuf[0], w.Kp1 == 128 ? gemv_tile<T, 4, 4>(sin, (const T*)w.wf1, 128, wave, lane)
+                                   : gemv_tile<T, 2, 2>(sin, (const T*)w.wf1, 64, wave, lane), w.bf1);
+  __syncthreads();
+  relu_store(hbuf[1], gemv_tile<T, 8, 8>(hbuf[0], (const T*)w.wf2, 256, wave, lane), w.bf2);
+  __syncthreads();
+  const InfCnnHead& h = hd.n[net];
+  relu_store(hbuf[2], gemv_tile<T, 8, 8>(hbuf[1], (const T*)h.w0, 256, wave, lane), h.b0);
+  __syncthreads();
+  relu_store(hbuf[3], gemv_tile<T, 8, 8>(hbuf[2], (const T*)h.w1, 256, wave, lane), h.b1);
+  __syncthreads();
+  if (wave == 0) {
+    const f32x4 a = gemv_tile<T, 8, 8>(hbuf[3], (const T*)h.w2, 256, 0, lane);
+    if (fr == 0) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int c = qr + r;
+        const float v = c < h.nout ? a[r] + h.b2[c] : 0.f;
+        so[c] = v;
+        h.out[(int64_t)b * OUT_LD + c] = v;
+      }
+    }
+  }
+  __syncthreads();
+  if (tid == 0) {  // sampling / filing epilogue: see infer_layer_kernel
+    const int i = b, A = fin.A;
+    if (net == 0) {
+      float e = 0.f, lp = 0.f;
+      for (int a = 0; a < A; ++a) {
+        const float mu = so[a];
+        const float ls = fminf(fmaxf(fin.logstd[a], LOG_SIG_MIN), LOG_SIG_MAX);
+        const float sg = expf(ls);
+        e += 0.5f + HALF_LOG_2PI + logf(sg);
+        const float act = fmaf(sg, fin.eps[(int64_t)i * A + a], mu);
+        fin.action[(int64_t)i * A + a] = act;
+        fin.mean[(int64_t)i * A + a] = mu;
+        fin.stdv[(int64_t)i * A + a] = sg;
+        if (fin.acts_roll != nullptr) fin.acts_roll[(t_step * E + i) * A + a] = act;
+        const float d = act - mu;
+        lp += -(d * d) / (2.f * sg * sg) - logf(sg) - HALF_LOG_2PI;
+      }
+      fin.ent[i] = e;
+      if (fin.logp_roll != nullptr) fin.logp_roll[t_step * E + i] = lp;
+    } else {
+      const float v = so[0];
+      fin.value[i] = v;
+      if (fin.values_roll != nullptr) fin.values_roll[t_step * E + i] = v;
+    }
+    __threadfence();
+    const unsigned long long done = atomicAdd(reinterpret_cast<unsigned long long*>(&fin.ctl->done), 1ull);
+    if (done == (unsigned long long)(gridDim.x * gridDim.y) - 1) {
+      fin.ctl->done = 0;
+      fin.ctl->t = t_step + 1;
+    }
+  }
+}
+
 }  // namespace v4l

@@ -1315,6 +1315,51 @@ static int run_actor_fused_cnn(v4l_actor* a, const float* obs, const float* eps,
   return 0;
 }
 
+// state-only MLP nets of the shipped shape: one launch per env step (rollout_mlp_kernel)
+static bool actor_fusable_mlp(const v4l_actor* a) {
+  const v4l_net_cfg &p = a->pf->cfg, &v = a->vf->cfg;
+  auto ok = [](const v4l_net_cfg& c) {
+    return c.kind == V4L_NET_MLP && c.n_enc_hidden == 2 && c.enc_hidden[0] == 256 && c.enc_hidden[1] == 256 &&
+           c.n_head_hidden == 2 && c.head_hidden[0] == 256 && c.head_hidden[1] == 256 && c.state_dim <= 128;
+  };
+  return ok(p) && ok(v) && getenv("V4L_NO_FUSED_ACTOR") == nullptr;
+}
+template <typename T>
+static int run_actor_fused_mlp(v4l_actor* a, const float* obs, const float* eps, float* state_roll, float* acts_roll,
+                               float* values_roll, float* logp_roll, float* action, float* mean, float* stdv, float* ent,
+                               float* value, hipStream_t s) {
+  v4l_net *pf = a->pf, *vf = a->vf;
+  const int E = a->E;
+  const T* pk = (const T*)pf->packed;
+  const T* vk = (const T*)vf->packed;
+  const Layout Lp = pf->layout(E), Lv = vf->layout(E);
+  float* ws_pf = a->ws;
+  float* ws_vf = a->ws + Lp.total;
+  PhaseScope ps("rollout");
+  InfMlp en;
+  en.wf1 = pk + pf->enc[0].pk; en.wf2 = pk + pf->enc[1].pk;
+  en.bf1 = pf->p[pf->enc[0].b]; en.bf2 = pf->p[pf->enc[1].b];
+  en.S = pf->cfg.state_dim; en.Sp = pf->Sp; en.Kp1 = pf->enc[0].Kp;
+  InfCnnHeadPair hd;
+  auto head = [&](InfCnnHead& h, v4l_net* net, const T* base, float* out) {
+    h.w0 = base + net->head[0].pk; h.w1 = base + net->head[1].pk; h.w2 = base + net->head[2].pk;
+    h.b0 = net->p[net->head[0].b]; h.b1 = net->p[net->head[1].b]; h.b2 = net->p[net->head[2].b];
+    h.out = out; h.nout = net->cfg.out_dim;
+  };
+  head(hd.n[0], pf, pk, ws_pf + Lp.out);
+  head(hd.n[1], vf, vk, ws_vf + Lv.out);
+  InfFinish fin;
+  memset(&fin, 0, sizeof(fin));
+  fin.ctl = a->ctl; fin.logstd = pf->p[pf->logstd]; fin.eps = eps; fin.A = pf->cfg.out_dim;
+  fin.acts_roll = acts_roll; fin.values_roll = values_roll; fin.logp_roll = logp_roll; fin.action = action;
+  fin.mean = mean; fin.stdv = stdv; fin.ent = ent; fin.value = value;
+  g_op = "step";
+  V4L_KLAUNCH("rollout_mlp", 2.0 * 2 * E * (128.0 * 256 + 4 * 256 * 256), s, rollout_mlp_kernel<T>, dim3(E, 2), dim3(1024), 0, s,
+              (const ActCtl*)a->ctl, obs, E, en, hd, fin, state_roll);
+  V4L_LAUNCH_CHECK();
+  return 0;
+}
+
 template <typename T>
 static int run_actor_fused(v4l_actor* a, const float* obs, const float* eps, float* state_roll, void* image_roll,
                            float* acts_roll, float* values_roll, float* logp_roll, float* action, float* mean, float* stdv,
@@ -1731,6 +1776,12 @@ static int run_actor_step(v4l_actor* a, const float* obs, const float* eps, floa
   const int E = a->E;
   int rc;
   V4L_REQUIRE(pf->bound && vf->bound, "v4l_actor_step: nets are not bound");
+  if (shared_encoder && actor_fusable_mlp(a) && pf->enc[0].Kp <= 128) {
+    if (pf->cfg.compute == V4L_BF16)
+      return run_actor_fused_mlp<__bf16>(a, obs, eps, state_roll, acts_roll, values_roll, logp_roll, action, mean, stdv, ent,
+                                         value, s);
+    return run_actor_fused_mlp<float>(a, obs, eps, state_roll, acts_roll, values_roll, logp_roll, action, mean, stdv, ent, value, s);
+  }
   if (shared_encoder && actor_fusable_cnn(a) && pf->enc[0].Kp <= 128) {
     if (pf->cfg.compute == V4L_BF16)
       return run_actor_fused_cnn<__bf16>(a, obs, eps, state_roll, image_roll, acts_roll, values_roll, logp_roll, action, mean,
