@@ -571,3 +571,35 @@ def test_dp_phase_sequence_on_one_rank(mode, tmp_path):
     assert np.allclose(sa[:, :18], sb[:, :18], rtol=tol, atol=tol / 10), np.abs(sa[:, :18] - sb[:, :18]).max()
     drift = sum((pa[k] - pb[k]).abs().sum().item() for k in pa) / sum(v.numel() for v in pa.values())
     assert drift <= (2e-7 if mode == "f32" else 2e-5), drift
+
+
+@pytest.mark.parametrize("n", [1, 30])
+def test_fused_kernels_on_ragged_batches(n, device):
+    """Shipped LocoTransformer shape (fused encoder / layer / head / conv-backward kernels) on batch sizes that do not
+    fill the last block (4 samples per layer block, 2 in the forward, 256 persistent conv-backward blocks): outputs and
+    every parameter gradient vs the fp32 oracle."""
+    mode = "f32"
+    case = dict(util.CASES["loco_s84"], B=n)
+    pf, vf = _build(case, mode, device)
+    b = util.make_batch(case)
+    obs = torch.tensor(b["obs"], dtype=torch.float32)
+    opf, ovf = _oracle_params(pf, vf, "loco")
+    rs = np.random.RandomState(3)
+    w = torch.tensor(rs.randn(n, 1), dtype=torch.float32)
+    hip = vf.hip
+    st, im, _ = hip.stage(obs.to(device))
+    out = hip.forward(st, im, n, train=True)
+    dout = torch.zeros(n, 16, dtype=torch.float32, device=device)
+    dout[:, :1] = w.to(device)
+    grads = torch.full((hip.total_params,), float("nan"), dtype=torch.float32, device=device)
+    hip.backward(st, im, n, dout, grads)
+    assert not torch.isnan(grads).any()
+    keys = list(ovf)
+    for k in keys:
+        ovf[k].requires_grad_(True)
+    ref_out = orc.FORWARDS["loco"](ovf, obs, case["S"], mode)
+    ref = torch.autograd.grad((ref_out * w).sum(), [ovf[k] for k in keys])
+    assert util.rel_err(out[:, :1].cpu(), ref_out.detach()) < TOL[mode]
+    for k, g in zip(keys, ref):
+        e = util.rel_err(hip.grad_view(grads, k).cpu(), g)
+        assert e < TOL[mode], (k, e)
