@@ -400,7 +400,7 @@ def main():
     }
     if rank == 0:
         res["roofline"] = roofline(ep, a.compute, a.breakdown)
-        if not a.no_cpu_baseline:
+        if not a.no_cpu_baseline and world == 1:  # the host baseline is an N = 1 measurement (the other ranks would idle)
             res["cpu_baseline"] = cpu_baseline(wl, a.compute)
             res["vs_cpu_baseline"] = round(value / world / res["cpu_baseline"]["value"], 1)
     elif dist_on:
