@@ -603,3 +603,52 @@ def test_fused_kernels_on_ragged_batches(n, device):
     for k, g in zip(keys, ref):
         e = util.rel_err(hip.grad_view(grads, k).cpu(), g)
         assert e < TOL[mode], (k, e)
+
+
+@pytest.mark.parametrize("mode", MODES)
+def test_epoch_device_buffer_equals_host_buffer(mode, device):
+    """PPO.update_per_epoch() end to end (last value, GAE, LR schedule, target sync, opt_epochs x minibatches, the 18 logger
+    infos): DeviceOnPolicyReplayBuffer (observations ingested into HBM as they arrive, row-index minibatches, all updates
+    as graph replays) vs OnPolicyReplayBuffer (the reference's host float64 arrays, one uploaded minibatch per update)."""
+    from vision4leg_amd.torchrl.algo import PPO
+    from vision4leg_amd.torchrl.replay_buffers import DeviceOnPolicyReplayBuffer, OnPolicyReplayBuffer
+    case = dict(util.CASES["loco_s84"])
+    T, E, B, A = 8, 4, 16, case["A"]
+    D = util.obs_dim(case)
+    rs = np.random.RandomState(31)
+    steps = []
+    for t in range(T):
+        steps.append({
+            "obs": np.concatenate([np.clip(rs.randn(E, case["S"]), -10, 10), np.clip(rs.randn(E, D - case["S"]), -2.5, 2.8)], 1),
+            "next_obs": np.concatenate([np.clip(rs.randn(E, case["S"]), -10, 10), np.clip(rs.randn(E, D - case["S"]), -2.5, 2.8)], 1),
+            "acts": 0.3 * rs.randn(E, A), "values": rs.randn(E, 1), "rewards": rs.randn(E, 1),
+            "terminals": (rs.rand(E, 1) < 0.2).astype(np.float64), "time_limits": (rs.rand(E, 1) < 0.1).astype(np.float64),
+        })
+
+    class Log:
+        def __init__(self): self.infos = []
+        def add_update_info(self, info): self.infos.append(dict(info))
+
+    class Coll: epoch_frames = T * E
+    results = []
+    for Buf in (DeviceOnPolicyReplayBuffer, OnPolicyReplayBuffer):
+        pf, vf = _build(case, mode, device)
+        buf = Buf(max_replay_buffer_size=T * E, env_nums=E, time_limit_filter=True)
+        log = Log()
+        agent = PPO(pf=pf, vf=vf, plr=1e-4, vlr=1e-4, clip_para=0.2, opt_epochs=2, tau=0.95, entropy_coeff=0.005, shuffle=True,
+                    collector=Coll(), replay_buffer=buf, logger=log, device=device, discount=0.99, num_epochs=100, batch_size=B)
+        agent.current_epoch = 3
+        for st in steps:
+            buf.add_sample({k: np.array(v, copy=True) for k, v in st.items()})
+        np.random.seed(5)  # minibatch permutations
+        agent.update_per_epoch()
+        torch.cuda.synchronize()
+        results.append((log.infos, {k: v.detach().cpu().clone() for k, v in pf.state_dict().items()}))
+    (ia, pa), (ib, pb) = results
+    assert len(ia) == len(ib) == 2 * (T * E // B)
+    tol = 2e-4 if mode == "f32" else 1e-2
+    for u, (x, y) in enumerate(zip(ia, ib)):
+        for k in util.STAT_KEYS:
+            assert abs(x[k] - y[k]) <= tol * max(1.0, abs(y[k])), (u, k, x[k], y[k])
+    drift = sum((pa[k] - pb[k]).abs().sum().item() for k in pa) / sum(v.numel() for v in pa.values())
+    assert drift <= (2e-7 if mode == "f32" else 2e-5), drift
