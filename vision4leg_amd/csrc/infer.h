@@ -116,21 +116,6 @@ template <int MT, int NTW> __device__ __forceinline__ void zero_acc(f32x4 (&acc)
     for (int j = 0; j < NTW; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 }
 
-// A by-value copy of a kernel-argument sub-struct selected with a RUNTIME index (net = blockIdx.y, layer l), forced into
-// scalar registers. Without it every use of `args.n[blockIdx.y].ptr` is a vector load from the kernarg segment followed
-// by s_waitcnt: one extra dependent memory round trip in front of every GEMM phase (measured: ~1 us per phase at one block
-// per CU). With it the whole descriptor is fetched once.
-template <typename S>
-__device__ __forceinline__ S uniform_copy(const S& src) {
-  static_assert(sizeof(S) % 4 == 0, "uniform_copy: struct size");
-  S dst;
-  const int* sp = reinterpret_cast<const int*>(&src);
-  int* dp = reinterpret_cast<int*>(&dst);
-#pragma unroll
-  for (int i = 0; i < (int)(sizeof(S) / 4); ++i) dp[i] = __builtin_amdgcn_readfirstlane(sp[i]);
-  return dst;
-}
-
 // ------------------------------------------------------------------------------------------ encoder
 struct InfEnc {
   const void *w1, *w2, *w3, *wup;          // packed conv weights (T): [32][256] [64][512] [64][576] [64][64]
@@ -502,7 +487,7 @@ __global__ __launch_bounds__(256) void infer_layer_kernel(InfLayerPair pr, InfHe
   constexpr int ROWS = InfRows<SPW>::ROWS, MT = InfRows<SPW>::MT, U = InfRows<SPW>::U;
   INF_STAMP(0);
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  const InfLayer w = uniform_copy(pr.n[blockIdx.y]);
+  const InfLayer& w = pr.n[blockIdx.y];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int fr = lane & 15, qr = (lane >> 4) * 4;
   float* xs = reinterpret_cast<float*>(smem);
@@ -653,7 +638,7 @@ __global__ __launch_bounds__(256) void infer_layer_kernel(InfLayerPair pr, InfHe
   INF_STAMP(8);
   if constexpr (HEAD) {
     // ---- heads on this block's samples: [state token | mean of the 16 depth tokens] -> 256 -> 256 -> nout
-    const InfHead h = uniform_copy(hd.n[blockIdx.y]);
+    const InfHead& h = hd.n[blockIdx.y];
     float* pooled = big;                                              // [16][LDP] fp32 (rows >= ns: zeros)
     T* h1 = reinterpret_cast<T*>(big + 16 * LY::LDP);                 // [16][LDF]
     T* h2 = h1 + 16 * LY::LDF;
@@ -781,8 +766,7 @@ __global__ __launch_bounds__(1024) void rollout_layer_kernel(InfLayerStack stk, 
   if (tid < ROWS * (TD / 4)) {
     const int r = tid >> 4, c4 = (tid & 15) * 4;
     const bool ok = r < NTOK;
-    const float* xin0 = stk.l[0].n[blockIdx.y].xin;
-    const float4 v = *reinterpret_cast<const float4*>(xin0 + (row0 + (ok ? r : 0)) * TD + c4);
+    const float4 v = *reinterpret_cast<const float4*>(stk.l[0].n[blockIdx.y].xin + (row0 + (ok ? r : 0)) * TD + c4);
     *reinterpret_cast<float4*>(xs + r * LY::LDX + c4) = ok ? v : float4{0.f, 0.f, 0.f, 0.f};
   }
   __syncthreads();
@@ -806,7 +790,7 @@ __global__ __launch_bounds__(1024) void rollout_layer_kernel(InfLayerStack stk, 
   };
 #pragma unroll 1
   for (int l = 0; l < stk.nl; ++l) {  // the token rows stay in `xs` from one layer to the next
-  const InfLayer w = uniform_copy(stk.l[l].n[blockIdx.y]);
+  const InfLayer& w = stk.l[l].n[blockIdx.y];
   if (l > 0) __syncthreads();
   if (wave < 12) {  // in_proj: 12 column tiles, one per wave
     const int nt[1] = {wave};
@@ -892,7 +876,7 @@ __global__ __launch_bounds__(1024) void rollout_layer_kernel(InfLayerStack stk, 
   ln2rows(cx, xs, w.g2, w.be2, w.xout);  // -> xs (next layer / heads) and the net's token tensor
   }
   if constexpr (HEAD) {
-    const InfHead h = uniform_copy(hd.n[blockIdx.y]);
+    const InfHead& h = hd.n[blockIdx.y];
     float* pooled = big;                                              // [16][LDP] fp32, row 0 = this sample
     T* h1 = reinterpret_cast<T*>(big + 16 * LY::LDP);                 // [16][LDF]
     T* h2 = h1 + 16 * LY::LDF;
@@ -1390,7 +1374,7 @@ __global__ __launch_bounds__(1024) void rollout_cnn_kernel(const ActCtl* __restr
     }
   }
   __syncthreads();
-  const InfCnnHead h = uniform_copy(hd.n[net]);
+  const InfCnnHead& h = hd.n[net];
   {
     const f32x4 a = gemv_tile<T, 16, 8>(cat, (const T*)h.w0, 512, wave, lane);
     if (fr == 0) {
@@ -1489,7 +1473,7 @@ __global__ __launch_bounds__(1024) void rollout_mlp_kernel(const ActCtl* __restr
   __syncthreads();
   relu_store(hbuf[1], gemv_tile<T, 8, 8>(hbuf[0], (const T*)w.wf2, 256, wave, lane), w.bf2);
   __syncthreads();
-  const InfCnnHead h = uniform_copy(hd.n[net]);
+  const InfCnnHead& h = hd.n[net];
   relu_store(hbuf[2], gemv_tile<T, 8, 8>(hbuf[1], (const T*)h.w0, 256, wave, lane), h.b0);
   __syncthreads();
   relu_store(hbuf[3], gemv_tile<T, 8, 8>(hbuf[2], (const T*)h.w1, 256, wave, lane), h.b1);
