@@ -741,15 +741,17 @@ __global__ __launch_bounds__(256) void infer_layer_kernel(InfLayerPair pr, InfHe
 }
 
 
-// ------------------------------------------------------------------------------------------ rollout layer (16 waves)
+// ------------------------------------------------------------------------------------------ rollout layer (8 / 16 waves)
 // The same TransformerEncoderLayer (+ heads + sampling epilogue when HEAD) for ONE sample per block, spread over 16
 // waves: a rollout step runs only 2E blocks, one per CU, so its time is the latency of one block — every phase is cut
 // into as many independent jobs as it has (12 + 8 + 16 + 8 MFMA tiles, 17 score rows, 32 norm rows) instead of four.
 // Same arithmetic, operand rounding and k order as infer_layer_kernel<T, 1, HEAD>.
 constexpr int ROLLOUT_MAX_LAYERS = 4;
 struct InfLayerStack { InfLayerPair l[ROLLOUT_MAX_LAYERS]; int nl; };  // all layers of both nets: ONE launch per env step
-template <typename T, bool HEAD>
-__global__ __launch_bounds__(1024) void rollout_layer_kernel(InfLayerStack stk, InfHeadPair hd, InfFinish fin, int E) {
+template <typename T, bool HEAD, int NW>
+__global__ __launch_bounds__(NW * 64) void rollout_layer_kernel(InfLayerStack stk, InfHeadPair hd, InfFinish fin, int E) {
+  static_assert(NW == 8 || NW == 16, "rollout_layer_kernel: 8 or 16 waves");
+  constexpr int NTH = NW * 64;
   typedef InfLayLds<T, 1> LY;
   constexpr int ROWS = 32;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -763,8 +765,8 @@ __global__ __launch_bounds__(1024) void rollout_layer_kernel(InfLayerStack stk, 
   const int64_t row0 = (int64_t)s0 * NTOK;
   long long t_step = 0;
   if constexpr (HEAD) { if (fin.ctl != nullptr) t_step = fin.ctl->t; }
-  if (tid < ROWS * (TD / 4)) {
-    const int r = tid >> 4, c4 = (tid & 15) * 4;
+  for (int i4 = tid; i4 < ROWS * (TD / 4); i4 += NTH) {
+    const int r = i4 >> 4, c4 = (i4 & 15) * 4;
     const bool ok = r < NTOK;
     const float4 v = *reinterpret_cast<const float4*>(stk.l[0].n[blockIdx.y].xin + (row0 + (ok ? r : 0)) * TD + c4);
     *reinterpret_cast<float4*>(xs + r * LY::LDX + c4) = ok ? v : float4{0.f, 0.f, 0.f, 0.f};
@@ -772,17 +774,18 @@ __global__ __launch_bounds__(1024) void rollout_layer_kernel(InfLayerStack stk, 
   __syncthreads();
   T* f = reinterpret_cast<T*>(big);
   auto ln2rows = [&](const float* z, float* out, const float* __restrict__ g, const float* __restrict__ be, float* gout) {
-    const float gg = g[lane], bb = be[lane];  // wave w: rows w and w + 16, both in flight
-    float v[2], mean[2], c[2], var[2];
+    const float gg = g[lane], bb = be[lane];  // wave w: rows w, w + NW, ...: all in flight
+    constexpr int U = ROWS / NW;
+    float v[U], mean[U], c[U], var[U];
 #pragma unroll
-    for (int u = 0; u < 2; ++u) v[u] = z[(wave + 16 * u) * LY::LDX + lane];
+    for (int u = 0; u < U; ++u) v[u] = z[(wave + NW * u) * LY::LDX + lane];
 #pragma unroll
-    for (int u = 0; u < 2; ++u) mean[u] = wave_sum(v[u]) * (1.f / TD);
+    for (int u = 0; u < U; ++u) mean[u] = wave_sum(v[u]) * (1.f / TD);
 #pragma unroll
-    for (int u = 0; u < 2; ++u) { c[u] = v[u] - mean[u]; var[u] = wave_sum(c[u] * c[u]) * (1.f / TD); }
+    for (int u = 0; u < U; ++u) { c[u] = v[u] - mean[u]; var[u] = wave_sum(c[u] * c[u]) * (1.f / TD); }
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
-      const int r = wave + 16 * u;
+    for (int u = 0; u < U; ++u) {
+      const int r = wave + NW * u;
       const float o = fmaf(c[u] * (1.f / sqrtf(var[u] + 1e-5f)), gg, bb);
       if (out != nullptr) out[r * LY::LDX + lane] = o;
       if (gout != nullptr && r < NTOK) gout[(row0 + r) * TD + lane] = o;
@@ -792,12 +795,12 @@ __global__ __launch_bounds__(1024) void rollout_layer_kernel(InfLayerStack stk, 
   for (int l = 0; l < stk.nl; ++l) {  // the token rows stay in `xs` from one layer to the next
   const InfLayer& w = stk.l[l].n[blockIdx.y];
   if (l > 0) __syncthreads();
-  if (wave < 12) {  // in_proj: 12 column tiles, one per wave
-    const int nt[1] = {wave};
+  for (int t = wave; t < 12; t += NW) {  // in_proj: 12 column tiles over the waves
+    const int nt[1] = {t};
     f32x4 acc[2][1];
     zero_acc(acc);
     block_gemm<T, 2, 1, 2>(acc, xs, LY::LDX, (const T*)w.win, 64, nt, lane);
-    const int n4 = wave * 16 + qr;
+    const int n4 = t * 16 + qr;
     const float4 bb = *reinterpret_cast<const float4*>(w.bin + n4);
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt)
@@ -805,7 +808,7 @@ __global__ __launch_bounds__(1024) void rollout_layer_kernel(InfLayerStack stk, 
           acc[mt][0][3] + bb.w);
   }
   __syncthreads();
-  if (tid < NTOK * NTOK) {  // scores, one (i, j) per thread
+  if (tid < NTOK * NTOK) {  // scores, one (i, j) per thread (NTH >= 289)
     const int i = tid / NTOK, j = tid - i * NTOK;
     sp[i * ATT_PLD + j] = dot64(big + i * LY::LDQ, big + j * LY::LDQ + TD) * 0.125f;
   }
@@ -823,7 +826,7 @@ __global__ __launch_bounds__(1024) void rollout_layer_kernel(InfLayerStack stk, 
     for (int j = 0; j < NTOK; ++j) p[j] = e[j] * inv;
   }
   __syncthreads();
-  for (int r = wave; r < ROWS; r += 16) {  // ctx row r = P[r] V; rows >= 17: zeros
+  for (int r = wave; r < ROWS; r += NW) {  // ctx row r = P[r] V; rows >= 17: zeros
     float a = 0.f;
     if (r < NTOK) {
       const float* v = big + 2 * TD + lane;
@@ -848,12 +851,12 @@ __global__ __launch_bounds__(1024) void rollout_layer_kernel(InfLayerStack stk, 
   __syncthreads();
   ln2rows(big, xs, w.g1, w.be1, nullptr);  // x1 -> xs
   __syncthreads();
-  {  // linear1 + ReLU -> f (T): 16 column tiles, one per wave
-    const int nt[1] = {wave};
+  for (int t = wave; t < 16; t += NW) {  // linear1 + ReLU -> f (T): 16 column tiles over the waves
+    const int nt[1] = {t};
     f32x4 acc[2][1];
     zero_acc(acc);
     block_gemm<T, 2, 1, 2>(acc, xs, LY::LDX, (const T*)w.w1, 64, nt, lane);
-    const int n4 = wave * 16 + qr;
+    const int n4 = t * 16 + qr;
     const float4 bb = *reinterpret_cast<const float4*>(w.b1 + n4);
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt)
@@ -882,7 +885,7 @@ __global__ __launch_bounds__(1024) void rollout_layer_kernel(InfLayerStack stk, 
     T* h2 = h1 + 16 * LY::LDF;
     float* so = reinterpret_cast<float*>(h2 + 16 * LY::LDF);          // [16][16]
     __syncthreads();
-    for (int idx = tid; idx < 16 * 128; idx += 1024) {
+    for (int idx = tid; idx < 16 * 128; idx += NTH) {
       const int r = idx >> 7, c = idx & 127;
       float v = 0.f;
       if (r == 0) {
@@ -897,21 +900,26 @@ __global__ __launch_bounds__(1024) void rollout_layer_kernel(InfLayerStack stk, 
       pooled[r * LY::LDP + c] = v;
     }
     __syncthreads();
-    const int nt[1] = {wave};
     f32x4 acc[1][1];
-    auto store_h = [&](T* dst, const float* bias) {
-      const int n4 = wave * 16 + qr;
+    auto store_h = [&](T* dst, const float* bias, int t) {
+      const int n4 = t * 16 + qr;
       const float4 bb = *reinterpret_cast<const float4*>(bias + n4);
       st4(dst + fr * LY::LDF + n4, fmaxf(acc[0][0][0] + bb.x, 0.f), fmaxf(acc[0][0][1] + bb.y, 0.f),
           fmaxf(acc[0][0][2] + bb.z, 0.f), fmaxf(acc[0][0][3] + bb.w, 0.f));
     };
-    zero_acc(acc);
-    block_gemm<T, 1, 1, 4>(acc, pooled, LY::LDP, (const T*)h.w0, 128, nt, lane);
-    store_h(h1, h.b0);
+    for (int t = wave; t < 16; t += NW) {
+      const int nt[1] = {t};
+      zero_acc(acc);
+      block_gemm<T, 1, 1, 4>(acc, pooled, LY::LDP, (const T*)h.w0, 128, nt, lane);
+      store_h(h1, h.b0, t);
+    }
     __syncthreads();
-    zero_acc(acc);
-    block_gemm<T, 1, 1, 8>(acc, h1, LY::LDF, (const T*)h.w1, 256, nt, lane);
-    store_h(h2, h.b1);
+    for (int t = wave; t < 16; t += NW) {
+      const int nt[1] = {t};
+      zero_acc(acc);
+      block_gemm<T, 1, 1, 8>(acc, h1, LY::LDF, (const T*)h.w1, 256, nt, lane);
+      store_h(h2, h.b1, t);
+    }
     __syncthreads();
     if (wave == 0) {
       const int nt0[1] = {0};

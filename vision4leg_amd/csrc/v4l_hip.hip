@@ -1376,7 +1376,9 @@ static int run_actor_fused(v4l_actor* a, const float* obs, const float* eps, flo
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)InfLayLds<T, 1>::bytes));
     V4L_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&rollout_encoder_kernel<T>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)InfEncLds<T>::bytes));
-    V4L_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&rollout_layer_kernel<T, true>),
+    V4L_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&rollout_layer_kernel<T, true, 16>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)InfLayLds<T, 1>::bytes));
+    V4L_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&rollout_layer_kernel<T, true, 8>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)InfLayLds<T, 1>::bytes));
     attr_done = true;
   }
@@ -1439,8 +1441,13 @@ static int run_actor_fused(v4l_actor* a, const float* obs, const float* eps, flo
       fill(stk.l[l].n[1], vf, vk, vf->layers[l], l == 0 ? x0 : ws_vf + Lv.x[l], ws_vf + Lv.x[l + 1]);
     }
     finish();
-    V4L_KLAUNCH("rollout_layers_head", 2.0 * 2 * E * (nl * 872576.0 + 99840.0), s, (rollout_layer_kernel<T, true>), dim3(E, 2),
-                dim3(1024), (InfLayLds<T, 1>::bytes), s, stk, hd, fin, E);
+    static const int nw = getenv("V4L_ROLLOUT_WAVES") ? atoi(getenv("V4L_ROLLOUT_WAVES")) : 8;
+    if (nw == 16)
+      V4L_KLAUNCH("rollout_layers_head", 2.0 * 2 * E * (nl * 872576.0 + 99840.0), s, (rollout_layer_kernel<T, true, 16>), dim3(E, 2),
+                  dim3(1024), (InfLayLds<T, 1>::bytes), s, stk, hd, fin, E);
+    else
+      V4L_KLAUNCH("rollout_layers_head", 2.0 * 2 * E * (nl * 872576.0 + 99840.0), s, (rollout_layer_kernel<T, true, 8>), dim3(E, 2),
+                  dim3(512), (InfLayLds<T, 1>::bytes), s, stk, hd, fin, E);
     V4L_LAUNCH_CHECK();
     return 0;
   }
