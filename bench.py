@@ -164,7 +164,8 @@ class Epoch:
 
 def cpu_baseline(wl, compute):
     """The CPU oracle (oracle/ppo_oracle.py, kind 'port': the restatement pinned against the reference) on a bounded
-    sample of the same workload: 2 minibatch updates, 8 inference step pairs, 1 GAE; extrapolated to one epoch."""
+    sample of the same workload (warm-up, then 16 minibatch updates + 64 inference step pairs +
+    1 GAE), extrapolated to one epoch. Threads: the best of 8/16/32/64 — torch's intra-op pool thrashes beyond that."""
     import util
     from oracle import ppo_oracle as orc
     import vision4leg_amd.torchrl.networks as networks
@@ -196,7 +197,7 @@ def cpu_baseline(wl, compute):
             break
     cores = best[0]
     torch.set_num_threads(cores)
-    n_upd = 2
+    n_upd = 16 if best[1] < 1.0 else 4  # ~4 s at 0.23 s per update; fewer on a slow host to stay inside ~30 s
     t0 = time.perf_counter()
     for _ in range(n_upd):
         oracle.update(*args)
@@ -206,7 +207,7 @@ def cpu_baseline(wl, compute):
     pp = {k: v for k, v in opf.items() if k != "logstd"}
     with torch.no_grad():
         fwd(pp, ob, wl["S"]); fwd(ovf, ob, wl["S"])
-        n_inf = 8
+        n_inf = 64
         t0 = time.perf_counter()
         for _ in range(n_inf):
             fwd(pp, ob, wl["S"]); fwd(ovf, ob, wl["S"])
