@@ -117,6 +117,21 @@ int v4l_gae(const double* rewards_dev, const double* values_dev, const double* t
             double tau, int use_time_limit, double* scratch_dev /* 3*T*E doubles */, double* advs_dev, double* rets_dev,
             float* advs32_dev, float* rets32_dev, void* stream);
 
+/* Running observation normaliser of the vectorised env on the device: what
+ * NormObsWithImg.observation (vision4leg/get_env.py:58-67) / NormObs.observation (torchrl/env/base_wrapper.py:119-122)
+ * do on the host per env step. raw_dev: the step's [E][S] fp64 proprio rows (row stride ld_raw). update != 0 (the
+ * wrapper's training mode): Normalizer.update_estimate (base_wrapper.py:77-84) merges the batch mean / variance over the
+ * E envs into mean_dev / var_dev [S] and count_dev [1] (update_mean_var_count, :44-61; a fresh Normalizer is mean 0,
+ * var 1, count 1e-4, :64-72). Then Normalizer.filt (:93-96): clip((raw - mean) / (sqrt(var) + 1e-4), -clip, clip), in
+ * fp64 and bit-identical to the numpy code, written as fp64 (out64_dev) and / or as the fp32 cast the collector makes
+ * (out32_dev); either may point into the [E][S + C*H*W] observation rows v4l_actor_step reads (row stride ld_out*).
+ * image_dev (optional): the step's [E][image_elems] depth stack, fp32 or fp64 (image_f64), copied / cast into
+ * image_out_dev — the np.hstack of get_env.py:64-67 without the host pass. */
+int v4l_obs_norm(const double* raw_dev, int64_t ld_raw, int E, int S, double* mean_dev, double* var_dev, double* count_dev,
+                 double clip, int update, float* out32_dev, int64_t ld_out32, double* out64_dev, int64_t ld_out64,
+                 const void* image_dev, int image_f64, int64_t ld_image, int64_t image_elems, float* image_out_dev,
+                 int64_t ld_image_out, void* stream);
+
 /* ---- rollout step: what VecOnPolicyCollector.take_actions asks of the networks per env step
  * (torchrl/collector/on_policy.py:90-100): out = pf.explore(ob) and values = vf(ob) for the E observation rows of the
  * step — as ONE captured launch sequence: ingest of the rows into rollout slots [t*E,(t+1)*E), the policy forward, the

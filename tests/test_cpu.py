@@ -80,6 +80,23 @@ def test_gae_oracles_match_reference_golden(name):
     assert np.array_equal(ca, oa.reshape(T, E)) and np.array_equal(cr, orr.reshape(T, E))
 
 
+@pytest.mark.parametrize("name", list(util.OBSNORM_CASES))
+def test_obsnorm_oracle_matches_reference_golden(name):
+    """oracle/obsnorm_ref.c reproduces the reference Normalizer / NormObs outputs (tests/golden/obsnorm.npz, minted by
+    tests/golden/make_golden_obsnorm.py from /root/reference) bit for bit, statistics included."""
+    from oracle.obsnorm_c import NormalizerOracle
+    case = util.OBSNORM_CASES[name]
+    raws, training = util.obsnorm_inputs(case)
+    gold = util.load_golden("obsnorm")
+    o = NormalizerOracle(case["S"])
+    for k, raw in enumerate(raws):
+        assert np.array_equal(o.observation(raw, training[k]), gold["%s/y%d" % (name, k)])
+    assert np.array_equal(o.mean, gold[name + "/mean"]) and np.array_equal(o.var, gold[name + "/var"])
+    assert o.count[0] == gold[name + "/count"][0]
+    if case["S"] == 5:  # the wild case really exercises the clip
+        assert gold["%s/y%d" % (name, len(raws) - 1)][0, 0] == 10.0 and gold["%s/y%d" % (name, len(raws) - 1)][1, 0] == -10.0
+
+
 def test_library_exports_every_declared_symbol():
     """include/v4l_hip.h is the contract: every declared entry point must be exported by the built library and
     bound by the ctypes layer (no compute calls here: there is no GPU)."""

@@ -306,6 +306,72 @@ def test_gae_full_size_properties(device):
         assert a.cpu().numpy()[t0, e0] == expect
 
 
+@pytest.mark.parametrize("name", list(util.OBSNORM_CASES))
+def test_obs_normaliser_bit_exact(name, device):
+    """v4l_obs_norm == the reference's NormObs.observation (golden from /root/reference) bit for bit: filtered rows as
+    fp64 and as the collector's fp32 cast, running mean / var / count, training and eval steps."""
+    from vision4leg_amd.torchrl.env import NormObs
+    case = util.OBSNORM_CASES[name]
+    raws, training = util.obsnorm_inputs(case)
+    gold = util.load_golden("obsnorm")
+    env = NormObs(case["S"], device=device)
+    nz = env._obs_normalizer
+    for k, raw in enumerate(raws):
+        env.training = training[k]
+        r = torch.from_numpy(raw).to(device)
+        y32 = env.observation(r)
+        want = gold["%s/y%d" % (name, k)]
+        assert y32.dtype == torch.float32 and np.array_equal(y32.cpu().numpy(), want.astype(np.float32))
+        assert np.array_equal(nz.filt(r).cpu().numpy(), want)  # fp64, statistics untouched by filt
+    assert np.array_equal(nz._mean, gold[name + "/mean"]) and np.array_equal(nz._var, gold[name + "/var"])
+    assert nz._count == gold[name + "/count"][0]
+
+
+def test_obs_normaliser_rows_images_and_pickle(device):
+    """NormObsWithImg at the BASELINE geometry (E=32, S=93, 4x64x64 depth): strided raw rows, fp32 and fp64 depth
+    stacks land in the [E][S+16384] observation rows next to the normalised proprio block; the statistics survive the
+    pickle round trip through a reference-shaped Normalizer; results equal the C oracle."""
+    import pickle
+    from oracle.obsnorm_c import NormalizerOracle
+    from vision4leg_amd.torchrl.env import NormObsWithImg, Normalizer
+    E, S, IMG = 32, 93, 4 * 64 * 64
+    rs = np.random.RandomState(5)
+    env = NormObsWithImg(S, IMG, E, device=device)
+    o = NormalizerOracle(S)
+    for k in range(3):
+        wide = rs.randn(E, S + 7) * 2.0 + 1.0  # raw rows embedded in a wider array: row stride != S
+        img = rs.randn(E, 4, 64, 64)
+        rw = torch.from_numpy(wide).to(device)[:, :S]
+        im = torch.from_numpy(img).to(device) if k % 2 else torch.from_numpy(img.astype(np.float32)).to(device)
+        rows = env.observation(rw, im)
+        want = o.observation(wide[:, :S], True)
+        got = rows.cpu().numpy()
+        assert rows.shape == (E, S + IMG) and rows.data_ptr() == env.rows.data_ptr()
+        assert np.array_equal(got[:, :S], want.astype(np.float32))
+        assert np.array_equal(got[:, S:], img.reshape(E, -1).astype(np.float32))
+    nz = env._obs_normalizer
+    assert np.array_equal(nz._mean, o.mean) and np.array_equal(nz._var, o.var) and nz._count == o.count[0]
+
+    class RefShaped:  # the attribute protocol of torchrl/env/base_wrapper.py:64-72
+        def __init__(self, shape, clip=10.):
+            self.shape, self.clip, self.should_estimate = shape, clip, True
+            self._mean, self._var, self._count = np.zeros(shape), np.ones(shape), 1e-4
+
+    ref = nz.to_reference(RefShaped)
+    back = Normalizer.from_reference(ref, device=device)
+    again = pickle.loads(pickle.dumps(nz))
+    x = torch.from_numpy(rs.randn(E, S)).to(device)
+    want = nz.filt(x).cpu().numpy()
+    assert np.array_equal(back.filt(x).cpu().numpy(), want) and np.array_equal(again.filt(x).cpu().numpy(), want)
+    # eval mode freezes the statistics
+    env.eval()
+    before = (nz._mean.copy(), nz._count)
+    env.observation(x, torch.zeros(E, IMG, device=device))
+    assert np.array_equal(nz._mean, before[0]) and nz._count == before[1]
+    with pytest.raises(RuntimeError):
+        nz.filt(x.float())
+
+
 @pytest.mark.parametrize("pair", ["eager-graph", "eager-eager"])
 @pytest.mark.parametrize("mode", MODES)
 def test_graph_replay_equals_eager(mode, pair, device):

@@ -38,6 +38,30 @@ GAE_CASES = {
 }
 
 
+# running observation normaliser: K vec-env steps of [E][S] raw proprio rows; `eval_from`: the
+# step from which the wrapper is in eval mode (statistics frozen, base_wrapper.py:119-122)
+OBSNORM_CASES = {
+    "e32_s93": dict(E=32, S=93, K=6, seed=20, eval_from=5),
+    "e16_s84": dict(E=16, S=84, K=5, seed=21, eval_from=99),
+    "e1_s93": dict(E=1, S=93, K=4, seed=22, eval_from=3),    # ppo_state: one env, batch variance 0
+    "e7_s5_wild": dict(E=7, S=5, K=4, seed=23, eval_from=3, scale=1e3),  # outliers in an eval step: the clip at +-10 is hit
+}
+
+
+def obsnorm_inputs(case):
+    """-> (list of K float64 [E][S] raw batches, list of K training flags). Per-dimension offsets and scales, like
+    joint angles vs velocities vs foot contacts in the real observation."""
+    rs = np.random.RandomState(case["seed"])
+    E, S, K = case["E"], case["S"], case["K"]
+    sc = case.get("scale", 1.0)
+    off, amp = rs.randn(S) * 3.0 * sc, np.exp(rs.randn(S)) * sc
+    raws = [off + amp * rs.randn(E, S) for _ in range(K)]
+    if sc > 1:
+        raws[-1][0, 0] = 1e9  # clipped to +10
+        raws[-1][1, 0] = -1e9
+    return raws, [k < case["eval_from"] for k in range(K)]
+
+
 def obs_dim(case):
     return case["S"] + (0 if case["kind"] == "mlp" else 4 * 64 * 64)
 

@@ -92,6 +92,8 @@ _SIGS = {
   "v4l_col0": (C.c_int, [_P, C.c_int, _P, _P]),
   "v4l_gae": (C.c_int, [_P, _P, _P, _P, C.c_int, _P, C.c_int, C.c_int, C.c_double, C.c_double, C.c_int,
                         _P, _P, _P, _P, _P, _P]),
+  "v4l_obs_norm": (C.c_int, [_P, C.c_int64, C.c_int, C.c_int, _P, _P, _P, C.c_double, C.c_int, _P, C.c_int64, _P, C.c_int64,
+                             _P, C.c_int, C.c_int64, C.c_int64, _P, C.c_int64, _P]),
   "v4l_actor_create": (C.c_int, [_P, _P, C.c_int, C.POINTER(_P)]),
   "v4l_actor_destroy": (None, [_P]),
   "v4l_actor_ws_floats": (C.c_int64, [_P]),

@@ -732,4 +732,81 @@ __global__ void gae_scan_kernel(const double* __restrict__ delta, const double* 
   }
 }
 
+// Running observation normaliser of the vectorised env: NormObsWithImg.observation (vision4leg/get_env.py:58-67) /
+// NormObs.observation (torchrl/env/base_wrapper.py:119-122) on the [E][S] proprio block of one env step —
+// Normalizer.update_estimate (base_wrapper.py:77-84: merge the batch mean / variance over the E envs into the running
+// statistics with update_mean_var_count, :44-61) when `update`, then Normalizer.filt (:93-96) with the new statistics.
+// fp64, the numpy expression order (axis-0 reductions run row after row), FMA contraction off: bit-identical to the
+// reference; out32 is the fp32 cast the collector's torch.Tensor(ob) makes (collector/on_policy.py:93). Block 0 owns
+// the statistics (one lane per proprio dimension: its E raw values are one coalesced column walk, nothing is shared
+// between lanes but the count); blocks 1.. move the step's depth stack into the same fp32 observation rows (the
+// reference's per-step np.hstack of a 16 K-float image row), converting from fp64 when the env hands that over.
+struct ObsNorm {
+  const double* raw; int64_t ld_raw;       // [E][S] raw proprio rows
+  double *mean, *var, *count;              // [S], [S], [1] running statistics (updated in place)
+  double clip; int E, S, update;
+  float* out32; int64_t ld32;              // normalised rows as fp32 (nullable)
+  double* out64; int64_t ld64;             // ... and as fp64 (nullable)
+  const void* img; int img_f64; int64_t ld_img, img_elems;  // [E][img_elems] fp32 / fp64 depth stack (nullable)
+  float* img_out; int64_t ld_img_out;
+};
+
+__global__ __launch_bounds__(256) void obs_norm_kernel(ObsNorm p) {
+#pragma clang fp contract(off)
+  if (blockIdx.x != 0) {
+    const int64_t n = (int64_t)p.E * p.img_elems, step = (int64_t)(gridDim.x - 1) * 256;
+    for (int64_t i = (int64_t)(blockIdx.x - 1) * 256 + threadIdx.x; i < n; i += step) {
+      const int64_t e = i / p.img_elems, c = i - e * p.img_elems;
+      const float v = p.img_f64 ? (float)((const double*)p.img)[e * p.ld_img + c] : ((const float*)p.img)[e * p.ld_img + c];
+      p.img_out[e * p.ld_img_out + c] = v;
+    }
+    return;
+  }
+  const double cnt = *p.count, bc = (double)p.E;
+  __syncthreads();  // every lane holds the old count before lane 0 replaces it
+  for (int d = threadIdx.x; d < p.S; d += 256) {
+    const double* col = p.raw + d;
+    double m = p.mean[d], v = p.var[d];
+    // the column's E values, 8 loads in flight at a time (the adds below are sequential by contract, the loads are not)
+    auto walk = [&](auto&& f) {
+      for (int e0 = 0; e0 < p.E; e0 += 8) {
+        double c[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) c[j] = col[(int64_t)(e0 + j < p.E ? e0 + j : e0) * p.ld_raw];
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+          if (e0 + j < p.E) f(e0 + j, c[j]);
+      }
+    };
+    if (p.update) {
+      double s = 0.0;
+      walk([&](int e, double c) { s = e == 0 ? c : s + c; });
+      const double bm = s / bc;
+      double q = 0.0;
+      walk([&](int e, double c) {
+        const double x = c - bm;
+        q = e == 0 ? x * x : q + x * x;
+      });
+      const double bv = q / bc;
+      const double delta = bm - m, tot = cnt + bc;
+      const double new_mean = m + delta * bc / tot;
+      const double m_a = v * cnt, m_b = bv * bc;
+      const double M2 = m_a + m_b + delta * delta * cnt * bc / tot;
+      m = new_mean;
+      v = M2 / tot;
+      p.mean[d] = m;
+      p.var[d] = v;
+    }
+    const double den = sqrt(v) + 1e-4;
+    walk([&](int e, double c) {
+      double y = (c - m) / den;
+      y = y < -p.clip ? -p.clip : y;
+      y = y > p.clip ? p.clip : y;
+      if (p.out64 != nullptr) p.out64[e * p.ld64 + d] = y;
+      if (p.out32 != nullptr) p.out32[e * p.ld32 + d] = (float)y;
+    });
+  }
+  if (p.update && threadIdx.x == 0) *p.count = cnt + bc;
+}
+
 }  // namespace v4l

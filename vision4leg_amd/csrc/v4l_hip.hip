@@ -1681,6 +1681,31 @@ int v4l_gae(const double* rewards_dev, const double* values_dev, const double* t
   return 0;
 }
 
+int v4l_obs_norm(const double* raw_dev, int64_t ld_raw, int E, int S, double* mean_dev, double* var_dev, double* count_dev,
+                 double clip, int update, float* out32_dev, int64_t ld_out32, double* out64_dev, int64_t ld_out64,
+                 const void* image_dev, int image_f64, int64_t ld_image, int64_t image_elems, float* image_out_dev,
+                 int64_t ld_image_out, void* stream) {
+  V4L_REQUIRE(raw_dev && mean_dev && var_dev && count_dev && E > 0 && S > 0 && ld_raw >= S, "v4l_obs_norm: bad argument");
+  V4L_REQUIRE(out32_dev || out64_dev, "v4l_obs_norm: no output buffer");
+  V4L_REQUIRE((!out32_dev || ld_out32 >= S) && (!out64_dev || ld_out64 >= S), "v4l_obs_norm: output row stride < S");
+  V4L_REQUIRE(!image_dev || (image_out_dev && image_elems > 0 && ld_image >= image_elems && ld_image_out >= image_elems),
+              "v4l_obs_norm: bad image arguments");
+  ObsNorm p;
+  p.raw = raw_dev; p.ld_raw = ld_raw;
+  p.mean = mean_dev; p.var = var_dev; p.count = count_dev;
+  p.clip = clip; p.E = E; p.S = S; p.update = update != 0;
+  p.out32 = out32_dev; p.ld32 = ld_out32;
+  p.out64 = out64_dev; p.ld64 = ld_out64;
+  p.img = image_dev; p.img_f64 = image_f64 != 0; p.ld_img = ld_image; p.img_elems = image_dev ? image_elems : 0;
+  p.img_out = image_out_dev; p.ld_img_out = ld_image_out;
+  const int64_t img_blocks = image_dev ? std::min<int64_t>(cdiv64((int64_t)E * image_elems, 1024), 1024) : 0;
+  g_op = "obs_norm";
+  V4L_KLAUNCH("obs_norm", 0, (hipStream_t)stream, obs_norm_kernel, dim3((unsigned)(1 + img_blocks)), dim3(256), 0,
+              (hipStream_t)stream, p);
+  V4L_LAUNCH_CHECK();
+  return 0;
+}
+
 #ifdef V4L_INFER_TIMING
 int v4l_debug_stamps(long long* out32) {
   if (hipDeviceSynchronize() != hipSuccess) return -2;
