@@ -336,6 +336,29 @@ def roofline(ep, compute, breakdown_path):
     }
 
 
+def batch1_latency(ep, policies, dev):
+    """the batch-1 deployment call (RolloutActor(env_nums=1).eval_act — the reference ships a
+    TensorRT engine for this, a1_hardware/convert_tensor_rt/): device time per call by events over 300 back-to-back
+    launches, and the synchronous host round trip incl. the action's D2H copy."""
+    actor = policies.RolloutActor(ep.pf, ep.vf, 1)
+    x = ep.obs[:1].clone()
+    for _ in range(30):
+        actor.eval_act(x)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(300):
+        actor.step(x, deterministic=True)
+    e1.record()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(100):
+        actor.eval_act(x)
+    return {"device_us": round(e0.elapsed_time(e1) * 1e3 / 300, 2),
+            "host_round_trip_us": round((time.perf_counter() - t0) * 1e6 / 100, 1),
+            "what": "policy mean for one observation row [1][S+4*64*64], operands in the net's compute type"}
+
+
 def main():
     a = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -404,6 +427,9 @@ def main():
         if not a.no_cpu_baseline and world == 1:  # the host baseline is an N = 1 measurement (the other ranks would idle)
             res["cpu_baseline"] = cpu_baseline(wl, a.compute)
             res["vs_cpu_baseline"] = round(value / world / res["cpu_baseline"]["value"], 1)
+        if world == 1 and ep.actor is not None:
+            import vision4leg_amd.torchrl.policies as policies
+            res["batch1_inference"] = batch1_latency(ep, policies, dev)
     elif dist_on:
         ep.update()  # keep collectives matched with rank 0's profiled pass
     if dist_on:

@@ -482,6 +482,36 @@ def test_rollout_actor_matches_separate_calls(name, mode, graph, device):
 
 
 @pytest.mark.parametrize("mode", MODES)
+@pytest.mark.parametrize("name", ["loco_s84", "cnn_s93", "mlp_s93"])
+def test_batch1_deployment_call(name, mode, device):
+    """RolloutActor(env_nums=1).eval_act — the batch-1 inference entry (the TensorRT engine's role):
+    equals pf.eval_act of the module API and the oracle's policy mean on the reference's one-row input shape
+    (a1_hardware/execute_locotransformer.py:88), draws nothing from the generator, files nothing."""
+    from vision4leg_amd.torchrl.policies import RolloutActor
+    case = util.CASES[name]
+    pf, vf = _build(case, mode, device)
+    actor = RolloutActor(pf, vf, 1)
+    rs = np.random.RandomState(11)
+    kind = case["kind"]
+    opf, _ = _oracle_params(pf, vf, kind)
+    for k in range(3):
+        parts = [np.clip(rs.randn(1, case["S"]), -10, 10)]
+        if kind != "mlp":
+            parts.append(np.clip(rs.randn(1, 4 * 64 * 64), -2.5, 2.8))
+        x = torch.tensor(np.concatenate(parts, 1), dtype=torch.float32, device=device)
+        g0 = torch.cuda.get_rng_state(device)
+        a = actor.eval_act(x)
+        assert torch.equal(torch.cuda.get_rng_state(device), g0)
+        b = pf.eval_act(x)
+        assert a.shape == (case["A"],) and b.shape == (case["A"],)
+        with torch.no_grad():
+            want = orc.FORWARDS[kind]({k: v for k, v in opf.items() if k != "logstd"}, x.cpu(), case["S"], mode).numpy()[0]
+        tol = 1e-5 if mode == "f32" else 4e-3
+        scale = max(1.0, np.abs(want).max())
+        assert np.abs(a - b).max() <= tol * scale and np.abs(a - want).max() <= (2e-5 if mode == "f32" else 1e-2) * scale
+
+
+@pytest.mark.parametrize("mode", MODES)
 def test_stored_logp_equals_target_forward(mode, device):
     """log pi_old recorded by the rollout step (v4l_rollout.logp_old_dev) vs the reference's per-minibatch evaluation of
     the frozen target policy (ppo.py:55-57): (a) the stored values are Normal(mean,std).log_prob(action).sum(-1) of the

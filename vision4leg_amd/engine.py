@@ -425,21 +425,22 @@ class HipActor:
   def seek(self, t):
     check(self.L.v4l_actor_seek(self.h, int(t), _stream()), "v4l_actor_seek")
 
-  def step(self, obs):
+  def step(self, obs, deterministic=False):
     """obs: [E][S+C*H*W] float32 cuda rows of this env step. Returns a dict of views of fixed output buffers
-    (valid until the next step): action/mean/std [E][A], ent/value [E][1]."""
+    (valid until the next step): action/mean/std [E][A], ent/value [E][1]. deterministic: no draw, action == mean
+    (the eval_act / deployment protocol, policies/continuous_policy.py:78-83)."""
     _require_gpu(obs, "observation batch")
     if self.graph:  # capture needs a non-default stream
       cur = torch.cuda.current_stream(self.device)
       self.stream.wait_stream(cur)
       with torch.cuda.stream(self.stream):
-        self._step(obs)
+        self._step(obs, deterministic)
       cur.wait_stream(self.stream)
     else:
-      self._step(obs)
+      self._step(obs, deterministic)
     return self._out
 
-  def _step(self, obs):
+  def _step(self, obs, deterministic=False):
     self.pf.pack_if_needed(fast=True)
     self.vf.pack_if_needed(fast=True)
     args = self._args
@@ -448,7 +449,12 @@ class HipActor:
         self.obs.copy_(obs.reshape(self.obs.shape), non_blocking=True)  # a captured graph reads the fixed buffer
       else:
         args = (C.c_void_p(obs.data_ptr()),) + args[1:]  # eager launches read the caller's rows in place
-    self.eps.normal_()  # torch's generator: the same standard-normal draws Normal(mean, std).sample() would use
+    if not deterministic:
+      self.eps.normal_()  # torch's generator: the same standard-normal draws Normal(mean, std).sample() would use
+      self._eps_zero = False
+    elif not getattr(self, "_eps_zero", False):
+      self.eps.zero_()  # action = mean + std * 0
+      self._eps_zero = True
     if self.own:
       self.seek(0)
     check(self.L.v4l_actor_step(self.h, *args, _stream()), "v4l_actor_step")

@@ -38,8 +38,16 @@ class RolloutActor:
     def seek(self, t):
         self._actor.seek(t)
 
-    def step(self, ob):
-        return self._actor.step(ob)
+    def step(self, ob, deterministic=False):
+        return self._actor.step(ob, deterministic)
+
+    def eval_act(self, x):
+        """`pf.eval_act(x)` (policies/continuous_policy.py:78-83) on the fused step: the policy mean as a numpy array,
+        no draw. With env_nums = 1 this is the batch-1 deployment call — the role the reference's TensorRT engine
+        plays on the robot (a1_hardware/convert_tensor_rt/convert_locotransformer_trt.py:67-88): one or two launches,
+        operands in the net's compute type."""
+        out = self._actor.step(x.reshape(self._actor.E, -1), deterministic=True)
+        return out["action"].squeeze(0).cpu().numpy()
 
 
 class GaussianContPolicyBase:
