@@ -40,11 +40,18 @@ WORKLOADS = {
     # configs[4] per-GPU shard: 64 envs/GPU
     "loco64": dict(kind="loco", S=93, A=6, E=64, T=256, B=1024, enc=[256, 256], head=[256, 256], layers=2, ff=256,
                    name="ppo_locotransformer challenge/mountain shard: E=64 envs x T=256 per GPU, B=1024"),
+    # the vision-only starters (config/mpc_vision_only/*/thin-goal.json: 8192 frames per epoch)
+    "loco_vis": dict(kind="loco_vis", S=0, A=6, E=32, T=256, B=1024, enc=[], head=[256, 256], layers=2, ff=256,
+                     name="ppo_locotransformer_vision_only: Transformer over 16 depth tokens, A=6, E=32 envs x T=256, B=1024"),
+    "cnn_vis": dict(kind="cnn_vis", S=0, A=6, E=32, T=256, B=1024, enc=[], head=[256, 256],
+                    name="ppo_nature_cnn_vision_only: NatureCNN -> 1024 -> head, A=6, E=32 envs x T=256, B=1024"),
 }
 # algorithmic MFLOP per env-step incl. rollout inference, and F_pf: the forward pass of the frozen
 # target policy that each of the 3 sample-visits skips when log pi_old is recorded at action time (§8d's declared saving)
-MFLOP_PER_ENV_STEP = {"loco": 258.9, "loco64": 258.9, "cnn": 191.4, "mlp": 10.2}
-MFLOP_TARGET_FWD = {"loco": 11.258, "loco64": 11.258, "cnn": 8.325, "mlp": 0.444}
+# vision-only nets, same accounting: F_pf = 2 * (3 612 672 conv + 65 536 up-conv + 2 * 819 200 layer (16 tokens) + 83 456 head)
+# = 10.800 MFLOP, F_vf = 10.798; NatureCNN: F_pf = 2 * (3 612 672 + 329 216) = 7.884, F_vf = 7.881
+MFLOP_PER_ENV_STEP = {"loco": 258.9, "loco64": 258.9, "cnn": 191.4, "mlp": 10.2, "loco_vis": 248.4, "cnn_vis": 181.3}
+MFLOP_TARGET_FWD = {"loco": 11.258, "loco64": 11.258, "cnn": 8.325, "mlp": 0.444, "loco_vis": 10.800, "cnn_vis": 7.884}
 OPT_EPOCHS = 3
 PEAK = {"bf16": 2500.0, "f32": 157.3}  # dense TFLOP/s, MI355X_MICROARCH.md (bf16 MFMA / f32 MFMA)
 

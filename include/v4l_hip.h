@@ -31,6 +31,12 @@ extern "C" {
 #define V4L_NET_MLP 0  /* networks.Net + MLPBase            torchrl/networks/nets.py:16-55 (ppo_state.py)      */
 #define V4L_NET_CNN 1  /* networks.ImpalaEncoderProjNet + NatureFuseEncoder   nets.py:194-262, base.py:345-385 */
 #define V4L_NET_LOCO 2 /* networks.LocoTransformer + LocoTransformerEncoder   nets.py:909-1038, base.py:497-626 */
+/* vision-only variants: the observation row is the 4x64x64 depth stack alone, state_dim = 0,
+ * n_enc_hidden = 0 */
+#define V4L_NET_CNN_VIS 3  /* networks.NatureEncoderProjNet + NatureEncoder(flatten)   nets.py:133-191, base.py:304-342
+                              (starter/ppo_nature_cnn_vision_only.py:80-97) */
+#define V4L_NET_LOCO_VIS 4 /* networks.Transformer + TransformerEncoder (depth only: 16 tokens, mean-pooled)
+                              nets.py:784-906, base.py:388-494 (starter/ppo_locotransformer_vision_only.py:77-97) */
 
 #define V4L_MAX_HIDDEN 4
 #define V4L_STATS 24 /* floats per update record; [0..17] = the 18 logger keys of ppo.py:77-92,122-123,142-145 */

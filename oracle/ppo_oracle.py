@@ -171,7 +171,35 @@ def mlp_forward(p, x, S=None, mode="f32", taps=None):
     return head(p, "seq_append_fcs", mlp(p, "base.seq_fcs", x, ne, mode), nh, mode)
 
 
-FORWARDS = {"loco": loco_forward, "cnn": cnn_forward, "mlp": mlp_forward}
+def loco_vis_forward(p, x, S=0, mode="f32", taps=None):
+    """Transformer.forward + TransformerEncoder.forward, depth only (nets.py:868-906, base.py:430-494): the observation
+    row is the depth stack; 16 patch tokens, mean over all of them (out[0:1+16] of a 16-token sequence), head."""
+    img = x.reshape(-1, 4, 64, 64)                                                              # nets.py:869-871
+    B = img.shape[0]
+    c3 = nature_cnn(p, "encoder.depth_visual_base", img, mode)                                  # base.py:449
+    up = conv2d(c3, p["encoder.depth_up_conv.weight"], p["encoder.depth_up_conv.bias"], 1, mode)   # base.py:452
+    tok = up.reshape(B, 64, 16).permute(0, 2, 1)                                                # base.py:474-481
+    if taps is not None:
+        taps["c3"] = c3; taps["x0"] = tok
+    l = 0
+    while ("visual_append_layers.%d.norm1.weight" % l) in p:
+        tok = transformer_layer(p, "visual_append_layers.%d" % l, tok, mode)                    # nets.py:881-883
+        l += 1
+    pooled = tok[:, 0:17].mean(dim=1)                                                           # nets.py:888-889
+    nh = _count(p, "visual_seq_append_fcs.%d.weight") - 1
+    return head(p, "visual_seq_append_fcs", pooled, nh, mode)                                   # nets.py:904
+
+
+def cnn_vis_forward(p, x, S=0, mode="f32", taps=None):
+    """NatureEncoderProjNet.forward + NatureEncoder.forward with Flatten (nets.py:176-191, base.py:333-342)."""
+    img = x.reshape(-1, 4, 64, 64)
+    c3 = nature_cnn(p, "encoder", img, mode)
+    nh = _count(p, "seq_append_fcs.%d.weight") - 1
+    return head(p, "seq_append_fcs", c3.flatten(1), nh, mode)
+
+
+FORWARDS = {"loco": loco_forward, "cnn": cnn_forward, "mlp": mlp_forward, "loco_vis": loco_vis_forward,
+            "cnn_vis": cnn_vis_forward}
 
 
 # ------------------------------------------------------------------------------------------ Gaussian head

@@ -437,7 +437,7 @@ def test_graph_replay_equals_eager(mode, pair, device):
 
 @pytest.mark.parametrize("graph", [False, True])
 @pytest.mark.parametrize("mode", MODES)
-@pytest.mark.parametrize("name", ["loco_s84", "cnn_s93", "mlp_s93"])
+@pytest.mark.parametrize("name", ["loco_s84", "cnn_s93", "mlp_s93", "loco_vis", "cnn_vis"])
 def test_rollout_actor_matches_separate_calls(name, mode, graph, device):
     """RolloutActor.step (shared encoder pass, graph replay, device-side cursor) == pf.explore + vf of the reference
     protocol: same mean/std/value, action = mean + std*eps, rows/actions/values filed at slots [t*E,(t+1)*E)."""
@@ -482,7 +482,7 @@ def test_rollout_actor_matches_separate_calls(name, mode, graph, device):
 
 
 @pytest.mark.parametrize("mode", MODES)
-@pytest.mark.parametrize("name", ["loco_s84", "cnn_s93", "mlp_s93"])
+@pytest.mark.parametrize("name", ["loco_s84", "cnn_s93", "mlp_s93", "loco_vis", "cnn_vis"])
 def test_batch1_deployment_call(name, mode, device):
     """RolloutActor(env_nums=1).eval_act — the batch-1 inference entry (the TensorRT engine's role):
     equals pf.eval_act of the module API and the oracle's policy mean on the reference's one-row input shape

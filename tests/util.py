@@ -28,6 +28,10 @@ CASES = {
     # a NON-shipped geometry (one layer, ff = 128, 128-wide MLPs, odd batch): runs on the general layer-by-layer kernels
     # (gemm_nt / attn / ln / gemm_tn), not on the fused ones that are specialised for the shipped shapes
     "loco_gen": dict(kind="loco", S=45, A=4, seed=4, B=22, enc=[128, 128], head=[128, 128], layers=1, ff=128),
+    # vision-only variants (starter/ppo_locotransformer_vision_only.py, ppo_nature_cnn_vision_only.py
+    # with the config/mpc_vision_only/{locotransformer,baseline}/thin-goal.json hyper-parameters): the observation row is the depth stack alone (S = 0)
+    "loco_vis": dict(kind="loco_vis", S=0, A=6, seed=5, B=32, enc=[], head=[256, 256], layers=2, ff=256),
+    "cnn_vis": dict(kind="cnn_vis", S=0, A=6, seed=6, B=32, enc=[], head=[256, 256]),
 }
 
 GAE_CASES = {
@@ -86,6 +90,16 @@ def build_nets(networks, policies, case):
                                                           visual_input_shape=(4, 64, 64), output_shape=A, **net)
         vf = networks.ImpalaEncoderProjNet(encoder=encoder, state_input_shape=S, visual_input_shape=(4, 64, 64),
                                            output_shape=1, **net)
+    elif kind == "loco_vis":
+        net["transformer_params"] = [[1, case["ff"]] for _ in range(case["layers"])]
+        encoder = networks.TransformerEncoder(in_channels=4)
+        pf = policies.GaussianContPolicyTransformer(encoder=encoder, visual_input_shape=(4, 64, 64), output_shape=A, **net)
+        vf = networks.Transformer(encoder=encoder, visual_input_shape=(4, 64, 64), output_shape=1, **net)
+    elif kind == "cnn_vis":
+        encoder = networks.NatureEncoder(in_channels=4)
+        pf = policies.GaussianContPolicyNatureEncoderProj(encoder=encoder, visual_input_shape=(4, 64, 64),
+                                                          output_shape=A, **net)
+        vf = networks.NatureEncoderProjNet(encoder=encoder, visual_input_shape=(4, 64, 64), output_shape=1, **net)
     else:
         net["hidden_shapes"] = list(case["enc"])
         pf = policies.GaussianContPolicyBasicBias(input_shape=S, output_shape=A, **net)

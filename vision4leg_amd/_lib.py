@@ -11,7 +11,7 @@ LIB_PATH = os.environ.get("V4L_LIB", os.path.join(_HERE, "libv4l_hip.so"))  # V4
 SRC_DIR = os.path.join(_HERE, "csrc")
 
 V4L_F32, V4L_BF16 = 0, 1
-V4L_NET_MLP, V4L_NET_CNN, V4L_NET_LOCO = 0, 1, 2
+V4L_NET_MLP, V4L_NET_CNN, V4L_NET_LOCO, V4L_NET_CNN_VIS, V4L_NET_LOCO_VIS = 0, 1, 2, 3, 4
 V4L_MAX_HIDDEN = 4
 V4L_STATS = 24
 V4L_OUT_LD = 16

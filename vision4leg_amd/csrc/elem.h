@@ -33,107 +33,109 @@ __global__ __launch_bounds__(256) void ingest_kernel(const float* __restrict__ o
 
 // --------------------------------------------------------------------------------- attention
 // nn.MultiheadAttention(64, 1 head) core on packed qkv rows [n*17][192] (q|k|v), per sample:
-//   P = softmax(q k^T / sqrt(64)),  ctx = P v.          (torch nn/functional.py multi_head_attention_forward;
+//   P = softmax(q k^T / sqrt(64)),  ctx = P v.   NT tokens per sample: 17 (LocoTransformer) or 16 (vision-only Transformer).          (torch nn/functional.py multi_head_attention_forward;
 // built by the reference at torchrl/networks/nets.py:948-955). One wave per sample, 4 samples per block.
 constexpr int ATT_LD = TD + 1;  // +1 float: conflict-free both for lane=d and lane=(i,j) access
 constexpr int ATT_PLD = 20;
 
+template <int NT>
 __global__ __launch_bounds__(256) void attn_fwd_kernel(const float* __restrict__ qkv, int n, float* __restrict__ P,
                                                        float* __restrict__ ctx) {
   // one sample per block: the 289 scores and the 17x64 context are spread over all 256 threads (the per-sample
   // dependency chain, not throughput, is what bounds this kernel)
-  __shared__ float q[NTOK * ATT_LD], k[NTOK * ATT_LD], v[NTOK * ATT_LD], p[NTOK * ATT_PLD];
+  __shared__ float q[NT * ATT_LD], k[NT * ATT_LD], v[NT * ATT_LD], p[NT * ATT_PLD];
   const int tid = threadIdx.x;
   const int b = blockIdx.x;
-  const float* src = qkv + (int64_t)b * NTOK * 3 * TD;
-  for (int idx = tid; idx < NTOK * 3 * TD; idx += 256) {
+  const float* src = qkv + (int64_t)b * NT * 3 * TD;
+  for (int idx = tid; idx < NT * 3 * TD; idx += 256) {
     const int t = idx / (3 * TD), c = idx - t * 3 * TD;
     const int part = c >> 6, d = c & 63;
     (part == 0 ? q : part == 1 ? k : v)[t * ATT_LD + d] = src[idx];
   }
   __syncthreads();
-  for (int pr = tid; pr < NTOK * NTOK; pr += 256) {
-    const int i = pr / NTOK, j = pr - i * NTOK;
+  for (int pr = tid; pr < NT * NT; pr += 256) {
+    const int i = pr / NT, j = pr - i * NT;
     float s = 0.f;
 #pragma unroll 16
     for (int d = 0; d < TD; ++d) s = fmaf(q[i * ATT_LD + d], k[j * ATT_LD + d], s);
     p[i * ATT_PLD + j] = s * 0.125f;
   }
   __syncthreads();
-  if (tid < NTOK) {
+  if (tid < NT) {
     float mx = -INFINITY;
-    for (int j = 0; j < NTOK; ++j) mx = fmaxf(mx, p[tid * ATT_PLD + j]);
-    float e[NTOK], sum = 0.f;
+    for (int j = 0; j < NT; ++j) mx = fmaxf(mx, p[tid * ATT_PLD + j]);
+    float e[NT], sum = 0.f;
 #pragma unroll
-    for (int j = 0; j < NTOK; ++j) { e[j] = expf(p[tid * ATT_PLD + j] - mx); sum += e[j]; }
+    for (int j = 0; j < NT; ++j) { e[j] = expf(p[tid * ATT_PLD + j] - mx); sum += e[j]; }
     const float inv = 1.f / sum;
 #pragma unroll
-    for (int j = 0; j < NTOK; ++j) {
+    for (int j = 0; j < NT; ++j) {
       const float pv = e[j] * inv;
       p[tid * ATT_PLD + j] = pv;
-      P[((int64_t)b * NTOK + tid) * NTOK + j] = pv;
+      P[((int64_t)b * NT + tid) * NT + j] = pv;
     }
   }
   __syncthreads();
-  for (int o = tid; o < NTOK * TD; o += 256) {
+  for (int o = tid; o < NT * TD; o += 256) {
     const int i = o >> 6, d = o & 63;
     float a = 0.f;
 #pragma unroll
-    for (int j = 0; j < NTOK; ++j) a = fmaf(p[i * ATT_PLD + j], v[j * ATT_LD + d], a);
-    ctx[(int64_t)b * NTOK * TD + o] = a;
+    for (int j = 0; j < NT; ++j) a = fmaf(p[i * ATT_PLD + j], v[j * ATT_LD + d], a);
+    ctx[(int64_t)b * NT * TD + o] = a;
   }
 }
 
 // Backward of the above: given dctx, saved P and qkv -> dqkv (same packed layout).
 //   dV = P^T dctx ; dP = dctx V^T ; dS = P o (dP - rowsum(P o dP)) ; dQ = dS K / 8 ; dK = dS^T Q / 8
+template <int NT>
 __global__ __launch_bounds__(256) void attn_bwd_kernel(const float* __restrict__ qkv, const float* __restrict__ P,
                                                        const float* __restrict__ dctx, int n,
                                                        float* __restrict__ dqkv) {
-  __shared__ float q[NTOK * ATT_LD], k[NTOK * ATT_LD], v[NTOK * ATT_LD], dc[NTOK * ATT_LD];
-  __shared__ float p[NTOK * ATT_PLD], ds[NTOK * ATT_PLD];
+  __shared__ float q[NT * ATT_LD], k[NT * ATT_LD], v[NT * ATT_LD], dc[NT * ATT_LD];
+  __shared__ float p[NT * ATT_PLD], ds[NT * ATT_PLD];
   const int tid = threadIdx.x;
   const int b = blockIdx.x;
-  const float* src = qkv + (int64_t)b * NTOK * 3 * TD;
-  for (int idx = tid; idx < NTOK * 3 * TD; idx += 256) {
+  const float* src = qkv + (int64_t)b * NT * 3 * TD;
+  for (int idx = tid; idx < NT * 3 * TD; idx += 256) {
     const int t = idx / (3 * TD), c = idx - t * 3 * TD;
     const int part = c >> 6, d = c & 63;
     (part == 0 ? q : part == 1 ? k : v)[t * ATT_LD + d] = src[idx];
   }
-  for (int o = tid; o < NTOK * TD; o += 256) dc[(o >> 6) * ATT_LD + (o & 63)] = dctx[(int64_t)b * NTOK * TD + o];
-  for (int pr = tid; pr < NTOK * NTOK; pr += 256) {
-    const int i = pr / NTOK, j = pr - i * NTOK;
-    p[i * ATT_PLD + j] = P[(int64_t)b * NTOK * NTOK + pr];
+  for (int o = tid; o < NT * TD; o += 256) dc[(o >> 6) * ATT_LD + (o & 63)] = dctx[(int64_t)b * NT * TD + o];
+  for (int pr = tid; pr < NT * NT; pr += 256) {
+    const int i = pr / NT, j = pr - i * NT;
+    p[i * ATT_PLD + j] = P[(int64_t)b * NT * NT + pr];
   }
   __syncthreads();
-  float* dst = dqkv + (int64_t)b * NTOK * 3 * TD;
-  for (int o = tid; o < NTOK * TD; o += 256) {  // dV[j][d]
+  float* dst = dqkv + (int64_t)b * NT * 3 * TD;
+  for (int o = tid; o < NT * TD; o += 256) {  // dV[j][d]
     const int j = o >> 6, d = o & 63;
     float a = 0.f;
 #pragma unroll
-    for (int i = 0; i < NTOK; ++i) a = fmaf(p[i * ATT_PLD + j], dc[i * ATT_LD + d], a);
+    for (int i = 0; i < NT; ++i) a = fmaf(p[i * ATT_PLD + j], dc[i * ATT_LD + d], a);
     dst[j * 3 * TD + 2 * TD + d] = a;
   }
-  for (int pr = tid; pr < NTOK * NTOK; pr += 256) {  // dP[i][j]
-    const int i = pr / NTOK, j = pr - i * NTOK;
+  for (int pr = tid; pr < NT * NT; pr += 256) {  // dP[i][j]
+    const int i = pr / NT, j = pr - i * NT;
     float s = 0.f;
 #pragma unroll 16
     for (int d = 0; d < TD; ++d) s = fmaf(dc[i * ATT_LD + d], v[j * ATT_LD + d], s);
     ds[i * ATT_PLD + j] = s;
   }
   __syncthreads();
-  if (tid < NTOK) {
+  if (tid < NT) {
     float rd = 0.f;
 #pragma unroll
-    for (int j = 0; j < NTOK; ++j) rd = fmaf(p[tid * ATT_PLD + j], ds[tid * ATT_PLD + j], rd);
+    for (int j = 0; j < NT; ++j) rd = fmaf(p[tid * ATT_PLD + j], ds[tid * ATT_PLD + j], rd);
 #pragma unroll
-    for (int j = 0; j < NTOK; ++j) ds[tid * ATT_PLD + j] = p[tid * ATT_PLD + j] * (ds[tid * ATT_PLD + j] - rd);
+    for (int j = 0; j < NT; ++j) ds[tid * ATT_PLD + j] = p[tid * ATT_PLD + j] * (ds[tid * ATT_PLD + j] - rd);
   }
   __syncthreads();
-  for (int o = tid; o < NTOK * TD; o += 256) {
+  for (int o = tid; o < NT * TD; o += 256) {
     const int t = o >> 6, d = o & 63;
     float aq = 0.f, ak = 0.f;
 #pragma unroll
-    for (int j = 0; j < NTOK; ++j) {
+    for (int j = 0; j < NT; ++j) {
       aq = fmaf(ds[t * ATT_PLD + j], k[j * ATT_LD + d], aq);  // dQ[t][d] = sum_j dS[t][j] K[j][d]
       ak = fmaf(ds[j * ATT_PLD + t], q[j * ATT_LD + d], ak);  // dK[t][d] = sum_i dS[i][t] Q[i][d]
     }
@@ -242,6 +244,24 @@ __global__ __launch_bounds__(64) void pool_bwd_kernel(const float* __restrict__ 
   o[d] = ds;
 #pragma unroll
   for (int i = 1; i < NTOK; ++i) o[i * TD + d] = dm;
+}
+
+// vision-only Transformer (torchrl/networks/nets.py:884-889: out[0 : 1 + 16].mean(dim=0) over a 16-token sequence is the
+// mean of all tokens) -> [n][64]
+__global__ __launch_bounds__(64) void pool_all_fwd_kernel(const float* __restrict__ x, int n, int ntok, float* __restrict__ pooled) {
+  const int b = blockIdx.x, d = threadIdx.x;
+  if (b >= n) return;
+  const float* xb = x + (int64_t)b * ntok * TD;
+  float s = 0.f;
+  for (int i = 0; i < ntok; ++i) s += xb[i * TD + d];
+  pooled[(int64_t)b * TD + d] = s * (1.f / (float)ntok);
+}
+__global__ __launch_bounds__(64) void pool_all_bwd_kernel(const float* __restrict__ dpooled, int n, int ntok, float* __restrict__ dx) {
+  const int b = blockIdx.x, d = threadIdx.x;
+  if (b >= n) return;
+  const float dm = dpooled[(int64_t)b * TD + d] * (1.f / (float)ntok);
+  float* o = dx + (int64_t)b * ntok * TD;
+  for (int i = 0; i < ntok; ++i) o[i * TD + d] = dm;
 }
 
 // --------------------------------------------------------------------------------- rollout step (actor)

@@ -75,6 +75,9 @@ struct Layout {
 struct v4l_net {
   v4l_net_cfg cfg;
   int Sp = 0;
+  int ntok = v4l::NTOK;  // tokens per sample: 17 (LocoTransformer), 16 (vision-only Transformer)
+  bool vis_only() const { return cfg.kind == V4L_NET_CNN_VIS || cfg.kind == V4L_NET_LOCO_VIS; }
+  bool is_tf() const { return cfg.kind == V4L_NET_LOCO || cfg.kind == V4L_NET_LOCO_VIS; }
   std::vector<v4l::ParamInfo> params;
   int64_t total_params = 0;
   // layers

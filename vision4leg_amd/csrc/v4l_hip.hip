@@ -561,11 +561,14 @@ using namespace v4l;
 // ------------------------------------------------------------------------------------------ plan
 int v4l_net::build() {
   const v4l_net_cfg& c = cfg;
-  V4L_REQUIRE(c.kind >= V4L_NET_MLP && c.kind <= V4L_NET_LOCO, "v4l_net_create: unknown net kind %d", c.kind);
+  V4L_REQUIRE(c.kind >= V4L_NET_MLP && c.kind <= V4L_NET_LOCO_VIS, "v4l_net_create: unknown net kind %d", c.kind);
   V4L_REQUIRE(c.compute == V4L_F32 || c.compute == V4L_BF16, "v4l_net_create: unknown compute mode %d", c.compute);
-  V4L_REQUIRE(c.state_dim > 0 && c.out_dim > 0 && c.out_dim <= 8, "v4l_net_create: state_dim>0 and 1<=out_dim<=8 required");
-  V4L_REQUIRE(c.n_enc_hidden >= 1 && c.n_enc_hidden <= V4L_MAX_HIDDEN && c.n_head_hidden >= 0 &&
-                  c.n_head_hidden <= V4L_MAX_HIDDEN,
+  V4L_REQUIRE(c.out_dim > 0 && c.out_dim <= 8, "v4l_net_create: 1<=out_dim<=8 required");
+  if (vis_only())  // vision-only nets have no proprio branch: the observation row is the depth stack alone
+    V4L_REQUIRE(c.state_dim == 0 && c.n_enc_hidden == 0, "v4l_net_create: vision-only nets take state_dim 0 and no encoder MLP");
+  else
+    V4L_REQUIRE(c.state_dim > 0 && c.n_enc_hidden >= 1, "v4l_net_create: state_dim>0 and an encoder MLP required");
+  V4L_REQUIRE(c.n_enc_hidden <= V4L_MAX_HIDDEN && c.n_head_hidden >= 0 && c.n_head_hidden <= V4L_MAX_HIDDEN,
               "v4l_net_create: hidden layer counts out of range");
   for (int i = 0; i < c.n_enc_hidden; ++i)
     V4L_REQUIRE(c.enc_hidden[i] > 0 && c.enc_hidden[i] % 8 == 0, "v4l_net_create: hidden widths must be multiples of 8");
@@ -574,12 +577,13 @@ int v4l_net::build() {
   if (c.kind != V4L_NET_MLP)
     V4L_REQUIRE(c.in_channels == 4 && c.img_hw == 64,
                 "v4l_net_create: only the 4x64x64 depth stack is supported (got %dx%dx%d)", c.in_channels, c.img_hw, c.img_hw);
-  if (c.kind == V4L_NET_LOCO)
+  if (is_tf())
     V4L_REQUIRE(c.token_dim == TD && c.n_layers >= 1 && c.n_layers <= 8 && c.ff_dim > 0 && c.ff_dim % 8 == 0,
                 "v4l_net_create: LocoTransformer needs token_dim 64, 1..8 layers, ff_dim %% 8 == 0");
   if (c.kind == V4L_NET_CNN)
     V4L_REQUIRE(c.visual_dim > 0 && c.visual_dim % 8 == 0, "v4l_net_create: visual_dim must be a positive multiple of 8");
-  Sp = round_up(c.state_dim, 32);
+  Sp = std::max(32, round_up(c.state_dim, 32));  // vision-only: a 32-float all-zero dummy row keeps every array non-empty
+  ntok = c.kind == V4L_NET_LOCO_VIS ? 16 : NTOK;
 
   auto add_param = [&](const std::string& name, std::initializer_list<int64_t> shp) {
     ParamInfo pi;
@@ -641,11 +645,16 @@ int v4l_net::build() {
     proj.cin = 64; proj.taps = 16;
     const int e = make_mlp("encoder.base.seq_fcs", c.state_dim, c.enc_hidden, c.n_enc_hidden, false, enc);
     head_in = c.visual_dim + e;
+  } else if (c.kind == V4L_NET_CNN_VIS) {
+    make_convs("encoder");  // the NatureEncoder(flatten=True) itself is `encoder` (starter/ppo_nature_cnn_vision_only.py:80-83)
+    head_in = 1024;
   } else {
     make_convs("encoder.depth_visual_base");
     upconv = make_lin("encoder.depth_up_conv.weight", "encoder.depth_up_conv.bias", TD, 64, true, true);
-    const int e = make_mlp("encoder.base.seq_fcs", c.state_dim, c.enc_hidden, c.n_enc_hidden, false, enc);
-    proj = make_lin("encoder.state_projector.projection.0.weight", "encoder.state_projector.projection.0.bias", TD, e, true);
+    if (c.kind == V4L_NET_LOCO) {
+      const int e = make_mlp("encoder.base.seq_fcs", c.state_dim, c.enc_hidden, c.n_enc_hidden, false, enc);
+      proj = make_lin("encoder.state_projector.projection.0.weight", "encoder.state_projector.projection.0.bias", TD, e, true);
+    }
     for (int l = 0; l < c.n_layers; ++l) {
       const std::string id = "visual_append_layers." + std::to_string(l);
       TLayer t;
@@ -659,13 +668,17 @@ int v4l_net::build() {
       t.ln2.b = add_param(id + ".norm2.bias", {TD});
       layers.push_back(t);
     }
-    head_in = 2 * TD;
+    head_in = c.kind == V4L_NET_LOCO ? 2 * TD : TD;
   }
   {
-    const std::string hp = c.kind == V4L_NET_LOCO ? "visual_seq_append_fcs" : "seq_append_fcs";
+    const std::string hp = is_tf() ? "visual_seq_append_fcs" : "seq_append_fcs";
     const int k = make_mlp(hp, head_in, c.head_hidden, c.n_head_hidden, true, head);
     const std::string id = hp + "." + std::to_string(2 * c.n_head_hidden);
     head.push_back(make_lin(id + ".weight", id + ".bias", c.out_dim, k, true));
+    if (c.kind == V4L_NET_CNN_VIS) {  // the first head layer reads conv3's NHWC rows as PyTorch's NCHW flatten
+      head[0].cin = 64;
+      head[0].taps = 16;
+    }
   }
   if (c.has_logstd) logstd = add_param("logstd", {c.out_dim});
 
@@ -710,8 +723,8 @@ int v4l_net::build() {
       }
     }
   }
-  if (c.kind == V4L_NET_LOCO) pack_lin(upconv);
-  if (c.kind != V4L_NET_MLP) pack_lin(proj);
+  if (is_tf()) pack_lin(upconv);
+  if (c.kind == V4L_NET_CNN || c.kind == V4L_NET_LOCO) pack_lin(proj);
   for (Lin& L : enc) pack_lin(L);
   for (TLayer& t : layers) { pack_lin(t.inproj); pack_lin(t.outproj); pack_lin(t.ff1); pack_lin(t.ff2); }
   for (Lin& L : head) pack_lin(L);
@@ -744,7 +757,7 @@ int64_t v4l_net::slab_floats(int n) const {
     for (int i = 0; i < 3; ++i) add(n * conv[i].OH * conv[i].OH, conv[i].Cout, conv[i].K);
     tot += (int64_t)CONV_BWD_MAX_BLOCKS * (32 * 256 + 64 * 512 + 64 * 576 + 3 * 64);  // fused conv backward: one slab set per block
   }
-  if (cfg.kind == V4L_NET_LOCO) add(n * 16, upconv.N, 64);
+  if (is_tf()) add(n * 16, upconv.N, 64);
   if (cfg.kind == V4L_NET_LOCO) add(n, proj.N, proj.K);
   if (cfg.kind == V4L_NET_CNN) add(n, proj.N, 1024);
   for (size_t i = 0; i < enc.size(); ++i) add(n, enc[i].N, i == 0 ? Sp : enc[i].K);
@@ -764,7 +777,7 @@ Layout v4l_net::layout(int n) const {
   int64_t off = 0;
   auto take = [&](int64_t floats) { int64_t o = off; off += (floats + 63) / 64 * 64; return o; };
   const v4l_net_cfg& c = cfg;
-  const int64_t R = (int64_t)n * NTOK;
+  const int64_t R = (int64_t)n * ntok;
   int maxw = 2 * TD;
   for (int i = 0; i < c.n_enc_hidden; ++i) maxw = std::max(maxw, c.enc_hidden[i]);
   for (int i = 0; i < c.n_head_hidden; ++i) maxw = std::max(maxw, c.head_hidden[i]);
@@ -776,7 +789,7 @@ Layout v4l_net::layout(int n) const {
   }
   for (int i = 0; i < c.n_enc_hidden; ++i) L.eh.push_back(take((int64_t)n * c.enc_hidden[i]));
   if (c.kind == V4L_NET_CNN) L.vis = take((int64_t)n * (c.visual_dim + c.enc_hidden[c.n_enc_hidden - 1]));
-  if (c.kind == V4L_NET_LOCO) {
+  if (is_tf()) {
     for (int l = 0; l <= c.n_layers; ++l) L.x.push_back(take(R * TD));
     for (int l = 0; l < c.n_layers; ++l) {
       LayerWs w;
@@ -802,7 +815,7 @@ Layout v4l_net::layout(int n) const {
   for (int i = 0; i < c.n_head_hidden; ++i) L.dhh.push_back(take((int64_t)n * c.head_hidden[i]));
   for (int i = 0; i < c.n_enc_hidden; ++i) L.deh.push_back(take((int64_t)n * c.enc_hidden[i]));
   L.dhc = take((int64_t)n * maxw);
-  if (c.kind == V4L_NET_LOCO) {
+  if (is_tf()) {
     for (int l = 0; l <= c.n_layers; ++l) L.dxl.push_back(take(R * TD));
     for (int l = 0; l < c.n_layers; ++l) {
       LayerBw b;
@@ -858,6 +871,12 @@ int v4l_net::forward_t(const float* state, const T* image, const int* rowidx, in
       if ((rc = par_end(cx))) return rc;
     }
     head_in = dense(ws + L.vis, cw, n, cw);
+  } else if (c.kind == V4L_NET_CNN_VIS) {
+    // NatureEncoderProjNet (nets.py:176-191): conv stack -> Flatten -> head; the flatten is conv3's NHWC rows, the
+    // first head layer's pack carries the NCHW -> NHWC permutation
+    if (enc_ws == nullptr && stage != 2 && (rc = conv_stack_fwd<T>(cx, image, rowidx, n, ws + L.c1, ws + L.c2, ws + L.c3)))
+      return rc;
+    head_in = dense((enc_ws != nullptr ? enc_ws : ws) + L.c3, 1024, n, 1024);
   } else {
     float* x0 = enc_ws != nullptr ? const_cast<float*>(enc_ws) + L.x[0] : ws + L.x[0];
     const bool fused_enc = ne == 2 && c.enc_hidden[0] == 256 && c.enc_hidden[1] == 256 && c.state_dim <= 128 &&
@@ -886,6 +905,10 @@ int v4l_net::forward_t(const float* state, const T* image, const int* rowidx, in
                   InfEncLds<T>::bytes, s, (const ActCtl*)nullptr, (const float*)nullptr, n, en, (float*)nullptr, (T*)nullptr, x0,
                   tr);
       V4L_LAUNCH_CHECK();
+    } else if (enc_ws == nullptr && stage != 2 && c.kind == V4L_NET_LOCO_VIS) {
+      // TransformerEncoder (base.py:388-494, depth only): conv stack -> 1x1 up-conv -> the 16 patch tokens, in order
+      if ((rc = conv_stack_fwd<T>(cx, image, rowidx, n, ws + L.c1, ws + L.c2, ws + L.c3))) return rc;
+      if ((rc = lin_fwd<T>(cx, upconv, dense(ws + L.c3, 64, n * 16, 64), mk_epi(x0, TD, TD)))) return rc;
     } else if (enc_ws == nullptr && stage != 2) {
       // proprio branch (MLP + state_projector -> token 0) on the aux stream next to the conv branch (-> tokens 1..16)
       if ((rc = par_begin(cx))) return rc;
@@ -906,7 +929,7 @@ int v4l_net::forward_t(const float* state, const T* image, const int* rowidx, in
       if ((rc = par_end(cx))) return rc;
     }
     if (stage == 1) return 0;
-    const int R = n * NTOK;
+    const int R = n * ntok;
     const bool fused_layers = this->fused_layers();
     // the last layer's blocks also run the pooled heads of their samples when the head stack has the shipped shape
     const bool fused_head = fused_layers && c.n_layers >= 1 && nh == 2 && c.head_hidden[0] == 256 && c.head_hidden[1] == 256 &&
@@ -975,7 +998,10 @@ int v4l_net::forward_t(const float* state, const T* image, const int* rowidx, in
       float* xin = l == 0 ? x0 : ws + L.x[l];
       if ((rc = lin_fwd<T>(cx, t.inproj, dense(xin, TD, R, TD), mk_epi(ws + w.qkv, 3 * TD, 3 * TD)))) return rc;
       g_op = "attn";
-      V4L_KLAUNCH("attn_fwd", 4.0 * n * NTOK * NTOK * TD, s, attn_fwd_kernel, dim3(n), dim3(256), 0, s, ws + w.qkv, n, ws + w.P, ws + w.ctx);
+      if (ntok == NTOK)
+        V4L_KLAUNCH("attn_fwd", 4.0 * n * NTOK * NTOK * TD, s, attn_fwd_kernel<NTOK>, dim3(n), dim3(256), 0, s, ws + w.qkv, n, ws + w.P, ws + w.ctx);
+      else
+        V4L_KLAUNCH("attn_fwd", 4.0 * n * 16 * 16 * TD, s, attn_fwd_kernel<16>, dim3(n), dim3(256), 0, s, ws + w.qkv, n, ws + w.P, ws + w.ctx);
       V4L_LAUNCH_CHECK();
       if ((rc = lin_fwd<T>(cx, t.outproj, dense(ws + w.ctx, TD, R, TD), mk_epi(ws + L.ytmp, TD, TD)))) return rc;
       g_op = "ln1";
@@ -990,9 +1016,14 @@ int v4l_net::forward_t(const float* state, const T* image, const int* rowidx, in
       V4L_LAUNCH_CHECK();
     }
     g_op = "pool";
-    V4L_KLAUNCH("pool_fwd", 0, s, pool_fwd_kernel, dim3(n), dim3(128), 0, s, ws + L.x[c.n_layers], n, ws + L.pooled);
+    if (c.kind == V4L_NET_LOCO_VIS) {
+      V4L_KLAUNCH("pool_fwd", 0, s, pool_all_fwd_kernel, dim3(n), dim3(64), 0, s, ws + L.x[c.n_layers], n, ntok, ws + L.pooled);
+      head_in = dense(ws + L.pooled, TD, n, TD);
+    } else {
+      V4L_KLAUNCH("pool_fwd", 0, s, pool_fwd_kernel, dim3(n), dim3(128), 0, s, ws + L.x[c.n_layers], n, ws + L.pooled);
+      head_in = dense(ws + L.pooled, 2 * TD, n, 2 * TD);
+    }
     V4L_LAUNCH_CHECK();
-    head_in = dense(ws + L.pooled, 2 * TD, n, 2 * TD);
   }
   if (stage == 1) return 0;
   Act hacts[V4L_MAX_HIDDEN + 1];
@@ -1068,8 +1099,20 @@ int v4l_net::backward_t(const float* state, const T* image, const int* rowidx, i
     return wgrad_finish<T>(cx);
   }
 
-  // ---- LocoTransformer
-  const int R = n * NTOK;
+  if (c.kind == V4L_NET_CNN_VIS) {
+    // head stack; its data-grad lands in dc3 viewed as the NHWC flatten [n][1024], masked by conv3's ReLU
+    Epi din = mk_epi(ws + L.dc3, 1024, 1024);
+    din.mask = ws + L.c3;
+    din.ldmask = 1024;
+    if ((rc = chain_bwd<T>(cx, head.data(), nh + 1, dense(ws + L.c3, 1024, n, 1024), hacts, dy, dhhp, &din))) return rc;
+    if ((rc = conv_stack_bwd<T>(cx, image, rowidx, n, ws + L.c1, ws + L.c2, ws + L.dc3, ws + L.dc2, ws + L.dc1))) return rc;
+    return wgrad_finish<T>(cx);
+  }
+
+  // ---- LocoTransformer / vision-only Transformer
+  const bool vis = c.kind == V4L_NET_LOCO_VIS;
+  const int pw = vis ? TD : 2 * TD;  // pooled width
+  const int R = n * ntok;
   const bool fused_bwd = fused_layers();  // forward and backward switch together: they share the T-typed saves
   // the last layer's launch starts from dout (heads + un-pool), layer 0's launch continues into the encoder MLP / up-conv
   const bool fused_head = fused_bwd && c.n_layers >= 1 && nh == 2 && c.head_hidden[0] == 256 && c.head_hidden[1] == 256 &&
@@ -1081,11 +1124,14 @@ int v4l_net::backward_t(const float* state, const T* image, const int* rowidx, i
     if ((rc = lin_wgrad<T>(cx, head[1], dense(dhhp[1], 256, n, 256), dense(hacts[0].p, 256, n, 256), 256))) return rc;
     if ((rc = lin_wgrad<T>(cx, head[0], dense(dhhp[0], 256, n, 256), dense(ws + L.pooled, 2 * TD, n, 2 * TD), 2 * TD))) return rc;
   } else {
-    Epi din = mk_epi(ws + L.dpool, 2 * TD, 2 * TD);
-    if ((rc = chain_bwd<T>(cx, head.data(), nh + 1, dense(ws + L.pooled, 2 * TD, n, 2 * TD), hacts, dy, dhhp, &din)))
+    Epi din = mk_epi(ws + L.dpool, pw, pw);
+    if ((rc = chain_bwd<T>(cx, head.data(), nh + 1, dense(ws + L.pooled, pw, n, pw), hacts, dy, dhhp, &din)))
       return rc;
     g_op = "pool";
-    V4L_KLAUNCH("pool_bwd", 0, s, pool_bwd_kernel, dim3(n), dim3(64), 0, s, ws + L.dpool, n, ws + L.dxl[c.n_layers]);
+    if (vis)
+      V4L_KLAUNCH("pool_bwd", 0, s, pool_all_bwd_kernel, dim3(n), dim3(64), 0, s, ws + L.dpool, n, ntok, ws + L.dxl[c.n_layers]);
+    else
+      V4L_KLAUNCH("pool_bwd", 0, s, pool_bwd_kernel, dim3(n), dim3(64), 0, s, ws + L.dpool, n, ws + L.dxl[c.n_layers]);
     V4L_LAUNCH_CHECK();
   }
   const int lnb = std::min(cdiv(R, 16), 128);
@@ -1200,8 +1246,12 @@ int v4l_net::backward_t(const float* state, const T* image, const int* rowidx, i
       if ((rc = lin_wgrad<T>(cx, t.outproj, y, dense(ws + w.ctx, TD, R, TD), TD))) return rc;
       if ((rc = lin_dgrad<T>(cx, t.outproj, y, mk_epi(ws + b.dctx, TD, TD)))) return rc;
       g_op = "attn";
-      V4L_KLAUNCH("attn_bwd", 8.0 * n * NTOK * NTOK * TD, s, attn_bwd_kernel, dim3(n), dim3(256), 0, s, ws + w.qkv, ws + w.P,
-                  ws + b.dctx, n, ws + b.dqkv);
+      if (ntok == NTOK)
+        V4L_KLAUNCH("attn_bwd", 8.0 * n * NTOK * NTOK * TD, s, attn_bwd_kernel<NTOK>, dim3(n), dim3(256), 0, s, ws + w.qkv, ws + w.P,
+                    ws + b.dctx, n, ws + b.dqkv);
+      else
+        V4L_KLAUNCH("attn_bwd", 8.0 * n * 16 * 16 * TD, s, attn_bwd_kernel<16>, dim3(n), dim3(256), 0, s, ws + w.qkv, ws + w.P,
+                    ws + b.dctx, n, ws + b.dqkv);
       V4L_LAUNCH_CHECK();
       ADense yq = dense(ws + b.dqkv, 3 * TD, R, 3 * TD);
       if ((rc = lin_wgrad<T>(cx, t.inproj, yq, dense(ws + L.x[l], TD, R, TD), TD))) return rc;
@@ -1220,7 +1270,7 @@ int v4l_net::backward_t(const float* state, const T* image, const int* rowidx, i
     if ((rc = lin_wgrad<T>(cx, enc[0], dense(dehp[0], 256, n, 256), sin, sin.K))) return rc;
     if ((rc = lin_wgrad<T>(cx, upconv, dense(dx, TD, n * 16, TD, nullptr, 1), dense(ws + L.c3, 64, n * 16, 64), 64))) return rc;
   }
-  if (!fused_tail) {  // token 0 -> state_projector -> encoder MLP
+  if (!fused_tail && !vis) {  // token 0 -> state_projector -> encoder MLP
     const Act& last = eacts[ne - 1];
     ADense yp = dense(dx, NTOK * TD, n, TD, nullptr, 0, x0);
     if ((rc = lin_wgrad<T>(cx, proj, yp, dense(last.p, last.ld, n, last.w), last.w))) return rc;
@@ -1230,8 +1280,8 @@ int v4l_net::backward_t(const float* state, const T* image, const int* rowidx, i
     if ((rc = lin_dgrad<T>(cx, proj, yp, ep))) return rc;
     if ((rc = chain_bwd<T>(cx, enc.data(), ne, sin, eacts, dense(ws + L.dhc, last.w, n, last.w), dehp, nullptr))) return rc;
   }
-  if (!fused_tail) {  // tokens 1..16 -> depth_up_conv -> conv stack
-    ADense yu = dense(dx, TD, n * 16, TD, nullptr, 1);
+  if (!fused_tail) {  // tokens 1..16 (vision-only: all 16) -> depth_up_conv -> conv stack
+    ADense yu = dense(dx, TD, n * 16, TD, nullptr, vis ? 0 : 1);
     if ((rc = lin_wgrad<T>(cx, upconv, yu, dense(ws + L.c3, 64, n * 16, 64), 64))) return rc;
     Epi ep = mk_epi(ws + L.dc3, 64, 64);
     ep.mask = ws + L.c3;

@@ -150,3 +150,24 @@ class LocoTransformerEncoder(_Container):
         self.visual_dim = token_dim
         self.per_modal_tokens = 4 if two_by_two else 16
         self.flatten_layer = Flatten()
+
+
+class TransformerEncoder(_Container):
+    """Vision-only token encoder: depth NatureCNN (un-flattened) + 1x1 up-conv -> 16 tokens, no proprio branch
+    (reference base.py:388-494; starter/ppo_locotransformer_vision_only.py:77-80). Depth-only (in_channels == 4)
+    runs on the HIP engine; the RGB branches are constructed for checkpoint compatibility only."""
+
+    def __init__(self, in_channels, token_dim=64, two_by_two=False, **kwargs):
+        super().__init__()
+        self.in_channels = in_channels
+        self.token_dim = token_dim
+        self.two_by_two = two_by_two
+        if in_channels in (12, 16):
+            self.rgb_visual_base = NatureEncoder(12, flatten=False)
+            self.rgb_up_conv = nn.Conv2d(64, token_dim, 2, stride=2) if two_by_two else nn.Conv2d(64, token_dim, 1)
+        if in_channels in (4, 16):
+            self.depth_visual_base = NatureEncoder(4, flatten=False)
+            self.depth_up_conv = nn.Conv2d(64, token_dim, 2, stride=2) if two_by_two else nn.Conv2d(64, token_dim, 1)
+        self.visual_dim = token_dim
+        self.per_modal_tokens = 4 if two_by_two else 16
+        self.flatten_layer = Flatten()

@@ -1,5 +1,6 @@
 """Top-level networks of the PPO hot path with the reference's names and constructor signatures
-(torchrl/networks/nets.py: Net 16-55, ImpalaEncoderProjNet 194-262, LocoTransformer 909-1038).
+(torchrl/networks/nets.py: Net 16-55, NatureEncoderProjNet 133-191, ImpalaEncoderProjNet 194-262, Transformer
+784-906, LocoTransformer 909-1038).
 
 Each module owns its parameters as ordinary nn.Parameters (reference state_dict keys, reference seeded
 initialisation) and evaluates `forward` by enqueuing the hand-written gfx950 kernels of libv4l_hip.so on the
@@ -226,6 +227,115 @@ class LocoTransformer(_HipNetMixin, nn.Module):
         c.n_layers = len(self.transformer_params)
         c.ff_dim = self.transformer_params[0][1]
         c.n_enc_hidden = _fill_hidden(c.enc_hidden, enc.base.hidden_shapes, "encoder hidden")
+        c.n_head_hidden = _fill_hidden(c.head_hidden, self.append_hidden_shapes, "append hidden")
+        c.has_logstd = int(hasattr(self, "logstd"))
+        return c
+
+
+class NatureEncoderProjNet(_HipNetMixin, nn.Module):
+    """Vision-only NatureCNN net: NatureEncoder(flatten) -> 1024 -> head; the observation row is the depth stack alone:
+    `encoder.layers.*`, `seq_append_fcs.*` (reference nets.py:133-191; ppo_nature_cnn_vision_only.py)."""
+
+    def __init__(self, encoder, output_shape, visual_input_shape, append_hidden_shapes=[],
+                 append_hidden_init_func=init.basic_init, net_last_init_func=init.uniform_init, activation_func=nn.ReLU,
+                 add_ln=False, detach=False, **kwargs):
+        super().__init__()
+        self.encoder = encoder
+        self.add_ln = add_ln
+        self.detach = detach
+        self.visual_input_shape = visual_input_shape
+        self.activation_func = activation_func
+        self.output_dim = int(output_shape)
+        self.append_hidden_shapes = [int(h) for h in append_hidden_shapes]
+        self.append_fcs = _make_head(self.encoder.output_dim, self.append_hidden_shapes, output_shape, activation_func,
+                                     add_ln, append_hidden_init_func, net_last_init_func)
+        self.seq_append_fcs = nn.Sequential(*self.append_fcs)
+        self.normalizer = None
+
+    def _net_cfg(self):
+        _check_relu(self, "NatureEncoderProjNet")
+        enc = self.encoder
+        if self.detach or getattr(enc, "groups", 1) != 1 or enc.output_dim != 1024 or len(enc.layers) != 7:
+            raise NotImplementedError("vision4leg_amd: NatureEncoderProjNet needs detach=False and a flattening "
+                                      "NatureEncoder with groups=1")
+        c = _lib.NetCfg()
+        c.kind = _lib.V4L_NET_CNN_VIS
+        c.compute = default_compute()
+        c.state_dim = 0
+        c.out_dim = self.output_dim
+        c.in_channels = int(self.visual_input_shape[0])
+        c.img_hw = int(self.visual_input_shape[1])
+        c.n_enc_hidden = 0
+        c.n_head_hidden = _fill_hidden(c.head_hidden, self.append_hidden_shapes, "append hidden")
+        c.has_logstd = int(hasattr(self, "logstd"))
+        return c
+
+
+class Transformer(_HipNetMixin, nn.Module):
+    """Vision-only transformer: the 16 depth tokens through the encoder layers, mean over all tokens, then the head:
+    `encoder.*`, `visual_append_layers.*`, `visual_seq_append_fcs.*` (reference nets.py:784-906;
+    ppo_locotransformer_vision_only.py)."""
+
+    def __init__(self, encoder, output_shape, visual_input_shape, transformer_params=[], append_hidden_shapes=[],
+                 append_hidden_init_func=init.basic_init, net_last_init_func=init.uniform_init, activation_func=nn.ReLU,
+                 add_ln=False, detach=False, state_detach=False, max_pool=False, token_norm=False,
+                 use_pytorch_encoder=False, **kwargs):
+        super().__init__()
+        self.encoder = encoder
+        self.add_ln = add_ln
+        self.detach = detach
+        self.state_detach = state_detach
+        self.visual_input_shape = visual_input_shape
+        self.activation_func = activation_func
+        self.max_pool = max_pool
+        self.token_norm = token_norm
+        self.use_pytorch_encoder = use_pytorch_encoder
+        self.output_dim = int(output_shape)
+        self.transformer_params = [(int(h), int(f)) for h, f in transformer_params]
+        self.append_hidden_shapes = [int(h) for h in append_hidden_shapes]
+        d = self.encoder.visual_dim
+        if token_norm:
+            self.token_ln = nn.LayerNorm(d)
+            self.state_token_ln = nn.LayerNorm(d)
+        if use_pytorch_encoder:
+            layer = nn.TransformerEncoderLayer(d, self.transformer_params[0][0], self.transformer_params[0][1], dropout=0)
+            self.visual_trans_encoder = nn.TransformerEncoder(layer, len(self.transformer_params), nn.LayerNorm(d))
+        else:
+            self.visual_append_layers = nn.ModuleList(
+                [nn.TransformerEncoderLayer(d, n_head, ff, dropout=0) for n_head, ff in self.transformer_params])
+        self.per_modal_tokens = self.encoder.per_modal_tokens
+        self.second = self.encoder.in_channels not in (4, 12)
+        in_dim = d + (d if self.second else 0)
+        self.visual_append_fcs = _make_head(in_dim, self.append_hidden_shapes, output_shape, activation_func, add_ln,
+                                            append_hidden_init_func, net_last_init_func)
+        self.visual_seq_append_fcs = nn.Sequential(*self.visual_append_fcs)
+        self.normalizer = None
+
+    def _net_cfg(self):
+        _check_relu(self, "Transformer")
+        enc = self.encoder
+        bad = []
+        if enc.in_channels != 4: bad.append("in_channels=%d (depth-only 4 supported)" % enc.in_channels)
+        if enc.two_by_two: bad.append("two_by_two")
+        if self.detach or self.state_detach: bad.append("detach")
+        if self.max_pool: bad.append("max_pool")
+        if self.token_norm: bad.append("token_norm")
+        if self.use_pytorch_encoder: bad.append("use_pytorch_encoder")
+        if any(h != 1 for h, _ in self.transformer_params): bad.append("n_head != 1")
+        if len({f for _, f in self.transformer_params}) != 1: bad.append("per-layer dim_feedforward differs")
+        if bad:
+            raise NotImplementedError("vision4leg_amd: Transformer option(s) not on the HIP engine: " + ", ".join(bad))
+        c = _lib.NetCfg()
+        c.kind = _lib.V4L_NET_LOCO_VIS
+        c.compute = default_compute()
+        c.state_dim = 0
+        c.out_dim = self.output_dim
+        c.in_channels = int(self.visual_input_shape[0])
+        c.img_hw = int(self.visual_input_shape[1])
+        c.token_dim = int(enc.token_dim)
+        c.n_layers = len(self.transformer_params)
+        c.ff_dim = self.transformer_params[0][1]
+        c.n_enc_hidden = 0
         c.n_head_hidden = _fill_hidden(c.head_hidden, self.append_hidden_shapes, "append hidden")
         c.has_logstd = int(hasattr(self, "logstd"))
         return c

@@ -1,6 +1,6 @@
 """Gaussian policies of the PPO hot path with the reference's names and method protocol
 (torchrl/policies/continuous_policy.py: GaussianContPolicyBase 77-146, ...BasicBias 239-254,
-...ImpalaEncoderProj 275-290, ...LocoTransformer 478-492).
+...NatureEncoderProj 257-272, ...ImpalaEncoderProj 275-290, ...Transformer 461-475, ...LocoTransformer 478-492).
 
 A policy is a top-level HIP net plus the state-independent `logstd` parameter. `forward/explore/eval_act/update`
 evaluate the trunk and the Gaussian head (clamp, exp, entropy, log-prob) with libv4l_hip.so kernels; only the
@@ -18,7 +18,8 @@ LOG_SIG_MAX = 2
 LOG_SIG_MIN = -5
 
 __all__ = ["LOG_SIG_MAX", "LOG_SIG_MIN", "GaussianContPolicyBase", "GaussianContPolicyBasicBias",
-           "GaussianContPolicyImpalaEncoderProj", "GaussianContPolicyLocoTransformer", "RolloutActor"]
+           "GaussianContPolicyImpalaEncoderProj", "GaussianContPolicyLocoTransformer",
+           "GaussianContPolicyNatureEncoderProj", "GaussianContPolicyTransformer", "RolloutActor"]
 
 
 class RolloutActor:
@@ -118,6 +119,22 @@ class GaussianContPolicyImpalaEncoderProj(networks.ImpalaEncoderProjNet, Gaussia
 
 
 class GaussianContPolicyLocoTransformer(networks.LocoTransformer, GaussianContPolicyBase):
+    def __init__(self, output_shape, tanh_action=False, log_init=0.125, **kwargs):
+        super().__init__(output_shape=output_shape, **kwargs)
+        self._init_policy(output_shape, tanh_action, log_init)
+
+    forward = GaussianContPolicyBase.forward
+
+
+class GaussianContPolicyNatureEncoderProj(networks.NatureEncoderProjNet, GaussianContPolicyBase):
+    def __init__(self, output_shape, tanh_action=False, log_init=0.125, **kwargs):
+        super().__init__(output_shape=output_shape, **kwargs)
+        self._init_policy(output_shape, tanh_action, log_init)
+
+    forward = GaussianContPolicyBase.forward
+
+
+class GaussianContPolicyTransformer(networks.Transformer, GaussianContPolicyBase):
     def __init__(self, output_shape, tanh_action=False, log_init=0.125, **kwargs):
         super().__init__(output_shape=output_shape, **kwargs)
         self._init_policy(output_shape, tanh_action, log_init)
