@@ -125,6 +125,8 @@ class Epoch:
         pf, vf, net = self.pf, self.vf, self.pf.hip
         if self.actor is not None:  # fused rollout step (shared encoder pass, one graph replay per env step)
             self.actor.seek(0)
+            if os.environ.get("V4L_BULK_NOISE", "1") != "0":
+                self.actor.draw_noise(T)  # the epoch's T x E x A exploration normals in one generator call
             for t in range(T):
                 self.actor.step(self.obs[t * E:(t + 1) * E])
             return

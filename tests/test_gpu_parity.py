@@ -481,6 +481,32 @@ def test_rollout_actor_matches_separate_calls(name, mode, graph, device):
     assert torch.equal(state, ref_state) and (image is None or torch.equal(image, ref_image))
 
 
+def test_rollout_bulk_noise(device):
+    """RolloutActor.draw_noise(n): one generator call serves the next n exploration steps (action = mean + std * slice),
+    then the actor returns to per-step draws; deterministic steps do not consume slices."""
+    from vision4leg_amd.torchrl.policies import RolloutActor
+    case = util.CASES["loco_s84"]
+    E = 4
+    pf, vf = _build(case, "bf16", device)
+    actor = RolloutActor(pf, vf, E)
+    rs = np.random.RandomState(2)
+    ob = torch.tensor(np.concatenate([rs.randn(E, case["S"]), rs.randn(E, 4 * 64 * 64)], 1), dtype=torch.float32, device=device)
+    torch.manual_seed(5)
+    actor.draw_noise(3)
+    torch.manual_seed(5)
+    want = torch.randn(3, E, case["A"], device=device)
+    det = actor.step(ob, deterministic=True)
+    assert torch.equal(det["action"], det["mean"])
+    for t in range(3):
+        out = actor.step(ob)
+        assert torch.allclose(out["action"], out["mean"] + out["std"] * want[t], rtol=1e-5, atol=1e-6), t
+    torch.manual_seed(9)
+    out = actor.step(ob)  # slices used up: a fresh per-step draw
+    torch.manual_seed(9)
+    eps = torch.randn(E, case["A"], device=device)
+    assert torch.allclose(out["action"], out["mean"] + out["std"] * eps, rtol=1e-5, atol=1e-6)
+
+
 @pytest.mark.parametrize("mode", MODES)
 @pytest.mark.parametrize("name", ["loco_s84", "cnn_s93", "mlp_s93", "loco_vis", "cnn_vis"])
 def test_batch1_deployment_call(name, mode, device):

@@ -425,6 +425,17 @@ class HipActor:
   def seek(self, t):
     check(self.L.v4l_actor_seek(self.h, int(t), _stream()), "v4l_actor_seek")
 
+  def draw_noise(self, n_steps):
+    """Draw the standard normals of the next n_steps env steps with ONE generator call ([n_steps][E][A], torch's
+    generator on the current stream) instead of one 5 us launch per step; the following non-deterministic eager steps
+    consume one [E][A] slice each. Same distribution and generator as the per-step draws, a different position in its
+    stream — call it only where reproducing a per-step seeded sequence does not matter."""
+    E, A = self.eps.shape
+    if getattr(self, "_bulk_buf", None) is None or self._bulk_buf.shape[0] != n_steps:
+      self._bulk_buf = torch.empty(n_steps, E, A, dtype=torch.float32, device=self.device)
+    self._bulk_buf.normal_()
+    self._bulk, self._bulk_t = self._bulk_buf, 0
+
   def step(self, obs, deterministic=False):
     """obs: [E][S+C*H*W] float32 cuda rows of this env step. Returns a dict of views of fixed output buffers
     (valid until the next step): action/mean/std [E][A], ent/value [E][1]. deterministic: no draw, action == mean
@@ -449,7 +460,14 @@ class HipActor:
         self.obs.copy_(obs.reshape(self.obs.shape), non_blocking=True)  # a captured graph reads the fixed buffer
       else:
         args = (C.c_void_p(obs.data_ptr()),) + args[1:]  # eager launches read the caller's rows in place
-    if not deterministic:
+    bulk = getattr(self, "_bulk", None)
+    if not deterministic and bulk is not None and not self.graph:
+      # this step's [E][A] slice of the draws made by draw_noise(): the kernel reads it in place
+      args = args[:1] + (C.c_void_p(bulk.data_ptr() + self._bulk_t * bulk.stride(0) * 4),) + args[2:]
+      self._bulk_t += 1
+      if self._bulk_t >= bulk.shape[0]:
+        self._bulk = None
+    elif not deterministic:
       self.eps.normal_()  # torch's generator: the same standard-normal draws Normal(mean, std).sample() would use
       self._eps_zero = False
     elif not getattr(self, "_eps_zero", False):

@@ -39,6 +39,10 @@ class RolloutActor:
     def seek(self, t):
         self._actor.seek(t)
 
+    def draw_noise(self, n_steps):
+        """One generator call for the exploration noise of the next n_steps steps (see HipActor.draw_noise)."""
+        self._actor.draw_noise(n_steps)
+
     def step(self, ob, deterministic=False):
         return self._actor.step(ob, deterministic)
 
