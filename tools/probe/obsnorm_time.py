@@ -3,7 +3,6 @@ import sys, time
 import numpy as np, torch
 sys.path.insert(0, ".")
 from vision4leg_amd.torchrl.env import NormObsWithImg
-from oracle.obsnorm_c import NormalizerOracle
 dev = torch.device("cuda:0")
 for E in (16, 32, 64):
     S, IMG = 93, 4 * 64 * 64
