@@ -481,6 +481,99 @@ def test_rollout_actor_matches_separate_calls(name, mode, graph, device):
     assert torch.equal(state, ref_state) and (image is None or torch.equal(image, ref_image))
 
 
+@pytest.mark.parametrize("buffer", ["host", "device"])
+def test_train_loop_end_to_end(buffer, device, tmp_path):
+    """PPO(...).train() as starter/ppo_locotransformer.py:105-122 drives it: a collector with the reference's
+    take_actions protocol (collector/on_policy.py:90-155: torch.Tensor(ob) -> pf.explore -> vf -> add_sample with
+    bool terminals and `[False]` time limits) over a synthetic vec env, two epochs, eval + snapshots. Checks the
+    bookkeeping the starters / viewers rely on: 18-key update infos, update counters, LR schedule, checkpoint files
+    that load back into a fresh policy and reproduce its actions."""
+    import vision4leg_amd.torchrl.networks as networks
+    import vision4leg_amd.torchrl.policies as policies
+    from vision4leg_amd.torchrl.algo import PPO
+    from vision4leg_amd.torchrl.replay_buffers import DeviceOnPolicyReplayBuffer, OnPolicyReplayBuffer
+    case = dict(util.CASES["loco_s84"])
+    E, T, B, D = 4, 8, 16, util.obs_dim(case)
+    os.environ["V4L_COMPUTE"] = "bf16"
+    torch.manual_seed(0)
+    pf, vf = util.build_nets(networks, policies, case)
+    rs = np.random.RandomState(0)
+
+    class Env:
+        def draw(self):
+            return np.concatenate([np.clip(rs.randn(E, case["S"]), -10, 10), np.clip(rs.randn(E, D - case["S"]), -2.5, 2.8)], 1)
+
+        def step(self, acts):
+            assert acts.shape == (E, case["A"]) and acts.dtype == np.float32
+            return self.draw(), rs.randn(E, 1), rs.rand(E, 1) < 0.2, {}
+
+    class Collector:
+        epoch_frames = E * T
+
+        def __init__(self, buf):
+            self.env, self.buf, self.ob, self.terminated = Env(), buf, None, False
+            self.ob = self.env.draw()
+
+        def train_one_epoch(self):
+            tot = 0.0
+            for _ in range(T):
+                ob_t = torch.Tensor(self.ob).to(device)
+                acts = pf.explore(ob_t)["action"].detach().cpu().numpy()
+                values = vf(ob_t).detach().cpu().numpy()
+                nxt, rew, done, _ = self.env.step(acts)
+                self.buf.add_sample({"obs": self.ob, "next_obs": nxt, "acts": acts, "values": values, "rewards": rew,
+                                     "terminals": done, "time_limits": [False]})
+                self.ob = nxt
+                tot += rew.sum()
+            return {"train_rewards": [tot], "train_epoch_reward": tot}
+
+        def eval_one_epoch(self):
+            a = pf.eval_act(torch.Tensor(self.ob[:1]).to(device))
+            assert a.shape == (case["A"],)
+            return {"eval_rewards": [float(a.sum())]}
+
+        def terminate(self):
+            self.terminated = True
+
+    class Logger:
+        def __init__(self):
+            self.updates, self.epochs = [], []
+
+        def add_update_info(self, info):
+            self.updates.append(info)
+
+        def add_epoch_info(self, epoch, frames, dt, infos):
+            self.epochs.append((epoch, frames, infos))
+
+    cls = DeviceOnPolicyReplayBuffer if buffer == "device" else OnPolicyReplayBuffer
+    buf = cls(max_replay_buffer_size=E * T, env_nums=E, time_limit_filter=True)
+    coll, log = Collector(buf), Logger()
+    before = {k: v.detach().clone() for k, v in pf.state_dict().items()}
+    agent = PPO(pf=pf, vf=vf, plr=1e-4, vlr=1e-4, clip_para=0.2, opt_epochs=3, tau=0.95, shuffle=True, entropy_coeff=0.005,
+                env=None, replay_buffer=buf, collector=coll, logger=log, device=device, discount=0.99, num_epochs=2,
+                batch_size=B, save_interval=1, eval_interval=1, save_dir=str(tmp_path))
+    agent.train()
+    n_upd = 2 * 3 * (E * T // B)
+    assert coll.terminated and agent.training_update_num == n_upd and agent.current_epoch == 1
+    assert len(log.updates) == n_upd and all(sorted(u) == sorted(util.STAT_KEYS) for u in log.updates)
+    assert all(np.isfinite(list(u.values())).all() for u in log.updates)
+    assert [e[0] for e in log.epochs] == [0, 1] and log.epochs[1][1] == 2 * E * T
+    assert {"Train___Time", "Explore_Time", "Running_Average_Rewards"} <= set(log.epochs[0][2])
+    assert agent.pf_optimizer.param_groups[0]["lr"] == pytest.approx(1e-4 * (1 - 1 / 2))
+    moved = max((pf.state_dict()[k] - before[k].to(device)).abs().max().item() for k in before)
+    assert 1e-5 < moved < 1e-2
+    for tag in ("0", "1", "best", "finish"):
+        assert os.path.exists(os.path.join(str(tmp_path), "model_pf_%s.pth" % tag)), tag
+        assert os.path.exists(os.path.join(str(tmp_path), "model_vf_%s.pth" % tag)), tag
+    # the checkpoint loads into a fresh policy (reference key names) and reproduces the trained policy's action
+    torch.manual_seed(123)
+    pf2, _ = util.build_nets(networks, policies, case)
+    pf2.load_state_dict(torch.load(os.path.join(str(tmp_path), "model_pf_finish.pth"), map_location="cpu"))
+    pf2.to(device)
+    x = torch.Tensor(coll.ob[:1]).to(device)
+    assert np.array_equal(pf2.eval_act(x), pf.eval_act(x))
+
+
 def test_rollout_bulk_noise(device):
     """RolloutActor.draw_noise(n): one generator call serves the next n exploration steps (action = mean + std * slice),
     then the actor returns to per-step draws; deterministic steps do not consume slices."""
