@@ -722,6 +722,80 @@ def test_fused_conv_backward_equals_layerwise(name, mode, device):
         assert e <= tol, (k, e)
 
 
+@pytest.mark.parametrize("name", ["loco_s84", "cnn_s93"])
+def test_two_rank_update_equals_big_batch(name, device):
+    """The data-parallel rule on one GPU, no process group: two 'ranks' (world_size = 2 trainers with identical
+    parameters) each run the grads phases on their own minibatch of n rows, the gradient buffers and the three
+    advantage sums are added by hand (what the RCCL all-reduce does), both step — and must land where ONE trainer lands
+    that sees the 2n-row batch (N GPUs == one process with the N*B batch: losses pre-scaled by 1/(n*world),
+    advantages normalised over the global batch, clip after averaging)."""
+    import copy as _copy
+    from vision4leg_amd.engine import HipTrainer
+    mode = "f32"
+    case = util.CASES[name]
+    n = 16
+    rs = np.random.RandomState(31)
+    D = util.obs_dim(case)
+    obs = np.concatenate([np.clip(rs.randn(2 * n, case["S"]), -10, 10), np.clip(rs.randn(2 * n, D - case["S"]), -2.5, 2.8)], 1)
+    acts, advs, rets = 0.1 * rs.randn(2 * n, case["A"]), rs.randn(2 * n), rs.randn(2 * n)
+    t = lambda a: torch.tensor(a, dtype=torch.float32, device=device)
+
+    def make(world, batch):
+        pf, vf = _build(case, mode, device)
+        tpf = _copy.deepcopy(pf).to(device)
+        tr = HipTrainer(pf.hip, vf.hip, tpf.hip, batch, 0.2, 0.005, world_size=world)
+        tr.sync_target()
+        return pf, vf, tpf, tr
+
+    def rollout(net, lo, hi):
+        net.ensure_bound()
+        st, im = net.alloc_rollout(hi - lo, device)
+        net.ingest(t(obs[lo:hi]), st, im)
+        return HipTrainer.rollout(st, im, t(acts[lo:hi]), t(advs[lo:hi]), t(rets[lo:hi]), t(rets[lo:hi]))
+
+    ranks = [make(2, n) for _ in range(2)]
+    ros = [rollout(r[0].hip, i * n, (i + 1) * n) for i, r in enumerate(ranks)]
+    stats = [torch.zeros(1, 24, device=device) for _ in ranks]
+    for (pf, vf, tpf, tr), ro, st in zip(ranks, ros, stats):
+        tr._pre(n)
+        tr.begin(None, st, 1e-4, 1e-4)
+        tr.critic_grads(ro, n)
+    g = ranks[0][3].g_vf + ranks[1][3].g_vf
+    a = ranks[0][3].stats_cur()[18:21] + ranks[1][3].stats_cur()[18:21]
+    for _, _, _, tr in ranks:
+        tr.g_vf.copy_(g)
+        tr.stats_cur()[18:21].copy_(a)
+        tr.critic_step()
+    for (_, _, _, tr), ro in zip(ranks, ros):
+        tr.actor_grads(ro, n)
+    g = ranks[0][3].g_pf + ranks[1][3].g_pf
+    for _, _, _, tr in ranks:
+        tr.g_pf.copy_(g)
+        tr.actor_step()
+    pfC, vfC, _, trC = make(1, 2 * n)
+    stC = torch.zeros(1, 24, device=device)
+    trC.update(rollout(pfC.hip, 0, 2 * n), None, 2 * n, 1e-4, 1e-4, stC)
+    torch.cuda.synchronize()
+    # the two ranks stay bit-identical (same summed gradient, deterministic kernels)
+    for k, v in ranks[0][0].state_dict().items():
+        assert torch.equal(v, ranks[1][0].state_dict()[k]), k
+    for k, v in ranks[0][1].state_dict().items():
+        assert torch.equal(v, ranks[1][1].state_dict()[k]), k
+    # global advantage statistics and the pre-clip gradient norms equal the big batch's
+    s0, sC = stats[0][0].cpu().numpy(), stC[0].cpu().numpy()
+    r0 = ranks[0][3].stats_cur().cpu().numpy()
+    assert np.allclose(r0[0:2], sC[0:2], rtol=1e-5), (r0[0:2], sC[0:2])            # advs/mean, advs/std
+    assert np.allclose(r0[[5, 17]], sC[[5, 17]], rtol=1e-4), (r0[[5, 17]], sC[[5, 17]])  # grad_norm/vf, grad_norm/pf
+    # and so do the parameters: |diff| far below one Adam step (lr = 1e-4) on average, never above 2*lr
+    for tag, a_net, c_net in (("pf", ranks[0][0], pfC), ("vf", ranks[0][1], vfC)):
+        tot = cnt = 0.0
+        for k, v in a_net.state_dict().items():
+            d = (v - c_net.state_dict()[k]).abs()
+            assert d.max().item() <= 2.1e-4, (tag, k, d.max().item())
+            tot += d.sum().item(); cnt += d.numel()
+        assert tot / cnt <= 2e-7, (tag, tot / cnt)
+
+
 def _dp_phases_worker(mode, out_path):
     """Runs in a fresh process: 1-rank RCCL group, the data-parallel phase sequence vs the fused single-GPU update."""
     os.environ["V4L_COMPUTE"] = mode
