@@ -330,6 +330,18 @@ def roofline(ep, compute, breakdown_path):
         except Exception:
             pass
     all_flops = sum(r[3] for r in rows)
+    # the transformer block's own kernels (north star: MFMA fraction "for the transformer block"; SURVEY 8d: kernel time x
+    # known FLOPs over the block's kernels only): fused layer forward / backward launches and their weight-grad GEMM
+    tb = [r for r in rows if r[0].split("|")[1] in ("layer", "layer.wgrad", "attn", "ln1", "ln2")
+          or ".self_attn." in r[0] or ".linear1." in r[0] or ".linear2." in r[0]]
+    tblock = None
+    if tb:
+        tb_us, tb_fl = sum(r[2] for r in tb), sum(r[3] for r in tb)
+        tblock = {"tflops": round(tb_fl / tb_us * 1e-6, 2), "mfma_frac": round(tb_fl / tb_us * 1e-6 / PEAK[compute], 5),
+                  "share_of_kernel_time": round(tb_us / total_us, 4),
+                  "kernels": sorted({r[0].split("|")[-1] for r in tb}),
+                  "note": "2*M*N*K FLOPs of the launches / their HIP-event time; at B = 1024 one layer pass is 1.8 GFLOP "
+                          "(0.7 us at peak) inside a 30-launch dependent chain: latency-bound by size, see DESIGN.md section 4"}
     return {
         "bound": "hbm" if hbm_bound else "mfma", "kernel": kern,
         "achieved": round(gbs, 1) if hbm_bound else round(tf, 2),
@@ -340,6 +352,7 @@ def roofline(ep, compute, breakdown_path):
         "hbm_frac": round(gbs / PEAK_HBM, 5) if gbs else None, "mfma_frac": round(tf / PEAK[compute], 5),
         "avg_launch_us": round(avg_us, 2), "launches": calls, "share_of_kernel_time": round(us / total_us, 4),
         "all_kernels_tflops": round(all_flops / total_us * 1e-6, 2),
+        "transformer_block": tblock,
         "method": "HIP events around every launch of one extra (untimed) epoch-update on the launch stream; achieved = "
                   "algorithmic bytes (bench.py algo_bytes, DESIGN.md section 4) or 2*M*N*K FLOPs per launch / average launch time",
     }
