@@ -441,32 +441,49 @@ __device__ __forceinline__ float dot64(const float* a, const float* b) {  // 16-
   return s0 + s1;
 }
 
-// LayerNorm of the ROWS LDS rows; optionally (training) saves xhat / rstd / the output rows < nrows to global memory
+// LayerNorm of the ROWS LDS rows; optionally (training) saves xhat / rstd / the output rows < nrows to global memory.
+// A row is owned by a quarter wave (16 lanes x 4 consecutive columns): both reductions are 4 DPP row_ror adds inside the
+// 16-lane DPP row, every load / store is 16 bytes, and a wave normalises 4 rows per step — ROWS/16 independent steps per
+// wave, all in flight together. (One row per wave, lane = column, cost 2 x (4 DPP + 4 v_readlane) and 4-byte accesses
+// per row: 7.5 K cycles of the 60 K a training-forward block takes; this form: see DESIGN.md.)
 template <int ROWS, int U, typename SO>
 __device__ __forceinline__ void ln_rows(const float* z, int ldz, float* out, int ldo, const float* __restrict__ g,
                                         const float* __restrict__ be, int wave, int lane, int nrows, float* s_xh,
                                         float* s_rs, SO* s_out) {
-  const float gg = g[lane], bb = be[lane];
-  // wave w owns rows w, w+4, ...: U independent rows are kept in flight (their reduce chains interleave)
-  for (int r0 = wave; r0 < ROWS; r0 += 4 * U) {
-    float v[U], mean[U], c[U], var[U];
+  (void)U;
+  const int l16 = lane & 15, c4 = l16 * 4, q = lane >> 4;
+  const float4 gg = *reinterpret_cast<const float4*>(g + c4), bb = *reinterpret_cast<const float4*>(be + c4);
+  constexpr int IT = ROWS / 16;
+  float4 v[IT];
+  float mean[IT], var[IT];
 #pragma unroll
-    for (int u = 0; u < U; ++u) v[u] = z[(r0 + 4 * u) * ldz + lane];
+  for (int it = 0; it < IT; ++it) v[it] = *reinterpret_cast<const float4*>(z + (it * 16 + wave * 4 + q) * ldz + c4);
 #pragma unroll
-    for (int u = 0; u < U; ++u) mean[u] = wave_sum(v[u]) * (1.f / TD);
+  for (int it = 0; it < IT; ++it) {
+    float s = (v[it].x + v[it].y) + (v[it].z + v[it].w);
+    s += dpp_mov<0x128>(s); s += dpp_mov<0x124>(s); s += dpp_mov<0x122>(s); s += dpp_mov<0x121>(s);
+    mean[it] = s * (1.f / TD);
+  }
 #pragma unroll
-    for (int u = 0; u < U; ++u) { c[u] = v[u] - mean[u]; var[u] = wave_sum(c[u] * c[u]) * (1.f / TD); }
+  for (int it = 0; it < IT; ++it) {
+    v[it].x -= mean[it]; v[it].y -= mean[it]; v[it].z -= mean[it]; v[it].w -= mean[it];
+    float s = (v[it].x * v[it].x + v[it].y * v[it].y) + (v[it].z * v[it].z + v[it].w * v[it].w);
+    s += dpp_mov<0x128>(s); s += dpp_mov<0x124>(s); s += dpp_mov<0x122>(s); s += dpp_mov<0x121>(s);
+    var[it] = s * (1.f / TD);
+  }
 #pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const int r = r0 + 4 * u;
-      const float rs = 1.f / sqrtf(var[u] + 1e-5f);
-      const float xh = c[u] * rs;
-      const float o = fmaf(xh, gg, bb);
-      if (out != nullptr) out[r * ldo + lane] = o;
-      if (r < nrows) {
-        if (s_xh != nullptr) { s_xh[r * TD + lane] = xh; if (lane == 0) s_rs[r] = rs; }
-        if (s_out != nullptr) s_out[r * TD + lane] = (SO)o;
+  for (int it = 0; it < IT; ++it) {
+    const int r = it * 16 + wave * 4 + q;
+    const float rs = 1.f / sqrtf(var[it] + 1e-5f);
+    const float4 xh = {v[it].x * rs, v[it].y * rs, v[it].z * rs, v[it].w * rs};
+    const float4 o = {fmaf(xh.x, gg.x, bb.x), fmaf(xh.y, gg.y, bb.y), fmaf(xh.z, gg.z, bb.z), fmaf(xh.w, gg.w, bb.w)};
+    if (out != nullptr) *reinterpret_cast<float4*>(out + r * ldo + c4) = o;
+    if (r < nrows) {
+      if (s_xh != nullptr) {
+        *reinterpret_cast<float4*>(s_xh + r * TD + c4) = xh;
+        if (l16 == 0) s_rs[r] = rs;
       }
+      if (s_out != nullptr) st4(s_out + r * TD + c4, o.x, o.y, o.z, o.w);
     }
   }
 }
@@ -534,41 +551,73 @@ __global__ __launch_bounds__(256) void infer_layer_kernel(InfLayerPair pr, InfHe
     }
   }
   {  // attention (17 tokens, one head, scale 1/8), fp32 VALU, the whole block on all of its samples
-    for (int idx = tid; idx < ns * NTOK * NTOK; idx += 256) {
-      const int sm = idx / (NTOK * NTOK), pr2 = idx - sm * NTOK * NTOK;
-      const int i = pr2 / NTOK, j = pr2 - i * NTOK;
+    // scores in 2x2 register tiles (rows 2a,2a+1 x keys 2b,2b+1; 81 tiles per sample, one per thread): every q / k row
+    // fragment read from LDS feeds two dot products
+    for (int idx = tid; idx < ns * 81; idx += 256) {
+      const int sm = idx / 81, t2 = idx - sm * 81;
+      const int a2 = t2 / 9, b2 = t2 - a2 * 9;
+      const int i0 = 2 * a2, i1 = min(i0 + 1, NTOK - 1), j0 = 2 * b2, j1 = min(j0 + 1, NTOK - 1);
       const float* q = big + (sm * NTOK) * LY::LDQ;
-      sp[(sm * NTOK + i) * ATT_PLD + j] = dot64(q + i * LY::LDQ, q + j * LY::LDQ + TD) * 0.125f;
-    }
-    __syncthreads();
-    if (tid < nrows) {  // one thread per score row
-      float* p = sp + tid * ATT_PLD;
-      float mx = -INFINITY;
-#pragma unroll
-      for (int j = 0; j < NTOK; ++j) mx = fmaxf(mx, p[j]);
-      float e[NTOK], sum = 0.f;
-#pragma unroll
-      for (int j = 0; j < NTOK; ++j) { e[j] = expf(p[j] - mx); sum += e[j]; }
-      const float inv = 1.f / sum;
-#pragma unroll
-      for (int j = 0; j < NTOK; ++j) {
-        const float pv = e[j] * inv;
-        p[j] = pv;
-        if (w.s_P != nullptr) w.s_P[(row0 + tid) * NTOK + j] = pv;
+      const float *qa = q + i0 * LY::LDQ, *qb = q + i1 * LY::LDQ, *ka = q + j0 * LY::LDQ + TD, *kb = q + j1 * LY::LDQ + TD;
+      float s00 = 0.f, s01 = 0.f, s10 = 0.f, s11 = 0.f;
+#pragma unroll 4
+      for (int d = 0; d < TD; d += 4) {
+        const float4 x0 = *reinterpret_cast<const float4*>(qa + d), x1 = *reinterpret_cast<const float4*>(qb + d);
+        const float4 y0 = *reinterpret_cast<const float4*>(ka + d), y1 = *reinterpret_cast<const float4*>(kb + d);
+        s00 = fmaf(x0.x, y0.x, s00); s00 = fmaf(x0.y, y0.y, s00); s00 = fmaf(x0.z, y0.z, s00); s00 = fmaf(x0.w, y0.w, s00);
+        s01 = fmaf(x0.x, y1.x, s01); s01 = fmaf(x0.y, y1.y, s01); s01 = fmaf(x0.z, y1.z, s01); s01 = fmaf(x0.w, y1.w, s01);
+        s10 = fmaf(x1.x, y0.x, s10); s10 = fmaf(x1.y, y0.y, s10); s10 = fmaf(x1.z, y0.z, s10); s10 = fmaf(x1.w, y0.w, s10);
+        s11 = fmaf(x1.x, y1.x, s11); s11 = fmaf(x1.y, y1.y, s11); s11 = fmaf(x1.z, y1.z, s11); s11 = fmaf(x1.w, y1.w, s11);
+      }
+      float* p0 = sp + (sm * NTOK + i0) * ATT_PLD;
+      float* p1 = sp + (sm * NTOK + i1) * ATT_PLD;
+      p0[j0] = s00 * 0.125f;
+      if (j0 + 1 < NTOK) p0[j0 + 1] = s01 * 0.125f;
+      if (i0 + 1 < NTOK) {
+        p1[j0] = s10 * 0.125f;
+        if (j0 + 1 < NTOK) p1[j0 + 1] = s11 * 0.125f;
       }
     }
     __syncthreads();
-    for (int r = wave; r < ROWS; r += 4) {  // ctx row r = P[r] V(sample of r); rows beyond the last sample: zeros
-      float a = 0.f;
+    // softmax: a quarter wave per score row (lane l: key l; key 16 is carried by every lane), max / sum by DPP row_ror
+    for (int r = (tid >> 4); r < ROWS; r += 16) {
+      const int l = lane & 15;
+      float* p = sp + min(r, nrows - 1) * ATT_PLD;
+      const float pl = p[l], p16 = p[16];
+      float mx = fmaxf(pl, p16);
+      mx = fmaxf(mx, dpp_mov<0x128>(mx)); mx = fmaxf(mx, dpp_mov<0x124>(mx));
+      mx = fmaxf(mx, dpp_mov<0x122>(mx)); mx = fmaxf(mx, dpp_mov<0x121>(mx));
+      const float el = expf(pl - mx), e16 = expf(p16 - mx);
+      float sum = el;
+      sum += dpp_mov<0x128>(sum); sum += dpp_mov<0x124>(sum); sum += dpp_mov<0x122>(sum); sum += dpp_mov<0x121>(sum);
+      const float inv = 1.f / (sum + e16);
+      if (r < nrows) {
+        p[l] = el * inv;
+        if (l == 0) p[16] = e16 * inv;
+        if (w.s_P != nullptr) {
+          w.s_P[(row0 + r) * NTOK + l] = el * inv;
+          if (l == 0) w.s_P[(row0 + r) * NTOK + 16] = e16 * inv;
+        }
+      }
+    }
+    __syncthreads();
+    // ctx = P V: thread = (row, 4 columns); the row's 17 probabilities are shared by its 16 lanes, V rows read as float4
+    for (int idx = tid; idx < ROWS * 16; idx += 256) {
+      const int r = idx >> 4, c4 = (idx & 15) * 4;
+      float4 a = {0.f, 0.f, 0.f, 0.f};
       if (r < nrows) {
         const int sm = r / NTOK;
-        const float* v = big + (sm * NTOK) * LY::LDQ + 2 * TD + lane;
+        const float* v = big + (sm * NTOK) * LY::LDQ + 2 * TD + c4;
         const float* p = sp + r * ATT_PLD;
 #pragma unroll
-        for (int j = 0; j < NTOK; ++j) a = fmaf(p[j], v[j * LY::LDQ], a);
-        if (w.s_ctx != nullptr) reinterpret_cast<T*>(w.s_ctx)[(row0 + r) * TD + lane] = (T)a;
+        for (int j = 0; j < NTOK; ++j) {
+          const float pj = p[j];
+          const float4 vv = *reinterpret_cast<const float4*>(v + j * LY::LDQ);
+          a.x = fmaf(pj, vv.x, a.x); a.y = fmaf(pj, vv.y, a.y); a.z = fmaf(pj, vv.z, a.z); a.w = fmaf(pj, vv.w, a.w);
+        }
+        if (w.s_ctx != nullptr) st4(reinterpret_cast<T*>(w.s_ctx) + (row0 + r) * TD + c4, a.x, a.y, a.z, a.w);
       }
-      cx[r * LY::LDX + lane] = a;
+      *reinterpret_cast<float4*>(cx + r * LY::LDX + c4) = a;
     }
   }
   __syncthreads();
