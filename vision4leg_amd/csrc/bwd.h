@@ -50,56 +50,65 @@ template <typename T, int SPW> struct BwdLayLds {
   static constexpr size_t f_b = (size_t)ROWS * LDF * sizeof(T);
   static constexpr size_t big_b = qkv_b > f_b ? qkv_b : f_b;
   static constexpr size_t p_b = (size_t)2 * SPW * NTOK * ATT_PLD * 4;  // P and dS of the block's samples
-  static constexpr size_t red_b = (size_t)2 * 4 * TD * 4;
-  static constexpr size_t bytes = 2 * a_b + big_b + p_b + red_b;     // a | b | df / qkv->dqkv | P,dS | LN partials
+  static constexpr size_t red_b = (size_t)2 * 16 * TD * 4;
+  static constexpr size_t bytes = 2 * a_b + big_b + p_b + red_b;     // a | b | df / qkv->dqkv | P,dS | LN partials [2][16 quarter waves][64]
 };
 
-// LayerNorm backward, in place over the 80 LDS rows of `d` (rows >= nrows hold zeros and stay zero); the rows < nrows
+// LayerNorm backward, in place over the ROWS LDS rows of `d` (rows >= nrows hold zeros and stay zero); the rows < nrows
 // also go to o_dz (global). Leaves the block's dgamma/dbeta partial in gpart/bpart[64]. Contains one __syncthreads.
+// Like ln_rows (infer.h): a row is owned by a quarter wave (16 lanes x 4 consecutive columns), both row reductions are
+// DPP row_ror adds, accesses are 16 bytes; the dgamma / dbeta column sums are kept per lane and combined over the 16
+// quarter waves of the block through `red` ([2][16][64]) in a fixed order.
 template <int ROWS, typename T>
 __device__ __forceinline__ void ln_bwd_rows(float* d, int ld, const float* __restrict__ xh, const float* __restrict__ rs,
                                             const float* __restrict__ gamma, int wave, int lane, int nrows,
                                             T* __restrict__ o_dz, float* red, float* __restrict__ gpart,
                                             float* __restrict__ bpart) {
-  const float g = gamma[lane];
-  float ag = 0.f, ab = 0.f;
-  constexpr int U = ROWS / 16;  // 80 -> 5, 48 -> 3 rows in flight per wave
-  for (int r0 = wave; r0 < ROWS; r0 += 4 * U) {
-    float dd[U], x[U], rr[U], dxh[U], c1[U], c2[U];
+  const int l16 = lane & 15, c4 = l16 * 4, q = lane >> 4;
+  const float4 g = *reinterpret_cast<const float4*>(gamma + c4);
+  constexpr int IT = ROWS / 16;
+  float4 ag = {0.f, 0.f, 0.f, 0.f}, ab = {0.f, 0.f, 0.f, 0.f};
+  float4 dd[IT], x[IT];
+  float rr[IT];
 #pragma unroll
-    for (int u = 0; u < U; ++u) {  // loads are unconditional (row 0 stands in for the padding rows), then selected
-      const int r = r0 + 4 * u;
-      const bool ok = r < nrows;
-      const int o = ok ? r : 0;
-      const float xv = xh[o * TD + lane], rv = rs[o];
-      dd[u] = d[r * ld + lane];
-      x[u] = ok ? xv : 0.f;
-      rr[u] = ok ? rv : 0.f;
-    }
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      ag = fmaf(dd[u], x[u], ag);
-      ab += dd[u];
-      dxh[u] = dd[u] * g;
-    }
-#pragma unroll
-    for (int u = 0; u < U; ++u) c1[u] = wave_sum(dxh[u]);
-#pragma unroll
-    for (int u = 0; u < U; ++u) c2[u] = wave_sum(dxh[u] * x[u]);
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const int r = r0 + 4 * u;
-      const float dz = rr[u] * (dxh[u] - c1[u] * (1.f / TD) - x[u] * (c2[u] * (1.f / TD)));
-      d[r * ld + lane] = dz;
-      if (r < nrows) o_dz[r * TD + lane] = (T)dz;
-    }
+  for (int it = 0; it < IT; ++it) {  // loads are unconditional (row 0 stands in for the padding rows), then selected
+    const int r = it * 16 + wave * 4 + q;
+    const bool ok = r < nrows;
+    const int o = ok ? r : 0;
+    const float4 xv = *reinterpret_cast<const float4*>(xh + o * TD + c4);
+    const float rv = rs[o];
+    dd[it] = *reinterpret_cast<const float4*>(d + r * ld + c4);
+    x[it] = ok ? xv : float4{0.f, 0.f, 0.f, 0.f};
+    rr[it] = ok ? rv : 0.f;
   }
-  red[wave * TD + lane] = ag;
-  red[4 * TD + wave * TD + lane] = ab;
+#pragma unroll
+  for (int it = 0; it < IT; ++it) {
+    const int r = it * 16 + wave * 4 + q;
+    ag.x = fmaf(dd[it].x, x[it].x, ag.x); ag.y = fmaf(dd[it].y, x[it].y, ag.y);
+    ag.z = fmaf(dd[it].z, x[it].z, ag.z); ag.w = fmaf(dd[it].w, x[it].w, ag.w);
+    ab.x += dd[it].x; ab.y += dd[it].y; ab.z += dd[it].z; ab.w += dd[it].w;
+    const float4 dxh = {dd[it].x * g.x, dd[it].y * g.y, dd[it].z * g.z, dd[it].w * g.w};
+    float c1 = (dxh.x + dxh.y) + (dxh.z + dxh.w);
+    float c2 = (dxh.x * x[it].x + dxh.y * x[it].y) + (dxh.z * x[it].z + dxh.w * x[it].w);
+    c1 += dpp_mov<0x128>(c1); c1 += dpp_mov<0x124>(c1); c1 += dpp_mov<0x122>(c1); c1 += dpp_mov<0x121>(c1);
+    c2 += dpp_mov<0x128>(c2); c2 += dpp_mov<0x124>(c2); c2 += dpp_mov<0x122>(c2); c2 += dpp_mov<0x121>(c2);
+    c1 *= (1.f / TD);
+    c2 *= (1.f / TD);
+    const float4 dz = {rr[it] * (dxh.x - c1 - x[it].x * c2), rr[it] * (dxh.y - c1 - x[it].y * c2),
+                       rr[it] * (dxh.z - c1 - x[it].z * c2), rr[it] * (dxh.w - c1 - x[it].w * c2)};
+    *reinterpret_cast<float4*>(d + r * ld + c4) = dz;
+    if (r < nrows) st4(o_dz + r * TD + c4, dz.x, dz.y, dz.z, dz.w);
+  }
+  const int slot = wave * 4 + q;
+  *reinterpret_cast<float4*>(red + slot * TD + c4) = ag;
+  *reinterpret_cast<float4*>(red + 16 * TD + slot * TD + c4) = ab;
   __syncthreads();
   if (wave == 0) {
-    gpart[lane] = (red[lane] + red[TD + lane]) + (red[2 * TD + lane] + red[3 * TD + lane]);
-    bpart[lane] = (red[4 * TD + lane] + red[5 * TD + lane]) + (red[6 * TD + lane] + red[7 * TD + lane]);
+    float sg = 0.f, sb = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) { sg += red[k * TD + lane]; sb += red[16 * TD + k * TD + lane]; }
+    gpart[lane] = sg;
+    bpart[lane] = sb;
   }
 }
 
