@@ -823,21 +823,22 @@ __global__ __launch_bounds__(NW * 64) void rollout_layer_kernel(InfLayerStack st
   __syncthreads();
   T* f = reinterpret_cast<T*>(big);
   auto ln2rows = [&](const float* z, float* out, const float* __restrict__ g, const float* __restrict__ be, float* gout) {
-    const float gg = g[lane], bb = be[lane];  // wave w: rows w, w + NW, ...: all in flight
-    constexpr int U = ROWS / NW;
-    float v[U], mean[U], c[U], var[U];
-#pragma unroll
-    for (int u = 0; u < U; ++u) v[u] = z[(wave + NW * u) * LY::LDX + lane];
-#pragma unroll
-    for (int u = 0; u < U; ++u) mean[u] = wave_sum(v[u]) * (1.f / TD);
-#pragma unroll
-    for (int u = 0; u < U; ++u) { c[u] = v[u] - mean[u]; var[u] = wave_sum(c[u] * c[u]) * (1.f / TD); }
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const int r = wave + NW * u;
-      const float o = fmaf(c[u] * (1.f / sqrtf(var[u] + 1e-5f)), gg, bb);
-      if (out != nullptr) out[r * LY::LDX + lane] = o;
-      if (gout != nullptr && r < NTOK) gout[(row0 + r) * TD + lane] = o;
+    // a quarter wave per row (16 lanes x 4 columns), reductions by DPP row_ror: the 32 rows are one step of 8 waves
+    const int l16 = lane & 15, c4 = l16 * 4;
+    const float4 gg = *reinterpret_cast<const float4*>(g + c4), bb = *reinterpret_cast<const float4*>(be + c4);
+    for (int r = wave * 4 + (lane >> 4); r < ROWS; r += NW * 4) {
+      float4 v = *reinterpret_cast<const float4*>(z + r * LY::LDX + c4);
+      float s = (v.x + v.y) + (v.z + v.w);
+      s += dpp_mov<0x128>(s); s += dpp_mov<0x124>(s); s += dpp_mov<0x122>(s); s += dpp_mov<0x121>(s);
+      const float mean = s * (1.f / TD);
+      v.x -= mean; v.y -= mean; v.z -= mean; v.w -= mean;
+      float q2 = (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+      q2 += dpp_mov<0x128>(q2); q2 += dpp_mov<0x124>(q2); q2 += dpp_mov<0x122>(q2); q2 += dpp_mov<0x121>(q2);
+      const float rs = 1.f / sqrtf(q2 * (1.f / TD) + 1e-5f);
+      const float4 o = {fmaf(v.x * rs, gg.x, bb.x), fmaf(v.y * rs, gg.y, bb.y), fmaf(v.z * rs, gg.z, bb.z),
+                        fmaf(v.w * rs, gg.w, bb.w)};
+      if (out != nullptr) *reinterpret_cast<float4*>(out + r * LY::LDX + c4) = o;
+      if (gout != nullptr && r < NTOK) *reinterpret_cast<float4*>(gout + (row0 + r) * TD + c4) = o;
     }
   };
 #pragma unroll 1
@@ -862,28 +863,39 @@ __global__ __launch_bounds__(NW * 64) void rollout_layer_kernel(InfLayerStack st
     sp[i * ATT_PLD + j] = dot64(big + i * LY::LDQ, big + j * LY::LDQ + TD) * 0.125f;
   }
   __syncthreads();
-  if (tid < NTOK) {
-    float* p = sp + tid * ATT_PLD;
-    float mx = -INFINITY;
-#pragma unroll
-    for (int j = 0; j < NTOK; ++j) mx = fmaxf(mx, p[j]);
-    float e[NTOK], sum = 0.f;
-#pragma unroll
-    for (int j = 0; j < NTOK; ++j) { e[j] = expf(p[j] - mx); sum += e[j]; }
-    const float inv = 1.f / sum;
-#pragma unroll
-    for (int j = 0; j < NTOK; ++j) p[j] = e[j] * inv;
+  {  // softmax: a quarter wave per score row (lane l: key l; key 16 is carried by every lane), max / sum by DPP
+    const int r = tid >> 4, l = lane & 15;
+    if (r < 32) {  // quarters 0..31 (whole waves): rows >= 17 shadow row 16 and write nothing
+      float* p = sp + min(r, NTOK - 1) * ATT_PLD;
+      const float pl = p[l], p16 = p[16];
+      float mx = fmaxf(pl, p16);
+      mx = fmaxf(mx, dpp_mov<0x128>(mx)); mx = fmaxf(mx, dpp_mov<0x124>(mx));
+      mx = fmaxf(mx, dpp_mov<0x122>(mx)); mx = fmaxf(mx, dpp_mov<0x121>(mx));
+      const float el = expf(pl - mx), e16 = expf(p16 - mx);
+      float sum = el;
+      sum += dpp_mov<0x128>(sum); sum += dpp_mov<0x124>(sum); sum += dpp_mov<0x122>(sum); sum += dpp_mov<0x121>(sum);
+      const float inv = 1.f / (sum + e16);
+      if (r < NTOK) {
+        p[l] = el * inv;
+        if (l == 0) p[16] = e16 * inv;
+      }
+    }
   }
   __syncthreads();
-  for (int r = wave; r < ROWS; r += NW) {  // ctx row r = P[r] V; rows >= 17: zeros
-    float a = 0.f;
+  for (int idx = tid; idx < ROWS * 16; idx += NTH) {  // ctx = P V: thread = (row, 4 columns); rows >= 17: zeros
+    const int r = idx >> 4, c4 = (idx & 15) * 4;
+    float4 a = {0.f, 0.f, 0.f, 0.f};
     if (r < NTOK) {
-      const float* v = big + 2 * TD + lane;
+      const float* v = big + 2 * TD + c4;
       const float* p = sp + r * ATT_PLD;
 #pragma unroll
-      for (int j = 0; j < NTOK; ++j) a = fmaf(p[j], v[j * LY::LDQ], a);
+      for (int j = 0; j < NTOK; ++j) {
+        const float pj = p[j];
+        const float4 vv = *reinterpret_cast<const float4*>(v + j * LY::LDQ);
+        a.x = fmaf(pj, vv.x, a.x); a.y = fmaf(pj, vv.y, a.y); a.z = fmaf(pj, vv.z, a.z); a.w = fmaf(pj, vv.w, a.w);
+      }
     }
-    cx[r * LY::LDX + lane] = a;
+    *reinterpret_cast<float4*>(cx + r * LY::LDX + c4) = a;
   }
   __syncthreads();
   if (wave < 8) {  // out_proj + residual -> z (in `big`, fp32 [32][LDX]): (row tile, column tile) = (wave >> 2, wave & 3)
