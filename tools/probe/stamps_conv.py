@@ -17,10 +17,15 @@ for it in range(3):
     hip.backward(st_, im, n, dout, grads)
 torch.cuda.synchronize()
 L=_lib.lib(); L.v4l_debug_stamps.argtypes=[C.c_void_p]; L.v4l_debug_stamps.restype=C.c_int
-buf=(C.c_longlong*32)(); L.v4l_debug_stamps(buf)
+buf=(C.c_longlong*48)(); L.v4l_debug_stamps(buf)
 st=np.array(buf[16:23],dtype=np.int64)
 names=["loads->LDS","dgrad3 (gather GEMM)","bias2+wgrad2","dgrad2 (gather GEMM)","bias1","wgrad1"]
 print("bwd_conv_kernel block 0, 4th sample, phase cycles (clock64, 100 MHz s_memtime or shader clock):")
 for nm,c in zip(names,np.diff(st)): print("  %-22s %8d"%(nm,c))
 print("  total %d"%(st[6]-st[0]))
 st=np.array(buf[:9],dtype=np.int64); print("layer kernel stamps diff", np.diff(st))
+st=np.array(buf[32:42],dtype=np.int64)
+names=["load dy / heads","ln2 bwd","df gemm","dx1 gemm","qkv,P loads + ln1 bwd","dctx gemm","attention bwd","dx_in gemm","tail"]
+print("bwd_layer_kernel (layer 0, TAIL variant) block 0 phase cycles:")
+for nm,c in zip(names,np.diff(st)): print("  %-24s %8d"%(nm,c))
+print("  total %d"%(st[9]-st[0]))

@@ -59,28 +59,40 @@ template <typename T, int SPW> struct BwdLayLds {
 // Like ln_rows (infer.h): a row is owned by a quarter wave (16 lanes x 4 consecutive columns), both row reductions are
 // DPP row_ror adds, accesses are 16 bytes; the dgamma / dbeta column sums are kept per lane and combined over the 16
 // quarter waves of the block through `red` ([2][16][64]) in a fixed order.
-template <int ROWS, typename T>
-__device__ __forceinline__ void ln_bwd_rows(float* d, int ld, const float* __restrict__ xh, const float* __restrict__ rs,
-                                            const float* __restrict__ gamma, int wave, int lane, int nrows,
-                                            T* __restrict__ o_dz, float* red, float* __restrict__ gpart,
-                                            float* __restrict__ bpart) {
-  const int l16 = lane & 15, c4 = l16 * 4, q = lane >> 4;
-  const float4 g = *reinterpret_cast<const float4*>(gamma + c4);
-  constexpr int IT = ROWS / 16;
-  float4 ag = {0.f, 0.f, 0.f, 0.f}, ab = {0.f, 0.f, 0.f, 0.f};
-  float4 dd[IT], x[IT];
-  float rr[IT];
+// The saved xhat / rstd rows of a LayerNorm backward, fetched from HBM ahead of the phase that consumes them (the kernel
+// runs one wave per SIMD with registers to spare: the fetch overlaps the GEMM in front of the norm).
+template <int ROWS> struct LnPre { float4 x[ROWS / 16]; float rr[ROWS / 16]; float4 g; };
+template <int ROWS>
+__device__ __forceinline__ LnPre<ROWS> ln_bwd_fetch(const float* __restrict__ xh, const float* __restrict__ rs,
+                                                    const float* __restrict__ gamma, int wave, int lane, int nrows) {
+  LnPre<ROWS> pre;
+  const int c4 = (lane & 15) * 4, q = lane >> 4;
+  pre.g = *reinterpret_cast<const float4*>(gamma + c4);
 #pragma unroll
-  for (int it = 0; it < IT; ++it) {  // loads are unconditional (row 0 stands in for the padding rows), then selected
+  for (int it = 0; it < ROWS / 16; ++it) {  // loads are unconditional (row 0 stands in for the padding rows), then selected
     const int r = it * 16 + wave * 4 + q;
     const bool ok = r < nrows;
     const int o = ok ? r : 0;
     const float4 xv = *reinterpret_cast<const float4*>(xh + o * TD + c4);
     const float rv = rs[o];
-    dd[it] = *reinterpret_cast<const float4*>(d + r * ld + c4);
-    x[it] = ok ? xv : float4{0.f, 0.f, 0.f, 0.f};
-    rr[it] = ok ? rv : 0.f;
+    pre.x[it] = ok ? xv : float4{0.f, 0.f, 0.f, 0.f};
+    pre.rr[it] = ok ? rv : 0.f;
   }
+  return pre;
+}
+template <int ROWS, typename T>
+__device__ __forceinline__ void ln_bwd_rows(float* d, int ld, const LnPre<ROWS>& pre, int wave, int lane, int nrows,
+                                            T* __restrict__ o_dz, float* red, float* __restrict__ gpart,
+                                            float* __restrict__ bpart) {
+  const int l16 = lane & 15, c4 = l16 * 4, q = lane >> 4;
+  const float4 g = pre.g;
+  constexpr int IT = ROWS / 16;
+  float4 ag = {0.f, 0.f, 0.f, 0.f}, ab = {0.f, 0.f, 0.f, 0.f};
+  float4 dd[IT];
+  const float4 (&x)[IT] = pre.x;
+  const float (&rr)[IT] = pre.rr;
+#pragma unroll
+  for (int it = 0; it < IT; ++it) dd[it] = *reinterpret_cast<const float4*>(d + (it * 16 + wave * 4 + q) * ld + c4);
 #pragma unroll
   for (int it = 0; it < IT; ++it) {
     const int r = it * 16 + wave * 4 + q;
@@ -112,6 +124,12 @@ __device__ __forceinline__ void ln_bwd_rows(float* d, int ld, const float* __res
   }
 }
 
+#ifdef V4L_INFER_TIMING
+#define LAY_STAMP(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) g_inf_stamps[32 + (i)] = clock64(); } while (0)
+#else
+#define LAY_STAMP(i)
+#endif
+
 template <typename T, int SPW, bool HEAD, bool TAIL>
 __global__ __launch_bounds__(256) void bwd_layer_kernel(BwdLayer w, BwdHead hd, BwdTail tl, int n) {
   typedef BwdLayLds<T, SPW> LY;
@@ -124,10 +142,13 @@ __global__ __launch_bounds__(256) void bwd_layer_kernel(BwdLayer w, BwdHead hd, 
   float* big = reinterpret_cast<float*>(smem + 2 * LY::a_b);         // df (T) -> qkv -> dqkv (fp32)
   float* sp = reinterpret_cast<float*>(smem + 2 * LY::a_b + LY::big_b);
   float* red = reinterpret_cast<float*>(smem + 2 * LY::a_b + LY::big_b + LY::p_b);
+  LAY_STAMP(0);
   const int s0 = blockIdx.x * SPW;
   const int ns = min(SPW, n - s0);
   const int nrows = ns * NTOK;
   const int64_t row0 = (int64_t)s0 * NTOK;
+  // norm2's saved rows start their trip from HBM now; they are consumed after dy is staged (or the heads are done)
+  const LnPre<ROWS> pre2 = ln_bwd_fetch<ROWS>(w.s_xh2 + row0 * TD, w.s_rs2 + row0, w.g2, wave, lane, nrows);
   const int nt1[1] = {wave};
   const int nt4[4] = {wave * 4, wave * 4 + 1, wave * 4 + 2, wave * 4 + 3};
   if constexpr (HEAD) {
@@ -194,26 +215,31 @@ __global__ __launch_bounds__(256) void bwd_layer_kernel(BwdLayer w, BwdHead hd, 
       *reinterpret_cast<float4*>(a + r * LY::LDX + c4) = ok ? v : float4{0.f, 0.f, 0.f, 0.f};
     }
   }
+  LAY_STAMP(1);
   __syncthreads();
   // ---- norm2 backward: a = dz2
-  ln_bwd_rows<ROWS>(a, LY::LDX, w.s_xh2 + row0 * TD, w.s_rs2 + row0, w.g2, wave, lane, nrows,
-              reinterpret_cast<T*>(w.o_dz2) + row0 * TD, red,
+  ln_bwd_rows<ROWS>(a, LY::LDX, pre2, wave, lane, nrows, reinterpret_cast<T*>(w.o_dz2) + row0 * TD, red,
               w.gp2 + (int64_t)blockIdx.x * TD, w.bp2 + (int64_t)blockIdx.x * TD);
   __syncthreads();
+  LAY_STAMP(2);
   // ---- df = (dz2 W2) o [f > 0]   (T in LDS for the next contraction, fp32 to HBM for linear1's weight-grad)
   T* f = reinterpret_cast<T*>(big);
   {
     f32x4 acc[MT][4];
     zero_acc(acc);
+    float4 fm[MT][4];  // the ReLU mask (saved f) is fetched before the GEMM, not after it
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        fm[mt][j] = ld4(reinterpret_cast<const T*>(w.s_f) + (row0 + (mt * 16 + fr < nrows ? mt * 16 + fr : 0)) * 256 +
+                        nt4[j] * 16 + qr);
     block_gemm<T, MT, 4, 2>(acc, a, LY::LDX, (const T*)w.w2t, 64, nt4, lane);
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
       const int row = mt * 16 + fr;
       const bool ok = row < nrows;
-      float4 m[4];
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
-        m[j] = ld4(reinterpret_cast<const T*>(w.s_f) + (row0 + (ok ? row : 0)) * 256 + nt4[j] * 16 + qr);
+      const float4 (&m)[4] = fm[mt];
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const int n4 = nt4[j] * 16 + qr;
@@ -225,6 +251,30 @@ __global__ __launch_bounds__(256) void bwd_layer_kernel(BwdLayer w, BwdHead hd, 
     }
   }
   __syncthreads();
+  LAY_STAMP(3);
+  // qkv and P of the block's samples and norm1's saved rows are requested before the dx1 GEMM and parked in registers;
+  // they go to LDS once `big` (df) has been consumed
+  constexpr int QV = (ROWS * 48 + 255) / 256, PV = (SPW * NTOK * NTOK + 255) / 256;
+  float4 qpre[QV];
+  float ppre[PV];
+  {
+    const float* qg = w.s_qkv + row0 * 192;
+#pragma unroll
+    for (int k = 0; k < QV; ++k) {
+      const int i4 = tid + k * 256;
+      const int r = i4 / 48, c4 = (i4 - r * 48) * 4;
+      const bool ok = i4 < ROWS * 48 && r < nrows;
+      const float4 v = *reinterpret_cast<const float4*>(qg + (ok ? r * 192 + c4 : 0));
+      qpre[k] = ok ? v : float4{0.f, 0.f, 0.f, 0.f};
+    }
+    const float* pg = w.s_P + (int64_t)s0 * NTOK * NTOK;
+#pragma unroll
+    for (int k = 0; k < PV; ++k) {
+      const int idx = tid + k * 256;
+      ppre[k] = pg[idx < ns * NTOK * NTOK ? idx : 0];
+    }
+  }
+  const LnPre<ROWS> pre1 = ln_bwd_fetch<ROWS>(w.s_xh1 + row0 * TD, w.s_rs1 + row0, w.g1, wave, lane, nrows);
   {  // ---- dx1 = dz2 + df W1 -> b
     f32x4 acc[MT][1];
     zero_acc(acc);
@@ -238,27 +288,30 @@ __global__ __launch_bounds__(256) void bwd_layer_kernel(BwdLayer w, BwdHead hd, 
     }
   }
   __syncthreads();
-  // qkv and P of the four samples come in while norm1' and the out_proj data-grad run (`big` is free: df was consumed)
+  LAY_STAMP(4);
+  // park -> LDS (`big` is free: df was consumed by the dx1 GEMM)
   {
-    const float* qg = w.s_qkv + row0 * 192;
-    for (int i4 = tid; i4 < ROWS * 48; i4 += 256) {
+#pragma unroll
+    for (int k = 0; k < QV; ++k) {
+      const int i4 = tid + k * 256;
       const int r = i4 / 48, c4 = (i4 - r * 48) * 4;
-      const bool ok = r < nrows;
-      const float4 v = *reinterpret_cast<const float4*>(qg + (ok ? r : 0) * 192 + c4);
-      *reinterpret_cast<float4*>(big + r * LY::LDQ + c4) = ok ? v : float4{0.f, 0.f, 0.f, 0.f};
+      if (i4 < ROWS * 48) *reinterpret_cast<float4*>(big + r * LY::LDQ + c4) = qpre[k];
     }
-    const float* pg = w.s_P + (int64_t)s0 * NTOK * NTOK;
-    for (int idx = tid; idx < ns * NTOK * NTOK; idx += 256) {
-      const int sm = idx / (NTOK * NTOK), pr = idx - sm * NTOK * NTOK;
-      const int i = pr / NTOK, j = pr - i * NTOK;
-      sp[(sm * NTOK + i) * ATT_PLD + j] = pg[idx];
+#pragma unroll
+    for (int k = 0; k < PV; ++k) {
+      const int idx = tid + k * 256;
+      if (idx < ns * NTOK * NTOK) {
+        const int sm = idx / (NTOK * NTOK), pr = idx - sm * NTOK * NTOK;
+        const int i = pr / NTOK, j = pr - i * NTOK;
+        sp[(sm * NTOK + i) * ATT_PLD + j] = ppre[k];
+      }
     }
   }
   // ---- norm1 backward: b = dz1
-  ln_bwd_rows<ROWS>(b, LY::LDX, w.s_xh1 + row0 * TD, w.s_rs1 + row0, w.g1, wave, lane, nrows,
-              reinterpret_cast<T*>(w.o_dz1) + row0 * TD, red,
+  ln_bwd_rows<ROWS>(b, LY::LDX, pre1, wave, lane, nrows, reinterpret_cast<T*>(w.o_dz1) + row0 * TD, red,
               w.gp1 + (int64_t)blockIdx.x * TD, w.bp1 + (int64_t)blockIdx.x * TD);
   __syncthreads();
+  LAY_STAMP(5);
   {  // ---- dctx = dz1 Wo -> a
     f32x4 acc[MT][1];
     zero_acc(acc);
@@ -269,6 +322,7 @@ __global__ __launch_bounds__(256) void bwd_layer_kernel(BwdLayer w, BwdHead hd, 
       st4(a + (mt * 16 + fr) * LY::LDX + n4, acc[mt][0][0], acc[mt][0][1], acc[mt][0][2], acc[mt][0][3]);
   }
   __syncthreads();
+  LAY_STAMP(6);
   // ---- attention backward of sample `wave` (fp32 VALU like the forward):
   //   dP = dctx V^T ; dS = P o (dP - rowsum(P o dP)) ; dV = P^T dctx ; dQ = dS K / 8 ; dK = dS^T Q / 8
   {
@@ -338,6 +392,7 @@ __global__ __launch_bounds__(256) void bwd_layer_kernel(BwdLayer w, BwdHead hd, 
     }
   }
   __syncthreads();
+  LAY_STAMP(7);
   {  // ---- dx_in = dz1 + dqkv Win -> global
     f32x4 acc[MT][1];
     zero_acc(acc);
@@ -352,6 +407,7 @@ __global__ __launch_bounds__(256) void bwd_layer_kernel(BwdLayer w, BwdHead hd, 
       if constexpr (TAIL) st4(a + row * LY::LDX + n4, v0, v1, v2, v3);  // dctx is dead: `a` takes dx_in (0 beyond nrows)
     }
   }
+  LAY_STAMP(8);
   if constexpr (TAIL) {
     __syncthreads();
     {  // ---- tokens 1..16: dc3 = (dx_in Wup) o [c3 > 0]; the token-0 rows of the tile are computed and dropped
@@ -405,6 +461,7 @@ __global__ __launch_bounds__(256) void bwd_layer_kernel(BwdLayer w, BwdHead hd, 
     block_gemm<T, 1, 4, 8>(acc, dh, LY::LDF, (const T*)tl.wf2t, 256, nt4, lane);
     masked(tl.s_e0, (T*)nullptr, tl.o_de0);
   }
+  LAY_STAMP(9);
 }
 
 

@@ -489,7 +489,7 @@ __device__ __forceinline__ void ln_rows(const float* z, int ldz, float* out, int
 }
 
 #ifdef V4L_INFER_TIMING
-__device__ long long g_inf_stamps[32];
+__device__ long long g_inf_stamps[48];
 #define INF_STAMP(i) do { if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) g_inf_stamps[i] = clock64(); } while (0)
 #else
 #define INF_STAMP(i)

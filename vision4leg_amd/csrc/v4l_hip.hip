@@ -1759,7 +1759,7 @@ int v4l_obs_norm(const double* raw_dev, int64_t ld_raw, int E, int S, double* me
 #ifdef V4L_INFER_TIMING
 int v4l_debug_stamps(long long* out32) {
   if (hipDeviceSynchronize() != hipSuccess) return -2;
-  return hipMemcpyFromSymbol(out32, HIP_SYMBOL(v4l::g_inf_stamps), 32 * sizeof(long long)) == hipSuccess ? 0 : -2;
+  return hipMemcpyFromSymbol(out32, HIP_SYMBOL(v4l::g_inf_stamps), 48 * sizeof(long long)) == hipSuccess ? 0 : -2;
 }
 #endif
 int v4l_prof_enable(int on) {
