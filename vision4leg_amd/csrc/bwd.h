@@ -217,13 +217,15 @@ __global__ __launch_bounds__(256) void bwd_layer_kernel(BwdLayer w, BwdHead hd, 
   }
   LAY_STAMP(1);
   __syncthreads();
-  // ---- norm2 backward: a = dz2
+  // ---- norm2 backward: a = dz2 (the next GEMM's first weight fragments are requested before the norm's global stores)
+  GemmRing<T, 4, 2> ring_df = gemm_prefetch<T, 4, 2>((const T*)w.w2t, 64, nt4, lane);
   ln_bwd_rows<ROWS>(a, LY::LDX, pre2, wave, lane, nrows, reinterpret_cast<T*>(w.o_dz2) + row0 * TD, red,
               w.gp2 + (int64_t)blockIdx.x * TD, w.bp2 + (int64_t)blockIdx.x * TD);
   __syncthreads();
   LAY_STAMP(2);
   // ---- df = (dz2 W2) o [f > 0]   (T in LDS for the next contraction, fp32 to HBM for linear1's weight-grad)
   T* f = reinterpret_cast<T*>(big);
+  GemmRing<T, 1, 8> ring_dx1;
   {
     f32x4 acc[MT][4];
     zero_acc(acc);
@@ -234,7 +236,8 @@ __global__ __launch_bounds__(256) void bwd_layer_kernel(BwdLayer w, BwdHead hd, 
       for (int j = 0; j < 4; ++j)
         fm[mt][j] = ld4(reinterpret_cast<const T*>(w.s_f) + (row0 + (mt * 16 + fr < nrows ? mt * 16 + fr : 0)) * 256 +
                         nt4[j] * 16 + qr);
-    block_gemm<T, MT, 4, 2>(acc, a, LY::LDX, (const T*)w.w2t, 64, nt4, lane);
+    block_gemm<T, MT, 4, 2>(acc, a, LY::LDX, (const T*)w.w2t, 64, nt4, lane, ring_df);
+    ring_dx1 = gemm_prefetch<T, 1, 8>((const T*)w.w1t, 256, nt1, lane);  // ahead of this epilogue's global stores
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
       const int row = mt * 16 + fr;
@@ -278,7 +281,7 @@ __global__ __launch_bounds__(256) void bwd_layer_kernel(BwdLayer w, BwdHead hd, 
   {  // ---- dx1 = dz2 + df W1 -> b
     f32x4 acc[MT][1];
     zero_acc(acc);
-    block_gemm<T, MT, 1, 8>(acc, f, LY::LDF, (const T*)w.w1t, 256, nt1, lane);
+    block_gemm<T, MT, 1, 8>(acc, f, LY::LDF, (const T*)w.w1t, 256, nt1, lane, ring_dx1);
     const int n4 = wave * 16 + qr;
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
@@ -308,6 +311,7 @@ __global__ __launch_bounds__(256) void bwd_layer_kernel(BwdLayer w, BwdHead hd, 
     }
   }
   // ---- norm1 backward: b = dz1
+  GemmRing<T, 1, 2> ring_dctx = gemm_prefetch<T, 1, 2>((const T*)w.wot, 64, nt1, lane);
   ln_bwd_rows<ROWS>(b, LY::LDX, pre1, wave, lane, nrows, reinterpret_cast<T*>(w.o_dz1) + row0 * TD, red,
               w.gp1 + (int64_t)blockIdx.x * TD, w.bp1 + (int64_t)blockIdx.x * TD);
   __syncthreads();
@@ -315,7 +319,7 @@ __global__ __launch_bounds__(256) void bwd_layer_kernel(BwdLayer w, BwdHead hd, 
   {  // ---- dctx = dz1 Wo -> a
     f32x4 acc[MT][1];
     zero_acc(acc);
-    block_gemm<T, MT, 1, 2>(acc, b, LY::LDX, (const T*)w.wot, 64, nt1, lane);
+    block_gemm<T, MT, 1, 2>(acc, b, LY::LDX, (const T*)w.wot, 64, nt1, lane, ring_dctx);
     const int n4 = wave * 16 + qr;
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
@@ -325,6 +329,7 @@ __global__ __launch_bounds__(256) void bwd_layer_kernel(BwdLayer w, BwdHead hd, 
   LAY_STAMP(6);
   // ---- attention backward of sample `wave` (fp32 VALU like the forward):
   //   dP = dctx V^T ; dS = P o (dP - rowsum(P o dP)) ; dV = P^T dctx ; dQ = dS K / 8 ; dK = dS^T Q / 8
+  GemmRing<T, 1, 6> ring_dxin = gemm_prefetch<T, 1, 6>((const T*)w.wint, 192, nt1, lane);
   {
     const bool act = wave < ns;
     float* qs = big + wave * NTOK * LY::LDQ;
@@ -396,7 +401,7 @@ __global__ __launch_bounds__(256) void bwd_layer_kernel(BwdLayer w, BwdHead hd, 
   {  // ---- dx_in = dz1 + dqkv Win -> global
     f32x4 acc[MT][1];
     zero_acc(acc);
-    block_gemm<T, MT, 1, 6>(acc, big, LY::LDQ, (const T*)w.wint, 192, nt1, lane);
+    block_gemm<T, MT, 1, 6>(acc, big, LY::LDQ, (const T*)w.wint, 192, nt1, lane, ring_dxin);
     const int n4 = wave * 16 + qr;
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {

@@ -58,21 +58,36 @@ __device__ __forceinline__ f32x8 afrag_t(const float* p) { return *reinterpret_c
 // acc[mt][j][r] = out[16*mt + (lane&15)][16*ntile[j] + 4*(lane>>4) + r]  -> vector epilogue stores.
 // The weight fragments come straight from L2/HBM: a ring of PD k-steps of them is kept in flight (a load issued per
 // step consumed) so the MFMAs never wait for a just-issued global load.
+// The first PD k-steps of a GEMM's weight fragments, requested ahead of time (gemm_prefetch) so that the L2 round trip —
+// and, on CDNA where loads and stores retire through the same in-order vmcnt queue, the acknowledgement of every global
+// store issued before it — overlaps the phase in front of the GEMM instead of opening it.
+template <typename T, int NTW, int KS> struct GemmRing {
+  // ring depth: every step in flight when that costs <= 16 fragment registers sets, else 4 steps
+  static constexpr int PD = KS * NTW <= 16 ? KS : (KS < 4 ? KS : 4);
+  typename Frag<T>::type fb[PD][NTW];
+};
+template <typename T, int NTW, int KS>
+__device__ __forceinline__ GemmRing<T, NTW, KS> gemm_prefetch(const T* __restrict__ Wp, int Kp, const int (&ntile)[NTW], int lane) {
+  typedef typename Frag<T>::type frag_t;
+  GemmRing<T, NTW, KS> ring;
+  const int fr = lane & 15, fg = (lane >> 4) * 8;
+#pragma unroll
+  for (int d = 0; d < GemmRing<T, NTW, KS>::PD; ++d)
+#pragma unroll
+    for (int j = 0; j < NTW; ++j)
+      ring.fb[d][j] = *reinterpret_cast<const frag_t*>(Wp + (int64_t)(ntile[j] * 16 + fr) * Kp + fg + d * 32);
+  return ring;
+}
 template <typename T, int MT, int NTW, int KS, typename AT>
 __device__ __forceinline__ void block_gemm(f32x4 (&acc)[MT][NTW], const AT* sA, int lda, const T* __restrict__ Wp, int Kp,
-                                           const int (&ntile)[NTW], int lane) {
+                                           const int (&ntile)[NTW], int lane, GemmRing<T, NTW, KS>& ring) {
   typedef typename Frag<T>::type frag_t;
-  // ring depth: every step in flight when that costs <= 16 fragment registers sets, else 4 steps
-  constexpr int PD = KS * NTW <= 16 ? KS : (KS < 4 ? KS : 4);
+  constexpr int PD = GemmRing<T, NTW, KS>::PD;
   const int fr = lane & 15, fg = (lane >> 4) * 8;
   const T* wrow[NTW];
 #pragma unroll
   for (int j = 0; j < NTW; ++j) wrow[j] = Wp + (int64_t)(ntile[j] * 16 + fr) * Kp + fg;
-  frag_t fb[PD][NTW];
-#pragma unroll
-  for (int d = 0; d < PD; ++d)
-#pragma unroll
-    for (int j = 0; j < NTW; ++j) fb[d][j] = *reinterpret_cast<const frag_t*>(wrow[j] + d * 32);
+  frag_t (&fb)[PD][NTW] = ring.fb;
 #pragma unroll
   for (int ks = 0; ks < KS; ++ks) {
     frag_t cur[NTW];
@@ -91,6 +106,12 @@ __device__ __forceinline__ void block_gemm(f32x4 (&acc)[MT][NTW], const AT* sA, 
       for (int j = 0; j < NTW; ++j) mma_k32(acc[mt][j], cur[j], fa);  // transposed tile
     }
   }
+}
+template <typename T, int MT, int NTW, int KS, typename AT>
+__device__ __forceinline__ void block_gemm(f32x4 (&acc)[MT][NTW], const AT* sA, int lda, const T* __restrict__ Wp, int Kp,
+                                           const int (&ntile)[NTW], int lane) {
+  GemmRing<T, NTW, KS> ring = gemm_prefetch<T, NTW, KS>(Wp, Kp, ntile, lane);
+  block_gemm<T, MT, NTW, KS, AT>(acc, sA, lda, Wp, Kp, ntile, lane, ring);
 }
 // 4 consecutive elements of one row -> one 8/16-byte store (LDS or global), T = __bf16 | float
 __device__ __forceinline__ void st4(__bf16* p, float a, float b, float c, float d) {
