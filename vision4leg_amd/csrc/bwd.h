@@ -330,6 +330,34 @@ __global__ __launch_bounds__(256) void bwd_layer_kernel(BwdLayer w, BwdHead hd, 
   // ---- attention backward of sample `wave` (fp32 VALU like the forward):
   //   dP = dctx V^T ; dS = P o (dP - rowsum(P o dP)) ; dV = P^T dctx ; dQ = dS K / 8 ; dK = dS^T Q / 8
   GemmRing<T, 1, 6> ring_dxin = gemm_prefetch<T, 1, 6>((const T*)w.wint, 192, nt1, lane);
+  // TAIL: everything the encoder-side data-grads read from HBM (conv3 / x0 / MLP ReLU masks, the first weight fragments of
+  // their three GEMMs) is requested here, in front of the long LDS-only attention phase
+  float4 tm_c3[MT], tm_e1[4], tm_e0[4];
+  float tm_x0[4];
+  GemmRing<T, 1, 2> ring_up;
+  GemmRing<T, 4, 2> ring_pr;
+  if constexpr (TAIL) {
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      const int row = mt * 16 + fr;
+      const int sm = row / NTOK, t = row - sm * NTOK;
+      const bool ok = row < nrows && t > 0;
+      tm_c3[mt] = *reinterpret_cast<const float4*>(tl.s_c3 + (ok ? ((int64_t)(s0 + sm) * 16 + (t - 1)) * TD + wave * 16 + qr : 0));
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int idx = tid + k * 256, r = idx >> 6, c = idx & 63;
+      tm_x0[k] = tl.x0[(row0 + (r < ns ? r * NTOK : 0)) * TD + c];
+    }
+    const int64_t mrow = (int64_t)(s0 + (fr < ns ? fr : 0)) * 256;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      tm_e1[j] = *reinterpret_cast<const float4*>(tl.s_e1 + mrow + nt4[j] * 16 + qr);
+      tm_e0[j] = *reinterpret_cast<const float4*>(tl.s_e0 + mrow + nt4[j] * 16 + qr);
+    }
+    ring_up = gemm_prefetch<T, 1, 2>((const T*)tl.wupt, 64, nt1, lane);
+    ring_pr = gemm_prefetch<T, 4, 2>((const T*)tl.wpt, 64, nt4, lane);
+  }
   {
     const bool act = wave < ns;
     float* qs = big + wave * NTOK * LY::LDQ;
@@ -418,7 +446,7 @@ __global__ __launch_bounds__(256) void bwd_layer_kernel(BwdLayer w, BwdHead hd, 
     {  // ---- tokens 1..16: dc3 = (dx_in Wup) o [c3 > 0]; the token-0 rows of the tile are computed and dropped
       f32x4 acc[MT][1];
       zero_acc(acc);
-      block_gemm<T, MT, 1, 2>(acc, a, LY::LDX, (const T*)tl.wupt, 64, nt1, lane);
+      block_gemm<T, MT, 1, 2>(acc, a, LY::LDX, (const T*)tl.wupt, 64, nt1, lane, ring_up);
       const int n4 = wave * 16 + qr;
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt) {
@@ -426,7 +454,7 @@ __global__ __launch_bounds__(256) void bwd_layer_kernel(BwdLayer w, BwdHead hd, 
         const int sm = row / NTOK, t = row - sm * NTOK;
         const bool ok = row < nrows && t > 0;
         const int64_t o = ok ? ((int64_t)(s0 + sm) * 16 + (t - 1)) * TD + n4 : 0;
-        const float4 m = *reinterpret_cast<const float4*>(tl.s_c3 + o);
+        const float4 m = tm_c3[mt];
         if (ok)
           st4(tl.o_dc3 + o, m.x > 0.f ? acc[mt][0][0] : 0.f, m.y > 0.f ? acc[mt][0][1] : 0.f, m.z > 0.f ? acc[mt][0][2] : 0.f,
               m.w > 0.f ? acc[mt][0][3] : 0.f);
@@ -435,20 +463,17 @@ __global__ __launch_bounds__(256) void bwd_layer_kernel(BwdLayer w, BwdHead hd, 
     // ---- token 0: (dx_in o [x0 > 0]) -> state_projector' -> [e1 > 0] -> dhc -> fc2' -> [e0 > 0] -> de0
     float* dt = big;                                   // [16][LDX] (dqkv was consumed by the in_proj data-grad)
     T* dh = reinterpret_cast<T*>(big + 16 * LY::LDX);  // [16][LDF]
+    GemmRing<T, 4, 8> ring_f2 = gemm_prefetch<T, 4, 8>((const T*)tl.wf2t, 256, nt4, lane);
     __syncthreads();
-    for (int idx = tid; idx < 16 * TD; idx += 256) {
-      const int r = idx >> 6, c = idx & 63;
-      const bool ok = r < ns;
-      const float m = tl.x0[(row0 + (ok ? r * NTOK : 0)) * TD + c];
-      dt[r * LY::LDX + c] = ok && m > 0.f ? a[(r * NTOK) * LY::LDX + c] : 0.f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int idx = tid + k * 256, r = idx >> 6, c = idx & 63;
+      dt[r * LY::LDX + c] = r < ns && tm_x0[k] > 0.f ? a[(r * NTOK) * LY::LDX + c] : 0.f;
     }
     __syncthreads();
     f32x4 acc[1][4];
-    auto masked = [&](const float* act, T* dst, float* save) {
+    auto masked = [&](const float4 (&m)[4], T* dst, float* save) {
       const bool ok = fr < ns;
-      float4 m[4];
-#pragma unroll
-      for (int j = 0; j < 4; ++j) m[j] = *reinterpret_cast<const float4*>(act + (int64_t)(s0 + (ok ? fr : 0)) * 256 + nt4[j] * 16 + qr);
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const int n4 = nt4[j] * 16 + qr;
@@ -459,12 +484,12 @@ __global__ __launch_bounds__(256) void bwd_layer_kernel(BwdLayer w, BwdHead hd, 
       }
     };
     zero_acc(acc);
-    block_gemm<T, 1, 4, 2>(acc, dt, LY::LDX, (const T*)tl.wpt, 64, nt4, lane);
-    masked(tl.s_e1, dh, tl.o_dhc);
+    block_gemm<T, 1, 4, 2>(acc, dt, LY::LDX, (const T*)tl.wpt, 64, nt4, lane, ring_pr);
+    masked(tm_e1, dh, tl.o_dhc);
     __syncthreads();
     zero_acc(acc);
-    block_gemm<T, 1, 4, 8>(acc, dh, LY::LDF, (const T*)tl.wf2t, 256, nt4, lane);
-    masked(tl.s_e0, (T*)nullptr, tl.o_de0);
+    block_gemm<T, 1, 4, 8>(acc, dh, LY::LDF, (const T*)tl.wf2t, 256, nt4, lane, ring_f2);
+    masked(tm_e0, (T*)nullptr, tl.o_de0);
   }
   LAY_STAMP(9);
 }
