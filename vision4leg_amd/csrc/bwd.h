@@ -157,19 +157,37 @@ __global__ __launch_bounds__(256) void bwd_layer_kernel(BwdLayer w, BwdHead hd, 
     T* dh1 = reinterpret_cast<T*>(big + 16 * LY::LDX);          // [16][LDF]
     T* dh0 = dh1 + 16 * LY::LDF;
     float* dpool = reinterpret_cast<float*>(dh0 + 16 * LY::LDF);  // [16][LDP]
-    for (int idx = tid; idx < 16 * TD; idx += 256) {
-      const int r = idx >> 6, c = idx & 63;
+    // all HBM operands of the head chain are requested up front: dout, both ReLU masks, the three GEMMs' first fragments
+    float dv[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int idx = tid + k * 256, r = idx >> 6, c = idx & 63;
       const bool ok = r < ns && c < OUT_LD;
       const float v = hd.dout[ok ? (int64_t)(s0 + r) * OUT_LD + c : 0];
-      dt[r * LY::LDX + c] = ok ? v : 0.f;
+      dv[k] = ok ? v : 0.f;
+    }
+    float4 m1[4], m0[4];
+    {
+      const int64_t mrow = (int64_t)(s0 + (fr < ns ? fr : 0)) * 256;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        m1[j] = *reinterpret_cast<const float4*>(hd.s_h1 + mrow + nt4[j] * 16 + qr);
+        m0[j] = *reinterpret_cast<const float4*>(hd.s_h0 + mrow + nt4[j] * 16 + qr);
+      }
+    }
+    const int nt2[2] = {wave * 2, wave * 2 + 1};
+    GemmRing<T, 4, 2> ring2 = gemm_prefetch<T, 4, 2>((const T*)hd.w2t, 64, nt4, lane);
+    GemmRing<T, 4, 8> ring1 = gemm_prefetch<T, 4, 8>((const T*)hd.w1t, 256, nt4, lane);
+    GemmRing<T, 2, 8> ring0 = gemm_prefetch<T, 2, 8>((const T*)hd.w0t, 256, nt2, lane);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int idx = tid + k * 256, r = idx >> 6, c = idx & 63;
+      dt[r * LY::LDX + c] = dv[k];
     }
     __syncthreads();
     f32x4 acc[1][4];
-    auto masked = [&](const float* act, T* dst, float* save) {  // ReLU mask from the saved activation, rows < ns
+    auto masked = [&](const float4 (&m)[4], T* dst, float* save) {  // ReLU mask from the saved activation, rows < ns
       const bool ok = fr < ns;
-      float4 m[4];
-#pragma unroll
-      for (int j = 0; j < 4; ++j) m[j] = *reinterpret_cast<const float4*>(act + (int64_t)(s0 + (ok ? fr : 0)) * 256 + nt4[j] * 16 + qr);
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const int n4 = nt4[j] * 16 + qr;
@@ -180,18 +198,17 @@ __global__ __launch_bounds__(256) void bwd_layer_kernel(BwdLayer w, BwdHead hd, 
       }
     };
     zero_acc(acc);
-    block_gemm<T, 1, 4, 2>(acc, dt, LY::LDX, (const T*)hd.w2t, 64, nt4, lane);
-    masked(hd.s_h1, dh1, hd.o_dh1);
+    block_gemm<T, 1, 4, 2>(acc, dt, LY::LDX, (const T*)hd.w2t, 64, nt4, lane, ring2);
+    masked(m1, dh1, hd.o_dh1);
     __syncthreads();
     zero_acc(acc);
-    block_gemm<T, 1, 4, 8>(acc, dh1, LY::LDF, (const T*)hd.w1t, 256, nt4, lane);
-    masked(hd.s_h0, dh0, hd.o_dh0);
+    block_gemm<T, 1, 4, 8>(acc, dh1, LY::LDF, (const T*)hd.w1t, 256, nt4, lane, ring1);
+    masked(m0, dh0, hd.o_dh0);
     __syncthreads();
     {
-      const int nt2[2] = {wave * 2, wave * 2 + 1};
       f32x4 a2[1][2];
       zero_acc(a2);
-      block_gemm<T, 1, 2, 8>(a2, dh0, LY::LDF, (const T*)hd.w0t, 256, nt2, lane);
+      block_gemm<T, 1, 2, 8>(a2, dh0, LY::LDF, (const T*)hd.w0t, 256, nt2, lane, ring0);
 #pragma unroll
       for (int j = 0; j < 2; ++j) st4(dpool + fr * LDP + nt2[j] * 16 + qr, a2[0][j][0], a2[0][j][1], a2[0][j][2], a2[0][j][3]);
     }
