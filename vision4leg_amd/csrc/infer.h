@@ -538,6 +538,12 @@ __global__ __launch_bounds__(256) void infer_layer_kernel(InfLayerPair pr, InfHe
   const int64_t row0 = (int64_t)s0 * NTOK;  // first token row of this block
   long long t_step = 0;
   if constexpr (HEAD) { if (fin.ctl != nullptr) t_step = fin.ctl->t; }
+  const int nt[3] = {wave, wave + 4, wave + 8};
+  const int nt1[1] = {wave};
+  const int nt4[4] = {wave * 4, wave * 4 + 1, wave * 4 + 2, wave * 4 + 3};
+  // every GEMM's first weight fragments are requested one phase early (GemmRing): the L2 round trip and the acknowledgement
+  // of the global stores in front of it overlap that phase
+  GemmRing<T, 3, 2> ring_in = gemm_prefetch<T, 3, 2>((const T*)w.win, 64, nt, lane);
   const float* xg = w.xin + (int64_t)s0 * NTOK * TD;
   for (int i4 = tid; i4 < ROWS * (TD / 4); i4 += 256) {
     const int r = i4 >> 4, c4 = (i4 & 15) * 4;
@@ -548,11 +554,12 @@ __global__ __launch_bounds__(256) void infer_layer_kernel(InfLayerPair pr, InfHe
   }
   __syncthreads();
   INF_STAMP(1);
+  GemmRing<T, 1, 2> ring_o;
   {  // in_proj: [ROWS][64] x [192][64]^T -> qkv (fp32)
-    const int nt[3] = {wave, wave + 4, wave + 8};
     f32x4 acc[MT][3];
     zero_acc(acc);
-    block_gemm<T, MT, 3, 2>(acc, xs, LY::LDX, (const T*)w.win, 64, nt, lane);
+    block_gemm<T, MT, 3, 2>(acc, xs, LY::LDX, (const T*)w.win, 64, nt, lane, ring_in);
+    ring_o = gemm_prefetch<T, 1, 2>((const T*)w.wo, 64, nt1, lane);
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
       const int n4 = nt[j] * 16 + qr;
@@ -643,11 +650,12 @@ __global__ __launch_bounds__(256) void infer_layer_kernel(InfLayerPair pr, InfHe
   }
   __syncthreads();
   INF_STAMP(3);
-  const int nt1[1] = {wave};
+  GemmRing<T, 4, 2> ring_1;
   {  // out_proj + residual -> z (in `big`, fp32 [ROWS][LDX])
     f32x4 acc[MT][1];
     zero_acc(acc);
-    block_gemm<T, MT, 1, 2>(acc, cx, LY::LDX, (const T*)w.wo, 64, nt1, lane);
+    block_gemm<T, MT, 1, 2>(acc, cx, LY::LDX, (const T*)w.wo, 64, nt1, lane, ring_o);
+    ring_1 = gemm_prefetch<T, 4, 2>((const T*)w.w1, 64, nt4, lane);  // in front of norm1 and its saves
     const int n4 = wave * 16 + qr;
     const float4 bb = *reinterpret_cast<const float4*>(w.bo + n4);
 #pragma unroll
@@ -666,11 +674,12 @@ __global__ __launch_bounds__(256) void infer_layer_kernel(InfLayerPair pr, InfHe
   __syncthreads();
   INF_STAMP(5);
   T* f = reinterpret_cast<T*>(big);
+  GemmRing<T, 1, 8> ring_2;
   {  // linear1 + ReLU -> f (T) ; ff <= 256: wave w owns column tiles 4w..4w+3
-    const int nt4[4] = {wave * 4, wave * 4 + 1, wave * 4 + 2, wave * 4 + 3};
     f32x4 acc[MT][4];
     zero_acc(acc);
-    block_gemm<T, MT, 4, 2>(acc, xs, LY::LDX, (const T*)w.w1, 64, nt4, lane);
+    block_gemm<T, MT, 4, 2>(acc, xs, LY::LDX, (const T*)w.w1, 64, nt4, lane, ring_1);
+    ring_2 = gemm_prefetch<T, 1, 8>((const T*)w.w2, 256, nt1, lane);  // in front of the f saves
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int n4 = nt4[j] * 16 + qr;
@@ -690,7 +699,7 @@ __global__ __launch_bounds__(256) void infer_layer_kernel(InfLayerPair pr, InfHe
   {  // linear2 + residual -> z2 (in `cx`)
     f32x4 acc[MT][1];
     zero_acc(acc);
-    block_gemm<T, MT, 1, 8>(acc, f, LY::LDF, (const T*)w.w2, 256, nt1, lane);
+    block_gemm<T, MT, 1, 8>(acc, f, LY::LDF, (const T*)w.w2, 256, nt1, lane, ring_2);
     const int n4 = wave * 16 + qr;
     const float4 bb = *reinterpret_cast<const float4*>(w.b2 + n4);
 #pragma unroll
@@ -731,7 +740,6 @@ __global__ __launch_bounds__(256) void infer_layer_kernel(InfLayerPair pr, InfHe
       pooled[r * LY::LDP + c] = v;
     }
     __syncthreads();
-    const int nt4[4] = {wave * 4, wave * 4 + 1, wave * 4 + 2, wave * 4 + 3};
     f32x4 acc[1][4];
     auto store_h = [&](T* dst, const float* bias, float* save) {
 #pragma unroll
