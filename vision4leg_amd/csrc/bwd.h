@@ -382,9 +382,34 @@ __global__ __launch_bounds__(256) void bwd_layer_kernel(BwdLayer w, BwdHead hd, 
     float* ds = sp + (SPW + wave) * NTOK * ATT_PLD;
     const float* dc = a + wave * NTOK * LY::LDX;
     if (act) {
-      for (int pr = lane; pr < NTOK * NTOK; pr += 64) {
-        const int i = pr / NTOK, j = pr - i * NTOK;
-        ds[i * ATT_PLD + j] = dot64(dc + i * LY::LDX, qs + j * LY::LDQ + 2 * TD);
+      if (lane < 54) {  // dP in 2x3 register tiles (rows 2a,2a+1 x keys 3b..3b+2): 5 LDS rows feed 6 dot products
+        const int a2 = lane / 6, b3 = lane - a2 * 6;
+        const int i0 = 2 * a2, i1 = min(i0 + 1, NTOK - 1), j0 = 3 * b3, j1 = min(j0 + 1, NTOK - 1), j2 = min(j0 + 2, NTOK - 1);
+        const float *da = dc + i0 * LY::LDX, *db = dc + i1 * LY::LDX;
+        const float *va = qs + j0 * LY::LDQ + 2 * TD, *vb = qs + j1 * LY::LDQ + 2 * TD, *vc = qs + j2 * LY::LDQ + 2 * TD;
+        float s00 = 0.f, s01 = 0.f, s02 = 0.f, s10 = 0.f, s11 = 0.f, s12 = 0.f;
+#pragma unroll 4
+        for (int d = 0; d < TD; d += 4) {
+          const float4 x0 = *reinterpret_cast<const float4*>(da + d), x1 = *reinterpret_cast<const float4*>(db + d);
+          const float4 y0 = *reinterpret_cast<const float4*>(va + d), y1 = *reinterpret_cast<const float4*>(vb + d);
+          const float4 y2 = *reinterpret_cast<const float4*>(vc + d);
+          s00 = fmaf(x0.x, y0.x, s00); s00 = fmaf(x0.y, y0.y, s00); s00 = fmaf(x0.z, y0.z, s00); s00 = fmaf(x0.w, y0.w, s00);
+          s01 = fmaf(x0.x, y1.x, s01); s01 = fmaf(x0.y, y1.y, s01); s01 = fmaf(x0.z, y1.z, s01); s01 = fmaf(x0.w, y1.w, s01);
+          s02 = fmaf(x0.x, y2.x, s02); s02 = fmaf(x0.y, y2.y, s02); s02 = fmaf(x0.z, y2.z, s02); s02 = fmaf(x0.w, y2.w, s02);
+          s10 = fmaf(x1.x, y0.x, s10); s10 = fmaf(x1.y, y0.y, s10); s10 = fmaf(x1.z, y0.z, s10); s10 = fmaf(x1.w, y0.w, s10);
+          s11 = fmaf(x1.x, y1.x, s11); s11 = fmaf(x1.y, y1.y, s11); s11 = fmaf(x1.z, y1.z, s11); s11 = fmaf(x1.w, y1.w, s11);
+          s12 = fmaf(x1.x, y2.x, s12); s12 = fmaf(x1.y, y2.y, s12); s12 = fmaf(x1.z, y2.z, s12); s12 = fmaf(x1.w, y2.w, s12);
+        }
+        float* r0 = ds + i0 * ATT_PLD;
+        float* r1 = ds + i1 * ATT_PLD;
+        r0[j0] = s00;
+        if (j0 + 1 < NTOK) r0[j0 + 1] = s01;
+        if (j0 + 2 < NTOK) r0[j0 + 2] = s02;
+        if (i0 + 1 < NTOK) {
+          r1[j0] = s10;
+          if (j0 + 1 < NTOK) r1[j0 + 1] = s11;
+          if (j0 + 2 < NTOK) r1[j0 + 2] = s12;
+        }
       }
       if (lane < 3 * NTOK) {  // zero the 3 padding columns of every P / dS row (read below as float4)
         const int i = lane / 3, j = NTOK + lane - i * 3;
