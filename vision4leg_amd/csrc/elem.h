@@ -450,17 +450,32 @@ __global__ __launch_bounds__(1024) void actor_loss_kernel(const float* __restric
   float lp_mx = -INFINITY, lp_mn = INFINITY, r_mx = -INFINITY, r_mn = INFINITY;
   for (int i = threadIdx.x; i < n; i += blockDim.x) {
     const int slot = rowidx ? rowidx[i] : i;
-    float lp = 0.f, lpo = 0.f, z2[8], dm[8];
-    for (int a = 0; a < A; ++a) {
-      const float x = acts[(int64_t)slot * A + a];
-      const float d = x - mean[(int64_t)i * OUT_LD + a];
-      const float var = sg[a] * sg[a];
-      lp += -(d * d) / (2.f * var) - lsg[a] - HALF_LOG_2PI;
-      z2[a] = d * d / var;
-      dm[a] = d / var;
+    float lp = 0.f, lpo = 0.f, z2[8], dm[8], mu[8], tmu[8];
+    {  // the padded [OUT_LD] rows are 64-byte aligned: two 16-byte loads per row instead of A strided scalar ones
+      const float4 m0 = *reinterpret_cast<const float4*>(mean + (int64_t)i * OUT_LD);
+      const float4 m1 = *reinterpret_cast<const float4*>(mean + (int64_t)i * OUT_LD + 4);
+      mu[0] = m0.x; mu[1] = m0.y; mu[2] = m0.z; mu[3] = m0.w; mu[4] = m1.x; mu[5] = m1.y; mu[6] = m1.z; mu[7] = m1.w;
       if (logp_old == nullptr) {
-        const float dt = x - tmean[(int64_t)i * OUT_LD + a];
-        lpo += -(dt * dt) / (2.f * tsg[a] * tsg[a]) - tlsg[a] - HALF_LOG_2PI;
+        const float4 t0 = *reinterpret_cast<const float4*>(tmean + (int64_t)i * OUT_LD);
+        const float4 t1 = *reinterpret_cast<const float4*>(tmean + (int64_t)i * OUT_LD + 4);
+        tmu[0] = t0.x; tmu[1] = t0.y; tmu[2] = t0.z; tmu[3] = t0.w; tmu[4] = t1.x; tmu[5] = t1.y; tmu[6] = t1.z; tmu[7] = t1.w;
+      }
+    }
+#pragma unroll
+    for (int a = 0; a < 8; ++a) {
+      if (a < A) {
+        const float x = acts[(int64_t)slot * A + a];
+        const float d = x - mu[a];
+        const float var = sg[a] * sg[a];
+        lp += -(d * d) / (2.f * var) - lsg[a] - HALF_LOG_2PI;
+        z2[a] = d * d / var;
+        dm[a] = d / var;
+        if (logp_old == nullptr) {
+          const float dt = x - tmu[a];
+          lpo += -(dt * dt) / (2.f * tsg[a] * tsg[a]) - tlsg[a] - HALF_LOG_2PI;
+        }
+      } else {
+        z2[a] = 0.f; dm[a] = 0.f;
       }
     }
     if (logp_old != nullptr) lpo = logp_old[slot];  // stored when the action was taken (== the target policy's)
@@ -471,8 +486,16 @@ __global__ __launch_bounds__(1024) void actor_loss_kernel(const float* __restric
     s_sur += fminf(pre, clp);
     // d(-mean(min(pre,clp)))/dlogp: the clipped branch has zero slope outside the clip range
     const float dlp = (pre <= clp) ? -inv_n * an * ratio : 0.f;
-    for (int a = 0; a < OUT_LD; ++a) dmean[(int64_t)i * OUT_LD + a] = a < A ? dlp * dm[a] : 0.f;
-    for (int a = 0; a < A; ++a) dl[a] += dlp * (z2[a] - 1.f);
+    {
+      float4* drow = reinterpret_cast<float4*>(dmean + (int64_t)i * OUT_LD);
+      drow[0] = float4{dlp * dm[0], dlp * dm[1], dlp * dm[2], dlp * dm[3]};  // dm[a >= A] == 0
+      drow[1] = float4{dlp * dm[4], dlp * dm[5], dlp * dm[6], dlp * dm[7]};
+      drow[2] = float4{0.f, 0.f, 0.f, 0.f};
+      drow[3] = float4{0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll
+    for (int a = 0; a < 8; ++a)
+      if (a < A) dl[a] += dlp * (z2[a] - 1.f);
     s_lp += lp; s_lp2 += (double)lp * lp;
     lp_mx = fmaxf(lp_mx, lp); lp_mn = fminf(lp_mn, lp);
     r_mx = fmaxf(r_mx, ratio); r_mn = fminf(r_mn, ratio);
