@@ -64,6 +64,8 @@ def parse():
     ap.add_argument("--workload", default="loco", choices=sorted(WORKLOADS))
     ap.add_argument("--compute", default=os.environ.get("V4L_COMPUTE", "bf16"), choices=["bf16", "f32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-parity", action="store_true", help="skip the oracle parity check, h2d and reference-protocol legs")
+    ap.add_argument("--no-reference-protocol", action="store_true")
     ap.add_argument("--no-rollout", action="store_true", help="time (ii)-(iv) only (the reference's Train___Time)")
     ap.add_argument("--breakdown", default=None, help="write the per-op HIP-event breakdown to this file")
     return ap.parse_args()
@@ -171,6 +173,29 @@ class Epoch:
         self.update()
 
 
+def host_cpu():
+    """CPU model string, physical cores (unique (package, core) pairs) and logical CPUs of this host."""
+    model, pairs, phys, core = "unknown", set(), None, None
+    try:
+        for line in open("/proc/cpuinfo"):
+            k, _, v = line.partition(":")
+            k, v = k.strip(), v.strip()
+            if k == "model name":
+                model = v
+            elif k == "physical id":
+                phys = v
+            elif k == "core id":
+                core = v
+            elif not k and phys is not None and core is not None:
+                pairs.add((phys, core)); phys = core = None
+        if phys is not None and core is not None:
+            pairs.add((phys, core))
+    except OSError:
+        pass
+    affinity = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    return {"model": model, "physical_cores": len(pairs) or None, "logical_cpus": os.cpu_count(), "usable_cpus": affinity}
+
+
 def cpu_baseline(wl, compute):
     """The CPU oracle (oracle/ppo_oracle.py, kind 'port': the restatement pinned against the reference) on a bounded
     sample of the same workload (warm-up, then 16 minibatch updates + 64 inference step pairs +
@@ -228,13 +253,128 @@ def cpu_baseline(wl, compute):
     n_mb = OPT_EPOCHS * (T * E // B)
     t_epoch = n_mb * t_upd + T * t_inf + t_gae
     return {
-        "value": round(E * T / t_epoch, 2), "unit": "env-steps/s", "cores": cores, "kind": "port",
+        "value": round(E * T / t_epoch, 2), "unit": "env-steps/s", "cores": cores, "kind": "port", "host": host_cpu(),
         "sample": "%d minibatch updates (B=%d) + %d rollout step pairs (pf+vf fwd, E=%d) + 1 GAE [%dx%d] of the same "
                   "workload, fp32 torch-CPU oracle with %d threads (best of 8/16/32/64 on this host), extrapolated to one epoch (%d updates, %d steps)"
                   % (n_upd, B, n_inf, E, T, E, cores, n_mb, T),
         "update_only_value": round(E * T / (n_mb * t_upd), 2),
         "s_per_update": round(t_upd, 4), "s_per_rollout_step": round(t_inf, 5), "s_gae": round(t_gae, 4),
     }
+
+
+def parity_check(wl, compute, dev):
+    """The checker leg (oracle = test infrastructure, never in the timed region): ONE minibatch update at the benchmark's
+    B through a fresh HIP trainer (PPO.update, the C ABI) and through the CPU oracle in the same compute flavour and in
+    fp32; max over the 18 logger scalars of |hip - oracle| / max(1, |oracle|) and the parameter distance after the step."""
+    import util
+    from oracle import ppo_oracle as orc
+    import vision4leg_amd.torchrl.networks as networks
+    import vision4leg_amd.torchrl.policies as policies
+    from vision4leg_amd.torchrl.algo import PPO
+    case = dict(wl, seed=0)
+    B = wl["B"]
+    b = util.make_batch(case, B=B)
+    t = lambda a: torch.tensor(a, dtype=torch.float32)
+    out = {"batch": B, "what": "one PPO.update (critic + actor, clip, Adam) on a seeded minibatch: 18 infos and parameters "
+                               "after the step, HIP vs CPU oracle"}
+    infos = {}
+
+    def fresh():
+        torch.manual_seed(0)
+        return util.build_nets(networks, policies, case)
+    pf, vf = fresh()
+
+    class Coll: epoch_frames = 1
+    agent = PPO(pf=pf, vf=vf, plr=1e-4, vlr=1e-4, clip_para=0.2, opt_epochs=OPT_EPOCHS, tau=0.95, entropy_coeff=0.005,
+                collector=Coll(), device=dev, batch_size=B)
+    agent.trainer.sync_target()
+    infos["hip"] = agent.update({k: b[k] for k in ("obs", "acts", "advs", "estimate_returns", "values")})
+    hip_p = {k: v.detach().cpu() for k, v in agent.pf.state_dict().items()}
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
+    for mode in dict.fromkeys((compute, "f32")):
+        opf_m, ovf_m = fresh()
+        opf = {k: v.detach().clone() for k, v in opf_m.state_dict().items()}
+        ovf = util.share_encoder(opf, {k: v.detach().clone() for k, v in ovf_m.state_dict().items()}, wl["kind"])
+        oracle = orc.PPOOracle(wl["kind"], opf, ovf, {k: v.clone() for k, v in opf.items()}, wl["S"], mode)
+        oracle.sync_target()
+        oi = oracle.update(t(b["obs"]), t(b["acts"]), t(b["advs"]), t(b["estimate_returns"]), t(b["values"]), 1e-4, 1e-4)
+        out["max_rel_err_infos_vs_%s_oracle" % mode] = float("%.3e" % max(
+            abs(infos["hip"][k] - oi[k]) / max(1.0, abs(oi[k])) for k in util.STAT_KEYS))
+        d = [(hip_p[k] - opf[k]).abs() for k in opf]
+        out["max_abs_param_diff_vs_%s_oracle" % mode] = float("%.3e" % max(x.max().item() for x in d))
+        out["mean_abs_param_diff_vs_%s_oracle" % mode] = float("%.3e" % (sum(x.sum().item() for x in d) / sum(x.numel() for x in d)))
+    out["finite"] = bool(np.isfinite(list(infos["hip"].values())).all())
+    return out
+
+
+def reference_protocol(wl, compute, dev):
+    """One epoch driven the way the UNCHANGED reference collector / PPO drive the modules (collector/on_policy.py:90-155,
+    ppo.py:28-40,125-153): per env step `torch.Tensor(ob).to(device)` from pageable float64 rows, `pf.explore`, `vf`,
+    D2H of action and value, float64 host `OnPolicyReplayBuffer.add_sample`; then last value + GAE and 48 minibatch
+    updates, each gathered from the float64 host arrays and uploaded (5 H2D copies). Simulator time is zero (synthetic
+    rows); this is what a maintainer gets from `overlay.install()` without touching the collector."""
+    import util
+    import vision4leg_amd.torchrl.networks as networks
+    import vision4leg_amd.torchrl.policies as policies
+    from vision4leg_amd.torchrl.algo import PPO
+    from vision4leg_amd.torchrl.replay_buffers import OnPolicyReplayBuffer
+    case = dict(wl, seed=0)
+    E, T, B, A = wl["E"], wl["T"], wl["B"], wl["A"]
+    D = util.obs_dim(case)
+    torch.manual_seed(0)
+    pf, vf = util.build_nets(networks, policies, case)
+    buf = OnPolicyReplayBuffer(max_replay_buffer_size=E * T, env_nums=E, time_limit_filter=True)
+
+    class Coll: epoch_frames = E * T
+
+    class Log:
+        def add_update_info(self, info): pass
+    agent = PPO(pf=pf, vf=vf, plr=1e-4, vlr=1e-4, clip_para=0.2, opt_epochs=OPT_EPOCHS, tau=0.95, shuffle=True,
+                entropy_coeff=0.005, collector=Coll(), replay_buffer=buf, logger=Log(), device=dev, discount=0.99,
+                num_epochs=1500, batch_size=B)
+    rs = np.random.RandomState(0)
+    pool = [np.concatenate([np.clip(rs.randn(E, wl["S"]), -10, 10), np.clip(rs.randn(E, D - wl["S"]), -2.5, 2.8)], 1)
+            for _ in range(8)]  # float64 rows as the env wrappers hand them over
+
+    def epoch():
+        ob = pool[0]
+        for t_ in range(T):
+            ob_t = torch.Tensor(ob).to(dev)
+            acts = agent.pf.explore(ob_t)["action"].detach().cpu().numpy()
+            values = agent.vf(ob_t).detach().cpu().numpy()
+            nxt = pool[(t_ + 1) % len(pool)]
+            buf.add_sample({"obs": ob, "next_obs": nxt, "acts": acts, "values": values, "rewards": np.ones((E, 1)),
+                            "terminals": np.zeros((E, 1), dtype=bool), "time_limits": [False]})
+            ob = nxt
+        t1 = time.perf_counter()
+        agent.update_per_epoch()
+        torch.cuda.synchronize()
+        return t1
+    epoch()  # warm-up (allocations, graph-free eager path)
+    t0 = time.perf_counter()
+    t1 = epoch()
+    t2 = time.perf_counter()
+    return {"value": round(E * T / (t2 - t0), 1), "unit": "env-steps/s", "ms_per_epoch": round(1e3 * (t2 - t0), 1),
+            "rollout_ms": round(1e3 * (t1 - t0), 1), "update_ms": round(1e3 * (t2 - t1), 1),
+            "what": "reference call protocol on the HIP modules: per-step pageable H2D + pf.explore + vf + D2H, float64 host "
+                    "buffer, per-minibatch gather + upload; no RolloutActor, no device-resident buffer, no stored log-prob"}
+
+
+def h2d_per_step(wl, dev, steps=64):
+    """Pinned-host -> HBM upload of one env step's E observation rows (E x (S+16384) fp32), what the fast collector pays
+    per step when it is NOT overlapped with the simulator: mean ms per step over back-to-back async copies + one sync."""
+    import util
+    D = util.obs_dim(dict(wl, seed=0))
+    host = [torch.empty(wl["E"], D, dtype=torch.float32).pin_memory() for _ in range(2)]
+    devb = [torch.empty(wl["E"], D, dtype=torch.float32, device=dev) for _ in range(2)]
+    for i in range(4):
+        devb[i & 1].copy_(host[i & 1], non_blocking=True)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        devb[i & 1].copy_(host[i & 1], non_blocking=True)
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) * 1e3 / steps
 
 
 PEAK_HBM = 8000.0  # GB/s, MI355X_MICROARCH.md
@@ -261,22 +401,26 @@ def algo_bytes(kernel, wl, compute):
         # both operands of the 4 linears x 2 layers (T) in; 55 slabs of the 4 weight shapes x 2 layers out
         "gemm_tn_wide": 2 * R * 2 * (64 + 256 + 64 + 192) * t + 2 * 55 * 49152 * 4,
     }
+    E = wl["E"]
+    enc_w = (4 * 64 * 32 + 32 * 16 * 64 + 64 * 9 * 64 + 64 * 64 + 128 * 256 + 256 * 256 + 256 * 64) * t
+    layer_w = (64 * 192 + 64 * 64 + 64 * 256 + 256 * 64) * t
+    head_w = (128 * 256 + 256 * 256 + 256 * 16) * t
+    # rollout step (E rows): observation rows in, rollout image / proprio rows + tokens out, weights streamed once;
+    # layer stack: tokens in for both nets, both nets' layer + head weights, action / value / log-prob out
+    per_launch["rollout_encoder"] = E * ((wl["S"] + 16384) * 4 + 16384 * t + 128 * 4 + 17 * tok) + enc_w
+    per_launch["rollout_layers_head"] = 2 * E * 17 * tok + 2 * (wl.get("layers", 2) * layer_w + head_w) + E * 64
     for k in sorted(per_launch, key=len, reverse=True):  # longest name first: fused_layer_bwd_* before fused_layer_*
         if kernel == k or kernel.startswith(k + "_"):
             return float(per_launch[k])
     return None
 
 
-def roofline(ep, compute, breakdown_path):
-    """Per-op timings of ONE profiled pass of (ii)-(iv): HIP events around every launch, on the launch stream. The
-    dominant kernel (largest total time) is priced against BOTH ceilings — algorithmic FLOPs / dense MFMA peak and
-    algorithmic HBM bytes / 8 TB/s — and reported against the one that bounds it (the larger lower-bound time)."""
+def _profiled(L, fn):
+    """Run fn() with the library's HIP-event profiler on; -> [(phase|op|kernel, calls, total_us, flops)]."""
     import ctypes as C
-    from vision4leg_amd import _lib
-    L = _lib.lib()
     torch.cuda.synchronize()
     L.v4l_prof_enable(1)
-    ep.update()
+    fn()
     buf = C.create_string_buffer(1 << 20)
     L.v4l_prof_collect(buf, len(buf))
     L.v4l_prof_enable(0)
@@ -284,78 +428,99 @@ def roofline(ep, compute, breakdown_path):
     for line in buf.value.decode().splitlines():
         label, calls, us, flops = line.split("\t")
         rows.append((label, int(calls), float(us), float(flops)))
+    return rows
+
+
+def _per_kernel(rows):
+    out = {}
+    for label, calls, us, fl in rows:
+        k = label.split("|")[-1]
+        c0, u0, f0 = out.get(k, (0, 0.0, 0.0))
+        out[k] = (c0 + calls, u0 + us, f0 + fl)
+    return out
+
+
+def roofline(ep, compute, breakdown_path):
+    """Per-op timings of ONE profiled step (rollout (i) + update (ii)-(iv), the same proportions as the timed region): HIP
+    events around every launch, on the launch stream. The dominant kernel of the WHOLE step (largest total time) is priced
+    against BOTH ceilings — algorithmic FLOPs / dense MFMA peak and algorithmic HBM bytes / 8 TB/s — and reported against
+    the one that bounds it (the larger lower-bound time). `rollout` and `update` carry the dominant kernel of each side."""
+    from vision4leg_amd import _lib
+    L = _lib.lib()
+    wl = ep.wl
+    upd = _profiled(L, ep.update)
+    roll = _profiled(L, ep.rollout) if ep.actor is not None else []
+    rows = sorted(upd + roll, key=lambda r: -r[2])
     if not rows:
         return None
-    rows.sort(key=lambda r: -r[2])
     total_us = sum(r[2] for r in rows)
+    upd_us, roll_us = sum(r[2] for r in upd), sum(r[2] for r in roll)
     if breakdown_path:
         with open(breakdown_path, "w") as f:
-            f.write("# one profiled epoch-update (%d updates): phase|op|kernel, calls, total_us, avg_us, TFLOP/s, share\n"
-                    % ep.stats.shape[0])
+            f.write("# one profiled step = rollout (%d env steps x %d envs) + epoch-update (%d updates): phase|op|kernel, calls, "
+                    "total_us, avg_us, TFLOP/s, share of the step's kernel time\n" % (wl["T"], wl["E"], ep.stats.shape[0]))
             for label, calls, us, fl in rows:
                 f.write("%-70s %6d %12.1f %9.2f %9.2f %6.2f%%\n"
                         % (label, calls, us, us / calls, fl / us * 1e-6 if us > 0 else 0.0, 100 * us / total_us))
-            f.write("# total kernel time %.1f us\n" % total_us)
-            if ep.actor is not None:  # the rollout side, profiled the same way
-                L.v4l_prof_enable(1)
-                ep.rollout()
-                torch.cuda.synchronize()
-                L.v4l_prof_collect(buf, len(buf))
-                L.v4l_prof_enable(0)
-                f.write("# one profiled rollout (%d env steps x %d envs)\n" % (ep.wl["T"], ep.wl["E"]))
-                for line in buf.value.decode().splitlines():
-                    label, calls, us, fl = line.split("\t")
-                    f.write("%-70s %6d %12.1f %9.2f\n" % (label, int(calls), float(us), float(us) / int(calls)))
-    # dominant KERNEL: sum the (phase, op) rows of the same kernel name
-    per_kernel = {}
-    for label, calls, us, fl in rows:
-        k = label.split("|")[-1]
-        c0, u0, f0 = per_kernel.get(k, (0, 0.0, 0.0))
-        per_kernel[k] = (c0 + calls, u0 + us, f0 + fl)
-    kern, (calls, us, fl) = max(per_kernel.items(), key=lambda kv: kv[1][1])
-    avg_us = us / calls
-    tf = fl / us * 1e-6                      # TFLOP/s
-    by = algo_bytes(kern, ep.wl, compute)
-    gbs = by / avg_us * 1e-3 if by else None  # GB/s
-    t_mfma = fl / calls / (PEAK[compute] * 1e12) * 1e6
-    t_hbm = by / (PEAK_HBM * 1e9) * 1e6 if by else 0.0
-    hbm_bound = t_hbm >= t_mfma
-    traffic, traffic_src = None, None
-    pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")  # written by tools/pmc_pass.sh + pmc_summary.py (same command)
-    if os.path.exists(pmc):
+            f.write("# total kernel time %.1f us (update %.1f, rollout %.1f)\n" % (total_us, upd_us, roll_us))
+    pmc = {}
+    pmc_path = os.path.join(ROOT, "profiles", "pmc_traffic.json")  # written by tools/pmc_pass.sh + pmc_summary.py (same command)
+    if os.path.exists(pmc_path):
         try:
-            rec = json.load(open(pmc)).get(kern)
-            if rec:
-                traffic, traffic_src = rec["hbm_bytes_per_launch"], rec.get("source")
+            pmc = json.load(open(pmc_path))
         except Exception:
-            pass
-    all_flops = sum(r[3] for r in rows)
+            pmc = {}
+
+    def price(kern, calls, us, fl):
+        avg_us = us / calls
+        tf = fl / us * 1e-6                      # TFLOP/s
+        by = algo_bytes(kern, wl, compute)
+        gbs = by / avg_us * 1e-3 if by else None  # GB/s
+        t_mfma = fl / calls / (PEAK[compute] * 1e12) * 1e6
+        t_hbm = by / (PEAK_HBM * 1e9) * 1e6 if by else 0.0
+        hbm_bound = bool(by) and t_hbm >= t_mfma
+        rec = pmc.get(kern) or {}
+        return {
+            "bound": "hbm" if hbm_bound else "mfma", "kernel": kern,
+            "achieved": round(gbs, 1) if hbm_bound else round(tf, 2),
+            "peak": PEAK_HBM if hbm_bound else PEAK[compute], "unit": "GB/s" if hbm_bound else "TFLOP/s",
+            "frac": round((gbs / PEAK_HBM) if hbm_bound else (tf / PEAK[compute]), 5),
+            "traffic": rec.get("hbm_bytes_per_launch"), "traffic_source": rec.get("source"),
+            "algorithmic_bytes_per_launch": by, "algorithmic_flops_per_launch": fl / calls,
+            "hbm_frac": round(gbs / PEAK_HBM, 5) if gbs else None, "mfma_frac": round(tf / PEAK[compute], 5),
+            "avg_launch_us": round(avg_us, 2), "launches": calls, "share_of_kernel_time": round(us / total_us, 4),
+        }
+    kern, (calls, us, fl) = max(_per_kernel(rows).items(), key=lambda kv: kv[1][1])
+    res = price(kern, calls, us, fl)
+    res["scope"] = "whole timed step: rollout-side inference + GAE + %d minibatch updates" % ep.stats.shape[0]
+    res["all_kernels_tflops"] = round(sum(r[3] for r in rows) / total_us * 1e-6, 2)
+    res["kernel_time_split"] = {"update_us": round(upd_us, 1), "rollout_us": round(roll_us, 1)}
+    if upd:
+        k, (c, u, f) = max(_per_kernel(upd).items(), key=lambda kv: kv[1][1])
+        res["update"] = price(k, c, u, f)
+    if roll:
+        k, (c, u, f) = max(_per_kernel(roll).items(), key=lambda kv: kv[1][1])
+        r = price(k, c, u, f)
+        nets = 2 if "layer" in k else 1
+        blocks = wl["E"] * nets + (wl["E"] + 31) // 32 * (0 if "layer" in k else 1)
+        r["workgroups"] = blocks
+        r["cu_occupancy"] = round(min(1.0, blocks / 256.0), 4)
+        r["env_step_us"] = round(roll_us / wl["T"], 2)
+        res["rollout"] = r
     # the transformer block's own kernels (north star: MFMA fraction "for the transformer block"; SURVEY 8d: kernel time x
     # known FLOPs over the block's kernels only): fused layer forward / backward launches and their weight-grad GEMM
-    tb = [r for r in rows if r[0].split("|")[1] in ("layer", "layer.wgrad", "attn", "ln1", "ln2")
+    tb = [r for r in upd if r[0].split("|")[1] in ("layer", "layer.wgrad", "attn", "ln1", "ln2")
           or ".self_attn." in r[0] or ".linear1." in r[0] or ".linear2." in r[0]]
-    tblock = None
     if tb:
         tb_us, tb_fl = sum(r[2] for r in tb), sum(r[3] for r in tb)
-        tblock = {"tflops": round(tb_fl / tb_us * 1e-6, 2), "mfma_frac": round(tb_fl / tb_us * 1e-6 / PEAK[compute], 5),
-                  "share_of_kernel_time": round(tb_us / total_us, 4),
-                  "kernels": sorted({r[0].split("|")[-1] for r in tb}),
-                  "note": "2*M*N*K FLOPs of the launches / their HIP-event time; at B = 1024 one layer pass is 1.8 GFLOP "
-                          "(0.7 us at peak) inside a 30-launch dependent chain: latency-bound by size, see DESIGN.md section 4"}
-    return {
-        "bound": "hbm" if hbm_bound else "mfma", "kernel": kern,
-        "achieved": round(gbs, 1) if hbm_bound else round(tf, 2),
-        "peak": PEAK_HBM if hbm_bound else PEAK[compute], "unit": "GB/s" if hbm_bound else "TFLOP/s",
-        "frac": round((gbs / PEAK_HBM) if hbm_bound else (tf / PEAK[compute]), 5),
-        "traffic": traffic, "traffic_source": traffic_src,
-        "algorithmic_bytes_per_launch": by, "algorithmic_flops_per_launch": fl / calls,
-        "hbm_frac": round(gbs / PEAK_HBM, 5) if gbs else None, "mfma_frac": round(tf / PEAK[compute], 5),
-        "avg_launch_us": round(avg_us, 2), "launches": calls, "share_of_kernel_time": round(us / total_us, 4),
-        "all_kernels_tflops": round(all_flops / total_us * 1e-6, 2),
-        "transformer_block": tblock,
-        "method": "HIP events around every launch of one extra (untimed) epoch-update on the launch stream; achieved = "
-                  "algorithmic bytes (bench.py algo_bytes, DESIGN.md section 4) or 2*M*N*K FLOPs per launch / average launch time",
-    }
+        res["transformer_block"] = {
+            "tflops": round(tb_fl / tb_us * 1e-6, 2), "mfma_frac": round(tb_fl / tb_us * 1e-6 / PEAK[compute], 5),
+            "share_of_kernel_time": round(tb_us / total_us, 4), "kernels": sorted({r[0].split("|")[-1] for r in tb}),
+            "note": "2*M*N*K FLOPs of the update's layer launches / their HIP-event time (DESIGN.md section 4)"}
+    res["method"] = ("HIP events around every launch of one extra (untimed) rollout + epoch-update on the launch stream; "
+                     "achieved = algorithmic bytes (bench.py algo_bytes, DESIGN.md section 4) or 2*M*N*K FLOPs per launch / "
+                     "average launch time")
+    return res
 
 
 def batch1_latency(ep, policies, dev):
@@ -444,8 +609,20 @@ def main():
         "algorithmic_tflops": round(value * (MFLOP_PER_ENV_STEP[a.workload] - (OPT_EPOCHS * MFLOP_TARGET_FWD[a.workload]
                                                                                if ep.logp is not None else 0.0)) * 1e-6, 3),
     }
+    stats_ok = bool(torch.isfinite(ep.stats[:, :18]).all().item())
+    if not stats_ok:
+        raise SystemExit("bench.py: non-finite logger statistics after the timed epochs: the step is invalid")
+    res["stats_finite"] = stats_ok
     if rank == 0:
         res["roofline"] = roofline(ep, a.compute, a.breakdown)
+        if world == 1 and not a.no_parity:
+            res["parity_check"] = parity_check(wl, a.compute, dev)
+            res["h2d_ms_per_step"] = round(h2d_per_step(wl, dev), 4)
+            res["h2d_note"] = ("pinned upload of E x (S+16384) fp32 observation rows per env step, NOT inside `value` (the "
+                               "epoch is resident in HBM when the timed region starts); value_incl_h2d adds T x this, unoverlapped")
+            res["value_incl_h2d"] = round(frames * a.steps / (dt + a.steps * wl["T"] * res["h2d_ms_per_step"] * 1e-3), 1)
+            if not a.no_rollout and not a.no_reference_protocol:
+                res["reference_protocol"] = reference_protocol(wl, a.compute, dev)
         if not a.no_cpu_baseline and world == 1:  # the host baseline is an N = 1 measurement (the other ranks would idle)
             res["cpu_baseline"] = cpu_baseline(wl, a.compute)
             res["vs_cpu_baseline"] = round(value / world / res["cpu_baseline"]["value"], 1)

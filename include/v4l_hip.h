@@ -220,6 +220,8 @@ int v4l_trainer_sync_target(v4l_trainer* tr, void* stream);
  * into buf (NUL terminated, truncated to cap) and returns the untruncated length. */
 int v4l_prof_enable(int on);
 int64_t v4l_prof_collect(char* buf, int64_t cap);
+/* (diagnostic builds compiled with -DV4L_INFER_TIMING additionally export a clock64 phase-stamp reader used by
+ * tools/probe/stamps*.py; it is not part of this ABI and absent from the shipped library.) */
 
 /* ---- introspection for tests: float offset of a named activation inside a workspace laid out for n rows
  * ("c1","c2","c3","eh<i>","x<l>","qkv<l>","P<l>","ctx<l>","mid<l>","ff<l>","pooled","hh<i>","out","dout",…); -1 if unknown */

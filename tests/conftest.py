@@ -19,3 +19,18 @@ def device():
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
     return torch.device("cuda:0")
+
+
+def pytest_sessionfinish(session, exitstatus):
+    """Keep the parity errors the GPU tests measured (util.record) as a file: gpurun_out/parity.json."""
+    import json
+    import util
+    if not util.PARITY:
+        return
+    out = os.path.join(ROOT, "gpurun_out")
+    try:
+        os.makedirs(out, exist_ok=True)
+        with open(os.path.join(out, "parity.json"), "w") as f:
+            json.dump({"exitstatus": int(exitstatus), "errors": dict(sorted(util.PARITY.items()))}, f, indent=1)
+    except OSError:
+        pass

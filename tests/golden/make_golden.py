@@ -117,8 +117,10 @@ def main():
         agent = RefPPO(pf=pf, vf=vf, plr=1e-4, vlr=1e-4, clip_para=0.2, opt_epochs=3, tau=0.95, shuffle=True,
                        entropy_coeff=0.005, env=Env(), replay_buffer=None, collector=Coll(), logger=Log(),
                        device=torch.device("cpu"), discount=0.99, num_epochs=1500, batch_size=case["B"],
-                       save_interval=100, eval_interval=10, save_dir=tmp)
-        oracle = orc.PPOOracle(case["kind"], opf, ovf, {k: v.clone() for k, v in opf.items()}, case["S"])
+                       save_interval=100, eval_interval=10, save_dir=tmp,
+                       clipped_value_loss=case.get("clipped_value_loss", False))
+        oracle = orc.PPOOracle(case["kind"], opf, ovf, {k: v.clone() for k, v in opf.items()}, case["S"],
+                               clipped_value_loss=case.get("clipped_value_loss", False))
         oracle.sync_target()
         small = util.small_param_names(pf.state_dict(), vf.state_dict())
         for u in range(2):

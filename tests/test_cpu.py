@@ -36,7 +36,8 @@ def test_oracle_matches_reference_golden(name):
         om = orc.FORWARDS[case["kind"]]({k: v for k, v in opf.items() if k != "logstd"}, t(b["obs"]), case["S"])
         ov = orc.FORWARDS[case["kind"]](ovf, t(b["obs"]), case["S"])
     assert util.rel_err(om, gold["fwd_mean"]) < 2e-5 and util.rel_err(ov, gold["fwd_value"]) < 2e-5
-    oracle = orc.PPOOracle(case["kind"], opf, ovf, {k: v.clone() for k, v in opf.items()}, case["S"])
+    oracle = orc.PPOOracle(case["kind"], opf, ovf, {k: v.clone() for k, v in opf.items()}, case["S"],
+                           clipped_value_loss=case.get("clipped_value_loss", False))
     oracle.sync_target()
     info = oracle.update(t(b["obs"]), t(b["acts"]), t(b["advs"]), t(b["estimate_returns"]), t(b["values"]), 1e-4, 1e-4)
     for k, g in zip(util.STAT_KEYS, gold["u0/info"]):

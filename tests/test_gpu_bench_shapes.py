@@ -1,0 +1,118 @@
+"""-m gpu: the kernels in the configuration bench.py times them in. util.CASES["loco_b1024" / "cnn_b1024" / "loco_rag"]
+put B = 1024 and a ragged B = 300 through test_forward / test_backward / test_ppo_update (tests/test_gpu_parity.py); the
+tests here force the persistent conv-backward kernels (bwd_conv_kernel, bwd_conv3_wgrad_kernel: register-resident dW1 /
+dW2 / dW3 carried across the samples a block owns, csrc/bwd.h) into many-samples-per-block shapes at small batches and
+check the epoch-sized graph replay at B = 1024 against the oracle."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import util
+from oracle import ppo_oracle as orc
+from test_gpu_parity import MODES, TOL, _build, _oracle_params
+
+pytestmark = pytest.mark.gpu
+
+
+def _vf_grads(case, mode, device, n, obs, w, blocks=None):
+    if blocks is None:
+        os.environ.pop("V4L_CONV_BWD_BLOCKS", None)
+    else:
+        os.environ["V4L_CONV_BWD_BLOCKS"] = str(blocks)
+    try:
+        pf, vf = _build(case, mode, device)
+        hip = vf.hip
+        st, im, _ = hip.stage(obs.to(device))
+        hip.forward(st, im, n, train=True)
+        dout = torch.zeros(n, 16, dtype=torch.float32, device=device)
+        dout[:, :1] = w.to(device)
+        grads = torch.full((hip.total_params,), float("nan"), dtype=torch.float32, device=device)
+        hip.backward(st, im, n, dout, grads)
+        torch.cuda.synchronize()
+        assert not torch.isnan(grads).any()
+        return pf, vf, {k: hip.grad_view(grads, k).cpu().clone() for k in hip.param_names}
+    finally:
+        os.environ.pop("V4L_CONV_BWD_BLOCKS", None)
+
+
+@pytest.mark.parametrize("mode", MODES)
+@pytest.mark.parametrize("name,blocks", [("loco_s93", 8), ("loco_s93", 5), ("cnn_s93", 3), ("loco_s93", 1)])
+def test_conv_backward_persistent_loop(name, blocks, mode, device):
+    """B = 64 on `blocks` persistent blocks: 8 samples per block; 13 / 12 (ragged); 22 / 21; all 64 on one block. Every
+    parameter gradient vs (a) the one-sample-per-block launch of the same kernels — same rounding points, only the fp32
+    accumulation order inside dW differs — and (b) in f32 the oracle's autograd."""
+    case = util.CASES[name]
+    n = case["B"]
+    obs = torch.tensor(util.make_batch(case)["obs"], dtype=torch.float32)
+    w = torch.tensor(np.random.RandomState(9).randn(n, 1), dtype=torch.float32)
+    _, _, base = _vf_grads(case, mode, device, n, obs, w)
+    pf, vf, got = _vf_grads(case, mode, device, n, obs, w, blocks)
+    conv = [k for k, v in got.items() if v.dim() == 4]
+    assert len(conv) >= 3
+    errs = {k: util.rel_err(got[k], base[k]) for k in got}
+    worst = max(errs.values())
+    print("\n[persistent conv bwd %s %s, %d blocks] worst rel diff vs 1 sample/block %.2e" % (name, mode, blocks, worst))
+    util.record("conv_bwd_persistent/%s/%s/blocks%d/worst_rel_vs_one_sample_per_block" % (name, mode, blocks), worst)
+    for k, e in errs.items():
+        assert e <= 2e-5, (k, e)
+    if mode == "f32":
+        _, ovf = _oracle_params(pf, vf, case["kind"])
+        keys = list(ovf)
+        for k in keys:
+            ovf[k].requires_grad_(True)
+        ref = torch.autograd.grad((orc.FORWARDS[case["kind"]](ovf, obs, case["S"], mode) * w).sum(), [ovf[k] for k in keys])
+        for k, g in zip(keys, ref):
+            assert util.rel_err(got[k], g) < TOL[mode], (k, util.rel_err(got[k], g))
+
+
+@pytest.mark.parametrize("mode", MODES)
+def test_epoch_of_graph_replays_at_b1024(mode, device):
+    """What bench.py's timed region runs: run_updates over a device-resident rollout with B = 1024 row-index minibatches
+    (hipGraph replay, device-side update cursor) — 4 consecutive updates on a 2048-row rollout vs the oracle fed the same
+    gathered rows: the 18 infos of every update and the parameters at the end."""
+    from vision4leg_amd.engine import HipTrainer
+    from vision4leg_amd.torchrl.algo import PPO
+    case = util.CASES["loco_b1024"]
+    B, slots, U = 1024, 2048, 4
+    rs = np.random.RandomState(77)
+    obs = np.concatenate([np.clip(rs.randn(slots, case["S"]), -10, 10), np.clip(rs.randn(slots, 4 * 64 * 64), -2.5, 2.8)], 1)
+    acts, advs, rets, vals = 0.1 * rs.randn(slots, case["A"]), rs.randn(slots), rs.randn(slots), rs.randn(slots)
+    rows = np.stack([rs.permutation(slots)[:B] for _ in range(U)]).astype(np.int32)
+    pf, vf = _build(case, mode, device)
+
+    class Coll: epoch_frames = slots
+    agent = PPO(pf=pf, vf=vf, plr=1e-4, vlr=1e-4, clip_para=0.2, opt_epochs=3, tau=0.95, entropy_coeff=0.005,
+                collector=Coll(), device=device, batch_size=B)
+    opf, ovf = _oracle_params(pf, vf, "loco")
+    oracle = orc.PPOOracle("loco", opf, ovf, {k: v.clone() for k, v in opf.items()}, case["S"], mode)
+    oracle.sync_target()
+    net = pf.hip
+    net.ensure_bound()
+    state, image = net.alloc_rollout(slots, device)
+    t = lambda a: torch.tensor(a, dtype=torch.float32, device=device)
+    net.ingest(t(obs), state, image)
+    ro = HipTrainer.rollout(state, image, t(acts), t(advs), t(rets), t(vals))
+    stats = torch.zeros(U, 24, device=device)
+    agent.trainer.sync_target()
+    agent.run_updates(ro, torch.tensor(rows, device=device), stats)
+    torch.cuda.synchronize()
+    got = stats.cpu().numpy()
+    c = lambda a: torch.tensor(a, dtype=torch.float32)
+    worst_info = 0.0
+    for u in range(U):
+        r = rows[u]
+        oinfo = oracle.update(c(obs[r]), c(acts[r]), c(advs[r, None]), c(rets[r, None]), c(vals[r, None]), 1e-4, 1e-4)
+        for j, k in enumerate(util.STAT_KEYS):
+            e = abs(got[u, j] - oinfo[k]) / max(1.0, abs(oinfo[k]))
+            worst_info = max(worst_info, e)
+            assert e <= (5e-4 if mode == "f32" else 1e-2), (u, k, got[u, j], oinfo[k])
+    diffs = [(pf.state_dict()[k].cpu() - opf[k]).abs() for k in opf] + [(vf.state_dict()[k].cpu() - ovf[k]).abs() for k in ovf]
+    worst = max(d.max().item() for d in diffs)
+    drift = sum(d.sum().item() for d in diffs) / sum(d.numel() for d in diffs)
+    print("\n[graph epoch B=1024 %s] worst info rel %.2e, worst |dparam| %.2e, mean |dparam| %.2e" % (mode, worst_info, worst, drift))
+    util.record("graph_epoch_b1024/%s/max_info_rel_vs_oracle" % mode, worst_info)
+    util.record("graph_epoch_b1024/%s/worst_abs_param_vs_oracle" % mode, worst)
+    util.record("graph_epoch_b1024/%s/mean_abs_param_vs_oracle" % mode, drift)
+    assert worst <= (5e-5 if mode == "f32" else 2.2e-4 * U) and drift <= (2e-7 if mode == "f32" else 2e-5 * U)

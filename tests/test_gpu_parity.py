@@ -75,6 +75,8 @@ def test_forward(name, mode, device):
     gm, gv = util.rel_err(mean.cpu(), gold["fwd_mean"]), util.rel_err(value.cpu(), gold["fwd_value"])
     print("\n[%s %s] fwd rel err vs %s-oracle: mean %.2e value %.2e | vs reference(fp32): mean %.2e value %.2e"
           % (name, mode, mode, em, ev, gm, gv))
+    for what, e in (("mean_vs_oracle", em), ("value_vs_oracle", ev), ("mean_vs_reference_f32", gm), ("value_vs_reference_f32", gv)):
+        util.record("forward/%s/%s/%s" % (name, mode, what), e)
     if mode == "f32":
         assert em < TOL[mode] and ev < TOL[mode]
         assert gm < TOL[mode] and gv < TOL[mode]
@@ -198,6 +200,7 @@ def test_backward(name, mode, device):
                 if e32 > max(5e-3, 2.0 * env) or e > max(5e-3, 2.0 * env):
                     bad.append((k, "hip-vs-bf16oracle %.2e hip-vs-f32 %.2e envelope %.2e" % (e, e32, env)))
         print("\n[%s %s %s] worst grad rel err so far %.2e" % (name, mode, tag, worst))
+        util.record("backward/%s/%s/%s/worst_grad_vs_oracle" % (name, mode, tag), worst)
         assert not bad, bad
 
 
@@ -213,9 +216,11 @@ def test_ppo_update(name, mode, device):
     class Coll: epoch_frames = 1
     agent = PPO(pf=pf, vf=vf, plr=1e-4, vlr=1e-4, clip_para=0.2, opt_epochs=3, tau=0.95, shuffle=True,
                 entropy_coeff=0.005, env=None, replay_buffer=None, collector=Coll(), logger=None, device=device,
-                discount=0.99, num_epochs=1500, batch_size=case["B"], save_dir=None)
+                discount=0.99, num_epochs=1500, batch_size=case["B"], save_dir=None,
+                clipped_value_loss=case.get("clipped_value_loss", False))
     opf, ovf = _oracle_params(pf, vf, case["kind"])
-    oracle = orc.PPOOracle(case["kind"], opf, ovf, {k: v.clone() for k, v in opf.items()}, case["S"], mode)
+    oracle = orc.PPOOracle(case["kind"], opf, ovf, {k: v.clone() for k, v in opf.items()}, case["S"], mode,
+                           clipped_value_loss=case.get("clipped_value_loss", False))
     oracle.sync_target()
     agent.trainer.sync_target()
     gold = util.load_golden("ppo_" + name)
@@ -252,6 +257,12 @@ def test_ppo_update(name, mode, device):
                     dg = np.abs(v.detach().cpu().numpy() - gold["u%d/%s/%s" % (u, tag, k)]).max()
                     assert dg <= 2e-5, (u, tag, k, dg)
         print("   mean |param - oracle| = %.2e" % (tot / cnt))
+        util.record("ppo_update/%s/%s/u%d/max_info_rel_vs_oracle" % (name, mode, u),
+                    max(abs(a - o) / max(1.0, abs(o)) for _, a, o, _ in rows))
+        util.record("ppo_update/%s/%s/u%d/max_info_rel_vs_reference_f32" % (name, mode, u),
+                    max(abs(a - g) / max(1.0, abs(g)) for _, a, _, g in rows))
+        util.record("ppo_update/%s/%s/u%d/worst_abs_param_vs_oracle" % (name, mode, u), worst)
+        util.record("ppo_update/%s/%s/u%d/mean_abs_param_vs_oracle" % (name, mode, u), tot / cnt)
         assert tot / cnt <= (1e-7 if mode == "f32" else 2e-5 * (u + 1))
         print("   worst |param - oracle| = %.2e (lr = 1e-4)" % worst)
         moved = max((pf.state_dict()[k].cpu() - before[k]).abs().max().item() for k in before)

@@ -1,0 +1,134 @@
+"""CPU: the INTEGRATION.md recipe (vision4leg_amd.overlay.install) against the real reference tree — the import block of
+every PPO starter resolves, hot-path names are the HIP classes, everything else stays the reference's — and the pin of
+oracle/collector_ref.py against the reference's own VecOnPolicyCollector. Needs /root/reference (build container only);
+each case runs in a fresh interpreter so stub modules never leak into the other tests."""
+import os
+import subprocess
+import sys
+import textwrap
+
+import pytest
+
+import util
+
+REF = "/root/reference"
+pytestmark = pytest.mark.skipif(not os.path.isdir(os.path.join(REF, "torchrl")), reason="reference tree not present")
+
+STARTERS = ["ppo_locotransformer.py", "ppo_nature_cnn.py", "ppo_state.py", "ppo_locotransformer_vision_only.py",
+            "ppo_nature_cnn_vision_only.py"]
+
+
+def _run(code):
+    env = dict(os.environ, PYTHONPATH=os.pathsep.join([util.ROOT, os.path.join(util.ROOT, "tests")]), PYTHONDONTWRITEBYTECODE="1")
+    r = subprocess.run([sys.executable, "-c", textwrap.dedent(code)], capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode == 0, r.stdout[-3000:] + "\n" + r.stderr[-3000:]
+    return r.stdout
+
+
+@pytest.mark.parametrize("fast", [False, True])
+@pytest.mark.parametrize("starter", STARTERS)
+def test_starter_import_block_under_overlay(starter, fast):
+    """Execute the starter's own import lines (everything before `args = get_args()`) after overlay.install()."""
+    out = _run("""
+        import sys
+        import ref_stubs
+        ref_stubs.install()
+        import vision4leg_amd.overlay as overlay
+        report = overlay.install(fast_path=%r)
+        src = open("/root/reference/starter/%s").read()
+        head = src[:src.index("args = get_args()")]
+        ns = {"__file__": "/root/reference/starter/%s", "__name__": "starter_imports"}
+        exec(compile(head, "starter_imports", "exec"), ns)
+        import vision4leg_amd.torchrl as hip
+        import vision4leg_amd.torchrl.collector, vision4leg_amd.torchrl.algo, vision4leg_amd.torchrl.replay_buffers
+        import torchrl
+        assert not getattr(torchrl, "__v4l_shell__", False) and torchrl.__file__.startswith("/root/reference/")
+        assert ns["PPO"] is hip.algo.PPO, ns["PPO"]
+        if "VMPO" in ns:
+            assert ns["VMPO"].__module__.startswith("torchrl.algo"), ns["VMPO"]      # still the reference's
+        assert ns["Logger"].__module__.startswith("torchrl.utils")
+        nets, pols = ns["networks"], ns["policies"]
+        assert nets is torchrl.networks and pols is torchrl.policies                    # the reference's packages ...
+        for name in overlay.HOT_NAMES["networks"]:
+            assert getattr(nets, name) is getattr(hip.networks, name), name             # ... with the hot classes rebound
+        for name in overlay.HOT_NAMES["policies"]:
+            assert getattr(pols, name) is getattr(hip.policies, name), name
+        assert pols.RolloutActor is hip.policies.RolloutActor
+        assert nets.QNet.__module__ == "torchrl.networks.nets"                          # off the hot path: untouched
+        import torchrl.algo.on_policy.ppo as ref_ppo_mod
+        import torchrl.networks.nets as ref_nets_mod
+        assert ref_ppo_mod.PPO is hip.algo.PPO and ref_nets_mod.LocoTransformer is hip.networks.LocoTransformer
+        fast = %r
+        want_buf = hip.replay_buffers.DeviceOnPolicyReplayBuffer if fast else hip.replay_buffers.OnPolicyReplayBuffer
+        assert ns["OnPolicyReplayBuffer"] is want_buf
+        coll = ns["VecOnPolicyCollector"]
+        assert (coll is hip.collector.VecOnPolicyCollector) == fast, coll
+        print("OK", len(report))
+    """ % (fast, starter, starter, fast))
+    assert out.startswith("OK")
+
+
+def test_overlay_uninstall_restores_reference():
+    _run("""
+        import ref_stubs
+        ref_stubs.install()
+        import torchrl.algo, torchrl.networks
+        ref_ppo, ref_net = torchrl.algo.PPO, torchrl.networks.LocoTransformer
+        import vision4leg_amd.overlay as overlay
+        overlay.install(fast_path=True)
+        assert torchrl.algo.PPO is not ref_ppo
+        overlay.uninstall()
+        assert torchrl.algo.PPO is ref_ppo and torchrl.networks.LocoTransformer is ref_net
+        assert not hasattr(torchrl.policies, "RolloutActor")
+    """)
+
+
+def test_collector_restatement_matches_reference():
+    """oracle/collector_ref.py vs the reference's VecOnPolicyCollector: same deterministic vec env (terminations and
+    max_episode_frames truncations both occur), same seeded CPU networks (ppo_state wiring), two epochs -> identical
+    replay buffers, train rewards and RNG consumption."""
+    _run("""
+        import numpy as np, torch
+        import ref_stubs
+        ref_stubs.install()
+        import util
+        import numpy
+        numpy.bool = bool                      # collector/base.py:250-251 uses the alias numpy >= 1.24 removed
+        import torchrl.networks as networks, torchrl.policies as policies
+        from torchrl.collector.on_policy import VecOnPolicyCollector
+        from torchrl.replay_buffers.on_policy import OnPolicyReplayBuffer
+        from oracle.collector_ref import RefVecOnPolicyCollector
+        case = util.CASES["mlp_s93"]
+        E, T = 4, 12
+        bufs, rews = [], []
+        for which in ("reference", "restatement"):
+            torch.manual_seed(3)
+            pf, vf = util.build_nets(networks, policies, case)
+            env = util.FakeVecEnv(E, case["S"], case["A"], img=0, seed=5, p_done=0.15, time_limit_key=(which and True))
+            import gym
+            for e in (env,):
+                sp = gym.spaces.Box()
+                sp.shape = (case["A"],)
+                e.action_space = sp
+            buf = OnPolicyReplayBuffer(env_nums=E, max_replay_buffer_size=E * T, time_limit_filter=True)
+            if which == "reference":
+                coll = VecOnPolicyCollector(vf, env=env, eval_env=util.FakeVecEnv(E, case["S"], case["A"], img=0), pf=pf,
+                                            replay_buffer=buf, device="cpu", train_render=False, epoch_frames=E * T,
+                                            max_episode_frames=5, eval_episodes=1)
+            else:
+                coll = RefVecOnPolicyCollector(vf, pf, env, buf, E * T, "cpu", discount=0.99, max_episode_frames=5)
+            torch.manual_seed(11)
+            outs = [coll.train_one_epoch() for _ in range(2)]
+            bufs.append(buf)
+            rews.append(outs)
+        a, b = bufs
+        keys = ["obs", "next_obs", "acts", "values", "rewards", "terminals", "time_limits"]
+        for k in keys:
+            x, y = getattr(a, "_" + k), getattr(b, "_" + k)
+            assert x.dtype == y.dtype and x.shape == y.shape and np.array_equal(x, y), k
+        assert a._terminals.sum() > 0 and (a._terminals.sum() > 2)
+        for ra, rb in zip(*rews):
+            assert ra["train_epoch_reward"] == rb["train_epoch_reward"]
+            assert np.array_equal(np.array(ra["train_rewards"]), np.array(rb["train_rewards"]))
+        print("OK")
+    """)

@@ -32,6 +32,15 @@ CASES = {
     # with the config/mpc_vision_only/{locotransformer,baseline}/thin-goal.json hyper-parameters): the observation row is the depth stack alone (S = 0)
     "loco_vis": dict(kind="loco_vis", S=0, A=6, seed=5, B=32, enc=[], head=[256, 256], layers=2, ff=256),
     "cnn_vis": dict(kind="cnn_vis", S=0, A=6, seed=6, B=32, enc=[], head=[256, 256]),
+    # the minibatch bench.py times (BASELINE configs[2] / configs[1], B = 1024): 4 samples per persistent block in the fused
+    # conv backward (register-resident dW carried across samples), 256 layer blocks of 4 samples
+    "loco_b1024": dict(kind="loco", S=93, A=6, seed=7, B=1024, enc=[256, 256], head=[256, 256], layers=2, ff=256),
+    "cnn_b1024": dict(kind="cnn", S=93, A=6, seed=8, B=1024, enc=[256, 256], head=[256, 256], visual_dim=256),
+    # ragged: 300 = 256 + 44 -> persistent conv blocks own 1 or 2 samples, 75 layer blocks of 4, MLP row tiles with a tail
+    "loco_rag": dict(kind="loco", S=93, A=6, seed=9, B=300, enc=[256, 256], head=[256, 256], layers=2, ff=256),
+    # PPO(clipped_value_loss=True): the clipped critic objective of ppo.py:105-112 (off in the shipped configs)
+    "loco_clipvf": dict(kind="loco", S=84, A=6, seed=10, B=32, enc=[256, 256], head=[256, 256], layers=2, ff=256,
+                        clipped_value_loss=True),
 }
 
 GAE_CASES = {
@@ -151,6 +160,15 @@ def make_gae_inputs(g):
     }
 
 
+# measured parity errors, keyed "test/case/mode/what"; tests/conftest.py dumps them to gpurun_out/parity.json at the end
+# of a GPU session (copied to profiles/parity_rNN.json for the record)
+PARITY = {}
+
+
+def record(key, value):
+    PARITY[key] = float(value)
+
+
 def load_golden(name):
     return np.load(os.path.join(GOLDEN, name + ".npz"))
 
@@ -158,3 +176,59 @@ def load_golden(name):
 def rel_err(a, b):
     a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
     return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-12))
+
+
+class FakeVecEnv:
+    """Deterministic stand-in for the reference's vectorised env (torchrl/env/vecenv.py protocol: env_nums, train / eval,
+    reset, step -> (obs [E][D] float64, rewards [E][1], dones [E][1] bool, infos), partial_reset(mask), close). Rewards and
+    the proprio part of the next observation depend on the actions, so a collector that feeds different actions diverges."""
+
+    class _Space:
+        def __init__(self, shape):
+            self.shape = shape
+
+    def __init__(self, E, S, A, img=4 * 64 * 64, seed=0, p_done=0.1, time_limit_key=False):
+        self.env_nums, self.S, self.A, self.img = E, S, A, img
+        self.rs = np.random.RandomState(seed)
+        self.action_space = self._Space((A,))
+        self.observation_space = self._Space((S,))
+        self.image_channels = 4
+        self.p_done, self.time_limit_key = p_done, time_limit_key
+        self.training, self.closed, self._reward_scale = True, False, 1
+        self.log = []
+
+    def _rows(self, n):
+        cols = [np.clip(self.rs.randn(n, self.S), -10, 10)]
+        if self.img:
+            cols.append(np.clip(self.rs.randn(n, self.img), -2.5, 2.8))
+        return np.concatenate(cols, axis=1)
+
+    def train(self):
+        self.training = True
+
+    def eval(self):
+        self.training = False
+
+    def reset(self):
+        self.ob = self._rows(self.env_nums)
+        return self.ob.copy()
+
+    def step(self, acts):
+        acts = np.asarray(acts, dtype=np.float64).reshape(self.env_nums, self.A)
+        self.log.append(acts.copy())
+        self.ob = self._rows(self.env_nums)
+        self.ob[:, :min(self.S, self.A)] += 0.5 * acts[:, :min(self.S, self.A)]
+        rewards = acts.sum(axis=1, keepdims=True) + self.rs.randn(self.env_nums, 1)
+        dones = self.rs.rand(self.env_nums, 1) < self.p_done
+        infos = {}
+        if self.time_limit_key:
+            infos["time_limit"] = self.rs.rand(self.env_nums) < 0.05
+        return self.ob.copy(), rewards, dones, infos
+
+    def partial_reset(self, mask):
+        mask = np.asarray(mask, dtype=bool).reshape(-1)
+        self.ob[mask] = self._rows(int(mask.sum()))
+        return self.ob.copy()
+
+    def close(self):
+        self.closed = True

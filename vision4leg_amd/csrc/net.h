@@ -110,6 +110,7 @@ struct v4l_net {
   int64_t slab_cap = 0;
   int64_t seg_blocks = 0;
   bool bound = false;
+  int gen = 0;  // bind generation: bumped by every v4l_net_bind; captured graphs of trainers / actors are keyed on it
   // auxiliary stream + fork/join events for sibling-kernel concurrency (created at bind; null = serial)
   hipStream_t aux = nullptr;
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
@@ -135,11 +136,11 @@ struct v4l_actor {
   v4l::ActCtl* ctl = nullptr;
   int* rowidx = nullptr;
   hipGraphExec_t gexec = nullptr;
-  const void* key[12] = {};
+  const void* key[16] = {};
   bool warm = false, bound = false;
 };
 
-struct GraphKey { v4l_rollout ro; v4l_ppo_hyper hp; int n; };
+struct GraphKey { v4l_rollout ro; v4l_ppo_hyper hp; int n; int gen[3]; };
 
 struct v4l_trainer {
   v4l_net *pf = nullptr, *vf = nullptr, *tpf = nullptr;

@@ -1633,6 +1633,7 @@ int v4l_net_bind(v4l_net* net, float* const* params_dev, void* packed_dev, void*
   V4L_HIP_CHECK(hipMemcpy(net->d_packs, net->packs.data(), net->packs.size() * sizeof(PackDesc), hipMemcpyHostToDevice));
   V4L_HIP_CHECK(hipMemcpy(net->d_segs, segs.data(), segs.size() * sizeof(ParamSeg), hipMemcpyHostToDevice));
   net->bound = true;
+  ++net->gen;  // graphs captured against the previous packed / table buffers must not be replayed
   return 0;
 }
 
@@ -1942,8 +1943,9 @@ int v4l_actor_step(v4l_actor* a, const float* obs_dev, const float* eps_dev, flo
                           action_dev, mean_dev, std_dev, ent_dev, value_dev, shared_encoder, stream);
   };
   if (!use_graph || g_prof || s == nullptr) return run();
-  const void* key[12] = {obs_dev, eps_dev, state_roll_dev, image_roll_dev, acts_roll_dev, values_roll_dev, action_dev,
-                         mean_dev, logp_roll_dev, ent_dev, value_dev, (const void*)(intptr_t)(shared_encoder + 1)};
+  const void* key[16] = {obs_dev, eps_dev, state_roll_dev, image_roll_dev, acts_roll_dev, values_roll_dev, action_dev,
+                         mean_dev, logp_roll_dev, ent_dev, value_dev, (const void*)(intptr_t)(shared_encoder + 1), std_dev,
+                         (const void*)(intptr_t)a->pf->gen, (const void*)(intptr_t)a->vf->gen, nullptr};
   if (memcmp(key, a->key, sizeof(key)) != 0) {
     if (a->gexec) { (void)hipGraphExecDestroy(a->gexec); a->gexec = nullptr; }
     a->warm = false;
@@ -2174,6 +2176,7 @@ int v4l_trainer_update_next(v4l_trainer* tr, const v4l_rollout* ro, int n, const
   GraphKey key;
   memset(&key, 0, sizeof(key));
   key.ro = *ro; key.hp = *hp; key.n = n;
+  key.gen[0] = tr->pf->gen; key.gen[1] = tr->vf->gen; key.gen[2] = tr->tpf->gen;
   if (memcmp(&key, &tr->gkey, sizeof(key)) != 0) { drop_graph(tr); tr->gkey = key; }
   if (!tr->warm) {  // first update of a configuration runs eagerly: it uploads the descriptor tables
     tr->warm = true;

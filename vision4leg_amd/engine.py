@@ -134,12 +134,17 @@ class HipNet:
     return ts
 
   def mark_dirty(self):
-    """Parameters were changed behind torch's back (an optimiser step inside the library)."""
+    """Parameters were changed behind torch's back (an optimiser step inside the library, or a write through
+    `param.data`, which has its own version counter: copy_model_params_from_to, soft_update_from_to, init.*,
+    dist.broadcast(p.data))."""
     self._dirty = True
 
   def pack_if_needed(self, fast=False):
+    """Refresh the operand-type weight copies. Module-level calls (fast=False: pf(x), vf(x), explore, update) repack
+    unconditionally — one ~5 us launch — because `.data` writes are invisible to the version check; per-step callers
+    (fast=True: RolloutActor) rely on the version sum and on mark_dirty() / module.mark_params_changed()."""
     self.ensure_bound(fast)
-    if self._dirty:
+    if self._dirty or not fast:
       check(self.L.v4l_net_pack(self.h, _stream()), "v4l_net_pack")
       self._dirty = False
 

@@ -112,6 +112,8 @@ class PPO:
             for p in list(self.pf.parameters()) + list(self.vf.parameters()):
                 torch.distributed.broadcast(p.data, src=0)
             atu.copy_model_params_from_to(self.pf, self.target_pf)
+            for net in self.networks:  # `.data` writes do not bump the Parameters' version counters
+                net.mark_params_changed()
         with torch.cuda.device(self.device):
             g_vf = None
             if self.dp_phases:
@@ -167,8 +169,10 @@ class PPO:
     def process_epoch_samples(self):
         """last_value = vf(next_obs[T-1]) * (1 - terminal) then GAE (on_rl_algo.py:23-34)."""
         sample = self.replay_buffer.last_sample(["next_obs", "terminals", "time_limits"])
-        last_ob = torch.from_numpy(np.ascontiguousarray(sample["next_obs"], dtype=np.float32)).to(self.device)
-        last_value = self.vf(last_ob).cpu().numpy()
+        last_ob = sample["next_obs"]
+        if not isinstance(last_ob, torch.Tensor):
+            last_ob = torch.from_numpy(np.ascontiguousarray(last_ob, dtype=np.float32))
+        last_value = self.vf(last_ob.to(self.device, torch.float32)).cpu().numpy()
         last_value = last_value * (1 - sample["terminals"])
         self.replay_buffer.generalized_advantage_estimation(last_value, self.discount, self.tau)
 
@@ -188,8 +192,8 @@ class PPO:
 
     def _update_epoch_resident(self):
         buf = self.replay_buffer
-        state, image, acts, advs, rets, vals = buf.device_rollout()
-        ro = HipTrainer.rollout(state, image, acts, advs, rets, vals)
+        state, image, acts, advs, rets, vals, logp = buf.device_rollout()
+        ro = HipTrainer.rollout(state, image, acts, advs, rets, vals, logp)
         batches = []
         for _ in range(self.opt_epochs):
             for b in buf.one_iteration(self.batch_size, self.sample_key, self.shuffle):

@@ -1,0 +1,191 @@
+"""Vectorised on-policy collector with the reference's constructor and epoch protocol
+(torchrl/collector/on_policy.py:84-155 on top of collector/base.py:10-52,113-127,177-288), host side only: the
+simulator (`env.step / partial_reset / reset`) stays on the CPU cores exactly where the reference has it.
+
+What changes is the per-step network work (collector/on_policy.py:90-100, 132-144). With a
+`DeviceOnPolicyReplayBuffer` the step is the MI355X fast path:
+
+  host rows [E][S+16384] float64 --(one fp64->fp32 pass into a pinned staging buffer, async H2D)--> HBM
+  RolloutActor.step: shared encoder once, policy + value stacks, draw, and the step's observation rows / action /
+  value / log pi_old(a|s) filed straight into the replay buffer's HBM arrays (2 launches)
+  D2H of the [E][A] action only (the simulator needs it); values never leave the device.
+
+With a host `OnPolicyReplayBuffer` it is the reference's own call sequence (`pf.explore`, `vf`, float64 host arrays).
+The truncation bootstrap (`rewards += discount * vf(next_obs) * surpass_flag`, `terminals |= surpass_flag`) is kept;
+the extra value forward is issued only on steps where some env actually ran past `max_episode_frames` (for steps with
+plain terminations the reference multiplies it by zero).
+"""
+import copy
+
+import numpy as np
+import torch
+
+from ..replay_buffers import DeviceOnPolicyReplayBuffer
+
+
+class VecOnPolicyCollector:
+    def __init__(self, vf, discount=0.99, *, env, eval_env, pf, replay_buffer, epoch_frames, train_render=False,
+                 eval_episodes=1, eval_render=False, device="cpu", max_episode_frames=999):
+        self.vf, self.pf = vf, pf
+        self.discount = discount
+        self.replay_buffer = replay_buffer
+        self.env = env
+        self.env.train()
+        self.continuous = not hasattr(getattr(env, "action_space", None), "n")
+        if not self.continuous:
+            raise NotImplementedError("vision4leg_amd: the HIP policies are Gaussian (continuous actions) only")
+        self.train_render = train_render
+        if eval_env is None:  # collector/base.py:30-35
+            eval_env = copy.deepcopy(env)
+            if hasattr(env, "_obs_normalizer"):
+                eval_env._obs_normalizer = env._obs_normalizer
+        self.eval_env = eval_env
+        self.eval_env._reward_scale = 1
+        self.eval_episodes = eval_episodes
+        self.eval_render = eval_render
+        self.current_ob = self.env.reset()
+        self.device = torch.device(device)
+        self.to(self.device)
+        E = self.env.env_nums
+        self.epoch_frames = epoch_frames
+        self.sample_epoch_frames = epoch_frames // E          # env steps per epoch (collector/base.py:180)
+        self.max_episode_frames = max_episode_frames
+        self.current_step = np.zeros((E, 1))
+        self.train_rew = np.zeros((E, 1))
+        self.train_rews = []
+        self._actor = None
+        self._cursor = -1
+        self._pins = None
+        self.fast_path = isinstance(replay_buffer, DeviceOnPolicyReplayBuffer)
+
+    # ---- reference plumbing (collector/base.py:54-58,113-115,166-174; on_policy.py:77-82) ----------------------------
+    def start_episode(self):
+        pass
+
+    def finish_episode(self):
+        pass
+
+    @property
+    def funcs(self):
+        return {"pf": self.pf, "vf": self.vf}
+
+    def to(self, device):
+        for f in self.funcs.values():
+            f.to(device)
+
+    def terminate(self):
+        self.env.close()
+        self.eval_env.close()
+
+    # ---- host -> HBM ----------------------------------------------------------------------------------------------
+    def _upload(self, rows):
+        """numpy [E][D] (float64 from the env wrappers) -> fp32 device rows via double-buffered pinned staging
+        (what `torch.Tensor(self.current_ob).to(self.device)`, collector/on_policy.py:91-93, does from pageable memory)."""
+        rows = np.asarray(rows)
+        if self._pins is None or self._pins[0][0].shape != rows.shape:
+            mk = lambda: (torch.empty(rows.shape, dtype=torch.float32).pin_memory(),
+                          torch.empty(rows.shape, dtype=torch.float32, device=self.device), torch.cuda.Event())
+            self._pins, self._pin_i = [mk(), mk()], 0
+        host, dev, ev = self._pins[self._pin_i]
+        self._pin_i ^= 1
+        ev.synchronize()  # the copy issued from this staging buffer two uploads ago
+        np.copyto(host.numpy(), rows, casting="same_kind")
+        dev.copy_(host, non_blocking=True)
+        ev.record()
+        return dev
+
+    def _ensure_actor(self):
+        if self._actor is None:
+            from ..policies import RolloutActor
+            buf = self.replay_buffer
+            if buf._net is None:  # PPO.__init__ normally attaches it
+                buf.attach(self.pf.hip, self.device)
+            self._actor = RolloutActor(self.pf, self.vf, self.env.env_nums)
+            self._actor.attach(buf.step_arrays(self.pf.hip.out_dim))
+        return self._actor
+
+    # ---- one vectorised env step -----------------------------------------------------------------------------------
+    def take_actions(self):
+        with torch.cuda.device(self.device):
+            if self.fast_path:
+                actor = self._ensure_actor()
+                top = self.replay_buffer._top
+                if top != self._cursor:  # the device-side step cursor advances by itself; re-aim it when the buffer wrapped
+                    actor.seek(top)
+                self._cursor = (top + 1) % self.replay_buffer._max_replay_buffer_size
+                out = actor.step(self._upload(self.current_ob))
+                acts = out["action"].cpu().numpy()  # the only device->host transfer of the step
+                values = None
+            else:
+                ob_tensor = self._upload(self.current_ob)
+                acts = self.pf.explore(ob_tensor)["action"].detach().cpu().numpy()
+                values = self.vf(ob_tensor).detach().cpu().numpy()
+        if not np.isfinite(acts).all():  # collector/on_policy.py:102-107 ("NaN detected. BOOM")
+            raise FloatingPointError("vision4leg_amd: non-finite action from the policy; observation rows "
+                                     "finite: %s" % bool(np.isfinite(np.asarray(self.current_ob)).all()))
+        next_obs, rewards, dones, infos = self.env.step(acts)
+        if self.train_render:
+            self.env.render()
+        self.current_step += 1
+        sample = {"obs": self.current_ob, "next_obs": next_obs, "acts": acts, "values": values, "rewards": rewards,
+                  "terminals": dones,
+                  "time_limits": infos["time_limit"][:, np.newaxis] if "time_limit" in infos else [False]}
+        self.train_rew += rewards
+        if np.any(dones):
+            self.train_rews += list(self.train_rew[dones])
+            self.train_rew[dones] = 0
+        surpass = self.current_step >= self.max_episode_frames
+        if np.any(dones) or np.any(surpass):
+            if np.any(surpass):  # bootstrap the truncated envs with V(next_obs) (collector/on_policy.py:132-144)
+                with torch.cuda.device(self.device):
+                    last_value = self.vf(self._upload(next_obs)).detach().cpu().numpy()
+                sample["rewards"] = rewards + self.discount * last_value * surpass
+            ended = dones | surpass
+            sample["terminals"] = ended
+            next_obs = self.env.partial_reset(np.squeeze(ended, axis=-1))
+            self.current_step[ended] = 0
+            self.train_rew[ended] = 0
+        if self.fast_path:
+            del sample["obs"], sample["acts"], sample["values"]
+            self.replay_buffer.add_sample(sample, filed=True)
+        else:
+            self.replay_buffer.add_sample(sample)
+        self.current_ob = next_obs
+        return np.sum(rewards)
+
+    def train_one_epoch(self):
+        self.train_rews = []
+        self.train_epoch_reward = 0
+        self.env.train()
+        for _ in range(self.sample_epoch_frames):
+            self.train_epoch_reward += self.take_actions()
+        return {"train_rewards": self.train_rews, "train_epoch_reward": self.train_epoch_reward}
+
+    def eval_one_epoch(self):
+        """collector/base.py:237-288: `eval_episodes` rounds over the vectorised eval env with the policy mean."""
+        if hasattr(self.env, "_obs_normalizer"):
+            self.eval_env._obs_normalizer = copy.deepcopy(self.env._obs_normalizer)
+        self.eval_env.eval()
+        E = self.eval_env.env_nums
+        eval_rews, traj_lens = [], []
+        for _ in range(self.eval_episodes):
+            epi_done = np.zeros((E, 1), dtype=bool)
+            eval_obs = self.eval_env.reset()
+            rews = np.zeros((E, 1))
+            traj_len = np.zeros((E, 1))
+            while not np.all(epi_done):
+                with torch.cuda.device(self.device):
+                    act = self.pf.eval_act(self._upload(eval_obs))
+                if not np.isfinite(act).all():
+                    raise FloatingPointError("vision4leg_amd: non-finite action from the policy (eval)")
+                eval_obs, r, done, _ = self.eval_env.step(act)
+                rews = rews + (1 - epi_done) * r
+                traj_len = traj_len + (1 - epi_done)
+                epi_done = epi_done | done
+                if np.any(done):
+                    eval_obs = self.eval_env.partial_reset(np.squeeze(done, axis=-1))
+                if self.eval_render:
+                    self.eval_env.render()
+            eval_rews += list(rews)
+            traj_lens += list(traj_len)
+        return {"eval_rewards": eval_rews, "eval_traj_length": np.mean(traj_lens)}

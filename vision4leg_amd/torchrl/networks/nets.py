@@ -46,6 +46,13 @@ class _HipNetMixin:
             self.__dict__["_hip"] = HipNet(self, self._net_cfg())
         return self.__dict__["_hip"]
 
+    def mark_params_changed(self):
+        """Tell the engine the parameters were rewritten through `.data` (invisible to torch's version counters, e.g.
+        `soft_update_from_to`, `dist.broadcast(p.data)`): the operand-type weight copies are rebuilt before the next
+        launch. Plain module calls repack anyway; a RolloutActor between two steps needs this call."""
+        if self.__dict__.get("_hip") is not None:
+            self.__dict__["_hip"].mark_dirty()
+
     def __deepcopy__(self, memo):
         # copy.deepcopy(pf) -> target_pf (reference ppo.py:21): clone parameters, never the engine handle
         new = self.__class__.__new__(self.__class__)

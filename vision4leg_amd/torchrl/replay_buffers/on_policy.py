@@ -99,23 +99,105 @@ class DeviceOnPolicyReplayBuffer(OnPolicyReplayBufferBase, BaseReplayBuffer):
         self._state_dev, self._image_dev = hip_net.alloc_rollout(slots, self.device)
         self._acts_dev = None
         self._values32_dev = None
+        self._logp_dev = None
+        self._filed = False
+        self._pinned = None
 
-    def add_sample(self, sample_dict, **kwargs):
+    def step_arrays(self, act_dim):
+        """HBM arrays a RolloutActor files one env step into: (state, image, acts [slots][A], values [slots],
+        logp [slots]) — `RolloutActor.attach(buf.step_arrays(A))`, then `add_sample(..., filed=True)` per step."""
         if self._net is None:
             raise RuntimeError("DeviceOnPolicyReplayBuffer.attach(net, device) has not been called")
-        obs = sample_dict["obs"]
-        if isinstance(obs, np.ndarray):
-            obs = torch.from_numpy(np.ascontiguousarray(obs, dtype=np.float32)).to(self.device, non_blocking=True)
-        obs = obs.reshape(self.env_nums, -1)
-        self._net.ingest(obs, self._state_dev, self._image_dev, slot0=self._top * self.env_nums)
+        slots = self._max_replay_buffer_size * self.env_nums
+        if self._acts_dev is None or tuple(self._acts_dev.shape) != (slots, act_dim):
+            self._acts_dev = torch.zeros(slots, act_dim, dtype=torch.float32, device=self.device)
+            self._values32_dev = torch.zeros(slots, dtype=torch.float32, device=self.device)
+        if self._logp_dev is None:
+            self._logp_dev = torch.zeros(slots, dtype=torch.float32, device=self.device)
+        return self._state_dev, self._image_dev, self._acts_dev, self._values32_dev, self._logp_dev
+
+    def add_sample(self, sample_dict, filed=False, **kwargs):
+        """filed=True: a RolloutActor attached to step_arrays() has already written this step's observation rows, actions,
+        values and log pi_old(a|s) at slot `_top * env_nums`; `obs` / `acts` / `values` in sample_dict are then optional
+        and ignored. Otherwise the observation rows are ingested here (numpy rows are converted on the host once and
+        uploaded through a pinned staging buffer)."""
+        if self._net is None:
+            raise RuntimeError("DeviceOnPolicyReplayBuffer.attach(net, device) has not been called")
+        if filed:
+            if self._logp_dev is None:
+                raise RuntimeError("add_sample(filed=True) needs step_arrays() to have been handed to a RolloutActor")
+            self._filed = True
+        else:
+            if self._filed and self._top != 0:
+                raise RuntimeError("DeviceOnPolicyReplayBuffer: filed and host steps mixed inside one epoch")
+            self._filed = self._filed and self._top != 0
+            obs = sample_dict["obs"]
+            if isinstance(obs, np.ndarray):
+                obs = self._upload(obs)
+            obs = obs.reshape(self.env_nums, -1)
+            self._net.ingest(obs, self._state_dev, self._image_dev, slot0=self._top * self.env_nums)
         for key, value in sample_dict.items():
-            if key == "obs":
+            if key == "obs" or (filed and key in ("acts", "values")):
                 continue
             if key == "next_obs":  # only the epoch's last next_obs is ever read (on_rl_algo.py:24-26)
-                self._last_next_obs = np.array(value, copy=True)
+                self._last_next_obs = value if isinstance(value, torch.Tensor) else np.array(value, copy=True)
                 continue
             self._store(key, value)
         self._advance()
+
+    def _upload(self, rows):
+        """float64 / float32 numpy rows -> fp32 device tensor through one of two pinned staging buffers (the copy is
+        asynchronous; a buffer is reused only after the copy issued from it two steps ago has completed)."""
+        if self._pinned is None or self._pinned[0].shape != rows.shape:
+            self._pinned = [torch.empty(rows.shape, dtype=torch.float32).pin_memory() for _ in range(2)]
+            self._pin_ev = [torch.cuda.Event(), torch.cuda.Event()]
+            self._pin_dev = [torch.empty(rows.shape, dtype=torch.float32, device=self.device) for _ in range(2)]
+            self._pin_i = 0
+        i = self._pin_i
+        self._pin_i ^= 1
+        self._pin_ev[i].synchronize()
+        np.copyto(self._pinned[i].numpy(), rows, casting="same_kind")  # fp64 -> fp32 in the same pass
+        self._pin_dev[i].copy_(self._pinned[i], non_blocking=True)
+        self._pin_ev[i].record()
+        return self._pin_dev[i]
+
+    def generalized_advantage_estimation(self, last_value, gamma, tau):
+        """As the base class; when the epoch's steps were filed by a RolloutActor the values are read where they are
+        (fp32 network outputs in HBM, widened to fp64 like the reference's float64 buffer holds them) and the fp64 host
+        copies `_advs` / `_estimate_returns` are produced on first access only."""
+        if not self._filed:
+            return super().generalized_advantage_estimation(last_value, gamma, tau)
+        T, E = self._max_replay_buffer_size, self.env_nums
+        dev = self.device
+        up = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float64).reshape(T, -1)).to(dev)
+        tl = None
+        if self.time_limit_filter:
+            tl = up(self._time_limits)
+            tl = tl.reshape(T) if tl.shape[1] == 1 and E > 1 else tl
+        if isinstance(last_value, torch.Tensor):
+            lv = last_value.to(dev, torch.float64).reshape(E)
+        else:
+            lv = torch.from_numpy(np.ascontiguousarray(last_value, dtype=np.float64).reshape(E)).to(dev)
+        if not hasattr(self, "_gae_out"):
+            self._gae_out = {}
+        advs, rets, a32, r32 = engine.gae(up(self._rewards), self._values32_dev.view(T, E).double(), up(self._terminals), tl,
+                                          lv, gamma, tau, self.time_limit_filter, want32=True, out=self._gae_out)
+        self._advs_dev64, self._rets_dev64 = advs, rets
+        self.__dict__.pop("_advs", None)
+        self.__dict__.pop("_estimate_returns", None)
+        self._advs32_dev, self._rets32_dev = a32.reshape(-1), r32.reshape(-1)
+
+    def __getattr__(self, name):  # lazily materialised host views of device-side results (filed epochs)
+        if name == "_advs" and "_advs_dev64" in self.__dict__:
+            self._advs = self._advs_dev64.cpu().numpy().reshape(self._max_replay_buffer_size, self.env_nums, 1)
+            return self._advs
+        if name == "_estimate_returns" and "_rets_dev64" in self.__dict__:
+            self._estimate_returns = self._rets_dev64.cpu().numpy().reshape(self._max_replay_buffer_size, self.env_nums, 1)
+            return self._estimate_returns
+        if name in ("_acts", "_values") and self.__dict__.get("_filed"):
+            src = self._acts_dev if name == "_acts" else self._values32_dev
+            return src.cpu().numpy().astype(np.float64).reshape(self._max_replay_buffer_size, self.env_nums, -1)
+        raise AttributeError(name)
 
     def last_sample(self, sample_key):
         last = self._max_replay_buffer_size - 1
@@ -125,7 +207,11 @@ class DeviceOnPolicyReplayBuffer(OnPolicyReplayBufferBase, BaseReplayBuffer):
         return out
 
     def device_rollout(self):
-        """Device views the trainer gathers from: acts [slots][A], advs/rets/values [slots] (fp32)."""
+        """Device views the trainer gathers from: acts [slots][A], advs/rets/values [slots] (fp32) and, for epochs a
+        RolloutActor filed, log pi_old(a|s) [slots] (None otherwise: the update evaluates the target policy)."""
+        if self._filed:
+            return (self._state_dev, self._image_dev, self._acts_dev, self._advs32_dev, self._rets32_dev,
+                    self._values32_dev, self._logp_dev)
         slots = self._max_replay_buffer_size * self.env_nums
         acts = torch.from_numpy(np.ascontiguousarray(self._acts.reshape(slots, -1), dtype=np.float32))
         vals = torch.from_numpy(np.ascontiguousarray(self._values.reshape(slots), dtype=np.float32))
@@ -134,7 +220,7 @@ class DeviceOnPolicyReplayBuffer(OnPolicyReplayBufferBase, BaseReplayBuffer):
             self._values32_dev = torch.empty(vals.shape, dtype=torch.float32, device=self.device)
         self._acts_dev.copy_(acts)       # same device addresses every epoch: the update graph is keyed on them
         self._values32_dev.copy_(vals)
-        return self._state_dev, self._image_dev, self._acts_dev, self._advs32_dev, self._rets32_dev, self._values32_dev
+        return self._state_dev, self._image_dev, self._acts_dev, self._advs32_dev, self._rets32_dev, self._values32_dev, None
 
     def _gather(self, sel, sample_key):
         E = self.env_nums
