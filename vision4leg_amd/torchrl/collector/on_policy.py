@@ -110,9 +110,9 @@ class VecOnPolicyCollector:
             if self.fast_path:
                 actor = self._ensure_actor()
                 top = self.replay_buffer._top
-                if top != self._cursor:  # the device-side step cursor advances by itself; re-aim it when the buffer wrapped
+                if top != self._cursor:  # the device-side step cursor advances by one per step; re-aim it when the buffer wrapped
                     actor.seek(top)
-                self._cursor = (top + 1) % self.replay_buffer._max_replay_buffer_size
+                self._cursor = top + 1
                 out = actor.step(self._upload(self.current_ob))
                 acts = out["action"].cpu().numpy()  # the only device->host transfer of the step
                 values = None
