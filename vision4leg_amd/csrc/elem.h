@@ -677,7 +677,7 @@ __global__ __launch_bounds__(256) void clip_adam_kernel(const ParamSeg* __restri
 
 // --------------------------------------------------------------------------------- weight packing
 // Builds the contraction-ready copies of a weight tensor (operand type T, zero padded to the GEMM tiles).
-enum { PK_NT = 0, PK_T = 1, PK_CONV_NHWC = 2, PK_CONV_NHWC_T = 3, PK_CONV_DGRAD = 4 };
+enum { PK_NT = 0, PK_T = 1, PK_CONV_NHWC = 2, PK_CONV_NHWC_T = 3, PK_CONV_DGRAD = 4, PK_FRAG = 5 };
 struct PackDesc {
   const float* src;  // PyTorch-layout weight
   int64_t dst_off;   // element offset in the packed buffer
@@ -697,6 +697,13 @@ __global__ __launch_bounds__(256) void pack_kernel(const PackDesc* __restrict__ 
   const int r = (int)(e / d.Cc), c = (int)(e - (int64_t)r * d.Cc);
   float val = 0.f;
   switch (d.kind) {
+    case PK_FRAG: {  // MFMA fragment order [column tile n/16][k-step k/32][lane = (k%32)/8*16 + n%16][k%8]: the 64 lanes of
+      // a wave read one fragment as ONE contiguous 64 x sizeof(fragment) block (8 whole cache lines for bf16)
+      const int j = (int)(e & 7), lane = (int)((e >> 3) & 63), blk = (int)(e >> 9), ksteps = d.Cc >> 5;
+      const int tile = blk / ksteps, ks = blk - tile * ksteps;
+      const int n = tile * 16 + (lane & 15), k = ks * 32 + (lane >> 4) * 8 + j;
+      if (n < d.N && k < d.K) val = src[(int64_t)n * d.K + k];
+    } break;
     case PK_NT: if (r < d.N && c < d.K) val = src[(int64_t)r * d.K + c]; break;
     case PK_T: if (r < d.K && c < d.N) val = src[(int64_t)c * d.K + r]; break;
     case PK_CONV_NHWC:  // dst[n][tap*Cin+ci] = W[n][ci][tap]

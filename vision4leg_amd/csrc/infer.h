@@ -510,10 +510,13 @@ __device__ __forceinline__ void ln_rows(const float* z, int ldz, float* out, int
 }
 
 #ifdef V4L_INFER_TIMING
-__device__ long long g_inf_stamps[48];
+__device__ long long g_inf_stamps[128];
 #define INF_STAMP(i) do { if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) g_inf_stamps[i] = clock64(); } while (0)
+// rollout kernels: [64..95] rollout_layer_kernel (layer 0: 64.., head: 80..), [96..111] rollout_encoder_kernel (depth block 0)
+#define ROLL_STAMP(i) do { if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) g_inf_stamps[i] = clock64(); } while (0)
 #else
 #define INF_STAMP(i)
+#define ROLL_STAMP(i)
 #endif
 
 // One nn.TransformerEncoderLayer for SPW samples per block (blockIdx.y = net). HEAD: the block continues with the
@@ -825,6 +828,7 @@ __global__ __launch_bounds__(256) void infer_layer_kernel(InfLayerPair pr, InfHe
 // into as many independent jobs as it has (12 + 8 + 16 + 8 MFMA tiles, 17 score rows, 32 norm rows) instead of four.
 // Same arithmetic, operand rounding and k order as infer_layer_kernel<T, 1, HEAD>.
 constexpr int ROLLOUT_MAX_LAYERS = 4;
+template <typename T> struct RollStackLds { static constexpr size_t bytes = InfLayLds<T, 1>::bytes + (size_t)(2 * 832 + 528) * 4 + (size_t)2 * 32 * (64 + InfLd<T>::PAD) * sizeof(T); };
 struct InfLayerStack { InfLayerPair l[ROLLOUT_MAX_LAYERS]; int nl; };  // all layers of both nets: ONE launch per env step
 template <typename T, bool HEAD, int NW>
 __global__ __launch_bounds__(NW * 64) void rollout_layer_kernel(InfLayerStack stk, InfHeadPair hd, InfFinish fin, int E) {
@@ -843,6 +847,7 @@ __global__ __launch_bounds__(NW * 64) void rollout_layer_kernel(InfLayerStack st
   const int64_t row0 = (int64_t)s0 * NTOK;
   long long t_step = 0;
   if constexpr (HEAD) { if (fin.ctl != nullptr) t_step = fin.ctl->t; }
+  ROLL_STAMP(64);
   for (int i4 = tid; i4 < ROWS * (TD / 4); i4 += NTH) {
     const int r = i4 >> 4, c4 = (i4 & 15) * 4;
     const bool ok = r < NTOK;
@@ -874,6 +879,7 @@ __global__ __launch_bounds__(NW * 64) void rollout_layer_kernel(InfLayerStack st
   for (int l = 0; l < stk.nl; ++l) {  // the token rows stay in `xs` from one layer to the next
   const InfLayer& w = stk.l[l].n[blockIdx.y];
   if (l > 0) __syncthreads();
+  if (l == 0) ROLL_STAMP(65);
   for (int t = wave; t < 12; t += NW) {  // in_proj: 12 column tiles over the waves
     const int nt[1] = {t};
     f32x4 acc[2][1];
@@ -887,11 +893,13 @@ __global__ __launch_bounds__(NW * 64) void rollout_layer_kernel(InfLayerStack st
           acc[mt][0][3] + bb.w);
   }
   __syncthreads();
+  if (l == 0) ROLL_STAMP(66);
   if (tid < NTOK * NTOK) {  // scores, one (i, j) per thread (NTH >= 289)
     const int i = tid / NTOK, j = tid - i * NTOK;
     sp[i * ATT_PLD + j] = dot64(big + i * LY::LDQ, big + j * LY::LDQ + TD) * 0.125f;
   }
   __syncthreads();
+  if (l == 0) ROLL_STAMP(67);
   {  // softmax: a quarter wave per score row (lane l: key l; key 16 is carried by every lane), max / sum by DPP
     const int r = tid >> 4, l = lane & 15;
     if (r < 32) {  // quarters 0..31 (whole waves): rows >= 17 shadow row 16 and write nothing
@@ -911,6 +919,7 @@ __global__ __launch_bounds__(NW * 64) void rollout_layer_kernel(InfLayerStack st
     }
   }
   __syncthreads();
+  if (l == 0) ROLL_STAMP(68);
   for (int idx = tid; idx < ROWS * 16; idx += NTH) {  // ctx = P V: thread = (row, 4 columns); rows >= 17: zeros
     const int r = idx >> 4, c4 = (idx & 15) * 4;
     float4 a = {0.f, 0.f, 0.f, 0.f};
@@ -927,6 +936,7 @@ __global__ __launch_bounds__(NW * 64) void rollout_layer_kernel(InfLayerStack st
     *reinterpret_cast<float4*>(cx + r * LY::LDX + c4) = a;
   }
   __syncthreads();
+  if (l == 0) ROLL_STAMP(69);
   if (wave < 8) {  // out_proj + residual -> z (in `big`, fp32 [32][LDX]): (row tile, column tile) = (wave >> 2, wave & 3)
     const int nt[1] = {wave & 3}, mt = wave >> 2;
     f32x4 acc[1][1];
@@ -939,8 +949,10 @@ __global__ __launch_bounds__(NW * 64) void rollout_layer_kernel(InfLayerStack st
         xr.w + acc[0][0][3] + bb.w);
   }
   __syncthreads();
+  if (l == 0) ROLL_STAMP(70);
   ln2rows(big, xs, w.g1, w.be1, nullptr);  // x1 -> xs
   __syncthreads();
+  if (l == 0) ROLL_STAMP(71);
   for (int t = wave; t < 16; t += NW) {  // linear1 + ReLU -> f (T): 16 column tiles over the waves
     const int nt[1] = {t};
     f32x4 acc[2][1];
@@ -954,6 +966,7 @@ __global__ __launch_bounds__(NW * 64) void rollout_layer_kernel(InfLayerStack st
           fmaxf(acc[mt][0][2] + bb.z, 0.f), fmaxf(acc[mt][0][3] + bb.w, 0.f));
   }
   __syncthreads();
+  if (l == 0) ROLL_STAMP(72);
   if (wave < 8) {  // linear2 + residual -> z2 (in `cx`)
     const int nt[1] = {wave & 3}, mt = wave >> 2;
     f32x4 acc[1][1];
@@ -966,7 +979,9 @@ __global__ __launch_bounds__(NW * 64) void rollout_layer_kernel(InfLayerStack st
         xr.w + acc[0][0][3] + bb.w);
   }
   __syncthreads();
+  if (l == 0) ROLL_STAMP(73);
   ln2rows(cx, xs, w.g2, w.be2, w.xout);  // -> xs (next layer / heads) and the net's token tensor
+  if (l == 0) ROLL_STAMP(74);
   }
   if constexpr (HEAD) {
     const InfHead& h = hd.n[blockIdx.y];
@@ -975,6 +990,7 @@ __global__ __launch_bounds__(NW * 64) void rollout_layer_kernel(InfLayerStack st
     T* h2 = h1 + 16 * LY::LDF;
     float* so = reinterpret_cast<float*>(h2 + 16 * LY::LDF);          // [16][16]
     __syncthreads();
+    ROLL_STAMP(80);
     for (int idx = tid; idx < 16 * 128; idx += NTH) {
       const int r = idx >> 7, c = idx & 127;
       float v = 0.f;
@@ -990,6 +1006,7 @@ __global__ __launch_bounds__(NW * 64) void rollout_layer_kernel(InfLayerStack st
       pooled[r * LY::LDP + c] = v;
     }
     __syncthreads();
+    ROLL_STAMP(81);
     f32x4 acc[1][1];
     auto store_h = [&](T* dst, const float* bias, int t) {
       const int n4 = t * 16 + qr;
@@ -1004,6 +1021,7 @@ __global__ __launch_bounds__(NW * 64) void rollout_layer_kernel(InfLayerStack st
       store_h(h1, h.b0, t);
     }
     __syncthreads();
+    ROLL_STAMP(82);
     for (int t = wave; t < 16; t += NW) {
       const int nt[1] = {t};
       zero_acc(acc);
@@ -1011,6 +1029,7 @@ __global__ __launch_bounds__(NW * 64) void rollout_layer_kernel(InfLayerStack st
       store_h(h2, h.b1, t);
     }
     __syncthreads();
+    ROLL_STAMP(83);
     if (wave == 0) {
       const int nt0[1] = {0};
       zero_acc(acc);
@@ -1025,6 +1044,7 @@ __global__ __launch_bounds__(NW * 64) void rollout_layer_kernel(InfLayerStack st
     }
     if (fin.ctl != nullptr) {  // rollout step epilogue: see infer_layer_kernel
       __syncthreads();
+      ROLL_STAMP(84);
       if (tid == 0) {
         const int i = s0, A = fin.A;
         if (blockIdx.y == 0) {
@@ -1055,9 +1075,458 @@ __global__ __launch_bounds__(NW * 64) void rollout_layer_kernel(InfLayerStack st
           fin.ctl->done = 0;
           fin.ctl->t = t_step + 1;
         }
+        ROLL_STAMP(85);
       }
     }
   }
+}
+
+
+// ------------------------------------------------------------------------------------------ rollout layer stack, weights ahead
+// rollout_layer_kernel<T, true, 8> with its weight traffic re-timed. What the phase stamps of that kernel showed
+// (tools/probe/stamps_rollout.py, E = 32: 67.6 K cycles per block): every kernel starts with a cold L2 — on a multi-XCD part
+// the L2s are written back and invalidated at kernel boundaries — so the FIRST touch of each weight tile is an
+// Infinity-Cache round trip of ~1.5 K cycles, and the kernel paid one per barrier-separated GEMM phase (in_proj 3.6 K,
+// FF1 3.9 K, FF2 4.7 K, head fc0 / fc1 / fc2 6.0 / 9.2 / 2.6 K cycles for a few dozen MFMAs each) plus a serial
+// thread-0 sampling epilogue of 7 K cycles (six dependent global loads). Here a wave's weight fragments of EVERY phase
+// are requested one layer ahead into registers (bf16: 34 fragments = 136 VGPRs of the 256 a 512-thread block may use):
+// layer 0's and the head's widest linear at kernel entry, layer l+1's as soon as layer l's MFMAs have consumed the
+// register, the other head linears during the last layer. The fp32 parity mode (8 VGPRs per fragment) loads at use.
+// Arithmetic, operand rounding and k order are those of rollout_layer_kernel / infer_layer_kernel<T, 1, HEAD>.
+template <typename T, int MT, int KS, typename AT>
+__device__ __forceinline__ void mm_held(f32x4 (&acc)[MT], const AT* sA, int lda, const typename Frag<T>::type (&fb)[KS], int lane) {
+  typedef typename Frag<T>::type frag_t;
+  const int fr = lane & 15, fg = (lane >> 4) * 8;
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      frag_t fa;
+      if constexpr (sizeof(AT) == sizeof(T)) fa = *reinterpret_cast<const frag_t*>(sA + (mt * 16 + fr) * lda + ks * 32 + fg);
+      else fa = afrag<T>(reinterpret_cast<const float*>(sA) + (mt * 16 + fr) * lda + ks * 32 + fg);
+      mma_k32(acc[mt], fb[ks], fa);
+    }
+}
+
+template <typename T, int NL>
+__global__ __launch_bounds__(512) void rollout_stack_kernel(InfLayerStack stk, InfHeadPair hd, InfFinish fin, int E, int warm) {
+  typedef typename Frag<T>::type frag_t;
+  typedef InfLayLds<T, 1> LY;
+  constexpr int NW = 8, NTH = 512, ROWS = 32;
+  constexpr bool PRE = sizeof(T) == 2;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int fr = lane & 15, fg = (lane >> 4) * 8, qr = (lane >> 4) * 4;
+  float* xs = reinterpret_cast<float*>(smem);
+  float* big = reinterpret_cast<float*>(smem + LY::xs_b);            // qkv, later z (fp32), later f (T), later heads
+  float* cx = reinterpret_cast<float*>(smem + LY::xs_b + LY::big_b); // ctx, later z2
+  float* sp = reinterpret_cast<float*>(smem + LY::xs_b + LY::big_b + LY::xs_b);
+  // biases / LayerNorm parameters of every layer and of the head, staged once: a global load in the middle of a phase would
+  // have to wait for every weight fragment requested before it (loads return in order)
+  float* prm = reinterpret_cast<float*>(smem + LY::bytes);
+  constexpr int P_BIN = 0, P_BO = 192, P_B1 = 256, P_B2 = 512, P_G1 = 576, P_BE1 = 640, P_G2 = 704, P_BE2 = 768, P_LAYER = 832;
+  constexpr int P_H0 = 0, P_H1 = 256, P_H2 = 512, P_HEAD = 528;
+  const int net = blockIdx.y, s0 = blockIdx.x;
+  constexpr int nl = NL;  // the layer loop is unrolled: the compiler's vmcnt bookkeeping stays exact (no loop-carried merges)
+  float* prm_h = prm + 2 * P_LAYER;  // [layer l & 1][832] | head [528]
+  // operand-type copies of the two GEMM inputs that also live in fp32 (token rows: residual / LayerNorm; attention context):
+  // written once by their producer, read as whole MFMA fragments (one ds_read_b128) by every wave that multiplies with them.
+  // (Building the fragment from the fp32 rows cost each wave 6 odd-sized LDS reads + 10 VALU per fragment: the in_proj / FF1
+  // phases were bound by the LDS pipe all 8 waves share, 1.5 K cycles per column tile.)
+  constexpr int LDT = 64 + LY::PAD;
+  T* xb = reinterpret_cast<T*>(prm_h + P_HEAD);   // [32][LDT] layer input, then x1
+  T* cb = xb + ROWS * LDT;                          // [32][LDT] attention context
+  const int64_t row0 = (int64_t)s0 * NTOK;
+  const InfHead& h = hd.n[net];
+  ROLL_STAMP(64);
+  // weights arrive in fragment order (PK_FRAG): one fragment = 64 consecutive frag_t, whole cache lines per wave load
+  auto wfrag = [&](const void* W, int Kp, int tile, int ks) -> frag_t {
+    return reinterpret_cast<const frag_t*>(W)[(tile * (Kp >> 5) + ks) * 64 + lane];
+  };
+  // a wave's fragments: in_proj tiles {wave, wave+8 (waves 0..3)}, out_proj / linear2 tile (wave & 3) for row tile
+  // (wave >> 2), linear1 tiles {wave, wave+8}; head: fc0 / fc1 tiles {wave, wave+8}, last linear tile 0 (wave 0)
+  frag_t r_in[2][2], r_o[2], r_f1[2][2], r_f2[8], r_h1[2][8];
+  auto load_in = [&](const InfLayer& w) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) r_in[j][ks] = wfrag(w.win, 64, min(wave + 8 * j, 11), ks);
+  };
+  auto load_o = [&](const InfLayer& w) {
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) r_o[ks] = wfrag(w.wo, 64, wave & 3, ks);
+  };
+  auto load_f1 = [&](const InfLayer& w) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) r_f1[j][ks] = wfrag(w.w1, 64, wave + 8 * j, ks);
+  };
+  auto load_f2 = [&](const InfLayer& w) {
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) r_f2[ks] = wfrag(w.w2, 256, wave & 3, ks);
+  };
+  // head fc0 ([256][128], 4 k-steps per tile) rides in r_in (k-steps 0,1) and r_f1 (k-steps 2,3) once the last layer is
+  // done with them; the last linear ([16][256]) in r_f2
+  auto load_h0a = [&]() {
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) r_in[j][ks] = wfrag(h.w0, 128, wave + 8 * j, ks);
+  };
+  auto load_h0b = [&]() {
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) r_f1[j][ks] = wfrag(h.w0, 128, wave + 8 * j, 2 + ks);
+  };
+  auto load_h1 = [&](int j) {  // j: compile-time tile slot
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) r_h1[j][ks] = wfrag(h.w1, 256, wave + 8 * j, ks);
+  };
+  auto load_h2 = [&]() {
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) r_f2[ks] = wfrag(h.w2, 256, 0, ks);
+  };
+  // thread t < 208 fetches float4 number t of a layer's [bin | bo | b1 | b2 | g1 | be1 | g2 | be2] (unconditional load from a
+  // clamped, always-valid address: a load inside a branch ends in a vmcnt(0) wait)
+  auto layer_params = [&](const InfLayer& wl) -> float4 {
+    const int o = min(tid, P_LAYER / 4 - 1) * 4;
+    const float *q0 = wl.bin, *q1 = wl.bo, *q2 = wl.b1, *q3 = wl.b2, *q4 = wl.g1, *q5 = wl.be1, *q6 = wl.g2, *q7 = wl.be2;
+    const float* src = q0 + o;
+    src = o >= P_BO ? q1 + (o - P_BO) : src;
+    src = o >= P_B1 ? q2 + (o - P_B1) : src;
+    src = o >= P_B2 ? q3 + (o - P_B2) : src;
+    src = o >= P_G1 ? q4 + (o - P_G1) : src;
+    src = o >= P_BE1 ? q5 + (o - P_BE1) : src;
+    src = o >= P_G2 ? q6 + (o - P_G2) : src;
+    src = o >= P_BE2 ? q7 + (o - P_BE2) : src;
+    return *reinterpret_cast<const float4*>(src);
+  };
+  long long t_step = 0;
+  if (fin.ctl != nullptr) t_step = fin.ctl->t;
+  float lsd = 0.f, ep = 0.f;  // sampling operands of lane a < A of wave 0 (policy blocks)
+  unsigned warm_word = 0;
+  {
+    const InfLayer& w0 = stk.l[0].n[net];
+    // (1) L2 warm-up: the kernel starts with a cold L2, and the blocks that share one (block b runs on XCD b % 8) want the
+    // same weight lines at the same time. Each touches a different quarter of this net's lines first (one dword per
+    // 128-byte line, <= 2 independent loads per thread), so that the fragment loads behind them find most lines already on
+    // their way into the L2. Placement is a speed assumption only: every block still loads every fragment it uses.
+    {
+      const int lin = blockIdx.x + gridDim.x * blockIdx.y, share = (lin >> 3) & 3;
+      const int L0 = tid * 4 + share, L1 = (tid + NTH) * 4 + share;  // line numbers in the concatenation of this net's weights
+      const char* p0 = reinterpret_cast<const char*>(w0.win);
+      const char* p1 = p0;
+      int c = 0;
+      auto seg = [&](const void* W, int bytes) {
+        const int nlines = bytes >> 7;
+        const char* base = reinterpret_cast<const char*>(W);
+        p0 = (L0 >= c && L0 < c + nlines) ? base + ((size_t)(L0 - c) << 7) : p0;
+        p1 = (L1 >= c && L1 < c + nlines) ? base + ((size_t)(L1 - c) << 7) : p1;
+        c += nlines;
+      };
+      for (int l = 0; l < nl; ++l) {
+        const InfLayer& wl = stk.l[l].n[net];
+        seg(wl.win, 192 * 64 * (int)sizeof(T)); seg(wl.wo, 64 * 64 * (int)sizeof(T));
+        seg(wl.w1, 256 * 64 * (int)sizeof(T)); seg(wl.w2, 64 * 256 * (int)sizeof(T));
+      }
+      seg(h.w0, 256 * 128 * (int)sizeof(T)); seg(h.w1, 256 * 256 * (int)sizeof(T)); seg(h.w2, 16 * 256 * (int)sizeof(T));
+      p0 = warm ? p0 : reinterpret_cast<const char*>(w0.win);
+      p1 = warm ? p1 : reinterpret_cast<const char*>(w0.win);
+      warm_word = *reinterpret_cast<const unsigned*>(p0) ^ *reinterpret_cast<const unsigned*>(p1);
+    }
+    // (2) what the first phases need: token rows (the encoder kernel just wrote them), parameters, sampling operands.
+    // Every load is unconditional from a clamped, always-valid address (a load inside a branch ends in a vmcnt(0) wait)
+    const int r = tid >> 4, c4 = (tid & 15) * 4;  // 32 rows x 16 float4 = 512 threads
+    const float4 xv = *reinterpret_cast<const float4*>(w0.xin + (row0 + (r < NTOK ? r : 0)) * TD + c4);
+    const float4 pv = layer_params(w0);
+    float4 hv;
+    {
+      const int o = min(tid, 127) * 4;
+      const float *q0 = h.b0, *q1 = h.b1;
+      hv = *reinterpret_cast<const float4*>(o >= P_H1 ? q1 + (o - P_H1) : q0 + o);
+    }
+    const float b2v = h.b2[min(tid, h.nout - 1)];
+    // (this kernel is the rollout step: fin.ctl, fin.eps and fin.logstd are always set)
+    lsd = fin.logstd[min(tid, fin.A - 1)];
+    ep = fin.eps[(int64_t)s0 * fin.A + min(tid, fin.A - 1)];
+    __builtin_amdgcn_sched_barrier(0);
+    // (3) the weight fragments, in the order the phases consume them
+    if constexpr (PRE) load_in(w0);
+    __builtin_amdgcn_sched_barrier(0);
+    {
+      const float4 x0v = r < NTOK ? xv : float4{0.f, 0.f, 0.f, 0.f};
+      *reinterpret_cast<float4*>(xs + r * LY::LDX + c4) = x0v;
+      st4(xb + r * LDT + c4, x0v.x, x0v.y, x0v.z, x0v.w);
+    }
+    if (tid < P_LAYER / 4) *reinterpret_cast<float4*>(prm + tid * 4) = pv;
+    if (tid < 128) *reinterpret_cast<float4*>(prm_h + tid * 4) = hv;
+    if (tid < 16) prm_h[P_H2 + tid] = tid < h.nout ? b2v : 0.f;
+  }
+  __syncthreads();
+  T* f = reinterpret_cast<T*>(big);
+  auto ln2rows = [&](const float* z, float* out, const float* g, const float* be, float* gout) {
+    const int l16 = lane & 15, c4 = l16 * 4;
+    const float4 gg = *reinterpret_cast<const float4*>(g + c4), bb = *reinterpret_cast<const float4*>(be + c4);
+    const int r = wave * 4 + (lane >> 4);  // 32 rows = one step of 8 waves, a quarter wave per row
+    float4 v = *reinterpret_cast<const float4*>(z + r * LY::LDX + c4);
+    float s = (v.x + v.y) + (v.z + v.w);
+    s += dpp_mov<0x128>(s); s += dpp_mov<0x124>(s); s += dpp_mov<0x122>(s); s += dpp_mov<0x121>(s);
+    const float mean = s * (1.f / TD);
+    v.x -= mean; v.y -= mean; v.z -= mean; v.w -= mean;
+    float q2 = (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+    q2 += dpp_mov<0x128>(q2); q2 += dpp_mov<0x124>(q2); q2 += dpp_mov<0x122>(q2); q2 += dpp_mov<0x121>(q2);
+    const float rs = 1.f / sqrtf(q2 * (1.f / TD) + 1e-5f);
+    const float4 o = {fmaf(v.x * rs, gg.x, bb.x), fmaf(v.y * rs, gg.y, bb.y), fmaf(v.z * rs, gg.z, bb.z),
+                      fmaf(v.w * rs, gg.w, bb.w)};
+    *reinterpret_cast<float4*>(out + r * LY::LDX + c4) = o;
+    st4(xb + r * LDT + c4, o.x, o.y, o.z, o.w);
+    if (gout != nullptr && r < NTOK) *reinterpret_cast<float4*>(gout + (row0 + r) * TD + c4) = o;
+  };
+#pragma unroll
+  for (int l = 0; l < NL; ++l) {  // the token rows stay in `xs` from one layer to the next
+    const InfLayer& w = stk.l[l].n[net];
+    const float* pl = prm + (l & 1) * P_LAYER;
+    const bool more = l + 1 < nl;
+    const InfLayer& wn = stk.l[more ? l + 1 : l].n[net];
+    const float4 pnext = layer_params(wn);  // next layer's parameters: requested now, put into LDS when this layer is done
+    if (l > 0) __syncthreads();
+    if (l == 0) ROLL_STAMP(65);
+    {  // in_proj: 12 column tiles, two row tiles each
+      if constexpr (!PRE) load_in(w);
+      if constexpr (PRE) { if (l == 0) { if (wave < 4) load_o(w); load_f1(w); } }
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int t = wave + 8 * j;
+        if (t < 12) {
+          f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+          mm_held<T, 2, 2>(acc, xb, LDT, r_in[j], lane);
+          const int n4 = t * 16 + qr;
+          const float4 bb = *reinterpret_cast<const float4*>(pl + P_BIN + n4);
+#pragma unroll
+          for (int mt = 0; mt < 2; ++mt)
+            st4(big + (mt * 16 + fr) * LY::LDQ + n4, acc[mt][0] + bb.x, acc[mt][1] + bb.y, acc[mt][2] + bb.z, acc[mt][3] + bb.w);
+        }
+      }
+      if constexpr (PRE) { if (more) load_in(wn); else load_h0a(); }
+    }
+    __syncthreads();
+    if (l == 0) ROLL_STAMP(66);
+    if constexpr (PRE) { if (l == 0 && wave < 4) load_f2(w); if (!more) load_h1(0); }
+    if (tid < NTOK * NTOK) {  // scores, one (i, j) per thread
+      const int i = tid / NTOK, j = tid - i * NTOK;
+      sp[i * ATT_PLD + j] = dot64(big + i * LY::LDQ, big + j * LY::LDQ + TD) * 0.125f;
+    }
+    __syncthreads();
+    if (l == 0) ROLL_STAMP(67);
+    {  // softmax: a quarter wave per score row (lane q: key q; key 16 is carried by every lane), max / sum by DPP
+      const int r = tid >> 4, q = lane & 15;
+      float* p = sp + min(r, NTOK - 1) * ATT_PLD;
+      const float pl = p[q], p16 = p[16];
+      float mx = fmaxf(pl, p16);
+      mx = fmaxf(mx, dpp_mov<0x128>(mx)); mx = fmaxf(mx, dpp_mov<0x124>(mx));
+      mx = fmaxf(mx, dpp_mov<0x122>(mx)); mx = fmaxf(mx, dpp_mov<0x121>(mx));
+      const float el = expf(pl - mx), e16 = expf(p16 - mx);
+      float sum = el;
+      sum += dpp_mov<0x128>(sum); sum += dpp_mov<0x124>(sum); sum += dpp_mov<0x122>(sum); sum += dpp_mov<0x121>(sum);
+      const float inv = 1.f / (sum + e16);
+      if (r < NTOK) {
+        p[q] = el * inv;
+        if (q == 0) p[16] = e16 * inv;
+      }
+    }
+    __syncthreads();
+    if (l == 0) ROLL_STAMP(68);
+    {  // ctx = P V: thread = (row, 4 columns); rows >= 17: zeros
+      const int r = tid >> 4, c4 = (tid & 15) * 4;
+      float4 a = {0.f, 0.f, 0.f, 0.f};
+      if (r < NTOK) {
+        const float* v = big + 2 * TD + c4;
+        const float* p = sp + r * ATT_PLD;
+#pragma unroll
+        for (int j = 0; j < NTOK; ++j) {
+          const float pj = p[j];
+          const float4 vv = *reinterpret_cast<const float4*>(v + j * LY::LDQ);
+          a.x = fmaf(pj, vv.x, a.x); a.y = fmaf(pj, vv.y, a.y); a.z = fmaf(pj, vv.z, a.z); a.w = fmaf(pj, vv.w, a.w);
+        }
+      }
+      st4(cb + r * LDT + c4, a.x, a.y, a.z, a.w);
+    }
+    __syncthreads();
+    if (l == 0) ROLL_STAMP(69);
+    {  // out_proj + residual -> z (in `big`, fp32 [32][LDX]): column tile = wave (waves 0..3), both row tiles: the 8 KB of
+      // weights enter the CU once
+      if (wave < 4) {
+        if constexpr (!PRE) load_o(w);
+        f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+        mm_held<T, 2, 2>(acc, cb, LDT, r_o, lane);
+        if constexpr (PRE) { if (more) load_o(wn); }
+        const int n4 = wave * 16 + qr;
+        const float4 bb = *reinterpret_cast<const float4*>(pl + P_BO + n4);
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+          const int row = mt * 16 + fr;
+          const float4 xr = *reinterpret_cast<const float4*>(xs + row * LY::LDX + n4);
+          st4(big + row * LY::LDX + n4, xr.x + acc[mt][0] + bb.x, xr.y + acc[mt][1] + bb.y, xr.z + acc[mt][2] + bb.z,
+              xr.w + acc[mt][3] + bb.w);
+        }
+      }
+      if constexpr (PRE) { if (!more) load_h1(1); }
+    }
+    __syncthreads();
+    if (l == 0) ROLL_STAMP(70);
+    ln2rows(big, xs, pl + P_G1, pl + P_BE1, nullptr);  // x1 -> xs
+    __syncthreads();
+    if (l == 0) ROLL_STAMP(71);
+    {  // linear1 + ReLU -> f (T): 16 column tiles, two per wave
+      if constexpr (!PRE) load_f1(w);
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int t = wave + 8 * j;
+        f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+        mm_held<T, 2, 2>(acc, xb, LDT, r_f1[j], lane);
+        if (l == 0 && j == 0) ROLL_STAMP(75);
+        const int n4 = t * 16 + qr;
+        const float4 bb = *reinterpret_cast<const float4*>(pl + P_B1 + n4);
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+          st4(f + (mt * 16 + fr) * LY::LDF + n4, fmaxf(acc[mt][0] + bb.x, 0.f), fmaxf(acc[mt][1] + bb.y, 0.f),
+              fmaxf(acc[mt][2] + bb.z, 0.f), fmaxf(acc[mt][3] + bb.w, 0.f));
+      }
+      if (l == 0) ROLL_STAMP(76);
+      if constexpr (PRE) { if (more) load_f1(wn); else load_h0b(); }
+      if (l == 0) ROLL_STAMP(77);
+    }
+    __syncthreads();
+    if (l == 0) ROLL_STAMP(72);
+    if (wave < 4) {  // linear2 + residual -> z2 (in `cx`): column tile = wave, both row tiles
+      if constexpr (!PRE) load_f2(w);
+      f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+      mm_held<T, 2, 8>(acc, f, LY::LDF, r_f2, lane);
+      if constexpr (PRE) { if (more) load_f2(wn); else if (wave == 0) load_h2(); }
+      const int n4 = wave * 16 + qr;
+      const float4 bb = *reinterpret_cast<const float4*>(pl + P_B2 + n4);
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt) {
+        const int row = mt * 16 + fr;
+        const float4 xr = *reinterpret_cast<const float4*>(xs + row * LY::LDX + n4);
+        st4(cx + row * LY::LDX + n4, xr.x + acc[mt][0] + bb.x, xr.y + acc[mt][1] + bb.y, xr.z + acc[mt][2] + bb.z,
+            xr.w + acc[mt][3] + bb.w);
+      }
+    }
+    __syncthreads();
+    if (l == 0) ROLL_STAMP(73);
+    ln2rows(cx, xs, pl + P_G2, pl + P_BE2, w.xout);  // -> xs (next layer / heads) and the net's token tensor
+    if (tid < P_LAYER / 4) *reinterpret_cast<float4*>(prm + ((l + 1) & 1) * P_LAYER + tid * 4) = pnext;
+    if (l == 0) ROLL_STAMP(74);
+  }
+  // ---- head on this sample: [state token | mean of the 16 depth tokens] -> 256 -> 256 -> nout (fragment row 0 carries data)
+  float* pooled = big;                                              // [16][LDP] fp32, row 0 = this sample
+  T* h1 = reinterpret_cast<T*>(big + 16 * LY::LDP);                 // [16][LDF]
+  T* h2 = h1 + 16 * LY::LDF;
+  float* so = reinterpret_cast<float*>(h2 + 16 * LY::LDF);          // [16] last-layer outputs of row 0
+  __syncthreads();
+  ROLL_STAMP(80);
+  if (tid < 128) {  // rows 1..15 of the operand tiles are never read back: only fragment row 0 is filled
+    float v;
+    if (tid < TD) v = xs[tid];
+    else {
+      float s = 0.f;
+#pragma unroll
+      for (int i = 1; i < NTOK; ++i) s += xs[i * LY::LDX + (tid - TD)];
+      v = s * (1.f / 16.f);
+    }
+    pooled[tid] = v;
+  }
+  __syncthreads();
+  ROLL_STAMP(81);
+  auto store_h = [&](T* dst, const f32x4& a, const float* bias, int t) {
+    const int n4 = t * 16 + qr;
+    const float4 bb = *reinterpret_cast<const float4*>(bias + n4);
+    if (fr == 0) st4(dst + n4, fmaxf(a[0] + bb.x, 0.f), fmaxf(a[1] + bb.y, 0.f), fmaxf(a[2] + bb.z, 0.f), fmaxf(a[3] + bb.w, 0.f));
+  };
+  {
+    if constexpr (!PRE) { load_h0a(); load_h0b(); }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      f32x4 acc[1] = {f32x4{0.f, 0.f, 0.f, 0.f}};
+      const frag_t fb[4] = {r_in[j][0], r_in[j][1], r_f1[j][0], r_f1[j][1]};
+      mm_held<T, 1, 4>(acc, pooled, LY::LDP, fb, lane);
+      store_h(h1, acc[0], prm_h + P_H0, wave + 8 * j);
+    }
+  }
+  __syncthreads();
+  ROLL_STAMP(82);
+  {
+    if constexpr (!PRE) { load_h1(0); load_h1(1); }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      f32x4 acc[1] = {f32x4{0.f, 0.f, 0.f, 0.f}};
+      mm_held<T, 1, 8>(acc, h1, LY::LDF, r_h1[j], lane);
+      store_h(h2, acc[0], prm_h + P_H1, wave + 8 * j);
+    }
+  }
+  __syncthreads();
+  ROLL_STAMP(83);
+  if (wave == 0) {
+    if constexpr (!PRE) load_h2();
+    // epilogue operands requested before the last GEMM: lane a < A carries action dimension a
+    const int A = fin.A, i = s0;
+    f32x4 acc[1] = {f32x4{0.f, 0.f, 0.f, 0.f}};
+    mm_held<T, 1, 8>(acc, h2, LY::LDF, r_f2, lane);
+    if (fr == 0) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int c = qr + r;
+        const float v = c < h.nout ? acc[0][r] + prm_h[P_H2 + c] : 0.f;
+        so[c] = v;
+        h.out[(int64_t)s0 * OUT_LD + c] = v;
+      }
+    }
+    if (fin.ctl != nullptr) {
+      // ---- rollout step epilogue (GaussianContPolicyBase.explore, continuous_policy.py:85-125, and the collector's value
+      // read-out, collector/on_policy.py:95-100): same expressions and summation order as act_finish_kernel /
+      // infer_layer_kernel, the per-dimension terms evaluated by A lanes side by side
+      __builtin_amdgcn_wave_barrier();  // `so` was written by this wave: LDS operations of one wave execute in order
+      if (net == 0) {
+        const float mu = so[lane < A ? lane : 0];
+        const float ls = fminf(fmaxf(lsd, LOG_SIG_MIN), LOG_SIG_MAX);
+        const float sg = expf(ls);
+        const float et = 0.5f + HALF_LOG_2PI + logf(sg);
+        const float act = fmaf(sg, ep, mu);
+        const float d = act - mu;
+        const float lt = -(d * d) / (2.f * sg * sg) - logf(sg) - HALF_LOG_2PI;
+        if (lane < A) {
+          fin.action[(int64_t)i * A + lane] = act;
+          fin.mean[(int64_t)i * A + lane] = mu;
+          fin.stdv[(int64_t)i * A + lane] = sg;
+          if (fin.acts_roll != nullptr) fin.acts_roll[(t_step * E + i) * A + lane] = act;
+        }
+        float e = 0.f, lp = 0.f;
+        for (int a = 0; a < A; ++a) { e += lane_bcast(et, a); lp += lane_bcast(lt, a); }  // a = 0 .. A-1, in order
+        if (lane == 0) {
+          fin.ent[i] = e;
+          if (fin.logp_roll != nullptr) fin.logp_roll[t_step * E + i] = lp;
+        }
+      } else if (lane == 0) {
+        const float v = so[0];
+        fin.value[i] = v;
+        if (fin.values_roll != nullptr) fin.values_roll[t_step * E + i] = v;
+      }
+      ROLL_STAMP(84);
+      if (lane == 0) {  // the last block to get here advances the step cursor: every block read it at entry
+        __threadfence();
+        const unsigned long long done = atomicAdd(reinterpret_cast<unsigned long long*>(&fin.ctl->done), 1ull);
+        if (done == (unsigned long long)(gridDim.x * gridDim.y) - 1) {
+          fin.ctl->done = 0;
+          fin.ctl->t = t_step + 1;
+        }
+      }
+      ROLL_STAMP(85);
+    }
+  }
+  if (warm_word == 0x7fc00123u && fin.ctl == nullptr) h.out[(int64_t)s0 * OUT_LD + 15] = 0.f;  // keeps the warm-up loads alive
 }
 
 
@@ -1132,6 +1601,7 @@ __global__ __launch_bounds__(1024) void rollout_encoder_kernel(const ActCtl* __r
   T* c1 = img + LY::IMG;
   T* c2 = c1 + LY::C1;
   T* c3 = c2 + LY::C2;
+  ROLL_STAMP(96);
   {
     const float4* src = reinterpret_cast<const float4*>(obs + (int64_t)b * D + w.S);  // 16B aligned iff S%4==0
     const bool al = (((int64_t)b * D + w.S) & 3) == 0;
@@ -1154,6 +1624,7 @@ __global__ __launch_bounds__(1024) void rollout_encoder_kernel(const ActCtl* __r
     }
   }
   __syncthreads();
+  ROLL_STAMP(97);
   if (wave < 15) {  // conv1: 225 pixels = 15 row tiles, one per wave; K = (c,ky,kx) = 256, N = 32
     f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
     const int p = min(wave * 16 + fr, 224);
@@ -1188,6 +1659,7 @@ __global__ __launch_bounds__(1024) void rollout_encoder_kernel(const ActCtl* __r
     }
   }
   __syncthreads();
+  ROLL_STAMP(98);
   if (wave < 12) {  // conv2: 36 pixels (3 row tiles) x 4 column tiles, one pair per wave; K = (ky,kx,c) = 512
     const int mt = wave >> 2, nt = wave & 3;
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
@@ -1212,6 +1684,7 @@ __global__ __launch_bounds__(1024) void rollout_encoder_kernel(const ActCtl* __r
           fmaxf(acc[3] + bb.w, 0.f));
   }
   __syncthreads();
+  ROLL_STAMP(99);
   float* part = reinterpret_cast<float*>(img);  // [4 K-quarters][16 pixels][64] fp32 partial sums (the image is dead)
   {  // conv3: 16 pixels, K = (ky,kx,c) = 576 = 18 steps: wave = (column tile, K-quarter of 5/5/5/3 steps)
     const int nt = wave & 3, kq = wave >> 2;
@@ -1234,12 +1707,14 @@ __global__ __launch_bounds__(1024) void rollout_encoder_kernel(const ActCtl* __r
     st4(part + (kq * 16 + fr) * 64 + nt * 16 + qr, acc[0], acc[1], acc[2], acc[3]);
   }
   __syncthreads();
+  ROLL_STAMP(100);
   {  // sum of the four K-quarters + bias + ReLU -> c3: one output per thread
     const int pix = tid >> 6, n = tid & 63;
     const float v = ((part[pix * 64 + n] + part[(16 + pix) * 64 + n]) + part[(32 + pix) * 64 + n]) + part[(48 + pix) * 64 + n];
     c3[pix * LY::LD2 + n] = (T)fmaxf(v + w.b3[n], 0.f);
   }
   __syncthreads();
+  ROLL_STAMP(101);
   if (wave < 4) {  // depth_up_conv (1x1, no activation) -> tokens 1..16
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -1252,6 +1727,7 @@ __global__ __launch_bounds__(1024) void rollout_encoder_kernel(const ActCtl* __r
     const float4 bb = *reinterpret_cast<const float4*>(w.bup + n4);
     st4(x0 + ((int64_t)b * NTOK + 1 + fr) * TD + n4, acc[0] + bb.x, acc[1] + bb.y, acc[2] + bb.z, acc[3] + bb.w);
   }
+  ROLL_STAMP(102);
 }
 
 

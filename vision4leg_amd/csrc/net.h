@@ -25,6 +25,7 @@ struct Lin {         // nn.Linear (or the 1x1 up-conv): y = x W^T + b, W [N][K]
   int64_t pk = 0;
   int Rt = 0, Ct = 0;     // transposed pack [Rt = pad16(K)][Ct = pad64(N)] for the data-grad
   int64_t pkt = 0;
+  int64_t pkf = -1;       // fragment-order pack [Np/16][Kp/32][64 lanes][8] (rollout kernels), -1: none
   int cin = 0, taps = 0;  // > 0: input is an NHWC flatten, packed k = tap*cin + c  (PyTorch k = c*taps + tap)
   bool need_dgrad = true;
   std::string tag_fwd, tag_wgrad, tag_dgrad;  // profiler labels

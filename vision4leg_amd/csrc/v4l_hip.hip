@@ -728,6 +728,11 @@ int v4l_net::build() {
   for (Lin& L : enc) pack_lin(L);
   for (TLayer& t : layers) { pack_lin(t.inproj); pack_lin(t.outproj); pack_lin(t.ff1); pack_lin(t.ff2); }
   for (Lin& L : head) pack_lin(L);
+  if (c.kind == V4L_NET_LOCO) {  // the rollout step streams these as whole MFMA fragments (rollout_stack_kernel)
+    auto pack_frag = [&](Lin& L) { L.pkf = add_pack(L.w, PK_FRAG, L.Np, L.Kp, L.N, L.K, 0, 0, 0, 0, 0, 0, 0); };
+    for (TLayer& t : layers) { pack_frag(t.inproj); pack_frag(t.outproj); pack_frag(t.ff1); pack_frag(t.ff2); }
+    for (Lin& L : head) pack_frag(L);
+  }
 
   seg_blocks = 0;
   for (const ParamInfo& pi : params) seg_blocks += cdiv64(pi.numel, 256);
@@ -1430,6 +1435,8 @@ static int run_actor_fused(v4l_actor* a, const float* obs, const float* eps, flo
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)InfLayLds<T, 1>::bytes));
     V4L_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&rollout_layer_kernel<T, true, 8>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)InfLayLds<T, 1>::bytes));
+    V4L_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&rollout_stack_kernel<T, 2>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)RollStackLds<T>::bytes));
     attr_done = true;
   }
   const T* pk = (const T*)pf->packed;
@@ -1454,21 +1461,26 @@ static int run_actor_fused(v4l_actor* a, const float* obs, const float* eps, flo
     V4L_KLAUNCH("infer_encoder", 2.0 * E * 3678208.0, s, infer_encoder_kernel<T>, dim3(E + cdiv(E, 32)), dim3(256),
                 InfEncLds<T>::bytes, s, (const ActCtl*)a->ctl, obs, E, en, state_roll, (T*)image_roll, x0, InfEncTrain{});
   V4L_LAUNCH_CHECK();
+  static const int nw = getenv("V4L_ROLLOUT_WAVES") ? atoi(getenv("V4L_ROLLOUT_WAVES")) : 8;
+  static const bool ahead = getenv("V4L_ROLLOUT_NO_PREFETCH") == nullptr;  // weights ahead of use (rollout_stack_kernel)
+  const int nl = pf->cfg.n_layers;
+  const bool stack = wide16 && nl == 2 && ahead && nw != 16 && pf->head.size() == 3 && pf->head[0].pkf >= 0;
   auto fill = [&](InfLayer& d, v4l_net* net, const T* base, const TLayer& t, const float* xin, float* xout) {
     d.win = base + t.inproj.pk; d.wo = base + t.outproj.pk; d.w1 = base + t.ff1.pk; d.w2 = base + t.ff2.pk;
+    if (stack) { d.win = base + t.inproj.pkf; d.wo = base + t.outproj.pkf; d.w1 = base + t.ff1.pkf; d.w2 = base + t.ff2.pkf; }
     d.bin = net->p[t.inproj.b]; d.bo = net->p[t.outproj.b]; d.b1 = net->p[t.ff1.b]; d.b2 = net->p[t.ff2.b];
     d.g1 = net->p[t.ln1.g]; d.be1 = net->p[t.ln1.b]; d.g2 = net->p[t.ln2.g]; d.be2 = net->p[t.ln2.b];
     d.xin = xin; d.xout = xout;
     d.s_qkv = d.s_P = d.s_xh1 = d.s_rs1 = d.s_xh2 = d.s_rs2 = nullptr;
     d.s_xin = d.s_ctx = d.s_x1 = d.s_f = nullptr;
   };
-  const int nl = pf->cfg.n_layers;
   InfHeadPair hd;
   memset(&hd, 0, sizeof(hd));
   InfFinish fin;
   memset(&fin, 0, sizeof(fin));
   auto head = [&](InfHead& h, v4l_net* net, const T* base, float* out) {
     h.w0 = base + net->head[0].pk; h.w1 = base + net->head[1].pk; h.w2 = base + net->head[2].pk;
+    if (stack) { h.w0 = base + net->head[0].pkf; h.w1 = base + net->head[1].pkf; h.w2 = base + net->head[2].pkf; }
     h.b0 = net->p[net->head[0].b]; h.b1 = net->p[net->head[1].b]; h.b2 = net->p[net->head[2].b];
     h.out = out; h.nout = net->cfg.out_dim;
   };
@@ -1492,7 +1504,12 @@ static int run_actor_fused(v4l_actor* a, const float* obs, const float* eps, flo
     }
     finish();
     static const int nw = getenv("V4L_ROLLOUT_WAVES") ? atoi(getenv("V4L_ROLLOUT_WAVES")) : 8;
-    if (nw == 16)
+    static const bool ahead = getenv("V4L_ROLLOUT_NO_PREFETCH") == nullptr;
+    static const int warm = getenv("V4L_ROLLOUT_WARM") ? atoi(getenv("V4L_ROLLOUT_WARM")) : 1;  // L2 warm-up touches  // weights one layer ahead (rollout_stack_kernel)
+    if (ahead && nw != 16)
+      V4L_KLAUNCH("rollout_layers_head", 2.0 * 2 * E * (nl * 872576.0 + 99840.0), s, (rollout_stack_kernel<T, 2>), dim3(E, 2),
+                  dim3(512), (RollStackLds<T>::bytes), s, stk, hd, fin, E, warm);
+    else if (nw == 16)
       V4L_KLAUNCH("rollout_layers_head", 2.0 * 2 * E * (nl * 872576.0 + 99840.0), s, (rollout_layer_kernel<T, true, 16>), dim3(E, 2),
                   dim3(1024), (InfLayLds<T, 1>::bytes), s, stk, hd, fin, E);
     else
@@ -1760,7 +1777,7 @@ int v4l_obs_norm(const double* raw_dev, int64_t ld_raw, int E, int S, double* me
 #ifdef V4L_INFER_TIMING
 int v4l_debug_stamps(long long* out32) {
   if (hipDeviceSynchronize() != hipSuccess) return -2;
-  return hipMemcpyFromSymbol(out32, HIP_SYMBOL(v4l::g_inf_stamps), 48 * sizeof(long long)) == hipSuccess ? 0 : -2;
+  return hipMemcpyFromSymbol(out32, HIP_SYMBOL(v4l::g_inf_stamps), 128 * sizeof(long long)) == hipSuccess ? 0 : -2;
 }
 #endif
 int v4l_prof_enable(int on) {
