@@ -702,7 +702,10 @@ __global__ __launch_bounds__(256) void pack_kernel(const PackDesc* __restrict__ 
       const int j = (int)(e & 7), lane = (int)((e >> 3) & 63), blk = (int)(e >> 9), ksteps = d.Cc >> 5;
       const int tile = blk / ksteps, ks = blk - tile * ksteps;
       const int n = tile * 16 + (lane & 15), k = ks * 32 + (lane >> 4) * 8 + j;
-      if (n < d.N && k < d.K) val = src[(int64_t)n * d.K + k];
+      if (n < d.N && k < d.K) {
+        if (d.Cin > 0) { const int tap = k / d.Cin, ci = k - tap * d.Cin; val = src[(int64_t)n * d.K + ci * d.taps + tap]; }  // NHWC k order
+        else val = src[(int64_t)n * d.K + k];
+      }
     } break;
     case PK_NT: if (r < d.N && c < d.K) val = src[(int64_t)r * d.K + c]; break;
     case PK_T: if (r < d.K && c < d.N) val = src[(int64_t)c * d.K + r]; break;

@@ -1731,6 +1731,257 @@ __global__ __launch_bounds__(1024) void rollout_encoder_kernel(const ActCtl* __r
 }
 
 
+// ------------------------------------------------------------------------------------------ rollout encoder, weights once per CU
+// rollout_encoder_kernel with its weight traffic cut to what the block needs ONCE. Phase stamps of that kernel
+// (tools/probe/stamps_rollout.py: 40 K cycles per depth block, conv1 16.4 K, conv2 13.0 K, conv3 6.2 K) against its MFMA work
+// (a few hundred MFMAs) said the time is the weight stream: all 15 conv1 waves pulled the same 16 KB of w1 (240 KB per block),
+// the three row-tile waves of a conv2 column tile the same 16 KB (192 KB), and a CU only takes ~16-25 B/clk of such loads.
+// Here every byte enters the CU once, as whole-cache-line fragment-order reads (PK_FRAG packs) requested at kernel entry in
+// the order of use: the observation row, w1 and w2 into LDS (16 + 64 KB, shared by all waves), w3 / w_up straight into the
+// registers of the wave that multiplies with them; biases are staged in LDS (a late global load would wait for every older
+// one). bf16 only (the fp32 parity mode keeps rollout_encoder_kernel: its fragments are twice the size).
+struct InfEncFrag {
+  const void *w1, *w2, *w3, *wup;          // fragment-order packs: [2][8][64] [4][16][64] [4][18][64] [4][2][64] fragments
+  const float *b1, *b2, *b3, *bup;
+  const void *wf1, *wf2, *wpr;             // proprio MLP: [16][4][64] [16][8][64] [4][8][64] fragments
+  const float *bf1, *bf2, *bpr;
+  int S, Sp;
+};
+struct RollEnc2Lds {
+  typedef InfEncLds<__bf16> E;
+  static constexpr size_t w1_b = 2 * 8 * 64 * 16, w2_b = 4 * 16 * 64 * 16, bias_b = 256 * 4;
+  static constexpr size_t conv_bytes = E::conv_bytes + w1_b + w2_b + bias_b;
+  static constexpr int LDB = 128 + 8;      // bf16 proprio rows
+  static constexpr size_t mlp_bytes = (size_t)32 * LDB * 2 + (size_t)2 * 32 * E::LDH * 2 + 576 * 4;
+  static constexpr size_t bytes = conv_bytes > mlp_bytes ? conv_bytes : mlp_bytes;
+};
+__global__ __launch_bounds__(1024) void rollout_encoder2_kernel(const ActCtl* __restrict__ ctl, const float* __restrict__ obs,
+                                                                int E, InfEncFrag w, float* __restrict__ state_roll,
+                                                                __bf16* __restrict__ image_roll, float* __restrict__ x0) {
+  typedef __bf16 T;
+  typedef bf16x8 frag_t;
+  typedef InfEncLds<T> LY;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int fr = lane & 15, fg = (lane >> 4) * 8, qr = (lane >> 4) * 4;
+  const int64_t slot0 = (int64_t)ctl->t * E;
+  const int D = w.S + LY::IMG;
+  auto gfrag = [&](const void* W, int idx) -> frag_t { return reinterpret_cast<const frag_t*>(W)[idx * 64 + lane]; };
+
+  if ((int)blockIdx.x >= E) {
+    // ---------------- proprio branch, 32 rows per block: Linear+ReLU, Linear+ReLU, state_projector+ReLU -> token 0
+    constexpr int MR = LY::MLP_ROWS, LDB = RollEnc2Lds::LDB;
+    const int r0 = ((int)blockIdx.x - E) * MR;
+    T* sb = reinterpret_cast<T*>(smem);                         // [32][LDB] proprio rows (T)
+    T* h1 = sb + MR * LDB;
+    T* h2 = h1 + MR * LY::LDH;
+    float* bs = reinterpret_cast<float*>(h2 + MR * LY::LDH);    // bf1[256] | bf2[256] | bpr[64]
+    float sv[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {  // 32 x 128 values, 4 per thread; unconditional loads from clamped addresses
+      const int idx = tid + k * 1024, r = idx >> 7, c = idx & 127;
+      sv[k] = obs[(int64_t)min(r0 + r, E - 1) * D + min(c, w.S - 1)];
+    }
+    float bv = 0.f;
+    {
+      const int o = min(tid, 575);
+      const float *q0 = w.bf1, *q1 = w.bf2, *q2 = w.bpr;
+      bv = *(o >= 512 ? q2 + (o - 512) : o >= 256 ? q1 + (o - 256) : q0 + o);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    frag_t r1[4], r2[8], r3[8];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) r1[ks] = gfrag(w.wf1, wave * 4 + ks);
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) r2[ks] = gfrag(w.wf2, wave * 8 + ks);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int idx = tid + k * 1024, r = idx >> 7, c = idx & 127;
+      const bool ok = r0 + r < E;
+      const float v = ok && c < w.S ? sv[k] : 0.f;
+      if (ok && c < w.Sp) state_roll[(slot0 + r0 + r) * w.Sp + c] = v;
+      sb[r * LDB + c] = (T)v;
+    }
+    if (tid < 576) bs[tid] = bv;
+    __syncthreads();
+    auto store_h = [&](T* h, const f32x4 (&acc)[2], const float* bias) {
+      const int n4 = wave * 16 + qr;
+      const float4 bb = *reinterpret_cast<const float4*>(bias + n4);
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt)
+        st4(h + (mt * 16 + fr) * LY::LDH + n4, fmaxf(acc[mt][0] + bb.x, 0.f), fmaxf(acc[mt][1] + bb.y, 0.f),
+            fmaxf(acc[mt][2] + bb.z, 0.f), fmaxf(acc[mt][3] + bb.w, 0.f));
+    };
+    {
+      f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+      mm_held<T, 2, 4>(acc, sb, LDB, r1, lane);
+      if (wave < 4) {
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) r3[ks] = gfrag(w.wpr, wave * 8 + ks);
+      }
+      store_h(h1, acc, bs);
+    }
+    __syncthreads();
+    {
+      f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+      mm_held<T, 2, 8>(acc, h1, LY::LDH, r2, lane);
+      store_h(h2, acc, bs + 256);
+    }
+    __syncthreads();
+    if (wave < 4) {
+      f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+      mm_held<T, 2, 8>(acc, h2, LY::LDH, r3, lane);
+      const int n4 = wave * 16 + qr;
+      const float4 bb = *reinterpret_cast<const float4*>(bs + 512 + n4);
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt) {
+        const int row = r0 + mt * 16 + fr;
+        if (row < E)
+          st4(x0 + ((int64_t)row * NTOK) * TD + n4, fmaxf(acc[mt][0] + bb.x, 0.f), fmaxf(acc[mt][1] + bb.y, 0.f),
+              fmaxf(acc[mt][2] + bb.z, 0.f), fmaxf(acc[mt][3] + bb.w, 0.f));
+      }
+    }
+    return;
+  }
+
+  // ---------------- depth branch, one sample per block
+  const int b = blockIdx.x;
+  T* img = reinterpret_cast<T*>(smem);
+  T* c1 = img + LY::IMG;
+  T* c2 = c1 + LY::C1;
+  T* c3 = c2 + LY::C2;
+  frag_t* w1s = reinterpret_cast<frag_t*>(smem + LY::conv_bytes);   // [2][8][64]
+  frag_t* w2s = w1s + 2 * 8 * 64;                                    // [4][16][64]
+  float* bs = reinterpret_cast<float*>(w2s + 4 * 16 * 64);           // b1[32] | b2[64] | b3[64] | bup[64]
+  ROLL_STAMP(96);
+  float4 v[4];
+  {
+    const float* row = obs + (int64_t)b * D + w.S;
+    const bool al = (((int64_t)b * D + w.S) & 3) == 0;  // 16-byte aligned rows iff S % 4 == 0
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {  // 4096 float4 per image: four per thread, all in flight
+      const int i = tid + k * 1024;
+      if (al) v[k] = reinterpret_cast<const float4*>(row)[i];
+      else v[k] = float4{row[i * 4], row[i * 4 + 1], row[i * 4 + 2], row[i * 4 + 3]};
+    }
+  }
+  const frag_t w1v = reinterpret_cast<const frag_t*>(w.w1)[tid];
+  float bv;
+  {
+    const int o = min(tid, 223);
+    const float *q0 = w.b1, *q1 = w.b2, *q2 = w.b3, *q3 = w.bup;
+    bv = *(o >= 160 ? q3 + (o - 160) : o >= 96 ? q2 + (o - 96) : o >= 32 ? q1 + (o - 32) : q0 + o);
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  frag_t w2v[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) w2v[k] = reinterpret_cast<const frag_t*>(w.w2)[tid + k * 1024];
+  // conv3: wave = (column tile, K-quarter of 5/5/5/3 k-steps); up-conv: waves 0..3, one column tile each
+  const int nt3 = wave & 3, kq = wave >> 2, ks0 = kq * 5, ks1 = min(18, ks0 + 5);
+  frag_t w3v[5], wuv[2];
+#pragma unroll
+  for (int d = 0; d < 5; ++d) w3v[d] = gfrag(w.w3, nt3 * 18 + min(ks0 + d, 17));
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks) wuv[ks] = gfrag(w.wup, nt3 * 2 + ks);
+  __builtin_amdgcn_sched_barrier(0);
+  {
+    T* roll = image_roll + (slot0 + b) * (int64_t)LY::IMG;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int i = tid + k * 1024;
+      st4(img + i * 4, v[k].x, v[k].y, v[k].z, v[k].w);
+      st4(roll + i * 4, v[k].x, v[k].y, v[k].z, v[k].w);
+    }
+    w1s[tid] = w1v;
+    if (tid < 224) bs[tid] = bv;
+  }
+  __syncthreads();
+  ROLL_STAMP(97);
+  if (wave < 15) {  // conv1: 225 pixels = 15 row tiles, one per wave; K = (c,ky,kx) = 256, N = 32
+    f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+    const int p = min(wave * 16 + fr, 224);
+    const int pbase = (p / 15) * 4 * 64 + (p % 15) * 4;
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) {
+      const int k0 = ks * 32 + fg, c = k0 >> 6, ky = (k0 >> 3) & 7;
+      const frag_t fa = afrag_t(img + c * 4096 + ky * 64 + pbase);
+      mma_k32(acc[0], w1s[(0 * 8 + ks) * 64 + lane], fa);
+      mma_k32(acc[1], w1s[(1 * 8 + ks) * 64 + lane], fa);
+    }
+    const int pp = wave * 16 + fr;
+    if (pp < 225) {
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int n4 = j * 16 + qr;
+        const float4 bb = *reinterpret_cast<const float4*>(bs + n4);
+        st4(c1 + pp * LY::LD1 + n4, fmaxf(acc[j][0] + bb.x, 0.f), fmaxf(acc[j][1] + bb.y, 0.f), fmaxf(acc[j][2] + bb.z, 0.f),
+            fmaxf(acc[j][3] + bb.w, 0.f));
+      }
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 4; ++k) w2s[tid + k * 1024] = w2v[k];
+  __syncthreads();
+  ROLL_STAMP(98);
+  if (wave < 12) {  // conv2: 36 pixels (3 row tiles) x 4 column tiles, one pair per wave; K = (ky,kx,c) = 512
+    const int mt = wave >> 2, nt = wave & 3;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    const int p = min(mt * 16 + fr, 35);
+    const int pb = ((p / 6) * 2 * 15 + (p % 6) * 2) * LY::LD1;
+#pragma unroll
+    for (int ks = 0; ks < 16; ++ks) {
+      const int ky = ks >> 2, kx = ks & 3;  // 32 channels per tap == one K=32 step
+      const frag_t fa = afrag_t(c1 + pb + (ky * 15 + kx) * LY::LD1 + fg);
+      mma_k32(acc, w2s[(nt * 16 + ks) * 64 + lane], fa);
+    }
+    const int pp = mt * 16 + fr, n4 = nt * 16 + qr;
+    const float4 bb = *reinterpret_cast<const float4*>(bs + 32 + n4);
+    if (pp < 36)
+      st4(c2 + pp * LY::LD2 + n4, fmaxf(acc[0] + bb.x, 0.f), fmaxf(acc[1] + bb.y, 0.f), fmaxf(acc[2] + bb.z, 0.f),
+          fmaxf(acc[3] + bb.w, 0.f));
+  }
+  __syncthreads();
+  ROLL_STAMP(99);
+  float* part = reinterpret_cast<float*>(img);  // [4 K-quarters][16 pixels][64] fp32 partial sums (the image is dead)
+  {  // conv3: 16 pixels, K = (ky,kx,c) = 576 = 18 steps
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    const int pb = ((fr >> 2) * 6 + (fr & 3)) * LY::LD2;
+#pragma unroll
+    for (int d = 0; d < 5; ++d) {
+      const int ks = ks0 + d;
+      if (ks < ks1) {
+        const int tap = ks >> 1, ky = tap / 3, kx = tap - ky * 3, c0 = (ks & 1) * 32 + fg;
+        const frag_t fa = afrag_t(c2 + pb + (ky * 6 + kx) * LY::LD2 + c0);
+        mma_k32(acc, w3v[d], fa);
+      }
+    }
+    st4(part + (kq * 16 + fr) * 64 + nt3 * 16 + qr, acc[0], acc[1], acc[2], acc[3]);
+  }
+  __syncthreads();
+  ROLL_STAMP(100);
+  {  // sum of the four K-quarters + bias + ReLU -> c3: one output per thread
+    const int pix = tid >> 6, n = tid & 63;
+    const float s4 = ((part[pix * 64 + n] + part[(16 + pix) * 64 + n]) + part[(32 + pix) * 64 + n]) + part[(48 + pix) * 64 + n];
+    c3[pix * LY::LD2 + n] = (T)fmaxf(s4 + bs[96 + n], 0.f);
+  }
+  __syncthreads();
+  ROLL_STAMP(101);
+  if (wave < 4) {  // depth_up_conv (1x1, no activation) -> tokens 1..16
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const frag_t fa = afrag_t(c3 + fr * LY::LD2 + ks * 32 + fg);
+      mma_k32(acc, wuv[ks], fa);
+    }
+    const int n4 = wave * 16 + qr;
+    const float4 bb = *reinterpret_cast<const float4*>(bs + 160 + n4);
+    st4(x0 + ((int64_t)b * NTOK + 1 + fr) * TD + n4, acc[0] + bb.x, acc[1] + bb.y, acc[2] + bb.z, acc[3] + bb.w);
+  }
+  ROLL_STAMP(102);
+}
+
+
 // ------------------------------------------------------------------------------------------ rollout step, NatureCNN fuse net
 // The whole env step of the NatureCNN policy / value pair (networks/nets.py:194-262, base.py:345-398) for ONE sample
 // per block (blockIdx.y = net: both recompute the encoder they share): ingest -> conv1..3 -> visual projector (1024 ->

@@ -36,6 +36,7 @@ struct Conv {        // nn.Conv2d, square kernel, no padding. Activations NHWC, 
   int Cin = 0, Cout = 0, KH = 0, stride = 0, IH = 0, OH = 0;
   int K = 0, Kp = 0, Np = 0;
   int64_t pk = 0;
+  int64_t pkf = -1;       // fragment-order pack (rollout_encoder2_kernel), -1: none
   bool chw = false;       // conv1
   int ncls = 0;           // stride*stride parity classes of the gather-form data-grad
   int Kd = 0, Kdp = 0, Rd = 0;

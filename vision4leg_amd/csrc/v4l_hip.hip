@@ -732,6 +732,12 @@ int v4l_net::build() {
     auto pack_frag = [&](Lin& L) { L.pkf = add_pack(L.w, PK_FRAG, L.Np, L.Kp, L.N, L.K, 0, 0, 0, 0, 0, 0, 0); };
     for (TLayer& t : layers) { pack_frag(t.inproj); pack_frag(t.outproj); pack_frag(t.ff1); pack_frag(t.ff2); }
     for (Lin& L : head) pack_frag(L);
+    pack_frag(upconv); pack_frag(proj);
+    for (Lin& L : enc) pack_frag(L);
+    for (int i = 0; i < 3; ++i) {
+      Conv& v = conv[i];
+      v.pkf = add_pack(v.w, PK_FRAG, v.Np, v.Kp, v.Cout, v.K, v.chw ? 0 : v.Cin, v.KH * v.KH, v.KH, 0, 0, 0, 0);
+    }
   }
 
   seg_blocks = 0;
@@ -1454,7 +1460,24 @@ static int run_actor_fused(v4l_actor* a, const float* obs, const float* eps, flo
   float* x0 = ws_pf + Lp.x[0];
   g_op = "encoder";
   static const bool wide16 = getenv("V4L_ROLLOUT_4WAVE") == nullptr;  // 16-wave blocks (default) or the 4-wave kernels
-  if (wide16)
+  static const bool enc2 = getenv("V4L_ROLLOUT_ENC_OLD") == nullptr;
+  if (wide16 && enc2 && sizeof(T) == 2 && pf->enc.size() == 2 && pf->enc[0].Kp == 128 && pf->conv[0].pkf >= 0) {
+    static bool attr2 = false;
+    if (!attr2) {
+      V4L_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&rollout_encoder2_kernel),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)RollEnc2Lds::bytes));
+      attr2 = true;
+    }
+    const __bf16* pb = (const __bf16*)pf->packed;
+    InfEncFrag ef;
+    ef.w1 = pb + pf->conv[0].pkf; ef.w2 = pb + pf->conv[1].pkf; ef.w3 = pb + pf->conv[2].pkf; ef.wup = pb + pf->upconv.pkf;
+    ef.b1 = en.b1; ef.b2 = en.b2; ef.b3 = en.b3; ef.bup = en.bup;
+    ef.wf1 = pb + pf->enc[0].pkf; ef.wf2 = pb + pf->enc[1].pkf; ef.wpr = pb + pf->proj.pkf;
+    ef.bf1 = en.bf1; ef.bf2 = en.bf2; ef.bpr = en.bpr;
+    ef.S = en.S; ef.Sp = en.Sp;
+    V4L_KLAUNCH("rollout_encoder", 2.0 * E * 3678208.0, s, rollout_encoder2_kernel, dim3(E + cdiv(E, 32)), dim3(1024),
+                RollEnc2Lds::bytes, s, (const ActCtl*)a->ctl, obs, E, ef, state_roll, (__bf16*)image_roll, x0);
+  } else if (wide16)
     V4L_KLAUNCH("rollout_encoder", 2.0 * E * 3678208.0, s, rollout_encoder_kernel<T>, dim3(E + cdiv(E, 32)), dim3(1024),
                 InfEncLds<T>::bytes, s, (const ActCtl*)a->ctl, obs, E, en, state_roll, (T*)image_roll, x0);
   else
