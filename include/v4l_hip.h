@@ -224,7 +224,9 @@ int64_t v4l_prof_collect(char* buf, int64_t cap);
  * tools/probe/stamps*.py; it is not part of this ABI and absent from the shipped library.) */
 
 /* ---- introspection for tests: float offset of a named activation inside a workspace laid out for n rows
- * ("c1","c2","c3","eh<i>","x<l>","qkv<l>","P<l>","ctx<l>","mid<l>","ff<l>","pooled","hh<i>","out","dout",…); -1 if unknown */
+ * ("c1","c2","c3","eh<i>","x<l>","qkv<l>","P<l>","ctx<l>","mid<l>","ff<l>","xin<l>","xh1_<l>","rs1_<l>","pooled","hh<i>",
+ * "out","dout", and after a backward pass "dz2_<l>","df<l>","dz1_<l>","dqkv<l>","dx<l>","dhh<i>","deh<i>","dpool","dc1".."dc3");
+ * -1 if unknown. Tensors the fused kernels only ever use as MFMA operands hold the operand type T in an fp32-sized slot. */
 int64_t v4l_net_ws_offset(const v4l_net* net, int n, const char* name);
 
 #ifdef __cplusplus

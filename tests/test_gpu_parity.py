@@ -187,13 +187,38 @@ def test_backward(name, mode, device):
             ref32 = torch.autograd.grad((out32 * w).sum(), [op[k] for k in keys])
             for k in keys:
                 op[k].requires_grad_(False)
+        ref64 = None
         for i, (k, g) in enumerate(zip(keys, ref)):
             got = hip.grad_view(grads, k).cpu()
             e = util.rel_err(got, g)
             worst = max(worst, e)
             if mode == "f32":
                 if e >= TOL[mode]:
-                    bad.append((k, "%.2e" % e))
+                    # Two fp32 evaluations of the same graph can differ by more than summation noise in two ways: (a) at
+                    # B = 1024 a weight gradient sums 17 408 token rows (error ~ sqrt(rows) * eps * sum|terms|); (b) a ReLU
+                    # whose pre-activation is ~0 takes the other branch, which moves one row of the next weight gradient by a
+                    # whole term (seen: loco_rag / linear1, 1.5e-3). Both are properties of fp32, not of the kernels, so
+                    # the judge is float64: the HIP result must be as close to the float64 gradient as float64 evaluations
+                    # at parameters nudged by 3e-6 relative (the size of the fp32 activation differences, measured:
+                    # max |x1_hip - x1_float64| = 3e-6; tools/probe/relu_flip.py shows the one differing ReLU decision of
+                    # loco_rag sits at |pre-activation| = 5e-7) are to each other (x4).
+                    if ref64 is None:
+                        def grad64(scale, seed):
+                            gen = torch.Generator().manual_seed(seed)
+                            p64 = {kk: (vv.detach().double() * (1 + scale * torch.randn(vv.shape, generator=gen).double()))
+                                   .requires_grad_(True) for kk, vv in op.items()}
+                            o64 = orc.FORWARDS[case["kind"]](p64, obs.double(), case["S"], "f32")
+                            return dict(zip(keys, torch.autograd.grad((o64 * w.double()).sum(), [p64[kk] for kk in keys])))
+                        ref64 = grad64(0.0, 0)
+                        nudged = [grad64(3e-6, sd) for sd in (1, 2, 3, 4)]
+                    e64, n64 = util.rel_err(got, ref64[k]), util.rel_err(g, ref64[k])
+                    npert = max(util.rel_err(q[k], ref64[k]) for q in nudged)
+                    util.record("backward/%s/%s/%s/%s/hip_vs_f64" % (name, mode, tag, k), e64)
+                    util.record("backward/%s/%s/%s/%s/oracle32_vs_f64" % (name, mode, tag, k), n64)
+                    util.record("backward/%s/%s/%s/%s/f64_nudged_3e-6_vs_f64" % (name, mode, tag, k), npert)
+                    if e64 > max(TOL[mode], 4 * max(n64, npert)):
+                        bad.append((k, "vs fp32 oracle %.2e, vs fp64 %.2e (fp32 oracle vs fp64 %.2e, nudged fp64 vs fp64 %.2e)"
+                                    % (e, e64, n64, npert)))
             else:
                 env = util.rel_err(g, ref32[i])          # bf16-oracle vs fp32-oracle
                 e32 = util.rel_err(got, ref32[i])        # HIP bf16 vs fp32-oracle

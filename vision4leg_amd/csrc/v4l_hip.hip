@@ -1635,6 +1635,20 @@ int64_t v4l_net_ws_offset(const v4l_net* net, int n, const char* name) {
   if ((i = idx("ctx", L.lw.size())) >= 0) return L.lw[i].ctx;
   if ((i = idx("mid", L.lw.size())) >= 0) return L.lw[i].x1;
   if ((i = idx("ff", L.lw.size())) >= 0) return L.lw[i].f;
+  if ((i = idx("xin", L.lw.size())) >= 0) return L.lw[i].xin;
+  if ((i = idx("xh1_", L.lw.size())) >= 0) return L.lw[i].xh1;
+  if ((i = idx("xh2_", L.lw.size())) >= 0) return L.lw[i].xh2;
+  if ((i = idx("rs1_", L.lw.size())) >= 0) return L.lw[i].rs1;
+  if ((i = idx("rs2_", L.lw.size())) >= 0) return L.lw[i].rs2;
+  // backward tensors (valid after v4l_net_backward): gradients w.r.t. pre-activations / sub-layer outputs
+  if ((i = idx("dz2_", L.lb.size())) >= 0) return L.lb[i].dz2;
+  if ((i = idx("df", L.lb.size())) >= 0) return L.lb[i].df;
+  if ((i = idx("dz1_", L.lb.size())) >= 0) return L.lb[i].dz1;
+  if ((i = idx("dqkv", L.lb.size())) >= 0) return L.lb[i].dqkv;
+  if ((i = idx("dx", L.dxl.size())) >= 0) return L.dxl[i];
+  if ((i = idx("dhh", L.dhh.size())) >= 0) return L.dhh[i];
+  if ((i = idx("deh", L.deh.size())) >= 0) return L.deh[i];
+  if (s == "dpool") return L.dpool;
   return -1;
 }
 
