@@ -1,6 +1,6 @@
 import os, sys, ctypes as C
-os.environ["V4L_LIB"] = "/root/repo/tools/probe/libv4l_timing.so"
-sys.path.insert(0,'/root/repo'); sys.path.insert(0,'/root/repo/tests')
+os.environ["V4L_LIB"] = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libv4l_timing.so")
+ROOT=os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path.insert(0,ROOT); sys.path.insert(0,os.path.join(ROOT,"tests"))
 import numpy as np, torch, util
 os.environ["V4L_COMPUTE"]="bf16"
 import vision4leg_amd.torchrl.networks as networks, vision4leg_amd.torchrl.policies as policies

@@ -1982,6 +1982,254 @@ __global__ __launch_bounds__(1024) void rollout_encoder2_kernel(const ActCtl* __
 }
 
 
+// ------------------------------------------------------------------------------------------ training encoder, persistent blocks
+// The update's encoder forward (infer_encoder_kernel launched one 4-wave block per sample: 62 us at B = 1024, every block
+// streaming the 160 KB of conv weights for its single sample) as rollout_encoder2_kernel's block made persistent: a 16-wave
+// block keeps w1 / w2 in LDS and w3 / w_up in registers and walks its samples smp = cb, cb + nconv, ...; the next sample's
+// depth stack (bf16 rollout row, gathered through rowidx) is requested while the current one is convolved. Saves c1 / c2 /
+// c3 (fp32 NHWC, what the backward kernels read) and the depth tokens. Blocks 0 .. nmlp-1 run the proprio MLP for 32 rows
+// each (they finish early; the conv blocks queued behind them start on their CUs). bf16 only.
+struct TrainEnc {
+  const __bf16* image;   // [slots][4*64*64]
+  const float* state;    // [slots][Sp]
+  const int* rowidx;     // [n] or null
+  float *s_c1, *s_c2, *s_c3;  // [n][225][32], [n][36][64], [n][16][64]
+  float *s_h1, *s_h2;         // [n][256] encoder-MLP activations
+  int n, nmlp, nconv;
+};
+struct TrainEncLds {
+  static constexpr size_t part_b = 4 * 16 * 64 * 4;
+  static constexpr size_t bytes = RollEnc2Lds::conv_bytes + part_b;
+};
+__global__ __launch_bounds__(1024) void train_encoder_kernel(InfEncFrag w, TrainEnc tr, float* __restrict__ x0) {
+  typedef __bf16 T;
+  typedef bf16x8 frag_t;
+  typedef InfEncLds<T> LY;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int fr = lane & 15, fg = (lane >> 4) * 8, qr = (lane >> 4) * 4;
+  const int n = tr.n;
+  auto gfrag = [&](const void* W, int idx) -> frag_t { return reinterpret_cast<const frag_t*>(W)[idx * 64 + lane]; };
+
+  if ((int)blockIdx.x < tr.nmlp) {
+    // ---------------- proprio branch, 32 rows per block: Linear+ReLU, Linear+ReLU, state_projector+ReLU -> token 0
+    constexpr int MR = LY::MLP_ROWS, LDB = RollEnc2Lds::LDB;
+    const int r0 = (int)blockIdx.x * MR;
+    T* sb = reinterpret_cast<T*>(smem);
+    T* h1 = sb + MR * LDB;
+    T* h2 = h1 + MR * LY::LDH;
+    float* bs = reinterpret_cast<float*>(h2 + MR * LY::LDH);    // bf1[256] | bf2[256] | bpr[64]
+    float sv[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {  // 32 x 128 values, 4 per thread; unconditional loads from clamped addresses (Sp >= 32)
+      const int idx = tid + k * 1024, r = idx >> 7, c = idx & 127;
+      const int row = min(r0 + r, n - 1);
+      sv[k] = tr.state[(int64_t)(tr.rowidx ? tr.rowidx[row] : row) * w.Sp + min(c, w.Sp - 1)];
+    }
+    float bv;
+    {
+      const int o = min(tid, 575);
+      const float *q0 = w.bf1, *q1 = w.bf2, *q2 = w.bpr;
+      bv = *(o >= 512 ? q2 + (o - 512) : o >= 256 ? q1 + (o - 256) : q0 + o);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    frag_t r1[4], r2[8], r3[8];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) r1[ks] = gfrag(w.wf1, wave * 4 + ks);
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) r2[ks] = gfrag(w.wf2, wave * 8 + ks);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int idx = tid + k * 1024, r = idx >> 7, c = idx & 127;
+      sb[r * LDB + c] = (T)((r0 + r < n && c < w.Sp) ? sv[k] : 0.f);  // columns S..Sp-1 of a rollout row are zero
+    }
+    if (tid < 576) bs[tid] = bv;
+    __syncthreads();
+    auto store_h = [&](T* h, const f32x4 (&acc)[2], const float* bias, float* save) {
+      const int n4 = wave * 16 + qr;
+      const float4 bb = *reinterpret_cast<const float4*>(bias + n4);
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt) {
+        const float v0 = fmaxf(acc[mt][0] + bb.x, 0.f), v1 = fmaxf(acc[mt][1] + bb.y, 0.f);
+        const float v2 = fmaxf(acc[mt][2] + bb.z, 0.f), v3 = fmaxf(acc[mt][3] + bb.w, 0.f);
+        st4(h + (mt * 16 + fr) * LY::LDH + n4, v0, v1, v2, v3);
+        if (r0 + mt * 16 + fr < n) st4(save + (int64_t)(r0 + mt * 16 + fr) * 256 + n4, v0, v1, v2, v3);
+      }
+    };
+    {
+      f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+      mm_held<T, 2, 4>(acc, sb, LDB, r1, lane);
+      if (wave < 4) {
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) r3[ks] = gfrag(w.wpr, wave * 8 + ks);
+      }
+      store_h(h1, acc, bs, tr.s_h1);
+    }
+    __syncthreads();
+    {
+      f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+      mm_held<T, 2, 8>(acc, h1, LY::LDH, r2, lane);
+      store_h(h2, acc, bs + 256, tr.s_h2);
+    }
+    __syncthreads();
+    if (wave < 4) {
+      f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+      mm_held<T, 2, 8>(acc, h2, LY::LDH, r3, lane);
+      const int n4 = wave * 16 + qr;
+      const float4 bb = *reinterpret_cast<const float4*>(bs + 512 + n4);
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt) {
+        const int row = r0 + mt * 16 + fr;
+        if (row < n)
+          st4(x0 + ((int64_t)row * NTOK) * TD + n4, fmaxf(acc[mt][0] + bb.x, 0.f), fmaxf(acc[mt][1] + bb.y, 0.f),
+              fmaxf(acc[mt][2] + bb.z, 0.f), fmaxf(acc[mt][3] + bb.w, 0.f));
+      }
+    }
+    return;
+  }
+
+  // ---------------- depth branch: a persistent block over samples cb, cb + nconv, ...
+  const int cb = (int)blockIdx.x - tr.nmlp;
+  if (cb >= n) return;
+  T* img = reinterpret_cast<T*>(smem);
+  T* c1 = img + LY::IMG;
+  T* c2 = c1 + LY::C1;
+  T* c3 = c2 + LY::C2;
+  frag_t* w1s = reinterpret_cast<frag_t*>(smem + LY::conv_bytes);   // [2][8][64]
+  frag_t* w2s = w1s + 2 * 8 * 64;                                    // [4][16][64]
+  float* bs = reinterpret_cast<float*>(w2s + 4 * 16 * 64);           // b1[32] | b2[64] | b3[64] | bup[64]
+  float* part = bs + 256;                                            // [4 K-quarters][16 pixels][64] fp32
+  auto image_of = [&](int smp) { return tr.image + (int64_t)(tr.rowidx ? tr.rowidx[smp] : smp) * LY::IMG; };
+  frag_t iv[2];
+  {
+    const frag_t* src = reinterpret_cast<const frag_t*>(image_of(cb));  // 2048 x 16 bytes, two per thread
+    iv[0] = src[tid]; iv[1] = src[tid + 1024];
+  }
+  const frag_t w1v = reinterpret_cast<const frag_t*>(w.w1)[tid];
+  float bv;
+  {
+    const int o = min(tid, 223);
+    const float *q0 = w.b1, *q1 = w.b2, *q2 = w.b3, *q3 = w.bup;
+    bv = *(o >= 160 ? q3 + (o - 160) : o >= 96 ? q2 + (o - 96) : o >= 32 ? q1 + (o - 32) : q0 + o);
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  frag_t w2v[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) w2v[k] = reinterpret_cast<const frag_t*>(w.w2)[tid + k * 1024];
+  const int nt3 = wave & 3, kq = wave >> 2, ks0 = kq * 5, ks1 = min(18, ks0 + 5);
+  frag_t w3v[5], wuv[2];
+#pragma unroll
+  for (int d = 0; d < 5; ++d) w3v[d] = gfrag(w.w3, nt3 * 18 + min(ks0 + d, 17));
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks) wuv[ks] = gfrag(w.wup, nt3 * 2 + ks);
+  __builtin_amdgcn_sched_barrier(0);
+  reinterpret_cast<frag_t*>(img)[tid] = iv[0];
+  reinterpret_cast<frag_t*>(img)[tid + 1024] = iv[1];
+  w1s[tid] = w1v;
+  if (tid < 224) bs[tid] = bv;
+  bool w2_pending = true;
+  __syncthreads();
+  for (int smp = cb; smp < n; smp += tr.nconv) {
+    const int nxt = smp + tr.nconv;
+    if (nxt < n) {  // the next depth stack starts its trip now
+      const frag_t* src = reinterpret_cast<const frag_t*>(image_of(nxt));
+      iv[0] = src[tid]; iv[1] = src[tid + 1024];
+    }
+    if (wave < 15) {  // conv1: 225 pixels = 15 row tiles, one per wave; K = (c,ky,kx) = 256, N = 32
+      f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+      const int p = min(wave * 16 + fr, 224);
+      const int pbase = (p / 15) * 4 * 64 + (p % 15) * 4;
+#pragma unroll
+      for (int ks = 0; ks < 8; ++ks) {
+        const int k0 = ks * 32 + fg, c = k0 >> 6, ky = (k0 >> 3) & 7;
+        const frag_t fa = afrag_t(img + c * 4096 + ky * 64 + pbase);
+        mma_k32(acc[0], w1s[(0 * 8 + ks) * 64 + lane], fa);
+        mma_k32(acc[1], w1s[(1 * 8 + ks) * 64 + lane], fa);
+      }
+      const int pp = wave * 16 + fr;
+      if (pp < 225) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const int n4 = j * 16 + qr;
+          const float4 bb = *reinterpret_cast<const float4*>(bs + n4);
+          const float v0 = fmaxf(acc[j][0] + bb.x, 0.f), v1 = fmaxf(acc[j][1] + bb.y, 0.f);
+          const float v2 = fmaxf(acc[j][2] + bb.z, 0.f), v3 = fmaxf(acc[j][3] + bb.w, 0.f);
+          st4(c1 + pp * LY::LD1 + n4, v0, v1, v2, v3);
+          st4(tr.s_c1 + ((int64_t)smp * 225 + pp) * 32 + n4, v0, v1, v2, v3);
+        }
+      }
+    }
+    if (w2_pending) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) w2s[tid + k * 1024] = w2v[k];
+      w2_pending = false;
+    }
+    __syncthreads();
+    if (nxt < n) {  // conv1 has consumed the image: the next one takes its place
+      reinterpret_cast<frag_t*>(img)[tid] = iv[0];
+      reinterpret_cast<frag_t*>(img)[tid + 1024] = iv[1];
+    }
+    if (wave < 12) {  // conv2: 36 pixels (3 row tiles) x 4 column tiles, one pair per wave; K = (ky,kx,c) = 512
+      const int mt = wave >> 2, nt = wave & 3;
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+      const int p = min(mt * 16 + fr, 35);
+      const int pb = ((p / 6) * 2 * 15 + (p % 6) * 2) * LY::LD1;
+#pragma unroll
+      for (int ks = 0; ks < 16; ++ks) {
+        const int ky = ks >> 2, kx = ks & 3;
+        const frag_t fa = afrag_t(c1 + pb + (ky * 15 + kx) * LY::LD1 + fg);
+        mma_k32(acc, w2s[(nt * 16 + ks) * 64 + lane], fa);
+      }
+      const int pp = mt * 16 + fr, n4 = nt * 16 + qr;
+      const float4 bb = *reinterpret_cast<const float4*>(bs + 32 + n4);
+      if (pp < 36) {
+        const float v0 = fmaxf(acc[0] + bb.x, 0.f), v1 = fmaxf(acc[1] + bb.y, 0.f);
+        const float v2 = fmaxf(acc[2] + bb.z, 0.f), v3 = fmaxf(acc[3] + bb.w, 0.f);
+        st4(c2 + pp * LY::LD2 + n4, v0, v1, v2, v3);
+        st4(tr.s_c2 + ((int64_t)smp * 36 + pp) * 64 + n4, v0, v1, v2, v3);
+      }
+    }
+    __syncthreads();
+    {  // conv3: 16 pixels, K = (ky,kx,c) = 576 = 18 steps: wave = (column tile, K-quarter of 5/5/5/3 steps)
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+      const int pb = ((fr >> 2) * 6 + (fr & 3)) * LY::LD2;
+#pragma unroll
+      for (int d = 0; d < 5; ++d) {
+        const int ks = ks0 + d;
+        if (ks < ks1) {
+          const int tap = ks >> 1, ky = tap / 3, kx = tap - ky * 3, c0 = (ks & 1) * 32 + fg;
+          const frag_t fa = afrag_t(c2 + pb + (ky * 6 + kx) * LY::LD2 + c0);
+          mma_k32(acc, w3v[d], fa);
+        }
+      }
+      st4(part + (kq * 16 + fr) * 64 + nt3 * 16 + qr, acc[0], acc[1], acc[2], acc[3]);
+    }
+    __syncthreads();
+    {  // sum of the four K-quarters + bias + ReLU -> c3: one output per thread
+      const int pix = tid >> 6, nn = tid & 63;
+      const float s4 = ((part[pix * 64 + nn] + part[(16 + pix) * 64 + nn]) + part[(32 + pix) * 64 + nn]) + part[(48 + pix) * 64 + nn];
+      const float v = fmaxf(s4 + bs[96 + nn], 0.f);
+      c3[pix * LY::LD2 + nn] = (T)v;
+      tr.s_c3[((int64_t)smp * 16 + pix) * 64 + nn] = v;
+    }
+    __syncthreads();
+    if (wave < 4) {  // depth_up_conv (1x1, no activation) -> tokens 1..16
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        const frag_t fa = afrag_t(c3 + fr * LY::LD2 + ks * 32 + fg);
+        mma_k32(acc, wuv[ks], fa);
+      }
+      const int n4 = wave * 16 + qr;
+      const float4 bb = *reinterpret_cast<const float4*>(bs + 160 + n4);
+      st4(x0 + ((int64_t)smp * NTOK + 1 + fr) * TD + n4, acc[0] + bb.x, acc[1] + bb.y, acc[2] + bb.z, acc[3] + bb.w);
+    }
+    // (no barrier: the next round's conv1 only reads img / w1s and writes c1, which conv2 of this round has finished reading)
+  }
+}
+
+
 // ------------------------------------------------------------------------------------------ rollout step, NatureCNN fuse net
 // The whole env step of the NatureCNN policy / value pair (networks/nets.py:194-262, base.py:345-398) for ONE sample
 // per block (blockIdx.y = net: both recompute the encoder they share): ingest -> conv1..3 -> visual projector (1024 ->

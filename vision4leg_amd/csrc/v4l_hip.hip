@@ -912,9 +912,35 @@ int v4l_net::forward_t(const float* state, const T* image, const int* rowidx, in
       tr.image = image; tr.state = state; tr.rowidx = rowidx;
       tr.s_c1 = ws + L.c1; tr.s_c2 = ws + L.c2; tr.s_c3 = ws + L.c3; tr.s_h1 = ws + L.eh[0]; tr.s_h2 = ws + L.eh[1];
       g_op = "encoder";
-      V4L_KLAUNCH("fused_encoder", 2.0 * n * 3784064.0, s, infer_encoder_kernel<T>, dim3(n + cdiv(n, 32)), dim3(256),
-                  InfEncLds<T>::bytes, s, (const ActCtl*)nullptr, (const float*)nullptr, n, en, (float*)nullptr, (T*)nullptr, x0,
-                  tr);
+      static const bool persistent_enc = getenv("V4L_TRAIN_ENC_OLD") == nullptr;
+      if (persistent_enc && sizeof(T) == 2 && enc[0].Kp == 128 && conv[0].pkf >= 0 && c.kind == V4L_NET_LOCO) {
+        // persistent 16-wave blocks: conv weights enter a CU once, not once per sample (csrc/infer.h train_encoder_kernel)
+        static bool attr2 = false;
+        if (!attr2) {
+          V4L_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&train_encoder_kernel),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)TrainEncLds::bytes));
+          attr2 = true;
+        }
+        const __bf16* pb = (const __bf16*)packed;
+        InfEncFrag ef;
+        ef.w1 = pb + conv[0].pkf; ef.w2 = pb + conv[1].pkf; ef.w3 = pb + conv[2].pkf; ef.wup = pb + upconv.pkf;
+        ef.b1 = en.b1; ef.b2 = en.b2; ef.b3 = en.b3; ef.bup = en.bup;
+        ef.wf1 = pb + enc[0].pkf; ef.wf2 = pb + enc[1].pkf; ef.wpr = pb + proj.pkf;
+        ef.bf1 = en.bf1; ef.bf2 = en.bf2; ef.bpr = en.bpr;
+        ef.S = en.S; ef.Sp = en.Sp;
+        TrainEnc te;
+        te.image = (const __bf16*)image; te.state = state; te.rowidx = rowidx;
+        te.s_c1 = tr.s_c1; te.s_c2 = tr.s_c2; te.s_c3 = tr.s_c3; te.s_h1 = tr.s_h1; te.s_h2 = tr.s_h2;
+        te.n = n; te.nmlp = cdiv(n, 32);
+        static const int cus = getenv("V4L_TRAIN_ENC_BLOCKS") ? atoi(getenv("V4L_TRAIN_ENC_BLOCKS")) : 256;
+        te.nconv = std::max(1, std::min(n, cus - te.nmlp));
+        V4L_KLAUNCH("fused_encoder", 2.0 * n * 3784064.0, s, train_encoder_kernel, dim3(te.nmlp + te.nconv), dim3(1024),
+                    TrainEncLds::bytes, s, ef, te, x0);
+      } else {
+        V4L_KLAUNCH("fused_encoder", 2.0 * n * 3784064.0, s, infer_encoder_kernel<T>, dim3(n + cdiv(n, 32)), dim3(256),
+                    InfEncLds<T>::bytes, s, (const ActCtl*)nullptr, (const float*)nullptr, n, en, (float*)nullptr, (T*)nullptr, x0,
+                    tr);
+      }
       V4L_LAUNCH_CHECK();
     } else if (enc_ws == nullptr && stage != 2 && c.kind == V4L_NET_LOCO_VIS) {
       // TransformerEncoder (base.py:388-494, depth only): conv stack -> 1x1 up-conv -> the 16 patch tokens, in order
