@@ -215,6 +215,26 @@ int v4l_trainer_update(v4l_trainer* tr, const v4l_rollout* ro, const int* rowidx
 /* copy_model_params_from_to(pf, target_pf) (torchrl/algo/utils.py:23-25, ppo.py:34) + repack of the target */
 int v4l_trainer_sync_target(v4l_trainer* tr, void* stream);
 
+/* ---- data parallel: one process per GPU, every rank owns an env shard and its own rollout; gradients are
+ * summed with ONE in-place RCCL all-reduce per optimiser step on the flat gradient buffer. The reference has no
+ * counterpart (single process); the exchange sits where `vf_loss.backward()` / `policy_loss.backward()` end
+ * (torchrl/algo/on_policy/ppo.py:71-72,116-117), before clip_grad_norm_, so that N ranks with batch n reproduce one process
+ * with batch N*n. RCCL is loaded at run time (dlopen librccl.so.1); nothing here is needed on a single GPU.
+ *   g_pf_dev / g_vf_dev of v4l_trainer_bind must have V4L_BUCKET_TAIL (8) floats of room behind total_params: the tail
+ *   carries the shard's advantage moments (global-minibatch normalisation, ppo.py:148) and loss shares through the same
+ *   collective. With a communicator attached and hyper.world_size > 1, v4l_trainer_update_next issues both all-reduces
+ *   itself on the update's stream (they are captured into its hipGraph); v4l_sync_grads is the same step for hosts that
+ *   drive the four phases (critic_grads / critic_step / actor_grads / actor_step) themselves. */
+#define V4L_COMM_ID_BYTES 128
+#define V4L_BUCKET_TAIL 8
+int v4l_comm_unique_id(char* id_out /* [V4L_COMM_ID_BYTES], rank 0; broadcast it to the other ranks by any means */);
+int v4l_trainer_comm_init(v4l_trainer* tr, const char* id /* [V4L_COMM_ID_BYTES] */, int rank, int world);
+int v4l_trainer_comm_destroy(v4l_trainer* tr);
+int v4l_sync_grads(v4l_trainer* tr, int which /* 1 = critic bucket, 0 = policy bucket */, void* stream);
+/* for a host that runs the collective itself (e.g. torch.distributed): statistics record -> bucket tail (pack = 1, before
+ * the all-reduce of total_params + V4L_BUCKET_TAIL floats) and back (pack = 0) */
+int v4l_trainer_bucket_tail(v4l_trainer* tr, int which, int pack, int world, void* stream);
+
 /* ---- built-in per-kernel timer (HIP events on the launch stream; used by bench.py for the roofline numbers).
  * v4l_prof_collect synchronises the device, writes "phase|op|kernel\tcalls\ttotal_us\talgorithmic_flops\n" lines
  * into buf (NUL terminated, truncated to cap) and returns the untruncated length. */

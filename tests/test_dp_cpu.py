@@ -79,17 +79,21 @@ def _worker(rank, world, port, out):
     p_vf = util.share_encoder(p_pf, {k: v.clone() for k, v in vf.state_dict().items()}, case["kind"])
     batch = util.make_batch(case, update=rank)  # each rank: its own env shard
     advs = torch.tensor(batch["advs"], dtype=torch.float32)
-    # critic phase: grads + the 3 advantage scalars in ONE buffer / ONE all-reduce
+    # critic phase: grads + the shard's advantage moments in ONE buffer / ONE all-reduce — the tail layout of
+    # bucket_tail_kernel (csrc/elem.h): [sum a, M2 = sum (a - mean_shard)^2, count, count * mean_shard^2, ...]
     g_vf, _ = _shard_grads(case, p_pf, p_vf, batch, world, 0.0, 1.0)
-    bucket = torch.cat([g_vf, torch.stack([advs.sum(), (advs ** 2).sum(), torch.tensor(float(advs.numel()))])])
+    m_loc = advs.double().mean()
+    tail = torch.stack([advs.double().sum(), ((advs.double() - m_loc) ** 2).sum(), torch.tensor(float(advs.numel()), dtype=torch.float64),
+                        advs.numel() * m_loc * m_loc]).float()
+    bucket = torch.cat([g_vf, tail, torch.zeros(4)])
     dist.all_reduce(bucket)
-    s, s2, c = bucket[-3].item(), bucket[-2].item(), bucket[-1].item()
+    s, m2, c, nm2 = (bucket[-8 + i].item() for i in range(4))
     mean = s / c
-    std = max(0.0, (s2 - c * mean * mean) / (c - 1.0)) ** 0.5  # adv_stats_finalize_kernel
+    std = max(0.0, (m2 + (nm2 - c * mean * mean)) / (c - 1.0)) ** 0.5  # adv_stats_finalize_kernel
     _, g_pf = _shard_grads(case, p_pf, p_vf, batch, world, mean, std)
     dist.all_reduce(g_pf)
     if rank == 0:
-        torch.save({"g_vf": bucket[:-3].clone(), "g_pf": g_pf, "mean": mean, "std": std}, out)
+        torch.save({"g_vf": bucket[:-8].clone(), "g_pf": g_pf, "mean": mean, "std": std}, out)
     dist.barrier()
     dist.destroy_process_group()
 

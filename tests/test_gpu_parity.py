@@ -804,17 +804,20 @@ def test_two_rank_update_equals_big_batch(name, device):
         tr._pre(n)
         tr.begin(None, st, 1e-4, 1e-4)
         tr.critic_grads(ro, n)
-    g = ranks[0][3].g_vf + ranks[1][3].g_vf
-    a = ranks[0][3].stats_cur()[18:21] + ranks[1][3].stats_cur()[18:21]
     for _, _, _, tr in ranks:
-        tr.g_vf.copy_(g)
-        tr.stats_cur()[18:21].copy_(a)
+        tr.bucket_tail(1, 1, 2)           # advantage moments + vf_loss share -> bucket tail (what the all-reduce carries)
+    g = ranks[0][3].g_vf_bucket + ranks[1][3].g_vf_bucket
+    for _, _, _, tr in ranks:
+        tr.g_vf_bucket.copy_(g)
+        tr.bucket_tail(1, 0, 2)
         tr.critic_step()
     for (_, _, _, tr), ro in zip(ranks, ros):
         tr.actor_grads(ro, n)
-    g = ranks[0][3].g_pf + ranks[1][3].g_pf
+        tr.bucket_tail(0, 1, 2)
+    g = ranks[0][3].g_pf_bucket + ranks[1][3].g_pf_bucket
     for _, _, _, tr in ranks:
-        tr.g_pf.copy_(g)
+        tr.g_pf_bucket.copy_(g)
+        tr.bucket_tail(0, 0, 2)
         tr.actor_step()
     pfC, vfC, _, trC = make(1, 2 * n)
     stC = torch.zeros(1, 24, device=device)
@@ -830,6 +833,7 @@ def test_two_rank_update_equals_big_batch(name, device):
     r0 = ranks[0][3].stats_cur().cpu().numpy()
     assert np.allclose(r0[0:2], sC[0:2], rtol=1e-5), (r0[0:2], sC[0:2])            # advs/mean, advs/std
     assert np.allclose(r0[[5, 17]], sC[[5, 17]], rtol=1e-4), (r0[[5, 17]], sC[[5, 17]])  # grad_norm/vf, grad_norm/pf
+    assert np.allclose(r0[[4, 6]], sC[[4, 6]], rtol=1e-4, atol=1e-6), (r0[[4, 6]], sC[[4, 6]])  # vf_loss, policy_loss: big-batch means
     # and so do the parameters: |diff| far below one Adam step (lr = 1e-4) on average, never above 2*lr
     for tag, a_net, c_net in (("pf", ranks[0][0], pfC), ("vf", ranks[0][1], vfC)):
         tot = cnt = 0.0
@@ -858,15 +862,18 @@ def _dp_phases_worker(mode, out_path):
     acts, advs, rets = 0.1 * rs.randn(T * E, case["A"]), rs.randn(T * E), rs.randn(T * E)
     rows = np.stack([rs.permutation(T * E)[:B] for _ in range(4)]).astype(np.int32)
     res = []
-    for phases in (True, False):
+    # (DP phases forced, exchange in: the library's RCCL communicator | torch.distributed, update as a captured graph)
+    for variant, (phases, comm, graph) in (("rccl-graph", (True, "rccl", True)), ("rccl-eager", (True, "rccl", False)),
+                                            ("torch-phases", (True, "torch", False)), ("single", (False, "rccl", False))):
         os.environ["V4L_FORCE_DP_PHASES"] = "1" if phases else "0"
+        os.environ["V4L_DP_COMM"] = comm
         pf, vf = _build(case, mode, device)
 
         class Coll: epoch_frames = T * E
         agent = PPO(pf=pf, vf=vf, plr=1e-4, vlr=1e-4, clip_para=0.2, opt_epochs=3, tau=0.95, entropy_coeff=0.005,
                     collector=Coll(), device=device, batch_size=B)
-        assert agent.dp_phases == phases
-        agent.use_graph = False
+        assert agent.dp_phases == (phases and comm == "torch") and agent.trainer.has_comm == (phases and comm == "rccl")
+        agent.use_graph = graph
         net = pf.hip
         net.ensure_bound()
         state, image = net.alloc_rollout(T * E, device)
@@ -877,7 +884,8 @@ def _dp_phases_worker(mode, out_path):
         agent.trainer.sync_target()
         agent.run_updates(ro, torch.tensor(rows, device=device), stats)
         torch.cuda.synchronize()
-        res.append(({k: v.detach().cpu().clone() for k, v in pf.state_dict().items()}, stats.cpu().numpy()))
+        res.append((variant, {k: v.detach().cpu().clone() for k, v in pf.state_dict().items()}, stats.cpu().numpy()))
+        del agent
     dist.destroy_process_group()
     torch.save(res, out_path)
 
@@ -886,8 +894,10 @@ def _dp_phases_worker(mode, out_path):
 @pytest.mark.timeout(600)
 @pytest.mark.parametrize("mode", MODES)
 def test_dp_phase_sequence_on_one_rank(mode, tmp_path):
-    """PPO._update_phases (critic grads -> all_reduce(grads + advantage sums) -> critic step -> actor grads -> all_reduce
-    -> actor step, over RCCL) on a 1-rank group must reproduce the fused single-GPU update."""
+    """The data-parallel update sequence (critic grads -> all-reduce [grads | advantage moments, loss share] -> critic step ->
+    actor grads -> all-reduce -> actor step) over a 1-rank RCCL group must reproduce the single-GPU update, in all three
+    forms: the library's own communicator inside the captured update graph (v4l_trainer_comm_init / v4l_sync_grads), the
+    same launched eagerly, and torch.distributed driving the four phases."""
     import torch.multiprocessing as mp
     out = str(tmp_path / "dp.pt")
     ctx = mp.get_context("spawn")
@@ -895,11 +905,17 @@ def test_dp_phase_sequence_on_one_rank(mode, tmp_path):
     p.start()
     p.join(540)
     assert p.exitcode == 0, "worker failed (exit code %s)" % p.exitcode
-    (pa, sa), (pb, sb) = torch.load(out, weights_only=False)
+    res = torch.load(out, weights_only=False)
+    assert [r[0] for r in res] == ["rccl-graph", "rccl-eager", "torch-phases", "single"]
+    _, pb, sb = res[-1]
     tol = 2e-4 if mode == "f32" else 1e-2
-    assert np.allclose(sa[:, :18], sb[:, :18], rtol=tol, atol=tol / 10), np.abs(sa[:, :18] - sb[:, :18]).max()
-    drift = sum((pa[k] - pb[k]).abs().sum().item() for k in pa) / sum(v.numel() for v in pa.values())
-    assert drift <= (2e-7 if mode == "f32" else 2e-5), drift
+    for variant, pa, sa in res[:-1]:
+        assert np.allclose(sa[:, :18], sb[:, :18], rtol=tol, atol=tol / 10), (variant, np.abs(sa[:, :18] - sb[:, :18]).max())
+        drift = sum((pa[k] - pb[k]).abs().sum().item() for k in pa) / sum(v.numel() for v in pa.values())
+        assert drift <= (2e-7 if mode == "f32" else 2e-5), (variant, drift)
+    # the captured graph (RCCL all-reduces inside) and the eager launch sequence are the same kernels in the same order
+    assert np.array_equal(res[0][2][:, :18], res[1][2][:, :18])
+    assert all(torch.equal(res[0][1][k], res[1][1][k]) for k in res[0][1])
 
 
 @pytest.mark.parametrize("n", [1, 30])

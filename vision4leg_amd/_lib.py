@@ -15,6 +15,8 @@ V4L_NET_MLP, V4L_NET_CNN, V4L_NET_LOCO, V4L_NET_CNN_VIS, V4L_NET_LOCO_VIS = 0, 1
 V4L_MAX_HIDDEN = 4
 V4L_STATS = 24
 V4L_OUT_LD = 16
+V4L_BUCKET_TAIL = 8   # scalars behind the gradients of an all-reduce bucket
+V4L_COMM_ID_BYTES = 128
 
 # order of the 18 logger keys inside a stats record (torchrl/algo/on_policy/ppo.py:77-92,122-123,142-145)
 STAT_KEYS = [
@@ -52,7 +54,7 @@ class Rollout(C.Structure):
 
 def build_command(out=LIB_PATH):
   hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-  return [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-munsafe-fp-atomics", "-fPIC", "-shared",
+  return [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
           os.path.join(SRC_DIR, "v4l_hip.hip"), "-o", out]
 
 
@@ -116,6 +118,11 @@ _SIGS = {
   "v4l_trainer_update": (C.c_int, [_P, C.POINTER(Rollout), _P, C.c_int, C.POINTER(PPOHyper), C.c_double,
                                    C.c_double, C.c_int64, _P, _P]),
   "v4l_trainer_sync_target": (C.c_int, [_P, _P]),
+  "v4l_comm_unique_id": (C.c_int, [C.c_char_p]),
+  "v4l_trainer_comm_init": (C.c_int, [_P, C.c_char_p, C.c_int, C.c_int]),
+  "v4l_trainer_comm_destroy": (C.c_int, [_P]),
+  "v4l_sync_grads": (C.c_int, [_P, C.c_int, _P]),
+  "v4l_trainer_bucket_tail": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, _P]),
   "v4l_net_ws_offset": (C.c_int64, [_P, C.c_int, C.c_char_p]),
   "v4l_prof_enable": (C.c_int, [C.c_int]),
   "v4l_prof_collect": (C.c_int64, [C.c_char_p, C.c_int64]),

@@ -3,6 +3,7 @@
 // global-norm + Adam, weight packing and GAE. All fp32 (GAE fp64) on the VALU; one wave = 64 lanes.
 #pragma once
 #include "common.h"
+#include "../../include/v4l_hip.h"
 
 namespace v4l {
 
@@ -343,8 +344,10 @@ enum {
   ST_ADV_MEAN = 0, ST_ADV_STD, ST_ADV_MAX, ST_ADV_MIN, ST_VF_LOSS, ST_GN_VF, ST_PI_LOSS,
   ST_LP_MEAN, ST_LP_STD, ST_LP_MAX, ST_LP_MIN, ST_LS_MEAN, ST_LS_STD, ST_LS_MAX, ST_LS_MIN,
   ST_RATIO_MAX, ST_RATIO_MIN, ST_GN_PF,
-  ST_ADV_SUM = 18, ST_ADV_SUMSQ, ST_ADV_CNT,  // raw sums for the data-parallel 3-scalar exchange
-  ST_SUMSQ_VF = 21, ST_SUMSQ_PF = 22,        // (unused since the norm partials moved to the control block)
+  // per-shard moments for the data-parallel exchange: sum a, M2 = sum (a - mean_shard)^2, count, count * mean_shard^2
+  // (the global variance is rebuilt as (sum M2_i + sum n_i mean_i^2 - N mean^2) / (N - 1): the only cancellation left is
+  // between shard means, not between a raw sum of squares and N mean^2)
+  ST_ADV_SUM = 18, ST_ADV_M2, ST_ADV_CNT, ST_ADV_NM2,
   ST_SIZE = 24
 };
 
@@ -370,20 +373,38 @@ __device__ __forceinline__ void adv_stats_body(const float* __restrict__ adv, co
     st[ST_ADV_MAX] = r.mx;
     st[ST_ADV_MIN] = r.mn;
     st[ST_ADV_SUM] = (float)r.s;
-    st[ST_ADV_SUMSQ] = (float)r2.s2;
+    st[ST_ADV_M2] = (float)r2.s;
     st[ST_ADV_CNT] = (float)n;
+    st[ST_ADV_NM2] = (float)(n * mean * mean);
   }
 }
 __global__ __launch_bounds__(256) void adv_stats_kernel(const float* __restrict__ adv, const int* __restrict__ rowidx, int n,
                                                         float* __restrict__ st) {
   adv_stats_body(adv, rowidx, n, st);
 }
-// Data-parallel: recompute mean/std from the all-reduced (sum, sumsq, count).
+// Data-parallel: mean / unbiased std of the GLOBAL minibatch from the all-reduced shard moments.
 __global__ void adv_stats_finalize_kernel(float* st) {
-  const double s = st[ST_ADV_SUM], s2 = st[ST_ADV_SUMSQ], c = st[ST_ADV_CNT];
+  const double s = st[ST_ADV_SUM], m2 = st[ST_ADV_M2], c = st[ST_ADV_CNT], nm2 = st[ST_ADV_NM2];
   const double mean = s / c;
   st[ST_ADV_MEAN] = (float)mean;
-  st[ST_ADV_STD] = (float)sqrt(fmax(0.0, (s2 - c * mean * mean) / (c - 1.0)));
+  st[ST_ADV_STD] = (float)sqrt(fmax(0.0, (m2 + (nm2 - c * mean * mean)) / (c - 1.0)));
+}
+// The scalars that ride in the tail of a gradient bucket through its all-reduce (8 floats behind the gradients):
+//   critic bucket: [sum a, M2, count, count * mean^2, vf_loss share, 0, 0, 0]   policy bucket: [policy_loss share, 0 ...]
+// pack = 1: record -> tail (before the collective); pack = 0: tail -> record (after it). A share is the shard's value / world:
+// the sum over ranks is the big-batch mean the reference would log.
+// V4L_BUCKET_TAIL (= 8) comes from include/v4l_hip.h
+__global__ void bucket_tail_kernel(float* __restrict__ st, float* __restrict__ tail, int which, int pack, float inv_world) {
+  const int t = threadIdx.x;
+  if (t >= V4L_BUCKET_TAIL) return;
+  if (which == 1) {  // critic
+    const int src[5] = {ST_ADV_SUM, ST_ADV_M2, ST_ADV_CNT, ST_ADV_NM2, ST_VF_LOSS};
+    if (pack) tail[t] = t < 5 ? st[src[t]] : 0.f;   // vf_loss is already a share: critic_loss_kernel scales by 1 / (n * world)
+    else if (t < 5) st[src[t]] = tail[t];
+  } else {
+    if (pack) tail[t] = t == 0 ? st[ST_PI_LOSS] * inv_world : 0.f;
+    else if (t == 0) st[ST_PI_LOSS] = tail[0];
+  }
 }
 
 // nn.MSELoss()(values, est_rets) and its gradient (ppo.py:94-123; clipped_value_loss=False path, and the

@@ -164,4 +164,7 @@ struct v4l_trainer {
   hipGraphExec_t gexec = nullptr;
   bool warm = false;
   bool bound = false;
+  // data parallel: RCCL communicator of this trainer's process group (null: single GPU, or the host drives the exchange)
+  void* comm = nullptr;
+  int comm_rank = 0, comm_world = 1;
 };

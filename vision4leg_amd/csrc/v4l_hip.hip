@@ -4,6 +4,8 @@
 
 #include <algorithm>
 
+#include <dlfcn.h>
+
 #include "net.h"
 #include "infer.h"
 #include "bwd.h"
@@ -553,6 +555,52 @@ static int conv_stack_bwd(Ctx& c, const T* image, const int* rowidx, int n, cons
   }
   return 0;
 }
+
+// ------------------------------------------------------------------------------------------ RCCL (data parallel)
+// The collective library is bound at run time (dlopen of the soname PyTorch-ROCm and /opt/rocm both ship): the shared
+// library has no link-time dependency on it and single-GPU users never load it. Only what the path needs is bound: one
+// in-place fp32 sum all-reduce per optimiser step, issued on the caller's stream so that it is captured
+// into the update's hipGraph like any kernel.
+struct RcclUid { char internal[128]; };
+struct Rccl {
+  void* h = nullptr;
+  int (*GetUniqueId)(RcclUid*) = nullptr;
+  int (*CommInitRank)(void**, int, RcclUid, int) = nullptr;
+  int (*CommDestroy)(void*) = nullptr;
+  int (*AllReduce)(const void*, void*, size_t, int, int, void*, hipStream_t) = nullptr;
+  const char* (*GetErrorString)(int) = nullptr;
+};
+static Rccl g_rccl;
+static int rccl_load() {
+  if (g_rccl.h != nullptr) return 0;
+  const char* names[] = {getenv("V4L_RCCL_LIB"), "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+  void* h = nullptr;
+  for (const char* nm : names) {
+    if (nm == nullptr || *nm == 0) continue;
+    h = dlopen(nm, RTLD_NOW | RTLD_GLOBAL);
+    if (h != nullptr) break;
+  }
+  V4L_REQUIRE(h != nullptr, "v4l_comm: cannot load RCCL (librccl.so.1): %s", dlerror());
+  Rccl r;
+  r.h = h;
+  r.GetUniqueId = (int (*)(RcclUid*))dlsym(h, "ncclGetUniqueId");
+  r.CommInitRank = (int (*)(void**, int, RcclUid, int))dlsym(h, "ncclCommInitRank");
+  r.CommDestroy = (int (*)(void*))dlsym(h, "ncclCommDestroy");
+  r.AllReduce = (int (*)(const void*, void*, size_t, int, int, void*, hipStream_t))dlsym(h, "ncclAllReduce");
+  r.GetErrorString = (const char* (*)(int))dlsym(h, "ncclGetErrorString");
+  V4L_REQUIRE(r.GetUniqueId && r.CommInitRank && r.CommDestroy && r.AllReduce && r.GetErrorString,
+              "v4l_comm: the loaded RCCL lacks a required symbol");
+  g_rccl = r;
+  return 0;
+}
+#define V4L_RCCL_CHECK(expr)                                                                      \
+  do {                                                                                            \
+    const int _e = (expr);                                                                        \
+    if (_e != 0) {                                                                                \
+      v4l::set_error("%s:%d: %s -> RCCL error %d (%s)", __FILE__, __LINE__, #expr, _e, v4l::g_rccl.GetErrorString(_e)); \
+      return -3;                                                                                  \
+    }                                                                                             \
+  } while (0)
 
 }  // namespace v4l
 
@@ -2071,6 +2119,7 @@ static void drop_graph(v4l_trainer* tr) {
 }
 void v4l_trainer_destroy(v4l_trainer* tr) {
   if (tr) drop_graph(tr);
+  if (tr && tr->comm && g_rccl.CommDestroy) { (void)g_rccl.CommDestroy(tr->comm); tr->comm = nullptr; }
   if (tr && tr->aux) {
     (void)hipStreamDestroy(tr->aux);
     (void)hipEventDestroy(tr->ev_fork);
@@ -2130,6 +2179,8 @@ static int check_update_args(const v4l_trainer* tr, const v4l_rollout* ro, int n
   V4L_REQUIRE(tr->pf->cfg.kind == V4L_NET_MLP || ro->image_dev, "v4l_trainer: rollout image array missing");
   V4L_REQUIRE(!hp->clipped_value_loss || ro->values_dev, "v4l_trainer: clipped_value_loss needs values_dev");
   V4L_REQUIRE(hp->world_size >= 1, "v4l_trainer: world_size must be >= 1");
+  V4L_REQUIRE(tr->comm == nullptr || hp->world_size == tr->comm_world,
+              "v4l_trainer: hyper.world_size (%d) differs from the communicator's (%d)", hp->world_size, tr->comm_world);
   V4L_REQUIRE(v4l_trainer_ws_floats(tr, n) <= tr->ws_floats, "v4l_trainer: workspace too small for n=%d", n);
   return 0;
 }
@@ -2187,7 +2238,7 @@ int v4l_trainer_actor_grads(v4l_trainer* tr, const v4l_rollout* ro, int n, const
   v4l_net *pf = tr->pf, *tp = tr->tpf;
   float* st = tr->stats_cur;
   const int* rowidx = tr->rowidx_cur;
-  if (hp->world_size > 1) {
+  if (hp->world_size > 1 || tr->comm != nullptr) {
     hipLaunchKernelGGL(adv_stats_finalize_kernel, dim3(1), dim3(1), 0, s, st);
     V4L_LAUNCH_CHECK();
   }
@@ -2238,11 +2289,73 @@ int v4l_trainer_actor_step(v4l_trainer* tr, const v4l_ppo_hyper* hp, void* strea
   return 0;
 }
 
+int v4l_comm_unique_id(char* id_out) {
+  V4L_REQUIRE(id_out != nullptr, "v4l_comm_unique_id: null argument");
+  int rc = rccl_load();
+  if (rc) return rc;
+  RcclUid id;
+  V4L_RCCL_CHECK(g_rccl.GetUniqueId(&id));
+  memcpy(id_out, id.internal, sizeof(id.internal));
+  return 0;
+}
+int v4l_trainer_comm_init(v4l_trainer* tr, const char* id, int rank, int world) {
+  V4L_REQUIRE(tr && id && world >= 1 && rank >= 0 && rank < world, "v4l_trainer_comm_init: bad argument");
+  V4L_REQUIRE(tr->comm == nullptr, "v4l_trainer_comm_init: the trainer already has a communicator");
+  int rc = rccl_load();
+  if (rc) return rc;
+  RcclUid uid;
+  memcpy(uid.internal, id, sizeof(uid.internal));
+  void* comm = nullptr;
+  V4L_RCCL_CHECK(g_rccl.CommInitRank(&comm, world, uid, rank));
+  drop_graph(tr);
+  tr->comm = comm; tr->comm_rank = rank; tr->comm_world = world;
+  return 0;
+}
+int v4l_trainer_comm_destroy(v4l_trainer* tr) {
+  V4L_REQUIRE(tr != nullptr, "v4l_trainer_comm_destroy: null argument");
+  if (tr->comm == nullptr) return 0;
+  drop_graph(tr);
+  void* comm = tr->comm;
+  tr->comm = nullptr; tr->comm_world = 1; tr->comm_rank = 0;
+  V4L_RCCL_CHECK(g_rccl.CommDestroy(comm));
+  return 0;
+}
+// The scalars of a bucket's tail, for hosts that run the collective themselves (pack = 1 before it, 0 after it)
+int v4l_trainer_bucket_tail(v4l_trainer* tr, int which, int pack, int world, void* stream) {
+  V4L_REQUIRE(tr && tr->bound && (which == 0 || which == 1) && world >= 1, "v4l_trainer_bucket_tail: bad argument");
+  v4l_net* net = which ? tr->vf : tr->pf;
+  float* tail = (which ? tr->g_vf : tr->g_pf) + net->total_params;
+  hipLaunchKernelGGL(bucket_tail_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, tr->stats_cur, tail, which, pack ? 1 : 0,
+                     1.f / (float)world);
+  V4L_LAUNCH_CHECK();
+  return 0;
+}
+// One in-place sum all-reduce of a gradient bucket: [gradients | V4L_BUCKET_TAIL scalars] (which: 1 = critic, 0 = policy)
+int v4l_sync_grads(v4l_trainer* tr, int which, void* stream) {
+  V4L_REQUIRE(tr && tr->bound && (which == 0 || which == 1), "v4l_sync_grads: bad argument");
+  V4L_REQUIRE(tr->comm != nullptr, "v4l_sync_grads: no communicator (v4l_trainer_comm_init)");
+  hipStream_t s = (hipStream_t)stream;
+  v4l_net* net = which ? tr->vf : tr->pf;
+  float* g = which ? tr->g_vf : tr->g_pf;
+  float* tail = g + net->total_params;
+  float* st = tr->stats_cur;
+  g_op = "allreduce";
+  hipLaunchKernelGGL(bucket_tail_kernel, dim3(1), dim3(64), 0, s, st, tail, which, 1, 1.f / (float)tr->comm_world);
+  V4L_LAUNCH_CHECK();
+  V4L_RCCL_CHECK(g_rccl.AllReduce(g, g, (size_t)net->total_params + V4L_BUCKET_TAIL, /*ncclFloat32*/ 7, /*ncclSum*/ 0, tr->comm, s));
+  hipLaunchKernelGGL(bucket_tail_kernel, dim3(1), dim3(64), 0, s, st, tail, which, 0, 1.f);
+  V4L_LAUNCH_CHECK();
+  return 0;
+}
+
 static int run_update(v4l_trainer* tr, const v4l_rollout* ro, int n, const v4l_ppo_hyper* hp, void* stream) {
   int rc;
+  const bool dp = tr->comm != nullptr;  // a 1-rank communicator runs the same sequence (how one GPU exercises it)
   if ((rc = v4l_trainer_critic_grads(tr, ro, n, hp, stream))) return rc;
+  if (dp && (rc = v4l_sync_grads(tr, 1, stream))) return rc;  // critic gradients + advantage moments + vf_loss share
   if ((rc = v4l_trainer_critic_step(tr, hp, stream))) return rc;
   if ((rc = v4l_trainer_actor_grads(tr, ro, n, hp, stream))) return rc;
+  if (dp && (rc = v4l_sync_grads(tr, 0, stream))) return rc;
   return v4l_trainer_actor_step(tr, hp, stream);
 }
 

@@ -263,7 +263,7 @@ class HipTrainer:
   torchrl/algo/on_policy/ppo.py:125-153."""
 
   def __init__(self, pf_net, vf_net, tpf_net, batch, clip_para, entropy_coeff, max_grad_norm=0.5,
-               betas=(0.9, 0.999), eps=1e-5, clipped_value_loss=False, world_size=1, g_vf=None):
+               betas=(0.9, 0.999), eps=1e-5, clipped_value_loss=False, world_size=1):
     self.pf, self.vf, self.tpf = pf_net, vf_net, tpf_net
     self.L = _lib.lib()
     for net in (pf_net, vf_net, tpf_net):
@@ -274,8 +274,11 @@ class HipTrainer:
     self.h = h
     dev = self.device
     z = lambda n: torch.zeros(n, dtype=torch.float32, device=dev)
-    self.g_pf, self.m_pf, self.v_pf = z(pf_net.total_params), z(pf_net.total_params), z(pf_net.total_params)
-    self.g_vf = g_vf if g_vf is not None else z(vf_net.total_params)
+    # gradient buckets: [total_params | V4L_BUCKET_TAIL scalars that ride through the data-parallel all-reduce]
+    self.g_pf_bucket = z(pf_net.total_params + _lib.V4L_BUCKET_TAIL)
+    self.g_vf_bucket = z(vf_net.total_params + _lib.V4L_BUCKET_TAIL)
+    self.g_pf, self.m_pf, self.v_pf = self.g_pf_bucket[:pf_net.total_params], z(pf_net.total_params), z(pf_net.total_params)
+    self.g_vf = self.g_vf_bucket[:vf_net.total_params]
     self.m_vf, self.v_vf = z(vf_net.total_params), z(vf_net.total_params)
     self.batch = 0
     self.stream = torch.cuda.Stream(device=dev)  # hipGraph capture needs a non-default stream
@@ -284,6 +287,22 @@ class HipTrainer:
                        int(bool(clipped_value_loss)), int(world_size))
     self.step = 0  # Adam steps taken (both optimisers step once per update)
     self._one_stats = torch.zeros(V4L_STATS, dtype=torch.float32, device=dev)
+    self.has_comm = False
+
+  def comm_init(self, comm_id, rank, world):
+    """Attach an RCCL communicator (v4l_trainer_comm_init): from then on update_next() issues the two all-reduces of an
+    update itself, on its stream, inside the captured graph. comm_id: the 128 bytes rank 0 got from comm_unique_id()."""
+    check(self.L.v4l_trainer_comm_init(self.h, bytes(comm_id), int(rank), int(world)), "v4l_trainer_comm_init")
+    self.has_comm = True
+
+  @staticmethod
+  def comm_unique_id():
+    buf = C.create_string_buffer(_lib.V4L_COMM_ID_BYTES)
+    check(_lib.lib().v4l_comm_unique_id(buf), "v4l_comm_unique_id")
+    return buf.raw
+
+  def bucket_tail(self, which, pack, world):
+    check(self.L.v4l_trainer_bucket_tail(self.h, int(which), int(pack), int(world), _stream()), "v4l_trainer_bucket_tail")
 
   def __del__(self):
     try:

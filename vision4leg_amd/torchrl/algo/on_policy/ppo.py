@@ -115,14 +115,24 @@ class PPO:
             for net in self.networks:  # `.data` writes do not bump the Parameters' version counters
                 net.mark_params_changed()
         with torch.cuda.device(self.device):
-            g_vf = None
-            if self.dp_phases:
-                # one buffer per all-reduce: critic grads + (sum adv, sum adv^2, count) in the tail
-                self._vf_bucket = torch.zeros(self.vf.hip.total_params + 3, dtype=torch.float32, device=self.device)
-                g_vf = self._vf_bucket[:self.vf.hip.total_params]
             self.trainer = HipTrainer(self.pf.hip, self.vf.hip, self.target_pf.hip, batch_size, clip_para,
                                       entropy_coeff, max_grad_norm=0.5, clipped_value_loss=clipped_value_loss,
-                                      world_size=self.world_size, g_vf=g_vf)
+                                      world_size=self.world_size)
+            # the exchange: by default the library's own RCCL communicator (all-reduces issued inside the captured update
+            # graph); V4L_DP_COMM=torch keeps them in torch.distributed (four eager phases per update)
+            self.dp_in_library = self.dp_phases and os.environ.get("V4L_DP_COMM", "rccl").lower() != "torch"
+            if self.dp_in_library:
+                dist = torch.distributed
+                rank = dist.get_rank()
+                if dist.get_backend() == "nccl":
+                    idt = torch.zeros(_lib.V4L_COMM_ID_BYTES, dtype=torch.uint8, device=self.device)
+                else:
+                    idt = torch.zeros(_lib.V4L_COMM_ID_BYTES, dtype=torch.uint8)
+                if rank == 0:
+                    idt.copy_(torch.frombuffer(bytearray(HipTrainer.comm_unique_id()), dtype=torch.uint8))
+                dist.broadcast(idt, src=0)
+                self.trainer.comm_init(bytes(idt.cpu().numpy().tobytes()), rank, self.world_size)
+                self.dp_phases = False  # update_next() carries the collectives itself
         self.use_graph = os.environ.get("V4L_GRAPH", "1") != "0"
         if isinstance(replay_buffer, rb.DeviceOnPolicyReplayBuffer):
             replay_buffer.attach(self.pf.hip, self.device)
@@ -230,16 +240,19 @@ class PPO:
         cur.wait_stream(tr.stream)
 
     def _update_phases(self, ro, n):
+        """The exchange done by torch.distributed (V4L_DP_COMM=torch): four eager phases, the buckets [gradients | tail]
+        all-reduced between them."""
         dist = torch.distributed
         tr = self.trainer
-        st = tr.stats_cur()
         tr.critic_grads(ro, n)
-        self._vf_bucket[-3:].copy_(st[18:21])
-        dist.all_reduce(self._vf_bucket)  # RCCL sum over env shards: critic grads + adv sums
-        st[18:21].copy_(self._vf_bucket[-3:])
+        tr.bucket_tail(1, 1, self.world_size)
+        dist.all_reduce(tr.g_vf_bucket)  # sum over env shards: critic grads + advantage moments + vf_loss share
+        tr.bucket_tail(1, 0, self.world_size)
         tr.critic_step()
         tr.actor_grads(ro, n)
-        dist.all_reduce(tr.g_pf)
+        tr.bucket_tail(0, 1, self.world_size)
+        dist.all_reduce(tr.g_pf_bucket)
+        tr.bucket_tail(0, 0, self.world_size)
         tr.actor_step()
 
     def update(self, batch):
