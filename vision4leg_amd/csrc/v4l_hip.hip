@@ -1685,7 +1685,9 @@ int64_t v4l_net_ws_offset(const v4l_net* net, int n, const char* name) {
   const Layout L = net->layout(n);
   const std::string s(name);
   auto idx = [&](const std::string& pre, size_t cnt) -> int {
-    if (s.compare(0, pre.size(), pre) != 0) return -1;
+    if (s.compare(0, pre.size(), pre) != 0 || s.size() == pre.size()) return -1;
+    for (size_t k = pre.size(); k < s.size(); ++k)
+      if (s[k] < '0' || s[k] > '9') return -1;  // "x1" is a token tensor, "xin1" / "xh1_0" are not
     int i = atoi(s.c_str() + pre.size());
     return (i >= 0 && (size_t)i < cnt) ? i : -1;
   };
