@@ -15,10 +15,11 @@ Every function cites the reference lines it follows (paths relative to /root/ref
 
 Two numeric flavours:
   mode="f32"  : what the reference computes.
-  mode="bf16" : same graph, but every contraction (Linear / Conv2d, forward and both backward products)
-                rounds its two operands to bfloat16 (round-to-nearest-even) and accumulates in fp32 — the
-                rounding points of the MI355X bf16 MFMA path. Attention score/value products, softmax,
-                LayerNorm, residuals, losses and Adam stay fp32 in both flavours.
+  mode="bf16" : same graph, but every contraction (Linear / Conv2d and the two attention products Q K^T and
+                P V, forward and both backward products of each) rounds its two operands to bfloat16
+                (round-to-nearest-even) and accumulates in fp32 — the rounding points of the MI355X bf16 MFMA
+                path (BASELINE.json north_star: "the transformer QK^T/softmax/V ... use MFMA bf16 tiles").
+                Softmax, the 1/sqrt(d) scale, LayerNorm, residuals, losses and Adam stay fp32 in both flavours.
 """
 import math
 
@@ -68,6 +69,26 @@ class _ConvBF16(torch.autograd.Function):
         return dx, dw, db, None
 
 
+class _MatmulBF16(torch.autograd.Function):
+    """a @ b with both operands rounded to bf16, fp32 accumulate; the backward products round theirs the same way."""
+
+    @staticmethod
+    def forward(ctx, a, b):
+        ar, br = rbf16(a), rbf16(b)
+        ctx.save_for_backward(ar, br)
+        return ar @ br
+
+    @staticmethod
+    def backward(ctx, dc):
+        ar, br = ctx.saved_tensors
+        dcr = rbf16(dc)
+        return dcr @ br.transpose(-1, -2), ar.transpose(-1, -2) @ dcr
+
+
+def matmul(a, b, mode):
+    return a @ b if mode == "f32" else _MatmulBF16.apply(a, b)
+
+
 def linear(x, w, b, mode):
     return F.linear(x, w, b) if mode == "f32" else _LinearBF16.apply(x, w, b)
 
@@ -105,8 +126,8 @@ def transformer_layer(p, prefix, x, mode):
     d = x.shape[-1]
     qkv = linear(x, p[prefix + ".self_attn.in_proj_weight"], p[prefix + ".self_attn.in_proj_bias"], mode)
     q, k, v = qkv.split(d, dim=-1)
-    scores = (q @ k.transpose(-1, -2)) * (1.0 / math.sqrt(d))
-    ctx = torch.softmax(scores, dim=-1) @ v
+    scores = matmul(q, k.transpose(-1, -2), mode) * (1.0 / math.sqrt(d))
+    ctx = matmul(torch.softmax(scores, dim=-1), v, mode)
     a = linear(ctx, p[prefix + ".self_attn.out_proj.weight"], p[prefix + ".self_attn.out_proj.bias"], mode)
     x = F.layer_norm(x + a, (d,), p[prefix + ".norm1.weight"], p[prefix + ".norm1.bias"], 1e-5)
     f = torch.relu(linear(x, p[prefix + ".linear1.weight"], p[prefix + ".linear1.bias"], mode))

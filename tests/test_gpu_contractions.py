@@ -25,7 +25,7 @@ def _close32(name, got, want, tag, tol=TOL):
     assert e <= tol, (name, e)
 
 
-def _close_t(name, got_t, want32, mode, tag):
+def _close_t(name, got_t, want32, mode, tag, max_ulp=1.0):
     """got_t: values the kernel stored in the compute type (as float64/32 tensor); want32: fp32 expectation before rounding."""
     if mode == "f32":
         return _close32(name, got_t, want32, tag)
@@ -37,7 +37,7 @@ def _close_t(name, got_t, want32, mode, tag):
     worst = (diff / ulp).max().item()
     util.record("contraction/%s/%s/frac_not_equal_to_rounded" % (tag, name), frac)
     util.record("contraction/%s/%s/worst_in_ulp" % (tag, name), worst)
-    assert worst <= 1.0 + 1e-3 and frac <= 5e-3, (name, worst, frac)
+    assert worst <= max_ulp + 1e-3 and frac <= 5e-3, (name, worst, frac)
 
 
 @pytest.mark.parametrize("mode", MODES)
@@ -102,9 +102,9 @@ def test_every_contraction_teacher_forced(mode, device):
             _close_t("L%d.layer_input_copy" % l, xin, xs[l], mode, tag)
             _close32("L%d.in_proj" % l, qkv, lin(xin, p + "self_attn.in_proj_weight", p + "self_attn.in_proj_bias"), tag)
             q, k, v = (t_.view(n, 17, 64) for t_ in qkv.split(64, dim=-1))
-            Pw = torch.softmax((q @ k.transpose(1, 2)) * 0.125, dim=-1)
+            Pw = torch.softmax((r(q) @ r(k).transpose(1, 2)) * 0.125, dim=-1)
             _close32("L%d.softmax(QK^T/8)" % l, P.view(n, 17, 17), Pw, tag)
-            _close_t("L%d.ctx=PV" % l, ctx.view(n, 17, 64), P.view(n, 17, 17) @ v, mode, tag)
+            _close_t("L%d.ctx=PV" % l, ctx.view(n, 17, 64), r(P.view(n, 17, 17)) @ r(v), mode, tag)
             z = xs[l] + lin(ctx, p + "self_attn.out_proj.weight", p + "self_attn.out_proj.bias")
             mu, var = z.mean(-1, keepdim=True), z.var(-1, unbiased=False, keepdim=True)
             _close32("L%d.out_proj+res+norm1.xhat" % l, xh1, (z - mu) / torch.sqrt(var + 1e-5), tag)
@@ -159,12 +159,14 @@ def test_every_contraction_teacher_forced(mode, device):
             dctx = dmm(dz1_w, p + "self_attn.out_proj.weight").view(n, 17, 64)
             q, k, v = (t_.view(n, 17, 64) for t_ in d["qkv"].split(64, dim=-1))
             P = d["P"]
-            dP = dctx @ v.transpose(1, 2)
+            dP = r(dctx) @ r(v).transpose(1, 2)          # every product on operands rounded to the compute type
             dS = P * (dP - (P * dP).sum(-1, keepdim=True))
-            dv_ = P.transpose(1, 2) @ dctx
-            dq_, dk_ = (dS @ k) * 0.125, (dS.transpose(1, 2) @ q) * 0.125
+            dv_ = r(P).transpose(1, 2) @ r(dctx)
+            dq_, dk_ = (r(dS) @ r(k)) * 0.125, (r(dS).transpose(1, 2) @ r(q)) * 0.125
             dqkv_w = torch.cat([dq_, dk_, dv_], -1).view(R, 192)
-            _close_t("d.L%d.attention_bwd" % l, dqkv, dqkv_w, mode, tag)
+            # (two rounding stages in a row — dS is rounded before it enters dQ / dK — so a 1e-7 difference in dS can move
+            # an output by a second ulp)
+            _close_t("d.L%d.attention_bwd" % l, dqkv, dqkv_w, mode, tag, max_ulp=2.0)
             dxin = dz1_w + dmm(dqkv_w, p + "self_attn.in_proj_weight")
             _close32("d.L%d.layer_input_grad" % l, dxs[l], dxin, tag, tol=1e-4 if mode == "bf16" else TOL)
             # ---- the four weight gradients of the layer: dW = dY^T X on the operands the kernels saved

@@ -315,7 +315,9 @@ __global__ __launch_bounds__(256) void bwd_layer_kernel(BwdLayer w, BwdHead hd, 
     for (int k = 0; k < QV; ++k) {
       const int i4 = tid + k * 256;
       const int r = i4 / 48, c4 = (i4 - r * 48) * 4;
-      if (i4 < ROWS * 48) *reinterpret_cast<float4*>(big + r * LY::LDQ + c4) = qpre[k];
+      // q | k | v as the attention products see them: rounded to T (the forward's attention runs on MFMA tiles of T, infer.h
+      // attn_tile); they are operands of those products only
+      if (i4 < ROWS * 48) *reinterpret_cast<float4*>(big + r * LY::LDQ + c4) = rt4<T>(qpre[k]);
     }
 #pragma unroll
     for (int k = 0; k < PV; ++k) {
@@ -339,12 +341,12 @@ __global__ __launch_bounds__(256) void bwd_layer_kernel(BwdLayer w, BwdHead hd, 
     block_gemm<T, MT, 1, 2>(acc, b, LY::LDX, (const T*)w.wot, 64, nt1, lane, ring_dctx);
     const int n4 = wave * 16 + qr;
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt)
-      st4(a + (mt * 16 + fr) * LY::LDX + n4, acc[mt][0][0], acc[mt][0][1], acc[mt][0][2], acc[mt][0][3]);
+    for (int mt = 0; mt < MT; ++mt)  // dctx is an operand of the attention products only: kept rounded to T
+      st4(a + (mt * 16 + fr) * LY::LDX + n4, rt<T>(acc[mt][0][0]), rt<T>(acc[mt][0][1]), rt<T>(acc[mt][0][2]), rt<T>(acc[mt][0][3]));
   }
   __syncthreads();
   LAY_STAMP(6);
-  // ---- attention backward of sample `wave` (fp32 VALU like the forward):
+  // ---- attention backward of sample `wave` (fp32 VALU on operands rounded to T: the products the forward's MFMA tiles make):
   //   dP = dctx V^T ; dS = P o (dP - rowsum(P o dP)) ; dV = P^T dctx ; dQ = dS K / 8 ; dK = dS^T Q / 8
   GemmRing<T, 1, 6> ring_dxin = gemm_prefetch<T, 1, 6>((const T*)w.wint, 192, nt1, lane);
   // TAIL: everything the encoder-side data-grads read from HBM (conv3 / x0 / MLP ReLU masks, the first weight fragments of
@@ -390,6 +392,7 @@ __global__ __launch_bounds__(256) void bwd_layer_kernel(BwdLayer w, BwdHead hd, 
         float s00 = 0.f, s01 = 0.f, s02 = 0.f, s10 = 0.f, s11 = 0.f, s12 = 0.f;
 #pragma unroll 4
         for (int d = 0; d < TD; d += 4) {
+          // (dctx and q | k | v sit in LDS already rounded to T: they are operands of these products only)
           const float4 x0 = *reinterpret_cast<const float4*>(da + d), x1 = *reinterpret_cast<const float4*>(db + d);
           const float4 y0 = *reinterpret_cast<const float4*>(va + d), y1 = *reinterpret_cast<const float4*>(vb + d);
           const float4 y2 = *reinterpret_cast<const float4*>(vc + d);
@@ -443,8 +446,8 @@ __global__ __launch_bounds__(256) void bwd_layer_kernel(BwdLayer w, BwdHead hd, 
         for (int j4 = 0; j4 < ATT_PLD; j4 += 4) {
           const float4 pv = *reinterpret_cast<const float4*>(p + i * ATT_PLD + j4);
           const float4 sv = *reinterpret_cast<const float4*>(ds + i * ATT_PLD + j4);
-          pi[j4] = pv.x; pi[j4 + 1] = pv.y; pi[j4 + 2] = pv.z; pi[j4 + 3] = pv.w;
-          si[j4] = sv.x; si[j4 + 1] = sv.y; si[j4 + 2] = sv.z; si[j4 + 3] = sv.w;
+          pi[j4] = rt<T>(pv.x); pi[j4 + 1] = rt<T>(pv.y); pi[j4 + 2] = rt<T>(pv.z); pi[j4 + 3] = rt<T>(pv.w);
+          si[j4] = rt<T>(sv.x); si[j4 + 1] = rt<T>(sv.y); si[j4 + 2] = rt<T>(sv.z); si[j4 + 3] = rt<T>(sv.w);
         }
 #pragma unroll
         for (int j = 0; j < NTOK; ++j) {

@@ -61,6 +61,10 @@ template <> struct Op<__bf16> {
   static __device__ __forceinline__ float to_f32(__bf16 x) { return (float)x; }
 };
 
+// x as the contraction sees it: rounded to the operand type (bf16: RNE; fp32: unchanged)
+template <typename T> __device__ __forceinline__ float rt(float x) { return Op<T>::to_f32(Op<T>::from_f32(x)); }
+template <typename T> __device__ __forceinline__ float4 rt4(float4 v) { return float4{rt<T>(v.x), rt<T>(v.y), rt<T>(v.z), rt<T>(v.w)}; }
+
 // One K=32 step of a 16x16 output tile. Every lane holds 8 operand elements whose k index is
 // 8*(lane>>4)+j for BOTH operands; row (A) / column (B) is lane&15.
 //   bf16: a single v_mfma_f32_16x16x32_bf16.

@@ -39,9 +39,12 @@ __global__ __launch_bounds__(256) void ingest_kernel(const float* __restrict__ o
 constexpr int ATT_LD = TD + 1;  // +1 float: conflict-free both for lane=d and lane=(i,j) access
 constexpr int ATT_PLD = 20;
 
+__device__ __forceinline__ float rbf(float x, int bf) { return bf ? (float)(__bf16)x : x; }
 template <int NT>
 __global__ __launch_bounds__(256) void attn_fwd_kernel(const float* __restrict__ qkv, int n, float* __restrict__ P,
-                                                       float* __restrict__ ctx) {
+                                                       float* __restrict__ ctx, int bf) {
+  // bf: bf16 compute mode — the operands of the two products (q, k; P, v) are rounded to bf16 like the MFMA tiles of the
+  // fused kernels round theirs (attn_tile, csrc/infer.h); accumulation, scale and softmax stay fp32
   // one sample per block: the 289 scores and the 17x64 context are spread over all 256 threads (the per-sample
   // dependency chain, not throughput, is what bounds this kernel)
   __shared__ float q[NT * ATT_LD], k[NT * ATT_LD], v[NT * ATT_LD], p[NT * ATT_PLD];
@@ -51,7 +54,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const float* __restrict__
   for (int idx = tid; idx < NT * 3 * TD; idx += 256) {
     const int t = idx / (3 * TD), c = idx - t * 3 * TD;
     const int part = c >> 6, d = c & 63;
-    (part == 0 ? q : part == 1 ? k : v)[t * ATT_LD + d] = src[idx];
+    (part == 0 ? q : part == 1 ? k : v)[t * ATT_LD + d] = rbf(src[idx], bf);
   }
   __syncthreads();
   for (int pr = tid; pr < NT * NT; pr += 256) {
@@ -81,7 +84,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const float* __restrict__
     const int i = o >> 6, d = o & 63;
     float a = 0.f;
 #pragma unroll
-    for (int j = 0; j < NT; ++j) a = fmaf(p[i * ATT_PLD + j], v[j * ATT_LD + d], a);
+    for (int j = 0; j < NT; ++j) a = fmaf(rbf(p[i * ATT_PLD + j], bf), v[j * ATT_LD + d], a);
     ctx[(int64_t)b * NT * TD + o] = a;
   }
 }
@@ -91,7 +94,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const float* __restrict__
 template <int NT>
 __global__ __launch_bounds__(256) void attn_bwd_kernel(const float* __restrict__ qkv, const float* __restrict__ P,
                                                        const float* __restrict__ dctx, int n,
-                                                       float* __restrict__ dqkv) {
+                                                       float* __restrict__ dqkv, int bf) {
   __shared__ float q[NT * ATT_LD], k[NT * ATT_LD], v[NT * ATT_LD], dc[NT * ATT_LD];
   __shared__ float p[NT * ATT_PLD], ds[NT * ATT_PLD];
   const int tid = threadIdx.x;
@@ -100,9 +103,9 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const float* __restrict__
   for (int idx = tid; idx < NT * 3 * TD; idx += 256) {
     const int t = idx / (3 * TD), c = idx - t * 3 * TD;
     const int part = c >> 6, d = c & 63;
-    (part == 0 ? q : part == 1 ? k : v)[t * ATT_LD + d] = src[idx];
+    (part == 0 ? q : part == 1 ? k : v)[t * ATT_LD + d] = rbf(src[idx], bf);  // q, k, v, dctx: contraction operands only
   }
-  for (int o = tid; o < NT * TD; o += 256) dc[(o >> 6) * ATT_LD + (o & 63)] = dctx[(int64_t)b * NT * TD + o];
+  for (int o = tid; o < NT * TD; o += 256) dc[(o >> 6) * ATT_LD + (o & 63)] = rbf(dctx[(int64_t)b * NT * TD + o], bf);
   for (int pr = tid; pr < NT * NT; pr += 256) {
     const int i = pr / NT, j = pr - i * NT;
     p[i * ATT_PLD + j] = P[(int64_t)b * NT * NT + pr];
@@ -113,7 +116,7 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const float* __restrict__
     const int j = o >> 6, d = o & 63;
     float a = 0.f;
 #pragma unroll
-    for (int i = 0; i < NT; ++i) a = fmaf(p[i * ATT_PLD + j], dc[i * ATT_LD + d], a);
+    for (int i = 0; i < NT; ++i) a = fmaf(rbf(p[i * ATT_PLD + j], bf), dc[i * ATT_LD + d], a);
     dst[j * 3 * TD + 2 * TD + d] = a;
   }
   for (int pr = tid; pr < NT * NT; pr += 256) {  // dP[i][j]
@@ -137,8 +140,8 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const float* __restrict__
     float aq = 0.f, ak = 0.f;
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
-      aq = fmaf(ds[t * ATT_PLD + j], k[j * ATT_LD + d], aq);  // dQ[t][d] = sum_j dS[t][j] K[j][d]
-      ak = fmaf(ds[j * ATT_PLD + t], q[j * ATT_LD + d], ak);  // dK[t][d] = sum_i dS[i][t] Q[i][d]
+      aq = fmaf(rbf(ds[t * ATT_PLD + j], bf), k[j * ATT_LD + d], aq);  // dQ[t][d] = sum_j dS[t][j] K[j][d]
+      ak = fmaf(rbf(ds[j * ATT_PLD + t], bf), q[j * ATT_LD + d], ak);  // dK[t][d] = sum_i dS[i][t] Q[i][d]
     }
     dst[t * 3 * TD + d] = aq * 0.125f;
     dst[t * 3 * TD + TD + d] = ak * 0.125f;
@@ -606,13 +609,18 @@ __device__ __forceinline__ int find_desc(const D* __restrict__ d, int n, int64_t
 }
 
 // --------------------------------------------------------------------------------- grad norm + Adam
-// sum of squares of a flat gradient buffer -> part[blockIdx.x] (<= 64 blocks; clip_adam_kernel adds them in order)
+// sum of squares of a flat gradient buffer -> part[blockIdx.x] (<= GRAD_NORM_PARTS blocks; clip_adam_kernel adds them in
+// order). 16-byte loads, one or two per thread: the 388 K-float buffer is one short burst over the whole chip, not 24
+// dependent trips of 64 blocks (12 us -> ~4 us).
+constexpr int GRAD_NORM_PARTS = 256;
 __global__ __launch_bounds__(256) void grad_sumsq_kernel(const float* __restrict__ g, int64_t n, float* __restrict__ part) {
   double s = 0.0;
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
-    const float x = g[i];
-    s += (double)x * x;
+  const int64_t n4 = n >> 2;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+    const float4 x = reinterpret_cast<const float4*>(g)[i];
+    s += ((double)x.x * x.x + (double)x.y * x.y) + ((double)x.z * x.z + (double)x.w * x.w);
   }
+  if (blockIdx.x == 0 && threadIdx.x < (int)(n & 3)) { const float x = g[(n4 << 2) + threadIdx.x]; s += (double)x * x; }
   Red4 r = block_red4(s, 0.0, 0.f, 0.f);
   if (threadIdx.x == 0) part[blockIdx.x] = (float)r.s;
 }
@@ -680,7 +688,10 @@ __global__ __launch_bounds__(256) void clip_adam_kernel(const ParamSeg* __restri
   const float beta1 = ctl->beta1, beta2 = ctl->beta2;
   const float step_size = ctl->step_size[which], bc2_sqrt = ctl->bc2_sqrt;
   const int lane_ = threadIdx.x & 63;
-  const float tot = sqrtf(wave_sum(lane_ < npart ? part[lane_] : 0.f));  // same order in every wave: deterministic
+  float ps = 0.f;  // GRAD_NORM_PARTS partials, four per lane, same order in every wave: deterministic
+#pragma unroll
+  for (int k = 0; k < GRAD_NORM_PARTS / 64; ++k) ps += lane_ + 64 * k < npart ? part[lane_ + 64 * k] : 0.f;
+  const float tot = sqrtf(wave_sum(ps));
   const float coef = fminf(max_norm / (tot + 1e-6f), 1.f);
   if (blockIdx.x == 0 && threadIdx.x == 0 && norm_out != nullptr) *norm_out = tot;
   const int64_t i = ((int64_t)blockIdx.x - sg.blk0) * 256 + threadIdx.x;

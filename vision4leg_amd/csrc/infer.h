@@ -137,6 +137,82 @@ template <int MT, int NTW> __device__ __forceinline__ void zero_acc(f32x4 (&acc)
     for (int j = 0; j < NTW; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 }
 
+// ------------------------------------------------------------------------------------------ attention tile (MFMA)
+// softmax(Q K^T / 8) V of ONE 16-query row tile of one sample (17 tokens, one head of 64) by ONE wave, on the matrix
+// cores (torchrl/networks/nets.py:948-955 builds nn.TransformerEncoderLayer(64, 1, ...); north star: "QK^T/softmax/V ... use
+// MFMA bf16 tiles"). Operands in the compute type T in LDS, written once by in_proj's epilogue:
+//   q0   : this tile's 16 query rows  [16][ldq]   (rows past the sample's 17th token are other rows of the block: finite,
+//          their results are discarded)
+//   k0   : the sample's key rows      [32][ldq]   (rows >= 17: ditto; their scores are masked to -inf)
+//   vt   : the sample's values, transposed [64][LDV], key columns 17..31 ZERO (0 x NaN would poison the row)
+//   pb   : wave-private scratch [16][LDV]: P in T, re-read as the A operand of P V
+// Scores and softmax live in registers (a lane owns query fr, keys 4g..4g+3 and 16+4g..16+4g+3; row max / sum cross the four
+// lane groups with two ds_bpermute each). nq: valid queries of the tile (16, or 1 for the tile that holds token 16).
+// Results: ctx rows -> cx (T, stride ldc; only valid queries are written), optionally P (fp32 [17][17]) and ctx (T [17][64])
+// of the sample to global memory for the backward pass.
+constexpr int ATT_LDV = 32 + 8;
+template <typename T>
+__device__ __forceinline__ void attn_tile(const T* q0, const T* k0, int ldq, const T* vt, T* pb, T* cx, int ldc, int lane,
+                                          int q_first, int nq, float* __restrict__ gP, T* __restrict__ gctx) {
+  typedef typename Frag<T>::type frag_t;
+  const int fr = lane & 15, g = lane >> 4, fg = g * 8, qr = g * 4;
+  f32x4 s[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks) {
+    const frag_t fa = *reinterpret_cast<const frag_t*>(q0 + fr * ldq + ks * 32 + fg);
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+      const frag_t fb = *reinterpret_cast<const frag_t*>(k0 + (nt * 16 + fr) * ldq + ks * 32 + fg);
+      mma_k32(s[nt], fb, fa);  // s[nt][r] = q[fr] . k[16 nt + 4g + r]
+    }
+  }
+  float pv[2][4];
+  float mx = -INFINITY;
+#pragma unroll
+  for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int key = nt * 16 + qr + r;
+      pv[nt][r] = key < NTOK ? s[nt][r] * 0.125f : -INFINITY;
+      mx = fmaxf(mx, pv[nt][r]);
+    }
+  mx = fmaxf(mx, __shfl_xor(mx, 16));
+  mx = fmaxf(mx, __shfl_xor(mx, 32));
+  float sum = 0.f;
+#pragma unroll
+  for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      pv[nt][r] = nt * 16 + qr + r < NTOK ? expf(pv[nt][r] - mx) : 0.f;
+      sum += pv[nt][r];
+    }
+  sum += __shfl_xor(sum, 16);
+  sum += __shfl_xor(sum, 32);
+  const float inv = 1.f / sum;
+#pragma unroll
+  for (int nt = 0; nt < 2; ++nt) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      pv[nt][r] *= inv;
+      const int key = nt * 16 + qr + r;
+      if (gP != nullptr && fr < nq && key < NTOK) gP[(q_first + fr) * NTOK + key] = pv[nt][r];
+    }
+    st4(pb + fr * ATT_LDV + nt * 16 + qr, pv[nt][0], pv[nt][1], pv[nt][2], pv[nt][3]);
+  }
+  __builtin_amdgcn_wave_barrier();  // pb is wave-private: LDS operations of one wave execute in order
+  const frag_t fp = *reinterpret_cast<const frag_t*>(pb + fr * ATT_LDV + fg);
+#pragma unroll
+  for (int nt = 0; nt < 4; ++nt) {
+    f32x4 c = {0.f, 0.f, 0.f, 0.f};
+    const frag_t fv = *reinterpret_cast<const frag_t*>(vt + (nt * 16 + fr) * ATT_LDV + fg);
+    mma_k32(c, fv, fp);  // c[r] = sum_key P[fr][key] v[key][16 nt + 4g + r]
+    if (fr < nq) {
+      st4(cx + fr * ldc + nt * 16 + qr, c[0], c[1], c[2], c[3]);
+      if (gctx != nullptr) st4(gctx + (q_first + fr) * TD + nt * 16 + qr, c[0], c[1], c[2], c[3]);
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------------------ encoder
 struct InfEnc {
   const void *w1, *w2, *w3, *wup;          // packed conv weights (T): [32][256] [64][512] [64][576] [64][64]
@@ -440,14 +516,17 @@ template <typename T, int SPW> struct InfLayLds {
   static constexpr int PAD = InfLd<T>::PAD;
   static constexpr int ROWS = InfRows<SPW>::ROWS;
   static constexpr int LDX = 64 + 4, LDQ = 192 + 4, LDF = 256 + PAD, LDP = 128 + 4;
+  static constexpr int LDT = 64 + PAD;                   // q / k / ctx rows in the compute type
+  static constexpr int QROWS = ROWS + 16;                // a sample's 32-row key window may run past the last token row
   static constexpr size_t xs_b = (size_t)ROWS * LDX * 4;
-  static constexpr size_t qkv_b = (size_t)ROWS * LDQ * 4;
   static constexpr size_t f_b = (size_t)ROWS * LDF * sizeof(T);
   static constexpr size_t head_b = (size_t)16 * LDP * 4 + (size_t)2 * 16 * LDF * sizeof(T) + 16 * 16 * 4;
-  static constexpr size_t big0_b = qkv_b > f_b ? qkv_b : f_b;
-  static constexpr size_t big_b = big0_b > head_b ? big0_b : head_b;
-  static constexpr size_t p_b = (size_t)SPW * NTOK * ATT_PLD * 4;
-  static constexpr size_t bytes = xs_b + big_b + xs_b + p_b;  // xs | qkv/z/f/head | ctx/z2 | scores
+  // attention operands (attn_tile): q | k rows, transposed values per sample, one P scratch tile per wave
+  static constexpr size_t att_b = ((size_t)2 * QROWS * LDT + (size_t)SPW * 64 * ATT_LDV + (size_t)4 * 16 * ATT_LDV) * sizeof(T);
+  static constexpr size_t big0_b = att_b > f_b ? att_b : f_b;
+  static constexpr size_t big_b = (big0_b > head_b ? big0_b : head_b) / 16 * 16 + 16;
+  static constexpr size_t p_b = (size_t)ROWS * LDT * sizeof(T);  // attention context rows (T)
+  static constexpr size_t bytes = xs_b + big_b + xs_b + p_b;  // xs | attention operands / z / f / head | z2 | ctx
 };
 
 __device__ __forceinline__ float dot64(const float* a, const float* b) {  // 16-byte aligned LDS rows of 64 floats
@@ -534,7 +613,12 @@ __global__ __launch_bounds__(256) void infer_layer_kernel(InfLayerPair pr, InfHe
   float* xs = reinterpret_cast<float*>(smem);
   float* big = reinterpret_cast<float*>(smem + LY::xs_b);            // qkv, later z (fp32), later f (T), later heads
   float* cx = reinterpret_cast<float*>(smem + LY::xs_b + LY::big_b); // ctx, later z2
-  float* sp = reinterpret_cast<float*>(smem + LY::xs_b + LY::big_b + LY::xs_b);
+  T* cb = reinterpret_cast<T*>(smem + LY::xs_b + LY::big_b + LY::xs_b);  // attention context rows (T): out_proj's operand
+  constexpr int LDT = LY::LDT;
+  T* qb = reinterpret_cast<T*>(big);                                   // q rows | k rows | v^T per sample | P scratch:
+  T* kb = qb + LY::QROWS * LDT;                                        // dead once the attention is done, `big` then takes z
+  T* vt = kb + LY::QROWS * LDT;
+  T* pbuf = vt + SPW * 64 * ATT_LDV;
   const int s0 = blockIdx.x * SPW;
   const int ns = min(SPW, E - s0);
   const int nrows = ns * NTOK;
@@ -554,6 +638,11 @@ __global__ __launch_bounds__(256) void infer_layer_kernel(InfLayerPair pr, InfHe
     const float4 v = *reinterpret_cast<const float4*>(xg + (ok ? r : 0) * TD + c4);
     *reinterpret_cast<float4*>(xs + r * LY::LDX + c4) = ok ? v : float4{0.f, 0.f, 0.f, 0.f};
     if (w.s_xin != nullptr && ok) st4(reinterpret_cast<T*>(w.s_xin) + (row0 + r) * TD + c4, v.x, v.y, v.z, v.w);
+    st4(cb + r * LDT + c4, 0.f, 0.f, 0.f, 0.f);  // rows the attention does not write (padding / absent samples)
+  }
+  for (int i = tid; i < SPW * 64 * (32 - NTOK); i += 256) {  // key columns 17..31 of v^T: zeros (P there is 0, 0 x NaN is not)
+    const int rr = i / (32 - NTOK), cc = NTOK + i - rr * (32 - NTOK);
+    vt[rr * ATT_LDV + cc] = (T)0.f;
   }
   __syncthreads();
   INF_STAMP(1);
@@ -564,92 +653,35 @@ __global__ __launch_bounds__(256) void infer_layer_kernel(InfLayerPair pr, InfHe
     block_gemm<T, MT, 3, 2>(acc, xs, LY::LDX, (const T*)w.win, 64, nt, lane, ring_in);
     ring_o = gemm_prefetch<T, 1, 2>((const T*)w.wo, 64, nt1, lane);
 #pragma unroll
-    for (int j = 0; j < 3; ++j) {
+    for (int j = 0; j < 3; ++j) {  // column tile wave + 4j: j = 0 -> q, 1 -> k, 2 -> v
       const int n4 = nt[j] * 16 + qr;
       const float4 bb = *reinterpret_cast<const float4*>(w.bin + n4);
 #pragma unroll
-      for (int mt = 0; mt < MT; ++mt)
-        st4(big + (mt * 16 + fr) * LY::LDQ + n4, acc[mt][j][0] + bb.x, acc[mt][j][1] + bb.y, acc[mt][j][2] + bb.z,
-            acc[mt][j][3] + bb.w);
+      for (int mt = 0; mt < MT; ++mt) {
+        const int row = mt * 16 + fr;
+        const float v0 = acc[mt][j][0] + bb.x, v1 = acc[mt][j][1] + bb.y, v2 = acc[mt][j][2] + bb.z, v3 = acc[mt][j][3] + bb.w;
+        if (w.s_qkv != nullptr && row < nrows) st4(w.s_qkv + (row0 + row) * 192 + n4, v0, v1, v2, v3);  // fp32, for the backward
+        if (j == 0) st4(qb + row * LDT + n4, v0, v1, v2, v3);
+        else if (j == 1) st4(kb + row * LDT + (n4 - TD), v0, v1, v2, v3);
+        else {
+          const int sm = row / NTOK, key = row - sm * NTOK;
+          if (sm < SPW) {  // values transposed per sample for the P V product
+            T* vc = vt + (sm * 64 + (n4 - 2 * TD)) * ATT_LDV + key;
+            vc[0] = (T)v0; vc[ATT_LDV] = (T)v1; vc[2 * ATT_LDV] = (T)v2; vc[3 * ATT_LDV] = (T)v3;
+          }
+        }
+      }
     }
   }
   __syncthreads();
   INF_STAMP(2);
-  if (w.s_qkv != nullptr) {
-    for (int idx = tid; idx < nrows * 48; idx += 256) {  // 48 float4 per row of 192
-      const int r = idx / 48, c4 = (idx - r * 48) * 4;
-      *reinterpret_cast<float4*>(w.s_qkv + (row0 + r) * 192 + c4) = *reinterpret_cast<const float4*>(big + r * LY::LDQ + c4);
-    }
-  }
-  {  // attention (17 tokens, one head, scale 1/8), fp32 VALU, the whole block on all of its samples
-    // scores in 2x2 register tiles (rows 2a,2a+1 x keys 2b,2b+1; 81 tiles per sample, one per thread): every q / k row
-    // fragment read from LDS feeds two dot products
-    for (int idx = tid; idx < ns * 81; idx += 256) {
-      const int sm = idx / 81, t2 = idx - sm * 81;
-      const int a2 = t2 / 9, b2 = t2 - a2 * 9;
-      const int i0 = 2 * a2, i1 = min(i0 + 1, NTOK - 1), j0 = 2 * b2, j1 = min(j0 + 1, NTOK - 1);
-      const float* q = big + (sm * NTOK) * LY::LDQ;
-      const float *qa = q + i0 * LY::LDQ, *qb = q + i1 * LY::LDQ, *ka = q + j0 * LY::LDQ + TD, *kb = q + j1 * LY::LDQ + TD;
-      float s00 = 0.f, s01 = 0.f, s10 = 0.f, s11 = 0.f;
-#pragma unroll 4
-      for (int d = 0; d < TD; d += 4) {
-        const float4 x0 = *reinterpret_cast<const float4*>(qa + d), x1 = *reinterpret_cast<const float4*>(qb + d);
-        const float4 y0 = *reinterpret_cast<const float4*>(ka + d), y1 = *reinterpret_cast<const float4*>(kb + d);
-        s00 = fmaf(x0.x, y0.x, s00); s00 = fmaf(x0.y, y0.y, s00); s00 = fmaf(x0.z, y0.z, s00); s00 = fmaf(x0.w, y0.w, s00);
-        s01 = fmaf(x0.x, y1.x, s01); s01 = fmaf(x0.y, y1.y, s01); s01 = fmaf(x0.z, y1.z, s01); s01 = fmaf(x0.w, y1.w, s01);
-        s10 = fmaf(x1.x, y0.x, s10); s10 = fmaf(x1.y, y0.y, s10); s10 = fmaf(x1.z, y0.z, s10); s10 = fmaf(x1.w, y0.w, s10);
-        s11 = fmaf(x1.x, y1.x, s11); s11 = fmaf(x1.y, y1.y, s11); s11 = fmaf(x1.z, y1.z, s11); s11 = fmaf(x1.w, y1.w, s11);
-      }
-      float* p0 = sp + (sm * NTOK + i0) * ATT_PLD;
-      float* p1 = sp + (sm * NTOK + i1) * ATT_PLD;
-      p0[j0] = s00 * 0.125f;
-      if (j0 + 1 < NTOK) p0[j0 + 1] = s01 * 0.125f;
-      if (i0 + 1 < NTOK) {
-        p1[j0] = s10 * 0.125f;
-        if (j0 + 1 < NTOK) p1[j0 + 1] = s11 * 0.125f;
-      }
-    }
-    __syncthreads();
-    // softmax: a quarter wave per score row (lane l: key l; key 16 is carried by every lane), max / sum by DPP row_ror
-    for (int r = (tid >> 4); r < ROWS; r += 16) {
-      const int l = lane & 15;
-      float* p = sp + min(r, nrows - 1) * ATT_PLD;
-      const float pl = p[l], p16 = p[16];
-      float mx = fmaxf(pl, p16);
-      mx = fmaxf(mx, dpp_mov<0x128>(mx)); mx = fmaxf(mx, dpp_mov<0x124>(mx));
-      mx = fmaxf(mx, dpp_mov<0x122>(mx)); mx = fmaxf(mx, dpp_mov<0x121>(mx));
-      const float el = expf(pl - mx), e16 = expf(p16 - mx);
-      float sum = el;
-      sum += dpp_mov<0x128>(sum); sum += dpp_mov<0x124>(sum); sum += dpp_mov<0x122>(sum); sum += dpp_mov<0x121>(sum);
-      const float inv = 1.f / (sum + e16);
-      if (r < nrows) {
-        p[l] = el * inv;
-        if (l == 0) p[16] = e16 * inv;
-        if (w.s_P != nullptr) {
-          w.s_P[(row0 + r) * NTOK + l] = el * inv;
-          if (l == 0) w.s_P[(row0 + r) * NTOK + 16] = e16 * inv;
-        }
-      }
-    }
-    __syncthreads();
-    // ctx = P V: thread = (row, 4 columns); the row's 17 probabilities are shared by its 16 lanes, V rows read as float4
-    for (int idx = tid; idx < ROWS * 16; idx += 256) {
-      const int r = idx >> 4, c4 = (idx & 15) * 4;
-      float4 a = {0.f, 0.f, 0.f, 0.f};
-      if (r < nrows) {
-        const int sm = r / NTOK;
-        const float* v = big + (sm * NTOK) * LY::LDQ + 2 * TD + c4;
-        const float* p = sp + r * ATT_PLD;
-#pragma unroll
-        for (int j = 0; j < NTOK; ++j) {
-          const float pj = p[j];
-          const float4 vv = *reinterpret_cast<const float4*>(v + j * LY::LDQ);
-          a.x = fmaf(pj, vv.x, a.x); a.y = fmaf(pj, vv.y, a.y); a.z = fmaf(pj, vv.z, a.z); a.w = fmaf(pj, vv.w, a.w);
-        }
-        if (w.s_ctx != nullptr) st4(reinterpret_cast<T*>(w.s_ctx) + (row0 + r) * TD + c4, a.x, a.y, a.z, a.w);
-      }
-      *reinterpret_cast<float4*>(cx + r * LY::LDX + c4) = a;
-    }
+  // attention on the matrix cores: one (sample, query tile) job per wave pass — tokens 0..15 | token 16 of each sample
+  for (int j = wave; j < 2 * ns; j += 4) {
+    const int sm = j >> 1, mt = j & 1;
+    attn_tile<T>(qb + (sm * NTOK + mt * 16) * LDT, kb + sm * NTOK * LDT, LDT, vt + sm * 64 * ATT_LDV, pbuf + wave * 16 * ATT_LDV,
+                 cb + (sm * NTOK + mt * 16) * LDT, LDT, lane, mt * 16, mt == 0 ? 16 : 1,
+                 w.s_P != nullptr ? w.s_P + (int64_t)(s0 + sm) * NTOK * NTOK : nullptr,
+                 w.s_ctx != nullptr ? reinterpret_cast<T*>(w.s_ctx) + (row0 + sm * NTOK) * TD : nullptr);
   }
   __syncthreads();
   INF_STAMP(3);
@@ -657,7 +689,7 @@ __global__ __launch_bounds__(256) void infer_layer_kernel(InfLayerPair pr, InfHe
   {  // out_proj + residual -> z (in `big`, fp32 [ROWS][LDX])
     f32x4 acc[MT][1];
     zero_acc(acc);
-    block_gemm<T, MT, 1, 2>(acc, cx, LY::LDX, (const T*)w.wo, 64, nt1, lane, ring_o);
+    block_gemm<T, MT, 1, 2>(acc, cb, LDT, (const T*)w.wo, 64, nt1, lane, ring_o);
     ring_1 = gemm_prefetch<T, 4, 2>((const T*)w.w1, 64, nt4, lane);  // in front of norm1 and its saves
     const int n4 = wave * 16 + qr;
     const float4 bb = *reinterpret_cast<const float4*>(w.bo + n4);
@@ -822,268 +854,14 @@ __global__ __launch_bounds__(256) void infer_layer_kernel(InfLayerPair pr, InfHe
 }
 
 
-// ------------------------------------------------------------------------------------------ rollout layer (8 / 16 waves)
-// The same TransformerEncoderLayer (+ heads + sampling epilogue when HEAD) for ONE sample per block, spread over 16
-// waves: a rollout step runs only 2E blocks, one per CU, so its time is the latency of one block — every phase is cut
-// into as many independent jobs as it has (12 + 8 + 16 + 8 MFMA tiles, 17 score rows, 32 norm rows) instead of four.
-// Same arithmetic, operand rounding and k order as infer_layer_kernel<T, 1, HEAD>.
+// ------------------------------------------------------------------------------------------ rollout layer stack
 constexpr int ROLLOUT_MAX_LAYERS = 4;
-template <typename T> struct RollStackLds { static constexpr size_t bytes = InfLayLds<T, 1>::bytes + (size_t)(2 * 832 + 528) * 4 + (size_t)2 * 32 * (64 + InfLd<T>::PAD) * sizeof(T); };
 struct InfLayerStack { InfLayerPair l[ROLLOUT_MAX_LAYERS]; int nl; };  // all layers of both nets: ONE launch per env step
-template <typename T, bool HEAD, int NW>
-__global__ __launch_bounds__(NW * 64) void rollout_layer_kernel(InfLayerStack stk, InfHeadPair hd, InfFinish fin, int E) {
-  static_assert(NW == 8 || NW == 16, "rollout_layer_kernel: 8 or 16 waves");
-  constexpr int NTH = NW * 64;
-  typedef InfLayLds<T, 1> LY;
-  constexpr int ROWS = 32;
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int fr = lane & 15, qr = (lane >> 4) * 4;
-  float* xs = reinterpret_cast<float*>(smem);
-  float* big = reinterpret_cast<float*>(smem + LY::xs_b);            // qkv, later z (fp32), later f (T), later heads
-  float* cx = reinterpret_cast<float*>(smem + LY::xs_b + LY::big_b); // ctx, later z2
-  float* sp = reinterpret_cast<float*>(smem + LY::xs_b + LY::big_b + LY::xs_b);
-  const int s0 = blockIdx.x;
-  const int64_t row0 = (int64_t)s0 * NTOK;
-  long long t_step = 0;
-  if constexpr (HEAD) { if (fin.ctl != nullptr) t_step = fin.ctl->t; }
-  ROLL_STAMP(64);
-  for (int i4 = tid; i4 < ROWS * (TD / 4); i4 += NTH) {
-    const int r = i4 >> 4, c4 = (i4 & 15) * 4;
-    const bool ok = r < NTOK;
-    const float4 v = *reinterpret_cast<const float4*>(stk.l[0].n[blockIdx.y].xin + (row0 + (ok ? r : 0)) * TD + c4);
-    *reinterpret_cast<float4*>(xs + r * LY::LDX + c4) = ok ? v : float4{0.f, 0.f, 0.f, 0.f};
-  }
-  __syncthreads();
-  T* f = reinterpret_cast<T*>(big);
-  auto ln2rows = [&](const float* z, float* out, const float* __restrict__ g, const float* __restrict__ be, float* gout) {
-    // a quarter wave per row (16 lanes x 4 columns), reductions by DPP row_ror: the 32 rows are one step of 8 waves
-    const int l16 = lane & 15, c4 = l16 * 4;
-    const float4 gg = *reinterpret_cast<const float4*>(g + c4), bb = *reinterpret_cast<const float4*>(be + c4);
-    for (int r = wave * 4 + (lane >> 4); r < ROWS; r += NW * 4) {
-      float4 v = *reinterpret_cast<const float4*>(z + r * LY::LDX + c4);
-      float s = (v.x + v.y) + (v.z + v.w);
-      s += dpp_mov<0x128>(s); s += dpp_mov<0x124>(s); s += dpp_mov<0x122>(s); s += dpp_mov<0x121>(s);
-      const float mean = s * (1.f / TD);
-      v.x -= mean; v.y -= mean; v.z -= mean; v.w -= mean;
-      float q2 = (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
-      q2 += dpp_mov<0x128>(q2); q2 += dpp_mov<0x124>(q2); q2 += dpp_mov<0x122>(q2); q2 += dpp_mov<0x121>(q2);
-      const float rs = 1.f / sqrtf(q2 * (1.f / TD) + 1e-5f);
-      const float4 o = {fmaf(v.x * rs, gg.x, bb.x), fmaf(v.y * rs, gg.y, bb.y), fmaf(v.z * rs, gg.z, bb.z),
-                        fmaf(v.w * rs, gg.w, bb.w)};
-      if (out != nullptr) *reinterpret_cast<float4*>(out + r * LY::LDX + c4) = o;
-      if (gout != nullptr && r < NTOK) *reinterpret_cast<float4*>(gout + (row0 + r) * TD + c4) = o;
-    }
-  };
-#pragma unroll 1
-  for (int l = 0; l < stk.nl; ++l) {  // the token rows stay in `xs` from one layer to the next
-  const InfLayer& w = stk.l[l].n[blockIdx.y];
-  if (l > 0) __syncthreads();
-  if (l == 0) ROLL_STAMP(65);
-  for (int t = wave; t < 12; t += NW) {  // in_proj: 12 column tiles over the waves
-    const int nt[1] = {t};
-    f32x4 acc[2][1];
-    zero_acc(acc);
-    block_gemm<T, 2, 1, 2>(acc, xs, LY::LDX, (const T*)w.win, 64, nt, lane);
-    const int n4 = t * 16 + qr;
-    const float4 bb = *reinterpret_cast<const float4*>(w.bin + n4);
-#pragma unroll
-    for (int mt = 0; mt < 2; ++mt)
-      st4(big + (mt * 16 + fr) * LY::LDQ + n4, acc[mt][0][0] + bb.x, acc[mt][0][1] + bb.y, acc[mt][0][2] + bb.z,
-          acc[mt][0][3] + bb.w);
-  }
-  __syncthreads();
-  if (l == 0) ROLL_STAMP(66);
-  if (tid < NTOK * NTOK) {  // scores, one (i, j) per thread (NTH >= 289)
-    const int i = tid / NTOK, j = tid - i * NTOK;
-    sp[i * ATT_PLD + j] = dot64(big + i * LY::LDQ, big + j * LY::LDQ + TD) * 0.125f;
-  }
-  __syncthreads();
-  if (l == 0) ROLL_STAMP(67);
-  {  // softmax: a quarter wave per score row (lane l: key l; key 16 is carried by every lane), max / sum by DPP
-    const int r = tid >> 4, l = lane & 15;
-    if (r < 32) {  // quarters 0..31 (whole waves): rows >= 17 shadow row 16 and write nothing
-      float* p = sp + min(r, NTOK - 1) * ATT_PLD;
-      const float pl = p[l], p16 = p[16];
-      float mx = fmaxf(pl, p16);
-      mx = fmaxf(mx, dpp_mov<0x128>(mx)); mx = fmaxf(mx, dpp_mov<0x124>(mx));
-      mx = fmaxf(mx, dpp_mov<0x122>(mx)); mx = fmaxf(mx, dpp_mov<0x121>(mx));
-      const float el = expf(pl - mx), e16 = expf(p16 - mx);
-      float sum = el;
-      sum += dpp_mov<0x128>(sum); sum += dpp_mov<0x124>(sum); sum += dpp_mov<0x122>(sum); sum += dpp_mov<0x121>(sum);
-      const float inv = 1.f / (sum + e16);
-      if (r < NTOK) {
-        p[l] = el * inv;
-        if (l == 0) p[16] = e16 * inv;
-      }
-    }
-  }
-  __syncthreads();
-  if (l == 0) ROLL_STAMP(68);
-  for (int idx = tid; idx < ROWS * 16; idx += NTH) {  // ctx = P V: thread = (row, 4 columns); rows >= 17: zeros
-    const int r = idx >> 4, c4 = (idx & 15) * 4;
-    float4 a = {0.f, 0.f, 0.f, 0.f};
-    if (r < NTOK) {
-      const float* v = big + 2 * TD + c4;
-      const float* p = sp + r * ATT_PLD;
-#pragma unroll
-      for (int j = 0; j < NTOK; ++j) {
-        const float pj = p[j];
-        const float4 vv = *reinterpret_cast<const float4*>(v + j * LY::LDQ);
-        a.x = fmaf(pj, vv.x, a.x); a.y = fmaf(pj, vv.y, a.y); a.z = fmaf(pj, vv.z, a.z); a.w = fmaf(pj, vv.w, a.w);
-      }
-    }
-    *reinterpret_cast<float4*>(cx + r * LY::LDX + c4) = a;
-  }
-  __syncthreads();
-  if (l == 0) ROLL_STAMP(69);
-  if (wave < 8) {  // out_proj + residual -> z (in `big`, fp32 [32][LDX]): (row tile, column tile) = (wave >> 2, wave & 3)
-    const int nt[1] = {wave & 3}, mt = wave >> 2;
-    f32x4 acc[1][1];
-    zero_acc(acc);
-    block_gemm<T, 1, 1, 2>(acc, cx + mt * 16 * LY::LDX, LY::LDX, (const T*)w.wo, 64, nt, lane);
-    const int n4 = nt[0] * 16 + qr, row = mt * 16 + fr;
-    const float4 bb = *reinterpret_cast<const float4*>(w.bo + n4);
-    const float4 xr = *reinterpret_cast<const float4*>(xs + row * LY::LDX + n4);
-    st4(big + row * LY::LDX + n4, xr.x + acc[0][0][0] + bb.x, xr.y + acc[0][0][1] + bb.y, xr.z + acc[0][0][2] + bb.z,
-        xr.w + acc[0][0][3] + bb.w);
-  }
-  __syncthreads();
-  if (l == 0) ROLL_STAMP(70);
-  ln2rows(big, xs, w.g1, w.be1, nullptr);  // x1 -> xs
-  __syncthreads();
-  if (l == 0) ROLL_STAMP(71);
-  for (int t = wave; t < 16; t += NW) {  // linear1 + ReLU -> f (T): 16 column tiles over the waves
-    const int nt[1] = {t};
-    f32x4 acc[2][1];
-    zero_acc(acc);
-    block_gemm<T, 2, 1, 2>(acc, xs, LY::LDX, (const T*)w.w1, 64, nt, lane);
-    const int n4 = t * 16 + qr;
-    const float4 bb = *reinterpret_cast<const float4*>(w.b1 + n4);
-#pragma unroll
-    for (int mt = 0; mt < 2; ++mt)
-      st4(f + (mt * 16 + fr) * LY::LDF + n4, fmaxf(acc[mt][0][0] + bb.x, 0.f), fmaxf(acc[mt][0][1] + bb.y, 0.f),
-          fmaxf(acc[mt][0][2] + bb.z, 0.f), fmaxf(acc[mt][0][3] + bb.w, 0.f));
-  }
-  __syncthreads();
-  if (l == 0) ROLL_STAMP(72);
-  if (wave < 8) {  // linear2 + residual -> z2 (in `cx`)
-    const int nt[1] = {wave & 3}, mt = wave >> 2;
-    f32x4 acc[1][1];
-    zero_acc(acc);
-    block_gemm<T, 1, 1, 8>(acc, f + mt * 16 * LY::LDF, LY::LDF, (const T*)w.w2, 256, nt, lane);
-    const int n4 = nt[0] * 16 + qr, row = mt * 16 + fr;
-    const float4 bb = *reinterpret_cast<const float4*>(w.b2 + n4);
-    const float4 xr = *reinterpret_cast<const float4*>(xs + row * LY::LDX + n4);
-    st4(cx + row * LY::LDX + n4, xr.x + acc[0][0][0] + bb.x, xr.y + acc[0][0][1] + bb.y, xr.z + acc[0][0][2] + bb.z,
-        xr.w + acc[0][0][3] + bb.w);
-  }
-  __syncthreads();
-  if (l == 0) ROLL_STAMP(73);
-  ln2rows(cx, xs, w.g2, w.be2, w.xout);  // -> xs (next layer / heads) and the net's token tensor
-  if (l == 0) ROLL_STAMP(74);
-  }
-  if constexpr (HEAD) {
-    const InfHead& h = hd.n[blockIdx.y];
-    float* pooled = big;                                              // [16][LDP] fp32, row 0 = this sample
-    T* h1 = reinterpret_cast<T*>(big + 16 * LY::LDP);                 // [16][LDF]
-    T* h2 = h1 + 16 * LY::LDF;
-    float* so = reinterpret_cast<float*>(h2 + 16 * LY::LDF);          // [16][16]
-    __syncthreads();
-    ROLL_STAMP(80);
-    for (int idx = tid; idx < 16 * 128; idx += NTH) {
-      const int r = idx >> 7, c = idx & 127;
-      float v = 0.f;
-      if (r == 0) {
-        if (c < TD) v = xs[c];
-        else {
-          float s = 0.f;
-#pragma unroll
-          for (int i = 1; i < NTOK; ++i) s += xs[i * LY::LDX + (c - TD)];
-          v = s * (1.f / 16.f);
-        }
-      }
-      pooled[r * LY::LDP + c] = v;
-    }
-    __syncthreads();
-    ROLL_STAMP(81);
-    f32x4 acc[1][1];
-    auto store_h = [&](T* dst, const float* bias, int t) {
-      const int n4 = t * 16 + qr;
-      const float4 bb = *reinterpret_cast<const float4*>(bias + n4);
-      st4(dst + fr * LY::LDF + n4, fmaxf(acc[0][0][0] + bb.x, 0.f), fmaxf(acc[0][0][1] + bb.y, 0.f),
-          fmaxf(acc[0][0][2] + bb.z, 0.f), fmaxf(acc[0][0][3] + bb.w, 0.f));
-    };
-    for (int t = wave; t < 16; t += NW) {
-      const int nt[1] = {t};
-      zero_acc(acc);
-      block_gemm<T, 1, 1, 4>(acc, pooled, LY::LDP, (const T*)h.w0, 128, nt, lane);
-      store_h(h1, h.b0, t);
-    }
-    __syncthreads();
-    ROLL_STAMP(82);
-    for (int t = wave; t < 16; t += NW) {
-      const int nt[1] = {t};
-      zero_acc(acc);
-      block_gemm<T, 1, 1, 8>(acc, h1, LY::LDF, (const T*)h.w1, 256, nt, lane);
-      store_h(h2, h.b1, t);
-    }
-    __syncthreads();
-    ROLL_STAMP(83);
-    if (wave == 0) {
-      const int nt0[1] = {0};
-      zero_acc(acc);
-      block_gemm<T, 1, 1, 8>(acc, h2, LY::LDF, (const T*)h.w2, 256, nt0, lane);
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int c = qr + r;
-        const float v = c < h.nout ? acc[0][0][r] + h.b2[c] : 0.f;
-        so[fr * 16 + c] = v;
-        if (fr == 0) h.out[(int64_t)s0 * OUT_LD + c] = v;
-      }
-    }
-    if (fin.ctl != nullptr) {  // rollout step epilogue: see infer_layer_kernel
-      __syncthreads();
-      ROLL_STAMP(84);
-      if (tid == 0) {
-        const int i = s0, A = fin.A;
-        if (blockIdx.y == 0) {
-          float e = 0.f, lp = 0.f;
-          for (int a = 0; a < A; ++a) {
-            const float mu = so[a];
-            const float ls = fminf(fmaxf(fin.logstd[a], LOG_SIG_MIN), LOG_SIG_MAX);
-            const float sg = expf(ls);
-            e += 0.5f + HALF_LOG_2PI + logf(sg);
-            const float act = fmaf(sg, fin.eps[(int64_t)i * A + a], mu);
-            fin.action[(int64_t)i * A + a] = act;
-            fin.mean[(int64_t)i * A + a] = mu;
-            fin.stdv[(int64_t)i * A + a] = sg;
-            if (fin.acts_roll != nullptr) fin.acts_roll[(t_step * E + i) * A + a] = act;
-            const float d = act - mu;
-            lp += -(d * d) / (2.f * sg * sg) - logf(sg) - HALF_LOG_2PI;
-          }
-          fin.ent[i] = e;
-          if (fin.logp_roll != nullptr) fin.logp_roll[t_step * E + i] = lp;
-        } else {
-          const float v = so[0];
-          fin.value[i] = v;
-          if (fin.values_roll != nullptr) fin.values_roll[t_step * E + i] = v;
-        }
-        __threadfence();
-        const unsigned long long done = atomicAdd(reinterpret_cast<unsigned long long*>(&fin.ctl->done), 1ull);
-        if (done == (unsigned long long)(gridDim.x * gridDim.y) - 1) {
-          fin.ctl->done = 0;
-          fin.ctl->t = t_step + 1;
-        }
-        ROLL_STAMP(85);
-      }
-    }
-  }
-}
-
+template <typename T> struct RollStackLds { static constexpr size_t bytes = InfLayLds<T, 1>::bytes + (size_t)(2 * 832 + 528) * 4 + ((size_t)4 * 32 * (64 + InfLd<T>::PAD) + (size_t)(64 + 32) * (32 + 8)) * sizeof(T); };
 
 // ------------------------------------------------------------------------------------------ rollout layer stack, weights ahead
-// rollout_layer_kernel<T, true, 8> with its weight traffic re-timed. What the phase stamps of that kernel showed
+// One nn.TransformerEncoderLayer stack (+ heads + sampling epilogue) for ONE sample per block, 8 waves: a rollout step runs
+// only 2E blocks, one per CU, so its time is the latency of one block. What the phase stamps of its first version showed
 // (tools/probe/stamps_rollout.py, E = 32: 67.6 K cycles per block): every kernel starts with a cold L2 — on a multi-XCD part
 // the L2s are written back and invalidated at kernel boundaries — so the FIRST touch of each weight tile is an
 // Infinity-Cache round trip of ~1.5 K cycles, and the kernel paid one per barrier-separated GEMM phase (in_proj 3.6 K,
@@ -1092,7 +870,7 @@ __global__ __launch_bounds__(NW * 64) void rollout_layer_kernel(InfLayerStack st
 // are requested one layer ahead into registers (bf16: 34 fragments = 136 VGPRs of the 256 a 512-thread block may use):
 // layer 0's and the head's widest linear at kernel entry, layer l+1's as soon as layer l's MFMAs have consumed the
 // register, the other head linears during the last layer. The fp32 parity mode (8 VGPRs per fragment) loads at use.
-// Arithmetic, operand rounding and k order are those of rollout_layer_kernel / infer_layer_kernel<T, 1, HEAD>.
+// Arithmetic, operand rounding and k order are those of infer_layer_kernel.
 template <typename T, int MT, int KS, typename AT>
 __device__ __forceinline__ void mm_held(f32x4 (&acc)[MT], const AT* sA, int lda, const typename Frag<T>::type (&fb)[KS], int lane) {
   typedef typename Frag<T>::type frag_t;
@@ -1120,7 +898,6 @@ __global__ __launch_bounds__(512) void rollout_stack_kernel(InfLayerStack stk, I
   float* xs = reinterpret_cast<float*>(smem);
   float* big = reinterpret_cast<float*>(smem + LY::xs_b);            // qkv, later z (fp32), later f (T), later heads
   float* cx = reinterpret_cast<float*>(smem + LY::xs_b + LY::big_b); // ctx, later z2
-  float* sp = reinterpret_cast<float*>(smem + LY::xs_b + LY::big_b + LY::xs_b);
   // biases / LayerNorm parameters of every layer and of the head, staged once: a global load in the middle of a phase would
   // have to wait for every weight fragment requested before it (loads return in order)
   float* prm = reinterpret_cast<float*>(smem + LY::bytes);
@@ -1136,6 +913,11 @@ __global__ __launch_bounds__(512) void rollout_stack_kernel(InfLayerStack stk, I
   constexpr int LDT = 64 + LY::PAD;
   T* xb = reinterpret_cast<T*>(prm_h + P_HEAD);   // [32][LDT] layer input, then x1
   T* cb = xb + ROWS * LDT;                          // [32][LDT] attention context
+  // attention operands (attn_tile): q / k rows and the transposed values in T, written by in_proj's epilogue
+  T* qb = cb + ROWS * LDT;                          // [32][LDT]
+  T* kb = qb + ROWS * LDT;                          // [32][LDT]
+  T* vt = kb + ROWS * LDT;                          // [64][ATT_LDV], key columns >= 17 zero
+  T* pbuf = vt + 64 * ATT_LDV;                      // [2][16][ATT_LDV] P of the two query tiles
   const int64_t row0 = (int64_t)s0 * NTOK;
   const InfHead& h = hd.n[net];
   ROLL_STAMP(64);
@@ -1259,6 +1041,7 @@ __global__ __launch_bounds__(512) void rollout_stack_kernel(InfLayerStack stk, I
       const float4 x0v = r < NTOK ? xv : float4{0.f, 0.f, 0.f, 0.f};
       *reinterpret_cast<float4*>(xs + r * LY::LDX + c4) = x0v;
       st4(xb + r * LDT + c4, x0v.x, x0v.y, x0v.z, x0v.w);
+      if (r >= NTOK) st4(cb + r * LDT + c4, 0.f, 0.f, 0.f, 0.f);  // the attention only writes the 17 real context rows
     }
     if (tid < P_LAYER / 4) *reinterpret_cast<float4*>(prm + tid * 4) = pv;
     if (tid < 128) *reinterpret_cast<float4*>(prm_h + tid * 4) = hv;
@@ -1305,8 +1088,18 @@ __global__ __launch_bounds__(512) void rollout_stack_kernel(InfLayerStack stk, I
           const int n4 = t * 16 + qr;
           const float4 bb = *reinterpret_cast<const float4*>(pl + P_BIN + n4);
 #pragma unroll
-          for (int mt = 0; mt < 2; ++mt)
-            st4(big + (mt * 16 + fr) * LY::LDQ + n4, acc[mt][0] + bb.x, acc[mt][1] + bb.y, acc[mt][2] + bb.z, acc[mt][3] + bb.w);
+          for (int mt = 0; mt < 2; ++mt) {
+            const int row = mt * 16 + fr;
+            const float v0 = acc[mt][0] + bb.x, v1 = acc[mt][1] + bb.y, v2 = acc[mt][2] + bb.z, v3 = acc[mt][3] + bb.w;
+            if (t < 4) st4(qb + row * LDT + n4, v0, v1, v2, v3);
+            else if (t < 8) st4(kb + row * LDT + (n4 - TD), v0, v1, v2, v3);
+            else {  // values, transposed for the P V product; keys past the 17 tokens are zeros
+              T* vc = vt + (n4 - 2 * TD) * ATT_LDV + row;
+              const bool ok = row < NTOK;
+              vc[0] = (T)(ok ? v0 : 0.f); vc[ATT_LDV] = (T)(ok ? v1 : 0.f);
+              vc[2 * ATT_LDV] = (T)(ok ? v2 : 0.f); vc[3 * ATT_LDV] = (T)(ok ? v3 : 0.f);
+            }
+          }
         }
       }
       if constexpr (PRE) { if (more) load_in(wn); else load_h0a(); }
@@ -1314,45 +1107,10 @@ __global__ __launch_bounds__(512) void rollout_stack_kernel(InfLayerStack stk, I
     __syncthreads();
     if (l == 0) ROLL_STAMP(66);
     if constexpr (PRE) { if (l == 0 && wave < 4) load_f2(w); if (!more) load_h1(0); }
-    if (tid < NTOK * NTOK) {  // scores, one (i, j) per thread
-      const int i = tid / NTOK, j = tid - i * NTOK;
-      sp[i * ATT_PLD + j] = dot64(big + i * LY::LDQ, big + j * LY::LDQ + TD) * 0.125f;
-    }
-    __syncthreads();
-    if (l == 0) ROLL_STAMP(67);
-    {  // softmax: a quarter wave per score row (lane q: key q; key 16 is carried by every lane), max / sum by DPP
-      const int r = tid >> 4, q = lane & 15;
-      float* p = sp + min(r, NTOK - 1) * ATT_PLD;
-      const float pl = p[q], p16 = p[16];
-      float mx = fmaxf(pl, p16);
-      mx = fmaxf(mx, dpp_mov<0x128>(mx)); mx = fmaxf(mx, dpp_mov<0x124>(mx));
-      mx = fmaxf(mx, dpp_mov<0x122>(mx)); mx = fmaxf(mx, dpp_mov<0x121>(mx));
-      const float el = expf(pl - mx), e16 = expf(p16 - mx);
-      float sum = el;
-      sum += dpp_mov<0x128>(sum); sum += dpp_mov<0x124>(sum); sum += dpp_mov<0x122>(sum); sum += dpp_mov<0x121>(sum);
-      const float inv = 1.f / (sum + e16);
-      if (r < NTOK) {
-        p[q] = el * inv;
-        if (q == 0) p[16] = e16 * inv;
-      }
-    }
-    __syncthreads();
-    if (l == 0) ROLL_STAMP(68);
-    {  // ctx = P V: thread = (row, 4 columns); rows >= 17: zeros
-      const int r = tid >> 4, c4 = (tid & 15) * 4;
-      float4 a = {0.f, 0.f, 0.f, 0.f};
-      if (r < NTOK) {
-        const float* v = big + 2 * TD + c4;
-        const float* p = sp + r * ATT_PLD;
-#pragma unroll
-        for (int j = 0; j < NTOK; ++j) {
-          const float pj = p[j];
-          const float4 vv = *reinterpret_cast<const float4*>(v + j * LY::LDQ);
-          a.x = fmaf(pj, vv.x, a.x); a.y = fmaf(pj, vv.y, a.y); a.z = fmaf(pj, vv.z, a.z); a.w = fmaf(pj, vv.w, a.w);
-        }
-      }
-      st4(cb + r * LDT + c4, a.x, a.y, a.z, a.w);
-    }
+    if (wave < 2)  // attention on the matrix cores: wave = query tile (tokens 0..15 | token 16)
+      attn_tile<T>(qb + wave * 16 * LDT, kb, LDT, vt, pbuf + wave * 16 * ATT_LDV, cb + wave * 16 * LDT, LDT, lane, wave * 16,
+                   wave == 0 ? 16 : 1, nullptr, nullptr);
+    if (l == 0) { ROLL_STAMP(67); ROLL_STAMP(68); }
     __syncthreads();
     if (l == 0) ROLL_STAMP(69);
     {  // out_proj + residual -> z (in `big`, fp32 [32][LDX]): column tile = wave (waves 0..3), both row tiles: the 8 KB of

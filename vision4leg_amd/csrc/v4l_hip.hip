@@ -1027,11 +1027,14 @@ int v4l_net::forward_t(const float* state, const T* image, const int* rowidx, in
       static int spw = 2;  // samples per block: 2 (48 MFMA rows, 2 blocks/CU: measured 20 % faster) or 4 (80 rows, 1 block/CU)
       if (!attr_done) {
         spw = 2;
-        if (const char* e = getenv("V4L_LAYER_SPW")) spw = atoi(e) == 4 ? 4 : 2;
-        V4L_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&infer_layer_kernel<T, 4, false>),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)InfLayLds<T, 4>::bytes));
-        V4L_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&infer_layer_kernel<T, 4, true>),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)InfLayLds<T, 4>::bytes));
+        constexpr bool spw4_fits = InfLayLds<T, 4>::bytes <= 160 * 1024;  // (not in the fp32 parity mode: 168 KB)
+        if (const char* e = getenv("V4L_LAYER_SPW")) spw = (atoi(e) == 4 && spw4_fits) ? 4 : 2;
+        if (spw4_fits) {
+          V4L_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&infer_layer_kernel<T, 4, false>),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)InfLayLds<T, 4>::bytes));
+          V4L_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&infer_layer_kernel<T, 4, true>),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)InfLayLds<T, 4>::bytes));
+        }
         V4L_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&infer_layer_kernel<T, 2, false>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)InfLayLds<T, 2>::bytes));
         V4L_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&infer_layer_kernel<T, 2, true>),
@@ -1084,9 +1087,9 @@ int v4l_net::forward_t(const float* state, const T* image, const int* rowidx, in
       if ((rc = lin_fwd<T>(cx, t.inproj, dense(xin, TD, R, TD), mk_epi(ws + w.qkv, 3 * TD, 3 * TD)))) return rc;
       g_op = "attn";
       if (ntok == NTOK)
-        V4L_KLAUNCH("attn_fwd", 4.0 * n * NTOK * NTOK * TD, s, attn_fwd_kernel<NTOK>, dim3(n), dim3(256), 0, s, ws + w.qkv, n, ws + w.P, ws + w.ctx);
+        V4L_KLAUNCH("attn_fwd", 4.0 * n * NTOK * NTOK * TD, s, attn_fwd_kernel<NTOK>, dim3(n), dim3(256), 0, s, ws + w.qkv, n, ws + w.P, ws + w.ctx, (int)(sizeof(T) == 2));
       else
-        V4L_KLAUNCH("attn_fwd", 4.0 * n * 16 * 16 * TD, s, attn_fwd_kernel<16>, dim3(n), dim3(256), 0, s, ws + w.qkv, n, ws + w.P, ws + w.ctx);
+        V4L_KLAUNCH("attn_fwd", 4.0 * n * 16 * 16 * TD, s, attn_fwd_kernel<16>, dim3(n), dim3(256), 0, s, ws + w.qkv, n, ws + w.P, ws + w.ctx, (int)(sizeof(T) == 2));
       V4L_LAUNCH_CHECK();
       if ((rc = lin_fwd<T>(cx, t.outproj, dense(ws + w.ctx, TD, R, TD), mk_epi(ws + L.ytmp, TD, TD)))) return rc;
       g_op = "ln1";
@@ -1333,10 +1336,10 @@ int v4l_net::backward_t(const float* state, const T* image, const int* rowidx, i
       g_op = "attn";
       if (ntok == NTOK)
         V4L_KLAUNCH("attn_bwd", 8.0 * n * NTOK * NTOK * TD, s, attn_bwd_kernel<NTOK>, dim3(n), dim3(256), 0, s, ws + w.qkv, ws + w.P,
-                    ws + b.dctx, n, ws + b.dqkv);
+                    ws + b.dctx, n, ws + b.dqkv, (int)(sizeof(T) == 2));
       else
         V4L_KLAUNCH("attn_bwd", 8.0 * n * 16 * 16 * TD, s, attn_bwd_kernel<16>, dim3(n), dim3(256), 0, s, ws + w.qkv, ws + w.P,
-                    ws + b.dctx, n, ws + b.dqkv);
+                    ws + b.dctx, n, ws + b.dqkv, (int)(sizeof(T) == 2));
       V4L_LAUNCH_CHECK();
       ADense yq = dense(ws + b.dqkv, 3 * TD, R, 3 * TD);
       if ((rc = lin_wgrad<T>(cx, t.inproj, yq, dense(ws + L.x[l], TD, R, TD), TD))) return rc;
@@ -1392,7 +1395,8 @@ static bool actor_fusable(const v4l_actor* a) {
            c.n_head_hidden == 2 && c.head_hidden[0] == 256 && c.head_hidden[1] == 256 && c.ff_dim == 256 &&
            c.state_dim <= 128;
   };
-  return ok(p) && ok(v) && p.n_layers == v.n_layers && a->E <= 64 && getenv("V4L_NO_FUSED_ACTOR") == nullptr;
+  return ok(p) && ok(v) && p.n_layers == 2 && v.n_layers == 2 && a->E <= 64 && a->pf->head.size() == 3 &&
+         a->pf->head[0].pkf >= 0 && a->vf->head[0].pkf >= 0 && getenv("V4L_NO_FUSED_ACTOR") == nullptr;
 }
 
 // NatureCNN fuse nets of the shipped shape: one launch per env step (rollout_cnn_kernel)
@@ -1503,18 +1507,8 @@ static int run_actor_fused(v4l_actor* a, const float* obs, const float* eps, flo
   const int E = a->E;
   static bool attr_done = false;
   if (!attr_done) {
-    V4L_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&infer_encoder_kernel<T>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)InfEncLds<T>::bytes));
-    V4L_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&infer_layer_kernel<T, 1, false>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)InfLayLds<T, 1>::bytes));
-    V4L_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&infer_layer_kernel<T, 1, true>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)InfLayLds<T, 1>::bytes));
     V4L_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&rollout_encoder_kernel<T>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)InfEncLds<T>::bytes));
-    V4L_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&rollout_layer_kernel<T, true, 16>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)InfLayLds<T, 1>::bytes));
-    V4L_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&rollout_layer_kernel<T, true, 8>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)InfLayLds<T, 1>::bytes));
     V4L_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&rollout_stack_kernel<T, 2>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)RollStackLds<T>::bytes));
     attr_done = true;
@@ -1533,9 +1527,8 @@ static int run_actor_fused(v4l_actor* a, const float* obs, const float* eps, flo
   en.S = pf->cfg.state_dim; en.Sp = pf->Sp; en.Kp1 = pf->enc[0].Kp;
   float* x0 = ws_pf + Lp.x[0];
   g_op = "encoder";
-  static const bool wide16 = getenv("V4L_ROLLOUT_4WAVE") == nullptr;  // 16-wave blocks (default) or the 4-wave kernels
   static const bool enc2 = getenv("V4L_ROLLOUT_ENC_OLD") == nullptr;
-  if (wide16 && enc2 && sizeof(T) == 2 && pf->enc.size() == 2 && pf->enc[0].Kp == 128 && pf->conv[0].pkf >= 0) {
+  if (enc2 && sizeof(T) == 2 && pf->enc.size() == 2 && pf->enc[0].Kp == 128 && pf->conv[0].pkf >= 0) {
     static bool attr2 = false;
     if (!attr2) {
       V4L_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&rollout_encoder2_kernel),
@@ -1551,17 +1544,12 @@ static int run_actor_fused(v4l_actor* a, const float* obs, const float* eps, flo
     ef.S = en.S; ef.Sp = en.Sp;
     V4L_KLAUNCH("rollout_encoder", 2.0 * E * 3678208.0, s, rollout_encoder2_kernel, dim3(E + cdiv(E, 32)), dim3(1024),
                 RollEnc2Lds::bytes, s, (const ActCtl*)a->ctl, obs, E, ef, state_roll, (__bf16*)image_roll, x0);
-  } else if (wide16)
+  } else  // fp32 parity mode (fragments twice the size): weights streamed per wave
     V4L_KLAUNCH("rollout_encoder", 2.0 * E * 3678208.0, s, rollout_encoder_kernel<T>, dim3(E + cdiv(E, 32)), dim3(1024),
                 InfEncLds<T>::bytes, s, (const ActCtl*)a->ctl, obs, E, en, state_roll, (T*)image_roll, x0);
-  else
-    V4L_KLAUNCH("infer_encoder", 2.0 * E * 3678208.0, s, infer_encoder_kernel<T>, dim3(E + cdiv(E, 32)), dim3(256),
-                InfEncLds<T>::bytes, s, (const ActCtl*)a->ctl, obs, E, en, state_roll, (T*)image_roll, x0, InfEncTrain{});
   V4L_LAUNCH_CHECK();
-  static const int nw = getenv("V4L_ROLLOUT_WAVES") ? atoi(getenv("V4L_ROLLOUT_WAVES")) : 8;
-  static const bool ahead = getenv("V4L_ROLLOUT_NO_PREFETCH") == nullptr;  // weights ahead of use (rollout_stack_kernel)
   const int nl = pf->cfg.n_layers;
-  const bool stack = wide16 && nl == 2 && ahead && nw != 16 && pf->head.size() == 3 && pf->head[0].pkf >= 0;
+  const bool stack = true;  // actor_fusable(): two layers, fragment-order packs present
   auto fill = [&](InfLayer& d, v4l_net* net, const T* base, const TLayer& t, const float* xin, float* xout) {
     d.win = base + t.inproj.pk; d.wo = base + t.outproj.pk; d.w1 = base + t.ff1.pk; d.w2 = base + t.ff2.pk;
     if (stack) { d.win = base + t.inproj.pkf; d.wo = base + t.outproj.pkf; d.w1 = base + t.ff1.pkf; d.w2 = base + t.ff2.pkf; }
@@ -1589,8 +1577,8 @@ static int run_actor_fused(v4l_actor* a, const float* obs, const float* eps, flo
     fin.mean = mean; fin.stdv = stdv; fin.ent = ent; fin.value = value;
   };
   g_op = "layer";
-  if (wide16 && nl <= ROLLOUT_MAX_LAYERS) {
-    // one sample per block and net (2E blocks of 16 waves): ALL layers, the heads, the sampling of the action, the filing
+  {
+    // one sample per block and net (2E blocks of 8 waves): ALL layers, the heads, the sampling of the action, the filing
     // of action / value / log-prob at rollout slot t*E + i and the advance of the step cursor in one launch
     InfLayerStack stk;
     memset(&stk, 0, sizeof(stk));
@@ -1600,33 +1588,9 @@ static int run_actor_fused(v4l_actor* a, const float* obs, const float* eps, flo
       fill(stk.l[l].n[1], vf, vk, vf->layers[l], l == 0 ? x0 : ws_vf + Lv.x[l], ws_vf + Lv.x[l + 1]);
     }
     finish();
-    static const int nw = getenv("V4L_ROLLOUT_WAVES") ? atoi(getenv("V4L_ROLLOUT_WAVES")) : 8;
-    static const bool ahead = getenv("V4L_ROLLOUT_NO_PREFETCH") == nullptr;
-    static const int warm = getenv("V4L_ROLLOUT_WARM") ? atoi(getenv("V4L_ROLLOUT_WARM")) : 1;  // L2 warm-up touches  // weights one layer ahead (rollout_stack_kernel)
-    if (ahead && nw != 16)
-      V4L_KLAUNCH("rollout_layers_head", 2.0 * 2 * E * (nl * 872576.0 + 99840.0), s, (rollout_stack_kernel<T, 2>), dim3(E, 2),
-                  dim3(512), (RollStackLds<T>::bytes), s, stk, hd, fin, E, warm);
-    else if (nw == 16)
-      V4L_KLAUNCH("rollout_layers_head", 2.0 * 2 * E * (nl * 872576.0 + 99840.0), s, (rollout_layer_kernel<T, true, 16>), dim3(E, 2),
-                  dim3(1024), (InfLayLds<T, 1>::bytes), s, stk, hd, fin, E);
-    else
-      V4L_KLAUNCH("rollout_layers_head", 2.0 * 2 * E * (nl * 872576.0 + 99840.0), s, (rollout_layer_kernel<T, true, 8>), dim3(E, 2),
-                  dim3(512), (InfLayLds<T, 1>::bytes), s, stk, hd, fin, E);
-    V4L_LAUNCH_CHECK();
-    return 0;
-  }
-  for (int l = 0; l < nl; ++l) {  // 4-wave kernels, one launch per layer
-    InfLayerPair pr;
-    fill(pr.n[0], pf, pk, pf->layers[l], l == 0 ? x0 : ws_pf + Lp.x[l], ws_pf + Lp.x[l + 1]);
-    fill(pr.n[1], vf, vk, vf->layers[l], l == 0 ? x0 : ws_vf + Lv.x[l], ws_vf + Lv.x[l + 1]);
-    if (l < nl - 1) {
-      V4L_KLAUNCH("infer_layer", 2.0 * 2 * E * 872576.0, s, (infer_layer_kernel<T, 1, false>), dim3(E, 2), dim3(256),
-                  (InfLayLds<T, 1>::bytes), s, pr, hd, fin, E, pf->cfg.ff_dim);
-    } else {
-      finish();
-      V4L_KLAUNCH("infer_layer_head", 2.0 * 2 * E * (872576.0 + 99840.0), s, (infer_layer_kernel<T, 1, true>), dim3(E, 2),
-                  dim3(256), (InfLayLds<T, 1>::bytes), s, pr, hd, fin, E, pf->cfg.ff_dim);
-    }
+    static const int warm = getenv("V4L_ROLLOUT_WARM") ? atoi(getenv("V4L_ROLLOUT_WARM")) : 0;  // L2 warm-up touches (measured: +-0)
+    V4L_KLAUNCH("rollout_layers_head", 2.0 * 2 * E * (nl * 872576.0 + 99840.0), s, (rollout_stack_kernel<T, 2>), dim3(E, 2),
+                dim3(512), (RollStackLds<T>::bytes), s, stk, hd, fin, E, warm);
     V4L_LAUNCH_CHECK();
   }
   return 0;
@@ -2135,7 +2099,7 @@ int64_t v4l_trainer_ws_floats(const v4l_trainer* tr, int n) {
 }
 int64_t v4l_trainer_ctl_bytes(const v4l_trainer* tr, int n) {
   if (!tr || n <= 0) return -1;
-  return 256 + 256 + 512 + (int64_t)round_up(n, 64) * sizeof(int);
+  return 256 + 256 + 2 * GRAD_NORM_PARTS * sizeof(float) + (int64_t)round_up(n, 64) * sizeof(int);
 }
 int v4l_trainer_bind(v4l_trainer* tr, float* g_pf_dev, float* m_pf_dev, float* v_pf_dev, float* g_vf_dev,
                      float* m_vf_dev, float* v_vf_dev, float* ws_dev, int64_t ws_floats, void* ctl_dev, int n_max,
@@ -2155,8 +2119,8 @@ int v4l_trainer_bind(v4l_trainer* tr, float* g_pf_dev, float* m_pf_dev, float* v
   }
   tr->ctl = (UpdCtl*)ctl_dev;
   tr->stats_cur = (float*)((char*)ctl_dev + 256);
-  tr->norm_part = (float*)((char*)ctl_dev + 512);  // [2][64] squared-norm partials (vf, pf)
-  tr->rowidx_cur = (int*)((char*)ctl_dev + 1024);
+  tr->norm_part = (float*)((char*)ctl_dev + 512);  // [2][GRAD_NORM_PARTS] squared-norm partials (vf, pf)
+  tr->rowidx_cur = (int*)((char*)ctl_dev + 512 + 2 * GRAD_NORM_PARTS * sizeof(float));
   tr->n_max = n_max;
   tr->bound = true;
   return 0;
@@ -2216,8 +2180,8 @@ int v4l_trainer_critic_grads(v4l_trainer* tr, const v4l_rollout* ro, int n, cons
 
 static int adam_step(v4l_trainer* tr, v4l_net* net, float* g, float* m, float* v, const v4l_ppo_hyper* hp, int which,
                      float* norm_out, hipStream_t s) {
-  const int gb = (int)std::min<int64_t>(64, cdiv64(net->total_params, 256));
-  float* part = tr->norm_part + which * 64;
+  const int gb = (int)std::min<int64_t>(GRAD_NORM_PARTS, cdiv64(net->total_params, 1024));
+  float* part = tr->norm_part + which * GRAD_NORM_PARTS;
   g_op = "optim";
   V4L_KLAUNCH("grad_sumsq", 0, s, grad_sumsq_kernel, dim3(gb), dim3(256), 0, s, g, net->total_params, part);
   V4L_LAUNCH_CHECK();
