@@ -8,7 +8,7 @@ export PYTHONPATH=$REPO
 python bench.py > "$OUT/bench_full.json" 2> "$OUT/bench_full.err"
 echo "bench rc=$?"
 ( cd /tmp && export TMPDIR=/tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- \
-    python $REPO/bench.py --no-cpu-baseline > "$OUT/bench_traced.json" 2> "$OUT/trace.log" )
+    python $REPO/bench.py --no-cpu-baseline --no-parity > "$OUT/bench_traced.json" 2> "$OUT/trace.log" )
 echo "trace rc=$?"
 python - "$OUT" <<'PY'
 import csv, glob, os, sys, collections

@@ -11,7 +11,7 @@ rocprofv3 -L > "$OUT/counters_list.txt" 2>&1
 run() {  # name, counters...
   local name=$1; shift
   timeout 600 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d "$OUT/$name" -- \
-    python $REPO/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-rollout > "$OUT/$name.log" 2>&1
+    python $REPO/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-parity > "$OUT/$name.log" 2>&1
   echo "$name rc=$?"
 }
 run fetch FETCH_SIZE

@@ -10,7 +10,8 @@ import sys
 NAMES = {  # rocprof kernel symbol fragment -> bench.py / profiler label
     "bwd_conv_kernel": "fused_conv_bwd", "bwd_conv3_wgrad_kernel": "fused_conv3_wgrad", "gemm_tn_wide_kernel": "gemm_tn_wide",
     "gemm_tn_group_kernel": "gemm_tn_group", "wgrad_reduce_kernel": "wgrad_reduce", "infer_encoder_kernel": "fused_encoder",
-    "bwd_layer_kernel": "fused_layer_bwd", "infer_layer_kernel": "fused_layer",
+    "bwd_layer_kernel": "fused_layer_bwd", "infer_layer_kernel": "fused_layer", "train_encoder_kernel": "fused_encoder",
+    "rollout_stack_kernel": "rollout_layers_head", "rollout_encoder2_kernel": "rollout_encoder",
 }
 rows = [l.rstrip("\n").split("\t") for l in open(sys.argv[1])]
 h = rows[0]

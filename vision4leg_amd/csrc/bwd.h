@@ -426,7 +426,12 @@ __global__ __launch_bounds__(256) void bwd_layer_kernel(BwdLayer w, BwdHead hd, 
 #pragma unroll
       for (int j = 0; j < NTOK; ++j) rd = fmaf(p[lane * ATT_PLD + j], ds[lane * ATT_PLD + j], rd);
 #pragma unroll
-      for (int j = 0; j < NTOK; ++j) ds[lane * ATT_PLD + j] = p[lane * ATT_PLD + j] * (ds[lane * ATT_PLD + j] - rd);
+      for (int j = 0; j < NTOK; ++j) {
+        // dS and, from here on, P are operands of the remaining products only (dQ / dK; dV): kept rounded to T
+        const float pj = p[lane * ATT_PLD + j];
+        ds[lane * ATT_PLD + j] = rt<T>(pj * (ds[lane * ATT_PLD + j] - rd));
+        p[lane * ATT_PLD + j] = rt<T>(pj);
+      }
     }
     __syncthreads();
     if (act) {  // lane = feature column; everything this lane needs of Q, K, dctx sits in registers before the rows
@@ -446,8 +451,8 @@ __global__ __launch_bounds__(256) void bwd_layer_kernel(BwdLayer w, BwdHead hd, 
         for (int j4 = 0; j4 < ATT_PLD; j4 += 4) {
           const float4 pv = *reinterpret_cast<const float4*>(p + i * ATT_PLD + j4);
           const float4 sv = *reinterpret_cast<const float4*>(ds + i * ATT_PLD + j4);
-          pi[j4] = rt<T>(pv.x); pi[j4 + 1] = rt<T>(pv.y); pi[j4 + 2] = rt<T>(pv.z); pi[j4 + 3] = rt<T>(pv.w);
-          si[j4] = rt<T>(sv.x); si[j4 + 1] = rt<T>(sv.y); si[j4 + 2] = rt<T>(sv.z); si[j4 + 3] = rt<T>(sv.w);
+          pi[j4] = pv.x; pi[j4 + 1] = pv.y; pi[j4 + 2] = pv.z; pi[j4 + 3] = pv.w;
+          si[j4] = sv.x; si[j4 + 1] = sv.y; si[j4 + 2] = sv.z; si[j4 + 3] = sv.w;
         }
 #pragma unroll
         for (int j = 0; j < NTOK; ++j) {

@@ -412,7 +412,7 @@ __global__ void bucket_tail_kernel(float* __restrict__ st, float* __restrict__ t
 
 // nn.MSELoss()(values, est_rets) and its gradient (ppo.py:94-123; clipped_value_loss=False path, and the
 // clipped variant of ppo.py:105-112 when clip > 0). values is the critic output [n][OUT_LD], column 0.
-__global__ __launch_bounds__(256) void critic_loss_kernel(const float* __restrict__ values, const float* __restrict__ ret,
+__global__ __launch_bounds__(1024) void critic_loss_kernel(const float* __restrict__ values, const float* __restrict__ ret,
                                                           const float* __restrict__ oldv, const int* __restrict__ rowidx,
                                                           int n, float inv_n, int clipped, float clip,
                                                           float* __restrict__ dvalues, float* __restrict__ st) {
@@ -652,10 +652,10 @@ __global__ void ctl_set_kernel(UpdCtl* c, int upd_index, long long step, double 
 // Opens update #upd_index: selects its rows (identity when rowidx_all is null), clears the statistics record and
 // advances the Adam step / bias corrections (double precision, like torch/optim/adam.py::_single_tensor_adam).
 // adv != null: also the advantage statistics of the selected rows (adv_stats_kernel's work, one launch less).
-__global__ __launch_bounds__(256) void upd_begin_kernel(UpdCtl* c, const int* __restrict__ rowidx_all, int n,
-                                                        int* rowidx_cur, float* stats_cur, const float* __restrict__ adv) {
+__global__ __launch_bounds__(1024) void upd_begin_kernel(UpdCtl* c, const int* __restrict__ rowidx_all, int n,
+                                                         int* rowidx_cur, float* stats_cur, const float* __restrict__ adv) {
   const int u = c->upd_index;
-  for (int i = threadIdx.x; i < n; i += 256) rowidx_cur[i] = rowidx_all ? rowidx_all[(int64_t)u * n + i] : i;
+  for (int i = threadIdx.x; i < n; i += blockDim.x) rowidx_cur[i] = rowidx_all ? rowidx_all[(int64_t)u * n + i] : i;
   if (threadIdx.x < ST_SIZE) stats_cur[threadIdx.x] = 0.f;
   if (adv != nullptr) {
     __syncthreads();  // rowidx_cur and the cleared record are visible to the whole block
@@ -671,19 +671,12 @@ __global__ __launch_bounds__(256) void upd_begin_kernel(UpdCtl* c, const int* __
     c->bc2_sqrt = (float)sqrt(bc2);
   }
 }
-// Closes the update: publishes the statistics record and moves on to the next minibatch.
-__global__ void upd_end_kernel(UpdCtl* c, const float* __restrict__ stats_cur, float* __restrict__ stats_all) {
-  const int u = c->upd_index;
-  if (stats_all != nullptr && threadIdx.x < ST_SIZE) stats_all[(int64_t)u * ST_SIZE + threadIdx.x] = stats_cur[threadIdx.x];
-  __syncthreads();
-  if (threadIdx.x == 0) c->upd_index = u + 1;
-}
-
 __global__ __launch_bounds__(256) void clip_adam_kernel(const ParamSeg* __restrict__ segs, int nseg,
                                                         const float* __restrict__ g, float* __restrict__ m,
                                                         float* __restrict__ v, const float* __restrict__ part, int npart,
                                                         float max_norm, float eps, const UpdCtl* __restrict__ ctl,
-                                                        int which, float* __restrict__ norm_out) {
+                                                        int which, float* __restrict__ norm_out, UpdCtl* close_ctl,
+                                                        const float* stats_cur, float* __restrict__ stats_all) {
   const ParamSeg sg = segs[find_desc(segs, nseg, (int64_t)blockIdx.x)];
   const float beta1 = ctl->beta1, beta2 = ctl->beta2;
   const float step_size = ctl->step_size[which], bc2_sqrt = ctl->bc2_sqrt;
@@ -694,6 +687,15 @@ __global__ __launch_bounds__(256) void clip_adam_kernel(const ParamSeg* __restri
   const float tot = sqrtf(wave_sum(ps));
   const float coef = fminf(max_norm / (tot + 1e-6f), 1.f);
   if (blockIdx.x == 0 && threadIdx.x == 0 && norm_out != nullptr) *norm_out = tot;
+  if (blockIdx.x == 0 && close_ctl != nullptr) {
+    // last launch of an update: publish the statistics record (this block just completed it with the policy's gradient
+    // norm) and move on to the next minibatch — what upd_end_kernel did as one more launch
+    __syncthreads();
+    const int u = close_ctl->upd_index;
+    if (stats_all != nullptr && threadIdx.x < ST_SIZE) stats_all[(int64_t)u * ST_SIZE + threadIdx.x] = stats_cur[threadIdx.x];
+    __syncthreads();
+    if (threadIdx.x == 0) close_ctl->upd_index = u + 1;
+  }
   const int64_t i = ((int64_t)blockIdx.x - sg.blk0) * 256 + threadIdx.x;
   if (i >= sg.n) return;
   const int64_t o = sg.goff + i;
@@ -720,44 +722,55 @@ struct PackDesc {
   int s, py, px, TW; // dgrad class
   int64_t blk0;
 };
+// 8 consecutive packed elements (one row: every packed row length is a multiple of 8) per thread, one 16 / 32-byte store
+constexpr int PACK_PER_BLOCK = 256 * 8;
 template <typename T>
 __global__ __launch_bounds__(256) void pack_kernel(const PackDesc* __restrict__ descs, int nd, T* __restrict__ dst) {
   const PackDesc d = descs[find_desc(descs, nd, (int64_t)blockIdx.x)];
   const V4L_GLOBAL float* src = as_global(d.src);
-  const int64_t e = ((int64_t)blockIdx.x - d.blk0) * 256 + threadIdx.x;
-  if (e >= (int64_t)d.R * d.Cc) return;
-  const int r = (int)(e / d.Cc), c = (int)(e - (int64_t)r * d.Cc);
-  float val = 0.f;
-  switch (d.kind) {
-    case PK_FRAG: {  // MFMA fragment order [column tile n/16][k-step k/32][lane = (k%32)/8*16 + n%16][k%8]: the 64 lanes of
-      // a wave read one fragment as ONE contiguous 64 x sizeof(fragment) block (8 whole cache lines for bf16)
-      const int j = (int)(e & 7), lane = (int)((e >> 3) & 63), blk = (int)(e >> 9), ksteps = d.Cc >> 5;
-      const int tile = blk / ksteps, ks = blk - tile * ksteps;
-      const int n = tile * 16 + (lane & 15), k = ks * 32 + (lane >> 4) * 8 + j;
-      if (n < d.N && k < d.K) {
-        if (d.Cin > 0) { const int tap = k / d.Cin, ci = k - tap * d.Cin; val = src[(int64_t)n * d.K + ci * d.taps + tap]; }  // NHWC k order
-        else val = src[(int64_t)n * d.K + k];
-      }
-    } break;
-    case PK_NT: if (r < d.N && c < d.K) val = src[(int64_t)r * d.K + c]; break;
-    case PK_T: if (r < d.K && c < d.N) val = src[(int64_t)c * d.K + r]; break;
-    case PK_CONV_NHWC:  // dst[n][tap*Cin+ci] = W[n][ci][tap]
-      if (r < d.N && c < d.K) { const int tap = c / d.Cin, ci = c - tap * d.Cin; val = src[(int64_t)r * d.K + ci * d.taps + tap]; }
-      break;
-    case PK_CONV_NHWC_T:  // dst[tap*Cin+ci][n] = W[n][ci][tap]
-      if (r < d.K && c < d.N) { const int tap = r / d.Cin, ci = r - tap * d.Cin; val = src[(int64_t)c * d.K + ci * d.taps + tap]; }
-      break;
-    case PK_CONV_DGRAD: {  // dst[ci][(a*TW+bb)*N + n] = W[n][ci][py+s*a][px+s*bb]
-      const int kk = d.TW * d.TW * d.N;
-      if (r < d.Cin && c < kk) {
-        const int tap = c / d.N, n = c - tap * d.N;
-        const int a = tap / d.TW, bb = tap - a * d.TW;
-        const int ky = d.py + d.s * a, kx = d.px + d.s * bb;
-        val = src[(int64_t)n * d.K + r * d.taps + ky * d.KW + kx];
-      }
-    } break;
+  const int64_t e0 = (((int64_t)blockIdx.x - d.blk0) * 256 + threadIdx.x) * 8;
+  if (e0 >= (int64_t)d.R * d.Cc) return;
+  const int r = (int)(e0 / d.Cc), c0 = (int)(e0 - (int64_t)r * d.Cc);
+  float val[8];
+#pragma unroll
+  for (int q = 0; q < 8; ++q) {
+    const int c = c0 + q;
+    const int64_t e = e0 + q;
+    float v = 0.f;
+    switch (d.kind) {
+      case PK_FRAG: {  // MFMA fragment order [column tile n/16][k-step k/32][lane = (k%32)/8*16 + n%16][k%8]: the 64 lanes
+        // of a wave read one fragment as ONE contiguous 64 x sizeof(fragment) block (8 whole cache lines for bf16)
+        const int j = (int)(e & 7), lane = (int)((e >> 3) & 63), blk = (int)(e >> 9), ksteps = d.Cc >> 5;
+        const int tile = blk / ksteps, ks = blk - tile * ksteps;
+        const int n = tile * 16 + (lane & 15), k = ks * 32 + (lane >> 4) * 8 + j;
+        if (n < d.N && k < d.K) {
+          if (d.Cin > 0) { const int tap = k / d.Cin, ci = k - tap * d.Cin; v = src[(int64_t)n * d.K + ci * d.taps + tap]; }  // NHWC k order
+          else v = src[(int64_t)n * d.K + k];
+        }
+      } break;
+      case PK_NT: if (r < d.N && c < d.K) v = src[(int64_t)r * d.K + c]; break;
+      case PK_T: if (r < d.K && c < d.N) v = src[(int64_t)c * d.K + r]; break;
+      case PK_CONV_NHWC:  // dst[n][tap*Cin+ci] = W[n][ci][tap]
+        if (r < d.N && c < d.K) { const int tap = c / d.Cin, ci = c - tap * d.Cin; v = src[(int64_t)r * d.K + ci * d.taps + tap]; }
+        break;
+      case PK_CONV_NHWC_T:  // dst[tap*Cin+ci][n] = W[n][ci][tap]
+        if (r < d.K && c < d.N) { const int tap = r / d.Cin, ci = r - tap * d.Cin; v = src[(int64_t)c * d.K + ci * d.taps + tap]; }
+        break;
+      case PK_CONV_DGRAD: {  // dst[ci][(a*TW+bb)*N + n] = W[n][ci][py+s*a][px+s*bb]
+        const int kk = d.TW * d.TW * d.N;
+        if (r < d.Cin && c < kk) {
+          const int tap = c / d.N, n = c - tap * d.N;
+          const int a = tap / d.TW, bb = tap - a * d.TW;
+          const int ky = d.py + d.s * a, kx = d.px + d.s * bb;
+          v = src[(int64_t)n * d.K + r * d.taps + ky * d.KW + kx];
+        }
+      } break;
+    }
+    val[q] = v;
   }
-  dst[d.dst_off + e] = Op<T>::from_f32(val);
+  T* o = dst + d.dst_off + e0;
+  st4(o, val[0], val[1], val[2], val[3]);
+  st4(o + 4, val[4], val[5], val[6], val[7]);
 }
 
 // --------------------------------------------------------------------------------- GAE

@@ -113,23 +113,6 @@ __device__ __forceinline__ void block_gemm(f32x4 (&acc)[MT][NTW], const AT* sA, 
   GemmRing<T, NTW, KS> ring = gemm_prefetch<T, NTW, KS>(Wp, Kp, ntile, lane);
   block_gemm<T, MT, NTW, KS, AT>(acc, sA, lda, Wp, Kp, ntile, lane, ring);
 }
-// 4 consecutive elements of one row -> one 8/16-byte store (LDS or global), T = __bf16 | float
-__device__ __forceinline__ void st4(__bf16* p, float a, float b, float c, float d) {
-  typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
-  bf16x4 v;
-  v[0] = (__bf16)a; v[1] = (__bf16)b; v[2] = (__bf16)c; v[3] = (__bf16)d;
-  *reinterpret_cast<bf16x4*>(p) = v;
-}
-__device__ __forceinline__ void st4(float* p, float a, float b, float c, float d) {
-  *reinterpret_cast<float4*>(p) = float4{a, b, c, d};
-}
-// 4 consecutive elements (8/16-byte load) -> float4
-__device__ __forceinline__ float4 ld4(const __bf16* p) {
-  typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
-  const bf16x4 v = *reinterpret_cast<const bf16x4*>(p);
-  return float4{(float)v[0], (float)v[1], (float)v[2], (float)v[3]};
-}
-__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 template <int MT, int NTW> __device__ __forceinline__ void zero_acc(f32x4 (&acc)[MT][NTW]) {
 #pragma unroll
   for (int i = 0; i < MT; ++i)

@@ -740,7 +740,7 @@ int v4l_net::build() {
     d.kind = kind; d.R = R; d.Cc = Cc; d.N = N; d.K = K; d.Cin = cin; d.taps = taps; d.KW = KW;
     d.s = s; d.py = py; d.px = px; d.TW = TW;
     d.blk0 = pack_blocks;
-    pack_blocks += cdiv64((int64_t)R * Cc, 256);
+    pack_blocks += cdiv64((int64_t)R * Cc, PACK_PER_BLOCK);
     packed_elems = align64(packed_elems + (int64_t)R * Cc);
     packs.push_back(d);
     pack_param.push_back(param);
@@ -2160,7 +2160,7 @@ int v4l_trainer_critic_grads(v4l_trainer* tr, const v4l_rollout* ro, int n, cons
   const int* rowidx = tr->rowidx_cur;
   g_op = "ctl";
   // selects the rows of this update, clears the statistics record, advances Adam's step, advantage statistics
-  V4L_KLAUNCH("upd_begin", 0, s, upd_begin_kernel, dim3(1), dim3(256), 0, s, tr->ctl, tr->rowidx_all, n, tr->rowidx_cur, st,
+  V4L_KLAUNCH("upd_begin", 0, s, upd_begin_kernel, dim3(1), dim3(n >= 512 ? 1024 : 256), 0, s, tr->ctl, tr->rowidx_all, n, tr->rowidx_cur, st,
               ro->advs_dev);
   V4L_LAUNCH_CHECK();
   // (no clearing of g_vf / g_pf: v4l_net_backward writes every element of the flat gradient — tests/test_gpu_parity.py
@@ -2171,7 +2171,7 @@ int v4l_trainer_critic_grads(v4l_trainer* tr, const v4l_rollout* ro, int n, cons
   const Layout L = vf->layout(n);
   const float inv_n = 1.f / ((float)n * (float)hp->world_size);
   g_op = "loss";
-  V4L_KLAUNCH("critic_loss", 0, s, critic_loss_kernel, dim3(1), dim3(256), 0, s, tr->ws + L.out, ro->rets_dev, ro->values_dev,
+  V4L_KLAUNCH("critic_loss", 0, s, critic_loss_kernel, dim3(1), dim3(n >= 512 ? 1024 : 256), 0, s, tr->ws + L.out, ro->rets_dev, ro->values_dev,
                      rowidx, n, inv_n, hp->clipped_value_loss, hp->clip_para, tr->ws + L.dout, st);
   V4L_LAUNCH_CHECK();
   PhaseScope ps("vf.bwd");
@@ -2179,14 +2179,15 @@ int v4l_trainer_critic_grads(v4l_trainer* tr, const v4l_rollout* ro, int n, cons
 }
 
 static int adam_step(v4l_trainer* tr, v4l_net* net, float* g, float* m, float* v, const v4l_ppo_hyper* hp, int which,
-                     float* norm_out, hipStream_t s) {
+                     float* norm_out, hipStream_t s, bool close_update = false) {
   const int gb = (int)std::min<int64_t>(GRAD_NORM_PARTS, cdiv64(net->total_params, 1024));
   float* part = tr->norm_part + which * GRAD_NORM_PARTS;
   g_op = "optim";
   V4L_KLAUNCH("grad_sumsq", 0, s, grad_sumsq_kernel, dim3(gb), dim3(256), 0, s, g, net->total_params, part);
   V4L_LAUNCH_CHECK();
   V4L_KLAUNCH("clip_adam", 0, s, clip_adam_kernel, dim3((unsigned)net->seg_blocks), dim3(256), 0, s, net->d_segs,
-              (int)net->params.size(), g, m, v, (const float*)part, gb, hp->max_grad_norm, hp->eps, tr->ctl, which, norm_out);
+              (int)net->params.size(), g, m, v, (const float*)part, gb, hp->max_grad_norm, hp->eps, tr->ctl, which, norm_out,
+              close_update ? tr->ctl : (UpdCtl*)nullptr, (const float*)tr->stats_cur, tr->stats_all);
   V4L_LAUNCH_CHECK();
   return 0;
 }
@@ -2247,12 +2248,8 @@ int v4l_trainer_actor_step(v4l_trainer* tr, const v4l_ppo_hyper* hp, void* strea
   V4L_REQUIRE(tr && tr->bound && hp, "v4l_trainer_actor_step: bad argument");
   hipStream_t s = (hipStream_t)stream;
   float* st = tr->stats_cur;
-  int rc = adam_step(tr, tr->pf, tr->g_pf, tr->m_pf, tr->v_pf, hp, 0, st + ST_GN_PF, s);
-  if (rc) return rc;
-  g_op = "ctl";
-  V4L_KLAUNCH("upd_end", 0, s, upd_end_kernel, dim3(1), dim3(64), 0, s, tr->ctl, st, tr->stats_all);
-  V4L_LAUNCH_CHECK();
-  return 0;
+  // the policy's Adam launch also closes the update (statistics record out, minibatch index + 1)
+  return adam_step(tr, tr->pf, tr->g_pf, tr->m_pf, tr->v_pf, hp, 0, st + ST_GN_PF, s, true);
 }
 
 int v4l_comm_unique_id(char* id_out) {
