@@ -39,7 +39,9 @@ extern "C" {
                               nets.py:784-906, base.py:388-494 (starter/ppo_locotransformer_vision_only.py:77-97) */
 
 #define V4L_MAX_HIDDEN 4
-#define V4L_STATS 24 /* floats per update record; [0..17] = the 18 logger keys of ppo.py:77-92,122-123,142-145 */
+#define V4L_STATS 24 /* floats per update record; [0..17] = the 18 logger keys of ppo.py:77-92,122-123,142-145;
+                        [18..21] shard moments of the advantages (data-parallel exchange); [22] = how many of the 18 are
+                        NaN / Inf (device-side form of the collector's NaN check, collector/on_policy.py:102-107) */
 #define V4L_OUT_LD 16 /* row stride of head outputs (action mean / value), zero padded */
 
 typedef struct v4l_net_cfg {
@@ -202,8 +204,9 @@ int v4l_trainer_begin(v4l_trainer* tr, const int* rowidx_all_dev, float* stats_a
  * The first update of a configuration always runs eagerly. */
 int v4l_trainer_update_next(v4l_trainer* tr, const v4l_rollout* ro, int n, const v4l_ppo_hyper* hp, int use_graph,
                             void* stream);
-/* Phases of the same update for the data-parallel schedule: critic_grads -> all-reduce(g_vf || stats[18..20]) ->
- * critic_step -> actor_grads -> all-reduce(g_pf) -> actor_step. v4l_trainer_stats_cur = the record being filled. */
+/* Phases of the same update for a host-driven data-parallel schedule: critic_grads -> all-reduce(critic bucket) ->
+ * critic_step -> actor_grads -> all-reduce(policy bucket) -> actor_step (buckets and their tails: see v4l_sync_grads).
+ * v4l_trainer_stats_cur = the record being filled. */
 int v4l_trainer_critic_grads(v4l_trainer* tr, const v4l_rollout* ro, int n, const v4l_ppo_hyper* hp, void* stream);
 int v4l_trainer_critic_step(v4l_trainer* tr, const v4l_ppo_hyper* hp, void* stream);
 int v4l_trainer_actor_grads(v4l_trainer* tr, const v4l_rollout* ro, int n, const v4l_ppo_hyper* hp, void* stream);

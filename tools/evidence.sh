@@ -22,7 +22,7 @@ for path in glob.glob(os.path.join(out, "trace", "**", "*kernel_trace.csv"), rec
             agg[k][1] += (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) * 1e-3
 tot = sum(v[1] for v in agg.values())
 with open(os.path.join(out, "kernel_stats.txt"), "w") as f:
-    f.write("# rocprofv3 --kernel-trace of `python bench.py --no-cpu-baseline` (1 warm-up + 3 timed epochs + 1 profiled update pass + rollouts)\n")
+    f.write("# rocprofv3 --kernel-trace of `python bench.py --no-cpu-baseline --no-parity` (1 warm-up + 3 timed epochs + 1 profiled rollout + update pass)\n")
     f.write("# %-100s %8s %12s %10s %7s\n" % ("kernel", "calls", "total_us", "avg_us", "share"))
     for k, (c, us) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
         f.write("%-102s %8d %12.1f %10.2f %6.2f%%\n" % (k[:102], c, us, us / c, 100 * us / tot))

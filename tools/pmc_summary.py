@@ -8,7 +8,7 @@ for path in glob.glob(os.path.join(out, "*", "**", "*counter_collection.csv"), r
     seen = set()
     with open(path) as f:
         for row in csv.DictReader(f):
-            k = row.get("Kernel_Name", "?").split("(")[0][-70:]
+            k = row.get("Kernel_Name", "?").split("(")[0][:120]
             agg[k][row["Counter_Name"]] += float(row["Counter_Value"])
             key = (path, row.get("Dispatch_Id"))
             if row["Counter_Name"] in ("FETCH_SIZE",) and key not in seen:

@@ -14,6 +14,7 @@ V4L_F32, V4L_BF16 = 0, 1
 V4L_NET_MLP, V4L_NET_CNN, V4L_NET_LOCO, V4L_NET_CNN_VIS, V4L_NET_LOCO_VIS = 0, 1, 2, 3, 4
 V4L_MAX_HIDDEN = 4
 V4L_STATS = 24
+ST_NONFINITE = 22   # record slot: number of NaN / Inf among the 18 logged scalars of an update
 V4L_OUT_LD = 16
 V4L_BUCKET_TAIL = 8   # scalars behind the gradients of an all-reduce bucket
 V4L_COMM_ID_BYTES = 128

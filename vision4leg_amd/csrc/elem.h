@@ -351,6 +351,8 @@ enum {
   // (the global variance is rebuilt as (sum M2_i + sum n_i mean_i^2 - N mean^2) / (N - 1): the only cancellation left is
   // between shard means, not between a raw sum of squares and N mean^2)
   ST_ADV_SUM = 18, ST_ADV_M2, ST_ADV_CNT, ST_ADV_NM2,
+  ST_NONFINITE = 22,  // how many of the 18 logged scalars of this update are NaN / Inf (the on-device form of the
+                      // collector's "NaN detected" check, collector/on_policy.py:102-107: the host reads one number per epoch)
   ST_SIZE = 24
 };
 
@@ -692,6 +694,12 @@ __global__ __launch_bounds__(256) void clip_adam_kernel(const ParamSeg* __restri
     // norm) and move on to the next minibatch — what upd_end_kernel did as one more launch
     __syncthreads();
     const int u = close_ctl->upd_index;
+    if (threadIdx.x < 64) {  // wave 0: count the non-finite logger scalars (losses, norms, ratios: a NaN anywhere reaches them)
+      const float sv = threadIdx.x < 18 ? stats_cur[threadIdx.x] : 0.f;
+      const unsigned long long badm = __ballot(!(fabsf(sv) <= 3.0e38f));
+      if (threadIdx.x == 0) const_cast<float*>(stats_cur)[ST_NONFINITE] = (float)__popcll(badm);
+    }
+    __syncthreads();
     if (stats_all != nullptr && threadIdx.x < ST_SIZE) stats_all[(int64_t)u * ST_SIZE + threadIdx.x] = stats_cur[threadIdx.x];
     __syncthreads();
     if (threadIdx.x == 0) close_ctl->upd_index = u + 1;

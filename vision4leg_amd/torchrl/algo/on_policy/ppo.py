@@ -170,6 +170,17 @@ class PPO:
         """state_dict checkpoints with the reference's file names (rl_algo.py:84-95)."""
         norm = getattr(self.env, "_obs_normalizer", None)
         if norm is not None:
+            if hasattr(norm, "to_reference"):
+                # the device-resident normaliser (vision4leg_amd.torchrl.env): write what the reference's viewers unpickle
+                # (starter/locotransformer_viewer.py:125-147) — an instance of the REFERENCE's Normalizer class — whenever that
+                # class is importable (it is under overlay.install(): the reference's torchrl.env is untouched)
+                try:
+                    import importlib
+                    ref_cls = importlib.import_module("torchrl.env.base_wrapper").Normalizer
+                    if ref_cls is not type(norm):
+                        norm = norm.to_reference(ref_cls)
+                except Exception:  # stand-alone use of this package: the pickle then needs this package to load
+                    pass
             with open(osp.join(prefix, "_obs_normalizer_{}.pkl".format(epoch)), "wb") as f:
                 pickle.dump(norm, f)
         for name, network in self.snapshot_networks:
@@ -212,6 +223,11 @@ class PPO:
         stats = torch.zeros(len(batches), _lib.V4L_STATS, dtype=torch.float32, device=self.device)
         self.run_updates(ro, rowidx, stats)
         host = stats.cpu().numpy()  # the only device->host sync of the epoch's updates
+        bad = np.nonzero(host[:, _lib.ST_NONFINITE] > 0)[0]
+        if len(bad):  # the device-side tripwire (collector/on_policy.py:102-107 "NaN detected. BOOM")
+            raise FloatingPointError("vision4leg_amd: non-finite training statistics in minibatch update %d of epoch %d: %s"
+                                     % (int(bad[0]), self.current_epoch,
+                                        {k: float(host[bad[0], j]) for j, k in enumerate(_lib.STAT_KEYS)}))
         for row in host:
             self.logger.add_update_info({k: float(row[j]) for j, k in enumerate(_lib.STAT_KEYS)})
 
