@@ -574,9 +574,11 @@ template <typename T> struct BwdConvLds {
   static constexpr int LC1 = 32 + (B16 ? 8 : 0);    // c1 rows (T)
   static constexpr int LD1 = 32 + 4;                // dc1 rows (fp32)
   static constexpr int IMGP = B16 ? 1 : 2;          // image passes (fp32: two channels at a time)
-  static constexpr size_t dc3_b = (size_t)17 * LF * 4;   // + one zero row (taps that fall outside the 4x4 plane)
+  static constexpr int LT = 64 + (B16 ? 8 : 4);     // rows in the compute type, read as whole MFMA fragments
+  static constexpr size_t dc3_b = (size_t)17 * LT * sizeof(T);   // T; + one zero row (taps that fall outside the 4x4 plane)
   static constexpr size_t c2_b = (size_t)36 * LF * 4;
-  static constexpr size_t dc2_b = (size_t)48 * LF * 4;   // rows 36..47: zeros (MFMA padding / out-of-plane taps)
+  static constexpr size_t dc2_b = (size_t)48 * LF * 4 + (size_t)48 * LT * sizeof(T);  // fp32 (bias sums, dW2 operand) + T copy
+                                                         // (conv2' operand); rows 36..47: zeros (MFMA padding / out-of-plane taps)
   static constexpr size_t c1_b = ((size_t)225 * LC1 * sizeof(T) + 15) / 16 * 16;
   static constexpr size_t dc1_b = (size_t)225 * LD1 * 4;
   static constexpr size_t img_b = (size_t)(4 / IMGP) * 4096 * sizeof(T);
@@ -604,7 +606,7 @@ __device__ __forceinline__ bf16x8 frag_of_t(const __bf16 (&v)[8]) {
 __device__ __forceinline__ f32x8 frag_of_t(const float (&v)[8]) { return frag_of<float>(v); }
 
 // Gather-form data-grad GEMM of one wave: acc[mt][j] += A(mt, ks) * W[row = (nt0 + j)*16 + lane&15][ks*32 ..]^T over KS
-// K=32 steps, where the A fragment of (row tile mt, step ks) comes from the LDS row arow(mt, ks >> 1) (64 channels = two
+// K=32 steps, where the A fragment of (row tile mt, step ks) comes from the LDS row (compute type T) arow(mt, ks >> 1) (64 channels = two
 // steps per tap) and feeds NT column tiles. Weight fragments stream from L2 through a ring of PD steps, like block_gemm.
 template <typename T, int MT, int NT, int KS, class RowF>
 __device__ __forceinline__ void gather_gemm(f32x4 (&acc)[MT][NT], const T* __restrict__ W, int Kp, int nt0, int lane, RowF arow) {
@@ -628,7 +630,7 @@ __device__ __forceinline__ void gather_gemm(f32x4 (&acc)[MT][NT], const T* __res
     }
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
-      const frag_t fa = afrag<T>(arow(mt, ks >> 1) + (ks & 1) * 32 + fg);
+      const frag_t fa = *reinterpret_cast<const frag_t*>(arow(mt, ks >> 1) + (ks & 1) * 32 + fg);  // rows already in T
 #pragma unroll
       for (int j = 0; j < NT; ++j)
         mma_k32(acc[mt][j], cur[j], fa);  // transposed tile: acc[mt][j][r] = out[16*mt + lane&15][16*(nt0+j) + 4*(lane>>4) + r]
@@ -647,9 +649,10 @@ __global__ __launch_bounds__(512) void bwd_conv_kernel(BwdConv a) {
   typedef typename Frag<T>::type frag_t;
   constexpr int NTH = 512;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  float* sdc3 = reinterpret_cast<float*>(smem);
+  T* sdc3 = reinterpret_cast<T*>(smem);
   float* sc2 = reinterpret_cast<float*>(smem + LY::dc3_b);
   float* sdc2 = reinterpret_cast<float*>(smem + LY::dc3_b + LY::c2_b);
+  T* sdc2t = reinterpret_cast<T*>(sdc2 + 48 * LY::LF);
   T* sc1 = reinterpret_cast<T*>(smem + LY::dc3_b + LY::c2_b + LY::dc2_b);
   float* sdc1 = reinterpret_cast<float*>(smem + LY::dc3_b + LY::c2_b + LY::dc2_b + LY::c1_b);
   T* simg = reinterpret_cast<T*>(smem + LY::dc3_b + LY::c2_b + LY::dc2_b + LY::c1_b + LY::dc1_b);
@@ -667,7 +670,8 @@ __global__ __launch_bounds__(512) void bwd_conv_kernel(BwdConv a) {
   }
   float bias2 = 0.f, bias1 = 0.f;  // per-thread partial column sums of dc2 (co = tid & 63) / dc1 (co = tid & 31)
   for (int i = tid; i < 12 * LY::LF; i += NTH) sdc2[36 * LY::LF + i] = 0.f;
-  for (int i = tid; i < LY::LF; i += NTH) sdc3[16 * LY::LF + i] = 0.f;
+  for (int i = tid; i < 12 * LY::LT; i += NTH) sdc2t[36 * LY::LT + i] = (T)0.f;
+  for (int i = tid; i < LY::LT; i += NTH) sdc3[16 * LY::LT + i] = (T)0.f;
   constexpr int CH = 4 / LY::IMGP;  // image channels resident at a time
 
   constexpr int V = 16 / sizeof(T);  // image elements per 16-byte load
@@ -688,7 +692,8 @@ __global__ __launch_bounds__(512) void bwd_conv_kernel(BwdConv a) {
                                          (__attribute__((address_space(3))) void*)(simg + ((tid & ~63) + k * NTH) * V), 16, 0, 0);
       if (tid < 256) {
         const int r = tid >> 4, c4 = (tid & 15) * 4;
-        *reinterpret_cast<float4*>(sdc3 + r * LY::LF + c4) = *reinterpret_cast<const float4*>(g3 + r * 64 + c4);
+        const float4 v3 = *reinterpret_cast<const float4*>(g3 + r * 64 + c4);  // dc3 is an MFMA operand only: kept in T
+        st4(sdc3 + r * LY::LT + c4, v3.x, v3.y, v3.z, v3.w);
       }
       for (int i4 = tid; i4 < 36 * 16; i4 += NTH) {
         const int r = i4 >> 4, c4 = (i4 & 15) * 4;
@@ -718,24 +723,27 @@ __global__ __launch_bounds__(512) void bwd_conv_kernel(BwdConv a) {
         f32x4 acc[MT][1];
 #pragma unroll
         for (int m = 0; m < MT; ++m) acc[m][0] = f32x4{0.f, 0.f, 0.f, 0.f};
-        gather_gemm<T, MT, 1, 18>(acc, W, 576, nt, lane, [&](int m, int tap) -> const float* {
+        gather_gemm<T, MT, 1, 18>(acc, W, 576, nt, lane, [&](int m, int tap) -> const T* {
           const int ta = tap / 3, tb = tap - ta * 3;
           const int oy = iy[m] - ta, ox = ix[m] - tb;
           const bool ok = okr[m] && oy >= 0 && oy < 4 && ox >= 0 && ox < 4;
-          return sdc3 + (ok ? oy * 4 + ox : 16) * LY::LF;
+          return sdc3 + (ok ? oy * 4 + ox : 16) * LY::LT;
         });
 #pragma unroll
         for (int m = 0; m < MT; ++m) {
           const int px = (mt0 + m) * 16 + fr, c4 = nt * 16 + qr;
           if (px < 36) {
             const float4 mk = *reinterpret_cast<const float4*>(sc2 + px * LY::LF + c4);
-            st4(sdc2 + px * LY::LF + c4, mk.x > 0.f ? acc[m][0][0] : 0.f, mk.y > 0.f ? acc[m][0][1] : 0.f,
-                mk.z > 0.f ? acc[m][0][2] : 0.f, mk.w > 0.f ? acc[m][0][3] : 0.f);
+            const float d0 = mk.x > 0.f ? acc[m][0][0] : 0.f, d1 = mk.y > 0.f ? acc[m][0][1] : 0.f;
+            const float d2 = mk.z > 0.f ? acc[m][0][2] : 0.f, d3 = mk.w > 0.f ? acc[m][0][3] : 0.f;
+            st4(sdc2 + px * LY::LF + c4, d0, d1, d2, d3);   // fp32: bias sums, dW2's column fragments
+            st4(sdc2t + px * LY::LT + c4, d0, d1, d2, d3);  // T: the A operand of conv2' below
           }
         }
       };
-      if (wave < 4) run(std::integral_constant<int, 2>{}, 0);
-      else run(std::integral_constant<int, 1>{}, 2);
+      // waves 0..3 own one ci tile each for all three row tiles: the 72 KB of w3' enter the CU once per sample (two waves
+      // per ci tile, splitting the row tiles, streamed them twice — and the phase is bound by exactly that stream)
+      if (wave < 4) run(std::integral_constant<int, 3>{}, 0);
     }
     __syncthreads();
     CONV_STAMP(2);
@@ -778,32 +786,29 @@ __global__ __launch_bounds__(512) void bwd_conv_kernel(BwdConv a) {
       }
     }
     CONV_STAMP(3);
-    {  // ---- dc1 = conv2' (gather form): wave pair = stride-parity class (py,px) with <= 8x8 input pixels; the pair
-       //      splits the 4 row tiles, each wave covers both 16-wide ci tiles (N = 32); K = 2x2 taps x 64 co
-      const int cls = wave >> 1, py = cls >> 1, pxx = cls & 1, mh = wave & 1;
+    {  // ---- dc1 = conv2' (gather form): wave pair = stride-parity class (py,px) with <= 8x8 input pixels (4 row tiles); the
+       //      pair splits the two 16-wide ci tiles (N = 32), so a class's 16 KB of weights are streamed once; K = 2x2 taps x 64 co
+      const int cls = wave >> 1, py = cls >> 1, pxx = cls & 1, nh = wave & 1;
       const int nIy = (15 - py + 1) >> 1, nIx = (15 - pxx + 1) >> 1;
-      int ry[2], rx[2];
+      int ry[4], rx[4];
 #pragma unroll
-      for (int m = 0; m < 2; ++m) { const int r = (mh * 2 + m) * 16 + fr; ry[m] = r >> 3; rx[m] = r & 7; }
-      f32x4 acc[2][2];
+      for (int m = 0; m < 4; ++m) { const int r = m * 16 + fr; ry[m] = r >> 3; rx[m] = r & 7; }
+      f32x4 acc[4][1];
 #pragma unroll
-      for (int m = 0; m < 2; ++m) acc[m][0] = acc[m][1] = f32x4{0.f, 0.f, 0.f, 0.f};
-      gather_gemm<T, 2, 2, 8>(acc, reinterpret_cast<const T*>(a.w2d[cls]), 256, 0, lane, [&](int m, int tap) -> const float* {
+      for (int m = 0; m < 4; ++m) acc[m][0] = f32x4{0.f, 0.f, 0.f, 0.f};
+      gather_gemm<T, 4, 1, 8>(acc, reinterpret_cast<const T*>(a.w2d[cls]), 256, nh, lane, [&](int m, int tap) -> const T* {
         const int oy = ry[m] - (tap >> 1), ox = rx[m] - (tap & 1);
         const bool ok = ry[m] < nIy && rx[m] < nIx && oy >= 0 && oy < 6 && ox >= 0 && ox < 6;
-        return sdc2 + (ok ? oy * 6 + ox : 36) * LY::LF;
+        return sdc2t + (ok ? oy * 6 + ox : 36) * LY::LT;
       });
 #pragma unroll
-      for (int m = 0; m < 2; ++m) {
+      for (int m = 0; m < 4; ++m) {
         if (ry[m] < nIy && rx[m] < nIx) {
           const int p = (py + 2 * ry[m]) * 15 + pxx + 2 * rx[m];
-#pragma unroll
-          for (int j = 0; j < 2; ++j) {
-            const int c4 = j * 16 + qr;
-            const float4 mk = ld4(sc1 + p * LY::LC1 + c4);
-            st4(sdc1 + p * LY::LD1 + c4, mk.x > 0.f ? acc[m][j][0] : 0.f, mk.y > 0.f ? acc[m][j][1] : 0.f,
-                mk.z > 0.f ? acc[m][j][2] : 0.f, mk.w > 0.f ? acc[m][j][3] : 0.f);
-          }
+          const int c4 = nh * 16 + qr;
+          const float4 mk = ld4(sc1 + p * LY::LC1 + c4);
+          st4(sdc1 + p * LY::LD1 + c4, mk.x > 0.f ? acc[m][0][0] : 0.f, mk.y > 0.f ? acc[m][0][1] : 0.f,
+              mk.z > 0.f ? acc[m][0][2] : 0.f, mk.w > 0.f ? acc[m][0][3] : 0.f);
         }
       }
     }
