@@ -570,19 +570,20 @@ struct BwdConv {
 };
 template <typename T> struct BwdConvLds {
   static constexpr bool B16 = sizeof(T) == 2;
-  static constexpr int LF = 64 + 4;                 // fp32 rows read as MFMA A operands
+  static constexpr int LF = 64 + 4;                 // c2 rows (fp32, the ReLU mask of conv3')
   static constexpr int LC1 = 32 + (B16 ? 8 : 0);    // c1 rows (T)
-  static constexpr int LD1 = 32 + 4;                // dc1 rows (fp32)
   static constexpr int IMGP = B16 ? 1 : 2;          // image passes (fp32: two channels at a time)
-  static constexpr int LT = 64 + (B16 ? 8 : 4);     // rows in the compute type, read as whole MFMA fragments
-  static constexpr size_t dc3_b = (size_t)17 * LT * sizeof(T);   // T; + one zero row (taps that fall outside the 4x4 plane)
+  static constexpr int LT = 64 + (B16 ? 8 : 4);     // [pixel][channel] rows in the compute type, read as whole MFMA fragments
+  static constexpr int LP2 = 64 + (B16 ? 8 : 4);    // dc2^T rows [co][pixel 0..63]  (weight-grad operand: 8 pixels = one fragment)
+  static constexpr int LP1 = 256 + (B16 ? 8 : 4);   // dc1^T rows [co][pixel 0..255]
+  static constexpr size_t dc3_b = (size_t)17 * LT * sizeof(T);   // + one zero row (taps that fall outside the 4x4 plane)
   static constexpr size_t c2_b = (size_t)36 * LF * 4;
-  static constexpr size_t dc2_b = (size_t)48 * LF * 4 + (size_t)48 * LT * sizeof(T);  // fp32 (bias sums, dW2 operand) + T copy
-                                                         // (conv2' operand); rows 36..47: zeros (MFMA padding / out-of-plane taps)
+  static constexpr size_t dc2_b = (size_t)48 * LT * sizeof(T);   // conv2' operand; rows 36..47: zeros (MFMA padding / out-of-plane taps)
+  static constexpr size_t dc2T_b = (size_t)64 * LP2 * sizeof(T); // dW2 operand; pixels 36..63: zeros
   static constexpr size_t c1_b = ((size_t)225 * LC1 * sizeof(T) + 15) / 16 * 16;
-  static constexpr size_t dc1_b = (size_t)225 * LD1 * 4;
+  static constexpr size_t dc1_b = (size_t)32 * LP1 * sizeof(T);  // dW1 operand (dc1^T); pixels 225..255: zeros
   static constexpr size_t img_b = (size_t)(4 / IMGP) * 4096 * sizeof(T);
-  static constexpr size_t bytes = dc3_b + c2_b + dc2_b + c1_b + dc1_b + img_b;
+  static constexpr size_t bytes = dc3_b + c2_b + dc2_b + dc2T_b + c1_b + dc1_b + img_b;
 };
 
 // MFMA operand (row = lane&15, 8 consecutive contraction indices 8*(lane>>4)+j) from 8 scalar values
@@ -651,26 +652,30 @@ __global__ __launch_bounds__(512) void bwd_conv_kernel(BwdConv a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   T* sdc3 = reinterpret_cast<T*>(smem);
   float* sc2 = reinterpret_cast<float*>(smem + LY::dc3_b);
-  float* sdc2 = reinterpret_cast<float*>(smem + LY::dc3_b + LY::c2_b);
-  T* sdc2t = reinterpret_cast<T*>(sdc2 + 48 * LY::LF);
-  T* sc1 = reinterpret_cast<T*>(smem + LY::dc3_b + LY::c2_b + LY::dc2_b);
-  float* sdc1 = reinterpret_cast<float*>(smem + LY::dc3_b + LY::c2_b + LY::dc2_b + LY::c1_b);
-  T* simg = reinterpret_cast<T*>(smem + LY::dc3_b + LY::c2_b + LY::dc2_b + LY::c1_b + LY::dc1_b);
+  T* sdc2t = reinterpret_cast<T*>(smem + LY::dc3_b + LY::c2_b);
+  T* sdc2T = reinterpret_cast<T*>(smem + LY::dc3_b + LY::c2_b + LY::dc2_b);
+  constexpr size_t o_c1 = LY::dc3_b + LY::c2_b + LY::dc2_b + LY::dc2T_b;
+  T* sc1 = reinterpret_cast<T*>(smem + o_c1);
+  T* sdc1T = reinterpret_cast<T*>(smem + o_c1 + LY::c1_b);
+  T* simg = reinterpret_cast<T*>(smem + o_c1 + LY::c1_b + LY::dc1_b);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int fr = lane & 15, g = lane >> 4, qr = g * 4;
   // weight-grad tiles of this wave
   const int kt2 = wave * 4;                    // conv2: k-tiles 4w..4w+3 x all 4 co-tiles
-  const int ch1 = wave >> 1, ct1 = wave & 1;   // conv1: input channel ch1 (= k-tiles 4*ch1..+3) x co-tile ct1
-  f32x4 acc2[4][4], acc1[4];
+  const int ch1 = wave >> 1, th1 = wave & 1;   // conv1: input channel ch1, k-tiles 4*ch1 + 2*th1 + {0,1} x both co-tiles
+  f32x4 acc2[4][4], acc1[2][2];
 #pragma unroll
   for (int t = 0; t < 4; ++t) {
 #pragma unroll
     for (int c = 0; c < 4; ++c) acc2[t][c] = f32x4{0.f, 0.f, 0.f, 0.f};
-    acc1[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    acc1[t >> 1][t & 1] = f32x4{0.f, 0.f, 0.f, 0.f};
   }
-  float bias2 = 0.f, bias1 = 0.f;  // per-thread partial column sums of dc2 (co = tid & 63) / dc1 (co = tid & 31)
-  for (int i = tid; i < 12 * LY::LF; i += NTH) sdc2[36 * LY::LF + i] = 0.f;
+  // bias grads: the data-grad epilogues add what they store (fp32, before the rounding to T) into per-lane partial column sums
+  float b2r[4] = {0.f, 0.f, 0.f, 0.f};  // waves 0..3: co = 16*(wave&3) + 4*(lane>>4) + i, partial over the lane's pixels
+  float b1r[4] = {0.f, 0.f, 0.f, 0.f};  // co = 16*(wave&1) + 4*(lane>>4) + i
   for (int i = tid; i < 12 * LY::LT; i += NTH) sdc2t[36 * LY::LT + i] = (T)0.f;
+  for (int i = tid; i < 64 * LY::LP2; i += NTH) sdc2T[i] = (T)0.f;
+  for (int i = tid; i < 32 * LY::LP1; i += NTH) sdc1T[i] = (T)0.f;
   for (int i = tid; i < LY::LT; i += NTH) sdc3[16 * LY::LT + i] = (T)0.f;
   constexpr int CH = 4 / LY::IMGP;  // image channels resident at a time
 
@@ -736,8 +741,10 @@ __global__ __launch_bounds__(512) void bwd_conv_kernel(BwdConv a) {
             const float4 mk = *reinterpret_cast<const float4*>(sc2 + px * LY::LF + c4);
             const float d0 = mk.x > 0.f ? acc[m][0][0] : 0.f, d1 = mk.y > 0.f ? acc[m][0][1] : 0.f;
             const float d2 = mk.z > 0.f ? acc[m][0][2] : 0.f, d3 = mk.w > 0.f ? acc[m][0][3] : 0.f;
-            st4(sdc2 + px * LY::LF + c4, d0, d1, d2, d3);   // fp32: bias sums, dW2's column fragments
-            st4(sdc2t + px * LY::LT + c4, d0, d1, d2, d3);  // T: the A operand of conv2' below
+            st4(sdc2t + px * LY::LT + c4, d0, d1, d2, d3);  // [pixel][co]: the A operand of conv2' below
+            T* tp = sdc2T + c4 * LY::LP2 + px;              // [co][pixel]: dW2's column fragments
+            tp[0] = (T)d0; tp[LY::LP2] = (T)d1; tp[2 * LY::LP2] = (T)d2; tp[3 * LY::LP2] = (T)d3;
+            b2r[0] += d0; b2r[1] += d1; b2r[2] += d2; b2r[3] += d3;
           }
         }
       };
@@ -747,26 +754,13 @@ __global__ __launch_bounds__(512) void bwd_conv_kernel(BwdConv a) {
     }
     __syncthreads();
     CONV_STAMP(2);
-    {  // column sums of dc2: thread (co = tid & 63, part = tid >> 6) takes pixels part, part + 8, ...
-      float t = 0.f;
-      for (int p = tid >> 6; p < 36; p += 8) t += sdc2[p * LY::LF + (tid & 63)];
-      bias2 += t;
-    }
-    // ---- dW2 += dc2^T col(c1): contraction over the 36 output pixels (two K=32 steps)
+    // ---- dW2 += dc2^T col(c1): contraction over the 36 output pixels (two K=32 steps; pixels 36..63 of dc2^T are zeros, so
+    //      the c1 side only has to stay in bounds there)
 #pragma unroll
     for (int st = 0; st < 2; ++st) {
       frag_t fy[4];
 #pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        float v[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          const int pos = st * 32 + g * 8 + j;
-          const float x = sdc2[(pos < 48 ? pos : 0) * LY::LF + c * 16 + fr];
-          v[j] = pos < 36 ? x : 0.f;
-        }
-        fy[c] = frag_of<T>(v);
-      }
+      for (int c = 0; c < 4; ++c) fy[c] = *reinterpret_cast<const frag_t*>(sdc2T + (c * 16 + fr) * LY::LP2 + st * 32 + g * 8);
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
         const int kt = kt2 + t, tap = kt >> 1, ci = (kt & 1) * 16 + fr;
@@ -775,10 +769,8 @@ __global__ __launch_bounds__(512) void bwd_conv_kernel(BwdConv a) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
           const int pos = st * 32 + g * 8 + j;
-          const bool ok = pos < 36;
-          const int pp = ok ? pos : 0, oy = pp / 6, ox = pp - oy * 6;
-          const T x = sc1[((2 * oy + ky) * 15 + 2 * ox + kx) * LY::LC1 + ci];
-          w[j] = ok ? x : (T)0.f;
+          const int pp = pos < 36 ? pos : 0, oy = pp / 6, ox = pp - oy * 6;
+          w[j] = sc1[((2 * oy + ky) * 15 + 2 * ox + kx) * LY::LC1 + ci];
         }
         const frag_t fx = frag_of_t(w);
 #pragma unroll
@@ -807,20 +799,18 @@ __global__ __launch_bounds__(512) void bwd_conv_kernel(BwdConv a) {
           const int p = (py + 2 * ry[m]) * 15 + pxx + 2 * rx[m];
           const int c4 = nh * 16 + qr;
           const float4 mk = ld4(sc1 + p * LY::LC1 + c4);
-          st4(sdc1 + p * LY::LD1 + c4, mk.x > 0.f ? acc[m][0][0] : 0.f, mk.y > 0.f ? acc[m][0][1] : 0.f,
-              mk.z > 0.f ? acc[m][0][2] : 0.f, mk.w > 0.f ? acc[m][0][3] : 0.f);
+          const float d0 = mk.x > 0.f ? acc[m][0][0] : 0.f, d1 = mk.y > 0.f ? acc[m][0][1] : 0.f;
+          const float d2 = mk.z > 0.f ? acc[m][0][2] : 0.f, d3 = mk.w > 0.f ? acc[m][0][3] : 0.f;
+          T* tp = sdc1T + c4 * LY::LP1 + p;  // dc1 exists only as dW1's operand: [co][pixel]
+          tp[0] = (T)d0; tp[LY::LP1] = (T)d1; tp[2 * LY::LP1] = (T)d2; tp[3 * LY::LP1] = (T)d3;
+          b1r[0] += d0; b1r[1] += d1; b1r[2] += d2; b1r[3] += d3;
         }
       }
     }
     __syncthreads();
     CONV_STAMP(4);
-    {  // column sums of dc1: thread (co = tid & 31, part = tid >> 5) takes pixels part, part + 16, ...
-      float t = 0.f;
-      for (int p = tid >> 5; p < 225; p += 16) t += sdc1[p * LY::LD1 + (tid & 31)];
-      bias1 += t;
-    }
     CONV_STAMP(5);
-    // ---- dW1 += dc1^T col(image): contraction over the 225 output pixels (eight K=32 steps)
+    // ---- dW1 += dc1^T col(image): contraction over the 225 output pixels (eight K=32 steps; pixels 225..255 of dc1^T are zeros)
 #pragma unroll 1
     for (int h = 0; h < LY::IMGP; ++h) {
       if (h > 0) {  // fp32 parity mode: the second channel pair replaces the first
@@ -833,29 +823,25 @@ __global__ __launch_bounds__(512) void bwd_conv_kernel(BwdConv a) {
         const T* ich = simg + (ch1 - h * CH) * 4096;
 #pragma unroll 1
         for (int st = 0; st < 8; ++st) {
-          float v[8];
+          frag_t fy[2];
+#pragma unroll
+          for (int c = 0; c < 2; ++c) fy[c] = *reinterpret_cast<const frag_t*>(sdc1T + (c * 16 + fr) * LY::LP1 + st * 32 + g * 8);
           int po2[8];
-          bool okp[8];
 #pragma unroll
           for (int j = 0; j < 8; ++j) {
             const int pos = st * 32 + g * 8 + j;
-            okp[j] = pos < 225;
-            const int pp = okp[j] ? pos : 0, oy = pp / 15, ox = pp - oy * 15;
+            const int pp = pos < 225 ? pos : 0, oy = pp / 15, ox = pp - oy * 15;
             po2[j] = (4 * oy) * 64 + 4 * ox;
-            const float x = sdc1[pp * LY::LD1 + ct1 * 16 + fr];
-            v[j] = okp[j] ? x : 0.f;
           }
-          const frag_t fy = frag_of<T>(v);
 #pragma unroll
-          for (int t = 0; t < 4; ++t) {
-            const int ky = t * 2 + (fr >> 3), kx = fr & 7;
+          for (int tt = 0; tt < 2; ++tt) {
+            const int ky = (th1 * 2 + tt) * 2 + (fr >> 3), kx = fr & 7;
             T w[8];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-              const T x = ich[po2[j] + ky * 64 + kx];
-              w[j] = okp[j] ? x : (T)0.f;
-            }
-            mma_k32(acc1[t], frag_of_t(w), fy);
+            for (int j = 0; j < 8; ++j) w[j] = ich[po2[j] + ky * 64 + kx];
+            const frag_t fx = frag_of_t(w);
+#pragma unroll
+            for (int c = 0; c < 2; ++c) mma_k32(acc1[c][tt], fx, fy[c]);
           }
         }
       }
@@ -873,24 +859,32 @@ __global__ __launch_bounds__(512) void bwd_conv_kernel(BwdConv a) {
             float4{acc2[t][c][0], acc2[t][c][1], acc2[t][c][2], acc2[t][c][3]};
     float* o1 = a.slab1 + (int64_t)blockIdx.x * 32 * 256;
 #pragma unroll
-    for (int t = 0; t < 4; ++t)
-      *reinterpret_cast<float4*>(o1 + (ct1 * 16 + fr) * 256 + (ch1 * 4 + t) * 16 + qr) =
-          float4{acc1[t][0], acc1[t][1], acc1[t][2], acc1[t][3]};
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+      for (int tt = 0; tt < 2; ++tt)
+        *reinterpret_cast<float4*>(o1 + (c * 16 + fr) * 256 + (ch1 * 4 + th1 * 2 + tt) * 16 + qr) =
+            float4{acc1[c][tt][0], acc1[c][tt][1], acc1[c][tt][2], acc1[c][tt][3]};
     __syncthreads();
-    float* red = sdc1;  // 512 + 512 partials
-    red[tid] = bias2;
-    red[NTH + tid] = bias1;
+    float* red2 = reinterpret_cast<float*>(sdc1T);  // [co 64][16 lanes], then [co 32][4 classes x 16 lanes]
+    float* red1 = red2 + 64 * 16;
+    static_assert(LY::dc1_b >= (64 * 16 + 32 * 64) * 4, "bias reduction scratch");
+    if (wave < 4) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) red2[((wave & 3) * 16 + qr + i) * 16 + fr] = b2r[i];
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) red1[((wave & 1) * 16 + qr + i) * 64 + (wave >> 1) * 16 + fr] = b1r[i];
     __syncthreads();
     if (tid < 64) {
       float t = 0.f;
 #pragma unroll
-      for (int k = 0; k < 8; ++k) t += red[k * 64 + tid];
+      for (int k = 0; k < 16; ++k) t += red2[tid * 16 + k];
       a.bslab2[(int64_t)blockIdx.x * 64 + tid] = t;
     }
     if (tid < 32) {
       float t = 0.f;
-#pragma unroll
-      for (int k = 0; k < 16; ++k) t += red[NTH + k * 32 + tid];
+#pragma unroll 8
+      for (int k = 0; k < 64; ++k) t += red1[tid * 64 + k];
       a.bslab1[(int64_t)blockIdx.x * 32 + tid] = t;
     }
   }
