@@ -583,7 +583,9 @@ template <typename T> struct BwdConvLds {
   static constexpr size_t c1_b = ((size_t)225 * LC1 * sizeof(T) + 15) / 16 * 16;
   static constexpr size_t dc1_b = (size_t)32 * LP1 * sizeof(T);  // dW1 operand (dc1^T); pixels 225..255: zeros
   static constexpr size_t img_b = (size_t)(4 / IMGP) * 4096 * sizeof(T);
-  static constexpr size_t bytes = dc3_b + c2_b + dc2_b + dc2T_b + c1_b + dc1_b + img_b;
+  static constexpr size_t w2_b = B16 ? (size_t)4 * 32 * 256 * sizeof(T) : 0;  // conv2' weights, resident in fragment order (bf16 only)
+  static constexpr size_t bytes = dc3_b + c2_b + dc2_b + dc2T_b + c1_b + dc1_b + img_b + w2_b;
+  static_assert(bytes <= 160 * 1024, "one block per CU");
 };
 
 // MFMA operand (row = lane&15, 8 consecutive contraction indices 8*(lane>>4)+j) from 8 scalar values
@@ -658,6 +660,7 @@ __global__ __launch_bounds__(512) void bwd_conv_kernel(BwdConv a) {
   T* sc1 = reinterpret_cast<T*>(smem + o_c1);
   T* sdc1T = reinterpret_cast<T*>(smem + o_c1 + LY::c1_b);
   T* simg = reinterpret_cast<T*>(smem + o_c1 + LY::c1_b + LY::dc1_b);
+  T* sw2 = reinterpret_cast<T*>(smem + o_c1 + LY::c1_b + LY::dc1_b + LY::img_b);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int fr = lane & 15, g = lane >> 4, qr = g * 4;
   // weight-grad tiles of this wave
@@ -677,6 +680,15 @@ __global__ __launch_bounds__(512) void bwd_conv_kernel(BwdConv a) {
   for (int i = tid; i < 64 * LY::LP2; i += NTH) sdc2T[i] = (T)0.f;
   for (int i = tid; i < 32 * LY::LP1; i += NTH) sdc1T[i] = (T)0.f;
   for (int i = tid; i < LY::LT; i += NTH) sdc3[16 * LY::LT + i] = (T)0.f;
+  if constexpr (LY::B16) {
+    // conv2' weights (4 parity classes x [ci 32][K 256]) stay in LDS for the block's whole life, stored as the MFMA fragments
+    // the waves read: [class][ci tile][K step][lane][8] — a wave's fragment is one contiguous, conflict-free 1 KB
+    for (int c = tid; c < 4096; c += NTH) {  // 16-byte chunk c = (class*32 + ci)*32 + k/8
+      const int k8 = c & 31, n = (c >> 5) & 31, cl = c >> 10;
+      const int dst = ((cl * 2 + (n >> 4)) * 8 + (k8 >> 2)) * 64 + (k8 & 3) * 16 + (n & 15);
+      *reinterpret_cast<float4*>(sw2 + dst * 8) = *reinterpret_cast<const float4*>(reinterpret_cast<const T*>(a.w2d[cl]) + n * 256 + k8 * 8);
+    }
+  }
   constexpr int CH = 4 / LY::IMGP;  // image channels resident at a time
 
   constexpr int V = 16 / sizeof(T);  // image elements per 16-byte load
@@ -685,16 +697,9 @@ __global__ __launch_bounds__(512) void bwd_conv_kernel(BwdConv a) {
     CONV_STAMP(0);
     const int64_t slot = a.rowidx != nullptr ? a.rowidx[smp] : smp;
     const T* gimg = reinterpret_cast<const T*>(a.image) + slot * 16384;
-    {  // ---- dc3, c2, c1, image of this sample -> LDS
+    {  // ---- dc3 and c2 of this sample -> LDS (all conv3' needs); c1 and the image follow behind the compute below
       const float* g3 = a.dc3 + (int64_t)smp * 16 * 64;
       const float* g2 = a.c2 + (int64_t)smp * 36 * 64;
-      const float* g1 = a.c1 + (int64_t)smp * 225 * 32;
-      // the image (contiguous, unpadded in LDS) goes global -> LDS directly: four 16-byte DMA transfers per lane, no
-      // staging registers, all in flight together (LDS destination = wave-uniform base + lane * 16)
-#pragma unroll
-      for (int k = 0; k < CH * 4096 / V / NTH; ++k)
-        __builtin_amdgcn_global_load_lds((const V4L_GLOBAL void*)(gimg + (int64_t)(tid + k * NTH) * V),
-                                         (__attribute__((address_space(3))) void*)(simg + ((tid & ~63) + k * NTH) * V), 16, 0, 0);
       if (tid < 256) {
         const int r = tid >> 4, c4 = (tid & 15) * 4;
         const float4 v3 = *reinterpret_cast<const float4*>(g3 + r * 64 + c4);  // dc3 is an MFMA operand only: kept in T
@@ -704,14 +709,25 @@ __global__ __launch_bounds__(512) void bwd_conv_kernel(BwdConv a) {
         const int r = i4 >> 4, c4 = (i4 & 15) * 4;
         *reinterpret_cast<float4*>(sc2 + r * LY::LF + c4) = *reinterpret_cast<const float4*>(g2 + r * 64 + c4);
       }
-      for (int i4 = tid; i4 < 225 * 8; i4 += NTH) {
-        const int r = i4 >> 3, c4 = (i4 & 7) * 4;
-        const float4 v = *reinterpret_cast<const float4*>(g1 + r * 32 + c4);
-        st4(sc1 + r * LY::LC1 + c4, v.x, v.y, v.z, v.w);
-      }
     }
     __syncthreads();
     CONV_STAMP(1);
+    if (wave >= 4) {  // ---- waves 4..7 bring c1 in (fp32 -> T) while waves 0..3 run conv3' (vmcnt is per wave: their weight
+                      //      stream does not queue behind these loads)
+      const float* g1 = a.c1 + (int64_t)smp * 225 * 32;
+      constexpr int N4 = 225 * 8, PT = (N4 + 255) / 256;
+      float4 v[PT];
+#pragma unroll
+      for (int k = 0; k < PT; ++k) {
+        const int i4 = tid - 256 + k * 256;
+        v[k] = *reinterpret_cast<const float4*>(g1 + (i4 < N4 ? i4 : 0) * 4);
+      }
+#pragma unroll
+      for (int k = 0; k < PT; ++k) {
+        const int i4 = tid - 256 + k * 256;
+        if (i4 < N4) st4(sc1 + (i4 >> 3) * LY::LC1 + (i4 & 7) * 4, v[k].x, v[k].y, v[k].z, v[k].w);
+      }
+    } else
     {  // ---- dc2 = conv3' (gather form): rows = 36 input pixels (3 row tiles), K = 9 taps x 64 co, N = 64 ci
       const int nt = wave & 3;
       const T* W = reinterpret_cast<const T*>(a.w3d);
@@ -748,12 +764,18 @@ __global__ __launch_bounds__(512) void bwd_conv_kernel(BwdConv a) {
           }
         }
       };
-      // waves 0..3 own one ci tile each for all three row tiles: the 72 KB of w3' enter the CU once per sample (two waves
+      // waves 0..3 (this branch) own one ci tile each for all three row tiles: the 72 KB of w3' enter the CU once per sample (two waves
       // per ci tile, splitting the row tiles, streamed them twice — and the phase is bound by exactly that stream)
-      if (wave < 4) run(std::integral_constant<int, 3>{}, 0);
+      run(std::integral_constant<int, 3>{}, 0);
     }
     __syncthreads();
     CONV_STAMP(2);
+    // the image (contiguous, unpadded in LDS) goes global -> LDS directly: four 16-byte DMA transfers per lane, no staging
+    // registers (LDS destination = wave-uniform base + lane * 16). Issued here, it lands while dW2 and conv2' run out of LDS.
+#pragma unroll
+    for (int k = 0; k < CH * 4096 / V / NTH; ++k)
+      __builtin_amdgcn_global_load_lds((const V4L_GLOBAL void*)(gimg + (int64_t)(tid + k * NTH) * V),
+                                       (__attribute__((address_space(3))) void*)(simg + ((tid & ~63) + k * NTH) * V), 16, 0, 0);
     // ---- dW2 += dc2^T col(c1): contraction over the 36 output pixels (two K=32 steps; pixels 36..63 of dc2^T are zeros, so
     //      the c1 side only has to stay in bounds there)
 #pragma unroll
@@ -788,11 +810,23 @@ __global__ __launch_bounds__(512) void bwd_conv_kernel(BwdConv a) {
       f32x4 acc[4][1];
 #pragma unroll
       for (int m = 0; m < 4; ++m) acc[m][0] = f32x4{0.f, 0.f, 0.f, 0.f};
-      gather_gemm<T, 4, 1, 8>(acc, reinterpret_cast<const T*>(a.w2d[cls]), 256, nh, lane, [&](int m, int tap) -> const T* {
+      auto arow = [&](int m, int tap) -> const T* {
         const int oy = ry[m] - (tap >> 1), ox = rx[m] - (tap & 1);
         const bool ok = ry[m] < nIy && rx[m] < nIx && oy >= 0 && oy < 6 && ox >= 0 && ox < 6;
         return sdc2t + (ok ? oy * 6 + ox : 36) * LY::LT;
-      });
+      };
+      if constexpr (LY::B16) {  // weights resident in LDS
+        const T* wl = sw2 + (cls * 2 + nh) * 8 * 512 + lane * 8;
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) {
+          const frag_t fw = *reinterpret_cast<const frag_t*>(wl + ks * 512);
+#pragma unroll
+          for (int m = 0; m < 4; ++m)
+            mma_k32(acc[m][0], fw, *reinterpret_cast<const frag_t*>(arow(m, ks >> 1) + (ks & 1) * 32 + g * 8));
+        }
+      } else {
+        gather_gemm<T, 4, 1, 8>(acc, reinterpret_cast<const T*>(a.w2d[cls]), 256, nh, lane, arow);
+      }
 #pragma unroll
       for (int m = 0; m < 4; ++m) {
         if (ry[m] < nIy && rx[m] < nIx) {
