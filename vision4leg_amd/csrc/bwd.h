@@ -608,15 +608,15 @@ __device__ __forceinline__ bf16x8 frag_of_t(const __bf16 (&v)[8]) {
 }
 __device__ __forceinline__ f32x8 frag_of_t(const float (&v)[8]) { return frag_of<float>(v); }
 
-// Gather-form data-grad GEMM of one wave: acc[mt][j] += A(mt, ks) * W[row = (nt0 + j)*16 + lane&15][ks*32 ..]^T over KS
-// K=32 steps, where the A fragment of (row tile mt, step ks) comes from the LDS row (compute type T) arow(mt, ks >> 1) (64 channels = two
+// Gather-form data-grad GEMM of one wave: acc[mt][j] += A(mt, ks) * W[row = (nt0 + j)*16 + lane&15][ks*32 ..]^T over the KS
+// K=32 steps starting at KS0, where the A fragment of (row tile mt, step ks) comes from the LDS row (compute type T) arow(mt, ks >> 1) (64 channels = two
 // steps per tap) and feeds NT column tiles. Weight fragments stream from L2 through a ring of PD steps, like block_gemm.
-template <typename T, int MT, int NT, int KS, class RowF>
+template <typename T, int MT, int NT, int KS, int KS0 = 0, int PDEPTH = 4, class RowF>
 __device__ __forceinline__ void gather_gemm(f32x4 (&acc)[MT][NT], const T* __restrict__ W, int Kp, int nt0, int lane, RowF arow) {
   typedef typename Frag<T>::type frag_t;
-  constexpr int PD = NT >= 2 ? 2 : (KS < 4 ? KS : 4);
+  constexpr int PD = NT >= 2 ? 2 : (KS < PDEPTH ? KS : PDEPTH);
   const int fr = lane & 15, fg = (lane >> 4) * 8;
-  const T* wrow = W + (int64_t)(nt0 * 16 + fr) * Kp + fg;
+  const T* wrow = W + (int64_t)(nt0 * 16 + fr) * Kp + fg + KS0 * 32;  // this call covers K steps KS0 .. KS0 + KS - 1
   frag_t fb[PD][NT];
 #pragma unroll
   for (int d = 0; d < PD; ++d)
@@ -633,7 +633,7 @@ __device__ __forceinline__ void gather_gemm(f32x4 (&acc)[MT][NT], const T* __res
     }
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
-      const frag_t fa = *reinterpret_cast<const frag_t*>(arow(mt, ks >> 1) + (ks & 1) * 32 + fg);  // rows already in T
+      const frag_t fa = *reinterpret_cast<const frag_t*>(arow(mt, (ks + KS0) >> 1) + ((ks + KS0) & 1) * 32 + fg);  // rows already in T
 #pragma unroll
       for (int j = 0; j < NT; ++j)
         mma_k32(acc[mt][j], cur[j], fa);  // transposed tile: acc[mt][j][r] = out[16*mt + lane&15][16*(nt0+j) + 4*(lane>>4) + r]
@@ -692,81 +692,90 @@ __global__ __launch_bounds__(512) void bwd_conv_kernel(BwdConv a) {
   constexpr int CH = 4 / LY::IMGP;  // image channels resident at a time
 
   constexpr int V = 16 / sizeof(T);  // image elements per 16-byte load
+  // dc3 [16][64], c2 [36][64] and c1 [225][32] of a sample are requested under the PREVIOUS sample's dW1 (the CU's fetch path is
+  // idle there: that phase runs out of LDS) and filed into LDS right after it — their readers (conv3', dW2, conv2''s mask) are
+  // done by then. 256 + 576 float4 of dc3 / c2: every thread takes c2 chunk tid, waves 4..7 dc3 chunk tid - 256, wave 0 the
+  // last 64 c2 chunks; c1: 1800 float4, chunk tid + 512 k.
+  constexpr int N4 = 225 * 8, PT = (N4 + NTH - 1) / NTH;
+  float4 hv0 = float4{0.f, 0.f, 0.f, 0.f}, hv1 = hv0, cv[PT];
+  auto load_next = [&](int sm) {
+    const float* g3 = a.dc3 + (int64_t)sm * 16 * 64;
+    const float* g2 = a.c2 + (int64_t)sm * 36 * 64;
+    const float* g1 = a.c1 + (int64_t)sm * 225 * 32;
+    hv0 = *reinterpret_cast<const float4*>(g2 + tid * 4);
+    if (tid >= 256) hv1 = *reinterpret_cast<const float4*>(g3 + (tid - 256) * 4);
+    else if (tid < 64) hv1 = *reinterpret_cast<const float4*>(g2 + (512 + tid) * 4);
+#pragma unroll
+    for (int k = 0; k < PT; ++k) {
+      const int i4 = tid + k * NTH;
+      cv[k] = *reinterpret_cast<const float4*>(g1 + (i4 < N4 ? i4 : 0) * 4);
+    }
+  };
+  auto store_next = [&]() {
+    *reinterpret_cast<float4*>(sc2 + (tid >> 4) * LY::LF + (tid & 15) * 4) = hv0;
+    if (tid >= 256) st4(sdc3 + ((tid - 256) >> 4) * LY::LT + (tid & 15) * 4, hv1.x, hv1.y, hv1.z, hv1.w);  // dc3: MFMA operand only, kept in T
+    else if (tid < 64) *reinterpret_cast<float4*>(sc2 + (32 + (tid >> 4)) * LY::LF + (tid & 15) * 4) = hv1;
+#pragma unroll
+    for (int k = 0; k < PT; ++k) {
+      const int i4 = tid + k * NTH;
+      if (i4 < N4) st4(sc1 + (i4 >> 3) * LY::LC1 + (i4 & 7) * 4, cv[k].x, cv[k].y, cv[k].z, cv[k].w);
+    }
+  };
+  if ((int)blockIdx.x < a.n) { load_next(blockIdx.x); store_next(); }
   for (int smp = blockIdx.x; smp < a.n; smp += gridDim.x) {
     __syncthreads();  // previous sample's readers are done
     CONV_STAMP(0);
     const int64_t slot = a.rowidx != nullptr ? a.rowidx[smp] : smp;
     const T* gimg = reinterpret_cast<const T*>(a.image) + slot * 16384;
-    {  // ---- dc3 and c2 of this sample -> LDS (all conv3' needs); c1 and the image follow behind the compute below
-      const float* g3 = a.dc3 + (int64_t)smp * 16 * 64;
-      const float* g2 = a.c2 + (int64_t)smp * 36 * 64;
-      if (tid < 256) {
-        const int r = tid >> 4, c4 = (tid & 15) * 4;
-        const float4 v3 = *reinterpret_cast<const float4*>(g3 + r * 64 + c4);  // dc3 is an MFMA operand only: kept in T
-        st4(sdc3 + r * LY::LT + c4, v3.x, v3.y, v3.z, v3.w);
-      }
-      for (int i4 = tid; i4 < 36 * 16; i4 += NTH) {
-        const int r = i4 >> 4, c4 = (i4 & 15) * 4;
-        *reinterpret_cast<float4*>(sc2 + r * LY::LF + c4) = *reinterpret_cast<const float4*>(g2 + r * 64 + c4);
-      }
-    }
-    __syncthreads();
     CONV_STAMP(1);
-    if (wave >= 4) {  // ---- waves 4..7 bring c1 in (fp32 -> T) while waves 0..3 run conv3' (vmcnt is per wave: their weight
-                      //      stream does not queue behind these loads)
-      const float* g1 = a.c1 + (int64_t)smp * 225 * 32;
-      constexpr int N4 = 225 * 8, PT = (N4 + 255) / 256;
-      float4 v[PT];
-#pragma unroll
-      for (int k = 0; k < PT; ++k) {
-        const int i4 = tid - 256 + k * 256;
-        v[k] = *reinterpret_cast<const float4*>(g1 + (i4 < N4 ? i4 : 0) * 4);
-      }
-#pragma unroll
-      for (int k = 0; k < PT; ++k) {
-        const int i4 = tid - 256 + k * 256;
-        if (i4 < N4) st4(sc1 + (i4 >> 3) * LY::LC1 + (i4 & 7) * 4, v[k].x, v[k].y, v[k].z, v[k].w);
-      }
-    } else
     {  // ---- dc2 = conv3' (gather form): rows = 36 input pixels (3 row tiles), K = 9 taps x 64 co, N = 64 ci
+      //      wave pair (w, w + 4) owns ci tile w & 3 for all three row tiles and splits the 18 K steps in halves: the 72 KB of
+      //      w3' enter the CU once per sample, nine 1 KB fragments per wave, all in flight together. (Splitting the ROW tiles
+      //      between the pair streamed every fragment twice, and this phase is bound by exactly that stream.)
       const int nt = wave & 3;
       const T* W = reinterpret_cast<const T*>(a.w3d);
-      auto run = [&](auto mt_tag, int mt0) {
-        constexpr int MT = decltype(mt_tag)::value;
-        int iy[MT], ix[MT];
-        bool okr[MT];
+      int iy[3], ix[3];
+      bool okr[3];
 #pragma unroll
-        for (int m = 0; m < MT; ++m) {
-          const int px = (mt0 + m) * 16 + fr;
-          okr[m] = px < 36;
-          iy[m] = px / 6; ix[m] = px - iy[m] * 6;
-        }
-        f32x4 acc[MT][1];
+      for (int m = 0; m < 3; ++m) {
+        const int px = m * 16 + fr;
+        okr[m] = px < 36;
+        iy[m] = px / 6; ix[m] = px - iy[m] * 6;
+      }
+      f32x4 acc[3][1];
 #pragma unroll
-        for (int m = 0; m < MT; ++m) acc[m][0] = f32x4{0.f, 0.f, 0.f, 0.f};
-        gather_gemm<T, MT, 1, 18>(acc, W, 576, nt, lane, [&](int m, int tap) -> const T* {
-          const int ta = tap / 3, tb = tap - ta * 3;
-          const int oy = iy[m] - ta, ox = ix[m] - tb;
-          const bool ok = okr[m] && oy >= 0 && oy < 4 && ox >= 0 && ox < 4;
-          return sdc3 + (ok ? oy * 4 + ox : 16) * LY::LT;
-        });
+      for (int m = 0; m < 3; ++m) acc[m][0] = f32x4{0.f, 0.f, 0.f, 0.f};
+      auto arow = [&](int m, int tap) -> const T* {
+        const int ta = tap / 3, tb = tap - ta * 3;
+        const int oy = iy[m] - ta, ox = ix[m] - tb;
+        const bool ok = okr[m] && oy >= 0 && oy < 4 && ox >= 0 && ox < 4;
+        return sdc3 + (ok ? oy * 4 + ox : 16) * LY::LT;
+      };
+      float4* part = reinterpret_cast<float4*>(simg);  // the image buffer is free until the DMA below
+      if (wave >= 4) {
+        gather_gemm<T, 3, 1, 9, 9, LY::B16 ? 9 : 3>(acc, W, 576, nt, lane, arow);
 #pragma unroll
-        for (int m = 0; m < MT; ++m) {
-          const int px = (mt0 + m) * 16 + fr, c4 = nt * 16 + qr;
+        for (int m = 0; m < 3; ++m) part[(nt * 3 + m) * 64 + lane] = float4{acc[m][0][0], acc[m][0][1], acc[m][0][2], acc[m][0][3]};
+      } else {
+        gather_gemm<T, 3, 1, 9, 0, LY::B16 ? 9 : 3>(acc, W, 576, nt, lane, arow);
+      }
+      __syncthreads();
+      if (wave < 4) {
+#pragma unroll
+        for (int m = 0; m < 3; ++m) {
+          const int px = m * 16 + fr, c4 = nt * 16 + qr;
           if (px < 36) {
+            const float4 hi = part[(nt * 3 + m) * 64 + lane];
             const float4 mk = *reinterpret_cast<const float4*>(sc2 + px * LY::LF + c4);
-            const float d0 = mk.x > 0.f ? acc[m][0][0] : 0.f, d1 = mk.y > 0.f ? acc[m][0][1] : 0.f;
-            const float d2 = mk.z > 0.f ? acc[m][0][2] : 0.f, d3 = mk.w > 0.f ? acc[m][0][3] : 0.f;
+            const float d0 = mk.x > 0.f ? acc[m][0][0] + hi.x : 0.f, d1 = mk.y > 0.f ? acc[m][0][1] + hi.y : 0.f;
+            const float d2 = mk.z > 0.f ? acc[m][0][2] + hi.z : 0.f, d3 = mk.w > 0.f ? acc[m][0][3] + hi.w : 0.f;
             st4(sdc2t + px * LY::LT + c4, d0, d1, d2, d3);  // [pixel][co]: the A operand of conv2' below
             T* tp = sdc2T + c4 * LY::LP2 + px;              // [co][pixel]: dW2's column fragments
             tp[0] = (T)d0; tp[LY::LP2] = (T)d1; tp[2 * LY::LP2] = (T)d2; tp[3 * LY::LP2] = (T)d3;
             b2r[0] += d0; b2r[1] += d1; b2r[2] += d2; b2r[3] += d3;
           }
         }
-      };
-      // waves 0..3 (this branch) own one ci tile each for all three row tiles: the 72 KB of w3' enter the CU once per sample (two waves
-      // per ci tile, splitting the row tiles, streamed them twice — and the phase is bound by exactly that stream)
-      run(std::integral_constant<int, 3>{}, 0);
+      }
     }
     __syncthreads();
     CONV_STAMP(2);
@@ -844,6 +853,8 @@ __global__ __launch_bounds__(512) void bwd_conv_kernel(BwdConv a) {
     __syncthreads();
     CONV_STAMP(4);
     CONV_STAMP(5);
+    const bool more = smp + (int)gridDim.x < a.n;
+    if (more) load_next(smp + gridDim.x);  // next sample's dc3 / c2 / c1: in flight under dW1
     // ---- dW1 += dc1^T col(image): contraction over the 225 output pixels (eight K=32 steps; pixels 225..255 of dc1^T are zeros)
 #pragma unroll 1
     for (int h = 0; h < LY::IMGP; ++h) {
@@ -880,6 +891,7 @@ __global__ __launch_bounds__(512) void bwd_conv_kernel(BwdConv a) {
         }
       }
     }
+    if (more) store_next();
     CONV_STAMP(6);
   }
   // ---- the block's partial weight-grads -> its slab (wgrad_reduce_kernel sums the slabs in a fixed order)
