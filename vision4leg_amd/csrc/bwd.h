@@ -51,7 +51,20 @@ template <typename T, int SPW> struct BwdLayLds {
   static constexpr size_t big_b = qkv_b > f_b ? qkv_b : f_b;
   static constexpr size_t p_b = (size_t)2 * SPW * NTOK * ATT_PLD * 4;  // P and dS of the block's samples
   static constexpr size_t red_b = (size_t)2 * 16 * TD * 4;
-  static constexpr size_t bytes = 2 * a_b + big_b + p_b + red_b;     // a | b | df / qkv->dqkv | P,dS | LN partials [2][16 quarter waves][64]
+  // bf16: the attention backward runs on MFMA tiles; every sample (= wave) owns 32 KB of operands in T, laid out so that each
+  // fragment is one 16-byte LDS read (the contraction index is contiguous): dctx [tok][64] and V [tok][64] for dP = dctx V^T,
+  // dctx^T / K^T / Q^T [64][tok] and dS, dS^T, P^T [tok][tok] for dV = P^T dctx, dQ = dS K, dK = dS^T Q. The dq | dk | dv rows
+  // (operand of the in_proj data-grad) then take the place of dctx / V. The region is a union with a | big | P,dS.
+  static constexpr bool MFMA_ATT = sizeof(T) == 2;
+  static constexpr int LDA = 64 + 8, LDK = 32 + 8, LDR = 192 + 8;
+  static constexpr size_t o_dc = 0, o_v = o_dc + (size_t)32 * LDA * 2, o_dct = o_v + (size_t)32 * LDA * 2;
+  static constexpr size_t o_kt = o_dct + (size_t)64 * LDK * 2, o_qt = o_kt + (size_t)64 * LDK * 2, o_ds = o_qt + (size_t)64 * LDK * 2;
+  static constexpr size_t o_dst = o_ds + (size_t)32 * LDK * 2, o_pt = o_dst + (size_t)32 * LDK * 2, att_w = 32768;
+  static_assert(o_pt + (size_t)32 * LDK * 2 <= att_w && (size_t)18 * LDR * 2 <= o_dct, "attention operand block");
+  static constexpr size_t att_b = MFMA_ATT ? (size_t)SPW * att_w : 0;
+  static constexpr size_t uni_b = a_b + big_b + p_b > att_b ? a_b + big_b + p_b : att_b;
+  static constexpr size_t bytes = a_b + red_b + uni_b;  // b | LN partials [2][16 quarter waves][64] | { a | df / qkv->dqkv | P,dS } U attention blocks
+  static_assert(bytes <= 160 * 1024, "one block per CU");
 };
 
 // LayerNorm backward, in place over the ROWS LDS rows of `d` (rows >= nrows hold zeros and stay zero); the rows < nrows
@@ -137,11 +150,17 @@ __global__ __launch_bounds__(256) void bwd_layer_kernel(BwdLayer w, BwdHead hd, 
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int fr = lane & 15, qr = (lane >> 4) * 4;
-  float* a = reinterpret_cast<float*>(smem);                         // dy -> dz2 -> dctx
-  float* b = reinterpret_cast<float*>(smem + LY::a_b);               // dx1 -> dz1
-  float* big = reinterpret_cast<float*>(smem + 2 * LY::a_b);         // df (T) -> qkv -> dqkv (fp32)
-  float* sp = reinterpret_cast<float*>(smem + 2 * LY::a_b + LY::big_b);
-  float* red = reinterpret_cast<float*>(smem + 2 * LY::a_b + LY::big_b + LY::p_b);
+  float* b = reinterpret_cast<float*>(smem);                         // dx1 -> dz1
+  float* red = reinterpret_cast<float*>(smem + LY::a_b);
+  unsigned char* att = smem + LY::a_b + LY::red_b;                   // bf16: per-sample attention operand blocks (union with a | big | sp)
+  float* a = reinterpret_cast<float*>(att);                          // dy -> dz2 -> dctx (fp32 mode)
+  float* big = reinterpret_cast<float*>(att + LY::a_b);              // df (T) -> qkv -> dqkv (fp32 mode)
+  float* sp = reinterpret_cast<float*>(att + LY::a_b + LY::big_b);   // P, dS (fp32 mode)
+  (void)sp;
+  // TAIL: dx_in rows for the encoder-side data-grads. fp32 mode: `a` (dctx is dead by then); bf16: the other waves may still be
+  // reading dq | dk | dv out of sample 0's block, so the rows go behind sample 1's (dead: its attention is done)
+  float* at = LY::MFMA_ATT ? reinterpret_cast<float*>(att + LY::att_w + LY::o_dct) : a;
+  (void)at;
   LAY_STAMP(0);
   const int s0 = blockIdx.x * SPW;
   const int ns = min(SPW, n - s0);
@@ -277,6 +296,8 @@ __global__ __launch_bounds__(256) void bwd_layer_kernel(BwdLayer w, BwdHead hd, 
   constexpr int QV = (ROWS * 48 + 255) / 256, PV = (SPW * NTOK * NTOK + 255) / 256;
   float4 qpre[QV];
   float ppre[PV];
+  float pp[2][2][4];
+  (void)ppre; (void)pp;
   {
     const float* qg = w.s_qkv + row0 * 192;
 #pragma unroll
@@ -287,11 +308,26 @@ __global__ __launch_bounds__(256) void bwd_layer_kernel(BwdLayer w, BwdHead hd, 
       const float4 v = *reinterpret_cast<const float4*>(qg + (ok ? r * 192 + c4 : 0));
       qpre[k] = ok ? v : float4{0.f, 0.f, 0.f, 0.f};
     }
-    const float* pg = w.s_P + (int64_t)s0 * NTOK * NTOK;
+    if constexpr (LY::MFMA_ATT) {  // P of sample `wave`, as the dP accumulator tiles will hold it: row 16 m + fr, columns 16 nn + qr + r
+      const float* pg = w.s_P + (int64_t)(s0 + (wave < ns ? wave : 0)) * NTOK * NTOK;
 #pragma unroll
-    for (int k = 0; k < PV; ++k) {
-      const int idx = tid + k * 256;
-      ppre[k] = pg[idx < ns * NTOK * NTOK ? idx : 0];
+      for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int nn = 0; nn < 2; ++nn)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int i = m * 16 + fr, j = nn * 16 + qr + r;
+            const bool ok = i < NTOK && j < NTOK && wave < ns;
+            const float v = pg[ok ? i * NTOK + j : 0];
+            pp[m][nn][r] = ok ? v : 0.f;
+          }
+    } else {
+      const float* pg = w.s_P + (int64_t)s0 * NTOK * NTOK;
+#pragma unroll
+      for (int k = 0; k < PV; ++k) {
+        const int idx = tid + k * 256;
+        ppre[k] = pg[idx < ns * NTOK * NTOK ? idx : 0];
+      }
     }
   }
   const LnPre<ROWS> pre1 = ln_bwd_fetch<ROWS>(w.s_xh1 + row0 * TD, w.s_rs1 + row0, w.g1, wave, lane, nrows);
@@ -310,7 +346,34 @@ __global__ __launch_bounds__(256) void bwd_layer_kernel(BwdLayer w, BwdHead hd, 
   __syncthreads();
   LAY_STAMP(4);
   // park -> LDS (`big` is free: df was consumed by the dx1 GEMM)
-  {
+  if constexpr (LY::MFMA_ATT) {
+    // contraction columns 17..31 of dctx^T / K^T / Q^T meet exact zeros of dS / dS^T / P^T: they only have to be finite.
+    // Zeroed without touching column 16 (2 + 4 + 8 + 16 bytes), so no ordering against the data writes is needed.
+    for (int rr = tid; rr < ns * 3 * 64; rr += 256) {
+      const int sm = rr / 192, q = rr - sm * 192;  // q = matrix * 64 + row: dctx^T, K^T, Q^T are consecutive
+      T* row = reinterpret_cast<T*>(att + (size_t)sm * LY::att_w + LY::o_dct) + q * LY::LDK;
+      row[17] = (T)0.f;
+      *reinterpret_cast<uint32_t*>(row + 18) = 0u;
+      *reinterpret_cast<uint2*>(row + 20) = uint2{0u, 0u};
+      *reinterpret_cast<uint4*>(row + 24) = uint4{0u, 0u, 0u, 0u};
+    }
+#pragma unroll
+    for (int k = 0; k < QV; ++k) {
+      const int i4 = tid + k * 256;
+      const int r = i4 / 48, c4 = (i4 - r * 48) * 4;
+      const int sm = r / NTOK, t = r - sm * NTOK;
+      if (i4 < ROWS * 48 && r < nrows) {  // q, k: transposed ([feature][token]); v: as stored. Rounded to T here, once.
+        unsigned char* aw = att + (size_t)sm * LY::att_w;
+        const float4 v = qpre[k];
+        if (c4 < 128) {
+          T* col = reinterpret_cast<T*>(aw + (c4 < 64 ? LY::o_qt : LY::o_kt)) + (c4 & 63) * LY::LDK + t;
+          col[0] = (T)v.x; col[LY::LDK] = (T)v.y; col[2 * LY::LDK] = (T)v.z; col[3 * LY::LDK] = (T)v.w;
+        } else {
+          st4(reinterpret_cast<T*>(aw + LY::o_v) + t * LY::LDA + (c4 - 128), v.x, v.y, v.z, v.w);
+        }
+      }
+    }
+  } else {
 #pragma unroll
     for (int k = 0; k < QV; ++k) {
       const int i4 = tid + k * 256;
@@ -341,8 +404,19 @@ __global__ __launch_bounds__(256) void bwd_layer_kernel(BwdLayer w, BwdHead hd, 
     block_gemm<T, MT, 1, 2>(acc, b, LY::LDX, (const T*)w.wot, 64, nt1, lane, ring_dctx);
     const int n4 = wave * 16 + qr;
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt)  // dctx is an operand of the attention products only: kept rounded to T
-      st4(a + (mt * 16 + fr) * LY::LDX + n4, rt<T>(acc[mt][0][0]), rt<T>(acc[mt][0][1]), rt<T>(acc[mt][0][2]), rt<T>(acc[mt][0][3]));
+    for (int mt = 0; mt < MT; ++mt) {  // dctx is an operand of the attention products only: kept rounded to T
+      if constexpr (LY::MFMA_ATT) {
+        const int row = mt * 16 + fr, sm = row / NTOK, t = row - sm * NTOK;
+        if (row < nrows) {  // [token][feature] for dP, [feature][token] for dV
+          unsigned char* aw = att + (size_t)sm * LY::att_w;
+          st4(reinterpret_cast<T*>(aw + LY::o_dc) + t * LY::LDA + n4, acc[mt][0][0], acc[mt][0][1], acc[mt][0][2], acc[mt][0][3]);
+          T* col = reinterpret_cast<T*>(aw + LY::o_dct) + n4 * LY::LDK + t;
+          col[0] = (T)acc[mt][0][0]; col[LY::LDK] = (T)acc[mt][0][1]; col[2 * LY::LDK] = (T)acc[mt][0][2]; col[3 * LY::LDK] = (T)acc[mt][0][3];
+        }
+      } else {
+        st4(a + (mt * 16 + fr) * LY::LDX + n4, rt<T>(acc[mt][0][0]), rt<T>(acc[mt][0][1]), rt<T>(acc[mt][0][2]), rt<T>(acc[mt][0][3]));
+      }
+    }
   }
   __syncthreads();
   LAY_STAMP(6);
@@ -377,7 +451,106 @@ __global__ __launch_bounds__(256) void bwd_layer_kernel(BwdLayer w, BwdHead hd, 
     ring_up = gemm_prefetch<T, 1, 2>((const T*)tl.wupt, 64, nt1, lane);
     ring_pr = gemm_prefetch<T, 4, 2>((const T*)tl.wpt, 64, nt4, lane);
   }
-  {
+  if constexpr (LY::MFMA_ATT) {
+    typedef typename Frag<T>::type frag_t;
+    if (wave < ns) {  // one wave = one sample, on MFMA tiles out of its own operand block (no block-level sync inside)
+      unsigned char* aw = att + (size_t)wave * LY::att_w;
+      const T* dC = reinterpret_cast<const T*>(aw + LY::o_dc);
+      const T* Vv = reinterpret_cast<const T*>(aw + LY::o_v);
+      const T* dCt = reinterpret_cast<const T*>(aw + LY::o_dct);
+      const T* Kt = reinterpret_cast<const T*>(aw + LY::o_kt);
+      const T* Qt = reinterpret_cast<const T*>(aw + LY::o_qt);
+      T* dS = reinterpret_cast<T*>(aw + LY::o_ds);
+      T* dSt = reinterpret_cast<T*>(aw + LY::o_dst);
+      T* Pt = reinterpret_cast<T*>(aw + LY::o_pt);
+      const int fg = (lane >> 4) * 8;
+      f32x4 ap[2][2];  // dP[i = 16 m + fr][j = 16 nn + qr + r] = sum_d dctx[i][d] V[j][d]
+#pragma unroll
+      for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int nn = 0; nn < 2; ++nn) ap[m][nn] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        frag_t fa[2], fb[2];
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+          fa[m] = *reinterpret_cast<const frag_t*>(dC + (m * 16 + fr) * LY::LDA + ks * 32 + fg);
+          fb[m] = *reinterpret_cast<const frag_t*>(Vv + (m * 16 + fr) * LY::LDA + ks * 32 + fg);
+        }
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+          for (int nn = 0; nn < 2; ++nn) mma_k32(ap[m][nn], fb[nn], fa[m]);
+      }
+      // softmax': dS = P o (dP - rowsum(P o dP)); rows / columns >= 17 of the tiles are padding (their dP may be anything:
+      // selected away, never multiplied). dS and P leave rounded to T: operands of the three products below only.
+#pragma unroll
+      for (int m = 0; m < 2; ++m) {
+        const int i = m * 16 + fr;
+        float rd = 0.f;
+#pragma unroll
+        for (int nn = 0; nn < 2; ++nn)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const bool ok = i < NTOK && nn * 16 + qr + r < NTOK;
+            rd = fmaf(pp[m][nn][r], ok ? ap[m][nn][r] : 0.f, rd);
+          }
+        rd += __shfl_xor(rd, 16, 64);
+        rd += __shfl_xor(rd, 32, 64);
+#pragma unroll
+        for (int nn = 0; nn < 2; ++nn) {
+          float d[4];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const bool ok = i < NTOK && nn * 16 + qr + r < NTOK;
+            d[r] = ok ? pp[m][nn][r] * (ap[m][nn][r] - rd) : 0.f;
+          }
+          const int j0 = nn * 16 + qr;
+          st4(dS + i * LY::LDK + j0, d[0], d[1], d[2], d[3]);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            dSt[(j0 + r) * LY::LDK + i] = (T)d[r];
+            Pt[(j0 + r) * LY::LDK + i] = (T)pp[m][nn][r];
+          }
+        }
+      }
+      // dq | dk | dv rows of this sample ([17][LDR] in T + one zero row for the padding rows of the GEMM below) over dctx / V,
+      // which the dP tiles have consumed
+      T* R = reinterpret_cast<T*>(aw);
+      if (lane < LY::LDR * 2 / 16) *reinterpret_cast<uint4*>(R + NTOK * LY::LDR + lane * 8) = uint4{0u, 0u, 0u, 0u};
+      T* og = reinterpret_cast<T*>(w.o_dqkv) + (row0 + wave * NTOK) * 192;
+      auto product = [&](const T* A, const T* B, float scale, int coff) {  // out[x][d] = scale * sum_y A[x][y] B[d][y]
+        f32x4 acc[2][4];
+        frag_t fa[2], fb[4];
+#pragma unroll
+        for (int m = 0; m < 2; ++m) fa[m] = *reinterpret_cast<const frag_t*>(A + (m * 16 + fr) * LY::LDK + fg);
+#pragma unroll
+        for (int nn = 0; nn < 4; ++nn) fb[nn] = *reinterpret_cast<const frag_t*>(B + (nn * 16 + fr) * LY::LDK + fg);
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+          for (int nn = 0; nn < 4; ++nn) {
+            acc[m][nn] = f32x4{0.f, 0.f, 0.f, 0.f};
+            mma_k32(acc[m][nn], fb[nn], fa[m]);
+          }
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+          const int x = m * 16 + fr;
+          if (x < NTOK) {
+#pragma unroll
+            for (int nn = 0; nn < 4; ++nn) {
+              const float v0 = acc[m][nn][0] * scale, v1 = acc[m][nn][1] * scale, v2 = acc[m][nn][2] * scale, v3 = acc[m][nn][3] * scale;
+              st4(R + x * LY::LDR + coff + nn * 16 + qr, v0, v1, v2, v3);
+              st4(og + x * 192 + coff + nn * 16 + qr, v0, v1, v2, v3);
+            }
+          }
+        }
+      };
+      product(dS, Kt, 0.125f, 0);        // dQ = dS K / 8
+      product(dSt, Qt, 0.125f, TD);      // dK = dS^T Q / 8
+      product(Pt, dCt, 1.f, 2 * TD);     // dV = P^T dctx
+    }
+  } else {
     const bool act = wave < ns;
     float* qs = big + wave * NTOK * LY::LDQ;
     float* p = sp + wave * NTOK * ATT_PLD;
@@ -479,7 +652,24 @@ __global__ __launch_bounds__(256) void bwd_layer_kernel(BwdLayer w, BwdHead hd, 
   {  // ---- dx_in = dz1 + dqkv Win -> global
     f32x4 acc[MT][1];
     zero_acc(acc);
-    block_gemm<T, MT, 1, 6>(acc, big, LY::LDQ, (const T*)w.wint, 192, nt1, lane, ring_dxin);
+    if constexpr (LY::MFMA_ATT) {  // the dq | dk | dv rows sit in the samples' operand blocks, already in T
+      typedef typename Frag<T>::type frag_t;
+      const int fg = (lane >> 4) * 8;
+      const T* rp[MT];
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+        const int row = mt * 16 + fr, sm = row / NTOK, t = row - sm * NTOK;
+        rp[mt] = row < nrows ? reinterpret_cast<const T*>(att + (size_t)sm * LY::att_w) + t * LY::LDR
+                             : reinterpret_cast<const T*>(att) + NTOK * LY::LDR;  // sample 0's zero row
+      }
+#pragma unroll
+      for (int ks = 0; ks < 6; ++ks)
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+          mma_k32(acc[mt][0], ring_dxin.fb[ks][0], *reinterpret_cast<const frag_t*>(rp[mt] + ks * 32 + fg));
+    } else {
+      block_gemm<T, MT, 1, 6>(acc, big, LY::LDQ, (const T*)w.wint, 192, nt1, lane, ring_dxin);
+    }
     const int n4 = wave * 16 + qr;
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
@@ -487,7 +677,7 @@ __global__ __launch_bounds__(256) void bwd_layer_kernel(BwdLayer w, BwdHead hd, 
       const float4 r = *reinterpret_cast<const float4*>(b + row * LY::LDX + n4);
       const float v0 = r.x + acc[mt][0][0], v1 = r.y + acc[mt][0][1], v2 = r.z + acc[mt][0][2], v3 = r.w + acc[mt][0][3];
       if (row < nrows) st4(w.o_dx + (row0 + row) * TD + n4, v0, v1, v2, v3);
-      if constexpr (TAIL) st4(a + row * LY::LDX + n4, v0, v1, v2, v3);  // dctx is dead: `a` takes dx_in (0 beyond nrows)
+      if constexpr (TAIL) st4(at + row * LY::LDX + n4, v0, v1, v2, v3);  // `at` takes dx_in (0 beyond nrows)
     }
   }
   LAY_STAMP(8);
@@ -496,7 +686,7 @@ __global__ __launch_bounds__(256) void bwd_layer_kernel(BwdLayer w, BwdHead hd, 
     {  // ---- tokens 1..16: dc3 = (dx_in Wup) o [c3 > 0]; the token-0 rows of the tile are computed and dropped
       f32x4 acc[MT][1];
       zero_acc(acc);
-      block_gemm<T, MT, 1, 2>(acc, a, LY::LDX, (const T*)tl.wupt, 64, nt1, lane, ring_up);
+      block_gemm<T, MT, 1, 2>(acc, at, LY::LDX, (const T*)tl.wupt, 64, nt1, lane, ring_up);
       const int n4 = wave * 16 + qr;
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt) {
@@ -518,7 +708,7 @@ __global__ __launch_bounds__(256) void bwd_layer_kernel(BwdLayer w, BwdHead hd, 
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       const int idx = tid + k * 256, r = idx >> 6, c = idx & 63;
-      dt[r * LY::LDX + c] = r < ns && tm_x0[k] > 0.f ? a[(r * NTOK) * LY::LDX + c] : 0.f;
+      dt[r * LY::LDX + c] = r < ns && tm_x0[k] > 0.f ? at[(r * NTOK) * LY::LDX + c] : 0.f;
     }
     __syncthreads();
     f32x4 acc[1][4];
