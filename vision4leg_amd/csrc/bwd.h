@@ -870,15 +870,6 @@ __global__ __launch_bounds__(512) void bwd_conv_kernel(BwdConv a) {
   for (int i = tid; i < 64 * LY::LP2; i += NTH) sdc2T[i] = (T)0.f;
   for (int i = tid; i < 32 * LY::LP1; i += NTH) sdc1T[i] = (T)0.f;
   for (int i = tid; i < LY::LT; i += NTH) sdc3[16 * LY::LT + i] = (T)0.f;
-  if constexpr (LY::B16) {
-    // conv2' weights (4 parity classes x [ci 32][K 256]) stay in LDS for the block's whole life, stored as the MFMA fragments
-    // the waves read: [class][ci tile][K step][lane][8] — a wave's fragment is one contiguous, conflict-free 1 KB
-    for (int c = tid; c < 4096; c += NTH) {  // 16-byte chunk c = (class*32 + ci)*32 + k/8
-      const int k8 = c & 31, n = (c >> 5) & 31, cl = c >> 10;
-      const int dst = ((cl * 2 + (n >> 4)) * 8 + (k8 >> 2)) * 64 + (k8 & 3) * 16 + (n & 15);
-      *reinterpret_cast<float4*>(sw2 + dst * 8) = *reinterpret_cast<const float4*>(reinterpret_cast<const T*>(a.w2d[cl]) + n * 256 + k8 * 8);
-    }
-  }
   constexpr int CH = 4 / LY::IMGP;  // image channels resident at a time
 
   constexpr int V = 16 / sizeof(T);  // image elements per 16-byte load
@@ -911,7 +902,28 @@ __global__ __launch_bounds__(512) void bwd_conv_kernel(BwdConv a) {
       if (i4 < N4) st4(sc1 + (i4 >> 3) * LY::LC1 + (i4 & 7) * 4, cv[k].x, cv[k].y, cv[k].z, cv[k].w);
     }
   };
-  if ((int)blockIdx.x < a.n) { load_next(blockIdx.x); store_next(); }
+  {
+    // prologue: the first sample's dc3 / c2 / c1 and (bf16) the conv2' weights are all requested before anything is filed
+    const bool first = (int)blockIdx.x < a.n;
+    if (first) load_next(blockIdx.x);
+    if constexpr (LY::B16) {
+      // conv2' weights (4 parity classes x [ci 32][K 256]) stay in LDS for the block's whole life, stored as the MFMA fragments
+      // the waves read: [class][ci tile][K step][lane][8] — a wave's fragment is one contiguous, conflict-free 1 KB
+      float4 wv[4096 / NTH];
+#pragma unroll
+      for (int k = 0; k < 4096 / NTH; ++k) {  // 16-byte chunk c = (class*32 + ci)*32 + k/8
+        const int c = tid + k * NTH, k8 = c & 31, n = (c >> 5) & 31, cl = c >> 10;
+        wv[k] = *reinterpret_cast<const float4*>(reinterpret_cast<const T*>(a.w2d[cl]) + n * 256 + k8 * 8);
+      }
+#pragma unroll
+      for (int k = 0; k < 4096 / NTH; ++k) {
+        const int c = tid + k * NTH, k8 = c & 31, n = (c >> 5) & 31, cl = c >> 10;
+        const int dst = ((cl * 2 + (n >> 4)) * 8 + (k8 >> 2)) * 64 + (k8 & 3) * 16 + (n & 15);
+        *reinterpret_cast<float4*>(sw2 + dst * 8) = wv[k];
+      }
+    }
+    if (first) store_next();
+  }
   for (int smp = blockIdx.x; smp < a.n; smp += gridDim.x) {
     __syncthreads();  // previous sample's readers are done
     CONV_STAMP(0);

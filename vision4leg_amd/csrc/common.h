@@ -139,4 +139,19 @@ __device__ __forceinline__ float wave_min(float v) {
 #define V4L_GLOBAL __attribute__((address_space(1)))
 template <typename P> __device__ __forceinline__ V4L_GLOBAL P* as_global(P* p) { return (V4L_GLOBAL P*)p; }
 
+// Which descriptor of a table sorted by first block (`blk0`, d[0].blk0 == 0) owns block b. The whole wave looks at once: lane l
+// tests descriptors l, l + 64, ... and a ballot counts the ones at or below b — one L2 round trip, where a binary search is
+// log2(n) dependent ones at the head of every table-driven kernel. Call with all 64 lanes active.
+template <class D>
+__device__ __forceinline__ int find_desc(const D* __restrict__ d, int n, int64_t b) {
+  const int lane = threadIdx.x & 63;
+  int cnt = 0;
+  for (int base = 0; base < n; base += 64) {
+    const int i = base + lane;
+    const bool le = i < n && d[i < n ? i : 0].blk0 <= b;
+    cnt += (int)__popcll(__ballot(le));
+  }
+  return cnt - 1;
+}
+
 }  // namespace v4l

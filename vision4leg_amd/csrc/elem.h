@@ -599,17 +599,6 @@ __global__ __launch_bounds__(256) void col0_kernel(const float* __restrict__ src
   if (i < n) dst[i] = src[(int64_t)i * OUT_LD];
 }
 
-// Largest i with blk0[i] <= b for descriptor tables sorted by their first block (stride in bytes).
-template <typename D>
-__device__ __forceinline__ int find_desc(const D* __restrict__ d, int n, int64_t b) {
-  int lo = 0, hi = n - 1;
-  while (lo < hi) {
-    const int mid = (lo + hi + 1) >> 1;
-    if (d[mid].blk0 <= b) lo = mid; else hi = mid - 1;
-  }
-  return lo;
-}
-
 // --------------------------------------------------------------------------------- grad norm + Adam
 // sum of squares of a flat gradient buffer -> part[blockIdx.x] (<= GRAD_NORM_PARTS blocks; clip_adam_kernel adds them in
 // order). 16-byte loads, one or two per thread: the 388 K-float buffer is one short burst over the whole chip, not 24

@@ -625,12 +625,7 @@ struct ADenseG {
 };
 template <typename T>
 __global__ __launch_bounds__(256) void gemm_tn_group_kernel(const TnProb* __restrict__ probs, int np) {
-  int lo = 0, hi = np - 1;
-  while (lo < hi) {
-    const int mid = (lo + hi + 1) >> 1;
-    if (probs[mid].blk0 <= (int64_t)blockIdx.x) lo = mid; else hi = mid - 1;
-  }
-  const TnProb p = probs[lo];
+  const TnProb p = probs[find_desc(probs, np, (int64_t)blockIdx.x)];
   const int lb = (int)((int64_t)blockIdx.x - p.blk0);
   const int bx = lb % p.gx, t = lb / p.gx;
   tn_body<T, 64, 1, ADenseG, ADenseG>(ADenseG(p.y), ADenseG(p.x), p.M, p.mpb, p.slab, p.bslab, p.Npad, p.Kpad, bx, t % p.gy,
@@ -817,12 +812,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const RedDesc* __rest
   // 64 outputs per block x 4 slab groups: thread (o, g) adds slabs g, g+4, g+8, ... (4 independent accumulators),
   // the 4 group sums are combined through LDS in a fixed order -> deterministic and latency-tolerant
   __shared__ float part[4][64];
-  int lo = 0, hi = nd - 1;
-  while (lo < hi) {
-    const int mid = (lo + hi + 1) >> 1;
-    if (descs[mid].blk0 <= (int64_t)blockIdx.x) lo = mid; else hi = mid - 1;
-  }
-  const RedDesc d = descs[lo];
+  const RedDesc d = descs[find_desc(descs, nd, (int64_t)blockIdx.x)];
   const int o = threadIdx.x & 63, g = threadIdx.x >> 6;
   const int64_t e = ((int64_t)blockIdx.x - d.blk0) * 64 + o;
   const int64_t nk = (int64_t)d.N * d.K;
