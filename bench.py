@@ -393,6 +393,8 @@ def algo_bytes(kernel, wl, compute):
         "fused_encoder": n * (16384 * t + 128 * 4 + conv_act + 17 * tok + 2 * 256 * 4),
         # x in; x out, qkv, P, xhat1/2, rstd1/2 (fp32) + layer-input copy, ctx, x1, f (T)
         "fused_layer": R * (2 * tok + 192 * 4 + 2 * tok + 8 + (64 + 64 + 64 + 256) * t) + n * 289 * 4,
+        # both layers in one launch: the second layer's input rows stay in LDS (one token-row read less)
+        "fused_layer_stack": 2 * (R * (2 * tok + 192 * 4 + 2 * tok + 8 + (64 + 64 + 64 + 256) * t) + n * 289 * 4) - R * tok,
         # dy, xhat1/2, rstd, qkv (fp32), P, f (T) in; dz2, df, dz1, dqkv (T) + dx (fp32) out
         "fused_layer_bwd": R * (tok + 2 * tok + 8 + 192 * 4 + 256 * t + (64 + 256 + 64 + 192) * t + tok) + n * 289 * 4,
         # dc3, c2, c1 (fp32) + image (T) in; one dW1 + dW2 slab per block out

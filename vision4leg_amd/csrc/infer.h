@@ -469,6 +469,8 @@ struct InfLayer {
   void *s_xin, *s_ctx, *s_x1, *s_f;
 };
 struct InfLayerPair { InfLayer n[2]; };
+constexpr int ROLLOUT_MAX_LAYERS = 4;
+struct InfLayerStack { InfLayerPair l[ROLLOUT_MAX_LAYERS]; int nl; };  // several layers of both nets in ONE launch
 
 // Heads (pool + append fcs + last linear), run by the LAST layer's blocks on their own samples
 struct InfHead {
@@ -584,13 +586,13 @@ __device__ long long g_inf_stamps[128];
 // One nn.TransformerEncoderLayer for SPW samples per block (blockIdx.y = net). HEAD: the block continues with the
 // pooled heads of its samples (nets.py:1015-1034) and, in a rollout step, with the sampling / filing epilogue.
 //   SPW = 4: training forward (68 of 80 MFMA rows used); SPW = 1: rollout steps (E blocks per net, shortest latency)
-template <typename T, int SPW, bool HEAD>
-__global__ __launch_bounds__(256) void infer_layer_kernel(InfLayerPair pr, InfHeadPair hd, InfFinish fin, int E, int ff) {
+// NL > 1: the block walks NL consecutive layers (stk.l[0..NL-1]) with the token rows staying in LDS between them.
+template <typename T, int SPW, bool HEAD, int NL = 1>
+__global__ __launch_bounds__(256) void infer_layer_kernel(InfLayerStack stk, InfHeadPair hd, InfFinish fin, int E, int ff) {
   typedef InfLayLds<T, SPW> LY;
   constexpr int ROWS = InfRows<SPW>::ROWS, MT = InfRows<SPW>::MT, U = InfRows<SPW>::U;
   INF_STAMP(0);
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  const InfLayer& w = pr.n[blockIdx.y];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int fr = lane & 15, qr = (lane >> 4) * 4;
   float* xs = reinterpret_cast<float*>(smem);
@@ -613,21 +615,35 @@ __global__ __launch_bounds__(256) void infer_layer_kernel(InfLayerPair pr, InfHe
   const int nt4[4] = {wave * 4, wave * 4 + 1, wave * 4 + 2, wave * 4 + 3};
   // every GEMM's first weight fragments are requested one phase early (GemmRing): the L2 round trip and the acknowledgement
   // of the global stores in front of it overlap that phase
-  GemmRing<T, 3, 2> ring_in = gemm_prefetch<T, 3, 2>((const T*)w.win, 64, nt, lane);
-  const float* xg = w.xin + (int64_t)s0 * NTOK * TD;
-  for (int i4 = tid; i4 < ROWS * (TD / 4); i4 += 256) {
-    const int r = i4 >> 4, c4 = (i4 & 15) * 4;
-    const bool ok = r < nrows;
-    const float4 v = *reinterpret_cast<const float4*>(xg + (ok ? r : 0) * TD + c4);
-    *reinterpret_cast<float4*>(xs + r * LY::LDX + c4) = ok ? v : float4{0.f, 0.f, 0.f, 0.f};
-    if (w.s_xin != nullptr && ok) st4(reinterpret_cast<T*>(w.s_xin) + (row0 + r) * TD + c4, v.x, v.y, v.z, v.w);
-    st4(cb + r * LDT + c4, 0.f, 0.f, 0.f, 0.f);  // rows the attention does not write (padding / absent samples)
+  GemmRing<T, 3, 2> ring_in = gemm_prefetch<T, 3, 2>((const T*)stk.l[0].n[blockIdx.y].win, 64, nt, lane);
+#pragma unroll
+  for (int l = 0; l < NL; ++l) {
+  const InfLayer& w = stk.l[l].n[blockIdx.y];
+  if (l == 0) {
+    const float* xg = w.xin + (int64_t)s0 * NTOK * TD;
+    for (int i4 = tid; i4 < ROWS * (TD / 4); i4 += 256) {
+      const int r = i4 >> 4, c4 = (i4 & 15) * 4;
+      const bool ok = r < nrows;
+      const float4 v = *reinterpret_cast<const float4*>(xg + (ok ? r : 0) * TD + c4);
+      *reinterpret_cast<float4*>(xs + r * LY::LDX + c4) = ok ? v : float4{0.f, 0.f, 0.f, 0.f};
+      if (w.s_xin != nullptr && ok) st4(reinterpret_cast<T*>(w.s_xin) + (row0 + r) * TD + c4, v.x, v.y, v.z, v.w);
+      st4(cb + r * LDT + c4, 0.f, 0.f, 0.f, 0.f);  // rows the attention does not write (padding / absent samples)
+    }
+  } else {
+    __syncthreads();  // the previous layer's norm2 left this layer's input rows in xs
+    if (w.s_xin != nullptr) {
+      for (int i4 = tid; i4 < ROWS * (TD / 4); i4 += 256) {
+        const int r = i4 >> 4, c4 = (i4 & 15) * 4;
+        const float4 v = *reinterpret_cast<const float4*>(xs + r * LY::LDX + c4);
+        if (r < nrows) st4(reinterpret_cast<T*>(w.s_xin) + (row0 + r) * TD + c4, v.x, v.y, v.z, v.w);
+      }
+    }
   }
   for (int i = tid; i < SPW * 64 * (32 - NTOK); i += 256) {  // key columns 17..31 of v^T: zeros (P there is 0, 0 x NaN is not)
     const int rr = i / (32 - NTOK), cc = NTOK + i - rr * (32 - NTOK);
     vt[rr * ATT_LDV + cc] = (T)0.f;
   }
-  __syncthreads();
+  if (l == 0) __syncthreads();
   INF_STAMP(1);
   GemmRing<T, 1, 2> ring_o;
   {  // in_proj: [ROWS][64] x [192][64]^T -> qkv (fp32)
@@ -730,9 +746,11 @@ __global__ __launch_bounds__(256) void infer_layer_kernel(InfLayerPair pr, InfHe
   }
   __syncthreads();
   INF_STAMP(7);
-  ln_rows<ROWS, U, float>(cx, LY::LDX, HEAD ? xs : nullptr, LY::LDX, w.g2, w.be2, wave, lane, nrows,
+  if (l + 1 < NL) ring_in = gemm_prefetch<T, 3, 2>((const T*)stk.l[l + 1 < NL ? l + 1 : l].n[blockIdx.y].win, 64, nt, lane);
+  ln_rows<ROWS, U, float>(cx, LY::LDX, (HEAD || l + 1 < NL) ? xs : nullptr, LY::LDX, w.g2, w.be2, wave, lane, nrows,
                    w.s_xh2 ? w.s_xh2 + row0 * TD : nullptr, w.s_rs2 ? w.s_rs2 + row0 : nullptr, w.xout + row0 * TD);
   INF_STAMP(8);
+  }  // layers
   if constexpr (HEAD) {
     // ---- heads on this block's samples: [state token | mean of the 16 depth tokens] -> 256 -> 256 -> nout
     const InfHead& h = hd.n[blockIdx.y];
@@ -838,8 +856,6 @@ __global__ __launch_bounds__(256) void infer_layer_kernel(InfLayerPair pr, InfHe
 
 
 // ------------------------------------------------------------------------------------------ rollout layer stack
-constexpr int ROLLOUT_MAX_LAYERS = 4;
-struct InfLayerStack { InfLayerPair l[ROLLOUT_MAX_LAYERS]; int nl; };  // all layers of both nets: ONE launch per env step
 template <typename T> struct RollStackLds { static constexpr size_t bytes = InfLayLds<T, 1>::bytes + (size_t)(2 * 832 + 528) * 4 + ((size_t)4 * 32 * (64 + InfLd<T>::PAD) + (size_t)(64 + 32) * (32 + 8)) * sizeof(T); };
 
 // ------------------------------------------------------------------------------------------ rollout layer stack, weights ahead

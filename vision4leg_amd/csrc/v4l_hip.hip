@@ -1019,63 +1019,74 @@ int v4l_net::forward_t(const float* state, const T* image, const int* rowidx, in
     // the last layer's blocks also run the pooled heads of their samples when the head stack has the shipped shape
     const bool fused_head = fused_layers && c.n_layers >= 1 && nh == 2 && c.head_hidden[0] == 256 && c.head_hidden[1] == 256 &&
                             c.out_dim <= OUT_LD && getenv("V4L_NO_FUSED_HEAD") == nullptr;
-    for (int l = 0; l < c.n_layers && fused_layers; ++l) {
-      // one launch per TransformerEncoderLayer (csrc/infer.h), 4 samples per block, saving what backward_t reads
-      const TLayer& t = layers[l];
-      const LayerWs& w = L.lw[l];
+    // both layers + the heads in ONE launch when the stack is the shipped two layers (the token rows stay in LDS between
+    // the layers); otherwise one launch per TransformerEncoderLayer. 2 or 4 samples per block, saving what backward_t reads.
+    static const bool stack_ok = getenv("V4L_NO_LAYER_STACK") == nullptr;
+    const bool stacked = fused_layers && fused_head && c.n_layers == 2 && stack_ok;
+    for (int l = 0; l < c.n_layers && fused_layers; l += stacked ? 2 : 1) {
       static bool attr_done = false;
       static int spw = 2;  // samples per block: 2 (48 MFMA rows, 2 blocks/CU: measured 20 % faster) or 4 (80 rows, 1 block/CU)
       if (!attr_done) {
         spw = 2;
         constexpr bool spw4_fits = InfLayLds<T, 4>::bytes <= 160 * 1024;  // (not in the fp32 parity mode: 168 KB)
         if (const char* e = getenv("V4L_LAYER_SPW")) spw = (atoi(e) == 4 && spw4_fits) ? 4 : 2;
+        auto lds = [](const void* fn, size_t bytes) { return hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes); };
         if (spw4_fits) {
-          V4L_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&infer_layer_kernel<T, 4, false>),
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)InfLayLds<T, 4>::bytes));
-          V4L_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&infer_layer_kernel<T, 4, true>),
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)InfLayLds<T, 4>::bytes));
+          V4L_HIP_CHECK(lds(reinterpret_cast<const void*>(&infer_layer_kernel<T, 4, false, 1>), InfLayLds<T, 4>::bytes));
+          V4L_HIP_CHECK(lds(reinterpret_cast<const void*>(&infer_layer_kernel<T, 4, true, 1>), InfLayLds<T, 4>::bytes));
+          V4L_HIP_CHECK(lds(reinterpret_cast<const void*>(&infer_layer_kernel<T, 4, true, 2>), InfLayLds<T, 4>::bytes));
         }
-        V4L_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&infer_layer_kernel<T, 2, false>),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)InfLayLds<T, 2>::bytes));
-        V4L_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&infer_layer_kernel<T, 2, true>),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)InfLayLds<T, 2>::bytes));
+        V4L_HIP_CHECK(lds(reinterpret_cast<const void*>(&infer_layer_kernel<T, 2, false, 1>), InfLayLds<T, 2>::bytes));
+        V4L_HIP_CHECK(lds(reinterpret_cast<const void*>(&infer_layer_kernel<T, 2, true, 1>), InfLayLds<T, 2>::bytes));
+        V4L_HIP_CHECK(lds(reinterpret_cast<const void*>(&infer_layer_kernel<T, 2, true, 2>), InfLayLds<T, 2>::bytes));
         attr_done = true;
       }
       const T* base = (const T*)packed;
-      InfLayerPair pr;
-      memset(&pr, 0, sizeof(pr));
-      InfLayer& d = pr.n[0];
-      d.win = base + t.inproj.pk; d.wo = base + t.outproj.pk; d.w1 = base + t.ff1.pk; d.w2 = base + t.ff2.pk;
-      d.bin = p[t.inproj.b]; d.bo = p[t.outproj.b]; d.b1 = p[t.ff1.b]; d.b2 = p[t.ff2.b];
-      d.g1 = p[t.ln1.g]; d.be1 = p[t.ln1.b]; d.g2 = p[t.ln2.g]; d.be2 = p[t.ln2.b];
-      d.xin = l == 0 ? x0 : ws + L.x[l];
-      d.xout = ws + L.x[l + 1];
-      d.s_qkv = ws + w.qkv; d.s_P = ws + w.P; d.s_ctx = ws + w.ctx; d.s_xh1 = ws + w.xh1; d.s_rs1 = ws + w.rs1;
-      d.s_x1 = ws + w.x1; d.s_f = ws + w.f; d.s_xh2 = ws + w.xh2; d.s_rs2 = ws + w.rs2;
-      d.s_xin = sizeof(T) == 2 ? ws + w.xin : nullptr;  // fp32 mode: the fp32 token tensor itself is the operand
+      InfLayerStack stk;
+      memset(&stk, 0, sizeof(stk));
+      stk.nl = stacked ? 2 : 1;
+      for (int k = 0; k < stk.nl; ++k) {
+        const TLayer& t = layers[l + k];
+        const LayerWs& w = L.lw[l + k];
+        InfLayer& d = stk.l[k].n[0];
+        d.win = base + t.inproj.pk; d.wo = base + t.outproj.pk; d.w1 = base + t.ff1.pk; d.w2 = base + t.ff2.pk;
+        d.bin = p[t.inproj.b]; d.bo = p[t.outproj.b]; d.b1 = p[t.ff1.b]; d.b2 = p[t.ff2.b];
+        d.g1 = p[t.ln1.g]; d.be1 = p[t.ln1.b]; d.g2 = p[t.ln2.g]; d.be2 = p[t.ln2.b];
+        d.xin = l + k == 0 ? x0 : ws + L.x[l + k];
+        d.xout = ws + L.x[l + k + 1];
+        d.s_qkv = ws + w.qkv; d.s_P = ws + w.P; d.s_ctx = ws + w.ctx; d.s_xh1 = ws + w.xh1; d.s_rs1 = ws + w.rs1;
+        d.s_x1 = ws + w.x1; d.s_f = ws + w.f; d.s_xh2 = ws + w.xh2; d.s_rs2 = ws + w.rs2;
+        d.s_xin = sizeof(T) == 2 ? ws + w.xin : nullptr;  // fp32 mode: the fp32 token tensor itself is the operand
+      }
       InfHeadPair hd;
       memset(&hd, 0, sizeof(hd));
       InfFinish fin;
       memset(&fin, 0, sizeof(fin));
       g_op = "layer";
-      if (fused_head && l == c.n_layers - 1) {
+      if (fused_head && l + stk.nl == c.n_layers) {
         InfHead& h = hd.n[0];
         h.w0 = base + head[0].pk; h.w1 = base + head[1].pk; h.w2 = base + head[2].pk;
         h.b0 = p[head[0].b]; h.b1 = p[head[1].b]; h.b2 = p[head[2].b];
         h.out = ws + L.out; h.nout = c.out_dim;
         h.s_pooled = ws + L.pooled; h.s_h0 = ws + L.hh[0]; h.s_h1 = ws + L.hh[1];
-        if (spw == 2)
-          V4L_KLAUNCH("fused_layer_head", 2.0 * n * (872576.0 + 99840.0), s, (infer_layer_kernel<T, 2, true>), dim3(cdiv(n, 2), 1),
-                      dim3(256), (InfLayLds<T, 2>::bytes), s, pr, hd, fin, n, c.ff_dim);
+        if (stacked && spw == 2)
+          V4L_KLAUNCH("fused_layer_stack_head", 2.0 * n * (2 * 872576.0 + 99840.0), s, (infer_layer_kernel<T, 2, true, 2>),
+                      dim3(cdiv(n, 2), 1), dim3(256), (InfLayLds<T, 2>::bytes), s, stk, hd, fin, n, c.ff_dim);
+        else if (stacked)
+          V4L_KLAUNCH("fused_layer_stack_head", 2.0 * n * (2 * 872576.0 + 99840.0), s, (infer_layer_kernel<T, 4, true, 2>),
+                      dim3(cdiv(n, 4), 1), dim3(256), (InfLayLds<T, 4>::bytes), s, stk, hd, fin, n, c.ff_dim);
+        else if (spw == 2)
+          V4L_KLAUNCH("fused_layer_head", 2.0 * n * (872576.0 + 99840.0), s, (infer_layer_kernel<T, 2, true, 1>), dim3(cdiv(n, 2), 1),
+                      dim3(256), (InfLayLds<T, 2>::bytes), s, stk, hd, fin, n, c.ff_dim);
         else
-          V4L_KLAUNCH("fused_layer_head", 2.0 * n * (872576.0 + 99840.0), s, (infer_layer_kernel<T, 4, true>), dim3(cdiv(n, 4), 1),
-                      dim3(256), (InfLayLds<T, 4>::bytes), s, pr, hd, fin, n, c.ff_dim);
+          V4L_KLAUNCH("fused_layer_head", 2.0 * n * (872576.0 + 99840.0), s, (infer_layer_kernel<T, 4, true, 1>), dim3(cdiv(n, 4), 1),
+                      dim3(256), (InfLayLds<T, 4>::bytes), s, stk, hd, fin, n, c.ff_dim);
       } else if (spw == 2) {
-        V4L_KLAUNCH("fused_layer", 2.0 * n * 872576.0, s, (infer_layer_kernel<T, 2, false>), dim3(cdiv(n, 2), 1), dim3(256),
-                    (InfLayLds<T, 2>::bytes), s, pr, hd, fin, n, c.ff_dim);
+        V4L_KLAUNCH("fused_layer", 2.0 * n * 872576.0, s, (infer_layer_kernel<T, 2, false, 1>), dim3(cdiv(n, 2), 1), dim3(256),
+                    (InfLayLds<T, 2>::bytes), s, stk, hd, fin, n, c.ff_dim);
       } else {
-        V4L_KLAUNCH("fused_layer", 2.0 * n * 872576.0, s, (infer_layer_kernel<T, 4, false>), dim3(cdiv(n, 4), 1), dim3(256),
-                    (InfLayLds<T, 4>::bytes), s, pr, hd, fin, n, c.ff_dim);
+        V4L_KLAUNCH("fused_layer", 2.0 * n * 872576.0, s, (infer_layer_kernel<T, 4, false, 1>), dim3(cdiv(n, 4), 1), dim3(256),
+                    (InfLayLds<T, 4>::bytes), s, stk, hd, fin, n, c.ff_dim);
       }
       V4L_LAUNCH_CHECK();
     }
