@@ -397,6 +397,8 @@ def algo_bytes(kernel, wl, compute):
         "fused_layer_stack": 2 * (R * (2 * tok + 192 * 4 + 2 * tok + 8 + (64 + 64 + 64 + 256) * t) + n * 289 * 4) - R * tok,
         # dy, xhat1/2, rstd, qkv (fp32), P, f (T) in; dz2, df, dz1, dqkv (T) + dx (fp32) out
         "fused_layer_bwd": R * (tok + 2 * tok + 8 + 192 * 4 + 256 * t + (64 + 256 + 64 + 192) * t + tok) + n * 289 * 4,
+        # both layers in one launch: the upper layer's dx is the lower layer's dy in LDS (one token-row read less)
+        "fused_layer_bwd_stack": 2 * (R * (tok + 2 * tok + 8 + 192 * 4 + 256 * t + (64 + 256 + 64 + 192) * t + tok) + n * 289 * 4) - R * tok,
         # dc3, c2, c1 (fp32) + image (T) in; one dW1 + dW2 slab per block out
         "fused_conv_bwd": n * ((16 * 64 + 36 * 64 + 225 * 32) * 4 + 16384 * t) + blocks * (32 * 256 + 64 * 512) * 4,
         "fused_conv3_wgrad": n * (16 * 64 + 36 * 64) * 4 + blocks * 64 * 576 * 4,

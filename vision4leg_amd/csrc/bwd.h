@@ -22,6 +22,8 @@ struct BwdLayer {
   float *gp2, *bp2, *gp1, *bp1;          // [gridDim.x][64] per-block dgamma / dbeta partials of norm2 / norm1
 };
 
+struct BwdLayerStack { BwdLayer l[2]; };  // NL = 2: the block walks layer l[0] (the upper one) and then l[1] backward, dx staying in LDS
+
 // HEAD (last layer): the block first walks the pooled heads of its samples backward (nets.py:1015-1034 reversed):
 //   dout -> (W2^T, mask h1) -> dh1 -> (W1^T, mask h0) -> dh0 -> (W0^T) -> dpool -> un-pool -> dy rows in LDS
 struct BwdHead {
@@ -143,8 +145,8 @@ __device__ __forceinline__ void ln_bwd_rows(float* d, int ld, const LnPre<ROWS>&
 #define LAY_STAMP(i)
 #endif
 
-template <typename T, int SPW, bool HEAD, bool TAIL>
-__global__ __launch_bounds__(256) void bwd_layer_kernel(BwdLayer w, BwdHead hd, BwdTail tl, int n) {
+template <typename T, int SPW, bool HEAD, bool TAIL, int NL = 1>
+__global__ __launch_bounds__(256) void bwd_layer_kernel(BwdLayerStack stk, BwdHead hd, BwdTail tl, int n) {
   typedef BwdLayLds<T, SPW> LY;
   constexpr int ROWS = InfRows<SPW>::ROWS, MT = InfRows<SPW>::MT;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -167,7 +169,7 @@ __global__ __launch_bounds__(256) void bwd_layer_kernel(BwdLayer w, BwdHead hd, 
   const int nrows = ns * NTOK;
   const int64_t row0 = (int64_t)s0 * NTOK;
   // norm2's saved rows start their trip from HBM now; they are consumed after dy is staged (or the heads are done)
-  const LnPre<ROWS> pre2 = ln_bwd_fetch<ROWS>(w.s_xh2 + row0 * TD, w.s_rs2 + row0, w.g2, wave, lane, nrows);
+  LnPre<ROWS> pre2 = ln_bwd_fetch<ROWS>(stk.l[0].s_xh2 + row0 * TD, stk.l[0].s_rs2 + row0, stk.l[0].g2, wave, lane, nrows);
   const int nt1[1] = {wave};
   const int nt4[4] = {wave * 4, wave * 4 + 1, wave * 4 + 2, wave * 4 + 3};
   if constexpr (HEAD) {
@@ -243,7 +245,7 @@ __global__ __launch_bounds__(256) void bwd_layer_kernel(BwdLayer w, BwdHead hd, 
       a[r * LY::LDX + c] = v;
     }
   } else {
-    const float* dyg = w.dy + row0 * TD;
+    const float* dyg = stk.l[0].dy + row0 * TD;
     for (int i4 = tid; i4 < ROWS * (TD / 4); i4 += 256) {
       const int r = i4 >> 4, c4 = (i4 & 15) * 4;
       const bool ok = r < nrows;
@@ -252,6 +254,14 @@ __global__ __launch_bounds__(256) void bwd_layer_kernel(BwdLayer w, BwdHead hd, 
     }
   }
   LAY_STAMP(1);
+  float4 tm_c3[MT], tm_e1[4], tm_e0[4];  // TAIL: encoder-side masks / first weight fragments, requested by the lowest layer
+  float tm_x0[4];
+  GemmRing<T, 1, 2> ring_up;
+  GemmRing<T, 4, 2> ring_pr;
+#pragma unroll
+  for (int l = 0; l < NL; ++l) {
+  const BwdLayer& w = stk.l[l];
+  const bool last = l == NL - 1;  // compile-time after unrolling: the TAIL part belongs to the lowest layer
   __syncthreads();
   // ---- norm2 backward: a = dz2 (the next GEMM's first weight fragments are requested before the norm's global stores)
   GemmRing<T, 4, 2> ring_df = gemm_prefetch<T, 4, 2>((const T*)w.w2t, 64, nt4, lane);
@@ -425,11 +435,12 @@ __global__ __launch_bounds__(256) void bwd_layer_kernel(BwdLayer w, BwdHead hd, 
   GemmRing<T, 1, 6> ring_dxin = gemm_prefetch<T, 1, 6>((const T*)w.wint, 192, nt1, lane);
   // TAIL: everything the encoder-side data-grads read from HBM (conv3 / x0 / MLP ReLU masks, the first weight fragments of
   // their three GEMMs) is requested here, in front of the long LDS-only attention phase
-  float4 tm_c3[MT], tm_e1[4], tm_e0[4];
-  float tm_x0[4];
-  GemmRing<T, 1, 2> ring_up;
-  GemmRing<T, 4, 2> ring_pr;
-  if constexpr (TAIL) {
+  LnPre<ROWS> pre2_next = pre2;
+  if (!last) {  // the next (lower) layer's norm2 rows start their trip here, in front of the long LDS-only attention phase
+    const BwdLayer& wn = stk.l[l + 1 < NL ? l + 1 : l];
+    pre2_next = ln_bwd_fetch<ROWS>(wn.s_xh2 + row0 * TD, wn.s_rs2 + row0, wn.g2, wave, lane, nrows);
+  }
+  if (TAIL && last) {
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
       const int row = mt * 16 + fr;
@@ -675,12 +686,22 @@ __global__ __launch_bounds__(256) void bwd_layer_kernel(BwdLayer w, BwdHead hd, 
     for (int mt = 0; mt < MT; ++mt) {
       const int row = mt * 16 + fr;
       const float4 r = *reinterpret_cast<const float4*>(b + row * LY::LDX + n4);
-      const float v0 = r.x + acc[mt][0][0], v1 = r.y + acc[mt][0][1], v2 = r.z + acc[mt][0][2], v3 = r.w + acc[mt][0][3];
-      if (row < nrows) st4(w.o_dx + (row0 + row) * TD + n4, v0, v1, v2, v3);
-      if constexpr (TAIL) st4(at + row * LY::LDX + n4, v0, v1, v2, v3);  // `at` takes dx_in (0 beyond nrows)
+      acc[mt][0][0] += r.x; acc[mt][0][1] += r.y; acc[mt][0][2] += r.z; acc[mt][0][3] += r.w;
+      if (row < nrows) st4(w.o_dx + (row0 + row) * TD + n4, acc[mt][0][0], acc[mt][0][1], acc[mt][0][2], acc[mt][0][3]);
+      if (TAIL && last) st4(at + row * LY::LDX + n4, acc[mt][0][0], acc[mt][0][1], acc[mt][0][2], acc[mt][0][3]);  // `at` takes dx_in (0 beyond nrows)
+    }
+    if (!last) {
+      // dx_in is the lower layer's dy: it goes straight into `a` (bf16: once every wave is done reading dq | dk | dv out of
+      // the operand blocks `a` overlaps)
+      if constexpr (LY::MFMA_ATT) __syncthreads();
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+        st4(a + (mt * 16 + fr) * LY::LDX + n4, acc[mt][0][0], acc[mt][0][1], acc[mt][0][2], acc[mt][0][3]);
     }
   }
+  pre2 = pre2_next;
   LAY_STAMP(8);
+  }  // layers
   if constexpr (TAIL) {
     __syncthreads();
     {  // ---- tokens 1..16: dc3 = (dx_in Wup) o [c3 > 0]; the token-0 rows of the tile are computed and dropped

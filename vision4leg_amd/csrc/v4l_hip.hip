@@ -1234,24 +1234,26 @@ int v4l_net::backward_t(const float* state, const T* image, const int* rowidx, i
     V4L_LAUNCH_CHECK();
   }
   const int lnb = std::min(cdiv(R, 16), 128);
-  for (int l = c.n_layers - 1; l >= 0 && fused_bwd; --l) {
-    // one launch per TransformerEncoderLayer (csrc/bwd.h): every data-grad of the layer with the intermediates in LDS;
-    // the four weight-grads are deferred to the grouped launch as before
-    const TLayer& t = layers[l];
-    const LayerWs& w = L.lw[l];
-    const LayerBw& b = L.lb[l];
+  // both layers (+ heads before, + encoder-side data-grads after) in ONE launch when the stack is the shipped two layers: the
+  // upper layer's dx stays in LDS as the lower layer's dy; otherwise one launch per TransformerEncoderLayer (csrc/bwd.h).
+  // Every data-grad of a layer has its intermediates in LDS; the four weight-grads are deferred to the grouped launch.
+  static const bool bwd_stack_ok = getenv("V4L_NO_LAYER_STACK") == nullptr;
+  const bool stacked = fused_bwd && fused_head && fused_tail && c.n_layers == 2 && bwd_stack_ok;
+  for (int l = c.n_layers - 1; l >= 0 && fused_bwd; l -= stacked ? 2 : 1) {
     static bool attr_done = false;
     static int spw = 4;  // samples per block: 4 (80 MFMA rows, 1 block per CU) or 2 (48 rows, 2 blocks per CU): measured equal
     if (!attr_done) {
       if (const char* e = getenv("V4L_LAYER_BWD_SPW")) spw = atoi(e) == 2 ? 2 : 4;
-      const void* f4[4] = {reinterpret_cast<const void*>(&bwd_layer_kernel<T, 4, false, false>),
-                           reinterpret_cast<const void*>(&bwd_layer_kernel<T, 4, true, false>),
-                           reinterpret_cast<const void*>(&bwd_layer_kernel<T, 4, false, true>),
-                           reinterpret_cast<const void*>(&bwd_layer_kernel<T, 4, true, true>)};
-      const void* f2[4] = {reinterpret_cast<const void*>(&bwd_layer_kernel<T, 2, false, false>),
-                           reinterpret_cast<const void*>(&bwd_layer_kernel<T, 2, true, false>),
-                           reinterpret_cast<const void*>(&bwd_layer_kernel<T, 2, false, true>),
-                           reinterpret_cast<const void*>(&bwd_layer_kernel<T, 2, true, true>)};
+      const void* f4[5] = {reinterpret_cast<const void*>(&bwd_layer_kernel<T, 4, false, false, 1>),
+                           reinterpret_cast<const void*>(&bwd_layer_kernel<T, 4, true, false, 1>),
+                           reinterpret_cast<const void*>(&bwd_layer_kernel<T, 4, false, true, 1>),
+                           reinterpret_cast<const void*>(&bwd_layer_kernel<T, 4, true, true, 1>),
+                           reinterpret_cast<const void*>(&bwd_layer_kernel<T, 4, true, true, 2>)};
+      const void* f2[5] = {reinterpret_cast<const void*>(&bwd_layer_kernel<T, 2, false, false, 1>),
+                           reinterpret_cast<const void*>(&bwd_layer_kernel<T, 2, true, false, 1>),
+                           reinterpret_cast<const void*>(&bwd_layer_kernel<T, 2, false, true, 1>),
+                           reinterpret_cast<const void*>(&bwd_layer_kernel<T, 2, true, true, 1>),
+                           reinterpret_cast<const void*>(&bwd_layer_kernel<T, 2, true, true, 2>)};
       for (const void* fn : f4)
         V4L_HIP_CHECK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)BwdLayLds<T, 4>::bytes));
       for (const void* fn : f2)
@@ -1259,19 +1261,28 @@ int v4l_net::backward_t(const float* state, const T* image, const int* rowidx, i
       attr_done = true;
     }
     const int nblk = cdiv(n, spw);
-    float* part = cx.slab + cx.slab_used;  // gp2 | bp2 | gp1 | bp1, [nblk][64] each
-    cx.slab_used += 4 * (int64_t)nblk * TD;
-    V4L_REQUIRE(cx.slab_used <= slab_cap, "internal: weight-grad slab arena overflow");
+    const int nl = stacked ? 2 : 1;
     const T* base = (const T*)packed;
-    BwdLayer d;
-    d.w2t = base + t.ff2.pkt; d.w1t = base + t.ff1.pkt; d.wot = base + t.outproj.pkt; d.wint = base + t.inproj.pkt;
-    d.g1 = p[t.ln1.g]; d.g2 = p[t.ln2.g];
-    d.dy = ws + L.dxl[l + 1];
-    d.s_qkv = ws + w.qkv; d.s_P = ws + w.P; d.s_xh1 = ws + w.xh1; d.s_rs1 = ws + w.rs1; d.s_f = ws + w.f;
-    d.s_xh2 = ws + w.xh2; d.s_rs2 = ws + w.rs2;
-    d.o_dz2 = ws + b.dz2; d.o_df = ws + b.df; d.o_dz1 = ws + b.dz1; d.o_dqkv = ws + b.dqkv; d.o_dx = ws + L.dxl[l];
-    d.gp2 = part; d.bp2 = part + (int64_t)nblk * TD; d.gp1 = part + 2 * (int64_t)nblk * TD; d.bp1 = part + 3 * (int64_t)nblk * TD;
-    const bool hd_on = fused_head && l == c.n_layers - 1, tl_on = fused_tail && l == 0;
+    BwdLayerStack d;
+    memset(&d, 0, sizeof(d));
+    for (int k = 0; k < nl; ++k) {  // d.l[0] = layer l (the upper one), d.l[1] = layer l - 1
+      const int li = l - k;
+      const TLayer& t = layers[li];
+      const LayerWs& w = L.lw[li];
+      const LayerBw& b = L.lb[li];
+      float* part = cx.slab + cx.slab_used;  // gp2 | bp2 | gp1 | bp1, [nblk][64] each
+      cx.slab_used += 4 * (int64_t)nblk * TD;
+      V4L_REQUIRE(cx.slab_used <= slab_cap, "internal: weight-grad slab arena overflow");
+      BwdLayer& e = d.l[k];
+      e.w2t = base + t.ff2.pkt; e.w1t = base + t.ff1.pkt; e.wot = base + t.outproj.pkt; e.wint = base + t.inproj.pkt;
+      e.g1 = p[t.ln1.g]; e.g2 = p[t.ln2.g];
+      e.dy = ws + L.dxl[li + 1];
+      e.s_qkv = ws + w.qkv; e.s_P = ws + w.P; e.s_xh1 = ws + w.xh1; e.s_rs1 = ws + w.rs1; e.s_f = ws + w.f;
+      e.s_xh2 = ws + w.xh2; e.s_rs2 = ws + w.rs2;
+      e.o_dz2 = ws + b.dz2; e.o_df = ws + b.df; e.o_dz1 = ws + b.dz1; e.o_dqkv = ws + b.dqkv; e.o_dx = ws + L.dxl[li];
+      e.gp2 = part; e.bp2 = part + (int64_t)nblk * TD; e.gp1 = part + 2 * (int64_t)nblk * TD; e.bp1 = part + 3 * (int64_t)nblk * TD;
+    }
+    const bool hd_on = fused_head && l == c.n_layers - 1, tl_on = fused_tail && l - (nl - 1) == 0;
     BwdHead bh;
     memset(&bh, 0, sizeof(bh));
     if (hd_on) {
@@ -1286,37 +1297,50 @@ int v4l_net::backward_t(const float* state, const T* image, const int* rowidx, i
       bt.o_dhc = ws + L.dhc; bt.o_de0 = dehp[0]; bt.o_dc3 = ws + L.dc3;
     }
     g_op = "layer";
-    const double fl = 4.0 * n * 872576.0 + (hd_on ? 2.0 * n * 2 * (16 * 256 + 256 * 256 + 256 * 128) : 0.0) +
+    const double fl = nl * 4.0 * n * 872576.0 + (hd_on ? 2.0 * n * 2 * (16 * 256 + 256 * 256 + 256 * 128) : 0.0) +
                       (tl_on ? 2.0 * n * (64 * 256 + 256 * 256 + 16 * 64 * 64) : 0.0);
 #define V4L_BWD_LAYER(H, TL)                                                                                              \
   do {                                                                                                                    \
     const char* kn = H ? (TL ? "fused_layer_bwd_head_tail" : "fused_layer_bwd_head")                                      \
                        : (TL ? "fused_layer_bwd_tail" : "fused_layer_bwd");                                               \
     if (spw == 2)                                                                                                         \
-      V4L_KLAUNCH(kn, fl, s, (bwd_layer_kernel<T, 2, H, TL>), dim3(nblk), dim3(256), (BwdLayLds<T, 2>::bytes), s, d, bh, bt, n); \
+      V4L_KLAUNCH(kn, fl, s, (bwd_layer_kernel<T, 2, H, TL, 1>), dim3(nblk), dim3(256), (BwdLayLds<T, 2>::bytes), s, d, bh, bt, n); \
     else                                                                                                                  \
-      V4L_KLAUNCH(kn, fl, s, (bwd_layer_kernel<T, 4, H, TL>), dim3(nblk), dim3(256), (BwdLayLds<T, 4>::bytes), s, d, bh, bt, n); \
+      V4L_KLAUNCH(kn, fl, s, (bwd_layer_kernel<T, 4, H, TL, 1>), dim3(nblk), dim3(256), (BwdLayLds<T, 4>::bytes), s, d, bh, bt, n); \
   } while (0)
+    if (stacked) {
+      if (spw == 2)
+        V4L_KLAUNCH("fused_layer_bwd_stack", fl, s, (bwd_layer_kernel<T, 2, true, true, 2>), dim3(nblk), dim3(256), (BwdLayLds<T, 2>::bytes), s, d, bh, bt, n);
+      else
+        V4L_KLAUNCH("fused_layer_bwd_stack", fl, s, (bwd_layer_kernel<T, 4, true, true, 2>), dim3(nblk), dim3(256), (BwdLayLds<T, 4>::bytes), s, d, bh, bt, n);
+    } else
     if (hd_on && tl_on) V4L_BWD_LAYER(true, true);
     else if (hd_on) V4L_BWD_LAYER(true, false);
     else if (tl_on) V4L_BWD_LAYER(false, true);
     else V4L_BWD_LAYER(false, false);
 #undef V4L_BWD_LAYER
     V4L_LAUNCH_CHECK();
-    const int lnp[4] = {t.ln2.g, t.ln2.b, t.ln1.g, t.ln1.b};
-    for (int k = 0; k < 4; ++k) {
-      RedDesc r;
-      memset(&r, 0, sizeof(r));
-      r.slab = part + (int64_t)k * nblk * TD;
-      r.dW = grads + params[lnp[k]].goff;
-      r.nsplit = nblk; r.N = 1; r.K = TD; r.Npad = 1; r.Kpad = TD; r.Ktorch = TD;
-      red.push_back(r);
+    for (int kk = 0; kk < nl; ++kk) {
+      const int li = l - kk;
+      const TLayer& t = layers[li];
+      const LayerWs& w = L.lw[li];
+      const LayerBw& b = L.lb[li];
+      const float* part = d.l[kk].gp2;
+      const int lnp[4] = {t.ln2.g, t.ln2.b, t.ln1.g, t.ln1.b};
+      for (int k = 0; k < 4; ++k) {
+        RedDesc r;
+        memset(&r, 0, sizeof(r));
+        r.slab = part + (int64_t)k * nblk * TD;
+        r.dW = grads + params[lnp[k]].goff;
+        r.nsplit = nblk; r.N = 1; r.K = TD; r.Npad = 1; r.Kpad = TD; r.Ktorch = TD;
+        red.push_back(r);
+      }
+      const float* xin = sizeof(T) == 2 ? ws + w.xin : ws + L.x[li];
+      if ((rc = lin_wgrad_wide(cx, t.ff2, ws + b.dz2, ws + w.f, R))) return rc;
+      if ((rc = lin_wgrad_wide(cx, t.ff1, ws + b.df, ws + w.x1, R))) return rc;
+      if ((rc = lin_wgrad_wide(cx, t.outproj, ws + b.dz1, ws + w.ctx, R))) return rc;
+      if ((rc = lin_wgrad_wide(cx, t.inproj, ws + b.dqkv, xin, R))) return rc;
     }
-    const float* xin = sizeof(T) == 2 ? ws + w.xin : ws + L.x[l];
-    if ((rc = lin_wgrad_wide(cx, t.ff2, ws + b.dz2, ws + w.f, R))) return rc;
-    if ((rc = lin_wgrad_wide(cx, t.ff1, ws + b.df, ws + w.x1, R))) return rc;
-    if ((rc = lin_wgrad_wide(cx, t.outproj, ws + b.dz1, ws + w.ctx, R))) return rc;
-    if ((rc = lin_wgrad_wide(cx, t.inproj, ws + b.dqkv, xin, R))) return rc;
   }
   for (int l = c.n_layers - 1; l >= 0 && !fused_bwd; --l) {
     const TLayer& t = layers[l];
