@@ -604,6 +604,7 @@ __global__ __launch_bounds__(256) void col0_kernel(const float* __restrict__ src
 // order). 16-byte loads, one or two per thread: the 388 K-float buffer is one short burst over the whole chip, not 24
 // dependent trips of 64 blocks (12 us -> ~4 us).
 constexpr int GRAD_NORM_PARTS = 256;
+constexpr int ADAM_MAX_PARTS = 8192;  // partials clip_adam_kernel can add up (32 per thread)
 __global__ __launch_bounds__(256) void grad_sumsq_kernel(const float* __restrict__ g, int64_t n, float* __restrict__ part) {
   double s = 0.0;
   const int64_t n4 = n >> 2;
@@ -643,8 +644,8 @@ __global__ void ctl_set_kernel(UpdCtl* c, int upd_index, long long step, double 
 // Opens update #upd_index: selects its rows (identity when rowidx_all is null), clears the statistics record and
 // advances the Adam step / bias corrections (double precision, like torch/optim/adam.py::_single_tensor_adam).
 // adv != null: also the advantage statistics of the selected rows (adv_stats_kernel's work, one launch less).
-__global__ __launch_bounds__(1024) void upd_begin_kernel(UpdCtl* c, const int* __restrict__ rowidx_all, int n,
-                                                         int* rowidx_cur, float* stats_cur, const float* __restrict__ adv) {
+__device__ __forceinline__ void upd_begin_body(UpdCtl* c, const int* __restrict__ rowidx_all, int n, int* rowidx_cur,
+                                               float* stats_cur, const float* __restrict__ adv) {
   const int u = c->upd_index;
   for (int i = threadIdx.x; i < n; i += blockDim.x) rowidx_cur[i] = rowidx_all ? rowidx_all[(int64_t)u * n + i] : i;
   if (threadIdx.x < ST_SIZE) stats_cur[threadIdx.x] = 0.f;
@@ -665,17 +666,30 @@ __global__ __launch_bounds__(1024) void upd_begin_kernel(UpdCtl* c, const int* _
 __global__ __launch_bounds__(256) void clip_adam_kernel(const ParamSeg* __restrict__ segs, int nseg,
                                                         const float* __restrict__ g, float* __restrict__ m,
                                                         float* __restrict__ v, const float* __restrict__ part, int npart,
-                                                        float max_norm, float eps, const UpdCtl* __restrict__ ctl,
+                                                        const float* __restrict__ extra, int nextra, float max_norm, float eps, const UpdCtl* __restrict__ ctl,
                                                         int which, float* __restrict__ norm_out, UpdCtl* close_ctl,
                                                         const float* stats_cur, float* __restrict__ stats_all) {
   const ParamSeg sg = segs[find_desc(segs, nseg, (int64_t)blockIdx.x)];
   const float beta1 = ctl->beta1, beta2 = ctl->beta2;
   const float step_size = ctl->step_size[which], bc2_sqrt = ctl->bc2_sqrt;
   const int lane_ = threadIdx.x & 63;
-  float ps = 0.f;  // GRAD_NORM_PARTS partials, four per lane, same order in every wave: deterministic
+  // the norm's partials (grad_sumsq_kernel's, or one per wgrad_reduce block: npart <= ADAM_MAX_PARTS), strided over the block's
+  // threads with every load in flight at once, then lanes -> waves in a fixed order: the same bits in every block
+  __shared__ float wpart[4];
+  float pv[ADAM_MAX_PARTS / 256];
 #pragma unroll
-  for (int k = 0; k < GRAD_NORM_PARTS / 64; ++k) ps += lane_ + 64 * k < npart ? part[lane_ + 64 * k] : 0.f;
-  const float tot = sqrtf(wave_sum(ps));
+  for (int i = 0; i < ADAM_MAX_PARTS / 256; ++i) {
+    const int k = (int)threadIdx.x + 256 * i;
+    pv[i] = part[k < npart ? k : 0];
+  }
+  float ps = 0.f;
+#pragma unroll
+  for (int i = 0; i < ADAM_MAX_PARTS / 256; ++i) ps += (int)threadIdx.x + 256 * i < npart ? pv[i] : 0.f;
+  if ((int)threadIdx.x < nextra) { const float x = extra[threadIdx.x]; ps = fmaf(x, x, ps); }  // gradients no reduce block wrote (log sigma)
+  ps = wave_sum(ps);
+  if (lane_ == 0) wpart[threadIdx.x >> 6] = ps;
+  __syncthreads();
+  const float tot = sqrtf((wpart[0] + wpart[1]) + (wpart[2] + wpart[3]));
   const float coef = fminf(max_norm / (tot + 1e-6f), 1.f);
   if (blockIdx.x == 0 && threadIdx.x == 0 && norm_out != nullptr) *norm_out = tot;
   if (blockIdx.x == 0 && close_ctl != nullptr) {
@@ -722,10 +736,10 @@ struct PackDesc {
 // 8 consecutive packed elements (one row: every packed row length is a multiple of 8) per thread, one 16 / 32-byte store
 constexpr int PACK_PER_BLOCK = 256 * 8;
 template <typename T>
-__global__ __launch_bounds__(256) void pack_kernel(const PackDesc* __restrict__ descs, int nd, T* __restrict__ dst) {
-  const PackDesc d = descs[find_desc(descs, nd, (int64_t)blockIdx.x)];
+__device__ __forceinline__ void pack_body(const PackDesc* __restrict__ descs, int nd, T* __restrict__ dst, int64_t blk) {
+  const PackDesc d = descs[find_desc(descs, nd, blk)];
   const V4L_GLOBAL float* src = as_global(d.src);
-  const int64_t e0 = (((int64_t)blockIdx.x - d.blk0) * 256 + threadIdx.x) * 8;
+  const int64_t e0 = ((blk - d.blk0) * 256 + threadIdx.x) * 8;
   if (e0 >= (int64_t)d.R * d.Cc) return;
   const int r = (int)(e0 / d.Cc), c0 = (int)(e0 - (int64_t)r * d.Cc);
   float val[8];
@@ -768,6 +782,19 @@ __global__ __launch_bounds__(256) void pack_kernel(const PackDesc* __restrict__ 
   T* o = dst + d.dst_off + e0;
   st4(o, val[0], val[1], val[2], val[3]);
   st4(o + 4, val[4], val[5], val[6], val[7]);
+}
+template <typename T>
+__global__ __launch_bounds__(256) void pack_kernel(const PackDesc* __restrict__ descs, int nd, T* __restrict__ dst) {
+  pack_body<T>(descs, nd, dst, (int64_t)blockIdx.x);
+}
+// The first launch of an update: block 0 opens the update (upd_begin_body), the others refresh the critic's operand-type
+// weight copies — two independent latency chains that used to be two launches back to back.
+template <typename T>
+__global__ __launch_bounds__(256) void begin_pack_kernel(UpdCtl* c, const int* __restrict__ rowidx_all, int n, int* rowidx_cur,
+                                                         float* stats_cur, const float* __restrict__ adv,
+                                                         const PackDesc* __restrict__ descs, int nd, T* __restrict__ dst) {
+  if (blockIdx.x == 0) upd_begin_body(c, rowidx_all, n, rowidx_cur, stats_cur, adv);
+  else pack_body<T>(descs, nd, dst, (int64_t)blockIdx.x - 1);
 }
 
 // --------------------------------------------------------------------------------- GAE

@@ -808,7 +808,7 @@ struct RedDesc {
   int nsplit, N, K, Npad, Kpad, Ktorch, Cin, taps;
   int64_t blk0;        // first block of this descriptor
 };
-__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const RedDesc* __restrict__ descs, int nd) {
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const RedDesc* __restrict__ descs, int nd, float* __restrict__ sq_part) {
   // 64 outputs per block x 4 slab groups: thread (o, g) adds slabs g, g+4, g+8, ... (4 independent accumulators),
   // the 4 group sums are combined through LDS in a fixed order -> deterministic and latency-tolerant
   __shared__ float part[4][64];
@@ -838,8 +838,13 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const RedDesc* __rest
   }
   part[g][o] = (s0 + s1) + (s2 + s3);
   __syncthreads();
-  if (g == 0 && p != nullptr) {
-    const float sum = (part[0][o] + part[1][o]) + (part[2][o] + part[3][o]);
+  if (g == 0) {  // wave 0: the 64 outputs of this block; their squares are the block's share of the gradient norm
+    const float sum = p != nullptr ? (part[0][o] + part[1][o]) + (part[2][o] + part[3][o]) : 0.f;
+    if (sq_part != nullptr) {
+      const float sq = wave_sum(sum * sum);
+      if (o == 0) sq_part[blockIdx.x] = sq;
+    }
+    if (p == nullptr) return;
     if (e < nk) {
       int kt = k;
       if (d.Cin != 0) { const int t = k / d.Cin, c = k - t * d.Cin; kt = c * d.taps + t; }

@@ -99,6 +99,9 @@ struct v4l_net {
   v4l::PackDesc* d_packs = nullptr;
   v4l::ParamSeg* d_segs = nullptr;
   v4l::RedDesc* d_red = nullptr;
+  float* d_sq = nullptr;             // sum of squares of what each wgrad_reduce block wrote (the gradient norm's partials)
+  int64_t sq_cap() const { return total_params / 64 + 2 * MAX_RED + 64; }
+  int red_blocks = 0;                // blocks of the last wgrad_reduce launch (0: no partials available)
   static constexpr int MAX_RED = 96;
   static constexpr int MAX_TNP = 64;
   v4l::TnProb* d_tnp = nullptr;

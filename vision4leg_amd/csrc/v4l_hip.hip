@@ -251,7 +251,9 @@ static int wgrad_reduce_all(Ctx& c) {
     net->red_cached = net->red;
   }
   g_op = "wgrad_reduce";
-  V4L_KLAUNCH("wgrad_reduce", 0, c.s, wgrad_reduce_kernel, dim3((unsigned)blk), dim3(256), 0, c.s, net->d_red, (int)net->red.size());
+  float* sq = blk <= net->sq_cap() ? net->d_sq : nullptr;
+  net->red_blocks = sq != nullptr ? (int)blk : 0;
+  V4L_KLAUNCH("wgrad_reduce", 0, c.s, wgrad_reduce_kernel, dim3((unsigned)blk), dim3(256), 0, c.s, net->d_red, (int)net->red.size(), sq);
   V4L_LAUNCH_CHECK();
   return 0;
 }
@@ -796,7 +798,7 @@ int v4l_net::build() {
 
 int64_t v4l_net::table_bytes() const {
   return (int64_t)(packs.size() * sizeof(PackDesc) + params.size() * sizeof(ParamSeg) + MAX_RED * sizeof(RedDesc) +
-                   MAX_TNP * sizeof(TnProb) + MAX_WIDE * sizeof(TnWide) + 1024);
+                   MAX_TNP * sizeof(TnProb) + MAX_WIDE * sizeof(TnWide) + sq_cap() * sizeof(float) + 1024);
 }
 bool v4l_net::fused_layers() const {
   return cfg.kind == V4L_NET_LOCO && cfg.ff_dim == 256 && getenv("V4L_NO_FUSED_LAYER") == nullptr;
@@ -1757,6 +1759,8 @@ int v4l_net_bind(v4l_net* net, float* const* params_dev, void* packed_dev, void*
   net->d_tnp = (TnProb*)((char*)net->d_red + (v4l_net::MAX_RED * sizeof(RedDesc) + 63) / 64 * 64);
   net->d_wide = (TnWide*)((char*)net->d_tnp + (v4l_net::MAX_TNP * sizeof(TnProb) + 63) / 64 * 64);
   net->tnp_cached.clear();
+  net->d_sq = (float*)((char*)net->d_wide + (v4l_net::MAX_WIDE * sizeof(TnWide) + 63) / 64 * 64);
+  net->red_blocks = 0;
   // synchronous pageable copies: the host vectors die at return
   V4L_HIP_CHECK(hipStreamSynchronize(s));
   V4L_HIP_CHECK(hipMemcpy(net->d_packs, net->packs.data(), net->packs.size() * sizeof(PackDesc), hipMemcpyHostToDevice));
@@ -2194,13 +2198,18 @@ int v4l_trainer_critic_grads(v4l_trainer* tr, const v4l_rollout* ro, int n, cons
   float* st = tr->stats_cur;
   const int* rowidx = tr->rowidx_cur;
   g_op = "ctl";
-  // selects the rows of this update, clears the statistics record, advances Adam's step, advantage statistics
-  V4L_KLAUNCH("upd_begin", 0, s, upd_begin_kernel, dim3(1), dim3(n >= 512 ? 1024 : 256), 0, s, tr->ctl, tr->rowidx_all, n, tr->rowidx_cur, st,
-              ro->advs_dev);
-  V4L_LAUNCH_CHECK();
+  // selects the rows of this update, clears the statistics record, advances Adam's step, advantage statistics (block 0) and
+  // refreshes the critic's packed weights (the other blocks) in one launch
   // (no clearing of g_vf / g_pf: v4l_net_backward writes every element of the flat gradient — tests/test_gpu_parity.py
   // test_backward starts from a NaN-filled buffer)
-  if ((rc = v4l_net_pack(vf, stream))) return rc;
+  V4L_REQUIRE(vf->bound, "v4l_trainer_critic_grads: the critic net is not bound");
+  if (vf->cfg.compute == V4L_BF16)
+    V4L_KLAUNCH("begin_pack", 0, s, begin_pack_kernel<__bf16>, dim3((unsigned)vf->pack_blocks + 1), dim3(256), 0, s, tr->ctl, tr->rowidx_all, n,
+                tr->rowidx_cur, st, ro->advs_dev, vf->d_packs, (int)vf->packs.size(), (__bf16*)vf->packed);
+  else
+    V4L_KLAUNCH("begin_pack", 0, s, begin_pack_kernel<float>, dim3((unsigned)vf->pack_blocks + 1), dim3(256), 0, s, tr->ctl, tr->rowidx_all, n,
+                tr->rowidx_cur, st, ro->advs_dev, vf->d_packs, (int)vf->packs.size(), (float*)vf->packed);
+  V4L_LAUNCH_CHECK();
   { PhaseScope ps("vf.fwd");
   if ((rc = v4l_net_forward(vf, ro->state_dev, ro->image_dev, rowidx, n, tr->ws, 1, stream))) return rc; }
   const Layout L = vf->layout(n);
@@ -2215,13 +2224,25 @@ int v4l_trainer_critic_grads(v4l_trainer* tr, const v4l_rollout* ro, int n, cons
 
 static int adam_step(v4l_trainer* tr, v4l_net* net, float* g, float* m, float* v, const v4l_ppo_hyper* hp, int which,
                      float* norm_out, hipStream_t s, bool close_update = false) {
-  const int gb = (int)std::min<int64_t>(GRAD_NORM_PARTS, cdiv64(net->total_params, 1024));
-  float* part = tr->norm_part + which * GRAD_NORM_PARTS;
+  int gb = (int)std::min<int64_t>(GRAD_NORM_PARTS, cdiv64(net->total_params, 1024));
+  const float* part = tr->norm_part + which * GRAD_NORM_PARTS;
+  const float* extra = nullptr;
+  int nextra = 0;
   g_op = "optim";
-  V4L_KLAUNCH("grad_sumsq", 0, s, grad_sumsq_kernel, dim3(gb), dim3(256), 0, s, g, net->total_params, part);
-  V4L_LAUNCH_CHECK();
+  // The gradient's sum of squares: on one GPU the backward's wgrad_reduce launch already left it, one partial per block
+  // (plus log sigma's gradient, which the loss kernel writes itself); after an all-reduce the buffer is summed again.
+  static const bool sq_from_reduce = getenv("V4L_NO_SQ_FROM_REDUCE") == nullptr;
+  if (sq_from_reduce && tr->comm == nullptr && hp->world_size == 1 && net->red_blocks > 0 && net->red_blocks <= ADAM_MAX_PARTS) {
+    part = net->d_sq;
+    gb = net->red_blocks;
+    if (net->logstd >= 0) { extra = g + net->params[net->logstd].goff; nextra = (int)net->params[net->logstd].numel; }
+    V4L_REQUIRE(nextra <= 64, "internal: log sigma wider than a wave");
+  } else {
+    V4L_KLAUNCH("grad_sumsq", 0, s, grad_sumsq_kernel, dim3(gb), dim3(256), 0, s, g, net->total_params, tr->norm_part + which * GRAD_NORM_PARTS);
+    V4L_LAUNCH_CHECK();
+  }
   V4L_KLAUNCH("clip_adam", 0, s, clip_adam_kernel, dim3((unsigned)net->seg_blocks), dim3(256), 0, s, net->d_segs,
-              (int)net->params.size(), g, m, v, (const float*)part, gb, hp->max_grad_norm, hp->eps, tr->ctl, which, norm_out,
+              (int)net->params.size(), g, m, v, part, gb, extra, nextra, hp->max_grad_norm, hp->eps, tr->ctl, which, norm_out,
               close_update ? tr->ctl : (UpdCtl*)nullptr, (const float*)tr->stats_cur, tr->stats_all);
   V4L_LAUNCH_CHECK();
   return 0;
