@@ -552,6 +552,11 @@ def batch1_latency(ep, policies, dev):
 
 def main():
     a = parse()
+    # stdout carries exactly ONE line (the JSON result of rank 0): everything else any library writes there while the run is
+    # going on (RCCL prints a version banner on communicator creation) is sent to stderr
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -639,7 +644,9 @@ def main():
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()
     if rank == 0:
-        print(json.dumps(res))
+        sys.stdout.flush()
+        os.dup2(real_stdout, 1)
+        print(json.dumps(res), flush=True)
 
 
 if __name__ == "__main__":

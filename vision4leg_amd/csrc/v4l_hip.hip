@@ -132,6 +132,10 @@ struct Ctx {  // per-call view of a bound net
   float* slab;         // arena for weight-grad partials (inside the workspace)
   int64_t slab_used;
   hipStream_t tn;      // stream weight-grad kernels go to: s, or the net's aux stream inside par_begin/par_end
+  // dW3's launch can be held back by conv_stack_bwd_fused and issued by the caller (next to the dense weight-grads)
+  bool defer_conv3 = false, conv3_pending = false;
+  v4l::BwdConv conv3_args = {};
+  int conv3_blocks = 0, conv3_n = 0;
 };
 
 // Fork/join of the net's auxiliary stream. Independent sibling kernels (a layer's weight-grad next to its data-grad,
@@ -482,8 +486,22 @@ static int conv_stack_bwd_fused(Ctx& c, const T* image, const int* rowidx, int n
   const double fl = 2.0 * n * (16.0 * 64 * 576 + 2.0 * 36 * 64 * 512 + 225.0 * 32 * 256);
   V4L_KLAUNCH("fused_conv_bwd", fl, c.s, bwd_conv_kernel<T>, dim3(nblk), dim3(512), BwdConvLds<T>::bytes, c.s, a);
   V4L_LAUNCH_CHECK();
+  if (c.defer_conv3) {
+    c.conv3_args = a; c.conv3_blocks = nblk; c.conv3_n = n; c.conv3_pending = true;
+    return 0;
+  }
   g_op = "conv3.wgrad";
   V4L_KLAUNCH("fused_conv3_wgrad", 2.0 * n * 16 * 64 * 576, c.tn, bwd_conv3_wgrad_kernel<T>, dim3(nblk), dim3(256), 0, c.tn, a);
+  V4L_LAUNCH_CHECK();
+  return 0;
+}
+template <typename T>
+static int conv3_wgrad_deferred(Ctx& c, hipStream_t s) {
+  if (!c.conv3_pending) return 0;
+  c.conv3_pending = false;
+  g_op = "conv3.wgrad";
+  V4L_KLAUNCH("fused_conv3_wgrad", 2.0 * c.conv3_n * 16 * 64 * 576, s, bwd_conv3_wgrad_kernel<T>, dim3(c.conv3_blocks), dim3(256), 0, s,
+              c.conv3_args);
   V4L_LAUNCH_CHECK();
   return 0;
 }
@@ -1413,11 +1431,22 @@ int v4l_net::backward_t(const float* state, const T* image, const int* rowidx, i
     ep.ldmask = 64;
     if ((rc = lin_dgrad<T>(cx, upconv, yu, ep))) return rc;
   }
-  // the dense weight-grad launches and dW3 only depend on what the layer kernels left behind. Forking them onto the
-  // auxiliary stream next to the conv-stack backward (V4L_PAR_WGRAD=1; a graph fork/join under capture) was measured:
-  // no gain in a graph, -3 % eagerly — bwd_conv_kernel's 256 blocks hold every CU's register file — so it is opt-in.
-  static const bool par_wgrad = getenv("V4L_PAR_WGRAD") != nullptr;
-  if (par_wgrad && (rc = par_begin(cx, true))) return rc;
+  // The three weight-grad launches (grouped dense, the layers' whole-output one, dW3) only depend on what the data-grad kernels
+  // left behind. Measured in the update graph (ms per 48 updates): all serial 33.75; dense ones forked next to the conv-stack
+  // data-grads 33.7 (bwd_conv_kernel holds every CU: nothing fits beside it); conv-stack data-grads FIRST, then dW3 on the
+  // main stream next to the two dense launches on the auxiliary stream 32.8 (default); three branches 34.8.
+  // V4L_PAR_WGRAD=0: serial, 1: the older fork.
+  static const int par_wgrad = getenv("V4L_PAR_WGRAD") ? atoi(getenv("V4L_PAR_WGRAD")) : 2;
+  if (par_wgrad == 2) {
+    cx.defer_conv3 = true;
+    if ((rc = conv_stack_bwd<T>(cx, image, rowidx, n, ws + L.c1, ws + L.c2, ws + L.dc3, ws + L.dc2, ws + L.dc1))) return rc;
+    if ((rc = par_begin(cx, true))) return rc;  // a graph fork / join under capture
+    if ((rc = wgrad_dense<T>(cx, cx.tn))) return rc;
+    if ((rc = conv3_wgrad_deferred<T>(cx, cx.s))) return rc;
+    if ((rc = par_end(cx))) return rc;
+    return wgrad_reduce_all<T>(cx);
+  }
+  if (par_wgrad == 1 && (rc = par_begin(cx, true))) return rc;
   if ((rc = wgrad_dense<T>(cx, cx.tn))) return rc;
   if ((rc = conv_stack_bwd<T>(cx, image, rowidx, n, ws + L.c1, ws + L.c2, ws + L.dc3, ws + L.dc2, ws + L.dc1))) return rc;
   if ((rc = par_end(cx))) return rc;
