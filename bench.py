@@ -419,6 +419,35 @@ def algo_bytes(kernel, wl, compute):
     return None
 
 
+CU_FETCH_B_PER_CLK = 13.0  # what one CU pulls from L2, measured (72 KB of weights alone take 6.1-6.4 K cycles)
+CU_CLOCK_HZ = 2.4e9
+
+
+def block_fetch_bytes(kernel, wl, compute):
+    """Bytes ONE block pulls through its CU (the weights it streams + its share of the launch's algorithmic bytes) for the
+    kernels that are bound by exactly that: each CU gets ~13 B/clk from L2 however the accesses look, so a
+    block's time has this floor whatever the chip-level HBM fraction says. -> (bytes, blocks) or None."""
+    n, E, t = wl["B"], wl["E"], (2 if compute == "bf16" else 4)
+    lw = (64 * 192 + 64 * 64 + 64 * 256 + 256 * 64) * t          # one transformer layer's weights
+    head_w = (128 * 256 + 256 * 256 + 256 * 16) * t
+    conv_w = (4 * 64 * 32 + 32 * 16 * 64 + 64 * 9 * 64 + 64 * 64) * t
+    mlp_w = (128 * 256 + 256 * 256 + 256 * 64) * t
+    L = wl.get("layers", 2)
+    table = {
+        "rollout_layers_head": (2 * E, L * lw + head_w),
+        "rollout_encoder": (E, conv_w),
+        "fused_conv_bwd": (min(n, 256), -(-n // min(n, 256)) * 64 * 576 * t + 4 * 32 * 256 * t),
+        "fused_layer_bwd_stack": (-(-n // 4), L * lw + head_w + mlp_w - 128 * 256 * t + 64 * 64 * t),
+        "fused_layer_stack_head": (-(-n // 2), L * lw + head_w),
+        "fused_encoder": (256, conv_w),
+    }
+    if kernel not in table:
+        return None
+    blocks, w = table[kernel]
+    by = algo_bytes(kernel, wl, compute)
+    return (w + (by / blocks if by else 0.0), blocks)
+
+
 def _profiled(L, fn):
     """Run fn() with the library's HIP-event profiler on; -> [(phase|op|kernel, calls, total_us, flops)]."""
     import ctypes as C
@@ -484,7 +513,19 @@ def roofline(ep, compute, breakdown_path):
         t_hbm = by / (PEAK_HBM * 1e9) * 1e6 if by else 0.0
         hbm_bound = bool(by) and t_hbm >= t_mfma
         rec = pmc.get(kern) or {}
+        for suffix in ("_stack_head", "_stack", "_head", "_tail"):  # PMC rows are keyed by kernel function (tools/pmc_traffic.py)
+            if not rec and kern.endswith(suffix):
+                rec = pmc.get(kern[:-len(suffix)]) or {}
+        bf = block_fetch_bytes(kern, wl, compute)
+        cu = None
+        if bf:
+            bpc = bf[0] / (avg_us * 1e-6 * CU_CLOCK_HZ)
+            cu = {"bytes_per_block": round(bf[0]), "blocks": bf[1], "achieved_B_per_clk": round(bpc, 2),
+                  "ceiling_B_per_clk": CU_FETCH_B_PER_CLK, "frac": round(bpc / CU_FETCH_B_PER_CLK, 3),
+                  "note": "L2 -> CU fetch of ONE block (its weights + its share of the algorithmic bytes) over the launch time, "
+                          "against the measured per-CU ceiling (DESIGN.md 4.1); the chip-level `frac` cannot see this bound"}
         return {
+            "cu_fetch": cu,
             "bound": "hbm" if hbm_bound else "mfma", "kernel": kern,
             "achieved": round(gbs, 1) if hbm_bound else round(tf, 2),
             "peak": PEAK_HBM if hbm_bound else PEAK[compute], "unit": "GB/s" if hbm_bound else "TFLOP/s",

@@ -29,5 +29,3 @@ names=["load dy / heads","ln2 bwd","df gemm","dx1 gemm","qkv,P loads + ln1 bwd",
 print("bwd_layer_kernel (layer 0, TAIL variant) block 0 phase cycles:")
 for nm,c in zip(names,np.diff(st)): print("  %-24s %8d"%(nm,c))
 print("  total %d"%(st[9]-st[0]))
-sub=np.array([buf[38],buf[42],buf[43],buf[44],buf[39]],dtype=np.int64)
-print("attention sub-phases (dP tiles | softmax' rows | 17x17 column loops | stores):", np.diff(sub))

@@ -22,10 +22,10 @@ def show(title, i0, names):
     for k, n in enumerate(names):
         print("  %-28s %8d" % (n, st[i0 + k + 1] - st[i0 + k]))
     print("  total %d cycles" % (st[i0 + len(names)] - st[i0]))
-show("rollout_layer_kernel block(0,0), layer 0:", 64,
+show("rollout_stack_kernel block(0,0), layer 0:", 64,
      ["load x", "in_proj", "scores", "softmax", "PV", "out_proj+res", "LN1", "FF1", "FF2+res", "LN2"])
 print("  FF1 detail: first tile MFMAs done +%d, both tiles stored +%d, next loads issued +%d, barrier +%d" % (st[75]-st[71], st[76]-st[75], st[77]-st[76], st[72]-st[77]))
 print("  layer 1 (all phases)         %8d" % (st[80] - st[74]))
 show("head:", 80, ["pool", "fc0", "fc1", "fc2", "sample+file"])
 print("  kernel total %d cycles" % (st[85] - st[64]))
-show("rollout_encoder_kernel block 0:", 96, ["image load+cast+file", "conv1", "conv2", "conv3", "sum+relu", "up-conv"])
+show("rollout_encoder2_kernel block 0:", 96, ["image load+cast+file", "conv1", "conv2", "conv3", "sum+relu", "up-conv"])

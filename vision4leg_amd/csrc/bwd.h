@@ -140,7 +140,7 @@ __device__ __forceinline__ void ln_bwd_rows(float* d, int ld, const LnPre<ROWS>&
 }
 
 #ifdef V4L_INFER_TIMING
-#define LAY_STAMP(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) g_inf_stamps[32 + (i)] = clock64(); } while (0)
+#define LAY_STAMP(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) g_inf_stamps[32 + (i)] = clock64(); } while (0)  // stacked launch: the lowest layer's pass overwrites the upper one's
 #else
 #define LAY_STAMP(i)
 #endif
@@ -262,6 +262,7 @@ __global__ __launch_bounds__(256) void bwd_layer_kernel(BwdLayerStack stk, BwdHe
   for (int l = 0; l < NL; ++l) {
   const BwdLayer& w = stk.l[l];
   const bool last = l == NL - 1;  // compile-time after unrolling: the TAIL part belongs to the lowest layer
+  if (l > 0) { LAY_STAMP(0); LAY_STAMP(1); }
   __syncthreads();
   // ---- norm2 backward: a = dz2 (the next GEMM's first weight fragments are requested before the norm's global stores)
   GemmRing<T, 4, 2> ring_df = gemm_prefetch<T, 4, 2>((const T*)w.w2t, 64, nt4, lane);

@@ -630,6 +630,7 @@ __global__ __launch_bounds__(256) void infer_layer_kernel(InfLayerStack stk, Inf
       st4(cb + r * LDT + c4, 0.f, 0.f, 0.f, 0.f);  // rows the attention does not write (padding / absent samples)
     }
   } else {
+    INF_STAMP(0);     // (stacked launch: the last layer's pass overwrites the earlier one's stamps)
     __syncthreads();  // the previous layer's norm2 left this layer's input rows in xs
     if (w.s_xin != nullptr) {
       for (int i4 = tid; i4 < ROWS * (TD / 4); i4 += 256) {
