@@ -118,3 +118,41 @@ def test_epoch_of_graph_replays_at_b1024(mode, device):
     util.record("graph_epoch_b1024/%s/worst_abs_param_vs_oracle" % mode, worst)
     util.record("graph_epoch_b1024/%s/mean_abs_param_vs_oracle" % mode, drift)
     assert worst <= (5e-5 if mode == "f32" else 2.2e-4 * U) and drift <= (1e-6 if mode == "f32" else 2e-5 * U)
+
+
+@pytest.mark.parametrize("mode", MODES)
+def test_stacked_layer_launches_equal_one_launch_per_layer(mode, device):
+    """The training forward / backward walk both transformer layers in ONE launch each (infer_layer_kernel<..., NL=2>,
+    bwd_layer_kernel<..., NL=2>: token rows / dx stay in LDS between the layers). V4L_NO_LAYER_STACK=1 selects one launch per
+    layer (the NL=1 instantiations every other depth uses). Same arithmetic in the same order: every output and every
+    parameter gradient must agree to the last bit."""
+    case = dict(util.CASES["loco_s93"], B=96)
+    n = case["B"]
+    obs = torch.tensor(util.make_batch(case)["obs"], dtype=torch.float32)
+    g = torch.Generator().manual_seed(7)
+    w = torch.randn(n, 1, generator=g)
+    res = []
+    for no_stack in (False, True):
+        if no_stack:
+            os.environ["V4L_NO_LAYER_STACK"] = "1"
+        try:
+            pf, vf = _build(case, mode, device)
+            hip = vf.hip
+            st, im, _ = hip.stage(obs.to(device))
+            out = hip.forward(st, im, n, train=True)
+            value = out[:, 0].cpu().clone() if out is not None and out.dim() == 2 else None
+            dout = torch.zeros(n, 16, dtype=torch.float32, device=device)
+            dout[:, :1] = w.to(device)
+            grads = torch.full((hip.total_params,), float("nan"), dtype=torch.float32, device=device)
+            hip.backward(st, im, n, dout, grads)
+            torch.cuda.synchronize()
+            assert not torch.isnan(grads).any()
+            res.append((value, grads.cpu().clone()))
+        finally:
+            os.environ.pop("V4L_NO_LAYER_STACK", None)
+    (v0, g0), (v1, g1) = res
+    if v0 is not None and v1 is not None:
+        assert torch.equal(v0, v1)
+    worst = (g0 - g1).abs().max().item()
+    util.record("stacked_layers/%s/max_abs_grad_diff_vs_per_layer_launches" % mode, worst)
+    assert worst == 0.0, worst

@@ -1041,7 +1041,7 @@ int v4l_net::forward_t(const float* state, const T* image, const int* rowidx, in
                             c.out_dim <= OUT_LD && getenv("V4L_NO_FUSED_HEAD") == nullptr;
     // both layers + the heads in ONE launch when the stack is the shipped two layers (the token rows stay in LDS between
     // the layers); otherwise one launch per TransformerEncoderLayer. 2 or 4 samples per block, saving what backward_t reads.
-    static const bool stack_ok = getenv("V4L_NO_LAYER_STACK") == nullptr;
+    const bool stack_ok = getenv("V4L_NO_LAYER_STACK") == nullptr;  // (read per call: tests switch it)
     const bool stacked = fused_layers && fused_head && c.n_layers == 2 && stack_ok;
     for (int l = 0; l < c.n_layers && fused_layers; l += stacked ? 2 : 1) {
       static bool attr_done = false;
@@ -1257,7 +1257,7 @@ int v4l_net::backward_t(const float* state, const T* image, const int* rowidx, i
   // both layers (+ heads before, + encoder-side data-grads after) in ONE launch when the stack is the shipped two layers: the
   // upper layer's dx stays in LDS as the lower layer's dy; otherwise one launch per TransformerEncoderLayer (csrc/bwd.h).
   // Every data-grad of a layer has its intermediates in LDS; the four weight-grads are deferred to the grouped launch.
-  static const bool bwd_stack_ok = getenv("V4L_NO_LAYER_STACK") == nullptr;
+  const bool bwd_stack_ok = getenv("V4L_NO_LAYER_STACK") == nullptr;
   const bool stacked = fused_bwd && fused_head && fused_tail && c.n_layers == 2 && bwd_stack_ok;
   for (int l = c.n_layers - 1; l >= 0 && fused_bwd; l -= stacked ? 2 : 1) {
     static bool attr_done = false;
