@@ -459,17 +459,35 @@ __global__ __launch_bounds__(256) void gemm_nt_dgrad_kernel(DgradClasses<T> cls)
 // LDS traffic). Row addresses are wave-uniform (scalar unit), column offsets are per-lane constants hoisted out of
 // the m loop. Block = 4 waves, stage = 64 rows (wave w stages rows 16w..16w+15), output tile BN(n) x 64*KT(k),
 // wave w owns k-tiles [w*KT, (w+1)*KT).
-template <typename T, int BN, int KT, class YL, class XL>
+// LDS of one tn_body block: sY [BN][LD] | sX [64 KT][LD] | bias partials [4][64]
+template <typename T, int BN, int KT> struct TnBodyLds {
+  static constexpr int LD = 64 + (sizeof(T) == 2 ? 8 : 4);
+  static constexpr size_t bytes = (size_t)(BN + 64 * KT) * LD * sizeof(T) + 4 * 64 * 4;
+};
+// DYN: the block's LDS comes from the caller (a kernel that hosts several kinds of blocks shares ONE dynamic allocation
+// between them instead of adding every kind's static arrays up)
+template <typename T, int BN, int KT, class YL, class XL, bool DYN = false>
 __device__ __forceinline__ void tn_body(const YL& yl, const XL& xl, int M, int m_per_block, float* __restrict__ slab,
-                                        float* __restrict__ bslab, int Npad, int Kpad, int bx, int by, int bz) {
+                                        float* __restrict__ bslab, int Npad, int Kpad, int bx, int by, int bz,
+                                        unsigned char* dyn_smem = nullptr) {
   constexpr int BMR = 64;
   constexpr int LD = BMR + (sizeof(T) == 2 ? 8 : 4);
   constexpr int NT = BN / 16;
   constexpr int BKO = 64 * KT;
   typedef typename Frag<T>::type frag_t;
-  __shared__ __attribute__((aligned(16))) T sY[BN * LD];   // [n][m]
-  __shared__ __attribute__((aligned(16))) T sX[BKO * LD];  // [k][m]
-  __shared__ float sBias[4][64];
+  T* sY;                  // [n][m]
+  T* sX;                  // [k][m]
+  float (*sBias)[64];
+  if constexpr (DYN) {
+    sY = reinterpret_cast<T*>(dyn_smem);
+    sX = sY + BN * LD;
+    sBias = reinterpret_cast<float (*)[64]>(sX + BKO * LD);
+  } else {
+    __shared__ __attribute__((aligned(16))) T sY_[BN * LD];
+    __shared__ __attribute__((aligned(16))) T sX_[BKO * LD];
+    __shared__ float sBias_[4][64];
+    sY = sY_; sX = sX_; sBias = sBias_;
+  }
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -791,6 +809,31 @@ __global__ __launch_bounds__(256) void gemm_tn_wide_kernel(const TnWide* __restr
   else if (p.N == 192 && p.K == 64) tn_wide_body<T, 192, 64>(p, bz, tn_wide_smem);
   else if (p.N == 64 && p.K == 256) tn_wide_body<T, 64, 256>(p, bz, tn_wide_smem);
   else tn_wide_body<T, 64, 64>(p, bz, tn_wide_smem);
+}
+// The grouped dense weight-grads and the layers' whole-output weight-grads in ONE launch: blocks [0, wblocks) are
+// gemm_tn_wide_kernel's, the rest gemm_tn_group_kernel's. Both kinds are short latency chains of a few hundred blocks; side by
+// side they cost the longer one's time instead of the sum. One dynamic LDS allocation (the larger need) serves either kind.
+template <typename T>
+__global__ __launch_bounds__(256) void gemm_tn_dense_kernel(const TnWide* __restrict__ wprobs, int nw, int wblocks,
+                                                            const TnProb* __restrict__ gprobs, int ng) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char tn_wide_smem[];
+  if ((int)blockIdx.x < wblocks) {
+    int pi = 0;
+    for (int i = 1; i < nw; ++i) pi = wprobs[i].blk0 <= (int)blockIdx.x ? i : pi;
+    const TnWide p = wprobs[pi];
+    const int bz = (int)blockIdx.x - p.blk0;
+    if (p.N == 256 && p.K == 64) tn_wide_body<T, 256, 64>(p, bz, tn_wide_smem);
+    else if (p.N == 192 && p.K == 64) tn_wide_body<T, 192, 64>(p, bz, tn_wide_smem);
+    else if (p.N == 64 && p.K == 256) tn_wide_body<T, 64, 256>(p, bz, tn_wide_smem);
+    else tn_wide_body<T, 64, 64>(p, bz, tn_wide_smem);
+  } else {
+    const int64_t b = (int64_t)blockIdx.x - wblocks;
+    const TnProb p = gprobs[find_desc(gprobs, ng, b)];
+    const int lb = (int)(b - p.blk0);
+    const int bx = lb % p.gx, t = lb / p.gx;
+    tn_body<T, 64, 1, ADenseG, ADenseG, true>(ADenseG(p.y), ADenseG(p.x), p.M, p.mpb, p.slab, p.bslab, p.Npad, p.Kpad, bx,
+                                              t % p.gy, t / p.gy, tn_wide_smem);
+  }
 }
 static inline bool tn_wide_shape(int N, int K) {
   return (N == 256 && K == 64) || (N == 192 && K == 64) || (N == 64 && K == 256) || (N == 64 && K == 64);

@@ -195,14 +195,16 @@ static int wgrad_finish(Ctx& c) {
   int rc = wgrad_dense<T>(c, c.s);
   return rc ? rc : wgrad_reduce_all<T>(c);
 }
-// the deferred dense weight-grad launches (grouped + whole-output kernels) on stream ds
+// the deferred dense weight-grad launches (grouped + whole-output kernels) on stream ds: ONE launch when both kinds are
+// present (gemm_tn_dense_kernel hosts both kinds of blocks; V4L_SPLIT_DENSE_WGRAD=1: one launch per kind)
 template <typename T>
 static int wgrad_dense(Ctx& c, hipStream_t ds) {
   v4l_net* net = c.net;
+  int64_t gb = 0;
+  int wb = 0;
   if (!net->tnp.empty()) {
     V4L_REQUIRE(net->tnp.size() <= (size_t)v4l_net::MAX_TNP, "internal: too many deferred weight-grads");
-    int64_t tb = 0;
-    for (TnProb& q : net->tnp) { const int64_t nb = q.blk0; q.blk0 = tb; tb += nb; }
+    for (TnProb& q : net->tnp) { const int64_t nb = q.blk0; q.blk0 = gb; gb += nb; }
     const size_t bytes = net->tnp.size() * sizeof(TnProb);
     if (net->tnp_cached.size() != net->tnp.size() || memcmp(net->tnp_cached.data(), net->tnp.data(), bytes) != 0) {
       V4L_REQUIRE(!capturing(c.s), "internal: weight-grad geometry changed while capturing a graph");
@@ -210,15 +212,10 @@ static int wgrad_dense(Ctx& c, hipStream_t ds) {
       V4L_HIP_CHECK(hipMemcpy(net->d_tnp, net->tnp.data(), bytes, hipMemcpyHostToDevice));
       net->tnp_cached = net->tnp;
     }
-    g_op = "dense.wgrad";
-    V4L_KLAUNCH("gemm_tn_group", net->tnp_flops, ds, gemm_tn_group_kernel<T>, dim3((unsigned)tb), dim3(256), 0, ds,
-                (const TnProb*)net->d_tnp, (int)net->tnp.size());
-    V4L_LAUNCH_CHECK();
   }
   if (!net->wide.empty()) {
     V4L_REQUIRE(net->wide.size() <= (size_t)v4l_net::MAX_WIDE, "internal: too many fused-layer weight-grads");
-    int tb = 0;
-    for (TnWide& q : net->wide) { const int nb = q.blk0; q.blk0 = tb; tb += nb; }
+    for (TnWide& q : net->wide) { const int nb = q.blk0; q.blk0 = wb; wb += nb; }
     const size_t bytes = net->wide.size() * sizeof(TnWide);
     if (net->wide_cached.size() != net->wide.size() || memcmp(net->wide_cached.data(), net->wide.data(), bytes) != 0) {
       V4L_REQUIRE(!capturing(c.s), "internal: weight-grad geometry changed while capturing a graph");
@@ -226,14 +223,33 @@ static int wgrad_dense(Ctx& c, hipStream_t ds) {
       V4L_HIP_CHECK(hipMemcpy(net->d_wide, net->wide.data(), bytes, hipMemcpyHostToDevice));
       net->wide_cached = net->wide;
     }
-    static bool attr_done = false;
-    if (!attr_done) {
-      V4L_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_wide_kernel<T>),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)TnWideLds<T>::max_bytes));
-      attr_done = true;
-    }
+  }
+  constexpr size_t dense_lds = TnWideLds<T>::max_bytes > TnBodyLds<T, 64, 1>::bytes ? TnWideLds<T>::max_bytes : TnBodyLds<T, 64, 1>::bytes;
+  static bool attr_done = false;
+  if (!attr_done) {
+    V4L_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_wide_kernel<T>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)TnWideLds<T>::max_bytes));
+    V4L_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_dense_kernel<T>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)dense_lds));
+    attr_done = true;
+  }
+  const bool split = getenv("V4L_SPLIT_DENSE_WGRAD") != nullptr;
+  if (gb > 0 && wb > 0 && !split) {
+    g_op = "layer.wgrad";  // (the layers' share dominates: 8 of the ~20 problems, 2/3 of the blocks)
+    V4L_KLAUNCH("gemm_tn_dense", net->wide_flops + net->tnp_flops, ds, gemm_tn_dense_kernel<T>, dim3((unsigned)(wb + gb)), dim3(256),
+                dense_lds, ds, (const TnWide*)net->d_wide, (int)net->wide.size(), wb, (const TnProb*)net->d_tnp, (int)net->tnp.size());
+    V4L_LAUNCH_CHECK();
+    return 0;
+  }
+  if (gb > 0) {
+    g_op = "dense.wgrad";
+    V4L_KLAUNCH("gemm_tn_group", net->tnp_flops, ds, gemm_tn_group_kernel<T>, dim3((unsigned)gb), dim3(256), 0, ds,
+                (const TnProb*)net->d_tnp, (int)net->tnp.size());
+    V4L_LAUNCH_CHECK();
+  }
+  if (wb > 0) {
     g_op = "layer.wgrad";
-    V4L_KLAUNCH("gemm_tn_wide", net->wide_flops, ds, gemm_tn_wide_kernel<T>, dim3((unsigned)tb), dim3(256),
+    V4L_KLAUNCH("gemm_tn_wide", net->wide_flops, ds, gemm_tn_wide_kernel<T>, dim3((unsigned)wb), dim3(256),
                 TnWideLds<T>::max_bytes, ds, (const TnWide*)net->d_wide, (int)net->wide.size());
     V4L_LAUNCH_CHECK();
   }
