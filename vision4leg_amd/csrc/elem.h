@@ -634,7 +634,7 @@ struct UpdCtl {
   long long step;       // optimiser steps taken so far (both Adams step once per update)
   double lr_pf, lr_vf;
   float beta1, beta2;
-  float step_size[2];   // lr / (1 - beta1^step) for [0] pf, [1] vf — refreshed by upd_begin_kernel
+  float step_size[2];   // lr / (1 - beta1^step) for [0] pf, [1] vf — refreshed by upd_begin_body (block 0 of begin_pack_kernel)
   float bc2_sqrt;       // sqrt(1 - beta2^step)
   float pad1;
 };
@@ -694,7 +694,7 @@ __global__ __launch_bounds__(256) void clip_adam_kernel(const ParamSeg* __restri
   if (blockIdx.x == 0 && threadIdx.x == 0 && norm_out != nullptr) *norm_out = tot;
   if (blockIdx.x == 0 && close_ctl != nullptr) {
     // last launch of an update: publish the statistics record (this block just completed it with the policy's gradient
-    // norm) and move on to the next minibatch — what upd_end_kernel did as one more launch
+    // norm) and move on to the next minibatch (no separate closing launch)
     __syncthreads();
     const int u = close_ctl->upd_index;
     if (threadIdx.x < 64) {  // wave 0: count the non-finite logger scalars (losses, norms, ratios: a NaN anywhere reaches them)

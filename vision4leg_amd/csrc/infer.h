@@ -576,7 +576,7 @@ __device__ __forceinline__ void ln_rows(const float* z, int ldz, float* out, int
 #ifdef V4L_INFER_TIMING
 __device__ long long g_inf_stamps[128];
 #define INF_STAMP(i) do { if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) g_inf_stamps[i] = clock64(); } while (0)
-// rollout kernels: [64..95] rollout_layer_kernel (layer 0: 64.., head: 80..), [96..111] rollout_encoder_kernel (depth block 0)
+// rollout kernels: [64..95] rollout_stack_kernel (layer 0: 64.., head: 80..), [96..111] rollout_encoder2_kernel (depth block 0)
 #define ROLL_STAMP(i) do { if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) g_inf_stamps[i] = clock64(); } while (0)
 #else
 #define INF_STAMP(i)
@@ -1289,7 +1289,7 @@ __global__ __launch_bounds__(512) void rollout_stack_kernel(InfLayerStack stk, I
 
 
 // ------------------------------------------------------------------------------------------ rollout encoder (16 waves)
-// infer_encoder_kernel's inference path with every phase spread over 16 waves (see rollout_layer_kernel): conv1 one row
+// infer_encoder_kernel's inference path with every phase spread over 16 waves (see rollout_stack_kernel): conv1 one row
 // tile per wave, conv2 one (row tile, column tile) per wave, conv3 column tile x K-quarter per wave + an LDS sum, the
 // proprio MLP one column tile per wave. Same arithmetic except conv3's fp32 partial sums (4 K-quarters added in order).
 template <typename T>
