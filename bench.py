@@ -419,14 +419,14 @@ def algo_bytes(kernel, wl, compute):
     return None
 
 
-CU_FETCH_B_PER_CLK = 13.0  # what one CU pulls from L2, measured (72 KB of weights alone take 6.1-6.4 K cycles)
+CU_FETCH_B_PER_CLK = 31.8  # what one CU streams from L2 into registers, every CU at once (tools/probe/cu_fetch.hip; DMA to LDS: 59-63)
 CU_CLOCK_HZ = 2.4e9
 
 
 def block_fetch_bytes(kernel, wl, compute):
     """Bytes ONE block pulls through its CU (the weights it streams + its share of the launch's algorithmic bytes) for the
-    kernels that are bound by exactly that: each CU gets ~13 B/clk from L2 however the accesses look, so a
-    block's time has this floor whatever the chip-level HBM fraction says. -> (bytes, blocks) or None."""
+    kernels whose time is their blocks' fetch-and-compute chain: a CU streams at most 31.8 B/clk from L2 into registers
+    (DESIGN.md 4.1), so this is the per-block view the chip-level HBM fraction cannot give. -> (bytes, blocks) or None."""
     n, E, t = wl["B"], wl["E"], (2 if compute == "bf16" else 4)
     lw = (64 * 192 + 64 * 64 + 64 * 256 + 256 * 64) * t          # one transformer layer's weights
     head_w = (128 * 256 + 256 * 256 + 256 * 16) * t
@@ -523,7 +523,7 @@ def roofline(ep, compute, breakdown_path):
             cu = {"bytes_per_block": round(bf[0]), "blocks": bf[1], "achieved_B_per_clk": round(bpc, 2),
                   "ceiling_B_per_clk": CU_FETCH_B_PER_CLK, "frac": round(bpc / CU_FETCH_B_PER_CLK, 3),
                   "note": "L2 -> CU fetch of ONE block (its weights + its share of the algorithmic bytes) over the launch time, "
-                          "against the measured per-CU ceiling (DESIGN.md 4.1); the chip-level `frac` cannot see this bound"}
+                          "against the measured per-CU streaming rate (tools/probe/cu_fetch.hip, DESIGN.md 4.1)"}
         return {
             "cu_fetch": cu,
             "bound": "hbm" if hbm_bound else "mfma", "kernel": kern,

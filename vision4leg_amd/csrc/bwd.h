@@ -769,7 +769,7 @@ __global__ __launch_bounds__(256) void bwd_layer_kernel(BwdLayerStack stk, BwdHe
 // and dc2 / dc1 never exist in HBM. bwd_conv_kernel (512 threads, 1 block per CU) carries dW2 and dW1 (20 MFMA tiles per
 // wave); dW3's 144 tiles would not fit beside them, so bwd_conv3_wgrad_kernel (256 threads, 36 tiles per wave) does that
 // contraction on its own from dc3 and c2 (13 KB per sample).
-// What shapes the per-sample loop (a CU pulls ~13 B/clk from L2 and vmcnt is per wave, in order):
+// What shapes the per-sample loop (every phase opens with an L2 round trip and vmcnt is per wave, in order):
 //   * every weight byte enters the CU once per sample: conv3' splits its ci tiles (and K halves) over the waves, conv2''s
 //     64 KB of weights live in LDS in fragment order for the block's whole life (bf16);
 //   * dc2 and dc1 exist only as MFMA operands: the data-grad epilogues store them in T, both as [pixel][co] (next data-grad)
