@@ -154,4 +154,12 @@ __device__ __forceinline__ int find_desc(const D* __restrict__ d, int n, int64_t
   return cnt - 1;
 }
 
+// Four consecutive floats from a 4-byte aligned address as ONE global_load_dwordx4 (the hardware takes dword-aligned
+// multi-dword global loads; the observation rows [S | 4x64x64] start on a 16-byte boundary only when S % 4 == 0)
+typedef float f32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));
+__device__ __forceinline__ float4 ld4u(const float* p) {
+  const f32x4_a4 v = *reinterpret_cast<const f32x4_a4*>(p);
+  return float4{v[0], v[1], v[2], v[3]};
+}
+
 }  // namespace v4l

@@ -320,16 +320,10 @@ __global__ __launch_bounds__(256) void infer_encoder_kernel(const ActCtl* __rest
       __builtin_amdgcn_global_load_lds((const V4L_GLOBAL void*)(src + (int64_t)(tid + k * 256) * V),
                                        (__attribute__((address_space(3))) void*)(img + ((tid & ~63) + k * 256) * V), 16, 0, 0);
   } else {
-    const float4* src = reinterpret_cast<const float4*>(obs + (int64_t)b * D + w.S);  // 16B aligned iff S%4==0
-    const bool al = (((int64_t)b * D + w.S) & 3) == 0;
+    const float* src = obs + (int64_t)b * D + w.S;  // 16-byte aligned only when S % 4 == 0: dword-aligned vector loads (ld4u)
     T* roll = image_roll + (slot0 + b) * (int64_t)LY::IMG;
     for (int i = tid; i < LY::IMG / 4; i += 256) {
-      float4 v;
-      if (al) v = src[i];
-      else {
-        const float* s1 = obs + (int64_t)b * D + w.S + i * 4;
-        v = float4{s1[0], s1[1], s1[2], s1[3]};
-      }
+      const float4 v = ld4u(src + i * 4);
       T t4[4] = {Op<T>::from_f32(v.x), Op<T>::from_f32(v.y), Op<T>::from_f32(v.z), Op<T>::from_f32(v.w)};
 #pragma unroll
       for (int j = 0; j < 4; ++j) { img[i * 4 + j] = t4[j]; roll[i * 4 + j] = t4[j]; }
@@ -1361,19 +1355,11 @@ __global__ __launch_bounds__(1024) void rollout_encoder_kernel(const ActCtl* __r
   T* c3 = c2 + LY::C2;
   ROLL_STAMP(96);
   {
-    const float4* src = reinterpret_cast<const float4*>(obs + (int64_t)b * D + w.S);  // 16B aligned iff S%4==0
-    const bool al = (((int64_t)b * D + w.S) & 3) == 0;
+    const float* src = obs + (int64_t)b * D + w.S;  // 16-byte aligned only when S % 4 == 0: dword-aligned vector loads (ld4u)
     T* roll = image_roll + (slot0 + b) * (int64_t)LY::IMG;
     float4 v[4];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {  // 4096 float4 per image: four per thread, all in flight
-      const int i = tid + k * 1024;
-      if (al) v[k] = src[i];
-      else {
-        const float* s1 = obs + (int64_t)b * D + w.S + i * 4;
-        v[k] = float4{s1[0], s1[1], s1[2], s1[3]};
-      }
-    }
+    for (int k = 0; k < 4; ++k) v[k] = ld4u(src + (tid + k * 1024) * 4);  // 4096 float4 per image: four per thread, all in flight
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       const int i = tid + k * 1024;
@@ -1615,14 +1601,9 @@ __global__ __launch_bounds__(1024) void rollout_encoder2_kernel(const ActCtl* __
   ROLL_STAMP(96);
   float4 v[4];
   {
-    const float* row = obs + (int64_t)b * D + w.S;
-    const bool al = (((int64_t)b * D + w.S) & 3) == 0;  // 16-byte aligned rows iff S % 4 == 0
+    const float* row = obs + (int64_t)b * D + w.S;  // 16-byte aligned only when S % 4 == 0: dword-aligned vector loads (ld4u)
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {  // 4096 float4 per image: four per thread, all in flight
-      const int i = tid + k * 1024;
-      if (al) v[k] = reinterpret_cast<const float4*>(row)[i];
-      else v[k] = float4{row[i * 4], row[i * 4 + 1], row[i * 4 + 2], row[i * 4 + 3]};
-    }
+    for (int k = 0; k < 4; ++k) v[k] = ld4u(row + (tid + k * 1024) * 4);  // 4096 float4 per image: four per thread, all in flight
   }
   const frag_t w1v = reinterpret_cast<const frag_t*>(w.w1)[tid];
   float bv;
@@ -2059,19 +2040,11 @@ __global__ __launch_bounds__(1024) void rollout_cnn_kernel(const ActCtl* __restr
   T* hs = h2 + 256;  // proprio fc1 output
   float* so = reinterpret_cast<float*>(smem + RL::conv_b + RL::sin_b + RL::cat_b + 3 * RL::h_b);
   {
-    const float4* src = reinterpret_cast<const float4*>(obs + (int64_t)b * D + w.S);  // 16B aligned iff S%4==0
-    const bool al = (((int64_t)b * D + w.S) & 3) == 0;
+    const float* src = obs + (int64_t)b * D + w.S;  // 16-byte aligned only when S % 4 == 0: dword-aligned vector loads (ld4u)
     T* roll = image_roll + (slot0 + b) * (int64_t)LY::IMG;
     float4 v[4];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const int i = tid + k * 1024;
-      if (al) v[k] = src[i];
-      else {
-        const float* s1 = obs + (int64_t)b * D + w.S + i * 4;
-        v[k] = float4{s1[0], s1[1], s1[2], s1[3]};
-      }
-    }
+    for (int k = 0; k < 4; ++k) v[k] = ld4u(src + (tid + k * 1024) * 4);
     if (tid < 128) {
       const float x = tid < w.S ? obs[(int64_t)b * D + tid] : 0.f;
       sin[tid] = x;
