@@ -24,6 +24,11 @@ print("bwd_conv_kernel block 0, 4th sample, phase cycles (clock64, 100 MHz s_mem
 for nm,c in zip(names,np.diff(st)): print("  %-22s %8d"%(nm,c))
 print("  total %d"%(st[6]-st[0]))
 st=np.array(buf[:9],dtype=np.int64); print("layer kernel stamps diff", np.diff(st))
+names=["stage x / wait","in_proj","attention","out_proj+res","norm1","linear1+relu","linear2+res","norm2"]
+print("infer_layer_kernel (training forward, last layer's pass) block 0 phase cycles:")
+for nm,c in zip(names,np.diff(st)): print("  %-22s %8d"%(nm,c))
+print("  in_proj:  GEMM done +%d, epilogue (bias, qkv saves, q|k|v^T to LDS) +%d, barrier +%d" % (buf[9]-buf[1], buf[10]-buf[9], buf[2]-buf[10]))
+print("  linear1:  GEMM done +%d, epilogue (bias, relu, f saves) +%d, barrier +%d" % (buf[11]-buf[5], buf[12]-buf[11], buf[6]-buf[12]))
 st=np.array(buf[32:42],dtype=np.int64)
 names=["load dy / heads","ln2 bwd","df gemm","dx1 gemm","qkv,P loads + ln1 bwd","dctx gemm","attention bwd","dx_in gemm","tail"]
 print("bwd_layer_kernel (layer 0, TAIL variant) block 0 phase cycles:")

@@ -610,9 +610,25 @@ __global__ __launch_bounds__(256) void infer_layer_kernel(InfLayerStack stk, Inf
   // every GEMM's first weight fragments are requested one phase early (GemmRing): the L2 round trip and the acknowledgement
   // of the global stores in front of it overlap that phase
   GemmRing<T, 3, 2> ring_in = gemm_prefetch<T, 3, 2>((const T*)stk.l[0].n[blockIdx.y].win, 64, nt, lane);
+  // A layer's biases are fetched before the layer stores anything (the next layer's: before this layer's last saves). Loads and
+  // stores retire through one in-order queue per wave: a bias fetched inside an epilogue loop made every iteration wait for
+  // the acknowledgement of the saves issued just before it (7-8 K cycles per in_proj / linear1 epilogue, clock64 stamps).
+  struct LayerBias { float4 in[3], o, f1[4], f2; };
+  auto fetch_bias = [&](const InfLayer& wl) {
+    LayerBias b;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) b.in[j] = *reinterpret_cast<const float4*>(wl.bin + nt[j] * 16 + qr);
+    b.o = *reinterpret_cast<const float4*>(wl.bo + wave * 16 + qr);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) b.f1[j] = *reinterpret_cast<const float4*>(wl.b1 + nt4[j] * 16 + qr);
+    b.f2 = *reinterpret_cast<const float4*>(wl.b2 + wave * 16 + qr);
+    return b;
+  };
+  LayerBias bias_next = fetch_bias(stk.l[0].n[blockIdx.y]);
 #pragma unroll
   for (int l = 0; l < NL; ++l) {
   const InfLayer& w = stk.l[l].n[blockIdx.y];
+  const LayerBias lb = bias_next;
   if (l == 0) {
     const float* xg = w.xin + (int64_t)s0 * NTOK * TD;
     for (int i4 = tid; i4 < ROWS * (TD / 4); i4 += 256) {
@@ -645,11 +661,12 @@ __global__ __launch_bounds__(256) void infer_layer_kernel(InfLayerStack stk, Inf
     f32x4 acc[MT][3];
     zero_acc(acc);
     block_gemm<T, MT, 3, 2>(acc, xs, LY::LDX, (const T*)w.win, 64, nt, lane, ring_in);
+    INF_STAMP(9);
     ring_o = gemm_prefetch<T, 1, 2>((const T*)w.wo, 64, nt1, lane);
 #pragma unroll
     for (int j = 0; j < 3; ++j) {  // column tile wave + 4j: j = 0 -> q, 1 -> k, 2 -> v
       const int n4 = nt[j] * 16 + qr;
-      const float4 bb = *reinterpret_cast<const float4*>(w.bin + n4);
+      const float4 bb = lb.in[j];
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt) {
         const int row = mt * 16 + fr;
@@ -667,6 +684,7 @@ __global__ __launch_bounds__(256) void infer_layer_kernel(InfLayerStack stk, Inf
       }
     }
   }
+  INF_STAMP(10);
   __syncthreads();
   INF_STAMP(2);
   // attention on the matrix cores: one (sample, query tile) job per wave pass — tokens 0..15 | token 16 of each sample
@@ -686,7 +704,7 @@ __global__ __launch_bounds__(256) void infer_layer_kernel(InfLayerStack stk, Inf
     block_gemm<T, MT, 1, 2>(acc, cb, LDT, (const T*)w.wo, 64, nt1, lane, ring_o);
     ring_1 = gemm_prefetch<T, 4, 2>((const T*)w.w1, 64, nt4, lane);  // in front of norm1 and its saves
     const int n4 = wave * 16 + qr;
-    const float4 bb = *reinterpret_cast<const float4*>(w.bo + n4);
+    const float4 bb = lb.o;
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
       const int row = mt * 16 + fr;
@@ -708,11 +726,12 @@ __global__ __launch_bounds__(256) void infer_layer_kernel(InfLayerStack stk, Inf
     f32x4 acc[MT][4];
     zero_acc(acc);
     block_gemm<T, MT, 4, 2>(acc, xs, LY::LDX, (const T*)w.w1, 64, nt4, lane, ring_1);
+    INF_STAMP(11);
     ring_2 = gemm_prefetch<T, 1, 8>((const T*)w.w2, 256, nt1, lane);  // in front of the f saves
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int n4 = nt4[j] * 16 + qr;
-      const float4 bb = *reinterpret_cast<const float4*>(w.b1 + n4);
+      const float4 bb = lb.f1[j];
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt) {
         const float f0 = fmaxf(acc[mt][j][0] + bb.x, 0.f), f1 = fmaxf(acc[mt][j][1] + bb.y, 0.f);
@@ -723,6 +742,7 @@ __global__ __launch_bounds__(256) void infer_layer_kernel(InfLayerStack stk, Inf
       }
     }
   }
+  INF_STAMP(12);
   __syncthreads();
   INF_STAMP(6);
   {  // linear2 + residual -> z2 (in `cx`)
@@ -730,7 +750,7 @@ __global__ __launch_bounds__(256) void infer_layer_kernel(InfLayerStack stk, Inf
     zero_acc(acc);
     block_gemm<T, MT, 1, 8>(acc, f, LY::LDF, (const T*)w.w2, 256, nt1, lane, ring_2);
     const int n4 = wave * 16 + qr;
-    const float4 bb = *reinterpret_cast<const float4*>(w.b2 + n4);
+    const float4 bb = lb.f2;
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
       const int row = mt * 16 + fr;
@@ -741,7 +761,10 @@ __global__ __launch_bounds__(256) void infer_layer_kernel(InfLayerStack stk, Inf
   }
   __syncthreads();
   INF_STAMP(7);
-  if (l + 1 < NL) ring_in = gemm_prefetch<T, 3, 2>((const T*)stk.l[l + 1 < NL ? l + 1 : l].n[blockIdx.y].win, 64, nt, lane);
+  if (l + 1 < NL) {
+    ring_in = gemm_prefetch<T, 3, 2>((const T*)stk.l[l + 1 < NL ? l + 1 : l].n[blockIdx.y].win, 64, nt, lane);
+    bias_next = fetch_bias(stk.l[l + 1 < NL ? l + 1 : l].n[blockIdx.y]);
+  }
   ln_rows<ROWS, U, float>(cx, LY::LDX, (HEAD || l + 1 < NL) ? xs : nullptr, LY::LDX, w.g2, w.be2, wave, lane, nrows,
                    w.s_xh2 ? w.s_xh2 + row0 * TD : nullptr, w.s_rs2 ? w.s_rs2 + row0 : nullptr, w.xout + row0 * TD);
   INF_STAMP(8);
@@ -753,6 +776,14 @@ __global__ __launch_bounds__(256) void infer_layer_kernel(InfLayerStack stk, Inf
     T* h1 = reinterpret_cast<T*>(big + 16 * LY::LDP);                 // [16][LDF]
     T* h2 = h1 + 16 * LY::LDF;
     float* so = reinterpret_cast<float*>(h2 + 16 * LY::LDF);          // [16][16] last-layer outputs
+    float4 hb0[4], hb1[4];  // head biases: fetched before the head stores anything (see LayerBias)
+    float hb2[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      hb0[j] = *reinterpret_cast<const float4*>(h.b0 + nt4[j] * 16 + qr);
+      hb1[j] = *reinterpret_cast<const float4*>(h.b1 + nt4[j] * 16 + qr);
+      hb2[j] = h.b2[min(qr + j, h.nout - 1)];
+    }
     __syncthreads();
     for (int idx = tid; idx < 16 * 128; idx += 256) {
       const int r = idx >> 7, c = idx & 127;
@@ -772,11 +803,11 @@ __global__ __launch_bounds__(256) void infer_layer_kernel(InfLayerStack stk, Inf
     }
     __syncthreads();
     f32x4 acc[1][4];
-    auto store_h = [&](T* dst, const float* bias, float* save) {
+    auto store_h = [&](T* dst, const float4 (&bias)[4], float* save) {
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const int n4 = nt4[j] * 16 + qr;
-        const float4 bb = *reinterpret_cast<const float4*>(bias + n4);
+        const float4 bb = bias[j];
         const float v0 = fmaxf(acc[0][j][0] + bb.x, 0.f), v1 = fmaxf(acc[0][j][1] + bb.y, 0.f);
         const float v2 = fmaxf(acc[0][j][2] + bb.z, 0.f), v3 = fmaxf(acc[0][j][3] + bb.w, 0.f);
         st4(dst + fr * LY::LDF + n4, v0, v1, v2, v3);
@@ -785,11 +816,11 @@ __global__ __launch_bounds__(256) void infer_layer_kernel(InfLayerStack stk, Inf
     };
     zero_acc(acc);
     block_gemm<T, 1, 4, 4>(acc, pooled, LY::LDP, (const T*)h.w0, 128, nt4, lane);
-    store_h(h1, h.b0, h.s_h0);
+    store_h(h1, hb0, h.s_h0);
     __syncthreads();
     zero_acc(acc);
     block_gemm<T, 1, 4, 8>(acc, h1, LY::LDF, (const T*)h.w1, 256, nt4, lane);
-    store_h(h2, h.b1, h.s_h1);
+    store_h(h2, hb1, h.s_h1);
     __syncthreads();
     if (wave == 0) {  // last linear: one 16-column tile
       const int nt0[1] = {0};
@@ -799,7 +830,7 @@ __global__ __launch_bounds__(256) void infer_layer_kernel(InfLayerStack stk, Inf
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int c = qr + r;
-        const float v = c < h.nout ? a1[0][0][r] + h.b2[c] : 0.f;
+        const float v = c < h.nout ? a1[0][0][r] + hb2[r] : 0.f;
         so[fr * 16 + c] = v;
         if (fr < ns) h.out[(int64_t)(s0 + fr) * OUT_LD + c] = v;
       }
