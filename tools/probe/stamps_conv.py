@@ -34,3 +34,7 @@ names=["load dy / heads","ln2 bwd","df gemm","dx1 gemm","qkv,P loads + ln1 bwd",
 print("bwd_layer_kernel (layer 0, TAIL variant) block 0 phase cycles:")
 for nm,c in zip(names,np.diff(st)): print("  %-24s %8d"%(nm,c))
 print("  total %d"%(st[9]-st[0]))
+b=buf
+print("  df:   GEMM done +%d, epilogue (mask, df saves, df to LDS) +%d, barrier +%d" % (b[32+10]-b[32+2], b[32+11]-b[32+10], b[32+3]-b[32+11]))
+print("  dx1:  qkv / P / norm1 rows requested +%d, GEMM +%d, epilogue + barrier +%d" % (b[32+12]-b[32+3], b[32+13]-b[32+12], b[32+4]-b[32+13]))
+print("  park: q|k|v^T to LDS +%d, norm1 backward +%d" % (b[32+14]-b[32+4], b[32+5]-b[32+14]))

@@ -284,6 +284,7 @@ __global__ __launch_bounds__(256) void bwd_layer_kernel(BwdLayerStack stk, BwdHe
         fm[mt][j] = ld4(reinterpret_cast<const T*>(w.s_f) + (row0 + (mt * 16 + fr < nrows ? mt * 16 + fr : 0)) * 256 +
                         nt4[j] * 16 + qr);
     block_gemm<T, MT, 4, 2>(acc, a, LY::LDX, (const T*)w.w2t, 64, nt4, lane, ring_df);
+    LAY_STAMP(10);
     ring_dx1 = gemm_prefetch<T, 1, 8>((const T*)w.w1t, 256, nt1, lane);  // ahead of this epilogue's global stores
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
@@ -300,6 +301,7 @@ __global__ __launch_bounds__(256) void bwd_layer_kernel(BwdLayerStack stk, BwdHe
       }
     }
   }
+  LAY_STAMP(11);
   __syncthreads();
   LAY_STAMP(3);
   // qkv and P of the block's samples and norm1's saved rows are requested before the dx1 GEMM and parked in registers;
@@ -345,7 +347,9 @@ __global__ __launch_bounds__(256) void bwd_layer_kernel(BwdLayerStack stk, BwdHe
   {  // ---- dx1 = dz2 + df W1 -> b
     f32x4 acc[MT][1];
     zero_acc(acc);
+    LAY_STAMP(12);
     block_gemm<T, MT, 1, 8>(acc, f, LY::LDF, (const T*)w.w1t, 256, nt1, lane, ring_dx1);
+    LAY_STAMP(13);
     const int n4 = wave * 16 + qr;
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
@@ -403,6 +407,7 @@ __global__ __launch_bounds__(256) void bwd_layer_kernel(BwdLayerStack stk, BwdHe
       }
     }
   }
+  LAY_STAMP(14);
   // ---- norm1 backward: b = dz1
   GemmRing<T, 1, 2> ring_dctx = gemm_prefetch<T, 1, 2>((const T*)w.wot, 64, nt1, lane);
   ln_bwd_rows<ROWS>(b, LY::LDX, pre1, wave, lane, nrows, reinterpret_cast<T*>(w.o_dz1) + row0 * TD, red,
