@@ -156,3 +156,40 @@ def test_stacked_layer_launches_equal_one_launch_per_layer(mode, device):
     worst = (g0 - g1).abs().max().item()
     util.record("stacked_layers/%s/max_abs_grad_diff_vs_per_layer_launches" % mode, worst)
     assert worst == 0.0, worst
+
+
+@pytest.mark.parametrize("mode", MODES)
+def test_forked_weight_grad_launches_equal_serial(mode, device):
+    """The backward runs dW3 on the main stream next to the dense weight-grad launch on the net's auxiliary stream (a fork /
+    join after the conv-stack data-grads, V4L_PAR_WGRAD=2, the default). V4L_PAR_WGRAD=0 issues the same launches one after
+    the other. Every slab has one writer and the reduce waits for both branches: the gradients must agree to the last bit,
+    three times in a row (a missing dependency would show up as a difference in some repetition)."""
+    case = dict(util.CASES["loco_s93"], B=256)
+    n = case["B"]
+    obs = torch.tensor(util.make_batch(case)["obs"], dtype=torch.float32)
+    g = torch.Generator().manual_seed(11)
+    w = torch.randn(n, 1, generator=g)
+    pf, vf = _build(case, mode, device)
+    hip = vf.hip
+    st, im, _ = hip.stage(obs.to(device))
+    dout = torch.zeros(n, 16, dtype=torch.float32, device=device)
+    dout[:, :1] = w.to(device)
+
+    def grads_with(par):
+        os.environ["V4L_PAR_WGRAD"] = str(par)
+        try:
+            hip.forward(st, im, n, train=True)
+            grads = torch.full((hip.total_params,), float("nan"), dtype=torch.float32, device=device)
+            hip.backward(st, im, n, dout, grads)
+            torch.cuda.synchronize()
+            assert not torch.isnan(grads).any()
+            return grads.cpu().clone()
+        finally:
+            os.environ.pop("V4L_PAR_WGRAD", None)
+
+    ref = grads_with(0)
+    worst = 0.0
+    for _ in range(3):
+        worst = max(worst, (grads_with(2) - ref).abs().max().item())
+    util.record("forked_wgrad/%s/max_abs_grad_diff_vs_serial" % mode, worst)
+    assert worst == 0.0, worst

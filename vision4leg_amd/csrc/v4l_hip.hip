@@ -1452,7 +1452,7 @@ int v4l_net::backward_t(const float* state, const T* image, const int* rowidx, i
   // data-grads 33.7 (bwd_conv_kernel holds every CU: nothing fits beside it); conv-stack data-grads FIRST, then dW3 on the
   // main stream next to the two dense launches on the auxiliary stream 32.8 (default); three branches 34.8.
   // V4L_PAR_WGRAD=0: serial, 1: the older fork.
-  static const int par_wgrad = getenv("V4L_PAR_WGRAD") ? atoi(getenv("V4L_PAR_WGRAD")) : 2;
+  const int par_wgrad = getenv("V4L_PAR_WGRAD") ? atoi(getenv("V4L_PAR_WGRAD")) : 2;  // (read per call: tests switch it)
   if (par_wgrad == 2) {
     cx.defer_conv3 = true;
     if ((rc = conv_stack_bwd<T>(cx, image, rowidx, n, ws + L.c1, ws + L.c2, ws + L.dc3, ws + L.dc2, ws + L.dc1))) return rc;
