@@ -16,6 +16,8 @@ library's built-in profiler on the launch stream) and "cpu_baseline" (the CPU or
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -24,7 +26,6 @@ import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 WORKLOADS = {
     # BASELINE.json configs[2]: ppo_locotransformer.py thin-goal, 1 MI355X, 32 envs (headline: the metric's MFMA
@@ -56,7 +57,20 @@ OPT_EPOCHS = 3
 PEAK = {"bf16": 2500.0, "f32": 157.3}  # dense TFLOP/s, MI355X_MICROARCH.md (bf16 MFMA / f32 MFMA)
 
 
-def parse():
+def launcher_argv(n, argv, port=None):
+    """The command `python bench.py --gpus N ...` re-executes itself with when it was not started by a launcher: one process
+    per GPU of this node over RCCL, rendezvous on 127.0.0.1 (the driver's own multi-GPU command line, spelled out)."""
+    if port is None:
+        port = os.environ.get("MASTER_PORT")
+    if port is None:
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr",
+            "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+
+
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
@@ -68,7 +82,7 @@ def parse():
     ap.add_argument("--no-reference-protocol", action="store_true")
     ap.add_argument("--no-rollout", action="store_true", help="time (ii)-(iv) only (the reference's Train___Time)")
     ap.add_argument("--breakdown", default=None, help="write the per-op HIP-event breakdown to this file")
-    return ap.parse_args()
+    return ap.parse_args(argv)
 
 
 class Epoch:
@@ -76,7 +90,7 @@ class Epoch:
 
     def __init__(self, wl, compute, dev, world):
         os.environ["V4L_COMPUTE"] = compute
-        import util
+        from vision4leg_amd import recipes as util
         import vision4leg_amd.torchrl.networks as networks
         import vision4leg_amd.torchrl.policies as policies
         from vision4leg_amd.torchrl.algo import PPO
@@ -200,7 +214,7 @@ def cpu_baseline(wl, compute):
     """The CPU oracle (oracle/ppo_oracle.py, kind 'port': the restatement pinned against the reference) on a bounded
     sample of the same workload (warm-up, then 16 minibatch updates + 64 inference step pairs +
     1 GAE), extrapolated to one epoch. Threads: the best of 8/16/32/64 — torch's intra-op pool thrashes beyond that."""
-    import util
+    from vision4leg_amd import recipes as util
     from oracle import ppo_oracle as orc
     import vision4leg_amd.torchrl.networks as networks
     import vision4leg_amd.torchrl.policies as policies
@@ -263,48 +277,76 @@ def cpu_baseline(wl, compute):
 
 
 def parity_check(wl, compute, dev):
-    """The checker leg (oracle = test infrastructure, never in the timed region): ONE minibatch update at the benchmark's
-    B through a fresh HIP trainer (PPO.update, the C ABI) and through the CPU oracle in the same compute flavour and in
-    fp32; max over the 18 logger scalars of |hip - oracle| / max(1, |oracle|) and the parameter distance after the step."""
-    import util
-    from oracle import ppo_oracle as orc
+    """The checker leg (oracle = test infrastructure, never in the timed region) on THE PATH THE BENCH TIMES, at the
+    workload's own E and B: 2 B / E steps of `RolloutActor.step` filing action / value / log pi_old, then 2 stored-log-pi
+    updates through `run_updates` (the second one is a hipGraph replay) — against the CPU oracle fed the reference protocol
+    (pf.explore / vf per step, frozen-target forward inside every minibatch update), in the bench's compute flavour and
+    in fp32 (oracle/bench_path.py; the same function tests/test_gpu_bench_path.py gates at E = 32 / 64, 4 updates)."""
+    from oracle import bench_path
+    E, B = wl["E"], wl["B"]
+    T = max(2, 2 * B // E)
+    r = bench_path.run(dict(wl, seed=0), E, T, B, 2, compute, dev, threads=min(16, os.cpu_count() or 1))
+    out = {"path": r["path"], "batch": B, "envs": E, "rollout_steps": T, "updates": 2, "finite": r["finite"],
+           "graph_replays": r["graph_replays"]}
+    for fl in dict.fromkeys((compute, "f32")):
+        out["max_rel_err_infos_vs_%s_oracle" % fl] = float("%.3e" % r["infos_vs_%s" % fl])
+        out["max_abs_param_diff_vs_%s_oracle" % fl] = float("%.3e" % r["param_max_vs_%s" % fl])
+        out["mean_abs_param_diff_vs_%s_oracle" % fl] = float("%.3e" % r["param_mean_vs_%s" % fl])
+        out["rollout_mean_rel_vs_%s_oracle" % fl] = float("%.3e" % r["rollout_mean_vs_%s" % fl])
+        out["rollout_value_rel_vs_%s_oracle" % fl] = float("%.3e" % r["rollout_value_vs_%s" % fl])
+        out["stored_logp_abs_vs_%s_oracle" % fl] = float("%.3e" % r["rollout_logp_abs_vs_%s" % fl])
+    if compute != "f32":
+        out["oracle_%s_vs_f32_infos_per_update" % compute] = r["oracle_%s_vs_f32_per_update" % compute]
+        out["hip_vs_f32_infos_per_update"] = r["infos_vs_f32_per_update"]
+    return out
+
+
+def fast_collector(wl, compute, dev):
+    """The critical-path transfers, timed: the product's own `VecOnPolicyCollector` (fast path) + `DeviceOnPolicyReplayBuffer`
+    + `PPO.update_per_epoch` over a zero-cost vec env that hands out float64 observation rows the way the reference's env
+    wrappers do (collector/on_policy.py:90-100). Per env step: fp64 -> fp32 cast into pinned memory, H2D of E x (S+16384)
+    fp32, the two rollout launches, D2H of the [E][A] action (the simulator needs it before it can step) — a synchronous
+    vec env cannot overlap any of it. One warm-up epoch, one timed."""
+    from vision4leg_amd import recipes
     import vision4leg_amd.torchrl.networks as networks
     import vision4leg_amd.torchrl.policies as policies
     from vision4leg_amd.torchrl.algo import PPO
+    from vision4leg_amd.torchrl.collector import VecOnPolicyCollector
+    from vision4leg_amd.torchrl.replay_buffers import DeviceOnPolicyReplayBuffer
     case = dict(wl, seed=0)
-    B = wl["B"]
-    b = util.make_batch(case, B=B)
-    t = lambda a: torch.tensor(a, dtype=torch.float32)
-    out = {"batch": B, "what": "one PPO.update (critic + actor, clip, Adam) on a seeded minibatch: 18 infos and parameters "
-                               "after the step, HIP vs CPU oracle"}
-    infos = {}
+    E, T, B = wl["E"], wl["T"], wl["B"]
+    torch.manual_seed(0)
+    pf, vf = recipes.build_nets(networks, policies, case)
+    env = recipes.ZeroCostVecEnv(E, case, p_done=0.0)
+    buf = DeviceOnPolicyReplayBuffer(max_replay_buffer_size=E * T, env_nums=E, time_limit_filter=True)
+    coll = VecOnPolicyCollector(vf, env=env, eval_env=recipes.ZeroCostVecEnv(E, case), pf=pf, replay_buffer=buf, device=dev,
+                                epoch_frames=E * T, max_episode_frames=10 ** 9)
 
-    def fresh():
-        torch.manual_seed(0)
-        return util.build_nets(networks, policies, case)
-    pf, vf = fresh()
+    class Log:
+        def add_update_info(self, info): pass
+    agent = PPO(pf=pf, vf=vf, plr=1e-4, vlr=1e-4, clip_para=0.2, opt_epochs=OPT_EPOCHS, tau=0.95, shuffle=True,
+                entropy_coeff=0.005, collector=coll, replay_buffer=buf, logger=Log(), device=dev, discount=0.99,
+                num_epochs=1500, batch_size=B)
 
-    class Coll: epoch_frames = 1
-    agent = PPO(pf=pf, vf=vf, plr=1e-4, vlr=1e-4, clip_para=0.2, opt_epochs=OPT_EPOCHS, tau=0.95, entropy_coeff=0.005,
-                collector=Coll(), device=dev, batch_size=B)
-    agent.trainer.sync_target()
-    infos["hip"] = agent.update({k: b[k] for k in ("obs", "acts", "advs", "estimate_returns", "values")})
-    hip_p = {k: v.detach().cpu() for k, v in agent.pf.state_dict().items()}
-    torch.set_num_threads(min(16, os.cpu_count() or 1))
-    for mode in dict.fromkeys((compute, "f32")):
-        opf_m, ovf_m = fresh()
-        opf = {k: v.detach().clone() for k, v in opf_m.state_dict().items()}
-        ovf = util.share_encoder(opf, {k: v.detach().clone() for k, v in ovf_m.state_dict().items()}, wl["kind"])
-        oracle = orc.PPOOracle(wl["kind"], opf, ovf, {k: v.clone() for k, v in opf.items()}, wl["S"], mode)
-        oracle.sync_target()
-        oi = oracle.update(t(b["obs"]), t(b["acts"]), t(b["advs"]), t(b["estimate_returns"]), t(b["values"]), 1e-4, 1e-4)
-        out["max_rel_err_infos_vs_%s_oracle" % mode] = float("%.3e" % max(
-            abs(infos["hip"][k] - oi[k]) / max(1.0, abs(oi[k])) for k in util.STAT_KEYS))
-        d = [(hip_p[k] - opf[k]).abs() for k in opf]
-        out["max_abs_param_diff_vs_%s_oracle" % mode] = float("%.3e" % max(x.max().item() for x in d))
-        out["mean_abs_param_diff_vs_%s_oracle" % mode] = float("%.3e" % (sum(x.sum().item() for x in d) / sum(x.numel() for x in d)))
-    out["finite"] = bool(np.isfinite(list(infos["hip"].values())).all())
-    return out
+    def epoch():
+        t0 = time.perf_counter()
+        coll.train_one_epoch()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        agent.update_per_epoch()
+        torch.cuda.synchronize()
+        return t1 - t0, time.perf_counter() - t1
+    epoch()
+    agent.current_epoch = 1
+    t_coll, t_upd = epoch()
+    D = recipes.obs_dim(case)
+    return {"value": round(E * T / (t_coll + t_upd), 1), "unit": "env-steps/s",
+            "collect_ms_per_epoch": round(1e3 * t_coll, 2), "update_ms_per_epoch": round(1e3 * t_upd, 2),
+            "collect_us_per_env_step": round(1e6 * t_coll / T, 1),
+            "h2d_bytes_per_env_step": E * D * 4, "host_cast_threads": coll.cast_threads,
+            "what": "VecOnPolicyCollector(fast path).train_one_epoch over a zero-cost vec env (float64 rows) + "
+                    "PPO.update_per_epoch (last-value forward, GAE, %d stored-log-pi graph updates, one stats read-back): "
+                    "everything the reference's train loop does except env.step" % (OPT_EPOCHS * (E * T // B))}
 
 
 def reference_protocol(wl, compute, dev):
@@ -313,7 +355,7 @@ def reference_protocol(wl, compute, dev):
     D2H of action and value, float64 host `OnPolicyReplayBuffer.add_sample`; then last value + GAE and 48 minibatch
     updates, each gathered from the float64 host arrays and uploaded (5 H2D copies). Simulator time is zero (synthetic
     rows); this is what a maintainer gets from `overlay.install()` without touching the collector."""
-    import util
+    from vision4leg_amd import recipes as util
     import vision4leg_amd.torchrl.networks as networks
     import vision4leg_amd.torchrl.policies as policies
     from vision4leg_amd.torchrl.algo import PPO
@@ -363,7 +405,7 @@ def reference_protocol(wl, compute, dev):
 def h2d_per_step(wl, dev, steps=64):
     """Pinned-host -> HBM upload of one env step's E observation rows (E x (S+16384) fp32), what the fast collector pays
     per step when it is NOT overlapped with the simulator: mean ms per step over back-to-back async copies + one sync."""
-    import util
+    from vision4leg_amd import recipes as util
     D = util.obs_dim(dict(wl, seed=0))
     host = [torch.empty(wl["E"], D, dtype=torch.float32).pin_memory() for _ in range(2)]
     devb = [torch.empty(wl["E"], D, dtype=torch.float32, device=dev) for _ in range(2)]
@@ -601,9 +643,13 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if a.gpus > 1 and world != a.gpus:
-        raise SystemExit("launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node %d --master-addr "
-                         "127.0.0.1 bench.py --gpus %d ..." % (a.gpus, a.gpus))
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` as typed: re-launch ourselves as N ranks (one per GPU) and pass rank 0's line through
+        os.dup2(real_stdout, 1)
+        raise SystemExit(subprocess.call(launcher_argv(a.gpus, sys.argv[1:])))
+    if a.gpus != world:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d (launch with: %s)"
+                         % (a.gpus, world, " ".join(launcher_argv(a.gpus, sys.argv[1:]))))
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     # V4L_FORCE_DP_PHASES=1 under a 1-process torchrun exercises the whole multi-GPU code path (RCCL group, barriers,
@@ -659,6 +705,11 @@ def main():
         "algorithmic_tflops": round(value * (MFLOP_PER_ENV_STEP[a.workload] - (OPT_EPOCHS * MFLOP_TARGET_FWD[a.workload]
                                                                                if ep.logp is not None else 0.0)) * 1e-6, 3),
     }
+    if dist_on:
+        ag = ep.agent
+        res["config"]["dp_comm"] = "library RCCL communicator inside the update graph" if ag.dp_in_library else "torch.distributed all-reduce between phases"
+        res["rccl_ranks"] = ag.trainer.comm_world() if ag.dp_in_library else torch.distributed.get_world_size()
+        res["scaling_note"] = "weak scaling: every rank owns E envs; multi-GPU numbers are only as good as the node they ran on"
     stats_ok = bool(torch.isfinite(ep.stats[:, :18]).all().item())
     if not stats_ok:
         raise SystemExit("bench.py: non-finite logger statistics after the timed epochs: the step is invalid")
@@ -673,6 +724,16 @@ def main():
             res["value_incl_h2d"] = round(frames * a.steps / (dt + a.steps * wl["T"] * res["h2d_ms_per_step"] * 1e-3), 1)
             if not a.no_rollout and not a.no_reference_protocol:
                 res["reference_protocol"] = reference_protocol(wl, a.compute, dev)
+            if not a.no_rollout and ep.actor is not None:
+                # the headline WITH the critical-path transfers: the product's collector over a zero-cost env
+                res["fast_collector"] = fast_collector(wl, a.compute, dev)
+                res["value_incl_transfers"] = res["fast_collector"]["value"]
+                res["value_incl_transfers_ratio"] = round(res["value_incl_transfers"] / value, 3)
+                res["value_incl_transfers_note"] = (
+                    "`value` starts with the epoch resident in HBM (the contract); value_incl_transfers is the same epoch "
+                    "driven by VecOnPolicyCollector from float64 host rows: per env step a host cast, %d bytes over PCIe, "
+                    "2 launches and the action's D2H, serialised by the synchronous vec-env protocol"
+                    % res["fast_collector"]["h2d_bytes_per_env_step"])
         if not a.no_cpu_baseline and world == 1:  # the host baseline is an N = 1 measurement (the other ranks would idle)
             res["cpu_baseline"] = cpu_baseline(wl, a.compute)
             res["vs_cpu_baseline"] = round(value / world / res["cpu_baseline"]["value"], 1)

@@ -16,6 +16,31 @@
  *     torchrl/algo/rl_algo.py:97-168).
  *   - all activations/params/grads are fp32; `compute` selects the contraction operand type:
  *     V4L_F32 = exact fp32 MFMA (parity mode), V4L_BF16 = bf16 operands, fp32 accumulate (production).
+ *
+ * Environment switches read by the library (all default to the fast path; tests flip them to cross-check a fused kernel
+ * against the general layer-by-layer ones). Values are read when first needed unless marked (per call).
+ *   V4L_TRACE                 launch / graph log on stderr
+ *   V4L_PAR=0                 no auxiliary streams (sibling kernels run serially)
+ *   V4L_PAR_WGRAD=0|1|2       weight-grad launch schedule of a backward pass (per call; 2 = default: conv data-grads first,
+ *                             then dW3 on the main stream next to the dense weight-grads on the auxiliary stream)
+ *   V4L_SPLIT_DENSE_WGRAD     grouped and whole-output dense weight-grads as two launches instead of one (per call)
+ *   V4L_NO_SQ_FROM_REDUCE     separate grad_sumsq launch on one GPU too (the norm's partials otherwise come from wgrad_reduce)
+ *   V4L_NO_FUSED_ENC          LocoTransformer encoder layer by layer (per call)
+ *   V4L_NO_FUSED_LAYER        transformer layers layer by layer, forward and backward (per call)
+ *   V4L_NO_FUSED_HEAD         pooled heads outside the last layer's forward launch (per call)
+ *   V4L_NO_FUSED_HEAD_BWD     heads' data-grads outside the layer backward launch (per call)
+ *   V4L_NO_FUSED_TAIL_BWD     encoder-MLP / up-conv data-grads outside the layer backward launch (per call)
+ *   V4L_NO_FUSED_CONV_BWD     conv-stack backward layer by layer (per call)
+ *   V4L_NO_FUSED_ACTOR        rollout step on the general kernels (per call)
+ *   V4L_NO_LAYER_STACK        one launch per transformer layer instead of one per direction (per call)
+ *   V4L_NO_WPS_LAYERS         transformer layers on the block-cooperative kernels instead of the wave-per-sample ones (per call)
+ *   V4L_LAYER_SPW=2|4, V4L_LAYER_BWD_SPW=2|4      samples per block of the block-cooperative layer kernels
+ *   V4L_CONV_BWD_BLOCKS, V4L_TRAIN_ENC_BLOCKS, V4L_WIDE_SPLITS   block / split counts (tests force ragged and many-samples-per-block shapes)
+ *   V4L_TRAIN_ENC_OLD, V4L_ROLLOUT_ENC_OLD        the streamed-weight encoder kernels
+ *   V4L_ROLLOUT_WARM          L2 warm-up touches at the start of rollout_stack_kernel (measured: no effect)
+ *   V4L_RCCL_LIB              path of the RCCL library to dlopen (default: librccl.so.1)
+ * Read by the Python shell, not by the library: V4L_COMPUTE=bf16|f32, V4L_GRAPH=0, V4L_DP_COMM=torch|rccl,
+ * V4L_FORCE_DP_PHASES, V4L_LIB (diagnostic builds).
  */
 #ifndef V4L_HIP_H
 #define V4L_HIP_H
@@ -199,7 +224,7 @@ int v4l_trainer_bind(v4l_trainer* tr, float* g_pf_dev, float* m_pf_dev, float* v
  * bias corrections then live on the device and advance by themselves, one per update. */
 int v4l_trainer_begin(v4l_trainer* tr, const int* rowidx_all_dev, float* stats_all_dev, double lr_pf, double lr_vf,
                       int64_t steps_done, const v4l_ppo_hyper* hp, void* stream);
-/* The next minibatch update, == PPO.update (ppo.py:125-153). use_graph=1: the launch sequence (~500 kernels) is
+/* The next minibatch update, == PPO.update (ppo.py:125-153). use_graph=1: the launch sequence (~20 kernels) is
  * captured once per (rollout pointers, n, hyper-parameters) as a hipGraph and replayed; needs a non-default stream.
  * The first update of a configuration always runs eagerly. */
 int v4l_trainer_update_next(v4l_trainer* tr, const v4l_rollout* ro, int n, const v4l_ppo_hyper* hp, int use_graph,
@@ -230,9 +255,13 @@ int v4l_trainer_sync_target(v4l_trainer* tr, void* stream);
  *   drive the four phases (critic_grads / critic_step / actor_grads / actor_step) themselves. */
 #define V4L_COMM_ID_BYTES 128
 #define V4L_BUCKET_TAIL 8
+int v4l_comm_available(void); /* 0 when RCCL can be loaded in this process (else -1 + message): ranks should agree on this
+                                 before any of them enters v4l_trainer_comm_init — the rendezvous blocks until all arrive */
 int v4l_comm_unique_id(char* id_out /* [V4L_COMM_ID_BYTES], rank 0; broadcast it to the other ranks by any means */);
 int v4l_trainer_comm_init(v4l_trainer* tr, const char* id /* [V4L_COMM_ID_BYTES] */, int rank, int world);
 int v4l_trainer_comm_destroy(v4l_trainer* tr);
+/* rank / size as the attached communicator reports them (ncclCommUserRank / ncclCommCount); 0 / 1 without one */
+int v4l_trainer_comm_info(const v4l_trainer* tr, int* rank_out, int* world_out);
 int v4l_sync_grads(v4l_trainer* tr, int which /* 1 = critic bucket, 0 = policy bucket */, void* stream);
 /* for a host that runs the collective itself (e.g. torch.distributed): statistics record -> bucket tail (pack = 1, before
  * the all-reduce of total_params + V4L_BUCKET_TAIL floats) and back (pack = 0) */

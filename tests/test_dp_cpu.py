@@ -119,3 +119,62 @@ def test_two_rank_update_equals_big_batch(tmp_path):
     g_vf, g_pf = _shard_grads(case, p_pf, p_vf, big, 1, mean, std)
     assert util.rel_err(got["g_vf"], g_vf) < 1e-5
     assert util.rel_err(got["g_pf"], g_pf) < 1e-4
+
+
+# ---- bootstrap of the library's own communicator (V4L_DP_COMM=rccl) and bench.py's self-launcher -----------------------
+def _handshake_worker(rank, world, port, out, broken_rank):
+    """The PPO.__init__ data-parallel branch up to (not including) ncclCommInitRank: the product's `exchange_comm_id` over
+    a gloo group. `available` / `unique_id` stand in for v4l_comm_available / v4l_comm_unique_id (RCCL needs a GPU)."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from vision4leg_amd.torchrl.algo.on_policy.ppo import exchange_comm_id
+    calls = {"id": 0}
+
+    def unique_id():
+        calls["id"] += 1
+        return bytes((7 * i + 3) % 256 for i in range(128))
+    got = exchange_comm_id(dist, torch.device("cpu"), lambda: rank != broken_rank, unique_id)
+    torch.save({"id": got, "id_calls": calls["id"]}, "%s.%d" % (out, rank))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize("broken_rank", [-1, 1])
+def test_comm_id_handshake_world2(tmp_path, broken_rank):
+    """Every rank gets rank 0's 128-byte id (only rank 0 generates one) — or, when ANY rank cannot load RCCL, every rank
+    gets None together, so none of them enters the communicator rendezvous alone (a one-sided dlopen failure
+    would hang the others in ncclCommInitRank)."""
+    world, out = 2, str(tmp_path / "hs")
+    mp.start_processes(_handshake_worker, args=(world, _free_port(), out, broken_rank), nprocs=world, join=True,
+                       start_method="spawn")
+    res = [torch.load("%s.%d" % (out, r), weights_only=False) for r in range(world)]
+    if broken_rank >= 0:
+        assert all(r["id"] is None for r in res) and all(r["id_calls"] == 0 for r in res)
+        return
+    want = bytes((7 * i + 3) % 256 for i in range(128))
+    assert all(r["id"] == want for r in res)
+    assert [r["id_calls"] for r in res] == [1, 0]
+
+
+def test_bench_launcher_argv():
+    """`python bench.py --gpus N ...` re-executes itself as N ranks with the driver's own command line (one process per GPU,
+    rendezvous on 127.0.0.1) and hands its flags through unchanged."""
+    import importlib
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    bench = importlib.import_module("bench")
+    argv = ["--gpus", "8", "--steps", "5", "--warmup", "2", "--workload", "loco64"]
+    cmd = bench.launcher_argv(8, argv, port=29611)
+    assert cmd[:3] == [sys.executable, "-m", "torch.distributed.run"]
+    assert "--nnodes=1" in cmd and cmd[cmd.index("--nproc-per-node") + 1] == "8"
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[cmd.index("--master-port") + 1] == "29611"
+    i = cmd.index(os.path.join(root, "bench.py"))
+    assert cmd[i + 1:] == argv
+    a = bench.parse(cmd[i + 1:])
+    assert a.gpus == 8 and a.steps == 5 and a.warmup == 2 and a.workload == "loco64"
+    # without an explicit port a free one is picked (or MASTER_PORT is honoured)
+    p = int(bench.launcher_argv(2, [])[bench.launcher_argv(2, []).index("--master-port") + 1])
+    assert 1024 < p < 65536

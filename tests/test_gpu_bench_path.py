@@ -1,0 +1,51 @@
+"""-m gpu: the configuration bench.py times, against the pinned oracle fed the REFERENCE protocol.
+
+bench.py's step = RolloutActor.step at batch E (stored action / value / log pi_old) followed by hipGraph-replayed B = 1024
+updates that read the stored log pi_old instead of evaluating the frozen target policy (SURVEY 8d's declared saving). The
+oracle (oracle/bench_path.py) does what the reference does: pf.explore / vf per env step (collector/on_policy.py:90-100),
+Normal(mean, std).log_prob (policies/continuous_policy.py:127-146) and a target_pf forward inside every minibatch update
+(algo/on_policy/ppo.py:34,55-59).
+
+Gates
+  f32 : rollout mean / value <= 2e-5, log pi_old <= 2e-5 (abs), the 18 infos of every update <= 5e-4, parameters <= 5e-5.
+  bf16: distances reported (profiles/parity_r3.json) and the TRAJECTORY RULE: per update, HIP-bf16 is no further from the
+        fp32 reference trajectory than the bf16 oracle is, up to a factor / floor that covers which side of a rounding tie
+        the two bf16 implementations happen to land on (they agree to 1 ulp per contraction: test_gpu_contractions.py).
+"""
+import pytest
+
+import util
+from oracle import bench_path
+
+pytestmark = pytest.mark.gpu
+
+TRAJ_FACTOR, TRAJ_FLOOR = 3.0, 3e-3
+
+
+@pytest.mark.parametrize("mode", ["f32", "bf16"])
+@pytest.mark.parametrize("E", [32, 64])
+def test_rollout_then_stored_logp_graph_updates_vs_reference_protocol(E, mode, device):
+    case = dict(util.CASES["loco_b1024"])
+    T, B, U = 64, 1024, 4
+    r = bench_path.run(case, E, T, B, U, mode, device, threads=16)
+    tag = "bench_path/E%d/%s/" % (E, mode)
+    for k, v in r.items():
+        if isinstance(v, float):
+            util.record(tag + k, v)
+    print("\n[bench path E=%d %s] %s" % (E, mode, {k: v for k, v in r.items() if k != "path"}))
+    assert r["finite"] and r["graph_replays"]
+    assert r["rollout_logp_abs_vs_own_normal"] <= 2e-5
+    if mode == "f32":
+        assert r["rollout_mean_vs_f32"] <= 2e-5 and r["rollout_value_vs_f32"] <= 2e-5 and r["rollout_std_vs_f32"] <= 1e-6
+        assert r["rollout_logp_abs_vs_f32"] <= 2e-4  # (a - mu)^2 / (2 sigma^2) with sigma = 0.125 amplifies d(mu) by ~ |a - mu| / sigma^2 = 8
+        assert r["infos_vs_f32"] <= 5e-4, (r["infos_vs_f32_worst_key"], r["infos_vs_f32_per_update"])
+        assert r["param_max_vs_f32"] <= 5e-5 and r["param_mean_vs_f32"] <= 1e-6
+        return
+    # bf16: where the bf16-rounded oracle sits ...
+    assert r["rollout_mean_vs_bf16"] <= 1e-2 and r["rollout_value_vs_bf16"] <= 1e-2
+    assert r["infos_vs_bf16_per_update"][0] <= 1e-2, r["infos_vs_bf16_per_update"]
+    # ... and the trajectory rule against the fp32 reference trajectory, update by update
+    for u in range(U):
+        hip, orc_d = r["infos_vs_f32_per_update"][u], r["oracle_bf16_vs_f32_per_update"][u]
+        assert hip <= TRAJ_FACTOR * orc_d + TRAJ_FLOOR, (u, hip, orc_d)
+    assert r["param_mean_vs_f32"] <= TRAJ_FACTOR * r["oracle_bf16_vs_f32_param_mean"] + 2e-6

@@ -268,8 +268,17 @@ def test_ppo_update(name, mode, device):
                 # (the surrogate's clip indicator makes its gradient discontinuous in the ratio: by the second update the ratios
                 # straddle 1 +- 0.2 — ratio/max 1.2085 in loco_rag — and a sample that two bf16 evaluations put on different
                 # sides of the boundary moves grad_norm/pf by a few per cent: 2.80 / 2.89 both occur)
-                ok = abs(info[k] - oinfo[k]) <= tol or abs(info[k] - ginfo[k]) <= 5e-2 * max(1.0, abs(ginfo[k]))
-                assert ok, (u, k, info[k], oinfo[k], ginfo[k])
+                # Only the statistics that ARE discontinuous in the ratio get the either-or rule; the smooth ones (vf_loss,
+                # advantage / log-prob / log-std moments, the critic's gradient norm) keep the strict bf16-oracle gate.
+                strict_ok = abs(info[k] - oinfo[k]) <= tol
+                if k in ("grad_norm/pf", "ratio/max", "ratio/min", "Training/policy_loss"):
+                    ref_ok = abs(info[k] - ginfo[k]) <= 5e-2 * max(1.0, abs(ginfo[k]))
+                    # which branch accepted it, for the record (profiles/parity_rNN.json): 0 = bf16 oracle, 1 = fp32 reference
+                    util.record("ppo_update/%s/%s/u%d/accepted_by_reference_only/%s" % (name, mode, u, k),
+                                0.0 if strict_ok else 1.0)
+                    assert strict_ok or ref_ok, (u, k, info[k], oinfo[k], ginfo[k])
+                else:
+                    assert strict_ok, (u, k, info[k], oinfo[k], ginfo[k])
                 continue
             assert abs(info[k] - oinfo[k]) <= tol, (u, k, info[k], oinfo[k])
             if mode == "f32":
@@ -720,11 +729,17 @@ def test_stored_logp_equals_target_forward(mode, device):
     (ps, ss), (pt, st) = results
     # rollout (fused inference kernels, E rows) and training forward (B rows) are different launch shapes of the same
     # arithmetic: fp32 agrees to rounding; bf16 operand rounding can flip an element (see _oracle_noise)
-    tol = 2e-5 if mode == "f32" else 1e-2
     print("\n[stored logp %s] first-update ratio max/min: stored %.6f/%.6f target-forward %.6f/%.6f"
           % (mode, ss[0, 15], ss[0, 16], st[0, 15], st[0, 16]))
     # (the first ratio is not 1: the critic step of the same minibatch already moved the encoder both nets share)
-    assert np.allclose(ss[:, :18], st[:, :18], rtol=10 * tol, atol=10 * tol), np.abs(ss[:, :18] - st[:, :18]).max()
+    # Bound: the two sources differ by what a bf16 mean moves when the SAME arithmetic runs in another launch shape — a few
+    # operand-rounding flips, |d mu| ~ 1e-3 |mu| with |mu| ~ 1e-2 -> |d log pi| ~ |a - mu| / sigma^2 |d mu| ~ 1e-4 on the first
+    # update — then grows through Adam (a sign flip of a tiny gradient moves a parameter by 2 lr). fp32 has no such flips.
+    err = np.abs(ss[:, :18] - st[:, :18]) / np.maximum(1.0, np.abs(st[:, :18]))
+    util.record("stored_logp/%s/infos_first_update" % mode, err[0].max())
+    util.record("stored_logp/%s/infos_all_updates" % mode, err.max())
+    assert err[0].max() <= (2e-5 if mode == "f32" else 2e-3), err[0]
+    assert err.max() <= (2e-4 if mode == "f32" else 2e-2), err.max(axis=1)
     drift = sum((ps[k] - pt[k]).abs().sum().item() for k in ps) / sum(v.numel() for v in ps.values())
     assert drift <= (1e-6 if mode == "f32" else 5e-5), drift
 

@@ -75,72 +75,9 @@ def obsnorm_inputs(case):
     return raws, [k < case["eval_from"] for k in range(K)]
 
 
-def obs_dim(case):
-    return case["S"] + (0 if case["kind"] == "mlp" else 4 * 64 * 64)
-
-
-def build_nets(networks, policies, case):
-    """pf / vf exactly as starter/ppo_{locotransformer,nature_cnn,state}.py wire them (shared encoder / base).
-    `networks` / `policies` are either the reference's modules or vision4leg_amd.torchrl's."""
-    S, A, kind = case["S"], case["A"], case["kind"]
-    net = {"append_hidden_shapes": list(case["head"]), "base_type": networks.MLPBase}
-    if kind == "loco":
-        net["transformer_params"] = [[1, case["ff"]] for _ in range(case["layers"])]
-        encoder = networks.LocoTransformerEncoder(in_channels=4, state_input_dim=S, hidden_shapes=list(case["enc"]),
-                                                  visual_dim=256)
-        pf = policies.GaussianContPolicyLocoTransformer(encoder=encoder, state_input_shape=S,
-                                                        visual_input_shape=(4, 64, 64), output_shape=A, **net)
-        vf = networks.LocoTransformer(encoder=encoder, state_input_shape=S, visual_input_shape=(4, 64, 64),
-                                      output_shape=1, **net)
-    elif kind == "cnn":
-        encoder = networks.NatureFuseEncoder(in_channels=4, state_input_dim=S, hidden_shapes=list(case["enc"]),
-                                             visual_dim=case["visual_dim"])
-        pf = policies.GaussianContPolicyImpalaEncoderProj(encoder=encoder, state_input_shape=S,
-                                                          visual_input_shape=(4, 64, 64), output_shape=A, **net)
-        vf = networks.ImpalaEncoderProjNet(encoder=encoder, state_input_shape=S, visual_input_shape=(4, 64, 64),
-                                           output_shape=1, **net)
-    elif kind == "loco_vis":
-        net["transformer_params"] = [[1, case["ff"]] for _ in range(case["layers"])]
-        encoder = networks.TransformerEncoder(in_channels=4)
-        pf = policies.GaussianContPolicyTransformer(encoder=encoder, visual_input_shape=(4, 64, 64), output_shape=A, **net)
-        vf = networks.Transformer(encoder=encoder, visual_input_shape=(4, 64, 64), output_shape=1, **net)
-    elif kind == "cnn_vis":
-        encoder = networks.NatureEncoder(in_channels=4)
-        pf = policies.GaussianContPolicyNatureEncoderProj(encoder=encoder, visual_input_shape=(4, 64, 64),
-                                                          output_shape=A, **net)
-        vf = networks.NatureEncoderProjNet(encoder=encoder, visual_input_shape=(4, 64, 64), output_shape=1, **net)
-    else:
-        net["hidden_shapes"] = list(case["enc"])
-        pf = policies.GaussianContPolicyBasicBias(input_shape=S, output_shape=A, **net)
-        vf = networks.Net(input_shape=(S,), output_shape=1, **net)
-        vf.base = pf.base
-    return pf, vf
-
-
-def share_encoder(pf_params, vf_params, kind):
-    """Make vf's dict reference pf's tensor objects for the shared sub-module (encoder.* / base.*)."""
-    pre = "base." if kind == "mlp" else "encoder."
-    for k in vf_params:
-        if k.startswith(pre):
-            vf_params[k] = pf_params[k]
-    return vf_params
-
-
-def make_batch(case, update=0, B=None):
-    """A seeded minibatch in the distributions of BASELINE.md §3."""
-    B = case["B"] if B is None else B
-    rs = np.random.RandomState(1000 * case["seed"] + 17 + update)
-    S, A = case["S"], case["A"]
-    cols = [np.clip(rs.randn(B, S), -10, 10)]
-    if case["kind"] != "mlp":
-        cols.append(np.clip(rs.randn(B, 4 * 64 * 64), -2.5, 2.8))
-    return {
-        "obs": np.concatenate(cols, axis=1),
-        "acts": 0.1 * rs.randn(B, A),
-        "advs": rs.randn(B, 1),
-        "estimate_returns": rs.randn(B, 1),
-        "values": rs.randn(B, 1),
-    }
+from vision4leg_amd.recipes import build_nets, make_batch, obs_dim, obs_rows, share_encoder  # noqa: E402,F401
+# (the starters' wiring and the synthetic-batch generators live in the package — vision4leg_amd/recipes.py — so that
+# bench.py and __graft_entry__ do not import the test tree; the tests and make_golden.py use the same functions)
 
 
 def small_param_names(pf_sd, vf_sd, limit=4096):

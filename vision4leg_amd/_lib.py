@@ -119,6 +119,8 @@ _SIGS = {
   "v4l_trainer_update": (C.c_int, [_P, C.POINTER(Rollout), _P, C.c_int, C.POINTER(PPOHyper), C.c_double,
                                    C.c_double, C.c_int64, _P, _P]),
   "v4l_trainer_sync_target": (C.c_int, [_P, _P]),
+  "v4l_comm_available": (C.c_int, []),
+  "v4l_trainer_comm_info": (C.c_int, [_P, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
   "v4l_comm_unique_id": (C.c_int, [C.c_char_p]),
   "v4l_trainer_comm_init": (C.c_int, [_P, C.c_char_p, C.c_int, C.c_int]),
   "v4l_trainer_comm_destroy": (C.c_int, [_P]),

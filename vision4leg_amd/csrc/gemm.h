@@ -1,7 +1,8 @@
 // MFMA GEMM cores for the gfx950 PPO hot path.
 //
 //   gemm_nt : C[m][n] = epi( sum_k A(m,k) * Bp[n][k] )        forward linears/convs and data-grads
-//   gemm_tn : dW[n][k] += sum_m Y(m,n) * X(m,k)               weight-grads (split over m, fp32 atomics)
+//   gemm_tn : dW[n][k]  = sum_m Y(m,n) * X(m,k)               weight-grads (split over m: one partial slab per split,
+//                                                               summed in a fixed order by wgrad_reduce_kernel — no atomics)
 //
 // A / X / Y are *loader functors*: a row context (all integer divisions hoisted out of the k loop) plus
 // a "give me 8 consecutive k as fp32" call. That is what turns one MFMA core into dense linear,

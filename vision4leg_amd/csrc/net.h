@@ -102,6 +102,7 @@ struct v4l_net {
   float* d_sq = nullptr;             // sum of squares of what each wgrad_reduce block wrote (the gradient norm's partials)
   int64_t sq_cap() const { return total_params / 64 + 2 * MAX_RED + 64; }
   int red_blocks = 0;                // blocks of the last wgrad_reduce launch (0: no partials available)
+  const float* red_grads = nullptr;  // the gradient buffer that launch wrote: the partials describe THIS buffer only
   static constexpr int MAX_RED = 96;
   static constexpr int MAX_TNP = 64;
   v4l::TnProb* d_tnp = nullptr;

@@ -273,6 +273,7 @@ static int wgrad_reduce_all(Ctx& c) {
   g_op = "wgrad_reduce";
   float* sq = blk <= net->sq_cap() ? net->d_sq : nullptr;
   net->red_blocks = sq != nullptr ? (int)blk : 0;
+  net->red_grads = c.grads;
   V4L_KLAUNCH("wgrad_reduce", 0, c.s, wgrad_reduce_kernel, dim3((unsigned)blk), dim3(256), 0, c.s, net->d_red, (int)net->red.size(), sq);
   V4L_LAUNCH_CHECK();
   return 0;
@@ -603,6 +604,8 @@ struct Rccl {
   int (*GetUniqueId)(RcclUid*) = nullptr;
   int (*CommInitRank)(void**, int, RcclUid, int) = nullptr;
   int (*CommDestroy)(void*) = nullptr;
+  int (*CommCount)(void*, int*) = nullptr;
+  int (*CommUserRank)(void*, int*) = nullptr;
   int (*AllReduce)(const void*, void*, size_t, int, int, void*, hipStream_t) = nullptr;
   const char* (*GetErrorString)(int) = nullptr;
 };
@@ -622,9 +625,11 @@ static int rccl_load() {
   r.GetUniqueId = (int (*)(RcclUid*))dlsym(h, "ncclGetUniqueId");
   r.CommInitRank = (int (*)(void**, int, RcclUid, int))dlsym(h, "ncclCommInitRank");
   r.CommDestroy = (int (*)(void*))dlsym(h, "ncclCommDestroy");
+  r.CommCount = (int (*)(void*, int*))dlsym(h, "ncclCommCount");
+  r.CommUserRank = (int (*)(void*, int*))dlsym(h, "ncclCommUserRank");
   r.AllReduce = (int (*)(const void*, void*, size_t, int, int, void*, hipStream_t))dlsym(h, "ncclAllReduce");
   r.GetErrorString = (const char* (*)(int))dlsym(h, "ncclGetErrorString");
-  V4L_REQUIRE(r.GetUniqueId && r.CommInitRank && r.CommDestroy && r.AllReduce && r.GetErrorString,
+  V4L_REQUIRE(r.GetUniqueId && r.CommInitRank && r.CommDestroy && r.AllReduce && r.GetErrorString && r.CommCount && r.CommUserRank,
               "v4l_comm: the loaded RCCL lacks a required symbol");
   g_rccl = r;
   return 0;
@@ -1017,7 +1022,9 @@ int v4l_net::forward_t(const float* state, const T* image, const int* rowidx, in
         te.s_c1 = tr.s_c1; te.s_c2 = tr.s_c2; te.s_c3 = tr.s_c3; te.s_h1 = tr.s_h1; te.s_h2 = tr.s_h2;
         te.n = n; te.nmlp = cdiv(n, 32);
         static const int cus = getenv("V4L_TRAIN_ENC_BLOCKS") ? atoi(getenv("V4L_TRAIN_ENC_BLOCKS")) : 256;
-        te.nconv = std::max(1, std::min(n, cus - te.nmlp));
+        // the conv share never collapses: a very large minibatch (n >~ 8 K: nmlp -> cus) still gets half the CUs' worth of
+        // persistent conv blocks (the MLP blocks are short; the two kinds then simply run in two waves over the chip)
+        te.nconv = std::max(1, std::min(n, std::max(cus / 2, cus - te.nmlp)));
         V4L_KLAUNCH("fused_encoder", 2.0 * n * 3784064.0, s, train_encoder_kernel, dim3(te.nmlp + te.nconv), dim3(1024),
                     TrainEncLds::bytes, s, ef, te, x0);
       } else {
@@ -2277,9 +2284,13 @@ static int adam_step(v4l_trainer* tr, v4l_net* net, float* g, float* m, float* v
   // The gradient's sum of squares: on one GPU the backward's wgrad_reduce launch already left it, one partial per block
   // (plus log sigma's gradient, which the loss kernel writes itself); after an all-reduce the buffer is summed again.
   static const bool sq_from_reduce = getenv("V4L_NO_SQ_FROM_REDUCE") == nullptr;
-  if (sq_from_reduce && tr->comm == nullptr && hp->world_size == 1 && net->red_blocks > 0 && net->red_blocks <= ADAM_MAX_PARTS) {
+  // (only for the buffer the last backward pass of this net wrote, and only once: a host that drives the phases itself and
+  // runs another v4l_net_backward — or hands over another buffer — between grads and step gets the summed-again norm)
+  if (sq_from_reduce && tr->comm == nullptr && hp->world_size == 1 && net->red_blocks > 0 && net->red_blocks <= ADAM_MAX_PARTS &&
+      net->red_grads == g) {
     part = net->d_sq;
     gb = net->red_blocks;
+    net->red_blocks = 0;  // consumed
     if (net->logstd >= 0) { extra = g + net->params[net->logstd].goff; nextra = (int)net->params[net->logstd].numel; }
     V4L_REQUIRE(nextra <= 64, "internal: log sigma wider than a wave");
   } else {
@@ -2353,6 +2364,18 @@ int v4l_trainer_actor_step(v4l_trainer* tr, const v4l_ppo_hyper* hp, void* strea
   return adam_step(tr, tr->pf, tr->g_pf, tr->m_pf, tr->v_pf, hp, 0, st + ST_GN_PF, s, true);
 }
 
+int v4l_comm_available(void) { return rccl_load(); }
+int v4l_trainer_comm_info(const v4l_trainer* tr, int* rank_out, int* world_out) {
+  V4L_REQUIRE(tr != nullptr, "v4l_trainer_comm_info: null argument");
+  int rank = 0, world = 1;
+  if (tr->comm != nullptr) {  // as the communicator itself reports them, not as the caller passed them in
+    V4L_RCCL_CHECK(g_rccl.CommCount(tr->comm, &world));
+    V4L_RCCL_CHECK(g_rccl.CommUserRank(tr->comm, &rank));
+  }
+  if (rank_out) *rank_out = rank;
+  if (world_out) *world_out = world;
+  return 0;
+}
 int v4l_comm_unique_id(char* id_out) {
   V4L_REQUIRE(id_out != nullptr, "v4l_comm_unique_id: null argument");
   int rc = rccl_load();

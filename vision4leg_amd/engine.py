@@ -296,6 +296,18 @@ class HipTrainer:
     self.has_comm = True
 
   @staticmethod
+  def comm_available():
+    """True when this process can load RCCL (v4l_comm_available); ranks agree on it before the communicator rendezvous."""
+    return _lib.lib().v4l_comm_available() == 0
+
+  def comm_world(self):
+    """Ranks of the attached communicator as RCCL reports them (ncclCommCount), 1 without one."""
+    world = C.c_int(1)
+    rank = C.c_int(0)
+    check(self.L.v4l_trainer_comm_info(self.h, C.byref(rank), C.byref(world)), "v4l_trainer_comm_info")
+    return world.value
+
+  @staticmethod
   def comm_unique_id():
     buf = C.create_string_buffer(_lib.V4L_COMM_ID_BYTES)
     check(_lib.lib().v4l_comm_unique_id(buf), "v4l_comm_unique_id")

@@ -49,6 +49,28 @@ def _dist_world():
     return 1
 
 
+def exchange_comm_id(dist, device, available, unique_id, id_bytes=_lib.V4L_COMM_ID_BYTES):
+    """Bootstrap of the library's own RCCL communicator over an existing process group (any backend): every rank first
+    reports whether it can load RCCL (`available()` -> bool) and the ranks AGREE (a min all-reduce) before anyone enters
+    ncclCommInitRank — a rank that cannot load the library would otherwise leave the others hanging in the rendezvous.
+    Then rank 0's `unique_id()` (128 bytes) is broadcast. -> the id bytes, or None when some rank cannot take part (all ranks
+    get None together and fall back to torch.distributed's all-reduce)."""
+    on_dev = dist.get_backend() == "nccl"
+    kw = {"device": device} if on_dev else {}
+    ok = torch.tensor([1 if available() else 0], dtype=torch.int32, **kw)
+    dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+    if int(ok.item()) == 0:
+        return None
+    idt = torch.zeros(id_bytes, dtype=torch.uint8, **kw)
+    if dist.get_rank() == 0:
+        raw = bytes(unique_id())
+        if len(raw) != id_bytes:
+            raise RuntimeError("vision4leg_amd: communicator id has %d bytes, expected %d" % (len(raw), id_bytes))
+        idt.copy_(torch.frombuffer(bytearray(raw), dtype=torch.uint8))
+    dist.broadcast(idt, src=0)
+    return bytes(idt.cpu().numpy().tobytes())
+
+
 class PPO:
     def __init__(self, pf, vf, plr=3e-4, vlr=3e-4, optimizer_class=None, entropy_coeff=0.001, clip_para=0.2,
                  opt_epochs=10, clipped_value_loss=False, shuffle=True, tau=None, gae=True, env=None,
@@ -118,21 +140,22 @@ class PPO:
             self.trainer = HipTrainer(self.pf.hip, self.vf.hip, self.target_pf.hip, batch_size, clip_para,
                                       entropy_coeff, max_grad_norm=0.5, clipped_value_loss=clipped_value_loss,
                                       world_size=self.world_size)
-            # the exchange: by default the library's own RCCL communicator (all-reduces issued inside the captured update
-            # graph); V4L_DP_COMM=torch keeps them in torch.distributed (four eager phases per update)
-            self.dp_in_library = self.dp_phases and os.environ.get("V4L_DP_COMM", "rccl").lower() != "torch"
+            # the exchange: torch.distributed's all-reduce (backend "nccl" == RCCL) between four eager phases per update by
+            # default; V4L_DP_COMM=rccl opts into the library's own RCCL communicator, whose two all-reduces are issued by
+            # update_next() inside the captured update graph. (Opt-in until a multi-GPU box has run it with world > 1: it has
+            # only been exercised on a 1-rank communicator, tests/test_gpu_parity.py::test_dp_phase_sequence_on_one_rank.)
+            self.dp_in_library = self.dp_phases and os.environ.get("V4L_DP_COMM", "torch").lower() == "rccl"
             if self.dp_in_library:
                 dist = torch.distributed
-                rank = dist.get_rank()
-                if dist.get_backend() == "nccl":
-                    idt = torch.zeros(_lib.V4L_COMM_ID_BYTES, dtype=torch.uint8, device=self.device)
+                comm_id = exchange_comm_id(dist, self.device, HipTrainer.comm_available, HipTrainer.comm_unique_id)
+                if comm_id is None:  # agreed by all ranks: some rank cannot load RCCL
+                    import warnings
+                    warnings.warn("vision4leg_amd: V4L_DP_COMM=rccl but a rank cannot load librccl; every rank keeps the "
+                                  "torch.distributed exchange")
+                    self.dp_in_library = False
                 else:
-                    idt = torch.zeros(_lib.V4L_COMM_ID_BYTES, dtype=torch.uint8)
-                if rank == 0:
-                    idt.copy_(torch.frombuffer(bytearray(HipTrainer.comm_unique_id()), dtype=torch.uint8))
-                dist.broadcast(idt, src=0)
-                self.trainer.comm_init(bytes(idt.cpu().numpy().tobytes()), rank, self.world_size)
-                self.dp_phases = False  # update_next() carries the collectives itself
+                    self.trainer.comm_init(comm_id, dist.get_rank(), self.world_size)
+                    self.dp_phases = False  # update_next() carries the collectives itself
         self.use_graph = os.environ.get("V4L_GRAPH", "1") != "0"
         if isinstance(replay_buffer, rb.DeviceOnPolicyReplayBuffer):
             replay_buffer.attach(self.pf.hip, self.device)
@@ -174,13 +197,13 @@ class PPO:
                 # the device-resident normaliser (vision4leg_amd.torchrl.env): write what the reference's viewers unpickle
                 # (starter/locotransformer_viewer.py:125-147) — an instance of the REFERENCE's Normalizer class — whenever that
                 # class is importable (it is under overlay.install(): the reference's torchrl.env is untouched)
+                import importlib
                 try:
-                    import importlib
                     ref_cls = importlib.import_module("torchrl.env.base_wrapper").Normalizer
-                    if ref_cls is not type(norm):
-                        norm = norm.to_reference(ref_cls)
-                except Exception:  # stand-alone use of this package: the pickle then needs this package to load
-                    pass
+                except ImportError:  # stand-alone use of this package (no reference tree): the pickle then needs this package
+                    ref_cls = None
+                if ref_cls is not None and ref_cls is not type(norm):
+                    norm = norm.to_reference(ref_cls)  # a failing conversion must not silently write an incompatible pickle
             with open(osp.join(prefix, "_obs_normalizer_{}.pkl".format(epoch)), "wb") as f:
                 pickle.dump(norm, f)
         for name, network in self.snapshot_networks:
@@ -233,8 +256,9 @@ class PPO:
 
     def run_updates(self, ro, rowidx, stats):
         """All minibatch updates of an epoch: rowidx [U][n] int32 (device), stats [U][V4L_STATS] (device).
-        Single GPU: each update is one hipGraph replay on the trainer's stream. Data parallel: four eager
-        phases per update with one RCCL all-reduce per optimiser step."""
+        Each update is one hipGraph replay on the trainer's stream — on one GPU, and data-parallel with the library's own
+        communicator (V4L_DP_COMM=rccl: both all-reduces are nodes of that graph). With torch.distributed doing the exchange
+        (the data-parallel default) an update is four eager phases with one all-reduce per optimiser step between them."""
         tr = self.trainer
         U, n = rowidx.shape
         # the captured graph is keyed on these addresses: keep them stable from epoch to epoch
@@ -300,6 +324,9 @@ class PPO:
                 tr.begin(None, stats, self.pf_optimizer.lr, self.vf_optimizer.lr)
                 self._update_phases(ro, n)
             host = stats[0].cpu().numpy()
+        if host[_lib.ST_NONFINITE] > 0:  # the device-side tripwire, as in _update_epoch_resident
+            raise FloatingPointError("vision4leg_amd: non-finite training statistics in minibatch update %d: %s"
+                                     % (self.training_update_num, {k: float(host[j]) for j, k in enumerate(_lib.STAT_KEYS)}))
         return {k: float(host[j]) for j, k in enumerate(_lib.STAT_KEYS)}
 
     # ---- outer loop (rl_algo.py:97-168) ----------------------------------------------------------------

@@ -16,6 +16,7 @@ the extra value forward is issued only on steps where some env actually ran past
 plain terminations the reference multiplies it by zero).
 """
 import copy
+import os
 
 import numpy as np
 import torch
@@ -56,6 +57,8 @@ class VecOnPolicyCollector:
         self._actor = None
         self._cursor = -1
         self._pins = None
+        # threads of the per-step fp64 -> fp32 host cast (torch's intra-op pool; the env workers own the other cores)
+        self.cast_threads = max(1, min(8, (os.cpu_count() or 1) // 2))
         self.fast_path = isinstance(replay_buffer, DeviceOnPolicyReplayBuffer)
 
     # ---- reference plumbing (collector/base.py:54-58,113-115,166-174; on_policy.py:77-82) ----------------------------
@@ -89,7 +92,17 @@ class VecOnPolicyCollector:
         host, dev, ev = self._pins[self._pin_i]
         self._pin_i ^= 1
         ev.synchronize()  # the copy issued from this staging buffer two uploads ago
-        np.copyto(host.numpy(), rows, casting="same_kind")
+        if rows.dtype == np.float64 and rows.flags.c_contiguous and self.cast_threads > 1:
+            # the cast is the longest host stage of a step (E x 16.5 K doubles): a few threads of torch's copy kernel
+            # instead of one numpy pass; round-to-nearest fp64 -> fp32 either way (== torch.Tensor(ob), on_policy.py:91)
+            prev = torch.get_num_threads()
+            if prev != self.cast_threads:
+                torch.set_num_threads(self.cast_threads)
+            host.copy_(torch.from_numpy(rows))
+            if prev != self.cast_threads:
+                torch.set_num_threads(prev)
+        else:
+            np.copyto(host.numpy(), rows, casting="same_kind")
         dev.copy_(host, non_blocking=True)
         ev.record()
         return dev

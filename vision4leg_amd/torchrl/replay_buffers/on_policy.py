@@ -126,7 +126,14 @@ class DeviceOnPolicyReplayBuffer(OnPolicyReplayBufferBase, BaseReplayBuffer):
         if filed:
             if self._logp_dev is None:
                 raise RuntimeError("add_sample(filed=True) needs step_arrays() to have been handed to a RolloutActor")
+            if not self._filed or self._top == 0:
+                # a filed epoch starts: host arrays an earlier host-path epoch left behind (and last epoch's materialised
+                # copies) must not shadow what __getattr__ serves from HBM
+                for stale in ("_acts", "_values"):
+                    self.__dict__.pop(stale, None)
+                self._host_cache = {}
             self._filed = True
+            self._filed_steps = self.__dict__.get("_filed_steps", 0) + 1
         else:
             if self._filed and self._top != 0:
                 raise RuntimeError("DeviceOnPolicyReplayBuffer: filed and host steps mixed inside one epoch")
@@ -195,8 +202,14 @@ class DeviceOnPolicyReplayBuffer(OnPolicyReplayBufferBase, BaseReplayBuffer):
             self._estimate_returns = self._rets_dev64.cpu().numpy().reshape(self._max_replay_buffer_size, self.env_nums, 1)
             return self._estimate_returns
         if name in ("_acts", "_values") and self.__dict__.get("_filed"):
-            src = self._acts_dev if name == "_acts" else self._values32_dev
-            return src.cpu().numpy().astype(np.float64).reshape(self._max_replay_buffer_size, self.env_nums, -1)
+            # one D2H copy per (epoch position, array): the cache is dropped when the next filed step lands
+            cache = self.__dict__.setdefault("_host_cache", {})
+            key = (name, self.__dict__.get("_top"), self.__dict__.get("_filed_steps"))
+            if key not in cache:
+                src = self._acts_dev if name == "_acts" else self._values32_dev
+                cache.clear()
+                cache[key] = src.cpu().numpy().astype(np.float64).reshape(self._max_replay_buffer_size, self.env_nums, -1)
+            return cache[key]
         raise AttributeError(name)
 
     def last_sample(self, sample_key):
