@@ -146,8 +146,13 @@ class DeviceOnPolicyReplayBuffer(OnPolicyReplayBufferBase, BaseReplayBuffer):
         for key, value in sample_dict.items():
             if key == "obs" or (filed and key in ("acts", "values")):
                 continue
-            if key == "next_obs":  # only the epoch's last next_obs is ever read (on_rl_algo.py:24-26)
-                self._last_next_obs = value if isinstance(value, torch.Tensor) else np.array(value, copy=True)
+            if key == "next_obs":
+                # only the epoch's LAST next_obs is ever read (last_sample at index T-1, on_rl_algo.py:24-26): that one is
+                # copied (the env may reuse its buffer); the others are only referenced — copying E x 16.5 K doubles per env
+                # step was the single largest host cost of the fast collector (tools/probe/collector_stages.py)
+                if self._top == self._max_replay_buffer_size - 1 and not isinstance(value, torch.Tensor):
+                    value = np.array(value, copy=True)
+                self._last_next_obs = value
                 continue
             self._store(key, value)
         self._advance()
