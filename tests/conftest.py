@@ -21,6 +21,16 @@ def device():
     return torch.device("cuda:0")
 
 
+@pytest.fixture
+def layer_taps():
+    """The wave-per-sample layer kernels keep a layer's intermediates in registers (production saves only the layer inputs);
+    V4L_LAYER_TAPS=1 makes the SAME kernels also write every intermediate row-major into the workspace slots the tap tests
+    read through v4l_net_ws_offset (read per call by the library)."""
+    os.environ["V4L_LAYER_TAPS"] = "1"
+    yield
+    os.environ.pop("V4L_LAYER_TAPS", None)
+
+
 def pytest_sessionfinish(session, exitstatus):
     """Keep the parity errors the GPU tests measured (util.record) as a file: gpurun_out/parity.json."""
     import json

@@ -41,7 +41,7 @@ def _close_t(name, got_t, want32, mode, tag, max_ulp=1.0):
 
 
 @pytest.mark.parametrize("mode", MODES)
-def test_every_contraction_teacher_forced(mode, device):
+def test_every_contraction_teacher_forced(mode, device, layer_taps):
     case = util.CASES["loco_s93"]
     n, S, A, R = case["B"], case["S"], case["A"], case["B"] * 17
     pf, vf = _build(case, mode, device)

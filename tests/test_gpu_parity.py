@@ -100,7 +100,7 @@ def test_forward(name, mode, device):
 
 
 @pytest.mark.parametrize("mode", MODES)
-def test_loco_intermediates(mode, device):
+def test_loco_intermediates(mode, device, layer_taps):
     """activation taps of the LocoTransformer forward (debug-grade localisation of a mismatch)."""
     case = util.CASES["loco_s93"]
     pf, vf = _build(case, mode, device)

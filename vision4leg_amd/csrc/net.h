@@ -26,6 +26,7 @@ struct Lin {         // nn.Linear (or the 1x1 up-conv): y = x W^T + b, W [N][K]
   int Rt = 0, Ct = 0;     // transposed pack [Rt = pad16(K)][Ct = pad64(N)] for the data-grad
   int64_t pkt = 0;
   int64_t pkf = -1;       // fragment-order pack [Np/16][Kp/32][64 lanes][8] (rollout kernels), -1: none
+  int64_t pkp = -1, pkpt = -1;  // k-permuted fragment-order packs of W / W^T (wave-per-sample layer kernels, csrc/wps.h), -1: none
   int cin = 0, taps = 0;  // > 0: input is an NHWC flatten, packed k = tap*cin + c  (PyTorch k = c*taps + tap)
   bool need_dgrad = true;
   std::string tag_fwd, tag_wgrad, tag_dgrad;  // profiler labels
@@ -68,6 +69,7 @@ struct Layout {
   std::vector<int64_t> dxl;      // LOCO: grad w.r.t. x[l], l = 0..L
   int64_t dhc = 0;               // [n][maxwidth] hand-off between two stacks (head -> encoder / concat)
   int64_t dpool = 0, dc3 = 0, dc2 = 0, dc1 = 0;
+  std::vector<int64_t> wps_wg, wps_tk;  // per layer: fragment-order weight-grad operand blocks of the wave-per-sample kernels
   int64_t slab = 0;              // weight-grad partial slabs
   int64_t total = 0;
 };
@@ -130,6 +132,7 @@ struct v4l_net {
   template <typename T> int forward_t(const float* state, const T* image, const int* rowidx, int n, float* ws, hipStream_t s,
                                       const float* enc_ws = nullptr, int stage = 0);
   bool fused_layers() const;  // the transformer layers run as fused forward / backward launches (csrc/infer.h, bwd.h)
+  bool wps_layers() const;    // ... as wave-per-sample launches (csrc/wps.h)
   template <typename T> int backward_t(const float* state, const T* image, const int* rowidx, int n, float* ws, float* grads, hipStream_t s);
 };
 

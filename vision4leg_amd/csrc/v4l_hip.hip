@@ -9,6 +9,7 @@
 #include "net.h"
 #include "infer.h"
 #include "bwd.h"
+#include "wps.h"
 
 namespace v4l {
 
@@ -136,6 +137,9 @@ struct Ctx {  // per-call view of a bound net
   bool defer_conv3 = false, conv3_pending = false;
   v4l::BwdConv conv3_args = {};
   int conv3_blocks = 0, conv3_n = 0;
+  // the wave-per-sample layers' weight-grad launch (csrc/wps.h), issued with the other dense weight-grads
+  bool wps_pending = false;
+  v4l::WpsWg wps_args = {};
 };
 
 // Fork/join of the net's auxiliary stream. Independent sibling kernels (a layer's weight-grad next to its data-grad,
@@ -200,6 +204,14 @@ static int wgrad_finish(Ctx& c) {
 template <typename T>
 static int wgrad_dense(Ctx& c, hipStream_t ds) {
   v4l_net* net = c.net;
+  if (c.wps_pending) {
+    c.wps_pending = false;
+    const int jobs = c.wps_args.nsplit * WPS_ROLES * c.wps_args.nlayers;
+    g_op = "layer.wgrad";
+    V4L_KLAUNCH("wps_wgrad", 2.0 * c.wps_args.n * NTOK * (double)WPS_LAYER_ELEMS * c.wps_args.nlayers, ds, wps_wgrad_kernel<T>,
+                dim3((unsigned)cdiv(jobs, 4)), dim3(256), 0, ds, c.wps_args);
+    V4L_LAUNCH_CHECK();
+  }
   int64_t gb = 0;
   int wb = 0;
   if (!net->tnp.empty()) {
@@ -817,6 +829,30 @@ int v4l_net::build() {
   for (Lin& L : enc) pack_lin(L);
   for (TLayer& t : layers) { pack_lin(t.inproj); pack_lin(t.outproj); pack_lin(t.ff1); pack_lin(t.ff2); }
   for (Lin& L : head) pack_lin(L);
+  if (c.kind == V4L_NET_LOCO && c.ff_dim == 256) {
+    // wave-per-sample layer kernels (csrc/wps.h): per layer ONE contiguous block [in_proj | out_proj | linear1 | linear2] of
+    // k-permuted fragment-order packs (it is DMA'd into LDS as a whole), and the same of the transposed weights
+    for (TLayer& t : layers) {
+      Lin* ls[4] = {&t.inproj, &t.outproj, &t.ff1, &t.ff2};
+      int64_t at = -1;
+      for (Lin* L : ls) {
+        L->pkp = add_pack(L->w, PK_FRAGP, L->N, L->K, L->N, L->K, 0, 0, 0, 0, 0, 0, 0);
+        V4L_REQUIRE(at < 0 || L->pkp == at, "internal: a layer's fragment packs are not adjacent");
+        at = L->pkp + (int64_t)L->N * L->K;
+      }
+      V4L_REQUIRE(t.outproj.pkp - t.inproj.pkp == WPS_OFF_WO && t.ff1.pkp - t.inproj.pkp == WPS_OFF_W1 &&
+                      t.ff2.pkp - t.inproj.pkp == WPS_OFF_W2, "internal: wave-per-sample weight block layout");
+      at = -1;
+      for (Lin* L : ls) {  // the transposed block: rows = input features, contraction = output features
+        L->pkpt = add_pack(L->w, PK_FRAGPT, L->K, L->N, L->N, L->K, 0, 0, 0, 0, 0, 0, 0);
+        V4L_REQUIRE(at < 0 || L->pkpt == at, "internal: a layer's transposed fragment packs are not adjacent");
+        at = L->pkpt + (int64_t)L->N * L->K;
+      }
+      V4L_REQUIRE(t.outproj.pkpt - t.inproj.pkpt == WPS_OFF_WO && t.ff1.pkpt - t.inproj.pkpt == WPS_OFF_W1 &&
+                      t.ff2.pkpt - t.inproj.pkpt == WPS_OFF_W2, "internal: wave-per-sample transposed weight block layout");
+    }
+    upconv.pkpt = add_pack(upconv.w, PK_FRAGPT, upconv.K, upconv.N, upconv.N, upconv.K, 0, 0, 0, 0, 0, 0, 0);
+  }
   if (c.kind == V4L_NET_LOCO) {  // the rollout step streams these as whole MFMA fragments (rollout_stack_kernel)
     auto pack_frag = [&](Lin& L) { L.pkf = add_pack(L.w, PK_FRAG, L.Np, L.Kp, L.N, L.K, 0, 0, 0, 0, 0, 0, 0); };
     for (TLayer& t : layers) { pack_frag(t.inproj); pack_frag(t.outproj); pack_frag(t.ff1); pack_frag(t.ff2); }
@@ -838,6 +874,9 @@ int v4l_net::build() {
 int64_t v4l_net::table_bytes() const {
   return (int64_t)(packs.size() * sizeof(PackDesc) + params.size() * sizeof(ParamSeg) + MAX_RED * sizeof(RedDesc) +
                    MAX_TNP * sizeof(TnProb) + MAX_WIDE * sizeof(TnWide) + sq_cap() * sizeof(float) + 1024);
+}
+bool v4l_net::wps_layers() const {
+  return fused_layers() && cfg.n_layers == 2 && layers[0].inproj.pkp >= 0 && getenv("V4L_NO_WPS_LAYERS") == nullptr;
 }
 bool v4l_net::fused_layers() const {
   return cfg.kind == V4L_NET_LOCO && cfg.ff_dim == 256 && getenv("V4L_NO_FUSED_LAYER") == nullptr;
@@ -868,6 +907,8 @@ int64_t v4l_net::slab_floats(int n) const {
     tot += 2 * 2 * (int64_t)std::max(128, cdiv(n, 2)) * TD;
   }
   for (const Lin& L : head) add(n, L.N, L.K);
+  if (!layers.empty() && layers[0].inproj.pkp >= 0)  // wave-per-sample weight-grads: one slab set per run of WPS_SPLIT samples
+    tot += (int64_t)layers.size() * cdiv(n, WPS_SPLIT) * (WPS_LAYER_ELEMS + 576) + 1024;
   return tot;
 }
 
@@ -924,6 +965,12 @@ Layout v4l_net::layout(int n) const {
       L.lb.push_back(b);
     }
     L.dpool = take((int64_t)n * 2 * TD);
+    if (!layers.empty() && layers[0].inproj.pkp >= 0) {
+      for (int l = 0; l < c.n_layers; ++l) {  // sized for fp32 operands (parity mode); bf16 uses half
+        L.wps_wg.push_back(take((int64_t)n * WPS_WG_ELEMS));
+        L.wps_tk.push_back(take((int64_t)n * WPS_TK_ELEMS));
+      }
+    }
   }
   if (c.kind != V4L_NET_MLP) {
     L.dc3 = take((int64_t)n * 16 * 64);
@@ -1066,6 +1113,49 @@ int v4l_net::forward_t(const float* state, const T* image, const int* rowidx, in
     // the layers); otherwise one launch per TransformerEncoderLayer. 2 or 4 samples per block, saving what backward_t reads.
     const bool stack_ok = getenv("V4L_NO_LAYER_STACK") == nullptr;  // (read per call: tests switch it)
     const bool stacked = fused_layers && fused_head && c.n_layers == 2 && stack_ok;
+    if (stacked && wps_layers()) {
+      // wave-per-sample launch (csrc/wps.h): both layers + the pooled heads, 4 samples per block, weights resident in LDS
+      static bool wps_attr = false;
+      if (!wps_attr) {
+        V4L_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&wps_layer_fwd_kernel<T, true, 2>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)WpsFwdLds<T>::bytes));
+        wps_attr = true;
+      }
+      const T* base = (const T*)packed;
+      InfLayerStack stk;
+      memset(&stk, 0, sizeof(stk));
+      stk.nl = 2;
+      for (int k = 0; k < 2; ++k) {
+        const TLayer& t = layers[k];
+        const LayerWs& w = L.lw[k];
+        InfLayer& d = stk.l[k].n[0];
+        d.win = base + t.inproj.pkp; d.wo = base + t.outproj.pkp; d.w1 = base + t.ff1.pkp; d.w2 = base + t.ff2.pkp;
+        d.bin = p[t.inproj.b]; d.bo = p[t.outproj.b]; d.b1 = p[t.ff1.b]; d.b2 = p[t.ff2.b];
+        d.g1 = p[t.ln1.g]; d.be1 = p[t.ln1.b]; d.g2 = p[t.ln2.g]; d.be2 = p[t.ln2.b];
+        d.xin = k == 0 ? x0 : ws + L.x[k];
+        // production: the forward saves nothing but the layers' input rows (the backward recomputes, csrc/wps.h);
+        // V4L_LAYER_TAPS=1 (tests): every intermediate goes out row-major, as the block-cooperative kernels save them
+        const bool taps = getenv("V4L_LAYER_TAPS") != nullptr;  // (read per call: tests switch it)
+        d.xout = (k + 1 < 2 || taps) ? ws + L.x[k + 1] : nullptr;
+        if (taps) {
+          d.s_qkv = ws + w.qkv; d.s_P = ws + w.P; d.s_ctx = ws + w.ctx; d.s_xh1 = ws + w.xh1; d.s_rs1 = ws + w.rs1;
+          d.s_x1 = ws + w.x1; d.s_f = ws + w.f; d.s_xh2 = ws + w.xh2; d.s_rs2 = ws + w.rs2;
+          d.s_xin = sizeof(T) == 2 ? ws + w.xin : nullptr;
+        }
+      }
+      InfHeadPair hd;
+      memset(&hd, 0, sizeof(hd));
+      InfHead& h = hd.n[0];
+      h.w0 = base + head[0].pk; h.w1 = base + head[1].pk; h.w2 = base + head[2].pk;
+      h.b0 = p[head[0].b]; h.b1 = p[head[1].b]; h.b2 = p[head[2].b];
+      h.out = ws + L.out; h.nout = c.out_dim;
+      h.s_pooled = ws + L.pooled; h.s_h0 = ws + L.hh[0]; h.s_h1 = ws + L.hh[1];
+      g_op = "layer";
+      V4L_KLAUNCH("wps_layer_stack_head", 2.0 * n * (2 * 872576.0 + 99840.0), s, (wps_layer_fwd_kernel<T, true, 2>),
+                  dim3(cdiv(n, WPS_WPB)), dim3(256), (WpsFwdLds<T>::bytes), s, stk, hd, n);
+      V4L_LAUNCH_CHECK();
+      return 0;
+    }
     for (int l = 0; l < c.n_layers && fused_layers; l += stacked ? 2 : 1) {
       static bool attr_done = false;
       static int spw = 2;  // samples per block: 2 (48 MFMA rows, 2 blocks/CU: measured 20 % faster) or 4 (80 rows, 1 block/CU)
@@ -1282,7 +1372,90 @@ int v4l_net::backward_t(const float* state, const T* image, const int* rowidx, i
   // Every data-grad of a layer has its intermediates in LDS; the four weight-grads are deferred to the grouped launch.
   const bool bwd_stack_ok = getenv("V4L_NO_LAYER_STACK") == nullptr;
   const bool stacked = fused_bwd && fused_head && fused_tail && c.n_layers == 2 && bwd_stack_ok;
-  for (int l = c.n_layers - 1; l >= 0 && fused_bwd; l -= stacked ? 2 : 1) {
+  const bool wps = stacked && wps_layers();
+  if (wps) {
+    // wave-per-sample launch (csrc/wps.h): heads -> per layer {recompute, backward} -> encoder-side data-grads; the four
+    // weight-grads of each layer come from the fragment-order operand blocks it leaves, in one launch of their own
+    static bool wps_attr = false;
+    if (!wps_attr) {
+      V4L_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&wps_layer_bwd_kernel<T, 2>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)WpsBwdLds<T>::bytes));
+      wps_attr = true;
+    }
+    const bool taps = getenv("V4L_LAYER_TAPS") != nullptr;  // (read per call: tests switch it)
+    const int nblk = cdiv(n, WPS_WPB);
+    const T* base = (const T*)packed;
+    WpsBwdStack d;
+    memset(&d, 0, sizeof(d));
+    for (int k = 0; k < 2; ++k) {  // d.l[0] = the upper layer
+      const int li = 1 - k;
+      const TLayer& t = layers[li];
+      const LayerBw& b = L.lb[li];
+      float* part = cx.slab + cx.slab_used;  // gp2 | bp2 | gp1 | bp1, [nblk][64] each
+      cx.slab_used += 4 * (int64_t)nblk * TD;
+      V4L_REQUIRE(cx.slab_used <= slab_cap, "internal: weight-grad slab arena overflow");
+      WpsBwdLayer& e = d.l[k];
+      e.w = base + t.inproj.pkp; e.wt = base + t.inproj.pkpt;
+      e.bin = p[t.inproj.b]; e.bo = p[t.outproj.b]; e.b1 = p[t.ff1.b]; e.b2 = p[t.ff2.b];
+      e.g1 = p[t.ln1.g]; e.be1 = p[t.ln1.b]; e.g2 = p[t.ln2.g]; e.be2 = p[t.ln2.b];
+      e.xin = ws + L.x[li];
+      e.wg = ws + L.wps_wg[li]; e.tk = ws + L.wps_tk[li];
+      e.gp2 = part; e.bp2 = part + (int64_t)nblk * TD; e.gp1 = part + 2 * (int64_t)nblk * TD; e.bp1 = part + 3 * (int64_t)nblk * TD;
+      e.o_dx = (li == 0 || taps) ? ws + L.dxl[li] : nullptr;  // layer 0's: operand of the projector / up-conv weight-grads
+      if (taps) { e.t_dz2 = ws + b.dz2; e.t_df = ws + b.df; e.t_dz1 = ws + b.dz1; e.t_dqkv = ws + b.dqkv; }
+      const int lnp[4] = {t.ln2.g, t.ln2.b, t.ln1.g, t.ln1.b};
+      for (int q = 0; q < 4; ++q) {
+        RedDesc r;
+        memset(&r, 0, sizeof(r));
+        r.slab = part + (int64_t)q * nblk * TD;
+        r.dW = grads + params[lnp[q]].goff;
+        r.nsplit = nblk; r.N = 1; r.K = TD; r.Npad = 1; r.Kpad = TD; r.Ktorch = TD;
+        red.push_back(r);
+      }
+    }
+    BwdHead bh;
+    memset(&bh, 0, sizeof(bh));
+    bh.w2t = base + head[2].pkt; bh.w1t = base + head[1].pkt; bh.w0t = base + head[0].pkt;
+    bh.dout = ws + L.dout; bh.s_h1 = hacts[1].p; bh.s_h0 = hacts[0].p; bh.o_dh1 = dhhp[1]; bh.o_dh0 = dhhp[0];
+    BwdTail bt;
+    memset(&bt, 0, sizeof(bt));
+    bt.wpt = base + proj.pkt; bt.wf2t = base + enc[1].pkt; bt.wupt = base + upconv.pkt;
+    bt.x0 = ws + L.x[0]; bt.s_e1 = eacts[1].p; bt.s_e0 = eacts[0].p; bt.s_c3 = ws + L.c3;
+    bt.o_dhc = ws + L.dhc; bt.o_de0 = dehp[0]; bt.o_dc3 = ws + L.dc3;
+    WpsTailExtra tx;
+    tx.wupt_f = base + upconv.pkpt;
+    g_op = "layer";
+    const double fl = 2 * 4.0 * n * 872576.0 + 2.0 * n * 2 * (16 * 256 + 256 * 256 + 256 * 128) + 2.0 * n * (64 * 256 + 256 * 256 + 16 * 64 * 64);
+    V4L_KLAUNCH("wps_layer_bwd_stack", fl, s, (wps_layer_bwd_kernel<T, 2>), dim3(nblk), dim3(256), (WpsBwdLds<T>::bytes), s, d, bh, bt, tx, n);
+    V4L_LAUNCH_CHECK();
+    // the layers' weight-grads: one partial slab set per run of WPS_SPLIT samples
+    WpsWg wa;
+    memset(&wa, 0, sizeof(wa));
+    wa.n = n; wa.nsplit = cdiv(n, WPS_SPLIT); wa.nlayers = 2;
+    for (int li = 0; li < 2; ++li) {
+      const TLayer& t = layers[li];
+      const Lin* ls[4] = {&t.inproj, &t.outproj, &t.ff1, &t.ff2};
+      wa.l[li].wg = ws + L.wps_wg[li]; wa.l[li].tk = ws + L.wps_tk[li];
+      for (int m = 0; m < 4; ++m) {
+        const Lin& Lm = *ls[m];
+        const int64_t sf = ((int64_t)wa.nsplit * Lm.N * Lm.K + 63) / 64 * 64, bf = ((int64_t)wa.nsplit * Lm.N + 63) / 64 * 64;
+        float* sl = cx.slab + cx.slab_used;
+        cx.slab_used += sf + bf;
+        V4L_REQUIRE(cx.slab_used <= slab_cap, "internal: weight-grad slab arena overflow");
+        wa.l[li].slab[m] = sl; wa.l[li].bslab[m] = sl + sf;
+        RedDesc o;
+        memset(&o, 0, sizeof(o));
+        o.dW = grads + params[Lm.w].goff;
+        o.db = grads + params[Lm.b].goff;
+        o.N = Lm.N; o.K = Lm.K; o.Ktorch = Lm.K;
+        o.slab = sl; o.bslab = sl + sf; o.nsplit = wa.nsplit; o.Npad = Lm.N; o.Kpad = Lm.K;
+        red.push_back(o);
+      }
+    }
+    cx.wps_args = wa;
+    cx.wps_pending = true;
+  }
+  for (int l = c.n_layers - 1; l >= 0 && fused_bwd && !wps; l -= stacked ? 2 : 1) {
     static bool attr_done = false;
     static int spw = 4;  // samples per block: 4 (80 MFMA rows, 1 block per CU) or 2 (48 rows, 2 blocks per CU): measured equal
     if (!attr_done) {
