@@ -225,7 +225,9 @@ def test_wave_per_sample_layers_match_block_cooperative_kernels(n, mode, device)
         else:
             moved = (d > 1e-4).double().mean().item()
             # layer 0's in_proj sees identical operands on both sides: fp32 noise only. Downstream, rounding ties move elements.
-            assert worst[name] <= (1e-5 if name == "qkv0" else 3e-2) and moved <= (0.0 if name == "qkv0" else 0.05), (name, worst[name], moved)
+            # (a head output is a 256-term sum of such elements: most of the few outputs move a little)
+            lim = 0.0 if name == "qkv0" else (0.5 if name == "out" else 0.05)
+            assert worst[name] <= (1e-5 if name == "qkv0" else 3e-2) and moved <= lim, (name, worst[name], moved)
     gd = util.rel_err(ga, gb)
     util.record("wps_layers/%s/n%d/max_tap_rel_diff_vs_block_kernels" % (mode, n), max(worst.values()))
     util.record("wps_layers/%s/n%d/grad_rel_diff_vs_block_kernels" % (mode, n), gd)

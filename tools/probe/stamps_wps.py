@@ -1,6 +1,6 @@
 import os, sys, ctypes as C
 ROOT=os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-os.environ["V4L_LIB"] = os.path.join(ROOT, "tools/probe/libv4l_timing.so")
+os.environ["V4L_LIB"] = os.path.join(ROOT, "tools/probe", os.environ.get("TIMING_LIB", "libv4l_timing.so"))
 sys.path.insert(0,ROOT); sys.path.insert(0,os.path.join(ROOT,"tests"))
 import numpy as np, torch, util
 os.environ["V4L_COMPUTE"]="bf16"
@@ -13,10 +13,18 @@ hip=vf.hip
 obs=torch.randn(n, 93+16384, device=dev)
 st_,im,_=hip.stage(obs)
 L=_lib.lib(); L.v4l_debug_stamps.argtypes=[C.c_void_p]; L.v4l_debug_stamps.restype=C.c_int
-for it in range(3): hip.forward(st_, im, n, train=True)
+dout=torch.zeros(n,16,device=dev); dout[:,0]=1.0
+grads=torch.zeros(hip.total_params, device=dev)
+for it in range(3):
+    hip.forward(st_, im, n, train=True)
+    hip.backward(st_, im, n, dout, grads)
 torch.cuda.synchronize()
 buf=(C.c_longlong*128)(); L.v4l_debug_stamps(buf)
-st=np.array(buf[:18],dtype=np.int64)
-names=["L0 stage","q,k","v","attn","outproj+ln1","ffn","ln2+saves","(gap)","L1 stage","q,k","v","attn","outproj+ln1","ffn","ln2+saves","(gap)","->heads","heads"]
-print("total cycles", st[17]-st[0])
-for i in range(1,18): print("%-14s %8d" % (names[i-1], st[i]-st[i-1]))
+st=np.array(buf[:64],dtype=np.int64)
+def show(title, idx, names):
+    print(title, "total cycles", st[idx[-1]]-st[idx[0]])
+    for a,b,nm in zip(idx[:-1], idx[1:], names): print("   %-26s %8d" % (nm, st[b]-st[a]))
+show("FWD", [0,7,1,2,3,4,5,6,8,15,9,10,11,12,13,14,16,17],
+     ["L0 stage+wait","q,k","v","attn","outproj+ln1","ffn","ln2(+xout)","barrier","L1 stage+wait","q,k","v","attn","outproj+ln1","ffn","ln2","(to heads)","heads"])
+show("BWD", [32,33,34,35,36,37,38,41,42,43,44,45,46,50,51],
+     ["heads","L1 stageW+rows","L1 recompute","barrier","L1 stageWt","L1 backward","LNred+barrier","L0 stageW+rows","L0 recompute","barrier","L0 stageWt","L0 backward","LNred+dx","tail"])

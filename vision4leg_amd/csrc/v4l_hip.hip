@@ -1117,10 +1117,13 @@ int v4l_net::forward_t(const float* state, const T* image, const int* rowidx, in
       // wave-per-sample launch (csrc/wps.h): both layers + the pooled heads, 4 samples per block, weights resident in LDS
       static bool wps_attr = false;
       if (!wps_attr) {
-        V4L_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&wps_layer_fwd_kernel<T, true, 2>),
+        V4L_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&wps_layer_fwd_kernel<T, true, 2, false>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)WpsFwdLds<T>::bytes));
+        V4L_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&wps_layer_fwd_kernel<T, true, 2, true>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)WpsFwdLds<T>::bytes));
         wps_attr = true;
       }
+      const bool taps = getenv("V4L_LAYER_TAPS") != nullptr;  // (read per call: tests switch it)
       const T* base = (const T*)packed;
       InfLayerStack stk;
       memset(&stk, 0, sizeof(stk));
@@ -1135,7 +1138,6 @@ int v4l_net::forward_t(const float* state, const T* image, const int* rowidx, in
         d.xin = k == 0 ? x0 : ws + L.x[k];
         // production: the forward saves nothing but the layers' input rows (the backward recomputes, csrc/wps.h);
         // V4L_LAYER_TAPS=1 (tests): every intermediate goes out row-major, as the block-cooperative kernels save them
-        const bool taps = getenv("V4L_LAYER_TAPS") != nullptr;  // (read per call: tests switch it)
         d.xout = (k + 1 < 2 || taps) ? ws + L.x[k + 1] : nullptr;
         if (taps) {
           d.s_qkv = ws + w.qkv; d.s_P = ws + w.P; d.s_ctx = ws + w.ctx; d.s_xh1 = ws + w.xh1; d.s_rs1 = ws + w.rs1;
@@ -1151,8 +1153,12 @@ int v4l_net::forward_t(const float* state, const T* image, const int* rowidx, in
       h.out = ws + L.out; h.nout = c.out_dim;
       h.s_pooled = ws + L.pooled; h.s_h0 = ws + L.hh[0]; h.s_h1 = ws + L.hh[1];
       g_op = "layer";
-      V4L_KLAUNCH("wps_layer_stack_head", 2.0 * n * (2 * 872576.0 + 99840.0), s, (wps_layer_fwd_kernel<T, true, 2>),
-                  dim3(cdiv(n, WPS_WPB)), dim3(256), (WpsFwdLds<T>::bytes), s, stk, hd, n);
+      if (taps)
+        V4L_KLAUNCH("wps_layer_stack_head", 2.0 * n * (2 * 872576.0 + 99840.0), s, (wps_layer_fwd_kernel<T, true, 2, true>),
+                    dim3(cdiv(n, WPS_WPB)), dim3(256), (WpsFwdLds<T>::bytes), s, stk, hd, n);
+      else
+        V4L_KLAUNCH("wps_layer_stack_head", 2.0 * n * (2 * 872576.0 + 99840.0), s, (wps_layer_fwd_kernel<T, true, 2, false>),
+                    dim3(cdiv(n, WPS_WPB)), dim3(256), (WpsFwdLds<T>::bytes), s, stk, hd, n);
       V4L_LAUNCH_CHECK();
       return 0;
     }
@@ -1378,7 +1384,9 @@ int v4l_net::backward_t(const float* state, const T* image, const int* rowidx, i
     // weight-grads of each layer come from the fragment-order operand blocks it leaves, in one launch of their own
     static bool wps_attr = false;
     if (!wps_attr) {
-      V4L_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&wps_layer_bwd_kernel<T, 2>),
+      V4L_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&wps_layer_bwd_kernel<T, 2, false>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)WpsBwdLds<T>::bytes));
+      V4L_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&wps_layer_bwd_kernel<T, 2, true>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)WpsBwdLds<T>::bytes));
       wps_attr = true;
     }
@@ -1426,7 +1434,10 @@ int v4l_net::backward_t(const float* state, const T* image, const int* rowidx, i
     tx.wupt_f = base + upconv.pkpt;
     g_op = "layer";
     const double fl = 2 * 4.0 * n * 872576.0 + 2.0 * n * 2 * (16 * 256 + 256 * 256 + 256 * 128) + 2.0 * n * (64 * 256 + 256 * 256 + 16 * 64 * 64);
-    V4L_KLAUNCH("wps_layer_bwd_stack", fl, s, (wps_layer_bwd_kernel<T, 2>), dim3(nblk), dim3(256), (WpsBwdLds<T>::bytes), s, d, bh, bt, tx, n);
+    if (taps)
+      V4L_KLAUNCH("wps_layer_bwd_stack", fl, s, (wps_layer_bwd_kernel<T, 2, true>), dim3(nblk), dim3(256), (WpsBwdLds<T>::bytes), s, d, bh, bt, tx, n);
+    else
+      V4L_KLAUNCH("wps_layer_bwd_stack", fl, s, (wps_layer_bwd_kernel<T, 2, false>), dim3(nblk), dim3(256), (WpsBwdLds<T>::bytes), s, d, bh, bt, tx, n);
     V4L_LAUNCH_CHECK();
     // the layers' weight-grads: one partial slab set per run of WPS_SPLIT samples
     WpsWg wa;

@@ -122,11 +122,17 @@ __device__ __forceinline__ void wps_gemm_f(f32x4 (&acc)[2], const T* W, int tile
   }
 }
 __device__ __forceinline__ float xsum(float v) {  // over the four lane groups that share a token (T layout row)
+#ifdef WPS_X2
+  return v * 4.f;
+#endif
   v += __shfl_xor(v, 16);
   v += __shfl_xor(v, 32);
   return v;
 }
 __device__ __forceinline__ float xmax(float v) {
+#ifdef WPS_X2
+  return v;
+#endif
   v = fmaxf(v, __shfl_xor(v, 16));
   v = fmaxf(v, __shfl_xor(v, 32));
   return v;
@@ -158,16 +164,21 @@ __device__ __forceinline__ typename Frag<T>::type wps_tr(const typename Frag<T>:
 }
 // One weight-grad operand pair: fragment f0 (tokens 0..15 x 32 features of k-step `pair`) -> F layout -> one whole-wave store;
 // f1 (tokens 16..31: only token 16, lane fr = 0, is real) -> the 17th-token block as it is.
+struct WpsOut { void *wg, *tk; bool live; };
+template <typename T> __device__ __forceinline__ WpsOut wps_out(T* wg, T* tk, bool live) { return WpsOut{wg, tk, live}; }
 template <typename T>
-__device__ __forceinline__ void wps_store_opnd(T* wg, T* tk, int pair, const typename Frag<T>::type& f0, const typename Frag<T>::type& f1,
-                                               const typename Frag<T>::type& E0, const typename Frag<T>::type& E1, int lane, bool live) {
+__device__ __forceinline__ void wps_store_opnd(const WpsOut& o, int pair, const typename Frag<T>::type& f0, const typename Frag<T>::type& f1,
+                                               const typename Frag<T>::type& E0, const typename Frag<T>::type& E1, int lane) {
   typedef typename Frag<T>::type frag_t;
+#ifdef WPS_X1
+  return;
+#endif
   f32x4 d0 = zero4(), d1 = zero4();
   mma_k32(d0, f0, E0);  // d0[r] = f0[token 4g + r][feature fr of tile 2 pair]
   mma_k32(d1, f0, E1);
-  if (live) {
-    *reinterpret_cast<frag_t*>(wg + ((int64_t)pair * 64 + lane) * 8) = wps_frag<T>(f4(d0), f4(d1));
-    if ((lane & 15) == 0) *reinterpret_cast<frag_t*>(tk + ((int64_t)pair * 4 + (lane >> 4)) * 8) = f1;
+  if (o.live) {
+    *reinterpret_cast<frag_t*>(reinterpret_cast<T*>(o.wg) + ((int64_t)pair * 64 + lane) * 8) = wps_frag<T>(f4(d0), f4(d1));
+    if ((lane & 15) == 0) *reinterpret_cast<frag_t*>(reinterpret_cast<T*>(o.tk) + ((int64_t)pair * 4 + (lane >> 4)) * 8) = f1;
   }
 }
 
@@ -209,9 +220,9 @@ template <typename T> struct WpsKeep {
 //     and the test taps. Production passes only xout (the next layer's input).
 //   * wg / tk non-null: the x-side weight-grad operands (layer input, ctx, x1, f) go out in fragment order (wps_store_opnd).
 //   * KEEP: fill `kp` for wps_layer_bwd.
-template <typename T, bool LDSW, bool KEEP>
+template <typename T, bool LDSW, bool KEEP, bool TAPS>
 __device__ __forceinline__ void wps_layer_fwd(const InfLayer& w, const T* W, const float* prm, const float4 (&xr)[2][4], int lane,
-                                              const bool (&ok)[2], int64_t row0, int64_t smp, float4 (&xo)[2][4], T* wg, T* tk,
+                                              const bool (&ok)[2], int64_t row0, int64_t smp, float4 (&xo)[2][4], const WpsOut* wo,
                                               const typename Frag<T>::type& E0, const typename Frag<T>::type& E1, WpsKeep<T>* kp, int sb = 0) {
   typedef typename Frag<T>::type frag_t;
   const int fr = lane & 15, g = lane >> 4, qr = g * 4;
@@ -223,7 +234,7 @@ __device__ __forceinline__ void wps_layer_fwd(const InfLayer& w, const T* W, con
   for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) xa[mt][ks] = wps_frag<T>(xr[mt][2 * ks], xr[mt][2 * ks + 1]);
-  if (w.s_xin != nullptr) {
+  if (TAPS && w.s_xin != nullptr) {
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt)
       if (ok[mt])
@@ -231,9 +242,9 @@ __device__ __forceinline__ void wps_layer_fwd(const InfLayer& w, const T* W, con
         for (int nt = 0; nt < 4; ++nt)
           st4(reinterpret_cast<T*>(w.s_xin) + (row0 + mt * 16 + fr) * TD + nt * 16 + qr, xr[mt][nt].x, xr[mt][nt].y, xr[mt][nt].z, xr[mt][nt].w);
   }
-  if (wg != nullptr) {
+  if constexpr (KEEP) {  // (the recompute inside the backward kernel is the pass that hands the x-side operands over)
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) wps_store_opnd<T>(wg, tk, WPS_T_XIN / 2 + ks, xa[0][ks], xa[1][ks], E0, E1, lane, live);
+    for (int ks = 0; ks < 2; ++ks) wps_store_opnd<T>(*wo, WPS_T_XIN / 2 + ks, xa[0][ks], xa[1][ks], E0, E1, lane);
   }
   // ---- in_proj: q | k in T layout (operands of S = Q K^T over the feature index), v in F layout (operand of P V over keys)
   frag_t qa[2][2], ka[2][2], vt[4];
@@ -251,7 +262,7 @@ __device__ __forceinline__ void wps_layer_fwd(const InfLayer& w, const T* W, con
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt) {
           two[mt][h] = f4add(acc[mt], bb);
-          if (w.s_qkv != nullptr && ok[mt])
+          if (TAPS && w.s_qkv != nullptr && ok[mt])
             st4(w.s_qkv + (row0 + mt * 16 + fr) * 192 + tile * 16 + qr, two[mt][h].x, two[mt][h].y, two[mt][h].z, two[mt][h].w);
         }
       }
@@ -262,7 +273,6 @@ __device__ __forceinline__ void wps_layer_fwd(const InfLayer& w, const T* W, con
       }
     }
   }
-  WPS_STAMP(sb + 1);
 #pragma unroll
   for (int dt = 0; dt < 4; ++dt) {
     f32x4 acc[2] = {zero4(), zero4()};
@@ -271,7 +281,7 @@ __device__ __forceinline__ void wps_layer_fwd(const InfLayer& w, const T* W, con
     const float4 v0 = {acc[0][0] + bv, acc[0][1] + bv, acc[0][2] + bv, acc[0][3] + bv};   // keys 4g + r
     const float4 v1 = {acc[1][0] + bv, acc[1][1] + bv, acc[1][2] + bv, acc[1][3] + bv};   // keys 16 + 4g + r (only key 16 is real)
     vt[dt] = wps_frag<T>(v0, v1);
-    if (w.s_qkv != nullptr) {  // v rows for the block-cooperative backward (fp32 [token][192]): one feature of 8 tokens per lane
+    if (TAPS && w.s_qkv != nullptr) {  // v rows for the block-cooperative backward (fp32 [token][192]): one feature of 8 tokens per lane
       const float va[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
@@ -303,7 +313,6 @@ __device__ __forceinline__ void wps_layer_fwd(const InfLayer& w, const T* W, con
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) kp->va[mt][ks] = wps_frag<T>(vv[mt][2 * ks], vv[mt][2 * ks + 1]);
   }
-  WPS_STAMP(sb + 2);
   // ---- attention: S^T tiles (lane = query, registers = keys), softmax in registers, P V
   float4 c[2][4];
 #pragma unroll
@@ -339,7 +348,7 @@ __device__ __forceinline__ void wps_layer_fwd(const InfLayer& w, const T* W, con
         pv[kt][r] *= inv;
         if constexpr (KEEP) kp->p[qt][kt][r] = pv[kt][r];
         const int key = kt * 16 + qr + r;
-        if (w.s_P != nullptr && ok[qt] && key < NTOK) w.s_P[smp * (NTOK * NTOK) + (qt * 16 + fr) * NTOK + key] = pv[kt][r];
+        if (TAPS && w.s_P != nullptr && ok[qt] && key < NTOK) w.s_P[smp * (NTOK * NTOK) + (qt * 16 + fr) * NTOK + key] = pv[kt][r];
       }
     const frag_t pa = wps_frag<T>(float4{pv[0][0], pv[0][1], pv[0][2], pv[0][3]}, float4{pv[1][0], pv[1][1], pv[1][2], pv[1][3]});
 #pragma unroll
@@ -347,11 +356,10 @@ __device__ __forceinline__ void wps_layer_fwd(const InfLayer& w, const T* W, con
       f32x4 a = zero4();
       mma_k32(a, vt[dt], pa);  // a[r] = sum_key P[16 qt + fr][key] v[key][16 dt + 4g + r]
       c[qt][dt] = f4(a);
-      if (w.s_ctx != nullptr && ok[qt])
+      if (TAPS && w.s_ctx != nullptr && ok[qt])
         st4(reinterpret_cast<T*>(w.s_ctx) + (row0 + qt * 16 + fr) * TD + dt * 16 + qr, a[0], a[1], a[2], a[3]);
     }
   }
-  WPS_STAMP(sb + 3);
   // ---- out_proj + residual, norm1
   float4 z[2][4];
   {
@@ -360,9 +368,9 @@ __device__ __forceinline__ void wps_layer_fwd(const InfLayer& w, const T* W, con
     for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) ca[mt][ks] = wps_frag<T>(c[mt][2 * ks], c[mt][2 * ks + 1]);
-    if (wg != nullptr) {
+    if constexpr (KEEP) {
 #pragma unroll
-      for (int ks = 0; ks < 2; ++ks) wps_store_opnd<T>(wg, tk, WPS_T_CTX / 2 + ks, ca[0][ks], ca[1][ks], E0, E1, lane, live);
+      for (int ks = 0; ks < 2; ++ks) wps_store_opnd<T>(*wo, WPS_T_CTX / 2 + ks, ca[0][ks], ca[1][ks], E0, E1, lane);
     }
 #pragma unroll
     for (int nt = 0; nt < 4; ++nt) {
@@ -389,18 +397,17 @@ __device__ __forceinline__ void wps_layer_fwd(const InfLayer& w, const T* W, con
       x1[mt][nt] = float4{fmaf(xh.x, gg.x, be.x), fmaf(xh.y, gg.y, be.y), fmaf(xh.z, gg.z, be.z), fmaf(xh.w, gg.w, be.w)};
       if (ok[mt]) {
         const int64_t o = (row0 + mt * 16 + fr) * TD + nt * 16 + qr;
-        if (w.s_xh1 != nullptr) *reinterpret_cast<float4*>(w.s_xh1 + o) = xh;
-        if (w.s_x1 != nullptr) st4(reinterpret_cast<T*>(w.s_x1) + o, x1[mt][nt].x, x1[mt][nt].y, x1[mt][nt].z, x1[mt][nt].w);
+        if (TAPS && w.s_xh1 != nullptr) *reinterpret_cast<float4*>(w.s_xh1 + o) = xh;
+        if (TAPS && w.s_x1 != nullptr) st4(reinterpret_cast<T*>(w.s_x1) + o, x1[mt][nt].x, x1[mt][nt].y, x1[mt][nt].z, x1[mt][nt].w);
       }
     }
   }
   if constexpr (KEEP) { kp->rs1[0] = rs1[0]; kp->rs1[1] = rs1[1]; }
-  if (w.s_rs1 != nullptr && g == 0) {
+  if (TAPS && w.s_rs1 != nullptr && g == 0) {
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt)
       if (ok[mt]) w.s_rs1[row0 + mt * 16 + fr] = rs1[mt];
   }
-  WPS_STAMP(sb + 4);
   // ---- FFN, 32 hidden features at a time: h = relu(W1 x1 + b1) is the B fragment of the linear2 step over those features
   {
     frag_t x1a[2][2];
@@ -408,9 +415,9 @@ __device__ __forceinline__ void wps_layer_fwd(const InfLayer& w, const T* W, con
     for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) x1a[mt][ks] = wps_frag<T>(x1[mt][2 * ks], x1[mt][2 * ks + 1]);
-    if (wg != nullptr) {
+    if constexpr (KEEP) {
 #pragma unroll
-      for (int ks = 0; ks < 2; ++ks) wps_store_opnd<T>(wg, tk, WPS_T_X1 / 2 + ks, x1a[0][ks], x1a[1][ks], E0, E1, lane, live);
+      for (int ks = 0; ks < 2; ++ks) wps_store_opnd<T>(*wo, WPS_T_X1 / 2 + ks, x1a[0][ks], x1a[1][ks], E0, E1, lane);
     }
     f32x4 z2[2][4];
     unsigned long long fm[2] = {0ull, 0ull};
@@ -438,14 +445,14 @@ __device__ __forceinline__ void wps_layer_fwd(const InfLayer& w, const T* W, con
                                           (hh[mt][h].z > 0.f ? 4ull : 0ull) | (hh[mt][h].w > 0.f ? 8ull : 0ull);
             fm[mt] |= b4 << (tile * 4);
           }
-          if (w.s_f != nullptr && ok[mt])
+          if (TAPS && w.s_f != nullptr && ok[mt])
             st4(reinterpret_cast<T*>(w.s_f) + (row0 + mt * 16 + fr) * 256 + tile * 16 + qr, hh[mt][h].x, hh[mt][h].y, hh[mt][h].z, hh[mt][h].w);
         }
       }
       frag_t fa[2];
 #pragma unroll
       for (int mt = 0; mt < 2; ++mt) fa[mt] = wps_frag<T>(hh[mt][0], hh[mt][1]);
-      if (wg != nullptr) wps_store_opnd<T>(wg, tk, WPS_T_F / 2 + ch, fa[0], fa[1], E0, E1, lane, live);
+      if constexpr (KEEP) wps_store_opnd<T>(*wo, WPS_T_F / 2 + ch, fa[0], fa[1], E0, E1, lane);
 #pragma unroll
       for (int nt = 0; nt < 4; ++nt) {
         const frag_t fw = wps_w<T, LDSW>(W + WPS_OFF_W2, nt * 8 + ch, lane);
@@ -463,7 +470,6 @@ __device__ __forceinline__ void wps_layer_fwd(const InfLayer& w, const T* W, con
                            x1[mt][nt].w + z2[mt][nt][3] + bb.w};
     }
   }
-  WPS_STAMP(sb + 5);
   float rs2[2];
   wps_ln(z, rs2);
   if constexpr (KEEP) { kp->rs2[0] = rs2[0]; kp->rs2[1] = rs2[1]; }
@@ -481,12 +487,12 @@ __device__ __forceinline__ void wps_layer_fwd(const InfLayer& w, const T* W, con
                             : float4{0.f, 0.f, 0.f, 0.f};
       if (ok[mt]) {
         const int64_t o = (row0 + mt * 16 + fr) * TD + nt * 16 + qr;
-        if (w.s_xh2 != nullptr) *reinterpret_cast<float4*>(w.s_xh2 + o) = xh;
+        if (TAPS && w.s_xh2 != nullptr) *reinterpret_cast<float4*>(w.s_xh2 + o) = xh;
         if (w.xout != nullptr) *reinterpret_cast<float4*>(w.xout + o) = xo[mt][nt];
       }
     }
   }
-  if (w.s_rs2 != nullptr && g == 0) {
+  if (TAPS && w.s_rs2 != nullptr && g == 0) {
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt)
       if (ok[mt]) w.s_rs2[row0 + mt * 16 + fr] = rs2[mt];
@@ -538,7 +544,7 @@ __device__ __forceinline__ void wps_load_rows(const float* __restrict__ xg, int 
 // Training forward of the transformer stack (+ pooled heads): NL layers for WPS_WPB samples per block, one wave each.
 // stk.l[l].n[0].win points at the layer's fragment-order weight block (PK_FRAGP packs, adjacent); the head packs are the
 // row-major ones of the block-cooperative kernel (the heads run cooperatively: 4 samples = one MFMA row tile).
-template <typename T, bool HEAD, int NL>
+template <typename T, bool HEAD, int NL, bool TAPS>
 __global__ __launch_bounds__(256) void wps_layer_fwd_kernel(InfLayerStack stk, InfHeadPair hd, int n) {
   typedef WpsFwdLds<T> LY;
   typedef typename Frag<T>::type frag_t;
@@ -575,8 +581,8 @@ __global__ __launch_bounds__(256) void wps_layer_fwd_kernel(InfLayerStack stk, I
     __syncthreads();
     WPS_STAMP(8 * l + 7);
     float4 xo[2][4];
-    wps_layer_fwd<T, LDSW, false>(w, LDSW ? wl : reinterpret_cast<const T*>(w.win), prm, xr, lane, ok, row0, srow, xo, (T*)nullptr,
-                                  (T*)nullptr, E0, E1, (WpsKeep<T>*)nullptr, 8 * l);
+    wps_layer_fwd<T, LDSW, false, TAPS>(w, LDSW ? wl : reinterpret_cast<const T*>(w.win), prm, xr, lane, ok, row0, srow, xo,
+                                        (const WpsOut*)nullptr, E0, E1, (WpsKeep<T>*)nullptr, 8 * l);
     WPS_STAMP(8 * l + 6);
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt)
@@ -673,9 +679,9 @@ struct WpsBwdStack { WpsBwdLayer l[2]; };  // l[0] = the upper layer
 // Backward of one layer of one sample by one wave. dy (T layout, fp32; rows >= 17 and dead samples exactly zero) is replaced by
 // the gradient w.r.t. the layer input. Wt: the transposed weight block. lnred: this wave's [4][64] LDS slots for the LayerNorm
 // parameter gradients.
-template <typename T, bool LDSW>
+template <typename T, bool LDSW, bool TAPS>
 __device__ __forceinline__ void wps_layer_bwd(const WpsBwdLayer& w, const T* Wt, const float* prm, const WpsKeep<T>& K, float4 (&dy)[2][4],
-                                              int lane, const bool (&ok)[2], int64_t row0, T* wg, T* tk, const typename Frag<T>::type& E0,
+                                              int lane, const bool (&ok)[2], int64_t row0, const WpsOut& wo, const typename Frag<T>::type& E0,
                                               const typename Frag<T>::type& E1, float* lnred) {
   typedef typename Frag<T>::type frag_t;
   const int fr = lane & 15, g = lane >> 4, qr = g * 4;
@@ -688,10 +694,10 @@ __device__ __forceinline__ void wps_layer_bwd(const WpsBwdLayer& w, const T* Wt,
       const float4 sg = {rowsum16(fmaf(a.x, xa_.x, b.x * xb_.x)), rowsum16(fmaf(a.y, xa_.y, b.y * xb_.y)),
                          rowsum16(fmaf(a.z, xa_.z, b.z * xb_.z)), rowsum16(fmaf(a.w, xa_.w, b.w * xb_.w))};
       const float4 sb = {rowsum16(a.x + b.x), rowsum16(a.y + b.y), rowsum16(a.z + b.z), rowsum16(a.w + b.w)};
-      if (fr == 0) {
-        *reinterpret_cast<float4*>(red_g + nt * 16 + qr) = sg;
-        *reinterpret_cast<float4*>(red_b + nt * 16 + qr) = sb;
-      }
+      // (after the row sums all 16 lanes of a group hold the same totals: every lane writes them — same address, same value —
+      // rather than lane fr = 0 alone under an exec-mask branch)
+      *reinterpret_cast<float4*>(red_g + nt * 16 + qr) = sg;
+      *reinterpret_cast<float4*>(red_b + nt * 16 + qr) = sb;
     }
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt) {
@@ -715,7 +721,7 @@ __device__ __forceinline__ void wps_layer_bwd(const WpsBwdLayer& w, const T* Wt,
     }
   };
   auto tap_rows = [&](void* dst, int ld, int col0, const float4 (&v)[2]) {  // test tap: 4 features of both row tiles, row-major T
-    if (dst == nullptr) return;
+    if (!TAPS || dst == nullptr) return;
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt)
       if (ok[mt]) st4(reinterpret_cast<T*>(dst) + (row0 + mt * 16 + fr) * ld + col0 + qr, v[mt].x, v[mt].y, v[mt].z, v[mt].w);
@@ -728,7 +734,7 @@ __device__ __forceinline__ void wps_layer_bwd(const WpsBwdLayer& w, const T* Wt,
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) dza[mt][ks] = wps_frag<T>(dy[mt][2 * ks], dy[mt][2 * ks + 1]);
 #pragma unroll
-  for (int ks = 0; ks < 2; ++ks) wps_store_opnd<T>(wg, tk, WPS_T_DZ2 / 2 + ks, dza[0][ks], dza[1][ks], E0, E1, lane, live);
+  for (int ks = 0; ks < 2; ++ks) wps_store_opnd<T>(wo, WPS_T_DZ2 / 2 + ks, dza[0][ks], dza[1][ks], E0, E1, lane);
 #pragma unroll
   for (int nt = 0; nt < 4; ++nt) { const float4 v[2] = {dy[0][nt], dy[1][nt]}; tap_rows(w.t_dz2, TD, nt * 16, v); }
   // ---- df = (dz2 W2) o [f > 0], 32 hidden features at a time, each chunk feeding dx1 += df W1
@@ -757,7 +763,7 @@ __device__ __forceinline__ void wps_layer_bwd(const WpsBwdLayer& w, const T* Wt,
     frag_t dfa[2];
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt) dfa[mt] = wps_frag<T>(dd[mt][0], dd[mt][1]);
-    wps_store_opnd<T>(wg, tk, WPS_T_DF / 2 + ch, dfa[0], dfa[1], E0, E1, lane, live);
+    wps_store_opnd<T>(wo, WPS_T_DF / 2 + ch, dfa[0], dfa[1], E0, E1, lane);
 #pragma unroll
     for (int nt = 0; nt < 4; ++nt) {
       const frag_t fw = wps_w<T, LDSW>(Wt + WPS_OFF_W1, nt * 8 + ch, lane);  // W1^T: rows = the 64 inputs, k = hidden features
@@ -778,7 +784,7 @@ __device__ __forceinline__ void wps_layer_bwd(const WpsBwdLayer& w, const T* Wt,
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) dz1a[mt][ks] = wps_frag<T>(d1[mt][2 * ks], d1[mt][2 * ks + 1]);
 #pragma unroll
-  for (int ks = 0; ks < 2; ++ks) wps_store_opnd<T>(wg, tk, WPS_T_DZ1 / 2 + ks, dz1a[0][ks], dz1a[1][ks], E0, E1, lane, live);
+  for (int ks = 0; ks < 2; ++ks) wps_store_opnd<T>(wo, WPS_T_DZ1 / 2 + ks, dz1a[0][ks], dz1a[1][ks], E0, E1, lane);
 #pragma unroll
   for (int nt = 0; nt < 4; ++nt) { const float4 v[2] = {d1[0][nt], d1[1][nt]}; tap_rows(w.t_dz1, TD, nt * 16, v); }
   // ---- dctx = dz1 Wo  (an operand of the attention products only: kept rounded to T)
@@ -845,7 +851,7 @@ __device__ __forceinline__ void wps_layer_bwd(const WpsBwdLayer& w, const T* Wt,
         dq[tt][dt] = float4{a[0] * 0.125f, a[1] * 0.125f, a[2] * 0.125f, a[3] * 0.125f};
         dk[tt][dt] = float4{b[0] * 0.125f, b[1] * 0.125f, b[2] * 0.125f, b[3] * 0.125f};
         dv[tt][dt] = f4(c);
-        if (w.t_dqkv != nullptr && ok[tt]) {  // test tap: the dq | dk | dv rows, row-major T
+        if (TAPS && w.t_dqkv != nullptr && ok[tt]) {  // test tap: the dq | dk | dv rows, row-major T
           T* o = reinterpret_cast<T*>(w.t_dqkv) + (row0 + tt * 16 + fr) * 192 + dt * 16 + qr;
           st4(o, dq[tt][dt].x, dq[tt][dt].y, dq[tt][dt].z, dq[tt][dt].w);
           st4(o + TD, dk[tt][dt].x, dk[tt][dt].y, dk[tt][dt].z, dk[tt][dt].w);
@@ -862,7 +868,7 @@ __device__ __forceinline__ void wps_layer_bwd(const WpsBwdLayer& w, const T* Wt,
       }
   }
 #pragma unroll
-  for (int ks = 0; ks < 6; ++ks) wps_store_opnd<T>(wg, tk, WPS_T_DQKV / 2 + ks, dqa[0][ks], dqa[1][ks], E0, E1, lane, live);
+  for (int ks = 0; ks < 6; ++ks) wps_store_opnd<T>(wo, WPS_T_DQKV / 2 + ks, dqa[0][ks], dqa[1][ks], E0, E1, lane);
   // ---- dx_in = dz1 + dqkv Win
 #pragma unroll
   for (int nt = 0; nt < 4; ++nt) {
@@ -877,7 +883,7 @@ __device__ __forceinline__ void wps_layer_bwd(const WpsBwdLayer& w, const T* Wt,
 // per layer {recompute the forward in registers, walk it backward} -> encoder-side data-grads (TAIL: up-conv per wave in
 // registers, the token-0 chain cooperatively).
 struct WpsTailExtra { const void* wupt_f; };  // up-conv's transposed weight as a k-permuted fragment pack
-template <typename T, int NL>
+template <typename T, int NL, bool TAPS>
 __global__ __launch_bounds__(256) void wps_layer_bwd_kernel(WpsBwdStack stk, BwdHead hd, BwdTail tl, WpsTailExtra tx, int n) {
   typedef WpsBwdLds<T> LY;
   typedef typename Frag<T>::type frag_t;
@@ -898,6 +904,7 @@ __global__ __launch_bounds__(256) void wps_layer_bwd_kernel(WpsBwdStack stk, Bwd
   const int nt4[4] = {wave * 4, wave * 4 + 1, wave * 4 + 2, wave * 4 + 3};
   const frag_t E0 = wps_sel<T>(0, lane), E1 = wps_sel<T>(1, lane);
   float4 dy[2][4];
+  WPS_STAMP(32);
   {
     // ---- heads (nets.py:1015-1034 reversed): dout -> (W2^T, mask h1) -> dh1 -> (W1^T, mask h0) -> dh0 -> (W0^T) -> dpool
     float* dt = reinterpret_cast<float*>(smem);                 // [16][LDX]: dout rows, zero padded to 64 columns
@@ -974,9 +981,9 @@ __global__ __launch_bounds__(256) void wps_layer_bwd_kernel(WpsBwdStack stk, Bwd
 #pragma unroll
   for (int l = 0; l < NL; ++l) {  // stk.l[0] = the upper layer
     const WpsBwdLayer& w = stk.l[l];
-    T* wg = reinterpret_cast<T*>(w.wg) + srow * WPS_WG_ELEMS;
-    T* tk = reinterpret_cast<T*>(w.tk) + srow * WPS_TK_ELEMS;
+    const WpsOut wo = wps_out<T>(reinterpret_cast<T*>(w.wg) + srow * WPS_WG_ELEMS, reinterpret_cast<T*>(w.tk) + srow * WPS_TK_ELEMS, live);
     __syncthreads();  // the scratch / the previous layer's transposed weights are dead
+    WPS_STAMP(33 + 8 * l);
     {
       const WpsPrm pp = WpsPrm{w.bin, w.bo, w.b1, w.b2, w.g1, w.be1, w.g2, w.be2};
       wps_stage<T, LDSW>(w.w, &pp, wl, prm, tid);
@@ -984,6 +991,7 @@ __global__ __launch_bounds__(256) void wps_layer_bwd_kernel(WpsBwdStack stk, Bwd
     wps_load_rows(w.xin + row0 * TD, lane, ok, xr);
     __builtin_amdgcn_s_waitcnt(0);
     __syncthreads();
+    WPS_STAMP(34 + 8 * l);
     WpsKeep<T> K;
     {
       InfLayer none;
@@ -993,13 +1001,17 @@ __global__ __launch_bounds__(256) void wps_layer_bwd_kernel(WpsBwdStack stk, Bwd
       none.s_qkv = none.s_P = none.s_xh1 = none.s_rs1 = none.s_xh2 = none.s_rs2 = nullptr;
       none.s_xin = none.s_ctx = none.s_x1 = none.s_f = nullptr;
       float4 xo[2][4];
-      wps_layer_fwd<T, LDSW, true>(none, LDSW ? wl : reinterpret_cast<const T*>(w.w), prm, xr, lane, ok, row0, srow, xo, wg, tk, E0, E1, &K);
+      wps_layer_fwd<T, LDSW, true, false>(none, LDSW ? wl : reinterpret_cast<const T*>(w.w), prm, xr, lane, ok, row0, srow, xo, &wo, E0, E1, &K);
     }
+    WPS_STAMP(35 + 8 * l);
     __syncthreads();  // every wave is done with the forward weights
+    WPS_STAMP(36 + 8 * l);
     wps_stage<T, LDSW>(w.wt, (const WpsPrm*)nullptr, wl, prm, tid);
     __builtin_amdgcn_s_waitcnt(0);
     __syncthreads();
-    wps_layer_bwd<T, LDSW>(w, LDSW ? wl : reinterpret_cast<const T*>(w.wt), prm, K, dy, lane, ok, row0, wg, tk, E0, E1, red + wave * 4 * TD);
+    WPS_STAMP(37 + 8 * l);
+    wps_layer_bwd<T, LDSW, TAPS>(w, LDSW ? wl : reinterpret_cast<const T*>(w.wt), prm, K, dy, lane, ok, row0, wo, E0, E1, red + wave * 4 * TD);
+    WPS_STAMP(38 + 8 * l);
     __syncthreads();
     {  // the block's LayerNorm parameter-gradient partials, waves summed in a fixed order
       const int k = tid >> 6, cidx = tid & 63;
@@ -1018,6 +1030,7 @@ __global__ __launch_bounds__(256) void wps_layer_bwd_kernel(WpsBwdStack stk, Bwd
     }
   }
   // ---- TAIL (base.py:602-622 reversed). dy = grad w.r.t. the layer-0 input tokens; xr = those tokens (the ReLU mask of token 0)
+  WPS_STAMP(50);
   {
     // tokens 1..16: dc3 = (dx_in Wup) o [c3 > 0], per wave in registers (up-conv's transposed weight: 8 KB, straight from L2)
     frag_t da[2][2];
@@ -1086,6 +1099,7 @@ __global__ __launch_bounds__(256) void wps_layer_bwd_kernel(WpsBwdStack stk, Bwd
     block_gemm<T, 1, 4, 8>(acc, dh, LY::LDF, (const T*)tl.wf2t, 256, nt4, lane, ring_f2);
     masked(tm_e0, (T*)nullptr, tl.o_de0);
   }
+  WPS_STAMP(51);
 }
 
 // ------------------------------------------------------------------------------------------ weight-grads
@@ -1152,22 +1166,41 @@ __global__ __launch_bounds__(256) void wps_wgrad_kernel(WpsWg a) {
       for (int j = 0; j < 4; ++j) mma_k32(accb[j], ones, fy[j]);     // every row: sum over the step's tokens of dY[.][n = 16 j + fr]
     }
   };
-  for (int s = sbeg; s < send; s += 2) {
+  // (software-pipelined: the operand pairs of the NEXT two samples are requested before this step's MFMAs — a wave has the
+  // SIMD to itself, so nothing else hides the L2 / HBM round trip)
+  auto fetch = [&](int s, frag_t (&u)[8]) {  // [x pair 0: A, B | x pair 1: A, B | y pair 0: A, B | y pair 1: A, B]
+    const int sa = s < send ? s : sbeg, sb_ = s + 1 < send ? s + 1 : sa;
+    const T* pa = wg + (int64_t)sa * WPS_WG_ELEMS + lane * 8;
+    const T* pb = wg + (int64_t)sb_ * WPS_WG_ELEMS + lane * 8;
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      u[2 * q] = *reinterpret_cast<const frag_t*>(pa + (int64_t)(ro.kt0 / 2 + q) * 512);
+      u[2 * q + 1] = *reinterpret_cast<const frag_t*>(pb + (int64_t)(ro.kt0 / 2 + q) * 512);
+      u[4 + 2 * q] = *reinterpret_cast<const frag_t*>(pa + (int64_t)(ro.nt0 / 2 + q) * 512);
+      u[5 + 2 * q] = *reinterpret_cast<const frag_t*>(pb + (int64_t)(ro.nt0 / 2 + q) * 512);
+    }
+  };
+  auto consume = [&](int s, const frag_t (&u)[8]) {
     const bool two = s + 1 < send;
-    const T* pa = wg + (int64_t)s * WPS_WG_ELEMS + lane * 8;
-    const T* pb = wg + (int64_t)(two ? s + 1 : s) * WPS_WG_ELEMS + lane * 8;
     frag_t fx[4], fy[4];
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
-      const frag_t xa_ = *reinterpret_cast<const frag_t*>(pa + (int64_t)(ro.kt0 / 2 + q) * 512);
-      frag_t xb_ = *reinterpret_cast<const frag_t*>(pb + (int64_t)(ro.kt0 / 2 + q) * 512);
-      const frag_t ya_ = *reinterpret_cast<const frag_t*>(pa + (int64_t)(ro.nt0 / 2 + q) * 512);
-      frag_t yb_ = *reinterpret_cast<const frag_t*>(pb + (int64_t)(ro.nt0 / 2 + q) * 512);
-      if (!two) { xb_ = zf; yb_ = zf; }
-      halves(xa_, xb_, fx[2 * q], fx[2 * q + 1]);
-      halves(ya_, yb_, fy[2 * q], fy[2 * q + 1]);
+      halves(u[2 * q], two ? u[2 * q + 1] : zf, fx[2 * q], fx[2 * q + 1]);
+      halves(u[4 + 2 * q], two ? u[5 + 2 * q] : zf, fy[2 * q], fy[2 * q + 1]);
     }
     step(fx, fy);
+  };
+  {
+    frag_t ua[8], ub[8];
+    fetch(sbeg, ua);
+    for (int s = sbeg; s < send; s += 4) {
+      fetch(s + 2, ub);
+      consume(s, ua);
+      if (s + 2 < send) {
+        fetch(s + 4, ua);
+        consume(s + 2, ub);
+      }
+    }
   }
   {  // the 17th tokens of the run's samples: slot (g, j) <-> sample sbeg + 8 g + j, gathered from the k-permuted side blocks
     frag_t fx[4], fy[4];
