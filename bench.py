@@ -446,6 +446,12 @@ def algo_bytes(kernel, wl, compute):
         "fused_conv3_wgrad": n * (16 * 64 + 36 * 64) * 4 + blocks * 64 * 576 * 4,
         # both operands of the 4 linears x 2 layers (T) in; 55 slabs of the 4 weight shapes x 2 layers out
         "gemm_tn_wide": 2 * R * 2 * (64 + 256 + 64 + 192) * t + 2 * 55 * 49152 * 4,
+        # wave-per-sample kernels (csrc/wps.h). forward: tokens in, layer 1's input rows out (+ pooled / head activations);
+        # backward: both layers' input rows + dout / masks in, 2 x 1024 features x 17 tokens of weight-grad operands (T) + dx,
+        # dc3, head / encoder-MLP grads out; weight-grads: those operands in, one slab set per 32 samples out
+        "wps_layer_stack_head": R * 2 * tok + n * (128 + 256 + 256 + 16) * 4,
+        "wps_layer_bwd_stack": R * 2 * tok + 2 * R * 1024 * t + R * tok + n * (16 * 64 + 16 + 4 * 256 + 2 * 256) * 4,
+        "wps_wgrad": 2 * R * 1024 * t + 2 * (-(-n // 32)) * (49152 + 576) * 4,
     }
     E = wl["E"]
     enc_w = (4 * 64 * 32 + 32 * 16 * 64 + 64 * 9 * 64 + 64 * 64 + 128 * 256 + 256 * 256 + 256 * 64) * t
@@ -481,6 +487,8 @@ def block_fetch_bytes(kernel, wl, compute):
         "fused_conv_bwd": (min(n, 256), -(-n // min(n, 256)) * 64 * 576 * t + 4 * 32 * 256 * t),
         "fused_layer_bwd_stack": (-(-n // 4), L * lw + head_w + mlp_w - 128 * 256 * t + 64 * 64 * t),
         "fused_layer_stack_head": (-(-n // 2), L * lw + head_w),
+        "wps_layer_stack_head": (-(-n // 4), L * lw + head_w),
+        "wps_layer_bwd_stack": (-(-n // 4), 2 * L * lw + head_w + mlp_w - 128 * 256 * t + 64 * 64 * t),
         "fused_encoder": (256, conv_w),
     }
     if kernel not in table:

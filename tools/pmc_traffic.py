@@ -12,6 +12,7 @@ NAMES = {  # rocprof kernel symbol fragment -> bench.py / profiler label
     "gemm_tn_group_kernel": "gemm_tn_group", "wgrad_reduce_kernel": "wgrad_reduce", "infer_encoder_kernel": "fused_encoder",
     "bwd_layer_kernel": "fused_layer_bwd", "infer_layer_kernel": "fused_layer", "train_encoder_kernel": "fused_encoder",
     "rollout_stack_kernel": "rollout_layers_head", "rollout_encoder2_kernel": "rollout_encoder",
+    "wps_layer_fwd_kernel": "wps_layer_stack_head", "wps_layer_bwd_kernel": "wps_layer_bwd_stack", "wps_wgrad_kernel": "wps_wgrad",
 }
 rows = [l.rstrip("\n").split("\t") for l in open(sys.argv[1])]
 h = rows[0]

@@ -20,11 +20,12 @@ for it in range(3):
     hip.backward(st_, im, n, dout, grads)
 torch.cuda.synchronize()
 buf=(C.c_longlong*128)(); L.v4l_debug_stamps(buf)
-st=np.array(buf[:64],dtype=np.int64)
+st=np.array(buf[:128],dtype=np.int64)
 def show(title, idx, names):
     print(title, "total cycles", st[idx[-1]]-st[idx[0]])
     for a,b,nm in zip(idx[:-1], idx[1:], names): print("   %-26s %8d" % (nm, st[b]-st[a]))
-show("FWD", [0,7,1,2,3,4,5,6,8,15,9,10,11,12,13,14,16,17],
-     ["L0 stage+wait","q,k","v","attn","outproj+ln1","ffn","ln2(+xout)","barrier","L1 stage+wait","q,k","v","attn","outproj+ln1","ffn","ln2","(to heads)","heads"])
+show("FWD", [0,7,6,8,15,14,16,17], ["L0 stage+rows+wait","L0 layer","barrier","L1 stage+wait","L1 layer","(to heads)","heads"])
 show("BWD", [32,33,34,35,36,37,38,41,42,43,44,45,46,50,51],
      ["heads","L1 stageW+rows","L1 recompute","barrier","L1 stageWt","L1 backward","LNred+barrier","L0 stageW+rows","L0 recompute","barrier","L0 stageWt","L0 backward","LNred+dx","tail"])
+show("BWD heads", [32,60,61,62,63,33], ["dout/masks/rings issue + stage dt","gemm w2t + mask","gemm w1t + mask","gemm w0t","unpool -> barrier"])
+show("BWD tail", [50,66,67,68,51], ["upconv' per wave (+c3, dc3)","token-0 rows -> LDS","proj' gemm + mask","fc2' gemm + mask"])

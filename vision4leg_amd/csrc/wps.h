@@ -938,6 +938,7 @@ __global__ __launch_bounds__(256) void wps_layer_bwd_kernel(WpsBwdStack stk, Bwd
       dt[r * LY::LDX + c] = dv[k];
     }
     __syncthreads();
+    WPS_STAMP(60);
     f32x4 acc[1][4];
     auto masked = [&](const float4 (&m)[4], T* dst, float* save) {  // ReLU mask from the saved activation, rows < ns
       const bool okr = fr < ns;
@@ -954,10 +955,12 @@ __global__ __launch_bounds__(256) void wps_layer_bwd_kernel(WpsBwdStack stk, Bwd
     block_gemm<T, 1, 4, 2>(acc, dt, LY::LDX, (const T*)hd.w2t, 64, nt4, lane, ring2);
     masked(m1, dh1, hd.o_dh1);
     __syncthreads();
+    WPS_STAMP(61);
     zero_acc(acc);
     block_gemm<T, 1, 4, 8>(acc, dh1, LY::LDF, (const T*)hd.w1t, 256, nt4, lane, ring1);
     masked(m0, dh0, hd.o_dh0);
     __syncthreads();
+    WPS_STAMP(62);
     {
       f32x4 a2[1][2];
       zero_acc(a2);
@@ -966,6 +969,7 @@ __global__ __launch_bounds__(256) void wps_layer_bwd_kernel(WpsBwdStack stk, Bwd
       for (int j = 0; j < 2; ++j) st4(dpool + fr * LY::LDP + nt2[j] * 16 + qr, a2[0][j][0], a2[0][j][1], a2[0][j][2], a2[0][j][3]);
     }
     __syncthreads();
+    WPS_STAMP(63);
     // un-pool (pool_bwd_kernel) straight into this wave's registers: token 0 <- dpool[:, 0:64], tokens 1..16 <- dpool[:, 64:128] / 16
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt)
@@ -1053,6 +1057,7 @@ __global__ __launch_bounds__(256) void wps_layer_bwd_kernel(WpsBwdStack stk, Bwd
                                                             m.z > 0.f ? acc[mt][2] : 0.f, m.w > 0.f ? acc[mt][3] : 0.f};
       }
     }
+    WPS_STAMP(66);
     // token 0: (dx_in o [x0 > 0]) -> state_projector' -> [e1 > 0] -> dhc -> fc2' -> [e0 > 0] -> de0, cooperatively (4 rows)
     float* dt = reinterpret_cast<float*>(smem);                 // [16][LDX]
     T* dh = reinterpret_cast<T*>(dt + 16 * LY::LDX);            // [16][LDF]
@@ -1078,6 +1083,7 @@ __global__ __launch_bounds__(256) void wps_layer_bwd_kernel(WpsBwdStack stk, Bwd
       }
     }
     __syncthreads();
+    WPS_STAMP(67);
     f32x4 acc[1][4];
     auto masked = [&](const float4 (&m)[4], T* dst, float* save) {
       const bool okr = fr < ns;
@@ -1095,6 +1101,7 @@ __global__ __launch_bounds__(256) void wps_layer_bwd_kernel(WpsBwdStack stk, Bwd
     GemmRing<T, 4, 8> ring_f2 = gemm_prefetch<T, 4, 8>((const T*)tl.wf2t, 256, nt4, lane);
     masked(tm_e1, dh, tl.o_dhc);
     __syncthreads();
+    WPS_STAMP(68);
     zero_acc(acc);
     block_gemm<T, 1, 4, 8>(acc, dh, LY::LDF, (const T*)tl.wf2t, 256, nt4, lane, ring_f2);
     masked(tm_e0, (T*)nullptr, tl.o_de0);
