@@ -487,6 +487,44 @@ class HipActor:
       self._step(obs, deterministic)
     return self._out
 
+  def step_host(self, obs_pinned, deterministic=False):
+    """The collector's per-step call without any copy of its own: `obs_pinned` is a PINNED host float32 tensor
+    [E][S+C*H*W] that the rollout kernels read in place over PCIe (pinned host memory is mapped into the device's address
+    space), and the action lands in a pinned host buffer the same way. One launch pair + one stream synchronise; returns the
+    [E][A] action as a numpy view of that buffer (valid until the next step). Eager launches only."""
+    if self.graph:
+      raise RuntimeError("vision4leg_amd: step_host drives eager launches (construct the actor with graph=False)")
+    if (not obs_pinned.is_pinned() or obs_pinned.dtype != torch.float32 or not obs_pinned.is_contiguous()
+        or obs_pinned.numel() != self.obs.numel()):
+      raise RuntimeError("vision4leg_amd: step_host needs a pinned, contiguous float32 [E][S+C*H*W] host tensor")
+    if getattr(self, "_act_host", None) is None:
+      self._act_host = torch.zeros(self.action.shape, dtype=torch.float32).pin_memory()
+      self._args_host = self._args[:7] + (C.c_void_p(self._act_host.data_ptr()),) + self._args[8:]
+      self._args_host_of = self._args
+    if self._args_host_of is not self._args:  # attach() rebuilt the argument tuple
+      self._args_host = self._args[:7] + (C.c_void_p(self._act_host.data_ptr()),) + self._args[8:]
+      self._args_host_of = self._args
+    self.pf.pack_if_needed(fast=True)
+    self.vf.pack_if_needed(fast=True)
+    args = (C.c_void_p(obs_pinned.data_ptr()),) + self._args_host[1:]
+    bulk = getattr(self, "_bulk", None)
+    if not deterministic and bulk is not None:
+      args = args[:1] + (C.c_void_p(bulk.data_ptr() + self._bulk_t * bulk.stride(0) * 4),) + args[2:]
+      self._bulk_t += 1
+      if self._bulk_t >= bulk.shape[0]:
+        self._bulk = None
+    elif not deterministic:
+      self.eps.normal_()
+      self._eps_zero = False
+    elif not getattr(self, "_eps_zero", False):
+      self.eps.zero_()
+      self._eps_zero = True
+    if self.own:
+      self.seek(0)
+    check(self.L.v4l_actor_step(self.h, *args, _stream()), "v4l_actor_step")
+    torch.cuda.current_stream(self.device).synchronize()
+    return self._act_host.numpy()
+
   def _step(self, obs, deterministic=False):
     self.pf.pack_if_needed(fast=True)
     self.vf.pack_if_needed(fast=True)

@@ -81,9 +81,10 @@ class VecOnPolicyCollector:
         self.eval_env.close()
 
     # ---- host -> HBM ----------------------------------------------------------------------------------------------
-    def _upload(self, rows):
+    def _upload(self, rows, host_only=False):
         """numpy [E][D] (float64 from the env wrappers) -> fp32 device rows via double-buffered pinned staging
-        (what `torch.Tensor(self.current_ob).to(self.device)`, collector/on_policy.py:91-93, does from pageable memory)."""
+        (what `torch.Tensor(self.current_ob).to(self.device)`, collector/on_policy.py:91-93, does from pageable memory).
+        host_only: stop at the pinned fp32 staging buffer and return it (the fast path's rollout kernels read it in place)."""
         rows = np.asarray(rows)
         if self._pins is None or self._pins[0][0].shape != rows.shape:
             mk = lambda: (torch.empty(rows.shape, dtype=torch.float32).pin_memory(),
@@ -103,6 +104,8 @@ class VecOnPolicyCollector:
                 torch.set_num_threads(prev)
         else:
             np.copyto(host.numpy(), rows, casting="same_kind")
+        if host_only:
+            return host  # (the caller synchronises the stream before the next step: the buffer is free again by then)
         dev.copy_(host, non_blocking=True)
         ev.record()
         return dev
@@ -126,8 +129,9 @@ class VecOnPolicyCollector:
                 if top != self._cursor:  # the device-side step cursor advances by one per step; re-aim it when the buffer wrapped
                     actor.seek(top)
                 self._cursor = top + 1
-                out = actor.step(self._upload(self.current_ob))
-                acts = out["action"].cpu().numpy()  # the only device->host transfer of the step
+                # observation rows and action cross PCIe inside the two rollout launches themselves: the kernels read the
+                # pinned staging buffer in place and write the [E][A] action into pinned host memory — no copy launches
+                acts = np.array(actor.step_host(self._upload(self.current_ob, host_only=True)), dtype=np.float32, copy=True)
                 values = None
             else:
                 ob_tensor = self._upload(self.current_ob)

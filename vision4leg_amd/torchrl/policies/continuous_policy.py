@@ -46,6 +46,10 @@ class RolloutActor:
     def step(self, ob, deterministic=False):
         return self._actor.step(ob, deterministic)
 
+    def step_host(self, ob_pinned, deterministic=False):
+        """One env step straight from / to pinned host memory (see HipActor.step_host): -> numpy action [E][A]."""
+        return self._actor.step_host(ob_pinned, deterministic)
+
     def eval_act(self, x):
         """`pf.eval_act(x)` (policies/continuous_policy.py:78-83) on the fused step: the policy mean as a numpy array,
         no draw. With env_nums = 1 this is the batch-1 deployment call — the role the reference's TensorRT engine
