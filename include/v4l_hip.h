@@ -34,6 +34,8 @@
  *   V4L_NO_FUSED_ACTOR        rollout step on the general kernels (per call)
  *   V4L_NO_LAYER_STACK        one launch per transformer layer instead of one per direction (per call)
  *   V4L_NO_WPS_LAYERS         transformer layers on the block-cooperative kernels instead of the wave-per-sample ones (per call)
+ *   V4L_LAYER_TAPS            tests: the wave-per-sample layer kernels and the fused conv backward also write every
+ *                             intermediate into its v4l_net_ws_offset slot (production keeps them on chip) (per call)
  *   V4L_LAYER_SPW=2|4, V4L_LAYER_BWD_SPW=2|4      samples per block of the block-cooperative layer kernels
  *   V4L_CONV_BWD_BLOCKS, V4L_TRAIN_ENC_BLOCKS, V4L_WIDE_SPLITS   block / split counts (tests force ragged and many-samples-per-block shapes)
  *   V4L_TRAIN_ENC_OLD, V4L_ROLLOUT_ENC_OLD        the streamed-weight encoder kernels

@@ -25,13 +25,16 @@ def _close32(name, got, want, tag, tol=TOL):
     assert e <= tol, (name, e)
 
 
-def _close_t(name, got_t, want32, mode, tag, max_ulp=1.0):
-    """got_t: values the kernel stored in the compute type (as float64/32 tensor); want32: fp32 expectation before rounding."""
+def _close_t(name, got_t, want32, mode, tag, max_ulp=1.0, floor=TOL):
+    """got_t: values the kernel stored in the compute type (as float64/32 tensor); want32: fp32 expectation before rounding.
+    floor: absolute noise floor as a fraction of the tensor's max-abs — fp32 accumulation noise for a single contraction; a
+    result that sits BEHIND further rounding stages (the attention backward: dctx and dS are rounded on the way) inherits their
+    1-ulp ties as a perturbation at the scale of the tensor, not of the element."""
     if mode == "f32":
         return _close32(name, got_t, want32, tag)
     want_r = orc.rbf16(want32.float())
-    # allowed distance: one bf16 ulp of the value (<= 2^-7 relative) on top of the fp32 accumulation noise floor of the tensor
-    ulp = want32.abs().float() * 2.0 ** -7 + TOL * want32.abs().max().float()
+    # allowed distance: one bf16 ulp of the value (<= 2^-7 relative) on top of the noise floor of the tensor
+    ulp = want32.abs().float() * 2.0 ** -7 + floor * want32.abs().max().float()
     diff = (got_t.float() - want32.float()).abs()
     frac = ((got_t.float() != want_r).float().mean()).item()
     worst = (diff / ulp).max().item()
@@ -40,12 +43,39 @@ def _close_t(name, got_t, want32, mode, tag, max_ulp=1.0):
     assert worst <= max_ulp + 1e-3 and frac <= 5e-3, (name, worst, frac)
 
 
+def _conv_backward_checks(tap, G, sd, enc, n, c1, c2, dc3, img_t, mode, tag):
+    """conv3' / conv2' data-grads and the conv2 / conv1 weight- and bias-gradients of the fused conv-stack backward
+    (bwd_conv_kernel: dc2 / dc1 never reach HBM in production; V4L_LAYER_TAPS writes them as the kernel holds them, in T),
+    each from the kernel's OWN operands: conv2d_input / conv2d_weight on (dc3, w3) -> dc2, (dc2, c1) -> dW2, (dc2, w2) -> dc1,
+    (dc1, image) -> dW1 (torchrl/networks/base.py:317-324 reversed)."""
+    r = (lambda x: x) if mode == "f32" else orc.rbf16
+    nhwc = lambda x: x.permute(0, 2, 3, 1).reshape(n, -1, x.shape[1])
+    nchw = lambda t2, hw, c: t2.reshape(n, hw, hw, c).permute(0, 3, 1, 2)
+    w3, w2, w1 = sd[enc + "4.weight"], sd[enc + "2.weight"], sd[enc + "0.weight"]
+    c1n, c2n = nchw(c1, 15, 32), nchw(c2, 6, 64)
+    dc2_t, dc1_t = tap("dc2", n * 36, 64, True), tap("dc1", n * 225, 32, True)
+    want2 = (c2n > 0) * torch.nn.grad.conv2d_input(c2n.shape, r(w3), r(nchw(dc3, 4, 64)), stride=1)
+    _close_t("d.conv3->dc2", dc2_t.view(n, 36, 64), nhwc(want2), mode, tag)
+    dc2n = nchw(dc2_t, 6, 64)  # (already in the compute type)
+    want1 = (c1n > 0) * torch.nn.grad.conv2d_input(c1n.shape, r(w2), dc2n, stride=2)
+    _close_t("d.conv2->dc1", dc1_t.view(n, 225, 32), nhwc(want1), mode, tag)
+    dc1n = nchw(dc1_t, 15, 32)
+    _close32("w.conv2.weight", G(enc + "2.weight"),
+             torch.nn.grad.conv2d_weight(r(c1n).double(), w2.shape, dc2n.double(), stride=2).float(), tag)
+    _close32("w.conv1.weight", G(enc + "0.weight"),
+             torch.nn.grad.conv2d_weight(img_t.double(), w1.shape, dc1n.double(), stride=4).float(), tag)
+    # bias gradients are summed from the fp32 values BEFORE they are rounded to T (oracle: db = dy.sum of the unrounded dy)
+    _close32("w.conv2.bias", G(enc + "2.bias"), want2.double().sum((0, 2, 3)).float(), tag)
+    _close32("w.conv1.bias", G(enc + "0.bias"), want1.double().sum((0, 2, 3)).float(), tag)
+
+
 @pytest.mark.parametrize("mode", MODES)
-def test_every_contraction_teacher_forced(mode, device, layer_taps):
-    case = util.CASES["loco_s93"]
+@pytest.mark.parametrize("name", ["loco_s93", "loco_b1024"])
+def test_every_contraction_teacher_forced(name, mode, device, layer_taps):
+    case = util.CASES[name]
     n, S, A, R = case["B"], case["S"], case["A"], case["B"] * 17
     pf, vf = _build(case, mode, device)
-    tag = "loco_s93/" + mode
+    tag = name + "/" + mode
     hip = pf.hip
     obs = torch.tensor(util.make_batch(case)["obs"], dtype=torch.float32)
     st, im, _ = hip.stage(obs.to(device))
@@ -152,11 +182,13 @@ def test_every_contraction_teacher_forced(mode, device, layer_taps):
             dz2, df, dz1, dqkv = tap("dz2_%d" % l, R, 64, True), tap("df%d" % l, R, 256, True), tap("dz1_%d" % l, R, 64, True), tap("dqkv%d" % l, R, 192, True)
             dz2_w = ln_bwd(dy, d["xh2"], d["rs2"], p + "norm2.weight")
             _close_t("d.L%d.norm2_bwd" % l, dz2, dz2_w, mode, tag)
-            _close_t("d.L%d.df=(dz2 W2)*mask" % l, df, (d["f"] > 0) * dmm(dz2_w, p + "linear2.weight"), mode, tag)
-            dx1 = dz2_w + dmm((d["f"] > 0) * dmm(dz2_w, p + "linear2.weight"), p + "linear1.weight")
+            # (GEMM operands: the kernel's OWN rounded tensors — the dz2 / df taps — so that a 1-ulp tie in an operand is not
+            # charged to the next contraction; the residual adds the fp32 value)
+            _close_t("d.L%d.df=(dz2 W2)*mask" % l, df, (d["f"] > 0) * dmm(dz2, p + "linear2.weight"), mode, tag)
+            dx1 = dz2_w + dmm(df, p + "linear1.weight")
             dz1_w = ln_bwd(dx1, d["xh1"], d["rs1"], p + "norm1.weight")
             _close_t("d.L%d.dx1+norm1_bwd" % l, dz1, dz1_w, mode, tag)
-            dctx = dmm(dz1_w, p + "self_attn.out_proj.weight").view(n, 17, 64)
+            dctx = dmm(dz1, p + "self_attn.out_proj.weight").view(n, 17, 64)
             q, k, v = (t_.view(n, 17, 64) for t_ in d["qkv"].split(64, dim=-1))
             P = d["P"]
             dP = r(dctx) @ r(v).transpose(1, 2)          # every product on operands rounded to the compute type
@@ -166,8 +198,8 @@ def test_every_contraction_teacher_forced(mode, device, layer_taps):
             dqkv_w = torch.cat([dq_, dk_, dv_], -1).view(R, 192)
             # (two rounding stages in a row — dS is rounded before it enters dQ / dK — so a 1e-7 difference in dS can move
             # an output by a second ulp)
-            _close_t("d.L%d.attention_bwd" % l, dqkv, dqkv_w, mode, tag, max_ulp=2.0)
-            dxin = dz1_w + dmm(dqkv_w, p + "self_attn.in_proj_weight")
+            _close_t("d.L%d.attention_bwd" % l, dqkv, dqkv_w, mode, tag, max_ulp=2.0, floor=1e-3)
+            dxin = dz1_w + dmm(dqkv, p + "self_attn.in_proj_weight")
             _close32("d.L%d.layer_input_grad" % l, dxs[l], dxin, tag, tol=1e-4 if mode == "bf16" else TOL)
             # ---- the four weight gradients of the layer: dW = dY^T X on the operands the kernels saved
             for nm, dyv, xv in (("linear1", df, d["x1t"]), ("linear2", dz2, d["f"]), ("self_attn.out_proj", dz1, d["ctx"]),
@@ -185,8 +217,189 @@ def test_every_contraction_teacher_forced(mode, device, layer_taps):
         _close32("w.conv3.weight", G(enc + "4.weight"),
                  torch.nn.grad.conv2d_weight(r(nchw(c2, 6, 64)).double(), w3.shape, r(nchw(dc3, 4, 64)).double(), stride=1).float(), tag)
         _close32("w.conv3.bias", G(enc + "4.bias"), dc3.double().sum(0).float(), tag)
+        _conv_backward_checks(tap, G, sd, enc, n, c1, c2, dc3, img_t, mode, tag)
+        # ---- encoder MLP / projector: data-grads of the TAIL launch and their weight gradients
+        dx0 = dxs[0].view(n, 17, 64)[:, 0]
+        ypr = (x0[:, 0] > 0) * dx0                                         # grad w.r.t. the projector's pre-activation
+        dhc, deh0 = tap("dhc", n, 256), tap("deh0", n, 256)
+        _close32("d.state_projector->dhc", dhc, (eh1 > 0) * dmm(ypr, "encoder.state_projector.projection.0.weight"), tag)
+        _close32("d.enc_fc2->deh0", deh0, (eh0 > 0) * dmm(dhc, "encoder.base.seq_fcs.2.weight"), tag)
+        _close32("w.state_projector.weight", G("encoder.state_projector.projection.0.weight"), (r(ypr).double().t() @ r(eh1).double()).float(), tag)
+        _close32("w.enc_fc2.weight", G("encoder.base.seq_fcs.2.weight"), (r(dhc).double().t() @ r(eh0).double()).float(), tag)
+        _close32("w.enc_fc1.weight", G("encoder.base.seq_fcs.0.weight"), (r(deh0).double().t() @ r(state).double()).float(), tag)
         # ---- head / encoder-MLP weight gradients
         _close32("w.head_out.weight", G(hp + "4.weight"), (r(dout.cpu()[:, :A]).double().t() @ r(hh1).double()).float(), tag)
         _close32("w.head_fc1.weight", G(hp + "2.weight"), (r(dhh1).double().t() @ r(hh0).double()).float(), tag)
         _close32("w.head_fc0.weight", G(hp + "0.weight"), (r(dhh0).double().t() @ r(pooled).double()).float(), tag)
         _close32("w.head_fc0.bias", G(hp + "0.bias"), dhh0.double().sum(0).float(), tag)
+
+
+@pytest.mark.parametrize("mode", MODES)
+@pytest.mark.parametrize("name", ["cnn_s93", "mlp_s93", "cnn_vis", "loco_vis"])
+def test_contractions_of_the_other_nets(name, mode, device, layer_taps):
+    """The same per-contraction statement for the nets that run on the general (layer-by-layer) GEMM kernels plus the fused
+    conv-stack backward: NatureCNN fuse net (nets.py:247-262, base.py:371-385), state MLP (nets.py:52-55) and the two
+    vision-only nets (nets.py:133-191, 784-906) — conv stack forward, projector / MLP / head chains forward, their data-grads,
+    and every weight gradient from the kernels' own operands. (The vision-only Transformer's layers run on the general
+    attention / LayerNorm kernels; its conv stack, up-conv and head are checked here.)"""
+    case = util.CASES[name]
+    kind = case["kind"]
+    n, S, A = case["B"], case["S"], case["A"]
+    pf, vf = _build(case, mode, device)
+    tag = name + "/" + mode
+    hip = pf.hip
+    obs = torch.tensor(util.make_batch(case)["obs"], dtype=torch.float32)
+    st, im, _ = hip.stage(obs.to(device))
+    hip.forward(st, im, n, train=True)
+    w = torch.tensor(np.random.RandomState(5).randn(n, A), dtype=torch.float32)
+    dout = torch.zeros(n, 16, dtype=torch.float32, device=device)
+    dout[:, :A] = w.to(device)
+    grads = torch.full((hip.total_params,), float("nan"), dtype=torch.float32, device=device)
+    hip.backward(st, im, n, dout, grads)
+    torch.cuda.synchronize()
+    ws = hip.workspace(n).cpu()
+    tdt = torch.float32 if mode == "f32" else torch.bfloat16
+
+    def tap(nm, rows, cols, t=False):
+        off = hip.ws_offset(n, nm)
+        raw = ws[off:off + rows * cols]
+        if t and tdt == torch.bfloat16:
+            return raw.view(torch.bfloat16)[:rows * cols].view(rows, cols).float()
+        return raw.view(rows, cols).clone()
+    sd = {k: v.detach().cpu() for k, v in pf.state_dict().items()}
+    G = lambda k: hip.grad_view(grads, k).cpu()
+    lin = lambda x, wk, bk: orc.linear(x, sd[wk], sd[bk], mode)
+    r = (lambda x: x) if mode == "f32" else orc.rbf16
+    dmm = lambda dy, wk: r(dy) @ r(sd[wk])
+    wg = lambda dy, x: (r(dy).double().t() @ r(x).double()).float()
+    nhwc = lambda x: x.permute(0, 2, 3, 1).reshape(n, -1, x.shape[1])
+    nchw = lambda t2, hw, c: t2.reshape(n, hw, hw, c).permute(0, 3, 1, 2)
+    d_out = dout.cpu()[:, :A]
+    with torch.no_grad():
+        if kind == "mlp":
+            hp, bp = "seq_append_fcs.", "base.seq_fcs."
+            eh0, eh1, hh0, hh1, out = tap("eh0", n, 256), tap("eh1", n, 256), tap("hh0", n, 256), tap("hh1", n, 256), tap("out", n, 16)
+            _close32("base_fc1", eh0, torch.relu(lin(obs, bp + "0.weight", bp + "0.bias")), tag)
+            _close32("base_fc2", eh1, torch.relu(lin(eh0, bp + "2.weight", bp + "2.bias")), tag)
+            _close32("head_fc0", hh0, torch.relu(lin(eh1, hp + "0.weight", hp + "0.bias")), tag)
+            _close32("head_fc1", hh1, torch.relu(lin(hh0, hp + "2.weight", hp + "2.bias")), tag)
+            _close32("head_out", out[:, :A], lin(hh1, hp + "4.weight", hp + "4.bias"), tag)
+            dhh1, dhh0, hand, deh0 = tap("dhh1", n, 256), tap("dhh0", n, 256), tap("dhc", n, 256), tap("deh0", n, 256)
+            _close32("d.head_fc1_pre", dhh1, (hh1 > 0) * dmm(d_out, hp + "4.weight"), tag)
+            _close32("d.head_fc0_pre", dhh0, (hh0 > 0) * dmm(dhh1, hp + "2.weight"), tag)
+            _close32("d.base_fc2_pre", hand, (eh1 > 0) * dmm(dhh0, hp + "0.weight"), tag)
+            _close32("d.base_fc1_pre", deh0, (eh0 > 0) * dmm(hand, bp + "2.weight"), tag)
+            for nm, dyv, xv in ((hp + "4", d_out, hh1), (hp + "2", dhh1, hh0), (hp + "0", dhh0, eh1), (bp + "2", hand, eh0), (bp + "0", deh0, obs)):
+                _close32("w." + nm + ".weight", G(nm + ".weight"), wg(dyv, xv), tag)
+                _close32("w." + nm + ".bias", G(nm + ".bias"), dyv.double().sum(0).float(), tag)
+            return
+        # ---- conv stack forward (all visual nets)
+        enc = {"cnn": "encoder.visual_base.layers.", "cnn_vis": "encoder.layers.", "loco_vis": "encoder.depth_visual_base.layers."}[kind]
+        state, img = (orc.split_obs(obs, S) if S > 0 else (None, obs.reshape(-1, 4, 64, 64)))
+        img_t = im.cpu().float().view(n, 4, 64, 64)
+        assert torch.equal(img_t, r(img))
+        c1, c2, c3 = tap("c1", n * 225, 32), tap("c2", n * 36, 64), tap("c3", n * 16, 64)
+        _close32("conv1", c1.view(n, 225, 32), nhwc(torch.relu(orc.conv2d(img_t, sd[enc + "0.weight"], sd[enc + "0.bias"], 4, mode))), tag)
+        _close32("conv2", c2.view(n, 36, 64), nhwc(torch.relu(orc.conv2d(nchw(c1, 15, 32), sd[enc + "2.weight"], sd[enc + "2.bias"], 2, mode))), tag)
+        _close32("conv3", c3.view(n, 16, 64), nhwc(torch.relu(orc.conv2d(nchw(c2, 6, 64), sd[enc + "4.weight"], sd[enc + "4.bias"], 1, mode))), tag)
+        flat = nchw(c3, 4, 64).flatten(1)                           # PyTorch's NCHW flatten of conv3's output
+        hp = "visual_seq_append_fcs." if kind == "loco_vis" else "seq_append_fcs."
+        hh0, hh1, out = tap("hh0", n, 256), tap("hh1", n, 256), tap("out", n, 16)
+        dhh1, dhh0 = tap("dhh1", n, 256), tap("dhh0", n, 256)
+        dc3 = tap("dc3", n * 16, 64)
+        if kind == "cnn":
+            vis = tap("vis", n, 512)
+            pk, bp = "encoder.visual_projector.projection.0.", "encoder.base.seq_fcs."
+            eh0 = tap("eh0", n, 256)
+            _close32("visual_projector", vis[:, :256], torch.relu(lin(flat, pk + "weight", pk + "bias")), tag)
+            _close32("enc_fc1", eh0, torch.relu(lin(state, bp + "0.weight", bp + "0.bias")), tag)
+            _close32("enc_fc2", vis[:, 256:], torch.relu(lin(eh0, bp + "2.weight", bp + "2.bias")), tag)
+            head_in = vis
+        elif kind == "cnn_vis":
+            head_in = flat
+        else:
+            x0 = tap("x0", n * 16, 64).view(n, 16, 64)
+            up = orc.conv2d(nchw(c3, 4, 64), sd["encoder.depth_up_conv.weight"], sd["encoder.depth_up_conv.bias"], 1, mode)
+            _close32("up_conv", x0, nhwc(up), tag)
+            xl = tap("x2", n * 16, 64).view(n, 16, 64)
+            head_in = xl.mean(1)
+            _close32("pool_all", tap("pooled", n, 64), head_in, tag)
+        _close32("head_fc0", hh0, torch.relu(lin(head_in, hp + "0.weight", hp + "0.bias")), tag)
+        _close32("head_fc1", hh1, torch.relu(lin(hh0, hp + "2.weight", hp + "2.bias")), tag)
+        _close32("head_out", out[:, :A], lin(hh1, hp + "4.weight", hp + "4.bias"), tag)
+        # ---- backward: head chain
+        _close32("d.head_fc1_pre", dhh1, (hh1 > 0) * dmm(d_out, hp + "4.weight"), tag)
+        _close32("d.head_fc0_pre", dhh0, (hh0 > 0) * dmm(dhh1, hp + "2.weight"), tag)
+        for nm, dyv, xv in ((hp + "4", d_out, hh1), (hp + "2", dhh1, hh0), (hp + "0", dhh0, head_in)):
+            _close32("w." + nm + ".weight", G(nm + ".weight"), wg(dyv, xv), tag)
+            _close32("w." + nm + ".bias", G(nm + ".bias"), dyv.double().sum(0).float(), tag)
+        dhead_in = dmm(dhh0, hp + "0.weight")
+        if kind == "cnn":
+            hand, deh0 = tap("dhc", n, 512), tap("deh0", n, 256)
+            _close32("d.head_fc0->concat", hand, dhead_in, tag)
+            yv = (vis[:, :256] > 0) * hand[:, :256]
+            want3 = (nchw(c3, 4, 64) > 0) * dmm(yv, pk + "weight").view(n, 64, 4, 4)
+            _close32("d.visual_projector->dc3", dc3.view(n, 16, 64), nhwc(want3), tag)
+            _close32("w.visual_projector.weight", G(pk + "weight"), wg(yv, flat), tag)
+            ys = (vis[:, 256:] > 0) * hand[:, 256:]
+            _close32("d.enc_fc2->deh0", deh0, (eh0 > 0) * dmm(ys, bp + "2.weight"), tag)
+            _close32("w.enc_fc2.weight", G(bp + "2.weight"), wg(ys, eh0), tag)
+            _close32("w.enc_fc1.weight", G(bp + "0.weight"), wg(deh0, state), tag)
+        elif kind == "cnn_vis":
+            want3 = (nchw(c3, 4, 64) > 0) * dhead_in.view(n, 64, 4, 4)
+            _close32("d.head_fc0->dc3", dc3.view(n, 16, 64), nhwc(want3), tag)
+        else:
+            dx0 = tap("dx0", n * 16, 64)
+            _close32("d.up_conv->dc3", dc3, (c3 > 0) * (r(dx0) @ r(sd["encoder.depth_up_conv.weight"].view(64, 64))), tag)
+            _close32("w.up_conv.weight", G("encoder.depth_up_conv.weight").view(64, 64), (r(dx0).double().t() @ r(c3).double()).float(), tag)
+        # ---- conv stack backward from the kernel's own dc3
+        w3 = sd[enc + "4.weight"]
+        _close32("w.conv3.weight", G(enc + "4.weight"),
+                 torch.nn.grad.conv2d_weight(r(nchw(c2, 6, 64)).double(), w3.shape, r(nchw(dc3, 4, 64)).double(), stride=1).float(), tag)
+        _close32("w.conv3.bias", G(enc + "4.bias"), dc3.double().sum(0).float(), tag)
+        _conv_backward_checks(tap, G, sd, enc, n, c1, c2, dc3, img_t, mode, tag)
+
+
+@pytest.mark.parametrize("mode", MODES)
+@pytest.mark.parametrize("E", [32, 64])
+def test_rollout_kernels_stage_by_stage(E, mode, device):
+    """The two rollout kernels (rollout_encoder2_kernel / rollout_encoder_kernel + rollout_stack_kernel: conv stack, proprio MLP,
+    both nets' layer stacks and heads in LDS, nothing saved) at the bench's E: every tensor they DO leave in HBM — the token
+    tensor, each layer's output for both nets, the head outputs — teacher-forced stage by stage: the oracle's stage applied to
+    the kernel's own stage input (collector/on_policy.py:95-100 -> nets.py:996-1038). A stage is a chain of contractions, so
+    bf16 is gated at the chain's tolerance, f32 at accumulation noise."""
+    from vision4leg_amd.torchrl.policies import RolloutActor
+    case = dict(util.CASES["loco_b1024"])
+    S, A = case["S"], case["A"]
+    pf, vf = _build(case, mode, device)
+    actor = RolloutActor(pf, vf, E)
+    rs = np.random.RandomState(31)
+    obs = torch.tensor(util.obs_rows(rs, E, case), dtype=torch.float32)
+    out = actor.step(obs.to(device), deterministic=True)
+    torch.cuda.synchronize()
+    a = actor._actor
+    ws = a.ws.cpu()
+    hp_, hv_ = pf.hip, vf.hip
+    off_v = hp_.ws_floats(E)
+    tapp = lambda nm, rows, cols: ws[hp_.ws_offset(E, nm):hp_.ws_offset(E, nm) + rows * cols].view(rows, cols).clone()
+    tapv = lambda nm, rows, cols: ws[off_v + hv_.ws_offset(E, nm):off_v + hv_.ws_offset(E, nm) + rows * cols].view(rows, cols).clone()
+    tag = "rollout/E%d/%s" % (E, mode)
+    tol = 2e-5 if mode == "f32" else 6e-3
+    R = E * 17
+    sdp = {k: v.detach().cpu() for k, v in pf.state_dict().items()}
+    sdv = {k: v.detach().cpu() for k, v in vf.state_dict().items()}
+    with torch.no_grad():
+        taps = {}
+        orc.loco_forward({k: v for k, v in sdp.items() if k != "logstd"}, obs, S, mode, taps)
+        x0 = tapp("x0", R, 64).view(E, 17, 64)
+        _close32("tokens", x0, taps["x0"], tag, tol=tol)
+        for nm, sd, tp, last in (("pf", sdp, tapp, out["mean"].cpu()), ("vf", sdv, tapv, out["value"].cpu())):
+            x = x0
+            for l in range(2):
+                want = orc.transformer_layer(sd, "visual_append_layers.%d" % l, x, mode)
+                got = tp("x%d" % (l + 1), R, 64).view(E, 17, 64)
+                _close32("%s.layer%d" % (nm, l), got, want, tag, tol=tol)
+                x = got
+            pooled = torch.cat([x[:, 0], x[:, 1:17].mean(1)], -1)
+            want = orc.head(sd, "visual_seq_append_fcs", pooled, 2, mode)
+            _close32("%s.head" % nm, last.view(E, -1), want, tag, tol=tol)

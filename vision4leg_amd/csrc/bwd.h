@@ -792,6 +792,7 @@ struct BwdConv {
   float *slab1, *slab2, *slab3;     // [gridDim.x][32][256], [gridDim.x][64][512], [gridDim.x][64][576]
   float *bslab1, *bslab2, *bslab3;  // [gridDim.x][32], [gridDim.x][64], [gridDim.x][64]
   int n;
+  void *t_dc2, *t_dc1;              // test taps (null in production): dc2 [n*36][64], dc1 [n*225][32] as the kernel holds them (T)
 };
 template <typename T> struct BwdConvLds {
   static constexpr bool B16 = sizeof(T) == 2;
@@ -1007,6 +1008,7 @@ __global__ __launch_bounds__(512) void bwd_conv_kernel(BwdConv a) {
             const float d0 = mk.x > 0.f ? acc[m][0][0] + hi.x : 0.f, d1 = mk.y > 0.f ? acc[m][0][1] + hi.y : 0.f;
             const float d2 = mk.z > 0.f ? acc[m][0][2] + hi.z : 0.f, d3 = mk.w > 0.f ? acc[m][0][3] + hi.w : 0.f;
             st4(sdc2t + px * LY::LT + c4, d0, d1, d2, d3);  // [pixel][co]: the A operand of conv2' below
+            if (a.t_dc2 != nullptr) st4(reinterpret_cast<T*>(a.t_dc2) + ((int64_t)smp * 36 + px) * 64 + c4, d0, d1, d2, d3);
             T* tp = sdc2T + c4 * LY::LP2 + px;              // [co][pixel]: dW2's column fragments
             tp[0] = (T)d0; tp[LY::LP2] = (T)d1; tp[2 * LY::LP2] = (T)d2; tp[3 * LY::LP2] = (T)d3;
             b2r[0] += d0; b2r[1] += d1; b2r[2] += d2; b2r[3] += d3;
@@ -1083,6 +1085,7 @@ __global__ __launch_bounds__(512) void bwd_conv_kernel(BwdConv a) {
           const float d2 = mk.z > 0.f ? acc[m][0][2] : 0.f, d3 = mk.w > 0.f ? acc[m][0][3] : 0.f;
           T* tp = sdc1T + c4 * LY::LP1 + p;  // dc1 exists only as dW1's operand: [co][pixel]
           tp[0] = (T)d0; tp[LY::LP1] = (T)d1; tp[2 * LY::LP1] = (T)d2; tp[3 * LY::LP1] = (T)d3;
+          if (a.t_dc1 != nullptr) st4(reinterpret_cast<T*>(a.t_dc1) + ((int64_t)smp * 225 + p) * 32 + c4, d0, d1, d2, d3);
           b1r[0] += d0; b1r[1] += d1; b1r[2] += d2; b1r[3] += d3;
         }
       }

@@ -474,7 +474,7 @@ static bool conv_bwd_fusable(const v4l_net* N) {
 }
 template <typename T>
 static int conv_stack_bwd_fused(Ctx& c, const T* image, const int* rowidx, int n, const float* c1, const float* c2,
-                                const float* dc3) {
+                                const float* dc3, float* dc2_tap, float* dc1_tap) {
   v4l_net* N = c.net;
   static bool attr_done = false;
   if (!attr_done) {
@@ -508,6 +508,7 @@ static int conv_stack_bwd_fused(Ctx& c, const T* image, const int* rowidx, int n
   a.w3d = (const T*)N->packed + N->conv[2].pkd[0];
   for (int cls = 0; cls < 4; ++cls) a.w2d[cls] = (const T*)N->packed + N->conv[1].pkd[cls];
   a.image = image; a.rowidx = rowidx; a.c1 = c1; a.c2 = c2; a.dc3 = dc3;
+  if (getenv("V4L_LAYER_TAPS") != nullptr) { a.t_dc2 = dc2_tap; a.t_dc1 = dc1_tap; }  // (tests; read per call)
   a.slab1 = slab[0]; a.slab2 = slab[1]; a.slab3 = slab[2];
   a.bslab1 = bslab[0]; a.bslab2 = bslab[1]; a.bslab3 = bslab[2];
   a.n = n;
@@ -539,7 +540,7 @@ static int conv3_wgrad_deferred(Ctx& c, hipStream_t s) {
 template <typename T>
 static int conv_stack_bwd(Ctx& c, const T* image, const int* rowidx, int n, const float* c1, const float* c2,
                           float* dc3, float* dc2, float* dc1) {
-  if (conv_bwd_fusable(c.net)) return conv_stack_bwd_fused<T>(c, image, rowidx, n, c1, c2, dc3);
+  if (conv_bwd_fusable(c.net)) return conv_stack_bwd_fused<T>(c, image, rowidx, n, c1, c2, dc3, dc2, dc1);
   const v4l_net* N = c.net;
   const Conv* cv = N->conv;
   const float* acts[3] = {nullptr, c1, c2};   // input activation of conv i
