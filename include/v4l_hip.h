@@ -37,7 +37,7 @@
  *   V4L_LAYER_TAPS            tests: the wave-per-sample layer kernels and the fused conv backward also write every
  *                             intermediate into its v4l_net_ws_offset slot (production keeps them on chip) (per call)
  *   V4L_LAYER_SPW=2|4, V4L_LAYER_BWD_SPW=2|4      samples per block of the block-cooperative layer kernels
- *   V4L_CONV_BWD_BLOCKS, V4L_TRAIN_ENC_BLOCKS, V4L_WIDE_SPLITS   block / split counts (tests force ragged and many-samples-per-block shapes)
+ *   V4L_CONV_BWD_BLOCKS, V4L_CONV3_WGRAD_BLOCKS, V4L_TRAIN_ENC_BLOCKS, V4L_WIDE_SPLITS   block / split counts (tests force ragged and many-samples-per-block shapes)
  *   V4L_TRAIN_ENC_OLD, V4L_ROLLOUT_ENC_OLD        the streamed-weight encoder kernels
  *   V4L_ROLLOUT_WARM          L2 warm-up touches at the start of rollout_stack_kernel (measured: no effect)
  *   V4L_RCCL_LIB              path of the RCCL library to dlopen (default: librccl.so.1)

@@ -484,11 +484,17 @@ static int conv_stack_bwd_fused(Ctx& c, const T* image, const int* rowidx, int n
   }
   int nblk = std::min(n, CONV_BWD_MAX_BLOCKS);
   if (const char* e = getenv("V4L_CONV_BWD_BLOCKS")) nblk = std::max(1, std::min(nblk, atoi(e)));
+  // dW3's launch runs beside the dense weight-grads on the other stream (~54 us) and is not on the critical path: fewer,
+  // fatter blocks cut its partial slabs (256 -> 64 x 147 KB written, and read again by wgrad_reduce). Measured in one session,
+  // env-steps/s at 256 / 128 / 64 blocks: 357.8 K / 364.2 K / 367.6 K (the launch itself 24 -> 33 -> 53 us, wgrad_reduce 25.7 -> 22.0 us)
+  int nblk3 = std::min(nblk, 64);
+  if (const char* e = getenv("V4L_CONV3_WGRAD_BLOCKS")) nblk3 = std::max(1, std::min(nblk, atoi(e)));
   const int Ns[3] = {32, 64, 64}, Ks[3] = {256, 512, 576};
   float* slab[3];
   float* bslab[3];
   for (int i = 0; i < 3; ++i) {
-    const int64_t sf = ((int64_t)nblk * Ns[i] * Ks[i] + 63) / 64 * 64, bf = ((int64_t)nblk * Ns[i] + 63) / 64 * 64;
+    const int nb = i == 2 ? nblk3 : nblk;
+    const int64_t sf = ((int64_t)nb * Ns[i] * Ks[i] + 63) / 64 * 64, bf = ((int64_t)nb * Ns[i] + 63) / 64 * 64;
     slab[i] = c.slab + c.slab_used;
     bslab[i] = slab[i] + sf;
     c.slab_used += sf + bf;
@@ -499,7 +505,7 @@ static int conv_stack_bwd_fused(Ctx& c, const T* image, const int* rowidx, int n
     o.db = c.grads + N->params[v.b].goff;
     o.N = v.Cout; o.K = v.K; o.Ktorch = v.K;
     o.Cin = v.chw ? 0 : v.Cin; o.taps = v.chw ? 0 : v.KH * v.KH;
-    o.slab = slab[i]; o.bslab = bslab[i]; o.nsplit = nblk; o.Npad = Ns[i]; o.Kpad = Ks[i];
+    o.slab = slab[i]; o.bslab = bslab[i]; o.nsplit = nb; o.Npad = Ns[i]; o.Kpad = Ks[i];
     N->red.push_back(o);
   }
   V4L_REQUIRE(c.slab_used <= N->slab_cap, "internal: weight-grad slab arena overflow");
@@ -517,11 +523,11 @@ static int conv_stack_bwd_fused(Ctx& c, const T* image, const int* rowidx, int n
   V4L_KLAUNCH("fused_conv_bwd", fl, c.s, bwd_conv_kernel<T>, dim3(nblk), dim3(512), BwdConvLds<T>::bytes, c.s, a);
   V4L_LAUNCH_CHECK();
   if (c.defer_conv3) {
-    c.conv3_args = a; c.conv3_blocks = nblk; c.conv3_n = n; c.conv3_pending = true;
+    c.conv3_args = a; c.conv3_blocks = nblk3; c.conv3_n = n; c.conv3_pending = true;
     return 0;
   }
   g_op = "conv3.wgrad";
-  V4L_KLAUNCH("fused_conv3_wgrad", 2.0 * n * 16 * 64 * 576, c.tn, bwd_conv3_wgrad_kernel<T>, dim3(nblk), dim3(256), 0, c.tn, a);
+  V4L_KLAUNCH("fused_conv3_wgrad", 2.0 * n * 16 * 64 * 576, c.tn, bwd_conv3_wgrad_kernel<T>, dim3(nblk3), dim3(256), 0, c.tn, a);
   V4L_LAUNCH_CHECK();
   return 0;
 }
