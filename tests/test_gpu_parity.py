@@ -493,9 +493,20 @@ def test_graph_replay_equals_eager(mode, pair, device):
 def test_rollout_actor_matches_separate_calls(name, mode, graph, device):
     """RolloutActor.step (shared encoder pass, graph replay, device-side cursor) == pf.explore + vf of the reference
     protocol: same mean/std/value, action = mean + std*eps, rows/actions/values filed at slots [t*E,(t+1)*E)."""
+    _actor_vs_separate(name, mode, graph, device, 8, 4)
+
+
+@pytest.mark.parametrize("E", [16, 33, 64])
+@pytest.mark.parametrize("name", ["cnn_s93", "cnn_vis"])
+def test_dense_rollout_step_env_counts(name, E, device):
+    """The NatureCNN nets' rollout step runs its dense layers as GEMMs over all E rows (csrc/rollout_dense.h): the bench's
+    E = 16, a ragged last row tile (33) and the largest supported count (64) against the layer-by-layer module calls."""
+    _actor_vs_separate(name, "bf16", False, device, E, 2)
+
+
+def _actor_vs_separate(name, mode, graph, device, E, T):
     from vision4leg_amd.torchrl.policies import RolloutActor
     case = util.CASES[name]
-    E, T = 8, 4
     pf, vf = _build(case, mode, device)
     net = pf.hip
     net.ensure_bound()

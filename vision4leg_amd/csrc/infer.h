@@ -1530,9 +1530,18 @@ struct RollEnc2Lds {
   static constexpr size_t mlp_bytes = (size_t)32 * LDB * 2 + (size_t)2 * 32 * E::LDH * 2 + 576 * 4;
   static constexpr size_t bytes = conv_bytes > mlp_bytes ? conv_bytes : mlp_bytes;
 };
+// MODE: what leaves the block. ENC_TOK17: LocoTransformer tokens (fp32 x0[E][17][64]: token 0 = proprio branch, 1..16 = depth
+// up-conv). ENC_TOK16: the vision-only Transformer's 16 depth tokens (x0[E][16][64], no proprio blocks in the grid).
+// ENC_FLAT: conv3's NHWC flatten (k = pixel*64 + c) as operand-type rows featv[E][1024] for the dense layer that follows
+// (NatureEncoder(flatten), base.py:304-342), no proprio blocks. ENC_FUSE: the NatureFuseEncoder (base.py:345-385): featv as
+// ENC_FLAT, and the proprio blocks stop after the second Linear+ReLU and write featp[E][512] columns 256..511 (the right half
+// of the concat the head reads; rollout_linear_kernel fills the left half with the visual projector's output).
+enum { ENC_TOK17 = 0, ENC_FUSE = 1, ENC_FLAT = 2, ENC_TOK16 = 3 };
+template <int MODE>
 __global__ __launch_bounds__(1024) void rollout_encoder2_kernel(const ActCtl* __restrict__ ctl, const float* __restrict__ obs,
                                                                 int E, InfEncFrag w, float* __restrict__ state_roll,
-                                                                __bf16* __restrict__ image_roll, float* __restrict__ x0) {
+                                                                __bf16* __restrict__ image_roll, float* __restrict__ x0,
+                                                                __bf16* __restrict__ featv, __bf16* __restrict__ featp) {
   typedef __bf16 T;
   typedef bf16x8 frag_t;
   typedef InfEncLds<T> LY;
@@ -1591,7 +1600,7 @@ __global__ __launch_bounds__(1024) void rollout_encoder2_kernel(const ActCtl* __
     {
       f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
       mm_held<T, 2, 4>(acc, sb, LDB, r1, lane);
-      if (wave < 4) {
+      if (MODE == ENC_TOK17 && wave < 4) {
 #pragma unroll
         for (int ks = 0; ks < 8; ++ks) r3[ks] = gfrag(w.wpr, wave * 8 + ks);
       }
@@ -1601,6 +1610,18 @@ __global__ __launch_bounds__(1024) void rollout_encoder2_kernel(const ActCtl* __
     {
       f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
       mm_held<T, 2, 8>(acc, h1, LY::LDH, r2, lane);
+      if constexpr (MODE == ENC_FUSE) {  // the concat's right half, operand type
+        const int n4 = wave * 16 + qr;
+        const float4 bb = *reinterpret_cast<const float4*>(bs + 256 + n4);
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+          const int row = r0 + mt * 16 + fr;
+          if (row < E)
+            st4(featp + (int64_t)row * 512 + 256 + n4, fmaxf(acc[mt][0] + bb.x, 0.f), fmaxf(acc[mt][1] + bb.y, 0.f),
+                fmaxf(acc[mt][2] + bb.z, 0.f), fmaxf(acc[mt][3] + bb.w, 0.f));
+        }
+        return;
+      }
       store_h(h2, acc, bs + 256);
     }
     __syncthreads();
@@ -1653,7 +1674,7 @@ __global__ __launch_bounds__(1024) void rollout_encoder2_kernel(const ActCtl* __
 #pragma unroll
   for (int d = 0; d < 5; ++d) w3v[d] = gfrag(w.w3, nt3 * 18 + min(ks0 + d, 17));
 #pragma unroll
-  for (int ks = 0; ks < 2; ++ks) wuv[ks] = gfrag(w.wup, nt3 * 2 + ks);
+  for (int ks = 0; ks < 2; ++ks) wuv[ks] = gfrag(MODE == ENC_TOK17 || MODE == ENC_TOK16 ? w.wup : w.w3, nt3 * 2 + ks);
   __builtin_amdgcn_sched_barrier(0);
   {
     T* roll = image_roll + (slot0 + b) * (int64_t)LY::IMG;
@@ -1665,6 +1686,9 @@ __global__ __launch_bounds__(1024) void rollout_encoder2_kernel(const ActCtl* __
     }
     w1s[tid] = w1v;
     if (tid < 224) bs[tid] = bv;
+    if constexpr (MODE == ENC_FLAT || MODE == ENC_TOK16) {  // vision-only: the all-zero dummy state row of this slot
+      if (tid < w.Sp) state_roll[(slot0 + b) * w.Sp + tid] = 0.f;
+    }
   }
   __syncthreads();
   ROLL_STAMP(97);
@@ -1733,11 +1757,14 @@ __global__ __launch_bounds__(1024) void rollout_encoder2_kernel(const ActCtl* __
   {  // sum of the four K-quarters + bias + ReLU -> c3: one output per thread
     const int pix = tid >> 6, n = tid & 63;
     const float s4 = ((part[pix * 64 + n] + part[(16 + pix) * 64 + n]) + part[(32 + pix) * 64 + n]) + part[(48 + pix) * 64 + n];
-    c3[pix * LY::LD2 + n] = (T)fmaxf(s4 + bs[96 + n], 0.f);
+    const T o = (T)fmaxf(s4 + bs[96 + n], 0.f);
+    if constexpr (MODE == ENC_FUSE || MODE == ENC_FLAT) { featv[(int64_t)b * 1024 + tid] = o; return; }
+    c3[pix * LY::LD2 + n] = o;
   }
   __syncthreads();
   ROLL_STAMP(101);
-  if (wave < 4) {  // depth_up_conv (1x1, no activation) -> tokens 1..16
+  constexpr int TOKS = MODE == ENC_TOK16 ? 16 : NTOK, TOK0 = MODE == ENC_TOK16 ? 0 : 1;
+  if (wave < 4) {  // depth_up_conv (1x1, no activation) -> tokens 1..16 (vision-only: 0..15)
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
@@ -1746,7 +1773,7 @@ __global__ __launch_bounds__(1024) void rollout_encoder2_kernel(const ActCtl* __
     }
     const int n4 = wave * 16 + qr;
     const float4 bb = *reinterpret_cast<const float4*>(bs + 160 + n4);
-    st4(x0 + ((int64_t)b * NTOK + 1 + fr) * TD + n4, acc[0] + bb.x, acc[1] + bb.y, acc[2] + bb.z, acc[3] + bb.w);
+    st4(x0 + ((int64_t)b * TOKS + TOK0 + fr) * TD + n4, acc[0] + bb.x, acc[1] + bb.y, acc[2] + bb.z, acc[3] + bb.w);
   }
   ROLL_STAMP(102);
 }
@@ -1764,13 +1791,18 @@ struct TrainEnc {
   const float* state;    // [slots][Sp]
   const int* rowidx;     // [n] or null
   float *s_c1, *s_c2, *s_c3;  // [n][225][32], [n][36][64], [n][16][64]
-  float *s_h1, *s_h2;         // [n][256] encoder-MLP activations
-  int n, nmlp, nconv;
+  float *s_h1, *s_h2;         // [n][256] encoder-MLP activations (s_h2: row stride ld_h2)
+  int n, nmlp, nconv, ld_h2;
 };
 struct TrainEncLds {
   static constexpr size_t part_b = 4 * 16 * 64 * 4;
   static constexpr size_t bytes = RollEnc2Lds::conv_bytes + part_b;
 };
+// MODE as in rollout_encoder2_kernel: ENC_TOK17 (LocoTransformer), ENC_TOK16 (vision-only Transformer: no proprio blocks,
+// 16 tokens per sample), ENC_FLAT (NatureEncoder(flatten): the saved conv3 rows ARE the output), ENC_FUSE (NatureFuseEncoder:
+// the proprio blocks stop after the second Linear+ReLU, whose rows go to tr.s_h2 with row stride tr.ld_h2 — the right half
+// of the concat buffer; the visual projector over the saved conv3 rows is the caller's next launch).
+template <int MODE>
 __global__ __launch_bounds__(1024) void train_encoder_kernel(InfEncFrag w, TrainEnc tr, float* __restrict__ x0) {
   typedef __bf16 T;
   typedef bf16x8 frag_t;
@@ -1816,7 +1848,7 @@ __global__ __launch_bounds__(1024) void train_encoder_kernel(InfEncFrag w, Train
     }
     if (tid < 576) bs[tid] = bv;
     __syncthreads();
-    auto store_h = [&](T* h, const f32x4 (&acc)[2], const float* bias, float* save) {
+    auto store_h = [&](T* h, const f32x4 (&acc)[2], const float* bias, float* save, int lds) {
       const int n4 = wave * 16 + qr;
       const float4 bb = *reinterpret_cast<const float4*>(bias + n4);
 #pragma unroll
@@ -1824,24 +1856,25 @@ __global__ __launch_bounds__(1024) void train_encoder_kernel(InfEncFrag w, Train
         const float v0 = fmaxf(acc[mt][0] + bb.x, 0.f), v1 = fmaxf(acc[mt][1] + bb.y, 0.f);
         const float v2 = fmaxf(acc[mt][2] + bb.z, 0.f), v3 = fmaxf(acc[mt][3] + bb.w, 0.f);
         st4(h + (mt * 16 + fr) * LY::LDH + n4, v0, v1, v2, v3);
-        if (r0 + mt * 16 + fr < n) st4(save + (int64_t)(r0 + mt * 16 + fr) * 256 + n4, v0, v1, v2, v3);
+        if (r0 + mt * 16 + fr < n) st4(save + (int64_t)(r0 + mt * 16 + fr) * lds + n4, v0, v1, v2, v3);
       }
     };
     {
       f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
       mm_held<T, 2, 4>(acc, sb, LDB, r1, lane);
-      if (wave < 4) {
+      if (MODE == ENC_TOK17 && wave < 4) {
 #pragma unroll
         for (int ks = 0; ks < 8; ++ks) r3[ks] = gfrag(w.wpr, wave * 8 + ks);
       }
-      store_h(h1, acc, bs, tr.s_h1);
+      store_h(h1, acc, bs, tr.s_h1, 256);
     }
     __syncthreads();
     {
       f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
       mm_held<T, 2, 8>(acc, h1, LY::LDH, r2, lane);
-      store_h(h2, acc, bs + 256, tr.s_h2);
+      store_h(h2, acc, bs + 256, tr.s_h2, tr.ld_h2);
     }
+    if constexpr (MODE != ENC_TOK17) return;
     __syncthreads();
     if (wave < 4) {
       f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
@@ -1892,7 +1925,7 @@ __global__ __launch_bounds__(1024) void train_encoder_kernel(InfEncFrag w, Train
 #pragma unroll
   for (int d = 0; d < 5; ++d) w3v[d] = gfrag(w.w3, nt3 * 18 + min(ks0 + d, 17));
 #pragma unroll
-  for (int ks = 0; ks < 2; ++ks) wuv[ks] = gfrag(w.wup, nt3 * 2 + ks);
+  for (int ks = 0; ks < 2; ++ks) wuv[ks] = gfrag(MODE == ENC_TOK17 || MODE == ENC_TOK16 ? w.wup : w.w3, nt3 * 2 + ks);
   __builtin_amdgcn_sched_barrier(0);
   reinterpret_cast<frag_t*>(img)[tid] = iv[0];
   reinterpret_cast<frag_t*>(img)[tid + 1024] = iv[1];
@@ -1984,7 +2017,8 @@ __global__ __launch_bounds__(1024) void train_encoder_kernel(InfEncFrag w, Train
       tr.s_c3[((int64_t)smp * 16 + pix) * 64 + nn] = v;
     }
     __syncthreads();
-    if (wave < 4) {  // depth_up_conv (1x1, no activation) -> tokens 1..16
+    constexpr int TOKS = MODE == ENC_TOK16 ? 16 : NTOK, TOK0 = MODE == ENC_TOK16 ? 0 : 1;
+    if ((MODE == ENC_TOK17 || MODE == ENC_TOK16) && wave < 4) {  // depth_up_conv (1x1, no activation) -> tokens 1..16 (vision-only: 0..15)
       f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) {
@@ -1993,7 +2027,7 @@ __global__ __launch_bounds__(1024) void train_encoder_kernel(InfEncFrag w, Train
       }
       const int n4 = wave * 16 + qr;
       const float4 bb = *reinterpret_cast<const float4*>(bs + 160 + n4);
-      st4(x0 + ((int64_t)smp * NTOK + 1 + fr) * TD + n4, acc[0] + bb.x, acc[1] + bb.y, acc[2] + bb.z, acc[3] + bb.w);
+      st4(x0 + ((int64_t)smp * TOKS + TOK0 + fr) * TD + n4, acc[0] + bb.x, acc[1] + bb.y, acc[2] + bb.z, acc[3] + bb.w);
     }
     // (no barrier: the next round's conv1 only reads img / w1s and writes c1, which conv2 of this round has finished reading)
   }

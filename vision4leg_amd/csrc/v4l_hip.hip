@@ -3,6 +3,7 @@
 #include <stdarg.h>
 
 #include <algorithm>
+#include <type_traits>
 
 #include <dlfcn.h>
 
@@ -10,6 +11,7 @@
 #include "infer.h"
 #include "bwd.h"
 #include "wps.h"
+#include "rollout_dense.h"
 
 namespace v4l {
 
@@ -860,11 +862,16 @@ int v4l_net::build() {
     }
     upconv.pkpt = add_pack(upconv.w, PK_FRAGPT, upconv.K, upconv.N, upconv.N, upconv.K, 0, 0, 0, 0, 0, 0, 0);
   }
-  if (c.kind == V4L_NET_LOCO) {  // the rollout step streams these as whole MFMA fragments (rollout_stack_kernel)
-    auto pack_frag = [&](Lin& L) { L.pkf = add_pack(L.w, PK_FRAG, L.Np, L.Kp, L.N, L.K, 0, 0, 0, 0, 0, 0, 0); };
-    for (TLayer& t : layers) { pack_frag(t.inproj); pack_frag(t.outproj); pack_frag(t.ff1); pack_frag(t.ff2); }
-    for (Lin& L : head) pack_frag(L);
-    pack_frag(upconv); pack_frag(proj);
+  if (c.kind != V4L_NET_MLP) {
+    // the rollout step streams these as whole MFMA fragments (rollout_stack_kernel, rollout_encoder2_kernel, csrc/rollout_dense.h);
+    // a linear that reads conv3's NHWC rows keeps that k order (L.cin / L.taps, as in its PK_CONV_NHWC pack)
+    auto pack_frag = [&](Lin& L) { L.pkf = add_pack(L.w, PK_FRAG, L.Np, L.Kp, L.N, L.K, L.cin, L.taps, 0, 0, 0, 0, 0); };
+    if (c.kind == V4L_NET_LOCO)
+      for (TLayer& t : layers) { pack_frag(t.inproj); pack_frag(t.outproj); pack_frag(t.ff1); pack_frag(t.ff2); }
+    if (c.kind != V4L_NET_LOCO_VIS)
+      for (Lin& L : head) pack_frag(L);
+    if (is_tf()) pack_frag(upconv);
+    if (c.kind == V4L_NET_CNN || c.kind == V4L_NET_LOCO) pack_frag(proj);
     for (Lin& L : enc) pack_frag(L);
     for (int i = 0; i < 3; ++i) {
       Conv& v = conv[i];
@@ -1002,6 +1009,47 @@ int v4l_net::forward_t(const float* state, const T* image, const int* rowidx, in
   Act eacts[V4L_MAX_HIDDEN];
   for (int i = 0; i < ne; ++i) eacts[i] = Act{ws + L.eh[i], c.enc_hidden[i], c.enc_hidden[i]};
   ADense head_in;
+  // persistent 16-wave encoder blocks (csrc/infer.h train_encoder_kernel<MODE>): conv weights enter a CU once, not once per
+  // sample; saves c1 / c2 / c3 (what the conv backward reads) and, with a proprio branch, the two MLP activations
+  static const bool persistent_enc = getenv("V4L_TRAIN_ENC_OLD") == nullptr;
+  const bool mlp256 = ne == 2 && c.enc_hidden[0] == 256 && c.enc_hidden[1] == 256 && c.state_dim <= 128;
+  const bool train_enc_ok = persistent_enc && sizeof(T) == 2 && c.kind != V4L_NET_MLP && conv[0].pkf >= 0 &&
+                            getenv("V4L_NO_FUSED_ENC") == nullptr &&
+                            (vis_only() || (mlp256 && enc[0].Kp == 128 && enc[0].pkf >= 0));
+  auto train_enc = [&](auto mode_tag, float* x0, float* s_h2, int ld_h2) -> int {
+    constexpr int MODE = decltype(mode_tag)::value;
+    static bool attr = false;
+    if (!attr) {
+      V4L_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&train_encoder_kernel<MODE>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)TrainEncLds::bytes));
+      attr = true;
+    }
+    const __bf16* pb = (const __bf16*)packed;
+    const bool tok = MODE == ENC_TOK17 || MODE == ENC_TOK16, prop = MODE == ENC_TOK17 || MODE == ENC_FUSE;
+    InfEncFrag ef;
+    memset(&ef, 0, sizeof(ef));
+    ef.w1 = pb + conv[0].pkf; ef.w2 = pb + conv[1].pkf; ef.w3 = pb + conv[2].pkf; ef.wup = tok ? pb + upconv.pkf : ef.w3;
+    ef.b1 = p[conv[0].b]; ef.b2 = p[conv[1].b]; ef.b3 = p[conv[2].b]; ef.bup = tok ? p[upconv.b] : ef.b3;
+    if (prop) {
+      ef.wf1 = pb + enc[0].pkf; ef.wf2 = pb + enc[1].pkf; ef.wpr = MODE == ENC_TOK17 ? pb + proj.pkf : ef.wf2;
+      ef.bf1 = p[enc[0].b]; ef.bf2 = p[enc[1].b]; ef.bpr = MODE == ENC_TOK17 ? p[proj.b] : ef.bf2;
+    }
+    ef.S = c.state_dim; ef.Sp = Sp;
+    TrainEnc te;
+    te.image = (const __bf16*)image; te.state = state; te.rowidx = rowidx;
+    te.s_c1 = ws + L.c1; te.s_c2 = ws + L.c2; te.s_c3 = ws + L.c3;
+    te.s_h1 = prop ? ws + L.eh[0] : nullptr; te.s_h2 = s_h2; te.ld_h2 = ld_h2;
+    te.n = n; te.nmlp = prop ? cdiv(n, 32) : 0;
+    static const int cus = getenv("V4L_TRAIN_ENC_BLOCKS") ? atoi(getenv("V4L_TRAIN_ENC_BLOCKS")) : 256;
+    // the conv share never collapses: a very large minibatch (n >~ 8 K: nmlp -> cus) still gets half the CUs' worth of
+    // persistent conv blocks (the MLP blocks are short; the two kinds then simply run in two waves over the chip)
+    te.nconv = std::max(1, std::min(n, std::max(cus / 2, cus - te.nmlp)));
+    g_op = "encoder";
+    V4L_KLAUNCH("fused_encoder", 2.0 * n * 3784064.0, s, train_encoder_kernel<MODE>, dim3(te.nmlp + te.nconv), dim3(1024),
+                TrainEncLds::bytes, s, ef, te, x0);
+    V4L_LAUNCH_CHECK();
+    return 0;
+  };
   if (c.kind == V4L_NET_MLP) {
     if (enc_ws != nullptr) eacts[ne - 1].p = const_cast<float*>(enc_ws) + L.eh[ne - 1];
     else if (stage != 2 && (rc = chain_fwd<T>(cx, enc.data(), ne, sin, eacts, true))) return rc;
@@ -1011,7 +1059,13 @@ int v4l_net::forward_t(const float* state, const T* image, const int* rowidx, in
     head_in = dense(enc_ws + L.vis, cw, n, cw);
   } else if (c.kind == V4L_NET_CNN) {
     const int cw = c.visual_dim + c.enc_hidden[ne - 1];
-    if (stage != 2) {
+    if (stage != 2 && train_enc_ok) {
+      // one launch: conv stack + proprio MLP (its last activation lands in the concat buffer's right half), then the
+      // visual projector on the NHWC flatten of conv3 -> columns [0, visual_dim)
+      if ((rc = train_enc(std::integral_constant<int, ENC_FUSE>(), nullptr, ws + L.vis + c.visual_dim, cw))) return rc;
+      Epi ep = mk_epi(ws + L.vis, cw, c.visual_dim, nullptr, 1);
+      if ((rc = lin_fwd<T>(cx, proj, dense(ws + L.c3, 1024, n, 1024), ep))) return rc;
+    } else if (stage != 2) {
       // proprio MLP on the aux stream next to the conv stack; both land in the concat buffer
       if ((rc = par_begin(cx))) return rc;
       Ctx cx2 = cx;
@@ -1028,8 +1082,11 @@ int v4l_net::forward_t(const float* state, const T* image, const int* rowidx, in
   } else if (c.kind == V4L_NET_CNN_VIS) {
     // NatureEncoderProjNet (nets.py:176-191): conv stack -> Flatten -> head; the flatten is conv3's NHWC rows, the
     // first head layer's pack carries the NCHW -> NHWC permutation
-    if (enc_ws == nullptr && stage != 2 && (rc = conv_stack_fwd<T>(cx, image, rowidx, n, ws + L.c1, ws + L.c2, ws + L.c3)))
-      return rc;
+    if (enc_ws == nullptr && stage != 2) {
+      if (train_enc_ok) rc = train_enc(std::integral_constant<int, ENC_FLAT>(), nullptr, nullptr, 0);
+      else rc = conv_stack_fwd<T>(cx, image, rowidx, n, ws + L.c1, ws + L.c2, ws + L.c3);
+      if (rc) return rc;
+    }
     head_in = dense((enc_ws != nullptr ? enc_ws : ws) + L.c3, 1024, n, 1024);
   } else {
     float* x0 = enc_ws != nullptr ? const_cast<float*>(enc_ws) + L.x[0] : ws + L.x[0];
@@ -1055,32 +1112,8 @@ int v4l_net::forward_t(const float* state, const T* image, const int* rowidx, in
       tr.image = image; tr.state = state; tr.rowidx = rowidx;
       tr.s_c1 = ws + L.c1; tr.s_c2 = ws + L.c2; tr.s_c3 = ws + L.c3; tr.s_h1 = ws + L.eh[0]; tr.s_h2 = ws + L.eh[1];
       g_op = "encoder";
-      static const bool persistent_enc = getenv("V4L_TRAIN_ENC_OLD") == nullptr;
-      if (persistent_enc && sizeof(T) == 2 && enc[0].Kp == 128 && conv[0].pkf >= 0 && c.kind == V4L_NET_LOCO) {
-        // persistent 16-wave blocks: conv weights enter a CU once, not once per sample (csrc/infer.h train_encoder_kernel)
-        static bool attr2 = false;
-        if (!attr2) {
-          V4L_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&train_encoder_kernel),
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)TrainEncLds::bytes));
-          attr2 = true;
-        }
-        const __bf16* pb = (const __bf16*)packed;
-        InfEncFrag ef;
-        ef.w1 = pb + conv[0].pkf; ef.w2 = pb + conv[1].pkf; ef.w3 = pb + conv[2].pkf; ef.wup = pb + upconv.pkf;
-        ef.b1 = en.b1; ef.b2 = en.b2; ef.b3 = en.b3; ef.bup = en.bup;
-        ef.wf1 = pb + enc[0].pkf; ef.wf2 = pb + enc[1].pkf; ef.wpr = pb + proj.pkf;
-        ef.bf1 = en.bf1; ef.bf2 = en.bf2; ef.bpr = en.bpr;
-        ef.S = en.S; ef.Sp = en.Sp;
-        TrainEnc te;
-        te.image = (const __bf16*)image; te.state = state; te.rowidx = rowidx;
-        te.s_c1 = tr.s_c1; te.s_c2 = tr.s_c2; te.s_c3 = tr.s_c3; te.s_h1 = tr.s_h1; te.s_h2 = tr.s_h2;
-        te.n = n; te.nmlp = cdiv(n, 32);
-        static const int cus = getenv("V4L_TRAIN_ENC_BLOCKS") ? atoi(getenv("V4L_TRAIN_ENC_BLOCKS")) : 256;
-        // the conv share never collapses: a very large minibatch (n >~ 8 K: nmlp -> cus) still gets half the CUs' worth of
-        // persistent conv blocks (the MLP blocks are short; the two kinds then simply run in two waves over the chip)
-        te.nconv = std::max(1, std::min(n, std::max(cus / 2, cus - te.nmlp)));
-        V4L_KLAUNCH("fused_encoder", 2.0 * n * 3784064.0, s, train_encoder_kernel, dim3(te.nmlp + te.nconv), dim3(1024),
-                    TrainEncLds::bytes, s, ef, te, x0);
+      if (train_enc_ok && c.kind == V4L_NET_LOCO) {
+        if ((rc = train_enc(std::integral_constant<int, ENC_TOK17>(), x0, ws + L.eh[1], 256))) return rc;
       } else {
         V4L_KLAUNCH("fused_encoder", 2.0 * n * 3784064.0, s, infer_encoder_kernel<T>, dim3(n + cdiv(n, 32)), dim3(256),
                     InfEncLds<T>::bytes, s, (const ActCtl*)nullptr, (const float*)nullptr, n, en, (float*)nullptr, (T*)nullptr, x0,
@@ -1089,8 +1122,12 @@ int v4l_net::forward_t(const float* state, const T* image, const int* rowidx, in
       V4L_LAUNCH_CHECK();
     } else if (enc_ws == nullptr && stage != 2 && c.kind == V4L_NET_LOCO_VIS) {
       // TransformerEncoder (base.py:388-494, depth only): conv stack -> 1x1 up-conv -> the 16 patch tokens, in order
-      if ((rc = conv_stack_fwd<T>(cx, image, rowidx, n, ws + L.c1, ws + L.c2, ws + L.c3))) return rc;
-      if ((rc = lin_fwd<T>(cx, upconv, dense(ws + L.c3, 64, n * 16, 64), mk_epi(x0, TD, TD)))) return rc;
+      if (train_enc_ok) {
+        if ((rc = train_enc(std::integral_constant<int, ENC_TOK16>(), x0, nullptr, 0))) return rc;
+      } else {
+        if ((rc = conv_stack_fwd<T>(cx, image, rowidx, n, ws + L.c1, ws + L.c2, ws + L.c3))) return rc;
+        if ((rc = lin_fwd<T>(cx, upconv, dense(ws + L.c3, 64, n * 16, 64), mk_epi(x0, TD, TD)))) return rc;
+      }
     } else if (enc_ws == nullptr && stage != 2) {
       // proprio branch (MLP + state_projector -> token 0) on the aux stream next to the conv branch (-> tokens 1..16)
       if ((rc = par_begin(cx))) return rc;
@@ -1734,6 +1771,106 @@ static int run_actor_fused_cnn(v4l_actor* a, const float* obs, const float* eps,
   return 0;
 }
 
+// NatureCNN nets (fuse net and vision-only), bf16: the step as batched GEMMs over all E rows (csrc/rollout_dense.h)
+static bool actor_dense_cnn(const v4l_actor* a) {
+  const v4l_net_cfg &p = a->pf->cfg, &v = a->vf->cfg;
+  auto ok = [](const v4l_net_cfg& c) {
+    const bool shape = c.n_head_hidden == 2 && c.head_hidden[0] == 256 && c.head_hidden[1] == 256 && c.in_channels == 4 &&
+                       c.img_hw == 64 && c.out_dim <= 16 && c.compute == V4L_BF16;
+    if (c.kind == V4L_NET_CNN)
+      return shape && c.n_enc_hidden == 2 && c.enc_hidden[0] == 256 && c.enc_hidden[1] == 256 && c.visual_dim == 256 &&
+             c.state_dim <= 128;
+    return shape && c.kind == V4L_NET_CNN_VIS;
+  };
+  return ok(p) && ok(v) && a->E <= 64 && a->pf->conv[0].pkf >= 0 && a->pf->head[0].pkf >= 0 && a->vf->head[0].pkf >= 0 &&
+         (p.kind == V4L_NET_CNN_VIS || a->pf->enc[0].Kp == 128) && getenv("V4L_NO_FUSED_ACTOR") == nullptr &&
+         getenv("V4L_ROLLOUT_CNN_OLD") == nullptr;
+}
+static int run_actor_dense_cnn(v4l_actor* a, const float* obs, const float* eps, float* state_roll, void* image_roll,
+                               float* acts_roll, float* values_roll, float* logp_roll, float* action, float* mean, float* stdv,
+                               float* ent, float* value, hipStream_t s) {
+  v4l_net *pf = a->pf, *vf = a->vf;
+  const int E = a->E;
+  const bool fuse = pf->cfg.kind == V4L_NET_CNN;
+  static bool attr_done = false;
+  if (!attr_done) {
+    V4L_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&rollout_encoder2_kernel<ENC_FUSE>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)RollEnc2Lds::bytes));
+    V4L_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&rollout_encoder2_kernel<ENC_FLAT>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)RollEnc2Lds::bytes));
+    V4L_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&rollout_head_kernel),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)RollHeadLds::bytes));
+    attr_done = true;
+  }
+  const __bf16* pk = (const __bf16*)pf->packed;
+  const __bf16* vk = (const __bf16*)vf->packed;
+  const Layout Lp = pf->layout(E), Lv = vf->layout(E);
+  float* ws_pf = a->ws;
+  float* ws_vf = a->ws + Lp.total;
+  // operand-type scratch rows inside the actor's workspace: conv3 flatten [E][1024], the concat [E][512], fc0 outputs [E][256]
+  __bf16* featv = reinterpret_cast<__bf16*>(ws_pf + Lp.c3);
+  __bf16* cat = fuse ? reinterpret_cast<__bf16*>(ws_pf + Lp.vis) : nullptr;
+  __bf16* h0p = reinterpret_cast<__bf16*>(ws_pf + Lp.hh[0]);
+  __bf16* h0v = reinterpret_cast<__bf16*>(ws_vf + Lv.hh[0]);
+  PhaseScope ps("rollout");
+  InfEncFrag ef;
+  memset(&ef, 0, sizeof(ef));
+  ef.w1 = pk + pf->conv[0].pkf; ef.w2 = pk + pf->conv[1].pkf; ef.w3 = pk + pf->conv[2].pkf; ef.wup = ef.w3;
+  ef.b1 = pf->p[pf->conv[0].b]; ef.b2 = pf->p[pf->conv[1].b]; ef.b3 = pf->p[pf->conv[2].b]; ef.bup = ef.b3;
+  ef.S = pf->cfg.state_dim; ef.Sp = pf->Sp;
+  g_op = "encoder";
+  if (fuse) {
+    ef.wf1 = pk + pf->enc[0].pkf; ef.wf2 = pk + pf->enc[1].pkf; ef.wpr = ef.wf2;
+    ef.bf1 = pf->p[pf->enc[0].b]; ef.bf2 = pf->p[pf->enc[1].b]; ef.bpr = ef.bf2;
+    V4L_KLAUNCH("rollout_encoder", 2.0 * E * (3612672.0 + 128 * 256 + 256 * 256), s, rollout_encoder2_kernel<ENC_FUSE>,
+                dim3(E + cdiv(E, 32)), dim3(1024), RollEnc2Lds::bytes, s, (const ActCtl*)a->ctl, obs, E, ef, state_roll,
+                (__bf16*)image_roll, (float*)nullptr, featv, cat);
+  } else {
+    V4L_KLAUNCH("rollout_encoder", 2.0 * E * 3612672.0, s, rollout_encoder2_kernel<ENC_FLAT>, dim3(E), dim3(1024),
+                RollEnc2Lds::bytes, s, (const ActCtl*)a->ctl, obs, E, ef, state_roll, (__bf16*)image_roll, (float*)nullptr,
+                featv, (__bf16*)nullptr);
+  }
+  V4L_LAUNCH_CHECK();
+  g_op = "dense";
+  RollLin fc0;
+  memset(&fc0, 0, sizeof(fc0));
+  fc0.w[0] = pk + pf->head[0].pkf; fc0.w[1] = vk + vf->head[0].pkf;
+  fc0.b[0] = pf->p[pf->head[0].b]; fc0.b[1] = vf->p[vf->head[0].b];
+  fc0.y[0] = h0p; fc0.y[1] = h0v; fc0.ldy = 256;
+  if (fuse) {
+    RollLin pr;
+    memset(&pr, 0, sizeof(pr));
+    pr.w[0] = pk + pf->proj.pkf; pr.b[0] = pf->p[pf->proj.b]; pr.x[0] = featv; pr.ldx = 1024; pr.y[0] = cat; pr.ldy = 512;
+    V4L_KLAUNCH("rollout_linear", 2.0 * E * 1024 * 256, s, rollout_linear_kernel<32>, dim3(16, 1), dim3(64), 0, s, pr, E);
+    V4L_LAUNCH_CHECK();
+    fc0.x[0] = fc0.x[1] = cat; fc0.ldx = 512;
+    V4L_KLAUNCH("rollout_linear", 2.0 * 2 * E * 512 * 256, s, rollout_linear_kernel<16>, dim3(16, 2), dim3(64), 0, s, fc0, E);
+  } else {
+    fc0.x[0] = fc0.x[1] = featv; fc0.ldx = 1024;
+    V4L_KLAUNCH("rollout_linear", 2.0 * 2 * E * 1024 * 256, s, rollout_linear_kernel<32>, dim3(16, 2), dim3(64), 0, s, fc0, E);
+  }
+  V4L_LAUNCH_CHECK();
+  RollHead hd;
+  memset(&hd, 0, sizeof(hd));
+  auto head = [&](int i, v4l_net* net, const __bf16* base, const __bf16* x, float* out) {
+    hd.wb[i] = base + net->head[1].pkf; hd.wo[i] = base + net->head[2].pkf;
+    hd.bb[i] = net->p[net->head[1].b]; hd.bo[i] = net->p[net->head[2].b];
+    hd.x[i] = x; hd.out[i] = out; hd.nout[i] = net->cfg.out_dim;
+  };
+  head(0, pf, pk, h0p, ws_pf + Lp.out);
+  head(1, vf, vk, h0v, ws_vf + Lv.out);
+  InfFinish fin;
+  memset(&fin, 0, sizeof(fin));
+  fin.ctl = a->ctl; fin.logstd = pf->p[pf->logstd]; fin.eps = eps; fin.A = pf->cfg.out_dim;
+  fin.acts_roll = acts_roll; fin.values_roll = values_roll; fin.logp_roll = logp_roll; fin.action = action;
+  fin.mean = mean; fin.stdv = stdv; fin.ent = ent; fin.value = value;
+  g_op = "head";
+  V4L_KLAUNCH("rollout_head", 2.0 * 2 * E * (256 * 256 + 256 * 16), s, rollout_head_kernel, dim3(2), dim3(512), RollHeadLds::bytes,
+              s, hd, fin, E);
+  V4L_LAUNCH_CHECK();
+  return 0;
+}
+
 // state-only MLP nets of the shipped shape: one launch per env step (rollout_mlp_kernel)
 static bool actor_fusable_mlp(const v4l_actor* a) {
   const v4l_net_cfg &p = a->pf->cfg, &v = a->vf->cfg;
@@ -1811,7 +1948,7 @@ static int run_actor_fused(v4l_actor* a, const float* obs, const float* eps, flo
   if (enc2 && sizeof(T) == 2 && pf->enc.size() == 2 && pf->enc[0].Kp == 128 && pf->conv[0].pkf >= 0) {
     static bool attr2 = false;
     if (!attr2) {
-      V4L_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&rollout_encoder2_kernel),
+      V4L_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&rollout_encoder2_kernel<ENC_TOK17>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)RollEnc2Lds::bytes));
       attr2 = true;
     }
@@ -1822,8 +1959,9 @@ static int run_actor_fused(v4l_actor* a, const float* obs, const float* eps, flo
     ef.wf1 = pb + pf->enc[0].pkf; ef.wf2 = pb + pf->enc[1].pkf; ef.wpr = pb + pf->proj.pkf;
     ef.bf1 = en.bf1; ef.bf2 = en.bf2; ef.bpr = en.bpr;
     ef.S = en.S; ef.Sp = en.Sp;
-    V4L_KLAUNCH("rollout_encoder", 2.0 * E * 3678208.0, s, rollout_encoder2_kernel, dim3(E + cdiv(E, 32)), dim3(1024),
-                RollEnc2Lds::bytes, s, (const ActCtl*)a->ctl, obs, E, ef, state_roll, (__bf16*)image_roll, x0);
+    V4L_KLAUNCH("rollout_encoder", 2.0 * E * 3678208.0, s, rollout_encoder2_kernel<ENC_TOK17>, dim3(E + cdiv(E, 32)), dim3(1024),
+                RollEnc2Lds::bytes, s, (const ActCtl*)a->ctl, obs, E, ef, state_roll, (__bf16*)image_roll, x0, (__bf16*)nullptr,
+                (__bf16*)nullptr);
   } else  // fp32 parity mode (fragments twice the size): weights streamed per wave
     V4L_KLAUNCH("rollout_encoder", 2.0 * E * 3678208.0, s, rollout_encoder_kernel<T>, dim3(E + cdiv(E, 32)), dim3(1024),
                 InfEncLds<T>::bytes, s, (const ActCtl*)a->ctl, obs, E, en, state_roll, (T*)image_roll, x0);
@@ -2241,6 +2379,9 @@ static int run_actor_step(v4l_actor* a, const float* obs, const float* eps, floa
                                          value, s);
     return run_actor_fused_mlp<float>(a, obs, eps, state_roll, acts_roll, values_roll, logp_roll, action, mean, stdv, ent, value, s);
   }
+  if (shared_encoder && actor_dense_cnn(a))
+    return run_actor_dense_cnn(a, obs, eps, state_roll, image_roll, acts_roll, values_roll, logp_roll, action, mean, stdv, ent,
+                               value, s);
   if (shared_encoder && actor_fusable_cnn(a) && pf->enc[0].Kp <= 128) {
     if (pf->cfg.compute == V4L_BF16)
       return run_actor_fused_cnn<__bf16>(a, obs, eps, state_roll, image_roll, acts_roll, values_roll, logp_roll, action, mean,
