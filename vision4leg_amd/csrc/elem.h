@@ -270,7 +270,9 @@ __global__ __launch_bounds__(64) void pool_all_bwd_kernel(const float* __restric
 
 // --------------------------------------------------------------------------------- rollout step (actor)
 // Device-side cursor of the rollout: env step t of the epoch owns rollout slots [t*E, (t+1)*E).
-struct ActCtl { long long t; unsigned long long done; };  // done: blocks of the step's last kernel that have finished
+// done: blocks of the step's last kernel that have finished. seq / stage / err: the hand-over counters of rollout_dense_kernel
+// (csrc/rollout_dense.h) — monotonic, never reset; the actor's control block starts zeroed (v4l_actor_bind)
+struct ActCtl { long long t; unsigned long long done; unsigned seq, err; unsigned stage[6]; };
 __global__ void act_set_kernel(ActCtl* c, long long t) { c->t = t; c->done = 0; }
 __global__ __launch_bounds__(256) void act_begin_kernel(const ActCtl* __restrict__ c, int E, int* __restrict__ rowidx) {
   const long long t = c->t;

@@ -1537,6 +1537,12 @@ struct RollEnc2Lds {
 // ENC_FLAT, and the proprio blocks stop after the second Linear+ReLU and write featp[E][512] columns 256..511 (the right half
 // of the concat the head reads; rollout_linear_kernel fills the left half with the visual projector's output).
 enum { ENC_TOK17 = 0, ENC_FUSE = 1, ENC_FLAT = 2, ENC_TOK16 = 3 };
+// featv / featp rows are handed to the dense launches in MFMA A-fragment order, so that a consumer wave reads a whole
+// fragment as one contiguous 1 KB block: element (row, k) of a [rows][32*KS] operand sits at act_frag_off(row, k, KS)
+// (a row-major [E][1024] operand would be read 16 bytes per lane at a 2 KB row stride: measured 6 us per row tile)
+__device__ __forceinline__ int64_t act_frag_off(int row, int k, int KS) {
+  return ((((int64_t)(row >> 4) * KS + (k >> 5)) * 64 + ((k >> 3) & 3) * 16 + (row & 15)) << 3) + (k & 7);
+}
 template <int MODE>
 __global__ __launch_bounds__(1024) void rollout_encoder2_kernel(const ActCtl* __restrict__ ctl, const float* __restrict__ obs,
                                                                 int E, InfEncFrag w, float* __restrict__ state_roll,
@@ -1617,7 +1623,7 @@ __global__ __launch_bounds__(1024) void rollout_encoder2_kernel(const ActCtl* __
         for (int mt = 0; mt < 2; ++mt) {
           const int row = r0 + mt * 16 + fr;
           if (row < E)
-            st4(featp + (int64_t)row * 512 + 256 + n4, fmaxf(acc[mt][0] + bb.x, 0.f), fmaxf(acc[mt][1] + bb.y, 0.f),
+            st4(featp + act_frag_off(row, 256 + n4, 16), fmaxf(acc[mt][0] + bb.x, 0.f), fmaxf(acc[mt][1] + bb.y, 0.f),
                 fmaxf(acc[mt][2] + bb.z, 0.f), fmaxf(acc[mt][3] + bb.w, 0.f));
         }
         return;
@@ -1758,7 +1764,7 @@ __global__ __launch_bounds__(1024) void rollout_encoder2_kernel(const ActCtl* __
     const int pix = tid >> 6, n = tid & 63;
     const float s4 = ((part[pix * 64 + n] + part[(16 + pix) * 64 + n]) + part[(32 + pix) * 64 + n]) + part[(48 + pix) * 64 + n];
     const T o = (T)fmaxf(s4 + bs[96 + n], 0.f);
-    if constexpr (MODE == ENC_FUSE || MODE == ENC_FLAT) { featv[(int64_t)b * 1024 + tid] = o; return; }
+    if constexpr (MODE == ENC_FUSE || MODE == ENC_FLAT) { featv[act_frag_off(b, tid, 32)] = o; return; }
     c3[pix * LY::LD2 + n] = o;
   }
   __syncthreads();

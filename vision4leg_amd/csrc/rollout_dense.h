@@ -20,16 +20,17 @@ namespace v4l {
 struct RollLin {
   const void* w[2];       // PK_FRAG pack [N/16][K/32][64] fragments, per net
   const float* b[2];
-  const __bf16* x[2];     // [E][ldx]
-  __bf16* y[2];           // [E][ldy] (+ column offset folded into the pointer)
-  int ldx, ldy;
+  const __bf16* x[2];     // [ceil16(E)][32*KS] in A-fragment order (act_frag_off)
+  __bf16* y[2];           // ks_out > 0: columns of a fragment-order [.][32*ks_out] operand; 0: row-major [E][ldy]
+  int ks_out, ldy;
 };
 // y[:, tile*16 .. +16] = relu(x . W[tile]^T + b): one wave per (column tile, net); the tile's KS weight fragments and one
-// row tile's KS activation fragments are all in flight at once (the launch is one dependent round trip + KS MFMAs long)
+// row tile's KS activation fragments (each one contiguous 1 KB read) are all in flight at once
 template <int KS>
 __global__ __launch_bounds__(64) void rollout_linear_kernel(RollLin a, int E) {
   const int lane = threadIdx.x, tile = blockIdx.x, net = blockIdx.y;
   const int fr = lane & 15, g = lane >> 4;
+  ROLL_STAMP(112);
   const bf16x8* W = reinterpret_cast<const bf16x8*>(a.w[net]) + (size_t)tile * KS * 64 + lane;
   bf16x8 wf[KS];
 #pragma unroll
@@ -38,16 +39,33 @@ __global__ __launch_bounds__(64) void rollout_linear_kernel(RollLin a, int E) {
   const int MT = (E + 15) >> 4;
   for (int mt = 0; mt < MT; ++mt) {
     const int row = mt * 16 + fr;
-    const __bf16* xr = a.x[net] + (size_t)min(row, E - 1) * a.ldx + g * 8;
+    // rows >= E were never written: those lanes re-read the last real row's chunk (their results are not stored)
+    const bf16x8* X = reinterpret_cast<const bf16x8*>(a.x[net]) + (size_t)mt * KS * 64 + g * 16 + min(fr, E - 1 - mt * 16);
     bf16x8 xa[KS];
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks) xa[ks] = *reinterpret_cast<const bf16x8*>(xr + ks * 32);
-    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    for (int ks = 0; ks < KS; ++ks) xa[ks] = X[ks * 64];
+#ifdef V4L_INFER_TIMING
+    ROLL_STAMP(113 + 4 * mt);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    ROLL_STAMP(114 + 4 * mt);
+#endif
+    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks) mma_k32(acc, wf[ks], xa[ks]);
-    if (row < E)
-      st4(a.y[net] + (size_t)row * a.ldy + tile * 16 + g * 4, fmaxf(acc[0] + bb.x, 0.f), fmaxf(acc[1] + bb.y, 0.f),
-          fmaxf(acc[2] + bb.z, 0.f), fmaxf(acc[3] + bb.w, 0.f));
+    for (int ks = 0; ks < KS; ks += 2) {
+      mma_k32(acc0, wf[ks], xa[ks]);
+      mma_k32(acc1, wf[ks + 1], xa[ks + 1]);
+    }
+    if (row < E) {
+      const int n4 = tile * 16 + g * 4;
+      __bf16* dst = a.ks_out > 0 ? a.y[net] + act_frag_off(row, n4, a.ks_out) : a.y[net] + (size_t)row * a.ldy + n4;
+      st4(dst, fmaxf((acc0[0] + acc1[0]) + bb.x, 0.f), fmaxf((acc0[1] + acc1[1]) + bb.y, 0.f),
+          fmaxf((acc0[2] + acc1[2]) + bb.z, 0.f), fmaxf((acc0[3] + acc1[3]) + bb.w, 0.f));
+    }
+#ifdef V4L_INFER_TIMING
+    ROLL_STAMP(115 + 4 * mt);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    ROLL_STAMP(116 + 4 * mt);
+#endif
   }
 }
 
@@ -152,6 +170,212 @@ __global__ __launch_bounds__(512) void rollout_head_kernel(RollHead a, InfFinish
     if (done == (unsigned long long)gridDim.x - 1) {
       fin.ctl->done = 0;
       fin.ctl->t = t_step + 1;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------ the dense part in ONE launch
+// The three launches above cost ~6.5 us each on the device (a cold start, one dependent round trip, the kernel boundary),
+// three times per env step. Here the same tiles run as 32 single-wave blocks of one launch (tile = blockIdx & 15, net =
+// blockIdx >> 4) that hand their results over through device-side counters: every block requests the weight fragments of
+// ALL its stages at entry (they arrive while the earlier stages run), then
+//   stage 0 (fuse net, the 16 blocks of net 0)  visual projector tile      -> cat (fragment order)   -> stage[0] += 1
+//   stage 1  wait stage[0]; fc0 tile of this net                            -> h0[net]               -> stage[1 + net] += 1
+//   stage 2  wait stage[1 + net]; fc1 tile                                   -> h1[net]               -> stage[3 + net] += 1
+//   stage 3 (tile 0 only) wait stage[3 + net]; last linear + explore / value epilogue + filing; the last of the two
+//           advances the step cursor and the launch sequence number.
+// Counters are monotonic (target = 16 (seq + 1)), released / acquired at agent scope (the blocks sit on different XCDs:
+// tools/probe/flag_hop.hip measured 1.7 - 2.5 us per hand-over). 32 one-wave blocks are always co-resident, producers have
+// the lower block indices, and every spin is bounded (ctl->err is set and the block carries on with whatever it finds: a
+// lost hand-over must never hang the GPU).
+struct RollDense {
+  const void* wpr; const float* bpr;                     // fuse net: visual projector (the shared encoder's = the policy's)
+  const void *w0[2], *w1[2], *w2[2];                     // PK_FRAG packs per net
+  const float *b0[2], *b1[2], *b2[2];
+  const __bf16* featv;                                   // [ceil16(E)][1024] fragment order (act_frag_off, KS 32)
+  __bf16* cat;                                           // fuse net: [ceil16(E)][512] (KS 16)
+  __bf16 *h0[2], *h1[2];                                 // [ceil16(E)][256] (KS 8)
+  float* out[2]; int nout[2];
+};
+__device__ __forceinline__ void dense_wait(ActCtl* ctl, int idx, unsigned target) {
+  if ((threadIdx.x & 63) == 0) {
+    long long spin = 0;
+    // relaxed polls (an acquire per poll invalidates caches 32 waves x every iteration), ONE acquire fence after the loop
+    while ((int)(__hip_atomic_load(&ctl->stage[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target) < 0) {
+      __builtin_amdgcn_s_sleep(2);
+      if (++spin > (1ll << 22)) { ctl->err = 1u + (unsigned)idx; break; }
+    }
+  }
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // the whole wave's later loads see what the producers released
+}
+__device__ __forceinline__ void dense_signal(ActCtl* ctl, int idx) {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");  // this wave's stores are out before the count moves
+  if ((threadIdx.x & 63) == 0) __hip_atomic_fetch_add(&ctl->stage[idx], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// one 16-column tile of relu(x . W^T + b) for every row tile, x and y in fragment order
+template <int KS>
+__device__ __forceinline__ void dense_x(bf16x8 (&xa)[KS], const __bf16* x, int mt, int E, int lane) {
+  const int fr = lane & 15, g = lane >> 4;
+  const bf16x8* X = reinterpret_cast<const bf16x8*>(x) + (size_t)mt * KS * 64 + g * 16 + min(fr, E - 1 - mt * 16);
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) xa[ks] = X[ks * 64];
+}
+// PRE: the caller already requested row tile 0's fragments into xa (ahead of the weights: loads return in order)
+template <int KS, bool PRE = false>
+__device__ __forceinline__ void dense_tile(const bf16x8 (&wf)[KS], const __bf16* x, const float4 bb, __bf16* y, int ks_out,
+                                           int tile, int E, int lane, bf16x8 (&xa)[KS]) {
+  const int fr = lane & 15, g = lane >> 4, MT = (E + 15) >> 4;
+  for (int mt = 0; mt < MT; ++mt) {
+    if (!PRE || mt > 0) dense_x<KS>(xa, x, mt, E, lane);
+    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < KS; ks += 2) {
+      mma_k32(acc0, wf[ks], xa[ks]);
+      mma_k32(acc1, wf[ks + 1], xa[ks + 1]);
+    }
+    const int row = mt * 16 + fr;
+    if (row < E)
+      st4(y + act_frag_off(row, tile * 16 + g * 4, ks_out), fmaxf((acc0[0] + acc1[0]) + bb.x, 0.f),
+          fmaxf((acc0[1] + acc1[1]) + bb.y, 0.f), fmaxf((acc0[2] + acc1[2]) + bb.z, 0.f), fmaxf((acc0[3] + acc1[3]) + bb.w, 0.f));
+  }
+}
+template <bool FUSE>
+__global__ __launch_bounds__(64) void rollout_dense_kernel(RollDense a, InfFinish fin, int E) {
+  constexpr int KS0 = FUSE ? 16 : 32;
+  __shared__ float so[16 * 16];
+  __shared__ float eps_s[64 * 16];
+  __shared__ float sg_s[16], lsg_s[16], lt_s[16 * 16];
+  const int lane = threadIdx.x, tile = blockIdx.x & 15, net = blockIdx.x >> 4;
+  const int fr = lane & 15, g = lane >> 4, MT = (E + 15) >> 4;
+  ActCtl* ctl = fin.ctl;
+  ROLL_STAMP(100);
+  const unsigned target = 16u * (ctl->seq + 1u);
+  const long long t_step = ctl->t;
+  auto frags = [&](const void* W, int ks_per_tile, int t, int ks) {
+    return reinterpret_cast<const bf16x8*>(W)[((size_t)t * ks_per_tile + ks) * 64 + lane];
+  };
+  // request order = arrival order: the first stage's activation fragments (the encoder launch left them), its weights,
+  // then the later stages' weights and the small operands
+  bf16x8 wp[FUSE ? 32 : 1], w0[KS0], w1[8], w2[8], xv[32], xs0[KS0], xs1[8];
+  const bool first = !FUSE || net == 0;  // this block's first stage reads featv
+  if (first) dense_x<32>(xv, a.featv, 0, E, lane);
+  if constexpr (FUSE) {
+    if (net == 0) {
+#pragma unroll
+      for (int ks = 0; ks < 32; ++ks) wp[ks] = frags(a.wpr, 32, tile, ks);
+    }
+  }
+#pragma unroll
+  for (int ks = 0; ks < KS0; ++ks) w0[ks] = frags(a.w0[net], KS0, tile, ks);
+#pragma unroll
+  for (int ks = 0; ks < 8; ++ks) w1[ks] = frags(a.w1[net], 8, tile, ks);
+  if (tile == 0) {
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) w2[ks] = frags(a.w2[net], 8, 0, ks);
+  }
+  const int n4 = tile * 16 + g * 4;
+  const float4 bpv = FUSE ? *reinterpret_cast<const float4*>(a.bpr + n4) : float4{0.f, 0.f, 0.f, 0.f};
+  const float4 b0v = *reinterpret_cast<const float4*>(a.b0[net] + n4), b1v = *reinterpret_cast<const float4*>(a.b1[net] + n4);
+  if (tile == 0 && net == 0) {  // explore operands of the policy's finishing block: E x A normals, A log-stds
+    const int A = fin.A;
+    for (int idx = lane; idx < E * A; idx += 64) eps_s[idx] = fin.eps[idx];
+    if (lane < 16) {
+      const float ls = fminf(fmaxf(fin.logstd[min(lane, A - 1)], LOG_SIG_MIN), LOG_SIG_MAX);
+      const float sg = expf(ls);
+      sg_s[lane] = sg;
+      lsg_s[lane] = logf(sg);
+    }
+  }
+  ROLL_STAMP(101);
+  if constexpr (FUSE) {
+    if (net == 0) {
+      dense_tile<32, true>(wp, a.featv, bpv, a.cat, 16, tile, E, lane, xv);
+      ROLL_STAMP(102);
+      dense_signal(ctl, 0);
+    }
+    ROLL_STAMP(103);
+    dense_wait(ctl, 0, target);
+  }
+  ROLL_STAMP(104);
+  if constexpr (FUSE) dense_tile<KS0>(w0, a.cat, b0v, a.h0[net], 8, tile, E, lane, xs0);
+  else dense_tile<32, true>(w0, a.featv, b0v, a.h0[net], 8, tile, E, lane, xv);
+  ROLL_STAMP(105);
+  dense_signal(ctl, 1 + net);
+  ROLL_STAMP(106);
+  dense_wait(ctl, 1 + net, target);
+  ROLL_STAMP(107);
+  dense_tile<8>(w1, a.h0[net], b1v, a.h1[net], 8, tile, E, lane, xs1);
+  ROLL_STAMP(108);
+  dense_signal(ctl, 3 + net);
+  if (tile != 0) return;
+  ROLL_STAMP(109);
+  dense_wait(ctl, 3 + net, target);
+  ROLL_STAMP(110);
+  const int nout = a.nout[net], A = fin.A;
+  float b2v[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) b2v[r] = a.b2[net][min(g * 4 + r, nout - 1)];
+  bf16x8 xl[4][8];  // every row tile's fragments of h1 in one round trip (E <= 64: at most 4 tiles)
+#pragma unroll
+  for (int mt = 0; mt < 4; ++mt)
+    if (mt < MT) dense_x<8>(xl[mt], a.h1[net], mt, E, lane);
+#pragma unroll
+  for (int mt = 0; mt < 4; ++mt) {  // last linear (one padded column tile) + the epilogue of rollout_head_kernel, 16 rows at a time
+    if (mt >= MT) break;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) mma_k32(acc, w2[ks], xl[mt][ks]);
+    const int row = mt * 16 + fr;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int c = g * 4 + r;
+      const float v = c < nout ? acc[r] + b2v[r] : 0.f;
+      so[fr * 16 + c] = v;
+      if (row < E) a.out[net][(int64_t)row * OUT_LD + c] = v;
+    }
+    __builtin_amdgcn_wave_barrier();  // LDS operations of one wave execute in order
+    // GaussianContPolicyBase.explore / the value read-out with act_finish_kernel's expressions; the per-dimension terms are
+    // evaluated (row, k) pair per lane, the log-prob is then summed over k = 0 .. A-1 in order by the row's lane
+    if (net == 0) {
+      for (int idx = lane; idx < 16 * A; idx += 64) {
+        const int r = idx / A, k = idx - r * A, i = mt * 16 + r;
+        const float mu = so[r * 16 + k], sg = sg_s[k];
+        const float act = fmaf(sg, eps_s[min(i, E - 1) * A + k], mu);
+        const float d = act - mu;
+        lt_s[r * 16 + k] = -(d * d) / (2.f * sg * sg) - logf(sg) - HALF_LOG_2PI;
+        if (i < E) {
+          fin.action[(int64_t)i * A + k] = act;
+          fin.mean[(int64_t)i * A + k] = mu;
+          fin.stdv[(int64_t)i * A + k] = sg;
+          if (fin.acts_roll != nullptr) fin.acts_roll[(t_step * E + i) * A + k] = act;
+        }
+      }
+      __builtin_amdgcn_wave_barrier();
+      const int i = mt * 16 + lane;
+      if (lane < 16 && i < E) {
+        float e = 0.f, lp = 0.f;
+        for (int k = 0; k < A; ++k) { e += 0.5f + HALF_LOG_2PI + lsg_s[k]; lp += lt_s[lane * 16 + k]; }
+        fin.ent[i] = e;
+        if (fin.logp_roll != nullptr) fin.logp_roll[t_step * E + i] = lp;
+      }
+    } else {
+      const int i = mt * 16 + lane;
+      if (lane < 16 && i < E) {
+        const float v = so[lane * 16];
+        fin.value[i] = v;
+        if (fin.values_roll != nullptr) fin.values_roll[t_step * E + i] = v;
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+  ROLL_STAMP(111);
+  if (lane == 0) {  // the second of the two finishing blocks closes the step
+    __threadfence();
+    const unsigned long long done = atomicAdd(reinterpret_cast<unsigned long long*>(&ctl->done), 1ull);
+    if (done == 1ull) {
+      ctl->done = 0;
+      ctl->t = t_step + 1;
+      ctl->seq = ctl->seq + 1u;
     }
   }
 }

@@ -1807,11 +1807,16 @@ static int run_actor_dense_cnn(v4l_actor* a, const float* obs, const float* eps,
   const Layout Lp = pf->layout(E), Lv = vf->layout(E);
   float* ws_pf = a->ws;
   float* ws_vf = a->ws + Lp.total;
-  // operand-type scratch rows inside the actor's workspace: conv3 flatten [E][1024], the concat [E][512], fc0 outputs [E][256]
-  __bf16* featv = reinterpret_cast<__bf16*>(ws_pf + Lp.c3);
-  __bf16* cat = fuse ? reinterpret_cast<__bf16*>(ws_pf + Lp.vis) : nullptr;
-  __bf16* h0p = reinterpret_cast<__bf16*>(ws_pf + Lp.hh[0]);
-  __bf16* h0v = reinterpret_cast<__bf16*>(ws_vf + Lv.hh[0]);
+  // operand-type scratch in fragment order (act_frag_off), carved from the actor's weight-grad slab region (a rollout step
+  // computes no gradients): conv3 flatten [R][1024], the concat [R][512], fc0 / fc1 outputs [R][256] per net, R = ceil16(E)
+  const int64_t R16 = round_up(E, 16);
+  V4L_REQUIRE(Lp.total - Lp.slab >= R16 * (512 + 256 + 4 * 128), "internal: rollout scratch does not fit the slab region");
+  __bf16* featv = reinterpret_cast<__bf16*>(ws_pf + Lp.slab);
+  __bf16* cat = featv + R16 * 1024;
+  __bf16* h0p = cat + R16 * 512;
+  __bf16* h0v = h0p + R16 * 256;
+  __bf16* h1p = h0v + R16 * 256;
+  __bf16* h1v = h1p + R16 * 256;
   PhaseScope ps("rollout");
   InfEncFrag ef;
   memset(&ef, 0, sizeof(ef));
@@ -1831,7 +1836,31 @@ static int run_actor_dense_cnn(v4l_actor* a, const float* obs, const float* eps,
                 featv, (__bf16*)nullptr);
   }
   V4L_LAUNCH_CHECK();
+  InfFinish fin;
+  memset(&fin, 0, sizeof(fin));
+  fin.ctl = a->ctl; fin.logstd = pf->p[pf->logstd]; fin.eps = eps; fin.A = pf->cfg.out_dim;
+  fin.acts_roll = acts_roll; fin.values_roll = values_roll; fin.logp_roll = logp_roll; fin.action = action;
+  fin.mean = mean; fin.stdv = stdv; fin.ent = ent; fin.value = value;
   g_op = "dense";
+  if (getenv("V4L_ROLLOUT_DENSE_SPLIT") == nullptr) {  // (read per call: tests switch it)
+    // projector -> fc0 -> fc1 -> last linear -> epilogue as stages of one launch (device-side hand-overs)
+    RollDense d;
+    memset(&d, 0, sizeof(d));
+    if (fuse) { d.wpr = pk + pf->proj.pkf; d.bpr = pf->p[pf->proj.b]; }
+    auto net_of = [&](int i, v4l_net* net, const __bf16* base, __bf16* h0, __bf16* h1, float* out) {
+      d.w0[i] = base + net->head[0].pkf; d.w1[i] = base + net->head[1].pkf; d.w2[i] = base + net->head[2].pkf;
+      d.b0[i] = net->p[net->head[0].b]; d.b1[i] = net->p[net->head[1].b]; d.b2[i] = net->p[net->head[2].b];
+      d.h0[i] = h0; d.h1[i] = h1; d.out[i] = out; d.nout[i] = net->cfg.out_dim;
+    };
+    net_of(0, pf, pk, h0p, h1p, ws_pf + Lp.out);
+    net_of(1, vf, vk, h0v, h1v, ws_vf + Lv.out);
+    d.featv = featv; d.cat = cat;
+    const double fl = 2.0 * E * ((fuse ? 1024.0 * 256 : 0.0) + 2 * ((fuse ? 512.0 : 1024.0) * 256 + 256 * 256 + 256 * 16));
+    if (fuse) V4L_KLAUNCH("rollout_dense", fl, s, rollout_dense_kernel<true>, dim3(32), dim3(64), 0, s, d, fin, E);
+    else V4L_KLAUNCH("rollout_dense", fl, s, rollout_dense_kernel<false>, dim3(32), dim3(64), 0, s, d, fin, E);
+    V4L_LAUNCH_CHECK();
+    return 0;
+  }
   RollLin fc0;
   memset(&fc0, 0, sizeof(fc0));
   fc0.w[0] = pk + pf->head[0].pkf; fc0.w[1] = vk + vf->head[0].pkf;
@@ -1840,13 +1869,13 @@ static int run_actor_dense_cnn(v4l_actor* a, const float* obs, const float* eps,
   if (fuse) {
     RollLin pr;
     memset(&pr, 0, sizeof(pr));
-    pr.w[0] = pk + pf->proj.pkf; pr.b[0] = pf->p[pf->proj.b]; pr.x[0] = featv; pr.ldx = 1024; pr.y[0] = cat; pr.ldy = 512;
+    pr.w[0] = pk + pf->proj.pkf; pr.b[0] = pf->p[pf->proj.b]; pr.x[0] = featv; pr.y[0] = cat; pr.ks_out = 16;
     V4L_KLAUNCH("rollout_linear", 2.0 * E * 1024 * 256, s, rollout_linear_kernel<32>, dim3(16, 1), dim3(64), 0, s, pr, E);
     V4L_LAUNCH_CHECK();
-    fc0.x[0] = fc0.x[1] = cat; fc0.ldx = 512;
+    fc0.x[0] = fc0.x[1] = cat;
     V4L_KLAUNCH("rollout_linear", 2.0 * 2 * E * 512 * 256, s, rollout_linear_kernel<16>, dim3(16, 2), dim3(64), 0, s, fc0, E);
   } else {
-    fc0.x[0] = fc0.x[1] = featv; fc0.ldx = 1024;
+    fc0.x[0] = fc0.x[1] = featv;
     V4L_KLAUNCH("rollout_linear", 2.0 * 2 * E * 1024 * 256, s, rollout_linear_kernel<32>, dim3(16, 2), dim3(64), 0, s, fc0, E);
   }
   V4L_LAUNCH_CHECK();
@@ -1859,11 +1888,6 @@ static int run_actor_dense_cnn(v4l_actor* a, const float* obs, const float* eps,
   };
   head(0, pf, pk, h0p, ws_pf + Lp.out);
   head(1, vf, vk, h0v, ws_vf + Lv.out);
-  InfFinish fin;
-  memset(&fin, 0, sizeof(fin));
-  fin.ctl = a->ctl; fin.logstd = pf->p[pf->logstd]; fin.eps = eps; fin.A = pf->cfg.out_dim;
-  fin.acts_roll = acts_roll; fin.values_roll = values_roll; fin.logp_roll = logp_roll; fin.action = action;
-  fin.mean = mean; fin.stdv = stdv; fin.ent = ent; fin.value = value;
   g_op = "head";
   V4L_KLAUNCH("rollout_head", 2.0 * 2 * E * (256 * 256 + 256 * 16), s, rollout_head_kernel, dim3(2), dim3(512), RollHeadLds::bytes,
               s, hd, fin, E);
