@@ -134,7 +134,7 @@ template <int MT, int NTW> __device__ __forceinline__ void zero_acc(f32x4 (&acc)
 // Results: ctx rows -> cx (T, stride ldc; only valid queries are written), optionally P (fp32 [17][17]) and ctx (T [17][64])
 // of the sample to global memory for the backward pass.
 constexpr int ATT_LDV = 32 + 8;
-template <typename T>
+template <typename T, int NT = NTOK>
 __device__ __forceinline__ void attn_tile(const T* q0, const T* k0, int ldq, const T* vt, T* pb, T* cx, int ldc, int lane,
                                           int q_first, int nq, float* __restrict__ gP, T* __restrict__ gctx) {
   typedef typename Frag<T>::type frag_t;
@@ -156,7 +156,7 @@ __device__ __forceinline__ void attn_tile(const T* q0, const T* k0, int ldq, con
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int key = nt * 16 + qr + r;
-      pv[nt][r] = key < NTOK ? s[nt][r] * 0.125f : -INFINITY;
+      pv[nt][r] = key < NT ? s[nt][r] * 0.125f : -INFINITY;
       mx = fmaxf(mx, pv[nt][r]);
     }
   mx = fmaxf(mx, __shfl_xor(mx, 16));
@@ -166,7 +166,7 @@ __device__ __forceinline__ void attn_tile(const T* q0, const T* k0, int ldq, con
   for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      pv[nt][r] = nt * 16 + qr + r < NTOK ? expf(pv[nt][r] - mx) : 0.f;
+      pv[nt][r] = nt * 16 + qr + r < NT ? expf(pv[nt][r] - mx) : 0.f;
       sum += pv[nt][r];
     }
   sum += __shfl_xor(sum, 16);
@@ -178,7 +178,7 @@ __device__ __forceinline__ void attn_tile(const T* q0, const T* k0, int ldq, con
     for (int r = 0; r < 4; ++r) {
       pv[nt][r] *= inv;
       const int key = nt * 16 + qr + r;
-      if (gP != nullptr && fr < nq && key < NTOK) gP[(q_first + fr) * NTOK + key] = pv[nt][r];
+      if (gP != nullptr && fr < nq && key < NT) gP[(q_first + fr) * NT + key] = pv[nt][r];
     }
     st4(pb + fr * ATT_LDV + nt * 16 + qr, pv[nt][0], pv[nt][1], pv[nt][2], pv[nt][3]);
   }
@@ -911,7 +911,9 @@ __device__ __forceinline__ void mm_held(f32x4 (&acc)[MT], const AT* sA, int lda,
     }
 }
 
-template <typename T, int NL>
+// NT: tokens per sample — 17 (LocoTransformer: proprio token + 16 depth tokens, head input [token 0 | mean of the depth
+// tokens]) or 16 (the vision-only Transformer, nets.py:884-889: head input = mean of all 16 tokens, fc0 contracts 64)
+template <typename T, int NL, int NT = NTOK>
 __global__ __launch_bounds__(512) void rollout_stack_kernel(InfLayerStack stk, InfHeadPair hd, InfFinish fin, int E, int warm) {
   typedef typename Frag<T>::type frag_t;
   typedef InfLayLds<T, 1> LY;
@@ -943,7 +945,7 @@ __global__ __launch_bounds__(512) void rollout_stack_kernel(InfLayerStack stk, I
   T* kb = qb + ROWS * LDT;                          // [32][LDT]
   T* vt = kb + ROWS * LDT;                          // [64][ATT_LDV], key columns >= 17 zero
   T* pbuf = vt + 64 * ATT_LDV;                      // [2][16][ATT_LDV] P of the two query tiles
-  const int64_t row0 = (int64_t)s0 * NTOK;
+  const int64_t row0 = (int64_t)s0 * NT;
   const InfHead& h = hd.n[net];
   ROLL_STAMP(64);
   // weights arrive in fragment order (PK_FRAG): one fragment = 64 consecutive frag_t, whole cache lines per wave load
@@ -979,13 +981,13 @@ __global__ __launch_bounds__(512) void rollout_stack_kernel(InfLayerStack stk, I
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
-      for (int ks = 0; ks < 2; ++ks) r_in[j][ks] = wfrag(h.w0, 128, wave + 8 * j, ks);
+      for (int ks = 0; ks < 2; ++ks) r_in[j][ks] = wfrag(h.w0, NT == 16 ? 64 : 128, wave + 8 * j, ks);
   };
   auto load_h0b = [&]() {
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
-      for (int ks = 0; ks < 2; ++ks) r_f1[j][ks] = wfrag(h.w0, 128, wave + 8 * j, 2 + ks);
+      for (int ks = 0; ks < 2; ++ks) r_f1[j][ks] = wfrag(h.w0, NT == 16 ? 64 : 128, wave + 8 * j, NT == 16 ? ks : 2 + ks);
   };
   auto load_h1 = [&](int j) {  // j: compile-time tile slot
 #pragma unroll
@@ -1046,7 +1048,7 @@ __global__ __launch_bounds__(512) void rollout_stack_kernel(InfLayerStack stk, I
     // (2) what the first phases need: token rows (the encoder kernel just wrote them), parameters, sampling operands.
     // Every load is unconditional from a clamped, always-valid address (a load inside a branch ends in a vmcnt(0) wait)
     const int r = tid >> 4, c4 = (tid & 15) * 4;  // 32 rows x 16 float4 = 512 threads
-    const float4 xv = *reinterpret_cast<const float4*>(w0.xin + (row0 + (r < NTOK ? r : 0)) * TD + c4);
+    const float4 xv = *reinterpret_cast<const float4*>(w0.xin + (row0 + (r < NT ? r : 0)) * TD + c4);
     const float4 pv = layer_params(w0);
     float4 hv;
     {
@@ -1063,10 +1065,10 @@ __global__ __launch_bounds__(512) void rollout_stack_kernel(InfLayerStack stk, I
     if constexpr (PRE) load_in(w0);
     __builtin_amdgcn_sched_barrier(0);
     {
-      const float4 x0v = r < NTOK ? xv : float4{0.f, 0.f, 0.f, 0.f};
+      const float4 x0v = r < NT ? xv : float4{0.f, 0.f, 0.f, 0.f};
       *reinterpret_cast<float4*>(xs + r * LY::LDX + c4) = x0v;
       st4(xb + r * LDT + c4, x0v.x, x0v.y, x0v.z, x0v.w);
-      if (r >= NTOK) st4(cb + r * LDT + c4, 0.f, 0.f, 0.f, 0.f);  // the attention only writes the 17 real context rows
+      if (r >= NT) st4(cb + r * LDT + c4, 0.f, 0.f, 0.f, 0.f);  // the attention only writes the 17 real context rows
     }
     if (tid < P_LAYER / 4) *reinterpret_cast<float4*>(prm + tid * 4) = pv;
     if (tid < 128) *reinterpret_cast<float4*>(prm_h + tid * 4) = hv;
@@ -1090,7 +1092,7 @@ __global__ __launch_bounds__(512) void rollout_stack_kernel(InfLayerStack stk, I
                       fmaf(v.w * rs, gg.w, bb.w)};
     *reinterpret_cast<float4*>(out + r * LY::LDX + c4) = o;
     st4(xb + r * LDT + c4, o.x, o.y, o.z, o.w);
-    if (gout != nullptr && r < NTOK) *reinterpret_cast<float4*>(gout + (row0 + r) * TD + c4) = o;
+    if (gout != nullptr && r < NT) *reinterpret_cast<float4*>(gout + (row0 + r) * TD + c4) = o;
   };
 #pragma unroll
   for (int l = 0; l < NL; ++l) {  // the token rows stay in `xs` from one layer to the next
@@ -1120,7 +1122,7 @@ __global__ __launch_bounds__(512) void rollout_stack_kernel(InfLayerStack stk, I
             else if (t < 8) st4(kb + row * LDT + (n4 - TD), v0, v1, v2, v3);
             else {  // values, transposed for the P V product; keys past the 17 tokens are zeros
               T* vc = vt + (n4 - 2 * TD) * ATT_LDV + row;
-              const bool ok = row < NTOK;
+              const bool ok = row < NT;
               vc[0] = (T)(ok ? v0 : 0.f); vc[ATT_LDV] = (T)(ok ? v1 : 0.f);
               vc[2 * ATT_LDV] = (T)(ok ? v2 : 0.f); vc[3 * ATT_LDV] = (T)(ok ? v3 : 0.f);
             }
@@ -1132,9 +1134,9 @@ __global__ __launch_bounds__(512) void rollout_stack_kernel(InfLayerStack stk, I
     __syncthreads();
     if (l == 0) ROLL_STAMP(66);
     if constexpr (PRE) { if (l == 0 && wave < 4) load_f2(w); if (!more) load_h1(0); }
-    if (wave < 2)  // attention on the matrix cores: wave = query tile (tokens 0..15 | token 16)
-      attn_tile<T>(qb + wave * 16 * LDT, kb, LDT, vt, pbuf + wave * 16 * ATT_LDV, cb + wave * 16 * LDT, LDT, lane, wave * 16,
-                   wave == 0 ? 16 : 1, nullptr, nullptr);
+    if (wave < (NT > 16 ? 2 : 1))  // attention on the matrix cores: wave = query tile (tokens 0..15 | token 16)
+      attn_tile<T, NT>(qb + wave * 16 * LDT, kb, LDT, vt, pbuf + wave * 16 * ATT_LDV, cb + wave * 16 * LDT, LDT, lane, wave * 16,
+                       wave == 0 ? 16 : NT - 16, nullptr, nullptr);
     if (l == 0) { ROLL_STAMP(67); ROLL_STAMP(68); }
     __syncthreads();
     if (l == 0) ROLL_STAMP(69);
@@ -1211,13 +1213,15 @@ __global__ __launch_bounds__(512) void rollout_stack_kernel(InfLayerStack stk, I
   float* so = reinterpret_cast<float*>(h2 + 16 * LY::LDF);          // [16] last-layer outputs of row 0
   __syncthreads();
   ROLL_STAMP(80);
-  if (tid < 128) {  // rows 1..15 of the operand tiles are never read back: only fragment row 0 is filled
+  constexpr bool VIS = NT == 16;
+  if (tid < (VIS ? TD : 2 * TD)) {  // rows 1..15 of the operand tiles are never read back: only fragment row 0 is filled
     float v;
-    if (tid < TD) v = xs[tid];
+    if (!VIS && tid < TD) v = xs[tid];
     else {
+      const int d = VIS ? tid : tid - TD;
       float s = 0.f;
 #pragma unroll
-      for (int i = 1; i < NTOK; ++i) s += xs[i * LY::LDX + (tid - TD)];
+      for (int i = VIS ? 0 : 1; i < NT; ++i) s += xs[i * LY::LDX + d];
       v = s * (1.f / 16.f);
     }
     pooled[tid] = v;
@@ -1234,8 +1238,13 @@ __global__ __launch_bounds__(512) void rollout_stack_kernel(InfLayerStack stk, I
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       f32x4 acc[1] = {f32x4{0.f, 0.f, 0.f, 0.f}};
-      const frag_t fb[4] = {r_in[j][0], r_in[j][1], r_f1[j][0], r_f1[j][1]};
-      mm_held<T, 1, 4>(acc, pooled, LY::LDP, fb, lane);
+      if constexpr (VIS) {
+        const frag_t fb[2] = {r_in[j][0], r_in[j][1]};
+        mm_held<T, 1, 2>(acc, pooled, LY::LDP, fb, lane);
+      } else {
+        const frag_t fb[4] = {r_in[j][0], r_in[j][1], r_f1[j][0], r_f1[j][1]};
+        mm_held<T, 1, 4>(acc, pooled, LY::LDP, fb, lane);
+      }
       store_h(h1, acc[0], prm_h + P_H0, wave + 8 * j);
     }
   }

@@ -866,10 +866,8 @@ int v4l_net::build() {
     // the rollout step streams these as whole MFMA fragments (rollout_stack_kernel, rollout_encoder2_kernel, csrc/rollout_dense.h);
     // a linear that reads conv3's NHWC rows keeps that k order (L.cin / L.taps, as in its PK_CONV_NHWC pack)
     auto pack_frag = [&](Lin& L) { L.pkf = add_pack(L.w, PK_FRAG, L.Np, L.Kp, L.N, L.K, L.cin, L.taps, 0, 0, 0, 0, 0); };
-    if (c.kind == V4L_NET_LOCO)
-      for (TLayer& t : layers) { pack_frag(t.inproj); pack_frag(t.outproj); pack_frag(t.ff1); pack_frag(t.ff2); }
-    if (c.kind != V4L_NET_LOCO_VIS)
-      for (Lin& L : head) pack_frag(L);
+    for (TLayer& t : layers) { pack_frag(t.inproj); pack_frag(t.outproj); pack_frag(t.ff1); pack_frag(t.ff2); }
+    for (Lin& L : head) pack_frag(L);
     if (is_tf()) pack_frag(upconv);
     if (c.kind == V4L_NET_CNN || c.kind == V4L_NET_LOCO) pack_frag(proj);
     for (Lin& L : enc) pack_frag(L);
@@ -1708,8 +1706,9 @@ int v4l_net::backward_t(const float* state, const T* image, const int* rowidx, i
 static bool actor_fusable(const v4l_actor* a) {
   const v4l_net_cfg &p = a->pf->cfg, &v = a->vf->cfg;
   auto ok = [](const v4l_net_cfg& c) {
-    return c.kind == V4L_NET_LOCO && c.n_enc_hidden == 2 && c.enc_hidden[0] == 256 && c.enc_hidden[1] == 256 &&
-           c.n_head_hidden == 2 && c.head_hidden[0] == 256 && c.head_hidden[1] == 256 && c.ff_dim == 256 &&
+    const bool trunk = c.n_head_hidden == 2 && c.head_hidden[0] == 256 && c.head_hidden[1] == 256 && c.ff_dim == 256;
+    if (c.kind == V4L_NET_LOCO_VIS) return trunk && c.compute == V4L_BF16;  // (16 tokens: bf16 kernels only)
+    return c.kind == V4L_NET_LOCO && c.n_enc_hidden == 2 && c.enc_hidden[0] == 256 && c.enc_hidden[1] == 256 && trunk &&
            c.state_dim <= 128;
   };
   return ok(p) && ok(v) && p.n_layers == 2 && v.n_layers == 2 && a->E <= 64 && a->pf->head.size() == 3 &&
@@ -1952,8 +1951,13 @@ static int run_actor_fused(v4l_actor* a, const float* obs, const float* eps, flo
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)InfEncLds<T>::bytes));
     V4L_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&rollout_stack_kernel<T, 2>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)RollStackLds<T>::bytes));
+    V4L_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&rollout_stack_kernel<T, 2, 16>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)RollStackLds<T>::bytes));
+    V4L_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&rollout_encoder2_kernel<ENC_TOK16>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)RollEnc2Lds::bytes));
     attr_done = true;
   }
+  const bool vis = pf->cfg.kind == V4L_NET_LOCO_VIS;
   const T* pk = (const T*)pf->packed;
   const T* vk = (const T*)vf->packed;
   const Layout Lp = pf->layout(E), Lv = vf->layout(E);
@@ -1961,15 +1965,29 @@ static int run_actor_fused(v4l_actor* a, const float* obs, const float* eps, flo
   float* ws_vf = a->ws + Lp.total;
   PhaseScope ps("rollout");
   InfEnc en;
+  memset(&en, 0, sizeof(en));
   en.w1 = pk + pf->conv[0].pk; en.w2 = pk + pf->conv[1].pk; en.w3 = pk + pf->conv[2].pk; en.wup = pk + pf->upconv.pk;
   en.b1 = pf->p[pf->conv[0].b]; en.b2 = pf->p[pf->conv[1].b]; en.b3 = pf->p[pf->conv[2].b]; en.bup = pf->p[pf->upconv.b];
-  en.wf1 = pk + pf->enc[0].pk; en.wf2 = pk + pf->enc[1].pk; en.wpr = pk + pf->proj.pk;
-  en.bf1 = pf->p[pf->enc[0].b]; en.bf2 = pf->p[pf->enc[1].b]; en.bpr = pf->p[pf->proj.b];
-  en.S = pf->cfg.state_dim; en.Sp = pf->Sp; en.Kp1 = pf->enc[0].Kp;
+  if (!vis) {
+    en.wf1 = pk + pf->enc[0].pk; en.wf2 = pk + pf->enc[1].pk; en.wpr = pk + pf->proj.pk;
+    en.bf1 = pf->p[pf->enc[0].b]; en.bf2 = pf->p[pf->enc[1].b]; en.bpr = pf->p[pf->proj.b];
+    en.Kp1 = pf->enc[0].Kp;
+  }
+  en.S = pf->cfg.state_dim; en.Sp = pf->Sp;
   float* x0 = ws_pf + Lp.x[0];
   g_op = "encoder";
   static const bool enc2 = getenv("V4L_ROLLOUT_ENC_OLD") == nullptr;
-  if (enc2 && sizeof(T) == 2 && pf->enc.size() == 2 && pf->enc[0].Kp == 128 && pf->conv[0].pkf >= 0) {
+  if (vis) {  // 16 depth tokens, no proprio blocks (actor_fusable: bf16 only)
+    const __bf16* pb = (const __bf16*)pf->packed;
+    InfEncFrag ef;
+    memset(&ef, 0, sizeof(ef));
+    ef.w1 = pb + pf->conv[0].pkf; ef.w2 = pb + pf->conv[1].pkf; ef.w3 = pb + pf->conv[2].pkf; ef.wup = pb + pf->upconv.pkf;
+    ef.b1 = en.b1; ef.b2 = en.b2; ef.b3 = en.b3; ef.bup = en.bup;
+    ef.S = en.S; ef.Sp = en.Sp;
+    V4L_KLAUNCH("rollout_encoder", 2.0 * E * 3678208.0, s, rollout_encoder2_kernel<ENC_TOK16>, dim3(E), dim3(1024),
+                RollEnc2Lds::bytes, s, (const ActCtl*)a->ctl, obs, E, ef, state_roll, (__bf16*)image_roll, x0, (__bf16*)nullptr,
+                (__bf16*)nullptr);
+  } else if (enc2 && sizeof(T) == 2 && pf->enc.size() == 2 && pf->enc[0].Kp == 128 && pf->conv[0].pkf >= 0) {
     static bool attr2 = false;
     if (!attr2) {
       V4L_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&rollout_encoder2_kernel<ENC_TOK17>),
@@ -2031,8 +2049,12 @@ static int run_actor_fused(v4l_actor* a, const float* obs, const float* eps, flo
     }
     finish();
     static const int warm = getenv("V4L_ROLLOUT_WARM") ? atoi(getenv("V4L_ROLLOUT_WARM")) : 0;  // L2 warm-up touches (measured: +-0)
-    V4L_KLAUNCH("rollout_layers_head", 2.0 * 2 * E * (nl * 872576.0 + 99840.0), s, (rollout_stack_kernel<T, 2>), dim3(E, 2),
-                dim3(512), (RollStackLds<T>::bytes), s, stk, hd, fin, E, warm);
+    if (vis)
+      V4L_KLAUNCH("rollout_layers_head", 2.0 * 2 * E * (nl * 872576.0 + 99840.0), s, (rollout_stack_kernel<T, 2, 16>), dim3(E, 2),
+                  dim3(512), (RollStackLds<T>::bytes), s, stk, hd, fin, E, warm);
+    else
+      V4L_KLAUNCH("rollout_layers_head", 2.0 * 2 * E * (nl * 872576.0 + 99840.0), s, (rollout_stack_kernel<T, 2>), dim3(E, 2),
+                  dim3(512), (RollStackLds<T>::bytes), s, stk, hd, fin, E, warm);
     V4L_LAUNCH_CHECK();
   }
   return 0;
