@@ -382,8 +382,8 @@ def reference_protocol(wl, compute, dev):
         ob = pool[0]
         for t_ in range(T):
             ob_t = torch.Tensor(ob).to(dev)
-            acts = agent.pf.explore(ob_t)["action"].detach().cpu().numpy()
-            values = agent.vf(ob_t).detach().cpu().numpy()
+            acts = agent.pf.explore(ob_t)["action"].detach().cpu().numpy().reshape(E, A)  # (explore squeezes a batch of 1)
+            values = agent.vf(ob_t).detach().cpu().numpy().reshape(E, 1)
             nxt = pool[(t_ + 1) % len(pool)]
             buf.add_sample({"obs": ob, "next_obs": nxt, "acts": acts, "values": values, "rewards": np.ones((E, 1)),
                             "terminals": np.zeros((E, 1), dtype=bool), "time_limits": [False]})
