@@ -39,6 +39,8 @@
  *   V4L_LAYER_SPW=2|4, V4L_LAYER_BWD_SPW=2|4      samples per block of the block-cooperative layer kernels
  *   V4L_CONV_BWD_BLOCKS, V4L_CONV3_WGRAD_BLOCKS, V4L_TRAIN_ENC_BLOCKS, V4L_WIDE_SPLITS   block / split counts (tests force ragged and many-samples-per-block shapes)
  *   V4L_TRAIN_ENC_OLD, V4L_ROLLOUT_ENC_OLD        the streamed-weight encoder kernels
+ *   V4L_ROLLOUT_DENSE_SPLIT   NatureCNN nets' rollout step: the dense layers as three launches instead of one launch with
+ *                             device-side hand-overs (per call); V4L_ROLLOUT_CNN_OLD: the per-sample rollout_cnn_kernel
  *   V4L_ROLLOUT_WARM          L2 warm-up touches at the start of rollout_stack_kernel (measured: no effect)
  *   V4L_RCCL_LIB              path of the RCCL library to dlopen (default: librccl.so.1)
  * Read by the Python shell, not by the library: V4L_COMPUTE=bf16|f32, V4L_GRAPH=0, V4L_DP_COMM=torch|rccl,
@@ -178,6 +180,7 @@ int v4l_actor_create(v4l_net* pf, v4l_net* vf, int E, v4l_actor** out);
 void v4l_actor_destroy(v4l_actor* a);
 int64_t v4l_actor_ws_floats(const v4l_actor* a);
 int64_t v4l_actor_ctl_bytes(const v4l_actor* a);
+/* ctl_dev: v4l_actor_ctl_bytes() bytes, ZEROED by the caller before the first bind (step cursor, hand-over counters). */
 int v4l_actor_bind(v4l_actor* a, float* ws_dev, void* ctl_dev, void* stream);
 int v4l_actor_seek(v4l_actor* a, int64_t t, void* stream);
 int v4l_actor_step(v4l_actor* a, const float* obs_dev, const float* eps_dev, float* state_roll_dev, void* image_roll_dev,

@@ -498,15 +498,16 @@ def test_rollout_actor_matches_separate_calls(name, mode, graph, device):
 
 @pytest.mark.parametrize("split", [False, True])
 @pytest.mark.parametrize("E", [16, 33, 64])
-@pytest.mark.parametrize("name", ["cnn_s93", "cnn_vis", "loco_vis"])
+@pytest.mark.parametrize("name", ["cnn_s93", "cnn_vis", "loco_vis", "mlp_s93"])
 def test_dense_rollout_step_env_counts(name, E, split, device, monkeypatch):
     """The NatureCNN nets' rollout step runs its dense layers as GEMMs over all E rows (csrc/rollout_dense.h): the bench's
     E = 16, a ragged last row tile (33) and the largest supported count (64) against the layer-by-layer module calls; as the
     single launch with device-side hand-overs (default) and as separate launches (V4L_ROLLOUT_DENSE_SPLIT).
-    (loco_vis: the vision-only Transformer's 16-token instantiation of the LocoTransformer step kernels.)"""
+    (loco_vis: the vision-only Transformer's 16-token instantiation of the LocoTransformer step kernels; mlp_s93: the state
+    MLP's one-block-per-net step kernel.)"""
     if split:
-        if name == "loco_vis":
-            pytest.skip("no dense launches in the Transformer step")
+        if name in ("loco_vis", "mlp_s93"):
+            pytest.skip("one step kernel, nothing to split")
         monkeypatch.setenv("V4L_ROLLOUT_DENSE_SPLIT", "1")
     _actor_vs_separate(name, "bf16", False, device, E, 3)
 

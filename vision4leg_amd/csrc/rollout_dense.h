@@ -13,6 +13,7 @@
 // (vision-only: encoder<ENC_FLAT>, rollout_linear_kernel<32> per net on featv, rollout_head_kernel). bf16 operands, fp32
 // accumulation, k order = the packed k order of the general kernels (NHWC flatten for the layer that reads conv3).
 #pragma once
+#include <type_traits>
 #include "infer.h"
 
 namespace v4l {
@@ -168,6 +169,149 @@ __global__ __launch_bounds__(512) void rollout_head_kernel(RollHead a, InfFinish
     __threadfence();
     const unsigned long long done = atomicAdd(reinterpret_cast<unsigned long long*>(&fin.ctl->done), 1ull);
     if (done == (unsigned long long)gridDim.x - 1) {
+      fin.ctl->done = 0;
+      fin.ctl->t = t_step + 1;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------ state MLP nets
+// Net / GaussianContPolicyBasicBias on proprioception only (networks/nets.py:16-55, starter/ppo_state.py): shared base MLP
+// (S -> 256 -> 256, ReLU) + per-net head (256 -> 256 -> 256 -> out). rollout_mlp_kernel ran one block per (sample, net) with
+// row-major weights requested at the start of each of its five phases (five cold round trips) and a serial epilogue with
+// global loads in its loop: 18 us per env step at E = 1. Here ONE block per net takes all E <= 64 rows as MFMA row tiles,
+// wave w owns column tile w of every 256-wide layer, and the fragment-order weights are requested ahead: the first three
+// layers' at entry, the fourth's once the first is done with its registers, the last one's after the second.
+struct RollMlp2 {
+  const void *wf1, *wf2; const float *bf1, *bf2;       // shared base (the policy's): [16][4][64], [16][8][64] fragments
+  const void *w0[2], *w1[2], *w2[2]; const float *b0[2], *b1[2], *b2[2];
+  float* out[2]; int nout[2];
+  int S, Sp;
+};
+struct RollMlp2Lds {
+  static constexpr int LDI = 128 + 8, LDH = 256 + 8;
+  static constexpr size_t bytes = (size_t)64 * LDI * 2 + (size_t)2 * 64 * LDH * 2 + (3 * 64 * 16 + 3 * 16) * 4;
+};
+__global__ __launch_bounds__(1024) void rollout_mlp2_kernel(const float* __restrict__ obs, int E, RollMlp2 a, InfFinish fin,
+                                                            float* __restrict__ state_roll) {
+  constexpr int LDI = RollMlp2Lds::LDI, LDH = RollMlp2Lds::LDH;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  __bf16* xin = reinterpret_cast<__bf16*>(smem);       // [64][LDI] proprio rows
+  __bf16* ha = xin + 64 * LDI;                          // [64][LDH]
+  __bf16* hb = ha + 64 * LDH;                           // [64][LDH]
+  float* so = reinterpret_cast<float*>(hb + 64 * LDH);  // [64][16] head outputs
+  float* eps_s = so + 64 * 16;                          // [64][A]
+  float* lt_s = eps_s + 64 * 16;                        // [64][16] log-prob terms
+  float* sg_s = lt_s + 64 * 16;                         // [16] | lsg [16] | b2 [16]
+  float* lsg_s = sg_s + 16;
+  float* b2_s = lsg_s + 16;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, net = blockIdx.x;
+  const int fr = lane & 15, g = lane >> 4, MT = (E + 15) >> 4, A = fin.A;
+  const long long t_step = fin.ctl->t;
+  auto frag = [&](const void* W, int ks_per_tile, int t, int ks) {
+    return reinterpret_cast<const bf16x8*>(W)[((size_t)t * ks_per_tile + ks) * 64 + lane];
+  };
+  // observation rows first (the first GEMM waits for them), then the weights in the order of use
+  for (int idx = tid; idx < MT * 16 * 128; idx += 1024) {
+    const int r = idx >> 7, c = idx & 127;
+    const float x = (r < E && c < a.S) ? obs[(int64_t)r * a.S + c] : 0.f;
+    xin[r * LDI + c] = (__bf16)x;
+    if (net == 0 && r < E && c < a.Sp) state_roll[((int64_t)t_step * E + r) * a.Sp + c] = x;
+  }
+  bf16x8 r1[4], r2[8], r3[8];
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) r1[ks] = frag(a.wf1, 4, wave, ks);
+#pragma unroll
+  for (int ks = 0; ks < 8; ++ks) r2[ks] = frag(a.wf2, 8, wave, ks);
+#pragma unroll
+  for (int ks = 0; ks < 8; ++ks) r3[ks] = frag(a.w0[net], 8, wave, ks);
+  const int n4 = wave * 16 + g * 4;
+  const float4 bb1 = *reinterpret_cast<const float4*>(a.bf1 + n4), bb2 = *reinterpret_cast<const float4*>(a.bf2 + n4);
+  const float4 bb3 = *reinterpret_cast<const float4*>(a.b0[net] + n4), bb4 = *reinterpret_cast<const float4*>(a.b1[net] + n4);
+  if (net == 0) {
+    for (int idx = tid; idx < E * A; idx += 1024) eps_s[idx] = fin.eps[idx];
+    if (tid < 16) {
+      const float ls = fminf(fmaxf(fin.logstd[min(tid, A - 1)], LOG_SIG_MIN), LOG_SIG_MAX);
+      const float sg = expf(ls);
+      sg_s[tid] = sg;
+      lsg_s[tid] = logf(sg);
+    }
+  }
+  if (tid < 16) b2_s[tid] = tid < a.nout[net] ? a.b2[net][tid] : 0.f;
+  __syncthreads();
+  // y[:, tile] = relu(x . W^T + b) for every row tile; x rows in LDS (stride ldx), weights held in registers
+  auto layer = [&](const bf16x8* w, auto ks_tag, const __bf16* x, int ldx, const float4 bb, __bf16* y) {
+    constexpr int KS = decltype(ks_tag)::value;
+    for (int mt = 0; mt < MT; ++mt) {
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks)
+        mma_k32(acc, w[ks], *reinterpret_cast<const bf16x8*>(x + (mt * 16 + fr) * ldx + ks * 32 + g * 8));
+      st4(y + (mt * 16 + fr) * LDH + n4, fmaxf(acc[0] + bb.x, 0.f), fmaxf(acc[1] + bb.y, 0.f), fmaxf(acc[2] + bb.z, 0.f),
+          fmaxf(acc[3] + bb.w, 0.f));
+    }
+  };
+  layer(r1, std::integral_constant<int, 4>(), xin, LDI, bb1, ha);
+  bf16x8 r4[8], r5[8];
+#pragma unroll
+  for (int ks = 0; ks < 8; ++ks) r4[ks] = frag(a.w1[net], 8, wave, ks);
+  __syncthreads();
+  layer(r2, std::integral_constant<int, 8>(), ha, LDH, bb2, hb);
+  if (wave < 4) {
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) r5[ks] = frag(a.w2[net], 8, 0, ks);
+  }
+  __syncthreads();
+  layer(r3, std::integral_constant<int, 8>(), hb, LDH, bb3, ha);
+  __syncthreads();
+  layer(r4, std::integral_constant<int, 8>(), ha, LDH, bb4, hb);
+  __syncthreads();
+  if (wave < MT) {  // last linear: row tile `wave`, the one (padded) column tile
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks)
+      mma_k32(acc, r5[ks], *reinterpret_cast<const bf16x8*>(hb + (wave * 16 + fr) * LDH + ks * 32 + g * 8));
+    const int row = wave * 16 + fr, nout = a.nout[net];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int c = g * 4 + r;
+      const float v = c < nout ? acc[r] + b2_s[c] : 0.f;
+      so[row * 16 + c] = v;
+      if (row < E) a.out[net][(int64_t)row * OUT_LD + c] = v;
+    }
+  }
+  __syncthreads();
+  // explore / value epilogue (act_finish_kernel's expressions): a (row, k) pair per thread, then the row's thread sums the
+  // log-prob terms over k = 0 .. A-1 in order
+  if (net == 0) {
+    for (int idx = tid; idx < E * A; idx += 1024) {
+      const int i = idx / A, k = idx - i * A;
+      const float mu = so[i * 16 + k], sg = sg_s[k];
+      const float act = fmaf(sg, eps_s[idx], mu);
+      const float d = act - mu;
+      lt_s[i * 16 + k] = -(d * d) / (2.f * sg * sg) - logf(sg) - HALF_LOG_2PI;
+      fin.action[idx] = act;
+      fin.mean[idx] = mu;
+      fin.stdv[idx] = sg;
+      if (fin.acts_roll != nullptr) fin.acts_roll[(t_step * E) * A + idx] = act;
+    }
+    __syncthreads();
+    if (tid < E) {
+      float e = 0.f, lp = 0.f;
+      for (int k = 0; k < A; ++k) { e += 0.5f + HALF_LOG_2PI + lsg_s[k]; lp += lt_s[tid * 16 + k]; }
+      fin.ent[tid] = e;
+      if (fin.logp_roll != nullptr) fin.logp_roll[t_step * E + tid] = lp;
+    }
+  } else if (tid < E) {
+    const float v = so[tid * 16];
+    fin.value[tid] = v;
+    if (fin.values_roll != nullptr) fin.values_roll[t_step * E + tid] = v;
+  }
+  __syncthreads();
+  if (tid == 0) {  // the second of the two blocks advances the step cursor: both read it at entry
+    __threadfence();
+    const unsigned long long done = atomicAdd(reinterpret_cast<unsigned long long*>(&fin.ctl->done), 1ull);
+    if (done == 1ull) {
       fin.ctl->done = 0;
       fin.ctl->t = t_step + 1;
     }

@@ -862,7 +862,7 @@ int v4l_net::build() {
     }
     upconv.pkpt = add_pack(upconv.w, PK_FRAGPT, upconv.K, upconv.N, upconv.N, upconv.K, 0, 0, 0, 0, 0, 0, 0);
   }
-  if (c.kind != V4L_NET_MLP) {
+  {
     // the rollout step streams these as whole MFMA fragments (rollout_stack_kernel, rollout_encoder2_kernel, csrc/rollout_dense.h);
     // a linear that reads conv3's NHWC rows keeps that k order (L.cin / L.taps, as in its PK_CONV_NHWC pack)
     auto pack_frag = [&](Lin& L) { L.pkf = add_pack(L.w, PK_FRAG, L.Np, L.Kp, L.N, L.K, L.cin, L.taps, 0, 0, 0, 0, 0); };
@@ -871,7 +871,7 @@ int v4l_net::build() {
     if (is_tf()) pack_frag(upconv);
     if (c.kind == V4L_NET_CNN || c.kind == V4L_NET_LOCO) pack_frag(proj);
     for (Lin& L : enc) pack_frag(L);
-    for (int i = 0; i < 3; ++i) {
+    for (int i = 0; i < 3 && c.kind != V4L_NET_MLP; ++i) {
       Conv& v = conv[i];
       v.pkf = add_pack(v.w, PK_FRAG, v.Np, v.Kp, v.Cout, v.K, v.chw ? 0 : v.Cin, v.KH * v.KH, v.KH, 0, 0, 0, 0);
     }
@@ -1894,6 +1894,51 @@ static int run_actor_dense_cnn(v4l_actor* a, const float* obs, const float* eps,
   return 0;
 }
 
+// state-only MLP nets, bf16: one launch per env step, one block per net for ALL E rows (csrc/rollout_dense.h rollout_mlp2_kernel)
+static bool actor_mlp2(const v4l_actor* a) {
+  const v4l_net_cfg& p = a->pf->cfg;
+  return p.compute == V4L_BF16 && a->E <= 64 && p.out_dim <= 16 && a->pf->enc[0].Kp == 128 && a->pf->enc[0].pkf >= 0 &&
+         a->pf->head[0].pkf >= 0 && a->vf->head[0].pkf >= 0 && getenv("V4L_ROLLOUT_MLP_OLD") == nullptr;
+}
+static int run_actor_mlp2(v4l_actor* a, const float* obs, const float* eps, float* state_roll, float* acts_roll,
+                          float* values_roll, float* logp_roll, float* action, float* mean, float* stdv, float* ent, float* value,
+                          hipStream_t s) {
+  v4l_net *pf = a->pf, *vf = a->vf;
+  const int E = a->E;
+  static bool attr_done = false;
+  if (!attr_done) {
+    V4L_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&rollout_mlp2_kernel),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)RollMlp2Lds::bytes));
+    attr_done = true;
+  }
+  const __bf16* pk = (const __bf16*)pf->packed;
+  const __bf16* vk = (const __bf16*)vf->packed;
+  const Layout Lp = pf->layout(E), Lv = vf->layout(E);
+  PhaseScope ps("rollout");
+  RollMlp2 m;
+  memset(&m, 0, sizeof(m));
+  m.wf1 = pk + pf->enc[0].pkf; m.wf2 = pk + pf->enc[1].pkf;
+  m.bf1 = pf->p[pf->enc[0].b]; m.bf2 = pf->p[pf->enc[1].b];
+  m.S = pf->cfg.state_dim; m.Sp = pf->Sp;
+  auto head = [&](int i, v4l_net* net, const __bf16* base, float* out) {
+    m.w0[i] = base + net->head[0].pkf; m.w1[i] = base + net->head[1].pkf; m.w2[i] = base + net->head[2].pkf;
+    m.b0[i] = net->p[net->head[0].b]; m.b1[i] = net->p[net->head[1].b]; m.b2[i] = net->p[net->head[2].b];
+    m.out[i] = out; m.nout[i] = net->cfg.out_dim;
+  };
+  head(0, pf, pk, a->ws + Lp.out);
+  head(1, vf, vk, a->ws + Lp.total + Lv.out);
+  InfFinish fin;
+  memset(&fin, 0, sizeof(fin));
+  fin.ctl = a->ctl; fin.logstd = pf->p[pf->logstd]; fin.eps = eps; fin.A = pf->cfg.out_dim;
+  fin.acts_roll = acts_roll; fin.values_roll = values_roll; fin.logp_roll = logp_roll; fin.action = action;
+  fin.mean = mean; fin.stdv = stdv; fin.ent = ent; fin.value = value;
+  g_op = "step";
+  V4L_KLAUNCH("rollout_mlp", 2.0 * 2 * E * (128.0 * 256 + 4 * 256 * 256), s, rollout_mlp2_kernel, dim3(2), dim3(1024),
+              RollMlp2Lds::bytes, s, obs, E, m, fin, state_roll);
+  V4L_LAUNCH_CHECK();
+  return 0;
+}
+
 // state-only MLP nets of the shipped shape: one launch per env step (rollout_mlp_kernel)
 static bool actor_fusable_mlp(const v4l_actor* a) {
   const v4l_net_cfg &p = a->pf->cfg, &v = a->vf->cfg;
@@ -2420,6 +2465,8 @@ static int run_actor_step(v4l_actor* a, const float* obs, const float* eps, floa
   int rc;
   V4L_REQUIRE(pf->bound && vf->bound, "v4l_actor_step: nets are not bound");
   if (shared_encoder && actor_fusable_mlp(a) && pf->enc[0].Kp <= 128) {
+    if (actor_mlp2(a))
+      return run_actor_mlp2(a, obs, eps, state_roll, acts_roll, values_roll, logp_roll, action, mean, stdv, ent, value, s);
     if (pf->cfg.compute == V4L_BF16)
       return run_actor_fused_mlp<__bf16>(a, obs, eps, state_roll, acts_roll, values_roll, logp_roll, action, mean, stdv, ent,
                                          value, s);

@@ -122,17 +122,11 @@ __device__ __forceinline__ void wps_gemm_f(f32x4 (&acc)[2], const T* W, int tile
   }
 }
 __device__ __forceinline__ float xsum(float v) {  // over the four lane groups that share a token (T layout row)
-#ifdef WPS_X2
-  return v * 4.f;
-#endif
   v += __shfl_xor(v, 16);
   v += __shfl_xor(v, 32);
   return v;
 }
 __device__ __forceinline__ float xmax(float v) {
-#ifdef WPS_X2
-  return v;
-#endif
   v = fmaxf(v, __shfl_xor(v, 16));
   v = fmaxf(v, __shfl_xor(v, 32));
   return v;
@@ -170,9 +164,6 @@ template <typename T>
 __device__ __forceinline__ void wps_store_opnd(const WpsOut& o, int pair, const typename Frag<T>::type& f0, const typename Frag<T>::type& f1,
                                                const typename Frag<T>::type& E0, const typename Frag<T>::type& E1, int lane) {
   typedef typename Frag<T>::type frag_t;
-#ifdef WPS_X1
-  return;
-#endif
   f32x4 d0 = zero4(), d1 = zero4();
   mma_k32(d0, f0, E0);  // d0[r] = f0[token 4g + r][feature fr of tile 2 pair]
   mma_k32(d1, f0, E1);
