@@ -39,6 +39,9 @@
  *   V4L_LAYER_SPW=2|4, V4L_LAYER_BWD_SPW=2|4      samples per block of the block-cooperative layer kernels
  *   V4L_CONV_BWD_BLOCKS, V4L_CONV3_WGRAD_BLOCKS, V4L_TRAIN_ENC_BLOCKS, V4L_WIDE_SPLITS   block / split counts (tests force ragged and many-samples-per-block shapes)
  *   V4L_TRAIN_ENC_OLD, V4L_ROLLOUT_ENC_OLD        the streamed-weight encoder kernels
+ *   V4L_GEMM_DEEP_MIN_M       smallest row count the dense layers of the general path send to gemm_nt_deep_kernel (default
+ *                             256; 0 = never; tests lower it) (per call)
+ *   V4L_ROLLOUT_MLP_OLD       state MLP rollout step: the per-sample rollout_mlp_kernel
  *   V4L_ROLLOUT_DENSE_SPLIT   NatureCNN nets' rollout step: the dense layers as three launches instead of one launch with
  *                             device-side hand-overs (per call); V4L_ROLLOUT_CNN_OLD: the per-sample rollout_cnn_kernel
  *   V4L_ROLLOUT_WARM          L2 warm-up touches at the start of rollout_stack_kernel (measured: no effect)

@@ -314,6 +314,18 @@ def test_ppo_update(name, mode, device):
         assert moved > 5e-5  # the optimiser really stepped
 
 
+@pytest.mark.parametrize("mode", MODES)
+@pytest.mark.parametrize("name", ["cnn_s93", "mlp_s93", "cnn_vis", "loco_vis"])
+def test_general_path_through_deep_gemm(name, mode, device, monkeypatch):
+    """The dense layers of a minibatch (M >= 256 rows) run on gemm_nt_deep_kernel (fragment-order weight, 32 x 64 blocks,
+    8 K-stages in flight); the B = 1024 cases exercise it by default, here the small cases are sent through it as well
+    (ragged row tiles, column tiles past the padded width, forward and data-grad packs of every Linear)."""
+    monkeypatch.setenv("V4L_GEMM_DEEP_MIN_M", "1")
+    test_forward(name, mode, device)
+    test_backward(name, mode, device)
+    test_ppo_update(name, mode, device)
+
+
 @pytest.mark.parametrize("name", list(util.GAE_CASES))
 def test_gae_bit_exact(name, device):
     from vision4leg_amd import engine

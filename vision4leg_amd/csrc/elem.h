@@ -724,7 +724,7 @@ __global__ __launch_bounds__(256) void clip_adam_kernel(const ParamSeg* __restri
 
 // --------------------------------------------------------------------------------- weight packing
 // Builds the contraction-ready copies of a weight tensor (operand type T, zero padded to the GEMM tiles).
-enum { PK_NT = 0, PK_T = 1, PK_CONV_NHWC = 2, PK_CONV_NHWC_T = 3, PK_CONV_DGRAD = 4, PK_FRAG = 5, PK_FRAGP = 6, PK_FRAGPT = 7 };
+enum { PK_NT = 0, PK_T = 1, PK_CONV_NHWC = 2, PK_CONV_NHWC_T = 3, PK_CONV_DGRAD = 4, PK_FRAG = 5, PK_FRAGP = 6, PK_FRAGPT = 7, PK_FRAGT = 8 };
 struct PackDesc {
   const float* src;  // PyTorch-layout weight
   int64_t dst_off;   // element offset in the packed buffer
@@ -759,6 +759,16 @@ __device__ __forceinline__ void pack_body(const PackDesc* __restrict__ descs, in
         if (n < d.N && k < d.K) {
           if (d.Cin > 0) { const int tap = k / d.Cin, ci = k - tap * d.Cin; v = src[(int64_t)n * d.K + ci * d.taps + tap]; }  // NHWC k order
           else v = src[(int64_t)n * d.K + k];
+        }
+      } break;
+      case PK_FRAGT: {  // PK_FRAG of the TRANSPOSED weight (data-grad GEMMs): rows = input features (NHWC order when
+        // d.Cin > 0, like PK_CONV_NHWC_T), contraction index = output feature
+        const int j = (int)(e & 7), lane = (int)((e >> 3) & 63), blk = (int)(e >> 9), ksteps = d.Cc >> 5;
+        const int tile = blk / ksteps, ks = blk - tile * ksteps;
+        const int row = tile * 16 + (lane & 15), k = ks * 32 + (lane >> 4) * 8 + j;
+        if (row < d.K && k < d.N) {
+          if (d.Cin > 0) { const int tap = row / d.Cin, ci = row - tap * d.Cin; v = src[(int64_t)k * d.K + ci * d.taps + tap]; }
+          else v = src[(int64_t)k * d.K + row];
         }
       } break;
       case PK_FRAGP:     // fragment order with the wave-per-sample kernels' k permutation (csrc/wps.h): slot (g = lane >> 4, j)

@@ -435,6 +435,101 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(AL al, const T* __restrict
   nt_body<T, BN, AL>(al, Bp, Kp, ep, blockIdx.x, blockIdx.y);
 }
 
+// ------------------------------------------------------------------------------------ gemm_nt, skinny M
+// C = epi(A * W^T) for the dense layers of a minibatch (M ~ 1 K rows, N <= 1 K, K <= 1 K): gemm_nt_kernel's 128 x 64 tiles
+// make 32 blocks of such a problem and walk K one 64-wide stage at a time with ONE stage in flight — 16 exposed round trips
+// for K = 1024 (27 us). Here a block is 32 rows x 64 columns (M/32 x N/64 blocks: 128 for the NatureCNN projector), wave w
+// owns column tile w for both row tiles, the weight arrives in fragment order (PK_FRAG / PK_FRAGT: one contiguous 1 KB read per
+// fragment, straight into registers, no LDS), and EIGHT K-stages of A rows and weight fragments are in flight per thread.
+template <typename T, class AL>
+__global__ __launch_bounds__(256) void gemm_nt_deep_kernel(AL al, const T* __restrict__ Bf, int Np, int Kp, Epi ep) {
+  constexpr int BM = 32, BK = Tile<T>::BK, LD = Tile<T>::LD, D = 8;
+  typedef typename Frag<T>::type frag_t;
+  __shared__ __attribute__((aligned(16))) T sA[2][BM * LD];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int fr = lane & 15, fg = (lane >> 4) * 8;
+  const int m0 = blockIdx.x * BM, tile = blockIdx.y * 4 + wave;
+  const bool live = tile * 16 < Np;  // (wave-uniform) a column tile past the padded width: stages A, multiplies nothing
+  const int KS = Kp >> 5, nkt = Kp / BK;
+  const RowCtx rc = al.row(m0 + (tid >> 3));
+  const int akc = (tid & 7) * 8;
+  const frag_t* Bw = reinterpret_cast<const frag_t*>(Bf) + (size_t)(live ? tile : 0) * KS * 64 + lane;
+  float ra[D][8];
+  frag_t rb[D][2];
+  f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+  for (int d = 0; d < D; ++d)
+    if (d < nkt) {
+      al.load(rc, d * BK + akc, ra[d]);
+      rb[d][0] = Bw[(d * 2) * 64];
+      rb[d][1] = Bw[(d * 2 + 1) * 64];
+    }
+  for (int kt0 = 0; kt0 < nkt; kt0 += D) {
+#pragma unroll
+    for (int d = 0; d < D; ++d) {
+      const int kt = kt0 + d;
+      if (kt < nkt) {  // (uniform)
+        T* buf = sA[d & 1];  // D is even: stage kt uses buffer kt & 1
+        st8<T>(buf + (tid >> 3) * LD + akc, ra[d]);
+        __syncthreads();  // one barrier per stage: the other buffer is only rewritten after the NEXT barrier
+        if (live) {
+#pragma unroll
+          for (int ks = 0; ks < BK / 32; ++ks)
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+              mma_k32(acc[i], rb[d][ks], *reinterpret_cast<const frag_t*>(buf + (i * 16 + fr) * LD + ks * 32 + fg));
+        }
+        if (kt + D < nkt) {
+          al.load(rc, (kt + D) * BK + akc, ra[d]);
+          rb[d][0] = Bw[((kt + D) * 2) * 64];
+          rb[d][1] = Bw[((kt + D) * 2 + 1) * 64];
+        }
+      }
+    }
+  }
+  if (!live) return;
+  // epilogue as in nt_body: acc[i][r] = C[m0 + 16 i + (lane & 15)][16 tile + 4 (lane >> 4) + r]
+  const bool vec = ((ep.N | ep.ldc) & 3) == 0 && (ep.mask == nullptr || (ep.ldmask & 3) == 0);
+  const float* add = ep.accumulate ? ep.C : ep.addend;
+  const int n4 = tile * 16 + (lane >> 4) * 4;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int m = m0 + i * 16 + fr;
+    const bool rok = m < ep.M;
+    const int64_t orow = ep.out_row(rok ? m : 0);
+    if (vec) {
+      const bool ok = rok && n4 < ep.N;
+      float4 v = {acc[i][0], acc[i][1], acc[i][2], acc[i][3]};
+      if (ep.bias != nullptr) {
+        const float4 bv = *reinterpret_cast<const float4*>(ep.bias + (n4 < ep.N ? n4 : 0));
+        v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
+      }
+      if (ep.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+      if (ep.mask != nullptr) {
+        const float4 mk = *reinterpret_cast<const float4*>(ep.mask + (ok ? orow * ep.ldmask + n4 : 0));
+        v.x = mk.x > 0.f ? v.x : 0.f; v.y = mk.y > 0.f ? v.y : 0.f; v.z = mk.z > 0.f ? v.z : 0.f; v.w = mk.w > 0.f ? v.w : 0.f;
+      }
+      if (add != nullptr) {
+        const float4 old = *reinterpret_cast<const float4*>(add + (ok ? orow * ep.ldc + n4 : 0));
+        v.x += old.x; v.y += old.y; v.z += old.z; v.w += old.w;
+      }
+      if (ok) *reinterpret_cast<float4*>(ep.C + orow * ep.ldc + n4) = v;
+    } else {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int n = n4 + r;
+        const bool ok = rok && n < ep.N;
+        float v = acc[i][r];
+        if (ep.bias != nullptr) v += ep.bias[n < ep.N ? n : 0];
+        if (ep.relu) v = fmaxf(v, 0.f);
+        if (ep.mask != nullptr) v = ep.mask[ok ? orow * ep.ldmask + n : 0] > 0.f ? v : 0.f;
+        if (add != nullptr) v += add[ok ? orow * ep.ldc + n : 0];
+        if (ok) ep.C[orow * ep.ldc + n] = v;
+      }
+    }
+  }
+}
+
 // The stride-parity classes of a gather-form conv data-grad (different row counts, weight slices and output pixel
 // maps, same tile shape) as ONE launch: blockIdx.z = class.
 template <typename T> struct DgradClasses {

@@ -25,7 +25,8 @@ struct Lin {         // nn.Linear (or the 1x1 up-conv): y = x W^T + b, W [N][K]
   int64_t pk = 0;
   int Rt = 0, Ct = 0;     // transposed pack [Rt = pad16(K)][Ct = pad64(N)] for the data-grad
   int64_t pkt = 0;
-  int64_t pkf = -1;       // fragment-order pack [Np/16][Kp/32][64 lanes][8] (rollout kernels), -1: none
+  int64_t pkf = -1;       // fragment-order pack [Np/16][Kp/32][64 lanes][8] (rollout kernels, gemm_nt_deep_kernel), -1: none
+  int64_t pkft = -1;      // the same of W^T: [Rt/16][Ct/32][64][8] (data-grads through gemm_nt_deep_kernel), -1: none
   int64_t pkp = -1, pkpt = -1;  // k-permuted fragment-order packs of W / W^T (wave-per-sample layer kernels, csrc/wps.h), -1: none
   int cin = 0, taps = 0;  // > 0: input is an NHWC flatten, packed k = tap*cin + c  (PyTorch k = c*taps + tap)
   bool need_dgrad = true;

@@ -295,10 +295,26 @@ static int wgrad_reduce_all(Ctx& c) {
 
 struct Act { float* p; int ld; int w; };
 
+// minibatch-sized dense problems go to gemm_nt_deep_kernel (csrc/gemm.h): fragment-order weight, 32 x 64 blocks, 8 K-stages in flight
+static inline bool nt_deep_shape(int M, int Kp) {
+  const char* e = getenv("V4L_GEMM_DEEP_MIN_M");  // (read per call: tests lower it to run their small batches through it; 0 = off)
+  const int min_m = e ? atoi(e) : 256;
+  return min_m > 0 && M >= min_m && M <= 65536 && Kp <= 4096;
+}
+template <typename T>
+static int launch_nt_deep(hipStream_t s, const ADense& al, const T* Bf, int Np, int Kp, Epi ep, double flops) {
+  ep.M = al.M;
+  V4L_KLAUNCH("gemm_nt_deep", flops, s, (gemm_nt_deep_kernel<T, ADense>), dim3(cdiv(al.M, 32), cdiv(Np, 64)), dim3(256), 0, s, al,
+              Bf, Np, Kp, ep);
+  V4L_LAUNCH_CHECK();
+  return 0;
+}
 template <typename T>
 static int lin_fwd(const Ctx& c, const Lin& L, const ADense& a, Epi ep) {
   ep.bias = c.net->p[L.b];
   g_op = L.tag_fwd.c_str();
+  if (L.pkf >= 0 && nt_deep_shape(a.M, L.Kp))
+    return launch_nt_deep<T>(c.s, a, (const T*)c.net->packed + L.pkf, L.Np, L.Kp, ep, 2.0 * a.M * L.N * L.K);
   return launch_nt<T>(c.s, a, a.M, (const T*)c.net->packed + L.pk, L.Np, L.Kp, ep, 2.0 * a.M * L.N * L.K);
 }
 // Dense weight-grads are not launched where they arise: they are collected and run as ONE grouped launch at the end
@@ -368,6 +384,8 @@ template <typename T>
 static int lin_dgrad(const Ctx& c, const Lin& L, const ADense& y, Epi ep) {
   ep.N = L.K;
   g_op = L.tag_dgrad.c_str();
+  if (L.pkft >= 0 && nt_deep_shape(y.M, L.Ct))
+    return launch_nt_deep<T>(c.s, y, (const T*)c.net->packed + L.pkft, L.Rt, L.Ct, ep, 2.0 * y.M * L.N * L.K);
   return launch_nt<T>(c.s, y, y.M, (const T*)c.net->packed + L.pkt, L.Rt, L.Ct, ep, 2.0 * y.M * L.N * L.K);
 }
 
@@ -865,7 +883,11 @@ int v4l_net::build() {
   {
     // the rollout step streams these as whole MFMA fragments (rollout_stack_kernel, rollout_encoder2_kernel, csrc/rollout_dense.h);
     // a linear that reads conv3's NHWC rows keeps that k order (L.cin / L.taps, as in its PK_CONV_NHWC pack)
-    auto pack_frag = [&](Lin& L) { L.pkf = add_pack(L.w, PK_FRAG, L.Np, L.Kp, L.N, L.K, L.cin, L.taps, 0, 0, 0, 0, 0); };
+    auto pack_frag = [&](Lin& L) {
+      L.pkf = add_pack(L.w, PK_FRAG, L.Np, L.Kp, L.N, L.K, L.cin, L.taps, 0, 0, 0, 0, 0);
+      if (L.need_dgrad && c.kind != V4L_NET_LOCO)  // (the LocoTransformer's data-grads live in the fused kernels)
+        L.pkft = add_pack(L.w, PK_FRAGT, L.Rt, L.Ct, L.N, L.K, L.cin, L.taps, 0, 0, 0, 0, 0);
+    };
     for (TLayer& t : layers) { pack_frag(t.inproj); pack_frag(t.outproj); pack_frag(t.ff1); pack_frag(t.ff2); }
     for (Lin& L : head) pack_frag(L);
     if (is_tf()) pack_frag(upconv);
