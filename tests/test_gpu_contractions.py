@@ -236,7 +236,7 @@ def test_every_contraction_teacher_forced(name, mode, device, layer_taps):
 
 @pytest.mark.parametrize("mode", MODES)
 @pytest.mark.parametrize("name", ["cnn_s93", "mlp_s93", "cnn_vis", "loco_vis"])
-def test_contractions_of_the_other_nets(name, mode, device, layer_taps):
+def test_contractions_of_the_other_nets(name, mode, device, layer_taps, monkeypatch):
     """The same per-contraction statement for the nets that run on the general (layer-by-layer) GEMM kernels plus the fused
     conv-stack backward: NatureCNN fuse net (nets.py:247-262, base.py:371-385), state MLP (nets.py:52-55) and the two
     vision-only nets (nets.py:133-191, 784-906) — conv stack forward, projector / MLP / head chains forward, their data-grads,
@@ -244,6 +244,10 @@ def test_contractions_of_the_other_nets(name, mode, device, layer_taps):
     attention / LayerNorm kernels; its conv stack, up-conv and head are checked here.)"""
     case = util.CASES[name]
     kind = case["kind"]
+    if kind == "loco_vis":
+        # the taps below are the layer-by-layer path's 16-row token tensors; the wave-per-sample path of this net (17-row stride,
+        # dummy row 0) is checked against this one by test_vision_only_transformer_on_wave_per_sample_kernels
+        monkeypatch.setenv("V4L_NO_WPS_LAYERS", "1")
     n, S, A = case["B"], case["S"], case["A"]
     pf, vf = _build(case, mode, device)
     tag = name + "/" + mode

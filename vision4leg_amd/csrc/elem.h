@@ -780,8 +780,10 @@ __device__ __forceinline__ void pack_body(const PackDesc* __restrict__ descs, in
         if (d.kind == PK_FRAGP) { if (row < d.N && k < d.K) v = src[(int64_t)row * d.K + k]; }
         else if (row < d.K && k < d.N) v = src[(int64_t)k * d.K + row];
       } break;
-      case PK_NT: if (r < d.N && c < d.K) v = src[(int64_t)r * d.K + c]; break;
-      case PK_T: if (r < d.K && c < d.N) v = src[(int64_t)c * d.K + r]; break;
+      // (d.px: the source's K axis starts at packed column / row px — the vision-only Transformer's first head layer inside
+      // the 128-wide pooled operand of the wave-per-sample kernels, csrc/wps.h; 0 everywhere else)
+      case PK_NT: if (r < d.N && c >= d.px && c - d.px < d.K) v = src[(int64_t)r * d.K + (c - d.px)]; break;
+      case PK_T: if (r >= d.px && r - d.px < d.K && c < d.N) v = src[(int64_t)c * d.K + (r - d.px)]; break;
       case PK_CONV_NHWC:  // dst[n][tap*Cin+ci] = W[n][ci][tap]
         if (r < d.N && c < d.K) { const int tap = c / d.Cin, ci = c - tap * d.Cin; v = src[(int64_t)r * d.K + ci * d.taps + tap]; }
         break;

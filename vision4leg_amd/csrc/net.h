@@ -28,6 +28,8 @@ struct Lin {         // nn.Linear (or the 1x1 up-conv): y = x W^T + b, W [N][K]
   int64_t pkf = -1;       // fragment-order pack [Np/16][Kp/32][64 lanes][8] (rollout kernels, gemm_nt_deep_kernel), -1: none
   int64_t pkft = -1;      // the same of W^T: [Rt/16][Ct/32][64][8] (data-grads through gemm_nt_deep_kernel), -1: none
   int64_t pkp = -1, pkpt = -1;  // k-permuted fragment-order packs of W / W^T (wave-per-sample layer kernels, csrc/wps.h), -1: none
+  int64_t pko = -1, pkto = -1;  // vision-only Transformer, first head layer: [N][128] / [128][N] row-major packs with the 64
+                                // real K entries at offset 64 (the pooled operand's second half), -1: none
   int cin = 0, taps = 0;  // > 0: input is an NHWC flatten, packed k = tap*cin + c  (PyTorch k = c*taps + tap)
   bool need_dgrad = true;
   std::string tag_fwd, tag_wgrad, tag_dgrad;  // profiler labels
@@ -133,7 +135,8 @@ struct v4l_net {
   template <typename T> int forward_t(const float* state, const T* image, const int* rowidx, int n, float* ws, hipStream_t s,
                                       const float* enc_ws = nullptr, int stage = 0);
   bool fused_layers() const;  // the transformer layers run as fused forward / backward launches (csrc/infer.h, bwd.h)
-  bool wps_layers() const;    // ... as wave-per-sample launches (csrc/wps.h)
+  bool wps_layers() const;
+  bool wps_vis() const;  // vision-only Transformer on the wave-per-sample kernels (dummy token row, csrc/wps.h)    // ... as wave-per-sample launches (csrc/wps.h)
   template <typename T> int backward_t(const float* state, const T* image, const int* rowidx, int n, float* ws, float* grads, hipStream_t s);
 };
 

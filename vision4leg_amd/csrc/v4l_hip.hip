@@ -856,7 +856,7 @@ int v4l_net::build() {
   for (Lin& L : enc) pack_lin(L);
   for (TLayer& t : layers) { pack_lin(t.inproj); pack_lin(t.outproj); pack_lin(t.ff1); pack_lin(t.ff2); }
   for (Lin& L : head) pack_lin(L);
-  if (c.kind == V4L_NET_LOCO && c.ff_dim == 256) {
+  if (is_tf() && c.ff_dim == 256) {
     // wave-per-sample layer kernels (csrc/wps.h): per layer ONE contiguous block [in_proj | out_proj | linear1 | linear2] of
     // k-permuted fragment-order packs (it is DMA'd into LDS as a whole), and the same of the transposed weights
     for (TLayer& t : layers) {
@@ -879,6 +879,12 @@ int v4l_net::build() {
                       t.ff2.pkpt - t.inproj.pkpt == WPS_OFF_W2, "internal: wave-per-sample transposed weight block layout");
     }
     upconv.pkpt = add_pack(upconv.w, PK_FRAGPT, upconv.K, upconv.N, upconv.N, upconv.K, 0, 0, 0, 0, 0, 0, 0);
+    if (c.kind == V4L_NET_LOCO_VIS && head[0].K == TD) {
+      // the first head layer against the 128-wide pooled operand [dummy row | mean of the 16 tokens]: K entries at offset 64
+      Lin& h0 = head[0];
+      h0.pko = add_pack(h0.w, PK_NT, h0.Np, 2 * TD, h0.N, h0.K, 0, 0, 0, 0, 0, TD, 0);
+      h0.pkto = add_pack(h0.w, PK_T, 2 * TD, h0.Ct, h0.N, h0.K, 0, 0, 0, 0, 0, TD, 0);
+    }
   }
   {
     // the rollout step streams these as whole MFMA fragments (rollout_stack_kernel, rollout_encoder2_kernel, csrc/rollout_dense.h);
@@ -911,6 +917,12 @@ int64_t v4l_net::table_bytes() const {
 }
 bool v4l_net::wps_layers() const {
   return fused_layers() && cfg.n_layers == 2 && layers[0].inproj.pkp >= 0 && getenv("V4L_NO_WPS_LAYERS") == nullptr;
+}
+bool v4l_net::wps_vis() const {
+  const v4l_net_cfg& c = cfg;
+  return c.kind == V4L_NET_LOCO_VIS && c.ff_dim == 256 && c.n_layers == 2 && c.n_head_hidden == 2 && c.head_hidden[0] == 256 &&
+         c.head_hidden[1] == 256 && c.out_dim <= OUT_LD && layers[0].inproj.pkp >= 0 && head[0].pko >= 0 &&
+         getenv("V4L_NO_WPS_LAYERS") == nullptr && getenv("V4L_NO_FUSED_LAYER") == nullptr;
 }
 bool v4l_net::fused_layers() const {
   return cfg.kind == V4L_NET_LOCO && cfg.ff_dim == 256 && getenv("V4L_NO_FUSED_LAYER") == nullptr;
@@ -952,7 +964,9 @@ Layout v4l_net::layout(int n) const {
   int64_t off = 0;
   auto take = [&](int64_t floats) { int64_t o = off; off += (floats + 63) / 64 * 64; return o; };
   const v4l_net_cfg& c = cfg;
-  const int64_t R = (int64_t)n * ntok;
+  // (the vision-only Transformer's token tensors are sized for 17 rows per sample too: its wave-per-sample path keeps the 16
+  // tokens in rows 1..16 of a 17-row stride, the layer-by-layer path packs them 16 per sample into the same buffers)
+  const int64_t R = (int64_t)n * (is_tf() ? NTOK : ntok);
   int maxw = 2 * TD;
   for (int i = 0; i < c.n_enc_hidden; ++i) maxw = std::max(maxw, c.enc_hidden[i]);
   for (int i = 0; i < c.n_head_hidden; ++i) maxw = std::max(maxw, c.head_hidden[i]);
@@ -1036,7 +1050,7 @@ int v4l_net::forward_t(const float* state, const T* image, const int* rowidx, in
   const bool train_enc_ok = persistent_enc && sizeof(T) == 2 && c.kind != V4L_NET_MLP && conv[0].pkf >= 0 &&
                             getenv("V4L_NO_FUSED_ENC") == nullptr &&
                             (vis_only() || (mlp256 && enc[0].Kp == 128 && enc[0].pkf >= 0));
-  auto train_enc = [&](auto mode_tag, float* x0, float* s_h2, int ld_h2) -> int {
+  auto train_enc = [&](auto mode_tag, float* x0, float* s_h2, int ld_h2, bool proprio = true) -> int {
     constexpr int MODE = decltype(mode_tag)::value;
     static bool attr = false;
     if (!attr) {
@@ -1045,7 +1059,7 @@ int v4l_net::forward_t(const float* state, const T* image, const int* rowidx, in
       attr = true;
     }
     const __bf16* pb = (const __bf16*)packed;
-    const bool tok = MODE == ENC_TOK17 || MODE == ENC_TOK16, prop = MODE == ENC_TOK17 || MODE == ENC_FUSE;
+    const bool tok = MODE == ENC_TOK17 || MODE == ENC_TOK16, prop = proprio && (MODE == ENC_TOK17 || MODE == ENC_FUSE);
     InfEncFrag ef;
     memset(&ef, 0, sizeof(ef));
     ef.w1 = pb + conv[0].pkf; ef.w2 = pb + conv[1].pkf; ef.w3 = pb + conv[2].pkf; ef.wup = tok ? pb + upconv.pkf : ef.w3;
@@ -1142,11 +1156,17 @@ int v4l_net::forward_t(const float* state, const T* image, const int* rowidx, in
       V4L_LAUNCH_CHECK();
     } else if (enc_ws == nullptr && stage != 2 && c.kind == V4L_NET_LOCO_VIS) {
       // TransformerEncoder (base.py:388-494, depth only): conv stack -> 1x1 up-conv -> the 16 patch tokens, in order
+      // wave-per-sample path: the 16 tokens go to rows 1..16 of a 17-row stride (row 0 = the dummy row, csrc/wps.h)
+      const bool rows17 = stage == 0 && wps_vis();
       if (train_enc_ok) {
-        if ((rc = train_enc(std::integral_constant<int, ENC_TOK16>(), x0, nullptr, 0))) return rc;
+        if (rows17) rc = train_enc(std::integral_constant<int, ENC_TOK17>(), x0, nullptr, 0, false);
+        else rc = train_enc(std::integral_constant<int, ENC_TOK16>(), x0, nullptr, 0);
+        if (rc) return rc;
       } else {
         if ((rc = conv_stack_fwd<T>(cx, image, rowidx, n, ws + L.c1, ws + L.c2, ws + L.c3))) return rc;
-        if ((rc = lin_fwd<T>(cx, upconv, dense(ws + L.c3, 64, n * 16, 64), mk_epi(x0, TD, TD)))) return rc;
+        Epi ep = mk_epi(x0, TD, TD);
+        if (rows17) ep.rowmap = ROWMAP_TOK_DEPTH;
+        if ((rc = lin_fwd<T>(cx, upconv, dense(ws + L.c3, 64, n * 16, 64), ep))) return rc;
       }
     } else if (enc_ws == nullptr && stage != 2) {
       // proprio branch (MLP + state_projector -> token 0) on the aux stream next to the conv branch (-> tokens 1..16)
@@ -1177,13 +1197,18 @@ int v4l_net::forward_t(const float* state, const T* image, const int* rowidx, in
     // the layers); otherwise one launch per TransformerEncoderLayer. 2 or 4 samples per block, saving what backward_t reads.
     const bool stack_ok = getenv("V4L_NO_LAYER_STACK") == nullptr;  // (read per call: tests switch it)
     const bool stacked = fused_layers && fused_head && c.n_layers == 2 && stack_ok;
-    if (stacked && wps_layers()) {
+    const bool vis_wps = c.kind == V4L_NET_LOCO_VIS && enc_ws == nullptr && stage == 0 && wps_vis();
+    if ((stacked && wps_layers()) || vis_wps) {
       // wave-per-sample launch (csrc/wps.h): both layers + the pooled heads, 4 samples per block, weights resident in LDS
       static bool wps_attr = false;
       if (!wps_attr) {
         V4L_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&wps_layer_fwd_kernel<T, true, 2, false>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)WpsFwdLds<T>::bytes));
         V4L_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&wps_layer_fwd_kernel<T, true, 2, true>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)WpsFwdLds<T>::bytes));
+        V4L_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&wps_layer_fwd_kernel<T, true, 2, false, true>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)WpsFwdLds<T>::bytes));
+        V4L_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&wps_layer_fwd_kernel<T, true, 2, true, true>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)WpsFwdLds<T>::bytes));
         wps_attr = true;
       }
@@ -1212,12 +1237,18 @@ int v4l_net::forward_t(const float* state, const T* image, const int* rowidx, in
       InfHeadPair hd;
       memset(&hd, 0, sizeof(hd));
       InfHead& h = hd.n[0];
-      h.w0 = base + head[0].pk; h.w1 = base + head[1].pk; h.w2 = base + head[2].pk;
+      h.w0 = base + (vis_wps ? head[0].pko : head[0].pk); h.w1 = base + head[1].pk; h.w2 = base + head[2].pk;
       h.b0 = p[head[0].b]; h.b1 = p[head[1].b]; h.b2 = p[head[2].b];
       h.out = ws + L.out; h.nout = c.out_dim;
       h.s_pooled = ws + L.pooled; h.s_h0 = ws + L.hh[0]; h.s_h1 = ws + L.hh[1];
       g_op = "layer";
-      if (taps)
+      if (vis_wps && taps)
+        V4L_KLAUNCH("wps_layer_stack_head", 2.0 * n * (2 * 872576.0 + 99840.0), s, (wps_layer_fwd_kernel<T, true, 2, true, true>),
+                    dim3(cdiv(n, WPS_WPB)), dim3(256), (WpsFwdLds<T>::bytes), s, stk, hd, n);
+      else if (vis_wps)
+        V4L_KLAUNCH("wps_layer_stack_head", 2.0 * n * (2 * 872576.0 + 99840.0), s, (wps_layer_fwd_kernel<T, true, 2, false, true>),
+                    dim3(cdiv(n, WPS_WPB)), dim3(256), (WpsFwdLds<T>::bytes), s, stk, hd, n);
+      else if (taps)
         V4L_KLAUNCH("wps_layer_stack_head", 2.0 * n * (2 * 872576.0 + 99840.0), s, (wps_layer_fwd_kernel<T, true, 2, true>),
                     dim3(cdiv(n, WPS_WPB)), dim3(256), (WpsFwdLds<T>::bytes), s, stk, hd, n);
       else
@@ -1421,10 +1452,14 @@ int v4l_net::backward_t(const float* state, const T* image, const int* rowidx, i
                           getenv("V4L_NO_FUSED_HEAD_BWD") == nullptr;
   const bool fused_tail = fused_bwd && c.n_layers >= 1 && ne == 2 && c.enc_hidden[0] == 256 && c.enc_hidden[1] == 256 &&
                           getenv("V4L_NO_FUSED_TAIL_BWD") == nullptr;
-  if (fused_head) {  // only the three weight-grads are registered here
+  // vision-only Transformer on the wave-per-sample kernels (17-row stride, dummy row 0: csrc/wps.h); the forward took the same path
+  const bool vis_wps = vis && wps_vis();
+  if (fused_head || vis_wps) {  // only the three weight-grads are registered here
     if ((rc = lin_wgrad<T>(cx, head[2], dy, dense(hacts[1].p, 256, n, 256), 256))) return rc;
     if ((rc = lin_wgrad<T>(cx, head[1], dense(dhhp[1], 256, n, 256), dense(hacts[0].p, 256, n, 256), 256))) return rc;
-    if ((rc = lin_wgrad<T>(cx, head[0], dense(dhhp[0], 256, n, 256), dense(ws + L.pooled, 2 * TD, n, 2 * TD), 2 * TD))) return rc;
+    if (vis_wps) rc = lin_wgrad<T>(cx, head[0], dense(dhhp[0], 256, n, 256), dense(ws + L.pooled + TD, 2 * TD, n, TD), TD);
+    else rc = lin_wgrad<T>(cx, head[0], dense(dhhp[0], 256, n, 256), dense(ws + L.pooled, 2 * TD, n, 2 * TD), 2 * TD);
+    if (rc) return rc;
   } else {
     Epi din = mk_epi(ws + L.dpool, pw, pw);
     if ((rc = chain_bwd<T>(cx, head.data(), nh + 1, dense(ws + L.pooled, pw, n, pw), hacts, dy, dhhp, &din)))
@@ -1442,7 +1477,7 @@ int v4l_net::backward_t(const float* state, const T* image, const int* rowidx, i
   // Every data-grad of a layer has its intermediates in LDS; the four weight-grads are deferred to the grouped launch.
   const bool bwd_stack_ok = getenv("V4L_NO_LAYER_STACK") == nullptr;
   const bool stacked = fused_bwd && fused_head && fused_tail && c.n_layers == 2 && bwd_stack_ok;
-  const bool wps = stacked && wps_layers();
+  const bool wps = (stacked && wps_layers()) || vis_wps;
   if (wps) {
     // wave-per-sample launch (csrc/wps.h): heads -> per layer {recompute, backward} -> encoder-side data-grads; the four
     // weight-grads of each layer come from the fragment-order operand blocks it leaves, in one launch of their own
@@ -1451,6 +1486,10 @@ int v4l_net::backward_t(const float* state, const T* image, const int* rowidx, i
       V4L_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&wps_layer_bwd_kernel<T, 2, false>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)WpsBwdLds<T>::bytes));
       V4L_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&wps_layer_bwd_kernel<T, 2, true>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)WpsBwdLds<T>::bytes));
+      V4L_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&wps_layer_bwd_kernel<T, 2, false, true>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)WpsBwdLds<T>::bytes));
+      V4L_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&wps_layer_bwd_kernel<T, 2, true, true>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)WpsBwdLds<T>::bytes));
       wps_attr = true;
     }
@@ -1487,18 +1526,25 @@ int v4l_net::backward_t(const float* state, const T* image, const int* rowidx, i
     }
     BwdHead bh;
     memset(&bh, 0, sizeof(bh));
-    bh.w2t = base + head[2].pkt; bh.w1t = base + head[1].pkt; bh.w0t = base + head[0].pkt;
+    bh.w2t = base + head[2].pkt; bh.w1t = base + head[1].pkt; bh.w0t = base + (vis_wps ? head[0].pkto : head[0].pkt);
     bh.dout = ws + L.dout; bh.s_h1 = hacts[1].p; bh.s_h0 = hacts[0].p; bh.o_dh1 = dhhp[1]; bh.o_dh0 = dhhp[0];
     BwdTail bt;
     memset(&bt, 0, sizeof(bt));
-    bt.wpt = base + proj.pkt; bt.wf2t = base + enc[1].pkt; bt.wupt = base + upconv.pkt;
-    bt.x0 = ws + L.x[0]; bt.s_e1 = eacts[1].p; bt.s_e0 = eacts[0].p; bt.s_c3 = ws + L.c3;
-    bt.o_dhc = ws + L.dhc; bt.o_de0 = dehp[0]; bt.o_dc3 = ws + L.dc3;
+    bt.wupt = base + upconv.pkt;
+    bt.x0 = ws + L.x[0]; bt.s_c3 = ws + L.c3; bt.o_dc3 = ws + L.dc3;
+    if (!vis_wps) {  // the proprio branch's data-grads (token 0)
+      bt.wpt = base + proj.pkt; bt.wf2t = base + enc[1].pkt;
+      bt.s_e1 = eacts[1].p; bt.s_e0 = eacts[0].p; bt.o_dhc = ws + L.dhc; bt.o_de0 = dehp[0];
+    }
     WpsTailExtra tx;
     tx.wupt_f = base + upconv.pkpt;
     g_op = "layer";
     const double fl = 2 * 4.0 * n * 872576.0 + 2.0 * n * 2 * (16 * 256 + 256 * 256 + 256 * 128) + 2.0 * n * (64 * 256 + 256 * 256 + 16 * 64 * 64);
-    if (taps)
+    if (vis_wps && taps)
+      V4L_KLAUNCH("wps_layer_bwd_stack", fl, s, (wps_layer_bwd_kernel<T, 2, true, true>), dim3(nblk), dim3(256), (WpsBwdLds<T>::bytes), s, d, bh, bt, tx, n);
+    else if (vis_wps)
+      V4L_KLAUNCH("wps_layer_bwd_stack", fl, s, (wps_layer_bwd_kernel<T, 2, false, true>), dim3(nblk), dim3(256), (WpsBwdLds<T>::bytes), s, d, bh, bt, tx, n);
+    else if (taps)
       V4L_KLAUNCH("wps_layer_bwd_stack", fl, s, (wps_layer_bwd_kernel<T, 2, true>), dim3(nblk), dim3(256), (WpsBwdLds<T>::bytes), s, d, bh, bt, tx, n);
     else
       V4L_KLAUNCH("wps_layer_bwd_stack", fl, s, (wps_layer_bwd_kernel<T, 2, false>), dim3(nblk), dim3(256), (WpsBwdLds<T>::bytes), s, d, bh, bt, tx, n);
@@ -1633,7 +1679,7 @@ int v4l_net::backward_t(const float* state, const T* image, const int* rowidx, i
       if ((rc = lin_wgrad_wide(cx, t.inproj, ws + b.dqkv, xin, R))) return rc;
     }
   }
-  for (int l = c.n_layers - 1; l >= 0 && !fused_bwd; --l) {
+  for (int l = c.n_layers - 1; l >= 0 && !fused_bwd && !vis_wps; --l) {
     const TLayer& t = layers[l];
     const LayerWs& w = L.lw[l];
     const LayerBw& b = L.lb[l];
@@ -1684,6 +1730,9 @@ int v4l_net::backward_t(const float* state, const T* image, const int* rowidx, i
     if ((rc = lin_wgrad<T>(cx, enc[0], dense(dehp[0], 256, n, 256), sin, sin.K))) return rc;
     if ((rc = lin_wgrad<T>(cx, upconv, dense(dx, TD, n * 16, TD, nullptr, 1), dense(ws + L.c3, 64, n * 16, 64), 64))) return rc;
   }
+  if (vis_wps) {  // the up-conv data-grad came out of the layer launch (dc3): its weight-grad reads rows 1..16 of the 17-row stride
+    if ((rc = lin_wgrad<T>(cx, upconv, dense(dx, TD, n * 16, TD, nullptr, 1), dense(ws + L.c3, 64, n * 16, 64), 64))) return rc;
+  }
   if (!fused_tail && !vis) {  // token 0 -> state_projector -> encoder MLP
     const Act& last = eacts[ne - 1];
     ADense yp = dense(dx, NTOK * TD, n, TD, nullptr, 0, x0);
@@ -1694,7 +1743,7 @@ int v4l_net::backward_t(const float* state, const T* image, const int* rowidx, i
     if ((rc = lin_dgrad<T>(cx, proj, yp, ep))) return rc;
     if ((rc = chain_bwd<T>(cx, enc.data(), ne, sin, eacts, dense(ws + L.dhc, last.w, n, last.w), dehp, nullptr))) return rc;
   }
-  if (!fused_tail) {  // tokens 1..16 (vision-only: all 16) -> depth_up_conv -> conv stack
+  if (!fused_tail && !vis_wps) {  // tokens 1..16 (vision-only: all 16) -> depth_up_conv -> conv stack
     ADense yu = dense(dx, TD, n * 16, TD, nullptr, vis ? 0 : 1);
     if ((rc = lin_wgrad<T>(cx, upconv, yu, dense(ws + L.c3, 64, n * 16, 64), 64))) return rc;
     Epi ep = mk_epi(ws + L.dc3, 64, 64);

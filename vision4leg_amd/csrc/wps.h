@@ -121,6 +121,7 @@ __device__ __forceinline__ void wps_gemm_f(f32x4 (&acc)[2], const T* W, int tile
     for (int mt = 0; mt < 2; ++mt) mma_k32(acc[mt], xa[mt][ks], fw);
   }
 }
+template <bool VIS> __device__ __forceinline__ bool wps_key_ok(int key) { return key < NTOK && (!VIS || key > 0); }
 __device__ __forceinline__ float xsum(float v) {  // over the four lane groups that share a token (T layout row)
   v += __shfl_xor(v, 16);
   v += __shfl_xor(v, 32);
@@ -211,7 +212,11 @@ template <typename T> struct WpsKeep {
 //     and the test taps. Production passes only xout (the next layer's input).
 //   * wg / tk non-null: the x-side weight-grad operands (layer input, ctx, x1, f) go out in fragment order (wps_store_opnd).
 //   * KEEP: fill `kp` for wps_layer_bwd.
-template <typename T, bool LDSW, bool KEEP, bool TAPS>
+//   * VIS: the vision-only Transformer (nets.py:784-906: 16 depth tokens, no proprio token) on the 17-row machinery: its tokens
+//     sit in rows 1..16, row 0 is a dummy (zero input rows) that no real token attends to — key 0 is masked out of every
+//     softmax. Whatever row 0 computes stays in row 0, the head ignores it (kernel epilogue), and its gradient rows are
+//     exactly zero in the backward (P[:, 0] = 0, zero output gradient), so the weight-grads never see it.
+template <typename T, bool LDSW, bool KEEP, bool TAPS, bool VIS = false>
 __device__ __forceinline__ void wps_layer_fwd(const InfLayer& w, const T* W, const float* prm, const float4 (&xr)[2][4], int lane,
                                               const bool (&ok)[2], int64_t row0, int64_t smp, float4 (&xo)[2][4], const WpsOut* wo,
                                               const typename Frag<T>::type& E0, const typename Frag<T>::type& E1, WpsKeep<T>* kp, int sb = 0) {
@@ -319,7 +324,7 @@ __device__ __forceinline__ void wps_layer_fwd(const InfLayer& w, const T* W, con
     for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        pv[kt][r] = kt * 16 + qr + r < NTOK ? s[kt][r] * 0.125f : -INFINITY;
+        pv[kt][r] = wps_key_ok<VIS>(kt * 16 + qr + r) ? s[kt][r] * 0.125f : -INFINITY;
         mx = fmaxf(mx, pv[kt][r]);
       }
     mx = xmax(mx);
@@ -328,7 +333,7 @@ __device__ __forceinline__ void wps_layer_fwd(const InfLayer& w, const T* W, con
     for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        pv[kt][r] = kt * 16 + qr + r < NTOK ? expf(pv[kt][r] - mx) : 0.f;
+        pv[kt][r] = wps_key_ok<VIS>(kt * 16 + qr + r) ? expf(pv[kt][r] - mx) : 0.f;
         sum += pv[kt][r];
       }
     const float inv = 1.f / xsum(sum);
@@ -521,6 +526,8 @@ __device__ __forceinline__ WpsPrm wps_prm_of(const InfLayer& w) {
 }
 
 // The layer input rows of one sample, row-major fp32 [17][64] -> T layout registers (rows >= 17 and dead samples: zeros)
+// ZERO0: row 0 reads as zeros whatever the buffer holds (the vision-only Transformer's dummy row, see wps_layer_fwd)
+template <bool ZERO0 = false>
 __device__ __forceinline__ void wps_load_rows(const float* __restrict__ xg, int lane, const bool (&ok)[2], float4 (&xr)[2][4]) {
   const int fr = lane & 15, qr = (lane >> 4) * 4;
 #pragma unroll
@@ -528,14 +535,15 @@ __device__ __forceinline__ void wps_load_rows(const float* __restrict__ xg, int 
 #pragma unroll
     for (int nt = 0; nt < 4; ++nt) {
       const float4 v = *reinterpret_cast<const float4*>(xg + (ok[mt] ? mt * 16 + fr : 0) * TD + nt * 16 + qr);
-      xr[mt][nt] = ok[mt] ? v : float4{0.f, 0.f, 0.f, 0.f};
+      const bool keep = ok[mt] && !(ZERO0 && mt == 0 && fr == 0);
+      xr[mt][nt] = keep ? v : float4{0.f, 0.f, 0.f, 0.f};
     }
 }
 
 // Training forward of the transformer stack (+ pooled heads): NL layers for WPS_WPB samples per block, one wave each.
 // stk.l[l].n[0].win points at the layer's fragment-order weight block (PK_FRAGP packs, adjacent); the head packs are the
 // row-major ones of the block-cooperative kernel (the heads run cooperatively: 4 samples = one MFMA row tile).
-template <typename T, bool HEAD, int NL, bool TAPS>
+template <typename T, bool HEAD, int NL, bool TAPS, bool VIS = false>
 __global__ __launch_bounds__(256) void wps_layer_fwd_kernel(InfLayerStack stk, InfHeadPair hd, int n) {
   typedef WpsFwdLds<T> LY;
   typedef typename Frag<T>::type frag_t;
@@ -557,7 +565,7 @@ __global__ __launch_bounds__(256) void wps_layer_fwd_kernel(InfLayerStack stk, I
     wps_stage<T, LDSW>(stk.l[0].n[0].win, &pp, wl, prm, tid);
   }
   float4 xr[2][4];
-  wps_load_rows(stk.l[0].n[0].xin + row0 * TD, lane, ok, xr);
+  wps_load_rows<VIS>(stk.l[0].n[0].xin + row0 * TD, lane, ok, xr);
   const frag_t E0 = wps_sel<T>(0, lane), E1 = wps_sel<T>(1, lane);
 #pragma unroll
   for (int l = 0; l < NL; ++l) {
@@ -572,8 +580,8 @@ __global__ __launch_bounds__(256) void wps_layer_fwd_kernel(InfLayerStack stk, I
     __syncthreads();
     WPS_STAMP(8 * l + 7);
     float4 xo[2][4];
-    wps_layer_fwd<T, LDSW, false, TAPS>(w, LDSW ? wl : reinterpret_cast<const T*>(w.win), prm, xr, lane, ok, row0, srow, xo,
-                                        (const WpsOut*)nullptr, E0, E1, (WpsKeep<T>*)nullptr, 8 * l);
+    wps_layer_fwd<T, LDSW, false, TAPS, VIS>(w, LDSW ? wl : reinterpret_cast<const T*>(w.win), prm, xr, lane, ok, row0, srow, xo,
+                                             (const WpsOut*)nullptr, E0, E1, (WpsKeep<T>*)nullptr, 8 * l);
     WPS_STAMP(8 * l + 6);
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt)
@@ -608,10 +616,13 @@ __global__ __launch_bounds__(256) void wps_layer_fwd_kernel(InfLayerStack stk, I
       const float4 mv = {rowsum16(m.x) * (1.f / 16.f), rowsum16(m.y) * (1.f / 16.f), rowsum16(m.z) * (1.f / 16.f),
                          rowsum16(m.w) * (1.f / 16.f)};
       if (fr == 0 && live) {
-        *reinterpret_cast<float4*>(pooled + wave * LY::LDP + nt * 16 + qr) = xr[0][nt];
+        // VIS: the head reads the mean of the 16 tokens only — the dummy row's half is zeros here and h.w0 is the [256][128]
+        // pack whose columns 0..63 are zero
+        const float4 t0 = VIS ? float4{0.f, 0.f, 0.f, 0.f} : xr[0][nt];
+        *reinterpret_cast<float4*>(pooled + wave * LY::LDP + nt * 16 + qr) = t0;
         *reinterpret_cast<float4*>(pooled + wave * LY::LDP + TD + nt * 16 + qr) = mv;
         if (h.s_pooled != nullptr) {
-          *reinterpret_cast<float4*>(h.s_pooled + (int64_t)smp * 128 + nt * 16 + qr) = xr[0][nt];
+          *reinterpret_cast<float4*>(h.s_pooled + (int64_t)smp * 128 + nt * 16 + qr) = t0;
           *reinterpret_cast<float4*>(h.s_pooled + (int64_t)smp * 128 + TD + nt * 16 + qr) = mv;
         }
       }
@@ -874,8 +885,10 @@ __device__ __forceinline__ void wps_layer_bwd(const WpsBwdLayer& w, const T* Wt,
 // per layer {recompute the forward in registers, walk it backward} -> encoder-side data-grads (TAIL: up-conv per wave in
 // registers, the token-0 chain cooperatively).
 struct WpsTailExtra { const void* wupt_f; };  // up-conv's transposed weight as a k-permuted fragment pack
-template <typename T, int NL, bool TAPS>
+template <typename T, int NL, bool TAPS, bool VIS = false>
 __global__ __launch_bounds__(256) void wps_layer_bwd_kernel(WpsBwdStack stk, BwdHead hd, BwdTail tl, WpsTailExtra tx, int n) {
+  // VIS (template parameter): see wps_layer_fwd — hd.w0t is then the [128][256] pack whose rows 0..63 are zero (the dummy
+  // row's un-pooled gradient is exactly zero), and the TAIL ends after the up-conv data-grad (there is no proprio branch)
   typedef WpsBwdLds<T> LY;
   typedef typename Frag<T>::type frag_t;
   constexpr bool LDSW = LY::LDSW;
@@ -983,7 +996,7 @@ __global__ __launch_bounds__(256) void wps_layer_bwd_kernel(WpsBwdStack stk, Bwd
       const WpsPrm pp = WpsPrm{w.bin, w.bo, w.b1, w.b2, w.g1, w.be1, w.g2, w.be2};
       wps_stage<T, LDSW>(w.w, &pp, wl, prm, tid);
     }
-    wps_load_rows(w.xin + row0 * TD, lane, ok, xr);
+    wps_load_rows<VIS>(w.xin + row0 * TD, lane, ok, xr);
     __builtin_amdgcn_s_waitcnt(0);
     __syncthreads();
     WPS_STAMP(34 + 8 * l);
@@ -996,7 +1009,7 @@ __global__ __launch_bounds__(256) void wps_layer_bwd_kernel(WpsBwdStack stk, Bwd
       none.s_qkv = none.s_P = none.s_xh1 = none.s_rs1 = none.s_xh2 = none.s_rs2 = nullptr;
       none.s_xin = none.s_ctx = none.s_x1 = none.s_f = nullptr;
       float4 xo[2][4];
-      wps_layer_fwd<T, LDSW, true, false>(none, LDSW ? wl : reinterpret_cast<const T*>(w.w), prm, xr, lane, ok, row0, srow, xo, &wo, E0, E1, &K);
+      wps_layer_fwd<T, LDSW, true, false, VIS>(none, LDSW ? wl : reinterpret_cast<const T*>(w.w), prm, xr, lane, ok, row0, srow, xo, &wo, E0, E1, &K);
     }
     WPS_STAMP(35 + 8 * l);
     __syncthreads();  // every wave is done with the forward weights
@@ -1049,6 +1062,7 @@ __global__ __launch_bounds__(256) void wps_layer_bwd_kernel(WpsBwdStack stk, Bwd
       }
     }
     WPS_STAMP(66);
+    if constexpr (VIS) return;
     // token 0: (dx_in o [x0 > 0]) -> state_projector' -> [e1 > 0] -> dhc -> fc2' -> [e0 > 0] -> de0, cooperatively (4 rows)
     float* dt = reinterpret_cast<float*>(smem);                 // [16][LDX]
     T* dh = reinterpret_cast<T*>(dt + 16 * LY::LDX);            // [16][LDF]
