@@ -504,10 +504,12 @@ static int conv_stack_bwd_fused(Ctx& c, const T* image, const int* rowidx, int n
   }
   int nblk = std::min(n, CONV_BWD_MAX_BLOCKS);
   if (const char* e = getenv("V4L_CONV_BWD_BLOCKS")) nblk = std::max(1, std::min(nblk, atoi(e)));
-  // dW3's launch runs beside the dense weight-grads on the other stream (~54 us) and is not on the critical path: fewer,
-  // fatter blocks cut its partial slabs (256 -> 64 x 147 KB written, and read again by wgrad_reduce). Measured in one session,
-  // env-steps/s at 256 / 128 / 64 blocks: 357.8 K / 364.2 K / 367.6 K (the launch itself 24 -> 33 -> 53 us, wgrad_reduce 25.7 -> 22.0 us)
-  int nblk3 = std::min(nblk, 64);
+  // dW3's launch runs beside the dense weight-grads on the other stream: fewer, fatter blocks cut its partial slabs (147 KB
+  // per block, written here and read again by wgrad_reduce) until the launch itself becomes the longer branch. The balance
+  // moved with the other branch: when the dense weight-grads took ~54 us, 64 blocks (53 us) won (357.8 / 364.2 / 367.6 K
+  // env-steps/s at 256 / 128 / 64); with wps_wgrad + gemm_tn_group at ~44 us, three interleaved runs per setting in one
+  // session give 358 K (64) / 372 K (96) / 369 K (128) / 366 K (192).
+  int nblk3 = std::min(nblk, 96);
   if (const char* e = getenv("V4L_CONV3_WGRAD_BLOCKS")) nblk3 = std::max(1, std::min(nblk, atoi(e)));
   const int Ns[3] = {32, 64, 64}, Ks[3] = {256, 512, 576};
   float* slab[3];
