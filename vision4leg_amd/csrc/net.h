@@ -125,6 +125,8 @@ struct v4l_net {
   // auxiliary stream + fork/join events for sibling-kernel concurrency (created at bind; null = serial)
   hipStream_t aux = nullptr;
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  hipStream_t aux2 = nullptr;  // third branch of the weight-grad section (V4L_PAR_WGRAD=3)
+  hipEvent_t ev_fork2 = nullptr, ev_join2 = nullptr;
 
   int build();
   v4l::Layout layout(int n) const;

@@ -194,7 +194,7 @@ static int launch_tn(Ctx& c, const YL& yl, const XL& xl, int M, int N, int Kx, R
 }
 
 // one launch: sum all registered slabs into the PyTorch-layout gradients
-template <typename T> static int wgrad_dense(Ctx& c, hipStream_t ds);
+template <typename T> static int wgrad_dense(Ctx& c, hipStream_t ds, hipStream_t dg = nullptr);
 template <typename T> static int wgrad_reduce_all(Ctx& c);
 template <typename T>
 static int wgrad_finish(Ctx& c) {
@@ -203,9 +203,11 @@ static int wgrad_finish(Ctx& c) {
 }
 // the deferred dense weight-grad launches (grouped + whole-output kernels) on stream ds: ONE launch when both kinds are
 // present (gemm_tn_dense_kernel hosts both kinds of blocks; V4L_SPLIT_DENSE_WGRAD=1: one launch per kind)
+// dg: stream of the grouped / whole-output launches when they run as a branch of their own (default: ds, after wps_wgrad)
 template <typename T>
-static int wgrad_dense(Ctx& c, hipStream_t ds) {
+static int wgrad_dense(Ctx& c, hipStream_t ds, hipStream_t dg) {
   v4l_net* net = c.net;
+  if (dg == nullptr) dg = ds;
   if (c.wps_pending) {
     c.wps_pending = false;
     const int jobs = c.wps_args.nsplit * WPS_ROLES * c.wps_args.nlayers;
@@ -250,21 +252,21 @@ static int wgrad_dense(Ctx& c, hipStream_t ds) {
   const bool split = getenv("V4L_SPLIT_DENSE_WGRAD") != nullptr;
   if (gb > 0 && wb > 0 && !split) {
     g_op = "layer.wgrad";  // (the layers' share dominates: 8 of the ~20 problems, 2/3 of the blocks)
-    V4L_KLAUNCH("gemm_tn_dense", net->wide_flops + net->tnp_flops, ds, gemm_tn_dense_kernel<T>, dim3((unsigned)(wb + gb)), dim3(256),
-                dense_lds, ds, (const TnWide*)net->d_wide, (int)net->wide.size(), wb, (const TnProb*)net->d_tnp, (int)net->tnp.size());
+    V4L_KLAUNCH("gemm_tn_dense", net->wide_flops + net->tnp_flops, dg, gemm_tn_dense_kernel<T>, dim3((unsigned)(wb + gb)), dim3(256),
+                dense_lds, dg, (const TnWide*)net->d_wide, (int)net->wide.size(), wb, (const TnProb*)net->d_tnp, (int)net->tnp.size());
     V4L_LAUNCH_CHECK();
     return 0;
   }
   if (gb > 0) {
     g_op = "dense.wgrad";
-    V4L_KLAUNCH("gemm_tn_group", net->tnp_flops, ds, gemm_tn_group_kernel<T>, dim3((unsigned)gb), dim3(256), 0, ds,
+    V4L_KLAUNCH("gemm_tn_group", net->tnp_flops, dg, gemm_tn_group_kernel<T>, dim3((unsigned)gb), dim3(256), 0, dg,
                 (const TnProb*)net->d_tnp, (int)net->tnp.size());
     V4L_LAUNCH_CHECK();
   }
   if (wb > 0) {
     g_op = "layer.wgrad";
-    V4L_KLAUNCH("gemm_tn_wide", net->wide_flops, ds, gemm_tn_wide_kernel<T>, dim3((unsigned)wb), dim3(256),
-                TnWideLds<T>::max_bytes, ds, (const TnWide*)net->d_wide, (int)net->wide.size());
+    V4L_KLAUNCH("gemm_tn_wide", net->wide_flops, dg, gemm_tn_wide_kernel<T>, dim3((unsigned)wb), dim3(256),
+                TnWideLds<T>::max_bytes, dg, (const TnWide*)net->d_wide, (int)net->wide.size());
     V4L_LAUNCH_CHECK();
   }
   return 0;
@@ -1759,12 +1761,22 @@ int v4l_net::backward_t(const float* state, const T* image, const int* rowidx, i
   // main stream next to the two dense launches on the auxiliary stream 32.8 (default); three branches 34.8.
   // V4L_PAR_WGRAD=0: serial, 1: the older fork.
   const int par_wgrad = getenv("V4L_PAR_WGRAD") ? atoi(getenv("V4L_PAR_WGRAD")) : 2;  // (read per call: tests switch it)
-  if (par_wgrad == 2) {
+  if (par_wgrad == 2 || par_wgrad == 3) {
     cx.defer_conv3 = true;
     if ((rc = conv_stack_bwd<T>(cx, image, rowidx, n, ws + L.c1, ws + L.c2, ws + L.dc3, ws + L.dc2, ws + L.dc1))) return rc;
     if ((rc = par_begin(cx, true))) return rc;  // a graph fork / join under capture
-    if ((rc = wgrad_dense<T>(cx, cx.tn))) return rc;
+    // 3: the grouped dense weight-grads as a third branch beside wps_wgrad (auxiliary stream) and dW3 (main stream)
+    const bool three = par_wgrad == 3 && aux2 != nullptr && cx.tn != cx.s && cx.wps_pending;
+    if (three) {
+      V4L_HIP_CHECK(hipEventRecord(ev_fork2, cx.s));
+      V4L_HIP_CHECK(hipStreamWaitEvent(aux2, ev_fork2, 0));
+    }
+    if ((rc = wgrad_dense<T>(cx, cx.tn, three ? aux2 : nullptr))) return rc;
     if ((rc = conv3_wgrad_deferred<T>(cx, cx.s))) return rc;
+    if (three) {
+      V4L_HIP_CHECK(hipEventRecord(ev_join2, aux2));
+      V4L_HIP_CHECK(hipStreamWaitEvent(cx.s, ev_join2, 0));
+    }
     if ((rc = par_end(cx))) return rc;
     return wgrad_reduce_all<T>(cx);
   }
@@ -2200,6 +2212,11 @@ void v4l_net_destroy(v4l_net* net) {
     (void)hipEventDestroy(net->ev_fork);
     (void)hipEventDestroy(net->ev_join);
   }
+  if (net && net->aux2) {
+    (void)hipStreamDestroy(net->aux2);
+    (void)hipEventDestroy(net->ev_fork2);
+    (void)hipEventDestroy(net->ev_join2);
+  }
   delete net;
 }
 int v4l_net_num_params(const v4l_net* net) { return net ? (int)net->params.size() : -1; }
@@ -2295,6 +2312,9 @@ int v4l_net_bind(v4l_net* net, float* const* params_dev, void* packed_dev, void*
     V4L_HIP_CHECK(hipStreamCreateWithFlags(&net->aux, hipStreamNonBlocking));
     V4L_HIP_CHECK(hipEventCreateWithFlags(&net->ev_fork, hipEventDisableTiming));
     V4L_HIP_CHECK(hipEventCreateWithFlags(&net->ev_join, hipEventDisableTiming));
+    V4L_HIP_CHECK(hipStreamCreateWithFlags(&net->aux2, hipStreamNonBlocking));
+    V4L_HIP_CHECK(hipEventCreateWithFlags(&net->ev_fork2, hipEventDisableTiming));
+    V4L_HIP_CHECK(hipEventCreateWithFlags(&net->ev_join2, hipEventDisableTiming));
   }
   net->packed = packed_dev;
   net->d_packs = (PackDesc*)table_dev;
