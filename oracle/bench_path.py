@@ -137,6 +137,14 @@ def run(case, E, T, B, U, mode, dev, seed=0, threads=None):
         d = [(pf.state_dict()[k].cpu() - o.pf[k]).abs() for k in o.pf] + [(vf.state_dict()[k].cpu() - o.vf[k]).abs() for k in o.vf]
         res["param_max_vs_%s" % fl] = float(max(x.max().item() for x in d))
         res["param_mean_vs_%s" % fl] = float(sum(x.sum().item() for x in d) / sum(x.numel() for x in d))
+        # elements further off than half an Adam step (lr = 1e-4): a gradient element whose two evaluations differ in SIGN moves
+        # its parameter by +lr in one and -lr in the other, however small the gradient (Adam normalises it) — counted, and named
+        names = list(o.pf) + ["vf." + k for k in o.vf]
+        res["param_frac_above_5e-5_vs_%s" % fl] = float(sum((x > 5e-5).sum().item() for x in d) / sum(x.numel() for x in d))
+        res["param_worst_key_vs_%s" % fl] = names[int(np.argmax([x.max().item() for x in d]))]
+    # the product's final parameters (for HIP-vs-HIP yardsticks in the tests; not a distance, not recorded)
+    res["_params"] = torch.cat([pf.state_dict()[k].detach().cpu().reshape(-1) for k in oracles["f32"].pf] +
+                               [vf.state_dict()[k].detach().cpu().reshape(-1) for k in oracles["f32"].vf])
     if mode != "f32":
         # how far the bf16 ORACLE is from the fp32 reference trajectory: the yardstick of the trajectory rule
         err = np.abs(infos[mode] - infos["f32"]) / np.maximum(1.0, np.abs(infos["f32"]))

@@ -7,7 +7,8 @@ Normal(mean, std).log_prob (policies/continuous_policy.py:127-146) and a target_
 (algo/on_policy/ppo.py:34,55-59).
 
 Gates
-  f32 : rollout mean / value <= 2e-5, log pi_old <= 2e-5 (abs), the 18 infos of every update <= 5e-4, parameters <= 5e-5.
+  f32 : rollout mean / value <= 2e-5, log pi_old <= 2e-5 (abs), the 18 infos of every update <= 5e-4, parameters: all but <= 1e-3
+        of the elements within half an Adam step (5e-5), none further than 2 lr U, mean <= 5e-6 (see the comment at the gate).
   bf16: distances reported (profiles/parity_r3.json) and the TRAJECTORY RULE: per update, HIP-bf16 is no further from the
         fp32 reference trajectory than the bf16 oracle is, up to a factor / floor that covers which side of a rounding tie
         the two bf16 implementations happen to land on (they agree to 1 ulp per contraction: test_gpu_contractions.py).
@@ -24,10 +25,11 @@ TRAJ_FACTOR, TRAJ_FLOOR = 3.0, 3e-3
 
 @pytest.mark.parametrize("mode", ["f32", "bf16"])
 @pytest.mark.parametrize("E", [32, 64])
-def test_rollout_then_stored_logp_graph_updates_vs_reference_protocol(E, mode, device):
+def test_rollout_then_stored_logp_graph_updates_vs_reference_protocol(E, mode, device, monkeypatch):
     case = dict(util.CASES["loco_b1024"])
     T, B, U = 64, 1024, 4
     r = bench_path.run(case, E, T, B, U, mode, device, threads=16)
+    params = r.pop("_params")
     tag = "bench_path/E%d/%s/" % (E, mode)
     for k, v in r.items():
         if isinstance(v, float):
@@ -39,7 +41,24 @@ def test_rollout_then_stored_logp_graph_updates_vs_reference_protocol(E, mode, d
         assert r["rollout_mean_vs_f32"] <= 2e-5 and r["rollout_value_vs_f32"] <= 2e-5 and r["rollout_std_vs_f32"] <= 1e-6
         assert r["rollout_logp_abs_vs_f32"] <= 2e-4  # (a - mu)^2 / (2 sigma^2) with sigma = 0.125 amplifies d(mu) by ~ |a - mu| / sigma^2 = 8
         assert r["infos_vs_f32"] <= 5e-4, (r["infos_vs_f32_worst_key"], r["infos_vs_f32_per_update"])
-        assert r["param_max_vs_f32"] <= 5e-5 and r["param_mean_vs_f32"] <= 1e-6
+        # Parameters after U Adam steps. Adam normalises every gradient element by its own magnitude: an element whose true
+        # value is below the fp32 summation noise (partial sums that cancel to ~1e-9) gets a step of up to +-lr whose SIGN is
+        # that noise — and every last-bit difference upstream (the shared encoder's weights after the critic's step, the order a
+        # weight-grad kernel sums its blocks in: dW3 on 64 / 96 / 128 blocks gives 0 / 130 / 0 such elements here) re-rolls it.
+        # So: the bulk within half a step (5e-5), the stragglers few (<= 1e-3 of the elements) and bounded by 2 lr U, the mean
+        # tight. tools/probe/dw3_blocks.py shows the gradients themselves agree to 1e-6 across those block counts.
+        assert r["param_frac_above_5e-5_vs_f32"] <= 1e-3 and r["param_max_vs_f32"] <= 2 * 1e-4 * U, r["param_worst_key_vs_f32"]
+        assert r["param_mean_vs_f32"] <= 5e-6
+        if E == 32:
+            # yardstick, recorded: the SAME kernels with dW3's partial sums taken over a different number of blocks (a last-bit
+            # change of one gradient tensor) — how many parameters of the product itself move by more than half a step
+            monkeypatch.setenv("V4L_CONV3_WGRAD_BLOCKS", "64")
+            other = bench_path.run(case, E, T, B, U, mode, device, threads=16).pop("_params")
+            d = (params - other).abs()
+            util.record(tag + "self_frac_above_5e-5_other_dW3_blocks", (d > 5e-5).double().mean().item())
+            util.record(tag + "self_max_other_dW3_blocks", d.max().item())
+            print("[bench path E=%d f32] product vs product with dW3 on 64 blocks: max %.2e, %.1e of the elements > 5e-5"
+                  % (E, d.max().item(), (d > 5e-5).double().mean().item()))
         return
     # bf16: where the bf16-rounded oracle sits ...
     assert r["rollout_mean_vs_bf16"] <= 1e-2 and r["rollout_value_vs_bf16"] <= 1e-2
