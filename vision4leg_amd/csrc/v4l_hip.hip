@@ -330,7 +330,8 @@ static int lin_wgrad(Ctx& c, const Lin& L, const ADense& y, const ADense& x, int
   memset(&p, 0, sizeof(p));
   p.y = y; p.x = x; p.M = M;
   p.gx = cdiv(Kx, 64); p.gy = cdiv(L.N, 64);
-  int splits = M >= 4096 ? std::min(64, M / 256) : std::max(1, M / 128);  // 2..4 staging rounds per block: latency-bound
+  static const int big_rows = getenv("V4L_TN_BIG_ROWS") ? std::max(64, atoi(getenv("V4L_TN_BIG_ROWS"))) : 256;
+  int splits = M >= 4096 ? std::min(16384 / big_rows, M / big_rows) : std::max(1, M / 128);  // 2..4 staging rounds per block: latency-bound
   p.mpb = round_up(cdiv(M, splits), 64);
   splits = cdiv(M, p.mpb);
   p.Npad = p.gy * 64; p.Kpad = p.gx * 64;
@@ -511,7 +512,9 @@ static int conv_stack_bwd_fused(Ctx& c, const T* image, const int* rowidx, int n
   // moved with the other branch: when the dense weight-grads took ~54 us, 64 blocks (53 us) won (357.8 / 364.2 / 367.6 K
   // env-steps/s at 256 / 128 / 64); with wps_wgrad + gemm_tn_group at ~44 us, three interleaved runs per setting in one
   // session give 358 K (64) / 372 K (96) / 369 K (128) / 366 K (192).
-  int nblk3 = std::min(nblk, 96);
+  // Without wps_wgrad on the other branch (NatureCNN nets: gemm_tn_group alone, ~25 us) dW3 has to be shorter still: 316 K (96) /
+  // 320 K (128, 192, 256) env-steps/s on ppo_nature_cnn.
+  int nblk3 = std::min(nblk, c.wps_pending ? 96 : 160);
   if (const char* e = getenv("V4L_CONV3_WGRAD_BLOCKS")) nblk3 = std::max(1, std::min(nblk, atoi(e)));
   const int Ns[3] = {32, 64, 64}, Ks[3] = {256, 512, 576};
   float* slab[3];
@@ -938,7 +941,7 @@ int64_t v4l_net::slab_floats(int n) const {
   int64_t tot = 0;
   auto add = [&](int M, int N, int Kx) {   // conv weight-grads (tn_plan) and, conservatively, dense ones
     const TnPlan p = tn_plan(M, N, Kx, cfg.compute == V4L_BF16);
-    const int64_t dense_splits = 64;
+    const int64_t dense_splits = 256;  // (lin_wgrad: at most 16384 / V4L_TN_BIG_ROWS slabs, rows per block >= 64)
     const int64_t np = round_up(N, 64), kp = round_up(Kx, 64);
     tot += std::max<int64_t>(p.slab_floats + p.bslab_floats, dense_splits * np * (kp + 1) + 128);
   };
