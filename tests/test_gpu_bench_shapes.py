@@ -336,3 +336,7 @@ def test_forked_weight_grad_launches_equal_serial(mode, device):
         worst = max(worst, (grads_with(2) - ref).abs().max().item())
     util.record("forked_wgrad/%s/max_abs_grad_diff_vs_serial" % mode, worst)
     assert worst == 0.0, worst
+    # V4L_PAR_WGRAD=3 (the grouped dense weight-grads as a third branch on a second auxiliary stream; measured slower, kept as a
+    # switch): the same single-writer slabs, one more join
+    for _ in range(2):
+        assert (grads_with(3) - ref).abs().max().item() == 0.0

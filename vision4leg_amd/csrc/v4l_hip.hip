@@ -141,6 +141,7 @@ struct Ctx {  // per-call view of a bound net
   int conv3_blocks = 0, conv3_n = 0;
   // the wave-per-sample layers' weight-grad launch (csrc/wps.h), issued with the other dense weight-grads
   bool wps_pending = false;
+  bool wps_used = false;     // this backward pass runs the wave-per-sample layer kernels (stays set: sizes the dW3 launch)
   v4l::WpsWg wps_args = {};
 };
 
@@ -514,7 +515,7 @@ static int conv_stack_bwd_fused(Ctx& c, const T* image, const int* rowidx, int n
   // session give 358 K (64) / 372 K (96) / 369 K (128) / 366 K (192).
   // Without wps_wgrad on the other branch (NatureCNN nets: gemm_tn_group alone, ~25 us) dW3 has to be shorter still: 316 K (96) /
   // 320 K (128, 192, 256) env-steps/s on ppo_nature_cnn.
-  int nblk3 = std::min(nblk, c.wps_pending ? 96 : 160);
+  int nblk3 = std::min(nblk, c.wps_used ? 96 : 160);
   if (const char* e = getenv("V4L_CONV3_WGRAD_BLOCKS")) nblk3 = std::max(1, std::min(nblk, atoi(e)));
   const int Ns[3] = {32, 64, 64}, Ks[3] = {256, 512, 576};
   float* slab[3];
@@ -1582,6 +1583,7 @@ int v4l_net::backward_t(const float* state, const T* image, const int* rowidx, i
     }
     cx.wps_args = wa;
     cx.wps_pending = true;
+    cx.wps_used = true;
   }
   for (int l = c.n_layers - 1; l >= 0 && fused_bwd && !wps; l -= stacked ? 2 : 1) {
     static bool attr_done = false;
