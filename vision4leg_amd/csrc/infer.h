@@ -483,6 +483,10 @@ struct InfFinish {
   const float *logstd, *eps;
   int A;
   float *acts_roll, *values_roll, *logp_roll, *action, *mean, *stdv, *ent, *value;
+  // eager launches: the env step index + 1 as the host counts it (v4l_actor_seek / one per step); 0: read the device cursor
+  // ctl->t and advance it through the last-block counter (graph replays, whose arguments are frozen). With the host's index no
+  // block has to find out whether it is the last one: that atomic round trip was 2.6 K cycles at the end of every step.
+  long long t_plus1;
 };
 
 template <int SPW> struct InfRows {
@@ -1013,7 +1017,8 @@ __global__ __launch_bounds__(512) void rollout_stack_kernel(InfLayerStack stk, I
     return *reinterpret_cast<const float4*>(src);
   };
   long long t_step = 0;
-  if (fin.ctl != nullptr) t_step = fin.ctl->t;
+  if (fin.t_plus1 > 0) t_step = fin.t_plus1 - 1;
+  else if (fin.ctl != nullptr) t_step = fin.ctl->t;
   float lsd = 0.f, ep = 0.f;  // sampling operands of lane a < A of wave 0 (policy blocks)
   unsigned warm_word = 0;
   {
@@ -1307,7 +1312,9 @@ __global__ __launch_bounds__(512) void rollout_stack_kernel(InfLayerStack stk, I
         if (fin.values_roll != nullptr) fin.values_roll[t_step * E + i] = v;
       }
       ROLL_STAMP(84);
-      if (lane == 0) {  // the last block to get here advances the step cursor: every block read it at entry
+      if (fin.t_plus1 > 0) {  // nobody in this launch reads the cursor: one plain store keeps it in step for graph replays
+        if (lane == 0 && blockIdx.x == 0 && blockIdx.y == 0) fin.ctl->t = t_step + 1;
+      } else if (lane == 0) {  // the last block to get here advances the step cursor: every block read it at entry
         __threadfence();
         const unsigned long long done = atomicAdd(reinterpret_cast<unsigned long long*>(&fin.ctl->done), 1ull);
         if (done == (unsigned long long)(gridDim.x * gridDim.y) - 1) {
@@ -1556,14 +1563,15 @@ template <int MODE>
 __global__ __launch_bounds__(1024) void rollout_encoder2_kernel(const ActCtl* __restrict__ ctl, const float* __restrict__ obs,
                                                                 int E, InfEncFrag w, float* __restrict__ state_roll,
                                                                 __bf16* __restrict__ image_roll, float* __restrict__ x0,
-                                                                __bf16* __restrict__ featv, __bf16* __restrict__ featp) {
+                                                                __bf16* __restrict__ featv, __bf16* __restrict__ featp,
+                                                                long long t_plus1) {
   typedef __bf16 T;
   typedef bf16x8 frag_t;
   typedef InfEncLds<T> LY;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int fr = lane & 15, fg = (lane >> 4) * 8, qr = (lane >> 4) * 4;
-  const int64_t slot0 = (int64_t)ctl->t * E;
+  const int64_t slot0 = (t_plus1 > 0 ? t_plus1 - 1 : ctl->t) * (int64_t)E;  // (InfFinish::t_plus1)
   const int D = w.S + LY::IMG;
   auto gfrag = [&](const void* W, int idx) -> frag_t { return reinterpret_cast<const frag_t*>(W)[idx * 64 + lane]; };
 

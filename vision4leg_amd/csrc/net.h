@@ -153,6 +153,7 @@ struct v4l_actor {
   hipGraphExec_t gexec = nullptr;
   const void* key[16] = {};
   bool warm = false, bound = false;
+  long long t_host = -1;  // the env step index as the host counts it (v4l_actor_seek sets it, eager steps advance it); -1: unknown
 };
 
 struct GraphKey { v4l_rollout ro; v4l_ppo_hyper hp; int n; int gen[3]; };

@@ -207,7 +207,7 @@ __global__ __launch_bounds__(1024) void rollout_mlp2_kernel(const float* __restr
   float* b2_s = lsg_s + 16;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, net = blockIdx.x;
   const int fr = lane & 15, g = lane >> 4, MT = (E + 15) >> 4, A = fin.A;
-  const long long t_step = fin.ctl->t;
+  const long long t_step = fin.t_plus1 > 0 ? fin.t_plus1 - 1 : fin.ctl->t;
   auto frag = [&](const void* W, int ks_per_tile, int t, int ks) {
     return reinterpret_cast<const bf16x8*>(W)[((size_t)t * ks_per_tile + ks) * 64 + lane];
   };
@@ -308,7 +308,9 @@ __global__ __launch_bounds__(1024) void rollout_mlp2_kernel(const float* __restr
     if (fin.values_roll != nullptr) fin.values_roll[t_step * E + tid] = v;
   }
   __syncthreads();
-  if (tid == 0) {  // the second of the two blocks advances the step cursor: both read it at entry
+  if (fin.t_plus1 > 0) {  // (InfFinish::t_plus1)
+    if (tid == 0 && net == 0) fin.ctl->t = t_step + 1;
+  } else if (tid == 0) {  // the second of the two blocks advances the step cursor: both read it at entry
     __threadfence();
     const unsigned long long done = atomicAdd(reinterpret_cast<unsigned long long*>(&fin.ctl->done), 1ull);
     if (done == 1ull) {
@@ -394,7 +396,7 @@ __global__ __launch_bounds__(64) void rollout_dense_kernel(RollDense a, InfFinis
   ActCtl* ctl = fin.ctl;
   ROLL_STAMP(100);
   const unsigned target = 16u * (ctl->seq + 1u);
-  const long long t_step = ctl->t;
+  const long long t_step = fin.t_plus1 > 0 ? fin.t_plus1 - 1 : ctl->t;
   auto frags = [&](const void* W, int ks_per_tile, int t, int ks) {
     return reinterpret_cast<const bf16x8*>(W)[((size_t)t * ks_per_tile + ks) * 64 + lane];
   };
@@ -513,7 +515,9 @@ __global__ __launch_bounds__(64) void rollout_dense_kernel(RollDense a, InfFinis
     __builtin_amdgcn_wave_barrier();
   }
   ROLL_STAMP(111);
-  if (lane == 0) {  // the second of the two finishing blocks closes the step
+  if (fin.t_plus1 > 0) {  // (InfFinish::t_plus1) every block of this launch read seq at entry and nobody reads the cursor
+    if (lane == 0 && net == 0) { ctl->t = t_step + 1; ctl->seq = ctl->seq + 1u; }
+  } else if (lane == 0) {  // the second of the two finishing blocks closes the step
     __threadfence();
     const unsigned long long done = atomicAdd(reinterpret_cast<unsigned long long*>(&ctl->done), 1ull);
     if (done == 1ull) {

@@ -1792,6 +1792,11 @@ int v4l_net::backward_t(const float* state, const T* image, const int* rowidx, i
   return wgrad_reduce_all<T>(cx);
 }
 
+// InfFinish::t_plus1 of a fused step: the host's step index + 1 for eager launches, 0 (= device cursor) under capture or when the
+// host lost count (no v4l_actor_seek yet)
+static inline long long actor_t_plus1(const v4l_actor* a, hipStream_t s) {
+  return (a->t_host >= 0 && !capturing(s)) ? a->t_host + 1 : 0;
+}
 // Fused rollout step for the shipped LocoTransformer shape (csrc/infer.h): 4 launches instead of ~50.
 static bool actor_fusable(const v4l_actor* a) {
   const v4l_net_cfg &p = a->pf->cfg, &v = a->vf->cfg;
@@ -1850,6 +1855,7 @@ static int run_actor_fused_cnn(v4l_actor* a, const float* obs, const float* eps,
   InfFinish fin;
   memset(&fin, 0, sizeof(fin));
   fin.ctl = a->ctl; fin.logstd = pf->p[pf->logstd]; fin.eps = eps; fin.A = pf->cfg.out_dim;
+  fin.t_plus1 = actor_t_plus1(a, s);
   fin.acts_roll = acts_roll; fin.values_roll = values_roll; fin.logp_roll = logp_roll; fin.action = action;
   fin.mean = mean; fin.stdv = stdv; fin.ent = ent; fin.value = value;
   g_op = "step";
@@ -1918,16 +1924,17 @@ static int run_actor_dense_cnn(v4l_actor* a, const float* obs, const float* eps,
     ef.bf1 = pf->p[pf->enc[0].b]; ef.bf2 = pf->p[pf->enc[1].b]; ef.bpr = ef.bf2;
     V4L_KLAUNCH("rollout_encoder", 2.0 * E * (3612672.0 + 128 * 256 + 256 * 256), s, rollout_encoder2_kernel<ENC_FUSE>,
                 dim3(E + cdiv(E, 32)), dim3(1024), RollEnc2Lds::bytes, s, (const ActCtl*)a->ctl, obs, E, ef, state_roll,
-                (__bf16*)image_roll, (float*)nullptr, featv, cat);
+                (__bf16*)image_roll, (float*)nullptr, featv, cat, actor_t_plus1(a, s));
   } else {
     V4L_KLAUNCH("rollout_encoder", 2.0 * E * 3612672.0, s, rollout_encoder2_kernel<ENC_FLAT>, dim3(E), dim3(1024),
                 RollEnc2Lds::bytes, s, (const ActCtl*)a->ctl, obs, E, ef, state_roll, (__bf16*)image_roll, (float*)nullptr,
-                featv, (__bf16*)nullptr);
+                featv, (__bf16*)nullptr, actor_t_plus1(a, s));
   }
   V4L_LAUNCH_CHECK();
   InfFinish fin;
   memset(&fin, 0, sizeof(fin));
   fin.ctl = a->ctl; fin.logstd = pf->p[pf->logstd]; fin.eps = eps; fin.A = pf->cfg.out_dim;
+  fin.t_plus1 = actor_t_plus1(a, s);
   fin.acts_roll = acts_roll; fin.values_roll = values_roll; fin.logp_roll = logp_roll; fin.action = action;
   fin.mean = mean; fin.stdv = stdv; fin.ent = ent; fin.value = value;
   g_op = "dense";
@@ -2020,6 +2027,7 @@ static int run_actor_mlp2(v4l_actor* a, const float* obs, const float* eps, floa
   InfFinish fin;
   memset(&fin, 0, sizeof(fin));
   fin.ctl = a->ctl; fin.logstd = pf->p[pf->logstd]; fin.eps = eps; fin.A = pf->cfg.out_dim;
+  fin.t_plus1 = actor_t_plus1(a, s);
   fin.acts_roll = acts_roll; fin.values_roll = values_roll; fin.logp_roll = logp_roll; fin.action = action;
   fin.mean = mean; fin.stdv = stdv; fin.ent = ent; fin.value = value;
   g_op = "step";
@@ -2065,6 +2073,7 @@ static int run_actor_fused_mlp(v4l_actor* a, const float* obs, const float* eps,
   InfFinish fin;
   memset(&fin, 0, sizeof(fin));
   fin.ctl = a->ctl; fin.logstd = pf->p[pf->logstd]; fin.eps = eps; fin.A = pf->cfg.out_dim;
+  fin.t_plus1 = actor_t_plus1(a, s);
   fin.acts_roll = acts_roll; fin.values_roll = values_roll; fin.logp_roll = logp_roll; fin.action = action;
   fin.mean = mean; fin.stdv = stdv; fin.ent = ent; fin.value = value;
   g_op = "step";
@@ -2121,7 +2130,7 @@ static int run_actor_fused(v4l_actor* a, const float* obs, const float* eps, flo
     ef.S = en.S; ef.Sp = en.Sp;
     V4L_KLAUNCH("rollout_encoder", 2.0 * E * 3678208.0, s, rollout_encoder2_kernel<ENC_TOK16>, dim3(E), dim3(1024),
                 RollEnc2Lds::bytes, s, (const ActCtl*)a->ctl, obs, E, ef, state_roll, (__bf16*)image_roll, x0, (__bf16*)nullptr,
-                (__bf16*)nullptr);
+                (__bf16*)nullptr, actor_t_plus1(a, s));
   } else if (enc2 && sizeof(T) == 2 && pf->enc.size() == 2 && pf->enc[0].Kp == 128 && pf->conv[0].pkf >= 0) {
     static bool attr2 = false;
     if (!attr2) {
@@ -2138,7 +2147,7 @@ static int run_actor_fused(v4l_actor* a, const float* obs, const float* eps, flo
     ef.S = en.S; ef.Sp = en.Sp;
     V4L_KLAUNCH("rollout_encoder", 2.0 * E * 3678208.0, s, rollout_encoder2_kernel<ENC_TOK17>, dim3(E + cdiv(E, 32)), dim3(1024),
                 RollEnc2Lds::bytes, s, (const ActCtl*)a->ctl, obs, E, ef, state_roll, (__bf16*)image_roll, x0, (__bf16*)nullptr,
-                (__bf16*)nullptr);
+                (__bf16*)nullptr, actor_t_plus1(a, s));
   } else  // fp32 parity mode (fragments twice the size): weights streamed per wave
     V4L_KLAUNCH("rollout_encoder", 2.0 * E * 3678208.0, s, rollout_encoder_kernel<T>, dim3(E + cdiv(E, 32)), dim3(1024),
                 InfEncLds<T>::bytes, s, (const ActCtl*)a->ctl, obs, E, en, state_roll, (T*)image_roll, x0);
@@ -2168,6 +2177,7 @@ static int run_actor_fused(v4l_actor* a, const float* obs, const float* eps, flo
     head(hd.n[0], pf, pk, ws_pf + Lp.out);
     head(hd.n[1], vf, vk, ws_vf + Lv.out);
     fin.ctl = a->ctl; fin.logstd = pf->p[pf->logstd]; fin.eps = eps; fin.A = pf->cfg.out_dim;
+  fin.t_plus1 = actor_t_plus1(a, s);
     fin.acts_roll = acts_roll; fin.values_roll = values_roll; fin.logp_roll = logp_roll; fin.action = action;
     fin.mean = mean; fin.stdv = stdv; fin.ent = ent; fin.value = value;
   };
@@ -2549,6 +2559,7 @@ int v4l_actor_bind(v4l_actor* a, float* ws_dev, void* ctl_dev, void* stream) {
 }
 int v4l_actor_seek(v4l_actor* a, int64_t t, void* stream) {
   V4L_REQUIRE(a && a->bound && t >= 0, "v4l_actor_seek: bad argument");
+  a->t_host = t;
   hipLaunchKernelGGL(act_set_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, a->ctl, (long long)t);
   V4L_LAUNCH_CHECK();
   return 0;
@@ -2638,9 +2649,20 @@ static int run_actor_step(v4l_actor* a, const float* obs, const float* eps, floa
   return 0;
 }
 
+static int actor_step_impl(v4l_actor* a, const float* obs_dev, const float* eps_dev, float* state_roll_dev, void* image_roll_dev,
+                           float* acts_roll_dev, float* values_roll_dev, float* logp_roll_dev, float* action_dev, float* mean_dev,
+                           float* std_dev, float* ent_dev, float* value_dev, int shared_encoder, int use_graph, void* stream);
 int v4l_actor_step(v4l_actor* a, const float* obs_dev, const float* eps_dev, float* state_roll_dev, void* image_roll_dev,
                    float* acts_roll_dev, float* values_roll_dev, float* logp_roll_dev, float* action_dev, float* mean_dev,
                    float* std_dev, float* ent_dev, float* value_dev, int shared_encoder, int use_graph, void* stream) {
+  const int rc = actor_step_impl(a, obs_dev, eps_dev, state_roll_dev, image_roll_dev, acts_roll_dev, values_roll_dev, logp_roll_dev,
+                                 action_dev, mean_dev, std_dev, ent_dev, value_dev, shared_encoder, use_graph, stream);
+  if (rc == 0 && a->t_host >= 0) ++a->t_host;  // one env step, whichever way it was launched (the device cursor moved too)
+  return rc;
+}
+static int actor_step_impl(v4l_actor* a, const float* obs_dev, const float* eps_dev, float* state_roll_dev, void* image_roll_dev,
+                           float* acts_roll_dev, float* values_roll_dev, float* logp_roll_dev, float* action_dev, float* mean_dev,
+                           float* std_dev, float* ent_dev, float* value_dev, int shared_encoder, int use_graph, void* stream) {
   V4L_REQUIRE(a && a->bound, "v4l_actor_step: actor is not bound");
   V4L_REQUIRE(obs_dev && eps_dev && state_roll_dev && action_dev && mean_dev && std_dev && ent_dev && value_dev,
               "v4l_actor_step: null argument");
