@@ -1,3 +1,6 @@
+"""Vision-only Transformer: every parameter gradient of the wave-per-sample path (17-row kernels, dummy row 0) against the
+layer-by-layer path (V4L_NO_WPS_LAYERS=1) and against itself with the test taps on, per tensor.
+usage: python tools/probe/vis_wps_grads.py"""
 import os, sys
 sys.path.insert(0, "tests"); sys.path.insert(0, ".")
 import torch, util
