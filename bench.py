@@ -461,6 +461,14 @@ def algo_bytes(kernel, wl, compute):
     # layer stack: tokens in for both nets, both nets' layer + head weights, action / value / log-prob out
     per_launch["rollout_encoder"] = E * ((wl["S"] + 16384) * 4 + 16384 * t + 128 * 4 + 17 * tok) + enc_w
     per_launch["rollout_layers_head"] = 2 * E * 17 * tok + 2 * (wl.get("layers", 2) * layer_w + head_w) + E * 64
+    # NatureCNN nets (csrc/rollout_dense.h): conv3's flatten (T) in, every dense weight once (the projector is the shared
+    # encoder's; the heads per net), action / value / log-prob out
+    if wl["kind"] == "cnn":
+        per_launch["rollout_dense"] = E * (1024 + 256) * t + (1024 * 256 + 2 * (512 * 256 + 256 * 256 + 256 * 16)) * t + E * 64
+    elif wl["kind"] == "cnn_vis":
+        per_launch["rollout_dense"] = E * 1024 * t + 2 * (1024 * 256 + 256 * 256 + 256 * 16) * t + E * 64
+    # state MLP (rollout_mlp2_kernel): proprio rows in, the shared base + each net's head once per net-block
+    per_launch["rollout_mlp"] = E * wl["S"] * 4 + 2 * (128 * 256 + 256 * 256 + 2 * 256 * 256 + 256 * 16) * t + E * 64
     for k in sorted(per_launch, key=len, reverse=True):  # longest name first: fused_layer_bwd_* before fused_layer_*
         if kernel == k or kernel.startswith(k + "_"):
             return float(per_launch[k])
