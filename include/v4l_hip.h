@@ -46,6 +46,8 @@
  *                             device-side hand-overs (per call); V4L_ROLLOUT_CNN_OLD: the per-sample rollout_cnn_kernel
  *   V4L_ROLLOUT_WARM          L2 warm-up touches at the start of rollout_stack_kernel (measured: no effect)
  *   V4L_RCCL_LIB              path of the RCCL library to dlopen (default: librccl.so.1)
+ *   V4L_ROCTX=1               roctx ranges (libroctx64 via dlopen) around every phase and launch call, labelled phase|op|kernel:
+ *                             `rocprofv3 --marker-trace --kernel-trace` then shows the library's structure next to its kernels
  * Read by the Python shell, not by the library: V4L_COMPUTE=bf16|f32, V4L_GRAPH=0, V4L_DP_COMM=torch|rccl,
  * V4L_FORCE_DP_PHASES, V4L_LIB (diagnostic builds).
  */

@@ -36,15 +36,45 @@ static bool g_prof = false;
 static std::vector<ProfRec> g_recs;
 static thread_local const char* g_phase = "";
 static thread_local const char* g_op = "";
+// roctx ranges (V4L_ROCTX=1): every phase and every launch call is bracketed by roctxRangePushA / roctxRangePop, labelled
+// phase|op|kernel like the built-in profiler's records, so `rocprofv3 --marker-trace --kernel-trace` lines the launches up with
+// the library's own structure. The roctx library (rocprofiler-sdk's, else libroctx64) is opened with dlopen: no link-time
+// dependency; absent library = switch ignored.
+struct Roctx {
+  int (*push)(const char*) = nullptr;
+  int (*pop)() = nullptr;
+  bool on = false;
+  Roctx() {
+    const char* e = getenv("V4L_ROCTX");
+    if (e == nullptr || atoi(e) == 0) return;
+    void* h = dlopen("librocprofiler-sdk-roctx.so.1", RTLD_NOW | RTLD_GLOBAL);  // what rocprofv3 --marker-trace listens to
+    if (h == nullptr) h = dlopen("libroctx64.so.4", RTLD_NOW | RTLD_GLOBAL);   // the roctracer-era library (rocprof v1 / v2)
+    if (h == nullptr) h = dlopen("libroctx64.so", RTLD_NOW | RTLD_GLOBAL);
+    if (h == nullptr) return;
+    push = reinterpret_cast<int (*)(const char*)>(dlsym(h, "roctxRangePushA"));
+    pop = reinterpret_cast<int (*)()>(dlsym(h, "roctxRangePop"));
+    on = push != nullptr && pop != nullptr;
+  }
+};
+static Roctx& roctx() { static Roctx r; return r; }
 struct PhaseScope {
   const char* prev;
-  explicit PhaseScope(const char* p) : prev(g_phase) { g_phase = p; }
-  ~PhaseScope() { g_phase = prev; }
+  bool ranged;
+  explicit PhaseScope(const char* p) : prev(g_phase), ranged(roctx().on) {
+    g_phase = p;
+    if (ranged) (void)roctx().push(p);
+  }
+  ~PhaseScope() {
+    if (ranged) (void)roctx().pop();
+    g_phase = prev;
+  }
 };
 struct ProfGuard {
   hipStream_t s;
   bool on;
-  ProfGuard(const char* kname, double flops, hipStream_t st) : s(st), on(g_prof) {
+  bool ranged;
+  ProfGuard(const char* kname, double flops, hipStream_t st) : s(st), on(g_prof), ranged(roctx().on) {
+    if (ranged) (void)roctx().push((std::string(g_phase) + "|" + g_op + "|" + kname).c_str());
     if (!on) return;
     ProfRec r;
     r.label = std::string(g_phase) + "|" + g_op + "|" + kname;
@@ -56,6 +86,7 @@ struct ProfGuard {
   }
   ~ProfGuard() {
     if (on) (void)hipEventRecord(g_recs.back().e1, s);
+    if (ranged) (void)roctx().pop();
   }
 };
 #define V4L_KLAUNCH(kname, flops, s, ...)            \
