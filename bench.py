@@ -75,14 +75,19 @@ def parse(argv=None):
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--workload", default="loco", choices=sorted(WORKLOADS))
+    ap.add_argument("--workload", default=None, choices=sorted(WORKLOADS),
+                    help="default: by --gpus — 1, 2, 4 GPUs: loco (BASELINE configs[2] / [3]: 32 envs per GPU); 8 GPUs: loco64 "
+                         "(configs[4]: 64 envs per GPU)")
     ap.add_argument("--compute", default=os.environ.get("V4L_COMPUTE", "bf16"), choices=["bf16", "f32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity", action="store_true", help="skip the oracle parity check, h2d and reference-protocol legs")
     ap.add_argument("--no-reference-protocol", action="store_true")
     ap.add_argument("--no-rollout", action="store_true", help="time (ii)-(iv) only (the reference's Train___Time)")
     ap.add_argument("--breakdown", default=None, help="write the per-op HIP-event breakdown to this file")
-    return ap.parse_args(argv)
+    a = ap.parse_args(argv)
+    if a.workload is None:
+        a.workload = "loco64" if a.gpus >= 8 else "loco"
+    return a
 
 
 class Epoch:
@@ -723,7 +728,7 @@ def main():
     }
     if dist_on:
         ag = ep.agent
-        res["config"]["dp_comm"] = "library RCCL communicator inside the update graph" if ag.dp_in_library else "torch.distributed all-reduce between phases"
+        res["config"]["dp_comm"] = ag.dp_comm_note  # which exchange runs, and the self-test that decided it (ppo.py::_library_comm)
         res["rccl_ranks"] = ag.trainer.comm_world() if ag.dp_in_library else torch.distributed.get_world_size()
         res["scaling_note"] = "weak scaling: every rank owns E envs; multi-GPU numbers are only as good as the node they ran on"
     stats_ok = bool(torch.isfinite(ep.stats[:, :18]).all().item())

@@ -48,7 +48,7 @@
  *   V4L_RCCL_LIB              path of the RCCL library to dlopen (default: librccl.so.1)
  *   V4L_ROCTX=1               roctx ranges (libroctx64 via dlopen) around every phase and launch call, labelled phase|op|kernel:
  *                             `rocprofv3 --marker-trace --kernel-trace` then shows the library's structure next to its kernels
- * Read by the Python shell, not by the library: V4L_COMPUTE=bf16|f32, V4L_GRAPH=0, V4L_DP_COMM=torch|rccl,
+ * Read by the Python shell, not by the library: V4L_COMPUTE=bf16|f32, V4L_GRAPH=0, V4L_DP_COMM=auto|torch|rccl,
  * V4L_FORCE_DP_PHASES, V4L_LIB (diagnostic builds).
  */
 #ifndef V4L_HIP_H
@@ -273,6 +273,12 @@ int v4l_trainer_comm_destroy(v4l_trainer* tr);
 /* rank / size as the attached communicator reports them (ncclCommUserRank / ncclCommCount); 0 / 1 without one */
 int v4l_trainer_comm_info(const v4l_trainer* tr, int* rank_out, int* world_out);
 int v4l_sync_grads(v4l_trainer* tr, int which /* 1 = critic bucket, 0 = policy bucket */, void* stream);
+/* Self-test of the attached communicator through the calls an update makes (v4l_sync_grads on both buckets, eagerly and —
+ * use_graph = 1 — as a captured hipGraph replayed twice): a rank-dependent integer pattern is all-reduced and every element
+ * checked on the device against the sum each rank can compute alone. *mismatches_out = elements wrong on this rank (0 = pass).
+ * Synchronises the stream; overwrites the gradient buckets and the current statistics record (call it between updates).
+ * The host makes the in-graph RCCL schedule its default only when every rank passes (algo/on_policy/ppo.py shell). */
+int v4l_trainer_comm_selftest(v4l_trainer* tr, int use_graph, int64_t* mismatches_out, void* stream);
 /* for a host that runs the collective itself (e.g. torch.distributed): statistics record -> bucket tail (pack = 1, before
  * the all-reduce of total_params + V4L_BUCKET_TAIL floats) and back (pack = 0) */
 int v4l_trainer_bucket_tail(v4l_trainer* tr, int which, int pack, int world, void* stream);

@@ -175,6 +175,10 @@ def test_bench_launcher_argv():
     assert cmd[i + 1:] == argv
     a = bench.parse(cmd[i + 1:])
     assert a.gpus == 8 and a.steps == 5 and a.warmup == 2 and a.workload == "loco64"
+    # without --workload the BASELINE configuration follows the GPU count: configs[2] / [3] (32 envs per GPU) up to 4 GPUs,
+    # configs[4] (64 envs per GPU) on 8
+    assert [bench.parse(["--gpus", str(g)]).workload for g in (1, 2, 4, 8)] == ["loco", "loco", "loco", "loco64"]
+    assert bench.parse(["--gpus", "8", "--workload", "cnn"]).workload == "cnn"
     # without an explicit port a free one is picked (or MASTER_PORT is honoured)
     p = int(bench.launcher_argv(2, [])[bench.launcher_argv(2, []).index("--master-port") + 1])
     assert 1024 < p < 65536

@@ -125,6 +125,7 @@ _SIGS = {
   "v4l_trainer_comm_init": (C.c_int, [_P, C.c_char_p, C.c_int, C.c_int]),
   "v4l_trainer_comm_destroy": (C.c_int, [_P]),
   "v4l_sync_grads": (C.c_int, [_P, C.c_int, _P]),
+  "v4l_trainer_comm_selftest": (C.c_int, [_P, C.c_int, C.POINTER(C.c_int64), _P]),
   "v4l_trainer_bucket_tail": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, _P]),
   "v4l_net_ws_offset": (C.c_int64, [_P, C.c_int, C.c_char_p]),
   "v4l_prof_enable": (C.c_int, [C.c_int]),

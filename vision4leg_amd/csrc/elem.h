@@ -414,6 +414,45 @@ __global__ void bucket_tail_kernel(float* __restrict__ st, float* __restrict__ t
   }
 }
 
+// Communicator self-test (v4l_trainer_comm_selftest): a rank-dependent pattern of small integers — exact in fp32 whatever
+// order a collective adds them in — into a gradient bucket and the record fields its tail carries, and the check of the
+// all-reduced result against the sum every rank can compute on its own.
+__device__ __forceinline__ float comm_pattern(int64_t i, int rank) { return (float)((i * 7 + (int64_t)rank * 13) % 251); }
+__global__ __launch_bounds__(256) void comm_pattern_kernel(float* __restrict__ g, int64_t n, int rank, float* __restrict__ st,
+                                                           int which) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) g[i] = comm_pattern(i, rank);
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    if (which == 1) {
+      st[ST_ADV_SUM] = (float)(rank + 1); st[ST_ADV_M2] = (float)(2 * rank + 1); st[ST_ADV_CNT] = 64.f;
+      st[ST_ADV_NM2] = (float)(rank + 3); st[ST_VF_LOSS] = (float)(rank + 5);
+    } else {
+      st[ST_PI_LOSS] = (float)(rank + 1);
+    }
+  }
+}
+__global__ __launch_bounds__(256) void comm_check_kernel(const float* __restrict__ g, int64_t n, int world,
+                                                         const float* __restrict__ st, int which, int* __restrict__ bad) {
+  int mine = 0;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    float want = 0.f;
+    for (int r = 0; r < world; ++r) want += comm_pattern(i, r);
+    mine += g[i] != want;
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    const float w = (float)world, tri = 0.5f * w * (w - 1.f);  // sum of the ranks
+    if (which == 1) {
+      mine += st[ST_ADV_SUM] != tri + w;
+      mine += st[ST_ADV_M2] != 2.f * tri + w;
+      mine += st[ST_ADV_CNT] != 64.f * w;
+      mine += st[ST_ADV_NM2] != tri + 3.f * w;
+      mine += st[ST_VF_LOSS] != tri + 5.f * w;
+    } else {
+      mine += fabsf(st[ST_PI_LOSS] - (tri + w) / w) > 1e-5f * (tri + w) / w;  // shares: mean over the ranks
+    }
+  }
+  if (mine) atomicAdd(bad, mine);
+}
+
 // nn.MSELoss()(values, est_rets) and its gradient (ppo.py:94-123; clipped_value_loss=False path, and the
 // clipped variant of ppo.py:105-112 when clip > 0). values is the critic output [n][OUT_LD], column 0.
 __global__ __launch_bounds__(1024) void critic_loss_kernel(const float* __restrict__ values, const float* __restrict__ ret,

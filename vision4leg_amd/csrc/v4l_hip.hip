@@ -3011,6 +3011,73 @@ int v4l_sync_grads(v4l_trainer* tr, int which, void* stream) {
   return 0;
 }
 
+// Self-test of the attached communicator through the very calls an update makes: both buckets get a rank-dependent integer
+// pattern (bucket + the record fields the tail carries), v4l_sync_grads all-reduces them — eagerly, then (use_graph) as a
+// captured hipGraph replayed twice, the way v4l_trainer_update_next runs it — and every element is compared on the device with
+// the sum each rank can compute alone. *mismatches_out = elements that differ on THIS rank (0 = pass). Synchronises the stream.
+// Overwrites the gradient buckets and the current statistics record: call it between updates (PPO.__init__ does).
+int v4l_trainer_comm_selftest(v4l_trainer* tr, int use_graph, int64_t* mismatches_out, void* stream) {
+  V4L_REQUIRE(tr && tr->bound && mismatches_out, "v4l_trainer_comm_selftest: bad argument");
+  V4L_REQUIRE(tr->comm != nullptr, "v4l_trainer_comm_selftest: no communicator (v4l_trainer_comm_init)");
+  hipStream_t s = (hipStream_t)stream;
+  V4L_REQUIRE(!use_graph || s != nullptr, "v4l_trainer_comm_selftest: graph capture needs a non-default stream");
+  int* bad = (int*)tr->norm_part;  // scratch between updates
+  V4L_HIP_CHECK(hipMemsetAsync(bad, 0, sizeof(int), s));
+  auto fill_and_reduce = [&](void) -> int {
+    for (int which = 1; which >= 0; --which) {
+      v4l_net* net = which ? tr->vf : tr->pf;
+      float* g = which ? tr->g_vf : tr->g_pf;
+      hipLaunchKernelGGL(comm_pattern_kernel, dim3(256), dim3(256), 0, s, g, net->total_params, tr->comm_rank, tr->stats_cur, which);
+      V4L_LAUNCH_CHECK();
+      int rc = v4l_sync_grads(tr, which, stream);
+      if (rc) return rc;
+    }
+    return 0;
+  };
+  auto check = [&](void) -> int {
+    for (int which = 1; which >= 0; --which) {
+      v4l_net* net = which ? tr->vf : tr->pf;
+      hipLaunchKernelGGL(comm_check_kernel, dim3(256), dim3(256), 0, s, which ? tr->g_vf : tr->g_pf, net->total_params,
+                         tr->comm_world, tr->stats_cur, which, bad);
+      V4L_LAUNCH_CHECK();
+    }
+    return 0;
+  };
+  int rc;
+  if ((rc = fill_and_reduce()) || (rc = check())) return rc;
+  hipGraphExec_t exec = nullptr;
+  if (use_graph) {
+    hipGraph_t graph = nullptr;
+    V4L_HIP_CHECK(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+    rc = fill_and_reduce();
+    const hipError_t e = hipStreamEndCapture(s, &graph);
+    if (rc) { if (graph) (void)hipGraphDestroy(graph); return rc; }
+    V4L_HIP_CHECK(e);
+    V4L_HIP_CHECK(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
+    V4L_HIP_CHECK(hipGraphDestroy(graph));
+    hipError_t el = hipSuccess;
+    for (int rep = 0; rep < 2 && !rc && el == hipSuccess; ++rep) {
+      el = hipGraphLaunch(exec, s);
+      if (el == hipSuccess) rc = check();
+    }
+    if (rc || el != hipSuccess) {
+      (void)hipStreamSynchronize(s);
+      (void)hipGraphExecDestroy(exec);
+      if (rc) return rc;
+      V4L_HIP_CHECK(el);
+    }
+  }
+  int host_bad = 0;
+  const hipError_t ec = hipMemcpyAsync(&host_bad, bad, sizeof(int), hipMemcpyDeviceToHost, s);
+  const hipError_t es = hipStreamSynchronize(s);
+  if (exec) (void)hipGraphExecDestroy(exec);  // only once nothing of it is in flight
+  V4L_HIP_CHECK(ec);
+  V4L_HIP_CHECK(es);
+  V4L_HIP_CHECK(hipMemsetAsync(bad, 0, sizeof(int), s));
+  *mismatches_out = host_bad;
+  return 0;
+}
+
 static int run_update(v4l_trainer* tr, const v4l_rollout* ro, int n, const v4l_ppo_hyper* hp, void* stream) {
   int rc;
   const bool dp = tr->comm != nullptr;  // a 1-rank communicator runs the same sequence (how one GPU exercises it)

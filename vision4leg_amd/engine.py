@@ -300,12 +300,29 @@ class HipTrainer:
     """True when this process can load RCCL (v4l_comm_available); ranks agree on it before the communicator rendezvous."""
     return _lib.lib().v4l_comm_available() == 0
 
+  def comm_info(self):
+    """(rank, ranks) of the attached communicator as RCCL reports them; (0, 1) without one."""
+    world, rank = C.c_int(1), C.c_int(0)
+    check(self.L.v4l_trainer_comm_info(self.h, C.byref(rank), C.byref(world)), "v4l_trainer_comm_info")
+    return rank.value, world.value
+
   def comm_world(self):
     """Ranks of the attached communicator as RCCL reports them (ncclCommCount), 1 without one."""
     world = C.c_int(1)
     rank = C.c_int(0)
     check(self.L.v4l_trainer_comm_info(self.h, C.byref(rank), C.byref(world)), "v4l_trainer_comm_info")
     return world.value
+
+  def comm_selftest(self, graph=True):
+    """v4l_trainer_comm_selftest on the current stream: -> number of wrong elements on this rank (0 = the communicator
+    all-reduces both buckets correctly, eagerly and as a replayed graph). Overwrites the gradient buckets."""
+    bad = C.c_int64(-1)
+    check(self.L.v4l_trainer_comm_selftest(self.h, int(graph), C.byref(bad), _stream()), "v4l_trainer_comm_selftest")
+    return bad.value
+
+  def comm_destroy(self):
+    check(self.L.v4l_trainer_comm_destroy(self.h), "v4l_trainer_comm_destroy")
+    self.has_comm = False
 
   @staticmethod
   def comm_unique_id():

@@ -71,6 +71,23 @@ def exchange_comm_id(dist, device, available, unique_id, id_bytes=_lib.V4L_COMM_
     return bytes(idt.cpu().numpy().tobytes())
 
 
+def device_identity(device):
+    """A 63-bit fingerprint of (host, physical GPU) — equal on two ranks exactly when they drive the same device."""
+    import hashlib
+    import socket
+    props = torch.cuda.get_device_properties(device)
+    ident = [socket.gethostname()]
+    uuid = str(getattr(props, "uuid", ""))
+    if uuid and uuid.strip("0-") != "":
+        ident.append(uuid)
+    elif hasattr(props, "pci_bus_id"):
+        ident.append((getattr(props, "pci_domain_id", 0), props.pci_bus_id, getattr(props, "pci_device_id", 0)))
+    else:
+        ident.append((os.environ.get("HIP_VISIBLE_DEVICES"), os.environ.get("ROCR_VISIBLE_DEVICES"),
+                      os.environ.get("CUDA_VISIBLE_DEVICES"), torch.device(device).index))
+    return int.from_bytes(hashlib.sha1(repr(ident).encode()).digest()[:8], "little") >> 1
+
+
 class PPO:
     def __init__(self, pf, vf, plr=3e-4, vlr=3e-4, optimizer_class=None, entropy_coeff=0.001, clip_para=0.2,
                  opt_epochs=10, clipped_value_loss=False, shuffle=True, tau=None, gae=True, env=None,
@@ -136,32 +153,108 @@ class PPO:
             atu.copy_model_params_from_to(self.pf, self.target_pf)
             for net in self.networks:  # `.data` writes do not bump the Parameters' version counters
                 net.mark_params_changed()
+        self.use_graph = os.environ.get("V4L_GRAPH", "1") != "0"
         with torch.cuda.device(self.device):
             self.trainer = HipTrainer(self.pf.hip, self.vf.hip, self.target_pf.hip, batch_size, clip_para,
                                       entropy_coeff, max_grad_norm=0.5, clipped_value_loss=clipped_value_loss,
                                       world_size=self.world_size)
-            # the exchange: torch.distributed's all-reduce (backend "nccl" == RCCL) between four eager phases per update by
-            # default; V4L_DP_COMM=rccl opts into the library's own RCCL communicator, whose two all-reduces are issued by
-            # update_next() inside the captured update graph. (Opt-in until a multi-GPU box has run it with world > 1: it has
-            # only been exercised on a 1-rank communicator, tests/test_gpu_parity.py::test_dp_phase_sequence_on_one_rank.)
-            self.dp_in_library = self.dp_phases and os.environ.get("V4L_DP_COMM", "torch").lower() == "rccl"
-            if self.dp_in_library:
-                dist = torch.distributed
-                comm_id = exchange_comm_id(dist, self.device, HipTrainer.comm_available, HipTrainer.comm_unique_id)
-                if comm_id is None:  # agreed by all ranks: some rank cannot load RCCL
-                    import warnings
-                    warnings.warn("vision4leg_amd: V4L_DP_COMM=rccl but a rank cannot load librccl; every rank keeps the "
-                                  "torch.distributed exchange")
-                    self.dp_in_library = False
+            # The exchange. Preferred: the library's own RCCL communicator, whose two all-reduces are issued by update_next()
+            # INSIDE the captured update graph (no host round trip between backward, all-reduce and Adam). It becomes the
+            # schedule only after every rank has passed a self-test of that communicator through the very calls an update
+            # makes (_library_comm); otherwise all ranks together keep torch.distributed's all-reduce between four eager
+            # phases per update (_update_phases). V4L_DP_COMM = auto (default) | rccl (same, but a failing self-test raises)
+            # | torch (never try the library's communicator).
+            self.dp_in_library, self.dp_comm_note = False, "single process"
+            if self.dp_phases:
+                want = os.environ.get("V4L_DP_COMM", "auto").lower()
+                if want not in ("auto", "rccl", "torch"):
+                    raise ValueError("V4L_DP_COMM must be auto, rccl or torch (got %r)" % want)
+                if want == "torch":
+                    self.dp_comm_note = "torch.distributed all-reduce between phases (V4L_DP_COMM=torch)"
                 else:
-                    self.trainer.comm_init(comm_id, dist.get_rank(), self.world_size)
-                    self.dp_phases = False  # update_next() carries the collectives itself
-        self.use_graph = os.environ.get("V4L_GRAPH", "1") != "0"
+                    ok, why = self._library_comm()
+                    if ok:
+                        self.dp_in_library = True
+                        self.dp_phases = False  # update_next() carries the collectives itself
+                        self.dp_comm_note = "library RCCL communicator inside the update graph (%s)" % why
+                    elif want == "rccl":
+                        raise RuntimeError("vision4leg_amd: V4L_DP_COMM=rccl but the library's communicator is not usable: " + why)
+                    else:
+                        self.dp_comm_note = "torch.distributed all-reduce between phases (library RCCL declined: %s)" % why
         if isinstance(replay_buffer, rb.DeviceOnPolicyReplayBuffer):
             replay_buffer.attach(self.pf.hip, self.device)
         elif replay_buffer is not None:
             replay_buffer.gae_device = self.device
         self._stage = None
+
+    # ---- data-parallel bootstrap ---------------------------------------------------------------------
+    def _agree(self, ok):
+        """True only if `ok` holds on EVERY rank (a MIN all-reduce over the host's process group)."""
+        dist = torch.distributed
+        kw = {"device": self.device} if dist.get_backend() == "nccl" else {}
+        t = torch.tensor([1 if ok else 0], dtype=torch.int32, **kw)
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        return int(t.item()) == 1
+
+    def _library_comm(self):
+        """Bring up the library's RCCL communicator over the host's process group and prove it before relying on it.
+        -> (True, what was checked) with the communicator attached on every rank, or (False, why) with none attached on
+        any rank. Every decision is taken by all ranks together, so no rank ever waits in a rendezvous alone:
+          1. one GPU per rank (RCCL refuses two ranks on a device — the 2-process / 1-GPU test setup);
+          2. every rank can load librccl (`exchange_comm_id`), then rank 0's unique id is broadcast and the ranks meet in
+             ncclCommInitRank;
+          3. v4l_trainer_comm_selftest: both gradient buckets [gradients | tail] carry a rank-dependent integer pattern
+             through v4l_sync_grads — eagerly and as a captured graph replayed twice, as update_next() will run it — and
+             are checked element by element on the device;
+          4. the same pattern through torch.distributed's all-reduce must give the same buffer, and the communicator's
+             own rank / size (ncclCommUserRank / ncclCommCount) must equal the process group's."""
+        dist = torch.distributed
+        tr = self.trainer
+        rank, world = dist.get_rank(), dist.get_world_size()
+        kw = {"device": self.device} if dist.get_backend() == "nccl" else {}
+        mine = torch.tensor([device_identity(self.device)], dtype=torch.int64, **kw)
+        every = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(every, mine)
+        if len({int(t.item()) for t in every}) < world:
+            return False, "ranks share a GPU; RCCL needs one device per rank"
+        comm_id = exchange_comm_id(dist, self.device, HipTrainer.comm_available, HipTrainer.comm_unique_id)
+        if comm_id is None:
+            return False, "a rank cannot load librccl"
+        err = ""
+        try:
+            tr.comm_init(comm_id, rank, world)
+        except RuntimeError as e:
+            err = str(e)
+        if not self._agree(not err):
+            if tr.has_comm:
+                tr.comm_destroy()
+            return False, "ncclCommInitRank failed on a rank" + (": " + err if err else "")
+        try:
+            with torch.cuda.stream(tr.stream):
+                bad = tr.comm_selftest(graph=self.use_graph)
+                if bad:
+                    err = "%d elements of the all-reduced self-test pattern are wrong on rank %d" % (bad, rank)
+                crank, cworld = tr.comm_info()
+                if (crank, cworld) != (rank, world):
+                    err = "communicator reports rank %d of %d, the process group %d of %d" % (crank, cworld, rank, world)
+                # the critic bucket still holds the library's all-reduced pattern: torch.distributed must produce the same
+                n = tr.vf.total_params
+                i = torch.arange(n, dtype=torch.int64, device=self.device)
+                ref = ((i * 7 + rank * 13) % 251).to(torch.float32)
+                got = tr.g_vf.clone()
+            tr.stream.synchronize()
+            dist.all_reduce(ref)
+            if not err and not torch.equal(ref, got):
+                err = "library all-reduce and torch.distributed all-reduce disagree on rank %d" % rank
+        except RuntimeError as e:
+            err = str(e)
+        tr.g_vf_bucket.zero_()
+        tr.g_pf_bucket.zero_()
+        if not self._agree(not err):
+            tr.comm_destroy()
+            return False, "self-test failed on a rank" + (": " + err if err else "")
+        return True, "self-test passed on %d ranks: eager + %s all-reduce of both buckets, cross-checked against " \
+                     "torch.distributed" % (world, "graph-replayed" if self.use_graph else "eager-only")
 
     # ---- reference plumbing ------------------------------------------------------------------------
     @property
