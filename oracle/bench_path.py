@@ -20,14 +20,31 @@ from . import ppo_oracle as orc
 
 
 def _rel(a, b):
+    """max |a - b| relative to the reference tensor's max-abs (policy means are O(1e-2): no floor at 1)."""
     a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
-    return float(np.abs(a - b).max() / max(1.0, np.abs(b).max()))
+    return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-12))
 
 
-def run(case, E, T, B, U, mode, dev, seed=0, threads=None):
+ENV_SEEDS = 8
+
+
+def _forward_envelope(fwd, params, obs, S, ref, scale=1e-7):
+    """The bf16 oracle's own sensitivity (as tests/test_gpu_parity.py::_bf16_envelope): p95 over ENV_SEEDS runs with the
+    parameters nudged by 1e-7 of the forward output's distance to the un-nudged run."""
+    errs = []
+    for sd in range(1, ENV_SEEDS + 1):
+        gen = torch.Generator().manual_seed(sd)
+        q = {k: v * (1 + scale * torch.randn(v.shape, generator=gen)) for k, v in params.items()}
+        errs.append(_rel(fwd(q, obs, S, "bf16").reshape(ref.shape), ref))
+    return float(np.percentile(errs, 95))
+
+
+def run(case, E, T, B, U, mode, dev, seed=0, threads=None, envelope=True):
     """case: a recipes case dict (kind, S, A, ...). Rollout of T steps x E envs, then U stored-log-pi updates of B rows.
     -> dict of measured distances. mode: the product's compute mode ("f32" | "bf16"); the oracle runs in that flavour
-    and (bf16) also in fp32, so the caller can apply the trajectory rule |hip - fp32| <= k |bf16 oracle - fp32|."""
+    and (bf16) also in fp32, so the caller can apply the trajectory rule |hip - fp32| <= k |bf16 oracle - fp32|.
+    Distances between tensors are relative to the reference tensor's max-abs. envelope (bf16): also the bf16 oracle's own
+    sensitivity on the rollout's mean / value (8 nudged forward passes each), the yardstick of the bf16 rollout gate."""
     os.environ["V4L_COMPUTE"] = mode
     import vision4leg_amd.torchrl.networks as networks
     import vision4leg_amd.torchrl.policies as policies
@@ -93,6 +110,10 @@ def run(case, E, T, B, U, mode, dev, seed=0, threads=None):
             lp_o, _ = orc.log_prob_entropy(m_o, s_o, acts_h)
             res["rollout_mean_vs_%s" % fl] = _rel(mean_h, m_o)
             res["rollout_value_vs_%s" % fl] = _rel(vals_h, v_o)
+            if fl == "bf16" and envelope:
+                res["rollout_mean_envelope_p95"] = _forward_envelope(fwd, {k: v for k, v in o.pf.items() if k != "logstd"},
+                                                                     ob_cpu, S, m_o)
+                res["rollout_value_envelope_p95"] = _forward_envelope(fwd, o.vf, ob_cpu, S, v_o)
             res["rollout_std_vs_%s" % fl] = _rel(std_h, s_o)
             # log pi_old of the FILED action under the oracle's own mean / std: what the reference's target forward yields
             res["rollout_logp_abs_vs_%s" % fl] = float((logp_h - lp_o.reshape(-1)).abs().max())

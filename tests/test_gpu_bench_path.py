@@ -6,10 +6,12 @@ oracle (oracle/bench_path.py) does what the reference does: pf.explore / vf per 
 Normal(mean, std).log_prob (policies/continuous_policy.py:127-146) and a target_pf forward inside every minibatch update
 (algo/on_policy/ppo.py:34,55-59).
 
-Gates
-  f32 : rollout mean / value <= 2e-5, log pi_old <= 2e-5 (abs), the 18 infos of every update <= 5e-4, parameters: all but <= 1e-3
+Gates (tensor distances are relative to the reference tensor's max-abs — policy means are O(1e-2), nothing is floored at 1)
+  f32 : rollout mean / value <= 2e-5, log pi_old <= 2e-4 (abs), the 18 infos of every update <= 5e-4, parameters: all but <= 1e-3
         of the elements within half an Adam step (5e-5), none further than 2 lr U, mean <= 5e-6 (see the comment at the gate).
-  bf16: distances reported (profiles/parity_r3.json) and the TRAJECTORY RULE: per update, HIP-bf16 is no further from the
+  bf16: rollout mean / value within 3 x the bf16 oracle's own sensitivity (p95 of 8 forward passes with parameters nudged by
+        1e-7, oracle/bench_path.py::_forward_envelope), update 0's infos within 1e-2 of the bf16 oracle's, distances recorded
+        (profiles/parity_r4.json), and the TRAJECTORY RULE: per update, HIP-bf16 is no further from the
         fp32 reference trajectory than the bf16 oracle is, up to a factor / floor that covers which side of a rounding tie
         the two bf16 implementations happen to land on (they agree to 1 ulp per contraction: test_gpu_contractions.py).
 """
@@ -61,7 +63,8 @@ def test_rollout_then_stored_logp_graph_updates_vs_reference_protocol(E, mode, d
                   % (E, d.max().item(), (d > 5e-5).double().mean().item()))
         return
     # bf16: where the bf16-rounded oracle sits ...
-    assert r["rollout_mean_vs_bf16"] <= 1e-2 and r["rollout_value_vs_bf16"] <= 1e-2
+    assert r["rollout_mean_vs_bf16"] <= max(3.0 * r["rollout_mean_envelope_p95"], 1e-4), (r["rollout_mean_vs_bf16"], r["rollout_mean_envelope_p95"])
+    assert r["rollout_value_vs_bf16"] <= max(3.0 * r["rollout_value_envelope_p95"], 1e-4), (r["rollout_value_vs_bf16"], r["rollout_value_envelope_p95"])
     assert r["infos_vs_bf16_per_update"][0] <= 1e-2, r["infos_vs_bf16_per_update"]
     # ... and the trajectory rule against the fp32 reference trajectory. Per update and per statistic the comparison is a coin
     # toss (grad_norm/pf jumps by a few per cent whenever ONE sample changes sides of the PPO clip, and which update that

@@ -2,9 +2,14 @@
 
 Tolerances (relative to the tensor's max-abs unless noted):
   compute=f32  (exact-fp32 MFMA): 2e-4 forward / grads — only summation order differs from the fp32 oracle.
-  compute=bf16 (bf16 operands, fp32 accumulate): 1e-3 against the bf16-operand-rounded oracle
-               (BASELINE.json north_star tolerance); distance to the fp32 oracle is printed, not gated
-               (~4e-3 by construction).
+  compute=bf16 (bf16 operands, fp32 accumulate): against the bf16-operand-rounded oracle (same rounding points). Per
+               contraction the statement is <= 1 bf16 ulp (tests/test_gpu_contractions.py). END TO END the yardstick is the
+               bf16 oracle's OWN sensitivity: the oracle is re-run with its parameters nudged by 1e-7 (8 seeds) — an
+               implementation with the same rounding points differs from the oracle the way those runs differ from each
+               other (summation order moves rounding decisions), one with different rounding points does not. Gates: every
+               output and every gradient tensor <= 3 x the 95th percentile of that envelope; the flat gradient of each net
+               cosine >= 0.9995 and relative L2 <= 2 x the envelope's. No bf16 tolerance refers to the bf16-vs-fp32 distance;
+               the distance to the fp32 reference is recorded and held to a fixed 2e-2 (~4e-3 by construction).
   GAE: bit-exact (np.array_equal) in fp64 and after the fp32 cast.
 """
 import copy
@@ -30,13 +35,54 @@ def _fp_close(v, fp):
     return abs(a - fp[0]) <= 1e-5 * max(1.0, abs(fp[1])) and abs(b - fp[1]) <= 1e-5 * max(1.0, abs(fp[1]))
 
 
-def _oracle_noise(fn, obs, params, S, ref_out, scale=1e-7):
-    """bf16 arithmetic is chaotic over ~20 stacked contractions: a 1e-7 relative nudge of the parameters moves
-    rounding decisions and changes the bf16-oracle's own output by O(1e-3). This measures that envelope."""
-    g = torch.Generator().manual_seed(1)
-    q = {k: v * (1 + scale * torch.randn(v.shape, generator=g)) for k, v in params.items()}
-    with torch.no_grad():
-        return util.rel_err(fn(q, obs, S, "bf16"), ref_out)
+ENV_SEEDS, ENV_FACTOR, ENV_FLOOR = 8, 3.0, 1e-4   # floor: fp32 summation-order noise of tensors no rounding decision touches
+COS_MIN, L2_FACTOR = 0.9995, 2.0
+_ENVELOPES = {}
+
+
+def _flat(gs, keys):
+    return torch.cat([gs[k].reshape(-1) for k in keys]).double()
+
+
+def _bf16_envelope(name, tag, kind, params, obs, S, w, scale=1e-7):
+    """The bf16 oracle's own sensitivity. bf16 arithmetic is chaotic over ~20 stacked contractions: a 1e-7 relative nudge of
+    the parameters (far below one bf16 ulp, 4e-3) moves a handful of rounding / ReLU decisions, and each moved decision
+    changes the output and single gradient elements by O(1e-3 .. 1e-1) of the tensor's max-abs. An implementation with the
+    oracle's rounding points differs from it in exactly that way (its fp32 partial sums are added in another order).
+    -> {"out", "grads": the un-nudged bf16 oracle's; "fwd": p95 over ENV_SEEDS nudged runs of rel_err(out);
+        "tensor": {key: p95 of rel_err(grad)}; "l2": p95, "cos": min of the flat gradient's relative L2 / cosine}.
+    Cached per (case, net): test_forward and test_backward (and the deep-GEMM reruns) share one set of runs."""
+    key = (name, tag)
+    if key in _ENVELOPES:
+        return _ENVELOPES[key]
+    fn = orc.FORWARDS[kind]
+    keys = list(params)
+
+    def run(p):
+        q = {k: v.detach().clone().requires_grad_(True) for k, v in p.items()}
+        out = fn(q, obs, S, "bf16")
+        g = torch.autograd.grad((out * w).sum(), [q[k] for k in keys])
+        return out.detach(), dict(zip(keys, g))
+    out0, g0 = run(params)
+    f0 = _flat(g0, keys)
+    fwd, l2, cos, per = [], [], [], {k: [] for k in keys}
+    for sd in range(1, ENV_SEEDS + 1):
+        gen = torch.Generator().manual_seed(sd)
+        out, g = run({k: v * (1 + scale * torch.randn(v.shape, generator=gen)) for k, v in params.items()})
+        fwd.append(util.rel_err(out, out0))
+        for k in keys:
+            per[k].append(util.rel_err(g[k], g0[k]))
+        f = _flat(g, keys)
+        l2.append(float((f - f0).norm() / f0.norm()))
+        cos.append(float((f @ f0) / (f.norm() * f0.norm())))
+    env = {"out": out0, "grads": g0, "fwd": float(np.percentile(fwd, 95)), "l2": float(np.percentile(l2, 95)),
+           "cos": min(cos), "tensor": {k: float(np.percentile(v, 95)) for k, v in per.items()}}
+    _ENVELOPES[key] = env
+    return env
+
+
+def _probe_weights(case, A):
+    return torch.tensor(np.random.RandomState(5).randn(case["B"], A), dtype=torch.float32)
 
 
 def _build(case, mode, dev):
@@ -81,20 +127,19 @@ def test_forward(name, mode, device):
         assert em < TOL[mode] and ev < TOL[mode]
         assert gm < TOL[mode] and gv < TOL[mode]
     else:
-        # end to end, two bf16 implementations agree only up to the bf16 oracle's own sensitivity (see
-        # _oracle_noise) and sit at the bf16 distance from the fp32 reference; first-layer exactness of the
-        # rounding points is asserted in test_bf16_first_layer_exact
-        fn = orc.FORWARDS[case["kind"]]
-        with torch.no_grad():
-            pm = {k: v for k, v in opf.items() if k != "logstd"}
-            nm = _oracle_noise(fn, obs, pm, case["S"], om)
-            nv = _oracle_noise(fn, obs, ovf, case["S"], ov)
-            fm = util.rel_err(om, fn(pm, obs, case["S"], "f32"))
-            fv = util.rel_err(ov, fn(ovf, obs, case["S"], "f32"))
-        print("   bf16 envelope: oracle self-noise mean %.2e value %.2e | bf16-oracle vs fp32: mean %.2e value %.2e"
-              % (nm, nv, fm, fv))
-        assert em < max(2e-3, 5 * nm, fm) and ev < max(2e-3, 5 * nv, fv)
-        assert gm < max(2e-3, 2.5 * fm) and gv < max(2e-3, 2.5 * fv)
+        # end to end, two bf16 implementations with the same rounding points agree up to the bf16 oracle's own sensitivity
+        # (_bf16_envelope: 8 runs with parameters nudged by 1e-7); first-layer exactness of the rounding points is asserted
+        # in test_bf16_first_layer_exact, every contraction in tests/test_gpu_contractions.py
+        pm = {k: v for k, v in opf.items() if k != "logstd"}
+        nm = _bf16_envelope(name, "pf", case["kind"], pm, obs, case["S"], _probe_weights(case, case["A"]))["fwd"]
+        nv = _bf16_envelope(name, "vf", case["kind"], ovf, obs, case["S"], _probe_weights(case, 1))["fwd"]
+        print("   bf16 envelope (p95 of %d nudged oracle runs): mean %.2e value %.2e -> hip / envelope: %.2f %.2f"
+              % (ENV_SEEDS, nm, nv, em / max(nm, 1e-12), ev / max(nv, 1e-12)))
+        util.record("forward/%s/%s/mean_envelope_p95" % (name, mode), nm)
+        util.record("forward/%s/%s/value_envelope_p95" % (name, mode), nv)
+        assert em <= max(ENV_FACTOR * nm, ENV_FLOOR), ("mean", em, nm)
+        assert ev <= max(ENV_FACTOR * nv, ENV_FLOOR), ("value", ev, nv)
+        assert gm < 2e-2 and gv < 2e-2  # fixed: the bf16 distance to the fp32 reference (~4e-3 by construction)
     assert torch.allclose(std.cpu(), torch.exp(opf["logstd"]).expand_as(om))
     assert tuple(mean.shape) == (case["B"], case["A"]) and tuple(value.shape) == (case["B"], 1)
 
@@ -180,13 +225,20 @@ def test_backward(name, mode, device):
             op[k].requires_grad_(False)
         bad = []
         if mode == "bf16":
-            # envelope: the bf16 oracle's distance to the fp32 oracle on the same gradients
-            for k in keys:
-                op[k].requires_grad_(True)
-            out32 = orc.FORWARDS[case["kind"]](op, obs, case["S"], "f32")
-            ref32 = torch.autograd.grad((out32 * w).sum(), [op[k] for k in keys])
-            for k in keys:
-                op[k].requires_grad_(False)
+            env = _bf16_envelope(name, tag, case["kind"], op, obs, case["S"], w)
+            got_all = {k: hip.grad_view(grads, k).cpu() for k in keys}
+            fh, fo = _flat(got_all, keys), _flat(dict(zip(keys, ref)), keys)
+            cos = float((fh @ fo) / (fh.norm() * fo.norm()))
+            l2 = float((fh - fo).norm() / fo.norm())
+            for what, val in (("flat_cos_vs_oracle", cos), ("flat_rel_l2_vs_oracle", l2), ("flat_rel_l2_envelope_p95", env["l2"]),
+                              ("flat_cos_envelope_min", env["cos"])):
+                util.record("backward/%s/%s/%s/%s" % (name, mode, tag, what), val)
+            print("\n[%s %s %s] flat gradient: cos %.7f (envelope min %.7f), rel L2 %.2e (envelope p95 %.2e)"
+                  % (name, mode, tag, cos, env["cos"], l2, env["l2"]))
+            if cos < COS_MIN:
+                bad.append(("<flat>", "cosine %.6f < %.4f" % (cos, COS_MIN)))
+            if l2 > max(L2_FACTOR * env["l2"], ENV_FLOOR):
+                bad.append(("<flat>", "relative L2 %.2e > %.1f x envelope %.2e" % (l2, L2_FACTOR, env["l2"])))
         ref64 = None
         for i, (k, g) in enumerate(zip(keys, ref)):
             got = hip.grad_view(grads, k).cpu()
@@ -220,10 +272,11 @@ def test_backward(name, mode, device):
                         bad.append((k, "vs fp32 oracle %.2e, vs fp64 %.2e (fp32 oracle vs fp64 %.2e, nudged fp64 vs fp64 %.2e)"
                                     % (e, e64, n64, npert)))
             else:
-                env = util.rel_err(g, ref32[i])          # bf16-oracle vs fp32-oracle
-                e32 = util.rel_err(got, ref32[i])        # HIP bf16 vs fp32-oracle
-                if e32 > max(5e-3, 2.0 * env) or e > max(5e-3, 2.0 * env):
-                    bad.append((k, "hip-vs-bf16oracle %.2e hip-vs-f32 %.2e envelope %.2e" % (e, e32, env)))
+                ek = env["tensor"][k]                    # p95 over the nudged bf16-oracle runs, this tensor
+                util.record("backward/%s/%s/%s/%s/hip_vs_oracle" % (name, mode, tag, k), e)
+                util.record("backward/%s/%s/%s/%s/envelope_p95" % (name, mode, tag, k), ek)
+                if e > max(ENV_FACTOR * ek, ENV_FLOOR):
+                    bad.append((k, "hip-vs-bf16oracle %.2e > %.0f x envelope %.2e" % (e, ENV_FACTOR, ek)))
         print("\n[%s %s %s] worst grad rel err so far %.2e" % (name, mode, tag, worst))
         util.record("backward/%s/%s/%s/worst_grad_vs_oracle" % (name, mode, tag), worst)
         assert not bad, bad
