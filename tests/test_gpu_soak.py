@@ -1,0 +1,229 @@
+"""-m gpu: does bf16 training LEARN like fp32 training? One soak run of the whole loop, three ways.
+
+A learnable vec env (reward = -|a - (c + W s[:A])|^2 for fixed c, W: the best action is an offset plus a linear read-out of
+the proprio block)
+is trained for 30 epochs (E = 8 envs x T = 32 steps, B = 64, 3 opt epochs = 360 optimiser steps, linear LR decay) through
+`algo.PPO.train()` with the product's fast collector and HBM-resident buffer (torchrl/algo/rl_algo.py:97-168,
+algo/on_policy/ppo.py:28-40, collector/on_policy.py:84-155) in HIP-bf16 and HIP-f32, and by the fp32 CPU oracle driving the
+same protocol (pf.explore / vf per step, GAE, target sync, minibatches of whole time rows, PPOOracle.update). All three
+start from the same seeded parameters and see the same env streams and minibatch permutations; the exploration noise
+comes from different generators (device / host), so the comparison is statistical: the deterministic evaluation return
+(action = policy mean on a fixed set of eval episodes) must improve by the same amount, up to a band measured by running
+the fp32 product twice with different exploration seeds. Bookkeeping (Adam step counter, training_update_num, LR schedule,
+finite infos) must agree exactly.
+"""
+import os
+import time
+
+import numpy as np
+import pytest
+import torch
+
+import util
+from oracle import ppo_oracle as orc
+
+E, T, B, EPOCHS, OPT_EPOCHS, HORIZON = 8, 32, 64, 30, 3, 16
+LR, GAMMA, TAU = 5e-4, 0.9, 0.95
+CASE = dict(util.CASES["loco_s84"])
+
+
+class LearnableVecEnv:
+    """Reference vec-env protocol (torchrl/env/vecenv.py). reward_e = -|a_e - (c + W s_e[:A])|^2 at the observation the action was
+    taken on; every env terminates after HORIZON steps; observations are fresh draws (no dynamics: a contextual bandit —
+    enough to tell a learning policy from a drifting one). reset() re-seeds the stream when `fixed` (the eval env: the same
+    episodes every epoch)."""
+
+    class _Space:
+        def __init__(self, shape):
+            self.shape = shape
+
+    def __init__(self, E, S, A, seed, fixed=False, img=4 * 64 * 64):
+        self.env_nums, self.S, self.A, self.img, self.seed, self.fixed = E, S, A, img, seed, fixed
+        self.rs = np.random.RandomState(seed)
+        self.W = 0.1 * np.linalg.qr(np.random.RandomState(4).randn(A, A))[0]
+        self.c = 0.4 * np.where(np.arange(A) % 2 == 0, 1.0, -1.0)
+        self.pool = np.clip(np.random.RandomState(5).randn(16, img), -2.5, 2.8)
+        self.action_space, self.observation_space = self._Space((A,)), self._Space((S,))
+        self.image_channels, self._reward_scale, self.training = 4, 1, True
+        self.t = 0
+
+    def _rows(self, n):
+        return np.concatenate([np.clip(self.rs.randn(n, self.S), -10, 10), self.pool[self.rs.randint(0, 16, n)]], axis=1)
+
+    def train(self):
+        self.training = True
+
+    def eval(self):
+        self.training = False
+
+    def reset(self):
+        if self.fixed:
+            self.rs = np.random.RandomState(self.seed)
+        self.t = 0
+        self.ob = self._rows(self.env_nums)
+        return self.ob.copy()
+
+    def step(self, acts):
+        acts = np.asarray(acts, dtype=np.float64).reshape(self.env_nums, self.A)
+        target = self.c + self.ob[:, :self.A] @ self.W
+        rewards = -((acts - target) ** 2).sum(axis=1, keepdims=True)
+        self.t += 1
+        dones = np.full((self.env_nums, 1), self.t % HORIZON == 0)
+        self.ob = self._rows(self.env_nums)
+        return self.ob.copy(), rewards, dones, {}
+
+    def partial_reset(self, mask):
+        return self.ob.copy()
+
+    def close(self):
+        pass
+
+
+def _evaluate(env, act_fn):
+    """collector/base.py:237-288 with eval_episodes = 1: mean over the E envs of the episode return under the policy mean."""
+    ob = env.reset()
+    done, rews = np.zeros((env.env_nums, 1), dtype=bool), np.zeros((env.env_nums, 1))
+    while not done.all():
+        ob, r, d, _ = env.step(act_fn(ob))
+        rews += (1 - done) * r
+        done |= d
+    return float(rews.mean())
+
+
+def oracle_run(noise_seed, epochs=EPOCHS, threads=None):
+    """The fp32 CPU oracle through the reference's epoch protocol. -> (eval returns per epoch, #updates, final lr)"""
+    import vision4leg_amd.torchrl.networks as networks
+    import vision4leg_amd.torchrl.policies as policies
+    torch.set_num_threads(threads or min(16, os.cpu_count() or 1))
+    case, S, A = CASE, CASE["S"], CASE["A"]
+    torch.manual_seed(case["seed"])
+    pf, vf = util.build_nets(networks, policies, case)
+    opf = {k: v.detach().clone() for k, v in pf.state_dict().items()}
+    ovf = util.share_encoder(opf, {k: v.detach().clone() for k, v in vf.state_dict().items()}, case["kind"])
+    oracle = orc.PPOOracle(case["kind"], opf, ovf, {k: v.clone() for k, v in opf.items()}, S, "f32", entropy_coeff=0.005)
+    fwd = orc.FORWARDS[case["kind"]]
+    env, eval_env = LearnableVecEnv(E, S, A, seed=11), LearnableVecEnv(E, S, A, seed=12, fixed=True)
+    gen = torch.Generator().manual_seed(noise_seed)
+    t32 = lambda a: torch.tensor(np.asarray(a), dtype=torch.float32)
+
+    def mean_of(ob):
+        with torch.no_grad():
+            return fwd({k: v for k, v in oracle.pf.items() if k != "logstd"}, t32(ob), S)
+    ob = env.reset()
+    hist, lr = [], LR
+    np.random.seed(21)
+    for epoch in range(epochs):
+        obs_l, act_l, val_l, rew_l, term_l = [], [], [], [], []
+        for _ in range(T):                                                     # collector/on_policy.py:90-155
+            mean = mean_of(ob)
+            _, std, _ = orc.gaussian(mean, oracle.pf["logstd"])
+            act = (mean + std * torch.randn(mean.shape, generator=gen)).numpy()
+            with torch.no_grad():
+                val = fwd(oracle.vf, t32(ob), S).numpy()
+            nxt, rew, done, _ = env.step(act)
+            obs_l.append(ob); act_l.append(act); val_l.append(val); rew_l.append(rew); term_l.append(done.astype(np.float64))
+            ob = env.partial_reset(done[:, 0]) if done.any() else nxt
+        with torch.no_grad():                                                  # on_rl_algo.py:23-34
+            last_value = fwd(oracle.vf, t32(ob), S).numpy() * (1 - term_l[-1])
+        advs, rets = orc.gae(np.array(rew_l), np.array(val_l).astype(np.float64), np.array(term_l), np.zeros((T, 1)),
+                             last_value.astype(np.float64), GAMMA, TAU, True)
+        lr = LR * (1 - epoch / float(epochs))                                  # algo/utils.py:28-32
+        oracle.sync_target()                                                   # ppo.py:34
+        obs_a, act_a, val_a = np.array(obs_l), np.array(act_l), np.array(val_l)
+        rows = B // E
+        for _ in range(OPT_EPOCHS):                                            # ppo.py:36-40, replay_buffers/on_policy.py:73-92
+            order = np.random.permutation(T)
+            for pos in range(0, T, rows):
+                sel = order[pos:pos + rows]
+                flat = lambda a: t32(a[sel].reshape((len(sel) * E,) + a.shape[2:]))
+                oracle.update(flat(obs_a), flat(act_a), flat(advs), flat(rets), flat(val_a), lr, lr)
+        hist.append(_evaluate(eval_env, lambda o: mean_of(o).numpy()))
+    return hist, oracle.step, lr
+
+
+class _Log:
+    def __init__(self):
+        self.updates, self.epochs = [], []
+
+    def add_update_info(self, info):
+        self.updates.append(dict(info))
+
+    def add_epoch_info(self, epoch, frames, dt, infos):
+        self.epochs.append((epoch, frames, dict(infos)))
+
+
+def hip_run(mode, device, noise_seed, tmp_path, epochs=EPOCHS):
+    os.environ["V4L_COMPUTE"] = mode
+    import vision4leg_amd.torchrl.networks as networks
+    import vision4leg_amd.torchrl.policies as policies
+    from vision4leg_amd.torchrl.algo import PPO
+    from vision4leg_amd.torchrl.collector import VecOnPolicyCollector
+    from vision4leg_amd.torchrl.replay_buffers import DeviceOnPolicyReplayBuffer
+    case, S, A = CASE, CASE["S"], CASE["A"]
+    torch.manual_seed(case["seed"])
+    pf, vf = util.build_nets(networks, policies, case)
+    env, eval_env = LearnableVecEnv(E, S, A, seed=11), LearnableVecEnv(E, S, A, seed=12, fixed=True)
+    buf = DeviceOnPolicyReplayBuffer(max_replay_buffer_size=E * T, env_nums=E, time_limit_filter=True)
+    coll = VecOnPolicyCollector(vf, env=env, eval_env=eval_env, pf=pf, replay_buffer=buf, device=device, epoch_frames=E * T,
+                                max_episode_frames=10 ** 9)
+    assert coll.fast_path
+    log, hist = _Log(), []
+    inner = coll.eval_one_epoch
+
+    def recording_eval():
+        r = inner()
+        hist.append(float(np.mean(r["eval_rewards"])))
+        return r
+    coll.eval_one_epoch = recording_eval
+    agent = PPO(pf=pf, vf=vf, plr=LR, vlr=LR, clip_para=0.2, opt_epochs=OPT_EPOCHS, tau=TAU, shuffle=True, entropy_coeff=0.005,
+                env=None, replay_buffer=buf, collector=coll, logger=log, device=device, discount=GAMMA, num_epochs=epochs,
+                batch_size=B, save_interval=10 ** 6, eval_interval=1, save_dir=str(tmp_path / ("soak_" + mode + str(noise_seed))))
+    np.random.seed(21)
+    torch.manual_seed(noise_seed)
+    torch.cuda.manual_seed(noise_seed)
+    agent.train()
+    return hist, agent, log
+
+
+def _gain(hist):
+    return float(np.mean(hist[-5:]) - np.mean(hist[:3]))
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(900)
+def test_bf16_training_learns_like_fp32(device, tmp_path):
+    t0 = time.time()
+    runs = {}
+    for tag, mode, seed in (("f32_a", "f32", 1), ("f32_b", "f32", 2), ("bf16", "bf16", 1)):
+        hist, agent, log = hip_run(mode, device, seed, tmp_path)
+        n_upd = EPOCHS * OPT_EPOCHS * (E * T // B)
+        # bookkeeping: update counters, Adam steps, LR schedule (algo/utils.py:28-32), 18 finite infos per update
+        assert agent.training_update_num == n_upd and agent.trainer.step == n_upd and len(log.updates) == n_upd
+        assert agent.pf_optimizer.param_groups[0]["lr"] == pytest.approx(LR * (1 - (EPOCHS - 1) / float(EPOCHS)))
+        assert agent.vf_optimizer.param_groups[0]["lr"] == pytest.approx(LR * (1 - (EPOCHS - 1) / float(EPOCHS)))
+        assert all(sorted(u) == sorted(util.STAT_KEYS) and np.isfinite(list(u.values())).all() for u in log.updates)
+        assert len(hist) == EPOCHS and [e[0] for e in log.epochs] == list(range(EPOCHS))
+        runs[tag] = hist
+    t_hip = time.time() - t0
+    ohist, osteps, olr = oracle_run(noise_seed=1)
+    assert osteps == EPOCHS * OPT_EPOCHS * (E * T // B) and olr == pytest.approx(LR * (1 - (EPOCHS - 1) / float(EPOCHS)))
+    runs["oracle_f32"] = ohist
+    gains = {k: _gain(v) for k, v in runs.items()}
+    band = abs(gains["f32_a"] - gains["f32_b"])          # run-to-run: same arithmetic, another exploration stream
+    ref = gains["oracle_f32"]
+    print("\n[soak] eval return, first 3 -> last 5 epochs: " +
+          " | ".join("%s %.3f -> %.3f (gain %.3f)" % (k, np.mean(v[:3]), np.mean(v[-5:]), gains[k]) for k, v in runs.items()))
+    print("[soak] run-to-run band of the gain (two fp32 product runs): %.3f; HIP runs %.1f s, oracle %.1f s"
+          % (band, t_hip, time.time() - t0 - t_hip))
+    for k, g in gains.items():
+        util.record("soak/gain/" + k, g)
+        util.record("soak/final_eval_return/" + k, float(np.mean(runs[k][-5:])))
+    util.record("soak/run_to_run_band", band)
+    # every run learns: the evaluation return rises by at least half of what the fp32 reference arithmetic achieves ...
+    assert ref > 0.3, ref
+    for k, g in gains.items():
+        assert g >= 0.5 * ref, (k, gains)
+    # ... and by the same amount: within 3 x the measured run-to-run band (+ 15 % of the gain) of the oracle's and of each other
+    tol = 3.0 * band + 0.15 * abs(ref)
+    assert abs(gains["bf16"] - ref) <= tol and abs(gains["f32_a"] - ref) <= tol, (gains, band)
+    assert abs(gains["bf16"] - gains["f32_a"]) <= tol, (gains, band)
