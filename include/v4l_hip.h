@@ -159,6 +159,15 @@ int v4l_gae(const double* rewards_dev, const double* values_dev, const double* t
             double tau, int use_time_limit, double* scratch_dev /* 3*T*E doubles */, double* advs_dev, double* rets_dev,
             float* advs32_dev, float* rets32_dev, void* stream);
 
+/* OnPolicyReplayBufferBase.discount_reward (torchrl/replay_buffers/on_policy.py:47-71; PPO(gae=False),
+ * algo/on_policy/on_rl_algo.py:29-33), fp64, bit-identical to the numpy loop: R_t = r_t + (1 - term_t) gamma R_{t+1} from
+ * R_T = last_value (time-limit filter: R_t = (r_t + (1 - term_t) gamma R_{t+1} (1 - tl_t)) + tl_t V_t); advs = R - V,
+ * estimate_returns = R. Array shapes as v4l_gae. */
+int v4l_discount_reward(const double* rewards_dev, const double* values_dev, const double* terminals_dev,
+                        const double* time_limits_dev, int tl_per_env, const double* last_value_dev, int T, int E, double gamma,
+                        int use_time_limit, double* advs_dev, double* rets_dev, float* advs32_dev, float* rets32_dev,
+                        void* stream);
+
 /* Running observation normaliser of the vectorised env on the device: what
  * NormObsWithImg.observation (vision4leg/get_env.py:58-67) / NormObs.observation (torchrl/env/base_wrapper.py:119-122)
  * do on the host per env step. raw_dev: the step's [E][S] fp64 proprio rows (row stride ld_raw). update != 0 (the
@@ -185,8 +194,13 @@ int v4l_actor_create(v4l_net* pf, v4l_net* vf, int E, v4l_actor** out);
 void v4l_actor_destroy(v4l_actor* a);
 int64_t v4l_actor_ws_floats(const v4l_actor* a);
 int64_t v4l_actor_ctl_bytes(const v4l_actor* a);
-/* ctl_dev: v4l_actor_ctl_bytes() bytes, ZEROED by the caller before the first bind (step cursor, hand-over counters). */
+/* ctl_dev: v4l_actor_ctl_bytes() bytes; bind zeroes its control block on `stream` (step cursor, hand-over counters, error
+ * flag) — issue the first step on the same stream or after synchronising it. */
 int v4l_actor_bind(v4l_actor* a, float* ws_dev, void* ctl_dev, void* stream);
+/* *err_out = 0, or 1 + the hand-over counter a block of the NatureCNN rollout step gave up waiting for since the last check
+ * (the step then filed NaN actions — collector/on_policy.py:102-107 "NaN detected" — instead of numbers computed from stale
+ * activations). Synchronises the stream, clears the flag. */
+int v4l_actor_check(v4l_actor* a, int* err_out, void* stream);
 int v4l_actor_seek(v4l_actor* a, int64_t t, void* stream);
 int v4l_actor_step(v4l_actor* a, const float* obs_dev, const float* eps_dev, float* state_roll_dev, void* image_roll_dev,
                    float* acts_roll_dev, float* values_roll_dev, float* logp_roll_dev, float* action_dev, float* mean_dev,

@@ -15,7 +15,8 @@ def build():
 
 
 def gae_c(rewards, values, terminals, time_limits, last_value, gamma, tau, use_tl):
-    """float64 arrays [T,E] (time_limits [T] or [T,E] or None) -> (advs, rets) [T,E]."""
+    """float64 arrays [T,E] (time_limits [T] or [T,E] or None) -> (advs, rets) [T,E]. tau=None: discount_ref
+    (PPO(gae=False), replay_buffers/on_policy.py:47-71)."""
     if not os.path.exists(_SO):
         build()
     lib = C.CDLL(_SO)
@@ -29,5 +30,10 @@ def gae_c(rewards, values, terminals, time_limits, last_value, gamma, tau, use_t
     lv = np.ascontiguousarray(last_value, dtype=np.float64).reshape(E)
     advs, rets = np.empty((T, E)), np.empty((T, E))
     p = lambda a: a.ctypes.data_as(dp)
+    if tau is None:
+        lib.discount_ref.argtypes = [dp, dp, dp, dp, C.c_int, dp, C.c_int, C.c_int, C.c_double, C.c_int, dp, dp]
+        lib.discount_ref.restype = None
+        lib.discount_ref(p(r), p(v), p(t), p(tl), per_env, p(lv), T, E, float(gamma), int(bool(use_tl)), p(advs), p(rets))
+        return advs, rets
     lib.gae_ref(p(r), p(v), p(t), p(tl), per_env, p(lv), T, E, float(gamma), float(tau), int(bool(use_tl)), p(advs), p(rets))
     return advs, rets

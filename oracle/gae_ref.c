@@ -28,3 +28,30 @@ void gae_ref(const double* rewards, const double* values, const double* terminal
     }
   }
 }
+
+/* discount_reward, torchrl/replay_buffers/on_policy.py:47-71 (PPO(gae=False)): same conventions as gae_ref.
+ *   filter:  R = (r[t] + (1 - term[t]) * gamma * R * (1 - tl[t])) + tl[t] * V[t]      (python precedence: left to right)
+ *   else:    R = r[t] + (1 - term[t]) * gamma * R
+ *   advs[t] = R - V[t], rets[t] = R */
+void discount_ref(const double* rewards, const double* values, const double* terminals, const double* time_limits,
+                  int tl_per_env, const double* last_value, int T, int E, double gamma, int use_time_limit,
+                  double* advs, double* rets) {
+  for (int e = 0; e < E; ++e) {
+    double R = last_value[e];
+    for (int t = T - 1; t >= 0; --t) {
+      const size_t o = (size_t)t * E + e;
+      double x = (1.0 - terminals[o]) * gamma;
+      x = x * R;
+      if (use_time_limit) {
+        const double tl = time_limits[tl_per_env ? o : (size_t)t];
+        x = x * (1.0 - tl);
+        x = rewards[o] + x;
+        R = x + tl * values[o];
+      } else {
+        R = rewards[o] + x;
+      }
+      advs[o] = R - values[o];
+      rets[o] = R;
+    }
+  }
+}

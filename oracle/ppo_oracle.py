@@ -259,6 +259,24 @@ def gae(rewards, values, terminals, time_limits, last_value, gamma, tau, time_li
     return np.array(advs), np.array(rets)
 
 
+def discount_reward(rewards, values, terminals, time_limits, last_value, gamma, time_limit_filter):
+    """discount_reward (torchrl/replay_buffers/on_policy.py:47-71; PPO(gae=False)): float64 numpy, the reference's
+    expression order. Shapes as gae()."""
+    rewards, values, terminals = (np.asarray(a, dtype=np.float64) for a in (rewards, values, terminals))
+    T = len(rewards)
+    R = np.asarray(last_value, dtype=np.float64)
+    advs, rets = [None] * T, [None] * T
+    for t in reversed(range(T)):
+        if time_limit_filter:
+            tl = np.asarray(time_limits[t], dtype=np.float64)
+            R = (rewards[t] + (1 - terminals[t]) * gamma * R * (1 - tl)) + tl * values[t]
+        else:
+            R = rewards[t] + (1 - terminals[t]) * gamma * R
+        advs[t] = R - values[t]
+        rets[t] = R
+    return np.array(advs), np.array(rets)
+
+
 # ------------------------------------------------------------------------------------------ optimiser pieces
 def clip_grad_norm(grads, max_norm):
     """torch.nn.utils.clip_grad_norm_ (ppo.py:73-74,118-119): L2 over all grads, scale by

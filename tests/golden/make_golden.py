@@ -177,6 +177,18 @@ def main():
         gout[name + "/advs"] = advs
         gout[name + "/rets"] = rets
         print("== gae", name, "bit-exact (numpy oracle, C oracle)")
+        # PPO(gae=False): discount_reward on the same rollout (replay_buffers/on_policy.py:47-71)
+        buf.discount_reward(ro["last_value"], g["gamma"])
+        dadvs, drets = buf._advs, buf._estimate_returns
+        oa, orr = orc.discount_reward(ro["rewards"], ro["values"], ro["terminals"], ro["time_limits"], ro["last_value"],
+                                      g["gamma"], g["tl_filter"])
+        assert np.array_equal(oa, dadvs) and np.array_equal(orr, drets), name
+        ca, cr = gae_c(ro["rewards"].reshape(T, E), ro["values"].reshape(T, E), ro["terminals"].reshape(T, E),
+                       tl.reshape(T) if tl.shape[1] == 1 and E > 1 else tl, ro["last_value"], g["gamma"], None, g["tl_filter"])
+        assert np.array_equal(ca, dadvs.reshape(T, E)) and np.array_equal(cr, drets.reshape(T, E)), name
+        gout[name + "/dr_advs"] = dadvs
+        gout[name + "/dr_rets"] = drets
+        print("== discount_reward", name, "bit-exact (numpy oracle, C oracle)")
     np.savez_compressed(os.path.join(HERE, "gae.npz"), **gout)
     print("golden fixtures written to", HERE)
 

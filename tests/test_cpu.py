@@ -81,6 +81,23 @@ def test_gae_oracles_match_reference_golden(name):
     assert np.array_equal(ca, oa.reshape(T, E)) and np.array_equal(cr, orr.reshape(T, E))
 
 
+@pytest.mark.parametrize("name", list(util.GAE_CASES))
+def test_discount_reward_oracles_match_reference_golden(name):
+    """PPO(gae=False): the numpy and C restatements of discount_reward (reference replay_buffers/on_policy.py:47-71) against
+    what the reference's own buffer produced (tests/golden/make_golden.py), bit for bit."""
+    g = util.GAE_CASES[name]
+    ro = util.make_gae_inputs(g)
+    gold = util.load_golden("gae")
+    oa, orr = orc.discount_reward(ro["rewards"], ro["values"], ro["terminals"], ro["time_limits"], ro["last_value"],
+                                  g["gamma"], g["tl_filter"])
+    assert np.array_equal(oa, gold[name + "/dr_advs"]) and np.array_equal(orr, gold[name + "/dr_rets"])
+    T, E = g["T"], g["E"]
+    tl = ro["time_limits"].reshape(T, -1)
+    ca, cr = gae_c(ro["rewards"].reshape(T, E), ro["values"].reshape(T, E), ro["terminals"].reshape(T, E),
+                   tl.reshape(T) if tl.shape[1] == 1 and E > 1 else tl, ro["last_value"], g["gamma"], None, g["tl_filter"])
+    assert np.array_equal(ca, oa.reshape(T, E)) and np.array_equal(cr, orr.reshape(T, E))
+
+
 @pytest.mark.parametrize("name", list(util.OBSNORM_CASES))
 def test_obsnorm_oracle_matches_reference_golden(name):
     """oracle/obsnorm_ref.c reproduces the reference Normalizer / NormObs outputs (tests/golden/obsnorm.npz, minted by

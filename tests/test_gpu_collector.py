@@ -125,3 +125,102 @@ def test_fast_collector_eval_and_uploads(device):
     assert len(ev["eval_rewards"]) == 2 * E and ev["eval_traj_length"] >= 1 and not eval_env.training
     coll.terminate()
     assert env.closed and eval_env.closed
+
+
+@pytest.mark.parametrize("name", ["cnn_s93", "cnn_vis"])
+def test_lost_handover_is_never_silent(name, device):
+    """The NatureCNN nets' rollout step hands activations between the blocks of ONE launch through monotonic device-side
+    counters with bounded spins (csrc/rollout_dense.h). Force the time-out path — rewind the counters behind the kernel's
+    back, so that no wait of the next step can be satisfied — and require that (a) the GPU does not hang, (b) the step's
+    actions are NaN (the collector's "NaN detected" check, collector/on_policy.py:102-107, then stops the epoch) instead of
+    numbers computed from stale activations, (c) RolloutActor.check() reports it and clears the flag, (d) after the counters
+    are put back the actor steps normally again."""
+    os.environ["V4L_COMPUTE"] = "bf16"
+    import vision4leg_amd.torchrl.networks as networks
+    import vision4leg_amd.torchrl.policies as policies
+    case = util.CASES[name]
+    E = 16
+    torch.manual_seed(case["seed"])
+    pf, vf = util.build_nets(networks, policies, case)
+    pf, vf = pf.to(device), vf.to(device)
+    actor = policies.RolloutActor(pf, vf, E)
+    rs = np.random.RandomState(1)
+    obs = torch.tensor(util.obs_rows(rs, E, case), dtype=torch.float32, device=device)
+    good = actor.step(obs, deterministic=True)["action"].clone()
+    actor.step(obs, deterministic=True)
+    torch.cuda.synchronize()
+    assert torch.isfinite(good).all()
+    actor.check()  # healthy: no exception
+    ctl = actor._actor.ctl  # ActCtl { i64 t; u64 done; u32 seq, err; u32 stage[6] } (csrc/elem.h)
+    words = ctl[:48].view(torch.int32)
+    saved = words[6:12].clone()
+    assert int(saved.max()) >= 32, saved  # 16 tiles x 2 launches went through the counters: the hand-over path is in use
+    words[6:12] = 0
+    t0 = __import__("time").time()
+    bad = actor.step(obs, deterministic=True)["action"].clone()
+    torch.cuda.synchronize()
+    assert __import__("time").time() - t0 < 60.0
+    assert torch.isnan(bad).all(), bad
+    with pytest.raises(RuntimeError, match="hand-over"):
+        actor.check()
+    actor.check()  # cleared
+    # the collector's own check on such an action (collector/on_policy.py take_actions)
+    assert not np.isfinite(bad.cpu().numpy()).all()
+    # put the counters where three launches leave them: the next step is healthy again and equals the first one
+    words[6:12] = saved // 2 * 3
+    again = actor.step(obs, deterministic=True)["action"].clone()
+    torch.cuda.synchronize()
+    actor.check()
+    assert torch.equal(again, good)
+
+
+@pytest.mark.parametrize("name", ["loco_s84", "cnn_s93", "mlp_s93"])
+def test_step_host_equals_step(name, device):
+    """HipActor.step_host — the fast collector's per-step call: the rollout kernels read the pinned host observation rows in
+    place and write the action into pinned host memory — must give bit for bit what step() gives on the same rows in HBM:
+    the action and the filed action / value / log pi_old, with per-step draws, with draw_noise() slices, and after attach()
+    swapped the rollout arrays."""
+    os.environ["V4L_COMPUTE"] = "bf16"
+    import vision4leg_amd.torchrl.networks as networks
+    import vision4leg_amd.torchrl.policies as policies
+    case = util.CASES[name]
+    E, T, A = 4, 6, case["A"]
+    torch.manual_seed(case["seed"])
+    pf, vf = util.build_nets(networks, policies, case)
+    pf, vf = pf.to(device), vf.to(device)
+    rs = np.random.RandomState(3)
+    rows = [util.obs_rows(rs, E, case).astype(np.float32) for _ in range(T)]
+
+    def rollout_arrays():
+        st, im = pf.hip.alloc_rollout(T * E, device)
+        return st, im, torch.zeros(T * E, A, device=device), torch.zeros(T * E, device=device), torch.zeros(T * E, device=device)
+
+    def run(host, arrays):
+        actor = policies.RolloutActor(pf, vf, E)
+        first = rollout_arrays()
+        actor.attach(first)
+        actor.seek(0)
+        pinned = torch.zeros(E, util.obs_dim(case), dtype=torch.float32).pin_memory()
+        acts = []
+        for t in range(T):
+            if t == 2:             # swap the rollout arrays mid-way: attach() rebuilds the argument tuples
+                actor.attach(arrays)
+                actor.seek(t)
+            if t == 4:
+                torch.manual_seed(77)
+                actor.draw_noise(T - 4)  # the remaining steps consume slices of one bulk draw
+            elif t < 4:
+                torch.manual_seed(500 + t)
+            if host:
+                pinned.copy_(torch.from_numpy(rows[t]))
+                acts.append(np.array(actor.step_host(pinned), copy=True))
+            else:
+                acts.append(actor.step(torch.from_numpy(rows[t]).to(device))["action"].cpu().numpy().copy())
+        torch.cuda.synchronize()
+        return np.stack(acts), [a.cpu().clone() if a is not None else None for a in arrays], [a.cpu().clone() if a is not None else None for a in first]
+    a_dev, filed_dev, first_dev = run(False, rollout_arrays())
+    a_host, filed_host, first_host = run(True, rollout_arrays())
+    assert np.array_equal(a_dev, a_host)
+    for x, y in list(zip(filed_dev, filed_host)) + list(zip(first_dev, first_host)):
+        assert (x is None and y is None) or torch.equal(x, y)
+    assert np.isfinite(a_host).all() and np.abs(a_host[2:]).max() > 0 and filed_host[4][2 * E:].abs().max() > 0

@@ -403,6 +403,38 @@ def test_gae_bit_exact(name, device):
     assert np.array_equal(buf._rets32_dev.cpu().numpy(), orr.astype(np.float32).reshape(-1))
 
 
+@pytest.mark.parametrize("name", list(util.GAE_CASES))
+def test_discount_reward_bit_exact(name, device):
+    """PPO(gae=False): OnPolicyReplayBuffer.discount_reward (reference replay_buffers/on_policy.py:47-71) on the fp64 HIP
+    kernel == the reference's own output (golden), the numpy and the C restatement, bit for bit, fp64 and the fp32 casts."""
+    from oracle.gae_c import gae_c
+    from vision4leg_amd.torchrl.replay_buffers import OnPolicyReplayBuffer
+    g = util.GAE_CASES[name]
+    ro = util.make_gae_inputs(g)
+    gold = util.load_golden("gae")
+    buf = OnPolicyReplayBuffer(max_replay_buffer_size=g["T"] * g["E"], env_nums=g["E"], time_limit_filter=g["tl_filter"])
+    buf.gae_device = device
+    for t in range(g["T"]):
+        buf.add_sample({"rewards": ro["rewards"][t], "values": ro["values"][t], "terminals": ro["terminals"][t],
+                        "time_limits": ro["time_limits"][t]})
+    buf.discount_reward(ro["last_value"], g["gamma"])
+    assert buf._advs.dtype == np.float64 and buf._advs.shape == gold[name + "/dr_advs"].shape
+    assert np.array_equal(buf._advs, gold[name + "/dr_advs"]) and np.array_equal(buf._estimate_returns, gold[name + "/dr_rets"])
+    oa, orr = orc.discount_reward(ro["rewards"], ro["values"], ro["terminals"], ro["time_limits"], ro["last_value"], g["gamma"],
+                                  g["tl_filter"])
+    assert np.array_equal(buf._advs, oa) and np.array_equal(buf._estimate_returns, orr)
+    T, E = g["T"], g["E"]
+    tl = ro["time_limits"].reshape(T, -1)
+    ca, cr = gae_c(ro["rewards"].reshape(T, E), ro["values"].reshape(T, E), ro["terminals"].reshape(T, E),
+                   tl.reshape(T) if tl.shape[1] == 1 and E > 1 else tl, ro["last_value"], g["gamma"], None, g["tl_filter"])
+    assert np.array_equal(buf._advs.reshape(T, E), ca) and np.array_equal(buf._estimate_returns.reshape(T, E), cr)
+    assert np.array_equal(buf._advs32_dev.cpu().numpy(), oa.astype(np.float32).reshape(-1))
+    assert np.array_equal(buf._rets32_dev.cpu().numpy(), orr.astype(np.float32).reshape(-1))
+    # it is not GAE: with tau = 1 and no time-limit filter the two coincide, otherwise they differ
+    buf.generalized_advantage_estimation(ro["last_value"], g["gamma"], g["tau"])
+    assert not np.array_equal(buf._advs, oa)
+
+
 def test_gae_full_size_properties(device):
     """BASELINE config sizes (T=512,E=32): bit-exact vs the C oracle + linearity in the rewards (size-independent)."""
     from oracle.gae_c import gae_c

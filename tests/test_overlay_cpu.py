@@ -15,7 +15,7 @@ REF = "/root/reference"
 pytestmark = pytest.mark.skipif(not os.path.isdir(os.path.join(REF, "torchrl")), reason="reference tree not present")
 
 STARTERS = ["ppo_locotransformer.py", "ppo_nature_cnn.py", "ppo_state.py", "ppo_locotransformer_vision_only.py",
-            "ppo_nature_cnn_vision_only.py"]
+            "ppo_nature_cnn_vision_only.py", "ppo_nature_cnn_sim2sim.py"]
 
 
 def _run(code):

@@ -23,6 +23,8 @@ STAT_KEYS = [
 CASES = {
     "loco_s93": dict(kind="loco", S=93, A=6, seed=0, B=64, enc=[256, 256], head=[256, 256], layers=2, ff=256),
     "loco_s84": dict(kind="loco", S=84, A=6, seed=1, B=32, enc=[256, 256], head=[256, 256], layers=2, ff=256),
+    # S = 90: the third proprio width the reference's env configurations produce (S in {84, 90, 93})
+    "loco_s90": dict(kind="loco", S=90, A=6, seed=11, B=32, enc=[256, 256], head=[256, 256], layers=2, ff=256),
     "cnn_s93": dict(kind="cnn", S=93, A=6, seed=2, B=64, enc=[256, 256], head=[256, 256], visual_dim=256),
     "mlp_s93": dict(kind="mlp", S=93, A=6, seed=3, B=128, enc=[256, 256], head=[256, 256]),
     # a NON-shipped geometry (one layer, ff = 128, 128-wide MLPs, odd batch): runs on the general layer-by-layer kernels

@@ -95,6 +95,7 @@ _SIGS = {
   "v4l_col0": (C.c_int, [_P, C.c_int, _P, _P]),
   "v4l_gae": (C.c_int, [_P, _P, _P, _P, C.c_int, _P, C.c_int, C.c_int, C.c_double, C.c_double, C.c_int,
                         _P, _P, _P, _P, _P, _P]),
+  "v4l_discount_reward": (C.c_int, [_P, _P, _P, _P, C.c_int, _P, C.c_int, C.c_int, C.c_double, C.c_int, _P, _P, _P, _P, _P]),
   "v4l_obs_norm": (C.c_int, [_P, C.c_int64, C.c_int, C.c_int, _P, _P, _P, C.c_double, C.c_int, _P, C.c_int64, _P, C.c_int64,
                              _P, C.c_int, C.c_int64, C.c_int64, _P, C.c_int64, _P]),
   "v4l_actor_create": (C.c_int, [_P, _P, C.c_int, C.POINTER(_P)]),
@@ -103,6 +104,7 @@ _SIGS = {
   "v4l_actor_ctl_bytes": (C.c_int64, [_P]),
   "v4l_actor_bind": (C.c_int, [_P, _P, _P, _P]),
   "v4l_actor_seek": (C.c_int, [_P, C.c_int64, _P]),
+  "v4l_actor_check": (C.c_int, [_P, C.POINTER(C.c_int), _P]),
   "v4l_actor_step": (C.c_int, [_P] + [_P] * 12 + [C.c_int, C.c_int, _P]),
   "v4l_trainer_create": (C.c_int, [_P, _P, _P, C.POINTER(_P)]),
   "v4l_trainer_destroy": (None, [_P]),

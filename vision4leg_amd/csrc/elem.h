@@ -916,6 +916,50 @@ __global__ void gae_scan_kernel(const double* __restrict__ delta, const double* 
   }
 }
 
+// discount_reward (PPO(gae=False)): torchrl/replay_buffers/on_policy.py:47-71 — fp64, the numpy expression order, FMA
+// contraction off: bit-identical to the reference. One lane per env walks t = T-1 .. 0 with 8 steps' loads in flight.
+//   time-limit filter:  R = (r + (((1 - term) * gamma) * R) * (1 - tl)) + tl * V;   else:  R = r + ((1 - term) * gamma) * R
+//   advs = R - V, estimate_returns = R.
+__global__ void discount_scan_kernel(const double* __restrict__ rewards, const double* __restrict__ values,
+                                     const double* __restrict__ terminals, const double* __restrict__ time_limits,
+                                     int tl_stride_e, const double* __restrict__ last_value, int T, int E, double gamma,
+                                     int use_tl, double* __restrict__ advs, double* __restrict__ rets,
+                                     float* __restrict__ advs32, float* __restrict__ rets32) {
+#pragma clang fp contract(off)
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= E) return;
+  double R = last_value[e];
+  for (int t0 = T - 1; t0 >= 0; t0 -= 8) {
+    double r[8], c[8], m[8], v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int t = t0 - j < 0 ? 0 : t0 - j;
+      const int64_t o = (int64_t)t * E + e;
+      r[j] = rewards[o]; v[j] = values[o];
+      c[j] = (1.0 - terminals[o]) * gamma;
+      m[j] = use_tl ? time_limits[tl_stride_e ? o : t] : 0.0;
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int t = t0 - j;
+      if (t < 0) break;
+      const int64_t o = (int64_t)t * E + e;
+      double x = c[j] * R;
+      if (use_tl) {
+        x = x * (1.0 - m[j]);
+        x = r[j] + x;
+        R = x + m[j] * v[j];
+      } else {
+        R = r[j] + x;
+      }
+      const double a = R - v[j];
+      advs[o] = a;
+      rets[o] = R;
+      if (advs32 != nullptr) { advs32[o] = (float)a; rets32[o] = (float)R; }
+    }
+  }
+}
+
 // Running observation normaliser of the vectorised env: NormObsWithImg.observation (vision4leg/get_env.py:58-67) /
 // NormObs.observation (torchrl/env/base_wrapper.py:119-122) on the [E][S] proprio block of one env step —
 // Normalizer.update_estimate (base_wrapper.py:77-84: merge the batch mean / variance over the E envs into the running

@@ -487,6 +487,10 @@ struct InfFinish {
   // ctl->t and advance it through the last-block counter (graph replays, whose arguments are frozen). With the host's index no
   // block has to find out whether it is the last one: that atomic round trip was 2.6 K cycles at the end of every step.
   long long t_plus1;
+  // eager launches of rollout_dense_kernel: the launch sequence number + 1 as the host counts it (v4l_actor::dense_seq mirrors
+  // ctl->seq), so that no block of the launch depends on WHEN it reads ctl->seq relative to the finishing block's bump of it;
+  // 0: read ctl->seq at entry (graph replays: frozen arguments, seq then moves only after BOTH finishing blocks are done)
+  unsigned seq_plus1;
 };
 
 template <int SPW> struct InfRows {

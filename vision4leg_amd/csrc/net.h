@@ -154,6 +154,10 @@ struct v4l_actor {
   const void* key[16] = {};
   bool warm = false, bound = false;
   long long t_host = -1;  // the env step index as the host counts it (v4l_actor_seek sets it, eager steps advance it); -1: unknown
+  // host mirror of ActCtl::seq (launches of rollout_dense_kernel so far; v4l_actor_bind zeroes both): eager launches pass it as
+  // an argument. dense_in_graph: the captured step contains that kernel, so every replay advances the device's count too.
+  unsigned dense_seq = 0;
+  bool dense_in_graph = false;
 };
 
 struct GraphKey { v4l_rollout ro; v4l_ppo_hyper hp; int n; int gen[3]; };

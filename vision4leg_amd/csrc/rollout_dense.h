@@ -332,8 +332,14 @@ __global__ __launch_bounds__(1024) void rollout_mlp2_kernel(const float* __restr
 //           advances the step cursor and the launch sequence number.
 // Counters are monotonic (target = 16 (seq + 1)), released / acquired at agent scope (the blocks sit on different XCDs:
 // tools/probe/flag_hop.hip measured 1.7 - 2.5 us per hand-over). 32 one-wave blocks are always co-resident, producers have
-// the lower block indices, and every spin is bounded (ctl->err is set and the block carries on with whatever it finds: a
-// lost hand-over must never hang the GPU).
+// the lower block indices, and every spin is bounded: a lost hand-over must never hang the GPU. A wait that runs out sets
+// ctl->err (sticky) and the block carries on — but nothing computed from a missed hand-over is ever used silently: the policy's
+// finishing block turns the step's actions into NaN whenever ctl->err is set (the collector's "non-finite action" check,
+// collector/on_policy.py:102-107, then stops the epoch), and v4l_actor_check reports and clears the flag for the host.
+// seq: eager launches get it from the host as an argument (InfFinish::seq_plus1) — a late-dispatched block can therefore not
+// pick up the NEXT launch's target after the finishing block has bumped ctl->seq; graph replays read ctl->seq, which in that
+// mode only moves once BOTH finishing blocks are done — each of them has waited for all 16 tiles of its net, so every block
+// of the launch has passed its entry by then.
 struct RollDense {
   const void* wpr; const float* bpr;                     // fuse net: visual projector (the shared encoder's = the policy's)
   const void *w0[2], *w1[2], *w2[2];                     // PK_FRAG packs per net
@@ -349,7 +355,7 @@ __device__ __forceinline__ void dense_wait(ActCtl* ctl, int idx, unsigned target
     // relaxed polls (an acquire per poll invalidates caches 32 waves x every iteration), ONE acquire fence after the loop
     while ((int)(__hip_atomic_load(&ctl->stage[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target) < 0) {
       __builtin_amdgcn_s_sleep(2);
-      if (++spin > (1ll << 22)) { ctl->err = 1u + (unsigned)idx; break; }
+      if (++spin > (1ll << 22)) { __hip_atomic_store(&ctl->err, 1u + (unsigned)idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
     }
   }
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // the whole wave's later loads see what the producers released
@@ -395,7 +401,8 @@ __global__ __launch_bounds__(64) void rollout_dense_kernel(RollDense a, InfFinis
   const int fr = lane & 15, g = lane >> 4, MT = (E + 15) >> 4;
   ActCtl* ctl = fin.ctl;
   ROLL_STAMP(100);
-  const unsigned target = 16u * (ctl->seq + 1u);
+  const unsigned seq = fin.seq_plus1 > 0 ? fin.seq_plus1 - 1u : ctl->seq;
+  const unsigned target = 16u * (seq + 1u);
   const long long t_step = fin.t_plus1 > 0 ? fin.t_plus1 - 1 : ctl->t;
   auto frags = [&](const void* W, int ks_per_tile, int t, int ks) {
     return reinterpret_cast<const bf16x8*>(W)[((size_t)t * ks_per_tile + ks) * 64 + lane];
@@ -483,10 +490,12 @@ __global__ __launch_bounds__(64) void rollout_dense_kernel(RollDense a, InfFinis
     // GaussianContPolicyBase.explore / the value read-out with act_finish_kernel's expressions; the per-dimension terms are
     // evaluated (row, k) pair per lane, the log-prob is then summed over k = 0 .. A-1 in order by the row's lane
     if (net == 0) {
+      // a hand-over of this or an earlier launch timed out (any block, any net): the step's inputs may be stale -> no action
+      const bool lost = __hip_atomic_load(&ctl->err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u;
       for (int idx = lane; idx < 16 * A; idx += 64) {
         const int r = idx / A, k = idx - r * A, i = mt * 16 + r;
         const float mu = so[r * 16 + k], sg = sg_s[k];
-        const float act = fmaf(sg, eps_s[min(i, E - 1) * A + k], mu);
+        const float act = lost ? __builtin_nanf("") : fmaf(sg, eps_s[min(i, E - 1) * A + k], mu);
         const float d = act - mu;
         lt_s[r * 16 + k] = -(d * d) / (2.f * sg * sg) - logf(sg) - HALF_LOG_2PI;
         if (i < E) {
@@ -515,8 +524,8 @@ __global__ __launch_bounds__(64) void rollout_dense_kernel(RollDense a, InfFinis
     __builtin_amdgcn_wave_barrier();
   }
   ROLL_STAMP(111);
-  if (fin.t_plus1 > 0) {  // (InfFinish::t_plus1) every block of this launch read seq at entry and nobody reads the cursor
-    if (lane == 0 && net == 0) { ctl->t = t_step + 1; ctl->seq = ctl->seq + 1u; }
+  if (fin.t_plus1 > 0 && fin.seq_plus1 > 0) {  // eager: nobody in this launch reads the cursor or the sequence number
+    if (lane == 0 && net == 0) { ctl->t = t_step + 1; ctl->seq = seq + 1u; }
   } else if (lane == 0) {  // the second of the two finishing blocks closes the step
     __threadfence();
     const unsigned long long done = atomicAdd(reinterpret_cast<unsigned long long*>(&ctl->done), 1ull);

@@ -1983,6 +1983,8 @@ static int run_actor_dense_cnn(v4l_actor* a, const float* obs, const float* eps,
     net_of(1, vf, vk, h0v, h1v, ws_vf + Lv.out);
     d.featv = featv; d.cat = cat;
     const double fl = 2.0 * E * ((fuse ? 1024.0 * 256 : 0.0) + 2 * ((fuse ? 512.0 : 1024.0) * 256 + 256 * 256 + 256 * 16));
+    if (capturing(s)) { fin.seq_plus1 = 0; a->dense_in_graph = true; }   // replays read (and advance) the device's count
+    else fin.seq_plus1 = ++a->dense_seq;                                  // eager: this launch's number + 1, from the host
     if (fuse) V4L_KLAUNCH("rollout_dense", fl, s, rollout_dense_kernel<true>, dim3(32), dim3(64), 0, s, d, fin, E);
     else V4L_KLAUNCH("rollout_dense", fl, s, rollout_dense_kernel<false>, dim3(32), dim3(64), 0, s, d, fin, E);
     V4L_LAUNCH_CHECK();
@@ -2476,6 +2478,23 @@ int v4l_gae(const double* rewards_dev, const double* values_dev, const double* t
   return 0;
 }
 
+int v4l_discount_reward(const double* rewards_dev, const double* values_dev, const double* terminals_dev,
+                        const double* time_limits_dev, int tl_per_env, const double* last_value_dev, int T, int E, double gamma,
+                        int use_time_limit, double* advs_dev, double* rets_dev, float* advs32_dev, float* rets32_dev,
+                        void* stream) {
+  V4L_REQUIRE(rewards_dev && values_dev && terminals_dev && last_value_dev && advs_dev && rets_dev && T > 0 && E > 0,
+              "v4l_discount_reward: bad argument");
+  V4L_REQUIRE(!use_time_limit || time_limits_dev != nullptr, "v4l_discount_reward: time_limits_dev is null");
+  V4L_REQUIRE((advs32_dev == nullptr) == (rets32_dev == nullptr), "v4l_discount_reward: advs32/rets32 must both be set or null");
+  hipStream_t s = (hipStream_t)stream;
+  g_op = "gae";
+  V4L_KLAUNCH("discount_scan", 0, s, discount_scan_kernel, dim3(cdiv(E, 64)), dim3(64), 0, s, rewards_dev, values_dev,
+              terminals_dev, time_limits_dev, tl_per_env, last_value_dev, T, E, gamma, use_time_limit, advs_dev, rets_dev,
+              advs32_dev, rets32_dev);
+  V4L_LAUNCH_CHECK();
+  return 0;
+}
+
 int v4l_obs_norm(const double* raw_dev, int64_t ld_raw, int E, int S, double* mean_dev, double* var_dev, double* count_dev,
                  double clip, int update, float* out32_dev, int64_t ld_out32, double* out64_dev, int64_t ld_out64,
                  const void* image_dev, int image_f64, int64_t ld_image, int64_t image_elems, float* image_out_dev,
@@ -2585,7 +2604,24 @@ int v4l_actor_bind(v4l_actor* a, float* ws_dev, void* ctl_dev, void* stream) {
   a->ws = ws_dev;
   a->ctl = (ActCtl*)ctl_dev;
   a->rowidx = (int*)((char*)ctl_dev + 256);
+  // step cursor, launch sequence number, hand-over counters and the error flag start from zero, together with their host mirrors
+  V4L_HIP_CHECK(hipMemsetAsync(ctl_dev, 0, sizeof(ActCtl), (hipStream_t)stream));
+  a->dense_seq = 0; a->dense_in_graph = false; a->t_host = -1;
   a->bound = true;
+  return 0;
+}
+// Health of the rollout step's device-side hand-overs (csrc/rollout_dense.h): *err_out = 0, or 1 + the index of the stage
+// counter a block gave up waiting for since the last check. Synchronises the stream and clears the flag. A step that ran with
+// the flag set has already filed NaN actions (the collector's non-finite-action check stops the epoch); this call is how a host
+// finds out about a lost hand-over on the value side as well — the collector calls it once per epoch.
+int v4l_actor_check(v4l_actor* a, int* err_out, void* stream) {
+  V4L_REQUIRE(a && a->bound && err_out, "v4l_actor_check: bad argument");
+  hipStream_t s = (hipStream_t)stream;
+  unsigned err = 0;
+  V4L_HIP_CHECK(hipMemcpyAsync(&err, &a->ctl->err, sizeof(err), hipMemcpyDeviceToHost, s));
+  V4L_HIP_CHECK(hipStreamSynchronize(s));
+  if (err != 0) V4L_HIP_CHECK(hipMemsetAsync(&a->ctl->err, 0, sizeof(err), s));
+  *err_out = (int)err;
   return 0;
 }
 int v4l_actor_seek(v4l_actor* a, int64_t t, void* stream) {
@@ -2710,6 +2746,7 @@ static int actor_step_impl(v4l_actor* a, const float* obs_dev, const float* eps_
   if (memcmp(key, a->key, sizeof(key)) != 0) {
     if (a->gexec) { (void)hipGraphExecDestroy(a->gexec); a->gexec = nullptr; }
     a->warm = false;
+    a->dense_in_graph = false;
     memcpy(a->key, key, sizeof(key));
   }
   if (!a->warm) { a->warm = true; return run(); }
@@ -2728,6 +2765,7 @@ static int actor_step_impl(v4l_actor* a, const float* obs_dev, const float* eps_
     V4L_TRACE("actor: instantiated");
   }
   V4L_HIP_CHECK(hipGraphLaunch(a->gexec, s));
+  if (a->dense_in_graph) ++a->dense_seq;  // the replayed rollout_dense_kernel advanced ctl->seq
   V4L_TRACE("actor: launched");
   return 0;
 }

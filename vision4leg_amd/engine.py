@@ -478,6 +478,15 @@ class HipActor:
   def seek(self, t):
     check(self.L.v4l_actor_seek(self.h, int(t), _stream()), "v4l_actor_seek")
 
+  def check(self):
+    """v4l_actor_check: raise if a device-side hand-over of the rollout step timed out since the last check (the affected
+    steps filed NaN actions rather than numbers computed from stale activations). One stream synchronise; once per epoch."""
+    err = C.c_int(0)
+    check(self.L.v4l_actor_check(self.h, C.byref(err), _stream()), "v4l_actor_check")
+    if err.value:
+      raise RuntimeError("vision4leg_amd: a block of the rollout step gave up waiting for hand-over counter %d "
+                         "(stale activations; the step's actions were replaced by NaN)" % (err.value - 1))
+
   def draw_noise(self, n_steps):
     """Draw the standard normals of the next n_steps env steps with ONE generator call ([n_steps][E][A], torch's
     generator on the current stream) instead of one 5 us launch per step; the following non-deterministic eager steps
@@ -572,7 +581,8 @@ class HipActor:
 def gae(rewards, values, terminals, time_limits, last_value, gamma, tau, use_time_limit, want32=True, out=None):
   """HIP GAE on float64 cuda tensors [T][E] (time_limits [T] or [T][E]); returns (advs, rets, advs32, rets32).
   out: a dict that keeps the output / scratch tensors between calls, so their addresses stay stable across epochs
-  (the captured update graph is keyed on the rollout pointers)."""
+  (the captured update graph is keyed on the rollout pointers).
+  tau=None: PPO(gae=False) — discounted rewards instead (v4l_discount_reward, replay_buffers/on_policy.py:47-71)."""
   L = _lib.lib()
   T, E = rewards.shape
   dev = rewards.device
@@ -589,7 +599,17 @@ def gae(rewards, values, terminals, time_limits, last_value, gamma, tau, use_tim
       out["key"], out["bufs"] = key, (advs, rets, a32, r32, scratch)
   tl_per_env = int(time_limits is not None and time_limits.dim() == 2 and time_limits.shape[1] == E and E > 1
                    or (time_limits is not None and time_limits.numel() == T * E and E == 1))
+  if tau is None:
+    check(L.v4l_discount_reward(_ptr(rewards), _ptr(values), _ptr(terminals), _ptr(time_limits), tl_per_env, _ptr(last_value),
+                                T, E, float(gamma), int(bool(use_time_limit)), _ptr(advs), _ptr(rets), _ptr(a32), _ptr(r32),
+                                _stream()), "v4l_discount_reward")
+    return advs, rets, a32, r32
   check(L.v4l_gae(_ptr(rewards), _ptr(values), _ptr(terminals), _ptr(time_limits), tl_per_env, _ptr(last_value), T, E,
                   float(gamma), float(tau), int(bool(use_time_limit)), _ptr(scratch), _ptr(advs), _ptr(rets), _ptr(a32),
                   _ptr(r32), _stream()), "v4l_gae")
   return advs, rets, a32, r32
+
+
+def discount_reward(rewards, values, terminals, time_limits, last_value, gamma, use_time_limit, want32=True, out=None):
+  """HIP discount_reward (PPO(gae=False)) on float64 cuda tensors [T][E]; same conventions as gae()."""
+  return gae(rewards, values, terminals, time_limits, last_value, gamma, None, use_time_limit, want32=want32, out=out)

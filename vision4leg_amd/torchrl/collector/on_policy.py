@@ -57,9 +57,15 @@ class VecOnPolicyCollector:
         self._actor = None
         self._cursor = -1
         self._pins = None
-        # threads of the per-step fp64 -> fp32 host cast (torch's intra-op pool; the env workers own the other cores)
-        self.cast_threads = max(1, min(8, (os.cpu_count() or 1) // 2))
+        # threads of the per-step fp64 -> fp32 host cast (torch's intra-op pool; the env workers own the other cores). The
+        # product runs no other torch CPU op on its hot path, so the process-wide setting is made once here and put back by
+        # terminate(); V4L_CAST_THREADS overrides the count (1 = leave torch's setting alone).
+        self.cast_threads = max(1, int(os.environ.get("V4L_CAST_THREADS", min(8, (os.cpu_count() or 1) // 2))))
         self.fast_path = isinstance(replay_buffer, DeviceOnPolicyReplayBuffer)
+        self._torch_threads = None
+        if self.fast_path and self.cast_threads > 1 and torch.get_num_threads() != self.cast_threads:
+            self._torch_threads = torch.get_num_threads()
+            torch.set_num_threads(self.cast_threads)
 
     # ---- reference plumbing (collector/base.py:54-58,113-115,166-174; on_policy.py:77-82) ----------------------------
     def start_episode(self):
@@ -79,6 +85,9 @@ class VecOnPolicyCollector:
     def terminate(self):
         self.env.close()
         self.eval_env.close()
+        if self._torch_threads is not None:
+            torch.set_num_threads(self._torch_threads)
+            self._torch_threads = None
 
     # ---- host -> HBM ----------------------------------------------------------------------------------------------
     def _upload(self, rows, host_only=False):
@@ -94,14 +103,11 @@ class VecOnPolicyCollector:
         self._pin_i ^= 1
         ev.synchronize()  # the copy issued from this staging buffer two uploads ago
         if rows.dtype == np.float64 and rows.flags.c_contiguous and self.cast_threads > 1:
-            # the cast is the longest host stage of a step (E x 16.5 K doubles): a few threads of torch's copy kernel
-            # instead of one numpy pass; round-to-nearest fp64 -> fp32 either way (== torch.Tensor(ob), on_policy.py:91)
-            prev = torch.get_num_threads()
-            if prev != self.cast_threads:
-                torch.set_num_threads(self.cast_threads)
+            # the cast is the longest host stage of a step (E x 16.5 K doubles): torch's copy kernel on `cast_threads` intra-op
+            # threads (40 us against 300 us for one numpy pass; a Python thread pool over numpy copies does not scale: the
+            # casting copy holds the GIL). Round-to-nearest fp64 -> fp32 either way (== torch.Tensor(ob), on_policy.py:91).
+            # The intra-op thread count is set ONCE, in __init__ (restored by terminate()), not toggled per step.
             host.copy_(torch.from_numpy(rows))
-            if prev != self.cast_threads:
-                torch.set_num_threads(prev)
         else:
             np.copyto(host.numpy(), rows, casting="same_kind")
         if host_only:
@@ -176,6 +182,9 @@ class VecOnPolicyCollector:
         self.env.train()
         for _ in range(self.sample_epoch_frames):
             self.train_epoch_reward += self.take_actions()
+        if self.fast_path and self._actor is not None:
+            with torch.cuda.device(self.device):
+                self._actor.check()  # a lost device-side hand-over on the value side must not reach the update silently
         return {"train_rewards": self.train_rews, "train_epoch_reward": self.train_epoch_reward}
 
     def eval_one_epoch(self):

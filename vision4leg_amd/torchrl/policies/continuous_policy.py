@@ -43,6 +43,10 @@ class RolloutActor:
         """One generator call for the exploration noise of the next n_steps steps (see HipActor.draw_noise)."""
         self._actor.draw_noise(n_steps)
 
+    def check(self):
+        """Raise if a device-side hand-over of the rollout step timed out since the last call (see HipActor.check)."""
+        self._actor.check()
+
     def step(self, ob, deterministic=False):
         return self._actor.step(ob, deterministic)
 

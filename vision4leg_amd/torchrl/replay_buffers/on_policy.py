@@ -55,8 +55,9 @@ class OnPolicyReplayBufferBase:
         self._advs32_dev, self._rets32_dev = a32.reshape(-1), r32.reshape(-1)
 
     def discount_reward(self, last_value, gamma):
-        raise NotImplementedError("vision4leg_amd: gae=False (discount_reward) is outside the HIP hot path; "
-                                  "every shipped PPO config sets gae=true")
+        """Discounted rewards as return / advantage estimates (reference on_policy.py:47-71, PPO(gae=False)): the same
+        fp64 HIP path with tau = None (v4l_discount_reward, bit-identical to the reference's numpy loop)."""
+        self.generalized_advantage_estimation(last_value, gamma, None)
 
     def one_iteration(self, batch_size, sample_key, shuffle):
         """Minibatches of batch_size/env_nums *time rows* (all envs of a row stay together), reference
@@ -207,18 +208,26 @@ class DeviceOnPolicyReplayBuffer(OnPolicyReplayBufferBase, BaseReplayBuffer):
             self._estimate_returns = self._rets_dev64.cpu().numpy().reshape(self._max_replay_buffer_size, self.env_nums, 1)
             return self._estimate_returns
         if name in ("_acts", "_values") and self.__dict__.get("_filed"):
-            # one D2H copy per (epoch position, array): the cache is dropped when the next filed step lands
+            # one D2H copy per (epoch position, array): entries of an older position are dropped when the next filed step
+            # lands; both arrays of the CURRENT position stay (alternating _acts / _values reads do not re-copy)
             cache = self.__dict__.setdefault("_host_cache", {})
-            key = (name, self.__dict__.get("_top"), self.__dict__.get("_filed_steps"))
+            pos = (self.__dict__.get("_top"), self.__dict__.get("_filed_steps"))
+            key = (name,) + pos
             if key not in cache:
+                for old in [k for k in cache if k[1:] != pos]:
+                    del cache[old]
                 src = self._acts_dev if name == "_acts" else self._values32_dev
-                cache.clear()
                 cache[key] = src.cpu().numpy().astype(np.float64).reshape(self._max_replay_buffer_size, self.env_nums, -1)
             return cache[key]
         raise AttributeError(name)
 
     def last_sample(self, sample_key):
+        """Valid on a FULL buffer only (its one caller, process_epoch_samples, runs after the epoch's last step): `next_obs`
+        is copied when step T-1 is stored and merely referenced — the env may overwrite it — for earlier steps."""
         last = self._max_replay_buffer_size - 1
+        if "next_obs" in sample_key and self._top != 0:
+            raise RuntimeError("DeviceOnPolicyReplayBuffer.last_sample: the epoch is not complete (%d of %d steps stored)"
+                               % (self._top, self._max_replay_buffer_size))
         out = {}
         for key in sample_key:
             out[key] = self._last_next_obs if key == "next_obs" else getattr(self, "_" + key)[last]
