@@ -353,7 +353,10 @@ def fast_collector(wl, compute, dev):
     return {"value": round(E * T / (t_coll + t_upd), 1), "unit": "env-steps/s",
             "collect_ms_per_epoch": round(1e3 * t_coll, 2), "update_ms_per_epoch": round(1e3 * t_upd, 2),
             "collect_us_per_env_step": round(1e6 * t_coll / T, 1),
-            "h2d_bytes_per_env_step": E * D * 4, "host_cast_threads": coll.cast_threads,
+            "h2d_bytes_per_env_step": (E * (wl["S"] * 4 + (D - wl["S"]) * 2) if coll._split else E * D * 4),
+            "observation_rows_over_pcie": ("proprio fp32 + depth stack bf16 (the type the bf16 kernels round the image to at ingest: "
+                                           "bit-identical results, RolloutActor.step_host_split)" if coll._split else "fp32 rows"),
+            "host_cast_threads": coll.cast_threads,
             "what": "VecOnPolicyCollector(fast path).train_one_epoch over a zero-cost vec env (float64 rows) + "
                     "PPO.update_per_epoch (last-value forward, GAE, %d stored-log-pi graph updates, one stats read-back): "
                     "everything the reference's train loop does except env.step" % (OPT_EPOCHS * (E * T // B))}
@@ -757,7 +760,7 @@ def main():
                 res["value_incl_transfers_ratio"] = round(res["value_incl_transfers"] / value, 3)
                 res["value_incl_transfers_note"] = (
                     "`value` starts with the epoch resident in HBM (the contract); value_incl_transfers is the same epoch "
-                    "driven by VecOnPolicyCollector from float64 host rows: per env step a host cast, %d bytes over PCIe, "
+                    "driven by VecOnPolicyCollector from float64 host rows: per env step a host cast, %d bytes read over PCIe by the kernels, "
                     "2 launches and the action's D2H, serialised by the synchronous vec-env protocol"
                     % res["fast_collector"]["h2d_bytes_per_env_step"])
         if not a.no_cpu_baseline and world == 1:  # the host baseline is an N = 1 measurement (the other ranks would idle)

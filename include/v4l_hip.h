@@ -206,6 +206,17 @@ int v4l_actor_step(v4l_actor* a, const float* obs_dev, const float* eps_dev, flo
                    float* acts_roll_dev, float* values_roll_dev, float* logp_roll_dev, float* action_dev, float* mean_dev,
                    float* std_dev, float* ent_dev, float* value_dev, int shared_encoder, int use_graph, void* stream);
 
+/* The same step with the observation handed over SPLIT: proprio rows [E][S] fp32 (NULL when S = 0) and the depth stacks
+ * [E][C*H*W] already in bf16 — the type the bf16 kernels round the image to at ingest anyway, so the result is bit-identical
+ * to v4l_actor_step on fp32 rows holding the same values, with half the bytes crossing PCIe when the pointers are pinned host
+ * memory (collector/on_policy.py:90-93 uploads one fp32 row per env). Eager launches only. v4l_actor_split_supported: 1 when
+ * this actor's step runs on kernels that take the split form (bf16 compute, image nets on the fused rollout step). */
+int v4l_actor_split_supported(const v4l_actor* a, int shared_encoder);
+int v4l_actor_step_split(v4l_actor* a, const float* proprio_dev, const void* image16_dev, const float* eps_dev,
+                         float* state_roll_dev, void* image_roll_dev, float* acts_roll_dev, float* values_roll_dev,
+                         float* logp_roll_dev, float* action_dev, float* mean_dev, float* std_dev, float* ent_dev,
+                         float* value_dev, int shared_encoder, void* stream);
+
 /* ---- PPO minibatch update: replaces PPO.update / update_critic / update_actor (ppo.py:42-153), the two
  * clip_grad_norm_(…, 0.5) calls and the two Adam steps (a2c.py:30-40). pf and vf may share encoder parameters
  * (same device pointers in both tables): the critic step runs first and the actor forward sees the updated

@@ -169,6 +169,25 @@ def test_unsupported_configs_fail_loudly():
         net(torch.zeros(3, 8))
 
 
+def test_host_bf16_cast_is_the_two_step_rounding():
+    """The fast collector hands the depth stack to the bf16 rollout kernels as bfloat16 rows cast on the host (half the PCIe
+    bytes). That is only bit-identical to the reference protocol (torch.Tensor(ob): float64 -> float32, then the kernels'
+    float32 -> bf16 at ingest) if torch's float64 -> bfloat16 copy rounds THROUGH float32 — it does (c10::BFloat16 is built from
+    float); values where a direct rounding would differ pin it."""
+    tricky = np.array([1 + 2 ** -8 + 2 ** -30, -(1 + 2 ** -8 + 2 ** -40), 3.0 + 3 * 2 ** -8 + 2 ** -33, 1 + 2 ** -8 - 2 ** -30])
+    rs = np.random.RandomState(0)
+    x = np.concatenate([tricky, np.clip(rs.randn(100000), -2.5, 2.8)])
+    one = torch.empty(len(x), dtype=torch.bfloat16)
+    one.copy_(torch.from_numpy(x))
+    two = torch.from_numpy(x).to(torch.float32).to(torch.bfloat16)
+    assert torch.equal(one, two)
+    assert one[0].item() == 1.0  # a direct float64 -> bf16 rounding would give 1.0078125
+    cols = torch.empty(50, 300, dtype=torch.bfloat16)
+    wide = rs.randn(50, 393)
+    cols.copy_(torch.from_numpy(wide)[:, 93:])  # a strided column block, as the collector slices the observation rows
+    assert torch.equal(cols, torch.from_numpy(wide[:, 93:].copy()).float().bfloat16())
+
+
 def test_replay_buffer_iteration_matches_reference_semantics():
     """one_iteration: batch_size/E time rows per minibatch, all envs of a row together, np.random stream."""
     from vision4leg_amd.torchrl.replay_buffers import OnPolicyReplayBuffer

@@ -174,7 +174,7 @@ def test_lost_handover_is_never_silent(name, device):
     assert torch.equal(again, good)
 
 
-@pytest.mark.parametrize("name", ["loco_s84", "cnn_s93", "mlp_s93"])
+@pytest.mark.parametrize("name", ["loco_s84", "cnn_s93", "mlp_s93", "loco_vis"])
 def test_step_host_equals_step(name, device):
     """HipActor.step_host — the fast collector's per-step call: the rollout kernels read the pinned host observation rows in
     place and write the action into pinned host memory — must give bit for bit what step() gives on the same rows in HBM:
@@ -195,6 +195,9 @@ def test_step_host_equals_step(name, device):
         st, im = pf.hip.alloc_rollout(T * E, device)
         return st, im, torch.zeros(T * E, A, device=device), torch.zeros(T * E, device=device), torch.zeros(T * E, device=device)
 
+    split = policies.RolloutActor(pf, vf, E).split_supported()
+    assert split == (name != "mlp_s93")  # image nets in bf16 take the observation split (bf16 depth rows over PCIe)
+
     def run(host, arrays):
         actor = policies.RolloutActor(pf, vf, E)
         first = rollout_arrays()
@@ -211,7 +214,12 @@ def test_step_host_equals_step(name, device):
                 actor.draw_noise(T - 4)  # the remaining steps consume slices of one bulk draw
             elif t < 4:
                 torch.manual_seed(500 + t)
-            if host:
+            if host == "split":
+                S = case["S"]
+                prop = torch.from_numpy(rows[t][:, :S].copy()).pin_memory() if S else None
+                img16 = torch.from_numpy(rows[t][:, S:].copy()).to(torch.bfloat16).pin_memory()
+                acts.append(np.array(actor.step_host_split(prop, img16), copy=True))
+            elif host:
                 pinned.copy_(torch.from_numpy(rows[t]))
                 acts.append(np.array(actor.step_host(pinned), copy=True))
             else:
@@ -224,3 +232,8 @@ def test_step_host_equals_step(name, device):
     for x, y in list(zip(filed_dev, filed_host)) + list(zip(first_dev, first_host)):
         assert (x is None and y is None) or torch.equal(x, y)
     assert np.isfinite(a_host).all() and np.abs(a_host[2:]).max() > 0 and filed_host[4][2 * E:].abs().max() > 0
+    if split:  # ... and the split hand-over (fp32 proprio + bf16 depth rows) gives the same bits again
+        a_split, filed_split, first_split = run("split", rollout_arrays())
+        assert np.array_equal(a_dev, a_split)
+        for x, y in list(zip(filed_dev, filed_split)) + list(zip(first_dev, first_split)):
+            assert (x is None and y is None) or torch.equal(x, y)

@@ -106,6 +106,8 @@ _SIGS = {
   "v4l_actor_seek": (C.c_int, [_P, C.c_int64, _P]),
   "v4l_actor_check": (C.c_int, [_P, C.POINTER(C.c_int), _P]),
   "v4l_actor_step": (C.c_int, [_P] + [_P] * 12 + [C.c_int, C.c_int, _P]),
+  "v4l_actor_split_supported": (C.c_int, [_P, C.c_int]),
+  "v4l_actor_step_split": (C.c_int, [_P] + [_P] * 13 + [C.c_int, _P]),
   "v4l_trainer_create": (C.c_int, [_P, _P, _P, C.POINTER(_P)]),
   "v4l_trainer_destroy": (None, [_P]),
   "v4l_trainer_ws_floats": (C.c_int64, [_P, C.c_int]),

@@ -879,7 +879,7 @@ __global__ __launch_bounds__(256) void infer_layer_kernel(InfLayerStack stk, Inf
       if (tid == 0) {
         __threadfence();
         const unsigned long long done = atomicAdd(reinterpret_cast<unsigned long long*>(&fin.ctl->done), 1ull);
-        if (done == (unsigned long long)(gridDim.x * gridDim.y) - 1) {
+        if (done == 2ull * (unsigned long long)E - 1ull) {  // (one block per (sample, net))
           fin.ctl->done = 0;
           fin.ctl->t = t_step + 1;
         }
@@ -922,7 +922,8 @@ __device__ __forceinline__ void mm_held(f32x4 (&acc)[MT], const AT* sA, int lda,
 // NT: tokens per sample — 17 (LocoTransformer: proprio token + 16 depth tokens, head input [token 0 | mean of the depth
 // tokens]) or 16 (the vision-only Transformer, nets.py:884-889: head input = mean of all 16 tokens, fc0 contracts 64)
 template <typename T, int NL, int NT = NTOK>
-__global__ __launch_bounds__(512) void rollout_stack_kernel(InfLayerStack stk, InfHeadPair hd, InfFinish fin, int E, int warm) {
+__global__ __launch_bounds__(512) void rollout_stack_kernel(InfLayerStack stk, InfHeadPair hd, InfFinish fin, int E, int warm,
+                                                            int xcd) {
   typedef typename Frag<T>::type frag_t;
   typedef InfLayLds<T, 1> LY;
   constexpr int NW = 8, NTH = 512, ROWS = 32;
@@ -938,7 +939,13 @@ __global__ __launch_bounds__(512) void rollout_stack_kernel(InfLayerStack stk, I
   float* prm = reinterpret_cast<float*>(smem + LY::bytes);
   constexpr int P_BIN = 0, P_BO = 192, P_B1 = 256, P_B2 = 512, P_G1 = 576, P_BE1 = 640, P_G2 = 704, P_BE2 = 768, P_LAYER = 832;
   constexpr int P_H0 = 0, P_H1 = 256, P_H2 = 512, P_HEAD = 528;
-  const int net = blockIdx.y, s0 = blockIdx.x;
+  // (sample, net) of this block. xcd: a 1-D grid of 2 * ceil4(E) blocks in which the net follows the XCD the block lands on
+  // (work-groups go round-robin over the 8 XCDs: block b runs on XCD b % 8) — XCDs 0..3 run the policy, 4..7 the value net, so
+  // each XCD's L2 holds ONE net's 401 KB of weights instead of both (PMC, round 3: 6.1 MB of HBM traffic per launch against
+  // 1.08 MB algorithmic — every L2 fetched both nets). Otherwise the (E, 2) grid: blockIdx.y = net.
+  const int lin = blockIdx.x + gridDim.x * blockIdx.y;
+  const int net = xcd ? (lin >> 2) & 1 : (int)blockIdx.y, s0 = xcd ? (lin >> 3) * 4 + (lin & 3) : (int)blockIdx.x;
+  if (s0 >= E) return;  // (xcd: E rounded up to a multiple of 4)
   constexpr int nl = NL;  // the layer loop is unrolled: the compiler's vmcnt bookkeeping stays exact (no loop-carried merges)
   float* prm_h = prm + 2 * P_LAYER;  // [layer l & 1][832] | head [528]
   // operand-type copies of the two GEMM inputs that also live in fp32 (token rows: residual / LayerNorm; attention context):
@@ -1032,7 +1039,7 @@ __global__ __launch_bounds__(512) void rollout_stack_kernel(InfLayerStack stk, I
     // 128-byte line, <= 2 independent loads per thread), so that the fragment loads behind them find most lines already on
     // their way into the L2. Placement is a speed assumption only: every block still loads every fragment it uses.
     {
-      const int lin = blockIdx.x + gridDim.x * blockIdx.y, share = (lin >> 3) & 3;
+      const int share = (lin >> 3) & 3;
       const int L0 = tid * 4 + share, L1 = (tid + NTH) * 4 + share;  // line numbers in the concatenation of this net's weights
       const char* p0 = reinterpret_cast<const char*>(w0.win);
       const char* p1 = p0;
@@ -1317,7 +1324,7 @@ __global__ __launch_bounds__(512) void rollout_stack_kernel(InfLayerStack stk, I
       }
       ROLL_STAMP(84);
       if (fin.t_plus1 > 0) {  // nobody in this launch reads the cursor: one plain store keeps it in step for graph replays
-        if (lane == 0 && blockIdx.x == 0 && blockIdx.y == 0) fin.ctl->t = t_step + 1;
+        if (lane == 0 && s0 == 0 && net == 0) fin.ctl->t = t_step + 1;
       } else if (lane == 0) {  // the last block to get here advances the step cursor: every block read it at entry
         __threadfence();
         const unsigned long long done = atomicAdd(reinterpret_cast<unsigned long long*>(&fin.ctl->done), 1ull);
@@ -1563,8 +1570,13 @@ enum { ENC_TOK17 = 0, ENC_FUSE = 1, ENC_FLAT = 2, ENC_TOK16 = 3 };
 __device__ __forceinline__ int64_t act_frag_off(int row, int k, int KS) {
   return ((((int64_t)(row >> 4) * KS + (k >> 5)) * 64 + ((k >> 3) & 3) * 16 + (row & 15)) << 3) + (k & 7);
 }
-template <int MODE>
+// IMG16: the observation arrives SPLIT (v4l_actor_step_split) — proprio rows [E][ld_obs] fp32 at `obs`, the depth stacks
+// [E][ld16] already in bf16 at `img16` (the collector's host threads round fp64 -> fp32 -> bf16, exactly the two roundings the
+// fp32 row path applies: torch.Tensor(ob) on the host, the cast to the operand type here) — half the bytes over PCIe when the
+// kernel reads pinned host memory in place. Otherwise one fp32 row [ld_obs = S + C*H*W] per sample.
+template <int MODE, bool IMG16 = false>
 __global__ __launch_bounds__(1024) void rollout_encoder2_kernel(const ActCtl* __restrict__ ctl, const float* __restrict__ obs,
+                                                                int ld_obs, const __bf16* __restrict__ img16, int64_t ld16,
                                                                 int E, InfEncFrag w, float* __restrict__ state_roll,
                                                                 __bf16* __restrict__ image_roll, float* __restrict__ x0,
                                                                 __bf16* __restrict__ featv, __bf16* __restrict__ featp,
@@ -1576,7 +1588,7 @@ __global__ __launch_bounds__(1024) void rollout_encoder2_kernel(const ActCtl* __
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int fr = lane & 15, fg = (lane >> 4) * 8, qr = (lane >> 4) * 4;
   const int64_t slot0 = (t_plus1 > 0 ? t_plus1 - 1 : ctl->t) * (int64_t)E;  // (InfFinish::t_plus1)
-  const int D = w.S + LY::IMG;
+  const int D = ld_obs;
   auto gfrag = [&](const void* W, int idx) -> frag_t { return reinterpret_cast<const frag_t*>(W)[idx * 64 + lane]; };
 
   if ((int)blockIdx.x >= E) {
@@ -1679,7 +1691,12 @@ __global__ __launch_bounds__(1024) void rollout_encoder2_kernel(const ActCtl* __
   float* bs = reinterpret_cast<float*>(w2s + 4 * 16 * 64);           // b1[32] | b2[64] | b3[64] | bup[64]
   ROLL_STAMP(96);
   float4 v[4];
-  {
+  bf16x8 u[2];
+  if constexpr (IMG16) {
+    const bf16x8* row = reinterpret_cast<const bf16x8*>(img16 + (int64_t)b * ld16);
+#pragma unroll
+    for (int k = 0; k < 2; ++k) u[k] = row[tid + k * 1024];  // 2048 x 16 bytes per image: two per thread
+  } else {
     const float* row = obs + (int64_t)b * D + w.S;  // 16-byte aligned only when S % 4 == 0: dword-aligned vector loads (ld4u)
 #pragma unroll
     for (int k = 0; k < 4; ++k) v[k] = ld4u(row + (tid + k * 1024) * 4);  // 4096 float4 per image: four per thread, all in flight
@@ -1705,11 +1722,20 @@ __global__ __launch_bounds__(1024) void rollout_encoder2_kernel(const ActCtl* __
   __builtin_amdgcn_sched_barrier(0);
   {
     T* roll = image_roll + (slot0 + b) * (int64_t)LY::IMG;
+    if constexpr (IMG16) {
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const int i = tid + k * 1024;
-      st4(img + i * 4, v[k].x, v[k].y, v[k].z, v[k].w);
-      st4(roll + i * 4, v[k].x, v[k].y, v[k].z, v[k].w);
+      for (int k = 0; k < 2; ++k) {
+        const int i = tid + k * 1024;
+        *reinterpret_cast<bf16x8*>(img + i * 8) = u[k];
+        *reinterpret_cast<bf16x8*>(roll + i * 8) = u[k];
+      }
+    } else {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int i = tid + k * 1024;
+        st4(img + i * 4, v[k].x, v[k].y, v[k].z, v[k].w);
+        st4(roll + i * 4, v[k].x, v[k].y, v[k].z, v[k].w);
+      }
     }
     w1s[tid] = w1v;
     if (tid < 224) bs[tid] = bv;

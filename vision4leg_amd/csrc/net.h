@@ -158,6 +158,9 @@ struct v4l_actor {
   // an argument. dense_in_graph: the captured step contains that kernel, so every replay advances the device's count too.
   unsigned dense_seq = 0;
   bool dense_in_graph = false;
+  // v4l_actor_step_split: the depth stacks of the step in flight as bf16 rows (null: fp32 observation rows)
+  const void* img16 = nullptr;
+  int64_t ld_img16 = 0;
 };
 
 struct GraphKey { v4l_rollout ro; v4l_ppo_hyper hp; int n; int gen[3]; };

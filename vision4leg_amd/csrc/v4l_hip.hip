@@ -1912,6 +1912,32 @@ static bool actor_dense_cnn(const v4l_actor* a) {
          (p.kind == V4L_NET_CNN_VIS || a->pf->enc[0].Kp == 128) && getenv("V4L_NO_FUSED_ACTOR") == nullptr &&
          getenv("V4L_ROLLOUT_CNN_OLD") == nullptr;
 }
+// rollout_encoder2_kernel<MODE> on the step's observation: fp32 rows [E][S + C*H*W], or — v4l_actor_step_split — fp32 proprio
+// rows [E][S] + bf16 depth stacks (a->img16)
+template <int MODE, bool IMG16>
+static int launch_encoder2_t(v4l_actor* a, hipStream_t s, double flops, dim3 grid, const float* obs, int E, const InfEncFrag& ef,
+                             float* state_roll, __bf16* image_roll, float* x0, __bf16* featv, __bf16* featp) {
+  static bool attr = false;
+  if (!attr) {
+    V4L_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&rollout_encoder2_kernel<MODE, IMG16>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)RollEnc2Lds::bytes));
+    attr = true;
+  }
+  const int img_elems = a->pf->cfg.in_channels * a->pf->cfg.img_hw * a->pf->cfg.img_hw;
+  const int ld_obs = IMG16 ? ef.S : ef.S + img_elems;
+  V4L_KLAUNCH("rollout_encoder", flops, s, (rollout_encoder2_kernel<MODE, IMG16>), grid, dim3(1024), RollEnc2Lds::bytes, s,
+              (const ActCtl*)a->ctl, obs, ld_obs, (const __bf16*)a->img16, a->ld_img16, E, ef, state_roll, image_roll, x0, featv,
+              featp, actor_t_plus1(a, s));
+  V4L_LAUNCH_CHECK();
+  return 0;
+}
+template <int MODE>
+static int launch_encoder2(v4l_actor* a, hipStream_t s, double flops, dim3 grid, const float* obs, int E, const InfEncFrag& ef,
+                           float* state_roll, __bf16* image_roll, float* x0, __bf16* featv, __bf16* featp) {
+  return a->img16 ? launch_encoder2_t<MODE, true>(a, s, flops, grid, obs, E, ef, state_roll, image_roll, x0, featv, featp)
+                  : launch_encoder2_t<MODE, false>(a, s, flops, grid, obs, E, ef, state_roll, image_roll, x0, featv, featp);
+}
+
 static int run_actor_dense_cnn(v4l_actor* a, const float* obs, const float* eps, float* state_roll, void* image_roll,
                                float* acts_roll, float* values_roll, float* logp_roll, float* action, float* mean, float* stdv,
                                float* ent, float* value, hipStream_t s) {
@@ -1953,15 +1979,14 @@ static int run_actor_dense_cnn(v4l_actor* a, const float* obs, const float* eps,
   if (fuse) {
     ef.wf1 = pk + pf->enc[0].pkf; ef.wf2 = pk + pf->enc[1].pkf; ef.wpr = ef.wf2;
     ef.bf1 = pf->p[pf->enc[0].b]; ef.bf2 = pf->p[pf->enc[1].b]; ef.bpr = ef.bf2;
-    V4L_KLAUNCH("rollout_encoder", 2.0 * E * (3612672.0 + 128 * 256 + 256 * 256), s, rollout_encoder2_kernel<ENC_FUSE>,
-                dim3(E + cdiv(E, 32)), dim3(1024), RollEnc2Lds::bytes, s, (const ActCtl*)a->ctl, obs, E, ef, state_roll,
-                (__bf16*)image_roll, (float*)nullptr, featv, cat, actor_t_plus1(a, s));
+    if (int rc = launch_encoder2<ENC_FUSE>(a, s, 2.0 * E * (3612672.0 + 128 * 256 + 256 * 256), dim3(E + cdiv(E, 32)), obs, E, ef,
+                                           state_roll, (__bf16*)image_roll, (float*)nullptr, featv, cat))
+      return rc;
   } else {
-    V4L_KLAUNCH("rollout_encoder", 2.0 * E * 3612672.0, s, rollout_encoder2_kernel<ENC_FLAT>, dim3(E), dim3(1024),
-                RollEnc2Lds::bytes, s, (const ActCtl*)a->ctl, obs, E, ef, state_roll, (__bf16*)image_roll, (float*)nullptr,
-                featv, (__bf16*)nullptr, actor_t_plus1(a, s));
+    if (int rc = launch_encoder2<ENC_FLAT>(a, s, 2.0 * E * 3612672.0, dim3(E), obs, E, ef, state_roll, (__bf16*)image_roll,
+                                           (float*)nullptr, featv, (__bf16*)nullptr))
+      return rc;
   }
-  V4L_LAUNCH_CHECK();
   InfFinish fin;
   memset(&fin, 0, sizeof(fin));
   fin.ctl = a->ctl; fin.logstd = pf->p[pf->logstd]; fin.eps = eps; fin.A = pf->cfg.out_dim;
@@ -2161,16 +2186,10 @@ static int run_actor_fused(v4l_actor* a, const float* obs, const float* eps, flo
     ef.w1 = pb + pf->conv[0].pkf; ef.w2 = pb + pf->conv[1].pkf; ef.w3 = pb + pf->conv[2].pkf; ef.wup = pb + pf->upconv.pkf;
     ef.b1 = en.b1; ef.b2 = en.b2; ef.b3 = en.b3; ef.bup = en.bup;
     ef.S = en.S; ef.Sp = en.Sp;
-    V4L_KLAUNCH("rollout_encoder", 2.0 * E * 3678208.0, s, rollout_encoder2_kernel<ENC_TOK16>, dim3(E), dim3(1024),
-                RollEnc2Lds::bytes, s, (const ActCtl*)a->ctl, obs, E, ef, state_roll, (__bf16*)image_roll, x0, (__bf16*)nullptr,
-                (__bf16*)nullptr, actor_t_plus1(a, s));
+    if (int rc = launch_encoder2<ENC_TOK16>(a, s, 2.0 * E * 3678208.0, dim3(E), obs, E, ef, state_roll, (__bf16*)image_roll, x0,
+                                            (__bf16*)nullptr, (__bf16*)nullptr))
+      return rc;
   } else if (enc2 && sizeof(T) == 2 && pf->enc.size() == 2 && pf->enc[0].Kp == 128 && pf->conv[0].pkf >= 0) {
-    static bool attr2 = false;
-    if (!attr2) {
-      V4L_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&rollout_encoder2_kernel<ENC_TOK17>),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)RollEnc2Lds::bytes));
-      attr2 = true;
-    }
     const __bf16* pb = (const __bf16*)pf->packed;
     InfEncFrag ef;
     ef.w1 = pb + pf->conv[0].pkf; ef.w2 = pb + pf->conv[1].pkf; ef.w3 = pb + pf->conv[2].pkf; ef.wup = pb + pf->upconv.pkf;
@@ -2178,9 +2197,9 @@ static int run_actor_fused(v4l_actor* a, const float* obs, const float* eps, flo
     ef.wf1 = pb + pf->enc[0].pkf; ef.wf2 = pb + pf->enc[1].pkf; ef.wpr = pb + pf->proj.pkf;
     ef.bf1 = en.bf1; ef.bf2 = en.bf2; ef.bpr = en.bpr;
     ef.S = en.S; ef.Sp = en.Sp;
-    V4L_KLAUNCH("rollout_encoder", 2.0 * E * 3678208.0, s, rollout_encoder2_kernel<ENC_TOK17>, dim3(E + cdiv(E, 32)), dim3(1024),
-                RollEnc2Lds::bytes, s, (const ActCtl*)a->ctl, obs, E, ef, state_roll, (__bf16*)image_roll, x0, (__bf16*)nullptr,
-                (__bf16*)nullptr, actor_t_plus1(a, s));
+    if (int rc = launch_encoder2<ENC_TOK17>(a, s, 2.0 * E * 3678208.0, dim3(E + cdiv(E, 32)), obs, E, ef, state_roll,
+                                            (__bf16*)image_roll, x0, (__bf16*)nullptr, (__bf16*)nullptr))
+      return rc;
   } else  // fp32 parity mode (fragments twice the size): weights streamed per wave
     V4L_KLAUNCH("rollout_encoder", 2.0 * E * 3678208.0, s, rollout_encoder_kernel<T>, dim3(E + cdiv(E, 32)), dim3(1024),
                 InfEncLds<T>::bytes, s, (const ActCtl*)a->ctl, obs, E, en, state_roll, (T*)image_roll, x0);
@@ -2227,12 +2246,15 @@ static int run_actor_fused(v4l_actor* a, const float* obs, const float* eps, flo
     }
     finish();
     static const int warm = getenv("V4L_ROLLOUT_WARM") ? atoi(getenv("V4L_ROLLOUT_WARM")) : 0;  // L2 warm-up touches (measured: +-0)
+    // one net per XCD half (see the kernel): V4L_ROLLOUT_XCD=0 keeps the (E, 2) grid, where every XCD's L2 serves both nets
+    static const int xcd = getenv("V4L_ROLLOUT_XCD") ? atoi(getenv("V4L_ROLLOUT_XCD")) : 1;
+    const dim3 grid = xcd ? dim3(2 * round_up(E, 4)) : dim3(E, 2);
     if (vis)
-      V4L_KLAUNCH("rollout_layers_head", 2.0 * 2 * E * (nl * 872576.0 + 99840.0), s, (rollout_stack_kernel<T, 2, 16>), dim3(E, 2),
-                  dim3(512), (RollStackLds<T>::bytes), s, stk, hd, fin, E, warm);
+      V4L_KLAUNCH("rollout_layers_head", 2.0 * 2 * E * (nl * 872576.0 + 99840.0), s, (rollout_stack_kernel<T, 2, 16>), grid,
+                  dim3(512), (RollStackLds<T>::bytes), s, stk, hd, fin, E, warm, xcd);
     else
-      V4L_KLAUNCH("rollout_layers_head", 2.0 * 2 * E * (nl * 872576.0 + 99840.0), s, (rollout_stack_kernel<T, 2>), dim3(E, 2),
-                  dim3(512), (RollStackLds<T>::bytes), s, stk, hd, fin, E, warm);
+      V4L_KLAUNCH("rollout_layers_head", 2.0 * 2 * E * (nl * 872576.0 + 99840.0), s, (rollout_stack_kernel<T, 2>), grid,
+                  dim3(512), (RollStackLds<T>::bytes), s, stk, hd, fin, E, warm, xcd);
     V4L_LAUNCH_CHECK();
   }
   return 0;
@@ -2768,6 +2790,39 @@ static int actor_step_impl(v4l_actor* a, const float* obs_dev, const float* eps_
   if (a->dense_in_graph) ++a->dense_seq;  // the replayed rollout_dense_kernel advanced ctl->seq
   V4L_TRACE("actor: launched");
   return 0;
+}
+
+// Which actors run their step on rollout_encoder2_kernel — the kernels that can take the observation split (the dispatch order
+// of run_actor_step)
+static bool actor_takes_split(const v4l_actor* a, int shared_encoder) {
+  const v4l_net* pf = a->pf;
+  if (!shared_encoder || pf->cfg.compute != V4L_BF16 || pf->cfg.kind == V4L_NET_MLP) return false;
+  if (actor_dense_cnn(a)) return true;
+  if (actor_fusable_cnn(a) && pf->enc[0].Kp <= 128) return false;  // the per-sample rollout_cnn_kernel reads fp32 rows
+  if (!actor_fusable(a)) return false;
+  if (pf->cfg.kind == V4L_NET_LOCO_VIS) return true;
+  return getenv("V4L_ROLLOUT_ENC_OLD") == nullptr && pf->enc.size() == 2 && pf->enc[0].Kp == 128 && pf->conv[0].pkf >= 0;
+}
+int v4l_actor_split_supported(const v4l_actor* a, int shared_encoder) {
+  return (a && a->bound && actor_takes_split(a, shared_encoder)) ? 1 : 0;
+}
+int v4l_actor_step_split(v4l_actor* a, const float* proprio_dev, const void* image16_dev, const float* eps_dev,
+                         float* state_roll_dev, void* image_roll_dev, float* acts_roll_dev, float* values_roll_dev,
+                         float* logp_roll_dev, float* action_dev, float* mean_dev, float* std_dev, float* ent_dev,
+                         float* value_dev, int shared_encoder, void* stream) {
+  V4L_REQUIRE(a && a->bound && image16_dev, "v4l_actor_step_split: bad argument");
+  V4L_REQUIRE(actor_takes_split(a, shared_encoder),
+              "v4l_actor_step_split: this actor's step does not run on the split-observation kernels (bf16 compute, an image "
+              "net on the fused rollout step); use v4l_actor_step with fp32 observation rows");
+  V4L_REQUIRE(proprio_dev != nullptr || a->pf->cfg.state_dim == 0, "v4l_actor_step_split: proprio rows missing");
+  a->img16 = image16_dev;
+  a->ld_img16 = (int64_t)a->pf->cfg.in_channels * a->pf->cfg.img_hw * a->pf->cfg.img_hw;
+  // (vision-only nets, S = 0: no kernel reads the row pointer; the argument check of v4l_actor_step wants it non-null)
+  const float* rows = proprio_dev != nullptr ? proprio_dev : reinterpret_cast<const float*>(image16_dev);
+  const int rc = v4l_actor_step(a, rows, eps_dev, state_roll_dev, image_roll_dev, acts_roll_dev, values_roll_dev, logp_roll_dev,
+                                action_dev, mean_dev, std_dev, ent_dev, value_dev, shared_encoder, /*use_graph=*/0, stream);
+  a->img16 = nullptr;
+  return rc;
 }
 
 // ------------------------------------------------------------------------------------------ trainer

@@ -551,6 +551,52 @@ class HipActor:
     torch.cuda.current_stream(self.device).synchronize()
     return self._act_host.numpy()
 
+  def split_supported(self):
+    """True when this actor's step can take the observation split (v4l_actor_step_split): bf16 compute, an image net on the
+    fused rollout step, eager launches."""
+    return (not self.graph) and bool(self.L.v4l_actor_split_supported(self.h, int(self.shared_encoder)))
+
+  def step_host_split(self, prop_pinned, img16_pinned, deterministic=False):
+    """step_host with the observation split: `prop_pinned` [E][S] float32 (None when the net has no proprio input) and
+    `img16_pinned` [E][C*H*W] bfloat16, both PINNED host tensors the rollout kernels read in place — the depth stack crosses
+    PCIe in the type the kernels round it to anyway (half the bytes of fp32 rows; same results bit for bit). Returns the [E][A]
+    action as a numpy view of a pinned buffer (valid until the next step)."""
+    if self.graph:
+      raise RuntimeError("vision4leg_amd: step_host_split drives eager launches (construct the actor with graph=False)")
+    S = self.pf.state_dim
+    ok = (img16_pinned.is_pinned() and img16_pinned.dtype == torch.bfloat16 and img16_pinned.is_contiguous()
+          and tuple(img16_pinned.shape) == (self.E, self.pf.img_elems))
+    if S:
+      ok = ok and (prop_pinned is not None and prop_pinned.is_pinned() and prop_pinned.dtype == torch.float32
+                   and prop_pinned.is_contiguous() and tuple(prop_pinned.shape) == (self.E, S))
+    if not ok:
+      raise RuntimeError("vision4leg_amd: step_host_split needs pinned, contiguous [E][S] float32 and [E][C*H*W] bfloat16 host tensors")
+    if getattr(self, "_act_host", None) is None:
+      self._act_host = torch.zeros(self.action.shape, dtype=torch.float32).pin_memory()
+    self.pf.pack_if_needed(fast=True)
+    self.vf.pack_if_needed(fast=True)
+    a = self._args  # (obs, eps, st, im, acts, vals, logp, action, mean, std, ent, value, shared_encoder, graph)
+    eps = a[1]
+    bulk = getattr(self, "_bulk", None)
+    if not deterministic and bulk is not None:
+      eps = C.c_void_p(bulk.data_ptr() + self._bulk_t * bulk.stride(0) * 4)
+      self._bulk_t += 1
+      if self._bulk_t >= bulk.shape[0]:
+        self._bulk = None
+    elif not deterministic:
+      self.eps.normal_()
+      self._eps_zero = False
+    elif not getattr(self, "_eps_zero", False):
+      self.eps.zero_()
+      self._eps_zero = True
+    if self.own:
+      self.seek(0)
+    check(self.L.v4l_actor_step_split(self.h, C.c_void_p(prop_pinned.data_ptr() if S else 0), C.c_void_p(img16_pinned.data_ptr()),
+                                      eps, a[2], a[3], a[4], a[5], a[6], C.c_void_p(self._act_host.data_ptr()), a[8], a[9], a[10],
+                                      a[11], a[12], _stream()), "v4l_actor_step_split")
+    torch.cuda.current_stream(self.device).synchronize()
+    return self._act_host.numpy()
+
   def _step(self, obs, deterministic=False):
     self.pf.pack_if_needed(fast=True)
     self.vf.pack_if_needed(fast=True)

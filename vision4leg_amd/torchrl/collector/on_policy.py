@@ -57,6 +57,8 @@ class VecOnPolicyCollector:
         self._actor = None
         self._cursor = -1
         self._pins = None
+        self._split_pins = None
+        self._split = None  # decided at the first fast-path step: does the actor take the observation split (bf16 depth rows)?
         # threads of the per-step fp64 -> fp32 host cast (torch's intra-op pool; the env workers own the other cores). The
         # product runs no other torch CPU op on its hot path, so the process-wide setting is made once here and put back by
         # terminate(); V4L_CAST_THREADS overrides the count (1 = leave torch's setting alone).
@@ -116,6 +118,28 @@ class VecOnPolicyCollector:
         ev.record()
         return dev
 
+    def _upload_split(self, rows):
+        """The fast path's observation hand-over in bf16 compute mode: numpy [E][S + C*H*W] float64 rows -> a pinned fp32
+        [E][S] proprio block and a pinned bfloat16 [E][C*H*W] depth block (double-buffered) that the rollout kernels read in
+        place (RolloutActor.step_host_split). The depth stack crosses PCIe in the type the kernels round it to at ingest anyway:
+        torch's float64 -> bfloat16 copy rounds through float32 (c10::BFloat16 is constructed from float), i.e. exactly
+        torch.Tensor(ob) (collector/on_policy.py:91) followed by the kernels' fp32 -> bf16 cast — asserted bit for bit in
+        tests/test_cpu.py::test_host_bf16_cast_is_the_two_step_rounding and tests/test_gpu_collector.py."""
+        rows = np.asarray(rows)
+        S = self.pf.hip.state_dim
+        E, D = rows.shape
+        if self._split_pins is None or self._split_pins[0][1].shape != (E, D - S):
+            mk = lambda: (torch.empty(E, S, dtype=torch.float32).pin_memory() if S else None,
+                          torch.empty(E, D - S, dtype=torch.bfloat16).pin_memory())
+            self._split_pins, self._split_i = [mk(), mk()], 0
+        prop, img = self._split_pins[self._split_i]
+        self._split_i ^= 1
+        src = torch.from_numpy(rows)
+        if S:
+            prop.copy_(src[:, :S])
+        img.copy_(src[:, S:])
+        return prop, img
+
     def _ensure_actor(self):
         if self._actor is None:
             from ..policies import RolloutActor
@@ -137,7 +161,12 @@ class VecOnPolicyCollector:
                 self._cursor = top + 1
                 # observation rows and action cross PCIe inside the two rollout launches themselves: the kernels read the
                 # pinned staging buffer in place and write the [E][A] action into pinned host memory — no copy launches
-                acts = np.array(actor.step_host(self._upload(self.current_ob, host_only=True)), dtype=np.float32, copy=True)
+                if self._split is None:
+                    self._split = os.environ.get("V4L_COLLECT_SPLIT", "1") != "0" and actor.split_supported()
+                if self._split:  # bf16 compute: the depth stack goes over as bf16 (half the PCIe bytes, same numbers)
+                    acts = np.array(actor.step_host_split(*self._upload_split(self.current_ob)), dtype=np.float32, copy=True)
+                else:
+                    acts = np.array(actor.step_host(self._upload(self.current_ob, host_only=True)), dtype=np.float32, copy=True)
                 values = None
             else:
                 ob_tensor = self._upload(self.current_ob)

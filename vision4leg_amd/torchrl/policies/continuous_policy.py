@@ -54,6 +54,13 @@ class RolloutActor:
         """One env step straight from / to pinned host memory (see HipActor.step_host): -> numpy action [E][A]."""
         return self._actor.step_host(ob_pinned, deterministic)
 
+    def split_supported(self):
+        return self._actor.split_supported()
+
+    def step_host_split(self, prop_pinned, img16_pinned, deterministic=False):
+        """step_host with the depth stack handed over in bfloat16 (see HipActor.step_host_split): -> numpy action [E][A]."""
+        return self._actor.step_host_split(prop_pinned, img16_pinned, deterministic)
+
     def eval_act(self, x):
         """`pf.eval_act(x)` (policies/continuous_policy.py:78-83) on the fused step: the policy mean as a numpy array,
         no draw. With env_nums = 1 this is the batch-1 deployment call — the role the reference's TensorRT engine
