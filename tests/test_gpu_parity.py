@@ -1131,3 +1131,43 @@ def test_epoch_device_buffer_equals_host_buffer(mode, device):
             assert abs(x[k] - y[k]) <= tol * max(1.0, abs(y[k])), (u, k, x[k], y[k])
     drift = sum((pa[k] - pb[k]).abs().sum().item() for k in pa) / sum(v.numel() for v in pa.values())
     assert drift <= (2e-7 if mode == "f32" else 2e-5), drift
+
+
+@pytest.mark.parametrize("mode", MODES)
+@pytest.mark.parametrize("name", ["loco_s93", "loco_rag", "loco_b1024"])
+def test_external_row_chains_equal_in_kernel_chains(name, mode, device, monkeypatch):
+    """Round 4: the pooled heads' data-grad chain runs beside the loss statistics (critic_loss_heads_kernel /
+    actor_loss_heads_kernel) and the proprio branch's chain beside the layers' weight-grads (wps_wgrad_kernel), 32 - 64 rows per
+    block, instead of inside wps_layer_bwd_kernel over the block's 4 samples (csrc/wps.h rows_chain). Same MFMA steps in the
+    same k order per output element: two PPO updates must give bit-identical statistics and parameters either way (B = 64: the
+    4-wave loss blocks, ragged 300 and 1024: the 16-wave ones)."""
+    case = util.CASES[name]
+    from vision4leg_amd.torchrl.algo import PPO
+    res = {}
+    for variant, env in (("external", {}), ("in_kernel", {"V4L_WPS_HEAD_IN": "1", "V4L_WPS_TOK0_IN": "1"}),
+                         ("heads_only_external", {"V4L_WPS_TOK0_IN": "1"})):
+        for k in ("V4L_WPS_HEAD_IN", "V4L_WPS_TOK0_IN"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        pf, vf = _build(case, mode, device)
+
+        class Coll: epoch_frames = 1
+        agent = PPO(pf=pf, vf=vf, plr=1e-4, vlr=1e-4, clip_para=0.2, opt_epochs=3, tau=0.95, entropy_coeff=0.005,
+                    collector=Coll(), device=device, batch_size=case["B"])
+        agent.trainer.sync_target()
+        infos = []
+        for u in range(2):
+            b = util.make_batch(case, update=u)
+            infos.append(agent.update({k: b[k] for k in ("obs", "acts", "advs", "estimate_returns", "values")}))
+        torch.cuda.synchronize()
+        res[variant] = (infos, {k: v.detach().cpu().clone() for k, v in pf.state_dict().items()},
+                        {k: v.detach().cpu().clone() for k, v in vf.state_dict().items()})
+    for other in ("in_kernel", "heads_only_external"):
+        for u in range(2):
+            for k in util.STAT_KEYS:
+                a, b = res["external"][0][u][k], res[other][0][u][k]
+                assert a == b or (np.isnan(a) and np.isnan(b)), (other, u, k, a, b)
+        for i in (1, 2):
+            for k, v in res["external"][i].items():
+                assert torch.equal(v, res[other][i][k]), (other, k)

@@ -455,30 +455,34 @@ __global__ __launch_bounds__(256) void comm_check_kernel(const float* __restrict
 
 // nn.MSELoss()(values, est_rets) and its gradient (ppo.py:94-123; clipped_value_loss=False path, and the
 // clipped variant of ppo.py:105-112 when clip > 0). values is the critic output [n][OUT_LD], column 0.
-__global__ __launch_bounds__(1024) void critic_loss_kernel(const float* __restrict__ values, const float* __restrict__ ret,
-                                                          const float* __restrict__ oldv, const int* __restrict__ rowidx,
-                                                          int n, float inv_n, int clipped, float clip,
-                                                          float* __restrict__ dvalues, float* __restrict__ st) {
+// One row: loss term l and d(loss)/d(value) g. (Shared by the statistics block and by the blocks that run the heads'
+// data-grads beside it, csrc/wps.h: both must see the same bits.)
+__device__ __forceinline__ void critic_row(float v, float r, float ov, int clipped, float clip, float inv_n, float& l, float& g) {
+  if (!clipped) {
+    const float d = v - r;
+    l = d * d;
+    g = 2.f * d * inv_n;
+  } else {
+    const float dv = v - ov;
+    const float vc = ov + fminf(fmaxf(dv, -clip), clip);
+    const float l1 = (v - r) * (v - r), l2 = (vc - r) * (vc - r);
+    // 0.5 * max(l1, l2).mean(); torch.max splits ties evenly between both arguments
+    const float g1 = 2.f * (v - r);
+    const float g2 = (dv >= -clip && dv <= clip) ? 2.f * (vc - r) : 0.f;
+    l = 0.5f * fmaxf(l1, l2);
+    g = 0.5f * inv_n * (l1 > l2 ? g1 : (l1 < l2 ? g2 : 0.5f * (g1 + g2)));
+  }
+}
+__device__ __forceinline__ void critic_loss_body(const float* __restrict__ values, const float* __restrict__ ret,
+                                                 const float* __restrict__ oldv, const int* __restrict__ rowidx, int n,
+                                                 float inv_n, int clipped, float clip, float* __restrict__ dvalues,
+                                                 float* __restrict__ st) {
   double s = 0.0;
   for (int i = threadIdx.x; i < n; i += blockDim.x) {
     const int slot = rowidx ? rowidx[i] : i;
     const float v = values[(int64_t)i * OUT_LD], r = ret[slot];
     float g, l;
-    if (!clipped) {
-      const float d = v - r;
-      l = d * d;
-      g = 2.f * d * inv_n;
-    } else {
-      const float ov = oldv[slot];
-      const float dv = v - ov;
-      const float vc = ov + fminf(fmaxf(dv, -clip), clip);
-      const float l1 = (v - r) * (v - r), l2 = (vc - r) * (vc - r);
-      // 0.5 * max(l1, l2).mean(); torch.max splits ties evenly between both arguments
-      const float g1 = 2.f * (v - r);
-      const float g2 = (dv >= -clip && dv <= clip) ? 2.f * (vc - r) : 0.f;
-      l = 0.5f * fmaxf(l1, l2);
-      g = 0.5f * inv_n * (l1 > l2 ? g1 : (l1 < l2 ? g2 : 0.5f * (g1 + g2)));
-    }
+    critic_row(v, r, clipped ? oldv[slot] : 0.f, clipped, clip, inv_n, l, g);
     s += l;
 #pragma unroll
     for (int c = 0; c < OUT_LD; ++c) dvalues[(int64_t)i * OUT_LD + c] = c == 0 ? g : 0.f;
@@ -486,122 +490,156 @@ __global__ __launch_bounds__(1024) void critic_loss_kernel(const float* __restri
   Red4 r = block_red4(s, 0.0, 0.f, 0.f);
   if (threadIdx.x == 0) st[ST_VF_LOSS] = (float)(r.s * (double)inv_n);
 }
+__global__ __launch_bounds__(1024) void critic_loss_kernel(const float* __restrict__ values, const float* __restrict__ ret,
+                                                          const float* __restrict__ oldv, const int* __restrict__ rowidx,
+                                                          int n, float inv_n, int clipped, float clip,
+                                                          float* __restrict__ dvalues, float* __restrict__ st) {
+  critic_loss_body(values, ret, oldv, rowidx, n, inv_n, clipped, clip, dvalues, st);
+}
 
 
 // Clipped-surrogate + entropy loss of PPO.update_actor (ppo.py:42-92) and its gradient w.r.t. the policy
 // mean [n][OUT_LD] and logstd [A]. logp_old comes from the frozen target policy's mean/logstd on the same
 // minibatch. Advantages are normalised with the minibatch statistics in st (ppo.py:148). Single block.
 // inv_n is 1/(global batch) so that data-parallel ranks sum to the big-batch gradient.
-__global__ __launch_bounds__(1024) void actor_loss_kernel(const float* __restrict__ mean, const float* __restrict__ logstd,
-                                                         const float* __restrict__ tmean, const float* __restrict__ tlogstd,
-                                                         const float* __restrict__ logp_old,
-                                                         const float* __restrict__ acts, const float* __restrict__ adv,
-                                                         const int* __restrict__ rowidx, int n, int A, float inv_n,
-                                                         float clip, float ent_coef, float* __restrict__ dmean,
-                                                         float* __restrict__ dlogstd, float* __restrict__ st) {
-  __shared__ float sdl[16][8];
-  float ls[8], sg[8], lsg[8], tls[8], tsg[8], tlsg[8], dl[8];
-  float ent = 0.f;
+struct ActorArgs {
+  const float *mean, *logstd, *tmean, *tlogstd, *logp_old, *acts, *adv;
+  const int* rowidx;
+  int n, A;
+  float inv_n, clip, ent_coef;
+  float *dmean, *dlogstd, *st;
+};
+struct ActorDims { float ls[8], sg[8], lsg[8], tls[8], tsg[8], tlsg[8]; float ent; };
+__device__ __forceinline__ ActorDims actor_dims(const ActorArgs& p) {
+  ActorDims d;
+  d.ent = 0.f;
+#pragma unroll
   for (int a = 0; a < 8; ++a) {
-    dl[a] = 0.f;
-    if (a < A) {
-      ls[a] = fminf(fmaxf(logstd[a], LOG_SIG_MIN), LOG_SIG_MAX);
-      sg[a] = expf(ls[a]); lsg[a] = logf(sg[a]);
-      tls[a] = tlogstd != nullptr ? fminf(fmaxf(tlogstd[a], LOG_SIG_MIN), LOG_SIG_MAX) : 0.f;
-      tsg[a] = expf(tls[a]); tlsg[a] = logf(tsg[a]);
-      ent += 0.5f + HALF_LOG_2PI + lsg[a];
+    d.ls[a] = d.sg[a] = d.lsg[a] = d.tls[a] = d.tsg[a] = d.tlsg[a] = 0.f;
+    if (a < p.A) {
+      d.ls[a] = fminf(fmaxf(p.logstd[a], LOG_SIG_MIN), LOG_SIG_MAX);
+      d.sg[a] = expf(d.ls[a]); d.lsg[a] = logf(d.sg[a]);
+      d.tls[a] = p.tlogstd != nullptr ? fminf(fmaxf(p.tlogstd[a], LOG_SIG_MIN), LOG_SIG_MAX) : 0.f;
+      d.tsg[a] = expf(d.tls[a]); d.tlsg[a] = logf(d.tsg[a]);
+      d.ent += 0.5f + HALF_LOG_2PI + d.lsg[a];
     }
   }
-  const float amean = st[ST_ADV_MEAN], astd = st[ST_ADV_STD];
+  return d;
+}
+// one minibatch row i (rollout slot `slot`): log pi, ratio, surrogate term, d(loss)/d(log pi) and the per-dimension factors of
+// d(log pi)/d(mean) (dm) and d(log pi)/d(log sigma) + 1 (z2)
+struct ActorRow { float lp, ratio, sur, dlp, dm[8], z2[8]; };
+__device__ __forceinline__ ActorRow actor_row(const ActorArgs& p, const ActorDims& D, int i, int slot, float amean, float astd) {
+  ActorRow o;
+  float lp = 0.f, lpo = 0.f, mu[8], tmu[8];
+  {  // the padded [OUT_LD] rows are 64-byte aligned: two 16-byte loads per row instead of A strided scalar ones
+    const float4 m0 = *reinterpret_cast<const float4*>(p.mean + (int64_t)i * OUT_LD);
+    const float4 m1 = *reinterpret_cast<const float4*>(p.mean + (int64_t)i * OUT_LD + 4);
+    mu[0] = m0.x; mu[1] = m0.y; mu[2] = m0.z; mu[3] = m0.w; mu[4] = m1.x; mu[5] = m1.y; mu[6] = m1.z; mu[7] = m1.w;
+    if (p.logp_old == nullptr) {
+      const float4 t0 = *reinterpret_cast<const float4*>(p.tmean + (int64_t)i * OUT_LD);
+      const float4 t1 = *reinterpret_cast<const float4*>(p.tmean + (int64_t)i * OUT_LD + 4);
+      tmu[0] = t0.x; tmu[1] = t0.y; tmu[2] = t0.z; tmu[3] = t0.w; tmu[4] = t1.x; tmu[5] = t1.y; tmu[6] = t1.z; tmu[7] = t1.w;
+    }
+  }
+#pragma unroll
+  for (int a = 0; a < 8; ++a) {
+    if (a < p.A) {
+      const float x = p.acts[(int64_t)slot * p.A + a];
+      const float d = x - mu[a];
+      const float var = D.sg[a] * D.sg[a];
+      lp += -(d * d) / (2.f * var) - D.lsg[a] - HALF_LOG_2PI;
+      o.z2[a] = d * d / var;
+      o.dm[a] = d / var;
+      if (p.logp_old == nullptr) {
+        const float dt = x - tmu[a];
+        lpo += -(dt * dt) / (2.f * D.tsg[a] * D.tsg[a]) - D.tlsg[a] - HALF_LOG_2PI;
+      }
+    } else {
+      o.z2[a] = 0.f; o.dm[a] = 0.f;
+    }
+  }
+  if (p.logp_old != nullptr) lpo = p.logp_old[slot];  // stored when the action was taken (== the target policy's)
+  const float ratio = expf(lp - lpo);
+  const float an = (p.adv[slot] - amean) / (astd + 1e-5f);
+  const float pre = ratio * an;
+  const float clp = fminf(fmaxf(ratio, 1.f - p.clip), 1.f + p.clip) * an;
+  o.lp = lp; o.ratio = ratio;
+  o.sur = fminf(pre, clp);
+  // d(-mean(min(pre,clp)))/dlogp: the clipped branch has zero slope outside the clip range
+  o.dlp = (pre <= clp) ? -p.inv_n * an * ratio : 0.f;
+  return o;
+}
+__device__ __forceinline__ void actor_loss_body(const ActorArgs& p) {
+  __shared__ float sdl[16][8];
+  const int n = p.n, A = p.A;
+  const ActorDims D = actor_dims(p);
+  float dl[8];
+#pragma unroll
+  for (int a = 0; a < 8; ++a) dl[a] = 0.f;
+  const float amean = p.st[ST_ADV_MEAN], astd = p.st[ST_ADV_STD];
   double s_lp = 0.0, s_lp2 = 0.0, s_sur = 0.0;
   float lp_mx = -INFINITY, lp_mn = INFINITY, r_mx = -INFINITY, r_mn = INFINITY;
   for (int i = threadIdx.x; i < n; i += blockDim.x) {
-    const int slot = rowidx ? rowidx[i] : i;
-    float lp = 0.f, lpo = 0.f, z2[8], dm[8], mu[8], tmu[8];
-    {  // the padded [OUT_LD] rows are 64-byte aligned: two 16-byte loads per row instead of A strided scalar ones
-      const float4 m0 = *reinterpret_cast<const float4*>(mean + (int64_t)i * OUT_LD);
-      const float4 m1 = *reinterpret_cast<const float4*>(mean + (int64_t)i * OUT_LD + 4);
-      mu[0] = m0.x; mu[1] = m0.y; mu[2] = m0.z; mu[3] = m0.w; mu[4] = m1.x; mu[5] = m1.y; mu[6] = m1.z; mu[7] = m1.w;
-      if (logp_old == nullptr) {
-        const float4 t0 = *reinterpret_cast<const float4*>(tmean + (int64_t)i * OUT_LD);
-        const float4 t1 = *reinterpret_cast<const float4*>(tmean + (int64_t)i * OUT_LD + 4);
-        tmu[0] = t0.x; tmu[1] = t0.y; tmu[2] = t0.z; tmu[3] = t0.w; tmu[4] = t1.x; tmu[5] = t1.y; tmu[6] = t1.z; tmu[7] = t1.w;
-      }
-    }
-#pragma unroll
-    for (int a = 0; a < 8; ++a) {
-      if (a < A) {
-        const float x = acts[(int64_t)slot * A + a];
-        const float d = x - mu[a];
-        const float var = sg[a] * sg[a];
-        lp += -(d * d) / (2.f * var) - lsg[a] - HALF_LOG_2PI;
-        z2[a] = d * d / var;
-        dm[a] = d / var;
-        if (logp_old == nullptr) {
-          const float dt = x - tmu[a];
-          lpo += -(dt * dt) / (2.f * tsg[a] * tsg[a]) - tlsg[a] - HALF_LOG_2PI;
-        }
-      } else {
-        z2[a] = 0.f; dm[a] = 0.f;
-      }
-    }
-    if (logp_old != nullptr) lpo = logp_old[slot];  // stored when the action was taken (== the target policy's)
-    const float ratio = expf(lp - lpo);
-    const float an = (adv[slot] - amean) / (astd + 1e-5f);
-    const float pre = ratio * an;
-    const float clp = fminf(fmaxf(ratio, 1.f - clip), 1.f + clip) * an;
-    s_sur += fminf(pre, clp);
-    // d(-mean(min(pre,clp)))/dlogp: the clipped branch has zero slope outside the clip range
-    const float dlp = (pre <= clp) ? -inv_n * an * ratio : 0.f;
+    const int slot = p.rowidx ? p.rowidx[i] : i;
+    const ActorRow o = actor_row(p, D, i, slot, amean, astd);
+    s_sur += o.sur;
     {
-      float4* drow = reinterpret_cast<float4*>(dmean + (int64_t)i * OUT_LD);
-      drow[0] = float4{dlp * dm[0], dlp * dm[1], dlp * dm[2], dlp * dm[3]};  // dm[a >= A] == 0
-      drow[1] = float4{dlp * dm[4], dlp * dm[5], dlp * dm[6], dlp * dm[7]};
+      float4* drow = reinterpret_cast<float4*>(p.dmean + (int64_t)i * OUT_LD);
+      drow[0] = float4{o.dlp * o.dm[0], o.dlp * o.dm[1], o.dlp * o.dm[2], o.dlp * o.dm[3]};  // dm[a >= A] == 0
+      drow[1] = float4{o.dlp * o.dm[4], o.dlp * o.dm[5], o.dlp * o.dm[6], o.dlp * o.dm[7]};
       drow[2] = float4{0.f, 0.f, 0.f, 0.f};
       drow[3] = float4{0.f, 0.f, 0.f, 0.f};
     }
 #pragma unroll
     for (int a = 0; a < 8; ++a)
-      if (a < A) dl[a] += dlp * (z2[a] - 1.f);
-    s_lp += lp; s_lp2 += (double)lp * lp;
-    lp_mx = fmaxf(lp_mx, lp); lp_mn = fminf(lp_mn, lp);
-    r_mx = fmaxf(r_mx, ratio); r_mn = fminf(r_mn, ratio);
+      if (a < A) dl[a] += o.dlp * (o.z2[a] - 1.f);
+    s_lp += o.lp; s_lp2 += (double)o.lp * o.lp;
+    lp_mx = fmaxf(lp_mx, o.lp); lp_mn = fminf(lp_mn, o.lp);
+    r_mx = fmaxf(r_mx, o.ratio); r_mn = fminf(r_mn, o.ratio);
   }
   Red4 r1 = block_red4(s_lp, s_lp2, lp_mx, lp_mn);
   Red4 r2 = block_red4(s_sur, 0.0, r_mx, r_mn);
   // reduce dlogstd over the block
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+#pragma unroll
   for (int a = 0; a < 8; ++a) {
     float v = wave_sum(dl[a]);
     if (lane == 0) sdl[w][a] = v;
   }
   __syncthreads();
+  float* st = p.st;
   if (threadIdx.x < A) {
     const int a = threadIdx.x;
-    const float raw = logstd[a];
+    const float raw = p.logstd[a];
     float g = 0.f;
     for (int k = 0; k < (int)(blockDim.x >> 6); ++k) g += sdl[k][a];
     // entropy term: -ent_coef * mean_b(sum_a log sigma_a + const); each local sample carries weight inv_n
-    g += -ent_coef * inv_n * (float)n;
-    dlogstd[a] = (raw >= LOG_SIG_MIN && raw <= LOG_SIG_MAX) ? g : 0.f;
+    g += -p.ent_coef * p.inv_n * (float)n;
+    p.dlogstd[a] = (raw >= LOG_SIG_MIN && raw <= LOG_SIG_MAX) ? g : 0.f;
   }
   if (threadIdx.x == 0) {
     const double lpm = r1.s / n;
-    st[ST_PI_LOSS] = (float)(-(r2.s / n) - (double)ent_coef * ent);
+    st[ST_PI_LOSS] = (float)(-(r2.s / n) - (double)p.ent_coef * D.ent);
     st[ST_LP_MEAN] = (float)lpm;
     st[ST_LP_STD] = (float)sqrt(fmax(0.0, (r1.s2 - n * lpm * lpm) / (double)(n - 1)));
     st[ST_LP_MAX] = r1.mx; st[ST_LP_MIN] = r1.mn;
     st[ST_RATIO_MAX] = r2.mx; st[ST_RATIO_MIN] = r2.mn;
     double m = 0.0; float mx = -INFINITY, mn = INFINITY;
-    for (int a = 0; a < A; ++a) { m += ls[a]; mx = fmaxf(mx, ls[a]); mn = fminf(mn, ls[a]); }
+#pragma unroll
+    for (int a = 0; a < 8; ++a)
+      if (a < A) { m += D.ls[a]; mx = fmaxf(mx, D.ls[a]); mn = fminf(mn, D.ls[a]); }
     m /= A;
     double q = 0.0;
-    for (int a = 0; a < A; ++a) q += (ls[a] - m) * (ls[a] - m);
+#pragma unroll
+    for (int a = 0; a < 8; ++a)
+      if (a < A) q += (D.ls[a] - m) * (D.ls[a] - m);
     st[ST_LS_MEAN] = (float)m;
     st[ST_LS_STD] = A > 1 ? (float)sqrt(q / (A - 1)) : NAN;
     st[ST_LS_MAX] = mx; st[ST_LS_MIN] = mn;
   }
 }
+__global__ __launch_bounds__(1024) void actor_loss_kernel(ActorArgs p) { actor_loss_body(p); }
 
 // Gaussian head post-processing for the policy API (continuous_policy.py:85-146,486-492): from the padded
 // mean [n][OUT_LD] and logstd [A] produce contiguous mean/std [n][A], clamped log_std [A], ent [n] and, when

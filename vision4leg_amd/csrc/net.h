@@ -8,6 +8,8 @@
 #include "elem.h"
 #include "gemm.h"
 
+namespace v4l { struct RowsChain; }
+
 namespace v4l {
 
 struct ParamInfo {
@@ -136,6 +138,12 @@ struct v4l_net {
   // stage: 0 = whole net, 1 = encoder only (up to the token / concat tensor), 2 = trunk + head only
   template <typename T> int forward_t(const float* state, const T* image, const int* rowidx, int n, float* ws, hipStream_t s,
                                       const float* enc_ws = nullptr, int stage = 0);
+  // round 4: the pooled heads' data-grads ran beside the loss statistics (heads_ext() handed the trainer their operands) for
+  // the backward pass over (heads_ext_ws, heads_ext_n) that follows; backward_t consumes the mark
+  float* heads_ext_ws = nullptr;
+  int heads_ext_n = 0;
+  bool wps_bwd_plain() const;   // backward_t will run the (non-vision) wave-per-sample backward
+  int heads_ext(float* ws, int n, v4l::RowsChain* out);
   bool fused_layers() const;  // the transformer layers run as fused forward / backward launches (csrc/infer.h, bwd.h)
   bool wps_layers() const;
   bool wps_vis() const;  // vision-only Transformer on the wave-per-sample kernels (dummy token row, csrc/wps.h)    // ... as wave-per-sample launches (csrc/wps.h)

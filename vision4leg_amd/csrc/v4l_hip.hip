@@ -243,9 +243,15 @@ static int wgrad_dense(Ctx& c, hipStream_t ds, hipStream_t dg) {
   if (c.wps_pending) {
     c.wps_pending = false;
     const int jobs = c.wps_args.nsplit * WPS_ROLES * c.wps_args.nlayers;
+    c.wps_args.wg_blocks = cdiv(jobs, 4);
+    const int chain = c.wps_args.chain_blocks;
+    // (the proprio chain's consumer — the grouped weight-grads below — must follow on the SAME stream)
+    V4L_REQUIRE(chain == 0 || dg == ds, "internal: proprio chain in the weight-grad launch, but the grouped weight-grads run elsewhere");
     g_op = "layer.wgrad";
-    V4L_KLAUNCH("wps_wgrad", 2.0 * c.wps_args.n * NTOK * (double)WPS_LAYER_ELEMS * c.wps_args.nlayers, ds, wps_wgrad_kernel<T>,
-                dim3((unsigned)cdiv(jobs, 4)), dim3(256), 0, ds, c.wps_args);
+    V4L_KLAUNCH("wps_wgrad", 2.0 * c.wps_args.n * NTOK * (double)WPS_LAYER_ELEMS * c.wps_args.nlayers +
+                                 (chain ? 2.0 * c.wps_args.n * (64 * 256 + 256 * 256) : 0.0),
+                ds, wps_wgrad_kernel<T>, dim3((unsigned)(c.wps_args.wg_blocks + chain)), dim3(256),
+                chain ? (RowsChainLds<T, RowsChainCfg<T>::MT_TOK0>::bytes2) : 0, ds, c.wps_args);
     V4L_LAUNCH_CHECK();
   }
   int64_t gb = 0;
@@ -966,6 +972,35 @@ bool v4l_net::wps_vis() const {
 bool v4l_net::fused_layers() const {
   return cfg.kind == V4L_NET_LOCO && cfg.ff_dim == 256 && getenv("V4L_NO_FUSED_LAYER") == nullptr;
 }
+// backward_t's own conditions for the (non-vision) wave-per-sample backward, for callers that prepare work for it
+bool v4l_net::wps_bwd_plain() const {
+  const v4l_net_cfg& c = cfg;
+  if (c.kind != V4L_NET_LOCO) return false;
+  const bool fused_bwd = fused_layers();
+  const bool fused_head = fused_bwd && c.n_layers >= 1 && c.n_head_hidden == 2 && c.head_hidden[0] == 256 &&
+                          c.head_hidden[1] == 256 && getenv("V4L_NO_FUSED_HEAD_BWD") == nullptr;
+  const bool fused_tail = fused_bwd && c.n_layers >= 1 && c.n_enc_hidden == 2 && c.enc_hidden[0] == 256 &&
+                          c.enc_hidden[1] == 256 && getenv("V4L_NO_FUSED_TAIL_BWD") == nullptr;
+  return fused_bwd && fused_head && fused_tail && c.n_layers == 2 && getenv("V4L_NO_LAYER_STACK") == nullptr && wps_layers();
+}
+// The operands of the pooled heads' data-grad chain over the workspace `ws` laid out for n rows, for a caller (the trainer's
+// loss launch) that runs the chain itself right before v4l_net_backward(ws, n): -> 1 and the backward pass is told (it then
+// starts from dpool), or 0 when that backward pass will not be the wave-per-sample one (or V4L_WPS_HEAD_IN / test taps ask for
+// the in-kernel heads).
+int v4l_net::heads_ext(float* ws, int n, v4l::RowsChain* out) {
+  heads_ext_ws = nullptr;
+  if (!bound || out == nullptr || !wps_bwd_plain() || getenv("V4L_WPS_HEAD_IN") != nullptr || getenv("V4L_LAYER_TAPS") != nullptr)
+    return 0;
+  const Layout L = layout(n);
+  const size_t es = cfg.compute == V4L_BF16 ? 2 : 4;
+  const char* base = (const char*)packed;
+  out->wa = base + (size_t)head[2].pkt * es; out->wb = base + (size_t)head[1].pkt * es; out->wc = base + (size_t)head[0].pkt * es;
+  out->ma = ws + L.hh[1]; out->mb = ws + L.hh[0];
+  out->oa = ws + L.dhh[1]; out->ob = ws + L.dhh[0];
+  out->oc = ws + L.dpool;
+  heads_ext_ws = ws; heads_ext_n = n;
+  return 1;
+}
 
 // Upper bound of the weight-grad slab arena for a batch of n: every weight tensor with the row count its
 // gradient contraction runs over.
@@ -1520,19 +1555,14 @@ int v4l_net::backward_t(const float* state, const T* image, const int* rowidx, i
   if (wps) {
     // wave-per-sample launch (csrc/wps.h): heads -> per layer {recompute, backward} -> encoder-side data-grads; the four
     // weight-grads of each layer come from the fragment-order operand blocks it leaves, in one launch of their own
-    static bool wps_attr = false;
-    if (!wps_attr) {
-      V4L_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&wps_layer_bwd_kernel<T, 2, false>),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)WpsBwdLds<T>::bytes));
-      V4L_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&wps_layer_bwd_kernel<T, 2, true>),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)WpsBwdLds<T>::bytes));
-      V4L_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&wps_layer_bwd_kernel<T, 2, false, true>),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)WpsBwdLds<T>::bytes));
-      V4L_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&wps_layer_bwd_kernel<T, 2, true, true>),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)WpsBwdLds<T>::bytes));
-      wps_attr = true;
-    }
     const bool taps = getenv("V4L_LAYER_TAPS") != nullptr;  // (read per call: tests switch it)
+    // round 4: the heads' and the proprio branch's data-grad chains outside this launch, 64 rows per block (csrc/wps.h
+    // rows_chain): the heads ran beside the loss statistics when the trainer said so (heads_ext), the proprio chain rides in
+    // the layers' weight-grad launch unless the grouped weight-grads (its consumer) go to a stream of their own
+    const bool head_ext = !vis_wps && !taps && heads_ext_ws == ws && heads_ext_n == n;
+    heads_ext_ws = nullptr;
+    const int par_wgrad_now = getenv("V4L_PAR_WGRAD") ? atoi(getenv("V4L_PAR_WGRAD")) : 2;
+    const bool tok0_ext = !vis_wps && !taps && par_wgrad_now != 3 && getenv("V4L_WPS_TOK0_IN") == nullptr;
     const int nblk = cdiv(n, WPS_WPB);
     const T* base = (const T*)packed;
     WpsBwdStack d;
@@ -1577,16 +1607,29 @@ int v4l_net::backward_t(const float* state, const T* image, const int* rowidx, i
     }
     WpsTailExtra tx;
     tx.wupt_f = base + upconv.pkpt;
+    tx.dpool = ws + L.dpool;
     g_op = "layer";
-    const double fl = 2 * 4.0 * n * 872576.0 + 2.0 * n * 2 * (16 * 256 + 256 * 256 + 256 * 128) + 2.0 * n * (64 * 256 + 256 * 256 + 16 * 64 * 64);
-    if (vis_wps && taps)
-      V4L_KLAUNCH("wps_layer_bwd_stack", fl, s, (wps_layer_bwd_kernel<T, 2, true, true>), dim3(nblk), dim3(256), (WpsBwdLds<T>::bytes), s, d, bh, bt, tx, n);
-    else if (vis_wps)
-      V4L_KLAUNCH("wps_layer_bwd_stack", fl, s, (wps_layer_bwd_kernel<T, 2, false, true>), dim3(nblk), dim3(256), (WpsBwdLds<T>::bytes), s, d, bh, bt, tx, n);
-    else if (taps)
-      V4L_KLAUNCH("wps_layer_bwd_stack", fl, s, (wps_layer_bwd_kernel<T, 2, true>), dim3(nblk), dim3(256), (WpsBwdLds<T>::bytes), s, d, bh, bt, tx, n);
-    else
-      V4L_KLAUNCH("wps_layer_bwd_stack", fl, s, (wps_layer_bwd_kernel<T, 2, false>), dim3(nblk), dim3(256), (WpsBwdLds<T>::bytes), s, d, bh, bt, tx, n);
+    const double fl_heads = 2.0 * n * 2 * (16 * 256 + 256 * 256 + 256 * 128) / 2, fl_tok0 = 2.0 * n * (64 * 256 + 256 * 256);
+    const double fl = 2 * 4.0 * n * 872576.0 + (head_ext ? 0.0 : 2 * fl_heads) + (tok0_ext ? 0.0 : fl_tok0) + 2.0 * n * 16 * 64 * 64;
+#define V4L_WPS_BWD(TAPS_, VIS_, HIN_, TIN_)                                                                              \
+  do {                                                                                                                    \
+    static bool attr_ = false;                                                                                            \
+    if (!attr_) {                                                                                                         \
+      V4L_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&wps_layer_bwd_kernel<T, 2, TAPS_, VIS_, HIN_, TIN_>), \
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)WpsBwdLds<T>::bytes));          \
+      attr_ = true;                                                                                                       \
+    }                                                                                                                     \
+    V4L_KLAUNCH("wps_layer_bwd_stack", fl, s, (wps_layer_bwd_kernel<T, 2, TAPS_, VIS_, HIN_, TIN_>), dim3(nblk), dim3(256), \
+                (WpsBwdLds<T>::bytes), s, d, bh, bt, tx, n);                                                              \
+  } while (0)
+    if (vis_wps && taps) V4L_WPS_BWD(true, true, true, true);
+    else if (vis_wps) V4L_WPS_BWD(false, true, true, true);
+    else if (taps) V4L_WPS_BWD(true, false, true, true);
+    else if (head_ext && tok0_ext) V4L_WPS_BWD(false, false, false, false);
+    else if (head_ext) V4L_WPS_BWD(false, false, false, true);
+    else if (tok0_ext) V4L_WPS_BWD(false, false, true, false);
+    else V4L_WPS_BWD(false, false, true, true);
+#undef V4L_WPS_BWD
     V4L_LAUNCH_CHECK();
     // the layers' weight-grads: one partial slab set per run of WPS_SPLIT samples
     WpsWg wa;
@@ -1611,6 +1654,11 @@ int v4l_net::backward_t(const float* state, const T* image, const int* rowidx, i
         o.slab = sl; o.bslab = sl + sf; o.nsplit = wa.nsplit; o.Npad = Lm.N; o.Kpad = Lm.K;
         red.push_back(o);
       }
+    }
+    if (tok0_ext) {  // the proprio chain as extra blocks of the layers' weight-grad launch (wgrad_dense)
+      wa.chain_blocks = cdiv(n, RowsChainCfg<T>::MT_TOK0 * 16);
+      wa.tl = bt;
+      wa.dx0 = ws + L.dxl[0];
     }
     cx.wps_args = wa;
     cx.wps_pending = true;
@@ -2260,6 +2308,39 @@ static int run_actor_fused(v4l_actor* a, const float* obs, const float* eps, flo
   return 0;
 }
 
+
+// dynamic LDS of the loss launches that carry the heads' data-grad chain (85 KB in bf16: above the 64 KB default)
+template <typename T, int NW> static int loss_heads_attr() {
+  static bool done = false;
+  if (!done) {
+    const int bytes = (int)RowsChainLds<T, RowsChainCfg<T>::MT>::bytes3;
+    V4L_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&critic_loss_heads_kernel<T, NW>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+    V4L_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&actor_loss_heads_kernel<T, NW>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+    done = true;
+  }
+  return 0;
+}
+// the loss launch with the heads' chain beside the statistics: grid = 1 + row blocks, NW waves per block
+template <typename T, int NW>
+static int launch_critic_loss_heads(hipStream_t s, const float* values, const float* ret, const float* oldv, const int* rowidx, int n,
+                                    float inv_n, int clipped, float clip, float* dvalues, float* st, const RowsChain& hc) {
+  int rc = loss_heads_attr<T, NW>();
+  if (rc) return rc;
+  V4L_KLAUNCH("critic_loss", 2.0 * n * (16 * 256 + 256 * 256 + 256 * 128), s, (critic_loss_heads_kernel<T, NW>),
+              dim3(1 + cdiv(n, RowsChainCfg<T>::MT * 16)), dim3(NW * 64), (RowsChainLds<T, RowsChainCfg<T>::MT>::bytes3), s, values, ret,
+              oldv, rowidx, n, inv_n, clipped, clip, dvalues, st, hc);
+  return 0;
+}
+template <typename T, int NW>
+static int launch_actor_loss_heads(hipStream_t s, const ActorArgs& aa, const RowsChain& hc) {
+  int rc = loss_heads_attr<T, NW>();
+  if (rc) return rc;
+  V4L_KLAUNCH("actor_loss", 2.0 * aa.n * (16 * 256 + 256 * 256 + 256 * 128), s, (actor_loss_heads_kernel<T, NW>),
+              dim3(1 + cdiv(aa.n, RowsChainCfg<T>::MT * 16)), dim3(NW * 64), (RowsChainLds<T, RowsChainCfg<T>::MT>::bytes3), s, aa, hc);
+  return 0;
+}
 
 // ------------------------------------------------------------------------------------------ C ABI
 extern "C" {
@@ -2936,8 +3017,23 @@ int v4l_trainer_critic_grads(v4l_trainer* tr, const v4l_rollout* ro, int n, cons
   const Layout L = vf->layout(n);
   const float inv_n = 1.f / ((float)n * (float)hp->world_size);
   g_op = "loss";
-  V4L_KLAUNCH("critic_loss", 0, s, critic_loss_kernel, dim3(1), dim3(n >= 512 ? 1024 : 256), 0, s, tr->ws + L.out, ro->rets_dev, ro->values_dev,
-                     rowidx, n, inv_n, hp->clipped_value_loss, hp->clip_para, tr->ws + L.dout, st);
+  {
+    // the heads' data-grad chain as extra blocks of the loss launch when the backward that follows is the wave-per-sample one
+    RowsChain hc;
+    const bool ext = vf->heads_ext(tr->ws, n, &hc) != 0;
+    const dim3 blk(n >= 512 ? 1024 : 256);
+    if (ext) {
+      const bool bf = vf->cfg.compute == V4L_BF16, big = n >= 512;
+#define V4L_CL(T_, NW_) launch_critic_loss_heads<T_, NW_>(s, tr->ws + L.out, ro->rets_dev, ro->values_dev, rowidx, n, inv_n, \
+                                                          hp->clipped_value_loss, hp->clip_para, tr->ws + L.dout, st, hc)
+      rc = bf ? (big ? V4L_CL(__bf16, 16) : V4L_CL(__bf16, 4)) : (big ? V4L_CL(float, 16) : V4L_CL(float, 4));
+#undef V4L_CL
+      if (rc) return rc;
+    } else {
+      V4L_KLAUNCH("critic_loss", 0, s, critic_loss_kernel, dim3(1), blk, 0, s, tr->ws + L.out, ro->rets_dev, ro->values_dev,
+                  rowidx, n, inv_n, hp->clipped_value_loss, hp->clip_para, tr->ws + L.dout, st);
+    }
+  }
   V4L_LAUNCH_CHECK();
   PhaseScope ps("vf.bwd");
   return v4l_net_backward(vf, ro->state_dev, ro->image_dev, rowidx, n, tr->ws, tr->g_vf, stream);
@@ -3016,10 +3112,25 @@ int v4l_trainer_actor_grads(v4l_trainer* tr, const v4l_rollout* ro, int n, const
   }
   const float inv_n = 1.f / ((float)n * (float)hp->world_size);
   g_op = "loss";
-  V4L_KLAUNCH("actor_loss", 0, s, actor_loss_kernel, dim3(1), dim3(n >= 512 ? 1024 : 256), 0, s, tr->ws + Lp.out, pf->p[pf->logstd],
-                     stored ? (const float*)nullptr : (const float*)(ws_t + Lt.out), stored ? (const float*)nullptr : (const float*)tp->p[tp->logstd],
-                     ro->logp_old_dev, ro->acts_dev, ro->advs_dev, rowidx, n, pf->cfg.out_dim, inv_n, hp->clip_para,
-                     hp->entropy_coeff, tr->ws + Lp.dout, tr->g_pf + pf->params[pf->logstd].goff, st);
+  {
+    ActorArgs aa;
+    aa.mean = tr->ws + Lp.out; aa.logstd = pf->p[pf->logstd];
+    aa.tmean = stored ? nullptr : ws_t + Lt.out; aa.tlogstd = stored ? nullptr : tp->p[tp->logstd];
+    aa.logp_old = ro->logp_old_dev; aa.acts = ro->acts_dev; aa.adv = ro->advs_dev; aa.rowidx = rowidx;
+    aa.n = n; aa.A = pf->cfg.out_dim; aa.inv_n = inv_n; aa.clip = hp->clip_para; aa.ent_coef = hp->entropy_coeff;
+    aa.dmean = tr->ws + Lp.dout; aa.dlogstd = tr->g_pf + pf->params[pf->logstd].goff; aa.st = st;
+    RowsChain hc;
+    const bool ext = pf->heads_ext(tr->ws, n, &hc) != 0;
+    const dim3 blk(n >= 512 ? 1024 : 256);
+    if (ext) {
+      const bool bf = pf->cfg.compute == V4L_BF16, big = n >= 512;
+      rc = bf ? (big ? launch_actor_loss_heads<__bf16, 16>(s, aa, hc) : launch_actor_loss_heads<__bf16, 4>(s, aa, hc))
+              : (big ? launch_actor_loss_heads<float, 16>(s, aa, hc) : launch_actor_loss_heads<float, 4>(s, aa, hc));
+      if (rc) return rc;
+    } else {
+      V4L_KLAUNCH("actor_loss", 0, s, actor_loss_kernel, dim3(1), blk, 0, s, aa);
+    }
+  }
   V4L_LAUNCH_CHECK();
   PhaseScope ps("pf.bwd");
   return v4l_net_backward(pf, ro->state_dev, ro->image_dev, rowidx, n, tr->ws, tr->g_pf, stream);

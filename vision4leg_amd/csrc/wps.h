@@ -881,11 +881,187 @@ __device__ __forceinline__ void wps_layer_bwd(const WpsBwdLayer& w, const T* Wt,
   }
 }
 
+// ------------------------------------------------------------------------------------------ batched row chains (round 4)
+// The pooled heads' data-grads (dout -> W2' -> dh1 -> W1' -> dh0 -> W0' -> dpool) and the proprio branch's (token-0 gradient ->
+// state_projector' -> dhc -> fc2' -> de0) are chains of row-independent GEMMs over the n samples. Inside the wave-per-sample
+// backward a block owns 4 samples, so each chain streams its 200 / 170 KB of weights for FOUR rows (19 K + 19 K of the kernel's
+// 157 K cycles). Here the same chains run over 16 MT rows per block — the same MFMA steps in the same k order
+// per output element (bit-identical to the in-kernel chains) — as extra blocks of launches that are on the update's path anyway:
+// the heads beside the loss statistics (critic_loss_kernel / actor_loss_kernel: a row's loss gradient needs nothing but that
+// row and the advantage statistics), the proprio chain beside the layers' weight-grads (wps_wgrad_kernel), whose successor
+// (the grouped dense weight-grads) is its only consumer.
+struct RowsChain {
+  const void *wa, *wb, *wc;  // data-grad packs [N][K] row-major: [256][64], [256][256], [128][256] (wc null: two stages)
+  const float *ma, *mb;      // [n][256] post-ReLU activations (ReLU masks) of the first / second stage's outputs
+  float *oa, *ob;            // [n][256] the masked outputs (dY operands of the weight-grads)
+  float* oc;                 // [n][128] third stage's output (un-masked)
+};
+template <typename T, int MT> struct RowsChainLds {
+  static constexpr int LDX = 64 + 4, LDF = 256 + InfLd<T>::PAD;
+  static constexpr size_t dt_b = (size_t)MT * 16 * LDX * 4, dh_b = (size_t)MT * 16 * LDF * sizeof(T);
+  static constexpr size_t bytes2 = dt_b + dh_b, bytes3 = dt_b + 2 * dh_b;  // two- / three-stage chain
+};
+// dt: LDS [16 MT][LDX] fp32 input rows (zero beyond the chain's input width and for rows >= n), filled and synchronised by the
+// caller; dha / dhb: LDS [16 MT][LDF] T. NW waves per block; rows r0 .. r0 + 16 MT - 1.
+template <typename T, int NW, int MT>
+__device__ __forceinline__ void rows_chain(const RowsChain& c, const float* dt, T* dha, T* dhb, int r0, int n, int tid) {
+  constexpr int LDX = RowsChainLds<T, MT>::LDX, LDF = RowsChainLds<T, MT>::LDF;
+  constexpr int NTW = 16 / NW;  // column tiles of a 256-wide stage per wave
+  static_assert(NW == 4 || NW == 8 || NW == 16, "rows_chain: 4, 8 or 16 waves");
+  const int lane = tid & 63, wave = tid >> 6, fr = lane & 15, qr = (lane >> 4) * 4;
+  int nt[NTW];
+#pragma unroll
+  for (int j = 0; j < NTW; ++j) nt[j] = wave * NTW + j;
+  GemmRing<T, NTW, 2> ring_a = gemm_prefetch<T, NTW, 2>((const T*)c.wa, 64, nt, lane);
+  GemmRing<T, NTW, 8> ring_b = gemm_prefetch<T, NTW, 8>((const T*)c.wb, 256, nt, lane);
+  f32x4 acc[MT][NTW];
+  auto masked = [&](const float* __restrict__ m, T* dst, float* __restrict__ save) {  // ReLU mask from the saved activation
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      const int row = r0 + mt * 16 + fr;
+      const bool ok = row < n;
+#pragma unroll
+      for (int j = 0; j < NTW; ++j) {
+        const int n4 = nt[j] * 16 + qr;
+        const float4 mk = *reinterpret_cast<const float4*>(m + (int64_t)(ok ? row : 0) * 256 + n4);
+        const float d0 = mk.x > 0.f ? acc[mt][j][0] : 0.f, d1 = mk.y > 0.f ? acc[mt][j][1] : 0.f;
+        const float d2 = mk.z > 0.f ? acc[mt][j][2] : 0.f, d3 = mk.w > 0.f ? acc[mt][j][3] : 0.f;
+        if (dst != nullptr) st4(dst + (mt * 16 + fr) * LDF + n4, d0, d1, d2, d3);
+        if (ok) st4(save + (int64_t)row * 256 + n4, d0, d1, d2, d3);
+      }
+    }
+  };
+  zero_acc(acc);
+  block_gemm<T, MT, NTW, 2>(acc, dt, LDX, (const T*)c.wa, 64, nt, lane, ring_a);
+  masked(c.ma, dha, c.oa);
+  __syncthreads();
+  zero_acc(acc);
+  block_gemm<T, MT, NTW, 8>(acc, dha, LDF, (const T*)c.wb, 256, nt, lane, ring_b);
+  const bool three = c.wc != nullptr;  // block-uniform
+  masked(c.mb, three ? dhb : (T*)nullptr, c.ob);
+  if (!three) return;
+  __syncthreads();
+  constexpr int NT3 = NW >= 8 ? 1 : 8 / NW;  // the 128-wide third stage: 8 column tiles
+  if (wave * NT3 < 8) {
+    int nt3[NT3];
+#pragma unroll
+    for (int j = 0; j < NT3; ++j) nt3[j] = wave * NT3 + j;
+    f32x4 a3[MT][NT3];
+    zero_acc(a3);
+    block_gemm<T, MT, NT3, 8>(a3, dhb, LDF, (const T*)c.wc, 256, nt3, lane);
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      const int row = r0 + mt * 16 + fr;
+      if (row < n) {
+#pragma unroll
+        for (int j = 0; j < NT3; ++j)
+          st4(c.oc + (int64_t)row * 128 + nt3[j] * 16 + qr, a3[mt][j][0], a3[mt][j][1], a3[mt][j][2], a3[mt][j][3]);
+      }
+    }
+  }
+}
+// rows per block of the heads' chain in the loss launches: 64 in bf16 (85 KB of LDS), 32 in the fp32 parity mode (fragments
+// twice the size); of the proprio chain inside wps_wgrad_kernel: 32 (its accumulators must fit beside that kernel's two waves
+// per SIMD)
+template <typename T> struct RowsChainCfg { static constexpr int MT = sizeof(T) == 2 ? 4 : 2; static constexpr int MT_TOK0 = 2; };
+
+// the proprio chain of BwdTail for rows r0.. : token-0 rows of the layer-0 input gradient, masked by the token's ReLU
+template <typename T, int NW>
+__device__ __forceinline__ void tok0_chain_block(const BwdTail& tl, const float* __restrict__ dx0, int n, int r0, unsigned char* smem,
+                                                 int tid) {
+  constexpr int MT = RowsChainCfg<T>::MT_TOK0;
+  typedef RowsChainLds<T, MT> LY;
+  float* dt = reinterpret_cast<float*>(smem);
+  T* dh = reinterpret_cast<T*>(smem + LY::dt_b);
+  for (int idx = tid; idx < MT * 16 * 16; idx += NW * 64) {
+    const int r = idx >> 4, c4 = (idx & 15) * 4, row = r0 + r;
+    const bool ok = row < n;
+    const int64_t o = (int64_t)(ok ? row : 0) * NTOK * TD + c4;
+    const float4 d = *reinterpret_cast<const float4*>(dx0 + o), x = *reinterpret_cast<const float4*>(tl.x0 + o);
+    *reinterpret_cast<float4*>(dt + r * LY::LDX + c4) =
+        ok ? float4{x.x > 0.f ? d.x : 0.f, x.y > 0.f ? d.y : 0.f, x.z > 0.f ? d.z : 0.f, x.w > 0.f ? d.w : 0.f}
+           : float4{0.f, 0.f, 0.f, 0.f};
+  }
+  __syncthreads();
+  RowsChain c;
+  c.wa = tl.wpt; c.wb = tl.wf2t; c.wc = nullptr;
+  c.ma = tl.s_e1; c.mb = tl.s_e0; c.oa = tl.o_dhc; c.ob = tl.o_de0; c.oc = nullptr;
+  rows_chain<T, NW, MT>(c, dt, dh, (T*)nullptr, r0, n, tid);
+}
+
+// The loss launches with the heads' data-grad chain beside the statistics: block 0 = critic_loss_kernel / actor_loss_kernel
+// (csrc/elem.h: statistics, the loss gradient rows for the last linear's weight-grad, d log sigma); block 1 + b = rows
+// 16 MT b .. of the same loss gradient (recomputed from the row: critic_row / actor_row, the same bits) -> W2' -> dh1 -> W1' ->
+// dh0 -> W0' -> dpool, which the wave-per-sample backward (HEAD_IN = false) un-pools. Dynamic LDS: RowsChainLds<T, MT>::bytes3.
+template <typename T, int NWAVES>
+__device__ __forceinline__ void loss_heads_run(const RowsChain& hc, float* dt, int r0, int n, unsigned char* smem, int tid) {
+  constexpr int MT = RowsChainCfg<T>::MT;
+  typedef RowsChainLds<T, MT> LY;
+  T* dha = reinterpret_cast<T*>(smem + LY::dt_b);
+  T* dhb = reinterpret_cast<T*>(smem + LY::dt_b + LY::dh_b);
+  rows_chain<T, NWAVES, MT>(hc, dt, dha, dhb, r0, n, tid);
+}
+template <typename T, int NWAVES>
+__global__ __launch_bounds__(NWAVES * 64) void critic_loss_heads_kernel(const float* __restrict__ values, const float* __restrict__ ret,
+                                                                const float* __restrict__ oldv, const int* __restrict__ rowidx,
+                                                                int n, float inv_n, int clipped, float clip,
+                                                                float* __restrict__ dvalues, float* __restrict__ st, RowsChain hc) {
+  if (blockIdx.x == 0) {
+    critic_loss_body(values, ret, oldv, rowidx, n, inv_n, clipped, clip, dvalues, st);
+    return;
+  }
+  constexpr int MT = RowsChainCfg<T>::MT;
+  typedef RowsChainLds<T, MT> LY;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  float* dt = reinterpret_cast<float*>(smem);
+  const int tid = threadIdx.x, r0 = ((int)blockIdx.x - 1) * MT * 16;
+  for (int idx = tid; idx < MT * 16 * 16; idx += NWAVES * 64) {
+    const int r = idx >> 4, c4 = (idx & 15) * 4, i = r0 + r;
+    float g = 0.f;
+    if (c4 == 0 && i < n) {
+      const int slot = rowidx ? rowidx[i] : i;
+      float l;
+      critic_row(values[(int64_t)i * OUT_LD], ret[slot], clipped ? oldv[slot] : 0.f, clipped, clip, inv_n, l, g);
+    }
+    *reinterpret_cast<float4*>(dt + r * LY::LDX + c4) = float4{g, 0.f, 0.f, 0.f};
+  }
+  __syncthreads();
+  loss_heads_run<T, NWAVES>(hc, dt, r0, n, smem, tid);
+}
+template <typename T, int NWAVES>
+__global__ __launch_bounds__(NWAVES * 64) void actor_loss_heads_kernel(ActorArgs p, RowsChain hc) {
+  if (blockIdx.x == 0) {
+    actor_loss_body(p);
+    return;
+  }
+  constexpr int MT = RowsChainCfg<T>::MT;
+  typedef RowsChainLds<T, MT> LY;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  float* dt = reinterpret_cast<float*>(smem);
+  const int tid = threadIdx.x, r0 = ((int)blockIdx.x - 1) * MT * 16;
+  for (int idx = tid; idx < MT * 16 * 16; idx += NWAVES * 64)  // columns 8.. (and rows >= n) stay zero
+    *reinterpret_cast<float4*>(dt + (idx >> 4) * LY::LDX + (idx & 15) * 4) = float4{0.f, 0.f, 0.f, 0.f};
+  __syncthreads();
+  if (tid < MT * 16 && r0 + tid < p.n) {  // one thread per row: the row's d(loss)/d(mean), as block 0 files it in dmean
+    const ActorDims D = actor_dims(p);
+    const int i = r0 + tid, slot = p.rowidx ? p.rowidx[i] : i;
+    const ActorRow o = actor_row(p, D, i, slot, p.st[ST_ADV_MEAN], p.st[ST_ADV_STD]);
+    float4* drow = reinterpret_cast<float4*>(dt + tid * LY::LDX);
+    drow[0] = float4{o.dlp * o.dm[0], o.dlp * o.dm[1], o.dlp * o.dm[2], o.dlp * o.dm[3]};
+    drow[1] = float4{o.dlp * o.dm[4], o.dlp * o.dm[5], o.dlp * o.dm[6], o.dlp * o.dm[7]};
+  }
+  __syncthreads();
+  loss_heads_run<T, NWAVES>(hc, dt, r0, p.n, smem, tid);
+}
+
 // Backward of the transformer stack for WPS_WPB samples per block: pooled heads (cooperative, as bwd_layer_kernel's HEAD) ->
 // per layer {recompute the forward in registers, walk it backward} -> encoder-side data-grads (TAIL: up-conv per wave in
 // registers, the token-0 chain cooperatively).
-struct WpsTailExtra { const void* wupt_f; };  // up-conv's transposed weight as a k-permuted fragment pack
-template <typename T, int NL, bool TAPS, bool VIS = false>
+// HEAD_IN / TOK0_IN = false: that chain ran / will run outside this kernel over 64 rows per block (rows_chain above) — the
+// heads beside the loss statistics, leaving dpool [n][128] (tx.dpool) for the un-pool here; the proprio chain beside the
+// layers' weight-grads, from the layer-0 input gradient this kernel writes (stk.l[NL-1].o_dx).
+struct WpsTailExtra { const void* wupt_f; const float* dpool; };  // up-conv's transposed weight as a k-permuted fragment pack
+template <typename T, int NL, bool TAPS, bool VIS = false, bool HEAD_IN = true, bool TOK0_IN = true>
 __global__ __launch_bounds__(256) void wps_layer_bwd_kernel(WpsBwdStack stk, BwdHead hd, BwdTail tl, WpsTailExtra tx, int n) {
   // VIS (template parameter): see wps_layer_fwd — hd.w0t is then the [128][256] pack whose rows 0..63 are zero (the dummy
   // row's un-pooled gradient is exactly zero), and the TAIL ends after the up-conv data-grad (there is no proprio branch)
@@ -909,7 +1085,18 @@ __global__ __launch_bounds__(256) void wps_layer_bwd_kernel(WpsBwdStack stk, Bwd
   const frag_t E0 = wps_sel<T>(0, lane), E1 = wps_sel<T>(1, lane);
   float4 dy[2][4];
   WPS_STAMP(32);
-  {
+  if constexpr (!HEAD_IN) {
+    // the heads ran beside the loss statistics: un-pool their dpool rows straight into this wave's registers
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) {
+        const bool tok0 = mt == 0 && fr == 0;
+        const float4 v = *reinterpret_cast<const float4*>(tx.dpool + srow * (2 * TD) + (tok0 ? 0 : TD) + nt * 16 + qr);
+        const float sc = tok0 ? 1.f : (1.f / 16.f);
+        dy[mt][nt] = ok[mt] ? float4{v.x * sc, v.y * sc, v.z * sc, v.w * sc} : float4{0.f, 0.f, 0.f, 0.f};
+      }
+  } else {
     // ---- heads (nets.py:1015-1034 reversed): dout -> (W2^T, mask h1) -> dh1 -> (W1^T, mask h0) -> dh0 -> (W0^T) -> dpool
     float* dt = reinterpret_cast<float*>(smem);                 // [16][LDX]: dout rows, zero padded to 64 columns
     T* dh1 = reinterpret_cast<T*>(dt + 16 * LY::LDX);           // [16][LDF]
@@ -1062,7 +1249,7 @@ __global__ __launch_bounds__(256) void wps_layer_bwd_kernel(WpsBwdStack stk, Bwd
       }
     }
     WPS_STAMP(66);
-    if constexpr (VIS) return;
+    if constexpr (VIS || !TOK0_IN) return;
     // token 0: (dx_in o [x0 > 0]) -> state_projector' -> [e1 > 0] -> dhc -> fc2' -> [e0 > 0] -> de0, cooperatively (4 rows)
     float* dt = reinterpret_cast<float*>(smem);                 // [16][LDX]
     T* dh = reinterpret_cast<T*>(dt + 16 * LY::LDX);            // [16][LDF]
@@ -1125,7 +1312,9 @@ struct WpsWgLayer {
   float* slab[4];          // per matrix (in_proj, out_proj, linear1, linear2): [nsplit][N][K]
   float* bslab[4];         // [nsplit][N]
 };
-struct WpsWg { WpsWgLayer l[2]; int n, nsplit, nlayers; };
+// chain_blocks > 0: the launch carries that many extra blocks (after the weight-grad ones) that run the proprio branch's
+// data-grad chain over RowsChainCfg<T>::MT_TOK0 * 16 rows each (tok0_chain_block; RowsChainLds<T, MT_TOK0>::bytes2 of dynamic LDS)
+struct WpsWg { WpsWgLayer l[2]; int n, nsplit, nlayers; int wg_blocks, chain_blocks; BwdTail tl; const float* dx0; };
 struct WpsRole { int mat, nt0, kt0, nrow0, kcol0, N, K, bias; };
 __device__ __forceinline__ WpsRole wps_role(int r) {
   // dY-side tiles (rows n of dW) x x-side tiles (columns k of dW), as tile numbers inside the operand block
@@ -1135,8 +1324,13 @@ __device__ __forceinline__ WpsRole wps_role(int r) {
   return WpsRole{3, WPS_T_DZ2, WPS_T_F + 4 * (r - 8), 0, 64 * (r - 8), 64, 256, r == 8};         // linear2: dz2 x f
 }
 template <typename T>
-__global__ __launch_bounds__(256) void wps_wgrad_kernel(WpsWg a) {
+__global__ __launch_bounds__(256, 2) void wps_wgrad_kernel(WpsWg a) {  // (two waves per SIMD: <= 256 registers, as before the chain role)
   typedef typename Frag<T>::type frag_t;
+  if (a.chain_blocks > 0 && (int)blockIdx.x >= a.wg_blocks) {  // (block-uniform)
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    tok0_chain_block<T, 4>(a.tl, a.dx0, a.n, ((int)blockIdx.x - a.wg_blocks) * RowsChainCfg<T>::MT_TOK0 * 16, smem, threadIdx.x);
+    return;
+  }
   const int lane = threadIdx.x & 63, fr = lane & 15, g = lane >> 4;
   const int job = blockIdx.x * 4 + (threadIdx.x >> 6);
   const int per_split = WPS_ROLES * a.nlayers;
