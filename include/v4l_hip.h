@@ -94,6 +94,8 @@ typedef struct v4l_net_cfg {
   int n_head_hidden;   /* append_hidden_shapes (nets.py:35-50, 224-243, 973-992)                         */
   int head_hidden[V4L_MAX_HIDDEN];
   int has_logstd;      /* 1: Gaussian policy with a state-independent logstd parameter                   */
+  int max_pool;        /* V4L_NET_LOCO / V4L_NET_LOCO_VIS: token pooling by max instead of mean (max_pool=True,
+                          nets.py:1022-1030, 884-889); runs on the layer-by-layer kernels (no shipped config sets it) */
 } v4l_net_cfg;
 
 typedef struct v4l_net v4l_net;         /* host-side plan of one network (no device memory)  */

@@ -148,8 +148,9 @@ def split_obs(x, S):
     return x[..., :S], x[..., S:].reshape(-1, 4, 64, 64)
 
 
-def loco_forward(p, x, S, mode="f32", taps=None):
-    """LocoTransformer.forward + LocoTransformerEncoder.forward (nets.py:996-1038, base.py:550-626), depth-only."""
+def loco_forward(p, x, S, mode="f32", taps=None, max_pool=False):
+    """LocoTransformer.forward + LocoTransformerEncoder.forward (nets.py:996-1038, base.py:550-626), depth-only.
+    max_pool: nets.py:1022-1023 — the depth tokens are pooled by `.max(dim=0)[0]` instead of the mean."""
     state, img = split_obs(x, S)
     B = state.shape[0]
     c3 = nature_cnn(p, "encoder.depth_visual_base", img, mode)                                  # base.py:578
@@ -168,7 +169,8 @@ def loco_forward(p, x, S, mode="f32", taps=None):
         if taps is not None:
             taps["x%d" % (l + 1)] = tok
         l += 1
-    pooled = torch.cat([tok[:, 0], tok[:, 1:17].mean(dim=1)], dim=-1)                           # nets.py:1015-1034
+    depth = tok[:, 1:17].max(dim=1)[0] if max_pool else tok[:, 1:17].mean(dim=1)
+    pooled = torch.cat([tok[:, 0], depth], dim=-1)                                              # nets.py:1015-1034
     nh = _count(p, "visual_seq_append_fcs.%d.weight") - 1
     return head(p, "visual_seq_append_fcs", pooled, nh, mode)                                   # nets.py:1036
 
@@ -192,7 +194,7 @@ def mlp_forward(p, x, S=None, mode="f32", taps=None):
     return head(p, "seq_append_fcs", mlp(p, "base.seq_fcs", x, ne, mode), nh, mode)
 
 
-def loco_vis_forward(p, x, S=0, mode="f32", taps=None):
+def loco_vis_forward(p, x, S=0, mode="f32", taps=None, max_pool=False):
     """Transformer.forward + TransformerEncoder.forward, depth only (nets.py:868-906, base.py:430-494): the observation
     row is the depth stack; 16 patch tokens, mean over all of them (out[0:1+16] of a 16-token sequence), head."""
     img = x.reshape(-1, 4, 64, 64)                                                              # nets.py:869-871
@@ -206,7 +208,7 @@ def loco_vis_forward(p, x, S=0, mode="f32", taps=None):
     while ("visual_append_layers.%d.norm1.weight" % l) in p:
         tok = transformer_layer(p, "visual_append_layers.%d" % l, tok, mode)                    # nets.py:881-883
         l += 1
-    pooled = tok[:, 0:17].mean(dim=1)                                                           # nets.py:888-889
+    pooled = tok[:, 0:17].max(dim=1)[0] if max_pool else tok[:, 0:17].mean(dim=1)               # nets.py:886-889
     nh = _count(p, "visual_seq_append_fcs.%d.weight") - 1
     return head(p, "visual_seq_append_fcs", pooled, nh, mode)                                   # nets.py:904
 
@@ -219,8 +221,16 @@ def cnn_vis_forward(p, x, S=0, mode="f32", taps=None):
     return head(p, "seq_append_fcs", c3.flatten(1), nh, mode)
 
 
+def loco_max_forward(p, x, S, mode="f32", taps=None):
+    return loco_forward(p, x, S, mode, taps, max_pool=True)
+
+
+def loco_vis_max_forward(p, x, S=0, mode="f32", taps=None):
+    return loco_vis_forward(p, x, S, mode, taps, max_pool=True)
+
+
 FORWARDS = {"loco": loco_forward, "cnn": cnn_forward, "mlp": mlp_forward, "loco_vis": loco_vis_forward,
-            "cnn_vis": cnn_vis_forward}
+            "cnn_vis": cnn_vis_forward, "loco_max": loco_max_forward, "loco_vis_max": loco_vis_max_forward}
 
 
 # ------------------------------------------------------------------------------------------ Gaussian head

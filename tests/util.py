@@ -34,6 +34,10 @@ CASES = {
     # with the config/mpc_vision_only/{locotransformer,baseline}/thin-goal.json hyper-parameters): the observation row is the depth stack alone (S = 0)
     "loco_vis": dict(kind="loco_vis", S=0, A=6, seed=5, B=32, enc=[], head=[256, 256], layers=2, ff=256),
     "cnn_vis": dict(kind="cnn_vis", S=0, A=6, seed=6, B=32, enc=[], head=[256, 256]),
+    # max_pool=True (nets.py:1022-1030, 884-889; no shipped config sets it): the depth tokens pooled by max — on the
+    # layer-by-layer kernels (pool_fwd / pool_bwd with the arg-max mask)
+    "loco_max": dict(kind="loco_max", S=84, A=6, seed=12, B=32, enc=[256, 256], head=[256, 256], layers=2, ff=256),
+    "loco_vis_max": dict(kind="loco_vis_max", S=0, A=6, seed=13, B=32, enc=[], head=[256, 256], layers=2, ff=256),
     # the minibatch bench.py times (BASELINE configs[2] / configs[1], B = 1024): 4 samples per persistent block in the fused
     # conv backward (register-resident dW carried across samples), 256 layer blocks of 4 samples
     "loco_b1024": dict(kind="loco", S=93, A=6, seed=7, B=1024, enc=[256, 256], head=[256, 256], layers=2, ff=256),

@@ -223,8 +223,9 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
 }
 
 // --------------------------------------------------------------------------------- token pooling
-// [state token | mean of the 16 depth tokens] -> [n][128]  (torchrl/networks/nets.py:1015-1021,1034)
-__global__ __launch_bounds__(128) void pool_fwd_kernel(const float* __restrict__ x, int n, float* __restrict__ pooled) {
+// [state token | mean of the 16 depth tokens] -> [n][128]  (torchrl/networks/nets.py:1015-1021,1034); mx: the max over the
+// depth tokens instead (max_pool=True, nets.py:1022-1023: `.max(dim=0)[0]`)
+__global__ __launch_bounds__(128) void pool_fwd_kernel(const float* __restrict__ x, int n, float* __restrict__ pooled, int mx) {
   const int b = blockIdx.x, t = threadIdx.x;
   if (b >= n) return;
   const float* xb = x + (int64_t)b * NTOK * TD;
@@ -232,40 +233,69 @@ __global__ __launch_bounds__(128) void pool_fwd_kernel(const float* __restrict__
   if (t < TD) o = xb[t];
   else {
     const int d = t - TD;
-    float s = 0.f;
+    float s = mx ? -INFINITY : 0.f;
 #pragma unroll
-    for (int i = 1; i < NTOK; ++i) s += xb[i * TD + d];
-    o = s * (1.f / 16.f);
+    for (int i = 1; i < NTOK; ++i) s = mx ? fmaxf(s, xb[i * TD + d]) : s + xb[i * TD + d];
+    o = mx ? s : s * (1.f / 16.f);
   }
   pooled[(int64_t)b * 2 * TD + t] = o;
 }
-__global__ __launch_bounds__(64) void pool_bwd_kernel(const float* __restrict__ dpooled, int n, float* __restrict__ dx) {
+// mx: the gradient of a max goes to the (first) token that attained it (torch.max(dim) backward), found again from the
+// layer stack's output rows x
+__global__ __launch_bounds__(64) void pool_bwd_kernel(const float* __restrict__ dpooled, int n, float* __restrict__ dx,
+                                                      const float* __restrict__ x, int mx) {
   const int b = blockIdx.x, d = threadIdx.x;
   if (b >= n) return;
   const float ds = dpooled[(int64_t)b * 2 * TD + d];
-  const float dm = dpooled[(int64_t)b * 2 * TD + TD + d] * (1.f / 16.f);
+  const float dg = dpooled[(int64_t)b * 2 * TD + TD + d];
   float* o = dx + (int64_t)b * NTOK * TD;
   o[d] = ds;
+  if (!mx) {
+    const float dm = dg * (1.f / 16.f);
 #pragma unroll
-  for (int i = 1; i < NTOK; ++i) o[i * TD + d] = dm;
+    for (int i = 1; i < NTOK; ++i) o[i * TD + d] = dm;
+    return;
+  }
+  const float* xb = x + (int64_t)b * NTOK * TD;
+  int arg = 1;
+  float best = xb[TD + d];
+  for (int i = 2; i < NTOK; ++i) {
+    const float v = xb[i * TD + d];
+    if (v > best) { best = v; arg = i; }
+  }
+  for (int i = 1; i < NTOK; ++i) o[i * TD + d] = i == arg ? dg : 0.f;
 }
 
 // vision-only Transformer (torchrl/networks/nets.py:884-889: out[0 : 1 + 16].mean(dim=0) over a 16-token sequence is the
-// mean of all tokens) -> [n][64]
-__global__ __launch_bounds__(64) void pool_all_fwd_kernel(const float* __restrict__ x, int n, int ntok, float* __restrict__ pooled) {
+// mean of all tokens; max_pool=True: their max) -> [n][64]
+__global__ __launch_bounds__(64) void pool_all_fwd_kernel(const float* __restrict__ x, int n, int ntok, float* __restrict__ pooled,
+                                                          int mx) {
   const int b = blockIdx.x, d = threadIdx.x;
   if (b >= n) return;
   const float* xb = x + (int64_t)b * ntok * TD;
-  float s = 0.f;
-  for (int i = 0; i < ntok; ++i) s += xb[i * TD + d];
-  pooled[(int64_t)b * TD + d] = s * (1.f / (float)ntok);
+  float s = mx ? -INFINITY : 0.f;
+  for (int i = 0; i < ntok; ++i) s = mx ? fmaxf(s, xb[i * TD + d]) : s + xb[i * TD + d];
+  pooled[(int64_t)b * TD + d] = mx ? s : s * (1.f / (float)ntok);
 }
-__global__ __launch_bounds__(64) void pool_all_bwd_kernel(const float* __restrict__ dpooled, int n, int ntok, float* __restrict__ dx) {
+__global__ __launch_bounds__(64) void pool_all_bwd_kernel(const float* __restrict__ dpooled, int n, int ntok, float* __restrict__ dx,
+                                                          const float* __restrict__ x, int mx) {
   const int b = blockIdx.x, d = threadIdx.x;
   if (b >= n) return;
-  const float dm = dpooled[(int64_t)b * TD + d] * (1.f / (float)ntok);
+  const float dg = dpooled[(int64_t)b * TD + d];
   float* o = dx + (int64_t)b * ntok * TD;
-  for (int i = 0; i < ntok; ++i) o[i * TD + d] = dm;
+  if (!mx) {
+    const float dm = dg * (1.f / (float)ntok);
+    for (int i = 0; i < ntok; ++i) o[i * TD + d] = dm;
+    return;
+  }
+  const float* xb = x + (int64_t)b * ntok * TD;
+  int arg = 0;
+  float best = xb[d];
+  for (int i = 1; i < ntok; ++i) {
+    const float v = xb[i * TD + d];
+    if (v > best) { best = v; arg = i; }
+  }
+  for (int i = 0; i < ntok; ++i) o[i * TD + d] = i == arg ? dg : 0.f;
 }
 
 // --------------------------------------------------------------------------------- rollout step (actor)
@@ -453,6 +483,9 @@ __global__ __launch_bounds__(256) void comm_check_kernel(const float* __restrict
   if (mine) atomicAdd(bad, mine);
 }
 
+// (per-statement contraction for the loss rows: the statistics block and the blocks that run the heads' chain beside it
+// evaluate the same row in different kernels / instantiations and must produce the same bits — see csrc/wps.h)
+#pragma clang fp contract(on)
 // nn.MSELoss()(values, est_rets) and its gradient (ppo.py:94-123; clipped_value_loss=False path, and the
 // clipped variant of ppo.py:105-112 when clip > 0). values is the critic output [n][OUT_LD], column 0.
 // One row: loss term l and d(loss)/d(value) g. (Shared by the statistics block and by the blocks that run the heads'
@@ -640,6 +673,7 @@ __device__ __forceinline__ void actor_loss_body(const ActorArgs& p) {
   }
 }
 __global__ __launch_bounds__(1024) void actor_loss_kernel(ActorArgs p) { actor_loss_body(p); }
+#pragma clang fp contract(fast)
 
 // Gaussian head post-processing for the policy API (continuous_policy.py:85-146,486-492): from the padded
 // mean [n][OUT_LD] and logstd [A] produce contiguous mean/std [n][A], clamped log_std [A], ent [n] and, when

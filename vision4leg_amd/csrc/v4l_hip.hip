@@ -965,7 +965,7 @@ bool v4l_net::wps_layers() const {
 }
 bool v4l_net::wps_vis() const {
   const v4l_net_cfg& c = cfg;
-  return c.kind == V4L_NET_LOCO_VIS && c.ff_dim == 256 && c.n_layers == 2 && c.n_head_hidden == 2 && c.head_hidden[0] == 256 &&
+  return c.kind == V4L_NET_LOCO_VIS && !c.max_pool && c.ff_dim == 256 && c.n_layers == 2 && c.n_head_hidden == 2 && c.head_hidden[0] == 256 &&
          c.head_hidden[1] == 256 && c.out_dim <= OUT_LD && layers[0].inproj.pkp >= 0 && head[0].pko >= 0 &&
          getenv("V4L_NO_WPS_LAYERS") == nullptr && getenv("V4L_NO_FUSED_LAYER") == nullptr;
 }
@@ -978,7 +978,7 @@ bool v4l_net::wps_bwd_plain() const {
   if (c.kind != V4L_NET_LOCO) return false;
   const bool fused_bwd = fused_layers();
   const bool fused_head = fused_bwd && c.n_layers >= 1 && c.n_head_hidden == 2 && c.head_hidden[0] == 256 &&
-                          c.head_hidden[1] == 256 && getenv("V4L_NO_FUSED_HEAD_BWD") == nullptr;
+                          c.head_hidden[1] == 256 && !c.max_pool && getenv("V4L_NO_FUSED_HEAD_BWD") == nullptr;
   const bool fused_tail = fused_bwd && c.n_layers >= 1 && c.n_enc_hidden == 2 && c.enc_hidden[0] == 256 &&
                           c.enc_hidden[1] == 256 && getenv("V4L_NO_FUSED_TAIL_BWD") == nullptr;
   return fused_bwd && fused_head && fused_tail && c.n_layers == 2 && getenv("V4L_NO_LAYER_STACK") == nullptr && wps_layers();
@@ -1266,7 +1266,7 @@ int v4l_net::forward_t(const float* state, const T* image, const int* rowidx, in
     const bool fused_layers = this->fused_layers();
     // the last layer's blocks also run the pooled heads of their samples when the head stack has the shipped shape
     const bool fused_head = fused_layers && c.n_layers >= 1 && nh == 2 && c.head_hidden[0] == 256 && c.head_hidden[1] == 256 &&
-                            c.out_dim <= OUT_LD && getenv("V4L_NO_FUSED_HEAD") == nullptr;
+                            c.out_dim <= OUT_LD && !c.max_pool && getenv("V4L_NO_FUSED_HEAD") == nullptr;
     // both layers + the heads in ONE launch when the stack is the shipped two layers (the token rows stay in LDS between
     // the layers); otherwise one launch per TransformerEncoderLayer. 2 or 4 samples per block, saving what backward_t reads.
     const bool stack_ok = getenv("V4L_NO_LAYER_STACK") == nullptr;  // (read per call: tests switch it)
@@ -1424,10 +1424,11 @@ int v4l_net::forward_t(const float* state, const T* image, const int* rowidx, in
     }
     g_op = "pool";
     if (c.kind == V4L_NET_LOCO_VIS) {
-      V4L_KLAUNCH("pool_fwd", 0, s, pool_all_fwd_kernel, dim3(n), dim3(64), 0, s, ws + L.x[c.n_layers], n, ntok, ws + L.pooled);
+      V4L_KLAUNCH("pool_fwd", 0, s, pool_all_fwd_kernel, dim3(n), dim3(64), 0, s, ws + L.x[c.n_layers], n, ntok, ws + L.pooled,
+                  c.max_pool);
       head_in = dense(ws + L.pooled, TD, n, TD);
     } else {
-      V4L_KLAUNCH("pool_fwd", 0, s, pool_fwd_kernel, dim3(n), dim3(128), 0, s, ws + L.x[c.n_layers], n, ws + L.pooled);
+      V4L_KLAUNCH("pool_fwd", 0, s, pool_fwd_kernel, dim3(n), dim3(128), 0, s, ws + L.x[c.n_layers], n, ws + L.pooled, c.max_pool);
       head_in = dense(ws + L.pooled, 2 * TD, n, 2 * TD);
     }
     V4L_LAUNCH_CHECK();
@@ -1523,7 +1524,7 @@ int v4l_net::backward_t(const float* state, const T* image, const int* rowidx, i
   const bool fused_bwd = fused_layers();  // forward and backward switch together: they share the T-typed saves
   // the last layer's launch starts from dout (heads + un-pool), layer 0's launch continues into the encoder MLP / up-conv
   const bool fused_head = fused_bwd && c.n_layers >= 1 && nh == 2 && c.head_hidden[0] == 256 && c.head_hidden[1] == 256 &&
-                          getenv("V4L_NO_FUSED_HEAD_BWD") == nullptr;
+                          !c.max_pool && getenv("V4L_NO_FUSED_HEAD_BWD") == nullptr;
   const bool fused_tail = fused_bwd && c.n_layers >= 1 && ne == 2 && c.enc_hidden[0] == 256 && c.enc_hidden[1] == 256 &&
                           getenv("V4L_NO_FUSED_TAIL_BWD") == nullptr;
   // vision-only Transformer on the wave-per-sample kernels (17-row stride, dummy row 0: csrc/wps.h); the forward took the same path
@@ -1540,9 +1541,11 @@ int v4l_net::backward_t(const float* state, const T* image, const int* rowidx, i
       return rc;
     g_op = "pool";
     if (vis)
-      V4L_KLAUNCH("pool_bwd", 0, s, pool_all_bwd_kernel, dim3(n), dim3(64), 0, s, ws + L.dpool, n, ntok, ws + L.dxl[c.n_layers]);
+      V4L_KLAUNCH("pool_bwd", 0, s, pool_all_bwd_kernel, dim3(n), dim3(64), 0, s, ws + L.dpool, n, ntok, ws + L.dxl[c.n_layers],
+                  ws + L.x[c.n_layers], c.max_pool);
     else
-      V4L_KLAUNCH("pool_bwd", 0, s, pool_bwd_kernel, dim3(n), dim3(64), 0, s, ws + L.dpool, n, ws + L.dxl[c.n_layers]);
+      V4L_KLAUNCH("pool_bwd", 0, s, pool_bwd_kernel, dim3(n), dim3(64), 0, s, ws + L.dpool, n, ws + L.dxl[c.n_layers],
+                  ws + L.x[c.n_layers], c.max_pool);
     V4L_LAUNCH_CHECK();
   }
   const int lnb = std::min(cdiv(R, 16), 128);
@@ -1885,7 +1888,7 @@ static bool actor_fusable(const v4l_actor* a) {
     return c.kind == V4L_NET_LOCO && c.n_enc_hidden == 2 && c.enc_hidden[0] == 256 && c.enc_hidden[1] == 256 && trunk &&
            c.state_dim <= 128;
   };
-  return ok(p) && ok(v) && p.n_layers == 2 && v.n_layers == 2 && a->E <= 64 && a->pf->head.size() == 3 &&
+  return ok(p) && ok(v) && !p.max_pool && !v.max_pool && p.n_layers == 2 && v.n_layers == 2 && a->E <= 64 && a->pf->head.size() == 3 &&
          a->pf->head[0].pkf >= 0 && a->vf->head[0].pkf >= 0 && getenv("V4L_NO_FUSED_ACTOR") == nullptr;
 }
 

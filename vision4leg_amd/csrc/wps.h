@@ -32,6 +32,14 @@
 #pragma once
 #include "bwd.h"
 
+// Floating-point contraction inside this file: per source statement only (a * b + c written as one expression is an FMA, a
+// product and a sum in different statements are not fused). HIP's default ("fast") lets the optimiser fuse across statements
+// wherever it sees fit, and it decides differently in different template instantiations of the same function — round 4 added
+// instantiations of wps_layer_bwd_kernel without the heads / proprio chains and their layer-0 input gradients came out a last
+// bit apart from the others' (3.7e-9 of the tensor: the tapped-vs-untapped and forked-vs-serial bit-equality tests caught it).
+// With "on" every instantiation performs the same fp32 operations.
+#pragma clang fp contract(on)
+
 namespace v4l {
 
 constexpr int WPS_WPB = 4;  // waves = samples per block
@@ -901,10 +909,13 @@ template <typename T, int MT> struct RowsChainLds {
   static constexpr size_t dt_b = (size_t)MT * 16 * LDX * 4, dh_b = (size_t)MT * 16 * LDF * sizeof(T);
   static constexpr size_t bytes2 = dt_b + dh_b, bytes3 = dt_b + 2 * dh_b;  // two- / three-stage chain
 };
-// dt: LDS [16 MT][LDX] fp32 input rows (zero beyond the chain's input width and for rows >= n), filled and synchronised by the
-// caller; dha / dhb: LDS [16 MT][LDF] T. NW waves per block; rows r0 .. r0 + 16 MT - 1.
-template <typename T, int NW, int MT>
-__device__ __forceinline__ void rows_chain(const RowsChain& c, const float* dt, T* dha, T* dhb, int r0, int n, int tid) {
+// dt: LDS [16 MT][LDX] fp32 input rows (zero beyond the chain's input width and for rows >= n), filled AND synchronised by
+// fill_dt(), which runs after the first weight fragments and ReLU masks have been requested (they arrive while the rows are
+// being computed: a row of the loss gradient is itself two dependent loads deep); dha / dhb: LDS [16 MT][LDF] T. NW waves per
+// block; rows r0 .. r0 + 16 MT - 1.
+// EARLY_B: also the second stage's first fragments before fill_dt() (not when fill_dt itself needs most of the registers)
+template <typename T, int NW, int MT, bool EARLY_B, class Fill>
+__device__ __forceinline__ void rows_chain(const RowsChain& c, const float* dt, T* dha, T* dhb, int r0, int n, int tid, Fill&& fill_dt) {
   constexpr int LDX = RowsChainLds<T, MT>::LDX, LDF = RowsChainLds<T, MT>::LDF;
   constexpr int NTW = 16 / NW;  // column tiles of a 256-wide stage per wave
   static_assert(NW == 4 || NW == 8 || NW == 16, "rows_chain: 4, 8 or 16 waves");
@@ -913,9 +924,22 @@ __device__ __forceinline__ void rows_chain(const RowsChain& c, const float* dt, 
 #pragma unroll
   for (int j = 0; j < NTW; ++j) nt[j] = wave * NTW + j;
   GemmRing<T, NTW, 2> ring_a = gemm_prefetch<T, NTW, 2>((const T*)c.wa, 64, nt, lane);
-  GemmRing<T, NTW, 8> ring_b = gemm_prefetch<T, NTW, 8>((const T*)c.wb, 256, nt, lane);
+  GemmRing<T, NTW, 8> ring_b;
+  if constexpr (EARLY_B) ring_b = gemm_prefetch<T, NTW, 8>((const T*)c.wb, 256, nt, lane);
+  float4 mk[MT][NTW];
+  auto load_masks = [&](const float* __restrict__ m) {  // unconditional loads from clamped rows
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      const int row = min(r0 + mt * 16 + fr, n - 1);
+#pragma unroll
+      for (int j = 0; j < NTW; ++j) mk[mt][j] = *reinterpret_cast<const float4*>(m + (int64_t)row * 256 + nt[j] * 16 + qr);
+    }
+  };
+  load_masks(c.ma);
+  fill_dt();
+  if constexpr (!EARLY_B) ring_b = gemm_prefetch<T, NTW, 8>((const T*)c.wb, 256, nt, lane);
   f32x4 acc[MT][NTW];
-  auto masked = [&](const float* __restrict__ m, T* dst, float* __restrict__ save) {  // ReLU mask from the saved activation
+  auto masked = [&](T* dst, float* __restrict__ save) {  // ReLU mask from the saved activation
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
       const int row = r0 + mt * 16 + fr;
@@ -923,9 +947,9 @@ __device__ __forceinline__ void rows_chain(const RowsChain& c, const float* dt, 
 #pragma unroll
       for (int j = 0; j < NTW; ++j) {
         const int n4 = nt[j] * 16 + qr;
-        const float4 mk = *reinterpret_cast<const float4*>(m + (int64_t)(ok ? row : 0) * 256 + n4);
-        const float d0 = mk.x > 0.f ? acc[mt][j][0] : 0.f, d1 = mk.y > 0.f ? acc[mt][j][1] : 0.f;
-        const float d2 = mk.z > 0.f ? acc[mt][j][2] : 0.f, d3 = mk.w > 0.f ? acc[mt][j][3] : 0.f;
+        const float4 m = mk[mt][j];
+        const float d0 = m.x > 0.f ? acc[mt][j][0] : 0.f, d1 = m.y > 0.f ? acc[mt][j][1] : 0.f;
+        const float d2 = m.z > 0.f ? acc[mt][j][2] : 0.f, d3 = m.w > 0.f ? acc[mt][j][3] : 0.f;
         if (dst != nullptr) st4(dst + (mt * 16 + fr) * LDF + n4, d0, d1, d2, d3);
         if (ok) st4(save + (int64_t)row * 256 + n4, d0, d1, d2, d3);
       }
@@ -933,22 +957,25 @@ __device__ __forceinline__ void rows_chain(const RowsChain& c, const float* dt, 
   };
   zero_acc(acc);
   block_gemm<T, MT, NTW, 2>(acc, dt, LDX, (const T*)c.wa, 64, nt, lane, ring_a);
-  masked(c.ma, dha, c.oa);
+  masked(dha, c.oa);
+  load_masks(c.mb);
   __syncthreads();
   zero_acc(acc);
   block_gemm<T, MT, NTW, 8>(acc, dha, LDF, (const T*)c.wb, 256, nt, lane, ring_b);
   const bool three = c.wc != nullptr;  // block-uniform
-  masked(c.mb, three ? dhb : (T*)nullptr, c.ob);
+  constexpr int NT3 = NW >= 8 ? 1 : 8 / NW;  // the 128-wide third stage: 8 column tiles
+  int nt3[NT3];
+#pragma unroll
+  for (int j = 0; j < NT3; ++j) nt3[j] = min(wave * NT3 + j, 7);
+  GemmRing<T, NT3, 8> ring_c;
+  if (three) ring_c = gemm_prefetch<T, NT3, 8>((const T*)c.wc, 256, nt3, lane);  // ahead of this stage's global stores
+  masked(three ? dhb : (T*)nullptr, c.ob);
   if (!three) return;
   __syncthreads();
-  constexpr int NT3 = NW >= 8 ? 1 : 8 / NW;  // the 128-wide third stage: 8 column tiles
   if (wave * NT3 < 8) {
-    int nt3[NT3];
-#pragma unroll
-    for (int j = 0; j < NT3; ++j) nt3[j] = wave * NT3 + j;
     f32x4 a3[MT][NT3];
     zero_acc(a3);
-    block_gemm<T, MT, NT3, 8>(a3, dhb, LDF, (const T*)c.wc, 256, nt3, lane);
+    block_gemm<T, MT, NT3, 8>(a3, dhb, LDF, (const T*)c.wc, 256, nt3, lane, ring_c);
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
       const int row = r0 + mt * 16 + fr;
@@ -973,33 +1000,34 @@ __device__ __forceinline__ void tok0_chain_block(const BwdTail& tl, const float*
   typedef RowsChainLds<T, MT> LY;
   float* dt = reinterpret_cast<float*>(smem);
   T* dh = reinterpret_cast<T*>(smem + LY::dt_b);
-  for (int idx = tid; idx < MT * 16 * 16; idx += NW * 64) {
-    const int r = idx >> 4, c4 = (idx & 15) * 4, row = r0 + r;
-    const bool ok = row < n;
-    const int64_t o = (int64_t)(ok ? row : 0) * NTOK * TD + c4;
-    const float4 d = *reinterpret_cast<const float4*>(dx0 + o), x = *reinterpret_cast<const float4*>(tl.x0 + o);
-    *reinterpret_cast<float4*>(dt + r * LY::LDX + c4) =
-        ok ? float4{x.x > 0.f ? d.x : 0.f, x.y > 0.f ? d.y : 0.f, x.z > 0.f ? d.z : 0.f, x.w > 0.f ? d.w : 0.f}
-           : float4{0.f, 0.f, 0.f, 0.f};
-  }
-  __syncthreads();
   RowsChain c;
   c.wa = tl.wpt; c.wb = tl.wf2t; c.wc = nullptr;
   c.ma = tl.s_e1; c.mb = tl.s_e0; c.oa = tl.o_dhc; c.ob = tl.o_de0; c.oc = nullptr;
-  rows_chain<T, NW, MT>(c, dt, dh, (T*)nullptr, r0, n, tid);
+  rows_chain<T, NW, MT, true>(c, dt, dh, (T*)nullptr, r0, n, tid, [&]() {
+    for (int idx = tid; idx < MT * 16 * 16; idx += NW * 64) {
+      const int r = idx >> 4, c4 = (idx & 15) * 4, row = r0 + r;
+      const bool ok = row < n;
+      const int64_t o = (int64_t)(ok ? row : 0) * NTOK * TD + c4;
+      const float4 d = *reinterpret_cast<const float4*>(dx0 + o), x = *reinterpret_cast<const float4*>(tl.x0 + o);
+      *reinterpret_cast<float4*>(dt + r * LY::LDX + c4) =
+          ok ? float4{x.x > 0.f ? d.x : 0.f, x.y > 0.f ? d.y : 0.f, x.z > 0.f ? d.z : 0.f, x.w > 0.f ? d.w : 0.f}
+             : float4{0.f, 0.f, 0.f, 0.f};
+    }
+    __syncthreads();
+  });
 }
 
 // The loss launches with the heads' data-grad chain beside the statistics: block 0 = critic_loss_kernel / actor_loss_kernel
 // (csrc/elem.h: statistics, the loss gradient rows for the last linear's weight-grad, d log sigma); block 1 + b = rows
 // 16 MT b .. of the same loss gradient (recomputed from the row: critic_row / actor_row, the same bits) -> W2' -> dh1 -> W1' ->
 // dh0 -> W0' -> dpool, which the wave-per-sample backward (HEAD_IN = false) un-pools. Dynamic LDS: RowsChainLds<T, MT>::bytes3.
-template <typename T, int NWAVES>
-__device__ __forceinline__ void loss_heads_run(const RowsChain& hc, float* dt, int r0, int n, unsigned char* smem, int tid) {
+template <typename T, int NWAVES, bool EARLY_B, class Fill>
+__device__ __forceinline__ void loss_heads_run(const RowsChain& hc, float* dt, int r0, int n, unsigned char* smem, int tid, Fill&& fill) {
   constexpr int MT = RowsChainCfg<T>::MT;
   typedef RowsChainLds<T, MT> LY;
   T* dha = reinterpret_cast<T*>(smem + LY::dt_b);
   T* dhb = reinterpret_cast<T*>(smem + LY::dt_b + LY::dh_b);
-  rows_chain<T, NWAVES, MT>(hc, dt, dha, dhb, r0, n, tid);
+  rows_chain<T, NWAVES, MT, EARLY_B>(hc, dt, dha, dhb, r0, n, tid, fill);
 }
 template <typename T, int NWAVES>
 __global__ __launch_bounds__(NWAVES * 64) void critic_loss_heads_kernel(const float* __restrict__ values, const float* __restrict__ ret,
@@ -1015,18 +1043,19 @@ __global__ __launch_bounds__(NWAVES * 64) void critic_loss_heads_kernel(const fl
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   float* dt = reinterpret_cast<float*>(smem);
   const int tid = threadIdx.x, r0 = ((int)blockIdx.x - 1) * MT * 16;
-  for (int idx = tid; idx < MT * 16 * 16; idx += NWAVES * 64) {
-    const int r = idx >> 4, c4 = (idx & 15) * 4, i = r0 + r;
-    float g = 0.f;
-    if (c4 == 0 && i < n) {
-      const int slot = rowidx ? rowidx[i] : i;
-      float l;
-      critic_row(values[(int64_t)i * OUT_LD], ret[slot], clipped ? oldv[slot] : 0.f, clipped, clip, inv_n, l, g);
+  loss_heads_run<T, NWAVES, true>(hc, dt, r0, n, smem, tid, [&]() {
+    for (int idx = tid; idx < MT * 16 * 16; idx += NWAVES * 64) {
+      const int r = idx >> 4, c4 = (idx & 15) * 4, i = r0 + r;
+      float g = 0.f;
+      if (c4 == 0 && i < n) {
+        const int slot = rowidx ? rowidx[i] : i;
+        float l;
+        critic_row(values[(int64_t)i * OUT_LD], ret[slot], clipped ? oldv[slot] : 0.f, clipped, clip, inv_n, l, g);
+      }
+      *reinterpret_cast<float4*>(dt + r * LY::LDX + c4) = float4{g, 0.f, 0.f, 0.f};
     }
-    *reinterpret_cast<float4*>(dt + r * LY::LDX + c4) = float4{g, 0.f, 0.f, 0.f};
-  }
-  __syncthreads();
-  loss_heads_run<T, NWAVES>(hc, dt, r0, n, smem, tid);
+    __syncthreads();
+  });
 }
 template <typename T, int NWAVES>
 __global__ __launch_bounds__(NWAVES * 64) void actor_loss_heads_kernel(ActorArgs p, RowsChain hc) {
@@ -1039,19 +1068,20 @@ __global__ __launch_bounds__(NWAVES * 64) void actor_loss_heads_kernel(ActorArgs
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   float* dt = reinterpret_cast<float*>(smem);
   const int tid = threadIdx.x, r0 = ((int)blockIdx.x - 1) * MT * 16;
-  for (int idx = tid; idx < MT * 16 * 16; idx += NWAVES * 64)  // columns 8.. (and rows >= n) stay zero
-    *reinterpret_cast<float4*>(dt + (idx >> 4) * LY::LDX + (idx & 15) * 4) = float4{0.f, 0.f, 0.f, 0.f};
-  __syncthreads();
-  if (tid < MT * 16 && r0 + tid < p.n) {  // one thread per row: the row's d(loss)/d(mean), as block 0 files it in dmean
-    const ActorDims D = actor_dims(p);
-    const int i = r0 + tid, slot = p.rowidx ? p.rowidx[i] : i;
-    const ActorRow o = actor_row(p, D, i, slot, p.st[ST_ADV_MEAN], p.st[ST_ADV_STD]);
-    float4* drow = reinterpret_cast<float4*>(dt + tid * LY::LDX);
-    drow[0] = float4{o.dlp * o.dm[0], o.dlp * o.dm[1], o.dlp * o.dm[2], o.dlp * o.dm[3]};
-    drow[1] = float4{o.dlp * o.dm[4], o.dlp * o.dm[5], o.dlp * o.dm[6], o.dlp * o.dm[7]};
-  }
-  __syncthreads();
-  loss_heads_run<T, NWAVES>(hc, dt, r0, p.n, smem, tid);
+  loss_heads_run<T, NWAVES, false>(hc, dt, r0, p.n, smem, tid, [&]() {
+    for (int idx = tid; idx < MT * 16 * 16; idx += NWAVES * 64)  // columns 8.. (and rows >= n) stay zero
+      *reinterpret_cast<float4*>(dt + (idx >> 4) * LY::LDX + (idx & 15) * 4) = float4{0.f, 0.f, 0.f, 0.f};
+    __syncthreads();
+    if (tid < MT * 16 && r0 + tid < p.n) {  // one thread per row: the row's d(loss)/d(mean), as block 0 files it in dmean
+      const ActorDims D = actor_dims(p);
+      const int i = r0 + tid, slot = p.rowidx ? p.rowidx[i] : i;
+      const ActorRow o = actor_row(p, D, i, slot, p.st[ST_ADV_MEAN], p.st[ST_ADV_STD]);
+      float4* drow = reinterpret_cast<float4*>(dt + tid * LY::LDX);
+      drow[0] = float4{o.dlp * o.dm[0], o.dlp * o.dm[1], o.dlp * o.dm[2], o.dlp * o.dm[3]};
+      drow[1] = float4{o.dlp * o.dm[4], o.dlp * o.dm[5], o.dlp * o.dm[6], o.dlp * o.dm[7]};
+    }
+    __syncthreads();
+  });
 }
 
 // Backward of the transformer stack for WPS_WPB samples per block: pooled heads (cooperative, as bwd_layer_kernel's HEAD) ->
@@ -1448,3 +1478,5 @@ __global__ __launch_bounds__(256, 2) void wps_wgrad_kernel(WpsWg a) {  // (two w
 }
 
 }  // namespace v4l
+
+#pragma clang fp contract(fast)  // (the including translation unit's default again)

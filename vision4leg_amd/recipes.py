@@ -23,6 +23,9 @@ def build_nets(networks, policies, case):
     S, A, enc (encoder hidden_shapes), head (append_hidden_shapes) and, per kind, layers / ff / visual_dim."""
     S, A, kind = case["S"], case["A"], case["kind"]
     net = {"append_hidden_shapes": list(case["head"]), "base_type": networks.MLPBase}
+    if kind in ("loco_max", "loco_vis_max"):  # the same nets with max_pool=True (nets.py:1022-1030, 884-889)
+        net["max_pool"] = True
+        kind = kind[:-4]
     if kind == "loco":
         net["transformer_params"] = [[1, case["ff"]] for _ in range(case["layers"])]
         encoder = networks.LocoTransformerEncoder(in_channels=4, state_input_dim=S, hidden_shapes=list(case["enc"]),
