@@ -1342,7 +1342,7 @@ struct WpsWgLayer {
   float* slab[4];          // per matrix (in_proj, out_proj, linear1, linear2): [nsplit][N][K]
   float* bslab[4];         // [nsplit][N]
 };
-// chain_blocks > 0: the launch carries that many extra blocks (after the weight-grad ones) that run the proprio branch's
+// chain_blocks > 0: the launch carries that many extra blocks (ahead of the weight-grad ones) that run the proprio branch's
 // data-grad chain over RowsChainCfg<T>::MT_TOK0 * 16 rows each (tok0_chain_block; RowsChainLds<T, MT_TOK0>::bytes2 of dynamic LDS)
 struct WpsWg { WpsWgLayer l[2]; int n, nsplit, nlayers; int wg_blocks, chain_blocks; BwdTail tl; const float* dx0; };
 struct WpsRole { int mat, nt0, kt0, nrow0, kcol0, N, K, bias; };
@@ -1354,15 +1354,15 @@ __device__ __forceinline__ WpsRole wps_role(int r) {
   return WpsRole{3, WPS_T_DZ2, WPS_T_F + 4 * (r - 8), 0, 64 * (r - 8), 64, 256, r == 8};         // linear2: dz2 x f
 }
 template <typename T>
-__global__ __launch_bounds__(256, 2) void wps_wgrad_kernel(WpsWg a) {  // (two waves per SIMD: <= 256 registers, as before the chain role)
+__global__ __launch_bounds__(256) void wps_wgrad_kernel(WpsWg a) {
   typedef typename Frag<T>::type frag_t;
-  if (a.chain_blocks > 0 && (int)blockIdx.x >= a.wg_blocks) {  // (block-uniform)
+  if ((int)blockIdx.x < a.chain_blocks) {  // (block-uniform; the chain blocks lead the grid: theirs is the longest latency chain)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    tok0_chain_block<T, 4>(a.tl, a.dx0, a.n, ((int)blockIdx.x - a.wg_blocks) * RowsChainCfg<T>::MT_TOK0 * 16, smem, threadIdx.x);
+    tok0_chain_block<T, 4>(a.tl, a.dx0, a.n, (int)blockIdx.x * RowsChainCfg<T>::MT_TOK0 * 16, smem, threadIdx.x);
     return;
   }
   const int lane = threadIdx.x & 63, fr = lane & 15, g = lane >> 4;
-  const int job = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int job = ((int)blockIdx.x - a.chain_blocks) * 4 + (threadIdx.x >> 6);
   const int per_split = WPS_ROLES * a.nlayers;
   const int split = job / per_split;
   if (split >= a.nsplit) return;
