@@ -1136,8 +1136,8 @@ def test_epoch_device_buffer_equals_host_buffer(mode, device):
 @pytest.mark.parametrize("mode", MODES)
 @pytest.mark.parametrize("name", ["loco_s93", "loco_rag", "loco_b1024"])
 def test_external_row_chains_equal_in_kernel_chains(name, mode, device, monkeypatch):
-    """Round 4: the pooled heads' data-grad chain runs beside the loss statistics (critic_loss_heads_kernel /
-    actor_loss_heads_kernel) and the proprio branch's chain beside the layers' weight-grads (wps_wgrad_kernel), 32 - 64 rows per
+    """Round 4: the pooled heads' data-grad chain runs beside the loss statistics (actor_loss_heads_kernel by default;
+    critic_loss_heads_kernel on request) and the proprio branch's chain beside the layers' weight-grads (wps_wgrad_kernel), 32 - 64 rows per
     block, instead of inside wps_layer_bwd_kernel over the block's 4 samples (csrc/wps.h rows_chain). Same MFMA steps in the
     same k order per output element: two PPO updates must give bit-identical statistics and parameters either way (B = 64: the
     4-wave loss blocks, ragged 300 and 1024: the 16-wave ones)."""
@@ -1145,8 +1145,8 @@ def test_external_row_chains_equal_in_kernel_chains(name, mode, device, monkeypa
     from vision4leg_amd.torchrl.algo import PPO
     res = {}
     for variant, env in (("external", {}), ("in_kernel", {"V4L_WPS_HEAD_IN": "1", "V4L_WPS_TOK0_IN": "1"}),
-                         ("heads_only_external", {"V4L_WPS_TOK0_IN": "1"})):
-        for k in ("V4L_WPS_HEAD_IN", "V4L_WPS_TOK0_IN"):
+                         ("heads_only_external", {"V4L_WPS_TOK0_IN": "1"}), ("critic_heads_external_too", {"V4L_WPS_HEAD_EXT_CRITIC": "1"})):
+        for k in ("V4L_WPS_HEAD_IN", "V4L_WPS_TOK0_IN", "V4L_WPS_HEAD_EXT_CRITIC"):
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
             monkeypatch.setenv(k, v)
@@ -1163,7 +1163,7 @@ def test_external_row_chains_equal_in_kernel_chains(name, mode, device, monkeypa
         torch.cuda.synchronize()
         res[variant] = (infos, {k: v.detach().cpu().clone() for k, v in pf.state_dict().items()},
                         {k: v.detach().cpu().clone() for k, v in vf.state_dict().items()})
-    for other in ("in_kernel", "heads_only_external"):
+    for other in ("in_kernel", "heads_only_external", "critic_heads_external_too"):
         for u in range(2):
             for k in util.STAT_KEYS:
                 a, b = res["external"][0][u][k], res[other][0][u][k]

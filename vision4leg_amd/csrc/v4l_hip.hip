@@ -3021,9 +3021,14 @@ int v4l_trainer_critic_grads(v4l_trainer* tr, const v4l_rollout* ro, int n, cons
   const float inv_n = 1.f / ((float)n * (float)hp->world_size);
   g_op = "loss";
   {
-    // the heads' data-grad chain as extra blocks of the loss launch when the backward that follows is the wave-per-sample one
+    // The heads' data-grad chain as extra blocks of the loss launch (when the backward that follows is the wave-per-sample
+    // one) pays for the POLICY: its statistics block takes 17 us on its own, so the 21 us chain rides along almost for free
+    // and wps_layer_bwd_kernel loses its 10 us heads phase. The critic's statistics take 6.7 us: there the chain would cost
+    // more (21 us launch) than it saves — measured with tools/update_timeline.py, profiles/r4_update_timeline.txt — so the
+    // critic keeps the in-kernel heads unless V4L_WPS_HEAD_EXT_CRITIC=1.
     RowsChain hc;
-    const bool ext = vf->heads_ext(tr->ws, n, &hc) != 0;
+    const bool ext_critic = getenv("V4L_WPS_HEAD_EXT_CRITIC") != nullptr;  // (read per call: tests switch it)
+    const bool ext = ext_critic && vf->heads_ext(tr->ws, n, &hc) != 0;
     const dim3 blk(n >= 512 ? 1024 : 256);
     if (ext) {
       const bool bf = vf->cfg.compute == V4L_BF16, big = n >= 512;
