@@ -45,11 +45,17 @@
  *   V4L_ROLLOUT_DENSE_SPLIT   NatureCNN nets' rollout step: the dense layers as three launches instead of one launch with
  *                             device-side hand-overs (per call); V4L_ROLLOUT_CNN_OLD: the per-sample rollout_cnn_kernel
  *   V4L_ROLLOUT_WARM          L2 warm-up touches at the start of rollout_stack_kernel (measured: no effect)
+ *   V4L_ROLLOUT_XCD=0         rollout_stack_kernel on the (E, 2) grid instead of the 1-D grid that keeps one net per XCD half
+ *   V4L_WPS_HEAD_IN, V4L_WPS_TOK0_IN   the pooled heads' / the proprio branch's data-grad chain inside wps_layer_bwd_kernel (4 rows per
+ *                             block) instead of beside the loss statistics / the layers' weight-grads (32 - 64 rows per block);
+ *                             V4L_WPS_HEAD_EXT_CRITIC=1: the critic's heads beside its loss statistics too (per call)
  *   V4L_RCCL_LIB              path of the RCCL library to dlopen (default: librccl.so.1)
  *   V4L_ROCTX=1               roctx ranges (libroctx64 via dlopen) around every phase and launch call, labelled phase|op|kernel:
  *                             `rocprofv3 --marker-trace --kernel-trace` then shows the library's structure next to its kernels
  * Read by the Python shell, not by the library: V4L_COMPUTE=bf16|f32, V4L_GRAPH=0, V4L_DP_COMM=auto|torch|rccl,
- * V4L_FORCE_DP_PHASES, V4L_LIB (diagnostic builds).
+ * V4L_CAST_THREADS, V4L_COLLECT_SPLIT=0 (fp32 observation rows over PCIe instead of fp32 proprio + bf16 depth rows),
+ * V4L_FORCE_DP_PHASES, V4L_LIB (diagnostic builds). Everything here except COMPUTE / GRAPH / DP_COMM / CAST_THREADS / RCCL_LIB /
+ * TRACE / ROCTX is a DIAGNOSTIC switch: the Python shell warns once at load time when one is set (_lib.diagnostic_switches).
  */
 #ifndef V4L_HIP_H
 #define V4L_HIP_H

@@ -144,9 +144,24 @@ def exported_symbols():
   return sorted(_SIGS)
 
 
+# V4L_* variables that configure a run; every OTHER V4L_* variable is a diagnostic switch that swaps kernels or schedules
+# (include/v4l_hip.h lists them) — fine for A/B probes and the cross-check tests, a trap when one is left in a shell by accident
+_CONFIG_ENV = {"V4L_COMPUTE", "V4L_GRAPH", "V4L_DP_COMM", "V4L_CAST_THREADS", "V4L_RCCL_LIB", "V4L_TRACE", "V4L_ROCTX", "V4L_LIB"}
+
+
+def diagnostic_switches():
+  """The diagnostic V4L_* switches present in the environment right now (name -> value)."""
+  return {k: v for k, v in sorted(os.environ.items()) if k.startswith("V4L_") and k not in _CONFIG_ENV}
+
+
 def lib():
   global _lib
   if _lib is None:
+    active = diagnostic_switches()
+    if active:  # said once, when the library is loaded: a stray switch must not change kernels under a user silently
+      import warnings
+      warnings.warn("vision4leg_amd: diagnostic switches are set and change which kernels / schedules run: %s"
+                    % ", ".join("%s=%s" % kv for kv in active.items()), RuntimeWarning, stacklevel=2)
     if not os.path.exists(LIB_PATH):
       raise RuntimeError(
         "vision4leg_amd: %s is missing — build it with `python -c 'import __graft_entry__ as g; g.build()'` "
