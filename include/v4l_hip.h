@@ -100,6 +100,10 @@ typedef struct v4l_net_cfg {
   int n_head_hidden;   /* append_hidden_shapes (nets.py:35-50, 224-243, 973-992)                         */
   int head_hidden[V4L_MAX_HIDDEN];
   int has_logstd;      /* 1: Gaussian policy with a state-independent logstd parameter                   */
+  int tanh_action;     /* Gaussian policy with tanh_action=True (policies/distribution.py:5-80 TanhNormal,
+                          continuous_policy.py:85-146): action = tanh(mean + std * eps), log-prob of a stored action through
+                          atanh(action) with the -log(1 - a^2 + 1e-6) correction. The rollout step of such a policy runs on
+                          the layer-by-layer kernels (no shipped config sets it) */
   int max_pool;        /* V4L_NET_LOCO / V4L_NET_LOCO_VIS: token pooling by max instead of mean (max_pool=True,
                           nets.py:1022-1030, 884-889); runs on the layer-by-layer kernels (no shipped config sets it) */
 } v4l_net_cfg;
@@ -154,6 +158,12 @@ int v4l_net_backward(v4l_net* net, const float* state_dev, const void* image_dev
 int v4l_gauss_head(const float* meanp_dev, const float* logstd_dev, const float* acts_dev, int n, int A,
                    float* mean_dev, float* std_dev, float* logstd_c_dev, float* ent_dev, float* logp_dev,
                    void* stream);
+/* the same for a tanh_action policy (TanhNormal, policies/distribution.py:38-51): log_prob of the post-tanh actions acts_dev
+ * through z = log((1 + a) / (1 - a)) / 2 — or through pre_tanh_dev [n][A] when given (explore(return_log_probs=True) hands the
+ * pre-tanh draw over) — minus log(1 - a^2 + 1e-6) per dimension. mean / std / entropy are the Normal's, as in the reference. */
+int v4l_gauss_head_tanh(const float* out_dev, const float* logstd_dev, const float* acts_dev, const float* pre_tanh_dev, int n,
+                        int A, float* mean_dev, float* std_dev, float* logstd_clamped_dev, float* ent_dev, float* logp_dev,
+                        void* stream);
 /* column 0 of a padded head output -> contiguous [n] (vf(x) for the collector, collector/on_policy.py:99-100) */
 int v4l_col0(const float* src_dev, int n, float* dst_dev, void* stream);
 

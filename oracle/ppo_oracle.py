@@ -230,7 +230,9 @@ def loco_vis_max_forward(p, x, S=0, mode="f32", taps=None):
 
 
 FORWARDS = {"loco": loco_forward, "cnn": cnn_forward, "mlp": mlp_forward, "loco_vis": loco_vis_forward,
-            "cnn_vis": cnn_vis_forward, "loco_max": loco_max_forward, "loco_vis_max": loco_vis_max_forward}
+            "cnn_vis": cnn_vis_forward, "loco_max": loco_max_forward, "loco_vis_max": loco_vis_max_forward,
+            # tanh_action=True policies: the same nets, a TanhNormal head (PPOOracle reads the suffix)
+            "mlp_tanh": mlp_forward, "loco_tanh": loco_forward}
 
 
 # ------------------------------------------------------------------------------------------ Gaussian head
@@ -241,11 +243,17 @@ def gaussian(mean, logstd_param):
     return mean, std, log_std
 
 
-def log_prob_entropy(mean, std, actions):
+def log_prob_entropy(mean, std, actions, tanh_action=False):
     """Normal(mean,std).log_prob(a).sum(-1,keepdim) and .entropy().sum(-1,keepdim) (continuous_policy.py:127-146;
-    torch/distributions/normal.py)."""
+    torch/distributions/normal.py). tanh_action: TanhNormal.log_prob of the stored post-tanh actions
+    (policies/distribution.py:38-51): Normal.log_prob(log((1 + a) / (1 - a)) / 2) - log(1 - a * a + 1e-6); the entropy is
+    the Normal's (distribution.py:82-83)."""
     var = std ** 2
-    lp = -((actions - mean) ** 2) / (2 * var) - std.log() - math.log(math.sqrt(2 * math.pi))
+    corr = 0.0
+    if tanh_action:
+        corr = torch.log(1 - actions * actions + 1e-6)
+        actions = torch.log((1 + actions) / (1 - actions)) / 2
+    lp = -((actions - mean) ** 2) / (2 * var) - std.log() - math.log(math.sqrt(2 * math.pi)) - corr
     ent = 0.5 + 0.5 * math.log(2 * math.pi) + torch.log(std)
     return lp.sum(-1, keepdim=True), ent.sum(-1, keepdim=True)
 
@@ -322,6 +330,7 @@ class PPOOracle:
     def __init__(self, kind, pf, vf, target_pf, S, mode="f32", clip_para=0.2, entropy_coeff=0.005, max_norm=0.5,
                  clipped_value_loss=False):
         self.fwd = FORWARDS[kind]
+        self.tanh_action = kind.endswith("_tanh")  # policies built with tanh_action=True (TanhNormal head)
         self.pf, self.vf, self.tpf = pf, vf, target_pf
         self.S, self.mode = S, mode
         self.clip_para, self.entropy_coeff, self.max_norm = clip_para, entropy_coeff, max_norm
@@ -376,11 +385,11 @@ class PPOOracle:
             self.pf[k].requires_grad_(True)
         mean = self.fwd({k: v for k, v in self.pf.items() if k != "logstd"}, obs, self.S, self.mode)
         mean, std, log_std = gaussian(mean, self.pf["logstd"])
-        log_probs, ent = log_prob_entropy(mean, std, acts)
+        log_probs, ent = log_prob_entropy(mean, std, acts, self.tanh_action)
         with torch.no_grad():
             tmean = self.fwd({k: v for k, v in self.tpf.items() if k != "logstd"}, obs, self.S, self.mode)
             tmean, tstd, _ = gaussian(tmean, self.tpf["logstd"])
-            target_log_probs, _ = log_prob_entropy(tmean, tstd, acts)
+            target_log_probs, _ = log_prob_entropy(tmean, tstd, acts, self.tanh_action)
         ratio = torch.exp(log_probs - target_log_probs)
         s1 = ratio * advs
         s2 = torch.clamp(ratio, 1.0 - self.clip_para, 1.0 + self.clip_para) * advs

@@ -1171,3 +1171,46 @@ def test_external_row_chains_equal_in_kernel_chains(name, mode, device, monkeypa
         for i in (1, 2):
             for k, v in res["external"][i].items():
                 assert torch.equal(v, res[other][i][k]), (other, k)
+
+
+@pytest.mark.parametrize("name", ["mlp_tanh", "loco_tanh"])
+def test_tanh_policy_head(name, device):
+    """tanh_action=True policies (TanhNormal, reference policies/distribution.py:5-80, continuous_policy.py:62-146): eval_act =
+    tanh(mean); explore draws tanh(mean + std eps) and, asked for log-probs, evaluates them with the pre-tanh draw; update()'s
+    log-prob of STORED actions goes through atanh(action); the rollout step (RolloutActor on the layer-by-layer kernels) files
+    tanh actions and the log pi_old the update's target evaluation would compute for them."""
+    from vision4leg_amd.torchrl.policies import RolloutActor
+    case = util.CASES[name]
+    pf, vf = _build(case, "f32", device)
+    assert pf.tanh_action and pf.hip.cfg.tanh_action == 1 and vf.hip.cfg.tanh_action == 0
+    b = util.make_batch(case)
+    obs = torch.tensor(b["obs"], dtype=torch.float32, device=device)
+    mean, std, _ = pf(obs)
+    assert np.allclose(pf.eval_act(obs), torch.tanh(mean).cpu().numpy(), atol=1e-7)
+    torch.manual_seed(3)
+    out = pf.explore(obs, return_log_probs=True)
+    z, act = out["pre_tanh"], out["action"]
+    assert torch.allclose(act, torch.tanh(z)) and act.abs().max().item() < 1.0
+    want = (torch.distributions.Normal(mean, std).log_prob(z) - torch.log(1 - act * act + 1e-6)).sum(-1, keepdim=True)
+    assert torch.allclose(out["log_prob"], want, rtol=1e-5, atol=1e-5)
+    acts = torch.tensor(b["acts"], dtype=torch.float32, device=device)
+    up = pf.update(obs, acts)
+    lp_ref, ent_ref = orc.log_prob_entropy(mean.cpu(), std.cpu(), acts.cpu(), tanh_action=True)
+    assert torch.allclose(up["log_prob"].cpu(), lp_ref, rtol=1e-5, atol=1e-5) and torch.allclose(up["ent"].cpu(), ent_ref, atol=1e-6)
+    # rollout step: general kernels (the fused steps have no tanh epilogue), actions / stored log-probs per the reference
+    E = 8
+    actor = RolloutActor(pf, vf, E)
+    st, im = pf.hip.alloc_rollout(E, device)
+    acts_roll, vals, logp = torch.zeros(E, case["A"], device=device), torch.zeros(E, device=device), torch.zeros(E, device=device)
+    actor.attach((st, im, acts_roll, vals, logp))
+    actor.seek(0)
+    torch.manual_seed(11)
+    o = {k: v.clone() for k, v in actor.step(obs[:E]).items()}
+    torch.manual_seed(11)
+    eps = torch.randn(E, case["A"], device=device)
+    assert torch.allclose(o["action"], torch.tanh(o["mean"] + o["std"] * eps), atol=1e-6) and torch.equal(acts_roll, o["action"])
+    lp_step, _ = orc.log_prob_entropy(o["mean"].cpu(), o["std"].cpu(), o["action"].cpu(), tanh_action=True)
+    assert torch.allclose(logp.cpu(), lp_step.reshape(-1), rtol=1e-4, atol=1e-4)
+    assert torch.allclose(o["mean"], mean[:E], atol=1e-5)
+    det = actor.step(obs[:E], deterministic=True)["action"]
+    assert torch.allclose(det, torch.tanh(mean[:E]), atol=1e-5)

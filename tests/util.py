@@ -38,6 +38,10 @@ CASES = {
     # layer-by-layer kernels (pool_fwd / pool_bwd with the arg-max mask)
     "loco_max": dict(kind="loco_max", S=84, A=6, seed=12, B=32, enc=[256, 256], head=[256, 256], layers=2, ff=256),
     "loco_vis_max": dict(kind="loco_vis_max", S=0, A=6, seed=13, B=32, enc=[], head=[256, 256], layers=2, ff=256),
+    # tanh_action=True (TanhNormal head, policies/distribution.py:5-80; no shipped config sets it): the update's log-probs go
+    # through atanh(stored action) with the -log(1 - a^2 + 1e-6) correction; the rollout step on the layer-by-layer kernels
+    "mlp_tanh": dict(kind="mlp_tanh", S=93, A=6, seed=14, B=64, enc=[256, 256], head=[256, 256]),
+    "loco_tanh": dict(kind="loco_tanh", S=84, A=6, seed=15, B=32, enc=[256, 256], head=[256, 256], layers=2, ff=256),
     # the minibatch bench.py times (BASELINE configs[2] / configs[1], B = 1024): 4 samples per persistent block in the fused
     # conv backward (register-resident dW carried across samples), 256 layer blocks of 4 samples
     "loco_b1024": dict(kind="loco", S=93, A=6, seed=7, B=1024, enc=[256, 256], head=[256, 256], layers=2, ff=256),

@@ -34,7 +34,7 @@ class NetCfg(C.Structure):
     ("in_channels", C.c_int), ("img_hw", C.c_int), ("n_enc_hidden", C.c_int),
     ("enc_hidden", C.c_int * V4L_MAX_HIDDEN), ("visual_dim", C.c_int), ("token_dim", C.c_int),
     ("n_layers", C.c_int), ("ff_dim", C.c_int), ("n_head_hidden", C.c_int),
-    ("head_hidden", C.c_int * V4L_MAX_HIDDEN), ("has_logstd", C.c_int), ("max_pool", C.c_int),
+    ("head_hidden", C.c_int * V4L_MAX_HIDDEN), ("has_logstd", C.c_int), ("tanh_action", C.c_int), ("max_pool", C.c_int),
   ]
 
 
@@ -92,6 +92,7 @@ _SIGS = {
   "v4l_net_dout_ptr": (_P, [_P, _P, C.c_int]),
   "v4l_net_backward": (C.c_int, [_P, _P, _P, _P, C.c_int, _P, _P, _P]),
   "v4l_gauss_head": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, _P, _P, _P, _P, _P, _P]),
+  "v4l_gauss_head_tanh": (C.c_int, [_P, _P, _P, _P, C.c_int, C.c_int, _P, _P, _P, _P, _P, _P]),
   "v4l_col0": (C.c_int, [_P, C.c_int, _P, _P]),
   "v4l_gae": (C.c_int, [_P, _P, _P, _P, C.c_int, _P, C.c_int, C.c_int, C.c_double, C.c_double, C.c_int,
                         _P, _P, _P, _P, _P, _P]),

@@ -308,6 +308,12 @@ __global__ __launch_bounds__(256) void act_begin_kernel(const ActCtl* __restrict
   const long long t = c->t;
   for (int i = threadIdx.x; i < E; i += 256) rowidx[i] = (int)(t * E + i);
 }
+// TanhNormal (policies/distribution.py:5-80): the pre-tanh value of a stored action, `log((1 + a) / (1 - a)) / 2`, and the
+// per-dimension change-of-variables term `log(1 - a * a + epsilon)`, epsilon = 1e-6 — the reference's expressions
+constexpr float TANH_EPS = 1e-6f;
+__device__ __forceinline__ float tanh_pre(float a) { return logf((1.f + a) / (1.f - a)) / 2.f; }
+__device__ __forceinline__ float tanh_corr(float a) { return logf(1.f - a * a + TANH_EPS); }
+
 // GaussianContPolicyBase.explore (continuous_policy.py:85-125) + the value read-out of the collector
 // (collector/on_policy.py:95-100) for one env step: action = mean + std * eps (== Normal(mean,std).sample() given the
 // same standard-normal draws), entropy, value; also files action and value into the rollout arrays and advances t.
@@ -317,7 +323,7 @@ __global__ __launch_bounds__(256) void act_finish_kernel(ActCtl* c, const float*
                                                          float* __restrict__ acts_roll, float* __restrict__ values_roll,
                                                          float* __restrict__ logp_roll, float* __restrict__ action,
                                                          float* __restrict__ mean, float* __restrict__ stdv,
-                                                         float* __restrict__ ent, float* __restrict__ value) {
+                                                         float* __restrict__ ent, float* __restrict__ value, int tanh_action) {
   const long long t = c->t;
   for (int i = threadIdx.x; i < E; i += 256) {
     float e = 0.f, lp = 0.f;
@@ -326,15 +332,18 @@ __global__ __launch_bounds__(256) void act_finish_kernel(ActCtl* c, const float*
       const float sg = expf(ls);
       e += 0.5f + HALF_LOG_2PI + logf(sg);
       const float mu = meanp[(int64_t)i * OUT_LD + a];
-      const float act = fmaf(sg, eps[(int64_t)i * A + a], mu);
+      float act = fmaf(sg, eps[(int64_t)i * A + a], mu);
+      if (tanh_action) act = tanhf(act);  // TanhNormal.rsample (distribution.py:61-80); eps = 0: eval_act's tanh(mean)
       action[(int64_t)i * A + a] = act;
       mean[(int64_t)i * A + a] = mu;
       stdv[(int64_t)i * A + a] = sg;
       if (acts_roll != nullptr) acts_roll[(t * E + i) * A + a] = act;
       // log pi(a|s) of the acting policy, with the expression actor_loss_kernel uses for the frozen target policy:
-      // the policy that acts during an epoch IS that epoch's target policy (ppo.py:34 copies it before the updates)
-      const float d = act - mu;
+      // the policy that acts during an epoch IS that epoch's target policy (ppo.py:34 copies it before the updates).
+      // tanh policies: through the STORED action like target_pf.update(obs, actions) does (distribution.py:38-51)
+      const float d = (tanh_action ? tanh_pre(act) : act) - mu;
       lp += -(d * d) / (2.f * sg * sg) - logf(sg) - HALF_LOG_2PI;
+      if (tanh_action) lp -= tanh_corr(act);
     }
     ent[i] = e;
     const float v = valuep[(int64_t)i * OUT_LD];
@@ -541,6 +550,7 @@ struct ActorArgs {
   int n, A;
   float inv_n, clip, ent_coef;
   float *dmean, *dlogstd, *st;
+  int tanh_action;  // TanhNormal policies: log-probs of the stored (post-tanh) actions through atanh, distribution.py:38-51
 };
 struct ActorDims { float ls[8], sg[8], lsg[8], tls[8], tsg[8], tlsg[8]; float ent; };
 __device__ __forceinline__ ActorDims actor_dims(const ActorArgs& p) {
@@ -578,15 +588,17 @@ __device__ __forceinline__ ActorRow actor_row(const ActorArgs& p, const ActorDim
 #pragma unroll
   for (int a = 0; a < 8; ++a) {
     if (a < p.A) {
-      const float x = p.acts[(int64_t)slot * p.A + a];
+      const float act = p.acts[(int64_t)slot * p.A + a];
+      const float x = p.tanh_action ? tanh_pre(act) : act;
+      const float corr = p.tanh_action ? tanh_corr(act) : 0.f;
       const float d = x - mu[a];
       const float var = D.sg[a] * D.sg[a];
-      lp += -(d * d) / (2.f * var) - D.lsg[a] - HALF_LOG_2PI;
+      lp += -(d * d) / (2.f * var) - D.lsg[a] - HALF_LOG_2PI - corr;
       o.z2[a] = d * d / var;
       o.dm[a] = d / var;
       if (p.logp_old == nullptr) {
         const float dt = x - tmu[a];
-        lpo += -(dt * dt) / (2.f * D.tsg[a] * D.tsg[a]) - D.tlsg[a] - HALF_LOG_2PI;
+        lpo += -(dt * dt) / (2.f * D.tsg[a] * D.tsg[a]) - D.tlsg[a] - HALF_LOG_2PI - corr;
       }
     } else {
       o.z2[a] = 0.f; o.dm[a] = 0.f;
@@ -682,7 +694,8 @@ __global__ __launch_bounds__(256) void gauss_head_kernel(const float* __restrict
                                                          const float* __restrict__ acts, int n, int A,
                                                          float* __restrict__ mean, float* __restrict__ stdv,
                                                          float* __restrict__ logstd_c, float* __restrict__ ent,
-                                                         float* __restrict__ logp) {
+                                                         float* __restrict__ logp, int tanh_action = 0,
+                                                         const float* __restrict__ pre_tanh = nullptr) {
   const int i = blockIdx.x * 256 + threadIdx.x;
   float e = 0.f, lp = 0.f;
   for (int a = 0; a < A; ++a) {
@@ -695,8 +708,11 @@ __global__ __launch_bounds__(256) void gauss_head_kernel(const float* __restrict
       mean[(int64_t)i * A + a] = mu;
       stdv[(int64_t)i * A + a] = sg;
       if (acts != nullptr) {
-        const float d = acts[(int64_t)i * A + a] - mu;
+        const float act = acts[(int64_t)i * A + a];
+        const float x = !tanh_action ? act : (pre_tanh != nullptr ? pre_tanh[(int64_t)i * A + a] : tanh_pre(act));
+        const float d = x - mu;
         lp += -(d * d) / (2.f * sg * sg) - lsg - HALF_LOG_2PI;
+        if (tanh_action) lp -= tanh_corr(act);
       }
     }
   }

@@ -2552,7 +2552,18 @@ int v4l_gauss_head(const float* meanp_dev, const float* logstd_dev, const float*
               "v4l_gauss_head: bad argument");
   V4L_REQUIRE(acts_dev == nullptr || logp_dev != nullptr, "v4l_gauss_head: logp_dev is null");
   hipLaunchKernelGGL(gauss_head_kernel, dim3(cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, meanp_dev, logstd_dev,
-                     acts_dev, n, A, mean_dev, std_dev, logstd_c_dev, ent_dev, logp_dev);
+                     acts_dev, n, A, mean_dev, std_dev, logstd_c_dev, ent_dev, logp_dev, 0, (const float*)nullptr);
+  V4L_LAUNCH_CHECK();
+  return 0;
+}
+int v4l_gauss_head_tanh(const float* meanp_dev, const float* logstd_dev, const float* acts_dev, const float* pre_tanh_dev, int n,
+                        int A, float* mean_dev, float* std_dev, float* logstd_c_dev, float* ent_dev, float* logp_dev,
+                        void* stream) {
+  V4L_REQUIRE(meanp_dev && logstd_dev && mean_dev && std_dev && logstd_c_dev && ent_dev && n > 0 && A > 0 && A <= 8,
+              "v4l_gauss_head_tanh: bad argument");
+  V4L_REQUIRE(acts_dev == nullptr || logp_dev != nullptr, "v4l_gauss_head_tanh: logp_dev is null");
+  hipLaunchKernelGGL(gauss_head_kernel, dim3(cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, meanp_dev, logstd_dev,
+                     acts_dev, n, A, mean_dev, std_dev, logstd_c_dev, ent_dev, logp_dev, 1, pre_tanh_dev);
   V4L_LAUNCH_CHECK();
   return 0;
 }
@@ -2746,7 +2757,9 @@ static int run_actor_step(v4l_actor* a, const float* obs, const float* eps, floa
   const int E = a->E;
   int rc;
   V4L_REQUIRE(pf->bound && vf->bound, "v4l_actor_step: nets are not bound");
-  if (shared_encoder && actor_fusable_mlp(a) && pf->enc[0].Kp <= 128) {
+  // tanh_action policies (TanhNormal): the general step below — act_finish_kernel holds their sampling / log-prob epilogue
+  const bool fused_ok = shared_encoder && !pf->cfg.tanh_action;
+  if (fused_ok && actor_fusable_mlp(a) && pf->enc[0].Kp <= 128) {
     if (actor_mlp2(a))
       return run_actor_mlp2(a, obs, eps, state_roll, acts_roll, values_roll, logp_roll, action, mean, stdv, ent, value, s);
     if (pf->cfg.compute == V4L_BF16)
@@ -2754,17 +2767,17 @@ static int run_actor_step(v4l_actor* a, const float* obs, const float* eps, floa
                                          value, s);
     return run_actor_fused_mlp<float>(a, obs, eps, state_roll, acts_roll, values_roll, logp_roll, action, mean, stdv, ent, value, s);
   }
-  if (shared_encoder && actor_dense_cnn(a))
+  if (fused_ok && actor_dense_cnn(a))
     return run_actor_dense_cnn(a, obs, eps, state_roll, image_roll, acts_roll, values_roll, logp_roll, action, mean, stdv, ent,
                                value, s);
-  if (shared_encoder && actor_fusable_cnn(a) && pf->enc[0].Kp <= 128) {
+  if (fused_ok && actor_fusable_cnn(a) && pf->enc[0].Kp <= 128) {
     if (pf->cfg.compute == V4L_BF16)
       return run_actor_fused_cnn<__bf16>(a, obs, eps, state_roll, image_roll, acts_roll, values_roll, logp_roll, action, mean,
                                          stdv, ent, value, s);
     return run_actor_fused_cnn<float>(a, obs, eps, state_roll, image_roll, acts_roll, values_roll, logp_roll, action, mean, stdv,
                                       ent, value, s);
   }
-  if (shared_encoder && actor_fusable(a)) {
+  if (fused_ok && actor_fusable(a)) {
     if (pf->cfg.compute == V4L_BF16)
       return run_actor_fused<__bf16>(a, obs, eps, state_roll, image_roll, acts_roll, values_roll, logp_roll, action, mean,
                                      stdv, ent, value, s);
@@ -2817,7 +2830,7 @@ static int run_actor_step(v4l_actor* a, const float* obs, const float* eps, floa
   g_op = "sample";
   V4L_KLAUNCH("act_finish", 0, s, act_finish_kernel, dim3(1), dim3(256), 0, s, a->ctl, ws_pf + pf->layout(E).out,
               pf->p[pf->logstd], ws_vf + vf->layout(E).out, eps, E, pf->cfg.out_dim, acts_roll, values_roll, logp_roll, action,
-              mean, stdv, ent, value);
+              mean, stdv, ent, value, pf->cfg.tanh_action);
   V4L_LAUNCH_CHECK();
   return 0;
 }
@@ -2880,7 +2893,7 @@ static int actor_step_impl(v4l_actor* a, const float* obs_dev, const float* eps_
 // of run_actor_step)
 static bool actor_takes_split(const v4l_actor* a, int shared_encoder) {
   const v4l_net* pf = a->pf;
-  if (!shared_encoder || pf->cfg.compute != V4L_BF16 || pf->cfg.kind == V4L_NET_MLP) return false;
+  if (!shared_encoder || pf->cfg.tanh_action || pf->cfg.compute != V4L_BF16 || pf->cfg.kind == V4L_NET_MLP) return false;
   if (actor_dense_cnn(a)) return true;
   if (actor_fusable_cnn(a) && pf->enc[0].Kp <= 128) return false;  // the per-sample rollout_cnn_kernel reads fp32 rows
   if (!actor_fusable(a)) return false;
@@ -3127,6 +3140,7 @@ int v4l_trainer_actor_grads(v4l_trainer* tr, const v4l_rollout* ro, int n, const
     aa.logp_old = ro->logp_old_dev; aa.acts = ro->acts_dev; aa.adv = ro->advs_dev; aa.rowidx = rowidx;
     aa.n = n; aa.A = pf->cfg.out_dim; aa.inv_n = inv_n; aa.clip = hp->clip_para; aa.ent_coef = hp->entropy_coeff;
     aa.dmean = tr->ws + Lp.dout; aa.dlogstd = tr->g_pf + pf->params[pf->logstd].goff; aa.st = st;
+    aa.tanh_action = pf->cfg.tanh_action;
     RowsChain hc;
     const bool ext = pf->heads_ext(tr->ws, n, &hc) != 0;
     const dim3 blk(n >= 512 ? 1024 : 256);

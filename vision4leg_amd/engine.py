@@ -236,13 +236,13 @@ class HipNet:
     check(self.L.v4l_col0(_ptr(out), n, _ptr(v), _stream()), "v4l_col0")
     return v.view(n, 1)
 
-  def gaussian(self, obs, logstd, acts=None):
+  def gaussian(self, obs, logstd, acts=None, tanh_action=False):
     """Policy head: mean/std [n][A], clamped log_std [A], ent [n][1] and log_prob [n][1] of acts (optional)."""
     st, im, n = self.stage(obs)
     out = self.forward(st, im, n)
-    return self.gauss_head(out, logstd, n, acts)
+    return self.gauss_head(out, logstd, n, acts, tanh_action=tanh_action)
 
-  def gauss_head(self, out, logstd, n, acts=None):
+  def gauss_head(self, out, logstd, n, acts=None, tanh_action=False, pre_tanh=None):
     A, dev = self.out_dim, out.device
     mean = torch.empty(n, A, dtype=torch.float32, device=dev)
     std = torch.empty(n, A, dtype=torch.float32, device=dev)
@@ -252,8 +252,14 @@ class HipNet:
     if acts is not None:
       acts = acts.reshape(n, A).contiguous().float()
       logp = torch.empty(n, dtype=torch.float32, device=dev)
-    check(self.L.v4l_gauss_head(_ptr(out), _ptr(logstd), _ptr(acts), n, A, _ptr(mean), _ptr(std), _ptr(lsc),
-                                _ptr(ent), _ptr(logp), _stream()), "v4l_gauss_head")
+    if tanh_action:  # TanhNormal.log_prob (policies/distribution.py:38-51)
+      if pre_tanh is not None:
+        pre_tanh = pre_tanh.reshape(n, A).contiguous().float()
+      check(self.L.v4l_gauss_head_tanh(_ptr(out), _ptr(logstd), _ptr(acts), _ptr(pre_tanh), n, A, _ptr(mean), _ptr(std),
+                                       _ptr(lsc), _ptr(ent), _ptr(logp), _stream()), "v4l_gauss_head_tanh")
+    else:
+      check(self.L.v4l_gauss_head(_ptr(out), _ptr(logstd), _ptr(acts), n, A, _ptr(mean), _ptr(std), _ptr(lsc),
+                                  _ptr(ent), _ptr(logp), _stream()), "v4l_gauss_head")
     return mean, std, lsc, ent.view(n, 1), (logp.view(n, 1) if logp is not None else None)
 
 

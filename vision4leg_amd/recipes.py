@@ -15,7 +15,7 @@ IMG_ELEMS = 4 * 64 * 64  # depth stack of one observation row (vision4leg/envs/l
 
 def obs_dim(case):
     """Columns of one observation row [S proprio | 4*64*64 depth] (env_utils.py:27-51); the state-only net has no image."""
-    return case["S"] + (0 if case["kind"] == "mlp" else IMG_ELEMS)
+    return case["S"] + (0 if case["kind"].startswith("mlp") else IMG_ELEMS)
 
 
 def build_nets(networks, policies, case):
@@ -23,6 +23,10 @@ def build_nets(networks, policies, case):
     S, A, enc (encoder hidden_shapes), head (append_hidden_shapes) and, per kind, layers / ff / visual_dim."""
     S, A, kind = case["S"], case["A"], case["kind"]
     net = {"append_hidden_shapes": list(case["head"]), "base_type": networks.MLPBase}
+    pol = {}
+    if kind.endswith("_tanh"):  # the same nets with a TanhNormal policy head (tanh_action=True, continuous_policy.py:85-146)
+        pol["tanh_action"] = True
+        kind = kind[:-5]
     if kind in ("loco_max", "loco_vis_max"):  # the same nets with max_pool=True (nets.py:1022-1030, 884-889)
         net["max_pool"] = True
         kind = kind[:-4]
@@ -31,7 +35,7 @@ def build_nets(networks, policies, case):
         encoder = networks.LocoTransformerEncoder(in_channels=4, state_input_dim=S, hidden_shapes=list(case["enc"]),
                                                   visual_dim=256)
         pf = policies.GaussianContPolicyLocoTransformer(encoder=encoder, state_input_shape=S,
-                                                        visual_input_shape=(4, 64, 64), output_shape=A, **net)
+                                                        visual_input_shape=(4, 64, 64), output_shape=A, **net, **pol)
         vf = networks.LocoTransformer(encoder=encoder, state_input_shape=S, visual_input_shape=(4, 64, 64),
                                       output_shape=1, **net)
     elif kind == "cnn":
@@ -53,7 +57,7 @@ def build_nets(networks, policies, case):
         vf = networks.NatureEncoderProjNet(encoder=encoder, visual_input_shape=(4, 64, 64), output_shape=1, **net)
     else:
         net["hidden_shapes"] = list(case["enc"])
-        pf = policies.GaussianContPolicyBasicBias(input_shape=S, output_shape=A, **net)
+        pf = policies.GaussianContPolicyBasicBias(input_shape=S, output_shape=A, **net, **pol)
         vf = networks.Net(input_shape=(S,), output_shape=1, **net)
         vf.base = pf.base
     return pf, vf
@@ -62,7 +66,7 @@ def build_nets(networks, policies, case):
 def share_encoder(pf_params, vf_params, kind):
     """Make vf's name->tensor dict reference pf's tensor objects for the shared sub-module (encoder.* / base.*), the way the
     starters hand ONE encoder module to both nets (starter/ppo_locotransformer.py:79-100, ppo_state.py:104)."""
-    pre = "base." if kind == "mlp" else "encoder."
+    pre = "base." if kind.startswith("mlp") else "encoder."
     for k in vf_params:
         if k.startswith(pre):
             vf_params[k] = pf_params[k]
@@ -73,7 +77,7 @@ def obs_rows(rs, n, case):
     """n float64 observation rows in BASELINE.md section 3's distributions: proprio ~ clip(N(0,1), +-10) (the normaliser's
     clip, torchrl/env/base_wrapper.py:91-94), depth ~ clip(N(0,1), -2.5, 2.8) (the range of the depth normalisation)."""
     cols = [np.clip(rs.randn(n, case["S"]), -10, 10)]
-    if case["kind"] != "mlp":
+    if not case["kind"].startswith("mlp"):
         cols.append(np.clip(rs.randn(n, IMG_ELEMS), -2.5, 2.8))
     return np.concatenate(cols, axis=1)
 

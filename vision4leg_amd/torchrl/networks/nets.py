@@ -43,7 +43,9 @@ class _HipNetMixin:
     @property
     def hip(self):
         if self.__dict__.get("_hip") is None:
-            self.__dict__["_hip"] = HipNet(self, self._net_cfg())
+            cfg = self._net_cfg()
+            cfg.tanh_action = int(bool(getattr(self, "tanh_action", False)))  # Gaussian policies (continuous_policy.py)
+            self.__dict__["_hip"] = HipNet(self, cfg)
         return self.__dict__["_hip"]
 
     def mark_params_changed(self):

@@ -74,17 +74,14 @@ class GaussianContPolicyBase:
     """Mixin: needs `self.hip` (HipNet), `self.logstd`, `self.tanh_action`."""
 
     def _init_policy(self, output_shape, tanh_action, log_init):
-        if tanh_action:
-            raise NotImplementedError("vision4leg_amd: tanh_action=True (TanhNormal) is not on the HIP engine; "
-                                      "every shipped PPO config uses the plain Normal head")
         self.continuous = True
         self.logstd = nn.Parameter(torch.ones(output_shape) * np.log(log_init))
-        self.tanh_action = tanh_action
+        self.tanh_action = bool(tanh_action)  # TanhNormal head (policies/distribution.py:5-80); read by _net_cfg -> v4l_net_cfg
 
     def _gaussian(self, x, actions=None):
         lead = x.shape[:-1]
         x2 = x.reshape(-1, x.shape[-1])
-        mean, std, log_std, ent, logp = self.hip.gaussian(x2, self.logstd.data, actions)
+        mean, std, log_std, ent, logp = self.hip.gaussian(x2, self.logstd.data, actions, tanh_action=self.tanh_action)
         A = mean.shape[-1]
         mean, std = mean.view(*lead, A), std.view(*lead, A)
         ent = ent.view(*lead, 1)
@@ -98,20 +95,27 @@ class GaussianContPolicyBase:
 
     def eval_act(self, x):
         mean, _, _ = self.forward(x)
+        if self.tanh_action:  # continuous_policy.py:64-69
+            mean = torch.tanh(mean)
         return mean.squeeze(0).cpu().numpy()
 
     def explore(self, x, return_log_probs=False, return_pre_tanh=False):
         mean, std, log_std, ent, _ = self._gaussian(x)
         # == Normal(mean, std).sample(): torch.normal(mean, std) is randn * std + mean on the same generator;
         # spelled out it skips normal()'s `std >= 0` validation (a reduction + a device->host sync per step)
-        action = torch.addcmul(mean, std, torch.randn_like(mean))
+        z = torch.addcmul(mean, std, torch.randn_like(mean))
+        action = torch.tanh(z) if self.tanh_action else z  # TanhNormal.rsample (distribution.py:61-80)
         dic = {"mean": mean, "log_std": log_std, "std": std, "ent": ent}
+        if self.tanh_action and (return_log_probs or return_pre_tanh):
+            dic["pre_tanh"] = z.squeeze(0)
         if return_log_probs:
             A = mean.shape[-1]
             n = mean.numel() // A
             padded = torch.zeros(n, 16, dtype=torch.float32, device=mean.device)  # V4L_OUT_LD rows
             padded[:, :A] = mean.reshape(n, A)
-            *_, logp = self.hip.gauss_head(padded, self.logstd.data, n, action)
+            # tanh: dis.log_prob(action, pre_tanh_value=z) (continuous_policy.py:99-106) — the draw itself, not atanh(action)
+            *_, logp = self.hip.gauss_head(padded, self.logstd.data, n, action, tanh_action=self.tanh_action,
+                                           pre_tanh=z if self.tanh_action else None)
             dic["log_prob"] = logp.view(*mean.shape[:-1], 1)
         dic["action"] = action.squeeze(0)
         return dic
