@@ -1200,17 +1200,18 @@ def test_tanh_policy_head(name, device):
     # rollout step: general kernels (the fused steps have no tanh epilogue), actions / stored log-probs per the reference
     E = 8
     actor = RolloutActor(pf, vf, E)
-    st, im = pf.hip.alloc_rollout(E, device)
-    acts_roll, vals, logp = torch.zeros(E, case["A"], device=device), torch.zeros(E, device=device), torch.zeros(E, device=device)
+    st, im = pf.hip.alloc_rollout(2 * E, device)  # two env steps are filed below
+    acts_roll, vals, logp = (torch.zeros(2 * E, case["A"], device=device), torch.zeros(2 * E, device=device),
+                             torch.zeros(2 * E, device=device))
     actor.attach((st, im, acts_roll, vals, logp))
     actor.seek(0)
     torch.manual_seed(11)
     o = {k: v.clone() for k, v in actor.step(obs[:E]).items()}
     torch.manual_seed(11)
     eps = torch.randn(E, case["A"], device=device)
-    assert torch.allclose(o["action"], torch.tanh(o["mean"] + o["std"] * eps), atol=1e-6) and torch.equal(acts_roll, o["action"])
+    assert torch.allclose(o["action"], torch.tanh(o["mean"] + o["std"] * eps), atol=1e-6) and torch.equal(acts_roll[:E], o["action"])
     lp_step, _ = orc.log_prob_entropy(o["mean"].cpu(), o["std"].cpu(), o["action"].cpu(), tanh_action=True)
-    assert torch.allclose(logp.cpu(), lp_step.reshape(-1), rtol=1e-4, atol=1e-4)
+    assert torch.allclose(logp[:E].cpu(), lp_step.reshape(-1), rtol=1e-4, atol=1e-4)
     assert torch.allclose(o["mean"], mean[:E], atol=1e-5)
     det = actor.step(obs[:E], deterministic=True)["action"]
     assert torch.allclose(det, torch.tanh(mean[:E]), atol=1e-5)

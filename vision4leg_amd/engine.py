@@ -28,6 +28,43 @@ def _stream():
   return torch.cuda.current_stream().cuda_stream
 
 
+# ---- guard bands (V4L_GUARD=1, tests): every device buffer the library writes into is carved out of a larger allocation with
+# a canary-filled band on both sides; check_guards() reports any band a kernel wrote into. The kernels index HBM with
+# hand-computed offsets (53 of them) and device-side AddressSanitizer does not build for this library in finite time (DESIGN.md
+# section 5), so this is the GPU-side out-of-bounds WRITE check the test-suite runs.
+GUARD_BYTES = 64 * 1024
+_CANARY = 0xA5
+_guards = []
+
+
+def _buf(count, dtype, device, zero=False):
+  """A [count] device tensor of dtype; with V4L_GUARD=1 a view between two canary bands of GUARD_BYTES."""
+  count = int(count)
+  if os.environ.get("V4L_GUARD", "0") == "0":
+    return torch.zeros(count, dtype=dtype, device=device) if zero else torch.empty(count, dtype=dtype, device=device)
+  nbytes = count * torch.empty((), dtype=dtype).element_size()
+  pad = (-nbytes) % 256  # keeps the tail band 256-byte aligned
+  raw = torch.full((GUARD_BYTES + nbytes + pad + GUARD_BYTES,), _CANARY, dtype=torch.uint8, device=device)
+  view = raw[GUARD_BYTES:GUARD_BYTES + nbytes].view(dtype)
+  if zero:
+    view.zero_()
+  _guards.append((raw, nbytes))
+  return view
+
+
+def check_guards(reset=False):
+  """-> list of (buffer index, which band, first corrupted byte offset) for every canary band that was written into."""
+  bad = []
+  for i, (raw, nbytes) in enumerate(_guards):
+    for name, band in (("head", raw[:GUARD_BYTES]), ("tail", raw[GUARD_BYTES + nbytes:])):
+      hit = (band != _CANARY).nonzero()
+      if hit.numel():
+        bad.append((i, name, int(hit[0].item())))
+  if reset:
+    _guards.clear()
+  return bad
+
+
 def _ptr(t):
   return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
 
@@ -118,8 +155,8 @@ class HipNet:
     if ptrs != self._ptrs:
       self.device = ts[0].device
       with torch.cuda.device(self.device):
-        self._packed = torch.empty(self.L.v4l_net_packed_bytes(self.h), dtype=torch.uint8, device=self.device)
-        self._table = torch.empty(self.L.v4l_net_table_bytes(self.h), dtype=torch.uint8, device=self.device)
+        self._packed = _buf(self.L.v4l_net_packed_bytes(self.h), torch.uint8, self.device)
+        self._table = _buf(self.L.v4l_net_table_bytes(self.h), torch.uint8, self.device)
         arr = (C.c_void_p * len(ptrs))(*ptrs)
         check(self.L.v4l_net_bind(self.h, arr, _ptr(self._packed), _ptr(self._table), _stream()), "v4l_net_bind")
       self._ptrs = ptrs
@@ -155,7 +192,7 @@ class HipNet:
   def workspace(self, n):
     ws = self._ws.get(n)
     if ws is None:
-      ws = torch.empty(self.ws_floats(n), dtype=torch.float32, device=self.device)
+      ws = _buf(self.ws_floats(n), torch.float32, self.device)
       self._ws = {n: ws}  # keep one
     return ws
 
@@ -163,10 +200,10 @@ class HipNet:
     return torch.bfloat16 if self.compute == V4L_BF16 else torch.float32
 
   def alloc_rollout(self, slots, device):
-    state = torch.zeros(slots, self.Sp, dtype=torch.float32, device=device)
+    state = _buf(slots * self.Sp, torch.float32, device, zero=True).view(slots, self.Sp)
     image = None
     if self.img_elems:
-      image = torch.zeros(slots, self.img_elems, dtype=self.image_dtype(), device=device)
+      image = _buf(slots * self.img_elems, self.image_dtype(), device, zero=True).view(slots, self.img_elems)
     return state, image
 
   def ingest(self, obs, state, image, slot0=0):
@@ -279,7 +316,7 @@ class HipTrainer:
     check(self.L.v4l_trainer_create(pf_net.h, vf_net.h, tpf_net.h, C.byref(h)), "v4l_trainer_create")
     self.h = h
     dev = self.device
-    z = lambda n: torch.zeros(n, dtype=torch.float32, device=dev)
+    z = lambda n: _buf(n, torch.float32, dev, zero=True)
     # gradient buckets: [total_params | V4L_BUCKET_TAIL scalars that ride through the data-parallel all-reduce]
     self.g_pf_bucket = z(pf_net.total_params + _lib.V4L_BUCKET_TAIL)
     self.g_vf_bucket = z(vf_net.total_params + _lib.V4L_BUCKET_TAIL)
@@ -351,8 +388,8 @@ class HipTrainer:
     if n <= self.batch:
       return
     self.batch = n
-    self.ws = torch.empty(self.L.v4l_trainer_ws_floats(self.h, n), dtype=torch.float32, device=self.device)
-    self.ctl = torch.zeros(self.L.v4l_trainer_ctl_bytes(self.h, n), dtype=torch.uint8, device=self.device)
+    self.ws = _buf(self.L.v4l_trainer_ws_floats(self.h, n), torch.float32, self.device)
+    self.ctl = _buf(self.L.v4l_trainer_ctl_bytes(self.h, n), torch.uint8, self.device, zero=True)
     check(self.L.v4l_trainer_bind(self.h, _ptr(self.g_pf), _ptr(self.m_pf), _ptr(self.v_pf), _ptr(self.g_vf),
                                   _ptr(self.m_vf), _ptr(self.v_vf), _ptr(self.ws), self.ws.numel(), _ptr(self.ctl), n,
                                   _stream()), "v4l_trainer_bind")
@@ -445,11 +482,11 @@ class HipActor:
     check(self.L.v4l_actor_create(pf_net.h, vf_net.h, E, C.byref(h)), "v4l_actor_create")
     self.h = h
     A = pf_net.out_dim
-    self.ws = torch.empty(self.L.v4l_actor_ws_floats(h), dtype=torch.float32, device=dev)
-    self.ctl = torch.zeros(self.L.v4l_actor_ctl_bytes(h), dtype=torch.uint8, device=dev)
+    self.ws = _buf(self.L.v4l_actor_ws_floats(h), torch.float32, dev)
+    self.ctl = _buf(self.L.v4l_actor_ctl_bytes(h), torch.uint8, dev, zero=True)
     self.obs = torch.zeros(E, pf_net.state_dim + pf_net.img_elems, dtype=torch.float32, device=dev)
     self.eps = torch.zeros(E, A, dtype=torch.float32, device=dev)
-    z = lambda *shape: torch.zeros(*shape, dtype=torch.float32, device=dev)
+    z = lambda *shape: _buf(int(np.prod(shape)), torch.float32, dev, zero=True).view(*shape)
     self.action, self.mean, self.std, self.ent, self.value = z(E, A), z(E, A), z(E, A), z(E, 1), z(E, 1)
     self.shared_encoder, self.graph = bool(shared_encoder), bool(graph)
     self.stream = torch.cuda.Stream(device=dev)
