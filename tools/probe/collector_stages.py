@@ -51,3 +51,27 @@ def full(i):
 bench("cast(8 thr) + H2D + step + D2H", full, sync=False)
 a = np.zeros((E, 6))
 bench("np.isfinite(acts).all()", lambda i: np.isfinite(a).all(), sync=False)
+# ---- round 4: the split hand-over (fp32 proprio + bf16 depth rows read in place over PCIe)
+S = case["S"]
+prop = [torch.empty(E, S, dtype=torch.float32).pin_memory() for _ in range(2)]
+img16 = [torch.empty(E, D - S, dtype=torch.bfloat16).pin_memory() for _ in range(2)]
+src = [torch.from_numpy(r) for r in rows]
+def cast_split(i):
+    prop[i & 1].copy_(src[i & 3][:, :S]); img16[i & 1].copy_(src[i & 3][:, S:])
+for th in (4, 8, 16, 32, 64):
+    torch.set_num_threads(th)
+    bench("split cast f64 -> f32 | bf16 pinned, %2d threads" % th, cast_split, sync=False)
+actor2 = RolloutActor(pf, vf, E)
+st, im = pf.hip.alloc_rollout(4 * E, dev)
+actor2.attach((st, im, torch.zeros(4 * E, 6, device=dev), torch.zeros(4 * E, device=dev), torch.zeros(4 * E, device=dev)))
+def host_split(i):
+    actor2.seek(i & 3)
+    return actor2.step_host_split(prop[i & 1], img16[i & 1])
+def host_rows(i):
+    actor2.seek(i & 3)
+    return actor2.step_host(pin[i & 1])
+bench("step_host_split (bf16 depth rows in place, incl. sync)", host_split, sync=False)
+bench("step_host (fp32 rows in place, incl. sync)", host_rows, sync=False)
+for th in (8, 16, 32):
+    torch.set_num_threads(th)
+    bench("split cast (%2d thr) + step_host_split" % th, lambda i: (cast_split(i), host_split(i)), sync=False)
