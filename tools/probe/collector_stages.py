@@ -70,7 +70,15 @@ def host_split(i):
 def host_rows(i):
     actor2.seek(i & 3)
     return actor2.step_host(pin[i & 1])
-bench("step_host_split (bf16 depth rows in place, incl. sync)", host_split, sync=False)
+def host_split_copy(i):
+    actor2.seek(i & 3)
+    return actor2._actor.step_host_split(prop[i & 1], img16[i & 1], via_copy=True)
+def host_split_inplace(i):
+    actor2.seek(i & 3)
+    return actor2._actor.step_host_split(prop[i & 1], img16[i & 1], via_copy=False)
+bench("step_host_split via 2 async H2D copies, incl. sync", host_split_copy, sync=False)
+bench("step_host_split, rows read in place over PCIe, incl. sync", host_split_inplace, sync=False)
+bench("step_host_split (default), incl. sync", host_split, sync=False)
 bench("step_host (fp32 rows in place, incl. sync)", host_rows, sync=False)
 for th in (8, 16, 32):
     torch.set_num_threads(th)

@@ -568,9 +568,7 @@ class HipActor:
       raise RuntimeError("vision4leg_amd: step_host needs a pinned, contiguous float32 [E][S+C*H*W] host tensor")
     if getattr(self, "_act_host", None) is None:
       self._act_host = torch.zeros(self.action.shape, dtype=torch.float32).pin_memory()
-      self._args_host = self._args[:7] + (C.c_void_p(self._act_host.data_ptr()),) + self._args[8:]
-      self._args_host_of = self._args
-    if self._args_host_of is not self._args:  # attach() rebuilt the argument tuple
+    if getattr(self, "_args_host_of", None) is not self._args:  # first call, or attach() rebuilt the argument tuple
       self._args_host = self._args[:7] + (C.c_void_p(self._act_host.data_ptr()),) + self._args[8:]
       self._args_host_of = self._args
     self.pf.pack_if_needed(fast=True)
@@ -599,11 +597,15 @@ class HipActor:
     fused rollout step, eager launches."""
     return (not self.graph) and bool(self.L.v4l_actor_split_supported(self.h, int(self.shared_encoder)))
 
-  def step_host_split(self, prop_pinned, img16_pinned, deterministic=False):
+  def step_host_split(self, prop_pinned, img16_pinned, deterministic=False, via_copy=None):
     """step_host with the observation split: `prop_pinned` [E][S] float32 (None when the net has no proprio input) and
     `img16_pinned` [E][C*H*W] bfloat16, both PINNED host tensors the rollout kernels read in place — the depth stack crosses
     PCIe in the type the kernels round it to anyway (half the bytes of fp32 rows; same results bit for bit). Returns the [E][A]
-    action as a numpy view of a pinned buffer (valid until the next step)."""
+    action as a numpy view of a pinned buffer (valid until the next step).
+    via_copy (V4L_SPLIT_VIA_COPY=1; default off): the rows first go to HBM with two asynchronous copies on the launch stream
+    and the kernels read them there — measured SLOWER (90 us per step against 72 us for the in-place read, 89 us for fp32 rows
+    in place: each copy costs ~10 us of launch / completion latency on top of its bytes; tools/probe/collector_stages.py,
+    profiles/r4_collector_stages.txt), kept as a switch for hosts whose PCIe reads from the GPU side are slower."""
     if self.graph:
       raise RuntimeError("vision4leg_amd: step_host_split drives eager launches (construct the actor with graph=False)")
     S = self.pf.state_dim
@@ -634,6 +636,17 @@ class HipActor:
       self._eps_zero = True
     if self.own:
       self.seek(0)
+    if via_copy is None:
+      via_copy = os.environ.get("V4L_SPLIT_VIA_COPY", "0") != "0"
+    if via_copy:
+      if getattr(self, "_split_dev", None) is None:
+        self._split_dev = (torch.empty(self.E, max(S, 1), dtype=torch.float32, device=self.device),
+                           torch.empty(self.E, self.pf.img_elems, dtype=torch.bfloat16, device=self.device))
+      dprop, dimg = self._split_dev
+      if S:
+        dprop.copy_(prop_pinned, non_blocking=True)
+      dimg.copy_(img16_pinned, non_blocking=True)
+      prop_pinned, img16_pinned = dprop, dimg
     check(self.L.v4l_actor_step_split(self.h, C.c_void_p(prop_pinned.data_ptr() if S else 0), C.c_void_p(img16_pinned.data_ptr()),
                                       eps, a[2], a[3], a[4], a[5], a[6], C.c_void_p(self._act_host.data_ptr()), a[8], a[9], a[10],
                                       a[11], a[12], _stream()), "v4l_actor_step_split")
