@@ -214,11 +214,11 @@ def test_step_host_equals_step(name, device):
                 actor.draw_noise(T - 4)  # the remaining steps consume slices of one bulk draw
             elif t < 4:
                 torch.manual_seed(500 + t)
-            if host == "split":
+            if host in ("split", "split_copy"):
                 S = case["S"]
                 prop = torch.from_numpy(rows[t][:, :S].copy()).pin_memory() if S else None
                 img16 = torch.from_numpy(rows[t][:, S:].copy()).to(torch.bfloat16).pin_memory()
-                acts.append(np.array(actor.step_host_split(prop, img16), copy=True))
+                acts.append(np.array(actor._actor.step_host_split(prop, img16, via_copy=(host == "split_copy")), copy=True))
             elif host:
                 pinned.copy_(torch.from_numpy(rows[t]))
                 acts.append(np.array(actor.step_host(pinned), copy=True))
@@ -233,7 +233,8 @@ def test_step_host_equals_step(name, device):
         assert (x is None and y is None) or torch.equal(x, y)
     assert np.isfinite(a_host).all() and np.abs(a_host[2:]).max() > 0 and filed_host[4][2 * E:].abs().max() > 0
     if split:  # ... and the split hand-over (fp32 proprio + bf16 depth rows) gives the same bits again
-        a_split, filed_split, first_split = run("split", rollout_arrays())
-        assert np.array_equal(a_dev, a_split)
-        for x, y in list(zip(filed_dev, filed_split)) + list(zip(first_dev, first_split)):
-            assert (x is None and y is None) or torch.equal(x, y)
+        for how in ("split", "split_copy"):  # rows read in place over PCIe / copied to HBM first (V4L_SPLIT_VIA_COPY)
+            a_split, filed_split, first_split = run(how, rollout_arrays())
+            assert np.array_equal(a_dev, a_split), how
+            for x, y in list(zip(filed_dev, filed_split)) + list(zip(first_dev, first_split)):
+                assert (x is None and y is None) or torch.equal(x, y), how
