@@ -11,9 +11,10 @@ Gates (tensor distances are relative to the reference tensor's max-abs — polic
         of the elements within half an Adam step (5e-5), none further than 2 lr U, mean <= 5e-6 (see the comment at the gate).
   bf16: rollout mean / value within 3 x the bf16 oracle's own sensitivity (p95 of 8 forward passes with parameters nudged by
         1e-7, oracle/bench_path.py::_forward_envelope), update 0's infos within 1e-2 of the bf16 oracle's, distances recorded
-        (profiles/parity_r4.json), and the TRAJECTORY RULE: per update, HIP-bf16 is no further from the
-        fp32 reference trajectory than the bf16 oracle is, up to a factor / floor that covers which side of a rounding tie
-        the two bf16 implementations happen to land on (they agree to 1 ulp per contraction: test_gpu_contractions.py).
+        (profiles/parity_r4.json), and the TRAJECTORY GATE: per update, HIP-bf16 is no further from the bf16 oracle than 3 x the
+        spread of 4 bf16 oracles started from parameters nudged by 1e-7 (oracle/bench_path.py::traj_seeds). (Round 3's rule —
+        "no further from the fp32 reference trajectory than 2 x the bf16 oracle is" — leaned on the bf16-vs-fp32 distance; that
+        distance is now recorded only.)
 """
 import pytest
 
@@ -22,7 +23,7 @@ from oracle import bench_path
 
 pytestmark = pytest.mark.gpu
 
-TRAJ_FACTOR, TRAJ_FLOOR = 3.0, 3e-3
+TRAJ_SEEDS, TRAJ_FACTOR, TRAJ_FLOOR = 4, 3.0, 2e-3
 
 
 @pytest.mark.parametrize("mode", ["f32", "bf16"])
@@ -30,7 +31,7 @@ TRAJ_FACTOR, TRAJ_FLOOR = 3.0, 3e-3
 def test_rollout_then_stored_logp_graph_updates_vs_reference_protocol(E, mode, device, monkeypatch):
     case = dict(util.CASES["loco_b1024"])
     T, B, U = 64, 1024, 4
-    r = bench_path.run(case, E, T, B, U, mode, device, threads=16)
+    r = bench_path.run(case, E, T, B, U, mode, device, threads=16, traj_seeds=TRAJ_SEEDS)
     params = r.pop("_params")
     tag = "bench_path/E%d/%s/" % (E, mode)
     for k, v in r.items():
@@ -66,11 +67,19 @@ def test_rollout_then_stored_logp_graph_updates_vs_reference_protocol(E, mode, d
     assert r["rollout_mean_vs_bf16"] <= max(3.0 * r["rollout_mean_envelope_p95"], 1e-4), (r["rollout_mean_vs_bf16"], r["rollout_mean_envelope_p95"])
     assert r["rollout_value_vs_bf16"] <= max(3.0 * r["rollout_value_envelope_p95"], 1e-4), (r["rollout_value_vs_bf16"], r["rollout_value_envelope_p95"])
     assert r["infos_vs_bf16_per_update"][0] <= 1e-2, r["infos_vs_bf16_per_update"]
-    # ... and the trajectory rule against the fp32 reference trajectory. Per update and per statistic the comparison is a coin
-    # toss (grad_norm/pf jumps by a few per cent whenever ONE sample changes sides of the PPO clip, and which update that
-    # happens in differs between any two bf16 evaluations): the rule is stated on the trajectory's envelope — the largest
-    # deviation from the fp32 reference over the U updates — and update 0 (identical parameters on all sides) on its own.
-    hip, orc_d = r["infos_vs_f32_per_update"], r["oracle_bf16_vs_f32_per_update"]
-    assert hip[0] <= TRAJ_FACTOR * orc_d[0] + TRAJ_FLOOR, (hip, orc_d)
-    assert max(hip) <= 2.0 * max(orc_d) + TRAJ_FLOOR, (hip, orc_d)
-    assert r["param_mean_vs_f32"] <= TRAJ_FACTOR * r["oracle_bf16_vs_f32_param_mean"] + 2e-6
+    # ... and the trajectory gate. From the second update on a bf16 trajectory is not unique: grad_norm/pf jumps by a few per
+    # cent whenever ONE sample changes sides of the PPO clip, and which update that happens in differs between any two bf16
+    # evaluations. The yardstick is therefore the bf16 ORACLE against itself: TRAJ_SEEDS oracles started from parameters nudged
+    # by 1e-7 run the same updates, and per update the HIP infos may be no further from the un-nudged bf16 oracle's than
+    # TRAJ_FACTOR x the largest distance among them (+ a floor for updates where no decision happened to flip). The distance to
+    # the fp32 reference trajectory is recorded (profiles/parity_r4.json), not gated; tests/test_gpu_soak.py shows it does not
+    # compound over 360 updates.
+    hip, env = r["infos_vs_bf16_per_update"], r["traj_envelope_per_update"]
+    print("[bench path E=%d bf16] infos vs bf16 oracle per update %s, nudged-oracle envelope %s" % (E, hip, env))
+    for u in range(U):
+        util.record(tag + "u%d/infos_vs_bf16" % u, hip[u])
+        util.record(tag + "u%d/traj_envelope" % u, env[u])
+        assert hip[u] <= TRAJ_FACTOR * env[u] + TRAJ_FLOOR, (u, hip, env)
+    pm_env = r["oracle_bf16_vs_f32_param_mean"]
+    util.record(tag + "param_mean_vs_f32_over_oracle_bf16_vs_f32", r["param_mean_vs_f32"] / max(pm_env, 1e-12))
+    assert r["param_mean_vs_bf16"] <= 2e-5 * U  # mean |param - bf16 oracle| after U Adam steps of 1e-4 (test_ppo_update: 2e-5 per update)
