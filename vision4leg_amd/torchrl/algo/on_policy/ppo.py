@@ -72,19 +72,16 @@ def exchange_comm_id(dist, device, available, unique_id, id_bytes=_lib.V4L_COMM_
 
 
 def device_identity(device):
-    """A 63-bit fingerprint of (host, physical GPU) — equal on two ranks exactly when they drive the same device."""
+    """A 63-bit fingerprint of (host, physical GPU) — equal on two ranks exactly when they drive the same device. Everything
+    that can tell two GPUs apart goes in (uuid and PCI ids where the runtime reports them, the device index together with the
+    visibility environment always): ranks on different GPUs differ in at least one component, ranks on the same GPU in none."""
     import hashlib
     import socket
     props = torch.cuda.get_device_properties(device)
-    ident = [socket.gethostname()]
-    uuid = str(getattr(props, "uuid", ""))
-    if uuid and uuid.strip("0-") != "":
-        ident.append(uuid)
-    elif hasattr(props, "pci_bus_id"):
-        ident.append((getattr(props, "pci_domain_id", 0), props.pci_bus_id, getattr(props, "pci_device_id", 0)))
-    else:
-        ident.append((os.environ.get("HIP_VISIBLE_DEVICES"), os.environ.get("ROCR_VISIBLE_DEVICES"),
-                      os.environ.get("CUDA_VISIBLE_DEVICES"), torch.device(device).index))
+    ident = [socket.gethostname(), str(getattr(props, "uuid", "")),
+             (getattr(props, "pci_domain_id", None), getattr(props, "pci_bus_id", None), getattr(props, "pci_device_id", None)),
+             (os.environ.get("HIP_VISIBLE_DEVICES"), os.environ.get("ROCR_VISIBLE_DEVICES"),
+              os.environ.get("CUDA_VISIBLE_DEVICES"), torch.device(device).index)]
     return int.from_bytes(hashlib.sha1(repr(ident).encode()).digest()[:8], "little") >> 1
 
 
