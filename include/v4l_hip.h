@@ -23,6 +23,8 @@
  *   V4L_PAR=0                 no auxiliary streams (sibling kernels run serially)
  *   V4L_PAR_WGRAD=0|1|2       weight-grad launch schedule of a backward pass (per call; 2 = default: conv data-grads first,
  *                             then dW3 on the main stream next to the dense weight-grads on the auxiliary stream)
+ *   V4L_SPLIT_REDUCE=0        schedule 2 issues wgrad_reduce as two launches INSIDE the forked section (conv-stack partials behind
+ *                             dW3, the others behind the dense weight-grads); 0 = one launch behind the join (same bits) (per call)
  *   V4L_SPLIT_DENSE_WGRAD     grouped and whole-output dense weight-grads as two launches instead of one (per call)
  *   V4L_NO_SQ_FROM_REDUCE     separate grad_sumsq launch on one GPU too (the norm's partials otherwise come from wgrad_reduce)
  *   V4L_NO_FUSED_ENC          LocoTransformer encoder layer by layer (per call)

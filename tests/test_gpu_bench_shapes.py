@@ -340,3 +340,10 @@ def test_forked_weight_grad_launches_equal_serial(mode, device):
     # switch): the same single-writer slabs, one more join
     for _ in range(2):
         assert (grads_with(3) - ref).abs().max().item() == 0.0
+    # round 4: mode 2 issues the reduction as two launches inside the forked section; V4L_SPLIT_REDUCE=0: one launch behind the join
+    os.environ["V4L_SPLIT_REDUCE"] = "0"
+    try:
+        for _ in range(2):
+            assert (grads_with(2) - ref).abs().max().item() == 0.0
+    finally:
+        os.environ.pop("V4L_SPLIT_REDUCE", None)

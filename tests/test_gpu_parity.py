@@ -1140,13 +1140,16 @@ def test_external_row_chains_equal_in_kernel_chains(name, mode, device, monkeypa
     critic_loss_heads_kernel on request) and the proprio branch's chain beside the layers' weight-grads (wps_wgrad_kernel), 32 - 64 rows per
     block, instead of inside wps_layer_bwd_kernel over the block's 4 samples (csrc/wps.h rows_chain). Same MFMA steps in the
     same k order per output element: two PPO updates must give bit-identical statistics and parameters either way (B = 64: the
-    4-wave loss blocks, ragged 300 and 1024: the 16-wave ones)."""
+    4-wave loss blocks, ragged 300 and 1024: the 16-wave ones). Likewise the weight-grad reduction issued as two launches inside
+    the forked weight-grad section (default) or as one launch behind its join (V4L_SPLIT_REDUCE=0): one descriptor table, one
+    block numbering, so the gradients AND the per-block partials of the gradient norm (clip_adam's input) are the same bits."""
     case = util.CASES[name]
     from vision4leg_amd.torchrl.algo import PPO
     res = {}
     for variant, env in (("external", {}), ("in_kernel", {"V4L_WPS_HEAD_IN": "1", "V4L_WPS_TOK0_IN": "1"}),
-                         ("heads_only_external", {"V4L_WPS_TOK0_IN": "1"}), ("critic_heads_external_too", {"V4L_WPS_HEAD_EXT_CRITIC": "1"})):
-        for k in ("V4L_WPS_HEAD_IN", "V4L_WPS_TOK0_IN", "V4L_WPS_HEAD_EXT_CRITIC"):
+                         ("heads_only_external", {"V4L_WPS_TOK0_IN": "1"}), ("critic_heads_external_too", {"V4L_WPS_HEAD_EXT_CRITIC": "1"}),
+                         ("one_reduce_launch", {"V4L_SPLIT_REDUCE": "0"})):
+        for k in ("V4L_WPS_HEAD_IN", "V4L_WPS_TOK0_IN", "V4L_WPS_HEAD_EXT_CRITIC", "V4L_SPLIT_REDUCE"):
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
             monkeypatch.setenv(k, v)
@@ -1163,7 +1166,7 @@ def test_external_row_chains_equal_in_kernel_chains(name, mode, device, monkeypa
         torch.cuda.synchronize()
         res[variant] = (infos, {k: v.detach().cpu().clone() for k, v in pf.state_dict().items()},
                         {k: v.detach().cpu().clone() for k, v in vf.state_dict().items()})
-    for other in ("in_kernel", "heads_only_external", "critic_heads_external_too"):
+    for other in ("in_kernel", "heads_only_external", "critic_heads_external_too", "one_reduce_launch"):
         for u in range(2):
             for k in util.STAT_KEYS:
                 a, b = res["external"][0][u][k], res[other][0][u][k]

@@ -946,14 +946,20 @@ struct RedDesc {
   float* db;           // [N] or null
   int nsplit, N, K, Npad, Kpad, Ktorch, Cin, taps;
   int64_t blk0;        // first block of this descriptor
+  int group, pad_;     // 1: partials of the fused conv-stack backward (bwd_conv_kernel / bwd_conv3_wgrad_kernel), 0: everything else
 };
-__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const RedDesc* __restrict__ descs, int nd, float* __restrict__ sq_part) {
+// blk_base: first block of the table this launch covers — the reduction can be issued as two launches (round 4: the conv
+// stack's partials on the main stream right behind dW3, the dense ones on the auxiliary stream behind the grouped weight-grads,
+// both INSIDE the forked section, so that only clip_adam waits for the join); sq_part is indexed by the table-wide block number.
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const RedDesc* __restrict__ descs, int nd, float* __restrict__ sq_part,
+                                                           int blk_base) {
   // 64 outputs per block x 4 slab groups: thread (o, g) adds slabs g, g+4, g+8, ... (4 independent accumulators),
   // the 4 group sums are combined through LDS in a fixed order -> deterministic and latency-tolerant
   __shared__ float part[4][64];
-  const RedDesc d = descs[find_desc(descs, nd, (int64_t)blockIdx.x)];
+  const int64_t bid = (int64_t)blockIdx.x + blk_base;
+  const RedDesc d = descs[find_desc(descs, nd, bid)];
   const int o = threadIdx.x & 63, g = threadIdx.x >> 6;
-  const int64_t e = ((int64_t)blockIdx.x - d.blk0) * 64 + o;
+  const int64_t e = (bid - d.blk0) * 64 + o;
   const int64_t nk = (int64_t)d.N * d.K;
   const V4L_GLOBAL float* p = nullptr;
   int64_t stride = 0;
@@ -981,7 +987,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const RedDesc* __rest
     const float sum = p != nullptr ? (part[0][o] + part[1][o]) + (part[2][o] + part[3][o]) : 0.f;
     if (sq_part != nullptr) {
       const float sq = wave_sum(sum * sum);
-      if (o == 0) sq_part[blockIdx.x] = sq;
+      if (o == 0) sq_part[bid] = sq;
     }
     if (p == nullptr) return;
     if (e < nk) {

@@ -310,27 +310,52 @@ static int wgrad_dense(Ctx& c, hipStream_t ds, hipStream_t dg) {
   return 0;
 }
 // one launch: sum all registered slabs into the PyTorch-layout gradients
-template <typename T>
-static int wgrad_reduce_all(Ctx& c) {
+// The reduce table: descriptors in a fixed order — the fused conv-stack backward's (group 1) first, then the others in
+// registration order — with table-wide block numbers; refreshed on the device when the geometry changed (first call for a batch
+// size; not capturable, by design). The order is the same in every launch schedule, so the per-block partials of the gradient
+// norm are summed in the same order whether the reduction runs as one launch or two.
+static int wgrad_reduce_prepare(Ctx& c, int64_t (&blocks)[2]) {
   v4l_net* net = c.net;
+  std::stable_partition(net->red.begin(), net->red.end(), [](const RedDesc& d) { return d.group == 1; });
   int64_t blk = 0;
-  for (RedDesc& d : net->red) { d.blk0 = blk; blk += cdiv64((int64_t)d.N * d.K + d.N, 64); }
+  blocks[0] = blocks[1] = 0;
+  for (RedDesc& d : net->red) {
+    d.blk0 = blk;
+    const int64_t nb = cdiv64((int64_t)d.N * d.K + d.N, 64);
+    blk += nb;
+    blocks[d.group == 1 ? 0 : 1] += nb;  // [0]: the conv stack's blocks (first in the table), [1]: the rest
+  }
   V4L_REQUIRE(net->red.size() <= (size_t)v4l_net::MAX_RED, "internal: too many weight-grad descriptors");
   const size_t bytes = net->red.size() * sizeof(RedDesc);
   if (net->red_cached.size() != net->red.size() || memcmp(net->red_cached.data(), net->red.data(), bytes) != 0) {
-    // geometry changed (first call for this batch size): refresh the device table. Not capturable, by design.
     V4L_REQUIRE(!capturing(c.s), "internal: weight-grad geometry changed while capturing a graph");
     V4L_HIP_CHECK(hipStreamSynchronize(c.s));
+    if (c.tn != c.s) V4L_HIP_CHECK(hipStreamSynchronize(c.tn));
     V4L_HIP_CHECK(hipMemcpy(net->d_red, net->red.data(), bytes, hipMemcpyHostToDevice));
     net->red_cached = net->red;
   }
-  g_op = "wgrad_reduce";
   float* sq = blk <= net->sq_cap() ? net->d_sq : nullptr;
   net->red_blocks = sq != nullptr ? (int)blk : 0;
   net->red_grads = c.grads;
-  V4L_KLAUNCH("wgrad_reduce", 0, c.s, wgrad_reduce_kernel, dim3((unsigned)blk), dim3(256), 0, c.s, net->d_red, (int)net->red.size(), sq);
+  return 0;
+}
+// blocks [base, base + count) of the prepared table on stream s
+static int wgrad_reduce_launch(Ctx& c, int64_t base, int64_t count, hipStream_t s) {
+  v4l_net* net = c.net;
+  if (count <= 0) return 0;
+  g_op = "wgrad_reduce";
+  float* sq = net->red_blocks > 0 ? net->d_sq : nullptr;
+  V4L_KLAUNCH("wgrad_reduce", 0, s, wgrad_reduce_kernel, dim3((unsigned)count), dim3(256), 0, s, net->d_red, (int)net->red.size(), sq,
+              (int)base);
   V4L_LAUNCH_CHECK();
   return 0;
+}
+template <typename T>
+static int wgrad_reduce_all(Ctx& c) {
+  int64_t blocks[2];
+  int rc = wgrad_reduce_prepare(c, blocks);
+  if (rc) return rc;
+  return wgrad_reduce_launch(c, 0, blocks[0] + blocks[1], c.s);
 }
 
 struct Act { float* p; int ld; int w; };
@@ -571,6 +596,7 @@ static int conv_stack_bwd_fused(Ctx& c, const T* image, const int* rowidx, int n
     o.N = v.Cout; o.K = v.K; o.Ktorch = v.K;
     o.Cin = v.chw ? 0 : v.Cin; o.taps = v.chw ? 0 : v.KH * v.KH;
     o.slab = slab[i]; o.bslab = bslab[i]; o.nsplit = nb; o.Npad = Ns[i]; o.Kpad = Ks[i];
+    o.group = 1;  // (reduced right behind dW3 on the main stream when the weight-grad section is forked)
     N->red.push_back(o);
   }
   V4L_REQUIRE(c.slab_used <= N->slab_cap, "internal: weight-grad slab arena overflow");
@@ -1857,6 +1883,23 @@ int v4l_net::backward_t(const float* state, const T* image, const int* rowidx, i
     if (three) {
       V4L_HIP_CHECK(hipEventRecord(ev_fork2, cx.s));
       V4L_HIP_CHECK(hipStreamWaitEvent(aux2, ev_fork2, 0));
+    }
+    // round 4: the reduction inside the forked section — the conv stack's partials (56 MB) right behind dW3 on the main
+    // stream, the others behind the grouped weight-grads on the auxiliary stream — so that the join only gates clip_adam
+    // (the update timeline showed 9 - 11 us of join latency in front of a 19 us reduce launch). V4L_SPLIT_REDUCE=0: one launch
+    // behind the join. (Same descriptor order, hence the same bits, either way.)
+    const bool split_red = !three && cx.tn != cx.s && (getenv("V4L_SPLIT_REDUCE") == nullptr || atoi(getenv("V4L_SPLIT_REDUCE")) != 0);
+    int64_t rblocks[2] = {0, 0};
+    if (split_red && (rc = wgrad_reduce_prepare(cx, rblocks))) return rc;
+    if (split_red) {
+      // (issue order matters to the graph's schedule: the auxiliary branch is the longer one and goes first)
+      const size_t nred = cx.net->red.size();
+      if ((rc = wgrad_dense<T>(cx, cx.tn, nullptr))) return rc;
+      V4L_REQUIRE(cx.net->red.size() == nred, "internal: a weight-grad registered after the reduce table was prepared");
+      if ((rc = conv3_wgrad_deferred<T>(cx, cx.s))) return rc;
+      if ((rc = wgrad_reduce_launch(cx, 0, rblocks[0], cx.s))) return rc;
+      if ((rc = wgrad_reduce_launch(cx, rblocks[0], rblocks[1], cx.tn))) return rc;
+      return par_end(cx);
     }
     if ((rc = wgrad_dense<T>(cx, cx.tn, three ? aux2 : nullptr))) return rc;
     if ((rc = conv3_wgrad_deferred<T>(cx, cx.s))) return rc;
