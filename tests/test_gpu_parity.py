@@ -36,6 +36,14 @@ def _fp_close(v, fp):
 
 
 ENV_SEEDS, ENV_FACTOR, ENV_FLOOR = 8, 3.0, 1e-4   # floor: fp32 summation-order noise of tensors no rounding decision touches
+# Nudge sizes of the envelope runs (ENV_SEEDS runs each, pooled): 1e-7 (one fp32 ulp) and 3e-6 — the measured size of the
+# activation differences between two fp32 summation orders of these nets (max |x1_hip - x1_float64| = 3e-6, see test_backward's
+# f32 branch), i.e. the perturbation an implementation with the oracle's rounding points actually is. Both are three orders
+# below one bf16 ulp (4e-3). With the 1e-7 runs alone the p95 of a small tensor was decided by whether ONE of 8 runs happened to
+# move a rounding / ReLU decision that reaches it: conv1's weight of cnn_s93's critic had envelope 1.5e-2 on one GPU box's host
+# CPU and 2.1e-3 on another's (the oracle's own fp32 sums run in a thread-count-dependent order) with the HIP distance at
+# 1.17e-2 on both — the gate flipped with the box, not with the code.
+ENV_SCALES = (1e-7, 3e-6)
 COS_MIN, L2_FACTOR = 0.9995, 2.0
 _ENVELOPES = {}
 
@@ -44,12 +52,12 @@ def _flat(gs, keys):
     return torch.cat([gs[k].reshape(-1) for k in keys]).double()
 
 
-def _bf16_envelope(name, tag, kind, params, obs, S, w, scale=1e-7):
+def _bf16_envelope(name, tag, kind, params, obs, S, w, scales=ENV_SCALES):
     """The bf16 oracle's own sensitivity. bf16 arithmetic is chaotic over ~20 stacked contractions: a 1e-7 relative nudge of
     the parameters (far below one bf16 ulp, 4e-3) moves a handful of rounding / ReLU decisions, and each moved decision
     changes the output and single gradient elements by O(1e-3 .. 1e-1) of the tensor's max-abs. An implementation with the
     oracle's rounding points differs from it in exactly that way (its fp32 partial sums are added in another order).
-    -> {"out", "grads": the un-nudged bf16 oracle's; "fwd": p95 over ENV_SEEDS nudged runs of rel_err(out);
+    -> {"out", "grads": the un-nudged bf16 oracle's; "fwd": p95 over the ENV_SEEDS x len(ENV_SCALES) nudged runs of rel_err(out);
         "tensor": {key: p95 of rel_err(grad)}; "l2": p95, "cos": min of the flat gradient's relative L2 / cosine}.
     Cached per (case, net): test_forward and test_backward (and the deep-GEMM reruns) share one set of runs."""
     key = (name, tag)
@@ -66,7 +74,7 @@ def _bf16_envelope(name, tag, kind, params, obs, S, w, scale=1e-7):
     out0, g0 = run(params)
     f0 = _flat(g0, keys)
     fwd, l2, cos, per = [], [], [], {k: [] for k in keys}
-    for sd in range(1, ENV_SEEDS + 1):
+    for sd, scale in [(sd, sc) for sc in scales for sd in range(1, ENV_SEEDS + 1)]:
         gen = torch.Generator().manual_seed(sd)
         out, g = run({k: v * (1 + scale * torch.randn(v.shape, generator=gen)) for k, v in params.items()})
         fwd.append(util.rel_err(out, out0))

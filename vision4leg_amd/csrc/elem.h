@@ -571,7 +571,10 @@ __device__ __forceinline__ ActorDims actor_dims(const ActorArgs& p) {
 }
 // one minibatch row i (rollout slot `slot`): log pi, ratio, surrogate term, d(loss)/d(log pi) and the per-dimension factors of
 // d(log pi)/d(mean) (dm) and d(log pi)/d(log sigma) + 1 (z2)
+// TANH: compiled in only for TanhNormal policies (as a run-time flag the atanh / correction logs were evaluated speculatively for
+// every policy: the single-block statistics launch went from 14 to 36 us)
 struct ActorRow { float lp, ratio, sur, dlp, dm[8], z2[8]; };
+template <bool TANH>
 __device__ __forceinline__ ActorRow actor_row(const ActorArgs& p, const ActorDims& D, int i, int slot, float amean, float astd) {
   ActorRow o;
   float lp = 0.f, lpo = 0.f, mu[8], tmu[8];
@@ -589,8 +592,8 @@ __device__ __forceinline__ ActorRow actor_row(const ActorArgs& p, const ActorDim
   for (int a = 0; a < 8; ++a) {
     if (a < p.A) {
       const float act = p.acts[(int64_t)slot * p.A + a];
-      const float x = p.tanh_action ? tanh_pre(act) : act;
-      const float corr = p.tanh_action ? tanh_corr(act) : 0.f;
+      const float x = TANH ? tanh_pre(act) : act;
+      const float corr = TANH ? tanh_corr(act) : 0.f;
       const float d = x - mu[a];
       const float var = D.sg[a] * D.sg[a];
       lp += -(d * d) / (2.f * var) - D.lsg[a] - HALF_LOG_2PI - corr;
@@ -615,6 +618,7 @@ __device__ __forceinline__ ActorRow actor_row(const ActorArgs& p, const ActorDim
   o.dlp = (pre <= clp) ? -p.inv_n * an * ratio : 0.f;
   return o;
 }
+template <bool TANH>
 __device__ __forceinline__ void actor_loss_body(const ActorArgs& p) {
   __shared__ float sdl[16][8];
   const int n = p.n, A = p.A;
@@ -627,7 +631,7 @@ __device__ __forceinline__ void actor_loss_body(const ActorArgs& p) {
   float lp_mx = -INFINITY, lp_mn = INFINITY, r_mx = -INFINITY, r_mn = INFINITY;
   for (int i = threadIdx.x; i < n; i += blockDim.x) {
     const int slot = p.rowidx ? p.rowidx[i] : i;
-    const ActorRow o = actor_row(p, D, i, slot, amean, astd);
+    const ActorRow o = actor_row<TANH>(p, D, i, slot, amean, astd);
     s_sur += o.sur;
     {
       float4* drow = reinterpret_cast<float4*>(p.dmean + (int64_t)i * OUT_LD);
@@ -684,7 +688,8 @@ __device__ __forceinline__ void actor_loss_body(const ActorArgs& p) {
     st[ST_LS_MAX] = mx; st[ST_LS_MIN] = mn;
   }
 }
-__global__ __launch_bounds__(1024) void actor_loss_kernel(ActorArgs p) { actor_loss_body(p); }
+template <bool TANH>
+__global__ __launch_bounds__(1024) void actor_loss_kernel(ActorArgs p) { actor_loss_body<TANH>(p); }
 #pragma clang fp contract(fast)
 
 // Gaussian head post-processing for the policy API (continuous_policy.py:85-146,486-492): from the padded
@@ -733,7 +738,7 @@ __global__ __launch_bounds__(256) void col0_kernel(const float* __restrict__ src
 // order). 16-byte loads, one or two per thread: the 388 K-float buffer is one short burst over the whole chip, not 24
 // dependent trips of 64 blocks (12 us -> ~4 us).
 constexpr int GRAD_NORM_PARTS = 256;
-constexpr int ADAM_MAX_PARTS = 8192;  // partials clip_adam_kernel can add up (32 per thread)
+constexpr int ADAM_MAX_PARTS = 16384;  // partials clip_adam_kernel can add up (64 per thread; the NatureCNN nets have 9.4 K reduce blocks)
 __global__ __launch_bounds__(256) void grad_sumsq_kernel(const float* __restrict__ g, int64_t n, float* __restrict__ part) {
   double s = 0.0;
   const int64_t n4 = n >> 2;

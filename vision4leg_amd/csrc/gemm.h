@@ -267,6 +267,7 @@ struct Epi {
   int accumulate;     // C += instead of C =   (shorthand for addend == C)
   const float* addend; // optional: C = result + addend[same row/col layout as C]
   int rowmap;
+  int npad;           // > N: columns [N, npad) of every output row are written as zeros (the heads' padded [OUT_LD] rows)
   // ROWMAP_DGRAD: class (py,px), stride s, class pixel counts, input plane
   int py, px, s, nIy, nIx, IH, IW;
   __device__ __forceinline__ int64_t out_row(int m) const {
@@ -411,6 +412,7 @@ __device__ __forceinline__ void nt_body(const AL& al, const T* __restrict__ Bp, 
         }
         if (add != nullptr) { v.x += old[j].x; v.y += old[j].y; v.z += old[j].z; v.w += old[j].w; }
         if (rok && n4 < ep.N) *reinterpret_cast<float4*>(ep.C + orow * ep.ldc + n4) = v;
+        else if (rok && n4 < ep.npad) *reinterpret_cast<float4*>(ep.C + orow * ep.ldc + n4) = float4{0.f, 0.f, 0.f, 0.f};
       }
     } else {
 #pragma unroll
@@ -425,6 +427,7 @@ __device__ __forceinline__ void nt_body(const AL& al, const T* __restrict__ Bp, 
           if (ep.mask != nullptr) v = ep.mask[ok ? orow * ep.ldmask + n : 0] > 0.f ? v : 0.f;
           if (add != nullptr) v += add[ok ? orow * ep.ldc + n : 0];
           if (ok) ep.C[orow * ep.ldc + n] = v;
+          else if (rok && n < ep.npad) ep.C[orow * ep.ldc + n] = 0.f;
         }
     }
   }
@@ -514,6 +517,7 @@ __global__ __launch_bounds__(256) void gemm_nt_deep_kernel(AL al, const T* __res
         v.x += old.x; v.y += old.y; v.z += old.z; v.w += old.w;
       }
       if (ok) *reinterpret_cast<float4*>(ep.C + orow * ep.ldc + n4) = v;
+      else if (rok && n4 < ep.npad) *reinterpret_cast<float4*>(ep.C + orow * ep.ldc + n4) = float4{0.f, 0.f, 0.f, 0.f};
     } else {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
@@ -525,6 +529,7 @@ __global__ __launch_bounds__(256) void gemm_nt_deep_kernel(AL al, const T* __res
         if (ep.mask != nullptr) v = ep.mask[ok ? orow * ep.ldmask + n : 0] > 0.f ? v : 0.f;
         if (add != nullptr) v += add[ok ? orow * ep.ldc + n : 0];
         if (ok) ep.C[orow * ep.ldc + n] = v;
+        else if (rok && n < ep.npad) ep.C[orow * ep.ldc + n] = 0.f;
       }
     }
   }

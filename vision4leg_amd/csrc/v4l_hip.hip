@@ -457,9 +457,12 @@ static int lin_dgrad(const Ctx& c, const Lin& L, const ADense& y, Epi ep) {
 
 // forward through Linear(+ReLU) layers; outs[i] receives layer i's output
 template <typename T>
-static int chain_fwd(const Ctx& c, const Lin* Ls, int k, ADense in, const Act* outs, bool relu_last) {
+static int chain_fwd(const Ctx& c, const Lin* Ls, int k, ADense in, const Act* outs, bool relu_last, bool zero_pad_last = false) {
   for (int i = 0; i < k; ++i) {
     Epi ep = mk_epi(outs[i].p, outs[i].ld, Ls[i].N, nullptr, (i < k - 1 || relu_last) ? 1 : 0);
+    // the last layer of a head stack writes out_dim of its row's OUT_LD columns: the rest as zeros from the same epilogue
+    // (its column tiles cover Np >= 16 = OUT_LD columns) instead of a memset launch ahead of the chain
+    if (i == k - 1 && zero_pad_last && outs[i].ld <= Ls[i].Np) ep.npad = outs[i].ld;
     int rc = lin_fwd<T>(c, Ls[i], in, ep);
     if (rc) return rc;
     in = dense(outs[i].p, outs[i].ld, in.M, outs[i].w);
@@ -1463,9 +1466,9 @@ int v4l_net::forward_t(const float* state, const T* image, const int* rowidx, in
   Act hacts[V4L_MAX_HIDDEN + 1];
   for (int i = 0; i < nh; ++i) hacts[i] = Act{ws + L.hh[i], c.head_hidden[i], c.head_hidden[i]};
   hacts[nh] = Act{ws + L.out, OUT_LD, c.out_dim};
-  // the last layer writes only out_dim columns: clear the padded row first
-  V4L_HIP_CHECK(hipMemsetAsync(ws + L.out, 0, (size_t)n * OUT_LD * sizeof(float), s));
-  return chain_fwd<T>(cx, head.data(), nh + 1, head_in, hacts, false);
+  // the last layer writes only out_dim columns: the padded row's other columns are zeros
+  if (OUT_LD > head[nh].Np) V4L_HIP_CHECK(hipMemsetAsync(ws + L.out, 0, (size_t)n * OUT_LD * sizeof(float), s));
+  return chain_fwd<T>(cx, head.data(), nh + 1, head_in, hacts, false, true);
 }
 
 // ------------------------------------------------------------------------------------------ backward
@@ -1499,6 +1502,57 @@ int v4l_net::backward_t(const float* state, const T* image, const int* rowidx, i
   hacts[nh] = Act{ws + L.out, OUT_LD, c.out_dim};
   const ADense dy = dense(ws + L.dout, OUT_LD, n, OUT_LD);
 
+  auto conv_bwd_and_wgrads = [&]() -> int {
+  int rc;
+  // The three weight-grad launches (grouped dense, the layers' whole-output one, dW3) only depend on what the data-grad kernels
+  // left behind. Measured in the update graph (ms per 48 updates): all serial 33.75; dense ones forked next to the conv-stack
+  // data-grads 33.7 (bwd_conv_kernel holds every CU: nothing fits beside it); conv-stack data-grads FIRST, then dW3 on the
+  // main stream next to the two dense launches on the auxiliary stream 32.8 (default); three branches 34.8.
+  // V4L_PAR_WGRAD=0: serial, 1: the older fork.
+  const int par_wgrad = getenv("V4L_PAR_WGRAD") ? atoi(getenv("V4L_PAR_WGRAD")) : 2;  // (read per call: tests switch it)
+  if (par_wgrad == 2 || par_wgrad == 3) {
+    cx.defer_conv3 = true;
+    if ((rc = conv_stack_bwd<T>(cx, image, rowidx, n, ws + L.c1, ws + L.c2, ws + L.dc3, ws + L.dc2, ws + L.dc1))) return rc;
+    if ((rc = par_begin(cx, true))) return rc;  // a graph fork / join under capture
+    // 3: the grouped dense weight-grads as a third branch beside wps_wgrad (auxiliary stream) and dW3 (main stream)
+    const bool three = par_wgrad == 3 && aux2 != nullptr && cx.tn != cx.s && cx.wps_pending;
+    if (three) {
+      V4L_HIP_CHECK(hipEventRecord(ev_fork2, cx.s));
+      V4L_HIP_CHECK(hipStreamWaitEvent(aux2, ev_fork2, 0));
+    }
+    // round 4: the reduction inside the forked section — the conv stack's partials (56 MB) right behind dW3 on the main
+    // stream, the others behind the grouped weight-grads on the auxiliary stream — so that the join only gates clip_adam
+    // (the update timeline showed 9 - 11 us of join latency in front of a 19 us reduce launch). V4L_SPLIT_REDUCE=0: one launch
+    // behind the join. (Same descriptor order, hence the same bits, either way.)
+    const bool split_red = !three && cx.tn != cx.s && (getenv("V4L_SPLIT_REDUCE") == nullptr || atoi(getenv("V4L_SPLIT_REDUCE")) != 0);
+    int64_t rblocks[2] = {0, 0};
+    if (split_red && (rc = wgrad_reduce_prepare(cx, rblocks))) return rc;
+    if (split_red) {
+      // (issue order matters to the graph's schedule: the auxiliary branch is the longer one and goes first)
+      const size_t nred = cx.net->red.size();
+      if ((rc = wgrad_dense<T>(cx, cx.tn, nullptr))) return rc;
+      V4L_REQUIRE(cx.net->red.size() == nred, "internal: a weight-grad registered after the reduce table was prepared");
+      if ((rc = conv3_wgrad_deferred<T>(cx, cx.s))) return rc;
+      if ((rc = wgrad_reduce_launch(cx, 0, rblocks[0], cx.s))) return rc;
+      if ((rc = wgrad_reduce_launch(cx, rblocks[0], rblocks[1], cx.tn))) return rc;
+      return par_end(cx);
+    }
+    if ((rc = wgrad_dense<T>(cx, cx.tn, three ? aux2 : nullptr))) return rc;
+    if ((rc = conv3_wgrad_deferred<T>(cx, cx.s))) return rc;
+    if (three) {
+      V4L_HIP_CHECK(hipEventRecord(ev_join2, aux2));
+      V4L_HIP_CHECK(hipStreamWaitEvent(cx.s, ev_join2, 0));
+    }
+    if ((rc = par_end(cx))) return rc;
+    return wgrad_reduce_all<T>(cx);
+  }
+  if (par_wgrad == 1 && (rc = par_begin(cx, true))) return rc;
+  if ((rc = wgrad_dense<T>(cx, cx.tn))) return rc;
+  if ((rc = conv_stack_bwd<T>(cx, image, rowidx, n, ws + L.c1, ws + L.c2, ws + L.dc3, ws + L.dc2, ws + L.dc1))) return rc;
+  if ((rc = par_end(cx))) return rc;
+  return wgrad_reduce_all<T>(cx);
+  };
+
   if (c.kind == V4L_NET_MLP) {
     // head stack, then the base MLP; the grad w.r.t. the base output (ReLU-masked) is handed over in `hand`
     const Act& last = eacts[ne - 1];
@@ -1529,8 +1583,7 @@ int v4l_net::backward_t(const float* state, const T* image, const int* rowidx, i
       ADense ys = dense(hand + c.visual_dim, cw, n, c.enc_hidden[ne - 1], nullptr, 0, ws + L.vis + c.visual_dim);
       if ((rc = chain_bwd<T>(cx, enc.data(), ne, sin, eacts, ys, dehp, nullptr))) return rc;
     }
-    if ((rc = conv_stack_bwd<T>(cx, image, rowidx, n, ws + L.c1, ws + L.c2, ws + L.dc3, ws + L.dc2, ws + L.dc1))) return rc;
-    return wgrad_finish<T>(cx);
+    return conv_bwd_and_wgrads();  // (round 4: the forked weight-grad section of the LocoTransformer backward, dW3 next to the dense ones)
   }
 
   if (c.kind == V4L_NET_CNN_VIS) {
@@ -1539,8 +1592,7 @@ int v4l_net::backward_t(const float* state, const T* image, const int* rowidx, i
     din.mask = ws + L.c3;
     din.ldmask = 1024;
     if ((rc = chain_bwd<T>(cx, head.data(), nh + 1, dense(ws + L.c3, 1024, n, 1024), hacts, dy, dhhp, &din))) return rc;
-    if ((rc = conv_stack_bwd<T>(cx, image, rowidx, n, ws + L.c1, ws + L.c2, ws + L.dc3, ws + L.dc2, ws + L.dc1))) return rc;
-    return wgrad_finish<T>(cx);
+    return conv_bwd_and_wgrads();
   }
 
   // ---- LocoTransformer / vision-only Transformer
@@ -1868,53 +1920,7 @@ int v4l_net::backward_t(const float* state, const T* image, const int* rowidx, i
     ep.ldmask = 64;
     if ((rc = lin_dgrad<T>(cx, upconv, yu, ep))) return rc;
   }
-  // The three weight-grad launches (grouped dense, the layers' whole-output one, dW3) only depend on what the data-grad kernels
-  // left behind. Measured in the update graph (ms per 48 updates): all serial 33.75; dense ones forked next to the conv-stack
-  // data-grads 33.7 (bwd_conv_kernel holds every CU: nothing fits beside it); conv-stack data-grads FIRST, then dW3 on the
-  // main stream next to the two dense launches on the auxiliary stream 32.8 (default); three branches 34.8.
-  // V4L_PAR_WGRAD=0: serial, 1: the older fork.
-  const int par_wgrad = getenv("V4L_PAR_WGRAD") ? atoi(getenv("V4L_PAR_WGRAD")) : 2;  // (read per call: tests switch it)
-  if (par_wgrad == 2 || par_wgrad == 3) {
-    cx.defer_conv3 = true;
-    if ((rc = conv_stack_bwd<T>(cx, image, rowidx, n, ws + L.c1, ws + L.c2, ws + L.dc3, ws + L.dc2, ws + L.dc1))) return rc;
-    if ((rc = par_begin(cx, true))) return rc;  // a graph fork / join under capture
-    // 3: the grouped dense weight-grads as a third branch beside wps_wgrad (auxiliary stream) and dW3 (main stream)
-    const bool three = par_wgrad == 3 && aux2 != nullptr && cx.tn != cx.s && cx.wps_pending;
-    if (three) {
-      V4L_HIP_CHECK(hipEventRecord(ev_fork2, cx.s));
-      V4L_HIP_CHECK(hipStreamWaitEvent(aux2, ev_fork2, 0));
-    }
-    // round 4: the reduction inside the forked section — the conv stack's partials (56 MB) right behind dW3 on the main
-    // stream, the others behind the grouped weight-grads on the auxiliary stream — so that the join only gates clip_adam
-    // (the update timeline showed 9 - 11 us of join latency in front of a 19 us reduce launch). V4L_SPLIT_REDUCE=0: one launch
-    // behind the join. (Same descriptor order, hence the same bits, either way.)
-    const bool split_red = !three && cx.tn != cx.s && (getenv("V4L_SPLIT_REDUCE") == nullptr || atoi(getenv("V4L_SPLIT_REDUCE")) != 0);
-    int64_t rblocks[2] = {0, 0};
-    if (split_red && (rc = wgrad_reduce_prepare(cx, rblocks))) return rc;
-    if (split_red) {
-      // (issue order matters to the graph's schedule: the auxiliary branch is the longer one and goes first)
-      const size_t nred = cx.net->red.size();
-      if ((rc = wgrad_dense<T>(cx, cx.tn, nullptr))) return rc;
-      V4L_REQUIRE(cx.net->red.size() == nred, "internal: a weight-grad registered after the reduce table was prepared");
-      if ((rc = conv3_wgrad_deferred<T>(cx, cx.s))) return rc;
-      if ((rc = wgrad_reduce_launch(cx, 0, rblocks[0], cx.s))) return rc;
-      if ((rc = wgrad_reduce_launch(cx, rblocks[0], rblocks[1], cx.tn))) return rc;
-      return par_end(cx);
-    }
-    if ((rc = wgrad_dense<T>(cx, cx.tn, three ? aux2 : nullptr))) return rc;
-    if ((rc = conv3_wgrad_deferred<T>(cx, cx.s))) return rc;
-    if (three) {
-      V4L_HIP_CHECK(hipEventRecord(ev_join2, aux2));
-      V4L_HIP_CHECK(hipStreamWaitEvent(cx.s, ev_join2, 0));
-    }
-    if ((rc = par_end(cx))) return rc;
-    return wgrad_reduce_all<T>(cx);
-  }
-  if (par_wgrad == 1 && (rc = par_begin(cx, true))) return rc;
-  if ((rc = wgrad_dense<T>(cx, cx.tn))) return rc;
-  if ((rc = conv_stack_bwd<T>(cx, image, rowidx, n, ws + L.c1, ws + L.c2, ws + L.dc3, ws + L.dc2, ws + L.dc1))) return rc;
-  if ((rc = par_end(cx))) return rc;
-  return wgrad_reduce_all<T>(cx);
+  return conv_bwd_and_wgrads();
 }
 
 // InfFinish::t_plus1 of a fused step: the host's step index + 1 for eager launches, 0 (= device cursor) under capture or when the
@@ -3185,7 +3191,7 @@ int v4l_trainer_actor_grads(v4l_trainer* tr, const v4l_rollout* ro, int n, const
     aa.dmean = tr->ws + Lp.dout; aa.dlogstd = tr->g_pf + pf->params[pf->logstd].goff; aa.st = st;
     aa.tanh_action = pf->cfg.tanh_action;
     RowsChain hc;
-    const bool ext = pf->heads_ext(tr->ws, n, &hc) != 0;
+    const bool ext = !pf->cfg.tanh_action && pf->heads_ext(tr->ws, n, &hc) != 0;
     const dim3 blk(n >= 512 ? 1024 : 256);
     if (ext) {
       const bool bf = pf->cfg.compute == V4L_BF16, big = n >= 512;
@@ -3193,7 +3199,8 @@ int v4l_trainer_actor_grads(v4l_trainer* tr, const v4l_rollout* ro, int n, const
               : (big ? launch_actor_loss_heads<float, 16>(s, aa, hc) : launch_actor_loss_heads<float, 4>(s, aa, hc));
       if (rc) return rc;
     } else {
-      V4L_KLAUNCH("actor_loss", 0, s, actor_loss_kernel, dim3(1), blk, 0, s, aa);
+      if (aa.tanh_action) V4L_KLAUNCH("actor_loss", 0, s, actor_loss_kernel<true>, dim3(1), blk, 0, s, aa);
+      else V4L_KLAUNCH("actor_loss", 0, s, actor_loss_kernel<false>, dim3(1), blk, 0, s, aa);
     }
   }
   V4L_LAUNCH_CHECK();

@@ -1060,7 +1060,7 @@ __global__ __launch_bounds__(NWAVES * 64) void critic_loss_heads_kernel(const fl
 template <typename T, int NWAVES>
 __global__ __launch_bounds__(NWAVES * 64) void actor_loss_heads_kernel(ActorArgs p, RowsChain hc) {
   if (blockIdx.x == 0) {
-    actor_loss_body(p);
+    actor_loss_body<false>(p);  // (TanhNormal policies keep the in-kernel heads and actor_loss_kernel<true>)
     return;
   }
   constexpr int MT = RowsChainCfg<T>::MT;
@@ -1075,7 +1075,7 @@ __global__ __launch_bounds__(NWAVES * 64) void actor_loss_heads_kernel(ActorArgs
     if (tid < MT * 16 && r0 + tid < p.n) {  // one thread per row: the row's d(loss)/d(mean), as block 0 files it in dmean
       const ActorDims D = actor_dims(p);
       const int i = r0 + tid, slot = p.rowidx ? p.rowidx[i] : i;
-      const ActorRow o = actor_row(p, D, i, slot, p.st[ST_ADV_MEAN], p.st[ST_ADV_STD]);
+      const ActorRow o = actor_row<false>(p, D, i, slot, p.st[ST_ADV_MEAN], p.st[ST_ADV_STD]);
       float4* drow = reinterpret_cast<float4*>(dt + tid * LY::LDX);
       drow[0] = float4{o.dlp * o.dm[0], o.dlp * o.dm[1], o.dlp * o.dm[2], o.dlp * o.dm[3]};
       drow[1] = float4{o.dlp * o.dm[4], o.dlp * o.dm[5], o.dlp * o.dm[6], o.dlp * o.dm[7]};
