@@ -26,6 +26,8 @@
  *   V4L_SPLIT_REDUCE=0        schedule 2 issues wgrad_reduce as two launches INSIDE the forked section (conv-stack partials behind
  *                             dW3, the others behind the dense weight-grads); 0 = one launch behind the join (same bits) (per call)
  *   V4L_SPLIT_DENSE_WGRAD     grouped and whole-output dense weight-grads as two launches instead of one (per call)
+ *   V4L_NO_DENSE_STACK        the NatureCNN nets' visual projector + head (forward) and their data-grads (backward) as one
+ *                             gemm_nt_deep launch per linear instead of one launch per direction (csrc/dense_stack.h; same bits) (per call)
  *   V4L_NO_SQ_FROM_REDUCE     separate grad_sumsq launch on one GPU too (the norm's partials otherwise come from wgrad_reduce)
  *   V4L_NO_FUSED_ENC          LocoTransformer encoder layer by layer (per call)
  *   V4L_NO_FUSED_LAYER        transformer layers layer by layer, forward and backward (per call)

@@ -1184,6 +1184,46 @@ def test_external_row_chains_equal_in_kernel_chains(name, mode, device, monkeypa
                 assert torch.equal(v, res[other][i][k]), (other, k)
 
 
+@pytest.mark.parametrize("mode", MODES)
+@pytest.mark.parametrize("name,B", [("cnn_b1024", 1024), ("cnn_s93", 300), ("cnn_s93", 64), ("cnn_vis", 257), ("cnn_vis", 1024)])
+def test_fused_dense_stack_equals_layer_by_layer(name, B, mode, device, monkeypatch):
+    """Round 4: the NatureCNN nets' visual projector + head run as ONE launch per direction that keeps a block's 16 / 32 rows
+    in LDS through the whole stack (csrc/dense_stack.h) instead of 4 forward + 5 data-grad gemm_nt_deep launches per net-pass.
+    Same k order per output element, same rounding points, same epilogue expressions: three PPO updates must leave bit-identical
+    statistics and parameters with and without it (V4L_NO_DENSE_STACK=1; the deep-GEMM threshold lowered so that the small and
+    ragged batches — 300 = 9 blocks + 12 rows, 257 = 8 + 1 row, 64 — compare against the same layer-by-layer kernel)."""
+    case = dict(util.CASES[name], B=B)
+    from vision4leg_amd.torchrl.algo import PPO
+    monkeypatch.setenv("V4L_GEMM_DEEP_MIN_M", "1")
+    res = {}
+    for variant in ("fused", "layers"):
+        if variant == "layers":
+            monkeypatch.setenv("V4L_NO_DENSE_STACK", "1")
+        else:
+            monkeypatch.delenv("V4L_NO_DENSE_STACK", raising=False)
+        pf, vf = _build(case, mode, device)
+
+        class Coll: epoch_frames = 1
+        agent = PPO(pf=pf, vf=vf, plr=1e-4, vlr=1e-4, clip_para=0.2, opt_epochs=3, tau=0.95, entropy_coeff=0.005,
+                    collector=Coll(), device=device, batch_size=case["B"])
+        agent.trainer.sync_target()
+        infos = []
+        for u in range(3):
+            b = util.make_batch(case, update=u)
+            infos.append(agent.update({k: b[k] for k in ("obs", "acts", "advs", "estimate_returns", "values")}))
+        torch.cuda.synchronize()
+        res[variant] = (infos, {k: v.detach().cpu().clone() for k, v in pf.state_dict().items()},
+                        {k: v.detach().cpu().clone() for k, v in vf.state_dict().items()})
+    for u in range(3):
+        for k in util.STAT_KEYS:
+            a, b = res["fused"][0][u][k], res["layers"][0][u][k]
+            assert np.isfinite(a), (u, k, a)
+            assert a == b, (u, k, a, b)
+    for i in (1, 2):
+        for k, v in res["fused"][i].items():
+            assert torch.equal(v, res["layers"][i][k]), k
+
+
 @pytest.mark.parametrize("name", ["mlp_tanh", "loco_tanh"])
 def test_tanh_policy_head(name, device):
     """tanh_action=True policies (TanhNormal, reference policies/distribution.py:5-80, continuous_policy.py:62-146): eval_act =

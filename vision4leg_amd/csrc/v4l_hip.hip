@@ -12,6 +12,7 @@
 #include "bwd.h"
 #include "wps.h"
 #include "rollout_dense.h"
+#include "dense_stack.h"
 
 namespace v4l {
 
@@ -989,6 +990,18 @@ int64_t v4l_net::table_bytes() const {
   return (int64_t)(packs.size() * sizeof(PackDesc) + params.size() * sizeof(ParamSeg) + MAX_RED * sizeof(RedDesc) +
                    MAX_TNP * sizeof(TnProb) + MAX_WIDE * sizeof(TnWide) + sq_cap() * sizeof(float) + 1024);
 }
+// the NatureCNN nets' dense stack as one launch per direction (csrc/dense_stack.h): the shipped widths only
+static bool dense_stack_shape(const v4l_net* N) {
+  const v4l_net_cfg& c = N->cfg;
+  if (getenv("V4L_NO_DENSE_STACK") != nullptr) return false;  // (read per call: tests switch it)
+  if (c.n_head_hidden != 2 || c.head_hidden[0] != 256 || c.head_hidden[1] != 256 || c.out_dim > OUT_LD) return false;
+  for (int i = 0; i < 3; ++i)
+    if (N->head[i].pkf < 0 || N->head[i].pkft < 0) return false;
+  if (c.kind == V4L_NET_CNN_VIS) return N->head[0].Kp == 1024 && N->head[0].Rt == 1024;
+  if (c.kind != V4L_NET_CNN) return false;
+  return c.visual_dim == 256 && c.n_enc_hidden == 2 && c.enc_hidden[0] == 256 && c.enc_hidden[1] == 256 && N->proj.pkf >= 0 &&
+         N->proj.pkft >= 0 && N->proj.Kp == 1024 && N->enc[1].pkft >= 0 && N->head[0].Kp == 512;
+}
 bool v4l_net::wps_layers() const {
   return fused_layers() && cfg.n_layers == 2 && layers[0].inproj.pkp >= 0 && getenv("V4L_NO_WPS_LAYERS") == nullptr;
 }
@@ -1187,6 +1200,9 @@ int v4l_net::forward_t(const float* state, const T* image, const int* rowidx, in
     V4L_LAUNCH_CHECK();
     return 0;
   };
+  // NatureCNN nets, whole forward: visual projector + head as ONE launch behind the encoder (csrc/dense_stack.h)
+  const bool dense_stack = stage == 0 && (c.kind == V4L_NET_CNN_VIS || (c.kind == V4L_NET_CNN && enc_ws == nullptr)) &&
+                           dense_stack_shape(this);
   if (c.kind == V4L_NET_MLP) {
     if (enc_ws != nullptr) eacts[ne - 1].p = const_cast<float*>(enc_ws) + L.eh[ne - 1];
     else if (stage != 2 && (rc = chain_fwd<T>(cx, enc.data(), ne, sin, eacts, true))) return rc;
@@ -1201,7 +1217,7 @@ int v4l_net::forward_t(const float* state, const T* image, const int* rowidx, in
       // visual projector on the NHWC flatten of conv3 -> columns [0, visual_dim)
       if ((rc = train_enc(std::integral_constant<int, ENC_FUSE>(), nullptr, ws + L.vis + c.visual_dim, cw))) return rc;
       Epi ep = mk_epi(ws + L.vis, cw, c.visual_dim, nullptr, 1);
-      if ((rc = lin_fwd<T>(cx, proj, dense(ws + L.c3, 1024, n, 1024), ep))) return rc;
+      if (!dense_stack && (rc = lin_fwd<T>(cx, proj, dense(ws + L.c3, 1024, n, 1024), ep))) return rc;
     } else if (stage != 2) {
       // proprio MLP on the aux stream next to the conv stack; both land in the concat buffer
       if ((rc = par_begin(cx))) return rc;
@@ -1212,7 +1228,7 @@ int v4l_net::forward_t(const float* state, const T* image, const int* rowidx, in
       if ((rc = conv_stack_fwd<T>(cx, image, rowidx, n, ws + L.c1, ws + L.c2, ws + L.c3))) return rc;
       // visual projector on the NHWC flatten of conv3 -> columns [0, visual_dim) of the concat buffer
       Epi ep = mk_epi(ws + L.vis, cw, c.visual_dim, nullptr, 1);
-      if ((rc = lin_fwd<T>(cx, proj, dense(ws + L.c3, 1024, n, 1024), ep))) return rc;
+      if (!dense_stack && (rc = lin_fwd<T>(cx, proj, dense(ws + L.c3, 1024, n, 1024), ep))) return rc;
       if ((rc = par_end(cx))) return rc;
     }
     head_in = dense(ws + L.vis, cw, n, cw);
@@ -1463,6 +1479,33 @@ int v4l_net::forward_t(const float* state, const T* image, const int* rowidx, in
     V4L_LAUNCH_CHECK();
   }
   if (stage == 1) return 0;
+  if (dense_stack) {
+    const bool fuse = c.kind == V4L_NET_CNN;
+    const T* pb = (const T*)packed;
+    DsFwd a;
+    memset(&a, 0, sizeof(a));
+    a.c3 = head_in.p;  // (vision-only net: the flatten is the head's input, possibly another net's workspace)
+    if (fuse) { a.c3 = ws + L.c3; a.cat = ws + L.vis; a.wp = pb + proj.pkf; a.bp = p[proj.b]; }
+    a.w0 = pb + head[0].pkf; a.w1 = pb + head[1].pkf; a.w2 = pb + head[2].pkf;
+    a.b0 = p[head[0].b]; a.b1 = p[head[1].b]; a.b2 = p[head[2].b];
+    a.h0 = ws + L.hh[0]; a.h1 = ws + L.hh[1]; a.out = ws + L.out;
+    a.n = n; a.nout = c.out_dim;
+    static bool attr_done = false;
+    if (!attr_done) {
+      V4L_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&dense_stack_fwd_kernel<T, true>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)DsFwdLds<T>::bytes));
+      V4L_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&dense_stack_fwd_kernel<T, false>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)DsFwdLds<T>::bytes));
+      attr_done = true;
+    }
+    g_op = "dense.stack";
+    const double fl = 2.0 * n * ((fuse ? 1024.0 * 256 + 512.0 * 256 : 1024.0 * 256) + 256.0 * 256 + 256.0 * c.out_dim);
+    const dim3 grid(cdiv(n, 16 * DsCfg<T>::MT));
+    if (fuse) V4L_KLAUNCH("dense_stack_fwd", fl, s, (dense_stack_fwd_kernel<T, true>), grid, dim3(256), DsFwdLds<T>::bytes, s, a);
+    else V4L_KLAUNCH("dense_stack_fwd", fl, s, (dense_stack_fwd_kernel<T, false>), grid, dim3(256), DsFwdLds<T>::bytes, s, a);
+    V4L_LAUNCH_CHECK();
+    return 0;
+  }
   Act hacts[V4L_MAX_HIDDEN + 1];
   for (int i = 0; i < nh; ++i) hacts[i] = Act{ws + L.hh[i], c.head_hidden[i], c.head_hidden[i]};
   hacts[nh] = Act{ws + L.out, OUT_LD, c.out_dim};
@@ -1563,6 +1606,52 @@ int v4l_net::backward_t(const float* state, const T* image, const int* rowidx, i
     if ((rc = chain_bwd<T>(cx, head.data(), nh + 1, dense(last.p, last.ld, n, last.w), hacts, dy, dhhp, &din))) return rc;
     if ((rc = chain_bwd<T>(cx, enc.data(), ne, sin, eacts, dense(hand, last.w, n, last.w), dehp, nullptr))) return rc;
     return wgrad_finish<T>(cx);
+  }
+
+  // NatureCNN nets: the dense stack's data-grads as ONE launch (csrc/dense_stack.h); the weight-grads are registered in the
+  // order chain_bwd registers them (same grouped launch, same reduce table, same norm partials)
+  if ((c.kind == V4L_NET_CNN || c.kind == V4L_NET_CNN_VIS) && dense_stack_shape(this)) {
+    const bool fuse = c.kind == V4L_NET_CNN;
+    const int cw = 512;
+    float* hand = ws + L.dhc;
+    const T* pb = (const T*)packed;
+    DsBwd a;
+    memset(&a, 0, sizeof(a));
+    a.dout = ws + L.dout;
+    a.w2t = pb + head[2].pkft; a.w1t = pb + head[1].pkft; a.w0t = pb + head[0].pkft;
+    a.h1 = ws + L.hh[1]; a.h0 = ws + L.hh[0]; a.c3 = ws + L.c3;
+    a.dh1 = dhhp[1]; a.dh0 = dhhp[0]; a.dc3 = ws + L.dc3;
+    if (fuse) {
+      a.wpt = pb + proj.pkft; a.wf2t = pb + enc[1].pkft;
+      a.cat = ws + L.vis; a.e0 = ws + L.eh[0]; a.dcat = hand; a.de0 = dehp[0];
+    }
+    a.n = n;
+    static bool attr_done = false;
+    if (!attr_done) {
+      V4L_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&dense_stack_bwd_kernel<T, true>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)DsBwdLds<T>::bytes));
+      V4L_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&dense_stack_bwd_kernel<T, false>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)DsBwdLds<T>::bytes));
+      attr_done = true;
+    }
+    g_op = "dense.stack.bwd";
+    const double fl = 2.0 * n * (256.0 * c.out_dim + 256.0 * 256 + (fuse ? 512.0 * 256 + 1024.0 * 256 + 256.0 * 256 : 1024.0 * 256));
+    const dim3 grid(cdiv(n, 16 * DsCfg<T>::MT));
+    if (fuse) V4L_KLAUNCH("dense_stack_bwd", fl, s, (dense_stack_bwd_kernel<T, true>), grid, dim3(256), DsBwdLds<T>::bytes, s, a);
+    else V4L_KLAUNCH("dense_stack_bwd", fl, s, (dense_stack_bwd_kernel<T, false>), grid, dim3(256), DsBwdLds<T>::bytes, s, a);
+    V4L_LAUNCH_CHECK();
+    const ADense x_in = fuse ? dense(ws + L.vis, cw, n, cw) : dense(ws + L.c3, 1024, n, 1024);
+    if ((rc = lin_wgrad<T>(cx, head[2], dy, dense(hacts[1].p, 256, n, 256), 256))) return rc;
+    if ((rc = lin_wgrad<T>(cx, head[1], dense(dhhp[1], 256, n, 256), dense(hacts[0].p, 256, n, 256), 256))) return rc;
+    if ((rc = lin_wgrad<T>(cx, head[0], dense(dhhp[0], 256, n, 256), x_in, x_in.K))) return rc;
+    if (fuse) {
+      ADense yv = dense(hand, cw, n, c.visual_dim, nullptr, 0, ws + L.vis);
+      if ((rc = lin_wgrad<T>(cx, proj, yv, dense(ws + L.c3, 1024, n, 1024), 1024))) return rc;
+      ADense ys = dense(hand + c.visual_dim, cw, n, 256, nullptr, 0, ws + L.vis + c.visual_dim);
+      if ((rc = lin_wgrad<T>(cx, enc[1], ys, dense(ws + L.eh[0], 256, n, 256), 256))) return rc;
+      if ((rc = lin_wgrad<T>(cx, enc[0], dense(dehp[0], 256, n, 256), sin, sin.K))) return rc;
+    }
+    return conv_bwd_and_wgrads();
   }
 
   if (c.kind == V4L_NET_CNN) {
