@@ -1,8 +1,8 @@
 """-m gpu: out-of-bounds WRITE check of the HIP path's device buffers (SURVEY.md §5 "sanitizers" row).
 
-Device-side AddressSanitizer is not available for this library (hipcc -fsanitize=address --offload-arch=gfx950:xnack+ did not
-finish instrumenting the fused kernels within three hours at -O1 and hits a compiler error at -O0: profiles/r4_gpu_asan_attempt.txt),
-so the suite checks what it can on the hardware: with V4L_GUARD=1 every buffer the library writes into (workspaces, control
+Device-side AddressSanitizer cannot run on this GPU pool (the instrumented library — tools/asan_gpu_check.sh, 75 minutes at
+-O1, a compiler error at -O0 — was built and taken to the box: the agent is gfx950:xnack- and the image has no ASAN build of the
+ROCm runtime, profiles/r4_gpu_asan.txt), so the suite checks what it can on the hardware: with V4L_GUARD=1 every buffer the library writes into (workspaces, control
 blocks, packed weights, descriptor tables, gradient buckets, Adam moments, rollout arrays, actor outputs) sits between two
 64 KB canary bands, the shapes that stress the hand-computed offsets run (ragged batches, E = 33 / 7 rollout steps, the
 B = 1024 update with graph replays, both compute modes), and no band may have been touched."""

@@ -22,10 +22,10 @@ run)
     echo "# tools/asan_gpu_check.sh run: device-ASAN build of csrc/v4l_hip.hip ($(stat -c %s "$LIB") bytes), HSA_XNACK=1, runtime $RT"
     export HSA_XNACK=1 V4L_LIB=$LIB LD_PRELOAD=$RT ASAN_OPTIONS=detect_leaks=0:halt_on_error=0:abort_on_error=0
     echo "## smoke()"
-    timeout 900 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -15
+    timeout 420 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -15
     echo "smoke exit code: ${PIPESTATUS[0]}"
     echo "## ragged batches (n = 1, 30), dense rollout step E = 33"
-    timeout 1500 python -m pytest tests/test_gpu_parity.py -q -m gpu -p no:cacheprovider \
+    timeout 600 python -m pytest tests/test_gpu_parity.py -q -m gpu -p no:cacheprovider \
       -k "fused_kernels_on_ragged_batches or (dense_rollout_step_env_counts and 33)" 2>&1 | tail -15
     echo "pytest exit code: ${PIPESTATUS[0]}"
   } > "$OUT" 2>&1
