@@ -466,6 +466,19 @@ def algo_bytes(kernel, wl, compute):
         "wps_layer_bwd_stack": R * 2 * tok + 2 * R * 1024 * t + R * tok + n * (16 * 64 + 16 + 4 * 256 + 2 * 256) * 4,
         "wps_wgrad": 2 * R * 1024 * t + 2 * (-(-n // 32)) * (49152 + 576) * 4,
     }
+    # NatureCNN nets' dense stack (csrc/dense_stack.h), fp32 rows. forward: conv3's flatten (+ the proprio half of the concat)
+    # in; projector output, h0, h1, padded head output out. backward: dout + the ReLU masks (h1, h0, concat, flatten, e0) in;
+    # dh1, dh0, dcat, dc3, de0 out. Weights: every (row-block) streams them; algorithmic = once.
+    if wl["kind"] == "cnn":
+        w_f = (1024 * 256 + 512 * 256 + 256 * 256 + 256 * 16) * t
+        w_b = (64 * 256 + 256 * 256 + 512 * 256 + 1024 * 256 + 256 * 256) * t
+        per_launch["dense_stack_fwd"] = n * (1024 + 256 + 256 + 256 + 256 + 16) * 4 + w_f
+        per_launch["dense_stack_bwd"] = n * (16 + 256 + 256 + 512 + 1024 + 256 + 256 + 256 + 512 + 1024 + 256) * 4 + w_b
+    elif wl["kind"] == "cnn_vis":
+        w_f = (1024 * 256 + 256 * 256 + 256 * 16) * t
+        w_b = (64 * 256 + 256 * 256 + 1024 * 256) * t
+        per_launch["dense_stack_fwd"] = n * (1024 + 256 + 256 + 16) * 4 + w_f
+        per_launch["dense_stack_bwd"] = n * (16 + 256 + 256 + 1024 + 256 + 256 + 1024) * 4 + w_b
     E = wl["E"]
     enc_w = (4 * 64 * 32 + 32 * 16 * 64 + 64 * 9 * 64 + 64 * 64 + 128 * 256 + 256 * 256 + 256 * 64) * t
     layer_w = (64 * 192 + 64 * 64 + 64 * 256 + 256 * 64) * t
@@ -512,6 +525,10 @@ def block_fetch_bytes(kernel, wl, compute):
         "wps_layer_bwd_stack": (-(-n // 4), 2 * L * lw + head_w + mlp_w - 128 * 256 * t + 64 * 64 * t),
         "fused_encoder": (256, conv_w),
     }
+    if wl["kind"] in ("cnn", "cnn_vis"):  # 16 rows per block, each block streams the whole stack's weights
+        fuse = wl["kind"] == "cnn"
+        table["dense_stack_fwd"] = (-(-n // 16), ((1024 * 256 + 512 * 256 if fuse else 1024 * 256) + 256 * 256 + 256 * 16) * t)
+        table["dense_stack_bwd"] = (-(-n // 16), (64 * 256 + 256 * 256 + (512 * 256 + 1024 * 256 + 256 * 256 if fuse else 1024 * 256)) * t)
     if kernel not in table:
         return None
     blocks, w = table[kernel]
