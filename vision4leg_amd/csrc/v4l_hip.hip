@@ -1131,7 +1131,7 @@ Layout v4l_net::layout(int n) const {
     L.dpool = take((int64_t)n * 2 * TD);
     if (!layers.empty() && layers[0].inproj.pkp >= 0) {
       for (int l = 0; l < c.n_layers; ++l) {  // sized for fp32 operands (parity mode); bf16 uses half
-        L.wps_wg.push_back(take((int64_t)n * WPS_WG_ELEMS));
+        L.wps_wg.push_back(take((int64_t)n * WPS_WG_STRIDE));
         L.wps_tk.push_back(take((int64_t)n * WPS_TK_ELEMS));
       }
     }

@@ -59,6 +59,11 @@ constexpr int WPS_P_BIN = 0, WPS_P_BO = 192, WPS_P_B1 = 256, WPS_P_B2 = 512, WPS
 // [64 lanes][tile 2p: tokens 4g..4g+3 | tile 2p+1: tokens 4g..4g+3] at feature fr. Feature tiles (x side, then dY side):
 constexpr int WPS_T_XIN = 0, WPS_T_CTX = 4, WPS_T_X1 = 8, WPS_T_F = 12, WPS_T_DZ2 = 28, WPS_T_DF = 32, WPS_T_DZ1 = 48, WPS_T_DQKV = 52;
 constexpr int WPS_WG_ELEMS = 32 * 64 * 8;  // per (sample, layer), elements of T
+// sample-to-sample stride of the operand blocks: NOT the power of two the block size is — at any moment the 1024 waves of the
+// backward write (and the weight-grad kernel's waves read) the same 1 KB piece of 1024 different samples' blocks, and with a
+// 32 KB stride (bf16) those addresses agree in every bit the memory channels are selected by below the page level:
+// wps_wgrad_kernel 23.7 -> 21.3 us with 512 bytes of padding per block (4 processes each, round 4)
+constexpr int WPS_WG_STRIDE = WPS_WG_ELEMS + 256;
 constexpr int WPS_TK_ELEMS = 32 * 4 * 8;   // the 17th token's 1024 features, in fragment (k-permuted) order [pair][g][8]
 constexpr int WPS_SPLIT = 32;              // samples per weight-grad partial (one K=32 step of 17th tokens)
 constexpr int WPS_ROLES = 12;              // 4x4-tile weight-grad jobs per layer
@@ -987,10 +992,12 @@ __device__ __forceinline__ void rows_chain(const RowsChain& c, const float* dt, 
     }
   }
 }
-// rows per block of the heads' chain in the loss launches: 64 in bf16 (85 KB of LDS), 32 in the fp32 parity mode (fragments
-// twice the size); of the proprio chain inside wps_wgrad_kernel: 32 (its accumulators must fit beside that kernel's two waves
-// per SIMD)
-template <typename T> struct RowsChainCfg { static constexpr int MT = sizeof(T) == 2 ? 4 : 2; static constexpr int MT_TOK0 = 2; };
+// rows per block of the heads' chain in the loss launches: 16 — a chain block's time is its CU pulling the chain's 224 KB of
+// weights plus its rows' masks and saves through one L1, so fewer rows per block and more blocks is faster (measured,
+// actor_loss_heads_kernel at B = 1024: 64 rows 21.3 us, 32 rows 17.2 - 18.5, 16 rows 15.8 = the statistics block's own time);
+// of the proprio chain inside wps_wgrad_kernel: 32 (16 measured the same; its accumulators must fit beside that kernel's two
+// waves per SIMD)
+template <typename T> struct RowsChainCfg { static constexpr int MT = 1; static constexpr int MT_TOK0 = 2; };
 
 // the proprio chain of BwdTail for rows r0.. : token-0 rows of the layer-0 input gradient, masked by the token's ReLU
 template <typename T, int NW>
@@ -1206,7 +1213,7 @@ __global__ __launch_bounds__(256) void wps_layer_bwd_kernel(WpsBwdStack stk, Bwd
 #pragma unroll
   for (int l = 0; l < NL; ++l) {  // stk.l[0] = the upper layer
     const WpsBwdLayer& w = stk.l[l];
-    const WpsOut wo = wps_out<T>(reinterpret_cast<T*>(w.wg) + srow * WPS_WG_ELEMS, reinterpret_cast<T*>(w.tk) + srow * WPS_TK_ELEMS, live);
+    const WpsOut wo = wps_out<T>(reinterpret_cast<T*>(w.wg) + srow * WPS_WG_STRIDE, reinterpret_cast<T*>(w.tk) + srow * WPS_TK_ELEMS, live);
     __syncthreads();  // the scratch / the previous layer's transposed weights are dead
     WPS_STAMP(33 + 8 * l);
     {
@@ -1406,8 +1413,8 @@ __global__ __launch_bounds__(256) void wps_wgrad_kernel(WpsWg a) {
   // SIMD to itself, so nothing else hides the L2 / HBM round trip)
   auto fetch = [&](int s, frag_t (&u)[8]) {  // [x pair 0: A, B | x pair 1: A, B | y pair 0: A, B | y pair 1: A, B]
     const int sa = s < send ? s : sbeg, sb_ = s + 1 < send ? s + 1 : sa;
-    const T* pa = wg + (int64_t)sa * WPS_WG_ELEMS + lane * 8;
-    const T* pb = wg + (int64_t)sb_ * WPS_WG_ELEMS + lane * 8;
+    const T* pa = wg + (int64_t)sa * WPS_WG_STRIDE + lane * 8;
+    const T* pb = wg + (int64_t)sb_ * WPS_WG_STRIDE + lane * 8;
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
       u[2 * q] = *reinterpret_cast<const frag_t*>(pa + (int64_t)(ro.kt0 / 2 + q) * 512);
