@@ -1193,17 +1193,33 @@ __global__ __launch_bounds__(256) void bwd_conv3_wgrad_kernel(BwdConv a) {
 #pragma unroll
     for (int c = 0; c < 4; ++c) acc3[t][c] = f32x4{0.f, 0.f, 0.f, 0.f};
   float bias3 = 0.f;
+  // a sample's rows (dc3 16 x 64, c2 36 x 64 fp32 = 13 KB) are requested one sample ahead into registers: the block used to
+  // load -> barrier -> compute one sample after the other, a cold HBM round trip per sample in front of ~100 LDS reads per lane
+  // (thread t: dc3 row t >> 4, columns 4 (t & 15); c2 float4s t, t + 256, t + 512 of the sample's 576)
+  const int i2 = tid + 512 < 36 * 16 ? tid + 512 : 0;
+  float4 r3 = {0.f, 0.f, 0.f, 0.f}, r2a = r3, r2b = r3, r2c = r3;
+  if ((int)blockIdx.x < a.n) {
+    const float* g3 = a.dc3 + (int64_t)blockIdx.x * 16 * 64;
+    const float* g2 = a.c2 + (int64_t)blockIdx.x * 36 * 64;
+    r3 = *reinterpret_cast<const float4*>(g3 + tid * 4);
+    r2a = *reinterpret_cast<const float4*>(g2 + tid * 4);
+    r2b = *reinterpret_cast<const float4*>(g2 + (tid + 256) * 4);
+    r2c = *reinterpret_cast<const float4*>(g2 + i2 * 4);
+  }
   for (int smp = blockIdx.x; smp < a.n; smp += gridDim.x) {
-    __syncthreads();
-    const float* g3 = a.dc3 + (int64_t)smp * 16 * 64;
-    const float* g2 = a.c2 + (int64_t)smp * 36 * 64;
-    {
-      const int r = tid >> 4, c4 = (tid & 15) * 4;
-      *reinterpret_cast<float4*>(sdc3 + r * LF + c4) = *reinterpret_cast<const float4*>(g3 + r * 64 + c4);
-    }
-    for (int i4 = tid; i4 < 36 * 16; i4 += 256) {
-      const int r = i4 >> 4, c4 = (i4 & 15) * 4;
-      *reinterpret_cast<float4*>(sc2 + r * LF + c4) = *reinterpret_cast<const float4*>(g2 + r * 64 + c4);
+    __syncthreads();  // the previous sample's readers are done
+    *reinterpret_cast<float4*>(sdc3 + (tid >> 4) * LF + (tid & 15) * 4) = r3;
+    *reinterpret_cast<float4*>(sc2 + (tid >> 4) * LF + (tid & 15) * 4) = r2a;
+    *reinterpret_cast<float4*>(sc2 + ((tid + 256) >> 4) * LF + (tid & 15) * 4) = r2b;
+    if (tid + 512 < 36 * 16) *reinterpret_cast<float4*>(sc2 + ((tid + 512) >> 4) * LF + (tid & 15) * 4) = r2c;
+    const int nxt = smp + (int)gridDim.x;
+    if (nxt < a.n) {  // (block-uniform)
+      const float* g3 = a.dc3 + (int64_t)nxt * 16 * 64;
+      const float* g2 = a.c2 + (int64_t)nxt * 36 * 64;
+      r3 = *reinterpret_cast<const float4*>(g3 + tid * 4);
+      r2a = *reinterpret_cast<const float4*>(g2 + tid * 4);
+      r2b = *reinterpret_cast<const float4*>(g2 + (tid + 256) * 4);
+      r2c = *reinterpret_cast<const float4*>(g2 + i2 * 4);
     }
     __syncthreads();
     if (tid < 64) {
