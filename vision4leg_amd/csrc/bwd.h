@@ -1193,6 +1193,20 @@ __global__ __launch_bounds__(256) void bwd_conv3_wgrad_kernel(BwdConv a) {
 #pragma unroll
     for (int c = 0; c < 4; ++c) acc3[t][c] = f32x4{0.f, 0.f, 0.f, 0.f};
   float bias3 = 0.f;
+  // LDS offsets of the im2col elements a lane reads, hoisted out of the sample loop (the tap of a k-tile depends on the wave:
+  // the division by 3 and the index arithmetic were ~700 of the loop body's 1 050 VALU instructions, for 36 MFMAs):
+  // element (tile t, slot j) = c2[(oy + ky) * 6 + ox + kx][ci] with pos = 8 (g & 1) + j = 4 oy + ox
+  int x_base[9], x_pos[8];
+#pragma unroll
+  for (int t = 0; t < 9; ++t) {
+    const int kt = kt3 + t, tap = kt >> 2, ky = tap / 3, kx = tap - ky * 3;
+    x_base[t] = (ky * 6 + kx) * LF + (kt & 3) * 16 + fr;
+  }
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int pos = (g & 1) * 8 + j;
+    x_pos[j] = ((pos >> 2) * 6 + (pos & 3)) * LF;
+  }
   // a sample's rows (dc3 16 x 64, c2 36 x 64 fp32 = 13 KB) are requested one sample ahead into registers: the block used to
   // load -> barrier -> compute one sample after the other, a cold HBM round trip per sample in front of ~100 LDS reads per lane
   // (thread t: dc3 row t >> 4, columns 4 (t & 15); c2 float4s t, t + 256, t + 512 of the sample's 576)
@@ -1241,12 +1255,9 @@ __global__ __launch_bounds__(256) void bwd_conv3_wgrad_kernel(BwdConv a) {
     }
 #pragma unroll
     for (int t = 0; t < 9; ++t) {
-      const int kt = kt3 + t, tap = kt >> 2, ci = (kt & 3) * 16 + fr;
-      const int ky = tap / 3, kx = tap - ky * 3;
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
-        const int pos = (g & 1) * 8 + j, oy = pos >> 2, ox = pos & 3;
-        const float x = sc2[((oy + ky) * 6 + ox + kx) * LF + ci];
+        const float x = sc2[x_base[t] + x_pos[j]];
         v[j] = g < 2 ? x : 0.f;
       }
       const frag_t fx = frag_of<T>(v);
