@@ -161,6 +161,8 @@ def loco_forward(p, x, S, mode="f32", taps=None, max_pool=False):
     st = torch.relu(linear(h, p["encoder.state_projector.projection.0.weight"],
                            p["encoder.state_projector.projection.0.bias"], mode))               # base.py:613
     tok = torch.cat([st.unsqueeze(1), depth_tok], dim=1)                                        # base.py:617-622
+    if "token_ln.weight" in p:                                                                  # token_norm=True: nets.py:1007-1008
+        tok = F.layer_norm(tok, (tok.shape[-1],), p["token_ln.weight"], p["token_ln.bias"], 1e-5)
     if taps is not None:
         taps["c3"] = c3; taps["x0"] = tok
     l = 0
@@ -202,6 +204,8 @@ def loco_vis_forward(p, x, S=0, mode="f32", taps=None, max_pool=False):
     c3 = nature_cnn(p, "encoder.depth_visual_base", img, mode)                                  # base.py:449
     up = conv2d(c3, p["encoder.depth_up_conv.weight"], p["encoder.depth_up_conv.bias"], 1, mode)   # base.py:452
     tok = up.reshape(B, 64, 16).permute(0, 2, 1)                                                # base.py:474-481
+    if "token_ln.weight" in p:                                                                  # token_norm=True: nets.py:879-880
+        tok = F.layer_norm(tok, (tok.shape[-1],), p["token_ln.weight"], p["token_ln.bias"], 1e-5)
     if taps is not None:
         taps["c3"] = c3; taps["x0"] = tok
     l = 0
@@ -232,7 +236,9 @@ def loco_vis_max_forward(p, x, S=0, mode="f32", taps=None):
 FORWARDS = {"loco": loco_forward, "cnn": cnn_forward, "mlp": mlp_forward, "loco_vis": loco_vis_forward,
             "cnn_vis": cnn_vis_forward, "loco_max": loco_max_forward, "loco_vis_max": loco_vis_max_forward,
             # tanh_action=True policies: the same nets, a TanhNormal head (PPOOracle reads the suffix)
-            "mlp_tanh": mlp_forward, "loco_tanh": loco_forward}
+            "mlp_tanh": mlp_forward, "loco_tanh": loco_forward,
+            # token_norm=True: the forwards see token_ln.* among the parameters
+            "loco_tn": loco_forward, "loco_vis_tn": loco_vis_forward}
 
 
 # ------------------------------------------------------------------------------------------ Gaussian head

@@ -53,6 +53,12 @@ def _flat(gs, keys):
     return torch.cat([gs[k].reshape(-1) for k in keys]).double()
 
 
+def _grad(loss, tensors):
+    """autograd.grad with zeros for parameters the forward never touches (token_norm=True: state_token_ln.*)"""
+    g = torch.autograd.grad(loss, tensors, allow_unused=True)
+    return tuple(torch.zeros_like(t) if x is None else x for x, t in zip(g, tensors))
+
+
 def _bf16_envelope(name, tag, kind, params, obs, S, w, scales=ENV_SCALES):
     """The bf16 oracle's own sensitivity. bf16 arithmetic is chaotic over ~20 stacked contractions: a 1e-7 relative nudge of
     the parameters (far below one bf16 ulp, 4e-3) moves a handful of rounding / ReLU decisions, and each moved decision
@@ -70,7 +76,7 @@ def _bf16_envelope(name, tag, kind, params, obs, S, w, scales=ENV_SCALES):
     def run(p):
         q = {k: v.detach().clone().requires_grad_(True) for k, v in p.items()}
         out = fn(q, obs, S, "bf16")
-        g = torch.autograd.grad((out * w).sum(), [q[k] for k in keys])
+        g = _grad((out * w).sum(), [q[k] for k in keys])
         return out.detach(), dict(zip(keys, g))
     out0, g0 = run(params)
     f0 = _flat(g0, keys)
@@ -229,7 +235,7 @@ def test_backward(name, mode, device):
         for k in keys:
             op[k].requires_grad_(True)
         out = orc.FORWARDS[case["kind"]](op, obs, case["S"], mode)
-        ref = torch.autograd.grad((out * w).sum(), [op[k] for k in keys])
+        ref = _grad((out * w).sum(), [op[k] for k in keys])
         for k in keys:
             op[k].requires_grad_(False)
         bad = []
@@ -269,7 +275,7 @@ def test_backward(name, mode, device):
                             p64 = {kk: (vv.detach().double() * (1 + scale * torch.randn(vv.shape, generator=gen).double()))
                                    .requires_grad_(True) for kk, vv in op.items()}
                             o64 = orc.FORWARDS[case["kind"]](p64, obs.double(), case["S"], "f32")
-                            return dict(zip(keys, torch.autograd.grad((o64 * w.double()).sum(), [p64[kk] for kk in keys])))
+                            return dict(zip(keys, _grad((o64 * w.double()).sum(), [p64[kk] for kk in keys])))
                         ref64 = grad64(0.0, 0)
                         nudged = [grad64(3e-6, sd) for sd in (1, 2, 3, 4)]
                     e64, n64 = util.rel_err(got, ref64[k]), util.rel_err(g, ref64[k])
@@ -359,10 +365,13 @@ def test_ppo_update(name, mode, device):
                 tot += dd.sum().item(); cnt += dd.numel()
                 # f32: fp32-roundoff. bf16: Adam's early steps are ~lr*sign(g) per element, so a gradient whose
                 # sign flips inside the bf16 envelope moves that element by up to 2*lr per update
-                assert d <= (2e-5 if mode == "f32" else 2.2e-4 * (u + 1)), (u, tag, k, d)
+                # (case["param_tol_f32"]: a LayerNorm in front of the stack leaves gradient elements of the order of Adam's eps;
+                # there the first step lr g / (|g| + 1e-8) turns 1e-8 of fp32 summation noise into a quarter of lr)
+                tol32 = case.get("param_tol_f32", 2e-5)
+                assert d <= (tol32 if mode == "f32" else 2.2e-4 * (u + 1)), (u, tag, k, d)
                 if mode == "f32" and ("u%d/%s/%s" % (u, tag, k)) in gold.files:
                     dg = np.abs(v.detach().cpu().numpy() - gold["u%d/%s/%s" % (u, tag, k)]).max()
-                    assert dg <= 2e-5, (u, tag, k, dg)
+                    assert dg <= tol32, (u, tag, k, dg)
         print("   mean |param - oracle| = %.2e" % (tot / cnt))
         util.record("ppo_update/%s/%s/u%d/max_info_rel_vs_oracle" % (name, mode, u),
                     max(abs(a - o) / max(1.0, abs(o)) for _, a, o, _ in rows))
@@ -595,7 +604,7 @@ def test_graph_replay_equals_eager(mode, pair, device):
 
 @pytest.mark.parametrize("graph", [False, True])
 @pytest.mark.parametrize("mode", MODES)
-@pytest.mark.parametrize("name", ["loco_s84", "cnn_s93", "mlp_s93", "loco_vis", "cnn_vis"])
+@pytest.mark.parametrize("name", ["loco_s84", "cnn_s93", "mlp_s93", "loco_vis", "cnn_vis", "loco_tn", "loco_vis_tn"])
 def test_rollout_actor_matches_separate_calls(name, mode, graph, device):
     """RolloutActor.step (shared encoder pass, graph replay, device-side cursor) == pf.explore + vf of the reference
     protocol: same mean/std/value, action = mean + std*eps, rows/actions/values filed at slots [t*E,(t+1)*E)."""

@@ -38,6 +38,10 @@ CASES = {
     # layer-by-layer kernels (pool_fwd / pool_bwd with the arg-max mask)
     "loco_max": dict(kind="loco_max", S=84, A=6, seed=12, B=32, enc=[256, 256], head=[256, 256], layers=2, ff=256),
     "loco_vis_max": dict(kind="loco_vis_max", S=0, A=6, seed=13, B=32, enc=[], head=[256, 256], layers=2, ff=256),
+    # token_norm=True (nets.py:815-818, 879-880, 1007-1008; no shipped config sets it): token_ln over every token in front of the
+    # transformer layers (and the state_token_ln parameters nobody uses) — on the layer-by-layer kernels
+    "loco_tn": dict(kind="loco_tn", S=84, A=6, seed=16, B=32, enc=[256, 256], head=[256, 256], layers=2, ff=256),
+    "loco_vis_tn": dict(kind="loco_vis_tn", S=0, A=6, seed=17, B=32, enc=[], head=[256, 256], layers=2, ff=256, param_tol_f32=4e-5),
     # tanh_action=True (TanhNormal head, policies/distribution.py:5-80; no shipped config sets it): the update's log-probs go
     # through atanh(stored action) with the -log(1 - a^2 + 1e-6) correction; the rollout step on the layer-by-layer kernels
     "mlp_tanh": dict(kind="mlp_tanh", S=93, A=6, seed=14, B=64, enc=[256, 256], head=[256, 256]),

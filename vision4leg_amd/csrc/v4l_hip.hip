@@ -858,6 +858,12 @@ int v4l_net::build() {
       const int e = make_mlp("encoder.base.seq_fcs", c.state_dim, c.enc_hidden, c.n_enc_hidden, false, enc);
       proj = make_lin("encoder.state_projector.projection.0.weight", "encoder.state_projector.projection.0.bias", TD, e, true);
     }
+    if (c.token_norm) {  // (the reference creates them between the encoder and the layers: nets.py:815-818)
+      tok_ln.g = add_param("token_ln.weight", {TD});
+      tok_ln.b = add_param("token_ln.bias", {TD});
+      stok_ln.g = add_param("state_token_ln.weight", {TD});
+      stok_ln.b = add_param("state_token_ln.bias", {TD});
+    }
     for (int l = 0; l < c.n_layers; ++l) {
       const std::string id = "visual_append_layers." + std::to_string(l);
       TLayer t;
@@ -1007,12 +1013,12 @@ bool v4l_net::wps_layers() const {
 }
 bool v4l_net::wps_vis() const {
   const v4l_net_cfg& c = cfg;
-  return c.kind == V4L_NET_LOCO_VIS && !c.max_pool && c.ff_dim == 256 && c.n_layers == 2 && c.n_head_hidden == 2 && c.head_hidden[0] == 256 &&
+  return c.kind == V4L_NET_LOCO_VIS && !c.max_pool && !c.token_norm && c.ff_dim == 256 && c.n_layers == 2 && c.n_head_hidden == 2 && c.head_hidden[0] == 256 &&
          c.head_hidden[1] == 256 && c.out_dim <= OUT_LD && layers[0].inproj.pkp >= 0 && head[0].pko >= 0 &&
          getenv("V4L_NO_WPS_LAYERS") == nullptr && getenv("V4L_NO_FUSED_LAYER") == nullptr;
 }
 bool v4l_net::fused_layers() const {
-  return cfg.kind == V4L_NET_LOCO && cfg.ff_dim == 256 && getenv("V4L_NO_FUSED_LAYER") == nullptr;
+  return cfg.kind == V4L_NET_LOCO && cfg.ff_dim == 256 && !cfg.token_norm && getenv("V4L_NO_FUSED_LAYER") == nullptr;
 }
 // backward_t's own conditions for the (non-vision) wave-per-sample backward, for callers that prepare work for it
 bool v4l_net::wps_bwd_plain() const {
@@ -1096,6 +1102,7 @@ Layout v4l_net::layout(int n) const {
   if (c.kind == V4L_NET_CNN) L.vis = take((int64_t)n * (c.visual_dim + c.enc_hidden[c.n_enc_hidden - 1]));
   if (is_tf()) {
     for (int l = 0; l <= c.n_layers; ++l) L.x.push_back(take(R * TD));
+    if (c.token_norm) { L.x0raw = take(R * TD); L.xh0 = take(R * TD); L.rs0 = take(R); L.dx0raw = take(R * TD); }
     for (int l = 0; l < c.n_layers; ++l) {
       LayerWs w;
       w.qkv = take(R * 3 * TD);
@@ -1242,7 +1249,10 @@ int v4l_net::forward_t(const float* state, const T* image, const int* rowidx, in
     }
     head_in = dense((enc_ws != nullptr ? enc_ws : ws) + L.c3, 1024, n, 1024);
   } else {
-    float* x0 = enc_ws != nullptr ? const_cast<float*>(enc_ws) + L.x[0] : ws + L.x[0];
+    // token_norm: the encoder's tokens go to x0raw (of the workspace the encoder ran in), x[0] of THIS net's workspace takes
+    // their LayerNorm — token_ln belongs to the net, not to the (possibly shared) encoder — and the layers read x[0] as ever
+    float* x0 = c.token_norm ? (enc_ws != nullptr ? const_cast<float*>(enc_ws) : ws) + L.x0raw
+                             : (enc_ws != nullptr ? const_cast<float*>(enc_ws) + L.x[0] : ws + L.x[0]);
     const bool fused_enc = ne == 2 && c.enc_hidden[0] == 256 && c.enc_hidden[1] == 256 && c.state_dim <= 128 &&
                            getenv("V4L_NO_FUSED_ENC") == nullptr;
     if (enc_ws == nullptr && stage != 2 && fused_enc) {
@@ -1308,6 +1318,14 @@ int v4l_net::forward_t(const float* state, const T* image, const int* rowidx, in
     }
     if (stage == 1) return 0;
     const int R = n * ntok;
+    if (c.token_norm) {  // out = token_ln(visual_out) (nets.py:879-880, 1007-1008): LayerNorm of (tokens + 0)
+      V4L_HIP_CHECK(hipMemsetAsync(ws + L.ytmp, 0, (size_t)R * TD * sizeof(float), s));
+      g_op = "token_ln";
+      V4L_KLAUNCH("add_ln_fwd", 0, s, add_ln_fwd_kernel, dim3(cdiv(R, 4)), dim3(256), 0, s, (const float*)x0, (const float*)(ws + L.ytmp), R,
+                  (const float*)p[tok_ln.g], (const float*)p[tok_ln.b], ws + L.x[0], ws + L.xh0, ws + L.rs0);
+      V4L_LAUNCH_CHECK();
+      x0 = ws + L.x[0];
+    }
     const bool fused_layers = this->fused_layers();
     // the last layer's blocks also run the pooled heads of their samples when the head stack has the shipped shape
     const bool fused_head = fused_layers && c.n_layers >= 1 && nh == 2 && c.head_hidden[0] == 256 && c.head_hidden[1] == 256 &&
@@ -1980,6 +1998,14 @@ int v4l_net::backward_t(const float* state, const T* image, const int* rowidx, i
   }
   float* dx = ws + L.dxl[0];
   const float* x0 = ws + L.x[0];
+  if (c.token_norm) {  // through token_ln: grad w.r.t. the encoder's tokens; state_token_ln takes part in nothing (zero gradient)
+    g_op = "token_ln";
+    if ((rc = ln_bwd_launch(cx, lnb, dx, ws + L.dx0raw, ws + L.xh0, ws + L.rs0, tok_ln, R))) return rc;
+    V4L_HIP_CHECK(hipMemsetAsync(grads + params[stok_ln.g].goff, 0, TD * sizeof(float), s));
+    V4L_HIP_CHECK(hipMemsetAsync(grads + params[stok_ln.b].goff, 0, TD * sizeof(float), s));
+    dx = ws + L.dx0raw;
+    x0 = ws + L.x0raw;
+  }
   if (fused_tail) {  // data-grads done by layer 0's launch: register the four weight-grads
     const Act& last = eacts[ne - 1];
     if ((rc = lin_wgrad<T>(cx, proj, dense(dx, NTOK * TD, n, TD, nullptr, 0, x0), dense(last.p, last.ld, n, last.w), last.w)))
@@ -2026,7 +2052,7 @@ static bool actor_fusable(const v4l_actor* a) {
     return c.kind == V4L_NET_LOCO && c.n_enc_hidden == 2 && c.enc_hidden[0] == 256 && c.enc_hidden[1] == 256 && trunk &&
            c.state_dim <= 128;
   };
-  return ok(p) && ok(v) && !p.max_pool && !v.max_pool && p.n_layers == 2 && v.n_layers == 2 && a->E <= 64 && a->pf->head.size() == 3 &&
+  return ok(p) && ok(v) && !p.max_pool && !v.max_pool && !p.token_norm && !v.token_norm && p.n_layers == 2 && v.n_layers == 2 && a->E <= 64 && a->pf->head.size() == 3 &&
          a->pf->head[0].pkf >= 0 && a->vf->head[0].pkf >= 0 && getenv("V4L_NO_FUSED_ACTOR") == nullptr;
 }
 

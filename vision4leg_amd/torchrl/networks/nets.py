@@ -217,7 +217,6 @@ class LocoTransformer(_HipNetMixin, nn.Module):
         if enc.in_channels != 4: bad.append("in_channels=%d (depth-only 4 supported)" % enc.in_channels)
         if enc.two_by_two: bad.append("two_by_two")
         if self.detach or self.state_detach: bad.append("detach")
-        if self.token_norm: bad.append("token_norm")
         if self.use_pytorch_encoder: bad.append("use_pytorch_encoder")
         if any(h != 1 for h, _ in self.transformer_params): bad.append("n_head != 1")
         if len({f for _, f in self.transformer_params}) != 1: bad.append("per-layer dim_feedforward differs")
@@ -237,6 +236,7 @@ class LocoTransformer(_HipNetMixin, nn.Module):
         c.n_enc_hidden = _fill_hidden(c.enc_hidden, enc.base.hidden_shapes, "encoder hidden")
         c.n_head_hidden = _fill_hidden(c.head_hidden, self.append_hidden_shapes, "append hidden")
         c.max_pool = int(bool(self.max_pool))  # max instead of mean pooling: layer-by-layer kernels (nets.py:1022-1030, 884-889)
+        c.token_norm = int(bool(self.token_norm))  # token_ln over every token in front of the layers (nets.py:879-880, 1007-1008)
         c.has_logstd = int(hasattr(self, "logstd"))
         return c
 
@@ -327,7 +327,6 @@ class Transformer(_HipNetMixin, nn.Module):
         if enc.in_channels != 4: bad.append("in_channels=%d (depth-only 4 supported)" % enc.in_channels)
         if enc.two_by_two: bad.append("two_by_two")
         if self.detach or self.state_detach: bad.append("detach")
-        if self.token_norm: bad.append("token_norm")
         if self.use_pytorch_encoder: bad.append("use_pytorch_encoder")
         if any(h != 1 for h, _ in self.transformer_params): bad.append("n_head != 1")
         if len({f for _, f in self.transformer_params}) != 1: bad.append("per-layer dim_feedforward differs")
@@ -346,5 +345,6 @@ class Transformer(_HipNetMixin, nn.Module):
         c.n_enc_hidden = 0
         c.n_head_hidden = _fill_hidden(c.head_hidden, self.append_hidden_shapes, "append hidden")
         c.max_pool = int(bool(self.max_pool))  # max instead of mean pooling: layer-by-layer kernels (nets.py:1022-1030, 884-889)
+        c.token_norm = int(bool(self.token_norm))  # token_ln over every token in front of the layers (nets.py:879-880, 1007-1008)
         c.has_logstd = int(hasattr(self, "logstd"))
         return c
