@@ -121,6 +121,10 @@ typedef struct v4l_actor v4l_actor;     /* host-side plan of one rollout step: p
 
 const char* v4l_last_error(void);
 int v4l_version(void);
+/* sizeof(v4l_net_cfg / v4l_ppo_hyper / v4l_rollout) as THIS library was compiled: a binding whose struct mirrors differ (a
+   stale libv4l_hip.so next to newer host code, or the other way round) must refuse to run instead of reading fields at the
+   wrong offsets. which: 0 net_cfg, 1 ppo_hyper, 2 rollout; anything else: -1 */
+int v4l_abi_sizeof(int which);
 
 /* ---- network plan: replaces the nn.Module constructors' shape bookkeeping (nets.py / base.py above) ---- */
 int v4l_net_create(const v4l_net_cfg* cfg, v4l_net** out);

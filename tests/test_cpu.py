@@ -127,7 +127,10 @@ def test_library_exports_every_declared_symbol():
     dll = ctypes.CDLL(_lib.LIB_PATH)
     for name in declared:
         assert hasattr(dll, name), name
-    assert _lib.lib().v4l_version() >= 100
+    assert _lib.lib().v4l_version() >= 104
+    for which, mirror in enumerate((_lib.NetCfg, _lib.PPOHyper, _lib.Rollout)):  # (also enforced when the library is loaded)
+        assert _lib.lib().v4l_abi_sizeof(which) == ctypes.sizeof(mirror)
+    assert _lib.lib().v4l_abi_sizeof(3) == -1
 
 
 def test_plan_matches_reference_state_dict_names():

@@ -75,6 +75,7 @@ _P = C.c_void_p
 _SIGS = {
   "v4l_last_error": (C.c_char_p, []),
   "v4l_version": (C.c_int, []),
+  "v4l_abi_sizeof": (C.c_int, [C.c_int]),
   "v4l_net_create": (C.c_int, [C.POINTER(NetCfg), C.POINTER(_P)]),
   "v4l_net_destroy": (None, [_P]),
   "v4l_net_num_params": (C.c_int, [_P]),
@@ -173,6 +174,13 @@ def lib():
       fn = getattr(l, name)
       fn.restype = res
       fn.argtypes = args
+    # the struct mirrors above must be the structs this library was compiled with (a stale .so next to newer host code reads
+    # fields at the wrong offsets otherwise)
+    for which, (name, mirror) in enumerate((("v4l_net_cfg", NetCfg), ("v4l_ppo_hyper", PPOHyper), ("v4l_rollout", Rollout))):
+      have = l.v4l_abi_sizeof(which)
+      if have != C.sizeof(mirror):
+        raise RuntimeError("vision4leg_amd: %s was compiled with sizeof(%s) = %d, the Python binding expects %d — rebuild it "
+                           "(python -c 'import __graft_entry__ as g; g.build()')" % (LIB_PATH, name, have, C.sizeof(mirror)))
     _lib = l
   return _lib
 

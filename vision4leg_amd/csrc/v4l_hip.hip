@@ -2513,7 +2513,10 @@ static int launch_actor_loss_heads(hipStream_t s, const ActorArgs& aa, const Row
 extern "C" {
 
 const char* v4l_last_error(void) { return v4l::last_error(); }
-int v4l_version(void) { return 100; }
+int v4l_version(void) { return 104; }  // round 4: v4l_net_cfg grew (tanh_action, max_pool, token_norm), v4l_abi_sizeof
+int v4l_abi_sizeof(int which) {
+  return which == 0 ? (int)sizeof(v4l_net_cfg) : which == 1 ? (int)sizeof(v4l_ppo_hyper) : which == 2 ? (int)sizeof(v4l_rollout) : -1;
+}
 
 int v4l_net_create(const v4l_net_cfg* cfg, v4l_net** out) {
   V4L_REQUIRE(cfg != nullptr && out != nullptr, "v4l_net_create: null argument");
