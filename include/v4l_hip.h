@@ -113,6 +113,9 @@ typedef struct v4l_net_cfg {
   int token_norm;      /* V4L_NET_LOCO / V4L_NET_LOCO_VIS: LayerNorm(token_dim) over every token in front of the transformer layers
                           (token_norm=True: nets.py:815-818, 879-880, 1007-1008; parameters token_ln.* and the never-used
                           state_token_ln.*); layer-by-layer kernels (no shipped config sets it) */
+  int pytorch_encoder; /* V4L_NET_LOCO / V4L_NET_LOCO_VIS: the layers are an nn.TransformerEncoder WITH a final LayerNorm
+                          (use_pytorch_encoder=True: nets.py:955-963, 884-885, 1012-1013; parameters
+                          visual_trans_encoder.layers.N.*, visual_trans_encoder.norm.*); layer-by-layer kernels */
 } v4l_net_cfg;
 
 typedef struct v4l_net v4l_net;         /* host-side plan of one network (no device memory)  */

@@ -148,6 +148,22 @@ def split_obs(x, S):
     return x[..., :S], x[..., S:].reshape(-1, 4, 64, 64)
 
 
+def _layers(p, tok, mode, taps=None):
+    """The transformer stack: visual_append_layers.N (a ModuleList) or, with use_pytorch_encoder=True, an nn.TransformerEncoder
+    — visual_trans_encoder.layers.N followed by its final LayerNorm visual_trans_encoder.norm (nets.py:955-963, 1009-1013)."""
+    pe = "visual_trans_encoder.layers.0.norm1.weight" in p
+    fmt = "visual_trans_encoder.layers.%d" if pe else "visual_append_layers.%d"
+    l = 0
+    while ((fmt + ".norm1.weight") % l) in p:
+        tok = transformer_layer(p, fmt % l, tok, mode)
+        if taps is not None:
+            taps["x%d" % (l + 1)] = tok
+        l += 1
+    if pe:
+        tok = F.layer_norm(tok, (tok.shape[-1],), p["visual_trans_encoder.norm.weight"], p["visual_trans_encoder.norm.bias"], 1e-5)
+    return tok
+
+
 def loco_forward(p, x, S, mode="f32", taps=None, max_pool=False):
     """LocoTransformer.forward + LocoTransformerEncoder.forward (nets.py:996-1038, base.py:550-626), depth-only.
     max_pool: nets.py:1022-1023 — the depth tokens are pooled by `.max(dim=0)[0]` instead of the mean."""
@@ -165,12 +181,7 @@ def loco_forward(p, x, S, mode="f32", taps=None, max_pool=False):
         tok = F.layer_norm(tok, (tok.shape[-1],), p["token_ln.weight"], p["token_ln.bias"], 1e-5)
     if taps is not None:
         taps["c3"] = c3; taps["x0"] = tok
-    l = 0
-    while ("visual_append_layers.%d.norm1.weight" % l) in p:
-        tok = transformer_layer(p, "visual_append_layers.%d" % l, tok, mode)                    # nets.py:1009-1011
-        if taps is not None:
-            taps["x%d" % (l + 1)] = tok
-        l += 1
+    tok = _layers(p, tok, mode, taps)                                                           # nets.py:1009-1013
     depth = tok[:, 1:17].max(dim=1)[0] if max_pool else tok[:, 1:17].mean(dim=1)
     pooled = torch.cat([tok[:, 0], depth], dim=-1)                                              # nets.py:1015-1034
     nh = _count(p, "visual_seq_append_fcs.%d.weight") - 1
@@ -208,10 +219,7 @@ def loco_vis_forward(p, x, S=0, mode="f32", taps=None, max_pool=False):
         tok = F.layer_norm(tok, (tok.shape[-1],), p["token_ln.weight"], p["token_ln.bias"], 1e-5)
     if taps is not None:
         taps["c3"] = c3; taps["x0"] = tok
-    l = 0
-    while ("visual_append_layers.%d.norm1.weight" % l) in p:
-        tok = transformer_layer(p, "visual_append_layers.%d" % l, tok, mode)                    # nets.py:881-883
-        l += 1
+    tok = _layers(p, tok, mode)                                                                 # nets.py:881-885
     pooled = tok[:, 0:17].max(dim=1)[0] if max_pool else tok[:, 0:17].mean(dim=1)               # nets.py:886-889
     nh = _count(p, "visual_seq_append_fcs.%d.weight") - 1
     return head(p, "visual_seq_append_fcs", pooled, nh, mode)                                   # nets.py:904
@@ -238,7 +246,9 @@ FORWARDS = {"loco": loco_forward, "cnn": cnn_forward, "mlp": mlp_forward, "loco_
             # tanh_action=True policies: the same nets, a TanhNormal head (PPOOracle reads the suffix)
             "mlp_tanh": mlp_forward, "loco_tanh": loco_forward,
             # token_norm=True: the forwards see token_ln.* among the parameters
-            "loco_tn": loco_forward, "loco_vis_tn": loco_vis_forward}
+            "loco_tn": loco_forward, "loco_vis_tn": loco_vis_forward,
+            # use_pytorch_encoder=True: the forwards see visual_trans_encoder.* among the parameters
+            "loco_pe": loco_forward, "loco_vis_pe": loco_vis_forward}
 
 
 # ------------------------------------------------------------------------------------------ Gaussian head

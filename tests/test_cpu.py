@@ -160,7 +160,7 @@ def test_unsupported_configs_fail_loudly():
     enc = networks.LocoTransformerEncoder(in_channels=4, state_input_dim=84, hidden_shapes=[256, 256])
     with pytest.raises(NotImplementedError):
         networks.LocoTransformer(encoder=enc, output_shape=1, state_input_shape=84, visual_input_shape=(4, 64, 64),
-                                 transformer_params=[[2, 256]], append_hidden_shapes=[256], use_pytorch_encoder=True).hip
+                                 transformer_params=[[2, 256]], append_hidden_shapes=[256]).hip
     with pytest.raises(NotImplementedError):
         enc(torch.zeros(1, 4, 64, 64), torch.zeros(1, 84))
     net = networks.Net(input_shape=8, output_shape=2, base_type=networks.MLPBase, hidden_shapes=[16],

@@ -38,7 +38,7 @@ def test_no_kernel_writes_outside_its_buffers(device, monkeypatch):
     for mode in ("bf16", "f32"):
         # PPO updates: small, ragged (300 = 256 + 44), B = 1024 with graph replays; every net kind once
         for name, n_upd in (("loco_s84", 2), ("loco_rag", 1), ("loco_b1024", 3), ("cnn_s93", 2), ("mlp_s93", 2), ("loco_vis", 1),
-                            ("cnn_vis", 1), ("loco_gen", 1), ("loco_max", 1), ("loco_tn", 1)):
+                            ("cnn_vis", 1), ("loco_gen", 1), ("loco_max", 1), ("loco_tn", 1), ("loco_pe", 1)):
             case, pf, vf = _nets(name, mode, device)
 
             class Coll: epoch_frames = 1

@@ -42,6 +42,10 @@ CASES = {
     # transformer layers (and the state_token_ln parameters nobody uses) — on the layer-by-layer kernels
     "loco_tn": dict(kind="loco_tn", S=84, A=6, seed=16, B=32, enc=[256, 256], head=[256, 256], layers=2, ff=256),
     "loco_vis_tn": dict(kind="loco_vis_tn", S=0, A=6, seed=17, B=32, enc=[], head=[256, 256], layers=2, ff=256, param_tol_f32=4e-5),
+    # use_pytorch_encoder=True (nets.py:955-963; no shipped config sets it): the layers are an nn.TransformerEncoder — clones of
+    # one layer, so they start identical — with a final LayerNorm; layer-by-layer kernels
+    "loco_pe": dict(kind="loco_pe", S=84, A=6, seed=18, B=32, enc=[256, 256], head=[256, 256], layers=2, ff=256),
+    "loco_vis_pe": dict(kind="loco_vis_pe", S=0, A=6, seed=19, B=32, enc=[], head=[256, 256], layers=2, ff=256, param_tol_f32=4e-5),
     # tanh_action=True (TanhNormal head, policies/distribution.py:5-80; no shipped config sets it): the update's log-probs go
     # through atanh(stored action) with the -log(1 - a^2 + 1e-6) correction; the rollout step on the layer-by-layer kernels
     "mlp_tanh": dict(kind="mlp_tanh", S=93, A=6, seed=14, B=64, enc=[256, 256], head=[256, 256]),

@@ -35,7 +35,7 @@ class NetCfg(C.Structure):
     ("enc_hidden", C.c_int * V4L_MAX_HIDDEN), ("visual_dim", C.c_int), ("token_dim", C.c_int),
     ("n_layers", C.c_int), ("ff_dim", C.c_int), ("n_head_hidden", C.c_int),
     ("head_hidden", C.c_int * V4L_MAX_HIDDEN), ("has_logstd", C.c_int), ("tanh_action", C.c_int), ("max_pool", C.c_int),
-    ("token_norm", C.c_int),
+    ("token_norm", C.c_int), ("pytorch_encoder", C.c_int),
   ]
 
 

@@ -62,6 +62,7 @@ struct Layout {
   std::vector<int64_t> eh;       // encoder MLP activations
   int64_t vis = 0;               // CNN: concat buffer [n][visual_dim + enc_last]
   std::vector<int64_t> x;        // LOCO: token tensors x[0..L]
+  int64_t xfin = 0, xhF = 0, rsF = 0, dxfin = 0;    // pytorch_encoder: the final LayerNorm's output, xhat / rstd, grad w.r.t. its output
   int64_t x0raw = 0, xh0 = 0, rs0 = 0, dx0raw = 0;  // token_norm: the encoder's tokens (x[0] = their LayerNorm), xhat / rstd, grad w.r.t. them
   std::vector<LayerWs> lw;
   int64_t ytmp = 0;              // [R][64] sub-layer output before add+LN
@@ -95,6 +96,7 @@ struct v4l_net {
   v4l::Lin upconv, proj;            // LOCO: depth_up_conv, state_projector ; CNN: proj = visual_projector
   std::vector<v4l::Lin> enc;        // encoder.base / Net.base MLP
   std::vector<v4l::TLayer> layers;
+  v4l::LNp fin_ln;                  // cfg.pytorch_encoder: nn.TransformerEncoder's final norm
   v4l::LNp tok_ln, stok_ln;         // cfg.token_norm: token_ln (applied to every token), state_token_ln (a parameter nobody uses)
   std::vector<v4l::Lin> head;       // append fcs + last
   int logstd = -1;

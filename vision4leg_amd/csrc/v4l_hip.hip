@@ -865,7 +865,7 @@ int v4l_net::build() {
       stok_ln.b = add_param("state_token_ln.bias", {TD});
     }
     for (int l = 0; l < c.n_layers; ++l) {
-      const std::string id = "visual_append_layers." + std::to_string(l);
+      const std::string id = (c.pytorch_encoder ? "visual_trans_encoder.layers." : "visual_append_layers.") + std::to_string(l);
       TLayer t;
       t.inproj = make_lin(id + ".self_attn.in_proj_weight", id + ".self_attn.in_proj_bias", 3 * TD, TD, true);
       t.outproj = make_lin(id + ".self_attn.out_proj.weight", id + ".self_attn.out_proj.bias", TD, TD, true);
@@ -876,6 +876,10 @@ int v4l_net::build() {
       t.ln2.g = add_param(id + ".norm2.weight", {TD});
       t.ln2.b = add_param(id + ".norm2.bias", {TD});
       layers.push_back(t);
+    }
+    if (c.pytorch_encoder) {
+      fin_ln.g = add_param("visual_trans_encoder.norm.weight", {TD});
+      fin_ln.b = add_param("visual_trans_encoder.norm.bias", {TD});
     }
     head_in = c.kind == V4L_NET_LOCO ? 2 * TD : TD;
   }
@@ -1013,12 +1017,12 @@ bool v4l_net::wps_layers() const {
 }
 bool v4l_net::wps_vis() const {
   const v4l_net_cfg& c = cfg;
-  return c.kind == V4L_NET_LOCO_VIS && !c.max_pool && !c.token_norm && c.ff_dim == 256 && c.n_layers == 2 && c.n_head_hidden == 2 && c.head_hidden[0] == 256 &&
+  return c.kind == V4L_NET_LOCO_VIS && !c.max_pool && !c.token_norm && !c.pytorch_encoder && c.ff_dim == 256 && c.n_layers == 2 && c.n_head_hidden == 2 && c.head_hidden[0] == 256 &&
          c.head_hidden[1] == 256 && c.out_dim <= OUT_LD && layers[0].inproj.pkp >= 0 && head[0].pko >= 0 &&
          getenv("V4L_NO_WPS_LAYERS") == nullptr && getenv("V4L_NO_FUSED_LAYER") == nullptr;
 }
 bool v4l_net::fused_layers() const {
-  return cfg.kind == V4L_NET_LOCO && cfg.ff_dim == 256 && !cfg.token_norm && getenv("V4L_NO_FUSED_LAYER") == nullptr;
+  return cfg.kind == V4L_NET_LOCO && cfg.ff_dim == 256 && !cfg.token_norm && !cfg.pytorch_encoder && getenv("V4L_NO_FUSED_LAYER") == nullptr;
 }
 // backward_t's own conditions for the (non-vision) wave-per-sample backward, for callers that prepare work for it
 bool v4l_net::wps_bwd_plain() const {
@@ -1103,6 +1107,7 @@ Layout v4l_net::layout(int n) const {
   if (is_tf()) {
     for (int l = 0; l <= c.n_layers; ++l) L.x.push_back(take(R * TD));
     if (c.token_norm) { L.x0raw = take(R * TD); L.xh0 = take(R * TD); L.rs0 = take(R); L.dx0raw = take(R * TD); }
+    if (c.pytorch_encoder) { L.xfin = take(R * TD); L.xhF = take(R * TD); L.rsF = take(R); L.dxfin = take(R * TD); }
     for (int l = 0; l < c.n_layers; ++l) {
       LayerWs w;
       w.qkv = take(R * 3 * TD);
@@ -1485,13 +1490,22 @@ int v4l_net::forward_t(const float* state, const T* image, const int* rowidx, in
                          p[t.ln2.b], ws + L.x[l + 1], ws + w.xh2, ws + w.rs2);
       V4L_LAUNCH_CHECK();
     }
+    const float* xlast = ws + L.x[c.n_layers];
+    if (c.pytorch_encoder) {  // nn.TransformerEncoder's final norm (nets.py:884-885, 1012-1013): LayerNorm of (rows + 0)
+      V4L_HIP_CHECK(hipMemsetAsync(ws + L.ytmp, 0, (size_t)R * TD * sizeof(float), s));
+      g_op = "final_ln";
+      V4L_KLAUNCH("add_ln_fwd", 0, s, add_ln_fwd_kernel, dim3(cdiv(R, 4)), dim3(256), 0, s, xlast, (const float*)(ws + L.ytmp), R,
+                  (const float*)p[fin_ln.g], (const float*)p[fin_ln.b], ws + L.xfin, ws + L.xhF, ws + L.rsF);
+      V4L_LAUNCH_CHECK();
+      xlast = ws + L.xfin;
+    }
     g_op = "pool";
     if (c.kind == V4L_NET_LOCO_VIS) {
-      V4L_KLAUNCH("pool_fwd", 0, s, pool_all_fwd_kernel, dim3(n), dim3(64), 0, s, ws + L.x[c.n_layers], n, ntok, ws + L.pooled,
+      V4L_KLAUNCH("pool_fwd", 0, s, pool_all_fwd_kernel, dim3(n), dim3(64), 0, s, xlast, n, ntok, ws + L.pooled,
                   c.max_pool);
       head_in = dense(ws + L.pooled, TD, n, TD);
     } else {
-      V4L_KLAUNCH("pool_fwd", 0, s, pool_fwd_kernel, dim3(n), dim3(128), 0, s, ws + L.x[c.n_layers], n, ws + L.pooled, c.max_pool);
+      V4L_KLAUNCH("pool_fwd", 0, s, pool_fwd_kernel, dim3(n), dim3(128), 0, s, xlast, n, ws + L.pooled, c.max_pool);
       head_in = dense(ws + L.pooled, 2 * TD, n, 2 * TD);
     }
     V4L_LAUNCH_CHECK();
@@ -1725,13 +1739,18 @@ int v4l_net::backward_t(const float* state, const T* image, const int* rowidx, i
     if ((rc = chain_bwd<T>(cx, head.data(), nh + 1, dense(ws + L.pooled, pw, n, pw), hacts, dy, dhhp, &din)))
       return rc;
     g_op = "pool";
+    // (pytorch_encoder: the pooled rows are the final LayerNorm's output; its backward then gives the grad w.r.t. the last layer's)
+    float* dlast = c.pytorch_encoder ? ws + L.dxfin : ws + L.dxl[c.n_layers];
+    const float* xlast = c.pytorch_encoder ? ws + L.xfin : ws + L.x[c.n_layers];
     if (vis)
-      V4L_KLAUNCH("pool_bwd", 0, s, pool_all_bwd_kernel, dim3(n), dim3(64), 0, s, ws + L.dpool, n, ntok, ws + L.dxl[c.n_layers],
-                  ws + L.x[c.n_layers], c.max_pool);
+      V4L_KLAUNCH("pool_bwd", 0, s, pool_all_bwd_kernel, dim3(n), dim3(64), 0, s, ws + L.dpool, n, ntok, dlast, xlast, c.max_pool);
     else
-      V4L_KLAUNCH("pool_bwd", 0, s, pool_bwd_kernel, dim3(n), dim3(64), 0, s, ws + L.dpool, n, ws + L.dxl[c.n_layers],
-                  ws + L.x[c.n_layers], c.max_pool);
+      V4L_KLAUNCH("pool_bwd", 0, s, pool_bwd_kernel, dim3(n), dim3(64), 0, s, ws + L.dpool, n, dlast, xlast, c.max_pool);
     V4L_LAUNCH_CHECK();
+    if (c.pytorch_encoder) {
+      g_op = "final_ln";
+      if ((rc = ln_bwd_launch(cx, std::min(cdiv(R, 16), 128), dlast, ws + L.dxl[c.n_layers], ws + L.xhF, ws + L.rsF, fin_ln, R))) return rc;
+    }
   }
   const int lnb = std::min(cdiv(R, 16), 128);
   // both layers (+ heads before, + encoder-side data-grads after) in ONE launch when the stack is the shipped two layers: the
@@ -2052,7 +2071,7 @@ static bool actor_fusable(const v4l_actor* a) {
     return c.kind == V4L_NET_LOCO && c.n_enc_hidden == 2 && c.enc_hidden[0] == 256 && c.enc_hidden[1] == 256 && trunk &&
            c.state_dim <= 128;
   };
-  return ok(p) && ok(v) && !p.max_pool && !v.max_pool && !p.token_norm && !v.token_norm && p.n_layers == 2 && v.n_layers == 2 && a->E <= 64 && a->pf->head.size() == 3 &&
+  return ok(p) && ok(v) && !p.max_pool && !v.max_pool && !p.token_norm && !v.token_norm && !p.pytorch_encoder && !v.pytorch_encoder && p.n_layers == 2 && v.n_layers == 2 && a->E <= 64 && a->pf->head.size() == 3 &&
          a->pf->head[0].pkf >= 0 && a->vf->head[0].pkf >= 0 && getenv("V4L_NO_FUSED_ACTOR") == nullptr;
 }
 

@@ -30,6 +30,9 @@ def build_nets(networks, policies, case):
     if kind in ("loco_max", "loco_vis_max"):  # the same nets with max_pool=True (nets.py:1022-1030, 884-889)
         net["max_pool"] = True
         kind = kind[:-4]
+    if kind in ("loco_pe", "loco_vis_pe"):  # use_pytorch_encoder=True: nn.TransformerEncoder (cloned layers) + final norm (nets.py:955-963)
+        net["use_pytorch_encoder"] = True
+        kind = kind[:-3]
     if kind in ("loco_tn", "loco_vis_tn"):  # the same nets with token_norm=True (nets.py:815-818, 879-880, 1007-1008)
         net["token_norm"] = True
         kind = kind[:-3]

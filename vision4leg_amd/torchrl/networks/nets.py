@@ -198,7 +198,8 @@ class LocoTransformer(_HipNetMixin, nn.Module):
             self.state_token_ln = nn.LayerNorm(d)
         if use_pytorch_encoder:
             layer = nn.TransformerEncoderLayer(d, self.transformer_params[0][0], self.transformer_params[0][1], dropout=0)
-            self.visual_trans_encoder = nn.TransformerEncoder(layer, len(self.transformer_params), nn.LayerNorm(d))
+            self.visual_trans_encoder = nn.TransformerEncoder(layer, len(self.transformer_params), nn.LayerNorm(d),
+                                                              enable_nested_tensor=False)
         else:
             self.visual_append_layers = nn.ModuleList(
                 [nn.TransformerEncoderLayer(d, n_head, ff, dropout=0) for n_head, ff in self.transformer_params])
@@ -217,7 +218,6 @@ class LocoTransformer(_HipNetMixin, nn.Module):
         if enc.in_channels != 4: bad.append("in_channels=%d (depth-only 4 supported)" % enc.in_channels)
         if enc.two_by_two: bad.append("two_by_two")
         if self.detach or self.state_detach: bad.append("detach")
-        if self.use_pytorch_encoder: bad.append("use_pytorch_encoder")
         if any(h != 1 for h, _ in self.transformer_params): bad.append("n_head != 1")
         if len({f for _, f in self.transformer_params}) != 1: bad.append("per-layer dim_feedforward differs")
         if not enc.base.hip_supported(): bad.append("encoder.base is not a ReLU MLPBase")
@@ -237,6 +237,7 @@ class LocoTransformer(_HipNetMixin, nn.Module):
         c.n_head_hidden = _fill_hidden(c.head_hidden, self.append_hidden_shapes, "append hidden")
         c.max_pool = int(bool(self.max_pool))  # max instead of mean pooling: layer-by-layer kernels (nets.py:1022-1030, 884-889)
         c.token_norm = int(bool(self.token_norm))  # token_ln over every token in front of the layers (nets.py:879-880, 1007-1008)
+        c.pytorch_encoder = int(bool(self.use_pytorch_encoder))  # nn.TransformerEncoder + final norm (nets.py:955-963)
         c.has_logstd = int(hasattr(self, "logstd"))
         return c
 
@@ -308,7 +309,8 @@ class Transformer(_HipNetMixin, nn.Module):
             self.state_token_ln = nn.LayerNorm(d)
         if use_pytorch_encoder:
             layer = nn.TransformerEncoderLayer(d, self.transformer_params[0][0], self.transformer_params[0][1], dropout=0)
-            self.visual_trans_encoder = nn.TransformerEncoder(layer, len(self.transformer_params), nn.LayerNorm(d))
+            self.visual_trans_encoder = nn.TransformerEncoder(layer, len(self.transformer_params), nn.LayerNorm(d),
+                                                              enable_nested_tensor=False)
         else:
             self.visual_append_layers = nn.ModuleList(
                 [nn.TransformerEncoderLayer(d, n_head, ff, dropout=0) for n_head, ff in self.transformer_params])
@@ -327,7 +329,6 @@ class Transformer(_HipNetMixin, nn.Module):
         if enc.in_channels != 4: bad.append("in_channels=%d (depth-only 4 supported)" % enc.in_channels)
         if enc.two_by_two: bad.append("two_by_two")
         if self.detach or self.state_detach: bad.append("detach")
-        if self.use_pytorch_encoder: bad.append("use_pytorch_encoder")
         if any(h != 1 for h, _ in self.transformer_params): bad.append("n_head != 1")
         if len({f for _, f in self.transformer_params}) != 1: bad.append("per-layer dim_feedforward differs")
         if bad:
@@ -346,5 +347,6 @@ class Transformer(_HipNetMixin, nn.Module):
         c.n_head_hidden = _fill_hidden(c.head_hidden, self.append_hidden_shapes, "append hidden")
         c.max_pool = int(bool(self.max_pool))  # max instead of mean pooling: layer-by-layer kernels (nets.py:1022-1030, 884-889)
         c.token_norm = int(bool(self.token_norm))  # token_ln over every token in front of the layers (nets.py:879-880, 1007-1008)
+        c.pytorch_encoder = int(bool(self.use_pytorch_encoder))  # nn.TransformerEncoder + final norm (nets.py:955-963)
         c.has_logstd = int(hasattr(self, "logstd"))
         return c
