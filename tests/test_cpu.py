@@ -214,3 +214,51 @@ def test_linear_schedule_and_stat_keys():
     atu.update_linear_schedule(Opt, 750, 1500, 1e-4)
     assert Opt.param_groups[0]["lr"] == 1e-4 - (1e-4 * (750 / 1500.0))
     assert _lib.STAT_KEYS == util.STAT_KEYS and len(_lib.STAT_KEYS) == 18
+
+
+def test_gae_without_tau_raises_and_discount_reward_has_its_own_entry():
+    """PPO's default is tau=None with gae=True; the reference fails on `gamma * None` (replay_buffers/on_policy.py:31). Here a
+    forgotten tau must not silently train on discounted rewards: only discount_reward() reaches v4l_discount_reward."""
+    import inspect
+    from vision4leg_amd import engine
+    from vision4leg_amd.torchrl.replay_buffers import OnPolicyReplayBuffer
+    buf = OnPolicyReplayBuffer(max_replay_buffer_size=4, env_nums=2, time_limit_filter=False)
+    with pytest.raises(TypeError, match="tau is None"):
+        buf.generalized_advantage_estimation(np.zeros((2, 1)), 0.99, None)
+    z = torch.zeros(2, 2, dtype=torch.float64)
+    with pytest.raises(TypeError, match="tau is None"):
+        engine.gae(z, z, z, None, torch.zeros(2, dtype=torch.float64), 0.99, None, False)
+    assert "v4l_discount_reward" in inspect.getsource(engine.discount_reward)
+    assert "v4l_discount_reward" not in inspect.getsource(engine.gae)
+
+
+def test_cast_threads_env_is_validated(monkeypatch):
+    from vision4leg_amd.torchrl.collector import on_policy as coll
+    monkeypatch.setenv("V4L_CAST_THREADS", "many")
+    with pytest.raises(ValueError, match="V4L_CAST_THREADS"):
+        coll._cast_threads_from_env()
+    monkeypatch.setenv("V4L_CAST_THREADS", "0")
+    with pytest.raises(ValueError, match="V4L_CAST_THREADS"):
+        coll._cast_threads_from_env()
+    monkeypatch.setenv("V4L_CAST_THREADS", "3")
+    assert coll._cast_threads_from_env() == 3
+
+
+def test_device_identity_ignores_visibility_strings_when_the_gpu_is_identified(monkeypatch):
+    """Two ranks that reach ONE physical GPU through different *_VISIBLE_DEVICES strings must get the same fingerprint (the
+    'ranks share a GPU' guard in front of ncclCommInitRank); without uuid / PCI ids the index + environment are the fallback."""
+    import types
+    from vision4leg_amd.torchrl.algo.on_policy import ppo
+    props = types.SimpleNamespace(uuid="GPU-12345678-abcd", pci_domain_id=0, pci_bus_id=5, pci_device_id=0)
+    monkeypatch.setattr(torch.cuda, "get_device_properties", lambda d: props)
+    monkeypatch.setenv("HIP_VISIBLE_DEVICES", "0")
+    a = ppo.device_identity(torch.device("cuda", 0))
+    monkeypatch.setenv("HIP_VISIBLE_DEVICES", "0,1")
+    assert ppo.device_identity(torch.device("cuda", 0)) == a
+    props.pci_bus_id = 6
+    props.uuid = "GPU-87654321-abcd"
+    assert ppo.device_identity(torch.device("cuda", 0)) != a
+    anon = types.SimpleNamespace()
+    monkeypatch.setattr(torch.cuda, "get_device_properties", lambda d: anon)
+    b0 = ppo.device_identity(torch.device("cuda", 0))
+    assert b0 != ppo.device_identity(torch.device("cuda", 1))

@@ -132,3 +132,89 @@ def test_collector_restatement_matches_reference():
             assert np.array_equal(np.array(ra["train_rewards"]), np.array(rb["train_rewards"]))
         print("OK")
     """)
+
+
+CKPT_CASES = ["loco_s84", "mlp_s93"]
+
+
+@pytest.mark.parametrize("name", CKPT_CASES)
+def test_checkpoint_files_cross_load_on_cpu(name):
+    """Both directions of rl_algo.py:84-95 / locotransformer_viewer.py:125-147 without a GPU: (1) the file the reference's
+    snapshot wrote (tests/golden/ckpt/) loads into this package's module strictly, tensor for tensor; (2) the file this
+    package's `PPO.snapshot` writes loads into the REFERENCE's class strictly and the reference then computes the golden
+    forward of that parameter set."""
+    _run("""
+        import os, types, numpy as np, torch
+        import ref_stubs
+        ref_stubs.install()
+        import util
+        import torchrl.networks as ref_networks, torchrl.policies as ref_policies
+        import vision4leg_amd.torchrl.networks as networks, vision4leg_amd.torchrl.policies as policies
+        from vision4leg_amd.torchrl.algo import PPO
+        name = %r
+        case = util.CASES[name]
+        ck = os.path.join(util.GOLDEN, "ckpt", name)
+        gold = np.load(os.path.join(util.GOLDEN, "ckpt_" + name + ".npz"))
+        # (1) reference-written file -> this package's modules (CPU tensors: no kernel runs)
+        torch.manual_seed(case["seed"] + 100)
+        pf, vf = util.build_nets(networks, policies, case)
+        for net, f in ((vf, "model_vf_2.pth"), (pf, "model_pf_2.pth")):
+            sd = torch.load(os.path.join(ck, f), map_location="cpu")
+            res = net.load_state_dict(sd)           # strict
+            assert not res.missing_keys and not res.unexpected_keys
+            assert list(net.state_dict().keys()) == list(sd.keys())
+        for k, v in torch.load(os.path.join(ck, "model_pf_2.pth"), map_location="cpu").items():
+            assert torch.equal(pf.state_dict()[k], v), k
+        # (2) this package's snapshot writer -> the reference's classes
+        import tempfile
+        tmp = tempfile.mkdtemp()
+        shell = types.SimpleNamespace(env=None, snapshot_networks=[("pf", pf), ("vf", vf)])
+        PPO.snapshot(shell, tmp, "best")
+        assert sorted(os.listdir(tmp)) == ["model_pf_best.pth", "model_vf_best.pth"]
+        torch.manual_seed(case["seed"] + 200)
+        rpf, rvf = util.build_nets(ref_networks, ref_policies, case)
+        rvf.load_state_dict(torch.load(os.path.join(tmp, "model_vf_best.pth"), map_location="cpu"))
+        rpf.load_state_dict(torch.load(os.path.join(tmp, "model_pf_best.pth"), map_location="cpu"))
+        obs = torch.tensor(util.make_batch(case, update=5)["obs"], dtype=torch.float32)
+        with torch.no_grad():
+            mean, std, _ = rpf(obs)
+            value = rvf(obs)
+        assert np.array_equal(mean.numpy(), gold["fwd_mean"]) and np.array_equal(value.numpy(), gold["fwd_value"])
+        print("OK")
+    """ % name)
+
+
+@pytest.mark.parametrize("name", CKPT_CASES)
+def test_hip_written_checkpoint_loads_into_reference_classes(name):
+    """tests/golden/ckpt_hip/<name>/: files `PPO.snapshot` wrote on an MI355X after two HIP (f32) updates, and the forward the
+    HIP modules computed from them (tests/test_gpu_ckpt.py::test_hip_snapshot_file_round_trip leaves both in gpurun_out/).
+    The reference's classes load the files strictly and reproduce that forward."""
+    d = os.path.join(util.GOLDEN, "ckpt_hip", name)
+    if not os.path.isdir(d):
+        pytest.skip("no HIP-written checkpoint fixture for " + name)
+    _run("""
+        import os, numpy as np, torch
+        import ref_stubs
+        ref_stubs.install()
+        import util
+        import torchrl.networks as ref_networks, torchrl.policies as ref_policies
+        name = %r
+        case = util.CASES[name]
+        d = os.path.join(util.GOLDEN, "ckpt_hip", name)
+        torch.manual_seed(case["seed"] + 300)
+        rpf, rvf = util.build_nets(ref_networks, ref_policies, case)
+        rvf.load_state_dict(torch.load(os.path.join(d, "model_vf_2.pth"), map_location="cpu"))
+        rpf.load_state_dict(torch.load(os.path.join(d, "model_pf_2.pth"), map_location="cpu"))
+        hip = np.load(os.path.join(d, "hip_fwd.npz"))
+        obs = torch.tensor(util.make_batch(case, update=5)["obs"], dtype=torch.float32)
+        with torch.no_grad():
+            mean, _, _ = rpf(obs)
+            value = rvf(obs)
+        em, ev = util.rel_err(hip["fwd_mean"], mean.numpy()), util.rel_err(hip["fwd_value"], value.numpy())
+        assert em <= 2e-5 and ev <= 2e-5, (em, ev)
+        # and it is a trained parameter set: two updates away from the reference-trained one by fp32 summation order only
+        ref = torch.load(os.path.join(util.GOLDEN, "ckpt", name, "model_pf_2.pth"), map_location="cpu")
+        mine = torch.load(os.path.join(d, "model_pf_2.pth"), map_location="cpu")
+        assert max((mine[k] - ref[k]).abs().max().item() for k in ref) <= 2e-5
+        print("OK")
+    """ % name)

@@ -1,0 +1,59 @@
+#!/bin/bash
+# One GPU-box session per invocation (run through gpurun from the repo root): tools/gpu_session.sh <session> [args...]
+# Everything lands in gpurun_out/<tag>_*; the summaries worth keeping are copied into profiles/ by hand afterwards.
+# (Round 4's twelve tools/r4_run_{c..p}.sh are this script's history: git log -- tools/r4_run_c.sh)
+set -u
+S=${1:?session name}; shift || true
+REPO=$(pwd); O=$REPO/gpurun_out; mkdir -p $O
+export PYTHONPATH=$REPO
+
+bench_ab() {  # tag, rounds, then pairs "name=libpath|env" ... : interleaved short bench runs, one JSON per run
+  local tag=$1 rounds=$2; shift 2
+  for i in $(seq 1 $rounds); do
+    for spec in "$@"; do
+      local name=${spec%%=*} rest=${spec#*=}
+      ( for kv in ${rest//|/ }; do [ -n "$kv" ] && export "$kv"; done
+        python bench.py --steps 12 --warmup 3 --no-cpu-baseline --no-parity --breakdown $O/${tag}_bd_${name}_$i.txt \
+          > $O/${tag}_ab_${name}_$i.json 2> $O/${tag}_ab_${name}_$i.err )
+    done
+  done
+  python - "$O" "$tag" <<'PY'
+import glob, json, sys
+o, tag = sys.argv[1:3]
+for f in sorted(glob.glob("%s/%s_ab_*.json" % (o, tag))):
+    try:
+        d = json.load(open(f))
+        tb = d["roofline"]["transformer_block"]
+        print(f.split("/")[-1], "value %.0f  ms/step %.3f  rollout %.3f  update-only %.0f  tblock mfma_frac %.4f" %
+              (d["value"], d["ms_per_step"], d["rollout_inference_ms_per_step"], d["update_only_env_steps_per_s"], tb["mfma_frac"]))
+    except Exception as e:
+        print(f, "ERR", e)
+PY
+}
+
+pmc() {  # tag, script, counter groups... (one rocprofv3 run per group; summarised per kernel)
+  local tag=$1 script=$2; shift 2
+  local n=0
+  for grp in "$@"; do
+    n=$((n+1))
+    ( cd /tmp && export TMPDIR=/tmp && timeout 300 rocprofv3 --kernel-trace --pmc $grp --output-format csv -d $O/${tag}_pmc/g$n -- \
+        python $REPO/$script > $O/${tag}_pmc_g$n.log 2>&1 ); echo "pmc $tag g$n rc=$?"
+  done
+  python tools/pmc_kernels.py $O/${tag}_pmc > $O/${tag}_pmc_summary.txt 2>&1
+  find $O/${tag}_pmc -name "*.csv" -size +1M -delete; find $O/${tag}_pmc -name "*.db" -delete
+}
+
+case $S in
+a)  # round 5, session A: today's baseline line, the rolled-layer-loop build (I-cache probe) A/B, I-fetch / wait counters, ckpt tests
+  python bench.py > $O/r5a_bench_base.json 2> $O/r5a_bench_base.err; tail -c 400 $O/r5a_bench_base.json
+  (timeout 600 python -m pytest tests/test_gpu_ckpt.py -q -m gpu --tb=short 2>&1 | tail -15) > $O/r5a_ckpt_tests.log; tail -5 $O/r5a_ckpt_tests.log
+  bench_ab r5a 3 "base=" "roll=V4L_LIB=$REPO/vision4leg_amd/libv4l_hip_roll.so"
+  G1="SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_IFETCH SQ_IFETCH_LEVEL"
+  G2="SQ_INST_LEVEL_VMEM SQ_INST_LEVEL_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS SQ_INST_CYCLES_VMEM_RD SQ_INST_CYCLES_VMEM_WR SQ_WAVES"
+  G3="SQC_ICACHE_REQ SQC_ICACHE_HITS SQC_ICACHE_MISSES SQC_ICACHE_MISSES_DUPLICATE SQC_ICACHE_BUSY_CYCLES SQC_TC_INST_REQ SQC_TC_STALL"
+  pmc r5a_base tools/probe/wps_run.py "$G1" "$G2" "$G3"
+  V4L_LIB=$REPO/vision4leg_amd/libv4l_hip_roll.so pmc r5a_roll tools/probe/wps_run.py "$G1" "$G2" "$G3"
+  head -120 $O/r5a_base_pmc_summary.txt
+  ;;
+*) echo "unknown session $S"; exit 2 ;;
+esac

@@ -170,17 +170,28 @@ def lib():
         "vision4leg_amd: %s is missing — build it with `python -c 'import __graft_entry__ as g; g.build()'` "
         "(there is no CPU fallback for the HIP hot path)" % LIB_PATH)
     l = C.CDLL(LIB_PATH)
-    for name, (res, args) in _SIGS.items():
-      fn = getattr(l, name)
-      fn.restype = res
-      fn.argtypes = args
+    rebuild = "rebuild it (python -c 'import __graft_entry__ as g; g.build()')"
+    # a stale .so is exactly what the guards below are for, and it lacks the newest symbols: resolve the version / ABI entries
+    # first and say "rebuild" instead of dying on a bare AttributeError('undefined symbol') in the binding loop
+    try:
+      l.v4l_version.restype, l.v4l_version.argtypes = _SIGS["v4l_version"]
+      l.v4l_abi_sizeof.restype, l.v4l_abi_sizeof.argtypes = _SIGS["v4l_abi_sizeof"]
+    except AttributeError as e:
+      raise RuntimeError("vision4leg_amd: %s predates this Python binding (%s) — %s" % (LIB_PATH, e, rebuild)) from None
     # the struct mirrors above must be the structs this library was compiled with (a stale .so next to newer host code reads
     # fields at the wrong offsets otherwise)
     for which, (name, mirror) in enumerate((("v4l_net_cfg", NetCfg), ("v4l_ppo_hyper", PPOHyper), ("v4l_rollout", Rollout))):
       have = l.v4l_abi_sizeof(which)
       if have != C.sizeof(mirror):
-        raise RuntimeError("vision4leg_amd: %s was compiled with sizeof(%s) = %d, the Python binding expects %d — rebuild it "
-                           "(python -c 'import __graft_entry__ as g; g.build()')" % (LIB_PATH, name, have, C.sizeof(mirror)))
+        raise RuntimeError("vision4leg_amd: %s was compiled with sizeof(%s) = %d, the Python binding expects %d — %s"
+                           % (LIB_PATH, name, have, C.sizeof(mirror), rebuild))
+    for name, (res, args) in _SIGS.items():
+      try:
+        fn = getattr(l, name)
+      except AttributeError:
+        raise RuntimeError("vision4leg_amd: %s does not export %s — %s" % (LIB_PATH, name, rebuild)) from None
+      fn.restype = res
+      fn.argtypes = args
     _lib = l
   return _lib
 

@@ -2935,6 +2935,15 @@ int v4l_actor_seek(v4l_actor* a, int64_t t, void* stream) {
   return 0;
 }
 
+static bool actor_same_encoder_layout(const v4l_actor* a) {
+  const v4l_net_cfg &p = a->pf->cfg, &v = a->vf->cfg;
+  bool same = p.token_norm == v.token_norm && p.pytorch_encoder == v.pytorch_encoder && p.n_layers == v.n_layers &&
+              p.n_enc_hidden == v.n_enc_hidden && p.token_dim == v.token_dim && p.visual_dim == v.visual_dim &&
+              p.ff_dim == v.ff_dim && p.in_channels == v.in_channels && p.img_hw == v.img_hw && p.max_pool == v.max_pool;
+  for (int i = 0; same && i < p.n_enc_hidden; ++i) same = p.enc_hidden[i] == v.enc_hidden[i];
+  return same;
+}
+
 static int run_actor_step(v4l_actor* a, const float* obs, const float* eps, float* state_roll, void* image_roll,
                           float* acts_roll, float* values_roll, float* logp_roll, float* action, float* mean, float* stdv,
                           float* ent, float* value, int shared_encoder, void* stream) {
@@ -2970,6 +2979,12 @@ static int run_actor_step(v4l_actor* a, const float* obs, const float* eps, floa
     return run_actor_fused<float>(a, obs, eps, state_roll, image_roll, acts_roll, values_roll, logp_roll, action, mean, stdv, ent,
                                   value, s);
   }
+  // General step. The value net may continue from the POLICY's encoder output (stage 2 reads enc_ws + its OWN layout's offset of
+  // the token tensor) only if both nets lay their workspaces out identically up to that tensor: token_norm, use_pytorch_encoder
+  // and the layer count belong to each net in the reference (nets.py:797-820, 948-963) and may differ between pf and vf — then
+  // each net runs its own encoder pass over the shared parameters (same values, one more encoder launch), never a read of a
+  // region the policy did not write.
+  if (shared_encoder && !actor_same_encoder_layout(a)) shared_encoder = 0;
   PhaseScope ps("rollout");
   g_op = "ctl";
   V4L_KLAUNCH("act_begin", 0, s, act_begin_kernel, dim3(1), dim3(256), 0, s, a->ctl, E, a->rowidx);

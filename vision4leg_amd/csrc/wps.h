@@ -48,6 +48,14 @@ constexpr int WPS_WPB = 4;  // waves = samples per block
 #else
 #define WPS_STAMP(i)
 #endif
+// Diagnostic build switch (tools/probe/build_variant.sh roll): the layer loops of the two stack kernels as run-time loops, i.e.
+// ONE copy of the layer code per kernel instead of NL — tests whether the straight-line 100 KB of wps_layer_bwd_kernel against
+// the 64 KB instruction cache a CU pair shares is what its launch time (and its two process-dependent modes) comes from.
+#ifdef V4L_WPS_ROLL_LAYERS
+#define WPS_LAYER_LOOP _Pragma("unroll 1")
+#else
+#define WPS_LAYER_LOOP _Pragma("unroll")
+#endif
 // per-layer fragment-order weight block [in_proj 192x64 | out_proj 64x64 | linear1 256x64 | linear2 64x256] (elements of T);
 // the transposed block (PK_FRAGPT) has the same four sizes at the same offsets
 constexpr int WPS_OFF_WO = 192 * 64, WPS_OFF_W1 = WPS_OFF_WO + 64 * 64, WPS_OFF_W2 = WPS_OFF_W1 + 256 * 64;
@@ -580,7 +588,7 @@ __global__ __launch_bounds__(256) void wps_layer_fwd_kernel(InfLayerStack stk, I
   float4 xr[2][4];
   wps_load_rows<VIS>(stk.l[0].n[0].xin + row0 * TD, lane, ok, xr);
   const frag_t E0 = wps_sel<T>(0, lane), E1 = wps_sel<T>(1, lane);
-#pragma unroll
+  WPS_LAYER_LOOP
   for (int l = 0; l < NL; ++l) {
     const InfLayer& w = stk.l[l].n[0];
     if (l > 0) {
@@ -1210,7 +1218,7 @@ __global__ __launch_bounds__(256) void wps_layer_bwd_kernel(WpsBwdStack stk, Bwd
       }
   }
   float4 xr[2][4];
-#pragma unroll
+  WPS_LAYER_LOOP
   for (int l = 0; l < NL; ++l) {  // stk.l[0] = the upper layer
     const WpsBwdLayer& w = stk.l[l];
     const WpsOut wo = wps_out<T>(reinterpret_cast<T*>(w.wg) + srow * WPS_WG_STRIDE, reinterpret_cast<T*>(w.tk) + srow * WPS_TK_ELEMS, live);

@@ -52,6 +52,15 @@ def _buf(count, dtype, device, zero=False):
   return view
 
 
+def release_guard(view):
+  """Forget the canary bands of a guarded buffer that is being replaced (HipNet.workspace keeps one workspace): without this
+  V4L_GUARD=1 keeps every replaced allocation alive for the life of the process."""
+  if view is None or not _guards:
+    return
+  want = view.data_ptr() - GUARD_BYTES
+  _guards[:] = [(raw, n) for raw, n in _guards if raw.data_ptr() != want]
+
+
 def check_guards(reset=False):
   """-> list of (buffer index, which band, first corrupted byte offset) for every canary band that was written into."""
   bad = []
@@ -192,6 +201,8 @@ class HipNet:
   def workspace(self, n):
     ws = self._ws.get(n)
     if ws is None:
+      for old in self._ws.values():
+        release_guard(old)
       ws = _buf(self.ws_floats(n), torch.float32, self.device)
       self._ws = {n: ws}  # keep one
     return ws
@@ -680,38 +691,49 @@ class HipActor:
     check(self.L.v4l_actor_step(self.h, *args, _stream()), "v4l_actor_step")
 
 
-def gae(rewards, values, terminals, time_limits, last_value, gamma, tau, use_time_limit, want32=True, out=None):
-  """HIP GAE on float64 cuda tensors [T][E] (time_limits [T] or [T][E]); returns (advs, rets, advs32, rets32).
-  out: a dict that keeps the output / scratch tensors between calls, so their addresses stay stable across epochs
-  (the captured update graph is keyed on the rollout pointers).
-  tau=None: PPO(gae=False) — discounted rewards instead (v4l_discount_reward, replay_buffers/on_policy.py:47-71)."""
-  L = _lib.lib()
+def _gae_buffers(rewards, want32, out):
   T, E = rewards.shape
   dev = rewards.device
   key = (T, E, bool(want32), str(dev))
   if out is not None and out.get("key") == key:
-    advs, rets, a32, r32, scratch = out["bufs"]
-  else:
-    advs = torch.empty(T, E, dtype=torch.float64, device=dev)
-    rets = torch.empty_like(advs)
-    a32 = torch.empty(T, E, dtype=torch.float32, device=dev) if want32 else None
-    r32 = torch.empty_like(a32) if want32 else None
-    scratch = torch.empty(3 * T * E, dtype=torch.float64, device=dev)
-    if out is not None:
-      out["key"], out["bufs"] = key, (advs, rets, a32, r32, scratch)
-  tl_per_env = int(time_limits is not None and time_limits.dim() == 2 and time_limits.shape[1] == E and E > 1
-                   or (time_limits is not None and time_limits.numel() == T * E and E == 1))
+    return out["bufs"]
+  advs = torch.empty(T, E, dtype=torch.float64, device=dev)
+  rets = torch.empty_like(advs)
+  a32 = torch.empty(T, E, dtype=torch.float32, device=dev) if want32 else None
+  r32 = torch.empty_like(a32) if want32 else None
+  scratch = torch.empty(3 * T * E, dtype=torch.float64, device=dev)
+  if out is not None:
+    out["key"], out["bufs"] = key, (advs, rets, a32, r32, scratch)
+  return advs, rets, a32, r32, scratch
+
+
+def _tl_per_env(time_limits, T, E):
+  return int(time_limits is not None and time_limits.dim() == 2 and time_limits.shape[1] == E and E > 1
+             or (time_limits is not None and time_limits.numel() == T * E and E == 1))
+
+
+def gae(rewards, values, terminals, time_limits, last_value, gamma, tau, use_time_limit, want32=True, out=None):
+  """HIP GAE on float64 cuda tensors [T][E] (time_limits [T] or [T][E]); returns (advs, rets, advs32, rets32).
+  out: a dict that keeps the output / scratch tensors between calls, so their addresses stay stable across epochs
+  (the captured update graph is keyed on the rollout pointers). tau must be a number: PPO(gae=False) is discount_reward()."""
   if tau is None:
-    check(L.v4l_discount_reward(_ptr(rewards), _ptr(values), _ptr(terminals), _ptr(time_limits), tl_per_env, _ptr(last_value),
-                                T, E, float(gamma), int(bool(use_time_limit)), _ptr(advs), _ptr(rets), _ptr(a32), _ptr(r32),
-                                _stream()), "v4l_discount_reward")
-    return advs, rets, a32, r32
-  check(L.v4l_gae(_ptr(rewards), _ptr(values), _ptr(terminals), _ptr(time_limits), tl_per_env, _ptr(last_value), T, E,
-                  float(gamma), float(tau), int(bool(use_time_limit)), _ptr(scratch), _ptr(advs), _ptr(rets), _ptr(a32),
+    raise TypeError("engine.gae: tau is None (use engine.discount_reward for PPO(gae=False))")
+  L = _lib.lib()
+  T, E = rewards.shape
+  advs, rets, a32, r32, scratch = _gae_buffers(rewards, want32, out)
+  check(L.v4l_gae(_ptr(rewards), _ptr(values), _ptr(terminals), _ptr(time_limits), _tl_per_env(time_limits, T, E), _ptr(last_value),
+                  T, E, float(gamma), float(tau), int(bool(use_time_limit)), _ptr(scratch), _ptr(advs), _ptr(rets), _ptr(a32),
                   _ptr(r32), _stream()), "v4l_gae")
   return advs, rets, a32, r32
 
 
 def discount_reward(rewards, values, terminals, time_limits, last_value, gamma, use_time_limit, want32=True, out=None):
-  """HIP discount_reward (PPO(gae=False)) on float64 cuda tensors [T][E]; same conventions as gae()."""
-  return gae(rewards, values, terminals, time_limits, last_value, gamma, None, use_time_limit, want32=want32, out=out)
+  """HIP discount_reward (PPO(gae=False), replay_buffers/on_policy.py:47-71) on float64 cuda tensors [T][E]; same conventions
+  as gae()."""
+  L = _lib.lib()
+  T, E = rewards.shape
+  advs, rets, a32, r32, _ = _gae_buffers(rewards, want32, out)
+  check(L.v4l_discount_reward(_ptr(rewards), _ptr(values), _ptr(terminals), _ptr(time_limits), _tl_per_env(time_limits, T, E),
+                              _ptr(last_value), T, E, float(gamma), int(bool(use_time_limit)), _ptr(advs), _ptr(rets), _ptr(a32),
+                              _ptr(r32), _stream()), "v4l_discount_reward")
+  return advs, rets, a32, r32

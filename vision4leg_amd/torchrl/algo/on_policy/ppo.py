@@ -72,16 +72,21 @@ def exchange_comm_id(dist, device, available, unique_id, id_bytes=_lib.V4L_COMM_
 
 
 def device_identity(device):
-    """A 63-bit fingerprint of (host, physical GPU) — equal on two ranks exactly when they drive the same device. Everything
-    that can tell two GPUs apart goes in (uuid and PCI ids where the runtime reports them, the device index together with the
-    visibility environment always): ranks on different GPUs differ in at least one component, ranks on the same GPU in none."""
+    """A 63-bit fingerprint of (host, physical GPU) — equal on two ranks exactly when they drive the same device. Where the
+    runtime reports a uuid or PCI ids, ONLY (hostname, uuid, PCI ids) go in: two ranks that reach one physical GPU through
+    different visibility strings ('0' and '0,1') must get the same fingerprint, or the 'ranks share a GPU' guard is bypassed and
+    ncclCommInitRank is entered with a duplicate device. The logical index and the *_VISIBLE_DEVICES strings are the fallback
+    when the runtime reports neither."""
     import hashlib
     import socket
     props = torch.cuda.get_device_properties(device)
-    ident = [socket.gethostname(), str(getattr(props, "uuid", "")),
-             (getattr(props, "pci_domain_id", None), getattr(props, "pci_bus_id", None), getattr(props, "pci_device_id", None)),
-             (os.environ.get("HIP_VISIBLE_DEVICES"), os.environ.get("ROCR_VISIBLE_DEVICES"),
-              os.environ.get("CUDA_VISIBLE_DEVICES"), torch.device(device).index)]
+    uuid = str(getattr(props, "uuid", "") or "")
+    pci = (getattr(props, "pci_domain_id", None), getattr(props, "pci_bus_id", None), getattr(props, "pci_device_id", None))
+    if uuid.strip("0-") or any(v is not None for v in pci):
+        ident = [socket.gethostname(), uuid, pci]
+    else:
+        ident = [socket.gethostname(), (os.environ.get("HIP_VISIBLE_DEVICES"), os.environ.get("ROCR_VISIBLE_DEVICES"),
+                                        os.environ.get("CUDA_VISIBLE_DEVICES"), torch.device(device).index)]
     return int.from_bytes(hashlib.sha1(repr(ident).encode()).digest()[:8], "little") >> 1
 
 

@@ -24,6 +24,19 @@ import torch
 from ..replay_buffers import DeviceOnPolicyReplayBuffer
 
 
+def _cast_threads_from_env():
+    raw = os.environ.get("V4L_CAST_THREADS")
+    if raw is None:
+        return max(1, min(8, (os.cpu_count() or 1) // 2))
+    try:
+        n = int(raw)
+    except ValueError:
+        raise ValueError("vision4leg_amd: V4L_CAST_THREADS must be a positive integer, got %r" % raw) from None
+    if n < 1:
+        raise ValueError("vision4leg_amd: V4L_CAST_THREADS must be a positive integer, got %r" % raw)
+    return n
+
+
 class VecOnPolicyCollector:
     def __init__(self, vf, discount=0.99, *, env, eval_env, pf, replay_buffer, epoch_frames, train_render=False,
                  eval_episodes=1, eval_render=False, device="cpu", max_episode_frames=999):
@@ -59,15 +72,12 @@ class VecOnPolicyCollector:
         self._pins = None
         self._split_pins = None
         self._split = None  # decided at the first fast-path step: does the actor take the observation split (bf16 depth rows)?
-        # threads of the per-step fp64 -> fp32 host cast (torch's intra-op pool; the env workers own the other cores). The
-        # product runs no other torch CPU op on its hot path, so the process-wide setting is made once here and put back by
-        # terminate(); V4L_CAST_THREADS overrides the count (1 = leave torch's setting alone).
-        self.cast_threads = max(1, int(os.environ.get("V4L_CAST_THREADS", min(8, (os.cpu_count() or 1) // 2))))
+        # threads of the per-step fp64 -> fp32 host cast (torch's intra-op pool; the env workers own the other cores). The count
+        # is scoped to train_one_epoch (set on entry, put back on exit, also when a step raises): evaluation, logging and the
+        # user's own torch CPU code between epochs keep the process's setting. V4L_CAST_THREADS overrides the count (1 = never
+        # touch torch's setting).
+        self.cast_threads = _cast_threads_from_env()
         self.fast_path = isinstance(replay_buffer, DeviceOnPolicyReplayBuffer)
-        self._torch_threads = None
-        if self.fast_path and self.cast_threads > 1 and torch.get_num_threads() != self.cast_threads:
-            self._torch_threads = torch.get_num_threads()
-            torch.set_num_threads(self.cast_threads)
 
     # ---- reference plumbing (collector/base.py:54-58,113-115,166-174; on_policy.py:77-82) ----------------------------
     def start_episode(self):
@@ -87,9 +97,6 @@ class VecOnPolicyCollector:
     def terminate(self):
         self.env.close()
         self.eval_env.close()
-        if self._torch_threads is not None:
-            torch.set_num_threads(self._torch_threads)
-            self._torch_threads = None
 
     # ---- host -> HBM ----------------------------------------------------------------------------------------------
     def _upload(self, rows, host_only=False):
@@ -108,7 +115,7 @@ class VecOnPolicyCollector:
             # the cast is the longest host stage of a step (E x 16.5 K doubles): torch's copy kernel on `cast_threads` intra-op
             # threads (40 us against 300 us for one numpy pass; a Python thread pool over numpy copies does not scale: the
             # casting copy holds the GIL). Round-to-nearest fp64 -> fp32 either way (== torch.Tensor(ob), on_policy.py:91).
-            # The intra-op thread count is set ONCE, in __init__ (restored by terminate()), not toggled per step.
+            # The intra-op thread count is set once per epoch (train_one_epoch), not toggled per step.
             host.copy_(torch.from_numpy(rows))
         else:
             np.copyto(host.numpy(), rows, casting="same_kind")
@@ -209,8 +216,16 @@ class VecOnPolicyCollector:
         self.train_rews = []
         self.train_epoch_reward = 0
         self.env.train()
-        for _ in range(self.sample_epoch_frames):
-            self.train_epoch_reward += self.take_actions()
+        before = torch.get_num_threads()
+        scoped = self.fast_path and self.cast_threads > 1 and before != self.cast_threads
+        if scoped:
+            torch.set_num_threads(self.cast_threads)
+        try:
+            for _ in range(self.sample_epoch_frames):
+                self.train_epoch_reward += self.take_actions()
+        finally:
+            if scoped:
+                torch.set_num_threads(before)
         if self.fast_path and self._actor is not None:
             with torch.cuda.device(self.device):
                 self._actor.check()  # a lost device-side hand-over on the value side must not reach the update silently

@@ -15,8 +15,9 @@ from .base import BaseReplayBuffer
 from ... import engine
 
 
-def _gae_on_device(rewards, values, terminals, time_limits, last_value, gamma, tau, use_tl, device, out=None):
-    """numpy [T,E,1] float64 in -> numpy [T,E,1] float64 advantages / returns via libv4l_hip's v4l_gae."""
+def _gae_on_device(rewards, values, terminals, time_limits, last_value, gamma, tau, use_tl, device, out=None, discount_only=False):
+    """numpy [T,E,1] float64 in -> numpy [T,E,1] float64 advantages / returns via libv4l_hip's v4l_gae (discount_only:
+    v4l_discount_reward; `tau` is then unused)."""
     T, E = rewards.shape[0], rewards.shape[1]
     up = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float64).reshape(T, -1)).to(device)
     r, v, t = up(rewards), up(values), up(terminals)
@@ -29,8 +30,9 @@ def _gae_on_device(rewards, values, terminals, time_limits, last_value, gamma, t
         elif tl.shape[1] != E:
             raise ValueError("time_limits has %d columns, expected 1 or %d" % (tl.shape[1], E))
     lv = torch.from_numpy(np.ascontiguousarray(last_value, dtype=np.float64).reshape(E)).to(device)
-    advs, rets, a32, r32 = engine.gae(r, v, t, tl, lv, gamma, tau, use_tl, want32=True, out=out)
-    return advs, rets, a32, r32
+    if discount_only:
+        return engine.discount_reward(r, v, t, tl, lv, gamma, use_tl, want32=True, out=out)
+    return engine.gae(r, v, t, tl, lv, gamma, tau, use_tl, want32=True, out=out)
 
 
 class OnPolicyReplayBufferBase:
@@ -43,12 +45,17 @@ class OnPolicyReplayBufferBase:
     def generalized_advantage_estimation(self, last_value, gamma, tau):
         """GAE(lambda) over the stored epoch (reference on_policy.py:17-45); results land in _advs and
         _estimate_returns as float64 [T, E, 1] exactly like the reference."""
+        if tau is None:  # the reference's loop fails on `gamma * None` (on_policy.py:31): PPO(gae=True) needs tau
+            raise TypeError("generalized_advantage_estimation: tau is None (PPO(gae=True) needs tau; gae=False calls discount_reward)")
+        self._estimate(last_value, gamma, tau, False)
+
+    def _estimate(self, last_value, gamma, tau, discount_only):
         dev = self.gae_device or torch.device("cuda", torch.cuda.current_device())
         if not hasattr(self, "_gae_out"):
             self._gae_out = {}  # persistent device outputs: stable addresses across epochs
         advs, rets, a32, r32 = _gae_on_device(self._rewards, self._values, self._terminals,
                                               getattr(self, "_time_limits", None), last_value, gamma, tau,
-                                              self.time_limit_filter, dev, self._gae_out)
+                                              self.time_limit_filter, dev, self._gae_out, discount_only)
         shape = np.shape(self._rewards)
         self._advs = advs.cpu().numpy().reshape(shape)
         self._estimate_returns = rets.cpu().numpy().reshape(shape)
@@ -56,8 +63,8 @@ class OnPolicyReplayBufferBase:
 
     def discount_reward(self, last_value, gamma):
         """Discounted rewards as return / advantage estimates (reference on_policy.py:47-71, PPO(gae=False)): the same
-        fp64 HIP path with tau = None (v4l_discount_reward, bit-identical to the reference's numpy loop)."""
-        self.generalized_advantage_estimation(last_value, gamma, None)
+        fp64 HIP path on its own entry point (v4l_discount_reward, bit-identical to the reference's numpy loop)."""
+        self._estimate(last_value, gamma, None, True)
 
     def one_iteration(self, batch_size, sample_key, shuffle):
         """Minibatches of batch_size/env_nums *time rows* (all envs of a row stay together), reference
