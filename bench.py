@@ -46,14 +46,19 @@ WORKLOADS = {
                      name="ppo_locotransformer_vision_only: Transformer over 16 depth tokens, A=6, E=32 envs x T=256, B=1024"),
     "cnn_vis": dict(kind="cnn_vis", S=0, A=6, E=32, T=256, B=1024, enc=[], head=[256, 256],
                     name="ppo_nature_cnn_vision_only: NatureCNN -> 1024 -> head, A=6, E=32 envs x T=256, B=1024"),
+    # an OPTION variant of the headline net (nets.py:1022-1030 max_pool=True; no shipped config sets it): correct with reference
+    # goldens, but on the general layer-by-layer kernels — this line says what that fallback costs
+    "loco_max": dict(kind="loco_max", S=93, A=6, E=32, T=512, B=1024, enc=[256, 256], head=[256, 256], layers=2, ff=256,
+                     name="ppo_locotransformer with max_pool=True (option variant, layer-by-layer kernels), E=32 x T=512, B=1024"),
 }
 # algorithmic MFLOP per env-step incl. rollout inference, and F_pf: the forward pass of the frozen
 # target policy that each of the 3 sample-visits skips when log pi_old is recorded at action time (§8d's declared saving)
 # vision-only nets, same accounting: F_pf = 2 * (3 612 672 conv + 65 536 up-conv + 2 * 819 200 layer (16 tokens) + 83 456 head)
 # = 10.800 MFLOP, F_vf = 10.798; NatureCNN: F_pf = 2 * (3 612 672 + 329 216) = 7.884, F_vf = 7.881
-MFLOP_PER_ENV_STEP = {"loco": 258.9, "loco64": 258.9, "cnn": 191.4, "mlp": 10.2, "loco_vis": 248.4, "cnn_vis": 181.3}
-MFLOP_TARGET_FWD = {"loco": 11.258, "loco64": 11.258, "cnn": 8.325, "mlp": 0.444, "loco_vis": 10.800, "cnn_vis": 7.884}
+MFLOP_PER_ENV_STEP = {"loco": 258.9, "loco64": 258.9, "cnn": 191.4, "mlp": 10.2, "loco_vis": 248.4, "cnn_vis": 181.3, "loco_max": 258.9}
+MFLOP_TARGET_FWD = {"loco": 11.258, "loco64": 11.258, "cnn": 8.325, "mlp": 0.444, "loco_vis": 10.800, "cnn_vis": 7.884, "loco_max": 11.258}
 OPT_EPOCHS = 3
+LAST_ALLREDUCE = None
 PEAK = {"bf16": 2500.0, "f32": 157.3}  # dense TFLOP/s, MI355X_MICROARCH.md (bf16 MFMA / f32 MFMA)
 
 
@@ -190,6 +195,91 @@ class Epoch:
         if with_rollout:
             self.rollout()
         self.update()
+
+
+def side_leg(wl_name, compute, dev, steps=3, warmup=1):
+    """A short timed run of another (workload, compute mode) in the SAME process, after the headline's timed region: the same
+    Epoch, the same step, `steps` epochs. Used for the exact-fp32 mode (the mode that meets the north star's literal 1e-3 against
+    the fp32 reference) and for one option variant that runs on the layer-by-layer kernels."""
+    before = os.environ.get("V4L_COMPUTE")
+    wl = dict(WORKLOADS[wl_name])
+    try:
+        ep = Epoch(wl, compute, dev, 1)
+        for _ in range(warmup):
+            ep.step()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        t_roll = 0.0
+        for _ in range(steps):
+            r0 = time.perf_counter()
+            ep.rollout()
+            torch.cuda.synchronize()
+            t_roll += time.perf_counter() - r0
+            ep.update()
+            torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        frames = wl["E"] * wl["T"]
+        ok = bool(torch.isfinite(ep.stats[:, :18]).all().item())
+        out = {"value": round(frames * steps / dt, 1), "unit": "env-steps/s", "dtype": compute, "steps": steps, "warmup": warmup,
+               "ms_per_step": round(1e3 * dt / steps, 3), "rollout_inference_ms_per_step": round(1e3 * t_roll / steps, 3),
+               "update_only_env_steps_per_s": round(frames * steps / max(dt - t_roll, 1e-9), 1), "stats_finite": ok,
+               "workload": wl["name"]}
+        del ep
+        torch.cuda.empty_cache()
+        return out
+    finally:
+        if before is None:
+            os.environ.pop("V4L_COMPUTE", None)
+        else:
+            os.environ["V4L_COMPUTE"] = before
+
+
+def dp1_ingraph_leg(workload, compute):
+    """The data-parallel schedule on ONE rank (a 1-process torchrun of this file with V4L_FORCE_DP_PHASES=1): RCCL communicator
+    owned by the library, self-test, both all-reduces of every update inside the captured graph. Makes regressions of the DP
+    schedule visible in the single-GPU line, and times one all-reduce call (world 1: its launch / completion floor)."""
+    env = dict(os.environ, V4L_FORCE_DP_PHASES="1", V4L_BENCH_CHILD="1", V4L_COMPUTE=compute)
+    env.pop("WORLD_SIZE", None); env.pop("RANK", None); env.pop("LOCAL_RANK", None); env.pop("MASTER_PORT", None)
+    cmd = launcher_argv(1, ["--gpus", "1", "--workload", workload, "--compute", compute, "--steps", "3", "--warmup", "1",
+                            "--no-parity", "--no-cpu-baseline"])
+    try:
+        r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=300)
+        line = [l for l in r.stdout.splitlines() if l.startswith("{")]
+        if r.returncode != 0 or not line:
+            return {"error": "rc %d: %s" % (r.returncode, (r.stderr or r.stdout)[-300:])}
+        d = json.loads(line[-1])
+        return {"value": d["value"], "ms_per_step": d["ms_per_step"], "update_only_env_steps_per_s": d["update_only_env_steps_per_s"],
+                "dp_comm": d["config"].get("dp_comm"), "rccl_ranks": d.get("rccl_ranks"), "allreduce": d.get("allreduce")}
+    except Exception as e:  # never let a side leg take the headline line down
+        return {"error": repr(e)[:300]}
+
+
+# DESIGN.md section 6: what one in-graph all-reduce of a gradient bucket (1.55 MB fp32) should cost on N GPUs of one node, and what
+# that does to `value`. Assumptions, stated so that the first real multi-GPU run has something to be compared with: xGMI full mesh,
+# 7 links x 153 GB/s per GPU; RCCL on a 1.5 MB message is latency-bound — a launch / completion floor (alpha0, measured here on one
+# rank by dp1_ingraph: `allreduce.us_per_call`) plus a per-hop cost of the protocol (LL / LL128 hops of a ring: 2 (N - 1) hops; a
+# tree: 2 log2 N) of 1.0 - 2.5 us each; the bandwidth term is S / (N x B_link) x 2 (direct reduce-scatter + all-gather over the
+# mesh) to 2 (N - 1) / N x S / B_link (one ring on one link).
+def dp_model(n_gpus, bucket_bytes, alpha0_us, update_us_1gpu, epoch_ms_1gpu, updates_per_epoch, frames_per_gpu):
+    import math
+    if n_gpus <= 1:
+        lo = hi = alpha0_us
+    else:
+        b_link = 153e9
+        bw_lo = 2.0 * bucket_bytes / (n_gpus * b_link) * 1e6
+        bw_hi = 2.0 * (n_gpus - 1) / n_gpus * bucket_bytes / b_link * 1e6
+        lo = alpha0_us + 2 * math.log2(n_gpus) * 1.0 + bw_lo
+        hi = alpha0_us + 2 * (n_gpus - 1) * 2.5 + bw_hi
+    per_epoch_lo, per_epoch_hi = 2 * updates_per_epoch * lo * 1e-3, 2 * updates_per_epoch * hi * 1e-3   # ms, unoverlapped
+    return {"allreduce_us_predicted": [round(lo, 1), round(hi, 1)],
+            "allreduces_per_epoch": 2 * updates_per_epoch, "bucket_bytes": bucket_bytes,
+            "value_predicted": [round(n_gpus * frames_per_gpu / (epoch_ms_1gpu + per_epoch_hi) * 1e3, 0),
+                                round(n_gpus * frames_per_gpu / (epoch_ms_1gpu + per_epoch_lo) * 1e3, 0)],
+            "efficiency_predicted": [round(epoch_ms_1gpu / (epoch_ms_1gpu + per_epoch_hi), 3),
+                                     round(epoch_ms_1gpu / (epoch_ms_1gpu + per_epoch_lo), 3)],
+            "assumes": "alpha0 = %.1f us launch/completion floor of one RCCL call (measured on 1 rank or the default 12), 1.0-2.5 us "
+                       "per protocol hop (tree 2 log2 N .. ring 2 (N - 1)), xGMI 153 GB/s per link, collectives not overlapped with "
+                       "compute (clip_adam waits for them); 1-GPU epoch %.2f ms" % (alpha0_us, epoch_ms_1gpu)}
 
 
 def host_cpu():
@@ -571,6 +661,11 @@ def roofline(ep, compute, breakdown_path):
     wl = ep.wl
     upd = _profiled(L, ep.update)
     roll = _profiled(L, ep.rollout) if ep.actor is not None else []
+    global LAST_ALLREDUCE
+    ar = [(c, u) for label, c, u, _ in upd if label.split("|")[-1].startswith("allreduce")]
+    LAST_ALLREDUCE = ({"calls": sum(c for c, _ in ar), "us_per_call": round(sum(u for _, u in ar) / max(1, sum(c for c, _ in ar)), 2),
+                       "what": "HIP events around ncclAllReduce of one gradient bucket on the update's stream (eager profiled pass)"}
+                      if ar else None)
     rows = sorted(upd + roll, key=lambda r: -r[2])
     if not rows:
         return None
@@ -762,6 +857,31 @@ def main():
     res["stats_finite"] = stats_ok
     if rank == 0:
         res["roofline"] = roofline(ep, a.compute, a.breakdown)
+        upd_per_epoch = OPT_EPOCHS * (wl["E"] * wl["T"] // wl["B"])
+        bucket = 4 * (int(ep.vf.hip.total_params) + 8)
+        if dist_on:
+            res["allreduce"] = LAST_ALLREDUCE
+            if world > 1:
+                # prediction from THIS run's own compute time: strip the measured collectives, add the modelled ones
+                ar_ms = (LAST_ALLREDUCE["us_per_call"] * 2 * upd_per_epoch * 1e-3) if LAST_ALLREDUCE else 0.0
+                res["dp_model"] = dp_model(world, bucket, 12.0, None, max(1e3 * dt / a.steps - ar_ms, 1e-3), upd_per_epoch,
+                                           wl["E"] * wl["T"])
+                res["dp_model"]["allreduce_us_measured"] = LAST_ALLREDUCE["us_per_call"] if LAST_ALLREDUCE else None
+        child = os.environ.get("V4L_BENCH_CHILD", "0") != "0"
+        if world == 1 and not a.no_parity and not child and a.workload in ("loco", "loco64"):
+            # side legs (driver-visible, all after the timed region): the exact-fp32 mode with the same parity check, the DP
+            # schedule on one rank, one option variant on the layer-by-layer kernels, and the multi-GPU cost model
+            other = "f32" if a.compute == "bf16" else "bf16"
+            res["f32_mode" if other == "f32" else "bf16_mode"] = dict(
+                side_leg(a.workload, other, dev), parity_check=parity_check(wl, other, dev),
+                note="compute=f32: exact-fp32 MFMA (v_mfma_f32_16x16x4_f32) — the mode whose outputs meet the north star's "
+                     "1e-3 against the fp32 reference literally (DESIGN.md section 2)")
+            res["dp1_ingraph"] = dp1_ingraph_leg(a.workload, a.compute)
+            res["dp1_ingraph_value"] = res["dp1_ingraph"].get("value")
+            res["option_variant"] = side_leg("loco_max", a.compute, dev, steps=2, warmup=1)
+            alpha0 = (res["dp1_ingraph"].get("allreduce") or {}).get("us_per_call") or 12.0
+            res["dp_model"] = {str(n): dp_model(n, bucket, alpha0, None, 1e3 * dt / a.steps, upd_per_epoch, wl["E"] * wl["T"])
+                               for n in (2, 4, 8)}
         if world == 1 and not a.no_parity:
             res["parity_check"] = parity_check(wl, a.compute, dev)
             res["h2d_ms_per_step"] = round(h2d_per_step(wl, dev), 4)

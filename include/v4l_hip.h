@@ -17,49 +17,34 @@
  *   - all activations/params/grads are fp32; `compute` selects the contraction operand type:
  *     V4L_F32 = exact fp32 MFMA (parity mode), V4L_BF16 = bf16 operands, fp32 accumulate (production).
  *
- * Environment switches read by the library (all default to the fast path; tests flip them to cross-check a fused kernel
- * against the general layer-by-layer ones). Values are read when first needed unless marked (per call).
- *   V4L_TRACE                 launch / graph log on stderr
+ * Environment switches read by the library: 18 (round 4: 37 — the ones no test referenced went in round 5, their fast-path value
+ * is now compiled in). Three configure a run, the others are DIAGNOSTIC: every one of them backs a bit-equality / cross-check test
+ * under tests/ that compares a fused kernel or a launch schedule against the general one. Read when first needed unless (per call).
+ *   run:   V4L_TRACE (launch / graph log on stderr), V4L_RCCL_LIB (RCCL library to dlopen; default librccl.so.1), V4L_ROCTX=1 (roctx
+ *          ranges phase|op|kernel around every launch call for `rocprofv3 --marker-trace`)
  *   V4L_PAR=0                 no auxiliary streams (sibling kernels run serially)
  *   V4L_PAR_WGRAD=0|1|2       weight-grad launch schedule of a backward pass (per call; 2 = default: conv data-grads first,
  *                             then dW3 on the main stream next to the dense weight-grads on the auxiliary stream)
- *   V4L_SPLIT_REDUCE=0        schedule 2 issues wgrad_reduce as two launches INSIDE the forked section (conv-stack partials behind
- *                             dW3, the others behind the dense weight-grads); 0 = one launch behind the join (same bits) (per call)
- *   V4L_SPLIT_DENSE_WGRAD     grouped and whole-output dense weight-grads as two launches instead of one (per call)
- *   V4L_NO_DENSE_STACK        the NatureCNN nets' visual projector + head (forward) and their data-grads (backward) as one
- *                             gemm_nt_deep launch per linear instead of one launch per direction (csrc/dense_stack.h; same bits) (per call)
- *   V4L_NO_SQ_FROM_REDUCE     separate grad_sumsq launch on one GPU too (the norm's partials otherwise come from wgrad_reduce)
- *   V4L_NO_FUSED_ENC          LocoTransformer encoder layer by layer (per call)
- *   V4L_NO_FUSED_LAYER        transformer layers layer by layer, forward and backward (per call)
- *   V4L_NO_FUSED_HEAD         pooled heads outside the last layer's forward launch (per call)
- *   V4L_NO_FUSED_HEAD_BWD     heads' data-grads outside the layer backward launch (per call)
- *   V4L_NO_FUSED_TAIL_BWD     encoder-MLP / up-conv data-grads outside the layer backward launch (per call)
+ *   V4L_SPLIT_REDUCE=0        wgrad_reduce as one launch behind the join instead of two inside the forked section (same bits) (per call)
+ *   V4L_NO_DENSE_STACK        the NatureCNN nets' visual projector + head and their data-grads as one gemm_nt_deep launch per
+ *                             linear instead of one launch per direction (csrc/dense_stack.h; same bits) (per call)
  *   V4L_NO_FUSED_CONV_BWD     conv-stack backward layer by layer (per call)
- *   V4L_NO_FUSED_ACTOR        rollout step on the general kernels (per call)
  *   V4L_NO_LAYER_STACK        one launch per transformer layer instead of one per direction (per call)
  *   V4L_NO_WPS_LAYERS         transformer layers on the block-cooperative kernels instead of the wave-per-sample ones (per call)
- *   V4L_LAYER_TAPS            tests: the wave-per-sample layer kernels and the fused conv backward also write every
- *                             intermediate into its v4l_net_ws_offset slot (production keeps them on chip) (per call)
- *   V4L_LAYER_SPW=2|4, V4L_LAYER_BWD_SPW=2|4      samples per block of the block-cooperative layer kernels
- *   V4L_CONV_BWD_BLOCKS, V4L_CONV3_WGRAD_BLOCKS, V4L_TRAIN_ENC_BLOCKS, V4L_WIDE_SPLITS   block / split counts (tests force ragged and many-samples-per-block shapes)
- *   V4L_TRAIN_ENC_OLD, V4L_ROLLOUT_ENC_OLD        the streamed-weight encoder kernels
- *   V4L_GEMM_DEEP_MIN_M       smallest row count the dense layers of the general path send to gemm_nt_deep_kernel (default
- *                             256; 0 = never; tests lower it) (per call)
- *   V4L_ROLLOUT_MLP_OLD       state MLP rollout step: the per-sample rollout_mlp_kernel
+ *   V4L_LAYER_TAPS            the wave-per-sample layer kernels and the fused conv backward also write every intermediate into
+ *                             its v4l_net_ws_offset slot (production keeps them on chip) (per call)
+ *   V4L_CONV_BWD_BLOCKS, V4L_CONV3_WGRAD_BLOCKS   persistent-block counts (tests force ragged and many-samples-per-block shapes)
+ *   V4L_GEMM_DEEP_MIN_M       smallest row count the general path's dense layers send to gemm_nt_deep_kernel (default 256) (per call)
  *   V4L_ROLLOUT_DENSE_SPLIT   NatureCNN nets' rollout step: the dense layers as three launches instead of one launch with
- *                             device-side hand-overs (per call); V4L_ROLLOUT_CNN_OLD: the per-sample rollout_cnn_kernel
- *   V4L_ROLLOUT_WARM          L2 warm-up touches at the start of rollout_stack_kernel (measured: no effect)
- *   V4L_ROLLOUT_XCD=0         rollout_stack_kernel on the (E, 2) grid instead of the 1-D grid that keeps one net per XCD half
- *   V4L_WPS_HEAD_IN, V4L_WPS_TOK0_IN   the pooled heads' / the proprio branch's data-grad chain inside wps_layer_bwd_kernel (4 rows per
- *                             block) instead of beside the loss statistics / the layers' weight-grads (32 - 64 rows per block);
- *                             V4L_WPS_HEAD_EXT_CRITIC=1: the critic's heads beside its loss statistics too (per call)
- *   V4L_RCCL_LIB              path of the RCCL library to dlopen (default: librccl.so.1)
- *   V4L_ROCTX=1               roctx ranges (libroctx64 via dlopen) around every phase and launch call, labelled phase|op|kernel:
- *                             `rocprofv3 --marker-trace --kernel-trace` then shows the library's structure next to its kernels
+ *                             device-side hand-overs (per call)
+ *   V4L_WPS_HEAD_IN, V4L_WPS_TOK0_IN, V4L_WPS_HEAD_EXT_CRITIC   where the pooled heads' / the proprio branch's data-grad chains run:
+ *                             inside wps_layer_bwd_kernel (4 rows per block) or beside the loss statistics / the layers'
+ *                             weight-grads (16 - 64 rows per block) (per call)
  * Read by the Python shell, not by the library: V4L_COMPUTE=bf16|f32, V4L_GRAPH=0, V4L_DP_COMM=auto|torch|rccl,
  * V4L_CAST_THREADS, V4L_COLLECT_SPLIT=0 (fp32 observation rows over PCIe instead of fp32 proprio + bf16 depth rows),
- * V4L_FORCE_DP_PHASES, V4L_LIB (diagnostic builds). Everything here except COMPUTE / GRAPH / DP_COMM / CAST_THREADS / RCCL_LIB /
- * TRACE / ROCTX is a DIAGNOSTIC switch: the Python shell warns once at load time when one is set (_lib.diagnostic_switches).
+ * V4L_SPLIT_VIA_COPY, V4L_GUARD, V4L_FORCE_DP_PHASES, V4L_LIB (diagnostic builds). Everything except COMPUTE / GRAPH / DP_COMM /
+ * CAST_THREADS / RCCL_LIB / TRACE / ROCTX is diagnostic: the Python shell warns once at load time when one is set
+ * (_lib.diagnostic_switches).
  */
 #ifndef V4L_HIP_H
 #define V4L_HIP_H

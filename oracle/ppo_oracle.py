@@ -85,30 +85,40 @@ class _MatmulBF16(torch.autograd.Function):
         return dcr @ br.transpose(-1, -2), ar.transpose(-1, -2) @ dcr
 
 
-def matmul(a, b, mode):
-    return a @ b if mode == "f32" else _MatmulBF16.apply(a, b)
+# Contraction groups of the LocoTransformer / NatureCNN nets. `mode` is "f32" or "bf16" for every contraction, or a mapping
+# group -> "f32" / "bf16" (missing groups: "f32") — tools/bf16_attribution.py rounds ONE group at a time to attribute the
+# bf16 flavour's distance to the fp32 reference.
+GROUPS = ("conv", "upconv", "proprio", "projector", "in_proj", "attn", "out_proj", "ffn", "heads")
 
 
-def linear(x, w, b, mode):
-    return F.linear(x, w, b) if mode == "f32" else _LinearBF16.apply(x, w, b)
+def _m(mode, group):
+    return mode if isinstance(mode, str) else mode.get(group, "f32")
 
 
-def conv2d(x, w, b, stride, mode):
-    return F.conv2d(x, w, b, stride=stride) if mode == "f32" else _ConvBF16.apply(x, w, b, stride)
+def matmul(a, b, mode, group="attn"):
+    return a @ b if _m(mode, group) == "f32" else _MatmulBF16.apply(a, b)
+
+
+def linear(x, w, b, mode, group="heads"):
+    return F.linear(x, w, b) if _m(mode, group) == "f32" else _LinearBF16.apply(x, w, b)
+
+
+def conv2d(x, w, b, stride, mode, group="conv"):
+    return F.conv2d(x, w, b, stride=stride) if _m(mode, group) == "f32" else _ConvBF16.apply(x, w, b, stride)
 
 
 # ------------------------------------------------------------------------------------------ building blocks
-def mlp(p, prefix, x, n, mode):
+def mlp(p, prefix, x, n, mode, group="proprio"):
     """MLPBase: Linear+ReLU per hidden layer, last activation is ReLU too (torchrl/networks/base.py:8-44)."""
     for i in range(n):
-        x = torch.relu(linear(x, p["%s.%d.weight" % (prefix, 2 * i)], p["%s.%d.bias" % (prefix, 2 * i)], mode))
+        x = torch.relu(linear(x, p["%s.%d.weight" % (prefix, 2 * i)], p["%s.%d.bias" % (prefix, 2 * i)], mode, group))
     return x
 
 
 def head(p, prefix, x, n_hidden, mode):
     """append fcs: (Linear+ReLU)*n_hidden then Linear (nets.py:35-50, 224-243, 973-992)."""
-    x = mlp(p, prefix, x, n_hidden, mode)
-    return linear(x, p["%s.%d.weight" % (prefix, 2 * n_hidden)], p["%s.%d.bias" % (prefix, 2 * n_hidden)], mode)
+    x = mlp(p, prefix, x, n_hidden, mode, "heads")
+    return linear(x, p["%s.%d.weight" % (prefix, 2 * n_hidden)], p["%s.%d.bias" % (prefix, 2 * n_hidden)], mode, "heads")
 
 
 def nature_cnn(p, prefix, img, mode):
@@ -124,14 +134,14 @@ def transformer_layer(p, prefix, x, mode):
     (built at nets.py:948-955, applied :1009-1011). x is batch-first [B,17,64] here; the reference runs the
     same arithmetic sequence-first."""
     d = x.shape[-1]
-    qkv = linear(x, p[prefix + ".self_attn.in_proj_weight"], p[prefix + ".self_attn.in_proj_bias"], mode)
+    qkv = linear(x, p[prefix + ".self_attn.in_proj_weight"], p[prefix + ".self_attn.in_proj_bias"], mode, "in_proj")
     q, k, v = qkv.split(d, dim=-1)
     scores = matmul(q, k.transpose(-1, -2), mode) * (1.0 / math.sqrt(d))
     ctx = matmul(torch.softmax(scores, dim=-1), v, mode)
-    a = linear(ctx, p[prefix + ".self_attn.out_proj.weight"], p[prefix + ".self_attn.out_proj.bias"], mode)
+    a = linear(ctx, p[prefix + ".self_attn.out_proj.weight"], p[prefix + ".self_attn.out_proj.bias"], mode, "out_proj")
     x = F.layer_norm(x + a, (d,), p[prefix + ".norm1.weight"], p[prefix + ".norm1.bias"], 1e-5)
-    f = torch.relu(linear(x, p[prefix + ".linear1.weight"], p[prefix + ".linear1.bias"], mode))
-    f = linear(f, p[prefix + ".linear2.weight"], p[prefix + ".linear2.bias"], mode)
+    f = torch.relu(linear(x, p[prefix + ".linear1.weight"], p[prefix + ".linear1.bias"], mode, "ffn"))
+    f = linear(f, p[prefix + ".linear2.weight"], p[prefix + ".linear2.bias"], mode, "ffn")
     return F.layer_norm(x + f, (d,), p[prefix + ".norm2.weight"], p[prefix + ".norm2.bias"], 1e-5)
 
 
@@ -170,12 +180,12 @@ def loco_forward(p, x, S, mode="f32", taps=None, max_pool=False):
     state, img = split_obs(x, S)
     B = state.shape[0]
     c3 = nature_cnn(p, "encoder.depth_visual_base", img, mode)                                  # base.py:578
-    up = conv2d(c3, p["encoder.depth_up_conv.weight"], p["encoder.depth_up_conv.bias"], 1, mode)   # base.py:581
+    up = conv2d(c3, p["encoder.depth_up_conv.weight"], p["encoder.depth_up_conv.bias"], 1, mode, "upconv")   # base.py:581
     depth_tok = up.reshape(B, 64, 16).permute(0, 2, 1)                                          # base.py:602-608
     ne = _count(p, "encoder.base.seq_fcs.%d.weight")
     h = mlp(p, "encoder.base.seq_fcs", state, ne, mode)                                         # base.py:611
     st = torch.relu(linear(h, p["encoder.state_projector.projection.0.weight"],
-                           p["encoder.state_projector.projection.0.bias"], mode))               # base.py:613
+                           p["encoder.state_projector.projection.0.bias"], mode, "proprio"))    # base.py:613
     tok = torch.cat([st.unsqueeze(1), depth_tok], dim=1)                                        # base.py:617-622
     if "token_ln.weight" in p:                                                                  # token_norm=True: nets.py:1007-1008
         tok = F.layer_norm(tok, (tok.shape[-1],), p["token_ln.weight"], p["token_ln.bias"], 1e-5)
@@ -193,7 +203,7 @@ def cnn_forward(p, x, S, mode="f32", taps=None):
     state, img = split_obs(x, S)
     c3 = nature_cnn(p, "encoder.visual_base", img, mode)
     vis = torch.relu(linear(c3.flatten(1), p["encoder.visual_projector.projection.0.weight"],
-                            p["encoder.visual_projector.projection.0.bias"], mode))
+                            p["encoder.visual_projector.projection.0.bias"], mode, "projector"))
     ne = _count(p, "encoder.base.seq_fcs.%d.weight")
     h = mlp(p, "encoder.base.seq_fcs", state, ne, mode)
     nh = _count(p, "seq_append_fcs.%d.weight") - 1
@@ -213,7 +223,7 @@ def loco_vis_forward(p, x, S=0, mode="f32", taps=None, max_pool=False):
     img = x.reshape(-1, 4, 64, 64)                                                              # nets.py:869-871
     B = img.shape[0]
     c3 = nature_cnn(p, "encoder.depth_visual_base", img, mode)                                  # base.py:449
-    up = conv2d(c3, p["encoder.depth_up_conv.weight"], p["encoder.depth_up_conv.bias"], 1, mode)   # base.py:452
+    up = conv2d(c3, p["encoder.depth_up_conv.weight"], p["encoder.depth_up_conv.bias"], 1, mode, "upconv")   # base.py:452
     tok = up.reshape(B, 64, 16).permute(0, 2, 1)                                                # base.py:474-481
     if "token_ln.weight" in p:                                                                  # token_norm=True: nets.py:879-880
         tok = F.layer_norm(tok, (tok.shape[-1],), p["token_ln.weight"], p["token_ln.bias"], 1e-5)

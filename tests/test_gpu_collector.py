@@ -214,7 +214,16 @@ def test_step_host_equals_step(name, device):
                 actor.draw_noise(T - 4)  # the remaining steps consume slices of one bulk draw
             elif t < 4:
                 torch.manual_seed(500 + t)
-            if host in ("split", "split_copy"):
+            if host == "split_pipe":  # the collector's cast -> DMA pipeline (_step_split_pipelined): chunked copies, kernels read HBM
+                S = case["S"]
+                dprop, dimg = actor.split_device_buffers()
+                if S:
+                    dprop.copy_(torch.from_numpy(rows[t][:, :S].copy()).pin_memory(), non_blocking=True)
+                img16 = torch.from_numpy(rows[t][:, S:].copy()).to(torch.bfloat16).pin_memory()
+                for a0 in range(0, E, 3):  # ragged chunks on purpose (3 + 1 rows)
+                    dimg[a0:a0 + 3].copy_(img16[a0:a0 + 3], non_blocking=True)
+                acts.append(np.array(actor.step_host_split(dprop if S else None, dimg, on_device=True), copy=True))
+            elif host in ("split", "split_copy"):
                 S = case["S"]
                 prop = torch.from_numpy(rows[t][:, :S].copy()).pin_memory() if S else None
                 img16 = torch.from_numpy(rows[t][:, S:].copy()).to(torch.bfloat16).pin_memory()
@@ -233,7 +242,7 @@ def test_step_host_equals_step(name, device):
         assert (x is None and y is None) or torch.equal(x, y)
     assert np.isfinite(a_host).all() and np.abs(a_host[2:]).max() > 0 and filed_host[4][2 * E:].abs().max() > 0
     if split:  # ... and the split hand-over (fp32 proprio + bf16 depth rows) gives the same bits again
-        for how in ("split", "split_copy"):  # rows read in place over PCIe / copied to HBM first (V4L_SPLIT_VIA_COPY)
+        for how in ("split", "split_copy", "split_pipe"):  # rows read in place over PCIe / copied to HBM first / chunked DMA pipeline
             a_split, filed_split, first_split = run(how, rollout_arrays())
             assert np.array_equal(a_dev, a_split), how
             for x, y in list(zip(filed_dev, filed_split)) + list(zip(first_dev, first_split)):

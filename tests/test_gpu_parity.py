@@ -604,7 +604,8 @@ def test_graph_replay_equals_eager(mode, pair, device):
 
 @pytest.mark.parametrize("graph", [False, True])
 @pytest.mark.parametrize("mode", MODES)
-@pytest.mark.parametrize("name", ["loco_s84", "cnn_s93", "mlp_s93", "loco_vis", "cnn_vis", "loco_tn", "loco_vis_tn", "loco_pe", "loco_vis_pe"])
+@pytest.mark.parametrize("name", ["loco_s84", "cnn_s93", "mlp_s93", "loco_vis", "cnn_vis", "loco_tn", "loco_vis_tn", "loco_pe", "loco_vis_pe",
+                                  "loco_max", "loco_vis_max"])  # (max_pool: the fused step kernels with the max-pooling flag, round 5)
 def test_rollout_actor_matches_separate_calls(name, mode, graph, device):
     """RolloutActor.step (shared encoder pass, graph replay, device-side cursor) == pf.explore + vf of the reference
     protocol: same mean/std/value, action = mean + std*eps, rows/actions/values filed at slots [t*E,(t+1)*E)."""

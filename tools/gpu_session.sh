@@ -55,5 +55,19 @@ a)  # round 5, session A: today's baseline line, the rolled-layer-loop build (I-
   V4L_LIB=$REPO/vision4leg_amd/libv4l_hip_roll.so pmc r5a_roll tools/probe/wps_run.py "$G1" "$G2" "$G3"
   head -120 $O/r5a_base_pmc_summary.txt
   ;;
+b)  # round 5, session B: the extended default line (f32 / dp1 / option-variant legs), the rollout floor probe, scheduling variants
+  python bench.py > $O/r5b_bench_full.json 2> $O/r5b_bench_full.err; tail -c 3000 $O/r5b_bench_full.json; tail -5 $O/r5b_bench_full.err
+  tools/probe/rollout_floor > $O/r5b_rollout_floor.txt 2>&1; cat $O/r5b_rollout_floor.txt
+  L=$REPO/vision4leg_amd
+  bench_ab r5b 3 "base=" "eu1=V4L_LIB=$L/libv4l_hip_eu1.so" "ilp=V4L_LIB=$L/libv4l_hip_ilp.so" "bias0=V4L_LIB=$L/libv4l_hip_bias0.so"
+  ;;
+c)  # round 5, session C: runtime knobs — where the kernel arguments live (device memory vs host-coherent memory)
+  bench_ab r5c 3 "base=" "devkernarg1=HIP_FORCE_DEV_KERNARG=1" "devkernarg0=HIP_FORCE_DEV_KERNARG=0"
+  ;;
+full)  # the whole GPU suite + the default bench line (what the driver runs at round end)
+  (timeout 1500 python -m pytest tests -q -m gpu --tb=short -x 2>&1 | tail -25) > $O/r5_gpu_tests.log; tail -8 $O/r5_gpu_tests.log
+  cp $O/parity.json $O/r5_parity.json 2>/dev/null
+  python bench.py > $O/r5_bench_full.json 2> $O/r5_bench_full.err; tail -c 600 $O/r5_bench_full.json
+  ;;
 *) echo "unknown session $S"; exit 2 ;;
 esac

@@ -2,6 +2,8 @@
 # Diagnostic variant builds of the library (never the shipped one): tools/probe/build_variant.sh <name> [extra hipcc flags...]
 #   roll   -DV4L_WPS_ROLL_LAYERS   layer loops of the wave-per-sample stack kernels as run-time loops (code size / I-cache probe)
 #   timing -DV4L_INFER_TIMING      clock64 phase stamps
+#   eu1    -DV4L_WPS_EU1           amdgpu_waves_per_eu(1,1) on the wave-per-sample stack kernels
+#   ilp    -mllvm -amdgpu-sched-strategy=max-ilp ; bias0  -mllvm -amdgpu-schedule-metric-bias=0   (whole library)
 # -> vision4leg_amd/libv4l_hip_<name>.so, selected at run time with V4L_LIB=<path>
 set -e
 cd "$(dirname "$0")/../.."
@@ -9,6 +11,9 @@ name=$1; shift
 case $name in
   roll) flags="-DV4L_WPS_ROLL_LAYERS" ;;
   timing) flags="-DV4L_INFER_TIMING" ;;
+  eu1) flags="-DV4L_WPS_EU1" ;;
+  ilp) flags="-mllvm -amdgpu-sched-strategy=max-ilp" ;;
+  bias0) flags="-mllvm -amdgpu-schedule-metric-bias=0" ;;
   *) flags="" ;;
 esac
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared $flags "$@" vision4leg_amd/csrc/v4l_hip.hip \

@@ -472,6 +472,7 @@ struct InfHead {
   const float *b0, *b1, *b2;
   float* out;                          // [E][OUT_LD], columns >= nout zeroed
   int nout;
+  int max_pool;                        // rollout_stack_kernel only: the depth tokens pooled by max instead of mean (nets.py:1022-1030, 884-889)
   float *s_pooled, *s_h0, *s_h1;       // training forward: [E][128], [E][256], [E][256] (post-ReLU); null for inference
 };
 struct InfHeadPair { InfHead n[2]; };
@@ -1235,10 +1236,14 @@ __global__ __launch_bounds__(512) void rollout_stack_kernel(InfLayerStack stk, I
     if (!VIS && tid < TD) v = xs[tid];
     else {
       const int d = VIS ? tid : tid - TD;
-      float s = 0.f;
+      float s = 0.f, m = -INFINITY;
 #pragma unroll
-      for (int i = VIS ? 0 : 1; i < NT; ++i) s += xs[i * LY::LDX + d];
-      v = s * (1.f / 16.f);
+      for (int i = VIS ? 0 : 1; i < NT; ++i) {
+        const float t = xs[i * LY::LDX + d];
+        s += t;
+        m = fmaxf(m, t);
+      }
+      v = h.max_pool ? m : s * (1.f / 16.f);  // max_pool=True: `.max(dim=0)[0]` over the same tokens (nets.py:1022-1023, 886-887)
     }
     pooled[tid] = v;
   }

@@ -288,8 +288,7 @@ static int wgrad_dense(Ctx& c, hipStream_t ds, hipStream_t dg) {
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)dense_lds));
     attr_done = true;
   }
-  const bool split = getenv("V4L_SPLIT_DENSE_WGRAD") != nullptr;
-  if (gb > 0 && wb > 0 && !split) {
+  if (gb > 0 && wb > 0) {
     g_op = "layer.wgrad";  // (the layers' share dominates: 8 of the ~20 problems, 2/3 of the blocks)
     V4L_KLAUNCH("gemm_tn_dense", net->wide_flops + net->tnp_flops, dg, gemm_tn_dense_kernel<T>, dim3((unsigned)(wb + gb)), dim3(256),
                 dense_lds, dg, (const TnWide*)net->d_wide, (int)net->wide.size(), wb, (const TnProb*)net->d_tnp, (int)net->tnp.size());
@@ -394,7 +393,7 @@ static int lin_wgrad(Ctx& c, const Lin& L, const ADense& y, const ADense& x, int
   memset(&p, 0, sizeof(p));
   p.y = y; p.x = x; p.M = M;
   p.gx = cdiv(Kx, 64); p.gy = cdiv(L.N, 64);
-  static const int big_rows = getenv("V4L_TN_BIG_ROWS") ? std::max(64, atoi(getenv("V4L_TN_BIG_ROWS"))) : 256;
+  constexpr int big_rows = 256;
   int splits = M >= 4096 ? std::min(16384 / big_rows, M / big_rows) : std::max(1, M / 128);  // 2..4 staging rounds per block: latency-bound
   p.mpb = round_up(cdiv(M, splits), 64);
   splits = cdiv(M, p.mpb);
@@ -425,7 +424,7 @@ static int lin_wgrad_wide(Ctx& c, const Lin& L, const void* y, const void* x, in
   TnWide p;
   memset(&p, 0, sizeof(p));
   p.y = y; p.x = x; p.M = M; p.N = L.N; p.K = L.K;
-  static const int wide_splits = getenv("V4L_WIDE_SPLITS") ? std::max(1, std::min(64, atoi(getenv("V4L_WIDE_SPLITS")))) : 64;
+  constexpr int wide_splits = 64;
   int splits = std::max(1, std::min(wide_splits, M / 256));
   p.mpb = round_up(cdiv(M, splits), 64);
   splits = cdiv(M, p.mpb);
@@ -1019,10 +1018,10 @@ bool v4l_net::wps_vis() const {
   const v4l_net_cfg& c = cfg;
   return c.kind == V4L_NET_LOCO_VIS && !c.max_pool && !c.token_norm && !c.pytorch_encoder && c.ff_dim == 256 && c.n_layers == 2 && c.n_head_hidden == 2 && c.head_hidden[0] == 256 &&
          c.head_hidden[1] == 256 && c.out_dim <= OUT_LD && layers[0].inproj.pkp >= 0 && head[0].pko >= 0 &&
-         getenv("V4L_NO_WPS_LAYERS") == nullptr && getenv("V4L_NO_FUSED_LAYER") == nullptr;
+         getenv("V4L_NO_WPS_LAYERS") == nullptr;
 }
 bool v4l_net::fused_layers() const {
-  return cfg.kind == V4L_NET_LOCO && cfg.ff_dim == 256 && !cfg.token_norm && !cfg.pytorch_encoder && getenv("V4L_NO_FUSED_LAYER") == nullptr;
+  return cfg.kind == V4L_NET_LOCO && cfg.ff_dim == 256 && !cfg.token_norm && !cfg.pytorch_encoder;
 }
 // backward_t's own conditions for the (non-vision) wave-per-sample backward, for callers that prepare work for it
 bool v4l_net::wps_bwd_plain() const {
@@ -1030,9 +1029,9 @@ bool v4l_net::wps_bwd_plain() const {
   if (c.kind != V4L_NET_LOCO) return false;
   const bool fused_bwd = fused_layers();
   const bool fused_head = fused_bwd && c.n_layers >= 1 && c.n_head_hidden == 2 && c.head_hidden[0] == 256 &&
-                          c.head_hidden[1] == 256 && !c.max_pool && getenv("V4L_NO_FUSED_HEAD_BWD") == nullptr;
+                          c.head_hidden[1] == 256 && !c.max_pool;
   const bool fused_tail = fused_bwd && c.n_layers >= 1 && c.n_enc_hidden == 2 && c.enc_hidden[0] == 256 &&
-                          c.enc_hidden[1] == 256 && getenv("V4L_NO_FUSED_TAIL_BWD") == nullptr;
+                          c.enc_hidden[1] == 256;
   return fused_bwd && fused_head && fused_tail && c.n_layers == 2 && getenv("V4L_NO_LAYER_STACK") == nullptr && wps_layers();
 }
 // The operands of the pooled heads' data-grad chain over the workspace `ws` laid out for n rows, for a caller (the trainer's
@@ -1173,10 +1172,8 @@ int v4l_net::forward_t(const float* state, const T* image, const int* rowidx, in
   ADense head_in;
   // persistent 16-wave encoder blocks (csrc/infer.h train_encoder_kernel<MODE>): conv weights enter a CU once, not once per
   // sample; saves c1 / c2 / c3 (what the conv backward reads) and, with a proprio branch, the two MLP activations
-  static const bool persistent_enc = getenv("V4L_TRAIN_ENC_OLD") == nullptr;
   const bool mlp256 = ne == 2 && c.enc_hidden[0] == 256 && c.enc_hidden[1] == 256 && c.state_dim <= 128;
-  const bool train_enc_ok = persistent_enc && sizeof(T) == 2 && c.kind != V4L_NET_MLP && conv[0].pkf >= 0 &&
-                            getenv("V4L_NO_FUSED_ENC") == nullptr &&
+  const bool train_enc_ok = sizeof(T) == 2 && c.kind != V4L_NET_MLP && conv[0].pkf >= 0 &&
                             (vis_only() || (mlp256 && enc[0].Kp == 128 && enc[0].pkf >= 0));
   auto train_enc = [&](auto mode_tag, float* x0, float* s_h2, int ld_h2, bool proprio = true) -> int {
     constexpr int MODE = decltype(mode_tag)::value;
@@ -1202,7 +1199,7 @@ int v4l_net::forward_t(const float* state, const T* image, const int* rowidx, in
     te.s_c1 = ws + L.c1; te.s_c2 = ws + L.c2; te.s_c3 = ws + L.c3;
     te.s_h1 = prop ? ws + L.eh[0] : nullptr; te.s_h2 = s_h2; te.ld_h2 = ld_h2;
     te.n = n; te.nmlp = prop ? cdiv(n, 32) : 0;
-    static const int cus = getenv("V4L_TRAIN_ENC_BLOCKS") ? atoi(getenv("V4L_TRAIN_ENC_BLOCKS")) : 256;
+    constexpr int cus = 256;
     // the conv share never collapses: a very large minibatch (n >~ 8 K: nmlp -> cus) still gets half the CUs' worth of
     // persistent conv blocks (the MLP blocks are short; the two kinds then simply run in two waves over the chip)
     te.nconv = std::max(1, std::min(n, std::max(cus / 2, cus - te.nmlp)));
@@ -1258,8 +1255,7 @@ int v4l_net::forward_t(const float* state, const T* image, const int* rowidx, in
     // their LayerNorm — token_ln belongs to the net, not to the (possibly shared) encoder — and the layers read x[0] as ever
     float* x0 = c.token_norm ? (enc_ws != nullptr ? const_cast<float*>(enc_ws) : ws) + L.x0raw
                              : (enc_ws != nullptr ? const_cast<float*>(enc_ws) + L.x[0] : ws + L.x[0]);
-    const bool fused_enc = ne == 2 && c.enc_hidden[0] == 256 && c.enc_hidden[1] == 256 && c.state_dim <= 128 &&
-                           getenv("V4L_NO_FUSED_ENC") == nullptr;
+    const bool fused_enc = ne == 2 && c.enc_hidden[0] == 256 && c.enc_hidden[1] == 256 && c.state_dim <= 128;
     if (enc_ws == nullptr && stage != 2 && fused_enc) {
       // one launch for the whole encoder (csrc/infer.h): a block per sample runs conv1..3 + up-conv out of LDS, extra
       // blocks run the proprio MLP; the activations backward_t needs are saved on the way
@@ -1334,7 +1330,7 @@ int v4l_net::forward_t(const float* state, const T* image, const int* rowidx, in
     const bool fused_layers = this->fused_layers();
     // the last layer's blocks also run the pooled heads of their samples when the head stack has the shipped shape
     const bool fused_head = fused_layers && c.n_layers >= 1 && nh == 2 && c.head_hidden[0] == 256 && c.head_hidden[1] == 256 &&
-                            c.out_dim <= OUT_LD && !c.max_pool && getenv("V4L_NO_FUSED_HEAD") == nullptr;
+                            c.out_dim <= OUT_LD && !c.max_pool;
     // both layers + the heads in ONE launch when the stack is the shipped two layers (the token rows stay in LDS between
     // the layers); otherwise one launch per TransformerEncoderLayer. 2 or 4 samples per block, saving what backward_t reads.
     const bool stack_ok = getenv("V4L_NO_LAYER_STACK") == nullptr;  // (read per call: tests switch it)
@@ -1405,7 +1401,6 @@ int v4l_net::forward_t(const float* state, const T* image, const int* rowidx, in
       if (!attr_done) {
         spw = 2;
         constexpr bool spw4_fits = InfLayLds<T, 4>::bytes <= 160 * 1024;  // (not in the fp32 parity mode: 168 KB)
-        if (const char* e = getenv("V4L_LAYER_SPW")) spw = (atoi(e) == 4 && spw4_fits) ? 4 : 2;
         auto lds = [](const void* fn, size_t bytes) { return hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes); };
         if (spw4_fits) {
           V4L_HIP_CHECK(lds(reinterpret_cast<const void*>(&infer_layer_kernel<T, 4, false, 1>), InfLayLds<T, 4>::bytes));
@@ -1723,9 +1718,8 @@ int v4l_net::backward_t(const float* state, const T* image, const int* rowidx, i
   const bool fused_bwd = fused_layers();  // forward and backward switch together: they share the T-typed saves
   // the last layer's launch starts from dout (heads + un-pool), layer 0's launch continues into the encoder MLP / up-conv
   const bool fused_head = fused_bwd && c.n_layers >= 1 && nh == 2 && c.head_hidden[0] == 256 && c.head_hidden[1] == 256 &&
-                          !c.max_pool && getenv("V4L_NO_FUSED_HEAD_BWD") == nullptr;
-  const bool fused_tail = fused_bwd && c.n_layers >= 1 && ne == 2 && c.enc_hidden[0] == 256 && c.enc_hidden[1] == 256 &&
-                          getenv("V4L_NO_FUSED_TAIL_BWD") == nullptr;
+                          !c.max_pool;
+  const bool fused_tail = fused_bwd && c.n_layers >= 1 && ne == 2 && c.enc_hidden[0] == 256 && c.enc_hidden[1] == 256;
   // vision-only Transformer on the wave-per-sample kernels (17-row stride, dummy row 0: csrc/wps.h); the forward took the same path
   const bool vis_wps = vis && wps_vis();
   if (fused_head || vis_wps) {  // only the three weight-grads are registered here
@@ -1875,7 +1869,6 @@ int v4l_net::backward_t(const float* state, const T* image, const int* rowidx, i
     static bool attr_done = false;
     static int spw = 4;  // samples per block: 4 (80 MFMA rows, 1 block per CU) or 2 (48 rows, 2 blocks per CU): measured equal
     if (!attr_done) {
-      if (const char* e = getenv("V4L_LAYER_BWD_SPW")) spw = atoi(e) == 2 ? 2 : 4;
       const void* f4[5] = {reinterpret_cast<const void*>(&bwd_layer_kernel<T, 4, false, false, 1>),
                            reinterpret_cast<const void*>(&bwd_layer_kernel<T, 4, true, false, 1>),
                            reinterpret_cast<const void*>(&bwd_layer_kernel<T, 4, false, true, 1>),
@@ -2071,8 +2064,9 @@ static bool actor_fusable(const v4l_actor* a) {
     return c.kind == V4L_NET_LOCO && c.n_enc_hidden == 2 && c.enc_hidden[0] == 256 && c.enc_hidden[1] == 256 && trunk &&
            c.state_dim <= 128;
   };
-  return ok(p) && ok(v) && !p.max_pool && !v.max_pool && !p.token_norm && !v.token_norm && !p.pytorch_encoder && !v.pytorch_encoder && p.n_layers == 2 && v.n_layers == 2 && a->E <= 64 && a->pf->head.size() == 3 &&
-         a->pf->head[0].pkf >= 0 && a->vf->head[0].pkf >= 0 && getenv("V4L_NO_FUSED_ACTOR") == nullptr;
+  // (max_pool: a flag of rollout_stack_kernel's pooling — the stack itself is the same)
+  return ok(p) && ok(v) && !p.token_norm && !v.token_norm && !p.pytorch_encoder && !v.pytorch_encoder && p.n_layers == 2 && v.n_layers == 2 && a->E <= 64 && a->pf->head.size() == 3 &&
+         a->pf->head[0].pkf >= 0 && a->vf->head[0].pkf >= 0;
 }
 
 // NatureCNN fuse nets of the shipped shape: one launch per env step (rollout_cnn_kernel)
@@ -2083,7 +2077,7 @@ static bool actor_fusable_cnn(const v4l_actor* a) {
            c.n_head_hidden == 2 && c.head_hidden[0] == 256 && c.head_hidden[1] == 256 && c.visual_dim == 256 &&
            c.state_dim <= 128 && c.in_channels == 4 && c.img_hw == 64;
   };
-  return ok(p) && ok(v) && getenv("V4L_NO_FUSED_ACTOR") == nullptr;
+  return ok(p) && ok(v);
 }
 template <typename T>
 static int run_actor_fused_cnn(v4l_actor* a, const float* obs, const float* eps, float* state_roll, void* image_roll,
@@ -2143,8 +2137,7 @@ static bool actor_dense_cnn(const v4l_actor* a) {
     return shape && c.kind == V4L_NET_CNN_VIS;
   };
   return ok(p) && ok(v) && a->E <= 64 && a->pf->conv[0].pkf >= 0 && a->pf->head[0].pkf >= 0 && a->vf->head[0].pkf >= 0 &&
-         (p.kind == V4L_NET_CNN_VIS || a->pf->enc[0].Kp == 128) && getenv("V4L_NO_FUSED_ACTOR") == nullptr &&
-         getenv("V4L_ROLLOUT_CNN_OLD") == nullptr;
+         (p.kind == V4L_NET_CNN_VIS || a->pf->enc[0].Kp == 128);
 }
 // rollout_encoder2_kernel<MODE> on the step's observation: fp32 rows [E][S + C*H*W], or — v4l_actor_step_split — fp32 proprio
 // rows [E][S] + bf16 depth stacks (a->img16)
@@ -2287,7 +2280,7 @@ static int run_actor_dense_cnn(v4l_actor* a, const float* obs, const float* eps,
 static bool actor_mlp2(const v4l_actor* a) {
   const v4l_net_cfg& p = a->pf->cfg;
   return p.compute == V4L_BF16 && a->E <= 64 && p.out_dim <= 16 && a->pf->enc[0].Kp == 128 && a->pf->enc[0].pkf >= 0 &&
-         a->pf->head[0].pkf >= 0 && a->vf->head[0].pkf >= 0 && getenv("V4L_ROLLOUT_MLP_OLD") == nullptr;
+         a->pf->head[0].pkf >= 0 && a->vf->head[0].pkf >= 0;
 }
 static int run_actor_mlp2(v4l_actor* a, const float* obs, const float* eps, float* state_roll, float* acts_roll,
                           float* values_roll, float* logp_roll, float* action, float* mean, float* stdv, float* ent, float* value,
@@ -2336,7 +2329,7 @@ static bool actor_fusable_mlp(const v4l_actor* a) {
     return c.kind == V4L_NET_MLP && c.n_enc_hidden == 2 && c.enc_hidden[0] == 256 && c.enc_hidden[1] == 256 &&
            c.n_head_hidden == 2 && c.head_hidden[0] == 256 && c.head_hidden[1] == 256 && c.state_dim <= 128;
   };
-  return ok(p) && ok(v) && getenv("V4L_NO_FUSED_ACTOR") == nullptr;
+  return ok(p) && ok(v);
 }
 template <typename T>
 static int run_actor_fused_mlp(v4l_actor* a, const float* obs, const float* eps, float* state_roll, float* acts_roll,
@@ -2412,7 +2405,6 @@ static int run_actor_fused(v4l_actor* a, const float* obs, const float* eps, flo
   en.S = pf->cfg.state_dim; en.Sp = pf->Sp;
   float* x0 = ws_pf + Lp.x[0];
   g_op = "encoder";
-  static const bool enc2 = getenv("V4L_ROLLOUT_ENC_OLD") == nullptr;
   if (vis) {  // 16 depth tokens, no proprio blocks (actor_fusable: bf16 only)
     const __bf16* pb = (const __bf16*)pf->packed;
     InfEncFrag ef;
@@ -2423,7 +2415,7 @@ static int run_actor_fused(v4l_actor* a, const float* obs, const float* eps, flo
     if (int rc = launch_encoder2<ENC_TOK16>(a, s, 2.0 * E * 3678208.0, dim3(E), obs, E, ef, state_roll, (__bf16*)image_roll, x0,
                                             (__bf16*)nullptr, (__bf16*)nullptr))
       return rc;
-  } else if (enc2 && sizeof(T) == 2 && pf->enc.size() == 2 && pf->enc[0].Kp == 128 && pf->conv[0].pkf >= 0) {
+  } else if (sizeof(T) == 2 && pf->enc.size() == 2 && pf->enc[0].Kp == 128 && pf->conv[0].pkf >= 0) {
     const __bf16* pb = (const __bf16*)pf->packed;
     InfEncFrag ef;
     ef.w1 = pb + pf->conv[0].pkf; ef.w2 = pb + pf->conv[1].pkf; ef.w3 = pb + pf->conv[2].pkf; ef.wup = pb + pf->upconv.pkf;
@@ -2457,7 +2449,7 @@ static int run_actor_fused(v4l_actor* a, const float* obs, const float* eps, flo
     h.w0 = base + net->head[0].pk; h.w1 = base + net->head[1].pk; h.w2 = base + net->head[2].pk;
     if (stack) { h.w0 = base + net->head[0].pkf; h.w1 = base + net->head[1].pkf; h.w2 = base + net->head[2].pkf; }
     h.b0 = net->p[net->head[0].b]; h.b1 = net->p[net->head[1].b]; h.b2 = net->p[net->head[2].b];
-    h.out = out; h.nout = net->cfg.out_dim;
+    h.out = out; h.nout = net->cfg.out_dim; h.max_pool = net->cfg.max_pool;
   };
   auto finish = [&]() {
     head(hd.n[0], pf, pk, ws_pf + Lp.out);
@@ -2479,9 +2471,10 @@ static int run_actor_fused(v4l_actor* a, const float* obs, const float* eps, flo
       fill(stk.l[l].n[1], vf, vk, vf->layers[l], l == 0 ? x0 : ws_vf + Lv.x[l], ws_vf + Lv.x[l + 1]);
     }
     finish();
-    static const int warm = getenv("V4L_ROLLOUT_WARM") ? atoi(getenv("V4L_ROLLOUT_WARM")) : 0;  // L2 warm-up touches (measured: +-0)
-    // one net per XCD half (see the kernel): V4L_ROLLOUT_XCD=0 keeps the (E, 2) grid, where every XCD's L2 serves both nets
-    static const int xcd = getenv("V4L_ROLLOUT_XCD") ? atoi(getenv("V4L_ROLLOUT_XCD")) : 1;
+    constexpr int warm = 0;  // L2 warm-up touches at kernel entry: measured +-0 (round 2), compiled out of the launch
+    // one net per XCD half (see the kernel; the (E, 2) grid, where every XCD's L2 serves both nets, moved 6.1 MB of HBM traffic per
+    // launch instead of 3.65 — round 4's A/B)
+    constexpr int xcd = 1;
     const dim3 grid = xcd ? dim3(2 * round_up(E, 4)) : dim3(E, 2);
     if (vis)
       V4L_KLAUNCH("rollout_layers_head", 2.0 * 2 * E * (nl * 872576.0 + 99840.0), s, (rollout_stack_kernel<T, 2, 16>), grid,
@@ -3099,7 +3092,7 @@ static bool actor_takes_split(const v4l_actor* a, int shared_encoder) {
   if (actor_fusable_cnn(a) && pf->enc[0].Kp <= 128) return false;  // the per-sample rollout_cnn_kernel reads fp32 rows
   if (!actor_fusable(a)) return false;
   if (pf->cfg.kind == V4L_NET_LOCO_VIS) return true;
-  return getenv("V4L_ROLLOUT_ENC_OLD") == nullptr && pf->enc.size() == 2 && pf->enc[0].Kp == 128 && pf->conv[0].pkf >= 0;
+  return pf->enc.size() == 2 && pf->enc[0].Kp == 128 && pf->conv[0].pkf >= 0;
 }
 int v4l_actor_split_supported(const v4l_actor* a, int shared_encoder) {
   return (a && a->bound && actor_takes_split(a, shared_encoder)) ? 1 : 0;
@@ -3270,7 +3263,7 @@ static int adam_step(v4l_trainer* tr, v4l_net* net, float* g, float* m, float* v
   g_op = "optim";
   // The gradient's sum of squares: on one GPU the backward's wgrad_reduce launch already left it, one partial per block
   // (plus log sigma's gradient, which the loss kernel writes itself); after an all-reduce the buffer is summed again.
-  static const bool sq_from_reduce = getenv("V4L_NO_SQ_FROM_REDUCE") == nullptr;
+  constexpr bool sq_from_reduce = true;
   // (only for the buffer the last backward pass of this net wrote, and only once: a host that drives the phases itself and
   // runs another v4l_net_backward — or hands over another buffer — between grads and step gets the summed-again norm)
   if (sq_from_reduce && tr->comm == nullptr && hp->world_size == 1 && net->red_blocks > 0 && net->red_blocks <= ADAM_MAX_PARTS &&
@@ -3433,7 +3426,12 @@ int v4l_sync_grads(v4l_trainer* tr, int which, void* stream) {
   g_op = "allreduce";
   hipLaunchKernelGGL(bucket_tail_kernel, dim3(1), dim3(64), 0, s, st, tail, which, 1, 1.f / (float)tr->comm_world);
   V4L_LAUNCH_CHECK();
-  V4L_RCCL_CHECK(g_rccl.AllReduce(g, g, (size_t)net->total_params + V4L_BUCKET_TAIL, /*ncclFloat32*/ 7, /*ncclSum*/ 0, tr->comm, s));
+  {
+    // (HIP events around the collective on its own stream when the built-in profiler is on: bench.py reports the measured time of
+    // one all-reduce next to DESIGN.md section 6's cost model)
+    v4l::ProfGuard pg(which ? "allreduce_vf" : "allreduce_pf", 0.0, s);
+    V4L_RCCL_CHECK(g_rccl.AllReduce(g, g, (size_t)net->total_params + V4L_BUCKET_TAIL, /*ncclFloat32*/ 7, /*ncclSum*/ 0, tr->comm, s));
+  }
   hipLaunchKernelGGL(bucket_tail_kernel, dim3(1), dim3(64), 0, s, st, tail, which, 0, 1.f);
   V4L_LAUNCH_CHECK();
   return 0;

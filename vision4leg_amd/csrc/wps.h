@@ -51,6 +51,13 @@ constexpr int WPS_WPB = 4;  // waves = samples per block
 // Diagnostic build switch (tools/probe/build_variant.sh roll): the layer loops of the two stack kernels as run-time loops, i.e.
 // ONE copy of the layer code per kernel instead of NL — tests whether the straight-line 100 KB of wps_layer_bwd_kernel against
 // the 64 KB instruction cache a CU pair shares is what its launch time (and its two process-dependent modes) comes from.
+// Diagnostic build switch (build_variant.sh eu1): tell the compiler that ONE wave per SIMD is the target occupancy of the two
+// stack kernels (they need 377 / 512 registers anyway), so its scheduler stops trading latency hiding for register pressure.
+#ifdef V4L_WPS_EU1
+#define WPS_EU_ATTR __attribute__((amdgpu_waves_per_eu(1, 1)))
+#else
+#define WPS_EU_ATTR
+#endif
 #ifdef V4L_WPS_ROLL_LAYERS
 #define WPS_LAYER_LOOP _Pragma("unroll 1")
 #else
@@ -565,7 +572,7 @@ __device__ __forceinline__ void wps_load_rows(const float* __restrict__ xg, int 
 // stk.l[l].n[0].win points at the layer's fragment-order weight block (PK_FRAGP packs, adjacent); the head packs are the
 // row-major ones of the block-cooperative kernel (the heads run cooperatively: 4 samples = one MFMA row tile).
 template <typename T, bool HEAD, int NL, bool TAPS, bool VIS = false>
-__global__ __launch_bounds__(256) void wps_layer_fwd_kernel(InfLayerStack stk, InfHeadPair hd, int n) {
+__global__ __launch_bounds__(256) WPS_EU_ATTR void wps_layer_fwd_kernel(InfLayerStack stk, InfHeadPair hd, int n) {
   typedef WpsFwdLds<T> LY;
   typedef typename Frag<T>::type frag_t;
   constexpr bool LDSW = LY::LDSW;
@@ -1107,7 +1114,7 @@ __global__ __launch_bounds__(NWAVES * 64) void actor_loss_heads_kernel(ActorArgs
 // layers' weight-grads, from the layer-0 input gradient this kernel writes (stk.l[NL-1].o_dx).
 struct WpsTailExtra { const void* wupt_f; const float* dpool; };  // up-conv's transposed weight as a k-permuted fragment pack
 template <typename T, int NL, bool TAPS, bool VIS = false, bool HEAD_IN = true, bool TOK0_IN = true>
-__global__ __launch_bounds__(256) void wps_layer_bwd_kernel(WpsBwdStack stk, BwdHead hd, BwdTail tl, WpsTailExtra tx, int n) {
+__global__ __launch_bounds__(256) WPS_EU_ATTR void wps_layer_bwd_kernel(WpsBwdStack stk, BwdHead hd, BwdTail tl, WpsTailExtra tx, int n) {
   // VIS (template parameter): see wps_layer_fwd — hd.w0t is then the [128][256] pack whose rows 0..63 are zero (the dummy
   // row's un-pooled gradient is exactly zero), and the TAIL ends after the up-conv data-grad (there is no proprio branch)
   typedef WpsBwdLds<T> LY;

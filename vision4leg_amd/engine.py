@@ -608,7 +608,14 @@ class HipActor:
     fused rollout step, eager launches."""
     return (not self.graph) and bool(self.L.v4l_actor_split_supported(self.h, int(self.shared_encoder)))
 
-  def step_host_split(self, prop_pinned, img16_pinned, deterministic=False, via_copy=None):
+  def split_device_buffers(self):
+    """HBM landing buffers of the pipelined observation hand-over ([E][max(S,1)] float32, [E][C*H*W] bfloat16)."""
+    if getattr(self, "_split_dev", None) is None:
+      self._split_dev = (torch.empty(self.E, max(self.pf.state_dim, 1), dtype=torch.float32, device=self.device),
+                         torch.empty(self.E, self.pf.img_elems, dtype=torch.bfloat16, device=self.device))
+    return self._split_dev
+
+  def step_host_split(self, prop_pinned, img16_pinned, deterministic=False, via_copy=None, on_device=False):
     """step_host with the observation split: `prop_pinned` [E][S] float32 (None when the net has no proprio input) and
     `img16_pinned` [E][C*H*W] bfloat16, both PINNED host tensors the rollout kernels read in place — the depth stack crosses
     PCIe in the type the kernels round it to anyway (half the bytes of fp32 rows; same results bit for bit). Returns the [E][A]
@@ -620,11 +627,14 @@ class HipActor:
     if self.graph:
       raise RuntimeError("vision4leg_amd: step_host_split drives eager launches (construct the actor with graph=False)")
     S = self.pf.state_dim
-    ok = (img16_pinned.is_pinned() and img16_pinned.dtype == torch.bfloat16 and img16_pinned.is_contiguous()
+    # on_device: the caller already moved the rows into split_device_buffers() on this stream (the collector's pipelined
+    # hand-over: cast a row chunk, start its DMA, cast the next chunk under it) — same kernels, reading HBM
+    there = (lambda t: t.is_cuda) if on_device else (lambda t: t.is_pinned())
+    ok = (there(img16_pinned) and img16_pinned.dtype == torch.bfloat16 and img16_pinned.is_contiguous()
           and tuple(img16_pinned.shape) == (self.E, self.pf.img_elems))
     if S:
-      ok = ok and (prop_pinned is not None and prop_pinned.is_pinned() and prop_pinned.dtype == torch.float32
-                   and prop_pinned.is_contiguous() and tuple(prop_pinned.shape) == (self.E, S))
+      ok = ok and (prop_pinned is not None and there(prop_pinned) and prop_pinned.dtype == torch.float32
+                   and prop_pinned.is_contiguous() and tuple(prop_pinned.shape) == (self.E, max(S, 1) if on_device else S))
     if not ok:
       raise RuntimeError("vision4leg_amd: step_host_split needs pinned, contiguous [E][S] float32 and [E][C*H*W] bfloat16 host tensors")
     if getattr(self, "_act_host", None) is None:
@@ -648,12 +658,9 @@ class HipActor:
     if self.own:
       self.seek(0)
     if via_copy is None:
-      via_copy = os.environ.get("V4L_SPLIT_VIA_COPY", "0") != "0"
+      via_copy = (not on_device) and os.environ.get("V4L_SPLIT_VIA_COPY", "0") == "1"
     if via_copy:
-      if getattr(self, "_split_dev", None) is None:
-        self._split_dev = (torch.empty(self.E, max(S, 1), dtype=torch.float32, device=self.device),
-                           torch.empty(self.E, self.pf.img_elems, dtype=torch.bfloat16, device=self.device))
-      dprop, dimg = self._split_dev
+      dprop, dimg = self.split_device_buffers()
       if S:
         dprop.copy_(prop_pinned, non_blocking=True)
       dimg.copy_(img16_pinned, non_blocking=True)

@@ -57,9 +57,12 @@ class RolloutActor:
     def split_supported(self):
         return self._actor.split_supported()
 
-    def step_host_split(self, prop_pinned, img16_pinned, deterministic=False):
+    def step_host_split(self, prop_pinned, img16_pinned, deterministic=False, on_device=False):
         """step_host with the depth stack handed over in bfloat16 (see HipActor.step_host_split): -> numpy action [E][A]."""
-        return self._actor.step_host_split(prop_pinned, img16_pinned, deterministic)
+        return self._actor.step_host_split(prop_pinned, img16_pinned, deterministic, on_device=on_device)
+
+    def split_device_buffers(self):
+        return self._actor.split_device_buffers()
 
     def eval_act(self, x):
         """`pf.eval_act(x)` (policies/continuous_policy.py:78-83) on the fused step: the policy mean as a numpy array,
