@@ -69,5 +69,9 @@ full)  # the whole GPU suite + the default bench line (what the driver runs at r
   cp $O/parity.json $O/r5_parity.json 2>/dev/null
   python bench.py > $O/r5_bench_full.json 2> $O/r5_bench_full.err; tail -c 600 $O/r5_bench_full.json
   ;;
+e)  # round 5, session E: the collector's hand-over variants (cast included) and fresh phase stamps of the rollout step kernels
+  python tools/probe/collector_pipe.py > $O/r5e_collector_pipe.txt 2> $O/r5e_collector_pipe.err; cat $O/r5e_collector_pipe.txt
+  python tools/probe/stamps_rollout.py > $O/r5e_stamps_rollout.txt 2>&1; tail -32 $O/r5e_stamps_rollout.txt
+  ;;
 *) echo "unknown session $S"; exit 2 ;;
 esac

@@ -72,5 +72,10 @@ print("# E = %d envs, %d cast threads; one env step = float64 rows [E][%d] -> [E
 bench("host cast alone (f64 -> f32 proprio | bf16 depth, pinned)", cast_only)
 bench("step on rows already in HBM (2 launches + action D2H + synchronise)", step_resident)
 bench("cast, then kernels read the pinned rows in place over PCIe (round 4)", inplace)
-for c in (1, 2, 4, 8):
+if actor._actor._poll is not None:
+    actor._actor._poll = not actor._actor._poll
+    bench("  the same with V4L_STEP_POLL=%d" % int(actor._actor._poll), inplace)
+    bench("  step on rows already in HBM, V4L_STEP_POLL=%d" % int(actor._actor._poll), step_resident)
+    actor._actor._poll = not actor._actor._poll
+for c in (1, 2):
     bench("cast -> DMA pipeline, %d chunk%s, kernels read HBM" % (c, "" if c == 1 else "s"), piped(c))

@@ -2,7 +2,7 @@
 needs the diagnostic build (tools/probe/build_timing.sh)."""
 import os, sys, ctypes as C
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-os.environ["V4L_LIB"] = os.path.join(ROOT, "tools/probe/libv4l_timing.so")
+os.environ.setdefault("V4L_LIB", os.path.join(ROOT, "vision4leg_amd/libv4l_hip_timing.so"))  # tools/probe/build_variant.sh timing
 os.environ["V4L_ROLLOUT_DENSE_SPLIT"] = "1"
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np, torch, util

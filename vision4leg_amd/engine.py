@@ -599,9 +599,33 @@ class HipActor:
       self._eps_zero = True
     if self.own:
       self.seek(0)
+    self._arm_action()
     check(self.L.v4l_actor_step(self.h, *args, _stream()), "v4l_actor_step")
+    return self._await_action()
+
+  # ---- completion of a host step: the policy blocks write the [E][A] action straight into pinned host memory, so the host can
+  # watch the action ARRIVE instead of asking the runtime for a stream synchronise (whose wake-up costs 20-50 us on ROCm 7.2:
+  # tools/probe/collector_pipe.py). The buffer is armed with NaN before the launch; the step is complete for the host when no NaN
+  # is left. A policy that really produces NaN never disarms it: after POLL_SPINS looks the call falls back to the synchronise and
+  # returns what is there (the collector's non-finite check then raises, as it always did). V4L_STEP_POLL=0: always synchronise.
+  POLL_SPINS = 4000
+
+  def _arm_action(self):
+    if getattr(self, "_act_np", None) is None or self._act_np_of is not self._act_host:
+      self._act_np, self._act_np_of = self._act_host.numpy(), self._act_host
+      self._poll = os.environ.get("V4L_STEP_POLL", "1") != "0"
+    if self._poll:
+      self._act_np.fill(np.nan)
+
+  def _await_action(self):
+    a = self._act_np
+    if self._poll:
+      isnan = np.isnan
+      for _ in range(self.POLL_SPINS):
+        if not isnan(a).any():
+          return a
     torch.cuda.current_stream(self.device).synchronize()
-    return self._act_host.numpy()
+    return a
 
   def split_supported(self):
     """True when this actor's step can take the observation split (v4l_actor_step_split): bf16 compute, an image net on the
@@ -665,11 +689,11 @@ class HipActor:
         dprop.copy_(prop_pinned, non_blocking=True)
       dimg.copy_(img16_pinned, non_blocking=True)
       prop_pinned, img16_pinned = dprop, dimg
+    self._arm_action()
     check(self.L.v4l_actor_step_split(self.h, C.c_void_p(prop_pinned.data_ptr() if S else 0), C.c_void_p(img16_pinned.data_ptr()),
                                       eps, a[2], a[3], a[4], a[5], a[6], C.c_void_p(self._act_host.data_ptr()), a[8], a[9], a[10],
                                       a[11], a[12], _stream()), "v4l_actor_step_split")
-    torch.cuda.current_stream(self.device).synchronize()
-    return self._act_host.numpy()
+    return self._await_action()
 
   def _step(self, obs, deterministic=False):
     self.pf.pack_if_needed(fast=True)

@@ -72,9 +72,10 @@ class VecOnPolicyCollector:
         self._pins = None
         self._split_pins = None
         self._split = None  # decided at the first fast-path step: does the actor take the observation split (bf16 depth rows)?
-        # V4L_COLLECT_PIPE=<chunks>: the split hand-over as a cast -> DMA pipeline over that many row chunks (0 = the kernels read
-        # the pinned rows in place; measured in profiles/r5_collector_handover.txt)
-        self._pipe_chunks = max(0, int(os.environ.get("V4L_COLLECT_PIPE", "0")))
+        # (the hand-over as a cast -> DMA pipeline — cast a row chunk, start its asynchronous copy, cast the next chunk under it,
+        # kernels read HBM — was measured in round 5: 99 / 104 / 141 us per env step for 1 / 2 / 4 chunks against 87 for the
+        # in-place read, every asynchronous copy costs ~15 us on this runtime; tools/probe/collector_pipe.py,
+        # profiles/r5_collector_handover.txt. Not kept in the collector.)
         # threads of the per-step fp64 -> fp32 host cast (torch's intra-op pool; the env workers own the other cores). The count
         # is scoped to train_one_epoch (set on entry, put back on exit, also when a step raises): evaluation, logging and the
         # user's own torch CPU code between epochs keep the process's setting. V4L_CAST_THREADS overrides the count (1 = never
@@ -150,32 +151,6 @@ class VecOnPolicyCollector:
         img.copy_(src[:, S:])
         return prop, img
 
-    def _step_split_pipelined(self, actor, rows, chunks):
-        """The observation hand-over as cast -> DMA pipeline: the proprio block and then `chunks` row
-        chunks of the depth stack are cast into pinned memory and each chunk's asynchronous copy to HBM is started before the
-        next chunk is cast, so the host cast runs under the DMA; the two rollout kernels then read HBM. Same values bit for bit
-        as the in-place read (the same pinned bytes reach the same kernels)."""
-        rows = np.asarray(rows)
-        S = self.pf.hip.state_dim
-        E, D = rows.shape
-        if self._split_pins is None or self._split_pins[0][1].shape != (E, D - S):
-            mk = lambda: (torch.empty(E, max(S, 1), dtype=torch.float32).pin_memory(),
-                          torch.empty(E, D - S, dtype=torch.bfloat16).pin_memory())
-            self._split_pins, self._split_i = [mk(), mk()], 0
-        prop, img = self._split_pins[self._split_i]
-        self._split_i ^= 1
-        dprop, dimg = actor.split_device_buffers()
-        src = torch.from_numpy(rows)
-        if S:
-            prop[:, :S].copy_(src[:, :S])
-            dprop.copy_(prop, non_blocking=True)
-        step = -(-E // chunks)
-        for a in range(0, E, step):
-            b = min(E, a + step)
-            img[a:b].copy_(src[a:b, S:])
-            dimg[a:b].copy_(img[a:b], non_blocking=True)
-        return actor.step_host_split(dprop if S else None, dimg, on_device=True)
-
     def _ensure_actor(self):
         if self._actor is None:
             from ..policies import RolloutActor
@@ -199,9 +174,7 @@ class VecOnPolicyCollector:
                 # pinned staging buffer in place and write the [E][A] action into pinned host memory — no copy launches
                 if self._split is None:
                     self._split = os.environ.get("V4L_COLLECT_SPLIT", "1") != "0" and actor.split_supported()
-                if self._split and self._pipe_chunks:
-                    acts = np.array(self._step_split_pipelined(actor, self.current_ob, self._pipe_chunks), dtype=np.float32, copy=True)
-                elif self._split:  # bf16 compute: the depth stack goes over as bf16 (half the PCIe bytes, same numbers)
+                if self._split:  # bf16 compute: the depth stack goes over as bf16 (half the PCIe bytes, same numbers)
                     acts = np.array(actor.step_host_split(*self._upload_split(self.current_ob)), dtype=np.float32, copy=True)
                 else:
                     acts = np.array(actor.step_host(self._upload(self.current_ob, host_only=True)), dtype=np.float32, copy=True)
