@@ -73,5 +73,9 @@ e)  # round 5, session E: the collector's hand-over variants (cast included) and
   python tools/probe/collector_pipe.py > $O/r5e_collector_pipe.txt 2> $O/r5e_collector_pipe.err; cat $O/r5e_collector_pipe.txt
   python tools/probe/stamps_rollout.py > $O/r5e_stamps_rollout.txt 2>&1; tail -32 $O/r5e_stamps_rollout.txt
   ;;
+f)  # round 5, session F: what the padding token tile costs (timing-only one-tile build: WRONG results, never shipped)
+  bench_ab r5f 3 "base=" "onetile=V4L_LIB=$REPO/vision4leg_amd/libv4l_hip_onetile.so"
+  for v in base onetile; do for i in 1 2 3; do printf "%s %d: " $v $i; grep -E "wps_layer|wps_wgrad" $O/r5f_bd_${v}_$i.txt | awk '{printf "%s=%.1f ", $1, $4}'; echo; done; done
+  ;;
 *) echo "unknown session $S"; exit 2 ;;
 esac

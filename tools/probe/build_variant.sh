@@ -2,6 +2,7 @@
 # Diagnostic variant builds of the library (never the shipped one): tools/probe/build_variant.sh <name> [extra hipcc flags...]
 #   roll   -DV4L_WPS_ROLL_LAYERS   layer loops of the wave-per-sample stack kernels as run-time loops (code size / I-cache probe)
 #   timing -DV4L_INFER_TIMING      clock64 phase stamps
+#   onetile -DV4L_WPS_PROBE_ONE_TILE  TIMING ONLY, wrong results: the layer functions walk one token tile (what the padding tile costs)
 #   eu1    -DV4L_WPS_EU1           amdgpu_waves_per_eu(1,1) on the wave-per-sample stack kernels
 #   ilp    -mllvm -amdgpu-sched-strategy=max-ilp ; bias0  -mllvm -amdgpu-schedule-metric-bias=0   (whole library)
 # -> vision4leg_amd/libv4l_hip_<name>.so, selected at run time with V4L_LIB=<path>
@@ -12,6 +13,7 @@ case $name in
   roll) flags="-DV4L_WPS_ROLL_LAYERS" ;;
   timing) flags="-DV4L_INFER_TIMING" ;;
   eu1) flags="-DV4L_WPS_EU1" ;;
+  onetile) flags="-DV4L_WPS_PROBE_ONE_TILE" ;;
   ilp) flags="-mllvm -amdgpu-sched-strategy=max-ilp" ;;
   bias0) flags="-mllvm -amdgpu-schedule-metric-bias=0" ;;
   *) flags="" ;;

@@ -58,6 +58,17 @@ constexpr int WPS_WPB = 4;  // waves = samples per block
 #else
 #define WPS_EU_ATTR
 #endif
+// Timing-only probe build (build_variant.sh onetile; results are WRONG, never shipped): the layer functions walk ONE token tile
+// instead of two — every MFMA, epilogue and softmax / LayerNorm pass of the padding tile (token 16 + 15 empty rows) is compiled
+// out. What is left is the upper bound of what ANY scheme that shares the 17th tokens' tile between samples could gain (VERDICT
+// r4 item 1a), before its own exchange costs.
+#ifdef V4L_WPS_PROBE_ONE_TILE
+#define WPS_NMT 1
+#define WPS_Z = {}
+#else
+#define WPS_NMT 2
+#define WPS_Z
+#endif
 #ifdef V4L_WPS_ROLL_LAYERS
 #define WPS_LAYER_LOOP _Pragma("unroll 1")
 #else
@@ -136,7 +147,7 @@ __device__ __forceinline__ void wps_gemm_t(f32x4 (&acc)[2], const T* W, int tile
   for (int ks = 0; ks < KS; ++ks) {
     const typename Frag<T>::type fw = wps_w<T, LDSW>(W, tile * KS + ks, lane);
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt) mma_k32(acc[mt], fw, xa[mt][ks]);
+    for (int mt = 0; mt < WPS_NMT; ++mt) mma_k32(acc[mt], fw, xa[mt][ks]);
   }
 }
 // F-layout GEMM step: acc[mt] (tokens 16 mt + 4g + r of feature 16 tile + fr) += x . W[tile]
@@ -146,7 +157,7 @@ __device__ __forceinline__ void wps_gemm_f(f32x4 (&acc)[2], const T* W, int tile
   for (int ks = 0; ks < KS; ++ks) {
     const typename Frag<T>::type fw = wps_w<T, LDSW>(W, tile * KS + ks, lane);
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt) mma_k32(acc[mt], xa[mt][ks], fw);
+    for (int mt = 0; mt < WPS_NMT; ++mt) mma_k32(acc[mt], xa[mt][ks], fw);
   }
 }
 template <bool VIS> __device__ __forceinline__ bool wps_key_ok(int key) { return key < NTOK && (!VIS || key > 0); }
@@ -206,7 +217,7 @@ __device__ __forceinline__ void wps_store_opnd(const WpsOut& o, int pair, const 
 // the centred values (the two-pass form of ln_rows / at::native::layer_norm), eps 1e-5. -> xhat in z, rstd per mt.
 __device__ __forceinline__ void wps_ln(float4 (&z)[2][4], float (&rs)[2]) {
 #pragma unroll
-  for (int mt = 0; mt < 2; ++mt) {
+  for (int mt = 0; mt < WPS_NMT; ++mt) {
     float s = 0.f;
 #pragma unroll
     for (int nt = 0; nt < 4; ++nt) s += (z[mt][nt].x + z[mt][nt].y) + (z[mt][nt].z + z[mt][nt].w);
@@ -227,11 +238,11 @@ __device__ __forceinline__ void wps_ln(float4 (&z)[2][4], float (&rs)[2]) {
 template <typename T> struct WpsKeep {
   typedef typename Frag<T>::type frag_t;
   frag_t ka_f[4], qa_f[4];          // K^T, Q^T: rows = features (tile dt), slots = tokens   (dQ = dS K, dK = dS^T Q)
-  frag_t va[2][2];                  // V: rows = tokens, slots = features                    (dP = dctx V^T)
-  float p[2][2][4];                 // softmax probabilities, fp32: [query tile][key tile][r]
-  float4 xh1[2][4], xh2[2][4];      // normalised rows of the two LayerNorms
-  float rs1[2], rs2[2];
-  unsigned long long fm[2];         // ReLU mask of the FFN activation: bit (hidden tile * 4 + r) of token row mt
+  frag_t va[2][2] WPS_Z;  // V: rows = tokens, slots = features                    (dP = dctx V^T)
+  float p[2][2][4] WPS_Z;  // softmax probabilities, fp32: [query tile][key tile][r]
+  float4 xh1[2][4] WPS_Z, xh2[2][4] WPS_Z;      // normalised rows of the two LayerNorms
+  float rs1[2] WPS_Z, rs2[2] WPS_Z;
+  unsigned long long fm[2] WPS_Z;  // ReLU mask of the FFN activation: bit (hidden tile * 4 + r) of token row mt
 };
 
 // One nn.TransformerEncoderLayer forward of ONE sample by ONE wave. xr: the layer input rows (T layout, rows >= 17 zero).
@@ -253,14 +264,14 @@ __device__ __forceinline__ void wps_layer_fwd(const InfLayer& w, const T* W, con
   const bool live = ok[0];
   (void)sb;
   // ---- layer input as fragments
-  frag_t xa[2][2];
+  frag_t xa[2][2] WPS_Z;
 #pragma unroll
-  for (int mt = 0; mt < 2; ++mt)
+  for (int mt = 0; mt < WPS_NMT; ++mt)
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) xa[mt][ks] = wps_frag<T>(xr[mt][2 * ks], xr[mt][2 * ks + 1]);
   if (TAPS && w.s_xin != nullptr) {
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt)
+    for (int mt = 0; mt < WPS_NMT; ++mt)
       if (ok[mt])
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt)
@@ -271,12 +282,12 @@ __device__ __forceinline__ void wps_layer_fwd(const InfLayer& w, const T* W, con
     for (int ks = 0; ks < 2; ++ks) wps_store_opnd<T>(*wo, WPS_T_XIN / 2 + ks, xa[0][ks], xa[1][ks], E0, E1, lane);
   }
   // ---- in_proj: q | k in T layout (operands of S = Q K^T over the feature index), v in F layout (operand of P V over keys)
-  frag_t qa[2][2], ka[2][2], vt[4];
+  frag_t qa[2][2] WPS_Z, ka[2][2] WPS_Z, vt[4];
 #pragma unroll
   for (int part = 0; part < 2; ++part) {  // 0: q, 1: k
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
-      float4 two[2][2];
+      float4 two[2][2] WPS_Z;
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
         const int tile = part * 4 + 2 * ks + h;
@@ -284,14 +295,14 @@ __device__ __forceinline__ void wps_layer_fwd(const InfLayer& w, const T* W, con
         wps_gemm_t<T, LDSW, 2>(acc, W, tile, xa, lane);
         const float4 bb = *reinterpret_cast<const float4*>(prm + WPS_P_BIN + tile * 16 + qr);
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt) {
+        for (int mt = 0; mt < WPS_NMT; ++mt) {
           two[mt][h] = f4add(acc[mt], bb);
           if (TAPS && w.s_qkv != nullptr && ok[mt])
             st4(w.s_qkv + (row0 + mt * 16 + fr) * 192 + tile * 16 + qr, two[mt][h].x, two[mt][h].y, two[mt][h].z, two[mt][h].w);
         }
       }
 #pragma unroll
-      for (int mt = 0; mt < 2; ++mt) {
+      for (int mt = 0; mt < WPS_NMT; ++mt) {
         if (part == 0) qa[mt][ks] = wps_frag<T>(two[mt][0], two[mt][1]);
         else ka[mt][ks] = wps_frag<T>(two[mt][0], two[mt][1]);
       }
@@ -323,9 +334,9 @@ __device__ __forceinline__ void wps_layer_fwd(const InfLayer& w, const T* W, con
         kp->qa_f[2 * ks + h] = wps_tr<T>(qa[0][ks], qa[1][ks], h ? E1 : E0);
         kp->ka_f[2 * ks + h] = wps_tr<T>(ka[0][ks], ka[1][ks], h ? E1 : E0);
       }
-    float4 vv[2][4];  // V in T layout: token tile mt, feature tile dt
+    float4 vv[2][4] WPS_Z;  // V in T layout: token tile mt, feature tile dt
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt)
+    for (int mt = 0; mt < WPS_NMT; ++mt)
 #pragma unroll
       for (int dt = 0; dt < 4; ++dt) {
         f32x4 t = zero4();
@@ -333,23 +344,23 @@ __device__ __forceinline__ void wps_layer_fwd(const InfLayer& w, const T* W, con
         vv[mt][dt] = f4(t);
       }
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt)
+    for (int mt = 0; mt < WPS_NMT; ++mt)
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) kp->va[mt][ks] = wps_frag<T>(vv[mt][2 * ks], vv[mt][2 * ks + 1]);
   }
   // ---- attention: S^T tiles (lane = query, registers = keys), softmax in registers, P V
-  float4 c[2][4];
+  float4 c[2][4] WPS_Z;
 #pragma unroll
-  for (int qt = 0; qt < 2; ++qt) {
+  for (int qt = 0; qt < WPS_NMT; ++qt) {
     f32x4 s[2] = {zero4(), zero4()};
 #pragma unroll
-    for (int kt = 0; kt < 2; ++kt)
+    for (int kt = 0; kt < WPS_NMT; ++kt)
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) mma_k32(s[kt], ka[kt][ks], qa[qt][ks]);  // s[kt][r] = q[16 qt + fr] . k[16 kt + 4g + r]
-    float pv[2][4];
+    float pv[2][4] WPS_Z;
     float mx = -INFINITY;
 #pragma unroll
-    for (int kt = 0; kt < 2; ++kt)
+    for (int kt = 0; kt < WPS_NMT; ++kt)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         pv[kt][r] = wps_key_ok<VIS>(kt * 16 + qr + r) ? s[kt][r] * 0.125f : -INFINITY;
@@ -358,7 +369,7 @@ __device__ __forceinline__ void wps_layer_fwd(const InfLayer& w, const T* W, con
     mx = xmax(mx);
     float sum = 0.f;
 #pragma unroll
-    for (int kt = 0; kt < 2; ++kt)
+    for (int kt = 0; kt < WPS_NMT; ++kt)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         pv[kt][r] = wps_key_ok<VIS>(kt * 16 + qr + r) ? expf(pv[kt][r] - mx) : 0.f;
@@ -366,7 +377,7 @@ __device__ __forceinline__ void wps_layer_fwd(const InfLayer& w, const T* W, con
       }
     const float inv = 1.f / xsum(sum);
 #pragma unroll
-    for (int kt = 0; kt < 2; ++kt)
+    for (int kt = 0; kt < WPS_NMT; ++kt)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         pv[kt][r] *= inv;
@@ -385,11 +396,11 @@ __device__ __forceinline__ void wps_layer_fwd(const InfLayer& w, const T* W, con
     }
   }
   // ---- out_proj + residual, norm1
-  float4 z[2][4];
+  float4 z[2][4] WPS_Z;
   {
-    frag_t ca[2][2];
+    frag_t ca[2][2] WPS_Z;
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt)
+    for (int mt = 0; mt < WPS_NMT; ++mt)
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) ca[mt][ks] = wps_frag<T>(c[mt][2 * ks], c[mt][2 * ks + 1]);
     if constexpr (KEEP) {
@@ -402,20 +413,20 @@ __device__ __forceinline__ void wps_layer_fwd(const InfLayer& w, const T* W, con
       wps_gemm_t<T, LDSW, 2>(acc, W + WPS_OFF_WO, nt, ca, lane);
       const float4 bb = *reinterpret_cast<const float4*>(prm + WPS_P_BO + nt * 16 + qr);
 #pragma unroll
-      for (int mt = 0; mt < 2; ++mt)
+      for (int mt = 0; mt < WPS_NMT; ++mt)
         z[mt][nt] = float4{xr[mt][nt].x + acc[mt][0] + bb.x, xr[mt][nt].y + acc[mt][1] + bb.y, xr[mt][nt].z + acc[mt][2] + bb.z,
                            xr[mt][nt].w + acc[mt][3] + bb.w};
     }
   }
-  float rs1[2];
+  float rs1[2] WPS_Z;
   wps_ln(z, rs1);
-  float4 x1[2][4];
+  float4 x1[2][4] WPS_Z;
 #pragma unroll
   for (int nt = 0; nt < 4; ++nt) {
     const float4 gg = *reinterpret_cast<const float4*>(prm + WPS_P_G1 + nt * 16 + qr);
     const float4 be = *reinterpret_cast<const float4*>(prm + WPS_P_BE1 + nt * 16 + qr);
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt) {
+    for (int mt = 0; mt < WPS_NMT; ++mt) {
       const float4 xh = z[mt][nt];
       if constexpr (KEEP) kp->xh1[mt][nt] = xh;
       x1[mt][nt] = float4{fmaf(xh.x, gg.x, be.x), fmaf(xh.y, gg.y, be.y), fmaf(xh.z, gg.z, be.z), fmaf(xh.w, gg.w, be.w)};
@@ -429,29 +440,29 @@ __device__ __forceinline__ void wps_layer_fwd(const InfLayer& w, const T* W, con
   if constexpr (KEEP) { kp->rs1[0] = rs1[0]; kp->rs1[1] = rs1[1]; }
   if (TAPS && w.s_rs1 != nullptr && g == 0) {
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt)
+    for (int mt = 0; mt < WPS_NMT; ++mt)
       if (ok[mt]) w.s_rs1[row0 + mt * 16 + fr] = rs1[mt];
   }
   // ---- FFN, 32 hidden features at a time: h = relu(W1 x1 + b1) is the B fragment of the linear2 step over those features
   {
-    frag_t x1a[2][2];
+    frag_t x1a[2][2] WPS_Z;
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt)
+    for (int mt = 0; mt < WPS_NMT; ++mt)
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) x1a[mt][ks] = wps_frag<T>(x1[mt][2 * ks], x1[mt][2 * ks + 1]);
     if constexpr (KEEP) {
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) wps_store_opnd<T>(*wo, WPS_T_X1 / 2 + ks, x1a[0][ks], x1a[1][ks], E0, E1, lane);
     }
-    f32x4 z2[2][4];
+    f32x4 z2[2][4] WPS_Z;
     unsigned long long fm[2] = {0ull, 0ull};
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt)
+    for (int mt = 0; mt < WPS_NMT; ++mt)
 #pragma unroll
       for (int nt = 0; nt < 4; ++nt) z2[mt][nt] = zero4();
 #pragma unroll
     for (int ch = 0; ch < 8; ++ch) {
-      float4 hh[2][2];
+      float4 hh[2][2] WPS_Z;
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
         const int tile = 2 * ch + h;
@@ -459,7 +470,7 @@ __device__ __forceinline__ void wps_layer_fwd(const InfLayer& w, const T* W, con
         wps_gemm_t<T, LDSW, 2>(acc, W + WPS_OFF_W1, tile, x1a, lane);
         const float4 bb = *reinterpret_cast<const float4*>(prm + WPS_P_B1 + tile * 16 + qr);
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt) {
+        for (int mt = 0; mt < WPS_NMT; ++mt) {
           hh[mt][h] = float4{fmaxf(acc[mt][0] + bb.x, 0.f), fmaxf(acc[mt][1] + bb.y, 0.f), fmaxf(acc[mt][2] + bb.z, 0.f),
                              fmaxf(acc[mt][3] + bb.w, 0.f)};
           if constexpr (KEEP) {
@@ -473,15 +484,15 @@ __device__ __forceinline__ void wps_layer_fwd(const InfLayer& w, const T* W, con
             st4(reinterpret_cast<T*>(w.s_f) + (row0 + mt * 16 + fr) * 256 + tile * 16 + qr, hh[mt][h].x, hh[mt][h].y, hh[mt][h].z, hh[mt][h].w);
         }
       }
-      frag_t fa[2];
+      frag_t fa[2] WPS_Z;
 #pragma unroll
-      for (int mt = 0; mt < 2; ++mt) fa[mt] = wps_frag<T>(hh[mt][0], hh[mt][1]);
+      for (int mt = 0; mt < WPS_NMT; ++mt) fa[mt] = wps_frag<T>(hh[mt][0], hh[mt][1]);
       if constexpr (KEEP) wps_store_opnd<T>(*wo, WPS_T_F / 2 + ch, fa[0], fa[1], E0, E1, lane);
 #pragma unroll
       for (int nt = 0; nt < 4; ++nt) {
         const frag_t fw = wps_w<T, LDSW>(W + WPS_OFF_W2, nt * 8 + ch, lane);
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt) mma_k32(z2[mt][nt], fw, fa[mt]);
+        for (int mt = 0; mt < WPS_NMT; ++mt) mma_k32(z2[mt][nt], fw, fa[mt]);
       }
     }
     if constexpr (KEEP) { kp->fm[0] = fm[0]; kp->fm[1] = fm[1]; }
@@ -489,12 +500,12 @@ __device__ __forceinline__ void wps_layer_fwd(const InfLayer& w, const T* W, con
     for (int nt = 0; nt < 4; ++nt) {
       const float4 bb = *reinterpret_cast<const float4*>(prm + WPS_P_B2 + nt * 16 + qr);
 #pragma unroll
-      for (int mt = 0; mt < 2; ++mt)
+      for (int mt = 0; mt < WPS_NMT; ++mt)
         z[mt][nt] = float4{x1[mt][nt].x + z2[mt][nt][0] + bb.x, x1[mt][nt].y + z2[mt][nt][1] + bb.y, x1[mt][nt].z + z2[mt][nt][2] + bb.z,
                            x1[mt][nt].w + z2[mt][nt][3] + bb.w};
     }
   }
-  float rs2[2];
+  float rs2[2] WPS_Z;
   wps_ln(z, rs2);
   if constexpr (KEEP) { kp->rs2[0] = rs2[0]; kp->rs2[1] = rs2[1]; }
 #pragma unroll
@@ -502,7 +513,7 @@ __device__ __forceinline__ void wps_layer_fwd(const InfLayer& w, const T* W, con
     const float4 gg = *reinterpret_cast<const float4*>(prm + WPS_P_G2 + nt * 16 + qr);
     const float4 be = *reinterpret_cast<const float4*>(prm + WPS_P_BE2 + nt * 16 + qr);
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt) {
+    for (int mt = 0; mt < WPS_NMT; ++mt) {
       const float4 xh = z[mt][nt];
       if constexpr (KEEP) kp->xh2[mt][nt] = xh;
       // rows past the sample's 17th token stay exactly zero: they are the next layer's padding rows
@@ -518,7 +529,7 @@ __device__ __forceinline__ void wps_layer_fwd(const InfLayer& w, const T* W, con
   }
   if (TAPS && w.s_rs2 != nullptr && g == 0) {
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt)
+    for (int mt = 0; mt < WPS_NMT; ++mt)
       if (ok[mt]) w.s_rs2[row0 + mt * 16 + fr] = rs2[mt];
   }
 }
@@ -730,7 +741,7 @@ __device__ __forceinline__ void wps_layer_bwd(const WpsBwdLayer& w, const T* Wt,
       *reinterpret_cast<float4*>(red_b + nt * 16 + qr) = sb;
     }
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt) {
+    for (int mt = 0; mt < WPS_NMT; ++mt) {
       float4 dxh[4];
       float c1 = 0.f, c2 = 0.f;
 #pragma unroll
@@ -753,14 +764,14 @@ __device__ __forceinline__ void wps_layer_bwd(const WpsBwdLayer& w, const T* Wt,
   auto tap_rows = [&](void* dst, int ld, int col0, const float4 (&v)[2]) {  // test tap: 4 features of both row tiles, row-major T
     if (!TAPS || dst == nullptr) return;
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt)
+    for (int mt = 0; mt < WPS_NMT; ++mt)
       if (ok[mt]) st4(reinterpret_cast<T*>(dst) + (row0 + mt * 16 + fr) * ld + col0 + qr, v[mt].x, v[mt].y, v[mt].z, v[mt].w);
   };
   // ---- norm2 backward: dy -> dz2
   ln_bwd(dy, K.xh2, K.rs2, WPS_P_G2, lnred, lnred + TD);
-  frag_t dza[2][2];
+  frag_t dza[2][2] WPS_Z;
 #pragma unroll
-  for (int mt = 0; mt < 2; ++mt)
+  for (int mt = 0; mt < WPS_NMT; ++mt)
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) dza[mt][ks] = wps_frag<T>(dy[mt][2 * ks], dy[mt][2 * ks + 1]);
 #pragma unroll
@@ -768,21 +779,21 @@ __device__ __forceinline__ void wps_layer_bwd(const WpsBwdLayer& w, const T* Wt,
 #pragma unroll
   for (int nt = 0; nt < 4; ++nt) { const float4 v[2] = {dy[0][nt], dy[1][nt]}; tap_rows(w.t_dz2, TD, nt * 16, v); }
   // ---- df = (dz2 W2) o [f > 0], 32 hidden features at a time, each chunk feeding dx1 += df W1
-  f32x4 dx1[2][4];
+  f32x4 dx1[2][4] WPS_Z;
 #pragma unroll
-  for (int mt = 0; mt < 2; ++mt)
+  for (int mt = 0; mt < WPS_NMT; ++mt)
 #pragma unroll
     for (int nt = 0; nt < 4; ++nt) dx1[mt][nt] = zero4();
 #pragma unroll
   for (int ch = 0; ch < 8; ++ch) {
-    float4 dd[2][2];
+    float4 dd[2][2] WPS_Z;
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
       const int tile = 2 * ch + h;
       f32x4 acc[2] = {zero4(), zero4()};
       wps_gemm_t<T, LDSW, 2>(acc, Wt + WPS_OFF_W2, tile, dza, lane);  // W2^T: rows = hidden features, k = the 64 outputs
 #pragma unroll
-      for (int mt = 0; mt < 2; ++mt) {
+      for (int mt = 0; mt < WPS_NMT; ++mt) {
         const unsigned b4 = (unsigned)(K.fm[mt] >> (tile * 4)) & 15u;
         dd[mt][h] = float4{(b4 & 1u) ? acc[mt][0] : 0.f, (b4 & 2u) ? acc[mt][1] : 0.f, (b4 & 4u) ? acc[mt][2] : 0.f,
                            (b4 & 8u) ? acc[mt][3] : 0.f};
@@ -790,27 +801,27 @@ __device__ __forceinline__ void wps_layer_bwd(const WpsBwdLayer& w, const T* Wt,
       const float4 v[2] = {dd[0][h], dd[1][h]};
       tap_rows(w.t_df, 256, tile * 16, v);
     }
-    frag_t dfa[2];
+    frag_t dfa[2] WPS_Z;
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt) dfa[mt] = wps_frag<T>(dd[mt][0], dd[mt][1]);
+    for (int mt = 0; mt < WPS_NMT; ++mt) dfa[mt] = wps_frag<T>(dd[mt][0], dd[mt][1]);
     wps_store_opnd<T>(wo, WPS_T_DF / 2 + ch, dfa[0], dfa[1], E0, E1, lane);
 #pragma unroll
     for (int nt = 0; nt < 4; ++nt) {
       const frag_t fw = wps_w<T, LDSW>(Wt + WPS_OFF_W1, nt * 8 + ch, lane);  // W1^T: rows = the 64 inputs, k = hidden features
 #pragma unroll
-      for (int mt = 0; mt < 2; ++mt) mma_k32(dx1[mt][nt], fw, dfa[mt]);
+      for (int mt = 0; mt < WPS_NMT; ++mt) mma_k32(dx1[mt][nt], fw, dfa[mt]);
     }
   }
-  float4 d1[2][4];
+  float4 d1[2][4] WPS_Z;
 #pragma unroll
-  for (int mt = 0; mt < 2; ++mt)
+  for (int mt = 0; mt < WPS_NMT; ++mt)
 #pragma unroll
     for (int nt = 0; nt < 4; ++nt) d1[mt][nt] = f4add(dx1[mt][nt], dy[mt][nt]);
   // ---- norm1 backward: dx1 -> dz1
   ln_bwd(d1, K.xh1, K.rs1, WPS_P_G1, lnred + 2 * TD, lnred + 3 * TD);
-  frag_t dz1a[2][2];
+  frag_t dz1a[2][2] WPS_Z;
 #pragma unroll
-  for (int mt = 0; mt < 2; ++mt)
+  for (int mt = 0; mt < WPS_NMT; ++mt)
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) dz1a[mt][ks] = wps_frag<T>(d1[mt][2 * ks], d1[mt][2 * ks + 1]);
 #pragma unroll
@@ -818,9 +829,9 @@ __device__ __forceinline__ void wps_layer_bwd(const WpsBwdLayer& w, const T* Wt,
 #pragma unroll
   for (int nt = 0; nt < 4; ++nt) { const float4 v[2] = {d1[0][nt], d1[1][nt]}; tap_rows(w.t_dz1, TD, nt * 16, v); }
   // ---- dctx = dz1 Wo  (an operand of the attention products only: kept rounded to T)
-  frag_t dca[2][2];
+  frag_t dca[2][2] WPS_Z;
   {
-    float4 dc[2][4];
+    float4 dc[2][4] WPS_Z;
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt) {
       f32x4 acc[2] = {zero4(), zero4()};
@@ -829,37 +840,37 @@ __device__ __forceinline__ void wps_layer_bwd(const WpsBwdLayer& w, const T* Wt,
       dc[1][dt] = f4(acc[1]);
     }
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt)
+    for (int mt = 0; mt < WPS_NMT; ++mt)
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) dca[mt][ks] = wps_frag<T>(dc[mt][2 * ks], dc[mt][2 * ks + 1]);
   }
   // ---- attention backward: dP = dctx V^T ; dS = P o (dP - rowsum(P o dP)) ; dV = P^T dctx ; dQ = dS K / 8 ; dK = dS^T Q / 8
-  frag_t dsa[2], pa[2];
+  frag_t dsa[2] WPS_Z, pa[2] WPS_Z;
 #pragma unroll
-  for (int qt = 0; qt < 2; ++qt) {
+  for (int qt = 0; qt < WPS_NMT; ++qt) {
     f32x4 dp[2] = {zero4(), zero4()};
 #pragma unroll
-    for (int kt = 0; kt < 2; ++kt)
+    for (int kt = 0; kt < WPS_NMT; ++kt)
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) mma_k32(dp[kt], K.va[kt][ks], dca[qt][ks]);  // dp[kt][r] = dctx[16 qt + fr] . v[16 kt + 4g + r]
     float rd = 0.f;
 #pragma unroll
-    for (int kt = 0; kt < 2; ++kt)
+    for (int kt = 0; kt < WPS_NMT; ++kt)
 #pragma unroll
       for (int r = 0; r < 4; ++r) rd = fmaf(K.p[qt][kt][r], kt * 16 + qr + r < NTOK ? dp[kt][r] : 0.f, rd);
     rd = xsum(rd);
-    float ds[2][4];
+    float ds[2][4] WPS_Z;
 #pragma unroll
-    for (int kt = 0; kt < 2; ++kt)
+    for (int kt = 0; kt < WPS_NMT; ++kt)
 #pragma unroll
       for (int r = 0; r < 4; ++r) ds[kt][r] = kt * 16 + qr + r < NTOK ? K.p[qt][kt][r] * (dp[kt][r] - rd) : 0.f;
     dsa[qt] = wps_frag<T>(float4{ds[0][0], ds[0][1], ds[0][2], ds[0][3]}, float4{ds[1][0], ds[1][1], ds[1][2], ds[1][3]});
     pa[qt] = wps_frag<T>(float4{K.p[qt][0][0], K.p[qt][0][1], K.p[qt][0][2], K.p[qt][0][3]},
                          float4{K.p[qt][1][0], K.p[qt][1][1], K.p[qt][1][2], K.p[qt][1][3]});
   }
-  frag_t dsT[2], pT[2], dcT[4];
+  frag_t dsT[2] WPS_Z, pT[2] WPS_Z, dcT[4];
 #pragma unroll
-  for (int kt = 0; kt < 2; ++kt) {
+  for (int kt = 0; kt < WPS_NMT; ++kt) {
     dsT[kt] = wps_tr<T>(dsa[0], dsa[1], kt ? E1 : E0);  // rows = keys of tile kt, slots = queries
     pT[kt] = wps_tr<T>(pa[0], pa[1], kt ? E1 : E0);
   }
@@ -867,11 +878,11 @@ __device__ __forceinline__ void wps_layer_bwd(const WpsBwdLayer& w, const T* Wt,
   for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
     for (int h = 0; h < 2; ++h) dcT[2 * ks + h] = wps_tr<T>(dca[0][ks], dca[1][ks], h ? E1 : E0);  // rows = features, slots = queries
-  frag_t dqa[2][6];
+  frag_t dqa[2][6] WPS_Z;
   {
-    float4 dq[2][4], dk[2][4], dv[2][4];
+    float4 dq[2][4] WPS_Z, dk[2][4] WPS_Z, dv[2][4] WPS_Z;
 #pragma unroll
-    for (int tt = 0; tt < 2; ++tt)
+    for (int tt = 0; tt < WPS_NMT; ++tt)
 #pragma unroll
       for (int dt = 0; dt < 4; ++dt) {
         f32x4 a = zero4(), b = zero4(), c = zero4();
@@ -889,7 +900,7 @@ __device__ __forceinline__ void wps_layer_bwd(const WpsBwdLayer& w, const T* Wt,
         }
       }
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt)
+    for (int mt = 0; mt < WPS_NMT; ++mt)
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) {
         dqa[mt][ks] = wps_frag<T>(dq[mt][2 * ks], dq[mt][2 * ks + 1]);
@@ -905,7 +916,7 @@ __device__ __forceinline__ void wps_layer_bwd(const WpsBwdLayer& w, const T* Wt,
     f32x4 acc[2] = {zero4(), zero4()};
     wps_gemm_t<T, LDSW, 6>(acc, Wt, nt, dqa, lane);  // Win^T: rows = the 64 inputs, k = the 192 outputs
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt) dy[mt][nt] = f4add(acc[mt], d1[mt][nt]);
+    for (int mt = 0; mt < WPS_NMT; ++mt) dy[mt][nt] = f4add(acc[mt], d1[mt][nt]);
   }
 }
 
