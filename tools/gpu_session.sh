@@ -77,5 +77,27 @@ f)  # round 5, session F: what the padding token tile costs (timing-only one-til
   bench_ab r5f 3 "base=" "onetile=V4L_LIB=$REPO/vision4leg_amd/libv4l_hip_onetile.so"
   for v in base onetile; do for i in 1 2 3; do printf "%s %d: " $v $i; grep -E "wps_layer|wps_wgrad" $O/r5f_bd_${v}_$i.txt | awk '{printf "%s=%.1f ", $1, $4}'; echo; done; done
   ;;
+evidence)  # the round's records for profiles/: tools/gpu_session.sh evidence <tag, e.g. r5>
+  TAG=${1:-r5}; EV=$O/${TAG}_ev; mkdir -p $EV
+  python bench.py --steps 20 --warmup 5 --breakdown $EV/breakdown.txt > $EV/bench_full.json 2> $EV/bench_full.err
+  ( cd /tmp && export TMPDIR=/tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d "$EV/trace" -- \
+      python $REPO/bench.py --no-cpu-baseline --no-parity > "$EV/bench_traced.json" 2> "$EV/trace.log" )
+  python tools/update_timeline.py $EV/trace $EV/update_timeline.txt > /dev/null
+  python tools/kernel_stats.py $EV/trace "rocprofv3 --kernel-trace of \`python bench.py --no-cpu-baseline --no-parity\` (1 warm-up + 3 timed epochs + 1 profiled rollout + update pass)" > $EV/kernel_stats.txt
+  tools/pmc_pass.sh "$EV/pmc" > "$EV/pmc.log" 2>&1
+  python tools/pmc_traffic.py "$EV/pmc/summary.txt" "$EV/pmc_traffic.json" > /dev/null
+  for w in cnn mlp loco64 loco_vis cnn_vis; do
+    python bench.py --workload $w --steps 10 --warmup 3 --no-cpu-baseline --no-reference-protocol > $EV/bench_$w.json 2> $EV/bench_$w.err
+  done
+  find "$EV" -name "*.csv" -size +1M -delete; find "$EV" -name "*.db" -delete
+  du -sh $EV
+  python - "$EV" <<'PY'
+import json, glob, sys
+for f in sorted(glob.glob(sys.argv[1] + "/bench_*.json")):
+    try:
+        d = json.load(open(f)); print(f.split("/")[-1], d["value"], d["ms_per_step"], d.get("value_incl_transfers_ratio"))
+    except Exception as e: print(f, "ERR", e)
+PY
+  ;;
 *) echo "unknown session $S"; exit 2 ;;
 esac

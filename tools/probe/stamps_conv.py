@@ -1,5 +1,5 @@
 import os, sys, ctypes as C
-os.environ["V4L_LIB"] = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libv4l_timing.so")
+os.environ.setdefault("V4L_LIB", os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "vision4leg_amd/libv4l_hip_timing.so"))  # tools/probe/build_variant.sh timing
 ROOT=os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path.insert(0,ROOT); sys.path.insert(0,os.path.join(ROOT,"tests"))
 import numpy as np, torch, util
 os.environ["V4L_COMPUTE"]="bf16"

@@ -1,5 +1,5 @@
 """Phase stamps (block (0,0), lane 0) of rollout_linear_kernel<32> on the vision-only NatureCNN step (E = 32, split launches);
-needs the diagnostic build (tools/probe/build_timing.sh)."""
+needs the diagnostic build (tools/probe/build_variant.sh timing)."""
 import os, sys, ctypes as C
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 os.environ.setdefault("V4L_LIB", os.path.join(ROOT, "vision4leg_amd/libv4l_hip_timing.so"))  # tools/probe/build_variant.sh timing

@@ -1,4 +1,4 @@
-"""Stage stamps (block 0 = net 0 / tile 0, lane 0) of rollout_dense_kernel; needs the diagnostic build (tools/probe/build_timing.sh).
+"""Stage stamps (block 0 = net 0 / tile 0, lane 0) of rollout_dense_kernel; needs the diagnostic build (tools/probe/build_variant.sh timing).
 usage: python tools/probe/stamps_dense1.py [cnn_vis|cnn_s93] [E]"""
 import os, sys, ctypes as C
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

@@ -1,5 +1,5 @@
 """Phase stamps (s_memtime, block (0,0), thread 0) of the two rollout-step kernels; needs the diagnostic build:
-hipcc ... -DV4L_INFER_TIMING -o tools/probe/libv4l_timing.so (tools/probe/build_timing.sh)."""
+hipcc ... -DV4L_INFER_TIMING (tools/probe/build_variant.sh timing -> vision4leg_amd/libv4l_hip_timing.so)."""
 import os, sys, ctypes as C
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 os.environ.setdefault("V4L_LIB", os.path.join(ROOT, "vision4leg_amd/libv4l_hip_timing.so"))  # tools/probe/build_variant.sh timing

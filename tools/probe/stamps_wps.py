@@ -1,6 +1,6 @@
 import os, sys, ctypes as C
 ROOT=os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-os.environ["V4L_LIB"] = os.path.join(ROOT, "tools/probe", os.environ.get("TIMING_LIB", "libv4l_timing.so"))
+os.environ.setdefault("V4L_LIB", os.path.join(ROOT, "vision4leg_amd", os.environ.get("TIMING_LIB", "libv4l_hip_timing.so")))  # tools/probe/build_variant.sh timing
 sys.path.insert(0,ROOT); sys.path.insert(0,os.path.join(ROOT,"tests"))
 import numpy as np, torch, util
 os.environ["V4L_COMPUTE"]="bf16"
