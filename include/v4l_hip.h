@@ -17,7 +17,7 @@
  *   - all activations/params/grads are fp32; `compute` selects the contraction operand type:
  *     V4L_F32 = exact fp32 MFMA (parity mode), V4L_BF16 = bf16 operands, fp32 accumulate (production).
  *
- * Environment switches read by the library: 18 (round 4: 37 — the ones no test referenced went in round 5, their fast-path value
+ * Environment switches read by the library: 19 (round 4: 37 — the ones no test referenced went in round 5, their fast-path value
  * is now compiled in). Three configure a run, the others are DIAGNOSTIC: every one of them backs a bit-equality / cross-check test
  * under tests/ that compares a fused kernel or a launch schedule against the general one. Read when first needed unless (per call).
  *   run:   V4L_TRACE (launch / graph log on stderr), V4L_RCCL_LIB (RCCL library to dlopen; default librccl.so.1), V4L_ROCTX=1 (roctx
@@ -29,6 +29,8 @@
  *   V4L_NO_DENSE_STACK        the NatureCNN nets' visual projector + head and their data-grads as one gemm_nt_deep launch per
  *                             linear instead of one launch per direction (csrc/dense_stack.h; same bits) (per call)
  *   V4L_NO_FUSED_CONV_BWD     conv-stack backward layer by layer (per call)
+ *   V4L_ACTS_F32              the training encoder saves conv1 / conv2 activations in fp32 even where the fused conv backward would
+ *                             take them in the operand type (round 5; same bits, 19 KB more per sample each way) (per call)
  *   V4L_NO_LAYER_STACK        one launch per transformer layer instead of one per direction (per call)
  *   V4L_NO_WPS_LAYERS         transformer layers on the block-cooperative kernels instead of the wave-per-sample ones (per call)
  *   V4L_LAYER_TAPS            the wave-per-sample layer kernels and the fused conv backward also write every intermediate into

@@ -1277,3 +1277,39 @@ def test_tanh_policy_head(name, device):
     assert torch.allclose(o["mean"], mean[:E], atol=1e-5)
     det = actor.step(obs[:E], deterministic=True)["action"]
     assert torch.allclose(det, torch.tanh(mean[:E]), atol=1e-5)
+
+
+@pytest.mark.parametrize("name", ["loco_s93", "loco_rag", "loco_b1024", "cnn_s93", "cnn_vis", "loco_vis"])
+def test_conv_acts_in_operand_type_same_bits(name, device, monkeypatch):
+    """Round 5 (HBM diet): in the trainer's passes the training encoder writes conv1 / conv2 activations in the operand type and
+    the fused conv backward (bwd_conv_kernel<T, true>, bwd_conv3_wgrad_kernel<T, true>) reads them as such — the type it rounded
+    the fp32 copies to when filing them into LDS anyway (c1: MFMA operand; c2: operand of dW3 and the ReLU mask of conv3').
+    Two PPO updates must leave bit-identical statistics and parameters with the fp32 copies (V4L_ACTS_F32=1)."""
+    case = util.CASES[name]
+    from vision4leg_amd.torchrl.algo import PPO
+    res = {}
+    for variant in ("operand_type", "fp32"):
+        if variant == "fp32":
+            monkeypatch.setenv("V4L_ACTS_F32", "1")
+        else:
+            monkeypatch.delenv("V4L_ACTS_F32", raising=False)
+        pf, vf = _build(case, "bf16", device)
+
+        class Coll: epoch_frames = 1
+        agent = PPO(pf=pf, vf=vf, plr=1e-4, vlr=1e-4, clip_para=0.2, opt_epochs=3, tau=0.95, entropy_coeff=0.005,
+                    collector=Coll(), device=device, batch_size=case["B"])
+        agent.trainer.sync_target()
+        infos = []
+        for u in range(2):
+            b = util.make_batch(case, update=u)
+            infos.append(agent.update({k: b[k] for k in ("obs", "acts", "advs", "estimate_returns", "values")}))
+        torch.cuda.synchronize()
+        res[variant] = (infos, {k: v.detach().cpu().clone() for k, v in pf.state_dict().items()},
+                        {k: v.detach().cpu().clone() for k, v in vf.state_dict().items()})
+    for u in range(2):
+        for k in util.STAT_KEYS:
+            a, b = res["operand_type"][0][u][k], res["fp32"][0][u][k]
+            assert a == b or (np.isnan(a) and np.isnan(b)), (u, k, a, b)
+    for i in (1, 2):
+        for k, v in res["operand_type"][i].items():
+            assert torch.equal(v, res["fp32"][i][k]), k

@@ -787,7 +787,8 @@ struct BwdConv {
   const void* w2d[4];               // conv2 data-grad packs, one per stride-parity class (py,px): [ci 32][(a,b,co) 256]
   const void* image;                // T [slots][4][64][64]
   const int* rowidx;                // minibatch row -> rollout slot, or null
-  const float *c1, *c2;             // [n*225][32], [n*36][64] post-ReLU activations
+  const float *c1, *c2;             // [n*225][32], [n*36][64] post-ReLU activations — fp32, or (kernels instantiated with A16) the
+                                    // same arrays in T: what train_encoder_kernel writes for the trainer's own passes (round 5)
   const float* dc3;                 // [n*16][64] grad w.r.t. conv3's pre-activation (already ReLU-masked)
   float *slab1, *slab2, *slab3;     // [gridDim.x][32][256], [gridDim.x][64][512], [gridDim.x][64][576]
   float *bslab1, *bslab2, *bslab3;  // [gridDim.x][32], [gridDim.x][64], [gridDim.x][64]
@@ -872,8 +873,12 @@ __device__ __forceinline__ void gather_gemm(f32x4 (&acc)[MT][NT], const T* __res
 #else
 #define CONV_STAMP(i)
 #endif
-template <typename T>
+// A16 (bf16 only): a.c1 / a.c2 hold the activations in T — the type this kernel rounds them to when it files them into LDS
+// anyway (c1: MFMA operand; c2: only its sign is used, as the ReLU mask of conv3'), so the results are bit-identical and the
+// launch reads 19 KB less per sample (the training encoder writes 19 KB less).
+template <typename T, bool A16 = false>
 __global__ __launch_bounds__(512) void bwd_conv_kernel(BwdConv a) {
+  static_assert(!A16 || sizeof(T) == 2, "A16: activations saved in the bf16 operand type");
   typedef BwdConvLds<T> LY;
   typedef typename Frag<T>::type frag_t;
   constexpr int NTH = 512;
@@ -914,28 +919,58 @@ __global__ __launch_bounds__(512) void bwd_conv_kernel(BwdConv a) {
   // done by then. 256 + 576 float4 of dc3 / c2: every thread takes c2 chunk tid, waves 4..7 dc3 chunk tid - 256, wave 0 the
   // last 64 c2 chunks; c1: 1800 float4, chunk tid + 512 k.
   constexpr int N4 = 225 * 8, PT = (N4 + NTH - 1) / NTH;
-  float4 hv0 = float4{0.f, 0.f, 0.f, 0.f}, hv1 = hv0, cv[PT];
+  // A16: 16-byte chunks of 8 elements — c2 36 x 64 = 288 chunks (thread t < 288: chunk t), c1 225 x 32 = 900 chunks (t, t + 512)
+  constexpr int N8 = 225 * 4, PT8 = (N8 + NTH - 1) / NTH;
+  typedef typename Frag<T>::type chunk_t;  // 8 elements of T
+  float4 hv0 = float4{0.f, 0.f, 0.f, 0.f}, hv1 = hv0, cv[A16 ? 1 : PT];
+  chunk_t h16 = {}, c16[A16 ? PT8 : 1] = {};
   auto load_next = [&](int sm) {
     const float* g3 = a.dc3 + (int64_t)sm * 16 * 64;
-    const float* g2 = a.c2 + (int64_t)sm * 36 * 64;
-    const float* g1 = a.c1 + (int64_t)sm * 225 * 32;
-    hv0 = *reinterpret_cast<const float4*>(g2 + tid * 4);
-    if (tid >= 256) hv1 = *reinterpret_cast<const float4*>(g3 + (tid - 256) * 4);
-    else if (tid < 64) hv1 = *reinterpret_cast<const float4*>(g2 + (512 + tid) * 4);
+    if constexpr (A16) {
+      const chunk_t* g2 = reinterpret_cast<const chunk_t*>(reinterpret_cast<const T*>(a.c2) + (int64_t)sm * 36 * 64);
+      const chunk_t* g1 = reinterpret_cast<const chunk_t*>(reinterpret_cast<const T*>(a.c1) + (int64_t)sm * 225 * 32);
+      h16 = g2[tid < 288 ? tid : 0];
+      if (tid >= 256) hv1 = *reinterpret_cast<const float4*>(g3 + (tid - 256) * 4);
 #pragma unroll
-    for (int k = 0; k < PT; ++k) {
-      const int i4 = tid + k * NTH;
-      cv[k] = *reinterpret_cast<const float4*>(g1 + (i4 < N4 ? i4 : 0) * 4);
+      for (int k = 0; k < PT8; ++k) {
+        const int i8 = tid + k * NTH;
+        c16[k] = g1[i8 < N8 ? i8 : 0];
+      }
+    } else {
+      const float* g2 = a.c2 + (int64_t)sm * 36 * 64;
+      const float* g1 = a.c1 + (int64_t)sm * 225 * 32;
+      hv0 = *reinterpret_cast<const float4*>(g2 + tid * 4);
+      if (tid >= 256) hv1 = *reinterpret_cast<const float4*>(g3 + (tid - 256) * 4);
+      else if (tid < 64) hv1 = *reinterpret_cast<const float4*>(g2 + (512 + tid) * 4);
+#pragma unroll
+      for (int k = 0; k < PT; ++k) {
+        const int i4 = tid + k * NTH;
+        cv[k] = *reinterpret_cast<const float4*>(g1 + (i4 < N4 ? i4 : 0) * 4);
+      }
     }
   };
   auto store_next = [&]() {
-    *reinterpret_cast<float4*>(sc2 + (tid >> 4) * LY::LF + (tid & 15) * 4) = hv0;
-    if (tid >= 256) st4(sdc3 + ((tid - 256) >> 4) * LY::LT + (tid & 15) * 4, hv1.x, hv1.y, hv1.z, hv1.w);  // dc3: MFMA operand only, kept in T
-    else if (tid < 64) *reinterpret_cast<float4*>(sc2 + (32 + (tid >> 4)) * LY::LF + (tid & 15) * 4) = hv1;
+    if constexpr (A16) {
+      if (tid < 288) {  // c2 chunk t = row t >> 3, columns 8 (t & 7) .. +7, widened to the fp32 mask rows
+        float* d = sc2 + (tid >> 3) * LY::LF + (tid & 7) * 8;
+        *reinterpret_cast<float4*>(d) = float4{(float)h16[0], (float)h16[1], (float)h16[2], (float)h16[3]};
+        *reinterpret_cast<float4*>(d + 4) = float4{(float)h16[4], (float)h16[5], (float)h16[6], (float)h16[7]};
+      }
+      if (tid >= 256) st4(sdc3 + ((tid - 256) >> 4) * LY::LT + (tid & 15) * 4, hv1.x, hv1.y, hv1.z, hv1.w);
 #pragma unroll
-    for (int k = 0; k < PT; ++k) {
-      const int i4 = tid + k * NTH;
-      if (i4 < N4) st4(sc1 + (i4 >> 3) * LY::LC1 + (i4 & 7) * 4, cv[k].x, cv[k].y, cv[k].z, cv[k].w);
+      for (int k = 0; k < PT8; ++k) {
+        const int i8 = tid + k * NTH;
+        if (i8 < N8) *reinterpret_cast<chunk_t*>(sc1 + (i8 >> 2) * LY::LC1 + (i8 & 3) * 8) = c16[k];  // already T: one 16-byte store
+      }
+    } else {
+      *reinterpret_cast<float4*>(sc2 + (tid >> 4) * LY::LF + (tid & 15) * 4) = hv0;
+      if (tid >= 256) st4(sdc3 + ((tid - 256) >> 4) * LY::LT + (tid & 15) * 4, hv1.x, hv1.y, hv1.z, hv1.w);  // dc3: MFMA operand only, kept in T
+      else if (tid < 64) *reinterpret_cast<float4*>(sc2 + (32 + (tid >> 4)) * LY::LF + (tid & 15) * 4) = hv1;
+#pragma unroll
+      for (int k = 0; k < PT; ++k) {
+        const int i4 = tid + k * NTH;
+        if (i4 < N4) st4(sc1 + (i4 >> 3) * LY::LC1 + (i4 & 7) * 4, cv[k].x, cv[k].y, cv[k].z, cv[k].w);
+      }
     }
   };
   {
@@ -1178,7 +1213,7 @@ __global__ __launch_bounds__(512) void bwd_conv_kernel(BwdConv a) {
 
 // dW3 += dc3^T col(c2) (see above): persistent blocks, sample = blockIdx.x, += gridDim.x; wave w owns k-tiles 9w..9w+8 x all
 // four co-tiles, the contraction runs over the 16 output pixels (one zero-padded K=32 MFMA step per sample)
-template <typename T>
+template <typename T, bool A16 = false>
 __global__ __launch_bounds__(256) void bwd_conv3_wgrad_kernel(BwdConv a) {
   typedef typename Frag<T>::type frag_t;
   constexpr int LF = 64 + 4;
@@ -1212,29 +1247,45 @@ __global__ __launch_bounds__(256) void bwd_conv3_wgrad_kernel(BwdConv a) {
   // (thread t: dc3 row t >> 4, columns 4 (t & 15); c2 float4s t, t + 256, t + 512 of the sample's 576)
   const int i2 = tid + 512 < 36 * 16 ? tid + 512 : 0;
   float4 r3 = {0.f, 0.f, 0.f, 0.f}, r2a = r3, r2b = r3, r2c = r3;
-  if ((int)blockIdx.x < a.n) {
-    const float* g3 = a.dc3 + (int64_t)blockIdx.x * 16 * 64;
-    const float* g2 = a.c2 + (int64_t)blockIdx.x * 36 * 64;
+  // A16: c2 in T, 288 chunks of 8 elements: thread t takes chunk t, threads 0..31 also chunk 256 + t
+  typedef typename Frag<T>::type chunk_t;
+  chunk_t q2a = {}, q2b = {};
+  auto fetch = [&](int sm) {
+    const float* g3 = a.dc3 + (int64_t)sm * 16 * 64;
     r3 = *reinterpret_cast<const float4*>(g3 + tid * 4);
-    r2a = *reinterpret_cast<const float4*>(g2 + tid * 4);
-    r2b = *reinterpret_cast<const float4*>(g2 + (tid + 256) * 4);
-    r2c = *reinterpret_cast<const float4*>(g2 + i2 * 4);
-  }
-  for (int smp = blockIdx.x; smp < a.n; smp += gridDim.x) {
-    __syncthreads();  // the previous sample's readers are done
-    *reinterpret_cast<float4*>(sdc3 + (tid >> 4) * LF + (tid & 15) * 4) = r3;
-    *reinterpret_cast<float4*>(sc2 + (tid >> 4) * LF + (tid & 15) * 4) = r2a;
-    *reinterpret_cast<float4*>(sc2 + ((tid + 256) >> 4) * LF + (tid & 15) * 4) = r2b;
-    if (tid + 512 < 36 * 16) *reinterpret_cast<float4*>(sc2 + ((tid + 512) >> 4) * LF + (tid & 15) * 4) = r2c;
-    const int nxt = smp + (int)gridDim.x;
-    if (nxt < a.n) {  // (block-uniform)
-      const float* g3 = a.dc3 + (int64_t)nxt * 16 * 64;
-      const float* g2 = a.c2 + (int64_t)nxt * 36 * 64;
-      r3 = *reinterpret_cast<const float4*>(g3 + tid * 4);
+    if constexpr (A16) {
+      const chunk_t* g2 = reinterpret_cast<const chunk_t*>(reinterpret_cast<const T*>(a.c2) + (int64_t)sm * 36 * 64);
+      q2a = g2[tid];
+      q2b = g2[tid < 32 ? 256 + tid : 0];
+    } else {
+      const float* g2 = a.c2 + (int64_t)sm * 36 * 64;
       r2a = *reinterpret_cast<const float4*>(g2 + tid * 4);
       r2b = *reinterpret_cast<const float4*>(g2 + (tid + 256) * 4);
       r2c = *reinterpret_cast<const float4*>(g2 + i2 * 4);
     }
+  };
+  auto file = [&]() {
+    *reinterpret_cast<float4*>(sdc3 + (tid >> 4) * LF + (tid & 15) * 4) = r3;
+    if constexpr (A16) {
+      auto put = [&](int j, const chunk_t& q) {
+        float* d = sc2 + (j >> 3) * LF + (j & 7) * 8;
+        *reinterpret_cast<float4*>(d) = float4{(float)q[0], (float)q[1], (float)q[2], (float)q[3]};
+        *reinterpret_cast<float4*>(d + 4) = float4{(float)q[4], (float)q[5], (float)q[6], (float)q[7]};
+      };
+      put(tid, q2a);
+      if (tid < 32) put(256 + tid, q2b);
+    } else {
+      *reinterpret_cast<float4*>(sc2 + (tid >> 4) * LF + (tid & 15) * 4) = r2a;
+      *reinterpret_cast<float4*>(sc2 + ((tid + 256) >> 4) * LF + (tid & 15) * 4) = r2b;
+      if (tid + 512 < 36 * 16) *reinterpret_cast<float4*>(sc2 + ((tid + 512) >> 4) * LF + (tid & 15) * 4) = r2c;
+    }
+  };
+  if ((int)blockIdx.x < a.n) fetch(blockIdx.x);
+  for (int smp = blockIdx.x; smp < a.n; smp += gridDim.x) {
+    __syncthreads();  // the previous sample's readers are done
+    file();
+    const int nxt = smp + (int)gridDim.x;
+    if (nxt < a.n) fetch(nxt);  // (block-uniform)
     __syncthreads();
     if (tid < 64) {
       float t = 0.f;

@@ -1851,6 +1851,7 @@ struct TrainEnc {
   float *s_c1, *s_c2, *s_c3;  // [n][225][32], [n][36][64], [n][16][64]
   float *s_h1, *s_h2;         // [n][256] encoder-MLP activations (s_h2: row stride ld_h2)
   int n, nmlp, nconv, ld_h2;
+  int acts16;                 // s_c1 / s_c2 are written in the operand type (bf16) for bwd_conv_kernel<T, true> (the trainer's passes)
 };
 struct TrainEncLds {
   static constexpr size_t part_b = 4 * 16 * 64 * 4;
@@ -2017,7 +2018,8 @@ __global__ __launch_bounds__(1024) void train_encoder_kernel(InfEncFrag w, Train
           const float v0 = fmaxf(acc[j][0] + bb.x, 0.f), v1 = fmaxf(acc[j][1] + bb.y, 0.f);
           const float v2 = fmaxf(acc[j][2] + bb.z, 0.f), v3 = fmaxf(acc[j][3] + bb.w, 0.f);
           st4(c1 + pp * LY::LD1 + n4, v0, v1, v2, v3);
-          st4(tr.s_c1 + ((int64_t)smp * 225 + pp) * 32 + n4, v0, v1, v2, v3);
+          if (tr.acts16) st4(reinterpret_cast<T*>(tr.s_c1) + ((int64_t)smp * 225 + pp) * 32 + n4, v0, v1, v2, v3);
+          else st4(tr.s_c1 + ((int64_t)smp * 225 + pp) * 32 + n4, v0, v1, v2, v3);
         }
       }
     }
@@ -2048,7 +2050,8 @@ __global__ __launch_bounds__(1024) void train_encoder_kernel(InfEncFrag w, Train
         const float v0 = fmaxf(acc[0] + bb.x, 0.f), v1 = fmaxf(acc[1] + bb.y, 0.f);
         const float v2 = fmaxf(acc[2] + bb.z, 0.f), v3 = fmaxf(acc[3] + bb.w, 0.f);
         st4(c2 + pp * LY::LD2 + n4, v0, v1, v2, v3);
-        st4(tr.s_c2 + ((int64_t)smp * 36 + pp) * 64 + n4, v0, v1, v2, v3);
+        if (tr.acts16) st4(reinterpret_cast<T*>(tr.s_c2) + ((int64_t)smp * 36 + pp) * 64 + n4, v0, v1, v2, v3);
+        else st4(tr.s_c2 + ((int64_t)smp * 36 + pp) * 64 + n4, v0, v1, v2, v3);
       }
     }
     __syncthreads();

@@ -87,6 +87,10 @@ struct v4l_net {
   v4l_net_cfg cfg;
   int Sp = 0;
   int ntok = v4l::NTOK;  // tokens per sample: 17 (LocoTransformer), 16 (vision-only Transformer)
+  // c1 / c2 of the training forward in the operand type (round 5): asked for by v4l_net_forward(train = 1) — the trainer's and
+  // the tests' forward / backward pairs —, granted by forward_t when the persistent training encoder writes them and the fused
+  // conv backward will read them (bf16, shipped conv geometry, no test taps), remembered for the backward of the same pass
+  bool want_acts16 = false, acts16_written = false;
   bool vis_only() const { return cfg.kind == V4L_NET_CNN_VIS || cfg.kind == V4L_NET_LOCO_VIS; }
   bool is_tf() const { return cfg.kind == V4L_NET_LOCO || cfg.kind == V4L_NET_LOCO_VIS; }
   std::vector<v4l::ParamInfo> params;

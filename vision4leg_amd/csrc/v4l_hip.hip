@@ -168,7 +168,7 @@ struct Ctx {  // per-call view of a bound net
   int64_t slab_used;
   hipStream_t tn;      // stream weight-grad kernels go to: s, or the net's aux stream inside par_begin/par_end
   // dW3's launch can be held back by conv_stack_bwd_fused and issued by the caller (next to the dense weight-grads)
-  bool defer_conv3 = false, conv3_pending = false;
+  bool defer_conv3 = false, conv3_pending = false, conv3_a16 = false;
   v4l::BwdConv conv3_args = {};
   int conv3_blocks = 0, conv3_n = 0;
   // the wave-per-sample layers' weight-grad launch (csrc/wps.h), issued with the other dense weight-grads
@@ -569,8 +569,12 @@ static int conv_stack_bwd_fused(Ctx& c, const T* image, const int* rowidx, int n
   if (!attr_done) {
     V4L_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&bwd_conv_kernel<T>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)BwdConvLds<T>::bytes));
+    if constexpr (sizeof(T) == 2)
+      V4L_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&bwd_conv_kernel<T, true>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)BwdConvLds<T>::bytes));
     attr_done = true;
   }
+  const bool a16 = sizeof(T) == 2 && N->acts16_written;  // c1 / c2 in T (what this pass's training encoder wrote)
   int nblk = std::min(n, CONV_BWD_MAX_BLOCKS);
   if (const char* e = getenv("V4L_CONV_BWD_BLOCKS")) nblk = std::max(1, std::min(nblk, atoi(e)));
   // dW3's launch runs beside the dense weight-grads on the other stream: fewer, fatter blocks cut its partial slabs (147 KB
@@ -614,14 +618,20 @@ static int conv_stack_bwd_fused(Ctx& c, const T* image, const int* rowidx, int n
   a.n = n;
   g_op = "conv.bwd";
   const double fl = 2.0 * n * (16.0 * 64 * 576 + 2.0 * 36 * 64 * 512 + 225.0 * 32 * 256);
-  V4L_KLAUNCH("fused_conv_bwd", fl, c.s, bwd_conv_kernel<T>, dim3(nblk), dim3(512), BwdConvLds<T>::bytes, c.s, a);
+  if constexpr (sizeof(T) == 2) {
+    if (a16) V4L_KLAUNCH("fused_conv_bwd", fl, c.s, (bwd_conv_kernel<T, true>), dim3(nblk), dim3(512), BwdConvLds<T>::bytes, c.s, a);
+  }
+  if (!a16) V4L_KLAUNCH("fused_conv_bwd", fl, c.s, bwd_conv_kernel<T>, dim3(nblk), dim3(512), BwdConvLds<T>::bytes, c.s, a);
   V4L_LAUNCH_CHECK();
   if (c.defer_conv3) {
-    c.conv3_args = a; c.conv3_blocks = nblk3; c.conv3_n = n; c.conv3_pending = true;
+    c.conv3_args = a; c.conv3_blocks = nblk3; c.conv3_n = n; c.conv3_pending = true; c.conv3_a16 = a16;
     return 0;
   }
   g_op = "conv3.wgrad";
-  V4L_KLAUNCH("fused_conv3_wgrad", 2.0 * n * 16 * 64 * 576, c.tn, bwd_conv3_wgrad_kernel<T>, dim3(nblk3), dim3(256), 0, c.tn, a);
+  if constexpr (sizeof(T) == 2) {
+    if (a16) V4L_KLAUNCH("fused_conv3_wgrad", 2.0 * n * 16 * 64 * 576, c.tn, (bwd_conv3_wgrad_kernel<T, true>), dim3(nblk3), dim3(256), 0, c.tn, a);
+  }
+  if (!a16) V4L_KLAUNCH("fused_conv3_wgrad", 2.0 * n * 16 * 64 * 576, c.tn, bwd_conv3_wgrad_kernel<T>, dim3(nblk3), dim3(256), 0, c.tn, a);
   V4L_LAUNCH_CHECK();
   return 0;
 }
@@ -630,8 +640,14 @@ static int conv3_wgrad_deferred(Ctx& c, hipStream_t s) {
   if (!c.conv3_pending) return 0;
   c.conv3_pending = false;
   g_op = "conv3.wgrad";
-  V4L_KLAUNCH("fused_conv3_wgrad", 2.0 * c.conv3_n * 16 * 64 * 576, s, bwd_conv3_wgrad_kernel<T>, dim3(c.conv3_blocks), dim3(256), 0, s,
-              c.conv3_args);
+  if constexpr (sizeof(T) == 2) {
+    if (c.conv3_a16)
+      V4L_KLAUNCH("fused_conv3_wgrad", 2.0 * c.conv3_n * 16 * 64 * 576, s, (bwd_conv3_wgrad_kernel<T, true>), dim3(c.conv3_blocks),
+                  dim3(256), 0, s, c.conv3_args);
+  }
+  if (!c.conv3_a16)
+    V4L_KLAUNCH("fused_conv3_wgrad", 2.0 * c.conv3_n * 16 * 64 * 576, s, bwd_conv3_wgrad_kernel<T>, dim3(c.conv3_blocks), dim3(256), 0, s,
+                c.conv3_args);
   V4L_LAUNCH_CHECK();
   return 0;
 }
@@ -1199,6 +1215,9 @@ int v4l_net::forward_t(const float* state, const T* image, const int* rowidx, in
     te.s_c1 = ws + L.c1; te.s_c2 = ws + L.c2; te.s_c3 = ws + L.c3;
     te.s_h1 = prop ? ws + L.eh[0] : nullptr; te.s_h2 = s_h2; te.ld_h2 = ld_h2;
     te.n = n; te.nmlp = prop ? cdiv(n, 32) : 0;
+    // (V4L_ACTS_F32: keep c1 / c2 in fp32 — the cross-check of tests/test_gpu_parity.py::test_conv_acts_in_operand_type_same_bits)
+    te.acts16 = want_acts16 && conv_bwd_fusable(this) && getenv("V4L_LAYER_TAPS") == nullptr && getenv("V4L_ACTS_F32") == nullptr;
+    acts16_written = te.acts16 != 0;
     constexpr int cus = 256;
     // the conv share never collapses: a very large minibatch (n >~ 8 K: nmlp -> cus) still gets half the CUs' worth of
     // persistent conv blocks (the MLP blocks are short; the two kinds then simply run in two waves over the chip)
@@ -2700,13 +2719,17 @@ int v4l_ingest(const v4l_net* net, const float* obs_dev, int n, float* state_dev
 
 int v4l_net_forward(v4l_net* net, const float* state_dev, const void* image_dev, const int* rowidx_dev, int n,
                     float* ws_dev, int train, void* stream) {
-  (void)train;
   V4L_REQUIRE(net && net->bound, "v4l_net_forward: net is not bound");
   V4L_REQUIRE(state_dev && ws_dev && n > 0, "v4l_net_forward: bad argument");
   V4L_REQUIRE(net->cfg.kind == V4L_NET_MLP || image_dev != nullptr, "v4l_net_forward: image_dev is null");
-  if (net->cfg.compute == V4L_BF16)
-    return net->forward_t<__bf16>(state_dev, (const __bf16*)image_dev, rowidx_dev, n, ws_dev, (hipStream_t)stream);
-  return net->forward_t<float>(state_dev, (const float*)image_dev, rowidx_dev, n, ws_dev, (hipStream_t)stream);
+  // train: a v4l_net_backward over this workspace follows — the conv activations it reads may then be saved in the operand type
+  net->want_acts16 = train != 0;
+  net->acts16_written = false;
+  const int rc = net->cfg.compute == V4L_BF16
+                     ? net->forward_t<__bf16>(state_dev, (const __bf16*)image_dev, rowidx_dev, n, ws_dev, (hipStream_t)stream)
+                     : net->forward_t<float>(state_dev, (const float*)image_dev, rowidx_dev, n, ws_dev, (hipStream_t)stream);
+  net->want_acts16 = false;
+  return rc;
 }
 float* v4l_net_out_ptr(const v4l_net* net, float* ws_dev, int n, int train) {
   (void)train;
