@@ -99,5 +99,10 @@ for f in sorted(glob.glob(sys.argv[1] + "/bench_*.json")):
     except Exception as e: print(f, "ERR", e)
 PY
   ;;
+g)  # round 5, session G: rows per block of the grouped dense weight-grads (probe builds -DV4L_TN_SMALL_ROWS=64|256 vs 128)
+  L=$REPO/vision4leg_amd
+  bench_ab r5g 3 "base=" "tn64=V4L_LIB=$L/libv4l_hip_tn64.so" "tn256=V4L_LIB=$L/libv4l_hip_tn256.so"
+  for v in base tn64 tn256; do for i in 1 2 3; do printf "%s %d: " $v $i; grep -E "gemm_tn_group|wps_wgrad|wgrad_reduce|fused_conv3" $O/r5g_bd_${v}_$i.txt | awk '{printf "%s=%.1f ", $1, $4}'; echo; done; done
+  ;;
 *) echo "unknown session $S"; exit 2 ;;
 esac

@@ -394,7 +394,10 @@ static int lin_wgrad(Ctx& c, const Lin& L, const ADense& y, const ADense& x, int
   p.y = y; p.x = x; p.M = M;
   p.gx = cdiv(Kx, 64); p.gy = cdiv(L.N, 64);
   constexpr int big_rows = 256;
-  int splits = M >= 4096 ? std::min(16384 / big_rows, M / big_rows) : std::max(1, M / 128);  // 2..4 staging rounds per block: latency-bound
+#ifndef V4L_TN_SMALL_ROWS
+#define V4L_TN_SMALL_ROWS 128  // rows per block of a grouped dense weight-grad below 4096 rows (probe builds: -DV4L_TN_SMALL_ROWS=64|256)
+#endif
+  int splits = M >= 4096 ? std::min(16384 / big_rows, M / big_rows) : std::max(1, M / V4L_TN_SMALL_ROWS);  // 2..4 staging rounds per block: latency-bound
   p.mpb = round_up(cdiv(M, splits), 64);
   splits = cdiv(M, p.mpb);
   p.Npad = p.gy * 64; p.Kpad = p.gx * 64;
