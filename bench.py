@@ -531,7 +531,8 @@ def algo_bytes(kernel, wl, compute):
     n, t = wl["B"], (2 if compute == "bf16" else 4)
     R = 17 * n                                   # token rows
     tok = 64 * 4                                 # one fp32 token row
-    conv_act = (225 * 32 + 36 * 64 + 16 * 64) * 4  # c1 + c2 + c3 of one sample, fp32
+    # c1 + c2 of one sample in the operand type (round 5: the trainer's passes save them as T), c3 fp32
+    conv_act = (225 * 32 + 36 * 64) * t + 16 * 64 * 4
     blocks = min(n, 256)
     per_launch = {
         # image + proprio row in; c1, c2, c3, tokens, 2 MLP activations out
@@ -544,9 +545,9 @@ def algo_bytes(kernel, wl, compute):
         "fused_layer_bwd": R * (tok + 2 * tok + 8 + 192 * 4 + 256 * t + (64 + 256 + 64 + 192) * t + tok) + n * 289 * 4,
         # both layers in one launch: the upper layer's dx is the lower layer's dy in LDS (one token-row read less)
         "fused_layer_bwd_stack": 2 * (R * (tok + 2 * tok + 8 + 192 * 4 + 256 * t + (64 + 256 + 64 + 192) * t + tok) + n * 289 * 4) - R * tok,
-        # dc3, c2, c1 (fp32) + image (T) in; one dW1 + dW2 slab per block out
-        "fused_conv_bwd": n * ((16 * 64 + 36 * 64 + 225 * 32) * 4 + 16384 * t) + blocks * (32 * 256 + 64 * 512) * 4,
-        "fused_conv3_wgrad": n * (16 * 64 + 36 * 64) * 4 + blocks * 64 * 576 * 4,
+        # dc3 (fp32), c2, c1 (T) + image (T) in; one dW1 + dW2 slab per block out
+        "fused_conv_bwd": n * (16 * 64 * 4 + (36 * 64 + 225 * 32) * t + 16384 * t) + blocks * (32 * 256 + 64 * 512) * 4,
+        "fused_conv3_wgrad": n * (16 * 64 * 4 + 36 * 64 * t) + blocks * 64 * 576 * 4,
         # both operands of the 4 linears x 2 layers (T) in; 55 slabs of the 4 weight shapes x 2 layers out
         "gemm_tn_wide": 2 * R * 2 * (64 + 256 + 64 + 192) * t + 2 * 55 * 49152 * 4,
         # wave-per-sample kernels (csrc/wps.h). forward: tokens in, layer 1's input rows out (+ pooled / head activations);
