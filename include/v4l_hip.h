@@ -142,7 +142,10 @@ int v4l_ingest(const v4l_net* net, const float* obs_dev, int n, float* state_dev
 
 /* Forward pass == nn.Module.forward of nets.py:52-55 / 247-262 / 996-1038 on rows rowidx[i] (or i when
  * rowidx_dev is NULL) of the ingested arrays. The head output (action mean or value) is left in the
- * workspace; v4l_net_out_ptr gives its address: [n][V4L_OUT_LD] fp32. train=1 keeps what backward needs. */
+ * workspace; v4l_net_out_ptr gives its address: [n][V4L_OUT_LD] fp32. train=1: a v4l_net_backward over this workspace
+ * follows — with bf16 compute and the shipped conv geometry the conv1 / conv2 activation slots ("c1", "c2" of
+ * v4l_net_ws_offset) then hold the operand type, not fp32 (bit-identical gradients; V4L_LAYER_TAPS / V4L_ACTS_F32 keep
+ * fp32). train=0 leaves every slot as documented. */
 int v4l_net_forward(v4l_net* net, const float* state_dev, const void* image_dev, const int* rowidx_dev, int n,
                     float* ws_dev, int train, void* stream);
 float* v4l_net_out_ptr(const v4l_net* net, float* ws_dev, int n, int train);
