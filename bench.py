@@ -49,7 +49,7 @@ WORKLOADS = {
     # an OPTION variant of the headline net (nets.py:1022-1030 max_pool=True; no shipped config sets it): correct with reference
     # goldens, but on the general layer-by-layer kernels — this line says what that fallback costs
     "loco_max": dict(kind="loco_max", S=93, A=6, E=32, T=512, B=1024, enc=[256, 256], head=[256, 256], layers=2, ff=256,
-                     name="ppo_locotransformer with max_pool=True (option variant, layer-by-layer kernels), E=32 x T=512, B=1024"),
+                     name="ppo_locotransformer with max_pool=True (option variant, fused kernels), E=32 x T=512, B=1024"),
 }
 # algorithmic MFLOP per env-step incl. rollout inference, and F_pf: the forward pass of the frozen
 # target policy that each of the 3 sample-visits skips when log pi_old is recorded at action time (§8d's declared saving)

@@ -96,7 +96,7 @@ typedef struct v4l_net_cfg {
                           atanh(action) with the -log(1 - a^2 + 1e-6) correction. The rollout step of such a policy runs on
                           the layer-by-layer kernels (no shipped config sets it) */
   int max_pool;        /* V4L_NET_LOCO / V4L_NET_LOCO_VIS: token pooling by max instead of mean (max_pool=True,
-                          nets.py:1022-1030, 884-889); runs on the layer-by-layer kernels (no shipped config sets it) */
+                          nets.py:1022-1030, 884-889); fused like the mean (round 5; no shipped config sets it) */
   int token_norm;      /* V4L_NET_LOCO / V4L_NET_LOCO_VIS: LayerNorm(token_dim) over every token in front of the transformer layers
                           (token_norm=True: nets.py:815-818, 879-880, 1007-1008; parameters token_ln.* and the never-used
                           state_token_ln.*); layer-by-layer kernels (no shipped config sets it) */

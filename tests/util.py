@@ -30,12 +30,16 @@ CASES = {
     # a NON-shipped geometry (one layer, ff = 128, 128-wide MLPs, odd batch): runs on the general layer-by-layer kernels
     # (gemm_nt / attn / ln / gemm_tn), not on the fused ones that are specialised for the shipped shapes
     "loco_gen": dict(kind="loco", S=45, A=4, seed=4, B=22, enc=[128, 128], head=[128, 128], layers=1, ff=128),
+    # mixed geometry (round 5): shipped layers and heads but a 128-wide proprio MLP -> the forward may fuse the layers and heads,
+    # the backward's encoder-side tail cannot: the two passes must still agree on what the forward saves
+    "loco_mix": dict(kind="loco", S=45, A=4, seed=20, B=22, enc=[128, 128], head=[256, 256], layers=2, ff=256),
     # vision-only variants (starter/ppo_locotransformer_vision_only.py, ppo_nature_cnn_vision_only.py
     # with the config/mpc_vision_only/{locotransformer,baseline}/thin-goal.json hyper-parameters): the observation row is the depth stack alone (S = 0)
     "loco_vis": dict(kind="loco_vis", S=0, A=6, seed=5, B=32, enc=[], head=[256, 256], layers=2, ff=256),
     "cnn_vis": dict(kind="cnn_vis", S=0, A=6, seed=6, B=32, enc=[], head=[256, 256]),
-    # max_pool=True (nets.py:1022-1030, 884-889; no shipped config sets it): the depth tokens pooled by max — on the
-    # layer-by-layer kernels (pool_fwd / pool_bwd with the arg-max mask)
+    # max_pool=True (nets.py:1022-1030, 884-889; no shipped config sets it): the depth tokens pooled by max — inside the
+    # wave-per-sample kernels (round 5; arg-max mask rebuilt from the stack's output rows), pool_fwd / pool_bwd under
+    # V4L_NO_WPS_LAYERS
     "loco_max": dict(kind="loco_max", S=84, A=6, seed=12, B=32, enc=[256, 256], head=[256, 256], layers=2, ff=256),
     "loco_vis_max": dict(kind="loco_vis_max", S=0, A=6, seed=13, B=32, enc=[], head=[256, 256], layers=2, ff=256),
     # token_norm=True (nets.py:815-818, 879-880, 1007-1008; no shipped config sets it): token_ln over every token in front of the

@@ -154,6 +154,7 @@ struct v4l_net {
   int heads_ext(float* ws, int n, v4l::RowsChain* out);
   bool fused_layers() const;  // the transformer layers run as fused forward / backward launches (csrc/infer.h, bwd.h)
   bool wps_layers() const;
+  bool wps_max_pool() const;  // max_pool=True pooled inside the wave-per-sample pair
   bool wps_vis() const;  // vision-only Transformer on the wave-per-sample kernels (dummy token row, csrc/wps.h)    // ... as wave-per-sample launches (csrc/wps.h)
   template <typename T> int backward_t(const float* state, const T* image, const int* rowidx, int n, float* ws, float* grads, hipStream_t s);
 };

@@ -1035,9 +1035,16 @@ bool v4l_net::wps_layers() const {
 }
 bool v4l_net::wps_vis() const {
   const v4l_net_cfg& c = cfg;
-  return c.kind == V4L_NET_LOCO_VIS && !c.max_pool && !c.token_norm && !c.pytorch_encoder && c.ff_dim == 256 && c.n_layers == 2 && c.n_head_hidden == 2 && c.head_hidden[0] == 256 &&
+  return c.kind == V4L_NET_LOCO_VIS && !c.token_norm && !c.pytorch_encoder && c.ff_dim == 256 && c.n_layers == 2 && c.n_head_hidden == 2 && c.head_hidden[0] == 256 &&
          c.head_hidden[1] == 256 && c.out_dim <= OUT_LD && layers[0].inproj.pkp >= 0 && head[0].pko >= 0 &&
          getenv("V4L_NO_WPS_LAYERS") == nullptr;
+}
+// max_pool=True on the (non-vision) wave-per-sample pair: forward and backward must both take it (the block-cooperative kernels
+// pool by mean only)
+bool v4l_net::wps_max_pool() const {
+  const v4l_net_cfg& c = cfg;
+  return c.kind == V4L_NET_LOCO && c.n_layers == 2 && c.n_enc_hidden == 2 && c.enc_hidden[0] == 256 && c.enc_hidden[1] == 256 &&
+         getenv("V4L_NO_LAYER_STACK") == nullptr && wps_layers();
 }
 bool v4l_net::fused_layers() const {
   return cfg.kind == V4L_NET_LOCO && cfg.ff_dim == 256 && !cfg.token_norm && !cfg.pytorch_encoder;
@@ -1048,7 +1055,7 @@ bool v4l_net::wps_bwd_plain() const {
   if (c.kind != V4L_NET_LOCO) return false;
   const bool fused_bwd = fused_layers();
   const bool fused_head = fused_bwd && c.n_layers >= 1 && c.n_head_hidden == 2 && c.head_hidden[0] == 256 &&
-                          c.head_hidden[1] == 256 && !c.max_pool;
+                          c.head_hidden[1] == 256 && c.out_dim <= OUT_LD && (!c.max_pool || wps_max_pool());
   const bool fused_tail = fused_bwd && c.n_layers >= 1 && c.n_enc_hidden == 2 && c.enc_hidden[0] == 256 &&
                           c.enc_hidden[1] == 256;
   return fused_bwd && fused_head && fused_tail && c.n_layers == 2 && getenv("V4L_NO_LAYER_STACK") == nullptr && wps_layers();
@@ -1351,14 +1358,17 @@ int v4l_net::forward_t(const float* state, const T* image, const int* rowidx, in
     }
     const bool fused_layers = this->fused_layers();
     // the last layer's blocks also run the pooled heads of their samples when the head stack has the shipped shape
+    // (max_pool=True pools inside the wave-per-sample kernels only: the block-cooperative fallback keeps pool_fwd_kernel)
     const bool fused_head = fused_layers && c.n_layers >= 1 && nh == 2 && c.head_hidden[0] == 256 && c.head_hidden[1] == 256 &&
-                            c.out_dim <= OUT_LD && !c.max_pool;
+                            c.out_dim <= OUT_LD && (!c.max_pool || wps_max_pool());
     // both layers + the heads in ONE launch when the stack is the shipped two layers (the token rows stay in LDS between
     // the layers); otherwise one launch per TransformerEncoderLayer. 2 or 4 samples per block, saving what backward_t reads.
     const bool stack_ok = getenv("V4L_NO_LAYER_STACK") == nullptr;  // (read per call: tests switch it)
     const bool stacked = fused_layers && fused_head && c.n_layers == 2 && stack_ok;
     const bool vis_wps = c.kind == V4L_NET_LOCO_VIS && enc_ws == nullptr && stage == 0 && wps_vis();
-    if ((stacked && wps_layers()) || vis_wps) {
+    // (wps_bwd_plain: the wave-per-sample forward keeps only the layers' input rows, which only the wave-per-sample backward
+    // can start from — a geometry whose backward stays layer-by-layer must not take it)
+    if ((stacked && wps_layers() && wps_bwd_plain()) || vis_wps) {
       // wave-per-sample launch (csrc/wps.h): both layers + the pooled heads, 4 samples per block, weights resident in LDS
       static bool wps_attr = false;
       if (!wps_attr) {
@@ -1387,7 +1397,8 @@ int v4l_net::forward_t(const float* state, const T* image, const int* rowidx, in
         d.xin = k == 0 ? x0 : ws + L.x[k];
         // production: the forward saves nothing but the layers' input rows (the backward recomputes, csrc/wps.h);
         // V4L_LAYER_TAPS=1 (tests): every intermediate goes out row-major, as the block-cooperative kernels save them
-        d.xout = (k + 1 < 2 || taps) ? ws + L.x[k + 1] : nullptr;
+        // (max_pool: the backward finds the arg-max tokens again from the stack's output rows)
+        d.xout = (k + 1 < 2 || taps || c.max_pool) ? ws + L.x[k + 1] : nullptr;
         if (taps) {
           d.s_qkv = ws + w.qkv; d.s_P = ws + w.P; d.s_ctx = ws + w.ctx; d.s_xh1 = ws + w.xh1; d.s_rs1 = ws + w.rs1;
           d.s_x1 = ws + w.x1; d.s_f = ws + w.f; d.s_xh2 = ws + w.xh2; d.s_rs2 = ws + w.rs2;
@@ -1399,7 +1410,7 @@ int v4l_net::forward_t(const float* state, const T* image, const int* rowidx, in
       InfHead& h = hd.n[0];
       h.w0 = base + (vis_wps ? head[0].pko : head[0].pk); h.w1 = base + head[1].pk; h.w2 = base + head[2].pk;
       h.b0 = p[head[0].b]; h.b1 = p[head[1].b]; h.b2 = p[head[2].b];
-      h.out = ws + L.out; h.nout = c.out_dim;
+      h.out = ws + L.out; h.nout = c.out_dim; h.max_pool = c.max_pool;
       h.s_pooled = ws + L.pooled; h.s_h0 = ws + L.hh[0]; h.s_h1 = ws + L.hh[1];
       g_op = "layer";
       if (vis_wps && taps)
@@ -1740,7 +1751,7 @@ int v4l_net::backward_t(const float* state, const T* image, const int* rowidx, i
   const bool fused_bwd = fused_layers();  // forward and backward switch together: they share the T-typed saves
   // the last layer's launch starts from dout (heads + un-pool), layer 0's launch continues into the encoder MLP / up-conv
   const bool fused_head = fused_bwd && c.n_layers >= 1 && nh == 2 && c.head_hidden[0] == 256 && c.head_hidden[1] == 256 &&
-                          !c.max_pool;
+                          c.out_dim <= OUT_LD && (!c.max_pool || wps_max_pool());
   const bool fused_tail = fused_bwd && c.n_layers >= 1 && ne == 2 && c.enc_hidden[0] == 256 && c.enc_hidden[1] == 256;
   // vision-only Transformer on the wave-per-sample kernels (17-row stride, dummy row 0: csrc/wps.h); the forward took the same path
   const bool vis_wps = vis && wps_vis();
@@ -1831,6 +1842,7 @@ int v4l_net::backward_t(const float* state, const T* image, const int* rowidx, i
     WpsTailExtra tx;
     tx.wupt_f = base + upconv.pkpt;
     tx.dpool = ws + L.dpool;
+    tx.xlast = c.max_pool ? ws + L.x[c.n_layers] : nullptr;
     g_op = "layer";
     const double fl_heads = 2.0 * n * 2 * (16 * 256 + 256 * 256 + 256 * 128) / 2, fl_tok0 = 2.0 * n * (64 * 256 + 256 * 256);
     const double fl = 2 * 4.0 * n * 872576.0 + (head_ext ? 0.0 : 2 * fl_heads) + (tok0_ext ? 0.0 : fl_tok0) + 2.0 * n * 16 * 64 * 64;

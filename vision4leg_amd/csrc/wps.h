@@ -175,6 +175,15 @@ __device__ __forceinline__ float rowsum16(float v) {  // over the 16 lanes of a 
   v += dpp_mov<0x128>(v); v += dpp_mov<0x124>(v); v += dpp_mov<0x122>(v); v += dpp_mov<0x121>(v);
   return v;
 }
+__device__ __forceinline__ float rowmax16(float v) {  // max over the 16 lanes of a DPP row
+  v = fmaxf(v, dpp_mov<0x128>(v)); v = fmaxf(v, dpp_mov<0x124>(v)); v = fmaxf(v, dpp_mov<0x122>(v)); v = fmaxf(v, dpp_mov<0x121>(v));
+  return v;
+}
+__device__ __forceinline__ int rowmin16(int v) {  // (the DPP move carries the bits unchanged)
+  v = min(v, __float_as_int(dpp_mov<0x128>(__int_as_float(v)))); v = min(v, __float_as_int(dpp_mov<0x124>(__int_as_float(v))));
+  v = min(v, __float_as_int(dpp_mov<0x122>(__int_as_float(v)))); v = min(v, __float_as_int(dpp_mov<0x121>(__int_as_float(v))));
+  return v;
+}
 // The 0/1 selector fragments: as the B operand, E_h picks index 16 h + fr out of a k-step's 32 (permuted) contraction
 // indices: mma(A = X fragment, B = E_h) = X^T restricted to those 16 indices, exactly.
 template <typename T> __device__ __forceinline__ typename Frag<T>::type wps_sel(int h, int lane) {
@@ -652,8 +661,10 @@ __global__ __launch_bounds__(256) WPS_EU_ATTR void wps_layer_fwd_kernel(InfLayer
     for (int nt = 0; nt < 4; ++nt) {
       // token 0 sits in lane fr = 0 of tile 0; tokens 1..15 in the other lanes of tile 0, token 16 in lane fr = 0 of tile 1
       const float4 m = fr == 0 ? xr[1][nt] : xr[0][nt];
-      const float4 mv = {rowsum16(m.x) * (1.f / 16.f), rowsum16(m.y) * (1.f / 16.f), rowsum16(m.z) * (1.f / 16.f),
-                         rowsum16(m.w) * (1.f / 16.f)};
+      // max_pool=True (nets.py:1022-1023, 886-887; round 5): the max over the same 16 tokens instead of their mean
+      const float4 mv = h.max_pool ? float4{rowmax16(m.x), rowmax16(m.y), rowmax16(m.z), rowmax16(m.w)}
+                                   : float4{rowsum16(m.x) * (1.f / 16.f), rowsum16(m.y) * (1.f / 16.f), rowsum16(m.z) * (1.f / 16.f),
+                                            rowsum16(m.w) * (1.f / 16.f)};
       if (fr == 0 && live) {
         // VIS: the head reads the mean of the 16 tokens only — the dummy row's half is zeros here and h.w0 is the [256][128]
         // pack whose columns 0..63 are zero
@@ -1123,7 +1134,38 @@ __global__ __launch_bounds__(NWAVES * 64) void actor_loss_heads_kernel(ActorArgs
 // HEAD_IN / TOK0_IN = false: that chain ran / will run outside this kernel over 64 rows per block (rows_chain above) — the
 // heads beside the loss statistics, leaving dpool [n][128] (tx.dpool) for the un-pool here; the proprio chain beside the
 // layers' weight-grads, from the layer-0 input gradient this kernel writes (stk.l[NL-1].o_dx).
-struct WpsTailExtra { const void* wupt_f; const float* dpool; };  // up-conv's transposed weight as a k-permuted fragment pack
+// xlast: the layer stack's output rows [n][17][64] when the head pools the depth tokens by max (max_pool=True): the gradient of
+// a max goes to the first token that attained it (torch.max(dim) backward; pool_bwd_kernel), found again from these rows
+struct WpsTailExtra { const void* wupt_f; const float* dpool; const float* xlast; };  // wupt_f: up-conv's transposed weight as a k-permuted fragment pack
+// un-pooling weights of a sample's depth tokens (lane fr: token fr of tile 0, lane fr = 0 of tile 1: token 16), per feature column:
+// 1/16 for the mean; for the max 1 on the first token that holds the maximum of its column, 0 elsewhere
+template <bool VIS>
+__device__ __forceinline__ void wps_unpool_weights(const float* xlast_rows, int lane, const bool (&ok)[2], float4 (&w0)[4]) {
+  const int fr = lane & 15;
+  if (xlast_rows == nullptr) {
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) w0[nt] = float4{1.f / 16.f, 1.f / 16.f, 1.f / 16.f, 1.f / 16.f};
+    return;
+  }
+  float4 xl[2][4];
+  wps_load_rows<VIS>(xlast_rows, lane, ok, xl);
+  const int idx = fr == 0 ? 16 : fr;  // the depth token this lane stands for in the row-wide reductions below
+#pragma unroll
+  for (int nt = 0; nt < 4; ++nt) {
+    const float4 m = fr == 0 ? xl[1][nt] : xl[0][nt];
+    const float mx[4] = {rowmax16(m.x), rowmax16(m.y), rowmax16(m.z), rowmax16(m.w)};
+    const float mv[4] = {m.x, m.y, m.z, m.w};
+    float wv[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int first = rowmin16(mv[r] == mx[r] ? idx : 99);
+      wv[r] = idx == first ? 1.f : 0.f;
+    }
+    const float4 wq = {wv[0], wv[1], wv[2], wv[3]};
+    // lane fr = 0 carries token 16's weight (its tile-1 slot); in tile 0 that lane is the proprio token (not pooled: unused there)
+    w0[nt] = wq;
+  }
+}
 template <typename T, int NL, bool TAPS, bool VIS = false, bool HEAD_IN = true, bool TOK0_IN = true>
 __global__ __launch_bounds__(256) WPS_EU_ATTR void wps_layer_bwd_kernel(WpsBwdStack stk, BwdHead hd, BwdTail tl, WpsTailExtra tx, int n) {
   // VIS (template parameter): see wps_layer_fwd — hd.w0t is then the [128][256] pack whose rows 0..63 are zero (the dummy
@@ -1148,6 +1190,8 @@ __global__ __launch_bounds__(256) WPS_EU_ATTR void wps_layer_bwd_kernel(WpsBwdSt
   const frag_t E0 = wps_sel<T>(0, lane), E1 = wps_sel<T>(1, lane);
   float4 dy[2][4];
   WPS_STAMP(32);
+  float4 upw[4];  // un-pooling weights of this lane's depth token (mean: 1/16; max_pool: the arg-max mask), both tiles
+  wps_unpool_weights<VIS>(tx.xlast != nullptr ? tx.xlast + row0 * TD : nullptr, lane, ok, upw);
   if constexpr (!HEAD_IN) {
     // the heads ran beside the loss statistics: un-pool their dpool rows straight into this wave's registers
 #pragma unroll
@@ -1156,8 +1200,8 @@ __global__ __launch_bounds__(256) WPS_EU_ATTR void wps_layer_bwd_kernel(WpsBwdSt
       for (int nt = 0; nt < 4; ++nt) {
         const bool tok0 = mt == 0 && fr == 0;
         const float4 v = *reinterpret_cast<const float4*>(tx.dpool + srow * (2 * TD) + (tok0 ? 0 : TD) + nt * 16 + qr);
-        const float sc = tok0 ? 1.f : (1.f / 16.f);
-        dy[mt][nt] = ok[mt] ? float4{v.x * sc, v.y * sc, v.z * sc, v.w * sc} : float4{0.f, 0.f, 0.f, 0.f};
+        const float4 sc = tok0 ? float4{1.f, 1.f, 1.f, 1.f} : upw[nt];
+        dy[mt][nt] = ok[mt] ? float4{v.x * sc.x, v.y * sc.y, v.z * sc.z, v.w * sc.w} : float4{0.f, 0.f, 0.f, 0.f};
       }
   } else {
     // ---- heads (nets.py:1015-1034 reversed): dout -> (W2^T, mask h1) -> dh1 -> (W1^T, mask h0) -> dh0 -> (W0^T) -> dpool
@@ -1231,8 +1275,8 @@ __global__ __launch_bounds__(256) WPS_EU_ATTR void wps_layer_bwd_kernel(WpsBwdSt
       for (int nt = 0; nt < 4; ++nt) {
         const bool tok0 = mt == 0 && fr == 0;
         const float4 v = *reinterpret_cast<const float4*>(dpool + wave * LY::LDP + (tok0 ? 0 : TD) + nt * 16 + qr);
-        const float sc = tok0 ? 1.f : (1.f / 16.f);
-        dy[mt][nt] = ok[mt] ? float4{v.x * sc, v.y * sc, v.z * sc, v.w * sc} : float4{0.f, 0.f, 0.f, 0.f};
+        const float4 sc = tok0 ? float4{1.f, 1.f, 1.f, 1.f} : upw[nt];
+        dy[mt][nt] = ok[mt] ? float4{v.x * sc.x, v.y * sc.y, v.z * sc.z, v.w * sc.w} : float4{0.f, 0.f, 0.f, 0.f};
       }
   }
   float4 xr[2][4];
