@@ -46,8 +46,8 @@ WORKLOADS = {
                      name="ppo_locotransformer_vision_only: Transformer over 16 depth tokens, A=6, E=32 envs x T=256, B=1024"),
     "cnn_vis": dict(kind="cnn_vis", S=0, A=6, E=32, T=256, B=1024, enc=[], head=[256, 256],
                     name="ppo_nature_cnn_vision_only: NatureCNN -> 1024 -> head, A=6, E=32 envs x T=256, B=1024"),
-    # an OPTION variant of the headline net (nets.py:1022-1030 max_pool=True; no shipped config sets it): correct with reference
-    # goldens, but on the general layer-by-layer kernels — this line says what that fallback costs
+    # an OPTION variant of the headline net (nets.py:1022-1030 max_pool=True; no shipped config sets it): reference goldens;
+    # on the fused kernels since round 5 — this line shows an option costs nothing against the headline
     "loco_max": dict(kind="loco_max", S=93, A=6, E=32, T=512, B=1024, enc=[256, 256], head=[256, 256], layers=2, ff=256,
                      name="ppo_locotransformer with max_pool=True (option variant, fused kernels), E=32 x T=512, B=1024"),
 }
