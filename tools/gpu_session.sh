@@ -77,6 +77,12 @@ f)  # round 5, session F: what the padding token tile costs (timing-only one-til
   bench_ab r5f 3 "base=" "onetile=V4L_LIB=$REPO/vision4leg_amd/libv4l_hip_onetile.so"
   for v in base onetile; do for i in 1 2 3; do printf "%s %d: " $v $i; grep -E "wps_layer|wps_wgrad" $O/r5f_bd_${v}_$i.txt | awk '{printf "%s=%.1f ", $1, $4}'; echo; done; done
   ;;
+h)  # round 5, session H: launch-chain trims (update opening in registers, Adam operands ahead of the norm, 16-byte slab loads
+    # in the reduce) against the build before them (vision4leg_amd/libv4l_hip_base.so = a copy of that build)
+  (timeout 900 python -m pytest tests/test_gpu_parity.py tests/test_gpu_dp2.py -q -m gpu --tb=short -x -k "ppo_update or graph or dp or backward" 2>&1 | tail -8) > $O/r5h_tests.log; tail -4 $O/r5h_tests.log
+  bench_ab r5h 3 "base=V4L_LIB=$REPO/vision4leg_amd/libv4l_hip_base.so" "new="
+  for v in base new; do for i in 1 2 3; do printf "%s %d: " $v $i; grep -E "begin_pack|clip_adam|wgrad_reduce|pack " $O/r5h_bd_${v}_$i.txt | awk '{printf "%s=%.1f ", $1, $4}'; echo; done; done
+  ;;
 evidence)  # the round's records for profiles/: tools/gpu_session.sh evidence <tag, e.g. r5>
   TAG=${1:-r5}; EV=$O/${TAG}_ev; mkdir -p $EV
   python bench.py --steps 20 --warmup 5 --breakdown $EV/breakdown.txt > $EV/bench_full.json 2> $EV/bench_full.err

@@ -424,6 +424,31 @@ __device__ __forceinline__ void adv_stats_body(const float* __restrict__ adv, co
     st[ST_ADV_NM2] = (float)(n * mean * mean);
   }
 }
+// the same statistics from values a block already holds in registers (thread t: elements t, t + blockDim, ... — the order
+// adv_stats_body's loops add them in, so the bits are the same)
+__device__ __forceinline__ void adv_stats_regs(const float (&a)[4], const bool (&ok)[4], int n, float* __restrict__ st) {
+  double s = 0.0; float mx = -INFINITY, mn = INFINITY;
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+    if (ok[j]) { s += a[j]; mx = fmaxf(mx, a[j]); mn = fminf(mn, a[j]); }
+  Red4 r = block_red4(s, 0.0, mx, mn);
+  const double mean = r.s / n;
+  double q = 0.0, sq = 0.0;
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+    if (ok[j]) { const double d = a[j]; q += (d - mean) * (d - mean); sq += d * d; }
+  Red4 r2 = block_red4(q, sq, 0.f, 0.f);
+  if (threadIdx.x == 0) {
+    st[ST_ADV_MEAN] = (float)mean;
+    st[ST_ADV_STD] = (float)sqrt(r2.s / (double)(n - 1));
+    st[ST_ADV_MAX] = r.mx;
+    st[ST_ADV_MIN] = r.mn;
+    st[ST_ADV_SUM] = (float)r.s;
+    st[ST_ADV_M2] = (float)r2.s;
+    st[ST_ADV_CNT] = (float)n;
+    st[ST_ADV_NM2] = (float)(n * mean * mean);
+  }
+}
 __global__ __launch_bounds__(256) void adv_stats_kernel(const float* __restrict__ adv, const int* __restrict__ rowidx, int n,
                                                         float* __restrict__ st) {
   adv_stats_body(adv, rowidx, n, st);
@@ -775,18 +800,8 @@ struct UpdCtl {
 __global__ void ctl_set_kernel(UpdCtl* c, int upd_index, long long step, double lr_pf, double lr_vf, float b1, float b2) {
   c->upd_index = upd_index; c->step = step; c->lr_pf = lr_pf; c->lr_vf = lr_vf; c->beta1 = b1; c->beta2 = b2;
 }
-// Opens update #upd_index: selects its rows (identity when rowidx_all is null), clears the statistics record and
-// advances the Adam step / bias corrections (double precision, like torch/optim/adam.py::_single_tensor_adam).
-// adv != null: also the advantage statistics of the selected rows (adv_stats_kernel's work, one launch less).
-__device__ __forceinline__ void upd_begin_body(UpdCtl* c, const int* __restrict__ rowidx_all, int n, int* rowidx_cur,
-                                               float* stats_cur, const float* __restrict__ adv) {
-  const int u = c->upd_index;
-  for (int i = threadIdx.x; i < n; i += blockDim.x) rowidx_cur[i] = rowidx_all ? rowidx_all[(int64_t)u * n + i] : i;
-  if (threadIdx.x < ST_SIZE) stats_cur[threadIdx.x] = 0.f;
-  if (adv != nullptr) {
-    __syncthreads();  // rowidx_cur and the cleared record are visible to the whole block
-    adv_stats_body(adv, rowidx_cur, n, stats_cur);
-  }
+// the Adam step / bias corrections of the update being opened (double precision, like torch/optim/adam.py::_single_tensor_adam)
+__device__ __forceinline__ void upd_begin_step(UpdCtl* c) {
   if (threadIdx.x == 0) {
     const long long step = c->step + 1;
     c->step = step;
@@ -796,6 +811,44 @@ __device__ __forceinline__ void upd_begin_body(UpdCtl* c, const int* __restrict_
     c->step_size[1] = (float)(c->lr_vf / bc1);
     c->bc2_sqrt = (float)sqrt(bc2);
   }
+}
+// Opens update #upd_index: selects its rows (identity when rowidx_all is null), clears the statistics record and
+// advances the Adam step / bias corrections.
+// adv != null: also the advantage statistics of the selected rows (adv_stats_kernel's work, one launch less).
+__device__ __forceinline__ void upd_begin_body(UpdCtl* c, const int* __restrict__ rowidx_all, int n, int* rowidx_cur,
+                                               float* stats_cur, const float* __restrict__ adv) {
+  const int u = c->upd_index;
+  if (adv != nullptr && n <= 4 * (int)blockDim.x) {
+    // (round 5) the rows' indices and advantages stay in registers: index -> advantage is the only dependent pair of round
+    // trips left in this block's chain (it was index -> store -> barrier -> reload -> advantage -> second pass)
+    int ri[4];
+    float av[4];
+    bool ok[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int i = (int)threadIdx.x + j * (int)blockDim.x;
+      ok[j] = i < n;
+      ri[j] = rowidx_all ? rowidx_all[(int64_t)u * n + (ok[j] ? i : 0)] : i;
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) av[j] = adv[ok[j] ? ri[j] : 0];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      if (ok[j]) rowidx_cur[(int)threadIdx.x + j * (int)blockDim.x] = ri[j];
+    if (threadIdx.x < ST_SIZE) stats_cur[threadIdx.x] = 0.f;
+    upd_begin_step(c);  // (thread 0's double-precision pow() runs while the loads above are in flight)
+    __syncthreads();  // the cleared record is in place before thread 0 fills its part
+    adv_stats_regs(av, ok, n, stats_cur);
+    return;
+  } else {
+    for (int i = threadIdx.x; i < n; i += blockDim.x) rowidx_cur[i] = rowidx_all ? rowidx_all[(int64_t)u * n + i] : i;
+    if (threadIdx.x < ST_SIZE) stats_cur[threadIdx.x] = 0.f;
+    if (adv != nullptr) {
+      __syncthreads();  // rowidx_cur and the cleared record are visible to the whole block
+      adv_stats_body(adv, rowidx_cur, n, stats_cur);
+    }
+  }
+  upd_begin_step(c);
 }
 __global__ __launch_bounds__(256) void clip_adam_kernel(const ParamSeg* __restrict__ segs, int nseg,
                                                         const float* __restrict__ g, float* __restrict__ m,
@@ -807,6 +860,12 @@ __global__ __launch_bounds__(256) void clip_adam_kernel(const ParamSeg* __restri
   const float beta1 = ctl->beta1, beta2 = ctl->beta2;
   const float step_size = ctl->step_size[which], bc2_sqrt = ctl->bc2_sqrt;
   const int lane_ = threadIdx.x & 63;
+  // this thread's element: its four operands are requested before the norm is summed (they do not depend on it; behind the
+  // barrier below they would be one more round trip at the end of the block's chain — round 5)
+  const int64_t i = ((int64_t)blockIdx.x - sg.blk0) * 256 + threadIdx.x;
+  const bool mine = i < sg.n;
+  const int64_t o = sg.goff + (mine ? i : 0);
+  const float g_in = g[o], m_in = m[o], v_in = v[o], p_in = sg.p[mine ? i : 0];
   // the norm's partials (grad_sumsq_kernel's, or one per wgrad_reduce block: npart <= ADAM_MAX_PARTS), strided over the block's
   // threads with every load in flight at once, then lanes -> waves in a fixed order: the same bits in every block
   __shared__ float wpart[4];
@@ -841,15 +900,13 @@ __global__ __launch_bounds__(256) void clip_adam_kernel(const ParamSeg* __restri
     __syncthreads();
     if (threadIdx.x == 0) close_ctl->upd_index = u + 1;
   }
-  const int64_t i = ((int64_t)blockIdx.x - sg.blk0) * 256 + threadIdx.x;
-  if (i >= sg.n) return;
-  const int64_t o = sg.goff + i;
-  const float gr = g[o] * coef;
-  float mm = m[o], vv = v[o];
+  if (!mine) return;
+  const float gr = g_in * coef;
+  float mm = m_in, vv = v_in;
   mm = mm + (gr - mm) * (1.f - beta1);           // exp_avg.lerp_(grad, 1 - beta1)
   vv = vv * beta2 + (1.f - beta2) * (gr * gr);   // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, value=1-beta2)
   const float denom = sqrtf(vv) / bc2_sqrt + eps;
-  sg.p[i] = sg.p[i] - step_size * (mm / denom);  // param.addcdiv_(exp_avg, denom, value=-step_size)
+  sg.p[i] = p_in - step_size * (mm / denom);     // param.addcdiv_(exp_avg, denom, value=-step_size)
   m[o] = mm;
   v[o] = vv;
 }
