@@ -77,8 +77,21 @@ __device__ __forceinline__ void mma_k32(f32x4& acc, const bf16x8& a, const bf16x
 }
 struct __attribute__((aligned(16))) f32x8 { float v[8]; };
 __device__ __forceinline__ void mma_k32(f32x4& acc, const f32x8& a, const f32x8& b) {
+#ifdef V4L_PROBE_F32_SPLIT3
+  // probe: fp32 operands split into bf16 high + low parts, three bf16 MFMAs (the low x low product is dropped)
+  bf16x8 ah, al, bh, bl;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    ah[j] = (__bf16)a.v[j]; al[j] = (__bf16)(a.v[j] - (float)ah[j]);
+    bh[j] = (__bf16)b.v[j]; bl[j] = (__bf16)(b.v[j] - (float)bh[j]);
+  }
+  acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh, acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl, acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh, acc, 0, 0, 0);
+#else
 #pragma unroll
   for (int j = 0; j < 8; ++j) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.v[j], b.v[j], acc, 0, 0, 0);
+#endif
 }
 template <typename T> struct Frag;
 template <> struct Frag<__bf16> { typedef bf16x8 type; };
