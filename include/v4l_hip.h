@@ -93,8 +93,8 @@ typedef struct v4l_net_cfg {
   int has_logstd;      /* 1: Gaussian policy with a state-independent logstd parameter                   */
   int tanh_action;     /* Gaussian policy with tanh_action=True (policies/distribution.py:5-80 TanhNormal,
                           continuous_policy.py:85-146): action = tanh(mean + std * eps), log-prob of a stored action through
-                          atanh(action) with the -log(1 - a^2 + 1e-6) correction. The rollout step of such a policy runs on
-                          the layer-by-layer kernels (no shipped config sets it) */
+                          atanh(action) with the -log(1 - a^2 + 1e-6) correction. The fused rollout step kernels sample through
+                          tanh in their epilogues (round 5; no shipped config sets it) */
   int max_pool;        /* V4L_NET_LOCO / V4L_NET_LOCO_VIS: token pooling by max instead of mean (max_pool=True,
                           nets.py:1022-1030, 884-889); fused like the mean (round 5; no shipped config sets it) */
   int token_norm;      /* V4L_NET_LOCO / V4L_NET_LOCO_VIS: LayerNorm(token_dim) over every token in front of the transformer layers

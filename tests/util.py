@@ -51,7 +51,7 @@ CASES = {
     "loco_pe": dict(kind="loco_pe", S=84, A=6, seed=18, B=32, enc=[256, 256], head=[256, 256], layers=2, ff=256),
     "loco_vis_pe": dict(kind="loco_vis_pe", S=0, A=6, seed=19, B=32, enc=[], head=[256, 256], layers=2, ff=256, param_tol_f32=4e-5),
     # tanh_action=True (TanhNormal head, policies/distribution.py:5-80; no shipped config sets it): the update's log-probs go
-    # through atanh(stored action) with the -log(1 - a^2 + 1e-6) correction; the rollout step on the layer-by-layer kernels
+    # through atanh(stored action) with the -log(1 - a^2 + 1e-6) correction; the rollout step on the fused kernels (round 5)
     "mlp_tanh": dict(kind="mlp_tanh", S=93, A=6, seed=14, B=64, enc=[256, 256], head=[256, 256]),
     "loco_tanh": dict(kind="loco_tanh", S=84, A=6, seed=15, B=32, enc=[256, 256], head=[256, 256], layers=2, ff=256),
     # the minibatch bench.py times (BASELINE configs[2] / configs[1], B = 1024): 4 samples per persistent block in the fused

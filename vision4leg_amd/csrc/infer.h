@@ -483,6 +483,7 @@ struct InfFinish {
   ActCtl* ctl;
   const float *logstd, *eps;
   int A;
+  int tanh_action;  // TanhNormal head (distribution.py:5-80): action = tanh(mean + std eps), log-prob through the stored action
   float *acts_roll, *values_roll, *logp_roll, *action, *mean, *stdv, *ent, *value;
   // eager launches: the env step index + 1 as the host counts it (v4l_actor_seek / one per step); 0: read the device cursor
   // ctl->t and advance it through the last-block counter (graph replays, whose arguments are frozen). With the host's index no
@@ -859,13 +860,15 @@ __global__ __launch_bounds__(256) void infer_layer_kernel(InfLayerStack stk, Inf
             const float ls = fminf(fmaxf(fin.logstd[a], LOG_SIG_MIN), LOG_SIG_MAX);
             const float sg = expf(ls);
             e += 0.5f + HALF_LOG_2PI + logf(sg);
-            const float act = fmaf(sg, fin.eps[(int64_t)i * A + a], mu);
+            float act = fmaf(sg, fin.eps[(int64_t)i * A + a], mu);
+            if (fin.tanh_action) act = tanhf(act);  // (eps = 0: eval_act's tanh(mean))
             fin.action[(int64_t)i * A + a] = act;
             fin.mean[(int64_t)i * A + a] = mu;
             fin.stdv[(int64_t)i * A + a] = sg;
             if (fin.acts_roll != nullptr) fin.acts_roll[(t_step * E + i) * A + a] = act;
-            const float d = act - mu;
+            const float d = (fin.tanh_action ? tanh_pre(act) : act) - mu;  // (through the STORED action, like act_finish_kernel)
             lp += -(d * d) / (2.f * sg * sg) - logf(sg) - HALF_LOG_2PI;
+            if (fin.tanh_action) lp -= tanh_corr(act);
           }
           fin.ent[i] = e;
           if (fin.logp_roll != nullptr) fin.logp_roll[t_step * E + i] = lp;
@@ -1307,9 +1310,11 @@ __global__ __launch_bounds__(512) void rollout_stack_kernel(InfLayerStack stk, I
         const float ls = fminf(fmaxf(lsd, LOG_SIG_MIN), LOG_SIG_MAX);
         const float sg = expf(ls);
         const float et = 0.5f + HALF_LOG_2PI + logf(sg);
-        const float act = fmaf(sg, ep, mu);
-        const float d = act - mu;
+        float act = fmaf(sg, ep, mu);
+        if (fin.tanh_action) act = tanhf(act);  // TanhNormal.rsample (distribution.py:61-80); eps = 0: eval_act's tanh(mean)
+        const float d = (fin.tanh_action ? tanh_pre(act) : act) - mu;
         const float lt = -(d * d) / (2.f * sg * sg) - logf(sg) - HALF_LOG_2PI;
+        const float ct = fin.tanh_action ? tanh_corr(act) : 0.f;
         if (lane < A) {
           fin.action[(int64_t)i * A + lane] = act;
           fin.mean[(int64_t)i * A + lane] = mu;
@@ -1317,7 +1322,11 @@ __global__ __launch_bounds__(512) void rollout_stack_kernel(InfLayerStack stk, I
           if (fin.acts_roll != nullptr) fin.acts_roll[(t_step * E + i) * A + lane] = act;
         }
         float e = 0.f, lp = 0.f;
-        for (int a = 0; a < A; ++a) { e += lane_bcast(et, a); lp += lane_bcast(lt, a); }  // a = 0 .. A-1, in order
+        if (fin.tanh_action) {  // (act_finish_kernel's order: the Gaussian term in, the tanh correction out, dimension by dimension)
+          for (int a = 0; a < A; ++a) { e += lane_bcast(et, a); lp += lane_bcast(lt, a); lp -= lane_bcast(ct, a); }
+        } else {
+          for (int a = 0; a < A; ++a) { e += lane_bcast(et, a); lp += lane_bcast(lt, a); }  // a = 0 .. A-1, in order
+        }
         if (lane == 0) {
           fin.ent[i] = e;
           if (fin.logp_roll != nullptr) fin.logp_roll[t_step * E + i] = lp;
@@ -2345,13 +2354,15 @@ __global__ __launch_bounds__(1024) void rollout_cnn_kernel(const ActCtl* __restr
         const float ls = fminf(fmaxf(fin.logstd[a], LOG_SIG_MIN), LOG_SIG_MAX);
         const float sg = expf(ls);
         e += 0.5f + HALF_LOG_2PI + logf(sg);
-        const float act = fmaf(sg, fin.eps[(int64_t)i * A + a], mu);
+        float act = fmaf(sg, fin.eps[(int64_t)i * A + a], mu);
+            if (fin.tanh_action) act = tanhf(act);  // (eps = 0: eval_act's tanh(mean))
         fin.action[(int64_t)i * A + a] = act;
         fin.mean[(int64_t)i * A + a] = mu;
         fin.stdv[(int64_t)i * A + a] = sg;
         if (fin.acts_roll != nullptr) fin.acts_roll[(t_step * E + i) * A + a] = act;
-        const float d = act - mu;
+        const float d = (fin.tanh_action ? tanh_pre(act) : act) - mu;  // (through the STORED action, like act_finish_kernel)
         lp += -(d * d) / (2.f * sg * sg) - logf(sg) - HALF_LOG_2PI;
+        if (fin.tanh_action) lp -= tanh_corr(act);
       }
       fin.ent[i] = e;
       if (fin.logp_roll != nullptr) fin.logp_roll[t_step * E + i] = lp;
@@ -2430,13 +2441,15 @@ __global__ __launch_bounds__(1024) void rollout_mlp_kernel(const ActCtl* __restr
         const float ls = fminf(fmaxf(fin.logstd[a], LOG_SIG_MIN), LOG_SIG_MAX);
         const float sg = expf(ls);
         e += 0.5f + HALF_LOG_2PI + logf(sg);
-        const float act = fmaf(sg, fin.eps[(int64_t)i * A + a], mu);
+        float act = fmaf(sg, fin.eps[(int64_t)i * A + a], mu);
+            if (fin.tanh_action) act = tanhf(act);  // (eps = 0: eval_act's tanh(mean))
         fin.action[(int64_t)i * A + a] = act;
         fin.mean[(int64_t)i * A + a] = mu;
         fin.stdv[(int64_t)i * A + a] = sg;
         if (fin.acts_roll != nullptr) fin.acts_roll[(t_step * E + i) * A + a] = act;
-        const float d = act - mu;
+        const float d = (fin.tanh_action ? tanh_pre(act) : act) - mu;  // (through the STORED action, like act_finish_kernel)
         lp += -(d * d) / (2.f * sg * sg) - logf(sg) - HALF_LOG_2PI;
+        if (fin.tanh_action) lp -= tanh_corr(act);
       }
       fin.ent[i] = e;
       if (fin.logp_roll != nullptr) fin.logp_roll[t_step * E + i] = lp;

@@ -148,13 +148,15 @@ __global__ __launch_bounds__(512) void rollout_head_kernel(RollHead a, InfFinish
         const float ls = fminf(fmaxf(lsd_s[k], LOG_SIG_MIN), LOG_SIG_MAX);
         const float sg = expf(ls);
         e += 0.5f + HALF_LOG_2PI + logf(sg);
-        const float act = fmaf(sg, eps_s[i * A + k], mu);
+        float act = fmaf(sg, eps_s[i * A + k], mu);
+        if (fin.tanh_action) act = tanhf(act);  // TanhNormal (distribution.py:61-80), as in act_finish_kernel
         fin.action[(int64_t)i * A + k] = act;
         fin.mean[(int64_t)i * A + k] = mu;
         fin.stdv[(int64_t)i * A + k] = sg;
         if (fin.acts_roll != nullptr) fin.acts_roll[(t_step * E + i) * A + k] = act;
-        const float d = act - mu;
+        const float d = (fin.tanh_action ? tanh_pre(act) : act) - mu;
         lp += -(d * d) / (2.f * sg * sg) - logf(sg) - HALF_LOG_2PI;
+        if (fin.tanh_action) lp -= tanh_corr(act);
       }
       fin.ent[i] = e;
       if (fin.logp_roll != nullptr) fin.logp_roll[t_step * E + i] = lp;

@@ -2147,7 +2147,7 @@ static int run_actor_fused_cnn(v4l_actor* a, const float* obs, const float* eps,
   head(hd.n[1], vf, vk, ws_vf + Lv.out);
   InfFinish fin;
   memset(&fin, 0, sizeof(fin));
-  fin.ctl = a->ctl; fin.logstd = pf->p[pf->logstd]; fin.eps = eps; fin.A = pf->cfg.out_dim;
+  fin.ctl = a->ctl; fin.logstd = pf->p[pf->logstd]; fin.eps = eps; fin.A = pf->cfg.out_dim; fin.tanh_action = pf->cfg.tanh_action;
   fin.t_plus1 = actor_t_plus1(a, s);
   fin.acts_roll = acts_roll; fin.values_roll = values_roll; fin.logp_roll = logp_roll; fin.action = action;
   fin.mean = mean; fin.stdv = stdv; fin.ent = ent; fin.value = value;
@@ -2250,7 +2250,7 @@ static int run_actor_dense_cnn(v4l_actor* a, const float* obs, const float* eps,
   }
   InfFinish fin;
   memset(&fin, 0, sizeof(fin));
-  fin.ctl = a->ctl; fin.logstd = pf->p[pf->logstd]; fin.eps = eps; fin.A = pf->cfg.out_dim;
+  fin.ctl = a->ctl; fin.logstd = pf->p[pf->logstd]; fin.eps = eps; fin.A = pf->cfg.out_dim; fin.tanh_action = pf->cfg.tanh_action;
   fin.t_plus1 = actor_t_plus1(a, s);
   fin.acts_roll = acts_roll; fin.values_roll = values_roll; fin.logp_roll = logp_roll; fin.action = action;
   fin.mean = mean; fin.stdv = stdv; fin.ent = ent; fin.value = value;
@@ -2345,7 +2345,7 @@ static int run_actor_mlp2(v4l_actor* a, const float* obs, const float* eps, floa
   head(1, vf, vk, a->ws + Lp.total + Lv.out);
   InfFinish fin;
   memset(&fin, 0, sizeof(fin));
-  fin.ctl = a->ctl; fin.logstd = pf->p[pf->logstd]; fin.eps = eps; fin.A = pf->cfg.out_dim;
+  fin.ctl = a->ctl; fin.logstd = pf->p[pf->logstd]; fin.eps = eps; fin.A = pf->cfg.out_dim; fin.tanh_action = pf->cfg.tanh_action;
   fin.t_plus1 = actor_t_plus1(a, s);
   fin.acts_roll = acts_roll; fin.values_roll = values_roll; fin.logp_roll = logp_roll; fin.action = action;
   fin.mean = mean; fin.stdv = stdv; fin.ent = ent; fin.value = value;
@@ -2391,7 +2391,7 @@ static int run_actor_fused_mlp(v4l_actor* a, const float* obs, const float* eps,
   head(hd.n[1], vf, vk, ws_vf + Lv.out);
   InfFinish fin;
   memset(&fin, 0, sizeof(fin));
-  fin.ctl = a->ctl; fin.logstd = pf->p[pf->logstd]; fin.eps = eps; fin.A = pf->cfg.out_dim;
+  fin.ctl = a->ctl; fin.logstd = pf->p[pf->logstd]; fin.eps = eps; fin.A = pf->cfg.out_dim; fin.tanh_action = pf->cfg.tanh_action;
   fin.t_plus1 = actor_t_plus1(a, s);
   fin.acts_roll = acts_roll; fin.values_roll = values_roll; fin.logp_roll = logp_roll; fin.action = action;
   fin.mean = mean; fin.stdv = stdv; fin.ent = ent; fin.value = value;
@@ -2488,7 +2488,7 @@ static int run_actor_fused(v4l_actor* a, const float* obs, const float* eps, flo
   auto finish = [&]() {
     head(hd.n[0], pf, pk, ws_pf + Lp.out);
     head(hd.n[1], vf, vk, ws_vf + Lv.out);
-    fin.ctl = a->ctl; fin.logstd = pf->p[pf->logstd]; fin.eps = eps; fin.A = pf->cfg.out_dim;
+    fin.ctl = a->ctl; fin.logstd = pf->p[pf->logstd]; fin.eps = eps; fin.A = pf->cfg.out_dim; fin.tanh_action = pf->cfg.tanh_action;
   fin.t_plus1 = actor_t_plus1(a, s);
     fin.acts_roll = acts_roll; fin.values_roll = values_roll; fin.logp_roll = logp_roll; fin.action = action;
     fin.mean = mean; fin.stdv = stdv; fin.ent = ent; fin.value = value;
@@ -2983,17 +2983,19 @@ static int run_actor_step(v4l_actor* a, const float* obs, const float* eps, floa
   const int E = a->E;
   int rc;
   V4L_REQUIRE(pf->bound && vf->bound, "v4l_actor_step: nets are not bound");
-  // tanh_action policies (TanhNormal): the general step below — act_finish_kernel holds their sampling / log-prob epilogue
-  const bool fused_ok = shared_encoder && !pf->cfg.tanh_action;
+  // tanh_action policies (TanhNormal): the fused kernels' epilogues sample through tanh like act_finish_kernel (round 5),
+  // except the two-launch state-MLP and the dense NatureCNN kernels (rollout_dense.h) — such a policy takes the other fused family
+  const bool fused_ok = shared_encoder;
+  const bool tanh_pol = pf->cfg.tanh_action != 0;
   if (fused_ok && actor_fusable_mlp(a) && pf->enc[0].Kp <= 128) {
-    if (actor_mlp2(a))
+    if (actor_mlp2(a) && !tanh_pol)
       return run_actor_mlp2(a, obs, eps, state_roll, acts_roll, values_roll, logp_roll, action, mean, stdv, ent, value, s);
     if (pf->cfg.compute == V4L_BF16)
       return run_actor_fused_mlp<__bf16>(a, obs, eps, state_roll, acts_roll, values_roll, logp_roll, action, mean, stdv, ent,
                                          value, s);
     return run_actor_fused_mlp<float>(a, obs, eps, state_roll, acts_roll, values_roll, logp_roll, action, mean, stdv, ent, value, s);
   }
-  if (fused_ok && actor_dense_cnn(a))
+  if (fused_ok && actor_dense_cnn(a) && !tanh_pol)
     return run_actor_dense_cnn(a, obs, eps, state_roll, image_roll, acts_roll, values_roll, logp_roll, action, mean, stdv, ent,
                                value, s);
   if (fused_ok && actor_fusable_cnn(a) && pf->enc[0].Kp <= 128) {
