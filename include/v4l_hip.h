@@ -31,6 +31,8 @@
  *   V4L_NO_FUSED_CONV_BWD     conv-stack backward layer by layer (per call)
  *   V4L_ACTS_F32              the training encoder saves conv1 / conv2 activations in fp32 even where the fused conv backward would
  *                             take them in the operand type (round 5; same bits, 19 KB more per sample each way) (per call)
+ *   V4L_VIS17                 the vision-only Transformer on the 17-row wave-per-sample instantiation (dummy row 0, masked key) instead
+ *                             of the native 16-token one (round 5; agrees to rounding: cross-checked) (per call)
  *   V4L_NO_LAYER_STACK        one launch per transformer layer instead of one per direction (per call)
  *   V4L_NO_WPS_LAYERS         transformer layers on the block-cooperative kernels instead of the wave-per-sample ones (per call)
  *   V4L_LAYER_TAPS            the wave-per-sample layer kernels and the fused conv backward also write every intermediate into

@@ -1328,3 +1328,39 @@ def test_conv_acts_in_operand_type_same_bits(name, device, monkeypatch):
     for i in (1, 2):
         for k, v in res["operand_type"][i].items():
             assert torch.equal(v, res["fp32"][i][k]), k
+
+
+@pytest.mark.parametrize("name", ["loco_vis", "loco_vis_max"])
+def test_native_16_token_vision_stack_equals_17_row_one(name, device, monkeypatch):
+    """Round 5: the vision-only Transformer's 16 depth tokens are exactly one MFMA row tile — its wave-per-sample kernels are
+    instantiated natively for that (wps_*<..., VIS = 2>: no dummy row, no padding tile). V4L_VIS17=1 puts the net back on the
+    17-row instantiation (dummy row 0, masked key): the same arithmetic per token with other lanes doing the reductions, so two
+    exact-fp32 PPO updates agree to rounding."""
+    case = util.CASES[name]
+    from vision4leg_amd.torchrl.algo import PPO
+    res = {}
+    for variant in ("native16", "rows17"):
+        if variant == "rows17":
+            monkeypatch.setenv("V4L_VIS17", "1")
+        else:
+            monkeypatch.delenv("V4L_VIS17", raising=False)
+        pf, vf = _build(case, "f32", device)
+
+        class Coll: epoch_frames = 1
+        agent = PPO(pf=pf, vf=vf, plr=1e-4, vlr=1e-4, clip_para=0.2, opt_epochs=3, tau=0.95, entropy_coeff=0.005,
+                    collector=Coll(), device=device, batch_size=case["B"])
+        agent.trainer.sync_target()
+        infos = []
+        for u in range(2):
+            b = util.make_batch(case, update=u)
+            infos.append(agent.update({k: b[k] for k in ("obs", "acts", "advs", "estimate_returns", "values")}))
+        torch.cuda.synchronize()
+        res[variant] = (infos, {k: v.detach().cpu().clone() for k, v in pf.state_dict().items()},
+                        {k: v.detach().cpu().clone() for k, v in vf.state_dict().items()})
+    for u in range(2):
+        for k in util.STAT_KEYS:
+            a, b = res["native16"][0][u][k], res["rows17"][0][u][k]
+            assert abs(a - b) <= 2e-5 * max(1.0, abs(b)), (u, k, a, b)
+    for i in (1, 2):
+        for k, v in res["native16"][i].items():
+            assert (v - res["rows17"][i][k]).abs().max().item() <= 2e-6, k

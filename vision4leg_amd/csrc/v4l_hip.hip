@@ -1033,6 +1033,9 @@ static bool dense_stack_shape(const v4l_net* N) {
 bool v4l_net::wps_layers() const {
   return fused_layers() && cfg.n_layers == 2 && layers[0].inproj.pkp >= 0 && getenv("V4L_NO_WPS_LAYERS") == nullptr;
 }
+// V4L_VIS17=1 (read per call: a test switches it): the vision-only Transformer on the 17-row wave-per-sample instantiation (dummy
+// row 0) instead of the native 16-token one — the two are cross-checked against each other
+static bool vis17_forced() { return getenv("V4L_VIS17") != nullptr; }
 bool v4l_net::wps_vis() const {
   const v4l_net_cfg& c = cfg;
   return c.kind == V4L_NET_LOCO_VIS && !c.token_norm && !c.pytorch_encoder && c.ff_dim == 256 && c.n_layers == 2 && c.n_head_hidden == 2 && c.head_hidden[0] == 256 &&
@@ -1380,6 +1383,8 @@ int v4l_net::forward_t(const float* state, const T* image, const int* rowidx, in
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)WpsFwdLds<T>::bytes));
         V4L_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&wps_layer_fwd_kernel<T, true, 2, true, true>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)WpsFwdLds<T>::bytes));
+        V4L_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&wps_layer_fwd_kernel<T, true, 2, false, 2>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)WpsFwdLds<T>::bytes));
         wps_attr = true;
       }
       const bool taps = getenv("V4L_LAYER_TAPS") != nullptr;  // (read per call: tests switch it)
@@ -1416,8 +1421,11 @@ int v4l_net::forward_t(const float* state, const T* image, const int* rowidx, in
       if (vis_wps && taps)
         V4L_KLAUNCH("wps_layer_stack_head", 2.0 * n * (2 * 872576.0 + 99840.0), s, (wps_layer_fwd_kernel<T, true, 2, true, true>),
                     dim3(cdiv(n, WPS_WPB)), dim3(256), (WpsFwdLds<T>::bytes), s, stk, hd, n);
-      else if (vis_wps)
+      else if (vis_wps && vis17_forced())
         V4L_KLAUNCH("wps_layer_stack_head", 2.0 * n * (2 * 872576.0 + 99840.0), s, (wps_layer_fwd_kernel<T, true, 2, false, true>),
+                    dim3(cdiv(n, WPS_WPB)), dim3(256), (WpsFwdLds<T>::bytes), s, stk, hd, n);
+      else if (vis_wps)  // native 16-token instantiation: one token tile per sample (round 5)
+        V4L_KLAUNCH("wps_layer_stack_head", 2.0 * n * (2 * 872576.0 + 99840.0), s, (wps_layer_fwd_kernel<T, true, 2, false, 2>),
                     dim3(cdiv(n, WPS_WPB)), dim3(256), (WpsFwdLds<T>::bytes), s, stk, hd, n);
       else if (taps)
         V4L_KLAUNCH("wps_layer_stack_head", 2.0 * n * (2 * 872576.0 + 99840.0), s, (wps_layer_fwd_kernel<T, true, 2, true>),
@@ -1858,7 +1866,8 @@ int v4l_net::backward_t(const float* state, const T* image, const int* rowidx, i
                 (WpsBwdLds<T>::bytes), s, d, bh, bt, tx, n);                                                              \
   } while (0)
     if (vis_wps && taps) V4L_WPS_BWD(true, true, true, true);
-    else if (vis_wps) V4L_WPS_BWD(false, true, true, true);
+    else if (vis_wps && vis17_forced()) V4L_WPS_BWD(false, true, true, true);
+    else if (vis_wps) V4L_WPS_BWD(false, 2, true, true);  // native 16 tokens: no 17th-token side blocks (wa.l[].tk = null below)
     else if (taps) V4L_WPS_BWD(true, false, true, true);
     else if (head_ext && tok0_ext) V4L_WPS_BWD(false, false, false, false);
     else if (head_ext) V4L_WPS_BWD(false, false, false, true);
@@ -1873,7 +1882,8 @@ int v4l_net::backward_t(const float* state, const T* image, const int* rowidx, i
     for (int li = 0; li < 2; ++li) {
       const TLayer& t = layers[li];
       const Lin* ls[4] = {&t.inproj, &t.outproj, &t.ff1, &t.ff2};
-      wa.l[li].wg = ws + L.wps_wg[li]; wa.l[li].tk = ws + L.wps_tk[li];
+      wa.l[li].wg = ws + L.wps_wg[li];
+      wa.l[li].tk = (vis_wps && !taps && !vis17_forced()) ? nullptr : ws + L.wps_tk[li];
       for (int m = 0; m < 4; ++m) {
         const Lin& Lm = *ls[m];
         const int64_t sf = ((int64_t)wa.nsplit * Lm.N * Lm.K + 63) / 64 * 64, bf = ((int64_t)wa.nsplit * Lm.N + 63) / 64 * 64;

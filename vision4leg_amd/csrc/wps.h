@@ -63,12 +63,14 @@ constexpr int WPS_WPB = 4;  // waves = samples per block
 // out. What is left is the upper bound of what ANY scheme that shares the 17th tokens' tile between samples could gain (VERDICT
 // r4 item 1a), before its own exchange costs.
 #ifdef V4L_WPS_PROBE_ONE_TILE
-#define WPS_NMT 1
-#define WPS_Z = {}
+#define WPS_NMT_DEF 1
 #else
-#define WPS_NMT 2
-#define WPS_Z
+#define WPS_NMT_DEF 2
 #endif
+// Token tiles a layer function walks: 2 (17 rows) — or 1 in the native 16-token instantiation of the vision-only Transformer
+// (VIS = 2, round 5: its 16 depth tokens ARE one MFMA row tile; no dummy row, no padding tile). Per-tile arrays keep two slots;
+// the unused one is zero-initialised (dead stores where both tiles are walked).
+#define WPS_Z = {}
 #ifdef V4L_WPS_ROLL_LAYERS
 #define WPS_LAYER_LOOP _Pragma("unroll 1")
 #else
@@ -141,26 +143,30 @@ __device__ __forceinline__ typename Frag<T>::type wps_w(const T* base, int idx, 
   }
 }
 // T-layout GEMM step: acc[mt] (features 16 tile + 4g + r of token 16 mt + fr) += W[tile] . x
-template <typename T, bool LDSW, int KS>
+template <typename T, bool LDSW, int KS, int NMT = WPS_NMT_DEF>
 __device__ __forceinline__ void wps_gemm_t(f32x4 (&acc)[2], const T* W, int tile, const typename Frag<T>::type (&xa)[2][KS], int lane) {
 #pragma unroll
   for (int ks = 0; ks < KS; ++ks) {
     const typename Frag<T>::type fw = wps_w<T, LDSW>(W, tile * KS + ks, lane);
 #pragma unroll
-    for (int mt = 0; mt < WPS_NMT; ++mt) mma_k32(acc[mt], fw, xa[mt][ks]);
+    for (int mt = 0; mt < NMT; ++mt) mma_k32(acc[mt], fw, xa[mt][ks]);
   }
 }
 // F-layout GEMM step: acc[mt] (tokens 16 mt + 4g + r of feature 16 tile + fr) += x . W[tile]
-template <typename T, bool LDSW, int KS>
+template <typename T, bool LDSW, int KS, int NMT = WPS_NMT_DEF>
 __device__ __forceinline__ void wps_gemm_f(f32x4 (&acc)[2], const T* W, int tile, const typename Frag<T>::type (&xa)[2][KS], int lane) {
 #pragma unroll
   for (int ks = 0; ks < KS; ++ks) {
     const typename Frag<T>::type fw = wps_w<T, LDSW>(W, tile * KS + ks, lane);
 #pragma unroll
-    for (int mt = 0; mt < WPS_NMT; ++mt) mma_k32(acc[mt], xa[mt][ks], fw);
+    for (int mt = 0; mt < NMT; ++mt) mma_k32(acc[mt], xa[mt][ks], fw);
   }
 }
-template <bool VIS> __device__ __forceinline__ bool wps_key_ok(int key) { return key < NTOK && (!VIS || key > 0); }
+// VIS: 0 = 17 tokens; 1 = the vision-only Transformer on the 17-row machinery (key 0 = the dummy row, masked); 2 = its native
+// 16-token instantiation (keys 0..15 = the depth tokens)
+template <int VIS> __device__ __forceinline__ bool wps_key_ok(int key) {
+  return VIS == 2 ? key < 16 : (key < NTOK && (VIS == 0 || key > 0));
+}
 __device__ __forceinline__ float xsum(float v) {  // over the four lane groups that share a token (T layout row)
   v += __shfl_xor(v, 16);
   v += __shfl_xor(v, 32);
@@ -209,7 +215,7 @@ __device__ __forceinline__ typename Frag<T>::type wps_tr(const typename Frag<T>:
 // f1 (tokens 16..31: only token 16, lane fr = 0, is real) -> the 17th-token block as it is.
 struct WpsOut { void *wg, *tk; bool live; };
 template <typename T> __device__ __forceinline__ WpsOut wps_out(T* wg, T* tk, bool live) { return WpsOut{wg, tk, live}; }
-template <typename T>
+template <typename T, int NMT = WPS_NMT_DEF>
 __device__ __forceinline__ void wps_store_opnd(const WpsOut& o, int pair, const typename Frag<T>::type& f0, const typename Frag<T>::type& f1,
                                                const typename Frag<T>::type& E0, const typename Frag<T>::type& E1, int lane) {
   typedef typename Frag<T>::type frag_t;
@@ -218,15 +224,16 @@ __device__ __forceinline__ void wps_store_opnd(const WpsOut& o, int pair, const 
   mma_k32(d1, f0, E1);
   if (o.live) {
     *reinterpret_cast<frag_t*>(reinterpret_cast<T*>(o.wg) + ((int64_t)pair * 64 + lane) * 8) = wps_frag<T>(f4(d0), f4(d1));
-    if ((lane & 15) == 0) *reinterpret_cast<frag_t*>(reinterpret_cast<T*>(o.tk) + ((int64_t)pair * 4 + (lane >> 4)) * 8) = f1;
+    if (NMT == 2 && (lane & 15) == 0) *reinterpret_cast<frag_t*>(reinterpret_cast<T*>(o.tk) + ((int64_t)pair * 4 + (lane >> 4)) * 8) = f1;
   }
 }
 
 // LayerNorm of one sample's rows in T layout (z[mt][nt]: token 16 mt + fr, features 16 nt + 4g + r): mean, then the variance of
 // the centred values (the two-pass form of ln_rows / at::native::layer_norm), eps 1e-5. -> xhat in z, rstd per mt.
+template <int NMT = WPS_NMT_DEF>
 __device__ __forceinline__ void wps_ln(float4 (&z)[2][4], float (&rs)[2]) {
 #pragma unroll
-  for (int mt = 0; mt < WPS_NMT; ++mt) {
+  for (int mt = 0; mt < NMT; ++mt) {
     float s = 0.f;
 #pragma unroll
     for (int nt = 0; nt < 4; ++nt) s += (z[mt][nt].x + z[mt][nt].y) + (z[mt][nt].z + z[mt][nt].w);
@@ -264,23 +271,26 @@ template <typename T> struct WpsKeep {
 //     sit in rows 1..16, row 0 is a dummy (zero input rows) that no real token attends to — key 0 is masked out of every
 //     softmax. Whatever row 0 computes stays in row 0, the head ignores it (kernel epilogue), and its gradient rows are
 //     exactly zero in the backward (P[:, 0] = 0, zero output gradient), so the weight-grads never see it.
-template <typename T, bool LDSW, bool KEEP, bool TAPS, bool VIS = false>
+template <typename T, bool LDSW, bool KEEP, bool TAPS, int VIS = 0>
 __device__ __forceinline__ void wps_layer_fwd(const InfLayer& w, const T* W, const float* prm, const float4 (&xr)[2][4], int lane,
                                               const bool (&ok)[2], int64_t row0, int64_t smp, float4 (&xo)[2][4], const WpsOut* wo,
                                               const typename Frag<T>::type& E0, const typename Frag<T>::type& E1, WpsKeep<T>* kp, int sb = 0) {
   typedef typename Frag<T>::type frag_t;
+  constexpr int NMT = VIS == 2 ? 1 : WPS_NMT_DEF;
+  constexpr int ROFF = VIS == 2 ? 1 : 0;  // native 16: tile row fr = token fr = memory row 1 + fr of the sample's 17-row slot
+  static_assert(!(TAPS && VIS == 2), "the test taps run on the 17-row instantiations");
   const int fr = lane & 15, g = lane >> 4, qr = g * 4;
   const bool live = ok[0];
   (void)sb;
   // ---- layer input as fragments
   frag_t xa[2][2] WPS_Z;
 #pragma unroll
-  for (int mt = 0; mt < WPS_NMT; ++mt)
+  for (int mt = 0; mt < NMT; ++mt)
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) xa[mt][ks] = wps_frag<T>(xr[mt][2 * ks], xr[mt][2 * ks + 1]);
   if (TAPS && w.s_xin != nullptr) {
 #pragma unroll
-    for (int mt = 0; mt < WPS_NMT; ++mt)
+    for (int mt = 0; mt < NMT; ++mt)
       if (ok[mt])
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt)
@@ -288,7 +298,7 @@ __device__ __forceinline__ void wps_layer_fwd(const InfLayer& w, const T* W, con
   }
   if constexpr (KEEP) {  // (the recompute inside the backward kernel is the pass that hands the x-side operands over)
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) wps_store_opnd<T>(*wo, WPS_T_XIN / 2 + ks, xa[0][ks], xa[1][ks], E0, E1, lane);
+    for (int ks = 0; ks < 2; ++ks) wps_store_opnd<T, NMT>(*wo, WPS_T_XIN / 2 + ks, xa[0][ks], xa[1][ks], E0, E1, lane);
   }
   // ---- in_proj: q | k in T layout (operands of S = Q K^T over the feature index), v in F layout (operand of P V over keys)
   frag_t qa[2][2] WPS_Z, ka[2][2] WPS_Z, vt[4];
@@ -301,17 +311,17 @@ __device__ __forceinline__ void wps_layer_fwd(const InfLayer& w, const T* W, con
       for (int h = 0; h < 2; ++h) {
         const int tile = part * 4 + 2 * ks + h;
         f32x4 acc[2] = {zero4(), zero4()};
-        wps_gemm_t<T, LDSW, 2>(acc, W, tile, xa, lane);
+        wps_gemm_t<T, LDSW, 2, NMT>(acc, W, tile, xa, lane);
         const float4 bb = *reinterpret_cast<const float4*>(prm + WPS_P_BIN + tile * 16 + qr);
 #pragma unroll
-        for (int mt = 0; mt < WPS_NMT; ++mt) {
+        for (int mt = 0; mt < NMT; ++mt) {
           two[mt][h] = f4add(acc[mt], bb);
           if (TAPS && w.s_qkv != nullptr && ok[mt])
             st4(w.s_qkv + (row0 + mt * 16 + fr) * 192 + tile * 16 + qr, two[mt][h].x, two[mt][h].y, two[mt][h].z, two[mt][h].w);
         }
       }
 #pragma unroll
-      for (int mt = 0; mt < WPS_NMT; ++mt) {
+      for (int mt = 0; mt < NMT; ++mt) {
         if (part == 0) qa[mt][ks] = wps_frag<T>(two[mt][0], two[mt][1]);
         else ka[mt][ks] = wps_frag<T>(two[mt][0], two[mt][1]);
       }
@@ -320,7 +330,7 @@ __device__ __forceinline__ void wps_layer_fwd(const InfLayer& w, const T* W, con
 #pragma unroll
   for (int dt = 0; dt < 4; ++dt) {
     f32x4 acc[2] = {zero4(), zero4()};
-    wps_gemm_f<T, LDSW, 2>(acc, W, 8 + dt, xa, lane);
+    wps_gemm_f<T, LDSW, 2, NMT>(acc, W, 8 + dt, xa, lane);
     const float bv = prm[WPS_P_BIN + 128 + dt * 16 + fr];
     const float4 v0 = {acc[0][0] + bv, acc[0][1] + bv, acc[0][2] + bv, acc[0][3] + bv};   // keys 4g + r
     const float4 v1 = {acc[1][0] + bv, acc[1][1] + bv, acc[1][2] + bv, acc[1][3] + bv};   // keys 16 + 4g + r (only key 16 is real)
@@ -345,7 +355,7 @@ __device__ __forceinline__ void wps_layer_fwd(const InfLayer& w, const T* W, con
       }
     float4 vv[2][4] WPS_Z;  // V in T layout: token tile mt, feature tile dt
 #pragma unroll
-    for (int mt = 0; mt < WPS_NMT; ++mt)
+    for (int mt = 0; mt < NMT; ++mt)
 #pragma unroll
       for (int dt = 0; dt < 4; ++dt) {
         f32x4 t = zero4();
@@ -353,23 +363,23 @@ __device__ __forceinline__ void wps_layer_fwd(const InfLayer& w, const T* W, con
         vv[mt][dt] = f4(t);
       }
 #pragma unroll
-    for (int mt = 0; mt < WPS_NMT; ++mt)
+    for (int mt = 0; mt < NMT; ++mt)
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) kp->va[mt][ks] = wps_frag<T>(vv[mt][2 * ks], vv[mt][2 * ks + 1]);
   }
   // ---- attention: S^T tiles (lane = query, registers = keys), softmax in registers, P V
   float4 c[2][4] WPS_Z;
 #pragma unroll
-  for (int qt = 0; qt < WPS_NMT; ++qt) {
+  for (int qt = 0; qt < NMT; ++qt) {
     f32x4 s[2] = {zero4(), zero4()};
 #pragma unroll
-    for (int kt = 0; kt < WPS_NMT; ++kt)
+    for (int kt = 0; kt < NMT; ++kt)
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) mma_k32(s[kt], ka[kt][ks], qa[qt][ks]);  // s[kt][r] = q[16 qt + fr] . k[16 kt + 4g + r]
     float pv[2][4] WPS_Z;
     float mx = -INFINITY;
 #pragma unroll
-    for (int kt = 0; kt < WPS_NMT; ++kt)
+    for (int kt = 0; kt < NMT; ++kt)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         pv[kt][r] = wps_key_ok<VIS>(kt * 16 + qr + r) ? s[kt][r] * 0.125f : -INFINITY;
@@ -378,7 +388,7 @@ __device__ __forceinline__ void wps_layer_fwd(const InfLayer& w, const T* W, con
     mx = xmax(mx);
     float sum = 0.f;
 #pragma unroll
-    for (int kt = 0; kt < WPS_NMT; ++kt)
+    for (int kt = 0; kt < NMT; ++kt)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         pv[kt][r] = wps_key_ok<VIS>(kt * 16 + qr + r) ? expf(pv[kt][r] - mx) : 0.f;
@@ -386,7 +396,7 @@ __device__ __forceinline__ void wps_layer_fwd(const InfLayer& w, const T* W, con
       }
     const float inv = 1.f / xsum(sum);
 #pragma unroll
-    for (int kt = 0; kt < WPS_NMT; ++kt)
+    for (int kt = 0; kt < NMT; ++kt)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         pv[kt][r] *= inv;
@@ -409,38 +419,38 @@ __device__ __forceinline__ void wps_layer_fwd(const InfLayer& w, const T* W, con
   {
     frag_t ca[2][2] WPS_Z;
 #pragma unroll
-    for (int mt = 0; mt < WPS_NMT; ++mt)
+    for (int mt = 0; mt < NMT; ++mt)
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) ca[mt][ks] = wps_frag<T>(c[mt][2 * ks], c[mt][2 * ks + 1]);
     if constexpr (KEEP) {
 #pragma unroll
-      for (int ks = 0; ks < 2; ++ks) wps_store_opnd<T>(*wo, WPS_T_CTX / 2 + ks, ca[0][ks], ca[1][ks], E0, E1, lane);
+      for (int ks = 0; ks < 2; ++ks) wps_store_opnd<T, NMT>(*wo, WPS_T_CTX / 2 + ks, ca[0][ks], ca[1][ks], E0, E1, lane);
     }
 #pragma unroll
     for (int nt = 0; nt < 4; ++nt) {
       f32x4 acc[2] = {zero4(), zero4()};
-      wps_gemm_t<T, LDSW, 2>(acc, W + WPS_OFF_WO, nt, ca, lane);
+      wps_gemm_t<T, LDSW, 2, NMT>(acc, W + WPS_OFF_WO, nt, ca, lane);
       const float4 bb = *reinterpret_cast<const float4*>(prm + WPS_P_BO + nt * 16 + qr);
 #pragma unroll
-      for (int mt = 0; mt < WPS_NMT; ++mt)
+      for (int mt = 0; mt < NMT; ++mt)
         z[mt][nt] = float4{xr[mt][nt].x + acc[mt][0] + bb.x, xr[mt][nt].y + acc[mt][1] + bb.y, xr[mt][nt].z + acc[mt][2] + bb.z,
                            xr[mt][nt].w + acc[mt][3] + bb.w};
     }
   }
   float rs1[2] WPS_Z;
-  wps_ln(z, rs1);
+  wps_ln<NMT>(z, rs1);
   float4 x1[2][4] WPS_Z;
 #pragma unroll
   for (int nt = 0; nt < 4; ++nt) {
     const float4 gg = *reinterpret_cast<const float4*>(prm + WPS_P_G1 + nt * 16 + qr);
     const float4 be = *reinterpret_cast<const float4*>(prm + WPS_P_BE1 + nt * 16 + qr);
 #pragma unroll
-    for (int mt = 0; mt < WPS_NMT; ++mt) {
+    for (int mt = 0; mt < NMT; ++mt) {
       const float4 xh = z[mt][nt];
       if constexpr (KEEP) kp->xh1[mt][nt] = xh;
       x1[mt][nt] = float4{fmaf(xh.x, gg.x, be.x), fmaf(xh.y, gg.y, be.y), fmaf(xh.z, gg.z, be.z), fmaf(xh.w, gg.w, be.w)};
       if (ok[mt]) {
-        const int64_t o = (row0 + mt * 16 + fr) * TD + nt * 16 + qr;
+        const int64_t o = (row0 + ROFF + mt * 16 + fr) * TD + nt * 16 + qr;
         if (TAPS && w.s_xh1 != nullptr) *reinterpret_cast<float4*>(w.s_xh1 + o) = xh;
         if (TAPS && w.s_x1 != nullptr) st4(reinterpret_cast<T*>(w.s_x1) + o, x1[mt][nt].x, x1[mt][nt].y, x1[mt][nt].z, x1[mt][nt].w);
       }
@@ -449,24 +459,24 @@ __device__ __forceinline__ void wps_layer_fwd(const InfLayer& w, const T* W, con
   if constexpr (KEEP) { kp->rs1[0] = rs1[0]; kp->rs1[1] = rs1[1]; }
   if (TAPS && w.s_rs1 != nullptr && g == 0) {
 #pragma unroll
-    for (int mt = 0; mt < WPS_NMT; ++mt)
+    for (int mt = 0; mt < NMT; ++mt)
       if (ok[mt]) w.s_rs1[row0 + mt * 16 + fr] = rs1[mt];
   }
   // ---- FFN, 32 hidden features at a time: h = relu(W1 x1 + b1) is the B fragment of the linear2 step over those features
   {
     frag_t x1a[2][2] WPS_Z;
 #pragma unroll
-    for (int mt = 0; mt < WPS_NMT; ++mt)
+    for (int mt = 0; mt < NMT; ++mt)
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) x1a[mt][ks] = wps_frag<T>(x1[mt][2 * ks], x1[mt][2 * ks + 1]);
     if constexpr (KEEP) {
 #pragma unroll
-      for (int ks = 0; ks < 2; ++ks) wps_store_opnd<T>(*wo, WPS_T_X1 / 2 + ks, x1a[0][ks], x1a[1][ks], E0, E1, lane);
+      for (int ks = 0; ks < 2; ++ks) wps_store_opnd<T, NMT>(*wo, WPS_T_X1 / 2 + ks, x1a[0][ks], x1a[1][ks], E0, E1, lane);
     }
     f32x4 z2[2][4] WPS_Z;
     unsigned long long fm[2] = {0ull, 0ull};
 #pragma unroll
-    for (int mt = 0; mt < WPS_NMT; ++mt)
+    for (int mt = 0; mt < NMT; ++mt)
 #pragma unroll
       for (int nt = 0; nt < 4; ++nt) z2[mt][nt] = zero4();
 #pragma unroll
@@ -476,10 +486,10 @@ __device__ __forceinline__ void wps_layer_fwd(const InfLayer& w, const T* W, con
       for (int h = 0; h < 2; ++h) {
         const int tile = 2 * ch + h;
         f32x4 acc[2] = {zero4(), zero4()};
-        wps_gemm_t<T, LDSW, 2>(acc, W + WPS_OFF_W1, tile, x1a, lane);
+        wps_gemm_t<T, LDSW, 2, NMT>(acc, W + WPS_OFF_W1, tile, x1a, lane);
         const float4 bb = *reinterpret_cast<const float4*>(prm + WPS_P_B1 + tile * 16 + qr);
 #pragma unroll
-        for (int mt = 0; mt < WPS_NMT; ++mt) {
+        for (int mt = 0; mt < NMT; ++mt) {
           hh[mt][h] = float4{fmaxf(acc[mt][0] + bb.x, 0.f), fmaxf(acc[mt][1] + bb.y, 0.f), fmaxf(acc[mt][2] + bb.z, 0.f),
                              fmaxf(acc[mt][3] + bb.w, 0.f)};
           if constexpr (KEEP) {
@@ -495,13 +505,13 @@ __device__ __forceinline__ void wps_layer_fwd(const InfLayer& w, const T* W, con
       }
       frag_t fa[2] WPS_Z;
 #pragma unroll
-      for (int mt = 0; mt < WPS_NMT; ++mt) fa[mt] = wps_frag<T>(hh[mt][0], hh[mt][1]);
-      if constexpr (KEEP) wps_store_opnd<T>(*wo, WPS_T_F / 2 + ch, fa[0], fa[1], E0, E1, lane);
+      for (int mt = 0; mt < NMT; ++mt) fa[mt] = wps_frag<T>(hh[mt][0], hh[mt][1]);
+      if constexpr (KEEP) wps_store_opnd<T, NMT>(*wo, WPS_T_F / 2 + ch, fa[0], fa[1], E0, E1, lane);
 #pragma unroll
       for (int nt = 0; nt < 4; ++nt) {
         const frag_t fw = wps_w<T, LDSW>(W + WPS_OFF_W2, nt * 8 + ch, lane);
 #pragma unroll
-        for (int mt = 0; mt < WPS_NMT; ++mt) mma_k32(z2[mt][nt], fw, fa[mt]);
+        for (int mt = 0; mt < NMT; ++mt) mma_k32(z2[mt][nt], fw, fa[mt]);
       }
     }
     if constexpr (KEEP) { kp->fm[0] = fm[0]; kp->fm[1] = fm[1]; }
@@ -509,20 +519,20 @@ __device__ __forceinline__ void wps_layer_fwd(const InfLayer& w, const T* W, con
     for (int nt = 0; nt < 4; ++nt) {
       const float4 bb = *reinterpret_cast<const float4*>(prm + WPS_P_B2 + nt * 16 + qr);
 #pragma unroll
-      for (int mt = 0; mt < WPS_NMT; ++mt)
+      for (int mt = 0; mt < NMT; ++mt)
         z[mt][nt] = float4{x1[mt][nt].x + z2[mt][nt][0] + bb.x, x1[mt][nt].y + z2[mt][nt][1] + bb.y, x1[mt][nt].z + z2[mt][nt][2] + bb.z,
                            x1[mt][nt].w + z2[mt][nt][3] + bb.w};
     }
   }
   float rs2[2] WPS_Z;
-  wps_ln(z, rs2);
+  wps_ln<NMT>(z, rs2);
   if constexpr (KEEP) { kp->rs2[0] = rs2[0]; kp->rs2[1] = rs2[1]; }
 #pragma unroll
   for (int nt = 0; nt < 4; ++nt) {
     const float4 gg = *reinterpret_cast<const float4*>(prm + WPS_P_G2 + nt * 16 + qr);
     const float4 be = *reinterpret_cast<const float4*>(prm + WPS_P_BE2 + nt * 16 + qr);
 #pragma unroll
-    for (int mt = 0; mt < WPS_NMT; ++mt) {
+    for (int mt = 0; mt < NMT; ++mt) {
       const float4 xh = z[mt][nt];
       if constexpr (KEEP) kp->xh2[mt][nt] = xh;
       // rows past the sample's 17th token stay exactly zero: they are the next layer's padding rows
@@ -530,7 +540,7 @@ __device__ __forceinline__ void wps_layer_fwd(const InfLayer& w, const T* W, con
       xo[mt][nt] = live_row ? float4{fmaf(xh.x, gg.x, be.x), fmaf(xh.y, gg.y, be.y), fmaf(xh.z, gg.z, be.z), fmaf(xh.w, gg.w, be.w)}
                             : float4{0.f, 0.f, 0.f, 0.f};
       if (ok[mt]) {
-        const int64_t o = (row0 + mt * 16 + fr) * TD + nt * 16 + qr;
+        const int64_t o = (row0 + ROFF + mt * 16 + fr) * TD + nt * 16 + qr;
         if (TAPS && w.s_xh2 != nullptr) *reinterpret_cast<float4*>(w.s_xh2 + o) = xh;
         if (w.xout != nullptr) *reinterpret_cast<float4*>(w.xout + o) = xo[mt][nt];
       }
@@ -538,7 +548,7 @@ __device__ __forceinline__ void wps_layer_fwd(const InfLayer& w, const T* W, con
   }
   if (TAPS && w.s_rs2 != nullptr && g == 0) {
 #pragma unroll
-    for (int mt = 0; mt < WPS_NMT; ++mt)
+    for (int mt = 0; mt < NMT; ++mt)
       if (ok[mt]) w.s_rs2[row0 + mt * 16 + fr] = rs2[mt];
   }
 }
@@ -575,15 +585,18 @@ __device__ __forceinline__ WpsPrm wps_prm_of(const InfLayer& w) {
 
 // The layer input rows of one sample, row-major fp32 [17][64] -> T layout registers (rows >= 17 and dead samples: zeros)
 // ZERO0: row 0 reads as zeros whatever the buffer holds (the vision-only Transformer's dummy row, see wps_layer_fwd)
-template <bool ZERO0 = false>
+// VIS = 2 (native 16 tokens): tile 0 row fr <- memory row 1 + fr, tile 1 zero
+template <int VIS = 0>
 __device__ __forceinline__ void wps_load_rows(const float* __restrict__ xg, int lane, const bool (&ok)[2], float4 (&xr)[2][4]) {
   const int fr = lane & 15, qr = (lane >> 4) * 4;
 #pragma unroll
   for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
     for (int nt = 0; nt < 4; ++nt) {
-      const float4 v = *reinterpret_cast<const float4*>(xg + (ok[mt] ? mt * 16 + fr : 0) * TD + nt * 16 + qr);
-      const bool keep = ok[mt] && !(ZERO0 && mt == 0 && fr == 0);
+      if (VIS == 2 && mt == 1) { xr[mt][nt] = float4{0.f, 0.f, 0.f, 0.f}; continue; }
+      const int r = VIS == 2 ? 1 + fr : mt * 16 + fr;
+      const float4 v = *reinterpret_cast<const float4*>(xg + (ok[mt] ? r : 0) * TD + nt * 16 + qr);
+      const bool keep = ok[mt] && !(VIS == 1 && mt == 0 && fr == 0);
       xr[mt][nt] = keep ? v : float4{0.f, 0.f, 0.f, 0.f};
     }
 }
@@ -591,7 +604,7 @@ __device__ __forceinline__ void wps_load_rows(const float* __restrict__ xg, int 
 // Training forward of the transformer stack (+ pooled heads): NL layers for WPS_WPB samples per block, one wave each.
 // stk.l[l].n[0].win points at the layer's fragment-order weight block (PK_FRAGP packs, adjacent); the head packs are the
 // row-major ones of the block-cooperative kernel (the heads run cooperatively: 4 samples = one MFMA row tile).
-template <typename T, bool HEAD, int NL, bool TAPS, bool VIS = false>
+template <typename T, bool HEAD, int NL, bool TAPS, int VIS = 0>
 __global__ __launch_bounds__(256) WPS_EU_ATTR void wps_layer_fwd_kernel(InfLayerStack stk, InfHeadPair hd, int n) {
   typedef WpsFwdLds<T> LY;
   typedef typename Frag<T>::type frag_t;
@@ -606,7 +619,7 @@ __global__ __launch_bounds__(256) WPS_EU_ATTR void wps_layer_fwd_kernel(InfLayer
   const bool live = smp < n;
   const int64_t srow = live ? smp : 0;
   const int64_t row0 = srow * NTOK;
-  const bool ok[2] = {live, live && fr == 0};
+  const bool ok[2] = {live, live && fr == 0 && VIS != 2};
   WPS_STAMP(0);
   {  // layer 0's weights start their trip first
     const WpsPrm pp = wps_prm_of(stk.l[0].n[0]);
@@ -627,7 +640,7 @@ __global__ __launch_bounds__(256) WPS_EU_ATTR void wps_layer_fwd_kernel(InfLayer
     __builtin_amdgcn_s_waitcnt(0);
     __syncthreads();
     WPS_STAMP(8 * l + 7);
-    float4 xo[2][4];
+    float4 xo[2][4] WPS_Z;
     wps_layer_fwd<T, LDSW, false, TAPS, VIS>(w, LDSW ? wl : reinterpret_cast<const T*>(w.win), prm, xr, lane, ok, row0, srow, xo,
                                              (const WpsOut*)nullptr, E0, E1, (WpsKeep<T>*)nullptr, 8 * l);
     WPS_STAMP(8 * l + 6);
@@ -660,7 +673,7 @@ __global__ __launch_bounds__(256) WPS_EU_ATTR void wps_layer_fwd_kernel(InfLayer
 #pragma unroll
     for (int nt = 0; nt < 4; ++nt) {
       // token 0 sits in lane fr = 0 of tile 0; tokens 1..15 in the other lanes of tile 0, token 16 in lane fr = 0 of tile 1
-      const float4 m = fr == 0 ? xr[1][nt] : xr[0][nt];
+      const float4 m = (VIS != 2 && fr == 0) ? xr[1][nt] : xr[0][nt];  // (native 16: token fr in lane fr)
       // max_pool=True (nets.py:1022-1023, 886-887; round 5): the max over the same 16 tokens instead of their mean
       const float4 mv = h.max_pool ? float4{rowmax16(m.x), rowmax16(m.y), rowmax16(m.z), rowmax16(m.w)}
                                    : float4{rowsum16(m.x) * (1.f / 16.f), rowsum16(m.y) * (1.f / 16.f), rowsum16(m.z) * (1.f / 16.f),
@@ -731,7 +744,7 @@ struct WpsBwdStack { WpsBwdLayer l[2]; };  // l[0] = the upper layer
 // Backward of one layer of one sample by one wave. dy (T layout, fp32; rows >= 17 and dead samples exactly zero) is replaced by
 // the gradient w.r.t. the layer input. Wt: the transposed weight block. lnred: this wave's [4][64] LDS slots for the LayerNorm
 // parameter gradients.
-template <typename T, bool LDSW, bool TAPS>
+template <typename T, bool LDSW, bool TAPS, int NMT = WPS_NMT_DEF>
 __device__ __forceinline__ void wps_layer_bwd(const WpsBwdLayer& w, const T* Wt, const float* prm, const WpsKeep<T>& K, float4 (&dy)[2][4],
                                               int lane, const bool (&ok)[2], int64_t row0, const WpsOut& wo, const typename Frag<T>::type& E0,
                                               const typename Frag<T>::type& E1, float* lnred) {
@@ -742,7 +755,9 @@ __device__ __forceinline__ void wps_layer_bwd(const WpsBwdLayer& w, const T* Wt,
     // dz = rstd (g dy - mean(g dy) - xhat mean(g dy xhat)); dgamma / dbeta partials of this sample -> LDS
 #pragma unroll
     for (int nt = 0; nt < 4; ++nt) {
-      const float4 a = d[0][nt], b = d[1][nt], xa_ = xh[0][nt], xb_ = xh[1][nt];
+      const float4 a = d[0][nt], xa_ = xh[0][nt];
+      float4 b = {0.f, 0.f, 0.f, 0.f}, xb_ = {0.f, 0.f, 0.f, 0.f};
+      if constexpr (NMT == 2) { b = d[1][nt]; xb_ = xh[1][nt]; }
       const float4 sg = {rowsum16(fmaf(a.x, xa_.x, b.x * xb_.x)), rowsum16(fmaf(a.y, xa_.y, b.y * xb_.y)),
                          rowsum16(fmaf(a.z, xa_.z, b.z * xb_.z)), rowsum16(fmaf(a.w, xa_.w, b.w * xb_.w))};
       const float4 sb = {rowsum16(a.x + b.x), rowsum16(a.y + b.y), rowsum16(a.z + b.z), rowsum16(a.w + b.w)};
@@ -752,7 +767,7 @@ __device__ __forceinline__ void wps_layer_bwd(const WpsBwdLayer& w, const T* Wt,
       *reinterpret_cast<float4*>(red_b + nt * 16 + qr) = sb;
     }
 #pragma unroll
-    for (int mt = 0; mt < WPS_NMT; ++mt) {
+    for (int mt = 0; mt < NMT; ++mt) {
       float4 dxh[4];
       float c1 = 0.f, c2 = 0.f;
 #pragma unroll
@@ -775,24 +790,24 @@ __device__ __forceinline__ void wps_layer_bwd(const WpsBwdLayer& w, const T* Wt,
   auto tap_rows = [&](void* dst, int ld, int col0, const float4 (&v)[2]) {  // test tap: 4 features of both row tiles, row-major T
     if (!TAPS || dst == nullptr) return;
 #pragma unroll
-    for (int mt = 0; mt < WPS_NMT; ++mt)
+    for (int mt = 0; mt < NMT; ++mt)
       if (ok[mt]) st4(reinterpret_cast<T*>(dst) + (row0 + mt * 16 + fr) * ld + col0 + qr, v[mt].x, v[mt].y, v[mt].z, v[mt].w);
   };
   // ---- norm2 backward: dy -> dz2
   ln_bwd(dy, K.xh2, K.rs2, WPS_P_G2, lnred, lnred + TD);
   frag_t dza[2][2] WPS_Z;
 #pragma unroll
-  for (int mt = 0; mt < WPS_NMT; ++mt)
+  for (int mt = 0; mt < NMT; ++mt)
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) dza[mt][ks] = wps_frag<T>(dy[mt][2 * ks], dy[mt][2 * ks + 1]);
 #pragma unroll
-  for (int ks = 0; ks < 2; ++ks) wps_store_opnd<T>(wo, WPS_T_DZ2 / 2 + ks, dza[0][ks], dza[1][ks], E0, E1, lane);
+  for (int ks = 0; ks < 2; ++ks) wps_store_opnd<T, NMT>(wo, WPS_T_DZ2 / 2 + ks, dza[0][ks], dza[1][ks], E0, E1, lane);
 #pragma unroll
   for (int nt = 0; nt < 4; ++nt) { const float4 v[2] = {dy[0][nt], dy[1][nt]}; tap_rows(w.t_dz2, TD, nt * 16, v); }
   // ---- df = (dz2 W2) o [f > 0], 32 hidden features at a time, each chunk feeding dx1 += df W1
   f32x4 dx1[2][4] WPS_Z;
 #pragma unroll
-  for (int mt = 0; mt < WPS_NMT; ++mt)
+  for (int mt = 0; mt < NMT; ++mt)
 #pragma unroll
     for (int nt = 0; nt < 4; ++nt) dx1[mt][nt] = zero4();
 #pragma unroll
@@ -802,9 +817,9 @@ __device__ __forceinline__ void wps_layer_bwd(const WpsBwdLayer& w, const T* Wt,
     for (int h = 0; h < 2; ++h) {
       const int tile = 2 * ch + h;
       f32x4 acc[2] = {zero4(), zero4()};
-      wps_gemm_t<T, LDSW, 2>(acc, Wt + WPS_OFF_W2, tile, dza, lane);  // W2^T: rows = hidden features, k = the 64 outputs
+      wps_gemm_t<T, LDSW, 2, NMT>(acc, Wt + WPS_OFF_W2, tile, dza, lane);  // W2^T: rows = hidden features, k = the 64 outputs
 #pragma unroll
-      for (int mt = 0; mt < WPS_NMT; ++mt) {
+      for (int mt = 0; mt < NMT; ++mt) {
         const unsigned b4 = (unsigned)(K.fm[mt] >> (tile * 4)) & 15u;
         dd[mt][h] = float4{(b4 & 1u) ? acc[mt][0] : 0.f, (b4 & 2u) ? acc[mt][1] : 0.f, (b4 & 4u) ? acc[mt][2] : 0.f,
                            (b4 & 8u) ? acc[mt][3] : 0.f};
@@ -814,29 +829,29 @@ __device__ __forceinline__ void wps_layer_bwd(const WpsBwdLayer& w, const T* Wt,
     }
     frag_t dfa[2] WPS_Z;
 #pragma unroll
-    for (int mt = 0; mt < WPS_NMT; ++mt) dfa[mt] = wps_frag<T>(dd[mt][0], dd[mt][1]);
-    wps_store_opnd<T>(wo, WPS_T_DF / 2 + ch, dfa[0], dfa[1], E0, E1, lane);
+    for (int mt = 0; mt < NMT; ++mt) dfa[mt] = wps_frag<T>(dd[mt][0], dd[mt][1]);
+    wps_store_opnd<T, NMT>(wo, WPS_T_DF / 2 + ch, dfa[0], dfa[1], E0, E1, lane);
 #pragma unroll
     for (int nt = 0; nt < 4; ++nt) {
       const frag_t fw = wps_w<T, LDSW>(Wt + WPS_OFF_W1, nt * 8 + ch, lane);  // W1^T: rows = the 64 inputs, k = hidden features
 #pragma unroll
-      for (int mt = 0; mt < WPS_NMT; ++mt) mma_k32(dx1[mt][nt], fw, dfa[mt]);
+      for (int mt = 0; mt < NMT; ++mt) mma_k32(dx1[mt][nt], fw, dfa[mt]);
     }
   }
   float4 d1[2][4] WPS_Z;
 #pragma unroll
-  for (int mt = 0; mt < WPS_NMT; ++mt)
+  for (int mt = 0; mt < NMT; ++mt)
 #pragma unroll
     for (int nt = 0; nt < 4; ++nt) d1[mt][nt] = f4add(dx1[mt][nt], dy[mt][nt]);
   // ---- norm1 backward: dx1 -> dz1
   ln_bwd(d1, K.xh1, K.rs1, WPS_P_G1, lnred + 2 * TD, lnred + 3 * TD);
   frag_t dz1a[2][2] WPS_Z;
 #pragma unroll
-  for (int mt = 0; mt < WPS_NMT; ++mt)
+  for (int mt = 0; mt < NMT; ++mt)
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) dz1a[mt][ks] = wps_frag<T>(d1[mt][2 * ks], d1[mt][2 * ks + 1]);
 #pragma unroll
-  for (int ks = 0; ks < 2; ++ks) wps_store_opnd<T>(wo, WPS_T_DZ1 / 2 + ks, dz1a[0][ks], dz1a[1][ks], E0, E1, lane);
+  for (int ks = 0; ks < 2; ++ks) wps_store_opnd<T, NMT>(wo, WPS_T_DZ1 / 2 + ks, dz1a[0][ks], dz1a[1][ks], E0, E1, lane);
 #pragma unroll
   for (int nt = 0; nt < 4; ++nt) { const float4 v[2] = {d1[0][nt], d1[1][nt]}; tap_rows(w.t_dz1, TD, nt * 16, v); }
   // ---- dctx = dz1 Wo  (an operand of the attention products only: kept rounded to T)
@@ -846,33 +861,33 @@ __device__ __forceinline__ void wps_layer_bwd(const WpsBwdLayer& w, const T* Wt,
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt) {
       f32x4 acc[2] = {zero4(), zero4()};
-      wps_gemm_t<T, LDSW, 2>(acc, Wt + WPS_OFF_WO, dt, dz1a, lane);
+      wps_gemm_t<T, LDSW, 2, NMT>(acc, Wt + WPS_OFF_WO, dt, dz1a, lane);
       dc[0][dt] = f4(acc[0]);
       dc[1][dt] = f4(acc[1]);
     }
 #pragma unroll
-    for (int mt = 0; mt < WPS_NMT; ++mt)
+    for (int mt = 0; mt < NMT; ++mt)
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) dca[mt][ks] = wps_frag<T>(dc[mt][2 * ks], dc[mt][2 * ks + 1]);
   }
   // ---- attention backward: dP = dctx V^T ; dS = P o (dP - rowsum(P o dP)) ; dV = P^T dctx ; dQ = dS K / 8 ; dK = dS^T Q / 8
   frag_t dsa[2] WPS_Z, pa[2] WPS_Z;
 #pragma unroll
-  for (int qt = 0; qt < WPS_NMT; ++qt) {
+  for (int qt = 0; qt < NMT; ++qt) {
     f32x4 dp[2] = {zero4(), zero4()};
 #pragma unroll
-    for (int kt = 0; kt < WPS_NMT; ++kt)
+    for (int kt = 0; kt < NMT; ++kt)
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) mma_k32(dp[kt], K.va[kt][ks], dca[qt][ks]);  // dp[kt][r] = dctx[16 qt + fr] . v[16 kt + 4g + r]
     float rd = 0.f;
 #pragma unroll
-    for (int kt = 0; kt < WPS_NMT; ++kt)
+    for (int kt = 0; kt < NMT; ++kt)
 #pragma unroll
       for (int r = 0; r < 4; ++r) rd = fmaf(K.p[qt][kt][r], kt * 16 + qr + r < NTOK ? dp[kt][r] : 0.f, rd);
     rd = xsum(rd);
     float ds[2][4] WPS_Z;
 #pragma unroll
-    for (int kt = 0; kt < WPS_NMT; ++kt)
+    for (int kt = 0; kt < NMT; ++kt)
 #pragma unroll
       for (int r = 0; r < 4; ++r) ds[kt][r] = kt * 16 + qr + r < NTOK ? K.p[qt][kt][r] * (dp[kt][r] - rd) : 0.f;
     dsa[qt] = wps_frag<T>(float4{ds[0][0], ds[0][1], ds[0][2], ds[0][3]}, float4{ds[1][0], ds[1][1], ds[1][2], ds[1][3]});
@@ -881,7 +896,7 @@ __device__ __forceinline__ void wps_layer_bwd(const WpsBwdLayer& w, const T* Wt,
   }
   frag_t dsT[2] WPS_Z, pT[2] WPS_Z, dcT[4];
 #pragma unroll
-  for (int kt = 0; kt < WPS_NMT; ++kt) {
+  for (int kt = 0; kt < NMT; ++kt) {
     dsT[kt] = wps_tr<T>(dsa[0], dsa[1], kt ? E1 : E0);  // rows = keys of tile kt, slots = queries
     pT[kt] = wps_tr<T>(pa[0], pa[1], kt ? E1 : E0);
   }
@@ -893,7 +908,7 @@ __device__ __forceinline__ void wps_layer_bwd(const WpsBwdLayer& w, const T* Wt,
   {
     float4 dq[2][4] WPS_Z, dk[2][4] WPS_Z, dv[2][4] WPS_Z;
 #pragma unroll
-    for (int tt = 0; tt < WPS_NMT; ++tt)
+    for (int tt = 0; tt < NMT; ++tt)
 #pragma unroll
       for (int dt = 0; dt < 4; ++dt) {
         f32x4 a = zero4(), b = zero4(), c = zero4();
@@ -911,7 +926,7 @@ __device__ __forceinline__ void wps_layer_bwd(const WpsBwdLayer& w, const T* Wt,
         }
       }
 #pragma unroll
-    for (int mt = 0; mt < WPS_NMT; ++mt)
+    for (int mt = 0; mt < NMT; ++mt)
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) {
         dqa[mt][ks] = wps_frag<T>(dq[mt][2 * ks], dq[mt][2 * ks + 1]);
@@ -920,14 +935,14 @@ __device__ __forceinline__ void wps_layer_bwd(const WpsBwdLayer& w, const T* Wt,
       }
   }
 #pragma unroll
-  for (int ks = 0; ks < 6; ++ks) wps_store_opnd<T>(wo, WPS_T_DQKV / 2 + ks, dqa[0][ks], dqa[1][ks], E0, E1, lane);
+  for (int ks = 0; ks < 6; ++ks) wps_store_opnd<T, NMT>(wo, WPS_T_DQKV / 2 + ks, dqa[0][ks], dqa[1][ks], E0, E1, lane);
   // ---- dx_in = dz1 + dqkv Win
 #pragma unroll
   for (int nt = 0; nt < 4; ++nt) {
     f32x4 acc[2] = {zero4(), zero4()};
-    wps_gemm_t<T, LDSW, 6>(acc, Wt, nt, dqa, lane);  // Win^T: rows = the 64 inputs, k = the 192 outputs
+    wps_gemm_t<T, LDSW, 6, NMT>(acc, Wt, nt, dqa, lane);  // Win^T: rows = the 64 inputs, k = the 192 outputs
 #pragma unroll
-    for (int mt = 0; mt < WPS_NMT; ++mt) dy[mt][nt] = f4add(acc[mt], d1[mt][nt]);
+    for (int mt = 0; mt < NMT; ++mt) dy[mt][nt] = f4add(acc[mt], d1[mt][nt]);
   }
 }
 
@@ -1139,7 +1154,7 @@ __global__ __launch_bounds__(NWAVES * 64) void actor_loss_heads_kernel(ActorArgs
 struct WpsTailExtra { const void* wupt_f; const float* dpool; const float* xlast; };  // wupt_f: up-conv's transposed weight as a k-permuted fragment pack
 // un-pooling weights of a sample's depth tokens (lane fr: token fr of tile 0, lane fr = 0 of tile 1: token 16), per feature column:
 // 1/16 for the mean; for the max 1 on the first token that holds the maximum of its column, 0 elsewhere
-template <bool VIS>
+template <int VIS>
 __device__ __forceinline__ void wps_unpool_weights(const float* xlast_rows, int lane, const bool (&ok)[2], float4 (&w0)[4]) {
   const int fr = lane & 15;
   if (xlast_rows == nullptr) {
@@ -1149,10 +1164,10 @@ __device__ __forceinline__ void wps_unpool_weights(const float* xlast_rows, int 
   }
   float4 xl[2][4];
   wps_load_rows<VIS>(xlast_rows, lane, ok, xl);
-  const int idx = fr == 0 ? 16 : fr;  // the depth token this lane stands for in the row-wide reductions below
+  const int idx = VIS == 2 ? fr : (fr == 0 ? 16 : fr);  // the depth token this lane stands for in the row-wide reductions below
 #pragma unroll
   for (int nt = 0; nt < 4; ++nt) {
-    const float4 m = fr == 0 ? xl[1][nt] : xl[0][nt];
+    const float4 m = (VIS != 2 && fr == 0) ? xl[1][nt] : xl[0][nt];
     const float mx[4] = {rowmax16(m.x), rowmax16(m.y), rowmax16(m.z), rowmax16(m.w)};
     const float mv[4] = {m.x, m.y, m.z, m.w};
     float wv[4];
@@ -1166,8 +1181,10 @@ __device__ __forceinline__ void wps_unpool_weights(const float* xlast_rows, int 
     w0[nt] = wq;
   }
 }
-template <typename T, int NL, bool TAPS, bool VIS = false, bool HEAD_IN = true, bool TOK0_IN = true>
+template <typename T, int NL, bool TAPS, int VIS = 0, bool HEAD_IN = true, bool TOK0_IN = true>
 __global__ __launch_bounds__(256) WPS_EU_ATTR void wps_layer_bwd_kernel(WpsBwdStack stk, BwdHead hd, BwdTail tl, WpsTailExtra tx, int n) {
+  constexpr int NMT = VIS == 2 ? 1 : WPS_NMT_DEF;
+  constexpr int ROFF = VIS == 2 ? 1 : 0;  // (see wps_layer_fwd)
   // VIS (template parameter): see wps_layer_fwd — hd.w0t is then the [128][256] pack whose rows 0..63 are zero (the dummy
   // row's un-pooled gradient is exactly zero), and the TAIL ends after the up-conv data-grad (there is no proprio branch)
   typedef WpsBwdLds<T> LY;
@@ -1185,7 +1202,7 @@ __global__ __launch_bounds__(256) WPS_EU_ATTR void wps_layer_bwd_kernel(WpsBwdSt
   const bool live = smp < n;
   const int64_t srow = live ? smp : 0;
   const int64_t row0 = srow * NTOK;
-  const bool ok[2] = {live, live && fr == 0};
+  const bool ok[2] = {live, live && fr == 0 && VIS != 2};
   const int nt4[4] = {wave * 4, wave * 4 + 1, wave * 4 + 2, wave * 4 + 3};
   const frag_t E0 = wps_sel<T>(0, lane), E1 = wps_sel<T>(1, lane);
   float4 dy[2][4];
@@ -1198,7 +1215,7 @@ __global__ __launch_bounds__(256) WPS_EU_ATTR void wps_layer_bwd_kernel(WpsBwdSt
     for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
       for (int nt = 0; nt < 4; ++nt) {
-        const bool tok0 = mt == 0 && fr == 0;
+        const bool tok0 = VIS != 2 && mt == 0 && fr == 0;
         const float4 v = *reinterpret_cast<const float4*>(tx.dpool + srow * (2 * TD) + (tok0 ? 0 : TD) + nt * 16 + qr);
         const float4 sc = tok0 ? float4{1.f, 1.f, 1.f, 1.f} : upw[nt];
         dy[mt][nt] = ok[mt] ? float4{v.x * sc.x, v.y * sc.y, v.z * sc.z, v.w * sc.w} : float4{0.f, 0.f, 0.f, 0.f};
@@ -1273,7 +1290,7 @@ __global__ __launch_bounds__(256) WPS_EU_ATTR void wps_layer_bwd_kernel(WpsBwdSt
     for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
       for (int nt = 0; nt < 4; ++nt) {
-        const bool tok0 = mt == 0 && fr == 0;
+        const bool tok0 = VIS != 2 && mt == 0 && fr == 0;
         const float4 v = *reinterpret_cast<const float4*>(dpool + wave * LY::LDP + (tok0 ? 0 : TD) + nt * 16 + qr);
         const float4 sc = tok0 ? float4{1.f, 1.f, 1.f, 1.f} : upw[nt];
         dy[mt][nt] = ok[mt] ? float4{v.x * sc.x, v.y * sc.y, v.z * sc.z, v.w * sc.w} : float4{0.f, 0.f, 0.f, 0.f};
@@ -1302,7 +1319,7 @@ __global__ __launch_bounds__(256) WPS_EU_ATTR void wps_layer_bwd_kernel(WpsBwdSt
       none.xin = nullptr; none.xout = nullptr;
       none.s_qkv = none.s_P = none.s_xh1 = none.s_rs1 = none.s_xh2 = none.s_rs2 = nullptr;
       none.s_xin = none.s_ctx = none.s_x1 = none.s_f = nullptr;
-      float4 xo[2][4];
+      float4 xo[2][4] WPS_Z;
       wps_layer_fwd<T, LDSW, true, false, VIS>(none, LDSW ? wl : reinterpret_cast<const T*>(w.w), prm, xr, lane, ok, row0, srow, xo, &wo, E0, E1, &K);
     }
     WPS_STAMP(35 + 8 * l);
@@ -1312,7 +1329,7 @@ __global__ __launch_bounds__(256) WPS_EU_ATTR void wps_layer_bwd_kernel(WpsBwdSt
     __builtin_amdgcn_s_waitcnt(0);
     __syncthreads();
     WPS_STAMP(37 + 8 * l);
-    wps_layer_bwd<T, LDSW, TAPS>(w, LDSW ? wl : reinterpret_cast<const T*>(w.wt), prm, K, dy, lane, ok, row0, wo, E0, E1, red + wave * 4 * TD);
+    wps_layer_bwd<T, LDSW, TAPS, NMT>(w, LDSW ? wl : reinterpret_cast<const T*>(w.wt), prm, K, dy, lane, ok, row0, wo, E0, E1, red + wave * 4 * TD);
     WPS_STAMP(38 + 8 * l);
     __syncthreads();
     {  // the block's LayerNorm parameter-gradient partials, waves summed in a fixed order
@@ -1328,27 +1345,27 @@ __global__ __launch_bounds__(256) WPS_EU_ATTR void wps_layer_bwd_kernel(WpsBwdSt
       for (int mt = 0; mt < 2; ++mt)
         if (ok[mt])
 #pragma unroll
-          for (int nt = 0; nt < 4; ++nt) *reinterpret_cast<float4*>(w.o_dx + (row0 + mt * 16 + fr) * TD + nt * 16 + qr) = dy[mt][nt];
+          for (int nt = 0; nt < 4; ++nt) *reinterpret_cast<float4*>(w.o_dx + (row0 + ROFF + mt * 16 + fr) * TD + nt * 16 + qr) = dy[mt][nt];
     }
   }
   // ---- TAIL (base.py:602-622 reversed). dy = grad w.r.t. the layer-0 input tokens; xr = those tokens (the ReLU mask of token 0)
   WPS_STAMP(50);
   {
     // tokens 1..16: dc3 = (dx_in Wup) o [c3 > 0], per wave in registers (up-conv's transposed weight: 8 KB, straight from L2)
-    frag_t da[2][2];
+    frag_t da[2][2] WPS_Z;
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt)
+    for (int mt = 0; mt < NMT; ++mt)
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) da[mt][ks] = wps_frag<T>(dy[mt][2 * ks], dy[mt][2 * ks + 1]);
 #pragma unroll
     for (int nt = 0; nt < 4; ++nt) {
       f32x4 acc[2] = {zero4(), zero4()};
-      wps_gemm_t<T, false, 2>(acc, reinterpret_cast<const T*>(tx.wupt_f), nt, da, lane);
+      wps_gemm_t<T, false, 2, NMT>(acc, reinterpret_cast<const T*>(tx.wupt_f), nt, da, lane);
 #pragma unroll
-      for (int mt = 0; mt < 2; ++mt) {
-        const int t = mt * 16 + fr;                   // token; depth patch t - 1
-        const bool okt = ok[mt] && t > 0;
-        const int64_t o = okt ? ((int64_t)smp * 16 + (t - 1)) * TD + nt * 16 + qr : 0;
+      for (int mt = 0; mt < NMT; ++mt) {
+        const int patch = VIS == 2 ? fr : mt * 16 + fr - 1;  // the depth patch of this row's token (17 rows: token t = patch + 1)
+        const bool okt = ok[mt] && patch >= 0;
+        const int64_t o = okt ? ((int64_t)smp * 16 + patch) * TD + nt * 16 + qr : 0;
         const float4 m = *reinterpret_cast<const float4*>(tl.s_c3 + o);
         if (okt)
           *reinterpret_cast<float4*>(tl.o_dc3 + o) = float4{m.x > 0.f ? acc[mt][0] : 0.f, m.y > 0.f ? acc[mt][1] : 0.f,
@@ -1515,7 +1532,8 @@ __global__ __launch_bounds__(256) void wps_wgrad_kernel(WpsWg a) {
       }
     }
   }
-  {  // the 17th tokens of the run's samples: slot (g, j) <-> sample sbeg + 8 g + j, gathered from the k-permuted side blocks
+  if (tk != nullptr) {  // the 17th tokens of the run's samples: slot (g, j) <-> sample sbeg + 8 g + j, gathered from the k-permuted
+    // side blocks (null: the native 16-token vision-only Transformer has no 17th token)
     frag_t fx[4], fy[4];
     auto gather = [&](int tile) {
       const int p = tile >> 1, h = tile & 1;
