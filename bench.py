@@ -50,13 +50,21 @@ WORKLOADS = {
     # on the fused kernels since round 5 — this line shows an option costs nothing against the headline
     "loco_max": dict(kind="loco_max", S=93, A=6, E=32, T=512, B=1024, enc=[256, 256], head=[256, 256], layers=2, ff=256,
                      name="ppo_locotransformer with max_pool=True (option variant, fused kernels), E=32 x T=512, B=1024"),
+    # token_norm=True / use_pytorch_encoder=True (nets.py:815-818, 955-963): the update's layers on the wave-per-sample kernels,
+    # token_ln / the final norm + pooling + heads as launches of their own (round 5); the rollout step layer by layer
+    "loco_tn": dict(kind="loco_tn", S=93, A=6, E=32, T=512, B=1024, enc=[256, 256], head=[256, 256], layers=2, ff=256,
+                    name="ppo_locotransformer with token_norm=True (option variant), E=32 x T=512, B=1024"),
+    "loco_pe": dict(kind="loco_pe", S=93, A=6, E=32, T=512, B=1024, enc=[256, 256], head=[256, 256], layers=2, ff=256,
+                    name="ppo_locotransformer with use_pytorch_encoder=True (option variant), E=32 x T=512, B=1024"),
 }
 # algorithmic MFLOP per env-step incl. rollout inference, and F_pf: the forward pass of the frozen
 # target policy that each of the 3 sample-visits skips when log pi_old is recorded at action time (§8d's declared saving)
 # vision-only nets, same accounting: F_pf = 2 * (3 612 672 conv + 65 536 up-conv + 2 * 819 200 layer (16 tokens) + 83 456 head)
 # = 10.800 MFLOP, F_vf = 10.798; NatureCNN: F_pf = 2 * (3 612 672 + 329 216) = 7.884, F_vf = 7.881
-MFLOP_PER_ENV_STEP = {"loco": 258.9, "loco64": 258.9, "cnn": 191.4, "mlp": 10.2, "loco_vis": 248.4, "cnn_vis": 181.3, "loco_max": 258.9}
-MFLOP_TARGET_FWD = {"loco": 11.258, "loco64": 11.258, "cnn": 8.325, "mlp": 0.444, "loco_vis": 10.800, "cnn_vis": 7.884, "loco_max": 11.258}
+MFLOP_PER_ENV_STEP = {"loco": 258.9, "loco64": 258.9, "cnn": 191.4, "mlp": 10.2, "loco_vis": 248.4, "cnn_vis": 181.3, "loco_max": 258.9,
+                      "loco_tn": 258.9, "loco_pe": 258.9}
+MFLOP_TARGET_FWD = {"loco": 11.258, "loco64": 11.258, "cnn": 8.325, "mlp": 0.444, "loco_vis": 10.800, "cnn_vis": 7.884, "loco_max": 11.258,
+                    "loco_tn": 11.258, "loco_pe": 11.258}
 OPT_EPOCHS = 3
 LAST_ALLREDUCE = None
 PEAK = {"bf16": 2500.0, "f32": 157.3}  # dense TFLOP/s, MI355X_MICROARCH.md (bf16 MFMA / f32 MFMA)

@@ -474,6 +474,9 @@ struct InfHead {
   int nout;
   int max_pool;                        // rollout_stack_kernel only: the depth tokens pooled by max instead of mean (nets.py:1022-1030, 884-889)
   float *s_pooled, *s_h0, *s_h1;       // training forward: [E][128], [E][256], [E][256] (post-ReLU); null for inference
+  // rollout_stack_kernel<..., OPT>: this net's token_ln (OPT & 1: nets.py:1007-1008, in front of the layers) and final encoder
+  // norm (OPT & 2: nets.py:955-963, behind them) weight / bias [64], or null
+  const float *tn_g, *tn_b, *fn_g, *fn_b;
 };
 struct InfHeadPair { InfHead n[2]; };
 
@@ -925,7 +928,7 @@ __device__ __forceinline__ void mm_held(f32x4 (&acc)[MT], const AT* sA, int lda,
 
 // NT: tokens per sample — 17 (LocoTransformer: proprio token + 16 depth tokens, head input [token 0 | mean of the depth
 // tokens]) or 16 (the vision-only Transformer, nets.py:884-889: head input = mean of all 16 tokens, fc0 contracts 64)
-template <typename T, int NL, int NT = NTOK>
+template <typename T, int NL, int NT = NTOK, int OPT = 0>
 __global__ __launch_bounds__(512) void rollout_stack_kernel(InfLayerStack stk, InfHeadPair hd, InfFinish fin, int E, int warm,
                                                             int xcd) {
   typedef typename Frag<T>::type frag_t;
@@ -1114,6 +1117,10 @@ __global__ __launch_bounds__(512) void rollout_stack_kernel(InfLayerStack stk, I
     st4(xb + r * LDT + c4, o.x, o.y, o.z, o.w);
     if (gout != nullptr && r < NT) *reinterpret_cast<float4*>(gout + (row0 + r) * TD + c4) = o;
   };
+  if constexpr ((OPT & 1) != 0) {  // token_norm=True: out = token_ln(tokens), each quarter wave its own row, in place
+    ln2rows(xs, xs, h.tn_g, h.tn_b, nullptr);
+    __syncthreads();
+  }
 #pragma unroll
   for (int l = 0; l < NL; ++l) {  // the token rows stay in `xs` from one layer to the next
     const InfLayer& w = stk.l[l].n[net];
@@ -1226,6 +1233,8 @@ __global__ __launch_bounds__(512) void rollout_stack_kernel(InfLayerStack stk, I
     if (tid < P_LAYER / 4) *reinterpret_cast<float4*>(prm + ((l + 1) & 1) * P_LAYER + tid * 4) = pnext;
     if (l == 0) ROLL_STAMP(74);
   }
+  // use_pytorch_encoder=True: nn.TransformerEncoder's final norm on the rows the last norm2 left (each lane re-reads what it wrote)
+  if constexpr ((OPT & 2) != 0) ln2rows(xs, xs, h.fn_g, h.fn_b, nullptr);
   // ---- head on this sample: [state token | mean of the 16 depth tokens] -> 256 -> 256 -> nout (fragment row 0 carries data)
   float* pooled = big;                                              // [16][LDP] fp32, row 0 = this sample
   T* h1 = reinterpret_cast<T*>(big + 16 * LY::LDP);                 // [16][LDF]

@@ -1049,6 +1049,17 @@ bool v4l_net::wps_max_pool() const {
   return c.kind == V4L_NET_LOCO && c.n_layers == 2 && c.n_enc_hidden == 2 && c.enc_hidden[0] == 256 && c.enc_hidden[1] == 256 &&
          getenv("V4L_NO_LAYER_STACK") == nullptr && wps_layers();
 }
+// token_norm / use_pytorch_encoder around the fused layers (round 5): the LocoTransformer's two layers (and, without the final
+// LayerNorm, its pooled heads) on the wave-per-sample kernels; token_ln, the final norm with the pooling and heads behind it, and
+// (token_norm) the encoder-side data-grads stay separate launches of the layer-by-layer path. Forward and backward decide alike.
+bool v4l_net::wps_opt() const {
+  const v4l_net_cfg& c = cfg;
+  if (c.kind != V4L_NET_LOCO || !(c.token_norm || c.pytorch_encoder) || c.max_pool) return false;
+  return c.ff_dim == 256 && c.n_layers == 2 && c.n_head_hidden == 2 && c.head_hidden[0] == 256 && c.head_hidden[1] == 256 &&
+         c.out_dim <= OUT_LD && c.n_enc_hidden == 2 && c.enc_hidden[0] == 256 && c.enc_hidden[1] == 256 &&
+         layers[0].inproj.pkp >= 0 && getenv("V4L_NO_WPS_LAYERS") == nullptr && getenv("V4L_NO_LAYER_STACK") == nullptr &&
+         getenv("V4L_LAYER_TAPS") == nullptr;
+}
 bool v4l_net::fused_layers() const {
   return cfg.kind == V4L_NET_LOCO && cfg.ff_dim == 256 && !cfg.token_norm && !cfg.pytorch_encoder;
 }
@@ -1371,7 +1382,9 @@ int v4l_net::forward_t(const float* state, const T* image, const int* rowidx, in
     const bool vis_wps = c.kind == V4L_NET_LOCO_VIS && enc_ws == nullptr && stage == 0 && wps_vis();
     // (wps_bwd_plain: the wave-per-sample forward keeps only the layers' input rows, which only the wave-per-sample backward
     // can start from — a geometry whose backward stays layer-by-layer must not take it)
-    if ((stacked && wps_layers() && wps_bwd_plain()) || vis_wps) {
+    const bool opt_wps = wps_opt() && enc_ws == nullptr && stage == 0;
+    bool wps_layers_done = false;  // (use_pytorch_encoder on the wave-per-sample layers: norm, pooling and heads still to come)
+    if ((stacked && wps_layers() && wps_bwd_plain()) || vis_wps || opt_wps) {
       // wave-per-sample launch (csrc/wps.h): both layers + the pooled heads, 4 samples per block, weights resident in LDS
       static bool wps_attr = false;
       if (!wps_attr) {
@@ -1384,6 +1397,8 @@ int v4l_net::forward_t(const float* state, const T* image, const int* rowidx, in
         V4L_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&wps_layer_fwd_kernel<T, true, 2, true, true>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)WpsFwdLds<T>::bytes));
         V4L_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&wps_layer_fwd_kernel<T, true, 2, false, 2>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)WpsFwdLds<T>::bytes));
+        V4L_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&wps_layer_fwd_kernel<T, false, 2, false>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)WpsFwdLds<T>::bytes));
         wps_attr = true;
       }
@@ -1403,7 +1418,8 @@ int v4l_net::forward_t(const float* state, const T* image, const int* rowidx, in
         // production: the forward saves nothing but the layers' input rows (the backward recomputes, csrc/wps.h);
         // V4L_LAYER_TAPS=1 (tests): every intermediate goes out row-major, as the block-cooperative kernels save them
         // (max_pool: the backward finds the arg-max tokens again from the stack's output rows)
-        d.xout = (k + 1 < 2 || taps || c.max_pool) ? ws + L.x[k + 1] : nullptr;
+        // (use_pytorch_encoder: the final norm is a launch of its own behind this one)
+        d.xout = (k + 1 < 2 || taps || c.max_pool || c.pytorch_encoder) ? ws + L.x[k + 1] : nullptr;
         if (taps) {
           d.s_qkv = ws + w.qkv; d.s_P = ws + w.P; d.s_ctx = ws + w.ctx; d.s_xh1 = ws + w.xh1; d.s_rs1 = ws + w.rs1;
           d.s_x1 = ws + w.x1; d.s_f = ws + w.f; d.s_xh2 = ws + w.xh2; d.s_rs2 = ws + w.rs2;
@@ -1418,7 +1434,10 @@ int v4l_net::forward_t(const float* state, const T* image, const int* rowidx, in
       h.out = ws + L.out; h.nout = c.out_dim; h.max_pool = c.max_pool;
       h.s_pooled = ws + L.pooled; h.s_h0 = ws + L.hh[0]; h.s_h1 = ws + L.hh[1];
       g_op = "layer";
-      if (vis_wps && taps)
+      if (opt_wps && c.pytorch_encoder)  // layers only: final norm, pooling and heads follow below
+        V4L_KLAUNCH("wps_layer_stack", 2.0 * n * (2 * 872576.0), s, (wps_layer_fwd_kernel<T, false, 2, false>),
+                    dim3(cdiv(n, WPS_WPB)), dim3(256), (WpsFwdLds<T>::bytes), s, stk, hd, n);
+      else if (vis_wps && taps)
         V4L_KLAUNCH("wps_layer_stack_head", 2.0 * n * (2 * 872576.0 + 99840.0), s, (wps_layer_fwd_kernel<T, true, 2, true, true>),
                     dim3(cdiv(n, WPS_WPB)), dim3(256), (WpsFwdLds<T>::bytes), s, stk, hd, n);
       else if (vis_wps && vis17_forced())
@@ -1434,7 +1453,8 @@ int v4l_net::forward_t(const float* state, const T* image, const int* rowidx, in
         V4L_KLAUNCH("wps_layer_stack_head", 2.0 * n * (2 * 872576.0 + 99840.0), s, (wps_layer_fwd_kernel<T, true, 2, false>),
                     dim3(cdiv(n, WPS_WPB)), dim3(256), (WpsFwdLds<T>::bytes), s, stk, hd, n);
       V4L_LAUNCH_CHECK();
-      return 0;
+      if (!(opt_wps && c.pytorch_encoder)) return 0;
+      wps_layers_done = true;
     }
     for (int l = 0; l < c.n_layers && fused_layers; l += stacked ? 2 : 1) {
       static bool attr_done = false;
@@ -1503,7 +1523,7 @@ int v4l_net::forward_t(const float* state, const T* image, const int* rowidx, in
       V4L_LAUNCH_CHECK();
     }
     if (fused_head) return 0;
-    for (int l = 0; l < c.n_layers && !fused_layers; ++l) {
+    for (int l = 0; l < c.n_layers && !fused_layers && !wps_layers_done; ++l) {
       const TLayer& t = layers[l];
       const LayerWs& w = L.lw[l];
       float* xin = l == 0 ? x0 : ws + L.x[l];
@@ -1763,7 +1783,11 @@ int v4l_net::backward_t(const float* state, const T* image, const int* rowidx, i
   const bool fused_tail = fused_bwd && c.n_layers >= 1 && ne == 2 && c.enc_hidden[0] == 256 && c.enc_hidden[1] == 256;
   // vision-only Transformer on the wave-per-sample kernels (17-row stride, dummy row 0: csrc/wps.h); the forward took the same path
   const bool vis_wps = vis && wps_vis();
-  if (fused_head || vis_wps) {  // only the three weight-grads are registered here
+  // token_norm / use_pytorch_encoder around the wave-per-sample layers (wps_opt): without the final norm the heads run inside
+  // the layers' launch as usual; with it they (and the pooling and the norm) are the layer-by-layer launches below
+  const bool opt_wps = wps_opt();
+  const bool opt_heads_in = opt_wps && !c.pytorch_encoder;
+  if (fused_head || vis_wps || opt_heads_in) {  // only the three weight-grads are registered here
     if ((rc = lin_wgrad<T>(cx, head[2], dy, dense(hacts[1].p, 256, n, 256), 256))) return rc;
     if ((rc = lin_wgrad<T>(cx, head[1], dense(dhhp[1], 256, n, 256), dense(hacts[0].p, 256, n, 256), 256))) return rc;
     if (vis_wps) rc = lin_wgrad<T>(cx, head[0], dense(dhhp[0], 256, n, 256), dense(ws + L.pooled + TD, 2 * TD, n, TD), TD);
@@ -1793,7 +1817,7 @@ int v4l_net::backward_t(const float* state, const T* image, const int* rowidx, i
   // Every data-grad of a layer has its intermediates in LDS; the four weight-grads are deferred to the grouped launch.
   const bool bwd_stack_ok = getenv("V4L_NO_LAYER_STACK") == nullptr;
   const bool stacked = fused_bwd && fused_head && fused_tail && c.n_layers == 2 && bwd_stack_ok;
-  const bool wps = (stacked && wps_layers()) || vis_wps;
+  const bool wps = (stacked && wps_layers()) || vis_wps || opt_wps;
   if (wps) {
     // wave-per-sample launch (csrc/wps.h): heads -> per layer {recompute, backward} -> encoder-side data-grads; the four
     // weight-grads of each layer come from the fragment-order operand blocks it leaves, in one launch of their own
@@ -1801,10 +1825,12 @@ int v4l_net::backward_t(const float* state, const T* image, const int* rowidx, i
     // round 4: the heads' and the proprio branch's data-grad chains outside this launch, 64 rows per block (csrc/wps.h
     // rows_chain): the heads ran beside the loss statistics when the trainer said so (heads_ext), the proprio chain rides in
     // the layers' weight-grad launch unless the grouped weight-grads (its consumer) go to a stream of their own
-    const bool head_ext = !vis_wps && !taps && heads_ext_ws == ws && heads_ext_n == n;
+    const bool head_ext = !vis_wps && !taps && !opt_wps && heads_ext_ws == ws && heads_ext_n == n;
     heads_ext_ws = nullptr;
     const int par_wgrad_now = getenv("V4L_PAR_WGRAD") ? atoi(getenv("V4L_PAR_WGRAD")) : 2;
-    const bool tok0_ext = !vis_wps && !taps && par_wgrad_now != 3 && getenv("V4L_WPS_TOK0_IN") == nullptr;
+    // (the option variants keep the proprio chain where the layer-0 gradient is: in the launch, or — token_norm — layer by layer
+    // behind token_ln's backward)
+    const bool tok0_ext = !vis_wps && !taps && !opt_wps && par_wgrad_now != 3 && getenv("V4L_WPS_TOK0_IN") == nullptr;
     const int nblk = cdiv(n, WPS_WPB);
     const T* base = (const T*)packed;
     WpsBwdStack d;
@@ -1851,28 +1877,32 @@ int v4l_net::backward_t(const float* state, const T* image, const int* rowidx, i
     tx.wupt_f = base + upconv.pkpt;
     tx.dpool = ws + L.dpool;
     tx.xlast = c.max_pool ? ws + L.x[c.n_layers] : nullptr;
+    tx.dyrows = (opt_wps && c.pytorch_encoder) ? ws + L.dxl[c.n_layers] : nullptr;  // (what the final norm's backward wrote)
     g_op = "layer";
     const double fl_heads = 2.0 * n * 2 * (16 * 256 + 256 * 256 + 256 * 128) / 2, fl_tok0 = 2.0 * n * (64 * 256 + 256 * 256);
     const double fl = 2 * 4.0 * n * 872576.0 + (head_ext ? 0.0 : 2 * fl_heads) + (tok0_ext ? 0.0 : fl_tok0) + 2.0 * n * 16 * 64 * 64;
-#define V4L_WPS_BWD(TAPS_, VIS_, HIN_, TIN_)                                                                              \
+#define V4L_WPS_BWD(TAPS_, VIS_, HIN_, TIN_, MODE_)                                                                       \
   do {                                                                                                                    \
     static bool attr_ = false;                                                                                            \
     if (!attr_) {                                                                                                         \
-      V4L_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&wps_layer_bwd_kernel<T, 2, TAPS_, VIS_, HIN_, TIN_>), \
+      V4L_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&wps_layer_bwd_kernel<T, 2, TAPS_, VIS_, HIN_, TIN_, MODE_>), \
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)WpsBwdLds<T>::bytes));          \
       attr_ = true;                                                                                                       \
     }                                                                                                                     \
-    V4L_KLAUNCH("wps_layer_bwd_stack", fl, s, (wps_layer_bwd_kernel<T, 2, TAPS_, VIS_, HIN_, TIN_>), dim3(nblk), dim3(256), \
+    V4L_KLAUNCH("wps_layer_bwd_stack", fl, s, (wps_layer_bwd_kernel<T, 2, TAPS_, VIS_, HIN_, TIN_, MODE_>), dim3(nblk), dim3(256), \
                 (WpsBwdLds<T>::bytes), s, d, bh, bt, tx, n);                                                              \
   } while (0)
-    if (vis_wps && taps) V4L_WPS_BWD(true, true, true, true);
-    else if (vis_wps && vis17_forced()) V4L_WPS_BWD(false, true, true, true);
-    else if (vis_wps) V4L_WPS_BWD(false, 2, true, true);  // native 16 tokens: no 17th-token side blocks (wa.l[].tk = null below)
-    else if (taps) V4L_WPS_BWD(true, false, true, true);
-    else if (head_ext && tok0_ext) V4L_WPS_BWD(false, false, false, false);
-    else if (head_ext) V4L_WPS_BWD(false, false, false, true);
-    else if (tok0_ext) V4L_WPS_BWD(false, false, true, false);
-    else V4L_WPS_BWD(false, false, true, true);
+    if (opt_wps && c.token_norm && c.pytorch_encoder) V4L_WPS_BWD(false, false, true, true, 3);
+    else if (opt_wps && c.pytorch_encoder) V4L_WPS_BWD(false, false, true, true, 2);  // from the final norm's gradient rows
+    else if (opt_wps) V4L_WPS_BWD(false, false, true, true, 1);                       // up to the layer-0 input gradient
+    else if (vis_wps && taps) V4L_WPS_BWD(true, true, true, true, 0);
+    else if (vis_wps && vis17_forced()) V4L_WPS_BWD(false, true, true, true, 0);
+    else if (vis_wps) V4L_WPS_BWD(false, 2, true, true, 0);  // native 16 tokens: no 17th-token side blocks (wa.l[].tk = null below)
+    else if (taps) V4L_WPS_BWD(true, false, true, true, 0);
+    else if (head_ext && tok0_ext) V4L_WPS_BWD(false, false, false, false, 0);
+    else if (head_ext) V4L_WPS_BWD(false, false, false, true, 0);
+    else if (tok0_ext) V4L_WPS_BWD(false, false, true, false, 0);
+    else V4L_WPS_BWD(false, false, true, true, 0);
 #undef V4L_WPS_BWD
     V4L_LAUNCH_CHECK();
     // the layers' weight-grads: one partial slab set per run of WPS_SPLIT samples
@@ -2011,7 +2041,7 @@ int v4l_net::backward_t(const float* state, const T* image, const int* rowidx, i
       if ((rc = lin_wgrad_wide(cx, t.inproj, ws + b.dqkv, xin, R))) return rc;
     }
   }
-  for (int l = c.n_layers - 1; l >= 0 && !fused_bwd && !vis_wps; --l) {
+  for (int l = c.n_layers - 1; l >= 0 && !fused_bwd && !vis_wps && !opt_wps; --l) {
     const TLayer& t = layers[l];
     const LayerWs& w = L.lw[l];
     const LayerBw& b = L.lb[l];
@@ -2062,7 +2092,10 @@ int v4l_net::backward_t(const float* state, const T* image, const int* rowidx, i
     dx = ws + L.dx0raw;
     x0 = ws + L.x0raw;
   }
-  if (fused_tail) {  // data-grads done by layer 0's launch: register the four weight-grads
+  // (the option variants: use_pytorch_encoder alone leaves the encoder-side data-grads inside the layers' launch like the plain
+  // net; token_norm takes them layer by layer from token_ln's backward)
+  const bool tail_in = fused_tail || (opt_wps && !c.token_norm);
+  if (tail_in) {  // data-grads done by layer 0's launch: register the four weight-grads
     const Act& last = eacts[ne - 1];
     if ((rc = lin_wgrad<T>(cx, proj, dense(dx, NTOK * TD, n, TD, nullptr, 0, x0), dense(last.p, last.ld, n, last.w), last.w)))
       return rc;
@@ -2073,7 +2106,7 @@ int v4l_net::backward_t(const float* state, const T* image, const int* rowidx, i
   if (vis_wps) {  // the up-conv data-grad came out of the layer launch (dc3): its weight-grad reads rows 1..16 of the 17-row stride
     if ((rc = lin_wgrad<T>(cx, upconv, dense(dx, TD, n * 16, TD, nullptr, 1), dense(ws + L.c3, 64, n * 16, 64), 64))) return rc;
   }
-  if (!fused_tail && !vis) {  // token 0 -> state_projector -> encoder MLP
+  if (!tail_in && !vis) {  // token 0 -> state_projector -> encoder MLP
     const Act& last = eacts[ne - 1];
     ADense yp = dense(dx, NTOK * TD, n, TD, nullptr, 0, x0);
     if ((rc = lin_wgrad<T>(cx, proj, yp, dense(last.p, last.ld, n, last.w), last.w))) return rc;
@@ -2083,7 +2116,7 @@ int v4l_net::backward_t(const float* state, const T* image, const int* rowidx, i
     if ((rc = lin_dgrad<T>(cx, proj, yp, ep))) return rc;
     if ((rc = chain_bwd<T>(cx, enc.data(), ne, sin, eacts, dense(ws + L.dhc, last.w, n, last.w), dehp, nullptr))) return rc;
   }
-  if (!fused_tail && !vis_wps) {  // tokens 1..16 (vision-only: all 16) -> depth_up_conv -> conv stack
+  if (!tail_in && !vis_wps) {  // tokens 1..16 (vision-only: all 16) -> depth_up_conv -> conv stack
     ADense yu = dense(dx, TD, n * 16, TD, nullptr, vis ? 0 : 1);
     if ((rc = lin_wgrad<T>(cx, upconv, yu, dense(ws + L.c3, 64, n * 16, 64), 64))) return rc;
     Epi ep = mk_epi(ws + L.dc3, 64, 64);
@@ -2109,7 +2142,8 @@ static bool actor_fusable(const v4l_actor* a) {
            c.state_dim <= 128;
   };
   // (max_pool: a flag of rollout_stack_kernel's pooling — the stack itself is the same)
-  return ok(p) && ok(v) && !p.token_norm && !v.token_norm && !p.pytorch_encoder && !v.pytorch_encoder && p.n_layers == 2 && v.n_layers == 2 && a->E <= 64 && a->pf->head.size() == 3 &&
+  const bool opt_ok = p.token_norm == v.token_norm && p.pytorch_encoder == v.pytorch_encoder && !(p.token_norm && p.pytorch_encoder);
+  return ok(p) && ok(v) && opt_ok && p.n_layers == 2 && v.n_layers == 2 && a->E <= 64 && a->pf->head.size() == 3 &&
          a->pf->head[0].pkf >= 0 && a->vf->head[0].pkf >= 0;
 }
 
@@ -2494,6 +2528,8 @@ static int run_actor_fused(v4l_actor* a, const float* obs, const float* eps, flo
     if (stack) { h.w0 = base + net->head[0].pkf; h.w1 = base + net->head[1].pkf; h.w2 = base + net->head[2].pkf; }
     h.b0 = net->p[net->head[0].b]; h.b1 = net->p[net->head[1].b]; h.b2 = net->p[net->head[2].b];
     h.out = out; h.nout = net->cfg.out_dim; h.max_pool = net->cfg.max_pool;
+    if (net->cfg.token_norm) { h.tn_g = net->p[net->tok_ln.g]; h.tn_b = net->p[net->tok_ln.b]; }
+    if (net->cfg.pytorch_encoder) { h.fn_g = net->p[net->fin_ln.g]; h.fn_b = net->p[net->fin_ln.b]; }
   };
   auto finish = [&]() {
     head(hd.n[0], pf, pk, ws_pf + Lp.out);
@@ -2520,12 +2556,27 @@ static int run_actor_fused(v4l_actor* a, const float* obs, const float* eps, flo
     // launch instead of 3.65 — round 4's A/B)
     constexpr int xcd = 1;
     const dim3 grid = xcd ? dim3(2 * round_up(E, 4)) : dim3(E, 2);
-    if (vis)
-      V4L_KLAUNCH("rollout_layers_head", 2.0 * 2 * E * (nl * 872576.0 + 99840.0), s, (rollout_stack_kernel<T, 2, 16>), grid,
-                  dim3(512), (RollStackLds<T>::bytes), s, stk, hd, fin, E, warm, xcd);
-    else
-      V4L_KLAUNCH("rollout_layers_head", 2.0 * 2 * E * (nl * 872576.0 + 99840.0), s, (rollout_stack_kernel<T, 2>), grid,
-                  dim3(512), (RollStackLds<T>::bytes), s, stk, hd, fin, E, warm, xcd);
+    // (token_norm / use_pytorch_encoder: the same kernel with the extra norm in front of / behind the layers; actor_fusable()
+    // admits one of the two, set alike on both nets)
+    const int opt = (pf->cfg.token_norm ? 1 : 0) | (pf->cfg.pytorch_encoder ? 2 : 0);
+#define V4L_ROLL_STACK(NT_, OPT_)                                                                                              \
+  do {                                                                                                                    \
+    static bool attr_ = false;                                                                                            \
+    if (!attr_) {                                                                                                         \
+      V4L_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&rollout_stack_kernel<T, 2, NT_, OPT_>),            \
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)RollStackLds<T>::bytes));       \
+      attr_ = true;                                                                                                       \
+    }                                                                                                                     \
+    V4L_KLAUNCH("rollout_layers_head", 2.0 * 2 * E * (nl * 872576.0 + 99840.0), s, (rollout_stack_kernel<T, 2, NT_, OPT_>), \
+                grid, dim3(512), (RollStackLds<T>::bytes), s, stk, hd, fin, E, warm, xcd);                                \
+  } while (0)
+    if (vis && opt == 1) V4L_ROLL_STACK(16, 1);
+    else if (vis && opt == 2) V4L_ROLL_STACK(16, 2);
+    else if (vis) V4L_ROLL_STACK(16, 0);
+    else if (opt == 1) V4L_ROLL_STACK(NTOK, 1);
+    else if (opt == 2) V4L_ROLL_STACK(NTOK, 2);
+    else V4L_ROLL_STACK(NTOK, 0);
+#undef V4L_ROLL_STACK
     V4L_LAUNCH_CHECK();
   }
   return 0;

@@ -1151,7 +1151,7 @@ __global__ __launch_bounds__(NWAVES * 64) void actor_loss_heads_kernel(ActorArgs
 // layers' weight-grads, from the layer-0 input gradient this kernel writes (stk.l[NL-1].o_dx).
 // xlast: the layer stack's output rows [n][17][64] when the head pools the depth tokens by max (max_pool=True): the gradient of
 // a max goes to the first token that attained it (torch.max(dim) backward; pool_bwd_kernel), found again from these rows
-struct WpsTailExtra { const void* wupt_f; const float* dpool; const float* xlast; };  // wupt_f: up-conv's transposed weight as a k-permuted fragment pack
+struct WpsTailExtra { const void* wupt_f; const float* dpool; const float* xlast; const float* dyrows; };  // wupt_f: up-conv's transposed weight as a k-permuted fragment pack
 // un-pooling weights of a sample's depth tokens (lane fr: token fr of tile 0, lane fr = 0 of tile 1: token 16), per feature column:
 // 1/16 for the mean; for the max 1 on the first token that holds the maximum of its column, 0 elsewhere
 template <int VIS>
@@ -1181,7 +1181,11 @@ __device__ __forceinline__ void wps_unpool_weights(const float* xlast_rows, int 
     w0[nt] = wq;
   }
 }
-template <typename T, int NL, bool TAPS, int VIS = 0, bool HEAD_IN = true, bool TOK0_IN = true>
+// MODE (round 5, the token_norm / use_pytorch_encoder options around the fused layers): bit 0 = the launch ends with the
+// layer-0 input gradient rows (o_dx) — the caller runs token_ln's backward and the encoder-side data-grads itself; bit 1 = the
+// launch starts from row-major gradient rows w.r.t. the stack's output (tx.dyrows: the final LayerNorm's backward wrote them)
+// instead of running / un-pooling the heads.
+template <typename T, int NL, bool TAPS, int VIS = 0, bool HEAD_IN = true, bool TOK0_IN = true, int MODE = 0>
 __global__ __launch_bounds__(256) WPS_EU_ATTR void wps_layer_bwd_kernel(WpsBwdStack stk, BwdHead hd, BwdTail tl, WpsTailExtra tx, int n) {
   constexpr int NMT = VIS == 2 ? 1 : WPS_NMT_DEF;
   constexpr int ROFF = VIS == 2 ? 1 : 0;  // (see wps_layer_fwd)
@@ -1208,8 +1212,10 @@ __global__ __launch_bounds__(256) WPS_EU_ATTR void wps_layer_bwd_kernel(WpsBwdSt
   float4 dy[2][4];
   WPS_STAMP(32);
   float4 upw[4];  // un-pooling weights of this lane's depth token (mean: 1/16; max_pool: the arg-max mask), both tiles
-  wps_unpool_weights<VIS>(tx.xlast != nullptr ? tx.xlast + row0 * TD : nullptr, lane, ok, upw);
-  if constexpr (!HEAD_IN) {
+  if constexpr ((MODE & 2) == 0) wps_unpool_weights<VIS>(tx.xlast != nullptr ? tx.xlast + row0 * TD : nullptr, lane, ok, upw);
+  if constexpr ((MODE & 2) != 0) {
+    wps_load_rows<VIS>(tx.dyrows + row0 * TD, lane, ok, dy);
+  } else if constexpr (!HEAD_IN) {
     // the heads ran beside the loss statistics: un-pool their dpool rows straight into this wave's registers
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt)
@@ -1348,6 +1354,7 @@ __global__ __launch_bounds__(256) WPS_EU_ATTR void wps_layer_bwd_kernel(WpsBwdSt
           for (int nt = 0; nt < 4; ++nt) *reinterpret_cast<float4*>(w.o_dx + (row0 + ROFF + mt * 16 + fr) * TD + nt * 16 + qr) = dy[mt][nt];
     }
   }
+  if constexpr ((MODE & 1) != 0) return;
   // ---- TAIL (base.py:602-622 reversed). dy = grad w.r.t. the layer-0 input tokens; xr = those tokens (the ReLU mask of token 0)
   WPS_STAMP(50);
   {
