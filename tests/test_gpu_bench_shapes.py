@@ -168,22 +168,25 @@ WPS_TAPS_T = ["xin0", "xin1", "ctx0", "ctx1", "mid0", "mid1", "ff0", "ff1"]
 @pytest.mark.parametrize("mode", MODES)
 @pytest.mark.parametrize("n", [32, 30, 1024])
 def test_vision_only_transformer_on_wave_per_sample_kernels(n, mode, device):
-    """The vision-only Transformer (16 depth tokens, no proprio token) runs its update on the 17-row wave-per-sample kernels:
-    tokens in rows 1..16, row 0 a dummy whose key is masked out of every softmax and whose half of the pooled head operand is
-    zero (csrc/wps.h). Against the layer-by-layer kernels (V4L_NO_WPS_LAYERS=1): head outputs and EVERY parameter gradient — f32:
-    fp32 summation noise; bf16: the fraction of elements that moved (rounding ties), as for the LocoTransformer. The dummy row
-    must not leak: the tapped run's row-0 gradient taps are exactly zero."""
+    """The vision-only Transformer (16 depth tokens, no proprio token) runs its update on the wave-per-sample kernels: natively
+    instantiated for 16 tokens = one MFMA row tile (round 5), or — V4L_VIS17=1 and the tapped test build — on the 17-row
+    instantiation: tokens in rows 1..16, row 0 a dummy whose key is masked out of every softmax and whose half of the pooled head
+    operand is zero (csrc/wps.h). Against the layer-by-layer kernels (V4L_NO_WPS_LAYERS=1): head outputs and EVERY parameter
+    gradient — f32: fp32 summation noise; bf16: the fraction of elements that moved (rounding ties), as for the LocoTransformer.
+    The dummy row must not leak: the tapped run's row-0 gradient taps are exactly zero."""
     case = dict(util.CASES["loco_vis"], B=n)
     obs = torch.tensor(util.make_batch(case)["obs"], dtype=torch.float32)
     g = torch.Generator().manual_seed(11)
     A = case["A"]
     w = torch.randn(n, A, generator=g)
     res = []
-    for variant in ("wps_taps", "general", "wps"):
+    for variant in ("wps_taps", "general", "wps17", "wps"):
         if variant == "general":
             os.environ["V4L_NO_WPS_LAYERS"] = "1"
         if variant == "wps_taps":
             os.environ["V4L_LAYER_TAPS"] = "1"
+        if variant == "wps17":
+            os.environ["V4L_VIS17"] = "1"
         try:
             pf, vf = _build(case, mode, device)
             hip = pf.hip
@@ -203,8 +206,9 @@ def test_vision_only_transformer_on_wave_per_sample_kernels(n, mode, device):
         finally:
             os.environ.pop("V4L_NO_WPS_LAYERS", None)
             os.environ.pop("V4L_LAYER_TAPS", None)
-    (oa, ga, xa), (ob, gb, _), (oc, gc, _) = res
-    assert torch.equal(oa, oc)  # the tapped instantiation is the same arithmetic compiled separately
+            os.environ.pop("V4L_VIS17", None)
+    (oa, ga, xa), (ob, gb, _), (oc, gc, _), (on, gn, _) = res
+    assert torch.equal(oa, oc)  # the tapped instantiation is the same arithmetic (17 rows) compiled separately
     for nm in ("dx0", "dx1"):                                                    # the dummy row carries no gradient
         assert torch.equal(xa[nm].view(n, 17, 64)[:, 0], torch.zeros(n, 64)), nm
     tag = "vis_wps/n%d/%s/" % (n, mode)
@@ -230,6 +234,9 @@ def test_vision_only_transformer_on_wave_per_sample_kernels(n, mode, device):
         # tapped vs untapped: gradients to the last fp32 bit or two; in bf16 such a bit in dc3 can flip a rounding tie of the conv
         # backward's operands, which the sums over rows spread
         check("taps/" + k, ga[k], gc[k], 1.0)
+        # the native 16-token instantiation against the layer-by-layer kernels, like the 17-row one above
+        check("native16/" + k, gn[k], gb[k], 1.0)
+    check("native16/out", on, ob, 0.5)
 
 
 @pytest.mark.parametrize("mode", MODES)
