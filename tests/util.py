@@ -30,8 +30,8 @@ CASES = {
     # a NON-shipped geometry (one layer, ff = 128, 128-wide MLPs, odd batch): runs on the general layer-by-layer kernels
     # (gemm_nt / attn / ln / gemm_tn), not on the fused ones that are specialised for the shipped shapes
     "loco_gen": dict(kind="loco", S=45, A=4, seed=4, B=22, enc=[128, 128], head=[128, 128], layers=1, ff=128),
-    # mixed geometry (round 5): shipped layers and heads but a 128-wide proprio MLP -> the forward may fuse the layers and heads,
-    # the backward's encoder-side tail cannot: the two passes must still agree on what the forward saves
+    # mixed geometry (round 5): shipped layers and heads but a 128-wide proprio MLP -> layers and heads on the wave-per-sample
+    # kernels in both passes, the backward launch ending with the layer-0 input gradient (its encoder-side tail is layer by layer)
     "loco_mix": dict(kind="loco", S=45, A=4, seed=20, B=22, enc=[128, 128], head=[256, 256], layers=2, ff=256),
     # vision-only variants (starter/ppo_locotransformer_vision_only.py, ppo_nature_cnn_vision_only.py
     # with the config/mpc_vision_only/{locotransformer,baseline}/thin-goal.json hyper-parameters): the observation row is the depth stack alone (S = 0)

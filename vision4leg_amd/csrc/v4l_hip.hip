@@ -1049,16 +1049,20 @@ bool v4l_net::wps_max_pool() const {
   return c.kind == V4L_NET_LOCO && c.n_layers == 2 && c.n_enc_hidden == 2 && c.enc_hidden[0] == 256 && c.enc_hidden[1] == 256 &&
          getenv("V4L_NO_LAYER_STACK") == nullptr && wps_layers();
 }
-// token_norm / use_pytorch_encoder around the fused layers (round 5): the LocoTransformer's two layers (and, without the final
-// LayerNorm, its pooled heads) on the wave-per-sample kernels; token_ln, the final norm with the pooling and heads behind it, and
-// (token_norm) the encoder-side data-grads stay separate launches of the layer-by-layer path. Forward and backward decide alike.
+// The wave-per-sample layers with layer-by-layer launches around them (round 5): token_norm / use_pytorch_encoder, or a proprio MLP
+// that is not the shipped 256-256 one. The LocoTransformer's two layers (and, without the final LayerNorm, its pooled heads) run
+// on the wave-per-sample kernels; token_ln, the final norm with the pooling and heads behind it, and (token_norm, other proprio
+// MLPs) the encoder-side data-grads stay separate launches of the layer-by-layer path. Forward and backward decide alike.
+bool v4l_net::wps_tail_shape() const {
+  return cfg.n_enc_hidden == 2 && cfg.enc_hidden[0] == 256 && cfg.enc_hidden[1] == 256;
+}
 bool v4l_net::wps_opt() const {
   const v4l_net_cfg& c = cfg;
-  if (c.kind != V4L_NET_LOCO || !(c.token_norm || c.pytorch_encoder) || c.max_pool) return false;
+  if (c.kind != V4L_NET_LOCO || c.max_pool) return false;
+  if (!(c.token_norm || c.pytorch_encoder) && wps_tail_shape()) return false;  // (the plain shipped net: wps_bwd_plain's launch)
   return c.ff_dim == 256 && c.n_layers == 2 && c.n_head_hidden == 2 && c.head_hidden[0] == 256 && c.head_hidden[1] == 256 &&
-         c.out_dim <= OUT_LD && c.n_enc_hidden == 2 && c.enc_hidden[0] == 256 && c.enc_hidden[1] == 256 &&
-         layers[0].inproj.pkp >= 0 && getenv("V4L_NO_WPS_LAYERS") == nullptr && getenv("V4L_NO_LAYER_STACK") == nullptr &&
-         getenv("V4L_LAYER_TAPS") == nullptr;
+         c.out_dim <= OUT_LD && layers[0].inproj.pkp >= 0 && getenv("V4L_NO_WPS_LAYERS") == nullptr &&
+         getenv("V4L_NO_LAYER_STACK") == nullptr && getenv("V4L_LAYER_TAPS") == nullptr;
 }
 bool v4l_net::fused_layers() const {
   return cfg.kind == V4L_NET_LOCO && cfg.ff_dim == 256 && !cfg.token_norm && !cfg.pytorch_encoder;
@@ -1869,7 +1873,7 @@ int v4l_net::backward_t(const float* state, const T* image, const int* rowidx, i
     memset(&bt, 0, sizeof(bt));
     bt.wupt = base + upconv.pkt;
     bt.x0 = ws + L.x[0]; bt.s_c3 = ws + L.c3; bt.o_dc3 = ws + L.dc3;
-    if (!vis_wps) {  // the proprio branch's data-grads (token 0)
+    if (!vis_wps && wps_tail_shape()) {  // the proprio branch's data-grads (token 0)
       bt.wpt = base + proj.pkt; bt.wf2t = base + enc[1].pkt;
       bt.s_e1 = eacts[1].p; bt.s_e0 = eacts[0].p; bt.o_dhc = ws + L.dhc; bt.o_de0 = dehp[0];
     }
@@ -1892,7 +1896,8 @@ int v4l_net::backward_t(const float* state, const T* image, const int* rowidx, i
     V4L_KLAUNCH("wps_layer_bwd_stack", fl, s, (wps_layer_bwd_kernel<T, 2, TAPS_, VIS_, HIN_, TIN_, MODE_>), dim3(nblk), dim3(256), \
                 (WpsBwdLds<T>::bytes), s, d, bh, bt, tx, n);                                                              \
   } while (0)
-    if (opt_wps && c.token_norm && c.pytorch_encoder) V4L_WPS_BWD(false, false, true, true, 3);
+    const bool opt_notail = opt_wps && (c.token_norm || !wps_tail_shape());
+    if (opt_notail && c.pytorch_encoder) V4L_WPS_BWD(false, false, true, true, 3);
     else if (opt_wps && c.pytorch_encoder) V4L_WPS_BWD(false, false, true, true, 2);  // from the final norm's gradient rows
     else if (opt_wps) V4L_WPS_BWD(false, false, true, true, 1);                       // up to the layer-0 input gradient
     else if (vis_wps && taps) V4L_WPS_BWD(true, true, true, true, 0);
@@ -2094,7 +2099,7 @@ int v4l_net::backward_t(const float* state, const T* image, const int* rowidx, i
   }
   // (the option variants: use_pytorch_encoder alone leaves the encoder-side data-grads inside the layers' launch like the plain
   // net; token_norm takes them layer by layer from token_ln's backward)
-  const bool tail_in = fused_tail || (opt_wps && !c.token_norm);
+  const bool tail_in = fused_tail || (opt_wps && !c.token_norm && wps_tail_shape());
   if (tail_in) {  // data-grads done by layer 0's launch: register the four weight-grads
     const Act& last = eacts[ne - 1];
     if ((rc = lin_wgrad<T>(cx, proj, dense(dx, NTOK * TD, n, TD, nullptr, 0, x0), dense(last.p, last.ld, n, last.w), last.w)))
