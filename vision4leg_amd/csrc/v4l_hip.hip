@@ -18,7 +18,10 @@ namespace v4l {
 
 // ------------------------------------------------------------------------------------------ errors
 static thread_local char g_err[1024] = "";
-static const bool g_trace = getenv("V4L_TRACE") != nullptr;
+// The library's switches (include/v4l_hip.h lists them): every one is read through these two, at the call that uses it
+static bool sw_on(const char* name) { return getenv(name) != nullptr; }
+static int sw_int(const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; }
+static const bool g_trace = sw_on("V4L_TRACE");
 #define V4L_TRACE(...) do { if (v4l::g_trace) { fprintf(stderr, "[v4l] " __VA_ARGS__); fputc('\n', stderr); fflush(stderr); } } while (0)
 void set_error(const char* fmt, ...) {
   va_list ap;
@@ -562,7 +565,7 @@ static bool conv_bwd_fusable(const v4l_net* N) {
   return v[1].Rd == 32 && v[1].Kdp == 256 && v[2].Rd == 64 && v[2].Kdp == 576 && v[0].chw && v[0].Cin == 4 && v[0].IH == 64 && v[0].KH == 8 && v[0].stride == 4 && v[0].Cout == 32 &&
          v[1].Cin == 32 && v[1].KH == 4 && v[1].stride == 2 && v[1].Cout == 64 && v[1].OH == 6 &&
          v[2].Cin == 64 && v[2].KH == 3 && v[2].stride == 1 && v[2].Cout == 64 && v[2].OH == 4 &&
-         getenv("V4L_NO_FUSED_CONV_BWD") == nullptr;
+         !sw_on("V4L_NO_FUSED_CONV_BWD");
 }
 template <typename T>
 static int conv_stack_bwd_fused(Ctx& c, const T* image, const int* rowidx, int n, const float* c1, const float* c2,
@@ -615,7 +618,7 @@ static int conv_stack_bwd_fused(Ctx& c, const T* image, const int* rowidx, int n
   a.w3d = (const T*)N->packed + N->conv[2].pkd[0];
   for (int cls = 0; cls < 4; ++cls) a.w2d[cls] = (const T*)N->packed + N->conv[1].pkd[cls];
   a.image = image; a.rowidx = rowidx; a.c1 = c1; a.c2 = c2; a.dc3 = dc3;
-  if (getenv("V4L_LAYER_TAPS") != nullptr) { a.t_dc2 = dc2_tap; a.t_dc1 = dc1_tap; }  // (tests; read per call)
+  if (sw_on("V4L_LAYER_TAPS")) { a.t_dc2 = dc2_tap; a.t_dc1 = dc1_tap; }  // (tests; read per call)
   a.slab1 = slab[0]; a.slab2 = slab[1]; a.slab3 = slab[2];
   a.bslab1 = bslab[0]; a.bslab2 = bslab[1]; a.bslab3 = bslab[2];
   a.n = n;
@@ -1021,7 +1024,7 @@ int64_t v4l_net::table_bytes() const {
 // the NatureCNN nets' dense stack as one launch per direction (csrc/dense_stack.h): the shipped widths only
 static bool dense_stack_shape(const v4l_net* N) {
   const v4l_net_cfg& c = N->cfg;
-  if (getenv("V4L_NO_DENSE_STACK") != nullptr) return false;  // (read per call: tests switch it)
+  if (sw_on("V4L_NO_DENSE_STACK")) return false;  // (read per call: tests switch it)
   if (c.n_head_hidden != 2 || c.head_hidden[0] != 256 || c.head_hidden[1] != 256 || c.out_dim > OUT_LD) return false;
   for (int i = 0; i < 3; ++i)
     if (N->head[i].pkf < 0 || N->head[i].pkft < 0) return false;
@@ -1031,23 +1034,23 @@ static bool dense_stack_shape(const v4l_net* N) {
          N->proj.pkft >= 0 && N->proj.Kp == 1024 && N->enc[1].pkft >= 0 && N->head[0].Kp == 512;
 }
 bool v4l_net::wps_layers() const {
-  return fused_layers() && cfg.n_layers == 2 && layers[0].inproj.pkp >= 0 && getenv("V4L_NO_WPS_LAYERS") == nullptr;
+  return fused_layers() && cfg.n_layers == 2 && layers[0].inproj.pkp >= 0 && !sw_on("V4L_NO_WPS_LAYERS");
 }
 // V4L_VIS17=1 (read per call: a test switches it): the vision-only Transformer on the 17-row wave-per-sample instantiation (dummy
 // row 0) instead of the native 16-token one — the two are cross-checked against each other
-static bool vis17_forced() { return getenv("V4L_VIS17") != nullptr; }
+static bool vis17_forced() { return sw_on("V4L_VIS17"); }
 bool v4l_net::wps_vis() const {
   const v4l_net_cfg& c = cfg;
   return c.kind == V4L_NET_LOCO_VIS && !c.token_norm && !c.pytorch_encoder && c.ff_dim == 256 && c.n_layers == 2 && c.n_head_hidden == 2 && c.head_hidden[0] == 256 &&
          c.head_hidden[1] == 256 && c.out_dim <= OUT_LD && layers[0].inproj.pkp >= 0 && head[0].pko >= 0 &&
-         getenv("V4L_NO_WPS_LAYERS") == nullptr;
+         !sw_on("V4L_NO_WPS_LAYERS");
 }
 // max_pool=True on the (non-vision) wave-per-sample pair: forward and backward must both take it (the block-cooperative kernels
 // pool by mean only)
 bool v4l_net::wps_max_pool() const {
   const v4l_net_cfg& c = cfg;
   return c.kind == V4L_NET_LOCO && c.n_layers == 2 && c.n_enc_hidden == 2 && c.enc_hidden[0] == 256 && c.enc_hidden[1] == 256 &&
-         getenv("V4L_NO_LAYER_STACK") == nullptr && wps_layers();
+         !sw_on("V4L_NO_LAYER_STACK") && wps_layers();
 }
 // The wave-per-sample layers with layer-by-layer launches around them (round 5): token_norm / use_pytorch_encoder, or a proprio MLP
 // that is not the shipped 256-256 one. The LocoTransformer's two layers (and, without the final LayerNorm, its pooled heads) run
@@ -1061,8 +1064,8 @@ bool v4l_net::wps_opt() const {
   if (c.kind != V4L_NET_LOCO || c.max_pool) return false;
   if (!(c.token_norm || c.pytorch_encoder) && wps_tail_shape()) return false;  // (the plain shipped net: wps_bwd_plain's launch)
   return c.ff_dim == 256 && c.n_layers == 2 && c.n_head_hidden == 2 && c.head_hidden[0] == 256 && c.head_hidden[1] == 256 &&
-         c.out_dim <= OUT_LD && layers[0].inproj.pkp >= 0 && getenv("V4L_NO_WPS_LAYERS") == nullptr &&
-         getenv("V4L_NO_LAYER_STACK") == nullptr && getenv("V4L_LAYER_TAPS") == nullptr;
+         c.out_dim <= OUT_LD && layers[0].inproj.pkp >= 0 && !sw_on("V4L_NO_WPS_LAYERS") &&
+         !sw_on("V4L_NO_LAYER_STACK") && !sw_on("V4L_LAYER_TAPS");
 }
 bool v4l_net::fused_layers() const {
   return cfg.kind == V4L_NET_LOCO && cfg.ff_dim == 256 && !cfg.token_norm && !cfg.pytorch_encoder;
@@ -1076,7 +1079,7 @@ bool v4l_net::wps_bwd_plain() const {
                           c.head_hidden[1] == 256 && c.out_dim <= OUT_LD && (!c.max_pool || wps_max_pool());
   const bool fused_tail = fused_bwd && c.n_layers >= 1 && c.n_enc_hidden == 2 && c.enc_hidden[0] == 256 &&
                           c.enc_hidden[1] == 256;
-  return fused_bwd && fused_head && fused_tail && c.n_layers == 2 && getenv("V4L_NO_LAYER_STACK") == nullptr && wps_layers();
+  return fused_bwd && fused_head && fused_tail && c.n_layers == 2 && !sw_on("V4L_NO_LAYER_STACK") && wps_layers();
 }
 // The operands of the pooled heads' data-grad chain over the workspace `ws` laid out for n rows, for a caller (the trainer's
 // loss launch) that runs the chain itself right before v4l_net_backward(ws, n): -> 1 and the backward pass is told (it then
@@ -1084,7 +1087,7 @@ bool v4l_net::wps_bwd_plain() const {
 // the in-kernel heads).
 int v4l_net::heads_ext(float* ws, int n, v4l::RowsChain* out) {
   heads_ext_ws = nullptr;
-  if (!bound || out == nullptr || !wps_bwd_plain() || getenv("V4L_WPS_HEAD_IN") != nullptr || getenv("V4L_LAYER_TAPS") != nullptr)
+  if (!bound || out == nullptr || !wps_bwd_plain() || sw_on("V4L_WPS_HEAD_IN") || sw_on("V4L_LAYER_TAPS"))
     return 0;
   const Layout L = layout(n);
   const size_t es = cfg.compute == V4L_BF16 ? 2 : 4;
@@ -1244,7 +1247,7 @@ int v4l_net::forward_t(const float* state, const T* image, const int* rowidx, in
     te.s_h1 = prop ? ws + L.eh[0] : nullptr; te.s_h2 = s_h2; te.ld_h2 = ld_h2;
     te.n = n; te.nmlp = prop ? cdiv(n, 32) : 0;
     // (V4L_ACTS_F32: keep c1 / c2 in fp32 — the cross-check of tests/test_gpu_parity.py::test_conv_acts_in_operand_type_same_bits)
-    te.acts16 = want_acts16 && conv_bwd_fusable(this) && getenv("V4L_LAYER_TAPS") == nullptr && getenv("V4L_ACTS_F32") == nullptr;
+    te.acts16 = want_acts16 && conv_bwd_fusable(this) && !sw_on("V4L_LAYER_TAPS") && !sw_on("V4L_ACTS_F32");
     acts16_written = te.acts16 != 0;
     constexpr int cus = 256;
     // the conv share never collapses: a very large minibatch (n >~ 8 K: nmlp -> cus) still gets half the CUs' worth of
@@ -1381,7 +1384,7 @@ int v4l_net::forward_t(const float* state, const T* image, const int* rowidx, in
                             c.out_dim <= OUT_LD && (!c.max_pool || wps_max_pool());
     // both layers + the heads in ONE launch when the stack is the shipped two layers (the token rows stay in LDS between
     // the layers); otherwise one launch per TransformerEncoderLayer. 2 or 4 samples per block, saving what backward_t reads.
-    const bool stack_ok = getenv("V4L_NO_LAYER_STACK") == nullptr;  // (read per call: tests switch it)
+    const bool stack_ok = !sw_on("V4L_NO_LAYER_STACK");  // (read per call: tests switch it)
     const bool stacked = fused_layers && fused_head && c.n_layers == 2 && stack_ok;
     const bool vis_wps = c.kind == V4L_NET_LOCO_VIS && enc_ws == nullptr && stage == 0 && wps_vis();
     // (wps_bwd_plain: the wave-per-sample forward keeps only the layers' input rows, which only the wave-per-sample backward
@@ -1406,7 +1409,7 @@ int v4l_net::forward_t(const float* state, const T* image, const int* rowidx, in
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)WpsFwdLds<T>::bytes));
         wps_attr = true;
       }
-      const bool taps = getenv("V4L_LAYER_TAPS") != nullptr;  // (read per call: tests switch it)
+      const bool taps = sw_on("V4L_LAYER_TAPS");  // (read per call: tests switch it)
       const T* base = (const T*)packed;
       InfLayerStack stk;
       memset(&stk, 0, sizeof(stk));
@@ -1644,7 +1647,7 @@ int v4l_net::backward_t(const float* state, const T* image, const int* rowidx, i
   // data-grads 33.7 (bwd_conv_kernel holds every CU: nothing fits beside it); conv-stack data-grads FIRST, then dW3 on the
   // main stream next to the two dense launches on the auxiliary stream 32.8 (default); three branches 34.8.
   // V4L_PAR_WGRAD=0: serial, 1: the older fork.
-  const int par_wgrad = getenv("V4L_PAR_WGRAD") ? atoi(getenv("V4L_PAR_WGRAD")) : 2;  // (read per call: tests switch it)
+  const int par_wgrad = sw_int("V4L_PAR_WGRAD", 2);  // (read per call: tests switch it)
   if (par_wgrad == 2 || par_wgrad == 3) {
     cx.defer_conv3 = true;
     if ((rc = conv_stack_bwd<T>(cx, image, rowidx, n, ws + L.c1, ws + L.c2, ws + L.dc3, ws + L.dc2, ws + L.dc1))) return rc;
@@ -1659,7 +1662,7 @@ int v4l_net::backward_t(const float* state, const T* image, const int* rowidx, i
     // stream, the others behind the grouped weight-grads on the auxiliary stream — so that the join only gates clip_adam
     // (the update timeline showed 9 - 11 us of join latency in front of a 19 us reduce launch). V4L_SPLIT_REDUCE=0: one launch
     // behind the join. (Same descriptor order, hence the same bits, either way.)
-    const bool split_red = !three && cx.tn != cx.s && (getenv("V4L_SPLIT_REDUCE") == nullptr || atoi(getenv("V4L_SPLIT_REDUCE")) != 0);
+    const bool split_red = !three && cx.tn != cx.s && sw_int("V4L_SPLIT_REDUCE", 1) != 0;
     int64_t rblocks[2] = {0, 0};
     if (split_red && (rc = wgrad_reduce_prepare(cx, rblocks))) return rc;
     if (split_red) {
@@ -1819,22 +1822,22 @@ int v4l_net::backward_t(const float* state, const T* image, const int* rowidx, i
   // both layers (+ heads before, + encoder-side data-grads after) in ONE launch when the stack is the shipped two layers: the
   // upper layer's dx stays in LDS as the lower layer's dy; otherwise one launch per TransformerEncoderLayer (csrc/bwd.h).
   // Every data-grad of a layer has its intermediates in LDS; the four weight-grads are deferred to the grouped launch.
-  const bool bwd_stack_ok = getenv("V4L_NO_LAYER_STACK") == nullptr;
+  const bool bwd_stack_ok = !sw_on("V4L_NO_LAYER_STACK");
   const bool stacked = fused_bwd && fused_head && fused_tail && c.n_layers == 2 && bwd_stack_ok;
   const bool wps = (stacked && wps_layers()) || vis_wps || opt_wps;
   if (wps) {
     // wave-per-sample launch (csrc/wps.h): heads -> per layer {recompute, backward} -> encoder-side data-grads; the four
     // weight-grads of each layer come from the fragment-order operand blocks it leaves, in one launch of their own
-    const bool taps = getenv("V4L_LAYER_TAPS") != nullptr;  // (read per call: tests switch it)
+    const bool taps = sw_on("V4L_LAYER_TAPS");  // (read per call: tests switch it)
     // round 4: the heads' and the proprio branch's data-grad chains outside this launch, 64 rows per block (csrc/wps.h
     // rows_chain): the heads ran beside the loss statistics when the trainer said so (heads_ext), the proprio chain rides in
     // the layers' weight-grad launch unless the grouped weight-grads (its consumer) go to a stream of their own
     const bool head_ext = !vis_wps && !taps && !opt_wps && heads_ext_ws == ws && heads_ext_n == n;
     heads_ext_ws = nullptr;
-    const int par_wgrad_now = getenv("V4L_PAR_WGRAD") ? atoi(getenv("V4L_PAR_WGRAD")) : 2;
+    const int par_wgrad_now = sw_int("V4L_PAR_WGRAD", 2);
     // (the option variants keep the proprio chain where the layer-0 gradient is: in the launch, or — token_norm — layer by layer
     // behind token_ln's backward)
-    const bool tok0_ext = !vis_wps && !taps && !opt_wps && par_wgrad_now != 3 && getenv("V4L_WPS_TOK0_IN") == nullptr;
+    const bool tok0_ext = !vis_wps && !taps && !opt_wps && par_wgrad_now != 3 && !sw_on("V4L_WPS_TOK0_IN");
     const int nblk = cdiv(n, WPS_WPB);
     const T* base = (const T*)packed;
     WpsBwdStack d;
@@ -2304,7 +2307,7 @@ static int run_actor_dense_cnn(v4l_actor* a, const float* obs, const float* eps,
   fin.acts_roll = acts_roll; fin.values_roll = values_roll; fin.logp_roll = logp_roll; fin.action = action;
   fin.mean = mean; fin.stdv = stdv; fin.ent = ent; fin.value = value;
   g_op = "dense";
-  if (getenv("V4L_ROLLOUT_DENSE_SPLIT") == nullptr) {  // (read per call: tests switch it)
+  if (!sw_on("V4L_ROLLOUT_DENSE_SPLIT")) {  // (read per call: tests switch it)
     // projector -> fc0 -> fc1 -> last linear -> epilogue as stages of one launch (device-side hand-overs)
     RollDense d;
     memset(&d, 0, sizeof(d));
@@ -2741,7 +2744,7 @@ int v4l_net_bind(v4l_net* net, float* const* params_dev, void* packed_dev, void*
     segs[i].blk0 = blk;
     blk += cdiv64(net->params[i].numel, 256);
   }
-  if (net->aux == nullptr && (getenv("V4L_PAR") == nullptr || atoi(getenv("V4L_PAR")) != 0)) {
+  if (net->aux == nullptr && sw_int("V4L_PAR", 1) != 0) {
     V4L_HIP_CHECK(hipStreamCreateWithFlags(&net->aux, hipStreamNonBlocking));
     V4L_HIP_CHECK(hipEventCreateWithFlags(&net->ev_fork, hipEventDisableTiming));
     V4L_HIP_CHECK(hipEventCreateWithFlags(&net->ev_join, hipEventDisableTiming));
@@ -3340,7 +3343,7 @@ int v4l_trainer_critic_grads(v4l_trainer* tr, const v4l_rollout* ro, int n, cons
     // more (21 us launch) than it saves — measured with tools/update_timeline.py, profiles/r4_update_timeline.txt — so the
     // critic keeps the in-kernel heads unless V4L_WPS_HEAD_EXT_CRITIC=1.
     RowsChain hc;
-    const bool ext_critic = getenv("V4L_WPS_HEAD_EXT_CRITIC") != nullptr;  // (read per call: tests switch it)
+    const bool ext_critic = sw_on("V4L_WPS_HEAD_EXT_CRITIC");  // (read per call: tests switch it)
     const bool ext = ext_critic && vf->heads_ext(tr->ws, n, &hc) != 0;
     const dim3 blk(n >= 512 ? 1024 : 256);
     if (ext) {
