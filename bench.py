@@ -208,7 +208,7 @@ class Epoch:
 def side_leg(wl_name, compute, dev, steps=3, warmup=1):
     """A short timed run of another (workload, compute mode) in the SAME process, after the headline's timed region: the same
     Epoch, the same step, `steps` epochs. Used for the exact-fp32 mode (the mode that meets the north star's literal 1e-3 against
-    the fp32 reference) and for one option variant that runs on the layer-by-layer kernels."""
+    the fp32 reference) and for the net's option variants."""
     before = os.environ.get("V4L_COMPUTE")
     wl = dict(WORKLOADS[wl_name])
     try:
@@ -879,7 +879,7 @@ def main():
         child = os.environ.get("V4L_BENCH_CHILD", "0") != "0"
         if world == 1 and not a.no_parity and not child and a.workload in ("loco", "loco64"):
             # side legs (driver-visible, all after the timed region): the exact-fp32 mode with the same parity check, the DP
-            # schedule on one rank, one option variant on the layer-by-layer kernels, and the multi-GPU cost model
+            # schedule on one rank, the net's option variants (max_pool; token_norm, use_pytorch_encoder), and the multi-GPU cost model
             other = "f32" if a.compute == "bf16" else "bf16"
             res["f32_mode" if other == "f32" else "bf16_mode"] = dict(
                 side_leg(a.workload, other, dev), parity_check=parity_check(wl, other, dev),
@@ -888,6 +888,8 @@ def main():
             res["dp1_ingraph"] = dp1_ingraph_leg(a.workload, a.compute)
             res["dp1_ingraph_value"] = res["dp1_ingraph"].get("value")
             res["option_variant"] = side_leg("loco_max", a.compute, dev, steps=2, warmup=1)
+            # (round 5: the other two net options, fused since this round — DESIGN.md section 1)
+            res["option_variants"] = {w: side_leg(w, a.compute, dev, steps=2, warmup=1) for w in ("loco_tn", "loco_pe")}
             alpha0 = (res["dp1_ingraph"].get("allreduce") or {}).get("us_per_call") or 12.0
             res["dp_model"] = {str(n): dp_model(n, bucket, alpha0, None, 1e3 * dt / a.steps, upd_per_epoch, wl["E"] * wl["T"])
                                for n in (2, 4, 8)}
