@@ -57,6 +57,7 @@ a)  # round 5, session A: today's baseline line, the rolled-layer-loop build (I-
   ;;
 b)  # round 5, session B: the extended default line (f32 / dp1 / option-variant legs), the rollout floor probe, scheduling variants
   python bench.py > $O/r5b_bench_full.json 2> $O/r5b_bench_full.err; tail -c 3000 $O/r5b_bench_full.json; tail -5 $O/r5b_bench_full.err
+  [ -x tools/probe/rollout_floor ] || /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 tools/probe/rollout_floor.hip -o tools/probe/rollout_floor
   tools/probe/rollout_floor > $O/r5b_rollout_floor.txt 2>&1; cat $O/r5b_rollout_floor.txt
   L=$REPO/vision4leg_amd
   bench_ab r5b 3 "base=" "eu1=V4L_LIB=$L/libv4l_hip_eu1.so" "ilp=V4L_LIB=$L/libv4l_hip_ilp.so" "bias0=V4L_LIB=$L/libv4l_hip_bias0.so"
