@@ -102,7 +102,7 @@ typedef struct v4l_net_cfg {
   int token_norm;      /* V4L_NET_LOCO / V4L_NET_LOCO_VIS: LayerNorm(token_dim) over every token in front of the transformer layers
                           (token_norm=True: nets.py:815-818, 879-880, 1007-1008; parameters token_ln.* and the never-used
                           state_token_ln.*); round 5: fused rollout step, update with the layers on the wave-per-sample kernels
-                          and token_ln as a launch of its own (vision-only net: layer by layer); no shipped config sets it */
+                          and token_ln as a launch of its own; no shipped config sets it */
   int pytorch_encoder; /* V4L_NET_LOCO / V4L_NET_LOCO_VIS: the layers are an nn.TransformerEncoder WITH a final LayerNorm
                           (use_pytorch_encoder=True: nets.py:955-963, 884-885, 1012-1013; parameters
                           visual_trans_encoder.layers.N.*, visual_trans_encoder.norm.*); round 5: as token_norm, with the

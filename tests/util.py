@@ -44,7 +44,7 @@ CASES = {
     "loco_vis_max": dict(kind="loco_vis_max", S=0, A=6, seed=13, B=32, enc=[], head=[256, 256], layers=2, ff=256),
     # token_norm=True (nets.py:815-818, 879-880, 1007-1008; no shipped config sets it): token_ln over every token in front of the
     # transformer layers (and the state_token_ln parameters nobody uses) — round 5: fused rollout step; update with the two layers
-    # on the wave-per-sample kernels around token_ln's own launches (the vision-only net: layer by layer)
+    # on the wave-per-sample kernels around token_ln's own launches
     "loco_tn": dict(kind="loco_tn", S=84, A=6, seed=16, B=32, enc=[256, 256], head=[256, 256], layers=2, ff=256),
     "loco_vis_tn": dict(kind="loco_vis_tn", S=0, A=6, seed=17, B=32, enc=[], head=[256, 256], layers=2, ff=256, param_tol_f32=4e-5),
     # use_pytorch_encoder=True (nets.py:955-963; no shipped config sets it): the layers are an nn.TransformerEncoder — clones of

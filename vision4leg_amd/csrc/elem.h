@@ -267,28 +267,29 @@ __global__ __launch_bounds__(64) void pool_bwd_kernel(const float* __restrict__ 
 }
 
 // vision-only Transformer (torchrl/networks/nets.py:884-889: out[0 : 1 + 16].mean(dim=0) over a 16-token sequence is the
-// mean of all tokens; max_pool=True: their max) -> [n][64]
-__global__ __launch_bounds__(64) void pool_all_fwd_kernel(const float* __restrict__ x, int n, int ntok, float* __restrict__ pooled,
-                                                          int mx) {
+// mean of all tokens; max_pool=True: their max) -> [n][64]. srows: rows between two samples' first tokens (ntok when the token
+// rows are dense; 17 with x pointing at row 1 of a 17-row slot: the wave-per-sample kernels' layout)
+__global__ __launch_bounds__(64) void pool_all_fwd_kernel(const float* __restrict__ x, int n, int ntok, int srows,
+                                                          float* __restrict__ pooled, int mx) {
   const int b = blockIdx.x, d = threadIdx.x;
   if (b >= n) return;
-  const float* xb = x + (int64_t)b * ntok * TD;
+  const float* xb = x + (int64_t)b * srows * TD;
   float s = mx ? -INFINITY : 0.f;
   for (int i = 0; i < ntok; ++i) s = mx ? fmaxf(s, xb[i * TD + d]) : s + xb[i * TD + d];
   pooled[(int64_t)b * TD + d] = mx ? s : s * (1.f / (float)ntok);
 }
-__global__ __launch_bounds__(64) void pool_all_bwd_kernel(const float* __restrict__ dpooled, int n, int ntok, float* __restrict__ dx,
-                                                          const float* __restrict__ x, int mx) {
+__global__ __launch_bounds__(64) void pool_all_bwd_kernel(const float* __restrict__ dpooled, int n, int ntok, int srows,
+                                                          float* __restrict__ dx, const float* __restrict__ x, int mx) {
   const int b = blockIdx.x, d = threadIdx.x;
   if (b >= n) return;
   const float dg = dpooled[(int64_t)b * TD + d];
-  float* o = dx + (int64_t)b * ntok * TD;
+  float* o = dx + (int64_t)b * srows * TD;
   if (!mx) {
     const float dm = dg * (1.f / (float)ntok);
     for (int i = 0; i < ntok; ++i) o[i * TD + d] = dm;
     return;
   }
-  const float* xb = x + (int64_t)b * ntok * TD;
+  const float* xb = x + (int64_t)b * srows * TD;
   int arg = 0;
   float best = xb[d];
   for (int i = 1; i < ntok; ++i) {

@@ -156,6 +156,7 @@ struct v4l_net {
   bool wps_layers() const;
   bool wps_max_pool() const;  // max_pool=True pooled inside the wave-per-sample pair
   bool wps_opt() const;       // token_norm / use_pytorch_encoder / another proprio MLP around the wave-per-sample layers
+  bool wps_opt_vis() const;   // the same for the vision-only Transformer (native 16-token kernels, 17-row slots)
   bool wps_tail_shape() const;  // the proprio MLP the wave-per-sample backward continues into (256-256)
   bool wps_vis() const;  // vision-only Transformer on the wave-per-sample kernels (dummy token row, csrc/wps.h)    // ... as wave-per-sample launches (csrc/wps.h)
   template <typename T> int backward_t(const float* state, const T* image, const int* rowidx, int n, float* ws, float* grads, hipStream_t s);

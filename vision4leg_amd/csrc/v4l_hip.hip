@@ -1067,6 +1067,15 @@ bool v4l_net::wps_opt() const {
          c.out_dim <= OUT_LD && layers[0].inproj.pkp >= 0 && !sw_on("V4L_NO_WPS_LAYERS") &&
          !sw_on("V4L_NO_LAYER_STACK") && !sw_on("V4L_LAYER_TAPS");
 }
+// The same for the vision-only Transformer: its layers on the native 16-token wave-per-sample kernels (17-row slots, tokens in
+// rows 1..16) with token_ln / the final norm + pooling + heads as launches over the 17-row slots (the dummy rows zeroed).
+bool v4l_net::wps_opt_vis() const {
+  const v4l_net_cfg& c = cfg;
+  if (c.kind != V4L_NET_LOCO_VIS || !(c.token_norm || c.pytorch_encoder) || c.max_pool) return false;
+  return c.ff_dim == 256 && c.n_layers == 2 && c.n_head_hidden == 2 && c.head_hidden[0] == 256 && c.head_hidden[1] == 256 &&
+         c.out_dim <= OUT_LD && layers[0].inproj.pkp >= 0 && head[0].pko >= 0 && !sw_on("V4L_NO_WPS_LAYERS") &&
+         !sw_on("V4L_NO_LAYER_STACK") && !sw_on("V4L_LAYER_TAPS");
+}
 bool v4l_net::fused_layers() const {
   return cfg.kind == V4L_NET_LOCO && cfg.ff_dim == 256 && !cfg.token_norm && !cfg.pytorch_encoder;
 }
@@ -1337,7 +1346,7 @@ int v4l_net::forward_t(const float* state, const T* image, const int* rowidx, in
     } else if (enc_ws == nullptr && stage != 2 && c.kind == V4L_NET_LOCO_VIS) {
       // TransformerEncoder (base.py:388-494, depth only): conv stack -> 1x1 up-conv -> the 16 patch tokens, in order
       // wave-per-sample path: the 16 tokens go to rows 1..16 of a 17-row stride (row 0 = the dummy row, csrc/wps.h)
-      const bool rows17 = stage == 0 && wps_vis();
+      const bool rows17 = stage == 0 && (wps_vis() || wps_opt_vis());
       if (train_enc_ok) {
         if (rows17) rc = train_enc(std::integral_constant<int, ENC_TOK17>(), x0, nullptr, 0, false);
         else rc = train_enc(std::integral_constant<int, ENC_TOK16>(), x0, nullptr, 0);
@@ -1368,7 +1377,14 @@ int v4l_net::forward_t(const float* state, const T* image, const int* rowidx, in
       if ((rc = par_end(cx))) return rc;
     }
     if (stage == 1) return 0;
-    const int R = n * ntok;
+    // (vision-only net with token_norm / use_pytorch_encoder on the wave-per-sample layers: 17-row slots, the dummy rows zeroed
+    // wherever a LayerNorm launch walks over them)
+    const bool vis_opt = c.kind == V4L_NET_LOCO_VIS && wps_opt_vis() && enc_ws == nullptr && stage == 0;
+    const int R = n * (vis_opt ? NTOK : ntok);
+    auto zero_row0 = [&](float* rows) {
+      return hipMemset2DAsync(rows, (size_t)NTOK * TD * sizeof(float), 0, (size_t)TD * sizeof(float), (size_t)n, s);
+    };
+    if (vis_opt && c.token_norm) V4L_HIP_CHECK(zero_row0(x0));
     if (c.token_norm) {  // out = token_ln(visual_out) (nets.py:879-880, 1007-1008): LayerNorm of (tokens + 0)
       V4L_HIP_CHECK(hipMemsetAsync(ws + L.ytmp, 0, (size_t)R * TD * sizeof(float), s));
       g_op = "token_ln";
@@ -1389,7 +1405,7 @@ int v4l_net::forward_t(const float* state, const T* image, const int* rowidx, in
     const bool vis_wps = c.kind == V4L_NET_LOCO_VIS && enc_ws == nullptr && stage == 0 && wps_vis();
     // (wps_bwd_plain: the wave-per-sample forward keeps only the layers' input rows, which only the wave-per-sample backward
     // can start from — a geometry whose backward stays layer-by-layer must not take it)
-    const bool opt_wps = wps_opt() && enc_ws == nullptr && stage == 0;
+    const bool opt_wps = (wps_opt() && enc_ws == nullptr && stage == 0) || vis_opt;
     bool wps_layers_done = false;  // (use_pytorch_encoder on the wave-per-sample layers: norm, pooling and heads still to come)
     if ((stacked && wps_layers() && wps_bwd_plain()) || vis_wps || opt_wps) {
       // wave-per-sample launch (csrc/wps.h): both layers + the pooled heads, 4 samples per block, weights resident in LDS
@@ -1406,6 +1422,8 @@ int v4l_net::forward_t(const float* state, const T* image, const int* rowidx, in
         V4L_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&wps_layer_fwd_kernel<T, true, 2, false, 2>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)WpsFwdLds<T>::bytes));
         V4L_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&wps_layer_fwd_kernel<T, false, 2, false>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)WpsFwdLds<T>::bytes));
+        V4L_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&wps_layer_fwd_kernel<T, false, 2, false, 2>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)WpsFwdLds<T>::bytes));
         wps_attr = true;
       }
@@ -1436,12 +1454,18 @@ int v4l_net::forward_t(const float* state, const T* image, const int* rowidx, in
       InfHeadPair hd;
       memset(&hd, 0, sizeof(hd));
       InfHead& h = hd.n[0];
-      h.w0 = base + (vis_wps ? head[0].pko : head[0].pk); h.w1 = base + head[1].pk; h.w2 = base + head[2].pk;
+      h.w0 = base + ((vis_wps || vis_opt) ? head[0].pko : head[0].pk); h.w1 = base + head[1].pk; h.w2 = base + head[2].pk;
       h.b0 = p[head[0].b]; h.b1 = p[head[1].b]; h.b2 = p[head[2].b];
       h.out = ws + L.out; h.nout = c.out_dim; h.max_pool = c.max_pool;
       h.s_pooled = ws + L.pooled; h.s_h0 = ws + L.hh[0]; h.s_h1 = ws + L.hh[1];
       g_op = "layer";
-      if (opt_wps && c.pytorch_encoder)  // layers only: final norm, pooling and heads follow below
+      if (vis_opt && c.pytorch_encoder)  // layers only: final norm, pooling and heads follow below
+        V4L_KLAUNCH("wps_layer_stack", 2.0 * n * (2 * 872576.0), s, (wps_layer_fwd_kernel<T, false, 2, false, 2>),
+                    dim3(cdiv(n, WPS_WPB)), dim3(256), (WpsFwdLds<T>::bytes), s, stk, hd, n);
+      else if (vis_opt)
+        V4L_KLAUNCH("wps_layer_stack_head", 2.0 * n * (2 * 872576.0 + 99840.0), s, (wps_layer_fwd_kernel<T, true, 2, false, 2>),
+                    dim3(cdiv(n, WPS_WPB)), dim3(256), (WpsFwdLds<T>::bytes), s, stk, hd, n);
+      else if (opt_wps && c.pytorch_encoder)
         V4L_KLAUNCH("wps_layer_stack", 2.0 * n * (2 * 872576.0), s, (wps_layer_fwd_kernel<T, false, 2, false>),
                     dim3(cdiv(n, WPS_WPB)), dim3(256), (WpsFwdLds<T>::bytes), s, stk, hd, n);
       else if (vis_wps && taps)
@@ -1554,6 +1578,7 @@ int v4l_net::forward_t(const float* state, const T* image, const int* rowidx, in
       V4L_LAUNCH_CHECK();
     }
     const float* xlast = ws + L.x[c.n_layers];
+    if (vis_opt && c.pytorch_encoder) V4L_HIP_CHECK(zero_row0(ws + L.x[c.n_layers]));  // (the layers' launch wrote rows 1..16)
     if (c.pytorch_encoder) {  // nn.TransformerEncoder's final norm (nets.py:884-885, 1012-1013): LayerNorm of (rows + 0)
       V4L_HIP_CHECK(hipMemsetAsync(ws + L.ytmp, 0, (size_t)R * TD * sizeof(float), s));
       g_op = "final_ln";
@@ -1564,8 +1589,8 @@ int v4l_net::forward_t(const float* state, const T* image, const int* rowidx, in
     }
     g_op = "pool";
     if (c.kind == V4L_NET_LOCO_VIS) {
-      V4L_KLAUNCH("pool_fwd", 0, s, pool_all_fwd_kernel, dim3(n), dim3(64), 0, s, xlast, n, ntok, ws + L.pooled,
-                  c.max_pool);
+      V4L_KLAUNCH("pool_fwd", 0, s, pool_all_fwd_kernel, dim3(n), dim3(64), 0, s, xlast + (vis_opt ? TD : 0), n, ntok,
+                  vis_opt ? NTOK : ntok, ws + L.pooled, c.max_pool);
       head_in = dense(ws + L.pooled, TD, n, TD);
     } else {
       V4L_KLAUNCH("pool_fwd", 0, s, pool_fwd_kernel, dim3(n), dim3(128), 0, s, xlast, n, ws + L.pooled, c.max_pool);
@@ -1782,7 +1807,12 @@ int v4l_net::backward_t(const float* state, const T* image, const int* rowidx, i
   // ---- LocoTransformer / vision-only Transformer
   const bool vis = c.kind == V4L_NET_LOCO_VIS;
   const int pw = vis ? TD : 2 * TD;  // pooled width
-  const int R = n * ntok;
+  // (vision-only net with token_norm / use_pytorch_encoder around the wave-per-sample layers: 17-row slots — see forward_t)
+  const bool vis_opt = vis && wps_opt_vis();
+  const int R = n * (vis_opt ? NTOK : ntok);
+  auto zero_row0 = [&](float* rows) {
+    return hipMemset2DAsync(rows, (size_t)NTOK * TD * sizeof(float), 0, (size_t)TD * sizeof(float), (size_t)n, s);
+  };
   const bool fused_bwd = fused_layers();  // forward and backward switch together: they share the T-typed saves
   // the last layer's launch starts from dout (heads + un-pool), layer 0's launch continues into the encoder MLP / up-conv
   const bool fused_head = fused_bwd && c.n_layers >= 1 && nh == 2 && c.head_hidden[0] == 256 && c.head_hidden[1] == 256 &&
@@ -1792,12 +1822,12 @@ int v4l_net::backward_t(const float* state, const T* image, const int* rowidx, i
   const bool vis_wps = vis && wps_vis();
   // token_norm / use_pytorch_encoder around the wave-per-sample layers (wps_opt): without the final norm the heads run inside
   // the layers' launch as usual; with it they (and the pooling and the norm) are the layer-by-layer launches below
-  const bool opt_wps = wps_opt();
+  const bool opt_wps = wps_opt() || vis_opt;
   const bool opt_heads_in = opt_wps && !c.pytorch_encoder;
   if (fused_head || vis_wps || opt_heads_in) {  // only the three weight-grads are registered here
     if ((rc = lin_wgrad<T>(cx, head[2], dy, dense(hacts[1].p, 256, n, 256), 256))) return rc;
     if ((rc = lin_wgrad<T>(cx, head[1], dense(dhhp[1], 256, n, 256), dense(hacts[0].p, 256, n, 256), 256))) return rc;
-    if (vis_wps) rc = lin_wgrad<T>(cx, head[0], dense(dhhp[0], 256, n, 256), dense(ws + L.pooled + TD, 2 * TD, n, TD), TD);
+    if (vis_wps || vis_opt) rc = lin_wgrad<T>(cx, head[0], dense(dhhp[0], 256, n, 256), dense(ws + L.pooled + TD, 2 * TD, n, TD), TD);
     else rc = lin_wgrad<T>(cx, head[0], dense(dhhp[0], 256, n, 256), dense(ws + L.pooled, 2 * TD, n, 2 * TD), 2 * TD);
     if (rc) return rc;
   } else {
@@ -1808,8 +1838,10 @@ int v4l_net::backward_t(const float* state, const T* image, const int* rowidx, i
     // (pytorch_encoder: the pooled rows are the final LayerNorm's output; its backward then gives the grad w.r.t. the last layer's)
     float* dlast = c.pytorch_encoder ? ws + L.dxfin : ws + L.dxl[c.n_layers];
     const float* xlast = c.pytorch_encoder ? ws + L.xfin : ws + L.x[c.n_layers];
+    if (vis_opt) V4L_HIP_CHECK(zero_row0(dlast));  // (the final norm's backward walks the 17-row slots)
     if (vis)
-      V4L_KLAUNCH("pool_bwd", 0, s, pool_all_bwd_kernel, dim3(n), dim3(64), 0, s, ws + L.dpool, n, ntok, dlast, xlast, c.max_pool);
+      V4L_KLAUNCH("pool_bwd", 0, s, pool_all_bwd_kernel, dim3(n), dim3(64), 0, s, ws + L.dpool, n, ntok, vis_opt ? NTOK : ntok,
+                  dlast + (vis_opt ? TD : 0), xlast + (vis_opt ? TD : 0), c.max_pool);
     else
       V4L_KLAUNCH("pool_bwd", 0, s, pool_bwd_kernel, dim3(n), dim3(64), 0, s, ws + L.dpool, n, dlast, xlast, c.max_pool);
     V4L_LAUNCH_CHECK();
@@ -1870,13 +1902,13 @@ int v4l_net::backward_t(const float* state, const T* image, const int* rowidx, i
     }
     BwdHead bh;
     memset(&bh, 0, sizeof(bh));
-    bh.w2t = base + head[2].pkt; bh.w1t = base + head[1].pkt; bh.w0t = base + (vis_wps ? head[0].pkto : head[0].pkt);
+    bh.w2t = base + head[2].pkt; bh.w1t = base + head[1].pkt; bh.w0t = base + ((vis_wps || vis_opt) ? head[0].pkto : head[0].pkt);
     bh.dout = ws + L.dout; bh.s_h1 = hacts[1].p; bh.s_h0 = hacts[0].p; bh.o_dh1 = dhhp[1]; bh.o_dh0 = dhhp[0];
     BwdTail bt;
     memset(&bt, 0, sizeof(bt));
     bt.wupt = base + upconv.pkt;
     bt.x0 = ws + L.x[0]; bt.s_c3 = ws + L.c3; bt.o_dc3 = ws + L.dc3;
-    if (!vis_wps && wps_tail_shape()) {  // the proprio branch's data-grads (token 0)
+    if (!vis && wps_tail_shape()) {  // the proprio branch's data-grads (token 0)
       bt.wpt = base + proj.pkt; bt.wf2t = base + enc[1].pkt;
       bt.s_e1 = eacts[1].p; bt.s_e0 = eacts[0].p; bt.o_dhc = ws + L.dhc; bt.o_de0 = dehp[0];
     }
@@ -1899,8 +1931,11 @@ int v4l_net::backward_t(const float* state, const T* image, const int* rowidx, i
     V4L_KLAUNCH("wps_layer_bwd_stack", fl, s, (wps_layer_bwd_kernel<T, 2, TAPS_, VIS_, HIN_, TIN_, MODE_>), dim3(nblk), dim3(256), \
                 (WpsBwdLds<T>::bytes), s, d, bh, bt, tx, n);                                                              \
   } while (0)
-    const bool opt_notail = opt_wps && (c.token_norm || !wps_tail_shape());
-    if (opt_notail && c.pytorch_encoder) V4L_WPS_BWD(false, false, true, true, 3);
+    const bool opt_notail = opt_wps && (c.token_norm || !(vis || wps_tail_shape()));
+    if (vis_opt && opt_notail && c.pytorch_encoder) V4L_WPS_BWD(false, 2, true, true, 3);
+    else if (vis_opt && c.pytorch_encoder) V4L_WPS_BWD(false, 2, true, true, 2);
+    else if (vis_opt) V4L_WPS_BWD(false, 2, true, true, 1);
+    else if (opt_notail && c.pytorch_encoder) V4L_WPS_BWD(false, false, true, true, 3);
     else if (opt_wps && c.pytorch_encoder) V4L_WPS_BWD(false, false, true, true, 2);  // from the final norm's gradient rows
     else if (opt_wps) V4L_WPS_BWD(false, false, true, true, 1);                       // up to the layer-0 input gradient
     else if (vis_wps && taps) V4L_WPS_BWD(true, true, true, true, 0);
@@ -1921,7 +1956,7 @@ int v4l_net::backward_t(const float* state, const T* image, const int* rowidx, i
       const TLayer& t = layers[li];
       const Lin* ls[4] = {&t.inproj, &t.outproj, &t.ff1, &t.ff2};
       wa.l[li].wg = ws + L.wps_wg[li];
-      wa.l[li].tk = (vis_wps && !taps && !vis17_forced()) ? nullptr : ws + L.wps_tk[li];
+      wa.l[li].tk = ((vis_wps && !taps && !vis17_forced()) || vis_opt) ? nullptr : ws + L.wps_tk[li];
       for (int m = 0; m < 4; ++m) {
         const Lin& Lm = *ls[m];
         const int64_t sf = ((int64_t)wa.nsplit * Lm.N * Lm.K + 63) / 64 * 64, bf = ((int64_t)wa.nsplit * Lm.N + 63) / 64 * 64;
@@ -2094,6 +2129,7 @@ int v4l_net::backward_t(const float* state, const T* image, const int* rowidx, i
   const float* x0 = ws + L.x[0];
   if (c.token_norm) {  // through token_ln: grad w.r.t. the encoder's tokens; state_token_ln takes part in nothing (zero gradient)
     g_op = "token_ln";
+    if (vis_opt) V4L_HIP_CHECK(zero_row0(dx));  // (the layers' launch wrote rows 1..16 of every slot)
     if ((rc = ln_bwd_launch(cx, lnb, dx, ws + L.dx0raw, ws + L.xh0, ws + L.rs0, tok_ln, R))) return rc;
     V4L_HIP_CHECK(hipMemsetAsync(grads + params[stok_ln.g].goff, 0, TD * sizeof(float), s));
     V4L_HIP_CHECK(hipMemsetAsync(grads + params[stok_ln.b].goff, 0, TD * sizeof(float), s));
@@ -2102,8 +2138,8 @@ int v4l_net::backward_t(const float* state, const T* image, const int* rowidx, i
   }
   // (the option variants: use_pytorch_encoder alone leaves the encoder-side data-grads inside the layers' launch like the plain
   // net; token_norm takes them layer by layer from token_ln's backward)
-  const bool tail_in = fused_tail || (opt_wps && !c.token_norm && wps_tail_shape());
-  if (tail_in) {  // data-grads done by layer 0's launch: register the four weight-grads
+  const bool tail_in = fused_tail || (opt_wps && !c.token_norm && (vis || wps_tail_shape()));
+  if (tail_in && !vis) {  // data-grads done by layer 0's launch: register the four weight-grads
     const Act& last = eacts[ne - 1];
     if ((rc = lin_wgrad<T>(cx, proj, dense(dx, NTOK * TD, n, TD, nullptr, 0, x0), dense(last.p, last.ld, n, last.w), last.w)))
       return rc;
@@ -2111,7 +2147,7 @@ int v4l_net::backward_t(const float* state, const T* image, const int* rowidx, i
     if ((rc = lin_wgrad<T>(cx, enc[0], dense(dehp[0], 256, n, 256), sin, sin.K))) return rc;
     if ((rc = lin_wgrad<T>(cx, upconv, dense(dx, TD, n * 16, TD, nullptr, 1), dense(ws + L.c3, 64, n * 16, 64), 64))) return rc;
   }
-  if (vis_wps) {  // the up-conv data-grad came out of the layer launch (dc3): its weight-grad reads rows 1..16 of the 17-row stride
+  if (vis_wps || (vis_opt && tail_in)) {  // the up-conv data-grad came out of the layer launch (dc3): its weight-grad reads rows 1..16 of the 17-row stride
     if ((rc = lin_wgrad<T>(cx, upconv, dense(dx, TD, n * 16, TD, nullptr, 1), dense(ws + L.c3, 64, n * 16, 64), 64))) return rc;
   }
   if (!tail_in && !vis) {  // token 0 -> state_projector -> encoder MLP
@@ -2125,7 +2161,7 @@ int v4l_net::backward_t(const float* state, const T* image, const int* rowidx, i
     if ((rc = chain_bwd<T>(cx, enc.data(), ne, sin, eacts, dense(ws + L.dhc, last.w, n, last.w), dehp, nullptr))) return rc;
   }
   if (!tail_in && !vis_wps) {  // tokens 1..16 (vision-only: all 16) -> depth_up_conv -> conv stack
-    ADense yu = dense(dx, TD, n * 16, TD, nullptr, vis ? 0 : 1);
+    ADense yu = dense(dx, TD, n * 16, TD, nullptr, (vis && !vis_opt) ? 0 : 1);  // (1: rows 1..16 of 17-row slots)
     if ((rc = lin_wgrad<T>(cx, upconv, yu, dense(ws + L.c3, 64, n * 16, 64), 64))) return rc;
     Epi ep = mk_epi(ws + L.dc3, 64, 64);
     ep.mask = ws + L.c3;
