@@ -17,8 +17,8 @@
  *   - all activations/params/grads are fp32; `compute` selects the contraction operand type:
  *     V4L_F32 = exact fp32 MFMA (parity mode), V4L_BF16 = bf16 operands, fp32 accumulate (production).
  *
- * Environment switches read by the library: 19 (round 4: 37 — the ones no test referenced went in round 5, their fast-path value
- * is now compiled in). Three configure a run, the others are DIAGNOSTIC: every one of them backs a bit-equality / cross-check test
+ * Environment switches read by the library: 20 (round 4: 37 — the ones no test referenced went in round 5, their fast-path value
+ * is now compiled in; V4L_VIS17 came with the native 16-token kernels). tests/test_cpu.py keeps this list and the source in step. Three configure a run, the others are DIAGNOSTIC: every one of them backs a bit-equality / cross-check test
  * under tests/ that compares a fused kernel or a launch schedule against the general one. Read when first needed unless (per call).
  *   run:   V4L_TRACE (launch / graph log on stderr), V4L_RCCL_LIB (RCCL library to dlopen; default librccl.so.1), V4L_ROCTX=1 (roctx
  *          ranges phase|op|kernel around every launch call for `rocprofv3 --marker-trace`)

@@ -262,3 +262,19 @@ def test_device_identity_ignores_visibility_strings_when_the_gpu_is_identified(m
     monkeypatch.setattr(torch.cuda, "get_device_properties", lambda d: anon)
     b0 = ppo.device_identity(torch.device("cuda", 0))
     assert b0 != ppo.device_identity(torch.device("cuda", 1))
+
+
+def test_header_lists_every_library_switch():
+    """include/v4l_hip.h documents the environment switches csrc/v4l_hip.hip reads — the two lists must be the same set."""
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = ""
+    for f in sorted(os.listdir(os.path.join(root, "vision4leg_amd", "csrc"))):
+        src += open(os.path.join(root, "vision4leg_amd", "csrc", f)).read()
+    read = set(re.findall(r'(?:sw_on|sw_int|getenv)\("(V4L_[A-Z0-9_]+)"', src))
+    header = open(os.path.join(root, "include", "v4l_hip.h")).read()
+    table = header[header.index("Environment switches read by the library"):header.index("Read by the Python shell")]
+    listed = set(re.findall(r"V4L_[A-Z0-9_]+", table)) - {"V4L_F32", "V4L_BF16"}
+    assert read == listed, (sorted(read - listed), sorted(listed - read))
+    m = re.search(r"Environment switches read by the library: (\d+)", header)
+    assert int(m.group(1)) == len(read), (m.group(1), len(read))
