@@ -67,7 +67,7 @@ MFLOP_TARGET_FWD = {"loco": 11.258, "loco64": 11.258, "cnn": 8.325, "mlp": 0.444
                     "loco_tn": 11.258, "loco_pe": 11.258}
 OPT_EPOCHS = 3
 LAST_ALLREDUCE = None
-PEAK = {"bf16": 2500.0, "f32": 157.3}  # dense TFLOP/s, MI355X_MICROARCH.md (bf16 MFMA / f32 MFMA)
+PEAK = {"bf16": 2500.0, "f16": 2500.0, "f32": 157.3}  # dense TFLOP/s, MI355X_MICROARCH.md (bf16 = f16 MFMA / f32 MFMA)
 
 
 def launcher_argv(n, argv, port=None):
@@ -91,7 +91,7 @@ def parse(argv=None):
     ap.add_argument("--workload", default=None, choices=sorted(WORKLOADS),
                     help="default: by --gpus — 1, 2, 4 GPUs: loco (BASELINE configs[2] / [3]: 32 envs per GPU); 8 GPUs: loco64 "
                          "(configs[4]: 64 envs per GPU)")
-    ap.add_argument("--compute", default=os.environ.get("V4L_COMPUTE", "bf16"), choices=["bf16", "f32"])
+    ap.add_argument("--compute", default=os.environ.get("V4L_COMPUTE", "bf16"), choices=["bf16", "f16", "f32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity", action="store_true", help="skip the oracle parity check, h2d and reference-protocol legs")
     ap.add_argument("--no-reference-protocol", action="store_true")
@@ -536,7 +536,7 @@ PEAK_HBM = 8000.0  # GB/s, MI355X_MICROARCH.md
 def algo_bytes(kernel, wl, compute):
     """ALGORITHMIC HBM bytes of one launch of the update's big kernels (DESIGN.md section 4 derives the per-sample figures):
     every operand / result the kernel must read / write once, at the storage width it has in this mode."""
-    n, t = wl["B"], (2 if compute == "bf16" else 4)
+    n, t = wl["B"], (4 if compute == "f32" else 2)
     R = 17 * n                                   # token rows
     tok = 64 * 4                                 # one fp32 token row
     # c1 + c2 of one sample in the operand type (round 5: the trainer's passes save them as T), c3 fp32
@@ -608,7 +608,7 @@ def block_fetch_bytes(kernel, wl, compute):
     """Bytes ONE block pulls through its CU (the weights it streams + its share of the launch's algorithmic bytes) for the
     kernels whose time is their blocks' fetch-and-compute chain: a CU streams at most 31.8 B/clk from L2 into registers
     (DESIGN.md 4.1), so this is the per-block view the chip-level HBM fraction cannot give. -> (bytes, blocks) or None."""
-    n, E, t = wl["B"], wl["E"], (2 if compute == "bf16" else 4)
+    n, E, t = wl["B"], wl["E"], (4 if compute == "f32" else 2)
     lw = (64 * 192 + 64 * 64 + 64 * 256 + 256 * 64) * t          # one transformer layer's weights
     head_w = (128 * 256 + 256 * 256 + 256 * 16) * t
     conv_w = (4 * 64 * 32 + 32 * 16 * 64 + 64 * 9 * 64 + 64 * 64) * t
@@ -753,7 +753,29 @@ def roofline(ep, compute, breakdown_path):
         res["transformer_block"] = {
             "tflops": round(tb_fl / tb_us * 1e-6, 2), "mfma_frac": round(tb_fl / tb_us * 1e-6 / PEAK[compute], 5),
             "share_of_kernel_time": round(tb_us / total_us, 4), "kernels": sorted({r[0].split("|")[-1] for r in tb}),
-            "note": "2*M*N*K FLOPs of the update's layer launches / their HIP-event time (DESIGN.md section 4)"}
+            "note": "2*M*N*K FLOPs PERFORMED by the update's layer launches (incl. the backward's recompute) / their HIP-event time "
+                    "(DESIGN.md section 4); the flat key transformer_block_mfma_frac has the ALGORITHMIC numerator"}
+        # ALGORITHMIC numerator: forward + data-grad + weight-grad of the layers = 3 x the forward's
+        # FLOPs per net-pass, whatever the kernels recompute; a net-pass = one launch of the layers' forward kernel
+        passes = sum(r[1] for r in tb if r[0].split("|")[1] == "layer" and "bwd" not in r[0].split("|")[-1])
+        alg = passes * 3 * 2.0 * wl["B"] * wl.get("layers", 2) * 872576.0
+        res["transformer_block_mfma_frac"] = round(alg / tb_us * 1e-6 / PEAK[compute], 5)
+        res["transformer_block_us_per_net_pass"] = round(tb_us / max(passes, 1), 2)
+    # flat, driver-visible keys
+    n_upd = ep.stats.shape[0]
+    res["launches_per_update"] = round(sum(r[1] for r in upd if not r[0].split("|")[-1].startswith("allreduce")) / n_upd, 2)
+    res["update_kernel_us"] = round(upd_us / n_upd, 1)
+    if roll:
+        res["rollout_us_per_env_step"] = round(roll_us / wl["T"], 2)
+    traffic = 0.0
+    for k, (c, _, _) in _per_kernel(upd).items():
+        rec = pmc.get(k) or {}
+        for suffix in ("_stack_head", "_stack", "_head", "_tail"):
+            if not rec and k.endswith(suffix):
+                rec = pmc.get(k[:-len(suffix)]) or {}
+        traffic += (rec.get("hbm_bytes_per_launch") or 0.0) * c / n_upd
+    res["hbm_bytes_per_update"] = round(traffic) if traffic else None
+    res["hbm_bytes_per_update_source"] = "profiles/pmc_traffic.json (PMC FETCH_SIZE x2 / WRITE_SIZE per launch) x this run's launches per update"
     res["method"] = ("HIP events around every launch of one extra (untimed) rollout + epoch-update on the launch stream; "
                      "achieved = algorithmic bytes (bench.py algo_bytes, DESIGN.md section 4) or 2*M*N*K FLOPs per launch / "
                      "average launch time")
@@ -866,6 +888,10 @@ def main():
     res["stats_finite"] = stats_ok
     if rank == 0:
         res["roofline"] = roofline(ep, a.compute, a.breakdown)
+        if res["roofline"]:
+            n_upd_epoch = OPT_EPOCHS * (wl["E"] * wl["T"] // wl["B"])
+            # wall clock of one update inside the timed region (graph replays incl. host gaps): (epoch - rollout) / updates
+            res["roofline"]["update_us"] = round(1e6 * (dt - t_roll) / (a.steps * n_upd_epoch), 1)
         upd_per_epoch = OPT_EPOCHS * (wl["E"] * wl["T"] // wl["B"])
         bucket = 4 * (int(ep.vf.hip.total_params) + 8)
         if dist_on:
@@ -878,13 +904,18 @@ def main():
                 res["dp_model"]["allreduce_us_measured"] = LAST_ALLREDUCE["us_per_call"] if LAST_ALLREDUCE else None
         child = os.environ.get("V4L_BENCH_CHILD", "0") != "0"
         if world == 1 and not a.no_parity and not child and a.workload in ("loco", "loco64"):
-            # side legs (driver-visible, all after the timed region): the exact-fp32 mode with the same parity check, the DP
+            # side legs (driver-visible, all after the timed region): the other two compute modes with the same parity check, the DP
             # schedule on one rank, the net's option variants (max_pool; token_norm, use_pytorch_encoder), and the multi-GPU cost model
-            other = "f32" if a.compute == "bf16" else "bf16"
-            res["f32_mode" if other == "f32" else "bf16_mode"] = dict(
-                side_leg(a.workload, other, dev), parity_check=parity_check(wl, other, dev),
-                note="compute=f32: exact-fp32 MFMA (v_mfma_f32_16x16x4_f32) — the mode whose outputs meet the north star's "
-                     "1e-3 against the fp32 reference literally (DESIGN.md section 2)")
+            notes = {"f32": "compute=f32: exact-fp32 MFMA (v_mfma_f32_16x16x4_f32) — the mode whose outputs meet the north star's "
+                            "1e-3 against the fp32 reference literally in every case (DESIGN.md section 2)",
+                     "f16": "compute=f16: IEEE half operands (v_mfma_f32_16x16x32_f16), fp32 accumulate, loss-gradient rows scaled by a "
+                            "power of two — bf16's speed, ~8 x closer to the fp32 reference (DESIGN.md section 2)",
+                     "bf16": "compute=bf16: bf16 operands (v_mfma_f32_16x16x32_bf16), fp32 accumulate"}
+            for other in ("f32", "f16", "bf16"):
+                if other != a.compute:
+                    res[other + "_mode"] = dict(side_leg(a.workload, other, dev), parity_check=parity_check(wl, other, dev),
+                                                note=notes[other])
+                    res[other + "_mode_value"] = res[other + "_mode"]["value"]  # flat: the driver's parser drops nested objects
             res["dp1_ingraph"] = dp1_ingraph_leg(a.workload, a.compute)
             res["dp1_ingraph_value"] = res["dp1_ingraph"].get("value")
             res["option_variant"] = side_leg("loco_max", a.compute, dev, steps=2, warmup=1)

@@ -15,7 +15,9 @@
  *   - one handle = one device, driven from one host thread at a time (the reference is single-threaded,
  *     torchrl/algo/rl_algo.py:97-168).
  *   - all activations/params/grads are fp32; `compute` selects the contraction operand type:
- *     V4L_F32 = exact fp32 MFMA (parity mode), V4L_BF16 = bf16 operands, fp32 accumulate (production).
+ *     V4L_F32 = exact fp32 MFMA (parity mode), V4L_BF16 = bf16 operands, fp32 accumulate, V4L_F16 = IEEE half operands,
+ *     fp32 accumulate (round 6: bf16's MFMA rate and bytes, three more significand bits — 8 x closer to the fp32 reference;
+ *     half's 5 exponent bits are why its backward runs on scaled loss-gradient rows: v4l_net_grad_scale).
  *
  * Environment switches read by the library: 20 (round 4: 37 — the ones no test referenced went in round 5, their fast-path value
  * is now compiled in; V4L_VIS17 came with the native 16-token kernels). tests/test_cpu.py keeps this list and the source in step. Three configure a run, the others are DIAGNOSTIC: every one of them backs a bit-equality / cross-check test
@@ -60,6 +62,14 @@ extern "C" {
 
 #define V4L_F32 0
 #define V4L_BF16 1
+#define V4L_F16 2
+/* V4L_F16: a backward pass over n rows runs on loss-gradient rows multiplied by 2^(V4L_F16_SCALE_LOG2 + ceil(log2 n)) — the
+   mean()'s 1/n taken out and 16 x on top: the rows' bulk sits inside half's normal range and the largest element two to three
+   decades under its overflow (profiles/r6_f16_attribution.txt) — and elements beyond +-V4L_F16_GRAD_CLAMP are clamped there
+   (counted in the record's slot 23). The weight-grad reduction multiplies the scale out again: gradients leave the library
+   unscaled in every mode. A power of two: scaling and unscaling are exact in fp32. */
+#define V4L_F16_SCALE_LOG2 4
+#define V4L_F16_GRAD_CLAMP 32768.0f
 
 #define V4L_NET_MLP 0  /* networks.Net + MLPBase            torchrl/networks/nets.py:16-55 (ppo_state.py)      */
 #define V4L_NET_CNN 1  /* networks.ImpalaEncoderProjNet + NatureFuseEncoder   nets.py:194-262, base.py:345-385 */
@@ -74,12 +84,14 @@ extern "C" {
 #define V4L_MAX_HIDDEN 4
 #define V4L_STATS 24 /* floats per update record; [0..17] = the 18 logger keys of ppo.py:77-92,122-123,142-145;
                         [18..21] shard moments of the advantages (data-parallel exchange); [22] = how many of the 18 are
-                        NaN / Inf (device-side form of the collector's NaN check, collector/on_policy.py:102-107) */
+                        NaN / Inf (device-side form of the collector's NaN check, collector/on_policy.py:102-107; a half
+                        operand that overflowed anywhere in a V4L_F16 pass ends up here through the losses / gradient norms);
+                        [23] = V4L_F16: loss-gradient elements of this update clamped at +-V4L_F16_GRAD_CLAMP (0 otherwise) */
 #define V4L_OUT_LD 16 /* row stride of head outputs (action mean / value), zero padded */
 
 typedef struct v4l_net_cfg {
   int kind;            /* V4L_NET_*                                                                      */
-  int compute;         /* V4L_F32 | V4L_BF16                                                             */
+  int compute;         /* V4L_F32 | V4L_BF16 | V4L_F16                                                   */
   int state_dim;       /* S: proprio length (state_input_dim, starter/ppo_locotransformer.py:81)         */
   int out_dim;         /* A for a policy, 1 for a value net                                              */
   int in_channels;     /* 4 (depth stack); ignored for V4L_NET_MLP                                       */
@@ -156,7 +168,10 @@ float* v4l_net_out_ptr(const v4l_net* net, float* ws_dev, int n, int train);
 float* v4l_net_dout_ptr(const v4l_net* net, float* ws_dev, int n);
 /* Backward of the same pass: reads d(out) at v4l_net_dout_ptr ([n][V4L_OUT_LD]), accumulates parameter
  * gradients into grads_dev (flat, offsets from v4l_net_param_info; caller zeroes it). Replaces
- * loss.backward() of ppo.py:72,117 for everything below the head output. */
+ * loss.backward() of ppo.py:72,117 for everything below the head output.
+ * The d(out) rows are expected MULTIPLIED by v4l_net_grad_scale(net, n) — 1 unless compute == V4L_F16 (see V4L_F16_SCALE_LOG2;
+ * the trainer's loss kernels do it, a caller that fills d(out) itself must) — and the gradients come out unscaled. */
+float v4l_net_grad_scale(const v4l_net* net, int n);
 int v4l_net_backward(v4l_net* net, const float* state_dev, const void* image_dev, const int* rowidx_dev, int n,
                      float* ws_dev, float* grads_dev, void* stream);
 

@@ -28,21 +28,21 @@ def _rel(a, b):
 ENV_SEEDS = 8
 
 
-def _forward_envelope(fwd, params, obs, S, ref, scale=1e-7):
+def _forward_envelope(fwd, params, obs, S, ref, scale=1e-7, mode="bf16"):
     """The bf16 oracle's own sensitivity (as tests/test_gpu_parity.py::_bf16_envelope): p95 over ENV_SEEDS runs with the
     parameters nudged by 1e-7 of the forward output's distance to the un-nudged run."""
     errs = []
     for sd in range(1, ENV_SEEDS + 1):
         gen = torch.Generator().manual_seed(sd)
         q = {k: v * (1 + scale * torch.randn(v.shape, generator=gen)) for k, v in params.items()}
-        errs.append(_rel(fwd(q, obs, S, "bf16").reshape(ref.shape), ref))
+        errs.append(_rel(fwd(q, obs, S, mode).reshape(ref.shape), ref))
     return float(np.percentile(errs, 95))
 
 
 def run(case, E, T, B, U, mode, dev, seed=0, threads=None, envelope=True, traj_seeds=0):
     """case: a recipes case dict (kind, S, A, ...). Rollout of T steps x E envs, then U stored-log-pi updates of B rows.
-    -> dict of measured distances. mode: the product's compute mode ("f32" | "bf16"); the oracle runs in that flavour
-    and (bf16) also in fp32, so the caller can apply the trajectory rule |hip - fp32| <= k |bf16 oracle - fp32|.
+    -> dict of measured distances. mode: the product's compute mode ("f32" | "bf16" | "f16"); the oracle runs in that flavour
+    and (16-bit modes) also in fp32, so the caller can apply the trajectory rule |hip - fp32| <= k |bf16 oracle - fp32|.
     Distances between tensors are relative to the reference tensor's max-abs. envelope (bf16): also the bf16 oracle's own
     sensitivity on the rollout's mean / value (8 nudged forward passes each), the yardstick of the bf16 rollout gate.
     traj_seeds (bf16): that many extra bf16 oracles start from parameters nudged by 1e-7 and run the same U updates; the largest
@@ -122,10 +122,10 @@ def run(case, E, T, B, U, mode, dev, seed=0, threads=None, envelope=True, traj_s
             lp_o, _ = orc.log_prob_entropy(m_o, s_o, acts_h)
             res["rollout_mean_vs_%s" % fl] = _rel(mean_h, m_o)
             res["rollout_value_vs_%s" % fl] = _rel(vals_h, v_o)
-            if fl == "bf16" and envelope:
+            if fl == mode and fl != "f32" and envelope:
                 res["rollout_mean_envelope_p95"] = _forward_envelope(fwd, {k: v for k, v in o.pf.items() if k != "logstd"},
-                                                                     ob_cpu, S, m_o)
-                res["rollout_value_envelope_p95"] = _forward_envelope(fwd, o.vf, ob_cpu, S, v_o)
+                                                                     ob_cpu, S, m_o, mode=fl)
+                res["rollout_value_envelope_p95"] = _forward_envelope(fwd, o.vf, ob_cpu, S, v_o, mode=fl)
             res["rollout_std_vs_%s" % fl] = _rel(std_h, s_o)
             # log pi_old of the FILED action under the oracle's own mean / std: what the reference's target forward yields
             res["rollout_logp_abs_vs_%s" % fl] = float((logp_h - lp_o.reshape(-1)).abs().max())

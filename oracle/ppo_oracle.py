@@ -13,13 +13,18 @@ A plain-PyTorch (CPU, fp32) restatement of the reference's arithmetic, which its
 unpinned `torch` dependency of /root/reference/setup.py:244-249; restated against torch 2.10 semantics).
 Every function cites the reference lines it follows (paths relative to /root/reference).
 
-Two numeric flavours:
+Three numeric flavours:
   mode="f32"  : what the reference computes.
   mode="bf16" : same graph, but every contraction (Linear / Conv2d and the two attention products Q K^T and
                 P V, forward and both backward products of each) rounds its two operands to bfloat16
                 (round-to-nearest-even) and accumulates in fp32 — the rounding points of the MI355X bf16 MFMA
                 path (BASELINE.json north_star: "the transformer QK^T/softmax/V ... use MFMA bf16 tiles").
-                Softmax, the 1/sqrt(d) scale, LayerNorm, residuals, losses and Adam stay fp32 in both flavours.
+                Softmax, the 1/sqrt(d) scale, LayerNorm, residuals, losses and Adam stay fp32 in every flavour.
+  mode="f16"  : the same rounding points with IEEE half operands (v_mfma_f32_16x16x32_f16: bf16's rate and bytes,
+                11 significand bits instead of 8, 5 exponent bits instead of 8). The backward operands need the
+                exponent range back: the loss is multiplied by grad_scale(B) — a power of two, so exact in fp32 —
+                before the backward and the parameter gradients divided by it afterwards (PPOOracle._grads), which
+                is where the HIP path scales (loss-gradient rows) and unscales (weight-grad reduction).
 """
 import math
 
@@ -34,59 +39,78 @@ def rbf16(x):
     return x.to(torch.bfloat16).to(torch.float32)
 
 
-class _LinearBF16(torch.autograd.Function):
+def rf16(x):
+    """IEEE half, round-to-nearest-even, subnormals kept, overflow -> inf (what v_cvt_f16_f32 does)."""
+    return x.to(torch.float16).to(torch.float32)
+
+
+ROUND = {"bf16": rbf16, "f16": rf16}
+F16_SCALE_LOG2 = 4  # f16 flavour: loss-gradient rows carry 2^F16_SCALE_LOG2 * (rows of the minibatch rounded up to a power of two)
+
+
+def grad_scale(mode, n):
+    """The power of two the f16 flavour multiplies the loss (= every loss-gradient row) by: it takes the mean's 1/n out and puts
+    the rows' bulk well inside half's normal range (1 for the other flavours; mirrors v4l_net_grad_scale of the HIP library)."""
+    if mode != "f16":
+        return 1.0
+    return float(2 ** (F16_SCALE_LOG2 + max(0, int(n) - 1).bit_length()))
+
+
+class _LinearR(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, w, b):
-        xr, wr = rbf16(x), rbf16(w)
+    def forward(ctx, x, w, b, rnd):
+        xr, wr = rnd(x), rnd(w)
         ctx.save_for_backward(xr, wr)
+        ctx.rnd = rnd
         return xr @ wr.t() + b
 
     @staticmethod
     def backward(ctx, dy):
         xr, wr = ctx.saved_tensors
-        dyr = rbf16(dy)
+        dyr = ctx.rnd(dy)
         dx = dyr @ wr
         dw = dyr.reshape(-1, dyr.shape[-1]).t() @ xr.reshape(-1, xr.shape[-1])
         db = dy.reshape(-1, dy.shape[-1]).sum(0)
-        return dx, dw, db
+        return dx, dw, db, None
 
 
-class _ConvBF16(torch.autograd.Function):
+class _ConvR(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, w, b, stride):
-        xr, wr = rbf16(x), rbf16(w)
+    def forward(ctx, x, w, b, stride, rnd):
+        xr, wr = rnd(x), rnd(w)
         ctx.save_for_backward(xr, wr)
-        ctx.stride = stride
+        ctx.stride, ctx.rnd = stride, rnd
         return F.conv2d(xr, wr, b, stride=stride)
 
     @staticmethod
     def backward(ctx, dy):
         xr, wr = ctx.saved_tensors
-        dyr = rbf16(dy)
+        dyr = ctx.rnd(dy)
         dx = torch.nn.grad.conv2d_input(xr.shape, wr, dyr, stride=ctx.stride)
         dw = torch.nn.grad.conv2d_weight(xr, wr.shape, dyr, stride=ctx.stride)
         db = dy.sum((0, 2, 3))
-        return dx, dw, db, None
+        return dx, dw, db, None, None
 
 
-class _MatmulBF16(torch.autograd.Function):
-    """a @ b with both operands rounded to bf16, fp32 accumulate; the backward products round theirs the same way."""
+class _MatmulR(torch.autograd.Function):
+    """a @ b with both operands rounded to the 16-bit operand type, fp32 accumulate; the backward products round theirs the same way."""
 
     @staticmethod
-    def forward(ctx, a, b):
-        ar, br = rbf16(a), rbf16(b)
+    def forward(ctx, a, b, rnd):
+        ar, br = rnd(a), rnd(b)
         ctx.save_for_backward(ar, br)
+        ctx.rnd = rnd
         return ar @ br
 
     @staticmethod
     def backward(ctx, dc):
         ar, br = ctx.saved_tensors
-        dcr = rbf16(dc)
-        return dcr @ br.transpose(-1, -2), ar.transpose(-1, -2) @ dcr
+        dcr = ctx.rnd(dc)
+        return dcr @ br.transpose(-1, -2), ar.transpose(-1, -2) @ dcr, None
 
 
-# Contraction groups of the LocoTransformer / NatureCNN nets. `mode` is "f32" or "bf16" for every contraction, or a mapping
-# group -> "f32" / "bf16" (missing groups: "f32") — tools/bf16_attribution.py rounds ONE group at a time to attribute the
+# Contraction groups of the LocoTransformer / NatureCNN nets. `mode` is "f32", "bf16" or "f16" for every contraction, or a mapping
+# group -> "f32" / "bf16" / "f16" (missing groups: "f32") — tools/bf16_attribution.py rounds ONE group at a time to attribute the
 # bf16 flavour's distance to the fp32 reference (VERDICT r4 item 3).
 GROUPS = ("conv", "upconv", "proprio", "projector", "in_proj", "attn", "out_proj", "ffn", "heads")
 
@@ -96,15 +120,18 @@ def _m(mode, group):
 
 
 def matmul(a, b, mode, group="attn"):
-    return a @ b if _m(mode, group) == "f32" else _MatmulBF16.apply(a, b)
+    m = _m(mode, group)
+    return a @ b if m == "f32" else _MatmulR.apply(a, b, ROUND[m])
 
 
 def linear(x, w, b, mode, group="heads"):
-    return F.linear(x, w, b) if _m(mode, group) == "f32" else _LinearBF16.apply(x, w, b)
+    m = _m(mode, group)
+    return F.linear(x, w, b) if m == "f32" else _LinearR.apply(x, w, b, ROUND[m])
 
 
 def conv2d(x, w, b, stride, mode, group="conv"):
-    return F.conv2d(x, w, b, stride=stride) if _m(mode, group) == "f32" else _ConvBF16.apply(x, w, b, stride)
+    m = _m(mode, group)
+    return F.conv2d(x, w, b, stride=stride) if m == "f32" else _ConvR.apply(x, w, b, stride, ROUND[m])
 
 
 # ------------------------------------------------------------------------------------------ building blocks
@@ -374,13 +401,15 @@ class PPOOracle:
             for k in self.pf_keys:
                 self.tpf[k].copy_(self.pf[k])
 
-    def _grads(self, loss, pdict, keys):
+    def _grads(self, loss, pdict, keys, n):
         for k in keys:
             pdict[k].requires_grad_(True)
-        gs = torch.autograd.grad(loss, [pdict[k] for k in keys], allow_unused=True)
+        sc = grad_scale(self.mode if isinstance(self.mode, str) else "f32", n)  # f16: scaled backward (exact power of two)
+        gs = torch.autograd.grad(loss * sc if sc != 1.0 else loss, [pdict[k] for k in keys], allow_unused=True)
         for k in keys:
             pdict[k].requires_grad_(False)
-        return [g if g is not None else torch.zeros_like(pdict[k]) for g, k in zip(gs, keys)]
+        # (log sigma's gradient never passes a contraction: the HIP loss kernel writes it unscaled; x * sc / sc is exact anyway)
+        return [(g / sc if sc != 1.0 else g) if g is not None else torch.zeros_like(pdict[k]) for g, k in zip(gs, keys)]
 
     def update(self, obs, acts, advs, est_rets, old_values, lr_pf, lr_vf):
         """obs [B,D], acts [B,A], advs/est_rets/old_values [B,1] (fp32 tensors). Returns the 18-key info dict."""
@@ -400,7 +429,7 @@ class PPOOracle:
             vf_loss = 0.5 * torch.max((values - est_rets).pow(2), (vc - est_rets).pow(2)).mean()
         else:
             vf_loss = F.mse_loss(values, est_rets)
-        g = self._grads(vf_loss, self.vf, self.vf_keys)
+        g = self._grads(vf_loss, self.vf, self.vf_keys, obs.shape[0])
         self.last_grads["vf"] = dict(zip(self.vf_keys, g))
         g, gn = clip_grad_norm(g, self.max_norm)
         adam_step([self.vf[k] for k in self.vf_keys], g, self.vf_state, lr_vf, self.step)
@@ -420,7 +449,7 @@ class PPOOracle:
         s1 = ratio * advs
         s2 = torch.clamp(ratio, 1.0 - self.clip_para, 1.0 + self.clip_para) * advs
         policy_loss = -torch.mean(torch.min(s2, s1)) - self.entropy_coeff * ent.mean()
-        g = self._grads(policy_loss, self.pf, self.pf_keys)
+        g = self._grads(policy_loss, self.pf, self.pf_keys, obs.shape[0])
         self.last_grads["pf"] = dict(zip(self.pf_keys, g))
         g, gn = clip_grad_norm(g, self.max_norm)
         adam_step([self.pf[k] for k in self.pf_keys], g, self.pf_state, lr_pf, self.step)

@@ -169,23 +169,25 @@ def test_unsupported_configs_fail_loudly():
         net(torch.zeros(3, 8))
 
 
-def test_host_bf16_cast_is_the_two_step_rounding():
-    """The fast collector hands the depth stack to the bf16 rollout kernels as bfloat16 rows cast on the host (half the PCIe
-    bytes). That is only bit-identical to the reference protocol (torch.Tensor(ob): float64 -> float32, then the kernels'
-    float32 -> bf16 at ingest) if torch's float64 -> bfloat16 copy rounds THROUGH float32 — it does (c10::BFloat16 is built from
-    float); values where a direct rounding would differ pin it."""
-    tricky = np.array([1 + 2 ** -8 + 2 ** -30, -(1 + 2 ** -8 + 2 ** -40), 3.0 + 3 * 2 ** -8 + 2 ** -33, 1 + 2 ** -8 - 2 ** -30])
+@pytest.mark.parametrize("dt,eps_log2", [(torch.bfloat16, -8), (torch.float16, -11)])
+def test_host_16bit_cast_is_the_two_step_rounding(dt, eps_log2):
+    """The fast collector hands the depth stack to the 16-bit rollout kernels as bfloat16 / float16 rows cast on the host (half the
+    PCIe bytes). That is only bit-identical to the reference protocol (torch.Tensor(ob): float64 -> float32, then the kernels'
+    float32 -> operand type at ingest) if torch's float64 -> 16-bit copy rounds THROUGH float32 — it does (c10::BFloat16 / c10::Half
+    are built from float); values where a direct rounding would differ pin it."""
+    h = 2.0 ** eps_log2  # half an ulp of 1.0 in the 16-bit type: 1 + h + tiny rounds to 1 + 2h directly, to 1 via float32 (tie to even)
+    tricky = np.array([1 + h + 2 ** -30, -(1 + h + 2 ** -40), 3.0 + 3 * h + 2 ** -33, 1 + h - 2 ** -30])
     rs = np.random.RandomState(0)
     x = np.concatenate([tricky, np.clip(rs.randn(100000), -2.5, 2.8)])
-    one = torch.empty(len(x), dtype=torch.bfloat16)
+    one = torch.empty(len(x), dtype=dt)
     one.copy_(torch.from_numpy(x))
-    two = torch.from_numpy(x).to(torch.float32).to(torch.bfloat16)
+    two = torch.from_numpy(x).to(torch.float32).to(dt)
     assert torch.equal(one, two)
-    assert one[0].item() == 1.0  # a direct float64 -> bf16 rounding would give 1.0078125
-    cols = torch.empty(50, 300, dtype=torch.bfloat16)
+    assert one[0].item() == 1.0  # a direct float64 -> 16-bit rounding would give 1 + 2h
+    cols = torch.empty(50, 300, dtype=dt)
     wide = rs.randn(50, 393)
     cols.copy_(torch.from_numpy(wide)[:, 93:])  # a strided column block, as the collector slices the observation rows
-    assert torch.equal(cols, torch.from_numpy(wide[:, 93:].copy()).float().bfloat16())
+    assert torch.equal(cols, torch.from_numpy(wide[:, 93:].copy()).float().to(dt))
 
 
 def test_replay_buffer_iteration_matches_reference_semantics():

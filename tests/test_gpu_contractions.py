@@ -32,9 +32,11 @@ def _close_t(name, got_t, want32, mode, tag, max_ulp=1.0, floor=TOL):
     1-ulp ties as a perturbation at the scale of the tensor, not of the element."""
     if mode == "f32":
         return _close32(name, got_t, want32, tag)
-    want_r = orc.rbf16(want32.float())
-    # allowed distance: one bf16 ulp of the value (<= 2^-7 relative) on top of the noise floor of the tensor
-    ulp = want32.abs().float() * 2.0 ** -7 + floor * want32.abs().max().float()
+    want_r = orc.ROUND[mode](want32.float())
+    # allowed distance: one ulp of the value in the operand type (bf16: <= 2^-7 relative; f16: <= 2^-10 relative, 2^-24 absolute
+    # in its subnormal range) on top of the noise floor of the tensor
+    ulp = want32.abs().float() * 2.0 ** (-7 if mode == "bf16" else -10) + (0.0 if mode == "bf16" else 2.0 ** -24) \
+        + floor * want32.abs().max().float()
     diff = (got_t.float() - want32.float()).abs()
     frac = ((got_t.float() != want_r).float().mean()).item()
     worst = (diff / ulp).max().item()
@@ -48,7 +50,7 @@ def _conv_backward_checks(tap, G, sd, enc, n, c1, c2, dc3, img_t, mode, tag):
     (bwd_conv_kernel: dc2 / dc1 never reach HBM in production; V4L_LAYER_TAPS writes them as the kernel holds them, in T),
     each from the kernel's OWN operands: conv2d_input / conv2d_weight on (dc3, w3) -> dc2, (dc2, c1) -> dW2, (dc2, w2) -> dc1,
     (dc1, image) -> dW1 (torchrl/networks/base.py:317-324 reversed)."""
-    r = (lambda x: x) if mode == "f32" else orc.rbf16
+    r = (lambda x: x) if mode == "f32" else orc.ROUND[mode]
     nhwc = lambda x: x.permute(0, 2, 3, 1).reshape(n, -1, x.shape[1])
     nchw = lambda t2, hw, c: t2.reshape(n, hw, hw, c).permute(0, 3, 1, 2)
     w3, w2, w1 = sd[enc + "4.weight"], sd[enc + "2.weight"], sd[enc + "0.weight"]
@@ -85,20 +87,25 @@ def test_every_contraction_teacher_forced(name, mode, device, layer_taps):
     dout[:, :A] = w.to(device)
     grads = torch.full((hip.total_params,), float("nan"), dtype=torch.float32, device=device)
     hip.backward(st, im, n, dout, grads)
+    # f16: the backward ran on d(out) x grad_scale (a power of two) and unscaled the parameter gradients at the end; the checks below
+    # follow the SCALED chain (the taps hold scaled tensors), so d(out) and the gradients are put on that scale here (exact)
+    gs = hip.grad_scale(n)
+    assert gs == orc.grad_scale(mode, n)
+    dout = dout * gs
     torch.cuda.synchronize()
     ws = hip.workspace(n).cpu()
-    tdt = torch.float32 if mode == "f32" else torch.bfloat16
+    tdt = {"f32": torch.float32, "bf16": torch.bfloat16, "f16": torch.float16}[mode]
 
     def tap(name, rows, cols, t=False):
         off = hip.ws_offset(n, name)
         raw = ws[off:off + rows * cols]
-        if t and tdt == torch.bfloat16:
-            return raw.view(torch.bfloat16)[:rows * cols].view(rows, cols).float()
+        if t and tdt != torch.float32:
+            return raw.view(tdt)[:rows * cols].view(rows, cols).float()
         return raw.view(rows, cols).clone()
     sd = {k: v.detach().cpu() for k, v in pf.state_dict().items()}
-    G = lambda k: hip.grad_view(grads, k).cpu()
+    G = lambda k: hip.grad_view(grads, k).cpu() * gs
     lin = lambda x, wk, bk: orc.linear(x, sd[wk], sd[bk], mode)
-    r = (lambda x: x) if mode == "f32" else orc.rbf16
+    r = (lambda x: x) if mode == "f32" else orc.ROUND[mode]
     state, img = orc.split_obs(obs, S)
     img_t = im.cpu().float().view(n, 4, 64, 64)                      # the ingested depth stack (compute type)
     assert torch.equal(img_t, r(img))
@@ -125,7 +132,7 @@ def test_every_contraction_teacher_forced(name, mode, device, layer_taps):
         for l in range(2):
             p = "visual_append_layers.%d." % l
             # (fp32 mode keeps no separate operand copy of the layer input: the fp32 token tensor is the operand)
-            xin = tap("xin%d" % l, R, 64, True) if mode == "bf16" else xs[l]
+            xin = tap("xin%d" % l, R, 64, True) if mode != "f32" else xs[l]
             qkv, P = tap("qkv%d" % l, R, 192), tap("P%d" % l, n * 17, 17)
             ctx, xh1, rs1 = tap("ctx%d" % l, R, 64, True), tap("xh1_%d" % l, R, 64), tap("rs1_%d" % l, R, 1)
             x1t, f, xh2, rs2 = tap("mid%d" % l, R, 64, True), tap("ff%d" % l, R, 256, True), tap("xh2_%d" % l, R, 64), tap("rs2_%d" % l, R, 1)
@@ -200,7 +207,7 @@ def test_every_contraction_teacher_forced(name, mode, device, layer_taps):
             # an output by a second ulp)
             _close_t("d.L%d.attention_bwd" % l, dqkv, dqkv_w, mode, tag, max_ulp=2.0, floor=1e-3)
             dxin = dz1_w + dmm(dqkv, p + "self_attn.in_proj_weight")
-            _close32("d.L%d.layer_input_grad" % l, dxs[l], dxin, tag, tol=1e-4 if mode == "bf16" else TOL)
+            _close32("d.L%d.layer_input_grad" % l, dxs[l], dxin, tag, tol=1e-4 if mode != "f32" else TOL)
             # ---- the four weight gradients of the layer: dW = dY^T X on the operands the kernels saved
             for nm, dyv, xv in (("linear1", df, d["x1t"]), ("linear2", dz2, d["f"]), ("self_attn.out_proj", dz1, d["ctx"]),
                                 ("self_attn.in_proj", dqkv, d["xin"])):
@@ -260,20 +267,25 @@ def test_contractions_of_the_other_nets(name, mode, device, layer_taps, monkeypa
     dout[:, :A] = w.to(device)
     grads = torch.full((hip.total_params,), float("nan"), dtype=torch.float32, device=device)
     hip.backward(st, im, n, dout, grads)
+    # f16: the backward ran on d(out) x grad_scale (a power of two) and unscaled the parameter gradients at the end; the checks below
+    # follow the SCALED chain (the taps hold scaled tensors), so d(out) and the gradients are put on that scale here (exact)
+    gs = hip.grad_scale(n)
+    assert gs == orc.grad_scale(mode, n)
+    dout = dout * gs
     torch.cuda.synchronize()
     ws = hip.workspace(n).cpu()
-    tdt = torch.float32 if mode == "f32" else torch.bfloat16
+    tdt = {"f32": torch.float32, "bf16": torch.bfloat16, "f16": torch.float16}[mode]
 
     def tap(nm, rows, cols, t=False):
         off = hip.ws_offset(n, nm)
         raw = ws[off:off + rows * cols]
-        if t and tdt == torch.bfloat16:
-            return raw.view(torch.bfloat16)[:rows * cols].view(rows, cols).float()
+        if t and tdt != torch.float32:
+            return raw.view(tdt)[:rows * cols].view(rows, cols).float()
         return raw.view(rows, cols).clone()
     sd = {k: v.detach().cpu() for k, v in pf.state_dict().items()}
-    G = lambda k: hip.grad_view(grads, k).cpu()
+    G = lambda k: hip.grad_view(grads, k).cpu() * gs
     lin = lambda x, wk, bk: orc.linear(x, sd[wk], sd[bk], mode)
-    r = (lambda x: x) if mode == "f32" else orc.rbf16
+    r = (lambda x: x) if mode == "f32" else orc.ROUND[mode]
     dmm = lambda dy, wk: r(dy) @ r(sd[wk])
     wg = lambda dy, x: (r(dy).double().t() @ r(x).double()).float()
     nhwc = lambda x: x.permute(0, 2, 3, 1).reshape(n, -1, x.shape[1])

@@ -5,6 +5,7 @@
 #   onetile -DV4L_WPS_PROBE_ONE_TILE  TIMING ONLY, wrong results: the layer functions walk one token tile (what the padding tile costs)
 #   eu1    -DV4L_WPS_EU1           amdgpu_waves_per_eu(1,1) on the wave-per-sample stack kernels
 #   x3     -DV4L_PROBE_F32_SPLIT3  the fp32 mode's MFMAs as three bf16 MFMAs on high / low operand halves (accuracy / speed probe)
+#   only1 / only2 / only0  -DV4L_DEV_ONLY=<mode>  development build holding ONE compute mode (bf16 / f16 / f32): a third of the compile time
 #   ilp    -mllvm -amdgpu-sched-strategy=max-ilp ; bias0  -mllvm -amdgpu-schedule-metric-bias=0   (whole library)
 # -> vision4leg_amd/libv4l_hip_<name>.so, selected at run time with V4L_LIB=<path>
 set -e
@@ -16,6 +17,9 @@ case $name in
   eu1) flags="-DV4L_WPS_EU1" ;;
   onetile) flags="-DV4L_WPS_PROBE_ONE_TILE" ;;
   x3) flags="-DV4L_PROBE_F32_SPLIT3" ;;
+  only0) flags="-DV4L_DEV_ONLY=0" ;;
+  only1) flags="-DV4L_DEV_ONLY=1" ;;
+  only2) flags="-DV4L_DEV_ONLY=2" ;;
   ilp) flags="-mllvm -amdgpu-sched-strategy=max-ilp" ;;
   bias0) flags="-mllvm -amdgpu-schedule-metric-bias=0" ;;
   *) flags="" ;;

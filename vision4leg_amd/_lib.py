@@ -10,11 +10,12 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("V4L_LIB", os.path.join(_HERE, "libv4l_hip.so"))  # V4L_LIB: diagnostic builds only
 SRC_DIR = os.path.join(_HERE, "csrc")
 
-V4L_F32, V4L_BF16 = 0, 1
+V4L_F32, V4L_BF16, V4L_F16 = 0, 1, 2
 V4L_NET_MLP, V4L_NET_CNN, V4L_NET_LOCO, V4L_NET_CNN_VIS, V4L_NET_LOCO_VIS = 0, 1, 2, 3, 4
 V4L_MAX_HIDDEN = 4
 V4L_STATS = 24
 ST_NONFINITE = 22   # record slot: number of NaN / Inf among the 18 logged scalars of an update
+ST_F16_SAT = 23     # record slot: V4L_F16 — loss-gradient elements of the update clamped at +-V4L_F16_GRAD_CLAMP
 V4L_OUT_LD = 16
 V4L_BUCKET_TAIL = 8   # scalars behind the gradients of an all-reduce bucket
 V4L_COMM_ID_BYTES = 128
@@ -92,6 +93,7 @@ _SIGS = {
   "v4l_net_forward": (C.c_int, [_P, _P, _P, _P, C.c_int, _P, C.c_int, _P]),
   "v4l_net_out_ptr": (_P, [_P, _P, C.c_int, C.c_int]),
   "v4l_net_dout_ptr": (_P, [_P, _P, C.c_int]),
+  "v4l_net_grad_scale": (C.c_float, [_P, C.c_int]),
   "v4l_net_backward": (C.c_int, [_P, _P, _P, _P, C.c_int, _P, _P, _P]),
   "v4l_gauss_head": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, _P, _P, _P, _P, _P, _P]),
   "v4l_gauss_head_tanh": (C.c_int, [_P, _P, _P, _P, C.c_int, C.c_int, _P, _P, _P, _P, _P, _P]),

@@ -820,15 +820,17 @@ template <typename T> __device__ __forceinline__ typename Frag<T>::type frag_of(
   typename Frag<T>::type f;
   if constexpr (sizeof(T) == 2) {
 #pragma unroll
-    for (int j = 0; j < 8; ++j) f[j] = (__bf16)v[j];
+    for (int j = 0; j < 8; ++j) f[j] = (T)v[j];
   } else {
 #pragma unroll
     for (int j = 0; j < 8; ++j) f.v[j] = v[j];
   }
   return f;
 }
-__device__ __forceinline__ bf16x8 frag_of_t(const __bf16 (&v)[8]) {
-  bf16x8 f;
+template <typename H>
+__device__ __forceinline__ typename Frag<H>::type frag_of_t(const H (&v)[8]) {
+  static_assert(sizeof(H) == 2, "16-bit operand type");
+  typename Frag<H>::type f;
 #pragma unroll
   for (int j = 0; j < 8; ++j) f[j] = v[j];
   return f;

@@ -9,7 +9,10 @@
 namespace v4l {
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
+// N adjacent 16-bit operand elements (H = __bf16 | _Float16) as one register vector
+template <typename H, int N> struct HVec { typedef H type __attribute__((ext_vector_type(N))); };
 
 // ---------------------------------------------------------------- error state
 // The C ABI never throws; every entry returns int and leaves a message here.
@@ -49,8 +52,9 @@ static inline int64_t cdiv64(int64_t a, int64_t b) { return (a + b - 1) / b; }
 static inline int round_up(int a, int b) { return cdiv(a, b) * b; }
 
 // ---------------------------------------------------------------- operand types
-// The contraction operand type T is either float (exact-f32 MFMA 16x16x4, used as the
-// parity mode) or __bf16 (MFMA 16x16x32 bf16, fp32 accumulate: the production mode).
+// The contraction operand type T is float (exact-f32 MFMA 16x16x4, the parity mode), __bf16 (MFMA 16x16x32 bf16, fp32
+// accumulate) or _Float16 (MFMA 16x16x32 f16, fp32 accumulate: bf16's rate and bytes, three more significand bits; the
+// backward runs on loss-gradient rows scaled by a power of two, see v4l_net_grad_scale). Kernels branch on sizeof(T) == 2.
 template <typename T> struct Op;
 template <> struct Op<float> {
   static __device__ __forceinline__ float from_f32(float x) { return x; }
@@ -60,6 +64,15 @@ template <> struct Op<__bf16> {
   static __device__ __forceinline__ __bf16 from_f32(float x) { return (__bf16)x; }  // v_cvt_pk_bf16_f32: RNE
   static __device__ __forceinline__ float to_f32(__bf16 x) { return (float)x; }
 };
+template <> struct Op<_Float16> {
+  static __device__ __forceinline__ _Float16 from_f32(float x) { return (_Float16)x; }  // v_cvt_f16_f32: RNE, subnormals kept, overflow -> inf
+  static __device__ __forceinline__ float to_f32(_Float16 x) { return (float)x; }
+};
+// compute-mode number of an operand type as device code sees it in `int mode` arguments (= V4L_F32 / V4L_BF16 / V4L_F16)
+template <typename T> struct ModeOf;
+template <> struct ModeOf<float> { static constexpr int value = 0; };
+template <> struct ModeOf<__bf16> { static constexpr int value = 1; };
+template <> struct ModeOf<_Float16> { static constexpr int value = 2; };
 
 // x as the contraction sees it: rounded to the operand type (bf16: RNE; fp32: unchanged)
 template <typename T> __device__ __forceinline__ float rt(float x) { return Op<T>::to_f32(Op<T>::from_f32(x)); }
@@ -67,13 +80,16 @@ template <typename T> __device__ __forceinline__ float4 rt4(float4 v) { return f
 
 // One K=32 step of a 16x16 output tile. Every lane holds 8 operand elements whose k index is
 // 8*(lane>>4)+j for BOTH operands; row (A) / column (B) is lane&15.
-//   bf16: a single v_mfma_f32_16x16x32_bf16.
+//   bf16 / f16: a single v_mfma_f32_16x16x32_bf16 / v_mfma_f32_16x16x32_f16.
 //   f32 : eight v_mfma_f32_16x16x4_f32; in the j-th one lane group g=lane>>4 supplies k=8g+j. The
 //         hardware pairs A's and B's k by lane group, so the permuted k order is still a full
 //         contraction over the 32 k's (exact f32 fma chain, order differs from a CPU dot only).
 // C/D layout (both): col = lane&15, row = 4*(lane>>4)+r.
 __device__ __forceinline__ void mma_k32(f32x4& acc, const bf16x8& a, const bf16x8& b) {
   acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc, 0, 0, 0);
+}
+__device__ __forceinline__ void mma_k32(f32x4& acc, const f16x8& a, const f16x8& b) {
+  acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, acc, 0, 0, 0);
 }
 struct __attribute__((aligned(16))) f32x8 { float v[8]; };
 __device__ __forceinline__ void mma_k32(f32x4& acc, const f32x8& a, const f32x8& b) {
@@ -95,22 +111,25 @@ __device__ __forceinline__ void mma_k32(f32x4& acc, const f32x8& a, const f32x8&
 }
 template <typename T> struct Frag;
 template <> struct Frag<__bf16> { typedef bf16x8 type; };
+template <> struct Frag<_Float16> { typedef f16x8 type; };
 template <> struct Frag<float> { typedef f32x8 type; };
 
-// 4 consecutive elements of one row -> one 8/16-byte store (LDS or global), T = __bf16 | float
-__device__ __forceinline__ void st4(__bf16* p, float a, float b, float c, float d) {
-  typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
-  bf16x4 v;
-  v[0] = (__bf16)a; v[1] = (__bf16)b; v[2] = (__bf16)c; v[3] = (__bf16)d;
-  *reinterpret_cast<bf16x4*>(p) = v;
+// 4 consecutive elements of one row -> one 8/16-byte store (LDS or global), T = __bf16 | _Float16 | float
+template <typename H>
+__device__ __forceinline__ void st4(H* p, float a, float b, float c, float d) {
+  static_assert(sizeof(H) == 2, "16-bit operand type");
+  typename HVec<H, 4>::type v;
+  v[0] = (H)a; v[1] = (H)b; v[2] = (H)c; v[3] = (H)d;
+  *reinterpret_cast<typename HVec<H, 4>::type*>(p) = v;
 }
 __device__ __forceinline__ void st4(float* p, float a, float b, float c, float d) {
   *reinterpret_cast<float4*>(p) = float4{a, b, c, d};
 }
 // 4 consecutive elements (8/16-byte load) -> float4
-__device__ __forceinline__ float4 ld4(const __bf16* p) {
-  typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
-  const bf16x4 v = *reinterpret_cast<const bf16x4*>(p);
+template <typename H>
+__device__ __forceinline__ float4 ld4(const H* p) {
+  static_assert(sizeof(H) == 2, "16-bit operand type");
+  const typename HVec<H, 4>::type v = *reinterpret_cast<const typename HVec<H, 4>::type*>(p);
   return float4{(float)v[0], (float)v[1], (float)v[2], (float)v[3]};
 }
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }

@@ -39,7 +39,8 @@ __global__ __launch_bounds__(256) void ingest_kernel(const float* __restrict__ o
 constexpr int ATT_LD = TD + 1;  // +1 float: conflict-free both for lane=d and lane=(i,j) access
 constexpr int ATT_PLD = 20;
 
-__device__ __forceinline__ float rbf(float x, int bf) { return bf ? (float)(__bf16)x : x; }
+// x as a contraction of compute mode `bf` sees it (0: fp32, 1: bf16, 2: f16 — ModeOf<T>::value)
+__device__ __forceinline__ float rbf(float x, int bf) { return bf == 1 ? (float)(__bf16)x : bf == 2 ? (float)(_Float16)x : x; }
 template <int NT>
 __global__ __launch_bounds__(256) void attn_fwd_kernel(const float* __restrict__ qkv, int n, float* __restrict__ P,
                                                        float* __restrict__ ctx, int bf) {
@@ -395,6 +396,7 @@ enum {
   ST_ADV_SUM = 18, ST_ADV_M2, ST_ADV_CNT, ST_ADV_NM2,
   ST_NONFINITE = 22,  // how many of the 18 logged scalars of this update are NaN / Inf (the on-device form of the
                       // collector's "NaN detected" check, collector/on_policy.py:102-107: the host reads one number per epoch)
+  ST_F16_SAT = 23,    // V4L_F16: how many loss-gradient elements of this update were clamped at +-V4L_F16_GRAD_CLAMP
   ST_SIZE = 24
 };
 
@@ -525,6 +527,15 @@ __global__ __launch_bounds__(256) void comm_check_kernel(const float* __restrict
 // clipped variant of ppo.py:105-112 when clip > 0). values is the critic output [n][OUT_LD], column 0.
 // One row: loss term l and d(loss)/d(value) g. (Shared by the statistics block and by the blocks that run the heads'
 // data-grads beside it, csrc/wps.h: both must see the same bits.)
+// A loss-gradient element as the backward's contractions get it: x gscale (1, or V4L_F16's power of two: exact) and, scaled, kept
+// inside half's range (a NaN stays a NaN). sat counts the clamped ones.
+__device__ __forceinline__ float grad_out(float g, float gscale, int& sat) {
+  if (gscale == 1.f) return g;
+  const float x = g * gscale;
+  const bool over = fabsf(x) > V4L_F16_GRAD_CLAMP;
+  sat += over ? 1 : 0;
+  return over ? copysignf(V4L_F16_GRAD_CLAMP, x) : x;
+}
 __device__ __forceinline__ void critic_row(float v, float r, float ov, int clipped, float clip, float inv_n, float& l, float& g) {
   if (!clipped) {
     const float d = v - r;
@@ -544,25 +555,30 @@ __device__ __forceinline__ void critic_row(float v, float r, float ov, int clipp
 __device__ __forceinline__ void critic_loss_body(const float* __restrict__ values, const float* __restrict__ ret,
                                                  const float* __restrict__ oldv, const int* __restrict__ rowidx, int n,
                                                  float inv_n, int clipped, float clip, float* __restrict__ dvalues,
-                                                 float* __restrict__ st) {
+                                                 float* __restrict__ st, float gscale) {
   double s = 0.0;
+  int sat = 0;
   for (int i = threadIdx.x; i < n; i += blockDim.x) {
     const int slot = rowidx ? rowidx[i] : i;
     const float v = values[(int64_t)i * OUT_LD], r = ret[slot];
     float g, l;
     critic_row(v, r, clipped ? oldv[slot] : 0.f, clipped, clip, inv_n, l, g);
+    g = grad_out(g, gscale, sat);
     s += l;
 #pragma unroll
     for (int c = 0; c < OUT_LD; ++c) dvalues[(int64_t)i * OUT_LD + c] = c == 0 ? g : 0.f;
   }
-  Red4 r = block_red4(s, 0.0, 0.f, 0.f);
-  if (threadIdx.x == 0) st[ST_VF_LOSS] = (float)(r.s * (double)inv_n);
+  Red4 r = block_red4(s, (double)sat, 0.f, 0.f);
+  if (threadIdx.x == 0) {
+    st[ST_VF_LOSS] = (float)(r.s * (double)inv_n);
+    if (gscale != 1.f) st[ST_F16_SAT] += (float)r.s2;
+  }
 }
 __global__ __launch_bounds__(1024) void critic_loss_kernel(const float* __restrict__ values, const float* __restrict__ ret,
                                                           const float* __restrict__ oldv, const int* __restrict__ rowidx,
                                                           int n, float inv_n, int clipped, float clip,
-                                                          float* __restrict__ dvalues, float* __restrict__ st) {
-  critic_loss_body(values, ret, oldv, rowidx, n, inv_n, clipped, clip, dvalues, st);
+                                                          float* __restrict__ dvalues, float* __restrict__ st, float gscale) {
+  critic_loss_body(values, ret, oldv, rowidx, n, inv_n, clipped, clip, dvalues, st, gscale);
 }
 
 
@@ -576,6 +592,7 @@ struct ActorArgs {
   int n, A;
   float inv_n, clip, ent_coef;
   float *dmean, *dlogstd, *st;
+  float gscale;     // the dmean rows leave multiplied by this (v4l_net_grad_scale: 1, or V4L_F16's power of two); d log sigma never does
   int tanh_action;  // TanhNormal policies: log-probs of the stored (post-tanh) actions through atanh, distribution.py:38-51
 };
 struct ActorDims { float ls[8], sg[8], lsg[8], tls[8], tsg[8], tlsg[8]; float ent; };
@@ -644,6 +661,11 @@ __device__ __forceinline__ ActorRow actor_row(const ActorArgs& p, const ActorDim
   o.dlp = (pre <= clp) ? -p.inv_n * an * ratio : 0.f;
   return o;
 }
+// the row's d(loss)/d(mean) as the backward gets it (statistics block and chain blocks: the same bits)
+__device__ __forceinline__ void actor_dmean_row(const ActorRow& o, float gscale, float (&dmr)[8], int& sat) {
+#pragma unroll
+  for (int a = 0; a < 8; ++a) dmr[a] = grad_out(o.dlp * o.dm[a], gscale, sat);
+}
 template <bool TANH>
 __device__ __forceinline__ void actor_loss_body(const ActorArgs& p) {
   __shared__ float sdl[16][8];
@@ -654,6 +676,7 @@ __device__ __forceinline__ void actor_loss_body(const ActorArgs& p) {
   for (int a = 0; a < 8; ++a) dl[a] = 0.f;
   const float amean = p.st[ST_ADV_MEAN], astd = p.st[ST_ADV_STD];
   double s_lp = 0.0, s_lp2 = 0.0, s_sur = 0.0;
+  int sat = 0;
   float lp_mx = -INFINITY, lp_mn = INFINITY, r_mx = -INFINITY, r_mn = INFINITY;
   for (int i = threadIdx.x; i < n; i += blockDim.x) {
     const int slot = p.rowidx ? p.rowidx[i] : i;
@@ -661,8 +684,10 @@ __device__ __forceinline__ void actor_loss_body(const ActorArgs& p) {
     s_sur += o.sur;
     {
       float4* drow = reinterpret_cast<float4*>(p.dmean + (int64_t)i * OUT_LD);
-      drow[0] = float4{o.dlp * o.dm[0], o.dlp * o.dm[1], o.dlp * o.dm[2], o.dlp * o.dm[3]};  // dm[a >= A] == 0
-      drow[1] = float4{o.dlp * o.dm[4], o.dlp * o.dm[5], o.dlp * o.dm[6], o.dlp * o.dm[7]};
+      float dmr[8];
+      actor_dmean_row(o, p.gscale, dmr, sat);
+      drow[0] = float4{dmr[0], dmr[1], dmr[2], dmr[3]};  // dm[a >= A] == 0
+      drow[1] = float4{dmr[4], dmr[5], dmr[6], dmr[7]};
       drow[2] = float4{0.f, 0.f, 0.f, 0.f};
       drow[3] = float4{0.f, 0.f, 0.f, 0.f};
     }
@@ -674,7 +699,7 @@ __device__ __forceinline__ void actor_loss_body(const ActorArgs& p) {
     r_mx = fmaxf(r_mx, o.ratio); r_mn = fminf(r_mn, o.ratio);
   }
   Red4 r1 = block_red4(s_lp, s_lp2, lp_mx, lp_mn);
-  Red4 r2 = block_red4(s_sur, 0.0, r_mx, r_mn);
+  Red4 r2 = block_red4(s_sur, (double)sat, r_mx, r_mn);
   // reduce dlogstd over the block
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
 #pragma unroll
@@ -700,6 +725,7 @@ __device__ __forceinline__ void actor_loss_body(const ActorArgs& p) {
     st[ST_LP_STD] = (float)sqrt(fmax(0.0, (r1.s2 - n * lpm * lpm) / (double)(n - 1)));
     st[ST_LP_MAX] = r1.mx; st[ST_LP_MIN] = r1.mn;
     st[ST_RATIO_MAX] = r2.mx; st[ST_RATIO_MIN] = r2.mn;
+    if (p.gscale != 1.f) st[ST_F16_SAT] += (float)r2.s2;
     double m = 0.0; float mx = -INFINITY, mn = INFINITY;
 #pragma unroll
     for (int a = 0; a < 8; ++a)

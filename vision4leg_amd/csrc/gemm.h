@@ -35,9 +35,11 @@ __device__ __forceinline__ void ld8(const float* p, float (&v)[8]) {
   v[0] = x.x; v[1] = x.y; v[2] = x.z; v[3] = x.w;
   v[4] = y.x; v[5] = y.y; v[6] = y.z; v[7] = y.w;
 }
-// 8 bf16 that are only guaranteed 8-byte aligned (conv1 windows start at 4*ox elements)
-__device__ __forceinline__ void ld8(const __bf16* p, float (&v)[8]) {
-  typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+// 8 16-bit operands that are only guaranteed 8-byte aligned (conv1 windows start at 4*ox elements)
+template <typename H>
+__device__ __forceinline__ void ld8(const H* p, float (&v)[8]) {
+  static_assert(sizeof(H) == 2, "16-bit operand type");
+  typedef typename HVec<H, 4>::type bf16x4;
   const bf16x4 x = *reinterpret_cast<const bf16x4*>(p);
   const bf16x4 y = *reinterpret_cast<const bf16x4*>(p + 4);
 #pragma unroll
@@ -50,10 +52,11 @@ template <int W> __device__ __forceinline__ void ldv(const float* p, float (&v)[
   else if constexpr (W == 2) { const float2 x = *reinterpret_cast<const float2*>(p); v[0] = x.x; v[1] = x.y; }
   else { const float4 x = *reinterpret_cast<const float4*>(p); v[0] = x.x; v[1] = x.y; v[2] = x.z; v[3] = x.w; }
 }
-template <int W> __device__ __forceinline__ void ldv(const __bf16* p, float (&v)[W]) {
+template <int W, typename H> __device__ __forceinline__ void ldv(const H* p, float (&v)[W]) {
+  static_assert(sizeof(H) == 2, "16-bit operand type");
   if constexpr (W == 1) v[0] = (float)p[0];
   else {
-    typedef __attribute__((ext_vector_type(W))) __bf16 bv_t;
+    typedef typename HVec<H, W>::type bv_t;
     const bv_t x = *reinterpret_cast<const bv_t*>(p);
 #pragma unroll
     for (int i = 0; i < W; ++i) v[i] = (float)x[i];
@@ -295,7 +298,7 @@ __device__ __forceinline__ void st8(T* dst, const float (&v)[8]) {
   typename Frag<T>::type f;
   if constexpr (sizeof(T) == 2) {
 #pragma unroll
-    for (int j = 0; j < 8; ++j) f[j] = (__bf16)v[j];
+    for (int j = 0; j < 8; ++j) f[j] = (T)v[j];
   } else {
 #pragma unroll
     for (int j = 0; j < 8; ++j) f.v[j] = v[j];
@@ -767,12 +770,15 @@ struct TnWide {
 };
 template <typename T> struct Pair;
 template <> struct Pair<__bf16> { typedef __attribute__((ext_vector_type(2))) __bf16 type; };
+template <> struct Pair<_Float16> { typedef __attribute__((ext_vector_type(2))) _Float16 type; };
 template <> struct Pair<float> { typedef __attribute__((ext_vector_type(2))) float type; };
-__device__ __forceinline__ void st8raw(__bf16* dst, const __bf16 (&v)[8]) {
-  bf16x8 t;
+template <typename H>
+__device__ __forceinline__ void st8raw(H* dst, const H (&v)[8]) {
+  static_assert(sizeof(H) == 2, "16-bit operand type");
+  typename Frag<H>::type t;
 #pragma unroll
   for (int j = 0; j < 8; ++j) t[j] = v[j];
-  *reinterpret_cast<bf16x8*>(dst) = t;
+  *reinterpret_cast<typename Frag<H>::type*>(dst) = t;
 }
 __device__ __forceinline__ void st8raw(float* dst, const float (&v)[8]) {
   *reinterpret_cast<float4*>(dst) = float4{v[0], v[1], v[2], v[3]};
@@ -956,8 +962,10 @@ struct RedDesc {
 // blk_base: first block of the table this launch covers — the reduction can be issued as two launches (round 4: the conv
 // stack's partials on the main stream right behind dW3, the dense ones on the auxiliary stream behind the grouped weight-grads,
 // both INSIDE the forked section, so that only clip_adam waits for the join); sq_part is indexed by the table-wide block number.
+// unscale: 1 / v4l_net_grad_scale of the pass (1, or a negative power of two in the f16 mode: exact) — the gradients and their
+// norm partials leave unscaled.
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const RedDesc* __restrict__ descs, int nd, float* __restrict__ sq_part,
-                                                           int blk_base) {
+                                                           int blk_base, float unscale) {
   // 64 outputs per block x 4 slab groups: thread (o, g) adds slabs g, g+4, g+8, ... (4 independent accumulators),
   // the 4 group sums are combined through LDS in a fixed order -> deterministic and latency-tolerant
   __shared__ float part[4][64];
@@ -989,7 +997,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const RedDesc* __rest
   part[g][o] = (s0 + s1) + (s2 + s3);
   __syncthreads();
   if (g == 0) {  // wave 0: the 64 outputs of this block; their squares are the block's share of the gradient norm
-    const float sum = p != nullptr ? (part[0][o] + part[1][o]) + (part[2][o] + part[3][o]) : 0.f;
+    const float sum = p != nullptr ? ((part[0][o] + part[1][o]) + (part[2][o] + part[3][o])) * unscale : 0.f;
     if (sq_part != nullptr) {
       const float sq = wave_sum(sum * sum);
       if (o == 0) sq_part[bid] = sq;

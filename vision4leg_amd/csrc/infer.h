@@ -35,18 +35,20 @@ __device__ __forceinline__ typename Frag<T>::type afrag(const float* p) {
   const float4 x = *reinterpret_cast<const float4*>(p);
   const float4 y = *reinterpret_cast<const float4*>(p + 4);
   if constexpr (sizeof(T) == 2) {
-    f[0] = (__bf16)x.x; f[1] = (__bf16)x.y; f[2] = (__bf16)x.z; f[3] = (__bf16)x.w;
-    f[4] = (__bf16)y.x; f[5] = (__bf16)y.y; f[6] = (__bf16)y.z; f[7] = (__bf16)y.w;
+    f[0] = (T)x.x; f[1] = (T)x.y; f[2] = (T)x.z; f[3] = (T)x.w;
+    f[4] = (T)y.x; f[5] = (T)y.y; f[6] = (T)y.z; f[7] = (T)y.w;
   } else {
     f.v[0] = x.x; f.v[1] = x.y; f.v[2] = x.z; f.v[3] = x.w; f.v[4] = y.x; f.v[5] = y.y; f.v[6] = y.z; f.v[7] = y.w;
   }
   return f;
 }
-__device__ __forceinline__ bf16x8 afrag_t(const __bf16* p) {  // 8-byte aligned source (conv1 windows)
-  typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+template <typename H>
+__device__ __forceinline__ typename Frag<H>::type afrag_t(const H* p) {  // 8-byte aligned source (conv1 windows)
+  static_assert(sizeof(H) == 2, "16-bit operand type");
+  typedef typename HVec<H, 4>::type bf16x4;
   const bf16x4 x = *reinterpret_cast<const bf16x4*>(p);
   const bf16x4 y = *reinterpret_cast<const bf16x4*>(p + 4);
-  bf16x8 f;
+  typename Frag<H>::type f;
 #pragma unroll
   for (int j = 0; j < 4; ++j) { f[j] = x[j]; f[4 + j] = y[j]; }
   return f;
@@ -1597,15 +1599,16 @@ __device__ __forceinline__ int64_t act_frag_off(int row, int k, int KS) {
 // [E][ld16] already in bf16 at `img16` (the collector's host threads round fp64 -> fp32 -> bf16, exactly the two roundings the
 // fp32 row path applies: torch.Tensor(ob) on the host, the cast to the operand type here) — half the bytes over PCIe when the
 // kernel reads pinned host memory in place. Otherwise one fp32 row [ld_obs = S + C*H*W] per sample.
-template <int MODE, bool IMG16 = false>
+// T: the 16-bit operand type (__bf16 | _Float16; both share InfEncLds<__bf16>'s byte layout).
+template <typename T, int MODE, bool IMG16 = false>
 __global__ __launch_bounds__(1024) void rollout_encoder2_kernel(const ActCtl* __restrict__ ctl, const float* __restrict__ obs,
-                                                                int ld_obs, const __bf16* __restrict__ img16, int64_t ld16,
+                                                                int ld_obs, const T* __restrict__ img16, int64_t ld16,
                                                                 int E, InfEncFrag w, float* __restrict__ state_roll,
-                                                                __bf16* __restrict__ image_roll, float* __restrict__ x0,
-                                                                __bf16* __restrict__ featv, __bf16* __restrict__ featp,
+                                                                T* __restrict__ image_roll, float* __restrict__ x0,
+                                                                T* __restrict__ featv, T* __restrict__ featp,
                                                                 long long t_plus1) {
-  typedef __bf16 T;
-  typedef bf16x8 frag_t;
+  static_assert(sizeof(T) == 2, "16-bit operand types only");
+  typedef typename Frag<T>::type frag_t;
   typedef InfEncLds<T> LY;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -1714,9 +1717,9 @@ __global__ __launch_bounds__(1024) void rollout_encoder2_kernel(const ActCtl* __
   float* bs = reinterpret_cast<float*>(w2s + 4 * 16 * 64);           // b1[32] | b2[64] | b3[64] | bup[64]
   ROLL_STAMP(96);
   float4 v[4];
-  bf16x8 u[2];
+  frag_t u[2];
   if constexpr (IMG16) {
-    const bf16x8* row = reinterpret_cast<const bf16x8*>(img16 + (int64_t)b * ld16);
+    const frag_t* row = reinterpret_cast<const frag_t*>(img16 + (int64_t)b * ld16);
 #pragma unroll
     for (int k = 0; k < 2; ++k) u[k] = row[tid + k * 1024];  // 2048 x 16 bytes per image: two per thread
   } else {
@@ -1749,8 +1752,8 @@ __global__ __launch_bounds__(1024) void rollout_encoder2_kernel(const ActCtl* __
 #pragma unroll
       for (int k = 0; k < 2; ++k) {
         const int i = tid + k * 1024;
-        *reinterpret_cast<bf16x8*>(img + i * 8) = u[k];
-        *reinterpret_cast<bf16x8*>(roll + i * 8) = u[k];
+        *reinterpret_cast<frag_t*>(img + i * 8) = u[k];
+        *reinterpret_cast<frag_t*>(roll + i * 8) = u[k];
       }
     } else {
 #pragma unroll
@@ -1863,7 +1866,7 @@ __global__ __launch_bounds__(1024) void rollout_encoder2_kernel(const ActCtl* __
 // c3 (fp32 NHWC, what the backward kernels read) and the depth tokens. Blocks 0 .. nmlp-1 run the proprio MLP for 32 rows
 // each (they finish early; the conv blocks queued behind them start on their CUs). bf16 only.
 struct TrainEnc {
-  const __bf16* image;   // [slots][4*64*64]
+  const void* image;     // [slots][4*64*64] in the 16-bit operand type
   const float* state;    // [slots][Sp]
   const int* rowidx;     // [n] or null
   float *s_c1, *s_c2, *s_c3;  // [n][225][32], [n][36][64], [n][16][64]
@@ -1879,10 +1882,10 @@ struct TrainEncLds {
 // 16 tokens per sample), ENC_FLAT (NatureEncoder(flatten): the saved conv3 rows ARE the output), ENC_FUSE (NatureFuseEncoder:
 // the proprio blocks stop after the second Linear+ReLU, whose rows go to tr.s_h2 with row stride tr.ld_h2 — the right half
 // of the concat buffer; the visual projector over the saved conv3 rows is the caller's next launch).
-template <int MODE>
+template <typename T, int MODE>
 __global__ __launch_bounds__(1024) void train_encoder_kernel(InfEncFrag w, TrainEnc tr, float* __restrict__ x0) {
-  typedef __bf16 T;
-  typedef bf16x8 frag_t;
+  static_assert(sizeof(T) == 2, "16-bit operand types only");
+  typedef typename Frag<T>::type frag_t;
   typedef InfEncLds<T> LY;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -1980,7 +1983,7 @@ __global__ __launch_bounds__(1024) void train_encoder_kernel(InfEncFrag w, Train
   frag_t* w2s = w1s + 2 * 8 * 64;                                    // [4][16][64]
   float* bs = reinterpret_cast<float*>(w2s + 4 * 16 * 64);           // b1[32] | b2[64] | b3[64] | bup[64]
   float* part = bs + 256;                                            // [4 K-quarters][16 pixels][64] fp32
-  auto image_of = [&](int smp) { return tr.image + (int64_t)(tr.rowidx ? tr.rowidx[smp] : smp) * LY::IMG; };
+  auto image_of = [&](int smp) { return reinterpret_cast<const T*>(tr.image) + (int64_t)(tr.rowidx ? tr.rowidx[smp] : smp) * LY::IMG; };
   frag_t iv[2];
   {
     const frag_t* src = reinterpret_cast<const frag_t*>(image_of(cb));  // 2048 x 16 bytes, two per thread
@@ -2146,7 +2149,7 @@ __device__ __forceinline__ f32x4 gemv_tile(const AT* x, const T* __restrict__ Wp
   for (int d = 0; d < PD; ++d) ring[d] = *reinterpret_cast<const frag_t*>(wrow + d * 32);
   f32x4 acc = {0.f, 0.f, 0.f, 0.f};
   frag_t zero;
-  if constexpr (sizeof(T) == 2) { for (int j = 0; j < 8; ++j) zero[j] = (__bf16)0.f; } else { for (int j = 0; j < 8; ++j) zero.v[j] = 0.f; }
+  if constexpr (sizeof(T) == 2) { for (int j = 0; j < 8; ++j) zero[j] = (T)0.f; } else { for (int j = 0; j < 8; ++j) zero.v[j] = 0.f; }
 #pragma unroll
   for (int ks = 0; ks < KS; ++ks) {
     const frag_t fb = ring[ks % PD];
@@ -2305,7 +2308,7 @@ __global__ __launch_bounds__(1024) void rollout_cnn_kernel(const ActCtl* __restr
     for (int d = 0; d < 8; ++d) ring[d] = *reinterpret_cast<const fr_t*>(wrow + d * 32);
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
     fr_t zero;
-    if constexpr (sizeof(T) == 2) { for (int j = 0; j < 8; ++j) zero[j] = (__bf16)0.f; } else { for (int j = 0; j < 8; ++j) zero.v[j] = 0.f; }
+    if constexpr (sizeof(T) == 2) { for (int j = 0; j < 8; ++j) zero[j] = (T)0.f; } else { for (int j = 0; j < 8; ++j) zero.v[j] = 0.f; }
 #pragma unroll
     for (int ks = 0; ks < 32; ++ks) {
       const fr_t fb = ring[ks & 7];

@@ -18,22 +18,25 @@
 
 namespace v4l {
 
-struct RollLin {
+// H below: the 16-bit operand type of the step (__bf16 | _Float16); hx8<H>: one MFMA fragment of it
+template <typename H> using hx8 = typename Frag<H>::type;
+
+template <typename H> struct RollLin {
   const void* w[2];       // PK_FRAG pack [N/16][K/32][64] fragments, per net
   const float* b[2];
-  const __bf16* x[2];     // [ceil16(E)][32*KS] in A-fragment order (act_frag_off)
-  __bf16* y[2];           // ks_out > 0: columns of a fragment-order [.][32*ks_out] operand; 0: row-major [E][ldy]
+  const H* x[2];     // [ceil16(E)][32*KS] in A-fragment order (act_frag_off)
+  H* y[2];           // ks_out > 0: columns of a fragment-order [.][32*ks_out] operand; 0: row-major [E][ldy]
   int ks_out, ldy;
 };
 // y[:, tile*16 .. +16] = relu(x . W[tile]^T + b): one wave per (column tile, net); the tile's KS weight fragments and one
 // row tile's KS activation fragments (each one contiguous 1 KB read) are all in flight at once
-template <int KS>
-__global__ __launch_bounds__(64) void rollout_linear_kernel(RollLin a, int E) {
+template <typename H, int KS>
+__global__ __launch_bounds__(64) void rollout_linear_kernel(RollLin<H> a, int E) {
   const int lane = threadIdx.x, tile = blockIdx.x, net = blockIdx.y;
   const int fr = lane & 15, g = lane >> 4;
   ROLL_STAMP(112);
-  const bf16x8* W = reinterpret_cast<const bf16x8*>(a.w[net]) + (size_t)tile * KS * 64 + lane;
-  bf16x8 wf[KS];
+  const hx8<H>* W = reinterpret_cast<const hx8<H>*>(a.w[net]) + (size_t)tile * KS * 64 + lane;
+  hx8<H> wf[KS];
 #pragma unroll
   for (int ks = 0; ks < KS; ++ks) wf[ks] = W[ks * 64];
   const float4 bb = *reinterpret_cast<const float4*>(a.b[net] + tile * 16 + g * 4);
@@ -41,8 +44,8 @@ __global__ __launch_bounds__(64) void rollout_linear_kernel(RollLin a, int E) {
   for (int mt = 0; mt < MT; ++mt) {
     const int row = mt * 16 + fr;
     // rows >= E were never written: those lanes re-read the last real row's chunk (their results are not stored)
-    const bf16x8* X = reinterpret_cast<const bf16x8*>(a.x[net]) + (size_t)mt * KS * 64 + g * 16 + min(fr, E - 1 - mt * 16);
-    bf16x8 xa[KS];
+    const hx8<H>* X = reinterpret_cast<const hx8<H>*>(a.x[net]) + (size_t)mt * KS * 64 + g * 16 + min(fr, E - 1 - mt * 16);
+    hx8<H> xa[KS];
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) xa[ks] = X[ks * 64];
 #ifdef V4L_INFER_TIMING
@@ -58,7 +61,7 @@ __global__ __launch_bounds__(64) void rollout_linear_kernel(RollLin a, int E) {
     }
     if (row < E) {
       const int n4 = tile * 16 + g * 4;
-      __bf16* dst = a.ks_out > 0 ? a.y[net] + act_frag_off(row, n4, a.ks_out) : a.y[net] + (size_t)row * a.ldy + n4;
+      H* dst = a.ks_out > 0 ? a.y[net] + act_frag_off(row, n4, a.ks_out) : a.y[net] + (size_t)row * a.ldy + n4;
       st4(dst, fmaxf((acc0[0] + acc1[0]) + bb.x, 0.f), fmaxf((acc0[1] + acc1[1]) + bb.y, 0.f),
           fmaxf((acc0[2] + acc1[2]) + bb.z, 0.f), fmaxf((acc0[3] + acc1[3]) + bb.w, 0.f));
     }
@@ -70,21 +73,22 @@ __global__ __launch_bounds__(64) void rollout_linear_kernel(RollLin a, int E) {
   }
 }
 
-struct RollHead {
+template <typename H> struct RollHead {
   const void *wb[2], *wo[2];   // PK_FRAG packs: [16][8][64] (256 -> 256), [1][8][64] (256 -> out, padded to 16 columns)
   const float *bb[2], *bo[2];
-  const __bf16* x[2];          // [E][256]
+  const H* x[2];          // [E][256]
   float* out[2];               // [E][OUT_LD] fp32 head outputs (what the general path leaves in the workspace)
   int nout[2];
 };
 struct RollHeadLds { static constexpr int LDH = 256 + 8; static constexpr size_t bytes = (size_t)2 * 64 * LDH * 2 + (2 * 64 * 16 + 16) * 4; };
 // One block per net, 8 waves, every row of the step: Linear(256,256)+ReLU -> last Linear -> the explore / value epilogue of
 // rollout_stack_kernel (same expressions and summation order), thread i = env i.
-__global__ __launch_bounds__(512) void rollout_head_kernel(RollHead a, InfFinish fin, int E) {
+template <typename H>
+__global__ __launch_bounds__(512) void rollout_head_kernel(RollHead<H> a, InfFinish fin, int E) {
   constexpr int LDH = RollHeadLds::LDH;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  __bf16* xs = reinterpret_cast<__bf16*>(smem);      // [64][LDH] input rows
-  __bf16* hs = xs + 64 * LDH;                          // [64][LDH] hidden rows
+  H* xs = reinterpret_cast<H*>(smem);      // [64][LDH] input rows
+  H* hs = xs + 64 * LDH;                          // [64][LDH] hidden rows
   float* so = reinterpret_cast<float*>(hs + 64 * LDH); // [64][16] head outputs
   float* eps_s = so + 64 * 16;                         // [64][A <= 16] exploration noise
   float* lsd_s = eps_s + 64 * 16;                      // [16]
@@ -92,18 +96,18 @@ __global__ __launch_bounds__(512) void rollout_head_kernel(RollHead a, InfFinish
   const int fr = lane & 15, g = lane >> 4;
   const int MT = (E + 15) >> 4, A = fin.A;
   const long long t_step = fin.ctl->t;
-  bf16x8 wo[8], wb[2][8];
+  hx8<H> wo[8], wb[2][8];
   if (wave < 4) {
 #pragma unroll
-    for (int ks = 0; ks < 8; ++ks) wo[ks] = reinterpret_cast<const bf16x8*>(a.wo[net])[ks * 64 + lane];
+    for (int ks = 0; ks < 8; ++ks) wo[ks] = reinterpret_cast<const hx8<H>*>(a.wo[net])[ks * 64 + lane];
   }
 #pragma unroll
   for (int j = 0; j < 2; ++j)
 #pragma unroll
-    for (int ks = 0; ks < 8; ++ks) wb[j][ks] = reinterpret_cast<const bf16x8*>(a.wb[net])[((wave + 8 * j) * 8 + ks) * 64 + lane];
+    for (int ks = 0; ks < 8; ++ks) wb[j][ks] = reinterpret_cast<const hx8<H>*>(a.wb[net])[((wave + 8 * j) * 8 + ks) * 64 + lane];
   for (int idx = tid; idx < MT * 16 * 32; idx += 512) {
     const int row = idx >> 5, c = (idx & 31) * 8;
-    *reinterpret_cast<bf16x8*>(xs + row * LDH + c) = *reinterpret_cast<const bf16x8*>(a.x[net] + (size_t)min(row, E - 1) * 256 + c);
+    *reinterpret_cast<hx8<H>*>(xs + row * LDH + c) = *reinterpret_cast<const hx8<H>*>(a.x[net] + (size_t)min(row, E - 1) * 256 + c);
   }
   if (net == 0) {
     for (int idx = tid; idx < E * A; idx += 512) eps_s[idx] = fin.eps[idx];
@@ -118,7 +122,7 @@ __global__ __launch_bounds__(512) void rollout_head_kernel(RollHead a, InfFinish
       f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int ks = 0; ks < 8; ++ks)
-        mma_k32(acc, wb[j][ks], *reinterpret_cast<const bf16x8*>(xs + (mt * 16 + fr) * LDH + ks * 32 + g * 8));
+        mma_k32(acc, wb[j][ks], *reinterpret_cast<const hx8<H>*>(xs + (mt * 16 + fr) * LDH + ks * 32 + g * 8));
       st4(hs + (mt * 16 + fr) * LDH + tile * 16 + g * 4, fmaxf(acc[0] + bb.x, 0.f), fmaxf(acc[1] + bb.y, 0.f),
           fmaxf(acc[2] + bb.z, 0.f), fmaxf(acc[3] + bb.w, 0.f));
     }
@@ -128,7 +132,7 @@ __global__ __launch_bounds__(512) void rollout_head_kernel(RollHead a, InfFinish
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int ks = 0; ks < 8; ++ks)
-      mma_k32(acc, wo[ks], *reinterpret_cast<const bf16x8*>(hs + (wave * 16 + fr) * LDH + ks * 32 + g * 8));
+      mma_k32(acc, wo[ks], *reinterpret_cast<const hx8<H>*>(hs + (wave * 16 + fr) * LDH + ks * 32 + g * 8));
     const int row = wave * 16 + fr, nout = a.nout[net];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
@@ -194,13 +198,14 @@ struct RollMlp2Lds {
   static constexpr int LDI = 128 + 8, LDH = 256 + 8;
   static constexpr size_t bytes = (size_t)64 * LDI * 2 + (size_t)2 * 64 * LDH * 2 + (3 * 64 * 16 + 3 * 16) * 4;
 };
+template <typename H>
 __global__ __launch_bounds__(1024) void rollout_mlp2_kernel(const float* __restrict__ obs, int E, RollMlp2 a, InfFinish fin,
                                                             float* __restrict__ state_roll) {
   constexpr int LDI = RollMlp2Lds::LDI, LDH = RollMlp2Lds::LDH;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  __bf16* xin = reinterpret_cast<__bf16*>(smem);       // [64][LDI] proprio rows
-  __bf16* ha = xin + 64 * LDI;                          // [64][LDH]
-  __bf16* hb = ha + 64 * LDH;                           // [64][LDH]
+  H* xin = reinterpret_cast<H*>(smem);       // [64][LDI] proprio rows
+  H* ha = xin + 64 * LDI;                          // [64][LDH]
+  H* hb = ha + 64 * LDH;                           // [64][LDH]
   float* so = reinterpret_cast<float*>(hb + 64 * LDH);  // [64][16] head outputs
   float* eps_s = so + 64 * 16;                          // [64][A]
   float* lt_s = eps_s + 64 * 16;                        // [64][16] log-prob terms
@@ -211,16 +216,16 @@ __global__ __launch_bounds__(1024) void rollout_mlp2_kernel(const float* __restr
   const int fr = lane & 15, g = lane >> 4, MT = (E + 15) >> 4, A = fin.A;
   const long long t_step = fin.t_plus1 > 0 ? fin.t_plus1 - 1 : fin.ctl->t;
   auto frag = [&](const void* W, int ks_per_tile, int t, int ks) {
-    return reinterpret_cast<const bf16x8*>(W)[((size_t)t * ks_per_tile + ks) * 64 + lane];
+    return reinterpret_cast<const hx8<H>*>(W)[((size_t)t * ks_per_tile + ks) * 64 + lane];
   };
   // observation rows first (the first GEMM waits for them), then the weights in the order of use
   for (int idx = tid; idx < MT * 16 * 128; idx += 1024) {
     const int r = idx >> 7, c = idx & 127;
     const float x = (r < E && c < a.S) ? obs[(int64_t)r * a.S + c] : 0.f;
-    xin[r * LDI + c] = (__bf16)x;
+    xin[r * LDI + c] = (H)x;
     if (net == 0 && r < E && c < a.Sp) state_roll[((int64_t)t_step * E + r) * a.Sp + c] = x;
   }
-  bf16x8 r1[4], r2[8], r3[8];
+  hx8<H> r1[4], r2[8], r3[8];
 #pragma unroll
   for (int ks = 0; ks < 4; ++ks) r1[ks] = frag(a.wf1, 4, wave, ks);
 #pragma unroll
@@ -242,19 +247,19 @@ __global__ __launch_bounds__(1024) void rollout_mlp2_kernel(const float* __restr
   if (tid < 16) b2_s[tid] = tid < a.nout[net] ? a.b2[net][tid] : 0.f;
   __syncthreads();
   // y[:, tile] = relu(x . W^T + b) for every row tile; x rows in LDS (stride ldx), weights held in registers
-  auto layer = [&](const bf16x8* w, auto ks_tag, const __bf16* x, int ldx, const float4 bb, __bf16* y) {
+  auto layer = [&](const hx8<H>* w, auto ks_tag, const H* x, int ldx, const float4 bb, H* y) {
     constexpr int KS = decltype(ks_tag)::value;
     for (int mt = 0; mt < MT; ++mt) {
       f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks)
-        mma_k32(acc, w[ks], *reinterpret_cast<const bf16x8*>(x + (mt * 16 + fr) * ldx + ks * 32 + g * 8));
+        mma_k32(acc, w[ks], *reinterpret_cast<const hx8<H>*>(x + (mt * 16 + fr) * ldx + ks * 32 + g * 8));
       st4(y + (mt * 16 + fr) * LDH + n4, fmaxf(acc[0] + bb.x, 0.f), fmaxf(acc[1] + bb.y, 0.f), fmaxf(acc[2] + bb.z, 0.f),
           fmaxf(acc[3] + bb.w, 0.f));
     }
   };
   layer(r1, std::integral_constant<int, 4>(), xin, LDI, bb1, ha);
-  bf16x8 r4[8], r5[8];
+  hx8<H> r4[8], r5[8];
 #pragma unroll
   for (int ks = 0; ks < 8; ++ks) r4[ks] = frag(a.w1[net], 8, wave, ks);
   __syncthreads();
@@ -272,7 +277,7 @@ __global__ __launch_bounds__(1024) void rollout_mlp2_kernel(const float* __restr
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int ks = 0; ks < 8; ++ks)
-      mma_k32(acc, r5[ks], *reinterpret_cast<const bf16x8*>(hb + (wave * 16 + fr) * LDH + ks * 32 + g * 8));
+      mma_k32(acc, r5[ks], *reinterpret_cast<const hx8<H>*>(hb + (wave * 16 + fr) * LDH + ks * 32 + g * 8));
     const int row = wave * 16 + fr, nout = a.nout[net];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
@@ -342,13 +347,13 @@ __global__ __launch_bounds__(1024) void rollout_mlp2_kernel(const float* __restr
 // pick up the NEXT launch's target after the finishing block has bumped ctl->seq; graph replays read ctl->seq, which in that
 // mode only moves once BOTH finishing blocks are done — each of them has waited for all 16 tiles of its net, so every block
 // of the launch has passed its entry by then.
-struct RollDense {
+template <typename H> struct RollDense {
   const void* wpr; const float* bpr;                     // fuse net: visual projector (the shared encoder's = the policy's)
   const void *w0[2], *w1[2], *w2[2];                     // PK_FRAG packs per net
   const float *b0[2], *b1[2], *b2[2];
-  const __bf16* featv;                                   // [ceil16(E)][1024] fragment order (act_frag_off, KS 32)
-  __bf16* cat;                                           // fuse net: [ceil16(E)][512] (KS 16)
-  __bf16 *h0[2], *h1[2];                                 // [ceil16(E)][256] (KS 8)
+  const H* featv;                                   // [ceil16(E)][1024] fragment order (act_frag_off, KS 32)
+  H* cat;                                           // fuse net: [ceil16(E)][512] (KS 16)
+  H *h0[2], *h1[2];                                 // [ceil16(E)][256] (KS 8)
   float* out[2]; int nout[2];
 };
 __device__ __forceinline__ void dense_wait(ActCtl* ctl, int idx, unsigned target) {
@@ -367,20 +372,20 @@ __device__ __forceinline__ void dense_signal(ActCtl* ctl, int idx) {
   if ((threadIdx.x & 63) == 0) __hip_atomic_fetch_add(&ctl->stage[idx], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 // one 16-column tile of relu(x . W^T + b) for every row tile, x and y in fragment order
-template <int KS>
-__device__ __forceinline__ void dense_x(bf16x8 (&xa)[KS], const __bf16* x, int mt, int E, int lane) {
+template <typename H, int KS>
+__device__ __forceinline__ void dense_x(hx8<H> (&xa)[KS], const H* x, int mt, int E, int lane) {
   const int fr = lane & 15, g = lane >> 4;
-  const bf16x8* X = reinterpret_cast<const bf16x8*>(x) + (size_t)mt * KS * 64 + g * 16 + min(fr, E - 1 - mt * 16);
+  const hx8<H>* X = reinterpret_cast<const hx8<H>*>(x) + (size_t)mt * KS * 64 + g * 16 + min(fr, E - 1 - mt * 16);
 #pragma unroll
   for (int ks = 0; ks < KS; ++ks) xa[ks] = X[ks * 64];
 }
 // PRE: the caller already requested row tile 0's fragments into xa (ahead of the weights: loads return in order)
-template <int KS, bool PRE = false>
-__device__ __forceinline__ void dense_tile(const bf16x8 (&wf)[KS], const __bf16* x, const float4 bb, __bf16* y, int ks_out,
-                                           int tile, int E, int lane, bf16x8 (&xa)[KS]) {
+template <typename H, int KS, bool PRE = false>
+__device__ __forceinline__ void dense_tile(const hx8<H> (&wf)[KS], const H* x, const float4 bb, H* y, int ks_out,
+                                           int tile, int E, int lane, hx8<H> (&xa)[KS]) {
   const int fr = lane & 15, g = lane >> 4, MT = (E + 15) >> 4;
   for (int mt = 0; mt < MT; ++mt) {
-    if (!PRE || mt > 0) dense_x<KS>(xa, x, mt, E, lane);
+    if (!PRE || mt > 0) dense_x<H, KS>(xa, x, mt, E, lane);
     f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int ks = 0; ks < KS; ks += 2) {
@@ -393,8 +398,8 @@ __device__ __forceinline__ void dense_tile(const bf16x8 (&wf)[KS], const __bf16*
           fmaxf((acc0[1] + acc1[1]) + bb.y, 0.f), fmaxf((acc0[2] + acc1[2]) + bb.z, 0.f), fmaxf((acc0[3] + acc1[3]) + bb.w, 0.f));
   }
 }
-template <bool FUSE>
-__global__ __launch_bounds__(64) void rollout_dense_kernel(RollDense a, InfFinish fin, int E) {
+template <typename H, bool FUSE>
+__global__ __launch_bounds__(64) void rollout_dense_kernel(RollDense<H> a, InfFinish fin, int E) {
   constexpr int KS0 = FUSE ? 16 : 32;
   __shared__ float so[16 * 16];
   __shared__ float eps_s[64 * 16];
@@ -407,13 +412,13 @@ __global__ __launch_bounds__(64) void rollout_dense_kernel(RollDense a, InfFinis
   const unsigned target = 16u * (seq + 1u);
   const long long t_step = fin.t_plus1 > 0 ? fin.t_plus1 - 1 : ctl->t;
   auto frags = [&](const void* W, int ks_per_tile, int t, int ks) {
-    return reinterpret_cast<const bf16x8*>(W)[((size_t)t * ks_per_tile + ks) * 64 + lane];
+    return reinterpret_cast<const hx8<H>*>(W)[((size_t)t * ks_per_tile + ks) * 64 + lane];
   };
   // request order = arrival order: the first stage's activation fragments (the encoder launch left them), its weights,
   // then the later stages' weights and the small operands
-  bf16x8 wp[FUSE ? 32 : 1], w0[KS0], w1[8], w2[8], xv[32], xs0[KS0], xs1[8];
+  hx8<H> wp[FUSE ? 32 : 1], w0[KS0], w1[8], w2[8], xv[32], xs0[KS0], xs1[8];
   const bool first = !FUSE || net == 0;  // this block's first stage reads featv
-  if (first) dense_x<32>(xv, a.featv, 0, E, lane);
+  if (first) dense_x<H, 32>(xv, a.featv, 0, E, lane);
   if constexpr (FUSE) {
     if (net == 0) {
 #pragma unroll
@@ -444,7 +449,7 @@ __global__ __launch_bounds__(64) void rollout_dense_kernel(RollDense a, InfFinis
   ROLL_STAMP(101);
   if constexpr (FUSE) {
     if (net == 0) {
-      dense_tile<32, true>(wp, a.featv, bpv, a.cat, 16, tile, E, lane, xv);
+      dense_tile<H, 32, true>(wp, a.featv, bpv, a.cat, 16, tile, E, lane, xv);
       ROLL_STAMP(102);
       dense_signal(ctl, 0);
     }
@@ -452,14 +457,14 @@ __global__ __launch_bounds__(64) void rollout_dense_kernel(RollDense a, InfFinis
     dense_wait(ctl, 0, target);
   }
   ROLL_STAMP(104);
-  if constexpr (FUSE) dense_tile<KS0>(w0, a.cat, b0v, a.h0[net], 8, tile, E, lane, xs0);
-  else dense_tile<32, true>(w0, a.featv, b0v, a.h0[net], 8, tile, E, lane, xv);
+  if constexpr (FUSE) dense_tile<H, KS0>(w0, a.cat, b0v, a.h0[net], 8, tile, E, lane, xs0);
+  else dense_tile<H, 32, true>(w0, a.featv, b0v, a.h0[net], 8, tile, E, lane, xv);
   ROLL_STAMP(105);
   dense_signal(ctl, 1 + net);
   ROLL_STAMP(106);
   dense_wait(ctl, 1 + net, target);
   ROLL_STAMP(107);
-  dense_tile<8>(w1, a.h0[net], b1v, a.h1[net], 8, tile, E, lane, xs1);
+  dense_tile<H, 8>(w1, a.h0[net], b1v, a.h1[net], 8, tile, E, lane, xs1);
   ROLL_STAMP(108);
   dense_signal(ctl, 3 + net);
   if (tile != 0) return;
@@ -470,10 +475,10 @@ __global__ __launch_bounds__(64) void rollout_dense_kernel(RollDense a, InfFinis
   float b2v[4];
 #pragma unroll
   for (int r = 0; r < 4; ++r) b2v[r] = a.b2[net][min(g * 4 + r, nout - 1)];
-  bf16x8 xl[4][8];  // every row tile's fragments of h1 in one round trip (E <= 64: at most 4 tiles)
+  hx8<H> xl[4][8];  // every row tile's fragments of h1 in one round trip (E <= 64: at most 4 tiles)
 #pragma unroll
   for (int mt = 0; mt < 4; ++mt)
-    if (mt < MT) dense_x<8>(xl[mt], a.h1[net], mt, E, lane);
+    if (mt < MT) dense_x<H, 8>(xl[mt], a.h1[net], mt, E, lane);
 #pragma unroll
   for (int mt = 0; mt < 4; ++mt) {  // last linear (one padded column tile) + the epilogue of rollout_head_kernel, 16 rows at a time
     if (mt >= MT) break;

@@ -20,6 +20,30 @@ namespace v4l {
 static thread_local char g_err[1024] = "";
 // The library's switches (include/v4l_hip.h lists them): every one is read through these two, at the call that uses it
 static bool sw_on(const char* name) { return getenv(name) != nullptr; }
+// Run f(TypeTag<T>) with T = the operand type of compute mode `compute` (float | __bf16 | _Float16); by_half: the 16-bit modes only
+template <typename T> struct TypeTag { typedef T type; };
+#ifdef V4L_DEV_ONLY  // development builds (tools/probe/build_variant.sh only=<mode>): ONE operand type instantiated, a third of the compile time
+template <class F> static inline int by_compute(int compute, F&& f) {
+  typedef std::conditional<V4L_DEV_ONLY == V4L_BF16, __bf16, std::conditional<V4L_DEV_ONLY == V4L_F16, _Float16, float>::type>::type T;
+  if (compute != V4L_DEV_ONLY) { set_error("this development build only holds compute mode %d", V4L_DEV_ONLY); return -1; }
+  return f(TypeTag<T>());
+}
+template <class F> static inline int by_half(int compute, F&& f) {
+  typedef std::conditional<V4L_DEV_ONLY == V4L_F16, _Float16, __bf16>::type T;
+  if (compute != V4L_DEV_ONLY) { set_error("this development build only holds compute mode %d", V4L_DEV_ONLY); return -1; }
+  return f(TypeTag<T>());
+}
+#else
+template <class F> static inline int by_compute(int compute, F&& f) {
+  return compute == V4L_BF16 ? f(TypeTag<__bf16>()) : compute == V4L_F16 ? f(TypeTag<_Float16>()) : f(TypeTag<float>());
+}
+template <class F> static inline int by_half(int compute, F&& f) {
+  return compute == V4L_F16 ? f(TypeTag<_Float16>()) : f(TypeTag<__bf16>());
+}
+#endif
+static inline bool is_half(int compute) { return compute == V4L_BF16 || compute == V4L_F16; }
+// the 16-bit operand type a kernel family that only exists for 16-bit operands is instantiated with from a function templated on T
+template <typename T> struct HalfOf { typedef typename std::conditional<sizeof(T) == 2, T, __bf16>::type type; };
 static int sw_int(const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; }
 static const bool g_trace = sw_on("V4L_TRACE");
 #define V4L_TRACE(...) do { if (v4l::g_trace) { fprintf(stderr, "[v4l] " __VA_ARGS__); fputc('\n', stderr); fflush(stderr); } } while (0)
@@ -349,7 +373,7 @@ static int wgrad_reduce_launch(Ctx& c, int64_t base, int64_t count, hipStream_t 
   g_op = "wgrad_reduce";
   float* sq = net->red_blocks > 0 ? net->d_sq : nullptr;
   V4L_KLAUNCH("wgrad_reduce", 0, s, wgrad_reduce_kernel, dim3((unsigned)count), dim3(256), 0, s, net->d_red, (int)net->red.size(), sq,
-              (int)base);
+              (int)base, net->grad_unscale);
   V4L_LAUNCH_CHECK();
   return 0;
 }
@@ -786,7 +810,7 @@ using namespace v4l;
 int v4l_net::build() {
   const v4l_net_cfg& c = cfg;
   V4L_REQUIRE(c.kind >= V4L_NET_MLP && c.kind <= V4L_NET_LOCO_VIS, "v4l_net_create: unknown net kind %d", c.kind);
-  V4L_REQUIRE(c.compute == V4L_F32 || c.compute == V4L_BF16, "v4l_net_create: unknown compute mode %d", c.compute);
+  V4L_REQUIRE(c.compute == V4L_F32 || c.compute == V4L_BF16 || c.compute == V4L_F16, "v4l_net_create: unknown compute mode %d", c.compute);
   V4L_REQUIRE(c.out_dim > 0 && c.out_dim <= 8, "v4l_net_create: 1<=out_dim<=8 required");
   if (vis_only())  // vision-only nets have no proprio branch: the observation row is the depth stack alone
     V4L_REQUIRE(c.state_dim == 0 && c.n_enc_hidden == 0, "v4l_net_create: vision-only nets take state_dim 0 and no encoder MLP");
@@ -1099,7 +1123,7 @@ int v4l_net::heads_ext(float* ws, int n, v4l::RowsChain* out) {
   if (!bound || out == nullptr || !wps_bwd_plain() || sw_on("V4L_WPS_HEAD_IN") || sw_on("V4L_LAYER_TAPS"))
     return 0;
   const Layout L = layout(n);
-  const size_t es = cfg.compute == V4L_BF16 ? 2 : 4;
+  const size_t es = is_half(cfg.compute) ? 2 : 4;
   const char* base = (const char*)packed;
   out->wa = base + (size_t)head[2].pkt * es; out->wb = base + (size_t)head[1].pkt * es; out->wc = base + (size_t)head[0].pkt * es;
   out->ma = ws + L.hh[1]; out->mb = ws + L.hh[0];
@@ -1114,7 +1138,7 @@ int v4l_net::heads_ext(float* ws, int n, v4l::RowsChain* out) {
 int64_t v4l_net::slab_floats(int n) const {
   int64_t tot = 0;
   auto add = [&](int M, int N, int Kx) {   // conv weight-grads (tn_plan) and, conservatively, dense ones
-    const TnPlan p = tn_plan(M, N, Kx, cfg.compute == V4L_BF16);
+    const TnPlan p = tn_plan(M, N, Kx, is_half(cfg.compute));
     const int64_t dense_splits = 256;  // (lin_wgrad: at most 16384 / V4L_TN_BIG_ROWS slabs, rows per block >= 64)
     const int64_t np = round_up(N, 64), kp = round_up(Kx, 64);
     tot += std::max<int64_t>(p.slab_floats + p.bslab_floats, dense_splits * np * (kp + 1) + 128);
@@ -1233,13 +1257,14 @@ int v4l_net::forward_t(const float* state, const T* image, const int* rowidx, in
                             (vis_only() || (mlp256 && enc[0].Kp == 128 && enc[0].pkf >= 0));
   auto train_enc = [&](auto mode_tag, float* x0, float* s_h2, int ld_h2, bool proprio = true) -> int {
     constexpr int MODE = decltype(mode_tag)::value;
+    typedef typename HalfOf<T>::type H;  // (train_enc_ok: 16-bit operand types only)
     static bool attr = false;
     if (!attr) {
-      V4L_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&train_encoder_kernel<MODE>),
+      V4L_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&train_encoder_kernel<H, MODE>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)TrainEncLds::bytes));
       attr = true;
     }
-    const __bf16* pb = (const __bf16*)packed;
+    const H* pb = (const H*)packed;
     const bool tok = MODE == ENC_TOK17 || MODE == ENC_TOK16, prop = proprio && (MODE == ENC_TOK17 || MODE == ENC_FUSE);
     InfEncFrag ef;
     memset(&ef, 0, sizeof(ef));
@@ -1251,7 +1276,7 @@ int v4l_net::forward_t(const float* state, const T* image, const int* rowidx, in
     }
     ef.S = c.state_dim; ef.Sp = Sp;
     TrainEnc te;
-    te.image = (const __bf16*)image; te.state = state; te.rowidx = rowidx;
+    te.image = (const void*)image; te.state = state; te.rowidx = rowidx;
     te.s_c1 = ws + L.c1; te.s_c2 = ws + L.c2; te.s_c3 = ws + L.c3;
     te.s_h1 = prop ? ws + L.eh[0] : nullptr; te.s_h2 = s_h2; te.ld_h2 = ld_h2;
     te.n = n; te.nmlp = prop ? cdiv(n, 32) : 0;
@@ -1263,7 +1288,7 @@ int v4l_net::forward_t(const float* state, const T* image, const int* rowidx, in
     // persistent conv blocks (the MLP blocks are short; the two kinds then simply run in two waves over the chip)
     te.nconv = std::max(1, std::min(n, std::max(cus / 2, cus - te.nmlp)));
     g_op = "encoder";
-    V4L_KLAUNCH("fused_encoder", 2.0 * n * 3784064.0, s, train_encoder_kernel<MODE>, dim3(te.nmlp + te.nconv), dim3(1024),
+    V4L_KLAUNCH("fused_encoder", 2.0 * n * 3784064.0, s, (train_encoder_kernel<H, MODE>), dim3(te.nmlp + te.nconv), dim3(1024),
                 TrainEncLds::bytes, s, ef, te, x0);
     V4L_LAUNCH_CHECK();
     return 0;
@@ -1561,9 +1586,9 @@ int v4l_net::forward_t(const float* state, const T* image, const int* rowidx, in
       if ((rc = lin_fwd<T>(cx, t.inproj, dense(xin, TD, R, TD), mk_epi(ws + w.qkv, 3 * TD, 3 * TD)))) return rc;
       g_op = "attn";
       if (ntok == NTOK)
-        V4L_KLAUNCH("attn_fwd", 4.0 * n * NTOK * NTOK * TD, s, attn_fwd_kernel<NTOK>, dim3(n), dim3(256), 0, s, ws + w.qkv, n, ws + w.P, ws + w.ctx, (int)(sizeof(T) == 2));
+        V4L_KLAUNCH("attn_fwd", 4.0 * n * NTOK * NTOK * TD, s, attn_fwd_kernel<NTOK>, dim3(n), dim3(256), 0, s, ws + w.qkv, n, ws + w.P, ws + w.ctx, (int)ModeOf<T>::value);
       else
-        V4L_KLAUNCH("attn_fwd", 4.0 * n * 16 * 16 * TD, s, attn_fwd_kernel<16>, dim3(n), dim3(256), 0, s, ws + w.qkv, n, ws + w.P, ws + w.ctx, (int)(sizeof(T) == 2));
+        V4L_KLAUNCH("attn_fwd", 4.0 * n * 16 * 16 * TD, s, attn_fwd_kernel<16>, dim3(n), dim3(256), 0, s, ws + w.qkv, n, ws + w.P, ws + w.ctx, (int)ModeOf<T>::value);
       V4L_LAUNCH_CHECK();
       if ((rc = lin_fwd<T>(cx, t.outproj, dense(ws + w.ctx, TD, R, TD), mk_epi(ws + L.ytmp, TD, TD)))) return rc;
       g_op = "ln1";
@@ -1647,6 +1672,7 @@ int v4l_net::backward_t(const float* state, const T* image, const int* rowidx, i
   wide.clear();
   wide_flops = 0;
   slab_cap = slab_floats(n);
+  grad_unscale = 1.f / v4l_net_grad_scale(this, n);  // (V4L_F16: the d(out) rows came scaled; wgrad_reduce multiplies it out)
   int rc;
   const int ne = c.n_enc_hidden, nh = c.n_head_hidden;
   const ADense sin = dense(state, Sp, n, Sp, rowidx);
@@ -2113,10 +2139,10 @@ int v4l_net::backward_t(const float* state, const T* image, const int* rowidx, i
       g_op = "attn";
       if (ntok == NTOK)
         V4L_KLAUNCH("attn_bwd", 8.0 * n * NTOK * NTOK * TD, s, attn_bwd_kernel<NTOK>, dim3(n), dim3(256), 0, s, ws + w.qkv, ws + w.P,
-                    ws + b.dctx, n, ws + b.dqkv, (int)(sizeof(T) == 2));
+                    ws + b.dctx, n, ws + b.dqkv, (int)ModeOf<T>::value);
       else
         V4L_KLAUNCH("attn_bwd", 8.0 * n * 16 * 16 * TD, s, attn_bwd_kernel<16>, dim3(n), dim3(256), 0, s, ws + w.qkv, ws + w.P,
-                    ws + b.dctx, n, ws + b.dqkv, (int)(sizeof(T) == 2));
+                    ws + b.dctx, n, ws + b.dqkv, (int)ModeOf<T>::value);
       V4L_LAUNCH_CHECK();
       ADense yq = dense(ws + b.dqkv, 3 * TD, R, 3 * TD);
       if ((rc = lin_wgrad<T>(cx, t.inproj, yq, dense(ws + L.x[l], TD, R, TD), TD))) return rc;
@@ -2181,7 +2207,7 @@ static bool actor_fusable(const v4l_actor* a) {
   const v4l_net_cfg &p = a->pf->cfg, &v = a->vf->cfg;
   auto ok = [](const v4l_net_cfg& c) {
     const bool trunk = c.n_head_hidden == 2 && c.head_hidden[0] == 256 && c.head_hidden[1] == 256 && c.ff_dim == 256;
-    if (c.kind == V4L_NET_LOCO_VIS) return trunk && c.compute == V4L_BF16;  // (16 tokens: bf16 kernels only)
+    if (c.kind == V4L_NET_LOCO_VIS) return trunk && is_half(c.compute);  // (16 tokens: 16-bit kernels only)
     return c.kind == V4L_NET_LOCO && c.n_enc_hidden == 2 && c.enc_hidden[0] == 256 && c.enc_hidden[1] == 256 && trunk &&
            c.state_dim <= 128;
   };
@@ -2252,7 +2278,7 @@ static bool actor_dense_cnn(const v4l_actor* a) {
   const v4l_net_cfg &p = a->pf->cfg, &v = a->vf->cfg;
   auto ok = [](const v4l_net_cfg& c) {
     const bool shape = c.n_head_hidden == 2 && c.head_hidden[0] == 256 && c.head_hidden[1] == 256 && c.in_channels == 4 &&
-                       c.img_hw == 64 && c.out_dim <= 16 && c.compute == V4L_BF16;
+                       c.img_hw == 64 && c.out_dim <= 16 && is_half(c.compute);
     if (c.kind == V4L_NET_CNN)
       return shape && c.n_enc_hidden == 2 && c.enc_hidden[0] == 256 && c.enc_hidden[1] == 256 && c.visual_dim == 256 &&
              c.state_dim <= 128;
@@ -2263,30 +2289,31 @@ static bool actor_dense_cnn(const v4l_actor* a) {
 }
 // rollout_encoder2_kernel<MODE> on the step's observation: fp32 rows [E][S + C*H*W], or — v4l_actor_step_split — fp32 proprio
 // rows [E][S] + bf16 depth stacks (a->img16)
-template <int MODE, bool IMG16>
+template <typename H, int MODE, bool IMG16>
 static int launch_encoder2_t(v4l_actor* a, hipStream_t s, double flops, dim3 grid, const float* obs, int E, const InfEncFrag& ef,
-                             float* state_roll, __bf16* image_roll, float* x0, __bf16* featv, __bf16* featp) {
+                             float* state_roll, H* image_roll, float* x0, H* featv, H* featp) {
   static bool attr = false;
   if (!attr) {
-    V4L_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&rollout_encoder2_kernel<MODE, IMG16>),
+    V4L_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&rollout_encoder2_kernel<H, MODE, IMG16>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)RollEnc2Lds::bytes));
     attr = true;
   }
   const int img_elems = a->pf->cfg.in_channels * a->pf->cfg.img_hw * a->pf->cfg.img_hw;
   const int ld_obs = IMG16 ? ef.S : ef.S + img_elems;
-  V4L_KLAUNCH("rollout_encoder", flops, s, (rollout_encoder2_kernel<MODE, IMG16>), grid, dim3(1024), RollEnc2Lds::bytes, s,
-              (const ActCtl*)a->ctl, obs, ld_obs, (const __bf16*)a->img16, a->ld_img16, E, ef, state_roll, image_roll, x0, featv,
+  V4L_KLAUNCH("rollout_encoder", flops, s, (rollout_encoder2_kernel<H, MODE, IMG16>), grid, dim3(1024), RollEnc2Lds::bytes, s,
+              (const ActCtl*)a->ctl, obs, ld_obs, (const H*)a->img16, a->ld_img16, E, ef, state_roll, image_roll, x0, featv,
               featp, actor_t_plus1(a, s));
   V4L_LAUNCH_CHECK();
   return 0;
 }
-template <int MODE>
+template <typename H, int MODE>
 static int launch_encoder2(v4l_actor* a, hipStream_t s, double flops, dim3 grid, const float* obs, int E, const InfEncFrag& ef,
-                           float* state_roll, __bf16* image_roll, float* x0, __bf16* featv, __bf16* featp) {
-  return a->img16 ? launch_encoder2_t<MODE, true>(a, s, flops, grid, obs, E, ef, state_roll, image_roll, x0, featv, featp)
-                  : launch_encoder2_t<MODE, false>(a, s, flops, grid, obs, E, ef, state_roll, image_roll, x0, featv, featp);
+                           float* state_roll, H* image_roll, float* x0, H* featv, H* featp) {
+  return a->img16 ? launch_encoder2_t<H, MODE, true>(a, s, flops, grid, obs, E, ef, state_roll, image_roll, x0, featv, featp)
+                  : launch_encoder2_t<H, MODE, false>(a, s, flops, grid, obs, E, ef, state_roll, image_roll, x0, featv, featp);
 }
 
+template <typename H>
 static int run_actor_dense_cnn(v4l_actor* a, const float* obs, const float* eps, float* state_roll, void* image_roll,
                                float* acts_roll, float* values_roll, float* logp_roll, float* action, float* mean, float* stdv,
                                float* ent, float* value, hipStream_t s) {
@@ -2295,16 +2322,16 @@ static int run_actor_dense_cnn(v4l_actor* a, const float* obs, const float* eps,
   const bool fuse = pf->cfg.kind == V4L_NET_CNN;
   static bool attr_done = false;
   if (!attr_done) {
-    V4L_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&rollout_encoder2_kernel<ENC_FUSE>),
+    V4L_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&rollout_encoder2_kernel<H, ENC_FUSE>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)RollEnc2Lds::bytes));
-    V4L_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&rollout_encoder2_kernel<ENC_FLAT>),
+    V4L_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&rollout_encoder2_kernel<H, ENC_FLAT>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)RollEnc2Lds::bytes));
-    V4L_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&rollout_head_kernel),
+    V4L_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&rollout_head_kernel<H>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)RollHeadLds::bytes));
     attr_done = true;
   }
-  const __bf16* pk = (const __bf16*)pf->packed;
-  const __bf16* vk = (const __bf16*)vf->packed;
+  const H* pk = (const H*)pf->packed;
+  const H* vk = (const H*)vf->packed;
   const Layout Lp = pf->layout(E), Lv = vf->layout(E);
   float* ws_pf = a->ws;
   float* ws_vf = a->ws + Lp.total;
@@ -2312,12 +2339,12 @@ static int run_actor_dense_cnn(v4l_actor* a, const float* obs, const float* eps,
   // computes no gradients): conv3 flatten [R][1024], the concat [R][512], fc0 / fc1 outputs [R][256] per net, R = ceil16(E)
   const int64_t R16 = round_up(E, 16);
   V4L_REQUIRE(Lp.total - Lp.slab >= R16 * (512 + 256 + 4 * 128), "internal: rollout scratch does not fit the slab region");
-  __bf16* featv = reinterpret_cast<__bf16*>(ws_pf + Lp.slab);
-  __bf16* cat = featv + R16 * 1024;
-  __bf16* h0p = cat + R16 * 512;
-  __bf16* h0v = h0p + R16 * 256;
-  __bf16* h1p = h0v + R16 * 256;
-  __bf16* h1v = h1p + R16 * 256;
+  H* featv = reinterpret_cast<H*>(ws_pf + Lp.slab);
+  H* cat = featv + R16 * 1024;
+  H* h0p = cat + R16 * 512;
+  H* h0v = h0p + R16 * 256;
+  H* h1p = h0v + R16 * 256;
+  H* h1v = h1p + R16 * 256;
   PhaseScope ps("rollout");
   InfEncFrag ef;
   memset(&ef, 0, sizeof(ef));
@@ -2328,12 +2355,12 @@ static int run_actor_dense_cnn(v4l_actor* a, const float* obs, const float* eps,
   if (fuse) {
     ef.wf1 = pk + pf->enc[0].pkf; ef.wf2 = pk + pf->enc[1].pkf; ef.wpr = ef.wf2;
     ef.bf1 = pf->p[pf->enc[0].b]; ef.bf2 = pf->p[pf->enc[1].b]; ef.bpr = ef.bf2;
-    if (int rc = launch_encoder2<ENC_FUSE>(a, s, 2.0 * E * (3612672.0 + 128 * 256 + 256 * 256), dim3(E + cdiv(E, 32)), obs, E, ef,
-                                           state_roll, (__bf16*)image_roll, (float*)nullptr, featv, cat))
+    if (int rc = launch_encoder2<H, ENC_FUSE>(a, s, 2.0 * E * (3612672.0 + 128 * 256 + 256 * 256), dim3(E + cdiv(E, 32)), obs, E, ef,
+                                           state_roll, (H*)image_roll, (float*)nullptr, featv, cat))
       return rc;
   } else {
-    if (int rc = launch_encoder2<ENC_FLAT>(a, s, 2.0 * E * 3612672.0, dim3(E), obs, E, ef, state_roll, (__bf16*)image_roll,
-                                           (float*)nullptr, featv, (__bf16*)nullptr))
+    if (int rc = launch_encoder2<H, ENC_FLAT>(a, s, 2.0 * E * 3612672.0, dim3(E), obs, E, ef, state_roll, (H*)image_roll,
+                                           (float*)nullptr, featv, (H*)nullptr))
       return rc;
   }
   InfFinish fin;
@@ -2345,10 +2372,10 @@ static int run_actor_dense_cnn(v4l_actor* a, const float* obs, const float* eps,
   g_op = "dense";
   if (!sw_on("V4L_ROLLOUT_DENSE_SPLIT")) {  // (read per call: tests switch it)
     // projector -> fc0 -> fc1 -> last linear -> epilogue as stages of one launch (device-side hand-overs)
-    RollDense d;
+    RollDense<H> d;
     memset(&d, 0, sizeof(d));
     if (fuse) { d.wpr = pk + pf->proj.pkf; d.bpr = pf->p[pf->proj.b]; }
-    auto net_of = [&](int i, v4l_net* net, const __bf16* base, __bf16* h0, __bf16* h1, float* out) {
+    auto net_of = [&](int i, v4l_net* net, const H* base, H* h0, H* h1, float* out) {
       d.w0[i] = base + net->head[0].pkf; d.w1[i] = base + net->head[1].pkf; d.w2[i] = base + net->head[2].pkf;
       d.b0[i] = net->p[net->head[0].b]; d.b1[i] = net->p[net->head[1].b]; d.b2[i] = net->p[net->head[2].b];
       d.h0[i] = h0; d.h1[i] = h1; d.out[i] = out; d.nout[i] = net->cfg.out_dim;
@@ -2359,32 +2386,32 @@ static int run_actor_dense_cnn(v4l_actor* a, const float* obs, const float* eps,
     const double fl = 2.0 * E * ((fuse ? 1024.0 * 256 : 0.0) + 2 * ((fuse ? 512.0 : 1024.0) * 256 + 256 * 256 + 256 * 16));
     if (capturing(s)) { fin.seq_plus1 = 0; a->dense_in_graph = true; }   // replays read (and advance) the device's count
     else fin.seq_plus1 = ++a->dense_seq;                                  // eager: this launch's number + 1, from the host
-    if (fuse) V4L_KLAUNCH("rollout_dense", fl, s, rollout_dense_kernel<true>, dim3(32), dim3(64), 0, s, d, fin, E);
-    else V4L_KLAUNCH("rollout_dense", fl, s, rollout_dense_kernel<false>, dim3(32), dim3(64), 0, s, d, fin, E);
+    if (fuse) V4L_KLAUNCH("rollout_dense", fl, s, (rollout_dense_kernel<H, true>), dim3(32), dim3(64), 0, s, d, fin, E);
+    else V4L_KLAUNCH("rollout_dense", fl, s, (rollout_dense_kernel<H, false>), dim3(32), dim3(64), 0, s, d, fin, E);
     V4L_LAUNCH_CHECK();
     return 0;
   }
-  RollLin fc0;
+  RollLin<H> fc0;
   memset(&fc0, 0, sizeof(fc0));
   fc0.w[0] = pk + pf->head[0].pkf; fc0.w[1] = vk + vf->head[0].pkf;
   fc0.b[0] = pf->p[pf->head[0].b]; fc0.b[1] = vf->p[vf->head[0].b];
   fc0.y[0] = h0p; fc0.y[1] = h0v; fc0.ldy = 256;
   if (fuse) {
-    RollLin pr;
+    RollLin<H> pr;
     memset(&pr, 0, sizeof(pr));
     pr.w[0] = pk + pf->proj.pkf; pr.b[0] = pf->p[pf->proj.b]; pr.x[0] = featv; pr.y[0] = cat; pr.ks_out = 16;
-    V4L_KLAUNCH("rollout_linear", 2.0 * E * 1024 * 256, s, rollout_linear_kernel<32>, dim3(16, 1), dim3(64), 0, s, pr, E);
+    V4L_KLAUNCH("rollout_linear", 2.0 * E * 1024 * 256, s, (rollout_linear_kernel<H, 32>), dim3(16, 1), dim3(64), 0, s, pr, E);
     V4L_LAUNCH_CHECK();
     fc0.x[0] = fc0.x[1] = cat;
-    V4L_KLAUNCH("rollout_linear", 2.0 * 2 * E * 512 * 256, s, rollout_linear_kernel<16>, dim3(16, 2), dim3(64), 0, s, fc0, E);
+    V4L_KLAUNCH("rollout_linear", 2.0 * 2 * E * 512 * 256, s, (rollout_linear_kernel<H, 16>), dim3(16, 2), dim3(64), 0, s, fc0, E);
   } else {
     fc0.x[0] = fc0.x[1] = featv;
-    V4L_KLAUNCH("rollout_linear", 2.0 * 2 * E * 1024 * 256, s, rollout_linear_kernel<32>, dim3(16, 2), dim3(64), 0, s, fc0, E);
+    V4L_KLAUNCH("rollout_linear", 2.0 * 2 * E * 1024 * 256, s, (rollout_linear_kernel<H, 32>), dim3(16, 2), dim3(64), 0, s, fc0, E);
   }
   V4L_LAUNCH_CHECK();
-  RollHead hd;
+  RollHead<H> hd;
   memset(&hd, 0, sizeof(hd));
-  auto head = [&](int i, v4l_net* net, const __bf16* base, const __bf16* x, float* out) {
+  auto head = [&](int i, v4l_net* net, const H* base, const H* x, float* out) {
     hd.wb[i] = base + net->head[1].pkf; hd.wo[i] = base + net->head[2].pkf;
     hd.bb[i] = net->p[net->head[1].b]; hd.bo[i] = net->p[net->head[2].b];
     hd.x[i] = x; hd.out[i] = out; hd.nout[i] = net->cfg.out_dim;
@@ -2392,7 +2419,7 @@ static int run_actor_dense_cnn(v4l_actor* a, const float* obs, const float* eps,
   head(0, pf, pk, h0p, ws_pf + Lp.out);
   head(1, vf, vk, h0v, ws_vf + Lv.out);
   g_op = "head";
-  V4L_KLAUNCH("rollout_head", 2.0 * 2 * E * (256 * 256 + 256 * 16), s, rollout_head_kernel, dim3(2), dim3(512), RollHeadLds::bytes,
+  V4L_KLAUNCH("rollout_head", 2.0 * 2 * E * (256 * 256 + 256 * 16), s, rollout_head_kernel<H>, dim3(2), dim3(512), RollHeadLds::bytes,
               s, hd, fin, E);
   V4L_LAUNCH_CHECK();
   return 0;
@@ -2401,9 +2428,10 @@ static int run_actor_dense_cnn(v4l_actor* a, const float* obs, const float* eps,
 // state-only MLP nets, bf16: one launch per env step, one block per net for ALL E rows (csrc/rollout_dense.h rollout_mlp2_kernel)
 static bool actor_mlp2(const v4l_actor* a) {
   const v4l_net_cfg& p = a->pf->cfg;
-  return p.compute == V4L_BF16 && a->E <= 64 && p.out_dim <= 16 && a->pf->enc[0].Kp == 128 && a->pf->enc[0].pkf >= 0 &&
+  return is_half(p.compute) && a->E <= 64 && p.out_dim <= 16 && a->pf->enc[0].Kp == 128 && a->pf->enc[0].pkf >= 0 &&
          a->pf->head[0].pkf >= 0 && a->vf->head[0].pkf >= 0;
 }
+template <typename H>
 static int run_actor_mlp2(v4l_actor* a, const float* obs, const float* eps, float* state_roll, float* acts_roll,
                           float* values_roll, float* logp_roll, float* action, float* mean, float* stdv, float* ent, float* value,
                           hipStream_t s) {
@@ -2411,12 +2439,12 @@ static int run_actor_mlp2(v4l_actor* a, const float* obs, const float* eps, floa
   const int E = a->E;
   static bool attr_done = false;
   if (!attr_done) {
-    V4L_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&rollout_mlp2_kernel),
+    V4L_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&rollout_mlp2_kernel<H>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)RollMlp2Lds::bytes));
     attr_done = true;
   }
-  const __bf16* pk = (const __bf16*)pf->packed;
-  const __bf16* vk = (const __bf16*)vf->packed;
+  const H* pk = (const H*)pf->packed;
+  const H* vk = (const H*)vf->packed;
   const Layout Lp = pf->layout(E), Lv = vf->layout(E);
   PhaseScope ps("rollout");
   RollMlp2 m;
@@ -2424,7 +2452,7 @@ static int run_actor_mlp2(v4l_actor* a, const float* obs, const float* eps, floa
   m.wf1 = pk + pf->enc[0].pkf; m.wf2 = pk + pf->enc[1].pkf;
   m.bf1 = pf->p[pf->enc[0].b]; m.bf2 = pf->p[pf->enc[1].b];
   m.S = pf->cfg.state_dim; m.Sp = pf->Sp;
-  auto head = [&](int i, v4l_net* net, const __bf16* base, float* out) {
+  auto head = [&](int i, v4l_net* net, const H* base, float* out) {
     m.w0[i] = base + net->head[0].pkf; m.w1[i] = base + net->head[1].pkf; m.w2[i] = base + net->head[2].pkf;
     m.b0[i] = net->p[net->head[0].b]; m.b1[i] = net->p[net->head[1].b]; m.b2[i] = net->p[net->head[2].b];
     m.out[i] = out; m.nout[i] = net->cfg.out_dim;
@@ -2438,7 +2466,7 @@ static int run_actor_mlp2(v4l_actor* a, const float* obs, const float* eps, floa
   fin.acts_roll = acts_roll; fin.values_roll = values_roll; fin.logp_roll = logp_roll; fin.action = action;
   fin.mean = mean; fin.stdv = stdv; fin.ent = ent; fin.value = value;
   g_op = "step";
-  V4L_KLAUNCH("rollout_mlp", 2.0 * 2 * E * (128.0 * 256 + 4 * 256 * 256), s, rollout_mlp2_kernel, dim3(2), dim3(1024),
+  V4L_KLAUNCH("rollout_mlp", 2.0 * 2 * E * (128.0 * 256 + 4 * 256 * 256), s, rollout_mlp2_kernel<H>, dim3(2), dim3(1024),
               RollMlp2Lds::bytes, s, obs, E, m, fin, state_roll);
   V4L_LAUNCH_CHECK();
   return 0;
@@ -2494,6 +2522,7 @@ template <typename T>
 static int run_actor_fused(v4l_actor* a, const float* obs, const float* eps, float* state_roll, void* image_roll,
                            float* acts_roll, float* values_roll, float* logp_roll, float* action, float* mean, float* stdv,
                            float* ent, float* value, hipStream_t s) {
+  typedef typename HalfOf<T>::type H;  // the fragment-pack encoder kernels exist for the 16-bit operand types only
   v4l_net *pf = a->pf, *vf = a->vf;
   const int E = a->E;
   static bool attr_done = false;
@@ -2504,7 +2533,7 @@ static int run_actor_fused(v4l_actor* a, const float* obs, const float* eps, flo
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)RollStackLds<T>::bytes));
     V4L_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&rollout_stack_kernel<T, 2, 16>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)RollStackLds<T>::bytes));
-    V4L_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&rollout_encoder2_kernel<ENC_TOK16>),
+    V4L_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&rollout_encoder2_kernel<H, ENC_TOK16>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)RollEnc2Lds::bytes));
     attr_done = true;
   }
@@ -2528,25 +2557,25 @@ static int run_actor_fused(v4l_actor* a, const float* obs, const float* eps, flo
   float* x0 = ws_pf + Lp.x[0];
   g_op = "encoder";
   if (vis) {  // 16 depth tokens, no proprio blocks (actor_fusable: bf16 only)
-    const __bf16* pb = (const __bf16*)pf->packed;
+    const H* pb = (const H*)pf->packed;
     InfEncFrag ef;
     memset(&ef, 0, sizeof(ef));
     ef.w1 = pb + pf->conv[0].pkf; ef.w2 = pb + pf->conv[1].pkf; ef.w3 = pb + pf->conv[2].pkf; ef.wup = pb + pf->upconv.pkf;
     ef.b1 = en.b1; ef.b2 = en.b2; ef.b3 = en.b3; ef.bup = en.bup;
     ef.S = en.S; ef.Sp = en.Sp;
-    if (int rc = launch_encoder2<ENC_TOK16>(a, s, 2.0 * E * 3678208.0, dim3(E), obs, E, ef, state_roll, (__bf16*)image_roll, x0,
-                                            (__bf16*)nullptr, (__bf16*)nullptr))
+    if (int rc = launch_encoder2<H, ENC_TOK16>(a, s, 2.0 * E * 3678208.0, dim3(E), obs, E, ef, state_roll, (H*)image_roll, x0,
+                                            (H*)nullptr, (H*)nullptr))
       return rc;
   } else if (sizeof(T) == 2 && pf->enc.size() == 2 && pf->enc[0].Kp == 128 && pf->conv[0].pkf >= 0) {
-    const __bf16* pb = (const __bf16*)pf->packed;
+    const H* pb = (const H*)pf->packed;
     InfEncFrag ef;
     ef.w1 = pb + pf->conv[0].pkf; ef.w2 = pb + pf->conv[1].pkf; ef.w3 = pb + pf->conv[2].pkf; ef.wup = pb + pf->upconv.pkf;
     ef.b1 = en.b1; ef.b2 = en.b2; ef.b3 = en.b3; ef.bup = en.bup;
     ef.wf1 = pb + pf->enc[0].pkf; ef.wf2 = pb + pf->enc[1].pkf; ef.wpr = pb + pf->proj.pkf;
     ef.bf1 = en.bf1; ef.bf2 = en.bf2; ef.bpr = en.bpr;
     ef.S = en.S; ef.Sp = en.Sp;
-    if (int rc = launch_encoder2<ENC_TOK17>(a, s, 2.0 * E * 3678208.0, dim3(E + cdiv(E, 32)), obs, E, ef, state_roll,
-                                            (__bf16*)image_roll, x0, (__bf16*)nullptr, (__bf16*)nullptr))
+    if (int rc = launch_encoder2<H, ENC_TOK17>(a, s, 2.0 * E * 3678208.0, dim3(E + cdiv(E, 32)), obs, E, ef, state_roll,
+                                            (H*)image_roll, x0, (H*)nullptr, (H*)nullptr))
       return rc;
   } else  // fp32 parity mode (fragments twice the size): weights streamed per wave
     V4L_KLAUNCH("rollout_encoder", 2.0 * E * 3678208.0, s, rollout_encoder_kernel<T>, dim3(E + cdiv(E, 32)), dim3(1024),
@@ -2643,12 +2672,12 @@ template <typename T, int NW> static int loss_heads_attr() {
 // the loss launch with the heads' chain beside the statistics: grid = 1 + row blocks, NW waves per block
 template <typename T, int NW>
 static int launch_critic_loss_heads(hipStream_t s, const float* values, const float* ret, const float* oldv, const int* rowidx, int n,
-                                    float inv_n, int clipped, float clip, float* dvalues, float* st, const RowsChain& hc) {
+                                    float inv_n, int clipped, float clip, float* dvalues, float* st, const RowsChain& hc, float gscale) {
   int rc = loss_heads_attr<T, NW>();
   if (rc) return rc;
   V4L_KLAUNCH("critic_loss", 2.0 * n * (16 * 256 + 256 * 256 + 256 * 128), s, (critic_loss_heads_kernel<T, NW>),
               dim3(1 + cdiv(n, RowsChainCfg<T>::MT * 16)), dim3(NW * 64), (RowsChainLds<T, RowsChainCfg<T>::MT>::bytes3), s, values, ret,
-              oldv, rowidx, n, inv_n, clipped, clip, dvalues, st, hc);
+              oldv, rowidx, n, inv_n, clipped, clip, dvalues, st, hc, gscale);
   return 0;
 }
 template <typename T, int NW>
@@ -2664,7 +2693,7 @@ static int launch_actor_loss_heads(hipStream_t s, const ActorArgs& aa, const Row
 extern "C" {
 
 const char* v4l_last_error(void) { return v4l::last_error(); }
-int v4l_version(void) { return 104; }  // round 4: v4l_net_cfg grew (tanh_action, max_pool, token_norm), v4l_abi_sizeof
+int v4l_version(void) { return 105; }  // round 6: V4L_F16 compute mode, v4l_net_grad_scale, record slot 23
 int v4l_abi_sizeof(int which) {
   return which == 0 ? (int)sizeof(v4l_net_cfg) : which == 1 ? (int)sizeof(v4l_ppo_hyper) : which == 2 ? (int)sizeof(v4l_rollout) : -1;
 }
@@ -2705,7 +2734,7 @@ int v4l_net_param_info(const v4l_net* net, int i, const char** name, int* ndim, 
 }
 int64_t v4l_net_total_params(const v4l_net* net) { return net ? net->total_params : -1; }
 int64_t v4l_net_packed_bytes(const v4l_net* net) {
-  return net ? net->packed_elems * (net->cfg.compute == V4L_BF16 ? 2 : 4) + 256 : -1;
+  return net ? net->packed_elems * (is_half(net->cfg.compute) ? 2 : 4) + 256 : -1;
 }
 int64_t v4l_net_table_bytes(const v4l_net* net) { return net ? net->table_bytes() : -1; }
 int64_t v4l_net_ws_floats(const v4l_net* net, int n, int train) {
@@ -2810,14 +2839,13 @@ int v4l_net_bind(v4l_net* net, float* const* params_dev, void* packed_dev, void*
 int v4l_net_pack(v4l_net* net, void* stream) {
   V4L_REQUIRE(net && net->bound, "v4l_net_pack: net is not bound");
   hipStream_t s = (hipStream_t)stream;
-  if (net->cfg.compute == V4L_BF16)
-    V4L_KLAUNCH("pack", 0, s, pack_kernel<__bf16>, dim3((unsigned)net->pack_blocks), dim3(256), 0, s, net->d_packs,
-                       (int)net->packs.size(), (__bf16*)net->packed);
-  else
-    V4L_KLAUNCH("pack", 0, s, pack_kernel<float>, dim3((unsigned)net->pack_blocks), dim3(256), 0, s, net->d_packs,
-                       (int)net->packs.size(), (float*)net->packed);
-  V4L_LAUNCH_CHECK();
-  return 0;
+  return by_compute(net->cfg.compute, [&](auto tag) -> int {
+    typedef typename decltype(tag)::type T;
+    V4L_KLAUNCH("pack", 0, s, pack_kernel<T>, dim3((unsigned)net->pack_blocks), dim3(256), 0, s, net->d_packs,
+                (int)net->packs.size(), (T*)net->packed);
+    V4L_LAUNCH_CHECK();
+    return 0;
+  });
 }
 
 int v4l_ingest(const v4l_net* net, const float* obs_dev, int n, float* state_dev, void* image_dev, int64_t slot0,
@@ -2827,14 +2855,13 @@ int v4l_ingest(const v4l_net* net, const float* obs_dev, int n, float* state_dev
   const int S = net->cfg.state_dim;
   const int img = net->cfg.kind == V4L_NET_MLP ? 0 : net->cfg.in_channels * net->cfg.img_hw * net->cfg.img_hw;
   V4L_REQUIRE(img == 0 || image_dev != nullptr, "v4l_ingest: image_dev is null for a visual net");
-  if (net->cfg.compute == V4L_BF16)
-    hipLaunchKernelGGL(ingest_kernel<__bf16>, dim3(n), dim3(256), 0, s, obs_dev, n, S, net->Sp, img, state_dev,
-                       (__bf16*)image_dev, slot0, (const long long*)nullptr);
-  else
-    hipLaunchKernelGGL(ingest_kernel<float>, dim3(n), dim3(256), 0, s, obs_dev, n, S, net->Sp, img, state_dev,
-                       (float*)image_dev, slot0, (const long long*)nullptr);
-  V4L_LAUNCH_CHECK();
-  return 0;
+  return by_compute(net->cfg.compute, [&](auto tag) -> int {
+    typedef typename decltype(tag)::type T;
+    hipLaunchKernelGGL(ingest_kernel<T>, dim3(n), dim3(256), 0, s, obs_dev, n, S, net->Sp, img, state_dev, (T*)image_dev, slot0,
+                       (const long long*)nullptr);
+    V4L_LAUNCH_CHECK();
+    return 0;
+  });
 }
 
 int v4l_net_forward(v4l_net* net, const float* state_dev, const void* image_dev, const int* rowidx_dev, int n,
@@ -2845,9 +2872,10 @@ int v4l_net_forward(v4l_net* net, const float* state_dev, const void* image_dev,
   // train: a v4l_net_backward over this workspace follows — the conv activations it reads may then be saved in the operand type
   net->want_acts16 = train != 0;
   net->acts16_written = false;
-  const int rc = net->cfg.compute == V4L_BF16
-                     ? net->forward_t<__bf16>(state_dev, (const __bf16*)image_dev, rowidx_dev, n, ws_dev, (hipStream_t)stream)
-                     : net->forward_t<float>(state_dev, (const float*)image_dev, rowidx_dev, n, ws_dev, (hipStream_t)stream);
+  const int rc = by_compute(net->cfg.compute, [&](auto tag) -> int {
+    typedef typename decltype(tag)::type T;
+    return net->forward_t<T>(state_dev, (const T*)image_dev, rowidx_dev, n, ws_dev, (hipStream_t)stream);
+  });
   net->want_acts16 = false;
   return rc;
 }
@@ -2856,15 +2884,21 @@ float* v4l_net_out_ptr(const v4l_net* net, float* ws_dev, int n, int train) {
   return ws_dev + net->layout(n).out;
 }
 float* v4l_net_dout_ptr(const v4l_net* net, float* ws_dev, int n) { return ws_dev + net->layout(n).dout; }
+float v4l_net_grad_scale(const v4l_net* net, int n) {
+  if (net == nullptr || net->cfg.compute != V4L_F16 || n < 1) return 1.f;
+  int lg = 0;
+  while ((1 << lg) < n && lg < 30) ++lg;  // ceil(log2 n)
+  return ldexpf(1.f, V4L_F16_SCALE_LOG2 + lg);
+}
 
 int v4l_net_backward(v4l_net* net, const float* state_dev, const void* image_dev, const int* rowidx_dev, int n,
                      float* ws_dev, float* grads_dev, void* stream) {
   V4L_REQUIRE(net && net->bound, "v4l_net_backward: net is not bound");
   V4L_REQUIRE(state_dev && ws_dev && grads_dev && n > 0, "v4l_net_backward: bad argument");
-  if (net->cfg.compute == V4L_BF16)
-    return net->backward_t<__bf16>(state_dev, (const __bf16*)image_dev, rowidx_dev, n, ws_dev, grads_dev,
-                                   (hipStream_t)stream);
-  return net->backward_t<float>(state_dev, (const float*)image_dev, rowidx_dev, n, ws_dev, grads_dev, (hipStream_t)stream);
+  return by_compute(net->cfg.compute, [&](auto tag) -> int {
+    typedef typename decltype(tag)::type T;
+    return net->backward_t<T>(state_dev, (const T*)image_dev, rowidx_dev, n, ws_dev, grads_dev, (hipStream_t)stream);
+  });
 }
 
 int v4l_gauss_head(const float* meanp_dev, const float* logstd_dev, const float* acts_dev, int n, int A,
@@ -3094,28 +3128,31 @@ static int run_actor_step(v4l_actor* a, const float* obs, const float* eps, floa
   const bool tanh_pol = pf->cfg.tanh_action != 0;
   if (fused_ok && actor_fusable_mlp(a) && pf->enc[0].Kp <= 128) {
     if (actor_mlp2(a) && !tanh_pol)
-      return run_actor_mlp2(a, obs, eps, state_roll, acts_roll, values_roll, logp_roll, action, mean, stdv, ent, value, s);
-    if (pf->cfg.compute == V4L_BF16)
-      return run_actor_fused_mlp<__bf16>(a, obs, eps, state_roll, acts_roll, values_roll, logp_roll, action, mean, stdv, ent,
-                                         value, s);
-    return run_actor_fused_mlp<float>(a, obs, eps, state_roll, acts_roll, values_roll, logp_roll, action, mean, stdv, ent, value, s);
+      return by_half(pf->cfg.compute, [&](auto tag) -> int {
+        return run_actor_mlp2<typename decltype(tag)::type>(a, obs, eps, state_roll, acts_roll, values_roll, logp_roll, action, mean,
+                                                            stdv, ent, value, s);
+      });
+    return by_compute(pf->cfg.compute, [&](auto tag) -> int {
+      return run_actor_fused_mlp<typename decltype(tag)::type>(a, obs, eps, state_roll, acts_roll, values_roll, logp_roll, action,
+                                                               mean, stdv, ent, value, s);
+    });
   }
   if (fused_ok && actor_dense_cnn(a) && !tanh_pol)
-    return run_actor_dense_cnn(a, obs, eps, state_roll, image_roll, acts_roll, values_roll, logp_roll, action, mean, stdv, ent,
-                               value, s);
+    return by_half(pf->cfg.compute, [&](auto tag) -> int {
+      return run_actor_dense_cnn<typename decltype(tag)::type>(a, obs, eps, state_roll, image_roll, acts_roll, values_roll, logp_roll,
+                                                               action, mean, stdv, ent, value, s);
+    });
   if (fused_ok && actor_fusable_cnn(a) && pf->enc[0].Kp <= 128) {
-    if (pf->cfg.compute == V4L_BF16)
-      return run_actor_fused_cnn<__bf16>(a, obs, eps, state_roll, image_roll, acts_roll, values_roll, logp_roll, action, mean,
-                                         stdv, ent, value, s);
-    return run_actor_fused_cnn<float>(a, obs, eps, state_roll, image_roll, acts_roll, values_roll, logp_roll, action, mean, stdv,
-                                      ent, value, s);
+    return by_compute(pf->cfg.compute, [&](auto tag) -> int {
+      return run_actor_fused_cnn<typename decltype(tag)::type>(a, obs, eps, state_roll, image_roll, acts_roll, values_roll, logp_roll,
+                                                               action, mean, stdv, ent, value, s);
+    });
   }
   if (fused_ok && actor_fusable(a)) {
-    if (pf->cfg.compute == V4L_BF16)
-      return run_actor_fused<__bf16>(a, obs, eps, state_roll, image_roll, acts_roll, values_roll, logp_roll, action, mean,
-                                     stdv, ent, value, s);
-    return run_actor_fused<float>(a, obs, eps, state_roll, image_roll, acts_roll, values_roll, logp_roll, action, mean, stdv, ent,
-                                  value, s);
+    return by_compute(pf->cfg.compute, [&](auto tag) -> int {
+      return run_actor_fused<typename decltype(tag)::type>(a, obs, eps, state_roll, image_roll, acts_roll, values_roll, logp_roll,
+                                                           action, mean, stdv, ent, value, s);
+    });
   }
   // General step. The value net may continue from the POLICY's encoder output (stage 2 reads enc_ws + its OWN layout's offset of
   // the token tensor) only if both nets lay their workspaces out identically up to that tensor: token_norm, use_pytorch_encoder
@@ -3130,22 +3167,24 @@ static int run_actor_step(v4l_actor* a, const float* obs, const float* eps, floa
   const int S = pf->cfg.state_dim;
   const int img = pf->cfg.kind == V4L_NET_MLP ? 0 : pf->cfg.in_channels * pf->cfg.img_hw * pf->cfg.img_hw;
   g_op = "ingest";
-  if (pf->cfg.compute == V4L_BF16)
-    V4L_KLAUNCH("ingest", 0, s, ingest_kernel<__bf16>, dim3(E), dim3(256), 0, s, obs, E, S, pf->Sp, img, state_roll,
-                (__bf16*)image_roll, (int64_t)0, (const long long*)&a->ctl->t);
-  else
-    V4L_KLAUNCH("ingest", 0, s, ingest_kernel<float>, dim3(E), dim3(256), 0, s, obs, E, S, pf->Sp, img, state_roll,
-                (float*)image_roll, (int64_t)0, (const long long*)&a->ctl->t);
-  V4L_LAUNCH_CHECK();
+  if ((rc = by_compute(pf->cfg.compute, [&](auto tag) -> int {
+        typedef typename decltype(tag)::type T;
+        V4L_KLAUNCH("ingest", 0, s, ingest_kernel<T>, dim3(E), dim3(256), 0, s, obs, E, S, pf->Sp, img, state_roll, (T*)image_roll,
+                    (int64_t)0, (const long long*)&a->ctl->t);
+        V4L_LAUNCH_CHECK();
+        return 0;
+      })))
+    return rc;
   float* ws_pf = a->ws;
   float* ws_vf = a->ws + pf->layout(E).total;
   V4L_REQUIRE(pf->bound && vf->bound, "v4l_actor_step: nets are not bound");
   // policy encoder, then the two trunks side by side: the value net shares the encoder with the policy
   // (starter/ppo_locotransformer.py:79-100) and continues from the policy's token tensor on the aux stream
-  const bool bf = pf->cfg.compute == V4L_BF16;
   auto fwd = [&](v4l_net* net, float* ws, hipStream_t st, const float* enc, int stage) {
-    return bf ? net->forward_t<__bf16>(state_roll, (const __bf16*)image_roll, a->rowidx, E, ws, st, enc, stage)
-              : net->forward_t<float>(state_roll, (const float*)image_roll, a->rowidx, E, ws, st, enc, stage);
+    return by_compute(pf->cfg.compute, [&](auto tag) -> int {
+      typedef typename decltype(tag)::type T;
+      return net->forward_t<T>(state_roll, (const T*)image_roll, a->rowidx, E, ws, st, enc, stage);
+    });
   };
   const bool par = shared_encoder && a->aux != nullptr && !capturing(s);
   if (shared_encoder) {
@@ -3232,7 +3271,7 @@ static int actor_step_impl(v4l_actor* a, const float* obs_dev, const float* eps_
 // of run_actor_step)
 static bool actor_takes_split(const v4l_actor* a, int shared_encoder) {
   const v4l_net* pf = a->pf;
-  if (!shared_encoder || pf->cfg.tanh_action || pf->cfg.compute != V4L_BF16 || pf->cfg.kind == V4L_NET_MLP) return false;
+  if (!shared_encoder || pf->cfg.tanh_action || !is_half(pf->cfg.compute) || pf->cfg.kind == V4L_NET_MLP) return false;
   if (actor_dense_cnn(a)) return true;
   if (actor_fusable_cnn(a) && pf->enc[0].Kp <= 128) return false;  // the per-sample rollout_cnn_kernel reads fp32 rows
   if (!actor_fusable(a)) return false;
@@ -3360,17 +3399,19 @@ int v4l_trainer_critic_grads(v4l_trainer* tr, const v4l_rollout* ro, int n, cons
   // (no clearing of g_vf / g_pf: v4l_net_backward writes every element of the flat gradient — tests/test_gpu_parity.py
   // test_backward starts from a NaN-filled buffer)
   V4L_REQUIRE(vf->bound, "v4l_trainer_critic_grads: the critic net is not bound");
-  if (vf->cfg.compute == V4L_BF16)
-    V4L_KLAUNCH("begin_pack", 0, s, begin_pack_kernel<__bf16>, dim3((unsigned)vf->pack_blocks + 1), dim3(256), 0, s, tr->ctl, tr->rowidx_all, n,
-                tr->rowidx_cur, st, ro->advs_dev, vf->d_packs, (int)vf->packs.size(), (__bf16*)vf->packed);
-  else
-    V4L_KLAUNCH("begin_pack", 0, s, begin_pack_kernel<float>, dim3((unsigned)vf->pack_blocks + 1), dim3(256), 0, s, tr->ctl, tr->rowidx_all, n,
-                tr->rowidx_cur, st, ro->advs_dev, vf->d_packs, (int)vf->packs.size(), (float*)vf->packed);
-  V4L_LAUNCH_CHECK();
+  if ((rc = by_compute(vf->cfg.compute, [&](auto tag) -> int {
+        typedef typename decltype(tag)::type T;
+        V4L_KLAUNCH("begin_pack", 0, s, begin_pack_kernel<T>, dim3((unsigned)vf->pack_blocks + 1), dim3(256), 0, s, tr->ctl, tr->rowidx_all, n,
+                    tr->rowidx_cur, st, ro->advs_dev, vf->d_packs, (int)vf->packs.size(), (T*)vf->packed);
+        V4L_LAUNCH_CHECK();
+        return 0;
+      })))
+    return rc;
   { PhaseScope ps("vf.fwd");
   if ((rc = v4l_net_forward(vf, ro->state_dev, ro->image_dev, rowidx, n, tr->ws, 1, stream))) return rc; }
   const Layout L = vf->layout(n);
   const float inv_n = 1.f / ((float)n * (float)hp->world_size);
+  const float gscale = v4l_net_grad_scale(vf, n);
   g_op = "loss";
   {
     // The heads' data-grad chain as extra blocks of the loss launch (when the backward that follows is the wave-per-sample
@@ -3383,15 +3424,18 @@ int v4l_trainer_critic_grads(v4l_trainer* tr, const v4l_rollout* ro, int n, cons
     const bool ext = ext_critic && vf->heads_ext(tr->ws, n, &hc) != 0;
     const dim3 blk(n >= 512 ? 1024 : 256);
     if (ext) {
-      const bool bf = vf->cfg.compute == V4L_BF16, big = n >= 512;
+      const bool big = n >= 512;
 #define V4L_CL(T_, NW_) launch_critic_loss_heads<T_, NW_>(s, tr->ws + L.out, ro->rets_dev, ro->values_dev, rowidx, n, inv_n, \
-                                                          hp->clipped_value_loss, hp->clip_para, tr->ws + L.dout, st, hc)
-      rc = bf ? (big ? V4L_CL(__bf16, 16) : V4L_CL(__bf16, 4)) : (big ? V4L_CL(float, 16) : V4L_CL(float, 4));
+                                                          hp->clipped_value_loss, hp->clip_para, tr->ws + L.dout, st, hc, gscale)
+      rc = by_compute(vf->cfg.compute, [&](auto tag) -> int {
+        typedef typename decltype(tag)::type T;
+        return big ? V4L_CL(T, 16) : V4L_CL(T, 4);
+      });
 #undef V4L_CL
       if (rc) return rc;
     } else {
       V4L_KLAUNCH("critic_loss", 0, s, critic_loss_kernel, dim3(1), blk, 0, s, tr->ws + L.out, ro->rets_dev, ro->values_dev,
-                  rowidx, n, inv_n, hp->clipped_value_loss, hp->clip_para, tr->ws + L.dout, st);
+                  rowidx, n, inv_n, hp->clipped_value_loss, hp->clip_para, tr->ws + L.dout, st, gscale);
     }
   }
   V4L_LAUNCH_CHECK();
@@ -3480,13 +3524,16 @@ int v4l_trainer_actor_grads(v4l_trainer* tr, const v4l_rollout* ro, int n, const
     aa.n = n; aa.A = pf->cfg.out_dim; aa.inv_n = inv_n; aa.clip = hp->clip_para; aa.ent_coef = hp->entropy_coeff;
     aa.dmean = tr->ws + Lp.dout; aa.dlogstd = tr->g_pf + pf->params[pf->logstd].goff; aa.st = st;
     aa.tanh_action = pf->cfg.tanh_action;
+    aa.gscale = v4l_net_grad_scale(pf, n);
     RowsChain hc;
     const bool ext = !pf->cfg.tanh_action && pf->heads_ext(tr->ws, n, &hc) != 0;
     const dim3 blk(n >= 512 ? 1024 : 256);
     if (ext) {
-      const bool bf = pf->cfg.compute == V4L_BF16, big = n >= 512;
-      rc = bf ? (big ? launch_actor_loss_heads<__bf16, 16>(s, aa, hc) : launch_actor_loss_heads<__bf16, 4>(s, aa, hc))
-              : (big ? launch_actor_loss_heads<float, 16>(s, aa, hc) : launch_actor_loss_heads<float, 4>(s, aa, hc));
+      const bool big = n >= 512;
+      rc = by_compute(pf->cfg.compute, [&](auto tag) -> int {
+        typedef typename decltype(tag)::type T;
+        return big ? launch_actor_loss_heads<T, 16>(s, aa, hc) : launch_actor_loss_heads<T, 4>(s, aa, hc);
+      });
       if (rc) return rc;
     } else {
       if (aa.tanh_action) V4L_KLAUNCH("actor_loss", 0, s, actor_loss_kernel<true>, dim3(1), blk, 0, s, aa);

@@ -119,8 +119,8 @@ template <typename T> struct WpsBwdLds {
 template <typename T> __device__ __forceinline__ typename Frag<T>::type wps_frag(const float4& a, const float4& b) {
   typename Frag<T>::type f;
   if constexpr (sizeof(T) == 2) {
-    f[0] = (__bf16)a.x; f[1] = (__bf16)a.y; f[2] = (__bf16)a.z; f[3] = (__bf16)a.w;
-    f[4] = (__bf16)b.x; f[5] = (__bf16)b.y; f[6] = (__bf16)b.z; f[7] = (__bf16)b.w;
+    f[0] = (T)a.x; f[1] = (T)a.y; f[2] = (T)a.z; f[3] = (T)a.w;
+    f[4] = (T)b.x; f[5] = (T)b.y; f[6] = (T)b.z; f[7] = (T)b.w;
   } else {
     f.v[0] = a.x; f.v[1] = a.y; f.v[2] = a.z; f.v[3] = a.w; f.v[4] = b.x; f.v[5] = b.y; f.v[6] = b.z; f.v[7] = b.w;
   }
@@ -1092,9 +1092,10 @@ template <typename T, int NWAVES>
 __global__ __launch_bounds__(NWAVES * 64) void critic_loss_heads_kernel(const float* __restrict__ values, const float* __restrict__ ret,
                                                                 const float* __restrict__ oldv, const int* __restrict__ rowidx,
                                                                 int n, float inv_n, int clipped, float clip,
-                                                                float* __restrict__ dvalues, float* __restrict__ st, RowsChain hc) {
+                                                                float* __restrict__ dvalues, float* __restrict__ st, RowsChain hc,
+                                                                float gscale) {
   if (blockIdx.x == 0) {
-    critic_loss_body(values, ret, oldv, rowidx, n, inv_n, clipped, clip, dvalues, st);
+    critic_loss_body(values, ret, oldv, rowidx, n, inv_n, clipped, clip, dvalues, st, gscale);
     return;
   }
   constexpr int MT = RowsChainCfg<T>::MT;
@@ -1110,6 +1111,8 @@ __global__ __launch_bounds__(NWAVES * 64) void critic_loss_heads_kernel(const fl
         const int slot = rowidx ? rowidx[i] : i;
         float l;
         critic_row(values[(int64_t)i * OUT_LD], ret[slot], clipped ? oldv[slot] : 0.f, clipped, clip, inv_n, l, g);
+        int sat = 0;
+        g = grad_out(g, gscale, sat);
       }
       *reinterpret_cast<float4*>(dt + r * LY::LDX + c4) = float4{g, 0.f, 0.f, 0.f};
     }
@@ -1136,8 +1139,11 @@ __global__ __launch_bounds__(NWAVES * 64) void actor_loss_heads_kernel(ActorArgs
       const int i = r0 + tid, slot = p.rowidx ? p.rowidx[i] : i;
       const ActorRow o = actor_row<false>(p, D, i, slot, p.st[ST_ADV_MEAN], p.st[ST_ADV_STD]);
       float4* drow = reinterpret_cast<float4*>(dt + tid * LY::LDX);
-      drow[0] = float4{o.dlp * o.dm[0], o.dlp * o.dm[1], o.dlp * o.dm[2], o.dlp * o.dm[3]};
-      drow[1] = float4{o.dlp * o.dm[4], o.dlp * o.dm[5], o.dlp * o.dm[6], o.dlp * o.dm[7]};
+      float dmr[8];
+      int sat = 0;
+      actor_dmean_row(o, p.gscale, dmr, sat);
+      drow[0] = float4{dmr[0], dmr[1], dmr[2], dmr[3]};
+      drow[1] = float4{dmr[4], dmr[5], dmr[6], dmr[7]};
     }
     __syncthreads();
   });

@@ -10,18 +10,29 @@ import numpy as np
 import torch
 
 from . import _lib
-from ._lib import (V4L_BF16, V4L_F32, V4L_NET_CNN, V4L_NET_LOCO, V4L_NET_MLP, V4L_OUT_LD, V4L_STATS,
+from ._lib import (V4L_BF16, V4L_F16, V4L_F32, V4L_NET_CNN, V4L_NET_LOCO, V4L_NET_MLP, V4L_OUT_LD, V4L_STATS,
                    NetCfg, PPOHyper, Rollout, check)
 
 
 def default_compute():
-  """Contraction operand type: bf16 (production) unless V4L_COMPUTE=f32 selects the exact-fp32 parity mode."""
+  """Contraction operand type: V4L_COMPUTE = bf16 (default) | f16 (IEEE half operands: bf16's speed, 8 x closer to the fp32
+  reference; scaled backward, include/v4l_hip.h V4L_F16) | f32 (the exact-fp32 parity mode)."""
   v = os.environ.get("V4L_COMPUTE", "bf16").lower()
   if v in ("f32", "fp32", "float32"):
     return V4L_F32
   if v in ("bf16", "bfloat16"):
     return V4L_BF16
-  raise ValueError("V4L_COMPUTE must be 'bf16' or 'f32', got %r" % v)
+  if v in ("f16", "fp16", "float16", "half"):
+    return V4L_F16
+  raise ValueError("V4L_COMPUTE must be 'bf16', 'f16' or 'f32', got %r" % v)
+
+
+COMPUTE_NAMES = {V4L_F32: "f32", V4L_BF16: "bf16", V4L_F16: "f16"}
+
+
+def operand_dtype(compute):
+  """torch dtype of the contraction operands (and of the stored depth stacks) in a compute mode."""
+  return {V4L_F32: torch.float32, V4L_BF16: torch.bfloat16, V4L_F16: torch.float16}[compute]
 
 
 def _stream():
@@ -208,7 +219,12 @@ class HipNet:
     return ws
 
   def image_dtype(self):
-    return torch.bfloat16 if self.compute == V4L_BF16 else torch.float32
+    return operand_dtype(self.compute)
+
+  def grad_scale(self, n):
+    """What the d(out) rows of a backward pass over n rows must be multiplied by (1 unless compute == f16); the gradients come
+    out unscaled (include/v4l_hip.h v4l_net_grad_scale)."""
+    return float(self.L.v4l_net_grad_scale(self.h, int(n)))
 
   def alloc_rollout(self, slots, device):
     state = _buf(slots * self.Sp, torch.float32, device, zero=True).view(slots, self.Sp)
@@ -255,7 +271,8 @@ class HipNet:
     if ws is None:
       ws = self.workspace(n)
     off = self.ws_offset(n, "dout")
-    ws[off:off + n * V4L_OUT_LD].view(n, V4L_OUT_LD).copy_(dout)
+    gs = self.grad_scale(n)
+    ws[off:off + n * V4L_OUT_LD].view(n, V4L_OUT_LD).copy_(dout if gs == 1.0 else dout * gs)
     check(self.L.v4l_net_backward(self.h, _ptr(state), _ptr(image), _ptr(rowidx), n, _ptr(ws), _ptr(grads), _stream()),
           "v4l_net_backward")
 
@@ -636,7 +653,7 @@ class HipActor:
     """HBM landing buffers of the pipelined observation hand-over ([E][max(S,1)] float32, [E][C*H*W] bfloat16)."""
     if getattr(self, "_split_dev", None) is None:
       self._split_dev = (torch.empty(self.E, max(self.pf.state_dim, 1), dtype=torch.float32, device=self.device),
-                         torch.empty(self.E, self.pf.img_elems, dtype=torch.bfloat16, device=self.device))
+                         torch.empty(self.E, self.pf.img_elems, dtype=self.pf.image_dtype(), device=self.device))
     return self._split_dev
 
   def step_host_split(self, prop_pinned, img16_pinned, deterministic=False, via_copy=None, on_device=False):
@@ -654,13 +671,14 @@ class HipActor:
     # on_device: the caller already moved the rows into split_device_buffers() on this stream (the collector's pipelined
     # hand-over: cast a row chunk, start its DMA, cast the next chunk under it) — same kernels, reading HBM
     there = (lambda t: t.is_cuda) if on_device else (lambda t: t.is_pinned())
-    ok = (there(img16_pinned) and img16_pinned.dtype == torch.bfloat16 and img16_pinned.is_contiguous()
+    ok = (there(img16_pinned) and img16_pinned.dtype == self.pf.image_dtype() and img16_pinned.is_contiguous()
           and tuple(img16_pinned.shape) == (self.E, self.pf.img_elems))
     if S:
       ok = ok and (prop_pinned is not None and there(prop_pinned) and prop_pinned.dtype == torch.float32
                    and prop_pinned.is_contiguous() and tuple(prop_pinned.shape) == (self.E, max(S, 1) if on_device else S))
     if not ok:
-      raise RuntimeError("vision4leg_amd: step_host_split needs pinned, contiguous [E][S] float32 and [E][C*H*W] bfloat16 host tensors")
+      raise RuntimeError("vision4leg_amd: step_host_split needs pinned, contiguous [E][S] float32 and [E][C*H*W] %s host tensors"
+                         % str(self.pf.image_dtype()))
     if getattr(self, "_act_host", None) is None:
       self._act_host = torch.zeros(self.action.shape, dtype=torch.float32).pin_memory()
     self.pf.pack_if_needed(fast=True)

@@ -130,18 +130,18 @@ class VecOnPolicyCollector:
         return dev
 
     def _upload_split(self, rows):
-        """The fast path's observation hand-over in bf16 compute mode: numpy [E][S + C*H*W] float64 rows -> a pinned fp32
-        [E][S] proprio block and a pinned bfloat16 [E][C*H*W] depth block (double-buffered) that the rollout kernels read in
+        """The fast path's observation hand-over in the 16-bit compute modes: numpy [E][S + C*H*W] float64 rows -> a pinned fp32
+        [E][S] proprio block and a pinned bfloat16 / float16 [E][C*H*W] depth block (double-buffered) that the rollout kernels read in
         place (RolloutActor.step_host_split). The depth stack crosses PCIe in the type the kernels round it to at ingest anyway:
-        torch's float64 -> bfloat16 copy rounds through float32 (c10::BFloat16 is constructed from float), i.e. exactly
-        torch.Tensor(ob) (collector/on_policy.py:91) followed by the kernels' fp32 -> bf16 cast — asserted bit for bit in
-        tests/test_cpu.py::test_host_bf16_cast_is_the_two_step_rounding and tests/test_gpu_collector.py."""
+        torch's float64 -> bfloat16 / float16 copy rounds through float32 (c10::BFloat16 / c10::Half are constructed from float),
+        i.e. exactly torch.Tensor(ob) (collector/on_policy.py:91) followed by the kernels' fp32 -> operand-type cast — asserted bit
+        for bit in tests/test_cpu.py::test_host_16bit_cast_is_the_two_step_rounding and tests/test_gpu_collector.py."""
         rows = np.asarray(rows)
         S = self.pf.hip.state_dim
         E, D = rows.shape
         if self._split_pins is None or self._split_pins[0][1].shape != (E, D - S):
             mk = lambda: (torch.empty(E, S, dtype=torch.float32).pin_memory() if S else None,
-                          torch.empty(E, D - S, dtype=torch.bfloat16).pin_memory())
+                          torch.empty(E, D - S, dtype=self.pf.hip.image_dtype()).pin_memory())
             self._split_pins, self._split_i = [mk(), mk()], 0
         prop, img = self._split_pins[self._split_i]
         self._split_i ^= 1
