@@ -1,6 +1,6 @@
 """-m gpu: out-of-bounds WRITE check of the HIP path's device buffers (SURVEY.md §5 "sanitizers" row).
 
-Device-side AddressSanitizer cannot run on this GPU pool (the instrumented library — tools/asan_gpu_check.sh, 75 minutes at
+Device-side AddressSanitizer cannot run on this GPU pool (the instrumented library — 75 minutes of hipcc at
 -O1, a compiler error at -O0 — was built and taken to the box: the agent is gfx950:xnack- and the image has no ASAN build of the
 ROCm runtime, profiles/r4_gpu_asan.txt), so the suite checks what it can on the hardware: with V4L_GUARD=1 every buffer the library writes into (workspaces, control
 blocks, packed weights, descriptor tables, gradient buckets, Adam moments, rollout arrays, actor outputs) sits between two
