@@ -91,7 +91,7 @@ def parse(argv=None):
     ap.add_argument("--workload", default=None, choices=sorted(WORKLOADS),
                     help="default: by --gpus — 1, 2, 4 GPUs: loco (BASELINE configs[2] / [3]: 32 envs per GPU); 8 GPUs: loco64 "
                          "(configs[4]: 64 envs per GPU)")
-    ap.add_argument("--compute", default=os.environ.get("V4L_COMPUTE", "bf16"), choices=["bf16", "f16", "f32"])
+    ap.add_argument("--compute", default=os.environ.get("V4L_COMPUTE", "f16"), choices=["bf16", "f16", "f32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity", action="store_true", help="skip the oracle parity check, h2d and reference-protocol legs")
     ap.add_argument("--no-reference-protocol", action="store_true")

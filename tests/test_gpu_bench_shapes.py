@@ -160,6 +160,17 @@ def test_stacked_layer_launches_equal_one_launch_per_layer(mode, device):
     assert worst == 0.0, worst
 
 
+def _same_up_to_isolated_ties(a, b, mode, what):
+    """a, b: [rows][cols] outputs of two compilations of the same arithmetic. f32 / bf16: the same bits. f16: at most 1 % of the rows
+    may differ, by at most 1e-3 of the tensor's max-abs (a rounding tie of an 11-bit operand that an fp32 last bit decided)."""
+    if mode != "f16":
+        assert torch.equal(a, b), what
+        return
+    d = (a.double() - b.double()).abs()
+    rows = (d.reshape(d.shape[0], -1).sum(1) > 0).double().mean().item()
+    assert rows <= 0.01 and d.max().item() <= 1e-3 * b.abs().max().item(), (what, rows, d.max().item())
+
+
 WPS_TAPS_F32 = ["x1", "x2", "qkv0", "qkv1", "P0", "P1", "xh1_0", "xh1_1", "xh2_0", "xh2_1", "rs1_0", "rs1_1", "rs2_0", "rs2_1",
                 "pooled", "hh0", "hh1"]
 WPS_TAPS_T = ["xin0", "xin1", "ctx0", "ctx1", "mid0", "mid1", "ff0", "ff1"]
@@ -208,7 +219,11 @@ def test_vision_only_transformer_on_wave_per_sample_kernels(n, mode, device):
             os.environ.pop("V4L_LAYER_TAPS", None)
             os.environ.pop("V4L_VIS17", None)
     (oa, ga, xa), (ob, gb, _), (oc, gc, _), (on, gn, _) = res
-    assert torch.equal(oa, oc)  # the tapped instantiation is the same arithmetic (17 rows) compiled separately
+    # the tapped instantiation is the same arithmetic (17 rows) compiled separately: the same bits — except in f16, whose 11-bit
+    # operands meet an fp32 last-bit difference between two compilations (contraction of a*b+c) at a rounding tie 8 x as often as
+    # bf16's: measured at n = 1024, 2 rows of 1024 differ by 3e-4 of the output's max-abs (tools/probe/f16_taps_diff.py; each
+    # variant is deterministic run to run)
+    _same_up_to_isolated_ties(oa, oc, mode, "tapped vs untapped forward")
     for nm in ("dx0", "dx1"):                                                    # the dummy row carries no gradient
         assert torch.equal(xa[nm].view(n, 17, 64)[:, 0], torch.zeros(n, 64)), nm
     tag = "vis_wps/n%d/%s/" % (n, mode)
@@ -273,7 +288,7 @@ def test_wave_per_sample_layers_match_block_cooperative_kernels(n, mode, device)
                 rows, cols = shapes[key]
                 v = hip.ws_view(n, name, rows, cols)
                 if name in WPS_TAPS_T and mode != "f32":  # tensors kept in the operand type inside an fp32-sized slot
-                    v = v.reshape(-1).view(torch.bfloat16)[:rows * cols].view(rows, cols)
+                    v = v.reshape(-1).view(torch.float16 if mode == "f16" else torch.bfloat16)[:rows * cols].view(rows, cols)
                 taps[name] = v.float().cpu().clone()
             dout = torch.zeros(n, 16, dtype=torch.float32, device=device)
             dout[:, :1] = w.to(device)
@@ -286,8 +301,13 @@ def test_wave_per_sample_layers_match_block_cooperative_kernels(n, mode, device)
             os.environ.pop("V4L_NO_WPS_LAYERS", None)
             os.environ.pop("V4L_LAYER_TAPS", None)
     (ta, ga), (tb, gb), (tc, gc) = res
-    # the shipped configuration (no taps) runs the very same arithmetic as the tapped one: bit-identical results
-    assert torch.equal(tc["out"], ta["out"]) and torch.equal(gc, ga)
+    # the shipped configuration (no taps) runs the very same arithmetic as the tapped one: bit-identical results (f16: up to
+    # isolated rounding ties, see _same_up_to_isolated_ties)
+    _same_up_to_isolated_ties(tc["out"].view(n, 1), ta["out"].view(n, 1), mode, "tapped vs untapped forward")
+    if mode == "f16":
+        assert util.rel_err(gc, ga) <= 1e-3, util.rel_err(gc, ga)
+    else:
+        assert torch.equal(gc, ga)
     worst = {}
     for name in ta:
         a, b = ta[name].double(), tb[name].double()

@@ -19,7 +19,7 @@ pytestmark = pytest.mark.gpu
 CKPT = os.path.join(util.GOLDEN, "ckpt")
 # f32: the north star's gate with margin; bf16: the fixed fp32-reference distance of tests/test_gpu_parity.py (bf16 operands
 # against an fp32 computation: ~4e-3 by construction)
-TOL = {"f32": 2e-4, "bf16": 2e-2}
+TOL = {"f32": 2e-4, "bf16": 2e-2, "f16": 4e-3}
 
 
 def _build(case, mode, dev, seed):
@@ -31,7 +31,7 @@ def _build(case, mode, dev, seed):
     return pf.to(dev), vf.to(dev)
 
 
-@pytest.mark.parametrize("mode", ["f32", "bf16"])
+@pytest.mark.parametrize("mode", ["f32", "bf16", "f16"])
 @pytest.mark.parametrize("name", ["loco_s84", "mlp_s93"])
 def test_reference_checkpoint_loads_into_hip_modules(name, mode, device):
     case = util.CASES[name]

@@ -64,7 +64,7 @@ def _run(which, case, mode, device, E, T, B, epochs, max_episode_frames):
     return snaps, log.infos, params, np.stack(env.log)
 
 
-@pytest.mark.parametrize("mode", ["f32", "bf16"])
+@pytest.mark.parametrize("mode", ["f32", "bf16", "f16"])
 @pytest.mark.parametrize("name", ["loco_s84", "mlp_s93"])
 def test_fast_collector_equals_reference_protocol(name, mode, device):
     case = util.CASES[name]
@@ -174,13 +174,15 @@ def test_lost_handover_is_never_silent(name, device):
     assert torch.equal(again, good)
 
 
+@pytest.mark.parametrize("mode", ["bf16", "f16"])
 @pytest.mark.parametrize("name", ["loco_s84", "cnn_s93", "mlp_s93", "loco_vis"])
-def test_step_host_equals_step(name, device):
+def test_step_host_equals_step(name, mode, device):
     """HipActor.step_host — the fast collector's per-step call: the rollout kernels read the pinned host observation rows in
     place and write the action into pinned host memory — must give bit for bit what step() gives on the same rows in HBM:
     the action and the filed action / value / log pi_old, with per-step draws, with draw_noise() slices, and after attach()
     swapped the rollout arrays."""
-    os.environ["V4L_COMPUTE"] = "bf16"
+    os.environ["V4L_COMPUTE"] = mode
+    dt16 = torch.float16 if mode == "f16" else torch.bfloat16
     import vision4leg_amd.torchrl.networks as networks
     import vision4leg_amd.torchrl.policies as policies
     case = util.CASES[name]
@@ -219,14 +221,14 @@ def test_step_host_equals_step(name, device):
                 dprop, dimg = actor.split_device_buffers()
                 if S:
                     dprop.copy_(torch.from_numpy(rows[t][:, :S].copy()).pin_memory(), non_blocking=True)
-                img16 = torch.from_numpy(rows[t][:, S:].copy()).to(torch.bfloat16).pin_memory()
+                img16 = torch.from_numpy(rows[t][:, S:].copy()).to(dt16).pin_memory()
                 for a0 in range(0, E, 3):  # ragged chunks on purpose (3 + 1 rows)
                     dimg[a0:a0 + 3].copy_(img16[a0:a0 + 3], non_blocking=True)
                 acts.append(np.array(actor.step_host_split(dprop if S else None, dimg, on_device=True), copy=True))
             elif host in ("split", "split_copy"):
                 S = case["S"]
                 prop = torch.from_numpy(rows[t][:, :S].copy()).pin_memory() if S else None
-                img16 = torch.from_numpy(rows[t][:, S:].copy()).to(torch.bfloat16).pin_memory()
+                img16 = torch.from_numpy(rows[t][:, S:].copy()).to(dt16).pin_memory()
                 acts.append(np.array(actor._actor.step_host_split(prop, img16, via_copy=(host == "split_copy")), copy=True))
             elif host:
                 pinned.copy_(torch.from_numpy(rows[t]))

@@ -96,7 +96,7 @@ def _worker(rank, world, port, out, mode, name):
 
 
 @pytest.mark.timeout(900)
-@pytest.mark.parametrize("mode", ["f32", "bf16"])
+@pytest.mark.parametrize("mode", ["f32", "bf16", "f16"])
 @pytest.mark.parametrize("name", ["loco_s84"])
 def test_two_processes_one_gpu_equal_one_big_batch(name, mode, device, tmp_path):
     import torch.multiprocessing as mp

@@ -35,7 +35,7 @@ def test_no_kernel_writes_outside_its_buffers(device, monkeypatch):
     monkeypatch.setenv("V4L_GUARD", "1")
     engine.check_guards(reset=True)
     ran = []
-    for mode in ("bf16", "f32"):
+    for mode in ("bf16", "f16", "f32"):
         # PPO updates: small, ragged (300 = 256 + 44), B = 1024 with graph replays; every net kind once
         for name, n_upd in (("loco_s84", 2), ("loco_rag", 1), ("loco_b1024", 3), ("cnn_s93", 2), ("mlp_s93", 2), ("loco_vis", 1),
                             ("cnn_vis", 1), ("loco_gen", 1), ("loco_max", 1), ("loco_tn", 1), ("loco_pe", 1)):

@@ -194,7 +194,7 @@ def _gain(hist):
 def test_bf16_training_learns_like_fp32(device, tmp_path):
     t0 = time.time()
     runs = {}
-    for tag, mode, seed in (("f32_a", "f32", 1), ("f32_b", "f32", 2), ("bf16", "bf16", 1)):
+    for tag, mode, seed in (("f32_a", "f32", 1), ("f32_b", "f32", 2), ("bf16", "bf16", 1), ("f16", "f16", 1)):
         hist, agent, log = hip_run(mode, device, seed, tmp_path)
         n_upd = EPOCHS * OPT_EPOCHS * (E * T // B)
         # bookkeeping: update counters, Adam steps, LR schedule (algo/utils.py:28-32), 18 finite infos per update
@@ -227,3 +227,4 @@ def test_bf16_training_learns_like_fp32(device, tmp_path):
     tol = 3.0 * band + 0.15 * abs(ref)
     assert abs(gains["bf16"] - ref) <= tol and abs(gains["f32_a"] - ref) <= tol, (gains, band)
     assert abs(gains["bf16"] - gains["f32_a"]) <= tol, (gains, band)
+    assert abs(gains["f16"] - ref) <= tol and abs(gains["f16"] - gains["f32_a"]) <= tol, (gains, band)

@@ -15,9 +15,10 @@ from ._lib import (V4L_BF16, V4L_F16, V4L_F32, V4L_NET_CNN, V4L_NET_LOCO, V4L_NE
 
 
 def default_compute():
-  """Contraction operand type: V4L_COMPUTE = bf16 (default) | f16 (IEEE half operands: bf16's speed, 8 x closer to the fp32
-  reference; scaled backward, include/v4l_hip.h V4L_F16) | f32 (the exact-fp32 parity mode)."""
-  v = os.environ.get("V4L_COMPUTE", "bf16").lower()
+  """Contraction operand type: V4L_COMPUTE = f16 (default since round 6: IEEE half operands — bf16's speed, 8 x closer to the
+  fp32 reference; scaled backward, include/v4l_hip.h V4L_F16) | bf16 (8 exponent bits: for observations / activations that
+  can exceed half's 65 504) | f32 (the exact-fp32 parity mode)."""
+  v = os.environ.get("V4L_COMPUTE", "f16").lower()
   if v in ("f32", "fp32", "float32"):
     return V4L_F32
   if v in ("bf16", "bfloat16"):

@@ -347,8 +347,22 @@ class PPO:
             raise FloatingPointError("vision4leg_amd: non-finite training statistics in minibatch update %d of epoch %d: %s"
                                      % (int(bad[0]), self.current_epoch,
                                         {k: float(host[bad[0], j]) for j, k in enumerate(_lib.STAT_KEYS)}))
+        self._note_f16_saturation(float(host[:, _lib.ST_F16_SAT].sum()))
         for row in host:
             self.logger.add_update_info({k: float(row[j]) for j, k in enumerate(_lib.STAT_KEYS)})
+
+    f16_saturated = 0.0  # V4L_COMPUTE=f16: loss-gradient elements clamped at +-V4L_F16_GRAD_CLAMP so far (include/v4l_hip.h, record slot 23)
+
+    def _note_f16_saturation(self, count):
+        """f16 compute mode: the loss-gradient rows enter the backward scaled by a power of two and clamped inside half's range.
+        A clamped element is a per-sample gradient clip the reference does not have: counted, and reported once."""
+        if count > 0:
+            if self.f16_saturated == 0:
+                import warnings
+                warnings.warn("vision4leg_amd: %d loss-gradient element(s) of an f16 update exceeded +-%g after scaling and were "
+                              "clamped (record slot %d; PPO.f16_saturated keeps the total). Returns / advantages of that size "
+                              "want V4L_COMPUTE=bf16." % (int(count), 32768.0, _lib.ST_F16_SAT), RuntimeWarning)
+            self.f16_saturated += count
 
     def run_updates(self, ro, rowidx, stats):
         """All minibatch updates of an epoch: rowidx [U][n] int32 (device), stats [U][V4L_STATS] (device).
@@ -423,6 +437,7 @@ class PPO:
         if host[_lib.ST_NONFINITE] > 0:  # the device-side tripwire, as in _update_epoch_resident
             raise FloatingPointError("vision4leg_amd: non-finite training statistics in minibatch update %d: %s"
                                      % (self.training_update_num, {k: float(host[j]) for j, k in enumerate(_lib.STAT_KEYS)}))
+        self._note_f16_saturation(float(host[_lib.ST_F16_SAT]))
         return {k: float(host[j]) for j, k in enumerate(_lib.STAT_KEYS)}
 
     # ---- outer loop (rl_algo.py:97-168) ----------------------------------------------------------------
