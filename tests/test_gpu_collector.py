@@ -249,3 +249,47 @@ def test_step_host_equals_step(name, mode, device):
             assert np.array_equal(a_dev, a_split), how
             for x, y in list(zip(filed_dev, filed_split)) + list(zip(first_dev, first_split)):
                 assert (x is None and y is None) or torch.equal(x, y), how
+
+
+@pytest.mark.parametrize("name,mode", [("mlp_s93", "f32"), ("mlp_tanh", "bf16"), ("cnn_s93", "f32")])
+def test_step_host_returns_only_when_the_observation_buffer_is_free(name, mode, device):
+    """step_host reads the caller's pinned observation rows in place. The one-launch step kernels (rollout_mlp_kernel<T> /
+    rollout_cnn_kernel, grid (E, 2)) run policy and value blocks side by side, and with more blocks than the chip holds at once
+    (E = 1024: 2048 blocks of 1024 threads on 256 CUs) the value blocks are dispatched after the policy blocks: a host that only
+    watched the ACTION arrive could overwrite rows the value blocks had not read yet (round-5 advisor finding). The call now
+    returns when action and value of every env have arrived. Here ONE pinned buffer is reused and poisoned right after every
+    call; the filed values must equal what step() files from the same rows in HBM."""
+    os.environ["V4L_COMPUTE"] = mode
+    import vision4leg_amd.torchrl.networks as networks
+    import vision4leg_amd.torchrl.policies as policies
+    case = util.CASES[name]
+    E, T, A = (1024 if case["kind"].startswith("mlp") else 384), 3, case["A"]
+    torch.manual_seed(case["seed"])
+    pf, vf = util.build_nets(networks, policies, case)
+    pf, vf = pf.to(device), vf.to(device)
+    rs = np.random.RandomState(5)
+    rows = [util.obs_rows(rs, E, case).astype(np.float32) for _ in range(T)]
+
+    def arrays():
+        st, im = pf.hip.alloc_rollout(T * E, device)
+        return st, im, torch.zeros(T * E, A, device=device), torch.zeros(T * E, device=device), torch.zeros(T * E, device=device)
+
+    def run(host):
+        actor = policies.RolloutActor(pf, vf, E)
+        arr = arrays()
+        actor.attach(arr)
+        actor.seek(0)
+        pinned = torch.zeros(E, util.obs_dim(case), dtype=torch.float32).pin_memory()
+        for t in range(T):
+            if host:
+                pinned.copy_(torch.from_numpy(rows[t]))
+                actor.step_host(pinned, deterministic=True)
+                pinned.fill_(float("nan"))  # the buffer is the caller's again the moment step_host returns
+            else:
+                actor.step(torch.from_numpy(rows[t]).to(device), deterministic=True)
+        torch.cuda.synchronize()
+        return [a.cpu().clone() if a is not None else None for a in arr]
+    dev_arr, host_arr = run(False), run(True)
+    assert torch.isfinite(host_arr[3]).all() and torch.isfinite(host_arr[2]).all()
+    for x, y in zip(dev_arr, host_arr):
+        assert (x is None and y is None) or torch.equal(x, y)

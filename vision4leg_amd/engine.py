@@ -5,6 +5,7 @@ current HIP stream; all arithmetic is enqueued through the C ABI. Nothing here f
 """
 import ctypes as C
 import os
+import time
 
 import numpy as np
 import torch
@@ -588,17 +589,19 @@ class HipActor:
   def step_host(self, obs_pinned, deterministic=False):
     """The collector's per-step call without any copy of its own: `obs_pinned` is a PINNED host float32 tensor
     [E][S+C*H*W] that the rollout kernels read in place over PCIe (pinned host memory is mapped into the device's address
-    space), and the action lands in a pinned host buffer the same way. One launch pair + one stream synchronise; returns the
+    space), and the action AND the value land in pinned host buffers the same way. One launch pair; the call returns when both
+    outputs of every env have arrived (no stream synchronise unless polling is off / times out), i.e. when every block that
+    reads `obs_pinned` has finished: the caller may overwrite the observation buffer as soon as this returns. Returns the
     [E][A] action as a numpy view of that buffer (valid until the next step). Eager launches only."""
     if self.graph:
       raise RuntimeError("vision4leg_amd: step_host drives eager launches (construct the actor with graph=False)")
     if (not obs_pinned.is_pinned() or obs_pinned.dtype != torch.float32 or not obs_pinned.is_contiguous()
         or obs_pinned.numel() != self.obs.numel()):
       raise RuntimeError("vision4leg_amd: step_host needs a pinned, contiguous float32 [E][S+C*H*W] host tensor")
-    if getattr(self, "_act_host", None) is None:
-      self._act_host = torch.zeros(self.action.shape, dtype=torch.float32).pin_memory()
+    self._host_outputs()
     if getattr(self, "_args_host_of", None) is not self._args:  # first call, or attach() rebuilt the argument tuple
-      self._args_host = self._args[:7] + (C.c_void_p(self._act_host.data_ptr()),) + self._args[8:]
+      self._args_host = (self._args[:7] + (C.c_void_p(self._act_host.data_ptr()),) + self._args[8:11]
+                         + (C.c_void_p(self._val_host.data_ptr()),) + self._args[12:])
       self._args_host_of = self._args
     self.pf.pack_if_needed(fast=True)
     self.vf.pack_if_needed(fast=True)
@@ -621,27 +624,41 @@ class HipActor:
     check(self.L.v4l_actor_step(self.h, *args, _stream()), "v4l_actor_step")
     return self._await_action()
 
-  # ---- completion of a host step: the policy blocks write the [E][A] action straight into pinned host memory, so the host can
-  # watch the action ARRIVE instead of asking the runtime for a stream synchronise (whose wake-up costs 20-50 us on ROCm 7.2:
-  # tools/probe/collector_pipe.py). The buffer is armed with NaN before the launch; the step is complete for the host when no NaN
-  # is left. A policy that really produces NaN never disarms it: after POLL_SPINS looks the call falls back to the synchronise and
-  # returns what is there (the collector's non-finite check then raises, as it always did). V4L_STEP_POLL=0: always synchronise.
-  POLL_SPINS = 4000
+  # ---- completion of a host step: the policy blocks write the [E][A] action and the value blocks the [E] value straight into
+  # pinned host memory, so the host can watch them ARRIVE instead of asking the runtime for a stream synchronise (whose wake-up
+  # costs 20-50 us on ROCm 7.2: tools/probe/collector_pipe.py). Both buffers are armed with NaN before the launch; the step is
+  # complete for the host when no NaN is left in EITHER — every (env, net) block writes its output last, after it has read its
+  # observation row, so at that point no block of the step still reads the caller's pinned observation buffer (the one-launch
+  # state-MLP / NatureCNN step kernels run policy and value blocks side by side: watching the action alone would not cover the
+  # value blocks' reads; round 6, advisor finding). A net that really produces NaN never disarms its buffer: after POLL_SECONDS
+  # of wall time the call falls back to the synchronise and returns what is there (the collector's non-finite check then raises,
+  # as it always did). V4L_STEP_POLL=0 (read when the actor takes its first host step): always synchronise.
+  POLL_SECONDS = 200e-6
+
+  def _host_outputs(self):
+    if getattr(self, "_act_host", None) is None:
+      self._act_host = torch.zeros(self.action.shape, dtype=torch.float32).pin_memory()
+      self._val_host = torch.zeros(self.value.shape, dtype=torch.float32).pin_memory()
 
   def _arm_action(self):
     if getattr(self, "_act_np", None) is None or self._act_np_of is not self._act_host:
-      self._act_np, self._act_np_of = self._act_host.numpy(), self._act_host
+      self._act_np, self._val_np, self._act_np_of = self._act_host.numpy(), self._val_host.numpy(), self._act_host
       self._poll = os.environ.get("V4L_STEP_POLL", "1") != "0"
     if self._poll:
       self._act_np.fill(np.nan)
+      self._val_np.fill(np.nan)
 
   def _await_action(self):
-    a = self._act_np
+    a, v = self._act_np, self._val_np
     if self._poll:
-      isnan = np.isnan
-      for _ in range(self.POLL_SPINS):
-        if not isnan(a).any():
+      isnan, now = np.isnan, time.perf_counter
+      t_end = now() + self.POLL_SECONDS
+      while True:
+        # (the value is looked at only once the action is there: one small array per look while waiting)
+        if not isnan(a).any() and not isnan(v).any():
           return a
+        if now() > t_end:
+          break
     torch.cuda.current_stream(self.device).synchronize()
     return a
 
@@ -680,8 +697,7 @@ class HipActor:
     if not ok:
       raise RuntimeError("vision4leg_amd: step_host_split needs pinned, contiguous [E][S] float32 and [E][C*H*W] %s host tensors"
                          % str(self.pf.image_dtype()))
-    if getattr(self, "_act_host", None) is None:
-      self._act_host = torch.zeros(self.action.shape, dtype=torch.float32).pin_memory()
+    self._host_outputs()
     self.pf.pack_if_needed(fast=True)
     self.vf.pack_if_needed(fast=True)
     a = self._args  # (obs, eps, st, im, acts, vals, logp, action, mean, std, ent, value, shared_encoder, graph)
@@ -711,7 +727,7 @@ class HipActor:
     self._arm_action()
     check(self.L.v4l_actor_step_split(self.h, C.c_void_p(prop_pinned.data_ptr() if S else 0), C.c_void_p(img16_pinned.data_ptr()),
                                       eps, a[2], a[3], a[4], a[5], a[6], C.c_void_p(self._act_host.data_ptr()), a[8], a[9], a[10],
-                                      a[11], a[12], _stream()), "v4l_actor_step_split")
+                                      C.c_void_p(self._val_host.data_ptr()), a[12], _stream()), "v4l_actor_step_split")
     return self._await_action()
 
   def _step(self, obs, deterministic=False):

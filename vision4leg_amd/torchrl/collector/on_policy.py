@@ -124,7 +124,8 @@ class VecOnPolicyCollector:
         else:
             np.copyto(host.numpy(), rows, casting="same_kind")
         if host_only:
-            return host  # (the caller synchronises the stream before the next step: the buffer is free again by then)
+            return host  # (step_host returns once every block that reads these rows has written its output — action AND value
+            # have arrived — and the staging is double-buffered on top of that: the buffer is free again by the step after next)
         dev.copy_(host, non_blocking=True)
         ev.record()
         return dev
