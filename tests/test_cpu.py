@@ -260,6 +260,19 @@ def test_device_identity_ignores_visibility_strings_when_the_gpu_is_identified(m
     props.pci_bus_id = 6
     props.uuid = "GPU-87654321-abcd"
     assert ppo.device_identity(torch.device("cuda", 0)) != a
+    # partitions of one GPU reporting the SAME uuid and bus id (CPX / SR-IOV guests): the physical index tells them apart ...
+    same = types.SimpleNamespace(uuid="GPU-00000000-0000", pci_domain_id=0, pci_bus_id=5, pci_device_id=0)
+    monkeypatch.setattr(torch.cuda, "get_device_properties", lambda d: same)
+    monkeypatch.setenv("HIP_VISIBLE_DEVICES", "0,1")
+    p0, p1 = ppo.device_identity(torch.device("cuda", 0)), ppo.device_identity(torch.device("cuda", 1))
+    assert p0 != p1
+    # ... and it is the index the visibility strings RESOLVE to, through both layers: "1" reaches what "0,1"[1] reaches
+    monkeypatch.setenv("HIP_VISIBLE_DEVICES", "1")
+    assert ppo.device_identity(torch.device("cuda", 0)) == p1
+    monkeypatch.setenv("ROCR_VISIBLE_DEVICES", "2,3")
+    assert ppo.physical_device_index(torch.device("cuda", 0)) == 3
+    assert ppo.physical_device_index(torch.device("cuda", 0), {"HIP_VISIBLE_DEVICES": "GPU-abc,GPU-def"}) == "GPU-abc"
+    monkeypatch.delenv("ROCR_VISIBLE_DEVICES")
     anon = types.SimpleNamespace()
     monkeypatch.setattr(torch.cuda, "get_device_properties", lambda d: anon)
     b0 = ppo.device_identity(torch.device("cuda", 0))

@@ -22,7 +22,7 @@ class _Log:
         self.infos.append(dict(info))
 
 
-def _run(which, case, mode, device, E, T, B, epochs, max_episode_frames):
+def _run(which, case, mode, device, E, T, B, epochs, max_episode_frames, gae=True):
     os.environ["V4L_COMPUTE"] = mode
     import vision4leg_amd.torchrl.networks as networks
     import vision4leg_amd.torchrl.policies as policies
@@ -46,7 +46,7 @@ def _run(which, case, mode, device, E, T, B, epochs, max_episode_frames):
         coll.epoch_frames = E * T
     log = _Log()
     agent = PPO(pf=pf, vf=vf, plr=1e-4, vlr=1e-4, clip_para=0.2, opt_epochs=2, tau=0.95, entropy_coeff=0.005, shuffle=True,
-                collector=coll, replay_buffer=buf, logger=log, device=device, discount=0.99, num_epochs=100, batch_size=B)
+                collector=coll, replay_buffer=buf, logger=log, device=device, discount=0.99, num_epochs=100, batch_size=B, gae=gae)
     snaps = []
     for ep in range(epochs):
         agent.current_epoch = ep
@@ -61,6 +61,8 @@ def _run(which, case, mode, device, E, T, B, epochs, max_episode_frames):
                           advs=np.array(buf._advs).copy(), rets=np.array(buf._estimate_returns).copy(),
                           epoch_reward=out["train_epoch_reward"], train_rewards=list(out["train_rewards"])))
     params = {k: v.detach().cpu().clone() for k, v in pf.state_dict().items()}
+    if which == "fast" and not gae:  # the filed epoch's discounted rewards were computed where the values are (the host path never sets this)
+        assert "_advs_dev64" in buf.__dict__
     return snaps, log.infos, params, np.stack(env.log)
 
 
@@ -95,6 +97,19 @@ def test_fast_collector_equals_reference_protocol(name, mode, device):
     drift = sum((fast[2][k] - ref[2][k]).abs().sum().item() for k in ref[2]) / sum(v.numel() for v in ref[2].values())
     util.record("collector/%s/%s/mean_abs_param_diff_after_2_epochs" % (name, mode), drift)
     assert drift <= (5e-7 if mode == "f32" else 5e-5), drift
+
+
+def test_fast_collector_discounted_rewards_stay_on_device(device):
+    """PPO(gae=False) (replay_buffers/on_policy.py:47-71) behind the fast collector: DeviceOnPolicyReplayBuffer.discount_reward of a
+    filed epoch reads the fp32 values where the rollout kernels filed them (round-5 advisor finding: it fell back to the host path);
+    advantages / returns as the reference protocol's, to the values' own agreement."""
+    case = util.CASES["mlp_s93"]
+    E, T, B = 4, 8, 16
+    fast = _run("fast", case, "f32", device, E, T, B, 2, 3, gae=False)
+    ref = _run("ref", case, "f32", device, E, T, B, 2, 3, gae=False)
+    for a, b in zip(fast[0], ref[0]):
+        for k in ("advs", "rets"):
+            assert a[k].shape == b[k].shape and np.abs(a[k] - b[k]).max() <= 2e-4 * max(1.0, np.abs(b[k]).max()), k
 
 
 def test_fast_collector_eval_and_uploads(device):

@@ -90,7 +90,8 @@ struct v4l_net {
   // c1 / c2 of the training forward in the operand type (round 5): asked for by v4l_net_forward(train = 1) — the trainer's and
   // the tests' forward / backward pairs —, granted by forward_t when the persistent training encoder writes them and the fused
   // conv backward will read them (bf16, shipped conv geometry, no test taps), remembered for the backward of the same pass
-  bool want_acts16 = false, acts16_written = false;
+  bool want_acts16 = false;
+  const float* acts16_c1 = nullptr;  // the c1 slot (= the workspace) whose c1 / c2 currently hold the operand type; null: none
   bool vis_only() const { return cfg.kind == V4L_NET_CNN_VIS || cfg.kind == V4L_NET_LOCO_VIS; }
   bool is_tf() const { return cfg.kind == V4L_NET_LOCO || cfg.kind == V4L_NET_LOCO_VIS; }
   std::vector<v4l::ParamInfo> params;

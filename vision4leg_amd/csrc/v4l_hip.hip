@@ -604,7 +604,9 @@ static int conv_stack_bwd_fused(Ctx& c, const T* image, const int* rowidx, int n
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)BwdConvLds<T>::bytes));
     attr_done = true;
   }
-  const bool a16 = sizeof(T) == 2 && N->acts16_written;  // c1 / c2 in T (what this pass's training encoder wrote)
+  // c1 / c2 in T: what the training encoder of THIS workspace's last forward wrote (the mark is the workspace's c1 address, so a
+  // forward of the same net over another workspace in between — HipNet.value() at another batch size — does not change it)
+  const bool a16 = sizeof(T) == 2 && N->acts16_c1 != nullptr && N->acts16_c1 == c1;
   int nblk = std::min(n, CONV_BWD_MAX_BLOCKS);
   if (const char* e = getenv("V4L_CONV_BWD_BLOCKS")) nblk = std::max(1, std::min(nblk, atoi(e)));
   // dW3's launch runs beside the dense weight-grads on the other stream: fewer, fatter blocks cut its partial slabs (147 KB
@@ -1250,6 +1252,8 @@ int v4l_net::forward_t(const float* state, const T* image, const int* rowidx, in
   Act eacts[V4L_MAX_HIDDEN];
   for (int i = 0; i < ne; ++i) eacts[i] = Act{ws + L.eh[i], c.enc_hidden[i], c.enc_hidden[i]};
   ADense head_in;
+  // an encoder pass over this workspace rewrites its c1 / c2: whatever type they held is gone (train_enc marks it again)
+  if (enc_ws == nullptr && stage != 2 && c.kind != V4L_NET_MLP && acts16_c1 == ws + L.c1) acts16_c1 = nullptr;
   // persistent 16-wave encoder blocks (csrc/infer.h train_encoder_kernel<MODE>): conv weights enter a CU once, not once per
   // sample; saves c1 / c2 / c3 (what the conv backward reads) and, with a proprio branch, the two MLP activations
   const bool mlp256 = ne == 2 && c.enc_hidden[0] == 256 && c.enc_hidden[1] == 256 && c.state_dim <= 128;
@@ -1282,7 +1286,7 @@ int v4l_net::forward_t(const float* state, const T* image, const int* rowidx, in
     te.n = n; te.nmlp = prop ? cdiv(n, 32) : 0;
     // (V4L_ACTS_F32: keep c1 / c2 in fp32 — the cross-check of tests/test_gpu_parity.py::test_conv_acts_in_operand_type_same_bits)
     te.acts16 = want_acts16 && conv_bwd_fusable(this) && !sw_on("V4L_LAYER_TAPS") && !sw_on("V4L_ACTS_F32");
-    acts16_written = te.acts16 != 0;
+    if (te.acts16) acts16_c1 = te.s_c1;
     constexpr int cus = 256;
     // the conv share never collapses: a very large minibatch (n >~ 8 K: nmlp -> cus) still gets half the CUs' worth of
     // persistent conv blocks (the MLP blocks are short; the two kinds then simply run in two waves over the chip)
@@ -2871,7 +2875,6 @@ int v4l_net_forward(v4l_net* net, const float* state_dev, const void* image_dev,
   V4L_REQUIRE(net->cfg.kind == V4L_NET_MLP || image_dev != nullptr, "v4l_net_forward: image_dev is null");
   // train: a v4l_net_backward over this workspace follows — the conv activations it reads may then be saved in the operand type
   net->want_acts16 = train != 0;
-  net->acts16_written = false;
   const int rc = by_compute(net->cfg.compute, [&](auto tag) -> int {
     typedef typename decltype(tag)::type T;
     return net->forward_t<T>(state_dev, (const T*)image_dev, rowidx_dev, n, ws_dev, (hipStream_t)stream);

@@ -71,19 +71,38 @@ def exchange_comm_id(dist, device, available, unique_id, id_bytes=_lib.V4L_COMM_
     return bytes(idt.cpu().numpy().tobytes())
 
 
+def physical_device_index(device, environ=None):
+    """The logical device index resolved through the visibility strings (HIP_ / CUDA_VISIBLE_DEVICES select among what
+    ROCR_VISIBLE_DEVICES left): '0' and '0,1' both give 0 for logical device 0; an entry that is not a number (a uuid) is kept
+    as it is. The tie-breaker of device_identity for runtimes that report one uuid / bus id for several partitions of a GPU."""
+    env = os.environ if environ is None else environ
+    idx = torch.device(device).index
+    if idx is None:
+        idx = torch.cuda.current_device() if torch.cuda.is_available() else 0
+    for name in (("HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"), ("ROCR_VISIBLE_DEVICES",)):
+        val = next((env.get(n) for n in name if env.get(n)), None)
+        if val is None or not isinstance(idx, int):
+            continue
+        entries = [e.strip() for e in val.split(",")]
+        if idx < len(entries):
+            idx = int(entries[idx]) if entries[idx].lstrip("-").isdigit() else entries[idx]
+    return idx
+
+
 def device_identity(device):
     """A 63-bit fingerprint of (host, physical GPU) — equal on two ranks exactly when they drive the same device. Where the
-    runtime reports a uuid or PCI ids, ONLY (hostname, uuid, PCI ids) go in: two ranks that reach one physical GPU through
-    different visibility strings ('0' and '0,1') must get the same fingerprint, or the 'ranks share a GPU' guard is bypassed and
-    ncclCommInitRank is entered with a duplicate device. The logical index and the *_VISIBLE_DEVICES strings are the fallback
-    when the runtime reports neither."""
+    runtime reports a uuid or PCI ids, (hostname, uuid, PCI ids, physical index) go in — the index RESOLVED through the visibility
+    strings, never the strings themselves: two ranks that reach one physical GPU through different visibility strings ('0' and
+    '0,1') must get the same fingerprint, or the 'ranks share a GPU' guard is bypassed and ncclCommInitRank is entered with a
+    duplicate device; two partitions of one GPU (CPX / SR-IOV guests reporting the same uuid and bus id) must NOT (round-5
+    advisor finding). The logical index and the *_VISIBLE_DEVICES strings are the fallback when the runtime reports neither."""
     import hashlib
     import socket
     props = torch.cuda.get_device_properties(device)
     uuid = str(getattr(props, "uuid", "") or "")
     pci = (getattr(props, "pci_domain_id", None), getattr(props, "pci_bus_id", None), getattr(props, "pci_device_id", None))
     if uuid.strip("0-") or any(v is not None for v in pci):
-        ident = [socket.gethostname(), uuid, pci]
+        ident = [socket.gethostname(), uuid, pci, physical_device_index(device)]
     else:
         ident = [socket.gethostname(), (os.environ.get("HIP_VISIBLE_DEVICES"), os.environ.get("ROCR_VISIBLE_DEVICES"),
                                         os.environ.get("CUDA_VISIBLE_DEVICES"), torch.device(device).index)]

@@ -187,6 +187,23 @@ class DeviceOnPolicyReplayBuffer(OnPolicyReplayBufferBase, BaseReplayBuffer):
         copies `_advs` / `_estimate_returns` are produced on first access only."""
         if not self._filed:
             return super().generalized_advantage_estimation(last_value, gamma, tau)
+        if tau is None:
+            raise TypeError("generalized_advantage_estimation: tau is None (PPO(gae=True) needs tau; gae=False calls discount_reward)")
+        self._estimate_filed(last_value, gamma, tau, False)
+
+    def discount_reward(self, last_value, gamma):
+        """As the base class; a filed epoch (PPO(gae=False) behind the fast collector) stays device-resident like the GAE path."""
+        if not self._filed:
+            return super().discount_reward(last_value, gamma)
+        self._estimate_filed(last_value, gamma, None, True)
+
+    def _estimate(self, last_value, gamma, tau, discount_only):
+        super()._estimate(last_value, gamma, tau, discount_only)
+        # host-path results are current: device-side fp64 results of an earlier filed epoch must not shadow them
+        self.__dict__.pop("_advs_dev64", None)
+        self.__dict__.pop("_rets_dev64", None)
+
+    def _estimate_filed(self, last_value, gamma, tau, discount_only):
         T, E = self._max_replay_buffer_size, self.env_nums
         dev = self.device
         up = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float64).reshape(T, -1)).to(dev)
@@ -200,8 +217,13 @@ class DeviceOnPolicyReplayBuffer(OnPolicyReplayBufferBase, BaseReplayBuffer):
             lv = torch.from_numpy(np.ascontiguousarray(last_value, dtype=np.float64).reshape(E)).to(dev)
         if not hasattr(self, "_gae_out"):
             self._gae_out = {}
-        advs, rets, a32, r32 = engine.gae(up(self._rewards), self._values32_dev.view(T, E).double(), up(self._terminals), tl,
-                                          lv, gamma, tau, self.time_limit_filter, want32=True, out=self._gae_out)
+        vals64 = self._values32_dev.view(T, E).double()
+        if discount_only:
+            advs, rets, a32, r32 = engine.discount_reward(up(self._rewards), vals64, up(self._terminals), tl, lv, gamma,
+                                                          self.time_limit_filter, want32=True, out=self._gae_out)
+        else:
+            advs, rets, a32, r32 = engine.gae(up(self._rewards), vals64, up(self._terminals), tl, lv, gamma, tau,
+                                              self.time_limit_filter, want32=True, out=self._gae_out)
         self._advs_dev64, self._rets_dev64 = advs, rets
         self.__dict__.pop("_advs", None)
         self.__dict__.pop("_estimate_returns", None)
