@@ -19,7 +19,7 @@
  *     fp32 accumulate (round 6: bf16's MFMA rate and bytes, three more significand bits — 8 x closer to the fp32 reference;
  *     half's 5 exponent bits are why its backward runs on scaled loss-gradient rows: v4l_net_grad_scale).
  *
- * Environment switches read by the library: 20 (round 4: 37 — the ones no test referenced went in round 5, their fast-path value
+ * Environment switches read by the library: 21 (round 4: 37 — the ones no test referenced went in round 5, their fast-path value
  * is now compiled in; V4L_VIS17 came with the native 16-token kernels). tests/test_cpu.py keeps this list and the source in step. Three configure a run, the others are DIAGNOSTIC: every one of them backs a bit-equality / cross-check test
  * under tests/ that compares a fused kernel or a launch schedule against the general one. Read when first needed unless (per call).
  *   run:   V4L_TRACE (launch / graph log on stderr), V4L_RCCL_LIB (RCCL library to dlopen; default librccl.so.1), V4L_ROCTX=1 (roctx
@@ -35,6 +35,8 @@
  *                             take them in the operand type (round 5; same bits, 19 KB more per sample each way) (per call)
  *   V4L_VIS17                 the vision-only Transformer on the 17-row wave-per-sample instantiation (dummy row 0, masked key) instead
  *                             of the native 16-token one (round 5; agrees to rounding: cross-checked) (per call)
+ *   V4L_NO_FB                 the LocoTransformer's layers + heads of an update pass as three launches (forward, loss, backward)
+ *                             instead of the fused forward-loss-backward launch (round 6, csrc/wps_fb.h; cross-checked) (per call)
  *   V4L_NO_LAYER_STACK        one launch per transformer layer instead of one per direction (per call)
  *   V4L_NO_WPS_LAYERS         transformer layers on the block-cooperative kernels instead of the wave-per-sample ones (per call)
  *   V4L_LAYER_TAPS            the wave-per-sample layer kernels and the fused conv backward also write every intermediate into
@@ -46,7 +48,8 @@
  *   V4L_WPS_HEAD_IN, V4L_WPS_TOK0_IN, V4L_WPS_HEAD_EXT_CRITIC   where the pooled heads' / the proprio branch's data-grad chains run:
  *                             inside wps_layer_bwd_kernel (4 rows per block) or beside the loss statistics / the layers'
  *                             weight-grads (16 - 64 rows per block) (per call)
- * Read by the Python shell, not by the library: V4L_COMPUTE=bf16|f32, V4L_GRAPH=0, V4L_DP_COMM=auto|torch|rccl,
+ * Read by the Python shell, not by the library: V4L_COMPUTE=f16|bf16|f32, V4L_GRAPH=0, V4L_EPOCH_GRAPH=0 (one hipGraph replay per
+ * update instead of one per epoch), V4L_DP_COMM=auto|torch|rccl,
  * V4L_CAST_THREADS, V4L_COLLECT_SPLIT=0 (fp32 observation rows over PCIe instead of fp32 proprio + bf16 depth rows),
  * V4L_SPLIT_VIA_COPY, V4L_GUARD, V4L_FORCE_DP_PHASES, V4L_LIB (diagnostic builds). Everything except COMPUTE / GRAPH / DP_COMM /
  * CAST_THREADS / RCCL_LIB / TRACE / ROCTX is diagnostic: the Python shell warns once at load time when one is set
@@ -305,6 +308,14 @@ int v4l_trainer_begin(v4l_trainer* tr, const int* rowidx_all_dev, float* stats_a
  * The first update of a configuration always runs eagerly. */
 int v4l_trainer_update_next(v4l_trainer* tr, const v4l_rollout* ro, int n, const v4l_ppo_hyper* hp, int use_graph,
                             void* stream);
+/* The next `count` minibatch updates, == the epoch loop of PPO.update_per_epoch (ppo.py:28-40: opt_epochs x minibatches) behind
+ * one v4l_trainer_begin. use_graph=1: ALL count updates are ONE hipGraph (count x ~22 kernel nodes; the row indices, the update
+ * index, Adam's step count and bias corrections and the learning rates live on the device, so the node sequence is the same for
+ * every update and every epoch), captured once per (rollout pointers, n, hyper-parameters, count) and replayed with one
+ * hipGraphLaunch per epoch (round 6; BASELINE configs[4] "hipGraph-captured PPO epoch"). The call that meets a new configuration
+ * runs it through v4l_trainer_update_next (first update eagerly, the others as single-update replays). */
+int v4l_trainer_update_run(v4l_trainer* tr, const v4l_rollout* ro, int n, const v4l_ppo_hyper* hp, int count, int use_graph,
+                           void* stream);
 /* Phases of the same update for a host-driven data-parallel schedule: critic_grads -> all-reduce(critic bucket) ->
  * critic_step -> actor_grads -> all-reduce(policy bucket) -> actor_step (buckets and their tails: see v4l_sync_grads).
  * v4l_trainer_stats_cur = the record being filled. */

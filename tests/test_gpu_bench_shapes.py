@@ -374,3 +374,63 @@ def test_forked_weight_grad_launches_equal_serial(mode, device):
             assert (grads_with(2) - ref).abs().max().item() == 0.0
     finally:
         os.environ.pop("V4L_SPLIT_REDUCE", None)
+
+
+@pytest.mark.parametrize("mode", MODES)
+@pytest.mark.parametrize("name", ["loco_s93", "loco_rag", "loco_b1024", "loco_clipvf"])
+def test_fused_forward_loss_backward_equals_three_launches(name, mode, device, monkeypatch):
+    """Round 6 (csrc/wps_fb.h): the LocoTransformer's layers + heads of an update pass as ONE launch — layer forwards, the block's
+    loss-gradient rows, heads and layer backwards, layer 1 not recomputed — against the three launches it replaces (V4L_NO_FB=1:
+    wps_layer_fwd_kernel, the loss launch, wps_layer_bwd_kernel). The same device functions in the same order per element: after
+    the first update every parameter except log sigma must hold the same bits (its gradient and the logged statistics are sums
+    over rows, taken per block and then over blocks instead of by one block: fp32 / fp64 summation order only); after the second
+    update, which starts from a log sigma that may differ in its last bit, everything agrees to that noise. Updates run from stored
+    log pi_old (the resident path, what the bench times): B = 64 (4-wave loss blocks), ragged 300, 1024, and the clipped value loss."""
+    from vision4leg_amd.engine import HipTrainer
+    from vision4leg_amd.torchrl.algo import PPO
+    case = util.CASES[name]
+    B, U = case["B"], 2
+    res = {}
+    for no_fb in ("1", "0"):
+        if no_fb == "1":
+            monkeypatch.setenv("V4L_NO_FB", "1")
+        else:
+            monkeypatch.delenv("V4L_NO_FB", raising=False)
+        pf, vf = _build(case, mode, device)
+
+        class Coll: epoch_frames = B
+        agent = PPO(pf=pf, vf=vf, plr=1e-4, vlr=1e-4, clip_para=0.2, opt_epochs=3, tau=0.95, entropy_coeff=0.005,
+                    collector=Coll(), device=device, batch_size=B, clipped_value_loss=case.get("clipped_value_loss", False))
+        agent.use_graph = False
+        b = util.make_batch(case)
+        t = lambda a: torch.tensor(a, dtype=torch.float32, device=device)
+        net = pf.hip
+        net.ensure_bound()
+        st, im = net.alloc_rollout(B, device)
+        net.ingest(t(b["obs"]), st, im)
+        rs = np.random.RandomState(3)
+        logp = t(-6.0 + 0.3 * rs.randn(B))  # stored log pi_old: the fused launch serves the stored-log-prob update
+        ro = HipTrainer.rollout(st, im, t(b["acts"]), t(b["advs"]).reshape(-1), t(b["estimate_returns"]).reshape(-1),
+                                t(b["values"]).reshape(-1), logp)
+        rows = torch.stack([torch.from_numpy(rs.permutation(B).astype(np.int32)) for _ in range(U)]).to(device)
+        agent.trainer.sync_target()
+        snaps = []
+        for u in range(U):
+            stats = torch.zeros(1, 24, device=device)
+            agent.run_updates(ro, rows[u:u + 1], stats)
+            torch.cuda.synchronize()
+            snaps.append((stats.cpu().numpy()[0], {k: v.detach().cpu().clone() for k, v in pf.state_dict().items()},
+                          {k: v.detach().cpu().clone() for k, v in vf.state_dict().items()}))
+        res[no_fb] = snaps
+    for u in range(U):
+        (sa, pa, va), (sb, pb, vb) = res["1"][u], res["0"][u]
+        assert np.isfinite(sb[:18]).all()
+        err = np.abs(sa[:18] - sb[:18]) / np.maximum(1.0, np.abs(sa[:18]))
+        assert err.max() <= (2e-6 if u == 0 else 2e-5), (u, util.STAT_KEYS[int(err.argmax())], err.max())
+        assert sa[23] == sb[23]  # (f16: the same rows were clamped — none here)
+        for tag, a, b2 in (("pf", pa, pb), ("vf", va, vb)):
+            for k in a:
+                if u == 0 and k != "logstd":
+                    assert torch.equal(a[k], b2[k]), (u, tag, k, (a[k] - b2[k]).abs().max().item())
+                else:
+                    assert (a[k] - b2[k]).abs().max().item() <= (1e-7 if u == 0 else 2e-6), (u, tag, k)

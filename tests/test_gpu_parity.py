@@ -651,6 +651,54 @@ def test_graph_replay_equals_eager(mode, pair, device):
         assert sum((pg[k] - opf[k]).abs().sum().item() for k in pg) / sum(v.numel() for v in pg.values()) <= 1e-5
 
 
+@pytest.mark.parametrize("mode", MODES)
+@pytest.mark.parametrize("name", ["loco_s84", "cnn_s93"])
+def test_epoch_graph_equals_per_update_replays(name, mode, device, monkeypatch):
+    """Round 6 (BASELINE configs[4]: "hipGraph-captured PPO epoch"): run_updates replays ONE hipGraph holding all U updates of an
+    epoch (v4l_trainer_update_run; the row indices, update index, Adam step and learning rates are device-side, torchrl/algo/
+    on_policy/ppo.py:28-40 is the loop) instead of one graph per update (V4L_EPOCH_GRAPH=0). Three epochs — the first runs update
+    by update (first update eagerly), the second captures the run, the third replays it, with another learning rate and other
+    rows each — must leave bit-identical statistics and parameters either way."""
+    from vision4leg_amd.engine import HipTrainer
+    from vision4leg_amd.torchrl.algo import PPO
+    case = dict(util.CASES[name], B=32)
+    T, E, B, U = 8, 8, 32, 5
+    rs = np.random.RandomState(17)
+    obs = util.obs_rows(rs, T * E, case)
+    acts, advs, rets = 0.1 * rs.randn(T * E, case["A"]), rs.randn(T * E), rs.randn(T * E)
+    rows = [np.stack([rs.permutation(T * E)[:B] for _ in range(U)]).astype(np.int32) for _ in range(3)]
+    results = []
+    for epoch_graph in ("0", "1"):
+        monkeypatch.setenv("V4L_EPOCH_GRAPH", epoch_graph)
+        pf, vf = _build(case, mode, device)
+
+        class Coll: epoch_frames = T * E
+        agent = PPO(pf=pf, vf=vf, plr=1e-4, vlr=1e-4, clip_para=0.2, opt_epochs=3, tau=0.95, entropy_coeff=0.005,
+                    collector=Coll(), device=device, batch_size=B)
+        assert agent.use_graph
+        net = pf.hip
+        net.ensure_bound()
+        state, image = net.alloc_rollout(T * E, device)
+        t = lambda a: torch.tensor(a, dtype=torch.float32, device=device)
+        net.ingest(t(obs), state, image)
+        ro = HipTrainer.rollout(state, image, t(acts), t(advs), t(rets), t(rets))
+        agent.trainer.sync_target()
+        all_stats = []
+        for ep in range(3):
+            agent.pf_optimizer.param_groups[0]["lr"] = agent.vf_optimizer.param_groups[0]["lr"] = 1e-4 * (1 - 0.1 * ep)
+            stats = torch.zeros(U, 24, device=device)
+            agent.run_updates(ro, torch.tensor(rows[ep], device=device), stats)
+            torch.cuda.synchronize()
+            all_stats.append(stats.cpu().numpy())
+        assert agent.trainer.step == 3 * U and agent.training_update_num == 3 * U
+        results.append((np.concatenate(all_stats), {k: v.detach().cpu().clone() for k, v in pf.state_dict().items()},
+                        {k: v.detach().cpu().clone() for k, v in vf.state_dict().items()}))
+    (sa, pa, va), (sb, pb, vb) = results
+    assert np.isfinite(sa[:, :18]).all() and np.array_equal(sa, sb), np.abs(sa - sb).max()
+    assert all(torch.equal(pa[k], pb[k]) for k in pa) and all(torch.equal(va[k], vb[k]) for k in va)
+    assert (sa[1:, 15] != 1.0).all()  # later updates really saw moved parameters (ratio/max != 1)
+
+
 @pytest.mark.parametrize("graph", [False, True])
 @pytest.mark.parametrize("mode", MODES)
 @pytest.mark.parametrize("name", ["loco_s84", "cnn_s93", "mlp_s93", "loco_vis", "cnn_vis", "loco_tn", "loco_vis_tn", "loco_pe", "loco_vis_pe",

@@ -120,6 +120,7 @@ _SIGS = {
   "v4l_trainer_bind": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, C.c_int64, _P, C.c_int, _P]),
   "v4l_trainer_begin": (C.c_int, [_P, _P, _P, C.c_double, C.c_double, C.c_int64, C.POINTER(PPOHyper), _P]),
   "v4l_trainer_update_next": (C.c_int, [_P, C.POINTER(Rollout), C.c_int, C.POINTER(PPOHyper), C.c_int, _P]),
+  "v4l_trainer_update_run": (C.c_int, [_P, C.POINTER(Rollout), C.c_int, C.POINTER(PPOHyper), C.c_int, C.c_int, _P]),
   "v4l_trainer_critic_grads": (C.c_int, [_P, C.POINTER(Rollout), C.c_int, C.POINTER(PPOHyper), _P]),
   "v4l_trainer_critic_step": (C.c_int, [_P, C.POINTER(PPOHyper), _P]),
   "v4l_trainer_actor_grads": (C.c_int, [_P, C.POINTER(Rollout), C.c_int, C.POINTER(PPOHyper), _P]),

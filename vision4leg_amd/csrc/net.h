@@ -8,7 +8,7 @@
 #include "elem.h"
 #include "gemm.h"
 
-namespace v4l { struct RowsChain; }
+namespace v4l { struct RowsChain; struct FbLoss; }
 
 namespace v4l {
 
@@ -154,6 +154,11 @@ struct v4l_net {
   int heads_ext_n = 0;
   bool wps_bwd_plain() const;   // backward_t will run the (non-vision) wave-per-sample backward
   int heads_ext(float* ws, int n, v4l::RowsChain* out);
+  // round 6: the trainer handed over the loss of the pass (rows, scalars, where the statistics go) — backward_t then runs the
+  // layers' forward, the loss rows and the backward as ONE launch (csrc/wps_fb.h) over a workspace whose forward stopped behind
+  // the encoder (forward_t stage 1); backward_t consumes the mark
+  const v4l::FbLoss* fb_loss = nullptr;
+  bool fb_ok() const;         // ... which serves the plain shipped LocoTransformer
   bool fused_layers() const;  // the transformer layers run as fused forward / backward launches (csrc/infer.h, bwd.h)
   bool wps_layers() const;
   bool wps_max_pool() const;  // max_pool=True pooled inside the wave-per-sample pair
@@ -205,6 +210,8 @@ struct v4l_trainer {
   // hipGraph of one minibatch update
   GraphKey gkey = {};
   hipGraphExec_t gexec = nullptr;
+  hipGraphExec_t gexec_run = nullptr;  // hipGraph of a whole run of updates (v4l_trainer_update_run), gexec_run_count of them
+  int gexec_run_count = 0;
   bool warm = false;
   bool bound = false;
   // data parallel: RCCL communicator of this trainer's process group (null: single GPU, or the host drives the exchange)

@@ -11,6 +11,7 @@
 #include "infer.h"
 #include "bwd.h"
 #include "wps.h"
+#include "wps_fb.h"
 #include "rollout_dense.h"
 #include "dense_stack.h"
 
@@ -202,6 +203,11 @@ struct Ctx {  // per-call view of a bound net
   bool wps_pending = false;
   bool wps_used = false;     // this backward pass runs the wave-per-sample layer kernels (stays set: sizes the dW3 launch)
   v4l::WpsWg wps_args = {};
+  // the fused forward-loss-backward launch (csrc/wps_fb.h) left per-block partial statistics: fb_loss_finish_kernel, issued
+  // with the dense weight-grads (auxiliary stream)
+  bool fb_pending = false;
+  v4l::FbLoss fb_args = {};
+  int fb_blocks = 0, fb_n = 0;
 };
 
 // Fork/join of the net's auxiliary stream. Independent sibling kernels (a layer's weight-grad next to its data-grad,
@@ -268,6 +274,12 @@ template <typename T>
 static int wgrad_dense(Ctx& c, hipStream_t ds, hipStream_t dg) {
   v4l_net* net = c.net;
   if (dg == nullptr) dg = ds;
+  if (c.fb_pending) {  // one block: off the chain of the big launches (only clip_adam and the record's readers wait for it)
+    c.fb_pending = false;
+    g_op = "loss";
+    V4L_KLAUNCH("fb_loss_finish", 0, ds, fb_loss_finish_kernel, dim3(1), dim3(256), 0, ds, c.fb_args, c.fb_blocks, c.fb_n);
+    V4L_LAUNCH_CHECK();
+  }
   if (c.wps_pending) {
     c.wps_pending = false;
     const int jobs = c.wps_args.nsplit * WPS_ROLES * c.wps_args.nlayers;
@@ -1116,6 +1128,13 @@ bool v4l_net::wps_bwd_plain() const {
                           c.enc_hidden[1] == 256;
   return fused_bwd && fused_head && fused_tail && c.n_layers == 2 && !sw_on("V4L_NO_LAYER_STACK") && wps_layers();
 }
+// The fused forward-loss-backward launch of the layers + heads (csrc/wps_fb.h) serves the plain shipped LocoTransformer on the
+// wave-per-sample kernels, mean pooling, no test taps. V4L_NO_FB (read per call: the cross-check tests switch it): the three
+// separate launches.
+bool v4l_net::fb_ok() const {
+  return wps_bwd_plain() && !cfg.max_pool && !sw_on("V4L_LAYER_TAPS") && !sw_on("V4L_NO_FB") && !sw_on("V4L_WPS_HEAD_IN") &&
+         !sw_on("V4L_WPS_HEAD_EXT_CRITIC");
+}
 // The operands of the pooled heads' data-grad chain over the workspace `ws` laid out for n rows, for a caller (the trainer's
 // loss launch) that runs the chain itself right before v4l_net_backward(ws, n): -> 1 and the backward pass is told (it then
 // starts from dpool), or 0 when that backward pass will not be the wave-per-sample one (or V4L_WPS_HEAD_IN / test taps ask for
@@ -1162,6 +1181,7 @@ int64_t v4l_net::slab_floats(int n) const {
   for (const Lin& L : head) add(n, L.N, L.K);
   if (!layers.empty() && layers[0].inproj.pkp >= 0)  // wave-per-sample weight-grads: one slab set per run of WPS_SPLIT samples
     tot += (int64_t)layers.size() * cdiv(n, WPS_SPLIT) * (WPS_LAYER_ELEMS + 576) + 1024;
+  if (cfg.kind == V4L_NET_LOCO) tot += 2 * (int64_t)cdiv(n, WPS_WPB) * FB_PART + 8;  // fused launch: per-block partial statistics (doubles)
   return tot;
 }
 
@@ -1961,7 +1981,58 @@ int v4l_net::backward_t(const float* state, const T* image, const int* rowidx, i
     V4L_KLAUNCH("wps_layer_bwd_stack", fl, s, (wps_layer_bwd_kernel<T, 2, TAPS_, VIS_, HIN_, TIN_, MODE_>), dim3(nblk), dim3(256), \
                 (WpsBwdLds<T>::bytes), s, d, bh, bt, tx, n);                                                              \
   } while (0)
+    // round 6: forward -> loss rows -> backward as ONE launch when the trainer handed the loss over (csrc/wps_fb.h)
+    const FbLoss* fbl = fb_loss;
+    fb_loss = nullptr;
+    V4L_REQUIRE(fbl == nullptr || (fb_ok() && !vis_wps && !opt_wps && !taps && !head_ext),
+                "internal: a fused forward-loss-backward pass was prepared for a net that does not take it");
     const bool opt_notail = opt_wps && (c.token_norm || !(vis || wps_tail_shape()));
+    if (fbl != nullptr) {
+      InfLayerStack fst;
+      memset(&fst, 0, sizeof(fst));
+      fst.nl = 2;
+      for (int k = 0; k < 2; ++k) {
+        const TLayer& t = layers[k];
+        InfLayer& f = fst.l[k].n[0];
+        f.win = base + t.inproj.pkp; f.wo = base + t.outproj.pkp; f.w1 = base + t.ff1.pkp; f.w2 = base + t.ff2.pkp;
+        f.bin = p[t.inproj.b]; f.bo = p[t.outproj.b]; f.b1 = p[t.ff1.b]; f.b2 = p[t.ff2.b];
+        f.g1 = p[t.ln1.g]; f.be1 = p[t.ln1.b]; f.g2 = p[t.ln2.g]; f.be2 = p[t.ln2.b];
+        f.xin = k == 0 ? ws + L.x[0] : nullptr;  // (layer 1's input rows stay in the wave's registers)
+      }
+      InfHeadPair fhd;
+      memset(&fhd, 0, sizeof(fhd));
+      InfHead& h = fhd.n[0];
+      h.w0 = base + head[0].pk; h.w1 = base + head[1].pk; h.w2 = base + head[2].pk;
+      h.b0 = p[head[0].b]; h.b1 = p[head[1].b]; h.b2 = p[head[2].b];
+      h.out = ws + L.out; h.nout = c.out_dim;
+      h.s_pooled = ws + L.pooled; h.s_h0 = ws + L.hh[0]; h.s_h1 = ws + L.hh[1];
+      FbLoss lo = *fbl;
+      lo.dout = ws + L.dout;
+      cx.slab_used = (cx.slab_used + 1) & ~(int64_t)1;  // doubles
+      lo.part = reinterpret_cast<double*>(cx.slab + cx.slab_used);
+      V4L_REQUIRE((reinterpret_cast<uintptr_t>(lo.part) & 7) == 0, "internal: partial-statistics block not 8-byte aligned");
+      cx.slab_used += 2 * (int64_t)nblk * FB_PART;
+      V4L_REQUIRE(cx.slab_used <= slab_cap, "internal: weight-grad slab arena overflow");
+      const double fl_fb = fl + 2.0 * n * (872576.0 + 99840.0);  // + layer 0's forward and the heads' (layer 1 is not recomputed)
+      static bool attr_fb = false;
+      if (!attr_fb) {
+        V4L_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&wps_layer_fb_kernel<T, true>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)WpsFbLds<T>::bytes));
+        V4L_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&wps_layer_fb_kernel<T, false>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)WpsFbLds<T>::bytes));
+        attr_fb = true;
+      }
+      if (tok0_ext)
+        V4L_KLAUNCH("wps_layer_fb_stack", fl_fb, s, (wps_layer_fb_kernel<T, false>), dim3(nblk), dim3(256), (WpsFbLds<T>::bytes), s, fst,
+                    fhd, d, bh, bt, tx, lo, n);
+      else
+        V4L_KLAUNCH("wps_layer_fb_stack", fl_fb, s, (wps_layer_fb_kernel<T, true>), dim3(nblk), dim3(256), (WpsFbLds<T>::bytes), s, fst,
+                    fhd, d, bh, bt, tx, lo, n);
+      cx.fb_pending = true;
+      cx.fb_args = lo;
+      cx.fb_blocks = nblk;
+      cx.fb_n = n;
+    } else
     if (vis_opt && opt_notail && c.pytorch_encoder) V4L_WPS_BWD(false, 2, true, true, 3);
     else if (vis_opt && c.pytorch_encoder) V4L_WPS_BWD(false, 2, true, true, 2);
     else if (vis_opt) V4L_WPS_BWD(false, 2, true, true, 1);
@@ -3319,6 +3390,8 @@ int v4l_trainer_create(v4l_net* pf, v4l_net* vf, v4l_net* target_pf, v4l_trainer
 }
 static void drop_graph(v4l_trainer* tr) {
   if (tr->gexec) { (void)hipGraphExecDestroy(tr->gexec); tr->gexec = nullptr; }
+  if (tr->gexec_run) { (void)hipGraphExecDestroy(tr->gexec_run); tr->gexec_run = nullptr; }
+  tr->gexec_run_count = 0;
   tr->warm = false;
 }
 void v4l_trainer_destroy(v4l_trainer* tr) {
@@ -3376,6 +3449,20 @@ int v4l_trainer_begin(v4l_trainer* tr, const int* rowidx_all_dev, float* stats_a
   return 0;
 }
 
+// The encoder half of a training forward (forward_t stage 1: up to the token tensor) for a pass whose layers, heads and loss
+// rows run inside the fused launch of the backward that follows (csrc/wps_fb.h)
+static int net_forward_encoder(v4l_net* net, const float* state_dev, const void* image_dev, const int* rowidx_dev, int n, float* ws_dev,
+                               void* stream) {
+  V4L_REQUIRE(net && net->bound, "v4l_net_forward: net is not bound");
+  net->want_acts16 = true;
+  const int rc = by_compute(net->cfg.compute, [&](auto tag) -> int {
+    typedef typename decltype(tag)::type T;
+    return net->forward_t<T>(state_dev, (const T*)image_dev, rowidx_dev, n, ws_dev, (hipStream_t)stream, nullptr, 1);
+  });
+  net->want_acts16 = false;
+  return rc;
+}
+
 static int check_update_args(const v4l_trainer* tr, const v4l_rollout* ro, int n, const v4l_ppo_hyper* hp) {
   V4L_REQUIRE(tr && tr->bound, "v4l_trainer: not bound");
   V4L_REQUIRE(ro && hp && n > 1 && n <= tr->n_max, "v4l_trainer: bad argument (need 1 < n <= n_max)");
@@ -3410,11 +3497,26 @@ int v4l_trainer_critic_grads(v4l_trainer* tr, const v4l_rollout* ro, int n, cons
         return 0;
       })))
     return rc;
+  const float inv_n = 1.f / ((float)n * (float)hp->world_size);
+  const float gscale = v4l_net_grad_scale(vf, n);
+  if (vf->fb_ok()) {
+    // round 6: encoder forward, then ONE launch for layers + heads forward, the loss rows and the backward (csrc/wps_fb.h)
+    { PhaseScope ps("vf.fwd");
+    if ((rc = net_forward_encoder(vf, ro->state_dev, ro->image_dev, rowidx, n, tr->ws, stream))) return rc; }
+    FbLoss lo;
+    memset(&lo, 0, sizeof(lo));
+    lo.actor = 0;
+    lo.ret = ro->rets_dev; lo.oldv = ro->values_dev; lo.clipped = hp->clipped_value_loss; lo.clip = hp->clip_para;
+    lo.rowidx = rowidx; lo.inv_n = inv_n; lo.gscale = gscale; lo.st = st;
+    vf->fb_loss = &lo;
+    PhaseScope ps("vf.bwd");
+    rc = v4l_net_backward(vf, ro->state_dev, ro->image_dev, rowidx, n, tr->ws, tr->g_vf, stream);
+    vf->fb_loss = nullptr;
+    return rc;
+  }
   { PhaseScope ps("vf.fwd");
   if ((rc = v4l_net_forward(vf, ro->state_dev, ro->image_dev, rowidx, n, tr->ws, 1, stream))) return rc; }
   const Layout L = vf->layout(n);
-  const float inv_n = 1.f / ((float)n * (float)hp->world_size);
-  const float gscale = v4l_net_grad_scale(vf, n);
   g_op = "loss";
   {
     // The heads' data-grad chain as extra blocks of the loss launch (when the backward that follows is the wave-per-sample
@@ -3511,8 +3613,12 @@ int v4l_trainer_actor_grads(v4l_trainer* tr, const v4l_rollout* ro, int n, const
     if ((rc = v4l_net_forward(tp, ro->state_dev, ro->image_dev, rowidx, n, ws_t, 0, (void*)s_tgt))) return rc;
   }
   if ((rc = v4l_net_pack(pf, stream))) return rc;  // the critic step moved the shared encoder
+  // round 6: with log pi_old stored at action time the policy's pass is encoder forward + ONE fused launch (csrc/wps_fb.h)
+  const bool fb = stored && !pf->cfg.tanh_action && pf->fb_ok();
   { PhaseScope ps("pf.fwd");
-  if ((rc = v4l_net_forward(pf, ro->state_dev, ro->image_dev, rowidx, n, tr->ws, 1, stream))) return rc; }
+  if (fb) rc = net_forward_encoder(pf, ro->state_dev, ro->image_dev, rowidx, n, tr->ws, stream);
+  else rc = v4l_net_forward(pf, ro->state_dev, ro->image_dev, rowidx, n, tr->ws, 1, stream);
+  if (rc) return rc; }
   if (par_tgt) {
     V4L_HIP_CHECK(hipEventRecord(tr->ev_join, tr->aux));
     V4L_HIP_CHECK(hipStreamWaitEvent(s, tr->ev_join, 0));
@@ -3528,6 +3634,18 @@ int v4l_trainer_actor_grads(v4l_trainer* tr, const v4l_rollout* ro, int n, const
     aa.dmean = tr->ws + Lp.dout; aa.dlogstd = tr->g_pf + pf->params[pf->logstd].goff; aa.st = st;
     aa.tanh_action = pf->cfg.tanh_action;
     aa.gscale = v4l_net_grad_scale(pf, n);
+    if (fb) {
+      FbLoss lo;
+      memset(&lo, 0, sizeof(lo));
+      lo.actor = 1;
+      lo.aa = aa;
+      lo.rowidx = rowidx; lo.inv_n = inv_n; lo.gscale = aa.gscale; lo.st = st;
+      pf->fb_loss = &lo;
+      PhaseScope ps("pf.bwd");
+      rc = v4l_net_backward(pf, ro->state_dev, ro->image_dev, rowidx, n, tr->ws, tr->g_pf, stream);
+      pf->fb_loss = nullptr;
+      return rc;
+    }
     RowsChain hc;
     const bool ext = !pf->cfg.tanh_action && pf->heads_ext(tr->ws, n, &hc) != 0;
     const dim3 blk(n >= 512 ? 1024 : 256);
@@ -3742,6 +3860,45 @@ int v4l_trainer_update_next(v4l_trainer* tr, const v4l_rollout* ro, int n, const
   }
   V4L_HIP_CHECK(hipGraphLaunch(tr->gexec, s));
   V4L_TRACE("update: launched");
+  return 0;
+}
+
+int v4l_trainer_update_run(v4l_trainer* tr, const v4l_rollout* ro, int n, const v4l_ppo_hyper* hp, int count, int use_graph,
+                           void* stream) {
+  int rc = check_update_args(tr, ro, n, hp);
+  if (rc) return rc;
+  V4L_REQUIRE(count >= 1, "v4l_trainer_update_run: count must be >= 1");
+  hipStream_t s = (hipStream_t)stream;
+  GraphKey key;
+  memset(&key, 0, sizeof(key));
+  key.ro = *ro; key.hp = *hp; key.n = n;
+  key.gen[0] = tr->pf->gen; key.gen[1] = tr->vf->gen; key.gen[2] = tr->tpf->gen;
+  const bool same = memcmp(&key, &tr->gkey, sizeof(key)) == 0;
+  if (!use_graph || g_prof || s == nullptr || !same || !tr->warm) {
+    // no graph, or a configuration this trainer has not run yet: update by update (the first one eagerly — it uploads the
+    // descriptor tables —, then single-update replays); the next call captures the whole run
+    for (int u = 0; u < count; ++u)
+      if ((rc = v4l_trainer_update_next(tr, ro, n, hp, use_graph, stream))) return rc;
+    return 0;
+  }
+  if (tr->gexec_run != nullptr && tr->gexec_run_count != count) {
+    (void)hipGraphExecDestroy(tr->gexec_run);
+    tr->gexec_run = nullptr;
+  }
+  if (tr->gexec_run == nullptr) {
+    hipGraph_t graph = nullptr;
+    V4L_TRACE("update run: begin capture of %d updates", count);
+    V4L_HIP_CHECK(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+    for (int u = 0; u < count && !rc; ++u) rc = run_update(tr, ro, n, hp, stream);
+    const hipError_t e = hipStreamEndCapture(s, &graph);
+    if (rc) { if (graph) (void)hipGraphDestroy(graph); return rc; }
+    V4L_HIP_CHECK(e);
+    V4L_HIP_CHECK(hipGraphInstantiate(&tr->gexec_run, graph, nullptr, nullptr, 0));
+    V4L_HIP_CHECK(hipGraphDestroy(graph));
+    tr->gexec_run_count = count;
+    V4L_TRACE("update run: instantiated");
+  }
+  V4L_HIP_CHECK(hipGraphLaunch(tr->gexec_run, s));
   return 0;
 }
 

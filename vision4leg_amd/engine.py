@@ -466,6 +466,14 @@ class HipTrainer:
     self.step += 1
     self._after_steps()
 
+  def update_run(self, ro, n, count, graph=True):
+    """The next `count` updates behind one begin(): with graph=True ONE hipGraph replay for all of them (v4l_trainer_update_run)."""
+    self._pre(n)
+    check(self.L.v4l_trainer_update_run(self.h, C.byref(ro), n, C.byref(self.hp), int(count), int(graph), _stream()),
+          "v4l_trainer_update_run")
+    self.step += int(count)
+    self._after_steps()
+
   def update(self, ro, rowidx, n, lr_pf, lr_vf, stats):
     """One eager PPO.update on minibatch rows rowidx (int32 device tensor or None); stats: [V4L_STATS] floats."""
     self._pre(n)

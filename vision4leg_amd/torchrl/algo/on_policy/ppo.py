@@ -385,8 +385,8 @@ class PPO:
 
     def run_updates(self, ro, rowidx, stats):
         """All minibatch updates of an epoch: rowidx [U][n] int32 (device), stats [U][V4L_STATS] (device).
-        Each update is one hipGraph replay on the trainer's stream — on one GPU, and data-parallel with the library's own
-        communicator (V4L_DP_COMM=rccl: both all-reduces are nodes of that graph). With torch.distributed doing the exchange
+        The whole run is ONE hipGraph replay on the trainer's stream (round 6; one replay per update with V4L_EPOCH_GRAPH=0) — on one
+        GPU, and data-parallel with the library's own communicator (V4L_DP_COMM=rccl: both all-reduces are nodes of that graph). With torch.distributed doing the exchange
         (the data-parallel default) an update is four eager phases with one all-reduce per optimiser step between them."""
         tr = self.trainer
         U, n = rowidx.shape
@@ -399,12 +399,17 @@ class PPO:
         tr.stream.wait_stream(cur)
         with torch.cuda.stream(tr.stream):
             tr.begin(self._rowidx_buf, self._stats_buf, self.pf_optimizer.lr, self.vf_optimizer.lr)
-            for _ in range(U):
-                self.training_update_num += 1
-                if not self.dp_phases:
-                    tr.update_next(ro, n, graph=self.use_graph)
-                else:
-                    self._update_phases(ro, n)
+            if not self.dp_phases and self.use_graph and os.environ.get("V4L_EPOCH_GRAPH", "1") != "0":
+                # the whole epoch loop (ppo.py:28-40) as ONE hipGraph replay (round 6); V4L_EPOCH_GRAPH=0: one replay per update
+                self.training_update_num += U
+                tr.update_run(ro, n, U, graph=True)
+            else:
+                for _ in range(U):
+                    self.training_update_num += 1
+                    if not self.dp_phases:
+                        tr.update_next(ro, n, graph=self.use_graph)
+                    else:
+                        self._update_phases(ro, n)
             stats.copy_(self._stats_buf)
         cur.wait_stream(tr.stream)
 
