@@ -381,10 +381,11 @@ def test_forked_weight_grad_launches_equal_serial(mode, device):
 def test_fused_forward_loss_backward_equals_three_launches(name, mode, device, monkeypatch):
     """Round 6 (csrc/wps_fb.h): the LocoTransformer's layers + heads of an update pass as ONE launch — layer forwards, the block's
     loss-gradient rows, heads and layer backwards, layer 1 not recomputed — against the three launches it replaces (V4L_NO_FB=1:
-    wps_layer_fwd_kernel, the loss launch, wps_layer_bwd_kernel). The same device functions in the same order per element: after
-    the first update every parameter except log sigma must hold the same bits (its gradient and the logged statistics are sums
-    over rows, taken per block and then over blocks instead of by one block: fp32 / fp64 summation order only); after the second
-    update, which starts from a log sigma that may differ in its last bit, everything agrees to that noise. Updates run from stored
+    wps_layer_fwd_kernel, the loss launch, wps_layer_bwd_kernel). The same device functions in the same order per element: in the
+    first update every GRADIENT element except log sigma's must hold the same bits (d log sigma and the logged statistics are sums
+    over rows, taken per block and then over blocks instead of by one block: fp32 / fp64 summation order only). The parameters agree
+    to that noise: d log sigma's last bit is in the policy's gradient norm, hence — the clip being active — in every step of its
+    Adam, and the second update starts from there. Updates run from stored
     log pi_old (the resident path, what the bench times): B = 64 (4-wave loss blocks), ragged 300, 1024, and the clipped value loss."""
     from vision4leg_amd.engine import HipTrainer
     from vision4leg_amd.torchrl.algo import PPO
@@ -419,18 +420,21 @@ def test_fused_forward_loss_backward_equals_three_launches(name, mode, device, m
             stats = torch.zeros(1, 24, device=device)
             agent.run_updates(ro, rows[u:u + 1], stats)
             torch.cuda.synchronize()
+            tr = agent.trainer
+            gp = tr.g_pf.cpu().clone()
+            gp[pf.hip.grad_offsets[pf.hip.param_names.index("logstd")]:][:case["A"]] = 0.0
             snaps.append((stats.cpu().numpy()[0], {k: v.detach().cpu().clone() for k, v in pf.state_dict().items()},
-                          {k: v.detach().cpu().clone() for k, v in vf.state_dict().items()}))
+                          {k: v.detach().cpu().clone() for k, v in vf.state_dict().items()}, gp, tr.g_vf.cpu().clone()))
         res[no_fb] = snaps
     for u in range(U):
-        (sa, pa, va), (sb, pb, vb) = res["1"][u], res["0"][u]
+        (sa, pa, va, gpa, gva), (sb, pb, vb, gpb, gvb) = res["1"][u], res["0"][u]
+        if u == 0:
+            assert torch.equal(gva, gvb), (gva - gvb).abs().max().item()
+            assert torch.equal(gpa, gpb), (gpa - gpb).abs().max().item()
         assert np.isfinite(sb[:18]).all()
         err = np.abs(sa[:18] - sb[:18]) / np.maximum(1.0, np.abs(sa[:18]))
         assert err.max() <= (2e-6 if u == 0 else 2e-5), (u, util.STAT_KEYS[int(err.argmax())], err.max())
         assert sa[23] == sb[23]  # (f16: the same rows were clamped — none here)
         for tag, a, b2 in (("pf", pa, pb), ("vf", va, vb)):
             for k in a:
-                if u == 0 and k != "logstd":
-                    assert torch.equal(a[k], b2[k]), (u, tag, k, (a[k] - b2[k]).abs().max().item())
-                else:
-                    assert (a[k] - b2[k]).abs().max().item() <= (1e-7 if u == 0 else 2e-6), (u, tag, k)
+                assert (a[k] - b2[k]).abs().max().item() <= (1e-7 if u == 0 else 2e-6), (u, tag, k)

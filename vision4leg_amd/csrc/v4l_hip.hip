@@ -267,6 +267,22 @@ static int wgrad_finish(Ctx& c) {
   int rc = wgrad_dense<T>(c, c.s);
   return rc ? rc : wgrad_reduce_all<T>(c);
 }
+// The statistics of a fused forward-loss-backward launch (csrc/wps_fb.h): one block, off the chain of the big launches — only
+// clip_adam and the record's readers wait for it
+static int fb_finish(Ctx& c, hipStream_t s) {
+  if (!c.fb_pending) return 0;
+  c.fb_pending = false;
+  static bool attr = false;
+  if (!attr) {
+    V4L_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&fb_loss_finish_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      (int)FbFinishLds::bytes));
+    attr = true;
+  }
+  g_op = "loss";
+  V4L_KLAUNCH("fb_loss_finish", 0, s, fb_loss_finish_kernel, dim3(1), dim3(256), FbFinishLds::bytes, s, c.fb_args, c.fb_blocks, c.fb_n);
+  V4L_LAUNCH_CHECK();
+  return 0;
+}
 // the deferred dense weight-grad launches (grouped + whole-output kernels) on stream ds: ONE launch when both kinds are
 // present (gemm_tn_dense_kernel hosts both kinds of blocks; V4L_SPLIT_DENSE_WGRAD=1: one launch per kind)
 // dg: stream of the grouped / whole-output launches when they run as a branch of their own (default: ds, after wps_wgrad)
@@ -274,12 +290,7 @@ template <typename T>
 static int wgrad_dense(Ctx& c, hipStream_t ds, hipStream_t dg) {
   v4l_net* net = c.net;
   if (dg == nullptr) dg = ds;
-  if (c.fb_pending) {  // one block: off the chain of the big launches (only clip_adam and the record's readers wait for it)
-    c.fb_pending = false;
-    g_op = "loss";
-    V4L_KLAUNCH("fb_loss_finish", 0, ds, fb_loss_finish_kernel, dim3(1), dim3(256), 0, ds, c.fb_args, c.fb_blocks, c.fb_n);
-    V4L_LAUNCH_CHECK();
-  }
+  if (int rc = fb_finish(c, ds)) return rc;  // (schedules without a shorter branch to put it on)
   if (c.wps_pending) {
     c.wps_pending = false;
     const int jobs = c.wps_args.nsplit * WPS_ROLES * c.wps_args.nlayers;
@@ -1743,7 +1754,13 @@ int v4l_net::backward_t(const float* state, const T* image, const int* rowidx, i
     if (split_red) {
       // (issue order matters to the graph's schedule: the auxiliary branch is the longer one and goes first)
       const size_t nred = cx.net->red.size();
+      // (round 6: the fused launch's statistics block rides on the main stream in front of dW3 — the shorter branch;
+      // wgrad_dense would put it at the head of the longer one. Launched AFTER the auxiliary branch's kernels were issued.)
+      const bool fb_main = cx.fb_pending && cx.tn != cx.s;
+      Ctx fbc = cx;
+      if (fb_main) cx.fb_pending = false;
       if ((rc = wgrad_dense<T>(cx, cx.tn, nullptr))) return rc;
+      if (fb_main && (rc = fb_finish(fbc, cx.s))) return rc;
       V4L_REQUIRE(cx.net->red.size() == nred, "internal: a weight-grad registered after the reduce table was prepared");
       if ((rc = conv3_wgrad_deferred<T>(cx, cx.s))) return rc;
       if ((rc = wgrad_reduce_launch(cx, 0, rblocks[0], cx.s))) return rc;
@@ -2013,7 +2030,7 @@ int v4l_net::backward_t(const float* state, const T* image, const int* rowidx, i
       V4L_REQUIRE((reinterpret_cast<uintptr_t>(lo.part) & 7) == 0, "internal: partial-statistics block not 8-byte aligned");
       cx.slab_used += 2 * (int64_t)nblk * FB_PART;
       V4L_REQUIRE(cx.slab_used <= slab_cap, "internal: weight-grad slab arena overflow");
-      const double fl_fb = fl + 2.0 * n * (872576.0 + 99840.0);  // + layer 0's forward and the heads' (layer 1 is not recomputed)
+      const double fl_fb = fl + 2.0 * n * (2 * 872576.0 + 99840.0);  // + the two layer forwards and the heads' forward
       static bool attr_fb = false;
       if (!attr_fb) {
         V4L_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&wps_layer_fb_kernel<T, true>),

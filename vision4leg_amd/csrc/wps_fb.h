@@ -6,15 +6,21 @@
 // pi_old) and of scalars known before the pass (the advantage moments of the minibatch: begin_pack_kernel; the mean()'s 1/n), so
 // the wave that carried a sample forward can turn around on the spot (torchrl/algo/on_policy/ppo.py:42-123 — the reference's
 // autograd graph has the same shape; nets.py:996-1038 is the forward it walks back through). One launch per net-pass then does:
-//   layer 0 forward -> layer 1 forward (KEEP: everything its backward needs stays in registers) -> pooled heads forward
-//   (cooperative, 4 rows) -> the block's loss-gradient rows + its share of the logged statistics -> heads backward (ReLU masks
-//   from registers, d(out) rows from LDS) -> layer 1 backward -> layer 0 recompute + backward -> encoder-side tail.
-// Against the three launches: one layer-forward less (3 instead of 4: layer 1 is not recomputed), layer 1's input rows and the
-// heads' masks never make a round trip, one weight staging less (5 instead of 6), two launch boundaries and the loss launch gone.
+//   layer 0 forward -> layer 1 forward -> pooled heads forward (cooperative, 4 rows) -> the block's loss-gradient rows + its share
+//   of the logged statistics -> heads backward (ReLU masks from registers, d(out) rows from LDS) -> per layer {recompute, walk back}
+//   (layer 1 from input rows that stayed in registers) -> encoder-side tail.
+// Against the three launches: two launch boundaries and the loss launch are gone, layer 1's input rows, the head outputs, the
+// loss-gradient rows and the heads' ReLU masks stop making round trips. The work per sample is the same (four layer-forwards).
+// Measured and NOT kept: layer 1's backward operands (WpsKeep, ~136 registers) held across the heads so that layer 1 is not
+// recomputed — the kernel then spills 131 registers to scratch and is slower than recomputing (update 619 - 632 us against
+// 596 - 618; profiles/r6_fused_layers_ab.txt), and its results are a last bit away from the recompute's (another instantiation of
+// the layer forward), which the f16 operands' rounding turns into visible tie flips.
 // The statistics of the update (losses, log-prob / ratio moments, d log sigma) leave as per-block partial sums (doubles) and are
-// finished by fb_loss_finish_kernel, one block on the auxiliary stream beside the weight-grad launches — off the update's chain.
-// The arithmetic per element is that of the separate kernels (the same device functions in the same order): activations,
-// gradients and the weight-grad operands are the same bits; only the statistics' summation order (per-block partials) differs.
+// finished by fb_loss_finish_kernel, one block beside the weight-grad launches — off the update's chain.
+// The arithmetic per element is that of the separate kernels (the same device functions, the same instantiations of the layer
+// functions, the same order): activations, gradients and the weight-grad operands are the same bits
+// (tests/test_gpu_bench_shapes.py::test_fused_forward_loss_backward_equals_three_launches); only the statistics' summation order
+// (per-block partials) differs.
 #pragma once
 #include "wps.h"
 
@@ -112,7 +118,7 @@ __global__ __launch_bounds__(256) WPS_EU_ATTR void wps_layer_fb_kernel(InfLayerS
   float4 xr[2][4];
   wps_load_rows<VIS>(fst.l[0].n[0].xin + row0 * TD, lane, ok, xr);
   const frag_t E0 = wps_sel<T>(0, lane), E1 = wps_sel<T>(1, lane);
-  WpsKeep<T> K;           // layer 1's: filled by its forward, consumed by its backward (no recompute)
+  WpsKeep<T> K;
   const WpsBwdLayer& wb1 = stk.l[0];
   const WpsOut wo1 = wps_out<T>(reinterpret_cast<T*>(wb1.wg) + srow * WPS_WG_STRIDE, reinterpret_cast<T*>(wb1.tk) + srow * WPS_TK_ELEMS, live);
   {
@@ -127,6 +133,11 @@ __global__ __launch_bounds__(256) WPS_EU_ATTR void wps_layer_fb_kernel(InfLayerS
 #pragma unroll
       for (int nt = 0; nt < 4; ++nt) xr[mt][nt] = xo[mt][nt];
   }
+  float4 x1k[2][4];  // layer 1's input rows stay in registers for its recompute (they never go to HBM)
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) x1k[mt][nt] = xr[mt][nt];
   {
     const InfLayer& w = fst.l[1].n[0];
     __syncthreads();  // every wave is done with layer 0's weights
@@ -137,9 +148,8 @@ __global__ __launch_bounds__(256) WPS_EU_ATTR void wps_layer_fb_kernel(InfLayerS
     __builtin_amdgcn_s_waitcnt(0);
     __syncthreads();
     float4 xo[2][4] WPS_Z;
-    // KEEP: also hands the x-side weight-grad operands of layer 1 over (what the backward kernel's recompute does)
-    wps_layer_fwd<T, LDSW, true, false, VIS>(w, LDSW ? wl : reinterpret_cast<const T*>(w.win), prm, xr, lane, ok, row0, srow, xo, &wo1,
-                                             E0, E1, &K);
+    wps_layer_fwd<T, LDSW, false, false, VIS>(w, LDSW ? wl : reinterpret_cast<const T*>(w.win), prm, xr, lane, ok, row0, srow, xo,
+                                              (const WpsOut*)nullptr, E0, E1, (WpsKeep<T>*)nullptr);
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
@@ -341,10 +351,27 @@ __global__ __launch_bounds__(256) WPS_EU_ATTR void wps_layer_fb_kernel(InfLayerS
           for (int nt = 0; nt < 4; ++nt) *reinterpret_cast<float4*>(w.o_dx + (row0 + ROFF + mt * 16 + fr) * TD + nt * 16 + qr) = dy[mt][nt];
     }
   };
-  {  // ---- layer 1: its forward's registers are live — transposed weights in, walk back
+  {  // ---- layer 1: recomputed from its input rows (registers), then walked back
     const WpsBwdLayer& w = wb1;
     __syncthreads();  // the heads' scratch is dead
-    wps_stage<T, LDSW>(w.wt, (const WpsPrm*)nullptr, wl, prm, tid);  // (prm still holds layer 1's parameters)
+    {
+      {
+        const WpsPrm pp = WpsPrm{w.bin, w.bo, w.b1, w.b2, w.g1, w.be1, w.g2, w.be2};
+        wps_stage<T, LDSW>(w.w, &pp, wl, prm, tid);
+      }
+      __builtin_amdgcn_s_waitcnt(0);
+      __syncthreads();
+      InfLayer none;
+      none.win = none.wo = none.w1 = none.w2 = nullptr;
+      none.bin = none.bo = none.b1 = none.b2 = none.g1 = none.be1 = none.g2 = none.be2 = nullptr;
+      none.xin = nullptr; none.xout = nullptr;
+      none.s_qkv = none.s_P = none.s_xh1 = none.s_rs1 = none.s_xh2 = none.s_rs2 = nullptr;
+      none.s_xin = none.s_ctx = none.s_x1 = none.s_f = nullptr;
+      float4 xo[2][4] WPS_Z;
+      wps_layer_fwd<T, LDSW, true, false, VIS>(none, LDSW ? wl : reinterpret_cast<const T*>(w.w), prm, x1k, lane, ok, row0, srow, xo, &wo1, E0, E1, &K);
+      __syncthreads();  // every wave is done with the forward weights
+    }
+    wps_stage<T, LDSW>(w.wt, (const WpsPrm*)nullptr, wl, prm, tid);  // (prm holds layer 1's parameters)
     __builtin_amdgcn_s_waitcnt(0);
     __syncthreads();
     wps_layer_bwd<T, LDSW, false, NMT>(w, LDSW ? wl : reinterpret_cast<const T*>(w.wt), prm, K, dy, lane, ok, row0, wo1, E0, E1, red + wave * 4 * TD);
@@ -453,31 +480,56 @@ __global__ __launch_bounds__(256) WPS_EU_ATTR void wps_layer_fb_kernel(InfLayerS
   }
 }
 
-// Finishes the statistics the fused launch left as per-block partials: one block, a fixed summation order (8 runs of blocks per
-// column, then the runs), the expressions of critic_loss_body / actor_loss_body's closing threads (elem.h). Runs beside the
-// weight-grad launches (auxiliary stream): only clip_adam_kernel — d log sigma, the norm — and the record's readers wait for it.
+// Finishes the statistics the fused launch left as per-block partials: one block, a fixed summation order, the expressions of
+// critic_loss_body / actor_loss_body's closing threads (elem.h). Thread t takes block t's record (one contiguous 192-byte read;
+// blocks t + 256, ... behind it), the records meet in LDS and thread k adds column k over the 256 rows in order: every load of the
+// launch is in flight at once (a loop over the blocks per column was 23 us of dependent L2 round trips). Dynamic LDS: FbFinishLds.
+struct FbFinishLds { static constexpr int LD = FB_PART + 1; static constexpr size_t bytes = (size_t)256 * LD * 8; };
 __global__ __launch_bounds__(256) void fb_loss_finish_kernel(FbLoss lo, int nblk, int n) {
-  __shared__ double run[8][FB_PART];
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_f[];
+  double* rows = reinterpret_cast<double*>(smem_f);  // [256][LD]
   __shared__ double tot[FB_PART];
   const int tid = threadIdx.x;
-  if (tid < 8 * FB_PART) {
-    const int k = tid % FB_PART, r = tid / FB_PART;
-    const bool mx = k == FBP_LPMAX || k == FBP_RMAX, mn = k == FBP_LPMIN || k == FBP_RMIN;
-    const int per = (nblk + 7) / 8, b0 = r * per, b1 = min(nblk, b0 + per);
-    double s = mx ? -INFINITY : mn ? INFINITY : 0.0;
-    for (int b = b0; b < b1; ++b) {
-      const double v = lo.part[(int64_t)b * FB_PART + k];
-      s = mx ? fmax(s, v) : mn ? fmin(s, v) : s + v;
+  auto is_max = [](int k) { return k == FBP_LPMAX || k == FBP_RMAX; };
+  auto is_min = [](int k) { return k == FBP_LPMIN || k == FBP_RMIN; };
+  {
+    double acc[FB_PART];
+#pragma unroll
+    for (int k = 0; k < FB_PART; ++k) acc[k] = is_max(k) ? -INFINITY : is_min(k) ? INFINITY : 0.0;
+    for (int b = tid; b < nblk; b += 256) {
+      const double2* src = reinterpret_cast<const double2*>(lo.part + (int64_t)b * FB_PART);
+      double v[FB_PART];
+#pragma unroll
+      for (int q = 0; q < FB_PART / 2; ++q) { const double2 t = src[q]; v[2 * q] = t.x; v[2 * q + 1] = t.y; }
+#pragma unroll
+      for (int k = 0; k < FB_PART; ++k) acc[k] = is_max(k) ? fmax(acc[k], v[k]) : is_min(k) ? fmin(acc[k], v[k]) : acc[k] + v[k];
     }
-    run[r][k] = s;
+#pragma unroll
+    for (int k = 0; k < FB_PART; ++k) rows[tid * FbFinishLds::LD + k] = acc[k];
+  }
+  __syncthreads();
+  // column k over the 256 rows: 8 runs of 32 rows (thread (run, k); the 32 LDS reads of a run are independent: all in flight),
+  // then the 8 runs in order
+  __shared__ double run[8][32];
+  {
+    const int k = tid & 31, r8 = tid >> 5;
+    if (k < FB_PART) {
+      double v[32];
+#pragma unroll
+      for (int j = 0; j < 32; ++j) v[j] = rows[(r8 * 32 + j) * FbFinishLds::LD + k];
+      double sacc = v[0];
+#pragma unroll
+      for (int j = 1; j < 32; ++j) sacc = is_max(k) ? fmax(sacc, v[j]) : is_min(k) ? fmin(sacc, v[j]) : sacc + v[j];
+      run[r8][k] = sacc;
+    }
   }
   __syncthreads();
   if (tid < FB_PART) {
     const int k = tid;
-    const bool mx = k == FBP_LPMAX || k == FBP_RMAX, mn = k == FBP_LPMIN || k == FBP_RMIN;
-    double s = run[0][k];
-    for (int r = 1; r < 8; ++r) s = mx ? fmax(s, run[r][k]) : mn ? fmin(s, run[r][k]) : s + run[r][k];
-    tot[k] = s;
+    double sacc = run[0][k];
+#pragma unroll
+    for (int r = 1; r < 8; ++r) sacc = is_max(k) ? fmax(sacc, run[r][k]) : is_min(k) ? fmin(sacc, run[r][k]) : sacc + run[r][k];
+    tot[k] = sacc;
   }
   __syncthreads();
   float* st = lo.st;
