@@ -173,8 +173,13 @@ float* v4l_net_dout_ptr(const v4l_net* net, float* ws_dev, int n);
  * gradients into grads_dev (flat, offsets from v4l_net_param_info; caller zeroes it). Replaces
  * loss.backward() of ppo.py:72,117 for everything below the head output.
  * The d(out) rows are expected MULTIPLIED by v4l_net_grad_scale(net, n) — 1 unless compute == V4L_F16 (see V4L_F16_SCALE_LOG2;
- * the trainer's loss kernels do it, a caller that fills d(out) itself must) — and the gradients come out unscaled. */
+ * the trainer's loss kernels do it, a caller that fills d(out) itself must) — and the gradients come out unscaled.
+ * v4l_net_grad_scale is the rule for MEAN-loss gradients (rows of size ~1/n). A caller whose d(out) rows have another size
+ * announces its own power of two with v4l_net_set_grad_scale before the backward call (consumed by it; ignored unless V4L_F16):
+ * the rows then arrive multiplied by THAT, sized so that the largest element sits around 2^12 .. 2^13 (the Python shell's
+ * HipNet.backward does this from max |d(out)|). */
 float v4l_net_grad_scale(const v4l_net* net, int n);
+int v4l_net_set_grad_scale(v4l_net* net, float scale);
 int v4l_net_backward(v4l_net* net, const float* state_dev, const void* image_dev, const int* rowidx_dev, int n,
                      float* ws_dev, float* grads_dev, void* stream);
 

@@ -56,6 +56,14 @@ def grad_scale(mode, n):
     return float(2 ** (F16_SCALE_LOG2 + max(0, int(n) - 1).bit_length()))
 
 
+def probe_scale(mode, amax):
+    """f16 flavour, gradient rows that are NOT a mean loss's (the tests' probe loss sum(out * w), w ~ N(0, 1)): the power of two
+    that puts the largest |d(out)| element into [2^12, 2^13) — mirrors HipNet.f16_scale_for / v4l_net_set_grad_scale."""
+    if mode != "f16" or not amax > 0:
+        return 1.0
+    return float(2.0 ** min(30, max(-14, math.floor(math.log2(8192.0 / amax)))))
+
+
 class _LinearR(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w, b, rnd):

@@ -58,10 +58,11 @@ def _flat(gs, keys):
     return torch.cat([gs[k].reshape(-1) for k in keys]).double()
 
 
-def _grad(loss, tensors, mode="f32", n=1):
+def _grad(loss, tensors, mode="f32", amax=0.0):
     """autograd.grad with zeros for parameters the forward never touches (token_norm=True: state_token_ln.*). mode="f16": the
-    backward runs on the loss scaled by the HIP path's power of two for n rows (oracle.grad_scale == v4l_net_grad_scale)."""
-    sc = orc.grad_scale(mode, n)
+    backward runs on the loss scaled by the power of two HipNet.backward picks for d(out) rows whose largest element is `amax`
+    (oracle.probe_scale == HipNet.f16_scale_for: the probe loss sum(out * w) is not a mean loss, the 1/n rule does not apply)."""
+    sc = orc.probe_scale(mode, amax)
     g = torch.autograd.grad(loss * sc if sc != 1.0 else loss, tensors, allow_unused=True)
     return tuple(torch.zeros_like(t) if x is None else (x / sc if sc != 1.0 else x) for x, t in zip(g, tensors))
 
@@ -83,7 +84,7 @@ def _bf16_envelope(name, tag, kind, params, obs, S, w, scales=ENV_SCALES, mode="
     def run(p):
         q = {k: v.detach().clone().requires_grad_(True) for k, v in p.items()}
         out = fn(q, obs, S, mode)
-        g = _grad((out * w).sum(), [q[k] for k in keys], mode, obs.shape[0])
+        g = _grad((out * w).sum(), [q[k] for k in keys], mode, float(w.abs().max()))
         return out.detach(), dict(zip(keys, g))
     out0, g0 = run(params)
     f0 = _flat(g0, keys)
@@ -251,7 +252,8 @@ def test_backward(name, mode, device):
         for k in keys:
             op[k].requires_grad_(True)
         out = orc.FORWARDS[case["kind"]](op, obs, case["S"], mode)
-        ref = _grad((out * w).sum(), [op[k] for k in keys], mode, n)
+        ref = _grad((out * w).sum(), [op[k] for k in keys], mode, float(w.abs().max()))
+        assert hip.last_grad_scale == orc.probe_scale(mode, float(w.abs().max()))
         for k in keys:
             op[k].requires_grad_(False)
         bad = []

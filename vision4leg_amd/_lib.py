@@ -94,6 +94,7 @@ _SIGS = {
   "v4l_net_out_ptr": (_P, [_P, _P, C.c_int, C.c_int]),
   "v4l_net_dout_ptr": (_P, [_P, _P, C.c_int]),
   "v4l_net_grad_scale": (C.c_float, [_P, C.c_int]),
+  "v4l_net_set_grad_scale": (C.c_int, [_P, C.c_float]),
   "v4l_net_backward": (C.c_int, [_P, _P, _P, _P, C.c_int, _P, _P, _P]),
   "v4l_gauss_head": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, _P, _P, _P, _P, _P, _P]),
   "v4l_gauss_head_tanh": (C.c_int, [_P, _P, _P, _P, C.c_int, C.c_int, _P, _P, _P, _P, _P, _P]),

@@ -130,7 +130,8 @@ struct v4l_net {
   std::vector<v4l::TnProb> tnp, tnp_cached;   // deferred dense weight-grad problems of the current / last backward
   std::vector<v4l::RedDesc> red, red_cached;  // weight-grad reduce descriptors of the current / last backward
   int64_t slab_cap = 0;
-  float grad_unscale = 1.f;          // 1 / v4l_net_grad_scale of the backward pass in flight (V4L_F16; 1 otherwise)
+  float grad_unscale = 1.f;          // 1 / the gradient scale of the backward pass in flight (V4L_F16; 1 otherwise)
+  float grad_scale_next = 0.f;       // v4l_net_set_grad_scale: the next backward pass's scale (0: the rule of v4l_net_grad_scale)
   int64_t seg_blocks = 0;
   bool bound = false;
   int gen = 0;  // bind generation: bumped by every v4l_net_bind; captured graphs of trainers / actors are keyed on it

@@ -1707,7 +1707,9 @@ int v4l_net::backward_t(const float* state, const T* image, const int* rowidx, i
   wide.clear();
   wide_flops = 0;
   slab_cap = slab_floats(n);
-  grad_unscale = 1.f / v4l_net_grad_scale(this, n);  // (V4L_F16: the d(out) rows came scaled; wgrad_reduce multiplies it out)
+  // (V4L_F16: the d(out) rows came scaled — by the rule, or by what the caller announced; wgrad_reduce multiplies it out)
+  grad_unscale = 1.f / ((c.compute == V4L_F16 && grad_scale_next > 0.f) ? grad_scale_next : v4l_net_grad_scale(this, n));
+  grad_scale_next = 0.f;
   int rc;
   const int ne = c.n_enc_hidden, nh = c.n_head_hidden;
   const ADense sin = dense(state, Sp, n, Sp, rowidx);
@@ -2975,6 +2977,13 @@ float* v4l_net_out_ptr(const v4l_net* net, float* ws_dev, int n, int train) {
   return ws_dev + net->layout(n).out;
 }
 float* v4l_net_dout_ptr(const v4l_net* net, float* ws_dev, int n) { return ws_dev + net->layout(n).dout; }
+int v4l_net_set_grad_scale(v4l_net* net, float scale) {
+  V4L_REQUIRE(net != nullptr, "v4l_net_set_grad_scale: null net");
+  int e = 0;
+  V4L_REQUIRE(scale > 0.f && frexpf(scale, &e) == 0.5f, "v4l_net_set_grad_scale: %g is not a positive power of two", (double)scale);
+  net->grad_scale_next = scale;
+  return 0;
+}
 float v4l_net_grad_scale(const v4l_net* net, int n) {
   if (net == nullptr || net->cfg.compute != V4L_F16 || n < 1) return 1.f;
   int lg = 0;

@@ -224,9 +224,17 @@ class HipNet:
     return operand_dtype(self.compute)
 
   def grad_scale(self, n):
-    """What the d(out) rows of a backward pass over n rows must be multiplied by (1 unless compute == f16); the gradients come
-    out unscaled (include/v4l_hip.h v4l_net_grad_scale)."""
+    """The library's rule for MEAN-loss gradient rows (size ~1/n): what they are multiplied by before a backward pass over n rows
+    (1 unless compute == f16); the gradients come out unscaled (include/v4l_hip.h v4l_net_grad_scale)."""
     return float(self.L.v4l_net_grad_scale(self.h, int(n)))
+
+  @staticmethod
+  def f16_scale_for(amax):
+    """The power of two that puts a largest |d(out)| element of `amax` into [2^12, 2^13): a factor of 8 under half's overflow for
+    the row itself, room for the backward's growth (LayerNorm's 1/sigma), and the bulk far above half's smallest normal."""
+    if not (amax > 0.0) or not np.isfinite(amax):
+      return 1.0
+    return float(2.0 ** min(30, max(-14, int(np.floor(np.log2(8192.0 / amax))))))
 
   def alloc_rollout(self, slots, device):
     state = _buf(slots * self.Sp, torch.float32, device, zero=True).view(slots, self.Sp)
@@ -268,12 +276,18 @@ class HipNet:
     off = self.ws_offset(n, "out")
     return ws[off:off + n * V4L_OUT_LD].view(n, V4L_OUT_LD)
 
-  def backward(self, state, image, n, dout, grads, rowidx=None, ws=None):
-    """dout: [n][V4L_OUT_LD] (zero padded). grads: flat float32 buffer, accumulated into."""
+  def backward(self, state, image, n, dout, grads, rowidx=None, ws=None, scale=None):
+    """dout: [n][V4L_OUT_LD] (zero padded), unscaled. grads: flat float32 buffer, every element written.
+    f16 compute: the rows enter the backward multiplied by a power of two (`scale`; default: chosen from max |dout| — one
+    device-to-host read — so that any row size is safe; last_grad_scale keeps it) and the gradients come out unscaled."""
     if ws is None:
       ws = self.workspace(n)
     off = self.ws_offset(n, "dout")
-    gs = self.grad_scale(n)
+    gs = 1.0
+    if self.compute == V4L_F16:
+      gs = float(scale) if scale is not None else self.f16_scale_for(float(dout.abs().max().item()))
+      check(self.L.v4l_net_set_grad_scale(self.h, gs), "v4l_net_set_grad_scale")
+    self.last_grad_scale = gs
     ws[off:off + n * V4L_OUT_LD].view(n, V4L_OUT_LD).copy_(dout if gs == 1.0 else dout * gs)
     check(self.L.v4l_net_backward(self.h, _ptr(state), _ptr(image), _ptr(rowidx), n, _ptr(ws), _ptr(grads), _stream()),
           "v4l_net_backward")
