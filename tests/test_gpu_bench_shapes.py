@@ -238,6 +238,15 @@ def test_vision_only_transformer_on_wave_per_sample_kernels(n, mode, device):
             # between two fp32 evaluations moves one sample-token's whole contribution, ~1e-4 of a weight gradient; see grad64 in
             # tests/test_gpu_parity.py for the same effect against the oracle)
             assert d.max().item() <= (2e-5 if name == "out" or n <= 64 else 1e-3), (name, d.max().item())
+        elif mode == "f16":
+            # f16: the pooled head operand differs between two evaluation orders at a rounding tie in about half of the rows (by
+            # <= 6e-5 of hh0, tools/probe/vis_head_rows.py), and with 256 hidden units per row one of them sits that close to zero
+            # every few thousand elements: its ReLU decision flips (n = 32: hh0[28][204]) and ONE row's whole contribution to that
+            # unit's bias / weight-row gradient moves — 3 % of the tensor's max-abs at n = 32, where the sum has 32 terms. Gate:
+            # the tensor as a whole (relative L2; a dropped or doubled row would be ~1/sqrt(n) >= 3e-2) and a looser element bound.
+            l2 = ((a.double() - b.double()).norm() / max(b.double().norm().item(), 1e-30)).item()
+            util.record(tag + name + "/rel_l2", l2)
+            assert l2 <= 2e-2 and d.max().item() <= 1e-1, (name, l2, d.max().item())
         else:
             moved = (d > 1e-4).double().mean().item()
             assert d.max().item() <= 3e-2 and moved <= lim_moved, (name, d.max().item(), moved)

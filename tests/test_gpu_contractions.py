@@ -51,7 +51,13 @@ def _close_t(name, got_t, want32, mode, tag, max_ulp=1.0, floor=TOL):
     util.record("contraction/%s/%s/frac_not_equal_to_rounded" % (tag, name), frac)
     util.record("contraction/%s/%s/worst_in_ulp" % (tag, name), worst)
     # (f16: 8 x as many elements sit within fp32 noise of a rounding tie as in bf16)
-    assert worst <= max_ulp + 1e-3 and frac <= (2e-2 if mode == "f16" else 5e-3), (name, worst, frac)
+    bad = (diff / ulp) > max_ulp + 1e-3
+    detail = ""
+    if bad.any():  # where: elements the kernel zeroed and the expectation did not (a mask), or the other way round, and how large
+        g, w_ = got_t.float()[bad], want32.float()[bad]
+        detail = "; %d off: got==0 %d, want==0 %d, |want| min %.3g max %.3g, |got| max %.3g" % (
+            int(bad.sum()), int((g == 0).sum()), int((w_ == 0).sum()), w_.abs().min().item(), w_.abs().max().item(), g.abs().max().item())
+    assert worst <= max_ulp + 1e-3 and frac <= (2e-2 if mode == "f16" else 5e-3), (name, worst, frac, detail)
 
 
 def _conv_backward_checks(tap, G, sd, enc, n, c1, c2, dc3, img_t, mode, tag):
@@ -201,7 +207,16 @@ def test_every_contraction_teacher_forced(name, mode, device, layer_taps):
             _close_t("d.L%d.norm2_bwd" % l, dz2, dz2_w, mode, tag)
             # (GEMM operands: the kernel's OWN rounded tensors — the dz2 / df taps — so that a 1-ulp tie in an operand is not
             # charged to the next contraction; the residual adds the fp32 value)
-            _close_t("d.L%d.df=(dz2 W2)*mask" % l, df, (d["f"] > 0) * dmm(dz2, p + "linear2.weight"), mode, tag)
+            dff = dmm(dz2, p + "linear2.weight")
+            fmask = d["f"] > 0
+            if mode == "f16":
+                # ReLU's mask is decided on the fp32 pre-activation (reference and oracle: relu's own backward); the tap holds it
+                # rounded to half, where a positive value below 2^-25 is zero (bf16 keeps fp32's exponent range: cannot happen).
+                # Where the tap is zero the kernel may legitimately have passed the gradient: take its decision there.
+                fmask = fmask | ((d["f"] == 0) & (df.float() != 0))
+                util.record("contraction/%s/L%d.relu_mask_below_half_range" % (tag, l), int(((d["f"] == 0) & (df.float() != 0)).sum()))
+                assert int(((d["f"] == 0) & (df.float() != 0)).sum()) <= 4
+            _close_t("d.L%d.df=(dz2 W2)*mask" % l, df, fmask * dff, mode, tag)
             dx1 = dz2_w + dmm(df, p + "linear1.weight")
             dz1_w = ln_bwd(dx1, d["xh1"], d["rs1"], p + "norm1.weight")
             _close_t("d.L%d.dx1+norm1_bwd" % l, dz1, dz1_w, mode, tag)
