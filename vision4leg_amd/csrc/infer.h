@@ -587,9 +587,20 @@ __device__ long long g_inf_stamps[128];
 #define INF_STAMP(i) do { if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) g_inf_stamps[i] = clock64(); } while (0)
 // rollout kernels: [64..95] rollout_stack_kernel (layer 0: 64.., head: 80..), [96..111] rollout_encoder2_kernel (depth block 0)
 #define ROLL_STAMP(i) do { if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) g_inf_stamps[i] = clock64(); } while (0)
+// per-block placement / time log of the fused forward-loss-backward launch (round 6, tools/probe/fb_blocks.py): block b ->
+// {wall clock at entry, shader clock at entry, HW_ID | XCC_ID << 32, wall clock at exit, shader clock at exit} — wall clock =
+// s_memrealtime (100 MHz, one counter for the chip), shader clock = s_memtime (runs at the XCD's current frequency)
+__device__ long long g_blk_log[1024 * 5];
+#define BLK_LOG_BEGIN() do { if (threadIdx.x == 0 && blockIdx.x < 1024) { long long* q_ = g_blk_log + 5 * blockIdx.x; \
+    q_[0] = wall_clock64(); q_[1] = clock64(); \
+    q_[2] = (long long)(unsigned)__builtin_amdgcn_s_getreg((31 << 11) | 4) | ((long long)(unsigned)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32); } } while (0)
+#define BLK_LOG_END() do { if (threadIdx.x == 0 && blockIdx.x < 1024) { long long* q_ = g_blk_log + 5 * blockIdx.x; \
+    q_[3] = wall_clock64(); q_[4] = clock64(); } } while (0)
 #else
 #define INF_STAMP(i)
 #define ROLL_STAMP(i)
+#define BLK_LOG_BEGIN()
+#define BLK_LOG_END()
 #endif
 
 // One nn.TransformerEncoderLayer for SPW samples per block (blockIdx.y = net). HEAD: the block continues with the

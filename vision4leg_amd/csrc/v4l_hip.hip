@@ -3098,6 +3098,10 @@ int v4l_debug_stamps(long long* out32) {
   if (hipDeviceSynchronize() != hipSuccess) return -2;
   return hipMemcpyFromSymbol(out32, HIP_SYMBOL(v4l::g_inf_stamps), 128 * sizeof(long long)) == hipSuccess ? 0 : -2;
 }
+int v4l_debug_block_log(long long* out5120) {
+  if (hipDeviceSynchronize() != hipSuccess) return -2;
+  return hipMemcpyFromSymbol(out5120, HIP_SYMBOL(v4l::g_blk_log), 1024 * 5 * sizeof(long long)) == hipSuccess ? 0 : -2;
+}
 #endif
 int v4l_prof_enable(int on) {
   g_prof = on != 0;

@@ -110,6 +110,7 @@ __global__ __launch_bounds__(256) WPS_EU_ATTR void wps_layer_fb_kernel(InfLayerS
   const int64_t row0 = srow * NTOK;
   const bool ok[2] = {live, live && fr == 0};
   const int nt4[4] = {wave * 4, wave * 4 + 1, wave * 4 + 2, wave * 4 + 3};
+  BLK_LOG_BEGIN();
   // ======================================================================================================== forward
   {  // layer 0's weights start their trip first
     const WpsPrm pp = wps_prm_of(fst.l[0].n[0]);
@@ -431,6 +432,7 @@ __global__ __launch_bounds__(256) WPS_EU_ATTR void wps_layer_fb_kernel(InfLayerS
                                                             m.z > 0.f ? acc[mt][2] : 0.f, m.w > 0.f ? acc[mt][3] : 0.f};
       }
     }
+    BLK_LOG_END();
     if constexpr (!TOK0_IN) return;
     // token 0: (dx_in o [x0 > 0]) -> state_projector' -> [e1 > 0] -> dhc -> fc2' -> [e0 > 0] -> de0, cooperatively (4 rows)
     float* dtt = reinterpret_cast<float*>(smem);                 // [16][LDX]
