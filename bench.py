@@ -919,6 +919,8 @@ def main():
                     res[other + "_mode"] = dict(side_leg(a.workload, other, dev), parity_check=parity_check(wl, other, dev),
                                                 note=notes[other])
                     res[other + "_mode_value"] = res[other + "_mode"]["value"]  # flat: the driver's parser drops nested objects
+                else:
+                    res[other + "_mode_value"] = value  # the headline's own mode, under the same flat name as the side legs
             res["dp1_ingraph"] = dp1_ingraph_leg(a.workload, a.compute)
             res["dp1_ingraph_value"] = res["dp1_ingraph"].get("value")
             res["option_variant"] = side_leg("loco_max", a.compute, dev, steps=2, warmup=1)

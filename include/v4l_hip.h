@@ -50,7 +50,8 @@
  *                             weight-grads (16 - 64 rows per block) (per call)
  * Read by the Python shell, not by the library: V4L_COMPUTE=f16|bf16|f32, V4L_GRAPH=0, V4L_EPOCH_GRAPH=0 (one hipGraph replay per
  * update instead of one per epoch), V4L_DP_COMM=auto|torch|rccl,
- * V4L_CAST_THREADS, V4L_COLLECT_SPLIT=0 (fp32 observation rows over PCIe instead of fp32 proprio + bf16 depth rows),
+ * V4L_CAST_THREADS, V4L_COLLECT_SPLIT=0 (fp32 observation rows over PCIe instead of fp32 proprio + 16-bit depth rows),
+ * V4L_COLLECT_HOST_STEP=0 (the collector's env step as torch cast + RolloutActor.step_host_split instead of ONE v4l_actor_step_rows call),
  * V4L_SPLIT_VIA_COPY, V4L_GUARD, V4L_FORCE_DP_PHASES, V4L_LIB (diagnostic builds). Everything except COMPUTE / GRAPH / DP_COMM /
  * CAST_THREADS / RCCL_LIB / TRACE / ROCTX is diagnostic: the Python shell warns once at load time when one is set
  * (_lib.diagnostic_switches).
@@ -265,6 +266,24 @@ int v4l_actor_step_split(v4l_actor* a, const float* proprio_dev, const void* ima
                          float* state_roll_dev, void* image_roll_dev, float* acts_roll_dev, float* values_roll_dev,
                          float* logp_roll_dev, float* action_dev, float* mean_dev, float* std_dev, float* ent_dev,
                          float* value_dev, int shared_encoder, void* stream);
+
+/* The collector's whole env step (collector/on_policy.py:90-100) as ONE host call, no interpreter in the loop (round 6):
+ * `rows_host` [E][ld] float64 — the rows the env wrappers hand over, pageable memory is fine — are cast on a persistent pool of
+ * `threads` host threads (AVX-512 where the CPU has it) into the caller's PINNED staging blocks (`proprio_pinned` [E][S] fp32,
+ * NULL when S = 0; `image16_pinned` [E][C*H*W] in the net's 16-bit operand type: float64 -> float32 -> operand type, both
+ * round-to-nearest-even, i.e. torch.Tensor(ob) followed by the kernels' ingest cast), the two launches of v4l_actor_step_split
+ * read them in place, and the call watches `action_pinned` [E][A] and `value_pinned` [E] (pinned, armed with NaN) until every
+ * slot holds a number or `poll_seconds` have passed. Returns 0: both outputs have arrived — every block has finished reading
+ * the staging blocks, they may be overwritten; 1: not waited for (poll_seconds <= 0) or timed out — synchronise the stream
+ * before touching the buffers; < 0: error. v4l_host_cast_rows is the cast alone (no GPU involved; compute V4L_F32: image_out
+ * is fp32); v4l_host_cast_simd: 1 when the AVX-512 path is in use. */
+int v4l_host_cast_rows(const double* rows_host, int64_t ld, int E, int S, int64_t img_elems, float* proprio_out, void* image_out,
+                       int compute, int threads);
+int v4l_host_cast_simd(void);
+int v4l_actor_step_rows(v4l_actor* a, const double* rows_host, int64_t ld, float* proprio_pinned, void* image16_pinned,
+                        const float* eps_dev, float* state_roll_dev, void* image_roll_dev, float* acts_roll_dev,
+                        float* values_roll_dev, float* logp_roll_dev, float* action_pinned, float* mean_dev, float* std_dev,
+                        float* ent_dev, float* value_pinned, int shared_encoder, int threads, double poll_seconds, void* stream);
 
 /* ---- PPO minibatch update: replaces PPO.update / update_critic / update_actor (ppo.py:42-153), the two
  * clip_grad_norm_(…, 0.5) calls and the two Adam steps (a2c.py:30-40). pf and vf may share encoder parameters

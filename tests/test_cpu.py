@@ -190,6 +190,44 @@ def test_host_16bit_cast_is_the_two_step_rounding(dt, eps_log2):
     assert torch.equal(cols, torch.from_numpy(wide[:, 93:].copy()).float().to(dt))
 
 
+@pytest.mark.parametrize("threads", [1, 3, 8])
+@pytest.mark.parametrize("mode", ["bf16", "f16", "f32"])
+def test_library_host_cast_equals_torch_two_step_rounding(mode, threads):
+    """v4l_host_cast_rows (csrc/host_step.h; the cast inside v4l_actor_step_rows, the collector's one-call env step): float64 rows
+    [E][S + C*H*W] -> fp32 proprio block + depth block in the operand type, on the library's thread pool (AVX-512 where the CPU
+    has it, the scalar path otherwise — both run here when the CPU allows). Bit for bit torch.Tensor(ob) (float64 -> float32)
+    followed by the float32 -> operand-type rounding of the kernels' ingest, including ties that a direct float64 -> 16-bit
+    rounding would decide the other way, subnormals of both types, overflow to inf and NaN; ragged sizes exercise the tails."""
+    import ctypes as C
+    from vision4leg_amd import _lib
+    L = _lib.lib()
+    compute = {"f32": _lib.V4L_F32, "bf16": _lib.V4L_BF16, "f16": _lib.V4L_F16}[mode]
+    dt = {"f32": torch.float32, "bf16": torch.bfloat16, "f16": torch.float16}[mode]
+    rs = np.random.RandomState(4)
+    for E, S, img in ((5, 93, 16384), (3, 0, 4099), (32, 7, 2048 * 3 + 5)):
+        rows = np.clip(rs.randn(E, S + img), -2.5, 2.8)
+        h = 2.0 ** (-8 if mode == "bf16" else -11)
+        tricky = [1 + h + 2 ** -30, -(1 + h + 2 ** -40), 3.0 + 3 * h + 2 ** -33, 1 + h - 2 ** -30, 0.0, -0.0, 6e-8, -3e-8, 5.9e-8, 1e-40, -1e-41,
+                  1e-46, 65504.0, 65519.9, 65520.0, -7e4, 3.3e38, 3.5e38, -1e300, np.inf, -np.inf, np.nan, 2.0 ** -24, 2.0 ** -25, 1.5 * 2.0 ** -25]
+        rows[0, S:S + len(tricky)] = tricky
+        rows[E - 1, -len(tricky):] = tricky
+        prop = torch.full((E, max(S, 1)), -7.0, dtype=torch.float32)
+        out = torch.zeros(E, img, dtype=dt)
+        rc = L.v4l_host_cast_rows(C.c_void_p(rows.ctypes.data), rows.shape[1], E, S, img, C.c_void_p(prop.data_ptr() if S else 0),
+                                  C.c_void_p(out.data_ptr()), compute, threads)
+        _lib.check(rc, "v4l_host_cast_rows")
+        with np.errstate(over="ignore"):
+            want32 = torch.from_numpy(rows).to(torch.float32)
+        want = want32[:, S:].to(dt)
+        bits = lambda t: t.view(torch.int16 if t.element_size() == 2 else torch.int32)
+        nan = torch.isnan(want.float())
+        assert torch.equal(torch.isnan(out.float()), nan)
+        assert torch.equal(bits(out)[~nan], bits(want)[~nan]), (mode, E, S, img)
+        if S:
+            assert torch.equal(prop[:, :S], want32[:, :S])
+    assert L.v4l_host_cast_simd() in (0, 1)
+
+
 def test_replay_buffer_iteration_matches_reference_semantics():
     """one_iteration: batch_size/E time rows per minibatch, all envs of a row together, np.random stream."""
     from vision4leg_amd.torchrl.replay_buffers import OnPolicyReplayBuffer

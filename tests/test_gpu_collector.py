@@ -240,6 +240,8 @@ def test_step_host_equals_step(name, mode, device):
                 for a0 in range(0, E, 3):  # ragged chunks on purpose (3 + 1 rows)
                     dimg[a0:a0 + 3].copy_(img16[a0:a0 + 3], non_blocking=True)
                 acts.append(np.array(actor.step_host_split(dprop if S else None, dimg, on_device=True), copy=True))
+            elif host == "rows":  # round 6: the one-call step on float64 rows (cast on the library's pool, launches, completion)
+                acts.append(np.array(actor._actor.step_host_rows(rows[t].astype(np.float64), threads=3), copy=True))
             elif host in ("split", "split_copy"):
                 S = case["S"]
                 prop = torch.from_numpy(rows[t][:, :S].copy()).pin_memory() if S else None
@@ -259,7 +261,7 @@ def test_step_host_equals_step(name, mode, device):
         assert (x is None and y is None) or torch.equal(x, y)
     assert np.isfinite(a_host).all() and np.abs(a_host[2:]).max() > 0 and filed_host[4][2 * E:].abs().max() > 0
     if split:  # ... and the split hand-over (fp32 proprio + bf16 depth rows) gives the same bits again
-        for how in ("split", "split_copy", "split_pipe"):  # rows read in place over PCIe / copied to HBM first / chunked DMA pipeline
+        for how in ("split", "split_copy", "split_pipe", "rows"):  # rows read in place over PCIe / copied to HBM first / chunked DMA pipeline / one library call
             a_split, filed_split, first_split = run(how, rollout_arrays())
             assert np.array_equal(a_dev, a_split), how
             for x, y in list(zip(filed_dev, filed_split)) + list(zip(first_dev, first_split)):

@@ -121,6 +121,10 @@ _SIGS = {
   "v4l_trainer_bind": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, C.c_int64, _P, C.c_int, _P]),
   "v4l_trainer_begin": (C.c_int, [_P, _P, _P, C.c_double, C.c_double, C.c_int64, C.POINTER(PPOHyper), _P]),
   "v4l_trainer_update_next": (C.c_int, [_P, C.POINTER(Rollout), C.c_int, C.POINTER(PPOHyper), C.c_int, _P]),
+  "v4l_host_cast_rows": (C.c_int, [_P, C.c_int64, C.c_int, C.c_int, C.c_int64, _P, _P, C.c_int, C.c_int]),
+  "v4l_host_cast_simd": (C.c_int, []),
+  "v4l_actor_step_rows": (C.c_int, [_P, _P, C.c_int64, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, C.c_int, C.c_int,
+                                    C.c_double, _P]),
   "v4l_trainer_update_run": (C.c_int, [_P, C.POINTER(Rollout), C.c_int, C.POINTER(PPOHyper), C.c_int, C.c_int, _P]),
   "v4l_trainer_critic_grads": (C.c_int, [_P, C.POINTER(Rollout), C.c_int, C.POINTER(PPOHyper), _P]),
   "v4l_trainer_critic_step": (C.c_int, [_P, C.POINTER(PPOHyper), _P]),

@@ -14,6 +14,7 @@
 #include "wps_fb.h"
 #include "rollout_dense.h"
 #include "dense_stack.h"
+#include "host_step.h"
 
 namespace v4l {
 
@@ -2787,7 +2788,7 @@ static int launch_actor_loss_heads(hipStream_t s, const ActorArgs& aa, const Row
 extern "C" {
 
 const char* v4l_last_error(void) { return v4l::last_error(); }
-int v4l_version(void) { return 105; }  // round 6: V4L_F16 compute mode, v4l_net_grad_scale, record slot 23
+int v4l_version(void) { return 106; }  // round 6: V4L_F16 compute mode, v4l_net_grad_scale, record slot 23; v4l_actor_step_rows / v4l_host_cast_rows
 int v4l_abi_sizeof(int which) {
   return which == 0 ? (int)sizeof(v4l_net_cfg) : which == 1 ? (int)sizeof(v4l_ppo_hyper) : which == 2 ? (int)sizeof(v4l_rollout) : -1;
 }
@@ -3402,6 +3403,49 @@ int v4l_actor_step_split(v4l_actor* a, const float* proprio_dev, const void* ima
                                 action_dev, mean_dev, std_dev, ent_dev, value_dev, shared_encoder, /*use_graph=*/0, stream);
   a->img16 = nullptr;
   return rc;
+}
+
+// ---- the collector's env step as one host call (csrc/host_step.h)
+int v4l_host_cast_rows(const double* rows_host, int64_t ld, int E, int S, int64_t img_elems, float* proprio_out, void* image_out,
+                       int compute, int threads) {
+  V4L_REQUIRE(rows_host && image_out && E > 0 && S >= 0 && img_elems > 0 && ld >= S + img_elems, "v4l_host_cast_rows: bad argument");
+  V4L_REQUIRE(S == 0 || proprio_out != nullptr, "v4l_host_cast_rows: proprio rows have nowhere to go");
+  V4L_REQUIRE(compute == V4L_F32 || compute == V4L_BF16 || compute == V4L_F16, "v4l_host_cast_rows: unknown compute mode %d", compute);
+  V4L_REQUIRE(threads >= 1 && threads <= 256, "v4l_host_cast_rows: threads must be in [1, 256]");
+  const int kind = compute == V4L_BF16 ? host::CAST_BF16 : compute == V4L_F16 ? host::CAST_F16 : 0;
+  return host::cast_rows(rows_host, ld, E, S, img_elems, proprio_out, image_out, kind, threads);
+}
+int v4l_host_cast_simd(void) { return host::have_avx512() ? 1 : 0; }
+int v4l_actor_step_rows(v4l_actor* a, const double* rows_host, int64_t ld, float* proprio_pinned, void* image16_pinned,
+                        const float* eps_dev, float* state_roll_dev, void* image_roll_dev, float* acts_roll_dev,
+                        float* values_roll_dev, float* logp_roll_dev, float* action_pinned, float* mean_dev, float* std_dev,
+                        float* ent_dev, float* value_pinned, int shared_encoder, int threads, double poll_seconds, void* stream) {
+  V4L_REQUIRE(a && a->bound && rows_host && image16_pinned && action_pinned && value_pinned, "v4l_actor_step_rows: bad argument");
+  V4L_REQUIRE(actor_takes_split(a, shared_encoder), "v4l_actor_step_rows: this actor's step does not take the split observation "
+              "(16-bit compute, an image net on the fused rollout step)");
+  const v4l_net_cfg& c = a->pf->cfg;
+  const int64_t img = (int64_t)c.in_channels * c.img_hw * c.img_hw;
+  int rc = v4l_host_cast_rows(rows_host, ld, a->E, c.state_dim, img, proprio_pinned, image16_pinned, c.compute, threads);
+  if (rc) return rc;
+  const int na = a->E * c.out_dim, nv = a->E;
+  const bool poll = poll_seconds > 0.0;
+  if (poll) {  // armed: a number in every slot means every (env, net) block has written its output, i.e. finished reading the rows
+    const float nan = __builtin_nanf("");
+    for (int i = 0; i < na; ++i) action_pinned[i] = nan;
+    for (int i = 0; i < nv; ++i) value_pinned[i] = nan;
+    std::atomic_thread_fence(std::memory_order_seq_cst);
+  }
+  rc = v4l_actor_step_split(a, c.state_dim ? proprio_pinned : nullptr, image16_pinned, eps_dev, state_roll_dev, image_roll_dev,
+                            acts_roll_dev, values_roll_dev, logp_roll_dev, action_pinned, mean_dev, std_dev, ent_dev, value_pinned,
+                            shared_encoder, stream);
+  if (rc) return rc;
+  if (!poll) return 1;
+  const auto t_end = std::chrono::steady_clock::now() + std::chrono::nanoseconds((int64_t)(poll_seconds * 1e9));
+  for (unsigned it = 0;; ++it) {
+    if (host::arrived(action_pinned, na) && host::arrived(value_pinned, nv)) return 0;
+    host::cpu_relax();
+    if ((it & 63) == 63 && std::chrono::steady_clock::now() > t_end) return 1;  // the caller synchronises (a policy that emits NaN ends here)
+  }
 }
 
 // ------------------------------------------------------------------------------------------ trainer

@@ -573,6 +573,24 @@ class HipActor:
   def seek(self, t):
     check(self.L.v4l_actor_seek(self.h, int(t), _stream()), "v4l_actor_seek")
 
+  # ---- are the operand-type weight copies current? Every step asks both nets (version counters of ~60 parameter tensors each:
+  # ~6 us per net and step in the interpreter). A caller that owns the loop and knows the parameters stand still — the collector's
+  # train_one_epoch: nothing steps an optimiser between two env steps — asks once and freezes the answer for the loop.
+  _frozen = False
+
+  def _refresh_packs(self):
+    if not self._frozen:
+      self.pf.pack_if_needed(fast=True)
+      self.vf.pack_if_needed(fast=True)
+
+  def freeze_params(self, on):
+    """on=True: check the parameters now (repacking if they changed) and skip the per-step check until freeze_params(False).
+    The caller promises not to change pf / vf parameters in between (a change would go unnoticed until the freeze ends)."""
+    self._frozen = False
+    if on:
+      self._refresh_packs()
+    self._frozen = bool(on)
+
   def check(self):
     """v4l_actor_check: raise if a device-side hand-over of the rollout step timed out since the last check (the affected
     steps filed NaN actions rather than numbers computed from stale activations). One stream synchronise; once per epoch."""
@@ -625,8 +643,7 @@ class HipActor:
       self._args_host = (self._args[:7] + (C.c_void_p(self._act_host.data_ptr()),) + self._args[8:11]
                          + (C.c_void_p(self._val_host.data_ptr()),) + self._args[12:])
       self._args_host_of = self._args
-    self.pf.pack_if_needed(fast=True)
-    self.vf.pack_if_needed(fast=True)
+    self._refresh_packs()
     args = (C.c_void_p(obs_pinned.data_ptr()),) + self._args_host[1:]
     bulk = getattr(self, "_bulk", None)
     if not deterministic and bulk is not None:
@@ -720,8 +737,7 @@ class HipActor:
       raise RuntimeError("vision4leg_amd: step_host_split needs pinned, contiguous [E][S] float32 and [E][C*H*W] %s host tensors"
                          % str(self.pf.image_dtype()))
     self._host_outputs()
-    self.pf.pack_if_needed(fast=True)
-    self.vf.pack_if_needed(fast=True)
+    self._refresh_packs()
     a = self._args  # (obs, eps, st, im, acts, vals, logp, action, mean, std, ent, value, shared_encoder, graph)
     eps = a[1]
     bulk = getattr(self, "_bulk", None)
@@ -752,9 +768,54 @@ class HipActor:
                                       C.c_void_p(self._val_host.data_ptr()), a[12], _stream()), "v4l_actor_step_split")
     return self._await_action()
 
+  def step_host_rows(self, rows, deterministic=False, threads=8):
+    """The collector's env step as ONE library call (v4l_actor_step_rows, csrc/host_step.h): `rows` is the numpy float64
+    [E][S+C*H*W] array the env wrappers hand over (C-contiguous, any memory); the library casts it on its own thread pool into
+    this actor's pinned staging blocks (fp32 proprio | 16-bit depth stack: the same two roundings as torch.Tensor(ob) followed by
+    the kernels' ingest), issues the step's two launches on them and watches the pinned action / value buffers fill. No torch
+    call and no Python loop per step. Returns the [E][A] action as a numpy view of pinned memory (valid until the next step).
+    Needs split_supported(); eager launches only."""
+    if self.graph:
+      raise RuntimeError("vision4leg_amd: step_host_rows drives eager launches (construct the actor with graph=False)")
+    S, img = self.pf.state_dim, self.pf.img_elems
+    if (rows.dtype != np.float64 or rows.ndim != 2 or rows.shape != (self.E, S + img) or not rows.flags.c_contiguous):
+      raise RuntimeError("vision4leg_amd: step_host_rows needs a C-contiguous float64 [E][S+C*H*W] array")
+    self._host_outputs()
+    if getattr(self, "_rows_pins", None) is None:
+      self._rows_pins = (torch.empty(self.E, max(S, 1), dtype=torch.float32).pin_memory(),
+                         torch.empty(self.E, img, dtype=self.pf.image_dtype()).pin_memory())
+      self._poll = os.environ.get("V4L_STEP_POLL", "1") != "0"
+      self._act_np, self._val_np, self._act_np_of = self._act_host.numpy(), self._val_host.numpy(), self._act_host
+    self._refresh_packs()
+    a = self._args  # (obs, eps, st, im, acts, vals, logp, action, mean, std, ent, value, shared_encoder, graph)
+    eps = a[1]
+    bulk = getattr(self, "_bulk", None)
+    if not deterministic and bulk is not None:
+      eps = C.c_void_p(bulk.data_ptr() + self._bulk_t * bulk.stride(0) * 4)
+      self._bulk_t += 1
+      if self._bulk_t >= bulk.shape[0]:
+        self._bulk = None
+    elif not deterministic:
+      self.eps.normal_()
+      self._eps_zero = False
+    elif not getattr(self, "_eps_zero", False):
+      self.eps.zero_()
+      self._eps_zero = True
+    if self.own:
+      self.seek(0)
+    prop, img16 = self._rows_pins
+    rc = self.L.v4l_actor_step_rows(self.h, C.c_void_p(rows.ctypes.data), rows.shape[1], C.c_void_p(prop.data_ptr()),
+                                    C.c_void_p(img16.data_ptr()), eps, a[2], a[3], a[4], a[5], a[6],
+                                    C.c_void_p(self._act_host.data_ptr()), a[8], a[9], a[10], C.c_void_p(self._val_host.data_ptr()),
+                                    a[12], int(threads), self.POLL_SECONDS if self._poll else 0.0, _stream())
+    if rc == 1:  # not waited for / timed out: the stream's completion is the step's
+      torch.cuda.current_stream(self.device).synchronize()
+    elif rc != 0:
+      check(rc, "v4l_actor_step_rows")
+    return self._act_np
+
   def _step(self, obs, deterministic=False):
-    self.pf.pack_if_needed(fast=True)
-    self.vf.pack_if_needed(fast=True)
+    self._refresh_packs()
     args = self._args
     if obs.data_ptr() != self._obs_ptr:
       if self.graph or obs.dtype != torch.float32 or not obs.is_contiguous() or obs.numel() != self.obs.numel():

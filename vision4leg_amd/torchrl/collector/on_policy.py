@@ -37,6 +37,14 @@ def _cast_threads_from_env():
     return n
 
 
+class _NoGuard:
+    def __enter__(self): return self
+    def __exit__(self, *exc): return False
+
+
+_NO_GUARD = _NoGuard()
+
+
 class VecOnPolicyCollector:
     def __init__(self, vf, discount=0.99, *, env, eval_env, pf, replay_buffer, epoch_frames, train_render=False,
                  eval_episodes=1, eval_render=False, device="cpu", max_episode_frames=999):
@@ -81,6 +89,10 @@ class VecOnPolicyCollector:
         # user's own torch CPU code between epochs keep the process's setting. V4L_CAST_THREADS overrides the count (1 = never
         # touch torch's setting).
         self.cast_threads = _cast_threads_from_env()
+        # V4L_COLLECT_HOST_STEP=0: the per-step cast through torch's copy kernel + RolloutActor.step_host_split (the arrangement
+        # before round 6; tests/test_gpu_collector.py compares the two bit for bit)
+        self._host_step = os.environ.get("V4L_COLLECT_HOST_STEP", "1") != "0"
+        self._in_epoch = False
         self.fast_path = isinstance(replay_buffer, DeviceOnPolicyReplayBuffer)
 
     # ---- reference plumbing (collector/base.py:54-58,113-115,166-174; on_policy.py:77-82) ----------------------------
@@ -164,7 +176,8 @@ class VecOnPolicyCollector:
 
     # ---- one vectorised env step -----------------------------------------------------------------------------------
     def take_actions(self):
-        with torch.cuda.device(self.device):
+        # (train_one_epoch holds the device guard for its whole loop: entering it per step costs ~3 us of interpreter time)
+        with (_NO_GUARD if self._in_epoch else torch.cuda.device(self.device)):
             if self.fast_path:
                 actor = self._ensure_actor()
                 top = self.replay_buffer._top
@@ -175,7 +188,12 @@ class VecOnPolicyCollector:
                 # pinned staging buffer in place and write the [E][A] action into pinned host memory — no copy launches
                 if self._split is None:
                     self._split = os.environ.get("V4L_COLLECT_SPLIT", "1") != "0" and actor.split_supported()
-                if self._split:  # bf16 compute: the depth stack goes over as bf16 (half the PCIe bytes, same numbers)
+                ob = self.current_ob
+                if (self._split and self._host_step and isinstance(ob, np.ndarray) and ob.dtype == np.float64
+                        and ob.flags.c_contiguous):
+                    # round 6: cast + launches + completion as ONE library call on the library's own thread pool
+                    acts = np.array(actor.step_host_rows(ob, threads=self.cast_threads), dtype=np.float32, copy=True)
+                elif self._split:  # 16-bit compute: the depth stack goes over in the operand type (half the PCIe bytes, same numbers)
                     acts = np.array(actor.step_host_split(*self._upload_split(self.current_ob)), dtype=np.float32, copy=True)
                 else:
                     acts = np.array(actor.step_host(self._upload(self.current_ob, host_only=True)), dtype=np.float32, copy=True)
@@ -184,6 +202,8 @@ class VecOnPolicyCollector:
                 ob_tensor = self._upload(self.current_ob)
                 acts = self.pf.explore(ob_tensor)["action"].detach().cpu().numpy()
                 values = self.vf(ob_tensor).detach().cpu().numpy()
+        # (ndarray methods below instead of the np.any / np.sum dispatchers: six reductions over [E][1] arrays per step, ~2 us each
+        # of pure call overhead through the wrappers — tools/probe/host_step.py)
         if not np.isfinite(acts).all():  # collector/on_policy.py:102-107 ("NaN detected. BOOM")
             raise FloatingPointError("vision4leg_amd: non-finite action from the policy; observation rows "
                                      "finite: %s" % bool(np.isfinite(np.asarray(self.current_ob)).all()))
@@ -195,12 +215,15 @@ class VecOnPolicyCollector:
                   "terminals": dones,
                   "time_limits": infos["time_limit"][:, np.newaxis] if "time_limit" in infos else [False]}
         self.train_rew += rewards
-        if np.any(dones):
+        dones = np.asarray(dones)
+        any_done = bool(dones.any())
+        if any_done:
             self.train_rews += list(self.train_rew[dones])
             self.train_rew[dones] = 0
         surpass = self.current_step >= self.max_episode_frames
-        if np.any(dones) or np.any(surpass):
-            if np.any(surpass):  # bootstrap the truncated envs with V(next_obs) (collector/on_policy.py:132-144)
+        any_surpass = bool(surpass.any())
+        if any_done or any_surpass:
+            if any_surpass:  # bootstrap the truncated envs with V(next_obs) (collector/on_policy.py:132-144)
                 with torch.cuda.device(self.device):
                     last_value = self.vf(self._upload(next_obs)).detach().cpu().numpy()
                 sample["rewards"] = rewards + self.discount * last_value * surpass
@@ -215,7 +238,7 @@ class VecOnPolicyCollector:
         else:
             self.replay_buffer.add_sample(sample)
         self.current_ob = next_obs
-        return np.sum(rewards)
+        return rewards.sum() if isinstance(rewards, np.ndarray) else np.sum(rewards)
 
     def train_one_epoch(self):
         self.train_rews = []
@@ -225,10 +248,21 @@ class VecOnPolicyCollector:
         scoped = self.fast_path and self.cast_threads > 1 and before != self.cast_threads
         if scoped:
             torch.set_num_threads(self.cast_threads)
+        actor = None
         try:
-            for _ in range(self.sample_epoch_frames):
-                self.train_epoch_reward += self.take_actions()
+            with torch.cuda.device(self.device):
+                if self.fast_path:
+                    # nothing steps an optimiser between two env steps of this loop: the "did the parameters change?" question
+                    # (version counters of every parameter tensor, ~12 us per step for the two nets) is asked once, here
+                    actor = self._ensure_actor()
+                    actor.freeze_params(True)
+                self._in_epoch = True
+                for _ in range(self.sample_epoch_frames):
+                    self.train_epoch_reward += self.take_actions()
         finally:
+            self._in_epoch = False
+            if actor is not None:
+                actor.freeze_params(False)
             if scoped:
                 torch.set_num_threads(before)
         if self.fast_path and self._actor is not None:

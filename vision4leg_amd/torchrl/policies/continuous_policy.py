@@ -64,6 +64,14 @@ class RolloutActor:
     def split_device_buffers(self):
         return self._actor.split_device_buffers()
 
+    def freeze_params(self, on):
+        """Skip the per-step "did the parameters change?" check between freeze_params(True) and freeze_params(False) (see HipActor)."""
+        self._actor.freeze_params(on)
+
+    def step_host_rows(self, rows, deterministic=False, threads=8):
+        """One env step from the env wrappers' float64 rows as ONE library call (see HipActor.step_host_rows): -> numpy action [E][A]."""
+        return self._actor.step_host_rows(rows, deterministic, threads)
+
     def eval_act(self, x):
         """`pf.eval_act(x)` (policies/continuous_policy.py:78-83) on the fused step: the policy mean as a numpy array,
         no draw. With env_nums = 1 this is the batch-1 deployment call — the role the reference's TensorRT engine
