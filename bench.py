@@ -161,8 +161,17 @@ class Epoch:
             self.actor.seek(0)
             if os.environ.get("V4L_BULK_NOISE", "1") != "0":
                 self.actor.draw_noise(T)  # the epoch's T x E x A exploration normals in one generator call
-            for t in range(T):
-                self.actor.step(self.obs[t * E:(t + 1) * E])
+            # The loop is the collector's (VecOnPolicyCollector.train_one_epoch): nothing steps an optimiser between two env steps,
+            # so "did the parameters change?" is asked once for the loop (round 6: the per-step question cost ~12 us of interpreter
+            # time, which made this loop host-bound on slower hosts: 13.0 - 15.2 ms for 512 x 24.7 us of kernels).
+            if getattr(self, "_obs_steps", None) is None:
+                self._obs_steps = [self.obs[t * E:(t + 1) * E] for t in range(T)]
+            self.actor.freeze_params(True)
+            try:
+                for ob in self._obs_steps:
+                    self.actor.step(ob)
+            finally:
+                self.actor.freeze_params(False)
             return
         for t in range(T):  # the reference's call protocol: pf.explore(ob) then vf(ob)
             ob = self.obs[t * E:(t + 1) * E]

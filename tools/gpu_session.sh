@@ -66,9 +66,9 @@ c)  # round 5, session C: runtime knobs — where the kernel arguments live (dev
   bench_ab r5c 3 "base=" "devkernarg1=HIP_FORCE_DEV_KERNARG=1" "devkernarg0=HIP_FORCE_DEV_KERNARG=0"
   ;;
 full)  # the whole GPU suite + the default bench line (what the driver runs at round end)
-  (timeout 1500 python -m pytest tests -q -m gpu --tb=short -x 2>&1 | tail -25) > $O/r5_gpu_tests.log; tail -8 $O/r5_gpu_tests.log
-  cp $O/parity.json $O/r5_parity.json 2>/dev/null
-  python bench.py > $O/r5_bench_full.json 2> $O/r5_bench_full.err; tail -c 600 $O/r5_bench_full.json
+  (timeout 1500 python -m pytest tests -q -m gpu --tb=short 2>&1 | tail -60) > $O/${TAG:-r6}_gpu_tests.log; tail -8 $O/${TAG:-r6}_gpu_tests.log
+  cp $O/parity.json $O/${TAG:-r6}_parity.json 2>/dev/null
+  python bench.py > $O/${TAG:-r6}_bench_full.json 2> $O/${TAG:-r6}_bench_full.err; tail -c 600 $O/${TAG:-r6}_bench_full.json
   ;;
 e)  # round 5, session E: the collector's hand-over variants (cast included) and fresh phase stamps of the rollout step kernels
   python tools/probe/collector_pipe.py > $O/r5e_collector_pipe.txt 2> $O/r5e_collector_pipe.err; cat $O/r5e_collector_pipe.txt
