@@ -228,6 +228,25 @@ def test_library_host_cast_equals_torch_two_step_rounding(mode, threads):
     assert L.v4l_host_cast_simd() in (0, 1)
 
 
+def test_cast_pool_is_clean_under_thread_sanitizer(tmp_path):
+    """The host thread pool behind v4l_actor_step_rows (csrc/host_step.h: workers that spin, sleep and wake, claim flags, a job
+    object on the caller's stack) under ThreadSanitizer: tools/host/cast_pool_check.cpp runs jobs with changing thread counts,
+    pool resizes and pauses longer than the workers' spin window, and compares every element with the scalar two-step rounding."""
+    import shutil, subprocess
+    cxx = os.environ.get("CXX", "/opt/rocm/lib/llvm/bin/clang++")
+    if not os.path.exists(cxx) and shutil.which(cxx) is None:
+        pytest.skip("no clang++ for the sanitizer build")
+    exe = str(tmp_path / "cast_check_tsan")
+    src = os.path.join(os.path.dirname(__file__), "..", "tools", "host", "cast_pool_check.cpp")
+    b = subprocess.run([cxx, "-std=c++17", "-O1", "-g", "-fsanitize=thread", "-fno-omit-frame-pointer", "-pthread", src, "-o", exe],
+                       capture_output=True, text=True)
+    if b.returncode != 0 and "sanitizer" in (b.stderr or "").lower():
+        pytest.skip("this toolchain has no ThreadSanitizer runtime")
+    assert b.returncode == 0, b.stderr[-2000:]
+    r = subprocess.run([exe, "90"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "OK" in r.stdout and "WARNING: ThreadSanitizer" not in r.stderr, (r.stdout[-500:], r.stderr[-3000:])
+
+
 def test_replay_buffer_iteration_matches_reference_semantics():
     """one_iteration: batch_size/E time rows per minibatch, all envs of a row together, np.random stream."""
     from vision4leg_amd.torchrl.replay_buffers import OnPolicyReplayBuffer

@@ -3,7 +3,7 @@ ROOT=os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 os.environ.setdefault("V4L_LIB", os.path.join(ROOT, "vision4leg_amd", os.environ.get("TIMING_LIB", "libv4l_hip_timing.so")))  # tools/probe/build_variant.sh timing
 sys.path.insert(0,ROOT); sys.path.insert(0,os.path.join(ROOT,"tests"))
 import numpy as np, torch, util
-os.environ["V4L_COMPUTE"]="bf16"
+os.environ.setdefault("V4L_COMPUTE","f16")
 import vision4leg_amd.torchrl.networks as networks, vision4leg_amd.torchrl.policies as policies
 from vision4leg_amd import _lib
 dev=torch.device("cuda:0")
