@@ -710,6 +710,12 @@ def roofline(ep, compute, breakdown_path):
 
     def price(kern, calls, us, fl):
         avg_us = us / calls
+        # ALGORITHMIC numerator: the library's per-launch FLOP counts are what the kernel PERFORMS; the layer
+        # backward (and the fused forward-loss-backward launch) re-run one forward per layer to rebuild activations — that recompute
+        # is the kernel's own choice, not work the algorithm asks for, and does not count
+        performed = fl / calls
+        if kern in ("wps_layer_fb_stack", "wps_layer_bwd_stack"):
+            fl = fl - calls * wl.get("layers", 2) * 2.0 * wl["B"] * 872576.0
         tf = fl / us * 1e-6                      # TFLOP/s
         by = algo_bytes(kern, wl, compute)
         gbs = by / avg_us * 1e-3 if by else None  # GB/s
@@ -735,7 +741,7 @@ def roofline(ep, compute, breakdown_path):
             "peak": PEAK_HBM if hbm_bound else PEAK[compute], "unit": "GB/s" if hbm_bound else "TFLOP/s",
             "frac": round((gbs / PEAK_HBM) if hbm_bound else (tf / PEAK[compute]), 5),
             "traffic": rec.get("hbm_bytes_per_launch"), "traffic_source": rec.get("source"),
-            "algorithmic_bytes_per_launch": by, "algorithmic_flops_per_launch": fl / calls,
+            "algorithmic_bytes_per_launch": by, "algorithmic_flops_per_launch": fl / calls, "performed_flops_per_launch": performed,
             "hbm_frac": round(gbs / PEAK_HBM, 5) if gbs else None, "mfma_frac": round(tf / PEAK[compute], 5),
             "avg_launch_us": round(avg_us, 2), "launches": calls, "share_of_kernel_time": round(us / total_us, 4),
         }
