@@ -785,14 +785,20 @@ def roofline(ep, compute, breakdown_path):
     res["update_kernel_us"] = round(upd_us / n_upd, 1)
     if roll:
         res["rollout_us_per_env_step"] = round(roll_us / wl["T"], 2)
-    traffic = 0.0
-    for k, (c, _, _) in _per_kernel(upd).items():
+    traffic, unpriced = 0.0, []
+    for k, (c, u, _) in _per_kernel(upd).items():
         rec = pmc.get(k) or {}
         for suffix in ("_stack_head", "_stack", "_head", "_tail"):
             if not rec and k.endswith(suffix):
                 rec = pmc.get(k[:-len(suffix)]) or {}
+        if not rec and u / n_upd >= 1.0 and not k.startswith("allreduce"):
+            unpriced.append(k)  # a launch of >= 1 us per update without a PMC row: the sum below would silently leave it out
         traffic += (rec.get("hbm_bytes_per_launch") or 0.0) * c / n_upd
-    res["hbm_bytes_per_update"] = round(traffic) if traffic else None
+    # (round 6: a line printed 0.84 GB while pmc_traffic.json predated the fused layer launch — its 2 x 116 MB were missing.
+    # The sum is only reported when every launch of the update has a row.)
+    res["hbm_bytes_per_update"] = round(traffic) if traffic and not unpriced else None
+    if unpriced:
+        res["hbm_bytes_per_update_unpriced_kernels"] = sorted(unpriced)
     res["hbm_bytes_per_update_source"] = "profiles/pmc_traffic.json (PMC FETCH_SIZE x2 / WRITE_SIZE per launch) x this run's launches per update"
     res["method"] = ("HIP events around every launch of one extra (untimed) rollout + epoch-update on the launch stream; "
                      "achieved = algorithmic bytes (bench.py algo_bytes, DESIGN.md section 4) or 2*M*N*K FLOPs per launch / "

@@ -13,7 +13,8 @@ NAMES = {  # rocprof kernel symbol fragment -> bench.py / profiler label
     "bwd_layer_kernel": "fused_layer_bwd", "infer_layer_kernel": "fused_layer", "train_encoder_kernel": "fused_encoder",
     "rollout_stack_kernel": "rollout_layers_head", "rollout_encoder2_kernel": "rollout_encoder",
     "wps_layer_fwd_kernel": "wps_layer_stack_head", "wps_layer_bwd_kernel": "wps_layer_bwd_stack", "wps_wgrad_kernel": "wps_wgrad",
-    "wps_layer_fb_kernel": "wps_layer_fb_stack", "clip_adam_kernel": "clip_adam", "pack_kernel": "pack",
+    "wps_layer_fb_kernel": "wps_layer_fb_stack", "clip_adam_kernel": "clip_adam", "fb_loss_finish_kernel": "fb_loss_finish",
+    "begin_pack_kernel": "begin_pack", "pack_kernel": "pack",  # (first match wins: begin_pack before pack)
 }
 rows = [l.rstrip("\n").split("\t") for l in open(sys.argv[1])]
 h = rows[0]
