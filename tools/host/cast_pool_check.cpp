@@ -48,6 +48,28 @@ int main(int argc, char** argv) {
     }
     if (it % 40 == 39) std::this_thread::sleep_for(std::chrono::milliseconds(2));  // longer than SPIN_NS: the workers go to sleep
   }
+  // two host threads (two collectors) share the process-wide pool and ask for different thread counts: they must take turns
+  {
+    std::atomic<int> bad{0};
+    auto caller = [&](int seed, int threads) {
+      std::mt19937_64 r2(seed);
+      std::normal_distribution<double> n2(0.0, 1.0);
+      const int E = 8, S = 5; const int64_t img = 4099, ld = S + img;
+      std::vector<double> rows((size_t)E * ld);
+      std::vector<float> prop((size_t)E * S);
+      std::vector<uint16_t> out((size_t)E * img);
+      for (int it = 0; it < 25; ++it) {
+        for (double& x : rows) x = n2(r2);
+        if (cast_rows(rows.data(), ld, E, S, img, prop.data(), out.data(), CAST_F16, threads) != 0) { bad++; return; }
+        for (int e = 0; e < E; ++e)
+          for (int64_t c = 0; c < img; ++c)
+            if (out[(size_t)e * img + c] != f32_to_f16_rne((float)rows[(size_t)e * ld + S + c])) { bad++; return; }
+      }
+    };
+    std::thread a(caller, 11, 4), b(caller, 12, 7);
+    a.join(); b.join();
+    if (bad.load() != 0) { std::printf("concurrent callers: mismatch\n"); return 1; }
+  }
   std::printf("cast pool check: %lld elements over %d jobs (1..13 threads, pool resized, sleep / wake), simd %d: OK\n", checked, iters, (int)have_avx512());
   return 0;
 }

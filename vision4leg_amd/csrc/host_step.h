@@ -211,11 +211,12 @@ class CastPool {
 };
 thread_local uint64_t CastPool::spins_ = 0;
 
-// process-wide pool, resized on demand (threads - 1 workers: the caller works too)
-static CastPool* pool_for(int threads) {
-  static std::mutex mu;
+// process-wide pool, resized on demand (threads - 1 workers: the caller works too). One job at a time: the library's contract is
+// one HANDLE per host thread at a time, but the pool is shared by all handles of the process — two collectors in two threads
+// take turns here (uncontended: one atomic exchange).
+static std::mutex& pool_mutex() { static std::mutex mu; return mu; }
+static CastPool* pool_for(int threads) {  // (call with pool_mutex() held)
   static CastPool* pool = nullptr;
-  std::lock_guard<std::mutex> g(mu);
   const int want = threads > 1 ? threads - 1 : 0;
   if (pool == nullptr || pool->workers() != want) {
     delete pool;
@@ -232,7 +233,8 @@ static int cast_rows(const double* rows, int64_t ld, int E, int S, int64_t img, 
   if (threads > CAST_MAX_PARTS) threads = CAST_MAX_PARTS;
   j.parts = threads < 1 ? 1 : (threads > j.units ? j.units : threads);
   if (j.parts <= 1) { cast_drain(j, 0); return 0; }
-  pool_for(threads)->run(j);
+  std::lock_guard<std::mutex> g(pool_mutex());
+  pool_for(j.parts)->run(j);
   return 0;
 }
 
