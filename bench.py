@@ -791,8 +791,8 @@ def roofline(ep, compute, breakdown_path):
         for suffix in ("_stack_head", "_stack", "_head", "_tail"):
             if not rec and k.endswith(suffix):
                 rec = pmc.get(k[:-len(suffix)]) or {}
-        if not rec and u / n_upd >= 1.0 and not k.startswith("allreduce"):
-            unpriced.append(k)  # a launch of >= 1 us per update without a PMC row: the sum below would silently leave it out
+        if not rec and c >= n_upd and u / n_upd >= 1.0 and not k.startswith("allreduce"):
+            unpriced.append(k)  # a launch of every update (>= 1 us) without a PMC row: the sum below would silently leave it out
         traffic += (rec.get("hbm_bytes_per_launch") or 0.0) * c / n_upd
     # (round 6: a line printed 0.84 GB while pmc_traffic.json predated the fused layer launch — its 2 x 116 MB were missing.
     # The sum is only reported when every launch of the update has a row.)
